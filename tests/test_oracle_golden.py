@@ -1,0 +1,248 @@
+"""Pins the CPU oracle (oracle/) against fixtures produced by RUNNING THE
+REFERENCE (tools/gen_golden.py).  Integer / index outputs must be bit-exact;
+floating point within the stated tolerance."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cases, load_golden
+from oracle import encodings as oenc
+from oracle import iwe as oiwe
+from oracle import loss as oloss
+from oracle import snn as osnn
+from oracle import train as otrain
+
+torch.set_num_threads(4)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+# --------------------------------------------------------------------- G1
+def test_g1_encodings_bit_exact():
+    g = load_golden("g1_encodings")
+    xs, ys, ts, ps = g["xs"], g["ys"], g["ts"], g["ps"]
+    res = tuple(g["sensor"])
+    assert np.array_equal(oenc.events_to_channels(xs, ys, ps, res), g["cnt"])
+    assert np.array_equal(oenc.create_mask_encoding(xs, ys, ps, res)[0], g["mask"])
+    assert np.array_equal(oenc.events_to_image(xs, ys, ps, res), g["image_acc"])
+    for nb in (2, 5):
+        for rnd in (0, 1):
+            got = oenc.events_to_voxel(xs, ys, ts, ps, nb, res, round_ts=bool(rnd))
+            assert np.array_equal(got, g[f"voxel_nb{nb}_r{rnd}"]), (nb, rnd)
+    assert np.array_equal(oenc.create_list_encoding(xs, ys, ts, ps), g["list"])
+    assert np.array_equal(oenc.create_polarity_mask(ps), g["polmask"])
+    _, _, ft, fp = oenc.event_formatting(xs[:64], ys[:64], g["raw_t"], g["raw_p"])
+    assert np.array_equal(ft, g["fmt_t"]) and np.array_equal(fp, g["fmt_p"])
+
+
+def test_g1_collate_layout():
+    g = load_golden("g1_encodings")
+    assert g["collate_event_list"].shape == (2, 50, 4)
+    assert g["collate_event_list_pol_mask"].shape == (2, 50, 2)
+    assert g["collate_event_cnt"].shape == (2, 2, 40, 48)
+    assert g["collate_event_mask"].shape == (2, 1, 40, 48)
+    samples = []
+    for b in range(2):
+        ev = g["collate_event_list"][b]
+        samples.append(oenc.encode_window(ev[:, 2], ev[:, 1], ev[:, 0], ev[:, 3], 2, (40, 48)))
+    col = oenc.collate(samples)
+    for k in col:
+        assert np.array_equal(col[k], g["collate_" + k]), k
+
+
+# --------------------------------------------------------------------- G2
+@pytest.mark.parametrize("tref", [1, 3, 0])
+@pytest.mark.parametrize("rnd", [0, 1])
+@pytest.mark.parametrize("S", [16, 128])
+def test_g2_get_interpolation_bit_exact(tref, rnd, S):
+    g = load_golden("g2_interpolation")
+    idx, w = oiwe.get_interpolation(g["events"], g["flow"], tref, tuple(g["res"]), S, round_idx=bool(rnd))
+    assert np.array_equal(idx, g[f"idx_t{tref}_r{rnd}_s{S}"])
+    assert np.array_equal(w, g[f"w_t{tref}_r{rnd}_s{S}"])
+
+
+# --------------------------------------------------------------------- G3
+@pytest.mark.parametrize("tag", ["c1", "b2"])
+@pytest.mark.parametrize("S", [128, 32])
+def test_g3_pol_iwe(tag, S):
+    g = load_golden("g3_pol_iwe")
+    ev, flow, pol, res = g[tag + "_events"], g[tag + "_flow"], g[tag + "_pol"], tuple(g[tag + "_res"])
+    got = oiwe.compute_pol_iwe(flow, ev, res, pol[:, :, 0:1], pol[:, :, 1:2], flow_scaling=S, round_idx=True)
+    ref = g[f"{tag}_iwe_s{S}_r1"]
+    assert np.array_equal(got, ref)  # integer histogram: bit exact
+    assert np.array_equal(ref, np.rint(ref))
+    got = oiwe.compute_pol_iwe(flow, ev, res, pol[:, :, 0:1], pol[:, :, 1:2], flow_scaling=S, round_idx=False)
+    np.testing.assert_allclose(got, g[f"{tag}_iwe_s{S}_r0"], rtol=0, atol=2e-6)
+
+
+# --------------------------------------------------------------------- G4
+def _g4_window(g, c, requires_grad=True):
+    tag = c["tag"]
+    res = tuple(g["res"])
+    win = oloss.Window(res)
+    flows = []
+    for k in range(c["P"]):
+        fl = [T(g[f"{tag}_p{k}_flow{s}"]).requires_grad_(requires_grad) for s in range(c["scales"])]
+        flows.append(fl)
+        win.add(fl, T(g[f"{tag}_p{k}_event_list"]), T(g[f"{tag}_p{k}_event_list_pol_mask"]), T(g[f"{tag}_p{k}_event_mask"]))
+    if c["overwrite"]:
+        win.overwrite(flows[-1])
+    return win, flows
+
+
+def test_g4_event_warping_loss_and_grad():
+    g = load_golden("g4_event_warping")
+    cases = golden_cases(g)
+    assert len(cases) >= 20
+    for c in cases:
+        win, flows = _g4_window(g, c)
+        val = oloss.event_warping_loss(win, max(win.res), 0.001, smoothing_mask=c["mask"], overwrite=c["overwrite"])
+        np.testing.assert_allclose(float(val.detach()), float(g[c["tag"] + "_loss"]), rtol=2e-6, err_msg=str(c))
+        leaves = [f for fl in flows for f in fl]
+        grads = torch.autograd.grad(val, leaves, allow_unused=True)
+        gi = 0
+        for k in range(c["P"]):
+            for s in range(c["scales"]):
+                ref = g[f"{c['tag']}_p{k}_gflow{s}"]
+                got = grads[gi].numpy() if grads[gi] is not None else np.zeros_like(ref)
+                scale = max(np.abs(ref).max(), 1e-12)
+                assert np.abs(got - ref).max() <= 2e-5 * scale + 1e-9, (c, k, s)
+                gi += 1
+
+
+# --------------------------------------------------------------------- G5
+@pytest.mark.parametrize("ow", [0, 1])
+def test_g5_metrics(ow):
+    g = load_golden("g5_metrics")
+    res, P = tuple(g["res"]), int(g["P"])
+    tag = f"ow{ow}"
+    win = oloss.Window(res)
+    last = None
+    for k in range(P):
+        last = T(g[f"{tag}_p{k}_flow"])
+        win.add([last], T(g[f"{tag}_p{k}_event_list"]), T(g[f"{tag}_p{k}_event_list_pol_mask"]), T(g[f"{tag}_p{k}_event_mask"]))
+    we = oloss.window_events(win)
+    if ow:
+        win.overwrite([last])
+    np.testing.assert_allclose(oloss.fwl(win, 32).numpy(), g[tag + "_fwl"], rtol=1e-5)
+    np.testing.assert_allclose(oloss.rsat(win, 32).numpy(), g[tag + "_rsat"], rtol=1e-5)
+    assert np.array_equal(we.numpy(), g[tag + "_window_events"])
+    assert np.array_equal(oloss.window_iwe(win, 32).numpy(), g[tag + "_window_iwe"])
+    np.testing.assert_allclose(oloss.masked_window_flow(win, bool(ow)).numpy(), g[tag + "_masked_flow"], rtol=1e-6, atol=1e-7)
+
+
+def test_g5_aee():
+    g = load_golden("g5_metrics")
+    a, p = oloss.aee(T(g["aee_flow"]), T(g["aee_gt"]), T(g["aee_event_mask"])[:, -1], 32, g["aee_dt"][0:1], g["aee_dt"][1:2])
+    np.testing.assert_allclose(a.numpy(), g["aee_val"], rtol=1e-5)
+    np.testing.assert_allclose(p.numpy(), g["aee_outl"], rtol=1e-5)
+
+
+# --------------------------------------------------------------------- G6
+def test_g6_cells_forward_backward():
+    g = load_golden("g6_cells")
+    cases = golden_cases(g)
+    assert len(cases) == 28
+    for c in cases:
+        tag = c["tag"]
+        pre = "c."
+        p = {}
+        for k in g.files:
+            if k.startswith(tag + "_param_"):
+                p[pre + k[len(tag + "_param_"):]] = T(g[k]).clone()
+        names = [k for k in p if not k.endswith("act_width")]
+        for k in names:
+            p[k].requires_grad_(True)
+        x = T(g[tag + "_x"]).requires_grad_(True)
+        st = T(g[tag + "_state"]).requires_grad_(True)
+        out, new = osnn.cell_step(c["kind"], p, pre, x, tuple(st.unbind(0)), recurrent=c["recurrent"], act=c["act"], hard_reset=c["hard_reset"])
+        new = torch.stack(new)
+        assert np.array_equal(out.detach().numpy(), g[tag + "_out"]), c  # spikes: exact
+        np.testing.assert_allclose(new.detach().numpy(), g[tag + "_new"], rtol=1e-6, atol=1e-7, err_msg=str(c))
+        grads = torch.autograd.grad([out, new], [x, st] + [p[k] for k in names], [T(g[tag + "_g_out"]), T(g[tag + "_g_new"])], allow_unused=True)
+        np.testing.assert_allclose(grads[0].numpy(), g[tag + "_gx"], rtol=1e-4, atol=1e-6, err_msg=str(c))
+        np.testing.assert_allclose(grads[1].numpy(), g[tag + "_gstate"], rtol=1e-4, atol=1e-6, err_msg=str(c))
+        for k, gr in zip(names, grads[2:]):
+            ref = g[f"{tag}_grad_{k[len(pre):]}"]
+            got = gr.numpy() if gr is not None else np.zeros_like(ref)
+            np.testing.assert_allclose(got, ref, rtol=2e-4, atol=1e-5 * max(1.0, np.abs(ref).max()), err_msg=f"{c} {k}")
+
+
+# --------------------------------------------------------------------- G7
+def _g7_passes(g):
+    P = int(g["meta_P"])
+    return [
+        {k: T(g[f"p{i}_{k}"]) for k in ("event_cnt", "event_voxel", "event_list", "event_list_pol_mask", "event_mask")}
+        for i in range(P)
+    ]
+
+
+@pytest.mark.parametrize("fix,name", [("g7_liffirenet_train", "LIFFireNet"), ("g7_liffirenet_lowthresh", "LIFFireNet"), ("g7_pliffirenet_train", "PLIFFireNet")])
+def test_g7_firenet_train_step(fix, name):
+    g = load_golden(fix)
+    params = {k[len("param0_"):]: T(g[k]).clone() for k in g.files if k.startswith("param0_")}
+    keys = osnn.trainable_keys(params)
+    passes = _g7_passes(g)
+    res = passes[0]["event_cnt"].shape[2:]
+    # forward per-layer parity (teacher-forced by construction: same inputs, same state)
+    states = [None] * 7
+    with torch.no_grad():
+        for i, d in enumerate(passes):
+            col = {}
+            flow, states = osnn.firenet_forward(name, params, d["event_cnt"], states, collect=col)
+            for ln in osnn.FIRENET_LAYERS:
+                v_ref, z_ref = g[f"p{i}_v_{ln}"], g[f"p{i}_z_{ln}"]
+                v, z = col[ln][1][0].numpy(), col[ln][1][1].numpy()
+                margin = np.abs(v_ref - params[ln + ".thresh"].clamp_min(0.01).numpy()[None]) > 1e-5
+                assert np.array_equal(z[margin], z_ref[margin].astype(np.float32)), (i, ln)
+                np.testing.assert_allclose(v, v_ref, rtol=1e-5, atol=1e-6, err_msg=f"{i} {ln}")
+            np.testing.assert_allclose(flow.numpy(), g[f"p{i}_flow"], rtol=1e-5, atol=1e-7)
+    opt = {"step": 0, "m": {}, "v": {}}
+    loss, grads, newp, _ = otrain.train_step(
+        name, params, keys, passes, [None] * 7, tuple(res), opt,
+        loss_cfg={"flow_regul_weight": 0.001, "mask_output": True}, lr=2e-4, clip=100.0,
+    )
+    np.testing.assert_allclose(loss, float(g["loss"]), rtol=1e-5)
+    gn = np.sqrt(sum(float((grads[k].double() ** 2).sum()) for k in keys))
+    np.testing.assert_allclose(gn, float(g["grad_norm"]), rtol=1e-4)
+    for k in keys:
+        ref = g["grad_" + k]
+        tol = 1e-4 * max(np.abs(ref).max(), 1e-8)
+        assert np.abs(grads[k].numpy() - ref).max() <= tol + 1e-9, k
+        np.testing.assert_allclose(newp[k].numpy(), g["param1_" + k], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+# --------------------------------------------------------------------- G8
+def test_g8_firenet_ann_forward():
+    g = load_golden("g8_firenet_ann")
+    params = {k[len("param_"):]: T(g[k]) for k in g.files if k.startswith("param_")}
+    states = [None] * 7
+    with torch.no_grad():
+        for i in range(2):
+            flow, states = osnn.firenet_forward("FireNet", params, T(g[f"p{i}_event_voxel"]), states)
+            np.testing.assert_allclose(flow.numpy(), g[f"p{i}_flow"], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(states[1].numpy(), g[f"p{i}_state_G1"], rtol=1e-4, atol=1e-6)
+
+
+# --------------------------------------------------------------------- G9
+def test_g9_spiking_unet():
+    g = load_golden("g9_spiking_unet")
+    params = {k[len("param_"):]: T(g[k]).clone() for k in g.files if k.startswith("param_")}
+    keys = osnn.trainable_keys(params)
+    for k in keys:
+        params[k].requires_grad_(True)
+    states = [None] * 10
+    for i in range(2):
+        flows, states = osnn.spiking_unet_forward("lif", params, T(g[f"p{i}_event_cnt"]), states)
+        assert len(flows) == 4
+        for s, f in enumerate(flows):
+            np.testing.assert_allclose(f.detach().numpy(), g[f"p{i}_flow{s}"], rtol=1e-4, atol=1e-6)
+    tot = sum(f.pow(2).sum() for f in flows)
+    grads = torch.autograd.grad(tot, [params[k] for k in keys], allow_unused=True)
+    for k, gr in zip(keys, grads):
+        ref = g["grad_" + k]
+        got = gr.numpy() if gr is not None else np.zeros_like(ref)
+        assert np.abs(got - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-10) + 1e-12, k
