@@ -1,0 +1,110 @@
+"""ctypes binding of libevflow_hip.so (the C ABI declared in include/evflow.h).
+
+There is NO fallback: if the shared library is missing or a call fails the
+product path raises.  PyTorch only provides device memory (`tensor.data_ptr()`)
+and the current HIP stream.
+"""
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libevflow_hip.so")
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+F = ctypes.c_float
+L = ctypes.c_int64
+
+# name -> argument types (all functions return int)
+SIGNATURES = {
+    "evf_version": [],
+    "evf_device_count": [],
+    "evf_events_to_image": [P, P, P, I, I, I, I, P, P],
+    "evf_encode_events": [P, I, I, I, I, I, I, P, P, P, P, P],
+    "evf_iwe_splat": [P, P, P, P, P, P, I, I, I, I, I, F, F, F, I, I, P, P],
+    "evf_get_interpolation": [P, P, I, I, I, I, F, F, I, P, P, P],
+    "evf_interpolate": [P, P, P, I, I, I, I, I, P, P],
+    "evf_cm_smooth_blocks": [I, I, I, I],
+    "evf_cm_loss_fwd": [P, P, P, P, P, I, I, I, I, I, I, F, F, I, P, P, P, P, P],
+    "evf_cm_loss_bwd": [P, P, P, P, P, I, I, I, I, I, I, F, F, I, P, P, P, P, P, P],
+    "evf_image_variance": [P, I, I, P, P],
+    "evf_avg_ts_ratio": [P, I, I, F, P, P],
+    "evf_aee": [P, P, P, P, I, I, I, F, P, P],
+}
+
+# network entry points (added as the kernels land)
+NETWORK_SIGNATURES = {
+    "evf_pack_conv_weight": [P, I, I, I, P, P],
+    "evf_unpack_conv_wgrad": [P, I, I, I, P, P],
+    "evf_head_lif_fwd": [P, P, P, P, P, P, I, I, I, I, I, P, P, P],
+    "evf_conv_lif_fwd": [P, P, P, P, P, P, P, I, I, I, I, P, P, P],
+    "evf_lif_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P],
+    "evf_conv_dgrad": [P, P, P, I, P, P, I, I, I, I, P],
+    "evf_conv_wgrad_bits": [P, P, I, I, I, P, I, P],
+    "evf_conv_wgrad_slabs": [I, I, I],
+    "evf_reduce_slabs": [P, I, I, I, P, P],
+    "evf_head_wgrad": [P, P, I, I, I, I, P, P],
+    "evf_pred_fwd": [P, P, P, I, I, I, P, P],
+    "evf_pred_bwd": [P, P, P, P, I, I, I, P, P, P, P],
+    "evf_bits_to_nchw": [P, I, I, I, P, P],
+    "evf_nchw_to_bits": [P, I, I, I, P, P],
+    "evf_nhwc_to_nchw": [P, I, I, I, I, P, P],
+    "evf_nchw_to_nhwc": [P, I, I, I, I, P, P],
+    "evf_clip_adam_step": [P, P, P, P, L, F, F, F, F, F, I, P, P],
+}
+# SIGNATURES.update(NETWORK_SIGNATURES)  # enabled once evf_network.hip lands
+
+_lib = None
+
+
+class EvflowError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises EvflowError when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EvflowError(
+            f"{LIB_PATH} not found: build it with `python -m event_flow_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise EvflowError("evflow kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def call(name, *args):
+    """Invoke an entry point on torch's current stream; raise on error."""
+    rc = getattr(load(), name)(*args, stream_ptr())
+    if rc != 0:
+        raise EvflowError(f"{name} failed with status {rc}")
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise EvflowError(f"{what}: tensor is on {t.device}; the evflow path runs on the MI355X only (no CPU fallback)")
+    if t.dtype != torch.float32 and t.dtype != torch.int32:
+        raise EvflowError(f"{what}: unsupported dtype {t.dtype}")

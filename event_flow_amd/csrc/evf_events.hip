@@ -1,0 +1,701 @@
+// Event-list kernels for gfx950: window encodings, IWE warp + splat, the
+// contrast-maximisation loss (forward + backward) and the metric reductions.
+//
+// All of these are HBM / L2-atomic bound scan+scatter kernels: one thread per
+// event, 16-byte coalesced event reads, two 4-byte flow gathers, fp32 hardware
+// atomics into per-sample images that stay L2 resident (a 128x128x8-channel
+// sample is 512 KiB).  Built with -ffp-contract=off: the warp
+// `y + ((tref - t) * f) * S` must round exactly like the reference's separate
+// torch ops (utils/iwe.py:37) for the rounded-index IWE to be bit-exact.
+#include "evf_common.h"
+
+// --------------------------------------------------------------------------
+// encodings
+// --------------------------------------------------------------------------
+__global__ void k_events_to_image(const float* __restrict__ xs, const float* __restrict__ ys,
+                                  const float* __restrict__ vals, int n, int H, int W, int accumulate,
+                                  float* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // .long() truncates toward zero (dataloader/encodings.py:39-42)
+  long x = (long)xs[i], y = (long)ys[i];
+  if (x < 0 || x >= W || y < 0 || y >= H) return;  // the reference would raise IndexError
+  float v = vals[i];
+  if (accumulate)
+    evf_atomic_add(out + y * W + x, v);
+  else
+    out[y * W + x] = v;
+}
+
+extern "C" int evf_events_to_image(const float* xs, const float* ys, const float* vals, int n, int H, int W,
+                                   int accumulate, float* out, void* stream) {
+  if (!out || H <= 0 || W <= 0 || n < 0 || (n > 0 && (!xs || !ys || !vals))) return EVF_EINVAL;
+  hipStream_t st = EVF_STREAM(stream);
+  int rc = evf_hip(hipMemsetAsync(out, 0, sizeof(float) * (size_t)H * W, st));
+  if (rc || n == 0) return rc;
+  hipLaunchKernelGGL(k_events_to_image, dim3(evf_cdiv(n, 256)), dim3(256), 0, st, xs, ys, vals, n, H, W, accumulate, out);
+  return evf_status();
+}
+
+__global__ void k_encode_events(const float4* __restrict__ ev, int B, int N, int H, int W, int nb, int round_ts,
+                                float* __restrict__ cnt, float* __restrict__ mask, float* __restrict__ voxel,
+                                float2* __restrict__ pol) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * N) return;
+  const int b = (int)(i / N);
+  const float4 e = ev[i];  // (t, y, x, p)
+  const float p = e.w;
+  if (pol) pol[i] = make_float2(p > 0.f ? p : 0.f, p < 0.f ? -p : 0.f);  // base.py:210-222
+  if (p == 0.f) return;  // padding
+  const long x = (long)e.z, y = (long)e.y;
+  if (x < 0 || x >= W || y < 0 || y >= H) return;
+  const long HW = (long)H * W, px = y * W + x;
+  if (cnt) evf_atomic_add(cnt + ((long)b * 2 + (p > 0.f ? 0 : 1)) * HW + px, p * p);  // encodings.py:77-83
+  if (mask) mask[(long)b * HW + px] = fabsf(p);  // non-accumulating put, base.py:168-170
+  if (voxel) {
+    float t = e.x * (float)(nb - 1);  // encodings.py:56-59
+    if (round_ts) t = rintf(t);
+    for (int k = 0; k < nb; ++k) {
+      float w = fmaxf(0.f, 1.0f - fabsf(t - (float)k));  // :63
+      if (w != 0.f) evf_atomic_add(voxel + ((long)b * nb + k) * HW + px, p * w);
+    }
+  }
+}
+
+extern "C" int evf_encode_events(const float* ev, int B, int N, int H, int W, int num_bins, int round_ts, float* cnt,
+                                 float* mask, float* voxel, float* pol, void* stream) {
+  if (!ev || B <= 0 || N < 0 || H <= 0 || W <= 0 || (voxel && num_bins < 1)) return EVF_EINVAL;
+  hipStream_t st = EVF_STREAM(stream);
+  const size_t HW = (size_t)H * W;
+  int rc = 0;
+  if (cnt) rc |= evf_hip(hipMemsetAsync(cnt, 0, sizeof(float) * B * 2 * HW, st));
+  if (mask) rc |= evf_hip(hipMemsetAsync(mask, 0, sizeof(float) * B * HW, st));
+  if (voxel) rc |= evf_hip(hipMemsetAsync(voxel, 0, sizeof(float) * B * num_bins * HW, st));
+  if (rc || N == 0) return rc;
+  hipLaunchKernelGGL(k_encode_events, dim3(evf_cdiv((long)B * N, 256)), dim3(256), 0, st, (const float4*)ev, B, N, H, W,
+                     num_bins, round_ts, cnt, mask, voxel, (float2*)pol);
+  return evf_status();
+}
+
+// --------------------------------------------------------------------------
+// warp + splat of one event into up to four image channels
+//   I0 += w*a0, I1 += w*a1, T0 += (w*tau)*a0, T1 += (w*tau)*a1
+// ROUND: torch.round indices, weight 1 (utils/iwe.py:39-43); else the four
+// bilinear corners (utils/iwe.py:48-62).  Out-of-image corners carry weight 0
+// (purge_unfeasible, :4-17) and are simply skipped.
+// --------------------------------------------------------------------------
+struct Warp {
+  float wy, wx;
+};
+
+__device__ __forceinline__ Warp evf_warp(float t, float y, float x, float fy, float fx, float tref, float S) {
+  // events[:, :, 1:3] + (tref - t) * flow * flow_scaling   (left-to-right)
+  const float dt = tref - t;
+  Warp w;
+  w.wy = y + (dt * fy) * S;
+  w.wx = x + (dt * fx) * S;
+  return w;
+}
+
+__device__ __forceinline__ void evf_put(float* __restrict__ img, long px, float v) {
+  if (img && v != 0.f) evf_atomic_add(img + px, v);
+}
+
+template <bool ROUND>
+__device__ __forceinline__ void evf_splat(const Warp w, int H, int W, float a0, float a1, float tau, float* I0,
+                                          float* I1, float* T0, float* T1) {
+  if (ROUND) {
+    const float iy = rintf(w.wy), ix = rintf(w.wx);  // half-to-even like torch.round
+    if (iy < 0.f || iy >= (float)H || ix < 0.f || ix >= (float)W) return;
+    const long px = (long)(iy * (float)W + ix);
+    evf_put(I0, px, a0);
+    evf_put(I1, px, a1);
+    evf_put(T0, px, tau * a0);
+    evf_put(T1, px, tau * a1);
+  } else {
+    const float cy[2] = {floorf(w.wy), floorf(w.wy + 1.0f)};
+    const float cx[2] = {floorf(w.wx), floorf(w.wx + 1.0f)};
+    float ay[2], ax[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      ay[k] = fmaxf(0.f, 1.0f - fabsf(w.wy - cy[k]));
+      ax[k] = fmaxf(0.f, 1.0f - fabsf(w.wx - cx[k]));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (cy[j] < 0.f || cy[j] >= (float)H || cx[i] < 0.f || cx[i] >= (float)W) continue;
+        const float wt = ay[j] * ax[i];
+        if (wt == 0.f) continue;
+        const long px = (long)(cy[j] * (float)W + cx[i]);
+        evf_put(I0, px, wt * a0);
+        evf_put(I1, px, wt * a1);
+        const float wtau = wt * tau;  // (fw_weights * ts_list) * polarity_mask, loss/flow.py:206-211
+        evf_put(T0, px, wtau * a0);
+        evf_put(T1, px, wtau * a1);
+      }
+  }
+}
+
+__device__ __forceinline__ void evf_event_flow(const float* __restrict__ flow, int map, int B, int b, long HW, float y,
+                                               float x, int W, float& fy, float& fx) {
+  // flow_idx = y*W + x in float, then .long()  (loss/flow.py:65-67)
+  const long lin = (long)(y * (float)W + x);
+  const float* f = flow + ((long)map * B + b) * 2 * HW;
+  fx = f[lin];       // horizontal component, channel 0 (:76)
+  fy = f[HW + lin];  // vertical component, channel 1 (:75)
+}
+
+template <bool ROUND>
+__global__ void k_iwe_splat(const float* __restrict__ flow, const float4* __restrict__ ev,
+                            const int32_t* __restrict__ map_of_event, const int32_t* __restrict__ ts_shift,
+                            const float* __restrict__ w0, const float* __restrict__ w1, int wstride, int B, int M, int H,
+                            int W, float S, float tref, float tref_ts, int mode, int nch, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * M) return;
+  const int b = (int)(i / M), e = (int)(i - (long)b * M);
+  const float4 q = ev[i];
+  float t = q.x;
+  if (ts_shift) t += (float)ts_shift[e];
+  const long HW = (long)H * W;
+  float fy = 0.f, fx = 0.f;
+  evf_event_flow(flow, map_of_event ? map_of_event[e] : 0, B, b, HW, q.y, q.z, W, fy, fx);
+  if (mode & 2) {  // `flow * 0` keeps the sign/NaN semantics of the reference
+    fy *= 0.f;
+    fx *= 0.f;
+  }
+  const float a0 = w0 ? w0[i * wstride] : 1.0f;
+  const float a1 = w1 ? w1[i * wstride] : 0.0f;
+  const float tau = (mode & 8) ? (tref_ts - t) : t;
+  float* o = out + (long)b * nch * HW;
+  float *I0 = o, *I1 = nullptr, *T0 = nullptr, *T1 = nullptr;
+  if (nch >= 2) I1 = o + HW;
+  if (nch == 4) {
+    T0 = o + 2 * HW;
+    T1 = o + 3 * HW;
+  }
+  evf_splat<ROUND>(evf_warp(t, q.y, q.z, fy, fx, tref, S), H, W, a0, a1, tau, I0, I1, T0, T1);
+}
+
+extern "C" int evf_iwe_splat(const float* flow, const float* ev, const int32_t* map_of_event, const int32_t* ts_shift,
+                             const float* w0, const float* w1, int wstride, int B, int M, int H, int W,
+                             float flow_scaling, float tref, float tref_ts, int mode, int nch, float* out, void* stream) {
+  if (!flow || !out || B <= 0 || M < 0 || H <= 0 || W <= 0 || (nch != 1 && nch != 2 && nch != 4)) return EVF_EINVAL;
+  if (nch == 4 && !(mode & 4)) return EVF_EINVAL;
+  if (M > 0 && !ev) return EVF_EINVAL;
+  hipStream_t st = EVF_STREAM(stream);
+  int rc = evf_hip(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * nch * H * W, st));
+  if (rc || M == 0) return rc;
+  dim3 grid(evf_cdiv((long)B * M, 256)), block(256);
+  if (mode & 1)
+    hipLaunchKernelGGL(k_iwe_splat<true>, grid, block, 0, st, flow, (const float4*)ev, map_of_event, ts_shift, w0, w1,
+                       wstride, B, M, H, W, flow_scaling, tref, tref_ts, mode, nch, out);
+  else
+    hipLaunchKernelGGL(k_iwe_splat<false>, grid, block, 0, st, flow, (const float4*)ev, map_of_event, ts_shift, w0, w1,
+                       wstride, B, M, H, W, flow_scaling, tref, tref_ts, mode, nch, out);
+  return evf_status();
+}
+
+// --------------------------------------------------------------------------
+// materialising forms of get_interpolation / interpolate (API parity with
+// utils/iwe.py:20-92; the fused kernels above never build these tensors)
+// --------------------------------------------------------------------------
+template <bool ROUND>
+__global__ void k_get_interpolation(const float4* __restrict__ ev, const float2* __restrict__ evflow, int B, int N, int H,
+                                    int W, float S, float tref, float* __restrict__ idx, float* __restrict__ wgt) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * N) return;
+  const int b = (int)(i / N), e = (int)(i - (long)b * N);
+  const float4 q = ev[i];
+  const float2 f = evflow[i];  // (fy, fx)
+  const Warp w = evf_warp(q.x, q.y, q.z, f.x, f.y, tref, S);
+  if (ROUND) {
+    const float iy = rintf(w.wy), ix = rintf(w.wx);
+    const bool ok = !(iy < 0.f || iy >= (float)H || ix < 0.f || ix >= (float)W);
+    idx[i] = ok ? iy * (float)W + ix : 0.f;
+    wgt[i] = ok ? 1.f : 0.f;
+  } else {
+    const float cy[2] = {floorf(w.wy), floorf(w.wy + 1.0f)};
+    const float cx[2] = {floorf(w.wx), floorf(w.wx + 1.0f)};
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float ay = fmaxf(0.f, 1.0f - fabsf(w.wy - cy[j])), ax = fmaxf(0.f, 1.0f - fabsf(w.wx - cx[k]));
+        const bool ok = !(cy[j] < 0.f || cy[j] >= (float)H || cx[k] < 0.f || cx[k] >= (float)W);
+        const long o = ((long)b * 4 + (j * 2 + k)) * N + e;  // corner blocks of N: tl, tr, bl, br (:53-57)
+        idx[o] = ok ? cy[j] * (float)W + cx[k] : 0.f;
+        wgt[o] = ok ? ay * ax : 0.f;
+      }
+  }
+}
+
+extern "C" int evf_get_interpolation(const float* ev, const float* evflow, int B, int N, int H, int W, float flow_scaling,
+                                     float tref, int round_idx, float* idx, float* weights, void* stream) {
+  if (!ev || !evflow || !idx || !weights || B <= 0 || N <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  dim3 grid(evf_cdiv((long)B * N, 256)), block(256);
+  if (round_idx)
+    hipLaunchKernelGGL(k_get_interpolation<true>, grid, block, 0, EVF_STREAM(stream), (const float4*)ev,
+                       (const float2*)evflow, B, N, H, W, flow_scaling, tref, idx, weights);
+  else
+    hipLaunchKernelGGL(k_get_interpolation<false>, grid, block, 0, EVF_STREAM(stream), (const float4*)ev,
+                       (const float2*)evflow, B, N, H, W, flow_scaling, tref, idx, weights);
+  return evf_status();
+}
+
+__global__ void k_interpolate(const float* __restrict__ idx, const float* __restrict__ wgt, const float* __restrict__ pm,
+                              int pstride, int B, int M, int HW, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * M) return;
+  const int b = (int)(i / M);
+  float w = wgt[i];
+  if (pm) w *= pm[i * pstride];
+  const long px = (long)idx[i];
+  if (px < 0 || px >= HW) return;
+  if (w != 0.f) evf_atomic_add(out + (long)b * HW + px, w);
+}
+
+extern "C" int evf_interpolate(const float* idx, const float* weights, const float* pol_mask, int pstride, int B, int M,
+                               int H, int W, float* out, void* stream) {
+  if (!idx || !weights || !out || B <= 0 || M <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  hipStream_t st = EVF_STREAM(stream);
+  int rc = evf_hip(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * H * W, st));
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_interpolate, dim3(evf_cdiv((long)B * M, 256)), dim3(256), 0, st, idx, weights, pol_mask, pstride,
+                     B, M, H * W, out);
+  return evf_status();
+}
+
+// --------------------------------------------------------------------------
+// contrast-maximisation loss, forward
+// --------------------------------------------------------------------------
+// images [S][B][8][HW]: channel = dir*4 + {0: I_pos, 1: I_neg, 2: TS_pos, 3: TS_neg}
+__global__ void k_cm_splat(const float* __restrict__ flow, const float4* __restrict__ ev, const float2* __restrict__ pol,
+                           const int32_t* __restrict__ ev_pass, int S, int Pm, int P, int B, int M, int H, int W,
+                           float Sc, float* __restrict__ images) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * M) return;
+  const int s = blockIdx.y;
+  const int b = (int)(i / M), e = (int)(i - (long)b * M);
+  const float4 q = ev[i];
+  const int pass = ev_pass[e];
+  const float t = q.x + (float)pass;  // event_list[:, :, 0:1] += passes (loss/flow.py:90)
+  const float2 pm = pol[i];
+  const long HW = (long)H * W;
+  float fy, fx;
+  evf_event_flow(flow + (long)s * Pm * B * 2 * HW, Pm == 1 ? 0 : pass, B, b, HW, q.y, q.z, W, fy, fx);
+  float* o = images + ((long)s * B + b) * 8 * HW;
+  const float maxts = (float)P;
+  // forward: t_ref = P, timestamp image of t          (loss/flow.py:196-211)
+  evf_splat<false>(evf_warp(t, q.y, q.z, fy, fx, maxts, Sc), H, W, pm.x, pm.y, t, o, o + HW, o + 2 * HW, o + 3 * HW);
+  // backward: t_ref = 0, timestamp image of (P - t)   (loss/flow.py:229-244)
+  evf_splat<false>(evf_warp(t, q.y, q.z, fy, fx, 0.f, Sc), H, W, pm.x, pm.y, maxts - t, o + 4 * HW, o + 5 * HW,
+                   o + 6 * HW, o + 7 * HW);
+}
+
+// stats [S][B][2][2] += (sum over px of A_pos^2 + A_neg^2, #px with I_pos+I_neg > 0)
+#define CM_RED_CHUNK 2048
+__global__ void k_cm_reduce(const float* __restrict__ images, int HW, float P, float* __restrict__ stats) {
+  __shared__ float red[16];
+  const int sbd = blockIdx.y;  // (s*B + b)*2 + dir
+  const float* im = images + ((long)(sbd >> 1) * 8 + (sbd & 1) * 4) * HW;
+  float sq = 0.f, nz = 0.f;
+  const int p0 = blockIdx.x * CM_RED_CHUNK;
+  for (int p = p0 + threadIdx.x; p < min(HW, p0 + CM_RED_CHUNK); p += blockDim.x) {
+    const float ip = im[p], in = im[HW + p];
+    const float ap = im[2 * HW + p] / (ip + 1e-9f) / P;  // loss/flow.py:212-215
+    const float an = im[3 * HW + p] / (in + 1e-9f) / P;
+    sq += ap * ap + an * an;
+    nz += (ip + in > 0.f) ? 1.f : 0.f;
+  }
+  sq = evf_block_sum(sq, red);
+  nz = evf_block_sum(nz, red);
+  if (threadIdx.x == 0) {
+    evf_atomic_add(stats + sbd * 2, sq);
+    evf_atomic_add(stats + sbd * 2 + 1, nz);
+  }
+}
+
+// Charbonnier smoothness, loss/flow.py:183-190,261-294.  One thread per pixel
+// of one (s, p, b) flow map; each thread owns the 4 spatial pairs anchored at
+// its pixel and the temporal pair (p, p+1).
+__device__ __forceinline__ float evf_charb(float fxa, float fya, float fxb, float fyb) {
+  const float u = (fxa - fxb) + (fya - fyb);  // components summed BEFORE the square (q5)
+  return sqrtf(u * u + 1e-6f);
+}
+
+#define SM_ROWS 8
+__global__ void k_cm_smooth(const float* __restrict__ flow, const float* __restrict__ mask, int Pm, int Pk, int B, int H,
+                            int W, int use_mask, int with_dt, float* __restrict__ part) {
+  __shared__ float red[16];
+  // grid: x = row-chunk within a map, y = map index over (s, p, b)
+  const int map = blockIdx.y;  // (s*Pm + p)*B + b
+  const int b = map % B, p = (map / B) % Pm;
+  const long HW = (long)H * W;
+  const float* fx = flow + (long)map * 2 * HW;
+  const float* fy = fx + HW;
+  const float* fxn = fx + (long)B * 2 * HW;  // next pass, same (s, b)
+  const float* fyn = fxn + HW;
+  const float* m = use_mask ? mask + ((long)b * Pk + (Pk == 1 ? 0 : p)) * HW : nullptr;
+  const float* mn = (use_mask && Pk > 1) ? m + HW : m;
+  float acc = 0.f;
+  const int y0 = blockIdx.x * SM_ROWS;
+  for (int idx = threadIdx.x; idx < SM_ROWS * W; idx += blockDim.x) {
+    const int y = y0 + idx / W, x = idx % W;
+    if (y >= H) break;
+    const long c = (long)y * W + x;
+    const float ax = fx[c], ay = fy[c];
+    const float mc = m ? m[c] : 1.f;
+    const bool xr = x + 1 < W, yd = y + 1 < H;
+    if (xr) {
+      float v = evf_charb(ax, ay, fx[c + 1], fy[c + 1]);
+      acc += m ? (mc * m[c + 1]) * v : v;
+    }
+    if (yd) {
+      float v = evf_charb(ax, ay, fx[c + W], fy[c + W]);
+      acc += m ? (mc * m[c + W]) * v : v;
+    }
+    if (xr && yd) {
+      float v = evf_charb(ax, ay, fx[c + W + 1], fy[c + W + 1]);  // [:-1,:-1] - [1:,1:]
+      acc += m ? (mc * m[c + W + 1]) * v : v;
+      float u = evf_charb(fx[c + W], fy[c + W], fx[c + 1], fy[c + 1]);  // [1:,:-1] - [:-1,1:]
+      acc += m ? (m[c + W] * m[c + 1]) * u : u;
+    }
+    if (with_dt && p + 1 < Pm) {
+      float v = evf_charb(ax, ay, fxn[c], fyn[c]);
+      acc += m ? (mc * mn[c]) * v : v;
+    }
+  }
+  acc = evf_block_sum(acc, red);
+  if (threadIdx.x == 0) part[(long)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+}
+
+__global__ void k_cm_finalize(const float* __restrict__ stats, const float* __restrict__ part, int S, int B, int Pm,
+                              int nblk_per_scale, float weight, int comps, int loss_scaling, float* __restrict__ loss) {
+  __shared__ float red[16];
+  float total = 0.f;
+  for (int s = 0; s < S; ++s) {
+    float v = 0.f;
+    for (int i = threadIdx.x; i < nblk_per_scale; i += blockDim.x) v += part[(long)s * nblk_per_scale + i];
+    v = evf_block_sum(v, red);  // thread 0
+    float data = 0.f;
+    for (int i = threadIdx.x; i < B * 2; i += blockDim.x) {
+      const float* st = stats + ((long)s * B * 2 + i) * 2;
+      data += loss_scaling ? st[0] / st[1] : st[0];
+    }
+    data = evf_block_sum(data, red);
+    if (threadIdx.x == 0) total += data + weight * (v / (float)comps / (float)Pm);
+  }
+  if (threadIdx.x == 0) loss[0] = total / (float)S;
+}
+
+extern "C" int evf_cm_smooth_blocks(int B, int P, int H, int W) {
+  (void)W;
+  return evf_cdiv(H, SM_ROWS) * P * B;
+}
+
+static int cm_args_ok(const void* flow, const void* ev, const void* pol, const void* ev_pass, const void* mask, int S,
+                      int P, int B, int M, int H, int W, int flags) {
+  if (!flow || !ev || !pol || !ev_pass || S <= 0 || P <= 0 || B <= 0 || M <= 0 || H <= 1 || W <= 1) return 0;
+  if ((flags & 1) && !mask) return 0;
+  return 1;
+}
+
+extern "C" int evf_cm_loss_fwd(const float* flow, const float* ev, const float* pol, const int32_t* ev_pass,
+                               const float* mask, int S, int P, int B, int M, int H, int W, float flow_scaling,
+                               float regul_weight, int flags, float* images, float* stats, float* smooth_part,
+                               float* loss, void* stream) {
+  if (!cm_args_ok(flow, ev, pol, ev_pass, mask, S, P, B, M, H, W, flags) || !images || !stats || !smooth_part || !loss)
+    return EVF_EINVAL;
+  hipStream_t st = EVF_STREAM(stream);
+  const int overwrite = (flags & 2) ? 1 : 0;
+  const int Pm = overwrite ? 1 : P, Pk = Pm;
+  const int HW = H * W;
+  int rc = evf_hip(hipMemsetAsync(images, 0, sizeof(float) * (size_t)S * B * 8 * HW, st));
+  rc |= evf_hip(hipMemsetAsync(stats, 0, sizeof(float) * (size_t)S * B * 4, st));
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_cm_splat, dim3(evf_cdiv((long)B * M, 256), S), dim3(256), 0, st, flow, (const float4*)ev,
+                     (const float2*)pol, ev_pass, S, Pm, P, B, M, H, W, flow_scaling, images);
+  hipLaunchKernelGGL(k_cm_reduce, dim3(evf_cdiv(HW, CM_RED_CHUNK), S * B * 2), dim3(256), 0, st, images, HW, (float)P,
+                     stats);
+  const int rows = evf_cdiv(H, SM_ROWS);
+  hipLaunchKernelGGL(k_cm_smooth, dim3(rows, S * Pm * B), dim3(256), 0, st, flow, mask, Pm, Pk, B, H, W, flags & 1,
+                     overwrite ? 0 : 1, smooth_part);
+  hipLaunchKernelGGL(k_cm_finalize, dim3(1), dim3(256), 0, st, stats, smooth_part, S, B, Pm, rows * Pm * B, regul_weight,
+                     overwrite ? 4 : 5, (flags & 4) ? 1 : 0, loss);
+  return evf_status();
+}
+
+// --------------------------------------------------------------------------
+// contrast-maximisation loss, backward
+// --------------------------------------------------------------------------
+// gimages[ch] = dL/d images[ch] (scaled by grad_out / S)
+__global__ void k_cm_gimages(const float* __restrict__ images, const float* __restrict__ stats,
+                             const float* __restrict__ grad_out, int S, int HW, float P, int loss_scaling,
+                             float* __restrict__ gim) {
+  const int sbd = blockIdx.y;
+  const long base = ((long)(sbd >> 1) * 8 + (sbd & 1) * 4) * HW;
+  const float* im = images + base;
+  float* g = gim + base;
+  const float sumsq = stats[sbd * 2], nnz = loss_scaling ? stats[sbd * 2 + 1] : 1.f;
+  const float c = grad_out[0] / (float)S;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    const float ip = im[p], in = im[HW + p];
+    const float dp = ip + 1e-9f, dn = in + 1e-9f;
+    const float ap = im[2 * HW + p] / dp / P, an = im[3 * HW + p] / dn / P;
+    // d(#nonzero)/dI = 1 only where I_pos + I_neg is exactly 0 (masked assign, loss/flow.py:222-225)
+    const float dnz = (loss_scaling && !(ip + in > 0.f)) ? -sumsq / (nnz * nnz) : 0.f;
+    g[p] = c * (-2.f * ap * ap / dp / nnz + dnz);
+    g[HW + p] = c * (-2.f * an * an / dn / nnz + dnz);
+    g[2 * HW + p] = c * (2.f * ap / (dp * P) / nnz);
+    g[3 * HW + p] = c * (2.f * an / (dn * P) / nnz);
+  }
+}
+
+// d max(0, 1-|d|) / d w with torch's sub-gradients: |.|'(0) = 0, and the
+// max(0, v) tie v == 0 passes half the gradient.
+__device__ __forceinline__ void evf_tent(float w, float c, float& val, float& dval) {
+  const float d = w - c;
+  const float v = 1.0f - fabsf(d);
+  const float sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+  if (v > 0.f) {
+    val = v;
+    dval = -sg;
+  } else if (v == 0.f) {
+    val = 0.f;
+    dval = -0.5f * sg;
+  } else {
+    val = 0.f;
+    dval = 0.f;
+  }
+}
+
+__device__ __forceinline__ void evf_dir_grad(const Warp w, int H, int W, float a0, float a1, float tau,
+                                             const float* __restrict__ g, long HW, float& gwy, float& gwx) {
+  const float cy[2] = {floorf(w.wy), floorf(w.wy + 1.0f)};
+  const float cx[2] = {floorf(w.wx), floorf(w.wx + 1.0f)};
+  float ay[2], day[2], ax[2], dax[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    evf_tent(w.wy, cy[k], ay[k], day[k]);
+    evf_tent(w.wx, cx[k], ax[k], dax[k]);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (cy[j] < 0.f || cy[j] >= (float)H || cx[i] < 0.f || cx[i] >= (float)W) continue;  // mask = 0
+      const long px = (long)(cy[j] * (float)W + cx[i]);
+      // dL/d(weight of this tap)
+      float gw = 0.f;
+      if (a0 != 0.f) gw += a0 * (g[px] + tau * g[2 * HW + px]);
+      if (a1 != 0.f) gw += a1 * (g[HW + px] + tau * g[3 * HW + px]);
+      gwy += gw * (day[j] * ax[i]);
+      gwx += gw * (ay[j] * dax[i]);
+    }
+}
+
+__global__ void k_cm_event_bwd(const float* __restrict__ flow, const float4* __restrict__ ev,
+                               const float2* __restrict__ pol, const int32_t* __restrict__ ev_pass, int S, int Pm, int P,
+                               int B, int M, int H, int W, float Sc, const float* __restrict__ gim,
+                               float* __restrict__ dflow) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * M) return;
+  const int s = blockIdx.y;
+  const int b = (int)(i / M), e = (int)(i - (long)b * M);
+  const float4 q = ev[i];
+  const int pass = ev_pass[e];
+  const float t = q.x + (float)pass;
+  const float2 pm = pol[i];
+  const long HW = (long)H * W;
+  const int map = Pm == 1 ? 0 : pass;
+  float fy, fx;
+  evf_event_flow(flow + (long)s * Pm * B * 2 * HW, map, B, b, HW, q.y, q.z, W, fy, fx);
+  const float* g = gim + ((long)s * B + b) * 8 * HW;
+  const float maxts = (float)P;
+  float gfy = 0.f, gfx = 0.f;
+  {
+    float gwy = 0.f, gwx = 0.f;
+    evf_dir_grad(evf_warp(t, q.y, q.z, fy, fx, maxts, Sc), H, W, pm.x, pm.y, t, g, HW, gwy, gwx);
+    const float k = (maxts - t) * Sc;  // d warped / d flow
+    gfy += gwy * k;
+    gfx += gwx * k;
+  }
+  {
+    float gwy = 0.f, gwx = 0.f;
+    evf_dir_grad(evf_warp(t, q.y, q.z, fy, fx, 0.f, Sc), H, W, pm.x, pm.y, maxts - t, g + 4 * HW, HW, gwy, gwx);
+    const float k = (0.f - t) * Sc;
+    gfy += gwy * k;
+    gfx += gwx * k;
+  }
+  const long lin = (long)(q.y * (float)W + q.z);
+  float* d = dflow + (((long)s * Pm + map) * B + b) * 2 * HW;
+  if (gfx != 0.f) evf_atomic_add(d + lin, gfx);
+  if (gfy != 0.f) evf_atomic_add(d + HW + lin, gfy);
+}
+
+__device__ __forceinline__ float evf_dcharb(float fxa, float fya, float fxb, float fyb) {
+  const float u = (fxa - fxb) + (fya - fyb);
+  return u / sqrtf(u * u + 1e-6f);
+}
+
+// writes dflow = d(weight * smoothness)/dflow (gather form, no atomics)
+__global__ void k_cm_smooth_bwd(const float* __restrict__ flow, const float* __restrict__ mask, int S, int Pm, int Pk,
+                                int B, int H, int W, int use_mask, int with_dt, const float* __restrict__ grad_out,
+                                float scale, float* __restrict__ dflow) {
+  const int map = blockIdx.y;
+  const int b = map % B, p = (map / B) % Pm;
+  const long HW = (long)H * W;
+  const float* fx = flow + (long)map * 2 * HW;
+  const float* fy = fx + HW;
+  const long pstride = (long)B * 2 * HW;
+  const float* m = use_mask ? mask + ((long)b * Pk + (Pk == 1 ? 0 : p)) * HW : nullptr;
+  const long mstride = (use_mask && Pk > 1) ? HW : 0;
+  const float c = grad_out[0] * scale;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < H * W; idx += gridDim.x * blockDim.x) {
+    const int y = idx / W, x = idx % W;
+    const long q = idx;
+    const float ax = fx[q], ay = fy[q];
+    const float mc = m ? m[q] : 1.f;
+    float g = 0.f;
+#define PAIR_A(dq, ok) /* this pixel is the minuend, partner at q+dq */ \
+  if (ok) g += (m ? mc * m[q + (dq)] : 1.f) * evf_dcharb(ax, ay, fx[q + (dq)], fy[q + (dq)]);
+#define PAIR_B(dq, ok) /* this pixel is the subtrahend */ \
+  if (ok) g -= (m ? mc * m[q + (dq)] : 1.f) * evf_dcharb(fx[q + (dq)], fy[q + (dq)], ax, ay);
+    const bool xl = x > 0, xr = x + 1 < W, yu = y > 0, yd = y + 1 < H;
+    PAIR_A(1, xr)            // dx anchored here
+    PAIR_B(-1, xl)           // dx anchored at (y, x-1)
+    PAIR_A(W, yd)            // dy
+    PAIR_B(-W, yu)
+    PAIR_A(W + 1, xr && yd)  // diag down-right
+    PAIR_B(-W - 1, xl && yu)
+    PAIR_A(-W + 1, xr && yu)  // up-right: a = (y, x) is the lower-left of the pair anchored at (y-1, x)
+    PAIR_B(W - 1, xl && yd)   // up-right anchored at (y, x-1): a = (y+1, x-1), b = (y, x)
+#undef PAIR_A
+#undef PAIR_B
+    if (with_dt) {
+      if (p + 1 < Pm)
+        g += (m ? mc * m[q + mstride] : 1.f) * evf_dcharb(ax, ay, fx[q + pstride], fy[q + pstride]);
+      if (p > 0) g -= (m ? mc * m[q - mstride] : 1.f) * evf_dcharb(fx[q - pstride], fy[q - pstride], ax, ay);
+    }
+    g *= c;
+    float* d = dflow + (long)map * 2 * HW;
+    d[q] = g;       // u depends on fx + fy symmetrically
+    d[HW + q] = g;
+  }
+}
+
+extern "C" int evf_cm_loss_bwd(const float* flow, const float* ev, const float* pol, const int32_t* ev_pass,
+                               const float* mask, int S, int P, int B, int M, int H, int W, float flow_scaling,
+                               float regul_weight, int flags, const float* images, const float* stats,
+                               const float* grad_out, float* gimages, float* dflow, void* stream) {
+  if (!cm_args_ok(flow, ev, pol, ev_pass, mask, S, P, B, M, H, W, flags) || !images || !stats || !grad_out ||
+      !gimages || !dflow)
+    return EVF_EINVAL;
+  hipStream_t st = EVF_STREAM(stream);
+  const int overwrite = (flags & 2) ? 1 : 0;
+  const int Pm = overwrite ? 1 : P, Pk = Pm;
+  const int HW = H * W;
+  const int comps = overwrite ? 4 : 5;
+  hipLaunchKernelGGL(k_cm_smooth_bwd, dim3(evf_cdiv(HW, 256), S * Pm * B), dim3(256), 0, st, flow, mask, S, Pm, Pk, B, H,
+                     W, flags & 1, overwrite ? 0 : 1, grad_out, regul_weight / (float)comps / (float)Pm / (float)S,
+                     dflow);
+  hipLaunchKernelGGL(k_cm_gimages, dim3(evf_cdiv(HW, 256), S * B * 2), dim3(256), 0, st, images, stats, grad_out, S, HW,
+                     (float)P, (flags & 4) ? 1 : 0, gimages);
+  hipLaunchKernelGGL(k_cm_event_bwd, dim3(evf_cdiv((long)B * M, 256), S), dim3(256), 0, st, flow, (const float4*)ev,
+                     (const float2*)pol, ev_pass, S, Pm, P, B, M, H, W, flow_scaling, gimages, dflow);
+  return evf_status();
+}
+
+// --------------------------------------------------------------------------
+// metric reductions
+// --------------------------------------------------------------------------
+__global__ void k_image_variance(const float* __restrict__ img, int HW, float* __restrict__ out) {
+  __shared__ float red[16];
+  __shared__ float mean_s;
+  const float* im = img + (long)blockIdx.x * HW;
+  float s = 0.f;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) s += im[p];
+  s = evf_block_sum(s, red);
+  if (threadIdx.x == 0) mean_s = s / (float)HW;
+  __syncthreads();
+  const float mean = mean_s;
+  float v = 0.f;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const float d = im[p] - mean;
+    v += d * d;
+  }
+  v = evf_block_sum(v, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = v / (float)(HW - 1);  // unbiased, loss/flow.py:13-23
+}
+
+extern "C" int evf_image_variance(const float* img, int B, int HW, float* out, void* stream) {
+  if (!img || !out || B <= 0 || HW <= 1) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_image_variance, dim3(B), dim3(1024), 0, EVF_STREAM(stream), img, HW, out);
+  return evf_status();
+}
+
+__global__ void k_avg_ts_ratio(const float* __restrict__ images, int HW, float P, float* __restrict__ out) {
+  __shared__ float red[16];
+  const float* im = images + (long)blockIdx.x * 4 * HW;
+  float sq = 0.f, nz = 0.f;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const float ip = im[p], in = im[HW + p];
+    const float ap = im[2 * HW + p] / (ip + 1e-9f) / P, an = im[3 * HW + p] / (in + 1e-9f) / P;
+    sq += ap * ap + an * an;
+    nz += (ip + in > 0.f) ? 1.f : 0.f;
+  }
+  sq = evf_block_sum(sq, red);
+  nz = evf_block_sum(nz, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = sq / nz;
+}
+
+extern "C" int evf_avg_ts_ratio(const float* images, int B, int HW, float P, float* out, void* stream) {
+  if (!images || !out || B <= 0 || HW <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_avg_ts_ratio, dim3(B), dim3(1024), 0, EVF_STREAM(stream), images, HW, P, out);
+  return evf_status();
+}
+
+__global__ void k_aee(const float* __restrict__ flow, const float* __restrict__ gt, const float* __restrict__ mask,
+                      const float* __restrict__ ratio, int HW, float S, float* __restrict__ out) {
+  __shared__ float red[16];
+  const int b = blockIdx.x;
+  const float* f = flow + (long)b * 2 * HW;
+  const float* g = gt + (long)b * 2 * HW;
+  const float* m = mask + (long)b * HW;
+  const float r = ratio[b];
+  float se = 0.f, nv = 0.f, no = 0.f;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const float fx = f[p] * S * r, fy = f[HW + p] * S * r;  // loss/flow.py:597-598
+    const float gx = g[p], gy = g[HW + p];
+    const bool valid = (m[p] != 0.f) && !((gx == 0.f) && (gy == 0.f));  // :605-614
+    const float err = valid ? sqrtf((fx - gx) * (fx - gx) + (fy - gy) * (fy - gy)) : 0.f;
+    const float mag = valid ? sqrtf(fx * fx + fy * fy) : 0.f;
+    se += err;
+    nv += valid ? 1.f : 0.f;
+    no += ((err > 3.0f) && (err > 0.05f * mag)) ? 1.f : 0.f;  // :625
+  }
+  se = evf_block_sum(se, red);
+  nv = evf_block_sum(nv, red);
+  no = evf_block_sum(no, red);
+  if (threadIdx.x == 0) {
+    out[b * 3] = se;
+    out[b * 3 + 1] = nv;
+    out[b * 3 + 2] = no;
+  }
+}
+
+extern "C" int evf_aee(const float* flow, const float* gt, const float* mask, const float* ratio, int B, int H, int W,
+                       float flow_scaling, float* out, void* stream) {
+  if (!flow || !gt || !mask || !ratio || !out || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_aee, dim3(B), dim3(1024), 0, EVF_STREAM(stream), flow, gt, mask, ratio, H * W, flow_scaling, out);
+  return evf_status();
+}
+
+extern "C" int evf_version(void) { return 100; }
+extern "C" int evf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}

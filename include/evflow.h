@@ -1,0 +1,228 @@
+/*
+ * evflow.h -- C ABI of libevflow_hip.so, the MI355X (gfx950) implementation of
+ * the tudelft/event_flow hot path.
+ *
+ * The reference has no FFI of its own: its boundary is the Python API of
+ * dataloader/encodings.py, utils/iwe.py, loss/flow.py and models/{model,...}.py
+ * (SURVEY.md section 8b).  The host-side mirror of that API lives in
+ * event_flow_amd/ and binds exactly these entry points through ctypes
+ * (event_flow_amd/_lib.py); INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to contiguous float32 unless noted;
+ *  - `stream` is a hipStream_t (passed as void*); work is only enqueued, the
+ *    call never synchronises, allocates or frees;
+ *  - return 0 on success, -22 (EINVAL) on a bad argument, -(1000+hipError_t)
+ *    when a launch fails; nothing throws;
+ *  - images are row-major [H][W]; events are rows (t, y, x, p) as in the
+ *    reference's `event_list` (dataloader/base.py:197-208, [B,N,4] after
+ *    custom_collate :248-265); flow maps are [B,2,H,W] with channel 0 = x and
+ *    channel 1 = y (loss/flow.py:74-76);
+ *  - activations inside the network are channels-last: v [B,H,W,C] float32,
+ *    spikes bit-packed one uint32 per pixel per 32 channels [B,H,W,C/32].
+ */
+#ifndef EVFLOW_H
+#define EVFLOW_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVF_OK 0
+#define EVF_EINVAL (-22)
+
+/* library / device probe (no GPU work) */
+int evf_version(void);          /* 100*major + minor */
+int evf_device_count(void);     /* hipGetDeviceCount, 0 when there is no GPU */
+
+/* ------------------------------------------------------------------ encodings
+ * dataloader/encodings.py:30-45  events_to_image: img[y][x] (+)= val.
+ * xs, ys, vals: [n] float32 (indices are truncated like .long()).
+ * accumulate=0 -> plain store (last writer wins), out is zero-filled first. */
+int evf_events_to_image(const float* xs, const float* ys, const float* vals, int n,
+                        int H, int W, int accumulate, float* out, void* stream);
+
+/* Batched window encoding straight from the event list (replaces the
+ * per-sample CPU loop of dataloader/h5.py:282-286):
+ *   cnt   [B,2,H,W]  dataloader/encodings.py:70-85  (events_to_channels)
+ *   mask  [B,1,H,W]  dataloader/base.py:159-171     (create_mask_encoding)
+ *   voxel [B,nb,H,W] dataloader/encodings.py:48-67  (events_to_voxel)
+ *   pol   [B,N,2]    dataloader/base.py:210-222     (create_polarity_mask)
+ * Any output pointer may be NULL.  Events with p == 0 are padding and are
+ * ignored everywhere. */
+int evf_encode_events(const float* ev, int B, int N, int H, int W, int num_bins, int round_ts,
+                      float* cnt, float* mask, float* voxel, float* pol, void* stream);
+
+/* ------------------------------------------------------------------ IWE
+ * Generic warp + splat (utils/iwe.py:20-92 get_interpolation + interpolate).
+ *   flow      [n_maps,B,2,H,W]   flow maps; event e of sample b uses map
+ *                                 map_of_event[e] (NULL -> map 0)
+ *   ev        [B,M,4]            events (t,y,x,p); t is shifted by
+ *                                 ts_shift[e] (int32 [M], NULL -> 0) before use
+ *                                 (loss/flow.py:90)
+ *   w0, w1    per-event weights with element stride wstride and batch stride
+ *             M*wstride (the polarity masks); NULL -> 1.0 / unused
+ *   out       [B,nch,H,W], zero-filled by the call.
+ *   mode bits: 1 = round indices (torch.round, half-to-even) instead of bilinear
+ *              2 = zero flow (FWL/RSAT "image of events", loss/flow.py:491-494)
+ *              4 = also accumulate w*tau images (tau = t, or tref_ts - t when
+ *                  mode&8): channel order (I_w0, I_w1, TS_w0, TS_w1)
+ *   nch = 1 (w0 only / no weights), 2 (w0,w1) or 4 (with mode&4).
+ * mode=1, nch=2, tref=1 is compute_pol_iwe (utils/iwe.py:132-153): integer
+ * valued, bit-exact. */
+int evf_iwe_splat(const float* flow, const float* ev, const int32_t* map_of_event, const int32_t* ts_shift,
+                  const float* w0, const float* w1, int wstride,
+                  int B, int M, int H, int W, float flow_scaling, float tref, float tref_ts,
+                  int mode, int nch, float* out, void* stream);
+
+/* Materialising forms kept for API parity with utils/iwe.py:
+ *   get_interpolation (:20-74): ev [B,N,4], evflow [B,N,2] (fy,fx) ->
+ *     idx, weights [B,M,1] float32, M = N (round_idx) or 4N in corner blocks
+ *     (top-left, top-right, bottom-left, bottom-right), purged like :4-17,65-72;
+ *   interpolate (:77-92): scatter-add weights (* pol_mask, element stride
+ *     pstride) into out [B,1,H,W] (zero-filled by the call). */
+int evf_get_interpolation(const float* ev, const float* evflow, int B, int N, int H, int W,
+                          float flow_scaling, float tref, int round_idx,
+                          float* idx, float* weights, void* stream);
+int evf_interpolate(const float* idx, const float* weights, const float* pol_mask, int pstride,
+                    int B, int M, int H, int W, float* out, void* stream);
+
+/* Contrast-maximisation loss, loss/flow.py:176-301 (EventWarping.forward).
+ * One call handles all S flow scales of one window.
+ *   flow   [S,Pm,B,2,H,W] (Pm = P, or 1 when overwrite_intermediate)
+ *   ev     [B,M,4], pol [B,M,2], ev_pass int32 [M] (pass index of each event)
+ *   mask   [B,Pk,H,W] event masks (Pk = P or 1), may be NULL when !use_mask
+ *   images [S,B,8,H,W] workspace: (fw,bw) x (pos,neg) x (IWE, TS)   (saved)
+ *   stats  [S,B,2,2]   workspace: per direction (sum A^2, #nonzero px) (saved)
+ *   smooth_part [S,nblk_smooth] workspace (evf_cm_smooth_blocks gives nblk)
+ *   loss   [1] output.
+ * flags: 1 = use smoothing mask, 2 = overwrite_intermediate, 4 = loss_scaling */
+int evf_cm_smooth_blocks(int B, int P, int H, int W);
+int evf_cm_loss_fwd(const float* flow, const float* ev, const float* pol, const int32_t* ev_pass,
+                    const float* mask, int S, int P, int B, int M, int H, int W,
+                    float flow_scaling, float regul_weight, int flags,
+                    float* images, float* stats, float* smooth_part, float* loss, void* stream);
+
+/* Backward of the above: dflow [S,Pm,B,2,H,W] = grad_out * dL/dflow (written,
+ * not accumulated).  gimages [S,B,8,H,W] is scratch.  Reproduces the
+ * max(0,1-|d|) tie sub-gradient (0.5) and the #nonzero-px denominator path
+ * of the reference under torch>=1.8 autograd. */
+int evf_cm_loss_bwd(const float* flow, const float* ev, const float* pol, const int32_t* ev_pass,
+                    const float* mask, int S, int P, int B, int M, int H, int W,
+                    float flow_scaling, float regul_weight, int flags,
+                    const float* images, const float* stats, const float* grad_out,
+                    float* gimages, float* dflow, void* stream);
+
+/* Per-sample reductions used by FWL / RSAT (loss/flow.py:481-579):
+ *   evf_image_variance: unbiased variance over H*W of img [B,1,H,W] -> [B]
+ *   evf_avg_ts_ratio  : images [B,4,H,W] (I_pos,I_neg,TS_pos,TS_neg) ->
+ *                       sum((TS/(I+1e-9)/P)^2)/#{I_pos+I_neg>0}  [B]            */
+int evf_image_variance(const float* img, int B, int HW, float* out, void* stream);
+int evf_avg_ts_ratio(const float* images, int B, int HW, float P, float* out, void* stream);
+
+/* AEE, loss/flow.py:594-628.  flow, gt [B,2,H,W]; mask [B,H,W]; ratio [B] =
+ * dt_gt/dt_input per sample; out [B,3] = (sum err, n valid, n outliers). */
+int evf_aee(const float* flow, const float* gt, const float* mask, const float* ratio,
+            int B, int H, int W, float flow_scaling, float* out, void* stream);
+
+/* ------------------------------------------------------------------ network
+ * Conv + spiking-neuron cells, models/spiking_submodules.py.
+ * Weights are passed in a packed layout produced by evf_pack_conv_weight from
+ * the reference's [Cout,Cin,k,k] tensors.
+ *
+ * neuron kinds */
+#define EVF_LIF 0
+#define EVF_PLIF 1
+#define EVF_ALIF 2
+#define EVF_XLIF 3
+/* surrogate gradients, models/spiking_util.py:28-93 */
+#define EVF_ARCTAN 0
+#define EVF_SUPERSPIKE 1
+#define EVF_TRIANGLE 2
+#define EVF_MULTIGAUSS 3
+
+/* Repack a conv weight [Cout,Cin,3,3] (float32, torch layout) into the MFMA
+ * operand layout used by the conv kernels: fwd -> B operand of
+ * out[pix][co] += x[pix+tap][ci]*w ; transposed=1 builds the (flipped,
+ * transposed) operand of the input-gradient conv.  dst has 9*Cin*Cout floats
+ * (Cin, Cout multiples of 32). */
+int evf_pack_conv_weight(const float* w, int Cout, int Cin, int transposed, float* dst, void* stream);
+/* inverse for weight gradients: packed [9][Cin][Cout] accumulators -> torch layout, dst (+)= */
+int evf_unpack_conv_wgrad(const float* packed, int Cout, int Cin, int accumulate, float* dst, void* stream);
+
+/* Head cell: dense small-Cin 3x3 conv (+ LIF update).  ConvLIF.forward
+ * (spiking_submodules.py:96-126) with real-valued input x [B,Cin,H,W] (NCHW,
+ * the event count / voxel tensor), Cin <= 8, Cout = 32.
+ *   w [32,Cin,3,3] torch layout; leak, thresh [32] raw parameters
+ *   v_prev [B,H,W,32] or NULL (zeros); z_prev bits [B,H,W] or NULL
+ *   outputs v_out [B,H,W,32], z_out bits [B,H,W] */
+int evf_head_lif_fwd(const float* x, const float* w, const float* leak, const float* thresh,
+                     const float* v_prev, const uint32_t* z_prev, int B, int Cin, int H, int W,
+                     int hard_reset, float* v_out, uint32_t* z_out, void* stream);
+
+/* 32->32 channel spiking conv cell on bit-packed spikes.
+ * ConvLIF.forward (:96-126) when z_rec_w == NULL, ConvLIFRecurrent.forward
+ * (:516-551) otherwise.  x bits [B,H,W] is the input spike map, z_prev the
+ * cell's own previous spikes.  w_ff / w_rec packed (evf_pack_conv_weight). */
+int evf_conv_lif_fwd(const uint32_t* x, const float* w_ff, const float* w_rec,
+                     const float* leak, const float* thresh,
+                     const float* v_prev, const uint32_t* z_prev, int B, int H, int W,
+                     int hard_reset, float* v_out, uint32_t* z_out, void* stream);
+
+/* Neuron backward (autograd of :103-126 / :523-551 with the surrogate of
+ * spiking_util.py:88-93).  Per element:
+ *   g_v = g_v_out + g_z_out * sg(v_out - thresh)
+ *   g_cur = g_v * (1 - leak)                 -> g_cur [B,H,W,32]
+ *   g_v_prev = g_v * leak * (1 - z_prev)     (hard)  |  g_v * leak (soft)
+ * and per-channel sums into g_leak[32], g_thresh[32] (accumulated).
+ * g_z_out may be NULL (zeros), g_v_out may be NULL (zeros). g_v_prev may alias g_v_out. */
+int evf_lif_bwd(const float* g_z_out, const float* g_v_out, const float* v_out,
+                const float* v_prev, const uint32_t* z_prev,
+                const float* leak, const float* thresh, int B, int H, int W,
+                int hard_reset, int surrogate, float act_width,
+                float* g_cur, float* g_v_prev, float* g_leak, float* g_thresh, void* stream);
+
+/* Input-gradient conv: g_x[pix][ci] (+)= sum_tap,co g_cur[pix-tap][co]*w[co][ci][tap]
+ * with wT packed by evf_pack_conv_weight(transposed=1).  g_cur, g_x [B,H,W,32].
+ * Second (optional) weight/output pair shares the g_cur tile (ff + rec). */
+int evf_conv_dgrad(const float* g_cur, const float* wT_a, float* g_a, int acc_a,
+                   const float* wT_b, float* g_b, int acc_b, int B, int H, int W, void* stream);
+
+/* Weight-gradient conv on bit-packed inputs:
+ * dW[tap][ci][co] += sum_pix x[pix+tap][ci] * g_cur[pix][co]; wg packed accumulators. */
+int evf_conv_wgrad_bits(const uint32_t* x, const float* g_cur, int B, int H, int W,
+                        float* wg_partial, int nslab, void* stream);
+int evf_conv_wgrad_slabs(int B, int H, int W);
+int evf_reduce_slabs(const float* partial, int nslab, int n, int accumulate, float* dst, void* stream);
+
+/* Head weight gradient: dW[co][ci][ky][kx] += sum g_cur[pix][co]*x[b][ci][pix+tap] (torch layout out). */
+int evf_head_wgrad(const float* x, const float* g_cur, int B, int Cin, int H, int W, float* dw, void* stream);
+
+/* Prediction head: 1x1 conv 32->2 + bias + tanh (models/submodules.py:52-61,
+ * model.py:197-199) on bit-packed spikes -> flow [B,2,H,W] (NCHW). */
+int evf_pred_fwd(const uint32_t* x, const float* w, const float* bias, int B, int H, int W,
+                 float* flow, void* stream);
+/* backward: g_x [B,H,W,32] (written), dw [2,32] and dbias [2] accumulated */
+int evf_pred_bwd(const uint32_t* x, const float* flow, const float* g_flow, const float* w,
+                 int B, int H, int W, float* g_x, float* dw, float* dbias, void* stream);
+
+/* spike bit maps <-> float tensors (state API, models/model.py:203-209) */
+int evf_bits_to_nchw(const uint32_t* bits, int B, int H, int W, float* out, void* stream);
+int evf_nchw_to_bits(const float* in, int B, int H, int W, uint32_t* bits, void* stream);
+int evf_nhwc_to_nchw(const float* in, int B, int C, int H, int W, float* out, void* stream);
+int evf_nchw_to_nhwc(const float* in, int B, int C, int H, int W, float* out, void* stream);
+
+/* ------------------------------------------------------------------ optimiser
+ * train_flow.py:157-163: clip_grad_norm_(max_norm) + Adam(lr) on one flat
+ * parameter buffer.  norm_ws [2] float workspace.  step counts from 1. */
+int evf_clip_adam_step(float* param, const float* grad, float* m, float* v, int64_t n,
+                       float max_norm, float lr, float beta1, float beta2, float eps, int step,
+                       float* norm_ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVFLOW_H */

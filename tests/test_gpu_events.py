@@ -1,0 +1,262 @@
+"""GPU parity of the event-list kernels (encodings, IWE, CM loss, metrics):
+HIP path (through the C ABI) vs the reference-generated golden fixtures and
+vs the CPU oracle on seeded inputs.  Integer results bit-exact."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cases, load_golden
+
+pytestmark = pytest.mark.gpu
+
+from event_flow_amd import synthetic  # noqa: E402
+from event_flow_amd.dataloader import encodings as enc  # noqa: E402
+from event_flow_amd.loss import flow as hloss  # noqa: E402
+from event_flow_amd.utils import iwe as hiwe  # noqa: E402
+from oracle import encodings as oenc  # noqa: E402
+from oracle import iwe as oiwe  # noqa: E402
+from oracle import loss as oloss  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def G(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def cfg(H, W, mask=True, overwrite=False, weight=0.001):
+    return {"loader": {"resolution": [H, W]}, "loss": {"flow_regul_weight": weight, "overwrite_intermediate": overwrite}, "model": {"mask_output": mask}}
+
+
+# ------------------------------------------------------------------ encodings
+def test_encodings_golden_bit_exact():
+    g = load_golden("g1_encodings")
+    xs, ys, ts, ps = (G(g[k]) for k in ("xs", "ys", "ts", "ps"))
+    res = tuple(int(v) for v in g["sensor"])
+    assert np.array_equal(N(enc.events_to_channels(xs, ys, ps, sensor_size=res)), g["cnt"])
+    assert np.array_equal(N(enc.events_to_image(xs, ys, ps.abs(), sensor_size=res, accumulate=False)), g["mask"])
+    assert np.array_equal(N(enc.events_to_image(xs, ys, ps, sensor_size=res, accumulate=True)), g["image_acc"])
+    for nb in (2, 5):
+        got = N(enc.events_to_voxel(xs, ys, ts, ps, nb, sensor_size=res, round_ts=True))
+        assert np.array_equal(got, g[f"voxel_nb{nb}_r1"])  # rounded ts: integer valued -> exact
+        got = N(enc.events_to_voxel(xs, ys, ts, ps, nb, sensor_size=res, round_ts=False))
+        np.testing.assert_allclose(got, g[f"voxel_nb{nb}_r0"], rtol=0, atol=2e-6)  # fp32 atomics reorder the sum
+
+
+def test_encode_event_list_batched_vs_oracle():
+    B, n, H, W = 8, 15000, 128, 128
+    ev = synthetic.event_list_batch(B, n, H, W, 1234)
+    out = enc.encode_event_list(G(ev), 2, (H, W))
+    for b in range(B):
+        o = oenc.encode_window(ev[b, :, 2], ev[b, :, 1], ev[b, :, 0], ev[b, :, 3], 2, (H, W))
+        assert np.array_equal(N(out["event_cnt"][b]), o["event_cnt"])
+        assert np.array_equal(N(out["event_mask"][b]), o["event_mask"])
+        assert np.array_equal(N(out["event_list_pol_mask"][b]), o["event_list_pol_mask"].T)
+        np.testing.assert_allclose(N(out["event_voxel"][b]), o["event_voxel"], rtol=0, atol=1e-5)
+    # checksum of checksums: every event counted exactly once
+    assert float(out["event_cnt"].sum()) == B * n
+
+
+def test_encodings_edge_cases():
+    H, W = 16, 20
+    empty = torch.zeros(0, device=DEV)
+    assert float(enc.events_to_image(empty, empty, empty, sensor_size=(H, W)).abs().sum()) == 0.0
+    # padded (p == 0) rows are ignored
+    ev = synthetic.event_list_batch(2, 100, H, W, 5)
+    ev[:, 50:, 3] = 0
+    out = enc.encode_event_list(G(ev), 3, (H, W))
+    assert float(out["event_cnt"].sum()) == 100.0
+    with pytest.raises(AssertionError):
+        enc.events_to_channels(torch.zeros(3, device=DEV), torch.zeros(2, device=DEV), torch.zeros(3, device=DEV))
+    from event_flow_amd._lib import EvflowError
+    with pytest.raises(EvflowError):
+        enc.events_to_image(torch.zeros(3), torch.zeros(3), torch.zeros(3))  # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------ IWE
+@pytest.mark.parametrize("tref", [1, 3, 0])
+@pytest.mark.parametrize("rnd", [0, 1])
+@pytest.mark.parametrize("S", [16, 128])
+def test_get_interpolation_golden_bit_exact(tref, rnd, S):
+    g = load_golden("g2_interpolation")
+    res = tuple(int(v) for v in g["res"])
+    idx, w = hiwe.get_interpolation(G(g["events"]), G(g["flow"]), tref, res, S, round_idx=bool(rnd))
+    assert np.array_equal(N(idx), g[f"idx_t{tref}_r{rnd}_s{S}"])
+    assert np.array_equal(N(w), g[f"w_t{tref}_r{rnd}_s{S}"])
+
+
+@pytest.mark.parametrize("tag", ["c1", "b2"])
+@pytest.mark.parametrize("S", [128, 32])
+def test_compute_pol_iwe_golden(tag, S):
+    g = load_golden("g3_pol_iwe")
+    ev, flow, pol = G(g[tag + "_events"]), G(g[tag + "_flow"]), G(g[tag + "_pol"])
+    res = tuple(int(v) for v in g[tag + "_res"])
+    got = hiwe.compute_pol_iwe(flow, ev, res, pol[:, :, 0:1], pol[:, :, 1:2], flow_scaling=S, round_idx=True)
+    assert np.array_equal(N(got), g[f"{tag}_iwe_s{S}_r1"])  # integer histogram: bit exact
+    got = hiwe.compute_pol_iwe(flow, ev, res, pol[:, :, 0:1], pol[:, :, 1:2], flow_scaling=S, round_idx=False)
+    np.testing.assert_allclose(N(got), g[f"{tag}_iwe_s{S}_r0"], rtol=0, atol=3e-6)
+    # materialising API gives the same image
+    idx, w = hiwe.get_interpolation(ev, oloss_gather(flow, ev, res), 1, res, S, round_idx=True)
+    pos = hiwe.interpolate(idx, w, res, polarity_mask=pol[:, :, 0:1])
+    assert np.array_equal(N(pos[:, 0]), g[f"{tag}_iwe_s{S}_r1"][:, 0])
+
+
+def oloss_gather(flow, ev, res):
+    return G(oiwe.gather_event_flow(N(flow), N(ev), res))
+
+
+def test_pol_iwe_full_size_vs_oracle_and_properties():
+    """BASELINE config 2 shape: B=8, 128x128, 15k events."""
+    B, n, H, W = 8, 15000, 128, 128
+    ev = synthetic.event_list_batch(B, n, H, W, 2000)
+    rng = np.random.default_rng(3)
+    flow = rng.uniform(-0.1, 0.1, size=(B, 2, H, W)).astype(np.float32)
+    pol = np.stack([(ev[:, :, 3] > 0), (ev[:, :, 3] < 0)], 2).astype(np.float32)
+    gpol = G(pol)
+    got = N(hiwe.compute_pol_iwe(G(flow), G(ev), (H, W), gpol[:, :, 0:1], gpol[:, :, 1:2], flow_scaling=128, round_idx=True))
+    ref = oiwe.compute_pol_iwe(flow, ev, (H, W), pol[:, :, 0:1], pol[:, :, 1:2], flow_scaling=128, round_idx=True)
+    assert np.array_equal(got, ref)
+    # zero flow => IWE == event count image (loss/flow.py:491-494)
+    z = N(hiwe.compute_pol_iwe(G(flow * 0), G(ev), (H, W), gpol[:, :, 0:1], gpol[:, :, 1:2], round_idx=True))
+    cnt = N(enc.encode_event_list(G(ev), 2, (H, W))["event_cnt"])
+    assert np.array_equal(z, cnt)
+    # bilinear weights of in-image events sum to 1: total mass <= number of events, equal for zero flow
+    bl = hiwe.compute_pol_iwe(G(flow * 0), G(ev), (H, W), gpol[:, :, 0:1], gpol[:, :, 1:2], round_idx=False)
+    assert float(bl.sum()) == B * n
+
+
+# ------------------------------------------------------------------ CM loss
+def _run_hip_loss(g, c, H, W):
+    tag = c["tag"]
+    lossf = hloss.EventWarping(cfg(H, W, c["mask"], c["overwrite"]), DEV)
+    flows = []
+    for k in range(c["P"]):
+        fl = [G(g[f"{tag}_p{k}_flow{s}"]).requires_grad_(True) for s in range(c["scales"])]
+        flows.append(fl)
+        ev = G(g[f"{tag}_p{k}_event_list"])
+        ev0 = ev.clone()
+        lossf.event_flow_association(fl, ev, G(g[f"{tag}_p{k}_event_list_pol_mask"]), G(g[f"{tag}_p{k}_event_mask"]))
+        assert torch.equal(ev, ev0)  # caller's tensor is not mutated
+    if c["overwrite"]:
+        lossf.overwrite_intermediate_flow(flows[-1])
+    val = lossf()
+    val.backward()
+    return val, flows
+
+
+def test_event_warping_golden_loss_and_grad():
+    g = load_golden("g4_event_warping")
+    H, W = (int(v) for v in g["res"])
+    for c in golden_cases(g):
+        val, flows = _run_hip_loss(g, c, H, W)
+        np.testing.assert_allclose(float(val.detach()), float(g[c["tag"] + "_loss"]), rtol=1e-5, err_msg=str(c))
+        for k in range(c["P"]):
+            for s in range(c["scales"]):
+                ref = g[f"{c['tag']}_p{k}_gflow{s}"]
+                got = flows[k][s].grad
+                got = N(got) if got is not None else np.zeros_like(ref)
+                # fp32 atomics reorder the image sums; the gradient divides by small IWE
+                # values, so element-wise noise reaches ~1e-4 of the max (the reference's own
+                # fp32 gradient is 1e-4..1e-2 away from a float64 evaluation on these cases)
+                scale = max(np.abs(ref).max(), 1e-12)
+                assert np.abs(got - ref).max() <= 1e-3 * scale + 1e-9, (c, k, s, np.abs(got - ref).max(), scale)
+                assert np.linalg.norm(got - ref) <= 2e-4 * np.linalg.norm(ref) + 1e-9, (c, k, s)
+
+
+@pytest.mark.parametrize("P,n", [(1, 15000), (10, 1500)])
+def test_event_warping_full_size_vs_oracle(P, n):
+    """config 2 shape (B=8, 128x128, 15k events per window) against the oracle."""
+    B, H, W = 8, 128, 128
+    rng = np.random.default_rng(100 + P)
+    lossf = hloss.EventWarping(cfg(H, W), DEV)
+    win = oloss.Window((H, W))
+    gflows, oflows = [], []
+    for k in range(P):
+        ev = synthetic.event_list_batch(B, n, H, W, 7000 + 100 * k)
+        d = oenc.collate([oenc.encode_window(ev[b, :, 2], ev[b, :, 1], ev[b, :, 0], ev[b, :, 3], 2, (H, W)) for b in range(B)])
+        f = rng.uniform(-0.05, 0.05, size=(B, 2, H, W)).astype(np.float32)
+        gf, of = G(f).requires_grad_(True), torch.from_numpy(f).requires_grad_(True)
+        gflows.append(gf)
+        oflows.append(of)
+        lossf.event_flow_association([gf], G(d["event_list"]), G(d["event_list_pol_mask"]), G(d["event_mask"]))
+        win.add([of], torch.from_numpy(d["event_list"]), torch.from_numpy(d["event_list_pol_mask"]), torch.from_numpy(d["event_mask"]))
+    val = lossf()
+    val.backward()
+    ref = oloss.event_warping_loss(win, max(H, W), 0.001)
+    ref.backward()
+    np.testing.assert_allclose(float(val), float(ref), rtol=2e-5)
+    for gf, of in zip(gflows, oflows):
+        r = of.grad.numpy()
+        assert np.abs(N(gf.grad) - r).max() <= 2e-4 * np.abs(r).max()
+
+
+def test_demo_iwe_known_answer():
+    """tools/demo_iwe.py:69-91 idea: for events generated by one constant
+    motion, the loss over a (u,v) grid is minimal at the true motion."""
+    H = W = 64
+    n, B = 4000, 1
+    xs, ys, ts, ps, (u, v) = synthetic.moving_dots_events(n, H, W, 99, max_disp=6.0, k=60)
+    d = oenc.collate([oenc.encode_window(xs, ys, ts, ps, 2, (H, W))])
+    ev, pol, mask = G(d["event_list"]), G(d["event_list_pol_mask"]), G(d["event_mask"])
+    best, arg = None, None
+    grid = np.arange(-8, 9, 2.0)
+    for uu in grid:
+        for vv in grid:
+            lossf = hloss.EventWarping(cfg(H, W, mask=False, weight=0.0), DEV)
+            flow = torch.zeros(B, 2, H, W, device=DEV)
+            flow[:, 0], flow[:, 1] = uu / 64.0, vv / 64.0
+            lossf.event_flow_association([flow], ev, pol, mask)
+            val = float(lossf())
+            if best is None or val < best:
+                best, arg = val, (uu, vv)
+    assert abs(arg[0] - u) <= 2.0 and abs(arg[1] - v) <= 2.0, (arg, (u, v))
+
+
+# ------------------------------------------------------------------ metrics
+@pytest.mark.parametrize("ow", [0, 1])
+def test_metrics_golden(ow):
+    g = load_golden("g5_metrics")
+    H, W = (int(v) for v in g["res"])
+    P = int(g["P"])
+    tag = f"ow{ow}"
+    c = cfg(H, W, overwrite=bool(ow))
+    ms = [hloss.FWL(c, DEV, flow_scaling=32), hloss.RSAT(c, DEV, flow_scaling=32)]
+    last = None
+    for k in range(P):
+        last = G(g[f"{tag}_p{k}_flow"])
+        inputs = {
+            "event_list": G(g[f"{tag}_p{k}_event_list"]), "event_list_pol_mask": G(g[f"{tag}_p{k}_event_list_pol_mask"]),
+            "event_mask": G(g[f"{tag}_p{k}_event_mask"]), "gtflow": G(g[f"{tag}_p{k}_gtflow"]),
+            "dt_input": torch.tensor([1.0]), "dt_gt": torch.tensor([1.0]),
+        }
+        for m in ms:
+            m.event_flow_association([last], inputs)
+    if ow:
+        for m in ms:
+            m.overwrite_intermediate_flow([last])
+    np.testing.assert_allclose(N(ms[0]()), g[tag + "_fwl"], rtol=1e-5)
+    np.testing.assert_allclose(N(ms[1]()), g[tag + "_rsat"], rtol=1e-5)
+    assert np.array_equal(N(ms[0].compute_window_events()), g[tag + "_window_events"])
+    assert np.array_equal(N(ms[0].compute_window_iwe()), g[tag + "_window_iwe"])
+    np.testing.assert_allclose(N(ms[0].compute_masked_window_flow()), g[tag + "_masked_flow"], rtol=1e-5, atol=1e-7)
+
+
+def test_aee_golden():
+    g = load_golden("g5_metrics")
+    H, W = (int(v) for v in g["res"])
+    m = hloss.AEE(cfg(H, W), DEV, flow_scaling=32)
+    assert m.num_events == float("inf")
+    inputs = {
+        "event_list": torch.zeros(1, 4, 4, device=DEV), "event_list_pol_mask": torch.zeros(1, 4, 2, device=DEV),
+        "event_mask": G(g["aee_event_mask"]), "gtflow": G(g["aee_gt"]),
+        "dt_input": torch.tensor([float(g["aee_dt"][1])]), "dt_gt": torch.tensor([float(g["aee_dt"][0])]),
+    }
+    m.event_flow_association([G(g["aee_flow"])], inputs)
+    a, p = m()
+    np.testing.assert_allclose(N(a), g["aee_val"], rtol=1e-5)
+    np.testing.assert_allclose(N(p), g["aee_outl"], rtol=1e-5)
