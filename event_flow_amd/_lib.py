@@ -55,7 +55,7 @@ NETWORK_SIGNATURES = {
     "evf_nchw_to_nhwc": [P, I, I, I, I, P, P],
     "evf_clip_adam_step": [P, P, P, P, L, F, F, F, F, F, I, P, P],
 }
-# SIGNATURES.update(NETWORK_SIGNATURES)  # enabled once evf_network.hip lands
+SIGNATURES.update(NETWORK_SIGNATURES)
 
 _lib = None
 

@@ -1,0 +1,796 @@
+// Spiking conv cells for gfx950: 3x3 convolutions as implicit GEMMs on the
+// fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fmaf chains), fused
+// with the LIF neuron update, plus the BPTT backward (neuron backward, input-
+// gradient conv, weight-gradient conv).
+//
+// Data layout:
+//   membrane potential / gradients : [B][H][W][32] float32 (channels last)
+//   spikes                         : one uint32 per pixel, bit c = channel c
+//   conv weights                   : packed per (tap, k-step) as the MFMA B
+//                                    operand, see k_pack_conv_weight
+//
+// GEMM view of one 3x3 conv with 32 in / 32 out channels:
+//   M = pixels (tile of 32 consecutive x), N = 32 output channels,
+//   K = 9 taps x 32 input channels.  The K order is permuted so that lane
+//   half h (= lane>>5) owns input channels 16h..16h+15: k-step t of tap tau
+//   multiplies channel 16h+t.  A operands of binary layers are built from the
+//   spike bit mask in registers (v_bfe + v_cvt), so spikes cost 4 B/pixel of
+//   HBM/LDS traffic instead of 128 B.
+#include "evf_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define C32 32
+#define TH 8   // tile rows  (4 waves x 2 rows)
+#define TW 32  // tile cols  (= one MFMA M tile)
+#define HALO_W (TW + 2)
+#define HALO_H (TH + 2)
+#define WPACK (9 * 16 * 64)  // floats per packed 32x32x3x3 weight
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// C/D layout of the 32x32 MFMA: column = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+__device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float evf_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// --------------------------------------------------------------------------
+// weight packing
+// --------------------------------------------------------------------------
+// fwd:  dst[(tau*16+t)*64 + h*32 + j] = w[co=j][ci=16h+t][tau]
+// bwd:  dst[(tau*16+t)*64 + h*32 + j] = w[co=16h+t][ci=j][8-tau]   (flipped, transposed)
+__global__ void k_pack_conv_weight(const float* __restrict__ w, int transposed, float* __restrict__ dst) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= WPACK) return;
+  const int l = e & 63, t = (e >> 6) & 15, tau = e >> 10;
+  const int h = l >> 5, j = l & 31;
+  float v;
+  if (!transposed)
+    v = w[(j * C32 + (16 * h + t)) * 9 + tau];
+  else
+    v = w[((16 * h + t) * C32 + j) * 9 + (8 - tau)];
+  dst[e] = v;
+}
+
+extern "C" int evf_pack_conv_weight(const float* w, int Cout, int Cin, int transposed, float* dst, void* stream) {
+  if (!w || !dst || Cout != C32 || Cin != C32) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_pack_conv_weight, dim3(evf_cdiv(WPACK, 256)), dim3(256), 0, EVF_STREAM(stream), w, transposed,
+                     dst);
+  return evf_status();
+}
+
+// slabs [nslab][9][ci][co] -> torch layout dst[co][ci][tau] (+)=
+__global__ void k_reduce_wgrad(const float* __restrict__ partial, int nslab, int accumulate, float* __restrict__ dst) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // e = (tau*32 + ci)*32 + co
+  if (e >= 9 * C32 * C32) return;
+  float s = 0.f;
+  for (int k = 0; k < nslab; ++k) s += partial[(long)k * (9 * C32 * C32) + e];
+  const int co = e & 31, ci = (e >> 5) & 31, tau = e >> 10;
+  float* d = dst + (co * C32 + ci) * 9 + tau;
+  *d = accumulate ? *d + s : s;
+}
+
+extern "C" int evf_unpack_conv_wgrad(const float* packed, int Cout, int Cin, int accumulate, float* dst, void* stream) {
+  if (!packed || !dst || Cout != C32 || Cin != C32) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_reduce_wgrad, dim3(evf_cdiv(9 * C32 * C32, 256)), dim3(256), 0, EVF_STREAM(stream), packed, 1,
+                     accumulate, dst);
+  return evf_status();
+}
+
+extern "C" int evf_reduce_slabs(const float* partial, int nslab, int n, int accumulate, float* dst, void* stream) {
+  if (!partial || !dst || nslab <= 0 || n != 9 * C32 * C32) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_reduce_wgrad, dim3(evf_cdiv(n, 256)), dim3(256), 0, EVF_STREAM(stream), partial, nslab,
+                     accumulate, dst);
+  return evf_status();
+}
+
+// --------------------------------------------------------------------------
+// forward: conv(s) + LIF update
+// --------------------------------------------------------------------------
+// LIF epilogue shared by the binary and the dense-input kernels.
+// ConvLIF.forward spiking_submodules.py:103-126 / ConvLIFRecurrent :523-551:
+//   v' = (v*leak)*(1-z) + (1-leak)*cur          (hard reset)
+//   v' = v*leak + (1-leak)*cur - z*thresh       (soft reset)
+//   z' = (v' - thresh) > 0
+template <typename ZPrev>
+__device__ __forceinline__ void lif_epilogue(const f32x16& acc, int b, int row, int x0, int H, int W, int lane,
+                                             float lam, float th, int hard_reset, const float* __restrict__ v_prev,
+                                             ZPrev zprev_word, float* __restrict__ v_out,
+                                             uint32_t* __restrict__ z_out) {
+  const int j = lane & 31;
+  const bool row_ok = row < H;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int col = x0 + mfma_row(r, lane);
+    const bool ok = row_ok && col < W;
+    const long pix = ((long)b * H + row) * W + col;
+    bool spike = false;
+    if (ok) {
+      const float v = v_prev ? v_prev[pix * C32 + j] : 0.f;
+      const float z = (float)((zprev_word(row, col) >> j) & 1u);
+      const float cur = acc[r];
+      float vo;
+      if (hard_reset)
+        vo = (v * lam) * (1.0f - z) + (1.0f - lam) * cur;
+      else
+        vo = v * lam + (1.0f - lam) * cur - z * th;
+      v_out[pix * C32 + j] = vo;
+      spike = (vo - th) > 0.f;
+    }
+    const unsigned long long m = __ballot(spike);
+    if (ok && j == 0) z_out[pix] = (lane >> 5) ? (uint32_t)(m >> 32) : (uint32_t)m;
+  }
+}
+
+template <bool REC>
+__global__ __launch_bounds__(256) void k_conv_lif_fwd(const uint32_t* __restrict__ x, const float* __restrict__ wff,
+                                                      const float* __restrict__ wrec, const float* __restrict__ leak,
+                                                      const float* __restrict__ thresh,
+                                                      const float* __restrict__ v_prev,
+                                                      const uint32_t* __restrict__ z_prev, int B, int H, int W,
+                                                      int hard_reset, float* __restrict__ v_out,
+                                                      uint32_t* __restrict__ z_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* s_wff = (float*)smem_raw;                                 // WPACK
+  float* s_wrec = s_wff + WPACK;                                   // WPACK (REC only)
+  uint32_t* s_x = (uint32_t*)(s_wff + (REC ? 2 : 1) * WPACK);      // HALO_H*HALO_W
+  uint32_t* s_z = s_x + HALO_H * HALO_W;                           // HALO_H*HALO_W (REC only)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+
+  // stage weights (coalesced float4) and the spike-bit halo tiles
+  for (int i = tid; i < WPACK / 4; i += 256) ((float4*)s_wff)[i] = ((const float4*)wff)[i];
+  if (REC)
+    for (int i = tid; i < WPACK / 4; i += 256) ((float4*)s_wrec)[i] = ((const float4*)wrec)[i];
+  for (int i = tid; i < HALO_H * HALO_W; i += 256) {
+    const int yy = y0 + i / HALO_W - 1, xx = x0 + i % HALO_W - 1;
+    const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const long p = ((long)b * H + yy) * W + xx;
+    s_x[i] = in ? x[p] : 0u;
+    if (REC) s_z[i] = (in && z_prev) ? z_prev[p] : 0u;
+  }
+  __syncthreads();
+
+  f32x16 acc0 = {0}, acc1 = {0};
+  const int i = lane & 31, sh = (lane >> 5) * 16;
+  const int r0 = 2 * wv;  // this wave's two tile rows
+#pragma unroll 1
+  for (int tau = 0; tau < 9; ++tau) {
+    const int dy = tau / 3, dx = tau % 3;
+    const uint32_t w0 = s_x[(r0 + dy) * HALO_W + i + dx] >> sh;
+    const uint32_t w1 = s_x[(r0 + 1 + dy) * HALO_W + i + dx] >> sh;
+    const float* wp = s_wff + tau * 1024 + lane;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float bw = wp[t * 64];
+      acc0 = mfma32((float)((w0 >> t) & 1u), bw, acc0);
+      acc1 = mfma32((float)((w1 >> t) & 1u), bw, acc1);
+    }
+    if (REC) {
+      const uint32_t q0 = s_z[(r0 + dy) * HALO_W + i + dx] >> sh;
+      const uint32_t q1 = s_z[(r0 + 1 + dy) * HALO_W + i + dx] >> sh;
+      const float* wq = s_wrec + tau * 1024 + lane;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float bw = wq[t * 64];
+        acc0 = mfma32((float)((q0 >> t) & 1u), bw, acc0);
+        acc1 = mfma32((float)((q1 >> t) & 1u), bw, acc1);
+      }
+    }
+  }
+
+  const int j = lane & 31;
+  const float lam = evf_sigmoid(leak[j]);        // torch.sigmoid(self.leak)   :111/:536
+  const float th = fmaxf(thresh[j], 0.01f);      // self.thresh.clamp_min(0.01) :108/:533
+  auto zword = [&](int row, int col) -> uint32_t {
+    if (REC) return s_z[(row - y0 + 1) * HALO_W + (col - x0 + 1)];
+    return z_prev ? z_prev[((long)b * H + row) * W + col] : 0u;
+  };
+  lif_epilogue(acc0, b, y0 + r0, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out);
+  lif_epilogue(acc1, b, y0 + r0 + 1, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out);
+}
+
+extern "C" int evf_conv_lif_fwd(const uint32_t* x, const float* w_ff, const float* w_rec, const float* leak,
+                                const float* thresh, const float* v_prev, const uint32_t* z_prev, int B, int H, int W,
+                                int hard_reset, float* v_out, uint32_t* z_out, void* stream) {
+  if (!x || !w_ff || !leak || !thresh || !v_out || !z_out || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(256);
+  hipStream_t st = EVF_STREAM(stream);
+  if (w_rec) {
+    const size_t lds = 2 * WPACK * 4 + 2 * HALO_H * HALO_W * 4;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)k_conv_lif_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL(k_conv_lif_fwd<true>, grid, block, lds, st, x, w_ff, w_rec, leak, thresh, v_prev, z_prev, B, H, W,
+                       hard_reset, v_out, z_out);
+  } else {
+    const size_t lds = WPACK * 4 + HALO_H * HALO_W * 4;
+    hipLaunchKernelGGL(k_conv_lif_fwd<false>, grid, block, lds, st, x, w_ff, (const float*)nullptr, leak, thresh, v_prev,
+                       z_prev, B, H, W, hard_reset, v_out, z_out);
+  }
+  return evf_status();
+}
+
+// Head: real-valued NCHW input with few channels (event counts / voxels).
+// K = 9 taps x Cin; one MFMA k-step covers channels (2s, 2s+1).
+#define HEAD_MAX_CIN 8
+__global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ leak, const float* __restrict__ thresh,
+                                                      const float* __restrict__ v_prev,
+                                                      const uint32_t* __restrict__ z_prev, int B, int Cin, int H, int W,
+                                                      int hard_reset, float* __restrict__ v_out,
+                                                      uint32_t* __restrict__ z_out) {
+  __shared__ float s_x[HEAD_MAX_CIN][HALO_H * HALO_W];
+  __shared__ float s_w[9 * (HEAD_MAX_CIN / 2) * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+  const int S2 = (Cin + 1) / 2;
+  for (int e = tid; e < 9 * S2 * 64; e += 256) {
+    const int l = e & 63, s = (e >> 6) % S2, tau = (e >> 6) / S2;
+    const int ci = 2 * s + (l >> 5), j = l & 31;
+    s_w[e] = ci < Cin ? w[(j * Cin + ci) * 9 + tau] : 0.f;
+  }
+  for (int e = tid; e < 2 * S2 * HALO_H * HALO_W; e += 256) {
+    const int ci = e / (HALO_H * HALO_W), p = e % (HALO_H * HALO_W);
+    const int yy = y0 + p / HALO_W - 1, xx = x0 + p % HALO_W - 1;
+    const bool in = ci < Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    s_x[ci][p] = in ? x[(((long)b * Cin + ci) * H + yy) * W + xx] : 0.f;
+  }
+  __syncthreads();
+  f32x16 acc0 = {0}, acc1 = {0};
+  const int i = lane & 31, h = lane >> 5, r0 = 2 * wv;
+  for (int tau = 0; tau < 9; ++tau) {
+    const int dy = tau / 3, dx = tau % 3;
+    for (int s = 0; s < S2; ++s) {
+      const float bw = s_w[(tau * S2 + s) * 64 + lane];
+      const float* xp = s_x[2 * s + h];
+      acc0 = mfma32(xp[(r0 + dy) * HALO_W + i + dx], bw, acc0);
+      acc1 = mfma32(xp[(r0 + 1 + dy) * HALO_W + i + dx], bw, acc1);
+    }
+  }
+  const int j = lane & 31;
+  const float lam = evf_sigmoid(leak[j]);
+  const float th = fmaxf(thresh[j], 0.01f);
+  auto zword = [&](int row, int col) -> uint32_t { return z_prev ? z_prev[((long)b * H + row) * W + col] : 0u; };
+  lif_epilogue(acc0, b, y0 + r0, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out);
+  lif_epilogue(acc1, b, y0 + r0 + 1, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out);
+}
+
+extern "C" int evf_head_lif_fwd(const float* x, const float* w, const float* leak, const float* thresh,
+                                const float* v_prev, const uint32_t* z_prev, int B, int Cin, int H, int W,
+                                int hard_reset, float* v_out, uint32_t* z_out, void* stream) {
+  if (!x || !w || !leak || !thresh || !v_out || !z_out || B <= 0 || Cin <= 0 || Cin > HEAD_MAX_CIN || H <= 0 || W <= 0)
+    return EVF_EINVAL;
+  dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(256);
+  hipLaunchKernelGGL(k_head_lif_fwd, grid, block, 0, EVF_STREAM(stream), x, w, leak, thresh, v_prev, z_prev, B, Cin, H, W,
+                     hard_reset, v_out, z_out);
+  return evf_status();
+}
+
+// --------------------------------------------------------------------------
+// neuron backward (elementwise, 4 channels per thread)
+// --------------------------------------------------------------------------
+__device__ __forceinline__ float evf_surrogate(int kind, float x, float width) {
+  // models/spiking_util.py:38-43 (superspike), :55-65 (multi-gauss), :74-79 (triangle), :88-93 (arctan)
+  switch (kind) {
+    case EVF_SUPERSPIKE: {
+      const float d = 1.0f + width * fabsf(x);
+      return 1.0f / (d * d);
+    }
+    case EVF_TRIANGLE:
+      return fmaxf(0.f, 1.0f - width * fabsf(x));
+    case EVF_MULTIGAUSS: {
+      const float s1 = width, s2 = 6.f * width;
+      const float k = 0.3989422804014327f;  // 1/sqrt(2*pi)
+      auto gs = [&](float v, float mu, float sg) { return expf(-((v - mu) * (v - mu)) / (2.f * sg * sg)) / sg * k; };
+      return 1.15f * gs(x, 0.f, s1) - 0.15f * gs(x, width, s2) - 0.15f * gs(x, -width, s2);
+    }
+    default:
+      return 1.0f / (1.0f + width * x * x);
+  }
+}
+
+__global__ void k_lif_bwd(const float4* __restrict__ g_z_out, const float4* __restrict__ g_v_out,
+                          const float4* __restrict__ v_out, const float4* __restrict__ v_prev,
+                          const uint32_t* __restrict__ z_prev, const float* __restrict__ leak,
+                          const float* __restrict__ thresh, long npix, int hard_reset, int surrogate, float width,
+                          float4* __restrict__ g_cur, float4* __restrict__ g_v_prev, float* __restrict__ g_leak,
+                          float* __restrict__ g_thresh) {
+  __shared__ float s_red[2][4][C32];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int cg = tid & 7;  // channel group: channels 4cg..4cg+3
+  float lam[4], th[4], thraw[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    lam[k] = evf_sigmoid(leak[4 * cg + k]);
+    thraw[k] = thresh[4 * cg + k];
+    th[k] = fmaxf(thraw[k], 0.01f);
+  }
+  float sl[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
+  for (long e = (long)blockIdx.x * blockDim.x + tid; e < npix * 8; e += (long)gridDim.x * blockDim.x) {
+    const long pix = e >> 3;
+    const float4 vo4 = v_out[e];
+    const float4 gz4 = g_z_out ? g_z_out[e] : make_float4(0, 0, 0, 0);
+    const float4 gv4 = g_v_out ? g_v_out[e] : make_float4(0, 0, 0, 0);
+    const float4 vp4 = v_prev ? v_prev[e] : make_float4(0, 0, 0, 0);
+    const uint32_t zw = z_prev ? (z_prev[pix] >> (4 * cg)) : 0u;
+    const float vo[4] = {vo4.x, vo4.y, vo4.z, vo4.w}, gz[4] = {gz4.x, gz4.y, gz4.z, gz4.w};
+    const float gvo[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, vp[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
+    float gc[4], gp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float z = (float)((zw >> k) & 1u);
+      const float sg = evf_surrogate(surrogate, vo[k] - th[k], width);
+      const float gsp = gz[k] * sg;          // through the spike: d z'/d(v'-th)
+      const float gv = gvo[k] + gsp;         // total gradient on v'
+      gc[k] = gv * (1.0f - lam[k]);          // -> input current (ff + rec)
+      float cur, dlam;
+      if (hard_reset) {
+        gp[k] = gv * lam[k] * (1.0f - z);    // z detached (:539-540)
+        cur = (vo[k] - (vp[k] * lam[k]) * (1.0f - z)) / (1.0f - lam[k]);
+        dlam = vp[k] * (1.0f - z) - cur;
+      } else {
+        gp[k] = gv * lam[k];
+        cur = (vo[k] - vp[k] * lam[k] + z * th[k]) / (1.0f - lam[k]);
+        dlam = vp[k] - cur;
+        st[k] -= gv * z;                      // - z * thresh term
+      }
+      sl[k] += gv * dlam;
+      st[k] -= gsp;                           // spike fn sees (v' - thresh)
+    }
+    g_cur[e] = make_float4(gc[0], gc[1], gc[2], gc[3]);
+    g_v_prev[e] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+  }
+  // reduce over the 8 lanes-per-pixel pattern: lanes with equal (lane & 7) share channels
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      sl[k] += __shfl_xor(sl[k], o, 64);
+      st[k] += __shfl_xor(st[k], o, 64);
+    }
+  }
+  if (lane < 8) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s_red[0][wv][4 * lane + k] = sl[k];
+      s_red[1][wv][4 * lane + k] = st[k];
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int which = tid >> 5, c = tid & 31;
+    float v = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += s_red[which][w][c];
+    if (which == 0) {
+      const float l = evf_sigmoid(leak[c]);
+      evf_atomic_add(g_leak + c, v * l * (1.0f - l));  // d sigmoid
+    } else if (thresh[c] > 0.01f) {                     // clamp_min passes gradient only above the floor
+      evf_atomic_add(g_thresh + c, v);
+    }
+  }
+}
+
+extern "C" int evf_lif_bwd(const float* g_z_out, const float* g_v_out, const float* v_out, const float* v_prev,
+                           const uint32_t* z_prev, const float* leak, const float* thresh, int B, int H, int W,
+                           int hard_reset, int surrogate, float act_width, float* g_cur, float* g_v_prev,
+                           float* g_leak, float* g_thresh, void* stream) {
+  if (!v_out || !leak || !thresh || !g_cur || !g_v_prev || !g_leak || !g_thresh || B <= 0 || H <= 0 || W <= 0)
+    return EVF_EINVAL;
+  const long npix = (long)B * H * W;
+  const int nblk = (int)((npix * 8 + 255) / 256 < 2048 ? (npix * 8 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_lif_bwd, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)g_z_out,
+                     (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev, z_prev, leak, thresh, npix,
+                     hard_reset, surrogate, act_width, (float4*)g_cur, (float4*)g_v_prev, g_leak, g_thresh);
+  return evf_status();
+}
+
+// --------------------------------------------------------------------------
+// input-gradient conv (fp32 activations through an LDS halo tile)
+// --------------------------------------------------------------------------
+#define PIX_STRIDE 36  // floats per halo pixel: 32 channels + 4 pad -> conflict-free ds_read_b128
+
+template <bool TWO>
+__global__ __launch_bounds__(256) void k_conv_dgrad(const float* __restrict__ g, const float* __restrict__ wa,
+                                                    float* __restrict__ ga, int acc_a, const float* __restrict__ wb,
+                                                    float* __restrict__ gb, int acc_b, int B, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* s_wa = (float*)smem_raw;
+  float* s_wb = s_wa + WPACK;
+  float* s_g = s_wa + (TWO ? 2 : 1) * WPACK;  // HALO_H*HALO_W*PIX_STRIDE
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+  for (int i = tid; i < WPACK / 4; i += 256) ((float4*)s_wa)[i] = ((const float4*)wa)[i];
+  if (TWO)
+    for (int i = tid; i < WPACK / 4; i += 256) ((float4*)s_wb)[i] = ((const float4*)wb)[i];
+  for (int e = tid; e < HALO_H * HALO_W * 8; e += 256) {
+    const int p = e >> 3, c4 = e & 7;
+    const int yy = y0 + p / HALO_W - 1, xx = x0 + p % HALO_W - 1;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = ((const float4*)g)[(((long)b * H + yy) * W + xx) * 8 + c4];
+    *(float4*)(s_g + p * PIX_STRIDE + c4 * 4) = v;
+  }
+  __syncthreads();
+  f32x16 a0 = {0}, a1 = {0}, b0 = {0}, b1 = {0};
+  const int i = lane & 31, h = lane >> 5, r0 = 2 * wv;
+#pragma unroll 1
+  for (int tau = 0; tau < 9; ++tau) {
+    const int dy = tau / 3, dx = tau % 3;
+    const float* p0 = s_g + ((r0 + dy) * HALO_W + i + dx) * PIX_STRIDE + 16 * h;
+    const float* p1 = p0 + HALO_W * PIX_STRIDE;
+    float x0v[16], x1v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 u = *(const float4*)(p0 + 4 * q), w = *(const float4*)(p1 + 4 * q);
+      x0v[4 * q] = u.x, x0v[4 * q + 1] = u.y, x0v[4 * q + 2] = u.z, x0v[4 * q + 3] = u.w;
+      x1v[4 * q] = w.x, x1v[4 * q + 1] = w.y, x1v[4 * q + 2] = w.z, x1v[4 * q + 3] = w.w;
+    }
+    const float* wpa = s_wa + tau * 1024 + lane;
+    const float* wpb = s_wb + tau * 1024 + lane;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float bw = wpa[t * 64];
+      a0 = mfma32(x0v[t], bw, a0);
+      a1 = mfma32(x1v[t], bw, a1);
+      if (TWO) {
+        const float bw2 = wpb[t * 64];
+        b0 = mfma32(x0v[t], bw2, b0);
+        b1 = mfma32(x1v[t], bw2, b1);
+      }
+    }
+  }
+  const int j = lane & 31;
+  auto store = [&](const f32x16& acc, int row, float* __restrict__ out, int accf) {
+    if (row >= H) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int col = x0 + mfma_row(r, lane);
+      if (col < W) {
+        float* d = out + (((long)b * H + row) * W + col) * C32 + j;
+        *d = accf ? *d + acc[r] : acc[r];
+      }
+    }
+  };
+  store(a0, y0 + r0, ga, acc_a);
+  store(a1, y0 + r0 + 1, ga, acc_a);
+  if (TWO) {
+    store(b0, y0 + r0, gb, acc_b);
+    store(b1, y0 + r0 + 1, gb, acc_b);
+  }
+}
+
+extern "C" int evf_conv_dgrad(const float* g_cur, const float* wT_a, float* g_a, int acc_a, const float* wT_b,
+                              float* g_b, int acc_b, int B, int H, int W, void* stream) {
+  if (!g_cur || !wT_a || !g_a || B <= 0 || H <= 0 || W <= 0 || ((wT_b != nullptr) != (g_b != nullptr)))
+    return EVF_EINVAL;
+  dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(256);
+  hipStream_t st = EVF_STREAM(stream);
+  const size_t halo = (size_t)HALO_H * HALO_W * PIX_STRIDE * 4;
+  static bool attr1 = false, attr2 = false;
+  if (wT_b) {
+    const size_t lds = 2 * WPACK * 4 + halo;
+    if (!attr2) {
+      (void)hipFuncSetAttribute((const void*)k_conv_dgrad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr2 = true;
+    }
+    hipLaunchKernelGGL(k_conv_dgrad<true>, grid, block, lds, st, g_cur, wT_a, g_a, acc_a, wT_b, g_b, acc_b, B, H, W);
+  } else {
+    const size_t lds = WPACK * 4 + halo;
+    if (!attr1) {
+      (void)hipFuncSetAttribute((const void*)k_conv_dgrad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr1 = true;
+    }
+    hipLaunchKernelGGL(k_conv_dgrad<false>, grid, block, lds, st, g_cur, wT_a, g_a, acc_a, (const float*)nullptr,
+                       (float*)nullptr, 0, B, H, W);
+  }
+  return evf_status();
+}
+
+// --------------------------------------------------------------------------
+// weight-gradient conv on bit-packed inputs
+//   dW[tau][ci][co] += sum_pix x[pix+tau][ci] * g[pix][co]
+// GEMM: M = ci, N = co, K = pixels (2 per MFMA).  Each wave walks whole image
+// rows; 9 accumulators (one per tap) share the B operand g[pix][co].
+// --------------------------------------------------------------------------
+#define WG_ROWS_PER_BLOCK 4
+__global__ __launch_bounds__(256) void k_conv_wgrad_bits(const uint32_t* __restrict__ x, const float* __restrict__ g,
+                                                         int B, int H, int W, int accumulate,
+                                                         float* __restrict__ partial) {
+  __shared__ float s_acc[9 * C32 * C32];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  for (int e = tid; e < 9 * C32 * C32; e += 256) s_acc[e] = 0.f;
+  __syncthreads();
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = (f32x16){0};
+  const long nrows = (long)B * H;
+  const long row = (long)blockIdx.x * WG_ROWS_PER_BLOCK + wv;
+  if (row < nrows) {
+    const int b = (int)(row / H), y = (int)(row % H);
+    const uint32_t* xb = x + (long)b * H * W;
+    const float* grow = g + row * W * C32;
+    for (int xs = 0; xs < W; xs += 2) {
+      const int xc = xs + h;  // this lane half's pixel
+      const float bv = xc < W ? grow[(long)xc * C32 + i] : 0.f;
+#pragma unroll
+      for (int tau = 0; tau < 9; ++tau) {
+        const int yy = y + tau / 3 - 1, xx = xc + tau % 3 - 1;
+        const uint32_t word = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xb[(long)yy * W + xx] : 0u;
+        acc[tau] = mfma32((float)((word >> i) & 1u), bv, acc[tau]);
+      }
+    }
+  }
+  // block reduction through LDS atomics, then one slab per block
+#pragma unroll
+  for (int tau = 0; tau < 9; ++tau)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) atomicAdd(&s_acc[(tau * C32 + mfma_row(r, lane)) * C32 + i], acc[tau][r]);
+  __syncthreads();
+  float* slab = partial + (long)blockIdx.x * (9 * C32 * C32);
+  for (int e = tid; e < 9 * C32 * C32; e += 256) slab[e] = accumulate ? slab[e] + s_acc[e] : s_acc[e];
+}
+
+extern "C" int evf_conv_wgrad_slabs(int B, int H, int W) {
+  (void)W;
+  return evf_cdiv((long)B * H, WG_ROWS_PER_BLOCK);
+}
+
+extern "C" int evf_conv_wgrad_bits(const uint32_t* x, const float* g_cur, int B, int H, int W, float* wg_partial,
+                                   int accumulate, void* stream) {
+  if (!x || !g_cur || !wg_partial || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_conv_wgrad_bits, dim3(evf_conv_wgrad_slabs(B, H, W)), dim3(256), 0, EVF_STREAM(stream), x, g_cur,
+                     B, H, W, accumulate, wg_partial);
+  return evf_status();
+}
+
+// Head weight gradient: rows = (ci, tau) pairs (<= 72 -> up to 3 M tiles), cols = co.
+__global__ __launch_bounds__(256) void k_head_wgrad(const float* __restrict__ x, const float* __restrict__ g, int B,
+                                                    int Cin, int H, int W, float* __restrict__ dw) {
+  __shared__ float s_acc[3 * C32 * C32];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int nrow = 9 * Cin, NT = (nrow + 31) / 32;
+  for (int e = tid; e < 3 * C32 * C32; e += 256) s_acc[e] = 0.f;
+  __syncthreads();
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) acc[t] = (f32x16){0};
+  const long nrows = (long)B * H;
+  const long row = (long)blockIdx.x * WG_ROWS_PER_BLOCK + wv;
+  if (row < nrows) {
+    const int b = (int)(row / H), y = (int)(row % H);
+    const float* grow = g + row * W * C32;
+    for (int xs = 0; xs < W; xs += 2) {
+      const int xc = xs + h;
+      const float bv = xc < W ? grow[(long)xc * C32 + i] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        if (t < NT) {
+          const int rr = 32 * t + i;  // (ci, tau)
+          float av = 0.f;
+          if (rr < nrow) {
+            const int ci = rr / 9, tau = rr % 9;
+            const int yy = y + tau / 3 - 1, xx = xc + tau % 3 - 1;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) av = x[(((long)b * Cin + ci) * H + yy) * W + xx];
+          }
+          acc[t] = mfma32(av, bv, acc[t]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+    if (t < NT)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) atomicAdd(&s_acc[(t * C32 + mfma_row(r, lane)) * C32 + i], acc[t][r]);
+  __syncthreads();
+  for (int e = tid; e < NT * C32 * C32; e += 256) {
+    const int co = e & 31, rr = e >> 5;
+    if (rr < nrow) {
+      const int ci = rr / 9, tau = rr % 9;
+      evf_atomic_add(dw + (co * Cin + ci) * 9 + tau, s_acc[e]);
+    }
+  }
+}
+
+extern "C" int evf_head_wgrad(const float* x, const float* g_cur, int B, int Cin, int H, int W, float* dw,
+                              void* stream) {
+  if (!x || !g_cur || !dw || B <= 0 || Cin <= 0 || Cin > HEAD_MAX_CIN || H <= 0 || W <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_head_wgrad, dim3(evf_cdiv((long)B * H, WG_ROWS_PER_BLOCK)), dim3(256), 0, EVF_STREAM(stream), x,
+                     g_cur, B, Cin, H, W, dw);
+  return evf_status();
+}
+
+// --------------------------------------------------------------------------
+// prediction layer: 1x1 conv 32 -> 2, bias, tanh
+// --------------------------------------------------------------------------
+__global__ void k_pred_fwd(const uint32_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                           int B, int HW, float* __restrict__ flow) {
+  __shared__ float s_w[2 * C32 + 2];
+  if (threadIdx.x < 2 * C32) s_w[threadIdx.x] = w[threadIdx.x];
+  if (threadIdx.x < 2) s_w[2 * C32 + threadIdx.x] = bias[threadIdx.x];
+  __syncthreads();
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (long)B * HW) return;
+  const uint32_t m = x[p];
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < C32; ++c) {
+    const float z = (float)((m >> c) & 1u);
+    s0 += z * s_w[c];
+    s1 += z * s_w[C32 + c];
+  }
+  const long b = p / HW, q = p % HW;
+  flow[(b * 2) * HW + q] = tanhf(s0 + s_w[2 * C32]);
+  flow[(b * 2 + 1) * HW + q] = tanhf(s1 + s_w[2 * C32 + 1]);
+}
+
+extern "C" int evf_pred_fwd(const uint32_t* x, const float* w, const float* bias, int B, int H, int W, float* flow,
+                            void* stream) {
+  if (!x || !w || !bias || !flow || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_pred_fwd, dim3(evf_cdiv((long)B * H * W, 256)), dim3(256), 0, EVF_STREAM(stream), x, w, bias, B,
+                     H * W, flow);
+  return evf_status();
+}
+
+// g_x[pix][c] = sum_o gpre[o] * w[o][c];  dw[o][c] += sum_pix gpre[o]*z[pix][c];  dbias[o] += sum gpre[o]
+__global__ void k_pred_bwd(const uint32_t* __restrict__ x, const float* __restrict__ flow,
+                           const float* __restrict__ g_flow, const float* __restrict__ w, int B, int HW,
+                           float* __restrict__ g_x, float* __restrict__ dw, float* __restrict__ dbias) {
+  __shared__ float s_w[2 * C32];
+  __shared__ float s_dw[2 * C32 + 2];
+  if (threadIdx.x < 2 * C32) s_w[threadIdx.x] = w[threadIdx.x];
+  if (threadIdx.x < 2 * C32 + 2) s_dw[threadIdx.x] = 0.f;
+  __syncthreads();
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float gp0 = 0.f, gp1 = 0.f;
+  uint32_t m = 0u;
+  if (p < (long)B * HW) {
+    const long b = p / HW, q = p % HW;
+    const float f0 = flow[(b * 2) * HW + q], f1 = flow[(b * 2 + 1) * HW + q];
+    gp0 = g_flow[(b * 2) * HW + q] * (1.0f - f0 * f0);  // tanh'
+    gp1 = g_flow[(b * 2 + 1) * HW + q] * (1.0f - f1 * f1);
+    m = x[p];
+    float4* o = (float4*)(g_x + p * C32);
+#pragma unroll
+    for (int c4 = 0; c4 < 8; ++c4) {
+      float4 v;
+      v.x = gp0 * s_w[4 * c4] + gp1 * s_w[C32 + 4 * c4];
+      v.y = gp0 * s_w[4 * c4 + 1] + gp1 * s_w[C32 + 4 * c4 + 1];
+      v.z = gp0 * s_w[4 * c4 + 2] + gp1 * s_w[C32 + 4 * c4 + 2];
+      v.w = gp0 * s_w[4 * c4 + 3] + gp1 * s_w[C32 + 4 * c4 + 3];
+      o[c4] = v;
+    }
+  }
+  // weight gradient: per channel, sum gp over the pixels whose bit c is set
+  const int lane = threadIdx.x & 63;
+#pragma unroll 4
+  for (int c = 0; c < C32; ++c) {
+    const bool on = (m >> c) & 1u;
+    float a = evf_wave_sum(on ? gp0 : 0.f), d = evf_wave_sum(on ? gp1 : 0.f);
+    if (lane == 0) {
+      atomicAdd(&s_dw[c], a);
+      atomicAdd(&s_dw[C32 + c], d);
+    }
+  }
+  {
+    float a = evf_wave_sum(gp0), d = evf_wave_sum(gp1);
+    if (lane == 0) {
+      atomicAdd(&s_dw[2 * C32], a);
+      atomicAdd(&s_dw[2 * C32 + 1], d);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * C32) evf_atomic_add(dw + threadIdx.x, s_dw[threadIdx.x]);
+  if (threadIdx.x < 2) evf_atomic_add(dbias + threadIdx.x, s_dw[2 * C32 + threadIdx.x]);
+}
+
+extern "C" int evf_pred_bwd(const uint32_t* x, const float* flow, const float* g_flow, const float* w, int B, int H,
+                            int W, float* g_x, float* dw, float* dbias, void* stream) {
+  if (!x || !flow || !g_flow || !w || !g_x || !dw || !dbias || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_pred_bwd, dim3(evf_cdiv((long)B * H * W, 256)), dim3(256), 0, EVF_STREAM(stream), x, flow, g_flow,
+                     w, B, H * W, g_x, dw, dbias);
+  return evf_status();
+}
+
+// --------------------------------------------------------------------------
+// layout conversions for the state API (models/model.py:203-209)
+// --------------------------------------------------------------------------
+__global__ void k_bits_to_nchw(const uint32_t* __restrict__ bits, int B, int HW, float* __restrict__ out) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over B*32*HW
+  if (e >= (long)B * C32 * HW) return;
+  const long q = e % HW, c = (e / HW) % C32, b = e / ((long)HW * C32);
+  out[e] = (float)((bits[b * HW + q] >> c) & 1u);
+}
+__global__ void k_nchw_to_bits(const float* __restrict__ in, int B, int HW, uint32_t* __restrict__ bits) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (long)B * HW) return;
+  const long b = p / HW, q = p % HW;
+  uint32_t m = 0u;
+  for (int c = 0; c < C32; ++c) m |= (in[(b * C32 + c) * HW + q] != 0.f ? 1u : 0u) << c;
+  bits[p] = m;
+}
+__global__ void k_nhwc_to_nchw(const float* __restrict__ in, int B, int C, int HW, float* __restrict__ out) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)B * C * HW) return;
+  const long q = e % HW, c = (e / HW) % C, b = e / ((long)HW * C);
+  out[e] = in[(b * HW + q) * C + c];
+}
+__global__ void k_nchw_to_nhwc(const float* __restrict__ in, int B, int C, int HW, float* __restrict__ out) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)B * C * HW) return;
+  const long c = e % C, q = (e / C) % HW, b = e / ((long)HW * C);
+  out[e] = in[(b * C + c) * HW + q];
+}
+
+extern "C" int evf_bits_to_nchw(const uint32_t* bits, int B, int H, int W, float* out, void* stream) {
+  if (!bits || !out || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_bits_to_nchw, dim3(evf_cdiv((long)B * C32 * H * W, 256)), dim3(256), 0, EVF_STREAM(stream), bits,
+                     B, H * W, out);
+  return evf_status();
+}
+extern "C" int evf_nchw_to_bits(const float* in, int B, int H, int W, uint32_t* bits, void* stream) {
+  if (!in || !bits || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_nchw_to_bits, dim3(evf_cdiv((long)B * H * W, 256)), dim3(256), 0, EVF_STREAM(stream), in, B, H * W,
+                     bits);
+  return evf_status();
+}
+extern "C" int evf_nhwc_to_nchw(const float* in, int B, int C, int H, int W, float* out, void* stream) {
+  if (!in || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(evf_cdiv((long)B * C * H * W, 256)), dim3(256), 0, EVF_STREAM(stream), in, B, C,
+                     H * W, out);
+  return evf_status();
+}
+extern "C" int evf_nchw_to_nhwc(const float* in, int B, int C, int H, int W, float* out, void* stream) {
+  if (!in || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(evf_cdiv((long)B * C * H * W, 256)), dim3(256), 0, EVF_STREAM(stream), in, B, C,
+                     H * W, out);
+  return evf_status();
+}
+
+// --------------------------------------------------------------------------
+// optimiser: global-norm clip + Adam on one flat buffer (train_flow.py:157-163)
+// --------------------------------------------------------------------------
+__global__ void k_sumsq(const float* __restrict__ g, long n, float* __restrict__ ws) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
+  s = evf_block_sum(s, red);
+  if (threadIdx.x == 0) evf_atomic_add(ws, s);
+}
+
+__global__ void k_clip_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float max_norm, float step_size, float b1, float b2,
+                            float bc2_sqrt, float eps, const float* __restrict__ ws) {
+  // clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
+  float coef = 1.f;
+  if (max_norm > 0.f) coef = fminf(1.f, max_norm / (sqrtf(ws[0]) + 1e-6f));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+extern "C" int evf_clip_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float max_norm,
+                                  float lr, float beta1, float beta2, float eps, int step, float* norm_ws,
+                                  void* stream) {
+  if (!param || !grad || !m || !v || !norm_ws || n <= 0 || step < 1) return EVF_EINVAL;
+  hipStream_t st = EVF_STREAM(stream);
+  int rc = evf_hip(hipMemsetAsync(norm_ws, 0, 2 * sizeof(float), st));
+  if (rc) return rc;
+  const int nblk = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(k_sumsq, dim3(nblk), dim3(256), 0, st, grad, (long)n, norm_ws);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(k_clip_adam, dim3(nblk), dim3(256), 0, st, param, grad, m, v, (long)n, max_norm,
+                     (float)((double)lr / bc1), beta1, beta2, (float)sqrt(bc2), eps, norm_ws);
+  return evf_status();
+}

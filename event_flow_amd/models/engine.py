@@ -1,0 +1,331 @@
+"""BPTT engine for the FireNet family on the MI355X.
+
+One forward pass of the network (reference models/model.py:255-265) is a single
+autograd node that sequences the HIP kernels of libevflow_hip.so:
+
+    forward   head: evf_head_lif_fwd, 6x evf_conv_lif_fwd, evf_pred_fwd     (8 launches)
+    backward  evf_pred_bwd, per layer evf_lif_bwd + evf_conv_wgrad_bits /
+              evf_head_wgrad + evf_conv_dgrad                                (<= 27 launches)
+
+State (membrane potential [B,H,W,32] fp32, spikes bit-packed [B,H,W] int32)
+and the saved activations live in a tape owned by the engine; PyTorch autograd
+only sees the flow map and a scalar token that chains consecutive passes, so
+that `loss.backward()` walks the passes in reverse time order (truncated BPTT,
+train_flow.py:141-171) while state gradients are carried between the nodes in
+engine buffers instead of materialised autograd edges.  Parameter gradients
+are accumulated over the window and delivered by the node of the window's
+first pass.
+"""
+
+import torch
+
+from .. import _lib
+from .spiking_util import SURROGATE_ID
+
+C = 32  # channels of the accelerated kernels (base_num_channels)
+
+
+def _i32(shape, dev):
+    return torch.empty(shape, dtype=torch.int32, device=dev)
+
+
+def _f32(shape, dev):
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+class _Window:
+    """Gradient carries and parameter-gradient accumulators of one BPTT window."""
+
+    def __init__(self, eng, B, H, W, dev):
+        n = len(eng.cells)
+        self.shape = (B, H, W)
+        self.dev = dev
+        self.gv = [None] * n  # dL/dv carried to the previous pass, per layer
+        self.gz = [None] * n  # dL/d(output spikes) of the pass being processed
+        self.gz_has = [False] * n
+        self.g_cur = None
+        self.small = torch.zeros(eng.small_size, dtype=torch.float32, device=dev)
+        self.slab_init = {}
+        self.token = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
+        self.n_passes = 0
+
+    def buf(self, lst, l):
+        if lst[l] is None:
+            B, H, W = self.shape
+            lst[l] = _f32((B, H, W, C), self.dev)
+        return lst[l]
+
+
+class _FireNetPass(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, win, is_first, x_in, token, *params):
+        ctx.set_materialize_grads(False)
+        flow, tape, new_states = eng._forward_pass(x_in, eng._states, record=True)
+        eng._states = new_states
+        ctx.eng, ctx.win, ctx.tape, ctx.is_first = eng, win, tape, is_first
+        new_token = torch.zeros((), dtype=torch.float32, device=flow.device)
+        return flow, new_token
+
+    @staticmethod
+    def backward(ctx, g_flow, g_token):
+        eng, win = ctx.eng, ctx.win
+        eng._backward_pass(win, ctx.tape, g_flow, ctx.is_first)
+        ctx.tape = None
+        grads = eng._finalize(win) if ctx.is_first else (None,) * len(eng.params)
+        return (None, None, None, None, g_token) + tuple(grads)
+
+
+class FireNetEngine:
+    """Sequences the kernels for head -> G1 -> R1a -> R1b -> G2 -> R2a -> R2b -> pred."""
+
+    def __init__(self, cells, pred, num_bins):
+        self.cells = cells  # list of 7 spiking cell modules
+        self.pred = pred
+        self.num_bins = num_bins
+        for i, c in enumerate(cells):
+            if c.kind != "lif":
+                raise NotImplementedError(
+                    f"{type(c).__name__}: only LIF cells are accelerated so far (PLIF/ALIF/XLIF are a later row of "
+                    "SURVEY.md section 8); there is no CPU fallback"
+                )
+            if c.hidden_size != C or c.kernel_size != 3 or c.stride != 1 or (i > 0 and c.input_size != C):
+                raise NotImplementedError("accelerated FireNet kernels need base_num_channels=32, kernel_size=3")
+            if i == 0 and c.recurrent:
+                raise NotImplementedError("recurrent head cell")
+        if cells[0].input_size > 8:
+            raise NotImplementedError("head cell supports at most 8 input channels")
+        # flat list of the tensors the autograd node depends on, with their owners
+        self.params, self.pnames = [], []
+        for i, c in enumerate(cells):
+            self._reg(f"{i}.ff", c.ff.weight)
+            if c.recurrent:
+                self._reg(f"{i}.rec", c.rec.weight)
+            self._reg(f"{i}.leak", c.leak)
+            self._reg(f"{i}.thresh", c.thresh)
+        self._reg("pred.w", pred.conv2d.weight)
+        self._reg("pred.b", pred.conv2d.bias)
+        # layout of the small-accumulator buffer
+        off = 0
+        self.small_off = {}
+        for name, p in zip(self.pnames, self.params):
+            if name.endswith(".ff") and not name.startswith("0.") or name.endswith(".rec"):
+                continue  # 32x32x3x3 gradients come from the slab reduction
+            self.small_off[name] = (off, p.numel())
+            off += p.numel()
+        self.small_size = off
+        self._states = [None] * len(cells)
+        self._win = None
+        self._packed = {}
+        self._packed_key = None
+        self._slabs = {}
+
+    def _reg(self, name, t):
+        self.params.append(t)
+        self.pnames.append(name)
+
+    # ------------------------------------------------------------------ state
+    def reset_states(self):
+        self._states = [None] * len(self.cells)
+        self._win = None
+
+    def detach_states(self):
+        self._win = None  # next pass opens a new window; tensors in _states carry no graph
+
+    def get_states(self):
+        """-> list of [2,B,C,H,W] float tensors (or None), the reference's layout."""
+        out = []
+        for st in self._states:
+            if st is None:
+                out.append(None)
+                continue
+            v, z = st
+            B, H, W, _ = v.shape
+            vv, zz = _f32((B, C, H, W), v.device), _f32((B, C, H, W), v.device)
+            _lib.call("evf_nhwc_to_nchw", _lib.ptr(v), B, C, H, W, _lib.ptr(vv))
+            _lib.call("evf_bits_to_nchw", _lib.ptr(z), B, H, W, _lib.ptr(zz))
+            out.append(torch.stack([vv, zz]))
+        return out
+
+    def set_states(self, states):
+        new = []
+        for st in states:
+            if st is None:
+                new.append(None)
+                continue
+            vv, zz = st[0].detach().float().contiguous(), st[1].detach().float().contiguous()
+            B, _, H, W = vv.shape
+            v, z = _f32((B, H, W, C), vv.device), _i32((B, H, W), vv.device)
+            _lib.call("evf_nchw_to_nhwc", _lib.ptr(vv), B, C, H, W, _lib.ptr(v))
+            _lib.call("evf_nchw_to_bits", _lib.ptr(zz), B, H, W, _lib.ptr(z))
+            new.append((v, z))
+        self._states = new
+        self._win = None
+
+    # ------------------------------------------------------------------ weights
+    def _prepare(self, dev):
+        key = tuple((p.data_ptr(), p._version) for p in self.params)
+        if key == self._packed_key:
+            return
+        for i, c in enumerate(self.cells):
+            if i == 0:
+                continue
+            for nm, w in (("ff", c.ff.weight),) + ((("rec", c.rec.weight),) if c.recurrent else ()):
+                wd = w.detach().float().contiguous()
+                for tr in (0, 1):
+                    k = (i, nm, tr)
+                    if k not in self._packed:
+                        self._packed[k] = _f32((9 * C * C,), dev)
+                    _lib.call("evf_pack_conv_weight", _lib.ptr(wd), C, C, tr, _lib.ptr(self._packed[k]))
+        self._flat = {}
+        for name, p in zip(self.pnames, self.params):
+            self._flat[name] = p.detach().float().contiguous().view(-1)
+        self._packed_key = key
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x_in):
+        _lib.require_gpu(x_in, "FireNet.forward")
+        x_in = x_in.detach().float().contiguous()
+        self._prepare(x_in.device)
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.params)
+        if not needs_grad:
+            flow, _, self._states = self._forward_pass(x_in, self._states, record=False)
+            return flow
+        B, _, H, W = x_in.shape
+        is_first = self._win is None
+        if is_first:
+            self._win = _Window(self, B, H, W, x_in.device)
+        win = self._win
+        flow, token = _FireNetPass.apply(self, win, is_first, x_in, win.token, *self.params)
+        win.token = token
+        win.n_passes += 1
+        return flow
+
+    def _forward_pass(self, x_in, states, record):
+        B, Cin, H, W = x_in.shape
+        dev = x_in.device
+        layers = []
+        new_states = []
+        in_bits = None
+        for i, c in enumerate(self.cells):
+            st = states[i]
+            v_prev, z_prev = st if st is not None else (None, None)
+            if v_prev is not None and tuple(v_prev.shape) != (B, H, W, C):
+                raise _lib.EvflowError("state shape does not match the input; call reset_states()")
+            v_out, z_out = _f32((B, H, W, C), dev), _i32((B, H, W), dev)
+            leak, thresh = self._flat[f"{i}.leak"], self._flat[f"{i}.thresh"]
+            if i == 0:
+                _lib.call("evf_head_lif_fwd", _lib.ptr(x_in), _lib.ptr(self._flat["0.ff"]), _lib.ptr(leak), _lib.ptr(thresh),
+                          _lib.ptr(v_prev), _lib.ptr(z_prev), B, Cin, H, W, 1 if c.hard_reset else 0, _lib.ptr(v_out),
+                          _lib.ptr(z_out))
+            else:
+                wrec = self._packed[(i, "rec", 0)] if c.recurrent else None
+                _lib.call("evf_conv_lif_fwd", _lib.ptr(in_bits), _lib.ptr(self._packed[(i, "ff", 0)]), _lib.ptr(wrec),
+                          _lib.ptr(leak), _lib.ptr(thresh), _lib.ptr(v_prev), _lib.ptr(z_prev), B, H, W,
+                          1 if c.hard_reset else 0, _lib.ptr(v_out), _lib.ptr(z_out))
+            if record:
+                layers.append((in_bits, v_prev, z_prev, v_out, z_out))
+            in_bits = z_out
+            new_states.append((v_out, z_out))
+        flow = _f32((B, 2, H, W), dev)
+        _lib.call("evf_pred_fwd", _lib.ptr(in_bits), _lib.ptr(self._flat["pred.w"]), _lib.ptr(self._flat["pred.b"]), B, H, W,
+                  _lib.ptr(flow))
+        tape = {"x_in": x_in, "layers": layers, "flow": flow} if record else None
+        return flow, tape, new_states
+
+    # ------------------------------------------------------------------ backward
+    def _small(self, win, name):
+        off, n = self.small_off[name]
+        return win.small[off : off + n]
+
+    def _slab(self, key, nslab, dev):
+        if key not in self._slabs or self._slabs[key].shape[0] != nslab or self._slabs[key].device != dev:
+            self._slabs[key] = _f32((nslab, 9 * C * C), dev)
+        return self._slabs[key]
+
+    def _backward_pass(self, win, tape, g_flow, is_first):
+        B, H, W = win.shape
+        dev = win.dev
+        n = len(self.cells)
+        layers = tape["layers"]
+        nslab = _lib.load().evf_conv_wgrad_slabs(B, H, W)
+        if g_flow is not None:
+            gz_top = win.buf(win.gz, n - 1)
+            _lib.call("evf_pred_bwd", _lib.ptr(layers[n - 1][4]), _lib.ptr(tape["flow"]),
+                      _lib.ptr(g_flow.float().contiguous()), _lib.ptr(self._flat["pred.w"]), B, H, W, _lib.ptr(gz_top),
+                      _lib.ptr(self._small(win, "pred.w")), _lib.ptr(self._small(win, "pred.b")))
+            win.gz_has[n - 1] = True
+        if win.g_cur is None:
+            win.g_cur = _f32((B, H, W, C), dev)
+        for i in range(n - 1, -1, -1):
+            c = self.cells[i]
+            in_bits, v_prev, z_prev, v_out, _ = layers[i]
+            g_z = win.gz[i] if win.gz_has[i] else None
+            g_v = win.gv[i]
+            win.gz_has[i] = False
+            if g_z is None and g_v is None:
+                continue  # no gradient reaches this layer at this pass
+            gv_out = win.buf(win.gv, i)
+            _lib.call("evf_lif_bwd", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
+                      _lib.ptr(self._flat[f"{i}.leak"]), _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W,
+                      1 if c.hard_reset else 0, SURROGATE_ID[c.activation], float(c.act_width), _lib.ptr(win.g_cur),
+                      _lib.ptr(gv_out), _lib.ptr(self._small(win, f"{i}.leak")), _lib.ptr(self._small(win, f"{i}.thresh")))
+            if is_first:
+                win.gv[i] = None  # the state entering the window is detached (train_flow.py:170)
+            # weight gradients
+            if i == 0:
+                _lib.call("evf_head_wgrad", _lib.ptr(tape["x_in"]), _lib.ptr(win.g_cur), B, tape["x_in"].shape[1], H, W,
+                          _lib.ptr(self._small(win, "0.ff")))
+            else:
+                k = (i, "ff")
+                _lib.call("evf_conv_wgrad_bits", _lib.ptr(in_bits), _lib.ptr(win.g_cur), B, H, W,
+                          _lib.ptr(self._slab(k, nslab, dev)), 1 if win.slab_init.get(k) else 0)
+                win.slab_init[k] = True
+            use_rec = c.recurrent and z_prev is not None
+            if use_rec:
+                k = (i, "rec")
+                _lib.call("evf_conv_wgrad_bits", _lib.ptr(z_prev), _lib.ptr(win.g_cur), B, H, W,
+                          _lib.ptr(self._slab(k, nslab, dev)), 1 if win.slab_init.get(k) else 0)
+                win.slab_init[k] = True
+            # input gradients: to the layer below (this pass) and to the own previous spikes (previous pass)
+            rec_grad = use_rec and not is_first
+            if i > 0:
+                ga = win.buf(win.gz, i - 1)
+                acc_a = 1 if win.gz_has[i - 1] else 0
+                if rec_grad:
+                    gb = win.buf(win.gz, i)
+                    _lib.call("evf_conv_dgrad", _lib.ptr(win.g_cur), _lib.ptr(self._packed[(i, "ff", 1)]), _lib.ptr(ga), acc_a,
+                              _lib.ptr(self._packed[(i, "rec", 1)]), _lib.ptr(gb), 0, B, H, W)
+                    win.gz_has[i] = True
+                else:
+                    _lib.call("evf_conv_dgrad", _lib.ptr(win.g_cur), _lib.ptr(self._packed[(i, "ff", 1)]), _lib.ptr(ga), acc_a,
+                              None, None, 0, B, H, W)
+                win.gz_has[i - 1] = True
+
+    def _finalize(self, win):
+        """Window complete: reduce the weight-gradient slabs, hand all parameter
+        gradients to autograd (in self.params order)."""
+        B, H, W = win.shape
+        nslab = _lib.load().evf_conv_wgrad_slabs(B, H, W)
+        grads = []
+        for name, p in zip(self.pnames, self.params):
+            if not p.requires_grad:
+                grads.append(None)
+                continue
+            if name in self.small_off:
+                grads.append(self._small(win, name).view(p.shape).to(p.dtype))
+                continue
+            i, nm = name.split(".")
+            k = (int(i), nm)
+            g = torch.zeros(p.shape, dtype=torch.float32, device=win.dev)
+            if win.slab_init.get(k):
+                _lib.call("evf_reduce_slabs", _lib.ptr(self._slabs[k]), nslab, 9 * C * C, 0, _lib.ptr(g))
+            grads.append(g.to(p.dtype))
+        self._last_window = win
+        return grads
+
+
+def single_cell_forward(cell, input_, prev_state, residual=0):
+    raise NotImplementedError(
+        "stand-alone spiking cell calls are not wired yet: use the FireNet-family models (models/model.py), "
+        "whose forward runs every cell through libevflow_hip.so"
+    )

@@ -1,0 +1,209 @@
+"""Spiking convolutional cells -- host-side mirror of reference
+models/spiking_submodules.py (same class names, constructor arguments,
+parameter names and initial distributions, so reference state_dicts load).
+
+The cells are parameter containers: `ff` / `rec` are nn.Conv2d modules only so
+that the state_dict keys (`ff.weight`, `rec.weight`) and the RNG draw order of
+the reference constructors (:63-75, :475-490) are reproduced.  The arithmetic
+of a cell step -- conv, neuron update, Heaviside, surrogate-gradient backward --
+runs in libevflow_hip.so, sequenced by models/engine.py for whole networks.
+"""
+
+import math
+
+import torch
+import torch.nn as nn
+
+from .spiking_util import SURROGATE_ID
+
+
+def _param_or_buffer(mod, name, value, learn):
+    if learn:
+        setattr(mod, name, nn.Parameter(value))
+    else:
+        mod.register_buffer(name, value)
+
+
+class _SpikingCell(nn.Module):
+    kind = None
+    recurrent = False
+    num_states = 2
+
+    def _common(self, input_size, hidden_size, kernel_size, stride, activation, act_width, hard_reset, detach, norm):
+        assert isinstance(
+            activation, str
+        ), "Spiking neurons need a valid activation, see models/spiking_util.py for choices"
+        if activation not in SURROGATE_ID:
+            raise AttributeError(activation)  # reference: getattr(spiking, activation)
+        if norm is not None:
+            raise NotImplementedError("norm='weight'/'group' cells are outside the accelerated path (SURVEY q14)")
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.kernel_size, self.stride = kernel_size, stride
+        self.activation = activation
+        self.register_buffer("act_width", torch.tensor(act_width))
+        self.hard_reset, self.detach = hard_reset, detach
+
+    def _init_conv(self, conv, fan):
+        w_scale = math.sqrt(1 / fan)
+        nn.init.uniform_(conv.weight, -w_scale, w_scale)
+
+    def forward(self, input_, prev_state, residual=0):
+        from .engine import single_cell_forward
+
+        return single_cell_forward(self, input_, prev_state, residual)
+
+
+class ConvLIF(_SpikingCell):
+    """Convolutional spiking LIF cell (reference: spiking_submodules.py:24-126):
+    arctan surrogate, hard reset, detached reset, per-channel sigmoid leak and
+    learnable threshold."""
+
+    kind = "lif"
+
+    def __init__(self, input_size, hidden_size, kernel_size, stride=1, activation="arctanspike", act_width=10.0,
+                 leak=(-4.0, 0.1), thresh=(0.8, 0.0), learn_leak=True, learn_thresh=True, hard_reset=True, detach=True,
+                 norm=None):
+        super().__init__()
+        padding = kernel_size // 2
+        self.ff = nn.Conv2d(input_size, hidden_size, kernel_size, stride=stride, padding=padding, bias=False)
+        _param_or_buffer(self, "leak", torch.randn(hidden_size, 1, 1) * leak[1] + leak[0], learn_leak)
+        _param_or_buffer(self, "thresh", torch.randn(hidden_size, 1, 1) * thresh[1] + thresh[0], learn_thresh)
+        self._init_conv(self.ff, input_size)
+        self._common(input_size, hidden_size, kernel_size, stride, activation, act_width, hard_reset, detach, norm)
+
+
+class ConvLIFRecurrent(_SpikingCell):
+    """Convolutional recurrent spiking LIF cell (reference: spiking_submodules.py:438-551)."""
+
+    kind = "lif"
+    recurrent = True
+
+    def __init__(self, input_size, hidden_size, kernel_size, activation="arctanspike", act_width=10.0, leak=(-4.0, 0.1),
+                 thresh=(0.8, 0.0), learn_leak=True, learn_thresh=True, hard_reset=True, detach=True, norm=None):
+        super().__init__()
+        padding = kernel_size // 2
+        self.ff = nn.Conv2d(input_size, hidden_size, kernel_size, padding=padding, bias=False)
+        self.rec = nn.Conv2d(hidden_size, hidden_size, kernel_size, padding=padding, bias=False)
+        _param_or_buffer(self, "leak", torch.randn(hidden_size, 1, 1) * leak[1] + leak[0], learn_leak)
+        _param_or_buffer(self, "thresh", torch.randn(hidden_size, 1, 1) * thresh[1] + thresh[0], learn_thresh)
+        self._init_conv(self.ff, input_size)
+        self._init_conv(self.rec, hidden_size)
+        self._common(input_size, hidden_size, kernel_size, 1, activation, act_width, hard_reset, detach, norm)
+
+
+class _PLIFBase(_SpikingCell):
+    kind = "plif"
+    num_states = 3
+
+    def _plif_params(self, hidden_size, leak_v, leak_pt, add_pt, thresh, learn_leak, learn_thresh):
+        _param_or_buffer(self, "leak_v", torch.randn(hidden_size, 1, 1) * leak_v[1] + leak_v[0], learn_leak)
+        _param_or_buffer(self, "leak_pt", torch.randn(hidden_size, 1, 1) * leak_pt[1] + leak_pt[0], learn_leak)
+        _param_or_buffer(self, "add_pt", torch.randn(hidden_size, 1, 1) * add_pt[1] + add_pt[0], learn_leak)
+        _param_or_buffer(self, "thresh", torch.randn(hidden_size, 1, 1) * thresh[1] + thresh[0], learn_thresh)
+
+
+class ConvPLIF(_PLIFBase):
+    """LIF cell with adaptation through a pre-synaptic trace (reference: spiking_submodules.py:129-227)."""
+
+    def __init__(self, input_size, hidden_size, kernel_size, stride=1, activation="arctanspike", act_width=10.0,
+                 leak_v=(-4.0, 0.1), leak_pt=(-4.0, 0.1), add_pt=(-2.0, 0.1), thresh=(0.8, 0.0), learn_leak=True,
+                 learn_thresh=True, hard_reset=True, detach=True, norm=None):
+        super().__init__()
+        self.ff = nn.Conv2d(input_size, hidden_size, kernel_size, stride=stride, padding=kernel_size // 2, bias=False)
+        self._plif_params(hidden_size, leak_v, leak_pt, add_pt, thresh, learn_leak, learn_thresh)
+        self._init_conv(self.ff, input_size)
+        self._common(input_size, hidden_size, kernel_size, stride, activation, act_width, hard_reset, detach, norm)
+
+
+class ConvPLIFRecurrent(_PLIFBase):
+    """Recurrent PLIF cell (reference: spiking_submodules.py:554-657)."""
+
+    recurrent = True
+
+    def __init__(self, input_size, hidden_size, kernel_size, activation="arctanspike", act_width=10.0,
+                 leak_v=(-4.0, 0.1), leak_pt=(-4.0, 0.1), add_pt=(-2.0, 0.1), thresh=(0.8, 0.0), learn_leak=True,
+                 learn_thresh=True, hard_reset=True, detach=True, norm=None):
+        super().__init__()
+        self.ff = nn.Conv2d(input_size, hidden_size, kernel_size, padding=kernel_size // 2, bias=False)
+        self.rec = nn.Conv2d(hidden_size, hidden_size, kernel_size, padding=kernel_size // 2, bias=False)
+        self._plif_params(hidden_size, leak_v, leak_pt, add_pt, thresh, learn_leak, learn_thresh)
+        self._init_conv(self.ff, input_size)
+        self._init_conv(self.rec, hidden_size)
+        self._common(input_size, hidden_size, kernel_size, 1, activation, act_width, hard_reset, detach, norm)
+
+
+class _ALIFBase(_SpikingCell):
+    kind = "alif"
+    num_states = 3
+    trace_name = "leak_t"
+
+    def _alif_params(self, hidden_size, leak_v, leak_x, t0, t1, learn_leak, learn_thresh):
+        _param_or_buffer(self, "leak_v", torch.randn(hidden_size, 1, 1) * leak_v[1] + leak_v[0], learn_leak)
+        _param_or_buffer(self, self.trace_name, torch.randn(hidden_size, 1, 1) * leak_x[1] + leak_x[0], learn_leak)
+        _param_or_buffer(self, "t0", torch.randn(hidden_size, 1, 1) * t0[1] + t0[0], learn_thresh)
+        _param_or_buffer(self, "t1", torch.randn(hidden_size, 1, 1) * t1[1] + t1[0], learn_thresh)
+
+
+class ConvALIF(_ALIFBase):
+    """Adaptive-threshold LIF cell, soft reset by default (reference: spiking_submodules.py:230-334)."""
+
+    def __init__(self, input_size, hidden_size, kernel_size, stride=1, activation="arctanspike", act_width=10.0,
+                 leak_v=(-4.0, 0.1), leak_t=(-4.0, 0.1), t0=(0.01, 0.0), t1=(1.8, 0.0), learn_leak=True,
+                 learn_thresh=False, hard_reset=False, detach=True, norm=None):
+        super().__init__()
+        self.ff = nn.Conv2d(input_size, hidden_size, kernel_size, stride=stride, padding=kernel_size // 2, bias=False)
+        self._alif_params(hidden_size, leak_v, leak_t, t0, t1, learn_leak, learn_thresh)
+        self._init_conv(self.ff, input_size)
+        self._common(input_size, hidden_size, kernel_size, stride, activation, act_width, hard_reset, detach, norm)
+
+
+class ConvALIFRecurrent(_ALIFBase):
+    """Recurrent ALIF cell (reference: spiking_submodules.py:660-768)."""
+
+    recurrent = True
+
+    def __init__(self, input_size, hidden_size, kernel_size, activation="arctanspike", act_width=10.0,
+                 leak_v=(-4.0, 0.1), leak_t=(-4.0, 0.1), t0=(0.01, 0.0), t1=(1.8, 0.0), learn_leak=True,
+                 learn_thresh=False, hard_reset=False, detach=True, norm=None):
+        super().__init__()
+        self.ff = nn.Conv2d(input_size, hidden_size, kernel_size, padding=kernel_size // 2, bias=False)
+        self.rec = nn.Conv2d(hidden_size, hidden_size, kernel_size, padding=kernel_size // 2, bias=False)
+        self._alif_params(hidden_size, leak_v, leak_t, t0, t1, learn_leak, learn_thresh)
+        self._init_conv(self.ff, input_size)
+        self._init_conv(self.rec, hidden_size)
+        self._common(input_size, hidden_size, kernel_size, 1, activation, act_width, hard_reset, detach, norm)
+
+
+class ConvXLIF(_ALIFBase):
+    """LIF cell whose threshold adapts to the pre-synaptic trace (reference: spiking_submodules.py:337-435)."""
+
+    kind = "xlif"
+    trace_name = "leak_pt"
+
+    def __init__(self, input_size, hidden_size, kernel_size, stride=1, activation="arctanspike", act_width=10.0,
+                 leak_v=(-4.0, 0.1), leak_pt=(-4.0, 0.1), t0=(0.01, 0.0), t1=(1.8, 0.0), learn_leak=True,
+                 learn_thresh=False, hard_reset=False, detach=True, norm=None):
+        super().__init__()
+        self.ff = nn.Conv2d(input_size, hidden_size, kernel_size, stride=stride, padding=kernel_size // 2, bias=False)
+        self._alif_params(hidden_size, leak_v, leak_pt, t0, t1, learn_leak, learn_thresh)
+        self._init_conv(self.ff, input_size)
+        self._common(input_size, hidden_size, kernel_size, stride, activation, act_width, hard_reset, detach, norm)
+
+
+class ConvXLIFRecurrent(_ALIFBase):
+    """Recurrent XLIF cell (reference: spiking_submodules.py:771-875)."""
+
+    kind = "xlif"
+    recurrent = True
+    trace_name = "leak_pt"
+
+    def __init__(self, input_size, hidden_size, kernel_size, stride=1, activation="arctanspike", act_width=10.0,
+                 leak_v=(-4.0, 0.1), leak_pt=(-4.0, 0.1), t0=(0.01, 0.0), t1=(1.8, 0.0), learn_leak=True,
+                 learn_thresh=False, hard_reset=False, detach=True, norm=None):
+        super().__init__()
+        self.ff = nn.Conv2d(input_size, hidden_size, kernel_size, stride=stride, padding=kernel_size // 2, bias=False)
+        self.rec = nn.Conv2d(hidden_size, hidden_size, kernel_size, padding=kernel_size // 2, bias=False)
+        self._alif_params(hidden_size, leak_v, leak_pt, t0, t1, learn_leak, learn_thresh)
+        self._init_conv(self.ff, input_size)
+        self._init_conv(self.rec, hidden_size)
+        self._common(input_size, hidden_size, kernel_size, stride, activation, act_width, hard_reset, detach, norm)

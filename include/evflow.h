@@ -192,9 +192,12 @@ int evf_conv_dgrad(const float* g_cur, const float* wT_a, float* g_a, int acc_a,
                    const float* wT_b, float* g_b, int acc_b, int B, int H, int W, void* stream);
 
 /* Weight-gradient conv on bit-packed inputs:
- * dW[tap][ci][co] += sum_pix x[pix+tap][ci] * g_cur[pix][co]; wg packed accumulators. */
+ * dW[tap][ci][co] = sum_pix x[pix+tap][ci] * g_cur[pix][co].  Every block reduces its
+ * rows into one slab wg_partial[blk][9][32][32] (written, or += when accumulate);
+ * evf_conv_wgrad_slabs gives the slab count, evf_reduce_slabs sums the slabs into the
+ * torch layout [Cout][Cin][3][3] (dst = or +=). */
 int evf_conv_wgrad_bits(const uint32_t* x, const float* g_cur, int B, int H, int W,
-                        float* wg_partial, int nslab, void* stream);
+                        float* wg_partial, int accumulate, void* stream);
 int evf_conv_wgrad_slabs(int B, int H, int W);
 int evf_reduce_slabs(const float* partial, int nslab, int n, int accumulate, float* dst, void* stream);
 
