@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""Benchmark of the event_flow hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+            --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+Metric (BASELINE.json): event-windows/s of the LIF-FireNet train step at
+128x128 with 15k events per window (10 passes x 1500 events, truncated BPTT
+over the window, contrast-maximisation loss, clip + Adam), 8 windows per GPU,
+pure data parallel (one RCCL all-reduce of the flat gradient per step).  One
+"step" = one window per batch slot = one optimizer step.  Inputs (raw event
+lists) are resident in HBM before the timed region; the timed region contains
+the event binning, every forward pass, the loss, the whole backward, the
+all-reduce and the optimizer -- nothing is skipped or cached.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel: algorithmic FLOP per launch / mean launch
+                duration (HIP events on the launch stream, inside the timed
+                region) against the dense fp32-MFMA peak
+  kernels       the same for every conv entry point
+  iwe_warp      compute_pol_iwe (integer IWE) GB/s at the spec shape and at a
+                bandwidth-saturating batch, against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (PyTorch-CPU port of the reference path) timed
+                on this box's host cores on a bounded sample
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+H = W = 128
+B_PER_GPU = 8
+PASSES = 10
+EV_PER_PASS = 1500
+FP32_MFMA_PEAK = 157.3  # TFLOP/s dense, MI355X_MICROARCH.md
+HBM_PEAK = 8000.0  # GB/s spec
+
+MODEL_CFG = {
+    "name": "LIFFireNet", "encoding": "cnt", "round_encoding": False, "norm_input": False, "num_bins": 2,
+    "base_num_channels": 32, "kernel_size": 3, "activations": ["arctanspike", "arctanspike"], "mask_output": True,
+    "spiking_neuron": {"leak": [-4.0, 0.1], "thresh": [0.8, 0.1], "learn_leak": True, "learn_thresh": True, "hard_reset": True},
+}
+LOSS_CFG = {"loader": {"resolution": [H, W]}, "loss": {"flow_regul_weight": 0.001, "overwrite_intermediate": False, "clip_grad": 100.0},
+            "model": {"mask_output": True}}
+
+CONV_FLOP = 2 * 9 * 32 * 32  # per pixel per 32->32 3x3 conv
+
+
+def make_windows(rank, n_pool, dev):
+    """n_pool windows, each PASSES event lists [B,1500,4] (platform-stable synthetic events)."""
+    from event_flow_amd import synthetic
+
+    pool = []
+    for wdx in range(n_pool):
+        lists = []
+        for k in range(PASSES):
+            seed0 = synthetic.seed_for(3, rank, 0) + 100000 * wdx + 1000 * k
+            ev = synthetic.event_list_batch(B_PER_GPU, EV_PER_PASS, H, W, seed0)
+            lists.append(torch.from_numpy(ev).to(dev))
+        pool.append(lists)
+    return pool
+
+
+def run_step(model, lossf, opt, dp, lists):
+    from event_flow_amd.dataloader.encodings import encode_event_list
+    from event_flow_amd.train import train_window
+
+    passes = [encode_event_list(ev, 2, (H, W), want=("cnt", "mask", "pol")) for ev in lists]
+    for d in passes:
+        d["event_voxel"] = None  # encoding = cnt
+    return train_window(model, lossf, opt, passes, dp=dp)
+
+
+def iwe_warp_bandwidth(dev, B, reps=20):
+    from event_flow_amd import synthetic
+    from event_flow_amd.utils.iwe import compute_pol_iwe
+
+    n = 15000
+    g = np.random.default_rng(1)
+    ev_small = synthetic.event_list_batch(min(B, 8), n, H, W, 4242)
+    ev = np.concatenate([ev_small] * (B // ev_small.shape[0]), 0) if B > ev_small.shape[0] else ev_small
+    flow = torch.from_numpy(g.uniform(-0.1, 0.1, size=(B, 2, H, W)).astype(np.float32)).to(dev)
+    ev = torch.from_numpy(ev).to(dev)
+    pol = torch.stack([(ev[:, :, 3] > 0).float(), (ev[:, :, 3] < 0).float()], 2).contiguous()
+    for _ in range(3):
+        compute_pol_iwe(flow, ev, (H, W), pol[:, :, 0:1], pol[:, :, 1:2], flow_scaling=128, round_idx=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        compute_pol_iwe(flow, ev, (H, W), pol[:, :, 0:1], pol[:, :, 1:2], flow_scaling=128, round_idx=True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    alg_bytes = B * (n * 28 + 2 * H * W * 4)  # 16 B event + 8 B flow gather + 4 B atomic dst, + final image
+    return {"B": B, "events": n, "ms_per_call": ms, "algorithmic_MB": alg_bytes / 1e6, "GBps": alg_bytes / ms / 1e6,
+            "frac_of_hbm_peak": alg_bytes / ms / 1e6 / HBM_PEAK}
+
+
+def cpu_baseline(threads, max_seconds=60.0):
+    """Oracle (PyTorch-CPU port of the reference path) on a bounded sample:
+    ONE window (B=1) of the same workload, full train step."""
+    from event_flow_amd import synthetic
+    from oracle import encodings as oenc
+    from oracle import snn as osnn
+    from oracle import train as otrain
+
+    gen = torch.Generator().manual_seed(0)
+    params = osnn.make_firenet_params("LIFFireNet", gen, neuron={"leak": (-4.0, 0.1), "thresh": (0.8, 0.1)})
+    keys = osnn.trainable_keys(params)
+    Bc = B_PER_GPU  # the same per-GPU batch of windows the GPU step processes
+    passes = []
+    for k in range(PASSES):
+        ev = synthetic.event_list_batch(Bc, EV_PER_PASS, H, W, 555 + 10 * k)
+        d = oenc.collate([oenc.encode_window(ev[b, :, 2], ev[b, :, 1], ev[b, :, 0], ev[b, :, 3], 2, (H, W)) for b in range(Bc)])
+        passes.append({k2: torch.from_numpy(v) for k2, v in d.items()})
+    lcfg = {"flow_regul_weight": 0.001, "mask_output": True}
+
+    def one_step(ps, st, opt, pr):
+        _, _, pr, st = otrain.train_step("LIFFireNet", pr, keys, ps, st, (H, W), opt, loss_cfg=lcfg)
+        return pr, st
+
+    # PyTorch-CPU convs of this size do not scale to hundreds of threads: probe a 2-pass
+    # slice at a few thread counts and keep the fastest (reported as `cores`)
+    cand = sorted({t for t in (8, 16, 32, 64, threads) if t <= threads})
+    best, best_t = None, None
+    for t in cand:
+        torch.set_num_threads(t)
+        one_step(passes[:1], [None] * 7, {"step": 0, "m": {}, "v": {}}, params)  # warm
+        t0 = time.perf_counter()
+        one_step(passes[:2], [None] * 7, {"step": 0, "m": {}, "v": {}}, params)
+        el = time.perf_counter() - t0
+        if best is None or el < best:
+            best, best_t = el, t
+        if el > 20.0:
+            break
+    torch.set_num_threads(best_t)
+    t0 = time.perf_counter()
+    opt = {"step": 0, "m": {}, "v": {}}
+    n_done = 0
+    states = [None] * 7
+    while True:
+        params, states = one_step(passes, states, opt, params)
+        n_done += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or n_done >= 10 or el > max_seconds:
+            break
+    el = time.perf_counter() - t0
+    return {"value": Bc * n_done / el, "unit": "event-windows/s", "cores": best_t, "kind": "port",
+            "sample": f"{n_done} full train step(s) of {Bc} windows (B={Bc}, {PASSES} passes x {EV_PER_PASS} events, {H}x{W}) = "
+                      f"the GPU step's per-GPU work; oracle = PyTorch-CPU fp32 port of the reference path; "
+                      f"{best_t} threads (fastest of {cand} on a {os.cpu_count()}-CPU host), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-iwe", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    from event_flow_amd import _lib
+    from event_flow_amd.loss.flow import EventWarping
+    from event_flow_amd.models.model import LIFFireNet
+    from event_flow_amd.parallel import DataParallel
+    from event_flow_amd.train import FlatAdam
+
+    _lib.load()  # fails loudly when the HIP library is missing
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    dp = DataParallel(device=dev)
+    if dp.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={dp.world}: launch with torch.distributed.run")
+
+    torch.manual_seed(0)  # identical replicas on every rank
+    model = LIFFireNet(dict(MODEL_CFG)).to(dev)
+    model.train()
+    lossf = EventWarping(LOSS_CFG, dev)
+    opt = FlatAdam(model, lr=2e-4, clip=100.0)
+    opt.zero_grad()
+    pool = make_windows(dp.rank, 2, dev)
+
+    for i in range(args.warmup):
+        run_step(model, lossf, opt, dp, pool[i % len(pool)])
+    names = ["evf_conv_lif_fwd", "evf_conv_dgrad", "evf_conv_wgrad_bits", "evf_lif_bwd", "evf_head_lif_fwd"]
+    dp.barrier()
+    torch.cuda.synchronize()
+    _lib.profile_start(names)
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(args.steps):
+        loss = run_step(model, lossf, opt, dp, pool[i % len(pool)])
+    torch.cuda.synchronize()
+    dp.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.profile_stop()
+    elapsed = dp.max_over_ranks(elapsed)
+    loss_val = float(loss)
+
+    if dp.rank == 0:
+        npix = B_PER_GPU * H * W
+        flop = {("evf_conv_lif_fwd", "ff"): CONV_FLOP * npix, ("evf_conv_lif_fwd", "rec"): 2 * CONV_FLOP * npix,
+                ("evf_conv_dgrad", "one"): CONV_FLOP * npix, ("evf_conv_dgrad", "two"): 2 * CONV_FLOP * npix,
+                ("evf_conv_wgrad_bits", ""): CONV_FLOP * npix}
+        kernels = {}
+        for key, ms in prof.items():
+            ms = np.array(ms)
+            ent = {"launches": int(ms.size), "mean_us": float(ms.mean() * 1e3), "total_ms_per_step": float(ms.sum() / args.steps)}
+            if key in flop:
+                ent["TFLOPs"] = flop[key] / (ms.mean() * 1e-3) / 1e12
+                ent["frac_of_fp32_mfma_peak"] = ent["TFLOPs"] / FP32_MFMA_PEAK
+            kernels["/".join(k for k in key if k)] = ent
+        dom_key = max((k for k in prof if k in flop), key=lambda k: sum(prof[k]))
+        dom = kernels["/".join(k for k in dom_key if k)]
+        out = {
+            "metric": "event-windows/sec (train step, 128x128x15k ev)", "value": B_PER_GPU * dp.world * args.steps / elapsed,
+            "unit": "event-windows/s", "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "LIF-FireNet full train step (BPTT over 10 passes x 1500 events = 15k events/window, "
+                                   "128x128, CM loss, clip+Adam), 8 windows per GPU [BASELINE configs[2] per-GPU shard; "
+                                   "superset of configs[1]]",
+                       "global_batch": B_PER_GPU * dp.world, "events_per_window": PASSES * EV_PER_PASS,
+                       "parallelism": f"dp{dp.world}", "loss": loss_val},
+            "roofline": {"kernel": "/".join(k for k in dom_key if k), "bound": "mfma", "achieved": dom["TFLOPs"],
+                         "peak": FP32_MFMA_PEAK, "unit": "TFLOP/s", "frac": dom["TFLOPs"] / FP32_MFMA_PEAK, "traffic": None},
+            "kernels": kernels,
+        }
+        if not args.no_iwe:
+            out["iwe_warp"] = {"spec_shape": iwe_warp_bandwidth(dev, 8), "saturating": iwe_warp_bandwidth(dev, 512, reps=5)}
+        if dp.world == 1 and not args.no_cpu_baseline:
+            threads = args.cpu_threads or (os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(threads)
+        print(json.dumps(out))
+    dp.barrier()
+    dp.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,9 +96,41 @@ def ptr(t):
     return t.data_ptr()
 
 
+# optional per-entry-point timing with HIP events on the launch stream (bench.py)
+_prof = None
+_PROF_VARIANT = {
+    "evf_conv_lif_fwd": lambda a: "rec" if a[2] is not None else "ff",
+    "evf_conv_dgrad": lambda a: "two" if a[4] is not None else "one",
+}
+
+
+def profile_start(names):
+    global _prof
+    _prof = {n: [] for n in names}
+
+
+def profile_stop():
+    """-> {(name, variant): [ms, ...]}; synchronises."""
+    global _prof
+    rec, _prof = _prof, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, lst in (rec or {}).items():
+        for variant, e0, e1 in lst:
+            out.setdefault((name, variant), []).append(e0.elapsed_time(e1))
+    return out
+
+
 def call(name, *args):
     """Invoke an entry point on torch's current stream; raise on error."""
-    rc = getattr(load(), name)(*args, stream_ptr())
+    if _prof is not None and name in _prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(load(), name)(*args, stream_ptr())
+        e1.record()
+        _prof[name].append((_PROF_VARIANT.get(name, lambda a: "")(args), e0, e1))
+    else:
+        rc = getattr(load(), name)(*args, stream_ptr())
     if rc != 0:
         raise EvflowError(f"{name} failed with status {rc}")
 

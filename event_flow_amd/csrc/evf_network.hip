@@ -381,7 +381,8 @@ extern "C" int evf_lif_bwd(const float* g_z_out, const float* g_v_out, const flo
   if (!v_out || !leak || !thresh || !g_cur || !g_v_prev || !g_leak || !g_thresh || B <= 0 || H <= 0 || W <= 0)
     return EVF_EINVAL;
   const long npix = (long)B * H * W;
-  const int nblk = (int)((npix * 8 + 255) / 256 < 2048 ? (npix * 8 + 255) / 256 : 2048);
+  // few, fat blocks: every block ends with 64 global atomics on the same 64 addresses
+  const int nblk = (int)((npix * 8 + 255) / 256 < 768 ? (npix * 8 + 255) / 256 : 768);
   hipLaunchKernelGGL(k_lif_bwd, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)g_z_out,
                      (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev, z_prev, leak, thresh, npix,
                      hard_reset, surrogate, act_width, (float4*)g_cur, (float4*)g_v_prev, g_leak, g_thresh);
@@ -489,110 +490,74 @@ extern "C" int evf_conv_dgrad(const float* g_cur, const float* wT_a, float* g_a,
   return evf_status();
 }
 
-// --------------------------------------------------------------------------
-// weight-gradient conv on bit-packed inputs
-//   dW[tau][ci][co] += sum_pix x[pix+tau][ci] * g[pix][co]
-// GEMM: M = ci, N = co, K = pixels (2 per MFMA).  Each wave walks whole image
-// rows; 9 accumulators (one per tap) share the B operand g[pix][co].
-// --------------------------------------------------------------------------
-#define WG_ROWS_PER_BLOCK 4
-__global__ __launch_bounds__(256) void k_conv_wgrad_bits(const uint32_t* __restrict__ x, const float* __restrict__ g,
-                                                         int B, int H, int W, int accumulate,
-                                                         float* __restrict__ partial) {
-  __shared__ float s_acc[9 * C32 * C32];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int i = lane & 31, h = lane >> 5;
-  for (int e = tid; e < 9 * C32 * C32; e += 256) s_acc[e] = 0.f;
-  __syncthreads();
-  f32x16 acc[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) acc[t] = (f32x16){0};
-  const long nrows = (long)B * H;
-  const long row = (long)blockIdx.x * WG_ROWS_PER_BLOCK + wv;
-  if (row < nrows) {
-    const int b = (int)(row / H), y = (int)(row % H);
-    const uint32_t* xb = x + (long)b * H * W;
-    const float* grow = g + row * W * C32;
-    for (int xs = 0; xs < W; xs += 2) {
-      const int xc = xs + h;  // this lane half's pixel
-      const float bv = xc < W ? grow[(long)xc * C32 + i] : 0.f;
-#pragma unroll
-      for (int tau = 0; tau < 9; ++tau) {
-        const int yy = y + tau / 3 - 1, xx = xc + tau % 3 - 1;
-        const uint32_t word = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xb[(long)yy * W + xx] : 0u;
-        acc[tau] = mfma32((float)((word >> i) & 1u), bv, acc[tau]);
-      }
-    }
-  }
-  // block reduction through LDS atomics, then one slab per block
-#pragma unroll
-  for (int tau = 0; tau < 9; ++tau)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) atomicAdd(&s_acc[(tau * C32 + mfma_row(r, lane)) * C32 + i], acc[tau][r]);
-  __syncthreads();
-  float* slab = partial + (long)blockIdx.x * (9 * C32 * C32);
-  for (int e = tid; e < 9 * C32 * C32; e += 256) slab[e] = accumulate ? slab[e] + s_acc[e] : s_acc[e];
-}
+// (weight-gradient conv on bit-packed inputs: see evf_wgrad.hip)
 
-extern "C" int evf_conv_wgrad_slabs(int B, int H, int W) {
-  (void)W;
-  return evf_cdiv((long)B * H, WG_ROWS_PER_BLOCK);
-}
-
-extern "C" int evf_conv_wgrad_bits(const uint32_t* x, const float* g_cur, int B, int H, int W, float* wg_partial,
-                                   int accumulate, void* stream) {
-  if (!x || !g_cur || !wg_partial || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
-  hipLaunchKernelGGL(k_conv_wgrad_bits, dim3(evf_conv_wgrad_slabs(B, H, W)), dim3(256), 0, EVF_STREAM(stream), x, g_cur,
-                     B, H, W, accumulate, wg_partial);
-  return evf_status();
-}
-
-// Head weight gradient: rows = (ci, tau) pairs (<= 72 -> up to 3 M tiles), cols = co.
+// Head weight gradient: GEMM rows = (ci, tau) pairs (<= 72 -> up to 3 M tiles), cols = co,
+// K = pixels.  Each wave walks whole image rows (grid-strided); the per-lane tap decode is
+// hoisted out of the pixel loop; the 4 waves of a block are summed through LDS stores and
+// the block adds its tile to dw (torch layout) with global atomics.
+#define HW_BLOCKS 256
 __global__ __launch_bounds__(256) void k_head_wgrad(const float* __restrict__ x, const float* __restrict__ g, int B,
                                                     int Cin, int H, int W, float* __restrict__ dw) {
-  __shared__ float s_acc[3 * C32 * C32];
+  __shared__ float s_p[4][3 * C32 * C32];  // 48 KiB
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int nrow = 9 * Cin, NT = (nrow + 31) / 32;
-  for (int e = tid; e < 3 * C32 * C32; e += 256) s_acc[e] = 0.f;
-  __syncthreads();
+  int ci_[3], dy_[3], dx_[3];
+  bool on_[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int rr = 32 * t + i;
+    on_[t] = t < NT && rr < nrow;
+    ci_[t] = on_[t] ? rr / 9 : 0;
+    const int tau = rr % 9;
+    dy_[t] = tau / 3 - 1;
+    dx_[t] = tau % 3 - 1;
+  }
   f32x16 acc[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) acc[t] = (f32x16){0};
   const long nrows = (long)B * H;
-  const long row = (long)blockIdx.x * WG_ROWS_PER_BLOCK + wv;
-  if (row < nrows) {
+  for (long row = (long)blockIdx.x * 4 + wv; row < nrows; row += (long)gridDim.x * 4) {
     const int b = (int)(row / H), y = (int)(row % H);
-    const float* grow = g + row * W * C32;
-    for (int xs = 0; xs < W; xs += 2) {
-      const int xc = xs + h;
-      const float bv = xc < W ? grow[(long)xc * C32 + i] : 0.f;
+    const float* grow = g + row * W * C32 + i;
+    const float* xr[3];
+    bool yok[3];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        if (t < NT) {
-          const int rr = 32 * t + i;  // (ci, tau)
-          float av = 0.f;
-          if (rr < nrow) {
-            const int ci = rr / 9, tau = rr % 9;
-            const int yy = y + tau / 3 - 1, xx = xc + tau % 3 - 1;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) av = x[(((long)b * Cin + ci) * H + yy) * W + xx];
-          }
-          acc[t] = mfma32(av, bv, acc[t]);
+    for (int t = 0; t < 3; ++t) {
+      const int yy = y + dy_[t];
+      yok[t] = on_[t] && yy >= 0 && yy < H;
+      xr[t] = x + (((long)b * Cin + ci_[t]) * H + (yok[t] ? yy : 0)) * W;
+    }
+    for (int xs = 0; xs < W; xs += 8) {
+      float bv[4], av[3][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int xc = xs + 2 * u + h;
+        bv[u] = xc < W ? grow[(long)xc * C32] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int xx = xc + dx_[t];
+          av[t][u] = (yok[t] && xx >= 0 && xx < W) ? xr[t][xx] : 0.f;
         }
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          if (t < NT) acc[t] = mfma32(av[t][u], bv[u], acc[t]);
     }
   }
 #pragma unroll
   for (int t = 0; t < 3; ++t)
-    if (t < NT)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) atomicAdd(&s_acc[(t * C32 + mfma_row(r, lane)) * C32 + i], acc[t][r]);
+    for (int r = 0; r < 16; ++r) s_p[wv][(t * C32 + mfma_row(r, lane)) * C32 + i] = acc[t][r];
   __syncthreads();
   for (int e = tid; e < NT * C32 * C32; e += 256) {
     const int co = e & 31, rr = e >> 5;
     if (rr < nrow) {
-      const int ci = rr / 9, tau = rr % 9;
-      evf_atomic_add(dw + (co * Cin + ci) * 9 + tau, s_acc[e]);
+      const float v = (s_p[0][e] + s_p[1][e]) + (s_p[2][e] + s_p[3][e]);
+      evf_atomic_add(dw + (co * Cin + rr / 9) * 9 + rr % 9, v);
     }
   }
 }
@@ -600,7 +565,8 @@ __global__ __launch_bounds__(256) void k_head_wgrad(const float* __restrict__ x,
 extern "C" int evf_head_wgrad(const float* x, const float* g_cur, int B, int Cin, int H, int W, float* dw,
                               void* stream) {
   if (!x || !g_cur || !dw || B <= 0 || Cin <= 0 || Cin > HEAD_MAX_CIN || H <= 0 || W <= 0) return EVF_EINVAL;
-  hipLaunchKernelGGL(k_head_wgrad, dim3(evf_cdiv((long)B * H, WG_ROWS_PER_BLOCK)), dim3(256), 0, EVF_STREAM(stream), x,
+  const long nb = ((long)B * H + 3) / 4;
+  hipLaunchKernelGGL(k_head_wgrad, dim3((int)(nb < HW_BLOCKS ? nb : HW_BLOCKS)), dim3(256), 0, EVF_STREAM(stream), x,
                      g_cur, B, Cin, H, W, dw);
   return evf_status();
 }

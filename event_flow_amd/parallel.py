@@ -1,0 +1,80 @@
+"""Data parallelism over the GPUs of one MI355X node: one process per GPU,
+batch slots (independent event sequences, reference dataloader/h5.py:51-68,184)
+sharded across ranks, ONE all-reduce per optimizer step on the flat gradient
+buffer over RCCL/xGMI (torch.distributed backend "nccl" is RCCL on ROCm).
+
+The reference has no distributed code.  Its loss SUMS over
+the batch (loss/flow.py:226,259,289), so the all-reduce is a SUM, not a mean:
+sum over ranks of the per-shard gradient == the single-process gradient of the
+global batch.  Clipping and Adam then run identically on every rank on the
+reduced buffer (clip AFTER the reduce).  The scalar loss and the `new_seq`
+reset flag (train_flow.py:100-105 resets all slots when any slot restarts)
+ride in two extra floats at the tail of the same buffer, so a step is exactly
+one collective: 299 KB for LIF-FireNet -- latency bound, never per-tensor.
+"""
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    TAIL = 2  # [loss, new_seq flag]
+
+    def __init__(self, backend=None, device=None, init=True):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = device
+        if backend is None:
+            backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
+        self.backend = backend
+        if init and self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            kw = {}
+            if backend == "nccl" and device is not None:
+                kw["device_id"] = torch.device(device)
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, **kw)
+
+    # -- sharding ------------------------------------------------------------
+    def shard(self, global_batch):
+        """Contiguous slot range [start, stop) of this rank."""
+        if global_batch % self.world:
+            raise ValueError(f"global batch {global_batch} not divisible by {self.world} ranks")
+        per = global_batch // self.world
+        return self.rank * per, (self.rank + 1) * per
+
+    # -- the one collective of a step ---------------------------------------
+    def all_reduce_grads(self, comm, loss=None, new_seq=False):
+        """comm: flat fp32 buffer [n + TAIL]; comm[:n] holds this rank's gradient.
+        Writes loss / flag into the tail, SUM all-reduces the whole buffer in
+        place, returns (global loss, any_new_seq)."""
+        n = comm.numel() - self.TAIL
+        if loss is not None:
+            comm[n : n + 1].copy_(loss.detach().reshape(1))
+        else:
+            comm[n : n + 1].zero_()
+        comm[n + 1 : n + 2].fill_(1.0 if new_seq else 0.0)
+        if self.world > 1:
+            dist.all_reduce(comm, op=dist.ReduceOp.SUM)
+        return comm[n], comm[n + 1]
+
+    def barrier(self):
+        if self.world > 1:
+            if self.backend == "nccl":
+                dist.barrier(device_ids=[torch.device(self.device).index])
+            else:
+                dist.barrier()
+
+    def max_over_ranks(self, value):
+        if self.world == 1:
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device if self.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.world > 1 and dist.is_initialized():
+            dist.destroy_process_group()

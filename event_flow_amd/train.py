@@ -26,7 +26,9 @@ class FlatAdam:
         n = sum(p.numel() for p in self.params)
         self.n = n
         self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        # gradient buffer + 2 tail floats (loss, new_seq flag): the unit of the DP all-reduce
+        self.comm = torch.zeros(n + 2, dtype=torch.float32, device=dev)
+        self.flat_grad = self.comm[:n]
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.norm_ws = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -80,12 +82,12 @@ def train_window(model, loss_function, optimizer, passes, dp=None):
     loss = loss_function()
     loss.backward()
     if dp is not None:
-        dp.all_reduce_grads(optimizer.flat_grad, loss)
+        loss, _ = dp.all_reduce_grads(optimizer.comm, loss)  # SUM over ranks (loss sums over the batch)
     optimizer.step()
     optimizer.zero_grad()
     model.detach_states()
     loss_function.reset()
-    return loss.detach()
+    return loss.detach().clone()
 
 
 def encode_passes(event_lists, num_bins, res):
