@@ -721,20 +721,32 @@ extern "C" int evf_nchw_to_nhwc(const float* in, int B, int C, int H, int W, flo
 // --------------------------------------------------------------------------
 // optimiser: global-norm clip + Adam on one flat buffer (train_flow.py:157-163)
 // --------------------------------------------------------------------------
-__global__ void k_sumsq(const float* __restrict__ g, long n, float* __restrict__ ws) {
+// ws[0] = sum of squares (zeroed per call), ws[1] = optimizer step counter kept on the
+// device (so that a captured hipGraph replays with an advancing step).
+__global__ void k_sumsq(const float* __restrict__ g, long n, float* __restrict__ ws, int device_step) {
   __shared__ float red[16];
   float s = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
   s = evf_block_sum(s, red);
-  if (threadIdx.x == 0) evf_atomic_add(ws, s);
+  if (threadIdx.x == 0) {
+    evf_atomic_add(ws, s);
+    if (device_step && blockIdx.x == 0) ws[1] += 1.0f;  // single writer
+  }
 }
 
 __global__ void k_clip_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long n, float max_norm, float step_size, float b1, float b2,
-                            float bc2_sqrt, float eps, const float* __restrict__ ws) {
+                            float* __restrict__ v, long n, float max_norm, float lr, float b1, float b2,
+                            float host_step_size, float host_bc2_sqrt, float eps, const float* __restrict__ ws,
+                            int device_step) {
   // clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
   float coef = 1.f;
   if (max_norm > 0.f) coef = fminf(1.f, max_norm / (sqrtf(ws[0]) + 1e-6f));
+  float step_size = host_step_size, bc2_sqrt = host_bc2_sqrt;
+  if (device_step) {  // bias corrections from the device-side counter
+    const float t = ws[1];
+    step_size = lr / (1.0f - powf(b1, t));
+    bc2_sqrt = sqrtf(1.0f - powf(b2, t));
+  }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gi = g[i] * coef;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -749,14 +761,19 @@ __global__ void k_clip_adam(float* __restrict__ p, const float* __restrict__ g, 
 extern "C" int evf_clip_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float max_norm,
                                   float lr, float beta1, float beta2, float eps, int step, float* norm_ws,
                                   void* stream) {
-  if (!param || !grad || !m || !v || !norm_ws || n <= 0 || step < 1) return EVF_EINVAL;
+  if (!param || !grad || !m || !v || !norm_ws || n <= 0) return EVF_EINVAL;
   hipStream_t st = EVF_STREAM(stream);
-  int rc = evf_hip(hipMemsetAsync(norm_ws, 0, 2 * sizeof(float), st));
+  const int device_step = step <= 0;  // step <= 0: use (and advance) the counter in norm_ws[1]
+  int rc = evf_hip(hipMemsetAsync(norm_ws, 0, sizeof(float), st));
   if (rc) return rc;
   const int nblk = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-  hipLaunchKernelGGL(k_sumsq, dim3(nblk), dim3(256), 0, st, grad, (long)n, norm_ws);
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(k_clip_adam, dim3(nblk), dim3(256), 0, st, param, grad, m, v, (long)n, max_norm,
-                     (float)((double)lr / bc1), beta1, beta2, (float)sqrt(bc2), eps, norm_ws);
+  hipLaunchKernelGGL(k_sumsq, dim3(nblk), dim3(256), 0, st, grad, (long)n, norm_ws, device_step);
+  double bc1 = 1.0, bc2 = 1.0;
+  if (!device_step) {
+    bc1 = 1.0 - pow((double)beta1, (double)step);
+    bc2 = 1.0 - pow((double)beta2, (double)step);
+  }
+  hipLaunchKernelGGL(k_clip_adam, dim3(nblk), dim3(256), 0, st, param, grad, m, v, (long)n, max_norm, lr, beta1, beta2,
+                     (float)((double)lr / bc1), (float)sqrt(bc2), eps, norm_ws, device_step);
   return evf_status();
 }

@@ -114,6 +114,8 @@ class FireNetEngine:
             off += p.numel()
         self.small_size = off
         self._states = [None] * len(cells)
+        self.static_states = False
+        self._static = [None] * len(cells)
         self._win = None
         self._packed = {}
         self._packed_key = None
@@ -123,6 +125,16 @@ class FireNetEngine:
         self.params.append(t)
         self.pnames.append(name)
 
+    def _act_width(self, i):
+        """Surrogate width as a host float; read back once per buffer version (a
+        .item() in the hot loop would stall the launch queue on every call)."""
+        t = self.cells[i].act_width
+        key = (t.data_ptr(), t._version)
+        cache = self.__dict__.setdefault("_aw_cache", {})
+        if cache.get(i, (None, None))[0] != key:
+            cache[i] = (key, float(t))
+        return cache[i][1]
+
     # ------------------------------------------------------------------ state
     def reset_states(self):
         self._states = [None] * len(self.cells)
@@ -130,6 +142,24 @@ class FireNetEngine:
 
     def detach_states(self):
         self._win = None  # next pass opens a new window; tensors in _states carry no graph
+        if self.static_states:
+            self._store_static()
+
+    def _store_static(self):
+        """Copy the current states into persistent buffers (fixed addresses), so a step
+        captured in a hipGraph carries its final state into the next replay."""
+        new = []
+        for i, st in enumerate(self._states):
+            if st is None:
+                new.append(None)
+                continue
+            if self._static[i] is None:
+                self._static[i] = (torch.empty_like(st[0]), torch.empty_like(st[1]))
+            if st[0].data_ptr() != self._static[i][0].data_ptr():
+                self._static[i][0].copy_(st[0])
+                self._static[i][1].copy_(st[1])
+            new.append(self._static[i])
+        self._states = new
 
     def get_states(self):
         """-> list of [2,B,C,H,W] float tensors (or None), the reference's layout."""
@@ -267,7 +297,7 @@ class FireNetEngine:
             gv_out = win.buf(win.gv, i)
             _lib.call("evf_lif_bwd", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
                       _lib.ptr(self._flat[f"{i}.leak"]), _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W,
-                      1 if c.hard_reset else 0, SURROGATE_ID[c.activation], float(c.act_width), _lib.ptr(win.g_cur),
+                      1 if c.hard_reset else 0, SURROGATE_ID[c.activation], self._act_width(i), _lib.ptr(win.g_cur),
                       _lib.ptr(gv_out), _lib.ptr(self._small(win, f"{i}.leak")), _lib.ptr(self._small(win, f"{i}.thresh")))
             if is_first:
                 win.gv[i] = None  # the state entering the window is detached (train_flow.py:170)

@@ -86,6 +86,11 @@ class FireNet(BaseModel):
         if self._engine is not None:
             self._engine._packed_key = None
 
+    def use_static_states(self, flag=True):
+        """Keep the recurrent state in persistent buffers across detach_states()
+        (required when a whole training step is replayed from a hipGraph)."""
+        self._eng().static_states = bool(flag)
+
     # -- state API (models/model.py:203-227) -------------------------------
     @property
     def states(self):

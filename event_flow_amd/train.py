@@ -18,8 +18,9 @@ class FlatAdam:
     """clip_grad_norm_(max_norm) + Adam(lr, betas, eps) fused on flat buffers.
     Reference semantics: train_flow.py:157-163 with torch.optim.Adam defaults."""
 
-    def __init__(self, model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, clip=100.0):
+    def __init__(self, model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, clip=100.0, device_step=False):
         self.model = model
+        self.device_step = device_step  # keep the step counter on the GPU (hipGraph replay)
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = self.params[0].device
         _lib.require_gpu(self.params[0], "FlatAdam")
@@ -58,7 +59,8 @@ class FlatAdam:
         self.steps += 1
         _lib.call("evf_clip_adam_step", _lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.m),
                   _lib.ptr(self.v), self.n, float(self.clip) if self.clip is not None else 0.0, float(self.lr),
-                  float(self.betas[0]), float(self.betas[1]), float(self.eps), self.steps, _lib.ptr(self.norm_ws))
+                  float(self.betas[0]), float(self.betas[1]), float(self.eps), 0 if self.device_step else self.steps,
+                  _lib.ptr(self.norm_ws))
         # the kernel rewrote the parameters behind torch's version counters: drop the
         # engine's packed-weight cache explicitly
         if hasattr(self.model, "invalidate_weight_cache"):

@@ -220,7 +220,10 @@ int evf_nchw_to_nhwc(const float* in, int B, int C, int H, int W, float* out, vo
 
 /* ------------------------------------------------------------------ optimiser
  * train_flow.py:157-163: clip_grad_norm_(max_norm) + Adam(lr) on one flat
- * parameter buffer.  norm_ws [2] float workspace.  step counts from 1. */
+ * parameter buffer.  norm_ws [2] float workspace: [0] receives the squared
+ * gradient norm, [1] is a device-side step counter.  step >= 1: bias corrections
+ * from the host value.  step <= 0: the kernel advances norm_ws[1] and uses it
+ * (zero it once at start) -- needed when the step is replayed from a hipGraph. */
 int evf_clip_adam_step(float* param, const float* grad, float* m, float* v, int64_t n,
                        float max_norm, float lr, float beta1, float beta2, float eps, int step,
                        float* norm_ws, void* stream);
