@@ -41,6 +41,8 @@ NETWORK_SIGNATURES = {
     "evf_unpack_conv_wgrad": [P, I, I, I, P, P],
     "evf_head_lif_fwd": [P, P, P, P, P, P, I, I, I, I, I, P, P, P],
     "evf_conv_lif_fwd": [P, P, P, P, P, P, P, I, I, I, I, P, P, P],
+    "evf_pack_conv_weight_b3": [P, I, I, P, P],
+    "evf_conv_lif_fwd_b3": [P, P, P, P, P, P, P, I, I, I, I, P, P, P],
     "evf_lif_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P],
     "evf_conv_dgrad": [P, P, P, I, P, P, I, I, I, I, P],
     "evf_conv_wgrad_bits": [P, P, I, I, I, P, I, P],
@@ -100,6 +102,7 @@ def ptr(t):
 _prof = None
 _PROF_VARIANT = {
     "evf_conv_lif_fwd": lambda a: "rec" if a[2] is not None else "ff",
+    "evf_conv_lif_fwd_b3": lambda a: "rec" if a[2] is not None else "ff",
     "evf_conv_dgrad": lambda a: "two" if a[4] is not None else "one",
 }
 

@@ -1,0 +1,180 @@
+// Forward spiking conv cell on the bf16 matrix cores with fp32-equivalent
+// numerics ("bf16x3"): the inputs of every 32->32 layer are binary spikes,
+// which bf16 represents exactly, and an fp32 weight is the exact sum of three
+// bf16 values  w = hi + mid + lo  (8+8+8 mantissa bits).  So
+//     sum_k z_k * w_k = sum_k z_k*hi_k + sum_k z_k*mid_k + sum_k z_k*lo_k
+// with exact products and fp32 accumulation inside v_mfma_f32_32x32x16_bf16:
+// three MFMAs of 32 cycles cover K = 16, against eight fp32 MFMAs of 64 cycles
+// (5.3x fewer matrix-core cycles); the rounding error is that of an fp32
+// accumulation, like any re-ordered fp32 convolution.  The kernel becomes
+// HBM bound (v in / v out), which is where a fused elementwise update belongs.
+//
+// A operand: lane (i, kg) needs the 8 channels 16m+8kg .. +7 of pixel i as
+// bf16: one byte of the pixel's spike word -> 16 bytes through a 256-entry
+// LDS table (one ds_read_b128, broadcast for the all-zero byte).
+// B operand: packed per (tap, m, term) as 64 lanes x 16 B (k_pack_conv_weight_b3).
+#include "evf_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define C32 32
+#define TH 8
+#define TW 32
+#define HALO_W (TW + 2)
+#define HALO_H (TH + 2)
+#define NFRAG 54                 // 9 taps x 2 k-halves x 3 terms
+#define WB3_BYTES (NFRAG * 1024)  // per conv
+
+__device__ __forceinline__ int b3_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ float b3_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ uint32_t bf16_rne(float f) {  // round-to-nearest-even, finite inputs
+  const uint32_t u = __float_as_uint(f);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// dst[((tau*2+m)*3+s)*64 + lane] (uint4 = 8 bf16): element e = term s of w[co=lane&31][ci=16m+8(lane>>5)+e][tau]
+__global__ void k_pack_conv_weight_b3(const float* __restrict__ w, uint4* __restrict__ dst) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (tau*2+m)*64 + lane
+  if (idx >= 18 * 64) return;
+  const int lane = idx & 63, tm = idx >> 6, m = tm & 1, tau = tm >> 1;
+  const int j = lane & 31, kg = lane >> 5;
+  uint32_t t[3][8];
+  for (int e = 0; e < 8; ++e) {
+    const float v = w[(j * C32 + (16 * m + 8 * kg + e)) * 9 + tau];
+    const uint32_t hi = bf16_rne(v);
+    const float r1 = v - __uint_as_float(hi << 16);
+    const uint32_t mid = bf16_rne(r1);
+    const float r2 = r1 - __uint_as_float(mid << 16);
+    const uint32_t lo = bf16_rne(r2);
+    t[0][e] = hi, t[1][e] = mid, t[2][e] = lo;
+  }
+  for (int s = 0; s < 3; ++s)
+    dst[(tm * 3 + s) * 64 + lane] = make_uint4(t[s][0] | (t[s][1] << 16), t[s][2] | (t[s][3] << 16),
+                                               t[s][4] | (t[s][5] << 16), t[s][6] | (t[s][7] << 16));
+}
+
+extern "C" int evf_pack_conv_weight_b3(const float* w, int Cout, int Cin, void* dst, void* stream) {
+  if (!w || !dst || Cout != C32 || Cin != C32) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_pack_conv_weight_b3, dim3(evf_cdiv(18 * 64, 256)), dim3(256), 0, EVF_STREAM(stream), w,
+                     (uint4*)dst);
+  return evf_status();
+}
+
+template <bool REC>
+__global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restrict__ x, const uint4* __restrict__ wff,
+                                                         const uint4* __restrict__ wrec,
+                                                         const float* __restrict__ leak,
+                                                         const float* __restrict__ thresh,
+                                                         const float* __restrict__ v_prev,
+                                                         const uint32_t* __restrict__ z_prev, int B, int H, int W,
+                                                         int hard_reset, float* __restrict__ v_out,
+                                                         uint32_t* __restrict__ z_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint4* s_w = (uint4*)smem_raw;    // NFRAG*64
+  uint4* s_lut = s_w + NFRAG * 64;  // 256
+  uint32_t* s_x = (uint32_t*)(s_lut + 256);
+  uint32_t* s_z = s_x + HALO_H * HALO_W;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+
+  for (int i = tid; i < NFRAG * 64; i += 256) s_w[i] = wff[i];
+  {  // byte -> 8 x bf16 {0, 1.0}
+    const uint32_t t = tid;
+    auto pr = [&](int e) { return ((t >> e) & 1u) * 0x3F80u | (((t >> (e + 1)) & 1u) * 0x3F80u) << 16; };
+    s_lut[tid] = make_uint4(pr(0), pr(2), pr(4), pr(6));
+  }
+  for (int i = tid; i < HALO_H * HALO_W; i += 256) {
+    const int yy = y0 + i / HALO_W - 1, xx = x0 + i % HALO_W - 1;
+    const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const long p = ((long)b * H + yy) * W + xx;
+    s_x[i] = in ? x[p] : 0u;
+    s_z[i] = (in && z_prev) ? z_prev[p] : 0u;
+  }
+  const int i = lane & 31, kg = lane >> 5, j = lane & 31;
+  const int r0 = 2 * wv;
+  // prefetch the previous membrane potential of this wave's two rows: in flight during the MFMAs
+  float vp[2][16];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = y0 + r0 + m, col = x0 + b3_row(r, lane);
+      vp[m][r] = (v_prev && row < H && col < W) ? v_prev[(((long)b * H + row) * W + col) * C32 + j] : 0.f;
+    }
+  __syncthreads();
+
+  f32x16 acc0 = {0}, acc1 = {0};
+  auto conv_phase = [&](const uint32_t* __restrict__ sb) {
+#pragma unroll 1
+    for (int tau = 0; tau < 9; ++tau) {
+      const int dy = tau / 3, dx = tau % 3;
+      const uint32_t w0 = sb[(r0 + dy) * HALO_W + i + dx] >> (8 * kg);
+      const uint32_t w1 = sb[(r0 + 1 + dy) * HALO_W + i + dx] >> (8 * kg);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const uint4 a0u = s_lut[(w0 >> (16 * m)) & 0xFFu], a1u = s_lut[(w1 >> (16 * m)) & 0xFFu];
+        const bf16x8 a0 = *(const bf16x8*)&a0u, a1 = *(const bf16x8*)&a1u;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const uint4 bu = s_w[((tau * 2 + m) * 3 + s) * 64 + lane];
+          const bf16x8 bw = *(const bf16x8*)&bu;
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bw, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw, acc1, 0, 0, 0);
+        }
+      }
+    }
+  };
+  conv_phase(s_x);
+  if (REC) {
+    __syncthreads();  // every wave is done with the ff weights
+    for (int q = tid; q < NFRAG * 64; q += 256) s_w[q] = wrec[q];
+    __syncthreads();
+    conv_phase(s_z);
+  }
+
+  const float lam = b3_sigmoid(leak[j]);     // torch.sigmoid(self.leak)     spiking_submodules.py:111/:536
+  const float th = fmaxf(thresh[j], 0.01f);  // self.thresh.clamp_min(0.01)  :108/:533
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const f32x16& acc = m ? acc1 : acc0;
+    const int row = y0 + r0 + m;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cl = b3_row(r, lane), col = x0 + cl;
+      const bool ok = row < H && col < W;
+      const long pix = ((long)b * H + row) * W + col;
+      bool spike = false;
+      if (ok) {
+        const float z = (float)((s_z[(r0 + m + 1) * HALO_W + cl + 1] >> j) & 1u);
+        const float v = vp[m][r], cur = acc[r];
+        float vo;
+        if (hard_reset)
+          vo = (v * lam) * (1.0f - z) + (1.0f - lam) * cur;  // :119/:544
+        else
+          vo = v * lam + (1.0f - lam) * cur - z * th;        // :121/:546
+        v_out[pix * C32 + j] = vo;
+        spike = (vo - th) > 0.f;
+      }
+      const unsigned long long mk = __ballot(spike);
+      if (ok && j == 0) z_out[pix] = kg ? (uint32_t)(mk >> 32) : (uint32_t)mk;
+    }
+  }
+}
+
+extern "C" int evf_conv_lif_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec, const float* leak,
+                                   const float* thresh, const float* v_prev, const uint32_t* z_prev, int B, int H,
+                                   int W, int hard_reset, float* v_out, uint32_t* z_out, void* stream) {
+  if (!x || !wb_ff || !leak || !thresh || !v_out || !z_out || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(256);
+  hipStream_t st = EVF_STREAM(stream);
+  const size_t lds = WB3_BYTES + 256 * 16 + 2 * HALO_H * HALO_W * 4;
+  if (wb_rec)
+    hipLaunchKernelGGL(k_conv_lif_fwd_b3<true>, grid, block, lds, st, x, (const uint4*)wb_ff, (const uint4*)wb_rec, leak,
+                       thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out);
+  else
+    hipLaunchKernelGGL(k_conv_lif_fwd_b3<false>, grid, block, lds, st, x, (const uint4*)wb_ff, (const uint4*)nullptr,
+                       leak, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out);
+  return evf_status();
+}

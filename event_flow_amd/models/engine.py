@@ -78,7 +78,12 @@ class _FireNetPass(torch.autograd.Function):
 class FireNetEngine:
     """Sequences the kernels for head -> G1 -> R1a -> R1b -> G2 -> R2a -> R2b -> pred."""
 
-    def __init__(self, cells, pred, num_bins):
+    def __init__(self, cells, pred, num_bins, precision="bf16x3"):
+        # "bf16x3": forward convs on the bf16 matrix cores with the exact 3-way weight split
+        # (fp32-equivalent numerics); "fp32": v_mfma_f32_32x32x2_f32 everywhere
+        if precision not in ("bf16x3", "fp32"):
+            raise ValueError(precision)
+        self.precision = precision
         self.cells = cells  # list of 7 spiking cell modules
         self.pred = pred
         self.num_bins = num_bins
@@ -206,6 +211,10 @@ class FireNetEngine:
                     if k not in self._packed:
                         self._packed[k] = _f32((9 * C * C,), dev)
                     _lib.call("evf_pack_conv_weight", _lib.ptr(wd), C, C, tr, _lib.ptr(self._packed[k]))
+                k = (i, nm, "b3")
+                if k not in self._packed:
+                    self._packed[k] = torch.empty(54 * 1024, dtype=torch.uint8, device=dev)
+                _lib.call("evf_pack_conv_weight_b3", _lib.ptr(wd), C, C, _lib.ptr(self._packed[k]))
         self._flat = {}
         for name, p in zip(self.pnames, self.params):
             self._flat[name] = p.detach().float().contiguous().view(-1)
@@ -248,8 +257,10 @@ class FireNetEngine:
                           _lib.ptr(v_prev), _lib.ptr(z_prev), B, Cin, H, W, 1 if c.hard_reset else 0, _lib.ptr(v_out),
                           _lib.ptr(z_out))
             else:
-                wrec = self._packed[(i, "rec", 0)] if c.recurrent else None
-                _lib.call("evf_conv_lif_fwd", _lib.ptr(in_bits), _lib.ptr(self._packed[(i, "ff", 0)]), _lib.ptr(wrec),
+                fmt = "b3" if self.precision == "bf16x3" else 0
+                wrec = self._packed[(i, "rec", fmt)] if c.recurrent else None
+                _lib.call("evf_conv_lif_fwd_b3" if fmt == "b3" else "evf_conv_lif_fwd", _lib.ptr(in_bits),
+                          _lib.ptr(self._packed[(i, "ff", fmt)]), _lib.ptr(wrec),
                           _lib.ptr(leak), _lib.ptr(thresh), _lib.ptr(v_prev), _lib.ptr(z_prev), B, H, W,
                           1 if c.hard_reset else 0, _lib.ptr(v_out), _lib.ptr(z_out))
             if record:

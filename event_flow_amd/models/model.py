@@ -41,6 +41,7 @@ class FireNet(BaseModel):
     residual = False
     num_recurrent_units = 7
     w_scale_pred = None
+    precision = "bf16x3"  # matrix-core path of the 32->32 forward convs: "bf16x3" (exact split) or "fp32"
 
     def __init__(self, unet_kwargs):
         super().__init__()
@@ -78,7 +79,7 @@ class FireNet(BaseModel):
                     f"{type(self).__name__}: the ANN FireNet (ConvLayer_/ConvGRU, reference config 1 is a CPU plumbing "
                     "case) has no HIP path yet; only the spiking FireNets are accelerated"
                 )
-            self._engine = FireNetEngine(self._cells(), self.pred, self.num_bins)
+            self._engine = FireNetEngine(self._cells(), self.pred, self.num_bins, precision=self.precision)
         return self._engine
 
     def invalidate_weight_cache(self):

@@ -172,6 +172,17 @@ int evf_conv_lif_fwd(const uint32_t* x, const float* w_ff, const float* w_rec,
                      const float* v_prev, const uint32_t* z_prev, int B, int H, int W,
                      int hard_reset, float* v_out, uint32_t* z_out, void* stream);
 
+/* Same cell on the bf16 matrix cores with fp32-equivalent numerics ("bf16x3"):
+ * spikes are exact in bf16, every fp32 weight is split exactly into three bf16
+ * terms (evf_pack_conv_weight_b3, dst = 54 KiB per conv), products are exact and
+ * the accumulation is fp32 -- 5.3x fewer matrix-core cycles than the fp32 MFMA
+ * form, same rounding class as any re-ordered fp32 convolution. */
+int evf_pack_conv_weight_b3(const float* w, int Cout, int Cin, void* dst, void* stream);
+int evf_conv_lif_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec,
+                        const float* leak, const float* thresh,
+                        const float* v_prev, const uint32_t* z_prev, int B, int H, int W,
+                        int hard_reset, float* v_out, uint32_t* z_out, void* stream);
+
 /* Neuron backward (autograd of :103-126 / :523-551 with the surrogate of
  * spiking_util.py:88-93).  Per element:
  *   g_v = g_v_out + g_z_out * sg(v_out - thresh)

@@ -208,3 +208,62 @@ def test_fireflownet_runs_and_unsupported_fail_loudly():
         bad = model_cfg()
         bad["encoding"] = "nope"
         LIFFireNet(bad).to(DEV)(x, x)
+
+
+@pytest.mark.parametrize("rec", [False, True])
+def test_bf16x3_forward_is_fp32_equivalent(rec):
+    """The bf16x3 forward (3-way exact weight split on the bf16 matrix cores) and the
+    fp32-MFMA forward against a float64 convolution: both must sit at fp32 round-off."""
+    B, H, W, C = 2, 24, 40, 32
+    g = torch.Generator(device="cpu").manual_seed(5)
+    w_ff = (torch.rand(C, C, 3, 3, generator=g) * 2 - 1) * 0.18
+    w_rec = (torch.rand(C, C, 3, 3, generator=g) * 2 - 1) * 0.18
+    xb = (torch.rand(B, C, H, W, generator=g) < 0.3).float()
+    zb = (torch.rand(B, C, H, W, generator=g) < 0.2).float()
+    v = torch.randn(B, C, H, W, generator=g) * 0.3
+    leak, thresh = torch.randn(C, generator=g) * 0.1 - 4, torch.randn(C, generator=g) * 0.1 + 0.8
+    lam, th = torch.sigmoid(leak.double()), thresh.double().clamp_min(0.01)
+    cur = torch.nn.functional.conv2d(xb.double(), w_ff.double(), padding=1)
+    if rec:
+        cur = cur + torch.nn.functional.conv2d(zb.double(), w_rec.double(), padding=1)
+    ref = v.double() * lam.view(1, C, 1, 1) * (1 - zb.double()) + (1 - lam.view(1, C, 1, 1)) * cur
+    scale = float((w_ff.abs().sum((1, 2, 3)).max() + (w_rec.abs().sum((1, 2, 3)).max() if rec else 0)))
+
+    keep = []  # device copies must outlive the asynchronous kernels that read them
+
+    def to_dev(t):
+        keep.append(t.to(DEV).contiguous())
+        return keep[-1]
+
+    xbits, zbits = torch.empty(B, H, W, dtype=torch.int32, device=DEV), torch.empty(B, H, W, dtype=torch.int32, device=DEV)
+    _lib.call("evf_nchw_to_bits", to_dev(xb).data_ptr(), B, H, W, xbits.data_ptr())
+    _lib.call("evf_nchw_to_bits", to_dev(zb).data_ptr(), B, H, W, zbits.data_ptr())
+    vin = torch.empty(B, H, W, C, device=DEV)
+    _lib.call("evf_nchw_to_nhwc", to_dev(v).data_ptr(), B, C, H, W, vin.data_ptr())
+    dleak, dthresh = to_dev(leak), to_dev(thresh)
+    outs = {}
+    for mode in ("fp32", "b3"):
+        packs = []
+        for wt in (w_ff, w_rec):
+            if mode == "fp32":
+                p = torch.empty(9216, device=DEV)
+                _lib.call("evf_pack_conv_weight", to_dev(wt).data_ptr(), C, C, 0, p.data_ptr())
+            else:
+                p = torch.empty(54 * 1024, dtype=torch.uint8, device=DEV)
+                _lib.call("evf_pack_conv_weight_b3", to_dev(wt).data_ptr(), C, C, p.data_ptr())
+            packs.append(p)
+        vo, zo = torch.empty(B, H, W, C, device=DEV), torch.empty(B, H, W, dtype=torch.int32, device=DEV)
+        _lib.call("evf_conv_lif_fwd_b3" if mode == "b3" else "evf_conv_lif_fwd", xbits.data_ptr(), packs[0].data_ptr(),
+                  packs[1].data_ptr() if rec else None, dleak.data_ptr(), dthresh.data_ptr(), vin.data_ptr(),
+                  zbits.data_ptr(), B, H, W, 1, vo.data_ptr(), zo.data_ptr())
+        vn = torch.empty(B, C, H, W, device=DEV)
+        _lib.call("evf_nhwc_to_nchw", vo.data_ptr(), B, C, H, W, vn.data_ptr())
+        zn = torch.empty(B, C, H, W, device=DEV)
+        _lib.call("evf_bits_to_nchw", zo.data_ptr(), B, H, W, zn.data_ptr())
+        err = float((vn.cpu().double() - ref).abs().max())
+        outs[mode] = err
+        assert err <= 4e-7 * max(scale, 1.0), (mode, err, scale)  # fp32 accumulation round-off
+        spikes_ref = ((ref - th.view(1, C, 1, 1)) > 0)
+        safe = (ref - th.view(1, C, 1, 1)).abs() > 1e-5
+        assert torch.equal(zn.cpu().bool()[safe], spikes_ref[safe])
+    assert outs["b3"] <= 3 * outs["fp32"] + 1e-7, outs  # same error class as the exact-fp32 chain

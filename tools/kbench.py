@@ -30,6 +30,8 @@ w = f(32, 32, 3, 3) * 0.1
 wp, wpt = torch.empty(9216, device=dev), torch.empty(9216, device=dev)
 _lib.call("evf_pack_conv_weight", w.data_ptr(), 32, 32, 0, wp.data_ptr())
 _lib.call("evf_pack_conv_weight", w.data_ptr(), 32, 32, 1, wpt.data_ptr())
+wb3 = torch.empty(54 * 1024, dtype=torch.uint8, device=dev)
+_lib.call("evf_pack_conv_weight_b3", w.data_ptr(), 32, 32, wb3.data_ptr())
 leak, thresh = f(32) * 0.1 - 4, f(32) * 0.1 + 0.8
 x, z = bits(), bits()
 v, vo, g1, g2, g3, g4 = (f(B, H, W, C) for _ in range(6))
@@ -46,6 +48,8 @@ FL = 2 * 9 * 32 * 32 * npix
 cases = [
     ("conv_lif_fwd ff", FL, 3 * npix * 128, lambda: _lib.call("evf_conv_lif_fwd", P(x), P(wp), None, P(leak), P(thresh), P(v), P(z), B, H, W, 1, P(vo), P(zo))),
     ("conv_lif_fwd rec", 2 * FL, 3 * npix * 128, lambda: _lib.call("evf_conv_lif_fwd", P(x), P(wp), P(wp), P(leak), P(thresh), P(v), P(z), B, H, W, 1, P(vo), P(zo))),
+    ("conv_lif_fwd_b3 ff", FL, 3 * npix * 128, lambda: _lib.call("evf_conv_lif_fwd_b3", P(x), P(wb3), None, P(leak), P(thresh), P(v), P(z), B, H, W, 1, P(vo), P(zo))),
+    ("conv_lif_fwd_b3 rec", 2 * FL, 3 * npix * 128, lambda: _lib.call("evf_conv_lif_fwd_b3", P(x), P(wb3), P(wb3), P(leak), P(thresh), P(v), P(z), B, H, W, 1, P(vo), P(zo))),
     ("head_lif_fwd", 2 * 18 * 32 * npix, 2 * npix * 128, lambda: _lib.call("evf_head_lif_fwd", P(xin), P(wh), P(leak), P(thresh), P(v), P(z), B, 2, H, W, 1, P(vo), P(zo))),
     ("conv_dgrad one", FL, 2 * npix * 128, lambda: _lib.call("evf_conv_dgrad", P(g1), P(wpt), P(g2), 0, None, None, 0, B, H, W)),
     ("conv_dgrad two", 2 * FL, 3 * npix * 128, lambda: _lib.call("evf_conv_dgrad", P(g1), P(wpt), P(g2), 0, P(wpt), P(g3), 0, B, H, W)),
