@@ -196,7 +196,9 @@ def main():
     if use_graph:
         model.use_static_states(True)  # recurrent state must live at fixed addresses across replays
     pool = make_windows(dp.rank, 2, dev)
-    names = ["evf_conv_lif_fwd", "evf_conv_dgrad", "evf_conv_wgrad_bits", "evf_lif_bwd", "evf_head_lif_fwd"]
+    names = ["evf_conv_lif_fwd", "evf_conv_lif_fwd_b3", "evf_conv_dgrad", "evf_conv_wgrad_bits", "evf_lif_bwd_wgrad",
+             "evf_lif_bwd", "evf_head_lif_fwd", "evf_head_wgrad", "evf_pred_bwd", "evf_reduce_slabs", "evf_cm_loss_fwd",
+             "evf_cm_loss_bwd"]
 
     # Everything runs on one side stream: warm-up (eager), then one whole training step
     # per input window is captured into a hipGraph on that same stream (autograd's
@@ -261,7 +263,9 @@ def main():
         npix = B_PER_GPU * H * W
         flop = {("evf_conv_lif_fwd", "ff"): CONV_FLOP * npix, ("evf_conv_lif_fwd", "rec"): 2 * CONV_FLOP * npix,
                 ("evf_conv_dgrad", "one"): CONV_FLOP * npix, ("evf_conv_dgrad", "two"): 2 * CONV_FLOP * npix,
-                ("evf_conv_wgrad_bits", ""): CONV_FLOP * npix}
+                ("evf_conv_wgrad_bits", ""): CONV_FLOP * npix,
+                ("evf_conv_lif_fwd_b3", "ff"): CONV_FLOP * npix, ("evf_conv_lif_fwd_b3", "rec"): 2 * CONV_FLOP * npix,
+                ("evf_lif_bwd_wgrad", "ff"): CONV_FLOP * npix, ("evf_lif_bwd_wgrad", "rec"): 2 * CONV_FLOP * npix}
         kernels = {}
         for key, ms in prof.items():
             ms = np.array(ms)

@@ -39,11 +39,13 @@ SIGNATURES = {
 NETWORK_SIGNATURES = {
     "evf_pack_conv_weight": [P, I, I, I, P, P],
     "evf_unpack_conv_wgrad": [P, I, I, I, P, P],
-    "evf_head_lif_fwd": [P, P, P, P, P, P, I, I, I, I, I, P, P, P],
-    "evf_conv_lif_fwd": [P, P, P, P, P, P, P, I, I, I, I, P, P, P],
+    "evf_head_lif_fwd": [P, P, P, P, P, P, I, I, I, I, I, P, P, P, P],
+    "evf_conv_lif_fwd": [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P],
     "evf_pack_conv_weight_b3": [P, I, I, P, P],
-    "evf_conv_lif_fwd_b3": [P, P, P, P, P, P, P, I, I, I, I, P, P, P],
+    "evf_conv_lif_fwd_b3": [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P],
     "evf_lif_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P],
+    "evf_lif_bwd_wgrad_slabs": [I, I, I],
+    "evf_lif_bwd_wgrad": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P, P, I, P],
     "evf_conv_dgrad": [P, P, P, I, P, P, I, I, I, I, P],
     "evf_conv_wgrad_bits": [P, P, I, I, I, P, I, P],
     "evf_conv_wgrad_slabs": [I, I, I],
@@ -52,6 +54,7 @@ NETWORK_SIGNATURES = {
     "evf_pred_fwd": [P, P, P, I, I, I, P, P],
     "evf_pred_bwd": [P, P, P, P, I, I, I, P, P, P, P],
     "evf_bits_to_nchw": [P, I, I, I, P, P],
+    "evf_bits_transpose": [P, I, I, I, P, P],
     "evf_nchw_to_bits": [P, I, I, I, P, P],
     "evf_nhwc_to_nchw": [P, I, I, I, I, P, P],
     "evf_nchw_to_nhwc": [P, I, I, I, I, P, P],
@@ -104,6 +107,7 @@ _PROF_VARIANT = {
     "evf_conv_lif_fwd": lambda a: "rec" if a[2] is not None else "ff",
     "evf_conv_lif_fwd_b3": lambda a: "rec" if a[2] is not None else "ff",
     "evf_conv_dgrad": lambda a: "two" if a[4] is not None else "one",
+    "evf_lif_bwd_wgrad": lambda a: "rec" if a[6] is not None else "ff",
 }
 
 

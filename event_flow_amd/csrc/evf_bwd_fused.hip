@@ -1,0 +1,341 @@
+// Fused neuron backward + weight-gradient conv (gfx950).
+//
+// Per layer and pass the backward needs (a) the elementwise neuron backward
+// (evf_lif_bwd: 6 x 128 B/pixel of HBM traffic) and (b) the weight gradients
+//   dW_ff [tau][ci][co] = sum_pix x     [pix+tau][ci] * g_cur[pix][co]
+//   dW_rec[tau][ci][co] = sum_pix z_prev[pix+tau][ci] * g_cur[pix][co]
+// This kernel does both in one pass over the row segment: the threads that
+// stream g_z, g_v, v', v through registers compute g_cur / g_v_prev, write
+// them out, and drop the exact 3-way bf16 split of g_cur into LDS in MFMA
+// B-operand order; the matrix cores then contract it with the binary spike
+// operands (bf16-exact) -- "bf16x3": products exact, fp32 accumulation, so the
+// result has fp32 round-off like the fp32-MFMA kernel at 1/5 of the matrix
+// cycles.  The kernel is HBM bound; the MFMAs ride under the memory stream.
+//
+// GEMM: M = ci, N = co, K = pixels (16 per v_mfma_f32_32x32x16_bf16).
+//   A[ci][pix]: 8 consecutive pixels of one channel = one byte of the
+//               channel-major spike bit plane (written by the forward kernels),
+//               expanded to 8 bf16 through a 256-entry LDS table;
+//   B[pix][co]: 8 consecutive pixels of one channel of g_cur, as hi/mid/lo bf16.
+// Tap per wave (8 waves own taps 0..7 over all pixels of the block, the ninth
+// tap is shared round-robin) -> no atomics, one slab [9][32][32] per block and
+// input, accumulated over the passes of a window.
+#include "evf_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define C32 32
+#define FB_CW 128
+#define FB_UNITS 4
+#define FB_THREADS 512
+#define FB_NW (FB_CW / 32 + 2)  // plane words per (row, channel): segment + one halo word each side
+
+__device__ __forceinline__ int fb_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ float fb_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ uint32_t fb_bf16(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float fb_surrogate(int kind, float x, float width) {
+  switch (kind) {  // models/spiking_util.py:38-43, 55-65, 74-79, 88-93
+    case EVF_SUPERSPIKE: {
+      const float d = 1.0f + width * fabsf(x);
+      return 1.0f / (d * d);
+    }
+    case EVF_TRIANGLE:
+      return fmaxf(0.f, 1.0f - width * fabsf(x));
+    case EVF_MULTIGAUSS: {
+      const float s2 = 6.f * width, k = 0.3989422804014327f;
+      auto gs = [&](float v, float mu, float sg) { return expf(-((v - mu) * (v - mu)) / (2.f * sg * sg)) / sg * k; };
+      return 1.15f * gs(x, 0.f, width) - 0.15f * gs(x, width, s2) - 0.15f * gs(x, -width, s2);
+    }
+    default:
+      return 1.0f / (1.0f + width * x * x);
+  }
+}
+
+struct FbStage {
+  float4 gz, gv, vo, vp;
+  uint32_t zw;
+};
+
+template <bool REC>
+__global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
+    const float4* __restrict__ g_z_out, const float4* __restrict__ g_v_out, const float4* __restrict__ v_out,
+    const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev, const uint32_t* __restrict__ xT,
+    const uint32_t* __restrict__ zT, const float* __restrict__ leak, const float* __restrict__ thresh, int B, int H,
+    int W, int nchunk, long nunits, int hard_reset, int surrogate, float width, int accumulate,
+    float4* __restrict__ g_cur, float4* __restrict__ g_v_prev, float* __restrict__ g_leak,
+    float* __restrict__ g_thresh, float* __restrict__ slab_ff, float* __restrict__ slab_rec) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  unsigned short* s_b = (unsigned short*)smem_raw;                    // [2][3][FB_CW*32] bf16
+  uint32_t* s_px = (uint32_t*)(s_b + 2 * 3 * FB_CW * C32);            // [2][3][32][FB_NW]
+  uint32_t* s_pz = s_px + 2 * 3 * C32 * FB_NW;                        // same (REC)
+  uint4* s_lut = (uint4*)(s_pz + 2 * 3 * C32 * FB_NW);                // [256]
+  float* s_red = (float*)(s_lut + 256);                               // [2][8][32]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = lane & 31, kg = lane >> 5;
+  const int cg = tid & 7;  // channel group of the elementwise part: channels 4cg..4cg+3
+  const int nW = (W + 31) / 32;
+
+  if (tid < 256) {
+    const uint32_t t = tid;
+    auto pr = [&](int e) { return ((t >> e) & 1u) * 0x3F80u | (((t >> (e + 1)) & 1u) * 0x3F80u) << 16; };
+    s_lut[tid] = make_uint4(pr(0), pr(2), pr(4), pr(6));
+  }
+  float lam[4], th[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    lam[k] = fb_sigmoid(leak[4 * cg + k]);
+    th[k] = fmaxf(thresh[4 * cg + k], 0.01f);
+  }
+  float sl[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
+
+  auto geom = [&](long u, int& b, int& y, int& x0, int& cw) {
+    const long row = u / nchunk;
+    b = (int)(row / H);
+    y = (int)(row % H);
+    x0 = (int)(u % nchunk) * FB_CW;
+    cw = min(FB_CW, W - x0);
+  };
+  FbStage stg[2];
+  auto issue_loads = [&](long u) {
+    int b, y, x0, cw;
+    geom(u, b, y, x0, cw);
+    const long pix0 = ((long)b * H + y) * W + x0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + k * FB_THREADS, p = e >> 3;
+      const long ge = pix0 * 8 + e;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = p < cw;
+      stg[k].vo = ok ? v_out[ge] : z4;
+      stg[k].gz = (ok && g_z_out) ? g_z_out[ge] : z4;
+      stg[k].gv = (ok && g_v_out) ? g_v_out[ge] : z4;
+      stg[k].vp = (ok && v_prev) ? v_prev[ge] : z4;
+      stg[k].zw = (ok && z_prev) ? z_prev[pix0 + p] : 0u;
+    }
+  };
+  auto commit = [&](long u, int buf) {
+    int b, y, x0, cw;
+    geom(u, b, y, x0, cw);
+    const long pix0 = ((long)b * H + y) * W + x0;
+    unsigned short* sb = s_b + buf * (3 * FB_CW * C32);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + k * FB_THREADS, p = e >> 3;
+      const bool ok = p < cw;
+      const float vo[4] = {stg[k].vo.x, stg[k].vo.y, stg[k].vo.z, stg[k].vo.w};
+      const float gz[4] = {stg[k].gz.x, stg[k].gz.y, stg[k].gz.z, stg[k].gz.w};
+      const float gvo[4] = {stg[k].gv.x, stg[k].gv.y, stg[k].gv.z, stg[k].gv.w};
+      const float vp[4] = {stg[k].vp.x, stg[k].vp.y, stg[k].vp.z, stg[k].vp.w};
+      const uint32_t zw = stg[k].zw >> (4 * cg);
+      float gc[4], gp[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        // autograd of spiking_submodules.py:103-126 / :523-551 (see evf_lif_bwd)
+        const float z = (float)((zw >> c) & 1u);
+        const float sg = fb_surrogate(surrogate, vo[c] - th[c], width);
+        const float gsp = gz[c] * sg;
+        const float gv = gvo[c] + gsp;
+        gc[c] = gv * (1.0f - lam[c]);
+        float cur, dlam;
+        if (hard_reset) {
+          gp[c] = gv * lam[c] * (1.0f - z);
+          cur = (vo[c] - (vp[c] * lam[c]) * (1.0f - z)) / (1.0f - lam[c]);
+          dlam = vp[c] * (1.0f - z) - cur;
+        } else {
+          gp[c] = gv * lam[c];
+          cur = (vo[c] - vp[c] * lam[c] + z * th[c]) / (1.0f - lam[c]);
+          dlam = vp[c] - cur;
+          st[c] -= gv * z;
+        }
+        if (ok) {
+          sl[c] += gv * dlam;
+          st[c] -= gsp;
+        }
+      }
+      if (ok) {
+        g_cur[pix0 * 8 + e] = make_float4(gc[0], gc[1], gc[2], gc[3]);
+        g_v_prev[pix0 * 8 + e] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+      }
+      // exact split g = hi + mid + lo (bf16 each), stored in B-operand order:
+      // pixel p = 16*kq + 8*kgp + ee, element ((kq*2 + kgp)*32 + j)*8 + ee
+      const int base = ((p >> 3) * C32) * 8 + (p & 7);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float g0 = ok ? gc[c] : 0.f;
+        const uint32_t hi = fb_bf16(g0);
+        const float r1 = g0 - __uint_as_float(hi << 16);
+        const uint32_t mid = fb_bf16(r1);
+        const float r2 = r1 - __uint_as_float(mid << 16);
+        const uint32_t lo = fb_bf16(r2);
+        const int o = base + (4 * cg + c) * 8;
+        sb[o] = (unsigned short)hi;
+        sb[FB_CW * C32 + o] = (unsigned short)mid;
+        sb[2 * FB_CW * C32 + o] = (unsigned short)lo;
+      }
+    }
+    // spike bit planes of the three rows around y, incl. one halo word each side
+    for (int q = tid; q < 3 * C32 * FB_NW; q += FB_THREADS) {
+      const int wq = q % FB_NW, c = (q / FB_NW) % C32, dy = q / (FB_NW * C32);
+      const int yy = y + dy - 1, xw = x0 / 32 - 1 + wq;
+      const bool in = yy >= 0 && yy < H && xw >= 0 && xw < nW;
+      const long src = (((long)b * H + yy) * C32 + c) * nW + xw;
+      s_px[buf * (3 * C32 * FB_NW) + q] = in ? xT[src] : 0u;
+      if (REC) s_pz[buf * (3 * C32 * FB_NW) + q] = in ? zT[src] : 0u;
+    }
+  };
+
+  f32x16 acc = {0}, acc8 = {0}, accz = {0}, accz8 = {0};
+  const int dy = wv / 3, dx = wv % 3;  // taps 0..7; tap 8 = (2, 2) is shared
+  const long u0 = (long)blockIdx.x * FB_UNITS;
+  const int nu = (int)min((long)FB_UNITS, nunits - u0);
+  if (nu > 0) {
+    issue_loads(u0);
+    commit(u0, 0);
+  }
+  __syncthreads();
+  for (int k = 0; k < nu; ++k) {
+    const int buf = k & 1;
+    if (k + 1 < nu) issue_loads(u0 + k + 1);  // in flight during the MFMAs below
+    const uint4* sbh = (const uint4*)(s_b + buf * (3 * FB_CW * C32));
+    const uint32_t* px = s_px + buf * (3 * C32 * FB_NW);
+    const uint32_t* pz = s_pz + buf * (3 * C32 * FB_NW);
+    auto afrag = [&](const uint32_t* planes, int ddy, int ddx, int kq) -> bf16x8 {
+      const int q = 32 + 16 * kq + 8 * kg + ddx - 1;  // bit offset of the first of the 8 pixels
+      const uint32_t* wr = planes + (ddy * C32 + i) * FB_NW + (q >> 5);
+      const uint32_t byte = __funnelshift_r(wr[0], wr[1], q & 31) & 0xFFu;
+      const uint4 a = s_lut[byte];
+      return *(const bf16x8*)&a;
+    };
+#pragma unroll 2
+    for (int kq = 0; kq < FB_CW / 16; ++kq) {
+      const int fo = (kq * 2 + kg) * C32 + i;  // uint4 index of this lane's 8 pixels of channel i (= co)
+      const uint4 uh = sbh[fo], um = sbh[FB_CW * C32 / 8 + fo], ul = sbh[2 * FB_CW * C32 / 8 + fo];
+      const bf16x8 bh = *(const bf16x8*)&uh, bm = *(const bf16x8*)&um, bl = *(const bf16x8*)&ul;
+      const bf16x8 a = afrag(px, dy, dx, kq);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc, 0, 0, 0);
+      if (REC) {
+        const bf16x8 az = afrag(pz, dy, dx, kq);
+        accz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(az, bh, accz, 0, 0, 0);
+        accz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(az, bm, accz, 0, 0, 0);
+        accz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(az, bl, accz, 0, 0, 0);
+      }
+      if (kq == wv) {  // this wave's share of the ninth tap
+        const bf16x8 a8 = afrag(px, 2, 2, kq);
+        acc8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, bh, acc8, 0, 0, 0);
+        acc8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, bm, acc8, 0, 0, 0);
+        acc8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, bl, acc8, 0, 0, 0);
+        if (REC) {
+          const bf16x8 az8 = afrag(pz, 2, 2, kq);
+          accz8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(az8, bh, accz8, 0, 0, 0);
+          accz8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(az8, bm, accz8, 0, 0, 0);
+          accz8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(az8, bl, accz8, 0, 0, 0);
+        }
+      }
+    }
+    if (k + 1 < nu) commit(u0 + k + 1, buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- weight-gradient slabs: taps 0..7 straight from the owning wave
+  auto store_tile = [&](const f32x16& a, float* slab) {
+    float* d = slab + (long)blockIdx.x * (9 * C32 * C32) + wv * (C32 * C32);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float* p = d + fb_row(q, lane) * C32 + i;
+      *p = accumulate ? *p + a[q] : a[q];
+    }
+  };
+  store_tile(acc, slab_ff);
+  if (REC) store_tile(accz, slab_rec);
+  // ---- tap 8: sum the 8 partial tiles through LDS (aliases the operand buffers)
+  float* s_t8 = (float*)smem_raw;  // [8][1024]
+  auto reduce_t8 = [&](const f32x16& a, float* slab) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s_t8[wv * (C32 * C32) + fb_row(q, lane) * C32 + i] = a[q];
+    __syncthreads();
+    for (int e = tid; e < C32 * C32; e += FB_THREADS) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += s_t8[w * (C32 * C32) + e];
+      float* p = slab + (long)blockIdx.x * (9 * C32 * C32) + 8 * (C32 * C32) + e;
+      *p = accumulate ? *p + v : v;
+    }
+    __syncthreads();
+  };
+  reduce_t8(acc8, slab_ff);
+  if (REC) reduce_t8(accz8, slab_rec);
+
+  // ---- per-channel sums for leak / thresh: lanes with equal (lane & 7) share channels
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      sl[c] += __shfl_xor(sl[c], o, 64);
+      st[c] += __shfl_xor(st[c], o, 64);
+    }
+  if (lane < 8) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      s_red[(0 * 8 + wv) * C32 + 4 * lane + c] = sl[c];
+      s_red[(1 * 8 + wv) * C32 + 4 * lane + c] = st[c];
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int which = tid >> 5, c = tid & 31;
+    float v = 0.f;
+    for (int w = 0; w < 8; ++w) v += s_red[(which * 8 + w) * C32 + c];
+    if (which == 0) {
+      const float l = fb_sigmoid(leak[c]);
+      evf_atomic_add(g_leak + c, v * l * (1.0f - l));
+    } else if (thresh[c] > 0.01f) {
+      evf_atomic_add(g_thresh + c, v);
+    }
+  }
+}
+
+static long fb_units(int B, int H, int W) { return (long)B * H * ((W + FB_CW - 1) / FB_CW); }
+#define FB_LDS (2 * 3 * FB_CW * C32 * 2 + 2 * (2 * 3 * C32 * FB_NW * 4) + 256 * 16 + 2 * 8 * C32 * 4)
+
+extern "C" int evf_lif_bwd_wgrad_slabs(int B, int H, int W) { return evf_cdiv(fb_units(B, H, W), FB_UNITS); }
+
+extern "C" int evf_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const float* v_out, const float* v_prev,
+                                 const uint32_t* z_prev, const uint32_t* xT, const uint32_t* zT_prev, const float* leak,
+                                 const float* thresh, int B, int H, int W, int hard_reset, int surrogate,
+                                 float act_width, float* g_cur, float* g_v_prev, float* g_leak, float* g_thresh,
+                                 float* slab_ff, float* slab_rec, int accumulate, void* stream) {
+  if (!v_out || !xT || !leak || !thresh || !g_cur || !g_v_prev || !g_leak || !g_thresh || !slab_ff || B <= 0 || H <= 0 ||
+      W <= 0 || ((zT_prev != nullptr) != (slab_rec != nullptr)))
+    return EVF_EINVAL;
+  const long nunits = fb_units(B, H, W);
+  const int nchunk = (W + FB_CW - 1) / FB_CW;
+  dim3 grid(evf_cdiv(nunits, FB_UNITS)), block(FB_THREADS);
+  hipStream_t st = EVF_STREAM(stream);
+  static bool a1 = false, a2 = false;
+  if (zT_prev) {
+    if (!a2) {
+      (void)hipFuncSetAttribute((const void*)k_lif_bwd_wgrad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+      a2 = true;
+    }
+    hipLaunchKernelGGL(k_lif_bwd_wgrad<true>, grid, block, FB_LDS, st, (const float4*)g_z_out, (const float4*)g_v_out,
+                       (const float4*)v_out, (const float4*)v_prev, z_prev, xT, zT_prev, leak, thresh, B, H, W, nchunk,
+                       nunits, hard_reset, surrogate, act_width, accumulate ? 1 : 0, (float4*)g_cur, (float4*)g_v_prev,
+                       g_leak, g_thresh, slab_ff, slab_rec);
+  } else {
+    if (!a1) {
+      (void)hipFuncSetAttribute((const void*)k_lif_bwd_wgrad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+      a1 = true;
+    }
+    hipLaunchKernelGGL(k_lif_bwd_wgrad<false>, grid, block, FB_LDS, st, (const float4*)g_z_out, (const float4*)g_v_out,
+                       (const float4*)v_out, (const float4*)v_prev, z_prev, xT, (const uint32_t*)nullptr, leak, thresh, B,
+                       H, W, nchunk, nunits, hard_reset, surrogate, act_width, accumulate ? 1 : 0, (float4*)g_cur,
+                       (float4*)g_v_prev, g_leak, g_thresh, slab_ff, (float*)nullptr);
+  }
+  return evf_status();
+}

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restr
                                                          const float* __restrict__ v_prev,
                                                          const uint32_t* __restrict__ z_prev, int B, int H, int W,
                                                          int hard_reset, float* __restrict__ v_out,
-                                                         uint32_t* __restrict__ z_out) {
+                                                         uint32_t* __restrict__ z_out,
+                                                         uint32_t* __restrict__ zT_out) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint4* s_w = (uint4*)smem_raw;    // NFRAG*64
   uint4* s_lut = s_w + NFRAG * 64;  // 256
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restr
   for (int m = 0; m < 2; ++m) {
     const f32x16& acc = m ? acc1 : acc0;
     const int row = y0 + r0 + m;
+    uint32_t plane = 0u;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int cl = b3_row(r, lane), col = x0 + cl;
@@ -159,22 +161,27 @@ __global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restr
       }
       const unsigned long long mk = __ballot(spike);
       if (ok && j == 0) z_out[pix] = kg ? (uint32_t)(mk >> 32) : (uint32_t)mk;
+      plane |= (spike ? 1u : 0u) << cl;
+    }
+    if (zT_out) {  // channel-major bit planes [B][H][32][ceil(W/32)]
+      plane |= __shfl_xor(plane, 32, 64);
+      if (row < H && lane < 32) zT_out[(((long)b * H + row) * C32 + j) * ((W + 31) / 32) + x0 / 32] = plane;
     }
   }
 }
 
 extern "C" int evf_conv_lif_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec, const float* leak,
                                    const float* thresh, const float* v_prev, const uint32_t* z_prev, int B, int H,
-                                   int W, int hard_reset, float* v_out, uint32_t* z_out, void* stream) {
+                                   int W, int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out, void* stream) {
   if (!x || !wb_ff || !leak || !thresh || !v_out || !z_out || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
   dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(256);
   hipStream_t st = EVF_STREAM(stream);
   const size_t lds = WB3_BYTES + 256 * 16 + 2 * HALO_H * HALO_W * 4;
   if (wb_rec)
     hipLaunchKernelGGL(k_conv_lif_fwd_b3<true>, grid, block, lds, st, x, (const uint4*)wb_ff, (const uint4*)wb_rec, leak,
-                       thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out);
+                       thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out);
   else
     hipLaunchKernelGGL(k_conv_lif_fwd_b3<false>, grid, block, lds, st, x, (const uint4*)wb_ff, (const uint4*)nullptr,
-                       leak, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out);
+                       leak, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out);
   return evf_status();
 }

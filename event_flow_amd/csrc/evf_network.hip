@@ -97,9 +97,10 @@ template <typename ZPrev>
 __device__ __forceinline__ void lif_epilogue(const f32x16& acc, int b, int row, int x0, int H, int W, int lane,
                                              float lam, float th, int hard_reset, const float* __restrict__ v_prev,
                                              ZPrev zprev_word, float* __restrict__ v_out,
-                                             uint32_t* __restrict__ z_out) {
+                                             uint32_t* __restrict__ z_out, uint32_t* __restrict__ zT_out) {
   const int j = lane & 31;
   const bool row_ok = row < H;
+  uint32_t plane = 0u;  // this channel's spikes over the tile's 32 pixels (bit = column)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int col = x0 + mfma_row(r, lane);
@@ -120,6 +121,11 @@ __device__ __forceinline__ void lif_epilogue(const f32x16& acc, int b, int row, 
     }
     const unsigned long long m = __ballot(spike);
     if (ok && j == 0) z_out[pix] = (lane >> 5) ? (uint32_t)(m >> 32) : (uint32_t)m;
+    plane |= (spike ? 1u : 0u) << mfma_row(r, lane);
+  }
+  if (zT_out) {  // channel-major bit planes [B][H][32][ceil(W/32)] for the weight-gradient kernel
+    plane |= __shfl_xor(plane, 32, 64);
+    if (row_ok && lane < 32) zT_out[(((long)b * H + row) * C32 + j) * ((W + 31) / 32) + x0 / 32] = plane;
   }
 }
 
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(256) void k_conv_lif_fwd(const uint32_t* __restrict
                                                       const float* __restrict__ v_prev,
                                                       const uint32_t* __restrict__ z_prev, int B, int H, int W,
                                                       int hard_reset, float* __restrict__ v_out,
-                                                      uint32_t* __restrict__ z_out) {
+                                                      uint32_t* __restrict__ z_out, uint32_t* __restrict__ zT_out) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* s_wff = (float*)smem_raw;                                 // WPACK
   float* s_wrec = s_wff + WPACK;                                   // WPACK (REC only)
@@ -187,13 +193,13 @@ __global__ __launch_bounds__(256) void k_conv_lif_fwd(const uint32_t* __restrict
     if (REC) return s_z[(row - y0 + 1) * HALO_W + (col - x0 + 1)];
     return z_prev ? z_prev[((long)b * H + row) * W + col] : 0u;
   };
-  lif_epilogue(acc0, b, y0 + r0, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out);
-  lif_epilogue(acc1, b, y0 + r0 + 1, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out);
+  lif_epilogue(acc0, b, y0 + r0, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out, zT_out);
+  lif_epilogue(acc1, b, y0 + r0 + 1, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out, zT_out);
 }
 
 extern "C" int evf_conv_lif_fwd(const uint32_t* x, const float* w_ff, const float* w_rec, const float* leak,
                                 const float* thresh, const float* v_prev, const uint32_t* z_prev, int B, int H, int W,
-                                int hard_reset, float* v_out, uint32_t* z_out, void* stream) {
+                                int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out, void* stream) {
   if (!x || !w_ff || !leak || !thresh || !v_out || !z_out || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
   dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(256);
   hipStream_t st = EVF_STREAM(stream);
@@ -205,11 +211,11 @@ extern "C" int evf_conv_lif_fwd(const uint32_t* x, const float* w_ff, const floa
       attr = true;
     }
     hipLaunchKernelGGL(k_conv_lif_fwd<true>, grid, block, lds, st, x, w_ff, w_rec, leak, thresh, v_prev, z_prev, B, H, W,
-                       hard_reset, v_out, z_out);
+                       hard_reset, v_out, z_out, zT_out);
   } else {
     const size_t lds = WPACK * 4 + HALO_H * HALO_W * 4;
     hipLaunchKernelGGL(k_conv_lif_fwd<false>, grid, block, lds, st, x, w_ff, (const float*)nullptr, leak, thresh, v_prev,
-                       z_prev, B, H, W, hard_reset, v_out, z_out);
+                       z_prev, B, H, W, hard_reset, v_out, z_out, zT_out);
   }
   return evf_status();
 }
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ 
                                                       const float* __restrict__ v_prev,
                                                       const uint32_t* __restrict__ z_prev, int B, int Cin, int H, int W,
                                                       int hard_reset, float* __restrict__ v_out,
-                                                      uint32_t* __restrict__ z_out) {
+                                                      uint32_t* __restrict__ z_out, uint32_t* __restrict__ zT_out) {
   __shared__ float s_x[HEAD_MAX_CIN][HALO_H * HALO_W];
   __shared__ float s_w[9 * (HEAD_MAX_CIN / 2) * 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -255,18 +261,18 @@ __global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ 
   const float lam = evf_sigmoid(leak[j]);
   const float th = fmaxf(thresh[j], 0.01f);
   auto zword = [&](int row, int col) -> uint32_t { return z_prev ? z_prev[((long)b * H + row) * W + col] : 0u; };
-  lif_epilogue(acc0, b, y0 + r0, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out);
-  lif_epilogue(acc1, b, y0 + r0 + 1, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out);
+  lif_epilogue(acc0, b, y0 + r0, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out, zT_out);
+  lif_epilogue(acc1, b, y0 + r0 + 1, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out, zT_out);
 }
 
 extern "C" int evf_head_lif_fwd(const float* x, const float* w, const float* leak, const float* thresh,
                                 const float* v_prev, const uint32_t* z_prev, int B, int Cin, int H, int W,
-                                int hard_reset, float* v_out, uint32_t* z_out, void* stream) {
+                                int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out, void* stream) {
   if (!x || !w || !leak || !thresh || !v_out || !z_out || B <= 0 || Cin <= 0 || Cin > HEAD_MAX_CIN || H <= 0 || W <= 0)
     return EVF_EINVAL;
   dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(256);
   hipLaunchKernelGGL(k_head_lif_fwd, grid, block, 0, EVF_STREAM(stream), x, w, leak, thresh, v_prev, z_prev, B, Cin, H, W,
-                     hard_reset, v_out, z_out);
+                     hard_reset, v_out, z_out, zT_out);
   return evf_status();
 }
 
@@ -693,6 +699,26 @@ __global__ void k_nchw_to_nhwc(const float* __restrict__ in, int B, int C, int H
   out[e] = in[(b * C + c) * HW + q];
 }
 
+// pixel-major spike words [B][H][W] -> channel-major bit planes [B][H][32][ceil(W/32)]
+__global__ void k_bits_transpose(const uint32_t* __restrict__ bits, int B, int H, int W, uint32_t* __restrict__ planes) {
+  const int nW = (W + 31) / 32;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over B*H*32*nW
+  if (e >= (long)B * H * C32 * nW) return;
+  const int xw = (int)(e % nW), c = (int)((e / nW) % C32);
+  const long row = e / ((long)nW * C32);
+  uint32_t m = 0u;
+  for (int k = 0; k < 32; ++k) {
+    const int x = xw * 32 + k;
+    if (x < W) m |= ((bits[row * W + x] >> c) & 1u) << k;
+  }
+  planes[e] = m;
+}
+extern "C" int evf_bits_transpose(const uint32_t* bits, int B, int H, int W, uint32_t* planes, void* stream) {
+  if (!bits || !planes || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  const long n = (long)B * H * C32 * ((W + 31) / 32);
+  hipLaunchKernelGGL(k_bits_transpose, dim3(evf_cdiv(n, 256)), dim3(256), 0, EVF_STREAM(stream), bits, B, H, W, planes);
+  return evf_status();
+}
 extern "C" int evf_bits_to_nchw(const uint32_t* bits, int B, int H, int W, float* out, void* stream) {
   if (!bits || !out || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
   hipLaunchKernelGGL(k_bits_to_nchw, dim3(evf_cdiv((long)B * C32 * H * W, 256)), dim3(256), 0, EVF_STREAM(stream), bits,

@@ -159,10 +159,10 @@ class FireNetEngine:
                 new.append(None)
                 continue
             if self._static[i] is None:
-                self._static[i] = (torch.empty_like(st[0]), torch.empty_like(st[1]))
+                self._static[i] = tuple(torch.empty_like(t) for t in st)
             if st[0].data_ptr() != self._static[i][0].data_ptr():
-                self._static[i][0].copy_(st[0])
-                self._static[i][1].copy_(st[1])
+                for dst, src in zip(self._static[i], st):
+                    dst.copy_(src)
             new.append(self._static[i])
         self._states = new
 
@@ -173,7 +173,7 @@ class FireNetEngine:
             if st is None:
                 out.append(None)
                 continue
-            v, z = st
+            v, z = st[0], st[1]
             B, H, W, _ = v.shape
             vv, zz = _f32((B, C, H, W), v.device), _f32((B, C, H, W), v.device)
             _lib.call("evf_nhwc_to_nchw", _lib.ptr(v), B, C, H, W, _lib.ptr(vv))
@@ -192,7 +192,9 @@ class FireNetEngine:
             v, z = _f32((B, H, W, C), vv.device), _i32((B, H, W), vv.device)
             _lib.call("evf_nchw_to_nhwc", _lib.ptr(vv), B, C, H, W, _lib.ptr(v))
             _lib.call("evf_nchw_to_bits", _lib.ptr(zz), B, H, W, _lib.ptr(z))
-            new.append((v, z))
+            zT = _i32((B, H, C, (W + 31) // 32), vv.device)
+            _lib.call("evf_bits_transpose", _lib.ptr(z), B, H, W, _lib.ptr(zT))
+            new.append((v, z, zT))
         self._states = new
         self._win = None
 
@@ -244,29 +246,30 @@ class FireNetEngine:
         dev = x_in.device
         layers = []
         new_states = []
-        in_bits = None
+        in_bits = in_bitsT = None
         for i, c in enumerate(self.cells):
             st = states[i]
-            v_prev, z_prev = st if st is not None else (None, None)
+            v_prev, z_prev, zT_prev = st if st is not None else (None, None, None)
             if v_prev is not None and tuple(v_prev.shape) != (B, H, W, C):
                 raise _lib.EvflowError("state shape does not match the input; call reset_states()")
             v_out, z_out = _f32((B, H, W, C), dev), _i32((B, H, W), dev)
+            zT_out = _i32((B, H, C, (W + 31) // 32), dev)  # channel-major bit planes for the weight gradients
             leak, thresh = self._flat[f"{i}.leak"], self._flat[f"{i}.thresh"]
             if i == 0:
                 _lib.call("evf_head_lif_fwd", _lib.ptr(x_in), _lib.ptr(self._flat["0.ff"]), _lib.ptr(leak), _lib.ptr(thresh),
                           _lib.ptr(v_prev), _lib.ptr(z_prev), B, Cin, H, W, 1 if c.hard_reset else 0, _lib.ptr(v_out),
-                          _lib.ptr(z_out))
+                          _lib.ptr(z_out), _lib.ptr(zT_out))
             else:
                 fmt = "b3" if self.precision == "bf16x3" else 0
                 wrec = self._packed[(i, "rec", fmt)] if c.recurrent else None
                 _lib.call("evf_conv_lif_fwd_b3" if fmt == "b3" else "evf_conv_lif_fwd", _lib.ptr(in_bits),
                           _lib.ptr(self._packed[(i, "ff", fmt)]), _lib.ptr(wrec),
                           _lib.ptr(leak), _lib.ptr(thresh), _lib.ptr(v_prev), _lib.ptr(z_prev), B, H, W,
-                          1 if c.hard_reset else 0, _lib.ptr(v_out), _lib.ptr(z_out))
+                          1 if c.hard_reset else 0, _lib.ptr(v_out), _lib.ptr(z_out), _lib.ptr(zT_out))
             if record:
-                layers.append((in_bits, v_prev, z_prev, v_out, z_out))
-            in_bits = z_out
-            new_states.append((v_out, z_out))
+                layers.append((in_bits, v_prev, z_prev, v_out, z_out, in_bitsT, zT_prev))
+            in_bits, in_bitsT = z_out, zT_out
+            new_states.append((v_out, z_out, zT_out))
         flow = _f32((B, 2, H, W), dev)
         _lib.call("evf_pred_fwd", _lib.ptr(in_bits), _lib.ptr(self._flat["pred.w"]), _lib.ptr(self._flat["pred.b"]), B, H, W,
                   _lib.ptr(flow))
@@ -299,34 +302,52 @@ class FireNetEngine:
             win.g_cur = _f32((B, H, W, C), dev)
         for i in range(n - 1, -1, -1):
             c = self.cells[i]
-            in_bits, v_prev, z_prev, v_out, _ = layers[i]
+            in_bits, v_prev, z_prev, v_out, _, in_bitsT, zT_prev = layers[i]
             g_z = win.gz[i] if win.gz_has[i] else None
             g_v = win.gv[i]
             win.gz_has[i] = False
             if g_z is None and g_v is None:
                 continue  # no gradient reaches this layer at this pass
             gv_out = win.buf(win.gv, i)
-            _lib.call("evf_lif_bwd", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
-                      _lib.ptr(self._flat[f"{i}.leak"]), _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W,
-                      1 if c.hard_reset else 0, SURROGATE_ID[c.activation], self._act_width(i), _lib.ptr(win.g_cur),
-                      _lib.ptr(gv_out), _lib.ptr(self._small(win, f"{i}.leak")), _lib.ptr(self._small(win, f"{i}.thresh")))
+            use_rec = c.recurrent and z_prev is not None
+            leak_g, thr_g = self._small(win, f"{i}.leak"), self._small(win, f"{i}.thresh")
+            if i > 0 and self.precision == "bf16x3":
+                # neuron backward + both weight gradients in one pass (evf_bwd_fused.hip)
+                kf, kr = (i, "ff"), (i, "rec")
+                nsl = _lib.load().evf_lif_bwd_wgrad_slabs(B, H, W)
+                acc_flag = 1 if win.slab_init.get(kf) else 0
+                if use_rec and bool(win.slab_init.get(kr)) != bool(acc_flag):
+                    # first recurrent contribution arrives later than the ff one: start its slab at zero
+                    self._slab(kr, nsl, dev).zero_()
+                _lib.call("evf_lif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
+                          _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None, _lib.ptr(self._flat[f"{i}.leak"]),
+                          _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
+                          self._act_width(i), _lib.ptr(win.g_cur), _lib.ptr(gv_out), _lib.ptr(leak_g), _lib.ptr(thr_g),
+                          _lib.ptr(self._slab(kf, nsl, dev)), _lib.ptr(self._slab(kr, nsl, dev)) if use_rec else None, acc_flag)
+                win.slab_init[kf] = True
+                if use_rec:
+                    win.slab_init[kr] = True
+            else:
+                _lib.call("evf_lif_bwd", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
+                          _lib.ptr(self._flat[f"{i}.leak"]), _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W,
+                          1 if c.hard_reset else 0, SURROGATE_ID[c.activation], self._act_width(i), _lib.ptr(win.g_cur),
+                          _lib.ptr(gv_out), _lib.ptr(leak_g), _lib.ptr(thr_g))
+                # weight gradients
+                if i == 0:
+                    _lib.call("evf_head_wgrad", _lib.ptr(tape["x_in"]), _lib.ptr(win.g_cur), B, tape["x_in"].shape[1], H, W,
+                              _lib.ptr(self._small(win, "0.ff")))
+                else:
+                    k = (i, "ff")
+                    _lib.call("evf_conv_wgrad_bits", _lib.ptr(in_bits), _lib.ptr(win.g_cur), B, H, W,
+                              _lib.ptr(self._slab(k, nslab, dev)), 1 if win.slab_init.get(k) else 0)
+                    win.slab_init[k] = True
+                if use_rec:
+                    k = (i, "rec")
+                    _lib.call("evf_conv_wgrad_bits", _lib.ptr(z_prev), _lib.ptr(win.g_cur), B, H, W,
+                              _lib.ptr(self._slab(k, nslab, dev)), 1 if win.slab_init.get(k) else 0)
+                    win.slab_init[k] = True
             if is_first:
                 win.gv[i] = None  # the state entering the window is detached (train_flow.py:170)
-            # weight gradients
-            if i == 0:
-                _lib.call("evf_head_wgrad", _lib.ptr(tape["x_in"]), _lib.ptr(win.g_cur), B, tape["x_in"].shape[1], H, W,
-                          _lib.ptr(self._small(win, "0.ff")))
-            else:
-                k = (i, "ff")
-                _lib.call("evf_conv_wgrad_bits", _lib.ptr(in_bits), _lib.ptr(win.g_cur), B, H, W,
-                          _lib.ptr(self._slab(k, nslab, dev)), 1 if win.slab_init.get(k) else 0)
-                win.slab_init[k] = True
-            use_rec = c.recurrent and z_prev is not None
-            if use_rec:
-                k = (i, "rec")
-                _lib.call("evf_conv_wgrad_bits", _lib.ptr(z_prev), _lib.ptr(win.g_cur), B, H, W,
-                          _lib.ptr(self._slab(k, nslab, dev)), 1 if win.slab_init.get(k) else 0)
-                win.slab_init[k] = True
             # input gradients: to the layer below (this pass) and to the own previous spikes (previous pass)
             rec_grad = use_rec and not is_first
             if i > 0:
@@ -346,7 +367,8 @@ class FireNetEngine:
         """Window complete: reduce the weight-gradient slabs, hand all parameter
         gradients to autograd (in self.params order)."""
         B, H, W = win.shape
-        nslab = _lib.load().evf_conv_wgrad_slabs(B, H, W)
+        nslab = (_lib.load().evf_lif_bwd_wgrad_slabs(B, H, W) if self.precision == "bf16x3"
+                 else _lib.load().evf_conv_wgrad_slabs(B, H, W))
         grads = []
         for name, p in zip(self.pnames, self.params):
             if not p.requires_grad:

@@ -158,10 +158,12 @@ int evf_unpack_conv_wgrad(const float* packed, int Cout, int Cin, int accumulate
  * the event count / voxel tensor), Cin <= 8, Cout = 32.
  *   w [32,Cin,3,3] torch layout; leak, thresh [32] raw parameters
  *   v_prev [B,H,W,32] or NULL (zeros); z_prev bits [B,H,W] or NULL
- *   outputs v_out [B,H,W,32], z_out bits [B,H,W] */
+ *   outputs v_out [B,H,W,32], z_out bits [B,H,W] and (optional, may be NULL) zT_out:
+ *   the same spikes as channel-major bit planes [B,H,32,ceil(W/32)] (bit = x mod 32),
+ *   the layout the weight-gradient kernel consumes */
 int evf_head_lif_fwd(const float* x, const float* w, const float* leak, const float* thresh,
                      const float* v_prev, const uint32_t* z_prev, int B, int Cin, int H, int W,
-                     int hard_reset, float* v_out, uint32_t* z_out, void* stream);
+                     int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out, void* stream);
 
 /* 32->32 channel spiking conv cell on bit-packed spikes.
  * ConvLIF.forward (:96-126) when z_rec_w == NULL, ConvLIFRecurrent.forward
@@ -170,7 +172,7 @@ int evf_head_lif_fwd(const float* x, const float* w, const float* leak, const fl
 int evf_conv_lif_fwd(const uint32_t* x, const float* w_ff, const float* w_rec,
                      const float* leak, const float* thresh,
                      const float* v_prev, const uint32_t* z_prev, int B, int H, int W,
-                     int hard_reset, float* v_out, uint32_t* z_out, void* stream);
+                     int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out, void* stream);
 
 /* Same cell on the bf16 matrix cores with fp32-equivalent numerics ("bf16x3"):
  * spikes are exact in bf16, every fp32 weight is split exactly into three bf16
@@ -181,7 +183,7 @@ int evf_pack_conv_weight_b3(const float* w, int Cout, int Cin, void* dst, void* 
 int evf_conv_lif_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec,
                         const float* leak, const float* thresh,
                         const float* v_prev, const uint32_t* z_prev, int B, int H, int W,
-                        int hard_reset, float* v_out, uint32_t* z_out, void* stream);
+                        int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out, void* stream);
 
 /* Neuron backward (autograd of :103-126 / :523-551 with the surrogate of
  * spiking_util.py:88-93).  Per element:
@@ -195,6 +197,21 @@ int evf_lif_bwd(const float* g_z_out, const float* g_v_out, const float* v_out,
                 const float* leak, const float* thresh, int B, int H, int W,
                 int hard_reset, int surrogate, float act_width,
                 float* g_cur, float* g_v_prev, float* g_leak, float* g_thresh, void* stream);
+
+/* Fused neuron backward + weight gradients of one 32->32 cell (layers fed by spikes):
+ * evf_lif_bwd and evf_conv_wgrad_bits (for the ff input and, when zT_prev != NULL, the
+ * recurrent input) in one pass over the data, with the matrix-core part in exact
+ * bf16x3 form.  xT / zT_prev are the channel-major spike bit planes written by the
+ * forward kernels (zT_out).  slab_* [nslab][9][32][32] with nslab =
+ * evf_lif_bwd_wgrad_slabs(B,H,W); written, or += when accumulate. */
+int evf_lif_bwd_wgrad_slabs(int B, int H, int W);
+int evf_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const float* v_out,
+                      const float* v_prev, const uint32_t* z_prev,
+                      const uint32_t* xT, const uint32_t* zT_prev,
+                      const float* leak, const float* thresh, int B, int H, int W,
+                      int hard_reset, int surrogate, float act_width,
+                      float* g_cur, float* g_v_prev, float* g_leak, float* g_thresh,
+                      float* slab_ff, float* slab_rec, int accumulate, void* stream);
 
 /* Input-gradient conv: g_x[pix][ci] (+)= sum_tap,co g_cur[pix-tap][co]*w[co][ci][tap]
  * with wT packed by evf_pack_conv_weight(transposed=1).  g_cur, g_x [B,H,W,32].
@@ -225,6 +242,8 @@ int evf_pred_bwd(const uint32_t* x, const float* flow, const float* g_flow, cons
 
 /* spike bit maps <-> float tensors (state API, models/model.py:203-209) */
 int evf_bits_to_nchw(const uint32_t* bits, int B, int H, int W, float* out, void* stream);
+/* pixel-major spike words [B,H,W] -> channel-major bit planes [B,H,32,ceil(W/32)] */
+int evf_bits_transpose(const uint32_t* bits, int B, int H, int W, uint32_t* planes, void* stream);
 int evf_nchw_to_bits(const float* in, int B, int H, int W, uint32_t* bits, void* stream);
 int evf_nhwc_to_nchw(const float* in, int B, int C, int H, int W, float* out, void* stream);
 int evf_nchw_to_nhwc(const float* in, int B, int C, int H, int W, float* out, void* stream);

@@ -255,7 +255,7 @@ def test_bf16x3_forward_is_fp32_equivalent(rec):
         vo, zo = torch.empty(B, H, W, C, device=DEV), torch.empty(B, H, W, dtype=torch.int32, device=DEV)
         _lib.call("evf_conv_lif_fwd_b3" if mode == "b3" else "evf_conv_lif_fwd", xbits.data_ptr(), packs[0].data_ptr(),
                   packs[1].data_ptr() if rec else None, dleak.data_ptr(), dthresh.data_ptr(), vin.data_ptr(),
-                  zbits.data_ptr(), B, H, W, 1, vo.data_ptr(), zo.data_ptr())
+                  zbits.data_ptr(), B, H, W, 1, vo.data_ptr(), zo.data_ptr(), None)
         vn = torch.empty(B, C, H, W, device=DEV)
         _lib.call("evf_nhwc_to_nchw", vo.data_ptr(), B, C, H, W, vn.data_ptr())
         zn = torch.empty(B, C, H, W, device=DEV)
@@ -267,3 +267,54 @@ def test_bf16x3_forward_is_fp32_equivalent(rec):
         safe = (ref - th.view(1, C, 1, 1)).abs() > 1e-5
         assert torch.equal(zn.cpu().bool()[safe], spikes_ref[safe])
     assert outs["b3"] <= 3 * outs["fp32"] + 1e-7, outs  # same error class as the exact-fp32 chain
+
+
+@pytest.mark.parametrize("rec", [False, True])
+@pytest.mark.parametrize("shape", [(2, 20, 128), (1, 9, 200)])
+def test_fused_lif_bwd_wgrad_matches_separate_kernels(rec, shape):
+    """evf_lif_bwd_wgrad (bf16x3 matrix part) == evf_lif_bwd + evf_conv_wgrad_bits (fp32 MFMA)."""
+    B, H, W = shape
+    C = 32
+    g = torch.Generator(device="cpu").manual_seed(11)
+    R = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    gz, gv, vo, vp = R(B, H, W, C), R(B, H, W, C) * 0.5, R(B, H, W, C) * 0.5 + 0.6, R(B, H, W, C) * 0.5
+    xb = (torch.rand(B, C, H, W, generator=g) < 0.3).float().to(DEV)
+    zb = (torch.rand(B, C, H, W, generator=g) < 0.2).float().to(DEV)
+    leak, thresh = R(C) * 0.1 - 4, R(C) * 0.1 + 0.8
+    xbits, zbits = (torch.empty(B, H, W, dtype=torch.int32, device=DEV) for _ in range(2))
+    _lib.call("evf_nchw_to_bits", xb.data_ptr(), B, H, W, xbits.data_ptr())
+    _lib.call("evf_nchw_to_bits", zb.data_ptr(), B, H, W, zbits.data_ptr())
+    nW = (W + 31) // 32
+    xT, zT = (torch.empty(B, H, C, nW, dtype=torch.int32, device=DEV) for _ in range(2))
+    _lib.call("evf_bits_transpose", xbits.data_ptr(), B, H, W, xT.data_ptr())
+    _lib.call("evf_bits_transpose", zbits.data_ptr(), B, H, W, zT.data_ptr())
+    lib = _lib.load()
+    # reference: separate kernels
+    gc0, gp0 = torch.empty_like(gz), torch.empty_like(gz)
+    gl0, gt0 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    _lib.call("evf_lif_bwd", gz.data_ptr(), gv.data_ptr(), vo.data_ptr(), vp.data_ptr(), zbits.data_ptr(), leak.data_ptr(),
+              thresh.data_ptr(), B, H, W, 1, 0, 10.0, gc0.data_ptr(), gp0.data_ptr(), gl0.data_ptr(), gt0.data_ptr())
+    ns0 = lib.evf_conv_wgrad_slabs(B, H, W)
+    dw0 = {}
+    for nm, bits in (("ff", xbits), ("rec", zbits)):
+        slab = torch.empty(ns0, 9216, device=DEV)
+        _lib.call("evf_conv_wgrad_bits", bits.data_ptr(), gc0.data_ptr(), B, H, W, slab.data_ptr(), 0)
+        dw0[nm] = torch.zeros(C, C, 3, 3, device=DEV)
+        _lib.call("evf_reduce_slabs", slab.data_ptr(), ns0, 9216, 0, dw0[nm].data_ptr())
+    # fused
+    gc1, gp1 = torch.empty_like(gz), torch.empty_like(gz)
+    gl1, gt1 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ns1 = lib.evf_lif_bwd_wgrad_slabs(B, H, W)
+    s_ff, s_rec = torch.empty(ns1, 9216, device=DEV), torch.empty(ns1, 9216, device=DEV)
+    for acc in (0, 1):  # second call accumulates: result must double
+        _lib.call("evf_lif_bwd_wgrad", gz.data_ptr(), gv.data_ptr(), vo.data_ptr(), vp.data_ptr(), zbits.data_ptr(), xT.data_ptr(),
+                  zT.data_ptr() if rec else None, leak.data_ptr(), thresh.data_ptr(), B, H, W, 1, 0, 10.0, gc1.data_ptr(),
+                  gp1.data_ptr(), gl1.data_ptr(), gt1.data_ptr(), s_ff.data_ptr(), s_rec.data_ptr() if rec else None, acc)
+    assert torch.equal(gc1, gc0) and torch.equal(gp1, gp0)  # elementwise part: identical arithmetic
+    np.testing.assert_allclose(N(gl1), 2 * N(gl0), rtol=2e-4, atol=1e-4)
+    np.testing.assert_allclose(N(gt1), 2 * N(gt0), rtol=2e-4, atol=1e-4)
+    for nm, slab in (("ff", s_ff),) + ((("rec", s_rec),) if rec else ()):
+        dw = torch.zeros(C, C, 3, 3, device=DEV)
+        _lib.call("evf_reduce_slabs", slab.data_ptr(), ns1, 9216, 0, dw.data_ptr())
+        ref = 2 * N(dw0[nm])
+        assert np.abs(N(dw) - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-5, nm

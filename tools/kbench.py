@@ -38,6 +38,8 @@ v, vo, g1, g2, g3, g4 = (f(B, H, W, C) for _ in range(6))
 zo = bits()
 nslab = _lib.load().evf_conv_wgrad_slabs(B, H, W)
 slab = torch.empty(nslab, 9216, device=dev)
+slab2 = torch.empty(nslab, 9216, device=dev)
+xT = torch.randint(-2**31, 2**31 - 1, (B, H, 32, (W + 31) // 32), dtype=torch.int32, device=dev)
 gl, gt = torch.zeros(32, device=dev), torch.zeros(32, device=dev)
 xin = f(B, 2, H, W)
 wh = f(32, 2, 3, 3)
@@ -46,14 +48,16 @@ P = lambda t: t.data_ptr()
 FL = 2 * 9 * 32 * 32 * npix
 
 cases = [
-    ("conv_lif_fwd ff", FL, 3 * npix * 128, lambda: _lib.call("evf_conv_lif_fwd", P(x), P(wp), None, P(leak), P(thresh), P(v), P(z), B, H, W, 1, P(vo), P(zo))),
-    ("conv_lif_fwd rec", 2 * FL, 3 * npix * 128, lambda: _lib.call("evf_conv_lif_fwd", P(x), P(wp), P(wp), P(leak), P(thresh), P(v), P(z), B, H, W, 1, P(vo), P(zo))),
-    ("conv_lif_fwd_b3 ff", FL, 3 * npix * 128, lambda: _lib.call("evf_conv_lif_fwd_b3", P(x), P(wb3), None, P(leak), P(thresh), P(v), P(z), B, H, W, 1, P(vo), P(zo))),
-    ("conv_lif_fwd_b3 rec", 2 * FL, 3 * npix * 128, lambda: _lib.call("evf_conv_lif_fwd_b3", P(x), P(wb3), P(wb3), P(leak), P(thresh), P(v), P(z), B, H, W, 1, P(vo), P(zo))),
-    ("head_lif_fwd", 2 * 18 * 32 * npix, 2 * npix * 128, lambda: _lib.call("evf_head_lif_fwd", P(xin), P(wh), P(leak), P(thresh), P(v), P(z), B, 2, H, W, 1, P(vo), P(zo))),
+    ("conv_lif_fwd ff", FL, 3 * npix * 128, lambda: _lib.call("evf_conv_lif_fwd", P(x), P(wp), None, P(leak), P(thresh), P(v), P(z), B, H, W, 1, P(vo), P(zo), None)),
+    ("conv_lif_fwd rec", 2 * FL, 3 * npix * 128, lambda: _lib.call("evf_conv_lif_fwd", P(x), P(wp), P(wp), P(leak), P(thresh), P(v), P(z), B, H, W, 1, P(vo), P(zo), None)),
+    ("conv_lif_fwd_b3 ff", FL, 3 * npix * 128, lambda: _lib.call("evf_conv_lif_fwd_b3", P(x), P(wb3), None, P(leak), P(thresh), P(v), P(z), B, H, W, 1, P(vo), P(zo), None)),
+    ("conv_lif_fwd_b3 rec", 2 * FL, 3 * npix * 128, lambda: _lib.call("evf_conv_lif_fwd_b3", P(x), P(wb3), P(wb3), P(leak), P(thresh), P(v), P(z), B, H, W, 1, P(vo), P(zo), None)),
+    ("head_lif_fwd", 2 * 18 * 32 * npix, 2 * npix * 128, lambda: _lib.call("evf_head_lif_fwd", P(xin), P(wh), P(leak), P(thresh), P(v), P(z), B, 2, H, W, 1, P(vo), P(zo), None)),
     ("conv_dgrad one", FL, 2 * npix * 128, lambda: _lib.call("evf_conv_dgrad", P(g1), P(wpt), P(g2), 0, None, None, 0, B, H, W)),
     ("conv_dgrad two", 2 * FL, 3 * npix * 128, lambda: _lib.call("evf_conv_dgrad", P(g1), P(wpt), P(g2), 0, P(wpt), P(g3), 0, B, H, W)),
     ("conv_wgrad_bits", FL, npix * 128, lambda: _lib.call("evf_conv_wgrad_bits", P(x), P(g1), B, H, W, P(slab), 1)),
+    ("lif_bwd_wgrad ff", FL, 6 * npix * 128, lambda: _lib.call("evf_lif_bwd_wgrad", P(g1), P(g2), P(vo), P(v), P(z), P(xT), None, P(leak), P(thresh), B, H, W, 1, 0, 10.0, P(g3), P(g4), P(gl), P(gt), P(slab), None, 1)),
+    ("lif_bwd_wgrad rec", 2 * FL, 6 * npix * 128, lambda: _lib.call("evf_lif_bwd_wgrad", P(g1), P(g2), P(vo), P(v), P(z), P(xT), P(xT), P(leak), P(thresh), B, H, W, 1, 0, 10.0, P(g3), P(g4), P(gl), P(gt), P(slab), P(slab2), 1)),
     ("lif_bwd", 0, 6 * npix * 128, lambda: _lib.call("evf_lif_bwd", P(g1), P(g2), P(vo), P(v), P(z), P(leak), P(thresh), B, H, W, 1, 0, 10.0, P(g3), P(g4), P(gl), P(gt))),
     ("head_wgrad", 2 * 18 * 32 * npix, npix * 128, lambda: _lib.call("evf_head_wgrad", P(xin), P(g1), B, 2, H, W, P(dwh))),
 ]
