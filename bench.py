@@ -196,7 +196,7 @@ def main():
     if use_graph:
         model.use_static_states(True)  # recurrent state must live at fixed addresses across replays
     pool = make_windows(dp.rank, 2, dev)
-    names = ["evf_conv_lif_fwd", "evf_conv_lif_fwd_b3", "evf_conv_dgrad", "evf_conv_wgrad_bits", "evf_lif_bwd_wgrad",
+    names = ["evf_conv_lif_fwd", "evf_conv_lif_fwd_b3", "evf_conv_dgrad", "evf_conv_dgrad_b3", "evf_conv_wgrad_bits", "evf_lif_bwd_wgrad",
              "evf_lif_bwd", "evf_head_lif_fwd", "evf_head_wgrad", "evf_pred_bwd", "evf_reduce_slabs", "evf_cm_loss_fwd",
              "evf_cm_loss_bwd"]
 
@@ -265,6 +265,7 @@ def main():
                 ("evf_conv_dgrad", "one"): CONV_FLOP * npix, ("evf_conv_dgrad", "two"): 2 * CONV_FLOP * npix,
                 ("evf_conv_wgrad_bits", ""): CONV_FLOP * npix,
                 ("evf_conv_lif_fwd_b3", "ff"): CONV_FLOP * npix, ("evf_conv_lif_fwd_b3", "rec"): 2 * CONV_FLOP * npix,
+                ("evf_conv_dgrad_b3", ""): CONV_FLOP * npix,
                 ("evf_lif_bwd_wgrad", "ff"): CONV_FLOP * npix, ("evf_lif_bwd_wgrad", "rec"): 2 * CONV_FLOP * npix}
         kernels = {}
         for key, ms in prof.items():

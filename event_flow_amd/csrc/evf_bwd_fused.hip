@@ -66,8 +66,9 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev, const uint32_t* __restrict__ xT,
     const uint32_t* __restrict__ zT, const float* __restrict__ leak, const float* __restrict__ thresh, int B, int H,
     int W, int nchunk, long nunits, int hard_reset, int surrogate, float width, int accumulate,
-    float4* __restrict__ g_cur, float4* __restrict__ g_v_prev, float* __restrict__ g_leak,
-    float* __restrict__ g_thresh, float* __restrict__ slab_ff, float* __restrict__ slab_rec) {
+    float4* __restrict__ g_cur, uint2* __restrict__ g_split, float4* __restrict__ g_v_prev,
+    float* __restrict__ g_leak, float* __restrict__ g_thresh, float* __restrict__ slab_ff,
+    float* __restrict__ slab_rec) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   unsigned short* s_b = (unsigned short*)smem_raw;                    // [2][3][FB_CW*32] bf16
   uint32_t* s_px = (uint32_t*)(s_b + 2 * 3 * FB_CW * C32);            // [2][3][32][FB_NW]
@@ -157,9 +158,10 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
         }
       }
       if (ok) {
-        g_cur[pix0 * 8 + e] = make_float4(gc[0], gc[1], gc[2], gc[3]);
+        if (g_cur) g_cur[pix0 * 8 + e] = make_float4(gc[0], gc[1], gc[2], gc[3]);
         g_v_prev[pix0 * 8 + e] = make_float4(gp[0], gp[1], gp[2], gp[3]);
       }
+      uint32_t tb[3][4];
       // exact split g = hi + mid + lo (bf16 each), stored in B-operand order:
       // pixel p = 16*kq + 8*kgp + ee, element ((kq*2 + kgp)*32 + j)*8 + ee
       const int base = ((p >> 3) * C32) * 8 + (p & 7);
@@ -175,6 +177,13 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
         sb[o] = (unsigned short)hi;
         sb[FB_CW * C32 + o] = (unsigned short)mid;
         sb[2 * FB_CW * C32 + o] = (unsigned short)lo;
+        tb[0][c] = hi, tb[1][c] = mid, tb[2][c] = lo;
+      }
+      if (ok && g_split) {  // the same split as three bf16 planes [term][pix][32] for evf_conv_dgrad_b3
+        const long ps = (long)B * H * W * 8;
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3)
+          g_split[t3 * ps + pix0 * 8 + e] = make_uint2(tb[t3][0] | (tb[t3][1] << 16), tb[t3][2] | (tb[t3][3] << 16));
       }
     }
     // spike bit planes of the three rows around y, incl. one halo word each side
@@ -308,9 +317,9 @@ extern "C" int evf_lif_bwd_wgrad_slabs(int B, int H, int W) { return evf_cdiv(fb
 extern "C" int evf_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const float* v_out, const float* v_prev,
                                  const uint32_t* z_prev, const uint32_t* xT, const uint32_t* zT_prev, const float* leak,
                                  const float* thresh, int B, int H, int W, int hard_reset, int surrogate,
-                                 float act_width, float* g_cur, float* g_v_prev, float* g_leak, float* g_thresh,
-                                 float* slab_ff, float* slab_rec, int accumulate, void* stream) {
-  if (!v_out || !xT || !leak || !thresh || !g_cur || !g_v_prev || !g_leak || !g_thresh || !slab_ff || B <= 0 || H <= 0 ||
+                                 float act_width, float* g_cur, void* g_split, float* g_v_prev, float* g_leak,
+                                 float* g_thresh, float* slab_ff, float* slab_rec, int accumulate, void* stream) {
+  if (!v_out || !xT || !leak || !thresh || (!g_cur && !g_split) || !g_v_prev || !g_leak || !g_thresh || !slab_ff || B <= 0 || H <= 0 ||
       W <= 0 || ((zT_prev != nullptr) != (slab_rec != nullptr)))
     return EVF_EINVAL;
   const long nunits = fb_units(B, H, W);
@@ -325,8 +334,8 @@ extern "C" int evf_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, con
     }
     hipLaunchKernelGGL(k_lif_bwd_wgrad<true>, grid, block, FB_LDS, st, (const float4*)g_z_out, (const float4*)g_v_out,
                        (const float4*)v_out, (const float4*)v_prev, z_prev, xT, zT_prev, leak, thresh, B, H, W, nchunk,
-                       nunits, hard_reset, surrogate, act_width, accumulate ? 1 : 0, (float4*)g_cur, (float4*)g_v_prev,
-                       g_leak, g_thresh, slab_ff, slab_rec);
+                       nunits, hard_reset, surrogate, act_width, accumulate ? 1 : 0, (float4*)g_cur, (uint2*)g_split,
+                       (float4*)g_v_prev, g_leak, g_thresh, slab_ff, slab_rec);
   } else {
     if (!a1) {
       (void)hipFuncSetAttribute((const void*)k_lif_bwd_wgrad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
@@ -335,7 +344,7 @@ extern "C" int evf_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, con
     hipLaunchKernelGGL(k_lif_bwd_wgrad<false>, grid, block, FB_LDS, st, (const float4*)g_z_out, (const float4*)g_v_out,
                        (const float4*)v_out, (const float4*)v_prev, z_prev, xT, (const uint32_t*)nullptr, leak, thresh, B,
                        H, W, nchunk, nunits, hard_reset, surrogate, act_width, accumulate ? 1 : 0, (float4*)g_cur,
-                       (float4*)g_v_prev, g_leak, g_thresh, slab_ff, (float*)nullptr);
+                       (uint2*)g_split, (float4*)g_v_prev, g_leak, g_thresh, slab_ff, (float*)nullptr);
   }
   return evf_status();
 }

@@ -1,0 +1,115 @@
+// Input-gradient conv in exact-split bf16 ("bf16x3 x bf16x3", 6 products):
+//   g_x[pix][ci] (+)= sum_{tap,co} g[pix + tap][co] * Wt[tap][co][ci]
+// Both operands are real valued.  g arrives already split into three bf16
+// planes g = gh + gm + gl (written by evf_lif_bwd_wgrad), the transposed /
+// flipped weights are split at pack time; the product keeps the six terms
+// gh*wh, gh*wm, gm*wh, gh*wl, gl*wh, gm*wm (the dropped three are below 2^-24
+// of the leading one), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.
+// 108 MFMAs of 32 cycles per 32-pixel tile against 144 of 64 cycles in fp32.
+//
+// One wave = one M tile (32 pixels of a row) x 32 input channels.  The A
+// fragments (8 consecutive channels of one pixel and term = 16 B) are loaded
+// straight from global memory / L2 per tap -- the 9x tap overlap is served by
+// L1/L2, no halo tile in LDS -- so LDS only holds the 54 KiB of split weights
+// and two 8-wave blocks fit per CU.
+#include "evf_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define C32 32
+#define DG_ROWS 8  // tile rows = waves per block
+#define NFRAG 54
+
+__device__ __forceinline__ int dg_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ uint32_t dg_bf16(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// dst[((tau*2+m)*3+s)*64 + lane]: element e = term s of Wt[tau][co=16m+8kg+e][ci=lane&31] = w[co][ci][8-tau]
+__global__ void k_pack_conv_weight_b3t(const float* __restrict__ w, uint4* __restrict__ dst) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 18 * 64) return;
+  const int lane = idx & 63, tm = idx >> 6, m = tm & 1, tau = tm >> 1;
+  const int j = lane & 31, kg = lane >> 5;
+  uint32_t t[3][8];
+  for (int e = 0; e < 8; ++e) {
+    const float v = w[((16 * m + 8 * kg + e) * C32 + j) * 9 + (8 - tau)];
+    const uint32_t hi = dg_bf16(v);
+    const float r1 = v - __uint_as_float(hi << 16);
+    const uint32_t mid = dg_bf16(r1);
+    const float r2 = r1 - __uint_as_float(mid << 16);
+    const uint32_t lo = dg_bf16(r2);
+    t[0][e] = hi, t[1][e] = mid, t[2][e] = lo;
+  }
+  for (int s = 0; s < 3; ++s)
+    dst[(tm * 3 + s) * 64 + lane] = make_uint4(t[s][0] | (t[s][1] << 16), t[s][2] | (t[s][3] << 16),
+                                               t[s][4] | (t[s][5] << 16), t[s][6] | (t[s][7] << 16));
+}
+
+extern "C" int evf_pack_conv_weight_b3t(const float* w, int Cout, int Cin, void* dst, void* stream) {
+  if (!w || !dst || Cout != C32 || Cin != C32) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_pack_conv_weight_b3t, dim3(evf_cdiv(18 * 64, 256)), dim3(256), 0, EVF_STREAM(stream), w,
+                     (uint4*)dst);
+  return evf_status();
+}
+
+__global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3(const uint4* __restrict__ gs, long plane_stride,
+                                                                const uint4* __restrict__ wt, float* __restrict__ gx,
+                                                                int accumulate, int B, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint4* s_w = (uint4*)smem_raw;  // NFRAG*64
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.z, y = blockIdx.y * DG_ROWS + wv, x0 = blockIdx.x * 32;
+  for (int q = tid; q < NFRAG * 64; q += DG_ROWS * 64) s_w[q] = wt[q];
+  __syncthreads();
+  if (y >= H) return;
+  const int i = lane & 31, kg = lane >> 5;
+  f32x16 acc = {0};
+  const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll 1
+  for (int tau = 0; tau < 9; ++tau) {
+    const int yy = y + tau / 3 - 1, xx = x0 + i + tau % 3 - 1;
+    const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    // uint4 index of (pixel, 8-channel group): pixel*4 + group, group = 2m + kg
+    const long pg = in ? ((((long)b * H + yy) * W + xx) * 4 + kg) : 0;
+    uint4 a[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) a[m][s] = in ? gs[s * plane_stride + pg + 2 * m] : z4;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const uint4* wf = s_w + ((tau * 2 + m) * 3) * 64 + lane;
+      const uint4 w0 = wf[0], w1 = wf[64], w2 = wf[128];
+      const bf16x8 wh = *(const bf16x8*)&w0, wm = *(const bf16x8*)&w1, wl = *(const bf16x8*)&w2;
+      const bf16x8 ah = *(const bf16x8*)&a[m][0], am = *(const bf16x8*)&a[m][1], al = *(const bf16x8*)&a[m][2];
+      // smallest terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int col = x0 + dg_row(r, lane);
+    if (col < W) {
+      float* d = gx + (((long)b * H + y) * W + col) * C32 + i;
+      *d = accumulate ? *d + acc[r] : acc[r];
+    }
+  }
+}
+
+extern "C" int evf_conv_dgrad_b3(const void* g_split, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W,
+                                 void* stream) {
+  if (!g_split || !wT_b3 || !g_x || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  dim3 grid(evf_cdiv(W, 32), evf_cdiv(H, DG_ROWS), B), block(DG_ROWS * 64);
+  const long plane_stride = (long)B * H * W * 4;  // uint4 per term plane: npix * 32 bf16 / 8
+  hipLaunchKernelGGL(k_conv_dgrad_b3, grid, block, NFRAG * 1024, EVF_STREAM(stream), (const uint4*)g_split, plane_stride,
+                     (const uint4*)wT_b3, g_x, accumulate, B, H, W);
+  return evf_status();
+}

@@ -78,10 +78,26 @@ extern "C" int evf_unpack_conv_wgrad(const float* packed, int Cout, int Cin, int
   return evf_status();
 }
 
+// slab groups in parallel: block (x, y) sums slabs y, y+G, ... for 256 outputs, then adds
+// its partial into dst (torch layout) with one atomic per output
+#define RS_GROUPS 8
+__global__ void k_reduce_wgrad_par(const float* __restrict__ partial, int nslab, float* __restrict__ dst) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // e = (tau*32 + ci)*32 + co
+  if (e >= 9 * C32 * C32) return;
+  float s = 0.f;
+  for (int k = blockIdx.y; k < nslab; k += RS_GROUPS) s += partial[(long)k * (9 * C32 * C32) + e];
+  const int co = e & 31, ci = (e >> 5) & 31, tau = e >> 10;
+  evf_atomic_add(dst + (co * C32 + ci) * 9 + tau, s);
+}
+
 extern "C" int evf_reduce_slabs(const float* partial, int nslab, int n, int accumulate, float* dst, void* stream) {
   if (!partial || !dst || nslab <= 0 || n != 9 * C32 * C32) return EVF_EINVAL;
-  hipLaunchKernelGGL(k_reduce_wgrad, dim3(evf_cdiv(n, 256)), dim3(256), 0, EVF_STREAM(stream), partial, nslab,
-                     accumulate, dst);
+  hipStream_t st = EVF_STREAM(stream);
+  if (!accumulate) {
+    int rc = evf_hip(hipMemsetAsync(dst, 0, sizeof(float) * n, st));
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_reduce_wgrad_par, dim3(evf_cdiv(n, 256), RS_GROUPS), dim3(256), 0, st, partial, nslab, dst);
   return evf_status();
 }
 
@@ -610,62 +626,76 @@ extern "C" int evf_pred_fwd(const uint32_t* x, const float* w, const float* bias
 }
 
 // g_x[pix][c] = sum_o gpre[o] * w[o][c];  dw[o][c] += sum_pix gpre[o]*z[pix][c];  dbias[o] += sum gpre[o]
-__global__ void k_pred_bwd(const uint32_t* __restrict__ x, const float* __restrict__ flow,
-                           const float* __restrict__ g_flow, const float* __restrict__ w, int B, int HW,
-                           float* __restrict__ g_x, float* __restrict__ dw, float* __restrict__ dbias) {
+// Grid-strided with few blocks: each block ends with 66 global atomics on the same 66 words.
+#define PB_BLOCKS 256
+__global__ __launch_bounds__(256) void k_pred_bwd(const uint32_t* __restrict__ x, const float* __restrict__ flow,
+                                                  const float* __restrict__ g_flow, const float* __restrict__ w,
+                                                  int B, int HW, float* __restrict__ g_x, float* __restrict__ dw,
+                                                  float* __restrict__ dbias) {
   __shared__ float s_w[2 * C32];
-  __shared__ float s_dw[2 * C32 + 2];
+  __shared__ float s_p[4][2 * C32 + 2];
   if (threadIdx.x < 2 * C32) s_w[threadIdx.x] = w[threadIdx.x];
-  if (threadIdx.x < 2 * C32 + 2) s_dw[threadIdx.x] = 0.f;
   __syncthreads();
-  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  float gp0 = 0.f, gp1 = 0.f;
-  uint32_t m = 0u;
-  if (p < (long)B * HW) {
-    const long b = p / HW, q = p % HW;
-    const float f0 = flow[(b * 2) * HW + q], f1 = flow[(b * 2 + 1) * HW + q];
-    gp0 = g_flow[(b * 2) * HW + q] * (1.0f - f0 * f0);  // tanh'
-    gp1 = g_flow[(b * 2 + 1) * HW + q] * (1.0f - f1 * f1);
-    m = x[p];
-    float4* o = (float4*)(g_x + p * C32);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float accw0 = 0.f, accw1 = 0.f, accb0 = 0.f, accb1 = 0.f;  // lane c (< 32) owns channel c of dw[0], dw[1]
+  const long npix = (long)B * HW;
+  for (long p0 = (long)blockIdx.x * 256 + wv * 64; p0 < npix; p0 += (long)gridDim.x * 256) {
+    const long p = p0 + lane;
+    float gp0 = 0.f, gp1 = 0.f;
+    uint32_t m = 0u;
+    if (p < npix) {
+      const long b = p / HW, q = p % HW;
+      const float f0 = flow[(b * 2) * HW + q], f1 = flow[(b * 2 + 1) * HW + q];
+      gp0 = g_flow[(b * 2) * HW + q] * (1.0f - f0 * f0);  // tanh'
+      gp1 = g_flow[(b * 2 + 1) * HW + q] * (1.0f - f1 * f1);
+      m = x[p];
+      float4* o = (float4*)(g_x + p * C32);
 #pragma unroll
-    for (int c4 = 0; c4 < 8; ++c4) {
-      float4 v;
-      v.x = gp0 * s_w[4 * c4] + gp1 * s_w[C32 + 4 * c4];
-      v.y = gp0 * s_w[4 * c4 + 1] + gp1 * s_w[C32 + 4 * c4 + 1];
-      v.z = gp0 * s_w[4 * c4 + 2] + gp1 * s_w[C32 + 4 * c4 + 2];
-      v.w = gp0 * s_w[4 * c4 + 3] + gp1 * s_w[C32 + 4 * c4 + 3];
-      o[c4] = v;
+      for (int c4 = 0; c4 < 8; ++c4) {
+        float4 v;
+        v.x = gp0 * s_w[4 * c4] + gp1 * s_w[C32 + 4 * c4];
+        v.y = gp0 * s_w[4 * c4 + 1] + gp1 * s_w[C32 + 4 * c4 + 1];
+        v.z = gp0 * s_w[4 * c4 + 2] + gp1 * s_w[C32 + 4 * c4 + 2];
+        v.w = gp0 * s_w[4 * c4 + 3] + gp1 * s_w[C32 + 4 * c4 + 3];
+        o[c4] = v;
+      }
     }
+    // channel c: sum of gp over the wave's pixels whose bit c is set; lane c keeps the result
+#pragma unroll 8
+    for (int c = 0; c < C32; ++c) {
+      const bool on = (m >> c) & 1u;
+      const float r0 = evf_wave_sum(on ? gp0 : 0.f), r1 = evf_wave_sum(on ? gp1 : 0.f);
+      if (lane == c) {
+        accw0 += r0;
+        accw1 += r1;
+      }
+    }
+    accb0 += gp0;
+    accb1 += gp1;
   }
-  // weight gradient: per channel, sum gp over the pixels whose bit c is set
-  const int lane = threadIdx.x & 63;
-#pragma unroll 4
-  for (int c = 0; c < C32; ++c) {
-    const bool on = (m >> c) & 1u;
-    float a = evf_wave_sum(on ? gp0 : 0.f), d = evf_wave_sum(on ? gp1 : 0.f);
-    if (lane == 0) {
-      atomicAdd(&s_dw[c], a);
-      atomicAdd(&s_dw[C32 + c], d);
-    }
+  accb0 = evf_wave_sum(accb0);
+  accb1 = evf_wave_sum(accb1);
+  if (lane < C32) {
+    s_p[wv][lane] = accw0;
+    s_p[wv][C32 + lane] = accw1;
   }
-  {
-    float a = evf_wave_sum(gp0), d = evf_wave_sum(gp1);
-    if (lane == 0) {
-      atomicAdd(&s_dw[2 * C32], a);
-      atomicAdd(&s_dw[2 * C32 + 1], d);
-    }
+  if (lane == 0) {
+    s_p[wv][2 * C32] = accb0;
+    s_p[wv][2 * C32 + 1] = accb1;
   }
   __syncthreads();
-  if (threadIdx.x < 2 * C32) evf_atomic_add(dw + threadIdx.x, s_dw[threadIdx.x]);
-  if (threadIdx.x < 2) evf_atomic_add(dbias + threadIdx.x, s_dw[2 * C32 + threadIdx.x]);
+  if (threadIdx.x < 2 * C32 + 2) {
+    const float v = (s_p[0][threadIdx.x] + s_p[1][threadIdx.x]) + (s_p[2][threadIdx.x] + s_p[3][threadIdx.x]);
+    evf_atomic_add(threadIdx.x < 2 * C32 ? dw + threadIdx.x : dbias + (threadIdx.x - 2 * C32), v);
+  }
 }
 
 extern "C" int evf_pred_bwd(const uint32_t* x, const float* flow, const float* g_flow, const float* w, int B, int H,
                             int W, float* g_x, float* dw, float* dbias, void* stream) {
   if (!x || !flow || !g_flow || !w || !g_x || !dw || !dbias || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
-  hipLaunchKernelGGL(k_pred_bwd, dim3(evf_cdiv((long)B * H * W, 256)), dim3(256), 0, EVF_STREAM(stream), x, flow, g_flow,
-                     w, B, H * W, g_x, dw, dbias);
+  const long nb = ((long)B * H * W + 255) / 256;
+  hipLaunchKernelGGL(k_pred_bwd, dim3((int)(nb < PB_BLOCKS ? nb : PB_BLOCKS)), dim3(256), 0, EVF_STREAM(stream), x, flow,
+                     g_flow, w, B, H * W, g_x, dw, dbias);
   return evf_status();
 }
 

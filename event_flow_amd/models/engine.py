@@ -44,6 +44,7 @@ class _Window:
         self.gz = [None] * n  # dL/d(output spikes) of the pass being processed
         self.gz_has = [False] * n
         self.g_cur = None
+        self.g_split = None  # [3,B,H,W,32] bf16: exact 3-way split of g_cur (bf16x3 path)
         self.small = torch.zeros(eng.small_size, dtype=torch.float32, device=dev)
         self.slab_init = {}
         self.token = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
@@ -217,6 +218,10 @@ class FireNetEngine:
                 if k not in self._packed:
                     self._packed[k] = torch.empty(54 * 1024, dtype=torch.uint8, device=dev)
                 _lib.call("evf_pack_conv_weight_b3", _lib.ptr(wd), C, C, _lib.ptr(self._packed[k]))
+                k = (i, nm, "b3t")
+                if k not in self._packed:
+                    self._packed[k] = torch.empty(54 * 1024, dtype=torch.uint8, device=dev)
+                _lib.call("evf_pack_conv_weight_b3t", _lib.ptr(wd), C, C, _lib.ptr(self._packed[k]))
         self._flat = {}
         for name, p in zip(self.pnames, self.params):
             self._flat[name] = p.detach().float().contiguous().view(-1)
@@ -300,6 +305,8 @@ class FireNetEngine:
             win.gz_has[n - 1] = True
         if win.g_cur is None:
             win.g_cur = _f32((B, H, W, C), dev)
+            if self.precision == "bf16x3":
+                win.g_split = torch.empty((3, B, H, W, C), dtype=torch.bfloat16, device=dev)
         for i in range(n - 1, -1, -1):
             c = self.cells[i]
             in_bits, v_prev, z_prev, v_out, _, in_bitsT, zT_prev = layers[i]
@@ -322,7 +329,7 @@ class FireNetEngine:
                 _lib.call("evf_lif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
                           _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None, _lib.ptr(self._flat[f"{i}.leak"]),
                           _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
-                          self._act_width(i), _lib.ptr(win.g_cur), _lib.ptr(gv_out), _lib.ptr(leak_g), _lib.ptr(thr_g),
+                          self._act_width(i), None, _lib.ptr(win.g_split), _lib.ptr(gv_out), _lib.ptr(leak_g), _lib.ptr(thr_g),
                           _lib.ptr(self._slab(kf, nsl, dev)), _lib.ptr(self._slab(kr, nsl, dev)) if use_rec else None, acc_flag)
                 win.slab_init[kf] = True
                 if use_rec:
@@ -353,7 +360,15 @@ class FireNetEngine:
             if i > 0:
                 ga = win.buf(win.gz, i - 1)
                 acc_a = 1 if win.gz_has[i - 1] else 0
-                if rec_grad:
+                if self.precision == "bf16x3":
+                    _lib.call("evf_conv_dgrad_b3", _lib.ptr(win.g_split), _lib.ptr(self._packed[(i, "ff", "b3t")]), _lib.ptr(ga),
+                              acc_a, B, H, W)
+                    if rec_grad:
+                        gb = win.buf(win.gz, i)
+                        _lib.call("evf_conv_dgrad_b3", _lib.ptr(win.g_split), _lib.ptr(self._packed[(i, "rec", "b3t")]),
+                                  _lib.ptr(gb), 0, B, H, W)
+                        win.gz_has[i] = True
+                elif rec_grad:
                     gb = win.buf(win.gz, i)
                     _lib.call("evf_conv_dgrad", _lib.ptr(win.g_cur), _lib.ptr(self._packed[(i, "ff", 1)]), _lib.ptr(ga), acc_a,
                               _lib.ptr(self._packed[(i, "rec", 1)]), _lib.ptr(gb), 0, B, H, W)

@@ -210,8 +210,16 @@ int evf_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const float* v
                       const uint32_t* xT, const uint32_t* zT_prev,
                       const float* leak, const float* thresh, int B, int H, int W,
                       int hard_reset, int surrogate, float act_width,
-                      float* g_cur, float* g_v_prev, float* g_leak, float* g_thresh,
+                      float* g_cur, void* g_split, float* g_v_prev, float* g_leak, float* g_thresh,
                       float* slab_ff, float* slab_rec, int accumulate, void* stream);
+
+/* Input-gradient conv on the exact bf16 split: g_split = three bf16 planes
+ * [3][B,H,W,32] (g = hi + mid + lo, optional output of evf_lif_bwd_wgrad; g_cur may then
+ * be NULL), wT_b3 = evf_pack_conv_weight_b3t(w) (54 KiB).  g_x [B,H,W,32] fp32 is written,
+ * or += when accumulate.  Six-term product, fp32 accumulation (fp32 round-off class). */
+int evf_pack_conv_weight_b3t(const float* w, int Cout, int Cin, void* dst, void* stream);
+int evf_conv_dgrad_b3(const void* g_split, const void* wT_b3, float* g_x, int accumulate,
+                      int B, int H, int W, void* stream);
 
 /* Input-gradient conv: g_x[pix][ci] (+)= sum_tap,co g_cur[pix-tap][co]*w[co][ci][tap]
  * with wT packed by evf_pack_conv_weight(transposed=1).  g_cur, g_x [B,H,W,32].

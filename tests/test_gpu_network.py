@@ -303,14 +303,27 @@ def test_fused_lif_bwd_wgrad_matches_separate_kernels(rec, shape):
         _lib.call("evf_reduce_slabs", slab.data_ptr(), ns0, 9216, 0, dw0[nm].data_ptr())
     # fused
     gc1, gp1 = torch.empty_like(gz), torch.empty_like(gz)
+    gs1 = torch.empty(3, B, H, W, C, dtype=torch.bfloat16, device=DEV)
     gl1, gt1 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     ns1 = lib.evf_lif_bwd_wgrad_slabs(B, H, W)
     s_ff, s_rec = torch.empty(ns1, 9216, device=DEV), torch.empty(ns1, 9216, device=DEV)
     for acc in (0, 1):  # second call accumulates: result must double
         _lib.call("evf_lif_bwd_wgrad", gz.data_ptr(), gv.data_ptr(), vo.data_ptr(), vp.data_ptr(), zbits.data_ptr(), xT.data_ptr(),
-                  zT.data_ptr() if rec else None, leak.data_ptr(), thresh.data_ptr(), B, H, W, 1, 0, 10.0, gc1.data_ptr(),
+                  zT.data_ptr() if rec else None, leak.data_ptr(), thresh.data_ptr(), B, H, W, 1, 0, 10.0, gc1.data_ptr(), gs1.data_ptr(),
                   gp1.data_ptr(), gl1.data_ptr(), gt1.data_ptr(), s_ff.data_ptr(), s_rec.data_ptr() if rec else None, acc)
     assert torch.equal(gc1, gc0) and torch.equal(gp1, gp0)  # elementwise part: identical arithmetic
+    # exact 3-way bf16 split of g_cur (error <= 2^-24 relative)
+    rec3 = gs1[0].float() + gs1[1].float() + gs1[2].float()
+    assert float((rec3 - gc0).abs().max()) <= 1.2e-7 * float(gc0.abs().max())
+    # input-gradient conv on the split vs the fp32-MFMA kernel
+    wt = (torch.rand(C, C, 3, 3, generator=g) * 2 - 1).mul(0.2).to(DEV)
+    p32, pb3 = torch.empty(9216, device=DEV), torch.empty(54 * 1024, dtype=torch.uint8, device=DEV)
+    _lib.call("evf_pack_conv_weight", wt.data_ptr(), C, C, 1, p32.data_ptr())
+    _lib.call("evf_pack_conv_weight_b3t", wt.data_ptr(), C, C, pb3.data_ptr())
+    gx0, gx1 = torch.empty_like(gz), torch.empty_like(gz)
+    _lib.call("evf_conv_dgrad", gc0.data_ptr(), p32.data_ptr(), gx0.data_ptr(), 0, None, None, 0, B, H, W)
+    _lib.call("evf_conv_dgrad_b3", gs1.data_ptr(), pb3.data_ptr(), gx1.data_ptr(), 0, B, H, W)
+    assert float((gx1 - gx0).abs().max()) <= 3e-6 * float(gx0.abs().max())
     np.testing.assert_allclose(N(gl1), 2 * N(gl0), rtol=2e-4, atol=1e-4)
     np.testing.assert_allclose(N(gt1), 2 * N(gt0), rtol=2e-4, atol=1e-4)
     for nm, slab in (("ff", s_ff),) + ((("rec", s_rec),) if rec else ()):
