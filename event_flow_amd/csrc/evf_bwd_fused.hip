@@ -26,10 +26,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define C32 32
-#define FB_CW 128
-#define FB_UNITS 4
+#define FB_CW 64    // pixels per unit (row segment): one float4 of every tensor per thread
+#define FB_UNITS 8
 #define FB_THREADS 512
 #define FB_NW (FB_CW / 32 + 2)  // plane words per (row, channel): segment + one halo word each side
+#define FB_R0 32768             // LDS region 0: operand double buffer (24 KiB), later the tap-8 reduction (32 KiB)
 
 __device__ __forceinline__ int fb_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 __device__ __forceinline__ float fb_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -41,7 +42,7 @@ __device__ __forceinline__ float fb_surrogate(int kind, float x, float width) {
   switch (kind) {  // models/spiking_util.py:38-43, 55-65, 74-79, 88-93
     case EVF_SUPERSPIKE: {
       const float d = 1.0f + width * fabsf(x);
-      return 1.0f / (d * d);
+      return __builtin_amdgcn_rcpf(d * d);
     }
     case EVF_TRIANGLE:
       return fmaxf(0.f, 1.0f - width * fabsf(x));
@@ -51,13 +52,14 @@ __device__ __forceinline__ float fb_surrogate(int kind, float x, float width) {
       return 1.15f * gs(x, 0.f, width) - 0.15f * gs(x, width, s2) - 0.15f * gs(x, -width, s2);
     }
     default:
-      return 1.0f / (1.0f + width * x * x);
+      return __builtin_amdgcn_rcpf(1.0f + width * x * x);  // v_rcp_f32 (1 ulp): the kernel is VALU bound
   }
 }
 
 struct FbStage {
   float4 gz, gv, vo, vp;
   uint32_t zw;
+  uint32_t px, pz, pin;  // one word of the x / z_prev bit planes (threads < 3*32*FB_NW) + in-image mask
 };
 
 template <bool REC>
@@ -70,14 +72,15 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     float* __restrict__ g_leak, float* __restrict__ g_thresh, float* __restrict__ slab_ff,
     float* __restrict__ slab_rec) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  unsigned short* s_b = (unsigned short*)smem_raw;                    // [2][3][FB_CW*32] bf16
-  uint32_t* s_px = (uint32_t*)(s_b + 2 * 3 * FB_CW * C32);            // [2][3][32][FB_NW]
-  uint32_t* s_pz = s_px + 2 * 3 * C32 * FB_NW;                        // same (REC)
-  uint4* s_lut = (uint4*)(s_pz + 2 * 3 * C32 * FB_NW);                // [256]
-  float* s_red = (float*)(s_lut + 256);                               // [2][8][32]
+  unsigned short* s_b = (unsigned short*)smem_raw;           // [2][3][FB_CW*32] bf16 (region of FB_R0 bytes)
+  uint32_t* s_px = (uint32_t*)(smem_raw + FB_R0);             // [2][3][32][FB_NW]
+  uint32_t* s_pz = s_px + 2 * 3 * C32 * FB_NW;                // same (REC)
+  uint4* s_lut = (uint4*)(s_pz + 2 * 3 * C32 * FB_NW);        // [256]
+  float* s_red = (float*)(s_lut + 256);                       // [2][8][32]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 31, kg = lane >> 5;
   const int cg = tid & 7;  // channel group of the elementwise part: channels 4cg..4cg+3
+  const int p = tid >> 3;  // pixel of the elementwise part within the 64-pixel unit
   const int nW = (W + 31) / 32;
 
   if (tid < 256) {
@@ -85,130 +88,141 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     auto pr = [&](int e) { return ((t >> e) & 1u) * 0x3F80u | (((t >> (e + 1)) & 1u) * 0x3F80u) << 16; };
     s_lut[tid] = make_uint4(pr(0), pr(2), pr(4), pr(6));
   }
-  float lam[4], th[4];
+  float lam[4], th[4], oml[4], inv_oml[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     lam[k] = fb_sigmoid(leak[4 * cg + k]);
     th[k] = fmaxf(thresh[4 * cg + k], 0.01f);
+    oml[k] = 1.0f - lam[k];
+    inv_oml[k] = 1.0f / oml[k];  // per-channel constant: no division in the element loop
   }
   float sl[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
 
-  auto geom = [&](long u, int& b, int& y, int& x0, int& cw) {
-    const long row = u / nchunk;
-    b = (int)(row / H);
-    y = (int)(row % H);
-    x0 = (int)(u % nchunk) * FB_CW;
+  // Units are dealt round-robin: block x takes units x, x + gridDim.x, ...  At any moment the
+  // resident blocks then stream one contiguous region (consecutive 8 KiB units), which spreads
+  // over all HBM channels; a contiguous chunk per block would make every block hit the same
+  // few channels at the same time (64 KiB stride between blocks).
+  const int nblk = gridDim.x;
+  const int nu = (int)((nunits - (long)blockIdx.x + nblk - 1) / nblk);
+  auto geom = [&](int k, int& b, int& y, int& x0, int& cw) {
+    const int u = blockIdx.x + k * nblk;  // nunits < 2^31
+    const int row = u / nchunk;
+    b = row / H;
+    y = row - b * H;
+    x0 = (u - row * nchunk) * FB_CW;
     cw = min(FB_CW, W - x0);
   };
-  FbStage stg[2];
-  auto issue_loads = [&](long u) {
+  // stage 1: issue the global loads of unit k (one float4 of each tensor per thread).
+  // Straight-line code on purpose: every load is unconditional (indices clamped into valid
+  // memory, optional tensors redirected to v_out and zeroed by a select afterwards), so the
+  // compiler can keep them in flight behind counted s_waitcnt instead of draining vmcnt(0)
+  // at every divergent branch.
+  const float4* pgz = g_z_out ? g_z_out : v_out;
+  const float4* pgv = g_v_out ? g_v_out : v_out;
+  const float4* pvp = v_prev ? v_prev : v_out;
+  const uint32_t* pzw = z_prev ? z_prev : xT;
+  const uint32_t* pzt = REC ? zT : xT;
+  const bool has_gz = g_z_out != nullptr, has_gv = g_v_out != nullptr, has_vp = v_prev != nullptr,
+             has_zw = z_prev != nullptr;
+  const int tpl = min(tid, 3 * C32 * FB_NW - 1);
+  const int pl_wq = tpl % FB_NW, pl_c = (tpl / FB_NW) % C32, pl_dy = tpl / (FB_NW * C32);
+  auto issue_loads = [&](int k, FbStage& s) {
     int b, y, x0, cw;
-    geom(u, b, y, x0, cw);
+    geom(min(k, nu - 1), b, y, x0, cw);
     const long pix0 = ((long)b * H + y) * W + x0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int e = tid + k * FB_THREADS, p = e >> 3;
-      const long ge = pix0 * 8 + e;
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      const bool ok = p < cw;
-      stg[k].vo = ok ? v_out[ge] : z4;
-      stg[k].gz = (ok && g_z_out) ? g_z_out[ge] : z4;
-      stg[k].gv = (ok && g_v_out) ? g_v_out[ge] : z4;
-      stg[k].vp = (ok && v_prev) ? v_prev[ge] : z4;
-      stg[k].zw = (ok && z_prev) ? z_prev[pix0 + p] : 0u;
-    }
+    const int pc = min(p, cw - 1);
+    const long ge = (pix0 + pc) * 8 + cg;
+    s.vo = v_out[ge];
+    s.gz = pgz[ge];
+    s.gv = pgv[ge];
+    s.vp = pvp[ge];
+    s.zw = pzw[z_prev ? pix0 + pc : 0];
+    const int yy = y + pl_dy - 1, xw = x0 / 32 - 1 + pl_wq;
+    const bool in = yy >= 0 && yy < H && xw >= 0 && xw < nW;
+    const long src = in ? (((long)b * H + yy) * C32 + pl_c) * nW + xw : 0;
+    s.px = xT[src];
+    s.pz = pzt[src];
+    s.pin = in ? 0xFFFFFFFFu : 0u;
   };
-  auto commit = [&](long u, int buf) {
+  // stage 2: neuron backward in registers, results to HBM, split g_cur + spike planes to LDS
+  auto commit = [&](int k, const FbStage& s, int buf) {
     int b, y, x0, cw;
-    geom(u, b, y, x0, cw);
+    geom(min(k, nu - 1), b, y, x0, cw);
     const long pix0 = ((long)b * H + y) * W + x0;
     unsigned short* sb = s_b + buf * (3 * FB_CW * C32);
+    const bool ok = p < cw && k < nu;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 gz4 = has_gz ? s.gz : z4, gv4 = has_gv ? s.gv : z4, vp4 = has_vp ? s.vp : z4;
+    const float vo[4] = {s.vo.x, s.vo.y, s.vo.z, s.vo.w}, gz[4] = {gz4.x, gz4.y, gz4.z, gz4.w};
+    const float gvo[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, vp[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
+    const uint32_t zw = (has_zw ? s.zw : 0u) >> (4 * cg);
+    float gc[4], gp[4];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int e = tid + k * FB_THREADS, p = e >> 3;
-      const bool ok = p < cw;
-      const float vo[4] = {stg[k].vo.x, stg[k].vo.y, stg[k].vo.z, stg[k].vo.w};
-      const float gz[4] = {stg[k].gz.x, stg[k].gz.y, stg[k].gz.z, stg[k].gz.w};
-      const float gvo[4] = {stg[k].gv.x, stg[k].gv.y, stg[k].gv.z, stg[k].gv.w};
-      const float vp[4] = {stg[k].vp.x, stg[k].vp.y, stg[k].vp.z, stg[k].vp.w};
-      const uint32_t zw = stg[k].zw >> (4 * cg);
-      float gc[4], gp[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        // autograd of spiking_submodules.py:103-126 / :523-551 (see evf_lif_bwd)
-        const float z = (float)((zw >> c) & 1u);
-        const float sg = fb_surrogate(surrogate, vo[c] - th[c], width);
-        const float gsp = gz[c] * sg;
-        const float gv = gvo[c] + gsp;
-        gc[c] = gv * (1.0f - lam[c]);
-        float cur, dlam;
-        if (hard_reset) {
-          gp[c] = gv * lam[c] * (1.0f - z);
-          cur = (vo[c] - (vp[c] * lam[c]) * (1.0f - z)) / (1.0f - lam[c]);
-          dlam = vp[c] * (1.0f - z) - cur;
-        } else {
-          gp[c] = gv * lam[c];
-          cur = (vo[c] - vp[c] * lam[c] + z * th[c]) / (1.0f - lam[c]);
-          dlam = vp[c] - cur;
-          st[c] -= gv * z;
-        }
-        if (ok) {
-          sl[c] += gv * dlam;
-          st[c] -= gsp;
-        }
+    for (int c = 0; c < 4; ++c) {
+      // autograd of spiking_submodules.py:103-126 / :523-551 (see evf_lif_bwd)
+      const float z = (float)((zw >> c) & 1u);
+      const float sg = fb_surrogate(surrogate, vo[c] - th[c], width);
+      const float gsp = gz[c] * sg;
+      const float gv = gvo[c] + gsp;
+      gc[c] = gv * oml[c];
+      float cur, dlam;
+      if (hard_reset) {
+        gp[c] = gv * lam[c] * (1.0f - z);
+        cur = (vo[c] - (vp[c] * lam[c]) * (1.0f - z)) * inv_oml[c];
+        dlam = vp[c] * (1.0f - z) - cur;
+      } else {
+        gp[c] = gv * lam[c];
+        cur = (vo[c] - vp[c] * lam[c] + z * th[c]) * inv_oml[c];
+        dlam = vp[c] - cur;
+        if (ok) st[c] -= gv * z;
       }
       if (ok) {
-        if (g_cur) g_cur[pix0 * 8 + e] = make_float4(gc[0], gc[1], gc[2], gc[3]);
-        g_v_prev[pix0 * 8 + e] = make_float4(gp[0], gp[1], gp[2], gp[3]);
-      }
-      uint32_t tb[3][4];
-      // exact split g = hi + mid + lo (bf16 each), stored in B-operand order:
-      // pixel p = 16*kq + 8*kgp + ee, element ((kq*2 + kgp)*32 + j)*8 + ee
-      const int base = ((p >> 3) * C32) * 8 + (p & 7);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float g0 = ok ? gc[c] : 0.f;
-        const uint32_t hi = fb_bf16(g0);
-        const float r1 = g0 - __uint_as_float(hi << 16);
-        const uint32_t mid = fb_bf16(r1);
-        const float r2 = r1 - __uint_as_float(mid << 16);
-        const uint32_t lo = fb_bf16(r2);
-        const int o = base + (4 * cg + c) * 8;
-        sb[o] = (unsigned short)hi;
-        sb[FB_CW * C32 + o] = (unsigned short)mid;
-        sb[2 * FB_CW * C32 + o] = (unsigned short)lo;
-        tb[0][c] = hi, tb[1][c] = mid, tb[2][c] = lo;
-      }
-      if (ok && g_split) {  // the same split as three bf16 planes [term][pix][32] for evf_conv_dgrad_b3
-        const long ps = (long)B * H * W * 8;
-#pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3)
-          g_split[t3 * ps + pix0 * 8 + e] = make_uint2(tb[t3][0] | (tb[t3][1] << 16), tb[t3][2] | (tb[t3][3] << 16));
+        sl[c] += gv * dlam;
+        st[c] -= gsp;
       }
     }
-    // spike bit planes of the three rows around y, incl. one halo word each side
-    for (int q = tid; q < 3 * C32 * FB_NW; q += FB_THREADS) {
-      const int wq = q % FB_NW, c = (q / FB_NW) % C32, dy = q / (FB_NW * C32);
-      const int yy = y + dy - 1, xw = x0 / 32 - 1 + wq;
-      const bool in = yy >= 0 && yy < H && xw >= 0 && xw < nW;
-      const long src = (((long)b * H + yy) * C32 + c) * nW + xw;
-      s_px[buf * (3 * C32 * FB_NW) + q] = in ? xT[src] : 0u;
-      if (REC) s_pz[buf * (3 * C32 * FB_NW) + q] = in ? zT[src] : 0u;
+    if (ok && !(accumulate & 64)) {
+      if (g_cur) g_cur[pix0 * 8 + tid] = make_float4(gc[0], gc[1], gc[2], gc[3]);
+      g_v_prev[pix0 * 8 + tid] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+    }
+    // exact split g = hi + mid + lo (bf16 each), stored in B-operand order:
+    // pixel p = 16*kq + 8*kgp + ee, element ((kq*2 + kgp)*32 + j)*8 + ee
+    uint32_t tb[3][4];
+    const int base = ((p >> 3) * C32) * 8 + (p & 7);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float g0 = ok ? gc[c] : 0.f;
+      const uint32_t hi = fb_bf16(g0);
+      const float r1 = g0 - __uint_as_float(hi << 16);
+      const uint32_t mid = fb_bf16(r1);
+      const float r2 = r1 - __uint_as_float(mid << 16);
+      const uint32_t lo = fb_bf16(r2);
+      const int o = base + (4 * cg + c) * 8;
+      if (!(accumulate & 32)) {
+      sb[o] = (unsigned short)hi;
+      sb[FB_CW * C32 + o] = (unsigned short)mid;
+      sb[2 * FB_CW * C32 + o] = (unsigned short)lo;
+      }
+      tb[0][c] = hi, tb[1][c] = mid, tb[2][c] = lo;
+    }
+    if (ok && g_split && !(accumulate & 64)) {  // the same split as three bf16 planes [term][pix][32] for evf_conv_dgrad_b3
+      const long ps = (long)B * H * W * 8;
+#pragma unroll
+      for (int t3 = 0; t3 < 3; ++t3)
+        g_split[t3 * ps + pix0 * 8 + tid] = make_uint2(tb[t3][0] | (tb[t3][1] << 16), tb[t3][2] | (tb[t3][3] << 16));
+    }
+    if (tid < 3 * C32 * FB_NW) {
+      s_px[buf * (3 * C32 * FB_NW) + tid] = s.px & s.pin;
+      if (REC) s_pz[buf * (3 * C32 * FB_NW) + tid] = s.pz & s.pin;
     }
   };
 
   f32x16 acc = {0}, acc8 = {0}, accz = {0}, accz8 = {0};
   const int dy = wv / 3, dx = wv % 3;  // taps 0..7; tap 8 = (2, 2) is shared
-  const long u0 = (long)blockIdx.x * FB_UNITS;
-  const int nu = (int)min((long)FB_UNITS, nunits - u0);
-  if (nu > 0) {
-    issue_loads(u0);
-    commit(u0, 0);
-  }
-  __syncthreads();
-  for (int k = 0; k < nu; ++k) {
+  // stage 3: matrix cores on the staged unit
+  auto mfma_unit = [&](int k) {
+    if (accumulate & 16) return;
     const int buf = k & 1;
-    if (k + 1 < nu) issue_loads(u0 + k + 1);  // in flight during the MFMAs below
     const uint4* sbh = (const uint4*)(s_b + buf * (3 * FB_CW * C32));
     const uint32_t* px = s_px + buf * (3 * C32 * FB_NW);
     const uint32_t* pz = s_pz + buf * (3 * C32 * FB_NW);
@@ -219,7 +233,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
       const uint4 a = s_lut[byte];
       return *(const bf16x8*)&a;
     };
-#pragma unroll 2
+#pragma unroll
     for (int kq = 0; kq < FB_CW / 16; ++kq) {
       const int fo = (kq * 2 + kg) * C32 + i;  // uint4 index of this lane's 8 pixels of channel i (= co)
       const uint4 uh = sbh[fo], um = sbh[FB_CW * C32 / 8 + fo], ul = sbh[2 * FB_CW * C32 / 8 + fo];
@@ -234,7 +248,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
         accz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(az, bm, accz, 0, 0, 0);
         accz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(az, bl, accz, 0, 0, 0);
       }
-      if (kq == wv) {  // this wave's share of the ninth tap
+      if (kq + (FB_CW / 16) * (k & 1) == wv) {  // this wave's share of the ninth tap
         const bf16x8 a8 = afrag(px, 2, 2, kq);
         acc8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, bh, acc8, 0, 0, 0);
         acc8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, bm, acc8, 0, 0, 0);
@@ -247,8 +261,22 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
         }
       }
     }
-    if (k + 1 < nu) commit(u0 + k + 1, buf ^ 1);
+  };
+
+  // software pipeline with two units of loads always in flight (register stages rotate by moves):
+  //   iteration k: loads(k+2) -> registers | MFMA(k) from LDS[k&1] | commit(k+1) -> LDS[(k+1)&1]
+  FbStage s_cur, s_nxt, s_new;
+  issue_loads(0, s_cur);
+  issue_loads(1, s_nxt);
+  commit(0, s_cur, 0);
+  __syncthreads();
+#pragma unroll 1
+  for (int k = 0; k < nu; ++k) {
+    issue_loads(k + 2, s_new);
+    mfma_unit(k);
+    commit(k + 1, s_nxt, (k + 1) & 1);
     __syncthreads();
+    s_nxt = s_new;
   }
 
   // ---- weight-gradient slabs: taps 0..7 straight from the owning wave
@@ -257,11 +285,13 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       float* p = d + fb_row(q, lane) * C32 + i;
-      *p = accumulate ? *p + a[q] : a[q];
+      *p = (accumulate & 1) ? *p + a[q] : a[q];
     }
   };
+  if (!(accumulate & 256)) {
   store_tile(acc, slab_ff);
   if (REC) store_tile(accz, slab_rec);
+  }
   // ---- tap 8: sum the 8 partial tiles through LDS (aliases the operand buffers)
   float* s_t8 = (float*)smem_raw;  // [8][1024]
   auto reduce_t8 = [&](const f32x16& a, float* slab) {
@@ -273,12 +303,14 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
 #pragma unroll
       for (int w = 0; w < 8; ++w) v += s_t8[w * (C32 * C32) + e];
       float* p = slab + (long)blockIdx.x * (9 * C32 * C32) + 8 * (C32 * C32) + e;
-      *p = accumulate ? *p + v : v;
+      *p = (accumulate & 1) ? *p + v : v;
     }
     __syncthreads();
   };
+  if (!(accumulate & 256)) {
   reduce_t8(acc8, slab_ff);
   if (REC) reduce_t8(accz8, slab_rec);
+  }
 
   // ---- per-channel sums for leak / thresh: lanes with equal (lane & 7) share channels
 #pragma unroll
@@ -296,7 +328,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     }
   }
   __syncthreads();
-  if (tid < 64) {
+  if (tid < 64 && !(accumulate & 128)) {
     const int which = tid >> 5, c = tid & 31;
     float v = 0.f;
     for (int w = 0; w < 8; ++w) v += s_red[(which * 8 + w) * C32 + c];
@@ -310,7 +342,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
 }
 
 static long fb_units(int B, int H, int W) { return (long)B * H * ((W + FB_CW - 1) / FB_CW); }
-#define FB_LDS (2 * 3 * FB_CW * C32 * 2 + 2 * (2 * 3 * C32 * FB_NW * 4) + 256 * 16 + 2 * 8 * C32 * 4)
+#define FB_LDS (FB_R0 + 2 * (2 * 3 * C32 * FB_NW * 4) + 256 * 16 + 2 * 8 * C32 * 4)
 
 extern "C" int evf_lif_bwd_wgrad_slabs(int B, int H, int W) { return evf_cdiv(fb_units(B, H, W), FB_UNITS); }
 
@@ -334,7 +366,7 @@ extern "C" int evf_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, con
     }
     hipLaunchKernelGGL(k_lif_bwd_wgrad<true>, grid, block, FB_LDS, st, (const float4*)g_z_out, (const float4*)g_v_out,
                        (const float4*)v_out, (const float4*)v_prev, z_prev, xT, zT_prev, leak, thresh, B, H, W, nchunk,
-                       nunits, hard_reset, surrogate, act_width, accumulate ? 1 : 0, (float4*)g_cur, (uint2*)g_split,
+                       nunits, hard_reset, surrogate, act_width, accumulate, (float4*)g_cur, (uint2*)g_split,
                        (float4*)g_v_prev, g_leak, g_thresh, slab_ff, slab_rec);
   } else {
     if (!a1) {
@@ -343,7 +375,7 @@ extern "C" int evf_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, con
     }
     hipLaunchKernelGGL(k_lif_bwd_wgrad<false>, grid, block, FB_LDS, st, (const float4*)g_z_out, (const float4*)g_v_out,
                        (const float4*)v_out, (const float4*)v_prev, z_prev, xT, (const uint32_t*)nullptr, leak, thresh, B,
-                       H, W, nchunk, nunits, hard_reset, surrogate, act_width, accumulate ? 1 : 0, (float4*)g_cur,
+                       H, W, nchunk, nunits, hard_reset, surrogate, act_width, accumulate, (float4*)g_cur,
                        (uint2*)g_split, (float4*)g_v_prev, g_leak, g_thresh, slab_ff, (float*)nullptr);
   }
   return evf_status();

@@ -67,31 +67,49 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3(const uint4* __r
   if (y >= H) return;
   const int i = lane & 31, kg = lane >> 5;
   f32x16 acc = {0};
-  const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+  const long rowpix = ((long)b * H) * W;
 #pragma unroll 1
-  for (int tau = 0; tau < 9; ++tau) {
-    const int yy = y + tau / 3 - 1, xx = x0 + i + tau % 3 - 1;
-    const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-    // uint4 index of (pixel, 8-channel group): pixel*4 + group, group = 2m + kg
-    const long pg = in ? ((((long)b * H + yy) * W + xx) * 4 + kg) : 0;
-    uint4 a[2][3];
+  for (int dy = 0; dy < 3; ++dy) {
+    const int yy = y + dy - 1;
+    const bool yin = yy >= 0 && yy < H;
+    // all 18 fragment loads of this input row (3 taps x 2 channel halves x 3 terms) are issued
+    // before the first MFMA: the memory latency is paid once per row, not per tap
+    uint4 a[3][2][3];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int dx = 0; dx < 3; ++dx) {
+      const int xx = x0 + i + dx - 1;
+      const bool in = yin && xx >= 0 && xx < W;
+      // unconditional loads from a clamped address + a mask afterwards: a load inside a
+      // divergent branch makes the compiler drain vmcnt(0) after each one
+      const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+      const long pg = (rowpix + (long)yc * W + xc) * 4 + kg;
+      const uint32_t msk = in ? 0xFFFFFFFFu : 0u;
 #pragma unroll
-      for (int s = 0; s < 3; ++s) a[m][s] = in ? gs[s * plane_stride + pg + 2 * m] : z4;
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const uint4* wf = s_w + ((tau * 2 + m) * 3) * 64 + lane;
-      const uint4 w0 = wf[0], w1 = wf[64], w2 = wf[128];
-      const bf16x8 wh = *(const bf16x8*)&w0, wm = *(const bf16x8*)&w1, wl = *(const bf16x8*)&w2;
-      const bf16x8 ah = *(const bf16x8*)&a[m][0], am = *(const bf16x8*)&a[m][1], al = *(const bf16x8*)&a[m][2];
-      // smallest terms first
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+        for (int s = 0; s < 3; ++s) {
+          uint4 v = gs[s * plane_stride + pg + 2 * m];
+          v.x &= msk, v.y &= msk, v.z &= msk, v.w &= msk;
+          a[dx][m][s] = v;
+        }
+    }
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int tau = dy * 3 + dx;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const uint4* wf = s_w + ((tau * 2 + m) * 3) * 64 + lane;
+        const uint4 w0 = wf[0], w1 = wf[64], w2 = wf[128];
+        const bf16x8 wh = *(const bf16x8*)&w0, wm = *(const bf16x8*)&w1, wl = *(const bf16x8*)&w2;
+        const bf16x8 ah = *(const bf16x8*)&a[dx][m][0], am = *(const bf16x8*)&a[dx][m][1], al = *(const bf16x8*)&a[dx][m][2];
+        // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+      }
     }
   }
 #pragma unroll

@@ -101,8 +101,11 @@ __global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restr
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = y0 + r0 + m, col = x0 + b3_row(r, lane);
-      vp[m][r] = (v_prev && row < H && col < W) ? v_prev[(((long)b * H + row) * W + col) * C32 + j] : 0.f;
+      // unconditional (clamped) load: loads inside divergent branches get a vmcnt(0) each
+      const int row = min(y0 + r0 + m, H - 1), col = min(x0 + b3_row(r, lane), W - 1);
+      const float* src = v_prev ? v_prev : v_out;
+      const float val = src[(((long)b * H + row) * W + col) * C32 + j];
+      vp[m][r] = v_prev ? val : 0.f;
     }
   __syncthreads();
 

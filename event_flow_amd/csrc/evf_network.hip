@@ -300,7 +300,7 @@ __device__ __forceinline__ float evf_surrogate(int kind, float x, float width) {
   switch (kind) {
     case EVF_SUPERSPIKE: {
       const float d = 1.0f + width * fabsf(x);
-      return 1.0f / (d * d);
+      return __builtin_amdgcn_rcpf(d * d);
     }
     case EVF_TRIANGLE:
       return fmaxf(0.f, 1.0f - width * fabsf(x));
@@ -311,7 +311,7 @@ __device__ __forceinline__ float evf_surrogate(int kind, float x, float width) {
       return 1.15f * gs(x, 0.f, s1) - 0.15f * gs(x, width, s2) - 0.15f * gs(x, -width, s2);
     }
     default:
-      return 1.0f / (1.0f + width * x * x);
+      return __builtin_amdgcn_rcpf(1.0f + width * x * x);  // v_rcp_f32 (1 ulp): the kernel is VALU bound
   }
 }
 
@@ -324,12 +324,13 @@ __global__ void k_lif_bwd(const float4* __restrict__ g_z_out, const float4* __re
   __shared__ float s_red[2][4][C32];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int cg = tid & 7;  // channel group: channels 4cg..4cg+3
-  float lam[4], th[4], thraw[4];
+  float lam[4], th[4], oml[4], inv_oml[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     lam[k] = evf_sigmoid(leak[4 * cg + k]);
-    thraw[k] = thresh[4 * cg + k];
-    th[k] = fmaxf(thraw[k], 0.01f);
+    th[k] = fmaxf(thresh[4 * cg + k], 0.01f);
+    oml[k] = 1.0f - lam[k];
+    inv_oml[k] = 1.0f / oml[k];  // per-channel constant: no division in the element loop
   }
   float sl[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
   for (long e = (long)blockIdx.x * blockDim.x + tid; e < npix * 8; e += (long)gridDim.x * blockDim.x) {
@@ -348,15 +349,15 @@ __global__ void k_lif_bwd(const float4* __restrict__ g_z_out, const float4* __re
       const float sg = evf_surrogate(surrogate, vo[k] - th[k], width);
       const float gsp = gz[k] * sg;          // through the spike: d z'/d(v'-th)
       const float gv = gvo[k] + gsp;         // total gradient on v'
-      gc[k] = gv * (1.0f - lam[k]);          // -> input current (ff + rec)
+      gc[k] = gv * oml[k];                   // -> input current (ff + rec)
       float cur, dlam;
       if (hard_reset) {
         gp[k] = gv * lam[k] * (1.0f - z);    // z detached (:539-540)
-        cur = (vo[k] - (vp[k] * lam[k]) * (1.0f - z)) / (1.0f - lam[k]);
+        cur = (vo[k] - (vp[k] * lam[k]) * (1.0f - z)) * inv_oml[k];
         dlam = vp[k] * (1.0f - z) - cur;
       } else {
         gp[k] = gv * lam[k];
-        cur = (vo[k] - vp[k] * lam[k] + z * th[k]) / (1.0f - lam[k]);
+        cur = (vo[k] - vp[k] * lam[k] + z * th[k]) * inv_oml[k];
         dlam = vp[k] - cur;
         st[k] -= gv * z;                      // - z * thresh term
       }
