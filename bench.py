@@ -91,16 +91,18 @@ def iwe_warp_bandwidth(dev, B, reps=20):
     flow = torch.from_numpy(g.uniform(-0.1, 0.1, size=(B, 2, H, W)).astype(np.float32)).to(dev)
     ev = torch.from_numpy(ev).to(dev)
     pol = torch.stack([(ev[:, :, 3] > 0).float(), (ev[:, :, 3] < 0).float()], 2).contiguous()
+    from event_flow_amd import _lib
+
     for _ in range(3):
         compute_pol_iwe(flow, ev, (H, W), pol[:, :, 0:1], pol[:, :, 1:2], flow_scaling=128, round_idx=True)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    e0.record()
+    # kernel duration from HIP events recorded around the launch on its stream (the call is one
+    # kernel; a host-paced loop would measure Python overhead at the small shape)
+    _lib.profile_start(["evf_iwe_splat"])
     for _ in range(reps):
         compute_pol_iwe(flow, ev, (H, W), pol[:, :, 0:1], pol[:, :, 1:2], flow_scaling=128, round_idx=True)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    times = _lib.profile_stop()[("evf_iwe_splat", "")]
+    ms = float(np.median(times))
     alg_bytes = B * (n * 28 + 2 * H * W * 4)  # 16 B event + 8 B flow gather + 4 B atomic dst, + final image
     return {"B": B, "events": n, "ms_per_call": ms, "algorithmic_MB": alg_bytes / 1e6, "GBps": alg_bytes / ms / 1e6,
             "frac_of_hbm_peak": alg_bytes / ms / 1e6 / HBM_PEAK}

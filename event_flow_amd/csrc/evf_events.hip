@@ -178,6 +178,102 @@ __global__ void k_iwe_splat(const float* __restrict__ flow, const float4* __rest
   evf_splat<ROUND>(evf_warp(t, q.y, q.z, fy, fx, tref, S), H, W, a0, a1, tau, I0, I1, T0, T1);
 }
 
+// LDS-privatised variant: one block owns a stripe of `rows` image rows of ONE sample (all
+// nch channels) in LDS, scans every event of that sample, keeps the taps that land in its
+// stripe with LDS atomics and finally writes the stripe with coalesced float4 stores.
+// Device-scope fp32 atomics on global memory top out near 21 G atomics/s on MI355X (they
+// are resolved at the memory side of the 8 non-coherent L2s); LDS atomics scale with the
+// CUs.  Same arithmetic as k_iwe_splat (integer histograms stay bit-exact).
+template <bool ROUND>
+__global__ __launch_bounds__(1024) void k_iwe_splat_lds(const float* __restrict__ flow, const float4* __restrict__ ev,
+                                                        const int32_t* __restrict__ map_of_event,
+                                                        const int32_t* __restrict__ ts_shift,
+                                                        const float* __restrict__ w0, const float* __restrict__ w1,
+                                                        int wstride, int B, int M, int H, int W, float S, float tref,
+                                                        float tref_ts, int mode, int nch, int rows,
+                                                        float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* img = (float*)smem_raw;  // [nch][rows][W]
+  const int b = blockIdx.y, r0 = blockIdx.x * rows;
+  const int nr = min(rows, H - r0);
+  const int plane = rows * W;
+  for (int q = threadIdx.x; q < nch * plane; q += blockDim.x) img[q] = 0.f;
+  __syncthreads();
+  const long HW = (long)H * W;
+  const float lo = (float)r0, hi = (float)(r0 + nr);
+  auto put = [&](int ch, float cy, float cx, float v) {
+    if (v != 0.f && cy >= lo && cy < hi) atomicAdd(&img[ch * plane + ((int)cy - r0) * W + (int)cx], v);
+  };
+  // events in batches of IW_U per thread: all event loads first, then all flow gathers (which
+  // depend on them), then the splats -- the two dependent memory latencies are paid once per batch
+#define IW_U 4
+  for (int e0 = threadIdx.x; e0 < M; e0 += IW_U * blockDim.x) {
+    float4 qs[IW_U];
+    float a0s[IW_U], a1s[IW_U], ts[IW_U], fys[IW_U], fxs[IW_U];
+    int maps[IW_U];
+#pragma unroll
+    for (int u = 0; u < IW_U; ++u) {
+      const int e = min(e0 + u * (int)blockDim.x, M - 1);  // clamped: loads stay unconditional
+      const long i = (long)b * M + e;
+      qs[u] = ev[i];
+      ts[u] = ts_shift ? (float)ts_shift[e] : 0.f;
+      maps[u] = map_of_event ? map_of_event[e] : 0;
+      a0s[u] = w0 ? w0[i * wstride] : 1.0f;
+      a1s[u] = w1 ? w1[i * wstride] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < IW_U; ++u) evf_event_flow(flow, maps[u], B, b, HW, qs[u].y, qs[u].z, W, fys[u], fxs[u]);
+#pragma unroll
+    for (int u = 0; u < IW_U; ++u) {
+    if (e0 + u * (int)blockDim.x >= M) continue;
+    const float4 q = qs[u];
+    const float t = q.x + ts[u];
+    float fy = fys[u], fx = fxs[u];
+    const float a0 = a0s[u], a1 = a1s[u];
+    if (mode & 2) {
+      fy *= 0.f;
+      fx *= 0.f;
+    }
+    const float tau = (mode & 8) ? (tref_ts - t) : t;
+    const Warp w = evf_warp(t, q.y, q.z, fy, fx, tref, S);
+    if (ROUND) {
+      const float iy = rintf(w.wy), ix = rintf(w.wx);
+      if (iy < 0.f || iy >= (float)H || ix < 0.f || ix >= (float)W) continue;
+      put(0, iy, ix, a0);
+      if (nch >= 2) put(1, iy, ix, a1);
+      if (nch == 4) {
+        put(2, iy, ix, tau * a0);
+        put(3, iy, ix, tau * a1);
+      }
+    } else {
+      const float cy[2] = {floorf(w.wy), floorf(w.wy + 1.0f)};
+      const float cx[2] = {floorf(w.wx), floorf(w.wx + 1.0f)};
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          if (cy[j] < 0.f || cy[j] >= (float)H || cx[k] < 0.f || cx[k] >= (float)W) continue;
+          const float wt = fmaxf(0.f, 1.0f - fabsf(w.wy - cy[j])) * fmaxf(0.f, 1.0f - fabsf(w.wx - cx[k]));
+          if (wt == 0.f) continue;
+          put(0, cy[j], cx[k], wt * a0);
+          if (nch >= 2) put(1, cy[j], cx[k], wt * a1);
+          if (nch == 4) {
+            const float wtau = wt * tau;
+            put(2, cy[j], cx[k], wtau * a0);
+            put(3, cy[j], cx[k], wtau * a1);
+          }
+        }
+    }
+    }
+  }
+#undef IW_U
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    float* dst = out + ((long)b * nch + ch) * HW + (long)r0 * W;
+    for (int q = threadIdx.x; q < nr * W; q += blockDim.x) dst[q] = img[ch * plane + q];
+  }
+}
+
 extern "C" int evf_iwe_splat(const float* flow, const float* ev, const int32_t* map_of_event, const int32_t* ts_shift,
                              const float* w0, const float* w1, int wstride, int B, int M, int H, int W,
                              float flow_scaling, float tref, float tref_ts, int mode, int nch, float* out, void* stream) {
@@ -185,8 +281,38 @@ extern "C" int evf_iwe_splat(const float* flow, const float* ev, const int32_t* 
   if (nch == 4 && !(mode & 4)) return EVF_EINVAL;
   if (M > 0 && !ev) return EVF_EINVAL;
   hipStream_t st = EVF_STREAM(stream);
+  if (M == 0) return evf_hip(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * nch * H * W, st));
+  // stripe height: as tall as 128 KiB of LDS allows, shrunk (down to 8 rows) until the grid has
+  // >= 256 blocks; every block re-reads the sample's events (L2 resident), so shorter stripes
+  // trade redundant event reads for parallelism
+  const int max_rows = (128 * 1024) / (nch * W * 4);
+  // small problems (a few 100k events) are latency bound: the plain global-atomic kernel (3 us at
+  // B=8 x 15k) wins there; the LDS version wins once the device-scope atomics saturate
+  if (max_rows >= 1 && (long)B * M >= 400000) {
+    int rows = max_rows < H ? max_rows : H;
+    while (rows > 8 && (long)B * evf_cdiv(H, rows) < 256) rows = (rows + 1) / 2;
+    const size_t lds = (size_t)nch * rows * W * 4;
+    static bool attr[2] = {false, false};
+    const int r = (mode & 1) ? 1 : 0;
+    if (!attr[r]) {
+      if (r)
+        (void)hipFuncSetAttribute((const void*)k_iwe_splat_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      else
+        (void)hipFuncSetAttribute((const void*)k_iwe_splat_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      attr[r] = true;
+    }
+    dim3 grid(evf_cdiv(H, rows), B), block(1024);
+    if (r)
+      hipLaunchKernelGGL(k_iwe_splat_lds<true>, grid, block, lds, st, flow, (const float4*)ev, map_of_event, ts_shift, w0, w1,
+                         wstride, B, M, H, W, flow_scaling, tref, tref_ts, mode, nch, rows, out);
+    else
+      hipLaunchKernelGGL(k_iwe_splat_lds<false>, grid, block, lds, st, flow, (const float4*)ev, map_of_event, ts_shift, w0,
+                         w1, wstride, B, M, H, W, flow_scaling, tref, tref_ts, mode, nch, rows, out);
+    return evf_status();
+  }
+  // very wide images: global-atomic fallback kernel
   int rc = evf_hip(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * nch * H * W, st));
-  if (rc || M == 0) return rc;
+  if (rc) return rc;
   dim3 grid(evf_cdiv((long)B * M, 256)), block(256);
   if (mode & 1)
     hipLaunchKernelGGL(k_iwe_splat<true>, grid, block, 0, st, flow, (const float4*)ev, map_of_event, ts_shift, w0, w1,
