@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-iwe", action="store_true")
+    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
+                    help="matrix-core path of the 32->32 convs: exact bf16x3 split (default) or fp32 MFMA")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -190,6 +192,7 @@ def main():
 
     torch.manual_seed(0)  # identical replicas on every rank
     model = LIFFireNet(dict(MODEL_CFG)).to(dev)
+    model.precision = args.precision
     model.train()
     lossf = EventWarping(LOSS_CFG, dev)
     use_graph = not args.no_graph
@@ -261,24 +264,48 @@ def main():
     elapsed = dp.max_over_ranks(elapsed)
     loss_val = float(loss)
 
+    model_precision = model.precision
     if dp.rank == 0:
         npix = B_PER_GPU * H * W
-        flop = {("evf_conv_lif_fwd", "ff"): CONV_FLOP * npix, ("evf_conv_lif_fwd", "rec"): 2 * CONV_FLOP * npix,
-                ("evf_conv_dgrad", "one"): CONV_FLOP * npix, ("evf_conv_dgrad", "two"): 2 * CONV_FLOP * npix,
-                ("evf_conv_wgrad_bits", ""): CONV_FLOP * npix,
-                ("evf_conv_lif_fwd_b3", "ff"): CONV_FLOP * npix, ("evf_conv_lif_fwd_b3", "rec"): 2 * CONV_FLOP * npix,
-                ("evf_conv_dgrad_b3", ""): CONV_FLOP * npix,
-                ("evf_lif_bwd_wgrad", "ff"): CONV_FLOP * npix, ("evf_lif_bwd_wgrad", "rec"): 2 * CONV_FLOP * npix}
+        # algorithmic work per launch: FLOP of the 3x3 32->32 contraction(s) and
+        # compulsory HBM bytes (fp32 tensors 128 B/px, split-bf16 planes 192 B/px, spike words 4 B/px)
+        model = {
+            ("evf_conv_lif_fwd", "ff"): (CONV_FLOP * npix, 268 * npix), ("evf_conv_lif_fwd", "rec"): (2 * CONV_FLOP * npix, 268 * npix),
+            ("evf_conv_lif_fwd_b3", "ff"): (CONV_FLOP * npix, 272 * npix), ("evf_conv_lif_fwd_b3", "rec"): (2 * CONV_FLOP * npix, 272 * npix),
+            ("evf_conv_dgrad", "one"): (CONV_FLOP * npix, 256 * npix), ("evf_conv_dgrad", "two"): (2 * CONV_FLOP * npix, 384 * npix),
+            ("evf_conv_dgrad_b3", ""): (CONV_FLOP * npix, 320 * npix),
+            ("evf_conv_wgrad_bits", ""): (CONV_FLOP * npix, 132 * npix),
+            ("evf_lif_bwd_wgrad", "ff"): (CONV_FLOP * npix, 840 * npix), ("evf_lif_bwd_wgrad", "rec"): (2 * CONV_FLOP * npix, 844 * npix),
+            ("evf_lif_bwd", ""): (0, 772 * npix), ("evf_head_lif_fwd", ""): (2 * 18 * 32 * npix, 272 * npix),
+        }
+        # which roofline bounds the kernel: the fp32-MFMA convs are matrix-core bound; the bf16x3 kernels
+        # need 1/5 of those cycles and are HBM bound, like the elementwise ones
+        hbm_bound = {"evf_conv_lif_fwd_b3", "evf_conv_dgrad_b3", "evf_lif_bwd_wgrad", "evf_lif_bwd", "evf_head_lif_fwd"}
         kernels = {}
         for key, ms in prof.items():
             ms = np.array(ms)
+            name = "/".join(k for k in key if k)
             ent = {"launches": int(ms.size), "mean_us": float(ms.mean() * 1e3), "total_ms_per_step": float(ms.sum() / prof_steps)}
-            if key in flop:
-                ent["TFLOPs"] = flop[key] / (ms.mean() * 1e-3) / 1e12
-                ent["frac_of_fp32_mfma_peak"] = ent["TFLOPs"] / FP32_MFMA_PEAK
-            kernels["/".join(k for k in key if k)] = ent
-        dom_key = max((k for k in prof if k in flop), key=lambda k: sum(prof[k]))
+            if key in model:
+                fl, by = model[key]
+                ent["algorithmic_MB"] = by / 1e6
+                ent["GBps"] = by / (ms.mean() * 1e-3) / 1e9
+                ent["frac_of_hbm_peak"] = ent["GBps"] / HBM_PEAK
+                if fl:
+                    ent["TFLOPs"] = fl / (ms.mean() * 1e-3) / 1e12
+                    ent["frac_of_fp32_mfma_peak"] = ent["TFLOPs"] / FP32_MFMA_PEAK
+                ent["bound"] = "hbm" if key[0] in hbm_bound else "mfma"
+            kernels[name] = ent
+        dom_key = max((k for k in prof if k in model), key=lambda k: sum(prof[k]))
         dom = kernels["/".join(k for k in dom_key if k)]
+        if dom["bound"] == "hbm":
+            roof = {"kernel": "/".join(k for k in dom_key if k), "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK,
+                    "unit": "GB/s", "frac": dom["frac_of_hbm_peak"], "traffic": None,
+                    "note": "bf16x3 kernel (exact 3-way bf16 split, fp32 accumulate): matrix work is 1/5 of the fp32-MFMA form, "
+                            "so the kernel sits on the HBM roofline; algorithmic bytes per launch in kernels[*].algorithmic_MB"}
+        else:
+            roof = {"kernel": "/".join(k for k in dom_key if k), "bound": "mfma", "achieved": dom["TFLOPs"], "peak": FP32_MFMA_PEAK,
+                    "unit": "TFLOP/s", "frac": dom["TFLOPs"] / FP32_MFMA_PEAK, "traffic": None}
         out = {
             "metric": "event-windows/sec (train step, 128x128x15k ev)", "value": B_PER_GPU * dp.world * args.steps / elapsed,
             "unit": "event-windows/s", "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
@@ -288,9 +315,10 @@ def main():
                                    "128x128, CM loss, clip+Adam), 8 windows per GPU [BASELINE configs[2] per-GPU shard; "
                                    "superset of configs[1]]",
                        "global_batch": B_PER_GPU * dp.world, "events_per_window": PASSES * EV_PER_PASS,
-                       "parallelism": f"dp{dp.world}", "launch": mode, "loss": loss_val},
-            "roofline": {"kernel": "/".join(k for k in dom_key if k), "bound": "mfma", "achieved": dom["TFLOPs"],
-                         "peak": FP32_MFMA_PEAK, "unit": "TFLOP/s", "frac": dom["TFLOPs"] / FP32_MFMA_PEAK, "traffic": None},
+                       "parallelism": f"dp{dp.world}", "launch": mode, "loss": loss_val,
+                       "conv_precision": ("fp32 results via exact 3-way bf16 splits of the fp32 operands on the bf16 matrix cores, "
+                                          "fp32 accumulation" if model_precision == "bf16x3" else "fp32 MFMA (v_mfma_f32_32x32x2_f32)")},
+            "roofline": roof,
             "kernels": kernels,
         }
         if not args.no_iwe:

@@ -262,3 +262,22 @@ def test_aee_golden():
     a, p = m()
     np.testing.assert_allclose(N(a), g["aee_val"], rtol=1e-5)
     np.testing.assert_allclose(N(p), g["aee_outl"], rtol=1e-5)
+
+
+def test_pol_iwe_large_batch_lds_path_bit_exact():
+    """B*N >= 400k events selects the LDS-privatised splat kernel: same integer histogram,
+    in both rounding modes, with and without polarity weights, on a non-square sensor."""
+    B, n, H, W = 30, 15000, 96, 160
+    ev = synthetic.event_list_batch(B, n, H, W, 9000)
+    rng = np.random.default_rng(4)
+    flow = rng.uniform(-0.15, 0.15, size=(B, 2, H, W)).astype(np.float32)
+    pol = np.stack([(ev[:, :, 3] > 0), (ev[:, :, 3] < 0)], 2).astype(np.float32)
+    gpol = G(pol)
+    got = N(hiwe.compute_pol_iwe(G(flow), G(ev), (H, W), gpol[:, :, 0:1], gpol[:, :, 1:2], flow_scaling=128, round_idx=True))
+    ref = oiwe.compute_pol_iwe(flow, ev, (H, W), pol[:, :, 0:1], pol[:, :, 1:2], flow_scaling=128, round_idx=True)
+    assert np.array_equal(got, ref)
+    got = N(hiwe.compute_pol_iwe(G(flow), G(ev), (H, W), gpol[:, :, 0:1], gpol[:, :, 1:2], flow_scaling=128, round_idx=False))
+    ref = oiwe.compute_pol_iwe(flow, ev, (H, W), pol[:, :, 0:1], pol[:, :, 1:2], flow_scaling=128, round_idx=False)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+    one = N(hiwe.deblur_events(G(flow), G(ev), (H, W), flow_scaling=128, round_idx=True))
+    assert np.array_equal(one[:, 0], got.shape and (oiwe.deblur_events(flow, ev, (H, W), 128, True))[:, 0])
