@@ -57,7 +57,9 @@ extern "C" int evf_pack_conv_weight_b3t(const float* w, int Cout, int Cin, void*
 
 __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3(const uint4* __restrict__ gs, long plane_stride,
                                                                 const uint4* __restrict__ wt, float* __restrict__ gx,
-                                                                int accumulate, int B, int H, int W) {
+                                                                int accumulate, int B, int H, int W,
+                                                                const float* __restrict__ gP,
+                                                                const uint32_t* __restrict__ xbits) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint4* s_w = (uint4*)smem_raw;  // NFRAG*64
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -116,18 +118,33 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3(const uint4* __r
   for (int r = 0; r < 16; ++r) {
     const int col = x0 + dg_row(r, lane);
     if (col < W) {
+      float v = acc[r];
+      if (gP) {
+        // PLIF: the pooled pre-synaptic trace also depends on the input spikes:
+        // d mean_c|x| / dx_c = sign(x_c)/32, AvgPool3x3^T = the same box filter / 9
+        float box = 0.f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = y + dy, xx = col + dx;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) box += gP[((long)b * H + yy) * W + xx];
+          }
+        if ((xbits[((long)b * H + y) * W + col] >> i) & 1u) v += (box / 9.0f) / 32.0f;
+      }
       float* d = gx + (((long)b * H + y) * W + col) * C32 + i;
-      *d = accumulate ? *d + acc[r] : acc[r];
+      *d = accumulate ? *d + v : v;
     }
   }
 }
 
 extern "C" int evf_conv_dgrad_b3(const void* g_split, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W,
-                                 void* stream) {
-  if (!g_split || !wT_b3 || !g_x || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+                                 const float* g_P, const uint32_t* x_bits, void* stream) {
+  if (!g_split || !wT_b3 || !g_x || B <= 0 || H <= 0 || W <= 0 || ((g_P != nullptr) != (x_bits != nullptr)))
+    return EVF_EINVAL;
   dim3 grid(evf_cdiv(W, 32), evf_cdiv(H, DG_ROWS), B), block(DG_ROWS * 64);
   const long plane_stride = (long)B * H * W * 4;  // uint4 per term plane: npix * 32 bf16 / 8
   hipLaunchKernelGGL(k_conv_dgrad_b3, grid, block, NFRAG * 1024, EVF_STREAM(stream), (const uint4*)g_split, plane_stride,
-                     (const uint4*)wT_b3, g_x, accumulate, B, H, W);
+                     (const uint4*)wT_b3, g_x, accumulate, B, H, W, g_P, x_bits);
   return evf_status();
 }

@@ -62,7 +62,19 @@ extern "C" int evf_pack_conv_weight_b3(const float* w, int Cout, int Cin, void* 
   return evf_status();
 }
 
-template <bool REC>
+// PLIF (spiking_submodules.py:191-227, :618-657): a per-channel pre-synaptic trace
+//   pt' = pt*sigma(leak_pt) + (1 - sigma(leak_pt)) * AvgPool3x3(mean_c |input|)
+// is subtracted from the current, cur = ff (+ rec) - sigma(add_pt) * pt'.  For binary inputs
+// mean_c|x| = popcount(word)/32, pooled here from the spike-word halo already in LDS.
+struct PlifArgs {
+  const float* leak_pt;
+  const float* add_pt;
+  const float* pt_prev;  // [B,H,W,32] or NULL
+  float* pt_out;         // [B,H,W,32]
+  float* P_out;          // [B,H,W] pooled pre-synaptic activity (saved for the backward)
+};
+
+template <bool REC, bool PLIF>
 __global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restrict__ x, const uint4* __restrict__ wff,
                                                          const uint4* __restrict__ wrec,
                                                          const float* __restrict__ leak,
@@ -71,12 +83,13 @@ __global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restr
                                                          const uint32_t* __restrict__ z_prev, int B, int H, int W,
                                                          int hard_reset, float* __restrict__ v_out,
                                                          uint32_t* __restrict__ z_out,
-                                                         uint32_t* __restrict__ zT_out) {
+                                                         uint32_t* __restrict__ zT_out, PlifArgs pl) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint4* s_w = (uint4*)smem_raw;    // NFRAG*64
   uint4* s_lut = s_w + NFRAG * 64;  // 256
   uint32_t* s_x = (uint32_t*)(s_lut + 256);
   uint32_t* s_z = s_x + HALO_H * HALO_W;
+  float* s_P = (float*)(s_z + HALO_H * HALO_W);  // TH*TW (PLIF)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
 
@@ -107,7 +120,31 @@ __global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restr
       const float val = src[(((long)b * H + row) * W + col) * C32 + j];
       vp[m][r] = v_prev ? val : 0.f;
     }
+  float ptp[PLIF ? 2 : 1][PLIF ? 16 : 1];
+  if (PLIF) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = min(y0 + r0 + m, H - 1), col = min(x0 + b3_row(r, lane), W - 1);
+        const float* src = pl.pt_prev ? pl.pt_prev : v_out;
+        const float val = src[(((long)b * H + row) * W + col) * C32 + j];
+        ptp[m][r] = pl.pt_prev ? val : 0.f;
+      }
+  }
   __syncthreads();
+  if (PLIF) {  // pooled pre-synaptic activity of the tile's 256 pixels (one per thread)
+    const int py = tid >> 5, px = tid & 31;
+    int cnt = 0;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) cnt += __popc(s_x[(py + dy) * HALO_W + px + dx]);
+    const float P = ((float)cnt / 32.0f) / 9.0f;  // sum of the 9 means (exact), then AvgPool's division
+    s_P[tid] = P;
+    if (y0 + py < H && x0 + px < W) pl.P_out[((long)b * H + y0 + py) * W + x0 + px] = P;
+    __syncthreads();
+  }
 
   f32x16 acc0 = {0}, acc1 = {0};
   auto conv_phase = [&](const uint32_t* __restrict__ sb) {
@@ -140,6 +177,7 @@ __global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restr
 
   const float lam = b3_sigmoid(leak[j]);     // torch.sigmoid(self.leak)     spiking_submodules.py:111/:536
   const float th = fmaxf(thresh[j], 0.01f);  // self.thresh.clamp_min(0.01)  :108/:533
+  const float lpt = PLIF ? b3_sigmoid(pl.leak_pt[j]) : 0.f, apt = PLIF ? b3_sigmoid(pl.add_pt[j]) : 0.f;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     const f32x16& acc = m ? acc1 : acc0;
@@ -153,7 +191,13 @@ __global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restr
       bool spike = false;
       if (ok) {
         const float z = (float)((s_z[(r0 + m + 1) * HALO_W + cl + 1] >> j) & 1u);
-        const float v = vp[m][r], cur = acc[r];
+        const float v = vp[m][r];
+        float cur = acc[r];
+        if (PLIF) {
+          const float pto = ptp[m][r] * lpt + (1.0f - lpt) * s_P[(r0 + m) * TW + cl];  // :212 / :642
+          pl.pt_out[pix * C32 + j] = pto;
+          cur = cur - apt * pto;  // (ff + rec) - add_pt * pt_out, :220 / :650
+        }
         float vo;
         if (hard_reset)
           vo = (v * lam) * (1.0f - z) + (1.0f - lam) * cur;  // :119/:544
@@ -173,18 +217,43 @@ __global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restr
   }
 }
 
+static int launch_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec, const float* leak,
+                         const float* thresh, const float* v_prev, const uint32_t* z_prev, int B, int H, int W,
+                         int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out, const PlifArgs* plif,
+                         void* stream) {
+  dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(256);
+  hipStream_t st = EVF_STREAM(stream);
+  const size_t lds = WB3_BYTES + 256 * 16 + 2 * HALO_H * HALO_W * 4 + TH * TW * 4;
+  PlifArgs pa = plif ? *plif : PlifArgs{nullptr, nullptr, nullptr, nullptr, nullptr};
+#define EVF_FWD(REC_, PLIF_)                                                                                           \
+  hipLaunchKernelGGL((k_conv_lif_fwd_b3<REC_, PLIF_>), grid, block, lds, st, x, (const uint4*)wb_ff,                   \
+                     (const uint4*)wb_rec, leak, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out, pa)
+  if (plif) {
+    if (wb_rec) EVF_FWD(true, true); else EVF_FWD(false, true);
+  } else {
+    if (wb_rec) EVF_FWD(true, false); else EVF_FWD(false, false);
+  }
+#undef EVF_FWD
+  return evf_status();
+}
+
 extern "C" int evf_conv_lif_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec, const float* leak,
                                    const float* thresh, const float* v_prev, const uint32_t* z_prev, int B, int H,
                                    int W, int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out, void* stream) {
   if (!x || !wb_ff || !leak || !thresh || !v_out || !z_out || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
-  dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(256);
-  hipStream_t st = EVF_STREAM(stream);
-  const size_t lds = WB3_BYTES + 256 * 16 + 2 * HALO_H * HALO_W * 4;
-  if (wb_rec)
-    hipLaunchKernelGGL(k_conv_lif_fwd_b3<true>, grid, block, lds, st, x, (const uint4*)wb_ff, (const uint4*)wb_rec, leak,
-                       thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out);
-  else
-    hipLaunchKernelGGL(k_conv_lif_fwd_b3<false>, grid, block, lds, st, x, (const uint4*)wb_ff, (const uint4*)nullptr,
-                       leak, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out);
-  return evf_status();
+  return launch_fwd_b3(x, wb_ff, wb_rec, leak, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out, nullptr,
+                       stream);
+}
+
+extern "C" int evf_conv_plif_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec, const float* leak_v,
+                                    const float* leak_pt, const float* add_pt, const float* thresh, const float* v_prev,
+                                    const uint32_t* z_prev, const float* pt_prev, int B, int H, int W, int hard_reset,
+                                    float* v_out, uint32_t* z_out, uint32_t* zT_out, float* pt_out, float* P_out,
+                                    void* stream) {
+  if (!x || !wb_ff || !leak_v || !leak_pt || !add_pt || !thresh || !v_out || !z_out || !pt_out || !P_out || B <= 0 ||
+      H <= 0 || W <= 0)
+    return EVF_EINVAL;
+  PlifArgs pa{leak_pt, add_pt, pt_prev, pt_out, P_out};
+  return launch_fwd_b3(x, wb_ff, wb_rec, leak_v, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out, &pa,
+                       stream);
 }

@@ -244,9 +244,14 @@ __global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ 
                                                       const float* __restrict__ v_prev,
                                                       const uint32_t* __restrict__ z_prev, int B, int Cin, int H, int W,
                                                       int hard_reset, float* __restrict__ v_out,
-                                                      uint32_t* __restrict__ z_out, uint32_t* __restrict__ zT_out) {
+                                                      uint32_t* __restrict__ z_out, uint32_t* __restrict__ zT_out,
+                                                      const float* __restrict__ leak_pt,
+                                                      const float* __restrict__ add_pt,
+                                                      const float* __restrict__ pt_prev, float* __restrict__ pt_out,
+                                                      float* __restrict__ P_out) {
   __shared__ float s_x[HEAD_MAX_CIN][HALO_H * HALO_W];
   __shared__ float s_w[9 * (HEAD_MAX_CIN / 2) * 64];
+  __shared__ float s_P[TH * TW];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
   const int S2 = (Cin + 1) / 2;
@@ -276,6 +281,36 @@ __global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ 
   const int j = lane & 31;
   const float lam = evf_sigmoid(leak[j]);
   const float th = fmaxf(thresh[j], 0.01f);
+  if (pt_out) {  // PLIF head (spiking_submodules.py:191-227): cur = ff - sigma(add_pt) * pt'
+    const int py = tid >> 5, px = tid & 31;
+    float sum9 = 0.f;
+    for (int dy = 0; dy < 3; ++dy)
+      for (int dx = 0; dx < 3; ++dx) {
+        float a = 0.f;
+        for (int ci = 0; ci < Cin; ++ci) a += fabsf(s_x[ci][(py + dy) * HALO_W + px + dx]);
+        sum9 += a / (float)Cin;  // input_.abs().mean(1)
+      }
+    const float P = sum9 / 9.0f;  // AvgPool2d(3, 1, 1), count_include_pad
+    s_P[tid] = P;
+    if (y0 + py < H && x0 + px < W) P_out[((long)b * H + y0 + py) * W + x0 + px] = P;
+    __syncthreads();
+    const float lpt = evf_sigmoid(leak_pt[j]), apt = evf_sigmoid(add_pt[j]);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      f32x16& acc = m ? acc1 : acc0;
+      const int row = y0 + r0 + m;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cl = mfma_row(r, lane), col = x0 + cl;
+        if (row < H && col < W) {
+          const long e = (((long)b * H + row) * W + col) * C32 + j;
+          const float pto = (pt_prev ? pt_prev[e] : 0.f) * lpt + (1.0f - lpt) * s_P[(r0 + m) * TW + cl];
+          pt_out[e] = pto;
+          acc[r] = acc[r] - apt * pto;
+        }
+      }
+    }
+  }
   auto zword = [&](int row, int col) -> uint32_t { return z_prev ? z_prev[((long)b * H + row) * W + col] : 0u; };
   lif_epilogue(acc0, b, y0 + r0, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out, zT_out);
   lif_epilogue(acc1, b, y0 + r0 + 1, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out, zT_out);
@@ -288,7 +323,110 @@ extern "C" int evf_head_lif_fwd(const float* x, const float* w, const float* lea
     return EVF_EINVAL;
   dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(256);
   hipLaunchKernelGGL(k_head_lif_fwd, grid, block, 0, EVF_STREAM(stream), x, w, leak, thresh, v_prev, z_prev, B, Cin, H, W,
-                     hard_reset, v_out, z_out, zT_out);
+                     hard_reset, v_out, z_out, zT_out, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (float*)nullptr, (float*)nullptr);
+  return evf_status();
+}
+
+extern "C" int evf_head_plif_fwd(const float* x, const float* w, const float* leak_v, const float* leak_pt,
+                                 const float* add_pt, const float* thresh, const float* v_prev, const uint32_t* z_prev,
+                                 const float* pt_prev, int B, int Cin, int H, int W, int hard_reset, float* v_out,
+                                 uint32_t* z_out, uint32_t* zT_out, float* pt_out, float* P_out, void* stream) {
+  if (!x || !w || !leak_v || !leak_pt || !add_pt || !thresh || !v_out || !z_out || !pt_out || !P_out || B <= 0 ||
+      Cin <= 0 || Cin > HEAD_MAX_CIN || H <= 0 || W <= 0)
+    return EVF_EINVAL;
+  dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(256);
+  hipLaunchKernelGGL(k_head_lif_fwd, grid, block, 0, EVF_STREAM(stream), x, w, leak_v, thresh, v_prev, z_prev, B, Cin, H,
+                     W, hard_reset, v_out, z_out, zT_out, leak_pt, add_pt, pt_prev, pt_out, P_out);
+  return evf_status();
+}
+
+// --------------------------------------------------------------------------
+// PLIF trace backward (elementwise).  With g_cur = dL/d(current) from the neuron backward:
+//   g_pt  = g_pt_carry - sigma(add_pt) * g_cur           (pt' enters the current with -add_pt)
+//   g_pt_prev = g_pt * sigma(leak_pt)                    -> carry to the previous pass
+//   g_P[pix]  = sum_c g_pt[c] * (1 - sigma(leak_pt[c]))  -> gradient on the pooled activity
+//   d add_pt  = ap(1-ap) * sum(-g_cur * pt'),  d leak_pt = lp(1-lp) * sum(g_pt * (pt - P))
+// autograd of spiking_submodules.py:204-222 / :634-652.
+// --------------------------------------------------------------------------
+__global__ void k_plif_trace_bwd(const float4* __restrict__ g_cur, const float4* __restrict__ g_pt_carry,
+                                 const float4* __restrict__ pt_prev, const float4* __restrict__ pt_out,
+                                 const float* __restrict__ P, const float* __restrict__ leak_pt,
+                                 const float* __restrict__ add_pt, long npix, float4* __restrict__ g_pt_prev,
+                                 float* __restrict__ g_P, float* __restrict__ g_leak_pt,
+                                 float* __restrict__ g_add_pt) {
+  __shared__ float s_red[2][4][C32];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, cg = tid & 7;
+  float lp[4], ap[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    lp[k] = evf_sigmoid(leak_pt[4 * cg + k]);
+    ap[k] = evf_sigmoid(add_pt[4 * cg + k]);
+  }
+  float sl[4] = {0, 0, 0, 0}, sa[4] = {0, 0, 0, 0};
+  for (long e0 = (long)blockIdx.x * blockDim.x; e0 < npix * 8; e0 += (long)gridDim.x * blockDim.x) {
+    const long e = e0 + tid;
+    const bool ok = e < npix * 8;
+    const long ec = ok ? e : npix * 8 - 1, pix = ec >> 3;
+    const float4 gc4 = g_cur[ec], po4 = pt_out[ec];
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 gk4 = g_pt_carry ? g_pt_carry[ec] : z4, pp4 = pt_prev ? pt_prev[ec] : z4;
+    const float Pv = P[pix];
+    const float gc[4] = {gc4.x, gc4.y, gc4.z, gc4.w}, po[4] = {po4.x, po4.y, po4.z, po4.w};
+    const float gk[4] = {gk4.x, gk4.y, gk4.z, gk4.w}, pp[4] = {pp4.x, pp4.y, pp4.z, pp4.w};
+    float gp[4], gPp = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float g = gk[k] - ap[k] * gc[k];
+      gp[k] = g * lp[k];
+      gPp += g * (1.0f - lp[k]);
+      if (ok) {
+        sl[k] += g * (pp[k] - Pv);
+        sa[k] -= gc[k] * po[k];
+      }
+    }
+    if (ok) g_pt_prev[e] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+    // the 8 threads of a pixel hold its 32 channels
+    gPp += __shfl_xor(gPp, 1, 64);
+    gPp += __shfl_xor(gPp, 2, 64);
+    gPp += __shfl_xor(gPp, 4, 64);
+    if (ok && cg == 0) g_P[pix] = gPp;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      sl[k] += __shfl_xor(sl[k], o, 64);
+      sa[k] += __shfl_xor(sa[k], o, 64);
+    }
+  if (lane < 8) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s_red[0][wv][4 * lane + k] = sl[k];
+      s_red[1][wv][4 * lane + k] = sa[k];
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int which = tid >> 5, c = tid & 31;
+    float v = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += s_red[which][w][c];
+    const float sgm = evf_sigmoid(which == 0 ? leak_pt[c] : add_pt[c]);
+    evf_atomic_add((which == 0 ? g_leak_pt : g_add_pt) + c, v * sgm * (1.0f - sgm));
+  }
+}
+
+extern "C" int evf_plif_trace_bwd(const float* g_cur, const float* g_pt_carry, const float* pt_prev, const float* pt_out,
+                                  const float* P, const float* leak_pt, const float* add_pt, int B, int H, int W,
+                                  float* g_pt_prev, float* g_P, float* g_leak_pt, float* g_add_pt, void* stream) {
+  if (!g_cur || !pt_out || !P || !leak_pt || !add_pt || !g_pt_prev || !g_P || !g_leak_pt || !g_add_pt || B <= 0 ||
+      H <= 0 || W <= 0)
+    return EVF_EINVAL;
+  const long npix = (long)B * H * W;
+  const int nblk = (int)((npix * 8 + 255) / 256 < 512 ? (npix * 8 + 255) / 256 : 512);
+  hipLaunchKernelGGL(k_plif_trace_bwd, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)g_cur,
+                     (const float4*)g_pt_carry, (const float4*)pt_prev, (const float4*)pt_out, P, leak_pt, add_pt, npix,
+                     (float4*)g_pt_prev, g_P, g_leak_pt, g_add_pt);
   return evf_status();
 }
 

@@ -45,6 +45,9 @@ class _Window:
         self.gz_has = [False] * n
         self.g_cur = None
         self.g_split = None  # [3,B,H,W,32] bf16: exact 3-way split of g_cur (bf16x3 path)
+        self.gpt = [None] * n  # PLIF: dL/d(trace) carried to the previous pass
+        self.gpt_has = [False] * n
+        self.gP = None  # PLIF: dL/d(pooled pre-synaptic activity) of the layer being processed [B,H,W]
         self.small = torch.zeros(eng.small_size, dtype=torch.float32, device=dev)
         self.slab_init = {}
         self.token = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
@@ -88,12 +91,15 @@ class FireNetEngine:
         self.cells = cells  # list of 7 spiking cell modules
         self.pred = pred
         self.num_bins = num_bins
+        self.kind = cells[0].kind
         for i, c in enumerate(cells):
-            if c.kind != "lif":
+            if c.kind not in ("lif", "plif") or c.kind != self.kind:
                 raise NotImplementedError(
-                    f"{type(c).__name__}: only LIF cells are accelerated so far (PLIF/ALIF/XLIF are a later row of "
+                    f"{type(c).__name__}: LIF and PLIF cells are accelerated so far (ALIF/XLIF are a later row of "
                     "SURVEY.md section 8); there is no CPU fallback"
                 )
+            if c.kind == "plif" and precision != "bf16x3":
+                raise NotImplementedError("PLIF cells are implemented on the bf16x3 path only")
             if c.hidden_size != C or c.kernel_size != 3 or c.stride != 1 or (i > 0 and c.input_size != C):
                 raise NotImplementedError("accelerated FireNet kernels need base_num_channels=32, kernel_size=3")
             if i == 0 and c.recurrent:
@@ -106,7 +112,12 @@ class FireNetEngine:
             self._reg(f"{i}.ff", c.ff.weight)
             if c.recurrent:
                 self._reg(f"{i}.rec", c.rec.weight)
-            self._reg(f"{i}.leak", c.leak)
+            if c.kind == "plif":
+                self._reg(f"{i}.leak", c.leak_v)
+                self._reg(f"{i}.leak_pt", c.leak_pt)
+                self._reg(f"{i}.add_pt", c.add_pt)
+            else:
+                self._reg(f"{i}.leak", c.leak)
             self._reg(f"{i}.thresh", c.thresh)
         self._reg("pred.w", pred.conv2d.weight)
         self._reg("pred.b", pred.conv2d.bias)
@@ -179,7 +190,12 @@ class FireNetEngine:
             vv, zz = _f32((B, C, H, W), v.device), _f32((B, C, H, W), v.device)
             _lib.call("evf_nhwc_to_nchw", _lib.ptr(v), B, C, H, W, _lib.ptr(vv))
             _lib.call("evf_bits_to_nchw", _lib.ptr(z), B, H, W, _lib.ptr(zz))
-            out.append(torch.stack([vv, zz]))
+            parts = [vv, zz]
+            if len(st) > 3:  # PLIF trace
+                pp = _f32((B, C, H, W), v.device)
+                _lib.call("evf_nhwc_to_nchw", _lib.ptr(st[3]), B, C, H, W, _lib.ptr(pp))
+                parts.append(pp)
+            out.append(torch.stack(parts))
         return out
 
     def set_states(self, states):
@@ -195,7 +211,13 @@ class FireNetEngine:
             _lib.call("evf_nchw_to_bits", _lib.ptr(zz), B, H, W, _lib.ptr(z))
             zT = _i32((B, H, C, (W + 31) // 32), vv.device)
             _lib.call("evf_bits_transpose", _lib.ptr(z), B, H, W, _lib.ptr(zT))
-            new.append((v, z, zT))
+            if self.kind == "plif":
+                pp = st[2].detach().float().contiguous()
+                pt = _f32((B, H, W, C), vv.device)
+                _lib.call("evf_nchw_to_nhwc", _lib.ptr(pp), B, C, H, W, _lib.ptr(pt))
+                new.append((v, z, zT, pt))
+            else:
+                new.append((v, z, zT))
         self._states = new
         self._win = None
 
@@ -254,13 +276,29 @@ class FireNetEngine:
         in_bits = in_bitsT = None
         for i, c in enumerate(self.cells):
             st = states[i]
-            v_prev, z_prev, zT_prev = st if st is not None else (None, None, None)
+            v_prev, z_prev, zT_prev = st[:3] if st is not None else (None, None, None)
+            plif = self.kind == "plif"
+            pt_prev = st[3] if (plif and st is not None) else None
+            pt_out = _f32((B, H, W, C), dev) if plif else None
+            P_out = _f32((B, H, W), dev) if plif else None
             if v_prev is not None and tuple(v_prev.shape) != (B, H, W, C):
                 raise _lib.EvflowError("state shape does not match the input; call reset_states()")
             v_out, z_out = _f32((B, H, W, C), dev), _i32((B, H, W), dev)
             zT_out = _i32((B, H, C, (W + 31) // 32), dev)  # channel-major bit planes for the weight gradients
             leak, thresh = self._flat[f"{i}.leak"], self._flat[f"{i}.thresh"]
-            if i == 0:
+            if plif and i == 0:
+                _lib.call("evf_head_plif_fwd", _lib.ptr(x_in), _lib.ptr(self._flat["0.ff"]), _lib.ptr(leak),
+                          _lib.ptr(self._flat["0.leak_pt"]), _lib.ptr(self._flat["0.add_pt"]), _lib.ptr(thresh), _lib.ptr(v_prev),
+                          _lib.ptr(z_prev), _lib.ptr(pt_prev), B, Cin, H, W, 1 if c.hard_reset else 0, _lib.ptr(v_out),
+                          _lib.ptr(z_out), _lib.ptr(zT_out), _lib.ptr(pt_out), _lib.ptr(P_out))
+            elif plif:
+                wrec = self._packed[(i, "rec", "b3")] if c.recurrent else None
+                _lib.call("evf_conv_plif_fwd_b3", _lib.ptr(in_bits), _lib.ptr(self._packed[(i, "ff", "b3")]), _lib.ptr(wrec),
+                          _lib.ptr(leak), _lib.ptr(self._flat[f"{i}.leak_pt"]), _lib.ptr(self._flat[f"{i}.add_pt"]),
+                          _lib.ptr(thresh), _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(pt_prev), B, H, W,
+                          1 if c.hard_reset else 0, _lib.ptr(v_out), _lib.ptr(z_out), _lib.ptr(zT_out), _lib.ptr(pt_out),
+                          _lib.ptr(P_out))
+            elif i == 0:
                 _lib.call("evf_head_lif_fwd", _lib.ptr(x_in), _lib.ptr(self._flat["0.ff"]), _lib.ptr(leak), _lib.ptr(thresh),
                           _lib.ptr(v_prev), _lib.ptr(z_prev), B, Cin, H, W, 1 if c.hard_reset else 0, _lib.ptr(v_out),
                           _lib.ptr(z_out), _lib.ptr(zT_out))
@@ -272,9 +310,9 @@ class FireNetEngine:
                           _lib.ptr(leak), _lib.ptr(thresh), _lib.ptr(v_prev), _lib.ptr(z_prev), B, H, W,
                           1 if c.hard_reset else 0, _lib.ptr(v_out), _lib.ptr(z_out), _lib.ptr(zT_out))
             if record:
-                layers.append((in_bits, v_prev, z_prev, v_out, z_out, in_bitsT, zT_prev))
+                layers.append((in_bits, v_prev, z_prev, v_out, z_out, in_bitsT, zT_prev, pt_prev, pt_out, P_out))
             in_bits, in_bitsT = z_out, zT_out
-            new_states.append((v_out, z_out, zT_out))
+            new_states.append((v_out, z_out, zT_out, pt_out) if plif else (v_out, z_out, zT_out))
         flow = _f32((B, 2, H, W), dev)
         _lib.call("evf_pred_fwd", _lib.ptr(in_bits), _lib.ptr(self._flat["pred.w"]), _lib.ptr(self._flat["pred.b"]), B, H, W,
                   _lib.ptr(flow))
@@ -309,7 +347,8 @@ class FireNetEngine:
                 win.g_split = torch.empty((3, B, H, W, C), dtype=torch.bfloat16, device=dev)
         for i in range(n - 1, -1, -1):
             c = self.cells[i]
-            in_bits, v_prev, z_prev, v_out, _, in_bitsT, zT_prev = layers[i]
+            in_bits, v_prev, z_prev, v_out, _, in_bitsT, zT_prev, pt_prev, pt_out, P_sav = layers[i]
+            plif = self.kind == "plif"
             g_z = win.gz[i] if win.gz_has[i] else None
             g_v = win.gv[i]
             win.gz_has[i] = False
@@ -329,7 +368,8 @@ class FireNetEngine:
                 _lib.call("evf_lif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
                           _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None, _lib.ptr(self._flat[f"{i}.leak"]),
                           _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
-                          self._act_width(i), None, _lib.ptr(win.g_split), _lib.ptr(gv_out), _lib.ptr(leak_g), _lib.ptr(thr_g),
+                          self._act_width(i), _lib.ptr(win.g_cur) if plif else None, _lib.ptr(win.g_split), _lib.ptr(gv_out),
+                          _lib.ptr(leak_g), _lib.ptr(thr_g),
                           _lib.ptr(self._slab(kf, nsl, dev)), _lib.ptr(self._slab(kr, nsl, dev)) if use_rec else None, acc_flag)
                 win.slab_init[kf] = True
                 if use_rec:
@@ -353,6 +393,16 @@ class FireNetEngine:
                     _lib.call("evf_conv_wgrad_bits", _lib.ptr(z_prev), _lib.ptr(win.g_cur), B, H, W,
                               _lib.ptr(self._slab(k, nslab, dev)), 1 if win.slab_init.get(k) else 0)
                     win.slab_init[k] = True
+            if plif:  # trace backward: carries dL/dpt, yields dL/d(pooled activity) for the input-spike gradient
+                if win.gP is None:
+                    win.gP = _f32((B, H, W), dev)
+                gpt_out = win.buf(win.gpt, i)
+                carry = gpt_out if win.gpt_has[i] else None
+                _lib.call("evf_plif_trace_bwd", _lib.ptr(win.g_cur), _lib.ptr(carry), _lib.ptr(pt_prev), _lib.ptr(pt_out),
+                          _lib.ptr(P_sav), _lib.ptr(self._flat[f"{i}.leak_pt"]), _lib.ptr(self._flat[f"{i}.add_pt"]), B, H, W,
+                          _lib.ptr(gpt_out), _lib.ptr(win.gP), _lib.ptr(self._small(win, f"{i}.leak_pt")),
+                          _lib.ptr(self._small(win, f"{i}.add_pt")))
+                win.gpt_has[i] = not is_first
             if is_first:
                 win.gv[i] = None  # the state entering the window is detached (train_flow.py:170)
             # input gradients: to the layer below (this pass) and to the own previous spikes (previous pass)
@@ -362,11 +412,11 @@ class FireNetEngine:
                 acc_a = 1 if win.gz_has[i - 1] else 0
                 if self.precision == "bf16x3":
                     _lib.call("evf_conv_dgrad_b3", _lib.ptr(win.g_split), _lib.ptr(self._packed[(i, "ff", "b3t")]), _lib.ptr(ga),
-                              acc_a, B, H, W)
+                              acc_a, B, H, W, _lib.ptr(win.gP) if plif else None, _lib.ptr(in_bits) if plif else None)
                     if rec_grad:
                         gb = win.buf(win.gz, i)
                         _lib.call("evf_conv_dgrad_b3", _lib.ptr(win.g_split), _lib.ptr(self._packed[(i, "rec", "b3t")]),
-                                  _lib.ptr(gb), 0, B, H, W)
+                                  _lib.ptr(gb), 0, B, H, W, None, None)
                         win.gz_has[i] = True
                 elif rec_grad:
                     gb = win.buf(win.gz, i)

@@ -219,7 +219,27 @@ int evf_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const float* v
  * or += when accumulate.  Six-term product, fp32 accumulation (fp32 round-off class). */
 int evf_pack_conv_weight_b3t(const float* w, int Cout, int Cin, void* dst, void* stream);
 int evf_conv_dgrad_b3(const void* g_split, const void* wT_b3, float* g_x, int accumulate,
-                      int B, int H, int W, void* stream);
+                      int B, int H, int W, const float* g_P, const uint32_t* x_bits, void* stream);
+
+/* PLIF cells (models/spiking_submodules.py:129-227, :554-657): LIF + a per-channel
+ * pre-synaptic trace pt' = pt*s(leak_pt) + (1-s(leak_pt))*AvgPool3x3(mean_c|input|),
+ * current = ff (+rec) - s(add_pt)*pt'.  Forward = the LIF kernels plus pt_prev/pt_out
+ * [B,H,W,32] and P_out [B,H,W] (the pooled activity, saved for the backward).  Backward =
+ * evf_lif_bwd_wgrad / evf_lif_bwd (they yield g_cur) followed by evf_plif_trace_bwd
+ * (g_pt carry, g_P, d leak_pt, d add_pt); the gradient that reaches the input spikes through
+ * the trace is added by evf_conv_dgrad_b3 when g_P / x_bits are given. */
+int evf_conv_plif_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec,
+                         const float* leak_v, const float* leak_pt, const float* add_pt, const float* thresh,
+                         const float* v_prev, const uint32_t* z_prev, const float* pt_prev,
+                         int B, int H, int W, int hard_reset,
+                         float* v_out, uint32_t* z_out, uint32_t* zT_out, float* pt_out, float* P_out, void* stream);
+int evf_head_plif_fwd(const float* x, const float* w, const float* leak_v, const float* leak_pt,
+                      const float* add_pt, const float* thresh, const float* v_prev, const uint32_t* z_prev,
+                      const float* pt_prev, int B, int Cin, int H, int W, int hard_reset,
+                      float* v_out, uint32_t* z_out, uint32_t* zT_out, float* pt_out, float* P_out, void* stream);
+int evf_plif_trace_bwd(const float* g_cur, const float* g_pt_carry, const float* pt_prev, const float* pt_out,
+                       const float* P, const float* leak_pt, const float* add_pt, int B, int H, int W,
+                       float* g_pt_prev, float* g_P, float* g_leak_pt, float* g_add_pt, void* stream);
 
 /* Input-gradient conv: g_x[pix][ci] (+)= sum_tap,co g_cur[pix-tap][co]*w[co][ci][tap]
  * with wT packed by evf_pack_conv_weight(transposed=1).  g_cur, g_x [B,H,W,32].

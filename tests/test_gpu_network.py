@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 from event_flow_amd import _lib  # noqa: E402
 from event_flow_amd.loss import flow as hloss  # noqa: E402
-from event_flow_amd.models.model import LIFFireFlowNet, LIFFireNet  # noqa: E402
+from event_flow_amd.models.model import LIFFireFlowNet, LIFFireNet, PLIFFireNet  # noqa: E402
 from event_flow_amd.train import FlatAdam, train_window  # noqa: E402
 from oracle import snn as osnn  # noqa: E402
 from oracle import train as otrain  # noqa: E402
@@ -23,6 +23,10 @@ from oracle import train as otrain  # noqa: E402
 DEV = "cuda:0"
 LAYERS = ["head", "G1", "R1a", "R1b", "G2", "R2a", "R2b"]
 NEURON = {"leak": [-4.0, 0.1], "thresh": [0.8, 0.1], "learn_leak": True, "learn_thresh": True, "hard_reset": True}
+PLIF_NEURON = {"leak_v": [-4.0, 0.1], "leak_pt": [-4.0, 0.1], "add_pt": [-2.0, 0.1], "thresh": [0.8, 0.1],
+               "learn_leak": True, "learn_thresh": True, "hard_reset": True}
+FIXTURES = {"g7_liffirenet_train": (LIFFireNet, NEURON), "g7_liffirenet_lowthresh": (LIFFireNet, NEURON),
+            "g7_pliffirenet_train": (PLIFFireNet, PLIF_NEURON)}
 
 
 def G(a):
@@ -43,8 +47,9 @@ def loss_cfg(H, W):
             "model": {"mask_output": True}}
 
 
-def build_from_golden(g, prefix="param0_", cls=LIFFireNet):
-    model = cls(model_cfg()).to(DEV)
+def build_from_golden(g, prefix="param0_", fix="g7_liffirenet_train"):
+    cls, neuron = FIXTURES[fix]
+    model = cls(model_cfg(neuron)).to(DEV)
     sd = {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
     model.load_state_dict(sd)  # reference state_dict keys load unchanged
     return model
@@ -56,10 +61,10 @@ def passes_from_golden(g):
     return [{k: G(g[f"p{i}_{k}"]) for k in keys} for i in range(P)]
 
 
-@pytest.mark.parametrize("fix", ["g7_liffirenet_train", "g7_liffirenet_lowthresh"])
+@pytest.mark.parametrize("fix", list(FIXTURES))
 def test_forward_per_layer_and_flow(fix):
     g = load_golden(fix)
-    model = build_from_golden(g)
+    model = build_from_golden(g, fix=fix)
     model.eval()
     passes = passes_from_golden(g)
     nflip = ntot = 0
@@ -79,14 +84,17 @@ def test_forward_per_layer_and_flow(fix):
                 # borderline spike upstream legitimately changes downstream v)
                 if nflip == 0:
                     np.testing.assert_allclose(v, v_ref, rtol=1e-5, atol=2e-6, err_msg=f"{i} {ln}")
+                    if f"p{i}_aux_{ln}" in g.files:  # PLIF pre-synaptic trace (third state)
+                        np.testing.assert_allclose(N(states[li][2]), g[f"p{i}_aux_{ln}"], rtol=1e-5, atol=1e-7,
+                                                   err_msg=f"{i} {ln} trace")
             if nflip == 0:
                 np.testing.assert_allclose(N(out["flow"][0]), g[f"p{i}_flow"], rtol=1e-4, atol=1e-7)
             assert set(out["activity"].keys()) == {"0:input", "1:head", "2:G1", "3:R1a", "4:R1b", "5:G2", "6:R2a", "7:R2b", "8:pred"}
     assert nflip <= 1e-5 * ntot, (nflip, ntot)
 
 
-def _train_once(g, use_flat_adam):
-    model = build_from_golden(g)
+def _train_once(g, use_flat_adam, fix="g7_liffirenet_train"):
+    model = build_from_golden(g, fix=fix)
     model.train()
     passes = passes_from_golden(g)
     H, W = passes[0]["event_cnt"].shape[2:]
@@ -110,11 +118,11 @@ def _train_once(g, use_flat_adam):
     return float(loss.detach()), grads, gn, newp
 
 
-@pytest.mark.parametrize("fix", ["g7_liffirenet_train", "g7_liffirenet_lowthresh"])
+@pytest.mark.parametrize("fix", list(FIXTURES))
 @pytest.mark.parametrize("flat", [True, False])
 def test_train_step_vs_golden(fix, flat):
     g = load_golden(fix)
-    loss, grads, gn, newp = _train_once(g, flat)
+    loss, grads, gn, newp = _train_once(g, flat, fix)
     np.testing.assert_allclose(loss, float(g["loss"]), rtol=2e-4)
     np.testing.assert_allclose(gn, float(g["grad_norm"]), rtol=2e-3)
     for k, got in grads.items():
@@ -193,14 +201,14 @@ def test_window_semantics_detach_and_reset():
 
 
 def test_fireflownet_runs_and_unsupported_fail_loudly():
-    from event_flow_amd.models.model import FireNet, PLIFFireNet
+    from event_flow_amd.models.model import ALIFFireNet
 
     model = LIFFireFlowNet(model_cfg()).to(DEV)
     x = torch.rand(1, 2, 16, 40, device=DEV).round()
     out = model(x, x)
     assert out["flow"][0].shape == (1, 2, 16, 40)
     with pytest.raises(NotImplementedError):
-        m = PLIFFireNet(model_cfg({"leak_v": [-4.0, 0.1], "thresh": [0.8, 0.1]})).to(DEV)
+        m = ALIFFireNet(model_cfg({"leak_v": [-4.0, 0.1], "t0": [0.8, 0.1]})).to(DEV)
         m(x, x)
     with pytest.raises(_lib.EvflowError):
         LIFFireNet(model_cfg())(x.cpu(), x.cpu())  # CPU tensors: no fallback
@@ -322,7 +330,7 @@ def test_fused_lif_bwd_wgrad_matches_separate_kernels(rec, shape):
     _lib.call("evf_pack_conv_weight_b3t", wt.data_ptr(), C, C, pb3.data_ptr())
     gx0, gx1 = torch.empty_like(gz), torch.empty_like(gz)
     _lib.call("evf_conv_dgrad", gc0.data_ptr(), p32.data_ptr(), gx0.data_ptr(), 0, None, None, 0, B, H, W)
-    _lib.call("evf_conv_dgrad_b3", gs1.data_ptr(), pb3.data_ptr(), gx1.data_ptr(), 0, B, H, W)
+    _lib.call("evf_conv_dgrad_b3", gs1.data_ptr(), pb3.data_ptr(), gx1.data_ptr(), 0, B, H, W, None, None)
     assert float((gx1 - gx0).abs().max()) <= 3e-6 * float(gx0.abs().max())
     np.testing.assert_allclose(N(gl1), 2 * N(gl0), rtol=2e-4, atol=1e-4)
     np.testing.assert_allclose(N(gt1), 2 * N(gt0), rtol=2e-4, atol=1e-4)

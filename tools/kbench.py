@@ -58,7 +58,7 @@ cases = [
     ("head_lif_fwd", 2 * 18 * 32 * npix, 2 * npix * 128, lambda: _lib.call("evf_head_lif_fwd", P(xin), P(wh), P(leak), P(thresh), P(v), P(z), B, 2, H, W, 1, P(vo), P(zo), None)),
     ("conv_dgrad one", FL, 2 * npix * 128, lambda: _lib.call("evf_conv_dgrad", P(g1), P(wpt), P(g2), 0, None, None, 0, B, H, W)),
     ("conv_dgrad two", 2 * FL, 3 * npix * 128, lambda: _lib.call("evf_conv_dgrad", P(g1), P(wpt), P(g2), 0, P(wpt), P(g3), 0, B, H, W)),
-    ("conv_dgrad_b3", FL, 2 * npix * 128, lambda: _lib.call("evf_conv_dgrad_b3", P(gsp), P(wb3t), P(g2), 0, B, H, W)),
+    ("conv_dgrad_b3", FL, 2 * npix * 128, lambda: _lib.call("evf_conv_dgrad_b3", P(gsp), P(wb3t), P(g2), 0, B, H, W, None, None)),
     ("conv_wgrad_bits", FL, npix * 128, lambda: _lib.call("evf_conv_wgrad_bits", P(x), P(g1), B, H, W, P(slab), 1)),
     ("lif_bwd_wgrad ff", FL, 6 * npix * 128, lambda: _lib.call("evf_lif_bwd_wgrad", P(g1), P(g2), P(vo), P(v), P(z), P(xT), None, P(leak), P(thresh), B, H, W, 1, 0, 10.0, P(g3), P(gsp), P(g4), P(gl), P(gt), P(slab), None, 1)),
     ("lif_bwd_wgrad rec", 2 * FL, 6 * npix * 128, lambda: _lib.call("evf_lif_bwd_wgrad", P(g1), P(g2), P(vo), P(v), P(z), P(xT), P(xT), P(leak), P(thresh), B, H, W, 1, 0, 10.0, P(g3), P(gsp), P(g4), P(gl), P(gt), P(slab), P(slab2), 1)),
