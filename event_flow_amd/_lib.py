@@ -64,7 +64,28 @@ NETWORK_SIGNATURES = {
     "evf_nhwc_to_nchw": [P, I, I, I, I, P, P],
     "evf_nchw_to_nhwc": [P, I, I, I, I, P, P],
     "evf_clip_adam_step": [P, P, P, P, L, F, F, F, F, F, I, P, P],
+    # general path (any channel count, NHWC fp32)
+    "evf_conv2d_packed_size": [I, I, I, I],
+    "evf_pack_conv2d_weight": [P, I, I, I, I, I, I, P, P],
+    "evf_conv2d_fwd": [P, I, P, P, P, I, I, I, I, I, I, I, I, I, P],
+    "evf_conv2d_dgrad": [P, I, P, P, I, I, I, I, I, I, I, I, I, P],
+    "evf_conv2d_wgrad": [P, I, P, I, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "evf_neuron_fwd": [I, P, P, P, P, P, P, P, P, P, P, L, I, I, P, P, P, P, P],
+    "evf_neuron_bwd": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, F, P, P, P, P, P, P, P, P, P, P],
+    "evf_pretrace_fwd": [P, I, I, I, I, I, I, I, P, P, P],
+    "evf_pretrace_bwd": [P, I, P, I, I, I, I, I, I, P, I, I, P],
+    "evf_upsample2x_fwd": [P, I, I, I, I, P, P],
+    "evf_upsample2x_bwd": [P, I, I, I, I, P, P],
+    "evf_upsample_nearest_fwd": [P, L, I, I, I, P, P],
+    "evf_upsample_nearest_bwd": [P, L, I, I, I, P, P],
+    "evf_act_fwd": [I, P, P, L, P, P],
+    "evf_act_bwd": [I, P, P, L, P, P],
+    "evf_gru_gates_fwd": [P, P, P, L, P, P, P, P],
+    "evf_gru_out_fwd": [P, P, P, L, P, P, P],
+    "evf_gru_out_bwd": [P, P, P, P, L, P, P, P, P],
+    "evf_gru_gates_bwd": [P, P, P, L, P, P, P],
 }
+RESTYPES = {"evf_conv2d_packed_size": ctypes.c_int64}
 SIGNATURES.update(NETWORK_SIGNATURES)
 
 _lib = None
@@ -88,7 +109,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = RESTYPES.get(name, ctypes.c_int)
     _lib = lib
     return lib
 

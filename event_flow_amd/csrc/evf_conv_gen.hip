@@ -1,0 +1,500 @@
+// General 2-D convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
+// k in {1,3}, stride in {1,2}, padding k/2, any channel counts, NHWC fp32 with
+// explicit pixel strides.  Used by every layer that is not one of the fused
+// 32->32 binary-spike kernels: the spiking EV-FlowNet encoders / residual
+// blocks / decoders (reference models/unet.py:418-465), the ANN FireNet
+// (models/submodules.py:64-83,377-418), the 1x1 prediction heads and the
+// stand-alone Conv{LIF,PLIF,ALIF,XLIF}[Recurrent] cells.
+//
+//   forward / input gradient : implicit GEMM, M = output pixels (flattened
+//       b,oy,ox), N = output channels, K = taps x input channels.  One wave =
+//       32 pixels x (32 NT) channels.  The A operand is read straight from
+//       global memory -- a lane holds 8 consecutive channels of its pixel and
+//       feeds them to 8 MFMAs (the K order inside a 16-channel chunk is a
+//       permutation the packed weights share), no LDS, no VALU.  The weights
+//       of one (tap, 64-channel group) are staged through LDS in fragment
+//       order (ds_read_b128, conflict free), double buffered, one barrier
+//       per 32 NT MFMAs per wave.
+//       The input gradient of a stride-s conv is the same kernel in
+//       "transposed" addressing (mode 1) with weights packed [tap][co][ci].
+//   weight gradient : GEMM over pixels, gw[tap][ci][co] = sum_px x[px+tap][ci] g[px][co].
+//       For the 32x32x2 fp32 MFMA a lane holds ONE k value, so the natural
+//       [pixel][channel] tiles in LDS are already in fragment order (no
+//       transpose).  Pixels are split over blocks (split-K), partial tiles
+//       are reduced across the 4 waves in LDS and added atomically.
+//
+// fp32 products, fp32 accumulation: the results equal a CPU fp32 convolution
+// up to summation order.
+#include "evf_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CG_BM 128  // output pixels per block (4 waves x 32)
+#define CG_KG 64   // input channels per stage
+
+struct ConvGeo {
+  int B, SH, SW, K;  // source image dims, contraction channels
+  int OH, OW, N;     // output image dims, output channels
+  int ksz, stride, mode;
+  int lds, ldo;      // pixel strides (floats) of source / output
+};
+
+__device__ __forceinline__ int cg_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+static inline int cg_nt(int N) { return N > 32 ? 2 : 1; }
+
+// ---------------------------------------------------------------------------
+// weight packing.  w is the torch layout [Cout][Cin][k][k].  transpose = 0:
+// K = Cin, N = Cout (forward); transpose = 1: K = Cout, N = Cin (input grad).
+// dst float4 index ((((nb*T + tap)*G + g)*NT + t)*8 + ch*2 + h)*64 + lane, element j:
+//   k = g*64 + ch*16 + 8*(lane>>5) + 4h + j,   n = (nb*NT + t)*32 + (lane&31)
+// ---------------------------------------------------------------------------
+__global__ void k_pack_conv2d(const float* __restrict__ w, int Cout, int Cin, int T, int transpose, int NT, long total,
+                              int cin_total, int cin_off, float4* __restrict__ dst) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int K = transpose ? Cout : Cin, N = transpose ? Cin : Cout;
+  const int G = (K + CG_KG - 1) / CG_KG;
+  const int lane = idx & 63;
+  long q = idx >> 6;
+  const int chh = q & 7;
+  q >>= 3;
+  const int t = q % NT;
+  q /= NT;
+  const int g = q % G;
+  q /= G;
+  const int tap = q % T;
+  const int nb = q / T;
+  const int ch = chh >> 1, h = chh & 1;
+  const int n = (nb * NT + t) * 32 + (lane & 31);
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = g * CG_KG + ch * 16 + 8 * (lane >> 5) + 4 * h + j;
+    float x = 0.f;
+    if (k < K && n < N) {
+      const int co = transpose ? k : n, ci = transpose ? n : k;
+      x = w[((long)co * cin_total + cin_off + ci) * T + tap];
+    }
+    v[j] = x;
+  }
+  dst[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+static long cg_packed_float4(int Cout, int Cin, int ksz, int transpose) {
+  const int K = transpose ? Cout : Cin, N = transpose ? Cin : Cout;
+  const int NT = cg_nt(N), NB = evf_cdiv(N, 32 * NT), G = evf_cdiv(K, CG_KG), T = ksz * ksz;
+  return (long)NB * T * G * NT * 512;
+}
+
+extern "C" int64_t evf_conv2d_packed_size(int Cout, int Cin, int ksz, int transpose) {
+  if (Cout <= 0 || Cin <= 0 || (ksz != 1 && ksz != 3)) return 0;
+  return cg_packed_float4(Cout, Cin, ksz, transpose) * 4;
+}
+
+extern "C" int evf_pack_conv2d_weight(const float* w, int Cout, int Cin, int ksz, int transpose, int cin_total, int cin_off,
+                                      float* dst, void* stream) {
+  if (!w || !dst || Cout <= 0 || Cin <= 0 || (ksz != 1 && ksz != 3) || cin_off < 0 || cin_off + Cin > cin_total)
+    return EVF_EINVAL;
+  const int N = transpose ? Cin : Cout;
+  const long total = cg_packed_float4(Cout, Cin, ksz, transpose);
+  hipLaunchKernelGGL(k_pack_conv2d, dim3(evf_cdiv(total, 256)), dim3(256), 0, EVF_STREAM(stream), w, Cout, Cin, ksz * ksz,
+                     transpose, cg_nt(N), total, cin_total, cin_off, (float4*)dst);
+  return evf_status();
+}
+
+// ---------------------------------------------------------------------------
+// forward / input-gradient kernel
+// ---------------------------------------------------------------------------
+template <int NT, int VEC>
+__global__ __launch_bounds__(256) void k_conv2d_f32(const float* __restrict__ src, const float4* __restrict__ wp,
+                                                    const float* __restrict__ bias, float* __restrict__ out, ConvGeo g,
+                                                    int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float4* s_b = (float4*)smem_raw;  // 2 stages x NT*512
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, row = lane & 31, kg = lane >> 5;
+  const long M = (long)g.B * g.OH * g.OW;
+  const long m = (long)blockIdx.x * CG_BM + wv * 32 + row;
+  const bool mok = m < M;
+  const long mc = mok ? m : M - 1;
+  const int ox = (int)(mc % g.OW);
+  const long t1 = mc / g.OW;
+  const int oy = (int)(t1 % g.OH), b = (int)(t1 / g.OH);
+  const int T = g.ksz * g.ksz, pad = g.ksz >> 1, G = (g.K + CG_KG - 1) / CG_KG;
+  const int S = T * G;
+  const float4* wblk = wp + (long)blockIdx.y * S * (NT * 512);
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // unconditional loads from clamped addresses + selects (a load inside a divergent
+  // branch makes the compiler drain vmcnt(0) after it)
+  auto load_a = [&](int s, float(&a)[32]) {
+    const int tap = s / G, cgi = s - tap * G;
+    const int dy = tap / g.ksz, dx = tap - dy * g.ksz;
+    int sy, sx;
+    bool ok;
+    if (g.mode == 0) {
+      sy = oy * g.stride + dy - pad;
+      sx = ox * g.stride + dx - pad;
+      ok = mok && sy >= 0 && sy < g.SH && sx >= 0 && sx < g.SW;
+    } else {
+      const int ty = oy + pad - dy, tx = ox + pad - dx;
+      sy = ty / g.stride;
+      sx = tx / g.stride;
+      ok = mok && ty >= 0 && tx >= 0 && sy * g.stride == ty && sx * g.stride == tx && sy < g.SH && sx < g.SW;
+    }
+    sy = min(max(sy, 0), g.SH - 1);
+    sx = min(max(sx, 0), g.SW - 1);
+    const float* p = src + (((long)b * g.SH + sy) * g.SW + sx) * g.lds;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      const int c0 = cgi * CG_KG + ch * 16 + 8 * kg;
+      if (VEC == 4) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int c = c0 + 4 * q;
+          const bool v = ok && c + 4 <= g.K;
+          const float4 t4 = *(const float4*)(p + (c + 4 <= g.K ? c : 0));
+          a[ch * 8 + 4 * q + 0] = v ? t4.x : 0.f;
+          a[ch * 8 + 4 * q + 1] = v ? t4.y : 0.f;
+          a[ch * 8 + 4 * q + 2] = v ? t4.z : 0.f;
+          a[ch * 8 + 4 * q + 3] = v ? t4.w : 0.f;
+        }
+      } else if (VEC == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = c0 + 2 * q;
+          const bool v = ok && c + 2 <= g.K;
+          const float2 t2 = *(const float2*)(p + (c + 2 <= g.K ? c : 0));
+          a[ch * 8 + 2 * q + 0] = v ? t2.x : 0.f;
+          a[ch * 8 + 2 * q + 1] = v ? t2.y : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int c = c0 + q;
+          const float t = p[c < g.K ? c : 0];
+          a[ch * 8 + q] = (ok && c < g.K) ? t : 0.f;
+        }
+      }
+    }
+  };
+
+  float a_cur[32], a_nxt[32];
+  float4 b_reg[2 * NT];
+#pragma unroll
+  for (int i = 0; i < 2 * NT; ++i) s_b[tid + 256 * i] = wblk[tid + 256 * i];
+  load_a(0, a_cur);
+  __syncthreads();
+
+#pragma unroll 1
+  for (int s = 0; s < S; ++s) {
+    const int sn = min(s + 1, S - 1);
+#pragma unroll
+    for (int i = 0; i < 2 * NT; ++i) b_reg[i] = wblk[(long)sn * (NT * 512) + tid + 256 * i];
+    load_a(sn, a_nxt);
+    const float4* sb = s_b + (s & 1) * (NT * 512);
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float4 bq = sb[(t * 8 + ch * 2 + h) * 64 + lane];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ch * 8 + 4 * h + 0], bq.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ch * 8 + 4 * h + 1], bq.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ch * 8 + 4 * h + 2], bq.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ch * 8 + 4 * h + 3], bq.w, acc[t], 0, 0, 0);
+        }
+    float4* sbn = s_b + ((s + 1) & 1) * (NT * 512);
+#pragma unroll
+    for (int i = 0; i < 2 * NT; ++i) sbn[tid + 256 * i] = b_reg[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; ++i) a_cur[i] = a_nxt[i];
+  }
+
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = (blockIdx.y * NT + t) * 32 + row;
+    if (n < g.N) {
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long mr = (long)blockIdx.x * CG_BM + wv * 32 + cg_row(r, lane);
+        if (mr < M) {
+          float* d = out + mr * g.ldo + n;
+          const float v = acc[t][r] + bv;
+          *d = accumulate ? *d + v : v;
+        }
+      }
+    }
+  }
+}
+
+template <int NT>
+static int cg_launch_vec(const float* src, const float* wp, const float* bias, float* out, const ConvGeo& g, int accumulate,
+                         hipStream_t st) {
+  const long M = (long)g.B * g.OH * g.OW;
+  dim3 grid(evf_cdiv(M, CG_BM), evf_cdiv(g.N, 32 * NT)), block(256);
+  const size_t smem = 2 * NT * 512 * sizeof(float4);
+  const bool a16 = ((uintptr_t)src & 15) == 0, a8 = ((uintptr_t)src & 7) == 0;
+  if (g.K % 4 == 0 && g.lds % 4 == 0 && a16)
+    hipLaunchKernelGGL((k_conv2d_f32<NT, 4>), grid, block, smem, st, src, (const float4*)wp, bias, out, g, accumulate);
+  else if (g.K % 2 == 0 && g.lds % 2 == 0 && a8)
+    hipLaunchKernelGGL((k_conv2d_f32<NT, 2>), grid, block, smem, st, src, (const float4*)wp, bias, out, g, accumulate);
+  else
+    hipLaunchKernelGGL((k_conv2d_f32<NT, 1>), grid, block, smem, st, src, (const float4*)wp, bias, out, g, accumulate);
+  return evf_status();
+}
+
+static int cg_launch(const float* src, const float* wp, const float* bias, float* out, const ConvGeo& g, int accumulate,
+                     void* stream) {
+  if (cg_nt(g.N) == 2) return cg_launch_vec<2>(src, wp, bias, out, g, accumulate, EVF_STREAM(stream));
+  return cg_launch_vec<1>(src, wp, bias, out, g, accumulate, EVF_STREAM(stream));
+}
+
+static inline int cg_out_dim(int n, int ksz, int stride) { return (n + 2 * (ksz >> 1) - ksz) / stride + 1; }
+
+extern "C" int evf_conv2d_fwd(const float* x, int ldx, const float* w_packed, const float* bias, float* y, int ldy, int B,
+                              int H, int W, int Cin, int Cout, int ksz, int stride, int accumulate, void* stream) {
+  if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksz != 1 && ksz != 3) ||
+      (stride != 1 && stride != 2) || ldx < Cin || ldy < Cout)
+    return EVF_EINVAL;
+  ConvGeo g;
+  g.B = B, g.SH = H, g.SW = W, g.K = Cin;
+  g.OH = cg_out_dim(H, ksz, stride), g.OW = cg_out_dim(W, ksz, stride), g.N = Cout;
+  g.ksz = ksz, g.stride = stride, g.mode = 0, g.lds = ldx, g.ldo = ldy;
+  return cg_launch(x, w_packed, bias, y, g, accumulate, stream);
+}
+
+// g_x [B,H,W,Cin] (+)= conv^T(g_y [B,Ho,Wo,Cout]); wT_packed from evf_pack_conv2d_weight(transpose = 1)
+extern "C" int evf_conv2d_dgrad(const float* g_y, int ldg, const float* wT_packed, float* g_x, int ldx, int B, int H, int W,
+                                int Cin, int Cout, int ksz, int stride, int accumulate, void* stream) {
+  if (!g_y || !wT_packed || !g_x || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksz != 1 && ksz != 3) ||
+      (stride != 1 && stride != 2) || ldx < Cin || ldg < Cout)
+    return EVF_EINVAL;
+  ConvGeo g;
+  g.B = B, g.SH = cg_out_dim(H, ksz, stride), g.SW = cg_out_dim(W, ksz, stride), g.K = Cout;
+  g.OH = H, g.OW = W, g.N = Cin;
+  g.ksz = ksz, g.stride = stride, g.mode = 1, g.lds = ldg, g.ldo = ldx;
+  return cg_launch(g_y, wT_packed, nullptr, g_x, g, accumulate, stream);
+}
+
+// ---------------------------------------------------------------------------
+// weight (and bias) gradient
+// ---------------------------------------------------------------------------
+struct WgGeo {
+  int B, H, W, Cin, OH, OW, Cout, ksz, stride, ldx, ldg, cin_total, cin_off;
+  int stages;  // 32-pixel stages per K split
+};
+
+template <int CT, int NT, int VEC>
+__global__ __launch_bounds__(256) void k_conv2d_wgrad_f32(const float* __restrict__ x, const float* __restrict__ gy,
+                                                          float* __restrict__ gw, float* __restrict__ gbias, WgGeo g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* s = (float*)smem_raw;
+  constexpr int XW = 32 * CT, GW = 32 * NT, STG = 32 * (XW + GW);  // floats per stage
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, row = lane & 31, kg = lane >> 5;
+  const int n_ct = (g.Cin + XW - 1) / XW;
+  const int cit = blockIdx.y % n_ct, cot = blockIdx.y / n_ct;
+  const int ci0 = cit * XW, co0 = cot * GW;
+  const int tap = blockIdx.z, dy = tap / g.ksz, dx = tap - dy * g.ksz, pad = g.ksz >> 1;
+  const long M = (long)g.B * g.OH * g.OW;
+  const long m_begin = (long)blockIdx.x * g.stages * 32;
+  const bool do_bias = gbias && cit == 0 && tap == 0;
+
+  f32x16 acc[CT][NT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
+  float bsum[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bsum[t] = 0.f;
+
+  // tile loads: x tile 32 px x XW ch = 8*CT float4 per pixel -> CT float4 per thread; g likewise
+  float4 xr[CT], gr[NT];
+  auto load_tiles = [&](int st) {
+    const long m0 = m_begin + (long)st * 32;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      const int idx = tid + 256 * i, px = idx / (8 * CT), q = idx - px * (8 * CT);
+      const long m = m0 + px;
+      const bool mok = m < M;
+      const long mc = mok ? m : M - 1;
+      const int ox = (int)(mc % g.OW);
+      const long t1 = mc / g.OW;
+      const int oy = (int)(t1 % g.OH), b = (int)(t1 / g.OH);
+      int sy = oy * g.stride + dy - pad, sx = ox * g.stride + dx - pad;
+      const bool ok = mok && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W;
+      sy = min(max(sy, 0), g.H - 1), sx = min(max(sx, 0), g.W - 1);
+      const float* p = x + (((long)b * g.H + sy) * g.W + sx) * g.ldx;
+      const int c = ci0 + 4 * q;
+      float4 v;
+      if (VEC == 4) {
+        const bool cv = c + 4 <= g.Cin;
+        v = *(const float4*)(p + (cv ? c : 0));
+        if (!(ok && cv)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float t = p[c + j < g.Cin ? c + j : 0];
+          e[j] = (ok && c + j < g.Cin) ? t : 0.f;
+        }
+        v = make_float4(e[0], e[1], e[2], e[3]);
+      }
+      xr[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int idx = tid + 256 * i, px = idx / (8 * NT), q = idx - px * (8 * NT);
+      const long m = m0 + px;
+      const bool mok = m < M;
+      const float* p = gy + (mok ? m : M - 1) * g.ldg;
+      const int c = co0 + 4 * q;
+      float4 v;
+      if (VEC == 4) {
+        const bool cv = c + 4 <= g.Cout;
+        v = *(const float4*)(p + (cv ? c : 0));
+        if (!(mok && cv)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float t = p[c + j < g.Cout ? c + j : 0];
+          e[j] = (mok && c + j < g.Cout) ? t : 0.f;
+        }
+        v = make_float4(e[0], e[1], e[2], e[3]);
+      }
+      gr[i] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* sx = s + buf * STG;
+    float* sg = sx + 32 * XW;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) *(float4*)(sx + (tid + 256 * i) * 4) = xr[i];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) *(float4*)(sg + (tid + 256 * i) * 4) = gr[i];
+  };
+
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int st = 0; st < g.stages; ++st) {
+    load_tiles(min(st + 1, g.stages - 1));
+    const float* sx = s + (st & 1) * STG;
+    const float* sg = sx + 32 * XW;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int p = 2 * (wv + 4 * jj) + kg;
+      float av[CT], bv[NT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) av[c] = sx[p * XW + c * 32 + row];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        bv[t] = sg[p * GW + t * 32 + row];
+        bsum[t] += bv[t];
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[t], acc[c][t], 0, 0, 0);
+    }
+    store_tiles((st + 1) & 1);
+    __syncthreads();
+  }
+
+  // cross-wave reduction in LDS, then one atomic per output element
+  float* red = s;  // [4 waves][CT*NT][32 rows][32 cols]
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wv * CT * NT + c * NT + t) * 32 + cg_row(r, lane)) * 32 + row] = acc[c][t][r];
+  __syncthreads();
+  const int T = g.ksz * g.ksz;
+  for (int e = tid; e < CT * NT * 1024; e += 256) {
+    const int sub = e >> 10, ci_l = (e >> 5) & 31, co_l = e & 31;
+    const int c = sub / NT, t = sub - c * NT;
+    float v = 0.f;
+#pragma unroll
+    for (int w4 = 0; w4 < 4; ++w4) v += red[(w4 * CT * NT + sub) * 1024 + (e & 1023)];
+    const int ci = ci0 + c * 32 + ci_l, co = co0 + t * 32 + co_l;
+    if (ci < g.Cin && co < g.Cout) evf_atomic_add(gw + ((long)co * g.cin_total + g.cin_off + ci) * T + tap, v);
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float v = bsum[t];
+      v += __shfl_xor(v, 32, 64);
+      const int co = co0 + t * 32 + row;
+      if (kg == 0 && co < g.Cout) evf_atomic_add(gbias + co, v);
+    }
+  }
+}
+
+template <int CT, int NT>
+static void wg_launch(const float* x, const float* gy, float* gw, float* gbias, const WgGeo& g, int ksplit, bool vec4,
+                      hipStream_t st) {
+  const int n_ct = evf_cdiv(g.Cin, 32 * CT), n_nt = evf_cdiv(g.Cout, 32 * NT);
+  dim3 grid(ksplit, n_ct * n_nt, g.ksz * g.ksz), block(256);
+  const size_t stage = 2 * 32 * (32 * CT + 32 * NT) * sizeof(float), red = 4 * CT * NT * 1024 * sizeof(float);
+  const size_t smem = stage > red ? stage : red;
+  if (vec4)
+    hipLaunchKernelGGL((k_conv2d_wgrad_f32<CT, NT, 4>), grid, block, smem, st, x, gy, gw, gbias, g);
+  else
+    hipLaunchKernelGGL((k_conv2d_wgrad_f32<CT, NT, 1>), grid, block, smem, st, x, gy, gw, gbias, g);
+}
+
+// g_w [Cout][cin_total][k][k] (torch layout; this call fills input channels cin_off .. cin_off+Cin) and optional
+// g_bias [Cout]; accumulate = 0 zeroes them first (only allowed when the call covers the whole weight)
+extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int ldg, float* g_w, float* g_bias, int B, int H,
+                                int W, int Cin, int Cout, int ksz, int stride, int cin_total, int cin_off, int accumulate,
+                                void* stream) {
+  if (!x || !g_y || !g_w || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksz != 1 && ksz != 3) ||
+      (stride != 1 && stride != 2) || ldx < Cin || ldg < Cout || cin_off < 0 || cin_off + Cin > cin_total ||
+      (!accumulate && cin_total != Cin))
+    return EVF_EINVAL;
+  hipStream_t st = EVF_STREAM(stream);
+  if (!accumulate) {
+    int rc = evf_hip(hipMemsetAsync(g_w, 0, sizeof(float) * (size_t)Cout * Cin * ksz * ksz, st));
+    if (rc) return rc;
+    if (g_bias && (rc = evf_hip(hipMemsetAsync(g_bias, 0, sizeof(float) * (size_t)Cout, st)))) return rc;
+  }
+  WgGeo g;
+  g.B = B, g.H = H, g.W = W, g.Cin = Cin, g.Cout = Cout, g.ksz = ksz, g.stride = stride, g.ldx = ldx, g.ldg = ldg;
+  g.cin_total = cin_total, g.cin_off = cin_off;
+  g.OH = cg_out_dim(H, ksz, stride), g.OW = cg_out_dim(W, ksz, stride);
+  const long M = (long)B * g.OH * g.OW;
+  const int CT = Cin > 32 ? 2 : 1, NT = Cout > 32 ? 2 : 1;
+  const long tiles = (long)evf_cdiv(Cin, 32 * CT) * evf_cdiv(Cout, 32 * NT) * ksz * ksz;
+  const long st_total = evf_cdiv(M, 32);
+  // enough blocks to fill 256 CUs several times over, at least 8 stages per block
+  long ksplit = evf_cdiv(2048, tiles);
+  if (ksplit > st_total / 8) ksplit = st_total / 8;
+  if (ksplit < 1) ksplit = 1;
+  g.stages = evf_cdiv(st_total, ksplit);
+  ksplit = evf_cdiv(st_total, g.stages);
+  const bool vec4 = Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && ldg % 4 == 0 && ((uintptr_t)x & 15) == 0 &&
+                    ((uintptr_t)g_y & 15) == 0;
+  if (CT == 2 && NT == 2)
+    wg_launch<2, 2>(x, g_y, g_w, g_bias, g, (int)ksplit, vec4, st);
+  else if (CT == 2)
+    wg_launch<2, 1>(x, g_y, g_w, g_bias, g, (int)ksplit, vec4, st);
+  else if (NT == 2)
+    wg_launch<1, 2>(x, g_y, g_w, g_bias, g, (int)ksplit, vec4, st);
+  else
+    wg_launch<1, 1>(x, g_y, g_w, g_bias, g, (int)ksplit, vec4, st);
+  return evf_status();
+}

@@ -1,0 +1,592 @@
+// Element-wise kernels of the general (any channel count, NHWC fp32) path:
+//   * neuron state update + surrogate-gradient backward for the four spiking
+//     cells (reference models/spiking_submodules.py: LIF :96-126/:516-551,
+//     PLIF :191-227/:618-657, ALIF :299-334/:730-768, XLIF :399-435/:836-875)
+//   * pooled pre-synaptic activity of PLIF/XLIF (:212,:418,:642)
+//   * bilinear x2 / nearest xf up-sampling (spiking_submodules.py:1011,
+//     models/model.py:529-539), tanh / sigmoid / relu, ConvGRU gate algebra
+//     (models/submodules.py:400-418)
+// All HBM bound: one float4 (4 channels of one pixel) per thread, per-channel
+// parameter gradients reduced per block in LDS, then one atomic per channel.
+#include "evf_common.h"
+
+__device__ __forceinline__ float ng_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float ng_surrogate(int kind, float x, float width) {
+  // models/spiking_util.py:38-43 (superspike), :55-65 (multi-gauss), :74-79 (triangle), :88-93 (arctan)
+  switch (kind) {
+    case EVF_SUPERSPIKE: {
+      const float d = 1.0f + width * fabsf(x);
+      return 1.0f / (d * d);
+    }
+    case EVF_TRIANGLE:
+      return fmaxf(0.f, 1.0f - width * fabsf(x));
+    case EVF_MULTIGAUSS: {
+      const float s1 = width, s2 = 6.f * width;
+      const float k = 0.3989422804014327f;  // 1/sqrt(2*pi)
+      auto gs = [&](float v, float mu, float sg) { return expf(-((v - mu) * (v - mu)) / (2.f * sg * sg)) / sg * k; };
+      return 1.15f * gs(x, 0.f, s1) - 0.15f * gs(x, width, s2) - 0.15f * gs(x, -width, s2);
+    }
+    default:
+      return 1.0f / (1.0f + width * x * x);
+  }
+}
+
+struct NgParams {
+  const float* p[4];
+  float* g[4];
+};
+// parameter slots per kind:
+//   LIF : p0 leak      p1 thresh
+//   PLIF: p0 leak_v    p1 thresh   p2 leak_pt  p3 add_pt
+//   ALIF: p0 leak_v    p1 t0       p2 t1       p3 leak_t
+//   XLIF: p0 leak_v    p1 t0       p2 t1       p3 leak_pt
+
+__device__ __forceinline__ float4 ng_ld(const float4* p, long e) { return p ? p[e] : make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int KIND>
+__global__ void k_neuron_fwd(const float4* __restrict__ cur, const float4* __restrict__ v_prev,
+                             const float4* __restrict__ z_prev, const float4* __restrict__ aux_prev,
+                             const float* __restrict__ P, const float4* __restrict__ residual, NgParams prm, long npix, int C,
+                             int hard, float4* __restrict__ v_out, float4* __restrict__ z_out, float4* __restrict__ aux_out,
+                             float4* __restrict__ out) {
+  const int Q = C >> 2;
+  const long total = npix * Q, stride = (long)gridDim.x * blockDim.x;
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int cq = (int)(e % Q);
+  float lam[4], a1[4], a2[4], a3[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = 4 * cq + k;
+    lam[k] = ng_sigmoid(prm.p[0][c]);
+    a1[k] = fmaxf(prm.p[1][c], 0.01f);  // thresh / t0 .clamp_min(0.01)
+    if (KIND == EVF_PLIF) a2[k] = ng_sigmoid(prm.p[2][c]), a3[k] = ng_sigmoid(prm.p[3][c]);
+    if (KIND == EVF_ALIF || KIND == EVF_XLIF) a2[k] = fmaxf(prm.p[2][c], 0.f), a3[k] = ng_sigmoid(prm.p[3][c]);
+  }
+  for (; e < total; e += stride) {
+    const long pix = e / Q;
+    const float4 c4 = cur[e], v4 = ng_ld(v_prev, e), z4 = ng_ld(z_prev, e), x4 = ng_ld(aux_prev, e);
+    const float Pv = (KIND == EVF_PLIF || KIND == EVF_XLIF) ? P[pix] : 0.f;
+    const float cu[4] = {c4.x, c4.y, c4.z, c4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w}, z[4] = {z4.x, z4.y, z4.z, z4.w};
+    const float ax[4] = {x4.x, x4.y, x4.z, x4.w};
+    float vo[4], zo[4], ao[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float th = a1[k], c = cu[k], soft_th = a1[k];
+      if (KIND == EVF_PLIF) {
+        ao[k] = ax[k] * a2[k] + (1.0f - a2[k]) * Pv;  // pt' (:212)
+        c = c - a3[k] * ao[k];                         // ff [+ rec] - add_pt * pt' (:220)
+      } else if (KIND == EVF_ALIF) {
+        ao[k] = ax[k] * a3[k] + (1.0f - a3[k]) * z[k];  // t' (:317)
+        th = a1[k] + a2[k] * ao[k];                      // t0 + t1 * t' (:319)
+        soft_th = a1[k] + a2[k] * ax[k];                 // soft reset uses the OLD trace (:329)
+      } else if (KIND == EVF_XLIF) {
+        ao[k] = ax[k] * a3[k] + (1.0f - a3[k]) * Pv;  // pt' (:418)
+        th = a1[k] + a2[k] * ao[k];
+        soft_th = a1[k] + a2[k] * ax[k];
+      }
+      if (hard)
+        vo[k] = v[k] * lam[k] * (1.0f - z[k]) + (1.0f - lam[k]) * c;
+      else
+        vo[k] = v[k] * lam[k] + (1.0f - lam[k]) * c - z[k] * soft_th;
+      zo[k] = (vo[k] - th) > 0.f ? 1.0f : 0.f;
+    }
+    v_out[e] = make_float4(vo[0], vo[1], vo[2], vo[3]);
+    z_out[e] = make_float4(zo[0], zo[1], zo[2], zo[3]);
+    if (KIND != EVF_LIF) aux_out[e] = make_float4(ao[0], ao[1], ao[2], ao[3]);
+    if (out) {
+      const float4 r4 = ng_ld(residual, e);
+      out[e] = make_float4(zo[0] + r4.x, zo[1] + r4.y, zo[2] + r4.z, zo[3] + r4.w);
+    }
+  }
+}
+
+// blockDim is a multiple of Q = C/4 so that a thread keeps its channel quad over the grid-stride loop
+static int ng_block(int Q) { return Q >= 256 ? 256 : (256 / Q) * Q; }
+
+extern "C" int evf_neuron_fwd(int kind, const float* cur, const float* v_prev, const float* z_prev, const float* aux_prev,
+                              const float* P, const float* residual, const float* p0, const float* p1, const float* p2,
+                              const float* p3, int64_t npix, int C, int hard_reset, float* v_out, float* z_out,
+                              float* aux_out, float* out, void* stream) {
+  if (!cur || !p0 || !p1 || !v_out || !z_out || npix <= 0 || C <= 0 || (C & 3) || C > 1024 || kind < 0 || kind > 3)
+    return EVF_EINVAL;
+  if (kind != EVF_LIF && (!p2 || !p3 || !aux_out)) return EVF_EINVAL;
+  if ((kind == EVF_PLIF || kind == EVF_XLIF) && !P) return EVF_EINVAL;
+  NgParams prm = {{p0, p1, p2, p3}, {nullptr, nullptr, nullptr, nullptr}};
+  const int Q = C >> 2, bs = ng_block(Q);
+  const long total = npix * Q;
+  const int nblk = (int)((total + bs - 1) / bs < 4096 ? (total + bs - 1) / bs : 4096);
+#define NG_FWD(K)                                                                                                       \
+  hipLaunchKernelGGL(k_neuron_fwd<K>, dim3(nblk), dim3(bs), 0, EVF_STREAM(stream), (const float4*)cur,                  \
+                     (const float4*)v_prev, (const float4*)z_prev, (const float4*)aux_prev, P, (const float4*)residual, \
+                     prm, (long)npix, C, hard_reset, (float4*)v_out, (float4*)z_out, (float4*)aux_out, (float4*)out)
+  switch (kind) {
+    case EVF_LIF: NG_FWD(EVF_LIF); break;
+    case EVF_PLIF: NG_FWD(EVF_PLIF); break;
+    case EVF_ALIF: NG_FWD(EVF_ALIF); break;
+    default: NG_FWD(EVF_XLIF); break;
+  }
+#undef NG_FWD
+  return evf_status();
+}
+
+// backward.  Saved: v_out, aux_out, v_prev, z_prev, aux_prev, P.  Upstream: g_v_out (state carry),
+// g_z_out + g_z_out2 (through the layer output and through the z entry of the state), g_aux_out (trace carry).
+// g_P [npix] = d loss / d pooled activity (PLIF/XLIF), g_z_prev only for ALIF (threshold trace reads z).
+template <int KIND>
+__global__ void k_neuron_bwd(const float4* __restrict__ g_v_out, const float4* __restrict__ g_z_out,
+                             const float4* __restrict__ g_z_out2, const float4* __restrict__ g_aux_out, const float4* __restrict__ v_out,
+                             const float4* __restrict__ aux_out, const float4* __restrict__ v_prev,
+                             const float4* __restrict__ z_prev, const float4* __restrict__ aux_prev,
+                             const float* __restrict__ P, NgParams prm, long npix, int C, int hard, int surrogate,
+                             float width, float4* __restrict__ g_cur, float4* __restrict__ g_v_prev,
+                             float4* __restrict__ g_z_prev, float4* __restrict__ g_aux_prev, float* __restrict__ g_P) {
+  extern __shared__ float s_acc[];  // [4][C]
+  const int Q = C >> 2;
+  const long total = npix * Q, stride = (long)gridDim.x * blockDim.x;
+  for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) s_acc[i] = 0.f;
+  __syncthreads();
+  const long gtid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cq = (int)(gtid % Q);
+  float lam[4], a1[4], a2[4], a3[4], m1[4], m2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = 4 * cq + k;
+    lam[k] = ng_sigmoid(prm.p[0][c]);
+    a1[k] = fmaxf(prm.p[1][c], 0.01f);
+    m1[k] = prm.p[1][c] >= 0.01f ? 1.f : 0.f;  // clamp_min passes the gradient where p >= min
+    a2[k] = a3[k] = m2[k] = 0.f;
+    if (KIND == EVF_PLIF) a2[k] = ng_sigmoid(prm.p[2][c]), a3[k] = ng_sigmoid(prm.p[3][c]);
+    if (KIND == EVF_ALIF || KIND == EVF_XLIF) {
+      a2[k] = fmaxf(prm.p[2][c], 0.f), a3[k] = ng_sigmoid(prm.p[3][c]);
+      m2[k] = prm.p[2][c] >= 0.f ? 1.f : 0.f;
+    }
+  }
+  float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, s3[4] = {0, 0, 0, 0};
+  const int tpp = Q < 64 ? Q : 64;  // threads of one pixel inside a wave (Q is then a power of two <= 64) -- see host check
+  for (long base = 0; base < total; base += stride) {  // uniform trip count: the pixel reduction shuffles
+    const long e = base + gtid;
+    const bool ok = e < total;
+    const long ec = ok ? e : total - 1, pix = ec / Q;
+    const float4 gv4 = ng_ld(g_v_out, ec), gza = ng_ld(g_z_out, ec), gzb = ng_ld(g_z_out2, ec), ga4 = ng_ld(g_aux_out, ec);
+    const float4 gz4 = make_float4(gza.x + gzb.x, gza.y + gzb.y, gza.z + gzb.z, gza.w + gzb.w);
+    const float4 vo4 = v_out[ec], v4 = ng_ld(v_prev, ec), z4 = ng_ld(z_prev, ec), x4 = ng_ld(aux_prev, ec);
+    const float4 ao4 = (KIND != EVF_LIF) ? aux_out[ec] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float Pv = (KIND == EVF_PLIF || KIND == EVF_XLIF) ? P[pix] : 0.f;
+    const float gvo[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, gz[4] = {gz4.x, gz4.y, gz4.z, gz4.w};
+    const float ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w}, vo[4] = {vo4.x, vo4.y, vo4.z, vo4.w};
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w}, z[4] = {z4.x, z4.y, z4.z, z4.w};
+    const float ax[4] = {x4.x, x4.y, x4.z, x4.w}, ao[4] = {ao4.x, ao4.y, ao4.z, ao4.w};
+    float gc[4], gp[4], gzp[4], gap[4], gPp = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float oml = 1.0f - lam[k];
+      float th = a1[k], soft_th = a1[k];
+      if (KIND == EVF_ALIF || KIND == EVF_XLIF) th = a1[k] + a2[k] * ao[k], soft_th = a1[k] + a2[k] * ax[k];
+      const float sg = ng_surrogate(surrogate, vo[k] - th, width);
+      const float gsp = gz[k] * sg;   // d z'/d(v' - th)
+      const float G = gvo[k] + gsp;   // total gradient on v'
+      const float gth = -gsp;         // on the threshold used by the spike function
+      float cT, dlam, gsoft = 0.f;
+      if (hard) {
+        gp[k] = G * lam[k] * (1.0f - z[k]);  // z detached in the reset
+        cT = (vo[k] - (v[k] * lam[k]) * (1.0f - z[k])) / oml;
+        dlam = v[k] * (1.0f - z[k]) - cT;
+      } else {
+        gp[k] = G * lam[k];
+        cT = (vo[k] - v[k] * lam[k] + z[k] * soft_th) / oml;
+        dlam = v[k] - cT;
+        gsoft = -z[k] * G;  // gradient on the soft-reset threshold
+      }
+      const float gcT = G * oml;
+      gc[k] = gcT;
+      gzp[k] = 0.f, gap[k] = 0.f;
+      if (ok) s0[k] += G * dlam;
+      if (KIND == EVF_LIF) {
+        if (ok) s1[k] += gth + gsoft;
+      } else if (KIND == EVF_PLIF) {
+        const float gpt = ga[k] - a3[k] * gcT;  // on pt'
+        gap[k] = gpt * a2[k];
+        gPp += gpt * (1.0f - a2[k]);
+        if (ok) {
+          s1[k] += gth + gsoft;
+          s2[k] += gpt * (ax[k] - Pv);  // d pt'/d sigma(leak_pt)
+          s3[k] -= gcT * ao[k];          // d / d sigma(add_pt)
+        }
+      } else {  // ALIF / XLIF: th = t0 + t1 * trace'
+        const float gtr = ga[k] + gth * a2[k];                 // on trace'
+        gap[k] = gtr * a3[k] + gsoft * a2[k];                  // on the old trace (soft reset reads it)
+        const float drive = (KIND == EVF_ALIF) ? z[k] : Pv;    // what the trace integrates
+        if (KIND == EVF_ALIF) gzp[k] = gtr * (1.0f - a3[k]);
+        else gPp += gtr * (1.0f - a3[k]);
+        if (ok) {
+          s1[k] += gth + gsoft;                       // t0
+          s2[k] += gth * ao[k] + gsoft * ax[k];       // t1
+          s3[k] += gtr * (ax[k] - drive);             // sigma(leak_t / leak_pt)
+        }
+      }
+    }
+    if (ok) {
+      g_cur[e] = make_float4(gc[0], gc[1], gc[2], gc[3]);
+      g_v_prev[e] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+      if (KIND != EVF_LIF) g_aux_prev[e] = make_float4(gap[0], gap[1], gap[2], gap[3]);
+      if (KIND == EVF_ALIF) g_z_prev[e] = make_float4(gzp[0], gzp[1], gzp[2], gzp[3]);
+    }
+    if (KIND == EVF_PLIF || KIND == EVF_XLIF) {
+      if (Q <= 64) {
+        // the Q threads of a pixel are consecutive lanes of one wave
+        for (int o = 1; o < tpp; o <<= 1) gPp += __shfl_xor(gPp, o, 64);
+        if (ok && cq == 0) g_P[pix] = gPp;
+      } else if (ok) {
+        evf_atomic_add(g_P + pix, gPp);  // g_P zeroed by the host wrapper
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = 4 * cq + k;
+    atomicAdd(&s_acc[0 * C + c], s0[k] * lam[k] * (1.0f - lam[k]));
+    atomicAdd(&s_acc[1 * C + c], s1[k] * m1[k]);
+    if (KIND == EVF_PLIF) {
+      atomicAdd(&s_acc[2 * C + c], s2[k] * a2[k] * (1.0f - a2[k]));
+      atomicAdd(&s_acc[3 * C + c], s3[k] * a3[k] * (1.0f - a3[k]));
+    } else if (KIND != EVF_LIF) {
+      atomicAdd(&s_acc[2 * C + c], s2[k] * m2[k]);
+      atomicAdd(&s_acc[3 * C + c], s3[k] * a3[k] * (1.0f - a3[k]));
+    }
+  }
+  __syncthreads();
+  const int np = KIND == EVF_LIF ? 2 : 4;
+  for (int i = threadIdx.x; i < np * C; i += blockDim.x) {
+    const int p = i / C, c = i - p * C;
+    if (prm.g[p]) evf_atomic_add(prm.g[p] + c, s_acc[i]);
+  }
+}
+
+extern "C" int evf_neuron_bwd(int kind, const float* g_v_out, const float* g_z_out, const float* g_z_out2,
+                              const float* g_aux_out,
+                              const float* v_out, const float* aux_out, const float* v_prev, const float* z_prev,
+                              const float* aux_prev, const float* P, const float* p0, const float* p1, const float* p2,
+                              const float* p3, int64_t npix, int C, int hard_reset, int surrogate, float act_width,
+                              float* g_cur, float* g_v_prev, float* g_z_prev, float* g_aux_prev, float* g_P, float* g_p0,
+                              float* g_p1, float* g_p2, float* g_p3, void* stream) {
+  if (!v_out || !p0 || !p1 || !g_cur || !g_v_prev || npix <= 0 || C <= 0 || (C & 3) || C > 1024 || kind < 0 || kind > 3)
+    return EVF_EINVAL;
+  const int Q = C >> 2;
+  if (Q < 64 && (Q & (Q - 1))) return EVF_EINVAL;  // the in-wave pixel reduction needs a power of two
+  if (kind != EVF_LIF && (!p2 || !p3 || !aux_out || !g_aux_prev)) return EVF_EINVAL;
+  if ((kind == EVF_PLIF || kind == EVF_XLIF) && (!P || !g_P)) return EVF_EINVAL;
+  if (kind == EVF_ALIF && !g_z_prev) return EVF_EINVAL;
+  hipStream_t st = EVF_STREAM(stream);
+  if ((kind == EVF_PLIF || kind == EVF_XLIF) && Q > 64) {
+    const int rc = evf_hip(hipMemsetAsync(g_P, 0, sizeof(float) * (size_t)npix, st));
+    if (rc) return rc;
+  }
+  NgParams prm = {{p0, p1, p2, p3}, {g_p0, g_p1, g_p2, g_p3}};
+  const int bs = ng_block(Q);
+  const long total = npix * Q;
+  const int nblk = (int)((total + bs - 1) / bs < 1024 ? (total + bs - 1) / bs : 1024);
+  const size_t smem = sizeof(float) * 4 * (size_t)C;
+#define NG_BWD(K)                                                                                                          \
+  hipLaunchKernelGGL(k_neuron_bwd<K>, dim3(nblk), dim3(bs), smem, st, (const float4*)g_v_out, (const float4*)g_z_out,      \
+                     (const float4*)g_z_out2, (const float4*)g_aux_out, (const float4*)v_out, (const float4*)aux_out, (const float4*)v_prev,        \
+                     (const float4*)z_prev, (const float4*)aux_prev, P, prm, (long)npix, C, hard_reset, surrogate,         \
+                     act_width, (float4*)g_cur, (float4*)g_v_prev, (float4*)g_z_prev, (float4*)g_aux_prev, g_P)
+  switch (kind) {
+    case EVF_LIF: NG_BWD(EVF_LIF); break;
+    case EVF_PLIF: NG_BWD(EVF_PLIF); break;
+    case EVF_ALIF: NG_BWD(EVF_ALIF); break;
+    default: NG_BWD(EVF_XLIF); break;
+  }
+#undef NG_BWD
+  return evf_status();
+}
+
+// ---------------------------------------------------------------------------
+// pooled pre-synaptic activity: P = AvgPool_k(mean_c |x|), stride s, pad k/2,
+// count_include_pad (F.avg_pool2d default).  spiking_submodules.py:212
+// ---------------------------------------------------------------------------
+__global__ void k_absmean(const float* __restrict__ x, long npix, int C, int ld, float* __restrict__ m) {
+  // one wave per pixel group: tpp lanes share one pixel
+  const int tpp = C >= 64 ? 64 : (C >= 32 ? 32 : (C >= 16 ? 16 : (C >= 8 ? 8 : (C >= 4 ? 4 : (C >= 2 ? 2 : 1)))));
+  const int ppw = 64 / tpp, lane = threadIdx.x & 63, sub = lane % tpp;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long pix = wave * ppw + lane / tpp;
+  const bool ok = pix < npix;
+  const float* p = x + (ok ? pix : npix - 1) * ld;
+  float s = 0.f;
+  for (int c = sub; c < C; c += tpp) s += fabsf(p[c]);
+  for (int o = 1; o < tpp; o <<= 1) s += __shfl_xor(s, o, 64);
+  if (ok && sub == 0) m[pix] = s / (float)C;
+}
+
+__global__ void k_boxpool(const float* __restrict__ m, int B, int H, int W, int OH, int OW, int ksz, int stride,
+                          float* __restrict__ P) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * OH * OW) return;
+  const int ox = (int)(idx % OW), oy = (int)((idx / OW) % OH), b = (int)(idx / ((long)OW * OH)), pad = ksz >> 1;
+  float s = 0.f;
+  for (int dy = 0; dy < ksz; ++dy)
+    for (int dx = 0; dx < ksz; ++dx) {
+      const int yy = oy * stride + dy - pad, xx = ox * stride + dx - pad;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) s += m[((long)b * H + yy) * W + xx];
+    }
+  P[idx] = s / (float)(ksz * ksz);
+}
+
+extern "C" int evf_pretrace_fwd(const float* x, int ldx, int B, int H, int W, int C, int ksz, int stride, float* absmean_ws,
+                                float* P, void* stream) {
+  if (!x || !absmean_ws || !P || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (ksz != 1 && ksz != 3) || stride < 1)
+    return EVF_EINVAL;
+  const long npix = (long)B * H * W;
+  const int tpp = C >= 64 ? 64 : (C >= 32 ? 32 : (C >= 16 ? 16 : (C >= 8 ? 8 : (C >= 4 ? 4 : (C >= 2 ? 2 : 1)))));
+  const long waves = (npix + (64 / tpp) - 1) / (64 / tpp);
+  hipLaunchKernelGGL(k_absmean, dim3(evf_cdiv(waves * 64, 256)), dim3(256), 0, EVF_STREAM(stream), x, npix, C, ldx,
+                     absmean_ws);
+  const int OH = (H + 2 * (ksz >> 1) - ksz) / stride + 1, OW = (W + 2 * (ksz >> 1) - ksz) / stride + 1;
+  hipLaunchKernelGGL(k_boxpool, dim3(evf_cdiv((long)B * OH * OW, 256)), dim3(256), 0, EVF_STREAM(stream), absmean_ws, B, H,
+                     W, OH, OW, ksz, stride, P);
+  return evf_status();
+}
+
+// g_x[pix][c] (+)= sign(x) / C * sum_{windows covering pix} g_P[o] / k^2
+__global__ void k_pretrace_bwd(const float* __restrict__ x, int ldx, const float* __restrict__ g_P, int B, int H, int W,
+                               int C, int OH, int OW, int ksz, int stride, float* __restrict__ g_x, int ldg,
+                               int accumulate) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * H * W * C;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const long pix = idx / C;
+  const int xx = (int)(pix % W), yy = (int)((pix / W) % H), b = (int)(pix / ((long)W * H)), pad = ksz >> 1;
+  float s = 0.f;
+  for (int dy = 0; dy < ksz; ++dy)
+    for (int dx = 0; dx < ksz; ++dx) {
+      const int ty = yy + pad - dy, tx = xx + pad - dx;
+      if (ty < 0 || tx < 0 || ty % stride || tx % stride) continue;
+      const int oy = ty / stride, ox = tx / stride;
+      if (oy < OH && ox < OW) s += g_P[((long)b * OH + oy) * OW + ox];
+    }
+  const float xv = x[pix * ldx + c];
+  const float sgn = xv > 0.f ? 1.f : (xv < 0.f ? -1.f : 0.f);
+  const float v = sgn * (s / (float)(ksz * ksz)) / (float)C;
+  float* d = g_x + pix * ldg + c;
+  *d = accumulate ? *d + v : v;
+}
+
+extern "C" int evf_pretrace_bwd(const float* x, int ldx, const float* g_P, int B, int H, int W, int C, int ksz, int stride,
+                                float* g_x, int ldg, int accumulate, void* stream) {
+  if (!x || !g_P || !g_x || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (ksz != 1 && ksz != 3) || stride < 1) return EVF_EINVAL;
+  const int OH = (H + 2 * (ksz >> 1) - ksz) / stride + 1, OW = (W + 2 * (ksz >> 1) - ksz) / stride + 1;
+  const long total = (long)B * H * W * C;
+  hipLaunchKernelGGL(k_pretrace_bwd, dim3(evf_cdiv(total, 256)), dim3(256), 0, EVF_STREAM(stream), x, ldx, g_P, B, H, W, C,
+                     OH, OW, ksz, stride, g_x, ldg, accumulate);
+  return evf_status();
+}
+
+// ---------------------------------------------------------------------------
+// bilinear x2 up-sampling, align_corners = False (F.interpolate default),
+// NHWC.  spiking_submodules.py:1011 / submodules.py:149
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void up2_src(int o, int n, int& i0, int& i1, float& w1) {
+  float s = 0.5f * ((float)o + 0.5f) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i1 = i0 + (i0 < n - 1 ? 1 : 0);
+  w1 = s - (float)i0;
+}
+
+// one thread = one channel of one pixel (any C); the 4 / 16 taps of neighbouring threads hit the same lines
+__global__ void k_up2_fwd(const float* __restrict__ x, int B, int H, int W, int C, float* __restrict__ y) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int OH = 2 * H, OW = 2 * W;
+  if (idx >= (long)B * OH * OW * C) return;
+  const int q = (int)(idx % C);
+  const long pix = idx / C;
+  const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((long)OW * OH));
+  int y0, y1, x0, x1;
+  float wy, wx;
+  up2_src(oy, H, y0, y1, wy);
+  up2_src(ox, W, x0, x1, wx);
+  const float a = x[(((long)b * H + y0) * W + x0) * C + q], bq = x[(((long)b * H + y0) * W + x1) * C + q];
+  const float c = x[(((long)b * H + y1) * W + x0) * C + q], d = x[(((long)b * H + y1) * W + x1) * C + q];
+  // same association as ATen's upsample_bilinear2d: h0 (w0 a + w1 b) + h1 (w0 c + w1 d)
+  y[idx] = (1.f - wy) * ((1.f - wx) * a + wx * bq) + wy * ((1.f - wx) * c + wx * d);
+}
+
+// gather form of the transpose: input pixel iy receives from output rows 2iy-1 .. 2iy+2
+__global__ void k_up2_bwd(const float* __restrict__ gy, int B, int H, int W, int C, float* __restrict__ gx) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * H * W * C) return;
+  const int OH = 2 * H, OW = 2 * W;
+  const int q = (int)(idx % C);
+  const long pix = idx / C;
+  const int ix = (int)(pix % W), iy = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+  float acc = 0.f;
+  for (int oy = 2 * iy - 1; oy <= 2 * iy + 2; ++oy) {
+    if (oy < 0 || oy >= OH) continue;
+    int y0, y1;
+    float wy;
+    up2_src(oy, H, y0, y1, wy);
+    const float cy = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);
+    if (cy == 0.f) continue;
+    for (int ox = 2 * ix - 1; ox <= 2 * ix + 2; ++ox) {
+      if (ox < 0 || ox >= OW) continue;
+      int x0, x1;
+      float wx;
+      up2_src(ox, W, x0, x1, wx);
+      const float cx = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
+      if (cx == 0.f) continue;
+      acc += (cy * cx) * gy[(((long)b * OH + oy) * OW + ox) * C + q];
+    }
+  }
+  gx[idx] = acc;
+}
+
+extern "C" int evf_upsample2x_fwd(const float* x, int B, int H, int W, int C, float* y, void* stream) {
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return EVF_EINVAL;
+  const long total = (long)B * 4 * H * W * C;
+  hipLaunchKernelGGL(k_up2_fwd, dim3(evf_cdiv(total, 256)), dim3(256), 0, EVF_STREAM(stream), x, B, H, W, C, y);
+  return evf_status();
+}
+
+extern "C" int evf_upsample2x_bwd(const float* g_y, int B, int H, int W, int C, float* g_x, void* stream) {
+  if (!g_y || !g_x || B <= 0 || H <= 0 || W <= 0 || C <= 0) return EVF_EINVAL;
+  const long total = (long)B * H * W * C;
+  hipLaunchKernelGGL(k_up2_bwd, dim3(evf_cdiv(total, 256)), dim3(256), 0, EVF_STREAM(stream), g_y, B, H, W, C, g_x);
+  return evf_status();
+}
+
+// nearest up-sampling by an integer factor of planes [n][h][w] (flow maps, NCHW): models/model.py:529-539
+__global__ void k_upnear_fwd(const float* __restrict__ x, long n, int h, int w, int f, float* __restrict__ y) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int OW = w * f, OH = h * f;
+  if (idx >= n * OH * OW) return;
+  const int ox = (int)(idx % OW), oy = (int)((idx / OW) % OH);
+  const long p = idx / ((long)OW * OH);
+  y[idx] = x[(p * h + oy / f) * w + ox / f];
+}
+__global__ void k_upnear_bwd(const float* __restrict__ gy, long n, int h, int w, int f, float* __restrict__ gx) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * h * w) return;
+  const int ix = (int)(idx % w), iy = (int)((idx / w) % h);
+  const long p = idx / ((long)w * h);
+  const int OW = w * f, OH = h * f;
+  float s = 0.f;
+  for (int dy = 0; dy < f; ++dy)
+    for (int dx = 0; dx < f; ++dx) s += gy[(p * OH + iy * f + dy) * OW + ix * f + dx];
+  gx[idx] = s;
+}
+extern "C" int evf_upsample_nearest_fwd(const float* x, int64_t planes, int h, int w, int factor, float* y, void* stream) {
+  if (!x || !y || planes <= 0 || h <= 0 || w <= 0 || factor < 1) return EVF_EINVAL;
+  const long total = planes * h * w * factor * factor;
+  hipLaunchKernelGGL(k_upnear_fwd, dim3(evf_cdiv(total, 256)), dim3(256), 0, EVF_STREAM(stream), x, (long)planes, h, w,
+                     factor, y);
+  return evf_status();
+}
+extern "C" int evf_upsample_nearest_bwd(const float* g_y, int64_t planes, int h, int w, int factor, float* g_x,
+                                        void* stream) {
+  if (!g_y || !g_x || planes <= 0 || h <= 0 || w <= 0 || factor < 1) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_upnear_bwd, dim3(evf_cdiv(planes * h * w, 256)), dim3(256), 0, EVF_STREAM(stream), g_y,
+                     (long)planes, h, w, factor, g_x);
+  return evf_status();
+}
+
+// ---------------------------------------------------------------------------
+// activations and ConvGRU gate algebra (flat element-wise)
+// ---------------------------------------------------------------------------
+// kind: 0 identity, 1 tanh, 2 sigmoid, 3 relu.   y = act(x [+ r])
+__global__ void k_act_fwd(int kind, const float* x, const float* __restrict__ r, long n, float* y) {  // y may alias x
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = x[i] + (r ? r[i] : 0.f);
+  if (kind == 1) v = tanhf(v);
+  else if (kind == 2) v = 1.0f / (1.0f + expf(-v));
+  else if (kind == 3) v = fmaxf(v, 0.f);
+  y[i] = v;
+}
+// g_x = g_y * act'(.) expressed through the output y
+__global__ void k_act_bwd(int kind, const float* __restrict__ y, const float* __restrict__ gy, long n, float* __restrict__ gx) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float o = y[i];
+  float d = 1.f;
+  if (kind == 1) d = 1.0f - o * o;
+  else if (kind == 2) d = o * (1.0f - o);
+  else if (kind == 3) d = o > 0.f ? 1.f : 0.f;
+  gx[i] = gy[i] * d;
+}
+extern "C" int evf_act_fwd(int kind, const float* x, const float* residual, int64_t n, float* y, void* stream) {
+  if (!x || !y || n <= 0 || kind < 0 || kind > 3) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_act_fwd, dim3(evf_cdiv(n, 256)), dim3(256), 0, EVF_STREAM(stream), kind, x, residual, (long)n, y);
+  return evf_status();
+}
+extern "C" int evf_act_bwd(int kind, const float* y, const float* g_y, int64_t n, float* g_x, void* stream) {
+  if (!y || !g_y || !g_x || n <= 0 || kind < 0 || kind > 3) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_act_bwd, dim3(evf_cdiv(n, 256)), dim3(256), 0, EVF_STREAM(stream), kind, y, g_y, (long)n, g_x);
+  return evf_status();
+}
+
+// ConvGRU (submodules.py:412-416).  Stage 1: u = sigmoid(cu), r = sigmoid(cr), hr = h * r.
+// Stage 2: o = tanh(co), new = h * (1 - u) + o * u.
+__global__ void k_gru_gates_fwd(const float* __restrict__ cu, const float* __restrict__ cr, const float* __restrict__ h,
+                                long n, float* __restrict__ u, float* __restrict__ r, float* __restrict__ hr) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float uu = 1.0f / (1.0f + expf(-cu[i])), rr = 1.0f / (1.0f + expf(-cr[i]));
+  u[i] = uu, r[i] = rr, hr[i] = (h ? h[i] : 0.f) * rr;
+}
+__global__ void k_gru_out_fwd(const float* __restrict__ co, const float* __restrict__ h, const float* __restrict__ u, long n,
+                              float* __restrict__ o, float* __restrict__ hn) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float oo = tanhf(co[i]), hh = h ? h[i] : 0.f;
+  o[i] = oo, hn[i] = hh * (1.0f - u[i]) + oo * u[i];
+}
+// backward of stage 2: g_new -> g_co, g_u (pre-sigmoid: g_cu), partial g_h
+__global__ void k_gru_out_bwd(const float* __restrict__ g_new, const float* __restrict__ h, const float* __restrict__ u,
+                              const float* __restrict__ o, long n, float* __restrict__ g_co, float* __restrict__ g_cu,
+                              float* __restrict__ g_h) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g = g_new[i], uu = u[i], oo = o[i], hh = h ? h[i] : 0.f;
+  g_co[i] = g * uu * (1.0f - oo * oo);
+  g_cu[i] = g * (oo - hh) * uu * (1.0f - uu);
+  g_h[i] = g * (1.0f - uu);
+}
+// backward of stage 1: g_hr (from the out-gate conv) -> g_cr, g_h += g_hr * r
+__global__ void k_gru_gates_bwd(const float* __restrict__ g_hr, const float* __restrict__ h, const float* __restrict__ r,
+                                long n, float* __restrict__ g_cr, float* __restrict__ g_h) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g = g_hr[i], rr = r[i], hh = h ? h[i] : 0.f;
+  g_cr[i] = g * hh * rr * (1.0f - rr);
+  g_h[i] += g * rr;
+}
+extern "C" int evf_gru_gates_fwd(const float* cu, const float* cr, const float* h, int64_t n, float* u, float* r, float* hr,
+                                 void* stream) {
+  if (!cu || !cr || !u || !r || !hr || n <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_gru_gates_fwd, dim3(evf_cdiv(n, 256)), dim3(256), 0, EVF_STREAM(stream), cu, cr, h, (long)n, u, r, hr);
+  return evf_status();
+}
+extern "C" int evf_gru_out_fwd(const float* co, const float* h, const float* u, int64_t n, float* o, float* h_new,
+                               void* stream) {
+  if (!co || !u || !o || !h_new || n <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_gru_out_fwd, dim3(evf_cdiv(n, 256)), dim3(256), 0, EVF_STREAM(stream), co, h, u, (long)n, o, h_new);
+  return evf_status();
+}
+extern "C" int evf_gru_out_bwd(const float* g_new, const float* h, const float* u, const float* o, int64_t n, float* g_co,
+                               float* g_cu, float* g_h, void* stream) {
+  if (!g_new || !u || !o || !g_co || !g_cu || !g_h || n <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_gru_out_bwd, dim3(evf_cdiv(n, 256)), dim3(256), 0, EVF_STREAM(stream), g_new, h, u, o, (long)n, g_co,
+                     g_cu, g_h);
+  return evf_status();
+}
+extern "C" int evf_gru_gates_bwd(const float* g_hr, const float* h, const float* r, int64_t n, float* g_cr, float* g_h,
+                                 void* stream) {
+  if (!g_hr || !r || !g_cr || !g_h || n <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_gru_gates_bwd, dim3(evf_cdiv(n, 256)), dim3(256), 0, EVF_STREAM(stream), g_hr, h, r, (long)n, g_cr,
+                     g_h);
+  return evf_status();
+}

@@ -450,10 +450,3 @@ class FireNetEngine:
             grads.append(g.to(p.dtype))
         self._last_window = win
         return grads
-
-
-def single_cell_forward(cell, input_, prev_state, residual=0):
-    raise NotImplementedError(
-        "stand-alone spiking cell calls are not wired yet: use the FireNet-family models (models/model.py), "
-        "whose forward runs every cell through libevflow_hip.so"
-    )

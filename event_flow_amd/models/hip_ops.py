@@ -1,0 +1,447 @@
+"""autograd nodes of the general path: every layer that is not one of the fused
+32->32 FireNet kernels (models/engine.py) runs through these.  Each node is a
+`torch.autograd.Function` whose forward and backward are calls into
+libevflow_hip.so (include/evflow.h, "general path"); torch provides device
+memory, the stream and the tape -- no torch arithmetic.
+
+Tensors cross the node boundary in the reference's logical NCHW shape; in
+memory they are NHWC (`channels_last` strides), which is what the kernels read.
+A node output feeds the next node without a copy; only foreign NCHW-contiguous
+inputs are transposed once (evf_nchw_to_nhwc).
+
+Reference semantics implemented here:
+  spiking cell step   models/spiking_submodules.py:96-126,191-227,299-334,399-435
+                      (+ recurrent :516-551,618-657,730-768,836-875)
+  ConvLayer / ConvLayer_  models/submodules.py:52-61,69-83
+  ConvGRU             models/submodules.py:400-418
+  bilinear x2         models/spiking_submodules.py:1011
+  nearest xf          models/model.py:529-539
+"""
+
+import weakref
+
+import torch
+
+from .. import _lib
+from .spiking_util import SURROGATE_ID
+
+KIND_ID = {"lif": 0, "plif": 1, "alif": 2, "xlif": 3}
+ACT_ID = {None: 0, "tanh": 1, "sigmoid": 2, "relu": 3}
+
+
+# ---------------------------------------------------------------------------
+# layout helpers (memory plumbing only)
+# ---------------------------------------------------------------------------
+def to_nhwc(t):
+    """Logical [B,C,H,W] (any strides) -> contiguous [B,H,W,C] fp32 device tensor."""
+    _lib.require_gpu(t, "general path")
+    if t.dtype != torch.float32:
+        raise _lib.EvflowError(f"general path: unsupported dtype {t.dtype}")
+    p = t.permute(0, 2, 3, 1)
+    if p.is_contiguous():
+        return p
+    if t.is_contiguous():
+        B, Cc, H, W = t.shape
+        out = torch.empty((B, H, W, Cc), dtype=torch.float32, device=t.device)
+        _lib.call("evf_nchw_to_nhwc", _lib.ptr(t), B, Cc, H, W, _lib.ptr(out))
+        return out
+    return p.contiguous()
+
+
+def from_nhwc(t):
+    """[B,H,W,C] -> logical [B,C,H,W] view (channels_last strides)."""
+    return t.permute(0, 3, 1, 2)
+
+
+def _new(shape, dev):
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+def _out_dim(n, k, s):
+    return (n + 2 * (k // 2) - k) // s + 1
+
+
+class _PackCache:
+    """Packed matrix-core operands of one weight tensor, re-packed when the
+    parameter changes (key: storage pointer + in-place version counter)."""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, w, transpose, cin_off=0, cin=None):
+        Cout, Ctot, k, _ = w.shape
+        cin = Ctot if cin is None else cin
+        key = (transpose, cin_off, cin)
+        tag = (w.data_ptr(), w._version, w.device)
+        hit = self.store.get(key)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+        wc = w.detach()
+        if not wc.is_contiguous():
+            wc = wc.contiguous()
+        n = _lib.load().evf_conv2d_packed_size(Cout, cin, k, transpose)
+        dst = _new((n,), w.device)
+        _lib.call("evf_pack_conv2d_weight", _lib.ptr(wc), Cout, cin, k, transpose, Ctot, cin_off, _lib.ptr(dst))
+        self.store[key] = (tag, dst)
+        return dst
+
+
+_CACHES = {}
+
+
+def pack_cache(owner):
+    """One cache per owning module (kept off the module so state_dict / deepcopy stay clean)."""
+    c = _CACHES.get(id(owner))
+    if c is None or c[0]() is not owner:
+        try:
+            ref = weakref.ref(owner, lambda _r, k=id(owner): _CACHES.pop(k, None))
+        except TypeError:  # not weak-referenceable: no caching
+            return {}
+        c = (ref, {})
+        _CACHES[id(owner)] = c
+    return c[1]
+
+
+def _wcache(owner, name):
+    d = pack_cache(owner)
+    if name not in d:
+        d[name] = _PackCache()
+    return d[name]
+
+
+def conv_fwd(x, wp, bias, y, Cin, Cout, k, stride, accumulate=0):
+    B, H, W, ldx = x.shape[0], x.shape[1], x.shape[2], x.stride(2)
+    _lib.call("evf_conv2d_fwd", _lib.ptr(x), ldx, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(y), y.stride(2), B, H, W, Cin, Cout,
+              k, stride, accumulate)
+
+
+def conv_dgrad(g_y, wtp, g_x, Cin, Cout, k, stride, accumulate=0):
+    B, H, W = g_x.shape[0], g_x.shape[1], g_x.shape[2]
+    _lib.call("evf_conv2d_dgrad", _lib.ptr(g_y), g_y.stride(2), _lib.ptr(wtp), _lib.ptr(g_x), g_x.stride(2), B, H, W, Cin,
+              Cout, k, stride, accumulate)
+
+
+def conv_wgrad(x, g_y, g_w, g_b, Cin, Cout, k, stride, cin_total=None, cin_off=0, accumulate=0):
+    B, H, W = x.shape[0], x.shape[1], x.shape[2]
+    _lib.call("evf_conv2d_wgrad", _lib.ptr(x), x.stride(2), _lib.ptr(g_y), g_y.stride(2), _lib.ptr(g_w), _lib.ptr(g_b), B, H,
+              W, Cin, Cout, k, stride, Cin if cin_total is None else cin_total, cin_off, accumulate)
+
+
+# ---------------------------------------------------------------------------
+# spiking cell step
+# ---------------------------------------------------------------------------
+def act_width(cell):
+    """Surrogate width as a host float, read from the device buffer once (it is never trained)."""
+    d = pack_cache(cell)
+    if "act_width" not in d:
+        d["act_width"] = float(cell.act_width)
+    return d["act_width"]
+
+
+def cell_params(cell):
+    """The four per-channel parameter slots of evf_neuron_fwd/bwd for this cell."""
+    if cell.kind == "lif":
+        return [cell.leak, cell.thresh, None, None]
+    if cell.kind == "plif":
+        return [cell.leak_v, cell.thresh, cell.leak_pt, cell.add_pt]
+    if cell.kind == "alif":
+        return [cell.leak_v, cell.t0, cell.t1, cell.leak_t]
+    return [cell.leak_v, cell.t0, cell.t1, cell.leak_pt]
+
+
+class _CellStep(torch.autograd.Function):
+    """(input, previous state, residual) -> (output spikes [+ residual], new state).
+    state: logical [S,B,C,H,W] (S = 2, or 3 with the adaptation trace), NHWC in memory."""
+
+    @staticmethod
+    def forward(ctx, cell, x, state, residual, wff, wrec, p0, p1, p2, p3):
+        ctx.set_materialize_grads(False)
+        kind = KIND_ID[cell.kind]
+        ns = 2 if kind == 0 else 3
+        xn = to_nhwc(x)
+        B, H, W, Cin = xn.shape
+        C, k, s = cell.hidden_size, cell.kernel_size, cell.stride
+        Ho, Wo = _out_dim(H, k, s), _out_dim(W, k, s)
+        dev = xn.device
+        sp = None
+        if state is not None:
+            sp = state.permute(0, 1, 3, 4, 2)
+            if not sp.is_contiguous():
+                sp = sp.contiguous()
+        rn = to_nhwc(residual) if residual is not None else None
+        cur = _new((B, Ho, Wo, C), dev)
+        conv_fwd(xn, _wcache(cell, "ff").get(wff, 0), None, cur, Cin, C, k, s)
+        if cell.recurrent and sp is not None:
+            conv_fwd(sp[1], _wcache(cell, "rec").get(wrec, 0), None, cur, C, C, k, 1, accumulate=1)
+        P = None
+        if kind in (1, 3):
+            ws = _new((B * H * W,), dev)
+            P = _new((B, Ho, Wo), dev)
+            _lib.call("evf_pretrace_fwd", _lib.ptr(xn), xn.stride(2), B, H, W, Cin, k, s, _lib.ptr(ws), _lib.ptr(P))
+        new = _new((ns, B, Ho, Wo, C), dev)
+        out = _new((B, Ho, Wo, C), dev)
+        prm = [p.detach().reshape(-1).contiguous() if p is not None else None for p in (p0, p1, p2, p3)]
+        _lib.call("evf_neuron_fwd", kind, _lib.ptr(cur), _lib.ptr(sp[0]) if sp is not None else None,
+                  _lib.ptr(sp[1]) if sp is not None else None, _lib.ptr(sp[2]) if (sp is not None and ns == 3) else None,
+                  _lib.ptr(P), _lib.ptr(rn), _lib.ptr(prm[0]), _lib.ptr(prm[1]), _lib.ptr(prm[2]), _lib.ptr(prm[3]),
+                  B * Ho * Wo, C, 1 if cell.hard_reset else 0, _lib.ptr(new[0]), _lib.ptr(new[1]),
+                  _lib.ptr(new[2]) if ns == 3 else None, _lib.ptr(out))
+        ctx.cell, ctx.kind, ctx.ns = cell, kind, ns
+        ctx.geom = (B, H, W, Cin, Ho, Wo, C, k, s)
+        ctx.saved = (xn, sp, new, P, prm, wff, wrec)
+        ctx.has_res = residual is not None
+        return from_nhwc(out), new.permute(0, 1, 4, 2, 3)
+
+    @staticmethod
+    def backward(ctx, g_out, g_state):
+        cell, kind, ns = ctx.cell, ctx.kind, ctx.ns
+        B, H, W, Cin, Ho, Wo, C, k, s = ctx.geom
+        xn, sp, new, P, prm, wff, wrec = ctx.saved
+        dev = xn.device
+        need = ctx.needs_input_grad  # (cell, x, state, residual, wff, wrec, p0..p3)
+        if g_out is None and g_state is None:
+            return (None,) * 10
+        gon = to_nhwc(g_out) if g_out is not None else None
+        gs = None
+        if g_state is not None:
+            gs = g_state.permute(0, 1, 3, 4, 2)
+            if not gs.is_contiguous():
+                gs = gs.contiguous()
+        g_cur = _new((B, Ho, Wo, C), dev)
+        g_prev = torch.zeros((ns, B, Ho, Wo, C), dtype=torch.float32, device=dev)
+        g_P = _new((B, Ho, Wo), dev) if kind in (1, 3) else None
+        g_prm = [torch.zeros(C, dtype=torch.float32, device=dev) if (prm[i] is not None and need[6 + i]) else None
+                 for i in range(4)]
+        _lib.call("evf_neuron_bwd", kind, _lib.ptr(gs[0]) if gs is not None else None, _lib.ptr(gon),
+                  _lib.ptr(gs[1]) if gs is not None else None, _lib.ptr(gs[2]) if (gs is not None and ns == 3) else None,
+                  _lib.ptr(new[0]), _lib.ptr(new[2]) if ns == 3 else None, _lib.ptr(sp[0]) if sp is not None else None,
+                  _lib.ptr(sp[1]) if sp is not None else None, _lib.ptr(sp[2]) if (sp is not None and ns == 3) else None,
+                  _lib.ptr(P), _lib.ptr(prm[0]), _lib.ptr(prm[1]), _lib.ptr(prm[2]), _lib.ptr(prm[3]), B * Ho * Wo, C,
+                  1 if cell.hard_reset else 0, SURROGATE_ID[cell.activation], act_width(cell), _lib.ptr(g_cur),
+                  _lib.ptr(g_prev[0]), _lib.ptr(g_prev[1]), _lib.ptr(g_prev[2]) if ns == 3 else None, _lib.ptr(g_P),
+                  _lib.ptr(g_prm[0]), _lib.ptr(g_prm[1]), _lib.ptr(g_prm[2]), _lib.ptr(g_prm[3]))
+        g_wff = g_wrec = g_x = None
+        if need[4]:
+            g_wff = _new(tuple(wff.shape), dev)
+            conv_wgrad(xn, g_cur, g_wff, None, Cin, C, k, s)
+        if cell.recurrent and need[5]:
+            if sp is not None:
+                g_wrec = _new(tuple(wrec.shape), dev)
+                conv_wgrad(sp[1], g_cur, g_wrec, None, C, C, k, 1)
+            else:
+                g_wrec = torch.zeros(tuple(wrec.shape), dtype=torch.float32, device=dev)
+        if need[1]:
+            g_xn = _new((B, H, W, Cin), dev)
+            conv_dgrad(g_cur, _wcache(cell, "ffT").get(wff, 1), g_xn, Cin, C, k, s)
+            if g_P is not None:
+                _lib.call("evf_pretrace_bwd", _lib.ptr(xn), xn.stride(2), _lib.ptr(g_P), B, H, W, Cin, k, s, _lib.ptr(g_xn),
+                          Cin, 1)
+            g_x = from_nhwc(g_xn)
+        g_st = None
+        if sp is not None and need[2]:
+            if cell.recurrent:  # the recurrent conv reads the previous spikes NOT detached (:530)
+                conv_dgrad(g_cur, _wcache(cell, "recT").get(wrec, 1), g_prev[1], C, C, k, 1, accumulate=1)
+            g_st = g_prev.permute(0, 1, 4, 2, 3)
+        g_res = g_out if (ctx.has_res and need[3]) else None
+        shp = lambda i: g_prm[i].view(C, 1, 1) if g_prm[i] is not None else None  # noqa: E731
+        return None, g_x, g_st, g_res, g_wff, g_wrec, shp(0), shp(1), shp(2), shp(3)
+
+
+def cell_forward(cell, input_, prev_state, residual=0):
+    """Reference signature: cell(input_, prev_state, residual=0) -> (out, state)."""
+    res = residual if torch.is_tensor(residual) else None
+    if not torch.is_tensor(residual) and residual != 0:
+        raise _lib.EvflowError("residual must be a tensor or 0")
+    p = cell_params(cell)
+    wrec = cell.rec.weight if cell.recurrent else None
+    return _CellStep.apply(cell, input_, prev_state, res, cell.ff.weight, wrec, *p)
+
+
+# ---------------------------------------------------------------------------
+# conv + bias + pointwise activation (ConvLayer / ConvLayer_)
+# ---------------------------------------------------------------------------
+class _ConvAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, owner, x, weight, bias, residual, stride, act):
+        xn = to_nhwc(x)
+        B, H, W, Cin = xn.shape
+        Cout, _, k, _ = weight.shape
+        Ho, Wo = _out_dim(H, k, stride), _out_dim(W, k, stride)
+        y = _new((B, Ho, Wo, Cout), xn.device)
+        bc = bias.detach().contiguous() if bias is not None else None
+        conv_fwd(xn, _wcache(owner, "w").get(weight, 0), bc, y, Cin, Cout, k, stride)
+        rn = to_nhwc(residual) if residual is not None else None
+        if act != 0 or rn is not None:
+            _lib.call("evf_act_fwd", act, _lib.ptr(y), _lib.ptr(rn), y.numel(), _lib.ptr(y))
+        ctx.owner, ctx.act, ctx.stride = owner, act, stride
+        ctx.saved = (xn, y, weight)
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        return from_nhwc(y)
+
+    @staticmethod
+    def backward(ctx, g_y):
+        xn, y, weight = ctx.saved
+        B, H, W, Cin = xn.shape
+        Cout, _, k, _ = weight.shape
+        need = ctx.needs_input_grad  # (owner, x, weight, bias, residual, stride, act)
+        g = to_nhwc(g_y)
+        if ctx.act != 0:
+            gp = _new(tuple(g.shape), g.device)
+            _lib.call("evf_act_bwd", ctx.act, _lib.ptr(y), _lib.ptr(g), g.numel(), _lib.ptr(gp))
+            g = gp
+        g_w = g_b = g_x = None
+        if need[2] or (ctx.has_bias and need[3]):
+            g_w = _new(tuple(weight.shape), g.device)
+            g_b = _new((Cout,), g.device) if ctx.has_bias else None
+            conv_wgrad(xn, g, g_w, g_b, Cin, Cout, k, ctx.stride)
+        if need[1]:
+            g_xn = _new((B, H, W, Cin), g.device)
+            conv_dgrad(g, _wcache(ctx.owner, "wT").get(weight, 1), g_xn, Cin, Cout, k, ctx.stride)
+            g_x = from_nhwc(g_xn)
+        g_res = from_nhwc(g) if (ctx.has_res and need[4]) else None
+        return None, g_x, g_w, g_b, g_res, None, None
+
+
+def conv_act(owner, x, weight, bias, stride=1, activation=None, residual=None):
+    if activation not in ACT_ID:
+        raise AttributeError(activation)
+    return _ConvAct.apply(owner, x, weight, bias, residual, stride, ACT_ID[activation])
+
+
+# ---------------------------------------------------------------------------
+# ConvGRU (submodules.py:400-418): the cat([x, h]) convolutions are evaluated
+# as conv(x, W[:, :Cx]) + conv(h, W[:, Cx:]) -- no concatenated copy
+# ---------------------------------------------------------------------------
+class _ConvGRU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, owner, x, h, wr, br, wu, bu, wo, bo):
+        xn = to_nhwc(x)
+        B, H, W, Cx = xn.shape
+        Ch, k = wr.shape[0], wr.shape[2]
+        hn = to_nhwc(h) if h is not None else None
+        dev = xn.device
+        n = B * H * W * Ch
+
+        def gate(name, w, b, hsrc):
+            y = _new((B, H, W, Ch), dev)
+            conv_fwd(xn, _wcache(owner, name + "x").get(w, 0, 0, Cx), b.detach().contiguous(), y, Cx, Ch, k, 1)
+            if hsrc is not None:
+                conv_fwd(hsrc, _wcache(owner, name + "h").get(w, 0, Cx, Ch), None, y, Ch, Ch, k, 1, accumulate=1)
+            return y
+
+        cu, cr = gate("u", wu, bu, hn), gate("r", wr, br, hn)
+        u, r, hr = _new((B, H, W, Ch), dev), _new((B, H, W, Ch), dev), _new((B, H, W, Ch), dev)
+        _lib.call("evf_gru_gates_fwd", _lib.ptr(cu), _lib.ptr(cr), _lib.ptr(hn), n, _lib.ptr(u), _lib.ptr(r), _lib.ptr(hr))
+        co = gate("o", wo, bo, hr if hn is not None else None)
+        o, new = _new((B, H, W, Ch), dev), _new((B, H, W, Ch), dev)
+        _lib.call("evf_gru_out_fwd", _lib.ptr(co), _lib.ptr(hn), _lib.ptr(u), n, _lib.ptr(o), _lib.ptr(new))
+        ctx.owner = owner
+        ctx.saved = (xn, hn, u, r, hr, o, wr, wu, wo)
+        return from_nhwc(new)
+
+    @staticmethod
+    def backward(ctx, g_new):
+        owner = ctx.owner
+        xn, hn, u, r, hr, o, wr, wu, wo = ctx.saved
+        B, H, W, Cx = xn.shape
+        Ch, k = wr.shape[0], wr.shape[2]
+        dev = xn.device
+        n = B * H * W * Ch
+        need = ctx.needs_input_grad  # (owner, x, h, wr, br, wu, bu, wo, bo)
+        g = to_nhwc(g_new)
+        g_co, g_cu, g_h = _new((B, H, W, Ch), dev), _new((B, H, W, Ch), dev), _new((B, H, W, Ch), dev)
+        _lib.call("evf_gru_out_bwd", _lib.ptr(g), _lib.ptr(hn), _lib.ptr(u), _lib.ptr(o), n, _lib.ptr(g_co), _lib.ptr(g_cu),
+                  _lib.ptr(g_h))
+        g_cr = _new((B, H, W, Ch), dev)
+        if hn is not None:
+            g_hr = _new((B, H, W, Ch), dev)
+            conv_dgrad(g_co, _wcache(owner, "ohT").get(wo, 1, Cx, Ch), g_hr, Ch, Ch, k, 1)
+            _lib.call("evf_gru_gates_bwd", _lib.ptr(g_hr), _lib.ptr(hn), _lib.ptr(r), n, _lib.ptr(g_cr), _lib.ptr(g_h))
+        else:
+            g_cr.zero_()
+
+        def wgrads(w, gate_g, hsrc):
+            g_w = torch.zeros(tuple(w.shape), dtype=torch.float32, device=dev)
+            g_b = torch.zeros((Ch,), dtype=torch.float32, device=dev)
+            conv_wgrad(xn, gate_g, g_w, g_b, Cx, Ch, k, 1, cin_total=Cx + Ch, cin_off=0, accumulate=1)
+            if hsrc is not None:
+                conv_wgrad(hsrc, gate_g, g_w, None, Ch, Ch, k, 1, cin_total=Cx + Ch, cin_off=Cx, accumulate=1)
+            return g_w, g_b
+
+        g_wo, g_bo = wgrads(wo, g_co, hr if hn is not None else None)
+        g_wu, g_bu = wgrads(wu, g_cu, hn)
+        g_wr, g_br = wgrads(wr, g_cr, hn)
+        g_x = g_hh = None
+        if need[1]:
+            g_xn = _new((B, H, W, Cx), dev)
+            conv_dgrad(g_co, _wcache(owner, "oxT").get(wo, 1, 0, Cx), g_xn, Cx, Ch, k, 1)
+            conv_dgrad(g_cu, _wcache(owner, "uxT").get(wu, 1, 0, Cx), g_xn, Cx, Ch, k, 1, accumulate=1)
+            conv_dgrad(g_cr, _wcache(owner, "rxT").get(wr, 1, 0, Cx), g_xn, Cx, Ch, k, 1, accumulate=1)
+            g_x = from_nhwc(g_xn)
+        if hn is not None and need[2]:
+            conv_dgrad(g_cu, _wcache(owner, "uhT").get(wu, 1, Cx, Ch), g_h, Ch, Ch, k, 1, accumulate=1)
+            conv_dgrad(g_cr, _wcache(owner, "rhT").get(wr, 1, Cx, Ch), g_h, Ch, Ch, k, 1, accumulate=1)
+            g_hh = from_nhwc(g_h)
+        return None, g_x, g_hh, g_wr, g_br, g_wu, g_bu, g_wo, g_bo
+
+
+def conv_gru(owner, x, h):
+    return _ConvGRU.apply(owner, x, h, owner.reset_gate.weight, owner.reset_gate.bias, owner.update_gate.weight,
+                          owner.update_gate.bias, owner.out_gate.weight, owner.out_gate.bias)
+
+
+# ---------------------------------------------------------------------------
+# up-sampling
+# ---------------------------------------------------------------------------
+class _Up2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xn = to_nhwc(x)
+        B, H, W, Cc = xn.shape
+        y = _new((B, 2 * H, 2 * W, Cc), xn.device)
+        _lib.call("evf_upsample2x_fwd", _lib.ptr(xn), B, H, W, Cc, _lib.ptr(y))
+        ctx.shape = (B, H, W, Cc)
+        return from_nhwc(y)
+
+    @staticmethod
+    def backward(ctx, g_y):
+        B, H, W, Cc = ctx.shape
+        g = to_nhwc(g_y)
+        gx = _new((B, H, W, Cc), g.device)
+        _lib.call("evf_upsample2x_bwd", _lib.ptr(g), B, H, W, Cc, _lib.ptr(gx))
+        return from_nhwc(gx)
+
+
+def upsample2x_bilinear(x):
+    """F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)."""
+    return _Up2.apply(x)
+
+
+class _UpNearest(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, f):
+        _lib.require_gpu(x, "nearest up-sampling")
+        xc = x.contiguous()
+        B, Cc, h, w = xc.shape
+        y = _new((B, Cc, h * f, w * f), xc.device)
+        _lib.call("evf_upsample_nearest_fwd", _lib.ptr(xc), B * Cc, h, w, f, _lib.ptr(y))
+        ctx.geom = (B, Cc, h, w, f)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        B, Cc, h, w, f = ctx.geom
+        g = g_y.contiguous()
+        gx = _new((B, Cc, h, w), g.device)
+        _lib.call("evf_upsample_nearest_bwd", _lib.ptr(g), B * Cc, h, w, f, _lib.ptr(gx))
+        return gx, None
+
+
+def upsample_nearest(x, factor):
+    """F.interpolate(x, scale_factor=factor) for an integer factor (flow pyramids, model.py:529-539)."""
+    f = int(round(factor))
+    if abs(f - factor) > 1e-9 or f < 1:
+        raise _lib.EvflowError(f"nearest up-sampling: integer factors only, got {factor}")
+    if f == 1:
+        return x
+    return _UpNearest.apply(x, f)

@@ -16,7 +16,9 @@ import torch
 from .. import _lib
 from .base import BaseModel
 from .engine import FireNetEngine
-from .model_util import copy_states
+from . import hip_ops
+from .model_util import CropParameters, copy_states
+from .unet import SpikingMultiResUNetRecurrent
 from .spiking_submodules import (
     ConvALIF,
     ConvALIFRecurrent,
@@ -64,21 +66,32 @@ class FireNet(BaseModel):
         self.R2b = self.ff_neuron(base_num_channels, base_num_channels, kernel_size, activation=ff_act, **kwargs)
         self.pred = ConvLayer(base_num_channels, out_channels=2, kernel_size=1, activation="tanh", w_scale=self.w_scale_pred)
         self._engine = None
+        self._use_fused = None
+        self._states = [None] * self.num_recurrent_units  # general path only
         self.reset_states()
 
     # -- engine ------------------------------------------------------------
     def _cells(self):
         return [self.head, self.G1, self.R1a, self.R1b, self.G2, self.R2a, self.R2b]
 
+    def _fused(self):
+        """True when the network runs on the fused 32->32 spike kernels of models/engine.py (LIF / PLIF
+        FireNets at the reference's width); every other variant -- ANN FireNet (ConvLayer_/ConvGRU), ALIF/XLIF,
+        other widths, residual -- is chained cell by cell through the general path (models/hip_ops.py)."""
+        if self._use_fused is None:
+            cells = self._cells()
+            self._use_fused = (
+                not self.residual
+                and all(getattr(c, "kind", None) in ("lif", "plif") for c in cells)
+                and len({c.kind for c in cells}) == 1
+                and all(c.hidden_size == 32 and c.kernel_size == 3 and c.stride == 1 for c in cells)
+            )
+        return self._use_fused
+
     def _eng(self):
         if self._engine is None:
-            if self.residual:
-                raise NotImplementedError("residual FireNet variants are not part of the shipped configurations")
-            if not hasattr(self.head, "kind"):
-                raise NotImplementedError(
-                    f"{type(self).__name__}: the ANN FireNet (ConvLayer_/ConvGRU, reference config 1 is a CPU plumbing "
-                    "case) has no HIP path yet; only the spiking FireNets are accelerated"
-                )
+            if not self._fused():
+                raise NotImplementedError(f"{type(self).__name__} runs on the general path; it has no fused engine")
             self._engine = FireNetEngine(self._cells(), self.pred, self.num_bins, precision=self.precision)
         return self._engine
 
@@ -95,19 +108,27 @@ class FireNet(BaseModel):
     # -- state API (models/model.py:203-227) -------------------------------
     @property
     def states(self):
+        if not self._fused():
+            return copy_states(self._states)
         if self._engine is None:
             return [None] * self.num_recurrent_units
         return copy_states(self._engine.get_states())
 
     @states.setter
     def states(self, states):
-        self._eng().set_states(states)
+        if not self._fused():
+            self._states = states
+        else:
+            self._eng().set_states(states)
 
     def detach_states(self):
-        if self._engine is not None:
+        if not self._fused():
+            self._states = [s.detach() if torch.is_tensor(s) else s for s in self._states]
+        elif self._engine is not None:
             self._engine.detach_states()
 
     def reset_states(self):
+        self._states = [None] * self.num_recurrent_units
         if self._engine is not None:
             self._engine.reset_states()
 
@@ -131,6 +152,9 @@ class FireNet(BaseModel):
             x = x.clone()
             x[nz] = (vals - vals.mean()) / vals.std()
 
+        if not self._fused():
+            return self._forward_general(x, log)
+
         eng = self._eng()
         flow = eng.forward(x)
 
@@ -144,6 +168,31 @@ class FireNet(BaseModel):
         else:
             activity = None
         return {"flow": [flow], "activity": activity}
+
+
+def _activity(names, tensors):
+    return {n: t.detach().ne(0).float().mean().item() for n, t in zip(names, tensors)}
+
+
+def _firenet_forward_general(self, x, log):
+    """models/model.py:253-286, one libevflow_hip.so cell step per layer."""
+    st = self._states
+    x1, st[0] = self.head(x, st[0])
+    x2, st[1] = self.G1(x1, st[1])
+    x3, st[2] = self.R1a(x2, st[2])
+    x4, st[3] = self.R1b(x3, st[3], residual=x2 if self.residual else 0)
+    x5, st[4] = self.G2(x4, st[4])
+    x6, st[5] = self.R2a(x5, st[5])
+    x7, st[6] = self.R2b(x6, st[6], residual=x5 if self.residual else 0)
+    flow = self.pred(x7).contiguous()
+    activity = None
+    if log:
+        names = ["0:input", "1:head", "2:G1", "3:R1a", "4:R1b", "5:G2", "6:R2a", "7:R2b", "8:pred"]
+        activity = _activity(names, [x, x1, x2, x3, x4, x5, x6, x7, flow])
+    return {"flow": [flow], "activity": activity}
+
+
+FireNet._forward_general = _firenet_forward_general
 
 
 class LIFFireNet(FireNet):
@@ -196,6 +245,135 @@ class LIFFireFlowNet(FireNet):
     w_scale_pred = 0.01
 
 
+class RecEVFlowNet(BaseModel):
+    """Recurrent EV-FlowNet (Zhu et al., RSS 2018) -- reference: models/model.py:412-547.  Only the spiking
+    variants below are on the accelerated path (the ConvGRU/ConvRNN/leaky UNets are ANN baselines)."""
+
+    unet_type = None
+    recurrent_block_type = "convgru"
+    spiking_feedforward_block_type = None
+
+    def __init__(self, unet_kwargs):
+        super().__init__()
+        if self.unet_type is None:
+            raise NotImplementedError(
+                f"{type(self).__name__}: the non-spiking recurrent EV-FlowNets are ANN baselines outside the accelerated path"
+            )
+        unet_kwargs = dict(unet_kwargs)  # the reference mutates the caller's dict (quirk q3); we do not
+        norm = unet_kwargs.get("norm", None)
+        use_upsample_conv = unet_kwargs.get("use_upsample_conv", True)
+        net_kwargs = {
+            "base_num_channels": unet_kwargs["base_num_channels"],
+            "num_encoders": 4,
+            "num_residual_blocks": 2,
+            "num_output_channels": 2,
+            "skip_type": "concat",
+            "norm": norm,
+            "use_upsample_conv": use_upsample_conv,
+            "kernel_size": unet_kwargs["kernel_size"],
+            "channel_multiplier": 2,
+            "recurrent_block_type": self.recurrent_block_type,
+            "final_activation": "tanh",
+            "spiking_feedforward_block_type": self.spiking_feedforward_block_type,
+            "spiking_neuron": unet_kwargs["spiking_neuron"],
+        }
+        self.crop = None
+        self.mask = unet_kwargs["mask_output"]
+        self.norm_input = False if "norm_input" not in unet_kwargs.keys() else unet_kwargs["norm_input"]
+        self.encoding = unet_kwargs["encoding"]
+        self.num_bins = unet_kwargs["num_bins"]
+        self.num_encoders = net_kwargs["num_encoders"]
+        unet_kwargs.update(net_kwargs)
+        for k in ("name", "encoding", "round_encoding", "norm_input", "mask_output"):
+            unet_kwargs.pop(k, None)
+        self.multires_unetrec = self.unet_type(unet_kwargs)
+
+    @property
+    def states(self):
+        return copy_states(self.multires_unetrec.states)
+
+    @states.setter
+    def states(self, states):
+        self.multires_unetrec.states = states
+
+    def detach_states(self):
+        det = []
+        for state in self.multires_unetrec.states:
+            if type(state) is tuple:
+                det.append(tuple(h.detach() for h in state))
+            else:
+                det.append(state.detach() if state is not None else None)
+        self.multires_unetrec.states = det
+
+    def reset_states(self):
+        self.multires_unetrec.states = [None] * self.multires_unetrec.num_states
+
+    def init_cropping(self, width, height, safety_margin=0):
+        self.crop = CropParameters(width, height, self.num_encoders, safety_margin)
+
+    def forward(self, event_voxel, event_cnt, log=False):
+        """-> {"flow": [4 x [N,2,H,W]] (coarse to fine, all at input resolution), "activity": None}."""
+        if self.encoding == "voxel":
+            x = event_voxel
+        elif self.encoding == "cnt" and self.num_bins == 2:
+            x = event_cnt
+        else:
+            print("Model error: Incorrect input encoding.")
+            raise AttributeError
+        if self.norm_input:
+            raise NotImplementedError("norm_input on the EV-FlowNet path is not accelerated (all shipped configs disable it)")
+        if self.crop is not None:
+            x = self.crop.pad(x)
+        multires_flow = self.multires_unetrec.forward(x)
+        if log:
+            raise NotImplementedError("Activity logging not implemented")  # reference :523-524
+        flow_list = []
+        for flow in multires_flow:
+            fy = multires_flow[-1].shape[2] / flow.shape[2]
+            fx = multires_flow[-1].shape[3] / flow.shape[3]
+            if fy != fx:
+                raise NotImplementedError("anisotropic flow pyramids")
+            flow_list.append(hip_ops.upsample_nearest(flow.contiguous(), fy))
+        if self.crop is not None:
+            for i, flow in enumerate(flow_list):
+                flow_list[i] = flow[:, :, self.crop.iy0 : self.crop.iy1, self.crop.ix0 : self.crop.ix1].contiguous()
+        return {"flow": flow_list, "activity": None}
+
+
+class SpikingRecEVFlowNet(RecEVFlowNet):
+    """LIF EV-FlowNet (reference: models/model.py:550-558; BASELINE config 4)."""
+
+    unet_type = SpikingMultiResUNetRecurrent
+    recurrent_block_type = "lif"
+    spiking_feedforward_block_type = "lif"
+
+
+class PLIFRecEVFlowNet(RecEVFlowNet):
+    """Reference: models/model.py:561-569."""
+
+    unet_type = SpikingMultiResUNetRecurrent
+    recurrent_block_type = "plif"
+    spiking_feedforward_block_type = "plif"
+
+
+class ALIFRecEVFlowNet(RecEVFlowNet):
+    """Reference: models/model.py:572-580."""
+
+    unet_type = SpikingMultiResUNetRecurrent
+    recurrent_block_type = "alif"
+    spiking_feedforward_block_type = "alif"
+
+
+class XLIFRecEVFlowNet(RecEVFlowNet):
+    """Reference: models/model.py:583-591."""
+
+    unet_type = SpikingMultiResUNetRecurrent
+    recurrent_block_type = "xlif"
+    spiking_feedforward_block_type = "xlif"
+
+
 MODELS = {
-    c.__name__: c for c in (FireNet, LIFFireNet, PLIFFireNet, ALIFFireNet, XLIFFireNet, LIFFireFlowNet)
+    c.__name__: c
+    for c in (FireNet, LIFFireNet, PLIFFireNet, ALIFFireNet, XLIFFireNet, LIFFireFlowNet, SpikingRecEVFlowNet,
+              PLIFRecEVFlowNet, ALIFRecEVFlowNet, XLIFRecEVFlowNet)
 }

@@ -2,11 +2,15 @@
 models/spiking_submodules.py (same class names, constructor arguments,
 parameter names and initial distributions, so reference state_dicts load).
 
-The cells are parameter containers: `ff` / `rec` are nn.Conv2d modules only so
-that the state_dict keys (`ff.weight`, `rec.weight`) and the RNG draw order of
-the reference constructors (:63-75, :475-490) are reproduced.  The arithmetic
-of a cell step -- conv, neuron update, Heaviside, surrogate-gradient backward --
-runs in libevflow_hip.so, sequenced by models/engine.py for whole networks.
+`ff` / `rec` are nn.Conv2d modules only so that the state_dict keys
+(`ff.weight`, `rec.weight`) and the RNG draw order of the reference
+constructors (:63-75, :475-490) are reproduced; they are never called.  The
+arithmetic of a cell step -- conv, neuron update, Heaviside, surrogate-gradient
+backward -- runs in libevflow_hip.so:
+  * whole FireNets are sequenced by models/engine.py (fused 32->32 kernels);
+  * a cell called on its own, `cell(input_, prev_state, residual=0) ->
+    (out, state)` exactly as in the reference, and the blocks of the spiking
+    EV-FlowNet below go through the general path (models/hip_ops.py).
 """
 
 import math
@@ -14,6 +18,7 @@ import math
 import torch
 import torch.nn as nn
 
+from . import hip_ops
 from .spiking_util import SURROGATE_ID
 
 
@@ -48,9 +53,8 @@ class _SpikingCell(nn.Module):
         nn.init.uniform_(conv.weight, -w_scale, w_scale)
 
     def forward(self, input_, prev_state, residual=0):
-        from .engine import single_cell_forward
-
-        return single_cell_forward(self, input_, prev_state, residual)
+        """-> (z_out + residual, stack([v_out, z_out(, trace)])), reference :96-126 etc."""
+        return hip_ops.cell_forward(self, input_, prev_state, residual)
 
 
 class ConvLIF(_SpikingCell):
@@ -207,3 +211,81 @@ class ConvXLIFRecurrent(_ALIFBase):
         self._init_conv(self.ff, input_size)
         self._init_conv(self.rec, hidden_size)
         self._common(input_size, hidden_size, kernel_size, stride, activation, act_width, hard_reset, detach, norm)
+
+
+# ---------------------------------------------------------------------------
+# blocks of the spiking EV-FlowNet (reference: spiking_submodules.py:878-1013)
+# ---------------------------------------------------------------------------
+_FF = {"lif": ConvLIF, "alif": ConvALIF, "plif": ConvPLIF, "xlif": ConvXLIF}
+_REC = {"lif": ConvLIFRecurrent, "alif": ConvALIFRecurrent, "plif": ConvPLIFRecurrent, "xlif": ConvXLIFRecurrent}
+
+
+def stack_states(states):
+    """torch.stack(states) of logical [S,B,C,H,W] states, keeping the NHWC memory layout
+    (stacking the NHWC views is a plain copy; a direct torch.stack would transpose twice per pass)."""
+    return torch.stack([s.permute(0, 1, 3, 4, 2) for s in states]).permute(0, 1, 2, 5, 3, 4)
+
+
+class SpikingRecurrentConvLayer(nn.Module):
+    """Spiking conv cell followed by a recurrent spiking conv cell (reference :878-929)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, recurrent_block_type="lif",
+                 activation_ff="arctanspike", activation_rec="arctanspike", **kwargs):
+        super().__init__()
+        assert recurrent_block_type in ["lif", "alif", "plif", "xlif"]
+        kwargs.pop("spiking_feedforward_block_type", None)
+        self.conv = _FF[recurrent_block_type](in_channels, out_channels, kernel_size, stride, activation_ff, **kwargs)
+        self.recurrent_block = _REC[recurrent_block_type](out_channels, out_channels, kernel_size, activation=activation_rec,
+                                                          **kwargs)
+
+    def forward(self, x, prev_state):
+        if prev_state is None:
+            prev_state = [None, None]
+        ff, rec = prev_state
+        x1, ff = self.conv(x, ff)
+        x2, rec = self.recurrent_block(x1, rec)
+        return x2, stack_states([ff, rec])
+
+
+class SpikingResidualBlock(nn.Module):
+    """Spike-based residual block, Fang et al. 2021: the block input is added to the second
+    cell's output spikes (reference :932-975)."""
+
+    def __init__(self, in_channels, out_channels, stride=1, spiking_feedforward_block_type="lif", activation="arctanspike",
+                 **kwargs):
+        super().__init__()
+        assert spiking_feedforward_block_type in ["lif", "alif", "plif", "xlif"]
+        cls = _FF[spiking_feedforward_block_type]
+        self.conv1 = cls(in_channels, out_channels, kernel_size=3, stride=stride, activation=activation, **kwargs)
+        self.conv2 = cls(out_channels, out_channels, kernel_size=3, stride=1, activation=activation, **kwargs)
+
+    def forward(self, x, prev_state):
+        if prev_state is None:
+            prev_state = [None, None]
+        conv1, conv2 = prev_state
+        x1, conv1 = self.conv1(x, conv1)
+        x2, conv2 = self.conv2(x1, conv2, residual=x)
+        return x2, stack_states([conv1, conv2])
+
+
+class SpikingUpsampleConvLayer(nn.Module):
+    """Bilinear x2 up-sampling followed by a spiking conv cell (reference :978-1013)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, spiking_feedforward_block_type="lif",
+                 activation="arctanspike", **kwargs):
+        super().__init__()
+        assert spiking_feedforward_block_type in ["lif", "alif", "plif", "xlif"]
+        self.conv2d = _FF[spiking_feedforward_block_type](in_channels, out_channels, kernel_size, stride=stride,
+                                                          activation=activation, **kwargs)
+
+    def forward(self, x, prev_state):
+        x_up = hip_ops.upsample2x_bilinear(x)
+        return self.conv2d(x_up, prev_state)
+
+
+class SpikingTransposedConvLayer(nn.Module):
+    """Reference :1016-1065 (use_upsample_conv=False).  Not on the accelerated path."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("transposed-conv decoders (use_upsample_conv=False) are not on the accelerated path")

@@ -1,0 +1,120 @@
+"""Spiking multi-resolution recurrent UNet -- host-side mirror of reference
+models/unet.py:28-145 (BaseUNet), :314-415 (MultiResUNetRecurrent) and
+:418-465 (SpikingMultiResUNetRecurrent): 4 strided spiking encoders each
+followed by a recurrent spiking block, 2 spiking residual blocks, 4 bilinear
+up-sampling spiking decoders on cat(prediction, x, skip) and a tanh 1x1
+prediction per scale.  Same module tree and parameter names as the reference,
+so its state_dicts load.  Every block runs in libevflow_hip.so through the
+general path (models/hip_ops.py); torch.cat / pad are the only torch calls
+(memory movement)."""
+
+import torch.nn as nn
+
+from .model_util import skip_concat, skip_sum  # noqa: F401  (resolved by name, reference unet.py:77)
+from .spiking_submodules import (
+    SpikingRecurrentConvLayer,
+    SpikingResidualBlock,
+    SpikingTransposedConvLayer,
+    SpikingUpsampleConvLayer,
+)
+from .submodules import ConvLayer
+
+
+class SpikingMultiResUNetRecurrent(nn.Module):
+    ff_type = ConvLayer
+    res_type = SpikingResidualBlock
+    upsample_type = SpikingUpsampleConvLayer
+    transpose_type = SpikingTransposedConvLayer
+    rec_type = SpikingRecurrentConvLayer
+    w_scale_pred = 0.01
+
+    def __init__(self, unet_kwargs):
+        super().__init__()
+        kw = dict(unet_kwargs)
+        self.final_activation = kw.pop("final_activation", None)
+        self._base_init(**kw)
+        self.encoders = self.build_recurrent_encoders()
+        self.resblocks = self.build_resblocks()
+        self.decoders = self.build_multires_prediction_decoders()
+        self.preds = self.build_multires_prediction_layer()
+        self.num_states = self.num_encoders * 2 + self.num_residual_blocks
+        self.states = [None] * self.num_states
+
+    # reference BaseUNet.__init__, unet.py:40-91
+    def _base_init(self, base_num_channels, num_encoders, num_residual_blocks, num_output_channels, skip_type, norm,
+                   use_upsample_conv, num_bins, recurrent_block_type=None, kernel_size=5, channel_multiplier=2,
+                   activations=("relu", None), spiking_feedforward_block_type=None, spiking_neuron=None):
+        self.base_num_channels = base_num_channels
+        self.num_encoders = num_encoders
+        self.num_residual_blocks = num_residual_blocks
+        self.num_output_channels = num_output_channels
+        self.kernel_size = kernel_size
+        self.skip_type = skip_type
+        self.norm = norm
+        self.num_bins = num_bins
+        self.recurrent_block_type = recurrent_block_type
+        self.channel_multiplier = channel_multiplier
+        self.ff_act, self.rec_act = activations
+        self.spiking_kwargs = {}
+        if spiking_feedforward_block_type is not None:
+            self.spiking_kwargs["spiking_feedforward_block_type"] = spiking_feedforward_block_type
+        if type(spiking_neuron) is dict:
+            self.spiking_kwargs.update(spiking_neuron)
+        self.skip_ftn = {"concat": skip_concat, "sum": skip_sum}[skip_type]
+        self.UpsampleLayer = self.upsample_type if use_upsample_conv else self.transpose_type
+        assert self.num_output_channels > 0
+        self.encoder_input_sizes = [int(base_num_channels * pow(channel_multiplier, i)) for i in range(num_encoders)]
+        self.encoder_output_sizes = [int(base_num_channels * pow(channel_multiplier, i + 1)) for i in range(num_encoders)]
+        self.max_num_channels = self.encoder_output_sizes[-1]
+
+    def build_recurrent_encoders(self):  # unet.py:335-353
+        encoders = nn.ModuleList()
+        for i, (cin, cout) in enumerate(zip(self.encoder_input_sizes, self.encoder_output_sizes)):
+            if i == 0:
+                cin = self.num_bins
+            encoders.append(self.rec_type(cin, cout, kernel_size=self.kernel_size, stride=2,
+                                          recurrent_block_type=self.recurrent_block_type, activation_ff=self.ff_act,
+                                          activation_rec=self.rec_act, norm=self.norm, **self.spiking_kwargs))
+        return encoders
+
+    def build_resblocks(self):  # unet.py:110-122
+        blocks = nn.ModuleList()
+        for _ in range(self.num_residual_blocks):
+            blocks.append(self.res_type(self.max_num_channels, self.max_num_channels, activation=self.ff_act, norm=self.norm,
+                                        **self.spiking_kwargs))
+        return blocks
+
+    def build_multires_prediction_decoders(self):  # unet.py:371-388
+        decoders = nn.ModuleList()
+        sizes = zip(reversed(self.encoder_output_sizes), reversed(self.encoder_input_sizes))
+        for i, (cin, cout) in enumerate(sizes):
+            pred_ch = 0 if i == 0 else self.num_output_channels
+            decoders.append(self.UpsampleLayer(2 * cin + pred_ch, cout, kernel_size=self.kernel_size, activation=self.ff_act,
+                                               norm=self.norm, **self.spiking_kwargs))
+        return decoders
+
+    def build_multires_prediction_layer(self):  # unet.py:355-369
+        preds = nn.ModuleList()
+        for cout in reversed(self.encoder_input_sizes):
+            preds.append(self.ff_type(cout, self.num_output_channels, 1, activation=self.final_activation, norm=self.norm,
+                                      w_scale=self.w_scale_pred))
+        return preds
+
+    def forward(self, x):
+        """x [N,num_bins,H,W] -> [N,2,H/8..H,W/8..W] x 4 (coarse to fine).  unet.py:437-465."""
+        blocks = []
+        for i, encoder in enumerate(self.encoders):
+            x, self.states[i] = encoder(x, self.states[i])
+            blocks.append(x)
+        offset = self.num_encoders
+        for i, resblock in enumerate(self.resblocks):
+            x, self.states[offset + i] = resblock(x, self.states[offset + i])
+        predictions = []
+        offset += self.num_residual_blocks
+        for i, (decoder, pred) in enumerate(zip(self.decoders, self.preds)):
+            x = self.skip_ftn(x, blocks[self.num_encoders - i - 1])
+            if i > 0:
+                x = self.skip_ftn(predictions[-1], x)
+            x, self.states[offset + i] = decoder(x, self.states[offset + i])
+            predictions.append(pred(x))
+        return predictions

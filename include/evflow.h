@@ -276,6 +276,101 @@ int evf_nchw_to_bits(const float* in, int B, int H, int W, uint32_t* bits, void*
 int evf_nhwc_to_nchw(const float* in, int B, int C, int H, int W, float* out, void* stream);
 int evf_nchw_to_nhwc(const float* in, int B, int C, int H, int W, float* out, void* stream);
 
+/* ------------------------------------------------------------------ general path
+ * Layers outside the fused 32->32 FireNet kernels: the spiking EV-FlowNet
+ * (models/unet.py:418-465, spiking_submodules.py:878-1013), the ANN FireNet
+ * (models/submodules.py:64-83,377-418), the 1x1 prediction heads
+ * (submodules.py:12-61) and stand-alone Conv{LIF,PLIF,ALIF,XLIF}[Recurrent]
+ * cells (spiking_submodules.py:24-875).  Activations are NHWC fp32 with an
+ * explicit pixel stride (ld, in floats); k in {1,3}, stride in {1,2}, padding
+ * k/2 (F.conv2d as used at spiking_submodules.py:99,519).  fp32 matrix-core
+ * arithmetic (v_mfma_f32_32x32x2_f32): results equal an fp32 CPU convolution
+ * up to summation order. */
+
+/* Packed-weight size in floats for evf_pack_conv2d_weight (0 on bad arguments). */
+int64_t evf_conv2d_packed_size(int Cout, int Cin, int ksz, int transpose);
+/* w: torch layout [Cout][cin_total][k][k]; packs input channels cin_off..cin_off+Cin.
+ * transpose = 0 -> operand of evf_conv2d_fwd, 1 -> operand of evf_conv2d_dgrad. */
+int evf_pack_conv2d_weight(const float* w, int Cout, int Cin, int ksz, int transpose, int cin_total,
+                           int cin_off, float* dst, void* stream);
+/* y [B,Ho,Wo,Cout] (+)= conv(x [B,H,W,Cin]) + bias  (nn.Conv2d.forward) */
+int evf_conv2d_fwd(const float* x, int ldx, const float* w_packed, const float* bias, float* y, int ldy,
+                   int B, int H, int W, int Cin, int Cout, int ksz, int stride, int accumulate,
+                   void* stream);
+/* g_x [B,H,W,Cin] (+)= conv^T(g_y [B,Ho,Wo,Cout])  (autograd of the above w.r.t. x) */
+int evf_conv2d_dgrad(const float* g_y, int ldg, const float* wT_packed, float* g_x, int ldx, int B, int H,
+                     int W, int Cin, int Cout, int ksz, int stride, int accumulate, void* stream);
+/* g_w [Cout][cin_total][k][k] (input channels cin_off..) and optional g_bias [Cout]
+ * (autograd w.r.t. weight / bias).  accumulate = 0 zeroes the outputs first and needs
+ * cin_total == Cin. */
+int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int ldg, float* g_w, float* g_bias, int B,
+                     int H, int W, int Cin, int Cout, int ksz, int stride, int cin_total, int cin_off,
+                     int accumulate, void* stream);
+
+/* Neuron update of one spiking cell on a precomputed input current `cur`
+ * (ff [+ rec] conv), all tensors [npix][C] fp32, C % 4 == 0, null previous
+ * state = zeros.  kind = EVF_LIF / PLIF / ALIF / XLIF; per-channel parameters:
+ *   LIF : p0 leak     p1 thresh                      (spiking_submodules.py:104-123)
+ *   PLIF: p0 leak_v   p1 thresh  p2 leak_pt p3 add_pt (:199-224)  aux = pt, needs P
+ *   ALIF: p0 leak_v   p1 t0      p2 t1      p3 leak_t (:307-331)  aux = t
+ *   XLIF: p0 leak_v   p1 t0      p2 t1      p3 leak_pt(:407-432)  aux = pt, needs P
+ * P [npix] = evf_pretrace_fwd of the cell input.  out (optional) = z_out + residual. */
+int evf_neuron_fwd(int kind, const float* cur, const float* v_prev, const float* z_prev,
+                   const float* aux_prev, const float* P, const float* residual, const float* p0,
+                   const float* p1, const float* p2, const float* p3, int64_t npix, int C, int hard_reset,
+                   float* v_out, float* z_out, float* aux_out, float* out, void* stream);
+/* Surrogate-gradient backward of evf_neuron_fwd (spiking_util.py:24-25,38-93; the reset
+ * uses z detached, spiking_submodules.py:116-120).  Upstream gradients (any may be null):
+ * g_v_out, g_z_out + g_z_out2, g_aux_out.  Writes g_cur, g_v_prev, g_aux_prev (kind != LIF),
+ * g_z_prev (ALIF only: its threshold trace integrates z), g_P [npix] (PLIF/XLIF); parameter
+ * gradients g_p0..g_p3 [C] are ACCUMULATED (null = skip). */
+int evf_neuron_bwd(int kind, const float* g_v_out, const float* g_z_out, const float* g_z_out2,
+                   const float* g_aux_out, const float* v_out, const float* aux_out, const float* v_prev,
+                   const float* z_prev, const float* aux_prev, const float* P, const float* p0,
+                   const float* p1, const float* p2, const float* p3, int64_t npix, int C, int hard_reset,
+                   int surrogate, float act_width, float* g_cur, float* g_v_prev, float* g_z_prev,
+                   float* g_aux_prev, float* g_P, float* g_p0, float* g_p1, float* g_p2, float* g_p3,
+                   void* stream);
+/* P [B,Ho,Wo] = avg_pool2d(mean_c |x|, k, stride, k/2) (spiking_submodules.py:212,418);
+ * absmean_ws [B*H*W] workspace.  Backward adds/writes sign(x)/C * pool^T(g_P) into g_x. */
+int evf_pretrace_fwd(const float* x, int ldx, int B, int H, int W, int C, int ksz, int stride,
+                     float* absmean_ws, float* P, void* stream);
+int evf_pretrace_bwd(const float* x, int ldx, const float* g_P, int B, int H, int W, int C, int ksz,
+                     int stride, float* g_x, int ldg, int accumulate, void* stream);
+
+/* F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) on NHWC
+ * (spiking_submodules.py:1011) and its adjoint. */
+int evf_upsample2x_fwd(const float* x, int B, int H, int W, int C, float* y, void* stream);
+int evf_upsample2x_bwd(const float* g_y, int B, int H, int W, int C, float* g_x, void* stream);
+/* F.interpolate(scale_factor=f) (nearest) of `planes` images [h][w] -> [h f][w f]
+ * (models/model.py:529-539) and its adjoint. */
+int evf_upsample_nearest_fwd(const float* x, int64_t planes, int h, int w, int factor, float* y,
+                             void* stream);
+int evf_upsample_nearest_bwd(const float* g_y, int64_t planes, int h, int w, int factor, float* g_x,
+                             void* stream);
+
+/* y = act(x [+ residual]); kind 0 identity, 1 tanh, 2 sigmoid, 3 relu
+ * (submodules.py:52-61,78-81).  Backward through the OUTPUT y: g_x = g_y act'(y). */
+#define EVF_ACT_NONE 0
+#define EVF_ACT_TANH 1
+#define EVF_ACT_SIGMOID 2
+#define EVF_ACT_RELU 3
+int evf_act_fwd(int kind, const float* x, const float* residual, int64_t n, float* y, void* stream);
+int evf_act_bwd(int kind, const float* y, const float* g_y, int64_t n, float* g_x, void* stream);
+
+/* ConvGRU gate algebra (submodules.py:404-416): u = sigmoid(cu), r = sigmoid(cr), hr = h r;
+ * o = tanh(co), h_new = h (1 - u) + o u.  h null = zeros.  Backward: evf_gru_out_bwd writes
+ * g_co, g_cu (pre-activation) and g_h = g_new (1-u); evf_gru_gates_bwd writes g_cr and ADDS
+ * g_hr r into g_h. */
+int evf_gru_gates_fwd(const float* cu, const float* cr, const float* h, int64_t n, float* u, float* r,
+                      float* hr, void* stream);
+int evf_gru_out_fwd(const float* co, const float* h, const float* u, int64_t n, float* o, float* h_new,
+                    void* stream);
+int evf_gru_out_bwd(const float* g_new, const float* h, const float* u, const float* o, int64_t n,
+                    float* g_co, float* g_cu, float* g_h, void* stream);
+int evf_gru_gates_bwd(const float* g_hr, const float* h, const float* r, int64_t n, float* g_cr,
+                      float* g_h, void* stream);
+
 /* ------------------------------------------------------------------ optimiser
  * train_flow.py:157-163: clip_grad_norm_(max_norm) + Adam(lr) on one flat
  * parameter buffer.  norm_ws [2] float workspace: [0] receives the squared

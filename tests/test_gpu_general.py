@@ -1,0 +1,296 @@
+"""GPU parity of the general path (any channel count / stride): matrix-core
+conv forward / input gradient / weight gradient, the four spiking cells as
+stand-alone modules against the reference-generated single-step goldens (G6),
+the ANN FireNet (G8), the spiking EV-FlowNet (G9) and the ALIF/XLIF FireNets
+against the CPU oracle.
+
+Tolerances: the conv kernels multiply and accumulate in fp32 (v_mfma_f32_32x32x2),
+so they differ from the CPU fp32 convolution only by summation order: 1e-5
+relative to the largest output.  Spikes are exact wherever the golden membrane
+potential is further than 1e-5 from the threshold."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cases, load_golden
+
+pytestmark = pytest.mark.gpu
+
+from event_flow_amd import _lib  # noqa: E402
+from event_flow_amd.models import hip_ops  # noqa: E402
+from event_flow_amd.models import spiking_submodules as cells  # noqa: E402
+from event_flow_amd.models.model import ALIFFireNet, FireNet, SpikingRecEVFlowNet, XLIFFireNet  # noqa: E402
+from oracle import snn as osnn  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def G(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def close(got, ref, rel, what=""):
+    scale = max(float(np.abs(ref).max()), 1e-12)
+    err = float(np.abs(got - ref).max())
+    assert err <= rel * scale, (what, err, scale)
+
+
+# ------------------------------------------------------------------ conv kernels
+CONV_CASES = [
+    # B, Cin, Cout, H, W, k, stride
+    (2, 2, 8, 12, 10, 3, 2),
+    (1, 4, 8, 9, 7, 3, 1),
+    (2, 66, 16, 10, 12, 3, 1),
+    (1, 130, 32, 20, 24, 3, 1),
+    (2, 64, 128, 16, 16, 3, 2),
+    (1, 32, 2, 17, 33, 1, 1),
+    (1, 256, 96, 5, 6, 3, 1),
+    (3, 5, 7, 11, 13, 3, 2),
+    (1, 8, 8, 13, 9, 3, 2),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_forward_dgrad_wgrad_vs_cpu(case):
+    B, Cin, Cout, H, W, k, s = case
+    gen = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, k, k, generator=gen) * 0.2
+    b = torch.randn(Cout, generator=gen)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = torch.nn.functional.conv2d(xr, wr, br, stride=s, padding=k // 2)
+    gy = torch.randn(y_ref.shape, generator=gen)
+    y_ref.backward(gy)
+
+    class Owner:
+        pass
+
+    owner = Owner()
+    xd, wd, bd = G(x.numpy()).requires_grad_(True), G(w.numpy()).requires_grad_(True), G(b.numpy()).requires_grad_(True)
+    y = hip_ops.conv_act(owner, xd, wd, bd, stride=s, activation=None)
+    assert tuple(y.shape) == tuple(y_ref.shape)
+    close(N(y), y_ref.detach().numpy(), 1e-5, "fwd")
+    y.backward(G(gy.numpy()))
+    close(N(xd.grad), xr.grad.numpy(), 1e-5, "dgrad")
+    close(N(wd.grad), wr.grad.numpy(), 2e-5, "wgrad")
+    close(N(bd.grad), br.grad.numpy(), 2e-5, "bias grad")
+
+
+def test_conv_bad_arguments_fail_loudly():
+    x = torch.zeros(1, 4, 8, 8, device=DEV)
+    w = torch.zeros(4, 4, 5, 5, device=DEV)  # 5x5 kernels are not built
+    with pytest.raises(_lib.EvflowError):
+        hip_ops.conv_act(object(), x, w, None)
+    with pytest.raises(_lib.EvflowError):
+        hip_ops.conv_act(object(), x.cpu(), torch.zeros(4, 4, 3, 3), None)  # CPU tensors: no fallback
+
+
+def test_upsampling_matches_torch_semantics():
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 6, 5, 7, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    y_ref = torch.nn.functional.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=False)
+    gy = torch.randn(y_ref.shape, generator=gen)
+    y_ref.backward(gy)
+    xd = G(x.numpy()).requires_grad_(True)
+    y = hip_ops.upsample2x_bilinear(xd)
+    np.testing.assert_allclose(N(y), y_ref.detach().numpy(), rtol=1e-6, atol=1e-6)
+    y.backward(G(gy.numpy()))
+    np.testing.assert_allclose(N(xd.grad), xr.grad.numpy(), rtol=1e-5, atol=1e-6)
+    f = torch.randn(2, 2, 4, 6, generator=gen)
+    fr = f.clone().requires_grad_(True)
+    u_ref = torch.nn.functional.interpolate(fr, scale_factor=(4.0, 4.0))
+    gu = torch.randn(u_ref.shape, generator=gen)
+    u_ref.backward(gu)
+    fd = G(f.numpy()).requires_grad_(True)
+    u = hip_ops.upsample_nearest(fd, 4.0)
+    assert np.array_equal(N(u), u_ref.detach().numpy())
+    u.backward(G(gu.numpy()))
+    np.testing.assert_allclose(N(fd.grad), fr.grad.numpy(), rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------ stand-alone cells (G6)
+CELL_CLS = {
+    ("lif", False): cells.ConvLIF, ("lif", True): cells.ConvLIFRecurrent,
+    ("plif", False): cells.ConvPLIF, ("plif", True): cells.ConvPLIFRecurrent,
+    ("alif", False): cells.ConvALIF, ("alif", True): cells.ConvALIFRecurrent,
+    ("xlif", False): cells.ConvXLIF, ("xlif", True): cells.ConvXLIFRecurrent,
+}
+
+
+def _thresh_of(c, g, tag, new_ref):
+    """Effective threshold of the golden step (to mask borderline neurons)."""
+    if c["kind"] in ("lif", "plif"):
+        return np.maximum(g[tag + "_param_thresh"], 0.01)[None]
+    t0 = np.maximum(g[tag + "_param_t0"], 0.01)[None]
+    t1 = np.maximum(g[tag + "_param_t1"], 0.0)[None]
+    return t0 + t1 * new_ref[2]
+
+
+def test_g6_cells_forward_backward_on_gpu():
+    g = load_golden("g6_cells")
+    cases = golden_cases(g)
+    assert len(cases) == 28
+    for c in cases:
+        tag = c["tag"]
+        x_np, st_np = g[tag + "_x"], g[tag + "_state"]
+        Cin, C = x_np.shape[1], st_np.shape[2]
+        kw = dict(activation=c["act"], hard_reset=c["hard_reset"], act_width=float(g[tag + "_param_act_width"]))
+        if c["kind"] in ("alif", "xlif"):
+            kw["learn_thresh"] = True
+        cell = CELL_CLS[(c["kind"], c["recurrent"])](Cin, C, 3, **kw).to(DEV)
+        sd = {k[len(tag + "_param_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "_param_")}
+        cell.load_state_dict(sd)
+        x = G(x_np).requires_grad_(True)
+        st = G(st_np).requires_grad_(True)
+        out, new = cell(x, st)
+        new_ref = g[tag + "_new"]
+        safe = np.abs(new_ref[0] - _thresh_of(c, g, tag, new_ref)) > 1e-5
+        assert np.array_equal(N(out)[safe], g[tag + "_out"][safe]), c
+        assert safe.mean() > 0.999
+        assert np.array_equal(N(out), g[tag + "_out"]), c  # none of the golden cases is borderline
+        np.testing.assert_allclose(N(new), new_ref, rtol=1e-5, atol=2e-6, err_msg=str(c))
+        params = dict(cell.named_parameters())
+        grads = torch.autograd.grad([out, new], [x, st] + list(params.values()), [G(g[tag + "_g_out"]), G(g[tag + "_g_new"])],
+                                    allow_unused=True)
+        close(N(grads[0]), g[tag + "_gx"], 2e-5, f"{c} gx")
+        close(N(grads[1]), g[tag + "_gstate"], 2e-5, f"{c} gstate")
+        for (pn, p), gr in zip(params.items(), grads[2:]):
+            ref = g[f"{tag}_grad_{pn}"]
+            got = N(gr) if gr is not None else np.zeros_like(ref)
+            close(got, ref, 1e-4, f"{c} {pn}")
+
+
+def test_cell_first_step_without_state_and_residual():
+    torch.manual_seed(0)
+    cell = cells.ConvLIFRecurrent(8, 8, 3, thresh=(0.3, 0.1)).to(DEV)
+    x = (torch.rand(1, 8, 6, 9, device=DEV) < 0.4).float()
+    res = torch.rand(1, 8, 6, 9, device=DEV).round()
+    out, st = cell(x, None, residual=res)
+    p = {"c." + k: v.detach().cpu() for k, v in cell.state_dict().items()}
+    o_ref, st_ref = osnn.cell_step("lif", p, "c.", x.cpu(), None, recurrent=True, residual=res.cpu())
+    assert np.array_equal(N(out), o_ref.numpy())
+    np.testing.assert_allclose(N(st), torch.stack(st_ref).numpy(), rtol=1e-5, atol=1e-6)
+    assert tuple(st.shape) == (2, 1, 8, 6, 9)
+
+
+# ------------------------------------------------------------------ ANN FireNet (G8, BASELINE config 1)
+def _ann_cfg():
+    return {"num_bins": 2, "base_num_channels": 32, "kernel_size": 3, "encoding": "voxel", "norm_input": False,
+            "mask_output": True, "activations": ["relu", None], "spiking_neuron": None}
+
+
+def test_g8_firenet_ann_forward_and_backward():
+    g = load_golden("g8_firenet_ann")
+    model = FireNet(_ann_cfg()).to(DEV)
+    sd = {k[len("param_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param_")}
+    model.load_state_dict(sd)
+    flows = []
+    for i in range(2):
+        out = model(G(g[f"p{i}_event_voxel"]), G(g[f"p{i}_event_cnt"]), log=(i == 1))
+        flows.append(out["flow"][0])
+        np.testing.assert_allclose(N(out["flow"][0]), g[f"p{i}_flow"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(N(model.states[1]), g[f"p{i}_state_G1"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(N(model.states[4]), g[f"p{i}_state_G2"], rtol=1e-4, atol=1e-6)
+    assert set(out["activity"]) == {"0:input", "1:head", "2:G1", "3:R1a", "4:R1b", "5:G2", "6:R2a", "7:R2b", "8:pred"}
+    # BPTT over the two passes against the CPU oracle (same parameters, same inputs)
+    loss = sum((f * f).sum() for f in flows)
+    loss.backward()
+    params = {k: torch.from_numpy(g["param_" + k]).clone().requires_grad_(True) for k in sd}
+    states = [None] * 7
+    tot = 0
+    for i in range(2):
+        f, states = osnn.firenet_forward("FireNet", params, torch.from_numpy(g[f"p{i}_event_voxel"]), states)
+        tot = tot + (f * f).sum()
+    tot.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(tot.detach()), rtol=1e-5)
+    for k, p in model.named_parameters():
+        close(N(p.grad), params[k].grad.numpy(), 2e-4, k)
+
+
+# ------------------------------------------------------------------ spiking EV-FlowNet (G9, BASELINE config 4 architecture)
+def _unet_cfg(C=4):
+    return {"num_bins": 2, "base_num_channels": C, "kernel_size": 3, "encoding": "cnt", "norm_input": False,
+            "mask_output": True, "activations": ["arctanspike", "arctanspike"],
+            "spiking_neuron": {"leak": [-4.0, 0.1], "thresh": [0.8, 0.1], "learn_leak": True, "learn_thresh": True,
+                               "hard_reset": True}}
+
+
+def test_g9_spiking_evflownet_forward_states_and_gradients():
+    g = load_golden("g9_spiking_unet")
+    model = SpikingRecEVFlowNet(_unet_cfg(4)).to(DEV)
+    sd = {k[len("param_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param_")}
+    model.load_state_dict(sd)
+    assert sum(p.numel() for p in model.parameters()) == sum(v.numel() for k, v in sd.items() if "act_width" not in k)
+    for i in range(2):
+        out = model(G(g[f"p{i}_event_cnt"]), G(g[f"p{i}_event_cnt"]))
+        flows = out["flow"]
+        assert len(flows) == 4 and out["activity"] is None
+        states = model.states
+        assert len(states) == 10
+        for s in range(10):
+            ref = g[f"p{i}_state{s}"]
+            assert tuple(states[s].shape) == ref.shape
+            close(N(states[s]), ref, 1e-5, f"pass {i} state {s}")  # v = sum of up to 9*130 fp32 products: summation-order noise
+        for s, f in enumerate(flows):
+            np.testing.assert_allclose(N(f), g[f"p{i}_flow{s}"], rtol=1e-4, atol=1e-6)
+    tot = sum(f.pow(2).sum() for f in flows)
+    tot.backward()
+    for k, p in model.named_parameters():
+        ref = g["grad_" + k]
+        got = N(p.grad) if p.grad is not None else np.zeros_like(ref)
+        assert np.abs(got - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-10) + 1e-12, k
+    with pytest.raises(NotImplementedError):
+        model(G(g["p0_event_cnt"]), G(g["p0_event_cnt"]), log=True)  # reference model.py:523-524
+    model.detach_states()
+    model.reset_states()
+    assert model.states == [None] * 10
+
+
+def test_evflownet_cropping_and_odd_sizes():
+    torch.manual_seed(1)
+    model = SpikingRecEVFlowNet(_unet_cfg(4)).to(DEV)
+    model.init_cropping(30, 20)  # width, height -> padded to 32 x 32
+    x = (torch.rand(1, 2, 20, 30, device=DEV) < 0.3).float()
+    out = model(x, x)
+    assert all(tuple(f.shape) == (1, 2, 20, 30) for f in out["flow"])
+
+
+# ------------------------------------------------------------------ ALIF / XLIF FireNets vs the CPU oracle
+@pytest.mark.parametrize("name,cls", [("ALIFFireNet", ALIFFireNet), ("XLIFFireNet", XLIFFireNet)])
+def test_adaptive_threshold_firenets_vs_oracle(name, cls):
+    torch.manual_seed(5)
+    neuron = {"leak_v": [-4.0, 0.1], "t0": [0.3, 0.05], "t1": [0.5, 0.1], "learn_leak": True, "learn_thresh": True}
+    neuron["leak_t" if name == "ALIFFireNet" else "leak_pt"] = [-2.0, 0.1]
+    cfg = {"num_bins": 2, "base_num_channels": 32, "kernel_size": 3, "encoding": "cnt", "norm_input": False,
+           "mask_output": True, "activations": ["arctanspike", "arctanspike"], "spiking_neuron": neuron}
+    model = cls(cfg).to(DEV)
+    params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    keys = [k for k, _ in model.named_parameters()]
+    for k in keys:
+        params[k].requires_grad_(True)
+    xs = [(torch.rand(2, 2, 16, 20) < 0.5).float() * torch.randint(1, 4, (2, 2, 16, 20)).float() for _ in range(3)]
+    states = [None] * 7
+    tot_ref, tot = 0, 0
+    for x in xs:
+        f_ref, states = osnn.firenet_forward(name, params, x, states)
+        out = model(x.to(DEV), x.to(DEV))
+        np.testing.assert_allclose(N(out["flow"][0]), f_ref.detach().numpy(), rtol=1e-4, atol=1e-7)
+        tot_ref = tot_ref + (f_ref * torch.arange(f_ref.numel()).view(f_ref.shape).remainder(7)).sum()
+        fl = out["flow"][0]
+        tot = tot + (fl * torch.arange(fl.numel(), device=DEV).view(fl.shape).remainder(7)).sum()
+    for li, st in enumerate(model.states):
+        np.testing.assert_allclose(N(st), torch.stack(states[li]).detach().numpy(), rtol=1e-5, atol=2e-6)
+    tot.backward()
+    tot_ref.backward()
+    for k, p in model.named_parameters():
+        ref = params[k].grad
+        ref = ref.numpy() if ref is not None else np.zeros(tuple(p.shape), np.float32)
+        got = N(p.grad) if p.grad is not None else np.zeros_like(ref)
+        denom = max(np.linalg.norm(ref), 1e-12)
+        assert np.linalg.norm(got - ref) <= 2e-3 * denom + 1e-9, (k, np.linalg.norm(got - ref) / denom)

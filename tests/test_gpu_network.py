@@ -201,15 +201,14 @@ def test_window_semantics_detach_and_reset():
 
 
 def test_fireflownet_runs_and_unsupported_fail_loudly():
-    from event_flow_amd.models.model import ALIFFireNet
+    from event_flow_amd.models.model import RecEVFlowNet
 
     model = LIFFireFlowNet(model_cfg()).to(DEV)
     x = torch.rand(1, 2, 16, 40, device=DEV).round()
     out = model(x, x)
     assert out["flow"][0].shape == (1, 2, 16, 40)
     with pytest.raises(NotImplementedError):
-        m = ALIFFireNet(model_cfg({"leak_v": [-4.0, 0.1], "t0": [0.8, 0.1]})).to(DEV)
-        m(x, x)
+        RecEVFlowNet(model_cfg())  # ConvGRU EV-FlowNet: an ANN baseline outside the accelerated path
     with pytest.raises(_lib.EvflowError):
         LIFFireNet(model_cfg())(x.cpu(), x.cpu())  # CPU tensors: no fallback
     with pytest.raises(AttributeError):
