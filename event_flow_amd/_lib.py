@@ -69,7 +69,8 @@ NETWORK_SIGNATURES = {
     "evf_pack_conv2d_weight": [P, I, I, I, I, I, I, P, P],
     "evf_conv2d_fwd": [P, I, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "evf_conv2d_dgrad": [P, I, P, P, I, I, I, I, I, I, I, I, I, P],
-    "evf_conv2d_wgrad": [P, I, P, I, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "evf_conv2d_wgrad_ws": [I, I, I, I, I, I, I],
+    "evf_conv2d_wgrad": [P, I, P, I, P, P, I, I, I, I, I, I, I, I, I, I, P, P],
     "evf_neuron_fwd": [I, P, P, P, P, P, P, P, P, P, P, L, I, I, P, P, P, P, P],
     "evf_neuron_bwd": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, F, P, P, P, P, P, P, P, P, P, P],
     "evf_pretrace_fwd": [P, I, I, I, I, I, I, I, P, P, P],
@@ -85,7 +86,7 @@ NETWORK_SIGNATURES = {
     "evf_gru_out_bwd": [P, P, P, P, L, P, P, P, P],
     "evf_gru_gates_bwd": [P, P, P, L, P, P, P],
 }
-RESTYPES = {"evf_conv2d_packed_size": ctypes.c_int64}
+RESTYPES = {"evf_conv2d_packed_size": ctypes.c_int64, "evf_conv2d_wgrad_ws": ctypes.c_int64}
 SIGNATURES.update(NETWORK_SIGNATURES)
 
 _lib = None

@@ -284,217 +284,3 @@ extern "C" int evf_conv2d_dgrad(const float* g_y, int ldg, const float* wT_packe
   g.ksz = ksz, g.stride = stride, g.mode = 1, g.lds = ldg, g.ldo = ldx;
   return cg_launch(g_y, wT_packed, nullptr, g_x, g, accumulate, stream);
 }
-
-// ---------------------------------------------------------------------------
-// weight (and bias) gradient
-// ---------------------------------------------------------------------------
-struct WgGeo {
-  int B, H, W, Cin, OH, OW, Cout, ksz, stride, ldx, ldg, cin_total, cin_off;
-  int stages;  // 32-pixel stages per K split
-};
-
-template <int CT, int NT, int VEC>
-__global__ __launch_bounds__(256) void k_conv2d_wgrad_f32(const float* __restrict__ x, const float* __restrict__ gy,
-                                                          float* __restrict__ gw, float* __restrict__ gbias, WgGeo g) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* s = (float*)smem_raw;
-  constexpr int XW = 32 * CT, GW = 32 * NT, STG = 32 * (XW + GW);  // floats per stage
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, row = lane & 31, kg = lane >> 5;
-  const int n_ct = (g.Cin + XW - 1) / XW;
-  const int cit = blockIdx.y % n_ct, cot = blockIdx.y / n_ct;
-  const int ci0 = cit * XW, co0 = cot * GW;
-  const int tap = blockIdx.z, dy = tap / g.ksz, dx = tap - dy * g.ksz, pad = g.ksz >> 1;
-  const long M = (long)g.B * g.OH * g.OW;
-  const long m_begin = (long)blockIdx.x * g.stages * 32;
-  const bool do_bias = gbias && cit == 0 && tap == 0;
-
-  f32x16 acc[CT][NT];
-#pragma unroll
-  for (int c = 0; c < CT; ++c)
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
-  float bsum[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) bsum[t] = 0.f;
-
-  // tile loads: x tile 32 px x XW ch = 8*CT float4 per pixel -> CT float4 per thread; g likewise
-  float4 xr[CT], gr[NT];
-  auto load_tiles = [&](int st) {
-    const long m0 = m_begin + (long)st * 32;
-#pragma unroll
-    for (int i = 0; i < CT; ++i) {
-      const int idx = tid + 256 * i, px = idx / (8 * CT), q = idx - px * (8 * CT);
-      const long m = m0 + px;
-      const bool mok = m < M;
-      const long mc = mok ? m : M - 1;
-      const int ox = (int)(mc % g.OW);
-      const long t1 = mc / g.OW;
-      const int oy = (int)(t1 % g.OH), b = (int)(t1 / g.OH);
-      int sy = oy * g.stride + dy - pad, sx = ox * g.stride + dx - pad;
-      const bool ok = mok && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W;
-      sy = min(max(sy, 0), g.H - 1), sx = min(max(sx, 0), g.W - 1);
-      const float* p = x + (((long)b * g.H + sy) * g.W + sx) * g.ldx;
-      const int c = ci0 + 4 * q;
-      float4 v;
-      if (VEC == 4) {
-        const bool cv = c + 4 <= g.Cin;
-        v = *(const float4*)(p + (cv ? c : 0));
-        if (!(ok && cv)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      } else {
-        float e[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float t = p[c + j < g.Cin ? c + j : 0];
-          e[j] = (ok && c + j < g.Cin) ? t : 0.f;
-        }
-        v = make_float4(e[0], e[1], e[2], e[3]);
-      }
-      xr[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int idx = tid + 256 * i, px = idx / (8 * NT), q = idx - px * (8 * NT);
-      const long m = m0 + px;
-      const bool mok = m < M;
-      const float* p = gy + (mok ? m : M - 1) * g.ldg;
-      const int c = co0 + 4 * q;
-      float4 v;
-      if (VEC == 4) {
-        const bool cv = c + 4 <= g.Cout;
-        v = *(const float4*)(p + (cv ? c : 0));
-        if (!(mok && cv)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      } else {
-        float e[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float t = p[c + j < g.Cout ? c + j : 0];
-          e[j] = (mok && c + j < g.Cout) ? t : 0.f;
-        }
-        v = make_float4(e[0], e[1], e[2], e[3]);
-      }
-      gr[i] = v;
-    }
-  };
-  auto store_tiles = [&](int buf) {
-    float* sx = s + buf * STG;
-    float* sg = sx + 32 * XW;
-#pragma unroll
-    for (int i = 0; i < CT; ++i) *(float4*)(sx + (tid + 256 * i) * 4) = xr[i];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) *(float4*)(sg + (tid + 256 * i) * 4) = gr[i];
-  };
-
-  load_tiles(0);
-  store_tiles(0);
-  __syncthreads();
-#pragma unroll 1
-  for (int st = 0; st < g.stages; ++st) {
-    load_tiles(min(st + 1, g.stages - 1));
-    const float* sx = s + (st & 1) * STG;
-    const float* sg = sx + 32 * XW;
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int p = 2 * (wv + 4 * jj) + kg;
-      float av[CT], bv[NT];
-#pragma unroll
-      for (int c = 0; c < CT; ++c) av[c] = sx[p * XW + c * 32 + row];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        bv[t] = sg[p * GW + t * 32 + row];
-        bsum[t] += bv[t];
-      }
-#pragma unroll
-      for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[t], acc[c][t], 0, 0, 0);
-    }
-    store_tiles((st + 1) & 1);
-    __syncthreads();
-  }
-
-  // cross-wave reduction in LDS, then one atomic per output element
-  float* red = s;  // [4 waves][CT*NT][32 rows][32 cols]
-#pragma unroll
-  for (int c = 0; c < CT; ++c)
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[((wv * CT * NT + c * NT + t) * 32 + cg_row(r, lane)) * 32 + row] = acc[c][t][r];
-  __syncthreads();
-  const int T = g.ksz * g.ksz;
-  for (int e = tid; e < CT * NT * 1024; e += 256) {
-    const int sub = e >> 10, ci_l = (e >> 5) & 31, co_l = e & 31;
-    const int c = sub / NT, t = sub - c * NT;
-    float v = 0.f;
-#pragma unroll
-    for (int w4 = 0; w4 < 4; ++w4) v += red[(w4 * CT * NT + sub) * 1024 + (e & 1023)];
-    const int ci = ci0 + c * 32 + ci_l, co = co0 + t * 32 + co_l;
-    if (ci < g.Cin && co < g.Cout) evf_atomic_add(gw + ((long)co * g.cin_total + g.cin_off + ci) * T + tap, v);
-  }
-  if (do_bias) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      float v = bsum[t];
-      v += __shfl_xor(v, 32, 64);
-      const int co = co0 + t * 32 + row;
-      if (kg == 0 && co < g.Cout) evf_atomic_add(gbias + co, v);
-    }
-  }
-}
-
-template <int CT, int NT>
-static void wg_launch(const float* x, const float* gy, float* gw, float* gbias, const WgGeo& g, int ksplit, bool vec4,
-                      hipStream_t st) {
-  const int n_ct = evf_cdiv(g.Cin, 32 * CT), n_nt = evf_cdiv(g.Cout, 32 * NT);
-  dim3 grid(ksplit, n_ct * n_nt, g.ksz * g.ksz), block(256);
-  const size_t stage = 2 * 32 * (32 * CT + 32 * NT) * sizeof(float), red = 4 * CT * NT * 1024 * sizeof(float);
-  const size_t smem = stage > red ? stage : red;
-  if (vec4)
-    hipLaunchKernelGGL((k_conv2d_wgrad_f32<CT, NT, 4>), grid, block, smem, st, x, gy, gw, gbias, g);
-  else
-    hipLaunchKernelGGL((k_conv2d_wgrad_f32<CT, NT, 1>), grid, block, smem, st, x, gy, gw, gbias, g);
-}
-
-// g_w [Cout][cin_total][k][k] (torch layout; this call fills input channels cin_off .. cin_off+Cin) and optional
-// g_bias [Cout]; accumulate = 0 zeroes them first (only allowed when the call covers the whole weight)
-extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int ldg, float* g_w, float* g_bias, int B, int H,
-                                int W, int Cin, int Cout, int ksz, int stride, int cin_total, int cin_off, int accumulate,
-                                void* stream) {
-  if (!x || !g_y || !g_w || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksz != 1 && ksz != 3) ||
-      (stride != 1 && stride != 2) || ldx < Cin || ldg < Cout || cin_off < 0 || cin_off + Cin > cin_total ||
-      (!accumulate && cin_total != Cin))
-    return EVF_EINVAL;
-  hipStream_t st = EVF_STREAM(stream);
-  if (!accumulate) {
-    int rc = evf_hip(hipMemsetAsync(g_w, 0, sizeof(float) * (size_t)Cout * Cin * ksz * ksz, st));
-    if (rc) return rc;
-    if (g_bias && (rc = evf_hip(hipMemsetAsync(g_bias, 0, sizeof(float) * (size_t)Cout, st)))) return rc;
-  }
-  WgGeo g;
-  g.B = B, g.H = H, g.W = W, g.Cin = Cin, g.Cout = Cout, g.ksz = ksz, g.stride = stride, g.ldx = ldx, g.ldg = ldg;
-  g.cin_total = cin_total, g.cin_off = cin_off;
-  g.OH = cg_out_dim(H, ksz, stride), g.OW = cg_out_dim(W, ksz, stride);
-  const long M = (long)B * g.OH * g.OW;
-  const int CT = Cin > 32 ? 2 : 1, NT = Cout > 32 ? 2 : 1;
-  const long tiles = (long)evf_cdiv(Cin, 32 * CT) * evf_cdiv(Cout, 32 * NT) * ksz * ksz;
-  const long st_total = evf_cdiv(M, 32);
-  // enough blocks to fill 256 CUs several times over, at least 8 stages per block
-  long ksplit = evf_cdiv(2048, tiles);
-  if (ksplit > st_total / 8) ksplit = st_total / 8;
-  if (ksplit < 1) ksplit = 1;
-  g.stages = evf_cdiv(st_total, ksplit);
-  ksplit = evf_cdiv(st_total, g.stages);
-  const bool vec4 = Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && ldg % 4 == 0 && ((uintptr_t)x & 15) == 0 &&
-                    ((uintptr_t)g_y & 15) == 0;
-  if (CT == 2 && NT == 2)
-    wg_launch<2, 2>(x, g_y, g_w, g_bias, g, (int)ksplit, vec4, st);
-  else if (CT == 2)
-    wg_launch<2, 1>(x, g_y, g_w, g_bias, g, (int)ksplit, vec4, st);
-  else if (NT == 2)
-    wg_launch<1, 2>(x, g_y, g_w, g_bias, g, (int)ksplit, vec4, st);
-  else
-    wg_launch<1, 1>(x, g_y, g_w, g_bias, g, (int)ksplit, vec4, st);
-  return evf_status();
-}

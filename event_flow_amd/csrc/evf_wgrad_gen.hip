@@ -1,0 +1,567 @@
+// Weight (and bias) gradient of the general convolution on the fp32 matrix cores:
+//   gw[co][ci][tap] = sum_px x[px (+) tap][ci] * g[px][co]      (autograd of nn.Conv2d w.r.t. weight)
+// a GEMM whose contraction runs over pixels.  For v_mfma_f32_32x32x2_f32 a lane
+// holds ONE k value, so [pixel][channel] tiles in LDS are already in fragment
+// order: A = x^T (32 ci x 2 px), B = g (2 px x 32 co), no transposes.
+//
+// 3x3 (k_wgrad9): one block (8 waves) owns a (32 CT ci) x (32 NT co) weight tile
+// for ALL nine taps and walks over 32-pixel tiles (R rows x TW cols) of its
+// pixel range.  Per tile it stages the g tile and ONE x halo tile in LDS and
+// every wave applies its own tap (wave w = tap w, the ninth tap is shared):
+// g is read once instead of nine times and x once (plus halo) instead of nine
+// times -- the first version (one tap per block) was bound by those re-reads.
+// Partial sums of the pixel splits go to slabs [split][tap][ci][co] (coalesced
+// stores, no atomics) and are summed by k_wgrad_reduce into the torch layout.
+//
+// 1x1 (k_conv2d_wgrad_f32): one tap, 4 waves split the pixel pairs.
+#include "evf_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int cg_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+static inline int cg_out_dim(int n, int ksz, int stride) { return (n + 2 * (ksz >> 1) - ksz) / stride + 1; }
+
+// ---------------------------------------------------------------------------
+// 1x1: one tap, the 4 waves split the pixel pairs, split-K + atomics
+// ---------------------------------------------------------------------------
+struct WgGeo {
+  int B, H, W, Cin, OH, OW, Cout, ksz, stride, ldx, ldg, cin_total, cin_off;
+  int stages;  // 32-pixel stages per K split
+};
+
+template <int CT, int NT, int VEC>
+__global__ __launch_bounds__(256) void k_conv2d_wgrad_f32(const float* __restrict__ x, const float* __restrict__ gy,
+                                                          float* __restrict__ gw, float* __restrict__ gbias, WgGeo g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* s = (float*)smem_raw;
+  constexpr int XW = 32 * CT, GW = 32 * NT, STG = 32 * (XW + GW);  // floats per stage
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, row = lane & 31, kg = lane >> 5;
+  const int n_ct = (g.Cin + XW - 1) / XW;
+  const int cit = blockIdx.y % n_ct, cot = blockIdx.y / n_ct;
+  const int ci0 = cit * XW, co0 = cot * GW;
+  const int tap = blockIdx.z, dy = tap / g.ksz, dx = tap - dy * g.ksz, pad = g.ksz >> 1;
+  const long M = (long)g.B * g.OH * g.OW;
+  const long m_begin = (long)blockIdx.x * g.stages * 32;
+  const bool do_bias = gbias && cit == 0 && tap == 0;
+
+  f32x16 acc[CT][NT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
+  float bsum[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bsum[t] = 0.f;
+
+  // tile loads: x tile 32 px x XW ch = 8*CT float4 per pixel -> CT float4 per thread; g likewise.
+  // The pixel a thread loads advances by 32 per stage: its (b, oy, ox) is tracked incrementally
+  // (one 32-bit division at kernel start instead of three 64-bit ones per load per stage).
+  float4 xr[CT], gr[NT];
+  int x_ox[CT], x_oy[CT], x_b[CT];
+#pragma unroll
+  for (int i = 0; i < CT; ++i) {
+    const int px = (tid + 256 * i) / (8 * CT);
+    const long m = m_begin + px;
+    const int mi = (int)(m < M ? m : M - 1);
+    x_ox[i] = mi % g.OW;
+    const int t1 = mi / g.OW;
+    x_oy[i] = t1 % g.OH, x_b[i] = t1 / g.OH;
+    if (m >= M) x_b[i] = g.B;  // past the end: stays invalid
+  }
+  auto load_tiles = [&](int st) {
+    const long m0 = m_begin + (long)st * 32;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      const int idx = tid + 256 * i, px = idx / (8 * CT), q = idx - px * (8 * CT);
+      const bool mok = x_b[i] < g.B;
+      const int oy = x_oy[i], ox = x_ox[i], b = mok ? x_b[i] : g.B - 1;
+      int sy = oy * g.stride + dy - pad, sx = ox * g.stride + dx - pad;
+      const bool ok = mok && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W;
+      sy = min(max(sy, 0), g.H - 1), sx = min(max(sx, 0), g.W - 1);
+      const float* p = x + (((long)b * g.H + sy) * g.W + sx) * g.ldx;
+      const int c = ci0 + 4 * q;
+      float4 v;
+      if (VEC == 4) {
+        const bool cv = c + 4 <= g.Cin;
+        v = *(const float4*)(p + (cv ? c : 0));
+        if (!(ok && cv)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float t = p[c + j < g.Cin ? c + j : 0];
+          e[j] = (ok && c + j < g.Cin) ? t : 0.f;
+        }
+        v = make_float4(e[0], e[1], e[2], e[3]);
+      }
+      xr[i] = v;
+      // advance this load's pixel by one stage
+      x_ox[i] += 32;
+      while (x_ox[i] >= g.OW) x_ox[i] -= g.OW, ++x_oy[i];
+      while (x_oy[i] >= g.OH) x_oy[i] -= g.OH, ++x_b[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int idx = tid + 256 * i, px = idx / (8 * NT), q = idx - px * (8 * NT);
+      const long m = m0 + px;
+      const bool mok = m < M;
+      const float* p = gy + (mok ? m : M - 1) * g.ldg;
+      const int c = co0 + 4 * q;
+      float4 v;
+      if (VEC == 4) {
+        const bool cv = c + 4 <= g.Cout;
+        v = *(const float4*)(p + (cv ? c : 0));
+        if (!(mok && cv)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float t = p[c + j < g.Cout ? c + j : 0];
+          e[j] = (mok && c + j < g.Cout) ? t : 0.f;
+        }
+        v = make_float4(e[0], e[1], e[2], e[3]);
+      }
+      gr[i] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* sx = s + buf * STG;
+    float* sg = sx + 32 * XW;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) *(float4*)(sx + (tid + 256 * i) * 4) = xr[i];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) *(float4*)(sg + (tid + 256 * i) * 4) = gr[i];
+  };
+
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int st = 0; st < g.stages; ++st) {
+    load_tiles(st + 1);  // past the split's last stage this prefetch is unused (and may read a neighbour split's pixels)
+    const float* sx = s + (st & 1) * STG;
+    const float* sg = sx + 32 * XW;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int p = 2 * (wv + 4 * jj) + kg;
+      float av[CT], bv[NT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) av[c] = sx[p * XW + c * 32 + row];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        bv[t] = sg[p * GW + t * 32 + row];
+        bsum[t] += bv[t];
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[t], acc[c][t], 0, 0, 0);
+    }
+    store_tiles((st + 1) & 1);
+    __syncthreads();
+  }
+
+  // cross-wave reduction in LDS, then one atomic per output element
+  float* red = s;  // [4 waves][CT*NT][32 rows][32 cols]
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wv * CT * NT + c * NT + t) * 32 + cg_row(r, lane)) * 32 + row] = acc[c][t][r];
+  __syncthreads();
+  const int T = g.ksz * g.ksz;
+  for (int e = tid; e < CT * NT * 1024; e += 256) {
+    const int sub = e >> 10, ci_l = (e >> 5) & 31, co_l = e & 31;
+    const int c = sub / NT, t = sub - c * NT;
+    float v = 0.f;
+#pragma unroll
+    for (int w4 = 0; w4 < 4; ++w4) v += red[(w4 * CT * NT + sub) * 1024 + (e & 1023)];
+    const int ci = ci0 + c * 32 + ci_l, co = co0 + t * 32 + co_l;
+    if (ci < g.Cin && co < g.Cout) evf_atomic_add(gw + ((long)co * g.cin_total + g.cin_off + ci) * T + tap, v);
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float v = bsum[t];
+      v += __shfl_xor(v, 32, 64);
+      const int co = co0 + t * 32 + row;
+      if (kg == 0 && co < g.Cout) evf_atomic_add(gbias + co, v);
+    }
+  }
+}
+
+template <int CT, int NT>
+static void wg_launch(const float* x, const float* gy, float* gw, float* gbias, const WgGeo& g, int ksplit, bool vec4,
+                      hipStream_t st) {
+  const int n_ct = evf_cdiv(g.Cin, 32 * CT), n_nt = evf_cdiv(g.Cout, 32 * NT);
+  dim3 grid(ksplit, n_ct * n_nt, g.ksz * g.ksz), block(256);
+  const size_t stage = 2 * 32 * (32 * CT + 32 * NT) * sizeof(float), red = 4 * CT * NT * 1024 * sizeof(float);
+  const size_t smem = stage > red ? stage : red;
+  if (vec4)
+    hipLaunchKernelGGL((k_conv2d_wgrad_f32<CT, NT, 4>), grid, block, smem, st, x, gy, gw, gbias, g);
+  else
+    hipLaunchKernelGGL((k_conv2d_wgrad_f32<CT, NT, 1>), grid, block, smem, st, x, gy, gw, gbias, g);
+}
+
+
+// ---------------------------------------------------------------------------
+// 3x3: tap-per-wave
+// ---------------------------------------------------------------------------
+struct Wg9Geo {
+  int B, H, W, Cin, OH, OW, Cout, ldx, ldg;
+  int TW, R, lgTW;        // pixel tile: R rows x TW cols (TW * R = 32)
+  int HR, HC;             // halo tile rows / cols
+  int tiles_x, tiles_y;   // tiles per image row / column
+  int tiles_per_split;    // pixel tiles per block
+  long ntiles;
+  int n_ct;
+};
+
+template <int CT, int NT, int S, int VX>
+__global__ __launch_bounds__(512) void k_wgrad9(const float* __restrict__ x, const float* __restrict__ gy,
+                                                float* __restrict__ slab, float* __restrict__ gbias, Wg9Geo g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int XW = 32 * CT, GW = 32 * NT, XQ = XW / 4, GQ = GW / 4;
+  constexpr int MAXHP = S == 1 ? 102 : 195;               // halo pixels: max over the (TW, R) choices
+  constexpr int NLX = (MAXHP * XQ + 511) / 512;           // x float4 loads per thread
+  constexpr int NLG = (32 * GQ + 511) / 512;              // g float4 loads per thread (1)
+  float* s_x = (float*)smem_raw;                          // [HR*HC][XW]
+  float* s_g = s_x + MAXHP * XW;                          // [32][GW]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, row = lane & 31, kg = lane >> 5;
+  const int cit = blockIdx.y % g.n_ct, cot = blockIdx.y / g.n_ct;
+  const int ci0 = cit * XW, co0 = cot * GW;
+  const int nhp = g.HR * g.HC;
+  const bool do_bias = gbias && cit == 0 && wv == 0;
+
+  // per-thread halo slots of the x loads, fixed for all tiles: (hr, hc) and the element offset
+  // from the tile's halo origin -- per tile only bounds compares and one add remain
+  int h_rc[NLX], h_off[NLX];
+#pragma unroll
+  for (int i = 0; i < NLX; ++i) {
+    const int idx = tid + 512 * i, hp = idx / XQ, q = idx - hp * XQ;
+    const int hr = hp / g.HC, hc = hp - hr * g.HC;
+    h_rc[i] = hp < nhp ? ((hr << 16) | hc) : -1;
+    h_off[i] = (hr * g.W + hc) * g.ldx + ci0 + 4 * q;
+  }
+  // g tile slots
+  int g_rc[NLG], g_off[NLG];
+#pragma unroll
+  for (int i = 0; i < NLG; ++i) {
+    const int idx = tid + 512 * i, px = idx / GQ, q = idx - px * GQ;
+    const int r = px >> g.lgTW, cc = px & (g.TW - 1);
+    g_rc[i] = px < 32 ? ((r << 16) | cc) : -1;
+    g_off[i] = (r * g.OW + cc) * g.ldg + co0 + 4 * q;
+  }
+  const bool g_vec = (g.ldg & 3) == 0 && (g.Cout & 3) == 0;
+
+  f32x16 acc[CT][NT], acc8[CT][NT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f, acc8[c][t][r] = 0.f;
+  float bsum[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bsum[t] = 0.f;
+
+  float4 xr[NLX], gr[NLG];
+  // tile coordinates of the NEXT prefetch, advanced incrementally (no divisions in the loop)
+  int n_tx, n_ty, n_b;
+  {
+    const long t0 = (long)blockIdx.x * g.tiles_per_split;
+    n_tx = (int)(t0 % g.tiles_x);
+    const long t1 = t0 / g.tiles_x;
+    n_ty = (int)(t1 % g.tiles_y), n_b = (int)(t1 / g.tiles_y);
+  }
+  auto prefetch = [&](bool want) {
+    const bool tok = want && n_b < g.B;
+    const int b = min(n_b, g.B - 1);
+    const int oy0 = n_ty * g.R, ox0 = n_tx * g.TW;
+    const int y_org = oy0 * S - 1, x_org = ox0 * S - 1;
+    const float* xo = x + (((long)b * g.H + y_org) * g.W + x_org) * g.ldx;  // may point before the image: only
+                                                                             // dereferenced for in-range slots
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+      const int hr = h_rc[i] >> 16, hc = h_rc[i] & 0xFFFF;
+      const int sy = y_org + hr, sx = x_org + hc;
+      const bool ok = tok && h_rc[i] >= 0 && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W;
+      const int c = ci0 + 4 * ((tid + 512 * i) % XQ);
+      float e[4];
+      if (VX == 4) {
+        const bool cv = ok && c + 4 <= g.Cin;
+        const float4 v = *(const float4*)(cv ? xo + h_off[i] : x);
+        e[0] = cv ? v.x : 0.f, e[1] = cv ? v.y : 0.f, e[2] = cv ? v.z : 0.f, e[3] = cv ? v.w : 0.f;
+      } else if (VX == 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bool cv = ok && c + 2 * j + 2 <= g.Cin;
+          const float2 v = *(const float2*)(cv ? xo + h_off[i] + 2 * j : x);
+          e[2 * j] = cv ? v.x : 0.f, e[2 * j + 1] = cv ? v.y : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool cv = ok && c + j < g.Cin;
+          const float t = *(cv ? xo + h_off[i] + j : x);
+          e[j] = cv ? t : 0.f;
+        }
+      }
+      xr[i] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+    const float* go = gy + (((long)b * g.OH + oy0) * g.OW + ox0) * g.ldg;
+#pragma unroll
+    for (int i = 0; i < NLG; ++i) {
+      const int r = g_rc[i] >> 16, cc = g_rc[i] & 0xFFFF;
+      const bool ok = tok && g_rc[i] >= 0 && oy0 + r < g.OH && ox0 + cc < g.OW;
+      const int c = co0 + 4 * ((tid + 512 * i) % GQ);
+      float e[4];
+      if (g_vec) {  // uniform branch
+        const bool cv = ok && c + 4 <= g.Cout;
+        const float4 v = *(const float4*)(cv ? go + g_off[i] : gy);
+        e[0] = cv ? v.x : 0.f, e[1] = cv ? v.y : 0.f, e[2] = cv ? v.z : 0.f, e[3] = cv ? v.w : 0.f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool cv = ok && c + j < g.Cout;
+          const float t = *(cv ? go + g_off[i] + j : gy);
+          e[j] = cv ? t : 0.f;
+        }
+      }
+      gr[i] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+    // advance to the next tile
+    if (++n_tx == g.tiles_x) {
+      n_tx = 0;
+      if (++n_ty == g.tiles_y) n_ty = 0, ++n_b;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLX; ++i)
+      if (h_rc[i] >= 0) *(float4*)(s_x + (tid + 512 * i) * 4) = xr[i];
+#pragma unroll
+    for (int i = 0; i < NLG; ++i)
+      if (tid + 512 * i < 32 * GQ) *(float4*)(s_g + (tid + 512 * i) * 4) = gr[i];
+  };
+
+  const int dy = wv / 3, dx = wv - 3 * dy;  // this wave's tap (waves 0..7 = taps 0..7)
+  prefetch(true);
+#pragma unroll 1
+  for (int it = 0; it < g.tiles_per_split; ++it) {
+    commit();
+    __syncthreads();
+    prefetch(it + 1 < g.tiles_per_split);
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      const int p = 2 * j + kg, r = p >> g.lgTW, cc = p & (g.TW - 1);
+      const int hidx = (r * S + dy) * g.HC + cc * S + dx;
+      float av[CT], bv[NT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) av[c] = s_x[hidx * XW + c * 32 + row];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        bv[t] = s_g[p * GW + t * 32 + row];
+        bsum[t] += bv[t];
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[t], acc[c][t], 0, 0, 0);
+    }
+    // ninth tap (dy = dx = 2): the 16 pixel pairs are split over the 8 waves
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int p = 2 * (wv + 8 * jj) + kg, r = p >> g.lgTW, cc = p & (g.TW - 1);
+      const int hidx = (r * S + 2) * g.HC + cc * S + 2;
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc8[c][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(s_x[hidx * XW + c * 32 + row], s_g[p * GW + t * 32 + row],
+                                                            acc8[c][t], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: slab[split][tap][ci][co] (co fastest)
+  float* sl = slab + (long)blockIdx.x * 9 * g.Cin * g.Cout;
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int co = co0 + t * 32 + row;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + c * 32 + cg_row(r, lane);
+        if (ci < g.Cin && co < g.Cout) sl[((long)wv * g.Cin + ci) * g.Cout + co] = acc[c][t][r];
+      }
+    }
+  // ninth tap: the 8 waves' partial tiles are summed through LDS (the staging buffers are free
+  // now), one ci half at a time: red[8 waves][NT][32][32]
+  float* red = (float*)smem_raw;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wv * NT + t) * 32 + cg_row(r, lane)) * 32 + row] = acc8[c][t][r];
+    __syncthreads();
+    for (int e = tid; e < NT * 1024; e += 512) {
+      float v = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) v += red[w8 * NT * 1024 + e];
+      const int t = e >> 10, ci_l = (e >> 5) & 31, co_l = e & 31;
+      const int ci = ci0 + c * 32 + ci_l, co = co0 + t * 32 + co_l;
+      if (ci < g.Cin && co < g.Cout) sl[((long)8 * g.Cin + ci) * g.Cout + co] = v;
+    }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float v = bsum[t];
+      v += __shfl_xor(v, 32, 64);
+      const int co = co0 + t * 32 + row;
+      if (kg == 0 && co < g.Cout) evf_atomic_add(gbias + co, v);
+    }
+  }
+}
+
+// gw[(co*cin_total + cin_off + ci)*9 + tap] (+)= sum_split slab[split][tap][ci][co]
+__global__ void k_wgrad_reduce(const float* __restrict__ slab, int nsplit, int Cin, int Cout, int cin_total, int cin_off,
+                               int accumulate, float* __restrict__ gw) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per = (long)9 * Cin * Cout;
+  if (e >= per) return;
+  const int co = (int)(e % Cout), ci = (int)((e / Cout) % Cin), tap = (int)(e / ((long)Cout * Cin));
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += slab[k * per + e];
+  float* d = gw + ((long)co * cin_total + cin_off + ci) * 9 + tap;
+  *d = accumulate ? *d + s : s;
+}
+
+struct Wg9Plan {
+  Wg9Geo g;
+  int CT, NT, nsplit, n_nt;
+};
+
+static Wg9Plan wg9_plan(int B, int H, int W, int Cin, int Cout, int stride, int ldx, int ldg) {
+  Wg9Plan p;
+  Wg9Geo& g = p.g;
+  g.B = B, g.H = H, g.W = W, g.Cin = Cin, g.Cout = Cout, g.ldx = ldx, g.ldg = ldg;
+  g.OH = cg_out_dim(H, 3, stride), g.OW = cg_out_dim(W, 3, stride);
+  g.TW = g.OW > 16 ? 32 : (g.OW > 8 ? 16 : 8);
+  g.R = 32 / g.TW;
+  g.lgTW = g.TW == 32 ? 5 : (g.TW == 16 ? 4 : 3);
+  g.HR = (g.R - 1) * stride + 3, g.HC = (g.TW - 1) * stride + 3;
+  g.tiles_x = evf_cdiv(g.OW, g.TW), g.tiles_y = evf_cdiv(g.OH, g.R);
+  g.ntiles = (long)B * g.tiles_x * g.tiles_y;
+  p.CT = Cin > 32 ? 2 : 1, p.NT = Cout > 32 ? 2 : 1;
+  g.n_ct = evf_cdiv(Cin, 32 * p.CT);
+  p.n_nt = evf_cdiv(Cout, 32 * p.NT);
+  const long wt = (long)g.n_ct * p.n_nt;
+  // ~2 blocks per CU, at least 4 pixel tiles per block (the slab traffic is 9*Cin*Cout per split)
+  long ns = evf_cdiv(512, wt);
+  if (ns > g.ntiles / 4) ns = g.ntiles / 4;
+  if (ns < 1) ns = 1;
+  g.tiles_per_split = evf_cdiv(g.ntiles, ns);
+  p.nsplit = evf_cdiv(g.ntiles, g.tiles_per_split);
+  return p;
+}
+
+// workspace (floats) evf_conv2d_wgrad needs for this geometry (0 for 1x1)
+extern "C" int64_t evf_conv2d_wgrad_ws(int B, int H, int W, int Cin, int Cout, int ksz, int stride) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksz != 3 || (stride != 1 && stride != 2)) return 0;
+  const Wg9Plan p = wg9_plan(B, H, W, Cin, Cout, stride, Cin, Cout);
+  return (int64_t)p.nsplit * 9 * Cin * Cout;
+}
+
+template <int CT, int NT, int S>
+static void wg9_launch(const float* x, const float* gy, float* slab, float* gbias, const Wg9Plan& p, hipStream_t st) {
+  const Wg9Geo& g = p.g;
+  dim3 grid(p.nsplit, g.n_ct * p.n_nt), block(512);
+  constexpr int MAXHP = S == 1 ? 102 : 195;
+  size_t smem = (size_t)(MAXHP * 32 * CT + 32 * 32 * NT) * sizeof(float);
+  const size_t red = (size_t)8 * NT * 1024 * sizeof(float);
+  if (smem < red) smem = red;
+  const bool a16 = ((uintptr_t)x & 15) == 0, a8 = ((uintptr_t)x & 7) == 0;
+  if (g.Cin % 4 == 0 && g.ldx % 4 == 0 && a16)
+    hipLaunchKernelGGL((k_wgrad9<CT, NT, S, 4>), grid, block, smem, st, x, gy, slab, gbias, g);
+  else if (g.Cin % 2 == 0 && g.ldx % 2 == 0 && a8)
+    hipLaunchKernelGGL((k_wgrad9<CT, NT, S, 2>), grid, block, smem, st, x, gy, slab, gbias, g);
+  else
+    hipLaunchKernelGGL((k_wgrad9<CT, NT, S, 1>), grid, block, smem, st, x, gy, slab, gbias, g);
+}
+
+// g_w [Cout][cin_total][k][k] (torch layout; this call fills input channels cin_off .. cin_off+Cin) and optional
+// g_bias [Cout]; accumulate = 0 overwrites them (only allowed when the call covers the whole weight).
+// ws: evf_conv2d_wgrad_ws() floats of scratch (3x3 only).
+extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int ldg, float* g_w, float* g_bias, int B, int H,
+                                int W, int Cin, int Cout, int ksz, int stride, int cin_total, int cin_off, int accumulate,
+                                float* ws, void* stream) {
+  if (!x || !g_y || !g_w || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksz != 1 && ksz != 3) ||
+      (stride != 1 && stride != 2) || ldx < Cin || ldg < Cout || cin_off < 0 || cin_off + Cin > cin_total ||
+      (!accumulate && cin_total != Cin) || (ksz == 3 && !ws) || ((uintptr_t)g_y & 15))
+    return EVF_EINVAL;
+  hipStream_t st = EVF_STREAM(stream);
+  if (!accumulate && g_bias) {
+    const int rc = evf_hip(hipMemsetAsync(g_bias, 0, sizeof(float) * (size_t)Cout, st));
+    if (rc) return rc;
+  }
+  if (ksz == 3) {
+    const Wg9Plan p = wg9_plan(B, H, W, Cin, Cout, stride, ldx, ldg);
+#define WG9(CT_, NT_)                                                 \
+  if (stride == 1)                                                    \
+    wg9_launch<CT_, NT_, 1>(x, g_y, ws, g_bias, p, st);               \
+  else                                                                \
+    wg9_launch<CT_, NT_, 2>(x, g_y, ws, g_bias, p, st)
+    if (p.CT == 2 && p.NT == 2) {
+      WG9(2, 2);
+    } else if (p.CT == 2) {
+      WG9(2, 1);
+    } else if (p.NT == 2) {
+      WG9(1, 2);
+    } else {
+      WG9(1, 1);
+    }
+#undef WG9
+    int rc = evf_status();
+    if (rc) return rc;
+    const long per = (long)9 * Cin * Cout;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(evf_cdiv(per, 256)), dim3(256), 0, st, ws, p.nsplit, Cin, Cout, cin_total,
+                       cin_off, accumulate, g_w);
+    return evf_status();
+  }
+  if (!accumulate) {
+    const int rc = evf_hip(hipMemsetAsync(g_w, 0, sizeof(float) * (size_t)Cout * Cin, st));
+    if (rc) return rc;
+  }
+  WgGeo g;
+  g.B = B, g.H = H, g.W = W, g.Cin = Cin, g.Cout = Cout, g.ksz = ksz, g.stride = stride, g.ldx = ldx, g.ldg = ldg;
+  g.cin_total = cin_total, g.cin_off = cin_off;
+  g.OH = cg_out_dim(H, ksz, stride), g.OW = cg_out_dim(W, ksz, stride);
+  const long M = (long)B * g.OH * g.OW;
+  const int CT = Cin > 32 ? 2 : 1, NT = Cout > 32 ? 2 : 1;
+  const long tiles = (long)evf_cdiv(Cin, 32 * CT) * evf_cdiv(Cout, 32 * NT) * ksz * ksz;
+  const long st_total = evf_cdiv(M, 32);
+  long ksplit = evf_cdiv(1024, tiles);
+  if (ksplit > st_total / 8) ksplit = st_total / 8;
+  if (ksplit < 1) ksplit = 1;
+  g.stages = evf_cdiv(st_total, ksplit);
+  ksplit = evf_cdiv(st_total, g.stages);
+  const bool vec4 = Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && ldg % 4 == 0 && ((uintptr_t)x & 15) == 0 &&
+                    ((uintptr_t)g_y & 15) == 0;
+  if (CT == 2 && NT == 2)
+    wg_launch<2, 2>(x, g_y, g_w, g_bias, g, (int)ksplit, vec4, st);
+  else if (CT == 2)
+    wg_launch<2, 1>(x, g_y, g_w, g_bias, g, (int)ksplit, vec4, st);
+  else if (NT == 2)
+    wg_launch<1, 2>(x, g_y, g_w, g_bias, g, (int)ksplit, vec4, st);
+  else
+    wg_launch<1, 1>(x, g_y, g_w, g_bias, g, (int)ksplit, vec4, st);
+  return evf_status();
+}

@@ -61,6 +61,14 @@ def _out_dim(n, k, s):
     return (n + 2 * (k // 2) - k) // s + 1
 
 
+_EPOCH = [0]
+
+
+def invalidate_packed_weights():
+    """Parameters were rewritten behind torch's version counters (fused optimizer kernel)."""
+    _EPOCH[0] += 1
+
+
 class _PackCache:
     """Packed matrix-core operands of one weight tensor, re-packed when the
     parameter changes (key: storage pointer + in-place version counter)."""
@@ -72,7 +80,7 @@ class _PackCache:
         Cout, Ctot, k, _ = w.shape
         cin = Ctot if cin is None else cin
         key = (transpose, cin_off, cin)
-        tag = (w.data_ptr(), w._version, w.device)
+        tag = (w.data_ptr(), w._version, w.device, _EPOCH[0])
         hit = self.store.get(key)
         if hit is not None and hit[0] == tag:
             return hit[1]
@@ -121,10 +129,23 @@ def conv_dgrad(g_y, wtp, g_x, Cin, Cout, k, stride, accumulate=0):
               Cout, k, stride, accumulate)
 
 
+_SCRATCH = {}
+
+
+def _scratch(n, dev):
+    """Stream-ordered scratch buffer (grown on demand, reused by every weight-gradient launch)."""
+    buf = _SCRATCH.get(dev)
+    if buf is None or buf.numel() < n:
+        buf = _new((max(int(n), 1),), dev)
+        _SCRATCH[dev] = buf
+    return buf
+
+
 def conv_wgrad(x, g_y, g_w, g_b, Cin, Cout, k, stride, cin_total=None, cin_off=0, accumulate=0):
     B, H, W = x.shape[0], x.shape[1], x.shape[2]
+    ws = _scratch(_lib.load().evf_conv2d_wgrad_ws(B, H, W, Cin, Cout, k, stride), x.device)
     _lib.call("evf_conv2d_wgrad", _lib.ptr(x), x.stride(2), _lib.ptr(g_y), g_y.stride(2), _lib.ptr(g_w), _lib.ptr(g_b), B, H,
-              W, Cin, Cout, k, stride, Cin if cin_total is None else cin_total, cin_off, accumulate)
+              W, Cin, Cout, k, stride, Cin if cin_total is None else cin_total, cin_off, accumulate, _lib.ptr(ws))
 
 
 # ---------------------------------------------------------------------------

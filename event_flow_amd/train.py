@@ -12,6 +12,7 @@ import torch
 
 from . import _lib
 from .dataloader.encodings import encode_event_list
+from .models import hip_ops
 
 
 class FlatAdam:
@@ -65,6 +66,7 @@ class FlatAdam:
         # engine's packed-weight cache explicitly
         if hasattr(self.model, "invalidate_weight_cache"):
             self.model.invalidate_weight_cache()
+        hip_ops.invalidate_packed_weights()
 
     def grad_norm(self):
         """L2 norm of the (pre-clip) gradient of the last step."""

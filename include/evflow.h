@@ -300,12 +300,14 @@ int evf_conv2d_fwd(const float* x, int ldx, const float* w_packed, const float* 
 /* g_x [B,H,W,Cin] (+)= conv^T(g_y [B,Ho,Wo,Cout])  (autograd of the above w.r.t. x) */
 int evf_conv2d_dgrad(const float* g_y, int ldg, const float* wT_packed, float* g_x, int ldx, int B, int H,
                      int W, int Cin, int Cout, int ksz, int stride, int accumulate, void* stream);
-/* g_w [Cout][cin_total][k][k] (input channels cin_off..) and optional g_bias [Cout]
- * (autograd w.r.t. weight / bias).  accumulate = 0 zeroes the outputs first and needs
- * cin_total == Cin. */
+/* g_w [Cout][cin_total][k][k] (input channels cin_off ..) and optional g_bias [Cout]
+ * (autograd w.r.t. weight / bias).  accumulate = 0 overwrites the outputs and needs
+ * cin_total == Cin.  ws: scratch of evf_conv2d_wgrad_ws() floats (3x3; may be null for 1x1):
+ * partial sums of the pixel splits, reduced without atomics. */
+int64_t evf_conv2d_wgrad_ws(int B, int H, int W, int Cin, int Cout, int ksz, int stride);
 int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int ldg, float* g_w, float* g_bias, int B,
                      int H, int W, int Cin, int Cout, int ksz, int stride, int cin_total, int cin_off,
-                     int accumulate, void* stream);
+                     int accumulate, float* ws, void* stream);
 
 /* Neuron update of one spiking cell on a precomputed input current `cur`
  * (ff [+ rec] conv), all tensors [npix][C] fp32, C % 4 == 0, null previous
