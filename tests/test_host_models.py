@@ -1,0 +1,112 @@
+"""CPU-side checks of the host mirror of the reference model API (no compute
+calls: there is no CPU path).  The reference's state_dict keys and shapes, as
+captured in the golden fixtures, must load unchanged; the state API keeps the
+reference's semantics; calling a model without the MI355X fails loudly."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+from event_flow_amd import _lib
+from event_flow_amd.models import model as M
+from event_flow_amd.models import spiking_submodules as cells
+from event_flow_amd.models.model_util import CropParameters, copy_states, skip_concat
+
+NEURON = {"leak": [-4.0, 0.1], "thresh": [0.8, 0.1], "learn_leak": True, "learn_thresh": True, "hard_reset": True}
+
+
+def cfg(C=32, neuron=NEURON, acts=("arctanspike", "arctanspike"), encoding="cnt"):
+    return {"name": "x", "num_bins": 2, "base_num_channels": C, "kernel_size": 3, "encoding": encoding, "round_encoding": False,
+            "norm_input": False, "mask_output": True, "activations": list(acts),
+            "spiking_neuron": dict(neuron) if neuron else None}
+
+
+def _load(model, g, prefix):
+    sd = {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return sd
+
+
+def test_reference_state_dicts_load_unchanged():
+    _load(M.LIFFireNet(cfg()), load_golden("g7_liffirenet_train"), "param0_")
+    plif = {"leak_v": [-4.0, 0.1], "leak_pt": [-4.0, 0.1], "add_pt": [-2.0, 0.1], "thresh": [0.8, 0.1]}
+    _load(M.PLIFFireNet(cfg(neuron=plif)), load_golden("g7_pliffirenet_train"), "param0_")
+    _load(M.FireNet(cfg(neuron=None, acts=("relu", None), encoding="voxel")), load_golden("g8_firenet_ann"), "param_")
+    sd = _load(M.SpikingRecEVFlowNet(cfg(C=4)), load_golden("g9_spiking_unet"), "param_")
+    assert sd["multires_unetrec.decoders.1.conv2d.ff.weight"].shape == (16, 66, 3, 3)  # cat(pred, x, skip)
+
+
+def test_parameter_counts_match_the_reference():
+    # 74 818 (LIF-FireNet), 148 450 (FireNet ANN), 20 400 840 (LIF-EV-FlowNet) parameters
+    n = lambda m: sum(p.numel() for p in m.parameters())  # noqa: E731
+    assert n(M.LIFFireNet(cfg())) == 74818
+    assert n(M.FireNet(cfg(neuron=None, acts=("relu", None)))) == 148450
+    assert n(M.SpikingRecEVFlowNet(cfg())) == 20400840
+
+
+def test_model_zoo_names_and_ctor_does_not_mutate_config():
+    for name in ("FireNet", "LIFFireNet", "PLIFFireNet", "ALIFFireNet", "XLIFFireNet", "LIFFireFlowNet", "SpikingRecEVFlowNet",
+                 "PLIFRecEVFlowNet", "ALIFRecEVFlowNet", "XLIFRecEVFlowNet"):
+        assert name in M.MODELS and getattr(M, name) is M.MODELS[name]
+    c = cfg(C=4)
+    before = {k: (list(v) if isinstance(v, list) else v) for k, v in c.items()}
+    M.SpikingRecEVFlowNet(c)
+    assert {k: (list(v) if isinstance(v, list) else v) for k, v in c.items()} == before  # reference quirk q3 not inherited
+    a, b = M.LIFFireNet(cfg()), M.PLIFFireNet(cfg(neuron={"leak_v": [-4.0, 0.1]}))
+    assert hasattr(a.head, "leak") and hasattr(b.head, "leak_v")  # no shared class-level kwargs (quirk q2)
+
+
+def test_cell_constructors_mirror_reference_defaults():
+    c = cells.ConvALIF(4, 8, 3)
+    assert not c.hard_reset and c.kind == "alif" and "t0" in dict(c.named_buffers())  # learn_thresh=False -> buffers
+    c = cells.ConvLIFRecurrent(8, 8, 3)
+    assert c.hard_reset and c.recurrent and set(dict(c.named_parameters())) == {"leak", "thresh", "ff.weight", "rec.weight"}
+    with pytest.raises(AssertionError):
+        cells.ConvLIF(4, 8, 3, activation=None)  # spiking_submodules.py:78-81
+    with pytest.raises(AttributeError):
+        cells.ConvLIF(4, 8, 3, activation="nospike")
+    blk = cells.SpikingRecurrentConvLayer(2, 8, 3, stride=2, recurrent_block_type="plif")
+    assert type(blk.conv).__name__ == "ConvPLIF" and type(blk.recurrent_block).__name__ == "ConvPLIFRecurrent"
+
+
+def test_state_api_without_a_forward():
+    m = M.LIFFireNet(cfg())
+    assert m.states == [None] * 7
+    m.reset_states()
+    m.detach_states()
+    u = M.SpikingRecEVFlowNet(cfg(C=4))
+    assert u.states == [None] * 10 and u.multires_unetrec.num_states == 10
+    u.detach_states()
+    u.reset_states()
+    st = [torch.zeros(2, 1, 4, 3, 3), None]
+    assert copy_states([None, 1]) == [None, 1]
+    cp = copy_states([st[0], st[0]])
+    assert cp[0] is not st[0] and torch.equal(cp[0], st[0])
+
+
+def test_no_cpu_execution_of_models_and_cells():
+    x = torch.zeros(1, 2, 16, 16)
+    for m in (M.LIFFireNet(cfg()), M.FireNet(cfg(neuron=None, acts=("relu", None))), M.SpikingRecEVFlowNet(cfg(C=4)),
+              M.ALIFFireNet(cfg(neuron={"leak_v": [-4.0, 0.1]}))):
+        with pytest.raises(_lib.EvflowError):
+            m(x, x)
+    with pytest.raises(_lib.EvflowError):
+        cells.ConvLIF(2, 8, 3)(x, None)
+    with pytest.raises(AttributeError):
+        bad = cfg()
+        bad["encoding"] = "nope"
+        M.SpikingRecEVFlowNet(bad)(x, x)
+
+
+def test_crop_parameters_and_skip_concat_shapes():
+    cp = CropParameters(346, 260, 4)  # MVSEC resolution: width, height
+    assert (cp.width_crop_size, cp.height_crop_size) == (352, 272)
+    padded = cp.pad(torch.zeros(1, 2, 260, 346))
+    assert tuple(padded.shape) == (1, 2, 272, 352)
+    assert tuple(padded[:, :, cp.iy0 : cp.iy1, cp.ix0 : cp.ix1].shape) == (1, 2, 260, 346)
+    a, b = torch.zeros(1, 3, 7, 9), torch.zeros(1, 5, 8, 10)
+    assert tuple(skip_concat(a, b).shape) == (1, 8, 8, 10)
+    assert np.isclose(float(skip_concat(torch.ones(1, 1, 2, 2), torch.zeros(1, 1, 4, 4)).sum()), 4.0)
