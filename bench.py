@@ -202,7 +202,7 @@ def main():
         model.use_static_states(True)  # recurrent state must live at fixed addresses across replays
     pool = make_windows(dp.rank, 2, dev)
     names = ["evf_conv_lif_fwd", "evf_conv_lif_fwd_b3", "evf_conv_dgrad", "evf_conv_dgrad_b3", "evf_conv_wgrad_bits", "evf_lif_bwd_wgrad",
-             "evf_lif_bwd", "evf_head_lif_fwd", "evf_head_wgrad", "evf_pred_bwd", "evf_reduce_slabs", "evf_cm_loss_fwd",
+             "evf_lif_bwd", "evf_head_lif_bwd_wgrad", "evf_head_lif_fwd", "evf_head_wgrad", "evf_pred_bwd", "evf_reduce_slabs", "evf_cm_loss_fwd",
              "evf_cm_loss_bwd"]
 
     # Everything runs on one side stream: warm-up (eager), then one whole training step
@@ -276,11 +276,13 @@ def main():
             ("evf_conv_dgrad_b3", ""): (CONV_FLOP * npix, 320 * npix),
             ("evf_conv_wgrad_bits", ""): (CONV_FLOP * npix, 132 * npix),
             ("evf_lif_bwd_wgrad", "ff"): (CONV_FLOP * npix, 840 * npix), ("evf_lif_bwd_wgrad", "rec"): (2 * CONV_FLOP * npix, 844 * npix),
-            ("evf_lif_bwd", ""): (0, 772 * npix), ("evf_head_lif_fwd", ""): (2 * 18 * 32 * npix, 272 * npix),
+            ("evf_lif_bwd", ""): (0, 772 * npix), ("evf_head_lif_bwd_wgrad", ""): (2 * 18 * 32 * npix, 652 * npix),
+            ("evf_head_lif_fwd", ""): (2 * 18 * 32 * npix, 272 * npix),
         }
         # which roofline bounds the kernel: the fp32-MFMA convs are matrix-core bound; the bf16x3 kernels
         # need 1/5 of those cycles and are HBM bound, like the elementwise ones
-        hbm_bound = {"evf_conv_lif_fwd_b3", "evf_conv_dgrad_b3", "evf_lif_bwd_wgrad", "evf_lif_bwd", "evf_head_lif_fwd"}
+        hbm_bound = {"evf_conv_lif_fwd_b3", "evf_conv_dgrad_b3", "evf_lif_bwd_wgrad", "evf_lif_bwd", "evf_head_lif_fwd",
+                     "evf_head_lif_bwd_wgrad"}
         kernels = {}
         for key, ms in prof.items():
             ms = np.array(ms)

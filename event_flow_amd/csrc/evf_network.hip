@@ -453,13 +453,24 @@ __device__ __forceinline__ float evf_surrogate(int kind, float x, float width) {
   }
 }
 
-__global__ void k_lif_bwd(const float4* __restrict__ g_z_out, const float4* __restrict__ g_v_out,
+// HCIN > 0: also the head layer's weight gradient dW[co][ci][tap] += g_cur[pix][co] * x[b][ci][pix + tap]
+// (x = the network input, NCHW, HCIN channels) while g_cur is in registers: 36 HCIN accumulators per thread,
+// summed per block into slab[block][32][HCIN][9] (torch layout), reduced once per window (evf_sum_rows).
+template <int HCIN>
+__global__ __launch_bounds__(256, 2) void k_lif_bwd(const float4* __restrict__ g_z_out, const float4* __restrict__ g_v_out,
                           const float4* __restrict__ v_out, const float4* __restrict__ v_prev,
                           const uint32_t* __restrict__ z_prev, const float* __restrict__ leak,
                           const float* __restrict__ thresh, long npix, int hard_reset, int surrogate, float width,
                           float4* __restrict__ g_cur, float4* __restrict__ g_v_prev, float* __restrict__ g_leak,
-                          float* __restrict__ g_thresh) {
+                          float* __restrict__ g_thresh, const float* __restrict__ x_in, int H, int W,
+                          float* __restrict__ slab, int slab_acc) {
   __shared__ float s_red[2][4][C32];
+  constexpr int NW = HCIN > 0 ? HCIN * 9 : 1;
+  float dw[4][NW];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int q = 0; q < NW; ++q) dw[k][q] = 0.f;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int cg = tid & 7;  // channel group: channels 4cg..4cg+3
   float lam[4], th[4], oml[4], inv_oml[4];
@@ -502,8 +513,43 @@ __global__ void k_lif_bwd(const float4* __restrict__ g_z_out, const float4* __re
       sl[k] += gv * dlam;
       st[k] -= gsp;                           // spike fn sees (v' - thresh)
     }
-    g_cur[e] = make_float4(gc[0], gc[1], gc[2], gc[3]);
+    if (g_cur) g_cur[e] = make_float4(gc[0], gc[1], gc[2], gc[3]);
     g_v_prev[e] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+    if (HCIN > 0) {
+      const int pi = (int)pix, xx = pi % W, t1 = pi / W, yy = t1 % H, b = t1 / H;
+      const float* xb = x_in + (long)b * HCIN * H * W;
+#pragma unroll
+      for (int ci = 0; ci < HCIN; ++ci)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int y2 = yy + dy - 1, x2 = xx + dx - 1;
+            const bool in = y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
+            const float xv = xb[((long)ci * H + min(max(y2, 0), H - 1)) * W + min(max(x2, 0), W - 1)];
+            const float xm = in ? xv : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dw[k][ci * 9 + dy * 3 + dx] += gc[k] * xm;
+          }
+    }
+  }
+  if (HCIN > 0) {
+    __shared__ float s_w[4][C32 * NW];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        float v = dw[k][q];
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+        if (lane < 8) s_w[wv][(4 * lane + k) * NW + q] = v;
+      }
+    __syncthreads();
+    float* sl_out = slab + (long)blockIdx.x * (C32 * NW);
+    for (int e2 = tid; e2 < C32 * NW; e2 += blockDim.x) {
+      const float v = (s_w[0][e2] + s_w[1][e2]) + (s_w[2][e2] + s_w[3][e2]);
+      sl_out[e2] = slab_acc ? sl_out[e2] + v : v;
+    }
   }
   // reduce over the 8 lanes-per-pixel pattern: lanes with equal (lane & 7) share channels
 #pragma unroll
@@ -544,9 +590,51 @@ extern "C" int evf_lif_bwd(const float* g_z_out, const float* g_v_out, const flo
   const long npix = (long)B * H * W;
   // few, fat blocks: every block ends with 64 global atomics on the same 64 addresses
   const int nblk = (int)((npix * 8 + 255) / 256 < 768 ? (npix * 8 + 255) / 256 : 768);
-  hipLaunchKernelGGL(k_lif_bwd, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)g_z_out,
+  hipLaunchKernelGGL(k_lif_bwd<0>, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)g_z_out,
                      (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev, z_prev, leak, thresh, npix,
-                     hard_reset, surrogate, act_width, (float4*)g_cur, (float4*)g_v_prev, g_leak, g_thresh);
+                     hard_reset, surrogate, act_width, (float4*)g_cur, (float4*)g_v_prev, g_leak, g_thresh,
+                     (const float*)nullptr, H, W, (float*)nullptr, 0);
+  return evf_status();
+}
+
+#define HEAD_BWD_BLOCKS 512
+extern "C" int evf_head_lif_bwd_wgrad_slabs(int B, int H, int W) {
+  const long npix = (long)B * H * W;
+  const long nb = (npix * 8 + 255) / 256;
+  return (int)(nb < HEAD_BWD_BLOCKS ? nb : HEAD_BWD_BLOCKS);
+}
+
+// Head layer: neuron backward + weight gradient in one pass over g (models/spiking_submodules.py:96-126
+// autograd).  x_in [B,Cin,H,W] is the network input (Cin = 2); slab [evf_head_lif_bwd_wgrad_slabs][32*Cin*9]
+// receives (accumulate = 1: is added) the per-block weight-gradient partials in torch layout.
+extern "C" int evf_head_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const float* v_out, const float* v_prev,
+                                      const uint32_t* z_prev, const float* x_in, const float* leak, const float* thresh,
+                                      int B, int Cin, int H, int W, int hard_reset, int surrogate, float act_width,
+                                      float* g_cur, float* g_v_prev, float* g_leak, float* g_thresh, float* slab,
+                                      int accumulate, void* stream) {
+  if (!v_out || !x_in || !leak || !thresh || !g_v_prev || !g_leak || !g_thresh || !slab || B <= 0 || H <= 0 || W <= 0 ||
+      Cin != 2)
+    return EVF_EINVAL;
+  const long npix = (long)B * H * W;
+  const int nblk = evf_head_lif_bwd_wgrad_slabs(B, H, W);
+  hipLaunchKernelGGL(k_lif_bwd<2>, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)g_z_out,
+                     (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev, z_prev, leak, thresh, npix,
+                     hard_reset, surrogate, act_width, (float4*)g_cur, (float4*)g_v_prev, g_leak, g_thresh, x_in, H, W,
+                     slab, accumulate);
+  return evf_status();
+}
+
+// dst[e] (+)= sum_k rows[k][e]
+__global__ void k_sum_rows(const float* __restrict__ rows, int nrows, int n, int accumulate, float* __restrict__ dst) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nrows; ++k) s += rows[(long)k * n + e];
+  dst[e] = accumulate ? dst[e] + s : s;
+}
+extern "C" int evf_sum_rows(const float* rows, int nrows, int n, int accumulate, float* dst, void* stream) {
+  if (!rows || !dst || nrows <= 0 || n <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_sum_rows, dim3(evf_cdiv(n, 256)), dim3(256), 0, EVF_STREAM(stream), rows, nrows, n, accumulate, dst);
   return evf_status();
 }
 
@@ -776,7 +864,7 @@ __global__ __launch_bounds__(256) void k_pred_bwd(const uint32_t* __restrict__ x
   if (threadIdx.x < 2 * C32) s_w[threadIdx.x] = w[threadIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float accw0 = 0.f, accw1 = 0.f, accb0 = 0.f, accb1 = 0.f;  // lane c (< 32) owns channel c of dw[0], dw[1]
+  float accw0 = 0.f, accb0 = 0.f, accb1 = 0.f;  // lane owns dw[lane >> 5][lane & 31]
   const long npix = (long)B * HW;
   for (long p0 = (long)blockIdx.x * 256 + wv * 64; p0 < npix; p0 += (long)gridDim.x * 256) {
     const long p = p0 + lane;
@@ -788,25 +876,35 @@ __global__ __launch_bounds__(256) void k_pred_bwd(const uint32_t* __restrict__ x
       gp0 = g_flow[(b * 2) * HW + q] * (1.0f - f0 * f0);  // tanh'
       gp1 = g_flow[(b * 2 + 1) * HW + q] * (1.0f - f1 * f1);
       m = x[p];
-      float4* o = (float4*)(g_x + p * C32);
+    }
+    // g_x rows of the wave's 64 pixels, written coalesced: per store instruction lane l covers float4 (l & 7) of pixel
+    // 8 i + (l >> 3), i.e. 8 whole 128-B rows; the pixel's (gp0, gp1) come from its owner lane by shuffle
+    {
+      const int c4 = lane & 7;
+      const float wa0 = s_w[4 * c4], wa1 = s_w[4 * c4 + 1], wa2 = s_w[4 * c4 + 2], wa3 = s_w[4 * c4 + 3];
+      const float wb0 = s_w[C32 + 4 * c4], wb1 = s_w[C32 + 4 * c4 + 1], wb2 = s_w[C32 + 4 * c4 + 2],
+                  wb3 = s_w[C32 + 4 * c4 + 3];
 #pragma unroll
-      for (int c4 = 0; c4 < 8; ++c4) {
-        float4 v;
-        v.x = gp0 * s_w[4 * c4] + gp1 * s_w[C32 + 4 * c4];
-        v.y = gp0 * s_w[4 * c4 + 1] + gp1 * s_w[C32 + 4 * c4 + 1];
-        v.z = gp0 * s_w[4 * c4 + 2] + gp1 * s_w[C32 + 4 * c4 + 2];
-        v.w = gp0 * s_w[4 * c4 + 3] + gp1 * s_w[C32 + 4 * c4 + 3];
-        o[c4] = v;
+      for (int i = 0; i < 8; ++i) {
+        const int src = 8 * i + (lane >> 3);
+        const float a = __shfl(gp0, src, 64), bq = __shfl(gp1, src, 64);
+        const long pp = p0 + src;
+        if (pp < npix)
+          *(float4*)(g_x + pp * C32 + 4 * c4) = make_float4(a * wa0 + bq * wb0, a * wa1 + bq * wb1, a * wa2 + bq * wb2,
+                                                            a * wa3 + bq * wb3);
       }
     }
-    // channel c: sum of gp over the wave's pixels whose bit c is set; lane c keeps the result
-#pragma unroll 8
-    for (int c = 0; c < C32; ++c) {
-      const bool on = (m >> c) & 1u;
-      const float r0 = evf_wave_sum(on ? gp0 : 0.f), r1 = evf_wave_sum(on ? gp1 : 0.f);
-      if (lane == c) {
-        accw0 += r0;
-        accw1 += r1;
+    // dw[o][c] += sum over the wave's 64 pixels of bit_c(pixel) * gp_o(pixel): lane (c = lane & 31, o = lane >> 5)
+    // walks the pixels with scalar broadcasts (v_readlane), no cross-lane reductions
+    {
+      const int c = lane & 31;
+      const bool second = lane >= 32;
+#pragma unroll
+      for (int jp = 0; jp < 64; ++jp) {
+        const uint32_t mj = __builtin_amdgcn_readlane(m, jp);
+        const float g0j = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gp0), jp));
+        const float g1j = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gp1), jp));
+        accw0 += ((mj >> c) & 1u) ? (second ? g1j : g0j) : 0.f;
       }
     }
     accb0 += gp0;
@@ -814,10 +912,7 @@ __global__ __launch_bounds__(256) void k_pred_bwd(const uint32_t* __restrict__ x
   }
   accb0 = evf_wave_sum(accb0);
   accb1 = evf_wave_sum(accb1);
-  if (lane < C32) {
-    s_p[wv][lane] = accw0;
-    s_p[wv][C32 + lane] = accw1;
-  }
+  s_p[wv][lane] = accw0;  // [0..31] = dw[0][c], [32..63] = dw[1][c]
   if (lane == 0) {
     s_p[wv][2 * C32] = accb0;
     s_p[wv][2 * C32 + 1] = accb1;

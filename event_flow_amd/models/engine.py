@@ -374,6 +374,18 @@ class FireNetEngine:
                 win.slab_init[kf] = True
                 if use_rec:
                     win.slab_init[kr] = True
+            elif i == 0 and tape["x_in"].shape[1] == 2:
+                # head: neuron backward + weight gradient in one pass (per-block slabs, summed in _finalize)
+                nsl = _lib.load().evf_head_lif_bwd_wgrad_slabs(B, H, W)
+                key = (0, "ff")
+                if key not in self._slabs or self._slabs[key].shape != (nsl, C * 18) or self._slabs[key].device != dev:
+                    self._slabs[key] = _f32((nsl, C * 18), dev)
+                _lib.call("evf_head_lif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev),
+                          _lib.ptr(z_prev), _lib.ptr(tape["x_in"]), _lib.ptr(self._flat["0.leak"]),
+                          _lib.ptr(self._flat["0.thresh"]), B, 2, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
+                          self._act_width(0), _lib.ptr(win.g_cur) if plif else None, _lib.ptr(gv_out), _lib.ptr(leak_g),
+                          _lib.ptr(thr_g), _lib.ptr(self._slabs[key]), 1 if win.slab_init.get(key) else 0)
+                win.slab_init[key] = True
             else:
                 _lib.call("evf_lif_bwd", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
                           _lib.ptr(self._flat[f"{i}.leak"]), _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W,
@@ -440,6 +452,9 @@ class FireNetEngine:
                 grads.append(None)
                 continue
             if name in self.small_off:
+                if name == "0.ff" and win.slab_init.get((0, "ff")):  # head weight gradient: per-block partials
+                    sl = self._slabs[(0, "ff")]
+                    _lib.call("evf_sum_rows", _lib.ptr(sl), sl.shape[0], sl.shape[1], 1, _lib.ptr(self._small(win, name)))
                 grads.append(self._small(win, name).view(p.shape).to(p.dtype))
                 continue
             i, nm = name.split(".")

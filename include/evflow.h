@@ -257,6 +257,18 @@ int evf_conv_wgrad_bits(const uint32_t* x, const float* g_cur, int B, int H, int
 int evf_conv_wgrad_slabs(int B, int H, int W);
 int evf_reduce_slabs(const float* partial, int nslab, int n, int accumulate, float* dst, void* stream);
 
+/* Head layer, neuron backward + weight gradient fused (one pass over the gradient tensors):
+ * evf_lif_bwd plus dW partials per block into slab [evf_head_lif_bwd_wgrad_slabs(B,H,W)][32*Cin*9]
+ * (torch layout [32][Cin][3][3]; accumulate = 1 adds to the slab), reduced once per window with
+ * evf_sum_rows.  x_in [B,Cin,H,W] = the network input, Cin = 2.  g_cur may be null. */
+int evf_head_lif_bwd_wgrad_slabs(int B, int H, int W);
+int evf_head_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const float* v_out,
+                           const float* v_prev, const uint32_t* z_prev, const float* x_in, const float* leak,
+                           const float* thresh, int B, int Cin, int H, int W, int hard_reset, int surrogate,
+                           float act_width, float* g_cur, float* g_v_prev, float* g_leak, float* g_thresh,
+                           float* slab, int accumulate, void* stream);
+/* dst[e] (+)= sum_k rows[k][e], e < n */
+int evf_sum_rows(const float* rows, int nrows, int n, int accumulate, float* dst, void* stream);
 /* Head weight gradient: dW[co][ci][ky][kx] += sum g_cur[pix][co]*x[b][ci][pix+tap] (torch layout out). */
 int evf_head_wgrad(const float* x, const float* g_cur, int B, int Cin, int H, int W, float* dw, void* stream);
 
