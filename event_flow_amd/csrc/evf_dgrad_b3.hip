@@ -58,7 +58,7 @@ extern "C" int evf_pack_conv_weight_b3t(const float* w, int Cout, int Cin, void*
 __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3(const uint4* __restrict__ gs, long plane_stride,
                                                                 const uint4* __restrict__ wt, float* __restrict__ gx,
                                                                 int accumulate, int B, int H, int W,
-                                                                const float* __restrict__ gP,
+                                                                const float* __restrict__ gPb,
                                                                 const uint32_t* __restrict__ xbits) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint4* s_w = (uint4*)smem_raw;  // NFRAG*64
@@ -70,31 +70,29 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3(const uint4* __r
   const int i = lane & 31, kg = lane >> 5;
   f32x16 acc = {0};
   const long rowpix = ((long)b * H) * W;
-#pragma unroll 1
+#pragma unroll
   for (int dy = 0; dy < 3; ++dy) {
     const int yy = y + dy - 1;
     const bool yin = yy >= 0 && yy < H;
     // all 18 fragment loads of this input row (3 taps x 2 channel halves x 3 terms) are issued
-    // before the first MFMA: the memory latency is paid once per row, not per tap
+    // before the first MFMA: the memory latency is paid once per row, not per tap.  Loads are
+    // unconditional from clamped addresses (a load inside a divergent branch gets its own vmcnt(0)).
     uint4 a[3][2][3];
+    uint32_t msk[3];
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       const int xx = x0 + i + dx - 1;
-      const bool in = yin && xx >= 0 && xx < W;
-      // unconditional loads from a clamped address + a mask afterwards: a load inside a
-      // divergent branch makes the compiler drain vmcnt(0) after each one
+      msk[dx] = (yin && xx >= 0 && xx < W) ? 0xFFFFFFFFu : 0u;
       const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
       const long pg = (rowpix + (long)yc * W + xc) * 4 + kg;
-      const uint32_t msk = in ? 0xFFFFFFFFu : 0u;
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          uint4 v = gs[s * plane_stride + pg + 2 * m];
-          v.x &= msk, v.y &= msk, v.z &= msk, v.w &= msk;
-          a[dx][m][s] = v;
-        }
+        for (int s = 0; s < 3; ++s) a[dx][m][s] = gs[s * plane_stride + pg + 2 * m];
     }
+    // keep the compiler from interleaving loads and MFMAs (it otherwise minimises registers and
+    // serialises nine load->wait->mfma round trips per tile)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       const int tau = dy * 3 + dx;
@@ -103,7 +101,11 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3(const uint4* __r
         const uint4* wf = s_w + ((tau * 2 + m) * 3) * 64 + lane;
         const uint4 w0 = wf[0], w1 = wf[64], w2 = wf[128];
         const bf16x8 wh = *(const bf16x8*)&w0, wm = *(const bf16x8*)&w1, wl = *(const bf16x8*)&w2;
-        const bf16x8 ah = *(const bf16x8*)&a[dx][m][0], am = *(const bf16x8*)&a[dx][m][1], al = *(const bf16x8*)&a[dx][m][2];
+        uint4 u0 = a[dx][m][0], u1 = a[dx][m][1], u2 = a[dx][m][2];
+        u0.x &= msk[dx], u0.y &= msk[dx], u0.z &= msk[dx], u0.w &= msk[dx];
+        u1.x &= msk[dx], u1.y &= msk[dx], u1.z &= msk[dx], u1.w &= msk[dx];
+        u2.x &= msk[dx], u2.y &= msk[dx], u2.z &= msk[dx], u2.w &= msk[dx];
+        const bf16x8 ah = *(const bf16x8*)&u0, am = *(const bf16x8*)&u1, al = *(const bf16x8*)&u2;
         // smallest terms first
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
@@ -114,27 +116,24 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3(const uint4* __r
       }
     }
   }
+  // epilogue: all read-modify-write / PLIF loads first (unconditional, clamped), then the stores
+  float oldv[16], pv[16];
+  uint32_t xb[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int col = min(x0 + dg_row(r, lane), W - 1);
+    const long pix = ((long)b * H + y) * W + col;
+    oldv[r] = accumulate ? gx[pix * C32 + i] : 0.f;  // uniform condition
+    pv[r] = gPb ? gPb[pix] : 0.f;
+    xb[r] = gPb ? xbits[pix] : 0u;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int col = x0 + dg_row(r, lane);
-    if (col < W) {
-      float v = acc[r];
-      if (gP) {
-        // PLIF: the pooled pre-synaptic trace also depends on the input spikes:
-        // d mean_c|x| / dx_c = sign(x_c)/32, AvgPool3x3^T = the same box filter / 9
-        float box = 0.f;
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-          for (int dx = -1; dx <= 1; ++dx) {
-            const int yy = y + dy, xx = col + dx;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) box += gP[((long)b * H + yy) * W + xx];
-          }
-        if ((xbits[((long)b * H + y) * W + col] >> i) & 1u) v += (box / 9.0f) / 32.0f;
-      }
-      float* d = gx + (((long)b * H + y) * W + col) * C32 + i;
-      *d = accumulate ? *d + v : v;
-    }
+    // PLIF: the pooled pre-synaptic trace also reads the input spikes: d mean_c|x| / dx_c = 1/32 where the
+    // spike is set, AvgPool3x3^T = box filter / 9 -- gPb is that filtered, scaled map (evf_plif_trace_bwd)
+    const float v = acc[r] + oldv[r] + (((xb[r] >> i) & 1u) ? pv[r] : 0.f);
+    if (col < W) gx[(((long)b * H + y) * W + col) * C32 + i] = v;
   }
 }
 

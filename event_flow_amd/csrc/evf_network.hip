@@ -416,17 +416,39 @@ __global__ void k_plif_trace_bwd(const float4* __restrict__ g_cur, const float4*
   }
 }
 
+// AvgPool3x3^T of g_P (zero padded) / 32: the factor the input-gradient kernel adds where an input spike is set
+__global__ void k_plif_box(const float* __restrict__ g, int B, int H, int W, float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * H * W) return;
+  const int xx = (int)(idx % W), yy = (int)((idx / W) % H);
+  const long base = idx - (long)yy * W - xx;
+  float s = 0.f;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int y2 = yy + dy, x2 = xx + dx;
+      if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) s += g[base + (long)y2 * W + x2];
+    }
+  out[idx] = (s / 9.0f) / 32.0f;
+}
+
+// g_P_raw [B,H,W]: scratch (d loss / d pooled activity); g_P_in [B,H,W]: its adjoint through the pooling and the
+// channel mean, i.e. d loss / d(input spike) contributed by the trace wherever the spike is set
+// (operand of evf_conv_dgrad_b3).
 extern "C" int evf_plif_trace_bwd(const float* g_cur, const float* g_pt_carry, const float* pt_prev, const float* pt_out,
                                   const float* P, const float* leak_pt, const float* add_pt, int B, int H, int W,
-                                  float* g_pt_prev, float* g_P, float* g_leak_pt, float* g_add_pt, void* stream) {
-  if (!g_cur || !pt_out || !P || !leak_pt || !add_pt || !g_pt_prev || !g_P || !g_leak_pt || !g_add_pt || B <= 0 ||
-      H <= 0 || W <= 0)
+                                  float* g_pt_prev, float* g_P_raw, float* g_P_in, float* g_leak_pt, float* g_add_pt,
+                                  void* stream) {
+  if (!g_cur || !pt_out || !P || !leak_pt || !add_pt || !g_pt_prev || !g_P_raw || !g_P_in || !g_leak_pt || !g_add_pt ||
+      B <= 0 || H <= 0 || W <= 0)
     return EVF_EINVAL;
   const long npix = (long)B * H * W;
   const int nblk = (int)((npix * 8 + 255) / 256 < 512 ? (npix * 8 + 255) / 256 : 512);
   hipLaunchKernelGGL(k_plif_trace_bwd, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)g_cur,
                      (const float4*)g_pt_carry, (const float4*)pt_prev, (const float4*)pt_out, P, leak_pt, add_pt, npix,
-                     (float4*)g_pt_prev, g_P, g_leak_pt, g_add_pt);
+                     (float4*)g_pt_prev, g_P_raw, g_leak_pt, g_add_pt);
+  hipLaunchKernelGGL(k_plif_box, dim3(evf_cdiv(npix, 256)), dim3(256), 0, EVF_STREAM(stream), g_P_raw, B, H, W, g_P_in);
   return evf_status();
 }
 
@@ -624,17 +646,27 @@ extern "C" int evf_head_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out
   return evf_status();
 }
 
-// dst[e] (+)= sum_k rows[k][e]
-__global__ void k_sum_rows(const float* __restrict__ rows, int nrows, int n, int accumulate, float* __restrict__ dst) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < nrows; ++k) s += rows[(long)k * n + e];
-  dst[e] = accumulate ? dst[e] + s : s;
+// dst[e] (+)= sum_k rows[k][e]: 16 columns x 16 row groups per block, LDS tree over the groups
+__global__ __launch_bounds__(256) void k_sum_rows(const float* __restrict__ rows, int nrows, int n, int accumulate,
+                                                  float* __restrict__ dst) {
+  __shared__ float s[16][17];
+  const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + c;
+  float v = 0.f;
+  if (e < n)
+    for (int k = grp; k < nrows; k += 16) v += rows[(long)k * n + e];
+  s[grp][c] = v;
+  __syncthreads();
+  if (grp == 0 && e < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += s[k][c];
+    dst[e] = accumulate ? dst[e] + t : t;
+  }
 }
 extern "C" int evf_sum_rows(const float* rows, int nrows, int n, int accumulate, float* dst, void* stream) {
   if (!rows || !dst || nrows <= 0 || n <= 0) return EVF_EINVAL;
-  hipLaunchKernelGGL(k_sum_rows, dim3(evf_cdiv(n, 256)), dim3(256), 0, EVF_STREAM(stream), rows, nrows, n, accumulate, dst);
+  hipLaunchKernelGGL(k_sum_rows, dim3(evf_cdiv(n, 16)), dim3(256), 0, EVF_STREAM(stream), rows, nrows, n, accumulate, dst);
   return evf_status();
 }
 

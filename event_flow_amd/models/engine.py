@@ -408,11 +408,12 @@ class FireNetEngine:
             if plif:  # trace backward: carries dL/dpt, yields dL/d(pooled activity) for the input-spike gradient
                 if win.gP is None:
                     win.gP = _f32((B, H, W), dev)
+                    win.gP_raw = _f32((B, H, W), dev)
                 gpt_out = win.buf(win.gpt, i)
                 carry = gpt_out if win.gpt_has[i] else None
                 _lib.call("evf_plif_trace_bwd", _lib.ptr(win.g_cur), _lib.ptr(carry), _lib.ptr(pt_prev), _lib.ptr(pt_out),
                           _lib.ptr(P_sav), _lib.ptr(self._flat[f"{i}.leak_pt"]), _lib.ptr(self._flat[f"{i}.add_pt"]), B, H, W,
-                          _lib.ptr(gpt_out), _lib.ptr(win.gP), _lib.ptr(self._small(win, f"{i}.leak_pt")),
+                          _lib.ptr(gpt_out), _lib.ptr(win.gP_raw), _lib.ptr(win.gP), _lib.ptr(self._small(win, f"{i}.leak_pt")),
                           _lib.ptr(self._small(win, f"{i}.add_pt")))
                 win.gpt_has[i] = not is_first
             if is_first:

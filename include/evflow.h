@@ -226,8 +226,10 @@ int evf_conv_dgrad_b3(const void* g_split, const void* wT_b3, float* g_x, int ac
  * current = ff (+rec) - s(add_pt)*pt'.  Forward = the LIF kernels plus pt_prev/pt_out
  * [B,H,W,32] and P_out [B,H,W] (the pooled activity, saved for the backward).  Backward =
  * evf_lif_bwd_wgrad / evf_lif_bwd (they yield g_cur) followed by evf_plif_trace_bwd
- * (g_pt carry, g_P, d leak_pt, d add_pt); the gradient that reaches the input spikes through
- * the trace is added by evf_conv_dgrad_b3 when g_P / x_bits are given. */
+ * (g_pt carry, d leak_pt, d add_pt; g_P_raw [B,H,W] scratch = d loss / d pooled activity,
+ * g_P_in [B,H,W] = its adjoint through AvgPool3x3 and the channel mean); the gradient that
+ * reaches the input spikes through the trace is added by evf_conv_dgrad_b3 when g_P = g_P_in
+ * and x_bits are given. */
 int evf_conv_plif_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec,
                          const float* leak_v, const float* leak_pt, const float* add_pt, const float* thresh,
                          const float* v_prev, const uint32_t* z_prev, const float* pt_prev,
@@ -239,7 +241,8 @@ int evf_head_plif_fwd(const float* x, const float* w, const float* leak_v, const
                       float* v_out, uint32_t* z_out, uint32_t* zT_out, float* pt_out, float* P_out, void* stream);
 int evf_plif_trace_bwd(const float* g_cur, const float* g_pt_carry, const float* pt_prev, const float* pt_out,
                        const float* P, const float* leak_pt, const float* add_pt, int B, int H, int W,
-                       float* g_pt_prev, float* g_P, float* g_leak_pt, float* g_add_pt, void* stream);
+                       float* g_pt_prev, float* g_P_raw, float* g_P_in, float* g_leak_pt, float* g_add_pt,
+                       void* stream);
 
 /* Input-gradient conv: g_x[pix][ci] (+)= sum_tap,co g_cur[pix-tap][co]*w[co][ci][tap]
  * with wT packed by evf_pack_conv_weight(transposed=1).  g_cur, g_x [B,H,W,32].
