@@ -48,6 +48,7 @@ NETWORK_SIGNATURES = {
     "evf_head_lif_bwd_wgrad_slabs": [I, I, I],
     "evf_head_lif_bwd_wgrad": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, P, P, P, P, I, P],
     "evf_sum_rows": [P, I, I, I, P, P],
+    "evf_add_segments": [P, P, P, P, I, P],
     "evf_lif_bwd_wgrad": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P, P, P, I, P],
     "evf_pack_conv_weight_b3t": [P, I, I, P, P],
     "evf_conv_dgrad_b3": [P, P, P, I, I, I, I, P, P, P],

@@ -646,6 +646,32 @@ extern "C" int evf_head_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out
   return evf_status();
 }
 
+// dst_k[i] += src[off_k + i], i < n_k, for up to 32 segments in one launch (block y = segment)
+struct AddSegs {
+  float* dst[32];
+  int off[32];
+  int n[32];
+};
+__global__ void k_add_segments(const float* __restrict__ src, AddSegs sg) {
+  const int k = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < sg.n[k]; i += gridDim.x * blockDim.x)
+    sg.dst[k][i] += src[sg.off[k] + i];
+}
+extern "C" int evf_add_segments(const float* src, void* const* dst, const int* off, const int* n, int nseg, void* stream) {
+  if (!src || !dst || !off || !n || nseg <= 0 || nseg > 32) return EVF_EINVAL;
+  AddSegs sg;
+  int nmax = 1;
+  for (int k = 0; k < 32; ++k) {
+    sg.dst[k] = k < nseg ? (float*)dst[k] : nullptr;
+    sg.off[k] = k < nseg ? off[k] : 0;
+    sg.n[k] = k < nseg ? n[k] : 0;
+    if (sg.n[k] > nmax) nmax = sg.n[k];
+  }
+  hipLaunchKernelGGL(k_add_segments, dim3(evf_cdiv(nmax, 256) < 8 ? evf_cdiv(nmax, 256) : 8, nseg), dim3(256), 0,
+                     EVF_STREAM(stream), src, sg);
+  return evf_status();
+}
+
 // dst[e] (+)= sum_k rows[k][e]: 16 columns x 16 row groups per block, LDS tree over the groups
 __global__ __launch_bounds__(256) void k_sum_rows(const float* __restrict__ rows, int nrows, int n, int accumulate,
                                                   float* __restrict__ dst) {

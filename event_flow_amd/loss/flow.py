@@ -58,14 +58,26 @@ class _WindowRecord:
         if self._cache is None:
             ev = torch.cat([e.to(torch.float32) for e in self.events], 1).contiguous()
             pol = torch.cat([p.to(torch.float32) for p in self.pol], 1).contiguous()
-            ev_pass = torch.cat(
-                [torch.full((e.shape[1],), k, dtype=torch.int32, device=ev.device) for k, e in enumerate(self.events)]
-            )
+            ev_pass = _pass_index(tuple(e.shape[1] for e in self.events), ev.device)
             self._cache = (ev, pol, ev_pass)
         return self._cache
 
     def mask_stack(self):
         return torch.cat([m.to(torch.float32) for m in self.masks], 1).contiguous()  # [B,P,H,W]
+
+
+_PASS_INDEX = {}
+
+
+def _pass_index(lengths, device):
+    """int32 [sum(lengths)]: pass number of every event of the concatenated window (built once per shape)."""
+    key = (lengths, str(device))
+    if key not in _PASS_INDEX:
+        import numpy as np
+
+        idx = np.repeat(np.arange(len(lengths), dtype=np.int32), lengths)
+        _PASS_INDEX[key] = torch.from_numpy(idx).to(device)
+    return _PASS_INDEX[key]
 
 
 class _CMLoss(torch.autograd.Function):

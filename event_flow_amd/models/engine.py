@@ -17,6 +17,8 @@ are accumulated over the window and delivered by the node of the window's
 first pass.
 """
 
+import ctypes
+
 import torch
 
 from .. import _lib
@@ -67,7 +69,7 @@ class _FireNetPass(torch.autograd.Function):
         flow, tape, new_states = eng._forward_pass(x_in, eng._states, record=True)
         eng._states = new_states
         ctx.eng, ctx.win, ctx.tape, ctx.is_first = eng, win, tape, is_first
-        new_token = torch.zeros((), dtype=torch.float32, device=flow.device)
+        new_token = torch.empty((), dtype=torch.float32, device=flow.device)  # only its autograd edge is used
         return flow, new_token
 
     @staticmethod
@@ -231,7 +233,7 @@ class FireNetEngine:
                 continue
             for nm, w in (("ff", c.ff.weight),) + ((("rec", c.rec.weight),) if c.recurrent else ()):
                 wd = w.detach().float().contiguous()
-                for tr in (0, 1):
+                for tr in (0, 1) if self.precision == "fp32" else ():
                     k = (i, nm, tr)
                     if k not in self._packed:
                         self._packed[k] = _f32((9 * C * C,), dev)
@@ -448,21 +450,42 @@ class FireNetEngine:
         nslab = (_lib.load().evf_lif_bwd_wgrad_slabs(B, H, W) if self.precision == "bf16x3"
                  else _lib.load().evf_conv_wgrad_slabs(B, H, W))
         grads = []
+        seg_src, seg_dst, seg_n = [], [], []
         for name, p in zip(self.pnames, self.params):
             if not p.requires_grad:
                 grads.append(None)
                 continue
+            # a bound fp32 .grad (FlatAdam's flat buffer, or a previous backward): accumulate into it in our
+            # kernels and hand autograd nothing -- saves one add kernel per parameter tensor per step
+            direct = p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.is_cuda
             if name in self.small_off:
                 if name == "0.ff" and win.slab_init.get((0, "ff")):  # head weight gradient: per-block partials
                     sl = self._slabs[(0, "ff")]
                     _lib.call("evf_sum_rows", _lib.ptr(sl), sl.shape[0], sl.shape[1], 1, _lib.ptr(self._small(win, name)))
-                grads.append(self._small(win, name).view(p.shape).to(p.dtype))
+                if direct:
+                    seg_src.append(self.small_off[name][0])
+                    seg_dst.append(p.grad)
+                    seg_n.append(self.small_off[name][1])
+                    grads.append(None)
+                else:
+                    grads.append(self._small(win, name).view(p.shape).to(p.dtype))
                 continue
             i, nm = name.split(".")
             k = (int(i), nm)
+            if direct:
+                if win.slab_init.get(k):
+                    _lib.call("evf_reduce_slabs", _lib.ptr(self._slabs[k]), nslab, 9 * C * C, 1, _lib.ptr(p.grad))
+                grads.append(None)
+                continue
             g = torch.zeros(p.shape, dtype=torch.float32, device=win.dev)
             if win.slab_init.get(k):
                 _lib.call("evf_reduce_slabs", _lib.ptr(self._slabs[k]), nslab, 9 * C * C, 0, _lib.ptr(g))
             grads.append(g.to(p.dtype))
+        for lo in range(0, len(seg_src), 32):  # all small gradients in one launch (32 segments per call)
+            hi = min(lo + 32, len(seg_src))
+            ptrs = (ctypes.c_void_p * 32)(*[t.data_ptr() for t in seg_dst[lo:hi]])
+            offs = (ctypes.c_int * 32)(*seg_src[lo:hi])
+            lens = (ctypes.c_int * 32)(*seg_n[lo:hi])
+            _lib.call("evf_add_segments", _lib.ptr(win.small), ptrs, offs, lens, hi - lo)
         self._last_window = win
         return grads

@@ -270,6 +270,9 @@ int evf_head_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const flo
                            const float* thresh, int B, int Cin, int H, int W, int hard_reset, int surrogate,
                            float act_width, float* g_cur, float* g_v_prev, float* g_leak, float* g_thresh,
                            float* slab, int accumulate, void* stream);
+/* dst[k][i] += src[off[k] + i], i < n[k], for nseg <= 32 segments (host arrays of device pointers / ints):
+ * the per-channel gradients of a window added into the optimizer's flat gradient buffer in one launch. */
+int evf_add_segments(const float* src, void* const* dst, const int* off, const int* n, int nseg, void* stream);
 /* dst[e] (+)= sum_k rows[k][e], e < n */
 int evf_sum_rows(const float* rows, int nrows, int n, int accumulate, float* dst, void* stream);
 /* Head weight gradient: dW[co][ci][ky][kx] += sum g_cur[pix][co]*x[b][ci][pix+tap] (torch layout out). */
