@@ -207,6 +207,7 @@ __global__ __launch_bounds__(1024) void k_iwe_splat_lds(const float* __restrict_
   // events in batches of IW_U per thread: all event loads first, then all flow gathers (which
   // depend on them), then the splats -- the two dependent memory latencies are paid once per batch
 #define IW_U 4
+  const bool pair = w0 && w1 == w0 + 1 && wstride == 2 && (((uintptr_t)w0) & 7) == 0;
   for (int e0 = threadIdx.x; e0 < M; e0 += IW_U * blockDim.x) {
     float4 qs[IW_U];
     float a0s[IW_U], a1s[IW_U], ts[IW_U], fys[IW_U], fxs[IW_U];
@@ -218,8 +219,13 @@ __global__ __launch_bounds__(1024) void k_iwe_splat_lds(const float* __restrict_
       qs[u] = ev[i];
       ts[u] = ts_shift ? (float)ts_shift[e] : 0.f;
       maps[u] = map_of_event ? map_of_event[e] : 0;
-      a0s[u] = w0 ? w0[i * wstride] : 1.0f;
-      a1s[u] = w1 ? w1[i * wstride] : 0.0f;
+      if (pair) {  // the two weights are adjacent floats (the reference's [B,N,2] polarity mask): one 8-byte load
+        const float2 a = *(const float2*)(w0 + i * 2);
+        a0s[u] = a.x, a1s[u] = a.y;
+      } else {
+        a0s[u] = w0 ? w0[i * wstride] : 1.0f;
+        a1s[u] = w1 ? w1[i * wstride] : 0.0f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < IW_U; ++u) evf_event_flow(flow, maps[u], B, b, HW, qs[u].y, qs[u].z, W, fys[u], fxs[u]);
