@@ -324,7 +324,8 @@ def main():
             "kernels": kernels,
         }
         if not args.no_iwe:
-            out["iwe_warp"] = {"spec_shape": iwe_warp_bandwidth(dev, 8), "saturating": iwe_warp_bandwidth(dev, 512, reps=5)}
+            out["iwe_warp"] = {"spec_shape": iwe_warp_bandwidth(dev, 8), "saturating": iwe_warp_bandwidth(dev, 512, reps=5),
+                               "saturating_2048": iwe_warp_bandwidth(dev, 2048, reps=3)}
         if dp.world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or (os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(threads)

@@ -280,6 +280,124 @@ __global__ __launch_bounds__(1024) void k_iwe_splat_lds(const float* __restrict_
   }
 }
 
+// Single flow map, one image plane <= 64 KiB, M <= 16 Ki events per sample (compute_pol_iwe at the
+// benchmark shape): the sample's events stay in registers (16 per thread) and ONE 64 KiB LDS plane is reused
+// in turn for flow_x, flow_y and each IWE channel:
+//   stage flow_x (coalesced) -> wx of every event;  stage flow_y -> wy;  per channel: zero, LDS-atomic splat,
+//   coalesced write-out.
+// The two random 4-byte gathers per event (which bound k_iwe_splat_lds: they miss the 32 KiB L1 and queue at
+// the L2) become LDS reads; HBM sees every input byte once, coalesced.  Same arithmetic, same bit-exact
+// integer histograms.
+#define IWR_EPT 15
+#define IWR_THREADS 1024
+#define IWR_NQ 4  // float4 per thread per 64 KiB plane
+// PAIRW: the two weights are adjacent floats (the reference's [B,N,2] polarity mask) -> one 8-byte load;
+// otherwise no weights at all (w0 = 1, single channel).  No per-event runtime branches: every uniform
+// condition inside the unrolled event loops costs a basic block (and a spill) per event.
+// When every weight of the sample is 0 or 1 (polarity masks) the splat uses INTEGER LDS atomics on one plane
+// holding both channels as 16-bit counters (ds_add_u32 runs ~5x faster than ds_add_f32 on gfx950, measured);
+// counts < 2^16 are exact in fp32, so the result is bit-identical to float accumulation.
+template <bool PAIRW>
+__global__ __launch_bounds__(IWR_THREADS) void k_iwe_splat_reg(const float* __restrict__ flow,
+                                                               const float4* __restrict__ ev,
+                                                               const float2* __restrict__ wpair, int B, int M, int H,
+                                                               int W, float S, float tref, float zero_flow, int nch,
+                                                               float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* pl = (float*)smem_raw;  // [H*W]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int HW = H * W, HQ = HW / 4;
+  // register budget: (t, y, x, lin) per event during the two flow stages, (wy, wx, a0, a1) afterwards --
+  // the polarity weights are only loaded once t and lin are dead
+  float t[IWR_EPT], y[IWR_EPT], x[IWR_EPT];
+  int lin[IWR_EPT];
+  const float4* evb = ev + (long)b * M;
+  const float4* f = (const float4*)(flow + (long)b * 2 * HW);
+  // both flow planes are requested up front, together with the events
+  float4 px[IWR_NQ], py[IWR_NQ];
+#pragma unroll
+  for (int k = 0; k < IWR_NQ; ++k) {
+    const int q = min(tid + k * IWR_THREADS, HQ - 1);
+    px[k] = f[q];        // horizontal component (channel 0, loss/flow.py:76)
+    py[k] = f[HQ + q];   // vertical component (channel 1, :75)
+  }
+#pragma unroll
+  for (int u = 0; u < IWR_EPT; ++u) {
+    const float4 q = evb[min(tid + u * IWR_THREADS, M - 1)];
+    t[u] = tref - q.x;
+    y[u] = q.y, x[u] = q.z;
+    lin[u] = min(max((int)(q.y * (float)W + q.z), 0), HW - 1);  // flow_idx = y*W + x in float, .long() (loss/flow.py:65-67)
+  }
+#pragma unroll
+  for (int k = 0; k < IWR_NQ; ++k)
+    if (tid + k * IWR_THREADS < HQ) ((float4*)pl)[tid + k * IWR_THREADS] = px[k];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < IWR_EPT; ++u) x[u] = x[u] + (t[u] * (pl[lin[u]] * zero_flow)) * S;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < IWR_NQ; ++k)
+    if (tid + k * IWR_THREADS < HQ) ((float4*)pl)[tid + k * IWR_THREADS] = py[k];
+  float a0[IWR_EPT], a1[IWR_EPT];
+#pragma unroll
+  for (int u = 0; u < IWR_EPT; ++u) {
+    if (PAIRW) {
+      const float2 a = wpair[(long)b * M + min(tid + u * IWR_THREADS, M - 1)];
+      a0[u] = a.x, a1[u] = a.y;
+    } else {
+      a0[u] = 1.0f, a1[u] = 0.f;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < IWR_EPT; ++u) y[u] = y[u] + (t[u] * (pl[lin[u]] * zero_flow)) * S;
+  // destination pixel (or -1) of every event: rounded indices, torch.round = half-to-even
+  int dst[IWR_EPT];
+  bool bin = true;
+#pragma unroll
+  for (int u = 0; u < IWR_EPT; ++u) {
+    const float iy = rintf(y[u]), ix = rintf(x[u]);
+    const bool in = !(iy < 0.f || iy >= (float)H || ix < 0.f || ix >= (float)W) && tid + u * IWR_THREADS < M;
+    dst[u] = in ? (int)(iy * (float)W + ix) : -1;
+    bin = bin && (a0[u] == 0.f || a0[u] == 1.f) && (a1[u] == 0.f || a1[u] == 1.f);
+  }
+  const bool packed = __syncthreads_and(bin) && M < 65536;  // also: every wave is done reading the flow plane
+  if (packed) {
+    for (int q = tid; q < HQ; q += IWR_THREADS) ((uint4*)pl)[q] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    unsigned* cnt = (unsigned*)pl;
+#pragma unroll
+    for (int u = 0; u < IWR_EPT; ++u) {
+      const unsigned inc = (a0[u] != 0.f ? 1u : 0u) | (a1[u] != 0.f ? 0x10000u : 0u);
+      if (dst[u] >= 0 && inc) atomicAdd(&cnt[dst[u]], inc);
+    }
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+      float4* o = (float4*)(out + ((long)b * nch + ch) * HW);
+      const int sh = 16 * ch;
+      for (int q = tid; q < HQ; q += IWR_THREADS) {
+        const uint4 c = ((const uint4*)pl)[q];
+        o[q] = make_float4((float)((c.x >> sh) & 0xFFFFu), (float)((c.y >> sh) & 0xFFFFu), (float)((c.z >> sh) & 0xFFFFu),
+                           (float)((c.w >> sh) & 0xFFFFu));
+      }
+    }
+    return;
+  }
+  for (int ch = 0; ch < nch; ++ch) {
+    if (ch) __syncthreads();
+    for (int q = tid; q < HQ; q += IWR_THREADS) ((float4*)pl)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < IWR_EPT; ++u) {
+      const float a = ch ? a1[u] : a0[u];
+      if (dst[u] >= 0 && a != 0.f) atomicAdd(&pl[dst[u]], a);
+    }
+    __syncthreads();
+    float4* o = (float4*)(out + ((long)b * nch + ch) * HW);
+    for (int q = tid; q < HQ; q += IWR_THREADS) o[q] = ((float4*)pl)[q];
+  }
+}
+
 extern "C" int evf_iwe_splat(const float* flow, const float* ev, const int32_t* map_of_event, const int32_t* ts_shift,
                              const float* w0, const float* w1, int wstride, int B, int M, int H, int W,
                              float flow_scaling, float tref, float tref_ts, int mode, int nch, float* out, void* stream) {
@@ -291,6 +409,28 @@ extern "C" int evf_iwe_splat(const float* flow, const float* ev, const int32_t* 
   // stripe height: as tall as 128 KiB of LDS allows, shrunk (down to 8 rows) until the grid has
   // >= 256 blocks; every block re-reads the sample's events (L2 resident), so shorter stripes
   // trade redundant event reads for parallelism
+  // register-resident events + one reused LDS plane: single flow map, plane <= 64 KiB, M <= 16 Ki events,
+  // enough samples to fill the CUs
+  // Register-resident events + one reused LDS plane (k_iwe_splat_reg): rounded indices, single flow map, no
+  // timestamp images / shifts, plane <= 64 KiB and a multiple of 16 bytes, M <= 15 Ki events, polarity weights as
+  // an interleaved pair (or none), enough samples to fill the CUs -- i.e. compute_pol_iwe at the benchmark shape.
+  {
+    const bool pairw = w0 && w1 == w0 + 1 && wstride == 2 && (((uintptr_t)w0) & 7) == 0 && nch == 2;
+    const bool now = !w0 && !w1 && nch == 1;
+    if ((mode & 1) && !(mode & 12) && !map_of_event && !ts_shift && (pairw || now) && (long)H * W * 4 <= 64 * 1024 &&
+        ((H * W) & 3) == 0 && H * W <= 4 * IWR_NQ * IWR_THREADS && M <= IWR_EPT * IWR_THREADS && B >= 64 && (((uintptr_t)flow) & 15) == 0 &&
+        (((uintptr_t)out) & 15) == 0) {
+      const size_t lds = (size_t)H * W * 4;
+      const float zf = (mode & 2) ? 0.f : 1.f;  // `flow * 0` (FWL/RSAT reference images) keeps NaN/sign semantics
+      if (pairw)
+        hipLaunchKernelGGL(k_iwe_splat_reg<true>, dim3(B), dim3(IWR_THREADS), lds, st, flow, (const float4*)ev,
+                           (const float2*)w0, B, M, H, W, flow_scaling, tref, zf, nch, out);
+      else
+        hipLaunchKernelGGL(k_iwe_splat_reg<false>, dim3(B), dim3(IWR_THREADS), lds, st, flow, (const float4*)ev,
+                           (const float2*)nullptr, B, M, H, W, flow_scaling, tref, zf, nch, out);
+      return evf_status();
+    }
+  }
   const int max_rows = (128 * 1024) / (nch * W * 4);
   // small problems (a few 100k events) are latency bound: the plain global-atomic kernel (3 us at
   // B=8 x 15k) wins there; the LDS version wins once the device-scope atomics saturate

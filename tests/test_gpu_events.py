@@ -281,3 +281,28 @@ def test_pol_iwe_large_batch_lds_path_bit_exact():
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
     one = N(hiwe.deblur_events(G(flow), G(ev), (H, W), flow_scaling=128, round_idx=True))
     assert np.array_equal(one[:, 0], got.shape and (oiwe.deblur_events(flow, ev, (H, W), 128, True))[:, 0])
+
+
+@pytest.mark.parametrize("shape", [(64, 15000, 128, 128), (70, 9000, 96, 160)])
+def test_pol_iwe_register_resident_kernel_bit_exact(shape):
+    """B >= 64, one flow map, plane <= 64 KiB, <= 15 Ki events per sample selects k_iwe_splat_reg (events in
+    registers, flow planes and the image through one reused LDS plane).  Binary polarity masks take the packed
+    16-bit integer-atomic path, other weights the float path; both must reproduce the oracle's histogram exactly
+    (weights that are multiples of 1/4 keep every partial sum exact), including events warped out of the image."""
+    B, n, H, W = shape
+    ev = synthetic.event_list_batch(B, n, H, W, 9100)
+    rng = np.random.default_rng(5)
+    flow = rng.uniform(-0.6, 0.6, size=(B, 2, H, W)).astype(np.float32)  # up to 77 px: many events leave the image
+    pol = np.stack([(ev[:, :, 3] > 0), (ev[:, :, 3] < 0)], 2).astype(np.float32)
+    gpol = G(pol)
+    got = N(hiwe.compute_pol_iwe(G(flow), G(ev), (H, W), gpol[:, :, 0:1], gpol[:, :, 1:2], flow_scaling=128, round_idx=True))
+    ref = oiwe.compute_pol_iwe(flow, ev, (H, W), pol[:, :, 0:1], pol[:, :, 1:2], flow_scaling=128, round_idx=True)
+    assert np.array_equal(got, ref)
+    assert got.sum() < B * n  # some events did leave
+    wts = pol * rng.integers(1, 9, size=pol.shape).astype(np.float32) * 0.25
+    gw = G(wts)
+    got = N(hiwe.compute_pol_iwe(G(flow), G(ev), (H, W), gw[:, :, 0:1], gw[:, :, 1:2], flow_scaling=128, round_idx=True))
+    ref = oiwe.compute_pol_iwe(flow, ev, (H, W), wts[:, :, 0:1], wts[:, :, 1:2], flow_scaling=128, round_idx=True)
+    assert np.array_equal(got, ref)
+    one = N(hiwe.deblur_events(G(flow), G(ev), (H, W), flow_scaling=128, round_idx=True))
+    assert np.array_equal(one, oiwe.deblur_events(flow, ev, (H, W), 128, True))
