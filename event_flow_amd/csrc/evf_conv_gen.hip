@@ -41,15 +41,15 @@ struct ConvGeo {
 
 __device__ __forceinline__ int cg_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-static inline int cg_nt(int N) { return N > 32 ? 2 : 1; }
 
 // ---------------------------------------------------------------------------
 // weight packing.  w is the torch layout [Cout][Cin][k][k].  transpose = 0:
 // K = Cin, N = Cout (forward); transpose = 1: K = Cout, N = Cin (input grad).
-// dst float4 index ((((nb*T + tap)*G + g)*NT + t)*8 + ch*2 + h)*64 + lane, element j:
-//   k = g*64 + ch*16 + 8*(lane>>5) + 4h + j,   n = (nb*NT + t)*32 + (lane&31)
+// dst float4 index (((nt*T + tap)*G + g)*8 + ch*2 + h)*64 + lane (nt = 32-wide N tile), element j:
+//   k = g*64 + ch*16 + 8*(lane>>5) + 4h + j,   n = nt*32 + (lane&31)
+// (independent of how many N tiles a block of the consumer kernel covers)
 // ---------------------------------------------------------------------------
-__global__ void k_pack_conv2d(const float* __restrict__ w, int Cout, int Cin, int T, int transpose, int NT, long total,
+__global__ void k_pack_conv2d(const float* __restrict__ w, int Cout, int Cin, int T, int transpose, long total,
                               int cin_total, int cin_off, float4* __restrict__ dst) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
@@ -59,14 +59,12 @@ __global__ void k_pack_conv2d(const float* __restrict__ w, int Cout, int Cin, in
   long q = idx >> 6;
   const int chh = q & 7;
   q >>= 3;
-  const int t = q % NT;
-  q /= NT;
   const int g = q % G;
   q /= G;
   const int tap = q % T;
-  const int nb = q / T;
+  const int nt = q / T;
   const int ch = chh >> 1, h = chh & 1;
-  const int n = (nb * NT + t) * 32 + (lane & 31);
+  const int n = nt * 32 + (lane & 31);
   float v[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -83,8 +81,8 @@ __global__ void k_pack_conv2d(const float* __restrict__ w, int Cout, int Cin, in
 
 static long cg_packed_float4(int Cout, int Cin, int ksz, int transpose) {
   const int K = transpose ? Cout : Cin, N = transpose ? Cin : Cout;
-  const int NT = cg_nt(N), NB = evf_cdiv(N, 32 * NT), G = evf_cdiv(K, CG_KG), T = ksz * ksz;
-  return (long)NB * T * G * NT * 512;
+  const int NTILES = evf_cdiv(N, 32), G = evf_cdiv(K, CG_KG), T = ksz * ksz;
+  return (long)NTILES * T * G * 512;
 }
 
 extern "C" int64_t evf_conv2d_packed_size(int Cout, int Cin, int ksz, int transpose) {
@@ -96,33 +94,42 @@ extern "C" int evf_pack_conv2d_weight(const float* w, int Cout, int Cin, int ksz
                                       float* dst, void* stream) {
   if (!w || !dst || Cout <= 0 || Cin <= 0 || (ksz != 1 && ksz != 3) || cin_off < 0 || cin_off + Cin > cin_total)
     return EVF_EINVAL;
-  const int N = transpose ? Cin : Cout;
   const long total = cg_packed_float4(Cout, Cin, ksz, transpose);
   hipLaunchKernelGGL(k_pack_conv2d, dim3(evf_cdiv(total, 256)), dim3(256), 0, EVF_STREAM(stream), w, Cout, Cin, ksz * ksz,
-                     transpose, cg_nt(N), total, cin_total, cin_off, (float4*)dst);
+                     transpose, total, cin_total, cin_off, (float4*)dst);
   return evf_status();
 }
 
 // ---------------------------------------------------------------------------
 // forward / input-gradient kernel
 // ---------------------------------------------------------------------------
-template <int NT, int VEC>
+// PAR (input gradient of a stride-2 3x3 conv): blockIdx.z = parity class (oy & 1, ox & 1) of the output
+// pixels of this block.  All pixels of a class share the taps that can reach them (1, 2, 2 or 4 of the 9), so no
+// MFMA runs on structurally-zero taps: 2.25 taps per pixel on average instead of 9.
+template <int NT, int VEC, bool PAR>
 __global__ __launch_bounds__(256) void k_conv2d_f32(const float* __restrict__ src, const float4* __restrict__ wp,
                                                     const float* __restrict__ bias, float* __restrict__ out, ConvGeo g,
                                                     int accumulate) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float4* s_b = (float4*)smem_raw;  // 2 stages x NT*512
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, row = lane & 31, kg = lane >> 5;
-  const long M = (long)g.B * g.OH * g.OW;
+  const int py = PAR ? (int)(blockIdx.z >> 1) : 0, px = PAR ? (int)(blockIdx.z & 1) : 0;
+  const int CH = PAR ? (g.OH - py + 1) / 2 : g.OH, CW = PAR ? (g.OW - px + 1) / 2 : g.OW;  // class image
+  const long M = (long)g.B * CH * CW;
   const long m = (long)blockIdx.x * CG_BM + wv * 32 + row;
   const bool mok = m < M;
-  const long mc = mok ? m : M - 1;
-  const int ox = (int)(mc % g.OW);
-  const long t1 = mc / g.OW;
-  const int oy = (int)(t1 % g.OH), b = (int)(t1 / g.OH);
+  const long mc = mok ? m : (M > 0 ? M - 1 : 0);
+  const int cx = (int)(mc % CW);
+  const long t1 = mc / CW;
+  const int ox = PAR ? 2 * cx + px : cx, oy = PAR ? 2 * (int)(t1 % CH) + py : (int)(t1 % CH), b = (int)(t1 / CH);
   const int T = g.ksz * g.ksz, pad = g.ksz >> 1, G = (g.K + CG_KG - 1) / CG_KG;
-  const int S = T * G;
-  const float4* wblk = wp + (long)blockIdx.y * S * (NT * 512);
+  const int ntx = PAR ? (px ? 2 : 1) : g.ksz, nty = PAR ? (py ? 2 : 1) : g.ksz;
+  const int S = (PAR ? ntx * nty : T) * G;
+  (void)T;
+  const int ntiles = (g.N + 31) >> 5;
+  const float4* wblk[NT];  // this block's N tiles (a tile past the end re-reads the last one; never stored)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wblk[t] = wp + (long)min((int)blockIdx.y * NT + t, ntiles - 1) * (T * G) * 512;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -133,8 +140,14 @@ __global__ __launch_bounds__(256) void k_conv2d_f32(const float* __restrict__ sr
   // unconditional loads from clamped addresses + selects (a load inside a divergent
   // branch makes the compiler drain vmcnt(0) after it)
   auto load_a = [&](int s, float(&a)[32]) {
-    const int tap = s / G, cgi = s - tap * G;
-    const int dy = tap / g.ksz, dx = tap - dy * g.ksz;
+    const int ti = s / G, cgi = s - ti * G;
+    int dy, dx;
+    if (PAR) {  // the class's taps: dy = 1 (even rows) or {0, 2} (odd rows), same for dx
+      const int iy = ti / ntx, ix = ti - iy * ntx;
+      dy = py ? 2 * iy : 1, dx = px ? 2 * ix : 1;
+    } else {
+      dy = ti / g.ksz, dx = ti - dy * g.ksz;
+    }
     int sy, sx;
     bool ok;
     if (g.mode == 0) {
@@ -184,10 +197,19 @@ __global__ __launch_bounds__(256) void k_conv2d_f32(const float* __restrict__ sr
     }
   };
 
+  // packed-weight stage (tap, 64-channel group) of pipeline stage s
+  auto wstage = [&](int s) -> long {
+    if (!PAR) return s;
+    const int ti = s / G, cgi = s - ti * G, iy = ti / ntx, ix = ti - iy * ntx;
+    return (long)((py ? 2 * iy : 1) * 3 + (px ? 2 * ix : 1)) * G + cgi;
+  };
   float a_cur[32], a_nxt[32];
   float4 b_reg[2 * NT];
+  if (S == 0 || M == 0) return;
 #pragma unroll
-  for (int i = 0; i < 2 * NT; ++i) s_b[tid + 256 * i] = wblk[tid + 256 * i];
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) s_b[t * 512 + tid + 256 * i] = wblk[t][wstage(0) * 512 + tid + 256 * i];
   load_a(0, a_cur);
   __syncthreads();
 
@@ -195,11 +217,16 @@ __global__ __launch_bounds__(256) void k_conv2d_f32(const float* __restrict__ sr
   for (int s = 0; s < S; ++s) {
     const int sn = min(s + 1, S - 1);
 #pragma unroll
-    for (int i = 0; i < 2 * NT; ++i) b_reg[i] = wblk[(long)sn * (NT * 512) + tid + 256 * i];
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) b_reg[t * 2 + i] = wblk[t][wstage(sn) * 512 + tid + 256 * i];
     load_a(sn, a_nxt);
     const float4* sb = s_b + (s & 1) * (NT * 512);
-#pragma unroll
-    for (int ch = 0; ch < 4; ++ch)
+    // 16-channel chunks of this stage that hold real channels (the last 64-channel group of K = 2, 130, 258 ...
+    // is mostly padding): uniform per stage, straight-line code per case
+    const int kleft = g.K - (s % G) * CG_KG;
+    const int nchunk = kleft >= CG_KG ? 4 : (kleft + 15) >> 4;
+    auto chunk = [&](int ch) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -210,9 +237,20 @@ __global__ __launch_bounds__(256) void k_conv2d_f32(const float* __restrict__ sr
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ch * 8 + 4 * h + 2], bq.z, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ch * 8 + 4 * h + 3], bq.w, acc[t], 0, 0, 0);
         }
+    };
+    chunk(0);
+    if (nchunk > 1) {
+      chunk(1);
+      if (nchunk > 2) {
+        chunk(2);
+        if (nchunk > 3) chunk(3);
+      }
+    }
     float4* sbn = s_b + ((s + 1) & 1) * (NT * 512);
 #pragma unroll
-    for (int i = 0; i < 2 * NT; ++i) sbn[tid + 256 * i] = b_reg[i];
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) sbn[t * 512 + tid + 256 * i] = b_reg[t * 2 + i];
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 32; ++i) a_cur[i] = a_nxt[i];
@@ -227,7 +265,13 @@ __global__ __launch_bounds__(256) void k_conv2d_f32(const float* __restrict__ sr
       for (int r = 0; r < 16; ++r) {
         const long mr = (long)blockIdx.x * CG_BM + wv * 32 + cg_row(r, lane);
         if (mr < M) {
-          float* d = out + mr * g.ldo + n;
+          long pix = mr;
+          if (PAR) {
+            const int rcx = (int)(mr % CW);
+            const long rt = mr / CW;
+            pix = (rt / CH * g.OH + 2 * (rt % CH) + py) * g.OW + 2 * rcx + px;
+          }
+          float* d = out + pix * g.ldo + n;
           const float v = acc[t][r] + bv;
           *d = accumulate ? *d + v : v;
         }
@@ -236,26 +280,34 @@ __global__ __launch_bounds__(256) void k_conv2d_f32(const float* __restrict__ sr
   }
 }
 
-template <int NT>
+template <int NT, bool PAR>
 static int cg_launch_vec(const float* src, const float* wp, const float* bias, float* out, const ConvGeo& g, int accumulate,
                          hipStream_t st) {
-  const long M = (long)g.B * g.OH * g.OW;
-  dim3 grid(evf_cdiv(M, CG_BM), evf_cdiv(g.N, 32 * NT)), block(256);
+  // PAR: the largest parity class (even rows, even columns) sizes the grid; blocks past a smaller class exit
+  const long M = PAR ? (long)g.B * ((g.OH + 1) / 2) * ((g.OW + 1) / 2) : (long)g.B * g.OH * g.OW;
+  dim3 grid(evf_cdiv(M, CG_BM), evf_cdiv(g.N, 32 * NT), PAR ? 4 : 1), block(256);
   const size_t smem = 2 * NT * 512 * sizeof(float4);
   const bool a16 = ((uintptr_t)src & 15) == 0, a8 = ((uintptr_t)src & 7) == 0;
   if (g.K % 4 == 0 && g.lds % 4 == 0 && a16)
-    hipLaunchKernelGGL((k_conv2d_f32<NT, 4>), grid, block, smem, st, src, (const float4*)wp, bias, out, g, accumulate);
+    hipLaunchKernelGGL((k_conv2d_f32<NT, 4, PAR>), grid, block, smem, st, src, (const float4*)wp, bias, out, g, accumulate);
   else if (g.K % 2 == 0 && g.lds % 2 == 0 && a8)
-    hipLaunchKernelGGL((k_conv2d_f32<NT, 2>), grid, block, smem, st, src, (const float4*)wp, bias, out, g, accumulate);
+    hipLaunchKernelGGL((k_conv2d_f32<NT, 2, PAR>), grid, block, smem, st, src, (const float4*)wp, bias, out, g, accumulate);
   else
-    hipLaunchKernelGGL((k_conv2d_f32<NT, 1>), grid, block, smem, st, src, (const float4*)wp, bias, out, g, accumulate);
+    hipLaunchKernelGGL((k_conv2d_f32<NT, 1, PAR>), grid, block, smem, st, src, (const float4*)wp, bias, out, g, accumulate);
   return evf_status();
 }
 
 static int cg_launch(const float* src, const float* wp, const float* bias, float* out, const ConvGeo& g, int accumulate,
                      void* stream) {
-  if (cg_nt(g.N) == 2) return cg_launch_vec<2>(src, wp, bias, out, g, accumulate, EVF_STREAM(stream));
-  return cg_launch_vec<1>(src, wp, bias, out, g, accumulate, EVF_STREAM(stream));
+  // two N tiles per wave halve the A traffic, but only pay when the grid still fills the 256 CUs twice over
+  const long mblocks = evf_cdiv((long)g.B * g.OH * g.OW, CG_BM), ntiles = evf_cdiv(g.N, 32);
+  const bool two = ntiles >= 2 && mblocks * ((ntiles + 1) / 2) >= 512;
+  if (g.mode == 1 && g.stride == 2 && g.ksz == 3) {
+    if (two) return cg_launch_vec<2, true>(src, wp, bias, out, g, accumulate, EVF_STREAM(stream));
+    return cg_launch_vec<1, true>(src, wp, bias, out, g, accumulate, EVF_STREAM(stream));
+  }
+  if (two) return cg_launch_vec<2, false>(src, wp, bias, out, g, accumulate, EVF_STREAM(stream));
+  return cg_launch_vec<1, false>(src, wp, bias, out, g, accumulate, EVF_STREAM(stream));
 }
 
 static inline int cg_out_dim(int n, int ksz, int stride) { return (n + 2 * (ksz >> 1) - ksz) / stride + 1; }
