@@ -220,7 +220,8 @@ struct Wg9Geo {
   int n_ct;
 };
 
-template <int CT, int NT, int S, int VX>
+// (no uniform branches around the tile loads: a load under a branch is followed by s_waitcnt vmcnt(0))
+template <int CT, int NT, int S, int VX, int VG>
 __global__ __launch_bounds__(512) void k_wgrad9(const float* __restrict__ x, const float* __restrict__ gy,
                                                 float* __restrict__ slab, float* __restrict__ gbias, Wg9Geo g) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -255,7 +256,6 @@ __global__ __launch_bounds__(512) void k_wgrad9(const float* __restrict__ x, con
     g_rc[i] = px < 32 ? ((r << 16) | cc) : -1;
     g_off[i] = (r * g.OW + cc) * g.ldg + co0 + 4 * q;
   }
-  const bool g_vec = (g.ldg & 3) == 0 && (g.Cout & 3) == 0;
 
   f32x16 acc[CT][NT], acc8[CT][NT];
 #pragma unroll
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(512) void k_wgrad9(const float* __restrict__ x, con
       const bool ok = tok && g_rc[i] >= 0 && oy0 + r < g.OH && ox0 + cc < g.OW;
       const int c = co0 + 4 * ((tid + 512 * i) % GQ);
       float e[4];
-      if (g_vec) {  // uniform branch
+      if (VG == 4) {
         const bool cv = ok && c + 4 <= g.Cout;
         const float4 v = *(const float4*)(cv ? go + g_off[i] : gy);
         e[0] = cv ? v.x : 0.f, e[1] = cv ? v.y : 0.f, e[2] = cv ? v.z : 0.f, e[3] = cv ? v.w : 0.f;
@@ -464,8 +464,10 @@ static Wg9Plan wg9_plan(int B, int H, int W, int Cin, int Cout, int stride, int 
   g.n_ct = evf_cdiv(Cin, 32 * p.CT);
   p.n_nt = evf_cdiv(Cout, 32 * p.NT);
   const long wt = (long)g.n_ct * p.n_nt;
-  // ~2 blocks per CU, at least 4 pixel tiles per block (the slab traffic is 9*Cin*Cout per split)
-  long ns = evf_cdiv(512, wt);
+  // one resident block per CU (192 VGPRs x 8 waves): one round of 256 blocks, at least 4 pixel tiles per block
+  // (the slab traffic is 9*Cin*Cout per split)
+  // (measured: the float2 / scalar x-load variants, Cin % 4 != 0, run faster with two rounds of blocks)
+  long ns = evf_cdiv((Cin % 4 == 0) ? 256 : 512, wt);  // a function of the shapes only (evf_conv2d_wgrad_ws)
   if (ns > g.ntiles / 4) ns = g.ntiles / 4;
   if (ns < 1) ns = 1;
   g.tiles_per_split = evf_cdiv(g.ntiles, ns);
@@ -489,12 +491,19 @@ static void wg9_launch(const float* x, const float* gy, float* slab, float* gbia
   const size_t red = (size_t)8 * NT * 1024 * sizeof(float);
   if (smem < red) smem = red;
   const bool a16 = ((uintptr_t)x & 15) == 0, a8 = ((uintptr_t)x & 7) == 0;
-  if (g.Cin % 4 == 0 && g.ldx % 4 == 0 && a16)
-    hipLaunchKernelGGL((k_wgrad9<CT, NT, S, 4>), grid, block, smem, st, x, gy, slab, gbias, g);
-  else if (g.Cin % 2 == 0 && g.ldx % 2 == 0 && a8)
-    hipLaunchKernelGGL((k_wgrad9<CT, NT, S, 2>), grid, block, smem, st, x, gy, slab, gbias, g);
-  else
-    hipLaunchKernelGGL((k_wgrad9<CT, NT, S, 1>), grid, block, smem, st, x, gy, slab, gbias, g);
+  const bool gv = (g.ldg & 3) == 0 && (g.Cout & 3) == 0 && ((uintptr_t)gy & 15) == 0;
+  const int vx = (g.Cin % 4 == 0 && g.ldx % 4 == 0 && a16) ? 4 : ((g.Cin % 2 == 0 && g.ldx % 2 == 0 && a8) ? 2 : 1);
+#define WG9_GO(VX_, VG_) hipLaunchKernelGGL((k_wgrad9<CT, NT, S, VX_, VG_>), grid, block, smem, st, x, gy, slab, gbias, g)
+  if (gv) {
+    if (vx == 4) WG9_GO(4, 4);
+    else if (vx == 2) WG9_GO(2, 4);
+    else WG9_GO(1, 4);
+  } else {
+    if (vx == 4) WG9_GO(4, 1);
+    else if (vx == 2) WG9_GO(2, 1);
+    else WG9_GO(1, 1);
+  }
+#undef WG9_GO
 }
 
 // g_w [Cout][cin_total][k][k] (torch layout; this call fills input channels cin_off .. cin_off+Cin) and optional
