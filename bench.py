@@ -108,6 +108,29 @@ def iwe_warp_bandwidth(dev, B, reps=20):
             "frac_of_hbm_peak": alg_bytes / ms / 1e6 / HBM_PEAK}
 
 
+_KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3", "evf_lif_bwd_wgrad/ff": "k_lif_bwd_wgrad<false>",
+              "evf_lif_bwd_wgrad/rec": "k_lif_bwd_wgrad<true>", "evf_conv_lif_fwd_b3/ff": "k_conv_lif_fwd_b3<false, false>",
+              "evf_conv_lif_fwd_b3/rec": "k_conv_lif_fwd_b3<true, false>", "evf_head_lif_fwd": "k_head_lif_fwd",
+              "evf_head_lif_bwd_wgrad": "k_lif_bwd<2>", "evf_conv_dgrad/one": "k_conv_dgrad<false>",
+              "evf_conv_dgrad/two": "k_conv_dgrad<true>", "evf_conv_lif_fwd/ff": "k_conv_lif_fwd<false>",
+              "evf_conv_lif_fwd/rec": "k_conv_lif_fwd<true>", "evf_conv_wgrad_bits": "k_conv_wgrad_bits"}
+
+
+def _pmc_traffic(entry):
+    """HBM bytes per launch of the kernel behind `entry`, from the committed PMC passes (rocprofv3 cannot run
+    inside this process): profiles/r*_bench_pmc_traffic.json, FETCH_SIZE (x2 corrected) + WRITE_SIZE."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_bench_pmc_traffic.json")))
+    if not files or entry not in _KERNEL_OF:
+        return None
+    t = json.load(open(files[-1]))["per_launch"].get(_KERNEL_OF[entry])
+    if not t or t["fetch_MB"] != t["fetch_MB"]:
+        return None
+    return {"MB_per_launch": round(t["fetch_MB"] + t["write_MB"], 2), "fetch_MB": t["fetch_MB"], "write_MB": t["write_MB"],
+            "source": os.path.basename(files[-1])}
+
+
 def cpu_baseline(threads, max_seconds=60.0):
     """Oracle (PyTorch-CPU port of the reference path) on a bounded sample:
     ONE window (B=1) of the same workload, full train step."""
@@ -300,14 +323,15 @@ def main():
             kernels[name] = ent
         dom_key = max((k for k in prof if k in model), key=lambda k: sum(prof[k]))
         dom = kernels["/".join(k for k in dom_key if k)]
+        traffic = _pmc_traffic("/".join(k for k in dom_key if k))
         if dom["bound"] == "hbm":
             roof = {"kernel": "/".join(k for k in dom_key if k), "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK,
-                    "unit": "GB/s", "frac": dom["frac_of_hbm_peak"], "traffic": None,
+                    "unit": "GB/s", "frac": dom["frac_of_hbm_peak"], "traffic": traffic,
                     "note": "bf16x3 kernel (exact 3-way bf16 split, fp32 accumulate): matrix work is 1/5 of the fp32-MFMA form, "
                             "so the kernel sits on the HBM roofline; algorithmic bytes per launch in kernels[*].algorithmic_MB"}
         else:
             roof = {"kernel": "/".join(k for k in dom_key if k), "bound": "mfma", "achieved": dom["TFLOPs"], "peak": FP32_MFMA_PEAK,
-                    "unit": "TFLOP/s", "frac": dom["TFLOPs"] / FP32_MFMA_PEAK, "traffic": None}
+                    "unit": "TFLOP/s", "frac": dom["TFLOPs"] / FP32_MFMA_PEAK, "traffic": traffic}
         out = {
             "metric": "event-windows/sec (train step, 128x128x15k ev)", "value": B_PER_GPU * dp.world * args.steps / elapsed,
             "unit": "event-windows/s", "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,

@@ -1,0 +1,82 @@
+"""Condense the rocprofv3 output of tools/profile_round.sh (gpurun_out/prof_<round>/) into the small files
+committed under profiles/.   usage: python tools/prof_summary.py r01"""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+from collections import defaultdict
+
+R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
+DST = os.path.join(ROOT, "profiles")
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(SRC, pattern))
+    return f[0] if f else None
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)  # drop the argument list
+    return name.replace("void ", "").strip()
+
+
+for run, out in (("graph", "bench_hipgraph"), ("eager", "bench_eager"), ("evfn", "evflownet"), ("iwe", "iwe_b2048")):
+    f = one(f"{run}/*/*kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(DST, f"{R}_{out}_kernel_stats.csv"))
+    log = os.path.join(SRC, f"{run}.log")
+    if os.path.exists(log):
+        for line in open(log):
+            if line.startswith("{"):
+                open(os.path.join(DST, f"{R}_{out}.json"), "w").write(line)
+            elif line.startswith("B="):
+                open(os.path.join(DST, f"{R}_{out}.txt"), "w").write(line)
+
+
+def counters(run):
+    f = one(f"{run}/*/*counter_collection.csv")
+    acc = defaultdict(lambda: defaultdict(list))
+    if not f:
+        return acc
+    for r in csv.DictReader(open(f)):
+        acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+fetch, write, mfma, mfma32 = counters("fetch"), counters("write"), counters("mfma"), counters("mfma32")
+rows = []
+names = sorted(set(fetch) | set(mfma) | set(mfma32), key=lambda n: -sum(mfma.get(n, {}).get("GRBM_GUI_ACTIVE", [0])))
+mean = lambda v: sum(v) / len(v) if v else float("nan")  # noqa: E731
+for n in names:
+    if n.startswith("at::") or n.startswith("__amd") or "elementwise" in n:
+        continue
+    src = mfma if n in mfma else mfma32
+    gui = mean(src[n].get("GRBM_GUI_ACTIVE", []))  # summed over the 8 XCDs
+    busy = mean(src[n].get("SQ_VALU_MFMA_BUSY_CYCLES", []))  # summed over all SIMDs (1024)
+    f_kb = mean(fetch.get(n, {}).get("FETCH_SIZE", []))
+    w_kb = mean(write.get(n, {}).get("WRITE_SIZE", []))
+    rows.append({
+        "kernel": n, "dispatches": len(src[n].get("GRBM_GUI_ACTIVE", [])), "precision_run": "bf16x3" if n in mfma else "fp32",
+        "gui_cycles_per_xcd": round(gui / 8, 0), "mfma_busy_cycles_per_simd": round(busy / 1024, 0) if busy == busy else "",
+        "mfma_util_pct": round(100 * (busy / 1024) / (gui / 8), 1) if busy == busy and gui > 0 else "",
+        "fetch_size_KB_raw": round(f_kb, 1), "fetch_MB_x2_corrected": round(2 * f_kb / 1024, 2), "write_size_KB": round(w_kb, 1),
+    })
+# kernels that only exist on the fp32 path
+for n in sorted(set(mfma32) - set(mfma)):
+    pass
+with open(os.path.join(DST, f"{R}_bench_pmc_summary.csv"), "w", newline="") as fh:
+    w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+    w.writeheader()
+    w.writerows(rows)
+# per-launch HBM traffic of the bench's dominant kernels for bench.py's roofline.traffic
+traffic = {r["kernel"]: {"fetch_MB": r["fetch_MB_x2_corrected"], "write_MB": round(r["write_size_KB"] / 1024, 2)} for r in rows
+           if r["fetch_size_KB_raw"] == r["fetch_size_KB_raw"]}
+json.dump({"round": R, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --no-graph` (tools/profile_round.sh); "
+           "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE uncalibrated",
+           "per_launch": traffic}, open(os.path.join(DST, f"{R}_bench_pmc_traffic.json"), "w"), indent=1)
+print(open(os.path.join(DST, f"{R}_bench_pmc_summary.csv")).read())

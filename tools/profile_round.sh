@@ -1,0 +1,19 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence of one round on the GPU box (run through gpurun from the repo root):
+#   bash tools/profile_round.sh r01
+# kernel-trace/stats passes and --pmc passes are separate runs (gpurun refuses --pmc together with API traces).
+set -u
+R=${1:-r01}
+O=gpurun_out/prof_$R
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+run() { name=$1; shift; timeout 900 "$@" > $O/$name.log 2>&1; echo "$name rc=$?"; }
+run graph  rocprofv3 --kernel-trace --stats --output-format csv -d $O/graph  -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline
+run eager  rocprofv3 --kernel-trace --stats --output-format csv -d $O/eager  -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph --no-iwe
+run fetch  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe
+run write  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe
+run mfma   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe
+run mfma32 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma32 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe --precision fp32
+run evfn   rocprofv3 --kernel-trace --stats --output-format csv -d $O/evfn -- python tools/bench_evflownet.py --steps 5
+run iwe    rocprofv3 --kernel-trace --stats --output-format csv -d $O/iwe -- python tools/iwe_bench.py 2048
+ls -R $O | head -60
