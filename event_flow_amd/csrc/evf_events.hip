@@ -418,7 +418,7 @@ extern "C" int evf_iwe_splat(const float* flow, const float* ev, const int32_t* 
     const bool pairw = w0 && w1 == w0 + 1 && wstride == 2 && (((uintptr_t)w0) & 7) == 0 && nch == 2;
     const bool now = !w0 && !w1 && nch == 1;
     if ((mode & 1) && !(mode & 12) && !map_of_event && !ts_shift && (pairw || now) && (long)H * W * 4 <= 64 * 1024 &&
-        ((H * W) & 3) == 0 && H * W <= 4 * IWR_NQ * IWR_THREADS && M <= IWR_EPT * IWR_THREADS && B >= 64 && (((uintptr_t)flow) & 15) == 0 &&
+        ((H * W) & 3) == 0 && H * W <= 4 * IWR_NQ * IWR_THREADS && M <= IWR_EPT * IWR_THREADS && B >= 16 && (((uintptr_t)flow) & 15) == 0 &&
         (((uintptr_t)out) & 15) == 0) {
       const size_t lds = (size_t)H * W * 4;
       const float zf = (mode & 2) ? 0.f : 1.f;  // `flow * 0` (FWL/RSAT reference images) keeps NaN/sign semantics
