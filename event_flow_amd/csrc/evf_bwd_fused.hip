@@ -181,7 +181,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
         st[c] -= gsp;
       }
     }
-    if (ok && !(accumulate & 64)) {
+    if (ok) {
       if (g_cur) g_cur[pix0 * 8 + tid] = make_float4(gc[0], gc[1], gc[2], gc[3]);
       g_v_prev[pix0 * 8 + tid] = make_float4(gp[0], gp[1], gp[2], gp[3]);
     }
@@ -198,14 +198,14 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
       const float r2 = r1 - __uint_as_float(mid << 16);
       const uint32_t lo = fb_bf16(r2);
       const int o = base + (4 * cg + c) * 8;
-      if (!(accumulate & 32)) {
+      {
       sb[o] = (unsigned short)hi;
       sb[FB_CW * C32 + o] = (unsigned short)mid;
       sb[2 * FB_CW * C32 + o] = (unsigned short)lo;
       }
       tb[0][c] = hi, tb[1][c] = mid, tb[2][c] = lo;
     }
-    if (ok && g_split && !(accumulate & 64)) {  // the same split as three bf16 planes [term][pix][32] for evf_conv_dgrad_b3
+    if (ok && g_split) {  // the same split as three bf16 planes [term][pix][32] for evf_conv_dgrad_b3
       const long ps = (long)B * H * W * 8;
 #pragma unroll
       for (int t3 = 0; t3 < 3; ++t3)
@@ -221,7 +221,6 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
   const int dy = wv / 3, dx = wv % 3;  // taps 0..7; tap 8 = (2, 2) is shared
   // stage 3: matrix cores on the staged unit
   auto mfma_unit = [&](int k) {
-    if (accumulate & 16) return;
     const int buf = k & 1;
     const uint4* sbh = (const uint4*)(s_b + buf * (3 * FB_CW * C32));
     const uint32_t* px = s_px + buf * (3 * C32 * FB_NW);
@@ -288,7 +287,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
       *p = (accumulate & 1) ? *p + a[q] : a[q];
     }
   };
-  if (!(accumulate & 256)) {
+  {
   store_tile(acc, slab_ff);
   if (REC) store_tile(accz, slab_rec);
   }
@@ -307,7 +306,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     }
     __syncthreads();
   };
-  if (!(accumulate & 256)) {
+  {
   reduce_t8(acc8, slab_ff);
   if (REC) reduce_t8(accz8, slab_rec);
   }
@@ -328,7 +327,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     }
   }
   __syncthreads();
-  if (tid < 64 && !(accumulate & 128)) {
+  if (tid < 64) {
     const int which = tid >> 5, c = tid & 31;
     float v = 0.f;
     for (int w = 0; w < 8; ++w) v += s_red[(which * 8 + w) * C32 + c];

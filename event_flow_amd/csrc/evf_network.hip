@@ -1091,9 +1091,11 @@ __global__ void k_clip_adam(float* __restrict__ p, const float* __restrict__ g, 
   if (max_norm > 0.f) coef = fminf(1.f, max_norm / (sqrtf(ws[0]) + 1e-6f));
   float step_size = host_step_size, bc2_sqrt = host_bc2_sqrt;
   if (device_step) {  // bias corrections from the device-side counter
-    const float t = ws[1];
-    step_size = lr / (1.0f - powf(b1, t));
-    bc2_sqrt = sqrtf(1.0f - powf(b2, t));
+    // in double, like the host path: an fp32 1 - b2^t is off by ~3e-5 at small t, and the spiking network
+    // amplifies such a difference into visibly different trajectories after a few steps
+    const double t = (double)ws[1];
+    step_size = (float)((double)lr / (1.0 - pow((double)b1, t)));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
   }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gi = g[i] * coef;

@@ -405,3 +405,70 @@ def test_fused_lif_bwd_wgrad_matches_separate_kernels(rec, shape):
         _lib.call("evf_reduce_slabs", slab.data_ptr(), ns1, 9216, 0, dw.data_ptr())
         ref = 2 * N(dw0[nm])
         assert np.abs(N(dw) - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-5, nm
+
+
+def test_hipgraph_replay_equals_eager_steps():
+    """bench.py replays the whole train step (binning -> passes -> loss -> backward -> clip+Adam) from a
+    hipGraph: the Adam step counter lives on the device and the recurrent state in static buffers.  Four steps
+    over two alternating windows must leave the parameters where four eager steps leave them."""
+    from event_flow_amd import synthetic
+    from event_flow_amd.dataloader.encodings import encode_event_list
+
+    B, n, H, W, P = 2, 600, 32, 64, 3
+    pool = [[G(synthetic.event_list_batch(B, n, H, W, 7000 + 100 * w + k)) for k in range(P)] for w in range(2)]
+
+    def make():
+        torch.manual_seed(3)
+        m = LIFFireNet(model_cfg()).to(DEV)
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                if k.endswith("thresh"):
+                    p.mul_(0.25)
+        m.train()
+        return m
+
+    def step(model, lossf, opt, lists):
+        passes = [encode_event_list(ev, 2, (H, W), want=("cnt", "mask", "pol")) for ev in lists]
+        for d in passes:
+            d["event_voxel"] = None
+        return train_window(model, lossf, opt, passes)
+
+    # graph mode: 2 eager warm-up steps, then capture one graph per window and replay
+    m1 = make()
+    opt1 = FlatAdam(m1, lr=2e-4, clip=100.0, device_step=True)
+    opt1.zero_grad()
+    m1.use_static_states(True)
+    l1 = hloss.EventWarping(loss_cfg(H, W), DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    losses1 = []
+    with torch.cuda.stream(side):
+        for i in range(2):
+            losses1.append(step(m1, l1, opt1, pool[i % 2]))
+        torch.cuda.synchronize()
+        graphs = []
+        for lists in pool:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                out = step(m1, l1, opt1, lists)
+            graphs.append((g, out))
+            losses1.append(out.clone())
+        for i in range(2):
+            g, out = graphs[i % 2]
+            g.replay()
+            losses1.append(out.clone())
+        torch.cuda.synchronize()
+    losses1 = [float(x) for x in losses1]
+    # capture executes nothing, so the graph model did 2 eager + 2 replayed = 4 steps (device-side step counter,
+    # static state buffers); the reference does 4 eager steps with the host-side counter
+    m2 = make()
+    opt2 = FlatAdam(m2, lr=2e-4, clip=100.0)
+    opt2.zero_grad()
+    l2 = hloss.EventWarping(loss_cfg(H, W), DEV)
+    ref_losses = [float(step(m2, l2, opt2, pool[i % 2])) for i in range(4)]
+    np.testing.assert_allclose([losses1[0], losses1[1], losses1[4], losses1[5]], ref_losses, rtol=2e-4)
+    for (k, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        d = np.abs(N(p) - N(q))
+        # Adam's first steps move every weight by ~lr; atomics reorder the gradient sums: bulk agreement
+        assert d.max() <= 4 * 2e-4 + 1e-6, k
+        assert np.mean(d > 4e-5) <= 0.05, (k, float(np.mean(d > 4e-5)))
