@@ -294,3 +294,51 @@ def test_adaptive_threshold_firenets_vs_oracle(name, cls):
         got = N(p.grad) if p.grad is not None else np.zeros_like(ref)
         denom = max(np.linalg.norm(ref), 1e-12)
         assert np.linalg.norm(got - ref) <= 2e-3 * denom + 1e-9, (k, np.linalg.norm(got - ref) / denom)
+
+
+def test_evflownet_at_config4_width_vs_oracle():
+    """BASELINE config 4 architecture at its real width (base 32: 64..512 channels, 1024/514/258/130-channel decoder
+    inputs, 20.4 M parameters) on a 128x128 crop, B=1, two passes: flows of all four scales and the parameter
+    gradients against the CPU oracle.  (256x256 x B=8 runs in tools/bench_evflownet.py; the oracle needs minutes there.)"""
+    torch.manual_seed(11)
+    model = SpikingRecEVFlowNet(_unet_cfg(32)).to(DEV)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if k.endswith("thresh"):
+                p.mul_(0.3)  # keep every layer active at this input rate
+    params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    keys = [k for k, _ in model.named_parameters()]
+    for k in keys:
+        params[k].requires_grad_(True)
+    xs = [(torch.rand(1, 2, 128, 128) < 0.3).float() * torch.randint(1, 4, (1, 2, 128, 128)).float() for _ in range(2)]
+    torch.set_num_threads(16)
+    states = [None] * 10
+    tot, tot_ref, nflip, ntot = 0, 0, 0, 0
+    for x in xs:
+        flows_ref, states = osnn.spiking_unet_forward("lif", params, x, states)
+        out = model(x.to(DEV), x.to(DEV))
+        for f, fr in zip(out["flow"], flows_ref):
+            tot = tot + (f * f).sum()
+            tot_ref = tot_ref + (fr * fr).sum()
+    got = model.states
+    for s in range(10):
+        ref = states[s]
+        ref = torch.stack([torch.stack(t) for t in ref]) if isinstance(ref[0], tuple) else torch.stack(ref)
+        z_got, z_ref = N(got[s])[..., 1, :, :, :, :] if ref.dim() == 6 else N(got[s])[1], None
+        z_ref = ref.detach().numpy()[..., 1, :, :, :, :] if ref.dim() == 6 else ref.detach().numpy()[1]
+        nflip += int((z_got != z_ref).sum())
+        ntot += z_ref.size
+    assert nflip <= 1e-4 * ntot, (nflip, ntot)
+    rel = 1e-4 if nflip == 0 else 5e-2
+    for f, fr in zip(out["flow"], flows_ref):
+        close(N(f), fr.detach().numpy(), rel if nflip == 0 else 0.5, "flow")
+    tot.backward()
+    tot_ref.backward()
+    gn = float(np.sqrt(sum(float((params[k].grad.numpy() ** 2).sum()) for k in keys if params[k].grad is not None)))
+    err = 0.0
+    for k, p in model.named_parameters():
+        ref = params[k].grad
+        ref = ref.numpy() if ref is not None else np.zeros(tuple(p.shape), np.float32)
+        g = N(p.grad) if p.grad is not None else np.zeros_like(ref)
+        err += float(((g - ref) ** 2).sum())
+    assert np.sqrt(err) <= (2e-3 if nflip == 0 else 1e-1) * gn, (np.sqrt(err) / gn, nflip)
