@@ -1,0 +1,97 @@
+"""Evaluation driver -- counterpart of the reference's eval_flow.py:40-258 on the MI355X path: runs a model over
+sequences, builds the per-polarity image of warped events (`compute_pol_iwe`) and accumulates FWL / RSAT / AEE
+exactly as the reference loop does (association per input window, metric once `window_eval` events are collected).
+No MLflow / visualiser; results are printed as JSON.
+
+  python eval_flow.py --config configs/eval_flow.yml --train-config configs/train_SNN.yml --synthetic [--weights model.pth]
+"""
+
+import argparse
+import json
+
+import numpy as np
+import torch
+
+from event_flow_amd.configs.parser import YAMLParser
+from event_flow_amd.loss import flow as metrics_mod
+from event_flow_amd.models.model import MODELS
+from event_flow_amd.utils.iwe import compute_pol_iwe
+
+
+def test(args, config_parser):
+    # the reference overlays the eval YAML on the training run's stored parameters (merge_configs); here the
+    # training YAML plays the role of the stored run
+    train_cfg = YAMLParser(args.train_config).config
+    config = config_parser.config
+    merged = {k: (dict(v) if isinstance(v, dict) else v) for k, v in train_cfg.items()}
+    for key, val in config.items():
+        if isinstance(val, dict):
+            merged.setdefault(key, {}).update(val)
+        else:
+            merged[key] = val
+    config = config_parser.combine_entries(merged)
+    config["data"].setdefault("window_eval", config["data"]["window"])
+    config["loss"] = config.get("loss", {"overwrite_intermediate": False})
+    device = config_parser.device
+
+    model = MODELS[config["model"]["name"]](config["model"].copy()).to(device)
+    if args.weights:
+        model.load_state_dict(torch.load(args.weights, map_location=device))
+    model.eval()
+
+    names = config.get("metrics", {}).get("name", [])
+    criteria = [getattr(metrics_mod, m)(config, device, flow_scaling=config["metrics"]["flow_scaling"]) for m in names]
+
+    if args.synthetic:
+        from event_flow_amd.dataloader.synthetic_loader import SyntheticLoader
+
+        data = SyntheticLoader(config, config["model"]["num_bins"], device=device, num_sequences=args.sequences)
+    else:
+        from event_flow_amd.dataloader.h5 import H5Loader
+
+        data = H5Loader(config, config["model"]["num_bins"])
+
+    results = {m: {"metric": 0.0, "it": 0, **({"percent": 0.0} if m == "AEE" else {})} for m in names}
+    iwe_sharpness = []
+    with torch.no_grad():
+        for inputs in data:
+            if data.new_seq:
+                data.new_seq = False
+                model.reset_states()
+            x = model(inputs["event_voxel"], inputs["event_cnt"])
+            iwe = compute_pol_iwe(x["flow"][-1], inputs["event_list"], config["loader"]["resolution"],
+                                  inputs["event_list_pol_mask"][:, :, 0:1], inputs["event_list_pol_mask"][:, :, 1:2],
+                                  flow_scaling=config["metrics"]["flow_scaling"], round_idx=True)
+            iwe_sharpness.append(iwe.sum(1).var(dim=(1, 2)).mean())
+            for metric in criteria:
+                metric.event_flow_association(x["flow"], inputs)
+            for i, name in enumerate(names):
+                if criteria[i].num_events >= config["data"]["window_eval"]:
+                    if config["loss"].get("overwrite_intermediate", False):
+                        criteria[i].overwrite_intermediate_flow(x["flow"])
+                    val = criteria[i]()
+                    results[name]["it"] += 1
+                    if name == "AEE":
+                        results[name]["metric"] += float(val[0].mean())
+                        results[name]["percent"] += float(val[1].mean())
+                    else:
+                        results[name]["metric"] += float(val.mean())
+                    criteria[i].reset()
+    out = {"model": config["model"]["name"], "iwe_variance": float(torch.stack(iwe_sharpness).mean())}
+    for name, r in results.items():
+        out[name] = r["metric"] / max(r["it"], 1)
+        if name == "AEE":
+            out["AEE_percent_outliers"] = r["percent"] / max(r["it"], 1)
+    print(json.dumps(out))
+    return out
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--config", default="configs/eval_flow.yml")
+    parser.add_argument("--train-config", default="configs/train_SNN.yml", help="configuration the model was trained with")
+    parser.add_argument("--weights", default="", help="state_dict (reference: the run id)")
+    parser.add_argument("--synthetic", action="store_true")
+    parser.add_argument("--sequences", type=int, default=4)
+    args = parser.parse_args()
+    test(args, YAMLParser(args.config))

@@ -22,3 +22,20 @@ def test_training_on_moving_dots_learns_the_motion(model):
     assert res["loss_last_100"] < 0.85 * res["loss_first_100"], res
     assert res["aee_after"] < 0.75 * res["aee_zero_flow"], res
     assert res["aee_after"] < res["aee_before"], res
+
+
+def test_reference_shaped_drivers_run_end_to_end(tmp_path):
+    """train_flow.py / eval_flow.py counterparts (reference train_flow.py:38-194, eval_flow.py:40-258) on the synthetic
+    loader: training writes a checkpoint, evaluation loads it and reports FWL / RSAT / AEE."""
+    w = str(tmp_path / "m.pth")
+    for extra in (["--fused-optimizer"], []):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "train_flow.py"), "--synthetic", "--epochs", "2", "--out", w] + extra,
+                             capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res = json.loads(out.stdout.strip().splitlines()[-1])
+        assert len(res["loss_per_epoch"]) == 2 and all(0 < v < 10 for v in res["loss_per_epoch"])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "eval_flow.py"), "--synthetic", "--weights", w],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert {"FWL", "RSAT", "AEE", "iwe_variance"} <= set(res) and all(v == v for v in res.values() if isinstance(v, float))

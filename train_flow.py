@@ -1,0 +1,111 @@
+"""Training driver -- counterpart of the reference's train_flow.py:38-194 on the MI355X path: the same YAML keys,
+the same loop (forward per input window, `event_flow_association`, loss / backward / clip / optimizer step once
+`window_loss` events are collected, `detach_states`, `reset`), the models / loss of `event_flow_amd`.
+
+Differences, all host side: MLflow and the visualiser are optional extras of the reference and not used here (metrics
+go to stdout and `--out` receives the checkpoint); the HDF5 reader is replaced by `--synthetic` windows (moving dots
+with known motion).  `--fused-optimizer` swaps `clip_grad_norm_` + `torch.optim.Adam` for the fused flat-buffer kernel
+(same update rule).
+
+  python train_flow.py --config configs/train_SNN.yml --synthetic [--epochs 5] [--out model.pth]
+"""
+
+import argparse
+import json
+import time
+
+import torch
+
+from event_flow_amd.configs.parser import YAMLParser
+from event_flow_amd.loss.flow import EventWarping
+from event_flow_amd.models.model import MODELS
+from event_flow_amd.train import FlatAdam
+
+
+def train(args, config_parser):
+    config = config_parser.config
+    if config["data"]["mode"] == "frames":
+        print("Config error: Training pipeline not compatible with frames mode.")
+        raise AttributeError
+    config = config_parser.combine_entries(config)
+    device = config_parser.device
+
+    if args.synthetic:
+        from event_flow_amd.dataloader.synthetic_loader import SyntheticLoader
+
+        data = SyntheticLoader(config, config["model"]["num_bins"], config["model"].get("round_encoding", False), device=device)
+    else:
+        from event_flow_amd.dataloader.h5 import H5Loader
+
+        data = H5Loader(config, config["model"]["num_bins"], config["model"].get("round_encoding", False))
+
+    loss_function = EventWarping(config, device)
+    model = MODELS[config["model"]["name"]](config["model"].copy()).to(device)
+    if args.prev:
+        model.load_state_dict(torch.load(args.prev, map_location=device))
+    model.train()
+
+    clip = config["loss"].get("clip_grad", None)
+    if args.fused_optimizer:
+        optimizer = FlatAdam(model, lr=config["optimizer"]["lr"], clip=clip)
+    else:
+        optimizer = getattr(torch.optim, config["optimizer"]["name"])(model.parameters(), lr=config["optimizer"]["lr"])
+    optimizer.zero_grad()
+
+    n_epochs = args.epochs if args.epochs is not None else config["loader"]["n_epochs"]
+    best_loss, history = 1.0e6, []
+    t_start = time.time()
+    for epoch in range(n_epochs):
+        data.shuffle(epoch)
+        train_loss, samples, steps = torch.zeros((), device=device), 0, 0
+        for inputs in data:
+            if data.new_seq:  # any slot restarted: reset everything (train_flow.py:100-105)
+                data.new_seq = False
+                loss_function.reset()
+                model.reset_states()
+                optimizer.zero_grad()
+
+            x = model(inputs["event_voxel"], inputs["event_cnt"])
+            loss_function.event_flow_association(x["flow"], inputs["event_list"], inputs["event_list_pol_mask"],
+                                                 inputs["event_mask"])
+
+            if loss_function.num_events >= config["data"]["window_loss"]:
+                if config["loss"]["overwrite_intermediate"]:
+                    loss_function.overwrite_intermediate_flow(x["flow"])
+                loss = loss_function()
+                train_loss += loss.detach()  # no host sync inside the loop
+                samples += config["loader"]["batch_size"]
+                steps += 1
+                loss.backward()
+                if args.fused_optimizer:
+                    optimizer.step()  # clip + Adam in one kernel
+                else:
+                    if clip is not None:
+                        torch.nn.utils.clip_grad.clip_grad_norm_(model.parameters(), clip)
+                    optimizer.step()
+                optimizer.zero_grad()
+                model.detach_states()
+                loss_function.reset()
+        epoch_loss = float(train_loss) / max(samples, 1)
+        history.append(epoch_loss)
+        if config["vis"].get("verbose", False):
+            print("Train Epoch: {:04d}  Loss: {:.6f}  ({} optimizer steps, {:.1f} s)".format(epoch, epoch_loss, steps,
+                                                                                             time.time() - t_start))
+        if epoch_loss < best_loss:
+            best_loss = epoch_loss
+            if args.out:
+                torch.save(model.state_dict(), args.out)
+    print(json.dumps({"model": config["model"]["name"], "epochs": n_epochs, "loss_per_epoch": history, "best_loss": best_loss}))
+    return history
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--config", default="configs/train_SNN.yml", help="training configuration")
+    parser.add_argument("--synthetic", action="store_true", help="synthetic moving-dots windows instead of HDF5 files")
+    parser.add_argument("--prev", default="", help="state_dict to resume from (reference: --prev_runid)")
+    parser.add_argument("--out", default="", help="where to save the best state_dict")
+    parser.add_argument("--epochs", type=int, default=None)
+    parser.add_argument("--fused-optimizer", action="store_true")
+    args = parser.parse_args()
+    train(args, YAMLParser(args.config))
