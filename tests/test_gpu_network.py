@@ -472,3 +472,53 @@ def test_hipgraph_replay_equals_eager_steps():
         # Adam's first steps move every weight by ~lr; atomics reorder the gradient sums: bulk agreement
         assert d.max() <= 4 * 2e-4 + 1e-6, k
         assert np.mean(d > 4e-5) <= 0.05, (k, float(np.mean(d > 4e-5)))
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 7), (3, 9, 33), (2, 8, 64)])
+def test_firenet_tiny_and_ragged_resolutions_vs_oracle(shape):
+    """Sensor sizes below / across the 8-row x 32-pixel tiles of the fused kernels (H < 8, W < 32, W = 33):
+    forward flow, states and parameter gradients over two passes against the CPU oracle."""
+    B, H, W = shape
+    torch.manual_seed(2)
+    model = LIFFireNet(model_cfg()).to(DEV)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if k.endswith("thresh"):
+                p.mul_(0.2)
+    params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    keys = [k for k, _ in model.named_parameters()]
+    for k in keys:
+        params[k].requires_grad_(True)
+    xs = [(torch.rand(B, 2, H, W) < 0.6).float() * torch.randint(1, 4, (B, 2, H, W)).float() for _ in range(2)]
+    states = [None] * 7
+    tot, tot_ref = 0, 0
+    model.train()
+    for x in xs:
+        f_ref, states = osnn.firenet_forward("LIFFireNet", params, x, states)
+        f = model(x.to(DEV), x.to(DEV))["flow"][0]
+        wgt = torch.arange(f_ref.numel()).view(f_ref.shape).remainder(5).float() - 2.0
+        tot_ref = tot_ref + (f_ref * wgt).sum()
+        tot = tot + (f * wgt.to(DEV)).sum()
+    nflip = sum(int((N(model.states[li][1]) != states[li][1].detach().numpy()).sum()) for li in range(7))
+    assert nflip == 0  # tiny images: no borderline neuron in these seeds
+    np.testing.assert_allclose(N(f), f_ref.detach().numpy(), rtol=1e-4, atol=1e-7)
+    for li in range(7):
+        np.testing.assert_allclose(N(model.states[li][0]), states[li][0].detach().numpy(), rtol=1e-5, atol=2e-6)
+    tot.backward()
+    tot_ref.backward()
+    for k, p in model.named_parameters():
+        ref = params[k].grad
+        ref = ref.numpy() if ref is not None else np.zeros(tuple(p.shape), np.float32)
+        denom = max(np.linalg.norm(ref), 1e-12)
+        assert np.linalg.norm(N(p.grad) - ref) <= 2e-3 * denom + 1e-9, (k, np.linalg.norm(N(p.grad) - ref) / denom)
+
+
+def test_event_warping_with_an_empty_pass_and_iwe_of_nothing():
+    """Ragged windows: a pass that contributes zero events, and an IWE of an empty event list."""
+    from event_flow_amd.utils import iwe as hiwe
+
+    B, H, W = 2, 16, 24
+    flow = torch.zeros(B, 2, H, W, device=DEV)
+    out = hiwe.compute_pol_iwe(flow, torch.zeros(B, 0, 4, device=DEV), (H, W), torch.zeros(B, 0, 1, device=DEV),
+                               torch.zeros(B, 0, 1, device=DEV))
+    assert tuple(out.shape) == (B, 2, H, W) and float(out.abs().sum()) == 0.0
