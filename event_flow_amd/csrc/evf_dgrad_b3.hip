@@ -137,13 +137,114 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3(const uint4* __r
   }
 }
 
+// ---------------------------------------------------------------------------
+// LDS-staged variant: the split gradient halo of an 8-row x 32-pixel tile (10 x 34 pixels x 3 planes x 64 B =
+// 65 KiB) and the 54 KiB of split weights are brought in by LDS-DMA (global_load_lds_dwordx4: no VGPRs, full
+// 64-byte pixel lines, everything in flight at once), ONE wait, then the 108 MFMAs of every wave read both operands
+// from LDS.  The register version above pays a chain of dependent latencies (weights -> row 0 -> row 1 -> row 2 ->
+// read-modify-write) and fetches each A fragment through the L1 nine times in 16-byte pieces.
+// LDS image of a plane: [halo pixel][4 x 16-byte chunks], chunk c of pixel p stored in slot c ^ ((p >> 2) & 3): the
+// DMA writes lane-linear (64 lanes = 16 pixels x 4 slots), the swizzle is applied on the SOURCE address, and a
+// fragment read (16 consecutive pixels, one chunk) touches all 64 banks once.
+// ---------------------------------------------------------------------------
+#define DL_HW 34
+#define DL_HR (DG_ROWS + 2)
+#define DL_HP (DL_HR * DL_HW)  // 340 halo pixels
+#define DL_UPP 22              // 16-pixel DMA units per plane (352 pixel slots, the last 12 are padding)
+#define DL_HPP (DL_UPP * 16)
+typedef __attribute__((address_space(3))) void dl_lds_void;
+typedef __attribute__((address_space(1))) const void dl_glb_void;
+
+__global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4* __restrict__ gs, long plane_stride,
+                                                                    const uint4* __restrict__ wt, float* __restrict__ gx,
+                                                                    int accumulate, int B, int H, int W,
+                                                                    const float* __restrict__ gPb,
+                                                                    const uint32_t* __restrict__ xbits) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint4* s_w = (uint4*)smem_raw;  // NFRAG*64
+  uint4* s_a = s_w + NFRAG * 64;  // [3][DL_HPP][4]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.z, y0 = blockIdx.y * DG_ROWS, y = y0 + wv, x0 = blockIdx.x * 32;
+  const int i = lane & 31, kg = lane >> 5;
+  // ---- everything this block reads, requested at once
+  for (int u = wv; u < NFRAG; u += DG_ROWS)
+    __builtin_amdgcn_global_load_lds((dl_glb_void*)(wt + u * 64 + lane), (dl_lds_void*)(s_w + u * 64), 16, 0, 0);
+  for (int q = wv; q < 3 * DL_UPP; q += DG_ROWS) {
+    const int sp = q / DL_UPP, u = q - sp * DL_UPP;
+    const int p = 16 * u + (lane >> 2), pc = min(p, DL_HP - 1);
+    const int hr = pc / DL_HW, hc = pc - hr * DL_HW;
+    const int yy = min(max(y0 - 1 + hr, 0), H - 1), xx = min(max(x0 - 1 + hc, 0), W - 1);  // out-of-image: masked at use
+    const int c = (lane & 3) ^ ((p >> 2) & 3);
+    const uint4* g = gs + sp * plane_stride + (((long)b * H + yy) * W + xx) * 4 + c;
+    __builtin_amdgcn_global_load_lds((dl_glb_void*)g, (dl_lds_void*)(s_a + (sp * DL_HPP + 16 * u) * 4), 16, 0, 0);
+  }
+  const int yq = min(y, H - 1);
+  float oldv[16], pv[16];
+  uint32_t xb[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int col = min(x0 + dg_row(r, lane), W - 1);
+    const long pix = ((long)b * H + yq) * W + col;
+    oldv[r] = accumulate ? gx[pix * C32 + i] : 0.f;  // uniform condition
+    pv[r] = gPb ? gPb[pix] : 0.f;
+    xb[r] = gPb ? xbits[pix] : 0u;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (y >= H) return;
+  f32x16 acc = {0};
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int yy = y + dy - 1;
+    const bool yin = yy >= 0 && yy < H;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int tau = dy * 3 + dx;
+      const int xx = x0 + i + dx - 1;
+      const uint32_t msk = (yin && xx >= 0 && xx < W) ? 0xFFFFFFFFu : 0u;
+      const int hp = (wv + dy) * DL_HW + i + dx, sw = (hp >> 2) & 3;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const uint4* wf = s_w + ((tau * 2 + m) * 3) * 64 + lane;
+        const uint4 w0 = wf[0], w1 = wf[64], w2 = wf[128];
+        const bf16x8 wh = *(const bf16x8*)&w0, wm = *(const bf16x8*)&w1, wl = *(const bf16x8*)&w2;
+        const int slot = hp * 4 + ((2 * m + kg) ^ sw);
+        uint4 u0 = s_a[slot], u1 = s_a[DL_HPP * 4 + slot], u2 = s_a[2 * DL_HPP * 4 + slot];
+        u0.x &= msk, u0.y &= msk, u0.z &= msk, u0.w &= msk;
+        u1.x &= msk, u1.y &= msk, u1.z &= msk, u1.w &= msk;
+        u2.x &= msk, u2.y &= msk, u2.z &= msk, u2.w &= msk;
+        const bf16x8 ah = *(const bf16x8*)&u0, am = *(const bf16x8*)&u1, al = *(const bf16x8*)&u2;
+        // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int col = x0 + dg_row(r, lane);
+    const float v = acc[r] + oldv[r] + (((xb[r] >> i) & 1u) ? pv[r] : 0.f);
+    if (col < W) gx[(((long)b * H + y) * W + col) * C32 + i] = v;
+  }
+}
+
 extern "C" int evf_conv_dgrad_b3(const void* g_split, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W,
                                  const float* g_P, const uint32_t* x_bits, void* stream) {
   if (!g_split || !wT_b3 || !g_x || B <= 0 || H <= 0 || W <= 0 || ((g_P != nullptr) != (x_bits != nullptr)))
     return EVF_EINVAL;
   dim3 grid(evf_cdiv(W, 32), evf_cdiv(H, DG_ROWS), B), block(DG_ROWS * 64);
   const long plane_stride = (long)B * H * W * 4;  // uint4 per term plane: npix * 32 bf16 / 8
-  hipLaunchKernelGGL(k_conv_dgrad_b3, grid, block, NFRAG * 1024, EVF_STREAM(stream), (const uint4*)g_split, plane_stride,
+  static bool attr = false;
+  const size_t lds = (size_t)(NFRAG * 64 + 3 * DL_HPP * 4) * sizeof(uint4);  // 120 KiB: one block per CU
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_conv_dgrad_b3_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k_conv_dgrad_b3_lds, grid, block, lds, EVF_STREAM(stream), (const uint4*)g_split, plane_stride,
                      (const uint4*)wT_b3, g_x, accumulate, B, H, W, g_P, x_bits);
   return evf_status();
 }
