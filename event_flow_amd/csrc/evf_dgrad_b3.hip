@@ -123,9 +123,14 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3(const uint4* __r
   for (int r = 0; r < 16; ++r) {
     const int col = min(x0 + dg_row(r, lane), W - 1);
     const long pix = ((long)b * H + y) * W + col;
-    oldv[r] = accumulate ? gx[pix * C32 + i] : 0.f;  // uniform condition
-    pv[r] = gPb ? gPb[pix] : 0.f;
-    xb[r] = gPb ? xbits[pix] : 0u;
+    // branch-free: a (uniform) branch around a load costs a basic block and a drained vmcnt per iteration; when the
+    // operand is absent every lane reads the same dummy word instead
+    const float o = *(accumulate ? gx + pix * C32 + i : gx);
+    const float pp = *(gPb ? gPb + pix : gx);
+    const uint32_t xw = *(gPb ? xbits + pix : (const uint32_t*)gx);
+    oldv[r] = accumulate ? o : 0.f;
+    pv[r] = gPb ? pp : 0.f;
+    xb[r] = gPb ? xw : 0u;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -185,9 +190,14 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
   for (int r = 0; r < 16; ++r) {
     const int col = min(x0 + dg_row(r, lane), W - 1);
     const long pix = ((long)b * H + yq) * W + col;
-    oldv[r] = accumulate ? gx[pix * C32 + i] : 0.f;  // uniform condition
-    pv[r] = gPb ? gPb[pix] : 0.f;
-    xb[r] = gPb ? xbits[pix] : 0u;
+    // branch-free: a (uniform) branch around a load costs a basic block and a drained vmcnt per iteration; when the
+    // operand is absent every lane reads the same dummy word instead
+    const float o = *(accumulate ? gx + pix * C32 + i : gx);
+    const float pp = *(gPb ? gPb + pix : gx);
+    const uint32_t xw = *(gPb ? xbits + pix : (const uint32_t*)gx);
+    oldv[r] = accumulate ? o : 0.f;
+    pv[r] = gPb ? pp : 0.f;
+    xb[r] = gPb ? xw : 0u;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
