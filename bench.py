@@ -108,7 +108,7 @@ def iwe_warp_bandwidth(dev, B, reps=20):
             "frac_of_hbm_peak": alg_bytes / ms / 1e6 / HBM_PEAK}
 
 
-_KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3", "evf_lif_bwd_wgrad/ff": "k_lif_bwd_wgrad<false>",
+_KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3_lds", "evf_lif_bwd_wgrad/ff": "k_lif_bwd_wgrad<false>",
               "evf_lif_bwd_wgrad/rec": "k_lif_bwd_wgrad<true>", "evf_conv_lif_fwd_b3/ff": "k_conv_lif_fwd_b3<false, false>",
               "evf_conv_lif_fwd_b3/rec": "k_conv_lif_fwd_b3<true, false>", "evf_head_lif_fwd": "k_head_lif_fwd",
               "evf_head_lif_bwd_wgrad": "k_lif_bwd<2>", "evf_conv_dgrad/one": "k_conv_dgrad<false>",
@@ -189,8 +189,8 @@ def cpu_baseline(threads, max_seconds=60.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-iwe", action="store_true")
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",

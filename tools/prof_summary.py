@@ -16,8 +16,8 @@ DST = os.path.join(ROOT, "profiles")
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(SRC, pattern))
-    return f[0] if f else None
+    f = sorted(glob.glob(os.path.join(SRC, pattern)), key=os.path.getmtime)
+    return f[-1] if f else None  # newest (earlier collections of the round may still be lying around)
 
 
 def short(name):
