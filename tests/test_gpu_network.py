@@ -168,10 +168,20 @@ def test_train_step_vs_oracle_at_config3_shape():
         loss_cfg={"flow_regul_weight": 0.001, "mask_output": True},
     )
     np.testing.assert_allclose(float(loss.detach()), oloss_v, rtol=1e-3)
+    # borderline spike flips (see the config-5 test below) would legitimately move the gradient by a few percent:
+    # count them and widen the tolerance only then
+    states = [None] * 7
+    with torch.no_grad():
+        for d in opasses:
+            _, states = osnn.firenet_forward("LIFFireNet", params, d["event_cnt"], states)
+    got_states = model.states
+    nflip = sum(int((N(got_states[li][1]) != states[li][1].numpy()).sum()) for li in range(7))
+    assert nflip <= 1e-4 * sum(states[li][1].numel() for li in range(7)), nflip
+    tol = 1e-2 if nflip == 0 else 1e-1
     for k, p in model.named_parameters():
         ref = ograds[k].numpy()
         denom = max(np.linalg.norm(ref), 1e-12)
-        assert np.linalg.norm(N(p.grad) - ref) <= 1e-2 * denom + 1e-9, (k, np.linalg.norm(N(p.grad) - ref) / denom)
+        assert np.linalg.norm(N(p.grad) - ref) <= tol * denom + 1e-9, (k, np.linalg.norm(N(p.grad) - ref) / denom, nflip)
 
 
 def test_plif_train_step_vs_oracle_at_config5_shape():
