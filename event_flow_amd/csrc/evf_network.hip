@@ -117,6 +117,19 @@ __device__ __forceinline__ void lif_epilogue(const f32x16& acc, int b, int row, 
   const int j = lane & 31;
   const bool row_ok = row < H;
   uint32_t plane = 0u;  // this channel's spikes over the tile's 32 pixels (bit = column)
+  // previous state of the 16 pixels of this lane: unconditional loads from clamped addresses, all in flight
+  // together (a load under `if (ok)` is followed by its own s_waitcnt vmcnt(0): 16 serial round trips)
+  float vpv[16];
+  uint32_t zw[16];
+  const int rq = min(row, H - 1);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int cq = min(x0 + mfma_row(r, lane), W - 1);
+    const float* src = v_prev ? v_prev : v_out;
+    const float val = src[(((long)b * H + rq) * W + cq) * C32 + j];
+    vpv[r] = v_prev ? val : 0.f;
+    zw[r] = zprev_word(rq, cq);
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int col = x0 + mfma_row(r, lane);
@@ -124,8 +137,8 @@ __device__ __forceinline__ void lif_epilogue(const f32x16& acc, int b, int row, 
     const long pix = ((long)b * H + row) * W + col;
     bool spike = false;
     if (ok) {
-      const float v = v_prev ? v_prev[pix * C32 + j] : 0.f;
-      const float z = (float)((zprev_word(row, col) >> j) & 1u);
+      const float v = vpv[r];
+      const float z = (float)((zw[r] >> j) & 1u);
       const float cur = acc[r];
       float vo;
       if (hard_reset)
@@ -311,7 +324,10 @@ __global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ 
       }
     }
   }
-  auto zword = [&](int row, int col) -> uint32_t { return z_prev ? z_prev[((long)b * H + row) * W + col] : 0u; };
+  auto zword = [&](int row, int col) -> uint32_t {
+    const uint32_t wd = *(z_prev ? z_prev + ((long)b * H + row) * W + col : (const uint32_t*)v_out);  // no branch around the load
+    return z_prev ? wd : 0u;
+  };
   lif_epilogue(acc0, b, y0 + r0, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out, zT_out);
   lif_epilogue(acc1, b, y0 + r0 + 1, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out, zT_out);
 }
