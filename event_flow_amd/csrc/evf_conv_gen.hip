@@ -256,27 +256,35 @@ __global__ __launch_bounds__(256) void k_conv2d_f32(const float* __restrict__ sr
     for (int i = 0; i < 32; ++i) a_cur[i] = a_nxt[i];
   }
 
+  // epilogue.  Output pixel of each accumulator row once (PAR needs divisions); when accumulating, all old values
+  // are read first from clamped addresses in one straight-line block (a load under `if (mr < M)` is followed by its
+  // own s_waitcnt vmcnt(0): 16 NT serial round trips)
+  int pixr[16];  // pixel index (B*OH*OW < 2^31), -1 = past the end
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const long mr = (long)blockIdx.x * CG_BM + wv * 32 + cg_row(r, lane);
+    int pix = (int)mr;
+    if (PAR) {
+      const int mi = (int)(mr < M ? mr : M - 1), rcx = mi % CW, rt = mi / CW;
+      pix = ((rt / CH) * g.OH + 2 * (rt % CH) + py) * g.OW + 2 * rcx + px;
+    }
+    pixr[r] = mr < M ? pix : -1;
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int n = (blockIdx.y * NT + t) * 32 + row;
-    if (n < g.N) {
-      const float bv = bias ? bias[n] : 0.f;
+    const int n = (blockIdx.y * NT + t) * 32 + row, nq = min(n, g.N - 1);
+    const float bv = (bias && n < g.N) ? bias[n] : 0.f;
+    float oldv[16];
+    if (accumulate) {  // uniform
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long mr = (long)blockIdx.x * CG_BM + wv * 32 + cg_row(r, lane);
-        if (mr < M) {
-          long pix = mr;
-          if (PAR) {
-            const int rcx = (int)(mr % CW);
-            const long rt = mr / CW;
-            pix = (rt / CH * g.OH + 2 * (rt % CH) + py) * g.OW + 2 * rcx + px;
-          }
-          float* d = out + pix * g.ldo + n;
-          const float v = acc[t][r] + bv;
-          *d = accumulate ? *d + v : v;
-        }
-      }
+      for (int r = 0; r < 16; ++r) oldv[r] = out[(long)max(pixr[r], 0) * g.ldo + nq];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oldv[r] = 0.f;
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (pixr[r] >= 0 && n < g.N) out[(long)pixr[r] * g.ldo + n] = (acc[t][r] + bv) + oldv[r];
   }
 }
 
