@@ -590,3 +590,31 @@ extern "C" int evf_gru_gates_bwd(const float* g_hr, const float* h, const float*
                      g_h);
   return evf_status();
 }
+
+// ---------------------------------------------------------------------------
+// stand-alone spike functions (models/spiking_util.py:13-109): z = (x - thresh > 0) as fp32,
+// backward g * surrogate(x - thresh).  thresh is one scalar (device pointer).
+// ---------------------------------------------------------------------------
+__global__ void k_spike_fwd(const float* __restrict__ x, const float* __restrict__ thresh, int tstride, long n,
+                            float* __restrict__ z) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) z[i] = (x[i] - thresh[i * tstride]) > 0.f ? 1.0f : 0.f;
+}
+__global__ void k_spike_bwd(int kind, const float* __restrict__ x, const float* __restrict__ thresh, int tstride,
+                            const float* __restrict__ g, float width, long n, float* __restrict__ gx) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) gx[i] = g[i] * ng_surrogate(kind, x[i] - thresh[i * tstride], width);
+}
+extern "C" int evf_spike_fwd(const float* x, const float* thresh, int thresh_per_element, int64_t n, float* z, void* stream) {
+  if (!x || !thresh || !z || n <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_spike_fwd, dim3(evf_cdiv(n, 256)), dim3(256), 0, EVF_STREAM(stream), x, thresh,
+                     thresh_per_element ? 1 : 0, (long)n, z);
+  return evf_status();
+}
+extern "C" int evf_spike_bwd(int surrogate, const float* x, const float* thresh, int thresh_per_element, const float* g,
+                             float width, int64_t n, float* g_x, void* stream) {
+  if (!x || !thresh || !g || !g_x || n <= 0 || surrogate < 0 || surrogate > 3) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_spike_bwd, dim3(evf_cdiv(n, 256)), dim3(256), 0, EVF_STREAM(stream), surrogate, x, thresh,
+                     thresh_per_element ? 1 : 0, g, width, (long)n, g_x);
+  return evf_status();
+}

@@ -378,6 +378,13 @@ int evf_upsample_nearest_bwd(const float* g_y, int64_t planes, int h, int w, int
 int evf_act_fwd(int kind, const float* x, const float* residual, int64_t n, float* y, void* stream);
 int evf_act_bwd(int kind, const float* y, const float* g_y, int64_t n, float* g_x, void* stream);
 
+/* Stand-alone spike functions (models/spiking_util.py:13-25 forward, :38-93 surrogates): z = (x - thresh > 0)
+ * as fp32; g_x = g * surrogate(x - thresh, width) with surrogate = EVF_ARCTAN / SUPERSPIKE / TRIANGLE / MULTIGAUSS.
+ * thresh: one scalar (thresh_per_element = 0) or one value per element of x (1). */
+int evf_spike_fwd(const float* x, const float* thresh, int thresh_per_element, int64_t n, float* z, void* stream);
+int evf_spike_bwd(int surrogate, const float* x, const float* thresh, int thresh_per_element, const float* g,
+                  float width, int64_t n, float* g_x, void* stream);
+
 /* ConvGRU gate algebra (submodules.py:404-416): u = sigmoid(cu), r = sigmoid(cr), hr = h r;
  * o = tanh(co), h_new = h (1 - u) + o u.  h null = zeros.  Backward: evf_gru_out_bwd writes
  * g_co, g_cu (pre-activation) and g_h = g_new (1-u); evf_gru_gates_bwd writes g_cr and ADDS

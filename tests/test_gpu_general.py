@@ -342,3 +342,25 @@ def test_evflownet_at_config4_width_vs_oracle():
         g = N(p.grad) if p.grad is not None else np.zeros_like(ref)
         err += float(((g - ref) ** 2).sum())
     assert np.sqrt(err) <= (2e-3 if nflip == 0 else 1e-1) * gn, (np.sqrt(err) / gn, nflip)
+
+
+@pytest.mark.parametrize("name", ["arctanspike", "superspike", "trianglespike", "mgspike"])
+def test_standalone_spike_functions(name):
+    """models/spiking_util.py API: forward Heaviside of (x - thresh), backward = the surrogate (oracle formulas)."""
+    from event_flow_amd.models import spiking_util as su
+
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 5, 7, generator=g)
+    th = torch.tensor([0.2, -0.1, 0.4, 0.0, 0.3]).view(1, 5, 1)
+    width = {"arctanspike": 10.0, "superspike": 10.0, "trianglespike": 1.0, "mgspike": 0.5}[name]
+    xd = x.to(DEV).requires_grad_(True)
+    z = getattr(su, name)(xd, th.to(DEV), torch.tensor(width))
+    assert z.dtype == torch.float32 and np.array_equal(N(z), (x - th).gt(0).float().numpy())
+    gy = torch.randn(x.shape, generator=g)
+    z.backward(gy.to(DEV))
+    ref = gy * osnn.surrogate(name, x - th, width)
+    np.testing.assert_allclose(N(xd.grad), ref.numpy(), rtol=1e-5, atol=1e-7)
+    z1 = getattr(su, name)(x.to(DEV))  # reference defaults: thresh = 1.0
+    assert np.array_equal(N(z1), (x - 1.0).gt(0).float().numpy())
+    with pytest.raises(_lib.EvflowError):
+        getattr(su, name)(x)  # CPU tensor: no fallback
