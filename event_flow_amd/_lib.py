@@ -33,6 +33,8 @@ SIGNATURES = {
     "evf_image_variance": [P, I, I, P, P],
     "evf_avg_ts_ratio": [P, I, I, F, P, P],
     "evf_aee": [P, P, P, P, I, I, I, F, P, P],
+    "evf_mask_union": [P, I, I, I, I, P, P],
+    "evf_masked_flow_mean": [P, P, I, I, I, I, P, P],
 }
 
 # network entry points (added as the kernels land)

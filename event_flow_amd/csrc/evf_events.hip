@@ -971,3 +971,46 @@ extern "C" int evf_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+
+// --------------------------------------------------------------------------
+// window masks (loss/flow.py:149-150, 443-452)
+// --------------------------------------------------------------------------
+// out[b][q] = min(sum_p mask[b][p][q], 1)
+__global__ void k_mask_union(const float* __restrict__ m, int B, int P, long HW, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * HW) return;
+  const long b = i / HW, q = i - b * HW;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += m[(b * P + p) * HW + q];
+  out[i] = fminf(s, 1.0f);
+}
+extern "C" int evf_mask_union(const float* masks, int B, int P, int H, int W, float* out, void* stream) {
+  if (!masks || !out || B <= 0 || P <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  const long HW = (long)H * W;
+  hipLaunchKernelGGL(k_mask_union, dim3(evf_cdiv(B * HW, 256)), dim3(256), 0, EVF_STREAM(stream), masks, B, P, HW, out);
+  return evf_status();
+}
+// out[b][c][q] = sum_p maps[b][p][c][q] * mask[b][p][q] / (sum_p mask[b][p][q] + 1e-9)
+__global__ void k_masked_flow_mean(const float* __restrict__ maps, const float* __restrict__ m, int B, int P, long HW,
+                                   float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * HW) return;
+  const long b = i / HW, q = i - b * HW;
+  float sx = 0.f, sy = 0.f, sm = 0.f;
+  for (int p = 0; p < P; ++p) {
+    const float w = m[(b * P + p) * HW + q];
+    sx += maps[((b * P + p) * 2 + 0) * HW + q] * w;
+    sy += maps[((b * P + p) * 2 + 1) * HW + q] * w;
+    sm += w;
+  }
+  out[(b * 2 + 0) * HW + q] = sx / (sm + 1e-9f);
+  out[(b * 2 + 1) * HW + q] = sy / (sm + 1e-9f);
+}
+extern "C" int evf_masked_flow_mean(const float* maps, const float* masks, int B, int P, int H, int W, float* out,
+                                    void* stream) {
+  if (!maps || !masks || !out || B <= 0 || P <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  const long HW = (long)H * W;
+  hipLaunchKernelGGL(k_masked_flow_mean, dim3(evf_cdiv(B * HW, 256)), dim3(256), 0, EVF_STREAM(stream), maps, masks, B, P, HW,
+                     out);
+  return evf_status();
+}

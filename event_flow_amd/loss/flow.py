@@ -66,6 +66,15 @@ class _WindowRecord:
         return torch.cat([m.to(torch.float32) for m in self.masks], 1).contiguous()  # [B,P,H,W]
 
 
+def _mask_union(masks):
+    """[B,P,H,W] binary masks of the passes -> [B,1,H,W] mask of the window, min(sum, 1)."""
+    masks = masks.contiguous()
+    B, P, H, W = masks.shape
+    out = torch.empty((B, 1, H, W), dtype=torch.float32, device=masks.device)
+    _lib.call("evf_mask_union", _lib.ptr(masks), B, P, H, W, _lib.ptr(out))
+    return out
+
+
 _PASS_INDEX = {}
 
 
@@ -175,8 +184,7 @@ class EventWarping(torch.nn.Module):
     def event_mask(self):
         """Mask of the window (overwrite) or of the last pass.  loss/flow.py:168-174."""
         if self._win.overwritten:
-            m = self._win.mask_stack().sum(1, keepdim=True)
-            return torch.clamp(m, max=1.0)  # loss/flow.py:149-150
+            return _mask_union(self._win.mask_stack())  # loss/flow.py:149-150
         if self.overwrite_intermediate:
             return self._win.mask_stack()
         return self._win.masks[-1].to(torch.float32)
@@ -188,8 +196,7 @@ class EventWarping(torch.nn.Module):
         overwritten = win.overwritten
         if overwritten:
             flows_by_pass = [self._final_flow]
-            m = win.mask_stack().sum(1, keepdim=True)
-            mask = torch.clamp(m, max=1.0).contiguous()
+            mask = _mask_union(win.mask_stack())
         else:
             flows_by_pass = win.flows
             mask = win.mask_stack()
@@ -267,7 +274,7 @@ class BaseValidationLoss(torch.nn.Module):
 
     def _event_mask_stack(self):
         if self._win.overwritten:
-            return torch.clamp(self._win.mask_stack().sum(1, keepdim=True), max=1.0)
+            return _mask_union(self._win.mask_stack())
         return self._win.mask_stack()
 
     def _splat(self, *, round_idx, nch, zero_flow=False, with_ts=False, pol=True):
@@ -286,10 +293,16 @@ class BaseValidationLoss(torch.nn.Module):
         """loss/flow.py:443-452."""
         mask = self._event_mask_stack()
         if self.overwrite_intermediate:
-            return self._final_flow * mask
-        maps = torch.stack([f[0].to(torch.float32) for f in self._win.flows], 1)  # [B,P,2,H,W]
-        avg = (maps * mask.unsqueeze(2)).sum(1)
-        return avg / (mask.sum(1, keepdim=True) + 1e-9)
+            ff = self._final_flow.to(torch.float32).contiguous()
+            B, _, H, W = ff.shape
+            out = torch.empty_like(ff)
+            _lib.call("evf_masked_flow_mean", _lib.ptr(ff), _lib.ptr(mask.contiguous()), B, 1, H, W, _lib.ptr(out))
+            return out  # flow * mask for a binary mask
+        maps = torch.stack([f[0].to(torch.float32) for f in self._win.flows], 1).contiguous()  # [B,P,2,H,W]
+        B, P, _, H, W = maps.shape
+        out = torch.empty((B, 2, H, W), dtype=torch.float32, device=maps.device)
+        _lib.call("evf_masked_flow_mean", _lib.ptr(maps), _lib.ptr(mask.contiguous()), B, P, H, W, _lib.ptr(out))
+        return out
 
     def compute_window_iwe(self, round_idx=True):
         """Per-polarity IWE of the window at t_ref = P [B,2,H,W].  loss/flow.py:454-465
