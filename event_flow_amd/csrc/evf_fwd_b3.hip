@@ -14,6 +14,7 @@
 // LDS table (one ds_read_b128, broadcast for the all-zero byte).
 // B operand: packed per (tap, m, term) as 64 lanes x 16 B (k_pack_conv_weight_b3).
 #include "evf_common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -62,6 +63,21 @@ extern "C" int evf_pack_conv_weight_b3(const float* w, int Cout, int Cin, void* 
   return evf_status();
 }
 
+
+// LDS-DMA of one 1 KiB piece (64 lanes x 16 B, destination = wave-uniform LDS address + lane*16), invisible to the
+// compiler's wait counting: completion is covered by the explicit s_waitcnt vmcnt(0) before the barrier that
+// publishes the buffer.  Staging the 54 KiB of split weights through registers (load -> wait -> ds_write, 13.5 uint4
+// per thread) cost 6.8 us of a 15.7 us block lifetime (s_memtime instrumentation); as DMA all pieces are in flight
+// at once and no VGPRs are held.
+__device__ __forceinline__ void b3_glds16(const void* gsrc, void* lds_dst) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+
 // PLIF (spiking_submodules.py:191-227, :618-657): a per-channel pre-synaptic trace
 //   pt' = pt*sigma(leak_pt) + (1 - sigma(leak_pt)) * AvgPool3x3(mean_c |input|)
 // is subtracted from the current, cur = ff (+ rec) - sigma(add_pt) * pt'.  For binary inputs
@@ -93,7 +109,7 @@ __global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restr
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
 
-  for (int i = tid; i < NFRAG * 64; i += 256) s_w[i] = wff[i];
+  for (int u = wv; u < NFRAG; u += 4) b3_glds16(wff + u * 64 + lane, s_w + u * 64);
   {  // byte -> 8 x bf16 {0, 1.0}
     const uint32_t t = tid;
     auto pr = [&](int e) { return ((t >> e) & 1u) * 0x3F80u | (((t >> (e + 1)) & 1u) * 0x3F80u) << 16; };
@@ -132,6 +148,7 @@ __global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restr
         ptp[m][r] = pl.pt_prev ? val : 0.f;
       }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weight DMA landed (and the state prefetch with it)
   __syncthreads();
   if (PLIF) {  // pooled pre-synaptic activity of the tile's 256 pixels (one per thread)
     const int py = tid >> 5, px = tid & 31;
@@ -170,7 +187,8 @@ __global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restr
   conv_phase(s_x);
   if (REC) {
     __syncthreads();  // every wave is done with the ff weights
-    for (int q = tid; q < NFRAG * 64; q += 256) s_w[q] = wrec[q];
+    for (int u = wv; u < NFRAG; u += 4) b3_glds16(wrec + u * 64 + lane, s_w + u * 64);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     conv_phase(s_z);
   }
@@ -178,43 +196,69 @@ __global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restr
   const float lam = b3_sigmoid(leak[j]);     // torch.sigmoid(self.leak)     spiking_submodules.py:111/:536
   const float th = fmaxf(thresh[j], 0.01f);  // self.thresh.clamp_min(0.01)  :108/:533
   const float lpt = PLIF ? b3_sigmoid(pl.leak_pt[j]) : 0.f, apt = PLIF ? b3_sigmoid(pl.add_pt[j]) : 0.f;
+  // Epilogue.  A lane owns channel j of 16 pixels per row; pixel (r, kg) sits at column (r&3) + 8(r>>2) + 4kg of
+  // the tile, so every address below is one per-row base pointer plus a compile-time offset.  Interior tiles (the
+  // common case) run without any bounds logic; edge tiles mask per element.
+  const bool interior = (x0 + TW <= W) && (y0 + TH <= H);  // block-uniform
+  const int nW = (W + 31) / 32;
+  auto epilogue = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const f32x16& acc = m ? acc1 : acc0;
-    const int row = y0 + r0 + m;
-    uint32_t plane = 0u;
+    for (int m = 0; m < 2; ++m) {
+      const f32x16& acc = m ? acc1 : acc0;
+      const int row = y0 + r0 + m;
+      const long rowbase = ((long)b * H + min(row, H - 1)) * W + x0 + 4 * kg;  // pixel index of (r = 0) for this lane
+      float* vo_p = v_out + rowbase * C32 + j;
+      float* pt_p = PLIF ? pl.pt_out + rowbase * C32 + j : nullptr;
+      uint32_t* z_p = z_out + rowbase;
+      const uint32_t* sz = s_z + (r0 + m + 1) * HALO_W + 1 + 4 * kg;
+      const float* sP = s_P + (r0 + m) * TW + 4 * kg;
+      uint32_t plane = 0u, myword = 0u;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int cl = b3_row(r, lane), col = x0 + cl;
-      const bool ok = row < H && col < W;
-      const long pix = ((long)b * H + row) * W + col;
-      bool spike = false;
-      if (ok) {
-        const float z = (float)((s_z[(r0 + m + 1) * HALO_W + cl + 1] >> j) & 1u);
+      for (int r = 0; r < 16; ++r) {
+        const int c0 = (r & 3) + 8 * (r >> 2);  // compile-time part of the column
+        const bool ok = FULL || (row < H && x0 + c0 + 4 * kg < W);
+        const float z = (float)((sz[c0] >> j) & 1u);
         const float v = vp[m][r];
         float cur = acc[r];
+        float pto = 0.f;
         if (PLIF) {
-          const float pto = ptp[m][r] * lpt + (1.0f - lpt) * s_P[(r0 + m) * TW + cl];  // :212 / :642
-          pl.pt_out[pix * C32 + j] = pto;
-          cur = cur - apt * pto;  // (ff + rec) - add_pt * pt_out, :220 / :650
+          pto = ptp[m][r] * lpt + (1.0f - lpt) * sP[c0];  // :212 / :642
+          cur = cur - apt * pto;                           // (ff + rec) - add_pt * pt_out, :220 / :650
         }
-        float vo;
-        if (hard_reset)
-          vo = (v * lam) * (1.0f - z) + (1.0f - lam) * cur;  // :119/:544
-        else
-          vo = v * lam + (1.0f - lam) * cur - z * th;        // :121/:546
-        v_out[pix * C32 + j] = vo;
-        spike = (vo - th) > 0.f;
+        // both reset rules evaluated, one selected: no per-element branch on the (uniform) flag
+        const float vo_hard = (v * lam) * (1.0f - z) + (1.0f - lam) * cur;  // :119/:544
+        const float vo_soft = v * lam + (1.0f - lam) * cur - z * th;        // :121/:546
+        const float vo = hard_reset ? vo_hard : vo_soft;
+        const bool spike = ok && (vo - th) > 0.f;
+        if (FULL) {
+          vo_p[c0 * C32] = vo;
+          if (PLIF) pt_p[c0 * C32] = pto;
+        } else if (ok) {
+          vo_p[c0 * C32] = vo;
+          if (PLIF) pt_p[c0 * C32] = pto;
+        }
+        // spike word of the pixel (32 channels = the 32 lanes of this half wave): the ballot is wave-uniform;
+        // lane (r, kg) keeps it and the 16 words of the row leave in ONE store below
+        const unsigned long long mk = __ballot(spike);
+        const uint32_t wd = kg ? (uint32_t)(mk >> 32) : (uint32_t)mk;
+        myword = (j == r) ? wd : myword;
+        plane |= (spike ? 1u : 0u) << (c0 + 4 * kg);
       }
-      const unsigned long long mk = __ballot(spike);
-      if (ok && j == 0) z_out[pix] = kg ? (uint32_t)(mk >> 32) : (uint32_t)mk;
-      plane |= (spike ? 1u : 0u) << cl;
+      {
+        const int rr = j & 15, cc = (rr & 3) + 8 * (rr >> 2);  // lane j < 16 of each half holds the word of pixel (rr, kg)
+        if (j < 16 && (FULL || (row < H && x0 + cc + 4 * kg < W))) z_p[cc] = myword;
+      }
+      if (zT_out) {  // channel-major bit planes [B][H][32][ceil(W/32)]
+        plane |= __shfl_xor(plane, 32, 64);
+        if ((FULL || row < H) && lane < 32) zT_out[(((long)b * H + row) * C32 + j) * nW + x0 / 32] = plane;
+      }
     }
-    if (zT_out) {  // channel-major bit planes [B][H][32][ceil(W/32)]
-      plane |= __shfl_xor(plane, 32, 64);
-      if (row < H && lane < 32) zT_out[(((long)b * H + row) * C32 + j) * ((W + 31) / 32) + x0 / 32] = plane;
-    }
-  }
+  };
+  if (interior)
+    epilogue(std::true_type{});
+  else
+    epilogue(std::false_type{});
 }
 
 static int launch_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec, const float* leak,
