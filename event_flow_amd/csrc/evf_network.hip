@@ -520,13 +520,20 @@ __global__ __launch_bounds__(256, 2) void k_lif_bwd(const float4* __restrict__ g
     inv_oml[k] = 1.0f / oml[k];  // per-channel constant: no division in the element loop
   }
   float sl[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
+  // optional tensors are redirected to v_out and zeroed by a select: no branch around a load (each would end
+  // its basic block with s_waitcnt vmcnt(0))
+  const float4* pgz = g_z_out ? g_z_out : v_out;
+  const float4* pgv = g_v_out ? g_v_out : v_out;
+  const float4* pvp = v_prev ? v_prev : v_out;
+  const uint32_t* pzw = z_prev ? z_prev : (const uint32_t*)v_out;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (long e = (long)blockIdx.x * blockDim.x + tid; e < npix * 8; e += (long)gridDim.x * blockDim.x) {
     const long pix = e >> 3;
     const float4 vo4 = v_out[e];
-    const float4 gz4 = g_z_out ? g_z_out[e] : make_float4(0, 0, 0, 0);
-    const float4 gv4 = g_v_out ? g_v_out[e] : make_float4(0, 0, 0, 0);
-    const float4 vp4 = v_prev ? v_prev[e] : make_float4(0, 0, 0, 0);
-    const uint32_t zw = z_prev ? (z_prev[pix] >> (4 * cg)) : 0u;
+    const float4 gzl = pgz[e], gvl = pgv[e], vpl = pvp[e];
+    const uint32_t zwl = pzw[pix];
+    const float4 gz4 = g_z_out ? gzl : zero4, gv4 = g_v_out ? gvl : zero4, vp4 = v_prev ? vpl : zero4;
+    const uint32_t zw = z_prev ? (zwl >> (4 * cg)) : 0u;
     const float vo[4] = {vo4.x, vo4.y, vo4.z, vo4.w}, gz[4] = {gz4.x, gz4.y, gz4.z, gz4.w};
     const float gvo[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, vp[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
     float gc[4], gp[4];

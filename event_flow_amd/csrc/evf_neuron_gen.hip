@@ -42,7 +42,12 @@ struct NgParams {
 //   ALIF: p0 leak_v    p1 t0       p2 t1       p3 leak_t
 //   XLIF: p0 leak_v    p1 t0       p2 t1       p3 leak_pt
 
-__device__ __forceinline__ float4 ng_ld(const float4* p, long e) { return p ? p[e] : make_float4(0.f, 0.f, 0.f, 0.f); }
+// optional tensor: read a valid dummy instead of branching around the load (a branch ends the basic block with
+// s_waitcnt vmcnt(0)), select zero afterwards
+__device__ __forceinline__ float4 ng_ld(const float4* p, const float4* dummy, long e) {
+  const float4 v = (p ? p : dummy)[e];
+  return p ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
 
 template <int KIND>
 __global__ void k_neuron_fwd(const float4* __restrict__ cur, const float4* __restrict__ v_prev,
@@ -66,7 +71,7 @@ __global__ void k_neuron_fwd(const float4* __restrict__ cur, const float4* __res
   }
   for (; e < total; e += stride) {
     const long pix = e / Q;
-    const float4 c4 = cur[e], v4 = ng_ld(v_prev, e), z4 = ng_ld(z_prev, e), x4 = ng_ld(aux_prev, e);
+    const float4 c4 = cur[e], v4 = ng_ld(v_prev, cur, e), z4 = ng_ld(z_prev, cur, e), x4 = ng_ld(aux_prev, cur, e);
     const float Pv = (KIND == EVF_PLIF || KIND == EVF_XLIF) ? P[pix] : 0.f;
     const float cu[4] = {c4.x, c4.y, c4.z, c4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w}, z[4] = {z4.x, z4.y, z4.z, z4.w};
     const float ax[4] = {x4.x, x4.y, x4.z, x4.w};
@@ -96,7 +101,7 @@ __global__ void k_neuron_fwd(const float4* __restrict__ cur, const float4* __res
     z_out[e] = make_float4(zo[0], zo[1], zo[2], zo[3]);
     if (KIND != EVF_LIF) aux_out[e] = make_float4(ao[0], ao[1], ao[2], ao[3]);
     if (out) {
-      const float4 r4 = ng_ld(residual, e);
+      const float4 r4 = ng_ld(residual, cur, e);
       out[e] = make_float4(zo[0] + r4.x, zo[1] + r4.y, zo[2] + r4.z, zo[3] + r4.w);
     }
   }
@@ -169,9 +174,10 @@ __global__ void k_neuron_bwd(const float4* __restrict__ g_v_out, const float4* _
     const long e = base + gtid;
     const bool ok = e < total;
     const long ec = ok ? e : total - 1, pix = ec / Q;
-    const float4 gv4 = ng_ld(g_v_out, ec), gza = ng_ld(g_z_out, ec), gzb = ng_ld(g_z_out2, ec), ga4 = ng_ld(g_aux_out, ec);
+    const float4 gv4 = ng_ld(g_v_out, v_out, ec), gza = ng_ld(g_z_out, v_out, ec), gzb = ng_ld(g_z_out2, v_out, ec),
+                 ga4 = ng_ld(g_aux_out, v_out, ec);
     const float4 gz4 = make_float4(gza.x + gzb.x, gza.y + gzb.y, gza.z + gzb.z, gza.w + gzb.w);
-    const float4 vo4 = v_out[ec], v4 = ng_ld(v_prev, ec), z4 = ng_ld(z_prev, ec), x4 = ng_ld(aux_prev, ec);
+    const float4 vo4 = v_out[ec], v4 = ng_ld(v_prev, v_out, ec), z4 = ng_ld(z_prev, v_out, ec), x4 = ng_ld(aux_prev, v_out, ec);
     const float4 ao4 = (KIND != EVF_LIF) ? aux_out[ec] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float Pv = (KIND == EVF_PLIF || KIND == EVF_XLIF) ? P[pix] : 0.f;
     const float gvo[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, gz[4] = {gz4.x, gz4.y, gz4.z, gz4.w};
