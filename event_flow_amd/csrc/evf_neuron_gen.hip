@@ -403,64 +403,106 @@ __device__ __forceinline__ void up2_src(int o, int n, int& i0, int& i1, float& w
   w1 = s - (float)i0;
 }
 
-// one thread = one channel of one pixel (any C); the 4 / 16 taps of neighbouring threads hit the same lines
-__global__ void k_up2_fwd(const float* __restrict__ x, int B, int H, int W, int C, float* __restrict__ y) {
+// one thread = V consecutive channels of one pixel (V = 4 / 2 / 1 by divisibility of C: the decoder inputs of the
+// EV-FlowNet have 2C+2 channels); all taps are loaded unconditionally (border taps carry weight 0)
+template <int V>
+struct UpVec;
+template <>
+struct UpVec<4> { typedef float4 T; };
+template <>
+struct UpVec<2> { typedef float2 T; };
+template <>
+struct UpVec<1> { typedef float T; };
+__device__ __forceinline__ float4 up_fma(float w, float4 a, float4 acc) { return make_float4(acc.x + w * a.x, acc.y + w * a.y, acc.z + w * a.z, acc.w + w * a.w); }
+__device__ __forceinline__ float2 up_fma(float w, float2 a, float2 acc) { return make_float2(acc.x + w * a.x, acc.y + w * a.y); }
+__device__ __forceinline__ float up_fma(float w, float a, float acc) { return acc + w * a; }
+__device__ __forceinline__ float4 up_mix(float wa, float4 a, float wb, float4 b) { return make_float4(wa * a.x + wb * b.x, wa * a.y + wb * b.y, wa * a.z + wb * b.z, wa * a.w + wb * b.w); }
+__device__ __forceinline__ float2 up_mix(float wa, float2 a, float wb, float2 b) { return make_float2(wa * a.x + wb * b.x, wa * a.y + wb * b.y); }
+__device__ __forceinline__ float up_mix(float wa, float a, float wb, float b) { return wa * a + wb * b; }
+
+template <int V>
+__global__ void k_up2_fwd(const typename UpVec<V>::T* __restrict__ x, int B, int H, int W, int Q,
+                          typename UpVec<V>::T* __restrict__ y) {
+  typedef typename UpVec<V>::T T;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int OH = 2 * H, OW = 2 * W;
-  if (idx >= (long)B * OH * OW * C) return;
-  const int q = (int)(idx % C);
-  const long pix = idx / C;
+  if (idx >= (long)B * OH * OW * Q) return;
+  const int q = (int)(idx % Q);
+  const long pix = idx / Q;
   const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((long)OW * OH));
   int y0, y1, x0, x1;
   float wy, wx;
   up2_src(oy, H, y0, y1, wy);
   up2_src(ox, W, x0, x1, wx);
-  const float a = x[(((long)b * H + y0) * W + x0) * C + q], bq = x[(((long)b * H + y0) * W + x1) * C + q];
-  const float c = x[(((long)b * H + y1) * W + x0) * C + q], d = x[(((long)b * H + y1) * W + x1) * C + q];
+  const T a = x[(((long)b * H + y0) * W + x0) * Q + q], bq = x[(((long)b * H + y0) * W + x1) * Q + q];
+  const T c = x[(((long)b * H + y1) * W + x0) * Q + q], d = x[(((long)b * H + y1) * W + x1) * Q + q];
   // same association as ATen's upsample_bilinear2d: h0 (w0 a + w1 b) + h1 (w0 c + w1 d)
-  y[idx] = (1.f - wy) * ((1.f - wx) * a + wx * bq) + wy * ((1.f - wx) * c + wx * d);
+  y[idx] = up_mix(1.f - wy, up_mix(1.f - wx, a, wx, bq), wy, up_mix(1.f - wx, c, wx, d));
 }
 
-// gather form of the transpose: input pixel iy receives from output rows 2iy-1 .. 2iy+2
-__global__ void k_up2_bwd(const float* __restrict__ gy, int B, int H, int W, int C, float* __restrict__ gx) {
+// gather form of the transpose: input pixel iy receives from output rows 2iy-1 .. 2iy+2 (clamped addresses, the
+// weight is 0 where the output pixel does not read this input pixel: no branch around the loads)
+template <int V>
+__global__ void k_up2_bwd(const typename UpVec<V>::T* __restrict__ gy, int B, int H, int W, int Q,
+                          typename UpVec<V>::T* __restrict__ gx) {
+  typedef typename UpVec<V>::T T;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)B * H * W * C) return;
+  if (idx >= (long)B * H * W * Q) return;
   const int OH = 2 * H, OW = 2 * W;
-  const int q = (int)(idx % C);
-  const long pix = idx / C;
+  const int q = (int)(idx % Q);
+  const long pix = idx / Q;
   const int ix = (int)(pix % W), iy = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
-  float acc = 0.f;
-  for (int oy = 2 * iy - 1; oy <= 2 * iy + 2; ++oy) {
-    if (oy < 0 || oy >= OH) continue;
-    int y0, y1;
-    float wy;
-    up2_src(oy, H, y0, y1, wy);
-    const float cy = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);
-    if (cy == 0.f) continue;
-    for (int ox = 2 * ix - 1; ox <= 2 * ix + 2; ++ox) {
-      if (ox < 0 || ox >= OW) continue;
-      int x0, x1;
-      float wx;
-      up2_src(ox, W, x0, x1, wx);
-      const float cx = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
-      if (cx == 0.f) continue;
-      acc += (cy * cx) * gy[(((long)b * OH + oy) * OW + ox) * C + q];
-    }
+  float cy[4], cx[4];
+  int oyc[4], oxc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int oy = 2 * iy - 1 + k, ox = 2 * ix - 1 + k;
+    int a0, a1;
+    float w;
+    oyc[k] = min(max(oy, 0), OH - 1);
+    up2_src(oyc[k], H, a0, a1, w);
+    cy[k] = (oy >= 0 && oy < OH) ? ((a0 == iy ? 1.f - w : 0.f) + (a1 == iy ? w : 0.f)) : 0.f;
+    oxc[k] = min(max(ox, 0), OW - 1);
+    up2_src(oxc[k], W, a0, a1, w);
+    cx[k] = (ox >= 0 && ox < OW) ? ((a0 == ix ? 1.f - w : 0.f) + (a1 == ix ? w : 0.f)) : 0.f;
   }
+  T acc = T();
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc = up_fma(cy[j] * cx[k], gy[(((long)b * OH + oyc[j]) * OW + oxc[k]) * Q + q], acc);
   gx[idx] = acc;
 }
 
 extern "C" int evf_upsample2x_fwd(const float* x, int B, int H, int W, int C, float* y, void* stream) {
   if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return EVF_EINVAL;
-  const long total = (long)B * 4 * H * W * C;
-  hipLaunchKernelGGL(k_up2_fwd, dim3(evf_cdiv(total, 256)), dim3(256), 0, EVF_STREAM(stream), x, B, H, W, C, y);
+  const bool a16 = (((uintptr_t)x | (uintptr_t)y) & 15) == 0, a8 = (((uintptr_t)x | (uintptr_t)y) & 7) == 0;
+  const int V = (C % 4 == 0 && a16) ? 4 : ((C % 2 == 0 && a8) ? 2 : 1);
+  const long total = (long)B * 4 * H * W * (C / V);
+  dim3 grid(evf_cdiv(total, 256)), block(256);
+  hipStream_t st = EVF_STREAM(stream);
+  if (V == 4)
+    hipLaunchKernelGGL(k_up2_fwd<4>, grid, block, 0, st, (const float4*)x, B, H, W, C / 4, (float4*)y);
+  else if (V == 2)
+    hipLaunchKernelGGL(k_up2_fwd<2>, grid, block, 0, st, (const float2*)x, B, H, W, C / 2, (float2*)y);
+  else
+    hipLaunchKernelGGL(k_up2_fwd<1>, grid, block, 0, st, x, B, H, W, C, y);
   return evf_status();
 }
 
 extern "C" int evf_upsample2x_bwd(const float* g_y, int B, int H, int W, int C, float* g_x, void* stream) {
   if (!g_y || !g_x || B <= 0 || H <= 0 || W <= 0 || C <= 0) return EVF_EINVAL;
-  const long total = (long)B * H * W * C;
-  hipLaunchKernelGGL(k_up2_bwd, dim3(evf_cdiv(total, 256)), dim3(256), 0, EVF_STREAM(stream), g_y, B, H, W, C, g_x);
+  const bool a16 = (((uintptr_t)g_y | (uintptr_t)g_x) & 15) == 0, a8 = (((uintptr_t)g_y | (uintptr_t)g_x) & 7) == 0;
+  const int V = (C % 4 == 0 && a16) ? 4 : ((C % 2 == 0 && a8) ? 2 : 1);
+  const long total = (long)B * H * W * (C / V);
+  dim3 grid(evf_cdiv(total, 256)), block(256);
+  hipStream_t st = EVF_STREAM(stream);
+  if (V == 4)
+    hipLaunchKernelGGL(k_up2_bwd<4>, grid, block, 0, st, (const float4*)g_y, B, H, W, C / 4, (float4*)g_x);
+  else if (V == 2)
+    hipLaunchKernelGGL(k_up2_bwd<2>, grid, block, 0, st, (const float2*)g_y, B, H, W, C / 2, (float2*)g_x);
+  else
+    hipLaunchKernelGGL(k_up2_bwd<1>, grid, block, 0, st, g_y, B, H, W, C, g_x);
   return evf_status();
 }
 
