@@ -72,7 +72,8 @@ __global__ void k_pack_conv2d(const float* __restrict__ w, int Cout, int Cin, in
     float x = 0.f;
     if (k < K && n < N) {
       const int co = transpose ? k : n, ci = transpose ? n : k;
-      x = w[((long)co * cin_total + cin_off + ci) * T + tap];
+      // input channels past the weight's own (cin_off + ci >= cin_total) are alignment padding of the activation: zero
+      if (cin_off + ci < cin_total) x = w[((long)co * cin_total + cin_off + ci) * T + tap];
     }
     v[j] = x;
   }
@@ -92,8 +93,7 @@ extern "C" int64_t evf_conv2d_packed_size(int Cout, int Cin, int ksz, int transp
 
 extern "C" int evf_pack_conv2d_weight(const float* w, int Cout, int Cin, int ksz, int transpose, int cin_total, int cin_off,
                                       float* dst, void* stream) {
-  if (!w || !dst || Cout <= 0 || Cin <= 0 || (ksz != 1 && ksz != 3) || cin_off < 0 || cin_off + Cin > cin_total)
-    return EVF_EINVAL;
+  if (!w || !dst || Cout <= 0 || Cin <= 0 || (ksz != 1 && ksz != 3) || cin_off < 0 || cin_off >= cin_total) return EVF_EINVAL;
   const long total = cg_packed_float4(Cout, Cin, ksz, transpose);
   hipLaunchKernelGGL(k_pack_conv2d, dim3(evf_cdiv(total, 256)), dim3(256), 0, EVF_STREAM(stream), w, Cout, Cin, ksz * ksz,
                      transpose, total, cin_total, cin_off, (float4*)dst);

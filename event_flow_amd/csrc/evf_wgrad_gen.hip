@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad_f32(const float* __restric
 #pragma unroll
     for (int w4 = 0; w4 < 4; ++w4) v += red[(w4 * CT * NT + sub) * 1024 + (e & 1023)];
     const int ci = ci0 + c * 32 + ci_l, co = co0 + t * 32 + co_l;
-    if (ci < g.Cin && co < g.Cout) evf_atomic_add(gw + ((long)co * g.cin_total + g.cin_off + ci) * T + tap, v);
+    if (ci < g.Cin && co < g.Cout && g.cin_off + ci < g.cin_total)
+      evf_atomic_add(gw + ((long)co * g.cin_total + g.cin_off + ci) * T + tap, v);
   }
   if (do_bias) {
 #pragma unroll
@@ -440,6 +441,7 @@ __global__ void k_wgrad_reduce(const float* __restrict__ slab, int nsplit, int C
   const int co = (int)(e % Cout), ci = (int)((e / Cout) % Cin), tap = (int)(e / ((long)Cout * Cin));
   float s = 0.f;
   for (int k = 0; k < nsplit; ++k) s += slab[k * per + e];
+  if (cin_off + ci >= cin_total) return;  // alignment-padding channel of the activation: no weight behind it
   float* d = gw + ((long)co * cin_total + cin_off + ci) * 9 + tap;
   *d = accumulate ? *d + s : s;
 }
@@ -464,10 +466,9 @@ static Wg9Plan wg9_plan(int B, int H, int W, int Cin, int Cout, int stride, int 
   g.n_ct = evf_cdiv(Cin, 32 * p.CT);
   p.n_nt = evf_cdiv(Cout, 32 * p.NT);
   const long wt = (long)g.n_ct * p.n_nt;
-  // one resident block per CU (192 VGPRs x 8 waves): one round of 256 blocks, at least 4 pixel tiles per block
-  // (the slab traffic is 9*Cin*Cout per split)
-  // (measured: the float2 / scalar x-load variants, Cin % 4 != 0, run faster with two rounds of blocks)
-  long ns = evf_cdiv((Cin % 4 == 0) ? 256 : 512, wt);  // a function of the shapes only (evf_conv2d_wgrad_ws)
+  // one resident block per CU (192 VGPRs x 8 waves): at most 256 blocks = ONE round (a 257th block would run alone
+  // in a second round), at least 4 pixel tiles per block (the slab traffic is 9*Cin*Cout per split)
+  long ns = 256 / wt;  // floor: weight tiles x splits <= 256
   if (ns > g.ntiles / 4) ns = g.ntiles / 4;
   if (ns < 1) ns = 1;
   g.tiles_per_split = evf_cdiv(g.ntiles, ns);
@@ -513,8 +514,8 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
                                 int W, int Cin, int Cout, int ksz, int stride, int cin_total, int cin_off, int accumulate,
                                 float* ws, void* stream) {
   if (!x || !g_y || !g_w || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksz != 1 && ksz != 3) ||
-      (stride != 1 && stride != 2) || ldx < Cin || ldg < Cout || cin_off < 0 || cin_off + Cin > cin_total ||
-      (!accumulate && cin_total != Cin) || (ksz == 3 && !ws) || ((uintptr_t)g_y & 15))
+      (stride != 1 && stride != 2) || ldx < Cin || ldg < Cout || cin_off < 0 || cin_off >= cin_total ||
+      (!accumulate && (cin_off != 0 || Cin < cin_total)) || (ksz == 3 && !ws) || ((uintptr_t)g_y & 15))
     return EVF_EINVAL;
   hipStream_t st = EVF_STREAM(stream);
   if (!accumulate && g_bias) {
@@ -546,7 +547,7 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
     return evf_status();
   }
   if (!accumulate) {
-    const int rc = evf_hip(hipMemsetAsync(g_w, 0, sizeof(float) * (size_t)Cout * Cin, st));
+    const int rc = evf_hip(hipMemsetAsync(g_w, 0, sizeof(float) * (size_t)Cout * cin_total, st));
     if (rc) return rc;
   }
   WgGeo g;

@@ -190,8 +190,12 @@ class _CellStep(torch.autograd.Function):
             if not sp.is_contiguous():
                 sp = sp.contiguous()
         rn = to_nhwc(residual) if residual is not None else None
+        Cw = wff.shape[1]
+        if not 0 <= Cin - Cw < 4:
+            raise _lib.EvflowError(f"input has {Cin} channels, the cell expects {Cw}")
+        # (Cin - Cw trailing channels = zero padding that keeps 16-byte alignment; the packed weight is zero there)
         cur = _new((B, Ho, Wo, C), dev)
-        conv_fwd(xn, _wcache(cell, "ff").get(wff, 0), None, cur, Cin, C, k, s)
+        conv_fwd(xn, _wcache(cell, "ff").get(wff, 0, 0, Cin), None, cur, Cin, C, k, s)
         if cell.recurrent and sp is not None:
             conv_fwd(sp[1], _wcache(cell, "rec").get(wrec, 0), None, cur, C, C, k, 1, accumulate=1)
         P = None
@@ -244,7 +248,7 @@ class _CellStep(torch.autograd.Function):
         g_wff = g_wrec = g_x = None
         if need[4]:
             g_wff = _new(tuple(wff.shape), dev)
-            conv_wgrad(xn, g_cur, g_wff, None, Cin, C, k, s)
+            conv_wgrad(xn, g_cur, g_wff, None, Cin, C, k, s, cin_total=wff.shape[1])
         if cell.recurrent and need[5]:
             if sp is not None:
                 g_wrec = _new(tuple(wrec.shape), dev)
@@ -253,7 +257,7 @@ class _CellStep(torch.autograd.Function):
                 g_wrec = torch.zeros(tuple(wrec.shape), dtype=torch.float32, device=dev)
         if need[1]:
             g_xn = _new((B, H, W, Cin), dev)
-            conv_dgrad(g_cur, _wcache(cell, "ffT").get(wff, 1), g_xn, Cin, C, k, s)
+            conv_dgrad(g_cur, _wcache(cell, "ffT").get(wff, 1, 0, Cin), g_xn, Cin, C, k, s)
             if g_P is not None:
                 _lib.call("evf_pretrace_bwd", _lib.ptr(xn), xn.stride(2), _lib.ptr(g_P), B, H, W, Cin, k, s, _lib.ptr(g_xn),
                           Cin, 1)

@@ -8,6 +8,7 @@ so its state_dicts load.  Every block runs in libevflow_hip.so through the
 general path (models/hip_ops.py); torch.cat / pad are the only torch calls
 (memory movement)."""
 
+import torch
 import torch.nn as nn
 
 from .model_util import skip_concat, skip_sum  # noqa: F401  (resolved by name, reference unet.py:77)
@@ -115,6 +116,11 @@ class SpikingMultiResUNetRecurrent(nn.Module):
             x = self.skip_ftn(x, blocks[self.num_encoders - i - 1])
             if i > 0:
                 x = self.skip_ftn(predictions[-1], x)
+                pad = (-x.shape[1]) % 4
+                if pad and self.skip_type == "concat" and decoder.conv2d.kind in ("lif", "alif"):
+                    # 2C+2 channels: two zero channels keep the activation 16-byte aligned for the conv kernels (the
+                    # packed weight is zero there; cells with a pre-synaptic trace average over the true channels)
+                    x = torch.cat([x, x.new_zeros((x.shape[0], pad) + tuple(x.shape[2:]))], 1)
             x, self.states[offset + i] = decoder(x, self.states[offset + i])
             predictions.append(pred(x))
         return predictions

@@ -313,7 +313,8 @@ int evf_masked_flow_mean(const float* maps, const float* masks, int B, int P, in
 
 /* Packed-weight size in floats for evf_pack_conv2d_weight (0 on bad arguments). */
 int64_t evf_conv2d_packed_size(int Cout, int Cin, int ksz, int transpose);
-/* w: torch layout [Cout][cin_total][k][k]; packs input channels cin_off..cin_off+Cin.
+/* w: torch layout [Cout][cin_total][k][k]; packs input channels cin_off..cin_off+Cin (channels past cin_total
+ * are zero: alignment padding of the activation tensor).
  * transpose = 0 -> operand of evf_conv2d_fwd, 1 -> operand of evf_conv2d_dgrad. */
 int evf_pack_conv2d_weight(const float* w, int Cout, int Cin, int ksz, int transpose, int cin_total,
                            int cin_off, float* dst, void* stream);
@@ -325,8 +326,8 @@ int evf_conv2d_fwd(const float* x, int ldx, const float* w_packed, const float* 
 int evf_conv2d_dgrad(const float* g_y, int ldg, const float* wT_packed, float* g_x, int ldx, int B, int H,
                      int W, int Cin, int Cout, int ksz, int stride, int accumulate, void* stream);
 /* g_w [Cout][cin_total][k][k] (input channels cin_off ..) and optional g_bias [Cout]
- * (autograd w.r.t. weight / bias).  accumulate = 0 overwrites the outputs and needs
- * cin_total == Cin.  ws: scratch of evf_conv2d_wgrad_ws() floats (3x3; may be null for 1x1):
+ * (autograd w.r.t. weight / bias).  accumulate = 0 overwrites the outputs and needs cin_off = 0 and
+ * Cin >= cin_total (channels past cin_total are activation padding and are skipped).  ws: scratch of evf_conv2d_wgrad_ws() floats (3x3; may be null for 1x1):
  * partial sums of the pixel splits, reduced without atomics. */
 int64_t evf_conv2d_wgrad_ws(int B, int H, int W, int Cin, int Cout, int ksz, int stride);
 int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int ldg, float* g_w, float* g_bias, int B,
