@@ -29,7 +29,7 @@ struct WgGeo {
   int stages;  // 32-pixel stages per K split
 };
 
-template <int CT, int NT, int VEC>
+template <int CT, int NT, int VEC, int VG>
 __global__ __launch_bounds__(256) void k_conv2d_wgrad_f32(const float* __restrict__ x, const float* __restrict__ gy,
                                                           float* __restrict__ gw, float* __restrict__ gbias, WgGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad_f32(const float* __restric
       const float* p = gy + (mok ? m : M - 1) * g.ldg;
       const int c = co0 + 4 * q;
       float4 v;
-      if (VEC == 4) {
+      if (VG == 4) {
         const bool cv = c + 4 <= g.Cout;
         v = *(const float4*)(p + (cv ? c : 0));
         if (!(mok && cv)) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -201,12 +201,118 @@ static void wg_launch(const float* x, const float* gy, float* gw, float* gbias, 
   dim3 grid(ksplit, n_ct * n_nt, g.ksz * g.ksz), block(256);
   const size_t stage = 2 * 32 * (32 * CT + 32 * NT) * sizeof(float), red = 4 * CT * NT * 1024 * sizeof(float);
   const size_t smem = stage > red ? stage : red;
-  if (vec4)
-    hipLaunchKernelGGL((k_conv2d_wgrad_f32<CT, NT, 4>), grid, block, smem, st, x, gy, gw, gbias, g);
+  const bool vx = g.Cin % 4 == 0 && g.ldx % 4 == 0 && ((uintptr_t)x & 15) == 0;
+  const bool vg = g.Cout % 4 == 0 && g.ldg % 4 == 0 && ((uintptr_t)gy & 15) == 0;
+  (void)vec4;
+  if (vx && vg)
+    hipLaunchKernelGGL((k_conv2d_wgrad_f32<CT, NT, 4, 4>), grid, block, smem, st, x, gy, gw, gbias, g);
+  else if (vx)  // e.g. the 32 -> 2 prediction heads
+    hipLaunchKernelGGL((k_conv2d_wgrad_f32<CT, NT, 4, 1>), grid, block, smem, st, x, gy, gw, gbias, g);
+  else if (vg)
+    hipLaunchKernelGGL((k_conv2d_wgrad_f32<CT, NT, 1, 4>), grid, block, smem, st, x, gy, gw, gbias, g);
   else
-    hipLaunchKernelGGL((k_conv2d_wgrad_f32<CT, NT, 1>), grid, block, smem, st, x, gy, gw, gbias, g);
+    hipLaunchKernelGGL((k_conv2d_wgrad_f32<CT, NT, 1, 1>), grid, block, smem, st, x, gy, gw, gbias, g);
 }
 
+
+// ---------------------------------------------------------------------------
+// 1x1 with a handful of output channels (the 32 -> 2 flow prediction heads):
+// a streaming reduction, not a matrix product.  Each thread owns one 4-channel
+// group of x for every PPB-th pixel of its block's pixel range and keeps
+// COUT x 4 sums in registers; blocks write partials to the workspace and
+// k_wgrad1_reduce sums them (no same-address atomics: 1024 blocks hammering 64
+// addresses was what bound the matrix-core version of this layer).
+// ---------------------------------------------------------------------------
+constexpr int WG1_BLOCKS = 512;
+
+template <int COUT>
+__global__ __launch_bounds__(256) void k_wgrad1_small(const float* __restrict__ x, const float* __restrict__ gy,
+                                                      float* __restrict__ part, long M, int Cin, int ldx, int ldg,
+                                                      int px_per_block) {
+  __shared__ float red[256 * (COUT * 4 + 1)];
+  const int tid = threadIdx.x, Q = Cin >> 2, q = tid % Q, pp = tid / Q, PPB = 256 / Q;
+  const long m0 = (long)blockIdx.x * px_per_block;
+  const long m1 = m0 + px_per_block < M ? m0 + px_per_block : M;
+  float acc[COUT][4];
+  float bs[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) {
+    bs[c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[c][j] = 0.f;
+  }
+  constexpr int U = 4;
+  for (long mb = m0 + pp; mb < m1; mb += (long)U * PPB) {
+    float4 xv[U];
+    float gv[U][COUT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // clamped addresses + select: no load sits under a branch
+      const long m = mb + (long)u * PPB;
+      const long mc = m < m1 ? m : M - 1;
+      xv[u] = *(const float4*)(x + mc * ldx + 4 * q);
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) gv[u][c] = gy[mc * ldg + c];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = mb + (long)u * PPB < m1;
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) {
+        const float gg = ok ? gv[u][c] : 0.f;
+        bs[c] += gg;
+        acc[c][0] += gg * xv[u].x, acc[c][1] += gg * xv[u].y, acc[c][2] += gg * xv[u].z, acc[c][3] += gg * xv[u].w;
+      }
+    }
+  }
+  constexpr int RW = COUT * 4 + 1;  // odd row stride: conflict-free column reads
+#pragma unroll
+  for (int c = 0; c < COUT; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[tid * RW + c * 4 + j] = acc[c][j];
+  __syncthreads();
+  float* out = part + (long)blockIdx.x * (COUT * Cin + COUT);
+  for (int e = tid; e < COUT * Cin; e += 256) {
+    const int co = e / Cin, ci = e - co * Cin, qq = ci >> 2, j = ci & 3;
+    float v = 0.f;
+    for (int k = 0; k < PPB; ++k) v += red[(k * Q + qq) * RW + co * 4 + j];
+    out[e] = v;
+  }
+  __syncthreads();
+  if (q == 0)
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) red[pp * COUT + c] = bs[c];
+  __syncthreads();
+  if (tid < COUT) {
+    float v = 0.f;
+    for (int k = 0; k < PPB; ++k) v += red[k * COUT + tid];
+    out[COUT * Cin + tid] = v;
+  }
+}
+
+// gw[co][cin_off + ci] (+)= sum_blocks part[blk][co*Cin + ci];  gbias[co] += sum_blocks part[blk][Cout*Cin + co]
+__global__ void k_wgrad1_reduce(const float* __restrict__ part, int nblk, int Cin, int Cout, int cin_total, int cin_off,
+                                int accumulate, float* __restrict__ gw, float* __restrict__ gbias) {
+  const int per = Cout * Cin + Cout, e = blockIdx.x, lane = threadIdx.x;  // one wave per output element
+  float s = 0.f;
+  for (int k = lane; k < nblk; k += 64) s += part[(long)k * per + e];
+#pragma unroll
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane) return;
+  if (e >= Cout * Cin) {
+    if (gbias) gbias[e - Cout * Cin] += s;  // zeroed by the caller when not accumulating
+    return;
+  }
+  const int co = e / Cin, ci = e - co * Cin;
+  if (cin_off + ci >= cin_total) return;
+  float* d = gw + (long)co * cin_total + cin_off + ci;
+  *d = accumulate ? *d + s : s;
+}
+
+static inline bool wg1_small_ok(int Cin, int Cout, int ksz, int stride, int ldx, const void* x) {
+  const int Q = Cin >> 2;
+  return ksz == 1 && stride == 1 && Cout <= 4 && Cin % 4 == 0 && ldx % 4 == 0 && Q >= 1 && Q <= 256 && 256 % Q == 0 &&
+         ((uintptr_t)x & 15) == 0;
+}
 
 // ---------------------------------------------------------------------------
 // 3x3: tap-per-wave
@@ -476,9 +582,11 @@ static Wg9Plan wg9_plan(int B, int H, int W, int Cin, int Cout, int stride, int 
   return p;
 }
 
-// workspace (floats) evf_conv2d_wgrad needs for this geometry (0 for 1x1)
+// workspace (floats) evf_conv2d_wgrad needs for this geometry (1x1: only the few-output-channel streaming kernel uses one)
 extern "C" int64_t evf_conv2d_wgrad_ws(int B, int H, int W, int Cin, int Cout, int ksz, int stride) {
-  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksz != 3 || (stride != 1 && stride != 2)) return 0;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (stride != 1 && stride != 2)) return 0;
+  if (ksz == 1) return wg1_small_ok(Cin, Cout, ksz, stride, Cin, nullptr) ? (int64_t)WG1_BLOCKS * (Cout * Cin + Cout) : 0;
+  if (ksz != 3) return 0;
   const Wg9Plan p = wg9_plan(B, H, W, Cin, Cout, stride, Cin, Cout);
   return (int64_t)p.nsplit * 9 * Cin * Cout;
 }
@@ -544,6 +652,27 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
     const long per = (long)9 * Cin * Cout;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(evf_cdiv(per, 256)), dim3(256), 0, st, ws, p.nsplit, Cin, Cout, cin_total,
                        cin_off, accumulate, g_w);
+    return evf_status();
+  }
+  if (ws && wg1_small_ok(Cin, Cout, ksz, stride, ldx, x)) {
+    const long M = (long)B * H * W;
+    const int ppb = (int)evf_cdiv(M, WG1_BLOCKS);
+    const int nblk = (int)evf_cdiv(M, ppb);
+#define WG1(C_)                                                                                                     \
+  case C_:                                                                                                          \
+    hipLaunchKernelGGL(k_wgrad1_small<C_>, dim3(nblk), dim3(256), 0, st, x, g_y, ws, M, Cin, ldx, ldg, ppb);        \
+    break
+    switch (Cout) {
+      WG1(1);
+      WG1(2);
+      WG1(3);
+      WG1(4);
+    }
+#undef WG1
+    int rc = evf_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_wgrad1_reduce, dim3(Cout * Cin + Cout), dim3(64), 0, st, ws, nblk, Cin, Cout, cin_total, cin_off,
+                       accumulate, g_w, g_bias);
     return evf_status();
   }
   if (!accumulate) {

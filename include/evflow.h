@@ -327,7 +327,7 @@ int evf_conv2d_dgrad(const float* g_y, int ldg, const float* wT_packed, float* g
                      int W, int Cin, int Cout, int ksz, int stride, int accumulate, void* stream);
 /* g_w [Cout][cin_total][k][k] (input channels cin_off ..) and optional g_bias [Cout]
  * (autograd w.r.t. weight / bias).  accumulate = 0 overwrites the outputs and needs cin_off = 0 and
- * Cin >= cin_total (channels past cin_total are activation padding and are skipped).  ws: scratch of evf_conv2d_wgrad_ws() floats (3x3; may be null for 1x1):
+ * Cin >= cin_total (channels past cin_total are activation padding and are skipped).  ws: scratch of evf_conv2d_wgrad_ws() floats (3x3, and 1x1 with Cout <= 4; null is accepted for 1x1 and selects the atomic split-K kernel):
  * partial sums of the pixel splits, reduced without atomics. */
 int64_t evf_conv2d_wgrad_ws(int B, int H, int W, int Cin, int Cout, int ksz, int stride);
 int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int ldg, float* g_w, float* g_bias, int B,

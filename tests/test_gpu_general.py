@@ -49,6 +49,12 @@ CONV_CASES = [
     (1, 130, 32, 20, 24, 3, 1),
     (2, 64, 128, 16, 16, 3, 2),
     (1, 32, 2, 17, 33, 1, 1),
+    (2, 32, 2, 64, 96, 1, 1),  # streaming few-output 1x1 wgrad, several pixels per block
+    (1, 64, 3, 9, 31, 1, 1),
+    (3, 128, 4, 7, 5, 1, 1),
+    (1, 8, 1, 40, 40, 1, 1),
+    (1, 32, 5, 17, 33, 1, 1),  # matrix-core 1x1 wgrad with scalar g loads
+    (1, 30, 2, 17, 33, 1, 1),
     (1, 256, 96, 5, 6, 3, 1),
     (3, 5, 7, 11, 13, 3, 2),
     (1, 8, 8, 13, 9, 3, 2),
