@@ -70,14 +70,51 @@ def make_windows(rank, n_pool, dev):
     return pool
 
 
-def run_step(model, lossf, opt, dp, lists):
+def _encode(lists):
     from event_flow_amd.dataloader.encodings import encode_event_list
-    from event_flow_amd.train import train_window
 
     passes = [encode_event_list(ev, 2, (H, W), want=("cnt", "mask", "pol")) for ev in lists]
     for d in passes:
         d["event_voxel"] = None  # encoding = cnt
-    return train_window(model, lossf, opt, passes, dp=dp)
+    return passes
+
+
+def run_step(model, lossf, opt, dp, lists):
+    from event_flow_amd.train import train_window
+
+    return train_window(model, lossf, opt, _encode(lists), dp=dp)
+
+
+class StepGraph:
+    """One training step of one input window as hipGraph replays.  On one GPU the whole step
+    is a single graph.  With several ranks the step is two graphs -- (binning, passes, loss,
+    backward, loss staged into the flat buffer) and (clip+Adam, detach, reset) -- with the
+    step's ONE RCCL all-reduce launched eagerly between them on the same stream: the
+    collective stays outside the captures, so a rank can never replay a different
+    collective sequence than its peers."""
+
+    def __init__(self, model, lossf, opt, dp, lists, stream):
+        from event_flow_amd.train import window_apply, window_backward
+
+        self.dp, self.comm = dp, opt.comm
+        if dp.world == 1:
+            self.pre = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.pre, stream=stream):
+                self.loss = run_step(model, lossf, opt, dp, lists)
+            self.post = None
+            return
+        self.pre, self.post = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.pre, stream=stream):
+            local = window_backward(model, lossf, opt, _encode(lists), dp)
+        with torch.cuda.graph(self.post, stream=stream):
+            self.loss = window_apply(model, lossf, opt, local, dp)
+
+    def replay(self):
+        self.pre.replay()
+        if self.post is not None:
+            self.dp.reduce(self.comm)
+            self.post.replay()
+        return self.loss
 
 
 def iwe_warp_bandwidth(dev, B, reps=20):
@@ -207,6 +244,8 @@ def main():
 
     _lib.load()  # fails loudly when the HIP library is missing
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("EVF_BENCH_SINGLE_DEVICE"):  # test hook: several ranks share one GPU (with EVF_DP_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     dp = DataParallel(device=dev)
@@ -242,21 +281,19 @@ def main():
     if use_graph:
         try:
             torch.cuda.synchronize()
-            graphs = []
-            for lists in pool:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
-                    out = run_step(model, lossf, opt, dp, lists)
-                graphs.append((g, out))
+            graphs = [StepGraph(model, lossf, opt, dp, lists, side) for lists in pool]
+        except Exception as e:  # capture unsupported in this environment: eager launches
+            print(f"[bench] rank {dp.rank}: hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            graphs = None
+        torch.cuda.synchronize()
+        # all ranks must issue the same collective sequence: graphs on every rank or on none
+        if dp.world > 1 and dp.max_over_ranks(0.0 if graphs is not None else 1.0) != 0.0:
+            graphs = None
+        if graphs is not None:
             for i in range(2):  # replay warm-up
-                graphs[i % len(graphs)][0].replay()
+                graphs[i % len(graphs)].replay()
             torch.cuda.synchronize()
             mode = "hipgraph"
-        except Exception as e:  # capture unsupported in this environment: eager launches
-            if dp.rank == 0:
-                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
-            graphs = None
-            torch.cuda.synchronize()
 
     dp.barrier()
     torch.cuda.synchronize()
@@ -266,8 +303,7 @@ def main():
     loss = None
     for i in range(args.steps):
         if graphs is not None:
-            g, loss = graphs[i % len(graphs)]
-            g.replay()
+            loss = graphs[i % len(graphs)].replay()
         else:
             loss = run_step(model, lossf, opt, dp, pool[i % len(pool)])
     torch.cuda.synchronize()

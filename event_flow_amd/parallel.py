@@ -28,6 +28,8 @@ class DataParallel:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = device
         if backend is None:
+            backend = os.environ.get("EVF_DP_BACKEND")  # test hook: gloo with GPU tensors on a one-GPU box
+        if backend is None:
             backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
         self.backend = backend
         if init and self.world > 1 and not dist.is_initialized():
@@ -47,19 +49,32 @@ class DataParallel:
         return self.rank * per, (self.rank + 1) * per
 
     # -- the one collective of a step ---------------------------------------
-    def all_reduce_grads(self, comm, loss=None, new_seq=False):
-        """comm: flat fp32 buffer [n + TAIL]; comm[:n] holds this rank's gradient.
-        Writes loss / flag into the tail, SUM all-reduces the whole buffer in
-        place, returns (global loss, any_new_seq)."""
+    def stage(self, comm, loss=None, new_seq=False):
+        """Write this rank's loss / new-sequence flag into the tail of the flat buffer
+        (device-side only; safe inside a hipGraph capture)."""
         n = comm.numel() - self.TAIL
         if loss is not None:
             comm[n : n + 1].copy_(loss.detach().reshape(1))
         else:
             comm[n : n + 1].zero_()
         comm[n + 1 : n + 2].fill_(1.0 if new_seq else 0.0)
+
+    def reduce(self, comm):
+        """THE collective of a step: in-place SUM all-reduce of gradient + tail."""
         if self.world > 1:
             dist.all_reduce(comm, op=dist.ReduceOp.SUM)
+
+    def staged(self, comm):
+        n = comm.numel() - self.TAIL
         return comm[n], comm[n + 1]
+
+    def all_reduce_grads(self, comm, loss=None, new_seq=False):
+        """comm: flat fp32 buffer [n + TAIL]; comm[:n] holds this rank's gradient.
+        Writes loss / flag into the tail, SUM all-reduces the whole buffer in
+        place, returns (global loss, any_new_seq)."""
+        self.stage(comm, loss, new_seq)
+        self.reduce(comm)
+        return self.staged(comm)
 
     def barrier(self):
         if self.world > 1:

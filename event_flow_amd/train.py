@@ -73,11 +73,10 @@ class FlatAdam:
         return float(self.norm_ws[0].sqrt())
 
 
-def train_window(model, loss_function, optimizer, passes, dp=None):
-    """One truncated-BPTT window = one optimizer step (train_flow.py:129-171).
-    `passes`: list of dicts with event_cnt, event_voxel, event_list,
-    event_list_pol_mask, event_mask (GPU tensors).  Returns the 0-d loss tensor
-    (no host sync)."""
+def window_backward(model, loss_function, optimizer, passes, dp=None):
+    """First half of a window: the passes, the loss and its backward (train_flow.py:129-154).
+    Leaves this rank's gradient in the optimizer's flat buffer and, with `dp`, the
+    local loss in the buffer's tail, ready for the all-reduce."""
     for d in passes:
         x = model(d["event_voxel"], d["event_cnt"])
         loss_function.event_flow_association(x["flow"], d["event_list"], d["event_list_pol_mask"], d["event_mask"])
@@ -86,12 +85,32 @@ def train_window(model, loss_function, optimizer, passes, dp=None):
     loss = loss_function()
     loss.backward()
     if dp is not None:
-        loss, _ = dp.all_reduce_grads(optimizer.comm, loss)  # SUM over ranks (loss sums over the batch)
+        dp.stage(optimizer.comm, loss)
+    return loss
+
+
+def window_apply(model, loss_function, optimizer, loss, dp=None):
+    """Second half: clip + Adam on the (reduced) gradient, state detach, loss reset
+    (train_flow.py:157-171).  Returns the 0-d (global) loss tensor."""
+    if dp is not None:
+        loss, _ = dp.staged(optimizer.comm)
     optimizer.step()
     optimizer.zero_grad()
     model.detach_states()
     loss_function.reset()
     return loss.detach().clone()
+
+
+def train_window(model, loss_function, optimizer, passes, dp=None):
+    """One truncated-BPTT window = one optimizer step (train_flow.py:129-171).
+    `passes`: list of dicts with event_cnt, event_voxel, event_list,
+    event_list_pol_mask, event_mask (GPU tensors).  Returns the 0-d loss tensor
+    (no host sync).  With `dp` the flat gradient (+ loss) is SUM all-reduced over
+    the ranks between the two halves (the loss sums over the batch)."""
+    loss = window_backward(model, loss_function, optimizer, passes, dp)
+    if dp is not None:
+        dp.reduce(optimizer.comm)
+    return window_apply(model, loss_function, optimizer, loss, dp)
 
 
 def encode_passes(event_lists, num_bins, res):

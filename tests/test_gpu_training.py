@@ -39,3 +39,28 @@ def test_reference_shaped_drivers_run_end_to_end(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert {"FWL", "RSAT", "AEE", "iwe_variance"} <= set(res) and all(v == v for v in res.values() if isinstance(v, float))
+
+
+def _bench_two_ranks(extra, port, warmup=2):
+    """bench.py under torch.distributed.run with 2 ranks sharing the one GPU of the test box (gloo moves the
+    flat gradient buffer; on a multi-GPU node the same code path runs over RCCL)."""
+    env = dict(os.environ, EVF_DP_BACKEND="gloo", EVF_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", str(warmup),
+           "--no-cpu-baseline", "--no-iwe"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_bench_data_parallel_step_two_ranks_graph_equals_eager():
+    """The multi-rank step (two hipGraphs around one eager all-reduce) must give the loss of the eager
+    multi-rank step: same windows, same replicas, gradients summed over both ranks."""
+    g = _bench_two_ranks([], 29611)
+    e = _bench_two_ranks(["--no-graph"], 29612, warmup=4)  # graph mode adds 2 replay warm-up steps: same 7 updates
+    assert g["n_gpus"] == 2 and g["config"]["launch"] == "hipgraph" and g["config"]["parallelism"] == "dp2", g
+    assert e["config"]["launch"] == "eager", e
+    assert g["config"]["global_batch"] == 16, g
+    lg, le = g["config"]["loss"], e["config"]["loss"]
+    assert lg == lg and abs(lg - le) <= 2e-3 * abs(le), (lg, le)
