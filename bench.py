@@ -71,9 +71,9 @@ def make_windows(rank, n_pool, dev):
 
 
 def _encode(lists):
-    from event_flow_amd.dataloader.encodings import encode_event_list
+    from event_flow_amd.train import encode_passes
 
-    passes = [encode_event_list(ev, 2, (H, W), want=("cnt", "mask", "pol")) for ev in lists]
+    passes = encode_passes(lists, 2, (H, W), want=("cnt", "mask", "pol"))  # all 10 passes binned in one launch
     for d in passes:
         d["event_voxel"] = None  # encoding = cnt
     return passes
@@ -264,7 +264,7 @@ def main():
         model.use_static_states(True)  # recurrent state must live at fixed addresses across replays
     pool = make_windows(dp.rank, 2, dev)
     names = ["evf_conv_lif_fwd", "evf_conv_lif_fwd_b3", "evf_conv_dgrad", "evf_conv_dgrad_b3", "evf_conv_wgrad_bits", "evf_lif_bwd_wgrad",
-             "evf_lif_bwd", "evf_head_lif_bwd_wgrad", "evf_head_lif_fwd", "evf_head_wgrad", "evf_pred_bwd", "evf_reduce_slabs", "evf_cm_loss_fwd",
+             "evf_lif_bwd", "evf_head_lif_bwd_wgrad", "evf_head_lif_fwd", "evf_head_wgrad", "evf_pred_bwd", "evf_reduce_slabs", "evf_reduce_slabs_multi", "evf_cm_loss_fwd",
              "evf_cm_loss_bwd"]
 
     # Everything runs on one side stream: warm-up (eager), then one whole training step
@@ -281,7 +281,16 @@ def main():
     if use_graph:
         try:
             torch.cuda.synchronize()
-            graphs = [StepGraph(model, lossf, opt, dp, lists, side) for lists in pool]
+            # The recurrent state crosses replays without a copy: graph 0 starts from the buffers the warm-up
+            # left, graph k from the tensors graph k-1's last pass wrote (fixed addresses in its capture pool),
+            # and the last graph's last pass writes straight back into the first buffers.  Replays cycle 0,1,0,1...
+            home = model.state_buffers()
+            model.use_static_states(False)
+            graphs = []
+            for gi, lists in enumerate(pool):
+                if gi == len(pool) - 1:
+                    model.final_states_into(home)
+                graphs.append(StepGraph(model, lossf, opt, dp, lists, side))
         except Exception as e:  # capture unsupported in this environment: eager launches
             print(f"[bench] rank {dp.rank}: hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
             graphs = None

@@ -55,6 +55,54 @@ extern "C" int evf_pack_conv_weight_b3t(const float* w, int Cout, int Cin, void*
   return evf_status();
 }
 
+// All 32->32 conv weights of a network in ONE launch (the weights change every optimizer step, and a
+// launch is ~4 us of graph time whatever it does): blockIdx.y = tensor, blockIdx.z = 0 forward layout
+// (evf_pack_conv_weight_b3), 1 transposed/flipped layout for the input gradient (evf_pack_conv_weight_b3t).
+struct PackMulti {
+  const float* w[16];
+  uint4* fwd[16];
+  uint4* bwd[16];
+};
+__global__ void k_pack_conv_weight_b3_multi(PackMulti a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 18 * 64) return;
+  const float* __restrict__ w = a.w[blockIdx.y];
+  const bool tr = blockIdx.z != 0;
+  uint4* __restrict__ dst = tr ? a.bwd[blockIdx.y] : a.fwd[blockIdx.y];
+  if (!dst) return;
+  const int lane = idx & 63, tm = idx >> 6, m = tm & 1, tau = tm >> 1;
+  const int j = lane & 31, kg = lane >> 5;
+  uint32_t t[3][8];
+  for (int e = 0; e < 8; ++e) {
+    const int k = 16 * m + 8 * kg + e;
+    const float v = tr ? w[(k * C32 + j) * 9 + (8 - tau)] : w[(j * C32 + k) * 9 + tau];
+    const uint32_t hi = dg_bf16(v);
+    const float r1 = v - __uint_as_float(hi << 16);
+    const uint32_t mid = dg_bf16(r1);
+    const float r2 = r1 - __uint_as_float(mid << 16);
+    const uint32_t lo = dg_bf16(r2);
+    t[0][e] = hi, t[1][e] = mid, t[2][e] = lo;
+  }
+  for (int s = 0; s < 3; ++s)
+    dst[(tm * 3 + s) * 64 + lane] = make_uint4(t[s][0] | (t[s][1] << 16), t[s][2] | (t[s][3] << 16),
+                                               t[s][4] | (t[s][5] << 16), t[s][6] | (t[s][7] << 16));
+}
+
+extern "C" int evf_pack_conv_weights_b3_multi(const void* const* w, void* const* dst_b3, void* const* dst_b3t, int count,
+                                              void* stream) {
+  if (!w || count <= 0 || count > 16 || (!dst_b3 && !dst_b3t)) return EVF_EINVAL;
+  PackMulti a;
+  for (int i = 0; i < 16; ++i) {
+    a.w[i] = i < count ? (const float*)w[i] : nullptr;
+    a.fwd[i] = (i < count && dst_b3) ? (uint4*)dst_b3[i] : nullptr;
+    a.bwd[i] = (i < count && dst_b3t) ? (uint4*)dst_b3t[i] : nullptr;
+    if (i < count && !a.w[i]) return EVF_EINVAL;
+  }
+  hipLaunchKernelGGL(k_pack_conv_weight_b3_multi, dim3(evf_cdiv(18 * 64, 256), count, 2), dim3(256), 0, EVF_STREAM(stream),
+                     a);
+  return evf_status();
+}
+
 __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3(const uint4* __restrict__ gs, long plane_stride,
                                                                 const uint4* __restrict__ wt, float* __restrict__ gx,
                                                                 int accumulate, int B, int H, int W,

@@ -101,6 +101,45 @@ extern "C" int evf_reduce_slabs(const float* partial, int nslab, int n, int accu
   return evf_status();
 }
 
+// The slabs of all weight tensors of a network in one launch (blockIdx.z = tensor): 8 launches of 16 us
+// become one of about the same length.  Always accumulates into dst[t] (torch layout).
+struct RsMulti {
+  const float* src[16];
+  float* dst[16];
+};
+#define RSM_GROUPS 16
+__global__ void k_reduce_wgrad_multi(RsMulti a, int nslab) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // e = (tau*32 + ci)*32 + co
+  if (e >= 9 * C32 * C32) return;
+  const float* __restrict__ p = a.src[blockIdx.z] + e;
+  constexpr long N = 9 * C32 * C32;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = blockIdx.y;
+  for (; k + 3 * RSM_GROUPS < nslab; k += 4 * RSM_GROUPS) {  // four independent loads in flight
+    s0 += p[(long)k * N];
+    s1 += p[(long)(k + RSM_GROUPS) * N];
+    s2 += p[(long)(k + 2 * RSM_GROUPS) * N];
+    s3 += p[(long)(k + 3 * RSM_GROUPS) * N];
+  }
+  for (; k < nslab; k += RSM_GROUPS) s0 += p[(long)k * N];
+  const int co = e & 31, ci = (e >> 5) & 31, tau = e >> 10;
+  evf_atomic_add(a.dst[blockIdx.z] + (co * C32 + ci) * 9 + tau, (s0 + s1) + (s2 + s3));
+}
+
+extern "C" int evf_reduce_slabs_multi(const void* const* partial, void* const* dst, int count, int nslab, int n,
+                                      void* stream) {
+  if (!partial || !dst || count <= 0 || count > 16 || nslab <= 0 || n != 9 * C32 * C32) return EVF_EINVAL;
+  RsMulti a;
+  for (int i = 0; i < 16; ++i) {
+    a.src[i] = i < count ? (const float*)partial[i] : nullptr;
+    a.dst[i] = i < count ? (float*)dst[i] : nullptr;
+    if (i < count && (!a.src[i] || !a.dst[i])) return EVF_EINVAL;
+  }
+  hipLaunchKernelGGL(k_reduce_wgrad_multi, dim3(evf_cdiv(n, 256), RSM_GROUPS, count), dim3(256), 0, EVF_STREAM(stream), a,
+                     nslab);
+  return evf_status();
+}
+
 // --------------------------------------------------------------------------
 // forward: conv(s) + LIF update
 // --------------------------------------------------------------------------

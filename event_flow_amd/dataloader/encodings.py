@@ -83,6 +83,18 @@ def encode_event_list(event_list, num_bins, sensor_size, round_ts=False, want=("
     return out
 
 
+def encode_event_lists(event_lists, num_bins, sensor_size, round_ts=False, want=("cnt", "mask", "voxel", "pol")):
+    """encode_event_list for all passes of a window at once: the P lists [B,N,4] are binned as ONE batch of P*B
+    samples (one zero-fill + one kernel instead of P of each) and handed back as P dicts of views."""
+    lists = [_f32(e) for e in event_lists]
+    if len(lists) < 2 or any(e.shape != lists[0].shape for e in lists):
+        return [encode_event_list(e, num_bins, sensor_size, round_ts, want) for e in lists]
+    P = len(lists)
+    B, N, _ = lists[0].shape
+    full = encode_event_list(torch.stack(lists).view(P * B, N, 4), num_bins, sensor_size, round_ts, want)
+    return [{k: v.view(P, B, *v.shape[1:])[i] for k, v in full.items()} for i in range(P)]
+
+
 def binary_search_array(array, x, left=None, right=None, side="left"):
     """Index of x in a sorted array (host-side loader helper).  Reference:
     dataloader/encodings.py:9-27 -- including its quirk that `side` only

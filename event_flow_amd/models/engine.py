@@ -134,6 +134,8 @@ class FireNetEngine:
         self.small_size = off
         self._states = [None] * len(cells)
         self.static_states = False
+        self._final_target = None  # state tensors the last pass of the window writes into (model.final_states_into)
+        self._final_hint = False
         self._static = [None] * len(cells)
         self._win = None
         self._packed = {}
@@ -228,6 +230,7 @@ class FireNetEngine:
         key = tuple((p.data_ptr(), p._version) for p in self.params)
         if key == self._packed_key:
             return
+        b3_w, b3_f, b3_t = [], [], []
         for i, c in enumerate(self.cells):
             if i == 0:
                 continue
@@ -238,14 +241,17 @@ class FireNetEngine:
                     if k not in self._packed:
                         self._packed[k] = _f32((9 * C * C,), dev)
                     _lib.call("evf_pack_conv_weight", _lib.ptr(wd), C, C, tr, _lib.ptr(self._packed[k]))
-                k = (i, nm, "b3")
-                if k not in self._packed:
-                    self._packed[k] = torch.empty(54 * 1024, dtype=torch.uint8, device=dev)
-                _lib.call("evf_pack_conv_weight_b3", _lib.ptr(wd), C, C, _lib.ptr(self._packed[k]))
-                k = (i, nm, "b3t")
-                if k not in self._packed:
-                    self._packed[k] = torch.empty(54 * 1024, dtype=torch.uint8, device=dev)
-                _lib.call("evf_pack_conv_weight_b3t", _lib.ptr(wd), C, C, _lib.ptr(self._packed[k]))
+                for fmt in ("b3", "b3t"):
+                    k = (i, nm, fmt)
+                    if k not in self._packed:
+                        self._packed[k] = torch.empty(54 * 1024, dtype=torch.uint8, device=dev)
+                b3_w.append(wd)
+                b3_f.append(self._packed[(i, nm, "b3")])
+                b3_t.append(self._packed[(i, nm, "b3t")])
+        for lo in range(0, len(b3_w), 16):  # both split layouts of all conv weights: one launch per 16 tensors
+            n = min(16, len(b3_w) - lo)
+            arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts[lo:lo + n]])  # noqa: E731
+            _lib.call("evf_pack_conv_weights_b3_multi", arr(b3_w), arr(b3_f), arr(b3_t), n)
         self._flat = {}
         for name, p in zip(self.pnames, self.params):
             self._flat[name] = p.detach().float().contiguous().view(-1)
@@ -276,17 +282,33 @@ class FireNetEngine:
         layers = []
         new_states = []
         in_bits = in_bitsT = None
+        target = self._final_target if self._final_hint else None
+        self._final_hint = False
+        if target is not None:
+            self._final_target = None
+            live = {t.data_ptr() for st in states if st is not None for t in st if t is not None}
+            ok = len(target) == len(self.cells) and all(
+                tg is not None and tuple(tg[0].shape) == (B, H, W, C) and all(t.data_ptr() not in live for t in tg)
+                for tg in target)
+            if not ok:  # one-pass window starting from the target itself, or another geometry: fresh tensors
+                target = None
         for i, c in enumerate(self.cells):
             st = states[i]
             v_prev, z_prev, zT_prev = st[:3] if st is not None else (None, None, None)
             plif = self.kind == "plif"
             pt_prev = st[3] if (plif and st is not None) else None
-            pt_out = _f32((B, H, W, C), dev) if plif else None
+            if target is not None:
+                pt_out = target[i][3] if plif else None
+            else:
+                pt_out = _f32((B, H, W, C), dev) if plif else None
             P_out = _f32((B, H, W), dev) if plif else None
             if v_prev is not None and tuple(v_prev.shape) != (B, H, W, C):
                 raise _lib.EvflowError("state shape does not match the input; call reset_states()")
-            v_out, z_out = _f32((B, H, W, C), dev), _i32((B, H, W), dev)
-            zT_out = _i32((B, H, C, (W + 31) // 32), dev)  # channel-major bit planes for the weight gradients
+            if target is not None:
+                v_out, z_out, zT_out = target[i][:3]
+            else:
+                v_out, z_out = _f32((B, H, W, C), dev), _i32((B, H, W), dev)
+                zT_out = _i32((B, H, C, (W + 31) // 32), dev)  # channel-major bit planes for the weight gradients
             leak, thresh = self._flat[f"{i}.leak"], self._flat[f"{i}.thresh"]
             if plif and i == 0:
                 _lib.call("evf_head_plif_fwd", _lib.ptr(x_in), _lib.ptr(self._flat["0.ff"]), _lib.ptr(leak),
@@ -451,6 +473,7 @@ class FireNetEngine:
                  else _lib.load().evf_conv_wgrad_slabs(B, H, W))
         grads = []
         seg_src, seg_dst, seg_n = [], [], []
+        red_src, red_dst = [], []
         for name, p in zip(self.pnames, self.params):
             if not p.requires_grad:
                 grads.append(None)
@@ -474,13 +497,18 @@ class FireNetEngine:
             k = (int(i), nm)
             if direct:
                 if win.slab_init.get(k):
-                    _lib.call("evf_reduce_slabs", _lib.ptr(self._slabs[k]), nslab, 9 * C * C, 1, _lib.ptr(p.grad))
+                    red_src.append(self._slabs[k])
+                    red_dst.append(p.grad)
                 grads.append(None)
                 continue
             g = torch.zeros(p.shape, dtype=torch.float32, device=win.dev)
             if win.slab_init.get(k):
                 _lib.call("evf_reduce_slabs", _lib.ptr(self._slabs[k]), nslab, 9 * C * C, 0, _lib.ptr(g))
             grads.append(g.to(p.dtype))
+        for lo in range(0, len(red_src), 16):  # all conv-weight slabs in one launch (16 tensors per call)
+            n = min(16, len(red_src) - lo)
+            _lib.call("evf_reduce_slabs_multi", (ctypes.c_void_p * n)(*[t.data_ptr() for t in red_src[lo:lo + n]]),
+                      (ctypes.c_void_p * n)(*[t.data_ptr() for t in red_dst[lo:lo + n]]), n, nslab, 9 * C * C)
         for lo in range(0, len(seg_src), 32):  # all small gradients in one launch (32 segments per call)
             hi = min(lo + 32, len(seg_src))
             ptrs = (ctypes.c_void_p * 32)(*[t.data_ptr() for t in seg_dst[lo:hi]])

@@ -105,6 +105,22 @@ class FireNet(BaseModel):
         (required when a whole training step is replayed from a hipGraph)."""
         self._eng().static_states = bool(flag)
 
+    def state_buffers(self):
+        """Opaque handle on the tensors that currently hold the recurrent state (fused engine)."""
+        return list(self._eng()._states)
+
+    def final_states_into(self, handle):
+        """The last pass of the NEXT window (announced by mark_last_pass()) writes its state straight
+        into the tensors of `handle` (from state_buffers()) instead of fresh ones.  With a cycle of
+        K >= 2 captured step graphs -- graph 0 starts from `handle`, graph k from the state graph k-1
+        left, the last one ends in `handle` -- the state crosses replays without any copy."""
+        self._eng()._final_target = handle
+
+    def mark_last_pass(self):
+        """The next forward pass is the last one of its window (see final_states_into)."""
+        if self._engine is not None:
+            self._engine._final_hint = True
+
     # -- state API (models/model.py:203-227) -------------------------------
     @property
     def states(self):

@@ -11,7 +11,7 @@ becomes a view into `flat_param`, every `.grad` a view into `flat_grad`.
 import torch
 
 from . import _lib
-from .dataloader.encodings import encode_event_list
+from .dataloader.encodings import encode_event_list, encode_event_lists
 from .models import hip_ops
 
 
@@ -77,7 +77,9 @@ def window_backward(model, loss_function, optimizer, passes, dp=None):
     """First half of a window: the passes, the loss and its backward (train_flow.py:129-154).
     Leaves this rank's gradient in the optimizer's flat buffer and, with `dp`, the
     local loss in the buffer's tail, ready for the all-reduce."""
-    for d in passes:
+    for k, d in enumerate(passes):
+        if k == len(passes) - 1 and hasattr(model, "mark_last_pass"):
+            model.mark_last_pass()  # lets a graph-captured step hand its final state over without a copy
         x = model(d["event_voxel"], d["event_cnt"])
         loss_function.event_flow_association(x["flow"], d["event_list"], d["event_list_pol_mask"], d["event_mask"])
     if loss_function.overwrite_intermediate:
@@ -113,6 +115,6 @@ def train_window(model, loss_function, optimizer, passes, dp=None):
     return window_apply(model, loss_function, optimizer, loss, dp)
 
 
-def encode_passes(event_lists, num_bins, res):
-    """[B,N,4] event lists (one per pass) -> the loader dicts, encoded on the GPU."""
-    return [encode_event_list(ev, num_bins, res) for ev in event_lists]
+def encode_passes(event_lists, num_bins, res, want=("cnt", "mask", "voxel", "pol")):
+    """[B,N,4] event lists (one per pass) -> the loader dicts, encoded on the GPU in one batched launch."""
+    return encode_event_lists(event_lists, num_bins, res, want=want)

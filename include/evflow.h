@@ -218,6 +218,10 @@ int evf_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const float* v
  * be NULL), wT_b3 = evf_pack_conv_weight_b3t(w) (54 KiB).  g_x [B,H,W,32] fp32 is written,
  * or += when accumulate.  Six-term product, fp32 accumulation (fp32 round-off class). */
 int evf_pack_conv_weight_b3t(const float* w, int Cout, int Cin, void* dst, void* stream);
+/* Both layouts of up to 16 conv weights [32][32][3][3] in one launch.  w, dst_b3, dst_b3t: HOST arrays of `count`
+ * device pointers (dst_b3 or dst_b3t may be NULL to skip that layout).  The weights change at every optimizer step
+ * (train_flow.py:163), so this runs once per step. */
+int evf_pack_conv_weights_b3_multi(const void* const* w, void* const* dst_b3, void* const* dst_b3t, int count, void* stream);
 int evf_conv_dgrad_b3(const void* g_split, const void* wT_b3, float* g_x, int accumulate,
                       int B, int H, int W, const float* g_P, const uint32_t* x_bits, void* stream);
 
@@ -259,6 +263,9 @@ int evf_conv_wgrad_bits(const uint32_t* x, const float* g_cur, int B, int H, int
                         float* wg_partial, int accumulate, void* stream);
 int evf_conv_wgrad_slabs(int B, int H, int W);
 int evf_reduce_slabs(const float* partial, int nslab, int n, int accumulate, float* dst, void* stream);
+/* evf_reduce_slabs (accumulate = 1) for up to 16 weight tensors in one launch: partial / dst are HOST arrays of `count`
+ * device pointers, every partial [nslab][n]. */
+int evf_reduce_slabs_multi(const void* const* partial, void* const* dst, int count, int nslab, int n, void* stream);
 
 /* Head layer, neuron backward + weight gradient fused (one pass over the gradient tensors):
  * evf_lif_bwd plus dW partials per block into slab [evf_head_lif_bwd_wgrad_slabs(B,H,W)][32*Cin*9]
