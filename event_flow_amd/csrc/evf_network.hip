@@ -108,13 +108,17 @@ struct RsMulti {
   float* dst[16];
 };
 #define RSM_GROUPS 16
-__global__ void k_reduce_wgrad_multi(RsMulti a, int nslab) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // e = (tau*32 + ci)*32 + co
-  if (e >= 9 * C32 * C32) return;
+// block = 64 outputs x 16 slab groups; the groups meet in LDS and ONE thread per output does a plain
+// read-modify-write (the first version had every group add atomically: 1.2 M atomics on 74 k addresses
+// took 50 of its 68 us)
+__global__ __launch_bounds__(64 * RSM_GROUPS) void k_reduce_wgrad_multi(RsMulti a, int nslab) {
+  __shared__ float red[RSM_GROUPS][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + tx;  // e = (tau*32 + ci)*32 + co;  9216 = 144 * 64
   const float* __restrict__ p = a.src[blockIdx.z] + e;
   constexpr long N = 9 * C32 * C32;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int k = blockIdx.y;
+  int k = ty;
   for (; k + 3 * RSM_GROUPS < nslab; k += 4 * RSM_GROUPS) {  // four independent loads in flight
     s0 += p[(long)k * N];
     s1 += p[(long)(k + RSM_GROUPS) * N];
@@ -122,8 +126,15 @@ __global__ void k_reduce_wgrad_multi(RsMulti a, int nslab) {
     s3 += p[(long)(k + 3 * RSM_GROUPS) * N];
   }
   for (; k < nslab; k += RSM_GROUPS) s0 += p[(long)k * N];
-  const int co = e & 31, ci = (e >> 5) & 31, tau = e >> 10;
-  evf_atomic_add(a.dst[blockIdx.z] + (co * C32 + ci) * 9 + tau, (s0 + s1) + (s2 + s3));
+  red[ty][tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ty == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < RSM_GROUPS; ++g) s += red[g][tx];
+    const int co = e & 31, ci = (e >> 5) & 31, tau = e >> 10;
+    a.dst[blockIdx.z][(co * C32 + ci) * 9 + tau] += s;
+  }
 }
 
 extern "C" int evf_reduce_slabs_multi(const void* const* partial, void* const* dst, int count, int nslab, int n,
@@ -135,8 +146,7 @@ extern "C" int evf_reduce_slabs_multi(const void* const* partial, void* const* d
     a.dst[i] = i < count ? (float*)dst[i] : nullptr;
     if (i < count && (!a.src[i] || !a.dst[i])) return EVF_EINVAL;
   }
-  hipLaunchKernelGGL(k_reduce_wgrad_multi, dim3(evf_cdiv(n, 256), RSM_GROUPS, count), dim3(256), 0, EVF_STREAM(stream), a,
-                     nslab);
+  hipLaunchKernelGGL(k_reduce_wgrad_multi, dim3(n / 64, 1, count), dim3(64 * RSM_GROUPS), 0, EVF_STREAM(stream), a, nslab);
   return evf_status();
 }
 

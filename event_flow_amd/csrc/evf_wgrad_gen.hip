@@ -539,14 +539,32 @@ __global__ __launch_bounds__(512) void k_wgrad9(const float* __restrict__ x, con
 }
 
 // gw[(co*cin_total + cin_off + ci)*9 + tap] (+)= sum_split slab[split][tap][ci][co]
-__global__ void k_wgrad_reduce(const float* __restrict__ slab, int nsplit, int Cin, int Cout, int cin_total, int cin_off,
-                               int accumulate, float* __restrict__ gw) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// block = 64 outputs x WGR_G split groups (a single thread walking up to 256 splits was one exposed load
+// latency per split); the groups meet in LDS, one plain store per output.
+#define WGR_G 16
+__global__ __launch_bounds__(64 * WGR_G) void k_wgrad_reduce(const float* __restrict__ slab, int nsplit, int Cin, int Cout,
+                                                             int cin_total, int cin_off, int accumulate,
+                                                             float* __restrict__ gw) {
+  __shared__ float red[WGR_G][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const long per = (long)9 * Cin * Cout;
-  if (e >= per) return;
-  const int co = (int)(e % Cout), ci = (int)((e / Cout) % Cin), tap = (int)(e / ((long)Cout * Cin));
+  const long e = (long)blockIdx.x * 64 + tx;
+  const long ec = e < per ? e : per - 1;
+  const float* __restrict__ p = slab + ec;
+  float s0 = 0.f, s1 = 0.f;
+  int k = ty;
+  for (; k + WGR_G < nsplit; k += 2 * WGR_G) {
+    s0 += p[(long)k * per];
+    s1 += p[(long)(k + WGR_G) * per];
+  }
+  if (k < nsplit) s0 += p[(long)k * per];
+  red[ty][tx] = s0 + s1;
+  __syncthreads();
+  if (ty != 0 || e >= per) return;
   float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += slab[k * per + e];
+#pragma unroll
+  for (int g = 0; g < WGR_G; ++g) s += red[g][tx];
+  const int co = (int)(e % Cout), ci = (int)((e / Cout) % Cin), tap = (int)(e / ((long)Cout * Cin));
   if (cin_off + ci >= cin_total) return;  // alignment-padding channel of the activation: no weight behind it
   float* d = gw + ((long)co * cin_total + cin_off + ci) * 9 + tap;
   *d = accumulate ? *d + s : s;
@@ -650,7 +668,7 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
     int rc = evf_status();
     if (rc) return rc;
     const long per = (long)9 * Cin * Cout;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(evf_cdiv(per, 256)), dim3(256), 0, st, ws, p.nsplit, Cin, Cout, cin_total,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(evf_cdiv(per, 64)), dim3(64 * WGR_G), 0, st, ws, p.nsplit, Cin, Cout, cin_total,
                        cin_off, accumulate, g_w);
     return evf_status();
   }

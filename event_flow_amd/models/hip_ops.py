@@ -149,6 +149,25 @@ def conv_wgrad(x, g_y, g_w, g_b, Cin, Cout, k, stride, cin_total=None, cin_off=0
 
 
 # ---------------------------------------------------------------------------
+# parameter gradients written in place
+# ---------------------------------------------------------------------------
+DIRECT_PARAM_GRADS = False  # switched on by train.FlatAdam (whose flat buffer every .grad is a view of)
+
+
+def bound_grad(t):
+    """The fp32 `.grad` buffer already bound to leaf parameter `t`, if our kernels may accumulate into it
+    directly (the backward then returns None for `t`: no temporary, no AccumulateGrad add kernel per tensor
+    and step).  Only with DIRECT_PARAM_GRADS: `loss.backward()` semantics are unchanged, `torch.autograd.grad`
+    users keep the flag off."""
+    if not DIRECT_PARAM_GRADS or t is None or not t.is_leaf or not t.requires_grad:
+        return None
+    g = t.grad
+    if g is None or g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous() or g.shape != t.shape:
+        return None
+    return g
+
+
+# ---------------------------------------------------------------------------
 # spiking cell step
 # ---------------------------------------------------------------------------
 def act_width(cell):
@@ -233,9 +252,17 @@ class _CellStep(torch.autograd.Function):
             if not gs.is_contiguous():
                 gs = gs.contiguous()
         g_cur = _new((B, Ho, Wo, C), dev)
-        g_prev = torch.zeros((ns, B, Ho, Wo, C), dtype=torch.float32, device=dev)
+        # the kernel writes dL/dv_prev and dL/d(trace)_prev; dL/dz_prev only for ALIF -- otherwise that slice is
+        # the recurrent conv's input gradient (written below) or zero
+        g_prev = _new((ns, B, Ho, Wo, C), dev)
+        rec_dgrad = cell.recurrent and sp is not None and need[2]
+        if kind != 2 and not rec_dgrad:
+            g_prev[1].zero_()
         g_P = _new((B, Ho, Wo), dev) if kind in (1, 3) else None
-        g_prm = [torch.zeros(C, dtype=torch.float32, device=dev) if (prm[i] is not None and need[6 + i]) else None
+        params = cell_params(cell)
+        d_prm = [bound_grad(params[i]) if (prm[i] is not None and need[6 + i]) else None for i in range(4)]
+        g_prm = [d_prm[i].view(-1) if d_prm[i] is not None else
+                 (torch.zeros(C, dtype=torch.float32, device=dev) if (prm[i] is not None and need[6 + i]) else None)
                  for i in range(4)]
         _lib.call("evf_neuron_bwd", kind, _lib.ptr(gs[0]) if gs is not None else None, _lib.ptr(gon),
                   _lib.ptr(gs[1]) if gs is not None else None, _lib.ptr(gs[2]) if (gs is not None and ns == 3) else None,
@@ -247,13 +274,20 @@ class _CellStep(torch.autograd.Function):
                   _lib.ptr(g_prm[0]), _lib.ptr(g_prm[1]), _lib.ptr(g_prm[2]), _lib.ptr(g_prm[3]))
         g_wff = g_wrec = g_x = None
         if need[4]:
-            g_wff = _new(tuple(wff.shape), dev)
-            conv_wgrad(xn, g_cur, g_wff, None, Cin, C, k, s, cin_total=wff.shape[1])
+            d = bound_grad(wff)
+            if d is not None:
+                conv_wgrad(xn, g_cur, d, None, Cin, C, k, s, cin_total=wff.shape[1], accumulate=1)
+            else:
+                g_wff = _new(tuple(wff.shape), dev)
+                conv_wgrad(xn, g_cur, g_wff, None, Cin, C, k, s, cin_total=wff.shape[1])
         if cell.recurrent and need[5]:
-            if sp is not None:
+            d = bound_grad(wrec)
+            if sp is not None and d is not None:
+                conv_wgrad(sp[1], g_cur, d, None, C, C, k, 1, accumulate=1)
+            elif sp is not None:
                 g_wrec = _new(tuple(wrec.shape), dev)
                 conv_wgrad(sp[1], g_cur, g_wrec, None, C, C, k, 1)
-            else:
+            elif d is None:
                 g_wrec = torch.zeros(tuple(wrec.shape), dtype=torch.float32, device=dev)
         if need[1]:
             g_xn = _new((B, H, W, Cin), dev)
@@ -265,10 +299,10 @@ class _CellStep(torch.autograd.Function):
         g_st = None
         if sp is not None and need[2]:
             if cell.recurrent:  # the recurrent conv reads the previous spikes NOT detached (:530)
-                conv_dgrad(g_cur, _wcache(cell, "recT").get(wrec, 1), g_prev[1], C, C, k, 1, accumulate=1)
+                conv_dgrad(g_cur, _wcache(cell, "recT").get(wrec, 1), g_prev[1], C, C, k, 1, accumulate=1 if kind == 2 else 0)
             g_st = g_prev.permute(0, 1, 4, 2, 3)
         g_res = g_out if (ctx.has_res and need[3]) else None
-        shp = lambda i: g_prm[i].view(C, 1, 1) if g_prm[i] is not None else None  # noqa: E731
+        shp = lambda i: g_prm[i].view(C, 1, 1) if (g_prm[i] is not None and d_prm[i] is None) else None  # noqa: E731
         return None, g_x, g_st, g_res, g_wff, g_wrec, shp(0), shp(1), shp(2), shp(3)
 
 
@@ -300,6 +334,7 @@ class _ConvAct(torch.autograd.Function):
             _lib.call("evf_act_fwd", act, _lib.ptr(y), _lib.ptr(rn), y.numel(), _lib.ptr(y))
         ctx.owner, ctx.act, ctx.stride = owner, act, stride
         ctx.saved = (xn, y, weight)
+        ctx.bias = bias
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         return from_nhwc(y)
 
@@ -316,9 +351,13 @@ class _ConvAct(torch.autograd.Function):
             g = gp
         g_w = g_b = g_x = None
         if need[2] or (ctx.has_bias and need[3]):
-            g_w = _new(tuple(weight.shape), g.device)
-            g_b = _new((Cout,), g.device) if ctx.has_bias else None
-            conv_wgrad(xn, g, g_w, g_b, Cin, Cout, k, ctx.stride)
+            d_w, d_b = bound_grad(weight), bound_grad(ctx.bias) if ctx.has_bias else None
+            if d_w is not None and (not ctx.has_bias or d_b is not None):
+                conv_wgrad(xn, g, d_w, d_b, Cin, Cout, k, ctx.stride, accumulate=1)
+            else:
+                g_w = _new(tuple(weight.shape), g.device)
+                g_b = _new((Cout,), g.device) if ctx.has_bias else None
+                conv_wgrad(xn, g, g_w, g_b, Cin, Cout, k, ctx.stride)
         if need[1]:
             g_xn = _new((B, H, W, Cin), g.device)
             conv_dgrad(g, _wcache(ctx.owner, "wT").get(weight, 1), g_xn, Cin, Cout, k, ctx.stride)
@@ -361,6 +400,7 @@ class _ConvGRU(torch.autograd.Function):
         o, new = _new((B, H, W, Ch), dev), _new((B, H, W, Ch), dev)
         _lib.call("evf_gru_out_fwd", _lib.ptr(co), _lib.ptr(hn), _lib.ptr(u), n, _lib.ptr(o), _lib.ptr(new))
         ctx.owner = owner
+        ctx.biases = (br, bu, bo)
         ctx.saved = (xn, hn, u, r, hr, o, wr, wu, wo)
         return from_nhwc(new)
 
@@ -385,17 +425,19 @@ class _ConvGRU(torch.autograd.Function):
         else:
             g_cr.zero_()
 
-        def wgrads(w, gate_g, hsrc):
-            g_w = torch.zeros(tuple(w.shape), dtype=torch.float32, device=dev)
-            g_b = torch.zeros((Ch,), dtype=torch.float32, device=dev)
+        def wgrads(w, b, gate_g, hsrc):
+            d_w, d_b = bound_grad(w), bound_grad(b)
+            direct = d_w is not None and d_b is not None
+            g_w = d_w if direct else torch.zeros(tuple(w.shape), dtype=torch.float32, device=dev)
+            g_b = d_b if direct else torch.zeros((Ch,), dtype=torch.float32, device=dev)
             conv_wgrad(xn, gate_g, g_w, g_b, Cx, Ch, k, 1, cin_total=Cx + Ch, cin_off=0, accumulate=1)
             if hsrc is not None:
                 conv_wgrad(hsrc, gate_g, g_w, None, Ch, Ch, k, 1, cin_total=Cx + Ch, cin_off=Cx, accumulate=1)
-            return g_w, g_b
+            return (None, None) if direct else (g_w, g_b)
 
-        g_wo, g_bo = wgrads(wo, g_co, hr if hn is not None else None)
-        g_wu, g_bu = wgrads(wu, g_cu, hn)
-        g_wr, g_br = wgrads(wr, g_cr, hn)
+        g_wo, g_bo = wgrads(wo, ctx.biases[2], g_co, hr if hn is not None else None)
+        g_wu, g_bu = wgrads(wu, ctx.biases[1], g_cu, hn)
+        g_wr, g_br = wgrads(wr, ctx.biases[0], g_cr, hn)
         g_x = g_hh = None
         if need[1]:
             g_xn = _new((B, H, W, Cx), dev)

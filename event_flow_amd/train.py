@@ -43,6 +43,7 @@ class FlatAdam:
             off += k
         self.lr, self.betas, self.eps, self.clip = lr, betas, eps, clip
         self.steps = 0
+        hip_ops.DIRECT_PARAM_GRADS = True  # every .grad is a view of flat_grad: the backward kernels add into it in place
 
     def zero_grad(self):
         self.flat_grad.zero_()

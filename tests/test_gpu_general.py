@@ -370,3 +370,48 @@ def test_standalone_spike_functions(name):
     assert np.array_equal(N(z1), (x - 1.0).gt(0).float().numpy())
     with pytest.raises(_lib.EvflowError):
         getattr(su, name)(x)  # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------ in-place parameter gradients
+@pytest.mark.parametrize("which", ["evflownet", "ann_firenet", "alif_firenet"])
+def test_direct_param_grads_equal_autograd_accumulation(which):
+    """With hip_ops.DIRECT_PARAM_GRADS (set by FlatAdam) the backward kernels add weight / bias / neuron-parameter
+    gradients straight into an already-bound fp32 .grad and return None to autograd.  Two identical backward
+    passes must then give exactly what autograd's own accumulation gives: grad(second pass) = 2 x grad(first)."""
+    torch.manual_seed(3)
+    if which == "evflownet":
+        model = SpikingRecEVFlowNet(_unet_cfg(8)).to(DEV)
+        H = W = 32
+    elif which == "ann_firenet":
+        model = FireNet(_ann_cfg()).to(DEV)
+        H = W = 24
+    else:
+        cfg = _unet_cfg(8)
+        cfg["spiking_neuron"] = {"hard_reset": False}
+        cfg["base_num_channels"] = 16
+        model = ALIFFireNet(cfg).to(DEV)
+        H = W = 24
+    gen = torch.Generator().manual_seed(5)
+    xs = [(torch.rand(2, 2, H, W, generator=gen) < 0.3).float().to(DEV) * 2 for _ in range(2)]
+
+    def run():
+        model.reset_states()
+        tot = 0
+        for x in xs:
+            out = model(x, x)
+            tot = tot + sum((f * f).sum() for f in out["flow"])
+        tot.backward()
+
+    old = hip_ops.DIRECT_PARAM_GRADS
+    try:
+        hip_ops.DIRECT_PARAM_GRADS = False
+        run()
+        first = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        assert len(first) > 4
+        hip_ops.DIRECT_PARAM_GRADS = True
+        run()  # .grad is bound now: the kernels accumulate in place
+    finally:
+        hip_ops.DIRECT_PARAM_GRADS = old
+    for k, p in model.named_parameters():
+        if k in first:
+            close(N(p.grad), 2 * N(first[k]), 2e-5, k)
