@@ -546,24 +546,23 @@ __global__ __launch_bounds__(64 * WGR_G) void k_wgrad_reduce(const float* __rest
                                                              int cin_total, int cin_off, int accumulate,
                                                              float* __restrict__ gw) {
   __shared__ float red[WGR_G][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, G = blockDim.x >> 6;  // G = min(16, nsplit) groups
   const long per = (long)9 * Cin * Cout;
   const long e = (long)blockIdx.x * 64 + tx;
   const long ec = e < per ? e : per - 1;
   const float* __restrict__ p = slab + ec;
   float s0 = 0.f, s1 = 0.f;
   int k = ty;
-  for (; k + WGR_G < nsplit; k += 2 * WGR_G) {
+  for (; k + G < nsplit; k += 2 * G) {
     s0 += p[(long)k * per];
-    s1 += p[(long)(k + WGR_G) * per];
+    s1 += p[(long)(k + G) * per];
   }
   if (k < nsplit) s0 += p[(long)k * per];
   red[ty][tx] = s0 + s1;
   __syncthreads();
   if (ty != 0 || e >= per) return;
   float s = 0.f;
-#pragma unroll
-  for (int g = 0; g < WGR_G; ++g) s += red[g][tx];
+  for (int g = 0; g < G; ++g) s += red[g][tx];
   const int co = (int)(e % Cout), ci = (int)((e / Cout) % Cin), tap = (int)(e / ((long)Cout * Cin));
   if (cin_off + ci >= cin_total) return;  // alignment-padding channel of the activation: no weight behind it
   float* d = gw + ((long)co * cin_total + cin_off + ci) * 9 + tap;
@@ -668,7 +667,8 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
     int rc = evf_status();
     if (rc) return rc;
     const long per = (long)9 * Cin * Cout;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(evf_cdiv(per, 64)), dim3(64 * WGR_G), 0, st, ws, p.nsplit, Cin, Cout, cin_total,
+    const int rg = p.nsplit >= 16 ? 16 : (p.nsplit >= 8 ? 8 : (p.nsplit >= 4 ? 4 : (p.nsplit >= 2 ? 2 : 1)));
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(evf_cdiv(per, 64)), dim3(64 * rg), 0, st, ws, p.nsplit, Cin, Cout, cin_total,
                        cin_off, accumulate, g_w);
     return evf_status();
   }
