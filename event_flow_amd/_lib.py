@@ -148,20 +148,46 @@ _PROF_VARIANT = {
 }
 
 
+_prof_cal = None
+last_event_overhead_ms = 0.0
+
+
 def profile_start(names):
-    global _prof
+    """Time every call of the named entry points with a pair of HIP events on the launch stream.  A bracket
+    reads more than the kernel it encloses (the command processor handles the two timestamp packets a few us
+    apart).  That overhead is calibrated here by a two-point fit -- brackets around one and around two launches
+    of the same tiny kernel, T1 = o + t and T2 = o + 2t, so o = 2 T1 - T2 -- and subtracted in profile_stop, so
+    the durations agree with rocprofv3's kernel-trace averages."""
+    global _prof, _prof_cal
+    _prof_cal = []
+    dummy = torch.zeros(64, device="cuda")
+    for i in range(48):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(1 + (i & 1)):
+            dummy.add_(1.0)
+        e1.record()
+        _prof_cal.append((1 + (i & 1), e0, e1))
     _prof = {n: [] for n in names}
 
 
 def profile_stop():
-    """-> {(name, variant): [ms, ...]}; synchronises."""
-    global _prof
+    """-> {(name, variant): [ms, ...]} (empty-bracket overhead removed); synchronises."""
+    global _prof, _prof_cal, last_event_overhead_ms
     rec, _prof = _prof, None
+    cal, _prof_cal = _prof_cal, None
     torch.cuda.synchronize()
+    ovh = 0.0
+    if cal:
+        med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
+        t1 = med([e0.elapsed_time(e1) for k, e0, e1 in cal[8:] if k == 1])  # first brackets: warm-up
+        t2 = med([e0.elapsed_time(e1) for k, e0, e1 in cal[8:] if k == 2])
+        ovh = max(2.0 * t1 - t2, 0.0)
+    last_event_overhead_ms = ovh
     out = {}
     for name, lst in (rec or {}).items():
         for variant, e0, e1 in lst:
-            out.setdefault((name, variant), []).append(e0.elapsed_time(e1))
+            out.setdefault((name, variant), []).append(max(e0.elapsed_time(e1) - ovh, 0.0))
     return out
 
 
