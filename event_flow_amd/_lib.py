@@ -28,7 +28,8 @@ SIGNATURES = {
     "evf_get_interpolation": [P, P, I, I, I, I, F, F, I, P, P, P],
     "evf_interpolate": [P, P, P, I, I, I, I, I, P, P],
     "evf_cm_smooth_blocks": [I, I, I, I],
-    "evf_cm_loss_fwd": [P, P, P, P, P, I, I, I, I, I, I, F, F, I, P, P, P, P, P],
+    "evf_cm_loss_ws": [I, I, I, I, I],
+    "evf_cm_loss_fwd": [P, P, P, P, P, I, I, I, I, I, I, F, F, I, P, P, P, P, P, P],
     "evf_cm_loss_bwd": [P, P, P, P, P, I, I, I, I, I, I, F, F, I, P, P, P, P, P, P],
     "evf_image_variance": [P, I, I, P, P],
     "evf_avg_ts_ratio": [P, I, I, F, P, P],
@@ -96,7 +97,7 @@ NETWORK_SIGNATURES = {
     "evf_gru_out_bwd": [P, P, P, P, L, P, P, P, P],
     "evf_gru_gates_bwd": [P, P, P, L, P, P, P],
 }
-RESTYPES = {"evf_conv2d_packed_size": ctypes.c_int64, "evf_conv2d_wgrad_ws": ctypes.c_int64}
+RESTYPES = {"evf_conv2d_packed_size": ctypes.c_int64, "evf_conv2d_wgrad_ws": ctypes.c_int64, "evf_cm_loss_ws": ctypes.c_int64}
 SIGNATURES.update(NETWORK_SIGNATURES)
 
 _lib = None

@@ -566,6 +566,106 @@ __global__ void k_cm_splat(const float* __restrict__ flow, const float4* __restr
                    o + 6 * HW, o + 7 * HW);
 }
 
+// ---- LDS-privatised splat (used when the caller passes a workspace) ----------------------------------------
+// Device-scope fp32 atomics resolve at the L2s at ~21 G/s: 16 per event and scale made k_cm_splat 1.1 ms of the
+// EV-FlowNet step (8 x 50 k events x 4 scales).  Here a pre-pass stores, per (scale, event), the warped
+// coordinates of both directions next to the polarity weights (the two random flow gathers happen once); then one
+// block per (scale, sample, direction, stripe of image rows) keeps its stripe of the four images in LDS, streams
+// the sample's pre-warped events (16 B, coalesced) and accumulates with LDS atomics, and finally writes the
+// stripe with plain coalesced stores -- no zero-fill of `images`, no global atomics.
+__global__ void k_cm_prewarp(const float* __restrict__ flow, const float4* __restrict__ ev, const float2* __restrict__ pol,
+                             const int32_t* __restrict__ ev_pass, int S, int Pm, int P, int B, int M, int H, int W,
+                             float Sc, float4* __restrict__ warp, float* __restrict__ tabs) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * M) return;
+  const int s = blockIdx.y;
+  const int b = (int)(i / M), e = (int)(i - (long)b * M);
+  const float4 q = ev[i];
+  const int pass = ev_pass[e];
+  const float t = q.x + (float)pass;  // event_list[:, :, 0:1] += passes (loss/flow.py:90)
+  const float2 pm = pol[i];
+  const long HW = (long)H * W;
+  float fy, fx;
+  evf_event_flow(flow + (long)s * Pm * B * 2 * HW, Pm == 1 ? 0 : pass, B, b, HW, q.y, q.z, W, fy, fx);
+  const Warp f = evf_warp(t, q.y, q.z, fy, fx, (float)P, Sc), g = evf_warp(t, q.y, q.z, fy, fx, 0.f, Sc);
+  float4* o = warp + ((long)(s * B + b) * 2) * M + e;
+  o[0] = make_float4(f.wy, f.wx, pm.x, pm.y);
+  o[M] = make_float4(g.wy, g.wx, pm.x, pm.y);
+  if (s == 0) tabs[i] = t;
+}
+
+__global__ __launch_bounds__(1024) void k_cm_splat_lds(const float4* __restrict__ warp, const float* __restrict__ tabs,
+                                                       int B, int M, int H, int W, int rows, float P,
+                                                       float* __restrict__ images) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* img = (float*)smem_raw;  // [4][rows*W]: I_pos, I_neg, TS_pos, TS_neg of this direction
+  const int sbd = blockIdx.y, d = sbd & 1, b = (sbd >> 1) % B;
+  const int r0 = blockIdx.x * rows, nr = min(rows, H - r0), plane = rows * W;
+  for (int q = threadIdx.x; q < 4 * plane; q += blockDim.x) img[q] = 0.f;
+  __syncthreads();
+  const float4* __restrict__ wp = warp + (long)sbd * M;
+  const float* __restrict__ tb = tabs + (long)b * M;
+  const float lo = (float)r0, hi = (float)(r0 + nr), fW = (float)W;
+  auto one = [&](const float4 w4, const float t) {
+    const float tau = d ? P - t : t;  // timestamp images: t forward, (P - t) backward (loss/flow.py:196-211, 229-244)
+    const float cy[2] = {floorf(w4.x), floorf(w4.x + 1.0f)};
+    const float cx[2] = {floorf(w4.y), floorf(w4.y + 1.0f)};
+    float ay[2], ax[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      ay[k] = fmaxf(0.f, 1.0f - fabsf(w4.x - cy[k]));
+      ax[k] = fmaxf(0.f, 1.0f - fabsf(w4.y - cx[k]));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (!(cy[j] >= lo && cy[j] < hi && cx[i] >= 0.f && cx[i] < fW)) continue;  // other stripes / outside (NaN too)
+        const float wt = ay[j] * ax[i];
+        if (wt == 0.f) continue;
+        float* px = img + ((int)cy[j] - r0) * W + (int)cx[i];
+        const float wtau = wt * tau;
+        const float v0 = wt * w4.z, v1 = wt * w4.w, u0 = wtau * w4.z, u1 = wtau * w4.w;
+        if (v0 != 0.f) atomicAdd(px, v0);
+        if (v1 != 0.f) atomicAdd(px + plane, v1);
+        if (u0 != 0.f) atomicAdd(px + 2 * plane, u0);
+        if (u1 != 0.f) atomicAdd(px + 3 * plane, u1);
+      }
+  };
+  // four events per thread and trip: their loads are issued together
+  int e = threadIdx.x;
+  for (; e + 3 * (int)blockDim.x < M; e += 4 * blockDim.x) {
+    const float4 a0 = wp[e], a1 = wp[e + blockDim.x], a2 = wp[e + 2 * blockDim.x], a3 = wp[e + 3 * blockDim.x];
+    const float t0 = tb[e], t1 = tb[e + blockDim.x], t2 = tb[e + 2 * blockDim.x], t3 = tb[e + 3 * blockDim.x];
+    one(a0, t0);
+    one(a1, t1);
+    one(a2, t2);
+    one(a3, t3);
+  }
+  for (; e < M; e += blockDim.x) one(wp[e], tb[e]);
+  __syncthreads();
+  const long HW = (long)H * W;
+  float* o = images + ((long)(sbd >> 1) * 8 + d * 4) * HW + (long)r0 * W;
+  const int n = nr * W;
+  for (int q = threadIdx.x; q < 4 * n; q += blockDim.x) {
+    const int ch = q / n, r = q - ch * n;
+    o[(long)ch * HW + r] = img[ch * plane + r];
+  }
+}
+
+static int cm_lds_rows(int S, int B, int H, int W) {
+  int rows = 8192 / W;  // 4 planes x rows x W floats <= 128 KiB of LDS
+  if (rows > H) rows = H;
+  while (rows > 8 && (long)S * B * 2 * evf_cdiv(H, rows) < 512) rows >>= 1;  // enough blocks to fill the CUs twice
+  return rows;
+}
+
+// floats of workspace that make evf_cm_loss_fwd take the LDS-privatised splat (0: image rows too wide for LDS)
+extern "C" int64_t evf_cm_loss_ws(int S, int B, int M, int H, int W) {
+  if (S <= 0 || B <= 0 || M <= 0 || H <= 0 || W <= 0 || W > 2048) return 0;
+  return (int64_t)S * B * 2 * M * 4 + (int64_t)B * M;
+}
+
 // stats [S][B][2][2] += (sum over px of A_pos^2 + A_neg^2, #px with I_pos+I_neg > 0)
 #define CM_RED_CHUNK 2048
 __global__ void k_cm_reduce(const float* __restrict__ images, int HW, float P, float* __restrict__ stats) {
@@ -677,18 +777,35 @@ static int cm_args_ok(const void* flow, const void* ev, const void* pol, const v
 extern "C" int evf_cm_loss_fwd(const float* flow, const float* ev, const float* pol, const int32_t* ev_pass,
                                const float* mask, int S, int P, int B, int M, int H, int W, float flow_scaling,
                                float regul_weight, int flags, float* images, float* stats, float* smooth_part,
-                               float* loss, void* stream) {
+                               float* loss, float* ws, void* stream) {
   if (!cm_args_ok(flow, ev, pol, ev_pass, mask, S, P, B, M, H, W, flags) || !images || !stats || !smooth_part || !loss)
     return EVF_EINVAL;
   hipStream_t st = EVF_STREAM(stream);
   const int overwrite = (flags & 2) ? 1 : 0;
   const int Pm = overwrite ? 1 : P, Pk = Pm;
   const int HW = H * W;
-  int rc = evf_hip(hipMemsetAsync(images, 0, sizeof(float) * (size_t)S * B * 8 * HW, st));
-  rc |= evf_hip(hipMemsetAsync(stats, 0, sizeof(float) * (size_t)S * B * 4, st));
+  int rc = evf_hip(hipMemsetAsync(stats, 0, sizeof(float) * (size_t)S * B * 4, st));
   if (rc) return rc;
-  hipLaunchKernelGGL(k_cm_splat, dim3(evf_cdiv((long)B * M, 256), S), dim3(256), 0, st, flow, (const float4*)ev,
-                     (const float2*)pol, ev_pass, S, Pm, P, B, M, H, W, flow_scaling, images);
+  if (ws && evf_cm_loss_ws(S, B, M, H, W) > 0) {
+    float4* warp = (float4*)ws;
+    float* tabs = ws + (size_t)S * B * 2 * M * 4;
+    hipLaunchKernelGGL(k_cm_prewarp, dim3(evf_cdiv((long)B * M, 256), S), dim3(256), 0, st, flow, (const float4*)ev,
+                       (const float2*)pol, ev_pass, S, Pm, P, B, M, H, W, flow_scaling, warp, tabs);
+    const int rows = cm_lds_rows(S, B, H, W);
+    const size_t lds = (size_t)4 * rows * W * sizeof(float);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+      (void)hipFuncSetAttribute((const void*)k_cm_splat_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_cm_splat_lds, dim3(evf_cdiv(H, rows), S * B * 2), dim3(1024), lds, st, (const float4*)warp, tabs, B,
+                       M, H, W, rows, (float)P, images);
+  } else {
+    rc = evf_hip(hipMemsetAsync(images, 0, sizeof(float) * (size_t)S * B * 8 * HW, st));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cm_splat, dim3(evf_cdiv((long)B * M, 256), S), dim3(256), 0, st, flow, (const float4*)ev,
+                       (const float2*)pol, ev_pass, S, Pm, P, B, M, H, W, flow_scaling, images);
+  }
   hipLaunchKernelGGL(k_cm_reduce, dim3(evf_cdiv(HW, CM_RED_CHUNK), S * B * 2), dim3(256), 0, st, images, HW, (float)P,
                      stats);
   const int rows = evf_cdiv(H, SM_ROWS);

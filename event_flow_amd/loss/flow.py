@@ -12,6 +12,8 @@ Differences in mechanism, not in results:
     loss/flow.py:90): the pass offset is added in-register.
 """
 
+import os
+
 import torch
 
 from .. import _lib
@@ -89,6 +91,11 @@ def _pass_index(lengths, device):
     return _PASS_INDEX[key]
 
 
+# event-scale pairs from which evf_cm_loss_fwd gets the workspace of its LDS-striped splat (MI355X: 59 -> 26 us at
+# 8 x 15 k events, 1164 -> 210 us at 4 scales x 8 x 50 k; below, the pre-warp pass does not pay)
+CM_LDS_MIN_EVENTS = int(os.environ.get("EVF_CM_LDS_MIN_EVENTS", 32768))
+
+
 class _CMLoss(torch.autograd.Function):
     """EventWarping.forward (loss/flow.py:176-301) as one fused op.
     Inputs: the flow maps, flat over (scale, pass); output: 0-d loss."""
@@ -106,10 +113,13 @@ class _CMLoss(torch.autograd.Function):
         nblk = _lib.load().evf_cm_smooth_blocks(B, Pm, H, W)
         part = torch.empty((S, nblk), dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
+        # enough event-scale pairs to amortise the pre-warp pass: LDS-striped accumulation instead of global atomics
+        nws = _lib.load().evf_cm_loss_ws(S, B, M, H, W) if S * B * M >= CM_LDS_MIN_EVENTS else 0
+        ws = torch.empty(nws, dtype=torch.float32, device=dev) if nws > 0 else None
         _lib.call(
             "evf_cm_loss_fwd", _lib.ptr(fl), _lib.ptr(ev), _lib.ptr(pol), _lib.ptr(ev_pass), _lib.ptr(mask), S, P, B, M, H,
             W, float(meta["flow_scaling"]), float(meta["weight"]), meta["flags"], _lib.ptr(images), _lib.ptr(stats),
-            _lib.ptr(part), _lib.ptr(loss),
+            _lib.ptr(part), _lib.ptr(loss), _lib.ptr(ws),
         )
         ctx.meta = meta
         ctx.save_for_backward(fl, images, stats)

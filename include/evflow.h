@@ -101,10 +101,13 @@ int evf_interpolate(const float* idx, const float* weights, const float* pol_mas
  *   loss   [1] output.
  * flags: 1 = use smoothing mask, 2 = overwrite_intermediate, 4 = loss_scaling */
 int evf_cm_smooth_blocks(int B, int P, int H, int W);
+/* ws: NULL, or evf_cm_loss_ws(S,B,M,H,W) floats of scratch (when that is > 0): the images are then accumulated in
+ * LDS stripes from pre-warped events instead of with device-scope atomics (same sums, other summation order). */
+int64_t evf_cm_loss_ws(int S, int B, int M, int H, int W);
 int evf_cm_loss_fwd(const float* flow, const float* ev, const float* pol, const int32_t* ev_pass,
                     const float* mask, int S, int P, int B, int M, int H, int W,
                     float flow_scaling, float regul_weight, int flags,
-                    float* images, float* stats, float* smooth_part, float* loss, void* stream);
+                    float* images, float* stats, float* smooth_part, float* loss, float* ws, void* stream);
 
 /* Backward of the above: dflow [S,Pm,B,2,H,W] = grad_out * dL/dflow (written,
  * not accumulated).  gimages [S,B,8,H,W] is scratch.  Reproduces the

@@ -149,7 +149,10 @@ def _run_hip_loss(g, c, H, W):
     return val, flows
 
 
-def test_event_warping_golden_loss_and_grad():
+@pytest.mark.parametrize("splat", ["atomics", "lds"])
+def test_event_warping_golden_loss_and_grad(splat, monkeypatch):
+    # both image-accumulation paths of evf_cm_loss_fwd: device-scope atomics, and LDS stripes over pre-warped events
+    monkeypatch.setattr(hloss, "CM_LDS_MIN_EVENTS", 1 if splat == "lds" else 1 << 60)
     g = load_golden("g4_event_warping")
     H, W = (int(v) for v in g["res"])
     for c in golden_cases(g):
