@@ -97,16 +97,18 @@ class StepGraph:
         from event_flow_amd.train import window_apply, window_backward
 
         self.dp, self.comm = dp, opt.comm
+        # other threads (the process group's watchdog polls events) must not invalidate a capture of this thread
+        mode = "thread_local" if dp.world > 1 else "global"
         if dp.world == 1:
             self.pre = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.pre, stream=stream):
+            with torch.cuda.graph(self.pre, stream=stream, capture_error_mode=mode):
                 self.loss = run_step(model, lossf, opt, dp, lists)
             self.post = None
             return
         self.pre, self.post = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.pre, stream=stream):
+        with torch.cuda.graph(self.pre, stream=stream, capture_error_mode=mode):
             local = window_backward(model, lossf, opt, _encode(lists), dp)
-        with torch.cuda.graph(self.post, stream=stream):
+        with torch.cuda.graph(self.post, stream=stream, capture_error_mode=mode):
             self.loss = window_apply(model, lossf, opt, local, dp)
 
     def replay(self):
