@@ -28,6 +28,7 @@ SIGNATURES = {
     "evf_get_interpolation": [P, P, I, I, I, I, F, F, I, P, P, P],
     "evf_interpolate": [P, P, P, I, I, I, I, I, P, P],
     "evf_cm_smooth_blocks": [I, I, I, I],
+    "evf_norm_nonzero": [P, ctypes.c_int64, P, P, P],
     "evf_cm_loss_ws": [I, I, I, I, I],
     "evf_cm_loss_fwd": [P, P, P, P, P, I, I, I, I, I, I, F, F, I, P, P, P, P, P, P],
     "evf_cm_loss_bwd": [P, P, P, P, P, I, I, I, I, I, I, F, F, I, P, P, P, P, P, P],

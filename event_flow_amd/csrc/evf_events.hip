@@ -1131,3 +1131,68 @@ extern "C" int evf_masked_flow_mean(const float* maps, const float* masks, int B
                      out);
   return evf_status();
 }
+
+// --------------------------------------------------------------------------
+// norm_input (models/model.py:247-252): x[x != 0] = (x[x != 0] - mean) / std over the NON-ZERO entries of the
+// whole tensor, std unbiased (torch.std).  Two passes over x with double accumulators (no host sync, no
+// boolean-index temporaries): (count, sum), then sum of squared deviations, then the element-wise update.
+// --------------------------------------------------------------------------
+__global__ void k_nz_sum(const float* __restrict__ x, long n, double* __restrict__ ws) {
+  __shared__ double red[2][16];
+  double s = 0.0, c = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    if (v != 0.f) s += (double)v, c += 1.0;
+  }
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64), c += __shfl_xor(c, o, 64);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) red[0][wv] = s, red[1][wv] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0.0, tc = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) ts += red[0][w], tc += red[1][w];
+    atomicAdd(ws, ts);
+    atomicAdd(ws + 1, tc);
+  }
+}
+__global__ void k_nz_dev(const float* __restrict__ x, long n, double* __restrict__ ws) {
+  __shared__ double red[16];
+  const double mean = ws[0] / ws[1];
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    if (v != 0.f) {
+      const double d = (double)v - mean;
+      s += d * d;
+    }
+  }
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) red[wv] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) ts += red[w];
+    atomicAdd(ws + 2, ts);
+  }
+}
+__global__ void k_nz_apply(const float* __restrict__ x, long n, const double* __restrict__ ws, float* __restrict__ out) {
+  const float mean = (float)(ws[0] / ws[1]);
+  const float sd = (float)sqrt(ws[2] / (ws[1] - 1.0));  // unbiased; one non-zero entry -> NaN like torch
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    out[i] = v != 0.f ? (v - mean) / sd : 0.f;
+  }
+}
+
+extern "C" int evf_norm_nonzero(const float* x, int64_t n, float* out, double* ws3, void* stream) {
+  if (!x || !out || !ws3 || n <= 0) return EVF_EINVAL;
+  hipStream_t st = EVF_STREAM(stream);
+  const int rc = evf_hip(hipMemsetAsync(ws3, 0, 3 * sizeof(double), st));
+  if (rc) return rc;
+  const int nb = (int)((n + 1023) / 1024 < 1024 ? (n + 1023) / 1024 : 1024);
+  hipLaunchKernelGGL(k_nz_sum, dim3(nb), dim3(256), 0, st, x, (long)n, ws3);
+  hipLaunchKernelGGL(k_nz_dev, dim3(nb), dim3(256), 0, st, x, (long)n, ws3);
+  hipLaunchKernelGGL(k_nz_apply, dim3(nb), dim3(256), 0, st, x, (long)n, ws3, out);
+  return evf_status();
+}

@@ -149,6 +149,21 @@ def conv_wgrad(x, g_y, g_w, g_b, Cin, Cout, k, stride, cin_total=None, cin_off=0
 
 
 # ---------------------------------------------------------------------------
+# norm_input (reference models/model.py:247-252)
+# ---------------------------------------------------------------------------
+def norm_nonzero(x):
+    """x with its non-zero entries standardised (mean / unbiased std over the non-zero entries of the whole
+    tensor) -- out of place (the reference writes into the caller's batch, quirk q4), no host sync.  The input
+    carries no gradient (it is the event encoding)."""
+    _lib.require_gpu(x, "norm_input")
+    xc = x.detach().float().contiguous()
+    out = torch.empty_like(xc)
+    ws = torch.empty(3, dtype=torch.float64, device=xc.device)
+    _lib.call("evf_norm_nonzero", _lib.ptr(xc), xc.numel(), _lib.ptr(out), ws.data_ptr())
+    return out
+
+
+# ---------------------------------------------------------------------------
 # parameter gradients written in place
 # ---------------------------------------------------------------------------
 DIRECT_PARAM_GRADS = False  # switched on by train.FlatAdam (whose flat buffer every .grad is a view of)

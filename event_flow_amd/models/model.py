@@ -163,10 +163,7 @@ class FireNet(BaseModel):
             raise AttributeError
 
         if self.norm_input:  # models/model.py:247-252, out of place (quirk q4)
-            nz = x != 0
-            vals = x[nz]
-            x = x.clone()
-            x[nz] = (vals - vals.mean()) / vals.std()
+            x = hip_ops.norm_nonzero(x)
 
         if not self._fused():
             return self._forward_general(x, log)
@@ -336,8 +333,8 @@ class RecEVFlowNet(BaseModel):
         else:
             print("Model error: Incorrect input encoding.")
             raise AttributeError
-        if self.norm_input:
-            raise NotImplementedError("norm_input on the EV-FlowNet path is not accelerated (all shipped configs disable it)")
+        if self.norm_input:  # models/model.py:494-500
+            x = hip_ops.norm_nonzero(x)
         if self.crop is not None:
             x = self.crop.pad(x)
         multires_flow = self.multires_unetrec.forward(x)

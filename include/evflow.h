@@ -288,6 +288,11 @@ int evf_sum_rows(const float* rows, int nrows, int n, int accumulate, float* dst
 /* Head weight gradient: dW[co][ci][ky][kx] += sum g_cur[pix][co]*x[b][ci][pix+tap] (torch layout out). */
 int evf_head_wgrad(const float* x, const float* g_cur, int B, int Cin, int H, int W, float* dw, void* stream);
 
+/* norm_input of every model's forward (models/model.py:247-252): out = x with its NON-ZERO entries replaced by
+ * (x - mean) / std, mean and unbiased std taken over the non-zero entries of the whole tensor.  ws3: 3 doubles of
+ * scratch.  out may alias x. */
+int evf_norm_nonzero(const float* x, int64_t n, float* out, double* ws3, void* stream);
+
 /* Prediction head: 1x1 conv 32->2 + bias + tanh (models/submodules.py:52-61,
  * model.py:197-199) on bit-packed spikes -> flow [B,2,H,W] (NCHW). */
 int evf_pred_fwd(const uint32_t* x, const float* w, const float* bias, int B, int H, int W,

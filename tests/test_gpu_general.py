@@ -415,3 +415,35 @@ def test_direct_param_grads_equal_autograd_accumulation(which):
     for k, p in model.named_parameters():
         if k in first:
             close(N(p.grad), 2 * N(first[k]), 2e-5, k)
+
+
+# ------------------------------------------------------------------ norm_input
+def test_norm_input_matches_reference_formula():
+    """models/model.py:247-252: the non-zero entries are standardised with their own mean / unbiased std."""
+    gen = torch.Generator().manual_seed(11)
+    x = torch.poisson(torch.full((3, 2, 37, 41), 0.7), generator=gen)
+    x[:, 1] *= -0.5
+    ref = x.clone()
+    nz = ref != 0
+    ref[nz] = (ref[nz] - ref[nz].mean()) / ref[nz].std()
+    xd = G(x.numpy())
+    got = hip_ops.norm_nonzero(xd)
+    assert torch.equal(xd.cpu(), x)  # out of place
+    np.testing.assert_allclose(N(got), ref.numpy(), rtol=2e-6, atol=2e-6)
+    # through a model: FireNet with norm_input equals the same model fed the pre-normalised input
+    cfg = _unet_cfg(32)
+    torch.manual_seed(1)
+    m1 = cells_model(cfg, norm=True)
+    torch.manual_seed(1)
+    m2 = cells_model(cfg, norm=False)
+    a = m1(xd, xd)["flow"][0]
+    b = m2(got, got)["flow"][0]
+    assert torch.equal(a, b)
+
+
+def cells_model(cfg, norm):
+    from event_flow_amd.models.model import LIFFireNet
+
+    c = dict(cfg)
+    c["norm_input"] = norm
+    return LIFFireNet(c).to(DEV)
