@@ -691,6 +691,148 @@ extern "C" int evf_lif_bwd(const float* g_z_out, const float* g_v_out, const flo
   return evf_status();
 }
 
+// Head layer, matrix-core form: neuron backward as in k_lif_bwd, and the head's weight gradient
+//   dW[co][(ci, tap)] += sum_pix g_cur[pix][co] * x[b][ci][pix + tap]        (<= 32 (ci, tap) columns: Cin <= 3)
+// as a 32 x 32 x (pixels) product on v_mfma_f32_32x32x2_f32: per wave and trip its 8 pixels of g_cur go through
+// LDS into A-operand order (lane (co, k) <- pixel 2m + k), the B operand x[pixel 2m + k][(ci, tap) = lane & 31] is
+// read straight from the input (one load per MFMA and lane).  16 accumulators instead of the 36 Cin sums per thread
+// of the VALU form (k_lif_bwd<HCIN>): ~3x the occupancy, which is what hides the HBM latency of this kernel.
+__global__ __launch_bounds__(256) void k_head_bwd_mfma(
+    const float4* __restrict__ g_z_out, const float4* __restrict__ g_v_out, const float4* __restrict__ v_out,
+    const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev, const float* __restrict__ leak,
+    const float* __restrict__ thresh, long npix, int hard_reset, int surrogate, float width, float4* __restrict__ g_cur,
+    float4* __restrict__ g_v_prev, float* __restrict__ g_leak, float* __restrict__ g_thresh,
+    const float* __restrict__ x_in, int Cin, int H, int W, float* __restrict__ slab, int slab_acc) {
+  __shared__ float s_red[2][4][C32];
+  __shared__ __attribute__((aligned(16))) float s_g[2][4][8 * C32];  // [buffer][wave][pixel][channel]
+  __shared__ float s_d[4][C32 * C32];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int cg = tid & 7;  // channel group of the element-wise part: channels 4cg..4cg+3
+  const int i = lane & 31, kg = lane >> 5;
+  float lam[4], th[4], oml[4], inv_oml[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    lam[k] = evf_sigmoid(leak[4 * cg + k]);
+    th[k] = fmaxf(thresh[4 * cg + k], 0.01f);
+    oml[k] = 1.0f - lam[k];
+    inv_oml[k] = 1.0f / oml[k];
+  }
+  float sl[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
+  const float4* pgz = g_z_out ? g_z_out : v_out;
+  const float4* pgv = g_v_out ? g_v_out : v_out;
+  const float4* pvp = v_prev ? v_prev : v_out;
+  const uint32_t* pzw = z_prev ? z_prev : (const uint32_t*)v_out;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // B operand column of this lane: (ci, dy, dx); columns >= 9 Cin are padding
+  const int ncol = 9 * Cin;
+  const bool colok = i < ncol;
+  const int ci = colok ? i / 9 : 0, tap = colok ? i - 9 * ci : 0, dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+  const long HW = (long)H * W;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const long total = npix * 8, stride = (long)gridDim.x * 256;
+  int it = 0;
+  for (long base = (long)blockIdx.x * 256; base < total; base += stride, ++it) {  // block-uniform trip count
+    const long e = base + tid;
+    const bool ok = e < total;
+    const long ec = ok ? e : total - 1;
+    const long pix = ec >> 3;
+    const float4 vo4 = v_out[ec];
+    const float4 gzl = pgz[ec], gvl = pgv[ec], vpl = pvp[ec];
+    const uint32_t zwl = pzw[pix];
+    // B operand: the input value of the wave's pixels 2m + kg at this lane's (ci, tap)
+    const long wp0 = (base >> 3) + wv * 8;  // first pixel of this wave
+    float xb[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const long q = wp0 + 2 * m + kg;
+      const long qc = q < npix ? q : npix - 1;
+      const int b = (int)(qc / HW), rem = (int)(qc - (long)b * HW), y = rem / W, x = rem - y * W;
+      const int y2 = y + dy, x2 = x + dx;
+      const bool in = colok && q < npix && y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
+      const float xv = x_in[((long)(b * Cin + ci) * H + min(max(y2, 0), H - 1)) * W + min(max(x2, 0), W - 1)];
+      xb[m] = in ? xv : 0.f;
+    }
+    const float4 gz4 = g_z_out ? gzl : zero4, gv4 = g_v_out ? gvl : zero4, vp4 = v_prev ? vpl : zero4;
+    const uint32_t zw = z_prev ? (zwl >> (4 * cg)) : 0u;
+    const float vo[4] = {vo4.x, vo4.y, vo4.z, vo4.w}, gz[4] = {gz4.x, gz4.y, gz4.z, gz4.w};
+    const float gvo[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, vp[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
+    float gc[4], gp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float z = (float)((zw >> k) & 1u);
+      const float sg = evf_surrogate(surrogate, vo[k] - th[k], width);
+      const float gsp = gz[k] * sg;
+      const float gv = gvo[k] + gsp;
+      gc[k] = gv * oml[k];
+      float cur, dlam, dth = 0.f;
+      if (hard_reset) {
+        gp[k] = gv * lam[k] * (1.0f - z);
+        cur = (vo[k] - (vp[k] * lam[k]) * (1.0f - z)) * inv_oml[k];
+        dlam = vp[k] * (1.0f - z) - cur;
+      } else {
+        gp[k] = gv * lam[k];
+        cur = (vo[k] - vp[k] * lam[k] + z * th[k]) * inv_oml[k];
+        dlam = vp[k] - cur;
+        dth = gv * z;
+      }
+      if (ok) {
+        sl[k] += gv * dlam;
+        st[k] -= dth + gsp;
+      }
+    }
+    if (ok) {
+      if (g_cur) g_cur[e] = make_float4(gc[0], gc[1], gc[2], gc[3]);
+      g_v_prev[e] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+    }
+    float* sg_w = s_g[it & 1][wv];
+    *(float4*)(sg_w + (lane >> 3) * C32 + 4 * cg) = ok ? make_float4(gc[0], gc[1], gc[2], gc[3]) : zero4;
+    __syncthreads();  // (double-buffered: one barrier per trip)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sg_w[(2 * m + kg) * C32 + i], xb[m], acc, 0, 0, 0);
+  }
+  // D[co][col] of the 4 waves -> slab[block][co][col] (torch layout [32][Cin][3][3])
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s_d[wv][((r & 3) + 8 * (r >> 2) + 4 * kg) * C32 + i] = acc[r];
+  __syncthreads();
+  float* sl_out = slab + (long)blockIdx.x * (C32 * ncol);
+  for (int e2 = tid; e2 < C32 * ncol; e2 += 256) {
+    const int co = e2 / ncol, col = e2 - co * ncol;
+    const int q = co * C32 + col;
+    const float v = (s_d[0][q] + s_d[1][q]) + (s_d[2][q] + s_d[3][q]);
+    sl_out[e2] = slab_acc ? sl_out[e2] + v : v;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      sl[k] += __shfl_xor(sl[k], o, 64);
+      st[k] += __shfl_xor(st[k], o, 64);
+    }
+  }
+  if (lane < 8) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s_red[0][wv][4 * lane + k] = sl[k];
+      s_red[1][wv][4 * lane + k] = st[k];
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int which = tid >> 5, c = tid & 31;
+    float v = 0.f;
+    for (int w = 0; w < 4; ++w) v += s_red[which][w][c];
+    if (which == 0) {
+      const float l = evf_sigmoid(leak[c]);
+      evf_atomic_add(g_leak + c, v * l * (1.0f - l));
+    } else if (thresh[c] > 0.01f) {
+      evf_atomic_add(g_thresh + c, v);
+    }
+  }
+}
+
 #define HEAD_BWD_BLOCKS 512
 extern "C" int evf_head_lif_bwd_wgrad_slabs(int B, int H, int W) {
   const long npix = (long)B * H * W;
@@ -711,9 +853,9 @@ extern "C" int evf_head_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out
     return EVF_EINVAL;
   const long npix = (long)B * H * W;
   const int nblk = evf_head_lif_bwd_wgrad_slabs(B, H, W);
-  hipLaunchKernelGGL(k_lif_bwd<2>, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)g_z_out,
+  hipLaunchKernelGGL(k_head_bwd_mfma, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)g_z_out,
                      (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev, z_prev, leak, thresh, npix,
-                     hard_reset, surrogate, act_width, (float4*)g_cur, (float4*)g_v_prev, g_leak, g_thresh, x_in, H, W,
+                     hard_reset, surrogate, act_width, (float4*)g_cur, (float4*)g_v_prev, g_leak, g_thresh, x_in, Cin, H, W,
                      slab, accumulate);
   return evf_status();
 }
