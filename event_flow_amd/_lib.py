@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libevflow_hip.so")
+LIB_PATH = os.environ.get("EVF_LIB") or os.path.join(_HERE, "libevflow_hip.so")  # EVF_LIB: A/B builds of the library
 
 P = ctypes.c_void_p
 I = ctypes.c_int
