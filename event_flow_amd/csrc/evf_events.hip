@@ -297,6 +297,9 @@ __global__ __launch_bounds__(1024) void k_iwe_splat_lds(const float* __restrict_
 // When every weight of the sample is 0 or 1 (polarity masks) the splat uses INTEGER LDS atomics on one plane
 // holding both channels as 16-bit counters (ds_add_u32 runs ~5x faster than ds_add_f32 on gfx950, measured);
 // counts < 2^16 are exact in fp32, so the result is bit-identical to float accumulation.
+typedef __attribute__((address_space(1))) void iw_glb_void;
+typedef __attribute__((address_space(3))) void iw_lds_void;
+
 template <bool PAIRW>
 __global__ __launch_bounds__(IWR_THREADS) void k_iwe_splat_reg(const float* __restrict__ flow,
                                                                const float4* __restrict__ ev,
@@ -304,23 +307,21 @@ __global__ __launch_bounds__(IWR_THREADS) void k_iwe_splat_reg(const float* __re
                                                                int W, float S, float tref, float zero_flow, int nch,
                                                                float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* pl = (float*)smem_raw;  // [H*W]
-  const int b = blockIdx.x, tid = threadIdx.x;
+  float* pl = (float*)smem_raw;  // [2][H*W]: flow_x, flow_y (+ 1 KiB slack for the last DMA piece); then the image
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int HW = H * W, HQ = HW / 4;
-  // register budget: (t, y, x, lin) per event during the two flow stages, (wy, wx, a0, a1) afterwards --
-  // the polarity weights are only loaded once t and lin are dead
+  // Both flow planes of the sample (contiguous [2][HW] in memory and in LDS) arrive by LDS-DMA: no VGPRs, no
+  // register -> LDS copy phase, and they are in flight together with the event and weight loads below.
+  {
+    const float4* f = (const float4*)(flow + (long)b * 2 * HW);
+    for (int q0 = wv * 64; q0 < 2 * HQ; q0 += IWR_THREADS)
+      __builtin_amdgcn_global_load_lds((iw_glb_void*)(f + min(q0 + lane, 2 * HQ - 1)), (iw_lds_void*)((float4*)pl + q0), 16, 0,
+                                       0);
+  }
   float t[IWR_EPT], y[IWR_EPT], x[IWR_EPT];
   int lin[IWR_EPT];
+  float a0[IWR_EPT], a1[IWR_EPT];
   const float4* evb = ev + (long)b * M;
-  const float4* f = (const float4*)(flow + (long)b * 2 * HW);
-  // both flow planes are requested up front, together with the events
-  float4 px[IWR_NQ], py[IWR_NQ];
-#pragma unroll
-  for (int k = 0; k < IWR_NQ; ++k) {
-    const int q = min(tid + k * IWR_THREADS, HQ - 1);
-    px[k] = f[q];        // horizontal component (channel 0, loss/flow.py:76)
-    py[k] = f[HQ + q];   // vertical component (channel 1, :75)
-  }
 #pragma unroll
   for (int u = 0; u < IWR_EPT; ++u) {
     const float4 q = evb[min(tid + u * IWR_THREADS, M - 1)];
@@ -328,17 +329,6 @@ __global__ __launch_bounds__(IWR_THREADS) void k_iwe_splat_reg(const float* __re
     y[u] = q.y, x[u] = q.z;
     lin[u] = min(max((int)(q.y * (float)W + q.z), 0), HW - 1);  // flow_idx = y*W + x in float, .long() (loss/flow.py:65-67)
   }
-#pragma unroll
-  for (int k = 0; k < IWR_NQ; ++k)
-    if (tid + k * IWR_THREADS < HQ) ((float4*)pl)[tid + k * IWR_THREADS] = px[k];
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < IWR_EPT; ++u) x[u] = x[u] + (t[u] * (pl[lin[u]] * zero_flow)) * S;
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < IWR_NQ; ++k)
-    if (tid + k * IWR_THREADS < HQ) ((float4*)pl)[tid + k * IWR_THREADS] = py[k];
-  float a0[IWR_EPT], a1[IWR_EPT];
 #pragma unroll
   for (int u = 0; u < IWR_EPT; ++u) {
     if (PAIRW) {
@@ -348,20 +338,20 @@ __global__ __launch_bounds__(IWR_THREADS) void k_iwe_splat_reg(const float* __re
       a0[u] = 1.0f, a1[u] = 0.f;
     }
   }
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < IWR_EPT; ++u) y[u] = y[u] + (t[u] * (pl[lin[u]] * zero_flow)) * S;
+  __syncthreads();  // (the compiler drains vmcnt before this barrier: DMA, events and weights have landed)
   // destination pixel (or -1) of every event: rounded indices, torch.round = half-to-even
   int dst[IWR_EPT];
   bool bin = true;
 #pragma unroll
   for (int u = 0; u < IWR_EPT; ++u) {
-    const float iy = rintf(y[u]), ix = rintf(x[u]);
+    const float wx = x[u] + (t[u] * (pl[lin[u]] * zero_flow)) * S;        // channel 0 = horizontal (loss/flow.py:76)
+    const float wy = y[u] + (t[u] * (pl[HW + lin[u]] * zero_flow)) * S;   // channel 1 = vertical (:75)
+    const float iy = rintf(wy), ix = rintf(wx);
     const bool in = !(iy < 0.f || iy >= (float)H || ix < 0.f || ix >= (float)W) && tid + u * IWR_THREADS < M;
     dst[u] = in ? (int)(iy * (float)W + ix) : -1;
     bin = bin && (a0[u] == 0.f || a0[u] == 1.f) && (a1[u] == 0.f || a1[u] == 1.f);
   }
-  const bool packed = __syncthreads_and(bin) && M < 65536;  // also: every wave is done reading the flow plane
+  const bool packed = __syncthreads_and(bin) && M < 65536;  // also: every wave is done reading the flow planes
   if (packed) {
     for (int q = tid; q < HQ; q += IWR_THREADS) ((uint4*)pl)[q] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
@@ -383,18 +373,22 @@ __global__ __launch_bounds__(IWR_THREADS) void k_iwe_splat_reg(const float* __re
     }
     return;
   }
+  // general weights: one fp32 plane per channel (the two planes are free now)
   for (int ch = 0; ch < nch; ++ch) {
-    if (ch) __syncthreads();
-    for (int q = tid; q < HQ; q += IWR_THREADS) ((float4*)pl)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
+    float* im = pl + (ch & 1) * HW;
+    for (int q = tid; q < HQ; q += IWR_THREADS) ((float4*)im)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
 #pragma unroll
-    for (int u = 0; u < IWR_EPT; ++u) {
-      const float a = ch ? a1[u] : a0[u];
-      if (dst[u] >= 0 && a != 0.f) atomicAdd(&pl[dst[u]], a);
-    }
-    __syncthreads();
+  for (int u = 0; u < IWR_EPT; ++u) {
+    if (dst[u] >= 0 && a0[u] != 0.f) atomicAdd(&pl[dst[u]], a0[u]);
+    if (nch > 1 && dst[u] >= 0 && a1[u] != 0.f) atomicAdd(&pl[HW + dst[u]], a1[u]);
+  }
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
     float4* o = (float4*)(out + ((long)b * nch + ch) * HW);
-    for (int q = tid; q < HQ; q += IWR_THREADS) o[q] = ((float4*)pl)[q];
+    const float4* im = (const float4*)(pl + ch * HW);
+    for (int q = tid; q < HQ; q += IWR_THREADS) o[q] = im[q];
   }
 }
 
@@ -420,8 +414,14 @@ extern "C" int evf_iwe_splat(const float* flow, const float* ev, const int32_t* 
     if ((mode & 1) && !(mode & 12) && !map_of_event && !ts_shift && (pairw || now) && (long)H * W * 4 <= 64 * 1024 &&
         ((H * W) & 3) == 0 && H * W <= 4 * IWR_NQ * IWR_THREADS && M <= IWR_EPT * IWR_THREADS && B >= 16 && (((uintptr_t)flow) & 15) == 0 &&
         (((uintptr_t)out) & 15) == 0) {
-      const size_t lds = (size_t)H * W * 4;
+      const size_t lds = (size_t)H * W * 8 + 1024;  // two planes + slack for the last (clamped) DMA piece
       const float zf = (mode & 2) ? 0.f : 1.f;  // `flow * 0` (FWL/RSAT reference images) keeps NaN/sign semantics
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_iwe_splat_reg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 129 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_iwe_splat_reg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 129 * 1024);
+        attr_set = true;
+      }
       if (pairw)
         hipLaunchKernelGGL(k_iwe_splat_reg<true>, dim3(B), dim3(IWR_THREADS), lds, st, flow, (const float4*)ev,
                            (const float2*)w0, B, M, H, W, flow_scaling, tref, zf, nch, out);

@@ -20,7 +20,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define C32 32
+#ifndef TH
 #define TH 8
+#endif
+#define FW_WAVES (TH / 2)        // a wave owns two tile rows
+#define FW_THREADS (64 * FW_WAVES)
 #define TW 32
 #define HALO_W (TW + 2)
 #define HALO_H (TH + 2)
@@ -91,7 +95,7 @@ struct PlifArgs {
 };
 
 template <bool REC, bool PLIF>
-__global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restrict__ x, const uint4* __restrict__ wff,
+__global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* __restrict__ x, const uint4* __restrict__ wff,
                                                          const uint4* __restrict__ wrec,
                                                          const float* __restrict__ leak,
                                                          const float* __restrict__ thresh,
@@ -109,13 +113,13 @@ __global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restr
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
 
-  for (int u = wv; u < NFRAG; u += 4) b3_glds16(wff + u * 64 + lane, s_w + u * 64);
-  {  // byte -> 8 x bf16 {0, 1.0}
+  for (int u = wv; u < NFRAG; u += FW_WAVES) b3_glds16(wff + u * 64 + lane, s_w + u * 64);
+  if (tid < 256) {  // byte -> 8 x bf16 {0, 1.0}
     const uint32_t t = tid;
     auto pr = [&](int e) { return ((t >> e) & 1u) * 0x3F80u | (((t >> (e + 1)) & 1u) * 0x3F80u) << 16; };
     s_lut[tid] = make_uint4(pr(0), pr(2), pr(4), pr(6));
   }
-  for (int i = tid; i < HALO_H * HALO_W; i += 256) {
+  for (int i = tid; i < HALO_H * HALO_W; i += FW_THREADS) {
     const int yy = y0 + i / HALO_W - 1, xx = x0 + i % HALO_W - 1;
     const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
     const long p = ((long)b * H + yy) * W + xx;
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256) void k_conv_lif_fwd_b3(const uint32_t* __restr
   conv_phase(s_x);
   if (REC) {
     __syncthreads();  // every wave is done with the ff weights
-    for (int u = wv; u < NFRAG; u += 4) b3_glds16(wrec + u * 64 + lane, s_w + u * 64);
+    for (int u = wv; u < NFRAG; u += FW_WAVES) b3_glds16(wrec + u * 64 + lane, s_w + u * 64);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     conv_phase(s_z);
@@ -265,13 +269,23 @@ static int launch_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_re
                          const float* thresh, const float* v_prev, const uint32_t* z_prev, int B, int H, int W,
                          int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out, const PlifArgs* plif,
                          void* stream) {
-  dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(256);
+  dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(FW_THREADS);
   hipStream_t st = EVF_STREAM(stream);
   const size_t lds = WB3_BYTES + 256 * 16 + 2 * HALO_H * HALO_W * 4 + TH * TW * 4;
   PlifArgs pa = plif ? *plif : PlifArgs{nullptr, nullptr, nullptr, nullptr, nullptr};
 #define EVF_FWD(REC_, PLIF_)                                                                                           \
+  do {                                                                                                                 \
+  if (lds > 65536) {                                                                                                   \
+    static bool attr_set = false;                                                                                      \
+    if (!attr_set) {                                                                                                   \
+      (void)hipFuncSetAttribute((const void*)k_conv_lif_fwd_b3<REC_, PLIF_>,                                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+  }                                                                                                                    \
   hipLaunchKernelGGL((k_conv_lif_fwd_b3<REC_, PLIF_>), grid, block, lds, st, x, (const uint4*)wb_ff,                   \
-                     (const uint4*)wb_rec, leak, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out, pa)
+                     (const uint4*)wb_rec, leak, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out, pa); \
+  } while (0)
   if (plif) {
     if (wb_rec) EVF_FWD(true, true); else EVF_FWD(false, true);
   } else {
