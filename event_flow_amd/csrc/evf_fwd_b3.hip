@@ -119,12 +119,16 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
     auto pr = [&](int e) { return ((t >> e) & 1u) * 0x3F80u | (((t >> (e + 1)) & 1u) * 0x3F80u) << 16; };
     s_lut[tid] = make_uint4(pr(0), pr(2), pr(4), pr(6));
   }
-  for (int i = tid; i < HALO_H * HALO_W; i += FW_THREADS) {
-    const int yy = y0 + i / HALO_W - 1, xx = x0 + i % HALO_W - 1;
-    const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-    const long p = ((long)b * H + yy) * W + xx;
-    s_x[i] = in ? x[p] : 0u;
-    s_z[i] = (in && z_prev) ? z_prev[p] : 0u;
+  {
+    const uint32_t* zsrc = z_prev ? z_prev : x;  // no load under a branch: clamped address, select afterwards
+    for (int i = tid; i < HALO_H * HALO_W; i += FW_THREADS) {
+      const int yy = y0 + i / HALO_W - 1, xx = x0 + i % HALO_W - 1;
+      const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const long p = ((long)b * H + min(max(yy, 0), H - 1)) * W + min(max(xx, 0), W - 1);
+      const uint32_t vx = x[p], vz = zsrc[p];
+      s_x[i] = in ? vx : 0u;
+      s_z[i] = (in && z_prev) ? vz : 0u;
+    }
   }
   const int i = lane & 31, kg = lane >> 5, j = lane & 31;
   const int r0 = 2 * wv;

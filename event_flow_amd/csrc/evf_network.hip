@@ -320,13 +320,16 @@ __global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ 
   for (int e = tid; e < 9 * S2 * 64; e += 256) {
     const int l = e & 63, s = (e >> 6) % S2, tau = (e >> 6) / S2;
     const int ci = 2 * s + (l >> 5), j = l & 31;
-    s_w[e] = ci < Cin ? w[(j * Cin + ci) * 9 + tau] : 0.f;
+    const float wv0 = w[(j * Cin + min(ci, Cin - 1)) * 9 + tau];
+    s_w[e] = ci < Cin ? wv0 : 0.f;
   }
   for (int e = tid; e < 2 * S2 * HALO_H * HALO_W; e += 256) {
     const int ci = e / (HALO_H * HALO_W), p = e % (HALO_H * HALO_W);
     const int yy = y0 + p / HALO_W - 1, xx = x0 + p % HALO_W - 1;
     const bool in = ci < Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    s_x[ci][p] = in ? x[(((long)b * Cin + ci) * H + yy) * W + xx] : 0.f;
+    // clamped address + select (a load under a branch is followed by s_waitcnt vmcnt(0))
+    const float xv = x[(((long)b * Cin + min(ci, Cin - 1)) * H + min(max(yy, 0), H - 1)) * W + min(max(xx, 0), W - 1)];
+    s_x[ci][p] = in ? xv : 0.f;
   }
   __syncthreads();
   f32x16 acc0 = {0}, acc1 = {0};
@@ -357,19 +360,23 @@ __global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ 
     if (y0 + py < H && x0 + px < W) P_out[((long)b * H + y0 + py) * W + x0 + px] = P;
     __syncthreads();
     const float lpt = evf_sigmoid(leak_pt[j]), apt = evf_sigmoid(add_pt[j]);
+    const float* ptsrc = pt_prev ? pt_prev : pt_out;  // dummy source when there is no previous trace
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       f32x16& acc = m ? acc1 : acc0;
-      const int row = y0 + r0 + m;
+      const int row = y0 + r0 + m, rq = min(row, H - 1);
+      // the 16 previous-trace values of this lane: unconditional loads from clamped addresses, all in flight
+      // together (under `if (ok)` each load is its own round trip: this loop was 32 serial latencies)
+      float ptv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        ptv[r] = ptsrc[(((long)b * H + rq) * W + min(x0 + mfma_row(r, lane), W - 1)) * C32 + j];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int cl = mfma_row(r, lane), col = x0 + cl;
-        if (row < H && col < W) {
-          const long e = (((long)b * H + row) * W + col) * C32 + j;
-          const float pto = (pt_prev ? pt_prev[e] : 0.f) * lpt + (1.0f - lpt) * s_P[(r0 + m) * TW + cl];
-          pt_out[e] = pto;
-          acc[r] = acc[r] - apt * pto;
-        }
+        const float pto = (pt_prev ? ptv[r] : 0.f) * lpt + (1.0f - lpt) * s_P[(r0 + m) * TW + cl];
+        acc[r] = acc[r] - apt * pto;
+        if (row < H && col < W) pt_out[(((long)b * H + row) * W + col) * C32 + j] = pto;
       }
     }
   }
@@ -435,7 +442,9 @@ __global__ void k_plif_trace_bwd(const float4* __restrict__ g_cur, const float4*
     const long ec = ok ? e : npix * 8 - 1, pix = ec >> 3;
     const float4 gc4 = g_cur[ec], po4 = pt_out[ec];
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 gk4 = g_pt_carry ? g_pt_carry[ec] : z4, pp4 = pt_prev ? pt_prev[ec] : z4;
+    // optional tensors: load from a valid dummy, select afterwards (no load under a branch)
+    const float4 gkl = (g_pt_carry ? g_pt_carry : g_cur)[ec], ppl = (pt_prev ? pt_prev : g_cur)[ec];
+    const float4 gk4 = g_pt_carry ? gkl : z4, pp4 = pt_prev ? ppl : z4;
     const float Pv = P[pix];
     const float gc[4] = {gc4.x, gc4.y, gc4.z, gc4.w}, po[4] = {po4.x, po4.y, po4.z, po4.w};
     const float gk[4] = {gk4.x, gk4.y, gk4.z, gk4.w}, pp[4] = {pp4.x, pp4.y, pp4.z, pp4.w};
