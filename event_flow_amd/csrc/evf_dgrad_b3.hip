@@ -7,11 +7,9 @@
 // of the leading one), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.
 // 108 MFMAs of 32 cycles per 32-pixel tile against 144 of 64 cycles in fp32.
 //
-// One wave = one M tile (32 pixels of a row) x 32 input channels.  The A
-// fragments (8 consecutive channels of one pixel and term = 16 B) are loaded
-// straight from global memory / L2 per tap -- the 9x tap overlap is served by
-// L1/L2, no halo tile in LDS -- so LDS only holds the 54 KiB of split weights
-// and two 8-wave blocks fit per CU.
+// One wave = one M tile (32 pixels of a row) x 32 input channels; a block = an
+// 8-row x 32-pixel tile whose gradient halo (3 planes) and split weights both
+// live in LDS, filled by LDS-DMA (see k_conv_dgrad_b3_lds below).
 #include "evf_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -103,99 +101,12 @@ extern "C" int evf_pack_conv_weights_b3_multi(const void* const* w, void* const*
   return evf_status();
 }
 
-__global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3(const uint4* __restrict__ gs, long plane_stride,
-                                                                const uint4* __restrict__ wt, float* __restrict__ gx,
-                                                                int accumulate, int B, int H, int W,
-                                                                const float* __restrict__ gPb,
-                                                                const uint32_t* __restrict__ xbits) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  uint4* s_w = (uint4*)smem_raw;  // NFRAG*64
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int b = blockIdx.z, y = blockIdx.y * DG_ROWS + wv, x0 = blockIdx.x * 32;
-  for (int q = tid; q < NFRAG * 64; q += DG_ROWS * 64) s_w[q] = wt[q];
-  __syncthreads();
-  if (y >= H) return;
-  const int i = lane & 31, kg = lane >> 5;
-  f32x16 acc = {0};
-  const long rowpix = ((long)b * H) * W;
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy) {
-    const int yy = y + dy - 1;
-    const bool yin = yy >= 0 && yy < H;
-    // all 18 fragment loads of this input row (3 taps x 2 channel halves x 3 terms) are issued
-    // before the first MFMA: the memory latency is paid once per row, not per tap.  Loads are
-    // unconditional from clamped addresses (a load inside a divergent branch gets its own vmcnt(0)).
-    uint4 a[3][2][3];
-    uint32_t msk[3];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int xx = x0 + i + dx - 1;
-      msk[dx] = (yin && xx >= 0 && xx < W) ? 0xFFFFFFFFu : 0u;
-      const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
-      const long pg = (rowpix + (long)yc * W + xc) * 4 + kg;
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) a[dx][m][s] = gs[s * plane_stride + pg + 2 * m];
-    }
-    // keep the compiler from interleaving loads and MFMAs (it otherwise minimises registers and
-    // serialises nine load->wait->mfma round trips per tile)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int tau = dy * 3 + dx;
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const uint4* wf = s_w + ((tau * 2 + m) * 3) * 64 + lane;
-        const uint4 w0 = wf[0], w1 = wf[64], w2 = wf[128];
-        const bf16x8 wh = *(const bf16x8*)&w0, wm = *(const bf16x8*)&w1, wl = *(const bf16x8*)&w2;
-        uint4 u0 = a[dx][m][0], u1 = a[dx][m][1], u2 = a[dx][m][2];
-        u0.x &= msk[dx], u0.y &= msk[dx], u0.z &= msk[dx], u0.w &= msk[dx];
-        u1.x &= msk[dx], u1.y &= msk[dx], u1.z &= msk[dx], u1.w &= msk[dx];
-        u2.x &= msk[dx], u2.y &= msk[dx], u2.z &= msk[dx], u2.w &= msk[dx];
-        const bf16x8 ah = *(const bf16x8*)&u0, am = *(const bf16x8*)&u1, al = *(const bf16x8*)&u2;
-        // smallest terms first
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
-      }
-    }
-  }
-  // epilogue: all read-modify-write / PLIF loads first (unconditional, clamped), then the stores
-  float oldv[16], pv[16];
-  uint32_t xb[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int col = min(x0 + dg_row(r, lane), W - 1);
-    const long pix = ((long)b * H + y) * W + col;
-    // branch-free: a (uniform) branch around a load costs a basic block and a drained vmcnt per iteration; when the
-    // operand is absent every lane reads the same dummy word instead
-    const float o = *(accumulate ? gx + pix * C32 + i : gx);
-    const float pp = *(gPb ? gPb + pix : gx);
-    const uint32_t xw = *(gPb ? xbits + pix : (const uint32_t*)gx);
-    oldv[r] = accumulate ? o : 0.f;
-    pv[r] = gPb ? pp : 0.f;
-    xb[r] = gPb ? xw : 0u;
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int col = x0 + dg_row(r, lane);
-    // PLIF: the pooled pre-synaptic trace also reads the input spikes: d mean_c|x| / dx_c = 1/32 where the
-    // spike is set, AvgPool3x3^T = box filter / 9 -- gPb is that filtered, scaled map (evf_plif_trace_bwd)
-    const float v = acc[r] + oldv[r] + (((xb[r] >> i) & 1u) ? pv[r] : 0.f);
-    if (col < W) gx[(((long)b * H + y) * W + col) * C32 + i] = v;
-  }
-}
-
 // ---------------------------------------------------------------------------
-// LDS-staged variant: the split gradient halo of an 8-row x 32-pixel tile (10 x 34 pixels x 3 planes x 64 B =
+// The split gradient halo of an 8-row x 32-pixel tile (10 x 34 pixels x 3 planes x 64 B =
 // 65 KiB) and the 54 KiB of split weights are brought in by LDS-DMA (global_load_lds_dwordx4: no VGPRs, full
 // 64-byte pixel lines, everything in flight at once), ONE wait, then the 108 MFMAs of every wave read both operands
-// from LDS.  The register version above pays a chain of dependent latencies (weights -> row 0 -> row 1 -> row 2 ->
-// read-modify-write) and fetches each A fragment through the L1 nine times in 16-byte pieces.
+// from LDS.  An earlier register-fragment version paid a chain of dependent latencies (weights -> row 0 -> row 1 -> row 2 ->
+// read-modify-write) and fetched each A fragment through the L1 nine times in 16-byte pieces (26.4 vs 22.5 us).
 // LDS image of a plane: [halo pixel][4 x 16-byte chunks], chunk c of pixel p stored in slot c ^ ((p >> 2) & 3): the
 // DMA writes lane-linear (64 lanes = 16 pixels x 4 slots), the swizzle is applied on the SOURCE address, and a
 // fragment read (16 consecutive pixels, one chunk) touches all 64 banks once.

@@ -549,24 +549,13 @@ __device__ __forceinline__ float evf_surrogate(int kind, float x, float width) {
   }
 }
 
-// HCIN > 0: also the head layer's weight gradient dW[co][ci][tap] += g_cur[pix][co] * x[b][ci][pix + tap]
-// (x = the network input, NCHW, HCIN channels) while g_cur is in registers: 36 HCIN accumulators per thread,
-// summed per block into slab[block][32][HCIN][9] (torch layout), reduced once per window (evf_sum_rows).
-template <int HCIN>
-__global__ __launch_bounds__(256, 2) void k_lif_bwd(const float4* __restrict__ g_z_out, const float4* __restrict__ g_v_out,
+__global__ __launch_bounds__(256) void k_lif_bwd(const float4* __restrict__ g_z_out, const float4* __restrict__ g_v_out,
                           const float4* __restrict__ v_out, const float4* __restrict__ v_prev,
                           const uint32_t* __restrict__ z_prev, const float* __restrict__ leak,
                           const float* __restrict__ thresh, long npix, int hard_reset, int surrogate, float width,
                           float4* __restrict__ g_cur, float4* __restrict__ g_v_prev, float* __restrict__ g_leak,
-                          float* __restrict__ g_thresh, const float* __restrict__ x_in, int H, int W,
-                          float* __restrict__ slab, int slab_acc) {
+                          float* __restrict__ g_thresh) {
   __shared__ float s_red[2][4][C32];
-  constexpr int NW = HCIN > 0 ? HCIN * 9 : 1;
-  float dw[4][NW];
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-#pragma unroll
-    for (int q = 0; q < NW; ++q) dw[k][q] = 0.f;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int cg = tid & 7;  // channel group: channels 4cg..4cg+3
   float lam[4], th[4], oml[4], inv_oml[4];
@@ -618,41 +607,6 @@ __global__ __launch_bounds__(256, 2) void k_lif_bwd(const float4* __restrict__ g
     }
     if (g_cur) g_cur[e] = make_float4(gc[0], gc[1], gc[2], gc[3]);
     g_v_prev[e] = make_float4(gp[0], gp[1], gp[2], gp[3]);
-    if (HCIN > 0) {
-      const int pi = (int)pix, xx = pi % W, t1 = pi / W, yy = t1 % H, b = t1 / H;
-      const float* xb = x_in + (long)b * HCIN * H * W;
-#pragma unroll
-      for (int ci = 0; ci < HCIN; ++ci)
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const int y2 = yy + dy - 1, x2 = xx + dx - 1;
-            const bool in = y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
-            const float xv = xb[((long)ci * H + min(max(y2, 0), H - 1)) * W + min(max(x2, 0), W - 1)];
-            const float xm = in ? xv : 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) dw[k][ci * 9 + dy * 3 + dx] += gc[k] * xm;
-          }
-    }
-  }
-  if (HCIN > 0) {
-    __shared__ float s_w[4][C32 * NW];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-      for (int q = 0; q < NW; ++q) {
-        float v = dw[k][q];
-#pragma unroll
-        for (int o = 8; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-        if (lane < 8) s_w[wv][(4 * lane + k) * NW + q] = v;
-      }
-    __syncthreads();
-    float* sl_out = slab + (long)blockIdx.x * (C32 * NW);
-    for (int e2 = tid; e2 < C32 * NW; e2 += blockDim.x) {
-      const float v = (s_w[0][e2] + s_w[1][e2]) + (s_w[2][e2] + s_w[3][e2]);
-      sl_out[e2] = slab_acc ? sl_out[e2] + v : v;
-    }
   }
   // reduce over the 8 lanes-per-pixel pattern: lanes with equal (lane & 7) share channels
 #pragma unroll
@@ -693,10 +647,9 @@ extern "C" int evf_lif_bwd(const float* g_z_out, const float* g_v_out, const flo
   const long npix = (long)B * H * W;
   // few, fat blocks: every block ends with 64 global atomics on the same 64 addresses
   const int nblk = (int)((npix * 8 + 255) / 256 < 768 ? (npix * 8 + 255) / 256 : 768);
-  hipLaunchKernelGGL(k_lif_bwd<0>, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)g_z_out,
+  hipLaunchKernelGGL(k_lif_bwd, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)g_z_out,
                      (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev, z_prev, leak, thresh, npix,
-                     hard_reset, surrogate, act_width, (float4*)g_cur, (float4*)g_v_prev, g_leak, g_thresh,
-                     (const float*)nullptr, H, W, (float*)nullptr, 0);
+                     hard_reset, surrogate, act_width, (float4*)g_cur, (float4*)g_v_prev, g_leak, g_thresh);
   return evf_status();
 }
 
@@ -705,7 +658,7 @@ extern "C" int evf_lif_bwd(const float* g_z_out, const float* g_v_out, const flo
 // as a 32 x 32 x (pixels) product on v_mfma_f32_32x32x2_f32: per wave and trip its 8 pixels of g_cur go through
 // LDS into A-operand order (lane (co, k) <- pixel 2m + k), the B operand x[pixel 2m + k][(ci, tap) = lane & 31] is
 // read straight from the input (one load per MFMA and lane).  16 accumulators instead of the 36 Cin sums per thread
-// of the VALU form (k_lif_bwd<HCIN>): ~3x the occupancy, which is what hides the HBM latency of this kernel.
+// of the earlier VALU form: ~3x the occupancy, which is what hides the HBM latency of this kernel.
 __global__ __launch_bounds__(256) void k_head_bwd_mfma(
     const float4* __restrict__ g_z_out, const float4* __restrict__ g_v_out, const float4* __restrict__ v_out,
     const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev, const float* __restrict__ leak,

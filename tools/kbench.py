@@ -47,6 +47,7 @@ gl, gt = torch.zeros(32, device=dev), torch.zeros(32, device=dev)
 xin = f(B, 2, H, W)
 wh = f(32, 2, 3, 3)
 dwh = torch.zeros(32, 2, 3, 3, device=dev)
+hslab = torch.zeros(_lib.load().evf_head_lif_bwd_wgrad_slabs(B, H, W), 32 * 18, device=dev)
 P = lambda t: t.data_ptr()
 FL = 2 * 9 * 32 * 32 * npix
 
@@ -60,14 +61,9 @@ cases = [
     ("conv_dgrad two", 2 * FL, 3 * npix * 128, lambda: _lib.call("evf_conv_dgrad", P(g1), P(wpt), P(g2), 0, P(wpt), P(g3), 0, B, H, W)),
     ("conv_dgrad_b3", FL, 2 * npix * 128, lambda: _lib.call("evf_conv_dgrad_b3", P(gsp), P(wb3t), P(g2), 0, B, H, W, None, None)),
     ("conv_wgrad_bits", FL, npix * 128, lambda: _lib.call("evf_conv_wgrad_bits", P(x), P(g1), B, H, W, P(slab), 1)),
+    ("head_lif_bwd_wgrad", 2 * 18 * 32 * npix, 5 * npix * 128, lambda: _lib.call("evf_head_lif_bwd_wgrad", P(g1), P(g2), P(vo), P(v), P(z), P(xin), P(leak), P(thresh), B, 2, H, W, 1, 0, 10.0, None, P(g4), P(gl), P(gt), P(hslab), 0)),
     ("lif_bwd_wgrad ff", FL, 6 * npix * 128, lambda: _lib.call("evf_lif_bwd_wgrad", P(g1), P(g2), P(vo), P(v), P(z), P(xT), None, P(leak), P(thresh), B, H, W, 1, 0, 10.0, P(g3), P(gsp), P(g4), P(gl), P(gt), P(slab), None, 1)),
     ("lif_bwd_wgrad rec", 2 * FL, 6 * npix * 128, lambda: _lib.call("evf_lif_bwd_wgrad", P(g1), P(g2), P(vo), P(v), P(z), P(xT), P(xT), P(leak), P(thresh), B, H, W, 1, 0, 10.0, P(g3), P(gsp), P(g4), P(gl), P(gt), P(slab), P(slab2), 1)),
-    ("fused ff noMFMA", FL, 6 * npix * 128, lambda: _lib.call("evf_lif_bwd_wgrad", P(g1), P(g2), P(vo), P(v), P(z), P(xT), None, P(leak), P(thresh), B, H, W, 1, 0, 10.0, P(g3), P(gsp), P(g4), P(gl), P(gt), P(slab), None, 17)),
-    ("fused ff noMFMA noLDSw", FL, 6 * npix * 128, lambda: _lib.call("evf_lif_bwd_wgrad", P(g1), P(g2), P(vo), P(v), P(z), P(xT), None, P(leak), P(thresh), B, H, W, 1, 0, 10.0, P(g3), P(gsp), P(g4), P(gl), P(gt), P(slab), None, 49)),
-    ("fused ff noMFMA noLDSw noST", FL, 6 * npix * 128, lambda: _lib.call("evf_lif_bwd_wgrad", P(g1), P(g2), P(vo), P(v), P(z), P(xT), None, P(leak), P(thresh), B, H, W, 1, 0, 10.0, P(g3), P(gsp), P(g4), P(gl), P(gt), P(slab), None, 113)),
-    ("fused bare noAtomics", FL, 6 * npix * 128, lambda: _lib.call("evf_lif_bwd_wgrad", P(g1), P(g2), P(vo), P(v), P(z), P(xT), None, P(leak), P(thresh), B, H, W, 1, 0, 10.0, P(g3), P(gsp), P(g4), P(gl), P(gt), P(slab), None, 113 + 128)),
-    ("fused bare noAtomics noSlab", FL, 6 * npix * 128, lambda: _lib.call("evf_lif_bwd_wgrad", P(g1), P(g2), P(vo), P(v), P(z), P(xT), None, P(leak), P(thresh), B, H, W, 1, 0, 10.0, P(g3), P(gsp), P(g4), P(gl), P(gt), P(slab), None, 113 + 128 + 256)),
-    ("fused ff noST", FL, 6 * npix * 128, lambda: _lib.call("evf_lif_bwd_wgrad", P(g1), P(g2), P(vo), P(v), P(z), P(xT), None, P(leak), P(thresh), B, H, W, 1, 0, 10.0, P(g3), P(gsp), P(g4), P(gl), P(gt), P(slab), None, 65)),
     ("lif_bwd", 0, 6 * npix * 128, lambda: _lib.call("evf_lif_bwd", P(g1), P(g2), P(vo), P(v), P(z), P(leak), P(thresh), B, H, W, 1, 0, 10.0, P(g3), P(g4), P(gl), P(gt))),
     ("head_wgrad", 2 * 18 * 32 * npix, npix * 128, lambda: _lib.call("evf_head_wgrad", P(xin), P(g1), B, 2, H, W, P(dwh))),
 ]
