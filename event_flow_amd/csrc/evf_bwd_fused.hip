@@ -279,17 +279,24 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
   }
 
   // ---- weight-gradient slabs: taps 0..7 straight from the owning wave
-  auto store_tile = [&](const f32x16& a, float* slab) {
-    float* d = slab + (long)blockIdx.x * (9 * C32 * C32) + wv * (C32 * C32);
+  // (the 16 previous partial sums are loaded unconditionally and together, then selected: as
+  //  `acc ? *p + a : a` every load sat under a branch and was its own HBM round trip -- s_memtime showed this
+  //  epilogue taking 30 % (ff) / 42 % (rec) of the kernel)
+  {
+    const long off = (long)blockIdx.x * (9 * C32 * C32) + wv * (C32 * C32) + i;
+    float* d = slab_ff + off;
+    float* dz = REC ? slab_rec + off : d;
+    float old[16], oldz[REC ? 16 : 1];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      float* p = d + fb_row(q, lane) * C32 + i;
-      *p = (accumulate & 1) ? *p + a[q] : a[q];
+      old[q] = d[fb_row(q, lane) * C32];
+      if (REC) oldz[q] = dz[fb_row(q, lane) * C32];
     }
-  };
-  {
-  store_tile(acc, slab_ff);
-  if (REC) store_tile(accz, slab_rec);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      d[fb_row(q, lane) * C32] = ((accumulate & 1) ? old[q] : 0.f) + acc[q];
+      if (REC) dz[fb_row(q, lane) * C32] = ((accumulate & 1) ? oldz[q] : 0.f) + accz[q];
+    }
   }
   // ---- tap 8: sum the 8 partial tiles through LDS (aliases the operand buffers)
   float* s_t8 = (float*)smem_raw;  // [8][1024]
@@ -302,7 +309,8 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
 #pragma unroll
       for (int w = 0; w < 8; ++w) v += s_t8[w * (C32 * C32) + e];
       float* p = slab + (long)blockIdx.x * (9 * C32 * C32) + 8 * (C32 * C32) + e;
-      *p = (accumulate & 1) ? *p + v : v;
+      const float prev = *p;
+      *p = ((accumulate & 1) ? prev : 0.f) + v;
     }
     __syncthreads();
   };
