@@ -278,6 +278,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     s_nxt = s_new;
   }
 
+  float prev8[2], prev8z[2] = {0.f, 0.f};
   // ---- weight-gradient slabs: taps 0..7 straight from the owning wave
   // (the 16 previous partial sums are loaded unconditionally and together, then selected: as
   //  `acc ? *p + a : a` every load sat under a branch and was its own HBM round trip -- s_memtime showed this
@@ -292,6 +293,13 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
       old[q] = d[fb_row(q, lane) * C32];
       if (REC) oldz[q] = dz[fb_row(q, lane) * C32];
     }
+    // ... and the ninth-tap tile's (two words per thread and slab), consumed after the LDS reduction below
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long o8 = (long)blockIdx.x * (9 * C32 * C32) + 8 * (C32 * C32) + tid + h * FB_THREADS;
+      prev8[h] = slab_ff[o8];
+      if (REC) prev8z[h] = slab_rec[o8];
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       d[fb_row(q, lane) * C32] = ((accumulate & 1) ? old[q] : 0.f) + acc[q];
@@ -300,23 +308,23 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
   }
   // ---- tap 8: sum the 8 partial tiles through LDS (aliases the operand buffers)
   float* s_t8 = (float*)smem_raw;  // [8][1024]
-  auto reduce_t8 = [&](const f32x16& a, float* slab) {
+  auto reduce_t8 = [&](const f32x16& a, float* slab, const float (&prev)[2]) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) s_t8[wv * (C32 * C32) + fb_row(q, lane) * C32 + i] = a[q];
     __syncthreads();
-    for (int e = tid; e < C32 * C32; e += FB_THREADS) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // C32*C32 = 2 * FB_THREADS
+      const int e = tid + h * FB_THREADS;
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) v += s_t8[w * (C32 * C32) + e];
-      float* p = slab + (long)blockIdx.x * (9 * C32 * C32) + 8 * (C32 * C32) + e;
-      const float prev = *p;
-      *p = ((accumulate & 1) ? prev : 0.f) + v;
+      slab[(long)blockIdx.x * (9 * C32 * C32) + 8 * (C32 * C32) + e] = ((accumulate & 1) ? prev[h] : 0.f) + v;
     }
     __syncthreads();
   };
   {
-  reduce_t8(acc8, slab_ff);
-  if (REC) reduce_t8(accz8, slab_rec);
+  reduce_t8(acc8, slab_ff, prev8);
+  if (REC) reduce_t8(accz8, slab_rec, prev8z);
   }
 
   // ---- per-channel sums for leak / thresh: lanes with equal (lane & 7) share channels
