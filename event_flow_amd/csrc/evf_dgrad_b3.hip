@@ -128,76 +128,83 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
   uint4* s_w = (uint4*)smem_raw;  // NFRAG*64
   uint4* s_a = s_w + NFRAG * 64;  // [3][DL_HPP][4]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int b = blockIdx.z, y0 = blockIdx.y * DG_ROWS, y = y0 + wv, x0 = blockIdx.x * 32;
+  const int y0 = blockIdx.y * DG_ROWS, y = y0 + wv, x0 = blockIdx.x * 32;
   const int i = lane & 31, kg = lane >> 5;
-  // ---- everything this block reads, requested at once
+  // the split weights are staged once per block and serve all its tiles (samples blockIdx.z, blockIdx.z + gridDim.z, ...)
   for (int u = wv; u < NFRAG; u += DG_ROWS)
     __builtin_amdgcn_global_load_lds((dl_glb_void*)(wt + u * 64 + lane), (dl_lds_void*)(s_w + u * 64), 16, 0, 0);
-  for (int q = wv; q < 3 * DL_UPP; q += DG_ROWS) {
-    const int sp = q / DL_UPP, u = q - sp * DL_UPP;
-    const int p = 16 * u + (lane >> 2), pc = min(p, DL_HP - 1);
-    const int hr = pc / DL_HW, hc = pc - hr * DL_HW;
-    const int yy = min(max(y0 - 1 + hr, 0), H - 1), xx = min(max(x0 - 1 + hc, 0), W - 1);  // out-of-image: masked at use
-    const int c = (lane & 3) ^ ((p >> 2) & 3);
-    const uint4* g = gs + sp * plane_stride + (((long)b * H + yy) * W + xx) * 4 + c;
-    __builtin_amdgcn_global_load_lds((dl_glb_void*)g, (dl_lds_void*)(s_a + (sp * DL_HPP + 16 * u) * 4), 16, 0, 0);
-  }
-  const int yq = min(y, H - 1);
-  float oldv[16], pv[16];
-  uint32_t xb[16];
+  for (int b = blockIdx.z; b < B; b += gridDim.z) {
+    if (b != (int)blockIdx.z) __syncthreads();  // every wave is done reading the previous tile's halo
+    // ---- everything this tile reads, requested at once
+    for (int q = wv; q < 3 * DL_UPP; q += DG_ROWS) {
+      const int sp = q / DL_UPP, u = q - sp * DL_UPP;
+      const int p = 16 * u + (lane >> 2), pc = min(p, DL_HP - 1);
+      const int hr = pc / DL_HW, hc = pc - hr * DL_HW;
+      const int yy = min(max(y0 - 1 + hr, 0), H - 1), xx = min(max(x0 - 1 + hc, 0), W - 1);  // out-of-image: masked at use
+      const int c = (lane & 3) ^ ((p >> 2) & 3);
+      const uint4* g = gs + sp * plane_stride + (((long)b * H + yy) * W + xx) * 4 + c;
+      __builtin_amdgcn_global_load_lds((dl_glb_void*)g, (dl_lds_void*)(s_a + (sp * DL_HPP + 16 * u) * 4), 16, 0, 0);
+    }
+    const int yq = min(y, H - 1);
+    float oldv[16], pv[16];
+    uint32_t xb[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int col = min(x0 + dg_row(r, lane), W - 1);
-    const long pix = ((long)b * H + yq) * W + col;
-    // branch-free: a (uniform) branch around a load costs a basic block and a drained vmcnt per iteration; when the
-    // operand is absent every lane reads the same dummy word instead
-    const float o = *(accumulate ? gx + pix * C32 + i : gx);
-    const float pp = *(gPb ? gPb + pix : gx);
-    const uint32_t xw = *(gPb ? xbits + pix : (const uint32_t*)gx);
-    oldv[r] = accumulate ? o : 0.f;
-    pv[r] = gPb ? pp : 0.f;
-    xb[r] = gPb ? xw : 0u;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (y >= H) return;
-  f32x16 acc = {0};
+    for (int r = 0; r < 16; ++r) {
+      const int col = min(x0 + dg_row(r, lane), W - 1);
+      const long pix = ((long)b * H + yq) * W + col;
+      // branch-free: a (uniform) branch around a load costs a basic block and a drained vmcnt per iteration; when the
+      // operand is absent every lane reads the same dummy word instead
+      const float o = *(accumulate ? gx + pix * C32 + i : gx);
+      const float pp = *(gPb ? gPb + pix : gx);
+      const uint32_t xw = *(gPb ? xbits + pix : (const uint32_t*)gx);
+      oldv[r] = accumulate ? o : 0.f;
+      pv[r] = gPb ? pp : 0.f;
+      xb[r] = gPb ? xw : 0u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 acc = {0};
 #pragma unroll
-  for (int dy = 0; dy < 3; ++dy) {
-    const int yy = y + dy - 1;
-    const bool yin = yy >= 0 && yy < H;
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y + dy - 1;
+      const bool yin = yy >= 0 && yy < H;
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int tau = dy * 3 + dx;
-      const int xx = x0 + i + dx - 1;
-      const uint32_t msk = (yin && xx >= 0 && xx < W) ? 0xFFFFFFFFu : 0u;
-      const int hp = (wv + dy) * DL_HW + i + dx, sw = (hp >> 2) & 3;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int tau = dy * 3 + dx;
+        const int xx = x0 + i + dx - 1;
+        const uint32_t msk = (yin && xx >= 0 && xx < W) ? 0xFFFFFFFFu : 0u;
+        const int hp = (wv + dy) * DL_HW + i + dx, sw = (hp >> 2) & 3;
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const uint4* wf = s_w + ((tau * 2 + m) * 3) * 64 + lane;
-        const uint4 w0 = wf[0], w1 = wf[64], w2 = wf[128];
-        const bf16x8 wh = *(const bf16x8*)&w0, wm = *(const bf16x8*)&w1, wl = *(const bf16x8*)&w2;
-        const int slot = hp * 4 + ((2 * m + kg) ^ sw);
-        uint4 u0 = s_a[slot], u1 = s_a[DL_HPP * 4 + slot], u2 = s_a[2 * DL_HPP * 4 + slot];
-        u0.x &= msk, u0.y &= msk, u0.z &= msk, u0.w &= msk;
-        u1.x &= msk, u1.y &= msk, u1.z &= msk, u1.w &= msk;
-        u2.x &= msk, u2.y &= msk, u2.z &= msk, u2.w &= msk;
-        const bf16x8 ah = *(const bf16x8*)&u0, am = *(const bf16x8*)&u1, al = *(const bf16x8*)&u2;
-        // smallest terms first
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+        for (int m = 0; m < 2; ++m) {
+          const uint4* wf = s_w + ((tau * 2 + m) * 3) * 64 + lane;
+          const uint4 w0 = wf[0], w1 = wf[64], w2 = wf[128];
+          const bf16x8 wh = *(const bf16x8*)&w0, wm = *(const bf16x8*)&w1, wl = *(const bf16x8*)&w2;
+          const int slot = hp * 4 + ((2 * m + kg) ^ sw);
+          uint4 u0 = s_a[slot], u1 = s_a[DL_HPP * 4 + slot], u2 = s_a[2 * DL_HPP * 4 + slot];
+          u0.x &= msk, u0.y &= msk, u0.z &= msk, u0.w &= msk;
+          u1.x &= msk, u1.y &= msk, u1.z &= msk, u1.w &= msk;
+          u2.x &= msk, u2.y &= msk, u2.z &= msk, u2.w &= msk;
+          const bf16x8 ah = *(const bf16x8*)&u0, am = *(const bf16x8*)&u1, al = *(const bf16x8*)&u2;
+          // smallest terms first
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+        }
       }
     }
-  }
+    if (y < H) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int col = x0 + dg_row(r, lane);
-    const float v = acc[r] + oldv[r] + (((xb[r] >> i) & 1u) ? pv[r] : 0.f);
-    if (col < W) gx[(((long)b * H + y) * W + col) * C32 + i] = v;
+      for (int r = 0; r < 16; ++r) {
+        const int col = x0 + dg_row(r, lane);
+        // PLIF: the pooled pre-synaptic trace also reads the input spikes: d mean_c|x| / dx_c = 1/32 where the
+        // spike is set, AvgPool3x3^T = box filter / 9 -- gPb is that filtered, scaled map (evf_plif_trace_bwd)
+        const float v = acc[r] + oldv[r] + (((xb[r] >> i) & 1u) ? pv[r] : 0.f);
+        if (col < W) gx[(((long)b * H + y) * W + col) * C32 + i] = v;
+      }
+    }
   }
 }
 
@@ -205,7 +212,14 @@ extern "C" int evf_conv_dgrad_b3(const void* g_split, const void* wT_b3, float* 
                                  const float* g_P, const uint32_t* x_bits, void* stream) {
   if (!g_split || !wT_b3 || !g_x || B <= 0 || H <= 0 || W <= 0 || ((g_P != nullptr) != (x_bits != nullptr)))
     return EVF_EINVAL;
-  dim3 grid(evf_cdiv(W, 32), evf_cdiv(H, DG_ROWS), B), block(DG_ROWS * 64);
+  // Samples per block (the 54 KiB of split weights are staged once per block): several only when the whole grid
+  // then is ONE round of the 256 CUs (B = 8 at 128 x 128: 256 blocks x 2 tiles, 1 % faster than 512 x 1); with more
+  // rounds than that, fat blocks only coarsen the tail (260 x 346: 726 x 2 tiles was 11 % slower than 1452 x 1).
+  const long tiles = (long)evf_cdiv(W, 32) * evf_cdiv(H, DG_ROWS);
+  int zb = B;
+  for (int z = 1; z < B; ++z)
+    if (B % z == 0 && tiles * z <= 256 && tiles * z >= 192) zb = z;
+  dim3 grid(evf_cdiv(W, 32), evf_cdiv(H, DG_ROWS), zb), block(DG_ROWS * 64);
   const long plane_stride = (long)B * H * W * 4;  // uint4 per term plane: npix * 32 bf16 / 8
   static bool attr = false;
   const size_t lds = (size_t)(NFRAG * 64 + 3 * DL_HPP * 4) * sizeof(uint4);  // 120 KiB: one block per CU
