@@ -156,7 +156,13 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
         ptp[m][r] = pl.pt_prev ? val : 0.f;
       }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weight DMA landed (and the state prefetch with it)
+  // The weight DMA (invisible to the compiler's counters) was issued before everything else and memory
+  // returns in order: once at most the state prefetches issued above (32, or 64 with the PLIF trace) are still
+  // outstanding, the DMA has landed -- the matrix phase does not wait for v_prev.
+  if (PLIF)
+    asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
   __syncthreads();
   if (PLIF) {  // pooled pre-synaptic activity of the tile's 256 pixels (one per thread)
     const int py = tid >> 5, px = tid & 31;
