@@ -760,11 +760,20 @@ __global__ __launch_bounds__(256) void k_head_bwd_mfma(
   for (int r = 0; r < 16; ++r) s_d[wv][((r & 3) + 8 * (r >> 2) + 4 * kg) * C32 + i] = acc[r];
   __syncthreads();
   float* sl_out = slab + (long)blockIdx.x * (C32 * ncol);
-  for (int e2 = tid; e2 < C32 * ncol; e2 += 256) {
-    const int co = e2 / ncol, col = e2 - co * ncol;
-    const int q = co * C32 + col;
-    const float v = (s_d[0][q] + s_d[1][q]) + (s_d[2][q] + s_d[3][q]);
-    sl_out[e2] = slab_acc ? sl_out[e2] + v : v;
+  {  // previous partial sums read together, selected afterwards (no load under a branch); ncol <= 32: <= 4 per thread
+    float prev[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) prev[h] = sl_out[min(tid + 256 * h, C32 * ncol - 1)];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int e2 = tid + 256 * h;
+      if (e2 < C32 * ncol) {
+        const int co = e2 / ncol, col = e2 - co * ncol;
+        const int q = co * C32 + col;
+        const float v = (s_d[0][q] + s_d[1][q]) + (s_d[2][q] + s_d[3][q]);
+        sl_out[e2] = (slab_acc ? prev[h] : 0.f) + v;
+      }
+    }
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -929,13 +938,13 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(const float* __restrict__ g,
   const int j = lane & 31;
   auto store = [&](const f32x16& acc, int row, float* __restrict__ out, int accf) {
     if (row >= H) return;
+    float prev[16];  // read together from clamped addresses, selected afterwards (no load under a branch)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) prev[r] = out[(((long)b * H + row) * W + min(x0 + mfma_row(r, lane), W - 1)) * C32 + j];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int col = x0 + mfma_row(r, lane);
-      if (col < W) {
-        float* d = out + (((long)b * H + row) * W + col) * C32 + j;
-        *d = accf ? *d + acc[r] : acc[r];
-      }
+      if (col < W) out[(((long)b * H + row) * W + col) * C32 + j] = (accf ? prev[r] : 0.f) + acc[r];
     }
   };
   store(a0, y0 + r0, ga, acc_a);

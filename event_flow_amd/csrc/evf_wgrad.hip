@@ -104,12 +104,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_conv_wgrad_bits(const uint32_t* 
   // taps 0..7: one wave each, straight to the slab
   float* slab = partial + (long)blockIdx.x * (9 * C32 * C32);
   {
-    float* d = slab + wv * (C32 * C32);
+    float* d = slab + wv * (C32 * C32) + i;
+    float prev[16];  // read together, selected afterwards (a load under `accumulate ? :` is its own round trip)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      float* p = d + wg_mfma_row(q, lane) * C32 + i;
-      *p = accumulate ? *p + acc[q] : acc[q];
-    }
+    for (int q = 0; q < 16; ++q) prev[q] = d[wg_mfma_row(q, lane) * C32];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) d[wg_mfma_row(q, lane) * C32] = (accumulate ? prev[q] : 0.f) + acc[q];
   }
   // tap 8: sum the 8 partial tiles through LDS
 #pragma unroll
