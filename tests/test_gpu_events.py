@@ -62,6 +62,24 @@ def test_encode_event_list_batched_vs_oracle():
     assert float(out["event_cnt"].sum()) == B * n
 
 
+def test_encode_event_lists_all_passes_in_one_launch():
+    """encode_event_lists bins the P lists of a window as one batch of P*B samples: bit-identical to P separate
+    encode_event_list calls; ragged lists fall back to the per-list path."""
+    B, n, H, W = 4, 1500, 64, 48
+    lists = [G(synthetic.event_list_batch(B, n, H, W, 900 + k)) for k in range(5)]
+    many = enc.encode_event_lists(lists, 2, (H, W), want=("cnt", "mask", "pol"))
+    assert len(many) == 5
+    for ev, d in zip(lists, many):
+        one = enc.encode_event_list(ev, 2, (H, W), want=("cnt", "mask", "pol"))
+        assert set(d) == set(one)
+        for k in one:
+            assert d[k].shape == one[k].shape and d[k].is_contiguous()
+            assert torch.equal(d[k], one[k]), k
+    ragged = lists[:2] + [lists[2][:, :700].contiguous()]
+    out = enc.encode_event_lists(ragged, 2, (H, W), want=("cnt",))
+    assert float(out[2]["event_cnt"].sum()) == B * 700 and float(out[0]["event_cnt"].sum()) == B * n
+
+
 def test_encodings_edge_cases():
     H, W = 16, 20
     empty = torch.zeros(0, device=DEV)
