@@ -119,6 +119,10 @@ extern "C" int evf_pack_conv_weights_b3_multi(const void* const* w, void* const*
 typedef __attribute__((address_space(3))) void dl_lds_void;
 typedef __attribute__((address_space(1))) const void dl_glb_void;
 
+// F32IN: the gradient arrives as ONE fp32 tensor [B,H,W,32] (g_cur of evf_lif_bwd_wgrad); the exact 3-way bf16
+// split happens here while the halo is staged through registers (same split, so the result is bit-identical to the
+// pre-split form) -- the producer writes 128 instead of 192 B/pixel and this kernel reads 128 instead of 192.
+template <bool F32IN>
 __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4* __restrict__ gs, long plane_stride,
                                                                     const uint4* __restrict__ wt, float* __restrict__ gx,
                                                                     int accumulate, int B, int H, int W,
@@ -136,7 +140,42 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
   for (int b = blockIdx.z; b < B; b += gridDim.z) {
     if (b != (int)blockIdx.z) __syncthreads();  // every wave is done reading the previous tile's halo
     // ---- everything this tile reads, requested at once
-    for (int q = wv; q < 3 * DL_UPP; q += DG_ROWS) {
+    if (F32IN) {
+      const float4* gf = (const float4*)gs;
+      constexpr int NIT = (DL_HP * 4 + DG_ROWS * 64 - 1) / (DG_ROWS * 64);  // (halo pixel, 8-channel chunk) items per thread
+      float4 lo4[NIT], hi4[NIT];
+#pragma unroll
+      for (int n = 0; n < NIT; ++n) {
+        const int it = min(tid + n * DG_ROWS * 64, DL_HP * 4 - 1), p = it >> 2, c = it & 3;
+        const int hr = p / DL_HW, hc = p - hr * DL_HW;
+        const int yy = min(max(y0 - 1 + hr, 0), H - 1), xx = min(max(x0 - 1 + hc, 0), W - 1);  // out-of-image: masked at use
+        const float4* src = gf + (((long)b * H + yy) * W + xx) * 8 + 2 * c;
+        lo4[n] = src[0], hi4[n] = src[1];
+      }
+#pragma unroll
+      for (int n = 0; n < NIT; ++n) {
+        const int it = tid + n * DG_ROWS * 64;
+        if (it < DL_HP * 4) {
+          const int p = it >> 2, c = it & 3;
+          const float v[8] = {lo4[n].x, lo4[n].y, lo4[n].z, lo4[n].w, hi4[n].x, hi4[n].y, hi4[n].z, hi4[n].w};
+          uint32_t t3[3][8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {  // g = hi + mid + lo, the split of evf_lif_bwd_wgrad
+            const uint32_t hi = dg_bf16(v[e]);
+            const float r1 = v[e] - __uint_as_float(hi << 16);
+            const uint32_t mid = dg_bf16(r1);
+            const float r2 = r1 - __uint_as_float(mid << 16);
+            t3[0][e] = hi, t3[1][e] = mid, t3[2][e] = dg_bf16(r2);
+          }
+          const int slot = p * 4 + (c ^ ((p >> 2) & 3));
+#pragma unroll
+          for (int sp = 0; sp < 3; ++sp)
+            s_a[sp * DL_HPP * 4 + slot] = make_uint4(t3[sp][0] | (t3[sp][1] << 16), t3[sp][2] | (t3[sp][3] << 16),
+                                                     t3[sp][4] | (t3[sp][5] << 16), t3[sp][6] | (t3[sp][7] << 16));
+        }
+      }
+    }
+    for (int q = wv; !F32IN && q < 3 * DL_UPP; q += DG_ROWS) {
       const int sp = q / DL_UPP, u = q - sp * DL_UPP;
       const int p = 16 * u + (lane >> 2), pc = min(p, DL_HP - 1);
       const int hr = pc / DL_HW, hc = pc - hr * DL_HW;
@@ -208,9 +247,9 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
   }
 }
 
-extern "C" int evf_conv_dgrad_b3(const void* g_split, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W,
-                                 const float* g_P, const uint32_t* x_bits, void* stream) {
-  if (!g_split || !wT_b3 || !g_x || B <= 0 || H <= 0 || W <= 0 || ((g_P != nullptr) != (x_bits != nullptr)))
+static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W,
+                     const float* g_P, const uint32_t* x_bits, void* stream) {
+  if (!g || !wT_b3 || !g_x || B <= 0 || H <= 0 || W <= 0 || ((g_P != nullptr) != (x_bits != nullptr)))
     return EVF_EINVAL;
   // Samples per block (the 54 KiB of split weights are staged once per block): several only when the whole grid
   // then is ONE round of the 256 CUs (B = 8 at 128 x 128: 256 blocks x 2 tiles, 1 % faster than 512 x 1); with more
@@ -224,10 +263,26 @@ extern "C" int evf_conv_dgrad_b3(const void* g_split, const void* wT_b3, float* 
   static bool attr = false;
   const size_t lds = (size_t)(NFRAG * 64 + 3 * DL_HPP * 4) * sizeof(uint4);  // 120 KiB: one block per CU
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_conv_dgrad_b3_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_conv_dgrad_b3_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_conv_dgrad_b3_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL(k_conv_dgrad_b3_lds, grid, block, lds, EVF_STREAM(stream), (const uint4*)g_split, plane_stride,
-                     (const uint4*)wT_b3, g_x, accumulate, B, H, W, g_P, x_bits);
+  if (f32in)
+    hipLaunchKernelGGL(k_conv_dgrad_b3_lds<true>, grid, block, lds, EVF_STREAM(stream), (const uint4*)g, plane_stride,
+                       (const uint4*)wT_b3, g_x, accumulate, B, H, W, g_P, x_bits);
+  else
+    hipLaunchKernelGGL(k_conv_dgrad_b3_lds<false>, grid, block, lds, EVF_STREAM(stream), (const uint4*)g, plane_stride,
+                       (const uint4*)wT_b3, g_x, accumulate, B, H, W, g_P, x_bits);
   return evf_status();
+}
+
+extern "C" int evf_conv_dgrad_b3(const void* g_split, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W,
+                                 const float* g_P, const uint32_t* x_bits, void* stream) {
+  return dg_launch(g_split, 0, wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, stream);
+}
+
+// the same from the fp32 gradient g_cur [B,H,W,32]: split on the fly, bit-identical result
+extern "C" int evf_conv_dgrad_b3_f32(const float* g_cur, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W,
+                                     const float* g_P, const uint32_t* x_bits, void* stream) {
+  return dg_launch(g_cur, 1, wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, stream);
 }

@@ -18,6 +18,7 @@ first pass.
 """
 
 import ctypes
+import os
 
 import torch
 
@@ -33,6 +34,10 @@ def _i32(shape, dev):
 
 def _f32(shape, dev):
     return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+# the input-gradient kernel takes the fp32 g_cur and splits it while staging (128 instead of 192 B/pixel written and read)
+F32_DGRAD = os.environ.get("EVF_F32_DGRAD", "1") != "0"
 
 
 class _Window:
@@ -368,7 +373,8 @@ class FireNetEngine:
         if win.g_cur is None:
             win.g_cur = _f32((B, H, W, C), dev)
             if self.precision == "bf16x3":
-                win.g_split = torch.empty((3, B, H, W, C), dtype=torch.bfloat16, device=dev)
+                if not F32_DGRAD:
+                    win.g_split = torch.empty((3, B, H, W, C), dtype=torch.bfloat16, device=dev)
         for i in range(n - 1, -1, -1):
             c = self.cells[i]
             in_bits, v_prev, z_prev, v_out, _, in_bitsT, zT_prev, pt_prev, pt_out, P_sav = layers[i]
@@ -392,7 +398,8 @@ class FireNetEngine:
                 _lib.call("evf_lif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
                           _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None, _lib.ptr(self._flat[f"{i}.leak"]),
                           _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
-                          self._act_width(i), _lib.ptr(win.g_cur) if plif else None, _lib.ptr(win.g_split), _lib.ptr(gv_out),
+                          self._act_width(i), _lib.ptr(win.g_cur) if (plif or F32_DGRAD) else None, _lib.ptr(win.g_split),
+                          _lib.ptr(gv_out),
                           _lib.ptr(leak_g), _lib.ptr(thr_g),
                           _lib.ptr(self._slab(kf, nsl, dev)), _lib.ptr(self._slab(kr, nsl, dev)) if use_rec else None, acc_flag)
                 win.slab_init[kf] = True
@@ -448,11 +455,12 @@ class FireNetEngine:
                 ga = win.buf(win.gz, i - 1)
                 acc_a = 1 if win.gz_has[i - 1] else 0
                 if self.precision == "bf16x3":
-                    _lib.call("evf_conv_dgrad_b3", _lib.ptr(win.g_split), _lib.ptr(self._packed[(i, "ff", "b3t")]), _lib.ptr(ga),
+                    dg, gsrc = ("evf_conv_dgrad_b3_f32", win.g_cur) if F32_DGRAD else ("evf_conv_dgrad_b3", win.g_split)
+                    _lib.call(dg, _lib.ptr(gsrc), _lib.ptr(self._packed[(i, "ff", "b3t")]), _lib.ptr(ga),
                               acc_a, B, H, W, _lib.ptr(win.gP) if plif else None, _lib.ptr(in_bits) if plif else None)
                     if rec_grad:
                         gb = win.buf(win.gz, i)
-                        _lib.call("evf_conv_dgrad_b3", _lib.ptr(win.g_split), _lib.ptr(self._packed[(i, "rec", "b3t")]),
+                        _lib.call(dg, _lib.ptr(gsrc), _lib.ptr(self._packed[(i, "rec", "b3t")]),
                                   _lib.ptr(gb), 0, B, H, W, None, None)
                         win.gz_has[i] = True
                 elif rec_grad:

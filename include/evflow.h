@@ -227,6 +227,10 @@ int evf_pack_conv_weight_b3t(const float* w, int Cout, int Cin, void* dst, void*
 int evf_pack_conv_weights_b3_multi(const void* const* w, void* const* dst_b3, void* const* dst_b3t, int count, void* stream);
 int evf_conv_dgrad_b3(const void* g_split, const void* wT_b3, float* g_x, int accumulate,
                       int B, int H, int W, const float* g_P, const uint32_t* x_bits, void* stream);
+/* The same from the fp32 gradient g_cur [B,H,W,32] of evf_lif_bwd_wgrad (g_split = NULL there): the exact 3-way split
+ * happens while the halo is staged, the result is bit-identical; 128 instead of 192 B/pixel on both sides. */
+int evf_conv_dgrad_b3_f32(const float* g_cur, const void* wT_b3, float* g_x, int accumulate,
+                          int B, int H, int W, const float* g_P, const uint32_t* x_bits, void* stream);
 
 /* PLIF cells (models/spiking_submodules.py:129-227, :554-657): LIF + a per-channel
  * pre-synaptic trace pt' = pt*s(leak_pt) + (1-s(leak_pt))*AvgPool3x3(mean_c|input|),
