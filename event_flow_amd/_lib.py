@@ -59,6 +59,7 @@ NETWORK_SIGNATURES = {
     "evf_pack_conv_weight_b3t": [P, I, I, P, P],
     "evf_conv_dgrad_b3": [P, P, P, I, I, I, I, P, P, P],
     "evf_conv_dgrad_b3_f32": [P, P, P, I, I, I, I, P, P, P],
+    "evf_conv_dgrad_b3_f32_pair": [P, P, P, I, P, P, I, I, I, P, P, P],
     "evf_conv_plif_fwd_b3": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P],
     "evf_head_plif_fwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P],
     "evf_plif_trace_bwd": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P],

@@ -127,7 +127,11 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
                                                                     const uint4* __restrict__ wt, float* __restrict__ gx,
                                                                     int accumulate, int B, int H, int W,
                                                                     const float* __restrict__ gPb,
-                                                                    const uint32_t* __restrict__ xbits) {
+                                                                    const uint32_t* __restrict__ xbits,
+                                                                    const uint4* __restrict__ wt2,
+                                                                    float* __restrict__ gx2) {
+  // wt2 / gx2 (optional): a SECOND weight set applied to the same gradient tile, written (not accumulated) to gx2 --
+  // the recurrent conv's input gradient next to the feed-forward one: one launch and one halo load instead of two.
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint4* s_w = (uint4*)smem_raw;  // NFRAG*64
   uint4* s_a = s_w + NFRAG * 64;  // [3][DL_HPP][4]
@@ -137,7 +141,8 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
   // the split weights are staged once per block and serve all its tiles (samples blockIdx.z, blockIdx.z + gridDim.z, ...)
   for (int u = wv; u < NFRAG; u += DG_ROWS)
     __builtin_amdgcn_global_load_lds((dl_glb_void*)(wt + u * 64 + lane), (dl_lds_void*)(s_w + u * 64), 16, 0, 0);
-  for (int b = blockIdx.z; b < B; b += gridDim.z) {
+  int tile_it = 0;
+  for (int b = blockIdx.z; b < B; b += gridDim.z, ++tile_it) {
     if (b != (int)blockIdx.z) __syncthreads();  // every wave is done reading the previous tile's halo
     // ---- everything this tile reads, requested at once
     if (F32IN) {
@@ -202,54 +207,80 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    f32x16 acc = {0};
+    auto matrix_phase = [&]() -> f32x16 {
+      f32x16 acc = {0};
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int yy = y + dy - 1;
-      const bool yin = yy >= 0 && yy < H;
+      for (int dy = 0; dy < 3; ++dy) {
+        const int yy = y + dy - 1;
+        const bool yin = yy >= 0 && yy < H;
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int tau = dy * 3 + dx;
-        const int xx = x0 + i + dx - 1;
-        const uint32_t msk = (yin && xx >= 0 && xx < W) ? 0xFFFFFFFFu : 0u;
-        const int hp = (wv + dy) * DL_HW + i + dx, sw = (hp >> 2) & 3;
+        for (int dx = 0; dx < 3; ++dx) {
+          const int tau = dy * 3 + dx;
+          const int xx = x0 + i + dx - 1;
+          const uint32_t msk = (yin && xx >= 0 && xx < W) ? 0xFFFFFFFFu : 0u;
+          const int hp = (wv + dy) * DL_HW + i + dx, sw = (hp >> 2) & 3;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const uint4* wf = s_w + ((tau * 2 + m) * 3) * 64 + lane;
-          const uint4 w0 = wf[0], w1 = wf[64], w2 = wf[128];
-          const bf16x8 wh = *(const bf16x8*)&w0, wm = *(const bf16x8*)&w1, wl = *(const bf16x8*)&w2;
-          const int slot = hp * 4 + ((2 * m + kg) ^ sw);
-          uint4 u0 = s_a[slot], u1 = s_a[DL_HPP * 4 + slot], u2 = s_a[2 * DL_HPP * 4 + slot];
-          u0.x &= msk, u0.y &= msk, u0.z &= msk, u0.w &= msk;
-          u1.x &= msk, u1.y &= msk, u1.z &= msk, u1.w &= msk;
-          u2.x &= msk, u2.y &= msk, u2.z &= msk, u2.w &= msk;
-          const bf16x8 ah = *(const bf16x8*)&u0, am = *(const bf16x8*)&u1, al = *(const bf16x8*)&u2;
-          // smallest terms first
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+          for (int m = 0; m < 2; ++m) {
+            const uint4* wf = s_w + ((tau * 2 + m) * 3) * 64 + lane;
+            const uint4 w0 = wf[0], w1 = wf[64], w2 = wf[128];
+            const bf16x8 wh = *(const bf16x8*)&w0, wm = *(const bf16x8*)&w1, wl = *(const bf16x8*)&w2;
+            const int slot = hp * 4 + ((2 * m + kg) ^ sw);
+            uint4 u0 = s_a[slot], u1 = s_a[DL_HPP * 4 + slot], u2 = s_a[2 * DL_HPP * 4 + slot];
+            u0.x &= msk, u0.y &= msk, u0.z &= msk, u0.w &= msk;
+            u1.x &= msk, u1.y &= msk, u1.z &= msk, u1.w &= msk;
+            u2.x &= msk, u2.y &= msk, u2.z &= msk, u2.w &= msk;
+            const bf16x8 ah = *(const bf16x8*)&u0, am = *(const bf16x8*)&u1, al = *(const bf16x8*)&u2;
+            // smallest terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+          }
         }
       }
-    }
-    if (y < H) {
+      return acc;
+    };
+    // with two weight sets the order alternates from tile to tile: the set left in LDS by the previous tile goes first
+    const int nset = wt2 ? 2 : 1;
+    for (int k = 0; k < nset; ++k) {
+      const int set = wt2 ? ((tile_it + k) & 1) : 0;
+      if (k) {  // swap the weight set
+        __syncthreads();  // every wave is done with the current one
+        const uint4* wsrc = set ? wt2 : wt;
+        for (int u = wv; u < NFRAG; u += DG_ROWS)
+          __builtin_amdgcn_global_load_lds((dl_glb_void*)(wsrc + u * 64 + lane), (dl_lds_void*)(s_w + u * 64), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      const f32x16 acc = matrix_phase();
+      if (y < H) {
+        if (set == 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int col = x0 + dg_row(r, lane);
-        // PLIF: the pooled pre-synaptic trace also reads the input spikes: d mean_c|x| / dx_c = 1/32 where the
-        // spike is set, AvgPool3x3^T = box filter / 9 -- gPb is that filtered, scaled map (evf_plif_trace_bwd)
-        const float v = acc[r] + oldv[r] + (((xb[r] >> i) & 1u) ? pv[r] : 0.f);
-        if (col < W) gx[(((long)b * H + y) * W + col) * C32 + i] = v;
+          for (int r = 0; r < 16; ++r) {
+            const int col = x0 + dg_row(r, lane);
+            // PLIF: the pooled pre-synaptic trace also reads the input spikes: d mean_c|x| / dx_c = 1/32 where the
+            // spike is set, AvgPool3x3^T = box filter / 9 -- gPb is that filtered, scaled map (evf_plif_trace_bwd)
+            const float v = acc[r] + oldv[r] + (((xb[r] >> i) & 1u) ? pv[r] : 0.f);
+            if (col < W) gx[(((long)b * H + y) * W + col) * C32 + i] = v;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int col = x0 + dg_row(r, lane);
+            if (col < W) gx2[(((long)b * H + y) * W + col) * C32 + i] = acc[r];
+          }
+        }
       }
     }
   }
 }
 
 static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W,
-                     const float* g_P, const uint32_t* x_bits, void* stream) {
-  if (!g || !wT_b3 || !g_x || B <= 0 || H <= 0 || W <= 0 || ((g_P != nullptr) != (x_bits != nullptr)))
+                     const float* g_P, const uint32_t* x_bits, const void* wT2_b3, float* g_x2, void* stream) {
+  if (!g || !wT_b3 || !g_x || B <= 0 || H <= 0 || W <= 0 || ((g_P != nullptr) != (x_bits != nullptr)) ||
+      ((wT2_b3 != nullptr) != (g_x2 != nullptr)))
     return EVF_EINVAL;
   // Samples per block (the 54 KiB of split weights are staged once per block): several only when the whole grid
   // then is ONE round of the 256 CUs (B = 8 at 128 x 128: 256 blocks x 2 tiles, 1 % faster than 512 x 1); with more
@@ -269,20 +300,29 @@ static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, in
   }
   if (f32in)
     hipLaunchKernelGGL(k_conv_dgrad_b3_lds<true>, grid, block, lds, EVF_STREAM(stream), (const uint4*)g, plane_stride,
-                       (const uint4*)wT_b3, g_x, accumulate, B, H, W, g_P, x_bits);
+                       (const uint4*)wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, (const uint4*)wT2_b3, g_x2);
   else
     hipLaunchKernelGGL(k_conv_dgrad_b3_lds<false>, grid, block, lds, EVF_STREAM(stream), (const uint4*)g, plane_stride,
-                       (const uint4*)wT_b3, g_x, accumulate, B, H, W, g_P, x_bits);
+                       (const uint4*)wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, (const uint4*)wT2_b3, g_x2);
   return evf_status();
 }
 
 extern "C" int evf_conv_dgrad_b3(const void* g_split, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W,
                                  const float* g_P, const uint32_t* x_bits, void* stream) {
-  return dg_launch(g_split, 0, wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, stream);
+  return dg_launch(g_split, 0, wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, nullptr, nullptr, stream);
 }
 
 // the same from the fp32 gradient g_cur [B,H,W,32]: split on the fly, bit-identical result
 extern "C" int evf_conv_dgrad_b3_f32(const float* g_cur, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W,
                                      const float* g_P, const uint32_t* x_bits, void* stream) {
-  return dg_launch(g_cur, 1, wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, stream);
+  return dg_launch(g_cur, 1, wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, nullptr, nullptr, stream);
+}
+
+// Both input gradients of a recurrent cell from one pass over g_cur: g_x (+)= conv^T(g, W_ff) as above and
+// g_x2 = conv^T(g, W_rec) (written: it is dL/d(previous output spikes), spiking_submodules.py:530).
+extern "C" int evf_conv_dgrad_b3_f32_pair(const float* g_cur, const void* wT_b3, float* g_x, int accumulate, const void* wT2_b3,
+                                          float* g_x2, int B, int H, int W, const float* g_P, const uint32_t* x_bits,
+                                          void* stream) {
+  if (!wT2_b3 || !g_x2) return EVF_EINVAL;
+  return dg_launch(g_cur, 1, wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, wT2_b3, g_x2, stream);
 }

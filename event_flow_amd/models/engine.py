@@ -38,6 +38,7 @@ def _f32(shape, dev):
 
 # the input-gradient kernel takes the fp32 g_cur and splits it while staging (128 instead of 192 B/pixel written and read)
 F32_DGRAD = os.environ.get("EVF_F32_DGRAD", "1") != "0"
+PAIR_DGRAD = os.environ.get("EVF_PAIR_DGRAD", "1") != "0"  # ff + rec input gradients of a recurrent cell in one launch
 
 
 class _Window:
@@ -456,13 +457,20 @@ class FireNetEngine:
                 acc_a = 1 if win.gz_has[i - 1] else 0
                 if self.precision == "bf16x3":
                     dg, gsrc = ("evf_conv_dgrad_b3_f32", win.g_cur) if F32_DGRAD else ("evf_conv_dgrad_b3", win.g_split)
-                    _lib.call(dg, _lib.ptr(gsrc), _lib.ptr(self._packed[(i, "ff", "b3t")]), _lib.ptr(ga),
-                              acc_a, B, H, W, _lib.ptr(win.gP) if plif else None, _lib.ptr(in_bits) if plif else None)
-                    if rec_grad:
+                    if rec_grad and F32_DGRAD and PAIR_DGRAD:  # both input gradients of the recurrent cell in one launch
                         gb = win.buf(win.gz, i)
-                        _lib.call(dg, _lib.ptr(gsrc), _lib.ptr(self._packed[(i, "rec", "b3t")]),
-                                  _lib.ptr(gb), 0, B, H, W, None, None)
+                        _lib.call("evf_conv_dgrad_b3_f32_pair", _lib.ptr(gsrc), _lib.ptr(self._packed[(i, "ff", "b3t")]),
+                                  _lib.ptr(ga), acc_a, _lib.ptr(self._packed[(i, "rec", "b3t")]), _lib.ptr(gb), B, H, W,
+                                  _lib.ptr(win.gP) if plif else None, _lib.ptr(in_bits) if plif else None)
                         win.gz_has[i] = True
+                    else:
+                        _lib.call(dg, _lib.ptr(gsrc), _lib.ptr(self._packed[(i, "ff", "b3t")]), _lib.ptr(ga),
+                                  acc_a, B, H, W, _lib.ptr(win.gP) if plif else None, _lib.ptr(in_bits) if plif else None)
+                        if rec_grad:
+                            gb = win.buf(win.gz, i)
+                            _lib.call(dg, _lib.ptr(gsrc), _lib.ptr(self._packed[(i, "rec", "b3t")]),
+                                      _lib.ptr(gb), 0, B, H, W, None, None)
+                            win.gz_has[i] = True
                 elif rec_grad:
                     gb = win.buf(win.gz, i)
                     _lib.call("evf_conv_dgrad", _lib.ptr(win.g_cur), _lib.ptr(self._packed[(i, "ff", 1)]), _lib.ptr(ga), acc_a,

@@ -231,6 +231,11 @@ int evf_conv_dgrad_b3(const void* g_split, const void* wT_b3, float* g_x, int ac
  * happens while the halo is staged, the result is bit-identical; 128 instead of 192 B/pixel on both sides. */
 int evf_conv_dgrad_b3_f32(const float* g_cur, const void* wT_b3, float* g_x, int accumulate,
                           int B, int H, int W, const float* g_P, const uint32_t* x_bits, void* stream);
+/* ... and for a recurrent cell both input gradients in one launch: g_x (+)= conv^T(g_cur, W_ff) as above,
+ * g_x2 = conv^T(g_cur, W_rec) (written) -- dL/d(previous output spikes), models/spiking_submodules.py:530. */
+int evf_conv_dgrad_b3_f32_pair(const float* g_cur, const void* wT_b3, float* g_x, int accumulate,
+                               const void* wT2_b3, float* g_x2, int B, int H, int W,
+                               const float* g_P, const uint32_t* x_bits, void* stream);
 
 /* PLIF cells (models/spiking_submodules.py:129-227, :554-657): LIF + a per-channel
  * pre-synaptic trace pt' = pt*s(leak_pt) + (1-s(leak_pt))*AvgPool3x3(mean_c|input|),
