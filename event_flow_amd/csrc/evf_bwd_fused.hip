@@ -58,11 +58,25 @@ __device__ __forceinline__ float fb_surrogate(int kind, float x, float width) {
 
 struct FbStage {
   float4 gz, gv, vo, vp;
+  float f0, f1, q0, q1;  // TOP: flow and dL/dflow of the pixel (x, y components)
+  uint32_t zo;           // TOP: the layer's own output spikes (input of the prediction head)
   uint32_t zw;
   uint32_t px, pz, pin;  // one word of the x / z_prev bit planes (threads < 3*32*FB_NW) + in-image mask
 };
 
-template <bool REC>
+// TOP: the (non-recurrent) layer under the 1x1 tanh prediction head (models/model.py:197-199, :265).  The head's
+// backward (evf_pred_bwd) runs inside this kernel: per pixel gpre = g_flow * (1 - flow^2); the layer's dL/d(spikes)
+// row is gpre_x * Wp[0][c] + gpre_y * Wp[1][c] (never written to HBM), and dWp[o][c] += gpre_o * z[c], db[o] += gpre_o.
+struct FbTop {
+  const float* flow;    // [B,2,H,W] tanh output of the head
+  const float* g_flow;  // [B,2,H,W]
+  const float* pred_w;  // [2][32]
+  const uint32_t* z_out;  // [B,H,W] this layer's output spikes
+  float* dw;            // [2][32] accumulated
+  float* db;            // [2]     accumulated
+};
+
+template <bool REC, bool TOP>
 __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     const float4* __restrict__ g_z_out, const float4* __restrict__ g_v_out, const float4* __restrict__ v_out,
     const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev, const uint32_t* __restrict__ xT,
@@ -70,7 +84,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     int W, int nchunk, long nunits, int hard_reset, int surrogate, float width, int accumulate,
     float4* __restrict__ g_cur, uint2* __restrict__ g_split, float4* __restrict__ g_v_prev,
     float* __restrict__ g_leak, float* __restrict__ g_thresh, float* __restrict__ slab_ff,
-    float* __restrict__ slab_rec) {
+    float* __restrict__ slab_rec, FbTop top) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   unsigned short* s_b = (unsigned short*)smem_raw;           // [2][3][FB_CW*32] bf16 (region of FB_R0 bytes)
   uint32_t* s_px = (uint32_t*)(smem_raw + FB_R0);             // [2][3][32][FB_NW]
@@ -97,6 +111,11 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     inv_oml[k] = 1.0f / oml[k];  // per-channel constant: no division in the element loop
   }
   float sl[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
+  float pwa[4] = {0, 0, 0, 0}, pwb[4] = {0, 0, 0, 0}, dwa[4] = {0, 0, 0, 0}, dwb[4] = {0, 0, 0, 0}, dba = 0.f, dbb = 0.f;
+  if (TOP) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pwa[k] = top.pred_w[4 * cg + k], pwb[k] = top.pred_w[C32 + 4 * cg + k];
+  }
 
   // Units are dealt round-robin: block x takes units x, x + gridDim.x, ...  At any moment the
   // resident blocks then stream one contiguous region (consecutive 8 KiB units), which spreads
@@ -133,7 +152,14 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     const int pc = min(p, cw - 1);
     const long ge = (pix0 + pc) * 8 + cg;
     s.vo = v_out[ge];
-    s.gz = pgz[ge];
+    if (TOP) {
+      const long hw = (long)H * W, q = (long)y * W + x0 + pc;
+      s.f0 = top.flow[(long)b * 2 * hw + q], s.f1 = top.flow[((long)b * 2 + 1) * hw + q];
+      s.q0 = top.g_flow[(long)b * 2 * hw + q], s.q1 = top.g_flow[((long)b * 2 + 1) * hw + q];
+      s.zo = top.z_out[pix0 + pc];
+    } else {
+      s.gz = pgz[ge];
+    }
     s.gv = pgv[ge];
     s.vp = pvp[ge];
     s.zw = pzw[z_prev ? pix0 + pc : 0];
@@ -152,7 +178,25 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     unsigned short* sb = s_b + buf * (3 * FB_CW * C32);
     const bool ok = p < cw && k < nu;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 gz4 = has_gz ? s.gz : z4, gv4 = has_gv ? s.gv : z4, vp4 = has_vp ? s.vp : z4;
+    float gp0 = 0.f, gp1 = 0.f;
+    if (TOP) {
+      gp0 = s.q0 * (1.0f - s.f0 * s.f0);  // tanh' (evf_pred_bwd)
+      gp1 = s.q1 * (1.0f - s.f1 * s.f1);
+    }
+    const float4 gz4 = TOP ? make_float4(gp0 * pwa[0] + gp1 * pwb[0], gp0 * pwa[1] + gp1 * pwb[1], gp0 * pwa[2] + gp1 * pwb[2],
+                                         gp0 * pwa[3] + gp1 * pwb[3])
+                           : (has_gz ? s.gz : z4);
+    const float4 gv4 = has_gv ? s.gv : z4, vp4 = has_vp ? s.vp : z4;
+    if (TOP && ok) {
+      const uint32_t zo = s.zo >> (4 * cg);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool on = (zo >> c) & 1u;
+        dwa[c] += on ? gp0 : 0.f;
+        dwb[c] += on ? gp1 : 0.f;
+      }
+      if (cg == 0) dba += gp0, dbb += gp1;
+    }
     const float vo[4] = {s.vo.x, s.vo.y, s.vo.z, s.vo.w}, gz[4] = {gz4.x, gz4.y, gz4.z, gz4.w};
     const float gvo[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, vp[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
     const uint32_t zw = (has_zw ? s.zw : 0u) >> (4 * cg);
@@ -354,6 +398,41 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
       evf_atomic_add(g_thresh + c, v);
     }
   }
+  if (TOP) {  // prediction-head weight / bias gradients, reduced the same way
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        dwa[c] += __shfl_xor(dwa[c], o, 64);
+        dwb[c] += __shfl_xor(dwb[c], o, 64);
+      }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      dba += __shfl_xor(dba, o, 64);
+      dbb += __shfl_xor(dbb, o, 64);
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        s_red[(0 * 8 + wv) * C32 + 4 * lane + c] = dwa[c];
+        s_red[(1 * 8 + wv) * C32 + 4 * lane + c] = dwb[c];
+      }
+    }
+    float* s_b2 = (float*)smem_raw;  // operand buffers are free now
+    if (lane == 0) s_b2[2 * wv] = dba, s_b2[2 * wv + 1] = dbb;
+    __syncthreads();
+    if (tid < 64) {
+      const int which = tid >> 5, c = tid & 31;
+      float v = 0.f;
+      for (int w = 0; w < 8; ++w) v += s_red[(which * 8 + w) * C32 + c];
+      evf_atomic_add(top.dw + which * C32 + c, v);
+    } else if (tid < 66) {
+      float v = 0.f;
+      for (int w = 0; w < 8; ++w) v += s_b2[2 * w + (tid - 64)];
+      evf_atomic_add(top.db + (tid - 64), v);
+    }
+  }
 }
 
 static long fb_units(int B, int H, int W) { return (long)B * H * ((W + FB_CW - 1) / FB_CW); }
@@ -361,37 +440,62 @@ static long fb_units(int B, int H, int W) { return (long)B * H * ((W + FB_CW - 1
 
 extern "C" int evf_lif_bwd_wgrad_slabs(int B, int H, int W) { return evf_cdiv(fb_units(B, H, W), FB_UNITS); }
 
-extern "C" int evf_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const float* v_out, const float* v_prev,
-                                 const uint32_t* z_prev, const uint32_t* xT, const uint32_t* zT_prev, const float* leak,
-                                 const float* thresh, int B, int H, int W, int hard_reset, int surrogate,
-                                 float act_width, float* g_cur, void* g_split, float* g_v_prev, float* g_leak,
-                                 float* g_thresh, float* slab_ff, float* slab_rec, int accumulate, void* stream) {
+static int fb_launch(const float* g_z_out, const FbTop* topp, const float* g_v_out, const float* v_out, const float* v_prev,
+                     const uint32_t* z_prev, const uint32_t* xT, const uint32_t* zT_prev, const float* leak,
+                     const float* thresh, int B, int H, int W, int hard_reset, int surrogate, float act_width,
+                     float* g_cur, void* g_split, float* g_v_prev, float* g_leak, float* g_thresh, float* slab_ff,
+                     float* slab_rec, int accumulate, void* stream) {
   if (!v_out || !xT || !leak || !thresh || (!g_cur && !g_split) || !g_v_prev || !g_leak || !g_thresh || !slab_ff || B <= 0 || H <= 0 ||
-      W <= 0 || ((zT_prev != nullptr) != (slab_rec != nullptr)))
+      W <= 0 || ((zT_prev != nullptr) != (slab_rec != nullptr)) || (topp && (g_z_out || zT_prev)))
     return EVF_EINVAL;
   const long nunits = fb_units(B, H, W);
   const int nchunk = (W + FB_CW - 1) / FB_CW;
   dim3 grid(evf_cdiv(nunits, FB_UNITS)), block(FB_THREADS);
   hipStream_t st = EVF_STREAM(stream);
-  static bool a1 = false, a2 = false;
-  if (zT_prev) {
-    if (!a2) {
-      (void)hipFuncSetAttribute((const void*)k_lif_bwd_wgrad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
-      a2 = true;
-    }
-    hipLaunchKernelGGL(k_lif_bwd_wgrad<true>, grid, block, FB_LDS, st, (const float4*)g_z_out, (const float4*)g_v_out,
-                       (const float4*)v_out, (const float4*)v_prev, z_prev, xT, zT_prev, leak, thresh, B, H, W, nchunk,
-                       nunits, hard_reset, surrogate, act_width, accumulate, (float4*)g_cur, (uint2*)g_split,
-                       (float4*)g_v_prev, g_leak, g_thresh, slab_ff, slab_rec);
-  } else {
-    if (!a1) {
-      (void)hipFuncSetAttribute((const void*)k_lif_bwd_wgrad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
-      a1 = true;
-    }
-    hipLaunchKernelGGL(k_lif_bwd_wgrad<false>, grid, block, FB_LDS, st, (const float4*)g_z_out, (const float4*)g_v_out,
-                       (const float4*)v_out, (const float4*)v_prev, z_prev, xT, (const uint32_t*)nullptr, leak, thresh, B,
-                       H, W, nchunk, nunits, hard_reset, surrogate, act_width, accumulate, (float4*)g_cur,
-                       (uint2*)g_split, (float4*)g_v_prev, g_leak, g_thresh, slab_ff, (float*)nullptr);
-  }
+  const FbTop top = topp ? *topp : FbTop{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  static bool a1 = false, a2 = false, a3 = false;
+#define FB_GO(REC_, TOP_, flag)                                                                                           \
+  do {                                                                                                                    \
+    if (!flag) {                                                                                                          \
+      (void)hipFuncSetAttribute((const void*)k_lif_bwd_wgrad<REC_, TOP_>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                FB_LDS);                                                                                  \
+      flag = true;                                                                                                        \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((k_lif_bwd_wgrad<REC_, TOP_>), grid, block, FB_LDS, st, (const float4*)g_z_out,                    \
+                       (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev, z_prev, xT, zT_prev, leak,    \
+                       thresh, B, H, W, nchunk, nunits, hard_reset, surrogate, act_width, accumulate, (float4*)g_cur,     \
+                       (uint2*)g_split, (float4*)g_v_prev, g_leak, g_thresh, slab_ff, slab_rec, top);                     \
+  } while (0)
+  if (topp)
+    FB_GO(false, true, a3);
+  else if (zT_prev)
+    FB_GO(true, false, a2);
+  else
+    FB_GO(false, false, a1);
+#undef FB_GO
   return evf_status();
+}
+
+extern "C" int evf_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const float* v_out, const float* v_prev,
+                                 const uint32_t* z_prev, const uint32_t* xT, const uint32_t* zT_prev, const float* leak,
+                                 const float* thresh, int B, int H, int W, int hard_reset, int surrogate,
+                                 float act_width, float* g_cur, void* g_split, float* g_v_prev, float* g_leak,
+                                 float* g_thresh, float* slab_ff, float* slab_rec, int accumulate, void* stream) {
+  return fb_launch(g_z_out, nullptr, g_v_out, v_out, v_prev, z_prev, xT, zT_prev, leak, thresh, B, H, W, hard_reset, surrogate,
+                   act_width, g_cur, g_split, g_v_prev, g_leak, g_thresh, slab_ff, slab_rec, accumulate, stream);
+}
+
+// The non-recurrent layer directly under the prediction head, with the head's backward (evf_pred_bwd) inside:
+// flow / g_flow [B,2,H,W], pred_w [2][32], z_out = this layer's output spikes [B,H,W]; d_pred_w [2][32] and
+// d_pred_b [2] are accumulated.  One launch and 2 x 128 B/pixel of HBM traffic less than evf_pred_bwd + evf_lif_bwd_wgrad.
+extern "C" int evf_lif_bwd_wgrad_top(const float* flow, const float* g_flow, const float* pred_w, const uint32_t* z_out,
+                                     float* d_pred_w, float* d_pred_b, const float* g_v_out, const float* v_out,
+                                     const float* v_prev, const uint32_t* z_prev, const uint32_t* xT, const float* leak,
+                                     const float* thresh, int B, int H, int W, int hard_reset, int surrogate,
+                                     float act_width, float* g_cur, void* g_split, float* g_v_prev, float* g_leak,
+                                     float* g_thresh, float* slab_ff, int accumulate, void* stream) {
+  if (!flow || !g_flow || !pred_w || !z_out || !d_pred_w || !d_pred_b) return EVF_EINVAL;
+  const FbTop top{flow, g_flow, pred_w, z_out, d_pred_w, d_pred_b};
+  return fb_launch(nullptr, &top, g_v_out, v_out, v_prev, z_prev, xT, nullptr, leak, thresh, B, H, W, hard_reset, surrogate,
+                   act_width, g_cur, g_split, g_v_prev, g_leak, g_thresh, slab_ff, nullptr, accumulate, stream);
 }

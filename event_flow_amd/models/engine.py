@@ -38,6 +38,7 @@ def _f32(shape, dev):
 
 # the input-gradient kernel takes the fp32 g_cur and splits it while staging (128 instead of 192 B/pixel written and read)
 F32_DGRAD = os.environ.get("EVF_F32_DGRAD", "1") != "0"
+TOP_FUSED = os.environ.get("EVF_TOP_FUSED", "1") != "0"  # prediction-head backward inside the top layer's fused backward
 PAIR_DGRAD = os.environ.get("EVF_PAIR_DGRAD", "1") != "0"  # ff + rec input gradients of a recurrent cell in one launch
 
 
@@ -365,10 +366,14 @@ class FireNetEngine:
         n = len(self.cells)
         layers = tape["layers"]
         nslab = _lib.load().evf_conv_wgrad_slabs(B, H, W)
-        if g_flow is not None:
+        # the prediction head's backward runs inside the fused backward of the (non-recurrent) layer below it
+        top_fused = (TOP_FUSED and g_flow is not None and self.precision == "bf16x3" and n > 1
+                     and not self.cells[n - 1].recurrent and not win.gz_has[n - 1])
+        g_flow_c = g_flow.float().contiguous() if g_flow is not None else None
+        if g_flow is not None and not top_fused:
             gz_top = win.buf(win.gz, n - 1)
             _lib.call("evf_pred_bwd", _lib.ptr(layers[n - 1][4]), _lib.ptr(tape["flow"]),
-                      _lib.ptr(g_flow.float().contiguous()), _lib.ptr(self._flat["pred.w"]), B, H, W, _lib.ptr(gz_top),
+                      _lib.ptr(g_flow_c), _lib.ptr(self._flat["pred.w"]), B, H, W, _lib.ptr(gz_top),
                       _lib.ptr(self._small(win, "pred.w")), _lib.ptr(self._small(win, "pred.b")))
             win.gz_has[n - 1] = True
         if win.g_cur is None:
@@ -383,7 +388,8 @@ class FireNetEngine:
             g_z = win.gz[i] if win.gz_has[i] else None
             g_v = win.gv[i]
             win.gz_has[i] = False
-            if g_z is None and g_v is None:
+            top = top_fused and i == n - 1
+            if g_z is None and g_v is None and not top:
                 continue  # no gradient reaches this layer at this pass
             gv_out = win.buf(win.gv, i)
             use_rec = c.recurrent and z_prev is not None
@@ -396,7 +402,16 @@ class FireNetEngine:
                 if use_rec and bool(win.slab_init.get(kr)) != bool(acc_flag):
                     # first recurrent contribution arrives later than the ff one: start its slab at zero
                     self._slab(kr, nsl, dev).zero_()
-                _lib.call("evf_lif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
+                if top:
+                    _lib.call("evf_lif_bwd_wgrad_top", _lib.ptr(tape["flow"]), _lib.ptr(g_flow_c), _lib.ptr(self._flat["pred.w"]),
+                              _lib.ptr(layers[i][4]), _lib.ptr(self._small(win, "pred.w")), _lib.ptr(self._small(win, "pred.b")),
+                              _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(in_bitsT),
+                              _lib.ptr(self._flat[f"{i}.leak"]), _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W,
+                              1 if c.hard_reset else 0, SURROGATE_ID[c.activation], self._act_width(i),
+                              _lib.ptr(win.g_cur) if (plif or F32_DGRAD) else None, _lib.ptr(win.g_split), _lib.ptr(gv_out),
+                              _lib.ptr(leak_g), _lib.ptr(thr_g), _lib.ptr(self._slab(kf, nsl, dev)), acc_flag)
+                else:
+                    _lib.call("evf_lif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
                           _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None, _lib.ptr(self._flat[f"{i}.leak"]),
                           _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
                           self._act_width(i), _lib.ptr(win.g_cur) if (plif or F32_DGRAD) else None, _lib.ptr(win.g_split),

@@ -215,6 +215,16 @@ int evf_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const float* v
                       int hard_reset, int surrogate, float act_width,
                       float* g_cur, void* g_split, float* g_v_prev, float* g_leak, float* g_thresh,
                       float* slab_ff, float* slab_rec, int accumulate, void* stream);
+/* The same for the non-recurrent layer directly under the prediction head (models/model.py:197-199, :265), with the
+ * head's backward (evf_pred_bwd) inside: flow / g_flow [B,2,H,W], pred_w [2][32], z_out [B,H,W] = this layer's output
+ * spikes; d_pred_w [2][32] and d_pred_b [2] are accumulated.  The layer's dL/d(spikes) rows are formed in registers. */
+int evf_lif_bwd_wgrad_top(const float* flow, const float* g_flow, const float* pred_w, const uint32_t* z_out,
+                          float* d_pred_w, float* d_pred_b, const float* g_v_out, const float* v_out,
+                          const float* v_prev, const uint32_t* z_prev, const uint32_t* xT,
+                          const float* leak, const float* thresh, int B, int H, int W,
+                          int hard_reset, int surrogate, float act_width,
+                          float* g_cur, void* g_split, float* g_v_prev, float* g_leak, float* g_thresh,
+                          float* slab_ff, int accumulate, void* stream);
 
 /* Input-gradient conv on the exact bf16 split: g_split = three bf16 planes
  * [3][B,H,W,32] (g = hi + mid + lo, optional output of evf_lif_bwd_wgrad; g_cur may then
