@@ -47,6 +47,7 @@ NETWORK_SIGNATURES = {
     "evf_conv_lif_fwd": [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P],
     "evf_pack_conv_weight_b3": [P, I, I, P, P],
     "evf_conv_lif_fwd_b3": [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P],
+    "evf_conv_lif_fwd_b3_pred": [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P, P],
     "evf_lif_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P],
     "evf_lif_bwd_wgrad_slabs": [I, I, I],
     "evf_head_lif_bwd_wgrad_slabs": [I, I, I],
@@ -148,6 +149,7 @@ _prof = None
 _PROF_VARIANT = {
     "evf_conv_lif_fwd": lambda a: "rec" if a[2] is not None else "ff",
     "evf_conv_lif_fwd_b3": lambda a: "rec" if a[2] is not None else "ff",
+    "evf_conv_lif_fwd_b3_pred": lambda a: "rec" if a[2] is not None else "ff",
     "evf_conv_dgrad": lambda a: "two" if a[4] is not None else "one",
     "evf_lif_bwd_wgrad": lambda a: "rec" if a[6] is not None else "ff",
 }

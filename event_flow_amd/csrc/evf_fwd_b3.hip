@@ -94,6 +94,14 @@ struct PlifArgs {
   float* P_out;          // [B,H,W] pooled pre-synaptic activity (saved for the backward)
 };
 
+// Prediction head (models/model.py:197-199, :265) fused into the epilogue of the layer it reads: flow = tanh(W z + b)
+// from the spike word of each pixel, same summation order as evf_pred_fwd.  All NULL: no head here.
+struct PredArgs {
+  const float* w;     // [2][32]
+  const float* bias;  // [2]
+  float* flow;        // [B,2,H,W]
+};
+
 template <bool REC, bool PLIF>
 __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* __restrict__ x, const uint4* __restrict__ wff,
                                                          const uint4* __restrict__ wrec,
@@ -103,17 +111,25 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
                                                          const uint32_t* __restrict__ z_prev, int B, int H, int W,
                                                          int hard_reset, float* __restrict__ v_out,
                                                          uint32_t* __restrict__ z_out,
-                                                         uint32_t* __restrict__ zT_out, PlifArgs pl) {
+                                                         uint32_t* __restrict__ zT_out, PlifArgs pl, PredArgs pr) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint4* s_w = (uint4*)smem_raw;    // NFRAG*64
   uint4* s_lut = s_w + NFRAG * 64;  // 256
   uint32_t* s_x = (uint32_t*)(s_lut + 256);
   uint32_t* s_z = s_x + HALO_H * HALO_W;
   float* s_P = (float*)(s_z + HALO_H * HALO_W);  // TH*TW (PLIF)
+  float* s_pw = s_P + TH * TW;                   // 2*32 + 2 prediction-head weights and bias
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
 
   for (int u = wv; u < NFRAG; u += FW_WAVES) b3_glds16(wff + u * 64 + lane, s_w + u * 64);
+  {
+    const float* psrc = pr.w ? pr.w : leak;  // no load under a branch: dummy source, the values are unused then
+    const float* bsrc = pr.w ? pr.bias : leak;
+    const float pwv = psrc[min(tid, 2 * C32 - 1) % (pr.w ? 2 * C32 : C32)], pbv = bsrc[tid & 1];
+    if (tid < 2 * C32) s_pw[tid] = pwv;
+    if (tid < 2) s_pw[2 * C32 + tid] = pbv;
+  }
   if (tid < 256) {  // byte -> 8 x bf16 {0, 1.0}
     const uint32_t t = tid;
     auto pr = [&](int e) { return ((t >> e) & 1u) * 0x3F80u | (((t >> (e + 1)) & 1u) * 0x3F80u) << 16; };
@@ -261,7 +277,22 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
       }
       {
         const int rr = j & 15, cc = (rr & 3) + 8 * (rr >> 2);  // lane j < 16 of each half holds the word of pixel (rr, kg)
-        if (j < 16 && (FULL || (row < H && x0 + cc + 4 * kg < W))) z_p[cc] = myword;
+        const bool pixok = j < 16 && (FULL || (row < H && x0 + cc + 4 * kg < W));
+        if (pixok) z_p[cc] = myword;
+        if (pr.w) {  // (block-uniform) the head on this pixel's spike word
+          float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+          for (int c = 0; c < C32; ++c) {
+            const float z = (float)((myword >> c) & 1u);
+            s0 += z * s_pw[c];
+            s1 += z * s_pw[C32 + c];
+          }
+          if (pixok) {
+            const long hw = (long)H * W, q = (long)row * W + x0 + cc + 4 * kg;
+            pr.flow[(long)b * 2 * hw + q] = tanhf(s0 + s_pw[2 * C32]);
+            pr.flow[((long)b * 2 + 1) * hw + q] = tanhf(s1 + s_pw[2 * C32 + 1]);
+          }
+        }
       }
       if (zT_out) {  // channel-major bit planes [B][H][32][ceil(W/32)]
         plane |= __shfl_xor(plane, 32, 64);
@@ -278,11 +309,12 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
 static int launch_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec, const float* leak,
                          const float* thresh, const float* v_prev, const uint32_t* z_prev, int B, int H, int W,
                          int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out, const PlifArgs* plif,
-                         void* stream) {
+                         void* stream, const PredArgs* pred = nullptr) {
   dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(FW_THREADS);
   hipStream_t st = EVF_STREAM(stream);
-  const size_t lds = WB3_BYTES + 256 * 16 + 2 * HALO_H * HALO_W * 4 + TH * TW * 4;
+  const size_t lds = WB3_BYTES + 256 * 16 + 2 * HALO_H * HALO_W * 4 + TH * TW * 4 + (2 * C32 + 2) * 4;
   PlifArgs pa = plif ? *plif : PlifArgs{nullptr, nullptr, nullptr, nullptr, nullptr};
+  PredArgs pd = pred ? *pred : PredArgs{nullptr, nullptr, nullptr};
 #define EVF_FWD(REC_, PLIF_)                                                                                           \
   do {                                                                                                                 \
   if (lds > 65536) {                                                                                                   \
@@ -294,7 +326,8 @@ static int launch_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_re
     }                                                                                                                  \
   }                                                                                                                    \
   hipLaunchKernelGGL((k_conv_lif_fwd_b3<REC_, PLIF_>), grid, block, lds, st, x, (const uint4*)wb_ff,                   \
-                     (const uint4*)wb_rec, leak, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out, pa); \
+                     (const uint4*)wb_rec, leak, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out, pa,   \
+                     pd);                                                                                              \
   } while (0)
   if (plif) {
     if (wb_rec) EVF_FWD(true, true); else EVF_FWD(false, true);
@@ -311,6 +344,19 @@ extern "C" int evf_conv_lif_fwd_b3(const uint32_t* x, const void* wb_ff, const v
   if (!x || !wb_ff || !leak || !thresh || !v_out || !z_out || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
   return launch_fwd_b3(x, wb_ff, wb_rec, leak, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out, nullptr,
                        stream);
+}
+
+// evf_conv_lif_fwd_b3 for the layer under the prediction head, with the head (evf_pred_fwd) in its epilogue:
+// pred_w [2][32], pred_b [2], flow [B,2,H,W] (written).
+extern "C" int evf_conv_lif_fwd_b3_pred(const uint32_t* x, const void* wb_ff, const void* wb_rec, const float* leak,
+                                        const float* thresh, const float* v_prev, const uint32_t* z_prev, int B, int H,
+                                        int W, int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out,
+                                        const float* pred_w, const float* pred_b, float* flow, void* stream) {
+  if (!x || !wb_ff || !leak || !thresh || !v_out || !z_out || !pred_w || !pred_b || !flow || B <= 0 || H <= 0 || W <= 0)
+    return EVF_EINVAL;
+  const PredArgs pd{pred_w, pred_b, flow};
+  return launch_fwd_b3(x, wb_ff, wb_rec, leak, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out, nullptr,
+                       stream, &pd);
 }
 
 extern "C" int evf_conv_plif_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec, const float* leak_v,

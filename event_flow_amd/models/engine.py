@@ -38,6 +38,7 @@ def _f32(shape, dev):
 
 # the input-gradient kernel takes the fp32 g_cur and splits it while staging (128 instead of 192 B/pixel written and read)
 F32_DGRAD = os.environ.get("EVF_F32_DGRAD", "1") != "0"
+PRED_FUSED = os.environ.get("EVF_PRED_FUSED", "1") != "0"  # prediction head in the epilogue of the last layer's forward
 TOP_FUSED = os.environ.get("EVF_TOP_FUSED", "1") != "0"  # prediction-head backward inside the top layer's fused backward
 PAIR_DGRAD = os.environ.get("EVF_PAIR_DGRAD", "1") != "0"  # ff + rec input gradients of a recurrent cell in one launch
 
@@ -289,6 +290,7 @@ class FireNetEngine:
         layers = []
         new_states = []
         in_bits = in_bitsT = None
+        flow = None  # written by the last layer's kernel when the prediction head is fused into it
         target = self._final_target if self._final_hint else None
         self._final_hint = False
         if target is not None:
@@ -336,17 +338,26 @@ class FireNetEngine:
             else:
                 fmt = "b3" if self.precision == "bf16x3" else 0
                 wrec = self._packed[(i, "rec", fmt)] if c.recurrent else None
-                _lib.call("evf_conv_lif_fwd_b3" if fmt == "b3" else "evf_conv_lif_fwd", _lib.ptr(in_bits),
-                          _lib.ptr(self._packed[(i, "ff", fmt)]), _lib.ptr(wrec),
-                          _lib.ptr(leak), _lib.ptr(thresh), _lib.ptr(v_prev), _lib.ptr(z_prev), B, H, W,
-                          1 if c.hard_reset else 0, _lib.ptr(v_out), _lib.ptr(z_out), _lib.ptr(zT_out))
+                if fmt == "b3" and i == len(self.cells) - 1 and PRED_FUSED:
+                    # last layer: the prediction head runs in this kernel's epilogue
+                    flow = _f32((B, 2, H, W), dev)
+                    _lib.call("evf_conv_lif_fwd_b3_pred", _lib.ptr(in_bits), _lib.ptr(self._packed[(i, "ff", fmt)]), _lib.ptr(wrec),
+                              _lib.ptr(leak), _lib.ptr(thresh), _lib.ptr(v_prev), _lib.ptr(z_prev), B, H, W,
+                              1 if c.hard_reset else 0, _lib.ptr(v_out), _lib.ptr(z_out), _lib.ptr(zT_out),
+                              _lib.ptr(self._flat["pred.w"]), _lib.ptr(self._flat["pred.b"]), _lib.ptr(flow))
+                else:
+                    _lib.call("evf_conv_lif_fwd_b3" if fmt == "b3" else "evf_conv_lif_fwd", _lib.ptr(in_bits),
+                              _lib.ptr(self._packed[(i, "ff", fmt)]), _lib.ptr(wrec),
+                              _lib.ptr(leak), _lib.ptr(thresh), _lib.ptr(v_prev), _lib.ptr(z_prev), B, H, W,
+                              1 if c.hard_reset else 0, _lib.ptr(v_out), _lib.ptr(z_out), _lib.ptr(zT_out))
             if record:
                 layers.append((in_bits, v_prev, z_prev, v_out, z_out, in_bitsT, zT_prev, pt_prev, pt_out, P_out))
             in_bits, in_bitsT = z_out, zT_out
             new_states.append((v_out, z_out, zT_out, pt_out) if plif else (v_out, z_out, zT_out))
-        flow = _f32((B, 2, H, W), dev)
-        _lib.call("evf_pred_fwd", _lib.ptr(in_bits), _lib.ptr(self._flat["pred.w"]), _lib.ptr(self._flat["pred.b"]), B, H, W,
-                  _lib.ptr(flow))
+        if flow is None:
+            flow = _f32((B, 2, H, W), dev)
+            _lib.call("evf_pred_fwd", _lib.ptr(in_bits), _lib.ptr(self._flat["pred.w"]), _lib.ptr(self._flat["pred.b"]), B, H, W,
+                      _lib.ptr(flow))
         tape = {"x_in": x_in, "layers": layers, "flow": flow} if record else None
         return flow, tape, new_states
 

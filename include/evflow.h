@@ -187,6 +187,12 @@ int evf_conv_lif_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec
                         const float* leak, const float* thresh,
                         const float* v_prev, const uint32_t* z_prev, int B, int H, int W,
                         int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out, void* stream);
+/* The same for the layer under the prediction head, with the head (evf_pred_fwd: models/model.py:197-199, :265) in its
+ * epilogue: pred_w [2][32], pred_b [2], flow [B,2,H,W] (written). */
+int evf_conv_lif_fwd_b3_pred(const uint32_t* x, const void* wb_ff, const void* wb_rec, const float* leak,
+                             const float* thresh, const float* v_prev, const uint32_t* z_prev, int B, int H, int W,
+                             int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out,
+                             const float* pred_w, const float* pred_b, float* flow, void* stream);
 
 /* Neuron backward (autograd of :103-126 / :523-551 with the surrogate of
  * spiking_util.py:88-93).  Per element:
