@@ -147,10 +147,12 @@ def iwe_warp_bandwidth(dev, B, reps=20):
             "frac_of_hbm_peak": alg_bytes / ms / 1e6 / HBM_PEAK}
 
 
-_KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3_lds", "evf_lif_bwd_wgrad/ff": "k_lif_bwd_wgrad<false>",
-              "evf_lif_bwd_wgrad/rec": "k_lif_bwd_wgrad<true>", "evf_conv_lif_fwd_b3/ff": "k_conv_lif_fwd_b3<false, false>",
+_KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3_lds<false>", "evf_conv_dgrad_b3_f32": "k_conv_dgrad_b3_lds<true>", "evf_conv_dgrad_b3_f32_pair": "k_conv_dgrad_b3_lds<true>",
+              "evf_conv_lif_fwd_b3_pred/ff": "k_conv_lif_fwd_b3<false, false>",
+              "evf_lif_bwd_wgrad/ff": "k_lif_bwd_wgrad<false, false>", "evf_lif_bwd_wgrad_top": "k_lif_bwd_wgrad<false, true>",
+              "evf_lif_bwd_wgrad/rec": "k_lif_bwd_wgrad<true, false>", "evf_conv_lif_fwd_b3/ff": "k_conv_lif_fwd_b3<false, false>",
               "evf_conv_lif_fwd_b3/rec": "k_conv_lif_fwd_b3<true, false>", "evf_head_lif_fwd": "k_head_lif_fwd",
-              "evf_head_lif_bwd_wgrad": "k_lif_bwd<2>", "evf_conv_dgrad/one": "k_conv_dgrad<false>",
+              "evf_head_lif_bwd_wgrad": "k_head_bwd_mfma", "evf_conv_dgrad/one": "k_conv_dgrad<false>",
               "evf_conv_dgrad/two": "k_conv_dgrad<true>", "evf_conv_lif_fwd/ff": "k_conv_lif_fwd<false>",
               "evf_conv_lif_fwd/rec": "k_conv_lif_fwd<true>", "evf_conv_wgrad_bits": "k_conv_wgrad_bits"}
 
@@ -265,7 +267,8 @@ def main():
     if use_graph:
         model.use_static_states(True)  # recurrent state must live at fixed addresses across replays
     pool = make_windows(dp.rank, 2, dev)
-    names = ["evf_conv_lif_fwd", "evf_conv_lif_fwd_b3", "evf_conv_dgrad", "evf_conv_dgrad_b3", "evf_conv_wgrad_bits", "evf_lif_bwd_wgrad",
+    names = ["evf_conv_lif_fwd", "evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_conv_dgrad", "evf_conv_dgrad_b3",
+             "evf_conv_dgrad_b3_f32", "evf_conv_dgrad_b3_f32_pair", "evf_conv_wgrad_bits", "evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad_top",
              "evf_lif_bwd", "evf_head_lif_bwd_wgrad", "evf_head_lif_fwd", "evf_head_wgrad", "evf_pred_bwd", "evf_reduce_slabs", "evf_reduce_slabs_multi", "evf_cm_loss_fwd",
              "evf_cm_loss_bwd"]
 
@@ -345,14 +348,21 @@ def main():
             ("evf_conv_lif_fwd_b3", "ff"): (CONV_FLOP * npix, 272 * npix), ("evf_conv_lif_fwd_b3", "rec"): (2 * CONV_FLOP * npix, 272 * npix),
             ("evf_conv_dgrad", "one"): (CONV_FLOP * npix, 256 * npix), ("evf_conv_dgrad", "two"): (2 * CONV_FLOP * npix, 384 * npix),
             ("evf_conv_dgrad_b3", ""): (CONV_FLOP * npix, 320 * npix),
+            # fp32 g_cur in (128 B/px, halo not counted), fp32 gradient out; the pair form writes two outputs
+            ("evf_conv_dgrad_b3_f32", ""): (CONV_FLOP * npix, 256 * npix), ("evf_conv_dgrad_b3_f32_pair", ""): (2 * CONV_FLOP * npix, 384 * npix),
+            ("evf_conv_lif_fwd_b3_pred", "ff"): (CONV_FLOP * npix, 280 * npix),
+            # top layer: g_v, v', v in, g_cur + g_v_prev out, flow / g_flow 16 B/px, spike words
+            ("evf_lif_bwd_wgrad_top", ""): (CONV_FLOP * npix, 668 * npix),
             ("evf_conv_wgrad_bits", ""): (CONV_FLOP * npix, 132 * npix),
-            ("evf_lif_bwd_wgrad", "ff"): (CONV_FLOP * npix, 840 * npix), ("evf_lif_bwd_wgrad", "rec"): (2 * CONV_FLOP * npix, 844 * npix),
+            # g_z, g_v, v', v in; g_cur (fp32, split later by the dgrad) + g_v_prev out; spike words / planes
+            ("evf_lif_bwd_wgrad", "ff"): (CONV_FLOP * npix, 776 * npix), ("evf_lif_bwd_wgrad", "rec"): (2 * CONV_FLOP * npix, 780 * npix),
             ("evf_lif_bwd", ""): (0, 772 * npix), ("evf_head_lif_bwd_wgrad", ""): (2 * 18 * 32 * npix, 652 * npix),
             ("evf_head_lif_fwd", ""): (2 * 18 * 32 * npix, 272 * npix),
         }
         # which roofline bounds the kernel: the fp32-MFMA convs are matrix-core bound; the bf16x3 kernels
         # need 1/5 of those cycles and are HBM bound, like the elementwise ones
-        hbm_bound = {"evf_conv_lif_fwd_b3", "evf_conv_dgrad_b3", "evf_lif_bwd_wgrad", "evf_lif_bwd", "evf_head_lif_fwd",
+        hbm_bound = {"evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_conv_dgrad_b3", "evf_conv_dgrad_b3_f32",
+                     "evf_conv_dgrad_b3_f32_pair", "evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad_top", "evf_lif_bwd", "evf_head_lif_fwd",
                      "evf_head_lif_bwd_wgrad"}
         kernels = {}
         for key, ms in prof.items():
