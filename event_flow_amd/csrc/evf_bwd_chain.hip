@@ -10,6 +10,13 @@
 // (layer, pass) costs one launch instead of two.  Same arithmetic as the separate kernels: exact 3-way bf16 splits of
 // the fp32 operands, fp32 accumulation, the six-term product for the real x real input gradient.
 //
+// STATUS: correct (bit-identical g_cur / g_v_prev / g_x2, weight gradients to 3e-7 of the separate kernels) but not
+// yet faster: 53 / 68 / 75 us (plain / with the recurrent input gradient / recurrent lower layer) against
+// 51 / 64 / 58 us for evf_conv_dgrad_b3_f32[_pair] + evf_lif_bwd_wgrad at B=8, 128x128 -- its phases (stage halo,
+// MFMAs, load operands, neuron backward, re-layout, MFMAs) run back to back, where the separate fused backward streams
+// its units through a double-buffered pipeline, and the recurrent form spills (4 x 16 persistent accumulators).  The
+// engine therefore uses it only with EVF_CHAIN=1; tests/test_gpu_network.py keeps it honest.
+//
 // Block = 8 waves = an 8-row x 32-pixel tile (wave = row), persistent over samples like the input-gradient kernel.
 // LDS: split weights 54 KiB | halo image of g_cur(l) 3 x 352 x 64 B = 66 KiB, overlaid after the input-gradient MFMAs
 // by the split g_cur(l-1) tile in weight-gradient operand order (48 KiB) | spike bit planes of the tile + halo
