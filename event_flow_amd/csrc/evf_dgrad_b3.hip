@@ -122,7 +122,9 @@ typedef __attribute__((address_space(1))) const void dl_glb_void;
 // F32IN: the gradient arrives as ONE fp32 tensor [B,H,W,32] (g_cur of evf_lif_bwd_wgrad); the exact 3-way bf16
 // split happens here while the halo is staged through registers (same split, so the result is bit-identical to the
 // pre-split form) -- the producer writes 128 instead of 192 B/pixel and this kernel reads 128 instead of 192.
-template <bool F32IN>
+// ACC / PLIF: compile-time, so that a launch that neither accumulates nor carries the PLIF term issues none of the 48
+// per-lane operand loads (as dummy loads they still cost the texture addresser 16 cycles each: 6 k cycles per tile).
+template <bool F32IN, bool ACC, bool PLIF>
 __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4* __restrict__ gs, long plane_stride,
                                                                     const uint4* __restrict__ wt, float* __restrict__ gx,
                                                                     int accumulate, int B, int H, int W,
@@ -196,14 +198,9 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
     for (int r = 0; r < 16; ++r) {
       const int col = min(x0 + dg_row(r, lane), W - 1);
       const long pix = ((long)b * H + yq) * W + col;
-      // branch-free: a (uniform) branch around a load costs a basic block and a drained vmcnt per iteration; when the
-      // operand is absent every lane reads the same dummy word instead
-      const float o = *(accumulate ? gx + pix * C32 + i : gx);
-      const float pp = *(gPb ? gPb + pix : gx);
-      const uint32_t xw = *(gPb ? xbits + pix : (const uint32_t*)gx);
-      oldv[r] = accumulate ? o : 0.f;
-      pv[r] = gPb ? pp : 0.f;
-      xb[r] = gPb ? xw : 0u;
+      oldv[r] = ACC ? gx[pix * C32 + i] : 0.f;
+      pv[r] = PLIF ? gPb[pix] : 0.f;
+      xb[r] = PLIF ? xbits[pix] : 0u;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -291,19 +288,37 @@ static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, in
     if (B % z == 0 && tiles * z <= 256 && tiles * z >= 192) zb = z;
   dim3 grid(evf_cdiv(W, 32), evf_cdiv(H, DG_ROWS), zb), block(DG_ROWS * 64);
   const long plane_stride = (long)B * H * W * 4;  // uint4 per term plane: npix * 32 bf16 / 8
-  static bool attr = false;
   const size_t lds = (size_t)(NFRAG * 64 + 3 * DL_HPP * 4) * sizeof(uint4);  // 120 KiB: one block per CU
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_conv_dgrad_b3_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)k_conv_dgrad_b3_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
+  const bool acc = accumulate != 0, plif = g_P != nullptr;
+#define DG_GO(F_, A_, P_)                                                                                                  \
+  do {                                                                                                                     \
+    static bool attr = false;                                                                                              \
+    if (!attr) {                                                                                                           \
+      (void)hipFuncSetAttribute((const void*)k_conv_dgrad_b3_lds<F_, A_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (int)lds);                                                                                 \
+      attr = true;                                                                                                         \
+    }                                                                                                                      \
+    hipLaunchKernelGGL((k_conv_dgrad_b3_lds<F_, A_, P_>), grid, block, lds, EVF_STREAM(stream), (const uint4*)g,           \
+                       plane_stride, (const uint4*)wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, (const uint4*)wT2_b3,     \
+                       g_x2);                                                                                              \
+  } while (0)
+#define DG_AP(F_)                  \
+  do {                             \
+    if (acc && plif)               \
+      DG_GO(F_, true, true);       \
+    else if (acc)                  \
+      DG_GO(F_, true, false);      \
+    else if (plif)                 \
+      DG_GO(F_, false, true);      \
+    else                           \
+      DG_GO(F_, false, false);     \
+  } while (0)
   if (f32in)
-    hipLaunchKernelGGL(k_conv_dgrad_b3_lds<true>, grid, block, lds, EVF_STREAM(stream), (const uint4*)g, plane_stride,
-                       (const uint4*)wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, (const uint4*)wT2_b3, g_x2);
+    DG_AP(true);
   else
-    hipLaunchKernelGGL(k_conv_dgrad_b3_lds<false>, grid, block, lds, EVF_STREAM(stream), (const uint4*)g, plane_stride,
-                       (const uint4*)wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, (const uint4*)wT2_b3, g_x2);
+    DG_AP(false);
+#undef DG_AP
+#undef DG_GO
   return evf_status();
 }
 
