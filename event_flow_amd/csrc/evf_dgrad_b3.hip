@@ -191,17 +191,13 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
       const uint4* g = gs + sp * plane_stride + (((long)b * H + yy) * W + xx) * 4 + c;
       __builtin_amdgcn_global_load_lds((dl_glb_void*)g, (dl_lds_void*)(s_a + (sp * DL_HPP + 16 * u) * 4), 16, 0, 0);
     }
-    const int yq = min(y, H - 1);
-    float oldv[16], pv[16];
-    uint32_t xb[16];
+    // epilogue operands of this lane's pixel (column x0 + i): channels 8q + 4kg .. +3, q = 0..3
+    const long pixq = ((long)b * H + min(y, H - 1)) * W + min(x0 + i, W - 1);
+    float4 oldv[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int col = min(x0 + dg_row(r, lane), W - 1);
-      const long pix = ((long)b * H + yq) * W + col;
-      oldv[r] = ACC ? gx[pix * C32 + i] : 0.f;
-      pv[r] = PLIF ? gPb[pix] : 0.f;
-      xb[r] = PLIF ? xbits[pix] : 0u;
-    }
+    for (int q = 0; q < 4; ++q) oldv[q] = ACC ? *(const float4*)(gx + pixq * C32 + 8 * q + 4 * kg) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float pv = PLIF ? gPb[pixq] : 0.f;
+    const uint32_t xb = PLIF ? xbits[pixq] : 0u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     auto matrix_phase = [&]() -> f32x16 {
@@ -227,13 +223,15 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
             u1.x &= msk, u1.y &= msk, u1.z &= msk, u1.w &= msk;
             u2.x &= msk, u2.y &= msk, u2.z &= msk, u2.w &= msk;
             const bf16x8 ah = *(const bf16x8*)&u0, am = *(const bf16x8*)&u1, al = *(const bf16x8*)&u2;
-            // smallest terms first
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+            // smallest terms first.  Weights as the A operand, gradient as B: the product comes out TRANSPOSED (lane =
+          // pixel, 16 channels in groups of four), so the epilogue moves float4s -- 4 instead of 16 memory instructions
+          // per tensor and lane (the texture addresser, not HBM, bounds a dword-per-lane epilogue)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, am, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, am, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, ah, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc, 0, 0, 0);
           }
         }
       }
@@ -253,20 +251,24 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
       }
       const f32x16 acc = matrix_phase();
       if (y < H) {
-        if (set == 0) {
+        const long pix = ((long)b * H + y) * W + x0 + i;
+        if (x0 + i < W) {
+          if (set == 0) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int col = x0 + dg_row(r, lane);
-            // PLIF: the pooled pre-synaptic trace also reads the input spikes: d mean_c|x| / dx_c = 1/32 where the
-            // spike is set, AvgPool3x3^T = box filter / 9 -- gPb is that filtered, scaled map (evf_plif_trace_bwd)
-            const float v = acc[r] + oldv[r] + (((xb[r] >> i) & 1u) ? pv[r] : 0.f);
-            if (col < W) gx[(((long)b * H + y) * W + col) * C32 + i] = v;
-          }
-        } else {
+            for (int q = 0; q < 4; ++q) {
+              // PLIF: the pooled pre-synaptic trace also reads the input spikes: d mean_c|x| / dx_c = 1/32 where the
+              // spike is set, AvgPool3x3^T = box filter / 9 -- gPb is that filtered, scaled map (evf_plif_trace_bwd)
+              const uint32_t xq = xb >> (8 * q + 4 * kg);
+              const float o[4] = {oldv[q].x, oldv[q].y, oldv[q].z, oldv[q].w};
+              float v[4];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int col = x0 + dg_row(r, lane);
-            if (col < W) gx2[(((long)b * H + y) * W + col) * C32 + i] = acc[r];
+              for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e] + o[e] + (((xq >> e) & 1u) ? pv : 0.f);
+              *(float4*)(gx + pix * C32 + 8 * q + 4 * kg) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *(float4*)(gx2 + pix * C32 + 8 * q + 4 * kg) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
           }
         }
       }
