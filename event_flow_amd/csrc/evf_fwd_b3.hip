@@ -119,6 +119,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
   uint32_t* s_z = s_x + HALO_H * HALO_W;
   float* s_P = (float*)(s_z + HALO_H * HALO_W);  // TH*TW (PLIF)
   float* s_pw = s_P + TH * TW;                   // 2*32 + 2 prediction-head weights and bias
+  float* s_par = s_pw + 2 * C32 + 2;             // [4][32]: sigmoid(leak), clamped thresh, sigmoid(leak_pt), sigmoid(add_pt)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
 
@@ -148,37 +149,40 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
   }
   const int i = lane & 31, kg = lane >> 5, j = lane & 31;
   const int r0 = 2 * wv;
-  // prefetch the previous membrane potential of this wave's two rows: in flight during the MFMAs
-  float vp[2][16];
+  if (tid < C32) {  // per-channel constants, once per block
+    s_par[tid] = b3_sigmoid(leak[tid]);       // torch.sigmoid(self.leak)     spiking_submodules.py:111/:536
+    s_par[C32 + tid] = fmaxf(thresh[tid], 0.01f);  // self.thresh.clamp_min(0.01)  :108/:533
+    s_par[2 * C32 + tid] = PLIF ? b3_sigmoid(pl.leak_pt[tid]) : 0.f;
+    s_par[3 * C32 + tid] = PLIF ? b3_sigmoid(pl.add_pt[tid]) : 0.f;
+  }
+  // The matrix phase computes the TRANSPOSED tile (weights as the A operand): a lane owns PIXEL i of its two rows
+  // and the 16 channels 8q + 4kg .. +3 (q = 0..3), so every state tensor moves as float4 -- 4 memory instructions per
+  // tensor, row and lane instead of 16 (the dword-per-lane epilogue was bound by the texture addresser: 128
+  // instructions per wave).  Prefetch of the previous state: in flight during the MFMAs.
+  float4 vp[2][4];
+  float4 ptp[PLIF ? 2 : 1][PLIF ? 4 : 1];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < 2; ++m) {
+    const long pq = ((long)b * H + min(y0 + r0 + m, H - 1)) * W + min(x0 + i, W - 1);
+    const float* src = v_prev ? v_prev : v_out;  // unconditional (clamped) loads, selected afterwards
+    const float* psrc = (PLIF && pl.pt_prev) ? pl.pt_prev : v_out;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      // unconditional (clamped) load: loads inside divergent branches get a vmcnt(0) each
-      const int row = min(y0 + r0 + m, H - 1), col = min(x0 + b3_row(r, lane), W - 1);
-      const float* src = v_prev ? v_prev : v_out;
-      const float val = src[(((long)b * H + row) * W + col) * C32 + j];
-      vp[m][r] = v_prev ? val : 0.f;
-    }
-  float ptp[PLIF ? 2 : 1][PLIF ? 16 : 1];
-  if (PLIF) {
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = min(y0 + r0 + m, H - 1), col = min(x0 + b3_row(r, lane), W - 1);
-        const float* src = pl.pt_prev ? pl.pt_prev : v_out;
-        const float val = src[(((long)b * H + row) * W + col) * C32 + j];
-        ptp[m][r] = pl.pt_prev ? val : 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const float4 val = *(const float4*)(src + pq * C32 + 8 * q + 4 * kg);
+      vp[m][q] = v_prev ? val : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (PLIF) {
+        const float4 pv4 = *(const float4*)(psrc + pq * C32 + 8 * q + 4 * kg);
+        ptp[m][q] = pl.pt_prev ? pv4 : make_float4(0.f, 0.f, 0.f, 0.f);
       }
+    }
   }
   // The weight DMA (invisible to the compiler's counters) was issued before everything else and memory
-  // returns in order: once at most the state prefetches issued above (32, or 64 with the PLIF trace) are still
+  // returns in order: once at most the state prefetches issued above (8, or 16 with the PLIF trace) are still
   // outstanding, the DMA has landed -- the matrix phase does not wait for v_prev.
   if (PLIF)
-    asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   else
-    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __syncthreads();
   if (PLIF) {  // pooled pre-synaptic activity of the tile's 256 pixels (one per thread)
     const int py = tid >> 5, px = tid & 31;
@@ -208,8 +212,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
         for (int s = 0; s < 3; ++s) {
           const uint4 bu = s_w[((tau * 2 + m) * 3 + s) * 64 + lane];
           const bf16x8 bw = *(const bf16x8*)&bu;
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bw, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw, a0, acc0, 0, 0, 0);  // weights as A: transposed product
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw, a1, acc1, 0, 0, 0);
         }
       }
     }
@@ -223,87 +227,69 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
     conv_phase(s_z);
   }
 
-  const float lam = b3_sigmoid(leak[j]);     // torch.sigmoid(self.leak)     spiking_submodules.py:111/:536
-  const float th = fmaxf(thresh[j], 0.01f);  // self.thresh.clamp_min(0.01)  :108/:533
-  const float lpt = PLIF ? b3_sigmoid(pl.leak_pt[j]) : 0.f, apt = PLIF ? b3_sigmoid(pl.add_pt[j]) : 0.f;
-  // Epilogue.  A lane owns channel j of 16 pixels per row; pixel (r, kg) sits at column (r&3) + 8(r>>2) + 4kg of
-  // the tile, so every address below is one per-row base pointer plus a compile-time offset.  Interior tiles (the
-  // common case) run without any bounds logic; edge tiles mask per element.
-  const bool interior = (x0 + TW <= W) && (y0 + TH <= H);  // block-uniform
+  // Epilogue (transposed tile): lane = pixel (x0 + i) of rows y0 + r0, y0 + r0 + 1; channel c = 8q + e + 4kg.
   const int nW = (W + 31) / 32;
-  auto epilogue = [&](auto full_tag) {
-    constexpr bool FULL = decltype(full_tag)::value;
+  const int rj = (j & 3) + 4 * (j >> 3), kgj = (j >> 2) & 1;  // (r, half) whose ballot holds channel j's bit plane
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const f32x16& acc = m ? acc1 : acc0;
-      const int row = y0 + r0 + m;
-      const long rowbase = ((long)b * H + min(row, H - 1)) * W + x0 + 4 * kg;  // pixel index of (r = 0) for this lane
-      float* vo_p = v_out + rowbase * C32 + j;
-      float* pt_p = PLIF ? pl.pt_out + rowbase * C32 + j : nullptr;
-      uint32_t* z_p = z_out + rowbase;
-      const uint32_t* sz = s_z + (r0 + m + 1) * HALO_W + 1 + 4 * kg;
-      const float* sP = s_P + (r0 + m) * TW + 4 * kg;
-      uint32_t plane = 0u, myword = 0u;
+  for (int m = 0; m < 2; ++m) {
+    const f32x16& acc = m ? acc1 : acc0;
+    const int row = y0 + r0 + m;
+    const bool ok = row < H && x0 + i < W;
+    const long pix = ((long)b * H + min(row, H - 1)) * W + min(x0 + i, W - 1);
+    const uint32_t zw = s_z[(r0 + m + 1) * HALO_W + 1 + i];  // previous output spikes of this pixel
+    const float Pq = PLIF ? s_P[(r0 + m) * TW + i] : 0.f;
+    uint32_t bits = 0u, myplane = 0u;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c0 = (r & 3) + 8 * (r >> 2);  // compile-time part of the column
-        const bool ok = FULL || (row < H && x0 + c0 + 4 * kg < W);
-        const float z = (float)((sz[c0] >> j) & 1u);
-        const float v = vp[m][r];
+    for (int q = 0; q < 4; ++q) {
+      const float v4[4] = {vp[m][q].x, vp[m][q].y, vp[m][q].z, vp[m][q].w};
+      const float p4[4] = {PLIF ? ptp[m][q].x : 0.f, PLIF ? ptp[m][q].y : 0.f, PLIF ? ptp[m][q].z : 0.f, PLIF ? ptp[m][q].w : 0.f};
+      float vo4[4], po4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * q + e, c = 8 * q + e + 4 * kg;
+        const float lam = s_par[c], th = s_par[C32 + c];
+        const float z = (float)((zw >> c) & 1u);
         float cur = acc[r];
         float pto = 0.f;
         if (PLIF) {
-          pto = ptp[m][r] * lpt + (1.0f - lpt) * sP[c0];  // :212 / :642
-          cur = cur - apt * pto;                           // (ff + rec) - add_pt * pt_out, :220 / :650
+          const float lpt = s_par[2 * C32 + c], apt = s_par[3 * C32 + c];
+          pto = p4[e] * lpt + (1.0f - lpt) * Pq;  // :212 / :642
+          cur = cur - apt * pto;                  // (ff + rec) - add_pt * pt_out, :220 / :650
         }
         // both reset rules evaluated, one selected: no per-element branch on the (uniform) flag
-        const float vo_hard = (v * lam) * (1.0f - z) + (1.0f - lam) * cur;  // :119/:544
-        const float vo_soft = v * lam + (1.0f - lam) * cur - z * th;        // :121/:546
+        const float vo_hard = (v4[e] * lam) * (1.0f - z) + (1.0f - lam) * cur;  // :119/:544
+        const float vo_soft = v4[e] * lam + (1.0f - lam) * cur - z * th;        // :121/:546
         const float vo = hard_reset ? vo_hard : vo_soft;
         const bool spike = ok && (vo - th) > 0.f;
-        if (FULL) {
-          vo_p[c0 * C32] = vo;
-          if (PLIF) pt_p[c0 * C32] = pto;
-        } else if (ok) {
-          vo_p[c0 * C32] = vo;
-          if (PLIF) pt_p[c0 * C32] = pto;
-        }
-        // spike word of the pixel (32 channels = the 32 lanes of this half wave): the ballot is wave-uniform;
-        // lane (r, kg) keeps it and the 16 words of the row leave in ONE store below
+        vo4[e] = vo, po4[e] = pto;
+        bits |= (spike ? 1u : 0u) << c;
+        // channel-major bit plane of channel c over the tile's 32 pixels = this ballot (low half: kg = 0)
         const unsigned long long mk = __ballot(spike);
-        const uint32_t wd = kg ? (uint32_t)(mk >> 32) : (uint32_t)mk;
-        myword = (j == r) ? wd : myword;
-        plane |= (spike ? 1u : 0u) << (c0 + 4 * kg);
+        myplane = (r == rj) ? (kgj ? (uint32_t)(mk >> 32) : (uint32_t)mk) : myplane;
       }
-      {
-        const int rr = j & 15, cc = (rr & 3) + 8 * (rr >> 2);  // lane j < 16 of each half holds the word of pixel (rr, kg)
-        const bool pixok = j < 16 && (FULL || (row < H && x0 + cc + 4 * kg < W));
-        if (pixok) z_p[cc] = myword;
-        if (pr.w) {  // (block-uniform) the head on this pixel's spike word
-          float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-          for (int c = 0; c < C32; ++c) {
-            const float z = (float)((myword >> c) & 1u);
-            s0 += z * s_pw[c];
-            s1 += z * s_pw[C32 + c];
-          }
-          if (pixok) {
-            const long hw = (long)H * W, q = (long)row * W + x0 + cc + 4 * kg;
-            pr.flow[(long)b * 2 * hw + q] = tanhf(s0 + s_pw[2 * C32]);
-            pr.flow[((long)b * 2 + 1) * hw + q] = tanhf(s1 + s_pw[2 * C32 + 1]);
-          }
-        }
-      }
-      if (zT_out) {  // channel-major bit planes [B][H][32][ceil(W/32)]
-        plane |= __shfl_xor(plane, 32, 64);
-        if ((FULL || row < H) && lane < 32) zT_out[(((long)b * H + row) * C32 + j) * nW + x0 / 32] = plane;
+      if (ok) {
+        *(float4*)(v_out + pix * C32 + 8 * q + 4 * kg) = make_float4(vo4[0], vo4[1], vo4[2], vo4[3]);
+        if (PLIF) *(float4*)(pl.pt_out + pix * C32 + 8 * q + 4 * kg) = make_float4(po4[0], po4[1], po4[2], po4[3]);
       }
     }
-  };
-  if (interior)
-    epilogue(std::true_type{});
-  else
-    epilogue(std::false_type{});
+    const uint32_t word = bits | __shfl_xor(bits, 32, 64);  // the pixel's 32 output spikes
+    if (ok && kg == 0) z_out[pix] = word;
+    if (pr.w) {  // (block-uniform) the prediction head on this pixel's spike word, summed like evf_pred_fwd
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < C32; ++c) {
+        const float z = (float)((word >> c) & 1u);
+        s0 += z * s_pw[c];
+        s1 += z * s_pw[C32 + c];
+      }
+      if (ok && kg == 0) {
+        const long hw = (long)H * W, qq = (long)row * W + x0 + i;
+        pr.flow[(long)b * 2 * hw + qq] = tanhf(s0 + s_pw[2 * C32]);
+        pr.flow[((long)b * 2 + 1) * hw + qq] = tanhf(s1 + s_pw[2 * C32 + 1]);
+      }
+    }
+    if (zT_out && row < H && lane < 32) zT_out[(((long)b * H + row) * C32 + j) * nW + x0 / 32] = myplane;
+  }
 }
 
 static int launch_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec, const float* leak,
@@ -312,7 +298,7 @@ static int launch_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_re
                          void* stream, const PredArgs* pred = nullptr) {
   dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(FW_THREADS);
   hipStream_t st = EVF_STREAM(stream);
-  const size_t lds = WB3_BYTES + 256 * 16 + 2 * HALO_H * HALO_W * 4 + TH * TW * 4 + (2 * C32 + 2) * 4;
+  const size_t lds = WB3_BYTES + 256 * 16 + 2 * HALO_H * HALO_W * 4 + TH * TW * 4 + (2 * C32 + 2) * 4 + 4 * C32 * 4;
   PlifArgs pa = plif ? *plif : PlifArgs{nullptr, nullptr, nullptr, nullptr, nullptr};
   PredArgs pd = pred ? *pred : PredArgs{nullptr, nullptr, nullptr};
 #define EVF_FWD(REC_, PLIF_)                                                                                           \
