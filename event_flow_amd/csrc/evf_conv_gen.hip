@@ -106,7 +106,9 @@ extern "C" int evf_pack_conv2d_weight(const float* w, int Cout, int Cin, int ksz
 // PAR (input gradient of a stride-2 3x3 conv): blockIdx.z = parity class (oy & 1, ox & 1) of the output
 // pixels of this block.  All pixels of a class share the taps that can reach them (1, 2, 2 or 4 of the 9), so no
 // MFMA runs on structurally-zero taps: 2.25 taps per pixel on average instead of 9.
-template <int NT, int VEC, bool PAR>
+// TR: weights as the A operand -> transposed tile (lane = pixel, float4 epilogue); chosen when an output pixel row is a
+// whole number of 128-byte lines (else the 16-byte pieces of neighbouring pixels share lines and the plain form wins)
+template <int NT, int VEC, bool PAR, bool TR>
 __global__ __launch_bounds__(256) void k_conv2d_f32(const float* __restrict__ src, const float4* __restrict__ wp,
                                                     const float* __restrict__ bias, float* __restrict__ out, ConvGeo g,
                                                     int accumulate) {
@@ -232,10 +234,14 @@ __global__ __launch_bounds__(256) void k_conv2d_f32(const float* __restrict__ sr
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const float4 bq = sb[(t * 8 + ch * 2 + h) * 64 + lane];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ch * 8 + 4 * h + 0], bq.x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ch * 8 + 4 * h + 1], bq.y, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ch * 8 + 4 * h + 2], bq.z, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ch * 8 + 4 * h + 3], bq.w, acc[t], 0, 0, 0);
+          acc[t] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(bq.x, a_cur[ch * 8 + 4 * h + 0], acc[t], 0, 0, 0)
+                      : __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ch * 8 + 4 * h + 0], bq.x, acc[t], 0, 0, 0);
+          acc[t] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(bq.y, a_cur[ch * 8 + 4 * h + 1], acc[t], 0, 0, 0)
+                      : __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ch * 8 + 4 * h + 1], bq.y, acc[t], 0, 0, 0);
+          acc[t] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(bq.z, a_cur[ch * 8 + 4 * h + 2], acc[t], 0, 0, 0)
+                      : __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ch * 8 + 4 * h + 2], bq.z, acc[t], 0, 0, 0);
+          acc[t] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(bq.w, a_cur[ch * 8 + 4 * h + 3], acc[t], 0, 0, 0)
+                      : __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ch * 8 + 4 * h + 3], bq.w, acc[t], 0, 0, 0);
         }
     };
     chunk(0);
@@ -256,6 +262,55 @@ __global__ __launch_bounds__(256) void k_conv2d_f32(const float* __restrict__ sr
     for (int i = 0; i < 32; ++i) a_cur[i] = a_nxt[i];
   }
 
+  if (TR) {
+    // epilogue.  The weights are the A operand of the MFMAs, so the tile is TRANSPOSED: this lane owns ONE output pixel and the 16 channels 8q + 4kg .. +3 of every N tile:
+    // the stores (and the accumulate loads, issued together before them) are float4s, 4 instead of 16 memory
+    // instructions per tile and lane (a dword-per-lane epilogue is bound by the texture addresser).
+    float* orow = out + ((long)(b * g.OH + oy) * g.OW + ox) * g.ldo;  // (b, oy, ox): this lane's output pixel (computed above)
+    const bool vec = (g.ldo & 3) == 0 && (((uintptr_t)out) & 15) == 0;  // uniform
+  #pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n0 = (blockIdx.y * NT + t) * 32 + 4 * kg;  // channels n0 + 8q + e
+      float4 oldv[4], bv[4];
+  #pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + 8 * q, nq = min(n, max(g.N - 4, 0));
+        const bool full = n + 4 <= g.N;
+        if (vec) {  // (uniform branch; both sides load unconditionally from clamped addresses)
+          const float4 o = *(const float4*)(orow + nq);
+          oldv[q] = (accumulate && full) ? o : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+          float o[4];
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = orow[min(n + e, g.N - 1)];
+          oldv[q] = accumulate ? make_float4(o[0], o[1], o[2], o[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float bb[4];
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float bl = (bias ? bias : out)[bias ? min(n + e, g.N - 1) : 0];
+          bb[e] = (bias && n + e < g.N) ? bl : 0.f;
+        }
+        bv[q] = make_float4(bb[0], bb[1], bb[2], bb[3]);
+      }
+      if (mok) {
+  #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + 8 * q;
+          const float v[4] = {(acc[t][4 * q + 0] + bv[q].x) + oldv[q].x, (acc[t][4 * q + 1] + bv[q].y) + oldv[q].y,
+                              (acc[t][4 * q + 2] + bv[q].z) + oldv[q].z, (acc[t][4 * q + 3] + bv[q].w) + oldv[q].w};
+          if (vec && n + 4 <= g.N) {
+            *(float4*)(orow + n) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+  #pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e < g.N) orow[n + e] = v[e];
+          }
+        }
+      }
+    }
+    return;
+  }
   // epilogue.  Output pixel of each accumulator row once (PAR needs divisions); when accumulating, all old values
   // are read first from clamped addresses in one straight-line block (a load under `if (mr < M)` is followed by its
   // own s_waitcnt vmcnt(0): 16 NT serial round trips)
@@ -296,12 +351,23 @@ static int cg_launch_vec(const float* src, const float* wp, const float* bias, f
   dim3 grid(evf_cdiv(M, CG_BM), evf_cdiv(g.N, 32 * NT), PAR ? 4 : 1), block(256);
   const size_t smem = 2 * NT * 512 * sizeof(float4);
   const bool a16 = ((uintptr_t)src & 15) == 0, a8 = ((uintptr_t)src & 7) == 0;
+  const bool tr = (g.ldo % 32) == 0 && (((uintptr_t)out) & 127) == 0;
+#define CG_GO(V_)                                                                                                           \
+  do {                                                                                                                      \
+    if (tr)                                                                                                                 \
+      hipLaunchKernelGGL((k_conv2d_f32<NT, V_, PAR, true>), grid, block, smem, st, src, (const float4*)wp, bias, out, g,    \
+                         accumulate);                                                                                       \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((k_conv2d_f32<NT, V_, PAR, false>), grid, block, smem, st, src, (const float4*)wp, bias, out, g,   \
+                         accumulate);                                                                                       \
+  } while (0)
   if (g.K % 4 == 0 && g.lds % 4 == 0 && a16)
-    hipLaunchKernelGGL((k_conv2d_f32<NT, 4, PAR>), grid, block, smem, st, src, (const float4*)wp, bias, out, g, accumulate);
+    CG_GO(4);
   else if (g.K % 2 == 0 && g.lds % 2 == 0 && a8)
-    hipLaunchKernelGGL((k_conv2d_f32<NT, 2, PAR>), grid, block, smem, st, src, (const float4*)wp, bias, out, g, accumulate);
+    CG_GO(2);
   else
-    hipLaunchKernelGGL((k_conv2d_f32<NT, 1, PAR>), grid, block, smem, st, src, (const float4*)wp, bias, out, g, accumulate);
+    CG_GO(1);
+#undef CG_GO
   return evf_status();
 }
 
