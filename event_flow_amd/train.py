@@ -119,3 +119,86 @@ def train_window(model, loss_function, optimizer, passes, dp=None):
 def encode_passes(event_lists, num_bins, res, want=("cnt", "mask", "voxel", "pol")):
     """[B,N,4] event lists (one per pass) -> the loader dicts, encoded on the GPU in one batched launch."""
     return encode_event_lists(event_lists, num_bins, res, want=want)
+
+
+class GraphedWindowStep:
+    """`train_window` for windows of a FIXED shape (P passes of [B,N,4] events) replayed from hipGraphs: one graph
+    launch per optimizer step instead of ~290 kernel launches (the eager step is host bound at this size).
+
+    New windows are copied into a static event buffer (P*B*N*16 bytes) before each replay.  Two graphs are captured
+    and replayed alternately so that the recurrent state crosses replays without copies (graph A starts from the
+    buffers the warm-up left and ends in its own pool tensors, graph B starts from those and writes its last pass
+    straight back; see FireNet.final_states_into).  With several ranks (`dp`) each step is two graphs around the one
+    eager all-reduce.  Needs `FlatAdam(..., device_step=True)` (the Adam step counter must live on the device) and a
+    model with the fused FireNet engine; the first `warmup` windows passed to `step` run eagerly.
+
+        stepper = GraphedWindowStep(model, loss_function, optimizer, num_bins, resolution)
+        for event_lists in windows:            # list of P tensors [B,N,4] (t, y, x, p)
+            loss = stepper.step(event_lists)   # 0-d tensor, no host sync
+    """
+
+    def __init__(self, model, loss_function, optimizer, num_bins, res, dp=None, want=("cnt", "mask", "voxel", "pol"), warmup=2):
+        if not getattr(optimizer, "device_step", False):
+            raise _lib.EvflowError("GraphedWindowStep needs FlatAdam(..., device_step=True)")
+        for name in ("use_static_states", "state_buffers", "final_states_into"):
+            if not hasattr(model, name):
+                raise _lib.EvflowError("GraphedWindowStep needs a model with the fused FireNet engine")
+        self.model, self.lossf, self.opt, self.dp = model, loss_function, optimizer, dp
+        self.num_bins, self.res, self.want = num_bins, res, want
+        self.warmup, self.seen = max(int(warmup), 2), 0
+        self.static_ev = None
+        self.graphs = None
+        self.stream = torch.cuda.Stream()
+        model.use_static_states(True)
+
+    def _passes(self):
+        d = encode_event_lists(list(self.static_ev.unbind(0)), self.num_bins, self.res, want=self.want)
+        for p in d:
+            p.setdefault("event_voxel", None)
+            p.setdefault("event_cnt", None)
+        return d
+
+    def _capture(self):
+        mode = "thread_local" if (self.dp is not None and self.dp.world > 1) else "global"
+        home = self.model.state_buffers()
+        self.model.use_static_states(False)
+        self.graphs = []
+        for gi in range(2):
+            if gi == 1:
+                self.model.final_states_into(home)
+            pre, post = torch.cuda.CUDAGraph(), None
+            if self.dp is None or self.dp.world == 1:
+                with torch.cuda.graph(pre, stream=self.stream, capture_error_mode=mode):
+                    loss = train_window(self.model, self.lossf, self.opt, self._passes(), dp=self.dp)
+            else:
+                post = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(pre, stream=self.stream, capture_error_mode=mode):
+                    local = window_backward(self.model, self.lossf, self.opt, self._passes(), self.dp)
+                with torch.cuda.graph(post, stream=self.stream, capture_error_mode=mode):
+                    loss = window_apply(self.model, self.lossf, self.opt, local, self.dp)
+            self.graphs.append((pre, post, loss))
+
+    def step(self, event_lists):
+        ev = torch.stack([e.to(torch.float32) for e in event_lists])
+        if self.static_ev is None:
+            self.static_ev = torch.empty_like(ev)
+        elif ev.shape != self.static_ev.shape:
+            raise _lib.EvflowError(f"window shape changed: {tuple(ev.shape)} vs {tuple(self.static_ev.shape)}")
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.static_ev.copy_(ev)
+            if self.seen < self.warmup:  # eager steps (they also fix the streams autograd will use)
+                loss = train_window(self.model, self.lossf, self.opt, self._passes(), dp=self.dp)
+            else:
+                if self.graphs is None:
+                    torch.cuda.synchronize()
+                    self._capture()
+                pre, post, loss = self.graphs[(self.seen - self.warmup) & 1]
+                pre.replay()
+                if post is not None:
+                    self.dp.reduce(self.opt.comm)
+                    post.replay()
+            self.seen += 1
+        cur.wait_stream(self.stream)
+        return loss

@@ -502,6 +502,50 @@ def test_hipgraph_replay_equals_eager_steps():
         assert np.mean(d > 4e-5) <= 0.05, (k, float(np.mean(d > 4e-5)))
 
 
+def test_graphed_window_step_equals_eager_training():
+    """train.GraphedWindowStep: fixed-shape windows copied into a static buffer and replayed from two alternating
+    hipGraphs (copy-free recurrent-state hand-over between them).  Six different windows, states carried across
+    windows, must give the losses and parameters of six eager train_window steps."""
+    from event_flow_amd import synthetic
+    from event_flow_amd.train import GraphedWindowStep, encode_passes
+
+    B, n, H, W, P = 2, 600, 32, 64, 3
+    wins = [[G(synthetic.event_list_batch(B, n, H, W, 9000 + 100 * w + k)) for k in range(P)] for w in range(6)]
+
+    def make():
+        torch.manual_seed(5)
+        m = LIFFireNet(model_cfg()).to(DEV)
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                if k.endswith("thresh"):
+                    p.mul_(0.25)
+        m.train()
+        return m
+
+    m1 = make()
+    opt1 = FlatAdam(m1, lr=2e-4, clip=100.0, device_step=True)
+    opt1.zero_grad()
+    stepper = GraphedWindowStep(m1, hloss.EventWarping(loss_cfg(H, W), DEV), opt1, 2, (H, W), want=("cnt", "mask", "pol"))
+    got = [float(stepper.step(lists)) for lists in wins]
+    assert stepper.graphs is not None and stepper.seen == 6
+
+    m2 = make()
+    opt2 = FlatAdam(m2, lr=2e-4, clip=100.0)
+    opt2.zero_grad()
+    l2 = hloss.EventWarping(loss_cfg(H, W), DEV)
+    ref = []
+    for lists in wins:
+        passes = encode_passes(lists, 2, (H, W), want=("cnt", "mask", "pol"))
+        for d in passes:
+            d["event_voxel"] = None
+        ref.append(float(train_window(m2, l2, opt2, passes)))
+    np.testing.assert_allclose(got, ref, rtol=5e-4)
+    for (k, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        d = np.abs(N(p) - N(q))
+        assert d.max() <= 6 * 2e-4 + 1e-6, k
+        assert np.mean(d > 6e-5) <= 0.05, (k, float(np.mean(d > 6e-5)))
+
+
 @pytest.mark.parametrize("shape", [(1, 5, 7), (3, 9, 33), (2, 8, 64)])
 def test_firenet_tiny_and_ragged_resolutions_vs_oracle(shape):
     """Sensor sizes below / across the 8-row x 32-pixel tiles of the fused kernels (H < 8, W < 32, W = 33):

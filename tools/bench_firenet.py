@@ -24,6 +24,7 @@ ap.add_argument("--passes", type=int, default=10)
 ap.add_argument("--events", type=int, default=1500)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--graph", action="store_true", help="replay the step from hipGraphs (train.GraphedWindowStep; fused LIF/PLIF FireNets)")
 a = ap.parse_args()
 dev = "cuda:0"
 torch.manual_seed(0)
@@ -40,13 +41,22 @@ model = M.MODELS[a.model](cfg).to(dev)
 model.train()
 lossf = EventWarping({"loader": {"resolution": [a.H, a.W]}, "loss": {"flow_regul_weight": 0.001, "overwrite_intermediate": False},
                       "model": {"mask_output": True}}, dev)
-opt = FlatAdam(model, lr=2e-4, clip=100.0)
+opt = FlatAdam(model, lr=2e-4, clip=100.0, device_step=a.graph)
 opt.zero_grad()
 lists = [torch.from_numpy(synthetic.event_list_batch(a.B, a.events, a.H, a.W, synthetic.seed_for(5, 0, k))).to(dev)
          for k in range(a.passes)]
 
 
+if a.graph:
+    from event_flow_amd.train import GraphedWindowStep
+
+    stepper = GraphedWindowStep(model, lossf, opt, 2, (a.H, a.W))
+    a.warmup = max(a.warmup, 4)  # 2 eager steps + capture + first replays
+
+
 def step():
+    if a.graph:
+        return stepper.step(lists)
     passes = [encode_event_list(ev, 2, (a.H, a.W)) for ev in lists]
     return train_window(model, lossf, opt, passes)
 
@@ -59,5 +69,5 @@ for _ in range(a.steps):
     loss = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
-print(json.dumps({"model": a.model, "shape": [a.B, a.H, a.W], "passes": a.passes, "events_per_pass": a.events, "launch": "eager",
+print(json.dumps({"model": a.model, "shape": [a.B, a.H, a.W], "passes": a.passes, "events_per_pass": a.events, "launch": "hipgraph" if a.graph else "eager",
                   "ms_per_step": dt * 1e3, "windows_per_s": a.B / dt, "loss": float(loss)}))
