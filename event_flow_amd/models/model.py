@@ -109,6 +109,11 @@ class FireNet(BaseModel):
         """Opaque handle on the tensors that currently hold the recurrent state (fused engine)."""
         return list(self._eng()._states)
 
+    def set_state_buffers(self, handle):
+        """Point the model at the tensors of `handle` (from state_buffers()) as its current recurrent state -- after
+        a hipGraph replay the state lives where the captured step left it, which Python did not see."""
+        self._eng()._states = list(handle)
+
     def final_states_into(self, handle):
         """The last pass of the NEXT window (announced by mark_last_pass()) writes its state straight
         into the tensors of `handle` (from state_buffers()) instead of fresh ones.  With a cycle of

@@ -176,7 +176,8 @@ class GraphedWindowStep:
                     local = window_backward(self.model, self.lossf, self.opt, self._passes(), self.dp)
                 with torch.cuda.graph(post, stream=self.stream, capture_error_mode=mode):
                     loss = window_apply(self.model, self.lossf, self.opt, local, self.dp)
-            self.graphs.append((pre, post, loss))
+            # where this graph leaves the recurrent state (graph 0: tensors of its own pool; graph 1: `home`)
+            self.graphs.append((pre, post, loss, self.model.state_buffers()))
 
     def step(self, event_lists):
         ev = torch.stack([e.to(torch.float32) for e in event_lists])
@@ -194,11 +195,12 @@ class GraphedWindowStep:
                 if self.graphs is None:
                     torch.cuda.synchronize()
                     self._capture()
-                pre, post, loss = self.graphs[(self.seen - self.warmup) & 1]
+                pre, post, loss, left = self.graphs[(self.seen - self.warmup) & 1]
                 pre.replay()
                 if post is not None:
                     self.dp.reduce(self.opt.comm)
                     post.replay()
+                self.model.set_state_buffers(left)  # keep model.states / eager calls consistent with the replayed step
             self.seen += 1
         cur.wait_stream(self.stream)
         return loss
