@@ -123,7 +123,7 @@ def encode_passes(event_lists, num_bins, res, want=("cnt", "mask", "voxel", "pol
 
 class GraphedWindowStep:
     """`train_window` for windows of a FIXED shape (P passes of [B,N,4] events) replayed from hipGraphs: one graph
-    launch per optimizer step instead of ~290 kernel launches (the eager step is host bound at this size).
+    launch per optimizer step instead of ~260 kernel launches (the eager step is host bound at this size).
 
     New windows are copied into a static event buffer (P*B*N*16 bytes) before each replay.  Two graphs are captured
     and replayed alternately so that the recurrent state crosses replays without copies (graph A starts from the
