@@ -713,30 +713,38 @@ __global__ void k_cm_smooth(const float* __restrict__ flow, const float* __restr
   const float* mn = (use_mask && Pk > 1) ? m + HW : m;
   float acc = 0.f;
   const int y0 = blockIdx.x * SM_ROWS;
+  // Branch-free: every neighbour is loaded from a clamped index (the pixel itself when the pair does not exist) and the
+  // pair's term is selected afterwards -- a load under `if (xr)` ends its basic block with s_waitcnt vmcnt(0).
+  const float* mp = m ? m : fx;    // dummy source without a mask
+  const float* mnp = m ? mn : fx;
   for (int idx = threadIdx.x; idx < SM_ROWS * W; idx += blockDim.x) {
     const int y = y0 + idx / W, x = idx % W;
     if (y >= H) break;
     const long c = (long)y * W + x;
+    const bool xr = x + 1 < W, yd = y + 1 < H, dg = xr && yd, dt = with_dt && p + 1 < Pm;
+    const long cr = xr ? c + 1 : c, cd = yd ? c + W : c, cdr = dg ? c + W + 1 : c;
     const float ax = fx[c], ay = fy[c];
-    const float mc = m ? m[c] : 1.f;
-    const bool xr = x + 1 < W, yd = y + 1 < H;
-    if (xr) {
-      float v = evf_charb(ax, ay, fx[c + 1], fy[c + 1]);
-      acc += m ? (mc * m[c + 1]) * v : v;
+    const float rx = fx[cr], ry = fy[cr], dxv = fx[cd], dyv = fy[cd], ex = fx[cdr], ey = fy[cdr];
+    // (the next pass's map does not exist behind the last pass: take the dummy from this map then)
+    const float nx = (dt ? fxn : fx)[c], ny = (dt ? fyn : fy)[c];
+    const float mc = mp[c], mr = mp[cr], md = mp[cd], mdr = mp[cdr], mnx = (dt ? mnp : mp)[c];
+    {
+      const float v = evf_charb(ax, ay, rx, ry);
+      acc += xr ? (m ? (mc * mr) * v : v) : 0.f;
     }
-    if (yd) {
-      float v = evf_charb(ax, ay, fx[c + W], fy[c + W]);
-      acc += m ? (mc * m[c + W]) * v : v;
+    {
+      const float v = evf_charb(ax, ay, dxv, dyv);
+      acc += yd ? (m ? (mc * md) * v : v) : 0.f;
     }
-    if (xr && yd) {
-      float v = evf_charb(ax, ay, fx[c + W + 1], fy[c + W + 1]);  // [:-1,:-1] - [1:,1:]
-      acc += m ? (mc * m[c + W + 1]) * v : v;
-      float u = evf_charb(fx[c + W], fy[c + W], fx[c + 1], fy[c + 1]);  // [1:,:-1] - [:-1,1:]
-      acc += m ? (m[c + W] * m[c + 1]) * u : u;
+    {
+      const float v = evf_charb(ax, ay, ex, ey);  // [:-1,:-1] - [1:,1:]
+      acc += dg ? (m ? (mc * mdr) * v : v) : 0.f;
+      const float u = evf_charb(dxv, dyv, rx, ry);  // [1:,:-1] - [:-1,1:]
+      acc += dg ? (m ? (md * mr) * u : u) : 0.f;
     }
-    if (with_dt && p + 1 < Pm) {
-      float v = evf_charb(ax, ay, fxn[c], fyn[c]);
-      acc += m ? (mc * mn[c]) * v : v;
+    {
+      const float v = evf_charb(ax, ay, nx, ny);
+      acc += dt ? (m ? (mc * mnx) * v : v) : 0.f;
     }
   }
   acc = evf_block_sum(acc, red);
@@ -942,31 +950,40 @@ __global__ void k_cm_smooth_bwd(const float* __restrict__ flow, const float* __r
   const float* m = use_mask ? mask + ((long)b * Pk + (Pk == 1 ? 0 : p)) * HW : nullptr;
   const long mstride = (use_mask && Pk > 1) ? HW : 0;
   const float c = grad_out[0] * scale;
+  const float* mp = m ? m : fx;  // dummy source without a mask
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < H * W; idx += gridDim.x * blockDim.x) {
     const int y = idx / W, x = idx % W;
     const long q = idx;
     const float ax = fx[q], ay = fy[q];
-    const float mc = m ? m[q] : 1.f;
+    const float mc = mp[q];
     float g = 0.f;
-#define PAIR_A(dq, ok) /* this pixel is the minuend, partner at q+dq */ \
-  if (ok) g += (m ? mc * m[q + (dq)] : 1.f) * evf_dcharb(ax, ay, fx[q + (dq)], fy[q + (dq)]);
-#define PAIR_B(dq, ok) /* this pixel is the subtrahend */ \
-  if (ok) g -= (m ? mc * m[q + (dq)] : 1.f) * evf_dcharb(fx[q + (dq)], fy[q + (dq)], ax, ay);
+    // branch-free: the partner is loaded from q + dq when the pair exists and from q itself otherwise; the term is
+    // selected afterwards (ten partners x three loads in flight instead of ten dependent round trips)
+    auto pair = [&](long dq, bool ok, bool minuend) {
+      const long qn = ok ? q + dq : q;
+      const float bx = fx[qn], by = fy[qn], mm = mp[qn];
+      const float w = m ? mc * mm : 1.f;
+      const float v = minuend ? evf_dcharb(ax, ay, bx, by) : evf_dcharb(bx, by, ax, ay);
+      const float t = ok ? w * v : 0.f;
+      g = minuend ? g + t : g - t;
+    };
     const bool xl = x > 0, xr = x + 1 < W, yu = y > 0, yd = y + 1 < H;
-    PAIR_A(1, xr)            // dx anchored here
-    PAIR_B(-1, xl)           // dx anchored at (y, x-1)
-    PAIR_A(W, yd)            // dy
-    PAIR_B(-W, yu)
-    PAIR_A(W + 1, xr && yd)  // diag down-right
-    PAIR_B(-W - 1, xl && yu)
-    PAIR_A(-W + 1, xr && yu)  // up-right: a = (y, x) is the lower-left of the pair anchored at (y-1, x)
-    PAIR_B(W - 1, xl && yd)   // up-right anchored at (y, x-1): a = (y+1, x-1), b = (y, x)
-#undef PAIR_A
-#undef PAIR_B
-    if (with_dt) {
-      if (p + 1 < Pm)
-        g += (m ? mc * m[q + mstride] : 1.f) * evf_dcharb(ax, ay, fx[q + pstride], fy[q + pstride]);
-      if (p > 0) g -= (m ? mc * m[q - mstride] : 1.f) * evf_dcharb(fx[q - pstride], fy[q - pstride], ax, ay);
+    pair(1, xr, true);              // dx anchored here
+    pair(-1, xl, false);            // dx anchored at (y, x-1)
+    pair(W, yd, true);              // dy
+    pair(-W, yu, false);
+    pair(W + 1, xr && yd, true);    // diag down-right
+    pair(-W - 1, xl && yu, false);
+    pair(-W + 1, xr && yu, true);   // up-right: a = (y, x) is the lower-left of the pair anchored at (y-1, x)
+    pair(W - 1, xl && yd, false);   // up-right anchored at (y, x-1): a = (y+1, x-1), b = (y, x)
+    {
+      const bool nx = with_dt && p + 1 < Pm, pv = with_dt && p > 0;
+      const float bx = fx[nx ? q + pstride : q], by = fy[nx ? q + pstride : q], mm = mp[nx ? q + mstride : q];
+      const float t = nx ? (m ? mc * mm : 1.f) * evf_dcharb(ax, ay, bx, by) : 0.f;
+      g += t;
+      const float cx = fx[pv ? q - pstride : q], cy = fy[pv ? q - pstride : q], mq = mp[pv ? q - mstride : q];
+      const float u = pv ? (m ? mc * mq : 1.f) * evf_dcharb(cx, cy, ax, ay) : 0.f;
+      g -= u;
     }
     g *= c;
     float* d = dflow + (long)map * 2 * HW;
