@@ -1,0 +1,175 @@
+"""Kernel-level equivalences through the C ABI: every fused / merged entry point of the 32->32 spiking stack against
+the separate entry points it replaces, on random tensors (incl. a ragged shape).  State tensors must agree bit for bit;
+sums that are taken in another order (weight-gradient slabs, per-channel parameter gradients) to fp32 round-off."""
+
+import numpy as np
+import pytest
+import torch
+
+from event_flow_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+C = 32
+P = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+
+
+def _f(*s, scale=1.0):
+    return torch.randn(*s, device=DEV) * scale
+
+
+def _bits(B, H, W, rate=0.15):
+    z = torch.rand(B, H, W, 32, device=DEV) < rate
+    w = torch.zeros(B, H, W, dtype=torch.int64, device=DEV)
+    for c in range(32):
+        w |= z[..., c].long() << c
+    return torch.where(w < 2**31, w, w - 2**32).to(torch.int32).contiguous()
+
+
+def _planes(bits):
+    B, H, W = bits.shape
+    t = torch.empty(B, H, 32, (W + 31) // 32, dtype=torch.int32, device=DEV)
+    _lib.call("evf_bits_transpose", P(bits), B, H, W, P(t))
+    return t
+
+
+def _packs():
+    w = _f(32, 32, 3, 3, scale=0.1)
+    fwd = torch.empty(54 * 1024, dtype=torch.uint8, device=DEV)
+    bwd = torch.empty(54 * 1024, dtype=torch.uint8, device=DEV)
+    _lib.call("evf_pack_conv_weight_b3", P(w), 32, 32, P(fwd))
+    _lib.call("evf_pack_conv_weight_b3t", P(w), 32, 32, P(bwd))
+    return fwd, bwd
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+SHAPES = [(8, 128, 128), (2, 37, 50)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_input_gradient_variants_are_bit_identical(shape):
+    """evf_conv_dgrad_b3 (pre-split planes) == evf_conv_dgrad_b3_f32 (split while staging); the _pair form == two calls."""
+    B, H, W = shape
+    torch.manual_seed(1)
+    g = _f(B, H, W, C, scale=0.3)
+    _, wt1 = _packs()
+    _, wt2 = _packs()
+    # the split the fused backward would have written (it also returns g_cur): reuse it from a dummy launch
+    z = _bits(B, H, W)
+    xT = _planes(z)
+    nsl = _lib.load().evf_lif_bwd_wgrad_slabs(B, H, W)
+    slab = torch.zeros(nsl, 9216, device=DEV)
+    leak, thresh = _f(32, scale=0.1) - 1, _f(32, scale=0.1) + 0.8
+    gsp = torch.empty(3, B, H, W, C, dtype=torch.bfloat16, device=DEV)
+    gcur, gvp = torch.empty(B, H, W, C, device=DEV), torch.empty(B, H, W, C, device=DEV)
+    gl, gt = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+    _lib.call("evf_lif_bwd_wgrad", P(g), None, P(_f(B, H, W, C)), None, None, P(xT), None, P(leak), P(thresh), B, H, W, 1, 0, 10.0,
+              P(gcur), P(gsp), P(gvp), P(gl), P(gt), P(slab), None, 0)
+    base = _f(B, H, W, C)
+    for acc in (0, 1):
+        a, b = base.clone(), base.clone()
+        _lib.call("evf_conv_dgrad_b3", P(gsp), P(wt1), P(a), acc, B, H, W, None, None)
+        _lib.call("evf_conv_dgrad_b3_f32", P(gcur), P(wt1), P(b), acc, B, H, W, None, None)
+        assert torch.equal(a, b), acc
+        c, d = base.clone(), torch.empty(B, H, W, C, device=DEV)
+        _lib.call("evf_conv_dgrad_b3_f32_pair", P(gcur), P(wt1), P(c), acc, P(wt2), P(d), B, H, W, None, None)
+        e = torch.empty(B, H, W, C, device=DEV)
+        _lib.call("evf_conv_dgrad_b3_f32", P(gcur), P(wt2), P(e), 0, B, H, W, None, None)
+        assert torch.equal(c, b) and torch.equal(d, e), acc
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_prediction_head_fused_into_its_neighbours(shape):
+    """evf_conv_lif_fwd_b3_pred == evf_conv_lif_fwd_b3 + evf_pred_fwd; evf_lif_bwd_wgrad_top == evf_pred_bwd +
+    evf_lif_bwd_wgrad."""
+    B, H, W = shape
+    torch.manual_seed(2)
+    x, zp = _bits(B, H, W), _bits(B, H, W)
+    wf, _ = _packs()
+    leak, thresh = _f(32, scale=0.1) - 1, _f(32, scale=0.1) + 0.3
+    v = _f(B, H, W, C, scale=0.5)
+    pw, pb = _f(2, 32, scale=0.05), _f(2, scale=0.01)
+    nW = (W + 31) // 32
+    outs = []
+    for fused in (False, True):
+        vo, zo = torch.empty(B, H, W, C, device=DEV), torch.empty(B, H, W, dtype=torch.int32, device=DEV)
+        zT = torch.empty(B, H, 32, nW, dtype=torch.int32, device=DEV)
+        flow = torch.empty(B, 2, H, W, device=DEV)
+        if fused:
+            _lib.call("evf_conv_lif_fwd_b3_pred", P(x), P(wf), None, P(leak), P(thresh), P(v), P(zp), B, H, W, 1, P(vo), P(zo), P(zT),
+                      P(pw), P(pb), P(flow))
+        else:
+            _lib.call("evf_conv_lif_fwd_b3", P(x), P(wf), None, P(leak), P(thresh), P(v), P(zp), B, H, W, 1, P(vo), P(zo), P(zT))
+            _lib.call("evf_pred_fwd", P(zo), P(pw), P(pb), B, H, W, P(flow))
+        outs.append((vo, zo, zT, flow))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    vo, zo, zT, flow = outs[0]
+    assert float((zo != 0).float().mean()) > 0.5  # the layer does spike
+    # backward
+    g_flow, gv = _f(B, 2, H, W), _f(B, H, W, C, scale=0.1)
+    xT = _planes(x)
+    nsl = _lib.load().evf_lif_bwd_wgrad_slabs(B, H, W)
+    res = []
+    for fused in (False, True):
+        slab = torch.zeros(nsl, 9216, device=DEV)
+        gcur, gvp = torch.empty(B, H, W, C, device=DEV), torch.empty(B, H, W, C, device=DEV)
+        gl, gt = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+        dw, db = torch.zeros(2, 32, device=DEV), torch.zeros(2, device=DEV)
+        if fused:
+            _lib.call("evf_lif_bwd_wgrad_top", P(flow), P(g_flow), P(pw), P(zo), P(dw), P(db), P(gv), P(vo), P(v), P(zp), P(xT), P(leak),
+                      P(thresh), B, H, W, 1, 0, 10.0, P(gcur), None, P(gvp), P(gl), P(gt), P(slab), 0)
+        else:
+            gz = torch.empty(B, H, W, C, device=DEV)
+            _lib.call("evf_pred_bwd", P(zo), P(flow), P(g_flow), P(pw), B, H, W, P(gz), P(dw), P(db))
+            _lib.call("evf_lif_bwd_wgrad", P(gz), P(gv), P(vo), P(v), P(zp), P(xT), None, P(leak), P(thresh), B, H, W, 1, 0, 10.0,
+                      P(gcur), None, P(gvp), P(gl), P(gt), P(slab), None, 0)
+        res.append((gcur, gvp, slab.sum(0), gl, gt, dw, db))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for k in range(2, 7):
+        assert _rel(res[1][k], res[0][k]) < 5e-6, k
+
+
+@pytest.mark.parametrize("shape,rec_lo,pair,hard", [((8, 128, 128), False, False, True), ((8, 128, 128), True, True, True),
+                                                     ((2, 37, 50), True, False, False), ((3, 16, 32), False, True, False)])
+def test_chained_backward_kernel_vs_separate_kernels(shape, rec_lo, pair, hard):
+    """evf_bwd_chain == evf_conv_dgrad_b3_f32[_pair] (layer l) + evf_lif_bwd_wgrad (layer l-1)."""
+    B, H, W = shape
+    torch.manual_seed(3)
+    zin, zprev = _bits(B, H, W), _bits(B, H, W)
+    xT, zT = _planes(zin), _planes(zprev)
+    _, wt1 = _packs()
+    _, wt2 = _packs()
+    g_hi = _f(B, H, W, C, scale=0.3)
+    gz_add = _f(B, H, W, C, scale=0.2) if rec_lo else None
+    gv, vo, vp = _f(B, H, W, C, scale=0.1), _f(B, H, W, C, scale=0.5) + 0.5, _f(B, H, W, C, scale=0.5)
+    leak, thresh = _f(32, scale=0.1) - 1, _f(32, scale=0.1) + 0.8
+    lib = _lib.load()
+    gz = gz_add.clone() if gz_add is not None else torch.empty(B, H, W, C, device=DEV)
+    gx2_ref = torch.empty(B, H, W, C, device=DEV)
+    if pair:
+        _lib.call("evf_conv_dgrad_b3_f32_pair", P(g_hi), P(wt1), P(gz), 1 if rec_lo else 0, P(wt2), P(gx2_ref), B, H, W, None, None)
+    else:
+        _lib.call("evf_conv_dgrad_b3_f32", P(g_hi), P(wt1), P(gz), 1 if rec_lo else 0, B, H, W, None, None)
+    nsl = lib.evf_lif_bwd_wgrad_slabs(B, H, W)
+    sf, sr = torch.zeros(nsl, 9216, device=DEV), torch.zeros(nsl, 9216, device=DEV)
+    gc_ref, gvp_ref = torch.empty(B, H, W, C, device=DEV), torch.empty(B, H, W, C, device=DEV)
+    gl_ref, gt_ref = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+    _lib.call("evf_lif_bwd_wgrad", P(gz), P(gv), P(vo), P(vp), P(zprev), P(xT), P(zT) if rec_lo else None, P(leak), P(thresh), B, H, W,
+              1 if hard else 0, 0, 10.0, P(gc_ref), None, P(gvp_ref), P(gl_ref), P(gt_ref), P(sf), P(sr) if rec_lo else None, 0)
+    nsc = lib.evf_bwd_chain_slabs(B, H, W)
+    cf, cr = torch.full((nsc, 9216), float("nan"), device=DEV), torch.full((nsc, 9216), float("nan"), device=DEV)
+    gc, gvp, gx2 = (torch.empty(B, H, W, C, device=DEV) for _ in range(3))
+    gl, gt = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+    _lib.call("evf_bwd_chain", P(g_hi), P(wt1), P(wt2) if pair else None, P(gx2) if pair else None, P(gz_add), P(gv), P(vo), P(vp),
+              P(zprev), P(xT), P(zT) if rec_lo else None, P(leak), P(thresh), B, H, W, 1 if hard else 0, 0, 10.0, P(gc), P(gvp), P(gl),
+              P(gt), P(cf), P(cr) if rec_lo else None, 0)
+    assert torch.equal(gc, gc_ref) and torch.equal(gvp, gvp_ref)
+    if pair:
+        assert torch.equal(gx2, gx2_ref)
+    assert _rel(cf.sum(0), sf.sum(0)) < 5e-6 and _rel(gl, gl_ref) < 1e-5 and _rel(gt, gt_ref) < 1e-5
+    if rec_lo:
+        assert _rel(cr.sum(0), sr.sum(0)) < 5e-6
