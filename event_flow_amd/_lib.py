@@ -97,6 +97,8 @@ NETWORK_SIGNATURES = {
     "evf_upsample_nearest_bwd": [P, L, I, I, I, P, P],
     "evf_act_fwd": [I, P, P, L, P, P],
     "evf_act_bwd": [I, P, P, L, P, P],
+    "evf_leaky_fwd": [P, P, P, P, I, L, I, P, P, P],
+    "evf_leaky_bwd": [P, P, P, P, P, I, L, I, P, P, P, P],
     "evf_spike_fwd": [P, P, I, L, P, P],
     "evf_spike_bwd": [I, P, P, I, P, F, L, P, P],
     "evf_gru_gates_fwd": [P, P, P, L, P, P, P, P],

@@ -310,6 +310,113 @@ extern "C" int evf_neuron_bwd(int kind, const float* g_v_out, const float* g_z_o
 }
 
 // ---------------------------------------------------------------------------
+// leaky (non-spiking) cells of the ANN comparisons -- models/submodules.py:502-554 (ConvLeaky) and :454-499
+// (ConvLeakyRecurrent):  mix = prev * sigmoid(leak) + (1 - sigmoid(leak)) * (cur [+ residual]),  out = act(mix).
+// ConvLeaky keeps `mix` as its state and returns act(mix); ConvLeakyRecurrent keeps tanh(mix) as state.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float ng_act(int kind, float v) {
+  if (kind == 1) return tanhf(v);
+  if (kind == 2) return 1.0f / (1.0f + expf(-v));
+  if (kind == 3) return fmaxf(v, 0.f);
+  return v;
+}
+__device__ __forceinline__ float ng_dact(int kind, float o) {  // through the output
+  if (kind == 1) return 1.0f - o * o;
+  if (kind == 2) return o * (1.0f - o);
+  if (kind == 3) return o > 0.f ? 1.f : 0.f;
+  return 1.f;
+}
+
+__global__ void k_leaky_fwd(const float4* __restrict__ cur, const float4* __restrict__ prev, const float4* __restrict__ residual,
+                            const float* __restrict__ leak, int act, long npix, int C, float4* __restrict__ mix,
+                            float4* __restrict__ out) {
+  const int Q = C >> 2;
+  const long total = npix * Q, stride = (long)gridDim.x * blockDim.x;
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int cq = (int)(e % Q);
+  float lam[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) lam[k] = ng_sigmoid(leak[4 * cq + k]);
+  for (; e < total; e += stride) {
+    const float4 c4 = cur[e], p4 = ng_ld(prev, cur, e), r4 = ng_ld(residual, cur, e);
+    const float c[4] = {c4.x + r4.x, c4.y + r4.y, c4.z + r4.z, c4.w + r4.w}, p[4] = {p4.x, p4.y, p4.z, p4.w};
+    float m[4], o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      m[k] = p[k] * lam[k] + (1.0f - lam[k]) * c[k];
+      o[k] = ng_act(act, m[k]);
+    }
+    mix[e] = make_float4(m[0], m[1], m[2], m[3]);
+    if (out) out[e] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+extern "C" int evf_leaky_fwd(const float* cur, const float* prev, const float* residual, const float* leak, int act,
+                             int64_t npix, int C, float* mix, float* out, void* stream) {
+  if (!cur || !leak || !mix || npix <= 0 || C <= 0 || (C & 3) || C > 1024 || act < 0 || act > 3) return EVF_EINVAL;
+  const int Q = C >> 2, bs = ng_block(Q);
+  const long total = npix * Q;
+  const int nblk = (int)((total + bs - 1) / bs < 4096 ? (total + bs - 1) / bs : 4096);
+  hipLaunchKernelGGL(k_leaky_fwd, dim3(nblk), dim3(bs), 0, EVF_STREAM(stream), (const float4*)cur, (const float4*)prev,
+                     (const float4*)residual, leak, act, (long)npix, C, (float4*)mix, (float4*)out);
+  return evf_status();
+}
+
+// g_mix = g_state + g_out * act'(act(mix));  g_cur (= g_residual) = g_mix (1 - lam);  g_prev = g_mix lam;
+// g_leak[c] += sum g_mix (prev - cur) lam (1 - lam), with cur recovered from mix as (mix - prev lam) / (1 - lam)
+__global__ void k_leaky_bwd(const float4* __restrict__ g_out, const float4* __restrict__ g_state, const float4* __restrict__ mix,
+                            const float4* __restrict__ prev, const float* __restrict__ leak, int act, long npix, int C,
+                            float4* __restrict__ g_cur, float4* __restrict__ g_prev, float* __restrict__ g_leak) {
+  extern __shared__ float s_acc[];  // [C]
+  const int Q = C >> 2;
+  const long total = npix * Q, stride = (long)gridDim.x * blockDim.x;
+  for (int i = threadIdx.x; i < C; i += blockDim.x) s_acc[i] = 0.f;
+  __syncthreads();
+  const long gtid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cq = (int)(gtid % Q);
+  float lam[4], s0[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) lam[k] = ng_sigmoid(leak[4 * cq + k]);
+  for (long e = gtid; e < total; e += stride) {
+    const float4 go4 = ng_ld(g_out, mix, e), gs4 = ng_ld(g_state, mix, e), m4 = mix[e], p4 = ng_ld(prev, mix, e);
+    const float go[4] = {go4.x, go4.y, go4.z, go4.w}, gs[4] = {gs4.x, gs4.y, gs4.z, gs4.w};
+    const float m[4] = {m4.x, m4.y, m4.z, m4.w}, p[4] = {p4.x, p4.y, p4.z, p4.w};
+    float gc[4], gp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float oml = 1.0f - lam[k];
+      const float G = gs[k] + go[k] * ng_dact(act, ng_act(act, m[k]));
+      const float c = (m[k] - p[k] * lam[k]) / oml;
+      gc[k] = G * oml;
+      gp[k] = G * lam[k];
+      s0[k] += G * (p[k] - c);
+    }
+    g_cur[e] = make_float4(gc[0], gc[1], gc[2], gc[3]);
+    if (g_prev) g_prev[e] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+  }
+  if (g_leak) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicAdd(&s_acc[4 * cq + k], s0[k] * lam[k] * (1.0f - lam[k]));
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += blockDim.x) evf_atomic_add(g_leak + i, s_acc[i]);
+  }
+}
+
+extern "C" int evf_leaky_bwd(const float* g_out, const float* g_state, const float* mix, const float* prev, const float* leak,
+                             int act, int64_t npix, int C, float* g_cur, float* g_prev, float* g_leak, void* stream) {
+  if (!mix || !leak || !g_cur || (!g_out && !g_state) || npix <= 0 || C <= 0 || (C & 3) || C > 1024 || act < 0 || act > 3)
+    return EVF_EINVAL;
+  const int Q = C >> 2, bs = ng_block(Q);
+  const long total = npix * Q;
+  const int nblk = (int)((total + bs - 1) / bs < 1024 ? (total + bs - 1) / bs : 1024);
+  hipLaunchKernelGGL(k_leaky_bwd, dim3(nblk), dim3(bs), sizeof(float) * (size_t)C, EVF_STREAM(stream), (const float4*)g_out,
+                     (const float4*)g_state, (const float4*)mix, (const float4*)prev, leak, act, (long)npix, C,
+                     (float4*)g_cur, (float4*)g_prev, g_leak);
+  return evf_status();
+}
+
+// ---------------------------------------------------------------------------
 // pooled pre-synaptic activity: P = AvgPool_k(mean_c |x|), stride s, pad k/2,
 // count_include_pad (F.avg_pool2d default).  spiking_submodules.py:212
 // ---------------------------------------------------------------------------

@@ -388,6 +388,67 @@ def conv_act(owner, x, weight, bias, stride=1, activation=None, residual=None):
 
 
 # ---------------------------------------------------------------------------
+# leaky state mix of ConvLeaky / ConvLeakyRecurrent (submodules.py:545-554, :488-499)
+# ---------------------------------------------------------------------------
+class _LeakyMix(torch.autograd.Function):
+    """(cur, prev, residual, leak) -> act(mix) and mix = prev * sigmoid(leak) + (1 - sigmoid(leak)) * (cur + residual);
+    with act None the one tensor `mix` is returned."""
+
+    @staticmethod
+    def forward(ctx, cur, prev, residual, leak, act):
+        ctx.set_materialize_grads(False)
+        cn = to_nhwc(cur)
+        B, H, W, C = cn.shape
+        pn = to_nhwc(prev) if prev is not None else None
+        rn = to_nhwc(residual) if residual is not None else None
+        lk = leak.detach().reshape(-1).contiguous()
+        mix = _new((B, H, W, C), cn.device)
+        out = _new((B, H, W, C), cn.device) if act != 0 else None
+        _lib.call("evf_leaky_fwd", _lib.ptr(cn), _lib.ptr(pn), _lib.ptr(rn), _lib.ptr(lk), act, B * H * W, C, _lib.ptr(mix),
+                  _lib.ptr(out))
+        ctx.act, ctx.leak = act, leak
+        ctx.saved = (mix, pn, lk)
+        ctx.has = (prev is not None, residual is not None)
+        if act == 0:
+            return from_nhwc(mix)
+        return from_nhwc(out), from_nhwc(mix)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        mix, pn, lk = ctx.saved
+        g_out, g_mix = (None, grads[0]) if ctx.act == 0 else grads
+        need = ctx.needs_input_grad  # (cur, prev, residual, leak, act)
+        if g_out is None and g_mix is None:
+            return None, None, None, None, None
+        B, H, W, C = mix.shape
+        gon = to_nhwc(g_out) if g_out is not None else None
+        gmn = to_nhwc(g_mix) if g_mix is not None else None
+        g_cur = _new((B, H, W, C), mix.device)
+        g_prev = _new((B, H, W, C), mix.device) if (ctx.has[0] and need[1]) else None
+        g_leak = d_leak = None
+        if need[3]:
+            d_leak = bound_grad(ctx.leak)
+            g_leak = d_leak.view(-1) if d_leak is not None else torch.zeros(C, dtype=torch.float32, device=mix.device)
+        _lib.call("evf_leaky_bwd", _lib.ptr(gon), _lib.ptr(gmn), _lib.ptr(mix), _lib.ptr(pn), _lib.ptr(lk), ctx.act, B * H * W, C,
+                  _lib.ptr(g_cur), _lib.ptr(g_prev), _lib.ptr(g_leak))
+        gc = from_nhwc(g_cur)
+        return (gc if need[0] else None, from_nhwc(g_prev) if g_prev is not None else None,
+                gc if (ctx.has[1] and need[2]) else None,
+                g_leak.view(ctx.leak.shape) if (g_leak is not None and d_leak is None) else None, None)
+
+
+def leaky_mix(cur, prev, residual, leak, activation):
+    """-> (act(mix), mix); the same tensor twice when activation is None."""
+    if activation not in ACT_ID:
+        raise NotImplementedError(f"leaky cell activation {activation!r} has no HIP kernel (tanh/sigmoid/relu/None)")
+    res = residual if torch.is_tensor(residual) else None
+    if not torch.is_tensor(residual) and residual != 0:
+        raise _lib.EvflowError("residual must be a tensor or 0")
+    r = _LeakyMix.apply(cur, prev, res, leak, ACT_ID[activation])
+    return (r, r) if ACT_ID[activation] == 0 else r
+
+
+# ---------------------------------------------------------------------------
 # ConvGRU (submodules.py:400-418): the cat([x, h]) convolutions are evaluated
 # as conv(x, W[:, :Cx]) + conv(h, W[:, Cx:]) -- no concatenated copy
 # ---------------------------------------------------------------------------

@@ -29,7 +29,7 @@ from .spiking_submodules import (
     ConvXLIF,
     ConvXLIFRecurrent,
 )
-from .submodules import ConvGRU, ConvLayer, ConvLayer_
+from .submodules import ConvGRU, ConvLayer, ConvLayer_, ConvLeaky, ConvLeakyRecurrent, ConvRecurrent
 
 
 class FireNet(BaseModel):
@@ -263,6 +263,43 @@ class LIFFireFlowNet(FireNet):
     w_scale_pred = 0.01
 
 
+class FireFlowNet(FireNet):
+    """EV-FireFlowNet: no recurrency, ConvLayer_ everywhere (reference: models/model.py:398-409)."""
+
+    head_neuron = ConvLayer_
+    ff_neuron = ConvLayer_
+    rec_neuron = ConvLayer_
+    residual = False
+    w_scale_pred = 0.01
+
+
+class RNNFireNet(FireNet):
+    """Recurrent FireNet of plain convolutional neurons (reference: models/model.py:614-622)."""
+
+    head_neuron = ConvLayer_
+    ff_neuron = ConvLayer_
+    rec_neuron = ConvRecurrent
+    residual = False
+
+
+class LeakyFireNet(FireNet):
+    """Recurrent FireNet of leaky / stateful convolutional neurons (reference: models/model.py:625-633)."""
+
+    head_neuron = ConvLeaky
+    ff_neuron = ConvLeaky
+    rec_neuron = ConvLeakyRecurrent
+    residual = False
+
+
+class LeakyFireFlowNet(FireNet):
+    """FireFlowNet with a leaky internal state (reference: models/model.py:696-704)."""
+
+    head_neuron = ConvLeaky
+    ff_neuron = ConvLeaky
+    rec_neuron = ConvLeaky
+    residual = False
+
+
 class RecEVFlowNet(BaseModel):
     """Recurrent EV-FlowNet (Zhu et al., RSS 2018) -- reference: models/model.py:412-547.  Only the spiking
     variants below are on the accelerated path (the ConvGRU/ConvRNN/leaky UNets are ANN baselines)."""
@@ -392,6 +429,6 @@ class XLIFRecEVFlowNet(RecEVFlowNet):
 
 MODELS = {
     c.__name__: c
-    for c in (FireNet, LIFFireNet, PLIFFireNet, ALIFFireNet, XLIFFireNet, LIFFireFlowNet, SpikingRecEVFlowNet,
-              PLIFRecEVFlowNet, ALIFRecEVFlowNet, XLIFRecEVFlowNet)
+    for c in (FireNet, FireFlowNet, RNNFireNet, LeakyFireNet, LeakyFireFlowNet, LIFFireNet, PLIFFireNet, ALIFFireNet,
+              XLIFFireNet, LIFFireFlowNet, SpikingRecEVFlowNet, PLIFRecEVFlowNet, ALIFRecEVFlowNet, XLIFRecEVFlowNet)
 }

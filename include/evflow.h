@@ -440,6 +440,16 @@ int evf_upsample_nearest_bwd(const float* g_y, int64_t planes, int h, int w, int
 int evf_act_fwd(int kind, const float* x, const float* residual, int64_t n, float* y, void* stream);
 int evf_act_bwd(int kind, const float* y, const float* g_y, int64_t n, float* g_x, void* stream);
 
+/* Leaky non-spiking cells (ANN comparisons): ConvLeaky models/submodules.py:502-554, ConvLeakyRecurrent :454-499.
+ *   mix = prev * sigmoid(leak[c]) + (1 - sigmoid(leak[c])) * (cur [+ residual]);   out = act(mix)   (act as evf_act_fwd)
+ * NHWC fp32 [npix, C], C % 4 == 0; prev / residual null = zeros; out null = not written.  Backward (saved: mix, prev):
+ *   g_mix = g_state + g_out * act'(out);  g_cur = g_mix (1 - lam) (also the residual's gradient);  g_prev = g_mix lam
+ *   (null = not needed);  g_leak[C] is ADDED to (null = not needed).  g_out / g_state: either may be null. */
+int evf_leaky_fwd(const float* cur, const float* prev, const float* residual, const float* leak, int act, int64_t npix, int C,
+                  float* mix, float* out, void* stream);
+int evf_leaky_bwd(const float* g_out, const float* g_state, const float* mix, const float* prev, const float* leak, int act,
+                  int64_t npix, int C, float* g_cur, float* g_prev, float* g_leak, void* stream);
+
 /* Stand-alone spike functions (models/spiking_util.py:13-25 forward, :38-93 surrogates): z = (x - thresh > 0)
  * as fp32; g_x = g * surrogate(x - thresh, width) with surrogate = EVF_ARCTAN / SUPERSPIKE / TRIANGLE / MULTIGAUSS.
  * thresh: one scalar (thresh_per_element = 0) or one value per element of x (1). */

@@ -164,6 +164,43 @@ def conv_relu_step(p, pre, x, residual=0):
     return torch.relu(out)
 
 
+def conv_act_step(p, pre, x, act, residual=0):
+    """ConvLayer_.forward, models/submodules.py:69-83 (activation by name or None)."""
+    out = _conv(x, p[pre + "conv2d.weight"], bias=p[pre + "conv2d.bias"]) + residual
+    return getattr(torch, act)(out) if act is not None else out
+
+
+def conv_rnn_step(p, pre, x, state):
+    """ConvRecurrent.forward, models/submodules.py:437-451."""
+    if state is None:
+        state = torch.zeros(x.shape[0], p[pre + "ff.weight"].shape[0], *x.shape[2:], dtype=x.dtype)
+    ff = _conv(x, p[pre + "ff.weight"], bias=p[pre + "ff.bias"])
+    rec = _conv(state, p[pre + "rec.weight"], bias=p[pre + "rec.bias"])
+    state = torch.tanh(ff + rec)
+    return torch.relu(_conv(state, p[pre + "out.weight"], bias=p[pre + "out.bias"])), state
+
+
+def conv_leaky_rec_step(p, pre, x, state):
+    """ConvLeakyRecurrent.forward, models/submodules.py:485-499."""
+    ff = _conv(x, p[pre + "ff.weight"], bias=p[pre + "ff.bias"])
+    if state is None:
+        state = torch.zeros_like(ff)
+    rec = _conv(state, p[pre + "rec.weight"], bias=p[pre + "rec.bias"])
+    leak = torch.sigmoid(p[pre + "leak"])
+    state = torch.tanh(state * leak + (1 - leak) * (ff + rec))
+    return torch.relu(_conv(state, p[pre + "out.weight"], bias=p[pre + "out.bias"])), state
+
+
+def conv_leaky_step(p, pre, x, state, act, residual=0, stride=1):
+    """ConvLeaky.forward, models/submodules.py:538-554."""
+    ff = _conv(x, p[pre + "ff.weight"], stride=stride, bias=p[pre + "ff.bias"])
+    if state is None:
+        state = torch.zeros_like(ff)
+    leak = torch.sigmoid(p[pre + "leak"])
+    state = state * leak + (1 - leak) * (ff + residual)
+    return (getattr(torch, act)(state) if act is not None else state), state
+
+
 def pred_layer(p, pre, x):
     """1x1 ConvLayer + tanh, models/submodules.py:52-61 via model.py:197-199."""
     return torch.tanh(F.conv2d(x, p[pre + "conv2d.weight"], p[pre + "conv2d.bias"]))
@@ -184,6 +221,15 @@ FIRENET_KINDS = {
 }
 
 
+# ANN comparison FireNets: model name -> (cell of head/R layers, cell of the G layers)
+ANN_FIRENETS = {
+    "FireFlowNet": ("conv", "conv"),
+    "RNNFireNet": ("conv", "rnn"),
+    "LeakyFireNet": ("leaky", "leaky_rec"),
+    "LeakyFireFlowNet": ("leaky", "leaky"),
+}
+
+
 def firenet_forward(name, p, x, states, *, acts=("arctanspike", "arctanspike"), hard_reset=None, collect=None):
     """One pass head->G1->R1a->R1b->G2->R2a->R2b->pred (model.py:255-265).
     `states`: list of 7 (tuples or None).  Returns (flow [B,2,H,W], new_states).
@@ -197,6 +243,25 @@ def firenet_forward(name, p, x, states, *, acts=("arctanspike", "arctanspike"), 
                 h, st = conv_gru_step(p, lname + ".", h, states[li])
             else:
                 h, st = conv_relu_step(p, lname + ".", h), None
+            new_states.append(st)
+            if collect is not None:
+                collect[lname] = (h, st)
+        return pred_layer(p, "pred.", h), new_states
+    if name in ANN_FIRENETS:  # models/model.py:398-409, 614-633, 696-704
+        ff_cell, g_cell = ANN_FIRENETS[name]
+        ff_act, rec_act = acts
+        h = x
+        for li, lname in enumerate(FIRENET_LAYERS):
+            is_g = lname.startswith("G")
+            cell, act = (g_cell, rec_act) if is_g else (ff_cell, ff_act)
+            if cell == "conv":
+                h, st = conv_act_step(p, lname + ".", h, act), None
+            elif cell == "leaky":
+                h, st = conv_leaky_step(p, lname + ".", h, states[li], act)
+            elif cell == "rnn":
+                h, st = conv_rnn_step(p, lname + ".", h, states[li])
+            else:
+                h, st = conv_leaky_rec_step(p, lname + ".", h, states[li])
             new_states.append(st)
             if collect is not None:
                 collect[lname] = (h, st)

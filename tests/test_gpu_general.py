@@ -219,6 +219,48 @@ def test_g8_firenet_ann_forward_and_backward():
         close(N(p.grad), params[k].grad.numpy(), 2e-4, k)
 
 
+# ------------------------------------------------------------------ ANN comparison FireNets (G10)
+ANN_VARIANTS = {
+    "FireFlowNet": (("relu", "relu"), None),
+    "RNNFireNet": (("relu", None), None),
+    "LeakyFireNet": (("relu", None), {"leak": [-1.0, 0.5], "learn_leak": True}),
+    "LeakyFireFlowNet": (("relu", "tanh"), {"leak": [-1.0, 0.5], "learn_leak": True}),
+}
+
+
+@pytest.mark.parametrize("name", sorted(ANN_VARIANTS))
+def test_g10_ann_firenet_variants(name):
+    """FireFlowNet / RNNFireNet / LeakyFireNet / LeakyFireFlowNet against the reference's outputs: flows of three
+    passes, final states, BPTT gradients of every parameter (incl. the per-channel leaks)."""
+    from event_flow_amd.models import model as M
+
+    g = load_golden("g10_ann_firenets")
+    acts, neuron = ANN_VARIANTS[name]
+    cfg = {"num_bins": 2, "base_num_channels": 8, "kernel_size": 3, "encoding": "cnt", "norm_input": False,
+           "mask_output": True, "activations": list(acts), "spiking_neuron": neuron}
+    model = getattr(M, name)(cfg).to(DEV)
+    pre = name + ".param_"
+    sd = {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+    model.load_state_dict(sd)
+    tot = 0
+    for i in range(3):
+        x = G(g[f"p{i}_event_cnt"])
+        flow = model(x, x)["flow"][0]
+        np.testing.assert_allclose(N(flow), g[f"{name}.p{i}_flow"], rtol=1e-4, atol=1e-6)
+        tot = tot + flow.pow(2).sum() + flow.sum()
+    states = model.states
+    for li in range(7):
+        key = f"{name}.state{li}"
+        if key in g.files:
+            np.testing.assert_allclose(N(states[li]), g[key], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(float(tot.detach()), float(g[f"{name}.loss"]), rtol=1e-5)
+    tot.backward()
+    for k, p in model.named_parameters():
+        close(N(p.grad), g[f"{name}.grad_{k}"], 2e-4, k)
+    model.detach_states()
+    model.reset_states()
+
+
 # ------------------------------------------------------------------ spiking EV-FlowNet (G9, BASELINE config 4 architecture)
 def _unet_cfg(C=4):
     return {"num_bins": 2, "base_num_channels": C, "kernel_size": 3, "encoding": "cnt", "norm_input": False,

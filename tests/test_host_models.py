@@ -35,6 +35,12 @@ def test_reference_state_dicts_load_unchanged():
     plif = {"leak_v": [-4.0, 0.1], "leak_pt": [-4.0, 0.1], "add_pt": [-2.0, 0.1], "thresh": [0.8, 0.1]}
     _load(M.PLIFFireNet(cfg(neuron=plif)), load_golden("g7_pliffirenet_train"), "param0_")
     _load(M.FireNet(cfg(neuron=None, acts=("relu", None), encoding="voxel")), load_golden("g8_firenet_ann"), "param_")
+    g10 = load_golden("g10_ann_firenets")
+    leaky = {"leak": [-1.0, 0.5], "learn_leak": True}
+    _load(M.FireFlowNet(cfg(C=8, neuron=None, acts=("relu", "relu"))), g10, "FireFlowNet.param_")
+    _load(M.RNNFireNet(cfg(C=8, neuron=None, acts=("relu", None))), g10, "RNNFireNet.param_")
+    _load(M.LeakyFireNet(cfg(C=8, neuron=leaky, acts=("relu", None))), g10, "LeakyFireNet.param_")
+    _load(M.LeakyFireFlowNet(cfg(C=8, neuron=leaky, acts=("relu", "tanh"))), g10, "LeakyFireFlowNet.param_")
     sd = _load(M.SpikingRecEVFlowNet(cfg(C=4)), load_golden("g9_spiking_unet"), "param_")
     assert sd["multires_unetrec.decoders.1.conv2d.ff.weight"].shape == (16, 66, 3, 3)  # cat(pred, x, skip)
 
@@ -48,7 +54,7 @@ def test_parameter_counts_match_the_reference():
 
 
 def test_model_zoo_names_and_ctor_does_not_mutate_config():
-    for name in ("FireNet", "LIFFireNet", "PLIFFireNet", "ALIFFireNet", "XLIFFireNet", "LIFFireFlowNet", "SpikingRecEVFlowNet",
+    for name in ("FireNet", "FireFlowNet", "RNNFireNet", "LeakyFireNet", "LeakyFireFlowNet", "LIFFireNet", "PLIFFireNet", "ALIFFireNet", "XLIFFireNet", "LIFFireFlowNet", "SpikingRecEVFlowNet",
                  "PLIFRecEVFlowNet", "ALIFRecEVFlowNet", "XLIFRecEVFlowNet"):
         assert name in M.MODELS and getattr(M, name) is M.MODELS[name]
     c = cfg(C=4)

@@ -246,3 +246,35 @@ def test_g9_spiking_unet():
         ref = g["grad_" + k]
         got = gr.numpy() if gr is not None else np.zeros_like(ref)
         assert np.abs(got - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-10) + 1e-12, k
+
+
+# --------------------------------------------------------------------- G10
+ANN_ACTS = {"FireFlowNet": ("relu", "relu"), "RNNFireNet": ("relu", None), "LeakyFireNet": ("relu", None),
+            "LeakyFireFlowNet": ("relu", "tanh")}
+
+
+@pytest.mark.parametrize("name", sorted(ANN_ACTS))
+def test_g10_ann_firenets(name):
+    """FireFlowNet / RNNFireNet / LeakyFireNet / LeakyFireFlowNet (reference models/model.py:398-409,614-633,696-704):
+    flows of three passes, final states, BPTT parameter gradients."""
+    g = load_golden("g10_ann_firenets")
+    pre = name + ".param_"
+    params = {k[len(pre):]: T(g[k]).clone().requires_grad_(True) for k in g.files if k.startswith(pre)}
+    states = [None] * 7
+    tot = 0
+    for i in range(3):
+        flow, states = osnn.firenet_forward(name, params, T(g[f"p{i}_event_cnt"]), states, acts=ANN_ACTS[name])
+        np.testing.assert_allclose(flow.detach().numpy(), g[f"{name}.p{i}_flow"], rtol=1e-4, atol=1e-6)
+        tot = tot + flow.pow(2).sum() + flow.sum()
+    for li, st in enumerate(states):
+        key = f"{name}.state{li}"
+        assert (key in g.files) == (st is not None)
+        if st is not None:
+            np.testing.assert_allclose(st.detach().numpy(), g[key], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(float(tot.detach()), float(g[f"{name}.loss"]), rtol=1e-5)
+    keys = sorted(params)
+    grads = torch.autograd.grad(tot, [params[k] for k in keys], allow_unused=True)
+    for k, gr in zip(keys, grads):
+        ref = g[f"{name}.grad_{k}"]
+        got = gr.numpy() if gr is not None else np.zeros_like(ref)
+        assert np.abs(got - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-10) + 1e-9, k

@@ -8,7 +8,7 @@ path.  Each fixture holds inputs + the reference's outputs (data only).
 This script is the only place the reference is imported; it cannot run on the
 GPU box (no /root/reference there) and nothing at test/bench time needs it.
 
-    PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+    PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [generator ...]
 
 Recorded skew: the reference pins torch==1.7.0 (requirements.txt:1); fixtures
 are produced with the torch in this image (see meta.json), whose
@@ -415,7 +415,50 @@ def g9_spiking_unet():
     save("g9_spiking_unet", **a)
 
 
+ANN_FIRENETS = {
+    # name: (activations, neuron kwargs)
+    "FireFlowNet": (("relu", "relu"), None),
+    "RNNFireNet": (("relu", None), None),
+    "LeakyFireNet": (("relu", None), {"leak": [-1.0, 0.5], "learn_leak": True}),
+    "LeakyFireFlowNet": (("relu", "tanh"), {"leak": [-1.0, 0.5], "learn_leak": True}),
+}
+
+
+def g10_ann_firenets():
+    """ANN comparison FireNets (models/model.py:398-409,614-633,696-704): 3 passes, loss = sum flow^2 + sum flow,
+    per-pass flows, final states, parameter gradients."""
+    B, n, H, W, P = 2, 400, 32, 32, 3
+    a = {}
+    batches = [batch_windows(B, n, H, W, 5000 + 10 * k) for k in range(P)]
+    for k, d in enumerate(batches):
+        a[f"p{k}_event_cnt"] = d["event_cnt"]
+    for name, (acts, neuron) in ANN_FIRENETS.items():
+        torch.manual_seed(3)
+        model = build(name, model_cfg(name, C=8, neuron=neuron, acts=acts))
+        model.train()
+        for pn, v in model.state_dict().items():
+            a[f"{name}.param_{pn}"] = v.clone()
+        tot = 0
+        for k, d in enumerate(batches):
+            out = model(d["event_voxel"], d["event_cnt"])
+            a[f"{name}.p{k}_flow"] = out["flow"][0]
+            tot = tot + out["flow"][0].pow(2).sum() + out["flow"][0].sum()
+        for li, st in enumerate(model._states):
+            if torch.is_tensor(st) and st.dim() == 4:
+                a[f"{name}.state{li}"] = st
+        tot.backward()
+        a[f"{name}.loss"] = tot
+        for pn, prm in model.named_parameters():
+            a[f"{name}.grad_{pn}"] = prm.grad.clone() if prm.grad is not None else torch.zeros_like(prm)
+        print(name, "loss", float(tot), "params", sum(p.numel() for p in model.parameters()))
+    save("g10_ann_firenets", **a)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # only the named generators, e.g. `tools/gen_golden.py g10_ann_firenets`
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
     g1_encodings()
     g2_interpolation()
     g3_pol_iwe()
@@ -427,6 +470,7 @@ if __name__ == "__main__":
     g7_firenet_train("LIFFireNet", LIF_NEURON, "g7_liffirenet_lowthresh", thresh_scale=0.15)
     g8_firenet_ann()
     g9_spiking_unet()
+    g10_ann_firenets()
     meta = {"torch": torch.__version__, "numpy": np.__version__, "reference": "tudelft/event_flow @ /root/reference (v1)",
             "note": "outputs of the reference run in the build container; reference pins torch==1.7.0"}
     with open(os.path.join(OUT, "meta.json"), "w") as f:
