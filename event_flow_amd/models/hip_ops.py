@@ -341,9 +341,12 @@ class _ConvAct(torch.autograd.Function):
         B, H, W, Cin = xn.shape
         Cout, _, k, _ = weight.shape
         Ho, Wo = _out_dim(H, k, stride), _out_dim(W, k, stride)
+        if not 0 <= Cin - weight.shape[1] < 4:
+            raise _lib.EvflowError(f"input has {Cin} channels, the layer expects {weight.shape[1]}")
+        # (Cin - Cw trailing channels = zero padding that keeps 16-byte alignment; the packed weight is zero there)
         y = _new((B, Ho, Wo, Cout), xn.device)
         bc = bias.detach().contiguous() if bias is not None else None
-        conv_fwd(xn, _wcache(owner, "w").get(weight, 0), bc, y, Cin, Cout, k, stride)
+        conv_fwd(xn, _wcache(owner, "w").get(weight, 0, 0, Cin), bc, y, Cin, Cout, k, stride)
         rn = to_nhwc(residual) if residual is not None else None
         if act != 0 or rn is not None:
             _lib.call("evf_act_fwd", act, _lib.ptr(y), _lib.ptr(rn), y.numel(), _lib.ptr(y))
@@ -368,14 +371,14 @@ class _ConvAct(torch.autograd.Function):
         if need[2] or (ctx.has_bias and need[3]):
             d_w, d_b = bound_grad(weight), bound_grad(ctx.bias) if ctx.has_bias else None
             if d_w is not None and (not ctx.has_bias or d_b is not None):
-                conv_wgrad(xn, g, d_w, d_b, Cin, Cout, k, ctx.stride, accumulate=1)
+                conv_wgrad(xn, g, d_w, d_b, Cin, Cout, k, ctx.stride, cin_total=weight.shape[1], accumulate=1)
             else:
                 g_w = _new(tuple(weight.shape), g.device)
                 g_b = _new((Cout,), g.device) if ctx.has_bias else None
-                conv_wgrad(xn, g, g_w, g_b, Cin, Cout, k, ctx.stride)
+                conv_wgrad(xn, g, g_w, g_b, Cin, Cout, k, ctx.stride, cin_total=weight.shape[1])
         if need[1]:
             g_xn = _new((B, H, W, Cin), g.device)
-            conv_dgrad(g, _wcache(ctx.owner, "wT").get(weight, 1), g_xn, Cin, Cout, k, ctx.stride)
+            conv_dgrad(g, _wcache(ctx.owner, "wT").get(weight, 1, 0, Cin), g_xn, Cin, Cout, k, ctx.stride)
             g_x = from_nhwc(g_xn)
         g_res = from_nhwc(g) if (ctx.has_res and need[4]) else None
         return None, g_x, g_w, g_b, g_res, None, None

@@ -18,7 +18,7 @@ from .base import BaseModel
 from .engine import FireNetEngine
 from . import hip_ops
 from .model_util import CropParameters, copy_states
-from .unet import SpikingMultiResUNetRecurrent
+from .unet import LeakyMultiResUNetRecurrent, MultiResUNet, MultiResUNetRecurrent, SpikingMultiResUNetRecurrent
 from .spiking_submodules import (
     ConvALIF,
     ConvALIFRecurrent,
@@ -301,19 +301,15 @@ class LeakyFireFlowNet(FireNet):
 
 
 class RecEVFlowNet(BaseModel):
-    """Recurrent EV-FlowNet (Zhu et al., RSS 2018) -- reference: models/model.py:412-547.  Only the spiking
-    variants below are on the accelerated path (the ConvGRU/ConvRNN/leaky UNets are ANN baselines)."""
+    """Recurrent EV-FlowNet (Zhu et al., RSS 2018) with ConvGRU encoders -- reference: models/model.py:412-547.
+    Every variant (ConvGRU / ConvRNN / leaky / spiking) runs cell by cell through the general path."""
 
-    unet_type = None
+    unet_type = MultiResUNetRecurrent
     recurrent_block_type = "convgru"
     spiking_feedforward_block_type = None
 
     def __init__(self, unet_kwargs):
         super().__init__()
-        if self.unet_type is None:
-            raise NotImplementedError(
-                f"{type(self).__name__}: the non-spiking recurrent EV-FlowNets are ANN baselines outside the accelerated path"
-            )
         unet_kwargs = dict(unet_kwargs)  # the reference mutates the caller's dict (quirk q3); we do not
         norm = unet_kwargs.get("norm", None)
         use_upsample_conv = unet_kwargs.get("use_upsample_conv", True)
@@ -368,31 +364,93 @@ class RecEVFlowNet(BaseModel):
 
     def forward(self, event_voxel, event_cnt, log=False):
         """-> {"flow": [4 x [N,2,H,W]] (coarse to fine, all at input resolution), "activity": None}."""
-        if self.encoding == "voxel":
-            x = event_voxel
-        elif self.encoding == "cnt" and self.num_bins == 2:
-            x = event_cnt
-        else:
-            print("Model error: Incorrect input encoding.")
-            raise AttributeError
-        if self.norm_input:  # models/model.py:494-500
-            x = hip_ops.norm_nonzero(x)
-        if self.crop is not None:
-            x = self.crop.pad(x)
-        multires_flow = self.multires_unetrec.forward(x)
-        if log:
-            raise NotImplementedError("Activity logging not implemented")  # reference :523-524
-        flow_list = []
-        for flow in multires_flow:
-            fy = multires_flow[-1].shape[2] / flow.shape[2]
-            fx = multires_flow[-1].shape[3] / flow.shape[3]
-            if fy != fx:
-                raise NotImplementedError("anisotropic flow pyramids")
-            flow_list.append(hip_ops.upsample_nearest(flow.contiguous(), fy))
-        if self.crop is not None:
-            for i, flow in enumerate(flow_list):
-                flow_list[i] = flow[:, :, self.crop.iy0 : self.crop.iy1, self.crop.ix0 : self.crop.ix1].contiguous()
-        return {"flow": flow_list, "activity": None}
+        return _multires_forward(self, self.multires_unetrec, event_voxel, event_cnt, log)
+
+
+def _multires_forward(self, unet, event_voxel, event_cnt, log):
+    """Shared body of RecEVFlowNet.forward (models/model.py:476-547) and EVFlowNet.forward (:337-395)."""
+    if self.encoding == "voxel":
+        x = event_voxel
+    elif self.encoding == "cnt" and self.num_bins == 2:
+        x = event_cnt
+    else:
+        print("Model error: Incorrect input encoding.")
+        raise AttributeError
+    if self.norm_input:  # models/model.py:494-500
+        x = hip_ops.norm_nonzero(x)
+    if self.crop is not None:
+        x = self.crop.pad(x)
+    multires_flow = unet.forward(x)
+    if log:
+        raise NotImplementedError("Activity logging not implemented")  # reference :523-524
+    flow_list = []
+    for flow in multires_flow:
+        fy = multires_flow[-1].shape[2] / flow.shape[2]
+        fx = multires_flow[-1].shape[3] / flow.shape[3]
+        if fy != fx:
+            raise NotImplementedError("anisotropic flow pyramids")
+        flow_list.append(hip_ops.upsample_nearest(flow.contiguous(), fy))
+    if self.crop is not None:
+        for i, flow in enumerate(flow_list):
+            flow_list[i] = flow[:, :, self.crop.iy0 : self.crop.iy1, self.crop.ix0 : self.crop.ix1].contiguous()
+    return {"flow": flow_list, "activity": None}
+
+
+class EVFlowNet(BaseModel):
+    """EV-FlowNet (Zhu et al., RSS 2018): feed-forward multi-resolution UNet, no state.
+    Reference: models/model.py:289-395."""
+
+    def __init__(self, unet_kwargs):
+        super().__init__()
+        unet_kwargs = dict(unet_kwargs)  # the reference mutates the caller's dict (quirk q3); we do not
+        net_kwargs = {
+            "base_num_channels": unet_kwargs["base_num_channels"],
+            "num_encoders": 4,
+            "num_residual_blocks": 2,
+            "num_output_channels": 2,
+            "skip_type": "concat",
+            "norm": None,
+            "use_upsample_conv": True,
+            "kernel_size": unet_kwargs["kernel_size"],
+            "channel_multiplier": 2,
+            "final_activation": "tanh",
+        }
+        self.crop = None
+        self.mask = unet_kwargs["mask_output"]
+        self.norm_input = False if "norm_input" not in unet_kwargs.keys() else unet_kwargs["norm_input"]
+        self.encoding = unet_kwargs["encoding"]
+        self.num_bins = unet_kwargs["num_bins"]
+        self.num_encoders = net_kwargs["num_encoders"]
+        unet_kwargs.update(net_kwargs)
+        for k in ("name", "eval", "encoding", "round_encoding", "mask_output", "norm_input", "spiking_neuron"):
+            unet_kwargs.pop(k, None)
+        self.multires_unet = MultiResUNet(unet_kwargs)
+
+    def detach_states(self):
+        pass
+
+    def reset_states(self):
+        pass
+
+    def init_cropping(self, width, height, safety_margin=0):
+        self.crop = CropParameters(width, height, self.num_encoders, safety_margin)
+
+    def forward(self, event_voxel, event_cnt, log=False):
+        return _multires_forward(self, self.multires_unet, event_voxel, event_cnt, log)
+
+
+class RNNRecEVFlowNet(RecEVFlowNet):
+    """Recurrent EV-FlowNet with ConvRecurrent encoders (reference: models/model.py:594-601)."""
+
+    unet_type = MultiResUNetRecurrent
+    recurrent_block_type = "convrnn"
+
+
+class LeakyRecEVFlowNet(RecEVFlowNet):
+    """Recurrent EV-FlowNet of leaky cells (reference: models/model.py:604-611)."""
+
+    unet_type = LeakyMultiResUNetRecurrent
+    recurrent_block_type = "convleaky"
 
 
 class SpikingRecEVFlowNet(RecEVFlowNet):
@@ -430,5 +488,6 @@ class XLIFRecEVFlowNet(RecEVFlowNet):
 MODELS = {
     c.__name__: c
     for c in (FireNet, FireFlowNet, RNNFireNet, LeakyFireNet, LeakyFireFlowNet, LIFFireNet, PLIFFireNet, ALIFFireNet,
-              XLIFFireNet, LIFFireFlowNet, SpikingRecEVFlowNet, PLIFRecEVFlowNet, ALIFRecEVFlowNet, XLIFRecEVFlowNet)
+              XLIFFireNet, LIFFireFlowNet, EVFlowNet, RecEVFlowNet, RNNRecEVFlowNet, LeakyRecEVFlowNet, SpikingRecEVFlowNet,
+              PLIFRecEVFlowNet, ALIFRecEVFlowNet, XLIFRecEVFlowNet)
 }

@@ -1,8 +1,10 @@
 """Non-spiking conv layers on the hot path -- mirror of the used part of
 reference models/submodules.py: ConvLayer (the 1x1 tanh prediction head of
 every model, :12-61), ConvLayer_ (:64-83), ConvGRU (:377-418, FireNet-ANN) and
-the cells of the ANN comparisons ConvRecurrent (:421-451), ConvLeakyRecurrent
-(:454-499), ConvLeaky (:502-554).
+the cells and blocks of the ANN comparisons: UpsampleConvLayer (:140-185),
+RecurrentConvLayer (:188-235), ResidualBlock (:238-311), ConvRecurrent
+(:421-451), ConvLeakyRecurrent (:454-499), ConvLeaky (:502-554) and the leaky
+blocks (:557-686).
 The nn.Conv2d members only hold the parameters under the reference's names
 and initialisation; `forward` runs in libevflow_hip.so through the general
 path (models/hip_ops.py; the FireNet prediction head on packed spikes through
@@ -158,3 +160,138 @@ class ConvLeaky(nn.Module, _LeakParam):
         ff = hip_ops.conv_act(self.ff, input_, self.ff.weight, self.ff.bias, self.stride)
         out, state = hip_ops.leaky_mix(ff, prev_state, residual, self.leak, self.activation)
         return out, state
+
+
+def _no_norm(norm, what):
+    if norm is not None:
+        raise NotImplementedError(f"{what}: BN/IN layers have no HIP kernel (the reference's configs use norm=None)")
+
+
+def stack_nhwc(states):
+    """torch.stack of logical [B,C,H,W] tensors that keeps their NHWC memory layout (a plain copy)."""
+    return torch.stack([s.permute(0, 2, 3, 1) for s in states]).permute(0, 1, 4, 2, 3)
+
+
+class UpsampleConvLayer(nn.Module):
+    """Bilinear x2 up-sampling + ConvLayer (decoder).  Reference: models/submodules.py:140-185."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, activation="relu", norm=None):
+        super().__init__()
+        _no_norm(norm, "UpsampleConvLayer")
+        self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, kernel_size // 2, bias=True)
+        if activation is not None and not hasattr(torch, activation) and activation not in SURROGATE_ID:
+            raise AttributeError(activation)
+        self.activation, self.norm, self.stride = activation, norm, stride
+
+    def forward(self, x):
+        if self.activation not in hip_ops.ACT_ID:
+            raise NotImplementedError(f"UpsampleConvLayer activation {self.activation!r} has no HIP kernel")
+        x_up = hip_ops.upsample2x_bilinear(x)
+        return hip_ops.conv_act(self, x_up, self.conv2d.weight, self.conv2d.bias, self.stride, self.activation)
+
+
+class TransposedConvLayer(nn.Module):
+    """Reference: models/submodules.py:86-137 (use_upsample_conv=False).  No HIP kernel."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("transposed-conv decoders (use_upsample_conv=False) have no HIP kernel")
+
+
+class RecurrentConvLayer(nn.Module):
+    """ConvLayer followed by a recurrent block (ConvGRU / ConvRecurrent).  Reference: models/submodules.py:188-235."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, recurrent_block_type="convlstm",
+                 activation_ff="relu", activation_rec=None, norm=None, BN_momentum=0.1):
+        super().__init__()
+        assert recurrent_block_type in ["convlstm", "convgru", "convrnn"]
+        if recurrent_block_type == "convlstm":
+            raise NotImplementedError("ConvLSTM blocks (E2VID image reconstruction) are not part of the flow path")
+        self.recurrent_block_type = recurrent_block_type
+        block = ConvGRU if recurrent_block_type == "convgru" else ConvRecurrent
+        self.conv = ConvLayer(in_channels, out_channels, kernel_size, stride, activation_ff, norm, BN_momentum=BN_momentum)
+        self.recurrent_block = block(input_size=out_channels, hidden_size=out_channels, kernel_size=3,
+                                     activation=activation_rec)
+
+    def forward(self, x, prev_state):
+        x = self.conv(x)
+        return self.recurrent_block(x, prev_state)
+
+
+class ResidualBlock(nn.Module):
+    """out1 = act(conv1(x)); out2 = act(conv2(out1) + x) -> (out2, out1).  Reference: models/submodules.py:238-311."""
+
+    def __init__(self, in_channels, out_channels, stride=1, activation="relu", downsample=None, norm=None, BN_momentum=0.1):
+        super().__init__()
+        _no_norm(norm, "ResidualBlock")
+        if downsample is not None:
+            raise NotImplementedError("ResidualBlock(downsample=...) is not used by the reference's networks")
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=stride, padding=1, bias=True)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True)
+        if activation is not None and not hasattr(torch, activation) and activation not in SURROGATE_ID:
+            raise AttributeError(activation)
+        self.activation, self.norm, self.stride, self.downsample = activation, norm, stride, downsample
+
+    def forward(self, x):
+        if self.activation not in hip_ops.ACT_ID:
+            raise NotImplementedError(f"ResidualBlock activation {self.activation!r} has no HIP kernel")
+        out1 = hip_ops.conv_act(self.conv1, x, self.conv1.weight, self.conv1.bias, self.stride, self.activation)
+        out2 = hip_ops.conv_act(self.conv2, out1, self.conv2.weight, self.conv2.bias, 1, self.activation, residual=x)
+        return out2, out1
+
+
+class LeakyResidualBlock(nn.Module):
+    """Two ConvLeaky cells, the block input added inside the second.  Reference: models/submodules.py:557-592."""
+
+    def __init__(self, in_channels, out_channels, stride=1, feedforward_block_type="convleaky", activation="relu", **kwargs):
+        super().__init__()
+        assert feedforward_block_type in ["convleaky"]
+        self.conv1 = ConvLeaky(in_channels, out_channels, kernel_size=3, stride=stride, activation=activation, **kwargs)
+        self.conv2 = ConvLeaky(out_channels, out_channels, kernel_size=3, stride=1, activation=activation, **kwargs)
+
+    def forward(self, x, prev_state):
+        if prev_state is None:
+            prev_state = [None, None]
+        conv1, conv2 = prev_state
+        x1, conv1 = self.conv1(x, conv1)
+        x2, conv2 = self.conv2(x1, conv2, residual=x)
+        return x2, stack_nhwc([conv1, conv2])
+
+
+class LeakyUpsampleConvLayer(nn.Module):
+    """Bilinear x2 up-sampling + ConvLeaky.  Reference: models/submodules.py:595-623."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, feedforward_block_type="convleaky",
+                 activation="relu", **kwargs):
+        super().__init__()
+        assert feedforward_block_type in ["convleaky"]
+        self.conv2d = ConvLeaky(in_channels, out_channels, kernel_size, stride=stride, activation=activation, **kwargs)
+
+    def forward(self, x, prev_state):
+        return self.conv2d(hip_ops.upsample2x_bilinear(x), prev_state)
+
+
+class LeakyTransposedConvLayer(nn.Module):
+    """Reference: models/submodules.py:626-641 (raises there as well)."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError
+
+
+class LeakyRecurrentConvLayer(nn.Module):
+    """ConvLeaky followed by ConvLeakyRecurrent.  Reference: models/submodules.py:644-686."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=2, recurrent_block_type="convleaky",
+                 activation_ff="relu", activation_rec=None, **kwargs):
+        super().__init__()
+        assert recurrent_block_type in ["convleaky"]
+        self.conv = ConvLeaky(in_channels, out_channels, kernel_size, stride, activation_ff, **kwargs)
+        self.recurrent_block = ConvLeakyRecurrent(out_channels, out_channels, kernel_size, activation=activation_rec, **kwargs)
+
+    def forward(self, x, prev_state):
+        if prev_state is None:
+            prev_state = [None, None]
+        ff, rec = prev_state
+        x1, ff = self.conv(x, ff)
+        x2, rec = self.recurrent_block(x1, rec)
+        return x2, stack_nhwc([ff, rec])

@@ -1,11 +1,12 @@
-"""Spiking multi-resolution recurrent UNet -- host-side mirror of reference
-models/unet.py:28-145 (BaseUNet), :314-415 (MultiResUNetRecurrent) and
-:418-465 (SpikingMultiResUNetRecurrent): 4 strided spiking encoders each
-followed by a recurrent spiking block, 2 spiking residual blocks, 4 bilinear
-up-sampling spiking decoders on cat(prediction, x, skip) and a tanh 1x1
-prediction per scale.  Same module tree and parameter names as the reference,
-so its state_dicts load.  Every block runs in libevflow_hip.so through the
-general path (models/hip_ops.py); torch.cat / pad are the only torch calls
+"""Multi-resolution UNets -- host-side mirror of reference models/unet.py:
+BaseUNet (:28-145), MultiResUNet (:224-311, EVFlowNet), MultiResUNetRecurrent
+(:314-415, ConvGRU / ConvRNN encoders), SpikingMultiResUNetRecurrent (:418-465)
+and LeakyMultiResUNetRecurrent (:468-480): 4 strided encoders (each followed by
+a recurrent block in the recurrent nets), 2 residual blocks, 4 bilinear
+up-sampling decoders on cat(prediction, x, skip) and a tanh 1x1 prediction per
+scale.  Same module tree and parameter names as the reference, so its
+state_dicts load.  Every block runs in libevflow_hip.so through the general
+path (models/hip_ops.py); torch.cat / pad / stack are the only torch calls
 (memory movement)."""
 
 import torch
@@ -18,28 +19,34 @@ from .spiking_submodules import (
     SpikingTransposedConvLayer,
     SpikingUpsampleConvLayer,
 )
-from .submodules import ConvLayer
+from .submodules import (
+    ConvLayer,
+    LeakyRecurrentConvLayer,
+    LeakyResidualBlock,
+    LeakyTransposedConvLayer,
+    LeakyUpsampleConvLayer,
+    RecurrentConvLayer,
+    ResidualBlock,
+    TransposedConvLayer,
+    UpsampleConvLayer,
+)
 
 
-class SpikingMultiResUNetRecurrent(nn.Module):
+class BaseUNet(nn.Module):
+    """Sizes and builders shared by the multi-resolution UNets (reference unet.py:28-145)."""
+
     ff_type = ConvLayer
-    res_type = SpikingResidualBlock
-    upsample_type = SpikingUpsampleConvLayer
-    transpose_type = SpikingTransposedConvLayer
-    rec_type = SpikingRecurrentConvLayer
-    w_scale_pred = 0.01
+    res_type = ResidualBlock
+    upsample_type = UpsampleConvLayer
+    transpose_type = TransposedConvLayer
+    rec_type = RecurrentConvLayer
+    w_scale_pred = None
 
     def __init__(self, unet_kwargs):
         super().__init__()
         kw = dict(unet_kwargs)
         self.final_activation = kw.pop("final_activation", None)
         self._base_init(**kw)
-        self.encoders = self.build_recurrent_encoders()
-        self.resblocks = self.build_resblocks()
-        self.decoders = self.build_multires_prediction_decoders()
-        self.preds = self.build_multires_prediction_layer()
-        self.num_states = self.num_encoders * 2 + self.num_residual_blocks
-        self.states = [None] * self.num_states
 
     # reference BaseUNet.__init__, unet.py:40-91
     def _base_init(self, base_num_channels, num_encoders, num_residual_blocks, num_output_channels, skip_type, norm,
@@ -101,6 +108,96 @@ class SpikingMultiResUNetRecurrent(nn.Module):
                                       w_scale=self.w_scale_pred))
         return preds
 
+    def build_encoders(self):  # unet.py:241-257 (MultiResUNet)
+        encoders = nn.ModuleList()
+        for i, (cin, cout) in enumerate(zip(self.encoder_input_sizes, self.encoder_output_sizes)):
+            if i == 0:
+                cin = self.num_bins
+            encoders.append(self.ff_type(cin, cout, kernel_size=self.kernel_size, stride=2, activation=self.ff_act,
+                                         norm=self.norm, **self.spiking_kwargs))
+        return encoders
+
+    def _decoder_input(self, x, skip, prediction, decoder):
+        """cat(prediction, cat(x, skip)) (unet.py:303-306); with 2C+2 channels two zero channels keep the activation
+        16-byte aligned for the conv kernels (the packed weight is zero there; cells with a pre-synaptic trace
+        average over the true channels and are left unpadded)."""
+        x = self.skip_ftn(x, skip)
+        if prediction is not None:
+            x = self.skip_ftn(prediction, x)
+            pad = (-x.shape[1]) % 4
+            if pad and self.skip_type == "concat" and getattr(decoder.conv2d, "kind", "ann") in ("lif", "alif", "ann"):
+                x = torch.cat([x, x.new_zeros((x.shape[0], pad) + tuple(x.shape[2:]))], 1)
+        return x
+
+
+class MultiResUNet(BaseUNet):
+    """Feed-forward multi-resolution UNet of EVFlowNet (reference unet.py:224-311); its prediction layers keep the
+    default initialisation (:259-266)."""
+
+    def __init__(self, unet_kwargs):
+        super().__init__(unet_kwargs)
+        self.encoders = self.build_encoders()
+        self.resblocks = self.build_resblocks()
+        self.decoders = self.build_multires_prediction_decoders()
+        self.preds = self.build_multires_prediction_layer()
+
+    def forward(self, x):
+        blocks = []
+        for encoder in self.encoders:
+            x = encoder(x)
+            blocks.append(x)
+        for resblock in self.resblocks:
+            x, _ = resblock(x)
+        predictions = []
+        for i, (decoder, pred) in enumerate(zip(self.decoders, self.preds)):
+            x = self._decoder_input(x, blocks[self.num_encoders - i - 1], predictions[-1] if i else None, decoder)
+            x = decoder(x)
+            predictions.append(pred(x))
+        return predictions
+
+
+class MultiResUNetRecurrent(BaseUNet):
+    """Every encoder is a ConvLayer followed by a ConvGRU / ConvRecurrent block; stateless residual blocks and
+    decoders (reference unet.py:314-415)."""
+
+    def __init__(self, unet_kwargs):
+        super().__init__(unet_kwargs)
+        self.encoders = self.build_recurrent_encoders()
+        self.resblocks = self.build_resblocks()
+        self.decoders = self.build_multires_prediction_decoders()
+        self.preds = self.build_multires_prediction_layer()
+        self.num_states = self.num_encoders
+        self.states = [None] * self.num_states
+
+    def forward(self, x):
+        blocks = []
+        for i, encoder in enumerate(self.encoders):
+            x, self.states[i] = encoder(x, self.states[i])
+            blocks.append(x)
+        for resblock in self.resblocks:
+            x, _ = resblock(x)
+        predictions = []
+        for i, (decoder, pred) in enumerate(zip(self.decoders, self.preds)):
+            x = self._decoder_input(x, blocks[self.num_encoders - i - 1], predictions[-1] if i else None, decoder)
+            x = decoder(x)
+            predictions.append(pred(x))
+        return predictions
+
+
+class SpikingMultiResUNetRecurrent(MultiResUNetRecurrent):
+    """Spiking cells everywhere, 2 * encoders + residual blocks + decoders states (reference unet.py:418-465)."""
+
+    res_type = SpikingResidualBlock
+    upsample_type = SpikingUpsampleConvLayer
+    transpose_type = SpikingTransposedConvLayer
+    rec_type = SpikingRecurrentConvLayer
+    w_scale_pred = 0.01
+
+    def __init__(self, unet_kwargs):
+        super().__init__(unet_kwargs)
+        self.num_states = self.num_encoders * 2 + self.num_residual_blocks
+        self.states = [None] * self.num_states
+
     def forward(self, x):
         """x [N,num_bins,H,W] -> [N,2,H/8..H,W/8..W] x 4 (coarse to fine).  unet.py:437-465."""
         blocks = []
@@ -113,14 +210,16 @@ class SpikingMultiResUNetRecurrent(nn.Module):
         predictions = []
         offset += self.num_residual_blocks
         for i, (decoder, pred) in enumerate(zip(self.decoders, self.preds)):
-            x = self.skip_ftn(x, blocks[self.num_encoders - i - 1])
-            if i > 0:
-                x = self.skip_ftn(predictions[-1], x)
-                pad = (-x.shape[1]) % 4
-                if pad and self.skip_type == "concat" and decoder.conv2d.kind in ("lif", "alif"):
-                    # 2C+2 channels: two zero channels keep the activation 16-byte aligned for the conv kernels (the
-                    # packed weight is zero there; cells with a pre-synaptic trace average over the true channels)
-                    x = torch.cat([x, x.new_zeros((x.shape[0], pad) + tuple(x.shape[2:]))], 1)
+            x = self._decoder_input(x, blocks[self.num_encoders - i - 1], predictions[-1] if i else None, decoder)
             x, self.states[offset + i] = decoder(x, self.states[offset + i])
             predictions.append(pred(x))
         return predictions
+
+
+class LeakyMultiResUNetRecurrent(SpikingMultiResUNetRecurrent):
+    """The spiking UNet's topology with leaky non-spiking cells (reference unet.py:468-480)."""
+
+    res_type = LeakyResidualBlock
+    upsample_type = LeakyUpsampleConvLayer
+    transpose_type = LeakyTransposedConvLayer
+    rec_type = LeakyRecurrentConvLayer

@@ -330,6 +330,68 @@ def spiking_unet_forward(kind, p, x, states, *, num_encoders=4, num_res=2, acts=
     return flows, new_states
 
 
+def _act(name, v):
+    return getattr(torch, name)(v) if name is not None else v
+
+
+def ann_unet_forward(name, p, x, states, *, num_encoders=4, num_res=2, acts=("relu", None)):
+    """Non-spiking EV-FlowNets: EVFlowNet (MultiResUNet.forward, unet.py:287-311), RecEVFlowNet / RNNRecEVFlowNet
+    (MultiResUNetRecurrent.forward, unet.py:390-415, ConvGRU / ConvRecurrent encoders) and LeakyRecEVFlowNet
+    (LeakyMultiResUNetRecurrent, unet.py:468-480 over the spiking forward :437-465), followed by the nearest
+    up-sampling of every scale (model.py:528-539).  states: [] (EVFlowNet), E tensors (recurrent nets) or
+    2E + R + E entries (leaky: (ff, rec) per encoder, (conv1, conv2) per residual block, one per decoder)."""
+    leaky = name == "LeakyRecEVFlowNet"
+    pre = "multires_unet." if name == "EVFlowNet" else "multires_unetrec."
+    ff_act, rec_act = acts
+    new_states = [None] * len(states)
+    blocks = []
+    for i in range(num_encoders):
+        e = f"{pre}encoders.{i}."
+        if name == "EVFlowNet":  # ConvLayer, submodules.py:52-61
+            x = _act(ff_act, _conv(x, p[e + "conv2d.weight"], stride=2, bias=p[e + "conv2d.bias"]))
+        elif leaky:  # LeakyRecurrentConvLayer.forward, submodules.py:679-686
+            st = states[i] if states[i] is not None else (None, None)
+            x, s_ff = conv_leaky_step(p, e + "conv.", x, st[0], ff_act, stride=2)
+            x, s_rec = conv_leaky_rec_step(p, e + "recurrent_block.", x, st[1])
+            new_states[i] = (s_ff, s_rec)
+        else:  # RecurrentConvLayer.forward, submodules.py:229-235
+            x = _act(ff_act, _conv(x, p[e + "conv.conv2d.weight"], stride=2, bias=p[e + "conv.conv2d.bias"]))
+            if name == "RecEVFlowNet":
+                x, new_states[i] = conv_gru_step(p, e + "recurrent_block.", x, states[i])
+            else:
+                x, new_states[i] = conv_rnn_step(p, e + "recurrent_block.", x, states[i])
+        blocks.append(x)
+    off = num_encoders
+    for i in range(num_res):
+        r = f"{pre}resblocks.{i}."
+        if leaky:  # LeakyResidualBlock.forward, submodules.py:583-592
+            st = states[off + i] if states[off + i] is not None else (None, None)
+            x1, s1 = conv_leaky_step(p, r + "conv1.", x, st[0], ff_act)
+            x, s2 = conv_leaky_step(p, r + "conv2.", x1, st[1], ff_act, residual=x)
+            new_states[off + i] = (s1, s2)
+        else:  # ResidualBlock.forward, submodules.py:290-311
+            o1 = _act(ff_act, _conv(x, p[r + "conv1.weight"], bias=p[r + "conv1.bias"]))
+            x = _act(ff_act, _conv(o1, p[r + "conv2.weight"], bias=p[r + "conv2.bias"]) + x)
+    off += num_res
+    preds = []
+    for i in range(num_encoders):
+        d = f"{pre}decoders.{i}."
+        x = skip_concat(x, blocks[num_encoders - i - 1])
+        if i > 0:
+            x = skip_concat(preds[-1], x)
+        x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+        if leaky:  # LeakyUpsampleConvLayer.forward, submodules.py:619-623
+            x, new_states[off + i] = conv_leaky_step(p, d + "conv2d.", x, states[off + i], ff_act)
+        else:  # UpsampleConvLayer.forward, submodules.py:175-185
+            x = _act(ff_act, _conv(x, p[d + "conv2d.weight"], bias=p[d + "conv2d.bias"]))
+        preds.append(pred_layer(p, f"{pre}preds.{i}.", x))
+    flows = []
+    for f in preds:
+        sf = (preds[-1].shape[2] / f.shape[2], preds[-1].shape[3] / f.shape[3])
+        flows.append(F.interpolate(f, scale_factor=sf))  # default mode = nearest
+    return flows, new_states
+
+
 def detach_states(states):
     def d(s):
         if s is None:

@@ -261,6 +261,50 @@ def test_g10_ann_firenet_variants(name):
     model.reset_states()
 
 
+# ------------------------------------------------------------------ non-spiking EV-FlowNets (G11)
+ANN_UNETS = {
+    "EVFlowNet": None,
+    "RecEVFlowNet": None,
+    "RNNRecEVFlowNet": None,
+    "LeakyRecEVFlowNet": {"leak": [-1.0, 0.5], "learn_leak": True},
+}
+
+
+@pytest.mark.parametrize("name", sorted(ANN_UNETS))
+def test_g11_ann_evflownets(name):
+    """EVFlowNet / RecEVFlowNet (ConvGRU) / RNNRecEVFlowNet / LeakyRecEVFlowNet against the reference's outputs:
+    4 flow scales of two passes, final states, BPTT gradients of every parameter."""
+    from event_flow_amd.models import model as M
+
+    g = load_golden("g11_ann_unets")
+    cfg = {"num_bins": 2, "base_num_channels": 4, "kernel_size": 3, "encoding": "cnt", "norm_input": False,
+           "mask_output": True, "activations": ["relu", None], "spiking_neuron": ANN_UNETS[name]}
+    model = getattr(M, name)(cfg).to(DEV)
+    pre = name + ".param_"
+    sd = {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+    model.load_state_dict(sd)
+    tot = 0
+    for i in range(2):
+        x = G(g[f"p{i}_event_cnt"])
+        flows = model(x, x)["flow"]
+        assert len(flows) == 4
+        for s_, f in enumerate(flows):
+            close(N(f), g[f"{name}.p{i}_flow{s_}"], 1e-4, f"pass {i} scale {s_}")
+            tot = tot + f.pow(2).sum() + f.sum()
+    if name != "EVFlowNet":
+        states = model.states
+        for si, st in enumerate(states):
+            ref = g[f"{name}.state{si}"]
+            assert tuple(st.shape) == ref.shape
+            close(N(st), ref, 1e-4, f"state {si}")
+    np.testing.assert_allclose(float(tot.detach()), float(g[f"{name}.loss"]), rtol=2e-5)
+    tot.backward()
+    for k, p in model.named_parameters():
+        close(N(p.grad), g[f"{name}.grad_{k}"], 3e-4, k)
+    model.detach_states()
+    model.reset_states()
+
+
 # ------------------------------------------------------------------ spiking EV-FlowNet (G9, BASELINE config 4 architecture)
 def _unet_cfg(C=4):
     return {"num_bins": 2, "base_num_channels": C, "kernel_size": 3, "encoding": "cnt", "norm_input": False,

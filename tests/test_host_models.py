@@ -41,6 +41,10 @@ def test_reference_state_dicts_load_unchanged():
     _load(M.RNNFireNet(cfg(C=8, neuron=None, acts=("relu", None))), g10, "RNNFireNet.param_")
     _load(M.LeakyFireNet(cfg(C=8, neuron=leaky, acts=("relu", None))), g10, "LeakyFireNet.param_")
     _load(M.LeakyFireFlowNet(cfg(C=8, neuron=leaky, acts=("relu", "tanh"))), g10, "LeakyFireFlowNet.param_")
+    g11 = load_golden("g11_ann_unets")
+    for name in ("EVFlowNet", "RecEVFlowNet", "RNNRecEVFlowNet"):
+        _load(getattr(M, name)(cfg(C=4, neuron=None, acts=("relu", None))), g11, name + ".param_")
+    _load(M.LeakyRecEVFlowNet(cfg(C=4, neuron=leaky, acts=("relu", None))), g11, "LeakyRecEVFlowNet.param_")
     sd = _load(M.SpikingRecEVFlowNet(cfg(C=4)), load_golden("g9_spiking_unet"), "param_")
     assert sd["multires_unetrec.decoders.1.conv2d.ff.weight"].shape == (16, 66, 3, 3)  # cat(pred, x, skip)
 
@@ -54,7 +58,8 @@ def test_parameter_counts_match_the_reference():
 
 
 def test_model_zoo_names_and_ctor_does_not_mutate_config():
-    for name in ("FireNet", "FireFlowNet", "RNNFireNet", "LeakyFireNet", "LeakyFireFlowNet", "LIFFireNet", "PLIFFireNet", "ALIFFireNet", "XLIFFireNet", "LIFFireFlowNet", "SpikingRecEVFlowNet",
+    for name in ("FireNet", "FireFlowNet", "RNNFireNet", "LeakyFireNet", "LeakyFireFlowNet", "EVFlowNet", "RecEVFlowNet",
+                 "RNNRecEVFlowNet", "LeakyRecEVFlowNet", "LIFFireNet", "PLIFFireNet", "ALIFFireNet", "XLIFFireNet", "LIFFireFlowNet", "SpikingRecEVFlowNet",
                  "PLIFRecEVFlowNet", "ALIFRecEVFlowNet", "XLIFRecEVFlowNet"):
         assert name in M.MODELS and getattr(M, name) is M.MODELS[name]
     c = cfg(C=4)

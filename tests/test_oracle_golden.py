@@ -278,3 +278,34 @@ def test_g10_ann_firenets(name):
         ref = g[f"{name}.grad_{k}"]
         got = gr.numpy() if gr is not None else np.zeros_like(ref)
         assert np.abs(got - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-10) + 1e-9, k
+
+
+# --------------------------------------------------------------------- G11
+ANN_UNET_STATES = {"EVFlowNet": 0, "RecEVFlowNet": 4, "RNNRecEVFlowNet": 4, "LeakyRecEVFlowNet": 10}
+
+
+@pytest.mark.parametrize("name", sorted(ANN_UNET_STATES))
+def test_g11_ann_unets(name):
+    """EVFlowNet / RecEVFlowNet (ConvGRU) / RNNRecEVFlowNet / LeakyRecEVFlowNet (reference models/model.py:289-395,
+    412-547, 594-611): 4 flow scales of two passes, final states, BPTT parameter gradients."""
+    g = load_golden("g11_ann_unets")
+    pre = name + ".param_"
+    params = {k[len(pre):]: T(g[k]).clone().requires_grad_(True) for k in g.files if k.startswith(pre)}
+    states = [None] * ANN_UNET_STATES[name]
+    tot = 0
+    for i in range(2):
+        flows, states = osnn.ann_unet_forward(name, params, T(g[f"p{i}_event_cnt"]), states)
+        assert len(flows) == 4
+        for s_, f in enumerate(flows):
+            np.testing.assert_allclose(f.detach().numpy(), g[f"{name}.p{i}_flow{s_}"], rtol=1e-4, atol=1e-6)
+            tot = tot + f.pow(2).sum() + f.sum()
+    for si, st in enumerate(states):
+        st = torch.stack(st) if isinstance(st, tuple) else st
+        np.testing.assert_allclose(st.detach().numpy(), g[f"{name}.state{si}"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(float(tot.detach()), float(g[f"{name}.loss"]), rtol=1e-5)
+    keys = sorted(params)
+    grads = torch.autograd.grad(tot, [params[k] for k in keys], allow_unused=True)
+    for k, gr in zip(keys, grads):
+        ref = g[f"{name}.grad_{k}"]
+        got = gr.numpy() if gr is not None else np.zeros_like(ref)
+        assert np.abs(got - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-10) + 1e-9, k

@@ -454,6 +454,47 @@ def g10_ann_firenets():
     save("g10_ann_firenets", **a)
 
 
+ANN_UNETS = {
+    "EVFlowNet": (("relu", None), None),
+    "RecEVFlowNet": (("relu", None), None),
+    "RNNRecEVFlowNet": (("relu", None), None),
+    "LeakyRecEVFlowNet": (("relu", None), {"leak": [-1.0, 0.5], "learn_leak": True}),
+}
+
+
+def g11_ann_unets():
+    """Non-spiking EV-FlowNets (models/model.py:289-395 EVFlowNet, :412-547 RecEVFlowNet/ConvGRU, :594-601 ConvRNN,
+    :604-611 leaky): 2 passes at 32x32, loss = sum flow^2 + sum flow over the 4 scales of both passes,
+    per-scale flows, final states, parameter gradients."""
+    B, n, H, W, P = 1, 600, 32, 32, 2
+    a = {}
+    batches = [batch_windows(B, n, H, W, 6000 + 10 * k) for k in range(P)]
+    for k, d in enumerate(batches):
+        a[f"p{k}_event_cnt"] = d["event_cnt"]
+    for name, (acts, neuron) in ANN_UNETS.items():
+        torch.manual_seed(4)
+        model = build(name, model_cfg(name, C=4, neuron=neuron, acts=acts))
+        model.train()
+        for pn, v in model.state_dict().items():
+            a[f"{name}.param_{pn}"] = v.clone()
+        tot = 0
+        for k, d in enumerate(batches):
+            out = model(d["event_voxel"], d["event_cnt"])
+            assert len(out["flow"]) == 4
+            for si, f in enumerate(out["flow"]):
+                a[f"{name}.p{k}_flow{si}"] = f
+                tot = tot + f.pow(2).sum() + f.sum()
+        if hasattr(model, "multires_unetrec"):
+            for si, st in enumerate(model.multires_unetrec.states):
+                a[f"{name}.state{si}"] = st
+        tot.backward()
+        a[f"{name}.loss"] = tot.detach()
+        for pn, prm in model.named_parameters():
+            a[f"{name}.grad_{pn}"] = prm.grad.clone() if prm.grad is not None else torch.zeros_like(prm)
+        print(name, "loss", float(tot.detach()), "params", sum(p.numel() for p in model.parameters()))
+    save("g11_ann_unets", **a)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # only the named generators, e.g. `tools/gen_golden.py g10_ann_firenets`
         for fn in sys.argv[1:]:
@@ -471,6 +512,7 @@ if __name__ == "__main__":
     g8_firenet_ann()
     g9_spiking_unet()
     g10_ann_firenets()
+    g11_ann_unets()
     meta = {"torch": torch.__version__, "numpy": np.__version__, "reference": "tudelft/event_flow @ /root/reference (v1)",
             "note": "outputs of the reference run in the build container; reference pins torch==1.7.0"}
     with open(os.path.join(OUT, "meta.json"), "w") as f:
