@@ -98,6 +98,8 @@ NETWORK_SIGNATURES = {
     "evf_act_fwd": [I, P, P, L, P, P],
     "evf_act_bwd": [I, P, P, L, P, P],
     "evf_leaky_fwd": [P, P, P, P, I, L, I, P, P, P],
+    "evf_lstm_fwd": [P, P, L, I, P, P, P],
+    "evf_lstm_bwd": [P, P, P, P, P, L, I, P, P, P],
     "evf_leaky_bwd": [P, P, P, P, P, I, L, I, P, P, P, P],
     "evf_spike_fwd": [P, P, I, L, P, P],
     "evf_spike_bwd": [I, P, P, I, P, F, L, P, P],

@@ -746,6 +746,56 @@ extern "C" int evf_gru_gates_bwd(const float* g_hr, const float* h, const float*
   return evf_status();
 }
 
+// ConvLSTM gate algebra (models/submodules.py:357-374).  gates [npix, 4*Ch] = conv(cat(x, h)) with the channel chunks
+// in | remember | out | cell;  i, r, o = sigmoid, cg = tanh;  cell' = r * cell + i * cg;  hidden = o * tanh(cell').
+// The activated gates overwrite `gates` (saved for the backward).
+__global__ void k_lstm_fwd(float* __restrict__ gates, const float* __restrict__ prev_cell, long npix, int Ch,
+                           float* __restrict__ cell, float* __restrict__ hidden) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * Ch) return;
+  const long pix = i / Ch;
+  const int c = (int)(i - pix * Ch);
+  float* gp = gates + pix * 4 * Ch + c;
+  const float ig = 1.0f / (1.0f + expf(-gp[0])), rg = 1.0f / (1.0f + expf(-gp[Ch])), og = 1.0f / (1.0f + expf(-gp[2 * Ch])),
+              cg = tanhf(gp[3 * Ch]);
+  const float cn = rg * (prev_cell ? prev_cell[i] : 0.f) + ig * cg;
+  gp[0] = ig, gp[Ch] = rg, gp[2 * Ch] = og, gp[3 * Ch] = cg;
+  cell[i] = cn;
+  hidden[i] = og * tanhf(cn);
+}
+__global__ void k_lstm_bwd(const float* __restrict__ g_hidden, const float* __restrict__ g_cell, const float* __restrict__ gates,
+                           const float* __restrict__ cell, const float* __restrict__ prev_cell, long npix, int Ch,
+                           float* __restrict__ g_gates, float* __restrict__ g_prev_cell) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * Ch) return;
+  const long pix = i / Ch;
+  const int c = (int)(i - pix * Ch);
+  const float* gp = gates + pix * 4 * Ch + c;
+  const float ig = gp[0], rg = gp[Ch], og = gp[2 * Ch], cg = gp[3 * Ch];
+  const float tc = tanhf(cell[i]), gh = g_hidden ? g_hidden[i] : 0.f, pc = prev_cell ? prev_cell[i] : 0.f;
+  const float gc = (g_cell ? g_cell[i] : 0.f) + gh * og * (1.0f - tc * tc);
+  float* go = g_gates + pix * 4 * Ch + c;
+  go[0] = gc * cg * ig * (1.0f - ig);
+  go[Ch] = gc * pc * rg * (1.0f - rg);
+  go[2 * Ch] = gh * tc * og * (1.0f - og);
+  go[3 * Ch] = gc * ig * (1.0f - cg * cg);
+  if (g_prev_cell) g_prev_cell[i] = gc * rg;
+}
+extern "C" int evf_lstm_fwd(float* gates, const float* prev_cell, int64_t npix, int Ch, float* cell, float* hidden,
+                            void* stream) {
+  if (!gates || !cell || !hidden || npix <= 0 || Ch <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_lstm_fwd, dim3(evf_cdiv(npix * Ch, 256)), dim3(256), 0, EVF_STREAM(stream), gates, prev_cell, (long)npix,
+                     Ch, cell, hidden);
+  return evf_status();
+}
+extern "C" int evf_lstm_bwd(const float* g_hidden, const float* g_cell, const float* gates, const float* cell,
+                            const float* prev_cell, int64_t npix, int Ch, float* g_gates, float* g_prev_cell, void* stream) {
+  if ((!g_hidden && !g_cell) || !gates || !cell || !g_gates || npix <= 0 || Ch <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_lstm_bwd, dim3(evf_cdiv(npix * Ch, 256)), dim3(256), 0, EVF_STREAM(stream), g_hidden, g_cell, gates,
+                     cell, prev_cell, (long)npix, Ch, g_gates, g_prev_cell);
+  return evf_status();
+}
+
 // ---------------------------------------------------------------------------
 // stand-alone spike functions (models/spiking_util.py:13-109): z = (x - thresh > 0) as fp32,
 // backward g * surrogate(x - thresh).  thresh is one scalar (device pointer).

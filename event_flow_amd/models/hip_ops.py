@@ -537,6 +537,95 @@ def conv_gru(owner, x, h):
 
 
 # ---------------------------------------------------------------------------
+# ConvLSTM (submodules.py:335-374): Gates(cat([x, hidden])) = conv(x, W[:, :Cx]) + conv(hidden, W[:, Cx:])
+# ---------------------------------------------------------------------------
+class _ConvLSTM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, owner, x, hidden, cell, w, b):
+        ctx.set_materialize_grads(False)
+        xn = to_nhwc(x)
+        B, H, W, Cx = xn.shape
+        Ch, k = w.shape[0] // 4, w.shape[2]
+        hn = to_nhwc(hidden) if hidden is not None else None
+        cn = to_nhwc(cell) if cell is not None else None
+        dev = xn.device
+        gates = _new((B, H, W, 4 * Ch), dev)
+        conv_fwd(xn, _wcache(owner, "x").get(w, 0, 0, Cx), b.detach().contiguous(), gates, Cx, 4 * Ch, k, 1)
+        if hn is not None:
+            conv_fwd(hn, _wcache(owner, "h").get(w, 0, Cx, Ch), None, gates, Ch, 4 * Ch, k, 1, accumulate=1)
+        new_c, new_h = _new((B, H, W, Ch), dev), _new((B, H, W, Ch), dev)
+        _lib.call("evf_lstm_fwd", _lib.ptr(gates), _lib.ptr(cn), B * H * W, Ch, _lib.ptr(new_c), _lib.ptr(new_h))
+        ctx.owner, ctx.bias = owner, b
+        ctx.saved = (xn, hn, cn, gates, new_c, w)
+        return from_nhwc(new_h), from_nhwc(new_c)
+
+    @staticmethod
+    def backward(ctx, g_h, g_c):
+        owner = ctx.owner
+        xn, hn, cn, gates, new_c, w = ctx.saved
+        if g_h is None and g_c is None:
+            return (None,) * 6
+        B, H, W, Cx = xn.shape
+        Ch, k = w.shape[0] // 4, w.shape[2]
+        dev = xn.device
+        need = ctx.needs_input_grad  # (owner, x, hidden, cell, w, b)
+        ghn = to_nhwc(g_h) if g_h is not None else None
+        gcn = to_nhwc(g_c) if g_c is not None else None
+        g_gates = _new((B, H, W, 4 * Ch), dev)
+        g_pc = _new((B, H, W, Ch), dev) if (cn is not None and need[3]) else None
+        _lib.call("evf_lstm_bwd", _lib.ptr(ghn), _lib.ptr(gcn), _lib.ptr(gates), _lib.ptr(new_c), _lib.ptr(cn), B * H * W, Ch,
+                  _lib.ptr(g_gates), _lib.ptr(g_pc))
+        g_w = g_b = None
+        if need[4] or need[5]:
+            d_w, d_b = bound_grad(w), bound_grad(ctx.bias)
+            direct = d_w is not None and d_b is not None
+            g_w = d_w if direct else torch.zeros(tuple(w.shape), dtype=torch.float32, device=dev)
+            g_b = d_b if direct else torch.zeros((4 * Ch,), dtype=torch.float32, device=dev)
+            conv_wgrad(xn, g_gates, g_w, g_b, Cx, 4 * Ch, k, 1, cin_total=Cx + Ch, cin_off=0, accumulate=1)
+            if hn is not None:
+                conv_wgrad(hn, g_gates, g_w, None, Ch, 4 * Ch, k, 1, cin_total=Cx + Ch, cin_off=Cx, accumulate=1)
+            if direct:
+                g_w = g_b = None
+        g_x = g_hid = None
+        if need[1]:
+            g_xn = _new((B, H, W, Cx), dev)
+            conv_dgrad(g_gates, _wcache(owner, "xT").get(w, 1, 0, Cx), g_xn, Cx, 4 * Ch, k, 1)
+            g_x = from_nhwc(g_xn)
+        if hn is not None and need[2]:
+            g_hn = _new((B, H, W, Ch), dev)
+            conv_dgrad(g_gates, _wcache(owner, "hT").get(w, 1, Cx, Ch), g_hn, Ch, 4 * Ch, k, 1)
+            g_hid = from_nhwc(g_hn)
+        return None, g_x, g_hid, from_nhwc(g_pc) if g_pc is not None else None, g_w, g_b
+
+
+def conv_lstm(owner, x, hidden, cell):
+    """-> (hidden', cell')"""
+    return _ConvLSTM.apply(owner, x, hidden, cell, owner.Gates.weight, owner.Gates.bias)
+
+
+# ---------------------------------------------------------------------------
+# x1 + x2 (skip_sum, model_util.py:22-27)
+# ---------------------------------------------------------------------------
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        an, bn = to_nhwc(a), to_nhwc(b)
+        y = _new(tuple(an.shape), an.device)
+        _lib.call("evf_act_fwd", 0, _lib.ptr(an), _lib.ptr(bn), y.numel(), _lib.ptr(y))
+        return from_nhwc(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    if a.shape != b.shape:
+        raise _lib.EvflowError(f"add: shapes {tuple(a.shape)} and {tuple(b.shape)} differ")
+    return _Add.apply(a, b)
+
+
+# ---------------------------------------------------------------------------
 # up-sampling
 # ---------------------------------------------------------------------------
 class _Up2(torch.autograd.Function):

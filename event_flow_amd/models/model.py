@@ -18,7 +18,13 @@ from .base import BaseModel
 from .engine import FireNetEngine
 from . import hip_ops
 from .model_util import CropParameters, copy_states
-from .unet import LeakyMultiResUNetRecurrent, MultiResUNet, MultiResUNetRecurrent, SpikingMultiResUNetRecurrent
+from .unet import (
+    LeakyMultiResUNetRecurrent,
+    MultiResUNet,
+    MultiResUNetRecurrent,
+    SpikingMultiResUNetRecurrent,
+    UNetRecurrent,
+)
 from .spiking_submodules import (
     ConvALIF,
     ConvALIFRecurrent,
@@ -396,6 +402,81 @@ def _multires_forward(self, unet, event_voxel, event_cnt, log):
     return {"flow": flow_list, "activity": None}
 
 
+class E2VID(BaseModel):
+    """E2VID (Rebecq et al., TPAMI 2021) adapted for optical flow: recurrent UNet with ConvLSTM encoders and one
+    flow map at full resolution.  Reference: models/model.py:29-145."""
+
+    def __init__(self, unet_kwargs):
+        super().__init__()
+        unet_kwargs = dict(unet_kwargs)  # the reference mutates the caller's dict (quirk q3); we do not
+        net_kwargs = {
+            "base_num_channels": unet_kwargs["base_num_channels"],
+            "num_encoders": 3,
+            "num_residual_blocks": 2,
+            "num_output_channels": 2,
+            "skip_type": "sum",
+            "norm": unet_kwargs.get("norm", None),
+            "use_upsample_conv": unet_kwargs.get("use_upsample_conv", True),
+            "kernel_size": unet_kwargs["kernel_size"],
+            "channel_multiplier": 2,
+            "recurrent_block_type": "convlstm",
+            "final_activation": "tanh",
+        }
+        self.crop = None
+        self.mask = unet_kwargs["mask_output"]
+        self.norm_input = False if "norm_input" not in unet_kwargs.keys() else unet_kwargs["norm_input"]
+        self.encoding = unet_kwargs["encoding"]
+        self.num_bins = unet_kwargs["num_bins"]
+        self.num_encoders = net_kwargs["num_encoders"]
+        unet_kwargs.update(net_kwargs)
+        for k in ("name", "encoding", "round_encoding", "norm_input", "mask_output", "spiking_neuron"):
+            unet_kwargs.pop(k, None)
+        self.unetrecurrent = UNetRecurrent(unet_kwargs)
+
+    @property
+    def states(self):
+        return copy_states(self.unetrecurrent.states)
+
+    @states.setter
+    def states(self, states):
+        self.unetrecurrent.states = states
+
+    def detach_states(self):
+        det = []
+        for state in self.unetrecurrent.states:
+            if type(state) is tuple:
+                det.append(tuple(h.detach() for h in state))
+            else:
+                det.append(state.detach() if state is not None else None)
+        self.unetrecurrent.states = det
+
+    def reset_states(self):
+        self.unetrecurrent.states = [None] * self.unetrecurrent.num_states
+
+    def init_cropping(self, width, height, safety_margin=0):
+        self.crop = CropParameters(width, height, self.num_encoders, safety_margin)
+
+    def forward(self, event_voxel, event_cnt, log=False):
+        """-> {"flow": [[N,2,H,W]], "activity": None}  (reference :100-145)."""
+        if self.encoding == "voxel":
+            x = event_voxel
+        elif self.encoding == "cnt" and self.num_bins == 2:
+            x = event_cnt
+        else:
+            print("Model error: Incorrect input encoding.")
+            raise AttributeError
+        if self.norm_input:
+            x = hip_ops.norm_nonzero(x)
+        if self.crop is not None:
+            x = self.crop.pad(x)
+        flow = self.unetrecurrent.forward(x)
+        if log:
+            raise NotImplementedError("Activity logging not implemented")
+        if self.crop is not None:
+            flow = flow[:, :, self.crop.iy0 : self.crop.iy1, self.crop.ix0 : self.crop.ix1]
+        return {"flow": [flow.contiguous()], "activity": None}
+
+
 class EVFlowNet(BaseModel):
     """EV-FlowNet (Zhu et al., RSS 2018): feed-forward multi-resolution UNet, no state.
     Reference: models/model.py:289-395."""
@@ -488,6 +569,6 @@ class XLIFRecEVFlowNet(RecEVFlowNet):
 MODELS = {
     c.__name__: c
     for c in (FireNet, FireFlowNet, RNNFireNet, LeakyFireNet, LeakyFireFlowNet, LIFFireNet, PLIFFireNet, ALIFFireNet,
-              XLIFFireNet, LIFFireFlowNet, EVFlowNet, RecEVFlowNet, RNNRecEVFlowNet, LeakyRecEVFlowNet, SpikingRecEVFlowNet,
+              XLIFFireNet, LIFFireFlowNet, E2VID, EVFlowNet, RecEVFlowNet, RNNRecEVFlowNet, LeakyRecEVFlowNet, SpikingRecEVFlowNet,
               PLIFRecEVFlowNet, ALIFRecEVFlowNet, XLIFRecEVFlowNet)
 }

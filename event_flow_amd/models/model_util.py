@@ -20,7 +20,9 @@ def skip_sum(x1, x2):
     """Reference: models/model_util.py:22-27."""
     dh, dw = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
     x1 = torch.nn.functional.pad(x1, (dw // 2, dw - dw // 2, dh // 2, dh - dh // 2))
-    return x1 + x2
+    from . import hip_ops  # the sum runs in libevflow_hip.so
+
+    return hip_ops.add(x1, x2)
 
 
 def optimal_crop_size(max_size, max_subsample_factor, safety_margin=0):

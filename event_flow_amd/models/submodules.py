@@ -81,6 +81,20 @@ class ConvGRU(nn.Module):
         return new, new
 
 
+class ConvLSTM(nn.Module):
+    """Convolutional LSTM cell: (input, (hidden, cell)) -> (hidden', cell').  Reference: models/submodules.py:314-374."""
+
+    def __init__(self, input_size, hidden_size, kernel_size, activation=None):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        assert activation is None, "ConvLSTM activation cannot be set (just for compatibility)"
+        self.Gates = nn.Conv2d(input_size + hidden_size, 4 * hidden_size, kernel_size, padding=kernel_size // 2)
+
+    def forward(self, input_, prev_state=None):
+        prev_hidden, prev_cell = prev_state if prev_state is not None else (None, None)
+        return hip_ops.conv_lstm(self, input_, prev_hidden, prev_cell)
+
+
 def _zeros_like_state(x, channels):
     B, _, H, W = x.shape
     return torch.zeros((B, H, W, channels), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
@@ -205,17 +219,18 @@ class RecurrentConvLayer(nn.Module):
                  activation_ff="relu", activation_rec=None, norm=None, BN_momentum=0.1):
         super().__init__()
         assert recurrent_block_type in ["convlstm", "convgru", "convrnn"]
-        if recurrent_block_type == "convlstm":
-            raise NotImplementedError("ConvLSTM blocks (E2VID image reconstruction) are not part of the flow path")
         self.recurrent_block_type = recurrent_block_type
-        block = ConvGRU if recurrent_block_type == "convgru" else ConvRecurrent
+        block = {"convlstm": ConvLSTM, "convgru": ConvGRU, "convrnn": ConvRecurrent}[recurrent_block_type]
         self.conv = ConvLayer(in_channels, out_channels, kernel_size, stride, activation_ff, norm, BN_momentum=BN_momentum)
         self.recurrent_block = block(input_size=out_channels, hidden_size=out_channels, kernel_size=3,
                                      activation=activation_rec)
 
     def forward(self, x, prev_state):
         x = self.conv(x)
-        return self.recurrent_block(x, prev_state)
+        x, state = self.recurrent_block(x, prev_state)
+        if isinstance(self.recurrent_block, ConvLSTM):
+            state = (x, state)  # (hidden, cell), reference :233-234
+        return x, state
 
 
 class ResidualBlock(nn.Module):

@@ -1,5 +1,6 @@
 """Multi-resolution UNets -- host-side mirror of reference models/unet.py:
-BaseUNet (:28-145), MultiResUNet (:224-311, EVFlowNet), MultiResUNetRecurrent
+BaseUNet (:28-145), UNetRecurrent (:148-221, E2VID), MultiResUNet (:224-311,
+EVFlowNet), MultiResUNetRecurrent
 (:314-415, ConvGRU / ConvRNN encoders), SpikingMultiResUNetRecurrent (:418-465)
 and LeakyMultiResUNetRecurrent (:468-480): 4 strided encoders (each followed by
 a recurrent block in the recurrent nets), 2 residual blocks, 4 bilinear
@@ -128,6 +129,59 @@ class BaseUNet(nn.Module):
             if pad and self.skip_type == "concat" and getattr(decoder.conv2d, "kind", "ann") in ("lif", "alif", "ann"):
                 x = torch.cat([x, x.new_zeros((x.shape[0], pad) + tuple(x.shape[2:]))], 1)
         return x
+
+
+class UNetRecurrent(BaseUNet):
+    """E2VID's UNet: head conv, ConvLayer + ConvLSTM encoders, residual blocks, up-sampling decoders on x + skip,
+    one prediction at full resolution (reference unet.py:148-221)."""
+
+    def __init__(self, unet_kwargs):
+        kw = dict(unet_kwargs)
+        final_activation = kw.pop("final_activation", "none")
+        nn.Module.__init__(self)
+        self.final_activation = final_activation if hasattr(torch, final_activation) else None
+        self._base_init(**kw)
+        self.head = ConvLayer(self.num_bins, self.base_num_channels, kernel_size=self.kernel_size, stride=1)
+        self.encoders = self.build_recurrent_encoders()
+        self.resblocks = self.build_resblocks()
+        self.decoders = self.build_decoders()
+        self.pred = self.ff_type(self.base_num_channels if self.skip_type == "sum" else 2 * self.base_num_channels,
+                                 self.num_output_channels, 1, activation=None, norm=self.norm)
+        self.num_states = self.num_encoders
+        self.states = [None] * self.num_states
+
+    def build_recurrent_encoders(self):  # unet.py:175-190: every encoder input is a feature map (the head comes first)
+        encoders = nn.ModuleList()
+        for cin, cout in zip(self.encoder_input_sizes, self.encoder_output_sizes):
+            encoders.append(self.rec_type(cin, cout, kernel_size=self.kernel_size, stride=2,
+                                          recurrent_block_type=self.recurrent_block_type, activation_ff=self.ff_act,
+                                          activation_rec=self.rec_act, norm=self.norm))
+        return encoders
+
+    def build_decoders(self):  # unet.py:124-138
+        decoders = nn.ModuleList()
+        for cin, cout in zip(reversed(self.encoder_output_sizes), reversed(self.encoder_input_sizes)):
+            decoders.append(self.UpsampleLayer(cin if self.skip_type == "sum" else 2 * cin, cout, kernel_size=self.kernel_size,
+                                               activation=self.ff_act, norm=self.norm, **self.spiking_kwargs))
+        return decoders
+
+    def forward(self, x):
+        """x [N,num_bins,H,W] -> [N,num_output_channels,H,W].  unet.py:192-221."""
+        from . import hip_ops
+
+        x = self.head(x)
+        head = x
+        blocks = []
+        for i, encoder in enumerate(self.encoders):
+            x, self.states[i] = encoder(x, self.states[i])
+            blocks.append(x)
+        for resblock in self.resblocks:
+            x, _ = resblock(x)
+        for i, decoder in enumerate(self.decoders):
+            x = decoder(self.skip_ftn(x, blocks[self.num_encoders - i - 1]))
+        x = self.skip_ftn(x, head)
+        # pred (1x1 ConvLayer, no activation) followed by the final activation = one conv + activation launch
+        return hip_ops.conv_act(self.pred, x, self.pred.conv2d.weight, self.pred.conv2d.bias, 1, self.final_activation)
 
 
 class MultiResUNet(BaseUNet):

@@ -470,6 +470,15 @@ int evf_gru_out_bwd(const float* g_new, const float* h, const float* u, const fl
 int evf_gru_gates_bwd(const float* g_hr, const float* h, const float* r, int64_t n, float* g_cr,
                       float* g_h, void* stream);
 
+/* ConvLSTM gate algebra (models/submodules.py:357-374).  gates [npix, 4*Ch] NHWC = Gates(cat(x, hidden)) with the
+ * channel chunks in | remember | out | cell (gates.chunk(4, 1)):  i, r, o = sigmoid, cg = tanh;
+ * cell' = r * prev_cell + i * cg;  hidden = o * tanh(cell').  evf_lstm_fwd overwrites `gates` with the activated
+ * gates (the backward's saved tensor); prev_cell null = zeros.  evf_lstm_bwd: g_gates = d loss / d (pre-activation
+ * gates), g_prev_cell (null = not needed); g_hidden / g_cell: either may be null. */
+int evf_lstm_fwd(float* gates, const float* prev_cell, int64_t npix, int Ch, float* cell, float* hidden, void* stream);
+int evf_lstm_bwd(const float* g_hidden, const float* g_cell, const float* gates, const float* cell, const float* prev_cell,
+                 int64_t npix, int Ch, float* g_gates, float* g_prev_cell, void* stream);
+
 /* ------------------------------------------------------------------ optimiser
  * train_flow.py:157-163: clip_grad_norm_(max_norm) + Adam(lr) on one flat
  * parameter buffer.  norm_ws [2] float workspace: [0] receives the squared

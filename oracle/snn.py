@@ -392,6 +392,56 @@ def ann_unet_forward(name, p, x, states, *, num_encoders=4, num_res=2, acts=("re
     return flows, new_states
 
 
+def conv_lstm_step(p, pre, x, state):
+    """ConvLSTM.forward, models/submodules.py:335-374."""
+    ch = p[pre + "Gates.weight"].shape[0] // 4
+    if state is None:
+        z = torch.zeros(x.shape[0], ch, *x.shape[2:], dtype=x.dtype)
+        state = (z, z)
+    prev_hidden, prev_cell = state
+    gates = _conv(torch.cat((x, prev_hidden), 1), p[pre + "Gates.weight"], bias=p[pre + "Gates.bias"])
+    in_gate, remember_gate, out_gate, cell_gate = gates.chunk(4, 1)
+    in_gate, remember_gate, out_gate = torch.sigmoid(in_gate), torch.sigmoid(remember_gate), torch.sigmoid(out_gate)
+    cell_gate = torch.tanh(cell_gate)
+    cell = remember_gate * prev_cell + in_gate * cell_gate
+    hidden = out_gate * torch.tanh(cell)
+    return hidden, cell
+
+
+def skip_sum(x1, x2):
+    """models/model_util.py:22-27."""
+    dh, dw = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
+    x1 = F.pad(x1, (dw // 2, dw - dw // 2, dh // 2, dh - dh // 2))
+    return x1 + x2
+
+
+def e2vid_forward(p, x, states, *, num_encoders=3, num_res=2, acts=("relu", None)):
+    """E2VID: UNetRecurrent.forward (unet.py:192-221) with ConvLSTM encoders (RecurrentConvLayer.forward,
+    submodules.py:229-235: the state is (hidden, cell)), skip 'sum', final tanh (model.py:45-56)."""
+    pre = "unetrecurrent."
+    ff_act, _ = acts
+    x = _act("relu", _conv(x, p[pre + "head.conv2d.weight"], bias=p[pre + "head.conv2d.bias"]))  # ConvLayer default relu
+    head = x
+    new_states, blocks = [], []
+    for i in range(num_encoders):
+        e = f"{pre}encoders.{i}."
+        x = _act(ff_act, _conv(x, p[e + "conv.conv2d.weight"], stride=2, bias=p[e + "conv.conv2d.bias"]))
+        x, cell = conv_lstm_step(p, e + "recurrent_block.", x, states[i])
+        new_states.append((x, cell))
+        blocks.append(x)
+    for i in range(num_res):
+        r = f"{pre}resblocks.{i}."
+        o1 = _act(ff_act, _conv(x, p[r + "conv1.weight"], bias=p[r + "conv1.bias"]))
+        x = _act(ff_act, _conv(o1, p[r + "conv2.weight"], bias=p[r + "conv2.bias"]) + x)
+    for i in range(num_encoders):
+        d = f"{pre}decoders.{i}."
+        x = skip_sum(x, blocks[num_encoders - i - 1])
+        x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+        x = _act(ff_act, _conv(x, p[d + "conv2d.weight"], bias=p[d + "conv2d.bias"]))
+    x = skip_sum(x, head)
+    return torch.tanh(F.conv2d(x, p[pre + "pred.conv2d.weight"], p[pre + "pred.conv2d.bias"])), new_states
+
+
 def detach_states(states):
     def d(s):
         if s is None:

@@ -305,6 +305,40 @@ def test_g11_ann_evflownets(name):
     model.reset_states()
 
 
+# ------------------------------------------------------------------ E2VID (G12)
+def test_g12_e2vid():
+    """E2VID (ConvLSTM encoders, skip 'sum') against the reference's outputs: flows of three passes, final
+    (hidden, cell) states, BPTT gradients of every parameter."""
+    from event_flow_amd.models import model as M
+
+    g = load_golden("g12_e2vid")
+    cfg = {"num_bins": 2, "base_num_channels": 4, "kernel_size": 3, "encoding": "cnt", "norm_input": False,
+           "mask_output": True, "activations": ["relu", None], "spiking_neuron": None}
+    model = M.E2VID(cfg).to(DEV)
+    sd = {k[len("param_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param_")}
+    model.load_state_dict(sd)
+    tot = 0
+    for i in range(3):
+        x = G(g[f"p{i}_event_cnt"])
+        out = model(x, x)
+        assert len(out["flow"]) == 1 and out["activity"] is None
+        close(N(out["flow"][0]), g[f"p{i}_flow"], 1e-4, f"pass {i}")
+        tot = tot + out["flow"][0].pow(2).sum() + out["flow"][0].sum()
+    states = model.states
+    assert len(states) == 3 and all(type(s_) is tuple and len(s_) == 2 for s_ in states)
+    for si, (h, c) in enumerate(states):
+        close(N(h), g[f"state{si}_hidden"], 1e-4, f"hidden {si}")
+        close(N(c), g[f"state{si}_cell"], 1e-4, f"cell {si}")
+    np.testing.assert_allclose(float(tot.detach()), float(g["loss"]), rtol=2e-5)
+    tot.backward()
+    for k, p in model.named_parameters():
+        close(N(p.grad), g["grad_" + k], 3e-4, k)
+    model.detach_states()
+    assert all(not h.requires_grad for st in model.unetrecurrent.states for h in st)
+    model.reset_states()
+    assert model.unetrecurrent.states == [None] * 3
+
+
 # ------------------------------------------------------------------ spiking EV-FlowNet (G9, BASELINE config 4 architecture)
 def _unet_cfg(C=4):
     return {"num_bins": 2, "base_num_channels": C, "kernel_size": 3, "encoding": "cnt", "norm_input": False,

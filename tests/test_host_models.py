@@ -41,6 +41,7 @@ def test_reference_state_dicts_load_unchanged():
     _load(M.RNNFireNet(cfg(C=8, neuron=None, acts=("relu", None))), g10, "RNNFireNet.param_")
     _load(M.LeakyFireNet(cfg(C=8, neuron=leaky, acts=("relu", None))), g10, "LeakyFireNet.param_")
     _load(M.LeakyFireFlowNet(cfg(C=8, neuron=leaky, acts=("relu", "tanh"))), g10, "LeakyFireFlowNet.param_")
+    _load(M.E2VID(cfg(C=4, neuron=None, acts=("relu", None))), load_golden("g12_e2vid"), "param_")
     g11 = load_golden("g11_ann_unets")
     for name in ("EVFlowNet", "RecEVFlowNet", "RNNRecEVFlowNet"):
         _load(getattr(M, name)(cfg(C=4, neuron=None, acts=("relu", None))), g11, name + ".param_")
@@ -58,7 +59,7 @@ def test_parameter_counts_match_the_reference():
 
 
 def test_model_zoo_names_and_ctor_does_not_mutate_config():
-    for name in ("FireNet", "FireFlowNet", "RNNFireNet", "LeakyFireNet", "LeakyFireFlowNet", "EVFlowNet", "RecEVFlowNet",
+    for name in ("FireNet", "FireFlowNet", "RNNFireNet", "LeakyFireNet", "LeakyFireFlowNet", "E2VID", "EVFlowNet", "RecEVFlowNet",
                  "RNNRecEVFlowNet", "LeakyRecEVFlowNet", "LIFFireNet", "PLIFFireNet", "ALIFFireNet", "XLIFFireNet", "LIFFireFlowNet", "SpikingRecEVFlowNet",
                  "PLIFRecEVFlowNet", "ALIFRecEVFlowNet", "XLIFRecEVFlowNet"):
         assert name in M.MODELS and getattr(M, name) is M.MODELS[name]

@@ -309,3 +309,26 @@ def test_g11_ann_unets(name):
         ref = g[f"{name}.grad_{k}"]
         got = gr.numpy() if gr is not None else np.zeros_like(ref)
         assert np.abs(got - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-10) + 1e-9, k
+
+
+# --------------------------------------------------------------------- G12
+def test_g12_e2vid():
+    """E2VID (reference models/model.py:29-145): flows of three passes, final (hidden, cell) states, BPTT gradients."""
+    g = load_golden("g12_e2vid")
+    params = {k[len("param_"):]: T(g[k]).clone().requires_grad_(True) for k in g.files if k.startswith("param_")}
+    states = [None] * 3
+    tot = 0
+    for i in range(3):
+        flow, states = osnn.e2vid_forward(params, T(g[f"p{i}_event_cnt"]), states)
+        np.testing.assert_allclose(flow.detach().numpy(), g[f"p{i}_flow"], rtol=1e-4, atol=1e-6)
+        tot = tot + flow.pow(2).sum() + flow.sum()
+    for si, (h, c) in enumerate(states):
+        np.testing.assert_allclose(h.detach().numpy(), g[f"state{si}_hidden"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(c.detach().numpy(), g[f"state{si}_cell"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(float(tot.detach()), float(g["loss"]), rtol=1e-5)
+    keys = sorted(params)
+    grads = torch.autograd.grad(tot, [params[k] for k in keys], allow_unused=True)
+    for k, gr in zip(keys, grads):
+        ref = g["grad_" + k]
+        got = gr.numpy() if gr is not None else np.zeros_like(ref)
+        assert np.abs(got - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-10) + 1e-9, k

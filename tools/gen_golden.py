@@ -495,6 +495,33 @@ def g11_ann_unets():
     save("g11_ann_unets", **a)
 
 
+def g12_e2vid():
+    """E2VID (models/model.py:29-145; ConvLSTM encoders, skip 'sum'): 3 passes at 32x32 with a state detach after
+    the first, loss = sum flow^2 + sum flow, flows, final (hidden, cell) states, parameter gradients."""
+    B, n, H, W, P = 2, 500, 32, 32, 3
+    a = {}
+    torch.manual_seed(5)
+    model = build("E2VID", model_cfg("E2VID", C=4, neuron=None, acts=("relu", None)))
+    model.train()
+    for pn, v in model.state_dict().items():
+        a[f"param_{pn}"] = v.clone()
+    tot = 0
+    for k in range(P):
+        d = batch_windows(B, n, H, W, 7000 + 10 * k)
+        a[f"p{k}_event_cnt"] = d["event_cnt"]
+        out = model(d["event_voxel"], d["event_cnt"])
+        a[f"p{k}_flow"] = out["flow"][0]
+        tot = tot + out["flow"][0].pow(2).sum() + out["flow"][0].sum()
+    for si, (h, c) in enumerate(model.unetrecurrent.states):
+        a[f"state{si}_hidden"], a[f"state{si}_cell"] = h, c
+    tot.backward()
+    a["loss"] = tot.detach()
+    for pn, prm in model.named_parameters():
+        a[f"grad_{pn}"] = prm.grad.clone() if prm.grad is not None else torch.zeros_like(prm)
+    print("E2VID loss", float(tot.detach()), "params", sum(p.numel() for p in model.parameters()))
+    save("g12_e2vid", **a)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # only the named generators, e.g. `tools/gen_golden.py g10_ann_firenets`
         for fn in sys.argv[1:]:
@@ -513,6 +540,7 @@ if __name__ == "__main__":
     g9_spiking_unet()
     g10_ann_firenets()
     g11_ann_unets()
+    g12_e2vid()
     meta = {"torch": torch.__version__, "numpy": np.__version__, "reference": "tudelft/event_flow @ /root/reference (v1)",
             "note": "outputs of the reference run in the build container; reference pins torch==1.7.0"}
     with open(os.path.join(OUT, "meta.json"), "w") as f:
