@@ -49,7 +49,7 @@ def test(args, config_parser):
     else:
         from event_flow_amd.dataloader.h5 import H5Loader
 
-        data = H5Loader(config, config["model"]["num_bins"])
+        data = H5Loader(config, config["model"]["num_bins"], device=device)
 
     results = {m: {"metric": 0.0, "it": 0, **({"percent": 0.0} if m == "AEE" else {})} for m in names}
     iwe_sharpness = []
@@ -58,6 +58,8 @@ def test(args, config_parser):
             if data.new_seq:
                 data.new_seq = False
                 model.reset_states()
+            if getattr(data, "pass_done", False):  # every sequence was visited (eval_flow.py:124-127)
+                break
             x = model(inputs["event_voxel"], inputs["event_cnt"])
             iwe = compute_pol_iwe(x["flow"][-1], inputs["event_list"], config["loader"]["resolution"],
                                   inputs["event_list_pol_mask"][:, :, 0:1], inputs["event_list_pol_mask"][:, :, 1:2],

@@ -1107,6 +1107,22 @@ extern "C" int evf_device_count(void) {
 }
 
 // --------------------------------------------------------------------------
+// hot-pixel mask applied to the encodings of a batch (dataloader/h5.py:289-295): x[b][c][q] *= mask[b][q]
+// --------------------------------------------------------------------------
+__global__ void k_apply_pixel_mask(float* __restrict__ x, const float* __restrict__ m, long BC, int C, long HW) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BC * HW) return;
+  const long bc = i / HW, q = i - bc * HW;
+  x[i] *= m[(bc / C) * HW + q];
+}
+extern "C" int evf_apply_pixel_mask(float* x, const float* mask, int B, int C, int H, int W, void* stream) {
+  if (!x || !mask || B <= 0 || C <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  const long HW = (long)H * W, BC = (long)B * C;
+  hipLaunchKernelGGL(k_apply_pixel_mask, dim3(evf_cdiv(BC * HW, 256)), dim3(256), 0, EVF_STREAM(stream), x, mask, BC, C, HW);
+  return evf_status();
+}
+
+// --------------------------------------------------------------------------
 // window masks (loss/flow.py:149-150, 443-452)
 // --------------------------------------------------------------------------
 // out[b][q] = min(sum_p mask[b][p][q], 1)

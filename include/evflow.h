@@ -349,6 +349,10 @@ int evf_nchw_to_bits(const float* in, int B, int H, int W, uint32_t* bits, void*
 int evf_nhwc_to_nchw(const float* in, int B, int C, int H, int W, float* out, void* stream);
 int evf_nchw_to_nhwc(const float* in, int B, int C, int H, int W, float* out, void* stream);
 
+/* Hot-pixel mask of the loader applied in place to a batch of encodings (dataloader/h5.py:289-295):
+ * x [B,C,H,W] *= mask [B,H,W] (one binary mask per batch slot, dataloader/base.py:224-243). */
+int evf_apply_pixel_mask(float* x, const float* mask, int B, int C, int H, int W, void* stream);
+
 /* Window masks: out [B,1,H,W] = min(sum_p masks[B,P,H,W], 1) (loss/flow.py:149-150); masked mean of the
  * per-pass flow maps [B,P,2,H,W] -> [B,2,H,W], sum_p maps*mask / (sum_p mask + 1e-9) (loss/flow.py:443-452). */
 int evf_mask_union(const float* masks, int B, int P, int H, int W, float* out, void* stream);

@@ -1,0 +1,67 @@
+"""Sequence loader end to end on the MI355X: batches of H5Loader (event windows read on the host, encodings binned
+on the GPU by custom_collate) against the batches the reference's BaseDataLoader code makes from the same raw
+sequences (fixture G13: augmentation + hot-pixel filter on), with and without the reader thread."""
+
+import numpy as np
+import pytest
+import torch
+
+from test_host_loader import _cfg, _timed_sequence, g13_loader
+
+from event_flow_amd.dataloader.h5 import H5Loader
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("prefetch", [0, 2])
+def test_batches_match_the_reference_collate(tmp_path, prefetch):
+    g, ld, (H, W, win, nwin, nb) = g13_loader(tmp_path, prefetch=prefetch)
+    seen = 0
+    for w, batch in enumerate(ld):
+        if w < nwin:
+            assert not ld.new_seq and not ld.pass_done
+            assert set(batch) == {"event_cnt", "event_voxel", "event_mask", "event_list", "event_list_pol_mask", "dt_gt", "dt_input"}
+            for k, v in batch.items():
+                ref = g[f"w{w}_{k}"]
+                assert v.is_cuda and tuple(v.shape) == ref.shape and str(v.dtype).split(".")[-1] == str(ref.dtype), k
+                if k == "event_voxel":  # sums of fp32 temporal weights: equal up to the order of the atomic adds
+                    np.testing.assert_allclose(v.cpu().numpy(), ref, rtol=0, atol=2e-6, err_msg=f"{w} {k}")
+                    assert np.array_equal(v.cpu().numpy() == 0, ref == 0)
+                else:  # integer-valued images and fp32 copies: bit for bit
+                    assert np.array_equal(v.cpu().numpy(), ref), (w, k)
+        else:  # both slots ran out of events: first windows of the next files, fresh augmentation flags
+            assert ld.new_seq and ld.pass_done and w == nwin
+            assert tuple(batch["event_list"].shape) == (2, win, 4)
+        seen += 1
+    assert seen == nwin + 1 and ld.epoch == 1 and ld.seq_num == 0 and ld.samples == 2 * (nwin + 1) and not ld.new_seq
+
+
+def test_ragged_time_windows_and_ground_truth(tmp_path):
+    """mode time: windows of different event counts in one batch are padded with p = 0 rows that every encoding
+    ignores; mode gtflow_dt1 carries the flow map and its time base."""
+    _timed_sequence(tmp_path / "a.npz", seed=5)
+    _timed_sequence(tmp_path / "b.npz", seed=6, n=3000)
+    ld = H5Loader(_cfg(tmp_path, "time", 0.25, 2, (16, 20)), 2, prefetch=0)
+    samples = [ld[0], ld[1]]
+    n0, n1 = (s["event_list"].shape[1] for s in samples)
+    assert n0 != n1
+    batch = ld.custom_collate(samples)
+    N = max(n0, n1)
+    assert tuple(batch["event_list"].shape) == (2, N, 4)
+    for b, n in enumerate((n0, n1)):
+        ev = samples[b]["event_list"]
+        cnt = np.zeros((2, 16, 20), np.float32)
+        np.add.at(cnt[0], (ev[1].astype(int), ev[2].astype(int)), (ev[3] > 0).astype(np.float32))
+        np.add.at(cnt[1], (ev[1].astype(int), ev[2].astype(int)), (ev[3] < 0).astype(np.float32))
+        assert np.array_equal(batch["event_cnt"][b].cpu().numpy(), cnt)
+        assert np.array_equal(batch["event_mask"][b, 0].cpu().numpy(), (cnt.sum(0) > 0).astype(np.float32))
+        assert float(batch["event_list_pol_mask"][b, n:].abs().sum()) == 0.0
+        assert float(batch["event_list_pol_mask"][b, :n].sum()) == n
+    (tmp_path / "b.npz").unlink()
+    _timed_sequence(tmp_path / "a.npz", seed=5, maps=1)
+    ld = H5Loader(_cfg(tmp_path, "gtflow_dt1", 1, 1, (16, 20)), 2)
+    batches = list(ld)
+    assert len(batches) == 4 and ld.epoch == 1  # 3 intervals + the wrap-around batch
+    b0 = batches[0]
+    assert tuple(b0["gtflow"].shape) == (1, 2, 16, 20) and b0["gtflow"].is_cuda and b0["dt_gt"].dtype == torch.float64
+    np.testing.assert_allclose(float(b0["dt_gt"][0]), 0.4, rtol=1e-12)

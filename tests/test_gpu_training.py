@@ -41,6 +41,52 @@ def test_reference_shaped_drivers_run_end_to_end(tmp_path):
     assert {"FWL", "RSAT", "AEE", "iwe_variance"} <= set(res) and all(v == v for v in res.values() if isinstance(v, float))
 
 
+def test_drivers_on_sequence_files(tmp_path):
+    """The same drivers fed by the sequence loader (dataloader/h5.py; `.npz` flavour of the reference's HDF5 layout):
+    training over 5 moving-dots sequences with augmentation and the hot-pixel filter on, then AEE against the stored
+    ground-truth flow maps in mode gtflow_dt1."""
+    import numpy as np
+    import yaml
+
+    from event_flow_amd import synthetic
+    from event_flow_amd.dataloader.h5 import write_npz_sequence
+
+    H = W = 64
+    data = tmp_path / "data"
+    data.mkdir()
+    for i in range(5):
+        xs, ys, ts, ps, (u, v) = synthetic.moving_dots_events(9000, H, W, 300 + i, max_disp=36.0)
+        ts = ts * 0.6 + 5.0
+        stamps = 5.0 + 0.1 * np.arange(7)
+        gt = np.zeros((2, H, W), np.float32)
+        gt[0], gt[1] = u / 6, v / 6  # pixels per 0.1 s interval
+        maps = [(f"{k:06d}", stamps[k], gt) for k in range(7)]
+        write_npz_sequence(str(data / f"seq{i}.npz"), xs.astype(np.int16), ys.astype(np.int16), ts, (ps > 0).astype(np.int8),
+                           flow_dt1=maps)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "train_SNN.yml")))
+    cfg["data"].update(path=str(data), window=1000, window_loss=3000)
+    cfg["loader"].update(batch_size=2, n_epochs=2, augment=["Horizontal", "Vertical", "Polarity"], augment_prob=[0.5, 0.5, 0.5])
+    cfg["hot_filter"] = {"enabled": True, "max_px": 100, "min_obvs": 5, "max_rate": 0.8}
+    tcfg = str(tmp_path / "train.yml")
+    yaml.safe_dump(cfg, open(tcfg, "w"))
+    w = str(tmp_path / "m.pth")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "train_flow.py"), "--config", tcfg, "--epochs", "2", "--out", w,
+                          "--fused-optimizer"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert len(res["loss_per_epoch"]) == 2 and all(0 < v < 10 for v in res["loss_per_epoch"])
+    ecfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "eval_flow.yml")))
+    ecfg["data"].update(path=str(data), mode="gtflow_dt1", window=1, window_eval=1000)
+    ecfg["metrics"]["name"] = ["AEE"]
+    epath = str(tmp_path / "eval.yml")
+    yaml.safe_dump(ecfg, open(epath, "w"))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "eval_flow.py"), "--config", epath, "--train-config", tcfg,
+                          "--weights", w], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["AEE"] == res["AEE"] and 0 <= res["AEE"] < 50 and 0 <= res["AEE_percent_outliers"] <= 1
+
+
 def _bench_two_ranks(extra, port, warmup=2):
     """bench.py under torch.distributed.run with 2 ranks sharing the one GPU of the test box (gloo moves the
     flat gradient buffer; on a multi-GPU node the same code path runs over RCCL)."""

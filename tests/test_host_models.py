@@ -147,8 +147,16 @@ def test_yaml_parser_reads_reference_style_configs(tmp_path):
     assert own["model"]["name"] in M.MODELS and own["data"]["window_loss"] % own["data"]["window"] == 0
 
 
-def test_h5_loader_fails_loudly():
+def test_h5_files_need_h5py(tmp_path):
+    """`.h5` sequences go through h5py, which this image lacks: opening one fails loudly (the `.npz` flavour of the
+    same layout is what tests/test_host_loader.py reads)."""
     from event_flow_amd.dataloader.h5 import H5Loader
 
-    with pytest.raises(ImportError):
-        H5Loader({}, 2)
+    (tmp_path / "a.h5").write_bytes(b"")
+    cfg = {"data": {"path": str(tmp_path), "mode": "events", "window": 10},
+           "loader": {"batch_size": 1, "resolution": [8, 8], "augment": []}, "hot_filter": {"enabled": False}}
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError):
+            H5Loader(cfg, 2)

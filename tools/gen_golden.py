@@ -522,6 +522,70 @@ def g12_e2vid():
     save("g12_e2vid", **a)
 
 
+def g13_loader():
+    """Loader batches as the reference makes them (dataloader/base.py: event_formatting :67-86, augment_events :88-116,
+    create_*_encoding :150-222, create_hot_mask :224-243, custom_collate :248-265; per-sample order of
+    dataloader/h5.py:276-295) for two raw sequences cut into count windows (mode "events", h5.py:148-150) with fixed
+    augmentation flags and the hot-pixel filter on.  The reference's own H5Loader needs h5py and is not importable."""
+    H, W, win, nwin, B, nb = 32, 40, 300, 5, 2, 5
+    cfg = {"loader": {"batch_size": B, "resolution": [H, W], "augment": ["Horizontal", "Vertical", "Polarity"],
+                      "augment_prob": [0.5, 0.5, 0.5]},
+           "hot_filter": {"enabled": True, "max_px": 100, "min_obvs": 2, "max_rate": 0.8}}
+
+    class L(r_Base):
+        def __getitem__(self, index):
+            raise NotImplementedError
+
+    loader = L(cfg, nb, round_encoding=False)
+    flags = {"Horizontal": [True, False], "Vertical": [False, True], "Polarity": [True, True]}
+    loader.batch_augmentation = {k: list(v) for k, v in flags.items()}
+    a = {"meta_HW_win_nwin_nb": np.array([H, W, win, nwin, nb])}
+    for k, v in flags.items():
+        a["aug_" + k] = np.array(v)
+    seqs = []
+    for b in range(B):
+        rng = np.random.Generator(np.random.PCG64(900 + b))
+        n = win * nwin + 37  # the tail is shorter than a window: the loader must move on to the next file there
+        xs, ys = rng.integers(0, W, n), rng.integers(0, H, n)
+        hot = [(3 + b, 5), (20, 7 + b), (31, 39)]  # pixels that fire in every window
+        for w in range(nwin + 1):
+            for j, (hy, hx) in enumerate(hot):
+                k = w * win + 11 * (j + 1)
+                if k < n:
+                    ys[k], xs[k] = hy, hx
+        ts = np.sort(rng.random(n)) * 0.5 + 12.25 + b  # seconds, t0 > 0
+        ps = rng.integers(0, 2, n)
+        seqs.append((xs, ys, ts, ps))
+        for nm, v in zip(("xs", "ys", "ts", "ps"), (xs, ys, ts, ps)):
+            a[f"seq{b}_{nm}"] = v
+    for w in range(nwin):
+        samples = []
+        for b in range(B):
+            xs, ys, ts, ps = (v[w * win:(w + 1) * win] for v in seqs[b])
+            ts = ts - seqs[b][2][0]
+            dt_input = np.asarray(ts[-1] - ts[0])
+            txs, tys, tts, tps = loader.event_formatting(xs, ys, ts, ps)
+            txs, tys, tps = loader.augment_events(txs, tys, tps, b)
+            cnt = loader.create_cnt_encoding(txs, tys, tps)
+            mask = loader.create_mask_encoding(txs, tys, tps)
+            voxel = loader.create_voxel_encoding(txs, tys, tts, tps)
+            lst = loader.create_list_encoding(txs, tys, tts, tps)
+            pol = loader.create_polarity_mask(tps)
+            hm = loader.create_hot_mask(cnt, b)
+            voxel = voxel * torch.stack([hm] * nb, axis=2).permute(2, 0, 1)
+            cnt = cnt * torch.stack([hm] * 2, axis=2).permute(2, 0, 1)
+            mask *= hm.view((1, H, W))
+            samples.append({"event_cnt": cnt, "event_voxel": voxel, "event_mask": mask, "event_list": lst,
+                            "event_list_pol_mask": pol, "dt_gt": torch.from_numpy(np.asarray(0.0)),
+                            "dt_input": torch.from_numpy(dt_input)})
+        batch = loader.custom_collate(samples)
+        for k, v in batch.items():
+            a[f"w{w}_{k}"] = v
+        print("window", w, "hot pixels removed:", [int((1 - (s["event_mask"] >= 0).float()).sum()) for s in samples],
+              "mask zeros", int((batch["event_mask"] == 0).sum()))
+    save("g13_loader", **a)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # only the named generators, e.g. `tools/gen_golden.py g10_ann_firenets`
         for fn in sys.argv[1:]:
@@ -541,6 +605,7 @@ if __name__ == "__main__":
     g10_ann_firenets()
     g11_ann_unets()
     g12_e2vid()
+    g13_loader()
     meta = {"torch": torch.__version__, "numpy": np.__version__, "reference": "tudelft/event_flow @ /root/reference (v1)",
             "note": "outputs of the reference run in the build container; reference pins torch==1.7.0"}
     with open(os.path.join(OUT, "meta.json"), "w") as f:

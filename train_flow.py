@@ -3,8 +3,9 @@ the same loop (forward per input window, `event_flow_association`, loss / backwa
 `window_loss` events are collected, `detach_states`, `reset`), the models / loss of `event_flow_amd`.
 
 Differences, all host side: MLflow and the visualiser are optional extras of the reference and not used here (metrics
-go to stdout and `--out` receives the checkpoint); the HDF5 reader is replaced by `--synthetic` windows (moving dots
-with known motion).  `--fused-optimizer` swaps `clip_grad_norm_` + `torch.optim.Adam` for the fused flat-buffer kernel
+go to stdout and `--out` receives the checkpoint).  Data: the sequence files under `data.path` (HDF5 through h5py, or
+the `.npz` flavour of the same layout, event_flow_amd/dataloader/h5.py), or `--synthetic` windows (moving dots with
+known motion).  `--fused-optimizer` swaps `clip_grad_norm_` + `torch.optim.Adam` for the fused flat-buffer kernel
 (same update rule).
 
   python train_flow.py --config configs/train_SNN.yml --synthetic [--epochs 5] [--out model.pth]
@@ -37,7 +38,7 @@ def train(args, config_parser):
     else:
         from event_flow_amd.dataloader.h5 import H5Loader
 
-        data = H5Loader(config, config["model"]["num_bins"], config["model"].get("round_encoding", False))
+        data = H5Loader(config, config["model"]["num_bins"], config["model"].get("round_encoding", False), device=device)
 
     loss_function = EventWarping(config, device)
     model = MODELS[config["model"]["name"]](config["model"].copy()).to(device)
