@@ -302,8 +302,13 @@ def test_fireflownet_runs_and_unsupported_fail_loudly():
     x = torch.rand(1, 2, 16, 40, device=DEV).round()
     out = model(x, x)
     assert out["flow"][0].shape == (1, 2, 16, 40)
+    ann = dict(model_cfg(), spiking_neuron=None, activations=["relu", None])
     with pytest.raises(NotImplementedError):
-        RecEVFlowNet(model_cfg())  # ConvGRU EV-FlowNet: an ANN baseline outside the accelerated path
+        RecEVFlowNet(dict(ann, norm="BN"))  # batch / instance norm layers have no HIP kernel
+    with pytest.raises(NotImplementedError):
+        RecEVFlowNet(dict(ann, use_upsample_conv=False))  # transposed-conv decoders neither
+    with pytest.raises(TypeError):
+        RecEVFlowNet(model_cfg())  # LIF neuron kwargs on the ConvGRU net: TypeError, as in the reference
     with pytest.raises(_lib.EvflowError):
         LIFFireNet(model_cfg())(x.cpu(), x.cpu())  # CPU tensors: no fallback
     with pytest.raises(AttributeError):
