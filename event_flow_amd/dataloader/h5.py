@@ -115,7 +115,9 @@ def write_npz_sequence(path, xs, ys, ts, ps, t0=None, duration=None, **groups):
 
 
 class H5Loader(BaseDataLoader):
-    def __init__(self, config, num_bins, round_encoding=False, device=None, prefetch=2):
+    def __init__(self, config, num_bins, round_encoding=False, device=None, prefetch=2, rank=0, world_size=1):
+        """rank / world_size: data-parallel sharding -- rank r reads the sequence files r, r + world_size, ... with
+        its own `loader.batch_size` slots (batch slots are independent sequences)."""
         super().__init__(config, num_bins, round_encoding, device)
         self.last_proc_timestamp = 0
         self.prefetch = prefetch
@@ -135,6 +137,7 @@ class H5Loader(BaseDataLoader):
             for file in sorted(files):
                 if file.endswith(".h5") or file.endswith(".npz"):
                     self.files.append(os.path.join(root, file))
+        self.files = sorted(self.files)[rank::world_size]
         if len(self.files) < self.batch_size:
             raise FileNotFoundError(f"{config['data']['path']}: {len(self.files)} sequence file(s) for batch_size "
                                     f"{self.batch_size} (the reference opens one file per batch slot, h5.py:64-68)")

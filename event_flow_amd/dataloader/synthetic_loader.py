@@ -18,7 +18,7 @@ from .encodings import encode_event_list
 
 class SyntheticLoader:
     def __init__(self, config, num_bins, round_encoding=False, device="cuda:0", kind="moving_dots", windows_per_seq=20,
-                 num_sequences=8, max_disp=6.0):
+                 num_sequences=8, max_disp=6.0, seed_offset=0):
         self.config = config
         self.num_bins = num_bins
         self.round_encoding = round_encoding
@@ -30,6 +30,7 @@ class SyntheticLoader:
         self.windows_per_seq = windows_per_seq
         self.num_sequences = num_sequences
         self.max_disp = max_disp
+        self.seed_offset = seed_offset  # data-parallel ranks draw different sequences
         self.new_seq = False
         self.seq_num = 0
         self._order = np.arange(num_sequences)
@@ -45,10 +46,10 @@ class SyntheticLoader:
         H, W = self.res
         total = self.n_events * self.windows_per_seq
         if self.kind == "uniform":
-            xs, ys, ts, ps = synthetic.uniform_events(total, H, W, 100 + seq)
+            xs, ys, ts, ps = synthetic.uniform_events(total, H, W, 100 + self.seed_offset + seq)
             uv = (0.0, 0.0)
         else:
-            xs, ys, ts, ps, uv = synthetic.moving_dots_events(total, H, W, 100 + seq, max_disp=self.max_disp * self.windows_per_seq)
+            xs, ys, ts, ps, uv = synthetic.moving_dots_events(total, H, W, 100 + self.seed_offset + seq, max_disp=self.max_disp * self.windows_per_seq)
         sl = slice(w * self.n_events, (w + 1) * self.n_events)
         t = ts[sl].astype(np.float64)
         t = (t - t[0]) / max(t[-1] - t[0], 1e-12)  # event_formatting: ts normalised per window (base.py:84-85)

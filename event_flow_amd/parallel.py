@@ -76,6 +76,22 @@ class DataParallel:
         self.reduce(comm)
         return self.staged(comm)
 
+    def broadcast(self, t, src=0):
+        """In-place broadcast (parameter replicas start from rank `src`'s values)."""
+        if self.world > 1:
+            dist.broadcast(t, src=src)
+
+    def any_flags(self, flags):
+        """Element-wise OR over the ranks of a few host booleans (one tiny MAX all-reduce): the loader events every
+        rank has to act on together -- a slot started a new sequence (all slots are reset, train_flow.py:100-105),
+        a rank finished its pass over the files (every rank ends the epoch)."""
+        if self.world == 1:
+            return [bool(f) for f in flags]
+        t = torch.tensor([1.0 if f else 0.0 for f in flags], dtype=torch.float32,
+                         device=self.device if self.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [bool(v) for v in t.tolist()]
+
     def barrier(self):
         if self.world > 1:
             if self.backend == "nccl":

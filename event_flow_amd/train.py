@@ -69,6 +69,12 @@ class FlatAdam:
             self.model.invalidate_weight_cache()
         hip_ops.invalidate_packed_weights()
 
+    def step_invalidate(self):
+        """The flat parameter buffer was rewritten from outside (broadcast, checkpoint): drop packed-weight caches."""
+        if hasattr(self.model, "invalidate_weight_cache"):
+            self.model.invalidate_weight_cache()
+        hip_ops.invalidate_packed_weights()
+
     def grad_norm(self):
         """L2 norm of the (pre-clip) gradient of the last step."""
         return float(self.norm_ws[0].sqrt())

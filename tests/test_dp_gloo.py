@@ -57,9 +57,14 @@ def _worker(rank, world, port, q):
     comm[: flat.numel()] = flat
     gl, flag = dp.all_reduce_grads(comm, torch.tensor(loss), new_seq=(rank == 1))
     t = dp.max_over_ranks(float(rank + 1))
+    flags = dp.any_flags([rank == 1, False, rank == 0])  # loader events every rank must act on (train_flow.py driver)
+    w = torch.full((3,), float(rank + 5))
+    dp.broadcast(w)  # replicas start from rank 0's parameters
     dp.barrier()
     if rank == 0:
         q.put((comm.numpy().copy(), float(gl), float(flag), t, (lo, hi)))
+    else:
+        q.put(("r1", flags, w.tolist()))
     dp.close()
 
 
@@ -73,7 +78,10 @@ def test_two_rank_allreduce_equals_global_batch_gradient():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    comm, gl, flag, tmax, shard0 = q.get(timeout=300)
+    got = [q.get(timeout=300), q.get(timeout=300)]
+    comm, gl, flag, tmax, shard0 = next(g for g in got if len(g) == 5)
+    _, flags1, w1 = next(g for g in got if len(g) == 3)
+    assert flags1 == [True, False, True] and w1 == [5.0, 5.0, 5.0]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -96,4 +104,4 @@ def test_single_process_dp_is_identity():
     comm = torch.arange(6, dtype=torch.float32)
     l, f = dp.all_reduce_grads(comm, torch.tensor(2.5))
     assert float(l) == 2.5 and float(f) == 0.0 and torch.equal(comm[:4], torch.arange(4, dtype=torch.float32))
-    assert dp.shard(8) == (0, 8)
+    assert dp.shard(8) == (0, 8) and dp.any_flags([True, False]) == [True, False]

@@ -87,6 +87,39 @@ def test_drivers_on_sequence_files(tmp_path):
     assert res["AEE"] == res["AEE"] and 0 <= res["AEE"] < 50 and 0 <= res["AEE_percent_outliers"] <= 1
 
 
+def test_train_driver_two_ranks_on_sequence_files(tmp_path):
+    """train_flow.py under torch.distributed.run with 2 ranks (sharing the test box's one GPU; gloo carries the
+    collectives): the sequence files are sharded over the ranks, the ranks reset / end their epochs together and
+    make one SUM all-reduce of the flat gradient per optimizer step."""
+    import numpy as np
+    import yaml
+
+    from event_flow_amd import synthetic
+    from event_flow_amd.dataloader.h5 import write_npz_sequence
+
+    data = tmp_path / "data"
+    data.mkdir()
+    for i in range(5):  # 3 files for rank 0, 2 for rank 1, of different lengths: rank 1 finishes its pass first
+        n = 6000 + 1500 * (i % 2)
+        xs, ys, ts, ps, _ = synthetic.moving_dots_events(n, 64, 64, 400 + i, max_disp=30.0)
+        write_npz_sequence(str(data / f"seq{i}.npz"), xs.astype(np.int16), ys.astype(np.int16), ts * 0.5 + 1.0, (ps > 0).astype(np.int8))
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "train_SNN.yml")))
+    cfg["data"].update(path=str(data), window=1000, window_loss=2000)
+    cfg["loader"].update(batch_size=1, n_epochs=2)
+    tcfg = str(tmp_path / "train.yml")
+    yaml.safe_dump(cfg, open(tcfg, "w"))
+    w = str(tmp_path / "m.pth")
+    env = dict(os.environ, EVF_DP_BACKEND="gloo", EVF_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", os.path.join(ROOT, "train_flow.py"), "--config", tcfg, "--epochs", "2", "--out", w,
+           "--fused-optimizer"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["ranks"] == 2 and len(res["loss_per_epoch"]) == 2 and all(0 < v < 10 for v in res["loss_per_epoch"])
+    assert os.path.exists(w)
+
+
 def _bench_two_ranks(extra, port, warmup=2):
     """bench.py under torch.distributed.run with 2 ranks sharing the one GPU of the test box (gloo moves the
     flat gradient buffer; on a multi-GPU node the same code path runs over RCCL)."""

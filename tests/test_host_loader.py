@@ -136,3 +136,14 @@ def test_frame_windows_and_errors(tmp_path):
         ld = H5Loader(_cfg(tmp_path, "events", 100, 1, (16, 20)), 2)
         with pytest.raises(_lib.EvflowError):
             ld.custom_collate([ld[0]])  # encodings are made on the MI355X only
+
+
+def test_ranks_read_disjoint_files(tmp_path):
+    for i in range(5):
+        _timed_sequence(tmp_path / f"s{i}.npz", n=500, seed=20 + i)
+    cfg = _cfg(tmp_path, "events", 100, 1, (16, 20))
+    shards = [H5Loader(cfg, 2, rank=r, world_size=2).files for r in range(2)]
+    assert [len(f) for f in shards] == [3, 2] and not set(shards[0]) & set(shards[1])
+    assert sorted(shards[0] + shards[1]) == sorted(str(tmp_path / f"s{i}.npz") for i in range(5))
+    with pytest.raises(FileNotFoundError):
+        H5Loader(_cfg(tmp_path, "events", 100, 3, (16, 20)), 2, rank=1, world_size=2)  # 2 files for 3 slots

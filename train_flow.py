@@ -13,6 +13,7 @@ known motion).  `--fused-optimizer` swaps `clip_grad_norm_` + `torch.optim.Adam`
 
 import argparse
 import json
+import os
 import time
 
 import torch
@@ -20,6 +21,7 @@ import torch
 from event_flow_amd.configs.parser import YAMLParser
 from event_flow_amd.loss.flow import EventWarping
 from event_flow_amd.models.model import MODELS
+from event_flow_amd.parallel import DataParallel
 from event_flow_amd.train import FlatAdam
 
 
@@ -31,14 +33,28 @@ def train(args, config_parser):
     config = config_parser.combine_entries(config)
     device = config_parser.device
 
+    # data parallel (one process per GPU under torch.distributed.run): sequence files sharded over the ranks, one SUM
+    # all-reduce of the flat gradient per optimizer step (event_flow_amd/parallel.py)
+    dp = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        if not args.fused_optimizer:
+            raise SystemExit("data-parallel training reduces the flat gradient buffer: add --fused-optimizer")
+        if not os.environ.get("EVF_BENCH_SINGLE_DEVICE"):  # (test hook: all ranks on the one GPU of the box)
+            device = torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
+            torch.cuda.set_device(device)
+        dp = DataParallel(device=device)
+    rank, world = (dp.rank, dp.world) if dp else (0, 1)
+
     if args.synthetic:
         from event_flow_amd.dataloader.synthetic_loader import SyntheticLoader
 
-        data = SyntheticLoader(config, config["model"]["num_bins"], config["model"].get("round_encoding", False), device=device)
+        data = SyntheticLoader(config, config["model"]["num_bins"], config["model"].get("round_encoding", False), device=device,
+                               seed_offset=1000 * rank)
     else:
         from event_flow_amd.dataloader.h5 import H5Loader
 
-        data = H5Loader(config, config["model"]["num_bins"], config["model"].get("round_encoding", False), device=device)
+        data = H5Loader(config, config["model"]["num_bins"], config["model"].get("round_encoding", False), device=device,
+                        rank=rank, world_size=world)
 
     loss_function = EventWarping(config, device)
     model = MODELS[config["model"]["name"]](config["model"].copy()).to(device)
@@ -51,6 +67,9 @@ def train(args, config_parser):
         optimizer = FlatAdam(model, lr=config["optimizer"]["lr"], clip=clip)
     else:
         optimizer = getattr(torch.optim, config["optimizer"]["name"])(model.parameters(), lr=config["optimizer"]["lr"])
+    if dp:  # every rank starts from rank 0's parameters
+        dp.broadcast(optimizer.flat_param)
+        optimizer.step_invalidate()
     optimizer.zero_grad()
 
     n_epochs = args.epochs if args.epochs is not None else config["loader"]["n_epochs"]
@@ -59,8 +78,15 @@ def train(args, config_parser):
     for epoch in range(n_epochs):
         data.shuffle(epoch)
         train_loss, samples, steps = torch.zeros((), device=device), 0, 0
-        for inputs in data:
-            if data.new_seq:  # any slot restarted: reset everything (train_flow.py:100-105)
+        batches = iter(data)
+        while True:
+            inputs = next(batches, None)
+            new_seq, done = bool(inputs is not None and data.new_seq), inputs is None
+            if dp:  # the ranks reset and end their epochs together
+                new_seq, done = dp.any_flags([new_seq, done])
+            if done:
+                break
+            if new_seq:  # any slot restarted: reset everything (train_flow.py:100-105)
                 data.new_seq = False
                 loss_function.reset()
                 model.reset_states()
@@ -74,10 +100,12 @@ def train(args, config_parser):
                 if config["loss"]["overwrite_intermediate"]:
                     loss_function.overwrite_intermediate_flow(x["flow"])
                 loss = loss_function()
-                train_loss += loss.detach()  # no host sync inside the loop
-                samples += config["loader"]["batch_size"]
+                samples += config["loader"]["batch_size"] * world
                 steps += 1
                 loss.backward()
+                if dp:  # gradient (+ loss) summed over the ranks: the step below is the global-batch step
+                    loss = dp.all_reduce_grads(optimizer.comm, loss)[0]
+                train_loss += loss.detach()  # no host sync inside the loop
                 if args.fused_optimizer:
                     optimizer.step()  # clip + Adam in one kernel
                 else:
@@ -87,16 +115,23 @@ def train(args, config_parser):
                 optimizer.zero_grad()
                 model.detach_states()
                 loss_function.reset()
+        if hasattr(batches, "close"):
+            batches.close()  # a rank that stops early (another rank ran out of files) ends its reader thread here
         epoch_loss = float(train_loss) / max(samples, 1)
         history.append(epoch_loss)
-        if config["vis"].get("verbose", False):
+        if config["vis"].get("verbose", False) and rank == 0:
             print("Train Epoch: {:04d}  Loss: {:.6f}  ({} optimizer steps, {:.1f} s)".format(epoch, epoch_loss, steps,
                                                                                              time.time() - t_start))
         if epoch_loss < best_loss:
             best_loss = epoch_loss
-            if args.out:
+            if args.out and rank == 0:
                 torch.save(model.state_dict(), args.out)
-    print(json.dumps({"model": config["model"]["name"], "epochs": n_epochs, "loss_per_epoch": history, "best_loss": best_loss}))
+    if dp:
+        dp.barrier()
+        dp.close()
+    if rank == 0:
+        print(json.dumps({"model": config["model"]["name"], "epochs": n_epochs, "loss_per_epoch": history, "best_loss": best_loss,
+                          "ranks": world}))
     return history
 
 
