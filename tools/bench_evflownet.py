@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from event_flow_amd import _lib, synthetic  # noqa: E402
 from event_flow_amd.loss.flow import EventWarping  # noqa: E402
-from event_flow_amd.models.model import SpikingRecEVFlowNet  # noqa: E402
+from event_flow_amd.models.model import MODELS  # noqa: E402
 from event_flow_amd.train import FlatAdam, encode_passes, train_window  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -26,6 +26,7 @@ ap.add_argument("--res", type=int, default=256)
 ap.add_argument("--events", type=int, default=50000)
 ap.add_argument("--base", type=int, default=32)
 ap.add_argument("--prof", action="store_true")
+ap.add_argument("--model", default="SpikingRecEVFlowNet", help="any multi-scale model of models/model.py (EVFlowNet, RecEVFlowNet, ...)")
 a = ap.parse_args()
 
 dev = "cuda:0"
@@ -34,7 +35,10 @@ cfg = {"num_bins": 2, "base_num_channels": a.base, "kernel_size": 3, "encoding":
        "mask_output": True, "activations": ["arctanspike", "arctanspike"],
        "spiking_neuron": {"leak": [-4.0, 0.1], "thresh": [0.8, 0.1], "learn_leak": True, "learn_thresh": True,
                           "hard_reset": True}}
-model = SpikingRecEVFlowNet(cfg).to(dev)
+if not a.model.startswith(("Spiking", "PLIF", "ALIF", "XLIF")):  # the non-spiking EV-FlowNets / E2VID
+    cfg["activations"] = ["relu", None]
+    cfg["spiking_neuron"] = {"leak": [-4.0, 0.1], "learn_leak": True} if a.model.startswith("Leaky") else None
+model = MODELS[a.model](cfg).to(dev)
 model.train()
 H = W = a.res
 lossf = EventWarping({"loader": {"resolution": [H, W]}, "loss": {"flow_regul_weight": 0.001, "overwrite_intermediate": False},
@@ -56,7 +60,7 @@ for _ in range(a.steps):
     loss = train_window(model, lossf, opt, passes)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
-res = {"config": f"SpikingRecEVFlowNet base{a.base} {H}x{W} B{a.B} {a.events}ev", "params": nparam, "ms_per_step": dt * 1e3,
+res = {"config": f"{a.model} base{a.base} {H}x{W} B{a.B} {a.events}ev", "params": nparam, "ms_per_step": dt * 1e3,
        "windows_per_s": a.B / dt, "loss": float(loss)}
 if a.prof:
     _lib.profile_start(NAMES)

@@ -34,9 +34,14 @@ if a.model.startswith("PLIF"):
               "learn_thresh": True, "hard_reset": True}
 elif a.model.startswith(("ALIF", "XLIF")):
     neuron = {"leak_v": [-4.0, 0.1], "t0": [0.3, 0.05], "t1": [0.5, 0.1], "learn_leak": True, "learn_thresh": True}
-acts = ["relu", None] if a.model == "FireNet" else ["arctanspike", "arctanspike"]
+acts = ["arctanspike", "arctanspike"]
+ANN = {"FireNet": (["relu", None], None), "RNNFireNet": (["relu", None], None), "FireFlowNet": (["relu", "relu"], None),
+       "LeakyFireNet": (["relu", None], {"leak": [-4.0, 0.1], "learn_leak": True}),
+       "LeakyFireFlowNet": (["relu", "relu"], {"leak": [-4.0, 0.1], "learn_leak": True})}
+if a.model in ANN:
+    acts, neuron = ANN[a.model]
 cfg = {"num_bins": 2, "base_num_channels": 32, "kernel_size": 3, "encoding": "cnt", "norm_input": False, "mask_output": True,
-       "activations": acts, "spiking_neuron": None if a.model == "FireNet" else neuron}
+       "activations": acts, "spiking_neuron": neuron}
 model = M.MODELS[a.model](cfg).to(dev)
 model.train()
 lossf = EventWarping({"loader": {"resolution": [a.H, a.W]}, "loss": {"flow_regul_weight": 0.001, "overwrite_intermediate": False},
