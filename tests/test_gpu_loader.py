@@ -65,3 +65,17 @@ def test_ragged_time_windows_and_ground_truth(tmp_path):
     b0 = batches[0]
     assert tuple(b0["gtflow"].shape) == (1, 2, 16, 20) and b0["gtflow"].is_cuda and b0["dt_gt"].dtype == torch.float64
     np.testing.assert_allclose(float(b0["dt_gt"][0]), 0.4, rtol=1e-12)
+
+
+def test_reference_style_dataloader_wrapping(tmp_path):
+    """The reference wraps the dataset in torch.utils.data.DataLoader(collate_fn=data.custom_collate), num_workers=0
+    (train_flow.py:66-73): same batches, `new_seq` raised by `__getitem__` itself."""
+    g, ld, (H, W, win, nwin, nb) = g13_loader(tmp_path)
+    dl = torch.utils.data.DataLoader(ld, drop_last=True, batch_size=2, collate_fn=ld.custom_collate)
+    for w, batch in enumerate(dl):
+        if w == nwin:
+            assert ld.new_seq and ld.seq_num >= len(ld.files)
+            break
+        assert not ld.new_seq
+        for k in ("event_cnt", "event_mask", "event_list", "event_list_pol_mask", "dt_input"):
+            assert np.array_equal(batch[k].cpu().numpy(), g[f"w{w}_{k}"]), (w, k)
