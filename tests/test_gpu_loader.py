@@ -79,3 +79,37 @@ def test_reference_style_dataloader_wrapping(tmp_path):
         assert not ld.new_seq
         for k in ("event_cnt", "event_mask", "event_list", "event_list_pol_mask", "dt_input"):
             assert np.array_equal(batch[k].cpu().numpy(), g[f"w{w}_{k}"]), (w, k)
+
+
+def test_empty_windows_flow_through_model_and_loss(tmp_path):
+    """A window with <= 10 events is handed on as an EMPTY one (dataloader/h5.py:240-245): the batch then carries
+    zero-length event lists and all-zero encodings; model, loss association and the loss itself must take them."""
+    from event_flow_amd.loss.flow import EventWarping
+    from event_flow_amd.models.model import LIFFireNet
+
+    rng = np.random.Generator(np.random.PCG64(3))
+    n = 2000
+    ts = np.concatenate([np.sort(rng.random(n - 5)) * 0.5, 0.5 + 0.3 + 0.01 * np.arange(5)]) + 10.0  # 5 events in [0.75, 1.0)
+    from event_flow_amd.dataloader.h5 import write_npz_sequence
+
+    write_npz_sequence(str(tmp_path / "a.npz"), rng.integers(0, 32, n), rng.integers(0, 32, n), ts, rng.integers(0, 2, n))
+    ld = H5Loader(_cfg(tmp_path, "time", 0.25, 1, (32, 32)), 2, prefetch=0)
+    samples = [ld[i] for i in range(3)]
+    assert [s["event_list"].shape[1] > 0 for s in samples] == [True, True, False]
+    empty = ld.custom_collate([samples[2]])
+    assert tuple(empty["event_list"].shape) == (1, 0, 4) and tuple(empty["event_list_pol_mask"].shape) == (1, 0, 2)
+    assert float(empty["event_cnt"].abs().sum()) == 0 and float(empty["event_mask"].sum()) == 0 and float(empty["dt_input"]) == 0
+    cfg = {"num_bins": 2, "base_num_channels": 32, "kernel_size": 3, "encoding": "cnt", "norm_input": False, "mask_output": True,
+           "activations": ["arctanspike", "arctanspike"],
+           "spiking_neuron": {"leak": [-4.0, 0.1], "thresh": [0.8, 0.1], "learn_leak": True, "learn_thresh": True, "hard_reset": True}}
+    model = LIFFireNet(cfg).to("cuda:0")
+    lossf = EventWarping({"loader": {"resolution": [32, 32]}, "loss": {"flow_regul_weight": 0.001, "overwrite_intermediate": False},
+                          "model": {"mask_output": True}}, "cuda:0")
+    full = ld.custom_collate([samples[0]])
+    for batch in (full, empty):
+        out = model(batch["event_voxel"], batch["event_cnt"])
+        lossf.event_flow_association(out["flow"], batch["event_list"], batch["event_list_pol_mask"], batch["event_mask"])
+    assert lossf.num_events == samples[0]["event_list"].shape[1]
+    loss = lossf()
+    loss.backward()
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
