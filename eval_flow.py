@@ -16,6 +16,7 @@ from event_flow_amd.configs.parser import YAMLParser
 from event_flow_amd.loss import flow as metrics_mod
 from event_flow_amd.models.model import MODELS
 from event_flow_amd.utils.iwe import compute_pol_iwe
+from event_flow_amd.utils.utils import load_model
 
 
 def test(args, config_parser):
@@ -35,8 +36,8 @@ def test(args, config_parser):
     device = config_parser.device
 
     model = MODELS[config["model"]["name"]](config["model"].copy()).to(device)
-    if args.weights:
-        model.load_state_dict(torch.load(args.weights, map_location=device))
+    if args.weights:  # a state_dict file, a reference checkpoint (pickled model) or its MLflow run id under ./mlruns
+        model = load_model(args.weights, model, device)
     model.eval()
 
     names = config.get("metrics", {}).get("name", [])

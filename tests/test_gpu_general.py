@@ -339,6 +339,27 @@ def test_g12_e2vid():
     assert model.unetrecurrent.states == [None] * 3
 
 
+# ------------------------------------------------------------------ reference checkpoint (G14)
+def test_g14_reference_checkpoint_gives_the_reference_flow():
+    """A checkpoint pickled by the reference (whole model object under an MLflow run id) restored into the HIP model
+    reproduces the flow the reference computed with it."""
+    import os
+
+    from event_flow_amd.models.model import LIFFireNet
+    from event_flow_amd.utils.utils import load_model
+
+    g = load_golden("g14_checkpoint")
+    cfg = {"num_bins": 2, "base_num_channels": 8, "kernel_size": 3, "encoding": "cnt", "norm_input": False, "mask_output": True,
+           "activations": ["arctanspike", "arctanspike"],
+           "spiking_neuron": {"leak": [-4.0, 0.1], "thresh": [0.8, 0.1], "learn_leak": True, "learn_thresh": True, "hard_reset": True}}
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mlruns")
+    model = load_model("0123456789abcdef0123456789abcdef", LIFFireNet(cfg).to(DEV), DEV, root=root)
+    x = G(g["event_cnt"])
+    with torch.no_grad():
+        flow = model(x, x)["flow"][0]
+    np.testing.assert_allclose(N(flow), g["flow"], rtol=1e-4, atol=1e-7)
+
+
 # ------------------------------------------------------------------ spiking EV-FlowNet (G9, BASELINE config 4 architecture)
 def _unet_cfg(C=4):
     return {"num_bins": 2, "base_num_channels": C, "kernel_size": 3, "encoding": "cnt", "norm_input": False,

@@ -160,3 +160,32 @@ def test_h5_files_need_h5py(tmp_path):
     except ImportError:
         with pytest.raises(ImportError):
             H5Loader(cfg, 2)
+
+
+def test_reference_pickled_checkpoint_restores(tmp_path):
+    """The reference stores whole pickled model objects (utils/utils.py:36-37) and restores through
+    `load_state_dict(torch.load(path).state_dict())` (:18-19): such a file, made by the reference itself, loads here
+    by run id or by path although its classes live in the reference's `models.*` modules."""
+    import os
+    import sys
+
+    from event_flow_amd.utils.utils import load_model, save_model
+
+    g = load_golden("g14_checkpoint")
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mlruns")
+    runid = "0123456789abcdef0123456789abcdef"
+    for ref in (runid, os.path.join(root, "0", runid, "artifacts", "model", "data", "model.pth")):
+        model = M.LIFFireNet(cfg(C=8))
+        before = {k: v.clone() for k, v in model.state_dict().items()}
+        load_model(ref, model, "cpu", root=root)
+        for k, v in model.state_dict().items():
+            assert np.array_equal(v.numpy(), g["param_" + k]), k
+        assert any(not torch.equal(before[k], v) for k, v in model.state_dict().items())
+    assert "models" not in sys.modules and "models.model" not in sys.modules  # the aliases are gone again
+    untouched = M.LIFFireNet(cfg(C=8))
+    sd = {k: v.clone() for k, v in untouched.state_dict().items()}
+    load_model("no-such-run", untouched, "cpu", root=root)  # unknown run: model unchanged (reference :9-12)
+    assert all(torch.equal(sd[k], v) for k, v in untouched.state_dict().items())
+    save_model(model, str(tmp_path / "x" / "m.pth"))
+    again = load_model(str(tmp_path / "x" / "m.pth"), M.LIFFireNet(cfg(C=8)), "cpu")
+    assert all(np.array_equal(v.numpy(), g["param_" + k]) for k, v in again.state_dict().items())

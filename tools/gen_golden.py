@@ -586,6 +586,21 @@ def g13_loader():
     save("g13_loader", **a)
 
 
+def g14_checkpoint():
+    """A checkpoint as the reference stores it (utils/utils.py:36-37 -> mlflow.pytorch.log_model: the pickled model
+    OBJECT in <run>/artifacts/model/data/model.pth) for a small LIF-FireNet, plus its flow on one input."""
+    torch.manual_seed(7)
+    model = build("LIFFireNet", model_cfg("LIFFireNet", C=8, neuron=LIF_NEURON))
+    d = batch_windows(1, 300, 16, 16, 8000)
+    with torch.no_grad():
+        flow = model(d["event_voxel"], d["event_cnt"])["flow"][0]
+    model.reset_states()
+    run = os.path.join(OUT, "mlruns", "0", "0123456789abcdef0123456789abcdef", "artifacts", "model", "data")
+    os.makedirs(run, exist_ok=True)
+    torch.save(model, os.path.join(run, "model.pth"))
+    save("g14_checkpoint", event_cnt=d["event_cnt"], flow=flow, **{"param_" + k: v for k, v in model.state_dict().items()})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # only the named generators, e.g. `tools/gen_golden.py g10_ann_firenets`
         for fn in sys.argv[1:]:
@@ -606,6 +621,7 @@ if __name__ == "__main__":
     g11_ann_unets()
     g12_e2vid()
     g13_loader()
+    g14_checkpoint()
     meta = {"torch": torch.__version__, "numpy": np.__version__, "reference": "tudelft/event_flow @ /root/reference (v1)",
             "note": "outputs of the reference run in the build container; reference pins torch==1.7.0"}
     with open(os.path.join(OUT, "meta.json"), "w") as f:

@@ -23,6 +23,7 @@ from event_flow_amd.loss.flow import EventWarping
 from event_flow_amd.models.model import MODELS
 from event_flow_amd.parallel import DataParallel
 from event_flow_amd.train import FlatAdam
+from event_flow_amd.utils.utils import load_model
 
 
 def train(args, config_parser):
@@ -58,8 +59,8 @@ def train(args, config_parser):
 
     loss_function = EventWarping(config, device)
     model = MODELS[config["model"]["name"]](config["model"].copy()).to(device)
-    if args.prev:
-        model.load_state_dict(torch.load(args.prev, map_location=device))
+    if args.prev:  # a state_dict file, a reference checkpoint (pickled model) or its MLflow run id under ./mlruns
+        model = load_model(args.prev, model, device)
     model.train()
 
     clip = config["loss"].get("clip_grad", None)
