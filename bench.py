@@ -381,15 +381,19 @@ def main():
             kernels[name] = ent
         dom_key = max((k for k in prof if k in model), key=lambda k: sum(prof[k]))
         dom = kernels["/".join(k for k in dom_key if k)]
-        traffic = _pmc_traffic("/".join(k for k in dom_key if k))
+        detail = _pmc_traffic("/".join(k for k in dom_key if k))
+        traffic = int(detail["MB_per_launch"] * 1e6) if detail else None  # HBM bytes per launch (PMC), next to ...
+        algo = int(dom["algorithmic_MB"] * 1e6) if "algorithmic_MB" in dom else None  # ... the algorithmic bytes per launch
         if dom["bound"] == "hbm":
             roof = {"kernel": "/".join(k for k in dom_key if k), "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK,
-                    "unit": "GB/s", "frac": dom["frac_of_hbm_peak"], "traffic": traffic,
+                    "unit": "GB/s", "frac": dom["frac_of_hbm_peak"], "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "algorithmic_bytes": algo, "traffic_detail": detail,
                     "note": "bf16x3 kernel (exact 3-way bf16 split, fp32 accumulate): matrix work is 1/5 of the fp32-MFMA form, "
                             "so the kernel sits on the HBM roofline; algorithmic bytes per launch in kernels[*].algorithmic_MB"}
         else:
             roof = {"kernel": "/".join(k for k in dom_key if k), "bound": "mfma", "achieved": dom["TFLOPs"], "peak": FP32_MFMA_PEAK,
-                    "unit": "TFLOP/s", "frac": dom["TFLOPs"] / FP32_MFMA_PEAK, "traffic": traffic}
+                    "unit": "TFLOP/s", "frac": dom["TFLOPs"] / FP32_MFMA_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "traffic_detail": detail}
         out = {
             "metric": "event-windows/sec (train step, 128x128x15k ev)", "value": B_PER_GPU * dp.world * args.steps / elapsed,
             "unit": "event-windows/s", "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
