@@ -52,6 +52,11 @@ def test(args, config_parser):
 
         data = H5Loader(config, config["model"]["num_bins"], device=device)
 
+    vis = None
+    if args.store:  # stored PNGs in the reference's folder layout (utils/visualization.py:120-226); batch size 1
+        from event_flow_amd.utils.visualization import Visualization
+
+        vis = Visualization(config, eval_id=0, path_results=args.store.rstrip("/") + "/")
     results = {m: {"metric": 0.0, "it": 0, **({"percent": 0.0} if m == "AEE" else {})} for m in names}
     iwe_sharpness = []
     with torch.no_grad():
@@ -66,6 +71,9 @@ def test(args, config_parser):
                                   inputs["event_list_pol_mask"][:, :, 0:1], inputs["event_list_pol_mask"][:, :, 1:2],
                                   flow_scaling=config["metrics"]["flow_scaling"], round_idx=True)
             iwe_sharpness.append(iwe.sum(1).var(dim=(1, 2)).mean())
+            if vis is not None and iwe.shape[0] == 1:
+                flow_vis = x["flow"][-1] * inputs["event_mask"] if config["model"].get("mask_output", True) else x["flow"][-1]
+                vis.store(inputs, flow_vis, iwe, "seq%03d" % getattr(data, "seq_num", 0), ts=getattr(data, "last_proc_timestamp", None))
             for metric in criteria:
                 metric.event_flow_association(x["flow"], inputs)
             for i, name in enumerate(names):
@@ -96,5 +104,6 @@ if __name__ == "__main__":
     parser.add_argument("--weights", default="", help="state_dict (reference: the run id)")
     parser.add_argument("--synthetic", action="store_true")
     parser.add_argument("--sequences", type=int, default=4)
+    parser.add_argument("--store", default="", help="directory that receives results/eval_0/<sequence>/{events,flow,iwe,...}/*.png")
     args = parser.parse_args()
     test(args, YAMLParser(args.config))

@@ -34,11 +34,13 @@ def test_reference_shaped_drivers_run_end_to_end(tmp_path):
         assert out.returncode == 0, out.stderr[-2000:]
         res = json.loads(out.stdout.strip().splitlines()[-1])
         assert len(res["loss_per_epoch"]) == 2 and all(0 < v < 10 for v in res["loss_per_epoch"])
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "eval_flow.py"), "--synthetic", "--weights", w],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "eval_flow.py"), "--synthetic", "--weights", w, "--store", str(tmp_path)],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert {"FWL", "RSAT", "AEE", "iwe_variance"} <= set(res) and all(v == v for v in res.values() if isinstance(v, float))
+    stored = list((tmp_path / "results" / "eval_0").glob("*/flow/*.png"))
+    assert stored and len(stored) == len(list((tmp_path / "results" / "eval_0").glob("*/iwe/*.png")))
 
 
 def test_drivers_on_sequence_files(tmp_path):
