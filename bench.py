@@ -221,7 +221,29 @@ def cpu_baseline(threads, max_seconds=60.0):
         if el > 12.0 or n_done >= 20 or el > max_seconds:  # a 10-30 s sample
             break
     el = time.perf_counter() - t0
-    return {"value": Bc * n_done / el, "unit": "event-windows/s", "cores": best_t, "kind": "port",
+    # SURVEY 8(d) asks for more CPU figures beside the headline one; each is a bounded sample of its own
+    extra = {}
+    try:
+        from oracle import iwe as oiwe
+
+        with torch.no_grad():  # configuration 2: forward + loss of the 10-pass window, no backward
+            t1 = time.perf_counter()
+            otrain.forward_window("LIFFireNet", params, passes, [None] * 7, (H, W), loss_cfg=lcfg)
+            extra["fwd_loss_windows_per_s"] = Bc / (time.perf_counter() - t1)
+        torch.set_num_threads(1)  # per-core figure: one pass of the full step on one thread, scaled to the window
+        t1 = time.perf_counter()
+        one_step(passes[:1], [None] * 7, {"step": 0, "m": {}, "v": {}}, params)
+        extra["one_thread_windows_per_s"] = Bc / ((time.perf_counter() - t1) * PASSES)
+        torch.set_num_threads(best_t)
+        ev = synthetic.event_list_batch(64, PASSES * EV_PER_PASS, H, W, 999)  # compute_pol_iwe, 64 windows of 15k events
+        fl = np.random.default_rng(0).standard_normal((64, 2, H, W)).astype(np.float32)
+        pos, neg = (ev[:, :, 3:4] > 0).astype(np.float32), (ev[:, :, 3:4] < 0).astype(np.float32)
+        t1 = time.perf_counter()
+        oiwe.compute_pol_iwe(fl, ev, (H, W), pos, neg, flow_scaling=128, round_idx=True)
+        extra["iwe_warp_GBps"] = 64 * (28 * PASSES * EV_PER_PASS + 2 * H * W * 4) / (time.perf_counter() - t1) / 1e9
+    except Exception as e:  # the extras never cost the headline baseline
+        extra["error"] = f"{type(e).__name__}: {e}"
+    return {"value": Bc * n_done / el, "unit": "event-windows/s", "cores": best_t, "kind": "port", "extra": extra,
             "sample": f"{n_done} full train step(s) of {Bc} windows (B={Bc}, {PASSES} passes x {EV_PER_PASS} events, {H}x{W}) = "
                       f"the GPU step's per-GPU work; oracle = PyTorch-CPU fp32 port of the reference path; "
                       f"{best_t} threads (fastest of {cand} on a {os.cpu_count()}-CPU host), {el:.1f} s"}
