@@ -67,38 +67,35 @@ class BaseDataLoader(torch.utils.data.Dataset):
             ts = (ts - ts[0]) / (ts[-1] - ts[0])
         return xs, ys, ts, ps
 
+    def _flipped(self, mechanism, batch):
+        flags = self.batch_augmentation.get(mechanism)
+        return bool(flags) and bool(flags[batch])
+
     def augment_events(self, xs, ys, ps, batch):
         """Horizontal / vertical / polarity flips of one slot's events (reference :88-116)."""
-        for mechanism in self.config["loader"]["augment"]:
-            if mechanism == "Horizontal":
-                if self.batch_augmentation["Horizontal"][batch]:
-                    xs = self.res[1] - 1 - xs
-            elif mechanism == "Vertical":
-                if self.batch_augmentation["Vertical"][batch]:
-                    ys = self.res[0] - 1 - ys
-            elif mechanism == "Polarity":
-                if self.batch_augmentation["Polarity"][batch]:
-                    ps = ps * -1
+        H, W = self.res
+        if self._flipped("Horizontal", batch):
+            xs = (W - 1) - xs
+        if self._flipped("Vertical", batch):
+            ys = (H - 1) - ys
+        if self._flipped("Polarity", batch):
+            ps = -ps
         return xs, ys, ps
 
     def augment_frames(self, img, batch):
-        """Reference :118-131."""
-        if self.batch_augmentation.get("Horizontal", None) and self.batch_augmentation["Horizontal"][batch]:
-            img = np.flip(img, 1)
-        if self.batch_augmentation.get("Vertical", None) and self.batch_augmentation["Vertical"][batch]:
-            img = np.flip(img, 0)
-        return img
+        """The same spatial flips on an APS frame [H,W] (reference :118-131)."""
+        axes = [ax for ax, mech in ((1, "Horizontal"), (0, "Vertical")) if self._flipped(mech, batch)]
+        return np.flip(img, axes) if axes else img
 
     def augment_flowmap(self, flowmap, batch):
-        """Flips of a [2,H,W] (x, y) flow map incl. the sign of the flipped component (reference :133-148)."""
-        flowmap = np.array(flowmap, dtype=np.float32, copy=True)
-        if self.batch_augmentation.get("Horizontal", None) and self.batch_augmentation["Horizontal"][batch]:
-            flowmap = np.flip(flowmap, 2).copy()
-            flowmap[0, :, :] *= -1.0
-        if self.batch_augmentation.get("Vertical", None) and self.batch_augmentation["Vertical"][batch]:
-            flowmap = np.flip(flowmap, 1).copy()
-            flowmap[1, :, :] *= -1.0
-        return flowmap
+        """... and on a [2,H,W] (x, y) flow map, where a flipped axis also negates its flow component
+        (reference :133-148)."""
+        out = np.array(flowmap, dtype=np.float32, copy=True)
+        for comp, axis, mech in ((0, 2, "Horizontal"), (1, 1, "Vertical")):
+            if self._flipped(mech, batch):
+                out = np.flip(out, axis).copy()
+                out[comp] *= -1.0
+        return out
 
     @staticmethod
     def create_list_encoding(xs, ys, ts, ps):

@@ -1,15 +1,15 @@
-"""Base class for the models -- mirror of reference models/base.py:1-31."""
+"""Common parent of the model classes (the role of reference models/base.py): an `nn.Module` whose printout ends
+with the number of trainable parameters, as the reference's does."""
 
-import numpy as np
 import torch.nn as nn
 
 
 class BaseModel(nn.Module):
-    """Base class for all models (reference: models/base.py:8-31)."""
-
     def forward(self, *inputs):
-        raise NotImplementedError
+        raise NotImplementedError(f"{type(self).__name__} does not define forward()")
+
+    def trainable_parameters(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
 
     def __str__(self):
-        params = sum(int(np.prod(p.size())) for p in self.parameters() if p.requires_grad)
-        return super().__str__() + "\nTrainable parameters: {}".format(params)
+        return f"{super().__str__()}\nTrainable parameters: {self.trainable_parameters()}"

@@ -1,72 +1,74 @@
-"""Model helpers -- mirror of reference models/model_util.py (host-side shape
-arithmetic and state copying; nothing here is on the GPU hot path)."""
+"""Model helpers -- same names and results as reference models/model_util.py (host-side shape arithmetic and state
+copying; nothing here is on the GPU hot path except the `skip_sum` addition, which runs in libevflow_hip.so)."""
 
 import copy
-from math import ceil, floor
 
 import torch
 from torch.nn import ZeroPad2d
 
 
+def _centred(x, like):
+    """x zero-padded to the spatial size of `like`, the odd pixel going to the right / bottom."""
+    gap_h, gap_w = like.shape[2] - x.shape[2], like.shape[3] - x.shape[3]
+    if gap_h == 0 and gap_w == 0:
+        return x
+    return torch.nn.functional.pad(x, (gap_w // 2, gap_w - gap_w // 2, gap_h // 2, gap_h - gap_h // 2))
+
+
 def skip_concat(x1, x2):
-    """Zero-pad x1 to x2's spatial size and concatenate on channels.
-    Reference: models/model_util.py:14-19."""
-    dh, dw = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
-    x1 = torch.nn.functional.pad(x1, (dw // 2, dw - dw // 2, dh // 2, dh - dh // 2))
-    return torch.cat([x1, x2], dim=1)
+    """cat([pad(x1), x2]) on channels.  Reference: models/model_util.py:14-19."""
+    return torch.cat([_centred(x1, x2), x2], dim=1)
 
 
 def skip_sum(x1, x2):
-    """Reference: models/model_util.py:22-27."""
-    dh, dw = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
-    x1 = torch.nn.functional.pad(x1, (dw // 2, dw - dw // 2, dh // 2, dh - dh // 2))
-    from . import hip_ops  # the sum runs in libevflow_hip.so
+    """pad(x1) + x2.  Reference: models/model_util.py:22-27."""
+    from . import hip_ops
 
-    return hip_ops.add(x1, x2)
+    return hip_ops.add(_centred(x1, x2), x2)
 
 
 def optimal_crop_size(max_size, max_subsample_factor, safety_margin=0):
-    """Smallest multiple of 2^factor that is >= max_size + margin.
+    """Smallest multiple of 2^factor that is >= max_size, plus `safety_margin` such multiples.
     Reference: models/model_util.py:30-38."""
-    k = 2 ** max_subsample_factor
-    return int(k * ceil(max_size / k)) + safety_margin * k
+    step = 1 << int(max_subsample_factor)
+    blocks = -(-int(max_size) // step) if float(max_size).is_integer() else int(-(-max_size // step))
+    return (blocks + safety_margin) * step
 
 
 class CropParameters:
-    """Pad/crop bookkeeping so every encoder sees even sizes.
-    Reference: models/model_util.py:41-79."""
+    """Pad an image so that every encoder halves an even size, and find the original again afterwards:
+    `.pad(x)` (ZeroPad2d), `.crop(x)`, `.ix0/.ix1/.iy0/.iy1`, `.padding_{top,bottom,left,right}`,
+    `.{width,height}_crop_size`.  Reference: models/model_util.py:41-79."""
 
     def __init__(self, width, height, num_encoders, safety_margin=0):
-        self.height, self.width, self.num_encoders = height, width, num_encoders
-        self.width_crop_size = optimal_crop_size(width, num_encoders, safety_margin)
-        self.height_crop_size = optimal_crop_size(height, num_encoders, safety_margin)
-        self.padding_top = ceil(0.5 * (self.height_crop_size - height))
-        self.padding_bottom = floor(0.5 * (self.height_crop_size - height))
-        self.padding_left = ceil(0.5 * (self.width_crop_size - width))
-        self.padding_right = floor(0.5 * (self.width_crop_size - width))
+        self.width, self.height, self.num_encoders = width, height, num_encoders
+        spans = {}
+        for axis, size in (("width", width), ("height", height)):
+            full = optimal_crop_size(size, num_encoders, safety_margin)
+            slack = full - size
+            lead, trail = (slack + 1) // 2, slack // 2  # ceil / floor of half the slack
+            start = full // 2 - size // 2
+            spans[axis] = (full, lead, trail, start, start + size)
+        self.width_crop_size, self.padding_left, self.padding_right, self.ix0, self.ix1 = spans["width"]
+        self.height_crop_size, self.padding_top, self.padding_bottom, self.iy0, self.iy1 = spans["height"]
+        self.cx, self.cy = self.width_crop_size // 2, self.height_crop_size // 2
         self.pad = ZeroPad2d((self.padding_left, self.padding_right, self.padding_top, self.padding_bottom))
-        self.cx, self.cy = floor(self.width_crop_size / 2), floor(self.height_crop_size / 2)
-        self.ix0, self.ix1 = self.cx - floor(width / 2), self.cx + ceil(width / 2)
-        self.iy0, self.iy1 = self.cy - floor(height / 2), self.cy + ceil(height / 2)
 
     def crop(self, img):
         return img[..., self.iy0 : self.iy1, self.ix0 : self.ix1]
 
 
 def recursive_clone(tensor):
-    """Deep clone of a tensor or a (nested) tuple/list of tensors.
+    """Clone of a tensor, or of every tensor inside nested tuples / lists (containers keep their type).
     Reference: models/model_util.py:82-93."""
-    if hasattr(tensor, "clone"):
+    if torch.is_tensor(tensor) or hasattr(tensor, "clone"):
         return tensor.clone()
-    try:
-        return type(tensor)(recursive_clone(t) for t in tensor)
-    except TypeError:
-        return copy.deepcopy(tensor)
+    if isinstance(tensor, (list, tuple)):
+        return type(tensor)(recursive_clone(item) for item in tensor)
+    return copy.deepcopy(tensor)
 
 
 def copy_states(states):
-    """Reference: models/model_util.py:96-102 (a list whose first entry is None
-    is passed through unchanged)."""
-    if states[0] is None:
-        return copy.deepcopy(states)
-    return recursive_clone(states)
+    """States of a model: cloned, unless the list still starts with None (then a plain deep copy).
+    Reference: models/model_util.py:96-102."""
+    return recursive_clone(states) if states[0] is not None else copy.deepcopy(states)

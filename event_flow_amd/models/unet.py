@@ -34,7 +34,10 @@ from .submodules import (
 
 
 class BaseUNet(nn.Module):
-    """Sizes and builders shared by the multi-resolution UNets (reference unet.py:28-145)."""
+    """Channel plan and layer factories shared by the UNets (reference unet.py:28-145).  The plan for
+    `num_encoders` = E, base width C, multiplier m:  encoder i maps C m^i -> C m^(i+1) at stride 2 (the first one
+    reads `num_bins` channels in the multi-resolution nets), the residual blocks work at C m^E, decoder i maps the
+    (concatenated or summed) skip pair back to the width of encoder E-1-i's input."""
 
     ff_type = ConvLayer
     res_type = ResidualBlock
@@ -47,76 +50,67 @@ class BaseUNet(nn.Module):
         super().__init__()
         kw = dict(unet_kwargs)
         self.final_activation = kw.pop("final_activation", None)
-        self._base_init(**kw)
+        self._plan(**kw)
 
-    # reference BaseUNet.__init__, unet.py:40-91
-    def _base_init(self, base_num_channels, num_encoders, num_residual_blocks, num_output_channels, skip_type, norm,
-                   use_upsample_conv, num_bins, recurrent_block_type=None, kernel_size=5, channel_multiplier=2,
-                   activations=("relu", None), spiking_feedforward_block_type=None, spiking_neuron=None):
-        self.base_num_channels = base_num_channels
-        self.num_encoders = num_encoders
-        self.num_residual_blocks = num_residual_blocks
-        self.num_output_channels = num_output_channels
-        self.kernel_size = kernel_size
-        self.skip_type = skip_type
-        self.norm = norm
-        self.num_bins = num_bins
-        self.recurrent_block_type = recurrent_block_type
-        self.channel_multiplier = channel_multiplier
+    def _plan(self, base_num_channels, num_encoders, num_residual_blocks, num_output_channels, skip_type, norm,
+              use_upsample_conv, num_bins, recurrent_block_type=None, kernel_size=5, channel_multiplier=2,
+              activations=("relu", None), spiking_feedforward_block_type=None, spiking_neuron=None):
+        assert num_output_channels > 0
+        for name, value in (("base_num_channels", base_num_channels), ("num_encoders", num_encoders),
+                            ("num_residual_blocks", num_residual_blocks), ("num_output_channels", num_output_channels),
+                            ("kernel_size", kernel_size), ("skip_type", skip_type), ("norm", norm), ("num_bins", num_bins),
+                            ("recurrent_block_type", recurrent_block_type), ("channel_multiplier", channel_multiplier)):
+            setattr(self, name, value)
         self.ff_act, self.rec_act = activations
-        self.spiking_kwargs = {}
+        # keyword arguments every cell / block of a spiking or leaky net receives (reference :69-73)
+        self.spiking_kwargs = dict(spiking_neuron) if type(spiking_neuron) is dict else {}
         if spiking_feedforward_block_type is not None:
-            self.spiking_kwargs["spiking_feedforward_block_type"] = spiking_feedforward_block_type
-        if type(spiking_neuron) is dict:
-            self.spiking_kwargs.update(spiking_neuron)
+            self.spiking_kwargs = {"spiking_feedforward_block_type": spiking_feedforward_block_type, **self.spiking_kwargs}
         self.skip_ftn = {"concat": skip_concat, "sum": skip_sum}[skip_type]
         self.UpsampleLayer = self.upsample_type if use_upsample_conv else self.transpose_type
-        assert self.num_output_channels > 0
-        self.encoder_input_sizes = [int(base_num_channels * pow(channel_multiplier, i)) for i in range(num_encoders)]
-        self.encoder_output_sizes = [int(base_num_channels * pow(channel_multiplier, i + 1)) for i in range(num_encoders)]
-        self.max_num_channels = self.encoder_output_sizes[-1]
+        widths = [int(base_num_channels * channel_multiplier ** i) for i in range(num_encoders + 1)]
+        self.encoder_input_sizes, self.encoder_output_sizes = widths[:-1], widths[1:]
+        self.max_num_channels = widths[-1]
 
-    def build_recurrent_encoders(self):  # unet.py:335-353
-        encoders = nn.ModuleList()
-        for i, (cin, cout) in enumerate(zip(self.encoder_input_sizes, self.encoder_output_sizes)):
-            if i == 0:
-                cin = self.num_bins
-            encoders.append(self.rec_type(cin, cout, kernel_size=self.kernel_size, stride=2,
-                                          recurrent_block_type=self.recurrent_block_type, activation_ff=self.ff_act,
-                                          activation_rec=self.rec_act, norm=self.norm, **self.spiking_kwargs))
-        return encoders
+    def _stack(self, make, n):
+        return nn.ModuleList(make(i) for i in range(n))
+
+    def build_encoders(self, recurrent, first_reads_bins):
+        """Stride-2 encoders: plain `ff_type` layers (unet.py:241-257) or `rec_type` layers with their recurrent
+        block (:335-353; :175-190 for the UNet whose head conv comes first)."""
+        def make(i):
+            cin = self.num_bins if (first_reads_bins and i == 0) else self.encoder_input_sizes[i]
+            common = dict(kernel_size=self.kernel_size, stride=2, norm=self.norm)
+            if not recurrent:
+                return self.ff_type(cin, self.encoder_output_sizes[i], activation=self.ff_act, **common, **self.spiking_kwargs)
+            extra = self.spiking_kwargs if first_reads_bins else {}
+            return self.rec_type(cin, self.encoder_output_sizes[i], recurrent_block_type=self.recurrent_block_type,
+                                 activation_ff=self.ff_act, activation_rec=self.rec_act, **common, **extra)
+
+        return self._stack(make, self.num_encoders)
 
     def build_resblocks(self):  # unet.py:110-122
-        blocks = nn.ModuleList()
-        for _ in range(self.num_residual_blocks):
-            blocks.append(self.res_type(self.max_num_channels, self.max_num_channels, activation=self.ff_act, norm=self.norm,
-                                        **self.spiking_kwargs))
-        return blocks
+        c = self.max_num_channels
+        return self._stack(lambda _i: self.res_type(c, c, activation=self.ff_act, norm=self.norm, **self.spiking_kwargs),
+                           self.num_residual_blocks)
 
-    def build_multires_prediction_decoders(self):  # unet.py:371-388
-        decoders = nn.ModuleList()
-        sizes = zip(reversed(self.encoder_output_sizes), reversed(self.encoder_input_sizes))
-        for i, (cin, cout) in enumerate(sizes):
-            pred_ch = 0 if i == 0 else self.num_output_channels
-            decoders.append(self.UpsampleLayer(2 * cin + pred_ch, cout, kernel_size=self.kernel_size, activation=self.ff_act,
-                                               norm=self.norm, **self.spiking_kwargs))
-        return decoders
+    def build_decoders(self, with_predictions):
+        """Up-sampling decoders, coarse to fine.  Their input is the skip pair (2x the channels for `concat`) plus, in the
+        multi-resolution nets, the previous scale's prediction (unet.py:124-138, :371-388)."""
+        def make(i):
+            cin = self.encoder_output_sizes[-1 - i]
+            cin = cin if self.skip_type == "sum" and not with_predictions else 2 * cin
+            if with_predictions and i > 0:
+                cin += self.num_output_channels
+            return self.UpsampleLayer(cin, self.encoder_input_sizes[-1 - i], kernel_size=self.kernel_size,
+                                      activation=self.ff_act, norm=self.norm, **self.spiking_kwargs)
 
-    def build_multires_prediction_layer(self):  # unet.py:355-369
-        preds = nn.ModuleList()
-        for cout in reversed(self.encoder_input_sizes):
-            preds.append(self.ff_type(cout, self.num_output_channels, 1, activation=self.final_activation, norm=self.norm,
-                                      w_scale=self.w_scale_pred))
-        return preds
+        return self._stack(make, self.num_encoders)
 
-    def build_encoders(self):  # unet.py:241-257 (MultiResUNet)
-        encoders = nn.ModuleList()
-        for i, (cin, cout) in enumerate(zip(self.encoder_input_sizes, self.encoder_output_sizes)):
-            if i == 0:
-                cin = self.num_bins
-            encoders.append(self.ff_type(cin, cout, kernel_size=self.kernel_size, stride=2, activation=self.ff_act,
-                                         norm=self.norm, **self.spiking_kwargs))
-        return encoders
+    def build_predictions(self):  # one 1x1 layer per scale, unet.py:259-266 / :355-369
+        return self._stack(lambda i: self.ff_type(self.encoder_input_sizes[-1 - i], self.num_output_channels, 1,
+                                                   activation=self.final_activation, norm=self.norm,
+                                                   w_scale=self.w_scale_pred), self.num_encoders)
 
     def _decoder_input(self, x, skip, prediction, decoder):
         """cat(prediction, cat(x, skip)) (unet.py:303-306); with 2C+2 channels two zero channels keep the activation
@@ -130,6 +124,18 @@ class BaseUNet(nn.Module):
                 x = torch.cat([x, x.new_zeros((x.shape[0], pad) + tuple(x.shape[2:]))], 1)
         return x
 
+    def _decode(self, x, blocks, stateful, offset=0):
+        """Decoders + per-scale predictions, coarse to fine (unet.py:298-311, :402-415, :455-465)."""
+        predictions = []
+        for i, (decoder, pred) in enumerate(zip(self.decoders, self.preds)):
+            x = self._decoder_input(x, blocks[-1 - i], predictions[-1] if i else None, decoder)
+            if stateful:
+                x, self.states[offset + i] = decoder(x, self.states[offset + i])
+            else:
+                x = decoder(x)
+            predictions.append(pred(x))
+        return predictions
+
 
 class UNetRecurrent(BaseUNet):
     """E2VID's UNet: head conv, ConvLayer + ConvLSTM encoders, residual blocks, up-sampling decoders on x + skip,
@@ -140,30 +146,15 @@ class UNetRecurrent(BaseUNet):
         final_activation = kw.pop("final_activation", "none")
         nn.Module.__init__(self)
         self.final_activation = final_activation if hasattr(torch, final_activation) else None
-        self._base_init(**kw)
+        self._plan(**kw)
         self.head = ConvLayer(self.num_bins, self.base_num_channels, kernel_size=self.kernel_size, stride=1)
-        self.encoders = self.build_recurrent_encoders()
+        self.encoders = self.build_encoders(recurrent=True, first_reads_bins=False)
         self.resblocks = self.build_resblocks()
-        self.decoders = self.build_decoders()
+        self.decoders = self.build_decoders(with_predictions=False)
         self.pred = self.ff_type(self.base_num_channels if self.skip_type == "sum" else 2 * self.base_num_channels,
                                  self.num_output_channels, 1, activation=None, norm=self.norm)
         self.num_states = self.num_encoders
         self.states = [None] * self.num_states
-
-    def build_recurrent_encoders(self):  # unet.py:175-190: every encoder input is a feature map (the head comes first)
-        encoders = nn.ModuleList()
-        for cin, cout in zip(self.encoder_input_sizes, self.encoder_output_sizes):
-            encoders.append(self.rec_type(cin, cout, kernel_size=self.kernel_size, stride=2,
-                                          recurrent_block_type=self.recurrent_block_type, activation_ff=self.ff_act,
-                                          activation_rec=self.rec_act, norm=self.norm))
-        return encoders
-
-    def build_decoders(self):  # unet.py:124-138
-        decoders = nn.ModuleList()
-        for cin, cout in zip(reversed(self.encoder_output_sizes), reversed(self.encoder_input_sizes)):
-            decoders.append(self.UpsampleLayer(cin if self.skip_type == "sum" else 2 * cin, cout, kernel_size=self.kernel_size,
-                                               activation=self.ff_act, norm=self.norm, **self.spiking_kwargs))
-        return decoders
 
     def forward(self, x):
         """x [N,num_bins,H,W] -> [N,num_output_channels,H,W].  unet.py:192-221."""
@@ -178,7 +169,7 @@ class UNetRecurrent(BaseUNet):
         for resblock in self.resblocks:
             x, _ = resblock(x)
         for i, decoder in enumerate(self.decoders):
-            x = decoder(self.skip_ftn(x, blocks[self.num_encoders - i - 1]))
+            x = decoder(self.skip_ftn(x, blocks[-1 - i]))
         x = self.skip_ftn(x, head)
         # pred (1x1 ConvLayer, no activation) followed by the final activation = one conv + activation launch
         return hip_ops.conv_act(self.pred, x, self.pred.conv2d.weight, self.pred.conv2d.bias, 1, self.final_activation)
@@ -190,10 +181,10 @@ class MultiResUNet(BaseUNet):
 
     def __init__(self, unet_kwargs):
         super().__init__(unet_kwargs)
-        self.encoders = self.build_encoders()
+        self.encoders = self.build_encoders(recurrent=False, first_reads_bins=True)
         self.resblocks = self.build_resblocks()
-        self.decoders = self.build_multires_prediction_decoders()
-        self.preds = self.build_multires_prediction_layer()
+        self.decoders = self.build_decoders(with_predictions=True)
+        self.preds = self.build_predictions()
 
     def forward(self, x):
         blocks = []
@@ -202,12 +193,7 @@ class MultiResUNet(BaseUNet):
             blocks.append(x)
         for resblock in self.resblocks:
             x, _ = resblock(x)
-        predictions = []
-        for i, (decoder, pred) in enumerate(zip(self.decoders, self.preds)):
-            x = self._decoder_input(x, blocks[self.num_encoders - i - 1], predictions[-1] if i else None, decoder)
-            x = decoder(x)
-            predictions.append(pred(x))
-        return predictions
+        return self._decode(x, blocks, stateful=False)
 
 
 class MultiResUNetRecurrent(BaseUNet):
@@ -216,26 +202,25 @@ class MultiResUNetRecurrent(BaseUNet):
 
     def __init__(self, unet_kwargs):
         super().__init__(unet_kwargs)
-        self.encoders = self.build_recurrent_encoders()
+        self.encoders = self.build_encoders(recurrent=True, first_reads_bins=True)
         self.resblocks = self.build_resblocks()
-        self.decoders = self.build_multires_prediction_decoders()
-        self.preds = self.build_multires_prediction_layer()
+        self.decoders = self.build_decoders(with_predictions=True)
+        self.preds = self.build_predictions()
         self.num_states = self.num_encoders
         self.states = [None] * self.num_states
 
-    def forward(self, x):
+    def _encode(self, x):
         blocks = []
         for i, encoder in enumerate(self.encoders):
             x, self.states[i] = encoder(x, self.states[i])
             blocks.append(x)
+        return x, blocks
+
+    def forward(self, x):
+        x, blocks = self._encode(x)
         for resblock in self.resblocks:
             x, _ = resblock(x)
-        predictions = []
-        for i, (decoder, pred) in enumerate(zip(self.decoders, self.preds)):
-            x = self._decoder_input(x, blocks[self.num_encoders - i - 1], predictions[-1] if i else None, decoder)
-            x = decoder(x)
-            predictions.append(pred(x))
-        return predictions
+        return self._decode(x, blocks, stateful=False)
 
 
 class SpikingMultiResUNetRecurrent(MultiResUNetRecurrent):
@@ -254,20 +239,11 @@ class SpikingMultiResUNetRecurrent(MultiResUNetRecurrent):
 
     def forward(self, x):
         """x [N,num_bins,H,W] -> [N,2,H/8..H,W/8..W] x 4 (coarse to fine).  unet.py:437-465."""
-        blocks = []
-        for i, encoder in enumerate(self.encoders):
-            x, self.states[i] = encoder(x, self.states[i])
-            blocks.append(x)
+        x, blocks = self._encode(x)
         offset = self.num_encoders
         for i, resblock in enumerate(self.resblocks):
             x, self.states[offset + i] = resblock(x, self.states[offset + i])
-        predictions = []
-        offset += self.num_residual_blocks
-        for i, (decoder, pred) in enumerate(zip(self.decoders, self.preds)):
-            x = self._decoder_input(x, blocks[self.num_encoders - i - 1], predictions[-1] if i else None, decoder)
-            x, self.states[offset + i] = decoder(x, self.states[offset + i])
-            predictions.append(pred(x))
-        return predictions
+        return self._decode(x, blocks, stateful=True, offset=offset + self.num_residual_blocks)
 
 
 class LeakyMultiResUNetRecurrent(SpikingMultiResUNetRecurrent):
