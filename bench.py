@@ -2,8 +2,10 @@
 """Benchmark of the event_flow hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
-            --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+    N > 1 without a launcher (WORLD_SIZE unset): bench.py starts its own N ranks, one per GPU, by
+    re-executing itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free port>`; launched under torch.distributed.run (or
+    torchrun) by the caller it uses the ranks it was given.
 
 Metric (BASELINE.json): event-windows/s of the LIF-FireNet train step at
 128x128 with 15k events per window (10 passes x 1500 events, truncated BPTT
@@ -249,6 +251,25 @@ def cpu_baseline(threads, max_seconds=60.0):
                       f"{best_t} threads (fastest of {cand} on a {os.cpu_count()}-CPU host), {el:.1f} s"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher: start N ranks (one per GPU) of this same command line under
+    torch.distributed.run on 127.0.0.1 and a free port, relay their output (rank 0 prints the JSON line) and
+    return the launcher's exit status."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL between processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,6 +283,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+
     from event_flow_amd import _lib
     from event_flow_amd.loss.flow import EventWarping
     from event_flow_amd.models.model import LIFFireNet
@@ -272,6 +296,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("EVF_BENCH_SINGLE_DEVICE"):  # test hook: several ranks share one GPU (with EVF_DP_BACKEND=gloo)
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {os.environ.get('RANK', '0')}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible "
+                         f"(--gpus {args.gpus} needs one GPU per rank)")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     dp = DataParallel(device=dev)
@@ -426,6 +453,10 @@ def main():
                                    "superset of configs[1]]",
                        "global_batch": B_PER_GPU * dp.world, "events_per_window": PASSES * EV_PER_PASS,
                        "parallelism": f"dp{dp.world}", "launch": mode, "loss": loss_val,
+                       "collective": ({"backend": dp.backend, "library": "RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
+                                       if dp.backend == "nccl" else dp.backend, "ranks": dp.world,
+                                       "per_step": "1 SUM all-reduce of [flat gradient | loss | new_seq] = %d bytes" % (opt.comm.numel() * 4)}
+                                      if dp.world > 1 else None),
                        "conv_precision": ("fp32 results via exact 3-way bf16 splits of the fp32 operands on the bf16 matrix cores, "
                                           "fp32 accumulation" if model_precision == "bf16x3" else "fp32 MFMA (v_mfma_f32_32x32x2_f32)")},
             "roofline": roof,

@@ -146,3 +146,34 @@ def test_bench_data_parallel_step_two_ranks_graph_equals_eager():
     assert g["config"]["global_batch"] == 16, g
     lg, le = g["config"]["loss"], e["config"]["loss"]
     assert lg == lg and abs(lg - le) <= 2e-3 * abs(le), (lg, le)
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (how the driver invokes it) re-executes itself under
+    torch.distributed.run with one rank per GPU and prints ONE JSON line with n_gpus = 2."""
+    env = dict(os.environ, EVF_DP_BACKEND="gloo", EVF_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-iwe"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 16, res
+    assert res["config"]["collective"]["ranks"] == 2 and res["value"] > 0
+
+
+@pytest.mark.parametrize("ranks,model", [(2, "LIFFireNet"), (4, "LIFFireNet"), (2, "PLIFFireNet")])
+def test_hip_sharded_gradient_equals_hip_global_batch_gradient(ranks, model):
+    """N ranks each running the HIP step on their slot range + ONE SUM all-reduce == the HIP gradient of the
+    global batch on one replica (rel-L2 <= 1e-5), same loss, bit-equal per-slot states, same parameters after clip+Adam."""
+    env = dict(os.environ, EVF_DP_BACKEND="gloo", EVF_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_shard_check.py"), "--ranks", str(ranks), "--model", model],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    print(res)
+    assert res["ok_all_ranks"] and res["ranks"] == ranks and res["grad_rel_l2"] <= 1e-5 and res["states_bit_equal"], res
