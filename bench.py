@@ -121,6 +121,23 @@ class StepGraph:
         return self.loss
 
 
+def capture_step_graphs(model, lossf, opt, dp, pool, stream):
+    """One StepGraph per window of `pool` (the warm-up must have run eagerly on `stream` with
+    model.use_static_states(True)).  The recurrent state crosses replays without a copy: graph 0 starts from the
+    buffers the warm-up left, graph k from the tensors graph k-1's last pass wrote (fixed addresses in its capture
+    pool), and the last graph's last pass writes straight back into the first buffers.  Replays cycle 0,1,0,1...
+    `graph.left` = the state tensors a replay of that graph leaves behind (model.set_state_buffers)."""
+    home = model.state_buffers()
+    model.use_static_states(False)
+    graphs = []
+    for gi, lists in enumerate(pool):
+        if gi == len(pool) - 1:
+            model.final_states_into(home)
+        graphs.append(StepGraph(model, lossf, opt, dp, lists, stream))
+        graphs[-1].left = model.state_buffers()
+    return graphs
+
+
 def iwe_warp_bandwidth(dev, B, reps=20):
     from event_flow_amd import synthetic
     from event_flow_amd.utils.iwe import compute_pol_iwe
@@ -335,16 +352,7 @@ def main():
     if use_graph:
         try:
             torch.cuda.synchronize()
-            # The recurrent state crosses replays without a copy: graph 0 starts from the buffers the warm-up
-            # left, graph k from the tensors graph k-1's last pass wrote (fixed addresses in its capture pool),
-            # and the last graph's last pass writes straight back into the first buffers.  Replays cycle 0,1,0,1...
-            home = model.state_buffers()
-            model.use_static_states(False)
-            graphs = []
-            for gi, lists in enumerate(pool):
-                if gi == len(pool) - 1:
-                    model.final_states_into(home)
-                graphs.append(StepGraph(model, lossf, opt, dp, lists, side))
+            graphs = capture_step_graphs(model, lossf, opt, dp, pool, side)
         except Exception as e:  # capture unsupported in this environment: eager launches
             print(f"[bench] rank {dp.rank}: hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
             graphs = None

@@ -34,6 +34,22 @@ def test(args, config_parser):
     config["data"].setdefault("window_eval", config["data"]["window"])
     config["loss"] = config.get("loss", {"overwrite_intermediate": False})
     device = config_parser.device
+    if torch.device(device).type == "cuda":
+        torch.cuda.set_device(device)  # the evf_* launches go to the current device's stream (loader.gpu may not be 0)
+
+    # configuration checks of the reference driver (eval_flow.py:54-73)
+    names_cfg = config.get("metrics", {}).get("name", [])
+    if "AEE" in names_cfg and not args.synthetic:  # (the synthetic loader carries one ground-truth map per input window)
+        assert config["data"]["mode"] in ("gtflow_dt1", "gtflow_dt4"), "AEE computation not possible without ground truth mode"
+        assert config["data"]["window"] <= 1, "AEE computation not compatible with window > 1"
+        assert np.isclose((1.0 / config["data"]["window"]) % 1.0, 0.0), \
+            "AEE computation not compatible with windows whose inverse is not a round number"
+    if config["data"]["mode"] == "frames":
+        if config["data"]["window"] <= 1.0:
+            assert np.isclose((1.0 / config["data"]["window"]) % 1.0, 0.0), \
+                "Frames mode not compatible with < 1 windows whose inverse is not a round number"
+        else:
+            assert np.isclose(config["data"]["window"] % 1.0, 0.0), "Frames mode not compatible with > 1 fractional windows"
 
     model = MODELS[config["model"]["name"]](config["model"].copy()).to(device)
     if args.weights:  # a state_dict file, a reference checkpoint (pickled model) or its MLflow run id under ./mlruns
@@ -59,6 +75,8 @@ def test(args, config_parser):
         vis = Visualization(config, eval_id=0, path_results=args.store.rstrip("/") + "/")
     results = {m: {"metric": 0.0, "it": 0, **({"percent": 0.0} if m == "AEE" else {})} for m in names}
     iwe_sharpness = []
+    idx_AEE = 0  # sub-windows since the last AEE evaluation (eval_flow.py:117,171-176)
+    aee_every = 1 if args.synthetic else int(np.round(1.0 / config["data"]["window"]))
     with torch.no_grad():
         for inputs in data:
             if data.new_seq:
@@ -80,7 +98,18 @@ def test(args, config_parser):
                 if criteria[i].num_events >= config["data"]["window_eval"]:
                     if config["loss"].get("overwrite_intermediate", False):
                         criteria[i].overwrite_intermediate_flow(x["flow"])
+                    if name == "AEE":
+                        # no ground truth interval yet: skip WITHOUT resetting; with window < 1 the ground-truth map
+                        # spans round(1/window) input windows, so the criterion keeps accumulating until the last
+                        # of them and is evaluated (and reset) only then (eval_flow.py:169-176)
+                        if float(torch.as_tensor(inputs["dt_gt"]).reshape(-1)[0]) <= 0.0:
+                            continue
+                        idx_AEE += 1
+                        if idx_AEE != aee_every:
+                            continue
                     val = criteria[i]()
+                    if name == "AEE":
+                        idx_AEE = 0
                     results[name]["it"] += 1
                     if name == "AEE":
                         results[name]["metric"] += float(val[0].mean())

@@ -222,5 +222,9 @@ def call(name, *args):
 def require_gpu(t, what):
     if not t.is_cuda:
         raise EvflowError(f"{what}: tensor is on {t.device}; the evflow path runs on the MI355X only (no CPU fallback)")
+    if t.device.index != torch.cuda.current_device():
+        # launches go to the CURRENT device's stream: a tensor on another GPU would be touched from the wrong context
+        raise EvflowError(f"{what}: tensor is on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                          "call torch.cuda.set_device(tensor.device) first (one process per GPU)")
     if t.dtype != torch.float32 and t.dtype != torch.int32:
         raise EvflowError(f"{what}: unsupported dtype {t.dtype}")

@@ -319,20 +319,25 @@ class H5Loader(BaseDataLoader):
             q = queue.Queue(maxsize=self.prefetch)
             stop = threading.Event()
 
+            def put(item):
+                """Blocking put that gives up once the consumer has closed the iterator (a full queue nobody
+                reads would otherwise hold the thread, and the consumer's join, forever) -> delivered?"""
+                while not stop.is_set():
+                    try:
+                        q.put(item, timeout=0.1)
+                        return True
+                    except queue.Full:
+                        continue
+                return False
+
             def produce():
                 try:
                     for item in self._host_batches():
-                        while not stop.is_set():
-                            try:
-                                q.put(item, timeout=0.1)
-                                break
-                            except queue.Full:
-                                continue
-                        if stop.is_set():
+                        if not put(item):
                             return
-                    q.put(None)
+                    put(None)
                 except BaseException as e:  # surfaced in the consumer
-                    q.put(e)
+                    put(e)
 
             th = threading.Thread(target=produce, daemon=True)
             th.start()

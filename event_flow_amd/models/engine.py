@@ -23,6 +23,7 @@ import os
 import torch
 
 from .. import _lib
+from . import hip_ops
 from .spiking_util import SURROGATE_ID
 
 C = 32  # channels of the accelerated kernels (base_num_channels)
@@ -571,9 +572,9 @@ class FireNetEngine:
             if not p.requires_grad:
                 grads.append(None)
                 continue
-            # a bound fp32 .grad (FlatAdam's flat buffer, or a previous backward): accumulate into it in our
+            # a bound fp32 .grad while FlatAdam is in charge (hip_ops.DIRECT_PARAM_GRADS; its flat buffer): accumulate into it in our
             # kernels and hand autograd nothing -- saves one add kernel per parameter tensor per step
-            direct = p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.is_cuda
+            direct = hip_ops.DIRECT_PARAM_GRADS and p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.is_cuda
             if name in self.small_off:
                 if name == "0.ff" and win.slab_init.get((0, "ff")):  # head weight gradient: per-block partials
                     sl = self._slabs[(0, "ff")]

@@ -33,6 +33,8 @@ def train(args, config_parser):
         raise AttributeError
     config = config_parser.combine_entries(config)
     device = config_parser.device
+    if torch.device(device).type == "cuda":
+        torch.cuda.set_device(device)  # the evf_* launches go to the current device's stream (loader.gpu may not be 0)
 
     # data parallel (one process per GPU under torch.distributed.run): sequence files sharded over the ranks, one SUM
     # all-reduce of the flat gradient per optimizer step (event_flow_amd/parallel.py)
@@ -76,8 +78,8 @@ def train(args, config_parser):
     n_epochs = args.epochs if args.epochs is not None else config["loader"]["n_epochs"]
     best_loss, history = 1.0e6, []
     t_start = time.time()
+    data.shuffle()  # once, before the first epoch (train_flow.py:92)
     for epoch in range(n_epochs):
-        data.shuffle(epoch)
         train_loss, samples, steps = torch.zeros((), device=device), 0, 0
         batches = iter(data)
         while True:
@@ -97,7 +99,13 @@ def train(args, config_parser):
             loss_function.event_flow_association(x["flow"], inputs["event_list"], inputs["event_list_pol_mask"],
                                                  inputs["event_mask"])
 
-            if loss_function.num_events >= config["data"]["window_loss"]:
+            # The optimizer step contains the step's collective, so with several ranks the decision to step is itself
+            # made collectively: `num_events` is a rank-local count (it differs between ranks in the time / gtflow
+            # modes), and a rank entering the all-reduce alone would pair it with another rank's flag exchange.
+            step_now = loss_function.num_events >= config["data"]["window_loss"]
+            if dp:
+                step_now = dp.any_flags([step_now])[0]
+            if step_now:
                 if config["loss"]["overwrite_intermediate"]:
                     loss_function.overwrite_intermediate_flow(x["flow"])
                 loss = loss_function()
