@@ -59,10 +59,9 @@ NETWORK_SIGNATURES = {
     "evf_lif_bwd_wgrad": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P, P, P, I, P],
     "evf_lif_bwd_wgrad_top": [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P, P, I, P],
     "evf_pack_conv_weight_b3t": [P, I, I, P, P],
-    "evf_bwd_chain_slabs": [I, I, I],
-    "evf_bwd_chain": [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P, P, I, P],
     "evf_conv_dgrad_b3": [P, P, P, I, I, I, I, P, P, P],
     "evf_conv_dgrad_b3_f32": [P, P, P, I, I, I, I, P, P, P],
+    "evf_conv_dgrad_select": [I],
     "evf_conv_dgrad_b3_f32_pair": [P, P, P, I, P, P, I, I, I, P, P, P],
     "evf_conv_plif_fwd_b3": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P],
     "evf_head_plif_fwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P],

@@ -21,6 +21,7 @@
 // tap is shared round-robin) -> no atomics, one slab [9][32][32] per block and
 // input, accumulated over the passes of a window.
 #include "evf_common.h"
+#include "evf_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -231,29 +232,24 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     }
     // exact split g = hi + mid + lo (bf16 each), stored in B-operand order:
     // pixel p = 16*kq + 8*kgp + ee, element ((kq*2 + kgp)*32 + j)*8 + ee
-    uint32_t tb[3][4];
+    // exact split g = hi + mid + lo (bf16 each; two channels per v_cvt_pk_bf16_f32, evf_split.h), stored in B-operand order:
+    // pixel p = 16*kq + 8*kgp + ee, element ((kq*2 + kgp)*32 + j)*8 + ee
+    uint32_t tp[3][2];  // [term][channel pair]: low half = channel 2e, high half = channel 2e+1
     const int base = ((p >> 3) * C32) * 8 + (p & 7);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float g0 = ok ? gc[c] : 0.f;
-      const uint32_t hi = fb_bf16(g0);
-      const float r1 = g0 - __uint_as_float(hi << 16);
-      const uint32_t mid = fb_bf16(r1);
-      const float r2 = r1 - __uint_as_float(mid << 16);
-      const uint32_t lo = fb_bf16(r2);
-      const int o = base + (4 * cg + c) * 8;
-      {
-      sb[o] = (unsigned short)hi;
-      sb[FB_CW * C32 + o] = (unsigned short)mid;
-      sb[2 * FB_CW * C32 + o] = (unsigned short)lo;
+    for (int e = 0; e < 2; ++e) {
+      evf_split3_pair(ok ? gc[2 * e] : 0.f, ok ? gc[2 * e + 1] : 0.f, tp[0][e], tp[1][e], tp[2][e]);
+#pragma unroll
+      for (int t3 = 0; t3 < 3; ++t3) {
+        const int o = t3 * FB_CW * C32 + base + (4 * cg + 2 * e) * 8;
+        sb[o] = (unsigned short)tp[t3][e];              // ds_write_b16
+        sb[o + 8] = (unsigned short)(tp[t3][e] >> 16);  // ds_write_b16_d16_hi
       }
-      tb[0][c] = hi, tb[1][c] = mid, tb[2][c] = lo;
     }
     if (ok && g_split) {  // the same split as three bf16 planes [term][pix][32] for evf_conv_dgrad_b3
       const long ps = (long)B * H * W * 8;
 #pragma unroll
-      for (int t3 = 0; t3 < 3; ++t3)
-        g_split[t3 * ps + pix0 * 8 + tid] = make_uint2(tb[t3][0] | (tb[t3][1] << 16), tb[t3][2] | (tb[t3][3] << 16));
+      for (int t3 = 0; t3 < 3; ++t3) g_split[t3 * ps + pix0 * 8 + tid] = make_uint2(tp[t3][0], tp[t3][1]);
     }
     if (tid < 3 * C32 * FB_NW) {
       s_px[buf * (3 * C32 * FB_NW) + tid] = s.px & s.pin;

@@ -41,3 +41,7 @@ __device__ __forceinline__ float evf_block_sum(float v, float* smem /* >= 16 flo
   __syncthreads();
   return r;
 }
+
+// evf_dgrad_ws.hip: wave-specialised input-gradient kernel behind evf_conv_dgrad_b3_f32[_pair]
+int evf_dgrad_ws_launch(const float* g_cur, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W, const float* g_P,
+                        const uint32_t* x_bits, const void* wT2_b3, float* g_x2, int max_blocks, void* stream);

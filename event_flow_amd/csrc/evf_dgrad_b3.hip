@@ -11,6 +11,9 @@
 // 8-row x 32-pixel tile whose gradient halo (3 planes) and split weights both
 // live in LDS, filled by LDS-DMA (see k_conv_dgrad_b3_lds below).
 #include "evf_common.h"
+#include "evf_dgrad_mma.h"
+#include "evf_split.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -165,20 +168,14 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
         if (it < DL_HP * 4) {
           const int p = it >> 2, c = it & 3;
           const float v[8] = {lo4[n].x, lo4[n].y, lo4[n].z, lo4[n].w, hi4[n].x, hi4[n].y, hi4[n].z, hi4[n].w};
-          uint32_t t3[3][8];
+          uint32_t t3[3][4];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {  // g = hi + mid + lo, the split of evf_lif_bwd_wgrad
-            const uint32_t hi = dg_bf16(v[e]);
-            const float r1 = v[e] - __uint_as_float(hi << 16);
-            const uint32_t mid = dg_bf16(r1);
-            const float r2 = r1 - __uint_as_float(mid << 16);
-            t3[0][e] = hi, t3[1][e] = mid, t3[2][e] = dg_bf16(r2);
-          }
+          for (int e = 0; e < 4; ++e)  // g = hi + mid + lo, the split of evf_lif_bwd_wgrad, two channels per step (evf_split.h)
+            evf_split3_pair(v[2 * e], v[2 * e + 1], t3[0][e], t3[1][e], t3[2][e]);
           const int slot = p * 4 + (c ^ ((p >> 2) & 3));
 #pragma unroll
           for (int sp = 0; sp < 3; ++sp)
-            s_a[sp * DL_HPP * 4 + slot] = make_uint4(t3[sp][0] | (t3[sp][1] << 16), t3[sp][2] | (t3[sp][3] << 16),
-                                                     t3[sp][4] | (t3[sp][5] << 16), t3[sp][6] | (t3[sp][7] << 16));
+            s_a[sp * DL_HPP * 4 + slot] = make_uint4(t3[sp][0], t3[sp][1], t3[sp][2], t3[sp][3]);
         }
       }
     }
@@ -200,43 +197,13 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
     const uint32_t xb = PLIF ? xbits[pixq] : 0u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    auto matrix_phase = [&]() -> f32x16 {
-      f32x16 acc = {0};
+    uint32_t msk[9];
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int yy = y + dy - 1;
-        const bool yin = yy >= 0 && yy < H;
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int tau = dy * 3 + dx;
-          const int xx = x0 + i + dx - 1;
-          const uint32_t msk = (yin && xx >= 0 && xx < W) ? 0xFFFFFFFFu : 0u;
-          const int hp = (wv + dy) * DL_HW + i + dx, sw = (hp >> 2) & 3;
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            const uint4* wf = s_w + ((tau * 2 + m) * 3) * 64 + lane;
-            const uint4 w0 = wf[0], w1 = wf[64], w2 = wf[128];
-            const bf16x8 wh = *(const bf16x8*)&w0, wm = *(const bf16x8*)&w1, wl = *(const bf16x8*)&w2;
-            const int slot = hp * 4 + ((2 * m + kg) ^ sw);
-            uint4 u0 = s_a[slot], u1 = s_a[DL_HPP * 4 + slot], u2 = s_a[2 * DL_HPP * 4 + slot];
-            u0.x &= msk, u0.y &= msk, u0.z &= msk, u0.w &= msk;
-            u1.x &= msk, u1.y &= msk, u1.z &= msk, u1.w &= msk;
-            u2.x &= msk, u2.y &= msk, u2.z &= msk, u2.w &= msk;
-            const bf16x8 ah = *(const bf16x8*)&u0, am = *(const bf16x8*)&u1, al = *(const bf16x8*)&u2;
-            // smallest terms first.  Weights as the A operand, gradient as B: the product comes out TRANSPOSED (lane =
-          // pixel, 16 channels in groups of four), so the epilogue moves float4s -- 4 instead of 16 memory instructions
-          // per tensor and lane (the texture addresser, not HBM, bounds a dword-per-lane epilogue)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, am, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, am, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, ah, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc, 0, 0, 0);
-          }
-        }
-      }
-      return acc;
-    };
+    for (int tau = 0; tau < 9; ++tau) {
+      const int yy = y + tau / 3 - 1, xx = x0 + i + tau % 3 - 1;
+      msk[tau] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? 0xFFFFFFFFu : 0u;
+    }
+    auto matrix_phase = [&]() -> f32x16 { return dg_matrix_phase<true>(s_w, s_a, DL_HPP * 4, wv * DL_HW + i, lane, msk); };
     // with two weight sets the order alternates from tile to tile: the set left in LDS by the previous tile goes first
     const int nset = wt2 ? 2 : 1;
     for (int k = 0; k < nset; ++k) {
@@ -276,11 +243,35 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
   }
 }
 
+static int dg_select = -1;  // -1 by shape, 0 k_conv_dgrad_b3_lds, 1 k_conv_dgrad_ws
+extern "C" int evf_conv_dgrad_select(int which) {
+  if (which < -1 || which > 1) return EVF_EINVAL;
+  dg_select = which;
+  return EVF_OK;
+}
+
 static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W,
                      const float* g_P, const uint32_t* x_bits, const void* wT2_b3, float* g_x2, void* stream) {
   if (!g || !wT_b3 || !g_x || B <= 0 || H <= 0 || W <= 0 || ((g_P != nullptr) != (x_bits != nullptr)) ||
       ((wT2_b3 != nullptr) != (g_x2 != nullptr)))
     return EVF_EINVAL;
+  // fp32 gradient in: two kernels with bit-identical results (shared matrix phase, evf_dgrad_mma.h).  The wave-specialised
+  // one (evf_dgrad_ws.hip: producers split the next tile's halo while the consumers' MFMAs run) wins once a CU gets several
+  // tiles (260 x 346 x B4: 46 vs 60 us); with <= 2 tiles per CU the cold first fetch dominates either way and the
+  // one-phase-after-the-other kernel below is ~1 % ahead in the train step (128 x 128 x B8: 20.1 vs 21.3 us in the step).
+  // evf_conv_dgrad_select() / EVF_DGRAD=lds|ws override the choice (A/B measurements, the equivalence test).
+  if (f32in) {
+    int mode = dg_select;
+    if (mode < 0) {
+      static const int env_mode = []() {
+        const char* e = getenv("EVF_DGRAD");
+        return !e ? -1 : (e[0] == 'l' ? 0 : (e[0] == 'w' ? 1 : -1));
+      }();
+      mode = env_mode;
+    }
+    if (mode < 0) mode = ((long)B * evf_cdiv(H, 4) * evf_cdiv(W, 32) >= 6L * 256) ? 1 : 0;
+    if (mode == 1) return evf_dgrad_ws_launch((const float*)g, wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, wT2_b3, g_x2, 0, stream);
+  }
   // Samples per block (the 54 KiB of split weights are staged once per block): several only when the whole grid
   // then is ONE round of the 256 CUs (B = 8 at 128 x 128: 256 blocks x 2 tiles, 1 % faster than 512 x 1); with more
   // rounds than that, fat blocks only coarsen the tail (260 x 346: 726 x 2 tiles was 11 % slower than 1452 x 1).

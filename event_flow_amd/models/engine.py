@@ -40,9 +40,6 @@ def _f32(shape, dev):
 # the input-gradient kernel takes the fp32 g_cur and splits it while staging (128 instead of 192 B/pixel written and read)
 F32_DGRAD = os.environ.get("EVF_F32_DGRAD", "1") != "0"
 PRED_FUSED = os.environ.get("EVF_PRED_FUSED", "1") != "0"  # prediction head in the epilogue of the last layer's forward
-# evf_bwd_chain: dgrad(l) + neuron backward / weight gradients (l-1) in one kernel.  Correct, but 3.5 % slower per step
-# than the separate kernels in its present form (see evf_bwd_chain.hip): off unless EVF_CHAIN=1
-CHAIN = os.environ.get("EVF_CHAIN", "0") == "1"
 TOP_FUSED = os.environ.get("EVF_TOP_FUSED", "1") != "0"  # prediction-head backward inside the top layer's fused backward
 PAIR_DGRAD = os.environ.get("EVF_PAIR_DGRAD", "1") != "0"  # ff + rec input gradients of a recurrent cell in one launch
 
@@ -58,7 +55,6 @@ class _Window:
         self.gz = [None] * n  # dL/d(output spikes) of the pass being processed
         self.gz_has = [False] * n
         self.g_cur = None
-        self.g_cur_alt = None  # second g_cur buffer (evf_bwd_chain reads one, writes the other)
         self.g_split = None  # [3,B,H,W,32] bf16: exact 3-way split of g_cur (bf16x3 path)
         self.gpt = [None] * n  # PLIF: dL/d(trace) carried to the previous pass
         self.gpt_has = [False] * n
@@ -397,10 +393,6 @@ class FireNetEngine:
             if self.precision == "bf16x3":
                 if not F32_DGRAD:
                     win.g_split = torch.empty((3, B, H, W, C), dtype=torch.bfloat16, device=dev)
-        chained_layer = -1  # the layer whose neuron backward + weight gradients the previous iteration's chain kernel did
-        chain_ok = (CHAIN and F32_DGRAD and self.precision == "bf16x3" and self.kind == "lif"
-                    and _lib.load().evf_bwd_chain_slabs(B, H, W) == _lib.load().evf_lif_bwd_wgrad_slabs(B, H, W)
-                    and B * H * W * C * 4 < 2 ** 31)
         for i in range(n - 1, -1, -1):
             c = self.cells[i]
             in_bits, v_prev, z_prev, v_out, _, in_bitsT, zT_prev, pt_prev, pt_out, P_sav = layers[i]
@@ -409,90 +401,85 @@ class FireNetEngine:
             g_v = win.gv[i]
             win.gz_has[i] = False
             top = top_fused and i == n - 1
-            chained = i == chained_layer
-            if g_z is None and g_v is None and not top and not chained:
+            if g_z is None and g_v is None and not top:
                 continue  # no gradient reaches this layer at this pass
             use_rec = c.recurrent and z_prev is not None
-            if not chained:  # (a chained layer's neuron backward and weight gradients ran inside evf_bwd_chain of the layer above)
-                gv_out = win.buf(win.gv, i)
-                leak_g, thr_g = self._small(win, f"{i}.leak"), self._small(win, f"{i}.thresh")
-                if i > 0 and self.precision == "bf16x3":
-                    # neuron backward + both weight gradients in one pass (evf_bwd_fused.hip)
-                    kf, kr = (i, "ff"), (i, "rec")
-                    nsl = _lib.load().evf_lif_bwd_wgrad_slabs(B, H, W)
-                    acc_flag = 1 if win.slab_init.get(kf) else 0
-                    if use_rec and bool(win.slab_init.get(kr)) != bool(acc_flag):
-                        # first recurrent contribution arrives later than the ff one: start its slab at zero
-                        self._slab(kr, nsl, dev).zero_()
-                    if top:
-                        _lib.call("evf_lif_bwd_wgrad_top", _lib.ptr(tape["flow"]), _lib.ptr(g_flow_c), _lib.ptr(self._flat["pred.w"]),
-                                  _lib.ptr(layers[i][4]), _lib.ptr(self._small(win, "pred.w")), _lib.ptr(self._small(win, "pred.b")),
-                                  _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(in_bitsT),
-                                  _lib.ptr(self._flat[f"{i}.leak"]), _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W,
-                                  1 if c.hard_reset else 0, SURROGATE_ID[c.activation], self._act_width(i),
-                                  _lib.ptr(win.g_cur) if (plif or F32_DGRAD) else None, _lib.ptr(win.g_split), _lib.ptr(gv_out),
-                                  _lib.ptr(leak_g), _lib.ptr(thr_g), _lib.ptr(self._slab(kf, nsl, dev)), acc_flag)
-                    else:
-                        _lib.call("evf_lif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
-                              _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None, _lib.ptr(self._flat[f"{i}.leak"]),
-                              _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
-                              self._act_width(i), _lib.ptr(win.g_cur) if (plif or F32_DGRAD) else None, _lib.ptr(win.g_split),
-                              _lib.ptr(gv_out),
-                              _lib.ptr(leak_g), _lib.ptr(thr_g),
-                              _lib.ptr(self._slab(kf, nsl, dev)), _lib.ptr(self._slab(kr, nsl, dev)) if use_rec else None, acc_flag)
-                    win.slab_init[kf] = True
-                    if use_rec:
-                        win.slab_init[kr] = True
-                elif i == 0 and tape["x_in"].shape[1] == 2:
-                    # head: neuron backward + weight gradient in one pass (per-block slabs, summed in _finalize)
-                    nsl = _lib.load().evf_head_lif_bwd_wgrad_slabs(B, H, W)
-                    key = (0, "ff")
-                    if key not in self._slabs or self._slabs[key].shape != (nsl, C * 18) or self._slabs[key].device != dev:
-                        self._slabs[key] = _f32((nsl, C * 18), dev)
-                    _lib.call("evf_head_lif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev),
-                              _lib.ptr(z_prev), _lib.ptr(tape["x_in"]), _lib.ptr(self._flat["0.leak"]),
-                              _lib.ptr(self._flat["0.thresh"]), B, 2, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
-                              self._act_width(0), _lib.ptr(win.g_cur) if plif else None, _lib.ptr(gv_out), _lib.ptr(leak_g),
-                              _lib.ptr(thr_g), _lib.ptr(self._slabs[key]), 1 if win.slab_init.get(key) else 0)
-                    win.slab_init[key] = True
-                else:
-                    _lib.call("evf_lif_bwd", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
+            gv_out = win.buf(win.gv, i)
+            leak_g, thr_g = self._small(win, f"{i}.leak"), self._small(win, f"{i}.thresh")
+            if i > 0 and self.precision == "bf16x3":
+                # neuron backward + both weight gradients in one pass (evf_bwd_fused.hip)
+                kf, kr = (i, "ff"), (i, "rec")
+                nsl = _lib.load().evf_lif_bwd_wgrad_slabs(B, H, W)
+                acc_flag = 1 if win.slab_init.get(kf) else 0
+                if use_rec and bool(win.slab_init.get(kr)) != bool(acc_flag):
+                    # first recurrent contribution arrives later than the ff one: start its slab at zero
+                    self._slab(kr, nsl, dev).zero_()
+                if top:
+                    _lib.call("evf_lif_bwd_wgrad_top", _lib.ptr(tape["flow"]), _lib.ptr(g_flow_c), _lib.ptr(self._flat["pred.w"]),
+                              _lib.ptr(layers[i][4]), _lib.ptr(self._small(win, "pred.w")), _lib.ptr(self._small(win, "pred.b")),
+                              _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(in_bitsT),
                               _lib.ptr(self._flat[f"{i}.leak"]), _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W,
-                              1 if c.hard_reset else 0, SURROGATE_ID[c.activation], self._act_width(i), _lib.ptr(win.g_cur),
-                              _lib.ptr(gv_out), _lib.ptr(leak_g), _lib.ptr(thr_g))
-                    # weight gradients
-                    if i == 0:
-                        _lib.call("evf_head_wgrad", _lib.ptr(tape["x_in"]), _lib.ptr(win.g_cur), B, tape["x_in"].shape[1], H, W,
-                                  _lib.ptr(self._small(win, "0.ff")))
-                    else:
-                        k = (i, "ff")
-                        _lib.call("evf_conv_wgrad_bits", _lib.ptr(in_bits), _lib.ptr(win.g_cur), B, H, W,
-                                  _lib.ptr(self._slab(k, nslab, dev)), 1 if win.slab_init.get(k) else 0)
-                        win.slab_init[k] = True
-                    if use_rec:
-                        k = (i, "rec")
-                        _lib.call("evf_conv_wgrad_bits", _lib.ptr(z_prev), _lib.ptr(win.g_cur), B, H, W,
-                                  _lib.ptr(self._slab(k, nslab, dev)), 1 if win.slab_init.get(k) else 0)
-                        win.slab_init[k] = True
-                if plif:  # trace backward: carries dL/dpt, yields dL/d(pooled activity) for the input-spike gradient
-                    if win.gP is None:
-                        win.gP = _f32((B, H, W), dev)
-                        win.gP_raw = _f32((B, H, W), dev)
-                    gpt_out = win.buf(win.gpt, i)
-                    carry = gpt_out if win.gpt_has[i] else None
-                    _lib.call("evf_plif_trace_bwd", _lib.ptr(win.g_cur), _lib.ptr(carry), _lib.ptr(pt_prev), _lib.ptr(pt_out),
-                              _lib.ptr(P_sav), _lib.ptr(self._flat[f"{i}.leak_pt"]), _lib.ptr(self._flat[f"{i}.add_pt"]), B, H, W,
-                              _lib.ptr(gpt_out), _lib.ptr(win.gP_raw), _lib.ptr(win.gP), _lib.ptr(self._small(win, f"{i}.leak_pt")),
-                              _lib.ptr(self._small(win, f"{i}.add_pt")))
-                    win.gpt_has[i] = not is_first
-                if is_first:
-                    win.gv[i] = None  # the state entering the window is detached (train_flow.py:170)
+                              1 if c.hard_reset else 0, SURROGATE_ID[c.activation], self._act_width(i),
+                              _lib.ptr(win.g_cur) if (plif or F32_DGRAD) else None, _lib.ptr(win.g_split), _lib.ptr(gv_out),
+                              _lib.ptr(leak_g), _lib.ptr(thr_g), _lib.ptr(self._slab(kf, nsl, dev)), acc_flag)
+                else:
+                    _lib.call("evf_lif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
+                          _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None, _lib.ptr(self._flat[f"{i}.leak"]),
+                          _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
+                          self._act_width(i), _lib.ptr(win.g_cur) if (plif or F32_DGRAD) else None, _lib.ptr(win.g_split),
+                          _lib.ptr(gv_out),
+                          _lib.ptr(leak_g), _lib.ptr(thr_g),
+                          _lib.ptr(self._slab(kf, nsl, dev)), _lib.ptr(self._slab(kr, nsl, dev)) if use_rec else None, acc_flag)
+                win.slab_init[kf] = True
+                if use_rec:
+                    win.slab_init[kr] = True
+            elif i == 0 and tape["x_in"].shape[1] == 2:
+                # head: neuron backward + weight gradient in one pass (per-block slabs, summed in _finalize)
+                nsl = _lib.load().evf_head_lif_bwd_wgrad_slabs(B, H, W)
+                key = (0, "ff")
+                if key not in self._slabs or self._slabs[key].shape != (nsl, C * 18) or self._slabs[key].device != dev:
+                    self._slabs[key] = _f32((nsl, C * 18), dev)
+                _lib.call("evf_head_lif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev),
+                          _lib.ptr(z_prev), _lib.ptr(tape["x_in"]), _lib.ptr(self._flat["0.leak"]),
+                          _lib.ptr(self._flat["0.thresh"]), B, 2, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
+                          self._act_width(0), _lib.ptr(win.g_cur) if plif else None, _lib.ptr(gv_out), _lib.ptr(leak_g),
+                          _lib.ptr(thr_g), _lib.ptr(self._slabs[key]), 1 if win.slab_init.get(key) else 0)
+                win.slab_init[key] = True
+            else:
+                _lib.call("evf_lif_bwd", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
+                          _lib.ptr(self._flat[f"{i}.leak"]), _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W,
+                          1 if c.hard_reset else 0, SURROGATE_ID[c.activation], self._act_width(i), _lib.ptr(win.g_cur),
+                          _lib.ptr(gv_out), _lib.ptr(leak_g), _lib.ptr(thr_g))
+                # weight gradients
+                if i == 0:
+                    _lib.call("evf_head_wgrad", _lib.ptr(tape["x_in"]), _lib.ptr(win.g_cur), B, tape["x_in"].shape[1], H, W,
+                              _lib.ptr(self._small(win, "0.ff")))
+                else:
+                    k = (i, "ff")
+                    _lib.call("evf_conv_wgrad_bits", _lib.ptr(in_bits), _lib.ptr(win.g_cur), B, H, W,
+                              _lib.ptr(self._slab(k, nslab, dev)), 1 if win.slab_init.get(k) else 0)
+                    win.slab_init[k] = True
+                if use_rec:
+                    k = (i, "rec")
+                    _lib.call("evf_conv_wgrad_bits", _lib.ptr(z_prev), _lib.ptr(win.g_cur), B, H, W,
+                              _lib.ptr(self._slab(k, nslab, dev)), 1 if win.slab_init.get(k) else 0)
+                    win.slab_init[k] = True
+            if plif:  # trace backward: carries dL/dpt, yields dL/d(pooled activity) for the input-spike gradient
+                if win.gP is None:
+                    win.gP = _f32((B, H, W), dev)
+                    win.gP_raw = _f32((B, H, W), dev)
+                gpt_out = win.buf(win.gpt, i)
+                carry = gpt_out if win.gpt_has[i] else None
+                _lib.call("evf_plif_trace_bwd", _lib.ptr(win.g_cur), _lib.ptr(carry), _lib.ptr(pt_prev), _lib.ptr(pt_out),
+                          _lib.ptr(P_sav), _lib.ptr(self._flat[f"{i}.leak_pt"]), _lib.ptr(self._flat[f"{i}.add_pt"]), B, H, W,
+                          _lib.ptr(gpt_out), _lib.ptr(win.gP_raw), _lib.ptr(win.gP), _lib.ptr(self._small(win, f"{i}.leak_pt")),
+                          _lib.ptr(self._small(win, f"{i}.add_pt")))
+                win.gpt_has[i] = not is_first
+            if is_first:
+                win.gv[i] = None  # the state entering the window is detached (train_flow.py:170)
             # input gradients: to the layer below (this pass) and to the own previous spikes (previous pass)
             rec_grad = use_rec and not is_first
-            if i >= 2 and chain_ok:
-                self._chain(win, layers, i, is_first, rec_grad)
-                chained_layer = i - 1
-            elif i > 0:
+            if i > 0:
                 ga = win.buf(win.gz, i - 1)
                 acc_a = 1 if win.gz_has[i - 1] else 0
                 if self.precision == "bf16x3":
@@ -520,44 +507,6 @@ class FireNetEngine:
                     _lib.call("evf_conv_dgrad", _lib.ptr(win.g_cur), _lib.ptr(self._packed[(i, "ff", 1)]), _lib.ptr(ga), acc_a,
                               None, None, 0, B, H, W)
                 win.gz_has[i - 1] = True
-
-    def _chain(self, win, layers, i, is_first, rec_grad):
-        """evf_bwd_chain for layer pair (i, i-1): the input gradient of layer i (from win.g_cur) feeds the neuron
-        backward and the weight gradients of layer i-1 in the same kernel; dL/d(spikes of layer i-1) stays on chip.
-        Afterwards win.g_cur holds g_cur of layer i-1."""
-        B, H, W = win.shape
-        dev = win.dev
-        j = i - 1
-        cj = self.cells[j]
-        in_bits, v_prev, z_prev, v_out, _, in_bitsT, zT_prev = layers[j][:7]
-        gz_add = win.gz[j] if win.gz_has[j] else None  # recurrent part, left by the previous (later) pass
-        win.gz_has[j] = False
-        g_v = win.gv[j]
-        gv_out = win.buf(win.gv, j)
-        use_rec = cj.recurrent and z_prev is not None
-        kf, kr = (j, "ff"), (j, "rec")
-        nsl = _lib.load().evf_bwd_chain_slabs(B, H, W)
-        acc_flag = 1 if win.slab_init.get(kf) else 0
-        if use_rec and bool(win.slab_init.get(kr)) != bool(acc_flag):
-            self._slab(kr, nsl, dev).zero_()  # first recurrent contribution arrives later than the ff one
-        if win.g_cur_alt is None:
-            win.g_cur_alt = _f32((B, H, W, C), dev)
-        gb = win.buf(win.gz, i) if rec_grad else None
-        _lib.call("evf_bwd_chain", _lib.ptr(win.g_cur), _lib.ptr(self._packed[(i, "ff", "b3t")]),
-                  _lib.ptr(self._packed[(i, "rec", "b3t")]) if rec_grad else None, _lib.ptr(gb), _lib.ptr(gz_add), _lib.ptr(g_v),
-                  _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None,
-                  _lib.ptr(self._flat[f"{j}.leak"]), _lib.ptr(self._flat[f"{j}.thresh"]), B, H, W, 1 if cj.hard_reset else 0,
-                  SURROGATE_ID[cj.activation], self._act_width(j), _lib.ptr(win.g_cur_alt), _lib.ptr(gv_out),
-                  _lib.ptr(self._small(win, f"{j}.leak")), _lib.ptr(self._small(win, f"{j}.thresh")),
-                  _lib.ptr(self._slab(kf, nsl, dev)), _lib.ptr(self._slab(kr, nsl, dev)) if use_rec else None, acc_flag)
-        win.g_cur, win.g_cur_alt = win.g_cur_alt, win.g_cur
-        win.slab_init[kf] = True
-        if use_rec:
-            win.slab_init[kr] = True
-        if rec_grad:
-            win.gz_has[i] = True
-        if is_first:
-            win.gv[j] = None  # the state entering the window is detached (train_flow.py:170)
 
     def _finalize(self, win):
         """Window complete: reduce the weight-gradient slabs, hand all parameter

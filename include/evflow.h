@@ -232,21 +232,6 @@ int evf_lif_bwd_wgrad_top(const float* flow, const float* g_flow, const float* p
                           float* g_cur, void* g_split, float* g_v_prev, float* g_leak, float* g_thresh,
                           float* slab_ff, int accumulate, void* stream);
 
-/* One backward kernel per (layer pair, pass) of the fused 32->32 LIF stack: the input gradient of layer l
- * (evf_conv_dgrad_b3_f32[_pair] on g_cur_hi with wT_ff_hi [, wT_rec_hi -> g_x2_hi]) feeds the neuron backward and the
- * weight gradients of layer l-1 (evf_lif_bwd_wgrad) without dL/d(spikes of layer l-1) ever reaching HBM.  gz_add
- * (optional) is the recurrent part of that gradient, left by the previous pass.  The l-1 arguments are those of
- * evf_lif_bwd_wgrad; g_cur [B,H,W,32] fp32 is written (and must differ from g_cur_hi).  slab_* have
- * evf_bwd_chain_slabs(B,H,W) rows [9][32][32]; written, or += when accumulate.  LIF cells only. */
-int evf_bwd_chain_slabs(int B, int H, int W);
-int evf_bwd_chain(const float* g_cur_hi, const void* wT_ff_hi, const void* wT_rec_hi, float* g_x2_hi,
-                  const float* gz_add, const float* g_v_out, const float* v_out, const float* v_prev,
-                  const uint32_t* z_prev, const uint32_t* xT, const uint32_t* zT_prev,
-                  const float* leak, const float* thresh, int B, int H, int W,
-                  int hard_reset, int surrogate, float act_width,
-                  float* g_cur, float* g_v_prev, float* g_leak, float* g_thresh,
-                  float* slab_ff, float* slab_rec, int accumulate, void* stream);
-
 /* Input-gradient conv on the exact bf16 split: g_split = three bf16 planes
  * [3][B,H,W,32] (g = hi + mid + lo, optional output of evf_lif_bwd_wgrad; g_cur may then
  * be NULL), wT_b3 = evf_pack_conv_weight_b3t(w) (54 KiB).  g_x [B,H,W,32] fp32 is written,
@@ -262,6 +247,10 @@ int evf_conv_dgrad_b3(const void* g_split, const void* wT_b3, float* g_x, int ac
  * happens while the halo is staged, the result is bit-identical; 128 instead of 192 B/pixel on both sides. */
 int evf_conv_dgrad_b3_f32(const float* g_cur, const void* wT_b3, float* g_x, int accumulate,
                           int B, int H, int W, const float* g_P, const uint32_t* x_bits, void* stream);
+/* Which kernel serves evf_conv_dgrad_b3_f32[_pair] (results are bit-identical): -1 chosen by shape (default), 0 the
+ * one-phase-after-the-other LDS kernel, 1 the wave-specialised one (producer / consumer waves, double-buffered planes).
+ * Process-wide; for A/B measurements and the equivalence test. */
+int evf_conv_dgrad_select(int which);
 /* ... and for a recurrent cell both input gradients in one launch: g_x (+)= conv^T(g_cur, W_ff) as above,
  * g_x2 = conv^T(g_cur, W_rec) (written) -- dL/d(previous output spikes), models/spiking_submodules.py:530. */
 int evf_conv_dgrad_b3_f32_pair(const float* g_cur, const void* wT_b3, float* g_x, int accumulate,

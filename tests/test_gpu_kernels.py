@@ -51,7 +51,9 @@ SHAPES = [(8, 128, 128), (2, 37, 50)]
 
 @pytest.mark.parametrize("shape", SHAPES)
 def test_input_gradient_variants_are_bit_identical(shape):
-    """evf_conv_dgrad_b3 (pre-split planes) == evf_conv_dgrad_b3_f32 (split while staging); the _pair form == two calls."""
+    """evf_conv_dgrad_b3 (pre-split planes) == evf_conv_dgrad_b3_f32 (split while staging), through BOTH kernels behind the
+    latter (0: one-phase-after-the-other LDS kernel, 1: wave-specialised producer / consumer kernel); the _pair form == two
+    calls; the PLIF term (pooled-trace gradient on the input spikes) through both kernels."""
     B, H, W = shape
     torch.manual_seed(1)
     g = _f(B, H, W, C, scale=0.3)
@@ -69,16 +71,27 @@ def test_input_gradient_variants_are_bit_identical(shape):
     _lib.call("evf_lif_bwd_wgrad", P(g), None, P(_f(B, H, W, C)), None, None, P(xT), None, P(leak), P(thresh), B, H, W, 1, 0, 10.0,
               P(gcur), P(gsp), P(gvp), P(gl), P(gt), P(slab), None, 0)
     base = _f(B, H, W, C)
-    for acc in (0, 1):
-        a, b = base.clone(), base.clone()
-        _lib.call("evf_conv_dgrad_b3", P(gsp), P(wt1), P(a), acc, B, H, W, None, None)
-        _lib.call("evf_conv_dgrad_b3_f32", P(gcur), P(wt1), P(b), acc, B, H, W, None, None)
-        assert torch.equal(a, b), acc
-        c, d = base.clone(), torch.empty(B, H, W, C, device=DEV)
-        _lib.call("evf_conv_dgrad_b3_f32_pair", P(gcur), P(wt1), P(c), acc, P(wt2), P(d), B, H, W, None, None)
-        e = torch.empty(B, H, W, C, device=DEV)
-        _lib.call("evf_conv_dgrad_b3_f32", P(gcur), P(wt2), P(e), 0, B, H, W, None, None)
-        assert torch.equal(c, b) and torch.equal(d, e), acc
+    gP, xb = _f(B, H, W), _bits(B, H, W)
+    try:
+        for which in (0, 1):
+            assert _lib.load().evf_conv_dgrad_select(which) == 0
+            for acc in (0, 1):
+                a, b = base.clone(), base.clone()
+                _lib.call("evf_conv_dgrad_b3", P(gsp), P(wt1), P(a), acc, B, H, W, None, None)
+                _lib.call("evf_conv_dgrad_b3_f32", P(gcur), P(wt1), P(b), acc, B, H, W, None, None)
+                assert torch.equal(a, b), (which, acc)
+                c, d = base.clone(), torch.empty(B, H, W, C, device=DEV)
+                _lib.call("evf_conv_dgrad_b3_f32_pair", P(gcur), P(wt1), P(c), acc, P(wt2), P(d), B, H, W, None, None)
+                e = torch.empty(B, H, W, C, device=DEV)
+                _lib.call("evf_conv_dgrad_b3_f32", P(gcur), P(wt2), P(e), 0, B, H, W, None, None)
+                assert torch.equal(c, b) and torch.equal(d, e), (which, acc)
+                a, b = base.clone(), base.clone()
+                _lib.call("evf_conv_dgrad_b3", P(gsp), P(wt1), P(a), acc, B, H, W, P(gP), P(xb))
+                _lib.call("evf_conv_dgrad_b3_f32", P(gcur), P(wt1), P(b), acc, B, H, W, P(gP), P(xb))
+                assert torch.equal(a, b), (which, acc, "plif")
+    finally:
+        _lib.load().evf_conv_dgrad_select(-1)
+    assert _lib.load().evf_conv_dgrad_select(7) != 0  # bad argument: status, no change
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -133,43 +146,3 @@ def test_prediction_head_fused_into_its_neighbours(shape):
         assert _rel(res[1][k], res[0][k]) < 5e-6, k
 
 
-@pytest.mark.parametrize("shape,rec_lo,pair,hard", [((8, 128, 128), False, False, True), ((8, 128, 128), True, True, True),
-                                                     ((2, 37, 50), True, False, False), ((3, 16, 32), False, True, False)])
-def test_chained_backward_kernel_vs_separate_kernels(shape, rec_lo, pair, hard):
-    """evf_bwd_chain == evf_conv_dgrad_b3_f32[_pair] (layer l) + evf_lif_bwd_wgrad (layer l-1)."""
-    B, H, W = shape
-    torch.manual_seed(3)
-    zin, zprev = _bits(B, H, W), _bits(B, H, W)
-    xT, zT = _planes(zin), _planes(zprev)
-    _, wt1 = _packs()
-    _, wt2 = _packs()
-    g_hi = _f(B, H, W, C, scale=0.3)
-    gz_add = _f(B, H, W, C, scale=0.2) if rec_lo else None
-    gv, vo, vp = _f(B, H, W, C, scale=0.1), _f(B, H, W, C, scale=0.5) + 0.5, _f(B, H, W, C, scale=0.5)
-    leak, thresh = _f(32, scale=0.1) - 1, _f(32, scale=0.1) + 0.8
-    lib = _lib.load()
-    gz = gz_add.clone() if gz_add is not None else torch.empty(B, H, W, C, device=DEV)
-    gx2_ref = torch.empty(B, H, W, C, device=DEV)
-    if pair:
-        _lib.call("evf_conv_dgrad_b3_f32_pair", P(g_hi), P(wt1), P(gz), 1 if rec_lo else 0, P(wt2), P(gx2_ref), B, H, W, None, None)
-    else:
-        _lib.call("evf_conv_dgrad_b3_f32", P(g_hi), P(wt1), P(gz), 1 if rec_lo else 0, B, H, W, None, None)
-    nsl = lib.evf_lif_bwd_wgrad_slabs(B, H, W)
-    sf, sr = torch.zeros(nsl, 9216, device=DEV), torch.zeros(nsl, 9216, device=DEV)
-    gc_ref, gvp_ref = torch.empty(B, H, W, C, device=DEV), torch.empty(B, H, W, C, device=DEV)
-    gl_ref, gt_ref = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
-    _lib.call("evf_lif_bwd_wgrad", P(gz), P(gv), P(vo), P(vp), P(zprev), P(xT), P(zT) if rec_lo else None, P(leak), P(thresh), B, H, W,
-              1 if hard else 0, 0, 10.0, P(gc_ref), None, P(gvp_ref), P(gl_ref), P(gt_ref), P(sf), P(sr) if rec_lo else None, 0)
-    nsc = lib.evf_bwd_chain_slabs(B, H, W)
-    cf, cr = torch.full((nsc, 9216), float("nan"), device=DEV), torch.full((nsc, 9216), float("nan"), device=DEV)
-    gc, gvp, gx2 = (torch.empty(B, H, W, C, device=DEV) for _ in range(3))
-    gl, gt = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
-    _lib.call("evf_bwd_chain", P(g_hi), P(wt1), P(wt2) if pair else None, P(gx2) if pair else None, P(gz_add), P(gv), P(vo), P(vp),
-              P(zprev), P(xT), P(zT) if rec_lo else None, P(leak), P(thresh), B, H, W, 1 if hard else 0, 0, 10.0, P(gc), P(gvp), P(gl),
-              P(gt), P(cf), P(cr) if rec_lo else None, 0)
-    assert torch.equal(gc, gc_ref) and torch.equal(gvp, gvp_ref)
-    if pair:
-        assert torch.equal(gx2, gx2_ref)
-    assert _rel(cf.sum(0), sf.sum(0)) < 5e-6 and _rel(gl, gl_ref) < 1e-5 and _rel(gt, gt_ref) < 1e-5
-    if rec_lo:
-        assert _rel(cr.sum(0), sr.sum(0)) < 5e-6

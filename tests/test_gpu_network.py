@@ -118,24 +118,6 @@ def _train_once(g, use_flat_adam, fix="g7_liffirenet_train"):
     return float(loss.detach()), grads, gn, newp
 
 
-def test_chained_backward_kernel_equals_separate_kernels(monkeypatch):
-    """evf_bwd_chain (input gradient of layer l + neuron backward and weight gradients of layer l-1 in one kernel;
-    EVF_CHAIN=1) must reproduce the separate-kernel backward: same state gradients bit for bit, weight gradients up to
-    the summation order of the pixel blocks."""
-    from event_flow_amd.models import engine as eng
-
-    g = load_golden("g7_liffirenet_train")
-    monkeypatch.setattr(eng, "CHAIN", False)
-    loss0, grads0, gn0, _ = _train_once(g, True)
-    monkeypatch.setattr(eng, "CHAIN", True)
-    loss1, grads1, gn1, _ = _train_once(g, True)
-    assert loss1 == loss0
-    np.testing.assert_allclose(gn1, gn0, rtol=1e-5)
-    for k in grads0:
-        denom = max(np.abs(grads0[k]).max(), 1e-12)
-        assert np.abs(grads1[k] - grads0[k]).max() <= 2e-5 * denom, k
-
-
 @pytest.mark.parametrize("fix", list(FIXTURES))
 @pytest.mark.parametrize("flat", [True, False])
 def test_train_step_vs_golden(fix, flat):
