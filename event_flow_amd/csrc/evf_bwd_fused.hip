@@ -57,6 +57,29 @@ __device__ __forceinline__ float fb_surrogate(int kind, float x, float width) {
   }
 }
 
+#ifdef FB_SPAN  // start / end of EVERY block in the chip-wide 100 MHz counter (debug build through EVF_LIB)
+__device__ unsigned long long fb_span[2 * 1024];
+extern "C" int evf_debug_fb_span(void* dst) { return evf_hip(hipMemcpyFromSymbol(dst, HIP_SYMBOL(fb_span), sizeof(fb_span))); }
+#define FB_SPAN_MARK(w)                                                                                      \
+  do {                                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) fb_span[2 * blockIdx.x + (w)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define FB_SPAN_MARK(w) do {} while (0)
+#endif
+
+#ifdef FB_STAMPS  // phase stamps (debug build loaded through EVF_LIB): [block < 16][wave 0 / wave 7][96] shader-clock values
+__device__ unsigned long long fb_stamps[16 * 2 * 96];
+extern "C" int evf_debug_fb_stamps(void* dst) { return evf_hip(hipMemcpyFromSymbol(dst, HIP_SYMBOL(fb_stamps), sizeof(fb_stamps))); }
+#define FB_STAMP()                                                                                   \
+  do {                                                                                               \
+    if (blockIdx.x < 16 && lane == 0 && (wv == 0 || wv == 7) && nst < 96)                            \
+      fb_stamps[(blockIdx.x * 2 + (wv ? 1 : 0)) * 96 + nst++] = __builtin_readcyclecounter();       \
+  } while (0)
+#else
+#define FB_STAMP() do {} while (0)
+#endif
+
 struct FbStage {
   float4 gz, gv, vo, vp;
   float f0, f1, q0, q1;  // TOP: flow and dL/dflow of the pixel (x, y components)
@@ -97,6 +120,10 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
   const int cg = tid & 7;  // channel group of the elementwise part: channels 4cg..4cg+3
   const int p = tid >> 3;  // pixel of the elementwise part within the 64-pixel unit
   const int nW = (W + 31) / 32;
+  int nst = 0;
+  (void)nst;
+  FB_STAMP();
+  FB_SPAN_MARK(0);
 
   if (tid < 256) {
     const uint32_t t = tid;
@@ -307,16 +334,23 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
   FbStage s_cur, s_nxt, s_new;
   issue_loads(0, s_cur);
   issue_loads(1, s_nxt);
+  FB_STAMP();
   commit(0, s_cur, 0);
+  FB_STAMP();
   __syncthreads();
 #pragma unroll 1
   for (int k = 0; k < nu; ++k) {
+    FB_STAMP();
     issue_loads(k + 2, s_new);
+    FB_STAMP();
     mfma_unit(k);
+    FB_STAMP();
     commit(k + 1, s_nxt, (k + 1) & 1);
+    FB_STAMP();
     __syncthreads();
     s_nxt = s_new;
   }
+  FB_STAMP();
 
   float prev8[2], prev8z[2] = {0.f, 0.f};
   // ---- weight-gradient slabs: taps 0..7 straight from the owning wave
@@ -394,6 +428,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
       evf_atomic_add(g_thresh + c, v);
     }
   }
+  FB_STAMP();
   if (TOP) {  // prediction-head weight / bias gradients, reduced the same way
     __syncthreads();
 #pragma unroll
@@ -429,6 +464,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
       evf_atomic_add(top.db + (tid - 64), v);
     }
   }
+  FB_SPAN_MARK(1);
 }
 
 static long fb_units(int B, int H, int W) { return (long)B * H * ((W + FB_CW - 1) / FB_CW); }

@@ -19,6 +19,20 @@ static inline int evf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // atomicAdd would lower to a CAS loop without -munsafe-fp-atomics.
 __device__ __forceinline__ void evf_atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
 
+// Non-temporal 16-byte store (global_store_dwordx4 ... nt) for tensors that are streamed out once: the lines do not stay
+// dirty in the XCD's L2, so the kernel does not end in a multi-microsecond L2 write-back.  Measured on MI355X (tools/probes/
+// stream_probe.hip, 4 tensors in / 2 out of 16.8 MB each): 16.3 us with nt stores against 22.6 us with plain ones (sc1 and
+// sc0 sc1 write-through: 21.7); a dependent pair of such kernels 33 against 37 us.  Non-temporal LOADS gained nothing.
+// NOT for partial-line writers: the MFMA epilogues of the forward / input-gradient kernels put 32 bytes of a pixel's 128-byte
+// line per instruction, and as nt stores those reach memory uncombined (dgrad 22.9 -> 27.2 us, forward 16.5 -> 20.9 us in
+// the step); the fused backward (full lines) neither gained nor lost.  Kept for kernels that end in a large full-line output.
+typedef float evf_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void evf_store_nt(float4* p, const float4 v) {
+  const evf_v4f t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, (evf_v4f*)p);
+}
+__device__ __forceinline__ void evf_store_nt(float* p, const float4 v) { evf_store_nt((float4*)p, v); }
+
 // wave64 sum, result valid in every lane
 __device__ __forceinline__ float evf_wave_sum(float v) {
 #pragma unroll
@@ -45,3 +59,4 @@ __device__ __forceinline__ float evf_block_sum(float v, float* smem /* >= 16 flo
 // evf_dgrad_ws.hip: wave-specialised input-gradient kernel behind evf_conv_dgrad_b3_f32[_pair]
 int evf_dgrad_ws_launch(const float* g_cur, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W, const float* g_P,
                         const uint32_t* x_bits, const void* wT2_b3, float* g_x2, int max_blocks, void* stream);
+

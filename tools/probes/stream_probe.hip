@@ -18,6 +18,38 @@ __global__ __launch_bounds__(256) void k_simple(const float4* a, const float4* b
   o2[i] = make_float4(z.x * w.x, z.y * w.y, z.z * w.z, z.w * w.w);
 }
 
+// A2: the same with write-through (sc1) or non-temporal stores -- does the end-of-kernel L2 write-back shrink?
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f tov(float4 v) { v4f r = {v.x, v.y, v.z, v.w}; return r; }
+__device__ __forceinline__ void st_sc1(float4* p, float4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(tov(v)) : "memory"); }
+__device__ __forceinline__ void st_sc01(float4* p, float4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(tov(v)) : "memory"); }
+__device__ __forceinline__ void st_nt(float4* p, float4 v) { asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(tov(v)) : "memory"); }
+template <int MODE>
+__global__ __launch_bounds__(256) void k_simple_st(const float4* a, const float4* b, const float4* c, const float4* d, float4* o1,
+                                                   float4* o2, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 x = a[i], y = b[i], z = c[i], w = d[i];
+  const float4 r1 = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w), r2 = make_float4(z.x * w.x, z.y * w.y, z.z * w.z, z.w * w.w);
+  if (MODE == 1) st_sc1(o1 + i, r1), st_sc1(o2 + i, r2);
+  if (MODE == 2) st_nt(o1 + i, r1), st_nt(o2 + i, r2);
+  if (MODE == 3) st_sc01(o1 + i, r1), st_sc01(o2 + i, r2);
+}
+// A3: compiler builtins: non-temporal stores (MODE 0), + non-temporal loads (MODE 1)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_simple_nt(const v4f* a, const v4f* b, const v4f* c, const v4f* d, v4f* o1, v4f* o2, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  v4f x, y, z, w;
+  if (MODE == 1) {
+    x = __builtin_nontemporal_load(a + i), y = __builtin_nontemporal_load(b + i), z = __builtin_nontemporal_load(c + i), w = __builtin_nontemporal_load(d + i);
+  } else {
+    x = a[i], y = b[i], z = c[i], w = d[i];
+  }
+  __builtin_nontemporal_store(x + y, o1 + i);
+  __builtin_nontemporal_store(z * w, o2 + i);
+}
+
 // B: persistent blocks of 512 threads, units of 512 float4 dealt round-robin, DEPTH units of loads in flight (registers)
 template <int DEPTH>
 __global__ __launch_bounds__(512) void k_pipe(const float4* a, const float4* b, const float4* c, const float4* d, float4* o1,
@@ -112,7 +144,21 @@ int main() {
     printf("%-34s mean %7.2f us  best %7.2f us   %6.2f TB/s (mean)\n", name, sum / reps * 1e3, best * 1e3, bytes / (sum / reps * 1e-3) / 1e12);
   };
   timeit("simple 256thr x n/256 blocks", [&] { hipLaunchKernelGGL(k_simple, dim3((n + 255) / 256), dim3(256), 0, 0, t[0], t[1], t[2], t[3], t[4], t[5], n); });
-  for (int blocks : {256, 512, 1024}) {
+  timeit("simple, sc1 stores", [&] { hipLaunchKernelGGL(k_simple_st<1>, dim3((n + 255) / 256), dim3(256), 0, 0, t[0], t[1], t[2], t[3], t[4], t[5], n); });
+  timeit("simple, nt stores", [&] { hipLaunchKernelGGL(k_simple_st<2>, dim3((n + 255) / 256), dim3(256), 0, 0, t[0], t[1], t[2], t[3], t[4], t[5], n); });
+  timeit("simple, sc0 sc1 stores", [&] { hipLaunchKernelGGL(k_simple_st<3>, dim3((n + 255) / 256), dim3(256), 0, 0, t[0], t[1], t[2], t[3], t[4], t[5], n); });
+  timeit("simple, builtin nt stores", [&] { hipLaunchKernelGGL(k_simple_nt<0>, dim3((n + 255) / 256), dim3(256), 0, 0, (v4f*)t[0], (v4f*)t[1], (v4f*)t[2], (v4f*)t[3], (v4f*)t[4], (v4f*)t[5], n); });
+  timeit("simple, builtin nt loads+stores", [&] { hipLaunchKernelGGL(k_simple_nt<1>, dim3((n + 255) / 256), dim3(256), 0, 0, (v4f*)t[0], (v4f*)t[1], (v4f*)t[2], (v4f*)t[3], (v4f*)t[4], (v4f*)t[5], n); });
+  timeit("2 x nt loads+stores (b2b)", [&] { hipLaunchKernelGGL(k_simple_nt<1>, dim3((n + 255) / 256), dim3(256), 0, 0, (v4f*)t[0], (v4f*)t[1], (v4f*)t[2], (v4f*)t[3], (v4f*)t[4], (v4f*)t[5], n);
+                                            hipLaunchKernelGGL(k_simple_nt<1>, dim3((n + 255) / 256), dim3(256), 0, 0, (v4f*)t[4], (v4f*)t[5], (v4f*)t[2], (v4f*)t[3], (v4f*)t[0], (v4f*)t[1], n); });
+  // pairs of dependent launches (the second reads what the first wrote): time per pair
+  timeit("2 x simple plain (b2b)", [&] { hipLaunchKernelGGL(k_simple, dim3((n + 255) / 256), dim3(256), 0, 0, t[0], t[1], t[2], t[3], t[4], t[5], n);
+                                         hipLaunchKernelGGL(k_simple, dim3((n + 255) / 256), dim3(256), 0, 0, t[4], t[5], t[2], t[3], t[0], t[1], n); });
+  timeit("2 x simple sc1 (b2b)", [&] { hipLaunchKernelGGL(k_simple_st<1>, dim3((n + 255) / 256), dim3(256), 0, 0, t[0], t[1], t[2], t[3], t[4], t[5], n);
+                                       hipLaunchKernelGGL(k_simple_st<1>, dim3((n + 255) / 256), dim3(256), 0, 0, t[4], t[5], t[2], t[3], t[0], t[1], n); });
+  timeit("2 x simple nt (b2b)", [&] { hipLaunchKernelGGL(k_simple_st<2>, dim3((n + 255) / 256), dim3(256), 0, 0, t[0], t[1], t[2], t[3], t[4], t[5], n);
+                                      hipLaunchKernelGGL(k_simple_st<2>, dim3((n + 255) / 256), dim3(256), 0, 0, t[4], t[5], t[2], t[3], t[0], t[1], n); });
+  for (int blocks : {256}) {
     char nm[64];
     snprintf(nm, 64, "pipe depth1 %d blocks", blocks);
     timeit(nm, [&] { hipLaunchKernelGGL(k_pipe<1>, dim3(blocks), dim3(512), 0, 0, t[0], t[1], t[2], t[3], t[4], t[5], nunits); });
@@ -126,7 +172,7 @@ int main() {
   hipFuncSetAttribute((const void*)k_dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipFuncSetAttribute((const void*)k_dma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipFuncSetAttribute((const void*)k_dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  for (int blocks : {256, 512}) {
+  for (int blocks : {256}) {
     char nm[64];
     snprintf(nm, 64, "dma ring depth2 %d blocks", blocks);
     timeit(nm, [&] { hipLaunchKernelGGL(k_dma<2>, dim3(blocks), dim3(512), 2 * 32768, 0, t[0], t[1], t[2], t[3], t[4], t[5], nunits); });
