@@ -44,7 +44,9 @@ B_PER_GPU = 8
 PASSES = 10
 EV_PER_PASS = 1500
 FP32_MFMA_PEAK = 157.3  # TFLOP/s dense, MI355X_MICROARCH.md
+BF16_MFMA_PEAK = 2500.0  # TFLOP/s dense (v_mfma_f32_32x32x16_bf16), MI355X_MICROARCH.md
 HBM_PEAK = 8000.0  # GB/s spec
+ATOMIC_RATE = 21.4e9  # random device-scope fp32 atomics per second, measured (tools/probes/atomic_probe.hip; u32: 27.4e9)
 
 MODEL_CFG = {
     "name": "LIFFireNet", "encoding": "cnt", "round_encoding": False, "norm_input": False, "num_bins": 2,
@@ -56,6 +58,48 @@ LOSS_CFG = {"loader": {"resolution": [H, W]}, "loss": {"flow_regul_weight": 0.00
 
 CONV_FLOP = 2 * 9 * 32 * 32  # per pixel per 32->32 3x3 conv
 
+PLIF_NEURON = {"leak_v": [-4.0, 0.1], "leak_pt": [-4.0, 0.1], "add_pt": [-2.0, 0.1], "thresh": [0.8, 0.1], "learn_leak": True,
+               "learn_thresh": True, "hard_reset": True}
+WORKLOADS = {
+    # BASELINE.json configs[2] (headline; per-GPU shard = configs[1] + backward): the default
+    "c3": {"model": "LIFFireNet", "H": 128, "W": 128, "B": 8, "neuron": None,
+           "text": "LIF-FireNet full train step (BPTT over 10 passes x 1500 events = 15k events/window, 128x128, CM loss, clip+Adam), "
+                   "8 windows per GPU [BASELINE configs[2] per-GPU shard; superset of configs[1]]"},
+    # BASELINE.json configs[4]: PLIF-FireNet on MVSEC-shaped windows, batch 32 over 8 GPUs = 4 per GPU
+    "c5": {"model": "PLIFFireNet", "H": 260, "W": 346, "B": 4, "neuron": PLIF_NEURON,
+           "text": "PLIF-FireNet full train step (BPTT over 10 passes x 1500 events, 260x346, CM loss, clip+Adam), 4 windows per GPU "
+                   "[BASELINE configs[4] per-GPU shard]"},
+}
+
+
+CONFIG_ID = 3
+
+
+def set_workload(name):
+    """Point the module-level workload constants at one of WORKLOADS (c3 is the import-time default)."""
+    global H, W, B_PER_GPU, MODEL_CFG, LOSS_CFG, CONFIG_ID
+    wl = WORKLOADS[name]
+    CONFIG_ID = int(name[1:])
+    H, W, B_PER_GPU = wl["H"], wl["W"], wl["B"]
+    MODEL_CFG = dict(MODEL_CFG, name=wl["model"])
+    if wl["neuron"] is not None:
+        MODEL_CFG["spiking_neuron"] = dict(wl["neuron"])
+    LOSS_CFG = {"loader": {"resolution": [H, W]}, "loss": dict(LOSS_CFG["loss"]), "model": {"mask_output": True}}
+    return wl
+
+
+def source_hash():
+    """sha1 over the kernel sources: PMC numbers measured on other sources are stale and are not reported."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "event_flow_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
 
 def make_windows(rank, n_pool, dev):
     """n_pool windows, each PASSES event lists [B,1500,4] (platform-stable synthetic events)."""
@@ -65,7 +109,7 @@ def make_windows(rank, n_pool, dev):
     for wdx in range(n_pool):
         lists = []
         for k in range(PASSES):
-            seed0 = synthetic.seed_for(3, rank, 0) + 100000 * wdx + 1000 * k
+            seed0 = synthetic.seed_for(CONFIG_ID, rank, 0) + 100000 * wdx + 1000 * k
             ev = synthetic.event_list_batch(B_PER_GPU, EV_PER_PASS, H, W, seed0)
             lists.append(torch.from_numpy(ev).to(dev))
         pool.append(lists)
@@ -138,11 +182,20 @@ def capture_step_graphs(model, lossf, opt, dp, pool, stream):
     return graphs
 
 
+def launch_floor_us():
+    """Duration of a launch that does nothing worth mentioning (a 64-element add), from the two-point calibration every
+    profile_start / profile_stop pair runs (T1 = o + t, T2 = o + 2t): the floor any single-kernel operator sits on."""
+    from event_flow_amd import _lib
+
+    return _lib.last_tiny_kernel_ms * 1e3, _lib.last_event_overhead_ms * 1e3
+
+
 def iwe_warp_bandwidth(dev, B, reps=20):
     from event_flow_amd import synthetic
     from event_flow_amd.utils.iwe import compute_pol_iwe
 
     n = 15000
+    H = W = 128  # the north-star shape of the IWE figure, whatever the benched workload
     g = np.random.default_rng(1)
     ev_small = synthetic.event_list_batch(min(B, 8), n, H, W, 4242)
     ev = np.concatenate([ev_small] * (B // ev_small.shape[0]), 0) if B > ev_small.shape[0] else ev_small
@@ -166,7 +219,8 @@ def iwe_warp_bandwidth(dev, B, reps=20):
             "frac_of_hbm_peak": alg_bytes / ms / 1e6 / HBM_PEAK}
 
 
-_KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3_lds<false>", "evf_conv_dgrad_b3_f32": "k_conv_dgrad_b3_lds<true>", "evf_conv_dgrad_b3_f32_pair": "k_conv_dgrad_b3_lds<true>",
+_KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3_lds<false, false, false>", "evf_conv_dgrad_b3_f32": "k_conv_dgrad_b3_lds<true, false, false>",
+              "evf_conv_dgrad_b3_f32_pair": "k_conv_dgrad_b3_lds<true, true, false>",
               "evf_conv_lif_fwd_b3_pred/ff": "k_conv_lif_fwd_b3<false, false>",
               "evf_lif_bwd_wgrad/ff": "k_lif_bwd_wgrad<false, false>", "evf_lif_bwd_wgrad_top": "k_lif_bwd_wgrad<false, true>",
               "evf_lif_bwd_wgrad/rec": "k_lif_bwd_wgrad<true, false>", "evf_conv_lif_fwd_b3/ff": "k_conv_lif_fwd_b3<false, false>",
@@ -176,22 +230,27 @@ _KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3_lds<false>", "evf_conv_dgrad
               "evf_conv_lif_fwd/rec": "k_conv_lif_fwd<true>", "evf_conv_wgrad_bits": "k_conv_wgrad_bits"}
 
 
-def _pmc_traffic(entry):
-    """HBM bytes per launch of the kernel behind `entry`, from the committed PMC passes (rocprofv3 cannot run
-    inside this process): profiles/r*_bench_pmc_traffic.json, FETCH_SIZE (x2 corrected) + WRITE_SIZE."""
+def _pmc(entry):
+    """PMC figures of the kernel behind `entry` from the newest committed passes (rocprofv3 cannot run inside this
+    process): profiles/r*_bench_pmc_traffic.json -- HBM bytes per launch (FETCH_SIZE x2-corrected + WRITE_SIZE) and MFMA busy
+    (SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD).  The file carries the hash of the kernel sources it was
+    measured on; on any other sources the numbers are stale and NOT reported (-> (None, reason))."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_bench_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_traffic.json")))
     if not files or entry not in _KERNEL_OF:
-        return None
-    t = json.load(open(files[-1]))["per_launch"].get(_KERNEL_OF[entry])
+        return None, "no PMC pass for this kernel"
+    d = json.load(open(files[-1]))
+    if d.get("src_hash") != source_hash():
+        return None, f"stale: {os.path.basename(files[-1])} was measured on sources {d.get('src_hash')}, these are {source_hash()}"
+    t = d["per_launch"].get(_KERNEL_OF[entry])
     if not t or t["fetch_MB"] != t["fetch_MB"]:
-        return None
+        return None, "kernel not in the PMC pass"
     return {"MB_per_launch": round(t["fetch_MB"] + t["write_MB"], 2), "fetch_MB": t["fetch_MB"], "write_MB": t["write_MB"],
-            "source": os.path.basename(files[-1])}
+            "mfma_busy_pct": t.get("mfma_busy_pct"), "source": os.path.basename(files[-1]), "src_hash": d["src_hash"]}, None
 
 
-def cpu_baseline(threads, max_seconds=60.0):
+def cpu_baseline(threads, max_seconds=60.0, name="LIFFireNet"):
     """Oracle (PyTorch-CPU port of the reference path) on a bounded sample:
     ONE window (B=1) of the same workload, full train step."""
     from event_flow_amd import synthetic
@@ -200,7 +259,9 @@ def cpu_baseline(threads, max_seconds=60.0):
     from oracle import train as otrain
 
     gen = torch.Generator().manual_seed(0)
-    params = osnn.make_firenet_params("LIFFireNet", gen, neuron={"leak": (-4.0, 0.1), "thresh": (0.8, 0.1)})
+    neuron = ({"leak": (-4.0, 0.1), "thresh": (0.8, 0.1)} if name == "LIFFireNet" else
+              {"leak_v": (-4.0, 0.1), "leak_pt": (-4.0, 0.1), "add_pt": (-2.0, 0.1), "thresh": (0.8, 0.1)})
+    params = osnn.make_firenet_params(name, gen, neuron=neuron)
     keys = osnn.trainable_keys(params)
     Bc = B_PER_GPU  # the same per-GPU batch of windows the GPU step processes
     passes = []
@@ -211,7 +272,7 @@ def cpu_baseline(threads, max_seconds=60.0):
     lcfg = {"flow_regul_weight": 0.001, "mask_output": True}
 
     def one_step(ps, st, opt, pr):
-        _, _, pr, st = otrain.train_step("LIFFireNet", pr, keys, ps, st, (H, W), opt, loss_cfg=lcfg)
+        _, _, pr, st = otrain.train_step(name, pr, keys, ps, st, (H, W), opt, loss_cfg=lcfg)
         return pr, st
 
     # PyTorch-CPU convs of this size do not scale to hundreds of threads: probe a 2-pass
@@ -247,7 +308,7 @@ def cpu_baseline(threads, max_seconds=60.0):
 
         with torch.no_grad():  # configuration 2: forward + loss of the 10-pass window, no backward
             t1 = time.perf_counter()
-            otrain.forward_window("LIFFireNet", params, passes, [None] * 7, (H, W), loss_cfg=lcfg)
+            otrain.forward_window(name, params, passes, [None] * 7, (H, W), loss_cfg=lcfg)
             extra["fwd_loss_windows_per_s"] = Bc / (time.perf_counter() - t1)
         torch.set_num_threads(1)  # per-core figure: one pass of the full step on one thread, scaled to the window
         t1 = time.perf_counter()
@@ -287,6 +348,84 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def main_c4(args):
+    """BASELINE configs[3]: LIF-EV-FlowNet (SpikingRecEVFlowNet, base 32, 20.4 M parameters), 256x256, one window of 50 000
+    events per sample, batch 8, 4 flow scales, full train step on the general fp32-MFMA path (eager launches).  Same JSON
+    shape as the headline line; the roofline object is the conv entry point with the largest total time, against the dense
+    fp32-MFMA peak (v_mfma_f32_32x32x2_f32)."""
+    from event_flow_amd import _lib, synthetic
+    from event_flow_amd.loss.flow import EventWarping
+    from event_flow_amd.models.model import SpikingRecEVFlowNet
+    from event_flow_amd.train import FlatAdam, encode_passes, train_window
+
+    if args.gpus != 1:
+        raise SystemExit("--config c4 is a single-GPU line (BASELINE configs[3]: 1 x MI355X)")
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    Hc = Wc = 256
+    Bc, nev = 8, 50000
+    torch.manual_seed(0)
+    cfg = dict(MODEL_CFG, name="SpikingRecEVFlowNet")
+    model = SpikingRecEVFlowNet(dict(cfg)).to(dev)
+    model.train()
+    lossf = EventWarping({"loader": {"resolution": [Hc, Wc]}, "loss": dict(LOSS_CFG["loss"]), "model": {"mask_output": True}}, dev)
+    opt = FlatAdam(model, lr=2e-4, clip=100.0)
+    opt.zero_grad()
+    pool = [encode_passes([torch.from_numpy(synthetic.event_list_batch(Bc, nev, Hc, Wc, synthetic.seed_for(4, 0, 0) + 100000 * w)).to(dev)],
+                          2, (Hc, Wc)) for w in range(2)]
+    for i in range(max(args.warmup, 2)):
+        loss = train_window(model, lossf, opt, pool[i % 2])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = train_window(model, lossf, opt, pool[i % 2])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    names = ["evf_conv2d_fwd", "evf_conv2d_dgrad", "evf_conv2d_wgrad", "evf_neuron_fwd", "evf_neuron_bwd", "evf_upsample2x_fwd",
+             "evf_upsample2x_bwd", "evf_upsample_nearest_fwd", "evf_upsample_nearest_bwd", "evf_cm_loss_fwd", "evf_cm_loss_bwd",
+             "evf_clip_adam_step", "evf_pack_conv2d_weight", "evf_encode_events"]
+    prof_steps = 2
+    _lib.profile_start(names)
+    for i in range(prof_steps):
+        train_window(model, lossf, opt, pool[i % 2])
+    prof = _lib.profile_stop()
+    kernels = {}
+    for (name, var), ms in prof.items():
+        ent = kernels.setdefault(name, {"launches": 0, "total_ms_per_step": 0.0, "flop_per_step": 0.0, "bytes_per_step": 0.0})
+        ent["launches"] += len(ms) // prof_steps
+        ent["total_ms_per_step"] += float(np.sum(ms)) / prof_steps
+        if name.startswith("evf_conv2d_") and var:
+            b, h, w, cin, cout, k, st = (int(v) for v in var.split(","))
+            ho, wo = (h + 2 * (k // 2) - k) // st + 1, (w + 2 * (k // 2) - k) // st + 1
+            ent["flop_per_step"] += 2.0 * k * k * cin * cout * b * ho * wo * len(ms) / prof_steps
+            ent["bytes_per_step"] += 4.0 * b * (h * w * cin + ho * wo * cout) * len(ms) / prof_steps
+    for ent in kernels.values():
+        if ent["flop_per_step"]:
+            ent["TFLOPs"] = ent["flop_per_step"] / (ent["total_ms_per_step"] * 1e-3) / 1e12
+            ent["frac_of_fp32_mfma_peak"] = ent["TFLOPs"] / FP32_MFMA_PEAK
+            ent["algorithmic_GBps"] = ent["bytes_per_step"] / (ent["total_ms_per_step"] * 1e-3) / 1e9
+        ent.pop("bytes_per_step")
+    dom_name = max((n for n in kernels if "TFLOPs" in kernels[n]), key=lambda n: kernels[n]["total_ms_per_step"])
+    dom = kernels[dom_name]
+    out = {
+        "metric": "event-windows/sec (train step, 256x256x50k ev, LIF-EV-FlowNet)", "value": Bc * args.steps / elapsed,
+        "unit": "event-windows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "LIF-EV-FlowNet (SpikingRecEVFlowNet, base 32) full train step, 256x256, 50k events/window, batch 8, "
+                               "4 flow scales, CM loss, clip+Adam [BASELINE configs[3]]", "baseline_config": "c4", "global_batch": Bc,
+                   "events_per_window": nev, "parallelism": "dp1", "launch": "eager", "loss": float(loss),
+                   "conv_precision": "fp32 MFMA (v_mfma_f32_32x32x2_f32), NHWC fp32 activations"},
+        "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": dom["TFLOPs"], "peak": FP32_MFMA_PEAK, "unit": "TFLOP/s",
+                     "frac": dom["TFLOPs"] / FP32_MFMA_PEAK, "traffic": None,
+                     "note": "all launches of the entry point in a step together: sum of 2*k*k*Cin*Cout*B*Ho*Wo over the launches / "
+                             "their summed HIP-event time"},
+        "kernels": kernels,
+        "kernel_timing": {"method": "HIP events around each launch over eager steps, bracket overhead removed",
+                          "bracket_overhead_us": round(_lib.last_event_overhead_ms * 1e3, 2)},
+    }
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -298,6 +437,9 @@ def main():
                     help="matrix-core path of the 32->32 convs: exact bf16x3 split (default) or fp32 MFMA")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--config", choices=["c3", "c4", "c5"], default="c3",
+                    help="BASELINE.json workload: c3 = headline LIF-FireNet train step (default), c5 = PLIF-FireNet 260x346 (4 per GPU), "
+                         "c4 = LIF-EV-FlowNet 256x256 x 50k events (general fp32-MFMA path)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -305,11 +447,14 @@ def main():
 
     from event_flow_amd import _lib
     from event_flow_amd.loss.flow import EventWarping
-    from event_flow_amd.models.model import LIFFireNet
+    from event_flow_amd.models import model as models
     from event_flow_amd.parallel import DataParallel
     from event_flow_amd.train import FlatAdam
 
     _lib.load()  # fails loudly when the HIP library is missing
+    if args.config == "c4":
+        return main_c4(args)
+    wl = set_workload(args.config)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("EVF_BENCH_SINGLE_DEVICE"):  # test hook: several ranks share one GPU (with EVF_DP_BACKEND=gloo)
         local_rank = 0
@@ -323,7 +468,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={dp.world}: launch with torch.distributed.run")
 
     torch.manual_seed(0)  # identical replicas on every rank
-    model = LIFFireNet(dict(MODEL_CFG)).to(dev)
+    model = getattr(models, wl["model"])(dict(MODEL_CFG)).to(dev)
     model.precision = args.precision
     model.train()
     lossf = EventWarping(LOSS_CFG, dev)
@@ -336,7 +481,7 @@ def main():
     names = ["evf_conv_lif_fwd", "evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_conv_dgrad", "evf_conv_dgrad_b3",
              "evf_conv_dgrad_b3_f32", "evf_conv_dgrad_b3_f32_pair", "evf_conv_wgrad_bits", "evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad_top",
              "evf_lif_bwd", "evf_head_lif_bwd_wgrad", "evf_head_lif_fwd", "evf_head_wgrad", "evf_pred_bwd", "evf_reduce_slabs", "evf_reduce_slabs_multi", "evf_cm_loss_fwd",
-             "evf_cm_loss_bwd"]
+             "evf_cm_loss_bwd", "evf_conv_plif_fwd_b3", "evf_head_plif_fwd", "evf_plif_trace_bwd", "evf_encode_events", "evf_clip_adam_step"]
 
     # Everything runs on one side stream: warm-up (eager), then one whole training step
     # per input window is captured into a hipGraph on that same stream (autograd's
@@ -421,7 +566,17 @@ def main():
         hbm_bound = {"evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_conv_dgrad_b3", "evf_conv_dgrad_b3_f32",
                      "evf_conv_dgrad_b3_f32_pair", "evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad_top", "evf_lif_bwd", "evf_head_lif_fwd",
                      "evf_head_lif_bwd_wgrad"}
+        # matrix-core accounting: the bf16x3 kernels issue 3 (forward, weight gradient: binary operand x 3-way split) or 6
+        # (input gradient: two real operands) bf16 MFMA products per algorithmic fp32 product
+        bf16_terms = {"evf_conv_lif_fwd_b3": 3, "evf_conv_lif_fwd_b3_pred": 3, "evf_conv_plif_fwd_b3": 3, "evf_lif_bwd_wgrad": 3,
+                      "evf_lif_bwd_wgrad_top": 3, "evf_conv_dgrad_b3": 6, "evf_conv_dgrad_b3_f32": 6, "evf_conv_dgrad_b3_f32_pair": 6}
+        model[("evf_conv_plif_fwd_b3", "")] = (CONV_FLOP * npix, 408 * npix)  # + trace in / out
+        model[("evf_head_plif_fwd", "")] = (2 * 18 * 32 * npix, 408 * npix)
+        # g_cur, g_pt carry, pt_prev, pt_out in; g_pt_prev out (fp32 [npix][32]); P, g_P_raw, g_P_in [npix]
+        model[("evf_plif_trace_bwd", "")] = (0, 652 * npix)
+        hbm_bound |= {"evf_conv_plif_fwd_b3", "evf_head_plif_fwd", "evf_plif_trace_bwd"}
         kernels = {}
+        step_alg_bytes = 0.0
         for key, ms in prof.items():
             ms = np.array(ms)
             name = "/".join(k for k in key if k)
@@ -431,34 +586,43 @@ def main():
                 ent["algorithmic_MB"] = by / 1e6
                 ent["GBps"] = by / (ms.mean() * 1e-3) / 1e9
                 ent["frac_of_hbm_peak"] = ent["GBps"] / HBM_PEAK
+                step_alg_bytes += by * ms.size / prof_steps
                 if fl:
-                    ent["TFLOPs"] = fl / (ms.mean() * 1e-3) / 1e12
-                    ent["frac_of_fp32_mfma_peak"] = ent["TFLOPs"] / FP32_MFMA_PEAK
+                    ent["fp32_equiv_TFLOPs"] = fl / (ms.mean() * 1e-3) / 1e12
+                    if key[0] in bf16_terms:
+                        ent["issued_bf16_TFLOPs"] = bf16_terms[key[0]] * ent["fp32_equiv_TFLOPs"]
+                        ent["frac_of_bf16_peak"] = ent["issued_bf16_TFLOPs"] / BF16_MFMA_PEAK
+                    else:
+                        ent["frac_of_fp32_mfma_peak"] = ent["fp32_equiv_TFLOPs"] / FP32_MFMA_PEAK
                 ent["bound"] = "hbm" if key[0] in hbm_bound else "mfma"
+                pm, why = _pmc(name)
+                ent["mfma_busy_pct"] = pm["mfma_busy_pct"] if pm else None  # SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE (PMC pass)
+                if not pm:
+                    ent["pmc"] = why
             kernels[name] = ent
         dom_key = max((k for k in prof if k in model), key=lambda k: sum(prof[k]))
         dom = kernels["/".join(k for k in dom_key if k)]
-        detail = _pmc_traffic("/".join(k for k in dom_key if k))
+        detail, why_not = _pmc("/".join(k for k in dom_key if k))
         traffic = int(detail["MB_per_launch"] * 1e6) if detail else None  # HBM bytes per launch (PMC), next to ...
         algo = int(dom["algorithmic_MB"] * 1e6) if "algorithmic_MB" in dom else None  # ... the algorithmic bytes per launch
         if dom["bound"] == "hbm":
             roof = {"kernel": "/".join(k for k in dom_key if k), "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK,
                     "unit": "GB/s", "frac": dom["frac_of_hbm_peak"], "traffic": traffic, "traffic_unit": "bytes/launch",
-                    "algorithmic_bytes": algo, "traffic_detail": detail,
+                    "algorithmic_bytes": algo, "traffic_detail": detail if detail else {"unavailable": why_not},
+                    "mfma_busy_pct": detail["mfma_busy_pct"] if detail else None,
+                    "issued_bf16_TFLOPs": dom.get("issued_bf16_TFLOPs"), "frac_of_bf16_peak": dom.get("frac_of_bf16_peak"),
                     "note": "bf16x3 kernel (exact 3-way bf16 split, fp32 accumulate): matrix work is 1/5 of the fp32-MFMA form, "
-                            "so the kernel sits on the HBM roofline; algorithmic bytes per launch in kernels[*].algorithmic_MB"}
+                            "so the kernel sits on the memory side; algorithmic bytes per launch in kernels[*].algorithmic_MB"}
         else:
-            roof = {"kernel": "/".join(k for k in dom_key if k), "bound": "mfma", "achieved": dom["TFLOPs"], "peak": FP32_MFMA_PEAK,
-                    "unit": "TFLOP/s", "frac": dom["TFLOPs"] / FP32_MFMA_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
-                    "traffic_detail": detail}
+            roof = {"kernel": "/".join(k for k in dom_key if k), "bound": "mfma", "achieved": dom["fp32_equiv_TFLOPs"], "peak": FP32_MFMA_PEAK,
+                    "unit": "TFLOP/s", "frac": dom["fp32_equiv_TFLOPs"] / FP32_MFMA_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "traffic_detail": detail if detail else {"unavailable": why_not}}
         out = {
             "metric": "event-windows/sec (train step, 128x128x15k ev)", "value": B_PER_GPU * dp.world * args.steps / elapsed,
             "unit": "event-windows/s", "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "LIF-FireNet full train step (BPTT over 10 passes x 1500 events = 15k events/window, "
-                                   "128x128, CM loss, clip+Adam), 8 windows per GPU [BASELINE configs[2] per-GPU shard; "
-                                   "superset of configs[1]]",
+            "config": {"workload": wl["text"], "baseline_config": args.config,
                        "global_batch": B_PER_GPU * dp.world, "events_per_window": PASSES * EV_PER_PASS,
                        "parallelism": f"dp{dp.world}", "launch": mode, "loss": loss_val,
                        "collective": ({"backend": dp.backend, "library": "RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -468,6 +632,8 @@ def main():
                        "conv_precision": ("fp32 results via exact 3-way bf16 splits of the fp32 operands on the bf16 matrix cores, "
                                           "fp32 accumulation" if model_precision == "bf16x3" else "fp32 MFMA (v_mfma_f32_32x32x2_f32)")},
             "roofline": roof,
+            # all modelled kernels of a step together: algorithmic bytes / step time against the HBM peak
+            "step_hbm_frac": step_alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK,
             "kernels": kernels,
             "kernel_timing": {"method": "HIP events around each launch on its stream over eager steps, minus the bracket overhead "
                                         "o = 2 T(1 tiny kernel) - T(2 tiny kernels) calibrated in the same run", "bracket_overhead_us": round(event_overhead_us, 2)},
@@ -475,14 +641,24 @@ def main():
         # the two side measurements must never cost the headline line: report their failure instead
         if not args.no_iwe:
             try:
-                out["iwe_warp"] = {"spec_shape": iwe_warp_bandwidth(dev, 8), "saturating": iwe_warp_bandwidth(dev, 512, reps=5),
-                                   "saturating_2048": iwe_warp_bandwidth(dev, 2048, reps=3)}
+                spec = iwe_warp_bandwidth(dev, 8)
+                floor, bracket = launch_floor_us()
+                # what bounds the call at the spec shape: one device-scope atomic per event (the image is far too small to
+                # saturate anything else) at the measured random-atomic rate, on top of the floor of a launch
+                spec["launch_floor_us"] = floor
+                spec["atomic_floor_us"] = 8 * 15000 / ATOMIC_RATE * 1e6
+                spec["note"] = ("latency / atomic-rate bound at this size: 4.4 MB is 0.55 us of HBM time; the call is a zero-fill + one "
+                                "scatter kernel whose 120 k device-scope atomics alone need atomic_floor_us at the measured "
+                                "21.4 G atomics/s (scope does not matter: tools/probes/atomic_probe.hip)")
+                out["iwe_warp"] = {"spec_shape": spec, "saturating": iwe_warp_bandwidth(dev, 512, reps=5),
+                                   "saturating_2048": iwe_warp_bandwidth(dev, 2048, reps=3),
+                                   "empty_launch_us": {"tiny_kernel": floor, "event_bracket_overhead": bracket}}
             except Exception as e:  # noqa: BLE001
                 out["iwe_warp"] = {"error": f"{type(e).__name__}: {e}"}
         if dp.world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or (os.cpu_count() or 1)
             try:
-                out["cpu_baseline"] = cpu_baseline(threads)
+                out["cpu_baseline"] = cpu_baseline(threads, name=wl["model"])
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)

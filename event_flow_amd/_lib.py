@@ -158,11 +158,16 @@ _PROF_VARIANT = {
     "evf_conv_lif_fwd_b3_pred": lambda a: "rec" if a[2] is not None else "ff",
     "evf_conv_dgrad": lambda a: "two" if a[4] is not None else "one",
     "evf_lif_bwd_wgrad": lambda a: "rec" if a[6] is not None else "ff",
+    # general convs: the shape is the variant ("B,H,W,Cin,Cout,k,stride"): bench.py derives the FLOP of every launch from it
+    "evf_conv2d_fwd": lambda a: ",".join(str(int(v)) for v in a[6:13]),
+    "evf_conv2d_dgrad": lambda a: ",".join(str(int(v)) for v in a[5:12]),
+    "evf_conv2d_wgrad": lambda a: ",".join(str(int(v)) for v in a[6:13]),
 }
 
 
 _prof_cal = None
 last_event_overhead_ms = 0.0
+last_tiny_kernel_ms = 0.0  # duration of one trivial launch (64-element add) from the same two-point fit: the launch floor
 
 
 def profile_start(names):
@@ -186,7 +191,7 @@ def profile_start(names):
 
 def profile_stop():
     """-> {(name, variant): [ms, ...]} (empty-bracket overhead removed); synchronises."""
-    global _prof, _prof_cal, last_event_overhead_ms
+    global _prof, _prof_cal, last_event_overhead_ms, last_tiny_kernel_ms
     rec, _prof = _prof, None
     cal, _prof_cal = _prof_cal, None
     torch.cuda.synchronize()
@@ -196,6 +201,7 @@ def profile_stop():
         t1 = med([e0.elapsed_time(e1) for k, e0, e1 in cal[8:] if k == 1])  # first brackets: warm-up
         t2 = med([e0.elapsed_time(e1) for k, e0, e1 in cal[8:] if k == 2])
         ovh = max(2.0 * t1 - t2, 0.0)
+        last_tiny_kernel_ms = max(t2 - t1, 0.0)
     last_event_overhead_ms = ovh
     out = {}
     for name, lst in (rec or {}).items():
