@@ -13,6 +13,9 @@ static inline int evf_status() {
 }
 static inline int evf_hip(hipError_t e) { return e == hipSuccess ? EVF_OK : -(1000 + (int)e); }
 
+// kernel sizes of the general convolution path: odd, padding k/2 (the reference's layers; models/unet.py:51 defaults to 5)
+#define EVF_KSZ_OK(k) ((k) == 1 || (k) == 3 || (k) == 5 || (k) == 7)
+
 static inline int evf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // hardware fp32 atomic add (global_atomic_add_f32 / ds_add_f32); plain

@@ -1,5 +1,5 @@
 // General 2-D convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
-// k in {1,3}, stride in {1,2}, padding k/2, any channel counts, NHWC fp32 with
+// k in {1,3,5,7}, stride in {1,2}, padding k/2, any channel counts, NHWC fp32 with
 // explicit pixel strides.  Used by every layer that is not one of the fused
 // 32->32 binary-spike kernels: the spiking EV-FlowNet encoders / residual
 // blocks / decoders (reference models/unet.py:418-465), the ANN FireNet
@@ -87,13 +87,13 @@ static long cg_packed_float4(int Cout, int Cin, int ksz, int transpose) {
 }
 
 extern "C" int64_t evf_conv2d_packed_size(int Cout, int Cin, int ksz, int transpose) {
-  if (Cout <= 0 || Cin <= 0 || (ksz != 1 && ksz != 3)) return 0;
+  if (Cout <= 0 || Cin <= 0 || !EVF_KSZ_OK(ksz)) return 0;
   return cg_packed_float4(Cout, Cin, ksz, transpose) * 4;
 }
 
 extern "C" int evf_pack_conv2d_weight(const float* w, int Cout, int Cin, int ksz, int transpose, int cin_total, int cin_off,
                                       float* dst, void* stream) {
-  if (!w || !dst || Cout <= 0 || Cin <= 0 || (ksz != 1 && ksz != 3) || cin_off < 0 || cin_off >= cin_total) return EVF_EINVAL;
+  if (!w || !dst || Cout <= 0 || Cin <= 0 || !EVF_KSZ_OK(ksz) || cin_off < 0 || cin_off >= cin_total) return EVF_EINVAL;
   const long total = cg_packed_float4(Cout, Cin, ksz, transpose);
   hipLaunchKernelGGL(k_pack_conv2d, dim3(evf_cdiv(total, 256)), dim3(256), 0, EVF_STREAM(stream), w, Cout, Cin, ksz * ksz,
                      transpose, total, cin_total, cin_off, (float4*)dst);
@@ -388,7 +388,7 @@ static inline int cg_out_dim(int n, int ksz, int stride) { return (n + 2 * (ksz 
 
 extern "C" int evf_conv2d_fwd(const float* x, int ldx, const float* w_packed, const float* bias, float* y, int ldy, int B,
                               int H, int W, int Cin, int Cout, int ksz, int stride, int accumulate, void* stream) {
-  if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksz != 1 && ksz != 3) ||
+  if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !EVF_KSZ_OK(ksz) ||
       (stride != 1 && stride != 2) || ldx < Cin || ldy < Cout)
     return EVF_EINVAL;
   ConvGeo g;
@@ -401,7 +401,7 @@ extern "C" int evf_conv2d_fwd(const float* x, int ldx, const float* w_packed, co
 // g_x [B,H,W,Cin] (+)= conv^T(g_y [B,Ho,Wo,Cout]); wT_packed from evf_pack_conv2d_weight(transpose = 1)
 extern "C" int evf_conv2d_dgrad(const float* g_y, int ldg, const float* wT_packed, float* g_x, int ldx, int B, int H, int W,
                                 int Cin, int Cout, int ksz, int stride, int accumulate, void* stream) {
-  if (!g_y || !wT_packed || !g_x || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksz != 1 && ksz != 3) ||
+  if (!g_y || !wT_packed || !g_x || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !EVF_KSZ_OK(ksz) ||
       (stride != 1 && stride != 2) || ldx < Cin || ldg < Cout)
     return EVF_EINVAL;
   ConvGeo g;

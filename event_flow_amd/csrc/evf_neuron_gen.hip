@@ -450,7 +450,7 @@ __global__ void k_boxpool(const float* __restrict__ m, int B, int H, int W, int 
 
 extern "C" int evf_pretrace_fwd(const float* x, int ldx, int B, int H, int W, int C, int ksz, int stride, float* absmean_ws,
                                 float* P, void* stream) {
-  if (!x || !absmean_ws || !P || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (ksz != 1 && ksz != 3) || stride < 1)
+  if (!x || !absmean_ws || !P || B <= 0 || H <= 0 || W <= 0 || C <= 0 || !EVF_KSZ_OK(ksz) || stride < 1)
     return EVF_EINVAL;
   const long npix = (long)B * H * W;
   const int tpp = C >= 64 ? 64 : (C >= 32 ? 32 : (C >= 16 ? 16 : (C >= 8 ? 8 : (C >= 4 ? 4 : (C >= 2 ? 2 : 1)))));
@@ -490,7 +490,7 @@ __global__ void k_pretrace_bwd(const float* __restrict__ x, int ldx, const float
 
 extern "C" int evf_pretrace_bwd(const float* x, int ldx, const float* g_P, int B, int H, int W, int C, int ksz, int stride,
                                 float* g_x, int ldg, int accumulate, void* stream) {
-  if (!x || !g_P || !g_x || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (ksz != 1 && ksz != 3) || stride < 1) return EVF_EINVAL;
+  if (!x || !g_P || !g_x || B <= 0 || H <= 0 || W <= 0 || C <= 0 || !EVF_KSZ_OK(ksz) || stride < 1) return EVF_EINVAL;
   const int OH = (H + 2 * (ksz >> 1) - ksz) / stride + 1, OW = (W + 2 * (ksz >> 1) - ksz) / stride + 1;
   const long total = (long)B * H * W * C;
   hipLaunchKernelGGL(k_pretrace_bwd, dim3(evf_cdiv(total, 256)), dim3(256), 0, EVF_STREAM(stream), x, ldx, g_P, B, H, W, C,

@@ -13,7 +13,7 @@
 // Partial sums of the pixel splits go to slabs [split][tap][ci][co] (coalesced
 // stores, no atomics) and are summed by k_wgrad_reduce into the torch layout.
 //
-// 1x1 (k_conv2d_wgrad_f32): one tap, 4 waves split the pixel pairs.
+// 1x1, 5x5, 7x7 (k_conv2d_wgrad_f32): one tap per block (blockIdx.z), 4 waves split the pixel pairs, split-K + atomics.
 #include "evf_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -638,7 +638,7 @@ static void wg9_launch(const float* x, const float* gy, float* slab, float* gbia
 extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int ldg, float* g_w, float* g_bias, int B, int H,
                                 int W, int Cin, int Cout, int ksz, int stride, int cin_total, int cin_off, int accumulate,
                                 float* ws, void* stream) {
-  if (!x || !g_y || !g_w || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksz != 1 && ksz != 3) ||
+  if (!x || !g_y || !g_w || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !EVF_KSZ_OK(ksz) ||
       (stride != 1 && stride != 2) || ldx < Cin || ldg < Cout || cin_off < 0 || cin_off >= cin_total ||
       (!accumulate && (cin_off != 0 || Cin < cin_total)) || (ksz == 3 && !ws) || ((uintptr_t)g_y & 15))
     return EVF_EINVAL;
@@ -694,7 +694,7 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
     return evf_status();
   }
   if (!accumulate) {
-    const int rc = evf_hip(hipMemsetAsync(g_w, 0, sizeof(float) * (size_t)Cout * cin_total, st));
+    const int rc = evf_hip(hipMemsetAsync(g_w, 0, sizeof(float) * (size_t)Cout * cin_total * ksz * ksz, st));
     if (rc) return rc;
   }
   WgGeo g;

@@ -354,7 +354,7 @@ int evf_masked_flow_mean(const float* maps, const float* masks, int B, int P, in
  * (models/submodules.py:64-83,377-418), the 1x1 prediction heads
  * (submodules.py:12-61) and stand-alone Conv{LIF,PLIF,ALIF,XLIF}[Recurrent]
  * cells (spiking_submodules.py:24-875).  Activations are NHWC fp32 with an
- * explicit pixel stride (ld, in floats); k in {1,3}, stride in {1,2}, padding
+ * explicit pixel stride (ld, in floats); k in {1,3,5,7} (models/unet.py:51 defaults to 5), stride in {1,2}, padding
  * k/2 (F.conv2d as used at spiking_submodules.py:99,519).  fp32 matrix-core
  * arithmetic (v_mfma_f32_32x32x2_f32): results equal an fp32 CPU convolution
  * up to summation order. */

@@ -58,6 +58,12 @@ CONV_CASES = [
     (1, 256, 96, 5, 6, 3, 1),
     (3, 5, 7, 11, 13, 3, 2),
     (1, 8, 8, 13, 9, 3, 2),
+    # 5x5 / 7x7 (models/unet.py:51: kernel_size defaults to 5)
+    (2, 6, 8, 12, 10, 5, 1),
+    (1, 32, 64, 20, 24, 5, 2),
+    (2, 66, 40, 9, 11, 5, 1),
+    (1, 4, 8, 15, 13, 7, 1),
+    (1, 16, 16, 14, 14, 7, 2),
 ]
 
 
@@ -89,7 +95,7 @@ def test_conv2d_forward_dgrad_wgrad_vs_cpu(case):
 
 def test_conv_bad_arguments_fail_loudly():
     x = torch.zeros(1, 4, 8, 8, device=DEV)
-    w = torch.zeros(4, 4, 5, 5, device=DEV)  # 5x5 kernels are not built
+    w = torch.zeros(4, 4, 4, 4, device=DEV)  # even kernel sizes do not exist in the reference (padding k/2) and are not built
     with pytest.raises(_lib.EvflowError):
         hip_ops.conv_act(object(), x, w, None)
     with pytest.raises(_lib.EvflowError):
@@ -138,10 +144,12 @@ def _thresh_of(c, g, tag, new_ref):
     return t0 + t1 * new_ref[2]
 
 
-def test_g6_cells_forward_backward_on_gpu():
-    g = load_golden("g6_cells")
+@pytest.mark.parametrize("fix,n", [("g6_cells", 28), ("g15_cells_k5", 8)])
+def test_g6_cells_forward_backward_on_gpu(fix, n):
+    """G6: 3x3 cells; G15: the 5x5 (models/unet.py:51 default) and 7x7 kernels of the general conv path, stride 1 / 2."""
+    g = load_golden(fix)
     cases = golden_cases(g)
-    assert len(cases) == 28
+    assert len(cases) == n
     for c in cases:
         tag = c["tag"]
         x_np, st_np = g[tag + "_x"], g[tag + "_state"]
@@ -149,7 +157,9 @@ def test_g6_cells_forward_backward_on_gpu():
         kw = dict(activation=c["act"], hard_reset=c["hard_reset"], act_width=float(g[tag + "_param_act_width"]))
         if c["kind"] in ("alif", "xlif"):
             kw["learn_thresh"] = True
-        cell = CELL_CLS[(c["kind"], c["recurrent"])](Cin, C, 3, **kw).to(DEV)
+        if not c["recurrent"] and c.get("stride", 1) != 1:
+            kw["stride"] = c["stride"]
+        cell = CELL_CLS[(c["kind"], c["recurrent"])](Cin, C, c.get("ksz", 3), **kw).to(DEV)
         sd = {k[len(tag + "_param_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "_param_")}
         cell.load_state_dict(sd)
         x = G(x_np).requires_grad_(True)
@@ -588,3 +598,47 @@ def cells_model(cfg, norm):
     c = dict(cfg)
     c["norm_input"] = norm
     return LIFFireNet(c).to(DEV)
+
+
+@pytest.mark.parametrize("which", ["LIFFireNet", "SpikingRecEVFlowNet"])
+def test_kernel_size_5_models_vs_oracle(which):
+    """kernel_size = 5 (the default of the reference's UNets, models/unet.py:51; FireNets take it from the config,
+    models/model.py:162-173): forward flows, states and every parameter gradient against the CPU oracle."""
+    from event_flow_amd.models.model import LIFFireNet
+
+    torch.manual_seed(21)
+    C = 32 if which == "LIFFireNet" else 8
+    cfg = dict(_unet_cfg(C), kernel_size=5)
+    cfg["spiking_neuron"] = dict(cfg["spiking_neuron"], thresh=[0.25, 0.05])
+    model = (LIFFireNet if which == "LIFFireNet" else SpikingRecEVFlowNet)(cfg).to(DEV)
+    ks = [p.shape[-1] for k, p in model.named_parameters() if k.endswith("weight")]
+    assert ks.count(5) >= 7 and set(ks) <= {1, 3, 5}  # (the residual blocks of the UNet are 3x3 whatever the config says)
+    params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    keys = [k for k, _ in model.named_parameters()]
+    for k in keys:
+        params[k].requires_grad_(True)
+    xs = [(torch.rand(2, 2, 32, 32) < 0.3).float() * torch.randint(1, 4, (2, 2, 32, 32)).float() for _ in range(2)]
+    states = [None] * (7 if which == "LIFFireNet" else 10)
+    tot = tot_ref = 0
+    for x in xs:
+        if which == "LIFFireNet":
+            f_ref, states = osnn.firenet_forward("LIFFireNet", params, x, states)
+            flows_ref = [f_ref]
+        else:
+            flows_ref, states = osnn.spiking_unet_forward("lif", params, x, states)
+        out = model(x.to(DEV), x.to(DEV))
+        for f, fr in zip(out["flow"], flows_ref):
+            close(N(f), fr.detach().numpy(), 1e-4, "flow")
+            tot = tot + (f * f).sum()
+            tot_ref = tot_ref + (fr * fr).sum()
+    assert float(tot_ref) > 0
+    tot.backward()
+    tot_ref.backward()
+    gn = float(np.sqrt(sum(float((params[k].grad.numpy() ** 2).sum()) for k in keys if params[k].grad is not None)))
+    err = 0.0
+    for k, p in model.named_parameters():
+        ref = params[k].grad
+        ref = ref.numpy() if ref is not None else np.zeros(tuple(p.shape), np.float32)
+        got = N(p.grad) if p.grad is not None else np.zeros_like(ref)
+        err += float(((got - ref) ** 2).sum())
+    assert np.sqrt(err) <= 2e-3 * gn, np.sqrt(err) / gn

@@ -142,10 +142,12 @@ def test_g5_aee():
 
 
 # --------------------------------------------------------------------- G6
-def test_g6_cells_forward_backward():
-    g = load_golden("g6_cells")
+@pytest.mark.parametrize("fix,n", [("g6_cells", 28), ("g15_cells_k5", 8)])
+def test_g6_cells_forward_backward(fix, n):
+    """G6: 3x3 cells, all kinds / resets / surrogates; G15: 5x5 and 7x7 kernels (models/unet.py:51 defaults to 5), stride 1 / 2."""
+    g = load_golden(fix)
     cases = golden_cases(g)
-    assert len(cases) == 28
+    assert len(cases) == n
     for c in cases:
         tag = c["tag"]
         pre = "c."
@@ -158,7 +160,8 @@ def test_g6_cells_forward_backward():
             p[k].requires_grad_(True)
         x = T(g[tag + "_x"]).requires_grad_(True)
         st = T(g[tag + "_state"]).requires_grad_(True)
-        out, new = osnn.cell_step(c["kind"], p, pre, x, tuple(st.unbind(0)), recurrent=c["recurrent"], act=c["act"], hard_reset=c["hard_reset"])
+        out, new = osnn.cell_step(c["kind"], p, pre, x, tuple(st.unbind(0)), recurrent=c["recurrent"], act=c["act"], hard_reset=c["hard_reset"],
+                                  stride=c.get("stride", 1))
         new = torch.stack(new)
         assert np.array_equal(out.detach().numpy(), g[tag + "_out"]), c  # spikes: exact
         np.testing.assert_allclose(new.detach().numpy(), g[tag + "_new"], rtol=1e-6, atol=1e-7, err_msg=str(c))

@@ -309,6 +309,46 @@ def g6_cells():
     save("g6_cells", **a)
 
 
+def g15_cells_k5():
+    """Single steps of the reference's cells with the 5x5 kernels models/unet.py:51 defaults to (and a 7x7 one): feed-forward
+    stride 1 and 2, recurrent, PLIF (its trace pools with the same kernel size, spiking_submodules.py:212)."""
+    B, Cin, C, H, W = 2, 4, 8, 13, 11
+    a, cases = {}, []
+    todo = [("lif", False, 5, 1), ("lif", False, 5, 2), ("lif", True, 5, 1), ("plif", False, 5, 1), ("plif", True, 5, 1),
+            ("alif", False, 5, 2), ("xlif", True, 5, 1), ("lif", False, 7, 1)]
+    for ci, (kind, recurrent, k, stride) in enumerate(todo):
+        FF, REC = CELLS[kind]
+        torch.manual_seed(150 + ci)
+        kw = dict(activation="arctanspike", hard_reset=True)
+        if kind in ("lif", "plif"):
+            kw["thresh"] = (0.3, 0.1)
+        else:
+            kw.update(t0=(0.2, 0.05), t1=(0.5, 0.1), learn_thresh=True)
+        cin = C if recurrent else Cin
+        cell = REC(cin, C, k, **kw) if recurrent else FF(cin, C, k, stride=stride, **kw)
+        x = (torch.rand(B, cin, H, W) < 0.3).float() * torch.randint(1, 3, (B, cin, H, W)).float()
+        x.requires_grad_(True)
+        Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+        nstate = 2 if kind == "lif" else 3
+        st = torch.rand(nstate, B, C, Ho, Wo)
+        st[1] = (st[1] < 0.3).float()
+        st.requires_grad_(True)
+        out, new = cell(x, st)
+        g_out, g_new = torch.randn_like(out), torch.randn_like(new) * 0.5
+        params = dict(cell.named_parameters())
+        grads = torch.autograd.grad([out, new], [x, st] + list(params.values()), [g_out, g_new], allow_unused=True)
+        tag = f"k{ci}"
+        cases.append(dict(tag=tag, kind=kind, recurrent=recurrent, hard_reset=True, act="arctanspike", ksz=k, stride=stride))
+        a.update({tag + "_x": x, tag + "_state": st, tag + "_out": out, tag + "_new": new, tag + "_g_out": g_out, tag + "_g_new": g_new,
+                  tag + "_gx": grads[0], tag + "_gstate": grads[1]})
+        for (pn, _), gr in zip(params.items(), grads[2:]):
+            a[f"{tag}_grad_{pn}"] = gr if gr is not None else torch.zeros_like(params[pn])
+        for pn, v in cell.state_dict().items():
+            a[f"{tag}_param_{pn}"] = v
+    a["cases_json"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    save("g15_cells_k5", **a)
+
+
 def model_cfg(name, C=32, neuron=None, num_bins=2, encoding="cnt", acts=("arctanspike", "arctanspike")):
     return {
         "name": name, "encoding": encoding, "round_encoding": False, "norm_input": False, "num_bins": num_bins,
@@ -626,3 +666,4 @@ if __name__ == "__main__":
             "note": "outputs of the reference run in the build container; reference pins torch==1.7.0"}
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1)
+    g15_cells_k5()
