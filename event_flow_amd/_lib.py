@@ -95,6 +95,8 @@ NETWORK_SIGNATURES = {
     "evf_upsample_nearest_fwd": [P, L, I, I, I, P, P],
     "evf_upsample_nearest_bwd": [P, L, I, I, I, P, P],
     "evf_apply_pixel_mask": [P, P, I, I, I, I, P],
+    "evf_chan_reduce": [P, I, P, I, P, P, I, I, L, I, P, P],
+    "evf_chan_affine": [P, I, P, I, P, P, P, I, L, I, P, I, P],
     "evf_act_fwd": [I, P, P, L, P, P],
     "evf_act_bwd": [I, P, P, L, P, P],
     "evf_leaky_fwd": [P, P, P, P, I, L, I, P, P, P],

@@ -391,6 +391,161 @@ def conv_act(owner, x, weight, bias, stride=1, activation=None, residual=None):
 
 
 # ---------------------------------------------------------------------------
+# stand-alone activation (+ residual), batch / instance norm, transposed conv: the ANN layers with norm = "BN" / "IN" and
+# the transposed-conv decoders (reference models/submodules.py:46-56, 86-137, 169-180, 273-301)
+# ---------------------------------------------------------------------------
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, act):
+        xn = to_nhwc(x)
+        rn = to_nhwc(residual) if residual is not None else None
+        y = _new(tuple(xn.shape), xn.device)
+        _lib.call("evf_act_fwd", act, _lib.ptr(xn), _lib.ptr(rn), xn.numel(), _lib.ptr(y))
+        ctx.act, ctx.has_res = act, residual is not None
+        ctx.saved = y
+        return from_nhwc(y)
+
+    @staticmethod
+    def backward(ctx, g_y):
+        g = to_nhwc(g_y)
+        if ctx.act != 0:
+            gp = _new(tuple(g.shape), g.device)
+            _lib.call("evf_act_bwd", ctx.act, _lib.ptr(ctx.saved), _lib.ptr(g), g.numel(), _lib.ptr(gp))
+            g = gp
+        gx = from_nhwc(g)
+        return gx, (gx if ctx.has_res else None), None
+
+
+def activation(x, act, residual=None):
+    """act(x [+ residual]) with act in tanh / sigmoid / relu / None."""
+    if act not in ACT_ID:
+        raise NotImplementedError(f"activation {act!r} has no HIP kernel (tanh/sigmoid/relu/None)")
+    if act is None and residual is None:
+        return x
+    return _Act.apply(x, residual if torch.is_tensor(residual) else None, ACT_ID[act])
+
+
+class _Norm2d(torch.autograd.Function):
+    """nn.BatchNorm2d / nn.InstanceNorm2d(track_running_stats=True) forward + backward.  `groups` = 1 (batch statistics over
+    B*H*W) or B (per-instance statistics over H*W).  use_input_stats False = eval mode: the running statistics normalise
+    (both layer types: torch/nn/modules/instancenorm.py uses them whenever track_running_stats is set)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, layer, instance, use_input_stats):
+        xn = to_nhwc(x)
+        B, H, W, C = xn.shape
+        G, npg = (B, H * W) if instance else (1, B * H * W)
+        dev = xn.device
+        eps = float(layer.eps)
+        if use_input_stats:
+            s1 = _new((G, C), dev)
+            _lib.call("evf_chan_reduce", _lib.ptr(xn), C, None, 0, None, None, 0, G, npg, C, _lib.ptr(s1))
+            mean = s1 / npg
+            s2 = _new((G, C), dev)
+            _lib.call("evf_chan_reduce", _lib.ptr(xn), C, None, 0, _lib.ptr(mean), None, 1, G, npg, C, _lib.ptr(s2))
+            var = s2 / npg  # biased: what normalises
+            if layer.track_running_stats and layer.running_mean is not None:
+                with torch.no_grad():
+                    m = layer.momentum if layer.momentum is not None else 1.0 / float(layer.num_batches_tracked + 1)  # cumulative average
+                    unb = s2 / max(npg - 1, 1)  # unbiased: what the running variance tracks
+                    layer.running_mean.mul_(1 - m).add_(m * mean.mean(0))
+                    layer.running_var.mul_(1 - m).add_(m * unb.mean(0))
+                    if layer.num_batches_tracked is not None and not instance:
+                        layer.num_batches_tracked += 1  # (nn.InstanceNorm2d never counts: F.instance_norm has no counter)
+        else:
+            mean = layer.running_mean.detach().float().reshape(1, C).expand(G, C).contiguous()
+            var = layer.running_var.detach().float().reshape(1, C).expand(G, C).contiguous()
+        rstd = torch.rsqrt(var + eps)
+        w = weight.detach().float().reshape(1, C) if weight is not None else torch.ones((1, C), device=dev)
+        b = bias.detach().float().reshape(1, C) if bias is not None else torch.zeros((1, C), device=dev)
+        scale = (w * rstd).contiguous()
+        shift = (b - mean * w * rstd).contiguous()
+        y = _new((B, H, W, C), dev)
+        _lib.call("evf_chan_affine", None, 0, _lib.ptr(xn), C, None, _lib.ptr(scale), _lib.ptr(shift), G, npg, C, _lib.ptr(y), C)
+        ctx.saved = (xn, mean.contiguous(), rstd.contiguous(), w)
+        ctx.geo = (G, npg, C, use_input_stats, weight is not None, bias is not None)
+        ctx.wshape = None if weight is None else tuple(weight.shape)
+        return from_nhwc(y)
+
+    @staticmethod
+    def backward(ctx, g_y):
+        xn, mean, rstd, w = ctx.saved
+        G, npg, C, stats, has_w, has_b = ctx.geo
+        g = to_nhwc(g_y)
+        dev = g.device
+        s1 = _new((G, C), dev)  # sum g
+        s2 = _new((G, C), dev)  # sum g * xhat
+        _lib.call("evf_chan_reduce", _lib.ptr(g), C, None, 0, None, None, 0, G, npg, C, _lib.ptr(s1))
+        _lib.call("evf_chan_reduce", _lib.ptr(xn), C, _lib.ptr(g), C, _lib.ptr(mean), _lib.ptr(rstd), 2, G, npg, C, _lib.ptr(s2))
+        A = (w * rstd).contiguous()
+        if stats:  # the statistics depend on x
+            Bc = (-(rstd * rstd) * w * s2 / npg).contiguous()
+            Cc = (-Bc * mean - rstd * w * s1 / npg).contiguous()
+        else:
+            Bc = torch.zeros_like(A)
+            Cc = torch.zeros_like(A)
+        gx = _new(tuple(xn.shape), dev)
+        _lib.call("evf_chan_affine", _lib.ptr(g), C, _lib.ptr(xn), C, _lib.ptr(A), _lib.ptr(Bc), _lib.ptr(Cc), G, npg, C, _lib.ptr(gx), C)
+        g_w = s2.sum(0).reshape(ctx.wshape) if has_w else None
+        g_b = s1.sum(0).reshape(ctx.wshape) if has_b else None
+        return from_nhwc(gx), g_w, g_b, None, None, None
+
+
+def norm2d(x, layer):
+    """Apply an nn.BatchNorm2d / nn.InstanceNorm2d module (parameter / buffer holder under the reference's names) on the GPU."""
+    instance = isinstance(layer, torch.nn.InstanceNorm2d)
+    use_input_stats = layer.training or not layer.track_running_stats
+    return _Norm2d.apply(x, layer.weight, layer.bias, layer, instance, use_input_stats)
+
+
+class _ConvTranspose(torch.autograd.Function):
+    """nn.ConvTranspose2d(k, stride 2, padding k/2, output_padding 1) (reference models/submodules.py:104-112): exactly the
+    input gradient of the stride-2 convolution with the same weight tensor [Cin][Cout][k][k] -- forward = evf_conv2d_dgrad,
+    gradient w.r.t. the input = evf_conv2d_fwd (stride 2), w.r.t. the weight = evf_conv2d_wgrad with the roles of input and
+    output gradient swapped."""
+
+    @staticmethod
+    def forward(ctx, owner, x, weight, bias):
+        xn = to_nhwc(x)
+        B, H, W, Ci = xn.shape
+        Ci_w, Co, k, _ = weight.shape
+        if Ci != Ci_w:
+            raise _lib.EvflowError(f"input has {Ci} channels, the transposed layer expects {Ci_w}")
+        y = _new((B, 2 * H, 2 * W, Co), xn.device)
+        # as a convolution: Cout_conv = Ci (its output = our input), Cin_conv = Co (its input = our output)
+        conv_dgrad(xn, _wcache(owner, "wT").get(weight, 1, 0, Co), y, Co, Ci, k, 2)
+        if bias is not None:
+            y += bias.detach().reshape(1, 1, 1, Co)
+        ctx.owner = owner
+        ctx.saved = (xn, weight)
+        ctx.has_bias = bias is not None
+        return from_nhwc(y)
+
+    @staticmethod
+    def backward(ctx, g_y):
+        xn, weight = ctx.saved
+        B, H, W, Ci = xn.shape
+        _, Co, k, _ = weight.shape
+        need = ctx.needs_input_grad  # (owner, x, weight, bias)
+        g = to_nhwc(g_y)
+        g_x = g_w = g_b = None
+        if need[1]:
+            gxn = _new((B, H, W, Ci), g.device)
+            conv_fwd(g, _wcache(ctx.owner, "w").get(weight, 0, 0, Co), None, gxn, Co, Ci, k, 2)
+            g_x = from_nhwc(gxn)
+        if need[2]:
+            g_w = _new(tuple(weight.shape), g.device)
+            conv_wgrad(g, xn, g_w, None, Co, Ci, k, 2, cin_total=Co)
+        if ctx.has_bias and need[3]:
+            g_b = g.sum((0, 1, 2))
+        return None, g_x, g_w, g_b
+
+
+def conv_transpose(owner, x, weight, bias):
+    return _ConvTranspose.apply(owner, x, weight, bias)
+
+
+# ---------------------------------------------------------------------------
 # leaky state mix of ConvLeaky / ConvLeakyRecurrent (submodules.py:545-554, :488-499)
 # ---------------------------------------------------------------------------
 class _LeakyMix(torch.autograd.Function):

@@ -24,9 +24,8 @@ class ConvLayer(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, activation="relu", norm=None, BN_momentum=0.1,
                  w_scale=None):
         super().__init__()
-        if norm is not None:
-            raise NotImplementedError("BN/IN ConvLayers belong to the ANN baselines, outside the accelerated path")
-        self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, kernel_size // 2, bias=True)
+        self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, kernel_size // 2, bias=norm != "BN")
+        _make_norm(self, norm, out_channels, BN_momentum)
         if w_scale is not None:
             nn.init.uniform_(self.conv2d.weight, -w_scale, w_scale)
             nn.init.zeros_(self.conv2d.bias)
@@ -44,6 +43,9 @@ class ConvLayer(nn.Module):
         return self.activation
 
     def forward(self, x):
+        if self.norm in ("BN", "IN"):  # conv -> norm -> activation (reference :52-61)
+            out = hip_ops.conv_act(self, x, self.conv2d.weight, self.conv2d.bias, self.stride, None)
+            return hip_ops.activation(hip_ops.norm2d(out, self.norm_layer), self._act())
         return hip_ops.conv_act(self, x, self.conv2d.weight, self.conv2d.bias, self.stride, self._act())
 
 
@@ -55,6 +57,9 @@ class ConvLayer_(ConvLayer):
         if prev_state is None:
             prev_state = torch.tensor(0)  # not used (reference :71-72)
         res = residual if torch.is_tensor(residual) else None
+        if self.norm in ("BN", "IN"):  # conv -> norm -> + residual -> activation (reference :74-81)
+            out = hip_ops.conv_act(self, x, self.conv2d.weight, self.conv2d.bias, self.stride, None)
+            return hip_ops.activation(hip_ops.norm2d(out, self.norm_layer), self._act(), res), prev_state
         out = hip_ops.conv_act(self, x, self.conv2d.weight, self.conv2d.bias, self.stride, self._act(), residual=res)
         return out, prev_state
 
@@ -176,9 +181,13 @@ class ConvLeaky(nn.Module, _LeakParam):
         return out, state
 
 
-def _no_norm(norm, what):
-    if norm is not None:
-        raise NotImplementedError(f"{what}: BN/IN layers have no HIP kernel (the reference's configs use norm=None)")
+def _make_norm(module, norm, channels, BN_momentum=0.1, name="norm_layer"):
+    """The reference's norm members (models/submodules.py:46-50): parameter / buffer holders under the reference's names; the
+    arithmetic runs in hip_ops.norm2d."""
+    if norm == "BN":
+        setattr(module, name, nn.BatchNorm2d(channels, momentum=BN_momentum))
+    elif norm == "IN":
+        setattr(module, name, nn.InstanceNorm2d(channels, track_running_stats=True))
 
 
 def stack_nhwc(states):
@@ -191,8 +200,8 @@ class UpsampleConvLayer(nn.Module):
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, activation="relu", norm=None):
         super().__init__()
-        _no_norm(norm, "UpsampleConvLayer")
-        self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, kernel_size // 2, bias=True)
+        self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, kernel_size // 2, bias=norm != "BN")
+        _make_norm(self, norm, out_channels)
         if activation is not None and not hasattr(torch, activation) and activation not in SURROGATE_ID:
             raise AttributeError(activation)
         self.activation, self.norm, self.stride = activation, norm, stride
@@ -201,15 +210,31 @@ class UpsampleConvLayer(nn.Module):
         if self.activation not in hip_ops.ACT_ID:
             raise NotImplementedError(f"UpsampleConvLayer activation {self.activation!r} has no HIP kernel")
         x_up = hip_ops.upsample2x_bilinear(x)
+        if self.norm in ("BN", "IN"):
+            out = hip_ops.conv_act(self, x_up, self.conv2d.weight, self.conv2d.bias, self.stride, None)
+            return hip_ops.activation(hip_ops.norm2d(out, self.norm_layer), self.activation)
         return hip_ops.conv_act(self, x_up, self.conv2d.weight, self.conv2d.bias, self.stride, self.activation)
 
 
 class TransposedConvLayer(nn.Module):
-    """Reference: models/submodules.py:86-137 (use_upsample_conv=False).  No HIP kernel."""
+    """Transposed conv (x2 up-sampling) decoder layer, use_upsample_conv=False.  Reference: models/submodules.py:86-137."""
 
-    def __init__(self, *args, **kwargs):
+    def __init__(self, in_channels, out_channels, kernel_size, activation="relu", norm=None):
         super().__init__()
-        raise NotImplementedError("transposed-conv decoders (use_upsample_conv=False) have no HIP kernel")
+        self.transposed_conv2d = nn.ConvTranspose2d(in_channels, out_channels, kernel_size, stride=2, padding=kernel_size // 2,
+                                                    output_padding=1, bias=norm != "BN")
+        if activation is not None and not hasattr(torch, activation) and activation not in SURROGATE_ID:
+            raise AttributeError(activation)
+        self.activation, self.norm = activation, norm
+        _make_norm(self, norm, out_channels)
+
+    def forward(self, x):
+        if self.activation not in hip_ops.ACT_ID:
+            raise NotImplementedError(f"TransposedConvLayer activation {self.activation!r} has no HIP kernel")
+        out = hip_ops.conv_transpose(self, x, self.transposed_conv2d.weight, self.transposed_conv2d.bias)
+        if self.norm in ("BN", "IN"):
+            out = hip_ops.norm2d(out, self.norm_layer)
+        return hip_ops.activation(out, self.activation)
 
 
 class RecurrentConvLayer(nn.Module):
@@ -238,11 +263,12 @@ class ResidualBlock(nn.Module):
 
     def __init__(self, in_channels, out_channels, stride=1, activation="relu", downsample=None, norm=None, BN_momentum=0.1):
         super().__init__()
-        _no_norm(norm, "ResidualBlock")
         if downsample is not None:
             raise NotImplementedError("ResidualBlock(downsample=...) is not used by the reference's networks")
-        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=stride, padding=1, bias=True)
-        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=stride, padding=1, bias=norm != "BN")
+        _make_norm(self, norm, out_channels, BN_momentum, "bn1")
+        _make_norm(self, norm, out_channels, BN_momentum, "bn2")
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=norm != "BN")
         if activation is not None and not hasattr(torch, activation) and activation not in SURROGATE_ID:
             raise AttributeError(activation)
         self.activation, self.norm, self.stride, self.downsample = activation, norm, stride, downsample
@@ -250,6 +276,12 @@ class ResidualBlock(nn.Module):
     def forward(self, x):
         if self.activation not in hip_ops.ACT_ID:
             raise NotImplementedError(f"ResidualBlock activation {self.activation!r} has no HIP kernel")
+        if self.norm in ("BN", "IN"):  # conv -> norm -> act; conv -> norm -> + x -> act (reference :286-311)
+            out1 = hip_ops.conv_act(self.conv1, x, self.conv1.weight, self.conv1.bias, self.stride, None)
+            out1 = hip_ops.activation(hip_ops.norm2d(out1, self.bn1), self.activation)
+            out2 = hip_ops.conv_act(self.conv2, out1, self.conv2.weight, self.conv2.bias, 1, None)
+            out2 = hip_ops.activation(hip_ops.norm2d(out2, self.bn2), self.activation, x)
+            return out2, out1
         out1 = hip_ops.conv_act(self.conv1, x, self.conv1.weight, self.conv1.bias, self.stride, self.activation)
         out2 = hip_ops.conv_act(self.conv2, out1, self.conv2.weight, self.conv2.bias, 1, self.activation, residual=x)
         return out2, out1

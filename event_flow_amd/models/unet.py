@@ -120,7 +120,8 @@ class BaseUNet(nn.Module):
         if prediction is not None:
             x = self.skip_ftn(prediction, x)
             pad = (-x.shape[1]) % 4
-            if pad and self.skip_type == "concat" and getattr(decoder.conv2d, "kind", "ann") in ("lif", "alif", "ann"):
+            conv = getattr(decoder, "conv2d", None)  # (None: transposed-conv decoder, which takes its exact channel count)
+            if pad and conv is not None and self.skip_type == "concat" and getattr(conv, "kind", "ann") in ("lif", "alif", "ann"):
                 x = torch.cat([x, x.new_zeros((x.shape[0], pad) + tuple(x.shape[2:]))], 1)
         return x
 

@@ -382,6 +382,17 @@ int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int ldg, float* 
                      int H, int W, int Cin, int Cout, int ksz, int stride, int cin_total, int cin_off,
                      int accumulate, float* ws, void* stream);
 
+/* Batch / instance normalisation of NHWC activations (nn.BatchNorm2d / nn.InstanceNorm2d(track_running_stats=True) of the
+ * reference's ANN layers, models/submodules.py:46-56, 122-132, 169-180, 273-301) = two per-element passes; the per-channel
+ * arithmetic in between is host-side (a few hundred floats).  Statistics group g covers npg consecutive pixels (batch norm:
+ * G = 1, npg = B*H*W; instance norm: G = B, npg = H*W); tensors [G*npg][C], pixel strides ld*.
+ *   evf_chan_reduce: out[g*C+c] = sum_pixels { mode 0: x | 1: (x - center)^2 | 2: y * (x - center) * scale }
+ *   evf_chan_affine: out = (g ? A*g : 0) + Bc*x + Cc with per-(group, channel) coefficients [G*C]. */
+int evf_chan_reduce(const float* x, int ldx, const float* y, int ldy, const float* center, const float* scale, int mode,
+                    int G, int64_t npg, int C, float* out, void* stream);
+int evf_chan_affine(const float* g, int ldg, const float* x, int ldx, const float* A, const float* Bc, const float* Cc,
+                    int G, int64_t npg, int C, float* out, int ldo, void* stream);
+
 /* Neuron update of one spiking cell on a precomputed input current `cur`
  * (ff [+ rec] conv), all tensors [npix][C] fp32, C % 4 == 0, null previous
  * state = zeros.  kind = EVF_LIF / PLIF / ALIF / XLIF; per-channel parameters:

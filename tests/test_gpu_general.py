@@ -642,3 +642,53 @@ def test_kernel_size_5_models_vs_oracle(which):
         got = N(p.grad) if p.grad is not None else np.zeros_like(ref)
         err += float(((got - ref) ** 2).sum())
     assert np.sqrt(err) <= 2e-3 * gn, np.sqrt(err) / gn
+
+
+# ------------------------------------------------------------------ BN / IN layers, transposed-conv decoders (G16)
+def test_g16_norm_and_transposed_conv_layers():
+    """The reference's ANN layers with norm = 'BN' / 'IN', its transposed-conv decoder layer and a MultiResUNet built with
+    norm='BN', use_upsample_conv=False (models/submodules.py:12-137, 140-185, 238-311; models/unet.py:196-311): outputs of two
+    training-mode calls, input / parameter gradients, the running statistics they leave, and the eval-mode output."""
+    from event_flow_amd.models import submodules as sub
+    from event_flow_amd.models import unet
+
+    g = load_golden("g16_norm_layers")
+    cases = golden_cases(g)
+    assert len(cases) == 10
+    for c in cases:
+        tag, cls, kw = c["tag"], c["cls"], c["kwargs"]
+        m = (unet.MultiResUNet(dict(kw)) if cls == "MultiResUNet" else getattr(sub, cls)(**kw)).to(DEV)
+        sd = {k[len(tag + "_param0_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "_param0_")}
+        m.load_state_dict(sd)  # the reference's state_dict keys (incl. norm buffers) load unchanged
+        m.train()
+        xs = [G(g[f"{tag}_x{k}"]).requires_grad_(True) for k in range(2)]
+        tot = 0
+        for k, x in enumerate(xs):
+            y = m(x, None, G(g[f"{tag}_res{k}"]))[0] if cls == "ConvLayer_" else m(x)
+            for j, yy in enumerate(y if isinstance(y, (list, tuple)) else [y]):
+                close(N(yy), g[f"{tag}_y{k}_{j}"], 2e-5, f"{cls} {kw.get('norm')} y{k}_{j}")
+                tot = tot + yy.pow(2).sum() + yy.sum()
+        grads = torch.autograd.grad(tot, xs + list(m.parameters()), allow_unused=True)
+        for k in range(2):  # (sum y^2 + sum y of an un-affine instance norm is nearly constant: tiny gradients, hence the atol)
+            np.testing.assert_allclose(N(grads[k]), g[f"{tag}_gx{k}"], rtol=0, atol=2e-4 * float(np.abs(g[f"{tag}_gx{k}"]).max()) + 1e-5,
+                                       err_msg=f"{cls} {kw.get('norm')} gx{k}")
+        # (a bias in front of a normalisation has a mathematically zero gradient: round-off on both sides -- every tensor is
+        #  held to 3e-4 of its own largest element or 1 % of the largest gradient element of the layer, whichever is larger)
+        gmax = max(float(np.abs(g[f"{tag}_grad_{pn}"]).max()) for pn, _ in m.named_parameters())
+        for (pn, prm), gr in zip(m.named_parameters(), grads[2:]):
+            ref = g[f"{tag}_grad_{pn}"]
+            got = N(gr) if gr is not None else np.zeros_like(ref)
+            # (1e-3 for the instance norm: its backward projects out most of the upstream gradient, which amplifies round-off)
+            tol = 1e-3 if kw.get("norm") == "IN" else 3e-4
+            if float(np.abs(ref).max()) < 1e-2 * gmax:  # structurally zero (bias in front of a norm): both sides are summation noise
+                assert np.abs(got - ref).max() <= 2e-3 * gmax, (cls, kw.get("norm"), pn, float(np.abs(got).max()))
+                continue
+            assert np.abs(got - ref).max() <= tol * max(float(np.abs(ref).max()), 1e-2 * gmax), (cls, kw.get("norm"), pn)
+        for pn, v in m.state_dict().items():  # running mean / variance / batch counter after the two calls
+            ref = g[f"{tag}_param1_{pn}"]
+            np.testing.assert_allclose(N(v).astype(np.float64), ref.astype(np.float64), rtol=1e-5, atol=1e-6, err_msg=f"{cls} {pn}")
+        m.eval()
+        with torch.no_grad():
+            ye = m(xs[0], None, G(g[f"{tag}_res0"]))[0] if cls == "ConvLayer_" else m(xs[0])
+        for j, yy in enumerate(ye if isinstance(ye, (list, tuple)) else [ye]):
+            close(N(yy), g[f"{tag}_yeval_{j}"], 2e-5, f"{cls} {kw.get('norm')} eval {j}")

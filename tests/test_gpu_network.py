@@ -285,10 +285,14 @@ def test_fireflownet_runs_and_unsupported_fail_loudly():
     out = model(x, x)
     assert out["flow"][0].shape == (1, 2, 16, 40)
     ann = dict(model_cfg(), spiking_neuron=None, activations=["relu", None])
-    with pytest.raises(NotImplementedError):
-        RecEVFlowNet(dict(ann, norm="BN"))  # batch / instance norm layers have no HIP kernel
-    with pytest.raises(NotImplementedError):
-        RecEVFlowNet(dict(ann, use_upsample_conv=False))  # transposed-conv decoders neither
+    # batch-norm layers and transposed-conv decoders run on the general path (layer-level parity: fixture G16)
+    net = RecEVFlowNet(dict(ann, norm="BN", use_upsample_conv=False)).to(DEV)
+    assert any(k.endswith("running_mean") for k in net.state_dict()) and any("transposed_conv2d" in k for k in net.state_dict())
+    xx = torch.rand(1, 2, 32, 32, device=DEV).round()
+    fl = net(xx, xx)["flow"]
+    assert len(fl) == 4 and fl[-1].shape == (1, 2, 32, 32)
+    sum(f.sum() for f in fl).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
     with pytest.raises(TypeError):
         RecEVFlowNet(model_cfg())  # LIF neuron kwargs on the ConvGRU net: TypeError, as in the reference
     with pytest.raises(_lib.EvflowError):

@@ -335,3 +335,34 @@ def test_g12_e2vid():
         ref = g["grad_" + k]
         got = gr.numpy() if gr is not None else np.zeros_like(ref)
         assert np.abs(got - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-10) + 1e-9, k
+
+
+# --------------------------------------------------------------------- G16 (BN / IN layers)
+def test_g16_norm_oracle_vs_reference():
+    """oracle.norm.norm2d against the reference's ConvLayer(norm='BN'/'IN') outputs (conv by torch-CPU): both training calls,
+    the running statistics they leave, and the eval-mode call."""
+    import torch.nn.functional as F
+
+    from oracle import norm as onorm
+
+    g = load_golden("g16_norm_layers")
+    for c in golden_cases(g):
+        if c["cls"] != "ConvLayer":
+            continue
+        tag, kw = c["tag"], c["kwargs"]
+        inst = kw["norm"] == "IN"
+        w = T(g[f"{tag}_param0_conv2d.weight"])
+        b = T(g[f"{tag}_param0_conv2d.bias"]) if f"{tag}_param0_conv2d.bias" in g.files else None
+        nw = g[f"{tag}_param0_norm_layer.weight"] if f"{tag}_param0_norm_layer.weight" in g.files else None
+        nb = g[f"{tag}_param0_norm_layer.bias"] if f"{tag}_param0_norm_layer.bias" in g.files else None
+        rm, rv = g[f"{tag}_param0_norm_layer.running_mean"], g[f"{tag}_param0_norm_layer.running_var"]
+        act = {"relu": lambda v: np.maximum(v, 0), "tanh": np.tanh}[kw["activation"]]
+        for k in range(2):
+            pre = F.conv2d(T(g[f"{tag}_x{k}"]), w, b, stride=kw.get("stride", 1), padding=kw["kernel_size"] // 2).detach().numpy()
+            y, rm, rv = onorm.norm2d(pre, nw, nb, rm, rv, instance=inst, training=True, momentum=kw.get("BN_momentum", 0.1))
+            np.testing.assert_allclose(act(y), g[f"{tag}_y{k}_0"], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(rm, g[f"{tag}_param1_norm_layer.running_mean"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(rv, g[f"{tag}_param1_norm_layer.running_var"], rtol=1e-5, atol=1e-7)
+        pre = F.conv2d(T(g[f"{tag}_x0"]), w, b, stride=kw.get("stride", 1), padding=kw["kernel_size"] // 2).detach().numpy()
+        y, _, _ = onorm.norm2d(pre, nw, nb, rm, rv, instance=inst, training=False)
+        np.testing.assert_allclose(act(y), g[f"{tag}_yeval_0"], rtol=1e-4, atol=2e-6)

@@ -349,6 +349,73 @@ def g15_cells_k5():
     save("g15_cells_k5", **a)
 
 
+def g16_norm_layers():
+    """The reference's ANN layers with norm = "BN" / "IN" and its transposed-conv decoder layer (models/submodules.py:12-137,
+    140-185, 238-311), and a MultiResUNet built with norm="BN", use_upsample_conv=False (models/unet.py:196-311): two
+    forward calls in train mode (the running statistics move), gradients of sum(y^2) + sum(y) over both, one forward in eval
+    mode (running statistics normalise)."""
+    from models import submodules as r_sub
+    from models import unet as r_unet
+
+    a, cases = {}, []
+    B, H, W = 2, 12, 10
+    todo = [
+        ("ConvLayer", dict(in_channels=4, out_channels=8, kernel_size=3, activation="relu", norm="BN", BN_momentum=0.3)),
+        ("ConvLayer", dict(in_channels=4, out_channels=8, kernel_size=3, stride=2, activation="tanh", norm="IN")),
+        ("ConvLayer_", dict(in_channels=8, out_channels=8, kernel_size=3, activation="relu", norm="BN")),
+        ("TransposedConvLayer", dict(in_channels=8, out_channels=4, kernel_size=3, activation="relu", norm=None)),
+        ("TransposedConvLayer", dict(in_channels=8, out_channels=4, kernel_size=5, activation="tanh", norm="BN")),
+        ("TransposedConvLayer", dict(in_channels=6, out_channels=8, kernel_size=3, activation=None, norm="IN")),
+        ("UpsampleConvLayer", dict(in_channels=4, out_channels=8, kernel_size=3, activation="relu", norm="IN")),
+        ("ResidualBlock", dict(in_channels=8, out_channels=8, activation="relu", norm="BN")),
+        ("ResidualBlock", dict(in_channels=8, out_channels=8, activation="relu", norm="IN")),
+        ("MultiResUNet", dict(base_num_channels=4, num_encoders=2, num_residual_blocks=1, num_output_channels=2, skip_type="concat",
+                              norm="BN", use_upsample_conv=False, num_bins=2, kernel_size=3, channel_multiplier=2,
+                              activations=["relu", None], final_activation="tanh")),
+    ]
+    for ci, (cls, kw) in enumerate(todo):
+        torch.manual_seed(300 + ci)
+        tag = f"n{ci}"
+        if cls == "MultiResUNet":
+            m = r_unet.MultiResUNet(dict(kw))
+            cin, hh, ww = 2, 16, 16
+        else:
+            m = getattr(r_sub, cls)(**kw)
+            cin, hh, ww = kw["in_channels"], H, W
+        m.train()
+        for pn, v in m.state_dict().items():
+            a[f"{tag}_param0_{pn}"] = v.clone()
+        xs = [torch.randn(B, cin, hh, ww).requires_grad_(True) for _ in range(2)]
+        res = [torch.randn(B, cin, hh, ww) for _ in range(2)]  # (ConvLayer_: residual of the output's shape, Cin = Cout here)
+        tot = 0
+        for k, x in enumerate(xs):
+            if cls == "ConvLayer_":
+                y = m(x, None, res[k])[0]
+                a[f"{tag}_res{k}"] = res[k]
+            else:
+                y = m(x)
+            ys = y if isinstance(y, (list, tuple)) else [y]
+            for j, yy in enumerate(ys):
+                a[f"{tag}_y{k}_{j}"] = yy
+                tot = tot + yy.pow(2).sum() + yy.sum()
+            a[f"{tag}_x{k}"] = x
+        grads = torch.autograd.grad(tot, xs + list(m.parameters()), allow_unused=True)
+        for k in range(2):
+            a[f"{tag}_gx{k}"] = grads[k]
+        for (pn, prm), gr in zip(m.named_parameters(), grads[2:]):
+            a[f"{tag}_grad_{pn}"] = gr if gr is not None else torch.zeros_like(prm)
+        for pn, v in m.state_dict().items():
+            a[f"{tag}_param1_{pn}"] = v.clone()  # running statistics after the two training calls
+        m.eval()
+        with torch.no_grad():
+            ye = m(xs[0], None, res[0])[0] if cls == "ConvLayer_" else m(xs[0])
+        for j, yy in enumerate(ye if isinstance(ye, (list, tuple)) else [ye]):
+            a[f"{tag}_yeval_{j}"] = yy
+        cases.append(dict(tag=tag, cls=cls, kwargs=kw))
+    a["cases_json"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    save("g16_norm_layers", **a)
+
+
 def model_cfg(name, C=32, neuron=None, num_bins=2, encoding="cnt", acts=("arctanspike", "arctanspike")):
     return {
         "name": name, "encoding": encoding, "round_encoding": False, "norm_input": False, "num_bins": num_bins,
@@ -667,3 +734,4 @@ if __name__ == "__main__":
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1)
     g15_cells_k5()
+    g16_norm_layers()
