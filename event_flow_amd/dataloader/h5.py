@@ -9,7 +9,7 @@ reads overlap the previous step's kernels.
 
 Storage: the reference's HDF5 layout (`events/{xs,ys,ts,ps}`, attrs `t0` / `duration`, groups `images`, `flow_dt1`,
 `flow_dt4` whose datasets carry a `timestamp` attribute; dataloader/h5.py:24-42,68,127-131) through h5py when it is
-installed, and the same layout flattened into `.npz` archives (`events/xs` ..., `t0`, `duration`,
+installed, through the HDF5 C library + ctypes otherwise (dataloader/hdf5_ctypes.py), and the same layout flattened into `.npz` archives (`events/xs` ..., `t0`, `duration`,
 `<group>/<name>` + `<group>_ts/<name>`) otherwise -- `write_npz_sequence` produces them.  Both go through one
 `_Sequence` interface, so the windowing logic is tested without h5py."""
 
@@ -73,6 +73,30 @@ class _H5Sequence(_Sequence):
         self.f.close()
 
 
+class _LibHdf5Sequence(_Sequence):
+    """The same `.h5` files through the HDF5 C library and ctypes (dataloader/hdf5_ctypes.py) -- used when h5py is not
+    installed for this interpreter."""
+
+    def __init__(self, path):
+        from . import hdf5_ctypes
+
+        self.f = hdf5_ctypes.File(path)
+        self.attrs = {"t0": self.f.attr("t0"), "duration": self.f.attr("duration")}
+
+    def events(self, name):
+        return self.f.dataset("events/" + name)
+
+    def group(self, group):
+        names = self.f.names(group)  # name order = the order h5py's visititems reports
+        return names, [self.f.dataset(f"{group}/{n}").attr("timestamp") for n in names]
+
+    def read(self, group, name):
+        return np.asarray(self.f.dataset(f"{group}/{name}"))
+
+    def close(self):
+        self.f.close()
+
+
 class _NpzSequence(_Sequence):
     def __init__(self, path):
         self.z = np.load(path, mmap_mode="r", allow_pickle=False)
@@ -96,7 +120,13 @@ class _NpzSequence(_Sequence):
 
 
 def open_sequence(path):
-    return _NpzSequence(path) if path.endswith(".npz") else _H5Sequence(path)
+    if path.endswith(".npz"):
+        return _NpzSequence(path)
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        return _LibHdf5Sequence(path)  # (raises hdf5_ctypes.Hdf5Error when no HDF5 library can be loaded either)
+    return _H5Sequence(path)
 
 
 def write_npz_sequence(path, xs, ys, ts, ps, t0=None, duration=None, **groups):

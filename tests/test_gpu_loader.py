@@ -113,3 +113,39 @@ def test_empty_windows_flow_through_model_and_loss(tmp_path):
     loss = lossf()
     loss.backward()
     assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_hdf5_sequence_batches_equal_npz_batches(tmp_path):
+    """A real HDF5 sequence file (tests/golden/seq_fixture.h5, written by h5py in the reference's layout) through the loader
+    + on-GPU binning gives bit for bit the batches of its `.npz` twin, with the reader thread on (dataloader/h5.py:45-94,249)."""
+    import os
+    import shutil
+
+    from test_host_loader import GOLDEN, _h5_reader_available
+
+    from event_flow_amd.dataloader.h5 import write_npz_sequence
+
+    if not _h5_reader_available():
+        pytest.skip("neither h5py nor an HDF5 C library on this box")
+    tw = np.load(os.path.join(GOLDEN, "seq_fixture_twin.npz"))
+    for d in ("h5", "npz"):
+        (tmp_path / d).mkdir()
+    shutil.copy(os.path.join(GOLDEN, "seq_fixture.h5"), tmp_path / "h5" / "a.h5")
+    groups = {g: [(k[len(g) + 1:], float(tw[f"{g}_ts/{k[len(g) + 1:]}"]), tw[k]) for k in sorted(tw.files) if k.startswith(g + "/")]
+              for g in ("flow_dt1",)}
+    write_npz_sequence(str(tmp_path / "npz" / "a.npz"), tw["events/xs"], tw["events/ys"], tw["events/ts"], tw["events/ps"], **groups)
+    for mode, window in (("events", 500), ("gtflow_dt1", 1)):
+        la = H5Loader(_cfg(tmp_path / "h5", mode, window, 1, (16, 20)), 5, prefetch=2)
+        lb = H5Loader(_cfg(tmp_path / "npz", mode, window, 1, (16, 20)), 5, prefetch=0)
+        n = 0
+        for ba, bb in zip(la, lb):
+            assert ba.keys() == bb.keys()
+            for k in ba:
+                if k == "event_voxel":  # sums of fp32 temporal weights: equal up to the order of the atomic adds
+                    assert torch.allclose(ba[k], bb[k], rtol=0, atol=2e-6), (mode, n, k)
+                else:
+                    assert ba[k].is_cuda and torch.equal(ba[k], bb[k]), (mode, n, k)
+            n += 1
+            if n == 3:
+                break
+        assert n == 3

@@ -147,3 +147,77 @@ def test_ranks_read_disjoint_files(tmp_path):
     assert sorted(shards[0] + shards[1]) == sorted(str(tmp_path / f"s{i}.npz") for i in range(5))
     with pytest.raises(FileNotFoundError):
         H5Loader(_cfg(tmp_path, "events", 100, 3, (16, 20)), 2, rank=1, world_size=2)  # 2 files for 3 slots
+
+
+# ------------------------------------------------------------------ real HDF5 files (fixture written by h5py)
+GOLDEN = __import__("os").path.join(__import__("os").path.dirname(__file__), "golden")
+
+
+def _h5_reader_available():
+    try:
+        import h5py  # noqa: F401
+        return True
+    except ImportError:
+        from event_flow_amd.dataloader import hdf5_ctypes
+        return hdf5_ctypes.available()
+
+
+needs_hdf5 = pytest.mark.skipif(not _h5_reader_available(), reason="neither h5py nor an HDF5 C library on this box")
+
+
+@needs_hdf5
+def test_hdf5_file_written_by_h5py_reads_back_exactly():
+    """tests/golden/seq_fixture.h5 was written by h5py 3.3 / libhdf5 1.10 in the reference's layout (tools/make_h5_fixture.py:
+    resizable chunked event datasets appended in pieces, boolean polarities, gzip-compressed flow maps, timestamp attributes);
+    seq_fixture_twin.npz holds the same arrays.  The sequence object the loader uses must give back exactly those arrays:
+    whole datasets, slices, single elements, file and dataset attributes, group members in name order."""
+    from event_flow_amd.dataloader.h5 import open_sequence
+
+    tw = np.load(GOLDEN + "/seq_fixture_twin.npz")
+    seq = open_sequence(GOLDEN + "/seq_fixture.h5")
+    assert float(seq.attrs["t0"]) == float(tw["t0"]) and float(seq.attrs["duration"]) == float(tw["duration"])
+    for name in ("xs", "ys", "ts", "ps"):
+        d = seq.events(name)
+        ref = tw["events/" + name]
+        assert len(d) == len(ref) == 4000
+        assert np.array_equal(np.asarray(d[:]).astype(ref.dtype), ref)
+        assert np.array_equal(np.asarray(d[1490:1510]).astype(ref.dtype), ref[1490:1510])  # across the append / chunk boundary
+        assert d[-1] == ref[-1] and d[0] == ref[0] and d[2777] == ref[2777]
+        assert np.asarray(d[4000:4000]).shape == (0,)
+    for g in ("images", "flow_dt1", "flow_dt4"):
+        names, stamps = seq.group(g)
+        want = sorted(k[len(g) + 1:] for k in tw.files if k.startswith(g + "/"))
+        assert names == want and len(names) == 4
+        for n_, st_ in zip(names, stamps):
+            assert float(st_) == float(tw[f"{g}_ts/{n_}"])
+            got = seq.read(g, n_)
+            assert got.dtype == tw[f"{g}/{n_}"].dtype and np.array_equal(got, tw[f"{g}/{n_}"])
+    seq.close()
+
+
+@needs_hdf5
+@pytest.mark.parametrize("mode,window", [("events", 300), ("time", 0.25), ("gtflow_dt1", 1), ("gtflow_dt4", 0.25), ("frames", 1)])
+def test_loader_on_hdf5_equals_loader_on_npz(tmp_path, mode, window):
+    """The reference's H5Loader logic (dataloader/h5.py:136-295) over the real HDF5 file gives sample for sample what it
+    gives over the `.npz` flavour of the same sequence (whose windowing the tests above pin)."""
+    import shutil
+
+    tw = np.load(GOLDEN + "/seq_fixture_twin.npz")
+    (tmp_path / "h5").mkdir()
+    (tmp_path / "npz").mkdir()
+    shutil.copy(GOLDEN + "/seq_fixture.h5", tmp_path / "h5" / "a.h5")
+    groups = {g: [(k[len(g) + 1:], float(tw[f"{g}_ts/{k[len(g) + 1:]}"]), tw[k]) for k in sorted(tw.files) if k.startswith(g + "/")]
+              for g in ("images", "flow_dt1", "flow_dt4")}
+    write_npz_sequence(str(tmp_path / "npz" / "a.npz"), tw["events/xs"], tw["events/ys"], tw["events/ts"], tw["events/ps"], **groups)
+    a = H5Loader(_cfg(tmp_path / "h5", mode, window, 1, (16, 20), ("Horizontal", "Polarity")), 2)
+    b = H5Loader(_cfg(tmp_path / "npz", mode, window, 1, (16, 20), ("Horizontal", "Polarity")), 2)
+    a.batch_augmentation = {"Horizontal": [True], "Polarity": [False]}
+    b.batch_augmentation = {"Horizontal": [True], "Polarity": [False]}
+    assert a.get_iters(0) == b.get_iters(0)
+    for i in range({"gtflow_dt1": 3, "frames": 2}.get(mode, 4)):  # (stay inside the sequence: a restart re-draws the augmentation)
+        sa, sb = a[i], b[i]
+        assert sa.keys() == sb.keys()
+        for k in sa:
+            va, vb = np.asarray(sa[k]), np.asarray(sb[k])
+            assert va.dtype == vb.dtype and np.array_equal(va, vb), (mode, i, k)
+    assert (a.seq_num, a.batch_row) == (b.seq_num, b.batch_row)

@@ -147,19 +147,25 @@ def test_yaml_parser_reads_reference_style_configs(tmp_path):
     assert own["model"]["name"] in M.MODELS and own["data"]["window_loss"] % own["data"]["window"] == 0
 
 
-def test_h5_files_need_h5py(tmp_path):
-    """`.h5` sequences go through h5py, which this image lacks: opening one fails loudly (the `.npz` flavour of the
-    same layout is what tests/test_host_loader.py reads)."""
+def test_h5_files_without_any_hdf5_reader_fail_loudly(tmp_path, monkeypatch):
+    """`.h5` sequences go through h5py or, without it, through the HDF5 C library (dataloader/hdf5_ctypes.py); a file that is
+    not HDF5 -- or a box with neither -- fails loudly instead of yielding empty batches."""
+    from event_flow_amd.dataloader import hdf5_ctypes
     from event_flow_amd.dataloader.h5 import H5Loader
 
-    (tmp_path / "a.h5").write_bytes(b"")
+    (tmp_path / "a.h5").write_bytes(b"not an hdf5 file")
     cfg = {"data": {"path": str(tmp_path), "mode": "events", "window": 10},
            "loader": {"batch_size": 1, "resolution": [8, 8], "augment": []}, "hot_filter": {"enabled": False}}
+    with pytest.raises((OSError, ImportError)):
+        H5Loader(cfg, 2)
     try:
         import h5py  # noqa: F401
     except ImportError:
-        with pytest.raises(ImportError):
+        monkeypatch.setattr(hdf5_ctypes, "_lib", None)
+        monkeypatch.setattr(hdf5_ctypes, "_CANDIDATES", ("/nonexistent/libhdf5.so",))
+        with pytest.raises(hdf5_ctypes.Hdf5Error):
             H5Loader(cfg, 2)
+
 
 
 def test_reference_pickled_checkpoint_restores(tmp_path):
