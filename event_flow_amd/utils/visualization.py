@@ -1,7 +1,9 @@
 """Stored visualisations -- counterpart of the rendering half of reference utils/visualization.py (colour coding
 :230-315, folder layout and file names of `Visualization.store` :120-226) with numpy + zlib only (the reference needs
-cv2 and matplotlib; neither is in this image, so this module is checked against hand-computed colours, NOT against
-reference output: parity unpinned).  The live window (`update`, :28-118) is not provided.
+cv2 and matplotlib).  The colour coding (flow_to_image, minmax_norm, events_to_image) is pinned by fixture G17 = the
+reference's own functions run on seeded inputs (tools/make_vis_fixture.py; matplotlib exists in the image's conda
+interpreter); what goes through cv2 in the reference -- resizing, BGR file writing, the live window (`update`, :28-118) --
+has no counterpart to compare with here: the PNG container and the folder layout are checked structurally only.
 
 Host-side by nature: tensors are fetched once per stored frame; nothing here is on the training path."""
 

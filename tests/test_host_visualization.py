@@ -74,3 +74,25 @@ def test_store_layout_and_png_round_trip(tmp_path):
     assert tuple(fl[2, 2]) == (0, 255, 255) and not fl[0, 0].any()
     fr = _read_png(base / "frames" / "000000000.png")
     assert np.array_equal(fr, frames[0, 1].numpy())
+
+
+def test_colour_coding_against_the_reference_functions():
+    """Fixture G17 = the reference's own Visualization.flow_to_image / minmax_norm / events_to_image
+    (utils/visualization.py:230-315, matplotlib's hsv_to_rgb inside) on seeded inputs, incl. axis-aligned / zero / constant
+    flow and single-polarity counts (tools/make_vis_fixture.py)."""
+    import os
+
+    from event_flow_amd.utils import visualization as vis
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g17_visualization.npz"))
+    for k in range(4):
+        got = vis.flow_to_image(g[f"flow{k}_x"], g[f"flow{k}_y"])
+        ref = g[f"flow{k}_rgb"]
+        assert got.shape == ref.shape and got.dtype == np.uint8
+        d = np.abs(got.astype(int) - ref.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 0.01, (k, d.max(), (d > 0).mean())  # 255 * x truncated: one level at exact ties
+    for k in range(3):
+        np.testing.assert_allclose(vis.events_to_image(g[f"cnt{k}"], "green_red"), g[f"cnt{k}_green_red"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(vis.events_to_image(g[f"cnt{k}"], "gray"), g[f"cnt{k}_gray"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(vis.minmax_norm(g[f"mm{k}_in"]), g[f"mm{k}_out"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(vis.minmax_norm(g["mm_const_in"]), g["mm_const_out"], rtol=0, atol=0)
