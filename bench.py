@@ -348,6 +348,12 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def hip_ops_conv_b3():
+    from event_flow_amd.models import hip_ops
+
+    return hip_ops.CONV_B3
+
+
 def main_c4(args):
     """BASELINE configs[3]: LIF-EV-FlowNet (SpikingRecEVFlowNet, base 32, 20.4 M parameters), 256x256, one window of 50 000
     events per sample, batch 8, 4 flow scales, full train step on the general fp32-MFMA path (eager launches).  Same JSON
@@ -381,9 +387,9 @@ def main_c4(args):
         loss = train_window(model, lossf, opt, pool[i % 2])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    names = ["evf_conv2d_fwd", "evf_conv2d_dgrad", "evf_conv2d_wgrad", "evf_neuron_fwd", "evf_neuron_bwd", "evf_upsample2x_fwd",
+    names = ["evf_conv2d_fwd", "evf_conv2d_dgrad", "evf_conv2d_fwd_b3", "evf_conv2d_dgrad_b3", "evf_conv2d_wgrad", "evf_neuron_fwd", "evf_neuron_bwd", "evf_upsample2x_fwd",
              "evf_upsample2x_bwd", "evf_upsample_nearest_fwd", "evf_upsample_nearest_bwd", "evf_cm_loss_fwd", "evf_cm_loss_bwd",
-             "evf_clip_adam_step", "evf_pack_conv2d_weight", "evf_encode_events"]
+             "evf_clip_adam_step", "evf_pack_conv2d_weight", "evf_pack_conv2d_weight_b3", "evf_encode_events"]
     prof_steps = 2
     _lib.profile_start(names)
     for i in range(prof_steps):
@@ -403,6 +409,12 @@ def main_c4(args):
         if ent["flop_per_step"]:
             ent["TFLOPs"] = ent["flop_per_step"] / (ent["total_ms_per_step"] * 1e-3) / 1e12
             ent["frac_of_fp32_mfma_peak"] = ent["TFLOPs"] / FP32_MFMA_PEAK
+            if name.endswith("_b3"):
+                # issued bf16 work lies between 3x (every wave's fragment exactly representable) and 6x the fp32-equivalent
+                # FLOPs, by the per-wave vote of evf_conv_b3gen.hip; the input gradient always takes 6
+                lo_terms = 6 if "dgrad" in name else 3
+                ent["issued_bf16_TFLOPs_range"] = [ent["TFLOPs"] * lo_terms, ent["TFLOPs"] * 6]
+                ent["frac_of_bf16_peak_range"] = [ent["TFLOPs"] * lo_terms / BF16_MFMA_PEAK, ent["TFLOPs"] * 6 / BF16_MFMA_PEAK]
             ent["algorithmic_GBps"] = ent["bytes_per_step"] / (ent["total_ms_per_step"] * 1e-3) / 1e9
         ent.pop("bytes_per_step")
     dom_name = max((n for n in kernels if "TFLOPs" in kernels[n]), key=lambda n: kernels[n]["total_ms_per_step"])
@@ -414,7 +426,10 @@ def main_c4(args):
         "config": {"workload": "LIF-EV-FlowNet (SpikingRecEVFlowNet, base 32) full train step, 256x256, 50k events/window, batch 8, "
                                "4 flow scales, CM loss, clip+Adam [BASELINE configs[3]]", "baseline_config": "c4", "global_batch": Bc,
                    "events_per_window": nev, "parallelism": "dp1", "launch": "eager", "loss": float(loss),
-                   "conv_precision": "fp32 MFMA (v_mfma_f32_32x32x2_f32), NHWC fp32 activations"},
+                   "conv_precision": ("forward / input gradient: bf16 MFMA with exact 3-way operand splits, fp32 accumulation "
+                                      "(3 products per 16 channels for spike-valued waves, 6 otherwise; EVF_CONV=f32 for the fp32 "
+                                      "kernels); " if hip_ops_conv_b3() else "") +
+                                     "weight gradient: fp32 MFMA (v_mfma_f32_32x32x2_f32); NHWC fp32 activations"},
         "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": dom["TFLOPs"], "peak": FP32_MFMA_PEAK, "unit": "TFLOP/s",
                      "frac": dom["TFLOPs"] / FP32_MFMA_PEAK, "traffic": None,
                      "note": "all launches of the entry point in a step together: sum of 2*k*k*Cin*Cout*B*Ho*Wo over the launches / "

@@ -84,6 +84,13 @@ NETWORK_SIGNATURES = {
     "evf_pack_conv2d_weight": [P, I, I, I, I, I, I, P, P],
     "evf_conv2d_fwd": [P, I, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "evf_conv2d_dgrad": [P, I, P, P, I, I, I, I, I, I, I, I, I, P],
+    "evf_conv2d_b3_packed_size": [I, I, I, I],
+    "evf_pack_conv2d_weight_b3": [P, I, I, I, I, I, I, P, P],
+    "evf_conv2d_b3_ws": [I, I, I, I],
+    "evf_conv2d_fwd_b3": [P, I, P, P, P, I, I, I, I, I, I, I, I, I, P, L, P],
+    "evf_conv2d_dgrad_b3": [P, I, P, P, I, I, I, I, I, I, I, I, I, P, L, P],
+    "evf_conv_tile_select": [I],
+    "evf_conv_split_select": [I],
     "evf_conv2d_wgrad_ws": [I, I, I, I, I, I, I],
     "evf_conv2d_wgrad": [P, I, P, I, P, P, I, I, I, I, I, I, I, I, I, I, P, P],
     "evf_neuron_fwd": [I, P, P, P, P, P, P, P, P, P, P, L, I, I, P, P, P, P, P],
@@ -110,7 +117,7 @@ NETWORK_SIGNATURES = {
     "evf_gru_out_bwd": [P, P, P, P, L, P, P, P, P],
     "evf_gru_gates_bwd": [P, P, P, L, P, P, P],
 }
-RESTYPES = {"evf_conv2d_packed_size": ctypes.c_int64, "evf_conv2d_wgrad_ws": ctypes.c_int64, "evf_cm_loss_ws": ctypes.c_int64}
+RESTYPES = {"evf_conv2d_packed_size": ctypes.c_int64, "evf_conv2d_b3_packed_size": ctypes.c_int64, "evf_conv2d_b3_ws": ctypes.c_int64, "evf_conv2d_wgrad_ws": ctypes.c_int64, "evf_cm_loss_ws": ctypes.c_int64}
 SIGNATURES.update(NETWORK_SIGNATURES)
 
 _lib = None
@@ -163,6 +170,8 @@ _PROF_VARIANT = {
     # general convs: the shape is the variant ("B,H,W,Cin,Cout,k,stride"): bench.py derives the FLOP of every launch from it
     "evf_conv2d_fwd": lambda a: ",".join(str(int(v)) for v in a[6:13]),
     "evf_conv2d_dgrad": lambda a: ",".join(str(int(v)) for v in a[5:12]),
+    "evf_conv2d_fwd_b3": lambda a: ",".join(str(int(v)) for v in a[6:13]),
+    "evf_conv2d_dgrad_b3": lambda a: ",".join(str(int(v)) for v in a[5:12]),
     "evf_conv2d_wgrad": lambda a: ",".join(str(int(v)) for v in a[6:13]),
 }
 

@@ -59,6 +59,11 @@ __device__ __forceinline__ float evf_block_sum(float v, float* smem /* >= 16 flo
   return r;
 }
 
+// evf_conv_b3tile.hip: spatially tiled 3x3 stride-1 convolution behind evf_conv2d_fwd_b3 / evf_conv2d_dgrad_b3
+int evf_conv3_b3t_plan(const float* src, int B, int H, int W, int K, int N, int lds, bool force, int max_split, int force_split);
+int evf_conv3_b3t_launch(const float* src, int lds, const void* wp, const float* bias, float* out, int ldo, int B, int H, int W,
+                         int K, int N, int flip, int accumulate, int ksplit, hipStream_t st);
+
 // evf_dgrad_ws.hip: wave-specialised input-gradient kernel behind evf_conv_dgrad_b3_f32[_pair]
 int evf_dgrad_ws_launch(const float* g_cur, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W, const float* g_P,
                         const uint32_t* x_bits, const void* wT2_b3, float* g_x2, int max_blocks, void* stream);

@@ -18,6 +18,7 @@ Reference semantics implemented here:
   nearest xf          models/model.py:529-539
 """
 
+import os
 import weakref
 
 import torch
@@ -62,6 +63,9 @@ def _out_dim(n, k, s):
 
 
 _EPOCH = [0]
+# General convolutions (forward / input gradient) on the bf16 matrix cores with exact operand splits
+# (csrc/evf_conv_b3gen.hip); EVF_CONV=f32 keeps the fp32-MFMA kernels (csrc/evf_conv_gen.hip).  Packed weights differ.
+CONV_B3 = os.environ.get("EVF_CONV", "b3") != "f32"
 
 
 def invalidate_packed_weights():
@@ -79,7 +83,8 @@ class _PackCache:
     def get(self, w, transpose, cin_off=0, cin=None):
         Cout, Ctot, k, _ = w.shape
         cin = Ctot if cin is None else cin
-        key = (transpose, cin_off, cin)
+        sfx = "_b3" if CONV_B3 else ""
+        key = (transpose, cin_off, cin, sfx)
         tag = (w.data_ptr(), w._version, w.device, _EPOCH[0])
         hit = self.store.get(key)
         if hit is not None and hit[0] == tag:
@@ -87,9 +92,9 @@ class _PackCache:
         wc = w.detach()
         if not wc.is_contiguous():
             wc = wc.contiguous()
-        n = _lib.load().evf_conv2d_packed_size(Cout, cin, k, transpose)
+        n = getattr(_lib.load(), "evf_conv2d" + sfx + "_packed_size")(Cout, cin, k, transpose)
         dst = _new((n,), w.device)
-        _lib.call("evf_pack_conv2d_weight", _lib.ptr(wc), Cout, cin, k, transpose, Ctot, cin_off, _lib.ptr(dst))
+        _lib.call("evf_pack_conv2d_weight" + sfx, _lib.ptr(wc), Cout, cin, k, transpose, Ctot, cin_off, _lib.ptr(dst))
         self.store[key] = (tag, dst)
         return dst
 
@@ -117,14 +122,33 @@ def _wcache(owner, name):
     return d[name]
 
 
+def _b3_ws(B, Ho, Wo, Cout, dev):
+    """Split-K scratch of the bf16x3 kernels (low-resolution, many-channel layers at small batch); (None, 0) when the
+    shape never splits."""
+    n = _lib.load().evf_conv2d_b3_ws(B, Ho, Wo, Cout)
+    if n <= 0:
+        return None, 0
+    return _scratch(n, dev), n
+
+
 def conv_fwd(x, wp, bias, y, Cin, Cout, k, stride, accumulate=0):
     B, H, W, ldx = x.shape[0], x.shape[1], x.shape[2], x.stride(2)
+    if CONV_B3:
+        ws, n = _b3_ws(B, y.shape[1], y.shape[2], Cout, x.device)
+        _lib.call("evf_conv2d_fwd_b3", _lib.ptr(x), ldx, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(y), y.stride(2), B, H, W, Cin,
+                  Cout, k, stride, accumulate, _lib.ptr(ws), n)
+        return
     _lib.call("evf_conv2d_fwd", _lib.ptr(x), ldx, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(y), y.stride(2), B, H, W, Cin, Cout,
               k, stride, accumulate)
 
 
 def conv_dgrad(g_y, wtp, g_x, Cin, Cout, k, stride, accumulate=0):
     B, H, W = g_x.shape[0], g_x.shape[1], g_x.shape[2]
+    if CONV_B3:
+        ws, n = _b3_ws(B, H, W, Cin, g_x.device)
+        _lib.call("evf_conv2d_dgrad_b3", _lib.ptr(g_y), g_y.stride(2), _lib.ptr(wtp), _lib.ptr(g_x), g_x.stride(2), B, H, W,
+                  Cin, Cout, k, stride, accumulate, _lib.ptr(ws), n)
+        return
     _lib.call("evf_conv2d_dgrad", _lib.ptr(g_y), g_y.stride(2), _lib.ptr(wtp), _lib.ptr(g_x), g_x.stride(2), B, H, W, Cin,
               Cout, k, stride, accumulate)
 

@@ -373,6 +373,32 @@ int evf_conv2d_fwd(const float* x, int ldx, const float* w_packed, const float* 
 /* g_x [B,H,W,Cin] (+)= conv^T(g_y [B,Ho,Wo,Cout])  (autograd of the above w.r.t. x) */
 int evf_conv2d_dgrad(const float* g_y, int ldg, const float* wT_packed, float* g_x, int ldx, int B, int H,
                      int W, int Cin, int Cout, int ksz, int stride, int accumulate, void* stream);
+/* The same two products on the bf16 matrix cores with exact operand splits (csrc/evf_conv_b3gen.hip; the host's default,
+ * EVF_CONV=f32 keeps the fp32 kernels above): weights packed as three bf16 planes (w = hi + mid + lo exactly), the
+ * activation / gradient converted on the fly; a wave whose 32 pixels x 16 channels are all exactly representable in bf16
+ * (binary spikes, event counts, bilinear blends of spikes) issues 3 products, any other wave the 6 terms above 2^-24 of
+ * the leading one.  fp32 accumulation; no promise needed from the caller, the vote never changes a result.
+ * Same arguments as the fp32 entry points; packed size in floats. */
+int64_t evf_conv2d_b3_packed_size(int Cout, int Cin, int ksz, int transpose);
+int evf_pack_conv2d_weight_b3(const float* w, int Cout, int Cin, int ksz, int transpose, int cin_total,
+                              int cin_off, void* dst, void* stream);
+/* ws: optional scratch of ws_floats floats (evf_conv2d_b3_ws() of the OUTPUT shape; 0 = this shape never needs it): layers
+ * whose output tiles alone cannot fill the chip split their contraction into up to 8 slabs, summed in a fixed order
+ * (deterministic; no atomics).  Null = never split. */
+int64_t evf_conv2d_b3_ws(int B, int Ho, int Wo, int Cout);
+int evf_conv2d_fwd_b3(const float* x, int ldx, const void* w_packed, const float* bias, float* y, int ldy,
+                      int B, int H, int W, int Cin, int Cout, int ksz, int stride, int accumulate,
+                      float* ws, int64_t ws_floats, void* stream);
+int evf_conv2d_dgrad_b3(const float* g_y, int ldg, const void* wT_packed, float* g_x, int ldx, int B, int H,
+                        int W, int Cin, int Cout, int ksz, int stride, int accumulate, float* ws,
+                        int64_t ws_floats, void* stream);
+/* Kernel choice behind the two entry points above for 3x3 stride-1 products: -1 by shape (default: the spatially tiled
+ * kernel of csrc/evf_conv_b3tile.hip for wide high-resolution layers, environment EVF_CONV_TILE=0|2 at load), 0 never,
+ * 2 whenever the operands are aligned for it.  Same results up to summation order. */
+int evf_conv_tile_select(int mode);
+/* K splits of the two entry points above: 0 by shape (default; environment EVF_CONV_SPLIT=n at load), n > 0 forces n
+ * splits wherever the caller's scratch allows (tests). */
+int evf_conv_split_select(int n);
 /* g_w [Cout][cin_total][k][k] (input channels cin_off ..) and optional g_bias [Cout]
  * (autograd w.r.t. weight / bias).  accumulate = 0 overwrites the outputs and needs cin_off = 0 and
  * Cin >= cin_total (channels past cin_total are activation padding and are skipped).  ws: scratch of evf_conv2d_wgrad_ws() floats (3x3, and 1x1 with Cout <= 4; null is accepted for 1x1 and selects the atomic split-K kernel):

@@ -64,11 +64,30 @@ CONV_CASES = [
     (2, 66, 40, 9, 11, 5, 1),
     (1, 4, 8, 15, 13, 7, 1),
     (1, 16, 16, 14, 14, 7, 2),
+    # ragged spatial tiles (16 x 32) and channel groups of the tiled 3x3 kernel
+    (2, 132, 64, 40, 70, 3, 1),
+    (1, 32, 132, 33, 65, 3, 1),
+    (1, 20, 96, 18, 34, 3, 1),
+    (2, 512, 64, 8, 8, 3, 1),  # low resolution, many channels: the layers that split their contraction
 ]
 
 
+@pytest.fixture
+def conv_mode(request, monkeypatch):
+    """b3: forward / input gradient on the bf16 matrix cores with exact splits (the default), general kernel only;
+    b3tile: its spatially tiled 3x3 stride-1 kernel wherever the operands allow; f32: the fp32-MFMA kernels."""
+    mode = request.param
+    monkeypatch.setattr(hip_ops, "CONV_B3", mode != "f32")
+    assert _lib.load().evf_conv_tile_select(2 if mode.startswith("b3tile") else 0) == 0
+    assert _lib.load().evf_conv_split_select(3 if mode.endswith("split") else 0) == 0  # (deterministic slab reduction)
+    yield mode
+    _lib.load().evf_conv_tile_select(-1)
+    _lib.load().evf_conv_split_select(0)
+
+
+@pytest.mark.parametrize("conv_mode", ["b3", "b3tile", "b3split", "b3tilesplit", "f32"], indirect=True)
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d_forward_dgrad_wgrad_vs_cpu(case):
+def test_conv2d_forward_dgrad_wgrad_vs_cpu(case, conv_mode):
     B, Cin, Cout, H, W, k, s = case
     gen = torch.Generator().manual_seed(hash(case) % 1000)
     x = torch.randn(B, Cin, H, W, generator=gen)
@@ -91,6 +110,38 @@ def test_conv2d_forward_dgrad_wgrad_vs_cpu(case):
     close(N(xd.grad), xr.grad.numpy(), 1e-5, "dgrad")
     close(N(wd.grad), wr.grad.numpy(), 2e-5, "wgrad")
     close(N(bd.grad), br.grad.numpy(), 2e-5, "bias grad")
+
+
+@pytest.mark.parametrize("conv_mode", ["b3", "b3tile"], indirect=True)
+@pytest.mark.parametrize("case", [(2, 130, 32, 20, 24, 3, 1), (1, 64, 128, 16, 16, 3, 2), (2, 66, 40, 9, 11, 5, 1),
+                                  (2, 132, 64, 40, 70, 3, 1)])
+def test_conv2d_b3_spike_inputs_take_the_three_term_product_without_changing_results(case, conv_mode):
+    """The wave vote of evf_conv_b3gen.hip: binary spikes / small integers / bilinear blends run 3 products per 16
+    channels, real-valued channels 6 -- decoder-like inputs mix both (2 flow channels + spikes).  Either way the result
+    is the fp32-rounded exact convolution: compare with float64.  (The tiled kernel votes per block and 16-channel
+    group, the general one per wave and chunk.)"""
+    B, Cin, Cout, H, W, k, s = case
+    gen = torch.Generator().manual_seed(11)
+    w = torch.randn(Cout, Cin, k, k, generator=gen) * 0.2
+    spikes = (torch.rand(B, Cin, H, W, generator=gen) < 0.2).float()
+    blend = spikes + torch.randint(0, 3, (B, Cin, H, W), generator=gen).float() / 16.0
+    mixed = spikes.clone()
+    mixed[:, :2] = torch.randn(B, 2, H, W, generator=gen)
+    for name, x in (("spikes", spikes), ("blend", blend), ("mixed", mixed)):
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), None, stride=s, padding=k // 2).numpy()
+        y = hip_ops.conv_act(object(), G(x.numpy()), G(w.numpy()), None, stride=s, activation=None)
+        scale = np.abs(ref).max()
+        assert np.abs(N(y) - ref).max() <= 4e-7 * scale * np.sqrt(Cin * k * k / 16.0), name
+    # the vote is an optimisation, never a different result: an inexact value far away (another wave's pixels) leaves
+    # every output outside its receptive field bit-identical
+    a = spikes.clone()
+    b = spikes.clone()
+    b[0, 0, 0, 0] = 0.3
+    ya = N(hip_ops.conv_act(object(), G(a.numpy()), G(w.numpy()), None, stride=s, activation=None))
+    yb = N(hip_ops.conv_act(object(), G(b.numpy()), G(w.numpy()), None, stride=s, activation=None))
+    r = k // 2 // s + 1
+    assert np.array_equal(ya[:, :, r:, :], yb[:, :, r:, :]) and np.array_equal(ya[1:], yb[1:])
+    assert not np.array_equal(ya[0, :, 0, 0], yb[0, :, 0, 0])
 
 
 def test_conv_bad_arguments_fail_loudly():
@@ -170,7 +221,9 @@ def test_g6_cells_forward_backward_on_gpu(fix, n):
         assert np.array_equal(N(out)[safe], g[tag + "_out"][safe]), c
         assert safe.mean() > 0.999
         assert np.array_equal(N(out), g[tag + "_out"]), c  # none of the golden cases is borderline
-        np.testing.assert_allclose(N(new), new_ref, rtol=1e-5, atol=2e-6, err_msg=str(c))
+        # (5x5 / 7x7 on real-valued inputs: 25-49 x Cin products per output, each exact up to the terms below 2^-24 of its
+        # leading one that the six-term bf16 product drops -- about twice the round-off of an fp32 accumulation)
+        np.testing.assert_allclose(N(new), new_ref, rtol=1e-5, atol=2e-6 if c.get("ksz", 3) == 3 else 1e-5, err_msg=str(c))
         params = dict(cell.named_parameters())
         grads = torch.autograd.grad([out, new], [x, st] + list(params.values()), [G(g[tag + "_g_out"]), G(g[tag + "_g_new"])],
                                     allow_unused=True)
