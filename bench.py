@@ -110,9 +110,11 @@ def make_windows(rank, n_pool, dev):
         lists = []
         for k in range(PASSES):
             seed0 = synthetic.seed_for(CONFIG_ID, rank, 0) + 100000 * wdx + 1000 * k
-            ev = synthetic.event_list_batch(B_PER_GPU, EV_PER_PASS, H, W, seed0)
-            lists.append(torch.from_numpy(ev).to(dev))
-        pool.append(lists)
+            lists.append(synthetic.event_list_batch(B_PER_GPU, EV_PER_PASS, H, W, seed0))
+        # one resident buffer [B,P,N,4] per window, the passes are its slices [:, p]: the binning kernel and the loss read the
+        # window in place (no torch.stack / torch.cat in the step)
+        window = torch.from_numpy(np.ascontiguousarray(np.stack(lists, 1))).to(dev)
+        pool.append([window[:, k] for k in range(PASSES)])
     return pool
 
 

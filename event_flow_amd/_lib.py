@@ -24,6 +24,7 @@ SIGNATURES = {
     "evf_device_count": [],
     "evf_events_to_image": [P, P, P, I, I, I, I, P, P],
     "evf_encode_events": [P, I, I, I, I, I, I, P, P, P, P, P],
+    "evf_encode_window": [P, I, I, I, I, I, I, I, I, P, P, P],
     "evf_iwe_splat": [P, P, P, P, P, P, I, I, I, I, I, F, F, F, I, I, P, P],
     "evf_get_interpolation": [P, P, I, I, I, I, F, F, I, P, P, P],
     "evf_interpolate": [P, P, P, I, I, I, I, I, P, P],
@@ -53,7 +54,7 @@ NETWORK_SIGNATURES = {
     "evf_head_lif_bwd_wgrad_slabs": [I, I, I],
     "evf_head_lif_bwd_wgrad": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, P, P, P, P, I, P],
     "evf_sum_rows": [P, I, I, I, P, P],
-    "evf_add_segments": [P, P, P, P, I, P],
+    "evf_add_segments": [P, P, P, P, I, I, P],
     "evf_pack_conv_weights_b3_multi": [P, P, P, I, P],
     "evf_reduce_slabs_multi": [P, P, I, I, I, P],
     "evf_lif_bwd_wgrad": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P, P, P, I, P],
@@ -78,7 +79,7 @@ NETWORK_SIGNATURES = {
     "evf_nchw_to_bits": [P, I, I, I, P, P],
     "evf_nhwc_to_nchw": [P, I, I, I, I, P, P],
     "evf_nchw_to_nhwc": [P, I, I, I, I, P, P],
-    "evf_clip_adam_step": [P, P, P, P, L, F, F, F, F, F, I, P, P],
+    "evf_clip_adam_step": [P, P, P, P, L, F, F, F, F, F, I, P, I, P],
     # general path (any channel count, NHWC fp32)
     "evf_conv2d_packed_size": [I, I, I, I],
     "evf_pack_conv2d_weight": [P, I, I, I, I, I, I, P, P],

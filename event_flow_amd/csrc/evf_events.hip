@@ -77,6 +77,58 @@ extern "C" int evf_encode_events(const float* ev, int B, int N, int H, int W, in
   return evf_status();
 }
 
+// All passes of a BPTT window in one launch.  ev [B][P][N] rows (t, y, x, p) -- batch-major, so that the window's event
+// list [B][P*N] the loss reads is the same memory.  The network inputs come out pass-major (cnt [P][B][2][H][W], voxel
+// [P][B][nb][H][W]: one contiguous tensor per pass), the loss inputs batch-major (mask [B][P][H][W], pol [B][P*N][2]):
+// no torch.stack / torch.cat between the binning and its consumers.
+__global__ void k_encode_window(const float4* __restrict__ ev, int B, int P, int N, int H, int W, int nb, int round_ts,
+                                float* __restrict__ cnt, float* __restrict__ mask, float* __restrict__ voxel,
+                                float2* __restrict__ pol) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * P * N) return;
+  const long bp = i / N;
+  const int b = (int)(bp / P), pp = (int)(bp - (long)b * P);
+  const long s = (long)pp * B + b;  // pass-major sample index of the network inputs
+  const float4 e = ev[i];
+  const float p = e.w;
+  if (pol) pol[i] = make_float2(p > 0.f ? p : 0.f, p < 0.f ? -p : 0.f);
+  if (p == 0.f) return;
+  const long x = (long)e.z, y = (long)e.y;
+  if (x < 0 || x >= W || y < 0 || y >= H) return;
+  const long HW = (long)H * W, px = y * W + x;
+  if (cnt) evf_atomic_add(cnt + (s * 2 + (p > 0.f ? 0 : 1)) * HW + px, p * p);
+  if (mask) mask[bp * HW + px] = fabsf(p);
+  if (voxel) {
+    float t = e.x * (float)(nb - 1);
+    if (round_ts) t = rintf(t);
+    for (int k = 0; k < nb; ++k) {
+      const float w = fmaxf(0.f, 1.0f - fabsf(t - (float)k));
+      if (w != 0.f) evf_atomic_add(voxel + (s * nb + k) * HW + px, p * w);
+    }
+  }
+}
+
+// dense: ONE allocation [cnt | voxel | mask] (the parts `want` selects: 1 cnt, 2 voxel, 4 mask), zero-filled here in one go
+extern "C" int evf_encode_window(const float* ev, int B, int P, int N, int H, int W, int num_bins, int round_ts, int want,
+                                 float* dense, float* pol, void* stream) {
+  if (!ev || B <= 0 || P <= 0 || N < 0 || H <= 0 || W <= 0 || ((want & 2) && num_bins < 1) || ((want & 7) && !dense))
+    return EVF_EINVAL;
+  hipStream_t st = EVF_STREAM(stream);
+  const size_t HW = (size_t)H * W, S = (size_t)B * P;
+  float* cnt = (want & 1) ? dense : nullptr;
+  float* voxel = (want & 2) ? dense + ((want & 1) ? S * 2 * HW : 0) : nullptr;
+  float* mask = (want & 4) ? dense + ((want & 1) ? S * 2 * HW : 0) + ((want & 2) ? S * num_bins * HW : 0) : nullptr;
+  const size_t total = ((want & 1) ? S * 2 * HW : 0) + ((want & 2) ? S * num_bins * HW : 0) + ((want & 4) ? S * HW : 0);
+  if (total) {
+    const int rc = evf_hip(hipMemsetAsync(dense, 0, sizeof(float) * total, st));
+    if (rc) return rc;
+  }
+  if (N == 0) return EVF_OK;
+  hipLaunchKernelGGL(k_encode_window, dim3(evf_cdiv((long)B * P * N, 256)), dim3(256), 0, st, (const float4*)ev, B, P, N, H, W,
+                     num_bins, round_ts, cnt, mask, voxel, (float2*)pol);
+  return evf_status();
+}
+
 // --------------------------------------------------------------------------
 // warp + splat of one event into up to four image channels
 //   I0 += w*a0, I1 += w*a1, T0 += (w*tau)*a0, T1 += (w*tau)*a1

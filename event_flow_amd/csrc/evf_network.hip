@@ -837,12 +837,14 @@ struct AddSegs {
   int off[32];
   int n[32];
 };
-__global__ void k_add_segments(const float* __restrict__ src, AddSegs sg) {
+__global__ void k_add_segments(float* __restrict__ src, AddSegs sg, int clear) {
   const int k = blockIdx.y;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < sg.n[k]; i += gridDim.x * blockDim.x)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < sg.n[k]; i += gridDim.x * blockDim.x) {
     sg.dst[k][i] += src[sg.off[k] + i];
+    if (clear) src[sg.off[k] + i] = 0.f;  // a persistent accumulator is handed back zeroed
+  }
 }
-extern "C" int evf_add_segments(const float* src, void* const* dst, const int* off, const int* n, int nseg, void* stream) {
+extern "C" int evf_add_segments(float* src, void* const* dst, const int* off, const int* n, int nseg, int clear, void* stream) {
   if (!src || !dst || !off || !n || nseg <= 0 || nseg > 32) return EVF_EINVAL;
   AddSegs sg;
   int nmax = 1;
@@ -853,7 +855,7 @@ extern "C" int evf_add_segments(const float* src, void* const* dst, const int* o
     if (sg.n[k] > nmax) nmax = sg.n[k];
   }
   hipLaunchKernelGGL(k_add_segments, dim3(evf_cdiv(nmax, 256) < 8 ? evf_cdiv(nmax, 256) : 8, nseg), dim3(256), 0,
-                     EVF_STREAM(stream), src, sg);
+                     EVF_STREAM(stream), src, sg, clear);
   return evf_status();
 }
 
@@ -1267,10 +1269,10 @@ __global__ void k_sumsq(const float* __restrict__ g, long n, float* __restrict__
   }
 }
 
-__global__ void k_clip_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__global__ void k_clip_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long n, float max_norm, float lr, float b1, float b2,
                             float host_step_size, float host_bc2_sqrt, float eps, const float* __restrict__ ws,
-                            int device_step) {
+                            int device_step, int zero_grad) {
   // clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
   float coef = 1.f;
   if (max_norm > 0.f) coef = fminf(1.f, max_norm / (sqrtf(ws[0]) + 1e-6f));
@@ -1290,12 +1292,13 @@ __global__ void k_clip_adam(float* __restrict__ p, const float* __restrict__ g, 
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] = p[i] - step_size * (mi / denom);
+    if (zero_grad) g[i] = 0.f;  // optimizer.zero_grad() of the next step, without its fill kernel
   }
 }
 
-extern "C" int evf_clip_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float max_norm,
+extern "C" int evf_clip_adam_step(float* param, float* grad, float* m, float* v, int64_t n, float max_norm,
                                   float lr, float beta1, float beta2, float eps, int step, float* norm_ws,
-                                  void* stream) {
+                                  int zero_grad, void* stream) {
   if (!param || !grad || !m || !v || !norm_ws || n <= 0) return EVF_EINVAL;
   hipStream_t st = EVF_STREAM(stream);
   const int device_step = step <= 0;  // step <= 0: use (and advance) the counter in norm_ws[1]
@@ -1309,6 +1312,6 @@ extern "C" int evf_clip_adam_step(float* param, const float* grad, float* m, flo
     bc2 = 1.0 - pow((double)beta2, (double)step);
   }
   hipLaunchKernelGGL(k_clip_adam, dim3(nblk), dim3(256), 0, st, param, grad, m, v, (long)n, max_norm, lr, beta1, beta2,
-                     (float)((double)lr / bc1), (float)sqrt(bc2), eps, norm_ws, device_step);
+                     (float)((double)lr / bc1), (float)sqrt(bc2), eps, norm_ws, device_step, zero_grad);
   return evf_status();
 }

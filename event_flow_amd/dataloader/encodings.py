@@ -83,9 +83,75 @@ def encode_event_list(event_list, num_bins, sensor_size, round_ts=False, want=("
     return out
 
 
+def window_base(tensors):
+    """If the P tensors [B, ...] are the slices base[:, p] of ONE contiguous fp32 tensor base [B, P, ...] (in order,
+    nothing in between), return that base, else None.  Lets the window's consumers read [B, P * ...] in place instead
+    of torch.cat-ing the passes back together."""
+    t0 = tensors[0]
+    P = len(tensors)
+    if t0.dtype != torch.float32 or t0.dim() < 2:
+        return None
+    inner = 1
+    for d in t0.shape[1:]:
+        inner *= d
+    want = (P * inner,) + tuple(torch.empty(t0.shape[1:]).stride())  # a row of P contiguous slices per batch element
+    base_ptr, store = t0.data_ptr(), t0.untyped_storage().data_ptr()
+    for p, t in enumerate(tensors):
+        if (t.dtype != t0.dtype or t.device != t0.device or t.shape != t0.shape or tuple(t.stride()) != want
+                or t.untyped_storage().data_ptr() != store or t.data_ptr() != base_ptr + 4 * p * inner):
+            return None
+    if t0.shape[0] > 1 and t0.stride(0) != P * inner:
+        return None
+    return torch.as_strided(t0, (t0.shape[0], P) + tuple(t0.shape[1:]), (P * inner, inner) + want[1:])
+
+
+def encode_window(ev, num_bins, sensor_size, round_ts=False, want=("cnt", "mask", "voxel", "pol")):
+    """All P passes of a BPTT window binned by ONE launch (+ one zero-fill).  ev [B,P,N,4] float32, batch-major.
+    Returns P dicts like encode_event_list's whose tensors are views of four window buffers: the network inputs
+    (event_cnt / event_voxel) are one contiguous tensor per pass, the loss inputs (event_list, event_list_pol_mask,
+    event_mask) are the slices [:, p] of batch-major buffers -- the window's [B,P*N,4] event list, [B,P*N,2] polarity
+    mask and [B,P,H,W] mask stack exist without a torch.cat (loss/flow.py's record reads them in place)."""
+    _lib.require_gpu(ev, "encode_window")
+    if ev.dtype != torch.float32 or ev.dim() != 4 or ev.shape[3] != 4 or not ev.is_contiguous():
+        raise _lib.EvflowError("encode_window needs a contiguous float32 [B,P,N,4] tensor")
+    B, P, N, _ = ev.shape
+    H, W = int(sensor_size[0]), int(sensor_size[1])
+    dev = ev.device
+    HW = H * W
+    n_cnt = P * B * 2 * HW if "cnt" in want else 0
+    n_vox = P * B * num_bins * HW if "voxel" in want else 0
+    n_mask = B * P * HW if "mask" in want else 0
+    dense = torch.empty(max(n_cnt + n_vox + n_mask, 1), dtype=torch.float32, device=dev)
+    pol = torch.empty((B, P, N, 2), dtype=torch.float32, device=dev) if "pol" in want else None
+    flags = (1 if n_cnt else 0) | (2 if n_vox else 0) | (4 if n_mask else 0)
+    _lib.call("evf_encode_window", _lib.ptr(ev), B, P, N, H, W, int(num_bins), 1 if round_ts else 0, flags,
+              _lib.ptr(dense) if flags else None, _lib.ptr(pol))
+    cnt = dense[:n_cnt].view(P, B, 2, H, W) if n_cnt else None
+    vox = dense[n_cnt:n_cnt + n_vox].view(P, B, num_bins, H, W) if n_vox else None
+    mask = dense[n_cnt + n_vox:n_cnt + n_vox + n_mask].view(B, P, H, W) if n_mask else None
+    out = []
+    for p in range(P):
+        d = {"event_list": ev[:, p]}
+        if cnt is not None:
+            d["event_cnt"] = cnt[p]
+        if vox is not None:
+            d["event_voxel"] = vox[p]
+        if mask is not None:
+            d["event_mask"] = mask[:, p:p + 1]
+        if pol is not None:
+            d["event_list_pol_mask"] = pol[:, p]
+        out.append(d)
+    return out
+
+
 def encode_event_lists(event_lists, num_bins, sensor_size, round_ts=False, want=("cnt", "mask", "voxel", "pol")):
     """encode_event_list for all passes of a window at once: the P lists [B,N,4] are binned as ONE batch of P*B
-    samples (one zero-fill + one kernel instead of P of each) and handed back as P dicts of views."""
+    samples (one zero-fill + one kernel instead of P of each) and handed back as P dicts of views.  Lists that are
+    the slices [:, p] of one [B,P,N,4] buffer go through encode_window (no torch.stack, loss inputs in place)."""
+    if len(event_lists) >= 2:
+        base = window_base(list(event_lists))
+        if base is not None and base.dim() == 4 and base.shape[3] == 4:
+            return encode_window(base, num_bins, sensor_size, round_ts, want)
     lists = [_f32(e) for e in event_lists]
     if len(lists) < 2 or any(e.shape != lists[0].shape for e in lists):
         return [encode_event_list(e, num_bins, sensor_size, round_ts, want) for e in lists]

@@ -56,16 +56,50 @@ class _WindowRecord:
         return sum(e.shape[1] for e in self.events)
 
     def packed(self):
-        """(ev [B,M,4], pol [B,M,2], ev_pass int32 [M]) concatenated over passes."""
+        """(ev [B,M,4], pol [B,M,2], ev_pass int32 [M]) concatenated over passes -- in place when the passes are
+        the slices of one window buffer (dataloader.encodings.encode_window), else by torch.cat."""
         if self._cache is None:
-            ev = torch.cat([e.to(torch.float32) for e in self.events], 1).contiguous()
-            pol = torch.cat([p.to(torch.float32) for p in self.pol], 1).contiguous()
+            ev = _in_place(self.events, 1)
+            if ev is None:
+                ev = torch.cat([e.to(torch.float32) for e in self.events], 1).contiguous()
+            pol = _in_place(self.pol, 1)
+            if pol is None:
+                pol = torch.cat([p.to(torch.float32) for p in self.pol], 1).contiguous()
             ev_pass = _pass_index(tuple(e.shape[1] for e in self.events), ev.device)
             self._cache = (ev, pol, ev_pass)
         return self._cache
 
     def mask_stack(self):
+        m = _in_place(self.masks, 1)
+        if m is not None:
+            return m
         return torch.cat([m.to(torch.float32) for m in self.masks], 1).contiguous()  # [B,P,H,W]
+
+
+def _in_place(tensors, dim):
+    """The concatenation of `tensors` along dim 1 WITHOUT a copy, if they are consecutive slices of one buffer."""
+    from ..dataloader.encodings import window_base
+
+    if len(tensors) < 2:
+        return None
+    base = window_base(tensors)  # [B, P, n, ...]
+    if base is None:
+        return None
+    return base.reshape((base.shape[0], base.shape[1] * base.shape[2]) + tuple(base.shape[3:]))
+
+
+def _stacked_in_place(tensors):
+    """torch.stack(tensors) WITHOUT a copy, if they are consecutive contiguous slices of one buffer."""
+    t0 = tensors[0]
+    if t0.dtype != torch.float32 or not t0.is_contiguous():
+        return None
+    n = t0.numel()
+    store = t0.untyped_storage().data_ptr()  # (neighbours in memory that are separate allocations do not count)
+    for k, t in enumerate(tensors):
+        if (t.dtype != t0.dtype or t.device != t0.device or t.shape != t0.shape or not t.is_contiguous()
+                or t.untyped_storage().data_ptr() != store or t.data_ptr() != t0.data_ptr() + 4 * k * n):
+            return None
+    return torch.as_strided(t0, (len(tensors),) + tuple(t0.shape), (n,) + tuple(t0.stride()))
 
 
 def _mask_union(masks):
@@ -107,7 +141,10 @@ class _CMLoss(torch.autograd.Function):
         B, M = ev.shape[0], ev.shape[1]
         H, W = meta["res"]
         dev = ev.device
-        fl = torch.stack([f.to(torch.float32) for f in flows]).view(S, Pm, B, 2, H, W).contiguous()
+        fl = _stacked_in_place(flows)  # (the engine writes a window's flow maps into one buffer)
+        if fl is None:
+            fl = torch.stack([f.to(torch.float32) for f in flows])
+        fl = fl.view(S, Pm, B, 2, H, W).contiguous()
         images = torch.empty((S, B, 8, H, W), dtype=torch.float32, device=dev)
         stats = torch.empty((S, B, 2, 2), dtype=torch.float32, device=dev)
         nblk = _lib.load().evf_cm_smooth_blocks(B, Pm, H, W)
@@ -197,7 +234,7 @@ class EventWarping(torch.nn.Module):
             return _mask_union(self._win.mask_stack())  # loss/flow.py:149-150
         if self.overwrite_intermediate:
             return self._win.mask_stack()
-        return self._win.masks[-1].to(torch.float32)
+        return self._win.masks[-1].to(torch.float32).contiguous()
 
     def forward(self):
         win = self._win

@@ -59,10 +59,14 @@ class _Window:
         self.gpt = [None] * n  # PLIF: dL/d(trace) carried to the previous pass
         self.gpt_has = [False] * n
         self.gP = None  # PLIF: dL/d(pooled pre-synaptic activity) of the layer being processed [B,H,W]
-        self.small = torch.zeros(eng.small_size, dtype=torch.float32, device=dev)
+        # small-parameter gradient accumulator: the engine's persistent buffer when FlatAdam owns the gradients (cleared by
+        # the kernel that consumes it, _finalize), else fresh zeros
+        self.small, self.small_persistent = eng._take_small(dev)
         self.slab_init = {}
-        self.token = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
+        self.token = eng._token(dev)  # (a leaf whose value is never read: only its autograd edge chains the passes)
         self.n_passes = 0
+        # flow maps of the window's passes in ONE buffer [cap,B,2,H,W]: the loss reads them in place (no torch.stack)
+        self.flow_buf = _f32((eng._flow_cap, B, 2, H, W), dev)
 
     def buf(self, lst, l):
         if lst[l] is None:
@@ -150,10 +154,35 @@ class FireNetEngine:
         self._packed = {}
         self._packed_key = None
         self._slabs = {}
+        self._small_buf = None  # persistent small-gradient accumulator (+ is it all zeros?)
+        self._small_clean = False
+        self._token0 = None
+        self._flow_cap = 16  # passes per window the flow buffer is sized for (grows with the windows seen)
+        self._flow_slot = None
 
     def _reg(self, name, t):
         self.params.append(t)
         self.pnames.append(name)
+
+    def _take_small(self, dev):
+        """-> (zeroed accumulator, persistent?).  Persistent only when every small parameter's gradient goes straight
+        into FlatAdam's buffer through evf_add_segments, which clears what it consumes."""
+        ok = hip_ops.DIRECT_PARAM_GRADS and all(
+            p.requires_grad and p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.is_cuda
+            for name, p in zip(self.pnames, self.params) if name in self.small_off)
+        if not ok:
+            return torch.zeros(self.small_size, dtype=torch.float32, device=dev), False
+        if self._small_buf is None or self._small_buf.device != dev:
+            self._small_buf = torch.zeros(self.small_size, dtype=torch.float32, device=dev)
+        elif not self._small_clean:  # (a window that never reached _finalize)
+            self._small_buf.zero_()
+        self._small_clean = False
+        return self._small_buf, True
+
+    def _token(self, dev):
+        if self._token0 is None or self._token0.device != dev:
+            self._token0 = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
+        return self._token0
 
     def _act_width(self, i):
         """Surrogate width as a host float; read back once per buffer version (a
@@ -280,10 +309,17 @@ class FireNetEngine:
         if is_first:
             self._win = _Window(self, B, H, W, x_in.device)
         win = self._win
+        self._flow_slot = win.flow_buf[win.n_passes] if win.n_passes < win.flow_buf.shape[0] else None
         flow, token = _FireNetPass.apply(self, win, is_first, x_in, win.token, *self.params)
+        self._flow_slot = None
         win.token = token
         win.n_passes += 1
+        self._flow_cap = max(self._flow_cap, win.n_passes)
         return flow
+
+    def _flow_out(self, B, H, W, dev):
+        slot, self._flow_slot = self._flow_slot, None
+        return slot if slot is not None else _f32((B, 2, H, W), dev)
 
     def _forward_pass(self, x_in, states, record):
         B, Cin, H, W = x_in.shape
@@ -341,7 +377,7 @@ class FireNetEngine:
                 wrec = self._packed[(i, "rec", fmt)] if c.recurrent else None
                 if fmt == "b3" and i == len(self.cells) - 1 and PRED_FUSED:
                     # last layer: the prediction head runs in this kernel's epilogue
-                    flow = _f32((B, 2, H, W), dev)
+                    flow = self._flow_out(B, H, W, dev)
                     _lib.call("evf_conv_lif_fwd_b3_pred", _lib.ptr(in_bits), _lib.ptr(self._packed[(i, "ff", fmt)]), _lib.ptr(wrec),
                               _lib.ptr(leak), _lib.ptr(thresh), _lib.ptr(v_prev), _lib.ptr(z_prev), B, H, W,
                               1 if c.hard_reset else 0, _lib.ptr(v_out), _lib.ptr(z_out), _lib.ptr(zT_out),
@@ -356,7 +392,7 @@ class FireNetEngine:
             in_bits, in_bitsT = z_out, zT_out
             new_states.append((v_out, z_out, zT_out, pt_out) if plif else (v_out, z_out, zT_out))
         if flow is None:
-            flow = _f32((B, 2, H, W), dev)
+            flow = self._flow_out(B, H, W, dev)
             _lib.call("evf_pred_fwd", _lib.ptr(in_bits), _lib.ptr(self._flat["pred.w"]), _lib.ptr(self._flat["pred.b"]), B, H, W,
                       _lib.ptr(flow))
         tape = {"x_in": x_in, "layers": layers, "flow": flow} if record else None
@@ -557,6 +593,8 @@ class FireNetEngine:
             ptrs = (ctypes.c_void_p * 32)(*[t.data_ptr() for t in seg_dst[lo:hi]])
             offs = (ctypes.c_int * 32)(*seg_src[lo:hi])
             lens = (ctypes.c_int * 32)(*seg_n[lo:hi])
-            _lib.call("evf_add_segments", _lib.ptr(win.small), ptrs, offs, lens, hi - lo)
+            _lib.call("evf_add_segments", _lib.ptr(win.small), ptrs, offs, lens, hi - lo, 1 if win.small_persistent else 0)
+        if win.small_persistent:
+            self._small_clean = True
         self._last_window = win
         return grads

@@ -54,7 +54,12 @@ def from_nhwc(t):
     return t.permute(0, 3, 1, 2)
 
 
+_POISON_NEW = os.environ.get("EVF_DEBUG_POISON_NEW", "0") == "1"
+
+
 def _new(shape, dev):
+    if _POISON_NEW:  # debugging aid: a kernel that leaves part of its output unwritten (or reads it) shows up as NaNs
+        return torch.full(shape, float("nan"), dtype=torch.float32, device=dev)
     return torch.empty(shape, dtype=torch.float32, device=dev)
 
 
@@ -154,6 +159,7 @@ def conv_dgrad(g_y, wtp, g_x, Cin, Cout, k, stride, accumulate=0):
 
 
 _SCRATCH = {}
+_POISON = os.environ.get("EVF_DEBUG_POISON_SCRATCH", "0") == "1"
 
 
 def _scratch(n, dev):
@@ -162,6 +168,8 @@ def _scratch(n, dev):
     if buf is None or buf.numel() < n:
         buf = _new((max(int(n), 1),), dev)
         _SCRATCH[dev] = buf
+    if _POISON:  # debugging aid: a kernel that reads scratch it did not write turns its result into NaNs
+        buf.fill_(float("nan"))
     return buf
 
 

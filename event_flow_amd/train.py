@@ -43,12 +43,21 @@ class FlatAdam:
             off += k
         self.lr, self.betas, self.eps, self.clip = lr, betas, eps, clip
         self.steps = 0
+        self._grad_clean = False  # True between step() (which clears the gradient as it consumes it) and the next backward
         hip_ops.DIRECT_PARAM_GRADS = True  # every .grad is a view of flat_grad: the backward kernels add into it in place
 
     def zero_grad(self):
-        self.flat_grad.zero_()
+        # the fused step clears the buffer as it consumes it: zero_grad() right after step() (train_flow.py:163-164)
+        # needs no fill kernel.  A loop that runs a backward between step() and zero_grad() calls mark_grad_dirty().
+        if not self._grad_clean:
+            self.flat_grad.zero_()
+        self._grad_clean = False
         if any(p.grad is None for p in self.params):  # keep .grad bound to the flat buffer
             self._rebind()
+
+    def mark_grad_dirty(self):
+        """A backward pass is about to add into the flat gradient buffer."""
+        self._grad_clean = False
 
     def _rebind(self):
         off = 0
@@ -62,7 +71,8 @@ class FlatAdam:
         _lib.call("evf_clip_adam_step", _lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.m),
                   _lib.ptr(self.v), self.n, float(self.clip) if self.clip is not None else 0.0, float(self.lr),
                   float(self.betas[0]), float(self.betas[1]), float(self.eps), 0 if self.device_step else self.steps,
-                  _lib.ptr(self.norm_ws))
+                  _lib.ptr(self.norm_ws), 1)
+        self._grad_clean = True
         # the kernel rewrote the parameters behind torch's version counters: drop the
         # engine's packed-weight cache explicitly
         if hasattr(self.model, "invalidate_weight_cache"):
@@ -80,6 +90,16 @@ class FlatAdam:
         return float(self.norm_ws[0].sqrt())
 
 
+_UNIT = {}
+
+
+def _unit_gradient(loss):
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    if key not in _UNIT:
+        _UNIT[key] = torch.ones_like(loss)
+    return _UNIT[key]
+
+
 def window_backward(model, loss_function, optimizer, passes, dp=None):
     """First half of a window: the passes, the loss and its backward (train_flow.py:129-154).
     Leaves this rank's gradient in the optimizer's flat buffer and, with `dp`, the
@@ -92,8 +112,10 @@ def window_backward(model, loss_function, optimizer, passes, dp=None):
     if loss_function.overwrite_intermediate:
         loss_function.overwrite_intermediate_flow(x["flow"])
     loss = loss_function()
-    loss.backward()
-    if dp is not None:
+    if hasattr(optimizer, "mark_grad_dirty"):
+        optimizer.mark_grad_dirty()
+    loss.backward(_unit_gradient(loss))  # (autograd would fill a fresh ones_like(loss) per step)
+    if dp is not None and dp.world > 1:
         dp.stage(optimizer.comm, loss)
     return loss
 
@@ -101,13 +123,16 @@ def window_backward(model, loss_function, optimizer, passes, dp=None):
 def window_apply(model, loss_function, optimizer, loss, dp=None):
     """Second half: clip + Adam on the (reduced) gradient, state detach, loss reset
     (train_flow.py:157-171).  Returns the 0-d (global) loss tensor."""
-    if dp is not None:
+    staged = dp is not None and dp.world > 1
+    if staged:
         loss, _ = dp.staged(optimizer.comm)
     optimizer.step()
     optimizer.zero_grad()
     model.detach_states()
     loss_function.reset()
-    return loss.detach().clone()
+    # (the staged loss is a view of the communication buffer, rewritten by the next step: hand out a copy; the local
+    # loss is a tensor of its own)
+    return loss.detach().clone() if staged else loss.detach()
 
 
 def train_window(model, loss_function, optimizer, passes, dp=None):
@@ -131,7 +156,7 @@ class GraphedWindowStep:
     """`train_window` for windows of a FIXED shape (P passes of [B,N,4] events) replayed from hipGraphs: one graph
     launch per optimizer step instead of ~260 kernel launches (the eager step is host bound at this size).
 
-    New windows are copied into a static event buffer (P*B*N*16 bytes) before each replay.  Two graphs are captured
+    New windows are copied into a static event buffer [B,P,N,4] (P*B*N*16 bytes) before each replay.  Two graphs are captured
     and replayed alternately so that the recurrent state crosses replays without copies (graph A starts from the
     buffers the warm-up left and ends in its own pool tensors, graph B starts from those and writes its last pass
     straight back; see FireNet.final_states_into).  With several ranks (`dp`) each step is two graphs around the one
@@ -158,7 +183,7 @@ class GraphedWindowStep:
         model.use_static_states(True)
 
     def _passes(self):
-        d = encode_event_lists(list(self.static_ev.unbind(0)), self.num_bins, self.res, want=self.want)
+        d = encode_event_lists(list(self.static_ev.unbind(1)), self.num_bins, self.res, want=self.want)
         for p in d:
             p.setdefault("event_voxel", None)
             p.setdefault("event_cnt", None)
@@ -186,7 +211,8 @@ class GraphedWindowStep:
             self.graphs.append((pre, post, loss, self.model.state_buffers()))
 
     def step(self, event_lists):
-        ev = torch.stack([e.to(torch.float32) for e in event_lists])
+        # static window buffer [B,P,N,4] (batch-major: the binning kernel and the loss read the window in place)
+        ev = torch.stack([e.to(torch.float32) for e in event_lists], 1)
         if self.static_ev is None:
             self.static_ev = torch.empty_like(ev)
         elif ev.shape != self.static_ev.shape:

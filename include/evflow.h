@@ -55,6 +55,12 @@ int evf_events_to_image(const float* xs, const float* ys, const float* vals, int
  * ignored everywhere. */
 int evf_encode_events(const float* ev, int B, int N, int H, int W, int num_bins, int round_ts,
                       float* cnt, float* mask, float* voxel, float* pol, void* stream);
+/* The same binning for all P passes of a BPTT window in one launch.  ev [B][P][N][4] is batch-major (the loss's window
+ * event list [B][P*N][4] is the same memory); network inputs come out pass-major, loss inputs batch-major:
+ *   dense = [cnt P*B*2*H*W | voxel P*B*num_bins*H*W | mask B*P*H*W] (the parts `want` selects: 1 cnt, 2 voxel, 4 mask; ONE
+ *   allocation, zero-filled here), pol [B][P*N][2] (null = not wanted). */
+int evf_encode_window(const float* ev, int B, int P, int N, int H, int W, int num_bins, int round_ts, int want,
+                      float* dense, float* pol, void* stream);
 
 /* ------------------------------------------------------------------ IWE
  * Generic warp + splat (utils/iwe.py:20-92 get_interpolation + interpolate).
@@ -310,8 +316,9 @@ int evf_head_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const flo
                            float act_width, float* g_cur, float* g_v_prev, float* g_leak, float* g_thresh,
                            float* slab, int accumulate, void* stream);
 /* dst[k][i] += src[off[k] + i], i < n[k], for nseg <= 32 segments (host arrays of device pointers / ints):
- * the per-channel gradients of a window added into the optimizer's flat gradient buffer in one launch. */
-int evf_add_segments(const float* src, void* const* dst, const int* off, const int* n, int nseg, void* stream);
+ * the per-channel gradients of a window added into the optimizer's flat gradient buffer in one launch.
+ * clear != 0: the consumed source elements are zeroed (a persistent accumulator, handed back clean). */
+int evf_add_segments(float* src, void* const* dst, const int* off, const int* n, int nseg, int clear, void* stream);
 /* dst[e] (+)= sum_k rows[k][e], e < n */
 int evf_sum_rows(const float* rows, int nrows, int n, int accumulate, float* dst, void* stream);
 /* Head weight gradient: dW[co][ci][ky][kx] += sum g_cur[pix][co]*x[b][ci][pix+tap] (torch layout out). */
@@ -514,10 +521,12 @@ int evf_lstm_bwd(const float* g_hidden, const float* g_cell, const float* gates,
  * parameter buffer.  norm_ws [2] float workspace: [0] receives the squared
  * gradient norm, [1] is a device-side step counter.  step >= 1: bias corrections
  * from the host value.  step <= 0: the kernel advances norm_ws[1] and uses it
- * (zero it once at start) -- needed when the step is replayed from a hipGraph. */
-int evf_clip_adam_step(float* param, const float* grad, float* m, float* v, int64_t n,
+ * (zero it once at start) -- needed when the step is replayed from a hipGraph.
+ * zero_grad != 0: the gradient buffer is cleared as it is consumed (optimizer.zero_grad(), train_flow.py:164, without a
+ * fill kernel of its own). */
+int evf_clip_adam_step(float* param, float* grad, float* m, float* v, int64_t n,
                        float max_norm, float lr, float beta1, float beta2, float eps, int step,
-                       float* norm_ws, void* stream);
+                       float* norm_ws, int zero_grad, void* stream);
 
 #ifdef __cplusplus
 }

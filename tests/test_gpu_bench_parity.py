@@ -304,6 +304,8 @@ def test_config4_evflownet_full_size_vs_oracle(scale):
     lossf = EventWarping(lc, DEV)
     d = passes[0]
     out = model(d["event_voxel"], d["event_cnt"])
+    for f in out["flow"]:
+        f.retain_grad()
     lossf.event_flow_association(out["flow"], d["event_list"], d["event_list_pol_mask"], d["event_mask"])
     loss = lossf()
     loss.backward()
@@ -315,7 +317,7 @@ def test_config4_evflownet_full_size_vs_oracle(scale):
     opasses = [{k: v.detach().cpu() for k, v in d.items()}]
     oloss_t, oflows, ostates = otrain.forward_window("SpikingRecEVFlowNet", leaves, opasses, [None] * 10, (H, W),
                                                      loss_cfg={"flow_regul_weight": 0.001, "mask_output": True}, model_cfg={"kind": "lif"})
-    og = torch.autograd.grad(oloss_t, [leaves[k] for k in keys], allow_unused=True)
+    og = torch.autograd.grad(oloss_t, [leaves[k] for k in keys], allow_unused=True, retain_graph=True)
     nflip = ntot = 0
     per_state = []
     for s in range(10):
@@ -334,12 +336,15 @@ def test_config4_evflownet_full_size_vs_oracle(scale):
         worst = max(worst, float(np.linalg.norm(N(f) - fr) / max(np.linalg.norm(fr), 1e-20)))
     lrel = abs(float(loss.detach()) - float(oloss_t.detach())) / abs(float(oloss_t.detach()))
     num = den = 0.0
+    per_key = []
     for k, gref in zip(keys, og):
         p = dict(model.named_parameters())[k]
         ref = gref.numpy() if gref is not None else np.zeros(tuple(p.shape), np.float32)
         got = N(p.grad) if p.grad is not None else np.zeros_like(ref)
         num, den = num + float(((got - ref) ** 2).sum()), den + float((ref ** 2).sum())
+        per_key.append((float(np.sqrt(((got - ref) ** 2).sum())), float(np.sqrt((ref ** 2).sum())), k))
     grel = np.sqrt(num) / max(np.sqrt(den), 1e-20)
+    print("  largest gradient differences (|diff|, |ref|, parameter):", sorted(per_key, reverse=True)[:6])
     fmax = max(float(fr.detach().abs().max()) for fr in oflows[0])
     print(f"[config 4 full size, thresholds x{scale}] flips {nflip} of {ntot}; flow rel-L2 (worst of 4 scales) {worst:.3e} (max |flow| {fmax:.3e}); "
           f"loss {float(loss.detach()):.8f} vs {float(oloss_t.detach()):.8f} (rel {lrel:.2e}); gradient rel-L2 {grel:.3e} (|g| {np.sqrt(den):.4e})")
@@ -350,7 +355,33 @@ def test_config4_evflownet_full_size_vs_oracle(scale):
     first_n = next((n_ for f, _, n_ in per_state if f), 1)
     assert first <= 5e-6 * first_n, per_state
     if nflip == 0:
-        assert worst <= 1e-4 and lrel <= 1e-5 and grel <= 1e-3, (worst, lrel, grel)
+        # No spike differs and the flow maps agree to fp32 round-off -- but the DERIVATIVE of the contrast loss w.r.t. the
+        # flow is discontinuous (an event whose warped position crosses a pixel boundary changes its four bilinear taps,
+        # utils/iwe.py:48-62): a 1e-7 difference in the flow moves a handful of the 400 k events across a boundary and the
+        # gradient by sqrt(handful / events) ~ 1 % (measured: the ORACLE's own dL/dflow on our flow maps differs by 2 % from
+        # its dL/dflow on its flow maps).  So the two derivatives are checked where each is well defined:
+        assert worst <= 1e-4 and lrel <= 1e-5 and grel <= 5e-2, (worst, lrel, grel)
+        # (1) loss derivative: the oracle's loss on OUR flow maps (as leaves) against our dL/dflow
+        from oracle import loss as oloss_mod
+
+        win = oloss_mod.Window((H, W))
+        leaf = [f.detach().cpu().clone().requires_grad_(True) for f in out["flow"]]
+        win.add(leaf, d["event_list"].cpu(), d["event_list_pol_mask"].cpu(), d["event_mask"].cpu())
+        oloss_mod.event_warping_loss(win, max(H, W), 0.001).backward()
+        for f, lf in zip(out["flow"], leaf):
+            assert np.linalg.norm(N(f.grad) - lf.grad.numpy()) <= 1e-4 * np.linalg.norm(lf.grad.numpy())
+        # (2) network derivative: OUR dL/dflow pushed through the oracle's network against our parameter gradients
+        og2 = torch.autograd.grad(list(oflows[0]), [leaves[k] for k in keys], grad_outputs=[f.grad.detach().cpu() for f in out["flow"]],
+                                  allow_unused=True)
+        num2 = den2 = 0.0
+        for k, gref in zip(keys, og2):
+            p = dict(model.named_parameters())[k]
+            ref = gref.numpy() if gref is not None else np.zeros(tuple(p.shape), np.float32)
+            got = N(p.grad) if p.grad is not None else np.zeros_like(ref)
+            num2, den2 = num2 + float(((got - ref) ** 2).sum()), den2 + float((ref ** 2).sum())
+        grel2 = np.sqrt(num2) / max(np.sqrt(den2), 1e-20)
+        print(f"  same upstream gradient through both networks: parameter gradient rel-L2 {grel2:.3e}")
+        assert grel2 <= 1e-3, grel2
     elif nflip <= 1e-6 * ntot:  # a few isolated flips: every flow map is exact except at those pixels
         assert worst <= 5e-3 and lrel <= 1e-5 and grel <= 1e-3, (worst, lrel, grel)
     else:  # high-activity stress case (thresholds x0.3): flips spread through 14 layers; loose aggregate bounds only

@@ -80,6 +80,45 @@ def test_encode_event_lists_all_passes_in_one_launch():
     assert float(out[2]["event_cnt"].sum()) == B * 700 and float(out[0]["event_cnt"].sum()) == B * n
 
 
+def test_encode_window_in_place_views_equal_the_per_list_encodings():
+    """Passes that are the slices [:, p] of one [B,P,N,4] buffer are binned by evf_encode_window: same bits as P
+    separate encode_event_list calls; the network inputs are contiguous per pass, and the loss's window tensors
+    ([B,P*N,4] events, [B,P*N,2] polarities, [B,P,H,W] masks) are the SAME memory, not copies."""
+    from event_flow_amd.loss.flow import _WindowRecord
+
+    B, P, n, H, W = 3, 4, 700, 40, 56
+    window = G(np.stack([synthetic.event_list_batch(B, n, H, W, 300 + k) for k in range(P)], 1))  # [B,P,N,4]
+    lists = [window[:, p] for p in range(P)]
+    assert enc.window_base(lists) is not None
+    many = enc.encode_event_lists(lists, 3, (H, W), want=("cnt", "mask", "voxel", "pol"))
+    rec = _WindowRecord()
+    for p, d in enumerate(many):
+        one = enc.encode_event_list(lists[p].contiguous(), 3, (H, W), want=("cnt", "mask", "voxel", "pol"))
+        assert set(d) == set(one)
+        for k in one:
+            assert d[k].shape == one[k].shape, k
+            if k == "event_voxel":  # (float atomics: summation order)
+                np.testing.assert_allclose(N(d[k]), N(one[k]), rtol=0, atol=1e-5)
+            else:
+                assert torch.equal(d[k], one[k]), k
+        assert d["event_cnt"].is_contiguous() and d["event_voxel"].is_contiguous()
+        rec.add([torch.zeros(B, 2, H, W, device=DEV)], d["event_list"], d["event_list_pol_mask"], d["event_mask"])
+    ev, pol, ev_pass = rec.packed()
+    assert ev.data_ptr() == window.data_ptr() and tuple(ev.shape) == (B, P * n, 4) and ev.is_contiguous()
+    assert torch.equal(ev, torch.cat(lists, 1))
+    assert pol.data_ptr() == many[0]["event_list_pol_mask"].data_ptr() and tuple(pol.shape) == (B, P * n, 2)
+    ms = rec.mask_stack()
+    assert ms.data_ptr() == many[0]["event_mask"].data_ptr() and tuple(ms.shape) == (B, P, H, W)
+    assert torch.equal(ms, torch.cat([d["event_mask"] for d in many], 1))
+    # separate tensors still take the copying path
+    sep = [t.clone() for t in lists]
+    assert enc.window_base(sep) is None
+    rec2 = _WindowRecord()
+    for t, d in zip(sep, many):
+        rec2.add([torch.zeros(B, 2, H, W, device=DEV)], t, d["event_list_pol_mask"].clone(), d["event_mask"].clone())
+    assert torch.equal(rec2.packed()[0], ev) and torch.equal(rec2.mask_stack(), ms)
+
+
 def test_encodings_edge_cases():
     H, W = 16, 20
     empty = torch.zeros(0, device=DEV)
