@@ -160,6 +160,16 @@ def ptr(t):
     return t.data_ptr()
 
 
+def ptr_strided(t):
+    """Device pointer of an NHWC activation whose channel dimension may be a slice of a wider tensor: everything but the
+    pixel stride must be dense (the kernels take the pixel stride as `ld`)."""
+    if t is None:
+        return None
+    if t.dim() != 4 or t.stride(3) != 1 or t.stride(1) != t.shape[2] * t.stride(2) or t.stride(0) != t.shape[1] * t.stride(1):
+        raise EvflowError("evflow kernels need NHWC tensors that are dense up to the pixel stride")
+    return t.data_ptr()
+
+
 # optional per-entry-point timing with HIP events on the launch stream (bench.py)
 _prof = None
 _PROF_VARIANT = {

@@ -64,6 +64,11 @@ int evf_conv3_b3t_plan(const float* src, int B, int H, int W, int K, int N, int 
 int evf_conv3_b3t_launch(const float* src, int lds, const void* wp, const float* bias, float* out, int ldo, int B, int H, int W,
                          int K, int N, int flip, int accumulate, int ksplit, hipStream_t st);
 
+// evf_wgrad_b3gen.hip: bf16 matrix-core weight gradient of the general 3x3 stride-1 convolution behind evf_conv2d_wgrad
+bool evf_wgrad9_b3_ok(const float* x, const float* gy, int Cin, int Cout, int ldx, int ldg);
+int evf_wgrad9_b3_launch(const float* x, int ldx, const float* gy, int ldg, float* slab, float* gbias, int* redo, int B, int H,
+                         int W, int Cin, int Cout, int nsplit, int CT, int NT, hipStream_t st);
+
 // evf_dgrad_ws.hip: wave-specialised input-gradient kernel behind evf_conv_dgrad_b3_f32[_pair]
 int evf_dgrad_ws_launch(const float* g_cur, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W, const float* g_P,
                         const uint32_t* x_bits, const void* wT2_b3, float* g_x2, int max_blocks, void* stream);

@@ -1,0 +1,240 @@
+// Weight gradient of the general 3x3 stride-1 convolution on the bf16 matrix cores:
+//   gw[co][ci][tap] = sum_px x[px (+) tap][ci] * g[px][co]
+// with the contraction over PIXELS (v_mfma_f32_32x32x16_bf16: 16 pixels per instruction against 2 for the fp32 MFMA of
+// k_wgrad9, evf_wgrad_gen.hip).  A spiking network's x is exactly representable in bf16 (binary spikes, event counts,
+// {0,1,2} residual sums, bilinear blends of those) and g = hi + mid + lo exactly (three bf16 planes), so
+//   sum x g = sum x g_hi + sum x g_mid + sum x g_lo      (three MFMAs of 32 cycles per 16 pixels, fp32 accumulation)
+// is the fp32 result up to summation order: 5.3x fewer matrix cycles.
+//
+// A lane of a bf16 MFMA holds EIGHT consecutive k (pixels) of one channel, so both operands are transposed on their way
+// into LDS ([channel][pixel] images, written by 2-byte stores while the tile is converted); the eight pixels of a lane
+// are one row of the 8 x 8 pixel tile.  Taps with dx = 1 read their row 16-byte aligned; dx = 0 / 2 are one pixel off:
+// one extra ds_read_b32 and four v_alignbit funnel shifts rebuild the fragment -- one x image serves all nine taps.
+//
+//   block   576 threads = 9 waves, one per tap: every tap has exactly one accumulator per block (no cross-wave reduction);
+//           a block owns 32 CT input x 32 NT output channels and walks a range of pixel tiles; partial sums go to the slabs
+//           [split][tap][ci][co] k_wgrad_reduce sums (same layout as k_wgrad9)
+//   x not exactly representable (a decoder's two flow channels, analog networks): the block raises redo[ci tile] and the
+//           caller re-runs the fp32 kernel for exactly those channel tiles (k_wgrad9 exits at once for the others).
+#include "evf_common.h"
+#include "evf_split.h"
+
+typedef float w_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 w_bf16x8 __attribute__((ext_vector_type(8)));
+
+#define WB_T 8                    // tile rows = tile columns
+#define WB_HP ((WB_T + 2) * (WB_T + 2))  // 100 halo pixels
+#define WB_ROWB 48                // bytes per halo row and channel: element 7 + hc, 16-byte aligned at hc = 1
+#define WB_XP ((WB_T + 2) * WB_ROWB + 16)  // 496: channel pitch of the x image (conflict-free b128 fragment reads)
+#define WB_GP (WB_T * WB_T * 2 + 16)       // 144: channel pitch of a g plane
+
+struct WgB3Geo {
+  int B, H, W, Cin, Cout, ldx, ldg;
+  int tiles_x, tiles_y, tiles_per_split, n_ct;
+  long ntiles;
+};
+
+__device__ __forceinline__ int wb_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+template <int CT, int NT>
+__global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, const float* __restrict__ gy,
+                                                   float* __restrict__ slab, float* __restrict__ gbias, int* __restrict__ redo,
+                                                   WgB3Geo g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int XQ = 8 * CT, GQ = 8 * NT;                 // float4 per pixel
+  constexpr int NLX = (WB_HP * XQ + 575) / 576;           // x float4 loads per thread
+  constexpr int NLG = (WB_T * WB_T * GQ + 575) / 576;     // g float4 loads per thread
+  constexpr int GPL = 32 * NT * WB_GP;                    // bytes per g plane
+  char* s_x = smem;                                       // [32 CT channels][WB_XP]
+  char* s_g = smem + 32 * CT * WB_XP;                     // [3 planes][32 NT channels][WB_GP]
+  float* s_b = (float*)(s_g + 3 * GPL);                   // [32 NT] bias partial sums
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, row = lane & 31, kg = lane >> 5;
+  const int cit = blockIdx.y % g.n_ct, cot = blockIdx.y / g.n_ct;
+  const int ci0 = cit * 32 * CT, co0 = cot * 32 * NT;
+  const bool do_bias = gbias && cit == 0;
+  if (tid < 32 * NT) s_b[tid] = 0.f;
+
+  w_f32x16 acc[CT][NT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
+
+  float4 xr[NLX], gr[NLG];
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};  // this thread's output-channel quad (fixed: 576 % GQ == 0)
+  int inexact = 0;
+  int n_tx, n_ty, n_b;
+  {
+    const long t0 = (long)blockIdx.x * g.tiles_per_split;
+    n_tx = (int)(t0 % g.tiles_x);
+    const long t1 = t0 / g.tiles_x;
+    n_ty = (int)(t1 % g.tiles_y), n_b = (int)(t1 / g.tiles_y);
+  }
+  // (no uniform branches around the tile loads: a load under a branch is followed by s_waitcnt vmcnt(0))
+  auto prefetch = [&](bool want) {
+    const bool tok = want && n_b < g.B;
+    const int b = min(n_b, g.B - 1);
+    const int y0 = n_ty * WB_T, x0 = n_tx * WB_T;
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+      const int idx = tid + 576 * i, hp = idx / XQ, q = idx - hp * XQ;
+      const int hr = hp / (WB_T + 2), hc = hp - hr * (WB_T + 2);
+      const int sy = y0 + hr - 1, sx = x0 + hc - 1, c = ci0 + 4 * q;
+      const bool ok = tok && hp < WB_HP && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W && c + 4 <= g.Cin;
+      const float4 v = *(const float4*)(ok ? x + (((long)b * g.H + sy) * g.W + sx) * g.ldx + c : x);
+      xr[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NLG; ++i) {
+      const int idx = tid + 576 * i, px = idx / GQ, q = idx - px * GQ;
+      const int oy = y0 + (px >> 3), ox = x0 + (px & 7), c = co0 + 4 * q;
+      const bool ok = tok && px < WB_T * WB_T && oy < g.H && ox < g.W && c + 4 <= g.Cout;
+      const float4 v = *(const float4*)(ok ? gy + (((long)b * g.H + oy) * g.W + ox) * g.ldg + c : gy);
+      gr[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (++n_tx == g.tiles_x) {
+      n_tx = 0;
+      if (++n_ty == g.tiles_y) n_ty = 0, ++n_b;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+      const int idx = tid + 576 * i, hp = idx / XQ, q = idx - hp * XQ;
+      if (hp >= WB_HP) continue;
+      const int hr = hp / (WB_T + 2), hc = hp - hr * (WB_T + 2);
+      const uint32_t h01 = evf_pk_bf16(xr[i].x, xr[i].y), h23 = evf_pk_bf16(xr[i].z, xr[i].w);
+      // exactly representable?  (else this channel tile is redone in fp32)
+      inexact |= (int)(xr[i].x != __uint_as_float(h01 << 16)) | (int)(xr[i].y != __uint_as_float(h01 & 0xFFFF0000u)) |
+                 (int)(xr[i].z != __uint_as_float(h23 << 16)) | (int)(xr[i].w != __uint_as_float(h23 & 0xFFFF0000u));
+      char* p = s_x + (4 * q) * WB_XP + hr * WB_ROWB + (7 + hc) * 2;
+      *(uint16_t*)(p) = (uint16_t)h01;
+      *(uint16_t*)(p + WB_XP) = (uint16_t)(h01 >> 16);
+      *(uint16_t*)(p + 2 * WB_XP) = (uint16_t)h23;
+      *(uint16_t*)(p + 3 * WB_XP) = (uint16_t)(h23 >> 16);
+    }
+#pragma unroll
+    for (int i = 0; i < NLG; ++i) {
+      const int idx = tid + 576 * i, px = idx / GQ, q = idx - px * GQ;
+      if (px >= WB_T * WB_T) continue;
+      uint32_t h0, m0, l0, h1, m1, l1;
+      evf_split3_pair(gr[i].x, gr[i].y, h0, m0, l0);
+      evf_split3_pair(gr[i].z, gr[i].w, h1, m1, l1);
+      bs[0] += gr[i].x, bs[1] += gr[i].y, bs[2] += gr[i].z, bs[3] += gr[i].w;
+      char* p = s_g + (4 * q) * WB_GP + px * 2;
+      *(uint16_t*)(p) = (uint16_t)h0, *(uint16_t*)(p + WB_GP) = (uint16_t)(h0 >> 16);
+      *(uint16_t*)(p + 2 * WB_GP) = (uint16_t)h1, *(uint16_t*)(p + 3 * WB_GP) = (uint16_t)(h1 >> 16);
+      *(uint16_t*)(p + GPL) = (uint16_t)m0, *(uint16_t*)(p + GPL + WB_GP) = (uint16_t)(m0 >> 16);
+      *(uint16_t*)(p + GPL + 2 * WB_GP) = (uint16_t)m1, *(uint16_t*)(p + GPL + 3 * WB_GP) = (uint16_t)(m1 >> 16);
+      *(uint16_t*)(p + 2 * GPL) = (uint16_t)l0, *(uint16_t*)(p + 2 * GPL + WB_GP) = (uint16_t)(l0 >> 16);
+      *(uint16_t*)(p + 2 * GPL + 2 * WB_GP) = (uint16_t)l1, *(uint16_t*)(p + 2 * GPL + 3 * WB_GP) = (uint16_t)(l1 >> 16);
+    }
+  };
+
+  const int dy = wv / 3, dx = wv - 3 * dy;  // this wave's tap
+  prefetch(true);
+#pragma unroll 1
+  for (int it = 0; it < g.tiles_per_split; ++it) {
+    commit();
+    __syncthreads();
+    prefetch(it + 1 < g.tiles_per_split);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {  // 16 pixels = tile rows 2 ks, 2 ks + 1 (lane half kg)
+      const int r = 2 * ks + kg;
+      w_bf16x8 xa[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const char* p = s_x + (c * 32 + row) * WB_XP + (r + dy) * WB_ROWB;  // element 7 + hc at byte 14 + 2 hc
+        const uint4 q = *(const uint4*)(p + 16);                             // elements 8 .. 15 (hc 1 .. 8)
+        uint4 o;
+        if (dx == 1) {
+          o = q;
+        } else if (dx == 0) {  // elements 7 .. 14
+          const uint32_t d = *(const uint32_t*)(p + 12);
+          o.x = __builtin_amdgcn_alignbit(q.x, d, 16), o.y = __builtin_amdgcn_alignbit(q.y, q.x, 16);
+          o.z = __builtin_amdgcn_alignbit(q.z, q.y, 16), o.w = __builtin_amdgcn_alignbit(q.w, q.z, 16);
+        } else {  // elements 9 .. 16
+          const uint32_t d = *(const uint32_t*)(p + 32);
+          o.x = __builtin_amdgcn_alignbit(q.y, q.x, 16), o.y = __builtin_amdgcn_alignbit(q.z, q.y, 16);
+          o.z = __builtin_amdgcn_alignbit(q.w, q.z, 16), o.w = __builtin_amdgcn_alignbit(d, q.w, 16);
+        }
+        xa[c] = *(const w_bf16x8*)&o;
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const char* p = s_g + (t * 32 + row) * WB_GP + (16 * ks + 8 * kg) * 2;
+        const uint4 q0 = *(const uint4*)p, q1 = *(const uint4*)(p + GPL), q2 = *(const uint4*)(p + 2 * GPL);
+        const w_bf16x8 gh = *(const w_bf16x8*)&q0, gm = *(const w_bf16x8*)&q1, gl = *(const w_bf16x8*)&q2;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[c], gl, acc[c][t], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[c], gm, acc[c][t], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[c], gh, acc[c][t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: slab[split][tap][ci][co] (co fastest); wave = tap
+  float* sl = slab + (long)blockIdx.x * 9 * g.Cin * g.Cout;
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int co = co0 + t * 32 + row;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + c * 32 + wb_row(r, lane);
+        if (ci < g.Cin && co < g.Cout) sl[((long)wv * g.Cin + ci) * g.Cout + co] = acc[c][t][r];
+      }
+    }
+  if (__syncthreads_or(inexact) && tid == 0) atomicOr(redo + cit, 1);
+  if (do_bias) {
+    const int q = tid % GQ;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(s_b + 4 * q + j, bs[j]);
+    __syncthreads();
+    if (tid < 32 * NT && co0 + tid < g.Cout) evf_atomic_add(gbias + co0 + tid, s_b[tid]);
+  }
+}
+
+template <int CT, int NT>
+static void wb_go(const float* x, const float* gy, float* slab, float* gbias, int* redo, const WgB3Geo& g, int nsplit, int n_nt,
+                  hipStream_t st) {
+  const size_t smem = (size_t)32 * CT * WB_XP + 3 * 32 * NT * WB_GP + 32 * NT * sizeof(float);
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute((const void*)k_wgrad9_b3<CT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    once = true;
+  }
+  hipLaunchKernelGGL((k_wgrad9_b3<CT, NT>), dim3(nsplit, g.n_ct * n_nt), dim3(576), smem, st, x, gy, slab, gbias, redo, g);
+}
+
+// Can the bf16 kernel take this 3x3 stride-1 weight gradient?  (float4 tile loads of both operands)
+bool evf_wgrad9_b3_ok(const float* x, const float* gy, int Cin, int Cout, int ldx, int ldg) {
+  return Cin % 4 == 0 && ldx % 4 == 0 && Cout % 4 == 0 && ldg % 4 == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)gy) & 15) == 0;
+}
+
+// nsplit slabs [tap][ci][co] (every split written, also the empty ones); redo[n_ct] must be zero on entry
+int evf_wgrad9_b3_launch(const float* x, int ldx, const float* gy, int ldg, float* slab, float* gbias, int* redo, int B, int H,
+                         int W, int Cin, int Cout, int nsplit, int CT, int NT, hipStream_t st) {
+  WgB3Geo g;
+  g.B = B, g.H = H, g.W = W, g.Cin = Cin, g.Cout = Cout, g.ldx = ldx, g.ldg = ldg;
+  g.tiles_x = evf_cdiv(W, WB_T), g.tiles_y = evf_cdiv(H, WB_T);
+  g.ntiles = (long)B * g.tiles_x * g.tiles_y;
+  g.tiles_per_split = (int)evf_cdiv(g.ntiles, (long)nsplit);
+  g.n_ct = evf_cdiv(Cin, 32 * CT);
+  const int n_nt = evf_cdiv(Cout, 32 * NT);
+  if (CT == 2 && NT == 2)
+    wb_go<2, 2>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st);
+  else if (CT == 2)
+    wb_go<2, 1>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st);
+  else if (NT == 2)
+    wb_go<1, 2>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st);
+  else
+    wb_go<1, 1>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st);
+  return evf_status();
+}

@@ -14,6 +14,9 @@
 // stores, no atomics) and are summed by k_wgrad_reduce into the torch layout.
 //
 // 1x1, 5x5, 7x7 (k_conv2d_wgrad_f32): one tap per block (blockIdx.z), 4 waves split the pixel pairs, split-K + atomics.
+#include <stdlib.h>
+#include <string.h>
+
 #include "evf_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -330,8 +333,12 @@ struct Wg9Geo {
 // (no uniform branches around the tile loads: a load under a branch is followed by s_waitcnt vmcnt(0))
 template <int CT, int NT, int S, int VX, int VG>
 __global__ __launch_bounds__(512) void k_wgrad9(const float* __restrict__ x, const float* __restrict__ gy,
-                                                float* __restrict__ slab, float* __restrict__ gbias, Wg9Geo g) {
+                                                float* __restrict__ slab, float* __restrict__ gbias, Wg9Geo g,
+                                                const int* __restrict__ redo) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // second pass behind k_wgrad9_b3 (evf_wgrad_b3gen.hip): only the input-channel tiles it flagged as not exactly
+  // representable in bf16 are recomputed here
+  if (redo && redo[(blockIdx.y % g.n_ct)] == 0) return;
   constexpr int XW = 32 * CT, GW = 32 * NT, XQ = XW / 4, GQ = GW / 4;
   constexpr int MAXHP = S == 1 ? 102 : 195;               // halo pixels: max over the (TW, R) choices
   constexpr int NLX = (MAXHP * XQ + 511) / 512;           // x float4 loads per thread
@@ -605,11 +612,12 @@ extern "C" int64_t evf_conv2d_wgrad_ws(int B, int H, int W, int Cin, int Cout, i
   if (ksz == 1) return wg1_small_ok(Cin, Cout, ksz, stride, Cin, nullptr) ? (int64_t)WG1_BLOCKS * (Cout * Cin + Cout) : 0;
   if (ksz != 3) return 0;
   const Wg9Plan p = wg9_plan(B, H, W, Cin, Cout, stride, Cin, Cout);
-  return (int64_t)p.nsplit * 9 * Cin * Cout;
+  return (int64_t)p.nsplit * 9 * Cin * Cout + 64;  // (+ the bf16 kernel's per-channel-tile redo flags)
 }
 
 template <int CT, int NT, int S>
-static void wg9_launch(const float* x, const float* gy, float* slab, float* gbias, const Wg9Plan& p, hipStream_t st) {
+static void wg9_launch(const float* x, const float* gy, float* slab, float* gbias, const Wg9Plan& p, hipStream_t st,
+                       const int* redo = nullptr) {
   const Wg9Geo& g = p.g;
   dim3 grid(p.nsplit, g.n_ct * p.n_nt), block(512);
   constexpr int MAXHP = S == 1 ? 102 : 195;
@@ -619,7 +627,7 @@ static void wg9_launch(const float* x, const float* gy, float* slab, float* gbia
   const bool a16 = ((uintptr_t)x & 15) == 0, a8 = ((uintptr_t)x & 7) == 0;
   const bool gv = (g.ldg & 3) == 0 && (g.Cout & 3) == 0 && ((uintptr_t)gy & 15) == 0;
   const int vx = (g.Cin % 4 == 0 && g.ldx % 4 == 0 && a16) ? 4 : ((g.Cin % 2 == 0 && g.ldx % 2 == 0 && a8) ? 2 : 1);
-#define WG9_GO(VX_, VG_) hipLaunchKernelGGL((k_wgrad9<CT, NT, S, VX_, VG_>), grid, block, smem, st, x, gy, slab, gbias, g)
+#define WG9_GO(VX_, VG_) hipLaunchKernelGGL((k_wgrad9<CT, NT, S, VX_, VG_>), grid, block, smem, st, x, gy, slab, gbias, g, redo)
   if (gv) {
     if (vx == 4) WG9_GO(4, 4);
     else if (vx == 2) WG9_GO(2, 4);
@@ -640,8 +648,10 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
                                 float* ws, void* stream) {
   if (!x || !g_y || !g_w || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !EVF_KSZ_OK(ksz) ||
       (stride != 1 && stride != 2) || ldx < Cin || ldg < Cout || cin_off < 0 || cin_off >= cin_total ||
-      (!accumulate && (cin_off != 0 || Cin < cin_total)) || (ksz == 3 && !ws) || ((uintptr_t)g_y & 15))
+      (!(accumulate & 1) && (cin_off != 0 || Cin < cin_total)) || (ksz == 3 && !ws) || ((uintptr_t)g_y & 15))
     return EVF_EINVAL;
+  const bool analog = (accumulate & 2) != 0;  // the caller knows x is not spike-valued: no bf16 attempt
+  accumulate &= 1;
   hipStream_t st = EVF_STREAM(stream);
   if (!accumulate && g_bias) {
     const int rc = evf_hip(hipMemsetAsync(g_bias, 0, sizeof(float) * (size_t)Cout, st));
@@ -649,11 +659,25 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
   }
   if (ksz == 3) {
     const Wg9Plan p = wg9_plan(B, H, W, Cin, Cout, stride, ldx, ldg);
+    // stride 1: the bf16 matrix-core kernel first (exact for spike-valued inputs); the fp32 kernel then recomputes only the
+    // input-channel tiles it flagged.  EVF_WGRAD=f32 keeps the fp32 kernel alone.
+    static const bool b3 = !(getenv("EVF_WGRAD") && !strcmp(getenv("EVF_WGRAD"), "f32"));
+    const int* redo = nullptr;
+    float* bias_f32 = g_bias;
+    if (b3 && !analog && stride == 1 && p.g.n_ct <= 64 && evf_wgrad9_b3_ok(x, g_y, Cin, Cout, ldx, ldg)) {
+      int* flags = (int*)(ws + (long)p.nsplit * 9 * Cin * Cout);
+      int rc = evf_hip(hipMemsetAsync(flags, 0, sizeof(int) * p.g.n_ct, st));
+      if (rc) return rc;
+      rc = evf_wgrad9_b3_launch(x, ldx, g_y, ldg, ws, g_bias, flags, B, H, W, Cin, Cout, p.nsplit, p.CT, p.NT, st);
+      if (rc) return rc;
+      redo = flags;
+      bias_f32 = nullptr;  // (summed by the bf16 kernel from the exact fp32 gradients)
+    }
 #define WG9(CT_, NT_)                                                 \
   if (stride == 1)                                                    \
-    wg9_launch<CT_, NT_, 1>(x, g_y, ws, g_bias, p, st);               \
+    wg9_launch<CT_, NT_, 1>(x, g_y, ws, bias_f32, p, st, redo);       \
   else                                                                \
-    wg9_launch<CT_, NT_, 2>(x, g_y, ws, g_bias, p, st)
+    wg9_launch<CT_, NT_, 2>(x, g_y, ws, bias_f32, p, st, redo)
     if (p.CT == 2 && p.NT == 2) {
       WG9(2, 2);
     } else if (p.CT == 2) {

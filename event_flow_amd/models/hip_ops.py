@@ -173,11 +173,25 @@ def _scratch(n, dev):
     return buf
 
 
-def conv_wgrad(x, g_y, g_w, g_b, Cin, Cout, k, stride, cin_total=None, cin_off=0, accumulate=0):
+def conv_wgrad(x, g_y, g_w, g_b, Cin, Cout, k, stride, cin_total=None, cin_off=0, accumulate=0, spikes=False, analog_head=0):
+    """Weight (+ bias) gradient.  spikes: x is spike-valued (binary spikes, counts, bilinear blends of spikes): the 3x3
+    stride-1 contraction runs on the bf16 matrix cores (exact there; anything else it finds is redone in fp32).
+    analog_head: the first `analog_head` channels of x are real-valued (a decoder's flow prediction): they are split off
+    into an fp32 call of their own so that the rest stays on the fast path."""
     B, H, W = x.shape[0], x.shape[1], x.shape[2]
+    ct = Cin if cin_total is None else cin_total
+    if spikes and analog_head and k == 3 and stride == 1 and cin_off == 0 and Cin > 8:
+        a = (analog_head + 3) // 4 * 4  # (the tail must stay 16-byte aligned)
+        if not accumulate:
+            g_w.zero_()
+            if g_b is not None:
+                g_b.zero_()
+        conv_wgrad(x, g_y, g_w, g_b, a, Cout, k, stride, ct, 0, 1, spikes=False)
+        conv_wgrad(x[..., a:], g_y, g_w, None, Cin - a, Cout, k, stride, ct, a, 1, spikes=True)
+        return
     ws = _scratch(_lib.load().evf_conv2d_wgrad_ws(B, H, W, Cin, Cout, k, stride), x.device)
-    _lib.call("evf_conv2d_wgrad", _lib.ptr(x), x.stride(2), _lib.ptr(g_y), g_y.stride(2), _lib.ptr(g_w), _lib.ptr(g_b), B, H,
-              W, Cin, Cout, k, stride, Cin if cin_total is None else cin_total, cin_off, accumulate, _lib.ptr(ws))
+    _lib.call("evf_conv2d_wgrad", _lib.ptr_strided(x), x.stride(2), _lib.ptr(g_y), g_y.stride(2), _lib.ptr(g_w), _lib.ptr(g_b),
+              B, H, W, Cin, Cout, k, stride, ct, cin_off, (accumulate & 1) | (0 if spikes else 2), _lib.ptr(ws))
 
 
 # ---------------------------------------------------------------------------
@@ -322,18 +336,19 @@ class _CellStep(torch.autograd.Function):
         g_wff = g_wrec = g_x = None
         if need[4]:
             d = bound_grad(wff)
+            head = int(getattr(cell, "analog_input_channels", 0))  # (a decoder's flow-prediction channels, models/unet.py)
             if d is not None:
-                conv_wgrad(xn, g_cur, d, None, Cin, C, k, s, cin_total=wff.shape[1], accumulate=1)
+                conv_wgrad(xn, g_cur, d, None, Cin, C, k, s, cin_total=wff.shape[1], accumulate=1, spikes=True, analog_head=head)
             else:
                 g_wff = _new(tuple(wff.shape), dev)
-                conv_wgrad(xn, g_cur, g_wff, None, Cin, C, k, s, cin_total=wff.shape[1])
+                conv_wgrad(xn, g_cur, g_wff, None, Cin, C, k, s, cin_total=wff.shape[1], spikes=True, analog_head=head)
         if cell.recurrent and need[5]:
             d = bound_grad(wrec)
             if sp is not None and d is not None:
-                conv_wgrad(sp[1], g_cur, d, None, C, C, k, 1, accumulate=1)
+                conv_wgrad(sp[1], g_cur, d, None, C, C, k, 1, accumulate=1, spikes=True)
             elif sp is not None:
                 g_wrec = _new(tuple(wrec.shape), dev)
-                conv_wgrad(sp[1], g_cur, g_wrec, None, C, C, k, 1)
+                conv_wgrad(sp[1], g_cur, g_wrec, None, C, C, k, 1, spikes=True)
             elif d is None:
                 g_wrec = torch.zeros(tuple(wrec.shape), dtype=torch.float32, device=dev)
         if need[1]:

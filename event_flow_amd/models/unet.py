@@ -102,8 +102,14 @@ class BaseUNet(nn.Module):
             cin = cin if self.skip_type == "sum" and not with_predictions else 2 * cin
             if with_predictions and i > 0:
                 cin += self.num_output_channels
-            return self.UpsampleLayer(cin, self.encoder_input_sizes[-1 - i], kernel_size=self.kernel_size,
-                                      activation=self.ff_act, norm=self.norm, **self.spiking_kwargs)
+            layer = self.UpsampleLayer(cin, self.encoder_input_sizes[-1 - i], kernel_size=self.kernel_size,
+                                       activation=self.ff_act, norm=self.norm, **self.spiking_kwargs)
+            cell = getattr(layer, "conv2d", None)
+            if with_predictions and i > 0 and hasattr(cell, "kind"):
+                # cat(prediction, x, skip): the leading flow channels are the only inputs of a spiking decoder that are
+                # not spike-valued (hip_ops.conv_wgrad keeps the rest on the bf16 matrix cores)
+                cell.analog_input_channels = self.num_output_channels
+            return layer
 
         return self._stack(make, self.num_encoders)
 

@@ -410,6 +410,10 @@ int evf_conv_split_select(int n);
  * (autograd w.r.t. weight / bias).  accumulate = 0 overwrites the outputs and needs cin_off = 0 and
  * Cin >= cin_total (channels past cin_total are activation padding and are skipped).  ws: scratch of evf_conv2d_wgrad_ws() floats (3x3, and 1x1 with Cout <= 4; null is accepted for 1x1 and selects the atomic split-K kernel):
  * partial sums of the pixel splits, reduced without atomics. */
+/* 3x3 stride 1: the contraction over pixels runs on the bf16 matrix cores first (csrc/evf_wgrad_b3gen.hip: x as one bf16
+ * plane, g_y as three; exact for spike-valued x), and the fp32 kernel recomputes only the input-channel tiles whose x was
+ * not exactly representable.  accumulate bit 1 (value 2) = "x is not spike-valued": fp32 kernel only.  EVF_WGRAD=f32 in the
+ * environment disables the bf16 kernel. */
 int64_t evf_conv2d_wgrad_ws(int B, int H, int W, int Cin, int Cout, int ksz, int stride);
 int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int ldg, float* g_w, float* g_bias, int B,
                      int H, int W, int Cin, int Cout, int ksz, int stride, int cin_total, int cin_off,
