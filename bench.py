@@ -411,9 +411,11 @@ def main_c4(args):
         if ent["flop_per_step"]:
             ent["TFLOPs"] = ent["flop_per_step"] / (ent["total_ms_per_step"] * 1e-3) / 1e12
             ent["frac_of_fp32_mfma_peak"] = ent["TFLOPs"] / FP32_MFMA_PEAK
-            if name.endswith("_b3"):
+            wgrad_b3 = name == "evf_conv2d_wgrad" and os.environ.get("EVF_WGRAD", "b3") != "f32"
+            if name.endswith("_b3") or wgrad_b3:
                 # issued bf16 work lies between 3x (every wave's fragment exactly representable) and 6x the fp32-equivalent
-                # FLOPs, by the per-wave vote of evf_conv_b3gen.hip; the input gradient always takes 6
+                # FLOPs, by the per-wave vote of evf_conv_b3gen.hip; the input gradient always takes 6; the weight gradient
+                # (evf_wgrad_b3gen.hip) issues 3x for the spike-valued channel tiles (stride-2 and flagged tiles: fp32 MFMA)
                 lo_terms = 6 if "dgrad" in name else 3
                 ent["issued_bf16_TFLOPs_range"] = [ent["TFLOPs"] * lo_terms, ent["TFLOPs"] * 6]
                 ent["frac_of_bf16_peak_range"] = [ent["TFLOPs"] * lo_terms / BF16_MFMA_PEAK, ent["TFLOPs"] * 6 / BF16_MFMA_PEAK]
@@ -431,11 +433,21 @@ def main_c4(args):
                    "conv_precision": ("forward / input gradient: bf16 MFMA with exact 3-way operand splits, fp32 accumulation "
                                       "(3 products per 16 channels for spike-valued waves, 6 otherwise; EVF_CONV=f32 for the fp32 "
                                       "kernels); " if hip_ops_conv_b3() else "") +
-                                     "weight gradient: fp32 MFMA (v_mfma_f32_32x32x2_f32); NHWC fp32 activations"},
-        "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": dom["TFLOPs"], "peak": FP32_MFMA_PEAK, "unit": "TFLOP/s",
-                     "frac": dom["TFLOPs"] / FP32_MFMA_PEAK, "traffic": None,
-                     "note": "all launches of the entry point in a step together: sum of 2*k*k*Cin*Cout*B*Ho*Wo over the launches / "
-                             "their summed HIP-event time"},
+                                     ("weight gradient: 3x3 stride 1 on the bf16 matrix cores (x one bf16 plane, g three; spike-valued "
+                                      "channel tiles), the rest fp32 MFMA; " if os.environ.get("EVF_WGRAD", "b3") != "f32" else
+                                      "weight gradient: fp32 MFMA (v_mfma_f32_32x32x2_f32); ") + "NHWC fp32 activations"},
+        "roofline": ({"kernel": dom_name, "bound": "mfma", "achieved": dom["issued_bf16_TFLOPs_range"][0], "peak": BF16_MFMA_PEAK,
+                      "unit": "TFLOP/s", "frac": dom["issued_bf16_TFLOPs_range"][0] / BF16_MFMA_PEAK, "traffic": None,
+                      "fp32_equivalent_TFLOPs": dom["TFLOPs"],
+                      "note": "all launches of the entry point in a step together: sum of 2*k*k*Cin*Cout*B*Ho*Wo over the launches / "
+                              "their summed HIP-event time = fp32-equivalent TFLOP/s; `achieved` = the bf16 matrix work ISSUED for it "
+                              "(at least 3 exact-split products per fp32 product; 6 for real-valued operands), priced against the "
+                              "dense bf16 MFMA peak"}
+                     if "issued_bf16_TFLOPs_range" in dom else
+                     {"kernel": dom_name, "bound": "mfma", "achieved": dom["TFLOPs"], "peak": FP32_MFMA_PEAK, "unit": "TFLOP/s",
+                      "frac": dom["TFLOPs"] / FP32_MFMA_PEAK, "traffic": None,
+                      "note": "all launches of the entry point in a step together: sum of 2*k*k*Cin*Cout*B*Ho*Wo over the launches / "
+                              "their summed HIP-event time"}),
         "kernels": kernels,
         "kernel_timing": {"method": "HIP events around each launch over eager steps, bracket overhead removed",
                           "bracket_overhead_us": round(_lib.last_event_overhead_ms * 1e3, 2)},

@@ -7,6 +7,8 @@
 // sample is 512 KiB).  Built with -ffp-contract=off: the warp
 // `y + ((tref - t) * f) * S` must round exactly like the reference's separate
 // torch ops (utils/iwe.py:37) for the rounded-index IWE to be bit-exact.
+#include <stdlib.h>
+
 #include "evf_common.h"
 
 // --------------------------------------------------------------------------
@@ -461,10 +463,11 @@ extern "C" int evf_iwe_splat(const float* flow, const float* ev, const int32_t* 
   // timestamp images / shifts, plane <= 64 KiB and a multiple of 16 bytes, M <= 15 Ki events, polarity weights as
   // an interleaved pair (or none), enough samples to fill the CUs -- i.e. compute_pol_iwe at the benchmark shape.
   {
+    static const int reg_min_b = getenv("EVF_IWE_REG_MIN_B") ? atoi(getenv("EVF_IWE_REG_MIN_B")) : 16;
     const bool pairw = w0 && w1 == w0 + 1 && wstride == 2 && (((uintptr_t)w0) & 7) == 0 && nch == 2;
     const bool now = !w0 && !w1 && nch == 1;
     if ((mode & 1) && !(mode & 12) && !map_of_event && !ts_shift && (pairw || now) && (long)H * W * 4 <= 64 * 1024 &&
-        ((H * W) & 3) == 0 && H * W <= 4 * IWR_NQ * IWR_THREADS && M <= IWR_EPT * IWR_THREADS && B >= 16 && (((uintptr_t)flow) & 15) == 0 &&
+        ((H * W) & 3) == 0 && H * W <= 4 * IWR_NQ * IWR_THREADS && M <= IWR_EPT * IWR_THREADS && B >= reg_min_b && (((uintptr_t)flow) & 15) == 0 &&
         (((uintptr_t)out) & 15) == 0) {
       const size_t lds = (size_t)H * W * 8 + 1024;  // two planes + slack for the last (clamped) DMA piece
       const float zf = (mode & 2) ? 0.f : 1.f;  // `flow * 0` (FWL/RSAT reference images) keeps NaN/sign semantics
@@ -486,7 +489,8 @@ extern "C" int evf_iwe_splat(const float* flow, const float* ev, const int32_t* 
   const int max_rows = (128 * 1024) / (nch * W * 4);
   // small problems (a few 100k events) are latency bound: the plain global-atomic kernel (3 us at
   // B=8 x 15k) wins there; the LDS version wins once the device-scope atomics saturate
-  if (max_rows >= 1 && (long)B * M >= 400000) {
+  static const long lds_min = getenv("EVF_IWE_LDS_MIN") ? atol(getenv("EVF_IWE_LDS_MIN")) : 400000;
+  if (max_rows >= 1 && (long)B * M >= lds_min) {
     int rows = max_rows < H ? max_rows : H;
     while (rows > 8 && (long)B * evf_cdiv(H, rows) < 256) rows = (rows + 1) / 2;
     const size_t lds = (size_t)nch * rows * W * 4;

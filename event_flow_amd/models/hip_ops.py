@@ -317,7 +317,7 @@ class _CellStep(torch.autograd.Function):
         # the recurrent conv's input gradient (written below) or zero
         g_prev = _new((ns, B, Ho, Wo, C), dev)
         rec_dgrad = cell.recurrent and sp is not None and need[2]
-        if kind != 2 and not rec_dgrad:
+        if kind != 2 and not rec_dgrad and sp is not None and need[2]:  # (only a returned state gradient needs the zeros)
             g_prev[1].zero_()
         g_P = _new((B, Ho, Wo), dev) if kind in (1, 3) else None
         params = cell_params(cell)

@@ -25,7 +25,7 @@ def short(name):
     return name.replace("void ", "").strip()
 
 
-for run, out in (("graph", "bench_hipgraph"), ("eager", "bench_eager"), ("evfn", "evflownet"), ("iwe", "iwe_b2048")):
+for run, out in (("graph", "bench_hipgraph"), ("eager", "bench_eager"), ("evfn", "evflownet"), ("plif", "plif_firenet"), ("iwe", "iwe_b2048")):
     f = one(f"{run}/*/*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(DST, f"{R}_{out}_kernel_stats.csv"))

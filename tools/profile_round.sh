@@ -14,6 +14,7 @@ run fetch  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/f
 run write  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe
 run mfma   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe
 run mfma32 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma32 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe --precision fp32
-run evfn   rocprofv3 --kernel-trace --stats --output-format csv -d $O/evfn -- python tools/bench_evflownet.py --steps 5
+run evfn   rocprofv3 --kernel-trace --stats --output-format csv -d $O/evfn -- python bench.py --config c4 --steps 10 --warmup 3
+run plif   rocprofv3 --kernel-trace --stats --output-format csv -d $O/plif -- python bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-iwe
 run iwe    rocprofv3 --kernel-trace --stats --output-format csv -d $O/iwe -- python tools/iwe_bench.py 2048
 ls -R $O | head -60
