@@ -391,7 +391,7 @@ def main_c4(args):
     elapsed = time.perf_counter() - t0
     names = ["evf_conv2d_fwd", "evf_conv2d_dgrad", "evf_conv2d_fwd_b3", "evf_conv2d_dgrad_b3", "evf_conv2d_wgrad", "evf_neuron_fwd", "evf_neuron_bwd", "evf_upsample2x_fwd",
              "evf_upsample2x_bwd", "evf_upsample_nearest_fwd", "evf_upsample_nearest_bwd", "evf_cm_loss_fwd", "evf_cm_loss_bwd",
-             "evf_clip_adam_step", "evf_pack_conv2d_weight", "evf_pack_conv2d_weight_b3", "evf_encode_events"]
+             "evf_clip_adam_step", "evf_pack_conv2d_weight", "evf_pack_conv2d_weight_b3", "evf_pack_conv2d_weights_b3_multi", "evf_encode_events"]
     prof_steps = 2
     _lib.profile_start(names)
     for i in range(prof_steps):

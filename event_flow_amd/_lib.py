@@ -87,6 +87,7 @@ NETWORK_SIGNATURES = {
     "evf_conv2d_dgrad": [P, I, P, P, I, I, I, I, I, I, I, I, I, P],
     "evf_conv2d_b3_packed_size": [I, I, I, I],
     "evf_pack_conv2d_weight_b3": [P, I, I, I, I, I, I, P, P],
+    "evf_pack_conv2d_weights_b3_multi": [P, P, P, I, P],
     "evf_conv2d_b3_ws": [I, I, I, I],
     "evf_conv2d_fwd_b3": [P, I, P, P, P, I, I, I, I, I, I, I, I, I, P, L, P],
     "evf_conv2d_dgrad_b3": [P, I, P, P, I, I, I, I, I, I, I, I, I, P, L, P],

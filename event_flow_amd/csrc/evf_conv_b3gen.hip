@@ -81,6 +81,78 @@ extern "C" int64_t evf_conv2d_b3_packed_size(int Cout, int Cin, int ksz, int tra
   return b3_packed_uint4(Cout, Cin, ksz, transpose) * 4;  // in floats (4 bytes), like evf_conv2d_packed_size
 }
 
+// All packed operands of a network in ONE launch (after an optimizer step every weight changed: 2 packs per layer were
+// ~45 launches of ~5 us each in the LIF-EV-FlowNet step).
+#define B3_MULTI 48
+struct B3PackMulti {
+  const float* w[B3_MULTI];
+  uint4* dst[B3_MULTI];
+  int Cout[B3_MULTI], Cin[B3_MULTI], T[B3_MULTI], tr[B3_MULTI], cin_total[B3_MULTI], cin_off[B3_MULTI];
+  int blk0[B3_MULTI + 1];  // first block of each tensor
+  int n;
+};
+__global__ void k_pack_conv2d_b3_multi(B3PackMulti m) {
+  int k = 0;
+  while (k + 1 < m.n && (int)blockIdx.x >= m.blk0[k + 1]) ++k;  // (uniform; n <= 48)
+  const int Cout = m.Cout[k], Cin = m.Cin[k], T = m.T[k], transpose = m.tr[k], cin_total = m.cin_total[k], cin_off = m.cin_off[k];
+  const float* __restrict__ w = m.w[k];
+  uint4* __restrict__ dst = m.dst[k];
+  const int K = transpose ? Cout : Cin, N = transpose ? Cin : Cout;
+  const int G = (K + CG_KG - 1) / CG_KG;
+  const long total = (long)((N + 31) / 32) * T * G * 4 * 64;
+  const long idx = (long)((int)blockIdx.x - m.blk0[k]) * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  long q = idx >> 6;
+  const int ch = q & 3;
+  q >>= 2;
+  const int g = q % G;
+  q /= G;
+  const int tap = q % T;
+  const int nt = q / T;
+  const int n = nt * 32 + (lane & 31);
+  uint32_t t3[3][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float v[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kk = g * CG_KG + ch * 16 + 8 * (lane >> 5) + 2 * e + j;
+      float x = 0.f;
+      if (kk < K && n < N) {
+        const int co = transpose ? kk : n, ci = transpose ? n : kk;
+        if (cin_off + ci < cin_total) x = w[((long)co * cin_total + cin_off + ci) * T + tap];
+      }
+      v[j] = x;
+    }
+    evf_split3_pair(v[0], v[1], t3[0][e], t3[1][e], t3[2][e]);
+  }
+  const long base = ((((long)nt * T + tap) * G + g) * 4 + ch) * 3;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) dst[(base + s) * 64 + lane] = make_uint4(t3[s][0], t3[s][1], t3[s][2], t3[s][3]);
+}
+
+// meta: 6 ints per tensor (Cout, Cin, ksz, transpose, cin_total, cin_off) -- the arguments of evf_pack_conv2d_weight_b3
+extern "C" int evf_pack_conv2d_weights_b3_multi(const void* const* w, void* const* dst, const int* meta, int n, void* stream) {
+  if (!w || !dst || !meta || n <= 0) return EVF_EINVAL;
+  for (int lo = 0; lo < n; lo += B3_MULTI) {
+    B3PackMulti m;
+    m.n = n - lo < B3_MULTI ? n - lo : B3_MULTI;
+    int blk = 0;
+    for (int k = 0; k < m.n; ++k) {
+      const int* t = meta + 6 * (lo + k);
+      if (!w[lo + k] || !dst[lo + k] || t[0] <= 0 || t[1] <= 0 || !EVF_KSZ_OK(t[2]) || t[5] < 0 || t[5] >= t[4]) return EVF_EINVAL;
+      m.w[k] = (const float*)w[lo + k], m.dst[k] = (uint4*)dst[lo + k];
+      m.Cout[k] = t[0], m.Cin[k] = t[1], m.T[k] = t[2] * t[2], m.tr[k] = t[3], m.cin_total[k] = t[4], m.cin_off[k] = t[5];
+      m.blk0[k] = blk;
+      blk += (int)evf_cdiv(b3_packed_uint4(t[0], t[1], t[2], t[3]) / 3, 256L);
+    }
+    m.blk0[m.n] = blk;
+    hipLaunchKernelGGL(k_pack_conv2d_b3_multi, dim3(blk), dim3(256), 0, EVF_STREAM(stream), m);
+  }
+  return evf_status();
+}
+
 extern "C" int evf_pack_conv2d_weight_b3(const float* w, int Cout, int Cin, int ksz, int transpose, int cin_total, int cin_off,
                                          void* dst, void* stream) {
   if (!w || !dst || Cout <= 0 || Cin <= 0 || !EVF_KSZ_OK(ksz) || cin_off < 0 || cin_off >= cin_total) return EVF_EINVAL;

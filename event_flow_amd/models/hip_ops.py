@@ -18,6 +18,7 @@ Reference semantics implemented here:
   nearest xf          models/model.py:529-539
 """
 
+import ctypes
 import os
 import weakref
 
@@ -100,8 +101,42 @@ class _PackCache:
         n = getattr(_lib.load(), "evf_conv2d" + sfx + "_packed_size")(Cout, cin, k, transpose)
         dst = _new((n,), w.device)
         _lib.call("evf_pack_conv2d_weight" + sfx, _lib.ptr(wc), Cout, cin, k, transpose, Ctot, cin_off, _lib.ptr(dst))
-        self.store[key] = (tag, dst)
+        try:
+            wref = weakref.ref(w)  # (repack_all re-packs in place after an optimizer step)
+        except TypeError:
+            wref = None
+        self.store[key] = (tag, dst, wref)
         return dst
+
+
+def repack_all():
+    """Re-pack every cached bf16 operand whose weight tensor is still alive, in ONE launch, into the buffers the caches
+    already hold.  Called by train.FlatAdam.step(): after an optimizer step every weight changed, and the lazy path
+    would re-pack them one launch at a time (two per layer) during the next forward / backward."""
+    if not CONV_B3:
+        return
+    by_dev = {}
+    for _ref, d in list(_CACHES.values()):
+        for pc in d.values():
+            if not isinstance(pc, _PackCache):
+                continue
+            for key, ent in pc.store.items():
+                w = ent[2]() if ent[2] is not None else None
+                if w is None or key[3] != "_b3" or not w.is_contiguous() or w.dtype != torch.float32 or w.device != ent[1].device:
+                    continue
+                by_dev.setdefault(w.device, []).append((pc, key, w, ent[1], ent[2]))
+    for dev, ents in by_dev.items():
+        n = len(ents)
+        wp = (ctypes.c_void_p * n)(*[e[2].data_ptr() for e in ents])
+        dp = (ctypes.c_void_p * n)(*[e[3].data_ptr() for e in ents])
+        meta = []
+        for _pc, key, w, _dst, _r in ents:
+            transpose, cin_off, cin, _sfx = key
+            meta += [w.shape[0], cin, w.shape[2], transpose, w.shape[1], cin_off]
+        with torch.cuda.device(dev):
+            _lib.call("evf_pack_conv2d_weights_b3_multi", wp, dp, (ctypes.c_int * len(meta))(*meta), n)
+        for pc, key, w, dst, r in ents:
+            pc.store[key] = ((w.data_ptr(), w._version, w.device, _EPOCH[0]), dst, r)
 
 
 _CACHES = {}
@@ -250,12 +285,55 @@ def cell_params(cell):
     return [cell.leak_v, cell.t0, cell.t1, cell.leak_pt]
 
 
+class StateSlots:
+    """New-state tensors of the n cells of a block in ONE buffer [n, S, B, H, W, C], so that the block's stacked state
+    (reference: torch.stack([ff, rec]), spiking_submodules.py:926, :973) exists without a copy."""
+
+    def __init__(self, n):
+        self.n, self.base, self.used = n, None, 0
+
+    def take(self, shape, dev):
+        if self.base is None:
+            self.base = _new((self.n,) + tuple(shape), dev)
+        if self.used >= self.n or tuple(self.base.shape[1:]) != tuple(shape):
+            self.used = self.n + 1  # (a cell of another shape: this block falls back to torch.stack)
+            return _new(shape, dev)
+        self.used += 1
+        return self.base[self.used - 1]
+
+    def complete(self):
+        return self.base is not None and self.used == self.n
+
+
+class _StackInPlace(torch.autograd.Function):
+    """torch.stack of states that already lie in one buffer: forward returns that buffer, backward hands each state its
+    slice of the gradient (views, no kernels)."""
+
+    @staticmethod
+    def forward(ctx, slots, *states):
+        ctx.n = len(states)
+        return slots.base.permute(0, 1, 2, 5, 3, 4)  # logical [n,S,B,C,H,W]
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + tuple(g[k] for k in range(ctx.n))
+
+
+def stack_states(states, slots=None):
+    """torch.stack(states) of logical [S,B,C,H,W] states, keeping the NHWC memory layout (stacking the NHWC views is a
+    plain copy; a direct torch.stack would transpose twice per pass) -- and no copy at all when the cells wrote their
+    states into the slots of one buffer."""
+    if slots is not None and slots.complete() and len(states) == slots.n:
+        return _StackInPlace.apply(slots, *states)
+    return torch.stack([s.permute(0, 1, 3, 4, 2) for s in states]).permute(0, 1, 2, 5, 3, 4)
+
+
 class _CellStep(torch.autograd.Function):
     """(input, previous state, residual) -> (output spikes [+ residual], new state).
     state: logical [S,B,C,H,W] (S = 2, or 3 with the adaptation trace), NHWC in memory."""
 
     @staticmethod
-    def forward(ctx, cell, x, state, residual, wff, wrec, p0, p1, p2, p3):
+    def forward(ctx, cell, x, state, residual, slots, wff, wrec, p0, p1, p2, p3):
         ctx.set_materialize_grads(False)
         kind = KIND_ID[cell.kind]
         ns = 2 if kind == 0 else 3
@@ -283,7 +361,7 @@ class _CellStep(torch.autograd.Function):
             ws = _new((B * H * W,), dev)
             P = _new((B, Ho, Wo), dev)
             _lib.call("evf_pretrace_fwd", _lib.ptr(xn), xn.stride(2), B, H, W, Cin, k, s, _lib.ptr(ws), _lib.ptr(P))
-        new = _new((ns, B, Ho, Wo, C), dev)
+        new = slots.take((ns, B, Ho, Wo, C), dev) if slots is not None else _new((ns, B, Ho, Wo, C), dev)
         out = _new((B, Ho, Wo, C), dev)
         prm = [p.detach().reshape(-1).contiguous() if p is not None else None for p in (p0, p1, p2, p3)]
         _lib.call("evf_neuron_fwd", kind, _lib.ptr(cur), _lib.ptr(sp[0]) if sp is not None else None,
@@ -303,9 +381,10 @@ class _CellStep(torch.autograd.Function):
         B, H, W, Cin, Ho, Wo, C, k, s = ctx.geom
         xn, sp, new, P, prm, wff, wrec = ctx.saved
         dev = xn.device
-        need = ctx.needs_input_grad  # (cell, x, state, residual, wff, wrec, p0..p3)
+        need = ctx.needs_input_grad  # (cell, x, state, residual, slots, wff, wrec, p0..p3)
+        need = need[:4] + need[5:]  # (indices below: cell, x, state, residual, wff, wrec, p0..p3)
         if g_out is None and g_state is None:
-            return (None,) * 10
+            return (None,) * 11
         gon = to_nhwc(g_out) if g_out is not None else None
         gs = None
         if g_state is not None:
@@ -365,17 +444,18 @@ class _CellStep(torch.autograd.Function):
             g_st = g_prev.permute(0, 1, 4, 2, 3)
         g_res = g_out if (ctx.has_res and need[3]) else None
         shp = lambda i: g_prm[i].view(C, 1, 1) if (g_prm[i] is not None and d_prm[i] is None) else None  # noqa: E731
-        return None, g_x, g_st, g_res, g_wff, g_wrec, shp(0), shp(1), shp(2), shp(3)
+        return None, g_x, g_st, g_res, None, g_wff, g_wrec, shp(0), shp(1), shp(2), shp(3)
 
 
-def cell_forward(cell, input_, prev_state, residual=0):
-    """Reference signature: cell(input_, prev_state, residual=0) -> (out, state)."""
+def cell_forward(cell, input_, prev_state, residual=0, slots=None):
+    """Reference signature: cell(input_, prev_state, residual=0) -> (out, state).  slots: optional StateSlots of the
+    enclosing block (the new state is written into the block's stacked-state buffer)."""
     res = residual if torch.is_tensor(residual) else None
     if not torch.is_tensor(residual) and residual != 0:
         raise _lib.EvflowError("residual must be a tensor or 0")
     p = cell_params(cell)
     wrec = cell.rec.weight if cell.recurrent else None
-    return _CellStep.apply(cell, input_, prev_state, res, cell.ff.weight, wrec, *p)
+    return _CellStep.apply(cell, input_, prev_state, res, slots, cell.ff.weight, wrec, *p)
 
 
 # ---------------------------------------------------------------------------

@@ -52,9 +52,9 @@ class _SpikingCell(nn.Module):
         w_scale = math.sqrt(1 / fan)
         nn.init.uniform_(conv.weight, -w_scale, w_scale)
 
-    def forward(self, input_, prev_state, residual=0):
+    def forward(self, input_, prev_state, residual=0, slots=None):
         """-> (z_out + residual, stack([v_out, z_out(, trace)])), reference :96-126 etc."""
-        return hip_ops.cell_forward(self, input_, prev_state, residual)
+        return hip_ops.cell_forward(self, input_, prev_state, residual, slots)
 
 
 class ConvLIF(_SpikingCell):
@@ -220,10 +220,7 @@ _FF = {"lif": ConvLIF, "alif": ConvALIF, "plif": ConvPLIF, "xlif": ConvXLIF}
 _REC = {"lif": ConvLIFRecurrent, "alif": ConvALIFRecurrent, "plif": ConvPLIFRecurrent, "xlif": ConvXLIFRecurrent}
 
 
-def stack_states(states):
-    """torch.stack(states) of logical [S,B,C,H,W] states, keeping the NHWC memory layout
-    (stacking the NHWC views is a plain copy; a direct torch.stack would transpose twice per pass)."""
-    return torch.stack([s.permute(0, 1, 3, 4, 2) for s in states]).permute(0, 1, 2, 5, 3, 4)
+stack_states = hip_ops.stack_states
 
 
 class SpikingRecurrentConvLayer(nn.Module):
@@ -242,9 +239,10 @@ class SpikingRecurrentConvLayer(nn.Module):
         if prev_state is None:
             prev_state = [None, None]
         ff, rec = prev_state
-        x1, ff = self.conv(x, ff)
-        x2, rec = self.recurrent_block(x1, rec)
-        return x2, stack_states([ff, rec])
+        slots = hip_ops.StateSlots(2)  # both new states in one buffer: the stacked state needs no copy
+        x1, ff = self.conv(x, ff, slots=slots)
+        x2, rec = self.recurrent_block(x1, rec, slots=slots)
+        return x2, stack_states([ff, rec], slots)
 
 
 class SpikingResidualBlock(nn.Module):
@@ -263,9 +261,10 @@ class SpikingResidualBlock(nn.Module):
         if prev_state is None:
             prev_state = [None, None]
         conv1, conv2 = prev_state
-        x1, conv1 = self.conv1(x, conv1)
-        x2, conv2 = self.conv2(x1, conv2, residual=x)
-        return x2, stack_states([conv1, conv2])
+        slots = hip_ops.StateSlots(2)
+        x1, conv1 = self.conv1(x, conv1, slots=slots)
+        x2, conv2 = self.conv2(x1, conv2, residual=x, slots=slots)
+        return x2, stack_states([conv1, conv2], slots)
 
 
 class SpikingUpsampleConvLayer(nn.Module):

@@ -121,15 +121,20 @@ class BaseUNet(nn.Module):
     def _decoder_input(self, x, skip, prediction, decoder):
         """cat(prediction, cat(x, skip)) (unet.py:303-306); with 2C+2 channels two zero channels keep the activation
         16-byte aligned for the conv kernels (the packed weight is zero there; cells with a pre-synaptic trace
-        average over the true channels and are left unpadded)."""
-        x = self.skip_ftn(x, skip)
+        average over the true channels and are left unpadded).  Concatenating skips: ONE torch.cat of all parts."""
+        from .model_util import _centred
+
+        if self.skip_type != "concat":
+            x = self.skip_ftn(x, skip)
+            return x if prediction is None else self.skip_ftn(prediction, x)
+        parts = [_centred(x, skip), skip]
         if prediction is not None:
-            x = self.skip_ftn(prediction, x)
-            pad = (-x.shape[1]) % 4
+            parts = [_centred(prediction, skip)] + parts
+            pad = (-sum(p.shape[1] for p in parts)) % 4
             conv = getattr(decoder, "conv2d", None)  # (None: transposed-conv decoder, which takes its exact channel count)
-            if pad and conv is not None and self.skip_type == "concat" and getattr(conv, "kind", "ann") in ("lif", "alif", "ann"):
-                x = torch.cat([x, x.new_zeros((x.shape[0], pad) + tuple(x.shape[2:]))], 1)
-        return x
+            if pad and conv is not None and getattr(conv, "kind", "ann") in ("lif", "alif", "ann"):
+                parts.append(skip.new_zeros((skip.shape[0], pad) + tuple(skip.shape[2:])))
+        return torch.cat(parts, 1)
 
     def _decode(self, x, blocks, stateful, offset=0):
         """Decoders + per-scale predictions, coarse to fine (unet.py:298-311, :402-415, :455-465)."""

@@ -78,6 +78,7 @@ class FlatAdam:
         if hasattr(self.model, "invalidate_weight_cache"):
             self.model.invalidate_weight_cache()
         hip_ops.invalidate_packed_weights()
+        hip_ops.repack_all()  # (general path: all packed operands in one launch instead of two per layer, lazily)
 
     def step_invalidate(self):
         """The flat parameter buffer was rewritten from outside (broadcast, checkpoint): drop packed-weight caches."""

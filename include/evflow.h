@@ -389,6 +389,9 @@ int evf_conv2d_dgrad(const float* g_y, int ldg, const float* wT_packed, float* g
 int64_t evf_conv2d_b3_packed_size(int Cout, int Cin, int ksz, int transpose);
 int evf_pack_conv2d_weight_b3(const float* w, int Cout, int Cin, int ksz, int transpose, int cin_total,
                               int cin_off, void* dst, void* stream);
+/* The same for n tensors in one launch (host arrays of device pointers; meta: 6 ints per tensor = Cout, Cin, ksz,
+ * transpose, cin_total, cin_off): every packed operand of a network after an optimizer step. */
+int evf_pack_conv2d_weights_b3_multi(const void* const* w, void* const* dst, const int* meta, int n, void* stream);
 /* ws: optional scratch of ws_floats floats (evf_conv2d_b3_ws() of the OUTPUT shape; 0 = this shape never needs it): layers
  * whose output tiles alone cannot fill the chip split their contraction into up to 8 slabs, summed in a fixed order
  * (deterministic; no atomics).  Null = never split. */
