@@ -613,6 +613,44 @@ extern "C" int evf_upsample2x_bwd(const float* g_y, int B, int H, int W, int C, 
   return evf_status();
 }
 
+// channel concatenation of up to 6 NHWC activations (decoder input cat(prediction, x, skip[, zero padding]),
+// models/unet.py:303-306; a null source = zeros): one pass, every output float written once
+struct CatParts {
+  const float* src[6];
+  int C[6], ld[6], off[7];  // channels, pixel stride (floats), first output channel of each part
+  int n;
+};
+__global__ void k_concat_channels(CatParts p, long npix, int Ctot, float* __restrict__ out, int ldo) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= npix * Ctot) return;
+  const long pix = idx / Ctot;
+  const int c = (int)(idx - pix * Ctot);
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < 6; ++j) k += (j < p.n && c >= p.off[j]) ? 1 : 0;
+  const float* s = p.src[k];
+  out[pix * ldo + c] = s ? s[pix * p.ld[k] + (c - p.off[k])] : 0.f;
+}
+extern "C" int evf_concat_channels(const void* const* src, const int* C, const int* ld, int n, int64_t npix, float* out, int ldo,
+                                   void* stream) {
+  if (!src || !C || !ld || !out || n <= 0 || n > 6 || npix <= 0) return EVF_EINVAL;
+  CatParts p;
+  int tot = 0;
+  for (int k = 0; k < 6; ++k) {
+    p.src[k] = k < n ? (const float*)src[k] : nullptr;
+    p.C[k] = k < n ? C[k] : 0;
+    p.ld[k] = k < n ? ld[k] : 0;
+    p.off[k] = tot;
+    if (k < n && (C[k] <= 0 || (src[k] && ld[k] < C[k]))) return EVF_EINVAL;
+    tot += p.C[k];
+  }
+  p.off[6] = tot, p.n = n;
+  if (ldo < tot) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_concat_channels, dim3(evf_cdiv(npix * tot, 256L)), dim3(256), 0, EVF_STREAM(stream), p, (long)npix, tot, out,
+                     ldo);
+  return evf_status();
+}
+
 // nearest up-sampling by an integer factor of planes [n][h][w] (flow maps, NCHW): models/model.py:529-539
 __global__ void k_upnear_fwd(const float* __restrict__ x, long n, int h, int w, int f, float* __restrict__ y) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -551,8 +551,10 @@ __global__ __launch_bounds__(512) void k_wgrad9(const float* __restrict__ x, con
 #define WGR_G 16
 __global__ __launch_bounds__(64 * WGR_G) void k_wgrad_reduce(const float* __restrict__ slab, int nsplit, int Cin, int Cout,
                                                              int cin_total, int cin_off, int accumulate,
-                                                             float* __restrict__ gw) {
+                                                             float* __restrict__ gw, int* __restrict__ clear_flags) {
   __shared__ float red[WGR_G][64];
+  // the redo flags of the bf16 pass (read by the fp32 pass, a kernel earlier in the stream) are handed back zeroed
+  if (clear_flags && blockIdx.x == 0 && threadIdx.x < 64) clear_flags[threadIdx.x] = 0;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, G = blockDim.x >> 6;  // G = min(16, nsplit) groups
   const long per = (long)9 * Cin * Cout;
   const long e = (long)blockIdx.x * 64 + tx;
@@ -612,7 +614,7 @@ extern "C" int64_t evf_conv2d_wgrad_ws(int B, int H, int W, int Cin, int Cout, i
   if (ksz == 1) return wg1_small_ok(Cin, Cout, ksz, stride, Cin, nullptr) ? (int64_t)WG1_BLOCKS * (Cout * Cin + Cout) : 0;
   if (ksz != 3) return 0;
   const Wg9Plan p = wg9_plan(B, H, W, Cin, Cout, stride, Cin, Cout);
-  return (int64_t)p.nsplit * 9 * Cin * Cout + 64;  // (+ the bf16 kernel's per-channel-tile redo flags)
+  return (int64_t)p.nsplit * 9 * Cin * Cout;
 }
 
 template <int CT, int NT, int S>
@@ -640,6 +642,15 @@ static void wg9_launch(const float* x, const float* gy, float* slab, float* gbia
 #undef WG9_GO
 }
 
+__device__ int g_wg_redo[64];
+static int* wg_redo_flags() {
+  static int* ptr[64] = {nullptr};  // per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!ptr[dev] && hipGetSymbolAddress((void**)&ptr[dev], HIP_SYMBOL(g_wg_redo)) != hipSuccess) return nullptr;
+  return ptr[dev];
+}
+
 // g_w [Cout][cin_total][k][k] (torch layout; this call fills input channels cin_off .. cin_off+Cin) and optional
 // g_bias [Cout]; accumulate = 0 overwrites them (only allowed when the call covers the whole weight).
 // ws: evf_conv2d_wgrad_ws() floats of scratch (3x3 only).
@@ -665,10 +676,11 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
     const int* redo = nullptr;
     float* bias_f32 = g_bias;
     if (b3 && !analog && stride == 1 && p.g.n_ct <= 64 && evf_wgrad9_b3_ok(x, g_y, Cin, Cout, ldx, ldg)) {
-      int* flags = (int*)(ws + (long)p.nsplit * 9 * Cin * Cout);
-      int rc = evf_hip(hipMemsetAsync(flags, 0, sizeof(int) * p.g.n_ct, st));
-      if (rc) return rc;
-      rc = evf_wgrad9_b3_launch(x, ldx, g_y, ldg, ws, g_bias, flags, B, H, W, Cin, Cout, p.nsplit, p.CT, p.NT, st);
+      // 64 persistent flags per device (zero at load, cleared again by k_wgrad_reduce: no memset per call; calls are
+      // stream-ordered on one stream per device)
+      int* flags = wg_redo_flags();
+      if (!flags) return EVF_EINVAL;
+      int rc = evf_wgrad9_b3_launch(x, ldx, g_y, ldg, ws, g_bias, flags, B, H, W, Cin, Cout, p.nsplit, p.CT, p.NT, st);
       if (rc) return rc;
       redo = flags;
       bias_f32 = nullptr;  // (summed by the bf16 kernel from the exact fp32 gradients)
@@ -693,7 +705,7 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
     const long per = (long)9 * Cin * Cout;
     const int rg = p.nsplit >= 16 ? 16 : (p.nsplit >= 8 ? 8 : (p.nsplit >= 4 ? 4 : (p.nsplit >= 2 ? 2 : 1)));
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(evf_cdiv(per, 64)), dim3(64 * rg), 0, st, ws, p.nsplit, Cin, Cout, cin_total,
-                       cin_off, accumulate, g_w);
+                       cin_off, accumulate, g_w, (int*)redo);
     return evf_status();
   }
   if (ws && wg1_small_ok(Cin, Cout, ksz, stride, ldx, x)) {

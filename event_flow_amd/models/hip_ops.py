@@ -888,6 +888,38 @@ def conv_lstm(owner, x, hidden, cell):
 # ---------------------------------------------------------------------------
 # x1 + x2 (skip_sum, model_util.py:22-27)
 # ---------------------------------------------------------------------------
+class _Concat(torch.autograd.Function):
+    """torch.cat(parts, 1) of logical [B,C,H,W] tensors (+ `pad` trailing zero channels) into one NHWC activation: one
+    kernel, every float written once (torch's cat of channels_last views takes its generic strided path, and an NCHW
+    part makes the whole result NCHW -- a layout conversion of the largest activations of the network)."""
+
+    @staticmethod
+    def forward(ctx, pad, *parts):
+        ps = [to_nhwc(p) for p in parts]
+        B, H, W = ps[0].shape[0], ps[0].shape[1], ps[0].shape[2]
+        Cs = [p.shape[3] for p in ps] + ([pad] if pad else [])
+        out = _new((B, H, W, sum(Cs)), ps[0].device)
+        n = len(Cs)
+        src = (ctypes.c_void_p * n)(*([_lib.ptr_strided(p) for p in ps] + ([None] if pad else [])))
+        _lib.call("evf_concat_channels", src, (ctypes.c_int * n)(*Cs), (ctypes.c_int * n)(*([p.stride(2) for p in ps] + ([0] if pad else []))),
+                  n, B * H * W, _lib.ptr(out), out.stride(2))
+        ctx.Cs = [p.shape[3] for p in ps]
+        return from_nhwc(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        gn = to_nhwc(g)
+        outs, off = [], 0
+        for c in ctx.Cs:
+            outs.append(from_nhwc(gn[..., off:off + c]))
+            off += c
+        return (None,) + tuple(outs)
+
+
+def concat_channels(parts, pad=0):
+    return _Concat.apply(int(pad), *parts)
+
+
 class _Add(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):

@@ -127,14 +127,16 @@ class BaseUNet(nn.Module):
         if self.skip_type != "concat":
             x = self.skip_ftn(x, skip)
             return x if prediction is None else self.skip_ftn(prediction, x)
+        from . import hip_ops
+
         parts = [_centred(x, skip), skip]
+        pad = 0
         if prediction is not None:
             parts = [_centred(prediction, skip)] + parts
-            pad = (-sum(p.shape[1] for p in parts)) % 4
             conv = getattr(decoder, "conv2d", None)  # (None: transposed-conv decoder, which takes its exact channel count)
-            if pad and conv is not None and getattr(conv, "kind", "ann") in ("lif", "alif", "ann"):
-                parts.append(skip.new_zeros((skip.shape[0], pad) + tuple(skip.shape[2:])))
-        return torch.cat(parts, 1)
+            if conv is not None and getattr(conv, "kind", "ann") in ("lif", "alif", "ann"):
+                pad = (-sum(p.shape[1] for p in parts)) % 4
+        return hip_ops.concat_channels(parts, pad)
 
     def _decode(self, x, blocks, stateful, offset=0):
         """Decoders + per-scale predictions, coarse to fine (unet.py:298-311, :402-415, :455-465)."""

@@ -468,6 +468,10 @@ int evf_pretrace_bwd(const float* x, int ldx, const float* g_P, int B, int H, in
  * (spiking_submodules.py:1011) and its adjoint. */
 int evf_upsample2x_fwd(const float* x, int B, int H, int W, int C, float* y, void* stream);
 int evf_upsample2x_bwd(const float* g_y, int B, int H, int W, int C, float* g_x, void* stream);
+/* Channel concatenation of n <= 6 NHWC activations into out (pixel stride ldo): torch.cat(..., 1) of the decoder inputs
+ * (models/unet.py:303-306, model_util.py:14-19).  src[k] null = C[k] channels of zeros (alignment padding). */
+int evf_concat_channels(const void* const* src, const int* C, const int* ld, int n, int64_t npix, float* out, int ldo,
+                        void* stream);
 /* F.interpolate(scale_factor=f) (nearest) of `planes` images [h][w] -> [h f][w f]
  * (models/model.py:529-539) and its adjoint. */
 int evf_upsample_nearest_fwd(const float* x, int64_t planes, int h, int w, int factor, float* y,
