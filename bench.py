@@ -101,8 +101,9 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def make_windows(rank, n_pool, dev):
-    """n_pool windows, each PASSES event lists [B,1500,4] (platform-stable synthetic events)."""
+def make_windows(rank, n_pool, dev, slices=1):
+    """n_pool windows, each PASSES event lists [B,1500,4] (platform-stable synthetic events).  slices > 1: every window as
+    `slices` lists of pass lists over contiguous batch ranges (the micro-batches of train.StreamReplicas)."""
     from event_flow_amd import synthetic
 
     pool = []
@@ -114,7 +115,12 @@ def make_windows(rank, n_pool, dev):
         # one resident buffer [B,P,N,4] per window, the passes are its slices [:, p]: the binning kernel and the loss read the
         # window in place (no torch.stack / torch.cat in the step)
         window = torch.from_numpy(np.ascontiguousarray(np.stack(lists, 1))).to(dev)
-        pool.append([window[:, k] for k in range(PASSES)])
+        if slices == 1:
+            pool.append([window[:, k] for k in range(PASSES)])
+        else:
+            b = B_PER_GPU // slices
+            parts = [window[j * b:(j + 1) * b].contiguous() for j in range(slices)]
+            pool.append([[part[:, k] for k in range(PASSES)] for part in parts])
     return pool
 
 
@@ -127,9 +133,11 @@ def _encode(lists):
     return passes
 
 
-def run_step(model, lossf, opt, dp, lists):
+def run_step(model, lossf, opt, dp, lists, reps=None):
     from event_flow_amd.train import train_window
 
+    if reps is not None:  # lists: one pass list per micro-batch
+        return reps.train_window([_encode(part) for part in lists], dp=dp)
     return train_window(model, lossf, opt, _encode(lists), dp=dp)
 
 
@@ -141,12 +149,38 @@ class StepGraph:
     collective stays outside the captures, so a rank can never replay a different
     collective sequence than its peers."""
 
-    def __init__(self, model, lossf, opt, dp, lists, stream):
+    def __init__(self, model, lossf, opt, dp, lists, stream, reps=None):
         from event_flow_amd.train import window_apply, window_backward
 
-        self.dp, self.comm = dp, opt.comm
+        self.dp, self.comm, self.reps = dp, opt.comm, reps
         # other threads (the process group's watchdog polls events) must not invalidate a capture of this thread
         mode = "thread_local" if dp.world > 1 else "global"
+        if reps is not None:
+            # micro-batch pipelining (train.StreamReplicas): one graph per replica on its own stream, then the join:
+            # gradients / losses summed, (all-reduce outside any capture,) clip+Adam, detach, reset
+            self.main = stream
+            self.slices, losses = [], []
+            for k in range(reps.n):
+                g = torch.cuda.CUDAGraph()
+                st = stream if k == 0 else reps.streams[k]
+                st.wait_stream(stream)
+                with torch.cuda.graph(g, stream=st, capture_error_mode=mode):
+                    losses.append(reps.backward_slice(k, _encode(lists[k])))
+                stream.wait_stream(st)
+                self.slices.append((g, st))
+            self.pre = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.pre, stream=stream, capture_error_mode=mode):
+                local = reps.combine(losses)
+                if dp.world > 1:
+                    dp.stage(opt.comm, local)
+                else:
+                    self.loss = reps.apply(local, dp)
+            self.post = None
+            if dp.world > 1:
+                self.post = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.post, stream=stream, capture_error_mode=mode):
+                    self.loss = reps.apply(local, dp)
+            return
         if dp.world == 1:
             self.pre = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.pre, stream=stream, capture_error_mode=mode):
@@ -160,6 +194,14 @@ class StepGraph:
             self.loss = window_apply(model, lossf, opt, local, dp)
 
     def replay(self):
+        if self.reps is not None:  # fork: every replica's graph on its stream; join on the main one
+            for _g, st in self.slices[1:]:
+                st.wait_stream(self.main)
+            for g, st in self.slices:
+                with torch.cuda.stream(st):
+                    g.replay()
+            for _g, st in self.slices[1:]:
+                self.main.wait_stream(st)
         self.pre.replay()
         if self.post is not None:
             self.dp.reduce(self.comm)
@@ -167,20 +209,23 @@ class StepGraph:
         return self.loss
 
 
-def capture_step_graphs(model, lossf, opt, dp, pool, stream):
+def capture_step_graphs(model, lossf, opt, dp, pool, stream, reps=None):
     """One StepGraph per window of `pool` (the warm-up must have run eagerly on `stream` with
     model.use_static_states(True)).  The recurrent state crosses replays without a copy: graph 0 starts from the
     buffers the warm-up left, graph k from the tensors graph k-1's last pass wrote (fixed addresses in its capture
     pool), and the last graph's last pass writes straight back into the first buffers.  Replays cycle 0,1,0,1...
     `graph.left` = the state tensors a replay of that graph leaves behind (model.set_state_buffers)."""
-    home = model.state_buffers()
-    model.use_static_states(False)
+    models = reps.models if reps is not None else [model]
+    home = [m.state_buffers() for m in models]
+    for m in models:
+        m.use_static_states(False)
     graphs = []
     for gi, lists in enumerate(pool):
         if gi == len(pool) - 1:
-            model.final_states_into(home)
-        graphs.append(StepGraph(model, lossf, opt, dp, lists, stream))
-        graphs[-1].left = model.state_buffers()
+            for m, h in zip(models, home):
+                m.final_states_into(h)
+        graphs.append(StepGraph(model, lossf, opt, dp, lists, stream, reps))
+        graphs[-1].left = model.state_buffers() if reps is None else [m.state_buffers() for m in models]
     return graphs
 
 
@@ -465,6 +510,10 @@ def main():
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="matrix-core path of the 32->32 convs: exact bf16x3 split (default) or fp32 MFMA")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="micro-batch pipelining (train.StreamReplicas): the per-GPU batch as this many slices on their own HIP "
+                         "streams; 2 gives +6.6 %% windows/s at the headline shape, but then every launch is a half-batch kernel "
+                         "and two are in flight, so per-launch roofline figures stop describing the device (default 1 = off)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--config", choices=["c3", "c4", "c5"], default="c3",
                     help="BASELINE.json workload: c3 = headline LIF-FireNet train step (default), c5 = PLIF-FireNet 260x346 (4 per GPU), "
@@ -504,9 +553,18 @@ def main():
     use_graph = not args.no_graph
     opt = FlatAdam(model, lr=2e-4, clip=100.0, device_step=use_graph)
     opt.zero_grad()
+    # micro-batch pipelining (train.StreamReplicas): the rank's batch as `--streams` slices, each through its own replica
+    # (shared weights, own state / tape / gradient buffer) on its own HIP stream; gradients summed before the one step
+    nstream = args.streams if (args.streams > 1 and B_PER_GPU % args.streams == 0) else 1
+    reps = None
+    if nstream > 1:
+        from event_flow_amd.train import StreamReplicas
+
+        reps = StreamReplicas(model, lossf, opt, n=nstream)
     if use_graph:
-        model.use_static_states(True)  # recurrent state must live at fixed addresses across replays
-    pool = make_windows(dp.rank, 2, dev)
+        for m in (reps.models if reps is not None else [model]):
+            m.use_static_states(True)  # recurrent state must live at fixed addresses across replays
+    pool = make_windows(dp.rank, 2, dev, slices=nstream)
     names = ["evf_conv_lif_fwd", "evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_conv_dgrad", "evf_conv_dgrad_b3",
              "evf_conv_dgrad_b3_f32", "evf_conv_dgrad_b3_f32_pair", "evf_conv_wgrad_bits", "evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad_top",
              "evf_lif_bwd", "evf_head_lif_bwd_wgrad", "evf_head_lif_fwd", "evf_head_wgrad", "evf_pred_bwd", "evf_reduce_slabs", "evf_reduce_slabs_multi", "evf_cm_loss_fwd",
@@ -520,13 +578,13 @@ def main():
     side.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(side)
     for i in range(max(args.warmup, 2)):
-        run_step(model, lossf, opt, dp, pool[i % len(pool)])
+        run_step(model, lossf, opt, dp, pool[i % len(pool)], reps)
     graphs = None
     mode = "eager"
     if use_graph:
         try:
             torch.cuda.synchronize()
-            graphs = capture_step_graphs(model, lossf, opt, dp, pool, side)
+            graphs = capture_step_graphs(model, lossf, opt, dp, pool, side, reps)
         except Exception as e:  # capture unsupported in this environment: eager launches
             print(f"[bench] rank {dp.rank}: hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
             graphs = None
@@ -550,7 +608,7 @@ def main():
         if graphs is not None:
             loss = graphs[i % len(graphs)].replay()
         else:
-            loss = run_step(model, lossf, opt, dp, pool[i % len(pool)])
+            loss = run_step(model, lossf, opt, dp, pool[i % len(pool)], reps)
     torch.cuda.synchronize()
     dp.barrier()
     elapsed = time.perf_counter() - t0
@@ -563,7 +621,7 @@ def main():
         prof_steps = 3
         _lib.profile_start(names)
         for i in range(prof_steps):
-            run_step(model, lossf, opt, dp, pool[i % len(pool)])
+            run_step(model, lossf, opt, dp, pool[i % len(pool)], reps)
         prof = _lib.profile_stop()
     event_overhead_us = _lib.last_event_overhead_ms * 1e3
     elapsed = dp.max_over_ranks(elapsed)
@@ -571,7 +629,7 @@ def main():
 
     model_precision = model.precision
     if dp.rank == 0:
-        npix = B_PER_GPU * H * W
+        npix = (B_PER_GPU // nstream) * H * W  # pixels one LAUNCH covers (a micro-batch when the step is pipelined)
         # algorithmic work per launch: FLOP of the 3x3 32->32 contraction(s) and
         # compulsory HBM bytes (fp32 tensors 128 B/px, split-bf16 planes 192 B/px, spike words 4 B/px)
         model = {
@@ -654,6 +712,11 @@ def main():
             "config": {"workload": wl["text"], "baseline_config": args.config,
                        "global_batch": B_PER_GPU * dp.world, "events_per_window": PASSES * EV_PER_PASS,
                        "parallelism": f"dp{dp.world}", "launch": mode, "loss": loss_val,
+                       "streams": nstream,
+                       "pipelining": (f"each rank's {B_PER_GPU} windows as {nstream} micro-batches of {B_PER_GPU // nstream} on {nstream} HIP "
+                                      "streams (replicas sharing the weights; gradients summed before the one optimizer step): "
+                                      "kernels[*] / roofline are per LAUNCH of a micro-batch, timed one at a time; in the replayed "
+                                      "step two such launches are in flight" if nstream > 1 else None),
                        "collective": ({"backend": dp.backend, "library": "RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
                                        if dp.backend == "nccl" else dp.backend, "ranks": dp.world,
                                        "per_step": "1 SUM all-reduce of [flat gradient | loss | new_seq] = %d bytes" % (opt.comm.numel() * 4)}

@@ -75,8 +75,9 @@ class FlatAdam:
         self._grad_clean = True
         # the kernel rewrote the parameters behind torch's version counters: drop the
         # engine's packed-weight cache explicitly
-        if hasattr(self.model, "invalidate_weight_cache"):
-            self.model.invalidate_weight_cache()
+        for m in [self.model] + list(getattr(self, "extra_models", [])):  # (+ the stream replicas sharing these weights)
+            if hasattr(m, "invalidate_weight_cache"):
+                m.invalidate_weight_cache()
         hip_ops.invalidate_packed_weights()
         hip_ops.repack_all()  # (general path: all packed operands in one launch instead of two per layer, lazily)
 
@@ -146,6 +147,98 @@ def train_window(model, loss_function, optimizer, passes, dp=None):
     if dp is not None:
         dp.reduce(optimizer.comm)
     return window_apply(model, loss_function, optimizer, loss, dp)
+
+
+class StreamReplicas:
+    """Micro-batch pipelining inside ONE GPU: the batch is cut into `n` slices and each slice runs its window (passes,
+    loss, backward) through its own replica of the model on its own HIP stream.  The replicas share the parameter
+    storage (one FlatAdam) and own their recurrent state, BPTT tape, packed weights and gradient buffer; the slices'
+    gradients (and losses) are summed into the optimizer's buffer before the ONE optimizer step.  Same result as the
+    unsplit step up to summation order -- the loss sums over the batch (train_flow.py:141-154), exactly the argument of
+    the data-parallel ranks.  Why: every kernel of the recurrent network is one short round of blocks (load, matrix phase,
+    store, ~5 us of ramp / drain per launch); two half-sized kernels of different layers in flight fill those gaps
+    (measured: 1490 -> 1730 windows/s at 8 x 128x128).
+
+        reps = StreamReplicas(model, loss_function, optimizer, n=2)      # before the first forward pass
+        loss = reps.train_window(passes_per_slice)                        # list of n pass lists
+    """
+
+    def __init__(self, model, loss_function, optimizer, n=2):
+        import copy
+
+        if not isinstance(optimizer, FlatAdam):
+            raise _lib.EvflowError("StreamReplicas needs FlatAdam (one flat gradient buffer per replica)")
+        self.n = int(n)
+        self.opt = optimizer
+        self.models, self.lossfs, self.streams, self.grads = [model], [loss_function], [None], [optimizer.flat_grad]
+        dev = optimizer.flat_param.device
+        for _ in range(1, self.n):
+            eng = getattr(model, "_engine", None)
+            if eng is not None:
+                model._engine = None  # (built lazily; never copied)
+            shadow = copy.deepcopy(model)
+            if eng is not None:
+                model._engine = eng
+            g = torch.zeros(optimizer.n, dtype=torch.float32, device=dev)
+            off = 0
+            for p, q in zip([p for p in model.parameters() if p.requires_grad], [q for q in shadow.parameters() if q.requires_grad]):
+                k = p.numel()
+                q.data = p.data  # the SAME storage: one set of weights
+                q.grad = g[off:off + k].view(q.shape)
+                off += k
+            shadow.train(model.training)
+            self.models.append(shadow)
+            self.lossfs.append(copy.deepcopy(loss_function))
+            self.streams.append(torch.cuda.Stream(device=dev))
+            self.grads.append(g)
+        optimizer.extra_models = self.models[1:]
+
+    def stream(self, k):
+        return self.streams[k] if self.streams[k] is not None else torch.cuda.current_stream()
+
+    def backward_slice(self, k, passes):
+        """Window of slice k on the CURRENT stream -> its 0-d loss; gradient left in grads[k]."""
+        return window_backward(self.models[k], self.lossfs[k], self.opt, passes, dp=None)
+
+    def combine(self, losses):
+        """Sum the shadows' gradients (cleared on the way) and losses into slice 0's; on the current stream, after it
+        has waited for the slice streams."""
+        import ctypes
+
+        for k in range(1, self.n):
+            ptrs = (ctypes.c_void_p * 32)(self.grads[0].data_ptr())
+            _lib.call("evf_add_segments", _lib.ptr(self.grads[k]), ptrs, (ctypes.c_int * 32)(0), (ctypes.c_int * 32)(self.opt.n), 1, 1)
+            ptrs = (ctypes.c_void_p * 32)(losses[0].data_ptr())
+            _lib.call("evf_add_segments", _lib.ptr(losses[k].detach().view(1)), ptrs, (ctypes.c_int * 32)(0), (ctypes.c_int * 32)(1), 1, 0)
+        return losses[0]
+
+    def apply(self, loss, dp=None):
+        """clip + Adam on the summed gradient, detach / reset of every replica (window_apply)."""
+        out = window_apply(self.models[0], self.lossfs[0], self.opt, loss, dp)
+        for m, lf in zip(self.models[1:], self.lossfs[1:]):
+            m.detach_states()
+            lf.reset()
+        return out
+
+    def train_window(self, passes_per_slice, dp=None):
+        """The whole step, eagerly (replicas on their streams, fork / join around them)."""
+        main = torch.cuda.current_stream()
+        losses = [None] * self.n
+        for k in range(1, self.n):
+            self.streams[k].wait_stream(main)
+        for k in range(self.n):
+            if k == 0:
+                losses[0] = self.backward_slice(0, passes_per_slice[0])
+            else:
+                with torch.cuda.stream(self.streams[k]):
+                    losses[k] = self.backward_slice(k, passes_per_slice[k])
+        for k in range(1, self.n):
+            main.wait_stream(self.streams[k])
+        loss = self.combine(losses)
+        if dp is not None and dp.world > 1:
+            dp.stage(self.opt.comm, loss)
+            dp.reduce(self.opt.comm)
+        return self.apply(loss, dp)
 
 
 def encode_passes(event_lists, num_bins, res, want=("cnt", "mask", "voxel", "pol")):

@@ -93,8 +93,10 @@ def test_forward_per_layer_and_flow(fix):
     assert nflip <= 1e-5 * ntot, (nflip, ntot)
 
 
-def _train_once(g, use_flat_adam, fix="g7_liffirenet_train"):
+def _train_once(g, use_flat_adam, fix="g7_liffirenet_train", precision=None):
     model = build_from_golden(g, fix=fix)
+    if precision:
+        model.precision = precision
     model.train()
     passes = passes_from_golden(g)
     H, W = passes[0]["event_cnt"].shape[2:]
@@ -136,6 +138,20 @@ def test_train_step_vs_golden(fix, flat):
         d = np.abs(newp[k] - ref)
         assert d.max() <= 2 * 2e-4 + 1e-6, k
         assert np.mean(d > 2e-5) <= 0.02, (k, np.mean(d > 2e-5))
+
+
+@pytest.mark.parametrize("fix", ["g7_liffirenet_train", "g7_liffirenet_lowthresh"])
+def test_train_step_vs_golden_on_the_fp32_matrix_path(fix):
+    """model.precision = "fp32" (v_mfma_f32_32x32x2_f32 kernels: k_conv_lif_fwd, k_conv_dgrad, k_conv_wgrad_bits, k_lif_bwd)
+    end to end against the same reference-generated train step as the default bf16x3 path."""
+    g = load_golden(fix)
+    loss, grads, gn, _ = _train_once(g, True, fix, precision="fp32")
+    np.testing.assert_allclose(loss, float(g["loss"]), rtol=2e-4)
+    np.testing.assert_allclose(gn, float(g["grad_norm"]), rtol=2e-3)
+    for k, got in grads.items():
+        ref = g["grad_" + k]
+        denom = max(np.linalg.norm(ref), 1e-12)
+        assert np.linalg.norm(got - ref) <= 2e-3 * denom + 1e-10, (k, np.linalg.norm(got - ref) / denom)
 
 
 def test_train_step_vs_oracle_at_config3_shape():
@@ -591,3 +607,51 @@ def test_event_warping_with_an_empty_pass_and_iwe_of_nothing():
     out = hiwe.compute_pol_iwe(flow, torch.zeros(B, 0, 4, device=DEV), (H, W), torch.zeros(B, 0, 1, device=DEV),
                                torch.zeros(B, 0, 1, device=DEV))
     assert tuple(out.shape) == (B, 2, H, W) and float(out.abs().sum()) == 0.0
+
+
+def test_stream_replicas_step_equals_the_unsplit_step():
+    """train.StreamReplicas: the batch as two micro-batches through two replicas (shared weights, own state / tape /
+    gradient buffer) on two HIP streams, gradients summed before the one optimizer step == the unsplit step, over two
+    consecutive windows (the second starts from the carried recurrent state and the updated weights).
+    (`bench.py --streams 2` replays the same step as one graph per replica on its stream + a join graph.)"""
+    from event_flow_amd.train import StreamReplicas, train_window
+
+    g = load_golden("g7_liffirenet_train")
+    B0 = passes_from_golden(g)[0]["event_cnt"].shape[0]
+    assert B0 % 2 == 0
+    H, W = passes_from_golden(g)[0]["event_cnt"].shape[2:]
+
+    def slice_passes(passes, lo, hi):
+        return [{k: (v[lo:hi].contiguous() if v is not None else None) for k, v in d.items()} for d in passes]
+
+    def run(split):
+        model = build_from_golden(g)
+        model.train()
+        lossf = hloss.EventWarping(loss_cfg(H, W), DEV)
+        opt = FlatAdam(model, lr=2e-4, clip=100.0)
+        opt.zero_grad()
+        reps = StreamReplicas(model, lossf, opt, n=2) if split else None
+        out = []
+        for w in range(2):
+            passes = passes_from_golden(g)
+            if split:
+                loss = reps.train_window([slice_passes(passes, 0, B0 // 2), slice_passes(passes, B0 // 2, B0)])
+            else:
+                loss = train_window(model, lossf, opt, passes)
+            torch.cuda.synchronize()
+            out.append((float(loss), {k: N(v).copy() for k, v in model.state_dict().items()}, opt.grad_norm()))
+        if split:  # the replicas really share the weights
+            for m in reps.models[1:]:
+                for p, q in zip(model.parameters(), m.parameters()):
+                    assert p.data_ptr() == q.data_ptr()
+        return out
+
+    ref, got = run(False), run(True)
+    for (l0, p0, n0), (l1, p1, n1) in zip(ref, got):
+        np.testing.assert_allclose(l1, l0, rtol=1e-5)
+        np.testing.assert_allclose(n1, n0, rtol=1e-4)
+        for k in p0:
+            # (Adam's first steps move every weight by ~lr * sign(g): compare the bulk, as the golden-step test does)
+            d = np.abs(p1[k] - p0[k])
+            assert d.max() <= 2 * 2e-4 + 1e-6, k
+            assert np.mean(d > 2e-5) <= 0.02, (k, np.mean(d > 2e-5))
