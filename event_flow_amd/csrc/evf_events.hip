@@ -113,7 +113,7 @@ __global__ void k_encode_window(const float4* __restrict__ ev, int B, int P, int
 // dense: ONE allocation [cnt | voxel | mask] (the parts `want` selects: 1 cnt, 2 voxel, 4 mask), zero-filled here in one go
 extern "C" int evf_encode_window(const float* ev, int B, int P, int N, int H, int W, int num_bins, int round_ts, int want,
                                  float* dense, float* pol, void* stream) {
-  if (!ev || B <= 0 || P <= 0 || N < 0 || H <= 0 || W <= 0 || ((want & 2) && num_bins < 1) || ((want & 7) && !dense))
+  if ((N > 0 && !ev) || B <= 0 || P <= 0 || N < 0 || H <= 0 || W <= 0 || ((want & 2) && num_bins < 1) || ((want & 7) && !dense))
     return EVF_EINVAL;
   hipStream_t st = EVF_STREAM(stream);
   const size_t HW = (size_t)H * W, S = (size_t)B * P;

@@ -10,7 +10,7 @@ from conftest import golden_cases, load_golden
 
 pytestmark = pytest.mark.gpu
 
-from event_flow_amd import synthetic  # noqa: E402
+from event_flow_amd import _lib, synthetic  # noqa: E402
 from event_flow_amd.dataloader import encodings as enc  # noqa: E402
 from event_flow_amd.loss import flow as hloss  # noqa: E402
 from event_flow_amd.utils import iwe as hiwe  # noqa: E402
@@ -366,3 +366,34 @@ def test_pol_iwe_register_resident_kernel_bit_exact(shape):
     assert np.array_equal(got, ref)
     one = N(hiwe.deblur_events(G(flow), G(ev), (H, W), flow_scaling=128, round_idx=True))
     assert np.array_equal(one, oiwe.deblur_events(flow, ev, (H, W), 128, True))
+
+
+def test_encode_window_edge_cases():
+    """evf_encode_window: subsets of the outputs, a single pass, padding events (p = 0), out-of-image coordinates, no
+    events at all, and loud failures for the wrong layout."""
+    B, P, n, H, W = 2, 3, 50, 12, 16
+    rng = np.random.default_rng(3)
+    ev = np.zeros((B, P, n, 4), np.float32)
+    ev[..., 0] = rng.uniform(0, 1, (B, P, n))
+    ev[..., 1] = rng.integers(-2, H + 2, (B, P, n))  # some rows outside the image
+    ev[..., 2] = rng.integers(0, W, (B, P, n))
+    ev[..., 3] = rng.choice([-1.0, 0.0, 1.0], (B, P, n))  # p = 0: padding
+    evd = G(ev)
+    for want in (("cnt",), ("mask", "pol"), ("voxel",), ("cnt", "mask", "voxel", "pol")):
+        many = enc.encode_window(evd, 4, (H, W), want=want)
+        for p, d in enumerate(many):
+            one = enc.encode_event_list(evd[:, p].contiguous(), 4, (H, W), want=want)
+            assert set(d) == set(one), want
+            for k in one:
+                if k == "event_voxel":
+                    np.testing.assert_allclose(N(d[k]), N(one[k]), rtol=0, atol=1e-5)
+                else:
+                    assert torch.equal(d[k], one[k]), (want, k)
+    single = enc.encode_window(evd[:, :1].contiguous(), 2, (H, W), want=("cnt", "mask", "pol"))
+    assert len(single) == 1 and torch.equal(single[0]["event_cnt"], enc.encode_event_list(evd[:, 0].contiguous(), 2, (H, W))["event_cnt"])
+    empty = enc.encode_window(torch.zeros(B, P, 0, 4, device=DEV), 2, (H, W), want=("cnt", "mask", "pol"))
+    assert float(empty[0]["event_cnt"].abs().sum()) == 0 and tuple(empty[2]["event_list_pol_mask"].shape) == (B, 0, 2)
+    with pytest.raises(_lib.EvflowError):
+        enc.encode_window(evd.permute(1, 0, 2, 3), 2, (H, W))  # pass-major view: not contiguous
+    with pytest.raises(_lib.EvflowError):
+        enc.encode_window(evd.cpu(), 2, (H, W))

@@ -144,6 +144,36 @@ def test_conv2d_b3_spike_inputs_take_the_three_term_product_without_changing_res
     assert not np.array_equal(ya[0, :, 0, 0], yb[0, :, 0, 0])
 
 
+@pytest.mark.parametrize("conv_mode", ["b3", "b3tile", "b3split", "b3tilesplit"], indirect=True)
+@pytest.mark.parametrize("case", [(2, 64, 96, 20, 36, 3, 1), (1, 132, 30, 17, 33, 3, 1), (2, 32, 64, 12, 12, 3, 2), (1, 48, 8, 9, 9, 1, 1)])
+def test_conv2d_b3_bias_and_accumulate_through_every_kernel(case, conv_mode):
+    """y (+)= conv(x) + bias and g_x (+)= conv^T(g_y) through the general, tiled and split-K kernels: the accumulate and
+    bias paths of their epilogues and of the slab reduction (recurrent cells accumulate the rec conv into the ff conv)."""
+    B, Cin, Cout, H, W, k, s = case
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H, W, Cin, generator=gen)
+    w = torch.randn(Cout, Cin, k, k, generator=gen) * 0.2
+    b = torch.randn(Cout, generator=gen)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=s, padding=k // 2).permute(0, 2, 3, 1)
+    y0 = torch.randn(ref.shape, generator=gen)
+    xd, wd, bd = G(x.numpy()), G(w.numpy()), G(b.numpy())
+    cache = hip_ops._PackCache()
+    y = G(y0.numpy())
+    hip_ops.conv_fwd(xd, cache.get(wd, 0, 0, Cin), bd, y, Cin, Cout, k, s, accumulate=1)
+    close(N(y), (ref + y0.double()).numpy(), 1e-5, "fwd accumulate + bias")
+    y = G(y0.numpy())
+    hip_ops.conv_fwd(xd, cache.get(wd, 0, 0, Cin), None, y, Cin, Cout, k, s, accumulate=0)
+    close(N(y), (ref - b.double()).numpy(), 1e-5, "fwd overwrite")
+    # input gradient, accumulate into an existing gradient
+    gy = torch.randn(ref.shape, generator=gen)
+    xr = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, w.double(), None, stride=s, padding=k // 2).backward(gy.permute(0, 3, 1, 2).double())
+    gx0 = torch.randn(B, H, W, Cin, generator=gen)
+    gx = G(gx0.numpy())
+    hip_ops.conv_dgrad(G(gy.numpy()), cache.get(wd, 1, 0, Cin), gx, Cin, Cout, k, s, accumulate=1)
+    close(N(gx), (xr.grad.permute(0, 2, 3, 1) + gx0.double()).numpy(), 1e-5, "dgrad accumulate")
+
+
 def test_conv_bad_arguments_fail_loudly():
     x = torch.zeros(1, 4, 8, 8, device=DEV)
     w = torch.zeros(4, 4, 4, 4, device=DEV)  # even kernel sizes do not exist in the reference (padding k/2) and are not built
