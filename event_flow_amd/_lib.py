@@ -96,7 +96,7 @@ NETWORK_SIGNATURES = {
     "evf_conv2d_wgrad_ws": [I, I, I, I, I, I, I],
     "evf_conv2d_wgrad": [P, I, P, I, P, P, I, I, I, I, I, I, I, I, I, I, P, P],
     "evf_neuron_fwd": [I, P, P, P, P, P, P, P, P, P, P, L, I, I, P, P, P, P, P],
-    "evf_neuron_bwd": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, F, P, P, P, P, P, P, P, P, P, P],
+    "evf_neuron_bwd": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P],
     "evf_pretrace_fwd": [P, I, I, I, I, I, I, I, P, P, P],
     "evf_pretrace_bwd": [P, I, P, I, I, I, I, I, I, P, I, I, P],
     "evf_concat_channels": [P, P, P, I, L, P, I, P],

@@ -49,7 +49,7 @@ __device__ __forceinline__ float4 ng_ld(const float4* p, const float4* dummy, lo
   return p ? v : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-template <int KIND>
+template <int KIND, bool PREV, bool RES>
 __global__ void k_neuron_fwd(const float4* __restrict__ cur, const float4* __restrict__ v_prev,
                              const float4* __restrict__ z_prev, const float4* __restrict__ aux_prev,
                              const float* __restrict__ P, const float4* __restrict__ residual, NgParams prm, long npix, int C,
@@ -71,7 +71,9 @@ __global__ void k_neuron_fwd(const float4* __restrict__ cur, const float4* __res
   }
   for (; e < total; e += stride) {
     const long pix = e / Q;
-    const float4 c4 = cur[e], v4 = ng_ld(v_prev, cur, e), z4 = ng_ld(z_prev, cur, e), x4 = ng_ld(aux_prev, cur, e);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);  // (absent operands: compile-time zeros, no dummy loads)
+    const float4 c4 = cur[e], v4 = PREV ? ng_ld(v_prev, cur, e) : zero4, z4 = PREV ? ng_ld(z_prev, cur, e) : zero4,
+                 x4 = (PREV && KIND != EVF_LIF) ? ng_ld(aux_prev, cur, e) : zero4;
     const float Pv = (KIND == EVF_PLIF || KIND == EVF_XLIF) ? P[pix] : 0.f;
     const float cu[4] = {c4.x, c4.y, c4.z, c4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w}, z[4] = {z4.x, z4.y, z4.z, z4.w};
     const float ax[4] = {x4.x, x4.y, x4.z, x4.w};
@@ -101,7 +103,7 @@ __global__ void k_neuron_fwd(const float4* __restrict__ cur, const float4* __res
     z_out[e] = make_float4(zo[0], zo[1], zo[2], zo[3]);
     if (KIND != EVF_LIF) aux_out[e] = make_float4(ao[0], ao[1], ao[2], ao[3]);
     if (out) {
-      const float4 r4 = ng_ld(residual, cur, e);
+      const float4 r4 = RES ? residual[e] : zero4;
       out[e] = make_float4(zo[0] + r4.x, zo[1] + r4.y, zo[2] + r4.z, zo[3] + r4.w);
     }
   }
@@ -122,10 +124,18 @@ extern "C" int evf_neuron_fwd(int kind, const float* cur, const float* v_prev, c
   const int Q = C >> 2, bs = ng_block(Q);
   const long total = npix * Q;
   const int nblk = (int)((total + bs - 1) / bs < 4096 ? (total + bs - 1) / bs : 4096);
-#define NG_FWD(K)                                                                                                       \
-  hipLaunchKernelGGL(k_neuron_fwd<K>, dim3(nblk), dim3(bs), 0, EVF_STREAM(stream), (const float4*)cur,                  \
+  const bool prev = v_prev || z_prev || aux_prev, res = residual != nullptr;
+#define NG_FWD_(K, P_, R_)                                                                                              \
+  hipLaunchKernelGGL((k_neuron_fwd<K, P_, R_>), dim3(nblk), dim3(bs), 0, EVF_STREAM(stream), (const float4*)cur,        \
                      (const float4*)v_prev, (const float4*)z_prev, (const float4*)aux_prev, P, (const float4*)residual, \
                      prm, (long)npix, C, hard_reset, (float4*)v_out, (float4*)z_out, (float4*)aux_out, (float4*)out)
+#define NG_FWD(K)                                 \
+  do {                                            \
+    if (prev && res) NG_FWD_(K, true, true);      \
+    else if (prev) NG_FWD_(K, true, false);       \
+    else if (res) NG_FWD_(K, false, true);        \
+    else NG_FWD_(K, false, false);                \
+  } while (0)
   switch (kind) {
     case EVF_LIF: NG_FWD(EVF_LIF); break;
     case EVF_PLIF: NG_FWD(EVF_PLIF); break;
@@ -133,20 +143,25 @@ extern "C" int evf_neuron_fwd(int kind, const float* cur, const float* v_prev, c
     default: NG_FWD(EVF_XLIF); break;
   }
 #undef NG_FWD
+#undef NG_FWD_
   return evf_status();
 }
 
 // backward.  Saved: v_out, aux_out, v_prev, z_prev, aux_prev, P.  Upstream: g_v_out (state carry),
 // g_z_out + g_z_out2 (through the layer output and through the z entry of the state), g_aux_out (trace carry).
 // g_P [npix] = d loss / d pooled activity (PLIF/XLIF), g_z_prev only for ALIF (threshold trace reads z).
-template <int KIND>
+// GST: a state gradient arrives from the next pass (g_v_out / g_z_out2 / g_aux_out); PREV: there is a previous state.
+// Absent groups are compile-time zeros: no dummy loads (each costs a texture-addresser slot), no wasted stores.
+#define NG_REP 32
+template <int KIND, bool GST, bool PREV>
 __global__ void k_neuron_bwd(const float4* __restrict__ g_v_out, const float4* __restrict__ g_z_out,
                              const float4* __restrict__ g_z_out2, const float4* __restrict__ g_aux_out, const float4* __restrict__ v_out,
                              const float4* __restrict__ aux_out, const float4* __restrict__ v_prev,
                              const float4* __restrict__ z_prev, const float4* __restrict__ aux_prev,
                              const float* __restrict__ P, NgParams prm, long npix, int C, int hard, int surrogate,
                              float width, float4* __restrict__ g_cur, float4* __restrict__ g_v_prev,
-                             float4* __restrict__ g_z_prev, float4* __restrict__ g_aux_prev, float* __restrict__ g_P) {
+                             float4* __restrict__ g_z_prev, float4* __restrict__ g_aux_prev, float* __restrict__ g_P,
+                             float* __restrict__ ws) {
   extern __shared__ float s_acc[];  // [4][C]
   const int Q = C >> 2;
   const long total = npix * Q, stride = (long)gridDim.x * blockDim.x;
@@ -174,10 +189,12 @@ __global__ void k_neuron_bwd(const float4* __restrict__ g_v_out, const float4* _
     const long e = base + gtid;
     const bool ok = e < total;
     const long ec = ok ? e : total - 1, pix = ec / Q;
-    const float4 gv4 = ng_ld(g_v_out, v_out, ec), gza = ng_ld(g_z_out, v_out, ec), gzb = ng_ld(g_z_out2, v_out, ec),
-                 ga4 = ng_ld(g_aux_out, v_out, ec);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 gv4 = GST ? ng_ld(g_v_out, v_out, ec) : zero4, gza = ng_ld(g_z_out, v_out, ec),
+                 gzb = GST ? ng_ld(g_z_out2, v_out, ec) : zero4, ga4 = (GST && KIND != EVF_LIF) ? ng_ld(g_aux_out, v_out, ec) : zero4;
     const float4 gz4 = make_float4(gza.x + gzb.x, gza.y + gzb.y, gza.z + gzb.z, gza.w + gzb.w);
-    const float4 vo4 = v_out[ec], v4 = ng_ld(v_prev, v_out, ec), z4 = ng_ld(z_prev, v_out, ec), x4 = ng_ld(aux_prev, v_out, ec);
+    const float4 vo4 = v_out[ec], v4 = PREV ? ng_ld(v_prev, v_out, ec) : zero4, z4 = PREV ? ng_ld(z_prev, v_out, ec) : zero4,
+                 x4 = (PREV && KIND != EVF_LIF) ? ng_ld(aux_prev, v_out, ec) : zero4;
     const float4 ao4 = (KIND != EVF_LIF) ? aux_out[ec] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float Pv = (KIND == EVF_PLIF || KIND == EVF_XLIF) ? P[pix] : 0.f;
     const float gvo[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, gz[4] = {gz4.x, gz4.y, gz4.z, gz4.w};
@@ -235,9 +252,11 @@ __global__ void k_neuron_bwd(const float4* __restrict__ g_v_out, const float4* _
     }
     if (ok) {
       g_cur[e] = make_float4(gc[0], gc[1], gc[2], gc[3]);
-      g_v_prev[e] = make_float4(gp[0], gp[1], gp[2], gp[3]);
-      if (KIND != EVF_LIF) g_aux_prev[e] = make_float4(gap[0], gap[1], gap[2], gap[3]);
-      if (KIND == EVF_ALIF) g_z_prev[e] = make_float4(gzp[0], gzp[1], gzp[2], gzp[3]);
+      if (g_v_prev) {  // (null: the previous state takes no gradient -- uniform)
+        g_v_prev[e] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+        if (KIND != EVF_LIF) g_aux_prev[e] = make_float4(gap[0], gap[1], gap[2], gap[3]);
+        if (KIND == EVF_ALIF) g_z_prev[e] = make_float4(gzp[0], gzp[1], gzp[2], gzp[3]);
+      }
     }
     if (KIND == EVF_PLIF || KIND == EVF_XLIF) {
       if (Q <= 64) {
@@ -249,6 +268,18 @@ __global__ void k_neuron_bwd(const float4* __restrict__ g_v_out, const float4* _
       }
     }
   }
+  // lanes l, l + Q, l + 2Q ... of a wave own the same channels (Q a power of two below 64): meet in registers first, so
+  // that one lane per channel quad and wave issues the LDS float atomics (slow on gfx950)
+  if (Q < 64) {
+    for (int o = Q; o < 64; o <<= 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s0[k] += __shfl_xor(s0[k], o, 64), s1[k] += __shfl_xor(s1[k], o, 64);
+        if (KIND != EVF_LIF) s2[k] += __shfl_xor(s2[k], o, 64), s3[k] += __shfl_xor(s3[k], o, 64);
+      }
+    }
+  }
+  if (Q >= 64 || (int)(threadIdx.x & 63) < Q) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int c = 4 * cq + k;
@@ -262,12 +293,37 @@ __global__ void k_neuron_bwd(const float4* __restrict__ g_v_out, const float4* _
       atomicAdd(&s_acc[3 * C + c], s3[k] * a3[k] * (1.0f - a3[k]));
     }
   }
+  }
   __syncthreads();
   const int np = KIND == EVF_LIF ? 2 : 4;
-  for (int i = threadIdx.x; i < np * C; i += blockDim.x) {
-    const int p = i / C, c = i - p * C;
-    if (prm.g[p]) evf_atomic_add(prm.g[p] + c, s_acc[i]);
+  if (!ws) {  // (no scratch: every block adds straight into the 2..4 x C outputs -- up to 1024 atomics per address)
+    for (int i = threadIdx.x; i < np * C; i += blockDim.x) {
+      const int p = i / C, c = i - p * C;
+      if (prm.g[p]) evf_atomic_add(prm.g[p] + c, s_acc[i]);
+    }
+    return;
   }
+  // Same-address atomics serialise at the memory side (1024 blocks on 128 words: +20..30 us per launch): the blocks are
+  // spread over NG_REP replicas in scratch; k_ng_finish (next launch) sums the replicas into the outputs and hands the
+  // scratch back zeroed.  ws: [NG_REP][4 * 1024] floats, zero on entry and on exit.
+  float* mine = ws + (size_t)(blockIdx.x % NG_REP) * 4096;
+  for (int i = threadIdx.x; i < np * C; i += blockDim.x) evf_atomic_add(mine + i, s_acc[i]);
+}
+
+__global__ void k_ng_finish(float* __restrict__ ws, int nrep, int n, int C, NgParams prm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v[NG_REP];
+#pragma unroll
+  for (int r = 0; r < NG_REP; ++r) v[r] = r < nrep ? ws[(size_t)r * 4096 + i] : 0.f;
+  float t = 0.f;
+#pragma unroll
+  for (int r = 0; r < NG_REP; ++r) {
+    t += v[r];
+    if (r < nrep) ws[(size_t)r * 4096 + i] = 0.f;
+  }
+  const int p = i / C, c = i - p * C;
+  if (prm.g[p]) prm.g[p][c] += t;
 }
 
 extern "C" int evf_neuron_bwd(int kind, const float* g_v_out, const float* g_z_out, const float* g_z_out2,
@@ -276,14 +332,14 @@ extern "C" int evf_neuron_bwd(int kind, const float* g_v_out, const float* g_z_o
                               const float* aux_prev, const float* P, const float* p0, const float* p1, const float* p2,
                               const float* p3, int64_t npix, int C, int hard_reset, int surrogate, float act_width,
                               float* g_cur, float* g_v_prev, float* g_z_prev, float* g_aux_prev, float* g_P, float* g_p0,
-                              float* g_p1, float* g_p2, float* g_p3, void* stream) {
-  if (!v_out || !p0 || !p1 || !g_cur || !g_v_prev || npix <= 0 || C <= 0 || (C & 3) || C > 1024 || kind < 0 || kind > 3)
+                              float* g_p1, float* g_p2, float* g_p3, float* ws, void* stream) {
+  if (!v_out || !p0 || !p1 || !g_cur || npix <= 0 || C <= 0 || (C & 3) || C > 1024 || kind < 0 || kind > 3)
     return EVF_EINVAL;
   const int Q = C >> 2;
   if (Q < 64 && (Q & (Q - 1))) return EVF_EINVAL;  // the in-wave pixel reduction needs a power of two
-  if (kind != EVF_LIF && (!p2 || !p3 || !aux_out || !g_aux_prev)) return EVF_EINVAL;
+  if (kind != EVF_LIF && (!p2 || !p3 || !aux_out || (g_v_prev && !g_aux_prev))) return EVF_EINVAL;
   if ((kind == EVF_PLIF || kind == EVF_XLIF) && (!P || !g_P)) return EVF_EINVAL;
-  if (kind == EVF_ALIF && !g_z_prev) return EVF_EINVAL;
+  if (kind == EVF_ALIF && g_v_prev && !g_z_prev) return EVF_EINVAL;
   hipStream_t st = EVF_STREAM(stream);
   if ((kind == EVF_PLIF || kind == EVF_XLIF) && Q > 64) {
     const int rc = evf_hip(hipMemsetAsync(g_P, 0, sizeof(float) * (size_t)npix, st));
@@ -294,11 +350,19 @@ extern "C" int evf_neuron_bwd(int kind, const float* g_v_out, const float* g_z_o
   const long total = npix * Q;
   const int nblk = (int)((total + bs - 1) / bs < 1024 ? (total + bs - 1) / bs : 1024);
   const size_t smem = sizeof(float) * 4 * (size_t)C;
-#define NG_BWD(K)                                                                                                          \
-  hipLaunchKernelGGL(k_neuron_bwd<K>, dim3(nblk), dim3(bs), smem, st, (const float4*)g_v_out, (const float4*)g_z_out,      \
+  const bool gst = g_v_out || g_z_out2 || g_aux_out, prev = v_prev || z_prev || aux_prev;
+#define NG_BWD_(K, G_, P_)                                                                                                 \
+  hipLaunchKernelGGL((k_neuron_bwd<K, G_, P_>), dim3(nblk), dim3(bs), smem, st, (const float4*)g_v_out, (const float4*)g_z_out, \
                      (const float4*)g_z_out2, (const float4*)g_aux_out, (const float4*)v_out, (const float4*)aux_out, (const float4*)v_prev,        \
                      (const float4*)z_prev, (const float4*)aux_prev, P, prm, (long)npix, C, hard_reset, surrogate,         \
-                     act_width, (float4*)g_cur, (float4*)g_v_prev, (float4*)g_z_prev, (float4*)g_aux_prev, g_P)
+                     act_width, (float4*)g_cur, (float4*)g_v_prev, (float4*)g_z_prev, (float4*)g_aux_prev, g_P, ws)
+#define NG_BWD(K)                                   \
+  do {                                              \
+    if (gst && prev) NG_BWD_(K, true, true);        \
+    else if (gst) NG_BWD_(K, true, false);          \
+    else if (prev) NG_BWD_(K, false, true);         \
+    else NG_BWD_(K, false, false);                  \
+  } while (0)
   switch (kind) {
     case EVF_LIF: NG_BWD(EVF_LIF); break;
     case EVF_PLIF: NG_BWD(EVF_PLIF); break;
@@ -306,6 +370,11 @@ extern "C" int evf_neuron_bwd(int kind, const float* g_v_out, const float* g_z_o
     default: NG_BWD(EVF_XLIF); break;
   }
 #undef NG_BWD
+#undef NG_BWD_
+  if (ws) {
+    const int np = kind == EVF_LIF ? 2 : 4, n = np * C;
+    hipLaunchKernelGGL(k_ng_finish, dim3(evf_cdiv(n, 64)), dim3(64), 0, st, ws, nblk < NG_REP ? nblk : NG_REP, n, C, prm);
+  }
   return evf_status();
 }
 

@@ -285,6 +285,16 @@ def cell_params(cell):
     return [cell.leak_v, cell.t0, cell.t1, cell.leak_pt]
 
 
+_NEURON_WS = {}
+
+
+def _neuron_ws(dev):
+    """Zeroed scratch of evf_neuron_bwd (the kernel hands it back zeroed; one per device, calls are stream-ordered)."""
+    if dev not in _NEURON_WS:
+        _NEURON_WS[dev] = torch.zeros(32 * 4096 + 64, dtype=torch.float32, device=dev)
+    return _NEURON_WS[dev]
+
+
 class StateSlots:
     """New-state tensors of the n cells of a block in ONE buffer [n, S, B, H, W, C], so that the block's stacked state
     (reference: torch.stack([ff, rec]), spiking_submodules.py:926, :973) exists without a copy."""
@@ -394,7 +404,9 @@ class _CellStep(torch.autograd.Function):
         g_cur = _new((B, Ho, Wo, C), dev)
         # the kernel writes dL/dv_prev and dL/d(trace)_prev; dL/dz_prev only for ALIF -- otherwise that slice is
         # the recurrent conv's input gradient (written below) or zero
-        g_prev = _new((ns, B, Ho, Wo, C), dev)
+        # (no previous state, or one that takes no gradient: the kernel skips those stores)
+        want_prev = sp is not None and need[2]
+        g_prev = _new((ns, B, Ho, Wo, C), dev) if want_prev else None
         rec_dgrad = cell.recurrent and sp is not None and need[2]
         if kind != 2 and not rec_dgrad and sp is not None and need[2]:  # (only a returned state gradient needs the zeros)
             g_prev[1].zero_()
@@ -410,8 +422,9 @@ class _CellStep(torch.autograd.Function):
                   _lib.ptr(sp[1]) if sp is not None else None, _lib.ptr(sp[2]) if (sp is not None and ns == 3) else None,
                   _lib.ptr(P), _lib.ptr(prm[0]), _lib.ptr(prm[1]), _lib.ptr(prm[2]), _lib.ptr(prm[3]), B * Ho * Wo, C,
                   1 if cell.hard_reset else 0, SURROGATE_ID[cell.activation], act_width(cell), _lib.ptr(g_cur),
-                  _lib.ptr(g_prev[0]), _lib.ptr(g_prev[1]), _lib.ptr(g_prev[2]) if ns == 3 else None, _lib.ptr(g_P),
-                  _lib.ptr(g_prm[0]), _lib.ptr(g_prm[1]), _lib.ptr(g_prm[2]), _lib.ptr(g_prm[3]))
+                  _lib.ptr(g_prev[0]) if want_prev else None, _lib.ptr(g_prev[1]) if want_prev else None,
+                  _lib.ptr(g_prev[2]) if (want_prev and ns == 3) else None, _lib.ptr(g_P),
+                  _lib.ptr(g_prm[0]), _lib.ptr(g_prm[1]), _lib.ptr(g_prm[2]), _lib.ptr(g_prm[3]), _lib.ptr(_neuron_ws(dev)))
         g_wff = g_wrec = g_x = None
         if need[4]:
             d = bound_grad(wff)

@@ -449,14 +449,19 @@ int evf_neuron_fwd(int kind, const float* cur, const float* v_prev, const float*
  * uses z detached, spiking_submodules.py:116-120).  Upstream gradients (any may be null):
  * g_v_out, g_z_out + g_z_out2, g_aux_out.  Writes g_cur, g_v_prev, g_aux_prev (kind != LIF),
  * g_z_prev (ALIF only: its threshold trace integrates z), g_P [npix] (PLIF/XLIF); parameter
- * gradients g_p0..g_p3 [C] are ACCUMULATED (null = skip). */
+ * gradients g_p0..g_p3 [C] are ACCUMULATED (null = skip).  g_v_prev null = the previous state takes no gradient
+ * (first pass of a window, detached state): g_v_prev / g_aux_prev / g_z_prev are not written.  Absent operand groups
+ * (no upstream state gradient, no previous state) select kernel variants without their loads.
+ * ws: optional scratch of EVF_NEURON_BWD_WS floats, ZERO on entry and left zero on exit: the blocks' parameter-gradient
+ * sums meet in 32 replicas there instead of 1024 blocks adding atomically into the same 2..4 x C words (null: they do). */
+#define EVF_NEURON_BWD_WS (32 * 4096)
 int evf_neuron_bwd(int kind, const float* g_v_out, const float* g_z_out, const float* g_z_out2,
                    const float* g_aux_out, const float* v_out, const float* aux_out, const float* v_prev,
                    const float* z_prev, const float* aux_prev, const float* P, const float* p0,
                    const float* p1, const float* p2, const float* p3, int64_t npix, int C, int hard_reset,
                    int surrogate, float act_width, float* g_cur, float* g_v_prev, float* g_z_prev,
                    float* g_aux_prev, float* g_P, float* g_p0, float* g_p1, float* g_p2, float* g_p3,
-                   void* stream);
+                   float* ws, void* stream);
 /* P [B,Ho,Wo] = avg_pool2d(mean_c |x|, k, stride, k/2) (spiking_submodules.py:212,418);
  * absmean_ws [B*H*W] workspace.  Backward adds/writes sign(x)/C * pool^T(g_P) into g_x. */
 int evf_pretrace_fwd(const float* x, int ldx, int B, int H, int W, int C, int ksz, int stride,
