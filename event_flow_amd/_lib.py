@@ -66,7 +66,7 @@ NETWORK_SIGNATURES = {
     "evf_conv_dgrad_b3_f32_pair": [P, P, P, I, P, P, I, I, I, P, P, P],
     "evf_conv_plif_fwd_b3": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P],
     "evf_head_plif_fwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P],
-    "evf_plif_trace_bwd": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P],
+    "evf_plif_trace_bwd": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, I, P],
     "evf_conv_dgrad": [P, P, P, I, P, P, I, I, I, I, P],
     "evf_conv_wgrad_bits": [P, P, I, I, I, P, I, P],
     "evf_conv_wgrad_slabs": [I, I, I],

@@ -426,7 +426,7 @@ __global__ void k_plif_trace_bwd(const float4* __restrict__ g_cur, const float4*
                                  const float* __restrict__ P, const float* __restrict__ leak_pt,
                                  const float* __restrict__ add_pt, long npix, float4* __restrict__ g_pt_prev,
                                  float* __restrict__ g_P, float* __restrict__ g_leak_pt,
-                                 float* __restrict__ g_add_pt) {
+                                 float* __restrict__ g_add_pt, int row_ld) {
   __shared__ float s_red[2][4][C32];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, cg = tid & 7;
   float lp[4], ap[4];
@@ -486,7 +486,9 @@ __global__ void k_plif_trace_bwd(const float4* __restrict__ g_cur, const float4*
     float v = 0.f;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += s_red[which][w][c];
     const float sgm = evf_sigmoid(which == 0 ? leak_pt[c] : add_pt[c]);
-    evf_atomic_add((which == 0 ? g_leak_pt : g_add_pt) + c, v * sgm * (1.0f - sgm));
+    float* dst = (which == 0 ? g_leak_pt : g_add_pt) + c;
+    if (row_ld) dst[(size_t)blockIdx.x * row_ld] += v * sgm * (1.0f - sgm);  // (per-block rows, see k_lif_bwd_wgrad)
+    else evf_atomic_add(dst, v * sgm * (1.0f - sgm));
   }
 }
 
@@ -513,7 +515,7 @@ __global__ void k_plif_box(const float* __restrict__ g, int B, int H, int W, flo
 extern "C" int evf_plif_trace_bwd(const float* g_cur, const float* g_pt_carry, const float* pt_prev, const float* pt_out,
                                   const float* P, const float* leak_pt, const float* add_pt, int B, int H, int W,
                                   float* g_pt_prev, float* g_P_raw, float* g_P_in, float* g_leak_pt, float* g_add_pt,
-                                  void* stream) {
+                                  int row_ld, void* stream) {
   if (!g_cur || !pt_out || !P || !leak_pt || !add_pt || !g_pt_prev || !g_P_raw || !g_P_in || !g_leak_pt || !g_add_pt ||
       B <= 0 || H <= 0 || W <= 0)
     return EVF_EINVAL;
@@ -521,7 +523,7 @@ extern "C" int evf_plif_trace_bwd(const float* g_cur, const float* g_pt_carry, c
   const int nblk = (int)((npix * 8 + 255) / 256 < 512 ? (npix * 8 + 255) / 256 : 512);
   hipLaunchKernelGGL(k_plif_trace_bwd, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)g_cur,
                      (const float4*)g_pt_carry, (const float4*)pt_prev, (const float4*)pt_out, P, leak_pt, add_pt, npix,
-                     (float4*)g_pt_prev, g_P_raw, g_leak_pt, g_add_pt);
+                     (float4*)g_pt_prev, g_P_raw, g_leak_pt, g_add_pt, row_ld);
   hipLaunchKernelGGL(k_plif_box, dim3(evf_cdiv(npix, 256)), dim3(256), 0, EVF_STREAM(stream), g_P_raw, B, H, W, g_P_in);
   return evf_status();
 }
@@ -664,7 +666,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_mfma(
     const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev, const float* __restrict__ leak,
     const float* __restrict__ thresh, long npix, int hard_reset, int surrogate, float width, float4* __restrict__ g_cur,
     float4* __restrict__ g_v_prev, float* __restrict__ g_leak, float* __restrict__ g_thresh,
-    const float* __restrict__ x_in, int Cin, int H, int W, float* __restrict__ slab, int slab_acc) {
+    const float* __restrict__ x_in, int Cin, int H, int W, float* __restrict__ slab, int slab_acc, int row_ld) {
   __shared__ float s_red[2][4][C32];
   __shared__ __attribute__((aligned(16))) float s_g[2][4][8 * C32];  // [buffer][wave][pixel][channel]
   __shared__ float s_d[4][C32 * C32];
@@ -795,11 +797,14 @@ __global__ __launch_bounds__(256) void k_head_bwd_mfma(
     const int which = tid >> 5, c = tid & 31;
     float v = 0.f;
     for (int w = 0; w < 4; ++w) v += s_red[which][w][c];
+    const size_t ro = (size_t)blockIdx.x * row_ld;  // (row_ld > 0: per-block rows instead of same-address atomics)
     if (which == 0) {
-      const float l = evf_sigmoid(leak[c]);
-      evf_atomic_add(g_leak + c, v * l * (1.0f - l));
+      const float l = evf_sigmoid(leak[c]), t = v * l * (1.0f - l);
+      if (row_ld) g_leak[ro + c] += t;
+      else evf_atomic_add(g_leak + c, t);
     } else if (thresh[c] > 0.01f) {
-      evf_atomic_add(g_thresh + c, v);
+      if (row_ld) g_thresh[ro + c] += v;
+      else evf_atomic_add(g_thresh + c, v);
     }
   }
 }
@@ -824,10 +829,12 @@ extern "C" int evf_head_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out
     return EVF_EINVAL;
   const long npix = (long)B * H * W;
   const int nblk = evf_head_lif_bwd_wgrad_slabs(B, H, W);
+  const int row_ld = accumulate >> 8;  // pitch of the per-block parameter-gradient rows (0: dense outputs, atomics)
+  accumulate &= 1;
   hipLaunchKernelGGL(k_head_bwd_mfma, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)g_z_out,
                      (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev, z_prev, leak, thresh, npix,
                      hard_reset, surrogate, act_width, (float4*)g_cur, (float4*)g_v_prev, g_leak, g_thresh, x_in, Cin, H, W,
-                     slab, accumulate);
+                     slab, accumulate, row_ld);
   return evf_status();
 }
 
@@ -860,14 +867,17 @@ extern "C" int evf_add_segments(float* src, void* const* dst, const int* off, co
 }
 
 // dst[e] (+)= sum_k rows[k][e]: 16 columns x 16 row groups per block, LDS tree over the groups
-__global__ __launch_bounds__(256) void k_sum_rows(const float* __restrict__ rows, int nrows, int n, int accumulate,
-                                                  float* __restrict__ dst) {
+__global__ __launch_bounds__(256) void k_sum_rows(float* __restrict__ rows, int nrows, int n, int accumulate,
+                                                  float* __restrict__ dst, int clear) {
   __shared__ float s[16][17];
   const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int e = blockIdx.x * 16 + c;
   float v = 0.f;
   if (e < n)
-    for (int k = grp; k < nrows; k += 16) v += rows[(long)k * n + e];
+    for (int k = grp; k < nrows; k += 16) {
+      v += rows[(long)k * n + e];
+      if (clear) rows[(long)k * n + e] = 0.f;  // (a persistent buffer of per-block partials is handed back zeroed)
+    }
   s[grp][c] = v;
   __syncthreads();
   if (grp == 0 && e < n) {
@@ -877,9 +887,11 @@ __global__ __launch_bounds__(256) void k_sum_rows(const float* __restrict__ rows
     dst[e] = accumulate ? dst[e] + t : t;
   }
 }
-extern "C" int evf_sum_rows(const float* rows, int nrows, int n, int accumulate, float* dst, void* stream) {
+extern "C" int evf_sum_rows(float* rows, int nrows, int n, int accumulate, float* dst, void* stream) {
   if (!rows || !dst || nrows <= 0 || n <= 0) return EVF_EINVAL;
-  hipLaunchKernelGGL(k_sum_rows, dim3(evf_cdiv(n, 16)), dim3(256), 0, EVF_STREAM(stream), rows, nrows, n, accumulate, dst);
+  // accumulate bit 0: dst += (else =); bit 1: zero the rows after reading them
+  hipLaunchKernelGGL(k_sum_rows, dim3(evf_cdiv(n, 16)), dim3(256), 0, EVF_STREAM(stream), rows, nrows, n, accumulate & 1, dst,
+                     (accumulate >> 1) & 1);
   return evf_status();
 }
 

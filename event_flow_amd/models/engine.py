@@ -41,7 +41,8 @@ def _f32(shape, dev):
 F32_DGRAD = os.environ.get("EVF_F32_DGRAD", "1") != "0"
 PRED_FUSED = os.environ.get("EVF_PRED_FUSED", "1") != "0"  # prediction head in the epilogue of the last layer's forward
 TOP_FUSED = os.environ.get("EVF_TOP_FUSED", "1") != "0"  # prediction-head backward inside the top layer's fused backward
-PAIR_DGRAD = os.environ.get("EVF_PAIR_DGRAD", "1") != "0"  # ff + rec input gradients of a recurrent cell in one launch
+PAIR_DGRAD = os.environ.get("EVF_PAIR_DGRAD", "1") != "0"
+PARAM_ROWS = os.environ.get("EVF_PARAM_ROWS", "1") != "0"  # per-channel gradients through per-block rows (0: atomics)  # ff + rec input gradients of a recurrent cell in one launch
 
 
 class _Window:
@@ -62,6 +63,8 @@ class _Window:
         # small-parameter gradient accumulator: the engine's persistent buffer when FlatAdam owns the gradients (cleared by
         # the kernel that consumes it, _finalize), else fresh zeros
         self.small, self.small_persistent = eng._take_small(dev)
+        # per-block partial sums of the per-channel gradients [blocks][small_size] (summed into `small` by _finalize)
+        self.rows = eng._take_rows(B, H, W, dev)
         self.slab_init = {}
         self.token = eng._token(dev)  # (a leaf whose value is never read: only its autograd edge chains the passes)
         self.n_passes = 0
@@ -178,6 +181,21 @@ class FireNetEngine:
             self._small_buf.zero_()
         self._small_clean = False
         return self._small_buf, True
+
+    def _take_rows(self, B, H, W, dev):
+        """Persistent [blocks][small_size] buffer of per-block parameter-gradient partials (zero; evf_sum_rows hands it
+        back zeroed).  The fused backward kernels add into their own row instead of 256-512 blocks adding atomically into
+        the same 64 words."""
+        if self.precision != "bf16x3" or not PARAM_ROWS:
+            return None
+        L = _lib.load()
+        n = max(L.evf_lif_bwd_wgrad_slabs(B, H, W), L.evf_head_lif_bwd_wgrad_slabs(B, H, W), 512)
+        buf = self.__dict__.get("_rows_buf")
+        if buf is None or buf.device != dev or buf.shape[0] < n or not self.__dict__.get("_rows_clean", False):
+            buf = torch.zeros((n, self.small_size), dtype=torch.float32, device=dev)
+            self._rows_buf = buf
+        self._rows_clean = False
+        return buf
 
     def _token(self, dev):
         if self._token0 is None or self._token0.device != dev:
@@ -403,6 +421,14 @@ class FireNetEngine:
         off, n = self.small_off[name]
         return win.small[off : off + n]
 
+    def _rowed(self, win, name):
+        """(tensor the kernel's per-channel output pointer refers to, row pitch): row 0 of the per-block rows when the
+        window has them, else the dense accumulator (pitch 0 = atomics)."""
+        off, n = self.small_off[name]
+        if win.rows is None:
+            return win.small[off : off + n], 0
+        return win.rows[0, off : off + n], win.rows.shape[1]
+
     def _slab(self, key, nslab, dev):
         if key not in self._slabs or self._slabs[key].shape[0] != nslab or self._slabs[key].device != dev:
             self._slabs[key] = _f32((nslab, 9 * C * C), dev)
@@ -442,6 +468,7 @@ class FireNetEngine:
             use_rec = c.recurrent and z_prev is not None
             gv_out = win.buf(win.gv, i)
             leak_g, thr_g = self._small(win, f"{i}.leak"), self._small(win, f"{i}.thresh")
+            (leak_r, row_ld), (thr_r, _) = self._rowed(win, f"{i}.leak"), self._rowed(win, f"{i}.thresh")
             if i > 0 and self.precision == "bf16x3":
                 # neuron backward + both weight gradients in one pass (evf_bwd_fused.hip)
                 kf, kr = (i, "ff"), (i, "rec")
@@ -452,20 +479,21 @@ class FireNetEngine:
                     self._slab(kr, nsl, dev).zero_()
                 if top:
                     _lib.call("evf_lif_bwd_wgrad_top", _lib.ptr(tape["flow"]), _lib.ptr(g_flow_c), _lib.ptr(self._flat["pred.w"]),
-                              _lib.ptr(layers[i][4]), _lib.ptr(self._small(win, "pred.w")), _lib.ptr(self._small(win, "pred.b")),
+                              _lib.ptr(layers[i][4]), _lib.ptr(self._rowed(win, "pred.w")[0]), _lib.ptr(self._rowed(win, "pred.b")[0]),
                               _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(in_bitsT),
                               _lib.ptr(self._flat[f"{i}.leak"]), _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W,
                               1 if c.hard_reset else 0, SURROGATE_ID[c.activation], self._act_width(i),
                               _lib.ptr(win.g_cur) if (plif or F32_DGRAD) else None, _lib.ptr(win.g_split), _lib.ptr(gv_out),
-                              _lib.ptr(leak_g), _lib.ptr(thr_g), _lib.ptr(self._slab(kf, nsl, dev)), acc_flag)
+                              _lib.ptr(leak_r), _lib.ptr(thr_r), _lib.ptr(self._slab(kf, nsl, dev)), acc_flag | (row_ld << 8))
                 else:
                     _lib.call("evf_lif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
                           _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None, _lib.ptr(self._flat[f"{i}.leak"]),
                           _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
                           self._act_width(i), _lib.ptr(win.g_cur) if (plif or F32_DGRAD) else None, _lib.ptr(win.g_split),
                           _lib.ptr(gv_out),
-                          _lib.ptr(leak_g), _lib.ptr(thr_g),
-                          _lib.ptr(self._slab(kf, nsl, dev)), _lib.ptr(self._slab(kr, nsl, dev)) if use_rec else None, acc_flag)
+                          _lib.ptr(leak_r), _lib.ptr(thr_r),
+                          _lib.ptr(self._slab(kf, nsl, dev)), _lib.ptr(self._slab(kr, nsl, dev)) if use_rec else None,
+                          acc_flag | (row_ld << 8))
                 win.slab_init[kf] = True
                 if use_rec:
                     win.slab_init[kr] = True
@@ -478,8 +506,8 @@ class FireNetEngine:
                 _lib.call("evf_head_lif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev),
                           _lib.ptr(z_prev), _lib.ptr(tape["x_in"]), _lib.ptr(self._flat["0.leak"]),
                           _lib.ptr(self._flat["0.thresh"]), B, 2, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
-                          self._act_width(0), _lib.ptr(win.g_cur) if plif else None, _lib.ptr(gv_out), _lib.ptr(leak_g),
-                          _lib.ptr(thr_g), _lib.ptr(self._slabs[key]), 1 if win.slab_init.get(key) else 0)
+                          self._act_width(0), _lib.ptr(win.g_cur) if plif else None, _lib.ptr(gv_out), _lib.ptr(leak_r),
+                          _lib.ptr(thr_r), _lib.ptr(self._slabs[key]), (1 if win.slab_init.get(key) else 0) | (row_ld << 8))
                 win.slab_init[key] = True
             else:
                 _lib.call("evf_lif_bwd", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
@@ -508,8 +536,8 @@ class FireNetEngine:
                 carry = gpt_out if win.gpt_has[i] else None
                 _lib.call("evf_plif_trace_bwd", _lib.ptr(win.g_cur), _lib.ptr(carry), _lib.ptr(pt_prev), _lib.ptr(pt_out),
                           _lib.ptr(P_sav), _lib.ptr(self._flat[f"{i}.leak_pt"]), _lib.ptr(self._flat[f"{i}.add_pt"]), B, H, W,
-                          _lib.ptr(gpt_out), _lib.ptr(win.gP_raw), _lib.ptr(win.gP), _lib.ptr(self._small(win, f"{i}.leak_pt")),
-                          _lib.ptr(self._small(win, f"{i}.add_pt")))
+                          _lib.ptr(gpt_out), _lib.ptr(win.gP_raw), _lib.ptr(win.gP), _lib.ptr(self._rowed(win, f"{i}.leak_pt")[0]),
+                          _lib.ptr(self._rowed(win, f"{i}.add_pt")[0]), self._rowed(win, f"{i}.add_pt")[1])
                 win.gpt_has[i] = not is_first
             if is_first:
                 win.gv[i] = None  # the state entering the window is detached (train_flow.py:170)
@@ -550,6 +578,9 @@ class FireNetEngine:
         B, H, W = win.shape
         nslab = (_lib.load().evf_lif_bwd_wgrad_slabs(B, H, W) if self.precision == "bf16x3"
                  else _lib.load().evf_conv_wgrad_slabs(B, H, W))
+        if win.rows is not None:  # per-block partials of the per-channel gradients -> the small accumulator (rows zeroed)
+            _lib.call("evf_sum_rows", _lib.ptr(win.rows), win.rows.shape[0], win.rows.shape[1], 1 | 2, _lib.ptr(win.small))
+            self._rows_clean = True
         grads = []
         seg_src, seg_dst, seg_n = [], [], []
         red_src, red_dst = [], []

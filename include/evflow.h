@@ -284,7 +284,7 @@ int evf_head_plif_fwd(const float* x, const float* w, const float* leak_v, const
 int evf_plif_trace_bwd(const float* g_cur, const float* g_pt_carry, const float* pt_prev, const float* pt_out,
                        const float* P, const float* leak_pt, const float* add_pt, int B, int H, int W,
                        float* g_pt_prev, float* g_P_raw, float* g_P_in, float* g_leak_pt, float* g_add_pt,
-                       void* stream);
+                       int row_ld, void* stream);
 
 /* Input-gradient conv: g_x[pix][ci] (+)= sum_tap,co g_cur[pix-tap][co]*w[co][ci][tap]
  * with wT packed by evf_pack_conv_weight(transposed=1).  g_cur, g_x [B,H,W,32].
@@ -319,8 +319,14 @@ int evf_head_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const flo
  * the per-channel gradients of a window added into the optimizer's flat gradient buffer in one launch.
  * clear != 0: the consumed source elements are zeroed (a persistent accumulator, handed back clean). */
 int evf_add_segments(float* src, void* const* dst, const int* off, const int* n, int nseg, int clear, void* stream);
-/* dst[e] (+)= sum_k rows[k][e], e < n */
-int evf_sum_rows(const float* rows, int nrows, int n, int accumulate, float* dst, void* stream);
+/* dst[e] (+)= sum_k rows[k][e], e < n.  accumulate bit 0: add to dst; bit 1 (value 2): zero the rows after reading them.
+ * PER-BLOCK PARAMETER-GRADIENT ROWS: evf_lif_bwd_wgrad[_top], evf_head_lif_bwd_wgrad (bits 8.. of their `accumulate`
+ * argument) and evf_plif_trace_bwd (`row_ld`) take the pitch, in floats, of a [blocks][pitch] buffer; their per-channel
+ * outputs (g_leak, g_thresh, d_pred_w, d_pred_b, g_leak_pt, g_add_pt) then address ROW 0 of it and every block adds its
+ * partial sums to its own row by plain read-modify-write -- 256 blocks adding atomically into the same 64 words keep a
+ * kernel alive ~4.5 us after its last block has finished.  evf_sum_rows reduces the rows once per window.  Pitch 0 =
+ * dense outputs, atomic adds. */
+int evf_sum_rows(float* rows, int nrows, int n, int accumulate, float* dst, void* stream);
 /* Head weight gradient: dW[co][ci][ky][kx] += sum g_cur[pix][co]*x[b][ci][pix+tap] (torch layout out). */
 int evf_head_wgrad(const float* x, const float* g_cur, int B, int Cin, int H, int W, float* dw, void* stream);
 
