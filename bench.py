@@ -452,7 +452,7 @@ def main_c4(args):
             ho, wo = (h + 2 * (k // 2) - k) // st + 1, (w + 2 * (k // 2) - k) // st + 1
             ent["flop_per_step"] += 2.0 * k * k * cin * cout * b * ho * wo * len(ms) / prof_steps
             ent["bytes_per_step"] += 4.0 * b * (h * w * cin + ho * wo * cout) * len(ms) / prof_steps
-    for ent in kernels.values():
+    for name, ent in kernels.items():
         if ent["flop_per_step"]:
             ent["TFLOPs"] = ent["flop_per_step"] / (ent["total_ms_per_step"] * 1e-3) / 1e12
             ent["frac_of_fp32_mfma_peak"] = ent["TFLOPs"] / FP32_MFMA_PEAK
