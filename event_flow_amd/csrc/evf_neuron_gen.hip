@@ -434,6 +434,8 @@ extern "C" int evf_leaky_fwd(const float* cur, const float* prev, const float* r
 
 // g_mix = g_state + g_out * act'(act(mix));  g_cur (= g_residual) = g_mix (1 - lam);  g_prev = g_mix lam;
 // g_leak[c] += sum g_mix (prev - cur) lam (1 - lam), with cur recovered from mix as (mix - prev lam) / (1 - lam)
+__device__ float g_leaky_rep[NG_REP * 1024];  // zero at load, zero after every evf_leaky_bwd
+
 __global__ void k_leaky_bwd(const float4* __restrict__ g_out, const float4* __restrict__ g_state, const float4* __restrict__ mix,
                             const float4* __restrict__ prev, const float* __restrict__ leak, int act, long npix, int C,
                             float4* __restrict__ g_cur, float4* __restrict__ g_prev, float* __restrict__ g_leak) {
@@ -468,8 +470,21 @@ __global__ void k_leaky_bwd(const float4* __restrict__ g_out, const float4* __re
 #pragma unroll
     for (int k = 0; k < 4; ++k) atomicAdd(&s_acc[4 * cq + k], s0[k] * lam[k] * (1.0f - lam[k]));
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += blockDim.x) evf_atomic_add(g_leak + i, s_acc[i]);
+    // (1024 blocks adding into the same C words serialise at the memory side: 32 replicas, summed by k_leaky_finish)
+    float* mine = g_leaky_rep + (blockIdx.x % NG_REP) * 1024;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) evf_atomic_add(mine + i, s_acc[i]);
   }
+}
+
+__global__ void k_leaky_finish(int nrep, int C, float* __restrict__ g_leak) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C) return;
+  float t = 0.f;
+  for (int r = 0; r < nrep; ++r) {
+    t += g_leaky_rep[r * 1024 + i];
+    g_leaky_rep[r * 1024 + i] = 0.f;  // (handed back zeroed; calls are stream-ordered on one stream per device)
+  }
+  g_leak[i] += t;
 }
 
 extern "C" int evf_leaky_bwd(const float* g_out, const float* g_state, const float* mix, const float* prev, const float* leak,
@@ -482,6 +497,9 @@ extern "C" int evf_leaky_bwd(const float* g_out, const float* g_state, const flo
   hipLaunchKernelGGL(k_leaky_bwd, dim3(nblk), dim3(bs), sizeof(float) * (size_t)C, EVF_STREAM(stream), (const float4*)g_out,
                      (const float4*)g_state, (const float4*)mix, (const float4*)prev, leak, act, (long)npix, C,
                      (float4*)g_cur, (float4*)g_prev, g_leak);
+  if (g_leak)
+    hipLaunchKernelGGL(k_leaky_finish, dim3(evf_cdiv(C, 64)), dim3(64), 0, EVF_STREAM(stream), nblk < NG_REP ? nblk : NG_REP, C,
+                       g_leak);
   return evf_status();
 }
 
