@@ -144,8 +144,10 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
   const int y0 = blockIdx.y * DG_ROWS, y = y0 + wv, x0 = blockIdx.x * 32;
   const int i = lane & 31, kg = lane >> 5;
   // the split weights are staged once per block and serve all its tiles (samples blockIdx.z, blockIdx.z + gridDim.z, ...)
+#ifndef PROBE_NO_WEIGHT_DMA  // (probe build: what does staging the 54 KiB of weights per block cost?)
   for (int u = wv; u < NFRAG; u += DG_ROWS)
     __builtin_amdgcn_global_load_lds((dl_glb_void*)(wt + u * 64 + lane), (dl_lds_void*)(s_w + u * 64), 16, 0, 0);
+#endif
   int tile_it = 0;
   for (int b = blockIdx.z; b < B; b += gridDim.z, ++tile_it) {
     if (b != (int)blockIdx.z) __syncthreads();  // every wave is done reading the previous tile's halo

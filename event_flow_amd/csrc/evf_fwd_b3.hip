@@ -123,7 +123,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
 
+#ifndef PROBE_NO_WEIGHT_DMA  // (probe build: what does staging the 54 KiB of weights per block cost?)
   for (int u = wv; u < NFRAG; u += FW_WAVES) b3_glds16(wff + u * 64 + lane, s_w + u * 64);
+#endif
   {
     const float* psrc = pr.w ? pr.w : leak;  // no load under a branch: dummy source, the values are unused then
     const float* bsrc = pr.w ? pr.bias : leak;

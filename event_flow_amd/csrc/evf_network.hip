@@ -887,8 +887,34 @@ __global__ __launch_bounds__(256) void k_sum_rows(float* __restrict__ rows, int 
     dst[e] = accumulate ? dst[e] + t : t;
   }
 }
+// accumulating form for many rows: block (x, y) sums rows [64 y, 64 y + 64) of 64 columns (256-byte row segments) and
+// adds its partial to dst (nrows / 64 adds per word): 8x the blocks of k_sum_rows and coalesced reads
+__global__ __launch_bounds__(256) void k_sum_rows_acc(float* __restrict__ rows, int nrows, int n, float* __restrict__ dst,
+                                                      int clear) {
+  __shared__ float s[4][64];
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + c, r0 = blockIdx.y * 64;
+  float v = 0.f;
+  if (e < n)
+    for (int k = r0 + grp; k < min(r0 + 64, nrows); k += 4) {
+      v += rows[(long)k * n + e];
+      if (clear) rows[(long)k * n + e] = 0.f;
+    }
+  s[grp][c] = v;
+  __syncthreads();
+  if (grp == 0 && e < n) {
+    const float t = (s[0][c] + s[1][c]) + (s[2][c] + s[3][c]);
+    if (t != 0.f) evf_atomic_add(dst + e, t);
+  }
+}
+
 extern "C" int evf_sum_rows(float* rows, int nrows, int n, int accumulate, float* dst, void* stream) {
   if (!rows || !dst || nrows <= 0 || n <= 0) return EVF_EINVAL;
+  if ((accumulate & 1) && nrows >= 128) {
+    hipLaunchKernelGGL(k_sum_rows_acc, dim3(evf_cdiv(n, 64), evf_cdiv(nrows, 64)), dim3(256), 0, EVF_STREAM(stream), rows, nrows, n,
+                       dst, (accumulate >> 1) & 1);
+    return evf_status();
+  }
   // accumulate bit 0: dst += (else =); bit 1: zero the rows after reading them
   hipLaunchKernelGGL(k_sum_rows, dim3(evf_cdiv(n, 16)), dim3(256), 0, EVF_STREAM(stream), rows, nrows, n, accumulate & 1, dst,
                      (accumulate >> 1) & 1);
