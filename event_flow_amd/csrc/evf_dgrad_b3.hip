@@ -127,6 +127,20 @@ typedef __attribute__((address_space(1))) const void dl_glb_void;
 // pre-split form) -- the producer writes 128 instead of 192 B/pixel and this kernel reads 128 instead of 192.
 // ACC / PLIF: compile-time, so that a launch that neither accumulates nor carries the PLIF term issues none of the 48
 // per-lane operand loads (as dummy loads they still cost the texture addresser 16 cycles each: 6 k cycles per tile).
+#ifdef EVF_SPAN  // start / end of every block in the chip-wide 100 MHz counter (probe build through EVF_LIB)
+__device__ unsigned long long dg_span[2 * 4096];
+extern "C" int evf_debug_dg_span(void* dst) { return evf_hip(hipMemcpyFromSymbol(dst, HIP_SYMBOL(dg_span), sizeof(dg_span))); }
+#define DG_SPAN_MARK(w)                                                                                                     \
+  do {                                                                                                                      \
+    const int bid_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                                        \
+    if (threadIdx.x == 0 && bid_ < 4096) dg_span[2 * bid_ + (w)] = __builtin_amdgcn_s_memrealtime();                        \
+  } while (0)
+#else
+#define DG_SPAN_MARK(w) do {} while (0)
+#endif
+
+#define DG_SP 36  // floats per pixel of the epilogue staging tile (32 + 4: conflict-free 16-byte writes)
+
 template <bool F32IN, bool ACC, bool PLIF>
 __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4* __restrict__ gs, long plane_stride,
                                                                     const uint4* __restrict__ wt, float* __restrict__ gx,
@@ -140,7 +154,9 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint4* s_w = (uint4*)smem_raw;  // NFRAG*64
   uint4* s_a = s_w + NFRAG * 64;  // [3][DL_HPP][4]
+  float* s_stage = (float*)(s_a + 3 * DL_HPP * 4);  // [DG_ROWS waves][32 pixels][DG_SP]: epilogue staging
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  DG_SPAN_MARK(0);
   const int y0 = blockIdx.y * DG_ROWS, y = y0 + wv, x0 = blockIdx.x * 32;
   const int i = lane & 31, kg = lane >> 5;
   // the split weights are staged once per block and serve all its tiles (samples blockIdx.z, blockIdx.z + gridDim.z, ...)
@@ -219,30 +235,41 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
         __syncthreads();
       }
       const f32x16 acc = matrix_phase();
-      if (y < H) {
-        const long pix = ((long)b * H + y) * W + x0 + i;
-        if (x0 + i < W) {
-          if (set == 0) {
+      // Epilogue through a wave-private LDS tile [32 pixels][32 channels] (144-byte pixel pitch: conflict-free b128
+      // writes): the MFMA layout gives a lane 4 x 16 bytes of its pixel's 128-byte line, i.e. four partial-line store
+      // instructions; read back as 8 pixels x 128 bytes per instruction the wave stores FULL lines, and those can be
+      // non-temporal -- the output does not stay dirty in the L2s, so the kernel no longer ends in their write-back
+      // (every block of this kernel was done 6-7 us before the kernel retired: tools/probes/span_step.py).
+      float* st = s_stage + wv * (32 * DG_SP);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              // PLIF: the pooled pre-synaptic trace also reads the input spikes: d mean_c|x| / dx_c = 1/32 where the
-              // spike is set, AvgPool3x3^T = box filter / 9 -- gPb is that filtered, scaled map (evf_plif_trace_bwd)
-              const uint32_t xq = xb >> (8 * q + 4 * kg);
-              const float o[4] = {oldv[q].x, oldv[q].y, oldv[q].z, oldv[q].w};
-              float v[4];
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+        if (set == 0) {
+          // PLIF: the pooled pre-synaptic trace also reads the input spikes: d mean_c|x| / dx_c = 1/32 where the
+          // spike is set, AvgPool3x3^T = box filter / 9 -- gPb is that filtered, scaled map (evf_plif_trace_bwd)
+          const uint32_t xq = xb >> (8 * q + 4 * kg);
+          const float o[4] = {oldv[q].x, oldv[q].y, oldv[q].z, oldv[q].w};
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e] + o[e] + (((xq >> e) & 1u) ? pv : 0.f);
-              *(float4*)(gx + pix * C32 + 8 * q + 4 * kg) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-          } else {
+          for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e] + o[e] + (((xq >> e) & 1u) ? pv : 0.f);
+        } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              *(float4*)(gx2 + pix * C32 + 8 * q + 4 * kg) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-          }
+          for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e];
         }
+        *(float4*)(st + i * DG_SP + 8 * q + 4 * kg) = make_float4(v[0], v[1], v[2], v[3]);
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float* dstp = set == 0 ? gx : gx2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = 8 * r + (lane >> 3), c4 = (lane & 7) * 4;
+        const float4 v = *(const float4*)(st + p * DG_SP + c4);
+        if (y < H && x0 + p < W) evf_store_nt(dstp + (((long)b * H + y) * W + x0 + p) * C32 + c4, v);
+      }
+      __builtin_amdgcn_wave_barrier();  // (the tile is rewritten by this wave's next product)
     }
   }
+  DG_SPAN_MARK(1);
 }
 
 static int dg_select = -1;  // -1 by shape, 0 k_conv_dgrad_b3_lds, 1 k_conv_dgrad_ws
@@ -283,7 +310,7 @@ static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, in
     if (B % z == 0 && tiles * z <= 256 && tiles * z >= 192) zb = z;
   dim3 grid(evf_cdiv(W, 32), evf_cdiv(H, DG_ROWS), zb), block(DG_ROWS * 64);
   const long plane_stride = (long)B * H * W * 4;  // uint4 per term plane: npix * 32 bf16 / 8
-  const size_t lds = (size_t)(NFRAG * 64 + 3 * DL_HPP * 4) * sizeof(uint4);  // 120 KiB: one block per CU
+  const size_t lds = (size_t)(NFRAG * 64 + 3 * DL_HPP * 4) * sizeof(uint4) + (size_t)DG_ROWS * 32 * DG_SP * 4;  // 138 KiB
   const bool acc = accumulate != 0, plif = g_P != nullptr;
 #define DG_GO(F_, A_, P_)                                                                                                  \
   do {                                                                                                                     \

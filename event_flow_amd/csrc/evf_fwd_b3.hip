@@ -102,6 +102,18 @@ struct PredArgs {
   float* flow;        // [B,2,H,W]
 };
 
+#ifdef EVF_SPAN  // start / end of every block in the chip-wide 100 MHz counter (probe build through EVF_LIB)
+__device__ unsigned long long fw_span[2 * 4096];
+extern "C" int evf_debug_fw_span(void* dst) { return evf_hip(hipMemcpyFromSymbol(dst, HIP_SYMBOL(fw_span), sizeof(fw_span))); }
+#define FW_SPAN_MARK(w)                                                                                                     \
+  do {                                                                                                                      \
+    const int bid_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                                        \
+    if (threadIdx.x == 0 && bid_ < 4096) fw_span[2 * bid_ + (w)] = __builtin_amdgcn_s_memrealtime();                        \
+  } while (0)
+#else
+#define FW_SPAN_MARK(w) do {} while (0)
+#endif
+
 template <bool REC, bool PLIF>
 __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* __restrict__ x, const uint4* __restrict__ wff,
                                                          const uint4* __restrict__ wrec,
@@ -122,6 +134,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
   float* s_par = s_pw + 2 * C32 + 2;             // [4][32]: sigmoid(leak), clamped thresh, sigmoid(leak_pt), sigmoid(add_pt)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+  FW_SPAN_MARK(0);
 
 #ifndef PROBE_NO_WEIGHT_DMA  // (probe build: what does staging the 54 KiB of weights per block cost?)
   for (int u = wv; u < NFRAG; u += FW_WAVES) b3_glds16(wff + u * 64 + lane, s_w + u * 64);
@@ -292,6 +305,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
     }
     if (zT_out && row < H && lane < 32) zT_out[(((long)b * H + row) * C32 + j) * nW + x0 / 32] = myplane;
   }
+  FW_SPAN_MARK(1);
 }
 
 static int launch_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec, const float* leak,
