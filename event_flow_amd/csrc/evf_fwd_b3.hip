@@ -29,6 +29,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define HALO_W (TW + 2)
 #define HALO_H (TH + 2)
 #define NFRAG 54                 // 9 taps x 2 k-halves x 3 terms
+#define FW_SP 36                 // floats per pixel of the epilogue staging tile (32 + 4: conflict-free 16-byte writes)
 #define WB3_BYTES (NFRAG * 1024)  // per conv
 
 __device__ __forceinline__ int b3_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
@@ -243,6 +244,11 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
   }
 
   // Epilogue (transposed tile): lane = pixel (x0 + i) of rows y0 + r0, y0 + r0 + 1; channel c = 8q + e + 4kg.
+  // v_out leaves through a wave-private staging tile [32 pixels][FW_SP floats] laid over the (now dead) weights, so that a
+  // store instruction writes 8 FULL 128-byte lines and can be non-temporal: the state does not stay dirty in the L2s for
+  // the end-of-kernel write-back (see evf_dgrad_b3.hip; the blocks of this kernel were done 3 us before it retired).
+  __syncthreads();  // every wave is done with the weights
+  float* stg = (float*)s_w + wv * (32 * FW_SP);
   const int nW = (W + 31) / 32;
   const int rj = (j & 3) + 4 * (j >> 3), kgj = (j >> 2) & 1;  // (r, half) whose ballot holds channel j's bit plane
 #pragma unroll
@@ -282,11 +288,18 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
         const unsigned long long mk = __ballot(spike);
         myplane = (r == rj) ? (kgj ? (uint32_t)(mk >> 32) : (uint32_t)mk) : myplane;
       }
-      if (ok) {
-        *(float4*)(v_out + pix * C32 + 8 * q + 4 * kg) = make_float4(vo4[0], vo4[1], vo4[2], vo4[3]);
-        if (PLIF) *(float4*)(pl.pt_out + pix * C32 + 8 * q + 4 * kg) = make_float4(po4[0], po4[1], po4[2], po4[3]);
-      }
+      *(float4*)(stg + i * FW_SP + 8 * q + 4 * kg) = make_float4(vo4[0], vo4[1], vo4[2], vo4[3]);
+      if (ok && PLIF) *(float4*)(pl.pt_out + pix * C32 + 8 * q + 4 * kg) = make_float4(po4[0], po4[1], po4[2], po4[3]);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p = 8 * r + (lane >> 3), c4 = (lane & 7) * 4;
+      const float4 v = *(const float4*)(stg + p * FW_SP + c4);
+      if (row < H && x0 + p < W) evf_store_nt(v_out + (((long)b * H + row) * W + x0 + p) * C32 + c4, v);
+    }
+    __builtin_amdgcn_wave_barrier();  // (the tile is rewritten for the wave's second row)
     const uint32_t word = bits | __shfl_xor(bits, 32, 64);  // the pixel's 32 output spikes
     if (ok && kg == 0) z_out[pix] = word;
     if (pr.w) {  // (block-uniform) the prediction head on this pixel's spike word, summed like evf_pred_fwd
