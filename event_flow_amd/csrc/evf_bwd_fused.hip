@@ -254,8 +254,8 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
       }
     }
     if (ok) {
-#ifdef FB_NT_STORES  // (probe build)
-      if (g_cur) evf_store_nt(g_cur + pix0 * 8 + tid, make_float4(gc[0], gc[1], gc[2], gc[3]));
+#ifdef FB_NT_STORES  // (probe build: g_cur is read by the very next kernel, g_v_prev only a pass later)
+      if (g_cur) g_cur[pix0 * 8 + tid] = make_float4(gc[0], gc[1], gc[2], gc[3]);
       evf_store_nt(g_v_prev + pix0 * 8 + tid, make_float4(gp[0], gp[1], gp[2], gp[3]));
 #else
       if (g_cur) g_cur[pix0 * 8 + tid] = make_float4(gc[0], gc[1], gc[2], gc[3]);
