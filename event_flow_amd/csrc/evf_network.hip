@@ -158,18 +158,14 @@ extern "C" int evf_reduce_slabs_multi(const void* const* partial, void* const* d
 //   v' = (v*leak)*(1-z) + (1-leak)*cur          (hard reset)
 //   v' = v*leak + (1-leak)*cur - z*thresh       (soft reset)
 //   z' = (v' - thresh) > 0
+// Previous state of the 16 pixels of this lane (MFMA accumulator layout): unconditional loads from clamped addresses,
+// all in flight together (a load under `if (ok)` is followed by its own s_waitcnt vmcnt(0): 16 serial round trips).
+// Split from the update so that a kernel can issue them BEFORE its staging / matrix phase.
 template <typename ZPrev>
-__device__ __forceinline__ void lif_epilogue(const f32x16& acc, int b, int row, int x0, int H, int W, int lane,
-                                             float lam, float th, int hard_reset, const float* __restrict__ v_prev,
-                                             ZPrev zprev_word, float* __restrict__ v_out,
-                                             uint32_t* __restrict__ z_out, uint32_t* __restrict__ zT_out) {
+__device__ __forceinline__ void lif_load_prev(int b, int row, int x0, int H, int W, int lane,
+                                              const float* __restrict__ v_prev, const float* __restrict__ v_out,
+                                              ZPrev zprev_word, float (&vpv)[16], uint32_t (&zw)[16]) {
   const int j = lane & 31;
-  const bool row_ok = row < H;
-  uint32_t plane = 0u;  // this channel's spikes over the tile's 32 pixels (bit = column)
-  // previous state of the 16 pixels of this lane: unconditional loads from clamped addresses, all in flight
-  // together (a load under `if (ok)` is followed by its own s_waitcnt vmcnt(0): 16 serial round trips)
-  float vpv[16];
-  uint32_t zw[16];
   const int rq = min(row, H - 1);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -179,6 +175,15 @@ __device__ __forceinline__ void lif_epilogue(const f32x16& acc, int b, int row, 
     vpv[r] = v_prev ? val : 0.f;
     zw[r] = zprev_word(rq, cq);
   }
+}
+
+__device__ __forceinline__ void lif_update(const f32x16& acc, const float (&vpv)[16], const uint32_t (&zw)[16], int b,
+                                           int row, int x0, int H, int W, int lane, float lam, float th, int hard_reset,
+                                           float* __restrict__ v_out, uint32_t* __restrict__ z_out,
+                                           uint32_t* __restrict__ zT_out) {
+  const int j = lane & 31;
+  const bool row_ok = row < H;
+  uint32_t plane = 0u;  // this channel's spikes over the tile's 32 pixels (bit = column)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int col = x0 + mfma_row(r, lane);
@@ -205,6 +210,17 @@ __device__ __forceinline__ void lif_epilogue(const f32x16& acc, int b, int row, 
     plane |= __shfl_xor(plane, 32, 64);
     if (row_ok && lane < 32) zT_out[(((long)b * H + row) * C32 + j) * ((W + 31) / 32) + x0 / 32] = plane;
   }
+}
+
+template <typename ZPrev>
+__device__ __forceinline__ void lif_epilogue(const f32x16& acc, int b, int row, int x0, int H, int W, int lane,
+                                             float lam, float th, int hard_reset, const float* __restrict__ v_prev,
+                                             ZPrev zprev_word, float* __restrict__ v_out,
+                                             uint32_t* __restrict__ z_out, uint32_t* __restrict__ zT_out) {
+  float vpv[16];
+  uint32_t zw[16];
+  lif_load_prev(b, row, x0, H, W, lane, v_prev, v_out, zprev_word, vpv, zw);
+  lif_update(acc, vpv, zw, b, row, x0, H, W, lane, lam, th, hard_reset, v_out, z_out, zT_out);
 }
 
 template <bool REC>
@@ -301,6 +317,7 @@ extern "C" int evf_conv_lif_fwd(const uint32_t* x, const float* w_ff, const floa
 // Head: real-valued NCHW input with few channels (event counts / voxels).
 // K = 9 taps x Cin; one MFMA k-step covers channels (2s, 2s+1).
 #define HEAD_MAX_CIN 8
+template <int S2>  // S2 = ceil(Cin / 2): compile-time trip counts, so that every staging load of a thread is in flight at once
 __global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ leak, const float* __restrict__ thresh,
                                                       const float* __restrict__ v_prev,
@@ -316,20 +333,43 @@ __global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ 
   __shared__ float s_P[TH * TW];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
-  const int S2 = (Cin + 1) / 2;
-  for (int e = tid; e < 9 * S2 * 64; e += 256) {
-    const int l = e & 63, s = (e >> 6) % S2, tau = (e >> 6) / S2;
-    const int ci = 2 * s + (l >> 5), j = l & 31;
-    const float wv0 = w[(j * Cin + min(ci, Cin - 1)) * 9 + tau];
-    s_w[e] = ci < Cin ? wv0 : 0.f;
-  }
-  for (int e = tid; e < 2 * S2 * HALO_H * HALO_W; e += 256) {
-    const int ci = e / (HALO_H * HALO_W), p = e % (HALO_H * HALO_W);
-    const int yy = y0 + p / HALO_W - 1, xx = x0 + p % HALO_W - 1;
-    const bool in = ci < Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    // clamped address + select (a load under a branch is followed by s_waitcnt vmcnt(0))
-    const float xv = x[(((long)b * Cin + min(ci, Cin - 1)) * H + min(max(yy, 0), H - 1)) * W + min(max(xx, 0), W - 1)];
-    s_x[ci][p] = in ? xv : 0.f;
+  // previous membrane potentials and spike words of this wave's two rows: issued first, consumed after the matrix phase
+  auto zword = [&](int row, int col) -> uint32_t {
+    const uint32_t wd = *(z_prev ? z_prev + ((long)b * H + row) * W + col : (const uint32_t*)v_out);  // no branch around the load
+    return z_prev ? wd : 0u;
+  };
+  float vp0[16], vp1[16];
+  uint32_t zw0[16], zw1[16];
+  lif_load_prev(b, y0 + 2 * wv, x0, H, W, lane, v_prev, v_out, zword, vp0, zw0);
+  lif_load_prev(b, y0 + 2 * wv + 1, x0, H, W, lane, v_prev, v_out, zword, vp1, zw1);
+  {
+    constexpr int NW = (9 * S2 * 64 + 255) / 256, NX = (2 * S2 * HALO_H * HALO_W + 255) / 256;
+    float wreg[NW], xreg[NX];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {  // clamped addresses, selected afterwards: no load under a branch
+      const int e = min(tid + 256 * k, 9 * S2 * 64 - 1);
+      const int l = e & 63, s = (e >> 6) % S2, tau = (e >> 6) / S2;
+      const int ci = 2 * s + (l >> 5), j = l & 31;
+      const float wv0 = w[(j * Cin + min(ci, Cin - 1)) * 9 + tau];
+      wreg[k] = ci < Cin ? wv0 : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int e = min(tid + 256 * k, 2 * S2 * HALO_H * HALO_W - 1);
+      const int ci = e / (HALO_H * HALO_W), p = e % (HALO_H * HALO_W);
+      const int yy = y0 + p / HALO_W - 1, xx = x0 + p % HALO_W - 1;
+      const bool in = ci < Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const float xv = x[(((long)b * Cin + min(ci, Cin - 1)) * H + min(max(yy, 0), H - 1)) * W + min(max(xx, 0), W - 1)];
+      xreg[k] = in ? xv : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NW; ++k)
+      if (tid + 256 * k < 9 * S2 * 64) s_w[tid + 256 * k] = wreg[k];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int e = tid + 256 * k;
+      if (e < 2 * S2 * HALO_H * HALO_W) s_x[e / (HALO_H * HALO_W)][e % (HALO_H * HALO_W)] = xreg[k];
+    }
   }
   __syncthreads();
   f32x16 acc0 = {0}, acc1 = {0};
@@ -380,12 +420,24 @@ __global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ 
       }
     }
   }
-  auto zword = [&](int row, int col) -> uint32_t {
-    const uint32_t wd = *(z_prev ? z_prev + ((long)b * H + row) * W + col : (const uint32_t*)v_out);  // no branch around the load
-    return z_prev ? wd : 0u;
-  };
-  lif_epilogue(acc0, b, y0 + r0, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out, zT_out);
-  lif_epilogue(acc1, b, y0 + r0 + 1, x0, H, W, lane, lam, th, hard_reset, v_prev, zword, v_out, z_out, zT_out);
+  lif_update(acc0, vp0, zw0, b, y0 + r0, x0, H, W, lane, lam, th, hard_reset, v_out, z_out, zT_out);
+  lif_update(acc1, vp1, zw1, b, y0 + r0 + 1, x0, H, W, lane, lam, th, hard_reset, v_out, z_out, zT_out);
+}
+
+static void launch_head_fwd(dim3 grid, dim3 block, hipStream_t st, const float* x, const float* w, const float* leak,
+                            const float* thresh, const float* v_prev, const uint32_t* z_prev, int B, int Cin, int H, int W,
+                            int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out, const float* leak_pt,
+                            const float* add_pt, const float* pt_prev, float* pt_out, float* P_out) {
+#define HEAD_FWD(S2)                                                                                                       \
+  hipLaunchKernelGGL(k_head_lif_fwd<S2>, grid, block, 0, st, x, w, leak, thresh, v_prev, z_prev, B, Cin, H, W, hard_reset, \
+                     v_out, z_out, zT_out, leak_pt, add_pt, pt_prev, pt_out, P_out)
+  switch ((Cin + 1) / 2) {
+    case 1: HEAD_FWD(1); break;
+    case 2: HEAD_FWD(2); break;
+    case 3: HEAD_FWD(3); break;
+    default: HEAD_FWD(4); break;
+  }
+#undef HEAD_FWD
 }
 
 extern "C" int evf_head_lif_fwd(const float* x, const float* w, const float* leak, const float* thresh,
@@ -394,9 +446,8 @@ extern "C" int evf_head_lif_fwd(const float* x, const float* w, const float* lea
   if (!x || !w || !leak || !thresh || !v_out || !z_out || B <= 0 || Cin <= 0 || Cin > HEAD_MAX_CIN || H <= 0 || W <= 0)
     return EVF_EINVAL;
   dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(256);
-  hipLaunchKernelGGL(k_head_lif_fwd, grid, block, 0, EVF_STREAM(stream), x, w, leak, thresh, v_prev, z_prev, B, Cin, H, W,
-                     hard_reset, v_out, z_out, zT_out, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                     (float*)nullptr, (float*)nullptr);
+  launch_head_fwd(grid, block, EVF_STREAM(stream), x, w, leak, thresh, v_prev, z_prev, B, Cin, H, W, hard_reset, v_out, z_out,
+                  zT_out, nullptr, nullptr, nullptr, nullptr, nullptr);
   return evf_status();
 }
 
@@ -408,8 +459,8 @@ extern "C" int evf_head_plif_fwd(const float* x, const float* w, const float* le
       Cin <= 0 || Cin > HEAD_MAX_CIN || H <= 0 || W <= 0)
     return EVF_EINVAL;
   dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(256);
-  hipLaunchKernelGGL(k_head_lif_fwd, grid, block, 0, EVF_STREAM(stream), x, w, leak_v, thresh, v_prev, z_prev, B, Cin, H,
-                     W, hard_reset, v_out, z_out, zT_out, leak_pt, add_pt, pt_prev, pt_out, P_out);
+  launch_head_fwd(grid, block, EVF_STREAM(stream), x, w, leak_v, thresh, v_prev, z_prev, B, Cin, H, W, hard_reset, v_out,
+                  z_out, zT_out, leak_pt, add_pt, pt_prev, pt_out, P_out);
   return evf_status();
 }
 
@@ -809,11 +860,21 @@ __global__ __launch_bounds__(256) void k_head_bwd_mfma(
   }
 }
 
-#define HEAD_BWD_BLOCKS 512
+#define HEAD_BWD_BLOCKS 1024  // 4 blocks per CU (512: 26.9 us, 768-1024: 25.5 us, 2048: 29.4 us at 8 x 128 x 128)
+static int head_bwd_blocks() {  // EVF_HEAD_BWD_BLOCKS: A/B of the grid (blocks resident per CU = bytes in flight)
+  static int n = 0;
+  if (!n) {
+    const char* e = getenv("EVF_HEAD_BWD_BLOCKS");
+    n = e ? atoi(e) : HEAD_BWD_BLOCKS;
+    if (n < 1 || n > 4096) n = HEAD_BWD_BLOCKS;
+  }
+  return n;
+}
 extern "C" int evf_head_lif_bwd_wgrad_slabs(int B, int H, int W) {
   const long npix = (long)B * H * W;
   const long nb = (npix * 8 + 255) / 256;
-  return (int)(nb < HEAD_BWD_BLOCKS ? nb : HEAD_BWD_BLOCKS);
+  const int cap = head_bwd_blocks();
+  return (int)(nb < cap ? nb : cap);
 }
 
 // Head layer: neuron backward + weight gradient in one pass over g (models/spiking_submodules.py:96-126
