@@ -339,6 +339,26 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
   FbStage s_cur, s_nxt, s_new;
   issue_loads(0, s_cur);
   issue_loads(1, s_nxt);
+  // Operands of the EPILOGUE, requested now (behind the first two units' loads): the previous partial sums of this
+  // wave's slab tile, of the ninth tap and of this block's row of per-channel sums.  Loaded after the unit loop they
+  // were two dependent HBM round trips (slab read-modify-write, then the row) at the end of every block's life.
+  // (REC: the recurrent slab's 16 words per lane stay after the loop -- the kernel is at 222 VGPRs -- but are issued
+  //  before the LDS reductions and consumed after them.)
+  const long slab_off = (long)blockIdx.x * (9 * C32 * C32) + wv * (C32 * C32) + i;
+  float old[16], prev8[2], prev8z[2] = {0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 16; ++q) old[q] = slab_ff[slab_off + fb_row(q, lane) * C32];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const long o8 = (long)blockIdx.x * (9 * C32 * C32) + 8 * (C32 * C32) + tid + h * FB_THREADS;
+    prev8[h] = slab_ff[o8];
+    if (REC) prev8z[h] = slab_rec[o8];
+  }
+  const size_t row_off = (size_t)blockIdx.x * row_ld;
+  const int row_c = tid & 31, row_which = (tid >> 5) & 1;
+  const float row_prev = (row_which ? g_thresh : g_leak)[row_off + row_c];          // (read by threads < 64)
+  float top_prev = 0.f;
+  if (TOP) top_prev = tid < 64 ? top.dw[row_off + row_which * C32 + row_c] : top.db[row_off + (tid & 1)];  // (threads < 66)
   FB_STAMP();
   commit(0, s_cur, 0);
   FB_STAMP();
@@ -357,34 +377,16 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
   }
   FB_STAMP();
 
-  float prev8[2], prev8z[2] = {0.f, 0.f};
-  // ---- weight-gradient slabs: taps 0..7 straight from the owning wave
-  // (the 16 previous partial sums are loaded unconditionally and together, then selected: as
-  //  `acc ? *p + a : a` every load sat under a branch and was its own HBM round trip -- s_memtime showed this
-  //  epilogue taking 30 % (ff) / 42 % (rec) of the kernel)
-  {
-    const long off = (long)blockIdx.x * (9 * C32 * C32) + wv * (C32 * C32) + i;
-    float* d = slab_ff + off;
-    float* dz = REC ? slab_rec + off : d;
-    float old[16], oldz[REC ? 16 : 1];
+  // ---- weight-gradient slabs: taps 0..7 straight from the owning wave (previous partial sums: see the prologue;
+  // as `acc ? *p + a : a` every load sat under a branch and was its own HBM round trip -- s_memtime showed the
+  // epilogue taking 30 % (ff) / 42 % (rec) of the kernel; loaded together after the loop it still was one round trip)
+  float oldz[REC ? 16 : 1];
+  if (REC) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      old[q] = d[fb_row(q, lane) * C32];
-      if (REC) oldz[q] = dz[fb_row(q, lane) * C32];
-    }
-    // ... and the ninth-tap tile's (two words per thread and slab), consumed after the LDS reduction below
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const long o8 = (long)blockIdx.x * (9 * C32 * C32) + 8 * (C32 * C32) + tid + h * FB_THREADS;
-      prev8[h] = slab_ff[o8];
-      if (REC) prev8z[h] = slab_rec[o8];
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      d[fb_row(q, lane) * C32] = ((accumulate & 1) ? old[q] : 0.f) + acc[q];
-      if (REC) dz[fb_row(q, lane) * C32] = ((accumulate & 1) ? oldz[q] : 0.f) + accz[q];
-    }
+    for (int q = 0; q < 16; ++q) oldz[q] = slab_rec[slab_off + fb_row(q, lane) * C32];
   }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) slab_ff[slab_off + fb_row(q, lane) * C32] = ((accumulate & 1) ? old[q] : 0.f) + acc[q];
   // ---- tap 8: sum the 8 partial tiles through LDS (aliases the operand buffers)
   float* s_t8 = (float*)smem_raw;  // [8][1024]
   auto reduce_t8 = [&](const f32x16& a, float* slab, const float (&prev)[2]) {
@@ -401,9 +403,11 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     }
     __syncthreads();
   };
-  {
   reduce_t8(acc8, slab_ff, prev8);
-  if (REC) reduce_t8(accz8, slab_rec, prev8z);
+  if (REC) {
+    reduce_t8(accz8, slab_rec, prev8z);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) slab_rec[slab_off + fb_row(q, lane) * C32] = ((accumulate & 1) ? oldz[q] : 0.f) + accz[q];
   }
 
   // ---- per-channel sums for leak / thresh: lanes with equal (lane & 7) share channels
@@ -429,13 +433,13 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     // row_ld > 0: every block owns ROW blockIdx.x of a [blocks][row_ld] buffer of per-block partial sums (plain
     // read-modify-write, summed once per window by evf_sum_rows).  256 blocks adding atomically into the same 64 words
     // kept the kernel alive 4.5 us after its last block was done (34.5 -> 29.9 us without them).
-    const size_t ro = (size_t)blockIdx.x * row_ld;
+    const size_t ro = row_off;  // (the row's previous value was requested in the prologue: row_prev)
     if (which == 0) {
       const float l = fb_sigmoid(leak[c]), t = v * l * (1.0f - l);
-      if (row_ld) g_leak[ro + c] += t;
+      if (row_ld) g_leak[ro + c] = row_prev + t;
       else evf_atomic_add(g_leak + c, t);
     } else if (thresh[c] > 0.01f) {
-      if (row_ld) g_thresh[ro + c] += v;
+      if (row_ld) g_thresh[ro + c] = row_prev + v;
       else evf_atomic_add(g_thresh + c, v);
     }
   }
@@ -468,12 +472,12 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
       const int which = tid >> 5, c = tid & 31;
       float v = 0.f;
       for (int w = 0; w < 8; ++w) v += s_red[(which * 8 + w) * C32 + c];
-      if (row_ld) top.dw[(size_t)blockIdx.x * row_ld + which * C32 + c] += v;
+      if (row_ld) top.dw[row_off + which * C32 + c] = top_prev + v;
       else evf_atomic_add(top.dw + which * C32 + c, v);
     } else if (tid < 66) {
       float v = 0.f;
       for (int w = 0; w < 8; ++w) v += s_b2[2 * w + (tid - 64)];
-      if (row_ld) top.db[(size_t)blockIdx.x * row_ld + (tid - 64)] += v;
+      if (row_ld) top.db[row_off + (tid - 64)] = top_prev + v;
       else evf_atomic_add(top.db + (tid - 64), v);
     }
   }

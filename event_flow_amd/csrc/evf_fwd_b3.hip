@@ -137,6 +137,11 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
   const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
   FW_SPAN_MARK(0);
 
+  // per-channel parameters: requested FIRST and by every thread (no load under a branch).  Memory returns in order: as
+  // `if (tid < 32) s_par[tid] = sigmoid(leak[tid])` below the halo loads, wave 0 waited for them there and issued its
+  // state prefetch one round trip after the other seven waves.
+  const float par_leak = leak[tid & 31], par_thresh = thresh[tid & 31];
+  const float par_lpt = PLIF ? pl.leak_pt[tid & 31] : 0.f, par_apt = PLIF ? pl.add_pt[tid & 31] : 0.f;
 #ifndef PROBE_NO_WEIGHT_DMA  // (probe build: what does staging the 54 KiB of weights per block cost?)
   for (int u = wv; u < NFRAG; u += FW_WAVES) b3_glds16(wff + u * 64 + lane, s_w + u * 64);
 #endif
@@ -165,12 +170,6 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
   }
   const int i = lane & 31, kg = lane >> 5, j = lane & 31;
   const int r0 = 2 * wv;
-  if (tid < C32) {  // per-channel constants, once per block
-    s_par[tid] = b3_sigmoid(leak[tid]);       // torch.sigmoid(self.leak)     spiking_submodules.py:111/:536
-    s_par[C32 + tid] = fmaxf(thresh[tid], 0.01f);  // self.thresh.clamp_min(0.01)  :108/:533
-    s_par[2 * C32 + tid] = PLIF ? b3_sigmoid(pl.leak_pt[tid]) : 0.f;
-    s_par[3 * C32 + tid] = PLIF ? b3_sigmoid(pl.add_pt[tid]) : 0.f;
-  }
   // The matrix phase computes the TRANSPOSED tile (weights as the A operand): a lane owns PIXEL i of its two rows
   // and the 16 channels 8q + 4kg .. +3 (q = 0..3), so every state tensor moves as float4 -- 4 memory instructions per
   // tensor, row and lane instead of 16 (the dword-per-lane epilogue was bound by the texture addresser: 128
@@ -191,6 +190,12 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
         ptp[m][q] = pl.pt_prev ? pv4 : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+  }
+  if (tid < C32) {  // per-channel constants, once per block (operands: top of the kernel)
+    s_par[tid] = b3_sigmoid(par_leak);             // torch.sigmoid(self.leak)     spiking_submodules.py:111/:536
+    s_par[C32 + tid] = fmaxf(par_thresh, 0.01f);   // self.thresh.clamp_min(0.01)  :108/:533
+    s_par[2 * C32 + tid] = PLIF ? b3_sigmoid(par_lpt) : 0.f;
+    s_par[3 * C32 + tid] = PLIF ? b3_sigmoid(par_apt) : 0.f;
   }
   // The weight DMA (invisible to the compiler's counters) was issued before everything else and memory
   // returns in order: once at most the state prefetches issued above (8, or 16 with the PLIF trace) are still

@@ -747,6 +747,14 @@ __global__ __launch_bounds__(256) void k_head_bwd_mfma(
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const long total = npix * 8, stride = (long)gridDim.x * 256;
+  // operands of the epilogue, requested now: this block's previous slab partial sums (ncol <= 32: <= 4 per thread) and its
+  // row of per-channel sums -- after the loop they were two dependent HBM round trips at the end of the block's life
+  float* sl_out = slab + (long)blockIdx.x * (C32 * ncol);
+  float prev[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) prev[h] = sl_out[min(tid + 256 * h, C32 * ncol - 1)];
+  const size_t row_off = (size_t)blockIdx.x * row_ld;
+  const float row_prev = (((tid >> 5) & 1) ? g_thresh : g_leak)[row_off + (tid & 31)];  // (used by threads < 64)
   int it = 0;
   for (long base = (long)blockIdx.x * 256; base < total; base += stride, ++it) {  // block-uniform trip count
     const long e = base + tid;
@@ -812,11 +820,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_mfma(
 #pragma unroll
   for (int r = 0; r < 16; ++r) s_d[wv][((r & 3) + 8 * (r >> 2) + 4 * kg) * C32 + i] = acc[r];
   __syncthreads();
-  float* sl_out = slab + (long)blockIdx.x * (C32 * ncol);
-  {  // previous partial sums read together, selected afterwards (no load under a branch); ncol <= 32: <= 4 per thread
-    float prev[4];
-#pragma unroll
-    for (int h = 0; h < 4; ++h) prev[h] = sl_out[min(tid + 256 * h, C32 * ncol - 1)];
+  {  // (previous partial sums: prologue)
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       const int e2 = tid + 256 * h;
@@ -848,13 +852,13 @@ __global__ __launch_bounds__(256) void k_head_bwd_mfma(
     const int which = tid >> 5, c = tid & 31;
     float v = 0.f;
     for (int w = 0; w < 4; ++w) v += s_red[which][w][c];
-    const size_t ro = (size_t)blockIdx.x * row_ld;  // (row_ld > 0: per-block rows instead of same-address atomics)
+    const size_t ro = row_off;  // (row_ld > 0: per-block rows instead of same-address atomics; previous value: prologue)
     if (which == 0) {
       const float l = evf_sigmoid(leak[c]), t = v * l * (1.0f - l);
-      if (row_ld) g_leak[ro + c] += t;
+      if (row_ld) g_leak[ro + c] = row_prev + t;
       else evf_atomic_add(g_leak + c, t);
     } else if (thresh[c] > 0.01f) {
-      if (row_ld) g_thresh[ro + c] += v;
+      if (row_ld) g_thresh[ro + c] = row_prev + v;
       else evf_atomic_add(g_thresh + c, v);
     }
   }
