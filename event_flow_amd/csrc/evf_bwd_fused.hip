@@ -100,12 +100,16 @@ struct FbTop {
   float* db;            // [2]     accumulated
 };
 
-template <bool REC, bool TOP>
+// FAST: the reference's default neuron (arctan surrogate, hard reset: configs/train_SNN.yml) fixed at compile time.  With
+// the kind and the reset mode as run-time values every channel of the element-wise part carries a `switch` and an `if`:
+// uniform branches, but branches -- the four channels' dependent chains (v_rcp, the products behind it) cannot be
+// interleaved across them, and the loop body holds the code of all four surrogates (805 VALU instructions).
+template <bool REC, bool TOP, bool FAST>
 __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     const float4* __restrict__ g_z_out, const float4* __restrict__ g_v_out, const float4* __restrict__ v_out,
     const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev, const uint32_t* __restrict__ xT,
     const uint32_t* __restrict__ zT, const float* __restrict__ leak, const float* __restrict__ thresh, int B, int H,
-    int W, int nchunk, long nunits, int hard_reset, int surrogate, float width, int accumulate,
+    int W, int nchunk, long nunits, int hard_reset_rt, int surrogate_rt, float width, int accumulate,
     float4* __restrict__ g_cur, uint2* __restrict__ g_split, float4* __restrict__ g_v_prev,
     float* __restrict__ g_leak, float* __restrict__ g_thresh, float* __restrict__ slab_ff,
     float* __restrict__ slab_rec, FbTop top, int row_ld) {
@@ -115,6 +119,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
   uint32_t* s_pz = s_px + 2 * 3 * C32 * FB_NW;                // same (REC)
   uint4* s_lut = (uint4*)(s_pz + 2 * 3 * C32 * FB_NW);        // [256]
   float* s_red = (float*)(s_lut + 256);                       // [2][8][32]
+  const int hard_reset = FAST ? 1 : hard_reset_rt, surrogate = FAST ? EVF_ARCTAN : surrogate_rt;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 31, kg = lane >> 5;
   const int cg = tid & 7;  // channel group of the elementwise part: channels 4cg..4cg+3
@@ -151,12 +156,23 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
   // few channels at the same time (64 KiB stride between blocks).
   const int nblk = gridDim.x;
   const int nu = (int)((nunits - (long)blockIdx.x + nblk - 1) / nblk);
-  auto geom = [&](int k, int& b, int& y, int& x0, int& cw) {
-    const int u = blockIdx.x + k * nblk;  // nunits < 2^31
+  // Geometry of the block's (<= FB_UNITS) units: lane (k & 7) holds unit k's (sample, row, first column), computed ONCE
+  // here; a unit's geometry then is three v_readlane into SGPRs.  As two integer divisions by run-time values per call
+  // (v_rcp + fix-up chains with VALU -> SALU hops), four calls per unit, it was the "0.75 k cycles of load issue" of the
+  // phase stamps.
+  static_assert(FB_UNITS <= 8, "geometry table: one lane per unit of the block");
+  int g_b, g_y, g_x0;
+  {
+    const int u = blockIdx.x + min(lane & 7, nu - 1) * nblk;  // nunits < 2^31
     const int row = u / nchunk;
-    b = row / H;
-    y = row - b * H;
-    x0 = (u - row * nchunk) * FB_CW;
+    g_b = row / H;
+    g_y = row - g_b * H;
+    g_x0 = (u - row * nchunk) * FB_CW;
+  }
+  auto geom = [&](int k, int& b, int& y, int& x0, int& cw) {  // k: block-uniform, < nu
+    b = __builtin_amdgcn_readlane(g_b, k);
+    y = __builtin_amdgcn_readlane(g_y, k);
+    x0 = __builtin_amdgcn_readlane(g_x0, k);
     cw = min(FB_CW, W - x0);
   };
   // stage 1: issue the global loads of unit k (one float4 of each tensor per thread).
@@ -368,9 +384,21 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     FB_STAMP();
     issue_loads(k + 2, s_new);
     FB_STAMP();
+#ifdef FB_STAGGER
+    // the two waves of a SIMD (w and w + 4) take the unit's two phases in opposite order -- they touch different LDS
+    // buffers, so either order is valid -- and the matrix pipe of a SIMD works for one wave while its VALU works for the other
+    if (wv < 4) {
+      mfma_unit(k);
+      commit(k + 1, s_nxt, (k + 1) & 1);
+    } else {
+      commit(k + 1, s_nxt, (k + 1) & 1);
+      mfma_unit(k);
+    }
+#else
     mfma_unit(k);
     FB_STAMP();
     commit(k + 1, s_nxt, (k + 1) & 1);
+#endif
     FB_STAMP();
     __syncthreads();
     s_nxt = s_new;
@@ -504,25 +532,34 @@ static int fb_launch(const float* g_z_out, const FbTop* topp, const float* g_v_o
   dim3 grid(evf_cdiv(nunits, FB_UNITS)), block(FB_THREADS);
   hipStream_t st = EVF_STREAM(stream);
   const FbTop top = topp ? *topp : FbTop{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  static bool a1 = false, a2 = false, a3 = false;
-#define FB_GO(REC_, TOP_, flag)                                                                                           \
+  static bool attr[12] = {false};
+  const bool fast = hard_reset != 0 && surrogate == EVF_ARCTAN;
+#define FB_GO(REC_, TOP_, FAST_, slot)                                                                                    \
   do {                                                                                                                    \
-    if (!flag) {                                                                                                          \
-      (void)hipFuncSetAttribute((const void*)k_lif_bwd_wgrad<REC_, TOP_>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                FB_LDS);                                                                                  \
-      flag = true;                                                                                                        \
+    if (!attr[slot]) {                                                                                                    \
+      (void)hipFuncSetAttribute((const void*)k_lif_bwd_wgrad<REC_, TOP_, FAST_>,                                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);                                      \
+      attr[slot] = true;                                                                                                  \
     }                                                                                                                     \
-    hipLaunchKernelGGL((k_lif_bwd_wgrad<REC_, TOP_>), grid, block, FB_LDS, st, (const float4*)g_z_out,                    \
+    hipLaunchKernelGGL((k_lif_bwd_wgrad<REC_, TOP_, FAST_>), grid, block, FB_LDS, st, (const float4*)g_z_out,             \
                        (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev, z_prev, xT, zT_prev, leak,    \
                        thresh, B, H, W, nchunk, nunits, hard_reset, surrogate, act_width, accumulate, (float4*)g_cur,     \
                        (uint2*)g_split, (float4*)g_v_prev, g_leak, g_thresh, slab_ff, slab_rec, top, row_ld);             \
   } while (0)
+#define FB_GO2(REC_, TOP_, slot)            \
+  do {                                      \
+    if (fast)                               \
+      FB_GO(REC_, TOP_, true, 2 * (slot));  \
+    else                                    \
+      FB_GO(REC_, TOP_, false, 2 * (slot) + 1); \
+  } while (0)
   if (topp)
-    FB_GO(false, true, a3);
+    FB_GO2(false, true, 2);
   else if (zT_prev)
-    FB_GO(true, false, a2);
+    FB_GO2(true, false, 1);
   else
-    FB_GO(false, false, a1);
+    FB_GO2(false, false, 0);
+#undef FB_GO2
 #undef FB_GO
   return evf_status();
 }

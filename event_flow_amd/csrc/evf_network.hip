@@ -194,11 +194,9 @@ __device__ __forceinline__ void lif_update(const f32x16& acc, const float (&vpv)
       const float v = vpv[r];
       const float z = (float)((zw[r] >> j) & 1u);
       const float cur = acc[r];
-      float vo;
-      if (hard_reset)
-        vo = (v * lam) * (1.0f - z) + (1.0f - lam) * cur;
-      else
-        vo = v * lam + (1.0f - lam) * cur - z * th;
+      const float vo_hard = (v * lam) * (1.0f - z) + (1.0f - lam) * cur;
+      const float vo_soft = v * lam + (1.0f - lam) * cur - z * th;
+      const float vo = hard_reset ? vo_hard : vo_soft;  // (a select, not a branch, inside the unrolled pixel loop)
       v_out[pix * C32 + j] = vo;
       spike = (vo - th) > 0.f;
     }
@@ -712,12 +710,16 @@ extern "C" int evf_lif_bwd(const float* g_z_out, const float* g_v_out, const flo
 // LDS into A-operand order (lane (co, k) <- pixel 2m + k), the B operand x[pixel 2m + k][(ci, tap) = lane & 31] is
 // read straight from the input (one load per MFMA and lane).  16 accumulators instead of the 36 Cin sums per thread
 // of the earlier VALU form: ~3x the occupancy, which is what hides the HBM latency of this kernel.
+// FAST: arctan surrogate + hard reset (the reference's default neuron) fixed at compile time -- no `switch` / `if` per
+// channel in the element-wise part (see k_lif_bwd_wgrad).
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_head_bwd_mfma(
     const float4* __restrict__ g_z_out, const float4* __restrict__ g_v_out, const float4* __restrict__ v_out,
     const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev, const float* __restrict__ leak,
-    const float* __restrict__ thresh, long npix, int hard_reset, int surrogate, float width, float4* __restrict__ g_cur,
+    const float* __restrict__ thresh, long npix, int hard_reset_rt, int surrogate_rt, float width, float4* __restrict__ g_cur,
     float4* __restrict__ g_v_prev, float* __restrict__ g_leak, float* __restrict__ g_thresh,
     const float* __restrict__ x_in, int Cin, int H, int W, float* __restrict__ slab, int slab_acc, int row_ld) {
+  const int hard_reset = FAST ? 1 : hard_reset_rt, surrogate = FAST ? EVF_ARCTAN : surrogate_rt;
   __shared__ float s_red[2][4][C32];
   __shared__ __attribute__((aligned(16))) float s_g[2][4][8 * C32];  // [buffer][wave][pixel][channel]
   __shared__ float s_d[4][C32 * C32];
@@ -896,10 +898,16 @@ extern "C" int evf_head_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out
   const int nblk = evf_head_lif_bwd_wgrad_slabs(B, H, W);
   const int row_ld = accumulate >> 8;  // pitch of the per-block parameter-gradient rows (0: dense outputs, atomics)
   accumulate &= 1;
-  hipLaunchKernelGGL(k_head_bwd_mfma, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)g_z_out,
-                     (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev, z_prev, leak, thresh, npix,
-                     hard_reset, surrogate, act_width, (float4*)g_cur, (float4*)g_v_prev, g_leak, g_thresh, x_in, Cin, H, W,
-                     slab, accumulate, row_ld);
+#define HEAD_BWD(FAST_)                                                                                                    \
+  hipLaunchKernelGGL(k_head_bwd_mfma<FAST_>, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)g_z_out,         \
+                     (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev, z_prev, leak, thresh, npix,      \
+                     hard_reset, surrogate, act_width, (float4*)g_cur, (float4*)g_v_prev, g_leak, g_thresh, x_in, Cin, H,  \
+                     W, slab, accumulate, row_ld)
+  if (hard_reset != 0 && surrogate == EVF_ARCTAN)
+    HEAD_BWD(true);
+  else
+    HEAD_BWD(false);
+#undef HEAD_BWD
   return evf_status();
 }
 
