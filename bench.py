@@ -269,10 +269,10 @@ def iwe_warp_bandwidth(dev, B, reps=20):
 _KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3_lds<false, false, false>", "evf_conv_dgrad_b3_f32": "k_conv_dgrad_b3_lds<true, false, false>",
               "evf_conv_dgrad_b3_f32_pair": "k_conv_dgrad_b3_lds<true, true, false>",
               "evf_conv_lif_fwd_b3_pred/ff": "k_conv_lif_fwd_b3<false, false>",
-              "evf_lif_bwd_wgrad/ff": "k_lif_bwd_wgrad<false, false>", "evf_lif_bwd_wgrad_top": "k_lif_bwd_wgrad<false, true>",
-              "evf_lif_bwd_wgrad/rec": "k_lif_bwd_wgrad<true, false>", "evf_conv_lif_fwd_b3/ff": "k_conv_lif_fwd_b3<false, false>",
-              "evf_conv_lif_fwd_b3/rec": "k_conv_lif_fwd_b3<true, false>", "evf_head_lif_fwd": "k_head_lif_fwd",
-              "evf_head_lif_bwd_wgrad": "k_head_bwd_mfma", "evf_conv_dgrad/one": "k_conv_dgrad<false>",
+              "evf_lif_bwd_wgrad/ff": "k_lif_bwd_wgrad<false, false, true>", "evf_lif_bwd_wgrad_top": "k_lif_bwd_wgrad<false, true, true>",
+              "evf_lif_bwd_wgrad/rec": "k_lif_bwd_wgrad<true, false, true>", "evf_conv_lif_fwd_b3/ff": "k_conv_lif_fwd_b3<false, false>",
+              "evf_conv_lif_fwd_b3/rec": "k_conv_lif_fwd_b3<true, false>", "evf_head_lif_fwd": "k_head_lif_fwd<1>",
+              "evf_head_lif_bwd_wgrad": "k_head_bwd_mfma<true>", "evf_conv_dgrad/one": "k_conv_dgrad<false>",
               "evf_conv_dgrad/two": "k_conv_dgrad<true>", "evf_conv_lif_fwd/ff": "k_conv_lif_fwd<false>",
               "evf_conv_lif_fwd/rec": "k_conv_lif_fwd<true>", "evf_conv_wgrad_bits": "k_conv_wgrad_bits"}
 
