@@ -308,8 +308,8 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
   f32x16 acc = {0}, acc8 = {0}, accz = {0}, accz8 = {0};
   const int dy = wv / 3, dx = wv % 3;  // taps 0..7; tap 8 = (2, 2) is shared
   // stage 3: matrix cores on the staged unit
-  auto mfma_unit = [&](int k) {
-    const int buf = k & 1;
+  auto mfma_unit = [&](int par) {  // par = parity of the unit = its LDS buffer
+    const int buf = par;
     const uint4* sbh = (const uint4*)(s_b + buf * (3 * FB_CW * C32));
     const uint32_t* px = s_px + buf * (3 * C32 * FB_NW);
     const uint32_t* pz = s_pz + buf * (3 * C32 * FB_NW);
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
         accz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(az, bm, accz, 0, 0, 0);
         accz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(az, bl, accz, 0, 0, 0);
       }
-      if (kq + (FB_CW / 16) * (k & 1) == wv) {  // this wave's share of the ninth tap
+      if (kq + (FB_CW / 16) * par == wv) {  // this wave's share of the ninth tap
         const bf16x8 a8 = afrag(px, 2, 2, kq);
         acc8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, bh, acc8, 0, 0, 0);
         acc8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, bm, acc8, 0, 0, 0);
@@ -350,8 +350,12 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     }
   };
 
-  // software pipeline with two units of loads always in flight (register stages rotate by moves):
-  //   iteration k: loads(k+2) -> registers | MFMA(k) from LDS[k&1] | commit(k+1) -> LDS[(k+1)&1]
+  // software pipeline with two units of loads always in flight:
+  //   unit k: loads(k+2) -> registers | MFMA(k) from LDS[k&1] | commit(k+1) -> LDS[(k+1)&1]
+  // The loop is unrolled by two and the two register stages swap ROLES instead of contents: `s_nxt = s_new` at the end
+  // of an iteration was 22 v_mov per unit -- and a move of a loaded register is a wait for that load, i.e. the loads of
+  // unit k+2 had to land within iteration k instead of by the commit of iteration k+1.  An odd unit count runs one more
+  // half-iteration on a unit of zeros (commit of a unit >= nu writes zeros: the MFMAs add nothing).
   FbStage s_cur, s_nxt, s_new;
   issue_loads(0, s_cur);
   issue_loads(1, s_nxt);
@@ -380,28 +384,19 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
   FB_STAMP();
   __syncthreads();
 #pragma unroll 1
-  for (int k = 0; k < nu; ++k) {
+  for (int k = 0; k < nu; k += 2) {
     FB_STAMP();
     issue_loads(k + 2, s_new);
     FB_STAMP();
-#ifdef FB_STAGGER
-    // the two waves of a SIMD (w and w + 4) take the unit's two phases in opposite order -- they touch different LDS
-    // buffers, so either order is valid -- and the matrix pipe of a SIMD works for one wave while its VALU works for the other
-    if (wv < 4) {
-      mfma_unit(k);
-      commit(k + 1, s_nxt, (k + 1) & 1);
-    } else {
-      commit(k + 1, s_nxt, (k + 1) & 1);
-      mfma_unit(k);
-    }
-#else
-    mfma_unit(k);
+    mfma_unit(0);
     FB_STAMP();
-    commit(k + 1, s_nxt, (k + 1) & 1);
-#endif
+    commit(k + 1, s_nxt, 1);
     FB_STAMP();
     __syncthreads();
-    s_nxt = s_new;
+    issue_loads(k + 3, s_nxt);
+    mfma_unit(1);
+    commit(k + 2, s_new, 0);
+    __syncthreads();
   }
   FB_STAMP();
 
