@@ -643,6 +643,67 @@ def test_fused_path_other_surrogates_and_soft_reset_vs_oracle(acts, hard):
         assert np.linalg.norm(N(p.grad) - ref) <= 2e-3 * denom + 1e-9, (k, np.linalg.norm(N(p.grad) - ref) / denom)
 
 
+def _two_passes_vs_oracle(cls, name, neuron, B, H, W, seed):
+    """Two passes of a fused FireNet against the CPU oracle.  Returns (#flipped spikes over all passes and layers, the
+    oracle's largest |v' - thresh| among the flipped neurons of the FIRST layer that has any (everything after it
+    diverges legitimately), max |flow difference| of the last pass, worst parameter-gradient
+    difference relative to max(|that gradient|, 1e-4 |largest gradient|))."""
+    torch.manual_seed(seed)
+    model = cls(model_cfg(neuron)).to(DEV)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if k.endswith("thresh"):
+                p.mul_(0.2)
+    params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    for k, _ in model.named_parameters():
+        params[k].requires_grad_(True)
+    xs = [(torch.rand(B, 2, H, W) < 0.6).float() * torch.randint(1, 4, (B, 2, H, W)).float() for _ in range(2)]
+    states, tot, tot_ref, nflip, margin = [None] * 7, 0, 0, 0, 0.0
+    model.train()
+    for x in xs:
+        f_ref, states = osnn.firenet_forward(name, params, x, states)
+        f = model(x.to(DEV), x.to(DEV))["flow"][0]
+        wgt = torch.arange(f_ref.numel()).view(f_ref.shape).remainder(5).float() - 2.0
+        tot_ref = tot_ref + (f_ref * wgt).sum()
+        tot = tot + (f * wgt.to(DEV)).sum()
+        for li, ln in enumerate(LAYERS):
+            bad = N(model.states[li][1]) != states[li][1].detach().numpy()
+            if bad.any():
+                if nflip == 0:  # the FIRST layer (of the first pass) with a flip: its inputs were still identical
+                    th = params[ln + ".thresh"].detach().clamp_min(0.01).numpy().reshape(1, -1, 1, 1)
+                    margin = float(np.abs(states[li][0].detach().numpy() - th)[bad].max())
+                nflip += int(bad.sum())
+    ferr = float((f.detach().cpu() - f_ref.detach()).abs().max())
+    tot.backward()
+    tot_ref.backward()
+    refs = {k: (params[k].grad.numpy() if params[k].grad is not None else np.zeros(tuple(p.shape), np.float32))
+            for k, p in model.named_parameters()}
+    scale = max(np.linalg.norm(r) for r in refs.values())
+    worst = max(float(np.linalg.norm(N(p.grad) - refs[k]) / max(np.linalg.norm(refs[k]), 1e-4 * scale, 1e-12))
+                for k, p in model.named_parameters())
+    return nflip, margin, ferr, worst
+
+
+@pytest.mark.parametrize("seed", [3, 7])
+def test_fused_firenets_on_random_shapes_vs_oracle(seed):
+    """A seeded sweep of sensor sizes (1..40 x 1..200, B 1..3; every third case PLIF) through the fused path: ragged
+    tiles in both directions, one-pixel-wide images, odd unit counts of the fused backward.  Where no spike flips, flow
+    and gradients must match the oracle; where one does, the oracle itself must sit within 1e-6 of the threshold there
+    (a rounding-order flip, not an error) -- tools/debug/fuzz_firenet.py is the long form of this test."""
+    rng = np.random.default_rng(seed)
+    compared = 0
+    for it in range(10):
+        B, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 41)), int(rng.integers(1, 201))
+        cls, name, neuron = (LIFFireNet, "LIFFireNet", NEURON) if it % 3 else (PLIFFireNet, "PLIFFireNet", PLIF_NEURON)
+        nflip, margin, ferr, worst = _two_passes_vs_oracle(cls, name, neuron, B, H, W, seed * 1000 + it)
+        if nflip:
+            assert margin <= 1e-6, (name, B, H, W, nflip, margin)
+            continue
+        compared += 1
+        assert ferr <= 1e-4 and worst <= 2e-3, (name, B, H, W, ferr, worst)
+    assert compared >= 6
+
+
 def test_event_warping_with_an_empty_pass_and_iwe_of_nothing():
     """Ragged windows: a pass that contributes zero events, and an IWE of an empty event list."""
     from event_flow_amd.utils import iwe as hiwe
