@@ -266,8 +266,11 @@ def iwe_warp_bandwidth(dev, B, reps=20):
             "frac_of_hbm_peak": alg_bytes / ms / 1e6 / HBM_PEAK}
 
 
-_KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3_lds<false, false, false>", "evf_conv_dgrad_b3_f32": "k_conv_dgrad_b3_lds<true, false, false>",
-              "evf_conv_dgrad_b3_f32_pair": "k_conv_dgrad_b3_lds<true, true, false>",
+_KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3_lds<false, false, false, false>",
+              "evf_conv_dgrad_b3_f32": "k_conv_dgrad_b3_lds<true, false, false, false>",
+              "evf_conv_dgrad_b3_f32/acc": "k_conv_dgrad_b3_lds<true, true, false, false>",
+              "evf_conv_dgrad_b3_f32_pair": "k_conv_dgrad_b3_lds<true, false, false, true>",
+              "evf_conv_dgrad_b3_f32_pair/acc": "k_conv_dgrad_b3_lds<true, true, false, true>",
               "evf_conv_lif_fwd_b3_pred/ff": "k_conv_lif_fwd_b3<false, false>",
               "evf_lif_bwd_wgrad/ff": "k_lif_bwd_wgrad<false, false, true>", "evf_lif_bwd_wgrad_top": "k_lif_bwd_wgrad<false, true, true>",
               "evf_lif_bwd_wgrad/rec": "k_lif_bwd_wgrad<true, false, true>", "evf_conv_lif_fwd_b3/ff": "k_conv_lif_fwd_b3<false, false>",
@@ -569,6 +572,13 @@ def main():
              "evf_conv_dgrad_b3_f32", "evf_conv_dgrad_b3_f32_pair", "evf_conv_wgrad_bits", "evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad_top",
              "evf_lif_bwd", "evf_head_lif_bwd_wgrad", "evf_head_lif_fwd", "evf_head_wgrad", "evf_pred_bwd", "evf_reduce_slabs", "evf_reduce_slabs_multi", "evf_cm_loss_fwd",
              "evf_cm_loss_bwd", "evf_conv_plif_fwd_b3", "evf_head_plif_fwd", "evf_plif_trace_bwd", "evf_encode_events", "evf_clip_adam_step"]
+    from event_flow_amd import train as _train
+
+    # diagonal launches (train.window_backward -> engine.defer_forward): the hidden forward cells of a window are recorded and
+    # launched by ONE evf_fwd_defer_flush call (P + 5 k_fwd_diag launches); the per-cell entry points then launch nothing
+    diag_fwd = _train.DEFER_FORWARD and getattr(model, "precision", "") == "bf16x3" and wl["model"] == "LIFFireNet"
+    if diag_fwd:
+        names = [n for n in names if n not in ("evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred")] + ["evf_fwd_defer_flush"]
 
     # Everything runs on one side stream: warm-up (eager), then one whole training step
     # per input window is captured into a hipGraph on that same stream (autograd's
@@ -639,6 +649,8 @@ def main():
             ("evf_conv_dgrad_b3", ""): (CONV_FLOP * npix, 320 * npix),
             # fp32 g_cur in (128 B/px, halo not counted), fp32 gradient out; the pair form writes two outputs
             ("evf_conv_dgrad_b3_f32", ""): (CONV_FLOP * npix, 256 * npix), ("evf_conv_dgrad_b3_f32_pair", ""): (2 * CONV_FLOP * npix, 384 * npix),
+            # accumulating forms: the previous g_x is read as well (+128 B/px)
+            ("evf_conv_dgrad_b3_f32", "acc"): (CONV_FLOP * npix, 384 * npix), ("evf_conv_dgrad_b3_f32_pair", "acc"): (2 * CONV_FLOP * npix, 512 * npix),
             ("evf_conv_lif_fwd_b3_pred", "ff"): (CONV_FLOP * npix, 280 * npix),
             # top layer: g_v, v', v in, g_cur + g_v_prev out, flow / g_flow 16 B/px, spike words
             ("evf_lif_bwd_wgrad_top", ""): (CONV_FLOP * npix, 668 * npix),
@@ -662,6 +674,11 @@ def main():
         # g_cur, g_pt carry, pt_prev, pt_out in; g_pt_prev out (fp32 [npix][32]); P, g_P_raw, g_P_in [npix]
         model[("evf_plif_trace_bwd", "")] = (0, 652 * npix)
         hbm_bound |= {"evf_conv_plif_fwd_b3", "evf_head_plif_fwd", "evf_plif_trace_bwd"}
+        if diag_fwd:  # one bracket = the window's PASSES + 5 k_fwd_diag launches: 6 hidden cells per pass (8 contractions: two
+            # recurrent cells), 272 B/px each, 280 under the prediction head
+            model[("evf_fwd_defer_flush", "")] = (8 * PASSES * CONV_FLOP * npix, PASSES * (5 * 272 + 280) * npix)
+            hbm_bound |= {"evf_fwd_defer_flush"}
+            bf16_terms["evf_fwd_defer_flush"] = 3
         kernels = {}
         step_alg_bytes = 0.0
         for key, ms in prof.items():
@@ -686,8 +703,13 @@ def main():
                 ent["mfma_busy_pct"] = pm["mfma_busy_pct"] if pm else None  # SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE (PMC pass)
                 if not pm:
                     ent["pmc"] = why
+            if key[0] == "evf_fwd_defer_flush":
+                ent["multi_launch"] = PASSES + 5
+                ent["note"] = (f"one call = {PASSES + 5} k_fwd_diag launches (the window's {6 * PASSES} hidden forward cells, diagonal by "
+                               "diagonal: cells (pass, layer) with equal pass + layer are independent); not a single kernel, so "
+                               "not a candidate for `roofline`")
             kernels[name] = ent
-        dom_key = max((k for k in prof if k in model), key=lambda k: sum(prof[k]))
+        dom_key = max((k for k in prof if k in model and k[0] != "evf_fwd_defer_flush"), key=lambda k: sum(prof[k]))
         dom = kernels["/".join(k for k in dom_key if k)]
         detail, why_not = _pmc("/".join(k for k in dom_key if k))
         traffic = int(detail["MB_per_launch"] * 1e6) if detail else None  # HBM bytes per launch (PMC), next to ...
@@ -713,6 +735,9 @@ def main():
                        "global_batch": B_PER_GPU * dp.world, "events_per_window": PASSES * EV_PER_PASS,
                        "parallelism": f"dp{dp.world}", "launch": mode, "loss": loss_val,
                        "streams": nstream,
+                       "forward_launches": ("diagonal: the window's hidden forward cells in P + 5 launches (k_fwd_diag, cells "
+                                            "(pass, layer) with equal pass + layer together); EVF_DEFER_FWD=0: one launch per cell"
+                                            if diag_fwd else "one launch per (pass, layer) cell"),
                        "pipelining": (f"each rank's {B_PER_GPU} windows as {nstream} micro-batches of {B_PER_GPU // nstream} on {nstream} HIP "
                                       "streams (replicas sharing the weights; gradients summed before the one optimizer step): "
                                       "kernels[*] / roofline are per LAUNCH of a micro-batch, timed one at a time; in the replayed "

@@ -49,6 +49,10 @@ NETWORK_SIGNATURES = {
     "evf_pack_conv_weight_b3": [P, I, I, P, P],
     "evf_conv_lif_fwd_b3": [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P],
     "evf_conv_lif_fwd_b3_pred": [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P, P],
+    "evf_fwd_defer_begin": [],
+    "evf_fwd_defer_slot": [I],
+    "evf_fwd_defer_pending": [],
+    "evf_fwd_defer_flush": [P],
     "evf_lif_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P],
     "evf_lif_bwd_wgrad_slabs": [I, I, I],
     "evf_head_lif_bwd_wgrad_slabs": [I, I, I],
@@ -180,6 +184,8 @@ _PROF_VARIANT = {
     "evf_conv_lif_fwd_b3_pred": lambda a: "rec" if a[2] is not None else "ff",
     "evf_conv_dgrad": lambda a: "two" if a[4] is not None else "one",
     "evf_lif_bwd_wgrad": lambda a: "rec" if a[6] is not None else "ff",
+    "evf_conv_dgrad_b3_f32": lambda a: "acc" if a[3] else "",
+    "evf_conv_dgrad_b3_f32_pair": lambda a: "acc" if a[3] else "",
     # general convs: the shape is the variant ("B,H,W,Cin,Cout,k,stride"): bench.py derives the FLOP of every launch from it
     "evf_conv2d_fwd": lambda a: ",".join(str(int(v)) for v in a[6:13]),
     "evf_conv2d_dgrad": lambda a: ",".join(str(int(v)) for v in a[5:12]),
@@ -234,8 +240,18 @@ def profile_stop():
     return out
 
 
+# Deferred forward cells (evf_fwd_defer_*, models/engine.py): while a recording is open, any OTHER entry point may read what
+# the recorded cells write, so it launches them first.  The names below never do: they record or launch a cell themselves,
+# or only produce network inputs.
+_defer_flush = None  # callable set by the engine that opened the recording
+_DEFER_SAFE = {"evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_head_lif_fwd", "evf_fwd_defer_flush",
+               "evf_encode_window", "evf_encode_events", "evf_events_to_image"}
+
+
 def call(name, *args):
     """Invoke an entry point on torch's current stream; raise on error."""
+    if _defer_flush is not None and name not in _DEFER_SAFE:
+        _defer_flush()
     if _prof is not None and name in _prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -141,7 +141,9 @@ extern "C" int evf_debug_dg_span(void* dst) { return evf_hip(hipMemcpyFromSymbol
 
 #define DG_SP 36  // floats per pixel of the epilogue staging tile (32 + 4: conflict-free 16-byte writes)
 
-template <bool F32IN, bool ACC, bool PLIF>
+// PAIR: two weight sets (wt2 / gx2) -- compile time, so that the profiler sees the one- and the two-product launches as
+// different kernels and the tile's product loop has a fixed trip count
+template <bool F32IN, bool ACC, bool PLIF, bool PAIR>
 __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4* __restrict__ gs, long plane_stride,
                                                                     const uint4* __restrict__ wt, float* __restrict__ gx,
                                                                     int accumulate, int B, int H, int W,
@@ -223,9 +225,10 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
     }
     auto matrix_phase = [&]() -> f32x16 { return dg_matrix_phase<true>(s_w, s_a, DL_HPP * 4, wv * DL_HW + i, lane, msk); };
     // with two weight sets the order alternates from tile to tile: the set left in LDS by the previous tile goes first
-    const int nset = wt2 ? 2 : 1;
+    constexpr int nset = PAIR ? 2 : 1;
+#pragma unroll
     for (int k = 0; k < nset; ++k) {
-      const int set = wt2 ? ((tile_it + k) & 1) : 0;
+      const int set = PAIR ? ((tile_it + k) & 1) : 0;
       if (k) {  // swap the weight set
         __syncthreads();  // every wave is done with the current one
         const uint4* wsrc = set ? wt2 : wt;
@@ -312,17 +315,24 @@ static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, in
   const long plane_stride = (long)B * H * W * 4;  // uint4 per term plane: npix * 32 bf16 / 8
   const size_t lds = (size_t)(NFRAG * 64 + 3 * DL_HPP * 4) * sizeof(uint4) + (size_t)DG_ROWS * 32 * DG_SP * 4;  // 138 KiB
   const bool acc = accumulate != 0, plif = g_P != nullptr;
-#define DG_GO(F_, A_, P_)                                                                                                  \
+#define DG_GO2(F_, A_, P_, R_)                                                                                                  \
   do {                                                                                                                     \
     static bool attr = false;                                                                                              \
     if (!attr) {                                                                                                           \
-      (void)hipFuncSetAttribute((const void*)k_conv_dgrad_b3_lds<F_, A_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+      (void)hipFuncSetAttribute((const void*)k_conv_dgrad_b3_lds<F_, A_, P_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                 (int)lds);                                                                                 \
       attr = true;                                                                                                         \
     }                                                                                                                      \
-    hipLaunchKernelGGL((k_conv_dgrad_b3_lds<F_, A_, P_>), grid, block, lds, EVF_STREAM(stream), (const uint4*)g,           \
+    hipLaunchKernelGGL((k_conv_dgrad_b3_lds<F_, A_, P_, R_>), grid, block, lds, EVF_STREAM(stream), (const uint4*)g,           \
                        plane_stride, (const uint4*)wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, (const uint4*)wT2_b3,     \
                        g_x2);                                                                                              \
+  } while (0)
+#define DG_GO(F_, A_, P_)          \
+  do {                             \
+    if (wT2_b3)                    \
+      DG_GO2(F_, A_, P_, true);    \
+    else                           \
+      DG_GO2(F_, A_, P_, false);   \
   } while (0)
 #define DG_AP(F_)                  \
   do {                             \
@@ -341,6 +351,7 @@ static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, in
     DG_AP(false);
 #undef DG_AP
 #undef DG_GO
+#undef DG_GO2
   return evf_status();
 }
 

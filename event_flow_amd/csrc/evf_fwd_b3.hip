@@ -116,7 +116,7 @@ extern "C" int evf_debug_fw_span(void* dst) { return evf_hip(hipMemcpyFromSymbol
 #endif
 
 template <bool REC, bool PLIF>
-__global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* __restrict__ x, const uint4* __restrict__ wff,
+__device__ __forceinline__ void fwd_b3_body(const int b, const uint32_t* __restrict__ x, const uint4* __restrict__ wff,
                                                          const uint4* __restrict__ wrec,
                                                          const float* __restrict__ leak,
                                                          const float* __restrict__ thresh,
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
   float* s_pw = s_P + TH * TW;                   // 2*32 + 2 prediction-head weights and bias
   float* s_par = s_pw + 2 * C32 + 2;             // [4][32]: sigmoid(leak), clamped thresh, sigmoid(leak_pt), sigmoid(add_pt)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+  const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;  // b: the sample (blockIdx.z of the one-layer kernel)
   FW_SPAN_MARK(0);
 
   // per-channel parameters: requested FIRST and by every thread (no load under a branch).  Memory returns in order: as
@@ -326,15 +326,143 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
   FW_SPAN_MARK(1);
 }
 
+template <bool REC, bool PLIF>
+__global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* __restrict__ x, const uint4* __restrict__ wff,
+                                                         const uint4* __restrict__ wrec,
+                                                         const float* __restrict__ leak,
+                                                         const float* __restrict__ thresh,
+                                                         const float* __restrict__ v_prev,
+                                                         const uint32_t* __restrict__ z_prev, int B, int H, int W,
+                                                         int hard_reset, float* __restrict__ v_out,
+                                                         uint32_t* __restrict__ z_out,
+                                                         uint32_t* __restrict__ zT_out, PlifArgs pl, PredArgs pr) {
+  fwd_b3_body<REC, PLIF>(blockIdx.z, x, wff, wrec, leak, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out, pl,
+                         pr);
+}
+
+// ---- several independent (pass, layer) cells of a window in ONE launch ------------------------------------------------
+// Cell (t, l) of the fused stack needs (t, l-1) and (t-1, l) only: all cells with the same t + l are independent.  A
+// window's forward is recorded by evf_fwd_defer_* (below) and launched diagonal by diagonal: P + L - 1 launches of
+// up to L cells instead of P x L launches -- every launch pays its fixed cost (cold first fetch, kernel boundary:
+// ~8 of the ~15 us of a single cell) once.  blockIdx.z = cell * B + sample; same body, same results.
+#define FW_MAX_JOBS 8
+struct FwJob {
+  const uint32_t* x;
+  const uint4* wff;
+  const uint4* wrec;  // NULL: feed-forward cell
+  const float* leak;
+  const float* thresh;
+  const float* v_prev;
+  const uint32_t* z_prev;
+  float* v_out;
+  uint32_t* z_out;
+  uint32_t* zT_out;
+  PredArgs pr;
+  int hard_reset;
+  int pad_;
+};
+struct FwJobs {
+  FwJob j[FW_MAX_JOBS];
+};
+__global__ __launch_bounds__(FW_THREADS) void k_fwd_diag(FwJobs jobs, int B, int H, int W) {
+  const int jb = blockIdx.z / B, b = blockIdx.z - jb * B;
+  const FwJob& J = jobs.j[jb];
+  const PlifArgs none{nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (J.wrec)
+    fwd_b3_body<true, false>(b, J.x, J.wff, J.wrec, J.leak, J.thresh, J.v_prev, J.z_prev, B, H, W, J.hard_reset, J.v_out,
+                             J.z_out, J.zT_out, none, J.pr);
+  else
+    fwd_b3_body<false, false>(b, J.x, J.wff, J.wrec, J.leak, J.thresh, J.v_prev, J.z_prev, B, H, W, J.hard_reset, J.v_out,
+                              J.z_out, J.zT_out, none, J.pr);
+}
+
+#define FW_MAX_DIAGS 96
+static struct {
+  bool active = false;
+  int slot = 0;
+  int B = 0, H = 0, W = 0;
+  int n[FW_MAX_DIAGS] = {0};
+  FwJob job[FW_MAX_DIAGS][FW_MAX_JOBS];
+} fw_defer;
+
+static size_t fw_lds_bytes() {
+  return WB3_BYTES + 256 * 16 + 2 * HALO_H * HALO_W * 4 + TH * TW * 4 + (2 * C32 + 2) * 4 + 4 * C32 * 4;
+}
+
+// Launch what has been recorded (diagonals in increasing order) and keep recording.
+static int fw_defer_launch(void* stream) {
+  const size_t lds = fw_lds_bytes();
+  static bool attr_set = false;
+  if (!attr_set && lds > 65536) {
+    (void)hipFuncSetAttribute((const void*)k_fwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  for (int d = 0; d < FW_MAX_DIAGS; ++d) {
+    const int n = fw_defer.n[d];
+    if (!n) continue;
+    FwJobs jobs;
+    for (int k = 0; k < FW_MAX_JOBS; ++k) jobs.j[k] = fw_defer.job[d][k < n ? k : 0];
+    dim3 grid(evf_cdiv(fw_defer.W, TW), evf_cdiv(fw_defer.H, TH), fw_defer.B * n), block(FW_THREADS);
+    hipLaunchKernelGGL(k_fwd_diag, grid, block, lds, EVF_STREAM(stream), jobs, fw_defer.B, fw_defer.H, fw_defer.W);
+    fw_defer.n[d] = 0;
+  }
+  return evf_status();
+}
+
+// evf_fwd_defer_begin(): from now on evf_conv_lif_fwd_b3 / evf_conv_lif_fwd_b3_pred RECORD their launch under the
+// diagonal index last set by evf_fwd_defer_slot() instead of launching.  evf_fwd_defer_flush() launches the recorded
+// cells (one k_fwd_diag per non-empty diagonal, increasing index) and ends the recording; it must run before anything
+// reads the cells' outputs.  The caller guarantees that cells recorded under one index are independent and that a cell's
+// operands come from lower indices (or from launches issued before).  Process-wide state, one recorder at a time.
+extern "C" int evf_fwd_defer_begin() {
+  if (fw_defer.active) return EVF_EINVAL;
+  fw_defer.active = true;
+  fw_defer.slot = 0;
+  fw_defer.B = fw_defer.H = fw_defer.W = 0;
+  for (int d = 0; d < FW_MAX_DIAGS; ++d) fw_defer.n[d] = 0;
+  return EVF_OK;
+}
+extern "C" int evf_fwd_defer_slot(int d) {
+  if (!fw_defer.active || d < 0 || d >= FW_MAX_DIAGS) return EVF_EINVAL;
+  fw_defer.slot = d;
+  return EVF_OK;
+}
+extern "C" int evf_fwd_defer_pending() {
+  if (!fw_defer.active) return 0;
+  int n = 0;
+  for (int d = 0; d < FW_MAX_DIAGS; ++d) n += fw_defer.n[d];
+  return n;
+}
+extern "C" int evf_fwd_defer_flush(void* stream) {
+  if (!fw_defer.active) return EVF_OK;
+  const int rc = fw_defer_launch(stream);
+  fw_defer.active = false;
+  return rc;
+}
+
 static int launch_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec, const float* leak,
                          const float* thresh, const float* v_prev, const uint32_t* z_prev, int B, int H, int W,
                          int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out, const PlifArgs* plif,
                          void* stream, const PredArgs* pred = nullptr) {
+  PredArgs pd = pred ? *pred : PredArgs{nullptr, nullptr, nullptr};
+  if (fw_defer.active && !plif) {  // recorded, launched by evf_fwd_defer_flush (or when a diagonal is full / the geometry changes)
+    if (fw_defer.B && (fw_defer.B != B || fw_defer.H != H || fw_defer.W != W)) {
+      const int rc = fw_defer_launch(stream);
+      if (rc) return rc;
+    }
+    if (fw_defer.n[fw_defer.slot] == FW_MAX_JOBS) {  // (cannot happen with one cell per layer and <= 8 layers)
+      const int rc = fw_defer_launch(stream);
+      if (rc) return rc;
+    }
+    fw_defer.B = B, fw_defer.H = H, fw_defer.W = W;
+    fw_defer.job[fw_defer.slot][fw_defer.n[fw_defer.slot]++] =
+        FwJob{x, (const uint4*)wb_ff, (const uint4*)wb_rec, leak, thresh, v_prev, z_prev, v_out, z_out, zT_out, pd, hard_reset, 0};
+    return EVF_OK;
+  }
   dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(FW_THREADS);
   hipStream_t st = EVF_STREAM(stream);
-  const size_t lds = WB3_BYTES + 256 * 16 + 2 * HALO_H * HALO_W * 4 + TH * TW * 4 + (2 * C32 + 2) * 4 + 4 * C32 * 4;
+  const size_t lds = fw_lds_bytes();
   PlifArgs pa = plif ? *plif : PlifArgs{nullptr, nullptr, nullptr, nullptr, nullptr};
-  PredArgs pd = pred ? *pred : PredArgs{nullptr, nullptr, nullptr};
 #define EVF_FWD(REC_, PLIF_)                                                                                           \
   do {                                                                                                                 \
   if (lds > 65536) {                                                                                                   \

@@ -91,6 +91,7 @@ class _FireNetPass(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_flow, g_token):
         eng, win = ctx.eng, ctx.win
+        eng.flush_forward()
         eng._backward_pass(win, ctx.tape, g_flow, ctx.is_first)
         ctx.tape = None
         grads = eng._finalize(win) if ctx.is_first else (None,) * len(eng.params)
@@ -335,6 +336,29 @@ class FireNetEngine:
         self._flow_cap = max(self._flow_cap, win.n_passes)
         return flow
 
+    # -- deferred forward: the window's hidden cells launched diagonal by diagonal (csrc/evf_fwd_b3.hip, k_fwd_diag) --------
+    def defer_forward(self, on=True):
+        """While on, the hidden layers of every recorded (training) pass are RECORDED (cell (t, l) under index t + l - 1)
+        and launched by flush_forward(): P + 5 launches of up to 6 independent cells instead of 6 P.  The head layer of a
+        pass still launches at once (it needs only its own previous state).  Anything that reads the cells' outputs through
+        this library flushes first (_lib.call); code that reads them through torch must call flush_forward() itself."""
+        if not on:
+            self.flush_forward()
+        self._defer_on = bool(on)
+
+    def flush_forward(self):
+        if self.__dict__.get("_defer_open"):
+            self._defer_open = False
+            _lib._defer_flush = None
+            _lib.call("evf_fwd_defer_flush")
+
+    def _defer_begin(self):
+        rc = _lib.load().evf_fwd_defer_begin()
+        if rc != 0:
+            raise _lib.EvflowError("evf_fwd_defer_begin: another recording is open (one engine at a time)")
+        self._defer_open, self._defer_t = True, 0
+        _lib._defer_flush = self.flush_forward
+
     def _flow_out(self, B, H, W, dev):
         slot, self._flow_slot = self._flow_slot, None
         return slot if slot is not None else _f32((B, 2, H, W), dev)
@@ -356,7 +380,16 @@ class FireNetEngine:
                 for tg in target)
             if not ok:  # one-pass window starting from the target itself, or another geometry: fresh tensors
                 target = None
+        defer = (record and self.__dict__.get("_defer_on", False) and self.precision == "bf16x3" and self.kind == "lif"
+                 and PRED_FUSED)
+        if defer:
+            if self.__dict__.get("_defer_open") and self._defer_t + len(self.cells) - 2 >= 96:
+                self.flush_forward()
+            if not self.__dict__.get("_defer_open"):
+                self._defer_begin()
         for i, c in enumerate(self.cells):
+            if defer and i > 0 and _lib.load().evf_fwd_defer_slot(self._defer_t + i - 1) != 0:
+                raise _lib.EvflowError("evf_fwd_defer_slot failed")
             st = states[i]
             v_prev, z_prev, zT_prev = st[:3] if st is not None else (None, None, None)
             plif = self.kind == "plif"
@@ -413,6 +446,8 @@ class FireNetEngine:
             flow = self._flow_out(B, H, W, dev)
             _lib.call("evf_pred_fwd", _lib.ptr(in_bits), _lib.ptr(self._flat["pred.w"]), _lib.ptr(self._flat["pred.b"]), B, H, W,
                       _lib.ptr(flow))
+        if defer:
+            self._defer_t += 1
         tape = {"x_in": x_in, "layers": layers, "flow": flow} if record else None
         return flow, tape, new_states
 

@@ -132,6 +132,15 @@ class FireNet(BaseModel):
         if self._engine is not None:
             self._engine._final_hint = True
 
+    def defer_forward(self, on=True):
+        """Fused path only: launch the window's hidden cells diagonal by diagonal (FireNetEngine.defer_forward)."""
+        if self._fused():
+            self._eng().defer_forward(on)
+
+    def flush_forward(self):
+        if self._engine is not None:
+            self._engine.flush_forward()
+
     # -- state API (models/model.py:203-227) -------------------------------
     @property
     def states(self):

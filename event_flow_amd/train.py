@@ -8,6 +8,8 @@ per optimizer step instead of per-tensor torch kernels): every nn.Parameter
 becomes a view into `flat_param`, every `.grad` a view into `flat_grad`.
 """
 
+import os
+
 import torch
 
 from . import _lib
@@ -92,6 +94,8 @@ class FlatAdam:
         return float(self.norm_ws[0].sqrt())
 
 
+# EVF_DEFER_FWD=0: every (pass, layer) cell of the fused FireNets as its own launch (the A/B switch of the diagonal launches)
+DEFER_FORWARD = os.environ.get("EVF_DEFER_FWD", "1") != "0"
 _UNIT = {}
 
 
@@ -106,11 +110,18 @@ def window_backward(model, loss_function, optimizer, passes, dp=None):
     """First half of a window: the passes, the loss and its backward (train_flow.py:129-154).
     Leaves this rank's gradient in the optimizer's flat buffer and, with `dp`, the
     local loss in the buffer's tail, ready for the all-reduce."""
-    for k, d in enumerate(passes):
-        if k == len(passes) - 1 and hasattr(model, "mark_last_pass"):
-            model.mark_last_pass()  # lets a graph-captured step hand its final state over without a copy
-        x = model(d["event_voxel"], d["event_cnt"])
-        loss_function.event_flow_association(x["flow"], d["event_list"], d["event_list_pol_mask"], d["event_mask"])
+    defer = DEFER_FORWARD and hasattr(model, "defer_forward")
+    if defer:
+        model.defer_forward(True)  # fused FireNets: the window's hidden cells run diagonal by diagonal (engine.defer_forward)
+    try:
+        for k, d in enumerate(passes):
+            if k == len(passes) - 1 and hasattr(model, "mark_last_pass"):
+                model.mark_last_pass()  # lets a graph-captured step hand its final state over without a copy
+            x = model(d["event_voxel"], d["event_cnt"])
+            loss_function.event_flow_association(x["flow"], d["event_list"], d["event_list_pol_mask"], d["event_mask"])
+    finally:
+        if defer:
+            model.defer_forward(False)  # (launches what was recorded)
     if loss_function.overwrite_intermediate:
         loss_function.overwrite_intermediate_flow(x["flow"])
     loss = loss_function()

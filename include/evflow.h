@@ -199,6 +199,18 @@ int evf_conv_lif_fwd_b3_pred(const uint32_t* x, const void* wb_ff, const void* w
                              const float* thresh, const float* v_prev, const uint32_t* z_prev, int B, int H, int W,
                              int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out,
                              const float* pred_w, const float* pred_b, float* flow, void* stream);
+/* Several (pass, layer) cells of one window in ONE launch.  The reference's loop (train_flow.py:98-139) runs the stack
+ * pass by pass (models/model.py:255-265); cell (t, l) needs cells (t, l-1) and (t-1, l) only, so all cells with equal
+ * t + l are independent.  Between evf_fwd_defer_begin() and evf_fwd_defer_flush(), evf_conv_lif_fwd_b3[_pred] RECORD their
+ * launch under the index last given to evf_fwd_defer_slot() (0 .. 95) instead of launching; the flush launches the recorded
+ * cells, one kernel per non-empty index in increasing order (blockIdx.z = cell x sample; same kernel body, bit-identical
+ * results), and ends the recording.  The caller guarantees that cells under one index are independent, that a cell's
+ * operands come from lower indices or from launches made before, and that nothing reads a cell's outputs before the
+ * flush.  Process-wide recorder (one at a time); evf_fwd_defer_pending() = cells recorded and not yet launched. */
+int evf_fwd_defer_begin(void);
+int evf_fwd_defer_slot(int index);
+int evf_fwd_defer_pending(void);
+int evf_fwd_defer_flush(void* stream);
 
 /* Neuron backward (autograd of :103-126 / :523-551 with the surrogate of
  * spiking_util.py:88-93).  Per element:

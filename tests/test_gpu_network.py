@@ -761,3 +761,54 @@ def test_stream_replicas_step_equals_the_unsplit_step():
             d = np.abs(p1[k] - p0[k])
             assert d.max() <= 2 * 2e-4 + 1e-6, k
             assert np.mean(d > 2e-5) <= 0.02, (k, np.mean(d > 2e-5))
+
+
+def test_diagonal_launches_equal_cell_by_cell_launches(monkeypatch):
+    """train.window_backward records the hidden cells of a window and launches them diagonal by diagonal (k_fwd_diag:
+    cells (t, l) with equal t + l in ONE launch, engine.defer_forward).  Same kernel body: the flow of every pass and the
+    recurrent state after the window must be BIT-identical to the cell-by-cell launches; a training step (whose backward
+    sums with float atomics, i.e. is reproducible to rounding only) must agree like two cell-by-cell runs do."""
+    from event_flow_amd import train as htrain
+
+    g = load_golden("g7_liffirenet_train")
+    H, W = passes_from_golden(g)[0]["event_cnt"].shape[2:]
+
+    def forward_only(defer):
+        model = build_from_golden(g)
+        model.train()
+        model.defer_forward(defer)
+        flows = [model(d["event_voxel"], d["event_cnt"])["flow"][0] for d in passes_from_golden(g)]
+        if defer:
+            assert _lib.load().evf_fwd_defer_pending() == 6 * len(flows)  # nothing but the head layers has run yet
+        model.defer_forward(False)
+        assert _lib.load().evf_fwd_defer_pending() == 0
+        return [N(f).copy() for f in flows], [N(s).copy() for s in model.states]
+
+    (f0, s0), (f1, s1) = forward_only(False), forward_only(True)
+    for a, b in zip(f0 + s0, f1 + s1):
+        assert np.array_equal(a, b)
+
+    def run(defer):
+        monkeypatch.setattr(htrain, "DEFER_FORWARD", defer)
+        model = build_from_golden(g)
+        model.train()
+        lossf = hloss.EventWarping(loss_cfg(H, W), DEV)
+        opt = FlatAdam(model, lr=2e-4, clip=100.0)
+        opt.zero_grad()
+        out = []
+        for w in range(2):
+            loss = htrain.train_window(model, lossf, opt, passes_from_golden(g))
+            torch.cuda.synchronize()
+            out.append((float(loss), opt.grad_norm(), {k: N(v).copy() for k, v in model.state_dict().items()}))
+        return out
+
+    ref, got = run(False), run(True)
+    assert _lib.load().evf_fwd_defer_pending() == 0
+    assert got[0][0] == ref[0][0]  # first window: same weights, same forward -> the same loss, bit for bit
+    for (l0, n0, p0), (l1, n1, p1) in zip(ref, got):
+        np.testing.assert_allclose(l1, l0, rtol=1e-5)
+        np.testing.assert_allclose(n1, n0, rtol=1e-4)
+        for k in p0:
+            d = np.abs(p1[k] - p0[k])
+            assert d.max() <= 2 * 2e-4 + 1e-6, k
+            assert np.mean(d > 2e-5) <= 0.02, (k, np.mean(d > 2e-5))
