@@ -82,6 +82,7 @@ extern "C" int evf_debug_fb_stamps(void* dst) { return evf_hip(hipMemcpyFromSymb
 
 struct FbStage {
   float4 gz, gv, vo, vp;
+  float4 gz2;            // the second part of dL/d(spikes) (from the cell's own recurrent input gradient, one pass later)
   float f0, f1, q0, q1;  // TOP: flow and dL/dflow of the pixel (x, y components)
   uint32_t zo;           // TOP: the layer's own output spikes (input of the prediction head)
   uint32_t zw;
@@ -106,7 +107,8 @@ struct FbTop {
 // interleaved across them, and the loop body holds the code of all four surrogates (805 VALU instructions).
 template <bool REC, bool TOP, bool FAST>
 __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
-    const float4* __restrict__ g_z_out, const float4* __restrict__ g_v_out, const float4* __restrict__ v_out,
+    const float4* __restrict__ g_z_out, const float4* __restrict__ g_z_out2, const float4* __restrict__ g_v_out,
+    const float4* __restrict__ v_out,
     const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev, const uint32_t* __restrict__ xT,
     const uint32_t* __restrict__ zT, const float* __restrict__ leak, const float* __restrict__ thresh, int B, int H,
     int W, int nchunk, long nunits, int hard_reset_rt, int surrogate_rt, float width, int accumulate,
@@ -181,6 +183,8 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
   // compiler can keep them in flight behind counted s_waitcnt instead of draining vmcnt(0)
   // at every divergent branch.
   const float4* pgz = g_z_out ? g_z_out : v_out;
+  const float4* pgz2 = g_z_out2 ? g_z_out2 : v_out;  // (not under the prediction head)
+  const bool has_gz2 = !TOP && g_z_out2 != nullptr;
   const float4* pgv = g_v_out ? g_v_out : v_out;
   const float4* pvp = v_prev ? v_prev : v_out;
   const uint32_t* pzw = z_prev ? z_prev : xT;
@@ -203,6 +207,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
       s.zo = top.z_out[pix0 + pc];
     } else {
       s.gz = pgz[ge];
+      s.gz2 = pgz2[ge];
     }
     s.gv = pgv[ge];
     s.vp = pvp[ge];
@@ -230,6 +235,8 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     const float4 gz4 = TOP ? make_float4(gp0 * pwa[0] + gp1 * pwb[0], gp0 * pwa[1] + gp1 * pwb[1], gp0 * pwa[2] + gp1 * pwb[2],
                                          gp0 * pwa[3] + gp1 * pwb[3])
                            : (has_gz ? s.gz : z4);
+    float4 gzb4 = z4;
+    if (!TOP) gzb4 = has_gz2 ? s.gz2 : z4;
     const float4 gv4 = has_gv ? s.gv : z4, vp4 = has_vp ? s.vp : z4;
     if (TOP && ok) {
       const uint32_t zo = s.zo >> (4 * cg);
@@ -241,7 +248,10 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
       }
       if (cg == 0) dba += gp0, dbb += gp1;
     }
-    const float vo[4] = {s.vo.x, s.vo.y, s.vo.z, s.vo.w}, gz[4] = {gz4.x, gz4.y, gz4.z, gz4.w};
+    const float vo[4] = {s.vo.x, s.vo.y, s.vo.z, s.vo.w};
+    // (the two parts in the order the accumulating input gradient added them: feed-forward part + recurrent part)
+    const float gz[4] = {!TOP ? gz4.x + gzb4.x : gz4.x, !TOP ? gz4.y + gzb4.y : gz4.y, !TOP ? gz4.z + gzb4.z : gz4.z,
+                         !TOP ? gz4.w + gzb4.w : gz4.w};
     const float gvo[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, vp[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
     const uint32_t zw = (has_zw ? s.zw : 0u) >> (4 * cg);
     float gc[4], gp[4];
@@ -512,13 +522,13 @@ static long fb_units(int B, int H, int W) { return (long)B * H * ((W + FB_CW - 1
 
 extern "C" int evf_lif_bwd_wgrad_slabs(int B, int H, int W) { return evf_cdiv(fb_units(B, H, W), FB_UNITS); }
 
-static int fb_launch(const float* g_z_out, const FbTop* topp, const float* g_v_out, const float* v_out, const float* v_prev,
+static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* topp, const float* g_v_out, const float* v_out, const float* v_prev,
                      const uint32_t* z_prev, const uint32_t* xT, const uint32_t* zT_prev, const float* leak,
                      const float* thresh, int B, int H, int W, int hard_reset, int surrogate, float act_width,
                      float* g_cur, void* g_split, float* g_v_prev, float* g_leak, float* g_thresh, float* slab_ff,
                      float* slab_rec, int accumulate, void* stream) {
   if (!v_out || !xT || !leak || !thresh || (!g_cur && !g_split) || !g_v_prev || !g_leak || !g_thresh || !slab_ff || B <= 0 || H <= 0 ||
-      W <= 0 || ((zT_prev != nullptr) != (slab_rec != nullptr)) || (topp && (g_z_out || zT_prev)))
+      W <= 0 || ((zT_prev != nullptr) != (slab_rec != nullptr)) || (topp && (g_z_out || zT_prev)) || (topp && g_z_out2))
     return EVF_EINVAL;
   const int row_ld = accumulate >> 8;  // pitch of the per-block parameter-gradient rows (0: dense outputs, atomics)
   accumulate &= 1;
@@ -537,7 +547,7 @@ static int fb_launch(const float* g_z_out, const FbTop* topp, const float* g_v_o
       attr[slot] = true;                                                                                                  \
     }                                                                                                                     \
     hipLaunchKernelGGL((k_lif_bwd_wgrad<REC_, TOP_, FAST_>), grid, block, FB_LDS, st, (const float4*)g_z_out,             \
-                       (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev, z_prev, xT, zT_prev, leak,    \
+                       (const float4*)g_z_out2, (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev, z_prev, xT, zT_prev, leak,    \
                        thresh, B, H, W, nchunk, nunits, hard_reset, surrogate, act_width, accumulate, (float4*)g_cur,     \
                        (uint2*)g_split, (float4*)g_v_prev, g_leak, g_thresh, slab_ff, slab_rec, top, row_ld);             \
   } while (0)
@@ -564,8 +574,21 @@ extern "C" int evf_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, con
                                  const float* thresh, int B, int H, int W, int hard_reset, int surrogate,
                                  float act_width, float* g_cur, void* g_split, float* g_v_prev, float* g_leak,
                                  float* g_thresh, float* slab_ff, float* slab_rec, int accumulate, void* stream) {
-  return fb_launch(g_z_out, nullptr, g_v_out, v_out, v_prev, z_prev, xT, zT_prev, leak, thresh, B, H, W, hard_reset, surrogate,
-                   act_width, g_cur, g_split, g_v_prev, g_leak, g_thresh, slab_ff, slab_rec, accumulate, stream);
+  return fb_launch(g_z_out, nullptr, nullptr, g_v_out, v_out, v_prev, z_prev, xT, zT_prev, leak, thresh, B, H, W, hard_reset,
+                   surrogate, act_width, g_cur, g_split, g_v_prev, g_leak, g_thresh, slab_ff, slab_rec, accumulate, stream);
+}
+
+// The same with dL/d(output spikes) in TWO parts, g_z_out + g_z_out2 (either may be NULL): the part from
+// the layer above (this pass) and the part from the cell's own recurrent input gradient (one pass later) stay in separate
+// buffers and meet here -- the order of those two launches then is free (evf_bwd_defer_*), and the input gradient of the layer
+// above no longer reads and rewrites the other part (its accumulating form).
+extern "C" int evf_lif_bwd_wgrad2(const float* g_z_out, const float* g_z_out2, const float* g_v_out, const float* v_out,
+                                  const float* v_prev, const uint32_t* z_prev, const uint32_t* xT, const uint32_t* zT_prev,
+                                  const float* leak, const float* thresh, int B, int H, int W, int hard_reset, int surrogate,
+                                  float act_width, float* g_cur, void* g_split, float* g_v_prev, float* g_leak,
+                                  float* g_thresh, float* slab_ff, float* slab_rec, int accumulate, void* stream) {
+  return fb_launch(g_z_out, g_z_out2, nullptr, g_v_out, v_out, v_prev, z_prev, xT, zT_prev, leak, thresh, B, H, W, hard_reset,
+                   surrogate, act_width, g_cur, g_split, g_v_prev, g_leak, g_thresh, slab_ff, slab_rec, accumulate, stream);
 }
 
 // The non-recurrent layer directly under the prediction head, with the head's backward (evf_pred_bwd) inside:
@@ -579,6 +602,6 @@ extern "C" int evf_lif_bwd_wgrad_top(const float* flow, const float* g_flow, con
                                      float* g_thresh, float* slab_ff, int accumulate, void* stream) {
   if (!flow || !g_flow || !pred_w || !z_out || !d_pred_w || !d_pred_b) return EVF_EINVAL;
   const FbTop top{flow, g_flow, pred_w, z_out, d_pred_w, d_pred_b};
-  return fb_launch(nullptr, &top, g_v_out, v_out, v_prev, z_prev, xT, nullptr, leak, thresh, B, H, W, hard_reset, surrogate,
+  return fb_launch(nullptr, nullptr, &top, g_v_out, v_out, v_prev, z_prev, xT, nullptr, leak, thresh, B, H, W, hard_reset, surrogate,
                    act_width, g_cur, g_split, g_v_prev, g_leak, g_thresh, slab_ff, nullptr, accumulate, stream);
 }

@@ -65,6 +65,8 @@ class _Window:
         self.small, self.small_persistent = eng._take_small(dev)
         # per-block partial sums of the per-channel gradients [blocks][small_size] (summed into `small` by _finalize)
         self.rows = eng._take_rows(B, H, W, dev)
+        n_ = len(eng.cells)
+        self.gzr, self.gzr_has = [None] * n_, [False] * n_  # recurrent part of dL/d(spikes), separate from gz (see _backward_pass)
         self.slab_init = {}
         self.token = eng._token(dev)  # (a leaf whose value is never read: only its autograd edge chains the passes)
         self.n_passes = 0
@@ -495,10 +497,11 @@ class FireNetEngine:
             in_bits, v_prev, z_prev, v_out, _, in_bitsT, zT_prev, pt_prev, pt_out, P_sav = layers[i]
             plif = self.kind == "plif"
             g_z = win.gz[i] if win.gz_has[i] else None
+            g_z2 = win.gzr[i] if win.gzr_has[i] else None  # from the cell's own recurrent input gradient (pass t + 1)
             g_v = win.gv[i]
-            win.gz_has[i] = False
+            win.gz_has[i] = win.gzr_has[i] = False
             top = top_fused and i == n - 1
-            if g_z is None and g_v is None and not top:
+            if g_z is None and g_z2 is None and g_v is None and not top:
                 continue  # no gradient reaches this layer at this pass
             use_rec = c.recurrent and z_prev is not None
             gv_out = win.buf(win.gv, i)
@@ -521,7 +524,8 @@ class FireNetEngine:
                               _lib.ptr(win.g_cur) if (plif or F32_DGRAD) else None, _lib.ptr(win.g_split), _lib.ptr(gv_out),
                               _lib.ptr(leak_r), _lib.ptr(thr_r), _lib.ptr(self._slab(kf, nsl, dev)), acc_flag | (row_ld << 8))
                 else:
-                    _lib.call("evf_lif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
+                    _lib.call("evf_lif_bwd_wgrad2", _lib.ptr(g_z), _lib.ptr(g_z2), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev),
+                          _lib.ptr(z_prev),
                           _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None, _lib.ptr(self._flat[f"{i}.leak"]),
                           _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
                           self._act_width(i), _lib.ptr(win.g_cur) if (plif or F32_DGRAD) else None, _lib.ptr(win.g_split),
@@ -584,11 +588,17 @@ class FireNetEngine:
                 if self.precision == "bf16x3":
                     dg, gsrc = ("evf_conv_dgrad_b3_f32", win.g_cur) if F32_DGRAD else ("evf_conv_dgrad_b3", win.g_split)
                     if rec_grad and F32_DGRAD and PAIR_DGRAD:  # both input gradients of the recurrent cell in one launch
-                        gb = win.buf(win.gz, i)
+                        # the recurrent one goes to its OWN buffer (gzr): the cell's backward of the previous pass adds the
+                        # two parts itself (evf_lif_bwd_wgrad2), so the input gradient of the layer above needs no
+                        # accumulating form there, and those two launches may come in either order
+                        gb = win.buf(win.gzr, i) if not plif else win.buf(win.gz, i)
                         _lib.call("evf_conv_dgrad_b3_f32_pair", _lib.ptr(gsrc), _lib.ptr(self._packed[(i, "ff", "b3t")]),
                                   _lib.ptr(ga), acc_a, _lib.ptr(self._packed[(i, "rec", "b3t")]), _lib.ptr(gb), B, H, W,
                                   _lib.ptr(win.gP) if plif else None, _lib.ptr(in_bits) if plif else None)
-                        win.gz_has[i] = True
+                        if plif:
+                            win.gz_has[i] = True
+                        else:
+                            win.gzr_has[i] = True
                     else:
                         _lib.call(dg, _lib.ptr(gsrc), _lib.ptr(self._packed[(i, "ff", "b3t")]), _lib.ptr(ga),
                                   acc_a, B, H, W, _lib.ptr(win.gP) if plif else None, _lib.ptr(in_bits) if plif else None)

@@ -239,6 +239,17 @@ int evf_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const float* v
                       int hard_reset, int surrogate, float act_width,
                       float* g_cur, void* g_split, float* g_v_prev, float* g_leak, float* g_thresh,
                       float* slab_ff, float* slab_rec, int accumulate, void* stream);
+/* The same with dL/d(output spikes) in two parts, g_z_out + g_z_out2 (either may be NULL): the part from the
+ * layer above (this pass) and the part from the cell's own recurrent input gradient (one pass later, autograd of
+ * spiking_submodules.py:523-551) stay in separate buffers and are added here, in that order -- what the accumulating form of
+ * evf_conv_dgrad_b3_f32 did by reading and rewriting one buffer. */
+int evf_lif_bwd_wgrad2(const float* g_z_out, const float* g_z_out2, const float* g_v_out, const float* v_out,
+                       const float* v_prev, const uint32_t* z_prev,
+                       const uint32_t* xT, const uint32_t* zT_prev,
+                       const float* leak, const float* thresh, int B, int H, int W,
+                       int hard_reset, int surrogate, float act_width,
+                       float* g_cur, void* g_split, float* g_v_prev, float* g_leak, float* g_thresh,
+                       float* slab_ff, float* slab_rec, int accumulate, void* stream);
 /* The same for the non-recurrent layer directly under the prediction head (models/model.py:197-199, :265), with the
  * head's backward (evf_pred_bwd) inside: flow / g_flow [B,2,H,W], pred_w [2][32], z_out [B,H,W] = this layer's output
  * spikes; d_pred_w [2][32] and d_pred_b [2] are accumulated.  The layer's dL/d(spikes) rows are formed in registers. */
