@@ -273,7 +273,8 @@ _KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3_lds<false, false, false, fal
               "evf_conv_dgrad_b3_f32_pair/acc": "k_conv_dgrad_b3_lds<true, true, false, true>",
               "evf_conv_lif_fwd_b3_pred/ff": "k_conv_lif_fwd_b3<false, false>",
               "evf_lif_bwd_wgrad/ff": "k_lif_bwd_wgrad<false, false, true>", "evf_lif_bwd_wgrad_top": "k_lif_bwd_wgrad<false, true, true>",
-              "evf_lif_bwd_wgrad/rec": "k_lif_bwd_wgrad<true, false, true>", "evf_conv_lif_fwd_b3/ff": "k_conv_lif_fwd_b3<false, false>",
+              "evf_lif_bwd_wgrad/rec": "k_lif_bwd_wgrad<true, false, true>", "evf_lif_bwd_wgrad/rec+2": "k_lif_bwd_wgrad<true, false, true>",
+              "evf_lif_bwd_wgrad/ff+2": "k_lif_bwd_wgrad<false, false, true>", "evf_conv_lif_fwd_b3/ff": "k_conv_lif_fwd_b3<false, false>",
               "evf_conv_lif_fwd_b3/rec": "k_conv_lif_fwd_b3<true, false>", "evf_head_lif_fwd": "k_head_lif_fwd<1>",
               "evf_head_lif_bwd_wgrad": "k_head_bwd_mfma<true>", "evf_conv_dgrad/one": "k_conv_dgrad<false>",
               "evf_conv_dgrad/two": "k_conv_dgrad<true>", "evf_conv_lif_fwd/ff": "k_conv_lif_fwd<false>",
@@ -568,7 +569,7 @@ def main():
         for m in (reps.models if reps is not None else [model]):
             m.use_static_states(True)  # recurrent state must live at fixed addresses across replays
     pool = make_windows(dp.rank, 2, dev, slices=nstream)
-    names = ["evf_conv_lif_fwd", "evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_conv_dgrad", "evf_conv_dgrad_b3",
+    names = ["evf_lif_bwd_wgrad2", "evf_conv_lif_fwd", "evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_conv_dgrad", "evf_conv_dgrad_b3",
              "evf_conv_dgrad_b3_f32", "evf_conv_dgrad_b3_f32_pair", "evf_conv_wgrad_bits", "evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad_top",
              "evf_lif_bwd", "evf_head_lif_bwd_wgrad", "evf_head_lif_fwd", "evf_head_wgrad", "evf_pred_bwd", "evf_reduce_slabs", "evf_reduce_slabs_multi", "evf_cm_loss_fwd",
              "evf_cm_loss_bwd", "evf_conv_plif_fwd_b3", "evf_head_plif_fwd", "evf_plif_trace_bwd", "evf_encode_events", "evf_clip_adam_step"]
@@ -633,6 +634,9 @@ def main():
         for i in range(prof_steps):
             run_step(model, lossf, opt, dp, pool[i % len(pool)], reps)
         prof = _lib.profile_stop()
+    # evf_lif_bwd_wgrad2 = evf_lif_bwd_wgrad with dL/d(spikes) in two parts: one kernel, reported under the one name
+    # (variant "+2": the second part present, +128 B/px)
+    prof = {(("evf_lif_bwd_wgrad",) + k[1:] if k[0] == "evf_lif_bwd_wgrad2" else k): v for k, v in prof.items()}
     event_overhead_us = _lib.last_event_overhead_ms * 1e3
     elapsed = dp.max_over_ranks(elapsed)
     loss_val = float(loss)
@@ -657,6 +661,7 @@ def main():
             ("evf_conv_wgrad_bits", ""): (CONV_FLOP * npix, 132 * npix),
             # g_z, g_v, v', v in; g_cur (fp32, split later by the dgrad) + g_v_prev out; spike words / planes
             ("evf_lif_bwd_wgrad", "ff"): (CONV_FLOP * npix, 776 * npix), ("evf_lif_bwd_wgrad", "rec"): (2 * CONV_FLOP * npix, 780 * npix),
+            ("evf_lif_bwd_wgrad", "ff+2"): (CONV_FLOP * npix, 904 * npix), ("evf_lif_bwd_wgrad", "rec+2"): (2 * CONV_FLOP * npix, 908 * npix),
             ("evf_lif_bwd", ""): (0, 772 * npix), ("evf_head_lif_bwd_wgrad", ""): (2 * 18 * 32 * npix, 652 * npix),
             ("evf_head_lif_fwd", ""): (2 * 18 * 32 * npix, 272 * npix),
         }

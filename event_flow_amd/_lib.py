@@ -185,7 +185,7 @@ _PROF_VARIANT = {
     "evf_conv_lif_fwd_b3_pred": lambda a: "rec" if a[2] is not None else "ff",
     "evf_conv_dgrad": lambda a: "two" if a[4] is not None else "one",
     "evf_lif_bwd_wgrad": lambda a: "rec" if a[6] is not None else "ff",
-    "evf_lif_bwd_wgrad2": lambda a: "rec" if a[7] is not None else "ff",
+    "evf_lif_bwd_wgrad2": lambda a: ("rec" if a[7] is not None else "ff") + ("+2" if a[1] is not None else ""),
     "evf_conv_dgrad_b3_f32": lambda a: "acc" if a[3] else "",
     "evf_conv_dgrad_b3_f32_pair": lambda a: "acc" if a[3] else "",
     # general convs: the shape is the variant ("B,H,W,Cin,Cout,k,stride"): bench.py derives the FLOP of every launch from it
