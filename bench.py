@@ -277,7 +277,8 @@ _KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3_lds<false, false, false, fal
               "evf_lif_bwd_wgrad/ff+2": "k_lif_bwd_wgrad<false, false, true>", "evf_conv_lif_fwd_b3/ff": "k_conv_lif_fwd_b3<false, false>",
               "evf_conv_lif_fwd_b3/rec": "k_conv_lif_fwd_b3<true, false>", "evf_head_lif_fwd": "k_head_lif_fwd<1>",
               "evf_head_lif_bwd_wgrad": "k_head_bwd_mfma<true>", "evf_conv_dgrad/one": "k_conv_dgrad<false>",
-              "evf_conv_dgrad/two": "k_conv_dgrad<true>", "evf_conv_lif_fwd/ff": "k_conv_lif_fwd<false>",
+              "evf_conv_dgrad/two": "k_conv_dgrad<true>", "k_fwd_diag": "k_fwd_diag", "k_bwd_diag": "k_bwd_diag",
+              "k_dgrad_diag": "k_dgrad_diag", "evf_conv_lif_fwd/ff": "k_conv_lif_fwd<false>",
               "evf_conv_lif_fwd/rec": "k_conv_lif_fwd<true>", "evf_conv_wgrad_bits": "k_conv_wgrad_bits"}
 
 
@@ -578,8 +579,12 @@ def main():
     # diagonal launches (train.window_backward -> engine.defer_forward): the hidden forward cells of a window are recorded and
     # launched by ONE evf_fwd_defer_flush call (P + 5 k_fwd_diag launches); the per-cell entry points then launch nothing
     diag_fwd = _train.DEFER_FORWARD and getattr(model, "precision", "") == "bf16x3" and wl["model"] == "LIFFireNet"
-    if diag_fwd:
-        names = [n for n in names if n not in ("evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred")] + ["evf_fwd_defer_flush"]
+    diag_bwd = _train.DEFER_BACKWARD and getattr(model, "precision", "") == "bf16x3" and wl["model"] == "LIFFireNet"
+    if diag_fwd:  # (these entry points then only record: timed inside the flush, evf_defer_profile)
+        names = [n for n in names if n not in ("evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred")]
+    if diag_bwd:
+        names = [n for n in names if n not in ("evf_lif_bwd_wgrad2", "evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad_top", "evf_conv_dgrad_b3_f32",
+                                               "evf_conv_dgrad_b3_f32_pair", "evf_head_lif_bwd_wgrad")]
 
     # Everything runs on one side stream: warm-up (eager), then one whole training step
     # per input window is captured into a hipGraph on that same stream (autograd's
@@ -613,6 +618,7 @@ def main():
     torch.cuda.synchronize()
     if graphs is None:
         _lib.profile_start(names)
+        _lib.load().evf_defer_profile(1)
     t0 = time.perf_counter()
     loss = None
     for i in range(args.steps):
@@ -631,9 +637,19 @@ def main():
         # kernels with HIP events over a few eager steps of the same workload
         prof_steps = 3
         _lib.profile_start(names)
+        _lib.load().evf_defer_profile(1)
         for i in range(prof_steps):
             run_step(model, lossf, opt, dp, pool[i % len(pool)], reps)
         prof = _lib.profile_stop()
+    # the diagonal launches, timed per launch inside the flushes (HIP events in the library, same bracket overhead)
+    import ctypes as _ct
+
+    _ms, _cnt = (_ct.c_float * 4)(), (_ct.c_int * 4)()
+    if _lib.load().evf_defer_profile_read(_ms, _cnt) != 0:
+        raise RuntimeError("evf_defer_profile_read failed")
+    for k, nm in enumerate([("k_fwd_diag", ""), ("k_bwd_diag", ""), ("k_dgrad_diag", ""), ("evf_head_lif_bwd_wgrad", "")]):
+        if _cnt[k]:
+            prof[nm] = [max(_ms[k] / _cnt[k] - _lib.last_event_overhead_ms, 0.0)] * _cnt[k]
     # evf_lif_bwd_wgrad2 = evf_lif_bwd_wgrad with dL/d(spikes) in two parts: one kernel, reported under the one name
     # (variant "+2": the second part present, +128 B/px)
     prof = {(("evf_lif_bwd_wgrad",) + k[1:] if k[0] == "evf_lif_bwd_wgrad2" else k): v for k, v in prof.items()}
@@ -679,11 +695,23 @@ def main():
         # g_cur, g_pt carry, pt_prev, pt_out in; g_pt_prev out (fp32 [npix][32]); P, g_P_raw, g_P_in [npix]
         model[("evf_plif_trace_bwd", "")] = (0, 652 * npix)
         hbm_bound |= {"evf_conv_plif_fwd_b3", "evf_head_plif_fwd", "evf_plif_trace_bwd"}
-        if diag_fwd:  # one bracket = the window's PASSES + 5 k_fwd_diag launches: 6 hidden cells per pass (8 contractions: two
-            # recurrent cells), 272 B/px each, 280 under the prediction head
-            model[("evf_fwd_defer_flush", "")] = (8 * PASSES * CONV_FLOP * npix, PASSES * (5 * 272 + 280) * npix)
-            hbm_bound |= {"evf_fwd_defer_flush"}
-            bf16_terms["evf_fwd_defer_flush"] = 3
+        # diagonal launches: PASSES + 5 launches hold the window's cells; per LAUNCH = the window's total / (PASSES + 5)
+        nl = PASSES + 5
+        if diag_fwd:  # 6 hidden cells per pass (8 contractions: two recurrent cells), 272 B/px each, 280 under the prediction head
+            model[("k_fwd_diag", "")] = (8 * PASSES * CONV_FLOP * npix / nl, PASSES * (5 * 272 + 280) * npix / nl)
+            hbm_bound |= {"k_fwd_diag"}
+            bf16_terms["k_fwd_diag"] = 3
+        if diag_bwd:
+            # fused-backward cells: per pass 3 feed-forward cells (776 B/px), the top one (668), 2 recurrent ones (780; 908 with the
+            # second gradient part: every pass but the last; in the first pass they have no previous state: 904)
+            by_b = (3 * PASSES * 776 + PASSES * 668 + 2 * ((PASSES - 2) * 908 + 780 + 904)) * npix
+            model[("k_bwd_diag", "")] = (8 * PASSES * CONV_FLOP * npix / nl, by_b / nl)
+            # input-gradient cells: per pass 4 with one weight set (256 B/px) and 2 with two (384); all six single in the first pass
+            by_d = ((PASSES - 1) * (4 * 256 + 2 * 384) + 6 * 256) * npix
+            model[("k_dgrad_diag", "")] = ((8 * (PASSES - 1) + 6) * CONV_FLOP * npix / nl, by_d / nl)
+            hbm_bound |= {"k_bwd_diag", "k_dgrad_diag"}
+            bf16_terms["k_bwd_diag"] = 3
+            bf16_terms["k_dgrad_diag"] = 6
         kernels = {}
         step_alg_bytes = 0.0
         for key, ms in prof.items():
@@ -708,13 +736,11 @@ def main():
                 ent["mfma_busy_pct"] = pm["mfma_busy_pct"] if pm else None  # SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE (PMC pass)
                 if not pm:
                     ent["pmc"] = why
-            if key[0] == "evf_fwd_defer_flush":
-                ent["multi_launch"] = PASSES + 5
-                ent["note"] = (f"one call = {PASSES + 5} k_fwd_diag launches (the window's {6 * PASSES} hidden forward cells, diagonal by "
-                               "diagonal: cells (pass, layer) with equal pass + layer are independent); not a single kernel, so "
-                               "not a candidate for `roofline`")
+            if key[0] in ("k_fwd_diag", "k_bwd_diag", "k_dgrad_diag"):
+                ent["note"] = (f"diagonal launches: the window's {6 * PASSES} cells of this kind in {nl} launches of 1..6 independent "
+                               "(pass, layer) cells; mean_us / algorithmic_MB are per LAUNCH (window total / launches)")
             kernels[name] = ent
-        dom_key = max((k for k in prof if k in model and k[0] != "evf_fwd_defer_flush"), key=lambda k: sum(prof[k]))
+        dom_key = max((k for k in prof if k in model), key=lambda k: sum(prof[k]))
         dom = kernels["/".join(k for k in dom_key if k)]
         detail, why_not = _pmc("/".join(k for k in dom_key if k))
         traffic = int(detail["MB_per_launch"] * 1e6) if detail else None  # HBM bytes per launch (PMC), next to ...
@@ -743,6 +769,9 @@ def main():
                        "forward_launches": ("diagonal: the window's hidden forward cells in P + 5 launches (k_fwd_diag, cells "
                                             "(pass, layer) with equal pass + layer together); EVF_DEFER_FWD=0: one launch per cell"
                                             if diag_fwd else "one launch per (pass, layer) cell"),
+                       "backward_launches": ("diagonal: fused-backward cells in P + 5 launches (k_bwd_diag), input-gradient cells in "
+                                             "P + 5 (k_dgrad_diag), head backward P; EVF_DEFER_BWD=0: 13 launches per pass"
+                                             if diag_bwd else "one launch per cell"),
                        "pipelining": (f"each rank's {B_PER_GPU} windows as {nstream} micro-batches of {B_PER_GPU // nstream} on {nstream} HIP "
                                       "streams (replicas sharing the weights; gradients summed before the one optimizer step): "
                                       "kernels[*] / roofline are per LAUNCH of a micro-batch, timed one at a time; in the replayed "

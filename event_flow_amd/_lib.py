@@ -53,6 +53,12 @@ NETWORK_SIGNATURES = {
     "evf_fwd_defer_slot": [I],
     "evf_fwd_defer_pending": [],
     "evf_fwd_defer_flush": [P],
+    "evf_bwd_defer_begin": [],
+    "evf_bwd_defer_slot": [I],
+    "evf_bwd_defer_pending": [],
+    "evf_bwd_defer_flush": [P],
+    "evf_defer_profile": [I],
+    "evf_defer_profile_read": [P, P],
     "evf_lif_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P],
     "evf_lif_bwd_wgrad_slabs": [I, I, I],
     "evf_head_lif_bwd_wgrad_slabs": [I, I, I],
@@ -246,8 +252,12 @@ def profile_stop():
 # the recorded cells write, so it launches them first.  The names below never do: they record or launch a cell themselves,
 # or only produce network inputs.
 _defer_flush = None  # callable set by the engine that opened the recording
-_DEFER_SAFE = {"evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_head_lif_fwd", "evf_fwd_defer_flush",
-               "evf_encode_window", "evf_encode_events", "evf_events_to_image"}
+_DEFER_SAFE_FWD = {"evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_head_lif_fwd", "evf_fwd_defer_flush",
+                   "evf_encode_window", "evf_encode_events", "evf_events_to_image"}
+# backward recording (evf_bwd_defer_*): these record themselves, or flush inside the library when they cannot
+_DEFER_SAFE_BWD = {"evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad2", "evf_lif_bwd_wgrad_top", "evf_conv_dgrad_b3_f32",
+                   "evf_conv_dgrad_b3_f32_pair", "evf_head_lif_bwd_wgrad", "evf_bwd_defer_flush"}
+_DEFER_SAFE = _DEFER_SAFE_FWD
 
 
 def call(name, *args):

@@ -106,7 +106,8 @@ struct FbTop {
 // uniform branches, but branches -- the four channels' dependent chains (v_rcp, the products behind it) cannot be
 // interleaved across them, and the loop body holds the code of all four surrogates (805 VALU instructions).
 template <bool REC, bool TOP, bool FAST>
-__global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
+__device__ __forceinline__ void fb_body(
+    const int bid, const int nblk_,  // this block and the number of blocks of its cell (blockIdx.x / gridDim.x of a one-cell launch)
     const float4* __restrict__ g_z_out, const float4* __restrict__ g_z_out2, const float4* __restrict__ g_v_out,
     const float4* __restrict__ v_out,
     const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev, const uint32_t* __restrict__ xT,
@@ -156,8 +157,8 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
   // resident blocks then stream one contiguous region (consecutive 8 KiB units), which spreads
   // over all HBM channels; a contiguous chunk per block would make every block hit the same
   // few channels at the same time (64 KiB stride between blocks).
-  const int nblk = gridDim.x;
-  const int nu = (int)((nunits - (long)blockIdx.x + nblk - 1) / nblk);
+  const int nblk = nblk_;
+  const int nu = (int)((nunits - (long)bid + nblk - 1) / nblk);
   // Geometry of the block's (<= FB_UNITS) units: lane (k & 7) holds unit k's (sample, row, first column), computed ONCE
   // here; a unit's geometry then is three v_readlane into SGPRs.  As two integer divisions by run-time values per call
   // (v_rcp + fix-up chains with VALU -> SALU hops), four calls per unit, it was the "0.75 k cycles of load issue" of the
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
   static_assert(FB_UNITS <= 8, "geometry table: one lane per unit of the block");
   int g_b, g_y, g_x0;
   {
-    const int u = blockIdx.x + min(lane & 7, nu - 1) * nblk;  // nunits < 2^31
+    const int u = bid + min(lane & 7, nu - 1) * nblk;  // nunits < 2^31
     const int row = u / nchunk;
     g_b = row / H;
     g_y = row - g_b * H;
@@ -374,17 +375,17 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
   // were two dependent HBM round trips (slab read-modify-write, then the row) at the end of every block's life.
   // (REC: the recurrent slab's 16 words per lane stay after the loop -- the kernel is at 222 VGPRs -- but are issued
   //  before the LDS reductions and consumed after them.)
-  const long slab_off = (long)blockIdx.x * (9 * C32 * C32) + wv * (C32 * C32) + i;
+  const long slab_off = (long)bid * (9 * C32 * C32) + wv * (C32 * C32) + i;
   float old[16], prev8[2], prev8z[2] = {0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < 16; ++q) old[q] = slab_ff[slab_off + fb_row(q, lane) * C32];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const long o8 = (long)blockIdx.x * (9 * C32 * C32) + 8 * (C32 * C32) + tid + h * FB_THREADS;
+    const long o8 = (long)bid * (9 * C32 * C32) + 8 * (C32 * C32) + tid + h * FB_THREADS;
     prev8[h] = slab_ff[o8];
     if (REC) prev8z[h] = slab_rec[o8];
   }
-  const size_t row_off = (size_t)blockIdx.x * row_ld;
+  const size_t row_off = (size_t)bid * row_ld;
   const int row_c = tid & 31, row_which = (tid >> 5) & 1;
   const float row_prev = (row_which ? g_thresh : g_leak)[row_off + row_c];          // (read by threads < 64)
   float top_prev = 0.f;
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) v += s_t8[w * (C32 * C32) + e];
-      slab[(long)blockIdx.x * (9 * C32 * C32) + 8 * (C32 * C32) + e] = ((accumulate & 1) ? prev[h] : 0.f) + v;
+      slab[(long)bid * (9 * C32 * C32) + 8 * (C32 * C32) + e] = ((accumulate & 1) ? prev[h] : 0.f) + v;
     }
     __syncthreads();
   };
@@ -517,10 +518,172 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
   FB_SPAN_MARK(1);
 }
 
+template <bool REC, bool TOP, bool FAST>
+__global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
+    const float4* __restrict__ g_z_out, const float4* __restrict__ g_z_out2, const float4* __restrict__ g_v_out,
+    const float4* __restrict__ v_out, const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev,
+    const uint32_t* __restrict__ xT, const uint32_t* __restrict__ zT, const float* __restrict__ leak,
+    const float* __restrict__ thresh, int B, int H, int W, int nchunk, long nunits, int hard_reset_rt, int surrogate_rt,
+    float width, int accumulate, float4* __restrict__ g_cur, uint2* __restrict__ g_split, float4* __restrict__ g_v_prev,
+    float* __restrict__ g_leak, float* __restrict__ g_thresh, float* __restrict__ slab_ff, float* __restrict__ slab_rec,
+    FbTop top, int row_ld) {
+  fb_body<REC, TOP, FAST>(blockIdx.x, gridDim.x, g_z_out, g_z_out2, g_v_out, v_out, v_prev, z_prev, xT, zT, leak, thresh, B, H, W,
+                          nchunk, nunits, hard_reset_rt, surrogate_rt, width, accumulate, g_cur, g_split, g_v_prev, g_leak,
+                          g_thresh, slab_ff, slab_rec, top, row_ld);
+}
+
+// ---- several independent backward cells of a window in ONE launch (see k_fwd_diag in evf_fwd_b3.hip) --------------------
+// The backward of a pass is a chain of 13 steps (fused backward of layer 6, its input gradient, layer 5, ... , head); step
+// s of pass t needs step s - 1 of pass t and step s (+1 for the recurrent input gradient) of pass t + 1: with the index
+// 2 (P - 1 - t) + s all cells under one index are independent AND of one kind (s even: fused backward, s odd: input
+// gradient).  evf_bwd_defer_* record the cells; the flush launches index after index: one k_bwd_diag (this file) or one
+// k_dgrad_diag (evf_dgrad_b3.hip) per index, the head layer's cells as their own launches in between.  Default neuron only
+// (the FAST bodies).  blockIdx.x = cell * nblk + block.
+#define FB_MAX_JOBS 8
+struct FbJob {
+  const float4 *g_z, *g_z2, *g_v, *v_out, *v_prev;
+  const uint32_t *z_prev, *xT, *zT;
+  const float *leak, *thresh;
+  float4* g_cur;
+  float4* g_v_prev;
+  float *g_leak, *g_thresh, *slab_ff, *slab_rec;
+  FbTop top;
+  float width;
+  int accumulate;
+  int kind;  // 0 feed-forward, 1 recurrent, 2 under the prediction head
+  int pad_;
+};
+struct FbJobs {
+  FbJob j[FB_MAX_JOBS];
+};
+__global__ __launch_bounds__(FB_THREADS) void k_bwd_diag(FbJobs jobs, int B, int H, int W, int nchunk, long nunits, int row_ld,
+                                                         int nblk) {
+  const int jb = blockIdx.x / nblk, bid = blockIdx.x - jb * nblk;
+  const FbJob& J = jobs.j[jb];
+  if (J.kind == 1)
+    fb_body<true, false, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
+                               nchunk, nunits, 1, EVF_ARCTAN, J.width, J.accumulate, J.g_cur, nullptr, J.g_v_prev, J.g_leak,
+                               J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld);
+  else if (J.kind == 2)
+    fb_body<false, true, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
+                               nchunk, nunits, 1, EVF_ARCTAN, J.width, J.accumulate, J.g_cur, nullptr, J.g_v_prev, J.g_leak,
+                               J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld);
+  else
+    fb_body<false, false, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
+                                nchunk, nunits, 1, EVF_ARCTAN, J.width, J.accumulate, J.g_cur, nullptr, J.g_v_prev, J.g_leak,
+                                J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld);
+}
+
 static long fb_units(int B, int H, int W) { return (long)B * H * ((W + FB_CW - 1) / FB_CW); }
 #define FB_LDS (FB_R0 + 2 * (2 * 3 * C32 * FB_NW * 4) + 256 * 16 + 2 * 8 * C32 * 4)
 
 extern "C" int evf_lif_bwd_wgrad_slabs(int B, int H, int W) { return evf_cdiv(fb_units(B, H, W), FB_UNITS); }
+
+EvfBwdDefer evf_bwd_defer = {false, 0};
+
+#define EVF_PROF_MAX 1024
+static struct {
+  bool on;
+  int n;
+  int kind[EVF_PROF_MAX];
+  hipEvent_t e0[EVF_PROF_MAX], e1[EVF_PROF_MAX];
+  int made;
+} evf_prof = {false, 0, {0}, {}, {}, 0};
+void evf_prof_mark(int kind, int end, void* stream) {
+  if (!evf_prof.on || (!end && evf_prof.n >= EVF_PROF_MAX)) return;
+  if (!end) {
+    if (evf_prof.n >= evf_prof.made) {
+      (void)hipEventCreate(&evf_prof.e0[evf_prof.made]);
+      (void)hipEventCreate(&evf_prof.e1[evf_prof.made]);
+      ++evf_prof.made;
+    }
+    evf_prof.kind[evf_prof.n] = kind;
+    (void)hipEventRecord(evf_prof.e0[evf_prof.n], EVF_STREAM(stream));
+  } else if (evf_prof.n < EVF_PROF_MAX) {
+    (void)hipEventRecord(evf_prof.e1[evf_prof.n], EVF_STREAM(stream));
+    ++evf_prof.n;
+  }
+}
+// evf_defer_profile(1): time every dispatcher launch of the following flushes; evf_defer_profile_read: device sync, then
+// ms[k] = summed duration and count[k] = number of launches of kind k (0 k_fwd_diag, 1 k_bwd_diag, 2 k_dgrad_diag, 3 head
+// backward) since it was switched on (event-bracket overhead included: ~1.6 us per launch); switches it off.
+extern "C" int evf_defer_profile(int on) {
+  evf_prof.on = on != 0;
+  evf_prof.n = 0;
+  return EVF_OK;
+}
+extern "C" int evf_defer_profile_read(float* ms, int* count) {
+  if (!ms || !count) return EVF_EINVAL;
+  evf_prof.on = false;
+  { const int rc = evf_hip(hipDeviceSynchronize()); if (rc) return rc; }
+  for (int k = 0; k < 4; ++k) ms[k] = 0.f, count[k] = 0;
+  for (int i = 0; i < evf_prof.n; ++i) {
+    float t = 0.f;
+    { const int rc = evf_hip(hipEventElapsedTime(&t, evf_prof.e0[i], evf_prof.e1[i])); if (rc) return rc; }
+    ms[evf_prof.kind[i] & 3] += t;
+    ++count[evf_prof.kind[i] & 3];
+  }
+  evf_prof.n = 0;
+  return EVF_OK;
+}
+static struct {
+  int B, H, W, row_ld;
+  int n[EVF_BWD_DIAGS];
+  FbJob job[EVF_BWD_DIAGS][FB_MAX_JOBS];
+} fb_defer = {0, 0, 0, 0, {0}, {}};
+
+static int fb_defer_launch(int d, void* stream) {
+  const int n = fb_defer.n[d];
+  if (!n) return EVF_OK;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_bwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    attr_set = true;
+  }
+  FbJobs jobs;
+  for (int k = 0; k < FB_MAX_JOBS; ++k) jobs.j[k] = fb_defer.job[d][k < n ? k : 0];
+  const long nunits = fb_units(fb_defer.B, fb_defer.H, fb_defer.W);
+  const int nblk = evf_cdiv(nunits, FB_UNITS), nchunk = (fb_defer.W + FB_CW - 1) / FB_CW;
+  evf_prof_mark(1, 0, stream);
+  hipLaunchKernelGGL(k_bwd_diag, dim3(nblk * n), dim3(FB_THREADS), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
+                     fb_defer.W, nchunk, nunits, fb_defer.row_ld, nblk);
+  evf_prof_mark(1, 1, stream);
+  fb_defer.n[d] = 0;
+  return evf_status();
+}
+
+int evf_bwd_defer_flush_now(void* stream) {
+  for (int d = 0; d < EVF_BWD_DIAGS; ++d) {
+    int rc = fb_defer_launch(d, stream);
+    if (!rc) rc = evf_dg_defer_launch(d, stream);
+    if (!rc) rc = evf_hd_defer_launch(d, stream);
+    if (rc) return rc;
+  }
+  return EVF_OK;
+}
+
+extern "C" int evf_bwd_defer_begin() {
+  if (evf_bwd_defer.active) return EVF_EINVAL;
+  evf_bwd_defer.active = true;
+  evf_bwd_defer.slot = 0;
+  return EVF_OK;
+}
+extern "C" int evf_bwd_defer_slot(int d) {
+  if (!evf_bwd_defer.active || d < 0 || d >= EVF_BWD_DIAGS) return EVF_EINVAL;
+  evf_bwd_defer.slot = d;
+  return EVF_OK;
+}
+extern "C" int evf_bwd_defer_pending() {
+  int n = evf_dg_defer_count() + evf_hd_defer_count();
+  for (int d = 0; d < EVF_BWD_DIAGS; ++d) n += fb_defer.n[d];
+  return n;
+}
+extern "C" int evf_bwd_defer_flush(void* stream) {
+  if (!evf_bwd_defer.active) return EVF_OK;
+  const int rc = evf_bwd_defer_flush_now(stream);
+  evf_bwd_defer.active = false;
+  return rc;
+}
 
 static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* topp, const float* g_v_out, const float* v_out, const float* v_prev,
                      const uint32_t* z_prev, const uint32_t* xT, const uint32_t* zT_prev, const float* leak,
@@ -539,6 +702,21 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
   const FbTop top = topp ? *topp : FbTop{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   static bool attr[12] = {false};
   const bool fast = hard_reset != 0 && surrogate == EVF_ARCTAN;
+  if (evf_bwd_defer.active) {
+    bool any = false;
+    for (int d = 0; d < EVF_BWD_DIAGS && !any; ++d) any = fb_defer.n[d] != 0;
+    const bool same = !any || (fb_defer.B == B && fb_defer.H == H && fb_defer.W == W && fb_defer.row_ld == row_ld);
+    if (fast && g_cur && !g_split && same && fb_defer.n[evf_bwd_defer.slot] < FB_MAX_JOBS) {
+      fb_defer.B = B, fb_defer.H = H, fb_defer.W = W, fb_defer.row_ld = row_ld;
+      FbJob& J = fb_defer.job[evf_bwd_defer.slot][fb_defer.n[evf_bwd_defer.slot]++];
+      J = FbJob{(const float4*)g_z_out, (const float4*)g_z_out2, (const float4*)g_v_out, (const float4*)v_out,
+                (const float4*)v_prev, z_prev, xT, zT_prev, leak, thresh, (float4*)g_cur, (float4*)g_v_prev, g_leak, g_thresh,
+                slab_ff, slab_rec, top, act_width, accumulate, topp ? 2 : (zT_prev ? 1 : 0), 0};
+      return EVF_OK;
+    }
+    const int rc = evf_bwd_defer_flush_now(stream);  // not recordable: everything recorded runs first
+    if (rc) return rc;
+  }
 #define FB_GO(REC_, TOP_, FAST_, slot)                                                                                    \
   do {                                                                                                                    \
     if (!attr[slot]) {                                                                                                    \

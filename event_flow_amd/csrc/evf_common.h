@@ -73,3 +73,24 @@ int evf_wgrad9_b3_launch(const float* x, int ldx, const float* gy, int ldg, floa
 int evf_dgrad_ws_launch(const float* g_cur, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W, const float* g_P,
                         const uint32_t* x_bits, const void* wT2_b3, float* g_x2, int max_blocks, void* stream);
 
+
+// Deferred backward cells (evf_bwd_defer_*, owner: evf_bwd_fused.hip): while `active`, the fused backward, the fp32 input
+// gradient and the head backward of the default-neuron FireNet path RECORD their launch under index `slot`; the flush
+// launches index after index -- the fused-backward cells of an index as one k_bwd_diag, the input-gradient cells as one
+// k_dgrad_diag, head cells one by one.  A launcher that cannot record its call first flushes everything recorded so far
+// (record order is a valid execution order) and then launches as usual.
+#define EVF_BWD_DIAGS 96
+struct EvfBwdDefer {
+  bool active;
+  int slot;
+};
+extern EvfBwdDefer evf_bwd_defer;
+int evf_bwd_defer_flush_now(void* stream);  // launch what is recorded, keep recording
+int evf_dg_defer_launch(int d, void* stream);  // evf_dgrad_b3.hip: launch and clear the cells of index d
+int evf_dg_defer_count();
+int evf_hd_defer_launch(int d, void* stream);  // evf_network.hip (head layer)
+int evf_hd_defer_count();
+// Per-launch timing of the diagonal launches (evf_defer_profile, evf_bwd_fused.hip): HIP events around every dispatcher
+// launch of a flush, by kind (0 k_fwd_diag, 1 k_bwd_diag, 2 k_dgrad_diag, 3 head backward).  No-ops unless switched on
+// (never during a graph capture).
+void evf_prof_mark(int kind, int end, void* stream);

@@ -144,7 +144,8 @@ extern "C" int evf_debug_dg_span(void* dst) { return evf_hip(hipMemcpyFromSymbol
 // PAIR: two weight sets (wt2 / gx2) -- compile time, so that the profiler sees the one- and the two-product launches as
 // different kernels and the tile's product loop has a fixed trip count
 template <bool F32IN, bool ACC, bool PLIF, bool PAIR>
-__global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4* __restrict__ gs, long plane_stride,
+__device__ __forceinline__ void dg_body(const int zz, const int zb,  // first sample of this block and the sample stride
+                                        const uint4* __restrict__ gs, long plane_stride,
                                                                     const uint4* __restrict__ wt, float* __restrict__ gx,
                                                                     int accumulate, int B, int H, int W,
                                                                     const float* __restrict__ gPb,
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
     __builtin_amdgcn_global_load_lds((dl_glb_void*)(wt + u * 64 + lane), (dl_lds_void*)(s_w + u * 64), 16, 0, 0);
 #endif
   int tile_it = 0;
-  for (int b = blockIdx.z; b < B; b += gridDim.z, ++tile_it) {
-    if (b != (int)blockIdx.z) __syncthreads();  // every wave is done reading the previous tile's halo
+  for (int b = zz; b < B; b += zb, ++tile_it) {
+    if (b != zz) __syncthreads();  // every wave is done reading the previous tile's halo
     // ---- everything this tile reads, requested at once
     if (F32IN) {
       const float4* gf = (const float4*)gs;
@@ -275,6 +276,81 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
   DG_SPAN_MARK(1);
 }
 
+template <bool F32IN, bool ACC, bool PLIF, bool PAIR>
+__global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4* __restrict__ gs, long plane_stride,
+                                                                    const uint4* __restrict__ wt, float* __restrict__ gx,
+                                                                    int accumulate, int B, int H, int W,
+                                                                    const float* __restrict__ gPb,
+                                                                    const uint32_t* __restrict__ xbits,
+                                                                    const uint4* __restrict__ wt2,
+                                                                    float* __restrict__ gx2) {
+  dg_body<F32IN, ACC, PLIF, PAIR>(blockIdx.z, gridDim.z, gs, plane_stride, wt, gx, accumulate, B, H, W, gPb, xbits, wt2, gx2);
+}
+
+// Several independent input-gradient cells of a window in one launch (evf_bwd_defer_*, see evf_bwd_fused.hip): the fp32
+// gradient form without accumulation, one or two weight sets per cell.  blockIdx.z = cell * zb + first sample.
+#define DG_MAX_JOBS 8
+struct DgJob {
+  const uint4* gs;
+  const uint4* wt;
+  float* gx;
+  const uint4* wt2;  // NULL: one weight set
+  float* gx2;
+};
+struct DgJobs {
+  DgJob j[DG_MAX_JOBS];
+};
+__global__ __launch_bounds__(DG_ROWS * 64) void k_dgrad_diag(DgJobs jobs, int B, int H, int W, int zb) {
+  const int jb = blockIdx.z / zb, zz = blockIdx.z - jb * zb;
+  const DgJob& J = jobs.j[jb];
+  if (J.wt2)
+    dg_body<true, false, false, true>(zz, zb, J.gs, 0, J.wt, J.gx, 0, B, H, W, nullptr, nullptr, J.wt2, J.gx2);
+  else
+    dg_body<true, false, false, false>(zz, zb, J.gs, 0, J.wt, J.gx, 0, B, H, W, nullptr, nullptr, nullptr, nullptr);
+}
+
+static struct {
+  int B, H, W;
+  int n[EVF_BWD_DIAGS];
+  DgJob job[EVF_BWD_DIAGS][DG_MAX_JOBS];
+} dg_defer = {0, 0, 0, {0}, {}};
+
+static int dg_zb(int B, int H, int W) {  // samples per block column, as in dg_launch
+  const long tiles = (long)evf_cdiv(W, 32) * evf_cdiv(H, DG_ROWS);
+  int zb = B;
+  for (int z = 1; z < B; ++z)
+    if (B % z == 0 && tiles * z <= 256 && tiles * z >= 192) zb = z;
+  return zb;
+}
+static size_t dg_lds_bytes() {
+  return (size_t)(NFRAG * 64 + 3 * DL_HPP * 4) * sizeof(uint4) + (size_t)DG_ROWS * 32 * DG_SP * 4;
+}
+
+int evf_dg_defer_count() {
+  int n = 0;
+  for (int d = 0; d < EVF_BWD_DIAGS; ++d) n += dg_defer.n[d];
+  return n;
+}
+int evf_dg_defer_launch(int d, void* stream) {
+  const int n = dg_defer.n[d];
+  if (!n) return EVF_OK;
+  const size_t lds = dg_lds_bytes();
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_dgrad_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  DgJobs jobs;
+  for (int k = 0; k < DG_MAX_JOBS; ++k) jobs.j[k] = dg_defer.job[d][k < n ? k : 0];
+  const int zb = dg_zb(dg_defer.B, dg_defer.H, dg_defer.W);
+  dim3 grid(evf_cdiv(dg_defer.W, 32), evf_cdiv(dg_defer.H, DG_ROWS), zb * n), block(DG_ROWS * 64);
+  evf_prof_mark(2, 0, stream);
+  hipLaunchKernelGGL(k_dgrad_diag, grid, block, lds, EVF_STREAM(stream), jobs, dg_defer.B, dg_defer.H, dg_defer.W, zb);
+  evf_prof_mark(2, 1, stream);
+  dg_defer.n[d] = 0;
+  return evf_status();
+}
+
 static int dg_select = -1;  // -1 by shape, 0 k_conv_dgrad_b3_lds, 1 k_conv_dgrad_ws
 extern "C" int evf_conv_dgrad_select(int which) {
   if (which < -1 || which > 1) return EVF_EINVAL;
@@ -302,7 +378,25 @@ static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, in
       mode = env_mode;
     }
     if (mode < 0) mode = ((long)B * evf_cdiv(H, 4) * evf_cdiv(W, 32) >= 6L * 256) ? 1 : 0;
-    if (mode == 1) return evf_dgrad_ws_launch((const float*)g, wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, wT2_b3, g_x2, 0, stream);
+    if (mode == 1) {
+      if (evf_bwd_defer.active) {  // (this kernel is not part of the recorded schedule: everything recorded runs first)
+        const int rc = evf_bwd_defer_flush_now(stream);
+        if (rc) return rc;
+      }
+      return evf_dgrad_ws_launch((const float*)g, wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, wT2_b3, g_x2, 0, stream);
+    }
+  }
+  if (evf_bwd_defer.active) {
+    const bool any = evf_dg_defer_count() != 0;
+    const bool same = !any || (dg_defer.B == B && dg_defer.H == H && dg_defer.W == W);
+    if (f32in && !accumulate && !g_P && same && dg_defer.n[evf_bwd_defer.slot] < DG_MAX_JOBS) {
+      dg_defer.B = B, dg_defer.H = H, dg_defer.W = W;
+      dg_defer.job[evf_bwd_defer.slot][dg_defer.n[evf_bwd_defer.slot]++] =
+          DgJob{(const uint4*)g, (const uint4*)wT_b3, g_x, (const uint4*)wT2_b3, g_x2};
+      return EVF_OK;
+    }
+    const int rc = evf_bwd_defer_flush_now(stream);  // not recordable: everything recorded runs first
+    if (rc) return rc;
   }
   // Samples per block (the 54 KiB of split weights are staged once per block): several only when the whole grid
   // then is ONE round of the 256 CUs (B = 8 at 128 x 128: 256 blocks x 2 tiles, 1 % faster than 512 x 1); with more

@@ -403,7 +403,9 @@ static int fw_defer_launch(void* stream) {
     FwJobs jobs;
     for (int k = 0; k < FW_MAX_JOBS; ++k) jobs.j[k] = fw_defer.job[d][k < n ? k : 0];
     dim3 grid(evf_cdiv(fw_defer.W, TW), evf_cdiv(fw_defer.H, TH), fw_defer.B * n), block(FW_THREADS);
+    evf_prof_mark(0, 0, stream);
     hipLaunchKernelGGL(k_fwd_diag, grid, block, lds, EVF_STREAM(stream), jobs, fw_defer.B, fw_defer.H, fw_defer.W);
+    evf_prof_mark(0, 1, stream);
     fw_defer.n[d] = 0;
   }
   return evf_status();

@@ -886,6 +886,55 @@ extern "C" int evf_head_lif_bwd_wgrad_slabs(int B, int H, int W) {
 // Head layer: neuron backward + weight gradient in one pass over g (models/spiking_submodules.py:96-126
 // autograd).  x_in [B,Cin,H,W] is the network input (Cin = 2); slab [evf_head_lif_bwd_wgrad_slabs][32*Cin*9]
 // receives (accumulate = 1: is added) the per-block weight-gradient partials in torch layout.
+struct HdArgs {
+  const float *g_z_out, *g_v_out, *v_out, *v_prev;
+  const uint32_t* z_prev;
+  const float *x_in, *leak, *thresh;
+  int B, Cin, H, W, hard_reset, surrogate;
+  float act_width;
+  float *g_cur, *g_v_prev, *g_leak, *g_thresh, *slab;
+  int accumulate;
+};
+static int head_bwd_go(const HdArgs& a, void* stream) {
+  const long npix = (long)a.B * a.H * a.W;
+  const int nblk = evf_head_lif_bwd_wgrad_slabs(a.B, a.H, a.W);
+  const int row_ld = a.accumulate >> 8;  // pitch of the per-block parameter-gradient rows (0: dense outputs, atomics)
+  const int accumulate = a.accumulate & 1;
+#define HEAD_BWD(FAST_)                                                                                                    \
+  hipLaunchKernelGGL(k_head_bwd_mfma<FAST_>, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)a.g_z_out,       \
+                     (const float4*)a.g_v_out, (const float4*)a.v_out, (const float4*)a.v_prev, a.z_prev, a.leak, a.thresh,  \
+                     npix, a.hard_reset, a.surrogate, a.act_width, (float4*)a.g_cur, (float4*)a.g_v_prev, a.g_leak,         \
+                     a.g_thresh, a.x_in, a.Cin, a.H, a.W, a.slab, accumulate, row_ld)
+  if (a.hard_reset != 0 && a.surrogate == EVF_ARCTAN)
+    HEAD_BWD(true);
+  else
+    HEAD_BWD(false);
+#undef HEAD_BWD
+  return evf_status();
+}
+
+// head cells recorded by evf_bwd_defer_* (evf_common.h): launched one by one when their index comes up
+#define HD_MAX_JOBS 4
+static struct {
+  int n[EVF_BWD_DIAGS];
+  HdArgs job[EVF_BWD_DIAGS][HD_MAX_JOBS];
+} hd_defer = {{0}, {}};
+int evf_hd_defer_count() {
+  int n = 0;
+  for (int d = 0; d < EVF_BWD_DIAGS; ++d) n += hd_defer.n[d];
+  return n;
+}
+int evf_hd_defer_launch(int d, void* stream) {
+  for (int k = 0; k < hd_defer.n[d]; ++k) {
+    evf_prof_mark(3, 0, stream);
+    const int rc = head_bwd_go(hd_defer.job[d][k], stream);
+    evf_prof_mark(3, 1, stream);
+    if (rc) return rc;
+  }
+  hd_defer.n[d] = 0;
+  return EVF_OK;
+}
+
 extern "C" int evf_head_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const float* v_out, const float* v_prev,
                                       const uint32_t* z_prev, const float* x_in, const float* leak, const float* thresh,
                                       int B, int Cin, int H, int W, int hard_reset, int surrogate, float act_width,
@@ -894,21 +943,17 @@ extern "C" int evf_head_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out
   if (!v_out || !x_in || !leak || !thresh || !g_v_prev || !g_leak || !g_thresh || !slab || B <= 0 || H <= 0 || W <= 0 ||
       Cin != 2)
     return EVF_EINVAL;
-  const long npix = (long)B * H * W;
-  const int nblk = evf_head_lif_bwd_wgrad_slabs(B, H, W);
-  const int row_ld = accumulate >> 8;  // pitch of the per-block parameter-gradient rows (0: dense outputs, atomics)
-  accumulate &= 1;
-#define HEAD_BWD(FAST_)                                                                                                    \
-  hipLaunchKernelGGL(k_head_bwd_mfma<FAST_>, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)g_z_out,         \
-                     (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev, z_prev, leak, thresh, npix,      \
-                     hard_reset, surrogate, act_width, (float4*)g_cur, (float4*)g_v_prev, g_leak, g_thresh, x_in, Cin, H,  \
-                     W, slab, accumulate, row_ld)
-  if (hard_reset != 0 && surrogate == EVF_ARCTAN)
-    HEAD_BWD(true);
-  else
-    HEAD_BWD(false);
-#undef HEAD_BWD
-  return evf_status();
+  const HdArgs a{g_z_out, g_v_out, v_out, v_prev, z_prev, x_in, leak, thresh, B, Cin, H, W, hard_reset, surrogate, act_width,
+                 g_cur, g_v_prev, g_leak, g_thresh, slab, accumulate};
+  if (evf_bwd_defer.active) {
+    if (hd_defer.n[evf_bwd_defer.slot] < HD_MAX_JOBS) {
+      hd_defer.job[evf_bwd_defer.slot][hd_defer.n[evf_bwd_defer.slot]++] = a;
+      return EVF_OK;
+    }
+    const int rc = evf_bwd_defer_flush_now(stream);
+    if (rc) return rc;
+  }
+  return head_bwd_go(a, stream);
 }
 
 // dst_k[i] += src[off_k + i], i < n_k, for up to 32 segments in one launch (block y = segment)

@@ -67,6 +67,8 @@ class _Window:
         self.rows = eng._take_rows(B, H, W, dev)
         n_ = len(eng.cells)
         self.gzr, self.gzr_has = [None] * n_, [False] * n_  # recurrent part of dL/d(spikes), separate from gz (see _backward_pass)
+        self.gcl = [None] * n_  # per-layer g_cur buffers (diagonal backward launches: several layers in flight)
+        self.bwd_k = 0          # backward passes of this window so far
         self.slab_init = {}
         self.token = eng._token(dev)  # (a leaf whose value is never read: only its autograd edge chains the passes)
         self.n_passes = 0
@@ -95,6 +97,9 @@ class _FireNetPass(torch.autograd.Function):
         eng, win = ctx.eng, ctx.win
         eng.flush_forward()
         eng._backward_pass(win, ctx.tape, g_flow, ctx.is_first)
+        win.bwd_k += 1
+        if ctx.is_first:
+            eng.flush_backward()  # (the recorded cells of all passes, diagonal by diagonal)
         ctx.tape = None
         grads = eng._finalize(win) if ctx.is_first else (None,) * len(eng.params)
         return (None, None, None, None, g_token) + tuple(grads)
@@ -354,12 +359,40 @@ class FireNetEngine:
             _lib._defer_flush = None
             _lib.call("evf_fwd_defer_flush")
 
+    def defer_backward(self, on=True):
+        """While on, the backward cells of the window (fused backward, input gradient, head backward of every pass) are
+        recorded under the index 2 * (backward pass number) + step and launched index by index when the window's first
+        pass has been recorded (csrc/evf_bwd_fused.hip, evf_bwd_defer_*): 15 + 15 + P launches instead of 13 P."""
+        if not on:
+            self.flush_backward()
+        self._bdefer_on = bool(on)
+
+    def flush_backward(self):
+        if self.__dict__.get("_bdefer_open"):
+            self._bdefer_open = False
+            _lib._defer_flush = None
+            _lib.call("evf_bwd_defer_flush")
+
+    def _bdefer_slot(self, win, step):
+        """Index of step `step` (0 = top layer's fused backward, 1 = its input gradient, ...) of the current backward pass."""
+        if not self.__dict__.get("_bdefer_open"):
+            if _lib.load().evf_bwd_defer_begin() != 0:
+                raise _lib.EvflowError("evf_bwd_defer_begin: another recording is open (one engine at a time)")
+            self._bdefer_open, self._bdefer_base = True, win.bwd_k
+            _lib._defer_flush, _lib._DEFER_SAFE = self.flush_backward, _lib._DEFER_SAFE_BWD
+        d = 2 * (win.bwd_k - self._bdefer_base) + step
+        if d >= 96:  # (more than ~40 passes: launch what is recorded, start over)
+            self.flush_backward()
+            return self._bdefer_slot(win, step)
+        if _lib.load().evf_bwd_defer_slot(d) != 0:
+            raise _lib.EvflowError("evf_bwd_defer_slot failed")
+
     def _defer_begin(self):
         rc = _lib.load().evf_fwd_defer_begin()
         if rc != 0:
             raise _lib.EvflowError("evf_fwd_defer_begin: another recording is open (one engine at a time)")
         self._defer_open, self._defer_t = True, 0
-        _lib._defer_flush = self.flush_forward
+        _lib._defer_flush, _lib._DEFER_SAFE = self.flush_forward, _lib._DEFER_SAFE_FWD
 
     def _flow_out(self, B, H, W, dev):
         slot, self._flow_slot = self._flow_slot, None
@@ -487,6 +520,8 @@ class FireNetEngine:
                       _lib.ptr(g_flow_c), _lib.ptr(self._flat["pred.w"]), B, H, W, _lib.ptr(gz_top),
                       _lib.ptr(self._small(win, "pred.w")), _lib.ptr(self._small(win, "pred.b")))
             win.gz_has[n - 1] = True
+        bdefer = (self.__dict__.get("_bdefer_on", False) and self.precision == "bf16x3" and self.kind == "lif" and F32_DGRAD
+                  and PAIR_DGRAD and (top_fused or g_flow is None) and tape["x_in"].shape[1] == 2)
         if win.g_cur is None:
             win.g_cur = _f32((B, H, W, C), dev)
             if self.precision == "bf16x3":
@@ -504,6 +539,9 @@ class FireNetEngine:
             if g_z is None and g_z2 is None and g_v is None and not top:
                 continue  # no gradient reaches this layer at this pass
             use_rec = c.recurrent and z_prev is not None
+            g_cur_i = win.buf(win.gcl, i) if bdefer else win.g_cur  # (several layers are in flight under diagonal launches)
+            if bdefer:
+                self._bdefer_slot(win, 2 * (n - 1 - i))
             gv_out = win.buf(win.gv, i)
             leak_g, thr_g = self._small(win, f"{i}.leak"), self._small(win, f"{i}.thresh")
             (leak_r, row_ld), (thr_r, _) = self._rowed(win, f"{i}.leak"), self._rowed(win, f"{i}.thresh")
@@ -521,14 +559,14 @@ class FireNetEngine:
                               _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(in_bitsT),
                               _lib.ptr(self._flat[f"{i}.leak"]), _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W,
                               1 if c.hard_reset else 0, SURROGATE_ID[c.activation], self._act_width(i),
-                              _lib.ptr(win.g_cur) if (plif or F32_DGRAD) else None, _lib.ptr(win.g_split), _lib.ptr(gv_out),
+                              _lib.ptr(g_cur_i) if (plif or F32_DGRAD) else None, _lib.ptr(win.g_split), _lib.ptr(gv_out),
                               _lib.ptr(leak_r), _lib.ptr(thr_r), _lib.ptr(self._slab(kf, nsl, dev)), acc_flag | (row_ld << 8))
                 else:
                     _lib.call("evf_lif_bwd_wgrad2", _lib.ptr(g_z), _lib.ptr(g_z2), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev),
                           _lib.ptr(z_prev),
                           _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None, _lib.ptr(self._flat[f"{i}.leak"]),
                           _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
-                          self._act_width(i), _lib.ptr(win.g_cur) if (plif or F32_DGRAD) else None, _lib.ptr(win.g_split),
+                          self._act_width(i), _lib.ptr(g_cur_i) if (plif or F32_DGRAD) else None, _lib.ptr(win.g_split),
                           _lib.ptr(gv_out),
                           _lib.ptr(leak_r), _lib.ptr(thr_r),
                           _lib.ptr(self._slab(kf, nsl, dev)), _lib.ptr(self._slab(kr, nsl, dev)) if use_rec else None,
@@ -583,10 +621,12 @@ class FireNetEngine:
             # input gradients: to the layer below (this pass) and to the own previous spikes (previous pass)
             rec_grad = use_rec and not is_first
             if i > 0:
+                if bdefer:
+                    self._bdefer_slot(win, 2 * (n - 1 - i) + 1)
                 ga = win.buf(win.gz, i - 1)
                 acc_a = 1 if win.gz_has[i - 1] else 0
                 if self.precision == "bf16x3":
-                    dg, gsrc = ("evf_conv_dgrad_b3_f32", win.g_cur) if F32_DGRAD else ("evf_conv_dgrad_b3", win.g_split)
+                    dg, gsrc = ("evf_conv_dgrad_b3_f32", g_cur_i) if F32_DGRAD else ("evf_conv_dgrad_b3", win.g_split)
                     if rec_grad and F32_DGRAD and PAIR_DGRAD:  # both input gradients of the recurrent cell in one launch
                         # the recurrent one goes to its OWN buffer (gzr): the cell's backward of the previous pass adds the
                         # two parts itself (evf_lif_bwd_wgrad2), so the input gradient of the layer above needs no

@@ -141,6 +141,11 @@ class FireNet(BaseModel):
         if self._engine is not None:
             self._engine.flush_forward()
 
+    def defer_backward(self, on=True):
+        """Fused path only: launch the window's backward cells diagonal by diagonal (FireNetEngine.defer_backward)."""
+        if self._fused():
+            self._eng().defer_backward(on)
+
     # -- state API (models/model.py:203-227) -------------------------------
     @property
     def states(self):

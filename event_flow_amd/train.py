@@ -96,6 +96,7 @@ class FlatAdam:
 
 # EVF_DEFER_FWD=0: every (pass, layer) cell of the fused FireNets as its own launch (the A/B switch of the diagonal launches)
 DEFER_FORWARD = os.environ.get("EVF_DEFER_FWD", "1") != "0"
+DEFER_BACKWARD = os.environ.get("EVF_DEFER_BWD", "1") != "0"  # ... and of the backward cells
 _UNIT = {}
 
 
@@ -127,7 +128,14 @@ def window_backward(model, loss_function, optimizer, passes, dp=None):
     loss = loss_function()
     if hasattr(optimizer, "mark_grad_dirty"):
         optimizer.mark_grad_dirty()
-    loss.backward(_unit_gradient(loss))  # (autograd would fill a fresh ones_like(loss) per step)
+    bdefer = DEFER_BACKWARD and hasattr(model, "defer_backward")
+    if bdefer:
+        model.defer_backward(True)  # fused FireNets: the backward cells of all passes run diagonal by diagonal
+    try:
+        loss.backward(_unit_gradient(loss))  # (autograd would fill a fresh ones_like(loss) per step)
+    finally:
+        if bdefer:
+            model.defer_backward(False)
     if dp is not None and dp.world > 1:
         dp.stage(optimizer.comm, loss)
     return loss

@@ -211,6 +211,26 @@ int evf_fwd_defer_begin(void);
 int evf_fwd_defer_slot(int index);
 int evf_fwd_defer_pending(void);
 int evf_fwd_defer_flush(void* stream);
+/* The same for the backward of a window (autograd of train_flow.py:141-154 over the passes of models/model.py:255-265): a
+ * pass's backward is a chain of 13 steps (fused backward of the top layer, its input gradient, the next layer, ..., the head
+ * layer); step s of pass t needs step s - 1 of pass t and steps s, s + 1 of pass t + 1.  Under the index 2 (P - 1 - t) + s
+ * the cells of one index are independent and of one kind.  While recording, evf_lif_bwd_wgrad[2|_top] (default neuron, fp32
+ * g_cur), evf_conv_dgrad_b3_f32[_pair] (no accumulation, no PLIF term) and evf_head_lif_bwd_wgrad record their launch under
+ * the index last given to evf_bwd_defer_slot (0 .. 95); any other call of these entry points first launches everything
+ * recorded.  evf_bwd_defer_flush launches index after index -- the fused-backward cells of an index as one kernel, its
+ * input-gradient cells as one kernel, head cells one by one -- and ends the recording.  Same kernel bodies as the one-cell
+ * launches.  Process-wide recorder; the caller guarantees the index order and that nothing else reads a cell's outputs
+ * before the flush. */
+int evf_bwd_defer_begin(void);
+int evf_bwd_defer_slot(int index);
+int evf_bwd_defer_pending(void);
+int evf_bwd_defer_flush(void* stream);
+/* Measurement aid: evf_defer_profile(1) brackets every launch of the following flushes with HIP events;
+ * evf_defer_profile_read synchronises the device, returns per kind (0 forward cells, 1 fused-backward cells, 2
+ * input-gradient cells, 3 head backward) the summed duration in ms and the number of launches, and switches it off.
+ * Not inside a graph capture. */
+int evf_defer_profile(int on);
+int evf_defer_profile_read(float* ms4, int* count4);
 
 /* Neuron backward (autograd of :103-126 / :523-551 with the surrogate of
  * spiking_util.py:88-93).  Per element:

@@ -790,6 +790,7 @@ def test_diagonal_launches_equal_cell_by_cell_launches(monkeypatch):
 
     def run(defer):
         monkeypatch.setattr(htrain, "DEFER_FORWARD", defer)
+        monkeypatch.setattr(htrain, "DEFER_BACKWARD", defer)  # the backward cells likewise (k_bwd_diag, k_dgrad_diag)
         model = build_from_golden(g)
         model.train()
         lossf = hloss.EventWarping(loss_cfg(H, W), DEV)
@@ -803,7 +804,7 @@ def test_diagonal_launches_equal_cell_by_cell_launches(monkeypatch):
         return out
 
     ref, got = run(False), run(True)
-    assert _lib.load().evf_fwd_defer_pending() == 0
+    assert _lib.load().evf_fwd_defer_pending() == 0 and _lib.load().evf_bwd_defer_pending() == 0
     assert got[0][0] == ref[0][0]  # first window: same weights, same forward -> the same loss, bit for bit
     for (l0, n0, p0), (l1, n1, p1) in zip(ref, got):
         np.testing.assert_allclose(l1, l0, rtol=1e-5)
