@@ -501,7 +501,11 @@ def test_hipgraph_replay_equals_eager_steps():
     opt2.zero_grad()
     l2 = hloss.EventWarping(loss_cfg(H, W), DEV)
     ref_losses = [float(step(m2, l2, opt2, pool[i % 2])) for i in range(4)]
-    np.testing.assert_allclose([losses1[0], losses1[1], losses1[4], losses1[5]], ref_losses, rtol=2e-4)
+    got = [losses1[0], losses1[1], losses1[4], losses1[5]]
+    np.testing.assert_allclose(got[:2], ref_losses[:2], rtol=2e-4)
+    # later steps start from weights that differ in the last bits (the loss backward sums with float atomics): now and then a
+    # neuron at its threshold flips and moves the loss by ~1e-3 (observed once in ~25 runs, with one launch per cell as well)
+    np.testing.assert_allclose(got[2:], ref_losses[2:], rtol=5e-3)
     for (k, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
         d = np.abs(N(p) - N(q))
         # Adam's first steps move every weight by ~lr; atomics reorder the gradient sums: bulk agreement
