@@ -809,7 +809,8 @@ def test_diagonal_launches_equal_cell_by_cell_launches(monkeypatch):
 
     ref, got = run(False), run(True)
     assert _lib.load().evf_fwd_defer_pending() == 0 and _lib.load().evf_bwd_defer_pending() == 0
-    assert got[0][0] == ref[0][0]  # first window: same weights, same forward -> the same loss, bit for bit
+    # first window: same weights, bit-identical flows -> the same loss up to the order of the loss's own float atomics
+    np.testing.assert_allclose(got[0][0], ref[0][0], rtol=1e-6)
     for (l0, n0, p0), (l1, n1, p1) in zip(ref, got):
         np.testing.assert_allclose(l1, l0, rtol=1e-5)
         np.testing.assert_allclose(n1, n0, rtol=1e-4)
@@ -822,7 +823,7 @@ def test_diagonal_launches_equal_cell_by_cell_launches(monkeypatch):
 @pytest.mark.parametrize("P", [1, 2, 50])
 def test_diagonal_launches_short_and_long_windows(monkeypatch, P):
     """Windows of 1 and 2 passes (diagonals of one cell) and of 50 passes (the backward index 2 (P - 1 - t) + step runs past
-    the recorder's 96 slots: it launches what it holds and starts over): loss bit-identical, gradient like a repeated run."""
+    the recorder's 96 slots: it launches what it holds and starts over): loss and gradient like a repeated cell-by-cell run."""
     from event_flow_amd import train as htrain
 
     B, H, W, n_ev = 2, 16, 40, 150
@@ -855,6 +856,6 @@ def test_diagonal_launches_short_and_long_windows(monkeypatch, P):
         return float(loss.detach()), N(opt.flat_grad).copy()
 
     (l0, g0), (l1, g1) = run(False), run(True)
-    assert l1 == l0
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)  # (bit-identical flows; the loss sums its images with float atomics)
     assert np.isfinite(g0).all() and np.linalg.norm(g0) > 0
     assert np.linalg.norm(g1 - g0) <= 1e-4 * np.linalg.norm(g0)
