@@ -49,7 +49,7 @@ def main():
     rng = np.random.default_rng(seed)
     bad = 0
     for it in range(n):
-        B, H, W, P = int(rng.integers(1, 5)), int(rng.integers(1, 41)), int(rng.integers(1, 161)), int(rng.integers(1, 7))
+        B, H, W, P = int(rng.integers(1, 5)), int(rng.integers(2, 41)), int(rng.integers(2, 161)), int(rng.integers(1, 7))  # (the loss needs H, W >= 2)
         n_ev = int(rng.integers(1, 400))
         gen = torch.Generator().manual_seed(seed * 100 + it)
         lists = []
