@@ -417,6 +417,8 @@ class FireNetEngine:
                 target = None
         defer = (record and self.__dict__.get("_defer_on", False) and self.precision == "bf16x3" and self.kind == "lif"
                  and PRED_FUSED)
+        if not defer:
+            self.flush_forward()  # (a pass outside the recorded schedule, e.g. under no_grad: what is recorded runs first)
         if defer:
             if self.__dict__.get("_defer_open") and self._defer_t + len(self.cells) - 2 >= 96:
                 self.flush_forward()
@@ -522,6 +524,8 @@ class FireNetEngine:
             win.gz_has[n - 1] = True
         bdefer = (self.__dict__.get("_bdefer_on", False) and self.precision == "bf16x3" and self.kind == "lif" and F32_DGRAD
                   and PAIR_DGRAD and (top_fused or g_flow is None) and tape["x_in"].shape[1] == 2)
+        if not bdefer:
+            self.flush_backward()  # (a pass outside the recorded schedule: what is recorded runs first)
         if win.g_cur is None:
             win.g_cur = _f32((B, H, W, C), dev)
             if self.precision == "bf16x3":
