@@ -154,7 +154,7 @@ class StepGraph:
 
         self.dp, self.comm, self.reps = dp, opt.comm, reps
         # other threads (the process group's watchdog polls events) must not invalidate a capture of this thread
-        mode = "thread_local" if dp.world > 1 else "global"
+        mode = "thread_local" if dp.active else "global"
         if reps is not None:
             # micro-batch pipelining (train.StreamReplicas): one graph per replica on its own stream, then the join:
             # gradients / losses summed, (all-reduce outside any capture,) clip+Adam, detach, reset
@@ -171,17 +171,17 @@ class StepGraph:
             self.pre = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.pre, stream=stream, capture_error_mode=mode):
                 local = reps.combine(losses)
-                if dp.world > 1:
+                if dp.active:
                     dp.stage(opt.comm, local)
                 else:
                     self.loss = reps.apply(local, dp)
             self.post = None
-            if dp.world > 1:
+            if dp.active:
                 self.post = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.post, stream=stream, capture_error_mode=mode):
                     self.loss = reps.apply(local, dp)
             return
-        if dp.world == 1:
+        if not dp.active:
             self.pre = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.pre, stream=stream, capture_error_mode=mode):
                 self.loss = run_step(model, lossf, opt, dp, lists)
@@ -302,6 +302,40 @@ def _pmc(entry):
             "mfma_busy_pct": t.get("mfma_busy_pct"), "source": os.path.basename(files[-1]), "src_hash": d["src_hash"]}, None
 
 
+def cpu_model():
+    """CPU model string of the host (stated next to the core count)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+
+    return platform.processor() or platform.machine()
+
+
+def other_config_line(cfg, steps=10, warmup=3, timeout=420):
+    """A short run of another BASELINE configuration in its own process (own model, own HIP context), summarised for the
+    headline line's `other_configs`: value, ms_per_step and the roofline object of that run."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(steps), "--warmup", str(warmup),
+           "--no-cpu-baseline", "--no-iwe", "--no-others"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"rc {r.returncode}: {r.stderr.strip()[-300:]}"}
+        d = json.loads(lines[-1])
+        roof = d.get("roofline") or {}
+        return {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                "warmup": d["warmup"], "dtype": d["dtype"], "launch": d["config"].get("launch"), "workload": d["config"]["workload"],
+                "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")}}
+    except Exception as e:  # noqa: BLE001  (never costs the headline line)
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def cpu_baseline(threads, max_seconds=60.0, name="LIFFireNet"):
     """Oracle (PyTorch-CPU port of the reference path) on a bounded sample:
     ONE window (B=1) of the same workload, full train step."""
@@ -375,7 +409,8 @@ def cpu_baseline(threads, max_seconds=60.0, name="LIFFireNet"):
         extra["iwe_warp_GBps"] = 64 * (28 * PASSES * EV_PER_PASS + 2 * H * W * 4) / (time.perf_counter() - t1) / 1e9
     except Exception as e:  # the extras never cost the headline baseline
         extra["error"] = f"{type(e).__name__}: {e}"
-    return {"value": Bc * n_done / el, "unit": "event-windows/s", "cores": best_t, "kind": "port", "extra": extra,
+    return {"value": Bc * n_done / el, "unit": "event-windows/s", "cores": best_t, "kind": "port", "cpu_model": cpu_model(),
+            "host_cpus": os.cpu_count(), "extra": extra,
             "sample": f"{n_done} full train step(s) of {Bc} windows (B={Bc}, {PASSES} passes x {EV_PER_PASS} events, {H}x{W}) = "
                       f"the GPU step's per-GPU work; oracle = PyTorch-CPU fp32 port of the reference path; "
                       f"{best_t} threads (fastest of {cand} on a {os.cpu_count()}-CPU host), {el:.1f} s"}
@@ -520,6 +555,8 @@ def main():
                          "streams; 2 gives +6.6 %% windows/s at the headline shape, but then every launch is a half-batch kernel "
                          "and two are in flight, so per-launch roofline figures stop describing the device (default 1 = off)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-others", action="store_true",
+                    help="skip the short c4 / c5 runs the default invocation appends as `other_configs` (after the c3 line's timed region)")
     ap.add_argument("--config", choices=["c3", "c4", "c5"], default="c3",
                     help="BASELINE.json workload: c3 = headline LIF-FireNet train step (default), c5 = PLIF-FireNet 260x346 (4 per GPU), "
                          "c4 = LIF-EV-FlowNet 256x256 x 50k events (general fp32-MFMA path)")
@@ -606,7 +643,7 @@ def main():
             graphs = None
         torch.cuda.synchronize()
         # all ranks must issue the same collective sequence: graphs on every rank or on none
-        if dp.world > 1 and dp.max_over_ranks(0.0 if graphs is not None else 1.0) != 0.0:
+        if dp.active and dp.max_over_ranks(0.0 if graphs is not None else 1.0) != 0.0:
             graphs = None
         if graphs is not None:
             for i in range(2):  # replay warm-up
@@ -695,6 +732,14 @@ def main():
         # g_cur, g_pt carry, pt_prev, pt_out in; g_pt_prev out (fp32 [npix][32]); P, g_P_raw, g_P_in [npix]
         model[("evf_plif_trace_bwd", "")] = (0, 652 * npix)
         hbm_bound |= {"evf_conv_plif_fwd_b3", "evf_head_plif_fwd", "evf_plif_trace_bwd"}
+        # contrast-maximisation loss: forward 88 B/event (24 B read + 2 directions x 4 corners x 2 images x 4 B) +
+        # the 8 images read once for the reduction + the flow maps of the P passes for the smoothness term; backward 96 B/event
+        # (24 B + 64 B image-gradient gather + 8 B atomic to dL/dflow) + the 8 images + dL/dflow of the P passes written
+        nev_w = PASSES * EV_PER_PASS
+        img = (8 + 2 * PASSES) * H * W * 4
+        model[("evf_cm_loss_fwd", "")] = (0, (B_PER_GPU // nstream) * (nev_w * 88 + img))
+        model[("evf_cm_loss_bwd", "")] = (0, (B_PER_GPU // nstream) * (nev_w * 96 + img))
+        hbm_bound |= {"evf_cm_loss_fwd", "evf_cm_loss_bwd"}
         # diagonal launches: PASSES + 5 launches hold the window's cells; per LAUNCH = the window's total / (PASSES + 5)
         nl = PASSES + 5
         if diag_fwd:  # 6 hidden cells per pass (8 contractions: two recurrent cells), 272 B/px each, 280 under the prediction head
@@ -736,6 +781,9 @@ def main():
                 ent["mfma_busy_pct"] = pm["mfma_busy_pct"] if pm else None  # SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE (PMC pass)
                 if not pm:
                     ent["pmc"] = why
+            if key[0] in ("evf_cm_loss_fwd", "evf_cm_loss_bwd"):
+                ent["note"] = ("one call = 5 (forward) / 3 (backward) launches over the window's events and its 8 warped-event images: "
+                               "latency of dependent launches at this size, not a bandwidth figure")
             if key[0] in ("k_fwd_diag", "k_bwd_diag", "k_dgrad_diag"):
                 ent["note"] = (f"diagonal launches: the window's {6 * PASSES} cells of this kind in {nl} launches of 1..6 independent "
                                "(pass, layer) cells; mean_us / algorithmic_MB are per LAUNCH (window total / launches)")
@@ -758,7 +806,8 @@ def main():
                     "unit": "TFLOP/s", "frac": dom["fp32_equiv_TFLOPs"] / FP32_MFMA_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_detail": detail if detail else {"unavailable": why_not}}
         out = {
-            "metric": "event-windows/sec (train step, 128x128x15k ev)", "value": B_PER_GPU * dp.world * args.steps / elapsed,
+            "metric": f"event-windows/sec (train step, {W}x{H}x{PASSES * EV_PER_PASS // 1000}k ev)" + ("" if args.config == "c3" else f" [{wl['model']}, {args.config}]"),
+            "value": B_PER_GPU * dp.world * args.steps / elapsed,
             "unit": "event-windows/s", "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -778,8 +827,13 @@ def main():
                                       "step two such launches are in flight" if nstream > 1 else None),
                        "collective": ({"backend": dp.backend, "library": "RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
                                        if dp.backend == "nccl" else dp.backend, "ranks": dp.world,
-                                       "per_step": "1 SUM all-reduce of [flat gradient | loss | new_seq] = %d bytes" % (opt.comm.numel() * 4)}
-                                      if dp.world > 1 else None),
+                                       "per_step": "1 SUM all-reduce of [flat gradient | loss | new_seq] = %d bytes" % (opt.comm.numel() * 4),
+                                       "forced_at_one_rank": dp.world == 1}
+                                      if dp.active else
+                                      {"backend": dp.backend, "library": ("RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
+                                                                          if torch.distributed.is_nccl_available() else None),
+                                       "ranks": 1, "per_step": "none at one rank (the all-reduce of [flat gradient | loss | new_seq] = "
+                                                               "%d bytes is issued from 2 ranks on)" % (opt.comm.numel() * 4)}),
                        "conv_precision": ("fp32 results via exact 3-way bf16 splits of the fp32 operands on the bf16 matrix cores, "
                                           "fp32 accumulation" if model_precision == "bf16x3" else "fp32 MFMA (v_mfma_f32_32x32x2_f32)")},
             "roofline": roof,
@@ -812,6 +866,13 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(threads, name=wl["model"])
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        if dp.world == 1 and args.config == "c3" and not args.no_others:
+            # BASELINE configs[3] / configs[4] next to the headline: short runs in their own processes AFTER everything of the
+            # c3 line has been measured (this process only waits meanwhile)
+            torch.cuda.synchronize()
+            out["other_configs"] = {"c4": other_config_line("c4"), "c5": other_config_line("c5"),
+                                    "note": "`python bench.py --config c4|c5 --steps 10 --warmup 3`, one process each, run after the c3 "
+                                            "line's timed region and side measurements; full lines: profiles/"}
         print(json.dumps(out), flush=True)
     dp.barrier()
     dp.close()

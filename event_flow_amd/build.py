@@ -62,5 +62,28 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_variant(name, defines, verbose=False):
+    """A/B build: libevflow_<name>.so with extra -D flags for some sources ({"evf_x.hip": ["-DFOO=1"]}), every other object
+    taken from the main build.  Loaded through EVF_LIB=<path> (measurements only; never the product path)."""
+    build(verbose=verbose)
+    vdir = os.path.join(CSRC, "_var_" + name)
+    os.makedirs(vdir, exist_ok=True)
+    objs, procs = [], []
+    for src in sources():
+        base = os.path.basename(src)
+        if base in defines:
+            obj = os.path.join(vdir, base[:-4] + ".o")
+            procs.append((src, subprocess.Popen([HIPCC] + FLAGS + list(defines[base]) + ["-c", src, "-o", obj])))
+        else:
+            obj = src[:-4] + ".o"
+        objs.append(obj)
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    out = os.path.join(HERE, f"libevflow_{name}.so")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))

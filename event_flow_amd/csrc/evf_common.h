@@ -73,6 +73,18 @@ int evf_wgrad9_b3_launch(const float* x, int ldx, const float* gy, int ldg, floa
 int evf_dgrad_ws_launch(const float* g_cur, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W, const float* g_P,
                         const uint32_t* x_bits, const void* wT2_b3, float* g_x2, int max_blocks, void* stream);
 
+// evf_dgrad_diag.hip: the input-gradient cells of one backward index as a flat list of products (gradient, weight set,
+// output) in one persistent wave-specialised launch (k_dgrad_diag_ws)
+#define EVF_DG_MAX_PROD 16
+struct EvfDgProd {
+  const void* g;   // fp32 gradient [B,H,W,32]
+  const void* wt;  // split transposed weights (evf_pack_conv_weight_b3t)
+  float* gx;       // [B,H,W,32], written
+};
+struct EvfDgProds {
+  EvfDgProd p[EVF_DG_MAX_PROD];
+};
+int evf_dgrad_diag_ws_launch(const EvfDgProds& P, int nprod, int B, int H, int W, void* stream);
 
 // Deferred backward cells (evf_bwd_defer_*, owner: evf_bwd_fused.hip): while `active`, the fused backward, the fp32 input
 // gradient and the head backward of the default-neuron FireNet path RECORD their launch under index `slot`; the flush

@@ -326,6 +326,13 @@ static size_t dg_lds_bytes() {
   return (size_t)(NFRAG * 64 + 3 * DL_HPP * 4) * sizeof(uint4) + (size_t)DG_ROWS * 32 * DG_SP * 4;
 }
 
+static int dg_diag_select = -1;  // -1 environment / default, 0 k_dgrad_diag, 1 k_dgrad_diag_ws
+extern "C" int evf_dgrad_diag_select(int which) {
+  if (which < -1 || which > 1) return EVF_EINVAL;
+  dg_diag_select = which;
+  return EVF_OK;
+}
+
 int evf_dg_defer_count() {
   int n = 0;
   for (int d = 0; d < EVF_BWD_DIAGS; ++d) n += dg_defer.n[d];
@@ -334,6 +341,27 @@ int evf_dg_defer_count() {
 int evf_dg_defer_launch(int d, void* stream) {
   const int n = dg_defer.n[d];
   if (!n) return EVF_OK;
+  // default: the persistent wave-specialised launch over the flat product list (evf_dgrad_diag.hip); EVF_DGRAD_DIAG=lds keeps
+  // the one-phase-after-the-other body below (A/B measurements, the bit-identity test)
+  static const bool env_ws = []() {
+    const char* e = getenv("EVF_DGRAD_DIAG");
+    return !(e && e[0] == 'l');
+  }();
+  if (dg_diag_select < 0 ? env_ws : dg_diag_select == 1) {
+    EvfDgProds P;
+    int np = 0;
+    for (int k = 0; k < n; ++k) {
+      const DgJob& J = dg_defer.job[d][k];
+      P.p[np++] = EvfDgProd{J.gs, J.wt, J.gx};
+      if (J.wt2) P.p[np++] = EvfDgProd{J.gs, J.wt2, J.gx2};
+    }
+    for (int k = np; k < EVF_DG_MAX_PROD; ++k) P.p[k] = P.p[0];
+    evf_prof_mark(2, 0, stream);
+    const int rc = evf_dgrad_diag_ws_launch(P, np, dg_defer.B, dg_defer.H, dg_defer.W, stream);
+    evf_prof_mark(2, 1, stream);
+    dg_defer.n[d] = 0;
+    return rc;
+  }
   const size_t lds = dg_lds_bytes();
   static bool attr_set = false;
   if (!attr_set) {
@@ -368,6 +396,18 @@ static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, in
   // tiles (260 x 346 x B4: 46 vs 60 us); with <= 2 tiles per CU the cold first fetch dominates either way and the
   // one-phase-after-the-other kernel below is ~1 % ahead in the train step (128 x 128 x B8: 20.1 vs 21.3 us in the step).
   // evf_conv_dgrad_select() / EVF_DGRAD=lds|ws override the choice (A/B measurements, the equivalence test).
+  if (evf_bwd_defer.active) {  // a recording is open: record the cell (any size: the persistent launch of evf_dgrad_diag.hip) ...
+    const bool any = evf_dg_defer_count() != 0;
+    const bool same = !any || (dg_defer.B == B && dg_defer.H == H && dg_defer.W == W);
+    if (f32in && !accumulate && !g_P && same && dg_defer.n[evf_bwd_defer.slot] < DG_MAX_JOBS) {
+      dg_defer.B = B, dg_defer.H = H, dg_defer.W = W;
+      dg_defer.job[evf_bwd_defer.slot][dg_defer.n[evf_bwd_defer.slot]++] =
+          DgJob{(const uint4*)g, (const uint4*)wT_b3, g_x, (const uint4*)wT2_b3, g_x2};
+      return EVF_OK;
+    }
+    const int rc = evf_bwd_defer_flush_now(stream);  // ... or, not recordable: everything recorded runs first
+    if (rc) return rc;
+  }
   if (f32in) {
     int mode = dg_select;
     if (mode < 0) {
@@ -378,25 +418,8 @@ static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, in
       mode = env_mode;
     }
     if (mode < 0) mode = ((long)B * evf_cdiv(H, 4) * evf_cdiv(W, 32) >= 6L * 256) ? 1 : 0;
-    if (mode == 1) {
-      if (evf_bwd_defer.active) {  // (this kernel is not part of the recorded schedule: everything recorded runs first)
-        const int rc = evf_bwd_defer_flush_now(stream);
-        if (rc) return rc;
-      }
+    if (mode == 1)
       return evf_dgrad_ws_launch((const float*)g, wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, wT2_b3, g_x2, 0, stream);
-    }
-  }
-  if (evf_bwd_defer.active) {
-    const bool any = evf_dg_defer_count() != 0;
-    const bool same = !any || (dg_defer.B == B && dg_defer.H == H && dg_defer.W == W);
-    if (f32in && !accumulate && !g_P && same && dg_defer.n[evf_bwd_defer.slot] < DG_MAX_JOBS) {
-      dg_defer.B = B, dg_defer.H = H, dg_defer.W = W;
-      dg_defer.job[evf_bwd_defer.slot][dg_defer.n[evf_bwd_defer.slot]++] =
-          DgJob{(const uint4*)g, (const uint4*)wT_b3, g_x, (const uint4*)wT2_b3, g_x2};
-      return EVF_OK;
-    }
-    const int rc = evf_bwd_defer_flush_now(stream);  // not recordable: everything recorded runs first
-    if (rc) return rc;
   }
   // Samples per block (the 54 KiB of split weights are staged once per block): several only when the whole grid
   // then is ONE round of the 256 CUs (B = 8 at 128 x 128: 256 blocks x 2 tiles, 1 % faster than 512 x 1); with more

@@ -70,3 +70,144 @@ __device__ __forceinline__ dgm_f32x16 dg_matrix_phase(const uint4* __restrict__ 
   }
   return acc[0] + acc[1];
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Second form of the matrix phase (k_dgrad_diag_ws, evf_dgrad_diag.hip): the same 108 products in the same order per
+// accumulator (acc0: the m = 0 groups in tap order, acc1: the m = 1 groups), so the result is bit-identical to
+// dg_matrix_phase -- only where the operands come from and when they are requested differ:
+//  * DPPX: in the transposed product a lane is a PIXEL, so the gradient fragment of tap (dy, 1) is the fragment of (dy, 0)
+//    moved down by one lane (and the fragment of (dy, 2) moved up by one).  Per tap row and K half only the dx = 0 and
+//    dx = 2 fragments are read from LDS; the middle one is two DPP moves per dword: `wave_shl:1` of the dx = 0 fragment
+//    (right for every lane but 31 and 63, whose neighbour belongs to the other K half / does not exist) patched by
+//    `wave_shr:1` of the dx = 2 fragment under row_mask 0xA, bank_mask 0x8 (lanes 28..31 and 60..63).  12 instead of 18
+//    gradient reads per tap row: 90 instead of 108 fragment reads per phase.
+//  * PF: the weight fragments are requested PF groups ahead (the gradient fragments one tap ROW ahead under DPPX).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dgm_dpp_mid1(uint32_t f0, uint32_t f2) {
+  uint32_t r = (uint32_t)__builtin_amdgcn_mov_dpp((int)f0, 0x130, 0xF, 0xF, true);  // wave_shl:1   lane i <- lane i + 1 (lane 63: 0)
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)r, (int)f2, 0x138, 0xA, 0x8, false);   // wave_shr:1   lanes 28..31, 60..63 <- lane i - 1
+}
+__device__ __forceinline__ uint4 dgm_dpp_mid(const uint4 f0, const uint4 f2) {
+  return make_uint4(dgm_dpp_mid1(f0.x, f2.x), dgm_dpp_mid1(f0.y, f2.y), dgm_dpp_mid1(f0.z, f2.z), dgm_dpp_mid1(f0.w, f2.w));
+}
+
+struct DgmW {
+  uint4 h, m, l;
+};
+struct DgmG {
+  uint4 h, m, l;
+};
+__device__ __forceinline__ void dgm_load_w(DgmW& w, int g, const uint4* __restrict__ s_w, int lane) {
+  const uint4* wf = s_w + (g * 3) * 64 + lane;
+  w.h = wf[0], w.m = wf[64], w.l = wf[128];
+}
+__device__ __forceinline__ void dgm_load_g(DgmG& a, int dy, int dx, int m, const uint4* __restrict__ pa, int plane, int hp0, int lane) {
+  const int kg = lane >> 5;
+  const int hp = hp0 + dy * DGM_HW + dx, sw = (hp >> 2) & 3;
+  const int slot = hp * 4 + ((2 * m + kg) ^ sw);
+  a.h = pa[slot], a.m = pa[plane + slot], a.l = pa[2 * plane + slot];
+}
+__device__ __forceinline__ dgm_f32x16 dgm_six(dgm_f32x16 a, const DgmW& w, const DgmG& g) {
+  const dgm_bf16x8 wh = *(const dgm_bf16x8*)&w.h, wm = *(const dgm_bf16x8*)&w.m, wl = *(const dgm_bf16x8*)&w.l;
+  const dgm_bf16x8 ah = *(const dgm_bf16x8*)&g.h, am = *(const dgm_bf16x8*)&g.m, al = *(const dgm_bf16x8*)&g.l;
+  a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, am, a, 0, 0, 0);  // (the order of dg_matrix_phase: smallest terms first)
+  a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, a, 0, 0, 0);
+  a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, a, 0, 0, 0);
+  a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, am, a, 0, 0, 0);
+  a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, ah, a, 0, 0, 0);
+  a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, a, 0, 0, 0);
+  return a;
+}
+
+template <int PF, bool DPPX>
+__device__ __forceinline__ dgm_f32x16 dg_matrix_phase2(const uint4* __restrict__ s_w, const uint4* __restrict__ pa, int plane,
+                                                       int hp0, int lane) {
+  static_assert(PF >= 1 && PF <= 3, "weight prefetch distance in K groups");
+  dgm_f32x16 acc[2] = {{0}, {0}};
+  DgmW w[PF + 1];
+#pragma unroll
+  for (int p = 0; p < PF; ++p) dgm_load_w(w[p], p, s_w, lane);
+  if (DPPX) {
+    // r0[m] / r2[m]: the dx = 0 and dx = 2 fragments of the current tap row.  Each set is re-requested for the NEXT tap row
+    // right behind its last use (r0[0] is dead once the middle fragment of (dx 1, m 0) is built, ...), three to four groups
+    // ahead of its first use there: one set of registers, no second buffer.
+    // The DPP moves that build a middle fragment are issued BETWEEN the six MFMAs of the group before it (a wave issues in
+    // order: behind the last MFMA of a dependent chain they would leave the matrix pipe idle for ~100 cycles per tap row
+    // and K half); scheduling barriers pin that order.
+    DgmG r0[2], r2[2], mid;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      dgm_load_g(r0[m], 0, 0, m, pa, plane, hp0, lane);
+      dgm_load_g(r2[m], 0, 2, m, pa, plane, hp0, lane);
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int g = (dy * 3 + dx) * 2 + m;
+          if (g + PF < 18) dgm_load_w(w[(g + PF) % (PF + 1)], g + PF, s_w, lane);
+          const DgmG cur = dx == 0 ? r0[m] : (dx == 2 ? r2[m] : mid);
+          // the group after this one is (dx, m ^ 1 ...) in the order dx-major: next = (dx + (m == 1), m ^ 1)
+          const int ndx = dx + (m == 1 ? 1 : 0), nm = m ^ 1;
+          const bool build = ndx == 1;  // the next group multiplies a middle fragment: build it under this group's MFMAs
+          if (dy > 0 && dx == 0 && m == 0) dgm_load_g(r2[1], dy, 2, 1, pa, plane, hp0, lane);
+          if (dy < 2) {  // next tap row: the set whose last use lies behind us (r0[.] is dead once its middle fragment is built)
+            if (dx == 2 && m == 0) dgm_load_g(r0[0], dy + 1, 0, 0, pa, plane, hp0, lane);
+            if (dx == 2 && m == 1) {
+              dgm_load_g(r0[1], dy + 1, 0, 1, pa, plane, hp0, lane);
+              dgm_load_g(r2[0], dy + 1, 2, 0, pa, plane, hp0, lane);
+            }
+          }
+          const dgm_bf16x8 wh = *(const dgm_bf16x8*)&w[g % (PF + 1)].h, wm = *(const dgm_bf16x8*)&w[g % (PF + 1)].m,
+                           wl = *(const dgm_bf16x8*)&w[g % (PF + 1)].l;
+          const dgm_bf16x8 ah = *(const dgm_bf16x8*)&cur.h, am = *(const dgm_bf16x8*)&cur.m, al = *(const dgm_bf16x8*)&cur.l;
+          DgmG nmid = mid;
+          dgm_f32x16 a = acc[m];
+          __builtin_amdgcn_sched_barrier(0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, am, a, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (build) nmid.h.x = dgm_dpp_mid1(r0[nm].h.x, r2[nm].h.x), nmid.h.y = dgm_dpp_mid1(r0[nm].h.y, r2[nm].h.y);
+          __builtin_amdgcn_sched_barrier(0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, a, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (build) nmid.h.z = dgm_dpp_mid1(r0[nm].h.z, r2[nm].h.z), nmid.h.w = dgm_dpp_mid1(r0[nm].h.w, r2[nm].h.w);
+          __builtin_amdgcn_sched_barrier(0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, a, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (build) nmid.m.x = dgm_dpp_mid1(r0[nm].m.x, r2[nm].m.x), nmid.m.y = dgm_dpp_mid1(r0[nm].m.y, r2[nm].m.y);
+          __builtin_amdgcn_sched_barrier(0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, am, a, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (build) nmid.m.z = dgm_dpp_mid1(r0[nm].m.z, r2[nm].m.z), nmid.m.w = dgm_dpp_mid1(r0[nm].m.w, r2[nm].m.w);
+          __builtin_amdgcn_sched_barrier(0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, ah, a, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (build) nmid.l.x = dgm_dpp_mid1(r0[nm].l.x, r2[nm].l.x), nmid.l.y = dgm_dpp_mid1(r0[nm].l.y, r2[nm].l.y);
+          if (build) nmid.l.z = dgm_dpp_mid1(r0[nm].l.z, r2[nm].l.z), nmid.l.w = dgm_dpp_mid1(r0[nm].l.w, r2[nm].l.w);
+          __builtin_amdgcn_sched_barrier(0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, a, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          acc[m] = a;
+          mid = nmid;
+        }
+      }
+    }
+  } else {
+    DgmG a[2];
+    dgm_load_g(a[0], 0, 0, 0, pa, plane, hp0, lane);
+#pragma unroll
+    for (int g = 0; g < 18; ++g) {
+      if (g + PF < 18) dgm_load_w(w[(g + PF) % (PF + 1)], g + PF, s_w, lane);
+      if (g + 1 < 18) {
+        const int tau = (g + 1) >> 1;
+        dgm_load_g(a[(g + 1) & 1], tau / 3, tau % 3, (g + 1) & 1, pa, plane, hp0, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[g & 1] = dgm_six(acc[g & 1], w[g % (PF + 1)], a[g & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  return acc[0] + acc[1];
+}

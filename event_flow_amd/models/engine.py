@@ -100,7 +100,7 @@ class _FireNetPass(torch.autograd.Function):
         win.bwd_k += 1
         if ctx.is_first:
             eng.flush_backward()  # (the recorded cells of all passes, diagonal by diagonal)
-        ctx.tape = None
+        ctx.tape = None  # (while a backward recording is open the engine holds the tape: _backward_pass, flush_backward)
         grads = eng._finalize(win) if ctx.is_first else (None,) * len(eng.params)
         return (None, None, None, None, g_token) + tuple(grads)
 
@@ -248,6 +248,7 @@ class FireNetEngine:
 
     def get_states(self):
         """-> list of [2,B,C,H,W] float tensors (or None), the reference's layout."""
+        self.flush_forward()  # (cells recorded for a diagonal launch write the states read here)
         out = []
         for st in self._states:
             if st is None:
@@ -372,6 +373,9 @@ class FireNetEngine:
             self._bdefer_open = False
             _lib._defer_flush = None
             _lib.call("evf_bwd_defer_flush")
+        # the recorded cells hold raw pointers into the passes' tapes and upstream gradients: those tensors are kept here
+        # until the cells have been launched (stream order then protects the memory like any other tensor's)
+        self._bdefer_keep = []
 
     def _bdefer_slot(self, win, step):
         """Index of step `step` (0 = top layer's fused backward, 1 = its input gradient, ...) of the current backward pass."""
@@ -516,6 +520,10 @@ class FireNetEngine:
         top_fused = (TOP_FUSED and g_flow is not None and self.precision == "bf16x3" and n > 1
                      and not self.cells[n - 1].recurrent and not win.gz_has[n - 1])
         g_flow_c = g_flow.float().contiguous() if g_flow is not None else None
+        if self.__dict__.get("_bdefer_on", False):
+            # recorded cells of this pass are launched later (flush_backward): its tape and the contiguous upstream gradient
+            # must outlive this function (autograd drops ctx.tape and g_flow as soon as the node returns)
+            self.__dict__.setdefault("_bdefer_keep", []).append((tape, g_flow, g_flow_c))
         if g_flow is not None and not top_fused:
             gz_top = win.buf(win.gz, n - 1)
             _lib.call("evf_pred_bwd", _lib.ptr(layers[n - 1][4]), _lib.ptr(tape["flow"]),

@@ -197,6 +197,7 @@ class FireNet(BaseModel):
         flow = eng.forward(x)
 
         if log:  # fraction of non-zero outputs per layer, models/model.py:268-284
+            eng.flush_forward()  # (recorded cells of this pass have not run yet: torch reads below would see stale memory)
             names = ["0:input", "1:head", "2:G1", "3:R1a", "4:R1b", "5:G2", "6:R2a", "7:R2b", "8:pred"]
             acts = [x.detach().ne(0).float().mean().item()]
             for st in eng.get_states():

@@ -22,7 +22,10 @@ import torch.distributed as dist
 class DataParallel:
     TAIL = 2  # [loss, new_seq flag]
 
-    def __init__(self, backend=None, device=None, init=True):
+    def __init__(self, backend=None, device=None, init=True, force_collectives=None):
+        """force_collectives (or EVF_DP_FORCE=1): initialise the process group and ISSUE every collective also at world
+        size 1 -- a one-rank RCCL communicator on the one GPU of a test box runs the same code path (init with device_id,
+        all-reduce between the two step graphs, barrier(device_ids)) the 8-GPU run takes."""
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -32,7 +35,11 @@ class DataParallel:
         if backend is None:
             backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
         self.backend = backend
-        if init and self.world > 1 and not dist.is_initialized():
+        if force_collectives is None:
+            force_collectives = os.environ.get("EVF_DP_FORCE", "0") == "1"
+        # `active`: collectives are issued (several ranks, or forced at one rank)
+        self.active = self.world > 1 or bool(force_collectives)
+        if init and self.active and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             kw = {}
@@ -61,7 +68,7 @@ class DataParallel:
 
     def reduce(self, comm):
         """THE collective of a step: in-place SUM all-reduce of gradient + tail."""
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(comm, op=dist.ReduceOp.SUM)
 
     def staged(self, comm):
@@ -78,14 +85,14 @@ class DataParallel:
 
     def broadcast(self, t, src=0):
         """In-place broadcast (parameter replicas start from rank `src`'s values)."""
-        if self.world > 1:
+        if self.active:
             dist.broadcast(t, src=src)
 
     def any_flags(self, flags):
         """Element-wise OR over the ranks of a few host booleans (one tiny MAX all-reduce): the loader events every
         rank has to act on together -- a slot started a new sequence (all slots are reset, train_flow.py:100-105),
         a rank finished its pass over the files (every rank ends the epoch)."""
-        if self.world == 1:
+        if not self.active:
             return [bool(f) for f in flags]
         t = torch.tensor([1.0 if f else 0.0 for f in flags], dtype=torch.float32,
                          device=self.device if self.backend == "nccl" else "cpu")
@@ -93,19 +100,19 @@ class DataParallel:
         return [bool(v) for v in t.tolist()]
 
     def barrier(self):
-        if self.world > 1:
+        if self.active:
             if self.backend == "nccl":
                 dist.barrier(device_ids=[torch.device(self.device).index])
             else:
                 dist.barrier()
 
     def max_over_ranks(self, value):
-        if self.world == 1:
+        if not self.active:
             return float(value)
         t = torch.tensor([float(value)], dtype=torch.float64, device=self.device if self.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def close(self):
-        if self.world > 1 and dist.is_initialized():
+        if self.active and dist.is_initialized():
             dist.destroy_process_group()

@@ -136,7 +136,7 @@ def window_backward(model, loss_function, optimizer, passes, dp=None):
     finally:
         if bdefer:
             model.defer_backward(False)
-    if dp is not None and dp.world > 1:
+    if dp is not None and dp.active:
         dp.stage(optimizer.comm, loss)
     return loss
 
@@ -144,7 +144,7 @@ def window_backward(model, loss_function, optimizer, passes, dp=None):
 def window_apply(model, loss_function, optimizer, loss, dp=None):
     """Second half: clip + Adam on the (reduced) gradient, state detach, loss reset
     (train_flow.py:157-171).  Returns the 0-d (global) loss tensor."""
-    staged = dp is not None and dp.world > 1
+    staged = dp is not None and dp.active
     if staged:
         loss, _ = dp.staged(optimizer.comm)
     optimizer.step()
@@ -254,7 +254,7 @@ class StreamReplicas:
         for k in range(1, self.n):
             main.wait_stream(self.streams[k])
         loss = self.combine(losses)
-        if dp is not None and dp.world > 1:
+        if dp is not None and dp.active:
             dp.stage(self.opt.comm, loss)
             dp.reduce(self.opt.comm)
         return self.apply(loss, dp)
@@ -303,7 +303,7 @@ class GraphedWindowStep:
         return d
 
     def _capture(self):
-        mode = "thread_local" if (self.dp is not None and self.dp.world > 1) else "global"
+        mode = "thread_local" if (self.dp is not None and self.dp.active) else "global"
         home = self.model.state_buffers()
         self.model.use_static_states(False)
         self.graphs = []
@@ -311,7 +311,7 @@ class GraphedWindowStep:
             if gi == 1:
                 self.model.final_states_into(home)
             pre, post = torch.cuda.CUDAGraph(), None
-            if self.dp is None or self.dp.world == 1:
+            if self.dp is None or not self.dp.active:
                 with torch.cuda.graph(pre, stream=self.stream, capture_error_mode=mode):
                     loss = train_window(self.model, self.lossf, self.opt, self._passes(), dp=self.dp)
             else:

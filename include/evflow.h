@@ -300,6 +300,10 @@ int evf_conv_dgrad_b3_f32(const float* g_cur, const void* wT_b3, float* g_x, int
  * one-phase-after-the-other LDS kernel, 1 the wave-specialised one (producer / consumer waves, double-buffered planes).
  * Process-wide; for A/B measurements and the equivalence test. */
 int evf_conv_dgrad_select(int which);
+/* Which kernel launches the RECORDED input-gradient cells of a backward index (evf_bwd_defer_*; results are bit-identical):
+ * -1 default (environment EVF_DGRAD_DIAG=lds|ws, else 1), 0 k_dgrad_diag (the LDS kernel's body, one block per tile pair),
+ * 1 k_dgrad_diag_ws (persistent producer / consumer blocks over the flat list of products).  Process-wide. */
+int evf_dgrad_diag_select(int which);
 /* ... and for a recurrent cell both input gradients in one launch: g_x (+)= conv^T(g_cur, W_ff) as above,
  * g_x2 = conv^T(g_cur, W_rec) (written) -- dL/d(previous output spikes), models/spiking_submodules.py:530. */
 int evf_conv_dgrad_b3_f32_pair(const float* g_cur, const void* wT_b3, float* g_x, int accumulate,

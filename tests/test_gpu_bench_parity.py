@@ -266,7 +266,8 @@ def test_config5_plif_at_per_gpu_batch_vs_oracle(scale):
     ora = _oracle_step("PLIFFireNet", snap, passes, (H, W), {"flow_regul_weight": 0.001, "mask_output": True})
     hip = _eager_step(model, EventWarping(lc, DEV), opt, passes)
     rep_o = _check_against_oracle(f"config 5, thresholds x{scale}", hip, ora, H, W)
-    if rep_o["nflip"] == 0:
+    if scale == 1.0 or rep_o["nflip"] == 0:
+        # the configured thresholds: tight bars whatever the flip count says (a flip there is a defect, not a stress artefact)
         assert rep_o["loss_rel"] <= 1e-5 and rep_o["grad_rel"] <= 1e-3 and rep_o["aee_rel"] <= 1e-4, rep_o
     else:
         # x0.25 thresholds: a high-activity stress case.  The handful of round-off ties of the first passes spread through
@@ -382,7 +383,7 @@ def test_config4_evflownet_full_size_vs_oracle(scale):
         grel2 = np.sqrt(num2) / max(np.sqrt(den2), 1e-20)
         print(f"  same upstream gradient through both networks: parameter gradient rel-L2 {grel2:.3e}")
         assert grel2 <= 1e-3, grel2
-    elif nflip <= 1e-6 * ntot:  # a few isolated flips: every flow map is exact except at those pixels
-        assert worst <= 5e-3 and lrel <= 1e-5 and grel <= 1e-3, (worst, lrel, grel)
+    elif scale == 1.0 or nflip <= 1e-6 * ntot:  # configured thresholds (unconditionally), or a few isolated flips: every flow
+        assert worst <= 5e-3 and lrel <= 1e-5 and grel <= 1e-3, (worst, lrel, grel)  # map is exact except at those pixels
     else:  # high-activity stress case (thresholds x0.3): flips spread through 14 layers; loose aggregate bounds only
         assert worst <= 0.5 and lrel <= 1e-3 and grel <= 0.25, (worst, lrel, grel)

@@ -94,6 +94,53 @@ def test_input_gradient_variants_are_bit_identical(shape):
     assert _lib.load().evf_conv_dgrad_select(7) != 0  # bad argument: status, no change
 
 
+@pytest.mark.parametrize("shape", SHAPES + [(3, 20, 96)])
+def test_recorded_input_gradient_cells_are_bit_identical(shape):
+    """The input-gradient cells of a backward index, recorded (evf_bwd_defer_*) and launched together -- through k_dgrad_diag
+    (the LDS kernel's body) and through the persistent wave-specialised k_dgrad_diag_ws (flat product list, DPP-built middle
+    taps) -- against one direct launch per cell: bit-identical outputs.  Several cells per index, one- and two-product
+    cells mixed, two indices, so that block ranges cross product boundaries (weight-set switches inside a block)."""
+    B, H, W = shape
+    torch.manual_seed(5)
+    L = _lib.load()
+    cells = []  # (index, gradient, weight set 1, weight set 2 or None)
+    for d, pair in ((0, False), (0, True), (0, False), (1, True), (1, True), (1, False), (1, False), (1, True)):
+        cells.append((d, _f(B, H, W, C, scale=0.3), _packs()[1], _packs()[1] if pair else None))
+    ref = []
+    for _, g, w1, w2 in cells:
+        a = torch.empty(B, H, W, C, device=DEV)
+        _lib.call("evf_conv_dgrad_b3_f32", P(g), P(w1), P(a), 0, B, H, W, None, None)
+        b = None
+        if w2 is not None:
+            b = torch.empty(B, H, W, C, device=DEV)
+            _lib.call("evf_conv_dgrad_b3_f32", P(g), P(w2), P(b), 0, B, H, W, None, None)
+        ref.append((a, b))
+    try:
+        for which in (0, 1):
+            assert L.evf_dgrad_diag_select(which) == 0
+            outs = [(torch.full((B, H, W, C), 7.0, device=DEV), torch.full((B, H, W, C), 7.0, device=DEV)) for _ in cells]
+            assert L.evf_bwd_defer_begin() == 0
+            try:
+                for (d, g, w1, w2), (a, b) in zip(cells, outs):
+                    assert L.evf_bwd_defer_slot(d) == 0
+                    if w2 is None:
+                        _lib.call("evf_conv_dgrad_b3_f32", P(g), P(w1), P(a), 0, B, H, W, None, None)
+                    else:
+                        _lib.call("evf_conv_dgrad_b3_f32_pair", P(g), P(w1), P(a), 0, P(w2), P(b), B, H, W, None, None)
+                assert L.evf_bwd_defer_pending() == len(cells)
+            finally:
+                _lib.call("evf_bwd_defer_flush")
+            assert L.evf_bwd_defer_pending() == 0
+            torch.cuda.synchronize()
+            for k, ((a, b), (ra, rb)) in enumerate(zip(outs, ref)):
+                assert torch.equal(a, ra), (which, k)
+                if rb is not None:
+                    assert torch.equal(b, rb), (which, k, "second product")
+    finally:
+        L.evf_dgrad_diag_select(-1)
+    assert L.evf_dgrad_diag_select(5) != 0
+
+
 @pytest.mark.parametrize("shape", SHAPES)
 def test_prediction_head_fused_into_its_neighbours(shape):
     """evf_conv_lif_fwd_b3_pred == evf_conv_lif_fwd_b3 + evf_pred_fwd; evf_lif_bwd_wgrad_top == evf_pred_bwd +

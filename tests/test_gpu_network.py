@@ -442,6 +442,117 @@ def test_fused_lif_bwd_wgrad_matches_separate_kernels(rec, shape):
         assert np.abs(N(dw) - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-5, nm
 
 
+@pytest.mark.parametrize("shape", [(2, 24, 40), (1, 13, 70)])
+def test_exact_split_input_gradient_is_fp32_equivalent(shape):
+    """evf_conv_dgrad_b3_f32 (six exact bf16 products of two real operands, three cross terms below 2^-24 dropped; both
+    kernels behind it and the recorded-cell launch) against conv_transpose2d in float64 -- the fp32 `conv2d` input
+    gradient of models/spiking_submodules.py:520,530.  Bound per output element: 4 * 2^-24 * sum |g| |w| (the fp32
+    accumulation round-off of a 288-long sum plus the dropped terms), and the same error class as the exact fp32-MFMA
+    chain (evf_conv_dgrad).  The gradient spans three decades, like dL/d(current) in a trained network."""
+    B, H, W = shape
+    C = 32
+    gen = torch.Generator(device="cpu").manual_seed(21)
+    g = torch.randn(B, C, H, W, generator=gen) * torch.pow(10.0, -3 * torch.rand(B, C, H, W, generator=gen))
+    w = (torch.rand(C, C, 3, 3, generator=gen) * 2 - 1) * 0.2
+    ref = torch.nn.functional.conv_transpose2d(g.double(), w.double(), padding=1)
+    mag = torch.nn.functional.conv_transpose2d(g.double().abs(), w.double().abs(), padding=1)
+    bound = 4 * 2.0 ** -24 * mag
+    gd, wd = g.to(DEV).contiguous(), w.to(DEV).contiguous()
+    g_nhwc = torch.empty(B, H, W, C, device=DEV)
+    _lib.call("evf_nchw_to_nhwc", gd.data_ptr(), B, C, H, W, g_nhwc.data_ptr())
+    p32, pb3 = torch.empty(9216, device=DEV), torch.empty(54 * 1024, dtype=torch.uint8, device=DEV)
+    _lib.call("evf_pack_conv_weight", wd.data_ptr(), C, C, 1, p32.data_ptr())
+    _lib.call("evf_pack_conv_weight_b3t", wd.data_ptr(), C, C, pb3.data_ptr())
+
+    def nchw(t):
+        o = torch.empty(B, C, H, W, device=DEV)
+        _lib.call("evf_nhwc_to_nchw", t.data_ptr(), B, C, H, W, o.data_ptr())
+        return o.cpu().double()
+
+    gx32 = torch.empty(B, H, W, C, device=DEV)
+    _lib.call("evf_conv_dgrad", g_nhwc.data_ptr(), p32.data_ptr(), gx32.data_ptr(), 0, None, None, 0, B, H, W)
+    err32 = (nchw(gx32) - ref).abs()
+    L = _lib.load()
+    outs = []
+    try:
+        for which in (0, 1):
+            assert L.evf_conv_dgrad_select(which) == 0
+            gx = torch.empty(B, H, W, C, device=DEV)
+            _lib.call("evf_conv_dgrad_b3_f32", g_nhwc.data_ptr(), pb3.data_ptr(), gx.data_ptr(), 0, B, H, W, None, None)
+            outs.append(gx)
+    finally:
+        L.evf_conv_dgrad_select(-1)
+    gx = torch.empty(B, H, W, C, device=DEV)  # the recorded-cell launch (k_dgrad_diag_ws)
+    assert L.evf_bwd_defer_begin() == 0
+    try:
+        assert L.evf_bwd_defer_slot(0) == 0
+        _lib.call("evf_conv_dgrad_b3_f32", g_nhwc.data_ptr(), pb3.data_ptr(), gx.data_ptr(), 0, B, H, W, None, None)
+    finally:
+        _lib.call("evf_bwd_defer_flush")
+    outs.append(gx)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    err = (nchw(outs[0]) - ref).abs()
+    worst = float((err / bound.clamp_min(1e-300)).max())
+    print(f"input gradient vs float64: max err / (4 * 2^-24 * sum|g||w|) = {worst:.3f} (exact split), "
+          f"{float((err32 / bound.clamp_min(1e-300)).max()):.3f} (fp32 MFMA); max abs err {float(err.max()):.3e} / {float(err32.max()):.3e}")
+    assert bool((err <= bound + 1e-30).all()), worst
+    assert float(err.max()) <= 3 * float(err32.max()) + 1e-9, (float(err.max()), float(err32.max()))
+
+
+@pytest.mark.parametrize("rec", [False, True])
+def test_exact_split_weight_gradient_is_fp32_equivalent(rec):
+    """The weight-gradient slabs of evf_lif_bwd_wgrad (binary spikes x the exact 3-way bf16 split of g_cur on the bf16 matrix
+    cores) against the float64 correlation of the same operands -- the fp32 `conv2d` weight gradients of
+    models/spiking_submodules.py:520,530.  Bound per weight: 4 * 2^-24 * sum_pix |x| |g_cur| (the products are exact; what is
+    left is the fp32 accumulation over pixels, blocks and slabs), and the same error class as the fp32-MFMA kernel
+    (evf_conv_wgrad_bits) on the same operands."""
+    B, H, W, C = 2, 40, 128, 32
+    gen = torch.Generator(device="cpu").manual_seed(23)
+    R = lambda *s: torch.randn(*s, generator=gen)
+    gz = (R(B, H, W, C) * torch.pow(10.0, -2 * torch.rand(B, H, W, C, generator=gen))).to(DEV)
+    gv, vo, vp = (R(B, H, W, C) * 0.5).to(DEV), (R(B, H, W, C) * 0.5 + 0.6).to(DEV), (R(B, H, W, C) * 0.5).to(DEV)
+    xb = (torch.rand(B, C, H, W, generator=gen) < 0.3).float()
+    zb = (torch.rand(B, C, H, W, generator=gen) < 0.2).float()
+    leak, thresh = (R(C) * 0.1 - 4).to(DEV), (R(C) * 0.1 + 0.8).to(DEV)
+    xbits, zbits = (torch.empty(B, H, W, dtype=torch.int32, device=DEV) for _ in range(2))
+    xbd, zbd = xb.to(DEV), zb.to(DEV)
+    _lib.call("evf_nchw_to_bits", xbd.data_ptr(), B, H, W, xbits.data_ptr())
+    _lib.call("evf_nchw_to_bits", zbd.data_ptr(), B, H, W, zbits.data_ptr())
+    nW = (W + 31) // 32
+    xT, zT = (torch.empty(B, H, C, nW, dtype=torch.int32, device=DEV) for _ in range(2))
+    _lib.call("evf_bits_transpose", xbits.data_ptr(), B, H, W, xT.data_ptr())
+    _lib.call("evf_bits_transpose", zbits.data_ptr(), B, H, W, zT.data_ptr())
+    lib = _lib.load()
+    gc, gp = torch.empty(B, H, W, C, device=DEV), torch.empty(B, H, W, C, device=DEV)
+    gl, gt = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ns = lib.evf_lif_bwd_wgrad_slabs(B, H, W)
+    s_ff, s_rec = torch.empty(ns, 9216, device=DEV), torch.empty(ns, 9216, device=DEV)
+    _lib.call("evf_lif_bwd_wgrad", gz.data_ptr(), gv.data_ptr(), vo.data_ptr(), vp.data_ptr(), zbits.data_ptr(), xT.data_ptr(),
+              zT.data_ptr() if rec else None, leak.data_ptr(), thresh.data_ptr(), B, H, W, 1, 0, 10.0, gc.data_ptr(), None,
+              gp.data_ptr(), gl.data_ptr(), gt.data_ptr(), s_ff.data_ptr(), s_rec.data_ptr() if rec else None, 0)
+    g_nchw = torch.empty(B, C, H, W, device=DEV)
+    _lib.call("evf_nhwc_to_nchw", gc.data_ptr(), B, C, H, W, g_nchw.data_ptr())
+    gd = g_nchw.cpu().double()
+    ns0 = lib.evf_conv_wgrad_slabs(B, H, W)
+    for nm, slab, bits, x in (("ff", s_ff, xbits, xb),) + ((("rec", s_rec, zbits, zb),) if rec else ()):
+        ref = torch.nn.grad.conv2d_weight(x.double(), (C, C, 3, 3), gd, padding=1)
+        mag = torch.nn.grad.conv2d_weight(x.double(), (C, C, 3, 3), gd.abs(), padding=1)
+        dw = torch.zeros(C, C, 3, 3, device=DEV)
+        _lib.call("evf_reduce_slabs", slab.data_ptr(), ns, 9216, 0, dw.data_ptr())
+        s32 = torch.empty(ns0, 9216, device=DEV)
+        _lib.call("evf_conv_wgrad_bits", bits.data_ptr(), gc.data_ptr(), B, H, W, s32.data_ptr(), 0)
+        dw32 = torch.zeros(C, C, 3, 3, device=DEV)
+        _lib.call("evf_reduce_slabs", s32.data_ptr(), ns0, 9216, 0, dw32.data_ptr())
+        err, err32 = (dw.cpu().double() - ref).abs(), (dw32.cpu().double() - ref).abs()
+        bound = 4 * 2.0 ** -24 * mag
+        worst = float((err / bound.clamp_min(1e-300)).max())
+        print(f"dW_{nm} vs float64: max err / (4 * 2^-24 * sum|x||g|) = {worst:.3f} (exact split), "
+              f"{float((err32 / bound.clamp_min(1e-300)).max()):.3f} (fp32 MFMA); rel-L2 {float(err.norm() / ref.norm()):.2e} / "
+              f"{float(err32.norm() / ref.norm()):.2e}")
+        assert bool((err <= bound + 1e-30).all()), (nm, worst)
+        assert float(err.norm()) <= 3 * float(err32.norm()) + 1e-12, nm
+
+
 def test_hipgraph_replay_equals_eager_steps():
     """bench.py replays the whole train step (binning -> passes -> loss -> backward -> clip+Adam) from a
     hipGraph: the Adam step counter lives on the device and the recurrent state in static buffers.  Four steps

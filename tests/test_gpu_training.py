@@ -148,6 +148,44 @@ def test_bench_data_parallel_step_two_ranks_graph_equals_eager():
     assert lg == lg and abs(lg - le) <= 2e-3 * abs(le), (lg, le)
 
 
+def _bench_rccl_one_rank(extra, port):
+    """bench.py under torch.distributed.run with ONE rank and EVF_DP_FORCE=1: backend "nccl" (= RCCL) on the one GPU."""
+    env = dict(os.environ, EVF_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "EVF_DP_BACKEND", "EVF_BENCH_SINGLE_DEVICE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-iwe", "--no-others"] + extra,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_rccl_code_path_on_one_rank_graph_equals_eager_and_plain_step():
+    """The code the multi-GPU run takes, on the one GPU there is: DataParallel(backend="nccl") initialised with device_id,
+    the step as TWO hipGraphs (thread_local capture) with the RCCL all-reduce launched eagerly between them,
+    barrier(device_ids), max_over_ranks -- forced at world size 1 (EVF_DP_FORCE=1).  A one-rank SUM all-reduce is the
+    identity, so the loss after the same number of updates must equal the plain one-GPU run's (graph and eager)."""
+    g = _bench_rccl_one_rank([], 29631)
+    e = _bench_rccl_one_rank(["--no-graph", "--warmup", "4"], 29632)  # graph mode adds 2 replay warm-up steps: same 8 updates
+    col = g["config"]["collective"]
+    assert col["backend"] == "nccl" and col["library"].startswith("RCCL") and col["ranks"] == 1 and col["forced_at_one_rank"], col
+    assert g["config"]["launch"] == "hipgraph" and e["config"]["launch"] == "eager", (g["config"], e["config"])
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "EVF_DP_FORCE", "EVF_DP_BACKEND"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-iwe",
+                          "--no-others"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    p = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert p["config"]["collective"]["ranks"] == 1 and not p["config"]["collective"].get("forced_at_one_rank"), p["config"]
+    lg, le, lp = g["config"]["loss"], e["config"]["loss"], p["config"]["loss"]
+    print("loss: rccl graph", lg, "rccl eager", le, "plain", lp)
+    assert lg == lg and abs(lg - le) <= 2e-3 * abs(le) and abs(lg - lp) <= 2e-3 * abs(lp), (lg, le, lp)
+
+
 def test_bench_starts_its_own_ranks_without_a_launcher():
     """`python bench.py --gpus 2` with WORLD_SIZE unset (how the driver invokes it) re-executes itself under
     torch.distributed.run with one rank per GPU and prints ONE JSON line with n_gpus = 2."""
