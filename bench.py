@@ -742,6 +742,7 @@ def main():
         hbm_bound |= {"evf_cm_loss_fwd", "evf_cm_loss_bwd"}
         # diagonal launches: PASSES + 5 launches hold the window's cells; per LAUNCH = the window's total / (PASSES + 5)
         nl = PASSES + 5
+        alt_bytes = {}
         if diag_fwd:  # 6 hidden cells per pass (8 contractions: two recurrent cells), 272 B/px each, 280 under the prediction head
             model[("k_fwd_diag", "")] = (8 * PASSES * CONV_FLOP * npix / nl, PASSES * (5 * 272 + 280) * npix / nl)
             hbm_bound |= {"k_fwd_diag"}
@@ -750,10 +751,20 @@ def main():
             # fused-backward cells: per pass 3 feed-forward cells (776 B/px), the top one (668), 2 recurrent ones (780; 908 with the
             # second gradient part: every pass but the last; in the first pass they have no previous state: 904)
             by_b = (3 * PASSES * 776 + PASSES * 668 + 2 * ((PASSES - 2) * 908 + 780 + 904)) * npix
-            model[("k_bwd_diag", "")] = (8 * PASSES * CONV_FLOP * npix / nl, by_b / nl)
             # input-gradient cells: per pass 4 with one weight set (256 B/px) and 2 with two (384); all six single in the first pass
             by_d = ((PASSES - 1) * (4 * 256 + 2 * 384) + 6 * 256) * npix
+            by_b32, by_d32 = by_b, by_d
+            from event_flow_amd.models import engine as _eng
+
+            if _eng.SPLIT_DGRAD:
+                # dL/d(current) travels as its exact 3-way bf16 split (three planes, 192 B/px) instead of the fp32 tensor (128): the
+                # fused backward writes +64 B/px per cell, the input gradient reads +64 B/px per cell (k_dgrad_diag_dma stages the
+                # planes by LDS-DMA).  `frac_fp32_layout` below prices the same launch with the fp32 layout's bytes.
+                by_b += 6 * PASSES * 64 * npix
+                by_d += 6 * PASSES * 64 * npix
+            model[("k_bwd_diag", "")] = (8 * PASSES * CONV_FLOP * npix / nl, by_b / nl)
             model[("k_dgrad_diag", "")] = ((8 * (PASSES - 1) + 6) * CONV_FLOP * npix / nl, by_d / nl)
+            alt_bytes = {"k_bwd_diag": by_b32 / nl, "k_dgrad_diag": by_d32 / nl}
             hbm_bound |= {"k_bwd_diag", "k_dgrad_diag"}
             bf16_terms["k_bwd_diag"] = 3
             bf16_terms["k_dgrad_diag"] = 6
@@ -784,6 +795,9 @@ def main():
             if key[0] in ("evf_cm_loss_fwd", "evf_cm_loss_bwd"):
                 ent["note"] = ("one call = 5 (forward) / 3 (backward) launches over the window's events and its 8 warped-event images: "
                                "latency of dependent launches at this size, not a bandwidth figure")
+            if diag_bwd and key[0] in alt_bytes and alt_bytes[key[0]] != model[key][1]:
+                ent["algorithmic_MB_fp32_layout"] = alt_bytes[key[0]] / 1e6
+                ent["frac_fp32_layout"] = alt_bytes[key[0]] / (ms.mean() * 1e-3) / 1e9 / HBM_PEAK
             if key[0] in ("k_fwd_diag", "k_bwd_diag", "k_dgrad_diag"):
                 ent["note"] = (f"diagonal launches: the window's {6 * PASSES} cells of this kind in {nl} launches of 1..6 independent "
                                "(pass, layer) cells; mean_us / algorithmic_MB are per LAUNCH (window total / launches)")

@@ -544,7 +544,8 @@ struct FbJob {
   const float4 *g_z, *g_z2, *g_v, *v_out, *v_prev;
   const uint32_t *z_prev, *xT, *zT;
   const float *leak, *thresh;
-  float4* g_cur;
+  float4* g_cur;   // fp32 dL/d(current) (NULL when only the split planes are wanted)
+  uint2* g_split;  // its exact 3-way bf16 split as three planes [term][pix][32] (NULL: not written) -- what k_dgrad_diag_dma reads
   float4* g_v_prev;
   float *g_leak, *g_thresh, *slab_ff, *slab_rec;
   FbTop top;
@@ -562,15 +563,15 @@ __global__ __launch_bounds__(FB_THREADS) void k_bwd_diag(FbJobs jobs, int B, int
   const FbJob& J = jobs.j[jb];
   if (J.kind == 1)
     fb_body<true, false, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
-                               nchunk, nunits, 1, EVF_ARCTAN, J.width, J.accumulate, J.g_cur, nullptr, J.g_v_prev, J.g_leak,
+                               nchunk, nunits, 1, EVF_ARCTAN, J.width, J.accumulate, J.g_cur, J.g_split, J.g_v_prev, J.g_leak,
                                J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld);
   else if (J.kind == 2)
     fb_body<false, true, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
-                               nchunk, nunits, 1, EVF_ARCTAN, J.width, J.accumulate, J.g_cur, nullptr, J.g_v_prev, J.g_leak,
+                               nchunk, nunits, 1, EVF_ARCTAN, J.width, J.accumulate, J.g_cur, J.g_split, J.g_v_prev, J.g_leak,
                                J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld);
   else
     fb_body<false, false, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
-                                nchunk, nunits, 1, EVF_ARCTAN, J.width, J.accumulate, J.g_cur, nullptr, J.g_v_prev, J.g_leak,
+                                nchunk, nunits, 1, EVF_ARCTAN, J.width, J.accumulate, J.g_cur, J.g_split, J.g_v_prev, J.g_leak,
                                 J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld);
 }
 
@@ -706,11 +707,11 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
     bool any = false;
     for (int d = 0; d < EVF_BWD_DIAGS && !any; ++d) any = fb_defer.n[d] != 0;
     const bool same = !any || (fb_defer.B == B && fb_defer.H == H && fb_defer.W == W && fb_defer.row_ld == row_ld);
-    if (fast && g_cur && !g_split && same && fb_defer.n[evf_bwd_defer.slot] < FB_MAX_JOBS) {
+    if (fast && (g_cur || g_split) && same && fb_defer.n[evf_bwd_defer.slot] < FB_MAX_JOBS) {
       fb_defer.B = B, fb_defer.H = H, fb_defer.W = W, fb_defer.row_ld = row_ld;
       FbJob& J = fb_defer.job[evf_bwd_defer.slot][fb_defer.n[evf_bwd_defer.slot]++];
       J = FbJob{(const float4*)g_z_out, (const float4*)g_z_out2, (const float4*)g_v_out, (const float4*)v_out,
-                (const float4*)v_prev, z_prev, xT, zT_prev, leak, thresh, (float4*)g_cur, (float4*)g_v_prev, g_leak, g_thresh,
+                (const float4*)v_prev, z_prev, xT, zT_prev, leak, thresh, (float4*)g_cur, (uint2*)g_split, (float4*)g_v_prev, g_leak, g_thresh,
                 slab_ff, slab_rec, top, act_width, accumulate, topp ? 2 : (zT_prev ? 1 : 0), 0};
       return EVF_OK;
     }

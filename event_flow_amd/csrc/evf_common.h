@@ -77,7 +77,7 @@ int evf_dgrad_ws_launch(const float* g_cur, const void* wT_b3, float* g_x, int a
 // output) in one persistent wave-specialised launch (k_dgrad_diag_ws)
 #define EVF_DG_MAX_PROD 16
 struct EvfDgProd {
-  const void* g;   // fp32 gradient [B,H,W,32]
+  const void* g;   // fp32 gradient [B,H,W,32] (k_dgrad_diag_ws) / its three bf16 planes [term][B,H,W,32] (k_dgrad_diag_dma)
   const void* wt;  // split transposed weights (evf_pack_conv_weight_b3t)
   float* gx;       // [B,H,W,32], written
 };
@@ -85,6 +85,8 @@ struct EvfDgProds {
   EvfDgProd p[EVF_DG_MAX_PROD];
 };
 int evf_dgrad_diag_ws_launch(const EvfDgProds& P, int nprod, int B, int H, int W, void* stream);
+// ... and with the gradient pre-split in HBM (three bf16 planes [term][B,H,W,32]): LDS-DMA fed, one wave per SIMD (k_dgrad_diag_dma)
+int evf_dgrad_diag_dma_launch(const EvfDgProds& P, int nprod, int B, int H, int W, void* stream);
 
 // Deferred backward cells (evf_bwd_defer_*, owner: evf_bwd_fused.hip): while `active`, the fused backward, the fp32 input
 // gradient and the head backward of the default-neuron FireNet path RECORD their launch under index `slot`; the flush

@@ -291,11 +291,12 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_conv_dgrad_b3_lds(const uint4*
 // gradient form without accumulation, one or two weight sets per cell.  blockIdx.z = cell * zb + first sample.
 #define DG_MAX_JOBS 8
 struct DgJob {
-  const uint4* gs;
+  const uint4* gs;   // fp32 g_cur [B,H,W,32], or (split) the three bf16 planes [term][B,H,W,32]
   const uint4* wt;
   float* gx;
   const uint4* wt2;  // NULL: one weight set
   float* gx2;
+  int split;         // the gradient arrives pre-split (evf_conv_dgrad_b3[_pair]): launched by k_dgrad_diag_dma
 };
 struct DgJobs {
   DgJob j[DG_MAX_JOBS];
@@ -310,10 +311,10 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_dgrad_diag(DgJobs jobs, int B,
 }
 
 static struct {
-  int B, H, W;
+  int B, H, W, split;
   int n[EVF_BWD_DIAGS];
   DgJob job[EVF_BWD_DIAGS][DG_MAX_JOBS];
-} dg_defer = {0, 0, 0, {0}, {}};
+} dg_defer = {0, 0, 0, 0, {0}, {}};
 
 static int dg_zb(int B, int H, int W) {  // samples per block column, as in dg_launch
   const long tiles = (long)evf_cdiv(W, 32) * evf_cdiv(H, DG_ROWS);
@@ -347,7 +348,7 @@ int evf_dg_defer_launch(int d, void* stream) {
     const char* e = getenv("EVF_DGRAD_DIAG");
     return !(e && e[0] == 'l');
   }();
-  if (dg_diag_select < 0 ? env_ws : dg_diag_select == 1) {
+  if (dg_defer.split || (dg_diag_select < 0 ? env_ws : dg_diag_select == 1)) {
     EvfDgProds P;
     int np = 0;
     for (int k = 0; k < n; ++k) {
@@ -357,7 +358,8 @@ int evf_dg_defer_launch(int d, void* stream) {
     }
     for (int k = np; k < EVF_DG_MAX_PROD; ++k) P.p[k] = P.p[0];
     evf_prof_mark(2, 0, stream);
-    const int rc = evf_dgrad_diag_ws_launch(P, np, dg_defer.B, dg_defer.H, dg_defer.W, stream);
+    const int rc = dg_defer.split ? evf_dgrad_diag_dma_launch(P, np, dg_defer.B, dg_defer.H, dg_defer.W, stream)
+                                  : evf_dgrad_diag_ws_launch(P, np, dg_defer.B, dg_defer.H, dg_defer.W, stream);
     evf_prof_mark(2, 1, stream);
     dg_defer.n[d] = 0;
     return rc;
@@ -398,11 +400,12 @@ static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, in
   // evf_conv_dgrad_select() / EVF_DGRAD=lds|ws override the choice (A/B measurements, the equivalence test).
   if (evf_bwd_defer.active) {  // a recording is open: record the cell (any size: the persistent launch of evf_dgrad_diag.hip) ...
     const bool any = evf_dg_defer_count() != 0;
-    const bool same = !any || (dg_defer.B == B && dg_defer.H == H && dg_defer.W == W);
-    if (f32in && !accumulate && !g_P && same && dg_defer.n[evf_bwd_defer.slot] < DG_MAX_JOBS) {
-      dg_defer.B = B, dg_defer.H = H, dg_defer.W = W;
+    const int split = f32in ? 0 : 1;  // (one kind per recording: the two are launched by different kernels)
+    const bool same = !any || (dg_defer.B == B && dg_defer.H == H && dg_defer.W == W && dg_defer.split == split);
+    if (!accumulate && !g_P && same && dg_defer.n[evf_bwd_defer.slot] < DG_MAX_JOBS) {
+      dg_defer.B = B, dg_defer.H = H, dg_defer.W = W, dg_defer.split = split;
       dg_defer.job[evf_bwd_defer.slot][dg_defer.n[evf_bwd_defer.slot]++] =
-          DgJob{(const uint4*)g, (const uint4*)wT_b3, g_x, (const uint4*)wT2_b3, g_x2};
+          DgJob{(const uint4*)g, (const uint4*)wT_b3, g_x, (const uint4*)wT2_b3, g_x2, split};
       return EVF_OK;
     }
     const int rc = evf_bwd_defer_flush_now(stream);  // ... or, not recordable: everything recorded runs first
@@ -475,6 +478,13 @@ static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, in
 extern "C" int evf_conv_dgrad_b3(const void* g_split, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W,
                                  const float* g_P, const uint32_t* x_bits, void* stream) {
   return dg_launch(g_split, 0, wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, nullptr, nullptr, stream);
+}
+
+// ... and both input gradients of a recurrent cell from the pre-split planes (see evf_conv_dgrad_b3_f32_pair)
+extern "C" int evf_conv_dgrad_b3_pair(const void* g_split, const void* wT_b3, float* g_x, int accumulate, const void* wT2_b3,
+                                      float* g_x2, int B, int H, int W, const float* g_P, const uint32_t* x_bits, void* stream) {
+  if (!wT2_b3 || !g_x2) return EVF_EINVAL;
+  return dg_launch(g_split, 0, wT_b3, g_x, accumulate, B, H, W, g_P, x_bits, wT2_b3, g_x2, stream);
 }
 
 // the same from the fp32 gradient g_cur [B,H,W,32]: split on the fly, bit-identical result

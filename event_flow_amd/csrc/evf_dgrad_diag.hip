@@ -22,6 +22,7 @@
 #include "evf_dgrad_mma.h"
 #include "evf_split.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void wd_lds_void;
@@ -232,6 +233,258 @@ __global__ __launch_bounds__(512) void k_dgrad_diag_ws(EvfDgProds P, int H, int 
     }
   }
   WD_STAMP();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_dgrad_diag_dma: the same flat (product, tile) list, gradient PRE-SPLIT in HBM.
+//
+// What the stamps of k_dgrad_diag_ws said (6 products, 24 items per block; cycles per item): consumers 4.4 k matrix phase +
+// 1.3 k epilogue + 0.7 k barrier, producers 1-2 k fetch issue + 4-4.5 k split: the producer wave of a SIMD needs ~550
+// instructions per item for addresses and the exact split, the consumer wave ~350, and a SIMD issues ONE vector instruction
+// per 4 cycles -- the two teams take each other's issue slots, and the matrix pipe idles during the epilogue and the barrier.
+// The split is free in the kernel that makes g_cur (evf_lif_bwd_wgrad has it in registers for its own weight gradient and
+// can write the three bf16 planes, `g_split`): with the planes in HBM this kernel needs no VALU work to stage a tile --
+// the halo comes in by LDS-DMA (global_load_lds_dwordx4, no VGPRs, source address per lane: out-of-image pixels read a
+// page of zeros), issued by the four waves themselves BETWEEN their MFMAs.
+//
+//   4 waves (one per SIMD, up to 512 VGPRs each), wave w = row w of the 4-row x 32-pixel tile;
+//   item k: [behind the MFMAs: DMA pieces of item k+1 into the other buffer; epilogue of item k-1 from registers]
+//           108 MFMAs, the two accumulators alternating (dg_matrix_phase3) -> s_waitcnt vmcnt(0) -> ONE barrier.
+// ---------------------------------------------------------------------------------------------------------------------
+#define WM_UPP 13                  // 16-pixel DMA units per plane (208 pixel slots, 204 used)
+#define WM_PLANE (WM_UPP * 64)     // uint4 per plane
+#define WM_BUF (3 * WM_PLANE)      // uint4 per halo buffer
+#define WM_NU (3 * WM_UPP)         // DMA pieces per item
+#define WM_NJ ((WM_NU + 3) / 4)    // pieces per wave
+#define WM_LDS ((size_t)(WD_NFRAG * 64 + 2 * WM_BUF) * sizeof(uint4) + (size_t)4 * 32 * WD_SP * 4)
+#ifndef WM_PIPE
+#define WM_PIPE 1  // the epilogue of item k-1 behind the MFMAs of item k (0: after the item's own matrix phase)
+#endif
+
+__device__ uint4 wm_zero_page[16];  // 256 bytes of zeros: the DMA source of out-of-image halo pixels
+
+#ifdef WD_STAMPS
+__device__ unsigned long long wm_stamps[16 * 4 * 128];
+extern "C" int evf_debug_wm_stamps(void* dst) { return evf_hip(hipMemcpyFromSymbol(dst, HIP_SYMBOL(wm_stamps), sizeof(wm_stamps))); }
+#define WM_STAMP()                                                                              \
+  do {                                                                                          \
+    if (blockIdx.x < 16 && lane == 0 && (wv & 3) == 0 && nst < 128)                             \
+      wm_stamps[(blockIdx.x * 4 + (wv >> 2)) * 128 + nst++] = __builtin_readcyclecounter();     \
+  } while (0)
+#else
+#define WM_STAMP() do {} while (0)
+#endif
+
+struct WmTile {
+  int prod, b, y0, x0;
+  const char* g;  // the product's gradient planes / output: scalar loads at item_of time, outside the matrix phase (a load
+  float* gx;      // from the argument table behind an MFMA would wait for lgkmcnt(0), i.e. for every operand read in flight)
+};
+
+template <bool FULL>  // FULL: H % 4 == 0 and W % 32 == 0 -- every output pixel of every tile exists, the stores need no test
+__global__ __launch_bounds__(512) void k_dgrad_diag_dma(EvfDgProds P, unsigned plane_bytes, int H, int W, int ntx, int nty,
+                                                        unsigned ntiles, unsigned total) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint4* s_w = (uint4*)smem_raw;     // [54][64]
+  uint4* s_a = s_w + WD_NFRAG * 64;  // [2][3][WM_UPP * 16 pixels][4], chunk c of pixel p in slot c ^ ((p >> 2) & 3)
+  float* s_stage = (float*)(s_a + 2 * WM_BUF);  // [4 waves][32 pixels][WD_SP]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = lane & 31, kg = lane >> 5;
+  int nst = 0;
+  (void)nst;
+  WM_STAMP();
+  const unsigned lo = (unsigned)(((unsigned long long)blockIdx.x * total) / gridDim.x);
+  const unsigned hi = (unsigned)(((unsigned long long)(blockIdx.x + 1) * total) / gridDim.x);
+  const int nitem = (int)(hi - lo);
+  if (nitem <= 0) return;
+  const float rnt = 1.0f / (float)ntiles, rntx = 1.0f / (float)ntx, rnty = 1.0f / (float)nty;
+  auto divmod = [](unsigned n, unsigned d, float rd, unsigned& q, unsigned& r) {  // exact for n < 2^22
+    q = (unsigned)((float)n * rd);
+    int rr = (int)n - (int)(q * d);
+    if (rr < 0) --q, rr += (int)d;
+    if (rr >= (int)d) ++q, rr -= (int)d;
+    r = (unsigned)rr;
+  };
+  auto item_of = [&](int k, WmTile& t) {  // (past the end: the last item again -- its DMA is issued and never used)
+    const unsigned id = lo + (unsigned)min(k, nitem - 1);
+    unsigned pr, tl, r, tx, b, ty;
+    divmod(id, ntiles, rnt, pr, tl);
+    divmod(tl, (unsigned)ntx, rntx, r, tx);
+    divmod(r, (unsigned)nty, rnty, b, ty);
+    t.prod = __builtin_amdgcn_readfirstlane((int)pr), t.x0 = __builtin_amdgcn_readfirstlane((int)tx * 32);
+    t.b = __builtin_amdgcn_readfirstlane((int)b), t.y0 = __builtin_amdgcn_readfirstlane((int)ty * WD_ROWS);
+    t.g = (const char*)P.p[t.prod].g, t.gx = P.p[t.prod].gx;
+  };
+  auto load_weights4 = [&](const uint4* src) {  // the four loader waves
+    for (int u = wv - 4; u < WD_NFRAG; u += 4)
+      __builtin_amdgcn_global_load_lds((wd_glb_void*)(src + u * 64 + lane), (wd_lds_void*)(s_w + u * 64), 16, 0, 0);
+  };
+  // a loader wave's DMA pieces: piece q = (wv - 4) + 4 j covers plane q / 13, pixels 16 u .. 16 u + 15 (u = q % 13); tile independent:
+  // halo row / column of this lane's pixel, the byte offset of its 16-byte chunk inside the plane, the LDS unit.  The 40th
+  // piece (wave 3, j = 9) repeats piece 38: same bytes to the same unit, so that no piece sits under a branch.
+  int p_hr[WM_NJ], p_hc[WM_NJ], p_lds[WM_NJ];
+  unsigned p_off[WM_NJ];
+#pragma unroll
+  for (int j = 0; j < WM_NJ; ++j) {
+    const int q = min((wv & 3) + 4 * j, WM_NU - 1), pl = q / WM_UPP, u = q - pl * WM_UPP;
+    const int p = 16 * u + (lane >> 2), pc = min(p, WD_HP - 1);
+    p_hr[j] = pc / WD_HW, p_hc[j] = pc - p_hr[j] * WD_HW;
+    p_off[j] = (unsigned)pl * plane_bytes + (unsigned)(((lane & 3) ^ ((p >> 2) & 3)) * 16);
+    p_lds[j] = __builtin_amdgcn_readfirstlane(pl * WM_PLANE + u * 64);
+  }
+  const char* zero_page = (const char*)wm_zero_page + (lane & 3) * 16;
+  auto dma_piece = [&](int j, const WmTile& t, int buf) {  // (j: compile-time after unrolling)
+    // ~10 VALU instructions, no branch: 32-bit offset arithmetic (the launcher bounds 3 planes below 4 GiB), bitwise select
+    const int y = t.y0 - 1 + p_hr[j], x = t.x0 - 1 + p_hc[j];
+    const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    const unsigned off = ((unsigned)(t.b * H + y) * (unsigned)W + (unsigned)x) * 64u + p_off[j];
+    const unsigned long long m = in ? ~0ull : 0ull;
+    const unsigned long long a = (((unsigned long long)t.g + off) & m) | ((unsigned long long)zero_page & ~m);
+    __builtin_amdgcn_global_load_lds((wd_glb_void*)a, (wd_lds_void*)(s_a + buf * WM_BUF + p_lds[j]), 16, 0, 0);
+  };
+  float* st = s_stage + (wv & 3) * (32 * WD_SP);
+  // epilogue through the wave-private LDS tile [32 pixels][32 channels] (144-byte pixel pitch): the MFMA layout gives a lane
+  // 4 x 16 bytes of its pixel's line; read back as 8 pixels x 128 bytes per instruction the wave stores FULL lines,
+  // non-temporal.  In parts, so that it can ride behind another item's MFMAs.
+  auto epi_write = [&](const f32x16& a) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *(float4*)(st + i * WD_SP + 8 * q + 4 * kg) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  };
+  float4 ev[4];  // the tile read back row-wise: 8 pixels x 128 bytes per instruction
+  auto epi_read = [&](int r) {
+    const int p = 8 * r + (lane >> 3), c4 = (lane & 7) * 4;
+    ev[r] = *(const float4*)(st + p * WD_SP + c4);
+  };
+  auto epi_store = [&](int r, const WmTile& t) {
+    const int y = t.y0 + wv;
+    const int p = 8 * r + (lane >> 3), c4 = (lane & 7) * 4;
+    float* dst = t.gx + ((unsigned)((t.b * H + y) * W + t.x0 + p) * (unsigned)C32 + (unsigned)c4);
+    if (FULL || (y < H && t.x0 + p < W)) evf_store_nt(dst, ev[r]);
+  };
+  // Two teams, SEPARATE loops with the same barrier sequence (one per item, one more at a product boundary):
+  //   waves 0..3  matrix waves, one per SIMD: 108 MFMAs of row w of the tile; behind them the epilogue of the previous item;
+  //   waves 4..7  loader waves, one per SIMD: the 39 LDS-DMA pieces of the NEXT item into the other buffer (last read during
+  //               item k - 1: every wave is past that barrier), `s_waitcnt vmcnt(0)`, barrier.
+  // tools/probes/mma_probe.hip (cycles per 108-MFMA phase, one wave per SIMD, 1.77 GHz under this load): bare MFMAs 3.68 k;
+  // + the 90 operand reads and the DPP moves 4.15 k; + the epilogue 4.48 k; + 10 DMA pieces issued by the SAME wave 6.2 k --
+  // a piece costs its issuing wave 130-160 cycles (45 among bare MFMAs), and a wave issues in order, so the pieces must come
+  // from waves that have nothing else to do.
+  WmTile cur, nxt, prv;
+  int wprod;
+  const bool loader = wv >= 4;
+  item_of(0, cur);
+  wprod = cur.prod;
+  if (loader) {
+#ifndef WM_NOPRIO
+    __builtin_amdgcn_s_setprio(3);  // (a few hundred instructions per item: ahead of the MFMA wave of the SIMD in the arbitration)
+#endif
+    load_weights4((const uint4*)P.p[wprod].wt);
+#pragma unroll
+    for (int j = 0; j < WM_NJ; ++j) dma_piece(j, cur, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WM_STAMP();
+    __syncthreads();
+    for (int k = 0; k < nitem; ++k) {
+      WM_STAMP();
+      item_of(k + 1, nxt);  // (past the end: the last item again, never used)
+#pragma unroll
+      for (int j = 0; j < WM_NJ; ++j) dma_piece(j, nxt, (k + 1) & 1);
+      WM_STAMP();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      WM_STAMP();
+      __syncthreads();
+      if (k + 1 < nitem && nxt.prod != wprod) {  // (block-uniform) next product: every matrix wave is done with the old weights
+        wprod = nxt.prod;
+        load_weights4((const uint4*)P.p[wprod].wt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    }
+  } else {
+    f32x16 acc_prev = {0};
+    auto run_item = [&](int k, auto epi_tag) {
+      constexpr bool EPI = decltype(epi_tag)::value;
+      WM_STAMP();
+      auto side = [&](int slot) {
+        if (slot == 70) item_of(k + 1, nxt);  // (~60 scalar-ish instructions: behind an MFMA, not between the barrier and the first one)
+        if (EPI) {
+          // accumulators -> LDS tile right away, read back a few MFMAs later (the LDS pipe is in order: these reads then sit
+          // BEHIND this tap's operand reads and cost no extra wait), stored one line group at a time far behind that
+          if (slot == 1) epi_write(acc_prev);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (slot == 13 + r) epi_read(r);
+            if (slot == 40 + 12 * r) epi_store(r, prv);
+          }
+        }
+      };
+      const f32x16 acc = dg_matrix_phase3<WD_DPPX != 0>(s_w, s_a + (k & 1) * WM_BUF, WM_PLANE, wv * WD_HW + i, lane, side);
+      WM_STAMP();
+      if (!WM_PIPE) {
+        epi_write(acc);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) epi_read(r);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) epi_store(r, cur);
+        __builtin_amdgcn_wave_barrier();
+      }
+      acc_prev = acc;
+      prv = cur;
+      WM_STAMP();
+      __syncthreads();
+      if (k + 1 < nitem && nxt.prod != wprod) {
+        wprod = nxt.prod;
+        __syncthreads();
+      }
+      cur = nxt;
+    };
+    WM_STAMP();
+    __syncthreads();
+    prv = cur;
+    run_item(0, std::false_type{});
+    for (int k = 1; k < nitem; ++k) run_item(k, std::integral_constant<bool, WM_PIPE != 0>{});
+    if (WM_PIPE) {  // the last item's epilogue
+      epi_write(acc_prev);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) epi_read(r);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) epi_store(r, prv);
+    }
+  }
+  WM_STAMP();
+}
+
+int evf_dgrad_diag_dma_launch(const EvfDgProds& P, int nprod, int B, int H, int W, void* stream) {
+  if (nprod <= 0 || nprod > EVF_DG_MAX_PROD || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  const int ntx = evf_cdiv(W, 32), nty = evf_cdiv(H, WD_ROWS);
+  const long ntiles = (long)ntx * nty * B, total = ntiles * nprod;
+  const long plane_bytes = (long)B * H * W * 64;
+  if (total >= (1L << 22) || 3 * plane_bytes >= (1L << 32) || (long)B * H * W * C32 >= (1L << 30)) return EVF_EINVAL;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+  }
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_dgrad_diag_dma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WM_LDS);
+    (void)hipFuncSetAttribute((const void*)k_dgrad_diag_dma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WM_LDS);
+    attr = true;
+  }
+  const int nblk = (int)(total < ncu ? total : ncu);
+  if (H % WD_ROWS == 0 && W % 32 == 0)
+    hipLaunchKernelGGL(k_dgrad_diag_dma<true>, dim3(nblk), dim3(512), WM_LDS, EVF_STREAM(stream), P, (unsigned)plane_bytes, H, W, ntx,
+                       nty, (unsigned)ntiles, (unsigned)total);
+  else
+    hipLaunchKernelGGL(k_dgrad_diag_dma<false>, dim3(nblk), dim3(512), WM_LDS, EVF_STREAM(stream), P, (unsigned)plane_bytes, H, W, ntx,
+                       nty, (unsigned)ntiles, (unsigned)total);
+  return evf_status();
 }
 
 // (internal: reached through evf_dg_defer_launch in evf_dgrad_b3.hip)

@@ -211,3 +211,97 @@ __device__ __forceinline__ dgm_f32x16 dg_matrix_phase2(const uint4* __restrict__
   }
   return acc[0] + acc[1];
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Third form (k_dgrad_diag_dma, evf_dgrad_diag.hip: ONE wave per SIMD, operands brought in by LDS-DMA, no producer team).
+// Same 108 products, same order per accumulator (bit-identical results), but the two accumulators now ALTERNATE MFMA by
+// MFMA: acc0 takes the m = 0 half of a tap, acc1 the m = 1 half, and consecutive matrix instructions never depend on each
+// other.  (A 6-long chain on one accumulator costs ~40 instead of 32 cycles per 32x32x16 MFMA when the wave has the SIMD's
+// matrix pipe to itself: phase stamps of the two earlier forms, 4.2-4.5 k cycles per 108 MFMAs.)
+// `side(slot)`, slot = 0..107, is called behind every MFMA: the caller's other work of the phase (LDS-DMA pieces of the next
+// tile, the previous tile's epilogue) is issued there, a few instructions at a time, pinned by scheduling barriers -- a wave
+// issues in order, so anything placed behind the last MFMA would leave the matrix pipe idle.
+// DPPX as above; the middle fragments of a tap row are built behind the MFMAs of its dx = 0 tap.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool DPPX, class Side>
+__device__ __forceinline__ dgm_f32x16 dg_matrix_phase3(const uint4* __restrict__ s_w, const uint4* __restrict__ pa, int plane,
+                                                       int hp0, int lane, Side&& side) {
+  dgm_f32x16 acc0 = {0}, acc1 = {0};
+  DgmW w[2][2];  // [tap parity][m]
+  dgm_load_w(w[0][0], 0, s_w, lane);
+  dgm_load_w(w[0][1], 1, s_w, lane);
+  DgmG r0[2], r2[2][2], mid[2], gq[2][2];  // DPPX: r0[m], r2[dy parity][m], mid[m];  else gq[tap parity][m]
+  if (DPPX) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      dgm_load_g(r0[m], 0, 0, m, pa, plane, hp0, lane);
+      dgm_load_g(r2[0][m], 0, 2, m, pa, plane, hp0, lane);
+    }
+  } else {
+    dgm_load_g(gq[0][0], 0, 0, 0, pa, plane, hp0, lane);
+    dgm_load_g(gq[0][1], 0, 0, 1, pa, plane, hp0, lane);
+  }
+#pragma unroll
+  for (int tau = 0; tau < 9; ++tau) {
+    const int dy = tau / 3, dx = tau - 3 * dy, tp = tau & 1;
+    // operands of the next tap (and, DPPX, of the next tap row), requested before this tap's 12 MFMAs
+    if (tau + 1 < 9) {
+      dgm_load_w(w[tp ^ 1][0], 2 * (tau + 1), s_w, lane);
+      dgm_load_w(w[tp ^ 1][1], 2 * (tau + 1) + 1, s_w, lane);
+      if (!DPPX) {
+        dgm_load_g(gq[tp ^ 1][0], (tau + 1) / 3, (tau + 1) % 3, 0, pa, plane, hp0, lane);
+        dgm_load_g(gq[tp ^ 1][1], (tau + 1) / 3, (tau + 1) % 3, 1, pa, plane, hp0, lane);
+      } else if (dx == 1 && dy < 2) {  // r0 is dead (its middle fragments are built), r2 of the next row goes to the other set
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          dgm_load_g(r0[m], dy + 1, 0, m, pa, plane, hp0, lane);
+          dgm_load_g(r2[(dy + 1) & 1][m], dy + 1, 2, m, pa, plane, hp0, lane);
+        }
+      }
+    }
+    const DgmG c0 = DPPX ? (dx == 0 ? r0[0] : (dx == 1 ? mid[0] : r2[dy & 1][0])) : gq[tp][0];
+    const DgmG c1 = DPPX ? (dx == 0 ? r0[1] : (dx == 1 ? mid[1] : r2[dy & 1][1])) : gq[tp][1];
+    const DgmW &w0 = w[tp][0], &w1 = w[tp][1];
+    const dgm_bf16x8 w0h = *(const dgm_bf16x8*)&w0.h, w0m = *(const dgm_bf16x8*)&w0.m, w0l = *(const dgm_bf16x8*)&w0.l;
+    const dgm_bf16x8 w1h = *(const dgm_bf16x8*)&w1.h, w1m = *(const dgm_bf16x8*)&w1.m, w1l = *(const dgm_bf16x8*)&w1.l;
+    const dgm_bf16x8 a0h = *(const dgm_bf16x8*)&c0.h, a0m = *(const dgm_bf16x8*)&c0.m, a0l = *(const dgm_bf16x8*)&c0.l;
+    const dgm_bf16x8 a1h = *(const dgm_bf16x8*)&c1.h, a1m = *(const dgm_bf16x8*)&c1.m, a1l = *(const dgm_bf16x8*)&c1.l;
+    DgmG nm0 = mid[0], nm1 = mid[1];
+    const bool build = DPPX && dx == 0;
+    // one of the 24 dwords of the two middle fragments per call (6 per MFMA gap over the first 4 gaps of each accumulator)
+    auto bld = [&](int e) {
+      if (!build) return;
+      const int m = e / 12, q = e % 12, pl = q / 4, d = q % 4;
+      const DgmG &a = r0[m], &b = r2[dy & 1][m];
+      DgmG& o = m ? nm1 : nm0;
+      const uint4& fa = pl == 0 ? a.h : (pl == 1 ? a.m : a.l);
+      const uint4& fb = pl == 0 ? b.h : (pl == 1 ? b.m : b.l);
+      uint4& fo = pl == 0 ? o.h : (pl == 1 ? o.m : o.l);
+      const uint32_t va = d == 0 ? fa.x : (d == 1 ? fa.y : (d == 2 ? fa.z : fa.w));
+      const uint32_t vb = d == 0 ? fb.x : (d == 1 ? fb.y : (d == 2 ? fb.z : fb.w));
+      const uint32_t r = dgm_dpp_mid1(va, vb);
+      if (d == 0) fo.x = r; else if (d == 1) fo.y = r; else if (d == 2) fo.z = r; else fo.w = r;
+    };
+#define DGM3_STEP(J, WA0, GA0, WA1, GA1)                                       \
+  __builtin_amdgcn_sched_barrier(0);                                           \
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, GA0, acc0, 0, 0, 0);     \
+  __builtin_amdgcn_sched_barrier(0);                                           \
+  bld(4 * (J)), bld(4 * (J) + 1);                                              \
+  side(tau * 12 + 2 * (J));                                                    \
+  __builtin_amdgcn_sched_barrier(0);                                           \
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, GA1, acc1, 0, 0, 0);     \
+  __builtin_amdgcn_sched_barrier(0);                                           \
+  bld(4 * (J) + 2), bld(4 * (J) + 3);                                          \
+  side(tau * 12 + 2 * (J) + 1);
+    DGM3_STEP(0, w0m, a0m, w1m, a1m)  // (the term order of dg_matrix_phase: smallest first)
+    DGM3_STEP(1, w0h, a0l, w1h, a1l)
+    DGM3_STEP(2, w0l, a0h, w1l, a1h)
+    DGM3_STEP(3, w0h, a0m, w1h, a1m)
+    DGM3_STEP(4, w0m, a0h, w1m, a1h)
+    DGM3_STEP(5, w0h, a0h, w1h, a1h)
+#undef DGM3_STEP
+    __builtin_amdgcn_sched_barrier(0);
+    mid[0] = nm0, mid[1] = nm1;
+  }
+  return acc0 + acc1;
+}

@@ -39,6 +39,10 @@ def _f32(shape, dev):
 
 # the input-gradient kernel takes the fp32 g_cur and splits it while staging (128 instead of 192 B/pixel written and read)
 F32_DGRAD = os.environ.get("EVF_F32_DGRAD", "1") != "0"
+# under the diagonal (recorded) backward the fused backward writes the exact bf16 split of g_cur (three planes, 192 B/pixel) instead
+# of the fp32 tensor, and the persistent input-gradient launch stages it by LDS-DMA (k_dgrad_diag_dma); 0: fp32 g_cur, split by
+# the input-gradient kernel's producer waves (k_dgrad_diag_ws)
+SPLIT_DGRAD = os.environ.get("EVF_DGRAD_SPLIT", "1") != "0"
 PRED_FUSED = os.environ.get("EVF_PRED_FUSED", "1") != "0"  # prediction head in the epilogue of the last layer's forward
 TOP_FUSED = os.environ.get("EVF_TOP_FUSED", "1") != "0"  # prediction-head backward inside the top layer's fused backward
 PAIR_DGRAD = os.environ.get("EVF_PAIR_DGRAD", "1") != "0"
@@ -68,6 +72,7 @@ class _Window:
         n_ = len(eng.cells)
         self.gzr, self.gzr_has = [None] * n_, [False] * n_  # recurrent part of dL/d(spikes), separate from gz (see _backward_pass)
         self.gcl = [None] * n_  # per-layer g_cur buffers (diagonal backward launches: several layers in flight)
+        self.gsl = [None] * n_  # ... or per-layer split planes [3,B,H,W,32] bf16 (SPLIT_DGRAD)
         self.bwd_k = 0          # backward passes of this window so far
         self.slab_init = {}
         self.token = eng._token(dev)  # (a leaf whose value is never read: only its autograd edge chains the passes)
@@ -551,7 +556,14 @@ class FireNetEngine:
             if g_z is None and g_z2 is None and g_v is None and not top:
                 continue  # no gradient reaches this layer at this pass
             use_rec = c.recurrent and z_prev is not None
-            g_cur_i = win.buf(win.gcl, i) if bdefer else win.g_cur  # (several layers are in flight under diagonal launches)
+            split = bdefer and SPLIT_DGRAD and i > 0
+            if split:  # the fused backward writes the three bf16 planes of g_cur instead of the fp32 tensor
+                if win.gsl[i] is None:
+                    win.gsl[i] = torch.empty((3, B, H, W, C), dtype=torch.bfloat16, device=dev)
+                g_cur_i, g_split_i = None, win.gsl[i]
+            else:
+                g_cur_i = win.buf(win.gcl, i) if bdefer else win.g_cur  # (several layers are in flight under diagonal launches)
+                g_split_i = win.g_split
             if bdefer:
                 self._bdefer_slot(win, 2 * (n - 1 - i))
             gv_out = win.buf(win.gv, i)
@@ -571,14 +583,14 @@ class FireNetEngine:
                               _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(in_bitsT),
                               _lib.ptr(self._flat[f"{i}.leak"]), _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W,
                               1 if c.hard_reset else 0, SURROGATE_ID[c.activation], self._act_width(i),
-                              _lib.ptr(g_cur_i) if (plif or F32_DGRAD) else None, _lib.ptr(win.g_split), _lib.ptr(gv_out),
+                              _lib.ptr(g_cur_i) if (plif or F32_DGRAD) else None, _lib.ptr(g_split_i), _lib.ptr(gv_out),
                               _lib.ptr(leak_r), _lib.ptr(thr_r), _lib.ptr(self._slab(kf, nsl, dev)), acc_flag | (row_ld << 8))
                 else:
                     _lib.call("evf_lif_bwd_wgrad2", _lib.ptr(g_z), _lib.ptr(g_z2), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev),
                           _lib.ptr(z_prev),
                           _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None, _lib.ptr(self._flat[f"{i}.leak"]),
                           _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
-                          self._act_width(i), _lib.ptr(g_cur_i) if (plif or F32_DGRAD) else None, _lib.ptr(win.g_split),
+                          self._act_width(i), _lib.ptr(g_cur_i) if (plif or F32_DGRAD) else None, _lib.ptr(g_split_i),
                           _lib.ptr(gv_out),
                           _lib.ptr(leak_r), _lib.ptr(thr_r),
                           _lib.ptr(self._slab(kf, nsl, dev)), _lib.ptr(self._slab(kr, nsl, dev)) if use_rec else None,
@@ -639,12 +651,15 @@ class FireNetEngine:
                 acc_a = 1 if win.gz_has[i - 1] else 0
                 if self.precision == "bf16x3":
                     dg, gsrc = ("evf_conv_dgrad_b3_f32", g_cur_i) if F32_DGRAD else ("evf_conv_dgrad_b3", win.g_split)
-                    if rec_grad and F32_DGRAD and PAIR_DGRAD:  # both input gradients of the recurrent cell in one launch
+                    if split:
+                        dg, gsrc = "evf_conv_dgrad_b3", g_split_i
+                    if rec_grad and (F32_DGRAD or split) and PAIR_DGRAD:  # both input gradients of the recurrent cell in one launch
                         # the recurrent one goes to its OWN buffer (gzr): the cell's backward of the previous pass adds the
                         # two parts itself (evf_lif_bwd_wgrad2), so the input gradient of the layer above needs no
                         # accumulating form there, and those two launches may come in either order
                         gb = win.buf(win.gzr, i) if not plif else win.buf(win.gz, i)
-                        _lib.call("evf_conv_dgrad_b3_f32_pair", _lib.ptr(gsrc), _lib.ptr(self._packed[(i, "ff", "b3t")]),
+                        _lib.call("evf_conv_dgrad_b3_pair" if split else "evf_conv_dgrad_b3_f32_pair", _lib.ptr(gsrc),
+                                  _lib.ptr(self._packed[(i, "ff", "b3t")]),
                                   _lib.ptr(ga), acc_a, _lib.ptr(self._packed[(i, "rec", "b3t")]), _lib.ptr(gb), B, H, W,
                                   _lib.ptr(win.gP) if plif else None, _lib.ptr(in_bits) if plif else None)
                         if plif:

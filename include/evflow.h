@@ -296,6 +296,11 @@ int evf_conv_dgrad_b3(const void* g_split, const void* wT_b3, float* g_x, int ac
  * happens while the halo is staged, the result is bit-identical; 128 instead of 192 B/pixel on both sides. */
 int evf_conv_dgrad_b3_f32(const float* g_cur, const void* wT_b3, float* g_x, int accumulate,
                           int B, int H, int W, const float* g_P, const uint32_t* x_bits, void* stream);
+/* Both input gradients of a recurrent cell from the pre-split planes in one call (one halo read):
+ * g_x (+)= conv^T(g, W_ff), g_x2 = conv^T(g, W_rec) (written) -- models/spiking_submodules.py:520,530. */
+int evf_conv_dgrad_b3_pair(const void* g_split, const void* wT_b3, float* g_x, int accumulate,
+                           const void* wT2_b3, float* g_x2, int B, int H, int W,
+                           const float* g_P, const uint32_t* x_bits, void* stream);
 /* Which kernel serves evf_conv_dgrad_b3_f32[_pair] (results are bit-identical): -1 chosen by shape (default), 0 the
  * one-phase-after-the-other LDS kernel, 1 the wave-specialised one (producer / consumer waves, double-buffered planes).
  * Process-wide; for A/B measurements and the equivalence test. */

@@ -94,20 +94,37 @@ def test_input_gradient_variants_are_bit_identical(shape):
     assert _lib.load().evf_conv_dgrad_select(7) != 0  # bad argument: status, no change
 
 
+def _gcur_and_split(B, H, W):
+    """dL/d(current) as the fused backward writes it: the fp32 tensor AND its exact 3-way bf16 split (three planes)."""
+    g = _f(B, H, W, C, scale=0.3)
+    xT = _planes(_bits(B, H, W))
+    nsl = _lib.load().evf_lif_bwd_wgrad_slabs(B, H, W)
+    slab = torch.zeros(nsl, 9216, device=DEV)
+    leak, thresh = _f(32, scale=0.1) - 1, _f(32, scale=0.1) + 0.8
+    gsp = torch.empty(3, B, H, W, C, dtype=torch.bfloat16, device=DEV)
+    gcur, gvp = torch.empty(B, H, W, C, device=DEV), torch.empty(B, H, W, C, device=DEV)
+    gl, gt = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+    _lib.call("evf_lif_bwd_wgrad", P(g), None, P(_f(B, H, W, C)), None, None, P(xT), None, P(leak), P(thresh), B, H, W, 1, 0, 10.0,
+              P(gcur), P(gsp), P(gvp), P(gl), P(gt), P(slab), None, 0)
+    return gcur, gsp
+
+
 @pytest.mark.parametrize("shape", SHAPES + [(3, 20, 96)])
 def test_recorded_input_gradient_cells_are_bit_identical(shape):
-    """The input-gradient cells of a backward index, recorded (evf_bwd_defer_*) and launched together -- through k_dgrad_diag
-    (the LDS kernel's body) and through the persistent wave-specialised k_dgrad_diag_ws (flat product list, DPP-built middle
-    taps) -- against one direct launch per cell: bit-identical outputs.  Several cells per index, one- and two-product
-    cells mixed, two indices, so that block ranges cross product boundaries (weight-set switches inside a block)."""
+    """The input-gradient cells of a backward index, recorded (evf_bwd_defer_*) and launched together, against one direct
+    launch per cell -- bit-identical outputs through all three dispatchers: k_dgrad_diag (the LDS kernel's body),
+    k_dgrad_diag_ws (persistent producer / consumer blocks over the flat product list, fp32 gradient in) and
+    k_dgrad_diag_dma (gradient pre-split by the fused backward, staged by LDS-DMA, one wave per SIMD, alternating
+    accumulators, DPP-built middle taps).  Several cells per index, one- and two-product cells mixed, two indices, so that
+    block ranges cross product boundaries (weight-set switches inside a block); ragged shapes (out-of-image halo = zero page)."""
     B, H, W = shape
     torch.manual_seed(5)
     L = _lib.load()
-    cells = []  # (index, gradient, weight set 1, weight set 2 or None)
+    cells = []  # (index, fp32 gradient, its split planes, weight set 1, weight set 2 or None)
     for d, pair in ((0, False), (0, True), (0, False), (1, True), (1, True), (1, False), (1, False), (1, True)):
-        cells.append((d, _f(B, H, W, C, scale=0.3), _packs()[1], _packs()[1] if pair else None))
+        cells.append((d,) + _gcur_and_split(B, H, W) + (_packs()[1], _packs()[1] if pair else None))
     ref = []
-    for _, g, w1, w2 in cells:
+    for _, g, _gs, w1, w2 in cells:
         a = torch.empty(B, H, W, C, device=DEV)
         _lib.call("evf_conv_dgrad_b3_f32", P(g), P(w1), P(a), 0, B, H, W, None, None)
         b = None
@@ -116,26 +133,28 @@ def test_recorded_input_gradient_cells_are_bit_identical(shape):
             _lib.call("evf_conv_dgrad_b3_f32", P(g), P(w2), P(b), 0, B, H, W, None, None)
         ref.append((a, b))
     try:
-        for which in (0, 1):
+        for which, split in ((0, False), (1, False), (1, True)):
             assert L.evf_dgrad_diag_select(which) == 0
             outs = [(torch.full((B, H, W, C), 7.0, device=DEV), torch.full((B, H, W, C), 7.0, device=DEV)) for _ in cells]
             assert L.evf_bwd_defer_begin() == 0
             try:
-                for (d, g, w1, w2), (a, b) in zip(cells, outs):
+                for (d, g, gs, w1, w2), (a, b) in zip(cells, outs):
                     assert L.evf_bwd_defer_slot(d) == 0
+                    src = gs if split else g
                     if w2 is None:
-                        _lib.call("evf_conv_dgrad_b3_f32", P(g), P(w1), P(a), 0, B, H, W, None, None)
+                        _lib.call("evf_conv_dgrad_b3" if split else "evf_conv_dgrad_b3_f32", P(src), P(w1), P(a), 0, B, H, W, None, None)
                     else:
-                        _lib.call("evf_conv_dgrad_b3_f32_pair", P(g), P(w1), P(a), 0, P(w2), P(b), B, H, W, None, None)
+                        _lib.call("evf_conv_dgrad_b3_pair" if split else "evf_conv_dgrad_b3_f32_pair", P(src), P(w1), P(a), 0, P(w2), P(b),
+                                  B, H, W, None, None)
                 assert L.evf_bwd_defer_pending() == len(cells)
             finally:
                 _lib.call("evf_bwd_defer_flush")
             assert L.evf_bwd_defer_pending() == 0
             torch.cuda.synchronize()
             for k, ((a, b), (ra, rb)) in enumerate(zip(outs, ref)):
-                assert torch.equal(a, ra), (which, k)
+                assert torch.equal(a, ra), (which, split, k)
                 if rb is not None:
-                    assert torch.equal(b, rb), (which, k, "second product")
+                    assert torch.equal(b, rb), (which, split, k, "second product")
     finally:
         L.evf_dgrad_diag_select(-1)
     assert L.evf_dgrad_diag_select(5) != 0
