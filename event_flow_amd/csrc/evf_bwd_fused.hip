@@ -22,13 +22,15 @@
 // input, accumulated over the passes of a window.
 #include "evf_common.h"
 #include "evf_split.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define C32 32
 #define FB_CW 64    // pixels per unit (row segment): one float4 of every tensor per thread
-#define FB_UNITS 8
+#define FB_UNITS 8       // units per block of a one-cell launch = slab rows per (cell, input): evf_lif_bwd_wgrad_slabs
+#define FB_UNITS_MAX 16  // a diagonal launch may give a block twice as many (fb_defer_launch)
 #define FB_THREADS 512
 #define FB_NW (FB_CW / 32 + 2)  // plane words per (row, channel): segment + one halo word each side
 #define FB_R0 32768             // LDS region 0: operand double buffer (24 KiB), later the tap-8 reduction (32 KiB)
@@ -112,7 +114,7 @@ __device__ __forceinline__ void fb_body(
     const float4* __restrict__ v_out,
     const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev, const uint32_t* __restrict__ xT,
     const uint32_t* __restrict__ zT, const float* __restrict__ leak, const float* __restrict__ thresh, int B, int H,
-    int W, int nchunk, long nunits, int hard_reset_rt, int surrogate_rt, float width, int accumulate,
+    int W, int nchunk, long nunits, int hard_reset_rt, int surrogate_rt, float width, int accumulate, int nrows_total,
     float4* __restrict__ g_cur, uint2* __restrict__ g_split, float4* __restrict__ g_v_prev,
     float* __restrict__ g_leak, float* __restrict__ g_thresh, float* __restrict__ slab_ff,
     float* __restrict__ slab_rec, FbTop top, int row_ld) {
@@ -159,14 +161,14 @@ __device__ __forceinline__ void fb_body(
   // few channels at the same time (64 KiB stride between blocks).
   const int nblk = nblk_;
   const int nu = (int)((nunits - (long)bid + nblk - 1) / nblk);
-  // Geometry of the block's (<= FB_UNITS) units: lane (k & 7) holds unit k's (sample, row, first column), computed ONCE
+  // Geometry of the block's (<= FB_UNITS_MAX) units: lane (k & 15) holds unit k's (sample, row, first column), computed ONCE
   // here; a unit's geometry then is three v_readlane into SGPRs.  As two integer divisions by run-time values per call
   // (v_rcp + fix-up chains with VALU -> SALU hops), four calls per unit, it was the "0.75 k cycles of load issue" of the
   // phase stamps.
-  static_assert(FB_UNITS <= 8, "geometry table: one lane per unit of the block");
+  static_assert(FB_UNITS_MAX <= 16, "geometry table: one lane per unit of the block");
   int g_b, g_y, g_x0;
   {
-    const int u = bid + min(lane & 7, nu - 1) * nblk;  // nunits < 2^31
+    const int u = bid + min(lane & 15, nu - 1) * nblk;  // nunits < 2^31
     const int row = u / nchunk;
     g_b = row / H;
     g_y = row - g_b * H;
@@ -444,6 +446,20 @@ __device__ __forceinline__ void fb_body(
     for (int q = 0; q < 16; ++q) slab_rec[slab_off + fb_row(q, lane) * C32] = ((accumulate & 1) ? oldz[q] : 0.f) + accz[q];
   }
 
+  // ---- first touch of the slabs in this window by a launch with FEWER blocks than slab rows (a diagonal launch whose blocks
+  // take 16 units): the rows this launch does not write start at zero, so that later launches -- with either block count --
+  // and the window's reduction find every row initialised
+  if (!(accumulate & 1) && nblk < nrows_total) {
+    for (int r = nblk + bid; r < nrows_total; r += nblk) {
+      float4* z0 = (float4*)(slab_ff + (long)r * (9 * C32 * C32));
+      float4* z1 = REC ? (float4*)(slab_rec + (long)r * (9 * C32 * C32)) : nullptr;
+      for (int e = tid; e < 9 * C32 * C32 / 4; e += FB_THREADS) {
+        z0[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (REC) z1[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+
   // ---- per-channel sums for leak / thresh: lanes with equal (lane & 7) share channels
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -528,7 +544,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     float* __restrict__ g_leak, float* __restrict__ g_thresh, float* __restrict__ slab_ff, float* __restrict__ slab_rec,
     FbTop top, int row_ld) {
   fb_body<REC, TOP, FAST>(blockIdx.x, gridDim.x, g_z_out, g_z_out2, g_v_out, v_out, v_prev, z_prev, xT, zT, leak, thresh, B, H, W,
-                          nchunk, nunits, hard_reset_rt, surrogate_rt, width, accumulate, g_cur, g_split, g_v_prev, g_leak,
+                          nchunk, nunits, hard_reset_rt, surrogate_rt, width, accumulate, (int)gridDim.x, g_cur, g_split, g_v_prev, g_leak,
                           g_thresh, slab_ff, slab_rec, top, row_ld);
 }
 
@@ -558,20 +574,20 @@ struct FbJobs {
   FbJob j[FB_MAX_JOBS];
 };
 __global__ __launch_bounds__(FB_THREADS) void k_bwd_diag(FbJobs jobs, int B, int H, int W, int nchunk, long nunits, int row_ld,
-                                                         int nblk) {
+                                                         int nblk, int nrows_total) {
   const int jb = blockIdx.x / nblk, bid = blockIdx.x - jb * nblk;
   const FbJob& J = jobs.j[jb];
   if (J.kind == 1)
     fb_body<true, false, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
-                               nchunk, nunits, 1, EVF_ARCTAN, J.width, J.accumulate, J.g_cur, J.g_split, J.g_v_prev, J.g_leak,
+                               nchunk, nunits, 1, EVF_ARCTAN, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak,
                                J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld);
   else if (J.kind == 2)
     fb_body<false, true, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
-                               nchunk, nunits, 1, EVF_ARCTAN, J.width, J.accumulate, J.g_cur, J.g_split, J.g_v_prev, J.g_leak,
+                               nchunk, nunits, 1, EVF_ARCTAN, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak,
                                J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld);
   else
     fb_body<false, false, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
-                                nchunk, nunits, 1, EVF_ARCTAN, J.width, J.accumulate, J.g_cur, J.g_split, J.g_v_prev, J.g_leak,
+                                nchunk, nunits, 1, EVF_ARCTAN, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak,
                                 J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld);
 }
 
@@ -644,15 +660,36 @@ static int fb_defer_launch(int d, void* stream) {
   FbJobs jobs;
   for (int k = 0; k < FB_MAX_JOBS; ++k) jobs.j[k] = fb_defer.job[d][k < n ? k : 0];
   const long nunits = fb_units(fb_defer.B, fb_defer.H, fb_defer.W);
-  const int nblk = evf_cdiv(nunits, FB_UNITS), nchunk = (fb_defer.W + FB_CW - 1) / FB_CW;
+  const int nrows = evf_cdiv(nunits, FB_UNITS), nchunk = (fb_defer.W + FB_CW - 1) / FB_CW;
+  // Units per block: 8 (one slab row per block) or 16 (half the blocks, half the slab read-modify-write and half the ~21 k
+  // cycles of prologue + epilogue a block pays on top of ~5.5 k per unit), whichever needs less time in whole rounds of one
+  // block per CU -- n cells x 256 blocks are n rounds of 65 k cycles, n x 128 blocks ceil(n / 2) rounds of 109 k (128 x 128 x B8).
+  static const int mode = []() {
+    const char* e = getenv("EVF_BWD_UNITS");  // 8 / 16: fixed; default: by rounds
+    return e ? atoi(e) : 0;
+  }();
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+  }
+  const int nb16 = evf_cdiv(nunits, FB_UNITS_MAX);
+  const long cost8 = (long)evf_cdiv((long)n * nrows, ncu) * (21 + 8 * 11 / 2), cost16 = (long)evf_cdiv((long)n * nb16, ncu) * (21 + 16 * 11 / 2);
+  const bool wide = mode == 16 || (mode != 8 && cost16 < cost8);
+  const int nblk = wide ? nb16 : nrows;
   evf_prof_mark(1, 0, stream);
   hipLaunchKernelGGL(k_bwd_diag, dim3(nblk * n), dim3(FB_THREADS), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
-                     fb_defer.W, nchunk, nunits, fb_defer.row_ld, nblk);
+                     fb_defer.W, nchunk, nunits, fb_defer.row_ld, nblk, nrows);
   evf_prof_mark(1, 1, stream);
   fb_defer.n[d] = 0;
   return evf_status();
 }
 
+// (Round 3, measured and dropped: the head layer's backward cells on a side stream forked inside this loop -- they form a chain
+//  of their own, but the next input-gradient launch rewrites the one buffer they read (dL/d(spikes) of the head layer), so each
+//  can only hide under ONE fused-backward launch; as parallel branches of the replayed graph: 4.21 against 4.20 ms per step.)
 int evf_bwd_defer_flush_now(void* stream) {
   for (int d = 0; d < EVF_BWD_DIAGS; ++d) {
     int rc = fb_defer_launch(d, stream);

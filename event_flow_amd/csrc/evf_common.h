@@ -102,8 +102,10 @@ extern EvfBwdDefer evf_bwd_defer;
 int evf_bwd_defer_flush_now(void* stream);  // launch what is recorded, keep recording
 int evf_dg_defer_launch(int d, void* stream);  // evf_dgrad_b3.hip: launch and clear the cells of index d
 int evf_dg_defer_count();
+int evf_dg_defer_pending(int d);  // cells recorded under index d
 int evf_hd_defer_launch(int d, void* stream);  // evf_network.hip (head layer)
 int evf_hd_defer_count();
+int evf_hd_defer_pending(int d);  // cells recorded under index d
 // Per-launch timing of the diagonal launches (evf_defer_profile, evf_bwd_fused.hip): HIP events around every dispatcher
 // launch of a flush, by kind (0 k_fwd_diag, 1 k_bwd_diag, 2 k_dgrad_diag, 3 head backward).  No-ops unless switched on
 // (never during a graph capture).

@@ -339,6 +339,7 @@ int evf_dg_defer_count() {
   for (int d = 0; d < EVF_BWD_DIAGS; ++d) n += dg_defer.n[d];
   return n;
 }
+int evf_dg_defer_pending(int d) { return dg_defer.n[d]; }
 int evf_dg_defer_launch(int d, void* stream) {
   const int n = dg_defer.n[d];
   if (!n) return EVF_OK;

@@ -924,6 +924,7 @@ int evf_hd_defer_count() {
   for (int d = 0; d < EVF_BWD_DIAGS; ++d) n += hd_defer.n[d];
   return n;
 }
+int evf_hd_defer_pending(int d) { return hd_defer.n[d]; }
 int evf_hd_defer_launch(int d, void* stream) {
   for (int k = 0; k < hd_defer.n[d]; ++k) {
     evf_prof_mark(3, 0, stream);
