@@ -462,16 +462,61 @@ def main_c4(args):
     model = SpikingRecEVFlowNet(dict(cfg)).to(dev)
     model.train()
     lossf = EventWarping({"loader": {"resolution": [Hc, Wc]}, "loss": dict(LOSS_CFG["loss"]), "model": {"mask_output": True}}, dev)
-    opt = FlatAdam(model, lr=2e-4, clip=100.0)
+    use_graph = not args.no_graph
+    opt = FlatAdam(model, lr=2e-4, clip=100.0, device_step=use_graph)
     opt.zero_grad()
     pool = [encode_passes([torch.from_numpy(synthetic.event_list_batch(Bc, nev, Hc, Wc, synthetic.seed_for(4, 0, 0) + 100000 * w)).to(dev)],
                           2, (Hc, Wc)) for w in range(2)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(side)
     for i in range(max(args.warmup, 2)):
         loss = train_window(model, lossf, opt, pool[i % 2])
     torch.cuda.synchronize()
+    # the whole step (passes, 4-scale loss, backward, clip + Adam, state reset) of each of the two windows as a hipGraph; a
+    # window of this workload is ONE pass, the recurrent state is reset per window (train_window detaches and the loss resets),
+    # so the two graphs are independent and replay alternately.  Falls back to eager launches if the capture is refused.
+    graphs, mode = None, "eager"
+
+    def state_tensors():
+        out = []
+        for st in model.multires_unetrec.states:
+            if st is not None:
+                out += list(st) if isinstance(st, tuple) else [st]
+        return out
+
+    if use_graph:
+        try:
+            # the recurrent state crosses the windows: graph 0 starts from the tensors the warm-up left (`home`), graph 1 from
+            # the tensors graph 0 produces (fixed addresses in its pool) and ends by copying its final state back into `home`
+            home = state_tensors()
+            home_struct = list(model.multires_unetrec.states)
+            graphs = []
+            for w in range(2):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    gl = train_window(model, lossf, opt, pool[w])
+                    if w == 1:
+                        for h, st in zip(home, state_tensors()):
+                            h.copy_(st)
+                graphs.append((g, gl))
+            model.multires_unetrec.states = home_struct
+            torch.cuda.synchronize()
+            for w in range(2):
+                graphs[w][0].replay()
+            torch.cuda.synchronize()
+            mode = "hipgraph"
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench c4] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            graphs = None
+            torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = train_window(model, lossf, opt, pool[i % 2])
+        if graphs is not None:
+            graphs[i % 2][0].replay()
+            loss = graphs[i % 2][1]
+        else:
+            loss = train_window(model, lossf, opt, pool[i % 2])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     names = ["evf_conv2d_fwd", "evf_conv2d_dgrad", "evf_conv2d_fwd_b3", "evf_conv2d_dgrad_b3", "evf_conv2d_wgrad", "evf_neuron_fwd", "evf_neuron_bwd", "evf_upsample2x_fwd",
@@ -514,7 +559,7 @@ def main_c4(args):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "LIF-EV-FlowNet (SpikingRecEVFlowNet, base 32) full train step, 256x256, 50k events/window, batch 8, "
                                "4 flow scales, CM loss, clip+Adam [BASELINE configs[3]]", "baseline_config": "c4", "global_batch": Bc,
-                   "events_per_window": nev, "parallelism": "dp1", "launch": "eager", "loss": float(loss),
+                   "events_per_window": nev, "parallelism": "dp1", "launch": mode, "loss": float(loss),
                    "conv_precision": ("forward / input gradient: bf16 MFMA with exact 3-way operand splits, fp32 accumulation "
                                       "(3 products per 16 channels for spike-valued waves, 6 otherwise; EVF_CONV=f32 for the fp32 "
                                       "kernels); " if hip_ops_conv_b3() else "") +

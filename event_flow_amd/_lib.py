@@ -49,13 +49,14 @@ NETWORK_SIGNATURES = {
     "evf_pack_conv_weight_b3": [P, I, I, P, P],
     "evf_conv_lif_fwd_b3": [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P],
     "evf_conv_lif_fwd_b3_pred": [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P, P],
-    "evf_fwd_defer_begin": [],
-    "evf_fwd_defer_slot": [I],
-    "evf_fwd_defer_pending": [],
+    "evf_fwd_defer_begin": [P],
+    "evf_fwd_defer_slot": [I, P],
+    "evf_fwd_defer_pending": [P],
     "evf_fwd_defer_flush": [P],
-    "evf_bwd_defer_begin": [],
-    "evf_bwd_defer_slot": [I],
-    "evf_bwd_defer_pending": [],
+    "evf_defer_poison": [I],
+    "evf_bwd_defer_begin": [P],
+    "evf_bwd_defer_slot": [I, P],
+    "evf_bwd_defer_pending": [P],
     "evf_bwd_defer_flush": [P],
     "evf_defer_profile": [I],
     "evf_defer_profile_read": [P, P],
@@ -253,19 +254,36 @@ def profile_stop():
 # Deferred forward cells (evf_fwd_defer_*, models/engine.py): while a recording is open, any OTHER entry point may read what
 # the recorded cells write, so it launches them first.  The names below never do: they record or launch a cell themselves,
 # or only produce network inputs.
-_defer_flush = None  # callable set by the engine that opened the recording
+# The recorders of the library are per STREAM (include/evflow.h, "CONTEXTS / THREADS"), and so is the hook that launches what
+# has been recorded on a stream before any entry point outside the recorded schedule runs on it: _hooks[stream] = (callable
+# set by the engine that opened the recording, the entry points that record themselves or flush inside the library).
+_hooks = {}
+
+
+def set_defer_hook(flush, safe):
+    _hooks[stream_ptr()] = (flush, safe)
+
+
+def clear_defer_hook():
+    _hooks.pop(stream_ptr(), None)
+
+
+def raw(name, *args):
+    """Status of an entry point called on torch's current stream (no hook, no exception): the evf_*_defer_* bookkeeping calls."""
+    return getattr(load(), name)(*args, stream_ptr())
+
 _DEFER_SAFE_FWD = {"evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_head_lif_fwd", "evf_fwd_defer_flush",
                    "evf_encode_window", "evf_encode_events", "evf_events_to_image"}
 # backward recording (evf_bwd_defer_*): these record themselves, or flush inside the library when they cannot
 _DEFER_SAFE_BWD = {"evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad2", "evf_lif_bwd_wgrad_top", "evf_conv_dgrad_b3_f32",
                    "evf_conv_dgrad_b3_f32_pair", "evf_conv_dgrad_b3", "evf_conv_dgrad_b3_pair", "evf_head_lif_bwd_wgrad", "evf_bwd_defer_flush"}
-_DEFER_SAFE = _DEFER_SAFE_FWD
 
 
 def call(name, *args):
     """Invoke an entry point on torch's current stream; raise on error."""
-    if _defer_flush is not None and name not in _DEFER_SAFE:
-        _defer_flush()
+    hook = _hooks.get(stream_ptr()) if _hooks else None
+    if hook is not None and name not in hook[1]:
+        hook[0]()
     if _prof is not None and name in _prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

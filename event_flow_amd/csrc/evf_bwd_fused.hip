@@ -23,6 +23,7 @@
 #include "evf_common.h"
 #include "evf_split.h"
 #include <stdlib.h>
+#include <mutex>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -596,7 +597,37 @@ static long fb_units(int B, int H, int W) { return (long)B * H * ((W + FB_CW - 1
 
 extern "C" int evf_lif_bwd_wgrad_slabs(int B, int H, int W) { return evf_cdiv(fb_units(B, H, W), FB_UNITS); }
 
-EvfBwdDefer evf_bwd_defer = {false, 0};
+EvfBwdDefer evf_bwd_defer_tab[EVF_CTX_MAX] = {};
+
+// recording contexts (evf_common.h): stream -> index, reference counted by the open recordings
+static struct {
+  std::mutex mu;
+  void* stream[EVF_CTX_MAX];
+  int refs[EVF_CTX_MAX];
+} evf_ctx = {};
+int evf_ctx_find(void* stream) {
+  std::lock_guard<std::mutex> g(evf_ctx.mu);
+  for (int c = 0; c < EVF_CTX_MAX; ++c)
+    if (evf_ctx.refs[c] > 0 && evf_ctx.stream[c] == stream) return c;
+  return -1;
+}
+int evf_ctx_acquire(void* stream) {
+  std::lock_guard<std::mutex> g(evf_ctx.mu);
+  int free_c = -1;
+  for (int c = 0; c < EVF_CTX_MAX; ++c) {
+    if (evf_ctx.refs[c] > 0 && evf_ctx.stream[c] == stream) {
+      ++evf_ctx.refs[c];
+      return c;
+    }
+    if (evf_ctx.refs[c] == 0 && free_c < 0) free_c = c;
+  }
+  if (free_c >= 0) evf_ctx.stream[free_c] = stream, evf_ctx.refs[free_c] = 1;
+  return free_c;
+}
+void evf_ctx_drop(int ctx) {
+  std::lock_guard<std::mutex> g(evf_ctx.mu);
+  if (ctx >= 0 && ctx < EVF_CTX_MAX && evf_ctx.refs[ctx] > 0) --evf_ctx.refs[ctx];
+}
 
 #define EVF_PROF_MAX 1024
 static struct {
@@ -643,13 +674,14 @@ extern "C" int evf_defer_profile_read(float* ms, int* count) {
   evf_prof.n = 0;
   return EVF_OK;
 }
-static struct {
+struct FbDefer {
   int B, H, W, row_ld;
   int n[EVF_BWD_DIAGS];
   FbJob job[EVF_BWD_DIAGS][FB_MAX_JOBS];
-} fb_defer = {0, 0, 0, 0, {0}, {}};
+};
+static FbDefer fb_tab[EVF_CTX_MAX];
 
-static int fb_defer_launch(int d, void* stream) {
+static int fb_defer_launch(FbDefer& fb_defer, int d, void* stream) {
   const int n = fb_defer.n[d];
   if (!n) return EVF_OK;
   static bool attr_set = false;
@@ -690,36 +722,44 @@ static int fb_defer_launch(int d, void* stream) {
 // (Round 3, measured and dropped: the head layer's backward cells on a side stream forked inside this loop -- they form a chain
 //  of their own, but the next input-gradient launch rewrites the one buffer they read (dL/d(spikes) of the head layer), so each
 //  can only hide under ONE fused-backward launch; as parallel branches of the replayed graph: 4.21 against 4.20 ms per step.)
-int evf_bwd_defer_flush_now(void* stream) {
+int evf_bwd_defer_flush_now(int ctx, void* stream) {
   for (int d = 0; d < EVF_BWD_DIAGS; ++d) {
-    int rc = fb_defer_launch(d, stream);
-    if (!rc) rc = evf_dg_defer_launch(d, stream);
-    if (!rc) rc = evf_hd_defer_launch(d, stream);
+    int rc = fb_defer_launch(fb_tab[ctx], d, stream);
+    if (!rc) rc = evf_dg_defer_launch(ctx, d, stream);
+    if (!rc) rc = evf_hd_defer_launch(ctx, d, stream);
     if (rc) return rc;
   }
   return EVF_OK;
 }
 
-extern "C" int evf_bwd_defer_begin() {
-  if (evf_bwd_defer.active) return EVF_EINVAL;
-  evf_bwd_defer.active = true;
-  evf_bwd_defer.slot = 0;
+extern "C" int evf_bwd_defer_begin(void* stream) {
+  const int c = evf_ctx_find(stream);
+  if (c >= 0 && evf_bwd_defer_tab[c].active) return EVF_EINVAL;  // one backward recording per stream
+  const int ctx = evf_ctx_acquire(stream);
+  if (ctx < 0) return EVF_EINVAL;
+  evf_bwd_defer_tab[ctx].active = true;
+  evf_bwd_defer_tab[ctx].slot = 0;
   return EVF_OK;
 }
-extern "C" int evf_bwd_defer_slot(int d) {
-  if (!evf_bwd_defer.active || d < 0 || d >= EVF_BWD_DIAGS) return EVF_EINVAL;
-  evf_bwd_defer.slot = d;
+extern "C" int evf_bwd_defer_slot(int d, void* stream) {
+  const int c = evf_ctx_find(stream);
+  if (c < 0 || !evf_bwd_defer_tab[c].active || d < 0 || d >= EVF_BWD_DIAGS) return EVF_EINVAL;
+  evf_bwd_defer_tab[c].slot = d;
   return EVF_OK;
 }
-extern "C" int evf_bwd_defer_pending() {
-  int n = evf_dg_defer_count() + evf_hd_defer_count();
-  for (int d = 0; d < EVF_BWD_DIAGS; ++d) n += fb_defer.n[d];
+extern "C" int evf_bwd_defer_pending(void* stream) {
+  const int c = evf_ctx_find(stream);
+  if (c < 0 || !evf_bwd_defer_tab[c].active) return 0;
+  int n = evf_dg_defer_count(c) + evf_hd_defer_count(c);
+  for (int d = 0; d < EVF_BWD_DIAGS; ++d) n += fb_tab[c].n[d];
   return n;
 }
 extern "C" int evf_bwd_defer_flush(void* stream) {
-  if (!evf_bwd_defer.active) return EVF_OK;
-  const int rc = evf_bwd_defer_flush_now(stream);
-  evf_bwd_defer.active = false;
+  const int c = evf_ctx_find(stream);
+  if (c < 0 || !evf_bwd_defer_tab[c].active) return EVF_OK;
+  const int rc = evf_bwd_defer_flush_now(c, stream);
+  evf_bwd_defer_tab[c].active = false;
+  evf_ctx_drop(c);
   return rc;
 }
 
@@ -740,6 +780,9 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
   const FbTop top = topp ? *topp : FbTop{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   static bool attr[12] = {false};
   const bool fast = hard_reset != 0 && surrogate == EVF_ARCTAN;
+  const int bctx = evf_ctx_find(stream);
+  const EvfBwdDefer evf_bwd_defer = bctx >= 0 ? evf_bwd_defer_tab[bctx] : EvfBwdDefer{false, 0};
+  FbDefer& fb_defer = fb_tab[bctx < 0 ? 0 : bctx];
   if (evf_bwd_defer.active) {
     bool any = false;
     for (int d = 0; d < EVF_BWD_DIAGS && !any; ++d) any = fb_defer.n[d] != 0;
@@ -752,7 +795,7 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
                 slab_ff, slab_rec, top, act_width, accumulate, topp ? 2 : (zT_prev ? 1 : 0), 0};
       return EVF_OK;
     }
-    const int rc = evf_bwd_defer_flush_now(stream);  // not recordable: everything recorded runs first
+    const int rc = evf_bwd_defer_flush_now(bctx, stream);  // not recordable: everything recorded runs first
     if (rc) return rc;
   }
 #define FB_GO(REC_, TOP_, FAST_, slot)                                                                                    \

@@ -93,19 +93,29 @@ int evf_dgrad_diag_dma_launch(const EvfDgProds& P, int nprod, int B, int H, int 
 // launches index after index -- the fused-backward cells of an index as one k_bwd_diag, the input-gradient cells as one
 // k_dgrad_diag, head cells one by one.  A launcher that cannot record its call first flushes everything recorded so far
 // (record order is a valid execution order) and then launches as usual.
+// RECORDING CONTEXTS.  A recording (forward or backward) belongs to the HIP STREAM it was opened on: every recorder below is
+// an array indexed by a context id, and a context is looked up by the `stream` argument every entry point has.  Two host
+// threads driving two models on two streams therefore record and launch independently -- also through PyTorch's autograd,
+// whose backward nodes run on ONE worker thread per device but on the stream of their forward.  (A process-global recorder
+// mixed such cells; a thread_local one did as well, because of that shared worker thread.)  Two recordings of one kind on
+// ONE stream are refused (EVF_EINVAL).  evf_ctx_* are implemented in evf_bwd_fused.hip.
+#define EVF_CTX_MAX 16
+int evf_ctx_find(void* stream);     // context of `stream`, or -1: no recording is open on it
+int evf_ctx_acquire(void* stream);  // find or create, one more open recording on it; -1: all EVF_CTX_MAX contexts are in use
+void evf_ctx_drop(int ctx);         // one recording of the context ended (at zero the context is free again)
 #define EVF_BWD_DIAGS 96
 struct EvfBwdDefer {
   bool active;
   int slot;
 };
-extern EvfBwdDefer evf_bwd_defer;
-int evf_bwd_defer_flush_now(void* stream);  // launch what is recorded, keep recording
-int evf_dg_defer_launch(int d, void* stream);  // evf_dgrad_b3.hip: launch and clear the cells of index d
-int evf_dg_defer_count();
-int evf_dg_defer_pending(int d);  // cells recorded under index d
-int evf_hd_defer_launch(int d, void* stream);  // evf_network.hip (head layer)
-int evf_hd_defer_count();
-int evf_hd_defer_pending(int d);  // cells recorded under index d
+extern EvfBwdDefer evf_bwd_defer_tab[EVF_CTX_MAX];
+int evf_bwd_defer_flush_now(int ctx, void* stream);  // launch what is recorded, keep recording
+int evf_dg_defer_launch(int ctx, int d, void* stream);  // evf_dgrad_b3.hip: launch and clear the cells of index d
+int evf_dg_defer_count(int ctx);
+int evf_dg_defer_pending(int ctx, int d);  // cells recorded under index d
+int evf_hd_defer_launch(int ctx, int d, void* stream);  // evf_network.hip (head layer)
+int evf_hd_defer_count(int ctx);
+int evf_hd_defer_pending(int ctx, int d);  // cells recorded under index d
 // Per-launch timing of the diagonal launches (evf_defer_profile, evf_bwd_fused.hip): HIP events around every dispatcher
 // launch of a flush, by kind (0 k_fwd_diag, 1 k_bwd_diag, 2 k_dgrad_diag, 3 head backward).  No-ops unless switched on
 // (never during a graph capture).

@@ -310,11 +310,12 @@ __global__ __launch_bounds__(DG_ROWS * 64) void k_dgrad_diag(DgJobs jobs, int B,
     dg_body<true, false, false, false>(zz, zb, J.gs, 0, J.wt, J.gx, 0, B, H, W, nullptr, nullptr, nullptr, nullptr);
 }
 
-static struct {
+struct DgDefer {
   int B, H, W, split;
   int n[EVF_BWD_DIAGS];
   DgJob job[EVF_BWD_DIAGS][DG_MAX_JOBS];
-} dg_defer = {0, 0, 0, 0, {0}, {}};
+};
+static DgDefer dg_tab[EVF_CTX_MAX];
 
 static int dg_zb(int B, int H, int W) {  // samples per block column, as in dg_launch
   const long tiles = (long)evf_cdiv(W, 32) * evf_cdiv(H, DG_ROWS);
@@ -334,13 +335,15 @@ extern "C" int evf_dgrad_diag_select(int which) {
   return EVF_OK;
 }
 
-int evf_dg_defer_count() {
+int evf_dg_defer_count(int ctx) {
+  const DgDefer& dg_defer = dg_tab[ctx];
   int n = 0;
   for (int d = 0; d < EVF_BWD_DIAGS; ++d) n += dg_defer.n[d];
   return n;
 }
-int evf_dg_defer_pending(int d) { return dg_defer.n[d]; }
-int evf_dg_defer_launch(int d, void* stream) {
+int evf_dg_defer_pending(int ctx, int d) { return dg_tab[ctx].n[d]; }
+int evf_dg_defer_launch(int ctx, int d, void* stream) {
+  DgDefer& dg_defer = dg_tab[ctx];
   const int n = dg_defer.n[d];
   if (!n) return EVF_OK;
   // default: the persistent wave-specialised launch over the flat product list (evf_dgrad_diag.hip); EVF_DGRAD_DIAG=lds keeps
@@ -399,8 +402,11 @@ static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, in
   // tiles (260 x 346 x B4: 46 vs 60 us); with <= 2 tiles per CU the cold first fetch dominates either way and the
   // one-phase-after-the-other kernel below is ~1 % ahead in the train step (128 x 128 x B8: 20.1 vs 21.3 us in the step).
   // evf_conv_dgrad_select() / EVF_DGRAD=lds|ws override the choice (A/B measurements, the equivalence test).
-  if (evf_bwd_defer.active) {  // a recording is open: record the cell (any size: the persistent launch of evf_dgrad_diag.hip) ...
-    const bool any = evf_dg_defer_count() != 0;
+  const int bctx = evf_ctx_find(stream);
+  const EvfBwdDefer evf_bwd_defer = bctx >= 0 ? evf_bwd_defer_tab[bctx] : EvfBwdDefer{false, 0};
+  DgDefer& dg_defer = dg_tab[bctx < 0 ? 0 : bctx];
+  if (evf_bwd_defer.active) {  // a recording is open on this stream: record the cell (any size: the persistent launch of evf_dgrad_diag.hip) ...
+    const bool any = evf_dg_defer_count(bctx) != 0;
     const int split = f32in ? 0 : 1;  // (one kind per recording: the two are launched by different kernels)
     const bool same = !any || (dg_defer.B == B && dg_defer.H == H && dg_defer.W == W && dg_defer.split == split);
     if (!accumulate && !g_P && same && dg_defer.n[evf_bwd_defer.slot] < DG_MAX_JOBS) {
@@ -409,7 +415,7 @@ static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, in
           DgJob{(const uint4*)g, (const uint4*)wT_b3, g_x, (const uint4*)wT2_b3, g_x2, split};
       return EVF_OK;
     }
-    const int rc = evf_bwd_defer_flush_now(stream);  // ... or, not recordable: everything recorded runs first
+    const int rc = evf_bwd_defer_flush_now(bctx, stream);  // ... or, not recordable: everything recorded runs first
     if (rc) return rc;
   }
   if (f32in) {

@@ -377,20 +377,22 @@ __global__ __launch_bounds__(FW_THREADS) void k_fwd_diag(FwJobs jobs, int B, int
 }
 
 #define FW_MAX_DIAGS 96
-static struct {
+// (one recorder per recording context = per stream, evf_common.h)
+struct FwDefer {
   bool active = false;
   int slot = 0;
   int B = 0, H = 0, W = 0;
   int n[FW_MAX_DIAGS] = {0};
   FwJob job[FW_MAX_DIAGS][FW_MAX_JOBS];
-} fw_defer;
+};
+static FwDefer fw_tab[EVF_CTX_MAX];
 
 static size_t fw_lds_bytes() {
   return WB3_BYTES + 256 * 16 + 2 * HALO_H * HALO_W * 4 + TH * TW * 4 + (2 * C32 + 2) * 4 + 4 * C32 * 4;
 }
 
 // Launch what has been recorded (diagonals in increasing order) and keep recording.
-static int fw_defer_launch(void* stream) {
+static int fw_defer_launch(FwDefer& fw_defer, void* stream) {
   const size_t lds = fw_lds_bytes();
   static bool attr_set = false;
   if (!attr_set && lds > 65536) {
@@ -415,30 +417,45 @@ static int fw_defer_launch(void* stream) {
 // diagonal index last set by evf_fwd_defer_slot() instead of launching.  evf_fwd_defer_flush() launches the recorded
 // cells (one k_fwd_diag per non-empty diagonal, increasing index) and ends the recording; it must run before anything
 // reads the cells' outputs.  The caller guarantees that cells recorded under one index are independent and that a cell's
-// operands come from lower indices (or from launches issued before).  Process-wide state, one recorder at a time.
-extern "C" int evf_fwd_defer_begin() {
-  if (fw_defer.active) return EVF_EINVAL;
+// operands come from lower indices (or from launches issued before).  One recorder per stream (recording contexts, evf_common.h).
+static bool fw_poison = false;  // evf_defer_poison: process-wide debug switch
+extern "C" int evf_defer_poison(int on) {
+  fw_poison = on != 0;
+  return EVF_OK;
+}
+
+extern "C" int evf_fwd_defer_begin(void* stream) {
+  const int c = evf_ctx_find(stream);
+  if (c >= 0 && fw_tab[c].active) return EVF_EINVAL;  // one forward recording per stream
+  const int ctx = evf_ctx_acquire(stream);
+  if (ctx < 0) return EVF_EINVAL;
+  FwDefer& fw_defer = fw_tab[ctx];
   fw_defer.active = true;
   fw_defer.slot = 0;
   fw_defer.B = fw_defer.H = fw_defer.W = 0;
   for (int d = 0; d < FW_MAX_DIAGS; ++d) fw_defer.n[d] = 0;
   return EVF_OK;
 }
-extern "C" int evf_fwd_defer_slot(int d) {
-  if (!fw_defer.active || d < 0 || d >= FW_MAX_DIAGS) return EVF_EINVAL;
-  fw_defer.slot = d;
+extern "C" int evf_fwd_defer_slot(int d, void* stream) {
+  const int c = evf_ctx_find(stream);
+  if (c < 0 || !fw_tab[c].active || d < 0 || d >= FW_MAX_DIAGS) return EVF_EINVAL;
+  fw_tab[c].slot = d;
   return EVF_OK;
 }
-extern "C" int evf_fwd_defer_pending() {
-  if (!fw_defer.active) return 0;
+extern "C" int evf_fwd_defer_pending(void* stream) {
+  const int c = evf_ctx_find(stream);
+  if (c < 0 || !fw_tab[c].active) return 0;
+  FwDefer& fw_defer = fw_tab[c];
   int n = 0;
   for (int d = 0; d < FW_MAX_DIAGS; ++d) n += fw_defer.n[d];
   return n;
 }
 extern "C" int evf_fwd_defer_flush(void* stream) {
-  if (!fw_defer.active) return EVF_OK;
-  const int rc = fw_defer_launch(stream);
-  fw_defer.active = false;
+  const int c = evf_ctx_find(stream);
+  if (c < 0 || !fw_tab[c].active) return EVF_OK;
+  const int rc = fw_defer_launch(fw_tab[c], stream);
+  fw_tab[c].active = false;
+  evf_ctx_drop(c);
   return rc;
 }
 
@@ -447,18 +464,27 @@ static int launch_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_re
                          int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out, const PlifArgs* plif,
                          void* stream, const PredArgs* pred = nullptr) {
   PredArgs pd = pred ? *pred : PredArgs{nullptr, nullptr, nullptr};
-  if (fw_defer.active && !plif) {  // recorded, launched by evf_fwd_defer_flush (or when a diagonal is full / the geometry changes)
+  const int fctx = evf_ctx_find(stream);
+  FwDefer& fw_defer = fw_tab[fctx < 0 ? 0 : fctx];
+  if (fctx >= 0 && fw_defer.active && !plif) {  // recorded, launched by evf_fwd_defer_flush (or when a diagonal is full / the geometry changes)
     if (fw_defer.B && (fw_defer.B != B || fw_defer.H != H || fw_defer.W != W)) {
-      const int rc = fw_defer_launch(stream);
+      const int rc = fw_defer_launch(fw_defer, stream);
       if (rc) return rc;
     }
     if (fw_defer.n[fw_defer.slot] == FW_MAX_JOBS) {  // (cannot happen with one cell per layer and <= 8 layers)
-      const int rc = fw_defer_launch(stream);
+      const int rc = fw_defer_launch(fw_defer, stream);
       if (rc) return rc;
     }
     fw_defer.B = B, fw_defer.H = H, fw_defer.W = W;
     fw_defer.job[fw_defer.slot][fw_defer.n[fw_defer.slot]++] =
         FwJob{x, (const uint4*)wb_ff, (const uint4*)wb_rec, leak, thresh, v_prev, z_prev, v_out, z_out, zT_out, pd, hard_reset, 0};
+    if (fw_poison) {  // debug aid: the outputs hold conspicuous garbage until the flush has run the cell
+      const size_t npix = (size_t)B * H * W;
+      int rc = evf_hip(hipMemsetAsync(v_out, 0xFF, npix * C32 * sizeof(float), EVF_STREAM(stream)));  // 0xFFFFFFFF = NaN
+      if (!rc && z_out) rc = evf_hip(hipMemsetAsync(z_out, 0xFF, npix * sizeof(uint32_t), EVF_STREAM(stream)));
+      if (!rc && pd.flow) rc = evf_hip(hipMemsetAsync(pd.flow, 0xFF, npix * 2 * sizeof(float), EVF_STREAM(stream)));
+      if (rc) return rc;
+    }
     return EVF_OK;
   }
   dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(FW_THREADS);

@@ -915,17 +915,20 @@ static int head_bwd_go(const HdArgs& a, void* stream) {
 
 // head cells recorded by evf_bwd_defer_* (evf_common.h): launched one by one when their index comes up
 #define HD_MAX_JOBS 4
-static struct {
+struct HdDefer {
   int n[EVF_BWD_DIAGS];
   HdArgs job[EVF_BWD_DIAGS][HD_MAX_JOBS];
-} hd_defer = {{0}, {}};
-int evf_hd_defer_count() {
+};
+static HdDefer hd_tab[EVF_CTX_MAX];
+int evf_hd_defer_count(int ctx) {
+  const HdDefer& hd_defer = hd_tab[ctx];
   int n = 0;
   for (int d = 0; d < EVF_BWD_DIAGS; ++d) n += hd_defer.n[d];
   return n;
 }
-int evf_hd_defer_pending(int d) { return hd_defer.n[d]; }
-int evf_hd_defer_launch(int d, void* stream) {
+int evf_hd_defer_pending(int ctx, int d) { return hd_tab[ctx].n[d]; }
+int evf_hd_defer_launch(int ctx, int d, void* stream) {
+  HdDefer& hd_defer = hd_tab[ctx];
   for (int k = 0; k < hd_defer.n[d]; ++k) {
     evf_prof_mark(3, 0, stream);
     const int rc = head_bwd_go(hd_defer.job[d][k], stream);
@@ -946,12 +949,15 @@ extern "C" int evf_head_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out
     return EVF_EINVAL;
   const HdArgs a{g_z_out, g_v_out, v_out, v_prev, z_prev, x_in, leak, thresh, B, Cin, H, W, hard_reset, surrogate, act_width,
                  g_cur, g_v_prev, g_leak, g_thresh, slab, accumulate};
+  const int bctx = evf_ctx_find(stream);
+  const EvfBwdDefer evf_bwd_defer = bctx >= 0 ? evf_bwd_defer_tab[bctx] : EvfBwdDefer{false, 0};
+  HdDefer& hd_defer = hd_tab[bctx < 0 ? 0 : bctx];
   if (evf_bwd_defer.active) {
     if (hd_defer.n[evf_bwd_defer.slot] < HD_MAX_JOBS) {
       hd_defer.job[evf_bwd_defer.slot][hd_defer.n[evf_bwd_defer.slot]++] = a;
       return EVF_OK;
     }
-    const int rc = evf_bwd_defer_flush_now(stream);
+    const int rc = evf_bwd_defer_flush_now(bctx, stream);
     if (rc) return rc;
   }
   return head_bwd_go(a, stream);

@@ -362,8 +362,9 @@ class FireNetEngine:
     def flush_forward(self):
         if self.__dict__.get("_defer_open"):
             self._defer_open = False
-            _lib._defer_flush = None
-            _lib.call("evf_fwd_defer_flush")
+            with torch.cuda.stream(self._defer_stream):  # the recording belongs to the stream it was opened on
+                _lib.clear_defer_hook()
+                _lib.call("evf_fwd_defer_flush")
 
     def defer_backward(self, on=True):
         """While on, the backward cells of the window (fused backward, input gradient, head backward of every pass) are
@@ -376,8 +377,9 @@ class FireNetEngine:
     def flush_backward(self):
         if self.__dict__.get("_bdefer_open"):
             self._bdefer_open = False
-            _lib._defer_flush = None
-            _lib.call("evf_bwd_defer_flush")
+            with torch.cuda.stream(self._bdefer_stream):  # the recording belongs to the stream it was opened on
+                _lib.clear_defer_hook()
+                _lib.call("evf_bwd_defer_flush")
         # the recorded cells hold raw pointers into the passes' tapes and upstream gradients: those tensors are kept here
         # until the cells have been launched (stream order then protects the memory like any other tensor's)
         self._bdefer_keep = []
@@ -385,23 +387,25 @@ class FireNetEngine:
     def _bdefer_slot(self, win, step):
         """Index of step `step` (0 = top layer's fused backward, 1 = its input gradient, ...) of the current backward pass."""
         if not self.__dict__.get("_bdefer_open"):
-            if _lib.load().evf_bwd_defer_begin() != 0:
-                raise _lib.EvflowError("evf_bwd_defer_begin: another recording is open (one engine at a time)")
+            if _lib.raw("evf_bwd_defer_begin") != 0:
+                raise _lib.EvflowError("evf_bwd_defer_begin: another backward recording is open on this stream (one engine per stream)")
             self._bdefer_open, self._bdefer_base = True, win.bwd_k
-            _lib._defer_flush, _lib._DEFER_SAFE = self.flush_backward, _lib._DEFER_SAFE_BWD
+            self._bdefer_stream = torch.cuda.current_stream()
+            _lib.set_defer_hook(self.flush_backward, _lib._DEFER_SAFE_BWD)
         d = 2 * (win.bwd_k - self._bdefer_base) + step
         if d >= 96:  # (more than ~40 passes: launch what is recorded, start over)
             self.flush_backward()
             return self._bdefer_slot(win, step)
-        if _lib.load().evf_bwd_defer_slot(d) != 0:
+        if _lib.raw("evf_bwd_defer_slot", d) != 0:
             raise _lib.EvflowError("evf_bwd_defer_slot failed")
 
     def _defer_begin(self):
-        rc = _lib.load().evf_fwd_defer_begin()
+        rc = _lib.raw("evf_fwd_defer_begin")
         if rc != 0:
-            raise _lib.EvflowError("evf_fwd_defer_begin: another recording is open (one engine at a time)")
+            raise _lib.EvflowError("evf_fwd_defer_begin: another forward recording is open on this stream (one engine per stream)")
         self._defer_open, self._defer_t = True, 0
-        _lib._defer_flush, _lib._DEFER_SAFE = self.flush_forward, _lib._DEFER_SAFE_FWD
+        self._defer_stream = torch.cuda.current_stream()
+        _lib.set_defer_hook(self.flush_forward, _lib._DEFER_SAFE_FWD)
 
     def _flow_out(self, B, H, W, dev):
         slot, self._flow_slot = self._flow_slot, None
@@ -434,7 +438,7 @@ class FireNetEngine:
             if not self.__dict__.get("_defer_open"):
                 self._defer_begin()
         for i, c in enumerate(self.cells):
-            if defer and i > 0 and _lib.load().evf_fwd_defer_slot(self._defer_t + i - 1) != 0:
+            if defer and i > 0 and _lib.raw("evf_fwd_defer_slot", self._defer_t + i - 1) != 0:
                 raise _lib.EvflowError("evf_fwd_defer_slot failed")
             st = states[i]
             v_prev, z_prev, zT_prev = st[:3] if st is not None else (None, None, None)

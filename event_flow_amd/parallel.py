@@ -46,6 +46,14 @@ class DataParallel:
             if backend == "nccl" and device is not None:
                 kw["device_id"] = torch.device(device)
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, **kw)
+        # RCCL collectives run on a stream of their own, never on the caller's: torch issues a blocking collective on the CURRENT
+        # stream and hands its end event to the process group's watchdog thread, which polls it -- and HIP refuses a query of an
+        # event whose stream has meanwhile entered a graph capture (hipErrorCapturedEvent: the watchdog throws, the process
+        # aborts).  The step graphs are captured on the stream the warm-up's all-reduces ran on, so that race is real (found by
+        # tests/test_gpu_training.py::test_rccl_code_path_on_one_rank_*).  Ordering against the caller's stream by events.
+        self.stream = None
+        if self.active and backend == "nccl" and device is not None:
+            self.stream = torch.cuda.Stream(device=torch.device(device))
 
     # -- sharding ------------------------------------------------------------
     def shard(self, global_batch):
@@ -66,10 +74,21 @@ class DataParallel:
             comm[n : n + 1].zero_()
         comm[n + 1 : n + 2].fill_(1.0 if new_seq else 0.0)
 
+    def _on_comm_stream(self, fn):
+        """Run a collective on the communication stream, ordered after / before the caller's current stream."""
+        if self.stream is None:
+            return fn()
+        cur = torch.cuda.current_stream(self.stream.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            out = fn()
+        cur.wait_stream(self.stream)
+        return out
+
     def reduce(self, comm):
         """THE collective of a step: in-place SUM all-reduce of gradient + tail."""
         if self.active:
-            dist.all_reduce(comm, op=dist.ReduceOp.SUM)
+            self._on_comm_stream(lambda: dist.all_reduce(comm, op=dist.ReduceOp.SUM))
 
     def staged(self, comm):
         n = comm.numel() - self.TAIL
@@ -86,7 +105,7 @@ class DataParallel:
     def broadcast(self, t, src=0):
         """In-place broadcast (parameter replicas start from rank `src`'s values)."""
         if self.active:
-            dist.broadcast(t, src=src)
+            self._on_comm_stream(lambda: dist.broadcast(t, src=src))
 
     def any_flags(self, flags):
         """Element-wise OR over the ranks of a few host booleans (one tiny MAX all-reduce): the loader events every
@@ -96,13 +115,13 @@ class DataParallel:
             return [bool(f) for f in flags]
         t = torch.tensor([1.0 if f else 0.0 for f in flags], dtype=torch.float32,
                          device=self.device if self.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        self._on_comm_stream(lambda: dist.all_reduce(t, op=dist.ReduceOp.MAX))
         return [bool(v) for v in t.tolist()]
 
     def barrier(self):
         if self.active:
             if self.backend == "nccl":
-                dist.barrier(device_ids=[torch.device(self.device).index])
+                self._on_comm_stream(lambda: dist.barrier(device_ids=[torch.device(self.device).index]))
             else:
                 dist.barrier()
 
@@ -110,7 +129,7 @@ class DataParallel:
         if not self.active:
             return float(value)
         t = torch.tensor([float(value)], dtype=torch.float64, device=self.device if self.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        self._on_comm_stream(lambda: dist.all_reduce(t, op=dist.ReduceOp.MAX))
         return float(t.item())
 
     def close(self):

@@ -206,11 +206,21 @@ int evf_conv_lif_fwd_b3_pred(const uint32_t* x, const void* wb_ff, const void* w
  * cells, one kernel per non-empty index in increasing order (blockIdx.z = cell x sample; same kernel body, bit-identical
  * results), and ends the recording.  The caller guarantees that cells under one index are independent, that a cell's
  * operands come from lower indices or from launches made before, and that nothing reads a cell's outputs before the
- * flush.  Process-wide recorder (one at a time); evf_fwd_defer_pending() = cells recorded and not yet launched. */
-int evf_fwd_defer_begin(void);
-int evf_fwd_defer_slot(int index);
-int evf_fwd_defer_pending(void);
+ * flush.  evf_fwd_defer_pending() = cells recorded and not yet launched.
+ * CONTEXTS / THREADS: a recording (this kind and evf_bwd_defer_*) belongs to the STREAM it was opened on -- the library keeps
+ * one recorder per stream with an open recording (up to 16) and every entry point consults the recorder of its `stream`
+ * argument only.  Host threads driving different models on different streams record and launch independently, also through
+ * PyTorch's autograd (one backward worker thread per device, but each node on the stream of its forward); calls that belong to
+ * ONE recording must not race with each other (one thread at a time per stream).  A second begin of the same kind on a stream
+ * with an open recording returns EVF_EINVAL; begin with all contexts in use as well.
+ * STALE READS: a recorded cell has not run, so its outputs hold old bytes until the flush.  evf_defer_poison(1) (debug aid)
+ * makes every recorded forward cell fill its v_out with NaN bit patterns and its spike word outputs with 0xFFFFFFFF at record
+ * time (on `stream`), so that a read outside the library before the flush is conspicuous instead of plausible. */
+int evf_fwd_defer_begin(void* stream);
+int evf_fwd_defer_slot(int index, void* stream);
+int evf_fwd_defer_pending(void* stream);
 int evf_fwd_defer_flush(void* stream);
+int evf_defer_poison(int on);
 /* The same for the backward of a window (autograd of train_flow.py:141-154 over the passes of models/model.py:255-265): a
  * pass's backward is a chain of 13 steps (fused backward of the top layer, its input gradient, the next layer, ..., the head
  * layer); step s of pass t needs step s - 1 of pass t and steps s, s + 1 of pass t + 1.  Under the index 2 (P - 1 - t) + s
@@ -219,11 +229,12 @@ int evf_fwd_defer_flush(void* stream);
  * the index last given to evf_bwd_defer_slot (0 .. 95); any other call of these entry points first launches everything
  * recorded.  evf_bwd_defer_flush launches index after index -- the fused-backward cells of an index as one kernel, its
  * input-gradient cells as one kernel, head cells one by one -- and ends the recording.  Same kernel bodies as the one-cell
- * launches.  Process-wide recorder; the caller guarantees the index order and that nothing else reads a cell's outputs
- * before the flush. */
-int evf_bwd_defer_begin(void);
-int evf_bwd_defer_slot(int index);
-int evf_bwd_defer_pending(void);
+ * launches.  Per-thread recorder (see above); the caller guarantees the index order, that nothing else reads a cell's outputs
+ * before the flush, and that every buffer a recorded cell refers to stays allocated until then.  With the gradient
+ * pre-split (evf_lif_bwd_wgrad* given g_split, evf_conv_dgrad_b3[_pair]) the input-gradient cells are recorded as well. */
+int evf_bwd_defer_begin(void* stream);
+int evf_bwd_defer_slot(int index, void* stream);
+int evf_bwd_defer_pending(void* stream);
 int evf_bwd_defer_flush(void* stream);
 /* Measurement aid: evf_defer_profile(1) brackets every launch of the following flushes with HIP events;
  * evf_defer_profile_read synchronises the device, returns per kind (0 forward cells, 1 fused-backward cells, 2

@@ -136,20 +136,20 @@ def test_recorded_input_gradient_cells_are_bit_identical(shape):
         for which, split in ((0, False), (1, False), (1, True)):
             assert L.evf_dgrad_diag_select(which) == 0
             outs = [(torch.full((B, H, W, C), 7.0, device=DEV), torch.full((B, H, W, C), 7.0, device=DEV)) for _ in cells]
-            assert L.evf_bwd_defer_begin() == 0
+            assert _lib.raw("evf_bwd_defer_begin") == 0
             try:
                 for (d, g, gs, w1, w2), (a, b) in zip(cells, outs):
-                    assert L.evf_bwd_defer_slot(d) == 0
+                    assert _lib.raw("evf_bwd_defer_slot", d) == 0
                     src = gs if split else g
                     if w2 is None:
                         _lib.call("evf_conv_dgrad_b3" if split else "evf_conv_dgrad_b3_f32", P(src), P(w1), P(a), 0, B, H, W, None, None)
                     else:
                         _lib.call("evf_conv_dgrad_b3_pair" if split else "evf_conv_dgrad_b3_f32_pair", P(src), P(w1), P(a), 0, P(w2), P(b),
                                   B, H, W, None, None)
-                assert L.evf_bwd_defer_pending() == len(cells)
+                assert _lib.raw("evf_bwd_defer_pending") == len(cells)
             finally:
                 _lib.call("evf_bwd_defer_flush")
-            assert L.evf_bwd_defer_pending() == 0
+            assert _lib.raw("evf_bwd_defer_pending") == 0
             torch.cuda.synchronize()
             for k, ((a, b), (ra, rb)) in enumerate(zip(outs, ref)):
                 assert torch.equal(a, ra), (which, split, k)

@@ -483,9 +483,9 @@ def test_exact_split_input_gradient_is_fp32_equivalent(shape):
     finally:
         L.evf_conv_dgrad_select(-1)
     gx = torch.empty(B, H, W, C, device=DEV)  # the recorded-cell launch (k_dgrad_diag_ws)
-    assert L.evf_bwd_defer_begin() == 0
+    assert _lib.raw("evf_bwd_defer_begin") == 0
     try:
-        assert L.evf_bwd_defer_slot(0) == 0
+        assert _lib.raw("evf_bwd_defer_slot", 0) == 0
         _lib.call("evf_conv_dgrad_b3_f32", g_nhwc.data_ptr(), pb3.data_ptr(), gx.data_ptr(), 0, B, H, W, None, None)
     finally:
         _lib.call("evf_bwd_defer_flush")
@@ -499,9 +499,9 @@ def test_exact_split_input_gradient_is_fp32_equivalent(shape):
     planes = torch.stack([hi, mid, lo]).contiguous()
     assert torch.equal(planes[0].float() + planes[1].float() + planes[2].float(), g_nhwc)  # exact split
     gx = torch.empty(B, H, W, C, device=DEV)
-    assert L.evf_bwd_defer_begin() == 0
+    assert _lib.raw("evf_bwd_defer_begin") == 0
     try:
-        assert L.evf_bwd_defer_slot(0) == 0
+        assert _lib.raw("evf_bwd_defer_slot", 0) == 0
         _lib.call("evf_conv_dgrad_b3", planes.data_ptr(), pb3.data_ptr(), gx.data_ptr(), 0, B, H, W, None, None)
     finally:
         _lib.call("evf_bwd_defer_flush")
@@ -725,6 +725,81 @@ def test_hipgraph_replay_is_bitwise_the_eager_step_under_a_deterministic_loss():
     for a, b in zip(m1.states, m2.states):
         assert torch.equal(a, b)
     assert float((opt1.flat_param - make().to(DEV).state_dict()["head.ff.weight"].new_zeros(1)).abs().sum()) > 0  # (it trained)
+
+
+def test_recorders_are_per_thread_and_poison_marks_stale_reads():
+    """The diagonal-launch recorders of the library are thread_local: two host threads, each driving its own model through a
+    window with recorded forward and backward cells at the same time, must get the gradients they get alone (a process-global
+    recorder would mix their cells or refuse the second evf_*_defer_begin).  evf_defer_poison(1): between recording and
+    flush the recorded cells' outputs hold NaN / all-ones words instead of plausible stale values."""
+    import threading
+
+    from event_flow_amd import synthetic
+    from event_flow_amd.dataloader.encodings import encode_event_list
+
+    B, n, H, W, P = 2, 500, 32, 64, 3
+    lists = [[G(synthetic.event_list_batch(B, n, H, W, 8100 + 100 * w + k)) for k in range(P)] for w in range(2)]
+
+    def make(seed):
+        torch.manual_seed(seed)
+        m = LIFFireNet(model_cfg()).to(DEV)
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                if k.endswith("thresh"):
+                    p.mul_(0.25)
+        m.train()
+        return m
+
+    def window(model, evs, out, key, barrier=None):
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            lossf = hloss.EventWarping(loss_cfg(H, W), DEV)
+            opt = FlatAdam(model, lr=2e-4, clip=100.0)
+            opt.zero_grad()
+            passes = [encode_event_list(ev, 2, (H, W), want=("cnt", "mask", "pol")) for ev in evs]
+            for d in passes:
+                d["event_voxel"] = None
+            if barrier is not None:
+                barrier.wait()  # both threads enter their windows together
+            from event_flow_amd.train import window_backward
+
+            loss = window_backward(model, lossf, opt, passes)
+            stream.synchronize()
+            out[key] = (float(loss), opt.flat_grad.detach().clone())
+
+    alone = {}
+    for w in range(2):
+        window(make(10 + w), lists[w], alone, w)
+    both = {}
+    bar = threading.Barrier(2)
+    ths = [threading.Thread(target=window, args=(make(10 + w), lists[w], both, w, bar)) for w in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert set(both) == {0, 1}
+    for w in range(2):
+        assert abs(both[w][0] - alone[w][0]) <= 1e-5 * abs(alone[w][0]), (w, both[w][0], alone[w][0])
+        ga, gb = alone[w][1], both[w][1]
+        assert float((ga - gb).norm()) <= 2e-4 * float(ga.norm()), w  # (the loss backward sums with float atomics)
+    L = _lib.load()
+    assert _lib.raw("evf_fwd_defer_pending") == 0 and _lib.raw("evf_bwd_defer_pending") == 0
+    # poison: record one pass, look at a hidden layer's state tensor through torch BEFORE the flush
+    m = make(3)
+    m.defer_forward(True)
+    assert L.evf_defer_poison(1) == 0
+    try:
+        d = encode_event_list(lists[0][0], 2, (H, W), want=("cnt", "mask", "pol"))
+        m(None, d["event_cnt"])
+        eng = m._eng()
+        v_hidden = eng._states[1][0]  # raw engine tensor of a recorded cell (the public accessors flush first)
+        assert _lib.raw("evf_fwd_defer_pending") > 0
+        assert bool(torch.isnan(v_hidden).all())
+        m.defer_forward(False)  # launches what was recorded
+        assert _lib.raw("evf_fwd_defer_pending") == 0 and bool(torch.isfinite(v_hidden).all())
+    finally:
+        L.evf_defer_poison(0)
+        m.defer_forward(False)
 
 
 def test_graphed_window_step_equals_eager_training():
@@ -997,9 +1072,9 @@ def test_diagonal_launches_equal_cell_by_cell_launches(monkeypatch):
         model.defer_forward(defer)
         flows = [model(d["event_voxel"], d["event_cnt"])["flow"][0] for d in passes_from_golden(g)]
         if defer:
-            assert _lib.load().evf_fwd_defer_pending() == 6 * len(flows)  # nothing but the head layers has run yet
+            assert _lib.raw("evf_fwd_defer_pending") == 6 * len(flows)  # nothing but the head layers has run yet
         model.defer_forward(False)
-        assert _lib.load().evf_fwd_defer_pending() == 0
+        assert _lib.raw("evf_fwd_defer_pending") == 0
         return [N(f).copy() for f in flows], [N(s).copy() for s in model.states]
 
     (f0, s0), (f1, s1) = forward_only(False), forward_only(True)
@@ -1022,7 +1097,7 @@ def test_diagonal_launches_equal_cell_by_cell_launches(monkeypatch):
         return out
 
     ref, got = run(False), run(True)
-    assert _lib.load().evf_fwd_defer_pending() == 0 and _lib.load().evf_bwd_defer_pending() == 0
+    assert _lib.raw("evf_fwd_defer_pending") == 0 and _lib.raw("evf_bwd_defer_pending") == 0
     # first window: same weights, bit-identical flows -> the same loss up to the order of the loss's own float atomics
     np.testing.assert_allclose(got[0][0], ref[0][0], rtol=1e-6)
     for (l0, n0, p0), (l1, n1, p1) in zip(ref, got):
@@ -1066,7 +1141,7 @@ def test_diagonal_launches_short_and_long_windows(monkeypatch, P):
         passes = htrain.encode_passes(lists, 2, (H, W))
         loss = htrain.window_backward(model, lossf, opt, passes)
         torch.cuda.synchronize()
-        assert _lib.load().evf_fwd_defer_pending() == 0 and _lib.load().evf_bwd_defer_pending() == 0
+        assert _lib.raw("evf_fwd_defer_pending") == 0 and _lib.raw("evf_bwd_defer_pending") == 0
         return float(loss.detach()), N(opt.flat_grad).copy()
 
     (l0, g0), (l1, g1) = run(False), run(True)

@@ -157,7 +157,7 @@ def _bench_rccl_one_rank(extra, port):
                           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
                           "--no-cpu-baseline", "--no-iwe", "--no-others"] + extra,
                          capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.returncode == 0, "\n".join(ln for ln in out.stderr.splitlines() if "frame #" not in ln)[-6000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     return json.loads(lines[0])
