@@ -541,11 +541,11 @@ __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     const float4* __restrict__ v_out, const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev,
     const uint32_t* __restrict__ xT, const uint32_t* __restrict__ zT, const float* __restrict__ leak,
     const float* __restrict__ thresh, int B, int H, int W, int nchunk, long nunits, int hard_reset_rt, int surrogate_rt,
-    float width, int accumulate, float4* __restrict__ g_cur, uint2* __restrict__ g_split, float4* __restrict__ g_v_prev,
-    float* __restrict__ g_leak, float* __restrict__ g_thresh, float* __restrict__ slab_ff, float* __restrict__ slab_rec,
-    FbTop top, int row_ld) {
+    float width, int accumulate, int nrows_total, float4* __restrict__ g_cur, uint2* __restrict__ g_split,
+    float4* __restrict__ g_v_prev, float* __restrict__ g_leak, float* __restrict__ g_thresh, float* __restrict__ slab_ff,
+    float* __restrict__ slab_rec, FbTop top, int row_ld) {
   fb_body<REC, TOP, FAST>(blockIdx.x, gridDim.x, g_z_out, g_z_out2, g_v_out, v_out, v_prev, z_prev, xT, zT, leak, thresh, B, H, W,
-                          nchunk, nunits, hard_reset_rt, surrogate_rt, width, accumulate, (int)gridDim.x, g_cur, g_split, g_v_prev, g_leak,
+                          nchunk, nunits, hard_reset_rt, surrogate_rt, width, accumulate, nrows_total, g_cur, g_split, g_v_prev, g_leak,
                           g_thresh, slab_ff, slab_rec, top, row_ld);
 }
 
@@ -681,6 +681,35 @@ struct FbDefer {
 };
 static FbDefer fb_tab[EVF_CTX_MAX];
 
+// Blocks per cell: a block takes u = 8..16 units (the slab rows a launch does not write are zero-filled on first touch, see
+// fb_body), and a launch of n cells runs in whole rounds of one block per CU -- a block costs ~21 k cycles of prologue +
+// epilogue and ~5.5 k per unit (phase stamps, 128 x 128 x B8).  The u with the least rounds x (21 + 5.5 u): one cell of
+// 128 x 128 x B8: u = 8, 256 blocks; four cells: u = 16, 512 blocks = 2 rounds; one cell of 260 x 346 x B4 (6240 units): u = 13,
+// 480 blocks = 2 rounds instead of 780 = 4.  EVF_BWD_UNITS=8..16 fixes u.
+static int fb_blocks_per_cell(long nunits, int n) {
+  static const int mode = []() {
+    const char* e = getenv("EVF_BWD_UNITS");
+    const int v = e ? atoi(e) : 0;
+    return (v >= FB_UNITS && v <= FB_UNITS_MAX) ? v : 0;
+  }();
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+  }
+  if (mode) return evf_cdiv(nunits, mode);
+  long best = -1;
+  int best_nb = evf_cdiv(nunits, FB_UNITS);
+  for (int u = FB_UNITS; u <= FB_UNITS_MAX; ++u) {
+    const int nb = evf_cdiv(nunits, u);
+    const long cost = (long)evf_cdiv((long)n * nb, ncu) * (42 + 11 * u);  // (x2: integers)
+    if (best < 0 || cost < best) best = cost, best_nb = nb;
+  }
+  return best_nb;
+}
+
 static int fb_defer_launch(FbDefer& fb_defer, int d, void* stream) {
   const int n = fb_defer.n[d];
   if (!n) return EVF_OK;
@@ -693,24 +722,7 @@ static int fb_defer_launch(FbDefer& fb_defer, int d, void* stream) {
   for (int k = 0; k < FB_MAX_JOBS; ++k) jobs.j[k] = fb_defer.job[d][k < n ? k : 0];
   const long nunits = fb_units(fb_defer.B, fb_defer.H, fb_defer.W);
   const int nrows = evf_cdiv(nunits, FB_UNITS), nchunk = (fb_defer.W + FB_CW - 1) / FB_CW;
-  // Units per block: 8 (one slab row per block) or 16 (half the blocks, half the slab read-modify-write and half the ~21 k
-  // cycles of prologue + epilogue a block pays on top of ~5.5 k per unit), whichever needs less time in whole rounds of one
-  // block per CU -- n cells x 256 blocks are n rounds of 65 k cycles, n x 128 blocks ceil(n / 2) rounds of 109 k (128 x 128 x B8).
-  static const int mode = []() {
-    const char* e = getenv("EVF_BWD_UNITS");  // 8 / 16: fixed; default: by rounds
-    return e ? atoi(e) : 0;
-  }();
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
-    if (ncu <= 0) ncu = 256;
-  }
-  const int nb16 = evf_cdiv(nunits, FB_UNITS_MAX);
-  const long cost8 = (long)evf_cdiv((long)n * nrows, ncu) * (21 + 8 * 11 / 2), cost16 = (long)evf_cdiv((long)n * nb16, ncu) * (21 + 16 * 11 / 2);
-  const bool wide = mode == 16 || (mode != 8 && cost16 < cost8);
-  const int nblk = wide ? nb16 : nrows;
+  const int nblk = fb_blocks_per_cell(nunits, n);
   evf_prof_mark(1, 0, stream);
   hipLaunchKernelGGL(k_bwd_diag, dim3(nblk * n), dim3(FB_THREADS), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
                      fb_defer.W, nchunk, nunits, fb_defer.row_ld, nblk, nrows);
@@ -775,7 +787,8 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
   accumulate &= 1;
   const long nunits = fb_units(B, H, W);
   const int nchunk = (W + FB_CW - 1) / FB_CW;
-  dim3 grid(evf_cdiv(nunits, FB_UNITS)), block(FB_THREADS);
+  const int nrows_all = evf_cdiv(nunits, FB_UNITS);
+  dim3 grid(fb_blocks_per_cell(nunits, 1)), block(FB_THREADS);
   hipStream_t st = EVF_STREAM(stream);
   const FbTop top = topp ? *topp : FbTop{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   static bool attr[12] = {false};
@@ -807,7 +820,7 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
     }                                                                                                                     \
     hipLaunchKernelGGL((k_lif_bwd_wgrad<REC_, TOP_, FAST_>), grid, block, FB_LDS, st, (const float4*)g_z_out,             \
                        (const float4*)g_z_out2, (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev, z_prev, xT, zT_prev, leak,    \
-                       thresh, B, H, W, nchunk, nunits, hard_reset, surrogate, act_width, accumulate, (float4*)g_cur,     \
+                       thresh, B, H, W, nchunk, nunits, hard_reset, surrogate, act_width, accumulate, nrows_all, (float4*)g_cur,     \
                        (uint2*)g_split, (float4*)g_v_prev, g_leak, g_thresh, slab_ff, slab_rec, top, row_ld);             \
   } while (0)
 #define FB_GO2(REC_, TOP_, slot)            \
