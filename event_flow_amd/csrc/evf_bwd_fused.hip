@@ -31,7 +31,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define C32 32
 #define FB_CW 64    // pixels per unit (row segment): one float4 of every tensor per thread
 #define FB_UNITS 8       // units per block of a one-cell launch = slab rows per (cell, input): evf_lif_bwd_wgrad_slabs
-#define FB_UNITS_MAX 16  // a diagonal launch may give a block twice as many (fb_defer_launch)
+#define FB_UNITS_MAX 64  // a launch may give a block up to this many (fb_blocks_per_cell): one lane of the geometry table each
 #define FB_THREADS 512
 #define FB_NW (FB_CW / 32 + 2)  // plane words per (row, channel): segment + one halo word each side
 #define FB_R0 32768             // LDS region 0: operand double buffer (24 KiB), later the tap-8 reduction (32 KiB)
@@ -162,14 +162,14 @@ __device__ __forceinline__ void fb_body(
   // few channels at the same time (64 KiB stride between blocks).
   const int nblk = nblk_;
   const int nu = (int)((nunits - (long)bid + nblk - 1) / nblk);
-  // Geometry of the block's (<= FB_UNITS_MAX) units: lane (k & 15) holds unit k's (sample, row, first column), computed ONCE
+  // Geometry of the block's (<= FB_UNITS_MAX) units: lane k holds unit k's (sample, row, first column), computed ONCE
   // here; a unit's geometry then is three v_readlane into SGPRs.  As two integer divisions by run-time values per call
   // (v_rcp + fix-up chains with VALU -> SALU hops), four calls per unit, it was the "0.75 k cycles of load issue" of the
   // phase stamps.
-  static_assert(FB_UNITS_MAX <= 16, "geometry table: one lane per unit of the block");
+  static_assert(FB_UNITS_MAX <= 64, "geometry table: one lane per unit of the block");
   int g_b, g_y, g_x0;
   {
-    const int u = bid + min(lane & 15, nu - 1) * nblk;  // nunits < 2^31
+    const int u = bid + min(lane, nu - 1) * nblk;  // nunits < 2^31
     const int row = u / nchunk;
     g_b = row / H;
     g_y = row - g_b * H;
@@ -681,11 +681,11 @@ struct FbDefer {
 };
 static FbDefer fb_tab[EVF_CTX_MAX];
 
-// Blocks per cell: a block takes u = 8..16 units (the slab rows a launch does not write are zero-filled on first touch, see
+// Blocks per cell: a block takes u = 8..64 units (the slab rows a launch does not write are zero-filled on first touch, see
 // fb_body), and a launch of n cells runs in whole rounds of one block per CU -- a block costs ~21 k cycles of prologue +
 // epilogue and ~5.5 k per unit (phase stamps, 128 x 128 x B8).  The u with the least rounds x (21 + 5.5 u): one cell of
-// 128 x 128 x B8: u = 8, 256 blocks; four cells: u = 16, 512 blocks = 2 rounds; one cell of 260 x 346 x B4 (6240 units): u = 13,
-// 480 blocks = 2 rounds instead of 780 = 4.  EVF_BWD_UNITS=8..16 fixes u.
+// 128 x 128 x B8 (2048 units): u = 8, 256 blocks; three cells: u = 25, 3 x 82 blocks = ONE round; six cells: u = 49, 6 x 42 blocks;
+// one cell of 260 x 346 x B4 (6240 units): u = 25, 250 blocks instead of 780 = 4 rounds.  EVF_BWD_UNITS=8..64 fixes u.
 static int fb_blocks_per_cell(long nunits, int n) {
   static const int mode = []() {
     const char* e = getenv("EVF_BWD_UNITS");

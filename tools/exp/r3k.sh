@@ -14,6 +14,7 @@ PY
 ARGS="--steps 30 --warmup 5"
 bench c3_auto A=1
 bench c3_u16 EVF_BWD_UNITS=16
+bench c3_auto2 A=1
 ARGS="--steps 10 --warmup 3 --config c5"
 bench c5_auto A=1
 bench c5_u8 EVF_BWD_UNITS=8
