@@ -15,6 +15,7 @@
 // B operand: packed per (tap, m, term) as 64 lanes x 16 B (k_pack_conv_weight_b3).
 #include "evf_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -376,6 +377,272 @@ __global__ __launch_bounds__(FW_THREADS) void k_fwd_diag(FwJobs jobs, int B, int
                               J.z_out, J.zT_out, none, J.pr);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_fwd_diag_p: the cells of a diagonal as ONE PERSISTENT launch (256 blocks x 8 waves), the forward counterpart of
+// k_dgrad_diag_dma.
+//
+// k_fwd_diag above runs one 8-row x 32-pixel tile per 4-wave block: every block stages 54 KiB of split weights by LDS-DMA
+// (the CU's DMA path takes ~30 B/clk: 1.8 k cycles, twice for a recurrent cell) for 3.7 k cycles of MFMAs, builds the byte
+// table, and its four waves run matrix phase and epilogue in lockstep -- the matrix pipe is busy a third of the time
+// (a launch of 5.3 products: 61 us against 22 us of MFMAs).  Here
+//   * a block takes a contiguous, cost-weighted range of the launch's (cell, strip) list (a recurrent cell's strip counts
+//     twice), stages the weights of a cell ONCE -- feed-forward and recurrent set side by side, 108 KiB -- and the table once;
+//   * the unit of work is a STRIP of 2 rows x 32 pixels owned by ONE wave: the wave loads its own 4 x 34 halo words
+//     (x and previous z), prefetches the previous state, runs its 108 (216) MFMAs and its epilogue, with wave-level
+//     synchronisation only.  The eight waves of a block drift apart, so one wave's epilogue (element-wise LIF update,
+//     ballots, stores) runs under the MFMAs of the other wave of its SIMD.
+// Same products in the same order per accumulator as fwd_b3_body: bit-identical results.  Default neuron path (LIF); PLIF
+// cells keep the per-tile kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+#define FP_WAVES 8
+#define FP_THREADS (64 * FP_WAVES)
+#define FP_HALO (4 * HALO_W)  // words of a strip's halo: rows y0 - 1 .. y0 + 2
+#define FP_LDS ((size_t)2 * WB3_BYTES + 256 * 16 + 4 * C32 * 4 + (2 * C32 + 2 + 2) * 4 + (size_t)FP_WAVES * (2 * FP_HALO * 4 + 32 * FW_SP * 4))
+
+struct FpPlan {
+  int njobs;
+  int ntx, nyy;      // strips per row of tiles / strip rows per sample
+  int nstrips;       // per cell
+  int weight[FW_MAX_JOBS];  // relative cost of a strip: 3 feed-forward, 4 recurrent
+  int total;         // sum of nstrips * weight
+};
+
+#ifdef FP_STAMPS  // phase stamps (debug build through EVF_LIB): [block < 16][wave 0 / 4][128] shader-clock values
+__device__ unsigned long long fp_stamps[16 * 2 * 128];
+extern "C" int evf_debug_fp_stamps(void* dst) { return evf_hip(hipMemcpyFromSymbol(dst, HIP_SYMBOL(fp_stamps), sizeof(fp_stamps))); }
+#define FP_STAMP()                                                                                   \
+  do {                                                                                               \
+    if (blockIdx.x < 16 && lane == 0 && (wv & 3) == 0 && nst < 128)                                  \
+      fp_stamps[(blockIdx.x * 2 + (wv >> 2)) * 128 + nst++] = __builtin_readcyclecounter();         \
+  } while (0)
+#else
+#define FP_STAMP() do {} while (0)
+#endif
+
+__global__ __launch_bounds__(FP_THREADS) void k_fwd_diag_p(FwJobs jobs, FpPlan plan, int B, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint4* s_wff = (uint4*)smem_raw;
+  uint4* s_wrec = s_wff + NFRAG * 64;
+  uint4* s_lut = s_wrec + NFRAG * 64;
+  float* s_par = (float*)(s_lut + 256);   // [4][32]
+  float* s_pw = s_par + 4 * C32;          // 2*32 + 2 (+2 pad)
+  uint32_t* s_halo = (uint32_t*)(s_pw + 2 * C32 + 4);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  uint32_t* s_x = s_halo + wv * (2 * FP_HALO);
+  uint32_t* s_z = s_x + FP_HALO;
+  float* stg = (float*)(s_halo + FP_WAVES * 2 * FP_HALO) + wv * (32 * FW_SP);
+  const int i = lane & 31, kg = lane >> 5, j = lane & 31;
+  const int nW = (W + 31) / 32;
+  const int rj = (j & 3) + 4 * (j >> 3), kgj = (j >> 2) & 1;  // (r, half) whose ballot holds channel j's bit plane
+  int nst = 0;
+  (void)nst;
+  FP_STAMP();
+  if (tid < 256) {  // byte -> 8 x bf16 {0, 1.0}
+    const uint32_t t = tid;
+    auto pr8 = [&](int e) { return ((t >> e) & 1u) * 0x3F80u | (((t >> (e + 1)) & 1u) * 0x3F80u) << 16; };
+    s_lut[tid] = make_uint4(pr8(0), pr8(2), pr8(4), pr8(6));
+  }
+  const long lo = ((long)blockIdx.x * plan.total) / gridDim.x, hi = ((long)(blockIdx.x + 1) * plan.total) / gridDim.x;
+  long cell0 = 0;  // weighted start of the cell
+  bool first = true;
+  for (int c = 0; c < plan.njobs; ++c) {
+    const int wgt = plan.weight[c];
+    const long cw = (long)plan.nstrips * wgt;
+    // strips of this cell whose weighted start S = cell0 + i * wgt lies in [lo, hi)
+    long a0 = lo - cell0, a1 = hi - cell0;
+    cell0 += cw;
+    int i0 = a0 <= 0 ? 0 : (int)((a0 + wgt - 1) / wgt), i1 = a1 <= 0 ? 0 : (int)((a1 + wgt - 1) / wgt);
+    i0 = min(i0, plan.nstrips), i1 = min(i1, plan.nstrips);
+    if (i0 >= i1) continue;  // (block-uniform)
+    const FwJob& J = jobs.j[c];
+    const bool rec = J.wrec != nullptr;
+    if (!first) __syncthreads();  // every wave is done with the previous cell's weights and parameters
+    first = false;
+    for (int u = wv; u < NFRAG; u += FP_WAVES) b3_glds16(J.wff + u * 64 + lane, s_wff + u * 64);
+    if (rec)
+      for (int u = wv; u < NFRAG; u += FP_WAVES) b3_glds16(J.wrec + u * 64 + lane, s_wrec + u * 64);
+    if (tid < C32) {
+      s_par[tid] = b3_sigmoid(J.leak[tid]);           // torch.sigmoid(self.leak)     spiking_submodules.py:111/:536
+      s_par[C32 + tid] = fmaxf(J.thresh[tid], 0.01f);  // self.thresh.clamp_min(0.01)  :108/:533
+    }
+    if (J.pr.w) {
+      if (tid < 2 * C32) s_pw[tid] = J.pr.w[tid];
+      if (tid < 2) s_pw[2 * C32 + tid] = J.pr.bias[tid];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    FP_STAMP();
+    const uint32_t* __restrict__ x = J.x;
+    const uint32_t* __restrict__ z_prev = J.z_prev;
+    const float* __restrict__ v_prev = J.v_prev;
+    float* __restrict__ v_out = J.v_out;
+    const int hard_reset = J.hard_reset;
+    uint32_t hx[3], hz[3];
+    bool hin[3];
+    auto halo_fetch = [&](int sj) {  // (past the range: the last strip again, never committed)
+      const int sk = min(sj, i1 - 1);
+      const int tx = sk % plan.ntx, rr = sk / plan.ntx, yy = rr % plan.nyy, b = rr / plan.nyy;
+      const int y0 = 2 * yy, x0 = tx * TW;
+      const uint32_t* zsrc = z_prev ? z_prev : x;  // no load under a branch: clamped address, select afterwards
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int l = min(lane + 64 * q, FP_HALO - 1), hr = l / HALO_W, hc = l - hr * HALO_W;
+        const int ya = y0 + hr - 1, xa = x0 + hc - 1;
+        hin[q] = ya >= 0 && ya < H && xa >= 0 && xa < W;
+        const long p = ((long)b * H + min(max(ya, 0), H - 1)) * W + min(max(xa, 0), W - 1);
+        hx[q] = x[p], hz[q] = zsrc[p];
+      }
+    };
+    for (int si = i0 + wv; si < i1; si += FP_WAVES) {
+      const int tx = si % plan.ntx, rr = si / plan.ntx, yy = rr % plan.nyy, b = rr / plan.nyy;
+      const int y0 = 2 * yy, x0 = tx * TW;
+      FP_STAMP();
+      // ---- the strip's halo words (x and the cell's previous output spikes), 3 per lane and array: requested one strip
+      // ahead (`hx`, `hz`, issued behind the previous strip's state prefetch), committed to the wave's LDS rows here
+      if (si == i0 + wv) halo_fetch(si);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int l = lane + 64 * q;
+        if (l < FP_HALO) s_x[l] = hin[q] ? hx[q] : 0u, s_z[l] = (hin[q] && z_prev) ? hz[q] : 0u;
+      }
+      // ---- previous state of the strip's two rows: in flight during the MFMAs
+      float4 vp[2][4];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const long pq = ((long)b * H + min(y0 + m, H - 1)) * W + min(x0 + i, W - 1);
+        const float* src = v_prev ? v_prev : v_out;  // unconditional (clamped) loads, selected afterwards
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 val = *(const float4*)(src + pq * C32 + 8 * q + 4 * kg);
+          vp[m][q] = v_prev ? val : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      halo_fetch(si + FP_WAVES);  // the next strip's words: land during this strip's MFMAs
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      f32x16 acc0 = {0}, acc1 = {0};
+      // Matrix phase, software pipelined: the 18 spike words of the lane's two pixels (9 taps x 2 rows) are read up front, the
+      // two A fragments (table look-ups) and the three weight fragments of stage g + 1 are requested BEFORE the 6 MFMAs of stage g
+      // and pinned there -- as `ds_read; s_waitcnt; v_mfma` per tap (the rolled loop of fwd_b3_body) the look-up chain
+      // word -> table -> MFMA was a dependent LDS round trip per tap that two waves per SIMD cannot hide.
+      auto conv_phase = [&](const uint32_t* __restrict__ sb, const uint4* __restrict__ sw) {
+        uint32_t wd[9][2];
+#pragma unroll
+        for (int tau = 0; tau < 9; ++tau) {
+          const int dy = tau / 3, dx = tau % 3;
+          wd[tau][0] = sb[dy * HALO_W + i + dx] >> (8 * kg);
+          wd[tau][1] = sb[(1 + dy) * HALO_W + i + dx] >> (8 * kg);
+        }
+        uint4 af[2][2], wf[2][3];  // [stage parity][row] / [stage parity][term]; a stage = (tap, K half m): 6 MFMAs
+        auto fetch = [&](int g) {
+          const int sp = g & 1, tau = g >> 1, m = g & 1;
+          af[sp][0] = s_lut[(wd[tau][0] >> (16 * m)) & 0xFFu];
+          af[sp][1] = s_lut[(wd[tau][1] >> (16 * m)) & 0xFFu];
+#pragma unroll
+          for (int t3 = 0; t3 < 3; ++t3) wf[sp][t3] = sw[(g * 3 + t3) * 64 + lane];
+        };
+        fetch(0);
+#pragma unroll
+        for (int g = 0; g < 18; ++g) {
+          const int sp = g & 1;
+          if (g + 1 < 18) fetch(g + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8 a0 = *(const bf16x8*)&af[sp][0], a1 = *(const bf16x8*)&af[sp][1];
+#pragma unroll
+          for (int t3 = 0; t3 < 3; ++t3) {
+            const bf16x8 bw = *(const bf16x8*)&wf[sp][t3];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw, a0, acc0, 0, 0, 0);  // weights as A: transposed product
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw, a1, acc1, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      FP_STAMP();
+      conv_phase(s_x, s_wff);
+      FP_STAMP();
+      if (rec) conv_phase(s_z, s_wrec);
+      FP_STAMP();
+      // ---- epilogue (transposed tile, as fwd_b3_body): lane = pixel x0 + i of rows y0, y0 + 1; channel c = 8q + e + 4kg.
+      // The lane's 16 leak / threshold values come in as eight 16-byte reads up front (as `s_par[c]` beside each use the
+      // element loop was 48 dependent LDS round trips per strip: 6-9 k cycles of epilogue against 4.2 k of MFMAs, phase stamps).
+      float lam[16], th[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 l4 = *(const float4*)(s_par + 8 * q + 4 * kg), t4 = *(const float4*)(s_par + C32 + 8 * q + 4 * kg);
+        lam[4 * q] = l4.x, lam[4 * q + 1] = l4.y, lam[4 * q + 2] = l4.z, lam[4 * q + 3] = l4.w;
+        th[4 * q] = t4.x, th[4 * q + 1] = t4.y, th[4 * q + 2] = t4.z, th[4 * q + 3] = t4.w;
+      }
+      const uint32_t zw2[2] = {s_z[HALO_W + 1 + i], s_z[2 * HALO_W + 1 + i]};  // previous output spikes of the lane's two pixels
+      __builtin_amdgcn_sched_barrier(0);  // (left alone the reads above are sunk next to their uses, one wait each)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const f32x16& acc = m ? acc1 : acc0;
+        const int row = y0 + m;
+        const bool ok = row < H && x0 + i < W;
+        const long pix = ((long)b * H + min(row, H - 1)) * W + min(x0 + i, W - 1);
+        const uint32_t zw = zw2[m];
+        uint32_t bits = 0u, myplane = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v4[4] = {vp[m][q].x, vp[m][q].y, vp[m][q].z, vp[m][q].w};
+          float vo4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e, cc = 8 * q + e + 4 * kg;
+            const float z = (float)((zw >> cc) & 1u);
+            const float cur = acc[r];
+            const float vo_hard = (v4[e] * lam[r]) * (1.0f - z) + (1.0f - lam[r]) * cur;  // :119/:544
+            const float vo_soft = v4[e] * lam[r] + (1.0f - lam[r]) * cur - z * th[r];      // :121/:546
+            const float vo = hard_reset ? vo_hard : vo_soft;
+            const bool spike = ok && (vo - th[r]) > 0.f;
+            vo4[e] = vo;
+            bits |= (spike ? 1u : 0u) << cc;
+            const unsigned long long mk = __ballot(spike);
+            myplane = (r == rj) ? (kgj ? (uint32_t)(mk >> 32) : (uint32_t)mk) : myplane;
+          }
+          *(float4*)(stg + i * FW_SP + 8 * q + 4 * kg) = make_float4(vo4[0], vo4[1], vo4[2], vo4[3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float4 ev[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ev[r] = *(const float4*)(stg + (8 * r + (lane >> 3)) * FW_SP + (lane & 7) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = 8 * r + (lane >> 3), c4 = (lane & 7) * 4;
+          if (row < H && x0 + p < W) evf_store_nt(v_out + (((long)b * H + row) * W + x0 + p) * C32 + c4, ev[r]);
+        }
+        __builtin_amdgcn_wave_barrier();  // (the tile is rewritten for the wave's second row)
+        const uint32_t word = bits | __shfl_xor(bits, 32, 64);  // the pixel's 32 output spikes
+        if (ok && kg == 0) J.z_out[pix] = word;
+        if (J.pr.w) {  // (cell-uniform) the prediction head on this pixel's spike word, summed like evf_pred_fwd
+          float s0 = 0.f, s1 = 0.f;
+#pragma unroll 1
+          for (int c4 = 0; c4 < C32; c4 += 4) {  // (rolled: fully unrolled its 64 table reads were the register peak of the kernel)
+            const float4 pa = *(const float4*)(s_pw + c4), pb = *(const float4*)(s_pw + C32 + c4);
+            const float pa4[4] = {pa.x, pa.y, pa.z, pa.w}, pb4[4] = {pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float z = (float)((word >> (c4 + e)) & 1u);
+              s0 += z * pa4[e];
+              s1 += z * pb4[e];
+            }
+          }
+          if (ok && kg == 0) {
+            const long hw = (long)H * W, qq = (long)row * W + x0 + i;
+            J.pr.flow[(long)b * 2 * hw + qq] = tanhf(s0 + s_pw[2 * C32]);
+            J.pr.flow[((long)b * 2 + 1) * hw + qq] = tanhf(s1 + s_pw[2 * C32 + 1]);
+          }
+        }
+        if (J.zT_out && row < H && lane < 32) J.zT_out[(((long)b * H + row) * C32 + j) * nW + x0 / 32] = myplane;
+      }
+      __builtin_amdgcn_wave_barrier();  // (the halo words are rewritten by this wave's next strip)
+      FP_STAMP();
+    }
+  }
+  FP_STAMP();
+}
+
 #define FW_MAX_DIAGS 96
 // (one recorder per recording context = per stream, evf_common.h)
 struct FwDefer {
@@ -395,18 +662,44 @@ static size_t fw_lds_bytes() {
 static int fw_defer_launch(FwDefer& fw_defer, void* stream) {
   const size_t lds = fw_lds_bytes();
   static bool attr_set = false;
-  if (!attr_set && lds > 65536) {
-    (void)hipFuncSetAttribute((const void*)k_fwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (!attr_set) {
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_fwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_fwd_diag_p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FP_LDS);
     attr_set = true;
+  }
+  static const bool persistent = []() {  // EVF_FWD_DIAG=tile|persistent (A/B measurements); default: persistent
+    const char* e = getenv("EVF_FWD_DIAG");
+    return !(e && e[0] == 't');
+  }();
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
   }
   for (int d = 0; d < FW_MAX_DIAGS; ++d) {
     const int n = fw_defer.n[d];
     if (!n) continue;
     FwJobs jobs;
     for (int k = 0; k < FW_MAX_JOBS; ++k) jobs.j[k] = fw_defer.job[d][k < n ? k : 0];
-    dim3 grid(evf_cdiv(fw_defer.W, TW), evf_cdiv(fw_defer.H, TH), fw_defer.B * n), block(FW_THREADS);
     evf_prof_mark(0, 0, stream);
-    hipLaunchKernelGGL(k_fwd_diag, grid, block, lds, EVF_STREAM(stream), jobs, fw_defer.B, fw_defer.H, fw_defer.W);
+    if (persistent) {
+      FpPlan plan;
+      plan.njobs = n, plan.ntx = evf_cdiv(fw_defer.W, TW), plan.nyy = evf_cdiv(fw_defer.H, 2);
+      plan.nstrips = plan.ntx * plan.nyy * fw_defer.B;
+      plan.total = 0;
+      for (int k = 0; k < FW_MAX_JOBS; ++k) {
+        plan.weight[k] = (k < n && jobs.j[k].wrec) ? 4 : 3;  // (a recurrent strip costs ~19 k cycles, a feed-forward one ~14.6 k: phase stamps)
+        if (k < n) plan.total += plan.nstrips * plan.weight[k];
+      }
+      const int nblk = plan.total / 24 < ncu ? evf_cdiv(plan.total, 24) : ncu;  // (tiny launches: at least ~8 strips per block)
+      hipLaunchKernelGGL(k_fwd_diag_p, dim3(nblk), dim3(FP_THREADS), FP_LDS, EVF_STREAM(stream), jobs, plan, fw_defer.B, fw_defer.H,
+                         fw_defer.W);
+    } else {
+      dim3 grid(evf_cdiv(fw_defer.W, TW), evf_cdiv(fw_defer.H, TH), fw_defer.B * n), block(FW_THREADS);
+      hipLaunchKernelGGL(k_fwd_diag, grid, block, lds, EVF_STREAM(stream), jobs, fw_defer.B, fw_defer.H, fw_defer.W);
+    }
     evf_prof_mark(0, 1, stream);
     fw_defer.n[d] = 0;
   }

@@ -188,6 +188,69 @@ __global__ __launch_bounds__(512) void k_probe(const uint4* __restrict__ gsrc, f
   for (int q = 0; q < 16; ++q) out[(size_t)(blockIdx.x * blockDim.x + tid) * 16 + q] = accp[q] + (float)keep;
 }
 
+
+// ---- two waves per SIMD with DIFFERENT roles: waves 0..3 run `reps` phases of 108 bare MFMAs, waves 4..7 run `reps` blocks of
+// NV independent VALU instructions (8 chains of v_fma_f32) -- how much does each slow the other?  role_mask: bit 0 = the
+// MFMA team runs, bit 1 = the VALU team runs.
+template <int NV>
+__global__ __launch_bounds__(512) void k_mix(float* __restrict__ out, unsigned long long* __restrict__ cyc, int reps, int role_mask) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  if (wv < 4) {
+    if (role_mask & 1) {
+      f32x16 acc0 = {0}, acc1 = {0};
+      bf16x8 a, b;
+      for (int e = 0; e < 8; ++e) a[e] = (__bf16)1.0f, b[e] = (__bf16)0.5f;
+      for (int rep = 0; rep < reps; ++rep) {
+#pragma unroll
+        for (int k = 0; k < 54; ++k) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
+        }
+      }
+      for (int q = 0; q < 16; ++q) out[(size_t)(blockIdx.x * 512 + tid) * 16 + q] = acc0[q] + acc1[q];
+    }
+  } else if (role_mask & 2) {
+    float r[8];
+    for (int e = 0; e < 8; ++e) r[e] = (float)(lane + e);
+    const float c = 1.0000001f, d = 1e-6f;
+    for (int rep = 0; rep < reps; ++rep) {
+#pragma unroll
+      for (int k = 0; k < NV / 8; ++k) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = __builtin_fmaf(r[e], c, d);
+      }
+    }
+    float sum = 0.f;
+    for (int e = 0; e < 8; ++e) sum += r[e];
+    out[(size_t)(blockIdx.x * 512 + tid) * 16] = sum;
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (lane == 0) cyc[blockIdx.x * 8 + wv] = t1 - t0;
+}
+
+template <int NV>
+void run_mix(int role_mask, float* out, unsigned long long* cyc, int reps) {
+  hipLaunchKernelGGL(k_mix<NV>, dim3(256), dim3(512), 0, 0, out, cyc, reps, role_mask);
+  hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0), hipEventCreate(&e1);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(k_mix<NV>, dim3(256), dim3(512), 0, 0, out, cyc, reps, role_mask);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> h(256 * 8);
+  hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+  std::vector<double> m, v;
+  for (int b = 0; b < 256; ++b)
+    for (int w = 0; w < 8; ++w) (w < 4 ? m : v).push_back((double)h[b * 8 + w] / reps);
+  std::sort(m.begin(), m.end()), std::sort(v.begin(), v.end());
+  printf("mix NV=%4d roles %d: MFMA team %7.0f cycles per 108 MFMAs (%5.1f each)   VALU team %7.0f cycles per %d VALU (%5.2f each)   kernel %.1f us\n", NV,
+         role_mask, m[m.size() / 2], m[m.size() / 2] / 108.0, v[v.size() / 2], NV, v[v.size() / 2] / NV, ms * 1e3);
+}
+
 template <int F>
 void run(const char* name, int threads, const uint4* gsrc, float* out, unsigned long long* cyc, int reps) {
   const size_t lds = (size_t)(54 * 64 + 2 * BUF) * 16 + (size_t)4 * 32 * 36 * 4;
@@ -251,5 +314,7 @@ int main() {
   RUN(FW | FG | FD | FC, 512);
   RUN(FW | FG, 512);
   RUN(FW | FG | FD | FL | FE, 512);
+  for (int roles : {1, 2, 3}) run_mix<800>(roles, out, cyc, reps);
+  for (int roles : {2, 3}) run_mix<3200>(roles, out, cyc, reps);
   return 0;
 }
