@@ -88,10 +88,11 @@ class _LibHdf5Sequence(_Sequence):
 
     def group(self, group):
         names = self.f.names(group)  # name order = the order h5py's visititems reports
-        return names, [self.f.dataset(f"{group}/{n}").attr("timestamp") for n in names]
+        # (one attribute read per frame, nothing kept open: a real sequence has tens of thousands of frame datasets)
+        return names, [self.f.dataset_attr(f"{group}/{n}", "timestamp") for n in names]
 
     def read(self, group, name):
-        return np.asarray(self.f.dataset(f"{group}/{name}"))
+        return self.f.read(f"{group}/{name}")
 
     def close(self):
         self.f.close()

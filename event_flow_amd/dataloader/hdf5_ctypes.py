@@ -72,7 +72,8 @@ def load():
         "H5Tclose": ([hid_t], herr_t), "H5Tget_class": ([hid_t], ctypes.c_int), "H5Tget_size": ([hid_t], ctypes.c_size_t),
         "H5Tget_sign": ([hid_t], ctypes.c_int), "H5Tget_native_type": ([hid_t, ctypes.c_int], hid_t),
         "H5Tget_super": ([hid_t], hid_t),
-        "H5Aopen": ([hid_t, ctypes.c_char_p, hid_t], hid_t), "H5Aclose": ([hid_t], herr_t), "H5Aget_type": ([hid_t], hid_t),
+        "H5Aopen": ([hid_t, ctypes.c_char_p, hid_t], hid_t),
+        "H5Aopen_by_name": ([hid_t, ctypes.c_char_p, ctypes.c_char_p, hid_t, hid_t], hid_t), "H5Aclose": ([hid_t], herr_t), "H5Aget_type": ([hid_t], hid_t),
         "H5Aread": ([hid_t, hid_t, ctypes.c_void_p], herr_t), "H5Aexists": ([hid_t, ctypes.c_char_p], ctypes.c_int),
         "H5Gopen2": ([hid_t, ctypes.c_char_p, hid_t], hid_t), "H5Gclose": ([hid_t], herr_t),
         "H5Gget_info": ([hid_t, ctypes.POINTER(_H5G_info)], herr_t),
@@ -157,7 +158,9 @@ class Dataset:
         fs = lib.H5Dget_space(self._id)
         st = (hsize_t * nd)(start, *([0] * (nd - 1)))
         cn = (hsize_t * nd)(count, *self.shape[1:])
-        lib.H5Sselect_hyperslab(fs, 0, st, None, cn, None)
+        if lib.H5Sselect_hyperslab(fs, 0, st, None, cn, None) < 0:
+            lib.H5Sclose(fs)
+            raise Hdf5Error(f"cannot select {self.name}[{start}:{start + count}]")
         ms = lib.H5Screate_simple(nd, cn, None)
         rc = lib.H5Dread(self._id, self._mt, ms, fs, 0, out.ctypes.data)
         lib.H5Sclose(ms)
@@ -217,13 +220,51 @@ class File:
                 return False
         return True
 
-    def dataset(self, path):
-        if path not in self._open:
-            did = self._lib.H5Dopen2(self._id, path.encode(), 0)
-            if did < 0:
-                raise KeyError(path)
-            self._open[path] = Dataset(self._lib, did, path)
-        return self._open[path]
+    def dataset(self, path, keep=True):
+        """keep=True: the handle stays open until File.close() (the few `events/*` arrays a loader slices all the time);
+        keep=False: a fresh handle the CALLER closes -- frame / flow-map datasets, of which a real sequence has tens of thousands."""
+        if keep and path in self._open:
+            return self._open[path]
+        did = self._lib.H5Dopen2(self._id, path.encode(), 0)
+        if did < 0:
+            raise KeyError(path)
+        d = Dataset(self._lib, did, path)
+        if keep:
+            self._open[path] = d
+        return d
+
+    def read(self, path):
+        """The whole dataset as an array; nothing stays open."""
+        d = self.dataset(path, keep=False)
+        try:
+            return np.asarray(d)
+        finally:
+            d.close()
+
+    def dataset_attr(self, path, name):
+        """An attribute of a dataset without keeping (or, where the library allows, without opening) the dataset."""
+        lib = self._lib
+        if hasattr(lib, "H5Aopen_by_name"):
+            a = lib.H5Aopen_by_name(self._id, path.encode(), name.encode(), 0, 0)
+            if a < 0:
+                raise KeyError(f"{path}@{name}")
+            try:
+                ft = lib.H5Aget_type(a)
+                mt = lib.H5Tget_native_type(ft, _DIR_ASCEND)
+                buf = np.empty((), dtype=_np_dtype(lib, mt))
+                rc = lib.H5Aread(a, mt, buf.ctypes.data)
+                lib.H5Tclose(mt)
+                lib.H5Tclose(ft)
+                if rc < 0:
+                    raise Hdf5Error(f"cannot read attribute {name!r} of {path}")
+                return buf[()]
+            finally:
+                lib.H5Aclose(a)
+        d = self.dataset(path, keep=False)
+        try:
+            return d.attr(name)
+        finally:
+            d.close()
 
     def names(self, group):
         """Link names of a group in increasing name order (the order of h5py's visit / visititems)."""
@@ -231,16 +272,22 @@ class File:
         gid = lib.H5Gopen2(self._id, group.encode(), 0)
         if gid < 0:
             raise KeyError(group)
-        info = _H5G_info()
-        lib.H5Gget_info(gid, ctypes.byref(info))
-        out = []
-        for i in range(int(info.nlinks)):
-            n = lib.H5Lget_name_by_idx(gid, b".", 0, 0, i, None, 0, 0)
-            buf = ctypes.create_string_buffer(n + 1)
-            lib.H5Lget_name_by_idx(gid, b".", 0, 0, i, buf, n + 1, 0)
-            out.append(buf.value.decode())
-        lib.H5Gclose(gid)
-        return out
+        try:
+            info = _H5G_info()
+            if lib.H5Gget_info(gid, ctypes.byref(info)) < 0:
+                raise Hdf5Error(f"cannot query group {group!r}")
+            out = []
+            for i in range(int(info.nlinks)):
+                n = lib.H5Lget_name_by_idx(gid, b".", 0, 0, i, None, 0, 0)
+                if n < 0:
+                    raise Hdf5Error(f"cannot list link {i} of group {group!r}")
+                buf = ctypes.create_string_buffer(n + 1)
+                if lib.H5Lget_name_by_idx(gid, b".", 0, 0, i, buf, n + 1, 0) < 0:
+                    raise Hdf5Error(f"cannot list link {i} of group {group!r}")
+                out.append(buf.value.decode())
+            return out
+        finally:
+            lib.H5Gclose(gid)
 
     def close(self):
         if self._id >= 0:

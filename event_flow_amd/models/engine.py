@@ -691,6 +691,8 @@ class FireNetEngine:
     def _finalize(self, win):
         """Window complete: reduce the weight-gradient slabs, hand all parameter
         gradients to autograd (in self.params order)."""
+        if hip_ops.DIRECT_PARAM_GRADS:
+            hip_ops.direct_grads_written()  # (the reductions below add straight into the optimizer's flat gradient buffer)
         B, H, W = win.shape
         nslab = (_lib.load().evf_lif_bwd_wgrad_slabs(B, H, W) if self.precision == "bf16x3"
                  else _lib.load().evf_conv_wgrad_slabs(B, H, W))

@@ -250,6 +250,25 @@ def norm_nonzero(x):
 DIRECT_PARAM_GRADS = False  # switched on by train.FlatAdam (whose flat buffer every .grad is a view of)
 
 
+_GRAD_LISTENERS = []  # weak references to optimizers that want to know when a kernel wrote into a bound .grad (train.FlatAdam)
+
+
+def on_direct_grads(listener):
+    import weakref
+
+    _GRAD_LISTENERS.append(weakref.ref(listener))
+
+
+def direct_grads_written():
+    """A backward kernel is about to add into bound `.grad` buffers (no AccumulateGrad node, hence no autograd hook, sees that)."""
+    for r in list(_GRAD_LISTENERS):
+        o = r()
+        if o is None:
+            _GRAD_LISTENERS.remove(r)
+        else:
+            o.mark_grad_dirty()
+
+
 def bound_grad(t):
     """The fp32 `.grad` buffer already bound to leaf parameter `t`, if our kernels may accumulate into it
     directly (the backward then returns None for `t`: no temporary, no AccumulateGrad add kernel per tensor
@@ -260,6 +279,7 @@ def bound_grad(t):
     g = t.grad
     if g is None or g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous() or g.shape != t.shape:
         return None
+    direct_grads_written()  # (the caller is about to let a kernel accumulate into it)
     return g
 
 

@@ -45,7 +45,14 @@ class FlatAdam:
             off += k
         self.lr, self.betas, self.eps, self.clip = lr, betas, eps, clip
         self.steps = 0
-        self._grad_clean = False  # True between step() (which clears the gradient as it consumes it) and the next backward
+        # True between step() (which CLEARS the gradient buffer as it consumes it: `.grad` reads zeros after step()) and the next
+        # write into the buffer.  Writers announce themselves: autograd's AccumulateGrad through the per-parameter hook below, our
+        # kernels that add into the bound .grad directly through hip_ops.direct_grads_written() -- so a `loss.backward()` issued
+        # anywhere between step() and zero_grad() (gradient accumulation, custom loops) is seen and zero_grad() then does clear.
+        self._grad_clean = False
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(lambda _p, _self=self: _self.mark_grad_dirty())
+        hip_ops.on_direct_grads(self)
         hip_ops.DIRECT_PARAM_GRADS = True  # every .grad is a view of flat_grad: the backward kernels add into it in place
 
     def zero_grad(self):
@@ -101,8 +108,12 @@ _UNIT = {}
 
 
 def _unit_gradient(loss):
+    """Cached `ones_like(loss)` (autograd would fill a fresh one per step).  Never created inside a graph capture: a tensor
+    allocated there belongs to the capture's memory pool and must not be handed to later eager steps."""
     key = (loss.device, loss.dtype, tuple(loss.shape))
     if key not in _UNIT:
+        if loss.is_cuda and torch.cuda.is_current_stream_capturing():
+            return torch.ones_like(loss)  # (this capture's own tensor; the cache is filled by the first eager step)
         _UNIT[key] = torch.ones_like(loss)
     return _UNIT[key]
 

@@ -802,6 +802,40 @@ def test_recorders_are_per_thread_and_poison_marks_stale_reads():
         m.defer_forward(False)
 
 
+def test_flat_adam_zero_grad_clears_a_backward_issued_after_step():
+    """FlatAdam.step() clears the flat gradient buffer as it consumes it and zero_grad() skips its fill kernel while the buffer
+    is known to be clean.  A backward issued between step() and zero_grad() -- gradient accumulation, a custom loop: not
+    announced by train.window_backward -- must still be cleared: the writers announce themselves (AccumulateGrad hooks, the
+    engine's direct accumulation into the bound .grad)."""
+    from event_flow_amd import synthetic
+    from event_flow_amd.dataloader.encodings import encode_event_list
+
+    B, n, H, W = 2, 400, 32, 32
+    torch.manual_seed(11)
+    m = LIFFireNet(model_cfg()).to(DEV)
+    m.train()
+    opt = FlatAdam(m, lr=2e-4, clip=100.0)
+    opt.zero_grad()
+    d = encode_event_list(G(synthetic.event_list_batch(B, n, H, W, 123)), 2, (H, W), want=("cnt", "mask", "pol"))
+
+    def backward_once():
+        m.reset_states()
+        out = m(None, d["event_cnt"])["flow"][0]
+        (out * out).sum().backward()
+
+    backward_once()
+    assert float(opt.flat_grad.abs().sum()) > 0
+    opt.step()
+    assert float(opt.flat_grad.abs().sum()) == 0.0  # step() hands the buffer back cleared (documented)
+    backward_once()  # NOT through train.window_backward
+    assert float(opt.flat_grad.abs().sum()) > 0
+    opt.zero_grad()
+    assert float(opt.flat_grad.abs().sum()) == 0.0
+    opt.step()
+    opt.zero_grad()  # clean after step(): no fill needed, still zero
+    assert float(opt.flat_grad.abs().sum()) == 0.0
+
+
 def test_graphed_window_step_equals_eager_training():
     """train.GraphedWindowStep: fixed-shape windows copied into a static buffer and replayed from two alternating
     hipGraphs (copy-free recurrent-state hand-over between them).  Six different windows, states carried across
