@@ -419,6 +419,8 @@ extern "C" int evf_debug_fp_stamps(void* dst) { return evf_hip(hipMemcpyFromSymb
 #define FP_STAMP() do {} while (0)
 #endif
 
+template <bool HARD>  // the reset rule of every cell of the launch (fixed at compile time: as a per-element select BOTH rules were evaluated, and
+                      // a vector instruction beside a saturated matrix pipe issues every ~8 cycles instead of every 2: tools/probes/mma_probe)
 __global__ __launch_bounds__(FP_THREADS) void k_fwd_diag_p(FwJobs jobs, FpPlan plan, int B, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint4* s_wff = (uint4*)smem_raw;
@@ -476,7 +478,6 @@ __global__ __launch_bounds__(FP_THREADS) void k_fwd_diag_p(FwJobs jobs, FpPlan p
     const uint32_t* __restrict__ z_prev = J.z_prev;
     const float* __restrict__ v_prev = J.v_prev;
     float* __restrict__ v_out = J.v_out;
-    const int hard_reset = J.hard_reset;
     uint32_t hx[3], hz[3];
     bool hin[3];
     auto halo_fetch = [&](int sj) {  // (past the range: the last strip again, never committed)
@@ -493,7 +494,12 @@ __global__ __launch_bounds__(FP_THREADS) void k_fwd_diag_p(FwJobs jobs, FpPlan p
         hx[q] = x[p], hz[q] = zsrc[p];
       }
     };
+    // (Measured and dropped: all eight waves taking their matrix phases together and their epilogues together, one barrier
+    //  between -- a vector instruction issues every ~2 cycles while the matrix pipe idles and only every ~8 beside a saturated
+    //  one, tools/probes/mma_probe -- 3.78 ms per step either way: the epilogue's ~10 k cycles are mostly waits (previous
+    //  state, staging round trips, stores), not vector issue.)
     for (int si = i0 + wv; si < i1; si += FP_WAVES) {
+      const bool valid = true;
       const int tx = si % plan.ntx, rr = si / plan.ntx, yy = rr % plan.nyy, b = rr / plan.nyy;
       const int y0 = 2 * yy, x0 = tx * TW;
       FP_STAMP();
@@ -558,9 +564,9 @@ __global__ __launch_bounds__(FP_THREADS) void k_fwd_diag_p(FwJobs jobs, FpPlan p
         }
       };
       FP_STAMP();
-      conv_phase(s_x, s_wff);
+      if (valid) conv_phase(s_x, s_wff);
       FP_STAMP();
-      if (rec) conv_phase(s_z, s_wrec);
+      if (valid && rec) conv_phase(s_z, s_wrec);
       FP_STAMP();
       // ---- epilogue (transposed tile, as fwd_b3_body): lane = pixel x0 + i of rows y0, y0 + 1; channel c = 8q + e + 4kg.
       // The lane's 16 leak / threshold values come in as eight 16-byte reads up front (as `s_par[c]` beside each use the
@@ -591,9 +597,8 @@ __global__ __launch_bounds__(FP_THREADS) void k_fwd_diag_p(FwJobs jobs, FpPlan p
             const int r = 4 * q + e, cc = 8 * q + e + 4 * kg;
             const float z = (float)((zw >> cc) & 1u);
             const float cur = acc[r];
-            const float vo_hard = (v4[e] * lam[r]) * (1.0f - z) + (1.0f - lam[r]) * cur;  // :119/:544
-            const float vo_soft = v4[e] * lam[r] + (1.0f - lam[r]) * cur - z * th[r];      // :121/:546
-            const float vo = hard_reset ? vo_hard : vo_soft;
+            const float vo = HARD ? (v4[e] * lam[r]) * (1.0f - z) + (1.0f - lam[r]) * cur   // :119/:544
+                                  : v4[e] * lam[r] + (1.0f - lam[r]) * cur - z * th[r];     // :121/:546
             const bool spike = ok && (vo - th[r]) > 0.f;
             vo4[e] = vo;
             bits |= (spike ? 1u : 0u) << cc;
@@ -604,6 +609,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_fwd_diag_p(FwJobs jobs, FpPlan p
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        FP_STAMP();
         float4 ev[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) ev[r] = *(const float4*)(stg + (8 * r + (lane >> 3)) * FW_SP + (lane & 7) * 4);
@@ -613,6 +619,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_fwd_diag_p(FwJobs jobs, FpPlan p
           if (row < H && x0 + p < W) evf_store_nt(v_out + (((long)b * H + row) * W + x0 + p) * C32 + c4, ev[r]);
         }
         __builtin_amdgcn_wave_barrier();  // (the tile is rewritten for the wave's second row)
+        FP_STAMP();
         const uint32_t word = bits | __shfl_xor(bits, 32, 64);  // the pixel's 32 output spikes
         if (ok && kg == 0) J.z_out[pix] = word;
         if (J.pr.w) {  // (cell-uniform) the prediction head on this pixel's spike word, summed like evf_pred_fwd
@@ -664,7 +671,8 @@ static int fw_defer_launch(FwDefer& fw_defer, void* stream) {
   static bool attr_set = false;
   if (!attr_set) {
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_fwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)k_fwd_diag_p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FP_LDS);
+    (void)hipFuncSetAttribute((const void*)k_fwd_diag_p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FP_LDS);
+    (void)hipFuncSetAttribute((const void*)k_fwd_diag_p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FP_LDS);
     attr_set = true;
   }
   static const bool persistent = []() {  // EVF_FWD_DIAG=tile|persistent (A/B measurements); default: persistent
@@ -683,8 +691,10 @@ static int fw_defer_launch(FwDefer& fw_defer, void* stream) {
     if (!n) continue;
     FwJobs jobs;
     for (int k = 0; k < FW_MAX_JOBS; ++k) jobs.j[k] = fw_defer.job[d][k < n ? k : 0];
+    int nhard = 0;
+    for (int k = 0; k < n; ++k) nhard += jobs.j[k].hard_reset ? 1 : 0;
     evf_prof_mark(0, 0, stream);
-    if (persistent) {
+    if (persistent && (nhard == 0 || nhard == n)) {  // (cells of both reset rules in one index: the per-tile kernel)
       FpPlan plan;
       plan.njobs = n, plan.ntx = evf_cdiv(fw_defer.W, TW), plan.nyy = evf_cdiv(fw_defer.H, 2);
       plan.nstrips = plan.ntx * plan.nyy * fw_defer.B;
@@ -694,8 +704,12 @@ static int fw_defer_launch(FwDefer& fw_defer, void* stream) {
         if (k < n) plan.total += plan.nstrips * plan.weight[k];
       }
       const int nblk = plan.total / 24 < ncu ? evf_cdiv(plan.total, 24) : ncu;  // (tiny launches: at least ~8 strips per block)
-      hipLaunchKernelGGL(k_fwd_diag_p, dim3(nblk), dim3(FP_THREADS), FP_LDS, EVF_STREAM(stream), jobs, plan, fw_defer.B, fw_defer.H,
-                         fw_defer.W);
+      if (nhard)
+        hipLaunchKernelGGL(k_fwd_diag_p<true>, dim3(nblk), dim3(FP_THREADS), FP_LDS, EVF_STREAM(stream), jobs, plan, fw_defer.B,
+                           fw_defer.H, fw_defer.W);
+      else
+        hipLaunchKernelGGL(k_fwd_diag_p<false>, dim3(nblk), dim3(FP_THREADS), FP_LDS, EVF_STREAM(stream), jobs, plan, fw_defer.B,
+                           fw_defer.H, fw_defer.W);
     } else {
       dim3 grid(evf_cdiv(fw_defer.W, TW), evf_cdiv(fw_defer.H, TH), fw_defer.B * n), block(FW_THREADS);
       hipLaunchKernelGGL(k_fwd_diag, grid, block, lds, EVF_STREAM(stream), jobs, fw_defer.B, fw_defer.H, fw_defer.W);

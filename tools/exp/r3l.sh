@@ -14,5 +14,6 @@ PY
 ARGS="--steps 30 --warmup 5"
 bench tile EVF_FWD_DIAG=tile
 bench pers A=1
-bench tile2 EVF_FWD_DIAG=tile
+bench phased EVF_LIB=$PWD/event_flow_amd/libevflow_fp_phased.so
 bench pers2 A=1
+bench phased2 EVF_LIB=$PWD/event_flow_amd/libevflow_fp_phased.so

@@ -66,6 +66,23 @@ for n in names:
         "mfma_util_pct": round(100 * (busy / 1024) / (gui / 8), 1) if busy == busy and gui > 0 else "",
         "fetch_size_KB_raw": round(f_kb, 1), "fetch_MB_x2_corrected": round(2 * f_kb / 1024, 2), "write_size_KB": round(w_kb, 1),
     })
+# LDS / VALU side of the kernels (separate PMC passes): per launch, per kernel
+lds, valu = counters("lds"), counters("valu")
+if lds or valu:
+    with open(os.path.join(DST, f"{R}_bench_pmc_lds_valu.csv"), "w", newline="") as fh:
+        cols = ["SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_LDS", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA",
+                "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"]
+        w = csv.writer(fh)
+        w.writerow(["kernel", "dispatches"] + [c + "_per_launch" for c in cols] + ["lds_conflict_share_of_lds_active", "valu_per_mfma"])
+        for n in sorted(set(lds) | set(valu)):
+            if n.startswith("at::") or n.startswith("__amd") or "elementwise" in n:
+                continue
+            vals = [mean((lds.get(n, {}) if c in lds.get(n, {}) else valu.get(n, {})).get(c, [])) for c in cols]
+            nd = max(len(lds.get(n, {}).get("SQ_INSTS_LDS", [])), len(valu.get(n, {}).get("SQ_INSTS_VALU", [])))
+            conf = vals[1] / vals[2] if vals[2] == vals[2] and vals[2] else float("nan")
+            vpm = vals[5] / vals[6] if vals[6] == vals[6] and vals[6] else float("nan")
+            w.writerow([n, nd] + [round(v, 0) if v == v else "" for v in vals] + [round(conf, 4) if conf == conf else "", round(vpm, 2) if vpm == vpm else ""])
+    print(open(os.path.join(DST, f"{R}_bench_pmc_lds_valu.csv")).read())
 # kernels that only exist on the fp32 path
 for n in sorted(set(mfma32) - set(mfma)):
     pass

@@ -9,12 +9,15 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 run() { name=$1; shift; timeout 900 "$@" > $O/$name.log 2>&1; echo "$name rc=$?"; }
 run graph  rocprofv3 --kernel-trace --stats --output-format csv -d $O/graph  -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline
-run eager  rocprofv3 --kernel-trace --stats --output-format csv -d $O/eager  -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph --no-iwe
-run fetch  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe
-run write  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe
-run mfma   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe
-run mfma32 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma32 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe --precision fp32
-run evfn   rocprofv3 --kernel-trace --stats --output-format csv -d $O/evfn -- python bench.py --config c4 --steps 10 --warmup 3
-run plif   rocprofv3 --kernel-trace --stats --output-format csv -d $O/plif -- python bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-iwe
+run eager  rocprofv3 --kernel-trace --stats --output-format csv -d $O/eager  -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph --no-iwe --no-others --no-others
+run fetch  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe --no-others
+run write  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe --no-others
+run mfma   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe --no-others
+run mfma32 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma32 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe --no-others --precision fp32
+# LDS side of the matrix-bound kernels: instructions, bank-conflict cycles, issue stalls on the LDS pipe
+run lds    rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $O/lds -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe --no-others
+run valu   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $O/valu -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe --no-others
+run evfn   rocprofv3 --kernel-trace --stats --output-format csv -d $O/evfn -- python bench.py --config c4 --steps 10 --warmup 3 --no-cpu-baseline --no-iwe --no-others
+run plif   rocprofv3 --kernel-trace --stats --output-format csv -d $O/plif -- python bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-iwe --no-others
 run iwe    rocprofv3 --kernel-trace --stats --output-format csv -d $O/iwe -- python tools/iwe_bench.py 2048
 ls -R $O | head -60
