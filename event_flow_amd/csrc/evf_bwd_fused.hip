@@ -734,14 +734,17 @@ static int fb_defer_launch(FbDefer& fb_defer, int d, void* stream) {
 // (Round 3, measured and dropped: the head layer's backward cells on a side stream forked inside this loop -- they form a chain
 //  of their own, but the next input-gradient launch rewrites the one buffer they read (dL/d(spikes) of the head layer), so each
 //  can only hide under ONE fused-backward launch; as parallel branches of the replayed graph: 4.21 against 4.20 ms per step.)
+// (Later in round 3: with one dL/d(spikes) buffer PER PASS the head cells have no tie to the indices at all and run after
+//  the last one, all passes in one launch: evf_hd_defer_launch_window, evf_network.hip.)
 int evf_bwd_defer_flush_now(int ctx, void* stream) {
+  const bool heads_last = evf_hd_defer_window_ok(ctx) != 0;
   for (int d = 0; d < EVF_BWD_DIAGS; ++d) {
     int rc = fb_defer_launch(fb_tab[ctx], d, stream);
     if (!rc) rc = evf_dg_defer_launch(ctx, d, stream);
-    if (!rc) rc = evf_hd_defer_launch(ctx, d, stream);
+    if (!rc && !heads_last) rc = evf_hd_defer_launch(ctx, d, stream);
     if (rc) return rc;
   }
-  return EVF_OK;
+  return heads_last ? evf_hd_defer_launch_window(ctx, stream) : EVF_OK;
 }
 
 extern "C" int evf_bwd_defer_begin(void* stream) {

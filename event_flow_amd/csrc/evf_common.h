@@ -116,6 +116,14 @@ int evf_dg_defer_pending(int ctx, int d);  // cells recorded under index d
 int evf_hd_defer_launch(int ctx, int d, void* stream);  // evf_network.hip (head layer)
 int evf_hd_defer_count(int ctx);
 int evf_hd_defer_pending(int ctx, int d);  // cells recorded under index d
+int evf_hd_defer_window_ok(int ctx);  // the recorded head cells may run after the last index (no shared dL/d(spikes) buffer)
+int evf_hd_defer_launch_window(int ctx, void* stream);  // ... all of them, consecutive passes in one launch
+// head cells of a FORWARD recording (evf_network.hip): launched before the diagonals, consecutive passes in one launch
+int evf_fwd_defer_active(int ctx);  // evf_fwd_b3.hip: a forward recording is open in this context
+int evf_defer_poisoned();           // evf_defer_poison is on
+int evf_hf_defer_launch(int ctx, void* stream);
+int evf_hf_defer_count(int ctx);
+void evf_hf_defer_reset(int ctx);
 // Per-launch timing of the diagonal launches (evf_defer_profile, evf_bwd_fused.hip): HIP events around every dispatcher
 // launch of a flush, by kind (0 k_fwd_diag, 1 k_bwd_diag, 2 k_dgrad_diag, 3 head backward).  No-ops unless switched on
 // (never during a graph capture).

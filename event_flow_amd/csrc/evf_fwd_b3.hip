@@ -667,6 +667,10 @@ static size_t fw_lds_bytes() {
 
 // Launch what has been recorded (diagonals in increasing order) and keep recording.
 static int fw_defer_launch(FwDefer& fw_defer, void* stream) {
+  {  // the head layer's recorded cells first: every diagonal cell of pass t reads (through its layers below) the head of pass t
+    const int rc = evf_hf_defer_launch((int)(&fw_defer - fw_tab), stream);
+    if (rc) return rc;
+  }
   const size_t lds = fw_lds_bytes();
   static bool attr_set = false;
   if (!attr_set) {
@@ -726,6 +730,8 @@ static int fw_defer_launch(FwDefer& fw_defer, void* stream) {
 // reads the cells' outputs.  The caller guarantees that cells recorded under one index are independent and that a cell's
 // operands come from lower indices (or from launches issued before).  One recorder per stream (recording contexts, evf_common.h).
 static bool fw_poison = false;  // evf_defer_poison: process-wide debug switch
+int evf_defer_poisoned() { return fw_poison ? 1 : 0; }
+int evf_fwd_defer_active(int ctx) { return fw_tab[ctx].active ? 1 : 0; }
 extern "C" int evf_defer_poison(int on) {
   fw_poison = on != 0;
   return EVF_OK;
@@ -741,6 +747,7 @@ extern "C" int evf_fwd_defer_begin(void* stream) {
   fw_defer.slot = 0;
   fw_defer.B = fw_defer.H = fw_defer.W = 0;
   for (int d = 0; d < FW_MAX_DIAGS; ++d) fw_defer.n[d] = 0;
+  evf_hf_defer_reset(ctx);
   return EVF_OK;
 }
 extern "C" int evf_fwd_defer_slot(int d, void* stream) {
@@ -753,7 +760,7 @@ extern "C" int evf_fwd_defer_pending(void* stream) {
   const int c = evf_ctx_find(stream);
   if (c < 0 || !fw_tab[c].active) return 0;
   FwDefer& fw_defer = fw_tab[c];
-  int n = 0;
+  int n = evf_hf_defer_count(c);  // (head cells)
   for (int d = 0; d < FW_MAX_DIAGS; ++d) n += fw_defer.n[d];
   return n;
 }

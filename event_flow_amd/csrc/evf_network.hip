@@ -438,11 +438,250 @@ static void launch_head_fwd(dim3 grid, dim3 block, hipStream_t st, const float* 
 #undef HEAD_FWD
 }
 
+// ---- the head layer of a whole WINDOW in one launch -----------------------------------------------------------------
+// The head (models/model.py: ConvLIF on the event input) reads only the network input and its OWN state, and that state is
+// per pixel: pass t of a tile needs nothing of any other tile's pass t-1.  So when the passes of a window are known up front
+// (a forward recording, evf_fwd_defer_*) one block runs ALL passes of its tile: v and the spike words stay in registers
+// between the passes (no v_prev / z_prev reads), the input halo of pass t+1 is fetched while pass t computes, and the weights
+// are staged once.  Every pass does exactly the arithmetic of k_head_lif_fwd (same MFMA order, same update), so the states
+// and spikes are bit-identical to P separate launches.
+#define HEADWIN_MAX_P 16
+#ifndef HEADWIN_LB
+#define HEADWIN_LB 256
+#endif
+struct HeadWinPass {
+  const float* x;
+  float* v_out;
+  uint32_t* z_out;
+  uint32_t* zT_out;
+};
+struct HeadWin {
+  HeadWinPass p[HEADWIN_MAX_P];
+  const float *w, *leak, *thresh, *v_prev;
+  const uint32_t* z_prev;
+  int np, B, Cin, H, W, hard_reset;
+};
+
+template <int S2>
+__global__ __launch_bounds__(HEADWIN_LB) void k_head_lif_fwd_win(HeadWin a) {
+  __shared__ float s_x[2][2 * S2][HALO_H * HALO_W];
+  __shared__ float s_w[9 * S2 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+  const int B = a.B, Cin = a.Cin, H = a.H, W = a.W;
+  (void)B;
+  const uint32_t* z_prev = a.z_prev;
+  auto zword = [&](int row, int col) -> uint32_t {
+    const uint32_t wd = *(z_prev ? z_prev + ((long)b * H + row) * W + col : (const uint32_t*)a.p[0].v_out);
+    return z_prev ? wd : 0u;
+  };
+  float vp0[16], vp1[16];
+  uint32_t zb0 = 0u, zb1 = 0u;  // bit r: the previous spike of this lane's channel at its pixel r (all a lane needs of the words)
+  {
+    uint32_t zw0[16], zw1[16];
+    lif_load_prev(b, y0 + 2 * wv, x0, H, W, lane, a.v_prev, a.p[0].v_out, zword, vp0, zw0);
+    lif_load_prev(b, y0 + 2 * wv + 1, x0, H, W, lane, a.v_prev, a.p[0].v_out, zword, vp1, zw1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      zb0 |= ((zw0[r] >> (lane & 31)) & 1u) << r;
+      zb1 |= ((zw1[r] >> (lane & 31)) & 1u) << r;
+    }
+  }
+  constexpr int NW = (9 * S2 * 64 + 255) / 256, NX = (2 * S2 * HALO_H * HALO_W + 255) / 256;
+  float xreg[NX];
+  auto fetch_x = [&](const float* __restrict__ x) {  // clamped addresses, selected afterwards: no load under a branch
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int e = min(tid + 256 * k, 2 * S2 * HALO_H * HALO_W - 1);
+      const int ci = e / (HALO_H * HALO_W), p = e % (HALO_H * HALO_W);
+      const int yy = y0 + p / HALO_W - 1, xx = x0 + p % HALO_W - 1;
+      const bool in = ci < Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const float xv = x[(((long)b * Cin + min(ci, Cin - 1)) * H + min(max(yy, 0), H - 1)) * W + min(max(xx, 0), W - 1)];
+      xreg[k] = in ? xv : 0.f;
+    }
+  };
+  auto put_x = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int e = tid + 256 * k;
+      if (e < 2 * S2 * HALO_H * HALO_W) s_x[buf][e / (HALO_H * HALO_W)][e % (HALO_H * HALO_W)] = xreg[k];
+    }
+  };
+  {
+    float wreg[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      const int e = min(tid + 256 * k, 9 * S2 * 64 - 1);
+      const int l = e & 63, s = (e >> 6) % S2, tau = (e >> 6) / S2;
+      const int ci = 2 * s + (l >> 5), j = l & 31;
+      const float wv0 = a.w[(j * Cin + min(ci, Cin - 1)) * 9 + tau];
+      wreg[k] = ci < Cin ? wv0 : 0.f;
+    }
+    fetch_x(a.p[0].x);
+#pragma unroll
+    for (int k = 0; k < NW; ++k)
+      if (tid + 256 * k < 9 * S2 * 64) s_w[tid + 256 * k] = wreg[k];
+    put_x(0);
+  }
+  const int i = lane & 31, h = lane >> 5, r0 = 2 * wv, j = lane & 31;
+  const float lam = evf_sigmoid(a.leak[j]);
+  const float th = fmaxf(a.thresh[j], 0.01f);
+  const int hard_reset = a.hard_reset;
+  const int nW = (W + 31) / 32;
+  // LIF update of one row (lif_update) that also leaves the new state in vpv / zb for the next pass.  FULL: the tile lies
+  // inside the image (block-uniform) -- no per-pixel branch.  The 16 spike words of the row go out in ONE store (lane r of
+  // each half wave keeps word r) instead of 16 stores by lanes 0 and 32.
+  auto update = [&](const f32x16& acc, float (&vpv)[16], uint32_t& zb, int row, const HeadWinPass& o, const bool FULL) {
+    const bool row_ok = FULL || row < H;
+    uint32_t plane = 0u, znew = 0u, zsel = 0u;
+    // one base address per row; pixel r of the lane is a compile-time offset from it ((r & 3) + 8 (r >> 2) pixels)
+    float* const vrow = o.v_out + (((long)b * H + row) * W + x0 + 4 * (lane >> 5)) * C32 + j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int col = x0 + mfma_row(r, lane);
+      const bool ok = FULL || (row_ok && col < W);
+      bool spike = false;
+      if (ok) {
+        const float v = vpv[r];
+        const float z = (float)((zb >> r) & 1u);
+        const float cur = acc[r];
+        const float vo_hard = (v * lam) * (1.0f - z) + (1.0f - lam) * cur;
+        const float vo_soft = v * lam + (1.0f - lam) * cur - z * th;
+        const float vo = hard_reset ? vo_hard : vo_soft;
+        vrow[((r & 3) + 8 * (r >> 2)) * C32] = vo;
+        spike = (vo - th) > 0.f;
+        vpv[r] = vo;
+      }
+      const unsigned long long m = __ballot(spike);
+      const uint32_t mw = (lane >> 5) ? (uint32_t)(m >> 32) : (uint32_t)m;
+      zsel = j == r ? mw : zsel;
+      znew |= (spike ? 1u : 0u) << r;  // (pixels outside the image: never stored, never spiking)
+      plane |= (spike ? 1u : 0u) << mfma_row(r, lane);
+    }
+    zb = znew;
+    if (j < 16) {
+      const int col = x0 + mfma_row(j, lane);
+      if (row_ok && (FULL || col < W)) o.z_out[((long)b * H + row) * W + col] = zsel;
+    }
+    if (o.zT_out) {
+      plane |= __shfl_xor(plane, 32, 64);
+      if (row_ok && lane < 32) o.zT_out[(((long)b * H + row) * C32 + j) * nW + x0 / 32] = plane;
+    }
+  };
+  const bool full = y0 + TH <= H && x0 + TW <= W;
+  for (int t = 0; t < a.np; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < a.np) fetch_x(a.p[t + 1].x);  // (in flight under this pass's matrix phase and stores)
+    __syncthreads();  // s_x[buf] (and, at t = 0, s_w) written; every wave is done reading s_x[buf ^ 1] (pass t - 1)
+    f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll 3
+    for (int tau = 0; tau < 9; ++tau) {
+      const int dy = tau / 3, dx = tau % 3;
+#pragma unroll
+      for (int s = 0; s < S2; ++s) {
+        const float bw = s_w[(tau * S2 + s) * 64 + lane];
+        const float* xp = s_x[buf][2 * s + h];
+        acc0 = mfma32(xp[(r0 + dy) * HALO_W + i + dx], bw, acc0);
+        acc1 = mfma32(xp[(r0 + 1 + dy) * HALO_W + i + dx], bw, acc1);
+      }
+    }
+    if (full) {
+      update(acc0, vp0, zb0, y0 + r0, a.p[t], true);
+      update(acc1, vp1, zb1, y0 + r0 + 1, a.p[t], true);
+    } else {
+      update(acc0, vp0, zb0, y0 + r0, a.p[t], false);
+      update(acc1, vp1, zb1, y0 + r0 + 1, a.p[t], false);
+    }
+    if (t + 1 < a.np) put_x(buf ^ 1);
+  }
+}
+
+// head cells recorded by a forward recording (evf_fwd_defer_*): launched by evf_hf_defer_launch before the diagonals
+struct HfJob {
+  const float *x, *w, *leak, *thresh, *v_prev;
+  const uint32_t* z_prev;
+  int B, Cin, H, W, hard_reset;
+  float* v_out;
+  uint32_t *z_out, *zT_out;
+};
+#define HF_MAX_JOBS 96
+struct HfDefer {
+  int n = 0;
+  HfJob job[HF_MAX_JOBS];
+};
+static HfDefer hf_tab[EVF_CTX_MAX];
+int evf_hf_defer_count(int ctx) { return hf_tab[ctx].n; }
+void evf_hf_defer_reset(int ctx) { hf_tab[ctx].n = 0; }
+
+static void head_fwd_one(const HfJob& q, hipStream_t st) {
+  dim3 grid(evf_cdiv(q.W, TW), evf_cdiv(q.H, TH), q.B), block(256);
+  launch_head_fwd(grid, block, st, q.x, q.w, q.leak, q.thresh, q.v_prev, q.z_prev, q.B, q.Cin, q.H, q.W, q.hard_reset, q.v_out,
+                  q.z_out, q.zT_out, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+int evf_hf_defer_launch(int ctx, void* stream) {
+  HfDefer& hf = hf_tab[ctx];
+  static const bool window = []() {  // EVF_HEAD_WIN=0: the recorded head cells one launch each (A/B measurements)
+    const char* e = getenv("EVF_HEAD_WIN");
+    return !(e && e[0] == '0');
+  }();
+  hipStream_t st = EVF_STREAM(stream);
+  int k = 0;
+  while (k < hf.n) {
+    // longest run of cells that continue each other: pass t + 1 starts from the state pass t wrote, same layer and geometry
+    int m = 1;
+    while (window && k + m < hf.n && m < HEADWIN_MAX_P) {
+      const HfJob &p = hf.job[k + m - 1], &q = hf.job[k + m];
+      if (!(q.v_prev == p.v_out && q.z_prev == p.z_out && q.w == p.w && q.leak == p.leak && q.thresh == p.thresh && q.B == p.B &&
+            q.Cin == p.Cin && q.H == p.H && q.W == p.W && q.hard_reset == p.hard_reset))
+        break;
+      ++m;
+    }
+    const HfJob& f = hf.job[k];
+    if (m == 1) {
+      head_fwd_one(f, st);
+    } else {
+      HeadWin a;
+      for (int t = 0; t < HEADWIN_MAX_P; ++t) {
+        const HfJob& q = hf.job[k + (t < m ? t : 0)];
+        a.p[t] = HeadWinPass{q.x, q.v_out, q.z_out, q.zT_out};
+      }
+      a.w = f.w, a.leak = f.leak, a.thresh = f.thresh, a.v_prev = f.v_prev, a.z_prev = f.z_prev;
+      a.np = m, a.B = f.B, a.Cin = f.Cin, a.H = f.H, a.W = f.W, a.hard_reset = f.hard_reset;
+      dim3 grid(evf_cdiv(f.W, TW), evf_cdiv(f.H, TH), f.B), block(256);
+      switch ((f.Cin + 1) / 2) {
+        case 1: hipLaunchKernelGGL(k_head_lif_fwd_win<1>, grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(k_head_lif_fwd_win<2>, grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL(k_head_lif_fwd_win<3>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(k_head_lif_fwd_win<4>, grid, block, 0, st, a); break;
+      }
+    }
+    k += m;
+  }
+  hf.n = 0;
+  return evf_status();
+}
+
 extern "C" int evf_head_lif_fwd(const float* x, const float* w, const float* leak, const float* thresh,
                                 const float* v_prev, const uint32_t* z_prev, int B, int Cin, int H, int W,
                                 int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out, void* stream) {
   if (!x || !w || !leak || !thresh || !v_out || !z_out || B <= 0 || Cin <= 0 || Cin > HEAD_MAX_CIN || H <= 0 || W <= 0)
     return EVF_EINVAL;
+  const int fctx = evf_ctx_find(stream);
+  if (fctx >= 0 && evf_fwd_defer_active(fctx)) {  // recorded: launched (all passes of the window in one launch) by the flush
+    HfDefer& hf = hf_tab[fctx];
+    if (hf.n == HF_MAX_JOBS) {
+      const int rc = evf_hf_defer_launch(fctx, stream);
+      if (rc) return rc;
+    }
+    hf.job[hf.n++] = HfJob{x, w, leak, thresh, v_prev, z_prev, B, Cin, H, W, hard_reset, v_out, z_out, zT_out};
+    if (evf_defer_poisoned()) {
+      const size_t npix = (size_t)B * H * W;
+      int rc = evf_hip(hipMemsetAsync(v_out, 0xFF, npix * C32 * sizeof(float), EVF_STREAM(stream)));
+      if (!rc) rc = evf_hip(hipMemsetAsync(z_out, 0xFF, npix * sizeof(uint32_t), EVF_STREAM(stream)));
+      if (rc) return rc;
+    }
+    return EVF_OK;
+  }
   dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(256);
   launch_head_fwd(grid, block, EVF_STREAM(stream), x, w, leak, thresh, v_prev, z_prev, B, Cin, H, W, hard_reset, v_out, z_out,
                   zT_out, nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -712,13 +951,31 @@ extern "C" int evf_lif_bwd(const float* g_z_out, const float* g_v_out, const flo
 // of the earlier VALU form: ~3x the occupancy, which is what hides the HBM latency of this kernel.
 // FAST: arctan surrogate + hard reset (the reference's default neuron) fixed at compile time -- no `switch` / `if` per
 // channel in the element-wise part (see k_lif_bwd_wgrad).
-template <bool FAST>
-__global__ __launch_bounds__(256) void k_head_bwd_mfma(
-    const float4* __restrict__ g_z_out, const float4* __restrict__ g_v_out, const float4* __restrict__ v_out,
-    const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev, const float* __restrict__ leak,
-    const float* __restrict__ thresh, long npix, int hard_reset_rt, int surrogate_rt, float width, float4* __restrict__ g_cur,
-    float4* __restrict__ g_v_prev, float* __restrict__ g_leak, float* __restrict__ g_thresh,
-    const float* __restrict__ x_in, int Cin, int H, int W, float* __restrict__ slab, int slab_acc, int row_ld) {
+// (No __restrict__ on the pointers: k_head_bwd_win runs this body once per pass of a window, and a pass reads what the SAME
+//  thread wrote in the pass before -- g_v_prev -> g_v_out, the slab and the per-channel rows; program order keeps that right.)
+struct HeadBwdPass {  // one pass of k_head_bwd_win
+  const float4 *g_z_out, *g_v_out, *v_out, *v_prev;
+  const uint32_t* z_prev;
+  const float* x_in;
+  float4* g_v_prev;
+  int slab_acc;
+};
+struct HeadTripIn {  // what one trip loads
+  float4 vo4, gvl, gzl, vpl;
+  uint32_t zwl;
+  float xb[4];
+};
+// NT > 0 (k_head_bwd_win, a block makes at most NT trips): the carried gradient and the membrane potential of the pass before
+// stay in REGISTERS between the passes of the launch -- gvc[trip] = dL/dv written by the previous pass (read instead of
+// g_v_out), voc[trip] = the v_prev it loaded, which IS this pass's v_out.  FIRST: the launch's first pass loads both from
+// memory; store_gv: the launch's last pass writes the carried gradient out.  Same values either way: bit-identical.
+template <bool FAST, int NT = 0, bool FIRST = true>
+__device__ __forceinline__ void head_bwd_pass(
+    const float4* g_z_out, const float4* g_v_out, const float4* v_out, const float4* v_prev, const uint32_t* z_prev,
+    const float* __restrict__ leak, const float* __restrict__ thresh, long npix, int hard_reset_rt, int surrogate_rt, float width,
+    float4* g_cur, float4* g_v_prev, float* g_leak, float* g_thresh, const float* __restrict__ x_in, int Cin, int H, int W,
+    float* slab, int slab_acc, int row_ld, float4 (&gvc)[NT ? NT : 1], float4 (&voc)[NT ? NT : 1], int (&xo)[NT ? NT : 1][4],
+    bool store_gv) {
   const int hard_reset = FAST ? 1 : hard_reset_rt, surrogate = FAST ? EVF_ARCTAN : surrogate_rt;
   __shared__ float s_red[2][4][C32];
   __shared__ __attribute__((aligned(16))) float s_g[2][4][8 * C32];  // [buffer][wave][pixel][channel]
@@ -757,29 +1014,69 @@ __global__ __launch_bounds__(256) void k_head_bwd_mfma(
   for (int h = 0; h < 4; ++h) prev[h] = sl_out[min(tid + 256 * h, C32 * ncol - 1)];
   const size_t row_off = (size_t)blockIdx.x * row_ld;
   const float row_prev = (((tid >> 5) & 1) ? g_thresh : g_leak)[row_off + (tid & 31)];  // (used by threads < 64)
-  int it = 0;
-  for (long base = (long)blockIdx.x * 256; base < total; base += stride, ++it) {  // block-uniform trip count
+  // a trip in two halves: fetch() issues its loads (unconditional, clamped addresses), work() consumes them.  NT > 0: the
+  // loads of ALL trips of the pass are issued before the first is consumed -- with one trip's loads in flight at a time (the
+  // barrier inside a trip keeps the next trip's loads behind it) the kernel ran at the memory latency, not the bandwidth.
+  typedef HeadTripIn TripIn;
+  // (`first`: also the carried operands and the geometry.  Requesting the NEXT pass's operands after the last trip, ahead of
+  //  the pass's own reductions, was measured and dropped: 166.6 against 161.3 us per window.)
+  auto fetch = [&](const long base, const int ic, TripIn& in, const bool first, const float4* pgz, const float4* pvp,
+                   const uint32_t* pzw, const float* x_in, const float4* v_out, const float4* pgv) {  // ic: the trip's carry register
     const long e = base + tid;
     const bool ok = e < total;
     const long ec = ok ? e : total - 1;
     const long pix = ec >> 3;
-    const float4 vo4 = v_out[ec];
-    const float4 gzl = pgz[ec], gvl = pgv[ec], vpl = pvp[ec];
-    const uint32_t zwl = pzw[pix];
+    if (NT == 0 || first) {
+      in.vo4 = v_out[ec];
+      in.gvl = pgv[ec];
+    }
+    in.gzl = pgz[ec], in.vpl = pvp[ec];
+    in.zwl = pzw[pix];
     // B operand: the input value of the wave's pixels 2m + kg at this lane's (ci, tap)
     const long wp0 = (base >> 3) + wv * 8;  // first pixel of this wave
-    float xb[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const long q = wp0 + 2 * m + kg;
-      const long qc = q < npix ? q : npix - 1;
-      const int b = (int)(qc / HW), rem = (int)(qc - (long)b * HW), y = rem / W, x = rem - y * W;
-      const int y2 = y + dy, x2 = x + dx;
-      const bool in = colok && q < npix && y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
-      const float xv = x_in[((long)(b * Cin + ci) * H + min(max(y2, 0), H - 1)) * W + min(max(x2, 0), W - 1)];
-      xb[m] = in ? xv : 0.f;
+      if (NT == 0) {
+        const long q = wp0 + 2 * m + kg;
+        const long qc = q < npix ? q : npix - 1;
+        const int b = (int)(qc / HW), rem = (int)(qc - (long)b * HW), y = rem / W, x = rem - y * W;
+        const int y2 = y + dy, x2 = x + dx;
+        const bool inb = colok && q < npix && y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
+        const float xv = x_in[((long)(b * Cin + ci) * H + min(max(y2, 0), H - 1)) * W + min(max(x2, 0), W - 1)];
+        in.xb[m] = inb ? xv : 0.f;
+      } else {
+        // the pixel geometry is the same in every pass of the launch: the element's offset into the input (-1: outside the
+        // image / padding column) is worked out by the first pass only -- two 64-bit and two 32-bit divisions by run-time
+        // values per element were most of this kernel's instructions
+        int off;
+        if (first) {
+          const long q = wp0 + 2 * m + kg;
+          const long qc = q < npix ? q : npix - 1;
+          const int b = (int)(qc / HW), rem = (int)(qc - (long)b * HW), y = rem / W, x = rem - y * W;
+          const int y2 = y + dy, x2 = x + dx;
+          const bool inb = colok && q < npix && y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
+          off = inb ? (int)(((long)(b * Cin + ci) * H + y2) * W + x2) : -1;
+          xo[ic][m] = off;
+        } else {
+          off = xo[ic][m];
+        }
+        const float xv = x_in[max(off, 0)];
+        in.xb[m] = off >= 0 ? xv : 0.f;
+      }
     }
-    const float4 gz4 = g_z_out ? gzl : zero4, gv4 = g_v_out ? gvl : zero4, vp4 = v_prev ? vpl : zero4;
+  };
+  auto work = [&](const long base, const int it, const int ic, const TripIn& in) {  // it: trip number (LDS buffer parity)
+    const long e = base + tid;
+    const bool ok = e < total;
+    float4 vo4, gvl;
+    if (NT == 0 || FIRST) {
+      vo4 = in.vo4, gvl = in.gvl;
+    } else {
+      vo4 = voc[ic], gvl = gvc[ic];
+    }
+    const float4 gzl = in.gzl, vpl = in.vpl;
+    const uint32_t zwl = in.zwl;
+    const float4 gz4 = g_z_out ? gzl : zero4, gv4 = (g_v_out || (NT > 0 && !FIRST)) ? gvl : zero4, vp4 = v_prev ? vpl : zero4;
     const uint32_t zw = z_prev ? (zwl >> (4 * cg)) : 0u;
     const float vo[4] = {vo4.x, vo4.y, vo4.z, vo4.w}, gz[4] = {gz4.x, gz4.y, gz4.z, gz4.w};
     const float gvo[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, vp[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
@@ -807,16 +1104,38 @@ __global__ __launch_bounds__(256) void k_head_bwd_mfma(
         st[k] -= dth + gsp;
       }
     }
+    if (NT > 0) {
+      gvc[ic] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+      voc[ic] = vpl;  // (v_prev == NULL: never read again -- the pass that starts from the zero state is the window's first)
+    }
     if (ok) {
       if (g_cur) g_cur[e] = make_float4(gc[0], gc[1], gc[2], gc[3]);
-      g_v_prev[e] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+      if (NT == 0 || store_gv) g_v_prev[e] = make_float4(gp[0], gp[1], gp[2], gp[3]);
     }
     float* sg_w = s_g[it & 1][wv];
     *(float4*)(sg_w + (lane >> 3) * C32 + 4 * cg) = ok ? make_float4(gc[0], gc[1], gc[2], gc[3]) : zero4;
     __syncthreads();  // (double-buffered: one barrier per trip)
 #pragma unroll
     for (int m = 0; m < 4; ++m)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sg_w[(2 * m + kg) * C32 + i], xb[m], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sg_w[(2 * m + kg) * C32 + i], in.xb[m], acc, 0, 0, 0);
+  };
+  if (NT == 0) {
+    int it = 0;
+    for (long base = (long)blockIdx.x * 256; base < total; base += stride, ++it) {  // block-uniform trip count
+      TripIn in;
+      fetch(base, 0, in, true, pgz, pvp, pzw, x_in, v_out, pgv);
+      work(base, it, 0, in);
+    }
+  } else {
+    TripIn tin[NT ? NT : 1];
+#pragma unroll
+    for (int it = 0; it < (NT ? NT : 1); ++it)
+      fetch((long)blockIdx.x * 256 + it * stride, it, tin[it], FIRST, pgz, pvp, pzw, x_in, v_out, pgv);
+#pragma unroll
+    for (int it = 0; it < (NT ? NT : 1); ++it) {
+      const long base = (long)blockIdx.x * 256 + it * stride;
+      if (base < total) work(base, it, it, tin[it]);
+    }
   }
   // D[co][col] of the 4 waves -> slab[block][co][col] (torch layout [32][Cin][3][3])
 #pragma unroll
@@ -863,6 +1182,57 @@ __global__ __launch_bounds__(256) void k_head_bwd_mfma(
       if (row_ld) g_thresh[ro + c] = row_prev + v;
       else evf_atomic_add(g_thresh + c, v);
     }
+  }
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void k_head_bwd_mfma(
+    const float4* __restrict__ g_z_out, const float4* __restrict__ g_v_out, const float4* __restrict__ v_out,
+    const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev, const float* __restrict__ leak,
+    const float* __restrict__ thresh, long npix, int hard_reset_rt, int surrogate_rt, float width, float4* __restrict__ g_cur,
+    float4* __restrict__ g_v_prev, float* __restrict__ g_leak, float* __restrict__ g_thresh,
+    const float* __restrict__ x_in, int Cin, int H, int W, float* __restrict__ slab, int slab_acc, int row_ld) {
+  float4 none[1];
+  int nox[1][4];
+  head_bwd_pass<FAST>(g_z_out, g_v_out, v_out, v_prev, z_prev, leak, thresh, npix, hard_reset_rt, surrogate_rt, width, g_cur,
+                      g_v_prev, g_leak, g_thresh, x_in, Cin, H, W, slab, slab_acc, row_ld, none, none, nox, true);
+}
+
+// The head layer's backward of a whole WINDOW in one launch.  The head's backward chain is per pixel (dL/dv carried from pass
+// t to pass t-1 by the thread that computed it; the weight-gradient and per-channel partial sums are per block), so once the
+// input gradients of the layer above have written dL/d(spikes) of EVERY pass -- each into its own buffer -- one launch runs
+// the passes back to back in every block: no device-wide launch boundary between them, the carried gradient and the block's
+// partial sums are re-read by the thread that just wrote them (cache hits).  Each pass is the body of k_head_bwd_mfma with the
+// same grid: bit-identical to one launch per pass.
+#define HEADBWD_MAX_P 16
+#ifndef HEADBWD_LB
+#define HEADBWD_LB 256
+#endif
+struct HeadBwdWin {
+  HeadBwdPass p[HEADBWD_MAX_P];
+  const float *leak, *thresh;
+  float *g_leak, *g_thresh, *slab;
+  long npix;
+  int np, hard_reset, surrogate, Cin, H, W, row_ld;
+  float width;
+};
+#define HEADBWD_NT 4  // trips of a block whose carried values fit registers (8 x 128 x 128 on 1024 blocks: 4)
+template <bool FAST, int NT>
+__global__ __launch_bounds__(HEADBWD_LB) void k_head_bwd_win(HeadBwdWin a) {
+  float4 gvc[NT ? NT : 1], voc[NT ? NT : 1];
+  int xo[NT ? NT : 1][4];
+  {
+    const HeadBwdPass& q = a.p[0];
+    head_bwd_pass<FAST, NT, true>(q.g_z_out, q.g_v_out, q.v_out, q.v_prev, q.z_prev, a.leak, a.thresh, a.npix, a.hard_reset,
+                                  a.surrogate, a.width, nullptr, q.g_v_prev, a.g_leak, a.g_thresh, q.x_in, a.Cin, a.H, a.W, a.slab,
+                                  q.slab_acc, a.row_ld, gvc, voc, xo, a.np == 1);
+  }
+  for (int t = 1; t < a.np; ++t) {
+    __syncthreads();  // (the pass's last reads of the reduction arrays before the next pass rewrites them)
+    const HeadBwdPass& q = a.p[t];
+    head_bwd_pass<FAST, NT, false>(q.g_z_out, q.g_v_out, q.v_out, q.v_prev, q.z_prev, a.leak, a.thresh, a.npix, a.hard_reset,
+                                   a.surrogate, a.width, nullptr, q.g_v_prev, a.g_leak, a.g_thresh, q.x_in, a.Cin, a.H, a.W, a.slab,
+                                   q.slab_acc, a.row_ld, gvc, voc, xo, t == a.np - 1);
   }
 }
 
@@ -927,6 +1297,85 @@ int evf_hd_defer_count(int ctx) {
   return n;
 }
 int evf_hd_defer_pending(int ctx, int d) { return hd_tab[ctx].n[d]; }
+// All recorded head cells at the END of a flush (after the last index), consecutive passes in one launch.  Allowed when no two
+// of them read the same dL/d(spikes) buffer (with ONE buffer the next pass's input gradient overwrites it: the cells then have
+// to run where they were recorded) -- nothing else they read is written by a recorded cell, nothing they write is read by one.
+int evf_hd_defer_window_ok(int ctx) {
+  static const bool window = []() {  // EVF_HEAD_WIN=0: head cells where they were recorded, one launch each
+    const char* e = getenv("EVF_HEAD_WIN");
+    return !(e && e[0] == '0');
+  }();
+  if (!window) return 0;
+  const HdDefer& hd = hd_tab[ctx];
+  const float* seen[EVF_BWD_DIAGS * HD_MAX_JOBS];
+  int ns = 0, n = 0;
+  for (int d = 0; d < EVF_BWD_DIAGS; ++d)
+    for (int k = 0; k < hd.n[d]; ++k, ++n) {
+      const float* g = hd.job[d][k].g_z_out;
+      if (!g) continue;
+      for (int i = 0; i < ns; ++i)
+        if (seen[i] == g) return 0;
+      seen[ns++] = g;
+    }
+  return n >= 2 ? 1 : 0;
+}
+int evf_hd_defer_launch_window(int ctx, void* stream) {
+  HdDefer& hd = hd_tab[ctx];
+  const HdArgs* jobs[EVF_BWD_DIAGS * HD_MAX_JOBS];
+  int n = 0;
+  for (int d = 0; d < EVF_BWD_DIAGS; ++d) {
+    for (int k = 0; k < hd.n[d]; ++k) jobs[n++] = &hd.job[d][k];
+  }
+  int rc = EVF_OK;
+  int k = 0;
+  while (k < n && !rc) {
+    const HdArgs& f = *jobs[k];
+    int m = 1;
+    while (k + m < n && m < HEADBWD_MAX_P && !f.g_cur) {  // pass k+m continues pass k+m-1: carried gradient, same accumulators
+      const HdArgs &p = *jobs[k + m - 1], &q = *jobs[k + m];
+      if (!(q.g_v_out == p.g_v_prev && q.v_out == p.v_prev && p.v_prev && !q.g_cur && q.leak == p.leak && q.thresh == p.thresh && q.B == p.B && q.Cin == p.Cin &&
+            q.H == p.H && q.W == p.W && q.hard_reset == p.hard_reset && q.surrogate == p.surrogate &&
+            q.act_width == p.act_width && q.g_leak == p.g_leak && q.g_thresh == p.g_thresh && q.slab == p.slab &&
+            (q.accumulate >> 8) == (p.accumulate >> 8)))
+        break;
+      ++m;
+    }
+    evf_prof_mark(3, 0, stream);
+    if (m == 1) {
+      rc = head_bwd_go(f, stream);
+    } else {
+      HeadBwdWin a;
+      for (int t = 0; t < HEADBWD_MAX_P; ++t) {
+        const HdArgs& q = *jobs[k + (t < m ? t : 0)];
+        a.p[t] = HeadBwdPass{(const float4*)q.g_z_out, (const float4*)q.g_v_out, (const float4*)q.v_out, (const float4*)q.v_prev,
+                             q.z_prev, q.x_in, (float4*)q.g_v_prev, q.accumulate & 1};
+      }
+      a.leak = f.leak, a.thresh = f.thresh, a.g_leak = f.g_leak, a.g_thresh = f.g_thresh, a.slab = f.slab;
+      a.npix = (long)f.B * f.H * f.W;
+      a.np = m, a.hard_reset = f.hard_reset, a.surrogate = f.surrogate, a.Cin = f.Cin, a.H = f.H, a.W = f.W;
+      a.row_ld = f.accumulate >> 8, a.width = f.act_width;
+      const int nblk = evf_head_lif_bwd_wgrad_slabs(f.B, f.H, f.W);
+      const bool fast = f.hard_reset != 0 && f.surrogate == EVF_ARCTAN;
+      const long trips = (a.npix * 8 + (long)nblk * 256 - 1) / ((long)nblk * 256);
+      static const bool carry = []() {  // EVF_HEAD_WIN=mem: carried values through memory (A/B measurements)
+        const char* e = getenv("EVF_HEAD_WIN");
+        return !(e && e[0] == 'm');
+      }();
+#define HEAD_BWD_WIN(FAST_, NT_) hipLaunchKernelGGL((k_head_bwd_win<FAST_, NT_>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a)
+      if (carry && fast && trips <= HEADBWD_NT && (long)f.B * f.Cin * f.H * f.W < (1L << 31)) {  // (other surrogates: 253 VGPRs)
+        HEAD_BWD_WIN(true, HEADBWD_NT);
+      } else {
+        if (fast) HEAD_BWD_WIN(true, 0); else HEAD_BWD_WIN(false, 0);
+      }
+#undef HEAD_BWD_WIN
+      rc = evf_status();
+    }
+    evf_prof_mark(3, 1, stream);
+    k += m;
+  }
+  for (int d = 0; d < EVF_BWD_DIAGS; ++d) hd.n[d] = 0;
+  return rc;
+}
 int evf_hd_defer_launch(int ctx, int d, void* stream) {
   HdDefer& hd_defer = hd_tab[ctx];
   for (int k = 0; k < hd_defer.n[d]; ++k) {

@@ -43,6 +43,8 @@ F32_DGRAD = os.environ.get("EVF_F32_DGRAD", "1") != "0"
 # of the fp32 tensor, and the persistent input-gradient launch stages it by LDS-DMA (k_dgrad_diag_dma); 0: fp32 g_cur, split by
 # the input-gradient kernel's producer waves (k_dgrad_diag_ws)
 SPLIT_DGRAD = os.environ.get("EVF_DGRAD_SPLIT", "1") != "0"
+# the head layer's cells of a recorded window in ONE launch each way (k_head_lif_fwd_win, k_head_bwd_win): its state is per pixel
+HEAD_WIN = os.environ.get("EVF_HEAD_WIN", "1") != "0"
 PRED_FUSED = os.environ.get("EVF_PRED_FUSED", "1") != "0"  # prediction head in the epilogue of the last layer's forward
 TOP_FUSED = os.environ.get("EVF_TOP_FUSED", "1") != "0"  # prediction-head backward inside the top layer's fused backward
 PAIR_DGRAD = os.environ.get("EVF_PAIR_DGRAD", "1") != "0"
@@ -73,6 +75,7 @@ class _Window:
         self.gzr, self.gzr_has = [None] * n_, [False] * n_  # recurrent part of dL/d(spikes), separate from gz (see _backward_pass)
         self.gcl = [None] * n_  # per-layer g_cur buffers (diagonal backward launches: several layers in flight)
         self.gsl = [None] * n_  # ... or per-layer split planes [3,B,H,W,32] bf16 (SPLIT_DGRAD)
+        self.gz0 = []           # dL/d(spikes) of the head layer, one buffer per backward pass (HEAD_WIN)
         self.bwd_k = 0          # backward passes of this window so far
         self.slab_init = {}
         self.token = eng._token(dev)  # (a leaf whose value is never read: only its autograd edge chains the passes)
@@ -651,6 +654,12 @@ class FireNetEngine:
             if i > 0:
                 if bdefer:
                     self._bdefer_slot(win, 2 * (n - 1 - i) + 1)
+                if bdefer and i == 1 and HEAD_WIN and not win.gz_has[0]:
+                    # dL/d(spikes) of the head layer in a buffer of this pass's own: the head's backward cells of the whole window
+                    # then run after the last diagonal, all passes in one launch (evf_hd_defer_launch_window)
+                    while len(win.gz0) <= win.bwd_k:
+                        win.gz0.append(_f32((B, H, W, C), dev))
+                    win.gz[0] = win.gz0[win.bwd_k]
                 ga = win.buf(win.gz, i - 1)
                 acc_a = 1 if win.gz_has[i - 1] else 0
                 if self.precision == "bf16x3":

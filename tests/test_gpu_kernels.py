@@ -212,3 +212,93 @@ def test_prediction_head_fused_into_its_neighbours(shape):
         assert _rel(res[1][k], res[0][k]) < 5e-6, k
 
 
+
+
+@pytest.mark.parametrize("shape,cin,hard,fresh", [((8, 128, 128), 2, 1, True), ((2, 37, 50), 2, 1, False), ((2, 37, 50), 4, 0, True),
+                                                    ((1, 64, 96), 3, 1, False)])
+def test_head_layer_of_a_window_in_one_launch_is_bit_identical_forward(shape, cin, hard, fresh):
+    """The head layer's cells of a forward recording run as ONE launch at the flush (k_head_lif_fwd_win: membrane potential
+    and spikes of a tile carried in registers from pass to pass) -- every pass's v', z' and channel-major planes must equal
+    one evf_head_lif_fwd launch per pass bit for bit.  Full and ragged tiles, Cin 2 / 3 / 4, both reset rules, starting from
+    the zero state and from a given state; 19 passes: more than one launch's worth (16), so a run is cut and continued."""
+    B, H, W = shape
+    npass = 19
+    torch.manual_seed(11)
+    w = _f(32, cin, 3, 3, scale=0.4)
+    leak, thresh = _f(32, scale=0.3), _f(32, scale=0.1) + 0.5
+    xs = [torch.poisson(torch.full((B, cin, H, W), 0.4, device=DEV)) for _ in range(npass)]
+    v0 = None if fresh else _f(B, H, W, C, scale=0.5)
+    z0 = None if fresh else _bits(B, H, W)
+
+    def run(record):
+        outs = []
+        v, z = v0, z0
+        if record:
+            assert _lib.raw("evf_fwd_defer_begin") == 0
+        try:
+            for x in xs:
+                vo = torch.full((B, H, W, C), 3.0, device=DEV)
+                zo = torch.full((B, H, W), 5, dtype=torch.int32, device=DEV)
+                zT = torch.full((B, H, C, (W + 31) // 32), 9, dtype=torch.int32, device=DEV)
+                _lib.call("evf_head_lif_fwd", P(x), P(w), P(leak), P(thresh), P(v), P(z), B, cin, H, W, hard, P(vo), P(zo), P(zT))
+                outs.append((vo, zo, zT))
+                v, z = vo, zo
+            if record:
+                assert _lib.raw("evf_fwd_defer_pending") == npass
+        finally:
+            if record:
+                _lib.call("evf_fwd_defer_flush")
+        torch.cuda.synchronize()
+        return outs
+
+    ref, got = run(False), run(True)
+    assert any(int((zo != 0).sum()) > 0 for _, zo, _ in ref)  # (the cells do spike)
+    for t, (a, b) in enumerate(zip(ref, got)):
+        for name, x, y in zip(("v", "z", "zT"), a, b):
+            assert torch.equal(x, y), (t, name)
+
+
+@pytest.mark.parametrize("shape,surrogate,hard", [((8, 128, 128), 0, 1), ((2, 37, 50), 0, 1), ((2, 37, 50), 2, 0), ((16, 128, 128), 0, 1)])
+def test_head_layer_of_a_window_in_one_launch_is_bit_identical_backward(shape, surrogate, hard):
+    """The head layer's backward cells of a recording run after the last index as ONE launch (k_head_bwd_win) when every
+    pass has a dL/d(spikes) buffer of its own -- carried dL/dv and the block's partial sums re-read by the thread that wrote
+    them (any shape / surrogate), or kept in registers with all loads of a pass in flight (<= 4 trips per block, the
+    reference's default neuron).  Against the same cells with ONE shared dL/d(spikes) buffer, which the library then runs
+    where they were recorded, one launch each: dL/dv of the window's start, the weight-gradient slabs and the per-block
+    per-channel rows must agree bit for bit.  (16 x 128 x 128: 8 trips per block -- the through-memory form of the default
+    neuron.)"""
+    B, H, W = shape
+    npass = 6
+    torch.manual_seed(13)
+    L = _lib.load()
+    nsl = L.evf_head_lif_bwd_wgrad_slabs(B, H, W)
+    leak, thresh = _f(32, scale=0.3), _f(32, scale=0.1) + 0.5
+    xs = [torch.poisson(torch.full((B, 2, H, W), 0.4, device=DEV)) for _ in range(npass)]
+    vs = [_f(B, H, W, C, scale=0.7) for _ in range(npass + 1)]  # vs[t]: v before pass t; vs[t + 1]: after
+    zs = [_bits(B, H, W) for _ in range(npass)]
+    gz = _f(B, H, W, C, scale=0.2)
+    row_ld = 64
+
+    def run(shared):
+        gzs = [gz if shared else gz.clone() for _ in range(npass)]
+        gv = torch.empty(B, H, W, C, device=DEV)
+        slab = torch.full((nsl, 32 * 18), 7.0, device=DEV)
+        rows = torch.zeros(nsl, row_ld, device=DEV)
+        assert _lib.raw("evf_bwd_defer_begin") == 0
+        try:
+            for k in range(npass):  # backward pass k = forward pass npass - 1 - k
+                t = npass - 1 - k
+                assert _lib.raw("evf_bwd_defer_slot", 2 * k + 3) == 0
+                _lib.call("evf_head_lif_bwd_wgrad", P(gzs[k]), P(gv) if k else None, P(vs[t + 1]), P(vs[t]) if t else None,
+                          P(zs[t]) if t else None, P(xs[t]), P(leak), P(thresh), B, 2, H, W, hard, surrogate, 10.0, None, P(gv),
+                          P(rows[:, :32]), P(rows[:, 32:]), P(slab), (1 if k else 0) | (row_ld << 8))
+            assert _lib.raw("evf_bwd_defer_pending") == npass
+        finally:
+            _lib.call("evf_bwd_defer_flush")
+        torch.cuda.synchronize()
+        return gv, slab, rows
+
+    ref, got = run(True), run(False)
+    assert float(ref[1].abs().max()) > 0 and float(ref[2].abs().max()) > 0
+    for name, a, b in zip(("g_v", "slab", "rows"), ref, got):
+        assert torch.equal(a, b), name
