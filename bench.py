@@ -276,6 +276,7 @@ _KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3_lds<false, false, false, fal
               "evf_lif_bwd_wgrad/rec": "k_lif_bwd_wgrad<true, false, true>", "evf_lif_bwd_wgrad/rec+2": "k_lif_bwd_wgrad<true, false, true>",
               "evf_lif_bwd_wgrad/ff+2": "k_lif_bwd_wgrad<false, false, true>", "evf_conv_lif_fwd_b3/ff": "k_conv_lif_fwd_b3<false, false>",
               "evf_conv_lif_fwd_b3/rec": "k_conv_lif_fwd_b3<true, false>", "evf_head_lif_fwd": "k_head_lif_fwd<1>",
+              "k_head_lif_fwd_win": "k_head_lif_fwd_win<1>", "k_head_bwd_win": "k_head_bwd_win<true, 4>",
               "evf_head_lif_bwd_wgrad": "k_head_bwd_mfma<true>", "evf_conv_dgrad/one": "k_conv_dgrad<false>",
               "evf_conv_dgrad/two": "k_conv_dgrad<true>", "k_fwd_diag": "k_fwd_diag_p", "k_bwd_diag": "k_bwd_diag",
               "k_dgrad_diag": "k_dgrad_diag_dma<true>", "evf_conv_lif_fwd/ff": "k_conv_lif_fwd<false>",
@@ -663,7 +664,7 @@ def main():
     diag_fwd = _train.DEFER_FORWARD and getattr(model, "precision", "") == "bf16x3" and wl["model"] == "LIFFireNet"
     diag_bwd = _train.DEFER_BACKWARD and getattr(model, "precision", "") == "bf16x3" and wl["model"] == "LIFFireNet"
     if diag_fwd:  # (these entry points then only record: timed inside the flush, evf_defer_profile)
-        names = [n for n in names if n not in ("evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred")]
+        names = [n for n in names if n not in ("evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_head_lif_fwd")]
     if diag_bwd:
         names = [n for n in names if n not in ("evf_lif_bwd_wgrad2", "evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad_top", "evf_conv_dgrad_b3_f32",
                                                "evf_conv_dgrad_b3_f32_pair", "evf_head_lif_bwd_wgrad")]
@@ -726,10 +727,11 @@ def main():
     # the diagonal launches, timed per launch inside the flushes (HIP events in the library, same bracket overhead)
     import ctypes as _ct
 
-    _ms, _cnt = (_ct.c_float * 4)(), (_ct.c_int * 4)()
+    _ms, _cnt = (_ct.c_float * 8)(), (_ct.c_int * 8)()
     if _lib.load().evf_defer_profile_read(_ms, _cnt) != 0:
         raise RuntimeError("evf_defer_profile_read failed")
-    for k, nm in enumerate([("k_fwd_diag", ""), ("k_bwd_diag", ""), ("k_dgrad_diag", ""), ("evf_head_lif_bwd_wgrad", "")]):
+    for k, nm in enumerate([("k_fwd_diag", ""), ("k_bwd_diag", ""), ("k_dgrad_diag", ""), ("evf_head_lif_bwd_wgrad", ""),
+                            ("k_head_lif_fwd_win", ""), ("k_head_bwd_win", "")]):
         if _cnt[k]:
             prof[nm] = [max(_ms[k] / _cnt[k] - _lib.last_event_overhead_ms, 0.0)] * _cnt[k]
     # evf_lif_bwd_wgrad2 = evf_lif_bwd_wgrad with dL/d(spikes) in two parts: one kernel, reported under the one name
@@ -813,6 +815,12 @@ def main():
             hbm_bound |= {"k_bwd_diag", "k_dgrad_diag"}
             bf16_terms["k_bwd_diag"] = 3
             bf16_terms["k_dgrad_diag"] = 6
+        # the head layer of a recorded window, one launch each way (per LAUNCH = per window).  Forward: per pass the 2-channel
+        # input in (8 B/px), v', spike words and planes out (136); the starting state once (132).  Backward: per pass dL/d(spikes),
+        # the previous potential, spike word and input in (268); v' of the last pass and the carried gradient in / out once (384)
+        model[("k_head_lif_fwd_win", "")] = (PASSES * 2 * 18 * 32 * npix, (PASSES * 144 + 132) * npix)
+        model[("k_head_bwd_win", "")] = (PASSES * 2 * 18 * 32 * npix, (PASSES * 268 + 384) * npix)
+        hbm_bound |= {"k_head_lif_fwd_win", "k_head_bwd_win"}
         kernels = {}
         step_alg_bytes = 0.0
         for key, ms in prof.items():
@@ -875,10 +883,10 @@ def main():
                        "parallelism": f"dp{dp.world}", "launch": mode, "loss": loss_val,
                        "streams": nstream,
                        "forward_launches": ("diagonal: the window's hidden forward cells in P + 5 launches (k_fwd_diag, cells "
-                                            "(pass, layer) with equal pass + layer together); EVF_DEFER_FWD=0: one launch per cell"
+                                            "(pass, layer) with equal pass + layer together), the head layer of all passes in 1 (k_head_lif_fwd_win); EVF_DEFER_FWD=0: one launch per cell"
                                             if diag_fwd else "one launch per (pass, layer) cell"),
                        "backward_launches": ("diagonal: fused-backward cells in P + 5 launches (k_bwd_diag), input-gradient cells in "
-                                             "P + 5 (k_dgrad_diag), head backward P; EVF_DEFER_BWD=0: 13 launches per pass"
+                                             "P + 5 (k_dgrad_diag), the head layer's backward of all passes in 1 (k_head_bwd_win); EVF_DEFER_BWD=0: 13 launches per pass"
                                              if diag_bwd else "one launch per cell"),
                        "pipelining": (f"each rank's {B_PER_GPU} windows as {nstream} micro-batches of {B_PER_GPU // nstream} on {nstream} HIP "
                                       "streams (replicas sharing the weights; gradients summed before the one optimizer step): "

@@ -653,8 +653,8 @@ void evf_prof_mark(int kind, int end, void* stream) {
   }
 }
 // evf_defer_profile(1): time every dispatcher launch of the following flushes; evf_defer_profile_read: device sync, then
-// ms[k] = summed duration and count[k] = number of launches of kind k (0 k_fwd_diag, 1 k_bwd_diag, 2 k_dgrad_diag, 3 head
-// backward) since it was switched on (event-bracket overhead included: ~1.6 us per launch); switches it off.
+// ms[k] = summed duration and count[k] = number of launches of kind k < 8 (0 k_fwd_diag, 1 k_bwd_diag, 2 k_dgrad_diag, 3 head
+// backward pass by pass, 4 k_head_lif_fwd_win, 5 k_head_bwd_win) since it was switched on (event-bracket overhead included: ~1.6 us per launch); switches it off.
 extern "C" int evf_defer_profile(int on) {
   evf_prof.on = on != 0;
   evf_prof.n = 0;
@@ -664,12 +664,12 @@ extern "C" int evf_defer_profile_read(float* ms, int* count) {
   if (!ms || !count) return EVF_EINVAL;
   evf_prof.on = false;
   { const int rc = evf_hip(hipDeviceSynchronize()); if (rc) return rc; }
-  for (int k = 0; k < 4; ++k) ms[k] = 0.f, count[k] = 0;
+  for (int k = 0; k < 8; ++k) ms[k] = 0.f, count[k] = 0;
   for (int i = 0; i < evf_prof.n; ++i) {
     float t = 0.f;
     { const int rc = evf_hip(hipEventElapsedTime(&t, evf_prof.e0[i], evf_prof.e1[i])); if (rc) return rc; }
-    ms[evf_prof.kind[i] & 3] += t;
-    ++count[evf_prof.kind[i] & 3];
+    ms[evf_prof.kind[i] & 7] += t;
+    ++count[evf_prof.kind[i] & 7];
   }
   evf_prof.n = 0;
   return EVF_OK;

@@ -640,6 +640,7 @@ int evf_hf_defer_launch(int ctx, void* stream) {
     if (m == 1) {
       head_fwd_one(f, st);
     } else {
+      evf_prof_mark(4, 0, stream);
       HeadWin a;
       for (int t = 0; t < HEADWIN_MAX_P; ++t) {
         const HfJob& q = hf.job[k + (t < m ? t : 0)];
@@ -654,6 +655,7 @@ int evf_hf_defer_launch(int ctx, void* stream) {
         case 3: hipLaunchKernelGGL(k_head_lif_fwd_win<3>, grid, block, 0, st, a); break;
         default: hipLaunchKernelGGL(k_head_lif_fwd_win<4>, grid, block, 0, st, a); break;
       }
+      evf_prof_mark(4, 1, stream);
     }
     k += m;
   }
@@ -1340,7 +1342,7 @@ int evf_hd_defer_launch_window(int ctx, void* stream) {
         break;
       ++m;
     }
-    evf_prof_mark(3, 0, stream);
+    evf_prof_mark(m == 1 ? 3 : 5, 0, stream);
     if (m == 1) {
       rc = head_bwd_go(f, stream);
     } else {
@@ -1370,7 +1372,7 @@ int evf_hd_defer_launch_window(int ctx, void* stream) {
 #undef HEAD_BWD_WIN
       rc = evf_status();
     }
-    evf_prof_mark(3, 1, stream);
+    evf_prof_mark(m == 1 ? 3 : 5, 1, stream);
     k += m;
   }
   for (int d = 0; d < EVF_BWD_DIAGS; ++d) hd.n[d] = 0;

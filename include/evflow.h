@@ -238,10 +238,11 @@ int evf_bwd_defer_pending(void* stream);
 int evf_bwd_defer_flush(void* stream);
 /* Measurement aid: evf_defer_profile(1) brackets every launch of the following flushes with HIP events;
  * evf_defer_profile_read synchronises the device, returns per kind (0 forward cells, 1 fused-backward cells, 2
- * input-gradient cells, 3 head backward) the summed duration in ms and the number of launches, and switches it off.
- * Not inside a graph capture. */
+ * input-gradient cells, 3 head backward one pass per launch, 4 head forward of a window in one launch, 5 head backward of
+ * a window in one launch; 6, 7 unused) the summed duration in ms and the number of launches -- EIGHT entries each -- and
+ * switches it off.  Not inside a graph capture. */
 int evf_defer_profile(int on);
-int evf_defer_profile_read(float* ms4, int* count4);
+int evf_defer_profile_read(float* ms8, int* count8);
 
 /* Neuron backward (autograd of :103-126 / :523-551 with the surrogate of
  * spiking_util.py:88-93).  Per element:
