@@ -76,6 +76,7 @@ NETWORK_SIGNATURES = {
     "evf_conv_dgrad_b3_f32": [P, P, P, I, I, I, I, P, P, P],
     "evf_conv_dgrad_select": [I],
     "evf_dgrad_diag_select": [I],
+    "evf_bwd_diag_select": [I],
     "evf_conv_dgrad_b3_f32_pair": [P, P, P, I, P, P, I, I, I, P, P, P],
     "evf_conv_dgrad_b3_pair": [P, P, P, I, P, P, I, I, I, P, P, P],
     "evf_conv_plif_fwd_b3": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P],

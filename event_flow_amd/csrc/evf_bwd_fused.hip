@@ -535,6 +535,447 @@ __device__ __forceinline__ void fb_body(
   FB_SPAN_MARK(1);
 }
 
+// ---- the same cell with the block's eight waves in two TEAMS (k_bwd_diag_ws) ---------------------------------------------
+// In fb_body every wave runs load -> neuron backward -> stage -> matrix phase one after the other and the block's barrier
+// keeps all eight in the same phase: per 64-pixel unit the vector pipes (~2.0 k cycles per SIMD), the matrix pipes (~1.2 k)
+// and the LDS (~2.2 k) are busy one AFTER the other, 5.5 k cycles (PMC: SQ_INSTS_VALU / MFMA / LDS_IDX_ACTIVE per unit).
+// Here waves 0-3 (team E) stream the tensors, do the neuron backward, write the results and stage the operands of unit
+// k + 1, while waves 4-7 (team M) contract unit k on the matrix cores: one wave of each team per SIMD, so a SIMD's vector
+// and matrix pipes work at the same time.  Team M: wave m owns taps 2m and 2m + 1 (the B fragments of a K step are read
+// once for both) and the ninth tap's K step m of every unit; team E: a thread takes one float4 of every tensor per HALF
+// unit (32 pixels), four half units of loads in flight.  Default neuron only (arctan surrogate, hard reset).
+// Same products in the same order per tap as fb_body; the ninth tap's partial tiles are grouped differently (4 instead of
+// 8) and the per-channel sums run over other thread subsets: equal to fp32 round-off, not bit for bit.
+template <bool REC, bool TOP>
+__device__ __forceinline__ void fb_body_ws(
+    const int bid, const int nblk_, const float4* __restrict__ g_z_out, const float4* __restrict__ g_z_out2,
+    const float4* __restrict__ g_v_out, const float4* __restrict__ v_out, const float4* __restrict__ v_prev,
+    const uint32_t* __restrict__ z_prev, const uint32_t* __restrict__ xT, const uint32_t* __restrict__ zT,
+    const float* __restrict__ leak, const float* __restrict__ thresh, int B, int H, int W, int nchunk, long nunits, float width,
+    int accumulate, int nrows_total, float4* __restrict__ g_cur, uint2* __restrict__ g_split, float4* __restrict__ g_v_prev,
+    float* __restrict__ g_leak, float* __restrict__ g_thresh, float* __restrict__ slab_ff, float* __restrict__ slab_rec, FbTop top,
+    int row_ld) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  unsigned short* s_b = (unsigned short*)smem_raw;           // [2][3][FB_CW*32] bf16 (region of FB_R0 bytes)
+  uint32_t* s_px = (uint32_t*)(smem_raw + FB_R0);             // [2][3][32][FB_NW]
+  uint32_t* s_pz = s_px + 2 * 3 * C32 * FB_NW;                // same (REC)
+  uint4* s_lut = (uint4*)(s_pz + 2 * 3 * C32 * FB_NW);        // [256]
+  float* s_red = (float*)(s_lut + 256);                       // [2][8][32]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const bool team_e = wv < 4;
+  int nst = 0;
+  (void)nst;
+#ifdef FB_STAMPS  // (team E: wave 0, team M: wave 4; before and after every barrier of the unit loop)
+#define FBW_STAMP()                                                                                  \
+  do {                                                                                               \
+    if (blockIdx.x < 16 && lane == 0 && (wv == 0 || wv == 4) && nst < 96)                            \
+      fb_stamps[(blockIdx.x * 2 + (wv ? 1 : 0)) * 96 + nst++] = __builtin_readcyclecounter();       \
+  } while (0)
+#else
+#define FBW_STAMP() do {} while (0)
+#endif
+  const int i = lane & 31, kg = lane >> 5;
+  const int et = tid & 255;  // thread within its team
+  const int cg = et & 7;     // team E: channel group (channels 4cg..4cg+3) ...
+  const int pe = et >> 3;    // ... and pixel within the half unit
+  const int mw = wv & 3;     // team M: wave within the team
+  const int nW = (W + 31) / 32;
+  if (tid < 256) {
+    const uint32_t t = tid;
+    auto pr = [&](int e) { return ((t >> e) & 1u) * 0x3F80u | (((t >> (e + 1)) & 1u) * 0x3F80u) << 16; };
+    s_lut[tid] = make_uint4(pr(0), pr(2), pr(4), pr(6));
+  }
+  const int nblk = nblk_;
+  const int nu = (int)((nunits - (long)bid + nblk - 1) / nblk);
+  static_assert(FB_UNITS_MAX <= 64, "geometry table: one lane per unit of the block");
+  static_assert(FB_NW == 4 && FB_CW == 64, "team E: half units of 32 pixels, 384 plane words per unit");
+  int g_b, g_y, g_x0;
+  {
+    const int u = bid + min(lane, nu - 1) * nblk;
+    const int row = u / nchunk;
+    g_b = row / H;
+    g_y = row - g_b * H;
+    g_x0 = (u - row * nchunk) * FB_CW;
+  }
+  auto geom = [&](int k, int& b, int& y, int& x0, int& cw) {
+    b = __builtin_amdgcn_readlane(g_b, k);
+    y = __builtin_amdgcn_readlane(g_y, k);
+    x0 = __builtin_amdgcn_readlane(g_x0, k);
+    cw = min(FB_CW, W - x0);
+  };
+  // operands of the epilogue, requested now (see fb_body): the ninth tap's previous partial sums (all threads), the
+  // block's row of per-channel sums (threads < 66 of team E)
+  float prev8[2], prev8z[2] = {0.f, 0.f};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const long o8 = (long)bid * (9 * C32 * C32) + 8 * (C32 * C32) + tid + h * FB_THREADS;
+    prev8[h] = slab_ff[o8];
+    if (REC) prev8z[h] = slab_rec[o8];
+  }
+  const size_t row_off = (size_t)bid * row_ld;
+  const int row_c = tid & 31, row_which = (tid >> 5) & 1;
+  const float row_prev = (row_which ? g_thresh : g_leak)[row_off + row_c];  // (read by threads < 64)
+  float top_prev = 0.f;
+  if (TOP) top_prev = tid < 64 ? top.dw[row_off + row_which * C32 + row_c] : top.db[row_off + (tid & 1)];  // (threads < 66)
+
+  // team E state
+  float sl[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
+  float dwa[4] = {0, 0, 0, 0}, dwb[4] = {0, 0, 0, 0}, dba = 0.f, dbb = 0.f;
+  // team M state: taps t0 = 2 mw, t1 = 2 mw + 1, the ninth tap's K step mw
+  f32x16 acc0 = {0}, acc1 = {0}, accz0 = {0}, accz1 = {0}, acc8 = {0}, accz8 = {0};
+  const int t0 = 2 * mw, t1 = 2 * mw + 1;
+  const long slab_off0 = (long)bid * (9 * C32 * C32) + t0 * (C32 * C32) + i, slab_off1 = slab_off0 + C32 * C32;
+
+  if (team_e) {
+    float lam[4], th[4], oml[4], inv_oml[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      lam[k] = fb_sigmoid(leak[4 * cg + k]);
+      th[k] = fmaxf(thresh[4 * cg + k], 0.01f);
+      oml[k] = 1.0f - lam[k];
+      inv_oml[k] = 1.0f / oml[k];
+    }
+    float pwa[4] = {0, 0, 0, 0}, pwb[4] = {0, 0, 0, 0};
+    if (TOP) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pwa[k] = top.pred_w[4 * cg + k], pwb[k] = top.pred_w[C32 + 4 * cg + k];
+    }
+    const float4* pgz = g_z_out ? g_z_out : v_out;
+    const float4* pgz2 = g_z_out2 ? g_z_out2 : v_out;
+    const bool has_gz2 = !TOP && g_z_out2 != nullptr;
+    const float4* pgv = g_v_out ? g_v_out : v_out;
+    const float4* pvp = v_prev ? v_prev : v_out;
+    const uint32_t* pzw = z_prev ? z_prev : xT;
+    const uint32_t* pzt = REC ? zT : xT;
+    const bool has_gz = g_z_out != nullptr, has_gv = g_v_out != nullptr, has_vp = v_prev != nullptr, has_zw = z_prev != nullptr;
+    // stage 1: the global loads of half h of unit k (straight-line, unconditional, clamped: see fb_body)
+    auto issue = [&](const int k, const int h, FbStage& s) {
+      int b, y, x0, cw;
+      geom(min(k, nu - 1), b, y, x0, cw);
+      const long pix0 = ((long)b * H + y) * W + x0;
+      const int pc = min(32 * h + pe, cw - 1);
+      const long ge = (pix0 + pc) * 8 + cg;
+      s.vo = v_out[ge];
+      if (TOP) {
+        const long hw = (long)H * W, q = (long)y * W + x0 + pc;
+        s.f0 = top.flow[(long)b * 2 * hw + q], s.f1 = top.flow[((long)b * 2 + 1) * hw + q];
+        s.q0 = top.g_flow[(long)b * 2 * hw + q], s.q1 = top.g_flow[((long)b * 2 + 1) * hw + q];
+        s.zo = top.z_out[pix0 + pc];
+      } else {
+        s.gz = pgz[ge];
+        s.gz2 = pgz2[ge];
+      }
+      s.gv = pgv[ge];
+      s.vp = pvp[ge];
+      s.zw = pzw[z_prev ? pix0 + pc : 0];
+      // this half's share of the unit's 384 plane words (3 rows x 32 channels x 4 words): 256 + 128
+      const int tpl = min(et + 256 * h, 3 * C32 * FB_NW - 1);
+      const int pl_wq = tpl % FB_NW, pl_c = (tpl / FB_NW) % C32, pl_dy = tpl / (FB_NW * C32);
+      const int yy = y + pl_dy - 1, xw = x0 / 32 - 1 + pl_wq;
+      const bool in = yy >= 0 && yy < H && xw >= 0 && xw < nW;
+      const long src = in ? (((long)b * H + yy) * C32 + pl_c) * nW + xw : 0;
+      s.px = xT[src];
+      s.pz = pzt[src];
+      s.pin = in ? 0xFFFFFFFFu : 0u;
+    };
+    // stage 2: neuron backward in registers, results to HBM, split g_cur + spike planes to LDS buffer `buf`
+    auto commit = [&](const int k, const int h, const FbStage& s, const int buf) {
+      int b, y, x0, cw;
+      geom(min(k, nu - 1), b, y, x0, cw);
+      const long pix0 = ((long)b * H + y) * W + x0;
+      unsigned short* sb = s_b + buf * (3 * FB_CW * C32);
+      const int p = 32 * h + pe;
+      const bool ok = p < cw && k < nu;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      float gp0 = 0.f, gp1 = 0.f;
+      if (TOP) {
+        gp0 = s.q0 * (1.0f - s.f0 * s.f0);  // tanh' (evf_pred_bwd)
+        gp1 = s.q1 * (1.0f - s.f1 * s.f1);
+      }
+      const float4 gz4 = TOP ? make_float4(gp0 * pwa[0] + gp1 * pwb[0], gp0 * pwa[1] + gp1 * pwb[1], gp0 * pwa[2] + gp1 * pwb[2],
+                                           gp0 * pwa[3] + gp1 * pwb[3])
+                             : (has_gz ? s.gz : z4);
+      float4 gzb4 = z4;
+      if (!TOP) gzb4 = has_gz2 ? s.gz2 : z4;
+      const float4 gv4 = has_gv ? s.gv : z4, vp4 = has_vp ? s.vp : z4;
+      if (TOP && ok) {
+        const uint32_t zo = s.zo >> (4 * cg);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool on = (zo >> c) & 1u;
+          dwa[c] += on ? gp0 : 0.f;
+          dwb[c] += on ? gp1 : 0.f;
+        }
+        if (cg == 0) dba += gp0, dbb += gp1;
+      }
+      const float vo[4] = {s.vo.x, s.vo.y, s.vo.z, s.vo.w};
+      const float gz[4] = {!TOP ? gz4.x + gzb4.x : gz4.x, !TOP ? gz4.y + gzb4.y : gz4.y, !TOP ? gz4.z + gzb4.z : gz4.z,
+                           !TOP ? gz4.w + gzb4.w : gz4.w};
+      const float gvo[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, vp[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
+      const uint32_t zw = (has_zw ? s.zw : 0u) >> (4 * cg);
+      float gc[4], gp[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {  // autograd of spiking_submodules.py:103-126 / :523-551 (hard reset, arctan surrogate)
+        const float z = (float)((zw >> c) & 1u);
+        const float sg = fb_surrogate(EVF_ARCTAN, vo[c] - th[c], width);
+        const float gsp = gz[c] * sg;
+        const float gv = gvo[c] + gsp;
+        gc[c] = gv * oml[c];
+        gp[c] = gv * lam[c] * (1.0f - z);
+        const float cur = (vo[c] - (vp[c] * lam[c]) * (1.0f - z)) * inv_oml[c];
+        const float dlam = vp[c] * (1.0f - z) - cur;
+        if (ok) {
+          sl[c] += gv * dlam;
+          st[c] -= gsp;
+        }
+      }
+      const long eo = pix0 * 8 + 256 * h + et;  // = (pix0 + p) * 8 + cg
+      if (ok) {
+        if (g_cur) g_cur[eo] = make_float4(gc[0], gc[1], gc[2], gc[3]);
+        g_v_prev[eo] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+      }
+      // exact split g = hi + mid + lo in B-operand order: pixel p = 16*kq + 8*kgp + ee, element ((kq*2 + kgp)*32 + j)*8 + ee
+      uint32_t tp[3][2];
+      const int base = ((p >> 3) * C32) * 8 + (p & 7);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        evf_split3_pair(ok ? gc[2 * e] : 0.f, ok ? gc[2 * e + 1] : 0.f, tp[0][e], tp[1][e], tp[2][e]);
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) {
+          const int o = t3 * FB_CW * C32 + base + (4 * cg + 2 * e) * 8;
+          sb[o] = (unsigned short)tp[t3][e];
+          sb[o + 8] = (unsigned short)(tp[t3][e] >> 16);
+        }
+      }
+      if (ok && g_split) {
+        const long ps = (long)B * H * W * 8;
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) g_split[t3 * ps + eo] = make_uint2(tp[t3][0], tp[t3][1]);
+      }
+      const int widx = et + 256 * h;
+      if (widx < 3 * C32 * FB_NW) {
+        s_px[buf * (3 * C32 * FB_NW) + widx] = s.px & s.pin;
+        if (REC) s_pz[buf * (3 * C32 * FB_NW) + widx] = s.pz & s.pin;
+      }
+    };
+    // half units j = 2k + h through four register stages (stage j % 4): the loads of j + 4 go out as soon as commit(j) has
+    // consumed the stage -- four half units (two units) of loads in flight, like fb_body's two units
+    FbStage s0, s1, s2, s3;
+    issue(0, 0, s0);
+    issue(0, 1, s1);
+    issue(1, 0, s2);
+    issue(1, 1, s3);
+    commit(0, 0, s0, 0);
+    issue(2, 0, s0);
+    commit(0, 1, s1, 0);
+    issue(2, 1, s1);
+    FBW_STAMP();
+    __syncthreads();  // unit 0 staged
+    FBW_STAMP();
+#pragma unroll 1
+    for (int k = 0; k < nu; k += 2) {
+      commit(k + 1, 0, s2, 1);
+      issue(k + 3, 0, s2);
+      commit(k + 1, 1, s3, 1);
+      issue(k + 3, 1, s3);
+      FBW_STAMP();
+      __syncthreads();  // unit k + 1 staged in buffer 1; team M is done with buffer 0 (unit k)
+      FBW_STAMP();
+      commit(k + 2, 0, s0, 0);
+      issue(k + 4, 0, s0);
+      commit(k + 2, 1, s1, 0);
+      issue(k + 4, 1, s1);
+      FBW_STAMP();
+      __syncthreads();
+      FBW_STAMP();
+    }
+  } else {
+    // previous partial sums of this wave's two feed-forward slab tiles (consumed in the epilogue)
+    float old0[16], old1[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      old0[q] = slab_ff[slab_off0 + fb_row(q, lane) * C32];
+      old1[q] = slab_ff[slab_off1 + fb_row(q, lane) * C32];
+    }
+    const int dy0 = t0 / 3, dx0 = t0 % 3, dy1 = t1 / 3, dx1 = t1 % 3;
+    auto mfma_unit = [&](const int buf) {
+      const uint4* sbh = (const uint4*)(s_b + buf * (3 * FB_CW * C32));
+      const uint32_t* px = s_px + buf * (3 * C32 * FB_NW);
+      const uint32_t* pz = s_pz + buf * (3 * C32 * FB_NW);
+      auto afrag = [&](const uint32_t* planes, int ddy, int ddx, int kq) -> bf16x8 {
+        const int q = 32 + 16 * kq + 8 * kg + ddx - 1;  // bit offset of the first of the 8 pixels
+        const uint32_t* wr = planes + (ddy * C32 + i) * FB_NW + (q >> 5);
+        const uint32_t byte = __funnelshift_r(wr[0], wr[1], q & 31) & 0xFFu;
+        const uint4 a = s_lut[byte];
+        return *(const bf16x8*)&a;
+      };
+      auto mma3 = [&](f32x16& c, const bf16x8& a, const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, c, 0, 0, 0);
+      };
+#pragma unroll
+      for (int kq = 0; kq < FB_CW / 16; ++kq) {
+        const int fo = (kq * 2 + kg) * C32 + i;  // uint4 index of this lane's 8 pixels of channel i (= co)
+        const uint4 uh = sbh[fo], um = sbh[FB_CW * C32 / 8 + fo], ul = sbh[2 * FB_CW * C32 / 8 + fo];
+        const bf16x8 bh = *(const bf16x8*)&uh, bm = *(const bf16x8*)&um, bl = *(const bf16x8*)&ul;
+        mma3(acc0, afrag(px, dy0, dx0, kq), bh, bm, bl);
+        mma3(acc1, afrag(px, dy1, dx1, kq), bh, bm, bl);
+        if (REC) {
+          mma3(accz0, afrag(pz, dy0, dx0, kq), bh, bm, bl);
+          mma3(accz1, afrag(pz, dy1, dx1, kq), bh, bm, bl);
+        }
+      }
+      {  // the ninth tap (2, 2): this wave's K step of the unit (no branch: the step is a run-time index)
+        const int fo = (mw * 2 + kg) * C32 + i;
+        const uint4 uh = sbh[fo], um = sbh[FB_CW * C32 / 8 + fo], ul = sbh[2 * FB_CW * C32 / 8 + fo];
+        const bf16x8 bh = *(const bf16x8*)&uh, bm = *(const bf16x8*)&um, bl = *(const bf16x8*)&ul;
+        mma3(acc8, afrag(px, 2, 2, mw), bh, bm, bl);
+        if (REC) mma3(accz8, afrag(pz, 2, 2, mw), bh, bm, bl);
+      }
+    };
+    FBW_STAMP();
+    __syncthreads();  // unit 0 staged
+    FBW_STAMP();
+#pragma unroll 1
+    for (int k = 0; k < nu; k += 2) {
+      mfma_unit(0);
+      FBW_STAMP();
+      __syncthreads();
+      FBW_STAMP();
+      mfma_unit(1);
+      FBW_STAMP();
+      __syncthreads();
+      FBW_STAMP();
+    }
+    // ---- this wave's slab tiles (taps t0, t1)
+    float oldz0[REC ? 16 : 1], oldz1[REC ? 16 : 1];
+    if (REC) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        oldz0[q] = slab_rec[slab_off0 + fb_row(q, lane) * C32];
+        oldz1[q] = slab_rec[slab_off1 + fb_row(q, lane) * C32];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      slab_ff[slab_off0 + fb_row(q, lane) * C32] = ((accumulate & 1) ? old0[q] : 0.f) + acc0[q];
+      slab_ff[slab_off1 + fb_row(q, lane) * C32] = ((accumulate & 1) ? old1[q] : 0.f) + acc1[q];
+    }
+    if (REC) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        slab_rec[slab_off0 + fb_row(q, lane) * C32] = ((accumulate & 1) ? oldz0[q] : 0.f) + accz0[q];
+        slab_rec[slab_off1 + fb_row(q, lane) * C32] = ((accumulate & 1) ? oldz1[q] : 0.f) + accz1[q];
+      }
+    }
+  }
+
+  // ---- tap 8: the four partial tiles of team M through LDS (aliases the operand buffers: both teams are past the loop's
+  // last barrier), summed and written by all 512 threads
+  float* s_t8 = (float*)smem_raw;  // [4][1024]
+  auto reduce_t8 = [&](const f32x16& a, float* slab, const float (&prev)[2]) {
+    if (!team_e) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) s_t8[mw * (C32 * C32) + fb_row(q, lane) * C32 + i] = a[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // C32*C32 = 2 * FB_THREADS
+      const int e = tid + h * FB_THREADS;
+      const float v = (s_t8[e] + s_t8[C32 * C32 + e]) + (s_t8[2 * C32 * C32 + e] + s_t8[3 * C32 * C32 + e]);
+      slab[(long)bid * (9 * C32 * C32) + 8 * (C32 * C32) + e] = ((accumulate & 1) ? prev[h] : 0.f) + v;
+    }
+    __syncthreads();
+  };
+  reduce_t8(acc8, slab_ff, prev8);
+  if (REC) reduce_t8(accz8, slab_rec, prev8z);
+
+  // ---- first touch of the slabs by a launch with fewer blocks than slab rows: the other rows start at zero (see fb_body)
+  if (!(accumulate & 1) && nblk < nrows_total) {
+    for (int r = nblk + bid; r < nrows_total; r += nblk) {
+      float4* z0 = (float4*)(slab_ff + (long)r * (9 * C32 * C32));
+      float4* z1 = REC ? (float4*)(slab_rec + (long)r * (9 * C32 * C32)) : nullptr;
+      for (int e = tid; e < 9 * C32 * C32 / 4; e += FB_THREADS) {
+        z0[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (REC) z1[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+
+  // ---- per-channel sums for leak / thresh (team E: lanes with equal (lane & 7) share channels)
+  if (team_e) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        sl[c] += __shfl_xor(sl[c], o, 64);
+        st[c] += __shfl_xor(st[c], o, 64);
+      }
+    if (lane < 8) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        s_red[(0 * 8 + wv) * C32 + 4 * lane + c] = sl[c];
+        s_red[(1 * 8 + wv) * C32 + 4 * lane + c] = st[c];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int which = tid >> 5, c = tid & 31;
+    float v = 0.f;
+    for (int w = 0; w < 4; ++w) v += s_red[(which * 8 + w) * C32 + c];
+    if (which == 0) {
+      const float l = fb_sigmoid(leak[c]), t = v * l * (1.0f - l);
+      if (row_ld) g_leak[row_off + c] = row_prev + t;
+      else evf_atomic_add(g_leak + c, t);
+    } else if (thresh[c] > 0.01f) {
+      if (row_ld) g_thresh[row_off + c] = row_prev + v;
+      else evf_atomic_add(g_thresh + c, v);
+    }
+  }
+  if (TOP) {  // prediction-head weight / bias gradients, reduced the same way
+    __syncthreads();
+    if (team_e) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+          dwa[c] += __shfl_xor(dwa[c], o, 64);
+          dwb[c] += __shfl_xor(dwb[c], o, 64);
+        }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        dba += __shfl_xor(dba, o, 64);
+        dbb += __shfl_xor(dbb, o, 64);
+      }
+      if (lane < 8) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          s_red[(0 * 8 + wv) * C32 + 4 * lane + c] = dwa[c];
+          s_red[(1 * 8 + wv) * C32 + 4 * lane + c] = dwb[c];
+        }
+      }
+    }
+    float* s_b2 = (float*)smem_raw;  // operand buffers are free now
+    if (team_e && lane == 0) s_b2[2 * wv] = dba, s_b2[2 * wv + 1] = dbb;
+    __syncthreads();
+    if (tid < 64) {
+      const int which = tid >> 5, c = tid & 31;
+      float v = 0.f;
+      for (int w = 0; w < 4; ++w) v += s_red[(which * 8 + w) * C32 + c];
+      if (row_ld) top.dw[row_off + which * C32 + c] = top_prev + v;
+      else evf_atomic_add(top.dw + which * C32 + c, v);
+    } else if (tid < 66) {
+      float v = 0.f;
+      for (int w = 0; w < 4; ++w) v += s_b2[2 * w + (tid - 64)];
+      if (row_ld) top.db[row_off + (tid - 64)] = top_prev + v;
+      else evf_atomic_add(top.db + (tid - 64), v);
+    }
+  }
+  FBW_STAMP();
+}
+
 template <bool REC, bool TOP, bool FAST>
 __global__ __launch_bounds__(FB_THREADS) void k_lif_bwd_wgrad(
     const float4* __restrict__ g_z_out, const float4* __restrict__ g_z_out2, const float4* __restrict__ g_v_out,
@@ -590,6 +1031,24 @@ __global__ __launch_bounds__(FB_THREADS) void k_bwd_diag(FbJobs jobs, int B, int
     fb_body<false, false, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
                                 nchunk, nunits, 1, EVF_ARCTAN, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak,
                                 J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld);
+}
+
+__global__ __launch_bounds__(FB_THREADS) void k_bwd_diag_ws(FbJobs jobs, int B, int H, int W, int nchunk, long nunits, int row_ld,
+                                                            int nblk, int nrows_total) {
+  const int jb = blockIdx.x / nblk, bid = blockIdx.x - jb * nblk;
+  const FbJob& J = jobs.j[jb];
+  if (J.kind == 1)
+    fb_body_ws<true, false>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W, nchunk,
+                            nunits, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak, J.g_thresh, J.slab_ff,
+                            J.slab_rec, J.top, row_ld);
+  else if (J.kind == 2)
+    fb_body_ws<false, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W, nchunk,
+                            nunits, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak, J.g_thresh, J.slab_ff,
+                            J.slab_rec, J.top, row_ld);
+  else
+    fb_body_ws<false, false>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W, nchunk,
+                             nunits, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak, J.g_thresh, J.slab_ff,
+                             J.slab_rec, J.top, row_ld);
 }
 
 static long fb_units(int B, int H, int W) { return (long)B * H * ((W + FB_CW - 1) / FB_CW); }
@@ -710,22 +1169,39 @@ static int fb_blocks_per_cell(long nunits, int n) {
   return best_nb;
 }
 
+static int fb_diag_select = -1;  // -1 environment / default, 0 k_bwd_diag, 1 k_bwd_diag_ws
+extern "C" int evf_bwd_diag_select(int which) {
+  if (which < -1 || which > 1) return EVF_EINVAL;
+  fb_diag_select = which;
+  return EVF_OK;
+}
+
 static int fb_defer_launch(FbDefer& fb_defer, int d, void* stream) {
   const int n = fb_defer.n[d];
   if (!n) return EVF_OK;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)k_bwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    (void)hipFuncSetAttribute((const void*)k_bwd_diag_ws, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
     attr_set = true;
   }
+  static const bool teams_env = []() {  // EVF_BWD_DIAG=fused: every wave through all phases (k_bwd_diag); default: two wave teams
+    const char* e = getenv("EVF_BWD_DIAG");
+    return !(e && e[0] == 'f');
+  }();
+  const bool teams = fb_diag_select < 0 ? teams_env : fb_diag_select == 1;
   FbJobs jobs;
   for (int k = 0; k < FB_MAX_JOBS; ++k) jobs.j[k] = fb_defer.job[d][k < n ? k : 0];
   const long nunits = fb_units(fb_defer.B, fb_defer.H, fb_defer.W);
   const int nrows = evf_cdiv(nunits, FB_UNITS), nchunk = (fb_defer.W + FB_CW - 1) / FB_CW;
   const int nblk = fb_blocks_per_cell(nunits, n);
   evf_prof_mark(1, 0, stream);
-  hipLaunchKernelGGL(k_bwd_diag, dim3(nblk * n), dim3(FB_THREADS), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
-                     fb_defer.W, nchunk, nunits, fb_defer.row_ld, nblk, nrows);
+  if (teams)
+    hipLaunchKernelGGL(k_bwd_diag_ws, dim3(nblk * n), dim3(FB_THREADS), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
+                       fb_defer.W, nchunk, nunits, fb_defer.row_ld, nblk, nrows);
+  else
+    hipLaunchKernelGGL(k_bwd_diag, dim3(nblk * n), dim3(FB_THREADS), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
+                       fb_defer.W, nchunk, nunits, fb_defer.row_ld, nblk, nrows);
   evf_prof_mark(1, 1, stream);
   fb_defer.n[d] = 0;
   return evf_status();

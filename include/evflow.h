@@ -321,6 +321,12 @@ int evf_conv_dgrad_select(int which);
  * -1 default (environment EVF_DGRAD_DIAG=lds|ws, else 1), 0 k_dgrad_diag (the LDS kernel's body, one block per tile pair),
  * 1 k_dgrad_diag_ws (persistent producer / consumer blocks over the flat list of products).  Process-wide. */
 int evf_dgrad_diag_select(int which);
+/* Which kernel launches the RECORDED fused-backward cells of a backward index: -1 default (environment
+ * EVF_BWD_DIAG=fused|teams, else 1), 0 k_bwd_diag (every wave through load / neuron backward / staging / matrix phase, the
+ * body of the one-cell launch), 1 k_bwd_diag_ws (four waves stream and stage, four contract: vector and matrix pipes of a
+ * SIMD busy at the same time).  Same state gradients bit for bit; the weight-gradient slabs and per-channel sums agree to
+ * fp32 round-off (other partial-sum grouping).  Process-wide. */
+int evf_bwd_diag_select(int which);
 /* ... and for a recurrent cell both input gradients in one launch: g_x (+)= conv^T(g_cur, W_ff) as above,
  * g_x2 = conv^T(g_cur, W_rec) (written) -- dL/d(previous output spikes), models/spiking_submodules.py:530. */
 int evf_conv_dgrad_b3_f32_pair(const float* g_cur, const void* wT_b3, float* g_x, int accumulate,

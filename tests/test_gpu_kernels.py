@@ -302,3 +302,78 @@ def test_head_layer_of_a_window_in_one_launch_is_bit_identical_backward(shape, s
     assert float(ref[1].abs().max()) > 0 and float(ref[2].abs().max()) > 0
     for name, a, b in zip(("g_v", "slab", "rows"), ref, got):
         assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("shape", SHAPES + [(3, 20, 96), (4, 64, 160)])
+def test_recorded_fused_backward_cells_match_the_one_cell_launches(shape):
+    """The fused-backward cells of a backward index, recorded and launched together -- through k_bwd_diag (the one-cell kernel's
+    body) and through k_bwd_diag_ws (four waves stream the tensors, do the neuron backward and stage the operands, four
+    contract them) -- against one evf_lif_bwd_wgrad2 / _top launch per cell: dL/d(current) (fp32 and its three split planes)
+    and dL/dv bit for bit; weight-gradient slabs (summed over their rows) and per-channel sums to fp32 round-off.  All three
+    cell kinds in one index (feed-forward, recurrent with the second gradient part, under the prediction head), ragged shapes
+    (partial units, a unit count that is odd per block), first touch and accumulation."""
+    B, H, W = shape
+    torch.manual_seed(17)
+    L = _lib.load()
+    nsl = L.evf_lif_bwd_wgrad_slabs(B, H, W)
+    nW = (W + 31) // 32
+    row_ld = 160
+
+    def cell(kind):
+        c = {"kind": kind, "gv": _f(B, H, W, C, scale=0.1), "vo": _f(B, H, W, C, scale=0.6), "vp": _f(B, H, W, C, scale=0.6),
+             "zp": _bits(B, H, W), "xT": _planes(_bits(B, H, W)), "leak": _f(32, scale=0.3), "thresh": _f(32, scale=0.1) + 0.4}
+        if kind == "top":
+            c.update(flow=torch.tanh(_f(B, 2, H, W)), g_flow=_f(B, 2, H, W), pw=_f(2, 32, scale=0.05), zo=_bits(B, H, W, rate=0.4))
+        else:
+            c.update(gz=_f(B, H, W, C, scale=0.2), gz2=_f(B, H, W, C, scale=0.2) if kind == "rec" else None)
+        if kind == "rec":
+            c["zT"] = _planes(c["zp"])
+        return c
+
+    cells = [cell(k) for k in ("ff", "rec", "top", "rec", "ff")]
+
+    def run(mode):  # None: one launch per cell; 0 / 1: recorded, k_bwd_diag / k_bwd_diag_ws
+        outs = []
+        for acc in (0, 1):  # first touch of the slabs, then accumulation (same inputs again)
+            if mode is not None:
+                assert L.evf_bwd_diag_select(mode) == 0 and _lib.raw("evf_bwd_defer_begin") == 0 and _lib.raw("evf_bwd_defer_slot", 4) == 0
+            try:
+                for n, c in enumerate(cells):
+                    if acc == 0:
+                        c["out"] = {"gcur": torch.full((B, H, W, C), 3.0, device=DEV), "gsp": torch.zeros(3, B, H, W, C, dtype=torch.bfloat16, device=DEV),
+                                    "gvp": torch.full((B, H, W, C), 3.0, device=DEV), "rows": torch.zeros(nsl, row_ld, device=DEV),
+                                    "sff": torch.full((nsl, 9216), 5.0, device=DEV), "srec": torch.full((nsl, 9216), 5.0, device=DEV)}
+                    o = c["out"]
+                    flag = acc | (row_ld << 8)
+                    if c["kind"] == "top":
+                        _lib.call("evf_lif_bwd_wgrad_top", P(c["flow"]), P(c["g_flow"]), P(c["pw"]), P(c["zo"]), P(o["rows"][:, 64:]),
+                                  P(o["rows"][:, 128:]), P(c["gv"]), P(c["vo"]), P(c["vp"]), P(c["zp"]), P(c["xT"]), P(c["leak"]), P(c["thresh"]),
+                                  B, H, W, 1, 0, 10.0, P(o["gcur"]), P(o["gsp"]), P(o["gvp"]), P(o["rows"][:, :32]), P(o["rows"][:, 32:]),
+                                  P(o["sff"]), flag)
+                    else:
+                        rec = c["kind"] == "rec"
+                        _lib.call("evf_lif_bwd_wgrad2", P(c["gz"]), P(c["gz2"]), P(c["gv"]), P(c["vo"]), P(c["vp"]), P(c["zp"]), P(c["xT"]),
+                                  P(c["zT"]) if rec else None, P(c["leak"]), P(c["thresh"]), B, H, W, 1, 0, 10.0, P(o["gcur"]), P(o["gsp"]),
+                                  P(o["gvp"]), P(o["rows"][:, :32]), P(o["rows"][:, 32:]), P(o["sff"]), P(o["srec"]) if rec else None, flag)
+                if mode is not None:
+                    assert _lib.raw("evf_bwd_defer_pending") == len(cells)
+            finally:
+                if mode is not None:
+                    _lib.call("evf_bwd_defer_flush")
+                    L.evf_bwd_diag_select(-1)
+        torch.cuda.synchronize()
+        for c in cells:
+            o = c.pop("out")
+            outs.append((o["gcur"], o["gsp"], o["gvp"], o["rows"].sum(0), o["sff"].sum(0), o["srec"].sum(0) if c["kind"] == "rec" else None))
+        return outs
+
+    ref = run(None)
+    for mode in (0, 1):
+        got = run(mode)
+        for n, (a, b) in enumerate(zip(ref, got)):
+            for name, x, y in zip(("g_cur", "split", "g_v_prev"), a[:3], b[:3]):
+                assert torch.equal(x, y), (mode, n, name)
+            for name, x, y in zip(("rows", "slab_ff", "slab_rec"), a[3:], b[3:]):
+                if x is not None:
+                    assert float(x.abs().max()) > 0 and _rel(y, x) < 2e-5, (mode, n, name, _rel(y, x))
+    assert L.evf_bwd_diag_select(2) != 0
