@@ -546,7 +546,10 @@ __device__ __forceinline__ void fb_body(
 // unit (32 pixels), four half units of loads in flight.  Default neuron only (arctan surrogate, hard reset).
 // Same products in the same order per tap as fb_body; the ninth tap's partial tiles are grouped differently (4 instead of
 // 8) and the per-channel sums run over other thread subsets: equal to fp32 round-off, not bit for bit.
-template <bool REC, bool TOP>
+// EW = waves of team E: 4 (a 512-thread block, one wave of each team per SIMD; a thread takes a float4 per HALF unit, four
+// half units of loads in flight) or 8 (a 768-thread block: two E waves per SIMD hide each other's dependent chains -- with
+// one, team E needed 4.4 k cycles per unit against team M's 3.6 k (phase stamps); a thread takes a float4 per unit).
+template <bool REC, bool TOP, int EW>
 __device__ __forceinline__ void fb_body_ws(
     const int bid, const int nblk_, const float4* __restrict__ g_z_out, const float4* __restrict__ g_z_out2,
     const float4* __restrict__ g_v_out, const float4* __restrict__ v_out, const float4* __restrict__ v_prev,
@@ -562,23 +565,25 @@ __device__ __forceinline__ void fb_body_ws(
   uint4* s_lut = (uint4*)(s_pz + 2 * 3 * C32 * FB_NW);        // [256]
   float* s_red = (float*)(s_lut + 256);                       // [2][8][32]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const bool team_e = wv < 4;
+  constexpr int NTHR = 64 * (EW + 4);  // threads of the block
+  constexpr int ETHR = 64 * EW;        // ... of team E
+  const bool team_e = wv < EW;
   int nst = 0;
   (void)nst;
 #ifdef FB_STAMPS  // (team E: wave 0, team M: wave 4; before and after every barrier of the unit loop)
 #define FBW_STAMP()                                                                                  \
   do {                                                                                               \
-    if (blockIdx.x < 16 && lane == 0 && (wv == 0 || wv == 4) && nst < 96)                            \
+    if (blockIdx.x < 16 && lane == 0 && (wv == 0 || wv == EW) && nst < 96)                           \
       fb_stamps[(blockIdx.x * 2 + (wv ? 1 : 0)) * 96 + nst++] = __builtin_readcyclecounter();       \
   } while (0)
 #else
 #define FBW_STAMP() do {} while (0)
 #endif
   const int i = lane & 31, kg = lane >> 5;
-  const int et = tid & 255;  // thread within its team
-  const int cg = et & 7;     // team E: channel group (channels 4cg..4cg+3) ...
-  const int pe = et >> 3;    // ... and pixel within the half unit
-  const int mw = wv & 3;     // team M: wave within the team
+  const int et = tid & (ETHR - 1);  // team E: thread within the team
+  const int cg = et & 7;            // ... channel group (channels 4cg..4cg+3) ...
+  const int pe = et >> 3;           // ... and pixel within the (half) unit
+  const int mw = (wv - EW) & 3;     // team M: wave within the team
   const int nW = (W + 31) / 32;
   if (tid < 256) {
     const uint32_t t = tid;
@@ -588,7 +593,7 @@ __device__ __forceinline__ void fb_body_ws(
   const int nblk = nblk_;
   const int nu = (int)((nunits - (long)bid + nblk - 1) / nblk);
   static_assert(FB_UNITS_MAX <= 64, "geometry table: one lane per unit of the block");
-  static_assert(FB_NW == 4 && FB_CW == 64, "team E: half units of 32 pixels, 384 plane words per unit");
+  static_assert(FB_NW == 4 && FB_CW == 64 && (EW == 4 || EW == 8), "team E: (half) units of 8 EW pixels, 384 plane words per unit");
   int g_b, g_y, g_x0;
   {
     const int u = bid + min(lane, nu - 1) * nblk;
@@ -605,18 +610,14 @@ __device__ __forceinline__ void fb_body_ws(
   };
   // operands of the epilogue, requested now (see fb_body): the ninth tap's previous partial sums (all threads), the
   // block's row of per-channel sums (threads < 66 of team E)
-  float prev8[2], prev8z[2] = {0.f, 0.f};
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const long o8 = (long)bid * (9 * C32 * C32) + 8 * (C32 * C32) + tid + h * FB_THREADS;
-    prev8[h] = slab_ff[o8];
-    if (REC) prev8z[h] = slab_rec[o8];
-  }
+  // (the slab tiles' previous partial sums: the accumulators START from them, see team M)
+  float row_prev, top_prev = 0.f;
   const size_t row_off = (size_t)bid * row_ld;
-  const int row_c = tid & 31, row_which = (tid >> 5) & 1;
-  const float row_prev = (row_which ? g_thresh : g_leak)[row_off + row_c];  // (read by threads < 64)
-  float top_prev = 0.f;
-  if (TOP) top_prev = tid < 64 ? top.dw[row_off + row_which * C32 + row_c] : top.db[row_off + (tid & 1)];  // (threads < 66)
+  {
+    const int row_c = tid & 31, row_which = (tid >> 5) & 1;
+    row_prev = (row_which ? g_thresh : g_leak)[row_off + row_c];  // (read by threads < 64)
+    if (TOP) top_prev = tid < 64 ? top.dw[row_off + row_which * C32 + row_c] : top.db[row_off + (tid & 1)];  // (threads < 66)
+  }
 
   // team E state
   float sl[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
@@ -653,7 +654,7 @@ __device__ __forceinline__ void fb_body_ws(
       int b, y, x0, cw;
       geom(min(k, nu - 1), b, y, x0, cw);
       const long pix0 = ((long)b * H + y) * W + x0;
-      const int pc = min(32 * h + pe, cw - 1);
+      const int pc = min(8 * EW * h + pe, cw - 1);
       const long ge = (pix0 + pc) * 8 + cg;
       s.vo = v_out[ge];
       if (TOP) {
@@ -668,8 +669,8 @@ __device__ __forceinline__ void fb_body_ws(
       s.gv = pgv[ge];
       s.vp = pvp[ge];
       s.zw = pzw[z_prev ? pix0 + pc : 0];
-      // this half's share of the unit's 384 plane words (3 rows x 32 channels x 4 words): 256 + 128
-      const int tpl = min(et + 256 * h, 3 * C32 * FB_NW - 1);
+      // this (half) unit's share of the unit's 384 plane words (3 rows x 32 channels x 4 words): EW = 4: 256 + 128
+      const int tpl = min(et + ETHR * h, 3 * C32 * FB_NW - 1);
       const int pl_wq = tpl % FB_NW, pl_c = (tpl / FB_NW) % C32, pl_dy = tpl / (FB_NW * C32);
       const int yy = y + pl_dy - 1, xw = x0 / 32 - 1 + pl_wq;
       const bool in = yy >= 0 && yy < H && xw >= 0 && xw < nW;
@@ -684,7 +685,7 @@ __device__ __forceinline__ void fb_body_ws(
       geom(min(k, nu - 1), b, y, x0, cw);
       const long pix0 = ((long)b * H + y) * W + x0;
       unsigned short* sb = s_b + buf * (3 * FB_CW * C32);
-      const int p = 32 * h + pe;
+      const int p = 8 * EW * h + pe;
       const bool ok = p < cw && k < nu;
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       float gp0 = 0.f, gp1 = 0.f;
@@ -729,22 +730,34 @@ __device__ __forceinline__ void fb_body_ws(
           st[c] -= gsp;
         }
       }
-      const long eo = pix0 * 8 + 256 * h + et;  // = (pix0 + p) * 8 + cg
+      const long eo = pix0 * 8 + ETHR * h + et;  // = (pix0 + p) * 8 + cg
       if (ok) {
         if (g_cur) g_cur[eo] = make_float4(gc[0], gc[1], gc[2], gc[3]);
         g_v_prev[eo] = make_float4(gp[0], gp[1], gp[2], gp[3]);
       }
-      // exact split g = hi + mid + lo in B-operand order: pixel p = 16*kq + 8*kgp + ee, element ((kq*2 + kgp)*32 + j)*8 + ee
+      // exact split g = hi + mid + lo in B-operand order: 16-byte chunk (pixel group G = p >> 3, channel j) = the 8 pixels of
+      // the group, chunk index G * 32 + (j ^ (j >> 4)).  A lane holds 4 channels of ONE pixel; as 12 two-byte stores a wave
+      // instruction hit 16 distinct words four times over (two lanes per word, channels j and j + 16 on one bank): half of the
+      // LDS cycles of the kernel were bank conflicts (PMC), and team M's reads queued behind them.  Instead the lanes of a
+      // pixel pair (lane ^ 8) swap half of their channels: the even pixel's lane ends up with channels 4cg, 4cg+1 of both
+      // pixels, the odd one's with 4cg+2, 4cg+3 -- 6 four-byte stores per lane, and with the swap of the channel halves
+      // 0-15 / 16-31 in the chunk index (j ^ (j >> 4)) the 64 lanes of a store hit 64 different banks.
       uint32_t tp[3][2];
-      const int base = ((p >> 3) * C32) * 8 + (p & 7);
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        evf_split3_pair(ok ? gc[2 * e] : 0.f, ok ? gc[2 * e + 1] : 0.f, tp[0][e], tp[1][e], tp[2][e]);
+      for (int e = 0; e < 2; ++e) evf_split3_pair(ok ? gc[2 * e] : 0.f, ok ? gc[2 * e + 1] : 0.f, tp[0][e], tp[1][e], tp[2][e]);
+      {
+        uint32_t* sbw = (uint32_t*)sb;
+        const bool odd = (p & 1) != 0;
+        const int j0 = 4 * cg + (odd ? 2 : 0);  // first of the two channels this lane stores (for pixels p & ~1, p | 1)
+        const int d0 = ((p >> 3) * C32 + (j0 ^ (j0 >> 4))) * 4 + ((p & 7) >> 1);
+        const int d1 = ((p >> 3) * C32 + ((j0 + 1) ^ (j0 >> 4))) * 4 + ((p & 7) >> 1);
 #pragma unroll
         for (int t3 = 0; t3 < 3; ++t3) {
-          const int o = t3 * FB_CW * C32 + base + (4 * cg + 2 * e) * 8;
-          sb[o] = (unsigned short)tp[t3][e];
-          sb[o + 8] = (unsigned short)(tp[t3][e] >> 16);
+          const uint32_t send = odd ? tp[t3][0] : tp[t3][1];
+          const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0x128, 0xF, 0xF, true);  // row_ror:8 = lane ^ 8
+          const uint32_t ev = odd ? recv : tp[t3][0], od = odd ? tp[t3][1] : recv;  // the even / the odd pixel's channel pair
+          sbw[t3 * (FB_CW * C32 / 2) + d0] = __builtin_amdgcn_perm(od, ev, 0x05040100u);  // channel j0:     [even px | odd px]
+          sbw[t3 * (FB_CW * C32 / 2) + d1] = __builtin_amdgcn_perm(od, ev, 0x07060302u);  // channel j0 + 1
         }
       }
       if (ok && g_split) {
@@ -752,61 +765,118 @@ __device__ __forceinline__ void fb_body_ws(
 #pragma unroll
         for (int t3 = 0; t3 < 3; ++t3) g_split[t3 * ps + eo] = make_uint2(tp[t3][0], tp[t3][1]);
       }
-      const int widx = et + 256 * h;
+      const int widx = et + ETHR * h;
       if (widx < 3 * C32 * FB_NW) {
         s_px[buf * (3 * C32 * FB_NW) + widx] = s.px & s.pin;
         if (REC) s_pz[buf * (3 * C32 * FB_NW) + widx] = s.pz & s.pin;
       }
     };
-    // half units j = 2k + h through four register stages (stage j % 4): the loads of j + 4 go out as soon as commit(j) has
-    // consumed the stage -- four half units (two units) of loads in flight, like fb_body's two units
-    FbStage s0, s1, s2, s3;
-    issue(0, 0, s0);
-    issue(0, 1, s1);
-    issue(1, 0, s2);
-    issue(1, 1, s3);
-    commit(0, 0, s0, 0);
-    issue(2, 0, s0);
-    commit(0, 1, s1, 0);
-    issue(2, 1, s1);
-    FBW_STAMP();
-    __syncthreads();  // unit 0 staged
-    FBW_STAMP();
+    if constexpr (EW == 4) {
+      // half units j = 2k + h through four register stages (stage j % 4): the loads of j + 4 go out as soon as commit(j) has
+      // consumed the stage -- four half units (two units) of loads in flight, like fb_body's two units
+      FbStage s0, s1, s2, s3;
+      issue(0, 0, s0);
+      issue(0, 1, s1);
+      issue(1, 0, s2);
+      issue(1, 1, s3);
+      commit(0, 0, s0, 0);
+      issue(2, 0, s0);
+      commit(0, 1, s1, 0);
+      issue(2, 1, s1);
+      FBW_STAMP();
+      __syncthreads();  // unit 0 staged
+      FBW_STAMP();
 #pragma unroll 1
-    for (int k = 0; k < nu; k += 2) {
-      commit(k + 1, 0, s2, 1);
-      issue(k + 3, 0, s2);
-      commit(k + 1, 1, s3, 1);
-      issue(k + 3, 1, s3);
+      for (int k = 0; k < nu; k += 2) {
+        commit(k + 1, 0, s2, 1);
+        issue(k + 3, 0, s2);
+        commit(k + 1, 1, s3, 1);
+        issue(k + 3, 1, s3);
+        FBW_STAMP();
+        __syncthreads();  // unit k + 1 staged in buffer 1; team M is done with buffer 0 (unit k)
+        FBW_STAMP();
+        commit(k + 2, 0, s0, 0);
+        issue(k + 4, 0, s0);
+        commit(k + 2, 1, s1, 0);
+        issue(k + 4, 1, s1);
+        FBW_STAMP();
+        __syncthreads();
+        FBW_STAMP();
+      }
+    } else {
+      // whole units through three register stages that swap roles (fb_body's pipeline): two units of loads in flight
+      FbStage s_cur, s_nxt, s_new;
+      issue(0, 0, s_cur);
+      issue(1, 0, s_nxt);
+      commit(0, 0, s_cur, 0);
       FBW_STAMP();
-      __syncthreads();  // unit k + 1 staged in buffer 1; team M is done with buffer 0 (unit k)
+      __syncthreads();  // unit 0 staged
       FBW_STAMP();
-      commit(k + 2, 0, s0, 0);
-      issue(k + 4, 0, s0);
-      commit(k + 2, 1, s1, 0);
-      issue(k + 4, 1, s1);
-      FBW_STAMP();
-      __syncthreads();
-      FBW_STAMP();
+#pragma unroll 1
+      for (int k = 0; k < nu; k += 2) {
+        issue(k + 2, 0, s_new);
+        commit(k + 1, 0, s_nxt, 1);
+        FBW_STAMP();
+        __syncthreads();  // unit k + 1 staged in buffer 1; team M is done with buffer 0 (unit k)
+        FBW_STAMP();
+        issue(k + 3, 0, s_nxt);
+        commit(k + 2, 0, s_new, 0);
+        FBW_STAMP();
+        __syncthreads();
+        FBW_STAMP();
+      }
     }
   } else {
     // previous partial sums of this wave's two feed-forward slab tiles (consumed in the epilogue)
-    float old0[16], old1[16];
+    // The accumulators START from the block's previous partial sums (an accumulating launch): the loads land while team E
+    // stages unit 0, and the epilogue is stores only -- as `previous + sum` it began with an HBM round trip at the end of
+    // every block's life.  (Sum order: ((previous + p1) + p2) + ... instead of previous + (p1 + p2 + ...).)  The ninth tap's
+    // previous tile goes into wave 0's partial.
+    if (accumulate & 1) {
+      const long o8 = (long)bid * (9 * C32 * C32) + 8 * (C32 * C32) + i;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      old0[q] = slab_ff[slab_off0 + fb_row(q, lane) * C32];
-      old1[q] = slab_ff[slab_off1 + fb_row(q, lane) * C32];
+      for (int q = 0; q < 16; ++q) {
+        acc0[q] = slab_ff[slab_off0 + fb_row(q, lane) * C32];
+        acc1[q] = slab_ff[slab_off1 + fb_row(q, lane) * C32];
+        if (mw == 0) acc8[q] = slab_ff[o8 + fb_row(q, lane) * C32];
+        if (REC) {
+          accz0[q] = slab_rec[slab_off0 + fb_row(q, lane) * C32];
+          accz1[q] = slab_rec[slab_off1 + fb_row(q, lane) * C32];
+          if (mw == 0) accz8[q] = slab_rec[o8 + fb_row(q, lane) * C32];
+        }
+      }
     }
     const int dy0 = t0 / 3, dx0 = t0 % 3, dy1 = t1 / 3, dx1 = t1 % 3;
+    const int isw = i ^ (i >> 4);  // chunk of channel i within a pixel group (team E's layout)
+    // One wave per SIMD has nobody to hide its LDS latencies behind: the unit is a hand-ordered pipeline (pinned with
+    // sched_barrier).  (1) The four plane words of a (row, channel) are 16 bytes: one ds_read_b128 per row gives this lane every
+    // 8-pixel byte of the unit for that row (all K steps, all column offsets) -- instead of two ds_read_b32 plus a dependent
+    // table lookup in front of every group of MFMAs.  (2) From them the table addresses of all 18 A fragments of the unit.
+    // (3) Five steps (four K steps, then the ninth tap's K step): the MFMAs of a step run tap by tap -- per accumulator still
+    // hi, mid, lo --, and as soon as a tap's three MFMAs are issued its A registers take the NEXT step's fragment; the B
+    // fragments alternate between two register sets, the next set requested in the middle of the step.
     auto mfma_unit = [&](const int buf) {
       const uint4* sbh = (const uint4*)(s_b + buf * (3 * FB_CW * C32));
       const uint32_t* px = s_px + buf * (3 * C32 * FB_NW);
       const uint32_t* pz = s_pz + buf * (3 * C32 * FB_NW);
-      auto afrag = [&](const uint32_t* planes, int ddy, int ddx, int kq) -> bf16x8 {
-        const int q = 32 + 16 * kq + 8 * kg + ddx - 1;  // bit offset of the first of the 8 pixels
-        const uint32_t* wr = planes + (ddy * C32 + i) * FB_NW + (q >> 5);
-        const uint32_t byte = __funnelshift_r(wr[0], wr[1], q & 31) & 0xFFu;
-        const uint4 a = s_lut[byte];
+      // table address (LUT entry) of the byte at bits q .. q + 7 of a row, q = 32 + 16 kq + 8 kg + ddx - 1
+      auto abits = [&](uint32_t lo, uint32_t hi, int sh) -> uint32_t {  // ((hi:lo) >> sh) & 0xFF as a table address (x 16 bytes)
+        const unsigned long long v = ((unsigned long long)hi << 32) | lo;  // (sh <= 41: the byte lies inside the pair)
+        return ((uint32_t)(v >> sh) & 0xFFu) * 16u;
+      };
+      auto aaddr = [&](const uint4& r, const int ddx, const int kq) -> uint32_t {  // kq: compile-time constant
+        const int a = (31 + 16 * kq) >> 5;  // first word that can hold bit q: 0, 1, 1, 2
+        return abits(a == 0 ? r.x : (a == 1 ? r.y : r.z), a == 0 ? r.y : (a == 1 ? r.z : r.w), 32 + 16 * kq - 32 * a + 8 * kg + ddx - 1);
+      };
+      // the ninth tap's K step is the wave's number: its word pair is picked by ADDRESS (a run-time pick among the registers of
+      // a row became a store to scratch and a dynamic load back)
+      auto aaddr8 = [&](const uint32_t* planes) -> uint32_t {
+        const int a = (31 + 16 * mw) >> 5;
+        const uint32_t* wr = planes + (2 * C32 + i) * FB_NW + a;
+        return abits(wr[0], wr[1], 32 + 16 * mw - 32 * a + 8 * kg + 2 - 1);
+      };
+      auto lut = [&](uint32_t addr) -> bf16x8 {
+        const uint4 a = *(const uint4*)((const char*)s_lut + addr);
         return *(const bf16x8*)&a;
       };
       auto mma3 = [&](f32x16& c, const bf16x8& a, const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {
@@ -814,25 +884,100 @@ __device__ __forceinline__ void fb_body_ws(
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bm, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, c, 0, 0, 0);
       };
+      // (two 12-bit table addresses per register: [tap 1 | tap 0] -- 168 registers per wave with EW = 8)
+      uint32_t adx[4], adz[4] = {0, 0, 0, 0}, ad8;
+      {
+        const uint4 rx0 = *(const uint4*)(px + (dy0 * C32 + i) * FB_NW), rx1 = *(const uint4*)(px + (dy1 * C32 + i) * FB_NW);
+        uint4 rz0 = rx0, rz1 = rx1;
+        if (REC) rz0 = *(const uint4*)(pz + (dy0 * C32 + i) * FB_NW), rz1 = *(const uint4*)(pz + (dy1 * C32 + i) * FB_NW);
+        ad8 = aaddr8(px);
+        if (REC) ad8 |= aaddr8(pz) << 16;
 #pragma unroll
-      for (int kq = 0; kq < FB_CW / 16; ++kq) {
-        const int fo = (kq * 2 + kg) * C32 + i;  // uint4 index of this lane's 8 pixels of channel i (= co)
-        const uint4 uh = sbh[fo], um = sbh[FB_CW * C32 / 8 + fo], ul = sbh[2 * FB_CW * C32 / 8 + fo];
-        const bf16x8 bh = *(const bf16x8*)&uh, bm = *(const bf16x8*)&um, bl = *(const bf16x8*)&ul;
-        mma3(acc0, afrag(px, dy0, dx0, kq), bh, bm, bl);
-        mma3(acc1, afrag(px, dy1, dx1, kq), bh, bm, bl);
-        if (REC) {
-          mma3(accz0, afrag(pz, dy0, dx0, kq), bh, bm, bl);
-          mma3(accz1, afrag(pz, dy1, dx1, kq), bh, bm, bl);
+        for (int kq = 0; kq < 4; ++kq) {
+          adx[kq] = aaddr(rx0, dx0, kq) | aaddr(rx1, dx1, kq) << 16;
+          if (REC) adz[kq] = aaddr(rz0, dx0, kq) | aaddr(rz1, dx1, kq) << 16;
+          // (pinned: left alone the compiler carries the 64-bit shift results -- two registers per address -- to the use)
+          asm volatile("" : "+v"(adx[kq]));
+          if (REC) asm volatile("" : "+v"(adz[kq]));
         }
+        asm volatile("" : "+v"(ad8));
       }
-      {  // the ninth tap (2, 2): this wave's K step of the unit (no branch: the step is a run-time index)
-        const int fo = (mw * 2 + kg) * C32 + i;
+      auto lo16 = [](uint32_t v) { return v & 0xFFFFu; };
+      auto hi16 = [](uint32_t v) { return v >> 16; };
+      auto bload = [&](const int kq, bf16x8& bh, bf16x8& bm, bf16x8& bl) {  // this lane's 8 pixels of channel i (= co), K step kq
+        const int fo = (kq * 2 + kg) * C32 + isw;
         const uint4 uh = sbh[fo], um = sbh[FB_CW * C32 / 8 + fo], ul = sbh[2 * FB_CW * C32 / 8 + fo];
-        const bf16x8 bh = *(const bf16x8*)&uh, bm = *(const bf16x8*)&um, bl = *(const bf16x8*)&ul;
-        mma3(acc8, afrag(px, 2, 2, mw), bh, bm, bl);
-        if (REC) mma3(accz8, afrag(pz, 2, 2, mw), bh, bm, bl);
+        bh = *(const bf16x8*)&uh, bm = *(const bf16x8*)&um, bl = *(const bf16x8*)&ul;
+      };
+      bf16x8 a0 = lut(lo16(adx[0])), a1 = lut(hi16(adx[0])), az0 = a0, az1 = a1;
+      if (REC) az0 = lut(lo16(adz[0])), az1 = lut(hi16(adz[0]));
+      auto bload1 = [&](const int kq, const int term, bf16x8& b) {
+        const uint4 u = sbh[term * (FB_CW * C32 / 8) + (kq * 2 + kg) * C32 + isw];
+        b = *(const bf16x8*)&u;
+      };
+      bf16x8 bAh, bAm, bAl, bBh, bBm, bBl;
+      bload(0, bAh, bAm, bAl);
+      __builtin_amdgcn_sched_barrier(0);
+      // K step kq on the B set (ch, cm, cl); requests the next step's fragments: A into the registers just used; B into the other
+      // set (nh, nm, nl) in the middle of the step (EW = 4: 256 registers per wave), or -- one set only, EW = 8: 168 registers --
+      // term by term behind the step's last three MFMAs
+      auto step = [&](const int kq, bf16x8& ch, bf16x8& cm, bf16x8& cl, bf16x8& nh, bf16x8& nm, bf16x8& nl,
+                      const uint32_t nx, const uint32_t nz) {  // nx / nz: packed table addresses of the next step's fragments
+        constexpr bool TWO = EW == 4;
+        const int nkq = kq < 3 ? kq + 1 : mw;
+        mma3(acc0, a0, ch, cm, cl);
+        a0 = lut(lo16(nx));  // (after the last K step: the ninth tap's fragment)
+        __builtin_amdgcn_sched_barrier(0);
+        if (REC || TWO) {
+          mma3(acc1, a1, ch, cm, cl);
+          if (kq < 3 || REC) a1 = lut(hi16(nx));  // (after the last K step: the ninth tap's recurrent fragment)
+          if (TWO) bload(nkq, nh, nm, nl);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (REC) {
+          mma3(accz0, az0, ch, cm, cl);
+          if (kq < 3) az0 = lut(lo16(nz));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (TWO) {
+          if (REC) {
+            mma3(accz1, az1, ch, cm, cl);
+            if (kq < 3) az1 = lut(hi16(nz));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {  // the step's last tap, its B registers refilled one by one
+          f32x16& c = REC ? accz1 : acc1;
+          const bf16x8& al = REC ? az1 : a1;
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ch, c, 0, 0, 0);
+          bload1(nkq, 0, ch);
+          __builtin_amdgcn_sched_barrier(0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, cm, c, 0, 0, 0);
+          bload1(nkq, 1, cm);
+          __builtin_amdgcn_sched_barrier(0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, cl, c, 0, 0, 0);
+          bload1(nkq, 2, cl);
+          if (REC) {
+            if (kq < 3) az1 = lut(hi16(nz));
+          } else if (kq < 3) {
+            a1 = lut(hi16(nx));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if (EW == 4) {
+        step(0, bAh, bAm, bAl, bBh, bBm, bBl, adx[1], adz[1]);
+        step(1, bBh, bBm, bBl, bAh, bAm, bAl, adx[2], adz[2]);
+        step(2, bAh, bAm, bAl, bBh, bBm, bBl, adx[3], adz[3]);
+        step(3, bBh, bBm, bBl, bAh, bAm, bAl, ad8, 0u);
+      } else {
+        step(0, bAh, bAm, bAl, bAh, bAm, bAl, adx[1], adz[1]);
+        step(1, bAh, bAm, bAl, bAh, bAm, bAl, adx[2], adz[2]);
+        step(2, bAh, bAm, bAl, bAh, bAm, bAl, adx[3], adz[3]);
+        step(3, bAh, bAm, bAl, bAh, bAm, bAl, ad8, 0u);
       }
+      // the ninth tap (2, 2): this wave's K step of the unit (fragments in a0 / a1, B in the first set again)
+      mma3(acc8, a0, bAh, bAm, bAl);
+      if (REC) mma3(accz8, a1, bAh, bAm, bAl);
     };
     FBW_STAMP();
     __syncthreads();  // unit 0 staged
@@ -849,62 +994,27 @@ __device__ __forceinline__ void fb_body_ws(
       FBW_STAMP();
     }
     // ---- this wave's slab tiles (taps t0, t1)
-    float oldz0[REC ? 16 : 1], oldz1[REC ? 16 : 1];
-    if (REC) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        oldz0[q] = slab_rec[slab_off0 + fb_row(q, lane) * C32];
-        oldz1[q] = slab_rec[slab_off1 + fb_row(q, lane) * C32];
-      }
-    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      slab_ff[slab_off0 + fb_row(q, lane) * C32] = ((accumulate & 1) ? old0[q] : 0.f) + acc0[q];
-      slab_ff[slab_off1 + fb_row(q, lane) * C32] = ((accumulate & 1) ? old1[q] : 0.f) + acc1[q];
-    }
-    if (REC) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        slab_rec[slab_off0 + fb_row(q, lane) * C32] = ((accumulate & 1) ? oldz0[q] : 0.f) + accz0[q];
-        slab_rec[slab_off1 + fb_row(q, lane) * C32] = ((accumulate & 1) ? oldz1[q] : 0.f) + accz1[q];
+      slab_ff[slab_off0 + fb_row(q, lane) * C32] = acc0[q];
+      slab_ff[slab_off1 + fb_row(q, lane) * C32] = acc1[q];
+      if (REC) {
+        slab_rec[slab_off0 + fb_row(q, lane) * C32] = accz0[q];
+        slab_rec[slab_off1 + fb_row(q, lane) * C32] = accz1[q];
       }
     }
   }
 
   // ---- tap 8: the four partial tiles of team M through LDS (aliases the operand buffers: both teams are past the loop's
   // last barrier), summed and written by all 512 threads
-  float* s_t8 = (float*)smem_raw;  // [4][1024]
-  auto reduce_t8 = [&](const f32x16& a, float* slab, const float (&prev)[2]) {
-    if (!team_e) {
+  float* s_t8 = (float*)smem_raw;  // [ff, rec][4][1024] (32 KiB = region 0)
+  if (!team_e) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) s_t8[mw * (C32 * C32) + fb_row(q, lane) * C32 + i] = a[q];
+    for (int q = 0; q < 16; ++q) {
+      s_t8[mw * (C32 * C32) + fb_row(q, lane) * C32 + i] = acc8[q];
+      if (REC) s_t8[(4 + mw) * (C32 * C32) + fb_row(q, lane) * C32 + i] = accz8[q];
     }
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {  // C32*C32 = 2 * FB_THREADS
-      const int e = tid + h * FB_THREADS;
-      const float v = (s_t8[e] + s_t8[C32 * C32 + e]) + (s_t8[2 * C32 * C32 + e] + s_t8[3 * C32 * C32 + e]);
-      slab[(long)bid * (9 * C32 * C32) + 8 * (C32 * C32) + e] = ((accumulate & 1) ? prev[h] : 0.f) + v;
-    }
-    __syncthreads();
-  };
-  reduce_t8(acc8, slab_ff, prev8);
-  if (REC) reduce_t8(accz8, slab_rec, prev8z);
-
-  // ---- first touch of the slabs by a launch with fewer blocks than slab rows: the other rows start at zero (see fb_body)
-  if (!(accumulate & 1) && nblk < nrows_total) {
-    for (int r = nblk + bid; r < nrows_total; r += nblk) {
-      float4* z0 = (float4*)(slab_ff + (long)r * (9 * C32 * C32));
-      float4* z1 = REC ? (float4*)(slab_rec + (long)r * (9 * C32 * C32)) : nullptr;
-      for (int e = tid; e < 9 * C32 * C32 / 4; e += FB_THREADS) {
-        z0[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (REC) z1[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-  }
-
-  // ---- per-channel sums for leak / thresh (team E: lanes with equal (lane & 7) share channels)
-  if (team_e) {
+  } else {  // per-channel sums for leak / thresh: lanes with equal (lane & 7) share channels
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -920,11 +1030,23 @@ __device__ __forceinline__ void fb_body_ws(
       }
     }
   }
-  __syncthreads();
+  __syncthreads();  // (one barrier for both: the partial tiles of team M and the per-wave channel sums of team E)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {  // C32 * C32 <= 2 * NTHR
+    const int e = tid + h * NTHR;
+    if (e < C32 * C32) {
+      const long o8 = (long)bid * (9 * C32 * C32) + 8 * (C32 * C32) + e;
+      slab_ff[o8] = (s_t8[e] + s_t8[C32 * C32 + e]) + (s_t8[2 * C32 * C32 + e] + s_t8[3 * C32 * C32 + e]);
+      if (REC) {
+        const float* z = s_t8 + 4 * C32 * C32;
+        slab_rec[o8] = (z[e] + z[C32 * C32 + e]) + (z[2 * C32 * C32 + e] + z[3 * C32 * C32 + e]);
+      }
+    }
+  }
   if (tid < 64) {
     const int which = tid >> 5, c = tid & 31;
     float v = 0.f;
-    for (int w = 0; w < 4; ++w) v += s_red[(which * 8 + w) * C32 + c];
+    for (int w = 0; w < EW; ++w) v += s_red[(which * 8 + w) * C32 + c];
     if (which == 0) {
       const float l = fb_sigmoid(leak[c]), t = v * l * (1.0f - l);
       if (row_ld) g_leak[row_off + c] = row_prev + t;
@@ -932,6 +1054,18 @@ __device__ __forceinline__ void fb_body_ws(
     } else if (thresh[c] > 0.01f) {
       if (row_ld) g_thresh[row_off + c] = row_prev + v;
       else evf_atomic_add(g_thresh + c, v);
+    }
+  }
+
+  // ---- first touch of the slabs by a launch with fewer blocks than slab rows: the other rows start at zero (see fb_body)
+  if (!(accumulate & 1) && nblk < nrows_total) {
+    for (int r = nblk + bid; r < nrows_total; r += nblk) {
+      float4* z0 = (float4*)(slab_ff + (long)r * (9 * C32 * C32));
+      float4* z1 = REC ? (float4*)(slab_rec + (long)r * (9 * C32 * C32)) : nullptr;
+      for (int e = tid; e < 9 * C32 * C32 / 4; e += NTHR) {
+        z0[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (REC) z1[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   }
   if (TOP) {  // prediction-head weight / bias gradients, reduced the same way
@@ -963,12 +1097,12 @@ __device__ __forceinline__ void fb_body_ws(
     if (tid < 64) {
       const int which = tid >> 5, c = tid & 31;
       float v = 0.f;
-      for (int w = 0; w < 4; ++w) v += s_red[(which * 8 + w) * C32 + c];
+      for (int w = 0; w < EW; ++w) v += s_red[(which * 8 + w) * C32 + c];
       if (row_ld) top.dw[row_off + which * C32 + c] = top_prev + v;
       else evf_atomic_add(top.dw + which * C32 + c, v);
     } else if (tid < 66) {
       float v = 0.f;
-      for (int w = 0; w < 4; ++w) v += s_b2[2 * w + (tid - 64)];
+      for (int w = 0; w < EW; ++w) v += s_b2[2 * w + (tid - 64)];
       if (row_ld) top.db[row_off + (tid - 64)] = top_prev + v;
       else evf_atomic_add(top.db + (tid - 64), v);
     }
@@ -1033,22 +1167,23 @@ __global__ __launch_bounds__(FB_THREADS) void k_bwd_diag(FbJobs jobs, int B, int
                                 J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld);
 }
 
-__global__ __launch_bounds__(FB_THREADS) void k_bwd_diag_ws(FbJobs jobs, int B, int H, int W, int nchunk, long nunits, int row_ld,
-                                                            int nblk, int nrows_total) {
+template <int EW>
+__global__ __launch_bounds__(64 * (EW + 4)) void k_bwd_diag_ws(FbJobs jobs, int B, int H, int W, int nchunk, long nunits, int row_ld,
+                                                             int nblk, int nrows_total) {
   const int jb = blockIdx.x / nblk, bid = blockIdx.x - jb * nblk;
   const FbJob& J = jobs.j[jb];
   if (J.kind == 1)
-    fb_body_ws<true, false>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W, nchunk,
-                            nunits, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak, J.g_thresh, J.slab_ff,
-                            J.slab_rec, J.top, row_ld);
+    fb_body_ws<true, false, EW>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
+                                nchunk, nunits, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak, J.g_thresh,
+                                J.slab_ff, J.slab_rec, J.top, row_ld);
   else if (J.kind == 2)
-    fb_body_ws<false, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W, nchunk,
-                            nunits, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak, J.g_thresh, J.slab_ff,
-                            J.slab_rec, J.top, row_ld);
+    fb_body_ws<false, true, EW>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
+                                nchunk, nunits, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak, J.g_thresh,
+                                J.slab_ff, J.slab_rec, J.top, row_ld);
   else
-    fb_body_ws<false, false>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W, nchunk,
-                             nunits, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak, J.g_thresh, J.slab_ff,
-                             J.slab_rec, J.top, row_ld);
+    fb_body_ws<false, false, EW>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
+                                 nchunk, nunits, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak, J.g_thresh,
+                                 J.slab_ff, J.slab_rec, J.top, row_ld);
 }
 
 static long fb_units(int B, int H, int W) { return (long)B * H * ((W + FB_CW - 1) / FB_CW); }
@@ -1145,7 +1280,7 @@ static FbDefer fb_tab[EVF_CTX_MAX];
 // epilogue and ~5.5 k per unit (phase stamps, 128 x 128 x B8).  The u with the least rounds x (21 + 5.5 u): one cell of
 // 128 x 128 x B8 (2048 units): u = 8, 256 blocks; three cells: u = 25, 3 x 82 blocks = ONE round; six cells: u = 49, 6 x 42 blocks;
 // one cell of 260 x 346 x B4 (6240 units): u = 25, 250 blocks instead of 780 = 4 rounds.  EVF_BWD_UNITS=8..64 fixes u.
-static int fb_blocks_per_cell(long nunits, int n) {
+static int fb_blocks_per_cell(long nunits, int n, int per_unit = 11) {  // per_unit: cycles per unit / 500 (11 fused, 8 two teams)
   static const int mode = []() {
     const char* e = getenv("EVF_BWD_UNITS");
     const int v = e ? atoi(e) : 0;
@@ -1163,15 +1298,15 @@ static int fb_blocks_per_cell(long nunits, int n) {
   int best_nb = evf_cdiv(nunits, FB_UNITS);
   for (int u = FB_UNITS; u <= FB_UNITS_MAX; ++u) {
     const int nb = evf_cdiv(nunits, u);
-    const long cost = (long)evf_cdiv((long)n * nb, ncu) * (42 + 11 * u);  // (x2: integers)
+    const long cost = (long)evf_cdiv((long)n * nb, ncu) * (42 + per_unit * u);  // (x2: integers)
     if (best < 0 || cost < best) best = cost, best_nb = nb;
   }
   return best_nb;
 }
 
-static int fb_diag_select = -1;  // -1 environment / default, 0 k_bwd_diag, 1 k_bwd_diag_ws
+static int fb_diag_select = -1;  // -1 environment / default, 0 k_bwd_diag, 1 k_bwd_diag_ws<4>, 2 k_bwd_diag_ws<8>
 extern "C" int evf_bwd_diag_select(int which) {
-  if (which < -1 || which > 1) return EVF_EINVAL;
+  if (which < -1 || which > 2) return EVF_EINVAL;
   fb_diag_select = which;
   return EVF_OK;
 }
@@ -1182,22 +1317,29 @@ static int fb_defer_launch(FbDefer& fb_defer, int d, void* stream) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)k_bwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
-    (void)hipFuncSetAttribute((const void*)k_bwd_diag_ws, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    (void)hipFuncSetAttribute((const void*)k_bwd_diag_ws<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    (void)hipFuncSetAttribute((const void*)k_bwd_diag_ws<8>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
     attr_set = true;
   }
-  static const bool teams_env = []() {  // EVF_BWD_DIAG=fused: every wave through all phases (k_bwd_diag); default: two wave teams
+  // EVF_BWD_DIAG=fused: every wave through all phases (k_bwd_diag); teams4: 4 + 4 waves; default (teams): 8 + 4 waves
+  static const int teams_env = []() {
     const char* e = getenv("EVF_BWD_DIAG");
-    return !(e && e[0] == 'f');
+    if (e && e[0] == 'f') return 0;
+    return (e && e[0] == 't' && e[5] == '4') ? 1 : 2;
   }();
-  const bool teams = fb_diag_select < 0 ? teams_env : fb_diag_select == 1;
+  const int teams = fb_diag_select < 0 ? teams_env : fb_diag_select;
   FbJobs jobs;
   for (int k = 0; k < FB_MAX_JOBS; ++k) jobs.j[k] = fb_defer.job[d][k < n ? k : 0];
   const long nunits = fb_units(fb_defer.B, fb_defer.H, fb_defer.W);
   const int nrows = evf_cdiv(nunits, FB_UNITS), nchunk = (fb_defer.W + FB_CW - 1) / FB_CW;
-  const int nblk = fb_blocks_per_cell(nunits, n);
+  static const int cost_env = []() { const char* e = getenv("EVF_BWD_COST"); return e ? atoi(e) : 0; }();  // (A/B measurements)
+  const int nblk = fb_blocks_per_cell(nunits, n, cost_env > 0 ? cost_env : (teams == 2 ? 8 : 11));  // (k_bwd_diag_ws<8>: ~4.0 k cycles per unit, phase stamps)
   evf_prof_mark(1, 0, stream);
-  if (teams)
-    hipLaunchKernelGGL(k_bwd_diag_ws, dim3(nblk * n), dim3(FB_THREADS), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
+  if (teams == 2)
+    hipLaunchKernelGGL(k_bwd_diag_ws<8>, dim3(nblk * n), dim3(768), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
+                       fb_defer.W, nchunk, nunits, fb_defer.row_ld, nblk, nrows);
+  else if (teams == 1)
+    hipLaunchKernelGGL(k_bwd_diag_ws<4>, dim3(nblk * n), dim3(512), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
                        fb_defer.W, nchunk, nunits, fb_defer.row_ld, nblk, nrows);
   else
     hipLaunchKernelGGL(k_bwd_diag, dim3(nblk * n), dim3(FB_THREADS), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,

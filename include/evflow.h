@@ -322,9 +322,9 @@ int evf_conv_dgrad_select(int which);
  * 1 k_dgrad_diag_ws (persistent producer / consumer blocks over the flat list of products).  Process-wide. */
 int evf_dgrad_diag_select(int which);
 /* Which kernel launches the RECORDED fused-backward cells of a backward index: -1 default (environment
- * EVF_BWD_DIAG=fused|teams, else 1), 0 k_bwd_diag (every wave through load / neuron backward / staging / matrix phase, the
- * body of the one-cell launch), 1 k_bwd_diag_ws (four waves stream and stage, four contract: vector and matrix pipes of a
- * SIMD busy at the same time).  Same state gradients bit for bit; the weight-gradient slabs and per-channel sums agree to
+ * EVF_BWD_DIAG=fused|teams4|teams, else 2), 0 k_bwd_diag (every wave through load / neuron backward / staging / matrix phase,
+ * the body of the one-cell launch), 1 / 2 k_bwd_diag_ws (four / eight waves stream and stage, four contract: vector and
+ * matrix pipes of a SIMD busy at the same time; 512 / 768 threads).  Same state gradients bit for bit; the weight-gradient slabs and per-channel sums agree to
  * fp32 round-off (other partial-sum grouping).  Process-wide. */
 int evf_bwd_diag_select(int which);
 /* ... and for a recurrent cell both input gradients in one launch: g_x (+)= conv^T(g_cur, W_ff) as above,

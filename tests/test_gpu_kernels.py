@@ -332,7 +332,7 @@ def test_recorded_fused_backward_cells_match_the_one_cell_launches(shape):
 
     cells = [cell(k) for k in ("ff", "rec", "top", "rec", "ff")]
 
-    def run(mode):  # None: one launch per cell; 0 / 1: recorded, k_bwd_diag / k_bwd_diag_ws
+    def run(mode):  # None: one launch per cell; 0 / 1 / 2: recorded, k_bwd_diag / k_bwd_diag_ws<4> / k_bwd_diag_ws<8>
         outs = []
         for acc in (0, 1):  # first touch of the slabs, then accumulation (same inputs again)
             if mode is not None:
@@ -368,7 +368,7 @@ def test_recorded_fused_backward_cells_match_the_one_cell_launches(shape):
         return outs
 
     ref = run(None)
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         got = run(mode)
         for n, (a, b) in enumerate(zip(ref, got)):
             for name, x, y in zip(("g_cur", "split", "g_v_prev"), a[:3], b[:3]):
@@ -376,4 +376,4 @@ def test_recorded_fused_backward_cells_match_the_one_cell_launches(shape):
             for name, x, y in zip(("rows", "slab_ff", "slab_rec"), a[3:], b[3:]):
                 if x is not None:
                     assert float(x.abs().max()) > 0 and _rel(y, x) < 2e-5, (mode, n, name, _rel(y, x))
-    assert L.evf_bwd_diag_select(2) != 0
+    assert L.evf_bwd_diag_select(3) != 0
