@@ -473,6 +473,9 @@ __global__ __launch_bounds__(FP_THREADS) void k_fwd_diag_p(FwJobs jobs, FpPlan p
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // (Measured and dropped: starting the second wave of every SIMD 60 / 110 x 64 cycles late, so that one wave's matrix phase
+    //  meets the other's epilogue: 3.55 / 3.59 against 3.51 ms per step.  A wave alone issues an MFMA every ~62 cycles, its
+    //  own LDS-read -> expand -> MFMA chain; two of them together just fill the pipe.)
     FP_STAMP();
     const uint32_t* __restrict__ x = J.x;
     const uint32_t* __restrict__ z_prev = J.z_prev;
