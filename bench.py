@@ -667,7 +667,7 @@ def main():
         names = [n for n in names if n not in ("evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_head_lif_fwd")]
     if diag_bwd:
         names = [n for n in names if n not in ("evf_lif_bwd_wgrad2", "evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad_top", "evf_conv_dgrad_b3_f32",
-                                               "evf_conv_dgrad_b3_f32_pair", "evf_head_lif_bwd_wgrad")]
+                                               "evf_conv_dgrad_b3_f32_pair", "evf_conv_dgrad_b3", "evf_head_lif_bwd_wgrad")]
 
     # Everything runs on one side stream: warm-up (eager), then one whole training step
     # per input window is captured into a hipGraph on that same stream (autograd's
