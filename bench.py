@@ -598,8 +598,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--streams", type=int, default=1,
                     help="micro-batch pipelining (train.StreamReplicas): the per-GPU batch as this many slices on their own HIP "
-                         "streams; 2 gives +6.6 %% windows/s at the headline shape, but then every launch is a half-batch kernel "
-                         "and two are in flight, so per-launch roofline figures stop describing the device (default 1 = off)")
+                         "streams (default 1 = off).  Round 2 (one block per tile, launches of a few cells): 2 gave +6.6 %% windows/s at the "
+                         "headline shape; with round 3's persistent one-block-per-CU launches it loses: 3.69 against 3.65 ms per step "
+                         "(4 streams: 4.62)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-others", action="store_true",
                     help="skip the short c4 / c5 runs the default invocation appends as `other_configs` (after the c3 line's timed region)")
