@@ -971,13 +971,20 @@ struct HeadTripIn {  // what one trip loads
 // stay in REGISTERS between the passes of the launch -- gvc[trip] = dL/dv written by the previous pass (read instead of
 // g_v_out), voc[trip] = the v_prev it loaded, which IS this pass's v_out.  FIRST: the launch's first pass loads both from
 // memory; store_gv: the launch's last pass writes the carried gradient out.  Same values either way: bit-identical.
+// What a block keeps across the passes of k_head_bwd_win (NT > 0): besides the carried tensors the per-channel constants and
+// the SUMS -- weight-gradient accumulator and per-channel partial sums run over all passes of the launch and are reduced
+// across the block's waves once, after the last pass (equal to the pass-by-pass sums to fp32 round-off, not bit for bit).
+struct HeadBwdKeep {
+  f32x16 acc;
+  float sl[4], st[4], lam[4], th[4], oml[4], inv_oml[4];
+};
 template <bool FAST, int NT = 0, bool FIRST = true>
 __device__ __forceinline__ void head_bwd_pass(
     const float4* g_z_out, const float4* g_v_out, const float4* v_out, const float4* v_prev, const uint32_t* z_prev,
     const float* __restrict__ leak, const float* __restrict__ thresh, long npix, int hard_reset_rt, int surrogate_rt, float width,
     float4* g_cur, float4* g_v_prev, float* g_leak, float* g_thresh, const float* __restrict__ x_in, int Cin, int H, int W,
     float* slab, int slab_acc, int row_ld, float4 (&gvc)[NT ? NT : 1], float4 (&voc)[NT ? NT : 1], int (&xo)[NT ? NT : 1][4],
-    bool store_gv) {
+    HeadBwdKeep& K, bool store_gv) {  // store_gv: the launch's last pass (NT = 0: every pass is first and last)
   const int hard_reset = FAST ? 1 : hard_reset_rt, surrogate = FAST ? EVF_ARCTAN : surrogate_rt;
   __shared__ float s_red[2][4][C32];
   __shared__ __attribute__((aligned(16))) float s_g[2][4][8 * C32];  // [buffer][wave][pixel][channel]
@@ -985,15 +992,21 @@ __device__ __forceinline__ void head_bwd_pass(
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int cg = tid & 7;  // channel group of the element-wise part: channels 4cg..4cg+3
   const int i = lane & 31, kg = lane >> 5;
-  float lam[4], th[4], oml[4], inv_oml[4];
+  float(&lam)[4] = K.lam, (&th)[4] = K.th, (&oml)[4] = K.oml, (&inv_oml)[4] = K.inv_oml, (&sl)[4] = K.sl, (&st)[4] = K.st;
+  f32x16& acc = K.acc;
+  const bool last = NT == 0 || store_gv;
+  if (NT == 0 || FIRST) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    lam[k] = evf_sigmoid(leak[4 * cg + k]);
-    th[k] = fmaxf(thresh[4 * cg + k], 0.01f);
-    oml[k] = 1.0f - lam[k];
-    inv_oml[k] = 1.0f / oml[k];
+    for (int k = 0; k < 4; ++k) {
+      lam[k] = evf_sigmoid(leak[4 * cg + k]);
+      th[k] = fmaxf(thresh[4 * cg + k], 0.01f);
+      oml[k] = 1.0f - lam[k];
+      inv_oml[k] = 1.0f / oml[k];
+      sl[k] = st[k] = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   }
-  float sl[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
   const float4* pgz = g_z_out ? g_z_out : v_out;
   const float4* pgv = g_v_out ? g_v_out : v_out;
   const float4* pvp = v_prev ? v_prev : v_out;
@@ -1004,18 +1017,17 @@ __device__ __forceinline__ void head_bwd_pass(
   const bool colok = i < ncol;
   const int ci = colok ? i / 9 : 0, tap = colok ? i - 9 * ci : 0, dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
   const long HW = (long)H * W;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const long total = npix * 8, stride = (long)gridDim.x * 256;
   // operands of the epilogue, requested now: this block's previous slab partial sums (ncol <= 32: <= 4 per thread) and its
   // row of per-channel sums -- after the loop they were two dependent HBM round trips at the end of the block's life
   float* sl_out = slab + (long)blockIdx.x * (C32 * ncol);
-  float prev[4];
-#pragma unroll
-  for (int h = 0; h < 4; ++h) prev[h] = sl_out[min(tid + 256 * h, C32 * ncol - 1)];
+  float prev[4] = {0.f, 0.f, 0.f, 0.f}, row_prev = 0.f;
   const size_t row_off = (size_t)blockIdx.x * row_ld;
-  const float row_prev = (((tid >> 5) & 1) ? g_thresh : g_leak)[row_off + (tid & 31)];  // (used by threads < 64)
+  if (last) {  // (block-uniform; a window launch: in its last pass only)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) prev[h] = sl_out[min(tid + 256 * h, C32 * ncol - 1)];
+    row_prev = (((tid >> 5) & 1) ? g_thresh : g_leak)[row_off + (tid & 31)];  // (used by threads < 64)
+  }
   // a trip in two halves: fetch() issues its loads (unconditional, clamped addresses), work() consumes them.  NT > 0: the
   // loads of ALL trips of the pass are issued before the first is consumed -- with one trip's loads in flight at a time (the
   // barrier inside a trip keeps the next trip's loads behind it) the kernel ran at the memory latency, not the bandwidth.
@@ -1139,6 +1151,7 @@ __device__ __forceinline__ void head_bwd_pass(
       if (base < total) work(base, it, it, tin[it]);
     }
   }
+  if (!last) return;  // (the sums go on into the next pass)
   // D[co][col] of the 4 waves -> slab[block][co][col] (torch layout [32][Cin][3][3])
 #pragma unroll
   for (int r = 0; r < 16; ++r) s_d[wv][((r & 3) + 8 * (r >> 2) + 4 * kg) * C32 + i] = acc[r];
@@ -1196,8 +1209,9 @@ __global__ __launch_bounds__(256) void k_head_bwd_mfma(
     const float* __restrict__ x_in, int Cin, int H, int W, float* __restrict__ slab, int slab_acc, int row_ld) {
   float4 none[1];
   int nox[1][4];
+  HeadBwdKeep keep;
   head_bwd_pass<FAST>(g_z_out, g_v_out, v_out, v_prev, z_prev, leak, thresh, npix, hard_reset_rt, surrogate_rt, width, g_cur,
-                      g_v_prev, g_leak, g_thresh, x_in, Cin, H, W, slab, slab_acc, row_ld, none, none, nox, true);
+                      g_v_prev, g_leak, g_thresh, x_in, Cin, H, W, slab, slab_acc, row_ld, none, none, nox, keep, true);
 }
 
 // The head layer's backward of a whole WINDOW in one launch.  The head's backward chain is per pixel (dL/dv carried from pass
@@ -1223,18 +1237,20 @@ template <bool FAST, int NT>
 __global__ __launch_bounds__(HEADBWD_LB) void k_head_bwd_win(HeadBwdWin a) {
   float4 gvc[NT ? NT : 1], voc[NT ? NT : 1];
   int xo[NT ? NT : 1][4];
+  HeadBwdKeep keep;
+  const int acc0 = a.p[0].slab_acc;  // (NT > 0: the sums of all passes are added to the slab once, by the first pass's rule)
   {
     const HeadBwdPass& q = a.p[0];
     head_bwd_pass<FAST, NT, true>(q.g_z_out, q.g_v_out, q.v_out, q.v_prev, q.z_prev, a.leak, a.thresh, a.npix, a.hard_reset,
                                   a.surrogate, a.width, nullptr, q.g_v_prev, a.g_leak, a.g_thresh, q.x_in, a.Cin, a.H, a.W, a.slab,
-                                  q.slab_acc, a.row_ld, gvc, voc, xo, a.np == 1);
+                                  NT > 0 ? acc0 : q.slab_acc, a.row_ld, gvc, voc, xo, keep, a.np == 1);
   }
   for (int t = 1; t < a.np; ++t) {
     __syncthreads();  // (the pass's last reads of the reduction arrays before the next pass rewrites them)
     const HeadBwdPass& q = a.p[t];
     head_bwd_pass<FAST, NT, false>(q.g_z_out, q.g_v_out, q.v_out, q.v_prev, q.z_prev, a.leak, a.thresh, a.npix, a.hard_reset,
                                    a.surrogate, a.width, nullptr, q.g_v_prev, a.g_leak, a.g_thresh, q.x_in, a.Cin, a.H, a.W, a.slab,
-                                   q.slab_acc, a.row_ld, gvc, voc, xo, t == a.np - 1);
+                                   NT > 0 ? acc0 : q.slab_acc, a.row_ld, gvc, voc, xo, keep, t == a.np - 1);
   }
 }
 

@@ -264,8 +264,8 @@ def test_head_layer_of_a_window_in_one_launch_is_bit_identical_backward(shape, s
     pass has a dL/d(spikes) buffer of its own -- carried dL/dv and the block's partial sums re-read by the thread that wrote
     them (any shape / surrogate), or kept in registers with all loads of a pass in flight (<= 4 trips per block, the
     reference's default neuron).  Against the same cells with ONE shared dL/d(spikes) buffer, which the library then runs
-    where they were recorded, one launch each: dL/dv of the window's start, the weight-gradient slabs and the per-block
-    per-channel rows must agree bit for bit.  (16 x 128 x 128: 8 trips per block -- the through-memory form of the default
+    where they were recorded, one launch each: dL/dv of the window's start must agree bit for bit, the weight-gradient slabs
+    and the per-block per-channel rows to fp32 round-off (the register form keeps its sums over all passes).  (16 x 128 x 128: 8 trips per block -- the through-memory form of the default
     neuron.)"""
     B, H, W = shape
     npass = 6
@@ -300,8 +300,10 @@ def test_head_layer_of_a_window_in_one_launch_is_bit_identical_backward(shape, s
 
     ref, got = run(True), run(False)
     assert float(ref[1].abs().max()) > 0 and float(ref[2].abs().max()) > 0
-    for name, a, b in zip(("g_v", "slab", "rows"), ref, got):
-        assert torch.equal(a, b), name
+    assert torch.equal(ref[0], got[0]), "g_v"
+    for name, a, b in zip(("slab", "rows"), ref[1:], got[1:]):
+        # (the register form sums over ALL passes before it reduces across the block's waves: fp32 round-off apart)
+        assert _rel(b.sum(0), a.sum(0)) < 5e-6 and _rel(b, a) < 5e-5, (name, _rel(b, a))
 
 
 @pytest.mark.parametrize("shape", SHAPES + [(3, 20, 96), (4, 64, 160)])
