@@ -1032,8 +1032,9 @@ __device__ __forceinline__ void head_bwd_pass(
   // loads of ALL trips of the pass are issued before the first is consumed -- with one trip's loads in flight at a time (the
   // barrier inside a trip keeps the next trip's loads behind it) the kernel ran at the memory latency, not the bandwidth.
   typedef HeadTripIn TripIn;
-  // (`first`: also the carried operands and the geometry.  Requesting the NEXT pass's operands after the last trip, ahead of
-  //  the pass's own reductions, was measured and dropped: 166.6 against 161.3 us per window.)
+  // (`first`: also the carried operands and the geometry.  Requesting the NEXT pass's operands early was measured twice and
+  //  dropped: all of them after the last trip, ahead of the pass's reductions: 166.6 against 161.3 us per window; trip by trip
+  //  as the registers come free, with the sums kept across the passes: 148.9 against 131.1.)
   auto fetch = [&](const long base, const int ic, TripIn& in, const bool first, const float4* pgz, const float4* pvp,
                    const uint32_t* pzw, const float* x_in, const float4* v_out, const float4* pgv) {  // ic: the trip's carry register
     const long e = base + tid;
