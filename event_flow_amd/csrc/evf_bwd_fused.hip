@@ -1432,6 +1432,27 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
     const int rc = evf_bwd_defer_flush_now(bctx, stream);  // not recordable: everything recorded runs first
     if (rc) return rc;
   }
+  // One cell of the default neuron through the two-team body as well (k_bwd_diag_ws<8> with a one-entry table;
+  // EVF_BWD_ONE=fused: k_lif_bwd_wgrad, every wave through all phases)
+  static const bool one_teams = []() {
+    const char* e = getenv("EVF_BWD_ONE");
+    return !(e && e[0] == 'f');
+  }();
+  if (fast && one_teams && (g_cur || g_split)) {
+    static bool attr_ws = false;
+    if (!attr_ws) {
+      (void)hipFuncSetAttribute((const void*)k_bwd_diag_ws<8>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+      attr_ws = true;
+    }
+    FbJobs jobs;
+    const FbJob J{(const float4*)g_z_out, (const float4*)g_z_out2, (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev,
+                  z_prev, xT, zT_prev, leak, thresh, (float4*)g_cur, (uint2*)g_split, (float4*)g_v_prev, g_leak, g_thresh, slab_ff,
+                  slab_rec, top, act_width, accumulate, topp ? 2 : (zT_prev ? 1 : 0), 0};
+    for (int k = 0; k < FB_MAX_JOBS; ++k) jobs.j[k] = J;
+    const int nblk = fb_blocks_per_cell(nunits, 1, 8);
+    hipLaunchKernelGGL(k_bwd_diag_ws<8>, dim3(nblk), dim3(768), FB_LDS, st, jobs, B, H, W, nchunk, nunits, row_ld, nblk, nrows_all);
+    return evf_status();
+  }
 #define FB_GO(REC_, TOP_, FAST_, slot)                                                                                    \
   do {                                                                                                                    \
     if (!attr[slot]) {                                                                                                    \
