@@ -629,18 +629,21 @@ __device__ __forceinline__ void fb_body_ws(
 
   if (team_e) {
     float lam[4], th[4], oml[4], inv_oml[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      lam[k] = fb_sigmoid(leak[4 * cg + k]);
-      th[k] = fmaxf(thresh[4 * cg + k], 0.01f);
-      oml[k] = 1.0f - lam[k];
-      inv_oml[k] = 1.0f / oml[k];
-    }
     float pwa[4] = {0, 0, 0, 0}, pwb[4] = {0, 0, 0, 0};
-    if (TOP) {
+    // (computed BEHIND the first units' loads: four exp, four divisions and the head's weights are not needed to request them)
+    auto constants = [&]() {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) pwa[k] = top.pred_w[4 * cg + k], pwb[k] = top.pred_w[C32 + 4 * cg + k];
-    }
+      for (int k = 0; k < 4; ++k) {
+        lam[k] = fb_sigmoid(leak[4 * cg + k]);
+        th[k] = fmaxf(thresh[4 * cg + k], 0.01f);
+        oml[k] = 1.0f - lam[k];
+        inv_oml[k] = 1.0f / oml[k];
+      }
+      if (TOP) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pwa[k] = top.pred_w[4 * cg + k], pwb[k] = top.pred_w[C32 + 4 * cg + k];
+      }
+    };
     const float4* pgz = g_z_out ? g_z_out : v_out;
     const float4* pgz2 = g_z_out2 ? g_z_out2 : v_out;
     const bool has_gz2 = !TOP && g_z_out2 != nullptr;
@@ -779,6 +782,7 @@ __device__ __forceinline__ void fb_body_ws(
       issue(0, 1, s1);
       issue(1, 0, s2);
       issue(1, 1, s3);
+      constants();
       commit(0, 0, s0, 0);
       issue(2, 0, s0);
       commit(0, 1, s1, 0);
@@ -808,6 +812,7 @@ __device__ __forceinline__ void fb_body_ws(
       FbStage s_cur, s_nxt, s_new;
       issue(0, 0, s_cur);
       issue(1, 0, s_nxt);
+      constants();
       commit(0, 0, s_cur, 0);
       FBW_STAMP();
       __syncthreads();  // unit 0 staged
