@@ -77,6 +77,7 @@ NETWORK_SIGNATURES = {
     "evf_conv_dgrad_select": [I],
     "evf_dgrad_diag_select": [I],
     "evf_bwd_diag_select": [I],
+    "evf_fwd_diag_select": [I],
     "evf_conv_dgrad_b3_f32_pair": [P, P, P, I, P, P, I, I, I, P, P, P],
     "evf_conv_dgrad_b3_pair": [P, P, P, I, P, P, I, I, I, P, P, P],
     "evf_conv_plif_fwd_b3": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P],
@@ -258,15 +259,22 @@ def profile_stop():
 # The recorders of the library are per STREAM (include/evflow.h, "CONTEXTS / THREADS"), and so is the hook that launches what
 # has been recorded on a stream before any entry point outside the recorded schedule runs on it: _hooks[stream] = (callable
 # set by the engine that opened the recording, the entry points that record themselves or flush inside the library).
+# The library allows a forward AND a backward recording open on one stream at once, so a stream holds one hook per kind:
+# _hooks[stream] = {"fwd": (flush, safe), "bwd": (flush, safe)}.
 _hooks = {}
 
 
-def set_defer_hook(flush, safe):
-    _hooks[stream_ptr()] = (flush, safe)
+def set_defer_hook(flush, safe, kind):
+    _hooks.setdefault(stream_ptr(), {})[kind] = (flush, safe)
 
 
-def clear_defer_hook():
-    _hooks.pop(stream_ptr(), None)
+def clear_defer_hook(kind):
+    sp = stream_ptr()
+    d = _hooks.get(sp)
+    if d is not None:
+        d.pop(kind, None)
+        if not d:
+            _hooks.pop(sp, None)
 
 
 def raw(name, *args):
@@ -282,9 +290,11 @@ _DEFER_SAFE_BWD = {"evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad2", "evf_lif_bwd_wgrad
 
 def call(name, *args):
     """Invoke an entry point on torch's current stream; raise on error."""
-    hook = _hooks.get(stream_ptr()) if _hooks else None
-    if hook is not None and name not in hook[1]:
-        hook[0]()
+    hooks = _hooks.get(stream_ptr()) if _hooks else None
+    if hooks:
+        for flush, safe in list(hooks.values()):
+            if name not in safe:
+                flush()
     if _prof is not None and name in _prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -87,6 +87,9 @@ struct EvfDgProds {
 int evf_dgrad_diag_ws_launch(const EvfDgProds& P, int nprod, int B, int H, int W, void* stream);
 // ... and with the gradient pre-split in HBM (three bf16 planes [term][B,H,W,32]): LDS-DMA fed, one wave per SIMD (k_dgrad_diag_dma)
 int evf_dgrad_diag_dma_launch(const EvfDgProds& P, int nprod, int B, int H, int W, void* stream);
+// whether a cell of this shape may be RECORDED for the persistent launches (their index arithmetic: < 2^22 items with a full
+// table of products, 32-bit plane offsets); a cell that does not fit launches directly instead of failing at the flush
+bool evf_dgrad_diag_fits(int split, int B, int H, int W);
 
 // Deferred backward cells (evf_bwd_defer_*, owner: evf_bwd_fused.hip): while `active`, the fused backward, the fp32 input
 // gradient and the head backward of the default-neuron FireNet path RECORD their launch under index `slot`; the flush

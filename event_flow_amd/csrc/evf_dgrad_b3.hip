@@ -409,7 +409,7 @@ static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, in
     const bool any = evf_dg_defer_count(bctx) != 0;
     const int split = f32in ? 0 : 1;  // (one kind per recording: the two are launched by different kernels)
     const bool same = !any || (dg_defer.B == B && dg_defer.H == H && dg_defer.W == W && dg_defer.split == split);
-    if (!accumulate && !g_P && same && dg_defer.n[evf_bwd_defer.slot] < DG_MAX_JOBS) {
+    if (!accumulate && !g_P && same && dg_defer.n[evf_bwd_defer.slot] < DG_MAX_JOBS && evf_dgrad_diag_fits(split, B, H, W)) {
       dg_defer.B = B, dg_defer.H = H, dg_defer.W = W, dg_defer.split = split;
       dg_defer.job[evf_bwd_defer.slot][dg_defer.n[evf_bwd_defer.slot]++] =
           DgJob{(const uint4*)g, (const uint4*)wT_b3, g_x, (const uint4*)wT2_b3, g_x2, split};

@@ -458,6 +458,14 @@ __global__ __launch_bounds__(512) void k_dgrad_diag_dma(EvfDgProds P, unsigned p
   WM_STAMP();
 }
 
+bool evf_dgrad_diag_fits(int split, int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return false;
+  const long ntiles = (long)evf_cdiv(W, 32) * evf_cdiv(H, WD_ROWS) * B;
+  if (ntiles * EVF_DG_MAX_PROD >= (1L << 22)) return false;
+  if (split && (3L * B * H * W * 64 >= (1L << 32) || (long)B * H * W * C32 >= (1L << 30))) return false;
+  return true;
+}
+
 int evf_dgrad_diag_dma_launch(const EvfDgProds& P, int nprod, int B, int H, int W, void* stream) {
   if (nprod <= 0 || nprod > EVF_DG_MAX_PROD || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
   const int ntx = evf_cdiv(W, 32), nty = evf_cdiv(H, WD_ROWS);

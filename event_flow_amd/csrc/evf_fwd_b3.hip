@@ -13,28 +13,16 @@
 // bf16: one byte of the pixel's spike word -> 16 bytes through a 256-entry
 // LDS table (one ds_read_b128, broadcast for the all-zero byte).
 // B operand: packed per (tap, m, term) as 64 lanes x 16 B (k_pack_conv_weight_b3).
-#include "evf_common.h"
-#include <type_traits>
-#include <stdlib.h>
+#include "evf_fwd.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-#define C32 32
 #ifndef TH
 #define TH 8
 #endif
 #define FW_WAVES (TH / 2)        // a wave owns two tile rows
 #define FW_THREADS (64 * FW_WAVES)
-#define TW 32
-#define HALO_W (TW + 2)
 #define HALO_H (TH + 2)
-#define NFRAG 54                 // 9 taps x 2 k-halves x 3 terms
-#define FW_SP 36                 // floats per pixel of the epilogue staging tile (32 + 4: conflict-free 16-byte writes)
-#define WB3_BYTES (NFRAG * 1024)  // per conv
 
 __device__ __forceinline__ int b3_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
-__device__ __forceinline__ float b3_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ uint32_t bf16_rne(float f) {  // round-to-nearest-even, finite inputs
   const uint32_t u = __float_as_uint(f);
@@ -70,20 +58,6 @@ extern "C" int evf_pack_conv_weight_b3(const float* w, int Cout, int Cin, void* 
 }
 
 
-// LDS-DMA of one 1 KiB piece (64 lanes x 16 B, destination = wave-uniform LDS address + lane*16), invisible to the
-// compiler's wait counting: completion is covered by the explicit s_waitcnt vmcnt(0) before the barrier that
-// publishes the buffer.  Staging the 54 KiB of split weights through registers (load -> wait -> ds_write, 13.5 uint4
-// per thread) cost 6.8 us of a 15.7 us block lifetime (s_memtime instrumentation); as DMA all pieces are in flight
-// at once and no VGPRs are held.
-__device__ __forceinline__ void b3_glds16(const void* gsrc, void* lds_dst) {
-  unsigned keep;
-  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst);
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(dst)
-               : "memory");
-}
-
 // PLIF (spiking_submodules.py:191-227, :618-657): a per-channel pre-synaptic trace
 //   pt' = pt*sigma(leak_pt) + (1 - sigma(leak_pt)) * AvgPool3x3(mean_c |input|)
 // is subtracted from the current, cur = ff (+ rec) - sigma(add_pt) * pt'.  For binary inputs
@@ -94,14 +68,6 @@ struct PlifArgs {
   const float* pt_prev;  // [B,H,W,32] or NULL
   float* pt_out;         // [B,H,W,32]
   float* P_out;          // [B,H,W] pooled pre-synaptic activity (saved for the backward)
-};
-
-// Prediction head (models/model.py:197-199, :265) fused into the epilogue of the layer it reads: flow = tanh(W z + b)
-// from the spike word of each pixel, same summation order as evf_pred_fwd.  All NULL: no head here.
-struct PredArgs {
-  const float* w;     // [2][32]
-  const float* bias;  // [2]
-  float* flow;        // [B,2,H,W]
 };
 
 #ifdef EVF_SPAN  // start / end of every block in the chip-wide 100 MHz counter (probe build through EVF_LIB)
@@ -346,25 +312,6 @@ __global__ __launch_bounds__(FW_THREADS) void k_conv_lif_fwd_b3(const uint32_t* 
 // window's forward is recorded by evf_fwd_defer_* (below) and launched diagonal by diagonal: P + L - 1 launches of
 // up to L cells instead of P x L launches -- every launch pays its fixed cost (cold first fetch, kernel boundary:
 // ~8 of the ~15 us of a single cell) once.  blockIdx.z = cell * B + sample; same body, same results.
-#define FW_MAX_JOBS 8
-struct FwJob {
-  const uint32_t* x;
-  const uint4* wff;
-  const uint4* wrec;  // NULL: feed-forward cell
-  const float* leak;
-  const float* thresh;
-  const float* v_prev;
-  const uint32_t* z_prev;
-  float* v_out;
-  uint32_t* z_out;
-  uint32_t* zT_out;
-  PredArgs pr;
-  int hard_reset;
-  int pad_;
-};
-struct FwJobs {
-  FwJob j[FW_MAX_JOBS];
-};
 __global__ __launch_bounds__(FW_THREADS) void k_fwd_diag(FwJobs jobs, int B, int H, int W) {
   const int jb = blockIdx.z / B, b = blockIdx.z - jb * B;
   const FwJob& J = jobs.j[jb];
@@ -668,6 +615,13 @@ static size_t fw_lds_bytes() {
   return WB3_BYTES + 256 * 16 + 2 * HALO_H * HALO_W * 4 + TH * TW * 4 + (2 * C32 + 2) * 4 + 4 * C32 * 4;
 }
 
+static int fw_diag_select = -1;  // -1 environment / default, 0 k_fwd_diag (a tile per block), 1 k_fwd_diag_p, 2 k_fwd_diag_t
+extern "C" int evf_fwd_diag_select(int which) {
+  if (which < -1 || which > 2) return EVF_EINVAL;
+  fw_diag_select = which;
+  return EVF_OK;
+}
+
 // Launch what has been recorded (diagonals in increasing order) and keep recording.
 static int fw_defer_launch(FwDefer& fw_defer, void* stream) {
   {  // the head layer's recorded cells first: every diagonal cell of pass t reads (through its layers below) the head of pass t
@@ -682,10 +636,13 @@ static int fw_defer_launch(FwDefer& fw_defer, void* stream) {
     (void)hipFuncSetAttribute((const void*)k_fwd_diag_p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FP_LDS);
     attr_set = true;
   }
-  static const bool persistent = []() {  // EVF_FWD_DIAG=tile|persistent (A/B measurements); default: persistent
+  // EVF_FWD_DIAG=tile|persistent|teams (A/B measurements, the bit-identity tests); default: teams (k_fwd_diag_t, evf_fwd_teams.hip)
+  static const int env_mode = []() {
     const char* e = getenv("EVF_FWD_DIAG");
-    return !(e && e[0] == 't');
+    return !e ? 2 : (e[0] == 't' && e[1] == 'i' ? 0 : (e[0] == 'p' ? 1 : 2));
   }();
+  const int mode = fw_diag_select < 0 ? env_mode : fw_diag_select;
+  const bool persistent = mode >= 1;
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;
@@ -701,7 +658,10 @@ static int fw_defer_launch(FwDefer& fw_defer, void* stream) {
     int nhard = 0;
     for (int k = 0; k < n; ++k) nhard += jobs.j[k].hard_reset ? 1 : 0;
     evf_prof_mark(0, 0, stream);
-    if (persistent && (nhard == 0 || nhard == n)) {  // (cells of both reset rules in one index: the per-tile kernel)
+    if (mode == 2 && (nhard == 0 || nhard == n)) {
+      const int rc = evf_fwd_diag_t_launch(jobs, n, fw_defer.B, fw_defer.H, fw_defer.W, stream);
+      if (rc) return rc;
+    } else if (persistent && (nhard == 0 || nhard == n)) {  // (cells of both reset rules in one index: the per-tile kernel)
       FpPlan plan;
       plan.njobs = n, plan.ntx = evf_cdiv(fw_defer.W, TW), plan.nyy = evf_cdiv(fw_defer.H, 2);
       plan.nstrips = plan.ntx * plan.nyy * fw_defer.B;

@@ -366,7 +366,7 @@ class FireNetEngine:
         if self.__dict__.get("_defer_open"):
             self._defer_open = False
             with torch.cuda.stream(self._defer_stream):  # the recording belongs to the stream it was opened on
-                _lib.clear_defer_hook()
+                _lib.clear_defer_hook("fwd")
                 _lib.call("evf_fwd_defer_flush")
 
     def defer_backward(self, on=True):
@@ -381,11 +381,14 @@ class FireNetEngine:
         if self.__dict__.get("_bdefer_open"):
             self._bdefer_open = False
             with torch.cuda.stream(self._bdefer_stream):  # the recording belongs to the stream it was opened on
-                _lib.clear_defer_hook()
+                _lib.clear_defer_hook("bwd")
                 _lib.call("evf_bwd_defer_flush")
         # the recorded cells hold raw pointers into the passes' tapes and upstream gradients: those tensors are kept here
-        # until the cells have been launched (stream order then protects the memory like any other tensor's)
-        self._bdefer_keep = []
+        # until the cells have been launched (stream order then protects the memory like any other tensor's).  A flush in the
+        # MIDDLE of a backward pass (index overflow in _bdefer_slot, the safety net of _lib.call) must not drop the entry of the
+        # pass in progress: the cells it records after the flush point into the same tape.
+        cur = self.__dict__.get("_bdefer_cur")
+        self._bdefer_keep = [cur] if cur is not None else []
 
     def _bdefer_slot(self, win, step):
         """Index of step `step` (0 = top layer's fused backward, 1 = its input gradient, ...) of the current backward pass."""
@@ -394,7 +397,7 @@ class FireNetEngine:
                 raise _lib.EvflowError("evf_bwd_defer_begin: another backward recording is open on this stream (one engine per stream)")
             self._bdefer_open, self._bdefer_base = True, win.bwd_k
             self._bdefer_stream = torch.cuda.current_stream()
-            _lib.set_defer_hook(self.flush_backward, _lib._DEFER_SAFE_BWD)
+            _lib.set_defer_hook(self.flush_backward, _lib._DEFER_SAFE_BWD, "bwd")
         d = 2 * (win.bwd_k - self._bdefer_base) + step
         if d >= 96:  # (more than ~40 passes: launch what is recorded, start over)
             self.flush_backward()
@@ -408,7 +411,7 @@ class FireNetEngine:
             raise _lib.EvflowError("evf_fwd_defer_begin: another forward recording is open on this stream (one engine per stream)")
         self._defer_open, self._defer_t = True, 0
         self._defer_stream = torch.cuda.current_stream()
-        _lib.set_defer_hook(self.flush_forward, _lib._DEFER_SAFE_FWD)
+        _lib.set_defer_hook(self.flush_forward, _lib._DEFER_SAFE_FWD, "fwd")
 
     def _flow_out(self, B, H, W, dev):
         slot, self._flow_slot = self._flow_slot, None
@@ -535,7 +538,8 @@ class FireNetEngine:
         if self.__dict__.get("_bdefer_on", False):
             # recorded cells of this pass are launched later (flush_backward): its tape and the contiguous upstream gradient
             # must outlive this function (autograd drops ctx.tape and g_flow as soon as the node returns)
-            self.__dict__.setdefault("_bdefer_keep", []).append((tape, g_flow, g_flow_c))
+            self._bdefer_cur = (tape, g_flow, g_flow_c)
+            self.__dict__.setdefault("_bdefer_keep", []).append(self._bdefer_cur)
         if g_flow is not None and not top_fused:
             gz_top = win.buf(win.gz, n - 1)
             _lib.call("evf_pred_bwd", _lib.ptr(layers[n - 1][4]), _lib.ptr(tape["flow"]),
@@ -696,6 +700,7 @@ class FireNetEngine:
                     _lib.call("evf_conv_dgrad", _lib.ptr(win.g_cur), _lib.ptr(self._packed[(i, "ff", 1)]), _lib.ptr(ga), acc_a,
                               None, None, 0, B, H, W)
                 win.gz_has[i - 1] = True
+        self._bdefer_cur = None  # (the pass is recorded completely; its entry stays in _bdefer_keep until the flush)
 
     def _finalize(self, win):
         """Window complete: reduce the weight-gradient slabs, hand all parameter

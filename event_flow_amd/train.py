@@ -9,6 +9,7 @@ becomes a view into `flat_param`, every `.grad` a view into `flat_grad`.
 """
 
 import os
+import weakref
 
 import torch
 
@@ -50,10 +51,30 @@ class FlatAdam:
         # kernels that add into the bound .grad directly through hip_ops.direct_grads_written() -- so a `loss.backward()` issued
         # anywhere between step() and zero_grad() (gradient accumulation, custom loops) is seen and zero_grad() then does clear.
         self._grad_clean = False
-        for p in self.params:
-            p.register_post_accumulate_grad_hook(lambda _p, _self=self: _self.mark_grad_dirty())
+        # (weak: a hook that held the optimizer would keep it and its flat buffers alive with the model, and a second
+        # FlatAdam on the same model would stack hooks; close() removes them)
+        wself = weakref.ref(self)
+
+        def _dirty(_p, _w=wself):
+            o = _w()
+            if o is not None:
+                o.mark_grad_dirty()
+
+        self._hook_handles = [p.register_post_accumulate_grad_hook(_dirty) for p in self.params]
         hip_ops.on_direct_grads(self)
         hip_ops.DIRECT_PARAM_GRADS = True  # every .grad is a view of flat_grad: the backward kernels add into it in place
+
+    def close(self):
+        """Detach from the model: remove the per-parameter hooks (the parameters keep their storage in the flat buffer)."""
+        for h in self.__dict__.get("_hook_handles", []):
+            h.remove()
+        self._hook_handles = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def zero_grad(self):
         # the fused step clears the buffer as it consumes it: zero_grad() right after step() (train_flow.py:163-164)

@@ -229,7 +229,7 @@ int evf_defer_poison(int on);
  * the index last given to evf_bwd_defer_slot (0 .. 95); any other call of these entry points first launches everything
  * recorded.  evf_bwd_defer_flush launches index after index -- the fused-backward cells of an index as one kernel, its
  * input-gradient cells as one kernel, head cells one by one -- and ends the recording.  Same kernel bodies as the one-cell
- * launches.  Per-thread recorder (see above); the caller guarantees the index order, that nothing else reads a cell's outputs
+ * launches.  Per-stream recorder (see above); the caller guarantees the index order, that nothing else reads a cell's outputs
  * before the flush, and that every buffer a recorded cell refers to stays allocated until then.  With the gradient
  * pre-split (evf_lif_bwd_wgrad* given g_split, evf_conv_dgrad_b3[_pair]) the input-gradient cells are recorded as well. */
 int evf_bwd_defer_begin(void* stream);
@@ -321,6 +321,11 @@ int evf_conv_dgrad_select(int which);
  * -1 default (environment EVF_DGRAD_DIAG=lds|ws, else 1), 0 k_dgrad_diag (the LDS kernel's body, one block per tile pair),
  * 1 k_dgrad_diag_ws (persistent producer / consumer blocks over the flat list of products).  Process-wide. */
 int evf_dgrad_diag_select(int which);
+/* Which kernel launches the RECORDED forward cells of an index (evf_fwd_defer_*; results are bit-identical): -1 default
+ * (environment EVF_FWD_DIAG=tile|persistent|teams, else 2), 0 k_fwd_diag (one 8 x 32 tile per block, the body of the one-cell
+ * launch), 1 k_fwd_diag_p (persistent blocks, a strip per wave), 2 k_fwd_diag_t (persistent blocks of a matrix team and an
+ * element-wise team, evf_fwd_teams.hip).  Process-wide; for A/B measurements and the equivalence test. */
+int evf_fwd_diag_select(int which);
 /* Which kernel launches the RECORDED fused-backward cells of a backward index: -1 default (environment
  * EVF_BWD_DIAG=fused|teams4|teams, else 2), 0 k_bwd_diag (every wave through load / neuron backward / staging / matrix phase,
  * the body of the one-cell launch), 1 / 2 k_bwd_diag_ws (four / eight waves stream and stage, four contract: vector and

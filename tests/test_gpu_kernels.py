@@ -379,3 +379,72 @@ def test_recorded_fused_backward_cells_match_the_one_cell_launches(shape):
                 if x is not None:
                     assert float(x.abs().max()) > 0 and _rel(y, x) < 2e-5, (mode, n, name, _rel(y, x))
     assert L.evf_bwd_diag_select(3) != 0
+
+
+@pytest.mark.parametrize("shape", SHAPES + [(3, 21, 96), (1, 2, 32)])
+@pytest.mark.parametrize("hard", [1, 0])
+def test_recorded_forward_cells_are_bit_identical(shape, hard):
+    """The forward cells of an index, recorded (evf_fwd_defer_*) and launched together, against one direct launch per cell --
+    bit-identical potentials, spike words, channel-major bit planes and flow through all three dispatchers: k_fwd_diag (a tile
+    per block), k_fwd_diag_p (persistent, a strip per wave) and k_fwd_diag_t (persistent, matrix team + element-wise team:
+    full-line state I/O, spike words by DPP, bit planes by a butterfly transpose).  Feed-forward and recurrent cells mixed,
+    one cell with the prediction head in its epilogue, cells without previous state (zero page), two indices (block ranges
+    cross cell boundaries), ragged shapes (odd H: half strips; W not a multiple of 32: partial rows)."""
+    B, H, W = shape
+    torch.manual_seed(9)
+    L = _lib.load()
+    nW = (W + 31) // 32
+    cells = []
+    for d, rec, state, pred in ((0, False, True, False), (0, True, True, False), (0, True, False, False), (1, False, False, False),
+                                (1, False, True, True), (1, True, True, False)):
+        x = _bits(B, H, W, 0.3)
+        wff, wrec = _packs()[0], (_packs()[0] if rec else None)
+        leak, thresh = _f(32, scale=0.3) - 1, _f(32, scale=0.1) + 0.4
+        v_prev = _f(B, H, W, C, scale=0.5) if state else None
+        z_prev = _bits(B, H, W, 0.2) if state else None
+        pw, pb = (_f(2, 32, scale=0.2), _f(2, scale=0.1)) if pred else (None, None)
+        cells.append((d, x, wff, wrec, leak, thresh, v_prev, z_prev, pw, pb))
+
+    def outs():
+        return (torch.full((B, H, W, C), 7.0, device=DEV), torch.full((B, H, W), 5, dtype=torch.int32, device=DEV),
+                torch.full((B, H, 32, nW), 5, dtype=torch.int32, device=DEV), torch.full((B, 2, H, W), 7.0, device=DEV))
+
+    def launch(cell, o):
+        d, x, wff, wrec, leak, thresh, v_prev, z_prev, pw, pb = cell
+        v, z, zT, flow = o
+        if pw is None:
+            _lib.call("evf_conv_lif_fwd_b3", P(x), P(wff), P(wrec), P(leak), P(thresh), P(v_prev), P(z_prev), B, H, W, hard, P(v), P(z), P(zT))
+        else:
+            _lib.call("evf_conv_lif_fwd_b3_pred", P(x), P(wff), P(wrec), P(leak), P(thresh), P(v_prev), P(z_prev), B, H, W, hard, P(v), P(z),
+                      P(zT), P(pw), P(pb), P(flow))
+
+    ref = []
+    for cell in cells:
+        o = outs()
+        launch(cell, o)
+        ref.append(o)
+    torch.cuda.synchronize()
+    assert any(int((r[1] != 0).sum()) > 0 for r in ref)  # (the cells do spike)
+    try:
+        for which in (0, 1, 2):
+            assert L.evf_fwd_diag_select(which) == 0
+            got = [outs() for _ in cells]
+            assert _lib.raw("evf_fwd_defer_begin") == 0
+            try:
+                for cell, o in zip(cells, got):
+                    assert _lib.raw("evf_fwd_defer_slot", cell[0]) == 0
+                    launch(cell, o)
+                assert _lib.raw("evf_fwd_defer_pending") == len(cells)
+            finally:
+                _lib.call("evf_fwd_defer_flush")
+            assert _lib.raw("evf_fwd_defer_pending") == 0
+            torch.cuda.synchronize()
+            for k, (o, r, cell) in enumerate(zip(got, ref, cells)):
+                assert torch.equal(o[0], r[0]), (which, k, "v")
+                assert torch.equal(o[1], r[1]), (which, k, "z")
+                assert torch.equal(o[2], r[2]), (which, k, "zT")
+                if cell[8] is not None:
+                    assert torch.equal(o[3], r[3]), (which, k, "flow")
+    finally:
+        L.evf_fwd_diag_select(-1)
+    assert L.evf_fwd_diag_select(7) != 0

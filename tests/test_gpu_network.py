@@ -1159,6 +1159,19 @@ def test_diagonal_launches_short_and_long_windows(monkeypatch, P):
         ps = torch.randint(0, 2, (B, n_ev), generator=gen).float() * 2 - 1
         lists.append(torch.stack([ts, ys, xs, ps], dim=2).to(DEV))
 
+    from event_flow_amd.models.engine import FireNetEngine
+
+    midpass = []  # flushes issued while a backward pass was being recorded: (its tape is still held afterwards)
+    plain_flush = FireNetEngine.flush_backward
+
+    def watched_flush(self):
+        plain_flush(self)
+        cur = self.__dict__.get("_bdefer_cur")
+        if cur is not None:
+            midpass.append(any(e is cur for e in self._bdefer_keep))
+
+    monkeypatch.setattr(FireNetEngine, "flush_backward", watched_flush)
+
     def run(defer):
         monkeypatch.setattr(htrain, "DEFER_FORWARD", defer)
         monkeypatch.setattr(htrain, "DEFER_BACKWARD", defer)
@@ -1179,6 +1192,9 @@ def test_diagonal_launches_short_and_long_windows(monkeypatch, P):
         return float(loss.detach()), N(opt.flat_grad).copy()
 
     (l0, g0), (l1, g1) = run(False), run(True)
+    # the overflow flush of the 50-pass window happens in the MIDDLE of a pass: the cells that pass records afterwards point
+    # into its tape, which must therefore stay referenced (a freed tape = silently corrupted gradients)
+    assert all(midpass) and (len(midpass) >= 1) == (P == 50), midpass
     np.testing.assert_allclose(l1, l0, rtol=1e-6)  # (bit-identical flows; the loss sums its images with float atomics)
     assert np.isfinite(g0).all() and np.linalg.norm(g0) > 0
     assert np.linalg.norm(g1 - g0) <= 1e-4 * np.linalg.norm(g0)

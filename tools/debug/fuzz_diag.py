@@ -39,7 +39,7 @@ def run(defer, lists, H, W, seed):
         model.detach_states()
         lossf.reset()
         opt.zero_grad()
-    assert _lib.load().evf_fwd_defer_pending() == 0 and _lib.load().evf_bwd_defer_pending() == 0
+    assert _lib.raw("evf_fwd_defer_pending") == 0 and _lib.raw("evf_bwd_defer_pending") == 0
     return out
 
 
