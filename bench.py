@@ -101,9 +101,10 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def make_windows(rank, n_pool, dev, slices=1):
-    """n_pool windows, each PASSES event lists [B,1500,4] (platform-stable synthetic events).  slices > 1: every window as
-    `slices` lists of pass lists over contiguous batch ranges (the micro-batches of train.StreamReplicas)."""
+def make_windows(rank, n_pool, dev, slices=1, kind="uniform"):
+    """n_pool windows, each PASSES event lists [B,1500,4] (platform-stable synthetic events; kind: synthetic.event_list_batch).
+    slices > 1: every window as `slices` lists of pass lists over contiguous batch ranges (the micro-batches of
+    train.StreamReplicas)."""
     from event_flow_amd import synthetic
 
     pool = []
@@ -111,7 +112,8 @@ def make_windows(rank, n_pool, dev, slices=1):
         lists = []
         for k in range(PASSES):
             seed0 = synthetic.seed_for(CONFIG_ID, rank, 0) + 100000 * wdx + 1000 * k
-            lists.append(synthetic.event_list_batch(B_PER_GPU, EV_PER_PASS, H, W, seed0))
+            ev = synthetic.event_list_batch(B_PER_GPU, EV_PER_PASS, H, W, seed0, kind=kind)
+            lists.append(ev[0] if isinstance(ev, tuple) else ev)  # (moving_dots also returns its ground-truth motion)
         # one resident buffer [B,P,N,4] per window, the passes are its slices [:, p]: the binning kernel and the loss read the
         # window in place (no torch.stack / torch.cat in the step)
         window = torch.from_numpy(np.ascontiguousarray(np.stack(lists, 1))).to(dev)
@@ -301,6 +303,44 @@ def _pmc(entry):
         return None, "kernel not in the PMC pass"
     return {"MB_per_launch": round(t["fetch_MB"] + t["write_MB"], 2), "fetch_MB": t["fetch_MB"], "write_MB": t["write_MB"],
             "mfma_busy_pct": t.get("mfma_busy_pct"), "source": os.path.basename(files[-1]), "src_hash": d["src_hash"]}, None
+
+
+def gpu_forward_loss_line(model, lossf, pool, reps=None, reps_n=20):
+    """BASELINE configs[1]: LIF-FireNet forward + IWE (contrast-maximisation) loss, 128x128, 15k events / window, batch 8 -- the
+    forward half of the headline step on the same windows, timed with the wall clock around `reps_n` windows."""
+    from event_flow_amd.train import window_forward_loss
+
+    if reps is not None:
+        return {"skipped": "micro-batch pipelining is on (--streams)"}
+    enc = [_encode(p) for p in pool]
+    for i in range(3):
+        window_forward_loss(model, lossf, enc[i % len(enc)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(reps_n):
+        loss = window_forward_loss(model, lossf, enc[i % len(enc)])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps_n
+    return {"workload": "LIF-FireNet forward + CM loss only (10 passes x 1500 events, 128x128, batch 8; BASELINE configs[1])",
+            "value": B_PER_GPU / dt, "unit": "event-windows/s", "ms_per_window_batch": dt * 1e3, "launch": "eager", "loss": float(loss),
+            "binning": "outside the timed region (the events are binned once per window batch before it)"}
+
+
+def parity_report_status():
+    """The committed parity report (profiles/rNN_parity_report.txt, tools/parity_report.sh) is stamped with the hash of the
+    kernel sources it measured: distances of other sources are STALE, and the line says so."""
+    import glob
+    import re
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_report.txt")))
+    if not files:
+        return {"file": None}
+    f = files[-1]
+    m = re.search(r"^# kernel sources: ([0-9a-f]+)", open(f).read(), re.M)
+    cur = source_hash()
+    return {"file": os.path.relpath(f, ROOT), "kernel_sources": m.group(1) if m else None, "current_sources": cur,
+            "stale": (m.group(1) != cur) if m else True}
 
 
 def cpu_model():
@@ -633,6 +673,15 @@ def main():
     dp = DataParallel(device=dev)
     if dp.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={dp.world}: launch with torch.distributed.run")
+    if dp.active:
+        # fail fast, with the reason, when the process group did not come up with one rank per requested GPU (the bench line's
+        # `ranks` below is what torch.distributed reports after init, never the environment's word)
+        import torch.distributed as _dist
+
+        ranks = _dist.get_world_size() if _dist.is_initialized() else 0
+        if ranks != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus}: the {dp.backend} process group has {ranks} rank(s) after init (expected {args.gpus}); "
+                             "check the launcher (one process per GPU, MASTER_ADDR=127.0.0.1) and HSA_ENABLE_IPC_MODE_LEGACY=0")
 
     torch.manual_seed(0)  # identical replicas on every rank
     model = getattr(models, wl["model"])(dict(MODEL_CFG)).to(dev)
@@ -703,6 +752,8 @@ def main():
     if graphs is None:
         _lib.profile_start(names)
         _lib.load().evf_defer_profile(1)
+    if dp.active:
+        dp.time_reduces(True)
     t0 = time.perf_counter()
     loss = None
     for i in range(args.steps):
@@ -713,6 +764,9 @@ def main():
     torch.cuda.synchronize()
     dp.barrier()
     elapsed = time.perf_counter() - t0
+    reduce_ms = dp.reduce_times_ms() if dp.active else []
+    if dp.active:
+        dp.time_reduces(False)
     if graphs is None:
         prof = _lib.profile_stop()
         prof_steps = args.steps
@@ -862,9 +916,15 @@ def main():
         traffic = int(detail["MB_per_launch"] * 1e6) if detail else None  # HBM bytes per launch (PMC), next to ...
         algo = int(dom["algorithmic_MB"] * 1e6) if "algorithmic_MB" in dom else None  # ... the algorithmic bytes per launch
         if dom["bound"] == "hbm":
-            roof = {"kernel": "/".join(k for k in dom_key if k), "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK,
-                    "unit": "GB/s", "frac": dom["frac_of_hbm_peak"], "traffic": traffic, "traffic_unit": "bytes/launch",
-                    "algorithmic_bytes": algo, "traffic_detail": detail if detail else {"unavailable": why_not},
+            # `achieved` / `frac` price the launch with its COMPULSORY bytes (every tensor once in the fp32 layout:
+            # dL/d(current) as 128 B/px).  What the kernel really moves in the layout it uses (that tensor as three bf16 planes,
+            # 192 B/px) is reported beside it as *_layout.
+            comp_frac = dom.get("frac_fp32_layout", dom["frac_of_hbm_peak"])
+            comp_bytes = int(dom["algorithmic_MB_fp32_layout"] * 1e6) if "algorithmic_MB_fp32_layout" in dom else algo
+            roof = {"kernel": "/".join(k for k in dom_key if k), "bound": "hbm", "achieved": comp_frac * HBM_PEAK, "peak": HBM_PEAK,
+                    "unit": "GB/s", "frac": comp_frac, "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "algorithmic_bytes": comp_bytes, "frac_layout": dom["frac_of_hbm_peak"], "achieved_layout": dom["GBps"],
+                    "algorithmic_bytes_layout": algo, "traffic_detail": detail if detail else {"unavailable": why_not},
                     "mfma_busy_pct": detail["mfma_busy_pct"] if detail else None,
                     "issued_bf16_TFLOPs": dom.get("issued_bf16_TFLOPs"), "frac_of_bf16_peak": dom.get("frac_of_bf16_peak"),
                     "note": "bf16x3 kernel (exact 3-way bf16 split, fp32 accumulate): matrix work is 1/5 of the fp32-MFMA form, "
@@ -894,8 +954,13 @@ def main():
                                       "kernels[*] / roofline are per LAUNCH of a micro-batch, timed one at a time; in the replayed "
                                       "step two such launches are in flight" if nstream > 1 else None),
                        "collective": ({"backend": dp.backend, "library": "RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
-                                       if dp.backend == "nccl" else dp.backend, "ranks": dp.world,
+                                       if dp.backend == "nccl" else dp.backend,
+                                       "ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else dp.world,
                                        "per_step": "1 SUM all-reduce of [flat gradient | loss | new_seq] = %d bytes" % (opt.comm.numel() * 4),
+                                       # the collective's own device time (HIP events on its stream around every all-reduce of
+                                       # the timed region, this rank): what a scaling run has to compare its step time with
+                                       "all_reduce_us": ({"mean": float(np.mean(reduce_ms) * 1e3), "max": float(np.max(reduce_ms) * 1e3),
+                                                          "n": len(reduce_ms)} if reduce_ms else None),
                                        "forced_at_one_rank": dp.world == 1}
                                       if dp.active else
                                       {"backend": dp.backend, "library": ("RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -934,13 +999,21 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(threads, name=wl["model"])
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        out["parity_report"] = parity_report_status()
+        if dp.world == 1 and args.config == "c3":
+            # BASELINE configs[1] on the GPU side (the CPU side: cpu_baseline.extra.fwd_loss_windows_per_s): forward passes + CM loss of
+            # the same windows, no backward, no optimizer step; eager launches (the recorded diagonal forward), after the timed region
+            try:
+                out.setdefault("other_configs", {})["c2"] = gpu_forward_loss_line(model, lossf, pool, reps)
+            except Exception as e:  # noqa: BLE001
+                out.setdefault("other_configs", {})["c2"] = {"error": f"{type(e).__name__}: {e}"}
         if dp.world == 1 and args.config == "c3" and not args.no_others:
             # BASELINE configs[3] / configs[4] next to the headline: short runs in their own processes AFTER everything of the
             # c3 line has been measured (this process only waits meanwhile)
             torch.cuda.synchronize()
-            out["other_configs"] = {"c4": other_config_line("c4"), "c5": other_config_line("c5"),
+            out.setdefault("other_configs", {}).update({"c4": other_config_line("c4"), "c5": other_config_line("c5"),
                                     "note": "`python bench.py --config c4|c5 --steps 10 --warmup 3`, one process each, run after the c3 "
-                                            "line's timed region and side measurements; full lines: profiles/"}
+                                            "line's timed region and side measurements; full lines: profiles/"})
         print(json.dumps(out), flush=True)
     dp.barrier()
     dp.close()

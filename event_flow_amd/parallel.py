@@ -88,7 +88,30 @@ class DataParallel:
     def reduce(self, comm):
         """THE collective of a step: in-place SUM all-reduce of gradient + tail."""
         if self.active:
-            self._on_comm_stream(lambda: dist.all_reduce(comm, op=dist.ReduceOp.SUM))
+            if self.__dict__.get("_timed") is not None and comm.is_cuda:
+                # (bench.py: the collective's own device time, HIP events on the stream it runs on)
+                def timed():
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    dist.all_reduce(comm, op=dist.ReduceOp.SUM)
+                    e1.record()
+                    self._timed.append((e0, e1))
+
+                self._on_comm_stream(timed)
+            else:
+                self._on_comm_stream(lambda: dist.all_reduce(comm, op=dist.ReduceOp.SUM))
+
+    def time_reduces(self, on=True):
+        """Bracket every reduce() with HIP events on the communication stream (never inside a graph capture: the all-reduce of a
+        step is an eager launch between the step's two graphs)."""
+        self._timed = [] if on else None
+
+    def reduce_times_ms(self):
+        """Device time of the bracketed reduces so far (synchronises)."""
+        ev = self.__dict__.get("_timed") or []
+        if ev:
+            torch.cuda.synchronize()
+        return [e0.elapsed_time(e1) for e0, e1 in ev]
 
     def staged(self, comm):
         n = comm.numel() - self.TAIL

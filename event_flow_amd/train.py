@@ -173,6 +173,28 @@ def window_backward(model, loss_function, optimizer, passes, dp=None):
     return loss
 
 
+def window_forward_loss(model, loss_function, passes):
+    """The passes of a window and its loss WITHOUT a backward pass and without an optimizer step (BASELINE.json configs[1]:
+    forward + IWE loss; eval-style timing).  Runs in grad mode so that the hidden cells take the recorded diagonal launches
+    like a training window; the window is dropped afterwards (states carried, graph discarded).  Returns the 0-d loss."""
+    defer = DEFER_FORWARD and hasattr(model, "defer_forward")
+    if defer:
+        model.defer_forward(True)
+    try:
+        for d in passes:
+            x = model(d["event_voxel"], d["event_cnt"])
+            loss_function.event_flow_association(x["flow"], d["event_list"], d["event_list_pol_mask"], d["event_mask"])
+    finally:
+        if defer:
+            model.defer_forward(False)
+    if loss_function.overwrite_intermediate:
+        loss_function.overwrite_intermediate_flow(x["flow"])
+    loss = loss_function().detach()
+    model.detach_states()
+    loss_function.reset()
+    return loss
+
+
 def window_apply(model, loss_function, optimizer, loss, dp=None):
     """Second half: clip + Adam on the (reduced) gradient, state detach, loss reset
     (train_flow.py:157-171).  Returns the 0-d (global) loss tensor."""

@@ -83,7 +83,7 @@ def _flip_report(hip_states_per_pass, ora_states_per_pass):
     return flips, per_pass, top_diff
 
 
-def _check_against_oracle(tag, hip, ora, H, W, gt_uv=(3.0, -2.0)):
+def _check_against_oracle(tag, hip, ora, H, W, gt_uv=(3.0, -2.0), flip_bar=True):
     """hip: dict(flows, states (per pass), loss, grads {name: ndarray}).  Prints the whole report, then asserts the bars."""
     flips, per_pass, top_diff = _flip_report(hip["states"], ora["states"])
     nflip, B = sum(flips), hip["flows"][0].shape[0]
@@ -122,10 +122,12 @@ def _check_against_oracle(tag, hip, ora, H, W, gt_uv=(3.0, -2.0)):
     print(f"[{tag}] gradient rel-L2 {grel:.3e} (|g| = {gn:.4e}); worst tensor {worst[0]} {worst[1]:.3e}")
     # --- the bars.  Flips in the FIRST pass have no earlier cause: they are fp32 round-off ties (|v - thresh| at the
     # last bit); later counts include what the recurrent dynamics make of them and are only bounded loosely.
-    assert flips[0] <= 2e-6 * per_pass and nflip <= 1e-3 * per_pass * len(flips), (flips, per_pass)
+    if flip_bar:
+        assert flips[0] <= 2e-6 * per_pass and nflip <= 1e-3 * per_pass * len(flips), (flips, per_pass)
     assert worst_flow <= 1e-4, worst_flow
     return {"nflip": nflip, "loss_rel": lrel, "grad_rel": grel, "worst_tensor": worst, "gn": gn, "masked_frac": masked / (B * H * W),
-            "aee_rel": worst_aee}
+            "aee_rel": worst_aee, "flips": flips, "per_pass": per_pass, "fmax": fmax, "flow_rel_masked": worst_flow,
+            "flow_rel_all": worst_flow_all}
 
 
 def _eager_step(model, lossf, opt, passes):
@@ -164,7 +166,11 @@ def _clone_from(cls, cfg, snap, precision=None):
     return m, opt
 
 
-def test_benched_workload_two_graph_replay_vs_oracle():
+def _benched_protocol(thresh_scale, kind):
+    """bench.py's timed cycle -- eager warm-up, the step captured as two hipGraphs (diagonal launches of the persistent forward /
+    backward kernels inside), graph 0 then graph 1 replayed with the copy-free state hand-over -- every replayed step checked
+    against the oracle from the same snapshot.  thresh_scale < 1 / kind = "moving_dots": the network is ALIVE (spikes in every
+    layer, gradient signal in most weights), which the default thresholds on uniform events do not give."""
     import bench
     from event_flow_amd.parallel import DataParallel
 
@@ -173,12 +179,17 @@ def test_benched_workload_two_graph_replay_vs_oracle():
     torch.manual_seed(0)
     model = LIFFireNet(dict(bench.MODEL_CFG)).to(DEV)
     model.precision = "bf16x3"
+    if thresh_scale != 1.0:
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                if k.endswith("thresh"):
+                    p.mul_(thresh_scale)
     model.train()
     lossf = EventWarping(bench.LOSS_CFG, DEV)
     opt = FlatAdam(model, lr=2e-4, clip=100.0, device_step=True)
     opt.zero_grad()
     model.use_static_states(True)
-    pool = bench.make_windows(0, 2, DEV)
+    pool = bench.make_windows(0, 2, DEV, kind=kind)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     lcfg = {"flow_regul_weight": 0.001, "mask_output": True}
@@ -197,20 +208,36 @@ def test_benched_workload_two_graph_replay_vs_oracle():
     torch.cuda.current_stream().wait_stream(side)
 
     snap = snap0
+    reports = []
     for gi in range(2):
         passes = bench._encode(pool[gi])
         ora = _oracle_step("LIFFireNet", snap, passes, (H, W), lcfg)
         # the same step eagerly from the same snapshot: exposes flows / states / gradient of the HIP path
         m2, o2 = _clone_from(LIFFireNet, bench.MODEL_CFG, snap, "bf16x3")
         hip = _eager_step(m2, EventWarping(bench.LOSS_CFG, DEV), o2, passes)
-        rep_o = _check_against_oracle(f"bench workload, replay {gi}", hip, ora, H, W)
+        alive = thresh_scale != 1.0 or kind != "uniform"
+        rep_o = _check_against_oracle(f"bench workload x{thresh_scale} {kind}, replay {gi}", hip, ora, H, W, flip_bar=not alive)
         nflip = rep_o["nflip"]
-        assert rep_o["masked_frac"] <= 1e-3 and rep_o["aee_rel"] <= 1e-4, rep_o
-        assert rep_o["loss_rel"] <= (1e-5 if nflip == 0 else 1e-4), rep_o
-        assert rep_o["grad_rel"] <= 1e-3, rep_o  # unconditionally: the flips of this workload stay local
-        for k in ora["keys"]:  # every tensor: 1e-3 of its own norm (+ 1e-4 of the whole gradient for the tiny ones)
-            ref, got = ora["grads"][k].numpy(), hip["grads"][k]
-            assert np.linalg.norm(got - ref) <= 1e-3 * np.linalg.norm(ref) + 1e-4 * rep_o["gn"], k
+        # census of what the step exercised: spikes per layer of the last pass, weights that carry gradient signal
+        rates = [float(x.mean()) for x in ora["states"][-1]]
+        gref_all = torch.cat([ora["grads"][k].reshape(-1) for k in ora["keys"]]).numpy()
+        nsig = int((np.abs(gref_all) > 1e-3 * np.abs(gref_all).max()).sum())
+        print(f"[census] spike rate per layer (last pass) {[f'{r:.4f}' for r in rates]}; {nsig} of {gref_all.size} weights with |g| > 1e-3 max|g|; "
+              f"max |flow| {rep_o['fmax']:.3e}; flips {rep_o['flips']} of {rep_o['per_pass']} per pass")
+        reports.append(dict(rep_o, replay=gi, rates=rates, nsig=nsig, nweights=int(gref_all.size)))
+        if alive:
+            assert min(rates[:4]) > 1e-3 and nsig > 0.2 * gref_all.size, (rates, nsig)  # (the point of these cases)
+            # flow <= 1e-4 outside the flipped cone: asserted in _check_against_oracle.  A flipped neuron changes the loss and the
+            # gradient for real (the Heaviside is discontinuous): tight bars when nothing flipped, the census + loose bounds else
+            assert rep_o["loss_rel"] <= (1e-4 if nflip == 0 else 2e-2), rep_o
+            assert rep_o["grad_rel"] <= (1e-3 if nflip == 0 else 0.5), rep_o
+        else:
+            assert rep_o["masked_frac"] <= 1e-3 and rep_o["aee_rel"] <= 1e-4, rep_o
+            assert rep_o["loss_rel"] <= (1e-5 if nflip == 0 else 1e-4), rep_o
+            assert rep_o["grad_rel"] <= 1e-3, rep_o  # unconditionally: the flips of this workload stay local
+            for k in ora["keys"]:  # every tensor: 1e-3 of its own norm (+ 1e-4 of the whole gradient for the tiny ones)
+                ref, got = ora["grads"][k].numpy(), hip["grads"][k]
+                assert np.linalg.norm(got - ref) <= 1e-3 * np.linalg.norm(ref) + 1e-4 * rep_o["gn"], k
         # (1) hipGraph replay == eager step (same kernels, same order; fp32 atomics in the loss may reorder)
         rep = results[gi]
         assert abs(rep["loss"] - hip["loss"]) <= 1e-6 * abs(hip["loss"]), (rep["loss"], hip["loss"])
@@ -229,8 +256,21 @@ def test_benched_workload_two_graph_replay_vs_oracle():
         sig = np.abs(gref) > 1e-3 * np.abs(gref).max()
         rel_sig = np.linalg.norm((upd - upd_ref)[sig]) / np.linalg.norm(upd_ref[sig])
         print(f"[replay {gi}] parameter update vs oracle: rel-L2 {rel:.3e} over all {upd.size} weights, {rel_sig:.3e} over the {int(sig.sum())} with signal")
-        assert rel <= 0.15 and rel_sig <= 1e-2, (rel, rel_sig)
+        if not alive or nflip == 0:
+            assert rel <= 0.15 and rel_sig <= 1e-2, (rel, rel_sig)
         snap = rep["snap"]  # the next replay starts from what this one left (states handed over without a copy)
+    return reports
+
+
+def test_benched_workload_two_graph_replay_vs_oracle():
+    _benched_protocol(1.0, "uniform")
+
+
+@pytest.mark.parametrize("thresh_scale,kind", [(0.25, "uniform"), (0.5, "moving_dots")])
+def test_benched_workload_with_the_network_alive_vs_oracle(thresh_scale, kind):
+    """The same 10-pass two-graph replay, persistent diagonal launches at full depth, on a network that spikes in every layer:
+    thresholds x 0.25 on the benched uniform events, and a `moving_dots` window (coherent motion) at thresholds x 0.5."""
+    _benched_protocol(thresh_scale, kind)
 
 
 @pytest.mark.parametrize("scale", [1.0, 0.25])
@@ -320,7 +360,7 @@ def test_config4_evflownet_full_size_vs_oracle(scale):
                                                      loss_cfg={"flow_regul_weight": 0.001, "mask_output": True}, model_cfg={"kind": "lif"})
     og = torch.autograd.grad(oloss_t, [leaves[k] for k in keys], allow_unused=True, retain_graph=True)
     nflip = ntot = 0
-    per_state = []
+    per_state, zdiff = [], []
     for s in range(10):
         ref = ostates[s]
         ref = torch.stack([torch.stack(t) for t in ref]) if isinstance(ref[0], tuple) else torch.stack(ref)
@@ -329,12 +369,26 @@ def test_config4_evflownet_full_size_vs_oracle(scale):
         z_ref = ref[..., 1, :, :, :, :] if ref.ndim == 6 else ref[1]
         nflip += int((z_got != z_ref).sum())
         per_state.append((int((z_got != z_ref).sum()), int(z_ref.sum()), z_ref.size))
+        zdiff.append(z_got != z_ref)
         ntot += z_ref.size
     print(f"[config 4 full size, thresholds x{scale}] per state (flips, oracle spikes, neurons): {per_state}")
-    worst = 0.0
-    for f, fr in zip(out["flow"], oflows[0]):
+    # The flow of scale i is tanh(1x1 conv) of decoder i's output spikes (models/unet.py:445-456), up-sampled to the input
+    # resolution: a flipped neuron anywhere below reaches flow map i only through the pixels where decoder i's spike vector
+    # differs.  Outside that cone the maps must agree to round-off.
+    worst = worst_masked = 0.0
+    cone = []
+    for i, (f, fr) in enumerate(zip(out["flow"], oflows[0])):
         fr = fr.detach().numpy()
-        worst = max(worst, float(np.linalg.norm(N(f) - fr) / max(np.linalg.norm(fr), 1e-20)))
+        dz = zdiff[6 + i]  # decoder i: [B, C, h, w]
+        assert dz.ndim == 4 and H % dz.shape[2] == 0 and W % dz.shape[3] == 0, dz.shape
+        m = dz.any(axis=1)
+        m = np.repeat(np.repeat(m, H // m.shape[1], axis=1), W // m.shape[2], axis=2)  # the nearest up-sampling of the flow map
+        keep = np.broadcast_to(~m[:, None], fr.shape)
+        den_ = max(np.linalg.norm(fr), 1e-20)
+        worst = max(worst, float(np.linalg.norm(N(f) - fr) / den_))
+        worst_masked = max(worst_masked, float(np.linalg.norm((N(f) - fr)[keep]) / den_))
+        cone.append(int(m.sum()))
+    print(f"  flow rel-L2 outside the flipped cone (worst of 4 scales) {worst_masked:.3e}; cone pixels per scale {cone} of {B * H * W}")
     lrel = abs(float(loss.detach()) - float(oloss_t.detach())) / abs(float(oloss_t.detach()))
     num = den = 0.0
     per_key = []
@@ -361,7 +415,7 @@ def test_config4_evflownet_full_size_vs_oracle(scale):
         # utils/iwe.py:48-62): a 1e-7 difference in the flow moves a handful of the 400 k events across a boundary and the
         # gradient by sqrt(handful / events) ~ 1 % (measured: the ORACLE's own dL/dflow on our flow maps differs by 2 % from
         # its dL/dflow on its flow maps).  So the two derivatives are checked where each is well defined:
-        assert worst <= 1e-4 and lrel <= 1e-5 and grel <= 5e-2, (worst, lrel, grel)
+        assert worst <= 1e-4 and worst_masked <= 1e-4 and lrel <= 1e-5 and grel <= 5e-2, (worst, lrel, grel)
         # (1) loss derivative: the oracle's loss on OUR flow maps (as leaves) against our dL/dflow
         from oracle import loss as oloss_mod
 
@@ -384,6 +438,9 @@ def test_config4_evflownet_full_size_vs_oracle(scale):
         print(f"  same upstream gradient through both networks: parameter gradient rel-L2 {grel2:.3e}")
         assert grel2 <= 1e-3, grel2
     elif scale == 1.0 or nflip <= 1e-6 * ntot:  # configured thresholds (unconditionally), or a few isolated flips: every flow
-        assert worst <= 5e-3 and lrel <= 1e-5 and grel <= 1e-3, (worst, lrel, grel)  # map is exact except at those pixels
+        # map is exact (north_star: 1e-4) except inside the flipped neurons' cone, whose size is bounded
+        assert worst_masked <= 1e-4 and max(cone) <= 1e-4 * B * H * W, (worst_masked, cone)
+        assert worst <= 5e-3 and lrel <= 1e-5 and grel <= 1e-3, (worst, lrel, grel)
     else:  # high-activity stress case (thresholds x0.3): flips spread through 14 layers; loose aggregate bounds only
+        assert worst_masked <= 1e-4, worst_masked
         assert worst <= 0.5 and lrel <= 1e-3 and grel <= 0.25, (worst, lrel, grel)

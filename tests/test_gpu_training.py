@@ -186,6 +186,23 @@ def test_rccl_code_path_on_one_rank_graph_equals_eager_and_plain_step():
     assert lg == lg and abs(lg - le) <= 2e-3 * abs(le) and abs(lg - lp) <= 2e-3 * abs(lp), (lg, le, lp)
 
 
+def test_two_graph_rccl_step_is_bitwise_the_one_graph_step():
+    """What a rank replays in a multi-GPU run (two hipGraphs around the eager RCCL all-reduce, forced at world size 1) leaves
+    EXACTLY the parameters, Adam moments and recurrent states of the single-GPU one-graph step (deterministic loss, no clipping):
+    tools/dp_two_graph_check.py in its own process (nccl process group)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29657")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "EVF_DP_FORCE", "EVF_DP_BACKEND"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_two_graph_check.py")], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    print(res)
+    assert res["one_graph_step_is_one_graph"] and res["forced_step_is_two_graphs"] and res["backend"] == "nccl", res
+    assert res["updates"] == [6.0, 6.0] and max(res["grad_norm"]) < 100.0 and res["trained"], res  # (2 eager + 4 replayed, unclipped)
+    assert res["params_bitwise_equal"] and res["moments_bitwise_equal"] and res["states_bitwise_equal"], res
+
+
 def test_bench_starts_its_own_ranks_without_a_launcher():
     """`python bench.py --gpus 2` with WORLD_SIZE unset (how the driver invokes it) re-executes itself under
     torch.distributed.run with one rank per GPU and prints ONE JSON line with n_gpus = 2."""
