@@ -305,26 +305,49 @@ def _pmc(entry):
             "mfma_busy_pct": t.get("mfma_busy_pct"), "source": os.path.basename(files[-1]), "src_hash": d["src_hash"]}, None
 
 
-def gpu_forward_loss_line(model, lossf, pool, reps=None, reps_n=20):
+def gpu_forward_loss_line(wl, dev, pool, precision, reps_n=20):
     """BASELINE configs[1]: LIF-FireNet forward + IWE (contrast-maximisation) loss, 128x128, 15k events / window, batch 8 -- the
-    forward half of the headline step on the same windows, timed with the wall clock around `reps_n` windows."""
+    forward half of the headline step on the same windows (binning, 10 passes, loss; no backward, no optimizer step), on a model
+    instance of its own, replayed from one hipGraph per window like the headline step and timed with the wall clock."""
+    from event_flow_amd.loss.flow import EventWarping
+    from event_flow_amd.models import model as models
     from event_flow_amd.train import window_forward_loss
 
-    if reps is not None:
-        return {"skipped": "micro-batch pipelining is on (--streams)"}
-    enc = [_encode(p) for p in pool]
+    torch.manual_seed(0)
+    net = getattr(models, wl["model"])(dict(MODEL_CFG)).to(dev)
+    net.precision = precision
+    net.train()
+    lossf = EventWarping(LOSS_CFG, dev)
+    net.use_static_states(True)  # (recurrent state at fixed addresses across replays; copied at the window boundary)
+    cur = torch.cuda.current_stream()
     for i in range(3):
-        window_forward_loss(model, lossf, enc[i % len(enc)])
+        window_forward_loss(net, lossf, _encode(pool[i % len(pool)]))
+    torch.cuda.synchronize()
+    graphs, losses, mode = [], [], "hipgraph"
+    try:
+        for lists in pool:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cur):
+                losses.append(window_forward_loss(net, lossf, _encode(lists)))
+            graphs.append(g)
+        for i in range(2):
+            graphs[i % len(graphs)].replay()
+    except Exception as e:  # noqa: BLE001 -- capture unsupported here: eager launches
+        print(f"[bench] c2: hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+        graphs, mode = [], "eager"
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loss = None
     for i in range(reps_n):
-        loss = window_forward_loss(model, lossf, enc[i % len(enc)])
+        if graphs:
+            graphs[i % len(graphs)].replay()
+            loss = losses[i % len(graphs)]
+        else:
+            loss = window_forward_loss(net, lossf, _encode(pool[i % len(pool)]))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps_n
-    return {"workload": "LIF-FireNet forward + CM loss only (10 passes x 1500 events, 128x128, batch 8; BASELINE configs[1])",
-            "value": B_PER_GPU / dt, "unit": "event-windows/s", "ms_per_window_batch": dt * 1e3, "launch": "eager", "loss": float(loss),
-            "binning": "outside the timed region (the events are binned once per window batch before it)"}
+    return {"workload": "LIF-FireNet forward + CM loss only (binning, 10 passes x 1500 events, 128x128, batch 8; BASELINE configs[1])",
+            "value": B_PER_GPU / dt, "unit": "event-windows/s", "ms_per_window_batch": dt * 1e3, "launch": mode, "loss": float(loss)}
 
 
 def parity_report_status():
@@ -1004,7 +1027,8 @@ def main():
             # BASELINE configs[1] on the GPU side (the CPU side: cpu_baseline.extra.fwd_loss_windows_per_s): forward passes + CM loss of
             # the same windows, no backward, no optimizer step; eager launches (the recorded diagonal forward), after the timed region
             try:
-                out.setdefault("other_configs", {})["c2"] = gpu_forward_loss_line(model, lossf, pool, reps)
+                out.setdefault("other_configs", {})["c2"] = (gpu_forward_loss_line(wl, dev, pool, model_precision) if reps is None else
+                                                             {"skipped": "micro-batch pipelining is on (--streams)"})
             except Exception as e:  # noqa: BLE001
                 out.setdefault("other_configs", {})["c2"] = {"error": f"{type(e).__name__}: {e}"}
         if dp.world == 1 and args.config == "c3" and not args.no_others:

@@ -48,6 +48,8 @@ HEAD_WIN = os.environ.get("EVF_HEAD_WIN", "1") != "0"
 PRED_FUSED = os.environ.get("EVF_PRED_FUSED", "1") != "0"  # prediction head in the epilogue of the last layer's forward
 TOP_FUSED = os.environ.get("EVF_TOP_FUSED", "1") != "0"  # prediction-head backward inside the top layer's fused backward
 PAIR_DGRAD = os.environ.get("EVF_PAIR_DGRAD", "1") != "0"
+# window gradients -> the flat gradient buffer in one launch (evf_grads_finalize); 0: row sums, slab reduction, segment add one by one
+FUSED_TAIL = os.environ.get("EVF_FUSED_TAIL", "1") != "0"
 PARAM_ROWS = os.environ.get("EVF_PARAM_ROWS", "1") != "0"  # per-channel gradients through per-block rows (0: atomics)  # ff + rec input gradients of a recurrent cell in one launch
 
 
@@ -702,6 +704,44 @@ class FireNetEngine:
                 win.gz_has[i - 1] = True
         self._bdefer_cur = None  # (the pass is recorded completely; its entry stays in _bdefer_keep until the flush)
 
+    def _finalize_fused(self, win, nslab):
+        """Every partial sum of the window -> the optimizer's flat gradient buffer in ONE launch (csrc/evf_step_tail.hip); only
+        when every trainable parameter's .grad is bound to that buffer (FlatAdam).  False: the caller takes the step-by-step path."""
+        if not hip_ops.DIRECT_PARAM_GRADS:
+            return False
+        red_src, red_dst, seg_dst, seg_off, seg_n = [], [], [], [], []
+        for name, p in zip(self.pnames, self.params):
+            if not p.requires_grad:
+                continue
+            if not (p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.is_cuda):
+                return False
+            if name in self.small_off:
+                seg_dst.append(p.grad)
+                seg_off.append(self.small_off[name][0])
+                seg_n.append(self.small_off[name][1])
+            else:
+                i, nm = name.split(".")
+                if win.slab_init.get((int(i), nm)):
+                    red_src.append(self._slabs[(int(i), nm)])
+                    red_dst.append(p.grad)
+        if len(red_src) > 16 or len(seg_dst) > 32 or not seg_dst:
+            return False
+        head = self._slabs[(0, "ff")] if ("0.ff" in self.small_off and win.slab_init.get((0, "ff"))) else None
+        rows = win.rows
+        n1, n2 = len(red_src), len(seg_dst)
+        _lib.call("evf_grads_finalize", (ctypes.c_void_p * max(n1, 1))(*[t.data_ptr() for t in red_src]),
+                  (ctypes.c_void_p * max(n1, 1))(*[t.data_ptr() for t in red_dst]), n1, nslab, _lib.ptr(win.small),
+                  1 if win.small_persistent else 0, _lib.ptr(rows), rows.shape[0] if rows is not None else 0,
+                  rows.shape[1] if rows is not None else 0, _lib.ptr(head), head.shape[0] if head is not None else 0,
+                  head.shape[1] if head is not None else 0, self.small_off["0.ff"][0] if head is not None else 0,
+                  (ctypes.c_void_p * n2)(*[t.data_ptr() for t in seg_dst]), (ctypes.c_int * n2)(*seg_off), (ctypes.c_int * n2)(*seg_n), n2)
+        if rows is not None:
+            self._rows_clean = True
+        if win.small_persistent:
+            self._small_clean = True
+        self._last_window = win
+        return True
+
     def _finalize(self, win):
         """Window complete: reduce the weight-gradient slabs, hand all parameter
         gradients to autograd (in self.params order)."""
@@ -710,6 +750,8 @@ class FireNetEngine:
         B, H, W = win.shape
         nslab = (_lib.load().evf_lif_bwd_wgrad_slabs(B, H, W) if self.precision == "bf16x3"
                  else _lib.load().evf_conv_wgrad_slabs(B, H, W))
+        if FUSED_TAIL and self._finalize_fused(win, nslab):
+            return [None] * len(self.params)
         if win.rows is not None:  # per-block partials of the per-channel gradients -> the small accumulator (rows zeroed)
             _lib.call("evf_sum_rows", _lib.ptr(win.rows), win.rows.shape[0], win.rows.shape[1], 1 | 2, _lib.ptr(win.small))
             self._rows_clean = True

@@ -18,6 +18,9 @@ from .dataloader.encodings import encode_event_list, encode_event_lists
 from .models import hip_ops
 
 
+FUSED_ADAM = os.environ.get("EVF_FUSED_ADAM", "1") != "0"
+
+
 class FlatAdam:
     """clip_grad_norm_(max_norm) + Adam(lr, betas, eps) fused on flat buffers.
     Reference semantics: train_flow.py:157-163 with torch.optim.Adam defaults."""
@@ -36,7 +39,8 @@ class FlatAdam:
         self.flat_grad = self.comm[:n]
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.norm_ws = torch.zeros(2, dtype=torch.float32, device=dev)
+        # [0] squared gradient norm of the last step, [1] device-side step counter, [2..4] the fused kernel's running sum / tickets
+        self.norm_ws = torch.zeros(8, dtype=torch.float32, device=dev)
         off = 0
         for p in self.params:
             k = p.numel()
@@ -98,7 +102,8 @@ class FlatAdam:
 
     def step(self):
         self.steps += 1
-        _lib.call("evf_clip_adam_step", _lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.m),
+        # one launch (squared norm, grid hand-shake, clip + Adam + zero_grad; csrc/evf_step_tail.hip); EVF_FUSED_ADAM=0: fill + two
+        _lib.call("evf_clip_adam_fused" if FUSED_ADAM else "evf_clip_adam_step", _lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.m),
                   _lib.ptr(self.v), self.n, float(self.clip) if self.clip is not None else 0.0, float(self.lr),
                   float(self.betas[0]), float(self.betas[1]), float(self.eps), 0 if self.device_step else self.steps,
                   _lib.ptr(self.norm_ws), 1)

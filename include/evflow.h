@@ -624,6 +624,21 @@ int evf_lstm_bwd(const float* g_hidden, const float* g_cell, const float* gates,
 int evf_clip_adam_step(float* param, float* grad, float* m, float* v, int64_t n,
                        float max_norm, float lr, float beta1, float beta2, float eps, int step,
                        float* norm_ws, int zero_grad, void* stream);
+/* The same step in ONE launch (squared norm, a grid-wide hand-shake of <= one block per CU, clip + Adam + zero_grad; no fill).
+ * ws: >= 8 floats, zeroed ONCE by the caller and owned by this entry point afterwards: [0] squared gradient norm of the last
+ * step, [1] the device-side step counter (as norm_ws[1] above), [2..4] the running sum and two tickets, left zero. */
+int evf_clip_adam_fused(float* param, float* grad, float* m, float* v, int64_t n,
+                        float max_norm, float lr, float beta1, float beta2, float eps, int step,
+                        float* ws, int zero_grad, void* stream);
+/* Every partial sum a window's backward leaves behind, added to the (flat) parameter gradients in one launch
+ * (evf_reduce_slabs_multi + evf_sum_rows x 2 + evf_add_segments; train_flow.py:154 loss.backward()'s parameter gradients):
+ *   slabs[t] [nslab][9*32*32] partial sums of conv weight t (nslabs <= 16) -> slab_dst[t] [32][32][3][3] +=;
+ *   total[e] = small[e] + sum_r rows[r][e] (e < ncols; rows zeroed; rows null = none)
+ *                       + sum_r head_rows[r][e - head_off] (head_off <= e < head_off + nhcols; null = none);
+ *   seg_dst[k][i] += total[seg_off[k] + i], i < seg_n[k] (nseg <= 32); clear_small != 0: small[e] = 0 afterwards. */
+int evf_grads_finalize(const void* const* slabs, void* const* slab_dst, int nslabs, int nslab, float* small, int clear_small,
+                       float* rows, int nrows, int ncols, const float* head_rows, int nhrows, int nhcols, int head_off,
+                       void* const* seg_dst, const int* seg_off, const int* seg_n, int nseg, void* stream);
 
 #ifdef __cplusplus
 }

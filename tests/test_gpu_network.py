@@ -1198,3 +1198,52 @@ def test_diagonal_launches_short_and_long_windows(monkeypatch, P):
     np.testing.assert_allclose(l1, l0, rtol=1e-6)  # (bit-identical flows; the loss sums its images with float atomics)
     assert np.isfinite(g0).all() and np.linalg.norm(g0) > 0
     assert np.linalg.norm(g1 - g0) <= 1e-4 * np.linalg.norm(g0)
+
+
+def test_fused_step_tail_equals_the_step_by_step_tail(monkeypatch):
+    """evf_grads_finalize (slab reduction + row sums + segment add in one launch) and evf_clip_adam_fused (squared norm, grid
+    hand-shake, clip + Adam + zero_grad in one launch) against the launches they replace, over three optimizer steps with
+    clipping active: conv-weight gradients bit-equal (the same slab sums in the same order), per-channel gradients and the norm to
+    fp32 round-off (another summation order), the same parameters after every step, the gradient buffer handed back zeroed and
+    the step counter advanced on the device."""
+    from event_flow_amd import train as htrain
+    from event_flow_amd.models import engine as heng
+
+    g = load_golden("g7_liffirenet_lowthresh")
+    H, W = passes_from_golden(g)[0]["event_cnt"].shape[2:]
+
+    def run(fused):
+        monkeypatch.setattr(heng, "FUSED_TAIL", fused)
+        monkeypatch.setattr(htrain, "FUSED_ADAM", fused)
+        model = build_from_golden(g, fix="g7_liffirenet_lowthresh")
+        model.train()
+        lossf = hloss.EventWarping(loss_cfg(H, W), DEV)
+        opt = FlatAdam(model, lr=2e-4, clip=0.5, device_step=True)  # (clip well below the gradient norm: the coefficient matters)
+        opt.zero_grad()
+        out = []
+        for _ in range(3):
+            loss = htrain.window_backward(model, lossf, opt, passes_from_golden(g))
+            grad = N(opt.flat_grad).copy()
+            htrain.window_apply(model, lossf, opt, loss)
+            torch.cuda.synchronize()
+            assert float(opt.flat_grad.abs().max()) == 0.0  # zero_grad folded into the step
+            out.append((float(loss), grad, opt.grad_norm(), N(opt.flat_param).copy(), float(opt.norm_ws[1])))
+        if fused:
+            assert float(opt.norm_ws[2:5].abs().max()) == 0.0  # (running sum and tickets handed back zeroed)
+        return out, {k: (o, p.numel()) for (k, p), o in zip([(k, p) for k, p in model.named_parameters() if p.requires_grad],
+                                                            np.cumsum([0] + [p.numel() for p in model.parameters() if p.requires_grad][:-1]))}
+
+    (ref, layout), (got, _) = run(False), run(True)
+    for step, ((l0, g0, n0, p0, c0), (l1, g1, n1, p1, c1)) in enumerate(zip(ref, got)):
+        assert c0 == c1 == step + 1
+        np.testing.assert_allclose(l1, l0, rtol=1e-5)
+        np.testing.assert_allclose(n1, n0, rtol=1e-5)
+        assert n0 > 0.5  # (clipping is active)
+        if step == 0:  # same weights, same forward: the window's gradient itself
+            for k, (off, n) in layout.items():
+                if k.endswith("ff.weight") and not k.startswith("head") or k.endswith("rec.weight"):
+                    assert np.array_equal(g1[off:off + n], g0[off:off + n]), k  # slab sums: same order
+                else:
+                    np.testing.assert_allclose(g1[off:off + n], g0[off:off + n], rtol=2e-4, atol=1e-6 * np.abs(g0).max(), err_msg=k)
+        d = np.abs(p1 - p0)
+        assert d.max() <= 2 * 2e-4 + 1e-6 and np.mean(d > 2e-5) <= 0.02, (step, d.max(), np.mean(d > 2e-5))
