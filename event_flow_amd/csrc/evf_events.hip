@@ -629,12 +629,12 @@ __global__ void k_cm_splat(const float* __restrict__ flow, const float4* __restr
 // block per (scale, sample, direction, stripe of image rows) keeps its stripe of the four images in LDS, streams
 // the sample's pre-warped events (16 B, coalesced) and accumulates with LDS atomics, and finally writes the
 // stripe with plain coalesced stores -- no zero-fill of `images`, no global atomics.
-__global__ void k_cm_prewarp(const float* __restrict__ flow, const float4* __restrict__ ev, const float2* __restrict__ pol,
-                             const int32_t* __restrict__ ev_pass, int S, int Pm, int P, int B, int M, int H, int W,
-                             float Sc, float4* __restrict__ warp, float* __restrict__ tabs) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void cm_prewarp_body(int bx, int s, const float* __restrict__ flow, const float4* __restrict__ ev,
+                                                const float2* __restrict__ pol, const int32_t* __restrict__ ev_pass, int S, int Pm,
+                                                int P, int B, int M, int H, int W, float Sc, float4* __restrict__ warp,
+                                                float* __restrict__ tabs) {
+  const long i = (long)bx * blockDim.x + threadIdx.x;
   if (i >= (long)B * M) return;
-  const int s = blockIdx.y;
   const int b = (int)(i / M), e = (int)(i - (long)b * M);
   const float4 q = ev[i];
   const int pass = ev_pass[e];
@@ -649,10 +649,26 @@ __global__ void k_cm_prewarp(const float* __restrict__ flow, const float4* __res
   o[M] = make_float4(g.wy, g.wx, pm.x, pm.y);
   if (s == 0) tabs[i] = t;
 }
+__global__ void k_cm_prewarp(const float* __restrict__ flow, const float4* __restrict__ ev, const float2* __restrict__ pol,
+                             const int32_t* __restrict__ ev_pass, int S, int Pm, int P, int B, int M, int H, int W,
+                             float Sc, float4* __restrict__ warp, float* __restrict__ tabs) {
+  cm_prewarp_body(blockIdx.x, blockIdx.y, flow, ev, pol, ev_pass, S, Pm, P, B, M, H, W, Sc, warp, tabs);
+}
+
+struct CmFin {  // what the LAST block of k_cm_splat_lds needs to finish the loss (stats == null: separate launches do it)
+  float* stats;          // [S][B][2][2], zeroed by k_cm_pre
+  unsigned* ticket;      // zeroed by k_cm_pre
+  const float* part;     // smoothness partials [S][nblk_per_scale]
+  float* loss;
+  int S, Pm, nblk_per_scale, comps, loss_scaling;
+  float weight;
+};
+__device__ void cm_finalize_body(float* red, const float* stats, const float* __restrict__ part, int S, int B, int Pm,
+                                 int nblk_per_scale, float weight, int comps, int loss_scaling, float* __restrict__ loss);
 
 __global__ __launch_bounds__(1024) void k_cm_splat_lds(const float4* __restrict__ warp, const float* __restrict__ tabs,
                                                        int B, int M, int H, int W, int rows, float P,
-                                                       float* __restrict__ images) {
+                                                       float* __restrict__ images, CmFin fin) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* img = (float*)smem_raw;  // [4][rows*W]: I_pos, I_neg, TS_pos, TS_neg of this direction
   const int sbd = blockIdx.y, d = sbd & 1, b = (sbd >> 1) % B;
@@ -707,6 +723,31 @@ __global__ __launch_bounds__(1024) void k_cm_splat_lds(const float4* __restrict_
     const int ch = q / n, r = q - ch * n;
     o[(long)ch * HW + r] = img[ch * plane + r];
   }
+  if (!fin.stats) return;
+  // ---- this stripe's part of the image statistics, straight from LDS (k_cm_reduce re-read the images from memory) ...
+  __shared__ float red[16];
+  __shared__ int s_last;
+  float sq = 0.f, nz = 0.f;
+  for (int p = threadIdx.x; p < n; p += blockDim.x) {
+    const float ip = img[p], in = img[plane + p];
+    const float ap = img[2 * plane + p] / (ip + 1e-9f) / P;  // loss/flow.py:212-215
+    const float an = img[3 * plane + p] / (in + 1e-9f) / P;
+    sq += ap * ap + an * an;
+    nz += (ip + in > 0.f) ? 1.f : 0.f;
+  }
+  sq = evf_block_sum(sq, red);
+  nz = evf_block_sum(nz, red);
+  if (threadIdx.x == 0) {
+    evf_atomic_add(fin.stats + sbd * 2, sq);
+    evf_atomic_add(fin.stats + sbd * 2 + 1, nz);
+    __threadfence();
+    const unsigned t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == gridDim.x * gridDim.y - 1;
+  }
+  __syncthreads();
+  // ... and the block that arrives last, when every stripe has added its part, finishes the loss (k_cm_finalize)
+  if (s_last) cm_finalize_body(red, fin.stats, fin.part, fin.S, B, fin.Pm, fin.nblk_per_scale, fin.weight, fin.comps,
+                               fin.loss_scaling, fin.loss);
 }
 
 static int cm_lds_rows(int S, int B, int H, int W) {
@@ -719,7 +760,7 @@ static int cm_lds_rows(int S, int B, int H, int W) {
 // floats of workspace that make evf_cm_loss_fwd take the LDS-privatised splat (0: image rows too wide for LDS)
 extern "C" int64_t evf_cm_loss_ws(int S, int B, int M, int H, int W) {
   if (S <= 0 || B <= 0 || M <= 0 || H <= 0 || W <= 0 || W > 2048) return 0;
-  return (int64_t)S * B * 2 * M * 4 + (int64_t)B * M;
+  return (int64_t)S * B * 2 * M * 4 + (int64_t)B * M + 4;  // pre-warped records, event times, the ticket of the merged launch
 }
 
 // stats [S][B][2][2] += (sum over px of A_pos^2 + A_neg^2, #px with I_pos+I_neg > 0)
@@ -754,11 +795,10 @@ __device__ __forceinline__ float evf_charb(float fxa, float fya, float fxb, floa
 }
 
 #define SM_ROWS 8
-__global__ void k_cm_smooth(const float* __restrict__ flow, const float* __restrict__ mask, int Pm, int Pk, int B, int H,
-                            int W, int use_mask, int with_dt, float* __restrict__ part) {
-  __shared__ float red[16];
-  // grid: x = row-chunk within a map, y = map index over (s, p, b)
-  const int map = blockIdx.y;  // (s*Pm + p)*B + b
+__device__ __forceinline__ void cm_smooth_body(int bx, int map, int gx, float* red, const float* __restrict__ flow,
+                                               const float* __restrict__ mask, int Pm, int Pk, int B, int H, int W, int use_mask,
+                                               int with_dt, float* __restrict__ part) {
+  // bx = row-chunk within a map (of gx), map = index over (s, p, b): (s*Pm + p)*B + b
   const int b = map % B, p = (map / B) % Pm;
   const long HW = (long)H * W;
   const float* fx = flow + (long)map * 2 * HW;
@@ -768,7 +808,7 @@ __global__ void k_cm_smooth(const float* __restrict__ flow, const float* __restr
   const float* m = use_mask ? mask + ((long)b * Pk + (Pk == 1 ? 0 : p)) * HW : nullptr;
   const float* mn = (use_mask && Pk > 1) ? m + HW : m;
   float acc = 0.f;
-  const int y0 = blockIdx.x * SM_ROWS;
+  const int y0 = bx * SM_ROWS;
   // Branch-free: every neighbour is loaded from a clamped index (the pixel itself when the pair does not exist) and the
   // pair's term is selected afterwards -- a load under `if (xr)` ends its basic block with s_waitcnt vmcnt(0).
   const float* mp = m ? m : fx;    // dummy source without a mask
@@ -804,12 +844,39 @@ __global__ void k_cm_smooth(const float* __restrict__ flow, const float* __restr
     }
   }
   acc = evf_block_sum(acc, red);
-  if (threadIdx.x == 0) part[(long)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+  if (threadIdx.x == 0) part[(long)map * gx + bx] = acc;
+}
+__global__ void k_cm_smooth(const float* __restrict__ flow, const float* __restrict__ mask, int Pm, int Pk, int B, int H,
+                            int W, int use_mask, int with_dt, float* __restrict__ part) {
+  __shared__ float red[16];
+  cm_smooth_body(blockIdx.x, blockIdx.y, gridDim.x, red, flow, mask, Pm, Pk, B, H, W, use_mask, with_dt, part);
 }
 
-__global__ void k_cm_finalize(const float* __restrict__ stats, const float* __restrict__ part, int S, int B, int Pm,
-                              int nblk_per_scale, float weight, int comps, int loss_scaling, float* __restrict__ loss) {
+// The two loss passes that only read the flow maps -- the pre-warp of the events and the smoothness partials -- in ONE launch
+// (block role by index; 256 threads either way); its first threads also clear `stats` and the ticket of k_cm_splat_lds, which
+// the next launch accumulates into (no fill node).
+__global__ __launch_bounds__(256) void k_cm_pre(const float* __restrict__ flow, const float4* __restrict__ ev,
+                                                const float2* __restrict__ pol, const int32_t* __restrict__ ev_pass,
+                                                const float* __restrict__ mask, int S, int Pm, int Pk, int P, int B, int M, int H,
+                                                int W, float Sc, int use_mask, int with_dt, float4* __restrict__ warp,
+                                                float* __restrict__ tabs, float* __restrict__ part, float* __restrict__ stats,
+                                                unsigned* __restrict__ ticket, int nbw) {
   __shared__ float red[16];
+  const int bid = blockIdx.x;
+  if (bid < nbw * S) {
+    if (bid == 0) {
+      for (int i = threadIdx.x; i < S * B * 4; i += blockDim.x) stats[i] = 0.f;
+      if (threadIdx.x == 0) ticket[0] = 0u;
+    }
+    cm_prewarp_body(bid % nbw, bid / nbw, flow, ev, pol, ev_pass, S, Pm, P, B, M, H, W, Sc, warp, tabs);
+    return;
+  }
+  const int sb = bid - nbw * S, gx = (H + SM_ROWS - 1) / SM_ROWS;
+  cm_smooth_body(sb % gx, sb / gx, gx, red, flow, mask, Pm, Pk, B, H, W, use_mask, with_dt, part);
+}
+
+__device__ void cm_finalize_body(float* red, const float* stats, const float* __restrict__ part, int S, int B, int Pm,
+                                 int nblk_per_scale, float weight, int comps, int loss_scaling, float* __restrict__ loss) {
   float total = 0.f;
   for (int s = 0; s < S; ++s) {
     float v = 0.f;
@@ -817,13 +884,21 @@ __global__ void k_cm_finalize(const float* __restrict__ stats, const float* __re
     v = evf_block_sum(v, red);  // thread 0
     float data = 0.f;
     for (int i = threadIdx.x; i < B * 2; i += blockDim.x) {
-      const float* st = stats + ((long)s * B * 2 + i) * 2;
-      data += loss_scaling ? st[0] / st[1] : st[0];
+      // (device-scope loads: inside k_cm_splat_lds the sums were made by other blocks' atomics of the same launch)
+      const unsigned* st = (const unsigned*)(stats + ((long)s * B * 2 + i) * 2);
+      const float s0 = __uint_as_float(__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const float s1 = __uint_as_float(__hip_atomic_load(st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      data += loss_scaling ? s0 / s1 : s0;
     }
     data = evf_block_sum(data, red);
     if (threadIdx.x == 0) total += data + weight * (v / (float)comps / (float)Pm);
   }
   if (threadIdx.x == 0) loss[0] = total / (float)S;
+}
+__global__ void k_cm_finalize(const float* __restrict__ stats, const float* __restrict__ part, int S, int B, int Pm,
+                              int nblk_per_scale, float weight, int comps, int loss_scaling, float* __restrict__ loss) {
+  __shared__ float red[16];
+  cm_finalize_body(red, stats, part, S, B, Pm, nblk_per_scale, weight, comps, loss_scaling, loss);
 }
 
 extern "C" int evf_cm_smooth_blocks(int B, int P, int H, int W) {
@@ -838,6 +913,12 @@ static int cm_args_ok(const void* flow, const void* ev, const void* pol, const v
   return 1;
 }
 
+static bool cm_merge_on = true;  // evf_cm_merge: process-wide switch (the equivalence test; EVF_CM_MERGE=0 in the environment: off)
+extern "C" int evf_cm_merge(int on) {
+  cm_merge_on = on != 0;
+  return EVF_OK;
+}
+
 extern "C" int evf_cm_loss_fwd(const float* flow, const float* ev, const float* pol, const int32_t* ev_pass,
                                const float* mask, int S, int P, int B, int M, int H, int W, float flow_scaling,
                                float regul_weight, int flags, float* images, float* stats, float* smooth_part,
@@ -848,13 +929,17 @@ extern "C" int evf_cm_loss_fwd(const float* flow, const float* ev, const float* 
   const int overwrite = (flags & 2) ? 1 : 0;
   const int Pm = overwrite ? 1 : P, Pk = Pm;
   const int HW = H * W;
-  int rc = evf_hip(hipMemsetAsync(stats, 0, sizeof(float) * (size_t)S * B * 4, st));
-  if (rc) return rc;
+  const int srows = evf_cdiv(H, SM_ROWS);
+  // EVF_CM_MERGE=0: one launch per pass (fill, pre-warp, splat, reduce, smooth, finalize) -- A/B measurements, the equivalence test
+  static const bool merge = []() {
+    const char* e = getenv("EVF_CM_MERGE");
+    return !(e && e[0] == '0');
+  }();
+  int rc = EVF_OK;
   if (ws && evf_cm_loss_ws(S, B, M, H, W) > 0) {
     float4* warp = (float4*)ws;
     float* tabs = ws + (size_t)S * B * 2 * M * 4;
-    hipLaunchKernelGGL(k_cm_prewarp, dim3(evf_cdiv((long)B * M, 256), S), dim3(256), 0, st, flow, (const float4*)ev,
-                       (const float2*)pol, ev_pass, S, Pm, P, B, M, H, W, flow_scaling, warp, tabs);
+    unsigned* ticket = (unsigned*)(tabs + (size_t)B * M);
     const int rows = cm_lds_rows(S, B, H, W);
     const size_t lds = (size_t)4 * rows * W * sizeof(float);
     static size_t lds_set = 0;
@@ -862,9 +947,28 @@ extern "C" int evf_cm_loss_fwd(const float* flow, const float* ev, const float* 
       (void)hipFuncSetAttribute((const void*)k_cm_splat_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       lds_set = lds;
     }
+    if (merge && cm_merge_on) {
+      // two launches: [pre-warp | smoothness partials | stats and ticket cleared], [striped splat + image statistics + the
+      // last block finishes the loss]
+      const int nbw = evf_cdiv((long)B * M, 256);
+      hipLaunchKernelGGL(k_cm_pre, dim3(nbw * S + srows * S * Pm * B), dim3(256), 0, st, flow, (const float4*)ev, (const float2*)pol,
+                         ev_pass, mask, S, Pm, Pk, P, B, M, H, W, flow_scaling, flags & 1, overwrite ? 0 : 1, warp, tabs, smooth_part,
+                         stats, ticket, nbw);
+      const CmFin fin{stats, ticket, smooth_part, loss, S, Pm, srows * Pm * B, overwrite ? 4 : 5, (flags & 4) ? 1 : 0, regul_weight};
+      hipLaunchKernelGGL(k_cm_splat_lds, dim3(evf_cdiv(H, rows), S * B * 2), dim3(1024), lds, st, (const float4*)warp, tabs, B, M, H, W,
+                         rows, (float)P, images, fin);
+      return evf_status();
+    }
+    rc = evf_hip(hipMemsetAsync(stats, 0, sizeof(float) * (size_t)S * B * 4, st));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cm_prewarp, dim3(evf_cdiv((long)B * M, 256), S), dim3(256), 0, st, flow, (const float4*)ev,
+                       (const float2*)pol, ev_pass, S, Pm, P, B, M, H, W, flow_scaling, warp, tabs);
+    const CmFin none{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0.f};
     hipLaunchKernelGGL(k_cm_splat_lds, dim3(evf_cdiv(H, rows), S * B * 2), dim3(1024), lds, st, (const float4*)warp, tabs, B,
-                       M, H, W, rows, (float)P, images);
+                       M, H, W, rows, (float)P, images, none);
   } else {
+    rc = evf_hip(hipMemsetAsync(stats, 0, sizeof(float) * (size_t)S * B * 4, st));
+    if (rc) return rc;
     rc = evf_hip(hipMemsetAsync(images, 0, sizeof(float) * (size_t)S * B * 8 * HW, st));
     if (rc) return rc;
     hipLaunchKernelGGL(k_cm_splat, dim3(evf_cdiv((long)B * M, 256), S), dim3(256), 0, st, flow, (const float4*)ev,
@@ -872,10 +976,9 @@ extern "C" int evf_cm_loss_fwd(const float* flow, const float* ev, const float* 
   }
   hipLaunchKernelGGL(k_cm_reduce, dim3(evf_cdiv(HW, CM_RED_CHUNK), S * B * 2), dim3(256), 0, st, images, HW, (float)P,
                      stats);
-  const int rows = evf_cdiv(H, SM_ROWS);
-  hipLaunchKernelGGL(k_cm_smooth, dim3(rows, S * Pm * B), dim3(256), 0, st, flow, mask, Pm, Pk, B, H, W, flags & 1,
+  hipLaunchKernelGGL(k_cm_smooth, dim3(srows, S * Pm * B), dim3(256), 0, st, flow, mask, Pm, Pk, B, H, W, flags & 1,
                      overwrite ? 0 : 1, smooth_part);
-  hipLaunchKernelGGL(k_cm_finalize, dim3(1), dim3(256), 0, st, stats, smooth_part, S, B, Pm, rows * Pm * B, regul_weight,
+  hipLaunchKernelGGL(k_cm_finalize, dim3(1), dim3(256), 0, st, stats, smooth_part, S, B, Pm, srows * Pm * B, regul_weight,
                      overwrite ? 4 : 5, (flags & 4) ? 1 : 0, loss);
   return evf_status();
 }
@@ -884,16 +987,15 @@ extern "C" int evf_cm_loss_fwd(const float* flow, const float* ev, const float* 
 // contrast-maximisation loss, backward
 // --------------------------------------------------------------------------
 // gimages[ch] = dL/d images[ch] (scaled by grad_out / S)
-__global__ void k_cm_gimages(const float* __restrict__ images, const float* __restrict__ stats,
-                             const float* __restrict__ grad_out, int S, int HW, float P, int loss_scaling,
-                             float* __restrict__ gim) {
-  const int sbd = blockIdx.y;
+__device__ __forceinline__ void cm_gimages_body(int bx, int sbd, int gx, const float* __restrict__ images,
+                                                const float* __restrict__ stats, const float* __restrict__ grad_out, int S, int HW,
+                                                float P, int loss_scaling, float* __restrict__ gim) {
   const long base = ((long)(sbd >> 1) * 8 + (sbd & 1) * 4) * HW;
   const float* im = images + base;
   float* g = gim + base;
   const float sumsq = stats[sbd * 2], nnz = loss_scaling ? stats[sbd * 2 + 1] : 1.f;
   const float c = grad_out[0] / (float)S;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+  for (int p = bx * blockDim.x + threadIdx.x; p < HW; p += gx * blockDim.x) {
     const float ip = im[p], in = im[HW + p];
     const float dp = ip + 1e-9f, dn = in + 1e-9f;
     const float ap = im[2 * HW + p] / dp / P, an = im[3 * HW + p] / dn / P;
@@ -904,6 +1006,11 @@ __global__ void k_cm_gimages(const float* __restrict__ images, const float* __re
     g[2 * HW + p] = c * (2.f * ap / (dp * P) / nnz);
     g[3 * HW + p] = c * (2.f * an / (dn * P) / nnz);
   }
+}
+__global__ void k_cm_gimages(const float* __restrict__ images, const float* __restrict__ stats,
+                             const float* __restrict__ grad_out, int S, int HW, float P, int loss_scaling,
+                             float* __restrict__ gim) {
+  cm_gimages_body(blockIdx.x, blockIdx.y, gridDim.x, images, stats, grad_out, S, HW, P, loss_scaling, gim);
 }
 
 // d max(0, 1-|d|) / d w with torch's sub-gradients: |.|'(0) = 0, and the
@@ -994,10 +1101,10 @@ __device__ __forceinline__ float evf_dcharb(float fxa, float fya, float fxb, flo
 }
 
 // writes dflow = d(weight * smoothness)/dflow (gather form, no atomics)
-__global__ void k_cm_smooth_bwd(const float* __restrict__ flow, const float* __restrict__ mask, int S, int Pm, int Pk,
-                                int B, int H, int W, int use_mask, int with_dt, const float* __restrict__ grad_out,
-                                float scale, float* __restrict__ dflow) {
-  const int map = blockIdx.y;
+__device__ __forceinline__ void cm_smooth_bwd_body(int bx, int map, int gx, const float* __restrict__ flow,
+                                                   const float* __restrict__ mask, int S, int Pm, int Pk, int B, int H, int W,
+                                                   int use_mask, int with_dt, const float* __restrict__ grad_out, float scale,
+                                                   float* __restrict__ dflow) {
   const int b = map % B, p = (map / B) % Pm;
   const long HW = (long)H * W;
   const float* fx = flow + (long)map * 2 * HW;
@@ -1007,7 +1114,7 @@ __global__ void k_cm_smooth_bwd(const float* __restrict__ flow, const float* __r
   const long mstride = (use_mask && Pk > 1) ? HW : 0;
   const float c = grad_out[0] * scale;
   const float* mp = m ? m : fx;  // dummy source without a mask
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < H * W; idx += gridDim.x * blockDim.x) {
+  for (int idx = bx * blockDim.x + threadIdx.x; idx < H * W; idx += gx * blockDim.x) {
     const int y = idx / W, x = idx % W;
     const long q = idx;
     const float ax = fx[q], ay = fy[q];
@@ -1047,6 +1154,24 @@ __global__ void k_cm_smooth_bwd(const float* __restrict__ flow, const float* __r
     d[HW + q] = g;
   }
 }
+__global__ void k_cm_smooth_bwd(const float* __restrict__ flow, const float* __restrict__ mask, int S, int Pm, int Pk,
+                                int B, int H, int W, int use_mask, int with_dt, const float* __restrict__ grad_out,
+                                float scale, float* __restrict__ dflow) {
+  cm_smooth_bwd_body(blockIdx.x, blockIdx.y, gridDim.x, flow, mask, S, Pm, Pk, B, H, W, use_mask, with_dt, grad_out, scale, dflow);
+}
+// The two backward passes in front of the event gather -- dL/dflow of the smoothness term (plain stores into dflow, which the
+// gather then adds to) and dL/d(images) -- are independent of each other: one launch, block role by index.
+__global__ __launch_bounds__(256) void k_cm_bwd_pre(const float* __restrict__ flow, const float* __restrict__ mask, int S, int Pm,
+                                                    int Pk, int B, int H, int W, int use_mask, int with_dt,
+                                                    const float* __restrict__ grad_out, float scale, float* __restrict__ dflow,
+                                                    const float* __restrict__ images, const float* __restrict__ stats, float P,
+                                                    int loss_scaling, float* __restrict__ gim) {
+  const int gx = (H * W + 255) / 256, nsm = gx * S * Pm * B, bid = blockIdx.x;
+  if (bid < nsm)
+    cm_smooth_bwd_body(bid % gx, bid / gx, gx, flow, mask, S, Pm, Pk, B, H, W, use_mask, with_dt, grad_out, scale, dflow);
+  else
+    cm_gimages_body((bid - nsm) % gx, (bid - nsm) / gx, gx, images, stats, grad_out, S, H * W, P, loss_scaling, gim);
+}
 
 extern "C" int evf_cm_loss_bwd(const float* flow, const float* ev, const float* pol, const int32_t* ev_pass,
                                const float* mask, int S, int P, int B, int M, int H, int W, float flow_scaling,
@@ -1060,11 +1185,22 @@ extern "C" int evf_cm_loss_bwd(const float* flow, const float* ev, const float* 
   const int Pm = overwrite ? 1 : P, Pk = Pm;
   const int HW = H * W;
   const int comps = overwrite ? 4 : 5;
-  hipLaunchKernelGGL(k_cm_smooth_bwd, dim3(evf_cdiv(HW, 256), S * Pm * B), dim3(256), 0, st, flow, mask, S, Pm, Pk, B, H,
-                     W, flags & 1, overwrite ? 0 : 1, grad_out, regul_weight / (float)comps / (float)Pm / (float)S,
-                     dflow);
-  hipLaunchKernelGGL(k_cm_gimages, dim3(evf_cdiv(HW, 256), S * B * 2), dim3(256), 0, st, images, stats, grad_out, S, HW,
-                     (float)P, (flags & 4) ? 1 : 0, gimages);
+  static const bool merge = []() {
+    const char* e = getenv("EVF_CM_MERGE");
+    return !(e && e[0] == '0');
+  }();
+  if (merge && cm_merge_on) {
+    const int gx = evf_cdiv(HW, 256);
+    hipLaunchKernelGGL(k_cm_bwd_pre, dim3(gx * S * Pm * B + gx * S * B * 2), dim3(256), 0, st, flow, mask, S, Pm, Pk, B, H, W, flags & 1,
+                       overwrite ? 0 : 1, grad_out, regul_weight / (float)comps / (float)Pm / (float)S, dflow, images, stats, (float)P,
+                       (flags & 4) ? 1 : 0, gimages);
+  } else {
+    hipLaunchKernelGGL(k_cm_smooth_bwd, dim3(evf_cdiv(HW, 256), S * Pm * B), dim3(256), 0, st, flow, mask, S, Pm, Pk, B, H,
+                       W, flags & 1, overwrite ? 0 : 1, grad_out, regul_weight / (float)comps / (float)Pm / (float)S,
+                       dflow);
+    hipLaunchKernelGGL(k_cm_gimages, dim3(evf_cdiv(HW, 256), S * B * 2), dim3(256), 0, st, images, stats, grad_out, S, HW,
+                       (float)P, (flags & 4) ? 1 : 0, gimages);
+  }
   hipLaunchKernelGGL(k_cm_event_bwd, dim3(evf_cdiv((long)B * M, 256), S), dim3(256), 0, st, flow, (const float4*)ev,
                      (const float2*)pol, ev_pass, S, Pm, P, B, M, H, W, flow_scaling, gimages, dflow);
   return evf_status();

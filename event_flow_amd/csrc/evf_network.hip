@@ -1927,9 +1927,15 @@ __global__ void k_clip_adam(float* __restrict__ p, float* __restrict__ g, float*
   }
 }
 
+int evf_clip_adam_step_impl(float* param, float* grad, float* m, float* v, int64_t n, float max_norm, float lr, float beta1,
+                            float beta2, float eps, int step, float* norm_ws, int zero_grad, void* stream);
 extern "C" int evf_clip_adam_step(float* param, float* grad, float* m, float* v, int64_t n, float max_norm,
                                   float lr, float beta1, float beta2, float eps, int step, float* norm_ws,
                                   int zero_grad, void* stream) {
+  return evf_clip_adam_step_impl(param, grad, m, v, n, max_norm, lr, beta1, beta2, eps, step, norm_ws, zero_grad, stream);
+}
+int evf_clip_adam_step_impl(float* param, float* grad, float* m, float* v, int64_t n, float max_norm, float lr, float beta1,
+                            float beta2, float eps, int step, float* norm_ws, int zero_grad, void* stream) {
   if (!param || !grad || !m || !v || !norm_ws || n <= 0) return EVF_EINVAL;
   hipStream_t st = EVF_STREAM(stream);
   const int device_step = step <= 0;  // step <= 0: use (and advance) the counter in norm_ws[1]

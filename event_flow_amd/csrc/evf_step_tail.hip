@@ -5,8 +5,8 @@
 //                        * the per-channel / head / prediction gradients: small accumulator + per-block rows + the head
 //                          layer's per-block weight-gradient rows, added to their segments of the flat buffer
 //                          (evf_sum_rows x 2 + evf_add_segments), sources handed back zeroed;
-//   evf_clip_adam_fused  squared norm, a grid-wide hand-shake, clip + Adam (+ zero_grad) -- k_sumsq, k_clip_adam and the
-//                        fill of the norm word in one launch of <= one block per CU.
+//   evf_clip_adam_fused  squared norm (every block sums the whole gradient itself), clip + Adam (+ zero_grad behind a short
+//                        hand-shake) -- k_sumsq, k_clip_adam and the fill of the norm word in one launch of 16 blocks.
 // With several ranks the all-reduce of the flat buffer sits between the two (train.window_backward / window_apply).
 // train_flow.py:157-164 (clip_grad_norm_, Adam.step, zero_grad).
 #include "evf_common.h"
@@ -23,6 +23,7 @@ struct GfArgs {
 };
 
 #define GF_GROUPS 16
+#define GF_RCHUNK 64  // rows of per-block partials one block of the segment part sums
 // blocks [0, 144 * nslabs): 64 outputs x 16 slab groups of tensor block / 144 (as k_reduce_wgrad_multi);
 // blocks behind them: 64 columns x 16 row groups of one segment of the small gradients
 __global__ __launch_bounds__(64 * GF_GROUPS) void k_grads_finalize(GfArgs a, int nslabs, int nslab, float* __restrict__ small,
@@ -57,30 +58,46 @@ __global__ __launch_bounds__(64 * GF_GROUPS) void k_grads_finalize(GfArgs a, int
     }
     return;
   }
+  // ---- small gradients: block = (segment k, 64 of its columns, GF_RCHUNK rows of the per-block partials); the blocks of one
+  // column group add their sums to the segment atomically (few, spread addresses); the block of row chunk 0 also moves the
+  // small accumulator.  (First version: ONE block per column group walked all rows -- 64 dependent trips, 65 us per launch.)
   const int sb = blockIdx.x - nb_slab;
   int k = 0;
   while (k + 1 < nseg && sb >= a.seg_blk0[k + 1]) ++k;  // (block-uniform, <= 32 steps)
-  const int i = (sb - a.seg_blk0[k]) * 64 + tx;  // element of segment k
+  const int rel = sb - a.seg_blk0[k], ncg = (a.seg_n[k] + 63) / 64;
+  const int cg = rel % ncg, rc = rel / ncg;  // column group, row chunk
+  const int i = cg * 64 + tx;                // element of segment k
   const bool in = i < a.seg_n[k];
   const int e = a.seg_off[k] + (in ? i : 0);  // column of the small accumulator
+  const int r0 = rc * GF_RCHUNK;
   float v = 0.f;
   if (in) {
-    if (rows && e < ncols)
-      for (int r = ty; r < nrows; r += GF_GROUPS) {
-        v += rows[(long)r * ncols + e];
-        rows[(long)r * ncols + e] = 0.f;  // (the persistent per-block rows are handed back zeroed)
+    if (rows && e < ncols) {
+#pragma unroll
+      for (int j = 0; j < GF_RCHUNK / GF_GROUPS; ++j) {
+        const int r = r0 + ty + j * GF_GROUPS;
+        if (r < nrows) {
+          v += rows[(long)r * ncols + e];
+          rows[(long)r * ncols + e] = 0.f;  // (the persistent per-block rows are handed back zeroed)
+        }
       }
-    if (hrows && e >= hoff && e < hoff + nhcols)
-      for (int r = ty; r < nhrows; r += GF_GROUPS) v += hrows[(long)r * nhcols + (e - hoff)];
+    }
+    if (hrows && e >= hoff && e < hoff + nhcols) {
+#pragma unroll
+      for (int j = 0; j < GF_RCHUNK / GF_GROUPS; ++j) {
+        const int r = r0 + ty + j * GF_GROUPS;
+        if (r < nhrows) v += hrows[(long)r * nhcols + (e - hoff)];
+      }
+    }
   }
   red[ty][tx] = v;
   __syncthreads();
   if (ty == 0 && in) {
-    float s = small[e];
+    float s = rc == 0 ? small[e] : 0.f;
 #pragma unroll
     for (int g = 0; g < GF_GROUPS; ++g) s += red[g][tx];
-    a.seg_dst[k][i] += s;
-    if (clear_small) small[e] = 0.f;
+    if (s != 0.f) evf_atomic_add(a.seg_dst[k] + i, s);
+    if (rc == 0 && clear_small) small[e] = 0.f;
   }
 }
 
@@ -105,7 +122,13 @@ extern "C" int evf_grads_finalize(const void* const* slabs, void* const* slab_ds
     a.seg_n[k] = k < nseg ? seg_n[k] : 0;
     if (k < nseg && (!a.seg_dst[k] || a.seg_off[k] < 0 || a.seg_n[k] <= 0)) return EVF_EINVAL;
     a.seg_blk0[k] = nb;
-    if (k < nseg) nb += evf_cdiv(a.seg_n[k], 64);
+    if (k < nseg) {
+      // rows this segment's columns have partials in: the per-block rows (columns < ncols), the head layer's (its own range)
+      int nr = 1;
+      if (rows && a.seg_off[k] < ncols) nr = nrows;
+      if (head_rows && a.seg_off[k] < head_off + nhcols && a.seg_off[k] + a.seg_n[k] > head_off && nhrows > nr) nr = nhrows;
+      nb += evf_cdiv(a.seg_n[k], 64) * evf_cdiv(nr, GF_RCHUNK);
+    }
   }
   a.seg_blk0[32] = nb;
   for (int k = nseg; k < 32; ++k) a.seg_blk0[k] = nb;
@@ -115,29 +138,40 @@ extern "C" int evf_grads_finalize(const void* const* slabs, void* const* slab_ds
 }
 
 // ---- clip_grad_norm_ + Adam in ONE launch ----------------------------------------------------------------------------------
-// ws (>= 8 floats, zeroed once by the caller): [0] squared gradient norm of the last step (for the host to read), [1] the
-// device-side step counter, [2] this step's running sum, [3] / [4] arrival / departure tickets (uint32).  Every block adds its
-// part of the squared norm to ws[2] and takes an arrival ticket; when all gridDim.x tickets are out the sum is complete --
-// the grid is at most one block per CU, i.e. all blocks are resident and the wait cannot deadlock.  The last block to LEAVE
-// publishes ws[0] and clears [2..4]: the next launch needs no fill.
-__global__ __launch_bounds__(256) void k_clip_adam_fused(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                         float* __restrict__ v, long n, float max_norm, float lr, float b1, float b2,
-                                                         float host_step_size, float host_bc2_sqrt, float eps, float* ws,
-                                                         int device_step, int zero_grad) {
+// For the parameter counts of the FireNets (75 k) the squared norm is cheap to compute REDUNDANTLY: CA_BLOCKS blocks of 1024
+// threads each sum the whole gradient (300 KB out of the L2; the same order in every block, i.e. a reproducible norm -- no
+// atomics, no word to clear) and then run clip + Adam on their own slice.  zero_grad is the one cross-block hazard (a block must
+// not clear its slice while another still sums it): one arrival ticket per block in ws[3], a short wait of CA_BLOCKS
+// participants, and the last block to leave resets the tickets.  (First version: one block per CU, partial sums by atomics and
+// a hand-shake of 256 blocks -- 34 us against 17 us for the three launches it replaced.)  Large models keep the two-launch
+// form (evf_clip_adam_step): n > CA_MAX_N.
+// ws (>= 8 floats, zeroed once by the caller): [0] squared gradient norm of the last step, [1] the device-side step counter,
+// [3] / [4] arrival / departure tickets (uint32, left zero).
+#define CA_BLOCKS 16
+#define CA_MAX_N (1 << 20)
+__global__ __launch_bounds__(1024) void k_clip_adam_fused(float* __restrict__ p, float* g, float* __restrict__ m,
+                                                          float* __restrict__ v, long n, float max_norm, float lr, float b1, float b2,
+                                                          float host_step_size, float host_bc2_sqrt, float eps, float* ws,
+                                                          int device_step, int zero_grad) {
   __shared__ float red[16];
   __shared__ float s_total;
-  float s = 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
-  s = evf_block_sum(s, red);
+  // ---- the whole gradient's sum of squares, the same in every block (float4 trips + tail)
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const long n4 = n >> 2;
+  const float4* g4 = (const float4*)g;
+  for (long i = threadIdx.x; i < n4; i += blockDim.x) {
+    const float4 q = g4[i];
+    s0 += q.x * q.x, s1 += q.y * q.y, s2 += q.z * q.z, s3 += q.w * q.w;
+  }
+  for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) s0 += g[i] * g[i];
+  const float tot = evf_block_sum((s0 + s1) + (s2 + s3), red);
   unsigned* tick = (unsigned*)(ws + 3);
   if (threadIdx.x == 0) {
-    evf_atomic_add(ws + 2, s);
-    if (device_step && blockIdx.x == 0) ws[1] += 1.0f;  // single writer; read by everybody behind the hand-shake
-    __threadfence();
-    __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(tick, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(2);
-    s_total = __uint_as_float(__hip_atomic_load((unsigned*)(ws + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    red[0] = __uint_as_float(__hip_atomic_load((unsigned*)(ws + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    s_total = tot;
+    if (zero_grad) {  // every block has finished reading the gradient before anybody clears a slice of it
+      __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(tick, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(1);
+    }
   }
   __syncthreads();
   const float total = s_total;
@@ -145,12 +179,13 @@ __global__ __launch_bounds__(256) void k_clip_adam_fused(float* __restrict__ p, 
   float coef = 1.f;
   if (max_norm > 0.f) coef = fminf(1.f, max_norm / (sqrtf(total) + 1e-6f));
   float step_size = host_step_size, bc2_sqrt = host_bc2_sqrt;
-  if (device_step) {  // bias corrections from the device-side counter, in double like the host path (k_clip_adam)
-    const double t = (double)red[0];
+  if (device_step) {  // bias corrections from the device-side counter (advanced by block 0 at the END of the launch), in double
+    const double t = (double)ws[1] + 1.0;
     step_size = (float)((double)lr / (1.0 - pow((double)b1, t)));
     bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
   }
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+  const long per = (n + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+  for (long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     const float gi = g[i] * coef;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -160,36 +195,34 @@ __global__ __launch_bounds__(256) void k_clip_adam_fused(float* __restrict__ p, 
     p[i] = p[i] - step_size * (mi / denom);
     if (zero_grad) g[i] = 0.f;  // optimizer.zero_grad() of the next step, without its fill kernel
   }
+  __syncthreads();  // (every thread of the block has read ws[1])
   if (threadIdx.x == 0) {
     const unsigned t = __hip_atomic_fetch_add(tick + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == gridDim.x - 1) {  // everybody has read the sum and the counter
+    if (t == gridDim.x - 1) {  // the last block to leave: everybody has read the counter
       ws[0] = total;
-      ws[2] = 0.f;
+      if (device_step) ws[1] += 1.0f;
       tick[0] = 0u;
       tick[1] = 0u;
     }
   }
 }
 
+int evf_clip_adam_step_impl(float* param, float* grad, float* m, float* v, int64_t n, float max_norm, float lr, float beta1,
+                            float beta2, float eps, int step, float* norm_ws, int zero_grad, void* stream);
+
 extern "C" int evf_clip_adam_fused(float* param, float* grad, float* m, float* v, int64_t n, float max_norm, float lr, float beta1,
                                    float beta2, float eps, int step, float* ws, int zero_grad, void* stream) {
   if (!param || !grad || !m || !v || !ws || n <= 0) return EVF_EINVAL;
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
-    if (ncu <= 0) ncu = 64;
-  }
+  if (n > CA_MAX_N || ((uintptr_t)grad & 15))  // large models: partial sums + a second launch (ws[0..1] mean the same there)
+    return evf_clip_adam_step_impl(param, grad, m, v, n, max_norm, lr, beta1, beta2, eps, step, ws, zero_grad, stream);
   const int device_step = step <= 0;  // step <= 0: use (and advance) the counter in ws[1]
-  const long want = (n + 255) / 256;
-  const int nblk = (int)(want < ncu ? want : ncu);  // all blocks resident: the hand-shake cannot deadlock
   double bc1 = 1.0, bc2 = 1.0;
   if (!device_step) {
     bc1 = 1.0 - pow((double)beta1, (double)step);
     bc2 = 1.0 - pow((double)beta2, (double)step);
   }
-  hipLaunchKernelGGL(k_clip_adam_fused, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), param, grad, m, v, (long)n, max_norm, lr,
+  const int nblk = (int)(n < 1024L * CA_BLOCKS ? (n + 1023) / 1024 : CA_BLOCKS);
+  hipLaunchKernelGGL(k_clip_adam_fused, dim3(nblk), dim3(1024), 0, EVF_STREAM(stream), param, grad, m, v, (long)n, max_norm, lr,
                      beta1, beta2, (float)((double)lr / bc1), (float)sqrt(bc2), eps, ws, device_step, zero_grad);
   return evf_status();
 }

@@ -107,6 +107,10 @@ int evf_interpolate(const float* idx, const float* weights, const float* pol_mas
  *   loss   [1] output.
  * flags: 1 = use smoothing mask, 2 = overwrite_intermediate, 4 = loss_scaling */
 int evf_cm_smooth_blocks(int B, int P, int H, int W);
+/* The loss launches merged (default): forward = [pre-warp | smoothness partials] + [striped splat + image statistics + the
+ * last block finishes the loss]; backward = [smoothness gradient | image gradients] + [event gather].  evf_cm_merge(0): one
+ * launch per pass as before (process-wide; the equivalence test, A/B measurements; environment EVF_CM_MERGE=0 likewise). */
+int evf_cm_merge(int on);
 /* ws: NULL, or evf_cm_loss_ws(S,B,M,H,W) floats of scratch (when that is > 0): the images are then accumulated in
  * LDS stripes from pre-warped events instead of with device-scope atomics (same sums, other summation order). */
 int64_t evf_cm_loss_ws(int S, int B, int M, int H, int W);
@@ -624,9 +628,10 @@ int evf_lstm_bwd(const float* g_hidden, const float* g_cell, const float* gates,
 int evf_clip_adam_step(float* param, float* grad, float* m, float* v, int64_t n,
                        float max_norm, float lr, float beta1, float beta2, float eps, int step,
                        float* norm_ws, int zero_grad, void* stream);
-/* The same step in ONE launch (squared norm, a grid-wide hand-shake of <= one block per CU, clip + Adam + zero_grad; no fill).
+/* The same step in ONE launch for parameter counts up to 2^20 (a few fat blocks; every block sums the whole gradient itself --
+ * a reproducible norm without atomics --, a short hand-shake guards zero_grad; larger n: the two launches above).
  * ws: >= 8 floats, zeroed ONCE by the caller and owned by this entry point afterwards: [0] squared gradient norm of the last
- * step, [1] the device-side step counter (as norm_ws[1] above), [2..4] the running sum and two tickets, left zero. */
+ * step, [1] the device-side step counter (as norm_ws[1] above), [3..4] two tickets, left zero. */
 int evf_clip_adam_fused(float* param, float* grad, float* m, float* v, int64_t n,
                         float max_norm, float lr, float beta1, float beta2, float eps, int step,
                         float* ws, int zero_grad, void* stream);

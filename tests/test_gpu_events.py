@@ -206,10 +206,20 @@ def _run_hip_loss(g, c, H, W):
     return val, flows
 
 
-@pytest.mark.parametrize("splat", ["atomics", "lds"])
+@pytest.mark.parametrize("splat", ["atomics", "lds", "lds-one-launch-per-pass"])
 def test_event_warping_golden_loss_and_grad(splat, monkeypatch):
-    # both image-accumulation paths of evf_cm_loss_fwd: device-scope atomics, and LDS stripes over pre-warped events
-    monkeypatch.setattr(hloss, "CM_LDS_MIN_EVENTS", 1 if splat == "lds" else 1 << 60)
+    # both image-accumulation paths of evf_cm_loss_fwd: device-scope atomics, and LDS stripes over pre-warped events -- the
+    # latter with the loss launches merged (default: 2 forward + 2 backward launches, the last splat block finishes the loss)
+    # and one launch per pass (evf_cm_merge(0): fill, pre-warp, splat, reduce, smooth, finalize / 3 backward)
+    monkeypatch.setattr(hloss, "CM_LDS_MIN_EVENTS", 1 if splat.startswith("lds") else 1 << 60)
+    assert _lib.load().evf_cm_merge(0 if splat.endswith("per-pass") else 1) == 0
+    try:
+        _golden_loss_and_grad()
+    finally:
+        _lib.load().evf_cm_merge(1)
+
+
+def _golden_loss_and_grad():
     g = load_golden("g4_event_warping")
     H, W = (int(v) for v in g["res"])
     for c in golden_cases(g):

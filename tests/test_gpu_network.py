@@ -1203,8 +1203,8 @@ def test_diagonal_launches_short_and_long_windows(monkeypatch, P):
 def test_fused_step_tail_equals_the_step_by_step_tail(monkeypatch):
     """evf_grads_finalize (slab reduction + row sums + segment add in one launch) and evf_clip_adam_fused (squared norm, grid
     hand-shake, clip + Adam + zero_grad in one launch) against the launches they replace, over three optimizer steps with
-    clipping active: conv-weight gradients bit-equal (the same slab sums in the same order), per-channel gradients and the norm to
-    fp32 round-off (another summation order), the same parameters after every step, the gradient buffer handed back zeroed and
+    clipping active: every gradient and the norm to fp32 round-off (the window itself is reproducible to round-off only, and
+    the per-channel sums take another order), the same parameters after every step, the gradient buffer handed back zeroed and
     the step counter advanced on the device."""
     from event_flow_amd import train as htrain
     from event_flow_amd.models import engine as heng
@@ -1227,7 +1227,7 @@ def test_fused_step_tail_equals_the_step_by_step_tail(monkeypatch):
             htrain.window_apply(model, lossf, opt, loss)
             torch.cuda.synchronize()
             assert float(opt.flat_grad.abs().max()) == 0.0  # zero_grad folded into the step
-            out.append((float(loss), grad, opt.grad_norm(), N(opt.flat_param).copy(), float(opt.norm_ws[1])))
+            out.append((float(loss.detach()), grad, opt.grad_norm(), N(opt.flat_param).copy(), float(opt.norm_ws[1])))
         if fused:
             assert float(opt.norm_ws[2:5].abs().max()) == 0.0  # (running sum and tickets handed back zeroed)
         return out, {k: (o, p.numel()) for (k, p), o in zip([(k, p) for k, p in model.named_parameters() if p.requires_grad],
@@ -1241,9 +1241,7 @@ def test_fused_step_tail_equals_the_step_by_step_tail(monkeypatch):
         assert n0 > 0.5  # (clipping is active)
         if step == 0:  # same weights, same forward: the window's gradient itself
             for k, (off, n) in layout.items():
-                if k.endswith("ff.weight") and not k.startswith("head") or k.endswith("rec.weight"):
-                    assert np.array_equal(g1[off:off + n], g0[off:off + n]), k  # slab sums: same order
-                else:
-                    np.testing.assert_allclose(g1[off:off + n], g0[off:off + n], rtol=2e-4, atol=1e-6 * np.abs(g0).max(), err_msg=k)
+                # (two runs of the window differ in the last bits already: the loss sums its images with float atomics)
+                np.testing.assert_allclose(g1[off:off + n], g0[off:off + n], rtol=2e-4, atol=2e-6 * np.abs(g0).max(), err_msg=k)
         d = np.abs(p1 - p0)
         assert d.max() <= 2 * 2e-4 + 1e-6 and np.mean(d > 2e-5) <= 0.02, (step, d.max(), np.mean(d > 2e-5))

@@ -25,6 +25,16 @@ def test_training_on_moving_dots_learns_the_motion(model):
     assert res["aee_after"] < res["aee_before"], res
 
 
+def _free_port():
+    """A TCP port nobody listens on right now (fixed port numbers collided between tests: a rendezvous port of an earlier
+    test still in TIME_WAIT made torch.distributed.run fail now and then)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_reference_shaped_drivers_run_end_to_end(tmp_path):
     """train_flow.py / eval_flow.py counterparts (reference train_flow.py:38-194, eval_flow.py:40-258) on the synthetic
     loader: training writes a checkpoint, evaluation loads it and reports FWL / RSAT / AEE."""
@@ -114,7 +124,7 @@ def test_train_driver_two_ranks_on_sequence_files(tmp_path):
     w = str(tmp_path / "m.pth")
     env = dict(os.environ, EVF_DP_BACKEND="gloo", EVF_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29631", os.path.join(ROOT, "train_flow.py"), "--config", tcfg, "--epochs", "2", "--out", w,
+           "--master-port", str(_free_port()), os.path.join(ROOT, "train_flow.py"), "--config", tcfg, "--epochs", "2", "--out", w,
            "--fused-optimizer"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -139,8 +149,8 @@ def _bench_two_ranks(extra, port, warmup=2):
 def test_bench_data_parallel_step_two_ranks_graph_equals_eager():
     """The multi-rank step (two hipGraphs around one eager all-reduce) must give the loss of the eager
     multi-rank step: same windows, same replicas, gradients summed over both ranks."""
-    g = _bench_two_ranks([], 29611)
-    e = _bench_two_ranks(["--no-graph"], 29612, warmup=4)  # graph mode adds 2 replay warm-up steps: same 7 updates
+    g = _bench_two_ranks([], _free_port())
+    e = _bench_two_ranks(["--no-graph"], _free_port(), warmup=4)  # graph mode adds 2 replay warm-up steps: same 7 updates
     assert g["n_gpus"] == 2 and g["config"]["launch"] == "hipgraph" and g["config"]["parallelism"] == "dp2", g
     assert e["config"]["launch"] == "eager", e
     assert g["config"]["global_batch"] == 16, g
@@ -168,8 +178,8 @@ def test_rccl_code_path_on_one_rank_graph_equals_eager_and_plain_step():
     the step as TWO hipGraphs (thread_local capture) with the RCCL all-reduce launched eagerly between them,
     barrier(device_ids), max_over_ranks -- forced at world size 1 (EVF_DP_FORCE=1).  A one-rank SUM all-reduce is the
     identity, so the loss after the same number of updates must equal the plain one-GPU run's (graph and eager)."""
-    g = _bench_rccl_one_rank([], 29631)
-    e = _bench_rccl_one_rank(["--no-graph", "--warmup", "4"], 29632)  # graph mode adds 2 replay warm-up steps: same 8 updates
+    g = _bench_rccl_one_rank([], _free_port())
+    e = _bench_rccl_one_rank(["--no-graph", "--warmup", "4"], _free_port())  # graph mode adds 2 replay warm-up steps: same 8 updates
     col = g["config"]["collective"]
     assert col["backend"] == "nccl" and col["library"].startswith("RCCL") and col["ranks"] == 1 and col["forced_at_one_rank"], col
     assert g["config"]["launch"] == "hipgraph" and e["config"]["launch"] == "eager", (g["config"], e["config"])
@@ -190,7 +200,7 @@ def test_two_graph_rccl_step_is_bitwise_the_one_graph_step():
     """What a rank replays in a multi-GPU run (two hipGraphs around the eager RCCL all-reduce, forced at world size 1) leaves
     EXACTLY the parameters, Adam moments and recurrent states of the single-GPU one-graph step (deterministic loss, no clipping):
     tools/dp_two_graph_check.py in its own process (nccl process group)."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29657")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "EVF_DP_FORCE", "EVF_DP_BACKEND"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_two_graph_check.py")], capture_output=True, text=True,
