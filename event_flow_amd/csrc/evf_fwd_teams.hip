@@ -128,6 +128,9 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
 
     if (wv < 4) {
       // =============================================== team M ===============================================================
+#ifdef FT_MPRIO  // (A/B builds)
+      __builtin_amdgcn_s_setprio(FT_MPRIO);
+#endif
       const int i = lane & 31, kg = lane >> 5;
       uint32_t* s_hx = (uint32_t*)(smem + FT_OFF_HALO) + wv * (2 * FT_HW * 2);
       uint32_t* s_hz = s_hx + FT_HW * 2;

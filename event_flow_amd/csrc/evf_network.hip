@@ -730,14 +730,20 @@ __global__ void k_plif_trace_bwd(const float4* __restrict__ g_cur, const float4*
     const long e = e0 + tid;
     const bool ok = e < npix * 8;
     const long ec = ok ? e : npix * 8 - 1, pix = ec >> 3;
-    const float4 gc4 = g_cur[ec], po4 = pt_out[ec];
+    const float4 gc4 = g_cur[ec];
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // optional tensors: load from a valid dummy, select afterwards (no load under a branch)
     const float4 gkl = (g_pt_carry ? g_pt_carry : g_cur)[ec], ppl = (pt_prev ? pt_prev : g_cur)[ec];
     const float4 gk4 = g_pt_carry ? gkl : z4, pp4 = pt_prev ? ppl : z4;
     const float Pv = P[pix];
-    const float gc[4] = {gc4.x, gc4.y, gc4.z, gc4.w}, po[4] = {po4.x, po4.y, po4.z, po4.w};
+    (void)pt_out;
+    const float gc[4] = {gc4.x, gc4.y, gc4.z, gc4.w};
     const float gk[4] = {gk4.x, gk4.y, gk4.z, gk4.w}, pp[4] = {pp4.x, pp4.y, pp4.z, pp4.w};
+    // pt' of the forward pass is RECOMPUTED from its two operands (pt_prev is read anyway, P is one word per pixel) with the
+    // forward's own expression (evf_fwd_b3.hip: pto = p * lpt + (1 - lpt) * P): 128 of the kernel's 640 B/px less
+    float po[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) po[k] = pp[k] * lp[k] + (1.0f - lp[k]) * Pv;
     float gp[4], gPp = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -33,6 +33,6 @@ if [ -n "$P" ]; then
     k=$((k + 1)); O=gpurun_out/ab_prof_$k; rm -rf $O
     env $E timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python bench.py --config $C --steps 20 --warmup 5 --no-cpu-baseline --no-iwe --no-others > /dev/null 2>&1
     f=$(find $O -name "*kernel_stats.csv" | head -1)
-    [ -n "$f" ] && grep "$P" "$f" | awk -F'","' -v t="[$k: $E]" '{gsub(/"/,"",$1); split($1,a,"("); printf "%s %-40s calls %s avg %.1f us\n", t, a[1], $2, $4/1000}'
+    [ -n "$f" ] && grep "$P" "$f" | awk -F'","' -v t="[$k: $E]" '{n=split($0,f,"\","); split(f[2],g,","); printf "%s %s: calls %s avg %.1f us\n", t, substr(f[1],2,40), g[1], g[3]/1000}'
   done
 fi
