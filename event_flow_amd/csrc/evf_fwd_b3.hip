@@ -658,9 +658,12 @@ static int fw_defer_launch(FwDefer& fw_defer, void* stream) {
     int nhard = 0;
     for (int k = 0; k < n; ++k) nhard += jobs.j[k].hard_reset ? 1 : 0;
     evf_prof_mark(0, 0, stream);
+    int rc_t = EVF_EINVAL;  // (the teams launch refuses geometries beyond its index arithmetic: those take the next path)
     if (mode == 2 && (nhard == 0 || nhard == n)) {
-      const int rc = evf_fwd_diag_t_launch(jobs, n, fw_defer.B, fw_defer.H, fw_defer.W, stream);
-      if (rc) return rc;
+      rc_t = evf_fwd_diag_t_launch(jobs, n, fw_defer.B, fw_defer.H, fw_defer.W, stream);
+      if (rc_t && rc_t != EVF_EINVAL) return rc_t;
+    }
+    if (rc_t == EVF_OK) {
     } else if (persistent && (nhard == 0 || nhard == n)) {  // (cells of both reset rules in one index: the per-tile kernel)
       FpPlan plan;
       plan.njobs = n, plan.ntx = evf_cdiv(fw_defer.W, TW), plan.nyy = evf_cdiv(fw_defer.H, 2);

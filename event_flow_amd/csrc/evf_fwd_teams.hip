@@ -25,6 +25,9 @@
 #include "evf_fwd.h"
 
 #define FT_EW 8
+#ifndef FT_DEPTH2
+#define FT_DEPTH2 1
+#endif
 #define FT_WAVES (4 + FT_EW)
 #define FT_THREADS (64 * FT_WAVES)
 #define FT_HW (4 * HALO_W)                              // halo pixels of a strip: rows y0 - 1 .. y0 + 2
@@ -35,8 +38,8 @@
 #define FT_OFF_PW (FT_OFF_PAR + 2 * C32 * 4)            // prediction head: 2 x 32 weights, 2 biases (+2 pad)
 #define FT_OFF_HALO (FT_OFF_PW + (2 * C32 + 4) * 4)     // [4 M waves][x | z][FT_HW pixels][2 words]
 #define FT_OFF_ACC (FT_OFF_HALO + 4 * 2 * FT_HW * 8)    // [4 strips][64 pixels][FW_SP floats]
-#define FT_OFF_FLAG (FT_OFF_ACC + 4 * 64 * FW_SP * 4)   // full[4]: tiles team M's wave has published; empty[4]: reads of them by team E (2 per tile)
-#define FT_LDS (FT_OFF_FLAG + 32)
+#define FT_OFF_FLAG (FT_OFF_ACC + 4 * 64 * FW_SP * 4)   // full[4]: tiles team M's wave has published; empty[4][2]: tiles read by each of the strip's two team E waves
+#define FT_LDS (FT_OFF_FLAG + 48)
 
 __device__ uint4 ft_zero_page[256];  // 4 KiB of zeros: what a cell without previous state reads (no load under a branch, no select)
 
@@ -49,13 +52,13 @@ struct FtPlan {
   int total;      // sum of nquads * weight
 };
 
-#ifdef FT_STAMPS  // phase stamps (debug build -DFT_STAMPS=<cells> through EVF_LIB; launches of that many cells): [block < 4][wave][128] shader-clock values
+#ifdef FT_STAMPS  // phase stamps (debug build -DFT_STAMPS=<cells> through EVF_LIB; launches of that many cells): [blocks 0, 80, 160, 240][wave][128] shader-clock values
 __device__ unsigned long long ft_stamps[4 * FT_WAVES * 128];
 extern "C" int evf_debug_ft_stamps(void* dst) { return evf_hip(hipMemcpyFromSymbol(dst, HIP_SYMBOL(ft_stamps), sizeof(ft_stamps))); }
 #define FT_STAMP()                                                                                     \
   do {                                                                                                 \
-    if (plan.njobs == FT_STAMPS && blockIdx.x < 4 && lane == 0 && nst < 128)                           \
-      ft_stamps[(blockIdx.x * FT_WAVES + wv) * 128 + nst++] = __builtin_readcyclecounter();            \
+    if (plan.njobs == FT_STAMPS && blockIdx.x % 80 == 0 && blockIdx.x < 320 && lane == 0 && nst < 128) \
+      ft_stamps[((blockIdx.x / 80) * FT_WAVES + wv) * 128 + nst++] = __builtin_readcyclecounter();     \
   } while (0)
 #else
 #define FT_STAMP() do {} while (0)
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
     auto pr8 = [&](int e) { return ((t >> e) & 1u) * 0x3F80u | (((t >> (e + 1)) & 1u) * 0x3F80u) << 16; };
     s_lut[tid] = make_uint4(pr8(0), pr8(2), pr8(4), pr8(6));
   }
-  if (tid < 8) ((uint32_t*)(smem + FT_OFF_FLAG))[tid] = 0u;
+  if (tid < 12) ((uint32_t*)(smem + FT_OFF_FLAG))[tid] = 0u;
   int tile0 = 0;  // tiles (rounds) of this block so far: the flag counters run on across its cells
   bool first_cell = true;
   const long lo = ((long)blockIdx.x * plan.total) / gridDim.x, hi = ((long)(blockIdx.x + 1) * plan.total) / gridDim.x;
@@ -97,6 +100,10 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
     if (i0 >= i1) continue;  // (block-uniform)
     const FwJob& J = jobs.j[c];
     const bool rec = J.wrec != nullptr;
+    // A feed-forward cell leaves the recurrent weights' 54 KiB unused: its tiles alternate between FT_OFF_ACC and that region,
+    // so team M may run TWO rounds ahead of team E (with one tile per strip the two teams took turns waiting for each other:
+    // phase stamps showed team M 3-6 k cycles per round at the `empty` poll although team E idles half of its round).
+    const int depth = (FT_DEPTH2 && !rec) ? 2 : 1;
     if (!first_cell) __syncthreads();  // every wave is done with the previous cell's weights, parameters and tiles
     first_cell = false;
     for (int u = wv; u < NFRAG; u += FT_WAVES) b3_glds16(J.wff + u * 64 + lane, s_wff + u * 64);
@@ -134,7 +141,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
       const int i = lane & 31, kg = lane >> 5;
       uint32_t* s_hx = (uint32_t*)(smem + FT_OFF_HALO) + wv * (2 * FT_HW * 2);
       uint32_t* s_hz = s_hx + FT_HW * 2;
-      float* s_acc = (float*)(smem + FT_OFF_ACC) + wv * (64 * FW_SP);
+      float* s_acc0 = (float*)(smem + FT_OFF_ACC) + wv * (64 * FW_SP);
+      float* s_acc1 = depth == 2 ? (float*)(smem + FT_OFF_WREC) + wv * (64 * FW_SP) : s_acc0;
       int hro[3], hco[3];
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
         }
       };
       halo_fetch(i0);
-      const unsigned fl_full = FT_OFF_FLAG + 4 * wv, fl_empty = FT_OFF_FLAG + 16 + 4 * wv;  // (LDS byte addresses)
+      const unsigned fl_full = FT_OFF_FLAG + 4 * wv, fl_empty = FT_OFF_FLAG + 16 + 8 * wv;  // (LDS byte addresses; `empty`: one counter per row's wave)
       for (int r = 0; r < n; ++r) {
         FT_STAMP();
         const bool valid = 4 * (i0 + r) + wv < nstrips;  // (wave-uniform)
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         f32x16 acc0 = {0}, acc1 = {0};
-        uint32_t ev = 0u;  // team E's read counter of this wave's tile, requested during the last matrix phase
+        unsigned long long ev = 0ull;  // team E's two read counters of this wave's tiles, requested during the last matrix phase
         // Matrix phase, software pipelined (as k_fwd_diag_p): the two A fragments (table look-ups) and the three weight
         // fragments of stage g + 1 are requested BEFORE the 6 MFMAs of stage g and pinned there.
         auto conv_phase = [&](const uint32_t* __restrict__ sh, const uint4* __restrict__ sw, auto last_tag) {
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
 #endif
             }
             // (the counter read rides in the LDS queue behind the operand reads: its latency is covered by the last six stages)
-            if (LAST && g == 11) asm volatile("ds_read_b32 %0, %1" : "=v"(ev) : "v"(fl_empty) : "memory");
+            if (LAST && g == 11) asm volatile("ds_read_b64 %0, %1" : "=v"(ev) : "v"(fl_empty) : "memory");
             __builtin_amdgcn_sched_barrier(0);
           }
         };
@@ -232,12 +240,14 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ev)::"memory");
         }
         FT_STAMP();
-        // ---- the tile of round r - 1 must have been read by both of team E's waves (it almost always has: they read it as
-        // soon as it is published, a whole matrix phase ago)
-        const uint32_t need = 2u * (uint32_t)(tile0 + r);
-        while ((uint32_t)__builtin_amdgcn_readfirstlane((int)ev) < need) {
+        // ---- the tile this round's buffer held before (round r - depth) must have been read by both of team E's waves
+        // (one counter per wave: with their sum and two tiles in flight, a wave two reads ahead would cover for the other one)
+        const uint32_t need = (uint32_t)(tile0 + max(r - (depth - 1), 0));
+        float* s_acc = (r & 1) ? s_acc1 : s_acc0;
+        while (min((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ev),
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ev >> 32))) < need) {
           __builtin_amdgcn_s_sleep(1);
-          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ev) : "v"(fl_empty) : "memory");
+          asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ev) : "v"(fl_empty) : "memory");
         }
         if (valid) {
           // ---- the two accumulator tiles -> LDS, [pixel][channel] rows: lane = pixel i of rows y0, y0 + 1; register
@@ -266,7 +276,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
 #endif
       const int e = wv - 4, sidx = e >> 1, m = e & 1;     // strip slot (= team M's wave) and row of the strip
       const int p8 = lane >> 3, c4 = (lane & 7) * 4;       // pixels p8 + 8k (k = 0..3), channels c4 .. c4 + 3
-      const float* s_accE = (const float*)(smem + FT_OFF_ACC) + sidx * (64 * FW_SP) + (m * 32) * FW_SP;
+      const float* s_accE0 = (const float*)(smem + FT_OFF_ACC) + sidx * (64 * FW_SP) + (m * 32) * FW_SP;
+      const float* s_accE1 = depth == 2 ? (const float*)(smem + FT_OFF_WREC) + sidx * (64 * FW_SP) + (m * 32) * FW_SP : s_accE0;
       float lam[4], th[4], oml[4];
       {
         const float4 l4 = *(const float4*)(s_par + c4), t4 = *(const float4*)(s_par + C32 + c4);
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
           }
         }
       };
-      const unsigned fl_full = FT_OFF_FLAG + 4 * sidx, fl_empty = FT_OFF_FLAG + 16 + 4 * sidx;  // (LDS byte addresses)
+      const unsigned fl_full = FT_OFF_FLAG + 4 * sidx, fl_empty = FT_OFF_FLAG + 16 + 8 * sidx + 4 * m;  // (LDS byte addresses)
       auto e_round = [&](int r, float4 (&vp)[4], uint32_t (&zq)[4]) {  // the epilogue of round r's strips (r = 0 .. n - 1)
         FT_STAMP();
         const int si = 4 * (i0 + r) + sidx;
@@ -349,6 +360,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
         }
         float4 a4[4];
         uint32_t zw[4];
+        const float* s_accE = (r & 1) ? s_accE1 : s_accE0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           a4[k] = *(const float4*)(s_accE + (p8 + 8 * k) * FW_SP + c4);
@@ -538,12 +550,15 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
     (void)hipFuncSetAttribute((const void*)k_fwd_diag_t<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
     attr_set = true;
   }
-  static int w_ff = 0, w_rec = 0;  // relative cost of a round: feed-forward / recurrent cell (EVF_FT_W=ff,rec: measurements)
+  // relative cost of a round: feed-forward / recurrent cell / feed-forward cell with the prediction head in team E's epilogue (its
+  // ~320 vector instructions per row make team E the slower team there: 8 k cycles per round against 5.8 k, phase stamps)
+  // (EVF_FT_W=ff,rec,pred: measurements)
+  static int w_ff = 0, w_rec = 0, w_pred = 0;
   if (!w_ff) {
-    w_ff = 4, w_rec = 7;
+    w_ff = 8, w_rec = 14, w_pred = 13;
     const char* e = getenv("EVF_FT_W");
-    int a = 0, b = 0;
-    if (e && sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && a < 64 && b < 64) w_ff = a, w_rec = b;
+    int a = 0, b = 0, c = 0;
+    if (e && sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0 && a < 64 && b < 64 && c < 64) w_ff = a, w_rec = b, w_pred = c;
   }
   int nhard = 0;
   for (int k = 0; k < n; ++k) nhard += jobs.j[k].hard_reset ? 1 : 0;
@@ -554,11 +569,13 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
   if (nstrips >= (1L << 28)) return EVF_EINVAL;
   plan.nstrips = (int)nstrips;
   plan.nquads = evf_cdiv(nstrips, 4);
-  plan.total = 0;
+  long total = 0;
   for (int k = 0; k < FW_MAX_JOBS; ++k) {
-    plan.weight[k] = (k < n && jobs.j[k].wrec) ? w_rec : w_ff;
-    if (k < n) plan.total += plan.nquads * plan.weight[k];
+    plan.weight[k] = (k < n && jobs.j[k].wrec) ? w_rec : ((k < n && jobs.j[k].pr.w) ? w_pred : w_ff);
+    if (k < n) total += (long)plan.nquads * plan.weight[k];
   }
+  if (total >= (1L << 31)) return EVF_EINVAL;
+  plan.total = (int)total;
   const long nq = (long)plan.nquads * n;
   const int nblk = (int)(nq / 2 < ncu ? (nq + 1) / 2 : ncu);  // (tiny launches: at least two rounds per block)
   const bool full = (H % 2 == 0) && (W % TW == 0);

@@ -22,7 +22,7 @@ lib.evf_debug_ft_stamps.argtypes = [ctypes.c_void_p]
 assert lib.evf_debug_ft_stamps(buf.ctypes.data) == 0
 st = buf.reshape(4, NW, 128)
 t0 = min(int(x) for x in st[st > 0].ravel())
-for b in (0, 3):
+for b in (0, 1, 2, 3):  # blocks 0, 80, 160, 240
     for w in range(NW):
         v = st[b, w]
         v = v[v > 0].astype(np.int64)
