@@ -1149,15 +1149,26 @@ struct FbJob {
   float width;
   int accumulate;
   int kind;  // 0 feed-forward, 1 recurrent, 2 under the prediction head
+  int blk0;  // first block of the cell in a launch of several (INT_MAX: unused entry)
+  int nblk;  // its number of blocks
   int pad_;
 };
+
 struct FbJobs {
   FbJob j[FB_MAX_JOBS];
 };
+// the cell of a block: cells own consecutive block ranges of DIFFERENT lengths (fb_split_blocks)
+__device__ __forceinline__ int fb_job_of_block(const FbJobs& jobs, int blk) {
+  int jb = 0;
+#pragma unroll
+  for (int k = 1; k < FB_MAX_JOBS; ++k) jb += blk >= jobs.j[k].blk0 ? 1 : 0;
+  return jb;
+}
 __global__ __launch_bounds__(FB_THREADS) void k_bwd_diag(FbJobs jobs, int B, int H, int W, int nchunk, long nunits, int row_ld,
-                                                         int nblk, int nrows_total) {
-  const int jb = blockIdx.x / nblk, bid = blockIdx.x - jb * nblk;
+                                                         int nrows_total) {
+  const int jb = fb_job_of_block(jobs, (int)blockIdx.x);
   const FbJob& J = jobs.j[jb];
+  const int bid = (int)blockIdx.x - J.blk0, nblk = J.nblk;
   if (J.kind == 1)
     fb_body<true, false, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
                                nchunk, nunits, 1, EVF_ARCTAN, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak,
@@ -1174,9 +1185,10 @@ __global__ __launch_bounds__(FB_THREADS) void k_bwd_diag(FbJobs jobs, int B, int
 
 template <int EW>
 __global__ __launch_bounds__(64 * (EW + 4)) void k_bwd_diag_ws(FbJobs jobs, int B, int H, int W, int nchunk, long nunits, int row_ld,
-                                                             int nblk, int nrows_total) {
-  const int jb = blockIdx.x / nblk, bid = blockIdx.x - jb * nblk;
+                                                             int nrows_total) {
+  const int jb = fb_job_of_block(jobs, (int)blockIdx.x);
   const FbJob& J = jobs.j[jb];
+  const int bid = (int)blockIdx.x - J.blk0, nblk = J.nblk;
   if (J.kind == 1)
     fb_body_ws<true, false, EW>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
                                 nchunk, nunits, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak, J.g_thresh,
@@ -1309,6 +1321,54 @@ static int fb_blocks_per_cell(long nunits, int n, int per_unit = 11) {  // per_u
   return best_nb;
 }
 
+// The n cells of a launch share n * nblk blocks IN PROPORTION TO WHAT A UNIT OF THEIR KIND COSTS: a recurrent cell contracts two
+// weight gradients per unit (its matrix team is the slower team), the cell under the prediction head carries the head's backward;
+// with equal block counts their blocks were the tail of every launch.  Weights per kind (feed-forward, recurrent, top) from
+// EVF_BWD_W=a,b,c (measurements); 0,0,0 = equal shares.  A block takes 8..64 units (fb_body*: one lane per unit in the geometry
+// table, one slab row per block).  Sets blk0 / nblk of every entry; returns the number of blocks of the launch.
+static int fb_split_blocks(FbJobs& jobs, int n, int nblk, long nunits, bool teams8) {
+  static int w[3] = {-1, 0, 0};
+  if (w[0] < 0) {
+    w[0] = 10, w[1] = 13, w[2] = 11;
+    const char* e = getenv("EVF_BWD_W");
+    int a = 0, b = 0, c = 0;
+    if (e && sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a >= 0 && b >= 0 && c >= 0 && a < 256 && b < 256 && c < 256) w[0] = a, w[1] = b, w[2] = c;
+  }
+  const int lo = evf_cdiv(nunits, FB_UNITS_MAX), hi = evf_cdiv(nunits, FB_UNITS);
+  int nb[FB_MAX_JOBS], wj[FB_MAX_JOBS];
+  long ws = 0;
+  for (int k = 0; k < n; ++k) wj[k] = (teams8 && w[0] > 0 && w[1] > 0 && w[2] > 0) ? w[jobs.j[k].kind] : 1, ws += wj[k];
+  const long tot = (long)nblk * n;
+  long used = 0;
+  for (int k = 0; k < n; ++k) {
+    long v = tot * wj[k] / ws;
+    nb[k] = (int)(v < lo ? lo : (v > hi ? hi : v));
+    used += nb[k];
+  }
+  // left-over blocks one at a time to the cell whose blocks are the slowest; too many (clamping): from the fastest
+  auto cost = [&](int k, int b) { return (long)wj[k] * evf_cdiv(nunits, b); };
+  while (used < tot) {
+    int best = -1;
+    for (int k = 0; k < n; ++k)
+      if (nb[k] < hi && (best < 0 || cost(k, nb[k]) > cost(best, nb[best]))) best = k;
+    if (best < 0) break;
+    ++nb[best], ++used;
+  }
+  while (used > tot) {
+    int best = -1;
+    for (int k = 0; k < n; ++k)
+      if (nb[k] > lo && (best < 0 || cost(k, nb[k] - 1) < cost(best, nb[best] - 1))) best = k;
+    if (best < 0) break;
+    --nb[best], --used;
+  }
+  int b0 = 0;
+  for (int k = 0; k < FB_MAX_JOBS; ++k) {
+    if (k < n) jobs.j[k].blk0 = b0, jobs.j[k].nblk = nb[k], b0 += nb[k];
+    else jobs.j[k].blk0 = 0x7fffffff, jobs.j[k].nblk = 1;
+  }
+  return b0;
+}
+
 static int fb_diag_select = -1;  // -1 environment / default, 0 k_bwd_diag, 1 k_bwd_diag_ws<4>, 2 k_bwd_diag_ws<8>
 extern "C" int evf_bwd_diag_select(int which) {
   if (which < -1 || which > 2) return EVF_EINVAL;
@@ -1339,16 +1399,17 @@ static int fb_defer_launch(FbDefer& fb_defer, int d, void* stream) {
   const int nrows = evf_cdiv(nunits, FB_UNITS), nchunk = (fb_defer.W + FB_CW - 1) / FB_CW;
   static const int cost_env = []() { const char* e = getenv("EVF_BWD_COST"); return e ? atoi(e) : 0; }();  // (A/B measurements)
   const int nblk = fb_blocks_per_cell(nunits, n, cost_env > 0 ? cost_env : (teams == 2 ? 8 : 11));  // (k_bwd_diag_ws<8>: ~4.0 k cycles per unit, phase stamps)
+  const int ntot = fb_split_blocks(jobs, n, nblk, nunits, teams == 2);
   evf_prof_mark(1, 0, stream);
   if (teams == 2)
-    hipLaunchKernelGGL(k_bwd_diag_ws<8>, dim3(nblk * n), dim3(768), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
-                       fb_defer.W, nchunk, nunits, fb_defer.row_ld, nblk, nrows);
+    hipLaunchKernelGGL(k_bwd_diag_ws<8>, dim3(ntot), dim3(768), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
+                       fb_defer.W, nchunk, nunits, fb_defer.row_ld, nrows);
   else if (teams == 1)
-    hipLaunchKernelGGL(k_bwd_diag_ws<4>, dim3(nblk * n), dim3(512), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
-                       fb_defer.W, nchunk, nunits, fb_defer.row_ld, nblk, nrows);
+    hipLaunchKernelGGL(k_bwd_diag_ws<4>, dim3(ntot), dim3(512), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
+                       fb_defer.W, nchunk, nunits, fb_defer.row_ld, nrows);
   else
-    hipLaunchKernelGGL(k_bwd_diag, dim3(nblk * n), dim3(FB_THREADS), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
-                       fb_defer.W, nchunk, nunits, fb_defer.row_ld, nblk, nrows);
+    hipLaunchKernelGGL(k_bwd_diag, dim3(ntot), dim3(FB_THREADS), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
+                       fb_defer.W, nchunk, nunits, fb_defer.row_ld, nrows);
   evf_prof_mark(1, 1, stream);
   fb_defer.n[d] = 0;
   return evf_status();
@@ -1431,7 +1492,7 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
       FbJob& J = fb_defer.job[evf_bwd_defer.slot][fb_defer.n[evf_bwd_defer.slot]++];
       J = FbJob{(const float4*)g_z_out, (const float4*)g_z_out2, (const float4*)g_v_out, (const float4*)v_out,
                 (const float4*)v_prev, z_prev, xT, zT_prev, leak, thresh, (float4*)g_cur, (uint2*)g_split, (float4*)g_v_prev, g_leak, g_thresh,
-                slab_ff, slab_rec, top, act_width, accumulate, topp ? 2 : (zT_prev ? 1 : 0), 0};
+                slab_ff, slab_rec, top, act_width, accumulate, topp ? 2 : (zT_prev ? 1 : 0), 0, 0, 0};
       return EVF_OK;
     }
     const int rc = evf_bwd_defer_flush_now(bctx, stream);  // not recordable: everything recorded runs first
@@ -1452,10 +1513,10 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
     FbJobs jobs;
     const FbJob J{(const float4*)g_z_out, (const float4*)g_z_out2, (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev,
                   z_prev, xT, zT_prev, leak, thresh, (float4*)g_cur, (uint2*)g_split, (float4*)g_v_prev, g_leak, g_thresh, slab_ff,
-                  slab_rec, top, act_width, accumulate, topp ? 2 : (zT_prev ? 1 : 0), 0};
-    for (int k = 0; k < FB_MAX_JOBS; ++k) jobs.j[k] = J;
+                  slab_rec, top, act_width, accumulate, topp ? 2 : (zT_prev ? 1 : 0), 0, 0, 0};
     const int nblk = fb_blocks_per_cell(nunits, 1, 8);
-    hipLaunchKernelGGL(k_bwd_diag_ws<8>, dim3(nblk), dim3(768), FB_LDS, st, jobs, B, H, W, nchunk, nunits, row_ld, nblk, nrows_all);
+    for (int k = 0; k < FB_MAX_JOBS; ++k) jobs.j[k] = J, jobs.j[k].blk0 = k ? 0x7fffffff : 0, jobs.j[k].nblk = nblk;
+    hipLaunchKernelGGL(k_bwd_diag_ws<8>, dim3(nblk), dim3(768), FB_LDS, st, jobs, B, H, W, nchunk, nunits, row_ld, nrows_all);
     return evf_status();
   }
 #define FB_GO(REC_, TOP_, FAST_, slot)                                                                                    \
