@@ -81,6 +81,7 @@ NETWORK_SIGNATURES = {
     "evf_conv_dgrad_b3_f32_pair": [P, P, P, I, P, P, I, I, I, P, P, P],
     "evf_conv_dgrad_b3_pair": [P, P, P, I, P, P, I, I, I, P, P, P],
     "evf_conv_plif_fwd_b3": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P],
+    "evf_conv_plif_fwd_b3_pred": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P],
     "evf_head_plif_fwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P],
     "evf_plif_trace_bwd": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, I, P],
     "evf_conv_dgrad": [P, P, P, I, P, P, I, I, I, I, P],
@@ -285,6 +286,8 @@ def raw(name, *args):
     return getattr(load(), name)(*args, stream_ptr())
 
 _DEFER_SAFE_FWD = {"evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_head_lif_fwd", "evf_fwd_defer_flush",
+                   "evf_conv_plif_fwd_b3", "evf_conv_plif_fwd_b3_pred",
+                   "evf_head_plif_fwd",  # (launches at once: reads the window's input and its own state only)
                    "evf_encode_window", "evf_encode_events", "evf_events_to_image"}
 # backward recording (evf_bwd_defer_*): these record themselves, or flush inside the library when they cannot
 _DEFER_SAFE_BWD = {"evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad2", "evf_lif_bwd_wgrad_top", "evf_conv_dgrad_b3_f32",

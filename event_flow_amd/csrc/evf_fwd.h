@@ -55,6 +55,13 @@ struct FwJob {
   PredArgs pr;
   int hard_reset;
   int pad_;
+  // PLIF cell (spiking_submodules.py:191-227, :618-657; leak_pt == NULL: LIF): per-channel trace parameters, previous trace
+  // [B,H,W,32] or NULL, new trace, pooled pre-synaptic activity [B,H,W] (saved for the backward)
+  const float* leak_pt;
+  const float* add_pt;
+  const float* pt_prev;
+  float* pt_out;
+  float* P_out;
 };
 struct FwJobs {
   FwJob j[FW_MAX_JOBS];

@@ -622,6 +622,11 @@ extern "C" int evf_fwd_diag_select(int which) {
   return EVF_OK;
 }
 
+static int launch_fwd_b3_now(const uint32_t* x, const void* wb_ff, const void* wb_rec, const float* leak,
+                             const float* thresh, const float* v_prev, const uint32_t* z_prev, int B, int H, int W,
+                             int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out, const PlifArgs* plif,
+                             void* stream, PredArgs pd);
+
 // Launch what has been recorded (diagonals in increasing order) and keep recording.
 static int fw_defer_launch(FwDefer& fw_defer, void* stream) {
   {  // the head layer's recorded cells first: every diagonal cell of pass t reads (through its layers below) the head of pass t
@@ -655,15 +660,23 @@ static int fw_defer_launch(FwDefer& fw_defer, void* stream) {
     if (!n) continue;
     FwJobs jobs;
     for (int k = 0; k < FW_MAX_JOBS; ++k) jobs.j[k] = fw_defer.job[d][k < n ? k : 0];
-    int nhard = 0;
-    for (int k = 0; k < n; ++k) nhard += jobs.j[k].hard_reset ? 1 : 0;
+    int nhard = 0, nplif = 0;
+    for (int k = 0; k < n; ++k) nhard += jobs.j[k].hard_reset ? 1 : 0, nplif += jobs.j[k].leak_pt ? 1 : 0;
     evf_prof_mark(0, 0, stream);
     int rc_t = EVF_EINVAL;  // (the teams launch refuses geometries beyond its index arithmetic: those take the next path)
-    if (mode == 2 && (nhard == 0 || nhard == n)) {
+    if ((mode == 2 || nplif) && (nhard == 0 || nhard == n)) {
       rc_t = evf_fwd_diag_t_launch(jobs, n, fw_defer.B, fw_defer.H, fw_defer.W, stream);
       if (rc_t && rc_t != EVF_EINVAL) return rc_t;
     }
     if (rc_t == EVF_OK) {
+    } else if (nplif) {  // (only the teams kernel and the one-cell kernel know the trace: cell by cell)
+      for (int k = 0; k < n; ++k) {
+        const FwJob& J = jobs.j[k];
+        const PlifArgs pa{J.leak_pt, J.add_pt, J.pt_prev, J.pt_out, J.P_out};
+        const int rc = launch_fwd_b3_now(J.x, J.wff, J.wrec, J.leak, J.thresh, J.v_prev, J.z_prev, fw_defer.B, fw_defer.H, fw_defer.W,
+                                         J.hard_reset, J.v_out, J.z_out, J.zT_out, J.leak_pt ? &pa : nullptr, stream, J.pr);
+        if (rc) return rc;
+      }
     } else if (persistent && (nhard == 0 || nhard == n)) {  // (cells of both reset rules in one index: the per-tile kernel)
       FpPlan plan;
       plan.njobs = n, plan.ntx = evf_cdiv(fw_defer.W, TW), plan.nyy = evf_cdiv(fw_defer.H, 2);
@@ -746,7 +759,7 @@ static int launch_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_re
   PredArgs pd = pred ? *pred : PredArgs{nullptr, nullptr, nullptr};
   const int fctx = evf_ctx_find(stream);
   FwDefer& fw_defer = fw_tab[fctx < 0 ? 0 : fctx];
-  if (fctx >= 0 && fw_defer.active && !plif) {  // recorded, launched by evf_fwd_defer_flush (or when a diagonal is full / the geometry changes)
+  if (fctx >= 0 && fw_defer.active) {  // recorded, launched by evf_fwd_defer_flush (or when a diagonal is full / the geometry changes)
     if (fw_defer.B && (fw_defer.B != B || fw_defer.H != H || fw_defer.W != W)) {
       const int rc = fw_defer_launch(fw_defer, stream);
       if (rc) return rc;
@@ -757,16 +770,27 @@ static int launch_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_re
     }
     fw_defer.B = B, fw_defer.H = H, fw_defer.W = W;
     fw_defer.job[fw_defer.slot][fw_defer.n[fw_defer.slot]++] =
-        FwJob{x, (const uint4*)wb_ff, (const uint4*)wb_rec, leak, thresh, v_prev, z_prev, v_out, z_out, zT_out, pd, hard_reset, 0};
+        FwJob{x, (const uint4*)wb_ff, (const uint4*)wb_rec, leak, thresh, v_prev, z_prev, v_out, z_out, zT_out, pd, hard_reset, 0,
+              plif ? plif->leak_pt : nullptr, plif ? plif->add_pt : nullptr, plif ? plif->pt_prev : nullptr,
+              plif ? plif->pt_out : nullptr, plif ? plif->P_out : nullptr};
     if (fw_poison) {  // debug aid: the outputs hold conspicuous garbage until the flush has run the cell
       const size_t npix = (size_t)B * H * W;
       int rc = evf_hip(hipMemsetAsync(v_out, 0xFF, npix * C32 * sizeof(float), EVF_STREAM(stream)));  // 0xFFFFFFFF = NaN
       if (!rc && z_out) rc = evf_hip(hipMemsetAsync(z_out, 0xFF, npix * sizeof(uint32_t), EVF_STREAM(stream)));
       if (!rc && pd.flow) rc = evf_hip(hipMemsetAsync(pd.flow, 0xFF, npix * 2 * sizeof(float), EVF_STREAM(stream)));
+      if (!rc && plif) rc = evf_hip(hipMemsetAsync(plif->pt_out, 0xFF, npix * C32 * sizeof(float), EVF_STREAM(stream)));
       if (rc) return rc;
     }
     return EVF_OK;
   }
+  return launch_fwd_b3_now(x, wb_ff, wb_rec, leak, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out, plif, stream, pd);
+}
+
+// one cell, one launch (k_conv_lif_fwd_b3: one 8 x 32 tile per block)
+static int launch_fwd_b3_now(const uint32_t* x, const void* wb_ff, const void* wb_rec, const float* leak,
+                             const float* thresh, const float* v_prev, const uint32_t* z_prev, int B, int H, int W,
+                             int hard_reset, float* v_out, uint32_t* z_out, uint32_t* zT_out, const PlifArgs* plif,
+                             void* stream, PredArgs pd) {
   dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(FW_THREADS);
   hipStream_t st = EVF_STREAM(stream);
   const size_t lds = fw_lds_bytes();
@@ -826,4 +850,20 @@ extern "C" int evf_conv_plif_fwd_b3(const uint32_t* x, const void* wb_ff, const 
   PlifArgs pa{leak_pt, add_pt, pt_prev, pt_out, P_out};
   return launch_fwd_b3(x, wb_ff, wb_rec, leak_v, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out, &pa,
                        stream);
+}
+
+// evf_conv_plif_fwd_b3 for the layer under the prediction head, with the head (evf_pred_fwd) in its epilogue -- what makes a
+// PLIF network's window recordable (no launch between the last cell of a pass and the first of the next).
+extern "C" int evf_conv_plif_fwd_b3_pred(const uint32_t* x, const void* wb_ff, const void* wb_rec, const float* leak_v,
+                                         const float* leak_pt, const float* add_pt, const float* thresh, const float* v_prev,
+                                         const uint32_t* z_prev, const float* pt_prev, int B, int H, int W, int hard_reset,
+                                         float* v_out, uint32_t* z_out, uint32_t* zT_out, float* pt_out, float* P_out,
+                                         const float* pred_w, const float* pred_b, float* flow, void* stream) {
+  if (!x || !wb_ff || !leak_v || !leak_pt || !add_pt || !thresh || !v_out || !z_out || !pt_out || !P_out || !pred_w || !pred_b ||
+      !flow || B <= 0 || H <= 0 || W <= 0)
+    return EVF_EINVAL;
+  PlifArgs pa{leak_pt, add_pt, pt_prev, pt_out, P_out};
+  const PredArgs pd{pred_w, pred_b, flow};
+  return launch_fwd_b3(x, wb_ff, wb_rec, leak_v, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out, &pa,
+                       stream, &pd);
 }

@@ -39,7 +39,9 @@
 #define FT_OFF_HALO (FT_OFF_PW + (2 * C32 + 4) * 4)     // [4 M waves][x | z][FT_HW pixels][2 words]
 #define FT_OFF_ACC (FT_OFF_HALO + 4 * 2 * FT_HW * 8)    // [4 strips][64 pixels][FW_SP floats]
 #define FT_OFF_FLAG (FT_OFF_ACC + 4 * 64 * FW_SP * 4)   // full[4]: tiles team M's wave has published; empty[4][2]: tiles read by each of the strip's two team E waves
-#define FT_LDS (FT_OFF_FLAG + 48)
+#define FT_OFF_PAR2 (FT_OFF_FLAG + 48)                  // PLIF: sigmoid(leak_pt)[32], sigmoid(add_pt)[32]
+#define FT_OFF_P (FT_OFF_PAR2 + 2 * C32 * 4)            // PLIF: pooled pre-synaptic activity [2 tiles][4 strips][64 pixels]
+#define FT_LDS (FT_OFF_P + 2 * 4 * 64 * 4)
 
 __device__ uint4 ft_zero_page[256];  // 4 KiB of zeros: what a cell without previous state reads (no load under a branch, no select)
 
@@ -65,7 +67,12 @@ extern "C" int evf_debug_ft_stamps(void* dst) { return evf_hip(hipMemcpyFromSymb
 #endif
 
 
-template <bool HARD, bool FULL>  // the reset rule of every cell of the launch / H even and W a multiple of 32 (no partial strips)
+// HARD: the reset rule of every cell of the launch; FULL: H even and W a multiple of 32 (no partial strips); PLIF: every cell
+// carries the pre-synaptic trace (spiking_submodules.py:191-227, :618-657) -- team M pools the strip's input spike counts from
+// its halo words (mean_c |x| = popcount / 32, AvgPool3x3 over the zero-padded halo) into a tile beside the accumulators, team E
+// reads the previous trace like the previous potential, updates it, subtracts sigma(add_pt) * pt' from the current and stores
+// pt' and the pooled activity (the backward's operands).  Same expressions as fwd_b3_body<.., true>: bit-identical.
+template <bool HARD, bool FULL, bool PLIF>
 __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan plan, int B, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* s_lut = (uint4*)(smem + FT_OFF_LUT);
@@ -73,6 +80,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
   uint4* s_wrec = (uint4*)(smem + FT_OFF_WREC);
   float* s_par = (float*)(smem + FT_OFF_PAR);
   float* s_pw = (float*)(smem + FT_OFF_PW);
+  float* s_par2 = (float*)(smem + FT_OFF_PAR2);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nW = (W + 31) / 32;
@@ -113,6 +121,10 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
       s_par[tid] = b3_sigmoid(J.leak[tid]);            // torch.sigmoid(self.leak)     spiking_submodules.py:111/:536
       s_par[C32 + tid] = fmaxf(J.thresh[tid], 0.01f);  // self.thresh.clamp_min(0.01)  :108/:533
     }
+    if (PLIF && tid < C32) {
+      s_par2[tid] = b3_sigmoid(J.leak_pt[tid]);
+      s_par2[C32 + tid] = b3_sigmoid(J.add_pt[tid]);
+    }
     if (J.pr.w) {
       if (tid < 2 * C32) s_pw[tid] = J.pr.w[tid];
       if (tid < 2) s_pw[2 * C32 + tid] = J.pr.bias[tid];
@@ -130,6 +142,9 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
     uint32_t* __restrict__ z_out = J.z_out;
     uint32_t* __restrict__ zT_out = J.zT_out;
     float* __restrict__ flow_out = J.pr.flow;
+    const float* __restrict__ pt_prev = PLIF ? J.pt_prev : nullptr;
+    float* __restrict__ pt_out = PLIF ? J.pt_out : nullptr;
+    float* __restrict__ P_out = PLIF ? J.P_out : nullptr;
     const bool has_pred = J.pr.w != nullptr;
     const int nstrips = plan.nstrips;
 
@@ -143,6 +158,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
       uint32_t* s_hz = s_hx + FT_HW * 2;
       float* s_acc0 = (float*)(smem + FT_OFF_ACC) + wv * (64 * FW_SP);
       float* s_acc1 = depth == 2 ? (float*)(smem + FT_OFF_WREC) + wv * (64 * FW_SP) : s_acc0;
+      float* s_Pm = (float*)(smem + FT_OFF_P) + wv * 64;
       int hro[3], hco[3];
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
@@ -260,6 +276,18 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
               *(float4*)(s_acc + (m * 32 + i) * FW_SP + 8 * q + 4 * kg) =
                   make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
           }
+          if (PLIF) {  // lane = pixel (row lane / 32, column lane % 32) of the strip: the 9 halo words around it, still committed
+            const int pm = lane >> 5;
+            int cnt = 0;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+              for (int dx = 0; dx < 3; ++dx) {
+                const uint2 hw2 = *(const uint2*)(s_hx + 2 * ((pm + dy) * HALO_W + i + dx));
+                cnt += __popc(hw2.x) + __popc(hw2.y);
+              }
+            s_Pm[((depth == 2 && (r & 1)) ? 256 : 0) + lane] = ((float)cnt / 32.0f) / 9.0f;  // as fwd_b3_body
+          }
         }
         // publish: the LDS pipe executes a wave's instructions in order, so the counter is written after the tile
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -286,6 +314,13 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
 #pragma unroll
         for (int q = 0; q < 4; ++q) oml[q] = 1.0f - lam[q];
       }
+      float lpt[4] = {0.f, 0.f, 0.f, 0.f}, apt[4] = {0.f, 0.f, 0.f, 0.f};
+      if (PLIF) {
+        const float4 l4 = *(const float4*)(s_par2 + c4), a4p = *(const float4*)(s_par2 + C32 + c4);
+        lpt[0] = l4.x, lpt[1] = l4.y, lpt[2] = l4.z, lpt[3] = l4.w;
+        apt[0] = a4p.x, apt[1] = a4p.y, apt[2] = a4p.z, apt[3] = a4p.w;
+      }
+      const float* s_PE = (const float*)(smem + FT_OFF_P) + sidx * 64 + m * 32;
       // After the element loop the words of the wave's 32 pixels sit in the lanes 8g + 4 + kq (g = lane / 8, kq = lane & 3): lane
       // 8g + 4 + kq PUBLISHES pixel vi = g + 8 kq -- its z_out word, its flow, and (after the transpose) bit plane vi.  No LDS
       // on the way (team M's operand reads keep the LDS pipe ~85 % busy, and every trip through it -- memory or crossbar -- is one
@@ -306,6 +341,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
 #else
       const bool has_v = v_prev != nullptr, has_z = z_prev != nullptr;
 #endif
+      const bool has_pt = PLIF && pt_prev != nullptr;
       const unsigned lane_off = has_v ? (unsigned)(p8 * C32 + c4) : 0u;  // floats
       const unsigned zlane = has_z ? (unsigned)p8 : 0u;
       auto geom = [&](int si, int& b, int& row, int& tx) {
@@ -316,13 +352,14 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
       // previous potential (full lines) and previous spike words of the row, requested TWO rounds ahead into one of two register
       // sets (requested one round ahead the loads had ~0.3 of a round to land and the epilogue waited for them: 8.5 k cycles per
       // round against 7.3 k of MFMAs, phase stamps)
-      auto e_fetch = [&](int qd, float4 (&vp)[4], uint32_t (&zq)[4]) {
+      auto e_fetch = [&](int qd, float4 (&vp)[4], uint32_t (&zq)[4], float4 (&pq)[PLIF ? 4 : 1]) {
         const int sk = min(4 * qd + sidx, nstrips - 1);
         int b, row, tx;
         geom(sk, b, row, tx);
         const long pb = ((long)b * H + (FULL ? row : min(row, H - 1))) * W + tx * TW;
         const uint32_t* zs = has_z ? z_prev + pb : (const uint32_t*)ft_zero_page;
         const float* vs = has_v ? v_prev + pb * C32 : (const float*)ft_zero_page;
+        const float* ps = has_pt ? pt_prev + pb * C32 : (const float*)ft_zero_page;
         // the previous spike words of the lane's four pixels: one dword load each (8 lanes per word; through a word per lane and
         // ds_bpermute they were one more LDS round trip in the epilogue's dependent chain)
         if (FULL) {
@@ -330,6 +367,10 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
           for (int k = 0; k < 4; ++k) zq[k] = zs[zlane + (has_z ? 8 * k : 0)];
 #pragma unroll
           for (int k = 0; k < 4; ++k) vp[k] = *(const float4*)(vs + lane_off + k * (8 * C32));
+          if (PLIF) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pq[k] = *(const float4*)(ps + (has_pt ? (unsigned)(p8 * C32 + c4 + k * (8 * C32)) : 0u));
+          }
         } else {
 #pragma unroll
           for (int k = 0; k < 4; ++k) zq[k] = zs[has_z ? (unsigned)min(p8 + 8 * k, W - 1 - tx * TW) : 0u];
@@ -337,11 +378,12 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
           for (int k = 0; k < 4; ++k) {
             const int pe = min(p8 + 8 * k, W - 1 - tx * TW);
             vp[k] = *(const float4*)(vs + (has_v ? (unsigned)(pe * C32 + c4) : 0u));
+            if (PLIF) pq[k] = *(const float4*)(ps + (has_pt ? (unsigned)(pe * C32 + c4) : 0u));
           }
         }
       };
       const unsigned fl_full = FT_OFF_FLAG + 4 * sidx, fl_empty = FT_OFF_FLAG + 16 + 8 * sidx + 4 * m;  // (LDS byte addresses)
-      auto e_round = [&](int r, float4 (&vp)[4], uint32_t (&zq)[4]) {  // the epilogue of round r's strips (r = 0 .. n - 1)
+      auto e_round = [&](int r, float4 (&vp)[4], uint32_t (&zq)[4], float4 (&pq)[PLIF ? 4 : 1]) {  // the epilogue of round r's strips (r = 0 .. n - 1)
         FT_STAMP();
         const int si = 4 * (i0 + r) + sidx;
         const bool valid = si < nstrips;  // (wave-uniform)
@@ -366,6 +408,13 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
           a4[k] = *(const float4*)(s_accE + (p8 + 8 * k) * FW_SP + c4);
           zw[k] = zq[k];  // previous word of pixel p8 + 8k
         }
+        float Pk[4] = {0.f, 0.f, 0.f, 0.f}, Pvi = 0.f;  // pooled activity of the lane's four pixels / of the pixel it publishes
+        if (PLIF) {
+          const float* sp = s_PE + ((depth == 2 && (r & 1)) ? 256 : 0);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) Pk[k] = sp[p8 + 8 * k];
+          Pvi = sp[vi];
+        }
         // the tile is in (or on its way into) registers: the LDS pipe runs a wave's instructions in order, so the counter moves
         // after the reads above have taken their data -- team M may overwrite the tile once both rows' waves have counted
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -387,7 +436,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
             for (int k = 0; k < 4; ++k) wk[k] = zw[k] ^ __float_as_uint(a4[k].x) ^ __float_as_uint(vp[k].x);
           } else
 #endif
-          if (HARD && FULL) {
+          if (HARD && FULL && !PLIF) {
             // The default cell on whole rows, written for the vector-issue budget (a vector instruction beside team M's MFMA
             // stream issues every ~8 cycles: this loop, not the matrix pipe, set the round time): packed fp32 pairs, the spike nibble by compare + add-with-carry (two
             // instructions per element, no subtraction: vo - th > 0 <=> vo > th for finite values), stores relative to a
@@ -432,20 +481,29 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
               const bool ok = FULL || (rowok && x0 + p < W);
               const float cu[4] = {a4[k].x, a4[k].y, a4[k].z, a4[k].w};
               const float v4[4] = {vp[k].x, vp[k].y, vp[k].z, vp[k].w};
+              const float p4[4] = {PLIF ? pq[PLIF ? k : 0].x : 0.f, PLIF ? pq[PLIF ? k : 0].y : 0.f, PLIF ? pq[PLIF ? k : 0].z : 0.f,
+                                   PLIF ? pq[PLIF ? k : 0].w : 0.f};
               const uint32_t zn = zw[k] >> c4;
-              float vo4[4];
+              float vo4[4], po4[4];
               uint32_t nib = 0u;
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 const float z = (float)((zn >> q) & 1u);
-                const float vo = HARD ? (v4[q] * lam[q]) * (1.0f - z) + oml[q] * cu[q]    // :119/:544
-                                      : v4[q] * lam[q] + oml[q] * cu[q] - z * th[q];      // :121/:546
+                float cur = cu[q];
+                po4[q] = 0.f;
+                if (PLIF) {
+                  po4[q] = p4[q] * lpt[q] + (1.0f - lpt[q]) * Pk[k];  // :212 / :642
+                  cur = cur - apt[q] * po4[q];                        // (ff + rec) - add_pt * pt_out, :220 / :650
+                }
+                const float vo = HARD ? (v4[q] * lam[q]) * (1.0f - z) + oml[q] * cur    // :119/:544
+                                      : v4[q] * lam[q] + oml[q] * cur - z * th[q];      // :121/:546
                 const bool spike = ok && (vo - th[q]) > 0.f;
                 vo4[q] = vo;
                 nib |= (spike ? 1u : 0u) << q;
               }
 #ifndef FT_PROBE_NOSTORE
               if (ok) evf_store_nt(v_out + (pb + p) * C32 + c4, make_float4(vo4[0], vo4[1], vo4[2], vo4[3]));
+              if (PLIF && ok) evf_store_nt(pt_out + (pb + p) * C32 + c4, make_float4(po4[0], po4[1], po4[2], po4[3]));
 #else  // (probe build: the new potential is computed and dropped)
               asm volatile("" ::"v"(vo4[0]), "v"(vo4[1]), "v"(vo4[2]), "v"(vo4[3]));
 #endif
@@ -462,6 +520,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
           const bool okx = pub && rowok && (FULL || x0 + vi < W);
 #ifndef FT_PROBE_NOZOUT
           if (okx) z_out[pb + vi] = word;
+          if (PLIF && okx) P_out[pb + vi] = Pvi;
 #else
           asm volatile("" ::"v"(word));
 #endif
@@ -515,17 +574,26 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
         // this register set's next use: round r + 2.  Unconditional (past the range: the last round again, never used) -- under
         // `if (r + 1 < n)` the compiler's counter bookkeeping at the join made round r + 1 wait for THESE loads as well
 #ifndef FT_PROBE_NOFETCH
-        e_fetch(min(i0 + r + 2, i1 - 1), vp, zq);
+        e_fetch(min(i0 + r + (PLIF ? 1 : 2), i1 - 1), vp, zq, pq);
 #endif
         FT_STAMP();
       };
-      float4 vpA[4], vpB[4];
-      uint32_t zqA[4], zqB[4];
-      e_fetch(i0, vpA, zqA);
-      e_fetch(min(i0 + 1, i1 - 1), vpB, zqB);
-      for (int r = 0; r < n; r += 2) {  // (unrolled by two: the register sets swap roles, no moves of loaded registers)
-        e_round(r, vpA, zqA);
-        if (r + 1 < n) e_round(r + 1, vpB, zqB);
+      if constexpr (PLIF) {
+        // (the trace doubles the state in flight: ONE register set, requested one round ahead -- two sets of potential + trace
+        //  spilled 27-47 registers at the 168 a wave of this 12-wave block may hold; team M's rounds are the longer ones here)
+        float4 vpA[4], pqA[PLIF ? 4 : 1];
+        uint32_t zqA[4];
+        e_fetch(i0, vpA, zqA, pqA);
+        for (int r = 0; r < n; ++r) e_round(r, vpA, zqA, pqA);
+      } else {
+        float4 vpA[4], vpB[4], pqA[1], pqB[1];
+        uint32_t zqA[4], zqB[4];
+        e_fetch(i0, vpA, zqA, pqA);
+        e_fetch(min(i0 + 1, i1 - 1), vpB, zqB, pqB);
+        for (int r = 0; r < n; r += 2) {  // (unrolled by two: the register sets swap roles, no moves of loaded registers)
+          e_round(r, vpA, zqA, pqA);
+          if (r + 1 < n) e_round(r + 1, vpB, zqB, pqB);
+        }
       }
     }
     tile0 += n;
@@ -544,10 +612,11 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
   }
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_fwd_diag_t<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
-    (void)hipFuncSetAttribute((const void*)k_fwd_diag_t<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
-    (void)hipFuncSetAttribute((const void*)k_fwd_diag_t<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
-    (void)hipFuncSetAttribute((const void*)k_fwd_diag_t<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
+#define FT_ATTR(H_, F_, P_) \
+  (void)hipFuncSetAttribute((const void*)k_fwd_diag_t<H_, F_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS)
+    FT_ATTR(true, true, false), FT_ATTR(true, false, false), FT_ATTR(false, true, false), FT_ATTR(false, false, false);
+    FT_ATTR(true, true, true), FT_ATTR(true, false, true), FT_ATTR(false, true, true), FT_ATTR(false, false, true);
+#undef FT_ATTR
     attr_set = true;
   }
   // relative cost of a round: feed-forward / recurrent cell / feed-forward cell with the prediction head in team E's epilogue (its
@@ -560,9 +629,9 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
     int a = 0, b = 0, c = 0;
     if (e && sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0 && a < 64 && b < 64 && c < 64) w_ff = a, w_rec = b, w_pred = c;
   }
-  int nhard = 0;
-  for (int k = 0; k < n; ++k) nhard += jobs.j[k].hard_reset ? 1 : 0;
-  if (nhard != 0 && nhard != n) return EVF_EINVAL;
+  int nhard = 0, nplif = 0;
+  for (int k = 0; k < n; ++k) nhard += jobs.j[k].hard_reset ? 1 : 0, nplif += jobs.j[k].leak_pt ? 1 : 0;
+  if ((nhard != 0 && nhard != n) || (nplif != 0 && nplif != n)) return EVF_EINVAL;
   FtPlan plan;
   plan.njobs = n, plan.ntx = evf_cdiv(W, TW), plan.nyy = evf_cdiv(H, 2);
   const long nstrips = (long)plan.ntx * plan.nyy * B;
@@ -580,8 +649,13 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
   const int nblk = (int)(nq / 2 < ncu ? (nq + 1) / 2 : ncu);  // (tiny launches: at least two rounds per block)
   const bool full = (H % 2 == 0) && (W % TW == 0);
   hipStream_t st = EVF_STREAM(stream);
-#define FT_GO(HARD_, FULL_) \
-  hipLaunchKernelGGL((k_fwd_diag_t<HARD_, FULL_>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, jobs, plan, B, H, W)
+#define FT_GO(HARD_, FULL_)                                                                                                  \
+  do {                                                                                                                       \
+    if (nplif)                                                                                                               \
+      hipLaunchKernelGGL((k_fwd_diag_t<HARD_, FULL_, true>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, jobs, plan, B, H, W);  \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((k_fwd_diag_t<HARD_, FULL_, false>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, jobs, plan, B, H, W); \
+  } while (0)
   if (nhard) {
     if (full) FT_GO(true, true); else FT_GO(true, false);
   } else {

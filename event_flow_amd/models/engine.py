@@ -436,7 +436,7 @@ class FireNetEngine:
                 for tg in target)
             if not ok:  # one-pass window starting from the target itself, or another geometry: fresh tensors
                 target = None
-        defer = (record and self.__dict__.get("_defer_on", False) and self.precision == "bf16x3" and self.kind == "lif"
+        defer = (record and self.__dict__.get("_defer_on", False) and self.precision == "bf16x3" and self.kind in ("lif", "plif")
                  and PRED_FUSED)
         if not defer:
             self.flush_forward()  # (a pass outside the recorded schedule, e.g. under no_grad: what is recorded runs first)
@@ -472,11 +472,17 @@ class FireNetEngine:
                           _lib.ptr(z_out), _lib.ptr(zT_out), _lib.ptr(pt_out), _lib.ptr(P_out))
             elif plif:
                 wrec = self._packed[(i, "rec", "b3")] if c.recurrent else None
-                _lib.call("evf_conv_plif_fwd_b3", _lib.ptr(in_bits), _lib.ptr(self._packed[(i, "ff", "b3")]), _lib.ptr(wrec),
-                          _lib.ptr(leak), _lib.ptr(self._flat[f"{i}.leak_pt"]), _lib.ptr(self._flat[f"{i}.add_pt"]),
-                          _lib.ptr(thresh), _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(pt_prev), B, H, W,
-                          1 if c.hard_reset else 0, _lib.ptr(v_out), _lib.ptr(z_out), _lib.ptr(zT_out), _lib.ptr(pt_out),
-                          _lib.ptr(P_out))
+                args = (_lib.ptr(in_bits), _lib.ptr(self._packed[(i, "ff", "b3")]), _lib.ptr(wrec),
+                        _lib.ptr(leak), _lib.ptr(self._flat[f"{i}.leak_pt"]), _lib.ptr(self._flat[f"{i}.add_pt"]),
+                        _lib.ptr(thresh), _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(pt_prev), B, H, W,
+                        1 if c.hard_reset else 0, _lib.ptr(v_out), _lib.ptr(z_out), _lib.ptr(zT_out), _lib.ptr(pt_out),
+                        _lib.ptr(P_out))
+                if i == len(self.cells) - 1 and PRED_FUSED:  # last layer: the prediction head runs in this kernel's epilogue
+                    flow = self._flow_out(B, H, W, dev)
+                    _lib.call("evf_conv_plif_fwd_b3_pred", *args, _lib.ptr(self._flat["pred.w"]), _lib.ptr(self._flat["pred.b"]),
+                              _lib.ptr(flow))
+                else:
+                    _lib.call("evf_conv_plif_fwd_b3", *args)
             elif i == 0:
                 _lib.call("evf_head_lif_fwd", _lib.ptr(x_in), _lib.ptr(self._flat["0.ff"]), _lib.ptr(leak), _lib.ptr(thresh),
                           _lib.ptr(v_prev), _lib.ptr(z_prev), B, Cin, H, W, 1 if c.hard_reset else 0, _lib.ptr(v_out),

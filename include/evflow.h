@@ -356,6 +356,15 @@ int evf_conv_plif_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_re
                          const float* v_prev, const uint32_t* z_prev, const float* pt_prev,
                          int B, int H, int W, int hard_reset,
                          float* v_out, uint32_t* z_out, uint32_t* zT_out, float* pt_out, float* P_out, void* stream);
+/* ... with the prediction head (evf_pred_fwd: models/model.py:197-199, :265) in its epilogue, for the layer under the head:
+ * pred_w [2][32], pred_b [2], flow [B,2,H,W] (written).  Like evf_conv_lif_fwd_b3_pred it makes a window's cells recordable
+ * (evf_fwd_defer_*): no launch of another kind between the last cell of a pass and the first cell of the next. */
+int evf_conv_plif_fwd_b3_pred(const uint32_t* x, const void* wb_ff, const void* wb_rec,
+                              const float* leak_v, const float* leak_pt, const float* add_pt, const float* thresh,
+                              const float* v_prev, const uint32_t* z_prev, const float* pt_prev,
+                              int B, int H, int W, int hard_reset,
+                              float* v_out, uint32_t* z_out, uint32_t* zT_out, float* pt_out, float* P_out,
+                              const float* pred_w, const float* pred_b, float* flow, void* stream);
 int evf_head_plif_fwd(const float* x, const float* w, const float* leak_v, const float* leak_pt,
                       const float* add_pt, const float* thresh, const float* v_prev, const uint32_t* z_prev,
                       const float* pt_prev, int B, int Cin, int H, int W, int hard_reset,

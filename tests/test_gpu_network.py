@@ -1090,6 +1090,49 @@ def test_stream_replicas_step_equals_the_unsplit_step():
             assert np.mean(d > 2e-5) <= 0.02, (k, np.mean(d > 2e-5))
 
 
+def test_plif_cells_recorded_on_diagonals_are_bit_identical(monkeypatch):
+    """PLIF cells (pre-synaptic trace) through the recorded forward -- k_fwd_diag_t<.., PLIF>: team M pools the input spike
+    counts of its strip, team E carries the trace -- against one launch per cell (k_conv_lif_fwd_b3<.., true>): flows of every
+    pass, potentials, spike words, traces after the window BIT for bit; and a training window's loss / gradient norm like two
+    cell-by-cell runs (the backward cells of a PLIF network are not recorded)."""
+    from event_flow_amd import train as htrain
+
+    g = load_golden("g7_pliffirenet_train")
+    H, W = passes_from_golden(g)[0]["event_cnt"].shape[2:]
+
+    def forward_only(defer):
+        model = build_from_golden(g)
+        model.train()
+        model.defer_forward(defer)
+        flows = [model(d["event_voxel"], d["event_cnt"])["flow"][0] for d in passes_from_golden(g)]
+        if defer:
+            assert _lib.raw("evf_fwd_defer_pending") == 6 * len(flows)  # the hidden cells; the PLIF head launches per pass
+        model.defer_forward(False)
+        assert _lib.raw("evf_fwd_defer_pending") == 0
+        return [N(f).copy() for f in flows], [N(s).copy() for s in model.states]
+
+    (f0, s0), (f1, s1) = forward_only(False), forward_only(True)
+    assert len(s0) == len(s1) and all(a.shape == b.shape for a, b in zip(s0, s1))
+    for a, b in zip(f0 + s0, f1 + s1):
+        assert np.array_equal(a, b)
+    assert max(float(np.abs(s).max()) for s in s1) > 0  # (the states are not trivially zero)
+
+    def run(defer):
+        monkeypatch.setattr(htrain, "DEFER_FORWARD", defer)
+        model = build_from_golden(g)
+        model.train()
+        lossf = hloss.EventWarping(loss_cfg(H, W), DEV)
+        opt = FlatAdam(model, lr=2e-4, clip=100.0)
+        opt.zero_grad()
+        loss = htrain.train_window(model, lossf, opt, passes_from_golden(g))
+        torch.cuda.synchronize()
+        return float(loss), opt.grad_norm()
+
+    (l0, n0), (l1, n1) = run(False), run(True)
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    np.testing.assert_allclose(n1, n0, rtol=1e-4)
+
+
 def test_diagonal_launches_equal_cell_by_cell_launches(monkeypatch):
     """train.window_backward records the hidden cells of a window and launches them diagonal by diagonal (k_fwd_diag:
     cells (t, l) with equal t + l in ONE launch, engine.defer_forward).  Same kernel body: the flow of every pass and the
