@@ -314,12 +314,6 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
 #pragma unroll
         for (int q = 0; q < 4; ++q) oml[q] = 1.0f - lam[q];
       }
-      float lpt[4] = {0.f, 0.f, 0.f, 0.f}, apt[4] = {0.f, 0.f, 0.f, 0.f};
-      if (PLIF) {
-        const float4 l4 = *(const float4*)(s_par2 + c4), a4p = *(const float4*)(s_par2 + C32 + c4);
-        lpt[0] = l4.x, lpt[1] = l4.y, lpt[2] = l4.z, lpt[3] = l4.w;
-        apt[0] = a4p.x, apt[1] = a4p.y, apt[2] = a4p.z, apt[3] = a4p.w;
-      }
       const float* s_PE = (const float*)(smem + FT_OFF_P) + sidx * 64 + m * 32;
       // After the element loop the words of the wave's 32 pixels sit in the lanes 8g + 4 + kq (g = lane / 8, kq = lane & 3): lane
       // 8g + 4 + kq PUBLISHES pixel vi = g + 8 kq -- its z_out word, its flow, and (after the transpose) bit plane vi.  No LDS
@@ -399,6 +393,27 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
             __builtin_amdgcn_s_sleep(1);
             asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(fv) : "v"(fl_full) : "memory");
           }
+        }
+        // PLIF: the per-channel constants are re-read from LDS and the transpose's masks rebuilt every round instead of living in
+        // ~30 registers across it -- what lets TWO sets of previous potential + trace (2 x 36 registers) stay in flight without
+        // spilling at the 168 registers a wave of this block may hold (one set: team E's loads covered half of a round,
+        // 3.1 TB/s; phase stamps: 3-11 k cycles per round at the issue of the next set's loads)
+        float lamL[4], thL[4], omlL[4], lptL[4] = {0.f, 0.f, 0.f, 0.f}, aptL[4] = {0.f, 0.f, 0.f, 0.f};
+        int viL = vi;
+        if constexpr (PLIF) {
+          unsigned offL = (unsigned)c4;
+          asm volatile("" : "+v"(offL), "+v"(viL));  // (opaque per round: neither the reads nor the masks are hoisted out of the loop)
+          const float4 l4 = *(const float4*)(s_par + offL), t4 = *(const float4*)(s_par + C32 + offL);
+          const float4 p4_ = *(const float4*)(s_par2 + offL), a4_ = *(const float4*)(s_par2 + C32 + offL);
+          lamL[0] = l4.x, lamL[1] = l4.y, lamL[2] = l4.z, lamL[3] = l4.w;
+          thL[0] = t4.x, thL[1] = t4.y, thL[2] = t4.z, thL[3] = t4.w;
+          lptL[0] = p4_.x, lptL[1] = p4_.y, lptL[2] = p4_.z, lptL[3] = p4_.w;
+          aptL[0] = a4_.x, aptL[1] = a4_.y, aptL[2] = a4_.z, aptL[3] = a4_.w;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) omlL[q] = 1.0f - lamL[q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) lamL[q] = lam[q], thL[q] = th[q], omlL[q] = oml[q];
         }
         float4 a4[4];
         uint32_t zw[4];
@@ -492,12 +507,12 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
                 float cur = cu[q];
                 po4[q] = 0.f;
                 if (PLIF) {
-                  po4[q] = p4[q] * lpt[q] + (1.0f - lpt[q]) * Pk[k];  // :212 / :642
-                  cur = cur - apt[q] * po4[q];                        // (ff + rec) - add_pt * pt_out, :220 / :650
+                  po4[q] = p4[q] * lptL[q] + (1.0f - lptL[q]) * Pk[k];  // :212 / :642
+                  cur = cur - aptL[q] * po4[q];                         // (ff + rec) - add_pt * pt_out, :220 / :650
                 }
-                const float vo = HARD ? (v4[q] * lam[q]) * (1.0f - z) + oml[q] * cur    // :119/:544
-                                      : v4[q] * lam[q] + oml[q] * cur - z * th[q];      // :121/:546
-                const bool spike = ok && (vo - th[q]) > 0.f;
+                const float vo = HARD ? (v4[q] * lamL[q]) * (1.0f - z) + omlL[q] * cur    // :119/:544
+                                      : v4[q] * lamL[q] + omlL[q] * cur - z * thL[q];     // :121/:546
+                const bool spike = ok && (vo - thL[q]) > 0.f;
                 vo4[q] = vo;
                 nib |= (spike ? 1u : 0u) << q;
               }
@@ -550,11 +565,23 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
           if (zT_out) {  // channel-major bit planes of the row = the transpose of its 32 words
 #endif
             uint32_t a = word;
+            uint32_t bf_keepL[5], bf_amtL[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+              if constexpr (PLIF) {
+                const int s = 16 >> t;
+                const uint32_t mlo = s == 16 ? 0x0000FFFFu : s == 8 ? 0x00FF00FFu : s == 4 ? 0x0F0F0F0Fu : s == 2 ? 0x33333333u : 0x55555555u;
+                bf_keepL[t] = (viL & s) ? ~mlo : mlo;
+                bf_amtL[t] = (viL & s) ? (uint32_t)s : (uint32_t)(32 - s);
+              } else {
+                bf_keepL[t] = bf_keep[t], bf_amtL[t] = bf_amt[t];
+              }
+            }
 #define FT_BFLY(t_, partner_)                                                                                       \
   do {                                                                                                             \
     const uint32_t p_ = (uint32_t)(partner_);                                                                      \
-    const uint32_t rot_ = __builtin_amdgcn_alignbit(p_, p_, bf_amt[t_]);                                           \
-    a = (a & bf_keep[t_]) | (rot_ & ~bf_keep[t_]);                                                                 \
+    const uint32_t rot_ = __builtin_amdgcn_alignbit(p_, p_, bf_amtL[t_]);                                          \
+    a = (a & bf_keepL[t_]) | (rot_ & ~bf_keepL[t_]);                                                               \
   } while (0)
             // pixel vi = p8 + 8 kq: vi ^ 16, vi ^ 8 flip kq (lanes ^ 2, ^ 1: quad permutes); vi ^ 4, ^ 2, ^ 1 flip p8 (lanes ^ 32, ^ 16, ^ 8)
             FT_BFLY(0, __builtin_amdgcn_update_dpp(0, (int)a, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
@@ -574,26 +601,17 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
         // this register set's next use: round r + 2.  Unconditional (past the range: the last round again, never used) -- under
         // `if (r + 1 < n)` the compiler's counter bookkeeping at the join made round r + 1 wait for THESE loads as well
 #ifndef FT_PROBE_NOFETCH
-        e_fetch(min(i0 + r + (PLIF ? 1 : 2), i1 - 1), vp, zq, pq);
+        e_fetch(min(i0 + r + 2, i1 - 1), vp, zq, pq);
 #endif
         FT_STAMP();
       };
-      if constexpr (PLIF) {
-        // (the trace doubles the state in flight: ONE register set, requested one round ahead -- two sets of potential + trace
-        //  spilled 27-47 registers at the 168 a wave of this 12-wave block may hold; team M's rounds are the longer ones here)
-        float4 vpA[4], pqA[PLIF ? 4 : 1];
-        uint32_t zqA[4];
-        e_fetch(i0, vpA, zqA, pqA);
-        for (int r = 0; r < n; ++r) e_round(r, vpA, zqA, pqA);
-      } else {
-        float4 vpA[4], vpB[4], pqA[1], pqB[1];
-        uint32_t zqA[4], zqB[4];
-        e_fetch(i0, vpA, zqA, pqA);
-        e_fetch(min(i0 + 1, i1 - 1), vpB, zqB, pqB);
-        for (int r = 0; r < n; r += 2) {  // (unrolled by two: the register sets swap roles, no moves of loaded registers)
-          e_round(r, vpA, zqA, pqA);
-          if (r + 1 < n) e_round(r + 1, vpB, zqB, pqB);
-        }
+      float4 vpA[4], vpB[4], pqA[PLIF ? 4 : 1], pqB[PLIF ? 4 : 1];
+      uint32_t zqA[4], zqB[4];
+      e_fetch(i0, vpA, zqA, pqA);
+      e_fetch(min(i0 + 1, i1 - 1), vpB, zqB, pqB);
+      for (int r = 0; r < n; r += 2) {  // (unrolled by two: the register sets swap roles, no moves of loaded registers)
+        e_round(r, vpA, zqA, pqA);
+        if (r + 1 < n) e_round(r + 1, vpB, zqB, pqB);
       }
     }
     tile0 += n;
@@ -639,8 +657,12 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
   plan.nstrips = (int)nstrips;
   plan.nquads = evf_cdiv(nstrips, 4);
   long total = 0;
+  static const bool w_env = getenv("EVF_FT_W") != nullptr;
+  // (PLIF cells: team E moves twice the state and sets the pace of every round -- recurrent and feed-forward cells cost nearly
+  //  the same there: 8 : 10 : 10 measured best at 260 x 346 x B4, 171 against 186 us per launch)
+  const int wf = (nplif && !w_env) ? 8 : w_ff, wr = (nplif && !w_env) ? 10 : w_rec, wp = (nplif && !w_env) ? 10 : w_pred;
   for (int k = 0; k < FW_MAX_JOBS; ++k) {
-    plan.weight[k] = (k < n && jobs.j[k].wrec) ? w_rec : ((k < n && jobs.j[k].pr.w) ? w_pred : w_ff);
+    plan.weight[k] = (k < n && jobs.j[k].wrec) ? wr : ((k < n && jobs.j[k].pr.w) ? wp : wf);
     if (k < n) total += (long)plan.nquads * plan.weight[k];
   }
   if (total >= (1L << 31)) return EVF_EINVAL;

@@ -1101,7 +1101,7 @@ def test_plif_cells_recorded_on_diagonals_are_bit_identical(monkeypatch):
     H, W = passes_from_golden(g)[0]["event_cnt"].shape[2:]
 
     def forward_only(defer):
-        model = build_from_golden(g)
+        model = build_from_golden(g, fix="g7_pliffirenet_train")
         model.train()
         model.defer_forward(defer)
         flows = [model(d["event_voxel"], d["event_cnt"])["flow"][0] for d in passes_from_golden(g)]
@@ -1119,7 +1119,7 @@ def test_plif_cells_recorded_on_diagonals_are_bit_identical(monkeypatch):
 
     def run(defer):
         monkeypatch.setattr(htrain, "DEFER_FORWARD", defer)
-        model = build_from_golden(g)
+        model = build_from_golden(g, fix="g7_pliffirenet_train")
         model.train()
         lossf = hloss.EventWarping(loss_cfg(H, W), DEV)
         opt = FlatAdam(model, lr=2e-4, clip=100.0)

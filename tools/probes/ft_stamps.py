@@ -9,7 +9,8 @@ import numpy as np, torch
 import bench
 from event_flow_amd import _lib
 
-sys.argv = ["bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-iwe", "--no-others", "--no-graph"]
+CFG = os.environ.get("FT_STAMPS_CONFIG", "c3")  # c5: the PLIF instantiation at 260 x 346
+sys.argv = ["bench.py", "--config", CFG, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-iwe", "--no-others", "--no-graph"]
 try:
     bench.main()
 except SystemExit:
