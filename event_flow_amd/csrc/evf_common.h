@@ -70,6 +70,26 @@ int evf_wgrad9_b3_launch(const float* x, int ldx, const float* gy, int ldg, floa
                          int W, int Cin, int Cout, int nsplit, int CT, int NT, hipStream_t st);
 
 // evf_dgrad_ws.hip: wave-specialised input-gradient kernel behind evf_conv_dgrad_b3_f32[_pair]
+// PLIF: d loss / d(input spike) through the pooled pre-synaptic trace at pixel (y, x) of sample b.  raw = 0: g_P is the boxed,
+// scaled map (evf_plif_trace_bwd's g_P_in); raw = 1: g_P is its g_P_raw and AvgPool3x3^T / 32 is applied here -- the same sums
+// in the same order as k_plif_box (a term outside the image adds 0.f).  Nine unconditional loads either way (no load under a
+// branch; raw = 0 reads the centre nine times, an L1 hit).
+__device__ __forceinline__ float evf_plif_gp(const float* __restrict__ gP, int raw, int b, int y, int x, int H, int W) {
+  const int yc = y < H - 1 ? y : H - 1, xc = x < W - 1 ? x : W - 1;
+  float s = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int yy = yc + dy - 1, xx = xc + dx - 1;
+      const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const int ya = raw ? (yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy)) : yc, xa = raw ? (xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx)) : xc;
+      const float v = gP[((long)b * H + ya) * W + xa];
+      s += (raw ? in : (dy == 1 && dx == 1)) ? v : 0.f;
+    }
+  return raw ? (s / 9.0f) / 32.0f : s;
+}
+
 int evf_dgrad_ws_launch(const float* g_cur, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W, const float* g_P,
                         const uint32_t* x_bits, const void* wT2_b3, float* g_x2, int max_blocks, void* stream);
 

@@ -214,7 +214,7 @@ __device__ __forceinline__ void dg_body(const int zz, const int zb,  // first sa
     float4 oldv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) oldv[q] = ACC ? *(const float4*)(gx + pixq * C32 + 8 * q + 4 * kg) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float pv = PLIF ? gPb[pixq] : 0.f;
+    const float pv = PLIF ? evf_plif_gp(gPb, (accumulate & 2) ? 1 : 0, b, y, x0 + i, H, W) : 0.f;
     const uint32_t xb = PLIF ? xbits[pixq] : 0u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -441,7 +441,7 @@ static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, in
   dim3 grid(evf_cdiv(W, 32), evf_cdiv(H, DG_ROWS), zb), block(DG_ROWS * 64);
   const long plane_stride = (long)B * H * W * 4;  // uint4 per term plane: npix * 32 bf16 / 8
   const size_t lds = (size_t)(NFRAG * 64 + 3 * DL_HPP * 4) * sizeof(uint4) + (size_t)DG_ROWS * 32 * DG_SP * 4;  // 138 KiB
-  const bool acc = accumulate != 0, plif = g_P != nullptr;
+  const bool acc = (accumulate & 1) != 0, plif = g_P != nullptr;  // (accumulate & 2: g_P is the raw map, see evf_plif_gp)
 #define DG_GO2(F_, A_, P_, R_)                                                                                                  \
   do {                                                                                                                     \
     static bool attr = false;                                                                                              \

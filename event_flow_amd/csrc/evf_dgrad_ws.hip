@@ -62,7 +62,7 @@ __global__ __launch_bounds__(512) void k_conv_dgrad_ws(const float4* __restrict_
                                                        float* __restrict__ gx, int B, int H, int W, int ntx, int nty,
                                                        long ntiles, const float* __restrict__ gPb,
                                                        const uint32_t* __restrict__ xbits, const uint4* __restrict__ wt2,
-                                                       float* __restrict__ gx2) {
+                                                       float* __restrict__ gx2, int plif_raw) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint4* s_w = (uint4*)smem_raw;          // [54][64]
   uint4* s_a = s_w + WS_NFRAG * 64;       // [2][3][WS_HP][4], chunk c of pixel p in slot c ^ ((p >> 2) & 3)
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(512) void k_conv_dgrad_ws(const float4* __restrict_
       float4 oldv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) oldv[q] = ACC ? *(const float4*)(gx + pixq * C32 + 8 * q + 4 * kg) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float pv = PLIF ? gPb[pixq] : 0.f;
+      const float pv = PLIF ? evf_plif_gp(gPb, plif_raw, cur.b, y, cur.x0 + i, H, W) : 0.f;
       const uint32_t xb = PLIF ? xbits[pixq] : 0u;
       const bool ok = y < H && cur.x0 + i < W;
       const long pix = ((long)cur.b * H + y) * W + cur.x0 + i;
@@ -271,7 +271,8 @@ int evf_dgrad_ws_launch(const float* g_cur, const void* wT_b3, float* g_x, int a
   if (max_blocks <= 0) max_blocks = 256;  // one block per CU (131 KiB of LDS each)
   const int nblk = (int)(ntiles < max_blocks ? ntiles : max_blocks);
   dim3 grid(nblk), block(512);
-  const bool acc = accumulate != 0, plif = g_P != nullptr, pair = wT2_b3 != nullptr;
+  const bool acc = (accumulate & 1) != 0, plif = g_P != nullptr, pair = wT2_b3 != nullptr;
+  const int plif_raw = (accumulate & 2) ? 1 : 0;  // g_P is evf_plif_trace_bwd's RAW map: AvgPool3x3^T / 32 applied in the kernel
 #define WS_GO(A_, P_, R_)                                                                                                     \
   do {                                                                                                                        \
     static bool attr = false;                                                                                                 \
@@ -281,7 +282,8 @@ int evf_dgrad_ws_launch(const float* g_cur, const void* wT_b3, float* g_x, int a
       attr = true;                                                                                                            \
     }                                                                                                                         \
     hipLaunchKernelGGL((k_conv_dgrad_ws<A_, P_, R_>), grid, block, WS_LDS, EVF_STREAM(stream), (const float4*)g_cur,          \
-                       (const uint4*)wT_b3, g_x, B, H, W, ntx, nty, ntiles, g_P, x_bits, (const uint4*)wT2_b3, g_x2);         \
+                       (const uint4*)wT_b3, g_x, B, H, W, ntx, nty, ntiles, g_P, x_bits, (const uint4*)wT2_b3, g_x2,          \
+                       plif_raw);                                                                                             \
   } while (0)
 #define WS_AP(R_)                  \
   do {                             \

@@ -812,7 +812,7 @@ extern "C" int evf_plif_trace_bwd(const float* g_cur, const float* g_pt_carry, c
                                   const float* P, const float* leak_pt, const float* add_pt, int B, int H, int W,
                                   float* g_pt_prev, float* g_P_raw, float* g_P_in, float* g_leak_pt, float* g_add_pt,
                                   int row_ld, void* stream) {
-  if (!g_cur || !pt_out || !P || !leak_pt || !add_pt || !g_pt_prev || !g_P_raw || !g_P_in || !g_leak_pt || !g_add_pt ||
+  if (!g_cur || !pt_out || !P || !leak_pt || !add_pt || !g_pt_prev || !g_P_raw || !g_leak_pt || !g_add_pt ||
       B <= 0 || H <= 0 || W <= 0)
     return EVF_EINVAL;
   const long npix = (long)B * H * W;
@@ -820,7 +820,8 @@ extern "C" int evf_plif_trace_bwd(const float* g_cur, const float* g_pt_carry, c
   hipLaunchKernelGGL(k_plif_trace_bwd, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)g_cur,
                      (const float4*)g_pt_carry, (const float4*)pt_prev, (const float4*)pt_out, P, leak_pt, add_pt, npix,
                      (float4*)g_pt_prev, g_P_raw, g_leak_pt, g_add_pt, row_ld);
-  hipLaunchKernelGGL(k_plif_box, dim3(evf_cdiv(npix, 256)), dim3(256), 0, EVF_STREAM(stream), g_P_raw, B, H, W, g_P_in);
+  // (g_P_in == NULL: the input-gradient kernels apply the pooling's adjoint to the raw map themselves, `accumulate | 2`)
+  if (g_P_in) hipLaunchKernelGGL(k_plif_box, dim3(evf_cdiv(npix, 256)), dim3(256), 0, EVF_STREAM(stream), g_P_raw, B, H, W, g_P_in);
   return evf_status();
 }
 

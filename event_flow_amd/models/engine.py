@@ -48,6 +48,8 @@ HEAD_WIN = os.environ.get("EVF_HEAD_WIN", "1") != "0"
 PRED_FUSED = os.environ.get("EVF_PRED_FUSED", "1") != "0"  # prediction head in the epilogue of the last layer's forward
 TOP_FUSED = os.environ.get("EVF_TOP_FUSED", "1") != "0"  # prediction-head backward inside the top layer's fused backward
 PAIR_DGRAD = os.environ.get("EVF_PAIR_DGRAD", "1") != "0"
+# PLIF: AvgPool3x3^T / 32 of dL/d(pooled activity) inside the input-gradient kernels (0: a k_plif_box launch per cell; A/B, tests)
+PLIF_BOX_IN_DGRAD = os.environ.get("EVF_PLIF_BOX", "dgrad") != "kernel"
 # window gradients -> the flat gradient buffer in one launch (evf_grads_finalize); 0: row sums, slab reduction, segment add one by one
 FUSED_TAIL = os.environ.get("EVF_FUSED_TAIL", "1") != "0"
 PARAM_ROWS = os.environ.get("EVF_PARAM_ROWS", "1") != "0"  # per-channel gradients through per-block rows (0: atomics)  # ff + rec input gradients of a recurrent cell in one launch
@@ -656,7 +658,8 @@ class FireNetEngine:
                 carry = gpt_out if win.gpt_has[i] else None
                 _lib.call("evf_plif_trace_bwd", _lib.ptr(win.g_cur), _lib.ptr(carry), _lib.ptr(pt_prev), _lib.ptr(pt_out),
                           _lib.ptr(P_sav), _lib.ptr(self._flat[f"{i}.leak_pt"]), _lib.ptr(self._flat[f"{i}.add_pt"]), B, H, W,
-                          _lib.ptr(gpt_out), _lib.ptr(win.gP_raw), _lib.ptr(win.gP), _lib.ptr(self._rowed(win, f"{i}.leak_pt")[0]),
+                          _lib.ptr(gpt_out), _lib.ptr(win.gP_raw), None if PLIF_BOX_IN_DGRAD else _lib.ptr(win.gP),
+                          _lib.ptr(self._rowed(win, f"{i}.leak_pt")[0]),
                           _lib.ptr(self._rowed(win, f"{i}.add_pt")[0]), self._rowed(win, f"{i}.add_pt")[1])
                 win.gpt_has[i] = not is_first
             if is_first:
@@ -674,6 +677,9 @@ class FireNetEngine:
                     win.gz[0] = win.gz0[win.bwd_k]
                 ga = win.buf(win.gz, i - 1)
                 acc_a = 1 if win.gz_has[i - 1] else 0
+                # PLIF: the input-gradient kernel applies AvgPool3x3^T / 32 to the trace backward's raw map itself (accumulate | 2)
+                gp_flag = 2 if (plif and PLIF_BOX_IN_DGRAD) else 0
+                gp_map = (win.gP_raw if PLIF_BOX_IN_DGRAD else win.gP) if plif else None
                 if self.precision == "bf16x3":
                     dg, gsrc = ("evf_conv_dgrad_b3_f32", g_cur_i) if F32_DGRAD else ("evf_conv_dgrad_b3", win.g_split)
                     if split:
@@ -685,15 +691,15 @@ class FireNetEngine:
                         gb = win.buf(win.gzr, i) if not plif else win.buf(win.gz, i)
                         _lib.call("evf_conv_dgrad_b3_pair" if split else "evf_conv_dgrad_b3_f32_pair", _lib.ptr(gsrc),
                                   _lib.ptr(self._packed[(i, "ff", "b3t")]),
-                                  _lib.ptr(ga), acc_a, _lib.ptr(self._packed[(i, "rec", "b3t")]), _lib.ptr(gb), B, H, W,
-                                  _lib.ptr(win.gP) if plif else None, _lib.ptr(in_bits) if plif else None)
+                                  _lib.ptr(ga), acc_a | gp_flag, _lib.ptr(self._packed[(i, "rec", "b3t")]), _lib.ptr(gb), B, H, W,
+                                  _lib.ptr(gp_map) if plif else None, _lib.ptr(in_bits) if plif else None)
                         if plif:
                             win.gz_has[i] = True
                         else:
                             win.gzr_has[i] = True
                     else:
                         _lib.call(dg, _lib.ptr(gsrc), _lib.ptr(self._packed[(i, "ff", "b3t")]), _lib.ptr(ga),
-                                  acc_a, B, H, W, _lib.ptr(win.gP) if plif else None, _lib.ptr(in_bits) if plif else None)
+                                  acc_a | gp_flag, B, H, W, _lib.ptr(gp_map) if plif else None, _lib.ptr(in_bits) if plif else None)
                         if rec_grad:
                             gb = win.buf(win.gz, i)
                             _lib.call(dg, _lib.ptr(gsrc), _lib.ptr(self._packed[(i, "rec", "b3t")]),

@@ -1131,6 +1131,14 @@ def test_plif_cells_recorded_on_diagonals_are_bit_identical(monkeypatch):
     (l0, n0), (l1, n1) = run(False), run(True)
     np.testing.assert_allclose(l1, l0, rtol=1e-6)
     np.testing.assert_allclose(n1, n0, rtol=1e-4)
+    # the pooling's adjoint (AvgPool3x3^T / 32 of dL/d(pooled activity)) inside the input-gradient kernels against a k_plif_box
+    # launch per cell: the same sums in the same order
+    from event_flow_amd.models import engine as heng
+
+    monkeypatch.setattr(heng, "PLIF_BOX_IN_DGRAD", False)
+    l2, n2 = run(True)
+    np.testing.assert_allclose(l2, l1, rtol=1e-6)
+    np.testing.assert_allclose(n2, n1, rtol=1e-6)
 
 
 def test_diagonal_launches_equal_cell_by_cell_launches(monkeypatch):
