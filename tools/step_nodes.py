@@ -17,7 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 files = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{R}", "graph", "*", "*kernel_trace.csv")), key=os.path.getmtime)
 if not files:
     sys.exit("no kernel trace under gpurun_out/prof_%s/graph" % R)
-rows = list(csv.DictReader(open(files[-1])))
+# (the default bench run appends the c4 / c5 lines from child processes, each with a trace of its own: the headline step is in the
+#  trace that holds the head layer's window kernel)
+pick = [f for f in files if "k_head_lif_fwd_win" in open(f).read()]
+rows = list(csv.DictReader(open(pick[-1] if pick else files[-1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 adam = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_clip_adam")]
 if len(adam) < 2:
