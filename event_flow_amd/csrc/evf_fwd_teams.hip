@@ -28,6 +28,9 @@
 #ifndef FT_DEPTH2
 #define FT_DEPTH2 1
 #endif
+#ifndef FT_ESLEEP
+#define FT_ESLEEP 1  // team E's poll interval for a published tile, in 64-cycle units
+#endif
 #define FT_WAVES (4 + FT_EW)
 #define FT_THREADS (64 * FT_WAVES)
 #define FT_HW (4 * HALO_W)                              // halo pixels of a strip: rows y0 - 1 .. y0 + 2
@@ -168,19 +171,35 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
       uint32_t hx[3], hz[3];
       bool hin[3];
       const uint32_t* zsrc = z_prev ? z_prev : x;  // no load under a branch: clamped address, select afterwards
-      auto halo_fetch = [&](int qd) {  // (past the range: the last strip again, never committed)
-        const int sk = min(4 * qd + wv, nstrips - 1);
-        const int tx = sk % plan.ntx, rr = sk / plan.ntx, yy = rr % plan.nyy, b = rr / plan.nyy;
-        const int y0 = 2 * yy, x0 = tx * TW;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const int ya = y0 + hro[q] - 1, xa = x0 + hco[q] - 1;
-          hin[q] = ya >= 0 && ya < H && xa >= 0 && xa < W;
-          const long p = ((long)b * H + min(max(ya, 0), H - 1)) * W + min(max(xa, 0), W - 1);
-          hx[q] = x[p], hz[q] = zsrc[p];
-        }
+      // The strip whose halo is requested next, as scalars: two integer divisions by run-time values once per cell, then + 4
+      // strips per round by compares (a strip index past the cell's last one keeps a valid address: it is never committed).
+      // The requests themselves -- ~15 vector instructions and two loads per third of the halo -- ride behind the MFMAs of the
+      // matrix phase (conv_phase's `side`): in front of it they were 0.5-1.1 k cycles of every round of the team that sets the
+      // launch's pace (phase stamps).
+      int gtx, gyy, gb;
+      {
+        const int sk = min(4 * i0 + wv, nstrips - 1);
+        gtx = sk % plan.ntx;
+        const int rr = sk / plan.ntx;
+        gyy = rr % plan.nyy, gb = rr / plan.nyy;
+      }
+      auto geom_adv = [&]() {
+        gtx += 4;
+        const int c = (gtx >= plan.ntx ? 1 : 0) + (gtx >= 2 * plan.ntx ? 1 : 0) + (gtx >= 3 * plan.ntx ? 1 : 0) + (gtx >= 4 * plan.ntx ? 1 : 0);
+        gtx -= c * plan.ntx, gyy += c;
+        const int d = (gyy >= plan.nyy ? 1 : 0) + (gyy >= 2 * plan.nyy ? 1 : 0) + (gyy >= 3 * plan.nyy ? 1 : 0) + (gyy >= 4 * plan.nyy ? 1 : 0);
+        gyy -= d * plan.nyy, gb += d;
       };
-      halo_fetch(i0);
+      auto halo_fetch_q = [&](int q) {
+        const int y0 = 2 * gyy, x0 = gtx * TW, b = min(gb, B - 1);
+        const int ya = y0 + hro[q] - 1, xa = x0 + hco[q] - 1;
+        hin[q] = ya >= 0 && ya < H && xa >= 0 && xa < W;
+        const long p = ((long)b * H + min(max(ya, 0), H - 1)) * W + min(max(xa, 0), W - 1);
+        hx[q] = x[p], hz[q] = zsrc[p];
+      };
+#pragma unroll
+      for (int q = 0; q < 3; ++q) halo_fetch_q(q);
+      geom_adv();
       const unsigned fl_full = FT_OFF_FLAG + 4 * wv, fl_empty = FT_OFF_FLAG + 16 + 8 * wv;  // (LDS byte addresses; `empty`: one counter per row's wave)
       for (int r = 0; r < n; ++r) {
         FT_STAMP();
@@ -196,15 +215,14 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
             *(uint2*)(s_hz + 2 * l) = make_uint2((wz & 0x00FF00FFu) << 4, ((wz >> 8) & 0x00FF00FFu) << 4);
           }
         }
-        halo_fetch(min(i0 + r + 1, i1 - 1));  // the next round's words: land during this round's MFMAs
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         f32x16 acc0 = {0}, acc1 = {0};
         unsigned long long ev = 0ull;  // team E's two read counters of this wave's tiles, requested during the last matrix phase
         // Matrix phase, software pipelined (as k_fwd_diag_p): the two A fragments (table look-ups) and the three weight
         // fragments of stage g + 1 are requested BEFORE the 6 MFMAs of stage g and pinned there.
-        auto conv_phase = [&](const uint32_t* __restrict__ sh, const uint4* __restrict__ sw, auto last_tag) {
-          constexpr bool LAST = decltype(last_tag)::value;
+        auto conv_phase = [&](const uint32_t* __restrict__ sh, const uint4* __restrict__ sw, auto last_tag, auto side_tag) {
+          constexpr bool LAST = decltype(last_tag)::value, SIDE = decltype(side_tag)::value;
           uint32_t hw[4][3];
 #pragma unroll
           for (int rho = 0; rho < 4; ++rho)
@@ -243,18 +261,24 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
             }
             // (the counter read rides in the LDS queue behind the operand reads: its latency is covered by the last six stages)
             if (LAST && g == 11) asm volatile("ds_read_b64 %0, %1" : "=v"(ev) : "v"(fl_empty) : "memory");
+            // the next round's halo words, a third at a time behind this stage's MFMAs: they land during the rest of the phase
+            if (SIDE && (g == 2 || g == 5 || g == 8)) halo_fetch_q((g - 2) / 3);
             __builtin_amdgcn_sched_barrier(0);
           }
         };
         if (valid) {
           if (rec) {
-            conv_phase(s_hx, s_wff, std::false_type{});
-            conv_phase(s_hz, s_wrec, std::true_type{});
+            conv_phase(s_hx, s_wff, std::false_type{}, std::true_type{});
+            conv_phase(s_hz, s_wrec, std::true_type{}, std::false_type{});
           } else {
-            conv_phase(s_hx, s_wff, std::true_type{});
+            conv_phase(s_hx, s_wff, std::true_type{}, std::true_type{});
           }
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ev)::"memory");
+        } else {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) halo_fetch_q(q);
         }
+        geom_adv();
         FT_STAMP();
         // ---- the tile this round's buffer held before (round r - depth) must have been read by both of team E's waves
         // (one counter per wave: with their sum and two tiles in flight, a wave two reads ahead would cover for the other one)
@@ -390,7 +414,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
           uint32_t fv;
           asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(fv) : "v"(fl_full) : "memory");
           while ((uint32_t)__builtin_amdgcn_readfirstlane((int)fv) < need) {
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(FT_ESLEEP);
             asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(fv) : "v"(fl_full) : "memory");
           }
         }
