@@ -234,8 +234,19 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
           uint4 af[FT_PF][2], wf[FT_PF][3];  // [stage slot][row] / [stage slot][term]; a stage = (tap, K half m): 6 MFMAs
           auto fetch = [&](int g) {
             const int sp = g % FT_PF, tau = g >> 1, m = g & 1, dy = tau / 3, dx = tau % 3;
+#ifdef FT_PROBE_NOLUT  // (probe build: every lane reads table entry 0 -- no data-dependent address, no bank conflict: 38.8
+                       //  against 44.9 us per launch.  Reading a third of the fragments less -- the upper row's fragment of
+                       //  tap (dy, dx, m) is the lower row's of tap (dy - 1, dx, m), kept in a ring of six register sets --
+                       //  gained 0.3 us: it is the chain commit -> word -> look-up -> first MFMA at the head of a phase, not
+                       //  the number of look-ups.  Committing and reading the NEXT round's words behind this round's last
+                       //  stages (second halo buffer on feed-forward cells) needs ~40 more registers in the matrix phase:
+                       //  60-80 spilled at the 168 a wave of this 12-wave block may hold.)
+            const uint32_t a0 = 0u, a1 = 0u;
+            asm volatile("" ::"v"(hw[dy][dx]), "v"(hw[dy + 1][dx]));
+#else
             const uint32_t a0 = m ? (hw[dy][dx] >> 16) : (hw[dy][dx] & 0xFFFFu);
             const uint32_t a1 = m ? (hw[dy + 1][dx] >> 16) : (hw[dy + 1][dx] & 0xFFFFu);
+#endif
             af[sp][0] = *(const uint4*)(smem + FT_OFF_LUT + a0);
             af[sp][1] = *(const uint4*)(smem + FT_OFF_LUT + a1);
 #pragma unroll
