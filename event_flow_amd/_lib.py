@@ -82,6 +82,8 @@ NETWORK_SIGNATURES = {
     "evf_conv_dgrad_b3_pair": [P, P, P, I, P, P, I, I, I, P, P, P],
     "evf_conv_plif_fwd_b3": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P],
     "evf_conv_plif_fwd_b3_pred": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P],
+    "evf_weight_norm_fwd": [P, P, I, I, P, P, P],
+    "evf_weight_norm_bwd": [P, P, P, P, I, I, P, P, P],
     "evf_head_plif_fwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P],
     "evf_plif_trace_bwd": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, I, P],
     "evf_conv_dgrad": [P, P, P, I, P, P, I, I, I, I, P],

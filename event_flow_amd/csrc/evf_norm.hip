@@ -93,3 +93,62 @@ extern "C" int evf_chan_affine(const float* g, int ldg, const float* x, int ldx,
                      ldg, ldx, ldo, total, out);
   return evf_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight normalisation of a conv weight (norm = "weight" cells, spiking_submodules.py:87-88, :502-504: nn.utils.weight_norm,
+// dim = 0):  w[o, :] = v[o, :] * g[o] / ||v[o, :]||, the norm over the n = Cin * k * k elements of an output channel.
+// One block per output channel; the norms are kept for the backward:
+//   d v[o, j] = (g / nrm) * gw[o, j] - (g * <gw[o], v[o]> / nrm^3) * v[o, j],    d g[o] = <gw[o], v[o]> / nrm
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wn_block_sum(float s, float* s_red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) s_red[wv] = s;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_red[w];
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(256) void k_weight_norm_fwd(const float* __restrict__ v, const float* __restrict__ g, int n,
+                                                         float* __restrict__ w, float* __restrict__ nrm) {
+  __shared__ float s_red[4];
+  const long o = blockIdx.x;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const float t = v[o * n + j];
+    s += t * t;
+  }
+  const float nr = sqrtf(wn_block_sum(s, s_red));
+  const float sc = g[o] / nr;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) w[o * n + j] = v[o * n + j] * sc;
+  if (threadIdx.x == 0) nrm[o] = nr;
+}
+
+__global__ __launch_bounds__(256) void k_weight_norm_bwd(const float* __restrict__ gw, const float* __restrict__ v,
+                                                         const float* __restrict__ g, const float* __restrict__ nrm, int n,
+                                                         float* __restrict__ gv, float* __restrict__ gg) {
+  __shared__ float s_red[4];
+  const long o = blockIdx.x;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) s += gw[o * n + j] * v[o * n + j];
+  const float dot = wn_block_sum(s, s_red);
+  const float nr = nrm[o], a = g[o] / nr, b = g[o] * dot / (nr * nr * nr);
+  for (int j = threadIdx.x; j < n; j += blockDim.x) gv[o * n + j] = a * gw[o * n + j] - b * v[o * n + j];
+  if (threadIdx.x == 0) gg[o] = dot / nr;
+}
+
+extern "C" int evf_weight_norm_fwd(const float* v, const float* g, int Cout, int n, float* w, float* nrm, void* stream) {
+  if (!v || !g || !w || !nrm || Cout <= 0 || n <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_weight_norm_fwd, dim3(Cout), dim3(256), 0, EVF_STREAM(stream), v, g, n, w, nrm);
+  return evf_status();
+}
+
+extern "C" int evf_weight_norm_bwd(const float* gw, const float* v, const float* g, const float* nrm, int Cout, int n, float* gv,
+                                   float* gg, void* stream) {
+  if (!gw || !v || !g || !nrm || !gv || !gg || Cout <= 0 || n <= 0) return EVF_EINVAL;
+  hipLaunchKernelGGL(k_weight_norm_bwd, dim3(Cout), dim3(256), 0, EVF_STREAM(stream), gw, v, g, nrm, n, gv, gg);
+  return evf_status();
+}

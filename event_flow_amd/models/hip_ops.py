@@ -91,7 +91,9 @@ class _PackCache:
         cin = Ctot if cin is None else cin
         sfx = "_b3" if CONV_B3 else ""
         key = (transpose, cin_off, cin, sfx)
-        tag = (w.data_ptr(), w._version, w.device, _EPOCH[0])
+        # (a weight-normalised weight is a fresh tensor per forward -- the allocator may hand out the same address again: its
+        #  identity is that of the (v, g) pair it was made from, see weight_norm())
+        tag = (w.data_ptr(), w._version, w.device, _EPOCH[0], getattr(w, "_evf_src", None))
         hit = self.store.get(key)
         if hit is not None and hit[0] == tag:
             return hit[1]
@@ -136,7 +138,7 @@ def repack_all():
         with torch.cuda.device(dev):
             _lib.call("evf_pack_conv2d_weights_b3_multi", wp, dp, (ctypes.c_int * len(meta))(*meta), n)
         for pc, key, w, dst, r in ents:
-            pc.store[key] = ((w.data_ptr(), w._version, w.device, _EPOCH[0]), dst, r)
+            pc.store[key] = ((w.data_ptr(), w._version, w.device, _EPOCH[0], getattr(w, "_evf_src", None)), dst, r)
 
 
 _CACHES = {}
@@ -480,6 +482,43 @@ class _CellStep(torch.autograd.Function):
         return None, g_x, g_st, g_res, None, g_wff, g_wrec, shp(0), shp(1), shp(2), shp(3)
 
 
+class _WeightNorm(torch.autograd.Function):
+    """w = v * g / ||v|| per output channel (nn.utils.weight_norm, dim = 0), evf_weight_norm_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, v, g):
+        vc, gc = v.detach().contiguous(), g.detach().reshape(-1).contiguous()
+        Cout, n = vc.shape[0], vc[0].numel()
+        w = _new(tuple(vc.shape), vc.device)
+        nrm = _new((Cout,), vc.device)
+        _lib.call("evf_weight_norm_fwd", _lib.ptr(vc), _lib.ptr(gc), Cout, n, _lib.ptr(w), _lib.ptr(nrm))
+        ctx.saved = (vc, gc, nrm)
+        ctx.gshape = tuple(g.shape)
+        return w
+
+    @staticmethod
+    def backward(ctx, gw):
+        vc, gc, nrm = ctx.saved
+        Cout, n = vc.shape[0], vc[0].numel()
+        gwc = gw.contiguous()
+        gv, gg = _new(tuple(vc.shape), vc.device), _new((Cout,), vc.device)
+        _lib.call("evf_weight_norm_bwd", _lib.ptr(gwc), _lib.ptr(vc), _lib.ptr(gc), _lib.ptr(nrm), Cout, n, _lib.ptr(gv), _lib.ptr(gg))
+        return gv, gg.reshape(ctx.gshape)
+
+
+def weight_norm(conv):
+    """The effective weight of an nn.utils.weight_norm-wrapped conv (parameters weight_g, weight_v under the reference's
+    names); its forward pre-hook never runs here because the conv module itself is never called."""
+    v, g = conv.weight_v, conv.weight_g
+    w = _WeightNorm.apply(v, g)
+    w._evf_src = (v.data_ptr(), v._version, g.data_ptr(), g._version)
+    return w
+
+
+def conv_weight(conv):
+    return weight_norm(conv) if hasattr(conv, "weight_g") else conv.weight
+
+
 def cell_forward(cell, input_, prev_state, residual=0, slots=None):
     """Reference signature: cell(input_, prev_state, residual=0) -> (out, state).  slots: optional StateSlots of the
     enclosing block (the new state is written into the block's stacked-state buffer)."""
@@ -487,8 +526,12 @@ def cell_forward(cell, input_, prev_state, residual=0, slots=None):
     if not torch.is_tensor(residual) and residual != 0:
         raise _lib.EvflowError("residual must be a tensor or 0")
     p = cell_params(cell)
-    wrec = cell.rec.weight if cell.recurrent else None
-    return _CellStep.apply(cell, input_, prev_state, res, slots, cell.ff.weight, wrec, *p)
+    if getattr(cell, "wnorm", False):  # (the normalised weights are new tensors every call: nothing cached may outlive them)
+        d = pack_cache(cell)
+        for name in ("ff", "rec", "ffT", "recT"):
+            d.pop(name, None)
+    wrec = conv_weight(cell.rec) if cell.recurrent else None
+    return _CellStep.apply(cell, input_, prev_state, res, slots, conv_weight(cell.ff), wrec, *p)
 
 
 # ---------------------------------------------------------------------------

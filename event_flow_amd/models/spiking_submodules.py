@@ -40,8 +40,16 @@ class _SpikingCell(nn.Module):
         ), "Spiking neurons need a valid activation, see models/spiking_util.py for choices"
         if activation not in SURROGATE_ID:
             raise AttributeError(activation)  # reference: getattr(spiking, activation)
-        if norm is not None:
-            raise NotImplementedError("norm='weight'/'group' cells are outside the accelerated path (SURVEY q14)")
+        # norm (reference spiking_submodules.py:87-94, :502-514): only the LIF cells look at it; the other kinds take the argument
+        # and ignore it, as the reference does
+        self.wnorm = False
+        if self.kind == "lif" and norm == "weight":
+            self.ff = nn.utils.weight_norm(self.ff)  # parameters ff.weight_g / ff.weight_v, the reference's state_dict keys
+            if self.recurrent:
+                self.rec = nn.utils.weight_norm(self.rec)
+            self.wnorm = True
+        elif self.kind == "lif" and norm == "group":
+            raise NotImplementedError("norm='group' (nn.GroupNorm on the cell's inputs) is not implemented; no reference config sets it")
         self.input_size, self.hidden_size = input_size, hidden_size
         self.kernel_size, self.stride = kernel_size, stride
         self.activation = activation

@@ -526,6 +526,12 @@ int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int ldg, float* 
  *   evf_chan_affine: out = (g ? A*g : 0) + Bc*x + Cc with per-(group, channel) coefficients [G*C]. */
 int evf_chan_reduce(const float* x, int ldx, const float* y, int ldy, const float* center, const float* scale, int mode,
                     int G, int64_t npg, int C, float* out, void* stream);
+/* Weight normalisation of a conv weight [Cout][n = Cin * k * k] (norm = "weight" cells: models/spiking_submodules.py:87-88,
+ * :502-504, nn.utils.weight_norm with dim = 0):  w[o] = v[o] * g[o] / ||v[o]||; nrm [Cout] keeps the norms for the backward, which
+ * maps dL/dw to dL/dv [Cout][n] and dL/dg [Cout]. */
+int evf_weight_norm_fwd(const float* v, const float* g, int Cout, int n, float* w, float* nrm, void* stream);
+int evf_weight_norm_bwd(const float* gw, const float* v, const float* g, const float* nrm, int Cout, int n,
+                        float* gv, float* gg, void* stream);
 int evf_chan_affine(const float* g, int ldg, const float* x, int ldx, const float* A, const float* Bc, const float* Cc,
                     int G, int64_t npg, int C, float* out, int ldo, void* stream);
 

@@ -69,6 +69,15 @@ def _pretrace(x, k, stride):
     return F.avg_pool2d(x.abs().mean(1, keepdim=True), k, stride, padding=k // 2)
 
 
+def conv_weight(p, name):
+    """A conv layer's weight: the plain parameter, or -- norm="weight" cells (spiking_submodules.py:87-88, :502-504:
+    nn.utils.weight_norm) -- g * v / ||v|| with the norm over everything but the output channel."""
+    if name + ".weight_g" in p:
+        v, g = p[name + ".weight_v"], p[name + ".weight_g"]
+        return torch._weight_norm(v, g, 0)  # (what nn.utils.weight_norm's hook evaluates: torch/nn/utils/weight_norm.py)
+    return p[name + ".weight"]
+
+
 def cell_step(kind, p, pre, x, state, *, recurrent, stride=1, act="arctanspike", hard_reset=None, detach=True, residual=0):
     """One step of Conv{LIF,PLIF,ALIF,XLIF}[Recurrent].
     spiking_submodules.py:96-126 (LIF), :191-227 (PLIF), :299-334 (ALIF),
@@ -76,7 +85,7 @@ def cell_step(kind, p, pre, x, state, *, recurrent, stride=1, act="arctanspike",
     if hard_reset is None:
         hard_reset = kind in ("lif", "plif")  # ctor defaults, :51,:151 vs :260,:359
     width = p[pre + "act_width"]
-    wff = p[pre + "ff.weight"]
+    wff = conv_weight(p, pre + "ff")
     ff = _conv(x, wff, stride)
     nstate = 2 if kind == "lif" else 3
     if state is None:
@@ -84,7 +93,7 @@ def cell_step(kind, p, pre, x, state, *, recurrent, stride=1, act="arctanspike",
     v, z = state[0], state[1]
     cur = ff
     if recurrent:
-        cur = ff + _conv(z, p[pre + "rec.weight"])  # z NOT detached here (:530)
+        cur = ff + _conv(z, conv_weight(p, pre + "rec"))  # z NOT detached here (:530)
     k = wff.shape[-1]
 
     if kind == "lif":

@@ -225,9 +225,10 @@ def _thresh_of(c, g, tag, new_ref):
     return t0 + t1 * new_ref[2]
 
 
-@pytest.mark.parametrize("fix,n", [("g6_cells", 28), ("g15_cells_k5", 8)])
+@pytest.mark.parametrize("fix,n", [("g6_cells", 28), ("g15_cells_k5", 8), ("g18_cells_weightnorm", 3)])
 def test_g6_cells_forward_backward_on_gpu(fix, n):
-    """G6: 3x3 cells; G15: the 5x5 (models/unet.py:51 default) and 7x7 kernels of the general conv path, stride 1 / 2."""
+    """G6: 3x3 cells; G15: the 5x5 (models/unet.py:51 default) and 7x7 kernels of the general conv path, stride 1 / 2; G18: LIF
+    cells with norm="weight" (evf_weight_norm_fwd / _bwd under the reference's weight_g / weight_v parameters)."""
     g = load_golden(fix)
     cases = golden_cases(g)
     assert len(cases) == n
@@ -240,6 +241,8 @@ def test_g6_cells_forward_backward_on_gpu(fix, n):
             kw["learn_thresh"] = True
         if not c["recurrent"] and c.get("stride", 1) != 1:
             kw["stride"] = c["stride"]
+        if c.get("norm"):
+            kw["norm"] = c["norm"]
         cell = CELL_CLS[(c["kind"], c["recurrent"])](Cin, C, c.get("ksz", 3), **kw).to(DEV)
         sd = {k[len(tag + "_param_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "_param_")}
         cell.load_state_dict(sd)
