@@ -539,6 +539,52 @@ def test_adaptive_threshold_firenets_vs_oracle(name, cls):
         assert np.linalg.norm(got - ref) <= 2e-3 * denom + 1e-9, (k, np.linalg.norm(got - ref) / denom)
 
 
+def test_weight_normalised_lif_firenet_vs_oracle():
+    """LIFFireNet whose cells are built with norm="weight" (spiking_neuron kwargs reach the cells, models/model.py:179-186): the
+    state_dict carries the reference's ff.weight_g / ff.weight_v (rec.* on the recurrent cells), the network runs cell by cell
+    through the general path (the fused engine takes plain weights), flows / states / every parameter gradient -- weight_g and
+    weight_v included -- against the CPU oracle over three passes."""
+    from event_flow_amd.models.model import LIFFireNet
+
+    torch.manual_seed(9)
+    neuron = {"leak": [-4.0, 0.1], "thresh": [0.3, 0.05], "learn_leak": True, "learn_thresh": True, "hard_reset": True, "norm": "weight"}
+    cfg = {"num_bins": 2, "base_num_channels": 32, "kernel_size": 3, "encoding": "cnt", "norm_input": False,
+           "mask_output": True, "activations": ["arctanspike", "arctanspike"], "spiking_neuron": neuron}
+    model = LIFFireNet(cfg).to(DEV)
+    assert not model._fused()
+    sd_keys = set(model.state_dict())
+    assert {"head.ff.weight_g", "head.ff.weight_v", "G1.rec.weight_g", "G1.rec.weight_v", "R2b.ff.weight_v"} <= sd_keys
+    assert "head.ff.weight" not in sd_keys
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if k.endswith("weight_g"):
+                p.mul_(torch.rand_like(p) + 0.5)  # (at construction g = ||v||, i.e. w = v)
+    params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    keys = [k for k, _ in model.named_parameters()]
+    for k in keys:
+        params[k].requires_grad_(True)
+    xs = [(torch.rand(2, 2, 16, 20) < 0.5).float() * torch.randint(1, 4, (2, 2, 16, 20)).float() for _ in range(3)]
+    states = [None] * 7
+    tot_ref, tot = 0, 0
+    for x in xs:
+        f_ref, states = osnn.firenet_forward("LIFFireNet", params, x, states)
+        out = model(x.to(DEV), x.to(DEV))
+        np.testing.assert_allclose(N(out["flow"][0]), f_ref.detach().numpy(), rtol=1e-4, atol=1e-7)
+        tot_ref = tot_ref + (f_ref * torch.arange(f_ref.numel()).view(f_ref.shape).remainder(7)).sum()
+        fl = out["flow"][0]
+        tot = tot + (fl * torch.arange(fl.numel(), device=DEV).view(fl.shape).remainder(7)).sum()
+    for li, st in enumerate(model.states):
+        np.testing.assert_allclose(N(st), torch.stack(states[li]).detach().numpy(), rtol=1e-5, atol=2e-6)
+    tot.backward()
+    tot_ref.backward()
+    for k, p in model.named_parameters():
+        ref = params[k].grad
+        ref = ref.numpy() if ref is not None else np.zeros(tuple(p.shape), np.float32)
+        got = N(p.grad) if p.grad is not None else np.zeros_like(ref)
+        denom = max(np.linalg.norm(ref), 1e-12)
+        assert np.linalg.norm(got - ref) <= 2e-3 * denom + 1e-9, (k, np.linalg.norm(got - ref) / denom)
+
+
 def test_evflownet_at_config4_width_vs_oracle():
     """BASELINE config 4 architecture at its real width (base 32: 64..512 channels, 1024/514/258/130-channel decoder
     inputs, 20.4 M parameters) on a 128x128 crop, B=1, two passes: flows of all four scales and the parameter
