@@ -734,10 +734,13 @@ def main():
 
     # diagonal launches (train.window_backward -> engine.defer_forward): the hidden forward cells of a window are recorded and
     # launched by ONE evf_fwd_defer_flush call (P + 5 k_fwd_diag launches); the per-cell entry points then launch nothing
-    diag_fwd = _train.DEFER_FORWARD and getattr(model, "precision", "") == "bf16x3" and wl["model"] == "LIFFireNet"
+    # (PLIF: the forward cells are recorded too -- k_fwd_diag_t<.., PLIF> --, the backward cells launch one by one)
+    plif_net = wl["model"] == "PLIFFireNet"
+    diag_fwd = _train.DEFER_FORWARD and getattr(model, "precision", "") == "bf16x3" and wl["model"] in ("LIFFireNet", "PLIFFireNet")
     diag_bwd = _train.DEFER_BACKWARD and getattr(model, "precision", "") == "bf16x3" and wl["model"] == "LIFFireNet"
     if diag_fwd:  # (these entry points then only record: timed inside the flush, evf_defer_profile)
-        names = [n for n in names if n not in ("evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_head_lif_fwd")]
+        names = [n for n in names if n not in ("evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_conv_plif_fwd_b3",
+                                               "evf_conv_plif_fwd_b3_pred") and (plif_net or n != "evf_head_lif_fwd")]
     if diag_bwd:
         names = [n for n in names if n not in ("evf_lif_bwd_wgrad2", "evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad_top", "evf_conv_dgrad_b3_f32",
                                                "evf_conv_dgrad_b3_f32_pair", "evf_conv_dgrad_b3", "evf_head_lif_bwd_wgrad")]
@@ -852,10 +855,12 @@ def main():
         # (input gradient: two real operands) bf16 MFMA products per algorithmic fp32 product
         bf16_terms = {"evf_conv_lif_fwd_b3": 3, "evf_conv_lif_fwd_b3_pred": 3, "evf_conv_plif_fwd_b3": 3, "evf_lif_bwd_wgrad": 3,
                       "evf_lif_bwd_wgrad_top": 3, "evf_conv_dgrad_b3": 6, "evf_conv_dgrad_b3_f32": 6, "evf_conv_dgrad_b3_f32_pair": 6}
-        model[("evf_conv_plif_fwd_b3", "")] = (CONV_FLOP * npix, 408 * npix)  # + trace in / out
-        model[("evf_head_plif_fwd", "")] = (2 * 18 * 32 * npix, 408 * npix)
-        # g_cur, g_pt carry, pt_prev, pt_out in; g_pt_prev out (fp32 [npix][32]); P, g_P_raw, g_P_in [npix]
-        model[("evf_plif_trace_bwd", "")] = (0, 652 * npix)
+        # PLIF: + previous trace in, new trace out (128 B/px each), pooled activity out (4)
+        model[("evf_conv_plif_fwd_b3", "")] = (CONV_FLOP * npix, 532 * npix)
+        model[("evf_head_plif_fwd", "")] = (2 * 18 * 32 * npix, 532 * npix)
+        # g_cur, g_pt carry, pt_prev in; g_pt_prev out (fp32 [npix][32]: 4 x 128 B/px); P in, g_P_raw out [npix] (the new trace is
+        # recomputed from pt_prev and P, the pooling's adjoint runs inside the input-gradient kernels)
+        model[("evf_plif_trace_bwd", "")] = (0, 520 * npix)
         hbm_bound |= {"evf_conv_plif_fwd_b3", "evf_head_plif_fwd", "evf_plif_trace_bwd"}
         # contrast-maximisation loss: forward 88 B/event (24 B read + 2 directions x 4 corners x 2 images x 4 B) +
         # the 8 images read once for the reduction + the flow maps of the P passes for the smoothness term; backward 96 B/event
@@ -869,7 +874,8 @@ def main():
         nl = PASSES + 5
         alt_bytes = {}
         if diag_fwd:  # 6 hidden cells per pass (8 contractions: two recurrent cells), 272 B/px each, 280 under the prediction head
-            model[("k_fwd_diag", "")] = (8 * PASSES * CONV_FLOP * npix / nl, PASSES * (5 * 272 + 280) * npix / nl)
+            per_cell = 532 if plif_net else 272  # (PLIF: + trace in / out + pooled activity)
+            model[("k_fwd_diag", "")] = (8 * PASSES * CONV_FLOP * npix / nl, PASSES * (5 * per_cell + per_cell + 8) * npix / nl)
             hbm_bound |= {"k_fwd_diag"}
             bf16_terms["k_fwd_diag"] = 3
         if diag_bwd:
@@ -967,7 +973,9 @@ def main():
                        "parallelism": f"dp{dp.world}", "launch": mode, "loss": loss_val,
                        "streams": nstream,
                        "forward_launches": ("diagonal: the window's hidden forward cells in P + 5 launches (k_fwd_diag, cells "
-                                            "(pass, layer) with equal pass + layer together), the head layer of all passes in 1 (k_head_lif_fwd_win); EVF_DEFER_FWD=0: one launch per cell"
+                                            "(pass, layer) with equal pass + layer together), "
+                                            + ("the PLIF head layer one launch per pass" if plif_net else
+                                               "the head layer of all passes in 1 (k_head_lif_fwd_win)") + "; EVF_DEFER_FWD=0: one launch per cell"
                                             if diag_fwd else "one launch per (pass, layer) cell"),
                        "backward_launches": ("diagonal: fused-backward cells in P + 5 launches (k_bwd_diag), input-gradient cells in "
                                              "P + 5 (k_dgrad_diag), the head layer's backward of all passes in 1 (k_head_bwd_win); EVF_DEFER_BWD=0: 13 launches per pass"
