@@ -1,5 +1,5 @@
 """Random windows through train.window_backward with the diagonal launches on and off (EVF_DEFER_FWD / EVF_DEFER_BWD):
-python tools/debug/fuzz_diag.py [n] [seed].  Loss and flat gradient must agree up to the float atomics of the loss (forward and backward);
+python tools/debug/fuzz_diag.py [n] [seed] [lif|plif].  Loss and flat gradient must agree up to the float atomics of the loss (forward and backward);
 '==' marks a bit-identical loss."""
 import sys
 
@@ -9,11 +9,15 @@ import torch
 sys.path.insert(0, ".")
 from event_flow_amd import _lib, train as htrain  # noqa: E402
 from event_flow_amd.loss import flow as hloss  # noqa: E402
-from event_flow_amd.models.model import LIFFireNet  # noqa: E402
+from event_flow_amd.models.model import LIFFireNet, PLIFFireNet  # noqa: E402
 from event_flow_amd.train import FlatAdam  # noqa: E402
 
 DEV = "cuda:0"
 NEURON = {"leak": [-4.0, 0.1], "thresh": [0.8, 0.1], "learn_leak": True, "learn_thresh": True, "hard_reset": True}
+PLIF = {"leak_v": [-4.0, 0.1], "leak_pt": [-4.0, 0.1], "add_pt": [-2.0, 0.1], "thresh": [0.8, 0.1], "learn_leak": True,
+        "learn_thresh": True, "hard_reset": True}
+KIND = sys.argv[3] if len(sys.argv) > 3 else "lif"
+CLS, NEURON = (PLIFFireNet, PLIF) if KIND == "plif" else (LIFFireNet, NEURON)
 CFG = {"num_bins": 2, "base_num_channels": 32, "kernel_size": 3, "encoding": "cnt", "norm_input": False, "mask_output": True,
        "activations": ["arctanspike", "arctanspike"], "spiking_neuron": dict(NEURON)}
 
@@ -21,7 +25,7 @@ CFG = {"num_bins": 2, "base_num_channels": 32, "kernel_size": 3, "encoding": "cn
 def run(defer, lists, H, W, seed):
     htrain.DEFER_FORWARD = htrain.DEFER_BACKWARD = defer
     torch.manual_seed(seed)
-    model = LIFFireNet(dict(CFG, spiking_neuron=dict(NEURON))).to(DEV)
+    model = CLS(dict(CFG, spiking_neuron=dict(NEURON))).to(DEV)
     with torch.no_grad():
         for k, p in model.named_parameters():
             if k.endswith("thresh"):
