@@ -257,6 +257,9 @@ __global__ __launch_bounds__(512) void k_dgrad_diag_ws(EvfDgProds P, int H, int 
 #define WM_NU (3 * WM_UPP)         // DMA pieces per item
 #define WM_NJ ((WM_NU + 3) / 4)    // pieces per wave
 #define WM_LDS ((size_t)(WD_NFRAG * 64 + 2 * WM_BUF) * sizeof(uint4) + (size_t)4 * 32 * WD_SP * 4)
+#ifndef WM_STAGE
+#define WM_STAGE 0  // 1: the loader team stages a tile through registers instead of by LDS-DMA pieces (measured: slower, see load_piece)
+#endif
 #ifndef WM_PIPE
 #define WM_PIPE 1  // the epilogue of item k-1 behind the MFMAs of item k (0: after the item's own matrix phase)
 #endif
@@ -342,6 +345,22 @@ __global__ __launch_bounds__(512) void k_dgrad_diag_dma(EvfDgProds P, unsigned p
     const unsigned long long a = (((unsigned long long)t.g + off) & m) | ((unsigned long long)zero_page & ~m);
     __builtin_amdgcn_global_load_lds((wd_glb_void*)a, (wd_lds_void*)(s_a + buf * WM_BUF + p_lds[j]), 16, 0, 0);
   };
+  // What the loader team costs the MATRIX team (probe builds, us per launch): loader idle (barriers only) 57.1; LDS-DMA pieces
+  // 71.9-72.8 (the default); the same pieces through registers (WM_STAGE=1: a plain 16-byte load per lane, one ds_write_b128
+  // once it has landed) 76.6-77.8 -- of which loads without the stores 63.1, stores without the loads 65.1.  Both halves
+  // count: the requests with their address arithmetic on the SIMD that also feeds a matrix wave, and the 39 KB per item
+  // written into the LDS the matrix waves read their operands from.  Fewer BYTES per item is what helps.
+#if WM_STAGE
+  auto load_piece = [&](int j, const WmTile& t) -> uint4 {
+    const int y = t.y0 - 1 + p_hr[j], x = t.x0 - 1 + p_hc[j];
+    const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    const unsigned off = ((unsigned)(t.b * H + y) * (unsigned)W + (unsigned)x) * 64u + p_off[j];
+    const unsigned long long m = in ? ~0ull : 0ull;
+    const unsigned long long a = (((unsigned long long)t.g + off) & m) | ((unsigned long long)zero_page & ~m);
+    return *(const uint4*)a;
+  };
+  auto store_piece = [&](int j, int buf, const uint4& v) { s_a[buf * WM_BUF + p_lds[j] + lane] = v; };
+#endif
   float* st = s_stage + (wv & 3) * (32 * WD_SP);
   // epilogue through the wave-private LDS tile [32 pixels][32 channels] (144-byte pixel pitch): the MFMA layout gives a lane
   // 4 x 16 bytes of its pixel's line; read back as 8 pixels x 128 bytes per instruction the wave stores FULL lines,
@@ -381,18 +400,49 @@ __global__ __launch_bounds__(512) void k_dgrad_diag_dma(EvfDgProds P, unsigned p
     __builtin_amdgcn_s_setprio(3);  // (a few hundred instructions per item: ahead of the MFMA wave of the SIMD in the arbitration)
 #endif
     load_weights4((const uint4*)P.p[wprod].wt);
+#if WM_STAGE
+    {
+      uint4 rg[WM_NJ];
+#pragma unroll
+      for (int j = 0; j < WM_NJ; ++j) rg[j] = load_piece(j, cur);
+#pragma unroll
+      for (int j = 0; j < WM_NJ; ++j) store_piece(j, 0, rg[j]);
+    }
+#else
 #pragma unroll
     for (int j = 0; j < WM_NJ; ++j) dma_piece(j, cur, 0);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WM_STAMP();
     __syncthreads();
     for (int k = 0; k < nitem; ++k) {
       WM_STAMP();
       item_of(k + 1, nxt);  // (past the end: the last item again, never used)
+#ifndef WM_PROBE_NOLOAD  // (probe build: the loader team only keeps the barriers -- what do its pieces cost the matrix team?)
+#if WM_STAGE
+      uint4 rg[WM_NJ];
+#ifndef WM_PROBE_NOGLOAD
+#pragma unroll
+      for (int j = 0; j < WM_NJ; ++j) rg[j] = load_piece(j, nxt);
+#else
+#pragma unroll
+      for (int j = 0; j < WM_NJ; ++j) rg[j] = make_uint4(k, j, lane, 0);
+#endif
+      WM_STAMP();
+#ifndef WM_PROBE_NOSTORE
+#pragma unroll
+      for (int j = 0; j < WM_NJ; ++j) store_piece(j, (k + 1) & 1, rg[j]);
+#else
+#pragma unroll
+      for (int j = 0; j < WM_NJ; ++j) asm volatile("" ::"v"(rg[j].x), "v"(rg[j].y), "v"(rg[j].z), "v"(rg[j].w));
+#endif
+#else
 #pragma unroll
       for (int j = 0; j < WM_NJ; ++j) dma_piece(j, nxt, (k + 1) & 1);
       WM_STAMP();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#endif
       WM_STAMP();
       __syncthreads();
       if (k + 1 < nitem && nxt.prod != wprod) {  // (block-uniform) next product: every matrix wave is done with the old weights
