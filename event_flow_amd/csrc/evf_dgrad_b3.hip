@@ -328,10 +328,12 @@ static size_t dg_lds_bytes() {
   return (size_t)(NFRAG * 64 + 3 * DL_HPP * 4) * sizeof(uint4) + (size_t)DG_ROWS * 32 * DG_SP * 4;
 }
 
-static int dg_diag_select = -1;  // -1 environment / default, 0 k_dgrad_diag, 1 k_dgrad_diag_ws
+static int dg_diag_select = -1;  // -1 environment / default, 0 k_dgrad_diag, 1 k_dgrad_diag_ws / _dma, 2 ... with the ring-halo kernel
+int evf_dgrad_ring_select = -1;  // (evf_dgrad_diag.hip) -1 environment, 0 k_dgrad_diag_dma, 1 k_dgrad_diag_ring
 extern "C" int evf_dgrad_diag_select(int which) {
-  if (which < -1 || which > 1) return EVF_EINVAL;
-  dg_diag_select = which;
+  if (which < -1 || which > 2) return EVF_EINVAL;
+  dg_diag_select = which == 2 ? 1 : which;
+  evf_dgrad_ring_select = which < 0 ? -1 : (which == 2 ? 1 : 0);
   return EVF_OK;
 }
 

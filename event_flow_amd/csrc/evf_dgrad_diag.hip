@@ -312,8 +312,13 @@ __global__ __launch_bounds__(512) void k_dgrad_diag_dma(EvfDgProds P, unsigned p
     const unsigned id = lo + (unsigned)min(k, nitem - 1);
     unsigned pr, tl, r, tx, b, ty;
     divmod(id, ntiles, rnt, pr, tl);
+#ifdef WM_PROBE_COLMAJOR  // (probe build: the items of a product column by column, as k_dgrad_diag_ring takes them)
+    divmod(tl, (unsigned)nty, rnty, r, ty);
+    divmod(r, (unsigned)ntx, rntx, b, tx);
+#else
     divmod(tl, (unsigned)ntx, rntx, r, tx);
     divmod(r, (unsigned)nty, rnty, b, ty);
+#endif
     t.prod = __builtin_amdgcn_readfirstlane((int)pr), t.x0 = __builtin_amdgcn_readfirstlane((int)tx * 32);
     t.b = __builtin_amdgcn_readfirstlane((int)b), t.y0 = __builtin_amdgcn_readfirstlane((int)ty * WD_ROWS);
     t.g = (const char*)P.p[t.prod].g, t.gx = P.p[t.prod].gx;
@@ -508,6 +513,255 @@ __global__ __launch_bounds__(512) void k_dgrad_diag_dma(EvfDgProds P, unsigned p
   WM_STAMP();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_dgrad_diag_ring: k_dgrad_diag_dma with the halo rows in a RING.  Vertically adjacent 4-row tiles share two of their six halo
+// rows; the items of a product run column by column (ty fastest), and a tile that continues the previous one keeps those two
+// rows in LDS: the loader team brings in four new rows (27-30 LDS-DMA pieces) instead of six (39) -- fewer bytes requested
+// and fewer bytes written into the LDS the matrix team reads from, which is what the loader team costs it (see dma_piece above).
+//   ring   12 rows x 36 pixel slots (34 used: 36 x 12 = 27 units of 16 pixels, so the ring closes on a unit boundary) per plane;
+//          tile k occupies rows r0 .. r0 + 5 (mod 12), halo row h of the tile = image row y0 - 1 + h;
+//          next tile continues it:  r0' = r0 + 4, rows r0' + 2 .. r0' + 5 are loaded (the four free rows r0 + 6 .. r0 + 9);
+//          otherwise:               r0' = r0 + 6, all six rows are loaded (the six free rows).
+//   A piece is a 16-pixel unit of one plane; the first / last unit of a region also holds pixels of the neighbouring rows: those
+//   lanes are switched off (the row before belongs to the tile in use).
+// Same products in the same order per output element: bit-identical to the other input-gradient kernels.
+// MEASURED (128 x 128 x B8, us per launch): 76.3-78.7 against 72.4-73.6 for k_dgrad_diag_dma -- NOT the default.  The probe builds
+// say why the bytes do not matter: with the loader team idle the dma kernel runs 57.1 and this one 60.4 (three row bases per
+// item instead of addresses that never change: +3), and the loader team's pieces cost ~15 us in BOTH -- with 39 pieces of ~25
+// vector instructions (here, generic path), 28 pieces of 2 (here, table path) or 39 of 10 (dma); the dma kernel's items taken
+// column by column run 72.4.  What the matrix team pays for is that the loader team requests data at all while it computes
+// (the launch is power-limited at 1.77 GHz; an idle loader team also means no HBM traffic), not how many requests that takes.
+// Kept behind EVF_DGRAD_RING=1 / evf_dgrad_diag_select(2) and under the bit-identity test.
+// ---------------------------------------------------------------------------------------------------------------------
+extern int evf_dgrad_ring_select;
+#define WR_ROWS 12
+#define WR_PITCH 36
+#define WR_UPP 27                  // 16-pixel units per plane: 12 x 36 / 16
+#define WR_PLANE (WR_UPP * 64)     // uint4 per plane
+#define WR_BUF (3 * WR_PLANE)      // uint4 of the ring
+#define WR_NJ 11                   // pieces per loader wave at most: ceil(3 planes x 14 units / 4 waves)
+#define WR_LDS ((size_t)(WD_NFRAG * 64 + WR_BUF) * sizeof(uint4) + (size_t)4 * 32 * WD_SP * 4)
+
+template <bool FULL>
+__global__ __launch_bounds__(512) void k_dgrad_diag_ring(EvfDgProds P, unsigned plane_bytes, int H, int W, int ntx, int nty,
+                                                         unsigned ntiles, unsigned total) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint4* s_w = (uint4*)smem_raw;     // [54][64]
+  uint4* s_a = s_w + WD_NFRAG * 64;  // [3][12 rows x 36 pixels][4], chunk c of the pixel in column x of its row in slot c ^ ((x >> 2) & 3)
+  float* s_stage = (float*)(s_a + WR_BUF);  // [4 waves][32 pixels][WD_SP]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, kg = lane >> 5;
+  const unsigned lo = (unsigned)(((unsigned long long)blockIdx.x * total) / gridDim.x);
+  const unsigned hi = (unsigned)(((unsigned long long)(blockIdx.x + 1) * total) / gridDim.x);
+  const int nitem = (int)(hi - lo);
+  if (nitem <= 0) return;
+  const float rnt = 1.0f / (float)ntiles, rntx = 1.0f / (float)ntx, rnty = 1.0f / (float)nty;
+  auto divmod = [](unsigned n, unsigned d, float rd, unsigned& q, unsigned& r) {  // exact for n < 2^22
+    q = (unsigned)((float)n * rd);
+    int rr = (int)n - (int)(q * d);
+    if (rr < 0) --q, rr += (int)d;
+    if (rr >= (int)d) ++q, rr -= (int)d;
+    r = (unsigned)rr;
+  };
+  auto item_of = [&](int k, WmTile& t) {  // (past the end: the last item again -- its pieces are issued and never used)
+    const unsigned id = lo + (unsigned)min(k, nitem - 1);
+    unsigned pr, tl, r, tx, b, ty;
+    divmod(id, ntiles, rnt, pr, tl);
+    divmod(tl, (unsigned)nty, rnty, r, ty);  // column by column: ty fastest
+    divmod(r, (unsigned)ntx, rntx, b, tx);
+    t.prod = __builtin_amdgcn_readfirstlane((int)pr), t.x0 = __builtin_amdgcn_readfirstlane((int)tx * 32);
+    t.b = __builtin_amdgcn_readfirstlane((int)b), t.y0 = __builtin_amdgcn_readfirstlane((int)ty * WD_ROWS);
+    t.g = (const char*)P.p[t.prod].g, t.gx = P.p[t.prod].gx;
+  };
+  auto continues = [&](const WmTile& a, const WmTile& b) {  // b is the tile below a, same product / sample / column
+    return b.prod == a.prod && b.b == a.b && b.x0 == a.x0 && b.y0 == a.y0 + WD_ROWS;
+  };
+  auto mod12 = [](int r) { return r >= WR_ROWS ? r - WR_ROWS : r; };
+  auto load_weights4 = [&](const uint4* src) {  // the four loader waves
+    for (int u = wv - 4; u < WD_NFRAG; u += 4)
+      __builtin_amdgcn_global_load_lds((wd_glb_void*)(src + u * 64 + lane), (wd_lds_void*)(s_w + u * 64), 16, 0, 0);
+  };
+  const char* zero_page = (const char*)wm_zero_page + (lane & 3) * 16;
+  // the loader team's pieces of tile t whose ring rows start at r0t: its rows 2 .. 5 (t continues the tile in use) or all six
+  auto load_region = [&](const WmTile& t, int r0t, bool cont) {
+    const int a = mod12(r0t + (cont ? 2 : 0)), n = cont ? 4 : 6;
+    const int ustart = (a * WR_PITCH) >> 4, nu = (((a + n) * WR_PITCH + 15) >> 4) - ustart;  // 9, 10 | 14 units per plane
+#pragma unroll
+    for (int j = 0; j < WR_NJ; ++j) {
+      const int e = (wv & 3) + 4 * j;
+      if (e < 3 * nu) {  // (wave-uniform)
+        const int pl = (e >= nu ? 1 : 0) + (e >= 2 * nu ? 1 : 0);
+        int u = ustart + e - pl * nu;
+        u = u >= WR_UPP ? u - WR_UPP : u;
+        const int q = 16 * u + (lane >> 2);        // ring pixel slot of this lane
+        const int rr = (q * 1821) >> 16;           // = q / 36 for q < 432
+        const int c = q - rr * WR_PITCH;
+        int h = rr - r0t;                          // halo row of the tile that ring row rr holds
+        h += h < 0 ? WR_ROWS : 0;
+        int hrel = rr - a;
+        hrel += hrel < 0 ? WR_ROWS : 0;
+        const int y = t.y0 - 1 + h, x = t.x0 - 1 + c;
+        const bool in = c < WD_HW && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        const unsigned off = ((unsigned)(t.b * H + y) * (unsigned)W + (unsigned)x) * 64u + (unsigned)pl * plane_bytes +
+                             (unsigned)(((lane & 3) ^ ((c >> 2) & 3)) * 16);  // (swizzle by column: dgm_load_g_at<true>)
+        const unsigned long long m = in ? ~0ull : 0ull;
+        const unsigned long long adr = (((unsigned long long)t.g + off) & m) | ((unsigned long long)zero_page & ~m);
+        const int dst = __builtin_amdgcn_readfirstlane(pl * WR_PLANE + u * 64);
+        if (hrel < n)  // (lanes on a neighbouring row of the first / last unit keep what the ring holds)
+          __builtin_amdgcn_global_load_lds((wd_glb_void*)adr, (wd_lds_void*)(s_a + dst), 16, 0, 0);
+      }
+    }
+  };
+  // FULL shapes (H % 4 == 0, W % 32 == 0): the same pieces from TABLES.  What the loader team costs the matrix team is, for
+  // about half, the vector instructions of its address arithmetic on the SIMD both share (~25 per piece above); here a piece is
+  // two of them.  Per lane and piece, fixed for a (region alignment, continues / full) pair -- which changes once per column --:
+  // the byte offset of the lane's chunk from the tile's halo origin (scalar base + 32-bit offset addressing) and five flag
+  // bits (in the region, left / right / top / bottom halo line).  Per item a scalar origin and the tile's border bits; a lane
+  // loads iff (flags & (border | 1)) == 1, and on a border tile the lanes of the lines outside the image store zeros.
+  uint32_t tb_off[WR_NJ], tb_flg[WR_NJ];
+  int tb_key = -1, tb_nu = 0;
+  auto build_tables = [&](int aph, bool cont) {  // aph = a & 3 (0 or 2)
+    const int sh = (aph * WR_PITCH) & 15, n = cont ? 4 : 6;
+    tb_nu = (sh + n * WR_PITCH + 15) >> 4;
+#pragma unroll
+    for (int j = 0; j < WR_NJ; ++j) {
+      const int e = (wv & 3) + 4 * j;
+      const int pl = min((e >= tb_nu ? 1 : 0) + (e >= 2 * tb_nu ? 1 : 0), 2), ui = e - pl * tb_nu;
+      const int qrel = 16 * ui + (lane >> 2) - sh;            // pixel slot relative to the region's first one
+      const int hrel = qrel < 0 ? -1 : (qrel * 1821) >> 16;   // (qrel < 16 * 14 + 16)
+      const int c = qrel - hrel * WR_PITCH, h = hrel + (cont ? 2 : 0);
+      const bool live = qrel >= 0 && hrel < n && c < WD_HW && e < 3 * tb_nu;
+      tb_off[j] = (unsigned)(h * W + c) * 64u + (unsigned)(((lane & 3) ^ ((c >> 2) & 3)) * 16) + (unsigned)pl * plane_bytes;
+      tb_flg[j] = (live ? 1u : 0u) | (c == 0 ? 2u : 0u) | (c == WD_HW - 1 ? 4u : 0u) | (h == 0 ? 8u : 0u) | (h == WD_ROWS + 1 ? 16u : 0u);
+    }
+  };
+  auto load_region_full = [&](const WmTile& t, int r0t, bool cont) {
+    const int a = mod12(r0t + (cont ? 2 : 0));
+    const int key = (a & 3) * 2 + (cont ? 1 : 0);
+    if (key != tb_key) {  // (wave-uniform; once per column)
+      build_tables(a & 3, cont);
+      tb_key = key;
+    }
+    const int ustart = (a * WR_PITCH) >> 4;
+    const unsigned tf = (t.x0 == 0 ? 2u : 0u) | (t.x0 + 32 == W ? 4u : 0u) | (t.y0 == 0 ? 8u : 0u) | (t.y0 + WD_ROWS == H ? 16u : 0u);
+    // halo origin (row y0 - 1, column x0 - 1; before the tensor on a top / left border tile: never dereferenced there)
+    const unsigned long long org = (unsigned long long)t.g + (unsigned long long)((long)(t.b * H + t.y0 - 1) * W + t.x0 - 1) * 64ull;
+    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int j = 0; j < WR_NJ; ++j) {
+      const int e = (wv & 3) + 4 * j;
+      if (e < 3 * tb_nu) {  // (wave-uniform)
+        const int pl = (e >= tb_nu ? 1 : 0) + (e >= 2 * tb_nu ? 1 : 0);
+        int u = ustart + e - pl * tb_nu;
+        u = u >= WR_UPP ? u - WR_UPP : u;
+        const int dst = pl * WR_PLANE + u * 64;  // (scalar)
+        const unsigned mk = tb_flg[j] & (tf | 1u);
+        if (mk == 1u) {
+          unsigned keep;
+          const unsigned ldsb = (unsigned)(uintptr_t)(s_a + dst);
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep)
+                       : "v"(tb_off[j]), "s"(org), "s"(ldsb)
+                       : "memory");
+        }
+        if (tf && mk > 1u) s_a[dst + lane] = z4;  // (a halo line outside the image)
+      }
+    }
+  };
+  float* st = s_stage + (wv & 3) * (32 * WD_SP);
+  auto epi_write = [&](const f32x16& a) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *(float4*)(st + i * WD_SP + 8 * q + 4 * kg) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  };
+  float4 ev[4];
+  auto epi_read = [&](int r) {
+    const int p = 8 * r + (lane >> 3), c4 = (lane & 7) * 4;
+    ev[r] = *(const float4*)(st + p * WD_SP + c4);
+  };
+  auto epi_store = [&](int r, const WmTile& t) {
+    const int y = t.y0 + wv;
+    const int p = 8 * r + (lane >> 3), c4 = (lane & 7) * 4;
+    float* dst = t.gx + ((unsigned)((t.b * H + y) * W + t.x0 + p) * (unsigned)C32 + (unsigned)c4);
+    if (FULL || (y < H && t.x0 + p < W)) evf_store_nt(dst, ev[r]);
+  };
+  WmTile cur, nxt, prv;
+  int wprod, r0 = 0;  // r0: first ring row of the tile in use (both teams keep the same sequence)
+  const bool loader = wv >= 4;
+  item_of(0, cur);
+  wprod = cur.prod;
+  if (loader) {
+    __builtin_amdgcn_s_setprio(3);
+    load_weights4((const uint4*)P.p[wprod].wt);
+    if (FULL) load_region_full(cur, 0, false); else load_region(cur, 0, false);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int k = 0; k < nitem; ++k) {
+      item_of(k + 1, nxt);  // (past the end: the last item again, never used)
+      const bool cont = k + 1 < nitem && continues(cur, nxt);
+      const int r0n = mod12(r0 + (cont ? 4 : 6));
+#ifndef WR_PROBE_NOLOAD  // (probe build: the loader team only keeps the barriers)
+      if (FULL) load_region_full(nxt, r0n, cont); else load_region(nxt, r0n, cont);
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (k + 1 < nitem && nxt.prod != wprod) {  // (block-uniform) next product: every matrix wave is done with the old weights
+        wprod = nxt.prod;
+        load_weights4((const uint4*)P.p[wprod].wt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      cur = nxt, r0 = r0n;
+    }
+  } else {
+    f32x16 acc_prev = {0};
+    auto run_item = [&](int k, auto epi_tag) {
+      constexpr bool EPI = decltype(epi_tag)::value;
+      auto side = [&](int slot) {
+        if (slot == 70) item_of(k + 1, nxt);
+        if (EPI) {
+          if (slot == 1) epi_write(acc_prev);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (slot == 13 + r) epi_read(r);
+            if (slot == 40 + 12 * r) epi_store(r, prv);
+          }
+        }
+      };
+      int hpd[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        int rb = r0 + wv + d;  // (< 24)
+        rb = rb >= WR_ROWS ? rb - WR_ROWS : rb;
+        hpd[d] = rb * WR_PITCH + i;
+      }
+      const f32x16 acc = dg_matrix_phase3h<WD_DPPX != 0, true>(s_w, s_a, WR_PLANE, [&](int dy) { return hpd[dy]; }, lane, side);
+      acc_prev = acc;
+      prv = cur;
+      __syncthreads();
+      const bool cont = k + 1 < nitem && continues(cur, nxt);
+      if (k + 1 < nitem && nxt.prod != wprod) {
+        wprod = nxt.prod;
+        __syncthreads();
+      }
+      r0 = mod12(r0 + (cont ? 4 : 6));
+      cur = nxt;
+    };
+    __syncthreads();
+    prv = cur;
+    run_item(0, std::false_type{});
+    for (int k = 1; k < nitem; ++k) run_item(k, std::true_type{});
+    epi_write(acc_prev);  // the last item's epilogue
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) epi_read(r);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) epi_store(r, prv);
+  }
+}
+
 bool evf_dgrad_diag_fits(int split, int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return false;
   const long ntiles = (long)evf_cdiv(W, 32) * evf_cdiv(H, WD_ROWS) * B;
@@ -536,6 +790,28 @@ int evf_dgrad_diag_dma_launch(const EvfDgProds& P, int nprod, int B, int H, int 
     attr = true;
   }
   const int nblk = (int)(total < ncu ? total : ncu);
+  // default: k_dgrad_diag_dma (every tile's six halo rows loaded, items row by row); EVF_DGRAD_RING=1 / evf_dgrad_diag_select(2):
+  // k_dgrad_diag_ring -- measured 76.3-78.7 against 72.4-73.6 us per launch at 128 x 128 x B8 (see the kernel's header)
+  static const bool ring_env = []() {
+    const char* e = getenv("EVF_DGRAD_RING");
+    return e && e[0] == '1';
+  }();
+  const bool ring = evf_dgrad_ring_select < 0 ? ring_env : evf_dgrad_ring_select == 1;
+  if (ring) {
+    static bool rattr = false;
+    if (!rattr) {
+      (void)hipFuncSetAttribute((const void*)k_dgrad_diag_ring<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS);
+      (void)hipFuncSetAttribute((const void*)k_dgrad_diag_ring<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS);
+      rattr = true;
+    }
+    if (H % WD_ROWS == 0 && W % 32 == 0)
+      hipLaunchKernelGGL(k_dgrad_diag_ring<true>, dim3(nblk), dim3(512), WR_LDS, EVF_STREAM(stream), P, (unsigned)plane_bytes, H, W,
+                         ntx, nty, (unsigned)ntiles, (unsigned)total);
+    else
+      hipLaunchKernelGGL(k_dgrad_diag_ring<false>, dim3(nblk), dim3(512), WR_LDS, EVF_STREAM(stream), P, (unsigned)plane_bytes, H, W,
+                         ntx, nty, (unsigned)ntiles, (unsigned)total);
+    return evf_status();
+  }
   if (H % WD_ROWS == 0 && W % 32 == 0)
     hipLaunchKernelGGL(k_dgrad_diag_dma<true>, dim3(nblk), dim3(512), WM_LDS, EVF_STREAM(stream), P, (unsigned)plane_bytes, H, W, ntx,
                        nty, (unsigned)ntiles, (unsigned)total);

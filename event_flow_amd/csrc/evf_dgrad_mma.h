@@ -107,6 +107,16 @@ __device__ __forceinline__ void dgm_load_g(DgmG& a, int dy, int dx, int m, const
   const int slot = hp * 4 + ((2 * m + kg) ^ sw);
   a.h = pa[slot], a.m = pa[plane + slot], a.l = pa[2 * plane + slot];
 }
+// ... with the halo-pixel index given (a tap row of a RING of halo rows has no fixed distance to the next one)
+// COLSWZ: the chunk swizzle follows the pixel's COLUMN in its halo row (col = (lane & 31) + dx) instead of its pixel index, so
+// that the per-lane part of an address does not depend on the ring row and stays out of the item loop.
+template <bool COLSWZ>
+__device__ __forceinline__ void dgm_load_g_at(DgmG& a, int hp, int dx, int m, const uint4* __restrict__ pa, int plane, int lane) {
+  const int kg = lane >> 5;
+  const int sw = COLSWZ ? ((((lane & 31) + dx) >> 2) & 3) : ((hp >> 2) & 3);
+  const int slot = hp * 4 + ((2 * m + kg) ^ sw);
+  a.h = pa[slot], a.m = pa[plane + slot], a.l = pa[2 * plane + slot];
+}
 __device__ __forceinline__ dgm_f32x16 dgm_six(dgm_f32x16 a, const DgmW& w, const DgmG& g) {
   const dgm_bf16x8 wh = *(const dgm_bf16x8*)&w.h, wm = *(const dgm_bf16x8*)&w.m, wl = *(const dgm_bf16x8*)&w.l;
   const dgm_bf16x8 ah = *(const dgm_bf16x8*)&g.h, am = *(const dgm_bf16x8*)&g.m, al = *(const dgm_bf16x8*)&g.l;
@@ -223,9 +233,16 @@ __device__ __forceinline__ dgm_f32x16 dg_matrix_phase2(const uint4* __restrict__
 // issues in order, so anything placed behind the last MFMA would leave the matrix pipe idle.
 // DPPX as above; the middle fragments of a tap row are built behind the MFMAs of its dx = 0 tap.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool DPPX, class Side>
-__device__ __forceinline__ dgm_f32x16 dg_matrix_phase3(const uint4* __restrict__ s_w, const uint4* __restrict__ pa, int plane,
-                                                       int hp0, int lane, Side&& side) {
+// hp_row(dy): halo-pixel index of this lane's pixel in tap row dy at dx = 0 (hp0 + dy * 34 for a plain tile; a ring of rows
+// wraps).
+template <bool DPPX, bool COLSWZ, class Side, class HpRow>
+__device__ __forceinline__ dgm_f32x16 dg_matrix_phase3h(const uint4* __restrict__ s_w, const uint4* __restrict__ pa, int plane,
+                                                        HpRow&& hp_row, int lane, Side&& side) {
+  auto dgm_load_g = [&](DgmG& a, int dy, int dx, int m, const uint4* __restrict__ pa_, int plane_, int, int lane_) {
+    dgm_load_g_at<COLSWZ>(a, hp_row(dy) + dx, dx, m, pa_, plane_, lane_);
+  };
+  const int hp0 = 0;
+  (void)hp0;
   dgm_f32x16 acc0 = {0}, acc1 = {0};
   DgmW w[2][2];  // [tap parity][m]
   dgm_load_w(w[0][0], 0, s_w, lane);
@@ -304,4 +321,10 @@ __device__ __forceinline__ dgm_f32x16 dg_matrix_phase3(const uint4* __restrict__
     mid[0] = nm0, mid[1] = nm1;
   }
   return acc0 + acc1;
+}
+
+template <bool DPPX, class Side>
+__device__ __forceinline__ dgm_f32x16 dg_matrix_phase3(const uint4* __restrict__ s_w, const uint4* __restrict__ pa, int plane,
+                                                       int hp0, int lane, Side&& side) {
+  return dg_matrix_phase3h<DPPX, false>(s_w, pa, plane, [&](int dy) { return hp0 + dy * DGM_HW; }, lane, side);
 }

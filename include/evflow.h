@@ -323,7 +323,9 @@ int evf_conv_dgrad_b3_pair(const void* g_split, const void* wT_b3, float* g_x, i
 int evf_conv_dgrad_select(int which);
 /* Which kernel launches the RECORDED input-gradient cells of a backward index (evf_bwd_defer_*; results are bit-identical):
  * -1 default (environment EVF_DGRAD_DIAG=lds|ws, else 1), 0 k_dgrad_diag (the LDS kernel's body, one block per tile pair),
- * 1 k_dgrad_diag_ws (persistent producer / consumer blocks over the flat list of products).  Process-wide. */
+ * 1 k_dgrad_diag_ws / k_dgrad_diag_dma (persistent blocks over the flat list of products: fp32 gradient in / pre-split planes
+ * staged by LDS-DMA), 2 like 1 with k_dgrad_diag_ring for the pre-split planes (halo rows in a ring: vertically adjacent tiles
+ * share two of six; measured slower, EVF_DGRAD_RING=1).  Process-wide. */
 int evf_dgrad_diag_select(int which);
 /* Which kernel launches the RECORDED forward cells of an index (evf_fwd_defer_*; results are bit-identical): -1 default
  * (environment EVF_FWD_DIAG=tile|persistent|teams, else 2), 0 k_fwd_diag (one 8 x 32 tile per block, the body of the one-cell

@@ -133,7 +133,7 @@ def test_recorded_input_gradient_cells_are_bit_identical(shape):
             _lib.call("evf_conv_dgrad_b3_f32", P(g), P(w2), P(b), 0, B, H, W, None, None)
         ref.append((a, b))
     try:
-        for which, split in ((0, False), (1, False), (1, True)):
+        for which, split in ((0, False), (1, False), (1, True), (2, True)):  # (2: the ring-halo kernel on the pre-split planes)
             assert L.evf_dgrad_diag_select(which) == 0
             outs = [(torch.full((B, H, W, C), 7.0, device=DEV), torch.full((B, H, W, C), 7.0, device=DEV)) for _ in cells]
             assert _lib.raw("evf_bwd_defer_begin") == 0
