@@ -526,6 +526,15 @@ def cell_forward(cell, input_, prev_state, residual=0, slots=None):
     if not torch.is_tensor(residual) and residual != 0:
         raise _lib.EvflowError("residual must be a tensor or 0")
     p = cell_params(cell)
+    if getattr(cell, "gnorm", False):  # norm="group" LIF cells: spiking_submodules.py:98-99, :518-529
+        input_ = group_norm1(input_, cell.norm_ff if cell.recurrent else cell.norm)
+        if cell.recurrent:
+            if prev_state is None:  # (the reference normalises the zero state as well: z becomes the layer's bias)
+                k, s = cell.kernel_size, cell.stride
+                shp = (input_.shape[0], cell.hidden_size, _out_dim(input_.shape[2], k, s), _out_dim(input_.shape[3], k, s))
+                prev_state = torch.zeros((2,) + shp, dtype=torch.float32, device=input_.device)
+            # the NORMALISED previous spikes feed the recurrent conv and the (detached) reset alike (:528-529, :539-546)
+            prev_state = torch.stack([prev_state[0], group_norm1(prev_state[1], cell.norm_rec)])
     if getattr(cell, "wnorm", False):  # (the normalised weights are new tensors every call: nothing cached may outlive them)
         d = pack_cache(cell)
         for name in ("ff", "rec", "ffT", "recT"):
@@ -692,6 +701,61 @@ class _Norm2d(torch.autograd.Function):
         g_w = s2.sum(0).reshape(ctx.wshape) if has_w else None
         g_b = s1.sum(0).reshape(ctx.wshape) if has_b else None
         return from_nhwc(gx), g_w, g_b, None, None, None
+
+
+class _GroupNorm1(torch.autograd.Function):
+    """nn.GroupNorm(1, C): statistics over (C, H, W) of every sample, per-channel affine.  The per-(sample, channel) sums come
+    from evf_chan_reduce, their combination over the channels is [B, C] host-side arithmetic, the element passes are
+    evf_chan_affine -- the scheme of _Norm2d with the group's sums in place of the channel's."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        xn = to_nhwc(x)
+        B, H, W, C = xn.shape
+        npg, dev = H * W, xn.device
+        N = float(C * npg)
+        s1 = _new((B, C), dev)
+        _lib.call("evf_chan_reduce", _lib.ptr(xn), C, None, 0, None, None, 0, B, npg, C, _lib.ptr(s1))
+        mean = (s1.sum(1, keepdim=True) / N).expand(B, C).contiguous()
+        s2 = _new((B, C), dev)
+        _lib.call("evf_chan_reduce", _lib.ptr(xn), C, None, 0, _lib.ptr(mean), None, 1, B, npg, C, _lib.ptr(s2))
+        rstd = torch.rsqrt(s2.sum(1, keepdim=True) / N + eps).expand(B, C).contiguous()
+        w = weight.detach().float().reshape(1, C)
+        b = bias.detach().float().reshape(1, C)
+        scale = (w * rstd).contiguous()
+        shift = (b - mean * w * rstd).contiguous()
+        y = _new((B, H, W, C), dev)
+        _lib.call("evf_chan_affine", None, 0, _lib.ptr(xn), C, None, _lib.ptr(scale), _lib.ptr(shift), B, npg, C, _lib.ptr(y), C)
+        ctx.saved = (xn, mean, rstd, w)
+        ctx.wshape = tuple(weight.shape)
+        return from_nhwc(y)
+
+    @staticmethod
+    def backward(ctx, g_y):
+        xn, mean, rstd, w = ctx.saved
+        B, H, W, C = xn.shape
+        npg, dev = H * W, xn.device
+        N = float(C * npg)
+        g = to_nhwc(g_y)
+        s1 = _new((B, C), dev)  # sum g
+        s2 = _new((B, C), dev)  # sum g * xhat
+        _lib.call("evf_chan_reduce", _lib.ptr(g), C, None, 0, None, None, 0, B, npg, C, _lib.ptr(s1))
+        _lib.call("evf_chan_reduce", _lib.ptr(xn), C, _lib.ptr(g), C, _lib.ptr(mean), _lib.ptr(rstd), 2, B, npg, C, _lib.ptr(s2))
+        S1 = (w * s1).sum(1, keepdim=True)
+        S2 = (w * s2).sum(1, keepdim=True)
+        A = (w * rstd).contiguous()
+        Bc = (-(rstd * rstd) * S2 / N).contiguous()
+        Cc = (-Bc * mean - rstd * S1 / N).contiguous()
+        gx = _new(tuple(xn.shape), dev)
+        _lib.call("evf_chan_affine", _lib.ptr(g), C, _lib.ptr(xn), C, _lib.ptr(A), _lib.ptr(Bc), _lib.ptr(Cc), B, npg, C, _lib.ptr(gx), C)
+        return from_nhwc(gx), s2.sum(0).reshape(ctx.wshape), s1.sum(0).reshape(ctx.wshape), None
+
+
+def group_norm1(x, layer):
+    """Apply an nn.GroupNorm(1, C) module (parameter holder under the reference's names) on the GPU."""
+    if layer.num_groups != 1:
+        raise _lib.EvflowError("only nn.GroupNorm(1, C) (the reference's cells) is implemented")
+    return _GroupNorm1.apply(x, layer.weight, layer.bias, float(layer.eps))
 
 
 def norm2d(x, layer):

@@ -88,7 +88,8 @@ class FireNet(BaseModel):
             cells = self._cells()
             self._use_fused = (
                 not self.residual
-                and all(getattr(c, "kind", None) in ("lif", "plif") and not getattr(c, "wnorm", False) for c in cells)
+                and all(getattr(c, "kind", None) in ("lif", "plif") and not getattr(c, "wnorm", False) and not getattr(c, "gnorm", False)
+                        for c in cells)
                 and len({c.kind for c in cells}) == 1
                 and all(c.hidden_size == 32 and c.kernel_size == 3 and c.stride == 1 for c in cells)
             )

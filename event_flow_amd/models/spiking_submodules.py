@@ -42,14 +42,22 @@ class _SpikingCell(nn.Module):
             raise AttributeError(activation)  # reference: getattr(spiking, activation)
         # norm (reference spiking_submodules.py:87-94, :502-514): only the LIF cells look at it; the other kinds take the argument
         # and ignore it, as the reference does
-        self.wnorm = False
+        self.wnorm = self.gnorm = False
         if self.kind == "lif" and norm == "weight":
             self.ff = nn.utils.weight_norm(self.ff)  # parameters ff.weight_g / ff.weight_v, the reference's state_dict keys
             if self.recurrent:
                 self.rec = nn.utils.weight_norm(self.rec)
             self.wnorm = True
         elif self.kind == "lif" and norm == "group":
-            raise NotImplementedError("norm='group' (nn.GroupNorm on the cell's inputs) is not implemented; no reference config sets it")
+            # nn.GroupNorm(1, C) on the input (and, recurrent cell, on the previous spikes): parameter holders under the
+            # reference's names (norm | norm_ff, norm_rec); the arithmetic is hip_ops.group_norm1.  `min(1, n // 4)` groups is
+            # the reference's expression: 1 for n >= 4, and nn.GroupNorm's own error below that.
+            if self.recurrent:
+                self.norm_ff = nn.GroupNorm(min(1, input_size // 4), input_size)
+                self.norm_rec = nn.GroupNorm(min(1, hidden_size // 4), hidden_size)
+            else:
+                self.norm = nn.GroupNorm(min(1, input_size // 4), input_size)
+            self.gnorm = True
         self.input_size, self.hidden_size = input_size, hidden_size
         self.kernel_size, self.stride = kernel_size, stride
         self.activation = activation

@@ -86,11 +86,18 @@ def cell_step(kind, p, pre, x, state, *, recurrent, stride=1, act="arctanspike",
         hard_reset = kind in ("lif", "plif")  # ctor defaults, :51,:151 vs :260,:359
     width = p[pre + "act_width"]
     wff = conv_weight(p, pre + "ff")
+    # norm="group" LIF cells (spiking_submodules.py:90-99, :507-529): nn.GroupNorm(1, C) on the input, and -- recurrent cell --
+    # on the previous spikes, whose NORMALISED values then also enter the reset
+    gn_in = pre + ("norm_ff" if recurrent else "norm") + ".weight"
+    if kind == "lif" and gn_in in p:
+        x = torch.nn.functional.group_norm(x, 1, p[gn_in], p[gn_in[:-6] + "bias"], 1e-5)
     ff = _conv(x, wff, stride)
     nstate = 2 if kind == "lif" else 3
     if state is None:
         state = tuple(torch.zeros_like(ff) for _ in range(nstate))
     v, z = state[0], state[1]
+    if kind == "lif" and recurrent and pre + "norm_rec.weight" in p:
+        z = torch.nn.functional.group_norm(z, 1, p[pre + "norm_rec.weight"], p[pre + "norm_rec.bias"], 1e-5)
     cur = ff
     if recurrent:
         cur = ff + _conv(z, conv_weight(p, pre + "rec"))  # z NOT detached here (:530)

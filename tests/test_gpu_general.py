@@ -225,10 +225,11 @@ def _thresh_of(c, g, tag, new_ref):
     return t0 + t1 * new_ref[2]
 
 
-@pytest.mark.parametrize("fix,n", [("g6_cells", 28), ("g15_cells_k5", 8), ("g18_cells_weightnorm", 3)])
+@pytest.mark.parametrize("fix,n", [("g6_cells", 28), ("g15_cells_k5", 8), ("g18_cells_weightnorm", 3), ("g19_cells_groupnorm", 3)])
 def test_g6_cells_forward_backward_on_gpu(fix, n):
     """G6: 3x3 cells; G15: the 5x5 (models/unet.py:51 default) and 7x7 kernels of the general conv path, stride 1 / 2; G18: LIF
-    cells with norm="weight" (evf_weight_norm_fwd / _bwd under the reference's weight_g / weight_v parameters)."""
+    cells with norm="weight" (evf_weight_norm_fwd / _bwd under the reference's weight_g / weight_v parameters); G19: with
+    norm="group" (hip_ops.group_norm1 on the input and -- recurrent cell -- on the previous spikes)."""
     g = load_golden(fix)
     cases = golden_cases(g)
     assert len(cases) == n

@@ -142,10 +142,11 @@ def test_g5_aee():
 
 
 # --------------------------------------------------------------------- G6
-@pytest.mark.parametrize("fix,n", [("g6_cells", 28), ("g15_cells_k5", 8), ("g18_cells_weightnorm", 3)])
+@pytest.mark.parametrize("fix,n", [("g6_cells", 28), ("g15_cells_k5", 8), ("g18_cells_weightnorm", 3), ("g19_cells_groupnorm", 3)])
 def test_g6_cells_forward_backward(fix, n):
     """G6: 3x3 cells, all kinds / resets / surrogates; G15: 5x5 and 7x7 kernels (models/unet.py:51 defaults to 5), stride 1 / 2;
-    G18: LIF cells with norm="weight" (nn.utils.weight_norm on ff / rec, spiking_submodules.py:87-88, :502-504)."""
+    G18 / G19: LIF cells with norm="weight" (nn.utils.weight_norm on ff / rec, spiking_submodules.py:87-88, :502-504) and
+    norm="group" (nn.GroupNorm(1, C) on the input / the previous spikes, :90-99, :507-529)."""
     g = load_golden(fix)
     cases = golden_cases(g)
     assert len(cases) == n

@@ -385,6 +385,43 @@ def g18_cells_weightnorm():
     save("g18_cells_weightnorm", **a)
 
 
+def g19_cells_groupnorm():
+    """Single steps of the reference's LIF cells with norm="group" (spiking_submodules.py:90-99, :507-529: nn.GroupNorm(1, C) on the
+    input; recurrent cell: also on the previous spikes, whose normalised values enter the reset too).  The affine parameters are
+    moved away from (1, 0)."""
+    B, Cin, C, H, W = 2, 4, 8, 12, 10
+    a, cases = {}, []
+    for ci, (recurrent, stride) in enumerate([(False, 1), (False, 2), (True, 1)]):
+        torch.manual_seed(190 + ci)
+        kw = dict(activation="arctanspike", hard_reset=True, thresh=(0.3, 0.1), norm="group")
+        cin = C if recurrent else Cin
+        cell = r_cells.ConvLIFRecurrent(cin, C, 3, **kw) if recurrent else r_cells.ConvLIF(cin, C, 3, stride=stride, **kw)
+        with torch.no_grad():
+            for n, p in cell.named_parameters():
+                if n.startswith("norm"):
+                    p.add_(torch.randn_like(p) * 0.3)
+        x = (torch.rand(B, cin, H, W) < 0.3).float() * torch.randint(1, 3, (B, cin, H, W)).float()
+        x.requires_grad_(True)
+        Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+        st = torch.rand(2, B, C, Ho, Wo)
+        st[1] = (st[1] < 0.3).float()
+        st.requires_grad_(True)
+        out, new = cell(x, st)
+        g_out, g_new = torch.randn_like(out), torch.randn_like(new) * 0.5
+        params = dict(cell.named_parameters())
+        grads = torch.autograd.grad([out, new], [x, st] + list(params.values()), [g_out, g_new], allow_unused=True)
+        tag = f"k{ci}"
+        cases.append(dict(tag=tag, kind="lif", recurrent=recurrent, hard_reset=True, act="arctanspike", ksz=3, stride=stride, norm="group"))
+        a.update({tag + "_x": x, tag + "_state": st, tag + "_out": out, tag + "_new": new, tag + "_g_out": g_out, tag + "_g_new": g_new,
+                  tag + "_gx": grads[0], tag + "_gstate": grads[1]})
+        for (pn, _), gr in zip(params.items(), grads[2:]):
+            a[f"{tag}_grad_{pn}"] = gr if gr is not None else torch.zeros_like(params[pn])
+        for pn, v in cell.state_dict().items():
+            a[f"{tag}_param_{pn}"] = v
+    a["cases_json"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    save("g19_cells_groupnorm", **a)
+
+
 def g16_norm_layers():
     """The reference's ANN layers with norm = "BN" / "IN" and its transposed-conv decoder layer (models/submodules.py:12-137,
     140-185, 238-311), and a MultiResUNet built with norm="BN", use_upsample_conv=False (models/unet.py:196-311): two
@@ -772,3 +809,4 @@ if __name__ == "__main__":
     g15_cells_k5()
     g16_norm_layers()
     g18_cells_weightnorm()
+    g19_cells_groupnorm()
