@@ -74,6 +74,31 @@ int evf_wgrad9_b3_launch(const float* x, int ldx, const float* gy, int ldg, floa
 // scaled map (evf_plif_trace_bwd's g_P_in); raw = 1: g_P is its g_P_raw and AvgPool3x3^T / 32 is applied here -- the same sums
 // in the same order as k_plif_box (a term outside the image adds 0.f).  Nine unconditional loads either way (no load under a
 // branch; raw = 0 reads the centre nine times, an L1 hit).
+// ... in two halves, for a caller that requests the nine values long before it needs their sum
+__device__ __forceinline__ void evf_plif_gp_load(const float* __restrict__ gP, int raw, int b, int y, int x, int H, int W, float (&v)[9]) {
+  const int yc = y < H - 1 ? y : H - 1, xc = x < W - 1 ? x : W - 1;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int yy = yc + dy - 1, xx = xc + dx - 1;
+      const int ya = raw ? (yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy)) : yc, xa = raw ? (xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx)) : xc;
+      v[3 * dy + dx] = gP[((long)b * H + ya) * W + xa];
+    }
+}
+__device__ __forceinline__ float evf_plif_gp_sum(int raw, int y, int x, int H, int W, const float (&v)[9]) {
+  const int yc = y < H - 1 ? y : H - 1, xc = x < W - 1 ? x : W - 1;
+  float s = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int yy = yc + dy - 1, xx = xc + dx - 1;
+      const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      s += (raw ? in : (dy == 1 && dx == 1)) ? v[3 * dy + dx] : 0.f;
+    }
+  return raw ? (s / 9.0f) / 32.0f : s;
+}
 __device__ __forceinline__ float evf_plif_gp(const float* __restrict__ gP, int raw, int b, int y, int x, int H, int W) {
   const int yc = y < H - 1 ? y : H - 1, xc = x < W - 1 ? x : W - 1;
   float s = 0.f;

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(512) void k_conv_dgrad_ws(const float4* __restrict_
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint4* s_w = (uint4*)smem_raw;          // [54][64]
   uint4* s_a = s_w + WS_NFRAG * 64;       // [2][3][WS_HP][4], chunk c of pixel p in slot c ^ ((p >> 2) & 3)
+  float* s_gp = (float*)(s_a + 2 * WS_BUF);  // PLIF: [2][4 rows x 32 pixels] d loss / d(input spike) through the trace, per tile
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const bool producer = wv >= WS_ROWS;
   const int i = lane & 31, kg = lane >> 5;
@@ -121,8 +122,12 @@ __global__ __launch_bounds__(512) void k_conv_dgrad_ws(const float4* __restrict_
   }
   // ---- producer: fp32 halo of a tile -> registers (one of two sets: the requests run TWO tiles ahead of the consumers,
   // so that an HBM round trip hides under a whole matrix phase) -> exact split -> planes of buffer `buf`
+  // PLIF: the producers also fetch, with the halo, the nine values of dL/d(pooled activity) around each of the tile's 128
+  // pixels (threads 0..127) and leave their pooled, scaled sum in LDS at split time -- in the consumers' prologue those nine
+  // loads and ~40 address instructions sat in front of every matrix phase (+7 us per launch at 260 x 346 x B4).
   struct Regs {
     float4 lo4[WS_NIT], hi4[WS_NIT];
+    float gp[PLIF ? 9 : 1];
   };
   const int ptid = tid - WS_ROWS * 64;  // 0..255 among the producers
   int ihr[WS_NIT], ihc[WS_NIT];  // halo row / column of this thread's items (tile independent)
@@ -140,9 +145,14 @@ __global__ __launch_bounds__(512) void k_conv_dgrad_ws(const float4* __restrict_
       const float4* src = gf + (((long)t.b * H + yy) * W + xx) * 8 + 2 * c;
       r.lo4[n] = src[0], r.hi4[n] = src[1];
     }
+    if constexpr (PLIF) evf_plif_gp_load(gPb, plif_raw, t.b, t.y0 + ((ptid & 127) >> 5), t.x0 + (ptid & 31), H, W, r.gp);
   };
   auto split_store = [&](const Regs& r, int buf, const WsTile& t) {
     uint4* dst = s_a + buf * WS_BUF;
+    if constexpr (PLIF) {
+      const float pv = evf_plif_gp_sum(plif_raw, t.y0 + ((ptid & 127) >> 5), t.x0 + (ptid & 31), H, W, r.gp);
+      if (ptid < 128) s_gp[buf * 128 + ptid] = pv;
+    }
 #pragma unroll
     for (int n = 0; n < WS_NIT; ++n) {
       const int it = ptid + n * 256;
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(512) void k_conv_dgrad_ws(const float4* __restrict_
       float4 oldv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) oldv[q] = ACC ? *(const float4*)(gx + pixq * C32 + 8 * q + 4 * kg) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float pv = PLIF ? evf_plif_gp(gPb, plif_raw, cur.b, y, cur.x0 + i, H, W) : 0.f;
+      const float pv = PLIF ? s_gp[buf * 128 + wv * 32 + i] : 0.f;  // (left by the producers with the tile's planes)
       const uint32_t xb = PLIF ? xbits[pixq] : 0u;
       const bool ok = y < H && cur.x0 + i < W;
       const long pix = ((long)cur.b * H + y) * W + cur.x0 + i;
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(512) void k_conv_dgrad_ws(const float4* __restrict_
   WS_STAMP();
 }
 
-#define WS_LDS ((size_t)(WS_NFRAG * 64 + 2 * WS_BUF) * sizeof(uint4))
+#define WS_LDS ((size_t)(WS_NFRAG * 64 + 2 * WS_BUF) * sizeof(uint4) + 2 * 128 * sizeof(float))
 
 // (internal: reached through evf_conv_dgrad_b3_f32[_pair], see dg_launch in evf_dgrad_b3.hip)
 int evf_dgrad_ws_launch(const float* g_cur, const void* wT_b3, float* g_x, int accumulate, int B, int H, int W,
