@@ -17,9 +17,14 @@ the event binning, every forward pass, the loss, the whole backward, the
 all-reduce and the optimizer -- nothing is skipped or cached.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel: algorithmic FLOP per launch / mean launch
-                duration (HIP events on the launch stream, inside the timed
-                region) against the dense fp32-MFMA peak
+  roofline      dominant kernel: algorithmic bytes per launch / mean launch
+                duration against the 8 TB/s HBM peak (the bf16x3 kernels are
+                HBM bound; --precision fp32: FLOP against the fp32-MFMA peak).
+                Durations: HIP events captured INTO the replayed hipGraph
+                (external event-record nodes around the diagonal launches of a
+                second, instrumented capture), i.e. the kernels as they run
+                inside the replayed step; the eager HIP-event figure is kept
+                beside it (`frac_eager`)
   kernels       the same for every conv entry point
   iwe_warp      compute_pol_iwe (integer IWE) GB/s at the spec shape and at a
                 bandwidth-saturating batch, against the 8 TB/s HBM peak
@@ -144,12 +149,13 @@ def run_step(model, lossf, opt, dp, lists, reps=None):
 
 
 class StepGraph:
-    """One training step of one input window as hipGraph replays.  On one GPU the whole step
-    is a single graph.  With several ranks the step is two graphs -- (binning, passes, loss,
-    backward, loss staged into the flat buffer) and (clip+Adam, detach, reset) -- with the
-    step's ONE RCCL all-reduce launched eagerly between them on the same stream: the
-    collective stays outside the captures, so a rank can never replay a different
-    collective sequence than its peers."""
+    """One training step of one input window as hipGraph replays.  The whole step is a single
+    graph -- with several ranks too: the step's ONE all-reduce is evf_allreduce_sum
+    (include/evflow.h) on the library's own RCCL communicator, a plain ncclAllReduce on the
+    capture stream, i.e. one more kernel node.  EVF_DP_TWO_GRAPHS=1 / EVF_DP_NATIVE=0 (or a
+    non-RCCL backend) keep the earlier form: two graphs -- (binning, passes, loss, backward,
+    loss staged into the flat buffer) and (clip+Adam, detach, reset) -- with the all-reduce
+    launched eagerly between them."""
 
     def __init__(self, model, lossf, opt, dp, lists, stream, reps=None):
         from event_flow_amd.train import window_apply, window_backward
@@ -183,7 +189,9 @@ class StepGraph:
                 with torch.cuda.graph(self.post, stream=stream, capture_error_mode=mode):
                     self.loss = reps.apply(local, dp)
             return
-        if not dp.active:
+        if not dp.active or (dp.capturable and os.environ.get("EVF_DP_TWO_GRAPHS", "0") != "1"):
+            # one rank -- or N ranks whose all-reduce is evf_allreduce_sum on the library's own RCCL communicator: a plain
+            # ncclAllReduce on this stream, captured like every other launch -- the whole step is ONE graph
             self.pre = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.pre, stream=stream, capture_error_mode=mode):
                 self.loss = run_step(model, lossf, opt, dp, lists)
@@ -305,7 +313,7 @@ def _pmc(entry):
             "mfma_busy_pct": t.get("mfma_busy_pct"), "source": os.path.basename(files[-1]), "src_hash": d["src_hash"]}, None
 
 
-def gpu_forward_loss_line(wl, dev, pool, precision, reps_n=20):
+def gpu_forward_loss_line(wl, dev, pool, precision, reps_n=20, capture_mode="global"):
     """BASELINE configs[1]: LIF-FireNet forward + IWE (contrast-maximisation) loss, 128x128, 15k events / window, batch 8 -- the
     forward half of the headline step on the same windows (binning, 10 passes, loss; no backward, no optimizer step), on a model
     instance of its own, replayed from one hipGraph per window like the headline step and timed with the wall clock."""
@@ -327,7 +335,8 @@ def gpu_forward_loss_line(wl, dev, pool, precision, reps_n=20):
     try:
         for lists in pool:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=cur):
+            # (with a process group up, its watchdog thread polls events: it must not invalidate this thread's capture)
+            with torch.cuda.graph(g, stream=cur, capture_error_mode=capture_mode):
                 losses.append(window_forward_loss(net, lossf, _encode(lists)))
             graphs.append(g)
         for i in range(2):
@@ -400,9 +409,31 @@ def other_config_line(cfg, steps=10, warmup=3, timeout=420):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def physical_cores():
+    """Physical cores of the host (unique (socket, core) pairs of /proc/cpuinfo; SMT siblings count once)."""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
 def cpu_baseline(threads, max_seconds=60.0, name="LIFFireNet"):
-    """Oracle (PyTorch-CPU port of the reference path) on a bounded sample:
-    ONE window (B=1) of the same workload, full train step."""
+    """Oracle (PyTorch-CPU port of the reference path) on a bounded sample: full train steps of the SAME per-GPU work as the GPU
+    step (B = 8 windows of 10 passes x 1500 events; c5: 4 windows), at three FIXED thread counts -- 1, 16 and all physical cores
+     -- each on at least one full step (>= 3 windows), all three reported (`by_threads`); `value` / `cores` = the
+    fastest of the three."""
     from event_flow_amd import synthetic
     from oracle import encodings as oenc
     from oracle import snn as osnn
@@ -411,8 +442,8 @@ def cpu_baseline(threads, max_seconds=60.0, name="LIFFireNet"):
     gen = torch.Generator().manual_seed(0)
     neuron = ({"leak": (-4.0, 0.1), "thresh": (0.8, 0.1)} if name == "LIFFireNet" else
               {"leak_v": (-4.0, 0.1), "leak_pt": (-4.0, 0.1), "add_pt": (-2.0, 0.1), "thresh": (0.8, 0.1)})
-    params = osnn.make_firenet_params(name, gen, neuron=neuron)
-    keys = osnn.trainable_keys(params)
+    params0 = osnn.make_firenet_params(name, gen, neuron=neuron)
+    keys = osnn.trainable_keys(params0)
     Bc = B_PER_GPU  # the same per-GPU batch of windows the GPU step processes
     passes = []
     for k in range(PASSES):
@@ -425,46 +456,39 @@ def cpu_baseline(threads, max_seconds=60.0, name="LIFFireNet"):
         _, _, pr, st = otrain.train_step(name, pr, keys, ps, st, (H, W), opt, loss_cfg=lcfg)
         return pr, st
 
-    # PyTorch-CPU convs of this size do not scale to hundreds of threads: probe a 2-pass
-    # slice at a few thread counts and keep the fastest (reported as `cores`)
-    cand = sorted({t for t in (8, 16, 32, 64) if t <= threads} or {threads})
-    best, best_t = None, None
-    for t in cand:
+    phys = physical_cores()
+    counts = sorted({t for t in (1, 16, phys) if 1 <= t <= max(threads, 1)} or {1})
+    budget = {1: 1, 16: 20}  # full steps at most per thread count (1 thread: one step of Bc windows, ~10 s)
+    by_threads, best = {}, None
+    params = params0
+    for t in counts:
         torch.set_num_threads(t)
-        one_step(passes[:1], [None] * 7, {"step": 0, "m": {}, "v": {}}, params)  # warm
+        one_step(passes[:1], [None] * 7, {"step": 0, "m": {}, "v": {}}, params0)  # warm (thread pool, allocator)
         t0 = time.perf_counter()
-        one_step(passes[:2], [None] * 7, {"step": 0, "m": {}, "v": {}}, params)
+        opt, states, n_done, params = {"step": 0, "m": {}, "v": {}}, [None] * 7, 0, params0
+        while True:
+            params, states = one_step(passes, states, opt, params)
+            n_done += 1
+            el = time.perf_counter() - t0
+            if el > (10.0 if t > 1 else 0.0) or n_done >= budget.get(t, 20) or el > max_seconds:
+                break
         el = time.perf_counter() - t0
-        if best is None or el < best:
-            best, best_t = el, t
-        if el > 20.0:
-            break
-    torch.set_num_threads(best_t)
-    t0 = time.perf_counter()
-    opt = {"step": 0, "m": {}, "v": {}}
-    n_done = 0
-    states = [None] * 7
-    while True:
-        params, states = one_step(passes, states, opt, params)
-        n_done += 1
-        el = time.perf_counter() - t0
-        if el > 12.0 or n_done >= 20 or el > max_seconds:  # a 10-30 s sample
-            break
-    el = time.perf_counter() - t0
+        by_threads[str(t)] = {"windows_per_s": Bc * n_done / el, "steps": n_done, "windows": Bc * n_done, "seconds": round(el, 2)}
+        if best is None or by_threads[str(t)]["windows_per_s"] > by_threads[str(best)]["windows_per_s"]:
+            best = t
+    best_t = best
+    n_done, el = by_threads[str(best_t)]["steps"], by_threads[str(best_t)]["seconds"]
     # SURVEY 8(d) asks for more CPU figures beside the headline one; each is a bounded sample of its own
     extra = {}
     try:
         from oracle import iwe as oiwe
 
+        torch.set_num_threads(best_t)
         with torch.no_grad():  # configuration 2: forward + loss of the 10-pass window, no backward
             t1 = time.perf_counter()
             otrain.forward_window(name, params, passes, [None] * 7, (H, W), loss_cfg=lcfg)
             extra["fwd_loss_windows_per_s"] = Bc / (time.perf_counter() - t1)
-        torch.set_num_threads(1)  # per-core figure: one pass of the full step on one thread, scaled to the window
-        t1 = time.perf_counter()
-        one_step(passes[:1], [None] * 7, {"step": 0, "m": {}, "v": {}}, params)
-        extra["one_thread_windows_per_s"] = Bc / ((time.perf_counter() - t1) * PASSES)
-        torch.set_num_threads(best_t)
+        extra["one_thread_windows_per_s"] = by_threads.get("1", {}).get("windows_per_s")  # per-core figure (a full step on one thread)
         ev = synthetic.event_list_batch(64, PASSES * EV_PER_PASS, H, W, 999)  # compute_pol_iwe, 64 windows of 15k events
         fl = np.random.default_rng(0).standard_normal((64, 2, H, W)).astype(np.float32)
         pos, neg = (ev[:, :, 3:4] > 0).astype(np.float32), (ev[:, :, 3:4] < 0).astype(np.float32)
@@ -473,11 +497,12 @@ def cpu_baseline(threads, max_seconds=60.0, name="LIFFireNet"):
         extra["iwe_warp_GBps"] = 64 * (28 * PASSES * EV_PER_PASS + 2 * H * W * 4) / (time.perf_counter() - t1) / 1e9
     except Exception as e:  # the extras never cost the headline baseline
         extra["error"] = f"{type(e).__name__}: {e}"
-    return {"value": Bc * n_done / el, "unit": "event-windows/s", "cores": best_t, "kind": "port", "cpu_model": cpu_model(),
-            "host_cpus": os.cpu_count(), "extra": extra,
-            "sample": f"{n_done} full train step(s) of {Bc} windows (B={Bc}, {PASSES} passes x {EV_PER_PASS} events, {H}x{W}) = "
-                      f"the GPU step's per-GPU work; oracle = PyTorch-CPU fp32 port of the reference path; "
-                      f"{best_t} threads (fastest of {cand} on a {os.cpu_count()}-CPU host), {el:.1f} s"}
+    return {"value": by_threads[str(best_t)]["windows_per_s"], "unit": "event-windows/s", "cores": best_t, "kind": "port",
+            "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "physical_cores": phys, "by_threads": by_threads, "extra": extra,
+            "sample": f"full train steps of {Bc} windows (B={Bc}, {PASSES} passes x {EV_PER_PASS} events, {H}x{W}) = the GPU step's "
+                      f"per-GPU work, at FIXED thread counts {counts} (1, 16, all {phys} physical cores of the {os.cpu_count()}-CPU host): "
+                      + ", ".join(f"{t} thr: {v['steps']} step(s) = {v['windows']} windows in {v['seconds']} s" for t, v in by_threads.items())
+                      + f"; value = the fastest ({best_t} threads); oracle = PyTorch-CPU fp32 port of the reference path"}
 
 
 def self_launch(n):
@@ -507,9 +532,9 @@ def hip_ops_conv_b3():
 
 def main_c4(args):
     """BASELINE configs[3]: LIF-EV-FlowNet (SpikingRecEVFlowNet, base 32, 20.4 M parameters), 256x256, one window of 50 000
-    events per sample, batch 8, 4 flow scales, full train step on the general fp32-MFMA path (eager launches).  Same JSON
-    shape as the headline line; the roofline object is the conv entry point with the largest total time, against the dense
-    fp32-MFMA peak (v_mfma_f32_32x32x2_f32)."""
+    events per sample, batch 8, 4 flow scales, full train step on the general path (bf16 MFMA with exact operand splits; replayed
+    from two hipGraphs).  Same JSON shape as the headline line; the roofline object is the conv entry point with the largest total
+    time: its ISSUED bf16 matrix work against the dense bf16 MFMA peak."""
     from event_flow_amd import _lib, synthetic
     from event_flow_amd.loss.flow import EventWarping
     from event_flow_amd.models.model import SpikingRecEVFlowNet
@@ -659,6 +684,9 @@ def main():
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="matrix-core path of the 32->32 convs: exact bf16x3 split (default) or fp32 MFMA")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--no-graph-profile", action="store_true",
+                    help="skip the second, instrumented capture (external event nodes around the diagonal launches) the per-kernel "
+                         "durations of the replayed step come from; kernels[*] then carry the eager HIP-event figures only")
     ap.add_argument("--streams", type=int, default=1,
                     help="micro-batch pipelining (train.StreamReplicas): the per-GPU batch as this many slices on their own HIP "
                          "streams (default 1 = off).  Round 2 (one block per tile, launches of a few cells): 2 gave +6.6 %% windows/s at the "
@@ -669,7 +697,7 @@ def main():
                     help="skip the short c4 / c5 runs the default invocation appends as `other_configs` (after the c3 line's timed region)")
     ap.add_argument("--config", choices=["c3", "c4", "c5"], default="c3",
                     help="BASELINE.json workload: c3 = headline LIF-FireNet train step (default), c5 = PLIF-FireNet 260x346 (4 per GPU), "
-                         "c4 = LIF-EV-FlowNet 256x256 x 50k events (general fp32-MFMA path)")
+                         "c4 = LIF-EV-FlowNet 256x256 x 50k events (general path)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -793,6 +821,45 @@ def main():
     reduce_ms = dp.reduce_times_ms() if dp.active else []
     if dp.active:
         dp.time_reduces(False)
+    one_graph = bool(dp.active and graphs is not None and graphs[0].post is None)
+    if dp.active and not reduce_ms:
+        # the collective sits inside the replayed graph (no bracket there): its own device time from 20 eager launches of the same
+        # all-reduce on a scratch buffer of the same size, after the timed region
+        scratch = torch.zeros_like(opt.comm)
+        dp.time_reduces(True)
+        for _ in range(20):
+            dp.reduce(scratch)
+        reduce_ms = dp.reduce_times_ms()[2:]
+        dp.time_reduces(False)
+    # the diagonal / head-window launches AS THEY RUN INSIDE A REPLAYED STEP: a second, instrumented capture of the same step
+    # graphs whose flushes bracket every dispatcher launch with external event-record nodes (evf_defer_profile(2)); replayed after
+    # the timed region, read once.  The timed graphs above carry no such nodes.
+    gprof = None
+    if graphs is not None and not args.no_graph_profile:
+        import ctypes as _ct0
+
+        try:
+            L = _lib.load()
+            L.evf_defer_profile(2)
+            try:
+                graphs_p = capture_step_graphs(model, lossf, opt, dp, pool, side, reps)
+            finally:
+                L.evf_defer_profile(0)
+            torch.cuda.synchronize()
+            nrep = 3 * len(graphs_p)
+            for i in range(nrep):
+                graphs_p[i % len(graphs_p)].replay()
+            torch.cuda.synchronize()
+            _gms, _gcnt = (_ct0.c_float * 8)(), (_ct0.c_int * 8)()
+            if L.evf_defer_profile_read(_gms, _gcnt) != 0:
+                raise RuntimeError("evf_defer_profile_read failed")
+            empty_ms = (_gms[7] / _gcnt[7]) if _gcnt[7] else 0.0
+            gprof = {"empty_bracket_us": empty_ms * 1e3, "per_kind": {k: (_gms[k] / _gcnt[k], _gcnt[k]) for k in range(7) if _gcnt[k]}}
+            del graphs_p
+        except Exception as e:  # noqa: BLE001 -- the instrumented capture never costs the headline line
+            print(f"[bench] rank {dp.rank}: instrumented graph capture failed ({type(e).__name__}: {e}); eager kernel timing only", file=sys.stderr)
+            gprof = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.synchronize()
     if graphs is None:
         prof = _lib.profile_stop()
         prof_steps = args.steps
@@ -811,10 +878,15 @@ def main():
     _ms, _cnt = (_ct.c_float * 8)(), (_ct.c_int * 8)()
     if _lib.load().evf_defer_profile_read(_ms, _cnt) != 0:
         raise RuntimeError("evf_defer_profile_read failed")
+    prof_eager = {}
     for k, nm in enumerate([("k_fwd_diag", ""), ("k_bwd_diag", ""), ("k_dgrad_diag", ""), ("evf_head_lif_bwd_wgrad", ""),
                             ("k_head_lif_fwd_win", ""), ("k_head_bwd_win", "")]):
         if _cnt[k]:
             prof[nm] = [max(_ms[k] / _cnt[k] - _lib.last_event_overhead_ms, 0.0)] * _cnt[k]
+            if gprof and "per_kind" in gprof and k in gprof["per_kind"]:
+                # inside the replayed graph: mean bracket of the last replay minus the empty bracket of the same graph
+                prof_eager[nm] = prof[nm][0]
+                prof[nm] = [max(gprof["per_kind"][k][0] - gprof["empty_bracket_us"] * 1e-3, 0.0)] * _cnt[k]
     # evf_lif_bwd_wgrad2 = evf_lif_bwd_wgrad with dL/d(spikes) in two parts: one kernel, reported under the one name
     # (variant "+2": the second part present, +128 B/px)
     prof = {(("evf_lif_bwd_wgrad",) + k[1:] if k[0] == "evf_lif_bwd_wgrad2" else k): v for k, v in prof.items()}
@@ -911,6 +983,9 @@ def main():
             ms = np.array(ms)
             name = "/".join(k for k in key if k)
             ent = {"launches": int(ms.size), "mean_us": float(ms.mean() * 1e3), "total_ms_per_step": float(ms.sum() / prof_steps)}
+            if key in prof_eager:
+                ent["timing"] = "inside the replayed hipGraph (external event nodes of an instrumented capture, empty bracket removed)"
+                ent["mean_us_eager"] = prof_eager[key] * 1e3
             if key in model:
                 fl, by = model[key]
                 ent["algorithmic_MB"] = by / 1e6
@@ -950,8 +1025,12 @@ def main():
             # 192 B/px) is reported beside it as *_layout.
             comp_frac = dom.get("frac_fp32_layout", dom["frac_of_hbm_peak"])
             comp_bytes = int(dom["algorithmic_MB_fp32_layout"] * 1e6) if "algorithmic_MB_fp32_layout" in dom else algo
+            eager_scale = (dom["mean_us"] / dom["mean_us_eager"]) if dom.get("mean_us_eager") else None
             roof = {"kernel": "/".join(k for k in dom_key if k), "bound": "hbm", "achieved": comp_frac * HBM_PEAK, "peak": HBM_PEAK,
-                    "unit": "GB/s", "frac": comp_frac, "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "unit": "GB/s", "frac": comp_frac, "mean_launch_us": dom["mean_us"],
+                    "timing": dom.get("timing", "HIP events around eager launches, bracket overhead removed"),
+                    "frac_eager": (comp_frac * eager_scale) if eager_scale else None, "mean_launch_us_eager": dom.get("mean_us_eager"),
+                    "traffic": traffic, "traffic_unit": "bytes/launch",
                     "algorithmic_bytes": comp_bytes, "frac_layout": dom["frac_of_hbm_peak"], "achieved_layout": dom["GBps"],
                     "algorithmic_bytes_layout": algo, "traffic_detail": detail if detail else {"unavailable": why_not},
                     "mfma_busy_pct": detail["mfma_busy_pct"] if detail else None,
@@ -992,6 +1071,10 @@ def main():
                                        # the timed region, this rank): what a scaling run has to compare its step time with
                                        "all_reduce_us": ({"mean": float(np.mean(reduce_ms) * 1e3), "max": float(np.max(reduce_ms) * 1e3),
                                                           "n": len(reduce_ms)} if reduce_ms else None),
+                                       "mode": ("captured: evf_allreduce_sum (ncclAllReduce on the library's own RCCL communicator) is a node "
+                                                "of the step's ONE hipGraph" if one_graph else
+                                                ("evf_allreduce_sum, eager" if dp.capturable else "torch.distributed all_reduce, eager")
+                                                + (" between the step's two hipGraphs" if graphs is not None else "")),
                                        "forced_at_one_rank": dp.world == 1}
                                       if dp.active else
                                       {"backend": dp.backend, "library": ("RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -1004,8 +1087,12 @@ def main():
             # all modelled kernels of a step together: algorithmic bytes / step time against the HBM peak
             "step_hbm_frac": step_alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK,
             "kernels": kernels,
-            "kernel_timing": {"method": "HIP events around each launch on its stream over eager steps, minus the bracket overhead "
-                                        "o = 2 T(1 tiny kernel) - T(2 tiny kernels) calibrated in the same run", "bracket_overhead_us": round(event_overhead_us, 2)},
+            "kernel_timing": {"method": "diagonal / head-window launches: HIP events captured into an instrumented copy of the step graphs "
+                                        "(external event-record nodes), read after its replays, minus the empty bracket of the same graph; "
+                                        "every other entry: HIP events around each launch on its stream over eager steps, minus the bracket "
+                                        "overhead o = 2 T(1 tiny kernel) - T(2 tiny kernels) calibrated in the same run",
+                              "bracket_overhead_us": round(event_overhead_us, 2),
+                              "graph_profile": ({k: v for k, v in gprof.items() if k != "per_kind"} if gprof else None)},
         }
         # the two side measurements must never cost the headline line: report their failure instead
         if not args.no_iwe:
@@ -1035,7 +1122,7 @@ def main():
             # BASELINE configs[1] on the GPU side (the CPU side: cpu_baseline.extra.fwd_loss_windows_per_s): forward passes + CM loss of
             # the same windows, no backward, no optimizer step; eager launches (the recorded diagonal forward), after the timed region
             try:
-                out.setdefault("other_configs", {})["c2"] = (gpu_forward_loss_line(wl, dev, pool, model_precision) if reps is None else
+                out.setdefault("other_configs", {})["c2"] = (gpu_forward_loss_line(wl, dev, pool, model_precision, capture_mode="thread_local" if dp.active else "global") if reps is None else
                                                              {"skipped": "micro-batch pipelining is on (--streams)"})
             except Exception as e:  # noqa: BLE001
                 out.setdefault("other_configs", {})["c2"] = {"error": f"{type(e).__name__}: {e}"}
@@ -1046,6 +1133,28 @@ def main():
             out.setdefault("other_configs", {}).update({"c4": other_config_line("c4"), "c5": other_config_line("c5"),
                                     "note": "`python bench.py --config c4|c5 --steps 10 --warmup 3`, one process each, run after the c3 "
                                             "line's timed region and side measurements; full lines: profiles/"})
+        # the driver's record keeps the scalar entries of `config` (strings cut at 120 characters) and drops nested objects: the
+        # figures of the other BASELINE configurations and of the collective are repeated there in compact form
+        oc = out.get("other_configs", {})
+        for cname in ("c2", "c4", "c5"):
+            ent = oc.get(cname) or {}
+            if "value" in ent:
+                out["config"][f"{cname}_windows_per_s"] = round(float(ent["value"]), 1)
+                ms = ent.get("ms_per_step", ent.get("ms_per_window_batch"))
+                if ms is not None:
+                    out["config"][f"{cname}_ms_per_step"] = round(float(ms), 3)
+            elif ent:
+                out["config"][f"{cname}_windows_per_s"] = None
+        col = out["config"].get("collective") or {}
+        ar = col.get("all_reduce_us") or {}
+        out["config"]["collective_short"] = ("%s, %s rank(s), %s%s" % (
+            col.get("library") or col.get("backend"), col.get("ranks"), col.get("mode", "eager all-reduce between two graphs") if dp.active else "none at one rank",
+            (", all-reduce mean %.1f us max %.1f us (n=%d)" % (ar["mean"], ar["max"], ar["n"])) if ar else ""))[:118]
+        # ... and the full objects move to the FRONT of the line (a truncated record keeps them)
+        front = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "other_configs", "collective", "config", "roofline", "cpu_baseline")
+        out["collective"] = out["config"].get("collective")
+        out = {**{k: out[k] for k in front if k in out}, **{k: v for k, v in out.items() if k not in front}}
         print(json.dumps(out), flush=True)
     dp.barrier()
     dp.close()

@@ -58,6 +58,14 @@ NETWORK_SIGNATURES = {
     "evf_bwd_defer_slot": [I, P],
     "evf_bwd_defer_pending": [P],
     "evf_bwd_defer_flush": [P],
+    "evf_comm_load": [ctypes.c_char_p],
+    "evf_comm_last_error": [],
+    "evf_comm_version": [P],
+    "evf_comm_unique_id": [P],
+    "evf_comm_init": [P, I, I, P],
+    "evf_comm_destroy": [P],
+    "evf_allreduce_sum": [P, P, L, P],
+    "evf_allreduce_max": [P, P, L, P],
     "evf_defer_profile": [I],
     "evf_defer_profile_read": [P, P],
     "evf_lif_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P],
@@ -142,7 +150,7 @@ NETWORK_SIGNATURES = {
     "evf_gru_out_bwd": [P, P, P, P, L, P, P, P, P],
     "evf_gru_gates_bwd": [P, P, P, L, P, P, P],
 }
-RESTYPES = {"evf_conv2d_packed_size": ctypes.c_int64, "evf_conv2d_b3_packed_size": ctypes.c_int64, "evf_conv2d_b3_ws": ctypes.c_int64, "evf_conv2d_wgrad_ws": ctypes.c_int64, "evf_cm_loss_ws": ctypes.c_int64}
+RESTYPES = {"evf_comm_last_error": ctypes.c_char_p, "evf_conv2d_packed_size": ctypes.c_int64, "evf_conv2d_b3_packed_size": ctypes.c_int64, "evf_conv2d_b3_ws": ctypes.c_int64, "evf_conv2d_wgrad_ws": ctypes.c_int64, "evf_cm_loss_ws": ctypes.c_int64}
 SIGNATURES.update(NETWORK_SIGNATURES)
 
 _lib = None

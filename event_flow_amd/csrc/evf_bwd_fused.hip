@@ -1242,14 +1242,21 @@ void evf_ctx_drop(int ctx) {
 
 #define EVF_PROF_MAX 1024
 static struct {
-  bool on;
+  int mode;  // 0 off, 1 eager brackets, 2 brackets recorded into a stream capture as EXTERNAL event nodes (read after replays)
   int n;
   int kind[EVF_PROF_MAX];
   hipEvent_t e0[EVF_PROF_MAX], e1[EVF_PROF_MAX];
   int made;
-} evf_prof = {false, 0, {0}, {}, {}, 0};
+} evf_prof = {0, 0, {0}, {}, {}, 0};
+static void evf_prof_record(hipEvent_t e, hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (evf_prof.mode == 2 && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive)
+    (void)hipEventRecordWithFlags(e, st, hipEventRecordExternal);  // an event-record NODE: every replay stamps the event anew
+  else
+    (void)hipEventRecord(e, st);
+}
 void evf_prof_mark(int kind, int end, void* stream) {
-  if (!evf_prof.on || (!end && evf_prof.n >= EVF_PROF_MAX)) return;
+  if (!evf_prof.mode || (!end && evf_prof.n >= EVF_PROF_MAX)) return;
   if (!end) {
     if (evf_prof.n >= evf_prof.made) {
       (void)hipEventCreate(&evf_prof.e0[evf_prof.made]);
@@ -1257,23 +1264,32 @@ void evf_prof_mark(int kind, int end, void* stream) {
       ++evf_prof.made;
     }
     evf_prof.kind[evf_prof.n] = kind;
-    (void)hipEventRecord(evf_prof.e0[evf_prof.n], EVF_STREAM(stream));
+    evf_prof_record(evf_prof.e0[evf_prof.n], EVF_STREAM(stream));
   } else if (evf_prof.n < EVF_PROF_MAX) {
-    (void)hipEventRecord(evf_prof.e1[evf_prof.n], EVF_STREAM(stream));
+    evf_prof_record(evf_prof.e1[evf_prof.n], EVF_STREAM(stream));
     ++evf_prof.n;
   }
 }
 // evf_defer_profile(1): time every dispatcher launch of the following flushes; evf_defer_profile_read: device sync, then
 // ms[k] = summed duration and count[k] = number of launches of kind k < 8 (0 k_fwd_diag, 1 k_bwd_diag, 2 k_dgrad_diag, 3 head
-// backward pass by pass, 4 k_head_lif_fwd_win, 5 k_head_bwd_win) since it was switched on (event-bracket overhead included: ~1.6 us per launch); switches it off.
+// backward pass by pass, 4 k_head_lif_fwd_win, 5 k_head_bwd_win, 7 an EMPTY bracket = the bracket's own cost) since it was
+// switched on (event-bracket overhead included: ~1.6 us per launch); switches it off.
+// evf_defer_profile(2): the same brackets while the step is CAPTURED into a hipGraph -- external event-record nodes around the
+// dispatcher launches (and one empty bracket per forward flush, kind 7); evf_defer_profile(0) after the capture stops the
+// recording and KEEPS the brackets, the graph is replayed, and evf_defer_profile_read returns the durations of the LAST replay:
+// the kernels as they run back to back inside the replayed step (clocks, caches), not as eager launches.
 extern "C" int evf_defer_profile(int on) {
-  evf_prof.on = on != 0;
+  if (on == 0) {  // stop; what is recorded stays readable (mode 2: after the replays)
+    evf_prof.mode = 0;
+    return EVF_OK;
+  }
+  evf_prof.mode = on == 2 ? 2 : 1;
   evf_prof.n = 0;
   return EVF_OK;
 }
 extern "C" int evf_defer_profile_read(float* ms, int* count) {
   if (!ms || !count) return EVF_EINVAL;
-  evf_prof.on = false;
+  evf_prof.mode = 0;
   { const int rc = evf_hip(hipDeviceSynchronize()); if (rc) return rc; }
   for (int k = 0; k < 8; ++k) ms[k] = 0.f, count[k] = 0;
   for (int i = 0; i < evf_prof.n; ++i) {
@@ -1285,6 +1301,7 @@ extern "C" int evf_defer_profile_read(float* ms, int* count) {
   evf_prof.n = 0;
   return EVF_OK;
 }
+int evf_prof_mode() { return evf_prof.mode; }
 struct FbDefer {
   int B, H, W, row_ld;
   int n[EVF_BWD_DIAGS];

@@ -59,6 +59,19 @@ __device__ __forceinline__ float evf_block_sum(float v, float* smem /* >= 16 flo
   return r;
 }
 
+// block-wide sum of up to 1024 threads, the same bits in EVERY thread (fixed order: wave sums, then the waves in index order)
+__device__ __forceinline__ float evf_block_sum_all(float v, float* smem /* >= 16 floats */) {
+  v = evf_wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) smem[wid] = v;
+  __syncthreads();
+  const int nw = (blockDim.x + 63) >> 6;
+  float r = 0.f;
+  for (int w = 0; w < nw; ++w) r += smem[w];
+  __syncthreads();
+  return r;
+}
+
 // evf_conv_b3tile.hip: spatially tiled 3x3 stride-1 convolution behind evf_conv2d_fwd_b3 / evf_conv2d_dgrad_b3
 int evf_conv3_b3t_plan(const float* src, int B, int H, int W, int K, int N, int lds, bool force, int max_split, int force_split);
 int evf_conv3_b3t_launch(const float* src, int lds, const void* wp, const float* bias, float* out, int ldo, int B, int H, int W,
@@ -176,3 +189,4 @@ void evf_hf_defer_reset(int ctx);
 // launch of a flush, by kind (0 k_fwd_diag, 1 k_bwd_diag, 2 k_dgrad_diag, 3 head backward).  No-ops unless switched on
 // (never during a graph capture).
 void evf_prof_mark(int kind, int end, void* stream);
+int evf_prof_mode();  // 0 off, 1 eager brackets, 2 brackets captured into a hipGraph

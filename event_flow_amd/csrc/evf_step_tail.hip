@@ -23,9 +23,9 @@ struct GfArgs {
 };
 
 #define GF_GROUPS 16
-#define GF_RCHUNK 64  // rows of per-block partials one block of the segment part sums
+#define GF_UNROLL 8   // independent row loads per thread and trip of the segment part
 // blocks [0, 144 * nslabs): 64 outputs x 16 slab groups of tensor block / 144 (as k_reduce_wgrad_multi);
-// blocks behind them: 64 columns x 16 row groups of one segment of the small gradients
+// blocks behind them: 64 columns x 16 row groups of one segment of the small gradients, all rows
 __global__ __launch_bounds__(64 * GF_GROUPS) void k_grads_finalize(GfArgs a, int nslabs, int nslab, float* __restrict__ small,
                                                                    int clear_small, float* __restrict__ rows, int nrows, int ncols,
                                                                    const float* __restrict__ hrows, int nhrows, int nhcols, int hoff,
@@ -58,46 +58,53 @@ __global__ __launch_bounds__(64 * GF_GROUPS) void k_grads_finalize(GfArgs a, int
     }
     return;
   }
-  // ---- small gradients: block = (segment k, 64 of its columns, GF_RCHUNK rows of the per-block partials); the blocks of one
-  // column group add their sums to the segment atomically (few, spread addresses); the block of row chunk 0 also moves the
-  // small accumulator.  (First version: ONE block per column group walked all rows -- 64 dependent trips, 65 us per launch.)
+  // ---- small gradients: block = (segment k, 64 of its columns).  The block walks ALL rows of the per-block partials in a fixed
+  // order (row group ty takes rows ty, ty + 16, ...; GF_UNROLL independent loads in flight per thread; the 16 row groups meet in
+  // LDS and are added in index order) and is the only writer of its elements: no atomics, the same bits whatever the block
+  // schedule, a zero or non-zero destination alike (the first fused version added one atomic per 64-row chunk).
   const int sb = blockIdx.x - nb_slab;
   int k = 0;
   while (k + 1 < nseg && sb >= a.seg_blk0[k + 1]) ++k;  // (block-uniform, <= 32 steps)
-  const int rel = sb - a.seg_blk0[k], ncg = (a.seg_n[k] + 63) / 64;
-  const int cg = rel % ncg, rc = rel / ncg;  // column group, row chunk
+  const int cg = sb - a.seg_blk0[k];         // column group
   const int i = cg * 64 + tx;                // element of segment k
   const bool in = i < a.seg_n[k];
   const int e = a.seg_off[k] + (in ? i : 0);  // column of the small accumulator
-  const int r0 = rc * GF_RCHUNK;
   float v = 0.f;
-  if (in) {
-    if (rows && e < ncols) {
+  if (rows && e < ncols) {  // (clamped rows + selects: every load of a trip is unconditional, i.e. in flight together)
+    float* __restrict__ rp = rows + e;
+    for (int r0 = 0; r0 < nrows; r0 += GF_GROUPS * GF_UNROLL) {
+      float q[GF_UNROLL];
 #pragma unroll
-      for (int j = 0; j < GF_RCHUNK / GF_GROUPS; ++j) {
+      for (int j = 0; j < GF_UNROLL; ++j) q[j] = rp[(long)min(r0 + ty + j * GF_GROUPS, nrows - 1) * ncols];
+#pragma unroll
+      for (int j = 0; j < GF_UNROLL; ++j) {
         const int r = r0 + ty + j * GF_GROUPS;
         if (r < nrows) {
-          v += rows[(long)r * ncols + e];
-          rows[(long)r * ncols + e] = 0.f;  // (the persistent per-block rows are handed back zeroed)
+          v += in ? q[j] : 0.f;
+          if (in) rp[(long)r * ncols] = 0.f;  // (the persistent per-block rows are handed back zeroed)
         }
       }
     }
-    if (hrows && e >= hoff && e < hoff + nhcols) {
+  }
+  if (hrows && e >= hoff && e < hoff + nhcols) {
+    const float* __restrict__ hp = hrows + (e - hoff);
+    for (int r0 = 0; r0 < nhrows; r0 += GF_GROUPS * GF_UNROLL) {
+      float q[GF_UNROLL];
 #pragma unroll
-      for (int j = 0; j < GF_RCHUNK / GF_GROUPS; ++j) {
-        const int r = r0 + ty + j * GF_GROUPS;
-        if (r < nhrows) v += hrows[(long)r * nhcols + (e - hoff)];
-      }
+      for (int j = 0; j < GF_UNROLL; ++j) q[j] = hp[(long)min(r0 + ty + j * GF_GROUPS, nhrows - 1) * nhcols];
+#pragma unroll
+      for (int j = 0; j < GF_UNROLL; ++j)
+        if (in && r0 + ty + j * GF_GROUPS < nhrows) v += q[j];
     }
   }
   red[ty][tx] = v;
   __syncthreads();
   if (ty == 0 && in) {
-    float s = rc == 0 ? small[e] : 0.f;
+    float s = small[e];
 #pragma unroll
     for (int g = 0; g < GF_GROUPS; ++g) s += red[g][tx];
-    if (s != 0.f) evf_atomic_add(a.seg_dst[k] + i, s);
-    if (rc == 0 && clear_small) small[e] = 0.f;
+    a.seg_dst[k][i] += s;
+    if (clear_small) small[e] = 0.f;
   }
 }
 
@@ -122,13 +129,7 @@ extern "C" int evf_grads_finalize(const void* const* slabs, void* const* slab_ds
     a.seg_n[k] = k < nseg ? seg_n[k] : 0;
     if (k < nseg && (!a.seg_dst[k] || a.seg_off[k] < 0 || a.seg_n[k] <= 0)) return EVF_EINVAL;
     a.seg_blk0[k] = nb;
-    if (k < nseg) {
-      // rows this segment's columns have partials in: the per-block rows (columns < ncols), the head layer's (its own range)
-      int nr = 1;
-      if (rows && a.seg_off[k] < ncols) nr = nrows;
-      if (head_rows && a.seg_off[k] < head_off + nhcols && a.seg_off[k] + a.seg_n[k] > head_off && nhrows > nr) nr = nhrows;
-      nb += evf_cdiv(a.seg_n[k], 64) * evf_cdiv(nr, GF_RCHUNK);
-    }
+    if (k < nseg) nb += evf_cdiv(a.seg_n[k], 64);
   }
   a.seg_blk0[32] = nb;
   for (int k = nseg; k < 32; ++k) a.seg_blk0[k] = nb;
@@ -141,12 +142,15 @@ extern "C" int evf_grads_finalize(const void* const* slabs, void* const* slab_ds
 // For the parameter counts of the FireNets (75 k) the squared norm is cheap to compute REDUNDANTLY: CA_BLOCKS blocks of 1024
 // threads each sum the whole gradient (300 KB out of the L2; the same order in every block, i.e. a reproducible norm -- no
 // atomics, no word to clear) and then run clip + Adam on their own slice.  zero_grad is the one cross-block hazard (a block must
-// not clear its slice while another still sums it): one arrival ticket per block in ws[3], a short wait of CA_BLOCKS
-// participants, and the last block to leave resets the tickets.  (First version: one block per CU, partial sums by atomics and
-// a hand-shake of 256 blocks -- 34 us against 17 us for the three launches it replaced.)  Large models keep the two-launch
-// form (evf_clip_adam_step): n > CA_MAX_N.
+// not clear its slice while another still sums it).  No block ever waits for another one (the first version spun on
+// an arrival ticket, which needs all blocks co-resident -- not guaranteed under a CU mask or beside other streams' blocks --
+// and left stale tickets behind an aborted launch): nobody clears anything while working; every block takes a DEPARTURE ticket
+// once it has read all it needs, and the block that draws the last ticket -- everybody else is provably done reading -- clears
+// the whole gradient (75 floats per thread), publishes the norm, advances the step counter and resets the ticket.  Blocks
+// that are scheduled late simply find the gradient still intact.  Large models keep the two-launch form
+// (evf_clip_adam_step): n > CA_MAX_N.
 // ws (>= 8 floats, zeroed once by the caller): [0] squared gradient norm of the last step, [1] the device-side step counter,
-// [3] / [4] arrival / departure tickets (uint32, left zero).
+// [4] departure tickets (uint32, left zero; [3] unused, kept zero).
 #define CA_BLOCKS 16
 #define CA_MAX_N (1 << 20)
 __global__ __launch_bounds__(1024) void k_clip_adam_fused(float* __restrict__ p, float* g, float* __restrict__ m,
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(1024) void k_clip_adam_fused(float* __restrict__ p,
                                                           float host_step_size, float host_bc2_sqrt, float eps, float* ws,
                                                           int device_step, int zero_grad) {
   __shared__ float red[16];
-  __shared__ float s_total;
+  __shared__ int s_last;
   // ---- the whole gradient's sum of squares, the same in every block (float4 trips + tail)
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   const long n4 = n >> 2;
@@ -164,22 +168,12 @@ __global__ __launch_bounds__(1024) void k_clip_adam_fused(float* __restrict__ p,
     s0 += q.x * q.x, s1 += q.y * q.y, s2 += q.z * q.z, s3 += q.w * q.w;
   }
   for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) s0 += g[i] * g[i];
-  const float tot = evf_block_sum((s0 + s1) + (s2 + s3), red);
-  unsigned* tick = (unsigned*)(ws + 3);
-  if (threadIdx.x == 0) {
-    s_total = tot;
-    if (zero_grad) {  // every block has finished reading the gradient before anybody clears a slice of it
-      __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      while (__hip_atomic_load(tick, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(1);
-    }
-  }
-  __syncthreads();
-  const float total = s_total;
+  const float total = evf_block_sum_all((s0 + s1) + (s2 + s3), red);
   // clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
   float coef = 1.f;
   if (max_norm > 0.f) coef = fminf(1.f, max_norm / (sqrtf(total) + 1e-6f));
   float step_size = host_step_size, bc2_sqrt = host_bc2_sqrt;
-  if (device_step) {  // bias corrections from the device-side counter (advanced by block 0 at the END of the launch), in double
+  if (device_step) {  // bias corrections from the device-side counter (advanced by the last block to leave), in double
     const double t = (double)ws[1] + 1.0;
     step_size = (float)((double)lr / (1.0 - pow((double)b1, t)));
     bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
@@ -193,17 +187,25 @@ __global__ __launch_bounds__(1024) void k_clip_adam_fused(float* __restrict__ p,
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] = p[i] - step_size * (mi / denom);
-    if (zero_grad) g[i] = 0.f;  // optimizer.zero_grad() of the next step, without its fill kernel
   }
-  __syncthreads();  // (every thread of the block has read ws[1])
+  __syncthreads();  // (every thread of the block has read the gradient and ws[1])
+  unsigned* tick = (unsigned*)(ws + 4);
   if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(tick + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == gridDim.x - 1) {  // the last block to leave: everybody has read the counter
-      ws[0] = total;
-      if (device_step) ws[1] += 1.0f;
-      tick[0] = 0u;
-      tick[1] = 0u;
-    }
+    const unsigned t = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t + 1u >= gridDim.x;  // (>=: a ticket left over by a launch that never finished cannot lock the tail out for good)
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // ---- the last block to leave: everybody has read the gradient and the counter
+  if (zero_grad) {  // optimizer.zero_grad() of the next step, without its fill kernel
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long i = threadIdx.x; i < n4; i += blockDim.x) ((float4*)g)[i] = z4;
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) g[i] = 0.f;
+  }
+  if (threadIdx.x == 0) {
+    ws[0] = total;
+    if (device_step) ws[1] += 1.0f;
+    __hip_atomic_store(tick, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

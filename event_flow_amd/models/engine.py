@@ -748,7 +748,9 @@ class FireNetEngine:
                   head.shape[1] if head is not None else 0, self.small_off["0.ff"][0] if head is not None else 0,
                   (ctypes.c_void_p * n2)(*[t.data_ptr() for t in seg_dst]), (ctypes.c_int * n2)(*seg_off), (ctypes.c_int * n2)(*seg_n), n2)
         if rows is not None:
-            self._rows_clean = True
+            # the kernel hands back zeroed the columns it consumed: the buffer as a whole is clean only when the trainable segments
+            # cover every column (a frozen per-channel parameter's column keeps its partial sums -> _take_rows starts afresh)
+            self._rows_clean = sum(seg_n) == self.small_size
         if win.small_persistent:
             self._small_clean = True
         self._last_window = win

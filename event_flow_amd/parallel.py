@@ -54,6 +54,52 @@ class DataParallel:
         self.stream = None
         if self.active and backend == "nccl" and device is not None:
             self.stream = torch.cuda.Stream(device=torch.device(device))
+        # The step's ONE collective on a communicator of the library's own (include/evflow.h: evf_comm_*, evf_allreduce_sum):
+        # a plain ncclAllReduce on the caller's stream -- no watchdog thread, no stream of its own -- and therefore CAPTURABLE:
+        # the N-rank step replays as ONE hipGraph (bench.StepGraph).  Bootstrapped from torch's store (rank 0's 128-byte id).
+        # EVF_DP_NATIVE=0 keeps every collective on torch.distributed (the step is then two graphs around an eager all-reduce).
+        self.native = None
+        if self.active and backend == "nccl" and device is not None and os.environ.get("EVF_DP_NATIVE", "1") != "0":
+            self._init_native()
+
+    def _init_native(self):
+        import ctypes
+
+        from . import _lib
+
+        L = _lib.load()
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")  # the RCCL this process has loaded already
+        rc = L.evf_comm_load(path.encode() if os.path.exists(path) else None)
+        if rc != 0:
+            raise _lib.EvflowError(f"evf_comm_load failed with status {rc}: {L.evf_comm_last_error().decode()} "
+                                   "(EVF_DP_NATIVE=0 keeps the collectives on torch.distributed)")
+        store = dist.distributed_c10d._get_default_store()
+        key = "evf_rccl_unique_id/%d" % DataParallel._native_seq
+        DataParallel._native_seq += 1
+        ident = (ctypes.c_char * 128)()
+        if self.rank == 0:
+            rc = L.evf_comm_unique_id(ident)
+            if rc != 0:
+                raise _lib.EvflowError(f"evf_comm_unique_id failed with status {rc}: {L.evf_comm_last_error().decode()}")
+            store.set(key, bytes(ident.raw))
+        else:
+            raw = store.get(key)  # (blocks until rank 0 has published it)
+            ident.raw = bytes(raw)[:128]
+        comm = ctypes.c_void_p()
+        with torch.cuda.device(torch.device(self.device)):
+            rc = L.evf_comm_init(ident, self.rank, self.world, ctypes.byref(comm))
+        if rc != 0:
+            raise _lib.EvflowError(f"evf_comm_init failed with status {rc}: {L.evf_comm_last_error().decode()}")
+        self.native = comm
+        ver = ctypes.c_int()
+        self.native_version = ver.value if L.evf_comm_version(ctypes.byref(ver)) == 0 else None
+
+    _native_seq = 0
+
+    @property
+    def capturable(self):
+        """The step's collective may sit inside a hipGraph capture (own RCCL communicator, caller's stream)."""
+        return self.native is not None
 
     # -- sharding ------------------------------------------------------------
     def shard(self, global_batch):
@@ -87,6 +133,18 @@ class DataParallel:
 
     def reduce(self, comm):
         """THE collective of a step: in-place SUM all-reduce of gradient + tail."""
+        if self.active and self.native is not None and comm.is_cuda:
+            from . import _lib
+
+            timed = self.__dict__.get("_timed") is not None and not torch.cuda.is_current_stream_capturing()
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            _lib.call("evf_allreduce_sum", self.native, _lib.ptr(comm), comm.numel())  # on the current stream
+            if timed:
+                e1.record()
+                self._timed.append((e0, e1))
+            return
         if self.active:
             if self.__dict__.get("_timed") is not None and comm.is_cuda:
                 # (bench.py: the collective's own device time, HIP events on the stream it runs on)
@@ -156,5 +214,11 @@ class DataParallel:
         return float(t.item())
 
     def close(self):
+        if self.native is not None:
+            from . import _lib
+
+            torch.cuda.synchronize()
+            _lib.load().evf_comm_destroy(self.native)
+            self.native = None
         if self.active and dist.is_initialized():
             dist.destroy_process_group()

@@ -33,6 +33,7 @@ extern "C" {
 
 #define EVF_OK 0
 #define EVF_EINVAL (-22)
+#define EVF_ENOTSUP (-95) /* a run-time dependency is absent (evf_comm_*: no librccl) */
 
 /* library / device probe (no GPU work) */
 int evf_version(void);          /* 100*major + minor */
@@ -243,8 +244,10 @@ int evf_bwd_defer_flush(void* stream);
 /* Measurement aid: evf_defer_profile(1) brackets every launch of the following flushes with HIP events;
  * evf_defer_profile_read synchronises the device, returns per kind (0 forward cells, 1 fused-backward cells, 2
  * input-gradient cells, 3 head backward one pass per launch, 4 head forward of a window in one launch, 5 head backward of
- * a window in one launch; 6, 7 unused) the summed duration in ms and the number of launches -- EIGHT entries each -- and
- * switches it off.  Not inside a graph capture. */
+ * a window in one launch; 6 unused; 7 an empty bracket) the summed duration in ms and the number of launches -- EIGHT entries
+ * each -- and switches it off.  evf_defer_profile(2): the brackets are recorded INTO a stream capture as external event-record
+ * nodes (hipEventRecordWithFlags(..., hipEventRecordExternal)); evf_defer_profile(0) after the capture stops recording and
+ * keeps them; after replays of the graph evf_defer_profile_read returns the durations inside the LAST replay. */
 int evf_defer_profile(int on);
 int evf_defer_profile_read(float* ms8, int* count8);
 
@@ -648,9 +651,10 @@ int evf_clip_adam_step(float* param, float* grad, float* m, float* v, int64_t n,
                        float max_norm, float lr, float beta1, float beta2, float eps, int step,
                        float* norm_ws, int zero_grad, void* stream);
 /* The same step in ONE launch for parameter counts up to 2^20 (a few fat blocks; every block sums the whole gradient itself --
- * a reproducible norm without atomics --, a short hand-shake guards zero_grad; larger n: the two launches above).
+ * a reproducible norm without atomics; no block waits for another: the block that draws the last departure ticket clears the
+ * gradient, publishes the norm and advances the counter; larger n: the two launches above).
  * ws: >= 8 floats, zeroed ONCE by the caller and owned by this entry point afterwards: [0] squared gradient norm of the last
- * step, [1] the device-side step counter (as norm_ws[1] above), [3..4] two tickets, left zero. */
+ * step, [1] the device-side step counter (as norm_ws[1] above), [4] the departure ticket, left zero ([3] unused). */
 int evf_clip_adam_fused(float* param, float* grad, float* m, float* v, int64_t n,
                         float max_norm, float lr, float beta1, float beta2, float eps, int step,
                         float* ws, int zero_grad, void* stream);
@@ -659,10 +663,34 @@ int evf_clip_adam_fused(float* param, float* grad, float* m, float* v, int64_t n
  *   slabs[t] [nslab][9*32*32] partial sums of conv weight t (nslabs <= 16) -> slab_dst[t] [32][32][3][3] +=;
  *   total[e] = small[e] + sum_r rows[r][e] (e < ncols; rows zeroed; rows null = none)
  *                       + sum_r head_rows[r][e - head_off] (head_off <= e < head_off + nhcols; null = none);
- *   seg_dst[k][i] += total[seg_off[k] + i], i < seg_n[k] (nseg <= 32); clear_small != 0: small[e] = 0 afterwards. */
+ *   seg_dst[k][i] += total[seg_off[k] + i], i < seg_n[k] (nseg <= 32); clear_small != 0: small[e] = 0 afterwards.
+ * Every output element has ONE writer that sums in a fixed order: the result does not depend on the block schedule (segments
+ * must not overlap).  Only the columns of `rows` that belong to a segment are read and zeroed. */
 int evf_grads_finalize(const void* const* slabs, void* const* slab_dst, int nslabs, int nslab, float* small, int clear_small,
                        float* rows, int nrows, int ncols, const float* head_rows, int nhrows, int nhcols, int head_off,
                        void* const* seg_dst, const int* seg_off, const int* seg_n, int nseg, void* stream);
+
+/* ---- data parallelism: the ONE collective of an optimizer step (SURVEY.md 8(b) `evf_allreduce_sum`, 8(e)) ----------------
+ * The reference is single-process (/root/reference/configs/parser.py:83-86, train_flow.py:98-171); its loss SUMS over the batch
+ * (loss/flow.py:226,259,289), so N ranks holding N shards of the batch need exactly one in-place SUM all-reduce of the flat
+ * gradient buffer [gradient | loss | new_seq flag] per step, before clip + Adam (evf_clip_adam_*), over RCCL / xGMI.
+ * evf_comm_*: a communicator of this library's own (RCCL bound at run time by dlopen; EVF_ENOTSUP when absent).
+ *   evf_comm_load(path)      bind RCCL from `path` (NULL / "": a librccl this process has loaded already, else the system's);
+ *   evf_comm_unique_id(id)   rank 0: 128 bytes (EVF_COMM_ID_BYTES) to hand to every rank out of band (torch's store, a file);
+ *   evf_comm_init(id, rank, world, &comm)   collective over the ranks (blocks until all have called), current HIP device;
+ *   evf_allreduce_sum / _max(comm, buf, n, stream)   in place, fp32, enqueued on `stream`; CAPTURABLE into a hipGraph (one
+ *                            kernel node), which is what makes the N-rank step ONE graph;
+ *   evf_comm_destroy(comm); evf_comm_version(&v) (RCCL's version code); evf_comm_last_error() (text of the last RCCL error).
+ * Status: 0, EVF_EINVAL, EVF_ENOTSUP, or -(2000 + ncclResult_t). */
+#define EVF_COMM_ID_BYTES 128
+int evf_comm_load(const char* librccl_path);
+const char* evf_comm_last_error(void);
+int evf_comm_version(int* version);
+int evf_comm_unique_id(void* id128);
+int evf_comm_init(const void* id128, int rank, int world, void** comm);
+int evf_comm_destroy(void* comm);
+int evf_allreduce_sum(void* comm, float* buf, int64_t n, void* stream);
+int evf_allreduce_max(void* comm, float* buf, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

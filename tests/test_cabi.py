@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "evflow.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|int64_t)\s+(evf_\w+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t|const char\s*\*)\s*(evf_\w+)\s*\(", src)))
 
 
 def test_header_declares_the_path():

@@ -182,6 +182,9 @@ def test_rccl_code_path_on_one_rank_graph_equals_eager_and_plain_step():
     e = _bench_rccl_one_rank(["--no-graph", "--warmup", "4"], _free_port())  # graph mode adds 2 replay warm-up steps: same 8 updates
     col = g["config"]["collective"]
     assert col["backend"] == "nccl" and col["library"].startswith("RCCL") and col["ranks"] == 1 and col["forced_at_one_rank"], col
+    # (round 5: the collective is evf_allreduce_sum on the library's own RCCL communicator, a node of the step's ONE graph)
+    assert col["mode"].startswith("captured") and col["all_reduce_us"] and col["all_reduce_us"]["n"] > 0, col
+    assert "evf_allreduce_sum" in e["config"]["collective"]["mode"], e["config"]["collective"]
     assert g["config"]["launch"] == "hipgraph" and e["config"]["launch"] == "eager", (g["config"], e["config"])
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "EVF_DP_FORCE", "EVF_DP_BACKEND"):
@@ -197,7 +200,8 @@ def test_rccl_code_path_on_one_rank_graph_equals_eager_and_plain_step():
 
 
 def test_two_graph_rccl_step_is_bitwise_the_one_graph_step():
-    """What a rank replays in a multi-GPU run (two hipGraphs around the eager RCCL all-reduce, forced at world size 1) leaves
+    """What a rank replays in a multi-GPU run, forced at world size 1 -- (b) ONE hipGraph with evf_allreduce_sum captured as a node,
+    (c) two hipGraphs around that collective launched eagerly, (d) two hipGraphs around torch.distributed's all_reduce -- leaves
     EXACTLY the parameters, Adam moments and recurrent states of the single-GPU one-graph step (deterministic loss, no clipping):
     tools/dp_two_graph_check.py in its own process (nccl process group)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
@@ -209,7 +213,9 @@ def test_two_graph_rccl_step_is_bitwise_the_one_graph_step():
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     print(res)
     assert res["one_graph_step_is_one_graph"] and res["forced_step_is_two_graphs"] and res["backend"] == "nccl", res
-    assert res["updates"] == [6.0, 6.0] and max(res["grad_norm"]) < 100.0 and res["trained"], res  # (2 eager + 4 replayed, unclipped)
+    # the N-rank step with evf_allreduce_sum (the library's own RCCL communicator) captured: ONE graph; torch's collective is not capturable
+    assert res["captured_rccl_step_is_one_graph"] and res["torch_path_not_capturable"] and res["rccl_version"], res
+    assert res["updates"] == [6.0] * 4 and max(res["grad_norm"]) < 100.0 and res["trained"], res  # (2 eager + 4 replayed, unclipped)
     assert res["params_bitwise_equal"] and res["moments_bitwise_equal"] and res["states_bitwise_equal"], res
 
 
