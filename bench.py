@@ -21,7 +21,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 duration against the 8 TB/s HBM peak (the bf16x3 kernels are
                 HBM bound; --precision fp32: FLOP against the fp32-MFMA peak).
                 Durations: HIP events captured INTO the replayed hipGraph
-                (external event-record nodes around the diagonal launches of a
+                (timestamp-kernel nodes around the diagonal launches of a
                 second, instrumented capture), i.e. the kernels as they run
                 inside the replayed step; the eager HIP-event figure is kept
                 beside it (`frac_eager`)
@@ -157,12 +157,12 @@ class StepGraph:
     loss staged into the flat buffer) and (clip+Adam, detach, reset) -- with the all-reduce
     launched eagerly between them."""
 
-    def __init__(self, model, lossf, opt, dp, lists, stream, reps=None):
+    def __init__(self, model, lossf, opt, dp, lists, stream, reps=None, capture_mode=None):
         from event_flow_amd.train import window_apply, window_backward
 
         self.dp, self.comm, self.reps = dp, opt.comm, reps
         # other threads (the process group's watchdog polls events) must not invalidate a capture of this thread
-        mode = "thread_local" if dp.active else "global"
+        mode = capture_mode or ("thread_local" if dp.active else "global")
         if reps is not None:
             # micro-batch pipelining (train.StreamReplicas): one graph per replica on its own stream, then the join:
             # gradients / losses summed, (all-reduce outside any capture,) clip+Adam, detach, reset
@@ -219,7 +219,7 @@ class StepGraph:
         return self.loss
 
 
-def capture_step_graphs(model, lossf, opt, dp, pool, stream, reps=None):
+def capture_step_graphs(model, lossf, opt, dp, pool, stream, reps=None, capture_mode=None):
     """One StepGraph per window of `pool` (the warm-up must have run eagerly on `stream` with
     model.use_static_states(True)).  The recurrent state crosses replays without a copy: graph 0 starts from the
     buffers the warm-up left, graph k from the tensors graph k-1's last pass wrote (fixed addresses in its capture
@@ -234,7 +234,7 @@ def capture_step_graphs(model, lossf, opt, dp, pool, stream, reps=None):
         if gi == len(pool) - 1:
             for m, h in zip(models, home):
                 m.final_states_into(h)
-        graphs.append(StepGraph(model, lossf, opt, dp, lists, stream, reps))
+        graphs.append(StepGraph(model, lossf, opt, dp, lists, stream, reps, capture_mode))
         graphs[-1].left = model.state_buffers() if reps is None else [m.state_buffers() for m in models]
     return graphs
 
@@ -608,7 +608,7 @@ def main_c4(args):
             loss = train_window(model, lossf, opt, pool[i % 2])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    names = ["evf_conv2d_fwd", "evf_conv2d_dgrad", "evf_conv2d_fwd_b3", "evf_conv2d_dgrad_b3", "evf_conv2d_wgrad", "evf_neuron_fwd", "evf_neuron_bwd", "evf_upsample2x_fwd",
+    names = ["evf_conv2d_fwd", "evf_conv2d_dgrad", "evf_conv2d_fwd_b3", "evf_conv2d_fwd_b3_parts", "evf_lif_fwd_parts", "evf_conv2d_dgrad_b3", "evf_conv2d_wgrad", "evf_neuron_fwd", "evf_neuron_bwd", "evf_upsample2x_fwd",
              "evf_upsample2x_bwd", "evf_upsample_nearest_fwd", "evf_upsample_nearest_bwd", "evf_cm_loss_fwd", "evf_cm_loss_bwd",
              "evf_clip_adam_step", "evf_pack_conv2d_weight", "evf_pack_conv2d_weight_b3", "evf_pack_conv2d_weights_b3_multi", "evf_encode_events"]
     prof_steps = 2
@@ -618,6 +618,8 @@ def main_c4(args):
     prof = _lib.profile_stop()
     kernels = {}
     for (name, var), ms in prof.items():
+        if name == "evf_conv2d_fwd_b3_parts":  # the same product, its K-split partial sums left to the neuron kernel
+            name = "evf_conv2d_fwd_b3"
         ent = kernels.setdefault(name, {"launches": 0, "total_ms_per_step": 0.0, "flop_per_step": 0.0, "bytes_per_step": 0.0})
         ent["launches"] += len(ms) // prof_steps
         ent["total_ms_per_step"] += float(np.sum(ms)) / prof_steps
@@ -684,8 +686,10 @@ def main():
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="matrix-core path of the 32->32 convs: exact bf16x3 split (default) or fp32 MFMA")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--profile-capture-mode", choices=["global", "thread_local", "relaxed"], default="thread_local",
+                    help="stream-capture mode of the instrumented capture (timestamp-kernel nodes)")
     ap.add_argument("--no-graph-profile", action="store_true",
-                    help="skip the second, instrumented capture (external event nodes around the diagonal launches) the per-kernel "
+                    help="skip the second, instrumented capture (timestamp kernels around the diagonal launches) the per-kernel "
                          "durations of the replayed step come from; kernels[*] then carry the eager HIP-event figures only")
     ap.add_argument("--streams", type=int, default=1,
                     help="micro-batch pipelining (train.StreamReplicas): the per-GPU batch as this many slices on their own HIP "
@@ -832,7 +836,7 @@ def main():
         reduce_ms = dp.reduce_times_ms()[2:]
         dp.time_reduces(False)
     # the diagonal / head-window launches AS THEY RUN INSIDE A REPLAYED STEP: a second, instrumented capture of the same step
-    # graphs whose flushes bracket every dispatcher launch with external event-record nodes (evf_defer_profile(2)); replayed after
+    # graphs whose flushes bracket every dispatcher launch with timestamp-kernel nodes (evf_defer_profile(2)); replayed after
     # the timed region, read once.  The timed graphs above carry no such nodes.
     gprof = None
     if graphs is not None and not args.no_graph_profile:
@@ -842,7 +846,7 @@ def main():
             L = _lib.load()
             L.evf_defer_profile(2)
             try:
-                graphs_p = capture_step_graphs(model, lossf, opt, dp, pool, side, reps)
+                graphs_p = capture_step_graphs(model, lossf, opt, dp, pool, side, reps, capture_mode=args.profile_capture_mode)
             finally:
                 L.evf_defer_profile(0)
             torch.cuda.synchronize()
@@ -984,7 +988,7 @@ def main():
             name = "/".join(k for k in key if k)
             ent = {"launches": int(ms.size), "mean_us": float(ms.mean() * 1e3), "total_ms_per_step": float(ms.sum() / prof_steps)}
             if key in prof_eager:
-                ent["timing"] = "inside the replayed hipGraph (external event nodes of an instrumented capture, empty bracket removed)"
+                ent["timing"] = "inside the replayed hipGraph (timestamp kernels of an instrumented capture, empty bracket removed)"
                 ent["mean_us_eager"] = prof_eager[key] * 1e3
             if key in model:
                 fl, by = model[key]
@@ -1088,7 +1092,7 @@ def main():
             "step_hbm_frac": step_alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK,
             "kernels": kernels,
             "kernel_timing": {"method": "diagonal / head-window launches: HIP events captured into an instrumented copy of the step graphs "
-                                        "(external event-record nodes), read after its replays, minus the empty bracket of the same graph; "
+                                        "(timestamp-kernel nodes), read after its replays, minus the empty bracket of the same graph; "
                                         "every other entry: HIP events around each launch on its stream over eager steps, minus the bracket "
                                         "overhead o = 2 T(1 tiny kernel) - T(2 tiny kernels) calibrated in the same run",
                               "bracket_overhead_us": round(event_overhead_us, 2),

@@ -126,6 +126,8 @@ NETWORK_SIGNATURES = {
     "evf_conv2d_wgrad_ws": [I, I, I, I, I, I, I],
     "evf_conv2d_wgrad": [P, I, P, I, P, P, I, I, I, I, I, I, I, I, I, I, P, P],
     "evf_neuron_fwd": [I, P, P, P, P, P, P, P, P, P, P, L, I, I, P, P, P, P, P],
+    "evf_conv2d_fwd_b3_parts": [P, I, P, P, I, I, I, I, I, I, I, I, I, P, L, P, P],
+    "evf_lif_fwd_parts": [P, I, L, P, I, L, P, P, P, P, P, L, I, I, P, P, P, P],
     "evf_neuron_bwd": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P],
     "evf_pretrace_fwd": [P, I, I, I, I, I, I, I, P, P, P],
     "evf_pretrace_bwd": [P, I, P, I, I, I, I, I, I, P, I, I, P],
@@ -217,6 +219,7 @@ _PROF_VARIANT = {
     "evf_conv2d_fwd": lambda a: ",".join(str(int(v)) for v in a[6:13]),
     "evf_conv2d_dgrad": lambda a: ",".join(str(int(v)) for v in a[5:12]),
     "evf_conv2d_fwd_b3": lambda a: ",".join(str(int(v)) for v in a[6:13]),
+    "evf_conv2d_fwd_b3_parts": lambda a: ",".join(str(int(v)) for v in a[5:12]),
     "evf_conv2d_dgrad_b3": lambda a: ",".join(str(int(v)) for v in a[5:12]),
     "evf_conv2d_wgrad": lambda a: ",".join(str(int(v)) for v in a[6:13]),
 }

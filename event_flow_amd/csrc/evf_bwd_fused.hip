@@ -20,6 +20,8 @@
 // Tap per wave (8 waves own taps 0..7 over all pixels of the block, the ninth
 // tap is shared round-robin) -> no atomics, one slab [9][32][32] per block and
 // input, accumulated over the passes of a window.
+#include <stdio.h>
+
 #include "evf_common.h"
 #include "evf_split.h"
 #include <stdlib.h>
@@ -1241,22 +1243,29 @@ void evf_ctx_drop(int ctx) {
 }
 
 #define EVF_PROF_MAX 1024
+#define EVF_PROF_STAMPS 256  // brackets of a captured step (mode 2)
 static struct {
-  int mode;  // 0 off, 1 eager brackets, 2 brackets recorded into a stream capture as EXTERNAL event nodes (read after replays)
+  int mode;  // 0 off, 1 eager brackets (HIP events), 2 brackets CAPTURED into a hipGraph as timestamp kernels (read after replays)
   int n;
   int kind[EVF_PROF_MAX];
   hipEvent_t e0[EVF_PROF_MAX], e1[EVF_PROF_MAX];
   int made;
-} evf_prof = {0, 0, {0}, {}, {}, 0};
-static void evf_prof_record(hipEvent_t e, hipStream_t st) {
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (evf_prof.mode == 2 && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive)
-    (void)hipEventRecordWithFlags(e, st, hipEventRecordExternal);  // an event-record NODE: every replay stamps the event anew
-  else
-    (void)hipEventRecord(e, st);
-}
+  unsigned long long* stamps;  // device [EVF_PROF_STAMPS][2]: wall-clock reading before / after the bracketed launch
+  bool stamped;                // the recorded brackets are timestamp pairs
+} evf_prof = {0, 0, {0}, {}, {}, 0, nullptr, false};
+// One thread reads the constant-rate wall clock (s_memrealtime; hipDeviceAttributeWallClockRate kHz).  As ordinary kernel
+// nodes these are what a capture can carry on every runtime (external event-record nodes inside torch's captures were refused
+// with hipErrorInvalidValue on ROCm 7.2); each replay overwrites the stamps.
+__global__ void k_prof_stamp(unsigned long long* dst) { *dst = wall_clock64(); }
 void evf_prof_mark(int kind, int end, void* stream) {
   if (!evf_prof.mode || (!end && evf_prof.n >= EVF_PROF_MAX)) return;
+  if (evf_prof.mode == 2) {
+    if (!evf_prof.stamps || evf_prof.n >= EVF_PROF_STAMPS) return;
+    if (!end) evf_prof.kind[evf_prof.n] = kind;
+    hipLaunchKernelGGL(k_prof_stamp, dim3(1), dim3(1), 0, EVF_STREAM(stream), evf_prof.stamps + 2 * evf_prof.n + (end ? 1 : 0));
+    if (end) ++evf_prof.n;
+    return;
+  }
   if (!end) {
     if (evf_prof.n >= evf_prof.made) {
       (void)hipEventCreate(&evf_prof.e0[evf_prof.made]);
@@ -1264,9 +1273,9 @@ void evf_prof_mark(int kind, int end, void* stream) {
       ++evf_prof.made;
     }
     evf_prof.kind[evf_prof.n] = kind;
-    evf_prof_record(evf_prof.e0[evf_prof.n], EVF_STREAM(stream));
+    (void)hipEventRecord(evf_prof.e0[evf_prof.n], EVF_STREAM(stream));
   } else if (evf_prof.n < EVF_PROF_MAX) {
-    evf_prof_record(evf_prof.e1[evf_prof.n], EVF_STREAM(stream));
+    (void)hipEventRecord(evf_prof.e1[evf_prof.n], EVF_STREAM(stream));
     ++evf_prof.n;
   }
 }
@@ -1274,10 +1283,11 @@ void evf_prof_mark(int kind, int end, void* stream) {
 // ms[k] = summed duration and count[k] = number of launches of kind k < 8 (0 k_fwd_diag, 1 k_bwd_diag, 2 k_dgrad_diag, 3 head
 // backward pass by pass, 4 k_head_lif_fwd_win, 5 k_head_bwd_win, 7 an EMPTY bracket = the bracket's own cost) since it was
 // switched on (event-bracket overhead included: ~1.6 us per launch); switches it off.
-// evf_defer_profile(2): the same brackets while the step is CAPTURED into a hipGraph -- external event-record nodes around the
-// dispatcher launches (and one empty bracket per forward flush, kind 7); evf_defer_profile(0) after the capture stops the
-// recording and KEEPS the brackets, the graph is replayed, and evf_defer_profile_read returns the durations of the LAST replay:
-// the kernels as they run back to back inside the replayed step (clocks, caches), not as eager launches.
+// evf_defer_profile(2): the same brackets while the step is CAPTURED into a hipGraph -- a one-thread timestamp kernel in front
+// of and behind every dispatcher launch (and one empty bracket per forward flush, kind 7); evf_defer_profile(0) after the
+// capture stops the recording and KEEPS the brackets, the graph is replayed, and evf_defer_profile_read returns the durations
+// of the LAST replay: the kernels as they run back to back inside the replayed step (clocks, caches), not as eager launches.
+// A bracket there = the launch + one inter-kernel gap + the empty bracket (kind 7).
 extern "C" int evf_defer_profile(int on) {
   if (on == 0) {  // stop; what is recorded stays readable (mode 2: after the replays)
     evf_prof.mode = 0;
@@ -1285,6 +1295,14 @@ extern "C" int evf_defer_profile(int on) {
   }
   evf_prof.mode = on == 2 ? 2 : 1;
   evf_prof.n = 0;
+  evf_prof.stamped = on == 2;
+  if (on == 2 && !evf_prof.stamps) {  // (nothing may be allocated once the capture is open)
+    const int rc = evf_hip(hipMalloc((void**)&evf_prof.stamps, sizeof(unsigned long long) * 2 * EVF_PROF_STAMPS));
+    if (rc) {
+      evf_prof.stamps = nullptr, evf_prof.mode = 0;
+      return rc;
+    }
+  }
   return EVF_OK;
 }
 extern "C" int evf_defer_profile_read(float* ms, int* count) {
@@ -1292,9 +1310,30 @@ extern "C" int evf_defer_profile_read(float* ms, int* count) {
   evf_prof.mode = 0;
   { const int rc = evf_hip(hipDeviceSynchronize()); if (rc) return rc; }
   for (int k = 0; k < 8; ++k) ms[k] = 0.f, count[k] = 0;
+  if (evf_prof.stamped) {
+    static unsigned long long host[2 * EVF_PROF_STAMPS];
+    int dev = 0, khz = 0;
+    if (evf_prof.n > 0) {
+      const int rc = evf_hip(hipMemcpy(host, evf_prof.stamps, sizeof(unsigned long long) * 2 * evf_prof.n, hipMemcpyDeviceToHost));
+      if (rc) return rc;
+    }
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+      khz = 100000;  // 100 MHz
+    for (int i = 0; i < evf_prof.n; ++i) {
+      ms[evf_prof.kind[i] & 7] += (float)((double)(host[2 * i + 1] - host[2 * i]) / (double)khz);
+      ++count[evf_prof.kind[i] & 7];
+    }
+    evf_prof.n = 0, evf_prof.stamped = false;
+    return EVF_OK;
+  }
   for (int i = 0; i < evf_prof.n; ++i) {
     float t = 0.f;
-    { const int rc = evf_hip(hipEventElapsedTime(&t, evf_prof.e0[i], evf_prof.e1[i])); if (rc) return rc; }
+    const int rc = evf_hip(hipEventElapsedTime(&t, evf_prof.e0[i], evf_prof.e1[i]));
+    if (rc) {
+      (void)hipGetLastError();  // (a failed measurement must not poison the next launch's status)
+      evf_prof.n = 0;
+      return rc;
+    }
     ms[evf_prof.kind[i] & 7] += t;
     ++count[evf_prof.kind[i] & 7];
   }

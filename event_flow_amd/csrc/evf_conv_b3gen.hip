@@ -535,11 +535,36 @@ extern "C" int evf_conv_split_select(int n) {  // n > 0: force n K splits wherev
 
 // ws: caller's scratch of ws_floats floats (may be null): split-K slabs of the layers whose output tiles alone cannot
 // fill the chip (low-resolution, many-channel layers at small batch)
+// parts (may be null): the caller takes the K split's partial sums itself -- when the plan splits, ws [nparts][M][N] is left
+// unreduced and *parts = the number of slabs (bias / accumulate must be off); *parts = 0: the result is in `out`
 static int b3_launch(const float* src, const void* wp, const float* bias, float* out, const ConvGeo& g, int accumulate,
-                     float* ws, long ws_floats, void* stream) {
+                     float* ws, long ws_floats, void* stream, int* parts = nullptr) {
   hipStream_t st = EVF_STREAM(stream);
+  if (parts) *parts = 0;
+  // bit 2: the source is exactly representable in bf16 BY CONSTRUCTION (hip_ops.spike_tag) from channel (flags >> 4) & 31 on
+  const bool exact = (accumulate & 4) != 0;
+  const int exact_from = (accumulate >> 4) & 31;
+  accumulate &= 1;
   const long M = (long)g.B * g.OH * g.OW;
   const long cap = (ws && (g.N & 3) == 0 && (((uintptr_t)ws) & 15) == 0) ? ws_floats / (M * g.N) : 0;  // slabs that fit
+  // spike-valued input: the single-plane kernel of evf_conv_b3small.hip (EVF_CONV_SMALL=0: off)
+  static const bool small_ok = !(getenv("EVF_CONV_SMALL") && getenv("EVF_CONV_SMALL")[0] == '0');
+  if (exact && small_ok && g.ksz == 3 && g.stride == 1 && g.mode == 0 && b3_split_force() == 0 && b3_tile_mode() != 0) {
+    const int ks = evf_conv3_b3x_plan(src, g.B, g.OH, g.OW, g.K, g.N, g.lds, exact_from, cap);
+    if (ks == 1 && !bias && !accumulate)  // raw sums = the result
+      return evf_conv3_b3x_launch(src, g.lds, wp, out, g.ldo, g.B, g.OH, g.OW, g.K, g.N, exact_from, cap, st);
+    if (ks >= 1 && cap >= ks) {
+      const int rc = evf_conv3_b3x_launch(src, g.lds, wp, ws, g.N, g.B, g.OH, g.OW, g.K, g.N, exact_from, cap, st);
+      if (rc != EVF_OK) return rc;
+      if (parts) {
+        *parts = ks;
+        return EVF_OK;
+      }
+      hipLaunchKernelGGL(k_b3_reduce, dim3(evf_cdiv(M * (g.N >> 2), 256)), dim3(256), 0, st, ws, ks, M, g.N, bias, out, g.ldo,
+                         accumulate);
+      return evf_status();
+    }
+  }
   // wide high-resolution 3x3 stride-1 layers: the spatially tiled kernel (evf_conv_b3tile.hip); EVF_CONV_TILE=0 disables
   if (g.ksz == 3 && g.stride == 1 && b3_tile_mode() != 0) {
     const int ks = evf_conv3_b3t_plan(src, g.B, g.OH, g.OW, g.K, g.N, g.lds, b3_tile_mode() == 2, (int)min(cap, 8L),
@@ -549,6 +574,10 @@ static int b3_launch(const float* src, const void* wp, const float* bias, float*
     if (ks > 1) {
       const int rc = evf_conv3_b3t_launch(src, g.lds, wp, nullptr, ws, g.N, g.B, g.OH, g.OW, g.K, g.N, g.mode, 0, ks, st);
       if (rc != EVF_OK) return rc;
+      if (parts) {
+        *parts = ks;
+        return EVF_OK;
+      }
       hipLaunchKernelGGL(k_b3_reduce, dim3(evf_cdiv(M * (g.N >> 2), 256)), dim3(256), 0, st, ws, ks, M, g.N, bias, out, g.ldo,
                          accumulate);
       return evf_status();
@@ -575,6 +604,10 @@ static int b3_launch(const float* src, const void* wp, const float* bias, float*
     const int rc = two ? b3_launch_vec<2, false>(src, wp, nullptr, ws, g2, 0, st, nsplit)
                        : b3_launch_vec<1, false>(src, wp, nullptr, ws, g2, 0, st, nsplit);
     if (rc != EVF_OK) return rc;
+    if (parts) {
+      *parts = nsplit;
+      return EVF_OK;
+    }
     hipLaunchKernelGGL(k_b3_reduce, dim3(evf_cdiv(M * (g.N >> 2), 256)), dim3(256), 0, st, ws, nsplit, M, g.N, bias, out,
                        g.ldo, accumulate);
     return evf_status();
@@ -606,6 +639,21 @@ extern "C" int evf_conv2d_fwd_b3(const float* x, int ldx, const void* w_packed, 
   g.OH = b3_out_dim(H, ksz, stride), g.OW = b3_out_dim(W, ksz, stride), g.N = Cout;
   g.ksz = ksz, g.stride = stride, g.mode = 0, g.lds = ldx, g.ldo = ldy;
   return b3_launch(x, w_packed, bias, y, g, accumulate, ws, ws_floats, stream);
+}
+
+// The same product with the K split's partial sums LEFT IN PARTS for a consumer that adds them itself (evf_lif_fwd_parts): no
+// bias, no accumulation; flags bit 2 = exact input as above.  *nparts = 0: y holds the result; n > 0: ws holds n slabs [B*Ho*Wo][Cout].
+extern "C" int evf_conv2d_fwd_b3_parts(const float* x, int ldx, const void* w_packed, float* y, int ldy, int B, int H, int W, int Cin,
+                                       int Cout, int ksz, int stride, int flags, float* ws, int64_t ws_floats, int* nparts,
+                                       void* stream) {
+  if (!x || !w_packed || !y || !nparts || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !EVF_KSZ_OK(ksz) ||
+      (stride != 1 && stride != 2) || ldx < Cin || ldy < Cout)
+    return EVF_EINVAL;
+  ConvGeo g;
+  g.B = B, g.SH = H, g.SW = W, g.K = Cin;
+  g.OH = b3_out_dim(H, ksz, stride), g.OW = b3_out_dim(W, ksz, stride), g.N = Cout;
+  g.ksz = ksz, g.stride = stride, g.mode = 0, g.lds = ldx, g.ldo = ldy;
+  return b3_launch(x, w_packed, nullptr, y, g, flags & (4 | (31 << 4)), ws, ws_floats, stream, nparts);
 }
 
 // g_x [B,H,W,Cin] (+)= conv^T(g_y [B,Ho,Wo,Cout]); wT_packed from evf_pack_conv2d_weight_b3(transpose = 1).

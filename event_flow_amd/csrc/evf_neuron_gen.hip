@@ -112,6 +112,81 @@ __global__ void k_neuron_fwd(const float4* __restrict__ cur, const float4* __res
 // blockDim is a multiple of Q = C/4 so that a thread keeps its channel quad over the grid-stride loop
 static int ng_block(int Q) { return Q >= 256 ? 256 : (256 / Q) * Q; }
 
+// LIF update on a current that arrives IN PARTS: cur = sum_z a[z] (+ sum_z b[z]) -- the K-split partial sums of the feed-forward
+// conv (and of the recurrent conv) as the conv kernels left them in scratch, added here in index order instead of by a
+// k_b3_reduce launch per conv that writes `cur` only for this kernel to read it back (LIF-EV-FlowNet step: 13 + 7 launches).
+// na / nb = 1 with the plain tensor when a conv did not split; b null = no recurrent part.
+template <bool PREV, bool RES>
+__global__ void k_lif_fwd_parts(const float4* __restrict__ a, int na, long sa, const float4* __restrict__ b, int nb, long sb,
+                                const float4* __restrict__ v_prev, const float4* __restrict__ z_prev,
+                                const float4* __restrict__ residual, const float* __restrict__ leak, const float* __restrict__ thresh,
+                                long npix, int C, int hard, float4* __restrict__ v_out, float4* __restrict__ z_out,
+                                float4* __restrict__ out) {
+  const int Q = C >> 2;
+  const long total = npix * Q, stride = (long)gridDim.x * blockDim.x;
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int cq = (int)(e % Q);
+  float lam[4], th[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) lam[k] = ng_sigmoid(leak[4 * cq + k]), th[k] = fmaxf(thresh[4 * cq + k], 0.01f);
+  for (; e < total; e += stride) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v4 = PREV ? ng_ld(v_prev, a, e) : zero4, z4 = PREV ? ng_ld(z_prev, a, e) : zero4, r4 = RES ? residual[e] : zero4;
+    float4 c4 = a[e];
+#pragma unroll 4
+    for (int z = 1; z < na; ++z) {
+      const float4 t = a[(long)z * sa + e];
+      c4.x += t.x, c4.y += t.y, c4.z += t.z, c4.w += t.w;
+    }
+    if (b) {  // (uniform)
+      float4 d4 = b[e];
+#pragma unroll 4
+      for (int z = 1; z < nb; ++z) {
+        const float4 t = b[(long)z * sb + e];
+        d4.x += t.x, d4.y += t.y, d4.z += t.z, d4.w += t.w;
+      }
+      c4.x = d4.x + c4.x, c4.y = d4.y + c4.y, c4.z = d4.z + c4.z, c4.w = d4.w + c4.w;  // (rec sum) + ff, as the accumulating conv adds
+    }
+    const float cu[4] = {c4.x, c4.y, c4.z, c4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w}, z[4] = {z4.x, z4.y, z4.z, z4.w};
+    float vo[4], zo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (hard)
+        vo[k] = v[k] * lam[k] * (1.0f - z[k]) + (1.0f - lam[k]) * cu[k];
+      else
+        vo[k] = v[k] * lam[k] + (1.0f - lam[k]) * cu[k] - z[k] * th[k];
+      zo[k] = (vo[k] - th[k]) > 0.f ? 1.0f : 0.f;
+    }
+    v_out[e] = make_float4(vo[0], vo[1], vo[2], vo[3]);
+    z_out[e] = make_float4(zo[0], zo[1], zo[2], zo[3]);
+    if (out) out[e] = make_float4(zo[0] + r4.x, zo[1] + r4.y, zo[2] + r4.z, zo[3] + r4.w);
+  }
+}
+
+extern "C" int evf_lif_fwd_parts(const float* a, int na, int64_t a_stride, const float* b, int nb, int64_t b_stride,
+                                 const float* v_prev, const float* z_prev, const float* residual, const float* leak,
+                                 const float* thresh, int64_t npix, int C, int hard_reset, float* v_out, float* z_out, float* out,
+                                 void* stream) {
+  if (!a || na < 1 || (b && nb < 1) || !leak || !thresh || !v_out || !z_out || npix <= 0 || C <= 0 || (C & 3) || C > 1024 ||
+      (a_stride & 3) || (b_stride & 3) || (((uintptr_t)a | (uintptr_t)b) & 15))
+    return EVF_EINVAL;
+  const int Q = C >> 2, bs = ng_block(Q);
+  const long total = npix * Q;
+  const int nblk = (int)((total + bs - 1) / bs < 4096 ? (total + bs - 1) / bs : 4096);
+  const bool prev = v_prev || z_prev, res = residual != nullptr;
+#define LP_GO(P_, R_)                                                                                                          \
+  hipLaunchKernelGGL((k_lif_fwd_parts<P_, R_>), dim3(nblk), dim3(bs), 0, EVF_STREAM(stream), (const float4*)a, na, (long)(a_stride >> 2), \
+                     (const float4*)b, nb, (long)(b_stride >> 2), (const float4*)v_prev, (const float4*)z_prev,                  \
+                     (const float4*)residual, leak, thresh, (long)npix, C, hard_reset, (float4*)v_out, (float4*)z_out, (float4*)out)
+  if (prev && res) LP_GO(true, true);
+  else if (prev) LP_GO(true, false);
+  else if (res) LP_GO(false, true);
+  else LP_GO(false, false);
+#undef LP_GO
+  return evf_status();
+}
+
 extern "C" int evf_neuron_fwd(int kind, const float* cur, const float* v_prev, const float* z_prev, const float* aux_prev,
                               const float* P, const float* residual, const float* p0, const float* p1, const float* p2,
                               const float* p3, int64_t npix, int C, int hard_reset, float* v_out, float* z_out,
@@ -279,7 +354,30 @@ __global__ void k_neuron_bwd(const float4* __restrict__ g_v_out, const float4* _
       }
     }
   }
-  if (Q >= 64 || (int)(threadIdx.x & 63) < Q) {
+  if (Q >= 64) {
+    // blockDim / Q threads own a channel quad (threads t, t + Q, ...): they add in turns with plain LDS read-modify-writes --
+    // ds_add_f32 is ~5x slower than an integer LDS atomic on gfx950, and 2048 of them per block were the fixed cost of this
+    // kernel on the many-channel layers (14 us of a 22 us launch)
+    const int turns = (int)blockDim.x / Q, mine = (int)threadIdx.x / Q;
+    for (int t = 0; t < turns; ++t) {
+      if (t == mine) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = 4 * cq + k;
+          s_acc[0 * C + c] += s0[k] * lam[k] * (1.0f - lam[k]);
+          s_acc[1 * C + c] += s1[k] * m1[k];
+          if (KIND == EVF_PLIF) {
+            s_acc[2 * C + c] += s2[k] * a2[k] * (1.0f - a2[k]);
+            s_acc[3 * C + c] += s3[k] * a3[k] * (1.0f - a3[k]);
+          } else if (KIND != EVF_LIF) {
+            s_acc[2 * C + c] += s2[k] * m2[k];
+            s_acc[3 * C + c] += s3[k] * a3[k] * (1.0f - a3[k]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  } else if ((int)(threadIdx.x & 63) < Q) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int c = 4 * cq + k;
@@ -304,26 +402,43 @@ __global__ void k_neuron_bwd(const float4* __restrict__ g_v_out, const float4* _
     return;
   }
   // Same-address atomics serialise at the memory side (1024 blocks on 128 words: +20..30 us per launch): the blocks are
-  // spread over NG_REP replicas in scratch; k_ng_finish (next launch) sums the replicas into the outputs and hands the
+  // spread over NG_REP replicas in scratch; the last block (below) sums the replicas into the outputs and hands the
   // scratch back zeroed.  ws: [NG_REP][4 * 1024] floats, zero on entry and on exit.
   float* mine = ws + (size_t)(blockIdx.x % NG_REP) * 4096;
   for (int i = threadIdx.x; i < np * C; i += blockDim.x) evf_atomic_add(mine + i, s_acc[i]);
-}
-
-__global__ void k_ng_finish(float* __restrict__ ws, int nrep, int n, int C, NgParams prm) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float v[NG_REP];
-#pragma unroll
-  for (int r = 0; r < NG_REP; ++r) v[r] = r < nrep ? ws[(size_t)r * 4096 + i] : 0.f;
-  float t = 0.f;
-#pragma unroll
-  for (int r = 0; r < NG_REP; ++r) {
-    t += v[r];
-    if (r < nrep) ws[(size_t)r * 4096 + i] = 0.f;
+  // ... the block that draws the LAST ticket (word NG_REP * 4096 of the scratch) does what k_ng_finish did as a launch of its own:
+  // replicas -> outputs, scratch and ticket handed back zeroed (17 launches of ~4 us + their boundaries per EV-FlowNet step)
+  __shared__ int s_fin;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (each thread: its atomics are out; one agent-scope fence per block below)
+  __syncthreads();
+  int* ticket = (int*)(ws + (size_t)NG_REP * 4096);
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const int t = atomicAdd(ticket, 1);
+    s_fin = t + 1 == (int)gridDim.x;
+    if (s_fin) {
+      *ticket = 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
   }
-  const int p = i / C, c = i - p * C;
-  if (prm.g[p]) prm.g[p][c] += t;
+  __syncthreads();
+  if (!s_fin) return;
+  const int nrep = (int)gridDim.x < NG_REP ? (int)gridDim.x : NG_REP;
+  for (int i = threadIdx.x; i < np * C; i += blockDim.x) {
+    float v[NG_REP];
+#pragma unroll
+    for (int r = 0; r < NG_REP; ++r) v[r] = __builtin_nontemporal_load(ws + (size_t)(r < nrep ? r : 0) * 4096 + i);
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < NG_REP; ++r) {
+      if (r < nrep) {
+        t += v[r];
+        ws[(size_t)r * 4096 + i] = 0.f;
+      }
+    }
+    const int p = i / C, c = i - p * C;
+    if (prm.g[p]) prm.g[p][c] += t;
+  }
 }
 
 extern "C" int evf_neuron_bwd(int kind, const float* g_v_out, const float* g_z_out, const float* g_z_out2,
@@ -348,7 +463,13 @@ extern "C" int evf_neuron_bwd(int kind, const float* g_v_out, const float* g_z_o
   NgParams prm = {{p0, p1, p2, p3}, {g_p0, g_p1, g_p2, g_p3}};
   const int bs = ng_block(Q);
   const long total = npix * Q;
-  const int nblk = (int)((total + bs - 1) / bs < 1024 ? (total + bs - 1) / bs : 1024);
+  // at least ~4 float4 per thread before a block pays its per-channel reduction (LDS float atomics + np * C global atomics): the
+  // 512-channel 16 x 16 layers ran ONE float4 per thread in 1024 blocks -- 1 M global atomics for 1 M elements, 22 us per launch
+  long want = (total + (long)bs * 4 - 1) / ((long)bs * 4);
+  if (want < 64) want = (total + bs - 1) / bs < 64 ? (total + bs - 1) / bs : 64;
+  const int nblk = (int)(want < 1024 ? want : 1024);
+  // few blocks: straight into the outputs (<= 256 adds per address); many: NG_REP replicas + the last block's finish
+  if (nblk <= 256) ws = nullptr;
   const size_t smem = sizeof(float) * 4 * (size_t)C;
   const bool gst = g_v_out || g_z_out2 || g_aux_out, prev = v_prev || z_prev || aux_prev;
 #define NG_BWD_(K, G_, P_)                                                                                                 \
@@ -371,10 +492,6 @@ extern "C" int evf_neuron_bwd(int kind, const float* g_v_out, const float* g_z_o
   }
 #undef NG_BWD
 #undef NG_BWD_
-  if (ws) {
-    const int np = kind == EVF_LIF ? 2 : 4, n = np * C;
-    hipLaunchKernelGGL(k_ng_finish, dim3(evf_cdiv(n, 64)), dim3(64), 0, st, ws, nblk < NG_REP ? nblk : NG_REP, n, C, prm);
-  }
   return evf_status();
 }
 

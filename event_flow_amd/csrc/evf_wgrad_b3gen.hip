@@ -36,10 +36,25 @@ struct WgB3Geo {
 
 __device__ __forceinline__ int wb_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// Fused slab reduction (WgFuse.ticket != null; the caller guarantees an x that is exactly representable in bf16, so no fp32
+// pass follows): the block that finishes LAST among the pixel splits of its weight tile -- one arrival ticket per tile, after a
+// device-scope release of its slab -- sums the tile's partial sums over the splits in INDEX order (a fixed order: the same
+// bits whatever the arrival order) and writes the torch layout [co][ci][tap] itself, tap by tap through an LDS transpose (slab
+// reads coalesced along co, gradient writes running along ci).  k_wgrad_reduce's launch, its ~5 us boundary and the second HBM
+// round trip of the slabs are gone.  MEASURED AND NOT THE DEFAULT (EVF_WGRAD_FUSE=1): the blocks of a launch finish together, so
+// the last blocks' chains run exposed at the end of the kernel -- +47 us per call over the 25 us reduce launch they replace
+// (evf_wgrad_gen.hip has the numbers).  An x that does break the promise is not silently rounded: NaN.
+struct WgFuse {
+  float* gw;     // [Cout][cin_total][3][3]
+  int* ticket;   // one per weight tile (zero on entry, handed back zero)
+  int cin_total, cin_off, accumulate;
+  int promised;  // the caller promised an exact x (with or without the fused reduction): a violation poisons the block's slab
+};
+
 template <int CT, int NT>
 __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, const float* __restrict__ gy,
                                                    float* __restrict__ slab, float* __restrict__ gbias, int* __restrict__ redo,
-                                                   WgB3Geo g) {
+                                                   WgB3Geo g, WgFuse fz) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int XQ = 8 * CT, GQ = 8 * NT;                 // float4 per pixel
   constexpr int NLX = (WB_HP * XQ + 575) / 576;           // x float4 loads per thread
@@ -178,6 +193,9 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
     __syncthreads();
   }
 
+  // an x the caller promised to be exact and that is not: this block's partial sums become NaN (whoever reduces them propagates it)
+  const int blk_inexact = __syncthreads_or(inexact);
+  const float poison = (fz.promised && blk_inexact) ? __builtin_nanf("") : 0.f;
   // epilogue: slab[split][tap][ci][co] (co fastest); wave = tap
   float* sl = slab + (long)blockIdx.x * 9 * g.Cin * g.Cout;
 #pragma unroll
@@ -188,10 +206,10 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = ci0 + c * 32 + wb_row(r, lane);
-        if (ci < g.Cin && co < g.Cout) sl[((long)wv * g.Cin + ci) * g.Cout + co] = acc[c][t][r];
+        if (ci < g.Cin && co < g.Cout) sl[((long)wv * g.Cin + ci) * g.Cout + co] = acc[c][t][r] + poison;
       }
     }
-  if (__syncthreads_or(inexact) && tid == 0) atomicOr(redo + cit, 1);
+  if (blk_inexact && tid == 0 && !fz.promised) atomicOr(redo + cit, 1);
   if (do_bias) {
     const int q = tid % GQ;
 #pragma unroll
@@ -199,18 +217,75 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
     __syncthreads();
     if (tid < 32 * NT && co0 + tid < g.Cout) evf_atomic_add(gbias + co0 + tid, s_b[tid]);
   }
+  if (!fz.ticket) return;
+  // ---- fused reduction: last block of the tile
+  __shared__ int s_last;
+  // release: every thread waits for ITS slab stores (workgroup scope: a wait, no cache maintenance), the barrier collects them, and
+  // ONE thread makes the block's stores visible device-wide (the agent-scope fence writes the XCD's L2 back: as 576 per-thread
+  // fences it cost ~170 us per launch) before it draws the ticket
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const int t = atomicAdd(fz.ticket + blockIdx.y, 1 + (blk_inexact ? 0x10000 : 0));
+    const bool last = (t & 0xFFFF) + 1 == (int)gridDim.x;
+    s_last = last ? (1 | (((t >> 16) != 0 || blk_inexact) ? 2 : 0)) : 0;
+    if (last) {
+      fz.ticket[blockIdx.y] = 0;  // (calls are stream-ordered: the next one finds its tickets at zero)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // acquire: the other splits' slabs (invalidates this CU's L1 / stale L2 lines)
+    }
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const bool tile_bad = (s_last & 2) != 0;
+  float* tile = (float*)smem;  // [32 CT][32 NT + 1]
+  constexpr int NE = 32 * CT * 32 * NT, NJ = (NE + 575) / 576, TP = 32 * NT + 1;
+  const long per = (long)9 * g.Cin * g.Cout;
+  const int nsplit = (int)gridDim.x;
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int idx = tid + 576 * j, co_l = idx % (32 * NT), ci_l = idx / (32 * NT);
+      const int ci = ci0 + ci_l, co = co0 + co_l;
+      const bool ok = idx < NE && ci < g.Cin && co < g.Cout;
+      const float* __restrict__ p = slab + ((long)tap * g.Cin + (ok ? ci : 0)) * g.Cout + (ok ? co : 0);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int k = 0;
+      for (; k + 3 < nsplit; k += 4) {  // four independent loads in flight; the association is fixed
+        a0 += p[(long)k * per];
+        a1 += p[(long)(k + 1) * per];
+        a2 += p[(long)(k + 2) * per];
+        a3 += p[(long)(k + 3) * per];
+      }
+      for (; k < nsplit; ++k) a0 += p[(long)k * per];
+      if (idx < NE) tile[ci_l * TP + co_l] = ok ? (a0 + a1) + (a2 + a3) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int idx = tid + 576 * j, ci_l = idx % (32 * CT), co_l = idx / (32 * CT);
+      const int ci = ci0 + ci_l, co = co0 + co_l;
+      if (idx < NE && ci < g.Cin && co < g.Cout && fz.cin_off + ci < fz.cin_total) {
+        float* d = fz.gw + ((long)co * fz.cin_total + fz.cin_off + ci) * 9 + tap;
+        const float v = tile_bad ? __builtin_nanf("") : tile[ci_l * TP + co_l];
+        *d = fz.accumulate ? *d + v : v;
+      }
+    }
+    __syncthreads();
+  }
 }
 
 template <int CT, int NT>
 static void wb_go(const float* x, const float* gy, float* slab, float* gbias, int* redo, const WgB3Geo& g, int nsplit, int n_nt,
-                  hipStream_t st) {
+                  hipStream_t st, const WgFuse& fz) {
   const size_t smem = (size_t)32 * CT * WB_XP + 3 * 32 * NT * WB_GP + 32 * NT * sizeof(float);
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute((const void*)k_wgrad9_b3<CT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     once = true;
   }
-  hipLaunchKernelGGL((k_wgrad9_b3<CT, NT>), dim3(nsplit, g.n_ct * n_nt), dim3(576), smem, st, x, gy, slab, gbias, redo, g);
+  hipLaunchKernelGGL((k_wgrad9_b3<CT, NT>), dim3(nsplit, g.n_ct * n_nt), dim3(576), smem, st, x, gy, slab, gbias, redo, g, fz);
 }
 
 // Can the bf16 kernel take this 3x3 stride-1 weight gradient?  (float4 tile loads of both operands)
@@ -219,8 +294,13 @@ bool evf_wgrad9_b3_ok(const float* x, const float* gy, int Cin, int Cout, int ld
 }
 
 // nsplit slabs [tap][ci][co] (every split written, also the empty ones); redo[n_ct] must be zero on entry
+// fuse_gw != null: the fused reduction (x promised exact; `tickets` >= n_ct * n_nt zeroed ints, handed back zeroed; nsplit < 65536)
 int evf_wgrad9_b3_launch(const float* x, int ldx, const float* gy, int ldg, float* slab, float* gbias, int* redo, int B, int H,
-                         int W, int Cin, int Cout, int nsplit, int CT, int NT, hipStream_t st) {
+                         int W, int Cin, int Cout, int nsplit, int CT, int NT, hipStream_t st, float* fuse_gw, int* tickets,
+                         int cin_total, int cin_off, int accumulate, int promised) {
+  WgFuse fz;
+  fz.gw = fuse_gw, fz.ticket = fuse_gw ? tickets : nullptr, fz.cin_total = cin_total, fz.cin_off = cin_off, fz.accumulate = accumulate;
+  fz.promised = (promised || fuse_gw) ? 1 : 0;
   WgB3Geo g;
   g.B = B, g.H = H, g.W = W, g.Cin = Cin, g.Cout = Cout, g.ldx = ldx, g.ldg = ldg;
   g.tiles_x = evf_cdiv(W, WB_T), g.tiles_y = evf_cdiv(H, WB_T);
@@ -229,12 +309,12 @@ int evf_wgrad9_b3_launch(const float* x, int ldx, const float* gy, int ldg, floa
   g.n_ct = evf_cdiv(Cin, 32 * CT);
   const int n_nt = evf_cdiv(Cout, 32 * NT);
   if (CT == 2 && NT == 2)
-    wb_go<2, 2>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st);
+    wb_go<2, 2>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st, fz);
   else if (CT == 2)
-    wb_go<2, 1>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st);
+    wb_go<2, 1>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st, fz);
   else if (NT == 2)
-    wb_go<1, 2>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st);
+    wb_go<1, 2>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st, fz);
   else
-    wb_go<1, 1>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st);
+    wb_go<1, 1>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st, fz);
   return evf_status();
 }

@@ -578,6 +578,90 @@ __global__ __launch_bounds__(64 * WGR_G) void k_wgrad_reduce(const float* __rest
   *d = accumulate ? *d + s : s;
 }
 
+// ---------------------------------------------------------------------------
+// 3x3 stride 1 with FOUR input channels: the real-valued head of a decoder's input (its two flow-prediction channels + the
+// alignment pair, models/unet.py:371-388 of the reference via hip_ops.conv_wgrad(analog_head=...)).  36 x Cout sums over all
+// pixels are a streaming reduction, not a matrix product: k_wgrad9 padded the four channels to a 32-wide MFMA tile and staged
+// every 32 pixels through LDS behind two barriers -- 149 / 57 / 31 us per LIF-EV-FlowNet decoder for 1.2 GFLOP.  Here a thread
+// owns ONE output channel and a run of FW_SEG pixels of one image row: it slides a 3 x 3 window of float4 (the four input
+// channels of a pixel) along the row -- three new float4 per pixel, the same for all Cout threads of the row (L1 broadcast) --
+// and keeps its 9 x 4 sums in registers; g is read once, coalesced along co.  The 256 / Cout rows of a block meet in LDS, blocks
+// write slabs [block][tap][4][co] for k_wgrad_reduce.
+// ---------------------------------------------------------------------------
+#define FW_SEG 64
+__global__ __launch_bounds__(256) void k_wgrad9_fewin(const float* __restrict__ x, const float* __restrict__ gy,
+                                                      float* __restrict__ slab, int B, int H, int W, int Cout, int ldx, int ldg,
+                                                      int nseg, long nitems) {
+  __shared__ float red[256 * 36];
+  const int tid = threadIdx.x, co = tid % Cout, grp = tid / Cout, NG = 256 / Cout;
+  float acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[t][j] = 0.f;
+  for (long it = (long)blockIdx.x * NG + grp; it < nitems; it += (long)gridDim.x * NG) {
+    const int seg = (int)(it % nseg);
+    const long row = it / nseg;  // b * H + y
+    const int y = (int)(row % H);
+    const long b = row / H;
+    const int c0 = seg * FW_SEG, c1 = min(c0 + FW_SEG, W);
+    const float* xb = x + (b * H) * (long)W * ldx;
+    const float* gr = gy + (row * W) * (long)ldg + co;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // clamped row pointers + validity (no load under a branch)
+    const bool rv[3] = {y >= 1, true, y + 1 < H};
+    const float* xr[3] = {xb + (long)max(y - 1, 0) * W * ldx, xb + (long)y * W * ldx, xb + (long)min(y + 1, H - 1) * W * ldx};
+    float4 w0[3], w1[3], w2[3];  // columns c - 1, c, c + 1 of the three rows
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float4 a = *(const float4*)(xr[r] + (long)max(c0 - 1, 0) * ldx), bq = *(const float4*)(xr[r] + (long)c0 * ldx);
+      w0[r] = (rv[r] && c0 >= 1) ? a : z4;
+      w1[r] = rv[r] ? bq : z4;
+    }
+#pragma unroll 4
+    for (int c = c0; c < c1; ++c) {
+      const float g = gr[(long)c * ldg];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float4 n = *(const float4*)(xr[r] + (long)min(c + 1, W - 1) * ldx);
+        w2[r] = (rv[r] && c + 1 < W) ? n : z4;
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        acc[3 * r + 0][0] = __fmaf_rn(w0[r].x, g, acc[3 * r + 0][0]), acc[3 * r + 0][1] = __fmaf_rn(w0[r].y, g, acc[3 * r + 0][1]);
+        acc[3 * r + 0][2] = __fmaf_rn(w0[r].z, g, acc[3 * r + 0][2]), acc[3 * r + 0][3] = __fmaf_rn(w0[r].w, g, acc[3 * r + 0][3]);
+        acc[3 * r + 1][0] = __fmaf_rn(w1[r].x, g, acc[3 * r + 1][0]), acc[3 * r + 1][1] = __fmaf_rn(w1[r].y, g, acc[3 * r + 1][1]);
+        acc[3 * r + 1][2] = __fmaf_rn(w1[r].z, g, acc[3 * r + 1][2]), acc[3 * r + 1][3] = __fmaf_rn(w1[r].w, g, acc[3 * r + 1][3]);
+        acc[3 * r + 2][0] = __fmaf_rn(w2[r].x, g, acc[3 * r + 2][0]), acc[3 * r + 2][1] = __fmaf_rn(w2[r].y, g, acc[3 * r + 2][1]);
+        acc[3 * r + 2][2] = __fmaf_rn(w2[r].z, g, acc[3 * r + 2][2]), acc[3 * r + 2][3] = __fmaf_rn(w2[r].w, g, acc[3 * r + 2][3]);
+        w0[r] = w1[r], w1[r] = w2[r];
+      }
+    }
+  }
+  // the NG rows of the block meet in LDS: red[grp][tap * 4 + ci][co]
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[(grp * 36 + t * 4 + j) * Cout + co] = acc[t][j];
+  __syncthreads();
+  float* out = slab + (long)blockIdx.x * 36 * Cout;  // [tap][ci 4][co]
+  for (int e = tid; e < 36 * Cout; e += 256) {
+    float v = 0.f;
+    for (int k = 0; k < NG; ++k) v += red[k * 36 * Cout + e];
+    out[e] = v;
+  }
+}
+
+static bool wg_fewin_ok(const float* x, const float* gy, int Cin, int Cout, int ksz, int stride, int ldx, const float* gbias) {
+  return ksz == 3 && stride == 1 && Cin == 4 && !gbias && (Cout == 32 || Cout == 64 || Cout == 128 || Cout == 256) && (ldx & 3) == 0 &&
+         (((uintptr_t)x) & 15) == 0 && gy;
+}
+static int wg_fewin_blocks(int B, int H, int W, int Cout) {
+  const long nitems = (long)B * H * evf_cdiv(W, FW_SEG);
+  const long nb = evf_cdiv(nitems, 256 / Cout);
+  return (int)(nb < 1024 ? nb : 1024);
+}
+
 struct Wg9Plan {
   Wg9Geo g;
   int CT, NT, nsplit, n_nt;
@@ -614,7 +698,12 @@ extern "C" int64_t evf_conv2d_wgrad_ws(int B, int H, int W, int Cin, int Cout, i
   if (ksz == 1) return wg1_small_ok(Cin, Cout, ksz, stride, Cin, nullptr) ? (int64_t)WG1_BLOCKS * (Cout * Cin + Cout) : 0;
   if (ksz != 3) return 0;
   const Wg9Plan p = wg9_plan(B, H, W, Cin, Cout, stride, Cin, Cout);
-  return (int64_t)p.nsplit * 9 * Cin * Cout;
+  int64_t n = (int64_t)p.nsplit * 9 * Cin * Cout;
+  if (Cin == 4 && stride == 1 && (Cout == 32 || Cout == 64 || Cout == 128 || Cout == 256)) {  // (k_wgrad9_fewin's slabs)
+    const int64_t m = (int64_t)wg_fewin_blocks(B, H, W, Cout) * 36 * Cout;
+    if (m > n) n = m;
+  }
+  return n;
 }
 
 template <int CT, int NT, int S>
@@ -643,6 +732,15 @@ static void wg9_launch(const float* x, const float* gy, float* slab, float* gbia
 }
 
 __device__ int g_wg_redo[64];
+#define WG_TICKETS 1024
+__device__ int g_wg_ticket[WG_TICKETS];  // arrival tickets of the fused slab reduction (k_wgrad9_b3): zero at load, handed back zero
+static int* wg_tickets() {
+  static int* ptr[64] = {nullptr};  // per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!ptr[dev] && hipGetSymbolAddress((void**)&ptr[dev], HIP_SYMBOL(g_wg_ticket)) != hipSuccess) return nullptr;
+  return ptr[dev];
+}
 static int* wg_redo_flags() {
   static int* ptr[64] = {nullptr};  // per device
   int dev = 0;
@@ -662,11 +760,26 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
       (!(accumulate & 1) && (cin_off != 0 || Cin < cin_total)) || (ksz == 3 && !ws) || ((uintptr_t)g_y & 15))
     return EVF_EINVAL;
   const bool analog = (accumulate & 2) != 0;  // the caller knows x is not spike-valued: no bf16 attempt
+  // 4: the caller GUARANTEES an x that is exactly representable in bf16 (spikes, {0,1,2,..} residual sums, bilinear x2 blends of
+  // those -- known from how the tensor was made, models/hip_ops.py): ONE launch, slab reduction fused into the kernel's tail
+  const bool exact = (accumulate & 4) != 0;
   accumulate &= 1;
   hipStream_t st = EVF_STREAM(stream);
   if (!accumulate && g_bias) {
     const int rc = evf_hip(hipMemsetAsync(g_bias, 0, sizeof(float) * (size_t)Cout, st));
     if (rc) return rc;
+  }
+  static const bool fewin_on = !(getenv("EVF_WGRAD_FEWIN") && !strcmp(getenv("EVF_WGRAD_FEWIN"), "0"));
+  if (fewin_on && wg_fewin_ok(x, g_y, Cin, Cout, ksz, stride, ldx, g_bias)) {
+    const int nseg = evf_cdiv(W, FW_SEG), nblk = wg_fewin_blocks(B, H, W, Cout);
+    hipLaunchKernelGGL(k_wgrad9_fewin, dim3(nblk), dim3(256), 0, st, x, g_y, ws, B, H, W, Cout, ldx, ldg, nseg, (long)B * H * nseg);
+    int rc = evf_status();
+    if (rc) return rc;
+    const long per = (long)36 * Cout;
+    const int rg = nblk >= 16 ? 16 : (nblk >= 8 ? 8 : (nblk >= 4 ? 4 : (nblk >= 2 ? 2 : 1)));
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(evf_cdiv(per, 64)), dim3(64 * rg), 0, st, ws, nblk, 4, Cout, cin_total, cin_off, accumulate,
+                       g_w, (int*)nullptr);
+    return evf_status();
   }
   if (ksz == 3) {
     const Wg9Plan p = wg9_plan(B, H, W, Cin, Cout, stride, ldx, ldg);
@@ -680,7 +793,19 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
       // stream-ordered on one stream per device)
       int* flags = wg_redo_flags();
       if (!flags) return EVF_EINVAL;
-      int rc = evf_wgrad9_b3_launch(x, ldx, g_y, ldg, ws, g_bias, flags, B, H, W, Cin, Cout, p.nsplit, p.CT, p.NT, st);
+      // The fused reduction is OFF by default (EVF_WGRAD_FUSE=1 switches it on), measured on the LIF-EV-FlowNet step: the blocks of
+      // a launch finish together, so every tile's last block runs its 9 x (read 4 slabs, transpose, scattered store) chain at the END
+      // of the kernel with nothing to hide it -- +47 us per call over k_wgrad_reduce's 25 us launch (8.75 against 8.42 ms per step)
+      // for <= 8 splits; with 16..256 splits (few weight tiles) the last block reads 1..9 MB through ONE CU: 13.4 ms per step.
+      static const bool fuse_ok = getenv("EVF_WGRAD_FUSE") && !strcmp(getenv("EVF_WGRAD_FUSE"), "1");
+      if (exact && fuse_ok && p.nsplit <= 8 && (long)p.g.n_ct * p.n_nt <= WG_TICKETS) {
+        int* tickets = wg_tickets();
+        if (!tickets) return EVF_EINVAL;
+        return evf_wgrad9_b3_launch(x, ldx, g_y, ldg, ws, g_bias, flags, B, H, W, Cin, Cout, p.nsplit, p.CT, p.NT, st, g_w, tickets,
+                                    cin_total, cin_off, accumulate);
+      }
+      int rc = evf_wgrad9_b3_launch(x, ldx, g_y, ldg, ws, g_bias, flags, B, H, W, Cin, Cout, p.nsplit, p.CT, p.NT, st, nullptr, nullptr,
+                                    0, 0, 0, exact ? 1 : 0);
       if (rc) return rc;
       redo = flags;
       bias_f32 = nullptr;  // (summed by the bf16 kernel from the exact fp32 gradients)
@@ -690,7 +815,9 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
     wg9_launch<CT_, NT_, 1>(x, g_y, ws, bias_f32, p, st, redo);       \
   else                                                                \
     wg9_launch<CT_, NT_, 2>(x, g_y, ws, bias_f32, p, st, redo)
-    if (p.CT == 2 && p.NT == 2) {
+    if (redo && exact) {
+      // x exact by construction: the bf16 kernel raised no flag, the fp32 pass would exit at once in every block -- not launched
+    } else if (p.CT == 2 && p.NT == 2) {
       WG9(2, 2);
     } else if (p.CT == 2) {
       WG9(2, 1);

@@ -173,15 +173,40 @@ def _b3_ws(B, Ho, Wo, Cout, dev):
     return _scratch(n, dev), n
 
 
-def conv_fwd(x, wp, bias, y, Cin, Cout, k, stride, accumulate=0):
+def _exact_flags(exact_from):
+    """evf_conv2d_fwd_b3[_parts] flag bits of a spike-valued input: bit 2 + the first exact channel in bits 4..8."""
+    if exact_from is None or not EXACT_WGRAD or not 0 <= exact_from <= 16:
+        return 0
+    return 4 | (int(exact_from) << 4)
+
+
+def conv_fwd(x, wp, bias, y, Cin, Cout, k, stride, accumulate=0, exact_from=None):
+    """exact_from: the channels of x from this index (<= 16) on are exactly representable in bf16 by construction (spike_tag
+    below): evf_conv2d_fwd_b3 bit 2."""
     B, H, W, ldx = x.shape[0], x.shape[1], x.shape[2], x.stride(2)
     if CONV_B3:
         ws, n = _b3_ws(B, y.shape[1], y.shape[2], Cout, x.device)
         _lib.call("evf_conv2d_fwd_b3", _lib.ptr(x), ldx, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(y), y.stride(2), B, H, W, Cin,
-                  Cout, k, stride, accumulate, _lib.ptr(ws), n)
+                  Cout, k, stride, (accumulate & 1) | _exact_flags(exact_from), _lib.ptr(ws), n)
         return
     _lib.call("evf_conv2d_fwd", _lib.ptr(x), ldx, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(y), y.stride(2), B, H, W, Cin, Cout,
               k, stride, accumulate)
+
+
+def conv_fwd_parts(x, wp, y, Cin, Cout, k, stride, exact_from, slot):
+    """conv(x) with its K-split partial sums left in parts: -> (tensor, n, stride in floats): n = 1 with y itself when the plan
+    does not split, else n slabs in scratch `slot`."""
+    import ctypes as _ct
+
+    B, H, W, ldx = x.shape[0], x.shape[1], x.shape[2], x.stride(2)
+    n = _lib.load().evf_conv2d_b3_ws(B, y.shape[1], y.shape[2], Cout)
+    ws = _scratch(n, x.device, slot) if n > 0 else None
+    parts = _ct.c_int(0)
+    _lib.call("evf_conv2d_fwd_b3_parts", _lib.ptr(x), ldx, _lib.ptr(wp), _lib.ptr(y), y.stride(2), B, H, W, Cin, Cout, k, stride,
+              _exact_flags(exact_from), _lib.ptr(ws), max(n, 0), _ct.byref(parts))
+    if parts.value > 0:
+        return ws, parts.value, y.numel()
+    return y, 1, 0
 
 
 def conv_dgrad(g_y, wtp, g_x, Cin, Cout, k, stride, accumulate=0):
@@ -197,24 +222,31 @@ def conv_dgrad(g_y, wtp, g_x, Cin, Cout, k, stride, accumulate=0):
 
 _SCRATCH = {}
 _POISON = os.environ.get("EVF_DEBUG_POISON_SCRATCH", "0") == "1"
+# LIF cells: the K-split partial sums of the cell's conv(s) go straight into the neuron update (evf_conv2d_fwd_b3_parts +
+# evf_lif_fwd_parts) instead of through a k_b3_reduce launch and a `cur` tensor per conv; 0: conv -> cur -> evf_neuron_fwd
+LIF_PARTS = os.environ.get("EVF_LIF_PARTS", "1") != "0"
 
 
-def _scratch(n, dev):
-    """Stream-ordered scratch buffer (grown on demand, reused by every weight-gradient launch)."""
-    buf = _SCRATCH.get(dev)
+def _scratch(n, dev, slot=0):
+    """Stream-ordered scratch buffer (grown on demand, reused by every weight-gradient launch; `slot`: a second one for a
+    consumer that needs two conv outputs in parts at once)."""
+    buf = _SCRATCH.get((dev, slot))
     if buf is None or buf.numel() < n:
         buf = _new((max(int(n), 1),), dev)
-        _SCRATCH[dev] = buf
+        _SCRATCH[(dev, slot)] = buf
     if _POISON:  # debugging aid: a kernel that reads scratch it did not write turns its result into NaNs
         buf.fill_(float("nan"))
     return buf
 
 
-def conv_wgrad(x, g_y, g_w, g_b, Cin, Cout, k, stride, cin_total=None, cin_off=0, accumulate=0, spikes=False, analog_head=0):
+def conv_wgrad(x, g_y, g_w, g_b, Cin, Cout, k, stride, cin_total=None, cin_off=0, accumulate=0, spikes=False, analog_head=0,
+               exact_from=None):
     """Weight (+ bias) gradient.  spikes: x is spike-valued (binary spikes, counts, bilinear blends of spikes): the 3x3
     stride-1 contraction runs on the bf16 matrix cores (exact there; anything else it finds is redone in fp32).
     analog_head: the first `analog_head` channels of x are real-valued (a decoder's flow prediction): they are split off
-    into an fp32 call of their own so that the rest stays on the fast path."""
+    into an fp32 call of their own so that the rest stays on the fast path.
+    exact_from: provenance (spike_tag below) -- the channels of x from this index on are exactly representable in bf16 BY
+    CONSTRUCTION: the bf16 kernel then reduces its own partial sums (one launch instead of three; evf_conv2d_wgrad bit 2)."""
     B, H, W = x.shape[0], x.shape[1], x.shape[2]
     ct = Cin if cin_total is None else cin_total
     if spikes and analog_head and k == 3 and stride == 1 and cin_off == 0 and Cin > 8:
@@ -224,11 +256,35 @@ def conv_wgrad(x, g_y, g_w, g_b, Cin, Cout, k, stride, cin_total=None, cin_off=0
             if g_b is not None:
                 g_b.zero_()
         conv_wgrad(x, g_y, g_w, g_b, a, Cout, k, stride, ct, 0, 1, spikes=False)
-        conv_wgrad(x[..., a:], g_y, g_w, None, Cin - a, Cout, k, stride, ct, a, 1, spikes=True)
+        conv_wgrad(x[..., a:], g_y, g_w, None, Cin - a, Cout, k, stride, ct, a, 1, spikes=True,
+                   exact_from=None if exact_from is None else max(exact_from - a, 0))
         return
     ws = _scratch(_lib.load().evf_conv2d_wgrad_ws(B, H, W, Cin, Cout, k, stride), x.device)
+    exact = 4 if (spikes and EXACT_WGRAD and exact_from is not None and exact_from <= 0) else 0
     _lib.call("evf_conv2d_wgrad", _lib.ptr_strided(x), x.stride(2), _lib.ptr(g_y), g_y.stride(2), _lib.ptr(g_w), _lib.ptr(g_b),
-              B, H, W, Cin, Cout, k, stride, ct, cin_off, (accumulate & 1) | (0 if spikes else 2), _lib.ptr(ws))
+              B, H, W, Cin, Cout, k, stride, ct, cin_off, (accumulate & 1) | (0 if spikes else 2) | exact, _lib.ptr(ws))
+
+
+# ---------------------------------------------------------------------------
+# provenance of spike-valued activations
+# ---------------------------------------------------------------------------
+# A tensor produced by this module carries `_evf_spike = (bound, exact_from)` when its channels from `exact_from` on are, BY
+# CONSTRUCTION, multiples of 1/16 of magnitude <= bound <= 15: output spikes of a cell ({0,1}; + a tagged residual: the bounds
+# add), channel concatenations and zero paddings of such tensors, their bilinear x2 blends (weights 1, 3, 3, 9 / 16).  Such values
+# have at most 8 significant bits: exactly representable in bf16, which is what lets the weight-gradient kernel skip its fp32
+# verification pass (conv_wgrad(exact_from=...)).  Anything that went through a foreign op has no tag and takes the verified path.
+EXACT_WGRAD = os.environ.get("EVF_WGRAD_EXACT", "1") != "0"
+SPIKE_BOUND_MAX = 15.0
+
+
+def spike_tag(t):
+    return getattr(t, "_evf_spike", None) if torch.is_tensor(t) else None
+
+
+def set_spike_tag(t, bound, exact_from=0):
+    if bound is not None and bound <= SPIKE_BOUND_MAX:
+        t._evf_spike = (float(bound), int(exact_from))
+    return t
 
 
 # ---------------------------------------------------------------------------
@@ -385,9 +441,22 @@ class _CellStep(torch.autograd.Function):
             raise _lib.EvflowError(f"input has {Cin} channels, the cell expects {Cw}")
         # (Cin - Cw trailing channels = zero padding that keeps 16-byte alignment; the packed weight is zero there)
         cur = _new((B, Ho, Wo, C), dev)
-        conv_fwd(xn, _wcache(cell, "ff").get(wff, 0, 0, Cin), None, cur, Cin, C, k, s)
-        if cell.recurrent and sp is not None:
-            conv_fwd(sp[1], _wcache(cell, "rec").get(wrec, 0), None, cur, C, C, k, 1, accumulate=1)
+        xtag = spike_tag(x)
+        x_exact = xtag[1] if xtag is not None else None  # (first exact channel: 0, or 2 behind a decoder's flow channels)
+        rec_exact = None if getattr(cell, "gnorm", False) else 0  # (the previous state's z slice: spikes unless group norm rescaled them)
+        parts = None
+        if kind == 0 and CONV_B3 and LIF_PARTS:
+            # the conv kernels leave their K-split partial sums in scratch, the neuron update adds them itself
+            pa = conv_fwd_parts(xn, _wcache(cell, "ff").get(wff, 0, 0, Cin), cur, Cin, C, k, s, x_exact, 0)
+            pb = (None, 0, 0)
+            if cell.recurrent and sp is not None:
+                cur2 = _new((B, Ho, Wo, C), dev)
+                pb = conv_fwd_parts(sp[1], _wcache(cell, "rec").get(wrec, 0), cur2, C, C, k, 1, rec_exact, 1)
+            parts = (pa, pb)
+        else:
+            conv_fwd(xn, _wcache(cell, "ff").get(wff, 0, 0, Cin), None, cur, Cin, C, k, s, exact_from=x_exact)
+            if cell.recurrent and sp is not None:
+                conv_fwd(sp[1], _wcache(cell, "rec").get(wrec, 0), None, cur, C, C, k, 1, accumulate=1, exact_from=rec_exact)
         P = None
         if kind in (1, 3):
             ws = _new((B * H * W,), dev)
@@ -396,15 +465,26 @@ class _CellStep(torch.autograd.Function):
         new = slots.take((ns, B, Ho, Wo, C), dev) if slots is not None else _new((ns, B, Ho, Wo, C), dev)
         out = _new((B, Ho, Wo, C), dev)
         prm = [p.detach().reshape(-1).contiguous() if p is not None else None for p in (p0, p1, p2, p3)]
-        _lib.call("evf_neuron_fwd", kind, _lib.ptr(cur), _lib.ptr(sp[0]) if sp is not None else None,
+        if parts is not None:
+            (ta, na, sa), (tb, nb, sb) = parts
+            _lib.call("evf_lif_fwd_parts", _lib.ptr(ta), na, sa, _lib.ptr(tb), nb, sb, _lib.ptr(sp[0]) if sp is not None else None,
+                      _lib.ptr(sp[1]) if sp is not None else None, _lib.ptr(rn), _lib.ptr(prm[0]), _lib.ptr(prm[1]), B * Ho * Wo, C,
+                      1 if cell.hard_reset else 0, _lib.ptr(new[0]), _lib.ptr(new[1]), _lib.ptr(out))
+        else:
+            _lib.call("evf_neuron_fwd", kind, _lib.ptr(cur), _lib.ptr(sp[0]) if sp is not None else None,
                   _lib.ptr(sp[1]) if sp is not None else None, _lib.ptr(sp[2]) if (sp is not None and ns == 3) else None,
                   _lib.ptr(P), _lib.ptr(rn), _lib.ptr(prm[0]), _lib.ptr(prm[1]), _lib.ptr(prm[2]), _lib.ptr(prm[3]),
                   B * Ho * Wo, C, 1 if cell.hard_reset else 0, _lib.ptr(new[0]), _lib.ptr(new[1]),
                   _lib.ptr(new[2]) if ns == 3 else None, _lib.ptr(out))
         ctx.cell, ctx.kind, ctx.ns = cell, kind, ns
+        tag = spike_tag(x)
+        ctx.exact_from = tag[1] if tag is not None else None  # provenance of the input (conv_wgrad)
         ctx.geom = (B, H, W, Cin, Ho, Wo, C, k, s)
         ctx.saved = (xn, sp, new, P, prm, wff, wrec)
         ctx.has_res = residual is not None
+        # the recurrent conv reads the z slice of the previous state: spikes by the cell's definition (a caller who hands in
+        # anything else gets NaN weight gradients from the exact path, never rounded ones) -- unless group norm rescaled them
+        ctx.rec_spikes = state is not None and not getattr(cell, "gnorm", False)
         return from_nhwc(out), new.permute(0, 1, 4, 2, 3)
 
     @staticmethod
@@ -452,17 +532,21 @@ class _CellStep(torch.autograd.Function):
             d = bound_grad(wff)
             head = int(getattr(cell, "analog_input_channels", 0))  # (a decoder's flow-prediction channels, models/unet.py)
             if d is not None:
-                conv_wgrad(xn, g_cur, d, None, Cin, C, k, s, cin_total=wff.shape[1], accumulate=1, spikes=True, analog_head=head)
+                conv_wgrad(xn, g_cur, d, None, Cin, C, k, s, cin_total=wff.shape[1], accumulate=1, spikes=True, analog_head=head,
+                           exact_from=ctx.exact_from)
             else:
                 g_wff = _new(tuple(wff.shape), dev)
-                conv_wgrad(xn, g_cur, g_wff, None, Cin, C, k, s, cin_total=wff.shape[1], spikes=True, analog_head=head)
+                conv_wgrad(xn, g_cur, g_wff, None, Cin, C, k, s, cin_total=wff.shape[1], spikes=True, analog_head=head,
+                           exact_from=ctx.exact_from)
         if cell.recurrent and need[5]:
             d = bound_grad(wrec)
+            # (the recurrent input is the cell's own previous SPIKES unless group norm rescaled them: exact by construction)
+            rec_exact = 0 if ctx.rec_spikes else None
             if sp is not None and d is not None:
-                conv_wgrad(sp[1], g_cur, d, None, C, C, k, 1, accumulate=1, spikes=True)
+                conv_wgrad(sp[1], g_cur, d, None, C, C, k, 1, accumulate=1, spikes=True, exact_from=rec_exact)
             elif sp is not None:
                 g_wrec = _new(tuple(wrec.shape), dev)
-                conv_wgrad(sp[1], g_cur, g_wrec, None, C, C, k, 1, spikes=True)
+                conv_wgrad(sp[1], g_cur, g_wrec, None, C, C, k, 1, spikes=True, exact_from=rec_exact)
             elif d is None:
                 g_wrec = torch.zeros(tuple(wrec.shape), dtype=torch.float32, device=dev)
         if need[1]:
@@ -540,7 +624,14 @@ def cell_forward(cell, input_, prev_state, residual=0, slots=None):
         for name in ("ff", "rec", "ffT", "recT"):
             d.pop(name, None)
     wrec = conv_weight(cell.rec) if cell.recurrent else None
-    return _CellStep.apply(cell, input_, prev_state, res, slots, conv_weight(cell.ff), wrec, *p)
+    out, new = _CellStep.apply(cell, input_, prev_state, res, slots, conv_weight(cell.ff), wrec, *p)
+    # provenance: out = spikes (+ residual); the state's z slice is spikes
+    rtag = spike_tag(res)
+    if res is None:
+        set_spike_tag(out, 1.0)
+    elif rtag is not None and rtag[1] == 0:
+        set_spike_tag(out, 1.0 + rtag[0])
+    return out, new
 
 
 # ---------------------------------------------------------------------------
@@ -1057,7 +1148,22 @@ class _Concat(torch.autograd.Function):
 
 
 def concat_channels(parts, pad=0):
-    return _Concat.apply(int(pad), *parts)
+    out = _Concat.apply(int(pad), *parts)
+    # provenance: exact from the end of the last untagged part on (the zero padding is exact)
+    off, exact_from, bound = 0, 0, 0.0
+    for p in parts:
+        tag = spike_tag(p)
+        if tag is None:
+            exact_from = off + p.shape[1]
+        else:
+            bound = max(bound, tag[0])
+            if tag[1] > 0:
+                exact_from = off + tag[1]
+        off += p.shape[1]
+    if exact_from < off:
+        set_spike_tag(out, max(bound, 1.0), exact_from)
+        out._evf_spike_int = all(getattr(p, "_evf_spike_int", True) for p in parts if spike_tag(p) is not None)
+    return out
 
 
 class _Add(torch.autograd.Function):
@@ -1103,7 +1209,13 @@ class _Up2(torch.autograd.Function):
 
 def upsample2x_bilinear(x):
     """F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)."""
-    return _Up2.apply(x)
+    y = _Up2.apply(x)
+    tag = spike_tag(x)
+    if tag is not None:  # blends with weights 1, 3, 3, 9 / 16 of multiples of 1 / 16?  No: only of INTEGERS (first-level blends)
+        if getattr(x, "_evf_spike_int", True):
+            set_spike_tag(y, tag[0], tag[1])
+            y._evf_spike_int = False  # (a second blend would need 1 / 256 steps: not tagged again)
+    return y
 
 
 class _UpNearest(torch.autograd.Function):

@@ -12,7 +12,11 @@ def _centred(x, like):
     gap_h, gap_w = like.shape[2] - x.shape[2], like.shape[3] - x.shape[3]
     if gap_h == 0 and gap_w == 0:
         return x
-    return torch.nn.functional.pad(x, (gap_w // 2, gap_w - gap_w // 2, gap_h // 2, gap_h - gap_h // 2))
+    y = torch.nn.functional.pad(x, (gap_w // 2, gap_w - gap_w // 2, gap_h // 2, gap_h - gap_h // 2))
+    for attr in ("_evf_spike", "_evf_spike_int"):  # zero padding keeps the provenance of a spike-valued tensor (hip_ops.spike_tag)
+        if hasattr(x, attr):
+            setattr(y, attr, getattr(x, attr))
+    return y
 
 
 def skip_concat(x1, x2):

@@ -245,8 +245,8 @@ int evf_bwd_defer_flush(void* stream);
  * evf_defer_profile_read synchronises the device, returns per kind (0 forward cells, 1 fused-backward cells, 2
  * input-gradient cells, 3 head backward one pass per launch, 4 head forward of a window in one launch, 5 head backward of
  * a window in one launch; 6 unused; 7 an empty bracket) the summed duration in ms and the number of launches -- EIGHT entries
- * each -- and switches it off.  evf_defer_profile(2): the brackets are recorded INTO a stream capture as external event-record
- * nodes (hipEventRecordWithFlags(..., hipEventRecordExternal)); evf_defer_profile(0) after the capture stops recording and
+ * each -- and switches it off.  evf_defer_profile(2): the brackets are recorded INTO a stream capture as one-thread timestamp
+ * kernels (wall clock) in front of and behind every launch; evf_defer_profile(0) after the capture stops recording and
  * keeps them; after replays of the graph evf_defer_profile_read returns the durations inside the LAST replay. */
 int evf_defer_profile(int on);
 int evf_defer_profile_read(float* ms8, int* count8);
@@ -495,7 +495,13 @@ int evf_pack_conv2d_weight_b3(const float* w, int Cout, int Cin, int ksz, int tr
 int evf_pack_conv2d_weights_b3_multi(const void* const* w, void* const* dst, const int* meta, int n, void* stream);
 /* ws: optional scratch of ws_floats floats (evf_conv2d_b3_ws() of the OUTPUT shape; 0 = this shape never needs it): layers
  * whose output tiles alone cannot fill the chip split their contraction into up to 8 slabs, summed in a fixed order
- * (deterministic; no atomics).  Null = never split. */
+ * (deterministic; no atomics).  Null = never split.
+ * evf_conv2d_fwd_b3, accumulate bit 2 (value 4) = "x is exactly representable in bf16 BY CONSTRUCTION from channel
+ * (accumulate >> 4) & 31 (<= 16) on" (spikes, small sums of spikes, their bilinear x2 blends behind a decoder's two flow channels;
+ * models/hip_ops.py spike_tag): 3x3 stride-1 products then take the single-plane kernel of csrc/evf_conv_b3small.hip (64 input
+ * channels of the halo tile staged ONCE in LDS as one bf16 plane for all nine taps, the first 16 channels as the exact 3-way split
+ * when they hold real values); an x that breaks the promise yields NaN there, never a rounded product.  Without the bit nothing
+ * changes (the kernels vote per wave). */
 int64_t evf_conv2d_b3_ws(int B, int Ho, int Wo, int Cout);
 int evf_conv2d_fwd_b3(const float* x, int ldx, const void* w_packed, const float* bias, float* y, int ldy,
                       int B, int H, int W, int Cin, int Cout, int ksz, int stride, int accumulate,
@@ -503,6 +509,17 @@ int evf_conv2d_fwd_b3(const float* x, int ldx, const void* w_packed, const float
 int evf_conv2d_dgrad_b3(const float* g_y, int ldg, const void* wT_packed, float* g_x, int ldx, int B, int H,
                         int W, int Cin, int Cout, int ksz, int stride, int accumulate, float* ws,
                         int64_t ws_floats, void* stream);
+/* evf_conv2d_fwd_b3 without bias / accumulation whose K-split partial sums stay IN PARTS for the consumer (evf_lif_fwd_parts):
+ * *nparts = 0: y holds the result; n > 0: ws holds n slabs [B*Ho*Wo][Cout] to be added in index order.  flags: bit 2 as above. */
+int evf_conv2d_fwd_b3_parts(const float* x, int ldx, const void* w_packed, float* y, int ldy, int B, int H, int W,
+                            int Cin, int Cout, int ksz, int stride, int flags, float* ws, int64_t ws_floats,
+                            int* nparts, void* stream);
+/* LIF update (evf_neuron_fwd, kind LIF: spiking_submodules.py:96-126, :516-551) on a current given in parts:
+ * cur = sum_{z < na} a[z * a_stride + .] + sum_{z < nb} b[z * b_stride + .] (b null: no recurrent part; strides in floats). */
+int evf_lif_fwd_parts(const float* a, int na, int64_t a_stride, const float* b, int nb, int64_t b_stride,
+                      const float* v_prev, const float* z_prev, const float* residual, const float* leak,
+                      const float* thresh, int64_t npix, int C, int hard_reset, float* v_out, float* z_out,
+                      float* out, void* stream);
 /* Kernel choice behind the two entry points above for 3x3 stride-1 products: -1 by shape (default: the spatially tiled
  * kernel of csrc/evf_conv_b3tile.hip for wide high-resolution layers, environment EVF_CONV_TILE=0|2 at load), 0 never,
  * 2 whenever the operands are aligned for it.  Same results up to summation order. */
@@ -516,8 +533,12 @@ int evf_conv_split_select(int n);
  * partial sums of the pixel splits, reduced without atomics. */
 /* 3x3 stride 1: the contraction over pixels runs on the bf16 matrix cores first (csrc/evf_wgrad_b3gen.hip: x as one bf16
  * plane, g_y as three; exact for spike-valued x), and the fp32 kernel recomputes only the input-channel tiles whose x was
- * not exactly representable.  accumulate bit 1 (value 2) = "x is not spike-valued": fp32 kernel only.  EVF_WGRAD=f32 in the
- * environment disables the bf16 kernel. */
+ * not exactly representable.  accumulate bit 1 (value 2) = "x is not spike-valued": fp32 kernel only.  accumulate bit 2
+ * (value 4) = "x IS exactly representable in bf16 by construction" (spikes, small residual sums of spikes, bilinear x2 blends
+ * of those): no fp32 verification pass (its launch would exit at once in every block); with EVF_WGRAD_FUSE=1 in the environment
+ * also no k_wgrad_reduce launch for <= 8 pixel splits -- the bf16 kernel's last block per weight tile sums the splits in index
+ * order (measured slower than the reduce launch, hence off).  An x that breaks the promise yields NaN in the gradient, never a
+ * silently rounded one.  EVF_WGRAD=f32 in the environment disables the bf16 kernel. */
 int64_t evf_conv2d_wgrad_ws(int B, int H, int W, int Cin, int Cout, int ksz, int stride);
 int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int ldg, float* g_w, float* g_bias, int B,
                      int H, int W, int Cin, int Cout, int ksz, int stride, int cin_total, int cin_off,
@@ -560,8 +581,10 @@ int evf_neuron_fwd(int kind, const float* cur, const float* v_prev, const float*
  * (first pass of a window, detached state): g_v_prev / g_aux_prev / g_z_prev are not written.  Absent operand groups
  * (no upstream state gradient, no previous state) select kernel variants without their loads.
  * ws: optional scratch of EVF_NEURON_BWD_WS floats, ZERO on entry and left zero on exit: the blocks' parameter-gradient
- * sums meet in 32 replicas there instead of 1024 blocks adding atomically into the same 2..4 x C words (null: they do). */
-#define EVF_NEURON_BWD_WS (32 * 4096)
+ * sums meet in 32 replicas there instead of 1024 blocks adding atomically into the same 2..4 x C words (null: they do); the
+ * block that finishes last sums the replicas into the outputs (arrival ticket in the word behind the replicas).  Launches of
+ * <= 256 blocks (at least ~8 float4 per thread) add straight into the outputs and leave the scratch alone. */
+#define EVF_NEURON_BWD_WS (32 * 4096 + 64)
 int evf_neuron_bwd(int kind, const float* g_v_out, const float* g_z_out, const float* g_z_out2,
                    const float* g_aux_out, const float* v_out, const float* aux_out, const float* v_prev,
                    const float* z_prev, const float* aux_prev, const float* P, const float* p0,

@@ -174,6 +174,207 @@ def test_conv2d_b3_bias_and_accumulate_through_every_kernel(case, conv_mode):
     close(N(gx), (xr.grad.permute(0, 2, 3, 1) + gx0.double()).numpy(), 1e-5, "dgrad accumulate")
 
 
+@pytest.mark.parametrize("case", [(2, 128, 64, 16, 16), (1, 64, 64, 32, 40), (2, 36, 32, 17, 23), (1, 512, 128, 8, 8), (8, 512, 512, 16, 16),
+                                  (2, 64, 130, 24, 24)])
+def test_wgrad_fused_slab_reduction_equals_the_three_launch_path(case, monkeypatch):
+    """evf_conv2d_wgrad with accumulate bit 2 ("x exactly representable in bf16 by construction"): ONE launch -- the last block of
+    every weight tile sums the pixel splits in index order -- against the verified path (bf16 kernel, fp32 redo pass,
+    k_wgrad_reduce) and against float64; overwrite and accumulate forms, a channel offset inside a wider weight; and an x that
+    breaks the promise gives NaN, never a rounded gradient."""
+    B, Cin, Cout, H, W = case
+    gen = torch.Generator().manual_seed(B * 1000 + Cin)
+    # (both forms of the exact path are exercised: this process runs the default -- reduce launch kept, fp32 pass skipped --, the
+    #  fused tail is measured slower and sits behind EVF_WGRAD_FUSE=1, read once per process: test_wgrad_fused_tail_in_a_subprocess)
+    # spike-valued input: bilinear x2 blends of {0, 1, 2} sums (multiples of 1/16)
+    lo = torch.randint(0, 3, (B, Cin, (H + 1) // 2, (W + 1) // 2), generator=gen).float()
+    x = torch.nn.functional.interpolate(lo, scale_factor=2, mode="bilinear", align_corners=False)[:, :, :H, :W].contiguous()
+    gy = torch.randn(B, Cout, H, W, generator=gen) * 0.1
+    xd = G(x.permute(0, 2, 3, 1).contiguous().numpy())
+    gd = G(gy.permute(0, 2, 3, 1).contiguous().numpy())
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), gy.double(), padding=1).numpy()
+    ct, off = Cin + 8, 4  # the weight tensor is wider than this call's channel range
+    L = _lib.load()
+    ws = torch.empty(max(L.evf_conv2d_wgrad_ws(B, H, W, Cin, Cout, 3, 1), 1), device=DEV)
+
+    def run(flags, base):
+        g_w = base.clone()
+        _lib.call("evf_conv2d_wgrad", _lib.ptr(xd), Cin, _lib.ptr(gd), Cout, _lib.ptr(g_w), None, B, H, W, Cin, Cout, 3, 1, ct, off,
+                  flags, _lib.ptr(ws))
+        torch.cuda.synchronize()
+        return N(g_w)
+
+    base = torch.randn(Cout, ct, 3, 3, generator=gen).to(DEV)
+    three, fused = run(1, base), run(1 | 4, base)
+    scale = np.abs(ref).max()
+    assert np.abs(fused - three).max() <= 2e-6 * scale, np.abs(fused - three).max() / scale
+    want = N(base).astype(np.float64)
+    want[:, off:off + Cin] += ref
+    assert np.abs(fused - want).max() <= 1e-5 * scale
+    assert np.array_equal(fused[:, :off], N(base)[:, :off]) and np.array_equal(fused[:, off + Cin:], N(base)[:, off + Cin:])
+    again = run(1 | 4, base)
+    assert np.array_equal(again, fused)  # fixed summation order: the same bits whatever the block schedule
+    # overwrite form (the call covers the whole weight)
+    zero = torch.full((Cout, Cin, 3, 3), 7.0, device=DEV)
+    g1, g2 = zero.clone(), zero.clone()
+    for g_w, fl in ((g1, 0), (g2, 4)):
+        _lib.call("evf_conv2d_wgrad", _lib.ptr(xd), Cin, _lib.ptr(gd), Cout, _lib.ptr(g_w), None, B, H, W, Cin, Cout, 3, 1, Cin, 0, fl,
+                  _lib.ptr(ws))
+    assert np.abs(N(g2) - N(g1)).max() <= 2e-6 * scale and np.abs(N(g2) - ref).max() <= 1e-5 * scale
+    # a broken promise is loud
+    xbad = xd.clone()
+    xbad[0, 1, 1, 0] = 0.3
+    g3 = zero.clone()
+    _lib.call("evf_conv2d_wgrad", _lib.ptr(xbad), Cin, _lib.ptr(gd), Cout, _lib.ptr(g3), None, B, H, W, Cin, Cout, 3, 1, Cin, 0, 4,
+              _lib.ptr(ws))
+    if Cout % 4 == 0:  # (else the shape is not the bf16 kernel's: the fp32 kernel takes it, exactly, promise or not)
+        assert np.isnan(N(g3)).any()
+    g4 = zero.clone()  # ... and the tickets were handed back zeroed: the next exact call is clean again
+    _lib.call("evf_conv2d_wgrad", _lib.ptr(xd), Cin, _lib.ptr(gd), Cout, _lib.ptr(g4), None, B, H, W, Cin, Cout, 3, 1, Cin, 0, 4,
+              _lib.ptr(ws))
+    assert np.array_equal(N(g4), N(g2))
+
+
+@pytest.mark.parametrize("case", [(8, 512, 512), (4, 128, 256), (2, 64, 512), (8, 1024, 128), (8, 256, 512), (16, 128, 512)])
+def test_small_image_exact_input_conv_equals_the_voting_kernels(case):
+    """evf_conv2d_fwd_b3 with accumulate bit 2 ("x exactly representable in bf16 by construction") on 16 x 16 images: the
+    two-images-per-block kernel of csrc/evf_conv_b3small.hip against the voting kernels (same exact products: fp32 round-off
+    of another summation order) and against float64; overwrite / accumulate / bias; a broken promise gives NaN."""
+    B, Cin, Cout = case
+    H = W = 16
+    gen = torch.Generator().manual_seed(B + Cin)
+    x = torch.randint(0, 3, (B, Cin, H, W), generator=gen).float() * (torch.rand(B, Cin, H, W, generator=gen) < 0.3)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) * 0.05
+    bias = torch.randn(Cout, generator=gen)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1).numpy()
+    xd = G(x.permute(0, 2, 3, 1).contiguous().numpy())
+    wd, bd = G(w.numpy()), G(bias.numpy())
+    L = _lib.load()
+    wp = torch.empty(L.evf_conv2d_b3_packed_size(Cout, Cin, 3, 0), device=DEV)
+    _lib.call("evf_pack_conv2d_weight_b3", _lib.ptr(wd), Cout, Cin, 3, 0, Cin, 0, _lib.ptr(wp))
+    nws = L.evf_conv2d_b3_ws(B, H, W, Cout)
+    ws = torch.empty(max(nws, 1), device=DEV)
+
+    def run(flags, base):
+        y = base.clone()
+        _lib.call("evf_conv2d_fwd_b3", _lib.ptr(xd), Cin, _lib.ptr(wp), _lib.ptr(bd), _lib.ptr(y), Cout, B, H, W, Cin, Cout, 3, 1, flags,
+                  _lib.ptr(ws), nws)
+        torch.cuda.synchronize()
+        return N(y)
+
+    base = torch.randn(B, H, W, Cout, generator=gen).to(DEV)
+    scale = np.abs(ref).max()
+    v0, e0 = run(0, base), run(4, base)
+    assert np.abs(e0 - v0).max() <= 2e-6 * scale and np.abs(e0 - ref).max() <= 1e-5 * scale
+    v1, e1 = run(1, base), run(1 | 4, base)
+    assert np.abs(e1 - v1).max() <= 2e-6 * scale and np.abs(e1 - (ref + N(base))).max() <= 1e-5 * scale
+    assert np.array_equal(run(4, base), e0)  # deterministic split sums
+    xd[0, 3, 5, 1] = 0.3  # not a multiple of 1/16 in 8 bits
+    # (evf_conv3_b3s_plan: enough blocks, and no more K splits than the 8 slabs of scratch: else the voting kernels take the call, exactly)
+    applies = (B // 2) * (Cout // 64) * (Cin // 64) >= 128 and Cin // 64 <= 8
+    assert np.isnan(run(4, base)).any() == applies and not np.isnan(run(0, base)).any()
+
+
+@pytest.mark.parametrize("case", [(16, 64, 64, 64, 64, 0), (2, 132, 32, 80, 130, 4), (16, 260, 64, 32, 32, 2), (2, 1024, 256, 32, 32, 0),
+                                  (8, 96, 40, 48, 100, 0), (4, 520, 128, 32, 64, 4)])  # (shapes evf_conv3_b3x_plan accepts: >= 96 blocks)
+def test_exact_input_conv_on_spatial_tiles_and_behind_a_real_valued_head(case):
+    """csrc/evf_conv_b3small.hip, GEOM 1 (16 x 32 tiles of larger images) and the real-valued head: a decoder input whose first
+    channels are flow values (exact_from = 2 / 4: channels 0..15 run as the exact 3-way split) -- against the voting kernels and
+    float64; ragged tiles / channel counts; K splits; a broken promise behind exact_from gives NaN, real values IN the head do not."""
+    B, Cin, Cout, H, W, ef = case
+    gen = torch.Generator().manual_seed(Cin + W)
+    x = torch.randint(0, 33, (B, Cin, H, W), generator=gen).float() / 16.0 * (torch.rand(B, Cin, H, W, generator=gen) < 0.4)
+    if ef:
+        x[:, :ef] = torch.randn(B, ef, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) * 0.05
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None, padding=1).permute(0, 2, 3, 1).numpy()
+    xd = G(x.permute(0, 2, 3, 1).contiguous().numpy())
+    wd = G(w.numpy())
+    L = _lib.load()
+    wp = torch.empty(L.evf_conv2d_b3_packed_size(Cout, Cin, 3, 0), device=DEV)
+    _lib.call("evf_pack_conv2d_weight_b3", _lib.ptr(wd), Cout, Cin, 3, 0, Cin, 0, _lib.ptr(wp))
+    nws = L.evf_conv2d_b3_ws(B, H, W, Cout)
+    ws = torch.empty(max(nws, 1), device=DEV)
+
+    def run(flags):
+        y = torch.full((B, H, W, Cout), 5.0, device=DEV)
+        _lib.call("evf_conv2d_fwd_b3", _lib.ptr(xd), Cin, _lib.ptr(wp), None, _lib.ptr(y), Cout, B, H, W, Cin, Cout, 3, 1, flags,
+                  _lib.ptr(ws), nws)
+        torch.cuda.synchronize()
+        return N(y)
+
+    scale = np.abs(ref).max()
+    fl = 4 | (ef << 4)
+    v0, e0 = run(0), run(fl)
+    assert np.abs(e0 - v0).max() <= 3e-6 * scale and np.abs(e0 - ref).max() <= 1e-5 * scale, (np.abs(e0 - v0).max() / scale, np.abs(e0 - ref).max() / scale)
+    assert np.array_equal(run(fl), e0)
+    xd[0, H // 2, W // 2, Cin - 3] = 0.3  # behind exact_from: the promise is broken
+    assert np.isnan(run(fl)).any() and not np.isnan(run(0)).any()
+
+
+@pytest.mark.parametrize("case", [(2, 32, 24, 40), (1, 64, 17, 130), (2, 128, 9, 64), (1, 256, 5, 7)])
+def test_wgrad_of_a_four_channel_input_streams(case):
+    """3x3 stride-1 weight gradient with Cin = 4 (the real-valued head of a decoder input): k_wgrad9_fewin (a thread per output
+    channel sliding a 3 x 3 float4 window along a row) against float64, inside a wider weight tensor, accumulating."""
+    B, Cout, H, W = case
+    gen = torch.Generator().manual_seed(Cout + W)
+    Ctot = 12  # the activation is wider than the four channels of this call
+    x = torch.randn(B, Ctot, H, W, generator=gen)
+    gy = torch.randn(B, Cout, H, W, generator=gen) * 0.1
+    xd = G(x.permute(0, 2, 3, 1).contiguous().numpy())
+    gd = G(gy.permute(0, 2, 3, 1).contiguous().numpy())
+    ref = torch.nn.grad.conv2d_weight(x[:, :4].double(), (Cout, 4, 3, 3), gy.double(), padding=1).numpy()
+    L = _lib.load()
+    ws = torch.empty(max(L.evf_conv2d_wgrad_ws(B, H, W, 4, Cout, 3, 1), 1), device=DEV)
+    base = torch.randn(Cout, Ctot, 3, 3, generator=gen).to(DEV)
+    g_w = base.clone()
+    _lib.call("evf_conv2d_wgrad", _lib.ptr(xd), Ctot, _lib.ptr(gd), Cout, _lib.ptr(g_w), None, B, H, W, 4, Cout, 3, 1, Ctot, 0, 1 | 2,
+              _lib.ptr(ws))
+    want = N(base).astype(np.float64)
+    want[:, :4] += ref
+    assert np.abs(N(g_w) - want).max() <= 1e-5 * np.abs(ref).max()
+    assert np.array_equal(N(g_w)[:, 4:], N(base)[:, 4:])
+
+
+def test_wgrad_fused_tail_in_a_subprocess():
+    """The same test with EVF_WGRAD_FUSE=1 (the last block of a weight tile reduces the pixel splits itself)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_general.py"), "-m", "gpu", "-x", "-q", "-k",
+                          "wgrad_fused_slab_reduction"], capture_output=True, text=True, timeout=900, cwd=root,
+                         env=dict(os.environ, EVF_WGRAD_FUSE="1"))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def test_spike_provenance_tags_follow_the_evflownet_dataflow():
+    """hip_ops.spike_tag: cell outputs, residual sums, channel concatenations, zero paddings and ONE bilinear x2 blend keep the
+    "exactly representable in bf16" provenance (which lets conv_wgrad skip its verification pass); a flow prediction in front of
+    a concatenation moves `exact_from` behind it, a foreign op or a second blend drops the tag."""
+    from event_flow_amd.models.model_util import _centred
+
+    torch.manual_seed(0)
+    cell = cells.ConvLIF(8, 16, 3).to(DEV)
+    x = (torch.rand(1, 8, 12, 12, device=DEV) > 0.5).float()
+    out, st = cell(x, None)
+    assert hip_ops.spike_tag(out) == (1.0, 0) and hip_ops.spike_tag(x) is None
+    cell2 = cells.ConvLIF(16, 16, 3).to(DEV)
+    out2, _ = cell2(out, None, residual=out)
+    assert hip_ops.spike_tag(out2) == (2.0, 0)
+    flow = torch.randn(1, 2, 12, 12, device=DEV)
+    cat = hip_ops.concat_channels([flow, out, out2], pad=2)
+    assert hip_ops.spike_tag(cat) == (2.0, 2)
+    up = hip_ops.upsample2x_bilinear(cat)
+    assert hip_ops.spike_tag(up) == (2.0, 2)
+    assert hip_ops.spike_tag(hip_ops.upsample2x_bilinear(up)) is None  # 1/256 steps: no longer 8 significant bits
+    assert hip_ops.spike_tag(_centred(out, torch.zeros(1, 1, 13, 14))) == (1.0, 0)
+    assert hip_ops.spike_tag(out * 1.0) is None  # a foreign op: the verified path
+    # the values really are what the tag promises
+    v = up[:, 2:].detach()
+    assert torch.equal(v, v.bfloat16().float())
+
+
 def test_conv_bad_arguments_fail_loudly():
     x = torch.zeros(1, 4, 8, 8, device=DEV)
     w = torch.zeros(4, 4, 4, 4, device=DEV)  # even kernel sizes do not exist in the reference (padding k/2) and are not built
