@@ -132,6 +132,7 @@ NETWORK_SIGNATURES = {
     "evf_pretrace_fwd": [P, I, I, I, I, I, I, I, P, P, P],
     "evf_pretrace_bwd": [P, I, P, I, I, I, I, I, I, P, I, I, P],
     "evf_concat_channels": [P, P, P, I, L, P, I, P],
+    "evf_concat_up2_fwd": [P, P, P, I, I, I, I, P, I, P],
     "evf_upsample2x_fwd": [P, I, I, I, I, P, P],
     "evf_upsample2x_bwd": [P, I, I, I, I, P, P],
     "evf_upsample_nearest_fwd": [P, L, I, I, I, P, P],

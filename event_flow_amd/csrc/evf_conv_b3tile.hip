@@ -39,10 +39,19 @@ struct TileGeo {
   int lds, ldo;       // pixel strides (floats)
   int flip;           // 0 forward (tap (dy,dx) reads pixel (+dy-1,+dx-1)), 1 input gradient (reads (+1-dy,+1-dx))
   int tiles_y, tiles_x;
+  int nt_off;         // first 32-channel N tile of this launch (a wide N with a short remainder: 64-wide blocks + one 32-wide launch)
 };
 
+#ifndef B3T_WAVES_ATTR
+#define B3T_WAVES_ATTR
+#endif
+#ifdef B3T_UNROLL_OX  // (A/B: the three taps of a kernel row unrolled, so that the next tap's fragment reads may issue under this tap's MFMAs)
+#define B3T_OX_LOOP _Pragma("unroll")
+#else
+#define B3T_OX_LOOP _Pragma("unroll 1")
+#endif
 template <int NT>
-__global__ __launch_bounds__(512) void k_conv3_b3t(const float* __restrict__ src, const uint4* __restrict__ wp,
+__global__ __launch_bounds__(512) B3T_WAVES_ATTR void k_conv3_b3t(const float* __restrict__ src, const uint4* __restrict__ wp,
                                                    const float* __restrict__ bias, float* __restrict__ out, TileGeo g,
                                                    int accumulate, int ksplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -60,7 +69,7 @@ __global__ __launch_bounds__(512) void k_conv3_b3t(const float* __restrict__ src
   const int G64 = (g.K + 63) >> 6, KC = (g.K + 15) >> 4, ntiles = (g.N + 31) >> 5;
   // this block's N tiles (a tile past the end re-reads the last one; never stored)
   const long wtile = (long)(9 * G64) * B3_STAGE;
-  const int nt_base = (int)blockIdx.y * NT;
+  const int nt_base = g.nt_off + (int)blockIdx.y * NT;
 
   // ---- staging: global -> registers (before the matrix phase) -> LDS (after it)
   t_f32x4 pa[T_AITER];
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(512) void k_conv3_b3t(const float* __restrict__ src
     if (!inexact) {
 #pragma unroll 1
       for (int oy = 0; oy < 3; ++oy) {
-#pragma unroll 1
+        B3T_OX_LOOP
         for (int ox = 0; ox < 3; ++ox) {
           const int wtap = g.flip ? (2 - oy) * 3 + (2 - ox) : oy * 3 + ox;
           const char* ap = arow + (oy * T_HC + ox) * T_PSTRIDE;
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(512) void k_conv3_b3t(const float* __restrict__ src
     } else {
 #pragma unroll 1
       for (int oy = 0; oy < 3; ++oy) {
-#pragma unroll 1
+        B3T_OX_LOOP
         for (int ox = 0; ox < 3; ++ox) {
           const int wtap = g.flip ? (2 - oy) * 3 + (2 - ox) : oy * 3 + ox;
           const char* ap = arow + (oy * T_HC + ox) * T_PSTRIDE;
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(512) void k_conv3_b3t(const float* __restrict__ src
     float* orow = out + (((long)b * g.H + min(oy, g.H - 1)) * g.W + min(oxx, g.W - 1)) * g.ldo;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int n0 = (blockIdx.y * NT + t) * 32 + 4 * kg;
+      const int n0 = (nt_base + t) * 32 + 4 * kg;
       float4 oldv[4], bv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -274,23 +283,36 @@ int evf_conv3_b3t_launch(const float* src, int lds, const void* wp, const float*
   g.B = B, g.H = H, g.W = W, g.K = K, g.N = N, g.lds = lds, g.ldo = ldo, g.flip = flip;
   g.tiles_y = evf_cdiv(H, T_ROWS), g.tiles_x = evf_cdiv(W, T_COLS);
   const int ntile = B * g.tiles_y * g.tiles_x, gx = 8 * evf_cdiv(ntile, 8);
+  g.nt_off = 0;
+  // N = 64 q + r with 0 < r <= 32 (a decoder's input gradient: 130 / 258 / 514 channels + alignment): q blocks of 64 channels, and
+  // the remainder as ONE launch of 32-channel blocks instead of a 64-channel block that is 94 % padding (LIF-EV-FlowNet, 132
+  // channels at 256 x 256: 3 x 64 -> 2 x 64 + 32)
+  const int rem = N % 64;
+  const bool tail32 = N > 64 && rem > 0 && rem <= 32;
+  static bool once2 = false, once1 = false;
+  const size_t smem2 = 3 * T_PLANE + 2 * 27 * 1024, smem1 = 3 * T_PLANE + 27 * 1024;
+  if (!once2) {
+    (void)hipFuncSetAttribute((const void*)k_conv3_b3t<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+    once2 = true;
+  }
+  if (!once1) {
+    (void)hipFuncSetAttribute((const void*)k_conv3_b3t<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
+    once1 = true;
+  }
+  if (tail32) {
+    hipLaunchKernelGGL((k_conv3_b3t<2>), dim3(gx, N / 64, ksplit), dim3(512), smem2, st, src, (const uint4*)wp, bias, out, g, accumulate,
+                       ksplit);
+    g.nt_off = 2 * (N / 64);
+    hipLaunchKernelGGL((k_conv3_b3t<1>), dim3(gx, 1, ksplit), dim3(512), smem1, st, src, (const uint4*)wp, bias, out, g, accumulate,
+                       ksplit);
+    return evf_status();
+  }
   if (N > 32) {
-    const size_t smem = 3 * T_PLANE + 2 * 27 * 1024;
-    static bool once = false;
-    if (!once) {
-      (void)hipFuncSetAttribute((const void*)k_conv3_b3t<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      once = true;
-    }
+    const size_t smem = smem2;
     hipLaunchKernelGGL((k_conv3_b3t<2>), dim3(gx, evf_cdiv(N, 64), ksplit), dim3(512), smem, st, src, (const uint4*)wp, bias, out,
                        g, accumulate, ksplit);
   } else {
-    const size_t smem = 3 * T_PLANE + 27 * 1024;
-    static bool once = false;
-    if (!once) {
-      (void)hipFuncSetAttribute((const void*)k_conv3_b3t<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      once = true;
-    }
-    hipLaunchKernelGGL((k_conv3_b3t<1>), dim3(gx, 1, ksplit), dim3(512), smem, st, src, (const uint4*)wp, bias, out, g, accumulate,
+    hipLaunchKernelGGL((k_conv3_b3t<1>), dim3(gx, 1, ksplit), dim3(512), smem1, st, src, (const uint4*)wp, bias, out, g, accumulate,
                        ksplit);
   }
   return evf_status();

@@ -409,11 +409,14 @@ __global__ void k_neuron_bwd(const float4* __restrict__ g_v_out, const float4* _
   // ... the block that draws the LAST ticket (word NG_REP * 4096 of the scratch) does what k_ng_finish did as a launch of its own:
   // replicas -> outputs, scratch and ticket handed back zeroed (17 launches of ~4 us + their boundaries per EV-FlowNet step)
   __shared__ int s_fin;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (each thread: its atomics are out; one agent-scope fence per block below)
+  // The replica sums are device-scope ATOMICS (performed at the memory side, never cached): it is enough that every thread's
+  // atomics have completed (workgroup-scope release = a wait, no cache maintenance) before thread 0 draws the ticket.  An
+  // agent-scope release fence here writes the XCD's whole dirty L2 back -- the 134 MB of g_cur / g_v_prev this kernel has just
+  // stored -- once per block: +45 us on the 256 x 256 layer when tried.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   int* ticket = (int*)(ws + (size_t)NG_REP * 4096);
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const int t = atomicAdd(ticket, 1);
     s_fin = t + 1 == (int)gridDim.x;
     if (s_fin) {
@@ -852,6 +855,67 @@ extern "C" int evf_concat_channels(const void* const* src, const int* C, const i
   if (ldo < tot) return EVF_EINVAL;
   hipLaunchKernelGGL(k_concat_channels, dim3(evf_cdiv(npix * tot, 256L)), dim3(256), 0, EVF_STREAM(stream), p, (long)npix, tot, out,
                      ldo);
+  return evf_status();
+}
+
+// The same concatenation READ THROUGH the bilinear x2 of a decoder (spiking_submodules.py:1011 on the cat of unet.py:303-306): the
+// low-resolution concatenation is never written -- a thread blends the four source pixels of its two output channels straight from
+// the part they live in (all part offsets of the decoder inputs are even: [2 flow | C | C | 2 zeros]).  Same association as
+// k_up2_fwd / ATen's upsample_bilinear2d.
+__global__ void k_concat_up2_fwd(CatParts p, int B, int H, int W, int Ctot, float* __restrict__ out, int ldo) {
+  // one thread = FOUR output channels of one pixel (one 16-byte store: the output is what this kernel moves, 4x the input), read
+  // as two channel pairs that may come from different parts (the part offsets are even, not multiples of four)
+  const int Q = Ctot >> 2;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int OH = 2 * H, OW = 2 * W;
+  if (idx >= (long)B * OH * OW * Q) return;
+  const int c = 4 * (int)(idx % Q);
+  const long pix = idx / Q;
+  const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((long)OW * OH));
+  int y0, y1, x0, x1;
+  float wy, wx;
+  up2_src(oy, H, y0, y1, wy);
+  up2_src(ox, W, x0, x1, wx);
+  const long p00 = ((long)b * H + y0) * W + x0, p01 = ((long)b * H + y0) * W + x1, p10 = ((long)b * H + y1) * W + x0,
+             p11 = ((long)b * H + y1) * W + x1;
+  float2 r[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int ch = c + 2 * h;
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 6; ++j) k += (j < p.n && ch >= p.off[j]) ? 1 : 0;
+    const float* s = p.src[k];
+    // (a null part = zero padding: a valid dummy address, selected away -- no load under a branch)
+    const float* q = (s ? s : p.src[0]) + (s ? ch - p.off[k] : 0);
+    const long ld = s ? p.ld[k] : p.ld[0];
+    const float2 a = *(const float2*)(q + p00 * ld), bq = *(const float2*)(q + p01 * ld);
+    const float2 cc = *(const float2*)(q + p10 * ld), d = *(const float2*)(q + p11 * ld);
+    const float2 v = up_mix(1.f - wy, up_mix(1.f - wx, a, wx, bq), wy, up_mix(1.f - wx, cc, wx, d));
+    r[h] = s ? v : make_float2(0.f, 0.f);
+  }
+  *(float4*)(out + pix * ldo + c) = make_float4(r[0].x, r[0].y, r[1].x, r[1].y);
+}
+// parts: NHWC [B,H,W,C[k]] with pixel stride ld[k]; out [B,2H,2W,sum C] with pixel stride ldo.  Every C[k], ld[k] even, sum C and
+// ldo multiples of four, part pointers 8-byte and `out` 16-byte aligned, the first part not null.
+extern "C" int evf_concat_up2_fwd(const void* const* src, const int* C, const int* ld, int n, int B, int H, int W, float* out, int ldo,
+                                  void* stream) {
+  if (!src || !C || !ld || !out || n <= 0 || n > 6 || !src[0] || B <= 0 || H <= 0 || W <= 0 || (ldo & 3) || (((uintptr_t)out) & 15))
+    return EVF_EINVAL;
+  CatParts p;
+  int tot = 0;
+  for (int k = 0; k < 6; ++k) {
+    p.src[k] = k < n ? (const float*)src[k] : nullptr;
+    p.C[k] = k < n ? C[k] : 0;
+    p.ld[k] = k < n ? ld[k] : 0;
+    p.off[k] = tot;
+    if (k < n && (C[k] <= 0 || (C[k] & 1) || (src[k] && (ld[k] < C[k] || (ld[k] & 1) || (((uintptr_t)src[k]) & 7))))) return EVF_EINVAL;
+    tot += p.C[k];
+  }
+  p.off[6] = tot, p.n = n;
+  if (ldo < tot || (tot & 3)) return EVF_EINVAL;
+  const long total = (long)B * 4 * H * W * (tot / 4);
+  hipLaunchKernelGGL(k_concat_up2_fwd, dim3(evf_cdiv(total, 256L)), dim3(256), 0, EVF_STREAM(stream), p, B, H, W, tot, out, ldo);
   return evf_status();
 }
 

@@ -561,13 +561,16 @@ __global__ __launch_bounds__(64 * WGR_G) void k_wgrad_reduce(const float* __rest
   const long ec = e < per ? e : per - 1;
   const float* __restrict__ p = slab + ec;
   float s0 = 0.f, s1 = 0.f;
+  float s2 = 0.f, s3 = 0.f;
   int k = ty;
-  for (; k + G < nsplit; k += 2 * G) {
+  for (; k + 3 * G < nsplit; k += 4 * G) {  // four independent loads in flight (hundreds of slabs of a few outputs: latency)
     s0 += p[(long)k * per];
     s1 += p[(long)(k + G) * per];
+    s2 += p[(long)(k + 2 * G) * per];
+    s3 += p[(long)(k + 3 * G) * per];
   }
-  if (k < nsplit) s0 += p[(long)k * per];
-  red[ty][tx] = s0 + s1;
+  for (; k < nsplit; k += G) s0 += p[(long)k * per];
+  red[ty][tx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (ty != 0 || e >= per) return;
   float s = 0.f;
@@ -592,6 +595,10 @@ __global__ __launch_bounds__(64 * WGR_G) void k_wgrad_reduce(const float* __rest
 __global__ __launch_bounds__(256) void k_wgrad9_fewin(const float* __restrict__ x, const float* __restrict__ gy,
                                                       float* __restrict__ slab, int B, int H, int W, int Cout, int ldx, int ldg,
                                                       int nseg, long nitems) {
+  // xs: the three input rows of every row segment of the block, columns c0 - 1 .. c0 + FW_SEG (zero outside the image), staged
+  // once by the whole block -- the Cout threads of a segment then read them as LDS broadcasts instead of issuing the same three
+  // global loads each (4 -> 1 global loads per pixel and thread); red: the block's 256 / Cout partial sums meet here afterwards
+  __shared__ float4 xs[8 * 3 * (FW_SEG + 2)];
   __shared__ float red[256 * 36];
   const int tid = threadIdx.x, co = tid % Cout, grp = tid / Cout, NG = 256 / Cout;
   float acc[9][4];
@@ -599,46 +606,46 @@ __global__ __launch_bounds__(256) void k_wgrad9_fewin(const float* __restrict__ 
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[t][j] = 0.f;
-  for (long it = (long)blockIdx.x * NG + grp; it < nitems; it += (long)gridDim.x * NG) {
-    const int seg = (int)(it % nseg);
-    const long row = it / nseg;  // b * H + y
-    const int y = (int)(row % H);
-    const long b = row / H;
-    const int c0 = seg * FW_SEG, c1 = min(c0 + FW_SEG, W);
-    const float* xb = x + (b * H) * (long)W * ldx;
-    const float* gr = gy + (row * W) * (long)ldg + co;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // clamped row pointers + validity (no load under a branch)
-    const bool rv[3] = {y >= 1, true, y + 1 < H};
-    const float* xr[3] = {xb + (long)max(y - 1, 0) * W * ldx, xb + (long)y * W * ldx, xb + (long)min(y + 1, H - 1) * W * ldx};
-    float4 w0[3], w1[3], w2[3];  // columns c - 1, c, c + 1 of the three rows
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const float4 a = *(const float4*)(xr[r] + (long)max(c0 - 1, 0) * ldx), bq = *(const float4*)(xr[r] + (long)c0 * ldx);
-      w0[r] = (rv[r] && c0 >= 1) ? a : z4;
-      w1[r] = rv[r] ? bq : z4;
+  constexpr int RW = FW_SEG + 2;
+  for (long it0 = (long)blockIdx.x * NG; it0 < nitems; it0 += (long)gridDim.x * NG) {  // (uniform trip count)
+    __syncthreads();
+    for (int idx = tid; idx < NG * 3 * RW; idx += 256) {
+      const int gi = idx / (3 * RW), r3 = idx - gi * 3 * RW, r = r3 / RW, cc = r3 - r * RW;
+      const long it = it0 + gi;
+      const long itc = it < nitems ? it : nitems - 1;
+      const int seg = (int)(itc % nseg);
+      const long row = itc / nseg;
+      const int y = (int)(row % H) + r - 1, c = seg * FW_SEG + cc - 1;
+      const long b = row / H;
+      const bool ok = it < nitems && y >= 0 && y < H && c >= 0 && c < W;
+      const float4 v = *(const float4*)(x + ((b * H + min(max(y, 0), H - 1)) * (long)W + min(max(c, 0), W - 1)) * ldx);
+      xs[idx] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-#pragma unroll 4
-    for (int c = c0; c < c1; ++c) {
-      const float g = gr[(long)c * ldg];
+    __syncthreads();
+    const long it = it0 + grp;
+    if (it < nitems) {
+      const int seg = (int)(it % nseg);
+      const long row = it / nseg;
+      const int c0 = seg * FW_SEG, n = min(FW_SEG, W - c0);
+      const float* gr = gy + (row * W + c0) * (long)ldg + co;
+      const float4* xr = xs + grp * 3 * RW;
+#pragma unroll 8
+      for (int c = 0; c < n; ++c) {
+        const float g = gr[(long)c * ldg];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const float4 n = *(const float4*)(xr[r] + (long)min(c + 1, W - 1) * ldx);
-        w2[r] = (rv[r] && c + 1 < W) ? n : z4;
-      }
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        acc[3 * r + 0][0] = __fmaf_rn(w0[r].x, g, acc[3 * r + 0][0]), acc[3 * r + 0][1] = __fmaf_rn(w0[r].y, g, acc[3 * r + 0][1]);
-        acc[3 * r + 0][2] = __fmaf_rn(w0[r].z, g, acc[3 * r + 0][2]), acc[3 * r + 0][3] = __fmaf_rn(w0[r].w, g, acc[3 * r + 0][3]);
-        acc[3 * r + 1][0] = __fmaf_rn(w1[r].x, g, acc[3 * r + 1][0]), acc[3 * r + 1][1] = __fmaf_rn(w1[r].y, g, acc[3 * r + 1][1]);
-        acc[3 * r + 1][2] = __fmaf_rn(w1[r].z, g, acc[3 * r + 1][2]), acc[3 * r + 1][3] = __fmaf_rn(w1[r].w, g, acc[3 * r + 1][3]);
-        acc[3 * r + 2][0] = __fmaf_rn(w2[r].x, g, acc[3 * r + 2][0]), acc[3 * r + 2][1] = __fmaf_rn(w2[r].y, g, acc[3 * r + 2][1]);
-        acc[3 * r + 2][2] = __fmaf_rn(w2[r].z, g, acc[3 * r + 2][2]), acc[3 * r + 2][3] = __fmaf_rn(w2[r].w, g, acc[3 * r + 2][3]);
-        w0[r] = w1[r], w1[r] = w2[r];
+        for (int r = 0; r < 3; ++r) {
+          const float4 w0 = xr[r * RW + c], w1 = xr[r * RW + c + 1], w2 = xr[r * RW + c + 2];
+          acc[3 * r + 0][0] = __fmaf_rn(w0.x, g, acc[3 * r + 0][0]), acc[3 * r + 0][1] = __fmaf_rn(w0.y, g, acc[3 * r + 0][1]);
+          acc[3 * r + 0][2] = __fmaf_rn(w0.z, g, acc[3 * r + 0][2]), acc[3 * r + 0][3] = __fmaf_rn(w0.w, g, acc[3 * r + 0][3]);
+          acc[3 * r + 1][0] = __fmaf_rn(w1.x, g, acc[3 * r + 1][0]), acc[3 * r + 1][1] = __fmaf_rn(w1.y, g, acc[3 * r + 1][1]);
+          acc[3 * r + 1][2] = __fmaf_rn(w1.z, g, acc[3 * r + 1][2]), acc[3 * r + 1][3] = __fmaf_rn(w1.w, g, acc[3 * r + 1][3]);
+          acc[3 * r + 2][0] = __fmaf_rn(w2.x, g, acc[3 * r + 2][0]), acc[3 * r + 2][1] = __fmaf_rn(w2.y, g, acc[3 * r + 2][1]);
+          acc[3 * r + 2][2] = __fmaf_rn(w2.z, g, acc[3 * r + 2][2]), acc[3 * r + 2][3] = __fmaf_rn(w2.w, g, acc[3 * r + 2][3]);
+        }
       }
     }
   }
-  // the NG rows of the block meet in LDS: red[grp][tap * 4 + ci][co]
+  // the NG segments of the block meet in LDS: red[grp][tap * 4 + ci][co]
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -660,6 +667,51 @@ static int wg_fewin_blocks(int B, int H, int W, int Cout) {
   const long nitems = (long)B * H * evf_cdiv(W, FW_SEG);
   const long nb = evf_cdiv(nitems, 256 / Cout);
   return (int)(nb < 1024 ? nb : 1024);
+}
+
+// The same reduction with COALESCED gradient accesses, for the big weights: k_wgrad_reduce walks the slab layout [tap][ci][co], so
+// the 64 lanes of a wave write (and, accumulating, read) 64 different lines of gw [co][ci][tap] -- 18 KB apart for 512 input
+// channels -- and every line is touched by 32 different waves: 27 us for the 56 MB of a 512 x 512 layer (2.1 TB/s), 0.47 ms per
+// LIF-EV-FlowNet step.  Here a block owns 16 output x 32 input channels x 9 taps: the slabs are read in 64-byte runs along co
+// and summed over the splits (index order, four loads in flight), the tile is transposed in LDS, and each output channel's
+// 32 x 9 = 288 consecutive floats of gw go out (and come in) as whole lines.
+#define WRT_CO 16
+#define WRT_CI 32
+__global__ __launch_bounds__(256) void k_wgrad_reduce_t(const float* __restrict__ slab, int nsplit, int Cin, int Cout, int cin_total,
+                                                        int cin_off, int accumulate, float* __restrict__ gw, int* __restrict__ clear_flags) {
+  __shared__ float tile[WRT_CO * (WRT_CI * 9 + 1)];
+  if (clear_flags && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) clear_flags[threadIdx.x] = 0;
+  const int tid = threadIdx.x, co0 = blockIdx.x * WRT_CO, ci0 = blockIdx.y * WRT_CI;
+  const long per = (long)9 * Cin * Cout;
+  constexpr int NE = WRT_CO * WRT_CI * 9, NJ = NE / 256, TP = WRT_CI * 9 + 1;
+#pragma unroll 2
+  for (int j = 0; j < NJ; ++j) {
+    const int idx = tid + 256 * j, co_l = idx % WRT_CO, r = idx / WRT_CO, ci_l = r % WRT_CI, tap = r / WRT_CI;
+    const int co = co0 + co_l, ci = ci0 + ci_l;
+    const bool ok = co < Cout && ci < Cin;
+    const float* __restrict__ p = slab + ((long)tap * Cin + (ok ? ci : 0)) * Cout + (ok ? co : 0);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int k = 0;
+    for (; k + 3 < nsplit; k += 4) {
+      a0 += p[(long)k * per];
+      a1 += p[(long)(k + 1) * per];
+      a2 += p[(long)(k + 2) * per];
+      a3 += p[(long)(k + 3) * per];
+    }
+    for (; k < nsplit; ++k) a0 += p[(long)k * per];
+    tile[co_l * TP + ci_l * 9 + tap] = ok ? (a0 + a1) + (a2 + a3) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll 2
+  for (int j = 0; j < NJ; ++j) {
+    const int idx = tid + 256 * j, r = idx % (WRT_CI * 9), co_l = idx / (WRT_CI * 9), ci_l = r / 9;
+    const int co = co0 + co_l, ci = ci0 + ci_l;
+    if (co < Cout && ci < Cin && cin_off + ci < cin_total) {
+      float* d = gw + ((long)co * cin_total + cin_off + ci0) * 9 + r;
+      const float v = tile[co_l * TP + r];
+      *d = accumulate ? *d + v : v;
+    }
+  }
 }
 
 struct Wg9Plan {
@@ -830,6 +882,14 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
     int rc = evf_status();
     if (rc) return rc;
     const long per = (long)9 * Cin * Cout;
+    static const bool rt_on = !(getenv("EVF_WGRAD_REDUCE_T") && !strcmp(getenv("EVF_WGRAD_REDUCE_T"), "0"));
+    // big weights with few splits: the transposing reduction (coalesced gradient lines); many splits of a small weight keep the
+    // 16 split groups per output of k_wgrad_reduce
+    if (rt_on && p.nsplit <= 32 && (long)evf_cdiv(Cout, WRT_CO) * evf_cdiv(Cin, WRT_CI) >= 128) {
+      hipLaunchKernelGGL(k_wgrad_reduce_t, dim3(evf_cdiv(Cout, WRT_CO), evf_cdiv(Cin, WRT_CI)), dim3(256), 0, st, ws, p.nsplit, Cin,
+                         Cout, cin_total, cin_off, accumulate, g_w, (int*)redo);
+      return evf_status();
+    }
     const int rg = p.nsplit >= 16 ? 16 : (p.nsplit >= 8 ? 8 : (p.nsplit >= 4 ? 4 : (p.nsplit >= 2 ? 2 : 1)));
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(evf_cdiv(per, 64)), dim3(64 * rg), 0, st, ws, p.nsplit, Cin, Cout, cin_total,
                        cin_off, accumulate, g_w, (int*)redo);

@@ -1166,6 +1166,69 @@ def concat_channels(parts, pad=0):
     return out
 
 
+class _ConcatUp2(torch.autograd.Function):
+    """upsample2x_bilinear(concat_channels(parts, pad)) in ONE kernel (evf_concat_up2_fwd): the low-resolution concatenation is
+    never written.  Backward: the transposed up-sampling of the whole gradient, then each part's channel slice (views)."""
+
+    @staticmethod
+    def forward(ctx, pad, *parts):
+        ps = [to_nhwc(p) for p in parts]
+        B, H, W = ps[0].shape[0], ps[0].shape[1], ps[0].shape[2]
+        Cs = [p.shape[3] for p in ps] + ([pad] if pad else [])
+        out = _new((B, 2 * H, 2 * W, sum(Cs)), ps[0].device)
+        n = len(Cs)
+        src = (ctypes.c_void_p * n)(*([_lib.ptr_strided(p) for p in ps] + ([None] if pad else [])))
+        _lib.call("evf_concat_up2_fwd", src, (ctypes.c_int * n)(*Cs), (ctypes.c_int * n)(*([p.stride(2) for p in ps] + ([0] if pad else []))),
+                  n, B, H, W, _lib.ptr(out), out.stride(2))
+        ctx.Cs = [p.shape[3] for p in ps]
+        ctx.geom = (B, H, W, sum(Cs))
+        return from_nhwc(out)
+
+    @staticmethod
+    def backward(ctx, g_y):
+        B, H, W, Ct = ctx.geom
+        g = to_nhwc(g_y)
+        gx = _new((B, H, W, Ct), g.device)
+        _lib.call("evf_upsample2x_bwd", _lib.ptr(g), B, H, W, Ct, _lib.ptr(gx))
+        outs, off = [], 0
+        for c in ctx.Cs:
+            outs.append(from_nhwc(gx[..., off:off + c]))
+            off += c
+        return (None,) + tuple(outs)
+
+
+CONCAT_UP2 = os.environ.get("EVF_CONCAT_UP2", "1") != "0"
+
+
+def concat_up2(parts, pad=0):
+    """upsample2x_bilinear(concat_channels(parts, pad)); one kernel when every part has an even channel count and pixel stride."""
+    ok = (CONCAT_UP2 and pad % 2 == 0 and all(p.shape[1] % 2 == 0 and p.shape[2:] == parts[0].shape[2:] for p in parts)
+          and (sum(p.shape[1] for p in parts) + pad) % 4 == 0)
+    if not ok:
+        return upsample2x_bilinear(concat_channels(parts, pad))
+    out = _ConcatUp2.apply(int(pad), *parts)
+    cat_like = _concat_tag(parts)
+    if cat_like is not None and all(getattr(p, "_evf_spike_int", True) for p in parts if spike_tag(p) is not None):
+        set_spike_tag(out, cat_like[0], cat_like[1])
+        out._evf_spike_int = False
+    return out
+
+
+def _concat_tag(parts):
+    """Provenance of a channel concatenation: (bound, exact_from) or None."""
+    off, exact_from, bound = 0, 0, 0.0
+    for p in parts:
+        tag = spike_tag(p)
+        if tag is None:
+            exact_from = off + p.shape[1]
+        else:
+            bound = max(bound, tag[0])
+            if tag[1] > 0:
+                exact_from = off + tag[1]
+        off += p.shape[1]
+    return (max(bound, 1.0), exact_from) if exact_from < off else None
+
+
 class _Add(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):

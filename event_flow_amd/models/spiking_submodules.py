@@ -297,6 +297,10 @@ class SpikingUpsampleConvLayer(nn.Module):
         x_up = hip_ops.upsample2x_bilinear(x)
         return self.conv2d(x_up, prev_state)
 
+    def forward_upsampled(self, x_up, prev_state):
+        """The cell on an input that is up-sampled already (models/unet.py builds cat + bilinear x2 in one kernel)."""
+        return self.conv2d(x_up, prev_state)
+
 
 class SpikingTransposedConvLayer(nn.Module):
     """Reference :1016-1065 (use_upsample_conv=False).  Not on the accelerated path."""

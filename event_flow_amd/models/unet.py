@@ -118,6 +118,19 @@ class BaseUNet(nn.Module):
                                                    activation=self.final_activation, norm=self.norm,
                                                    w_scale=self.w_scale_pred), self.num_encoders)
 
+    def _decoder_parts(self, x, skip, prediction, decoder):
+        """The parts of cat(prediction, cat(x, skip)) and the alignment padding behind them (see _decoder_input)."""
+        from .model_util import _centred
+
+        parts = [_centred(x, skip), skip]
+        pad = 0
+        if prediction is not None:
+            parts = [_centred(prediction, skip)] + parts
+            conv = getattr(decoder, "conv2d", None)
+            if conv is not None and getattr(conv, "kind", "ann") in ("lif", "alif", "ann"):
+                pad = (-sum(p.shape[1] for p in parts)) % 4
+        return parts, pad
+
     def _decoder_input(self, x, skip, prediction, decoder):
         """cat(prediction, cat(x, skip)) (unet.py:303-306); with 2C+2 channels two zero channels keep the activation
         16-byte aligned for the conv kernels (the packed weight is zero there; cells with a pre-synaptic trace
@@ -141,7 +154,15 @@ class BaseUNet(nn.Module):
     def _decode(self, x, blocks, stateful, offset=0):
         """Decoders + per-scale predictions, coarse to fine (unet.py:298-311, :402-415, :455-465)."""
         predictions = []
+        from . import hip_ops
+
         for i, (decoder, pred) in enumerate(zip(self.decoders, self.preds)):
+            if stateful and self.skip_type == "concat" and hasattr(decoder, "forward_upsampled"):
+                # concatenation and bilinear x2 in one kernel: the low-resolution cat is never written
+                parts, pad = self._decoder_parts(x, blocks[-1 - i], predictions[-1] if i else None, decoder)
+                x, self.states[offset + i] = decoder.forward_upsampled(hip_ops.concat_up2(parts, pad), self.states[offset + i])
+                predictions.append(pred(x))
+                continue
             x = self._decoder_input(x, blocks[-1 - i], predictions[-1] if i else None, decoder)
             if stateful:
                 x, self.states[offset + i] = decoder(x, self.states[offset + i])

@@ -607,6 +607,12 @@ int evf_upsample2x_bwd(const float* g_y, int B, int H, int W, int C, float* g_x,
  * (models/unet.py:303-306, model_util.py:14-19).  src[k] null = C[k] channels of zeros (alignment padding). */
 int evf_concat_channels(const void* const* src, const int* C, const int* ld, int n, int64_t npix, float* out, int ldo,
                         void* stream);
+/* The concatenation above READ THROUGH a bilinear x2 up-sampling (a decoder's input, spiking_submodules.py:1011 on the cat of
+ * models/unet.py:303-306): parts [B,H,W,C[k]] (pixel stride ld[k]) -> out [B,2H,2W,sum C] without writing the low-resolution
+ * concatenation.  All C[k], ld[k] even, sum C and ldo multiples of four (a thread stores four channels read as two pairs); a null
+ * part (not the first) = zero padding. */
+int evf_concat_up2_fwd(const void* const* src, const int* C, const int* ld, int n, int B, int H, int W, float* out,
+                       int ldo, void* stream);
 /* F.interpolate(scale_factor=f) (nearest) of `planes` images [h][w] -> [h f][w f]
  * (models/model.py:529-539) and its adjoint. */
 int evf_upsample_nearest_fwd(const float* x, int64_t planes, int h, int w, int factor, float* y,

@@ -335,6 +335,29 @@ def test_wgrad_of_a_four_channel_input_streams(case):
     assert np.array_equal(N(g_w)[:, 4:], N(base)[:, 4:])
 
 
+def test_concat_up2_in_one_kernel_equals_the_two_kernels():
+    """hip_ops.concat_up2 = upsample2x_bilinear(concat_channels(parts, pad)) bit for bit (the same blend per element), its gradients
+    to the parts equal too; odd channel counts fall back to the two kernels."""
+    torch.manual_seed(3)
+    B, H, W = 2, 9, 13
+    parts = [torch.randn(B, c, H, W, device=DEV) for c in (2, 16, 16)]
+    a = [p.clone().requires_grad_(True) for p in parts]
+    b = [p.clone().requires_grad_(True) for p in parts]
+    y1 = hip_ops.concat_up2(a, 2)
+    y2 = hip_ops.upsample2x_bilinear(hip_ops.concat_channels(b, 2))
+    assert y1.shape == y2.shape == (B, 36, 2 * H, 2 * W) and torch.equal(y1, y2)
+    g = torch.randn_like(y1)
+    y1.backward(g)
+    y2.backward(g)
+    for p, q in zip(a, b):
+        assert torch.equal(p.grad, q.grad)
+    ref = torch.nn.functional.interpolate(torch.cat(parts + [torch.zeros(B, 2, H, W, device=DEV)], 1), scale_factor=2, mode="bilinear",
+                                          align_corners=False)
+    assert torch.allclose(y1, ref, atol=1e-6)
+    odd = [torch.randn(B, 3, H, W, device=DEV), torch.randn(B, 5, H, W, device=DEV)]
+    assert torch.equal(hip_ops.concat_up2(odd), hip_ops.upsample2x_bilinear(hip_ops.concat_channels(odd)))
+
+
 def test_wgrad_fused_tail_in_a_subprocess():
     """The same test with EVF_WGRAD_FUSE=1 (the last block of a weight tile reduces the pixel splits itself)."""
     import os
