@@ -133,6 +133,9 @@ NETWORK_SIGNATURES = {
     "evf_pretrace_bwd": [P, I, P, I, I, I, I, I, I, P, I, I, P],
     "evf_concat_channels": [P, P, P, I, L, P, I, P],
     "evf_concat_up2_fwd": [P, P, P, I, I, I, I, P, I, P],
+    "evf_head1x1_ws": [I, I],
+    "evf_head1x1_fwd": [P, I, P, P, I, L, I, I, P, I, P],
+    "evf_head1x1_bwd": [P, I, P, I, P, L, P, I, L, I, I, P, I, P, P, I, P, P],
     "evf_upsample2x_fwd": [P, I, I, I, I, P, P],
     "evf_upsample2x_bwd": [P, I, I, I, I, P, P],
     "evf_upsample_nearest_fwd": [P, L, I, I, I, P, P],
@@ -153,7 +156,7 @@ NETWORK_SIGNATURES = {
     "evf_gru_out_bwd": [P, P, P, P, L, P, P, P, P],
     "evf_gru_gates_bwd": [P, P, P, L, P, P, P],
 }
-RESTYPES = {"evf_comm_last_error": ctypes.c_char_p, "evf_conv2d_packed_size": ctypes.c_int64, "evf_conv2d_b3_packed_size": ctypes.c_int64, "evf_conv2d_b3_ws": ctypes.c_int64, "evf_conv2d_wgrad_ws": ctypes.c_int64, "evf_cm_loss_ws": ctypes.c_int64}
+RESTYPES = {"evf_head1x1_ws": ctypes.c_int64, "evf_comm_last_error": ctypes.c_char_p, "evf_conv2d_packed_size": ctypes.c_int64, "evf_conv2d_b3_packed_size": ctypes.c_int64, "evf_conv2d_b3_ws": ctypes.c_int64, "evf_conv2d_wgrad_ws": ctypes.c_int64, "evf_cm_loss_ws": ctypes.c_int64}
 SIGNATURES.update(NETWORK_SIGNATURES)
 
 _lib = None

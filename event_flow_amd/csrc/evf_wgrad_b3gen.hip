@@ -21,12 +21,26 @@
 
 typedef float w_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 w_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short wb_s16x4 __attribute__((ext_vector_type(4)));
+typedef short wb_s16x8 __attribute__((ext_vector_type(8)));
+#define WB_LDS __attribute__((address_space(3)))
 
 #define WB_T 8                    // tile rows = tile columns
 #define WB_HP ((WB_T + 2) * (WB_T + 2))  // 100 halo pixels
 #define WB_ROWB 48                // bytes per halo row and channel: element 7 + hc, 16-byte aligned at hc = 1
 #define WB_XP ((WB_T + 2) * WB_ROWB + 16)  // 496: channel pitch of the x image (conflict-free b128 fragment reads)
 #define WB_GP (WB_T * WB_T * 2 + 16)       // 144: channel pitch of a g plane
+// WB_TR (default): the LDS images stay in the NATURAL [pixel][channel] order -- a thread drops the four bf16 of its float4 with ONE
+// 8-byte store (the [channel][pixel] images above take four 2-byte stores into four channel rows: 36 per thread and tile, with
+// 8-way bank conflicts; a probe build without them: LIF-EV-FlowNet weight gradients 2.12 -> 1.72 ms per step) -- and the
+// transposition happens in the READ: ds_read_b64_tr_b16 (gfx950) hands lane c of a 16-lane group column c of a [4 pixels][16
+// channels] block, i.e. four consecutive pixels of one channel = half an MFMA fragment.  A pixel pitch of 64 (mod 256) bytes puts
+// the 2 x 4 row pieces a half-wave reads on distinct bank slots; the tap's column shift is just another base address (no
+// funnel shifts).
+#ifndef WB_TR
+#define WB_TR 1
+#endif
+#define WB_PPITCH(CH) ((CH) == 64 ? 192 : 64)  // bytes per pixel of a [pixel][CH channels] bf16 image
 
 struct WgB3Geo {
   int B, H, W, Cin, Cout, ldx, ldg;
@@ -60,9 +74,17 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
   constexpr int NLX = (WB_HP * XQ + 575) / 576;           // x float4 loads per thread
   constexpr int NLG = (WB_T * WB_T * GQ + 575) / 576;     // g float4 loads per thread
   constexpr int GPL = 32 * NT * WB_GP;                    // bytes per g plane
+#if WB_TR
+  constexpr int XPP = WB_PPITCH(32 * CT), GPP = WB_PPITCH(32 * NT);  // pixel pitches
+  constexpr int GPL_TR = WB_T * WB_T * GPP;                             // bytes per g plane
+  char* s_x = smem;                                       // [100 halo pixels][XPP]
+  char* s_g = smem + WB_HP * XPP;                         // [3 planes][64 pixels][GPP]
+  float* s_b = (float*)(s_g + 3 * GPL_TR);                // [32 NT] bias partial sums
+#else
   char* s_x = smem;                                       // [32 CT channels][WB_XP]
   char* s_g = smem + 32 * CT * WB_XP;                     // [3 planes][32 NT channels][WB_GP]
   float* s_b = (float*)(s_g + 3 * GPL);                   // [32 NT] bias partial sums
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, row = lane & 31, kg = lane >> 5;
   const int cit = blockIdx.y % g.n_ct, cot = blockIdx.y / g.n_ct;
   const int ci0 = cit * 32 * CT, co0 = cot * 32 * NT;
@@ -124,11 +146,16 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
       // exactly representable?  (else this channel tile is redone in fp32)
       inexact |= (int)(xr[i].x != __uint_as_float(h01 << 16)) | (int)(xr[i].y != __uint_as_float(h01 & 0xFFFF0000u)) |
                  (int)(xr[i].z != __uint_as_float(h23 << 16)) | (int)(xr[i].w != __uint_as_float(h23 & 0xFFFF0000u));
+#if WB_TR
+      (void)hr, (void)hc;
+      *(uint2*)(s_x + hp * XPP + q * 8) = make_uint2(h01, h23);
+#else
       char* p = s_x + (4 * q) * WB_XP + hr * WB_ROWB + (7 + hc) * 2;
       *(uint16_t*)(p) = (uint16_t)h01;
       *(uint16_t*)(p + WB_XP) = (uint16_t)(h01 >> 16);
       *(uint16_t*)(p + 2 * WB_XP) = (uint16_t)h23;
       *(uint16_t*)(p + 3 * WB_XP) = (uint16_t)(h23 >> 16);
+#endif
     }
 #pragma unroll
     for (int i = 0; i < NLG; ++i) {
@@ -138,6 +165,15 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
       evf_split3_pair(gr[i].x, gr[i].y, h0, m0, l0);
       evf_split3_pair(gr[i].z, gr[i].w, h1, m1, l1);
       bs[0] += gr[i].x, bs[1] += gr[i].y, bs[2] += gr[i].z, bs[3] += gr[i].w;
+#if WB_TR
+      {
+        char* pt = s_g + px * GPP + q * 8;
+        *(uint2*)(pt) = make_uint2(h0, h1);
+        *(uint2*)(pt + GPL_TR) = make_uint2(m0, m1);
+        *(uint2*)(pt + 2 * GPL_TR) = make_uint2(l0, l1);
+        continue;
+      }
+#endif
       char* p = s_g + (4 * q) * WB_GP + px * 2;
       *(uint16_t*)(p) = (uint16_t)h0, *(uint16_t*)(p + WB_GP) = (uint16_t)(h0 >> 16);
       *(uint16_t*)(p + 2 * WB_GP) = (uint16_t)h1, *(uint16_t*)(p + 3 * WB_GP) = (uint16_t)(h1 >> 16);
@@ -152,9 +188,51 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
   prefetch(true);
 #pragma unroll 1
   for (int it = 0; it < g.tiles_per_split; ++it) {
+#ifdef WB_PROBE_NOCOMMIT  // (A/B probe, never shipped: what the transposing LDS stores cost -- the first tile's image is reused)
+    if (it == 0)
+#endif
     commit();
     __syncthreads();
     prefetch(it + 1 < g.tiles_per_split);
+#if WB_TR
+    // transpose reads: lane i16 = lane & 15 of a 16-lane group addresses pixel (i16 >> 2) of a 4-pixel run and the 4-channel piece
+    // (i16 & 3) of the group's 16 channels ((lane >> 4) & 1: lower / upper half of the 32-channel tile) and RECEIVES the four
+    // pixels of channel (lane & 31); two reads (pixels 0..3, 4..7 of the tile row) make the fragment
+    const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int lane_x = (i16 >> 2) * XPP + (g16 * 16 + (i16 & 3) * 4) * 2;
+    const int lane_g = (i16 >> 2) * GPP + (g16 * 16 + (i16 & 3) * 4) * 2;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int r = 2 * ks + kg;
+      w_bf16x8 xa[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const char* pp = s_x + ((r + dy) * (WB_T + 2) + dx) * XPP + c * 64 + lane_x;
+        const wb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((WB_LDS wb_s16x4*)pp);
+        const wb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((WB_LDS wb_s16x4*)(pp + 4 * XPP));
+        const wb_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        xa[c] = *(const w_bf16x8*)&v;
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        w_bf16x8 gq[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const char* pp = s_g + pl * GPL_TR + (r * WB_T) * GPP + t * 64 + lane_g;
+          const wb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((WB_LDS wb_s16x4*)pp);
+          const wb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((WB_LDS wb_s16x4*)(pp + 4 * GPP));
+          const wb_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          gq[pl] = *(const w_bf16x8*)&v;
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[c], gq[2], acc[c][t], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[c], gq[1], acc[c][t], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[c], gq[0], acc[c][t], 0, 0, 0);
+      }
+    }
+#else
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {  // 16 pixels = tile rows 2 ks, 2 ks + 1 (lane half kg)
       const int r = 2 * ks + kg;
@@ -190,6 +268,7 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
         for (int c = 0; c < CT; ++c) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[c], gh, acc[c][t], 0, 0, 0);
       }
     }
+#endif
     __syncthreads();
   }
 
@@ -219,7 +298,9 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
   }
   if (!fz.ticket) return;
   // ---- fused reduction: last block of the tile
-  __shared__ int s_last;
+  // (no static __shared__ in this kernel: statics precede the dynamic region unpadded, and a 4-byte one would take the 16-byte
+  //  alignment the b128 / transpose reads need away from it -- the flag lives behind the bias sums)
+  int& s_last = *(int*)(s_b + 32 * NT);
   // release: every thread waits for ITS slab stores (workgroup scope: a wait, no cache maintenance), the barrier collects them, and
   // ONE thread makes the block's stores visible device-wide (the agent-scope fence writes the XCD's L2 back: as 576 per-thread
   // fences it cost ~170 us per launch) before it draws the ticket
@@ -279,7 +360,11 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
 template <int CT, int NT>
 static void wb_go(const float* x, const float* gy, float* slab, float* gbias, int* redo, const WgB3Geo& g, int nsplit, int n_nt,
                   hipStream_t st, const WgFuse& fz) {
-  const size_t smem = (size_t)32 * CT * WB_XP + 3 * 32 * NT * WB_GP + 32 * NT * sizeof(float);
+#if WB_TR
+  const size_t smem = (size_t)WB_HP * WB_PPITCH(32 * CT) + 3 * WB_T * WB_T * WB_PPITCH(32 * NT) + 32 * NT * sizeof(float) + 16;
+#else
+  const size_t smem = (size_t)32 * CT * WB_XP + 3 * 32 * NT * WB_GP + 32 * NT * sizeof(float) + 16;
+#endif
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute((const void*)k_wgrad9_b3<CT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

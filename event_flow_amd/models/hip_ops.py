@@ -637,6 +637,15 @@ def cell_forward(cell, input_, prev_state, residual=0, slots=None):
 # ---------------------------------------------------------------------------
 # conv + bias + pointwise activation (ConvLayer / ConvLayer_)
 # ---------------------------------------------------------------------------
+HEAD1X1 = os.environ.get("EVF_HEAD1X1", "1") != "0"
+
+
+def _head1x1_ok(Cin, Cout, k, stride, residual, weight):
+    q = Cin // 4
+    return (HEAD1X1 and CONV_B3 and k == 1 and stride == 1 and residual is None and 1 <= Cout <= 4 and Cin % 4 == 0 and Cin == weight.shape[1]
+            and 1 <= q <= 64 and (q & (q - 1)) == 0)
+
+
 class _ConvAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, x, weight, bias, residual, stride, act):
@@ -644,6 +653,18 @@ class _ConvAct(torch.autograd.Function):
         B, H, W, Cin = xn.shape
         Cout, _, k, _ = weight.shape
         Ho, Wo = _out_dim(H, k, stride), _out_dim(W, k, stride)
+        ctx.head1 = _head1x1_ok(Cin, Cout, k, stride, residual, weight)
+        if ctx.head1:  # a 1x1 layer with a handful of outputs (the flow predictions): one streaming kernel each way
+            y = _new((B, H, W, Cout), xn.device)
+            wc = weight.detach().reshape(Cout, Cin).contiguous()
+            bc = bias.detach().contiguous() if bias is not None else None
+            _lib.call("evf_head1x1_fwd", _lib.ptr_strided(xn), xn.stride(2), _lib.ptr(wc), _lib.ptr(bc), act, B * H * W, Cin, Cout,
+                      _lib.ptr(y), Cout)
+            ctx.owner, ctx.act, ctx.stride = owner, act, stride
+            ctx.saved = (xn, y, weight)
+            ctx.bias = bias
+            ctx.has_bias, ctx.has_res = bias is not None, False
+            return from_nhwc(y)
         if not 0 <= Cin - weight.shape[1] < 4:
             raise _lib.EvflowError(f"input has {Cin} channels, the layer expects {weight.shape[1]}")
         # (Cin - Cw trailing channels = zero padding that keeps 16-byte alignment; the packed weight is zero there)
@@ -665,6 +686,25 @@ class _ConvAct(torch.autograd.Function):
         B, H, W, Cin = xn.shape
         Cout, _, k, _ = weight.shape
         need = ctx.needs_input_grad  # (owner, x, weight, bias, residual, stride, act)
+        if ctx.head1:
+            _lib.require_gpu(g_y, "1x1 head backward")
+            # the upstream gradient as it comes: NCHW planes (the loss's flow-map gradient) or NHWC rows -- no layout pass
+            if g_y.is_contiguous():
+                gsrc, hw = g_y, H * W
+            else:
+                gsrc, hw = to_nhwc(g_y), 0
+            d_w = bound_grad(weight) if need[2] else None
+            d_b = bound_grad(ctx.bias) if (ctx.has_bias and need[3]) else None
+            direct = d_w is not None and (not ctx.has_bias or d_b is not None)
+            g_w = d_w if direct else _new(tuple(weight.shape), xn.device)
+            g_b = (d_b if direct else _new((Cout,), xn.device)) if ctx.has_bias else None
+            g_xn = _new((B, H, W, Cin), xn.device) if need[1] else None
+            ws = _scratch(_lib.load().evf_head1x1_ws(Cin, Cout), xn.device)
+            wc = weight.detach().reshape(Cout, Cin).contiguous()
+            _lib.call("evf_head1x1_bwd", _lib.ptr_strided(xn), xn.stride(2), _lib.ptr(y), Cout, _lib.ptr(gsrc), hw, _lib.ptr(wc), ctx.act,
+                      B * H * W, Cin, Cout, _lib.ptr(g_xn), Cin, _lib.ptr(g_w), _lib.ptr(g_b), 1 if direct else 0, _lib.ptr(ws))
+            return (None, from_nhwc(g_xn) if g_xn is not None else None, None if direct else g_w,
+                    None if (direct or not ctx.has_bias) else g_b, None, None, None)
         g = to_nhwc(g_y)
         if ctx.act != 0:
             gp = _new(tuple(g.shape), g.device)

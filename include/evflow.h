@@ -509,6 +509,17 @@ int evf_conv2d_fwd_b3(const float* x, int ldx, const void* w_packed, const float
 int evf_conv2d_dgrad_b3(const float* g_y, int ldg, const void* wT_packed, float* g_x, int ldx, int B, int H,
                         int W, int Cin, int Cout, int ksz, int stride, int accumulate, float* ws,
                         int64_t ws_floats, void* stream);
+/* A 1x1 layer with <= 4 outputs in ONE pass each way (the tanh flow prediction of every scale: models/submodules.py:52-61,
+ * models/unet.py:355-369): y[m][0..Cout) = act(W x[m] + bias) and its backward -- g_pre = g_y * act'(y); g_x = W^T g_pre; g_w, g_bias
+ * summed over the M pixels (per-block partials in ws, evf_head1x1_ws() floats; accumulate: += instead of =).  W [Cout][Cin] is the
+ * torch weight of the 1x1 conv; Cin / 4 a power of two <= 64; act 0 none / 1 tanh / 2 sigmoid / 3 relu; g_y as [M][Cout] rows or,
+ * with gy_nchw_hw = H*W, as NCHW planes [b][Cout][H*W] (how the loss hands the flow maps' gradient back). */
+int64_t evf_head1x1_ws(int Cin, int Cout);
+int evf_head1x1_fwd(const float* x, int ldx, const float* w, const float* bias, int act, int64_t M, int Cin, int Cout,
+                    float* y, int ldy, void* stream);
+int evf_head1x1_bwd(const float* x, int ldx, const float* y, int ldy, const float* g_y, int64_t gy_nchw_hw, const float* w,
+                    int act, int64_t M, int Cin, int Cout, float* g_x, int ldgx, float* g_w, float* g_bias, int accumulate,
+                    float* ws, void* stream);
 /* evf_conv2d_fwd_b3 without bias / accumulation whose K-split partial sums stay IN PARTS for the consumer (evf_lif_fwd_parts):
  * *nparts = 0: y holds the result; n > 0: ws holds n slabs [B*Ho*Wo][Cout] to be added in index order.  flags: bit 2 as above. */
 int evf_conv2d_fwd_b3_parts(const float* x, int ldx, const void* w_packed, float* y, int ldy, int B, int H, int W,
