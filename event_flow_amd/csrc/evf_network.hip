@@ -726,41 +726,59 @@ __global__ void k_plif_trace_bwd(const float4* __restrict__ g_cur, const float4*
     ap[k] = evf_sigmoid(add_pt[4 * cg + k]);
   }
   float sl[4] = {0, 0, 0, 0}, sa[4] = {0, 0, 0, 0};
-  for (long e0 = (long)blockIdx.x * blockDim.x; e0 < npix * 8; e0 += (long)gridDim.x * blockDim.x) {
-    const long e = e0 + tid;
-    const bool ok = e < npix * 8;
-    const long ec = ok ? e : npix * 8 - 1, pix = ec >> 3;
-    const float4 gc4 = g_cur[ec];
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // optional tensors: load from a valid dummy, select afterwards (no load under a branch)
-    const float4 gkl = (g_pt_carry ? g_pt_carry : g_cur)[ec], ppl = (pt_prev ? pt_prev : g_cur)[ec];
-    const float4 gk4 = g_pt_carry ? gkl : z4, pp4 = pt_prev ? ppl : z4;
-    const float Pv = P[pix];
-    (void)pt_out;
-    const float gc[4] = {gc4.x, gc4.y, gc4.z, gc4.w};
-    const float gk[4] = {gk4.x, gk4.y, gk4.z, gk4.w}, pp[4] = {pp4.x, pp4.y, pp4.z, pp4.w};
-    // pt' of the forward pass is RECOMPUTED from its two operands (pt_prev is read anyway, P is one word per pixel) with the
-    // forward's own expression (evf_fwd_b3.hip: pto = p * lpt + (1 - lpt) * P): 128 of the kernel's 640 B/px less
-    float po[4];
+  // TWO grid strides per trip: all eight loads of a thread's two elements are requested before the first is used (one element per
+  // trip kept ~3 KB per wave in flight: 41.6 us per launch at 260 x 346 x B4 = 0.56 of the HBM peak, 70 launches per PLIF step)
+  const long total = npix * 8, gs = (long)gridDim.x * blockDim.x;
+  for (long e0 = (long)blockIdx.x * blockDim.x; e0 < total; e0 += 2 * gs) {
+    long ev[2], ecv[2];
+    bool okv[2];
+    float4 gc4v[2], gklv[2], pplv[2];
+    float Pvv[2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) po[k] = pp[k] * lp[k] + (1.0f - lp[k]) * Pv;
-    float gp[4], gPp = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float g = gk[k] - ap[k] * gc[k];
-      gp[k] = g * lp[k];
-      gPp += g * (1.0f - lp[k]);
-      if (ok) {
-        sl[k] += g * (pp[k] - Pv);
-        sa[k] -= gc[k] * po[k];
-      }
+    for (int u = 0; u < 2; ++u) {
+      ev[u] = e0 + u * gs + tid;
+      okv[u] = ev[u] < total;
+      ecv[u] = okv[u] ? ev[u] : total - 1;
+      gc4v[u] = g_cur[ecv[u]];
+      // optional tensors: load from a valid dummy, select afterwards (no load under a branch)
+      gklv[u] = (g_pt_carry ? g_pt_carry : g_cur)[ecv[u]];
+      pplv[u] = (pt_prev ? pt_prev : g_cur)[ecv[u]];
+      Pvv[u] = P[ecv[u] >> 3];
     }
-    if (ok) g_pt_prev[e] = make_float4(gp[0], gp[1], gp[2], gp[3]);
-    // the 8 threads of a pixel hold its 32 channels
-    gPp += __shfl_xor(gPp, 1, 64);
-    gPp += __shfl_xor(gPp, 2, 64);
-    gPp += __shfl_xor(gPp, 4, 64);
-    if (ok && cg == 0) g_P[pix] = gPp;
+    (void)pt_out;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long e = ev[u], pix = ecv[u] >> 3;
+      const bool ok = okv[u];
+      const float4 gc4 = gc4v[u];
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 gk4 = g_pt_carry ? gklv[u] : z4, pp4 = pt_prev ? pplv[u] : z4;
+      const float Pv = Pvv[u];
+      const float gc[4] = {gc4.x, gc4.y, gc4.z, gc4.w};
+      const float gk[4] = {gk4.x, gk4.y, gk4.z, gk4.w}, pp[4] = {pp4.x, pp4.y, pp4.z, pp4.w};
+      // pt' of the forward pass is RECOMPUTED from its two operands (pt_prev is read anyway, P is one word per pixel) with the
+      // forward's own expression (evf_fwd_b3.hip: pto = p * lpt + (1 - lpt) * P): 128 of the kernel's 640 B/px less
+      float po[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) po[k] = pp[k] * lp[k] + (1.0f - lp[k]) * Pv;
+      float gp[4], gPp = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float g = gk[k] - ap[k] * gc[k];
+        gp[k] = g * lp[k];
+        gPp += g * (1.0f - lp[k]);
+        if (ok) {
+          sl[k] += g * (pp[k] - Pv);
+          sa[k] -= gc[k] * po[k];
+        }
+      }
+      if (ok) g_pt_prev[e] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+      // the 8 threads of a pixel hold its 32 channels
+      gPp += __shfl_xor(gPp, 1, 64);
+      gPp += __shfl_xor(gPp, 2, 64);
+      gPp += __shfl_xor(gPp, 4, 64);
+      if (ok && cg == 0) g_P[pix] = gPp;
+    }
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k)
