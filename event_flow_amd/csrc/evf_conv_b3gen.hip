@@ -91,64 +91,89 @@ struct B3PackMulti {
   int blk0[B3_MULTI + 1];  // first block of each tensor
   int n;
 };
-__global__ void k_pack_conv2d_b3_multi(B3PackMulti m) {
+// One block = one (N tile of 32, 64-channel K group) of one tensor, all taps: the 32 x 64 x T source weights are read in whole
+// contiguous runs of the torch layout [co][ci][tap] (64 ci x T floats per co, or 32 ci x T per co when transposed) into LDS, and the
+// fragments are built from there.  (A thread per fragment reading its eight weights straight from memory touched eight different
+// lines 36 bytes .. 18 KB apart: 130 us for the 20 M weights of LIF-EV-FlowNet in both layouts, every step.)
+#define B3P_MAXT 9  // taps of the LDS path (3x3 and 1x1); larger kernels take the per-fragment loads
+__global__ __launch_bounds__(256) void k_pack_conv2d_b3_multi(B3PackMulti m) {
+  extern __shared__ __attribute__((aligned(16))) float s_w[];  // [32 n][64 k][T] (72 KiB for 3x3)
   int k = 0;
   while (k + 1 < m.n && (int)blockIdx.x >= m.blk0[k + 1]) ++k;  // (uniform; n <= 48)
   const int Cout = m.Cout[k], Cin = m.Cin[k], T = m.T[k], transpose = m.tr[k], cin_total = m.cin_total[k], cin_off = m.cin_off[k];
   const float* __restrict__ w = m.w[k];
   uint4* __restrict__ dst = m.dst[k];
-  const int K = transpose ? Cout : Cin, N = transpose ? Cin : Cout;
+  const int K = transpose ? Cout : Cin;
   const int G = (K + CG_KG - 1) / CG_KG;
-  const long total = (long)((N + 31) / 32) * T * G * 4 * 64;
-  const long idx = (long)((int)blockIdx.x - m.blk0[k]) * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int lane = idx & 63;
-  long q = idx >> 6;
-  const int ch = q & 3;
-  q >>= 2;
-  const int g = q % G;
-  q /= G;
-  const int tap = q % T;
-  const int nt = q / T;
-  const int n = nt * 32 + (lane & 31);
-  uint32_t t3[3][4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float v[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int kk = g * CG_KG + ch * 16 + 8 * (lane >> 5) + 2 * e + j;
-      float x = 0.f;
-      if (kk < K && n < N) {
-        const int co = transpose ? kk : n, ci = transpose ? n : kk;
-        if (cin_off + ci < cin_total) x = w[((long)co * cin_total + cin_off + ci) * T + tap];
-      }
-      v[j] = x;
+  const int rel = (int)blockIdx.x - m.blk0[k], g = rel % G, nt = rel / G;
+  const int tid = threadIdx.x;
+  // ---- source tile -> LDS as s_w[(n_l * 64 + k_l) * T + tap]
+  if (!transpose) {  // n = co, k = ci: per co a run of 64 ci x T floats
+    const int run = 64 * T;
+    for (int e = tid; e < 32 * run; e += 256) {
+      const int n_l = e / run, r = e - n_l * run, k_l = r / T;
+      const int co = nt * 32 + n_l, ci = g * 64 + k_l;
+      s_w[e] = (co < Cout && ci < Cin && cin_off + ci < cin_total) ? w[((long)co * cin_total + cin_off + g * 64) * T + r] : 0.f;
     }
-    evf_split3_pair(v[0], v[1], t3[0][e], t3[1][e], t3[2][e]);
+  } else {  // n = ci, k = co: per co a run of 32 ci x T floats
+    const int run = 32 * T;
+    for (int e = tid; e < 64 * run; e += 256) {
+      const int k_l = e / run, r = e - k_l * run, n_l = r / T, tap = r - n_l * T;
+      const int co = g * 64 + k_l, ci = nt * 32 + n_l;
+      s_w[(n_l * 64 + k_l) * T + tap] =
+          (co < Cout && ci < Cin && cin_off + ci < cin_total) ? w[((long)co * cin_total + cin_off + nt * 32) * T + r] : 0.f;
+    }
   }
-  const long base = ((((long)nt * T + tap) * G + g) * 4 + ch) * 3;
+  __syncthreads();
+  // ---- fragments: (tap, chunk, lane) -> three uint4 (hi, mid, lo planes of 8 consecutive k of row n)
+  for (int f = tid; f < T * 4 * 64; f += 256) {
+    const int lane = f & 63, ch = (f >> 6) & 3, tap = f >> 8;
+    const int n_l = lane & 31;
+    uint32_t t3[3][4];
 #pragma unroll
-  for (int s = 0; s < 3; ++s) dst[(base + s) * 64 + lane] = make_uint4(t3[s][0], t3[s][1], t3[s][2], t3[s][3]);
+    for (int e = 0; e < 4; ++e) {
+      const int k_l = ch * 16 + 8 * (lane >> 5) + 2 * e;
+      evf_split3_pair(s_w[(n_l * 64 + k_l) * T + tap], s_w[(n_l * 64 + k_l + 1) * T + tap], t3[0][e], t3[1][e], t3[2][e]);
+    }
+    const long base = ((((long)nt * T + tap) * G + g) * 4 + ch) * 3;
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) dst[(base + s3) * 64 + lane] = make_uint4(t3[s3][0], t3[s3][1], t3[s3][2], t3[s3][3]);
+  }
 }
 
 // meta: 6 ints per tensor (Cout, Cin, ksz, transpose, cin_total, cin_off) -- the arguments of evf_pack_conv2d_weight_b3
+extern "C" int evf_pack_conv2d_weight_b3(const float* w, int Cout, int Cin, int ksz, int transpose, int cin_total, int cin_off,
+                                         void* dst, void* stream);
 extern "C" int evf_pack_conv2d_weights_b3_multi(const void* const* w, void* const* dst, const int* meta, int n, void* stream) {
   if (!w || !dst || !meta || n <= 0) return EVF_EINVAL;
-  for (int lo = 0; lo < n; lo += B3_MULTI) {
+  static bool once = false;
+  const size_t smem = sizeof(float) * 32 * 64 * B3P_MAXT;
+  if (!once) {
+    (void)hipFuncSetAttribute((const void*)k_pack_conv2d_b3_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    once = true;
+  }
+  int i = 0;
+  while (i < n) {
     B3PackMulti m;
-    m.n = n - lo < B3_MULTI ? n - lo : B3_MULTI;
+    m.n = 0;
     int blk = 0;
-    for (int k = 0; k < m.n; ++k) {
-      const int* t = meta + 6 * (lo + k);
-      if (!w[lo + k] || !dst[lo + k] || t[0] <= 0 || t[1] <= 0 || !EVF_KSZ_OK(t[2]) || t[5] < 0 || t[5] >= t[4]) return EVF_EINVAL;
-      m.w[k] = (const float*)w[lo + k], m.dst[k] = (uint4*)dst[lo + k];
+    for (; i < n && m.n < B3_MULTI; ++i) {
+      const int* t = meta + 6 * i;
+      if (!w[i] || !dst[i] || t[0] <= 0 || t[1] <= 0 || !EVF_KSZ_OK(t[2]) || t[5] < 0 || t[5] >= t[4]) return EVF_EINVAL;
+      if (t[2] * t[2] > B3P_MAXT) {  // 5x5 / 7x7: the single-tensor kernel (per-fragment loads)
+        const int rc = evf_pack_conv2d_weight_b3((const float*)w[i], t[0], t[1], t[2], t[3], t[4], t[5], dst[i], stream);
+        if (rc) return rc;
+        continue;
+      }
+      const int k = m.n++;
+      m.w[k] = (const float*)w[i], m.dst[k] = (uint4*)dst[i];
       m.Cout[k] = t[0], m.Cin[k] = t[1], m.T[k] = t[2] * t[2], m.tr[k] = t[3], m.cin_total[k] = t[4], m.cin_off[k] = t[5];
       m.blk0[k] = blk;
-      blk += (int)evf_cdiv(b3_packed_uint4(t[0], t[1], t[2], t[3]) / 3, 256L);
+      const int Kk = t[3] ? t[0] : t[1], Nn = t[3] ? t[1] : t[0];
+      blk += evf_cdiv(Nn, 32) * evf_cdiv(Kk, CG_KG);  // one block per (N tile, 64-channel group)
     }
     m.blk0[m.n] = blk;
-    hipLaunchKernelGGL(k_pack_conv2d_b3_multi, dim3(blk), dim3(256), 0, EVF_STREAM(stream), m);
+    if (m.n > 0) hipLaunchKernelGGL(k_pack_conv2d_b3_multi, dim3(blk), dim3(256), smem, EVF_STREAM(stream), m);
   }
   return evf_status();
 }

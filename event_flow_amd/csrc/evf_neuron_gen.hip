@@ -862,39 +862,64 @@ extern "C" int evf_concat_channels(const void* const* src, const int* C, const i
 // low-resolution concatenation is never written -- a thread blends the four source pixels of its two output channels straight from
 // the part they live in (all part offsets of the decoder inputs are even: [2 flow | C | C | 2 zeros]).  Same association as
 // k_up2_fwd / ATen's upsample_bilinear2d.
+__device__ __forceinline__ float2 up_sel(bool c, float2 a, float2 b) { return c ? a : b; }
 __global__ void k_concat_up2_fwd(CatParts p, int B, int H, int W, int Ctot, float* __restrict__ out, int ldo) {
-  // one thread = FOUR output channels of one pixel (one 16-byte store: the output is what this kernel moves, 4x the input), read
-  // as two channel pairs that may come from different parts (the part offsets are even, not multiples of four)
+  // One thread = FOUR output channels of the 2 x 2 output pixels of ONE source pixel (i, j): its 3 x 3 source neighbourhood is read
+  // once (18 eight-byte loads for four 16-byte stores; a thread per output pixel issued 8 per store, and the output -- 4x the
+  // input -- is what this kernel moves).  The four channels are two pairs that may come from different parts (the part offsets
+  // are even, not multiples of four).  Rows: A = i0(2i), Bm = i1(2i), C = i1(2i + 1), and i0(2i + 1) is A for i = 0 and Bm
+  // otherwise (up2_src); columns alike -- the SAME operands in the same expression as k_up2_fwd, bit for bit.
   const int Q = Ctot >> 2;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int OH = 2 * H, OW = 2 * W;
-  if (idx >= (long)B * OH * OW * Q) return;
+  if (idx >= (long)B * H * W * Q) return;
   const int c = 4 * (int)(idx % Q);
   const long pix = idx / Q;
-  const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((long)OW * OH));
-  int y0, y1, x0, x1;
-  float wy, wx;
-  up2_src(oy, H, y0, y1, wy);
-  up2_src(ox, W, x0, x1, wx);
-  const long p00 = ((long)b * H + y0) * W + x0, p01 = ((long)b * H + y0) * W + x1, p10 = ((long)b * H + y1) * W + x0,
-             p11 = ((long)b * H + y1) * W + x1;
-  float2 r[2];
+  const int j = (int)(pix % W), i = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+  int ya, yb, yb0, yc, xa, xb, xb0, xc;
+  float wy0, wy1, wx0, wx1;
+  up2_src(2 * i, H, ya, yb, wy0);
+  up2_src(2 * i + 1, H, yb0, yc, wy1);
+  up2_src(2 * j, W, xa, xb, wx0);
+  up2_src(2 * j + 1, W, xb0, xc, wx1);
+  const bool ry = yb0 == ya, rx = xb0 == xa;  // (i == 0 / j == 0: the odd output's first tap is slot A, else slot B)
+  const int ys[3] = {ya, yb, yc}, xs[3] = {xa, xb, xc};
+  float2 r[2][2][2];  // [output row][output column][channel pair]
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int ch = c + 2 * h;
     int k = 0;
 #pragma unroll
-    for (int j = 1; j < 6; ++j) k += (j < p.n && ch >= p.off[j]) ? 1 : 0;
+    for (int jj = 1; jj < 6; ++jj) k += (jj < p.n && ch >= p.off[jj]) ? 1 : 0;
     const float* s = p.src[k];
     // (a null part = zero padding: a valid dummy address, selected away -- no load under a branch)
     const float* q = (s ? s : p.src[0]) + (s ? ch - p.off[k] : 0);
     const long ld = s ? p.ld[k] : p.ld[0];
-    const float2 a = *(const float2*)(q + p00 * ld), bq = *(const float2*)(q + p01 * ld);
-    const float2 cc = *(const float2*)(q + p10 * ld), d = *(const float2*)(q + p11 * ld);
-    const float2 v = up_mix(1.f - wy, up_mix(1.f - wx, a, wx, bq), wy, up_mix(1.f - wx, cc, wx, d));
-    r[h] = s ? v : make_float2(0.f, 0.f);
+    float2 v[3][3];
+#pragma unroll
+    for (int yy = 0; yy < 3; ++yy)
+#pragma unroll
+      for (int xx = 0; xx < 3; ++xx) v[yy][xx] = *(const float2*)(q + (((long)b * H + ys[yy]) * W + xs[xx]) * ld);
+    // output (0, 0): rows A, Bm; columns A, Bm
+    const float2 o00 = up_mix(1.f - wy0, up_mix(1.f - wx0, v[0][0], wx0, v[0][1]), wy0, up_mix(1.f - wx0, v[1][0], wx0, v[1][1]));
+    // output (0, 1): columns (rx ? A : Bm), C
+    const float2 t0 = up_sel(rx, v[0][0], v[0][1]), t1 = up_sel(rx, v[1][0], v[1][1]), t2 = up_sel(rx, v[2][0], v[2][1]);
+    const float2 o01 = up_mix(1.f - wy0, up_mix(1.f - wx1, t0, wx1, v[0][2]), wy0, up_mix(1.f - wx1, t1, wx1, v[1][2]));
+    // output (1, 0): rows (ry ? A : Bm), C
+    const float2 u0 = up_sel(ry, v[0][0], v[1][0]), u1 = up_sel(ry, v[0][1], v[1][1]), u2 = up_sel(ry, v[0][2], v[1][2]);
+    const float2 o10 = up_mix(1.f - wy1, up_mix(1.f - wx0, u0, wx0, u1), wy1, up_mix(1.f - wx0, v[2][0], wx0, v[2][1]));
+    // output (1, 1)
+    const float2 w0 = up_sel(rx, u0, u1);
+    const float2 o11 = up_mix(1.f - wy1, up_mix(1.f - wx1, w0, wx1, u2), wy1, up_mix(1.f - wx1, t2, wx1, v[2][2]));
+    const float2 z2 = make_float2(0.f, 0.f);
+    r[0][0][h] = s ? o00 : z2, r[0][1][h] = s ? o01 : z2, r[1][0][h] = s ? o10 : z2, r[1][1][h] = s ? o11 : z2;
   }
-  *(float4*)(out + pix * ldo + c) = make_float4(r[0].x, r[0].y, r[1].x, r[1].y);
+  const int OW = 2 * W;
+  float* o = out + (((long)b * 2 * H + 2 * i) * OW + 2 * j) * ldo + c;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+      *(float4*)(o + ((long)a * OW + bb) * ldo) = make_float4(r[a][bb][0].x, r[a][bb][0].y, r[a][bb][1].x, r[a][bb][1].y);
 }
 // parts: NHWC [B,H,W,C[k]] with pixel stride ld[k]; out [B,2H,2W,sum C] with pixel stride ldo.  Every C[k], ld[k] even, sum C and
 // ldo multiples of four, part pointers 8-byte and `out` 16-byte aligned, the first part not null.
@@ -914,7 +939,7 @@ extern "C" int evf_concat_up2_fwd(const void* const* src, const int* C, const in
   }
   p.off[6] = tot, p.n = n;
   if (ldo < tot || (tot & 3)) return EVF_EINVAL;
-  const long total = (long)B * 4 * H * W * (tot / 4);
+  const long total = (long)B * H * W * (tot / 4);  // (a thread per source pixel and channel quad: its 2 x 2 output pixels)
   hipLaunchKernelGGL(k_concat_up2_fwd, dim3(evf_cdiv(total, 256L)), dim3(256), 0, EVF_STREAM(stream), p, B, H, W, tot, out, ldo);
   return evf_status();
 }

@@ -799,11 +799,11 @@ static int wg_fewin_blocks(int B, int H, int W, int Cout) {
 // The same reduction with COALESCED gradient accesses, for the big weights: k_wgrad_reduce walks the slab layout [tap][ci][co], so
 // the 64 lanes of a wave write (and, accumulating, read) 64 different lines of gw [co][ci][tap] -- 18 KB apart for 512 input
 // channels -- and every line is touched by 32 different waves: 27 us for the 56 MB of a 512 x 512 layer (2.1 TB/s), 0.47 ms per
-// LIF-EV-FlowNet step.  Here a block owns 16 output x 32 input channels x 9 taps: the slabs are read in 64-byte runs along co
+// LIF-EV-FlowNet step.  Here a block owns 32 output x 16 input channels x 9 taps: the slabs are read in 128-byte lines along co
 // and summed over the splits (index order, four loads in flight), the tile is transposed in LDS, and each output channel's
-// 32 x 9 = 288 consecutive floats of gw go out (and come in) as whole lines.
-#define WRT_CO 16
-#define WRT_CI 32
+// 16 x 9 = 144 consecutive floats of gw go out (and come in) as whole lines.
+#define WRT_CO 32  // (32 output channels = one whole 128-byte line of a slab row per (tap, input channel))
+#define WRT_CI 16
 __global__ __launch_bounds__(256) void k_wgrad_reduce_t(const float* __restrict__ slab, int nsplit, int Cin, int Cout, int cin_total,
                                                         int cin_off, int accumulate, float* __restrict__ gw, int* __restrict__ clear_flags) {
   __shared__ float tile[WRT_CO * (WRT_CI * 9 + 1)];
@@ -811,8 +811,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_t(const float* __restrict_
   const int tid = threadIdx.x, co0 = blockIdx.x * WRT_CO, ci0 = blockIdx.y * WRT_CI;
   const long per = (long)9 * Cin * Cout;
   constexpr int NE = WRT_CO * WRT_CI * 9, NJ = NE / 256, TP = WRT_CI * 9 + 1;
-#pragma unroll 2
-  for (int j = 0; j < NJ; ++j) {
+#pragma unroll 3
+  for (int j = 0; j < NJ; ++j) {  // (18 trips: three of them, i.e. twelve loads, in flight)
     const int idx = tid + 256 * j, co_l = idx % WRT_CO, r = idx / WRT_CO, ci_l = r % WRT_CI, tap = r / WRT_CI;
     const int co = co0 + co_l, ci = ci0 + ci_l;
     const bool ok = co < Cout && ci < Cin;
