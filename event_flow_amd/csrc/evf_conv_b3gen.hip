@@ -97,7 +97,7 @@ struct B3PackMulti {
 // lines 36 bytes .. 18 KB apart: 130 us for the 20 M weights of LIF-EV-FlowNet in both layouts, every step.)
 #define B3P_MAXT 9  // taps of the LDS path (3x3 and 1x1); larger kernels take the per-fragment loads
 __global__ __launch_bounds__(256) void k_pack_conv2d_b3_multi(B3PackMulti m) {
-  extern __shared__ __attribute__((aligned(16))) float s_w[];  // [32 n][64 k][T] (72 KiB for 3x3)
+  extern __shared__ __attribute__((aligned(16))) float s_w[];  // [32 n][64 k x T + 1] (72 KiB for 3x3)
   int k = 0;
   while (k + 1 < m.n && (int)blockIdx.x >= m.blk0[k + 1]) ++k;  // (uniform; n <= 48)
   const int Cout = m.Cout[k], Cin = m.Cin[k], T = m.T[k], transpose = m.tr[k], cin_total = m.cin_total[k], cin_off = m.cin_off[k];
@@ -107,21 +107,33 @@ __global__ __launch_bounds__(256) void k_pack_conv2d_b3_multi(B3PackMulti m) {
   const int G = (K + CG_KG - 1) / CG_KG;
   const int rel = (int)blockIdx.x - m.blk0[k], g = rel % G, nt = rel / G;
   const int tid = threadIdx.x;
-  // ---- source tile -> LDS as s_w[(n_l * 64 + k_l) * T + tap]
+  // ---- source tile -> LDS as s_w[n_l * NP + k_l * T + tap], NP = 64 T + 1 (odd: the 32 rows a fragment pass reads lie on 32 banks)
+  const int NP = 64 * T + 1;
   if (!transpose) {  // n = co, k = ci: per co a run of 64 ci x T floats
     const int run = 64 * T;
-    for (int e = tid; e < 32 * run; e += 256) {
-      const int n_l = e / run, r = e - n_l * run, k_l = r / T;
-      const int co = nt * 32 + n_l, ci = g * 64 + k_l;
-      s_w[e] = (co < Cout && ci < Cin && cin_off + ci < cin_total) ? w[((long)co * cin_total + cin_off + g * 64) * T + r] : 0.f;
+    for (int r = tid; r < run; r += 256) {  // (the divisions once per column, not per element)
+      const int k_l = r / T, ci = g * 64 + k_l;
+      const bool cok = ci < Cin && cin_off + ci < cin_total;
+#pragma unroll 8
+      for (int n_l = 0; n_l < 32; ++n_l) {
+        const int co = nt * 32 + n_l;
+        const bool ok = cok && co < Cout;
+        const float v = w[((long)(ok ? co : 0) * cin_total + cin_off + (ok ? g * 64 : 0)) * T + (ok ? r : 0)];
+        s_w[n_l * NP + r] = ok ? v : 0.f;
+      }
     }
   } else {  // n = ci, k = co: per co a run of 32 ci x T floats
     const int run = 32 * T;
-    for (int e = tid; e < 64 * run; e += 256) {
-      const int k_l = e / run, r = e - k_l * run, n_l = r / T, tap = r - n_l * T;
-      const int co = g * 64 + k_l, ci = nt * 32 + n_l;
-      s_w[(n_l * 64 + k_l) * T + tap] =
-          (co < Cout && ci < Cin && cin_off + ci < cin_total) ? w[((long)co * cin_total + cin_off + nt * 32) * T + r] : 0.f;
+    for (int r = tid; r < run; r += 256) {
+      const int n_l = r / T, tap = r - n_l * T, ci = nt * 32 + n_l;
+      const bool cok = ci < Cin && cin_off + ci < cin_total;
+#pragma unroll 8
+      for (int k_l = 0; k_l < 64; ++k_l) {
+        const int co = g * 64 + k_l;
+        const bool ok = cok && co < Cout;
+        const float v = w[((long)(ok ? co : 0) * cin_total + cin_off + (ok ? nt * 32 : 0)) * T + (ok ? r : 0)];
+        s_w[n_l * NP + k_l * T + tap] = ok ? v : 0.f;
+      }
     }
   }
   __syncthreads();
@@ -129,12 +141,10 @@ __global__ __launch_bounds__(256) void k_pack_conv2d_b3_multi(B3PackMulti m) {
   for (int f = tid; f < T * 4 * 64; f += 256) {
     const int lane = f & 63, ch = (f >> 6) & 3, tap = f >> 8;
     const int n_l = lane & 31;
+    const float* row = s_w + n_l * NP + (ch * 16 + 8 * (lane >> 5)) * T + tap;
     uint32_t t3[3][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int k_l = ch * 16 + 8 * (lane >> 5) + 2 * e;
-      evf_split3_pair(s_w[(n_l * 64 + k_l) * T + tap], s_w[(n_l * 64 + k_l + 1) * T + tap], t3[0][e], t3[1][e], t3[2][e]);
-    }
+    for (int e = 0; e < 4; ++e) evf_split3_pair(row[(2 * e) * T], row[(2 * e + 1) * T], t3[0][e], t3[1][e], t3[2][e]);
     const long base = ((((long)nt * T + tap) * G + g) * 4 + ch) * 3;
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3) dst[(base + s3) * 64 + lane] = make_uint4(t3[s3][0], t3[s3][1], t3[s3][2], t3[s3][3]);
@@ -147,7 +157,7 @@ extern "C" int evf_pack_conv2d_weight_b3(const float* w, int Cout, int Cin, int 
 extern "C" int evf_pack_conv2d_weights_b3_multi(const void* const* w, void* const* dst, const int* meta, int n, void* stream) {
   if (!w || !dst || !meta || n <= 0) return EVF_EINVAL;
   static bool once = false;
-  const size_t smem = sizeof(float) * 32 * 64 * B3P_MAXT;
+  const size_t smem = sizeof(float) * 32 * (64 * B3P_MAXT + 1);
   if (!once) {
     (void)hipFuncSetAttribute((const void*)k_pack_conv2d_b3_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     once = true;

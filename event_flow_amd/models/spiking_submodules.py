@@ -58,6 +58,12 @@ class _SpikingCell(nn.Module):
             else:
                 self.norm = nn.GroupNorm(min(1, input_size // 4), input_size)
             self.gnorm = True
+        if self.kind == "lif" and not self.gnorm:
+            # attribute parity: the reference's LIF cells always carry the attribute(s), None when no group norm (:87-94, :502-514)
+            if self.recurrent:
+                self.norm_ff = self.norm_rec = None
+            else:
+                self.norm = None
         self.input_size, self.hidden_size = input_size, hidden_size
         self.kernel_size, self.stride = kernel_size, stride
         self.activation = activation

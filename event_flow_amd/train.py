@@ -182,6 +182,8 @@ def window_forward_loss(model, loss_function, passes):
     """The passes of a window and its loss WITHOUT a backward pass and without an optimizer step (BASELINE.json configs[1]:
     forward + IWE loss; eval-style timing).  Runs in grad mode so that the hidden cells take the recorded diagonal launches
     like a training window; the window is dropped afterwards (states carried, graph discarded).  Returns the 0-d loss."""
+    if not passes:
+        raise _lib.EvflowError("window_forward_loss: an empty window (no passes)")
     defer = DEFER_FORWARD and hasattr(model, "defer_forward")
     if defer:
         model.defer_forward(True)
