@@ -23,7 +23,7 @@ struct GfArgs {
 };
 
 #define GF_GROUPS 16
-#define GF_UNROLL 8   // independent row loads per thread and trip of the segment part
+#define GF_UNROLL 16  // independent row loads per thread and trip of the segment part (512 .. 1024 rows: 2 .. 4 trips)
 // blocks [0, 144 * nslabs): 64 outputs x 16 slab groups of tensor block / 144 (as k_reduce_wgrad_multi);
 // blocks behind them: 64 columns x 16 row groups of one segment of the small gradients, all rows
 __global__ __launch_bounds__(64 * GF_GROUPS) void k_grads_finalize(GfArgs a, int nslabs, int nslab, float* __restrict__ small,

@@ -933,41 +933,46 @@ def test_fused_path_other_surrogates_and_soft_reset_vs_oracle(acts, hard):
     fast path; every other surrogate (models/spiking_util.py:28-93) and the soft reset (spiking_submodules.py:119-123)
     run the general instantiation: two passes of LIF-FireNet against the CPU oracle (flow, states, parameter gradients)."""
     B, H, W = 2, 24, 40
-    torch.manual_seed(5)
     neuron = dict(NEURON, hard_reset=hard)
     cfg = model_cfg(neuron)
     cfg["activations"] = list(acts)
-    model = LIFFireNet(cfg).to(DEV)
-    with torch.no_grad():
+    flips = {}
+    for seed in (5, 6, 7, 8):  # a borderline spike (|v' - thresh| at fp32 round-off) makes the gradients incomparable: the next seed
+        torch.manual_seed(seed)
+        model = LIFFireNet(dict(cfg)).to(DEV)
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                if k.endswith("thresh"):
+                    p.mul_(0.2)
+        params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        for k, _ in model.named_parameters():
+            params[k].requires_grad_(True)
+        xs = [(torch.rand(B, 2, H, W) < 0.6).float() * torch.randint(1, 4, (B, 2, H, W)).float() for _ in range(2)]
+        states = [None] * 7
+        tot, tot_ref = 0, 0
+        model.train()
+        for x in xs:
+            f_ref, states = osnn.firenet_forward("LIFFireNet", params, x, states, acts=acts, hard_reset=hard)
+            f = model(x.to(DEV), x.to(DEV))["flow"][0]
+            wgt = torch.arange(f_ref.numel()).view(f_ref.shape).remainder(5).float() - 2.0
+            tot_ref = tot_ref + (f_ref * wgt).sum()
+            tot = tot + (f * wgt.to(DEV)).sum()
+        nflip = sum(int((N(model.states[li][1]) != states[li][1].detach().numpy()).sum()) for li in range(7))
+        flips[seed] = nflip
+        if nflip:
+            continue
+        np.testing.assert_allclose(N(f), f_ref.detach().numpy(), rtol=1e-4, atol=1e-7)
+        for li in range(7):
+            np.testing.assert_allclose(N(model.states[li][0]), states[li][0].detach().numpy(), rtol=1e-5, atol=2e-6)
+        tot.backward()
+        tot_ref.backward()
         for k, p in model.named_parameters():
-            if k.endswith("thresh"):
-                p.mul_(0.2)
-    params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    for k, _ in model.named_parameters():
-        params[k].requires_grad_(True)
-    xs = [(torch.rand(B, 2, H, W) < 0.6).float() * torch.randint(1, 4, (B, 2, H, W)).float() for _ in range(2)]
-    states = [None] * 7
-    tot, tot_ref = 0, 0
-    model.train()
-    for x in xs:
-        f_ref, states = osnn.firenet_forward("LIFFireNet", params, x, states, acts=acts, hard_reset=hard)
-        f = model(x.to(DEV), x.to(DEV))["flow"][0]
-        wgt = torch.arange(f_ref.numel()).view(f_ref.shape).remainder(5).float() - 2.0
-        tot_ref = tot_ref + (f_ref * wgt).sum()
-        tot = tot + (f * wgt.to(DEV)).sum()
-    nflip = sum(int((N(model.states[li][1]) != states[li][1].detach().numpy()).sum()) for li in range(7))
-    if nflip:
-        pytest.skip(f"{nflip} borderline spikes at this seed: gradients not comparable")
-    np.testing.assert_allclose(N(f), f_ref.detach().numpy(), rtol=1e-4, atol=1e-7)
-    for li in range(7):
-        np.testing.assert_allclose(N(model.states[li][0]), states[li][0].detach().numpy(), rtol=1e-5, atol=2e-6)
-    tot.backward()
-    tot_ref.backward()
-    for k, p in model.named_parameters():
-        ref = params[k].grad
-        ref = ref.numpy() if ref is not None else np.zeros(tuple(p.shape), np.float32)
-        denom = max(np.linalg.norm(ref), 1e-12)
-        assert np.linalg.norm(N(p.grad) - ref) <= 2e-3 * denom + 1e-9, (k, np.linalg.norm(N(p.grad) - ref) / denom)
+            ref = params[k].grad
+            ref = ref.numpy() if ref is not None else np.zeros(tuple(p.shape), np.float32)
+            denom = max(np.linalg.norm(ref), 1e-12)
+            assert np.linalg.norm(N(p.grad) - ref) <= 2e-3 * denom + 1e-9, (k, np.linalg.norm(N(p.grad) - ref) / denom)
+        return
+    raise AssertionError(f"borderline spikes at every seed tried: {flips} (no flip-free pair of passes to compare gradients on)")
 
 
 def _two_passes_vs_oracle(cls, name, neuron, B, H, W, seed):
