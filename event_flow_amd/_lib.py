@@ -79,6 +79,11 @@ NETWORK_SIGNATURES = {
     "evf_lif_bwd_wgrad": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P, P, P, I, P],
     "evf_lif_bwd_wgrad2": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P, P, P, I, P],
     "evf_lif_bwd_wgrad_top": [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P, P, I, P],
+    "evf_debug_poison_lds": [ctypes.c_uint32, P],
+    "evf_memset": [P, I, ctypes.c_size_t, P],
+    "evf_plif_bwd_wgrad2": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P],
+    "evf_plif_bwd_wgrad_top": [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P, P, I,
+                               P, P, P, P, P, P, P, P, P, P],
     "evf_pack_conv_weight_b3t": [P, I, I, P, P],
     "evf_conv_dgrad_b3": [P, P, P, I, I, I, I, P, P, P],
     "evf_conv_dgrad_b3_f32": [P, P, P, I, I, I, I, P, P, P],
@@ -307,8 +312,29 @@ _DEFER_SAFE_FWD = {"evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_head_
                    "evf_head_plif_fwd",  # (launches at once: reads the window's input and its own state only)
                    "evf_encode_window", "evf_encode_events", "evf_events_to_image"}
 # backward recording (evf_bwd_defer_*): these record themselves, or flush inside the library when they cannot
-_DEFER_SAFE_BWD = {"evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad2", "evf_lif_bwd_wgrad_top", "evf_conv_dgrad_b3_f32",
+_DEFER_SAFE_BWD = {"evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad2", "evf_lif_bwd_wgrad_top", "evf_plif_bwd_wgrad2", "evf_plif_bwd_wgrad_top", "evf_conv_dgrad_b3_f32",
                    "evf_conv_dgrad_b3_f32_pair", "evf_conv_dgrad_b3", "evf_conv_dgrad_b3_pair", "evf_head_lif_bwd_wgrad", "evf_bwd_defer_flush"}
+
+
+def zero_(t):
+    """t.zero_() as a KERNEL launch (evf_memset): torch's zero_() / torch.zeros are hipMemsetAsync, i.e. memset nodes inside a
+    captured step, and graphs with memset nodes between kernel nodes replayed corrupted after a device synchronize on ROCm 7.2
+    (include/evflow.h, evf_memset).  Dense CUDA tensors; anything else through torch."""
+    if t.is_cuda and t.is_contiguous() and t.numel():
+        rc = load().evf_memset(t.data_ptr(), 0, t.numel() * t.element_size(), stream_ptr())
+        if rc != 0:
+            raise EvflowError(f"evf_memset failed with status {rc}")
+        return t
+    return t.zero_()
+
+
+def zeros(shape, dtype=torch.float32, device=None):
+    """torch.zeros through zero_() above."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    return zero_(t)
+
+
+_POISON_LDS = os.environ.get("EVF_DEBUG_POISON_LDS", "0") == "1"  # debugging: NaN in every CU's LDS before every entry point
 
 
 def call(name, *args):
@@ -318,6 +344,8 @@ def call(name, *args):
         for flush, safe in list(hooks.values()):
             if name not in safe:
                 flush()
+    if _POISON_LDS:
+        load().evf_debug_poison_lds(0, stream_ptr())
     if _prof is not None and name in _prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -93,6 +93,22 @@ struct FbStage {
   uint32_t zw;
   uint32_t px, pz, pin;  // one word of the x / z_prev bit planes (threads < 3*32*FB_NW) + in-image mask
 };
+struct FbStagePlif {  // PLIF cells: the trace backward's operands of the same (pixel, channel quad)
+  float4 gk, pp;  // dL/d(pt') carried from pass t + 1, pt of pass t - 1
+  float P;        // pooled input activity of the pixel
+};
+
+// PLIF (spiking_submodules.py:634-652): the presynaptic trace's backward inside team E (evf_plif_trace_bwd as its own pass read
+// g_cur back from HBM and was one more launch per cell).  NULL g_pt_prev = a LIF cell.
+struct FbPlif {
+  const float4* gpt_carry;  // [B,H,W,32] or NULL (last pass of the window)
+  const float4* pt_prev;    // [B,H,W,32] or NULL (zero state)
+  const float* P;           // [B,H,W]
+  const float *leak_pt, *add_pt;  // [32] raw parameters
+  float4* g_pt_prev;        // [B,H,W,32] -> carry of pass t - 1 (may alias gpt_carry: same thread reads, then writes)
+  float* g_P;               // [B,H,W] dL/d(pooled activity), raw (the input-gradient kernel applies the pooling's adjoint)
+  float *g_leak_pt, *g_add_pt;  // per-block rows (row_ld) or dense (atomics)
+};
 
 // TOP: the (non-recurrent) layer under the 1x1 tanh prediction head (models/model.py:197-199, :265).  The head's
 // backward (evf_pred_bwd) runs inside this kernel: per pixel gpre = g_flow * (1 - flow^2); the layer's dL/d(spikes)
@@ -551,7 +567,7 @@ __device__ __forceinline__ void fb_body(
 // EW = waves of team E: 4 (a 512-thread block, one wave of each team per SIMD; a thread takes a float4 per HALF unit, four
 // half units of loads in flight) or 8 (a 768-thread block: two E waves per SIMD hide each other's dependent chains -- with
 // one, team E needed 4.4 k cycles per unit against team M's 3.6 k (phase stamps); a thread takes a float4 per unit).
-template <bool REC, bool TOP, int EW>
+template <bool REC, bool TOP, int EW, bool PLIF = false>
 __device__ __forceinline__ void fb_body_ws(
     const int bid, const int nblk_, const float4* __restrict__ g_z_out, const float4* __restrict__ g_z_out2,
     const float4* __restrict__ g_v_out, const float4* __restrict__ v_out, const float4* __restrict__ v_prev,
@@ -559,13 +575,15 @@ __device__ __forceinline__ void fb_body_ws(
     const float* __restrict__ leak, const float* __restrict__ thresh, int B, int H, int W, int nchunk, long nunits, float width,
     int accumulate, int nrows_total, float4* __restrict__ g_cur, uint2* __restrict__ g_split, float4* __restrict__ g_v_prev,
     float* __restrict__ g_leak, float* __restrict__ g_thresh, float* __restrict__ slab_ff, float* __restrict__ slab_rec, FbTop top,
-    int row_ld) {
+    int row_ld, const FbPlif pl = FbPlif{}) {
+  static_assert(!PLIF || EW == 8, "PLIF cells: whole-unit stages only");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   unsigned short* s_b = (unsigned short*)smem_raw;           // [2][3][FB_CW*32] bf16 (region of FB_R0 bytes)
   uint32_t* s_px = (uint32_t*)(smem_raw + FB_R0);             // [2][3][32][FB_NW]
   uint32_t* s_pz = s_px + 2 * 3 * C32 * FB_NW;                // same (REC)
   uint4* s_lut = (uint4*)(s_pz + 2 * 3 * C32 * FB_NW);        // [256]
   float* s_red = (float*)(s_lut + 256);                       // [2][8][32]
+  float* s_red2 = s_red + 2 * 8 * C32;                        // [2][8][32] (PLIF: the trace parameters' sums)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   constexpr int NTHR = 64 * (EW + 4);  // threads of the block
   constexpr int ETHR = 64 * EW;        // ... of team E
@@ -620,9 +638,12 @@ __device__ __forceinline__ void fb_body_ws(
     row_prev = (row_which ? g_thresh : g_leak)[row_off + row_c];  // (read by threads < 64)
     if (TOP) top_prev = tid < 64 ? top.dw[row_off + row_which * C32 + row_c] : top.db[row_off + (tid & 1)];  // (threads < 66)
   }
+  float rowp_prev = 0.f;  // PLIF: the block's previous sums for leak_pt / add_pt (threads 128 .. 191)
+  if (PLIF && tid >= 128 && tid < 192) rowp_prev = ((tid >> 5) & 1 ? pl.g_add_pt : pl.g_leak_pt)[row_off + (tid & 31)];
 
   // team E state
   float sl[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
+  float slp[4] = {0, 0, 0, 0}, sap[4] = {0, 0, 0, 0};  // PLIF: sums for leak_pt / add_pt
   float dwa[4] = {0, 0, 0, 0}, dwb[4] = {0, 0, 0, 0}, dba = 0.f, dbb = 0.f;
   // team M state: taps t0 = 2 mw, t1 = 2 mw + 1, the ninth tap's K step mw
   f32x16 acc0 = {0}, acc1 = {0}, accz0 = {0}, accz1 = {0}, acc8 = {0}, accz8 = {0};
@@ -632,6 +653,7 @@ __device__ __forceinline__ void fb_body_ws(
   if (team_e) {
     float lam[4], th[4], oml[4], inv_oml[4];
     float pwa[4] = {0, 0, 0, 0}, pwb[4] = {0, 0, 0, 0};
+    float lpt[4] = {0, 0, 0, 0}, apt[4] = {0, 0, 0, 0};  // PLIF: sigma(leak_pt), sigma(add_pt)
     // (computed BEHIND the first units' loads: four exp, four divisions and the head's weights are not needed to request them)
     auto constants = [&]() {
 #pragma unroll
@@ -645,6 +667,10 @@ __device__ __forceinline__ void fb_body_ws(
 #pragma unroll
         for (int k = 0; k < 4; ++k) pwa[k] = top.pred_w[4 * cg + k], pwb[k] = top.pred_w[C32 + 4 * cg + k];
       }
+      if (PLIF) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lpt[k] = fb_sigmoid(pl.leak_pt[4 * cg + k]), apt[k] = fb_sigmoid(pl.add_pt[4 * cg + k]);
+      }
     };
     const float4* pgz = g_z_out ? g_z_out : v_out;
     const float4* pgz2 = g_z_out2 ? g_z_out2 : v_out;
@@ -654,8 +680,11 @@ __device__ __forceinline__ void fb_body_ws(
     const uint32_t* pzw = z_prev ? z_prev : xT;
     const uint32_t* pzt = REC ? zT : xT;
     const bool has_gz = g_z_out != nullptr, has_gv = g_v_out != nullptr, has_vp = v_prev != nullptr, has_zw = z_prev != nullptr;
+    const float4* pgk = (PLIF && pl.gpt_carry) ? pl.gpt_carry : v_out;  // (optional tensors: a valid dummy, selected afterwards)
+    const float4* ppp = (PLIF && pl.pt_prev) ? pl.pt_prev : v_out;
+    const bool has_gk = PLIF && pl.gpt_carry != nullptr, has_pp = PLIF && pl.pt_prev != nullptr;
     // stage 1: the global loads of half h of unit k (straight-line, unconditional, clamped: see fb_body)
-    auto issue = [&](const int k, const int h, FbStage& s) {
+    auto issue = [&](const int k, const int h, FbStage& s, FbStagePlif& sp) {
       int b, y, x0, cw;
       geom(min(k, nu - 1), b, y, x0, cw);
       const long pix0 = ((long)b * H + y) * W + x0;
@@ -674,6 +703,11 @@ __device__ __forceinline__ void fb_body_ws(
       s.gv = pgv[ge];
       s.vp = pvp[ge];
       s.zw = pzw[z_prev ? pix0 + pc : 0];
+      if (PLIF) {
+        sp.gk = pgk[ge];
+        sp.pp = ppp[ge];
+        sp.P = pl.P[pix0 + pc];
+      }
       // this (half) unit's share of the unit's 384 plane words (3 rows x 32 channels x 4 words): EW = 4: 256 + 128
       const int tpl = min(et + ETHR * h, 3 * C32 * FB_NW - 1);
       const int pl_wq = tpl % FB_NW, pl_c = (tpl / FB_NW) % C32, pl_dy = tpl / (FB_NW * C32);
@@ -685,7 +719,7 @@ __device__ __forceinline__ void fb_body_ws(
       s.pin = in ? 0xFFFFFFFFu : 0u;
     };
     // stage 2: neuron backward in registers, results to HBM, split g_cur + spike planes to LDS buffer `buf`
-    auto commit = [&](const int k, const int h, const FbStage& s, const int buf) {
+    auto commit = [&](const int k, const int h, const FbStage& s, const FbStagePlif& sp, const int buf) {
       int b, y, x0, cw;
       geom(min(k, nu - 1), b, y, x0, cw);
       const long pix0 = ((long)b * H + y) * W + x0;
@@ -740,6 +774,28 @@ __device__ __forceinline__ void fb_body_ws(
         if (g_cur) g_cur[eo] = make_float4(gc[0], gc[1], gc[2], gc[3]);
         g_v_prev[eo] = make_float4(gp[0], gp[1], gp[2], gp[3]);
       }
+      if (PLIF) {  // trace backward (the expressions of k_plif_trace_bwd, evf_network.hip: the same bits per element)
+        const float4 gk4 = has_gk ? sp.gk : z4, pp4 = has_pp ? sp.pp : z4;
+        const float gk[4] = {gk4.x, gk4.y, gk4.z, gk4.w}, pp[4] = {pp4.x, pp4.y, pp4.z, pp4.w};
+        const float Pv = sp.P;
+        float gq[4], gPp = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float po = pp[c] * lpt[c] + (1.0f - lpt[c]) * Pv;  // pt' of the forward pass, recomputed
+          const float g = gk[c] - apt[c] * gc[c];
+          gq[c] = g * lpt[c];
+          gPp += g * (1.0f - lpt[c]);
+          if (ok) {
+            slp[c] += g * (pp[c] - Pv);
+            sap[c] -= gc[c] * po;
+          }
+        }
+        if (ok) pl.g_pt_prev[eo] = make_float4(gq[0], gq[1], gq[2], gq[3]);
+        gPp += __shfl_xor(gPp, 1, 64);  // the 8 lanes of a pixel hold its 32 channels
+        gPp += __shfl_xor(gPp, 2, 64);
+        gPp += __shfl_xor(gPp, 4, 64);
+        if (ok && cg == 0) pl.g_P[pix0 + p] = gPp;
+      }
       // exact split g = hi + mid + lo in B-operand order: 16-byte chunk (pixel group G = p >> 3, channel j) = the 8 pixels of
       // the group, chunk index G * 32 + (j ^ (j >> 4)).  A lane holds 4 channels of ONE pixel; as 12 two-byte stores a wave
       // instruction hit 16 distinct words four times over (two lanes per word, channels j and j + 16 on one bank): half of the
@@ -780,31 +836,32 @@ __device__ __forceinline__ void fb_body_ws(
       // half units j = 2k + h through four register stages (stage j % 4): the loads of j + 4 go out as soon as commit(j) has
       // consumed the stage -- four half units (two units) of loads in flight, like fb_body's two units
       FbStage s0, s1, s2, s3;
-      issue(0, 0, s0);
-      issue(0, 1, s1);
-      issue(1, 0, s2);
-      issue(1, 1, s3);
+      FbStagePlif pd;  // (LIF only)
+      issue(0, 0, s0, pd);
+      issue(0, 1, s1, pd);
+      issue(1, 0, s2, pd);
+      issue(1, 1, s3, pd);
       constants();
-      commit(0, 0, s0, 0);
-      issue(2, 0, s0);
-      commit(0, 1, s1, 0);
-      issue(2, 1, s1);
+      commit(0, 0, s0, pd, 0);
+      issue(2, 0, s0, pd);
+      commit(0, 1, s1, pd, 0);
+      issue(2, 1, s1, pd);
       FBW_STAMP();
       __syncthreads();  // unit 0 staged
       FBW_STAMP();
 #pragma unroll 1
       for (int k = 0; k < nu; k += 2) {
-        commit(k + 1, 0, s2, 1);
-        issue(k + 3, 0, s2);
-        commit(k + 1, 1, s3, 1);
-        issue(k + 3, 1, s3);
+        commit(k + 1, 0, s2, pd, 1);
+        issue(k + 3, 0, s2, pd);
+        commit(k + 1, 1, s3, pd, 1);
+        issue(k + 3, 1, s3, pd);
         FBW_STAMP();
         __syncthreads();  // unit k + 1 staged in buffer 1; team M is done with buffer 0 (unit k)
         FBW_STAMP();
-        commit(k + 2, 0, s0, 0);
-        issue(k + 4, 0, s0);
-        commit(k + 2, 1, s1, 0);
-        issue(k + 4, 1, s1);
+        commit(k + 2, 0, s0, pd, 0);
+        issue(k + 4, 0, s0, pd);
+        commit(k + 2, 1, s1, pd, 0);
+        issue(k + 4, 1, s1, pd);
         FBW_STAMP();
         __syncthreads();
         FBW_STAMP();
@@ -812,22 +869,23 @@ __device__ __forceinline__ void fb_body_ws(
     } else {
       // whole units through three register stages that swap roles (fb_body's pipeline): two units of loads in flight
       FbStage s_cur, s_nxt, s_new;
-      issue(0, 0, s_cur);
-      issue(1, 0, s_nxt);
+      FbStagePlif p_cur, p_nxt, p_new;
+      issue(0, 0, s_cur, p_cur);
+      issue(1, 0, s_nxt, p_nxt);
       constants();
-      commit(0, 0, s_cur, 0);
+      commit(0, 0, s_cur, p_cur, 0);
       FBW_STAMP();
       __syncthreads();  // unit 0 staged
       FBW_STAMP();
 #pragma unroll 1
       for (int k = 0; k < nu; k += 2) {
-        issue(k + 2, 0, s_new);
-        commit(k + 1, 0, s_nxt, 1);
+        issue(k + 2, 0, s_new, p_new);
+        commit(k + 1, 0, s_nxt, p_nxt, 1);
         FBW_STAMP();
         __syncthreads();  // unit k + 1 staged in buffer 1; team M is done with buffer 0 (unit k)
         FBW_STAMP();
-        issue(k + 3, 0, s_nxt);
-        commit(k + 2, 0, s_new, 0);
+        issue(k + 3, 0, s_nxt, p_nxt);
+        commit(k + 2, 0, s_new, p_new, 0);
         FBW_STAMP();
         __syncthreads();
         FBW_STAMP();
@@ -1028,12 +1086,20 @@ __device__ __forceinline__ void fb_body_ws(
       for (int o = 8; o < 64; o <<= 1) {
         sl[c] += __shfl_xor(sl[c], o, 64);
         st[c] += __shfl_xor(st[c], o, 64);
+        if (PLIF) {
+          slp[c] += __shfl_xor(slp[c], o, 64);
+          sap[c] += __shfl_xor(sap[c], o, 64);
+        }
       }
     if (lane < 8) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         s_red[(0 * 8 + wv) * C32 + 4 * lane + c] = sl[c];
         s_red[(1 * 8 + wv) * C32 + 4 * lane + c] = st[c];
+        if (PLIF) {
+          s_red2[(0 * 8 + wv) * C32 + 4 * lane + c] = slp[c];
+          s_red2[(1 * 8 + wv) * C32 + 4 * lane + c] = sap[c];
+        }
       }
     }
   }
@@ -1062,6 +1128,14 @@ __device__ __forceinline__ void fb_body_ws(
       if (row_ld) g_thresh[row_off + c] = row_prev + v;
       else evf_atomic_add(g_thresh + c, v);
     }
+  } else if (PLIF && tid >= 128 && tid < 192) {
+    const int which = (tid >> 5) & 1, c = tid & 31;
+    float v = 0.f;
+    for (int w = 0; w < EW; ++w) v += s_red2[(which * 8 + w) * C32 + c];
+    const float sgm = fb_sigmoid(which == 0 ? pl.leak_pt[c] : pl.add_pt[c]);
+    float* dst = which == 0 ? pl.g_leak_pt : pl.g_add_pt;
+    if (row_ld) dst[row_off + c] = rowp_prev + v * sgm * (1.0f - sgm);
+    else evf_atomic_add(dst + c, v * sgm * (1.0f - sgm));
   }
 
   // ---- first touch of the slabs by a launch with fewer blocks than slab rows: the other rows start at zero (see fb_body)
@@ -1150,10 +1224,11 @@ struct FbJob {
   FbTop top;
   float width;
   int accumulate;
-  int kind;  // 0 feed-forward, 1 recurrent, 2 under the prediction head
+  int kind;  // 0 feed-forward, 1 recurrent, 2 under the prediction head; + 3: the same as PLIF cells (k_bwd_diag_ws_plif)
   int blk0;  // first block of the cell in a launch of several (INT_MAX: unused entry)
   int nblk;  // its number of blocks
   int pad_;
+  FbPlif pl;  // (kind >= 3)
 };
 
 struct FbJobs {
@@ -1205,8 +1280,29 @@ __global__ __launch_bounds__(64 * (EW + 4)) void k_bwd_diag_ws(FbJobs jobs, int 
                                  J.slab_ff, J.slab_rec, J.top, row_ld);
 }
 
+// PLIF cells (kind 3 .. 5): team E carries the trace backward as well; a kernel of its own, so that the LIF kernel's register
+// allocation (167 of the 168 a 768-thread block may have) stays what it is
+__global__ __launch_bounds__(768) void k_bwd_diag_ws_plif(FbJobs jobs, int B, int H, int W, int nchunk, long nunits, int row_ld,
+                                                          int nrows_total) {
+  const int jb = fb_job_of_block(jobs, (int)blockIdx.x);
+  const FbJob& J = jobs.j[jb];
+  const int bid = (int)blockIdx.x - J.blk0, nblk = J.nblk;
+  if (J.kind == 4)
+    fb_body_ws<true, false, 8, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
+                                     nchunk, nunits, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak,
+                                     J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld, J.pl);
+  else if (J.kind == 5)
+    fb_body_ws<false, true, 8, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
+                                     nchunk, nunits, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak,
+                                     J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld, J.pl);
+  else
+    fb_body_ws<false, false, 8, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
+                                      nchunk, nunits, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak,
+                                      J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld, J.pl);
+}
+
 static long fb_units(int B, int H, int W) { return (long)B * H * ((W + FB_CW - 1) / FB_CW); }
-#define FB_LDS (FB_R0 + 2 * (2 * 3 * C32 * FB_NW * 4) + 256 * 16 + 2 * 8 * C32 * 4)
+#define FB_LDS (FB_R0 + 2 * (2 * 3 * C32 * FB_NW * 4) + 256 * 16 + 2 * (2 * 8 * C32 * 4))  // (the second [2][8][32]: PLIF)
 
 extern "C" int evf_lif_bwd_wgrad_slabs(int B, int H, int W) { return evf_cdiv(fb_units(B, H, W), FB_UNITS); }
 
@@ -1393,7 +1489,7 @@ static int fb_split_blocks(FbJobs& jobs, int n, int nblk, long nunits, bool team
   const int lo = evf_cdiv(nunits, FB_UNITS_MAX), hi = evf_cdiv(nunits, FB_UNITS);
   int nb[FB_MAX_JOBS], wj[FB_MAX_JOBS];
   long ws = 0;
-  for (int k = 0; k < n; ++k) wj[k] = (teams8 && w[0] > 0 && w[1] > 0 && w[2] > 0) ? w[jobs.j[k].kind] : 1, ws += wj[k];
+  for (int k = 0; k < n; ++k) wj[k] = (teams8 && w[0] > 0 && w[1] > 0 && w[2] > 0) ? w[jobs.j[k].kind % 3] : 1, ws += wj[k];
   const long tot = (long)nblk * n;
   long used = 0;
   for (int k = 0; k < n; ++k) {
@@ -1440,6 +1536,7 @@ static int fb_defer_launch(FbDefer& fb_defer, int d, void* stream) {
     (void)hipFuncSetAttribute((const void*)k_bwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
     (void)hipFuncSetAttribute((const void*)k_bwd_diag_ws<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
     (void)hipFuncSetAttribute((const void*)k_bwd_diag_ws<8>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    (void)hipFuncSetAttribute((const void*)k_bwd_diag_ws_plif, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
     attr_set = true;
   }
   // EVF_BWD_DIAG=fused: every wave through all phases (k_bwd_diag); teams4: 4 + 4 waves; default (teams): 8 + 4 waves
@@ -1448,7 +1545,8 @@ static int fb_defer_launch(FbDefer& fb_defer, int d, void* stream) {
     if (e && e[0] == 'f') return 0;
     return (e && e[0] == 't' && e[5] == '4') ? 1 : 2;
   }();
-  const int teams = fb_diag_select < 0 ? teams_env : fb_diag_select;
+  const bool plif = fb_defer.job[d][0].kind >= 3;  // (a recording holds cells of one neuron model: fb_launch)
+  const int teams = plif ? 2 : (fb_diag_select < 0 ? teams_env : fb_diag_select);
   FbJobs jobs;
   for (int k = 0; k < FB_MAX_JOBS; ++k) jobs.j[k] = fb_defer.job[d][k < n ? k : 0];
   const long nunits = fb_units(fb_defer.B, fb_defer.H, fb_defer.W);
@@ -1457,7 +1555,10 @@ static int fb_defer_launch(FbDefer& fb_defer, int d, void* stream) {
   const int nblk = fb_blocks_per_cell(nunits, n, cost_env > 0 ? cost_env : (teams == 2 ? 8 : 11));  // (k_bwd_diag_ws<8>: ~4.0 k cycles per unit, phase stamps)
   const int ntot = fb_split_blocks(jobs, n, nblk, nunits, teams == 2);
   evf_prof_mark(1, 0, stream);
-  if (teams == 2)
+  if (plif)
+    hipLaunchKernelGGL(k_bwd_diag_ws_plif, dim3(ntot), dim3(768), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
+                       fb_defer.W, nchunk, nunits, fb_defer.row_ld, nrows);
+  else if (teams == 2)
     hipLaunchKernelGGL(k_bwd_diag_ws<8>, dim3(ntot), dim3(768), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
                        fb_defer.W, nchunk, nunits, fb_defer.row_ld, nrows);
   else if (teams == 1)
@@ -1522,7 +1623,8 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
                      const uint32_t* z_prev, const uint32_t* xT, const uint32_t* zT_prev, const float* leak,
                      const float* thresh, int B, int H, int W, int hard_reset, int surrogate, float act_width,
                      float* g_cur, void* g_split, float* g_v_prev, float* g_leak, float* g_thresh, float* slab_ff,
-                     float* slab_rec, int accumulate, void* stream) {
+                     float* slab_rec, int accumulate, void* stream, const FbPlif* plp = nullptr) {
+  if (plp && !(hard_reset != 0 && surrogate == EVF_ARCTAN)) return EVF_ENOTSUP;  // (the trace backward lives in the two-team body)
   if (!v_out || !xT || !leak || !thresh || (!g_cur && !g_split) || !g_v_prev || !g_leak || !g_thresh || !slab_ff || B <= 0 || H <= 0 ||
       W <= 0 || ((zT_prev != nullptr) != (slab_rec != nullptr)) || (topp && (g_z_out || zT_prev)) || (topp && g_z_out2))
     return EVF_EINVAL;
@@ -1542,13 +1644,16 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
   if (evf_bwd_defer.active) {
     bool any = false;
     for (int d = 0; d < EVF_BWD_DIAGS && !any; ++d) any = fb_defer.n[d] != 0;
-    const bool same = !any || (fb_defer.B == B && fb_defer.H == H && fb_defer.W == W && fb_defer.row_ld == row_ld);
+    bool same = !any || (fb_defer.B == B && fb_defer.H == H && fb_defer.W == W && fb_defer.row_ld == row_ld);
+    for (int d = 0; d < EVF_BWD_DIAGS && same; ++d)
+      if (fb_defer.n[d]) same = (fb_defer.job[d][0].kind >= 3) == (plp != nullptr);  // one neuron model per recording
     if (fast && (g_cur || g_split) && same && fb_defer.n[evf_bwd_defer.slot] < FB_MAX_JOBS) {
       fb_defer.B = B, fb_defer.H = H, fb_defer.W = W, fb_defer.row_ld = row_ld;
       FbJob& J = fb_defer.job[evf_bwd_defer.slot][fb_defer.n[evf_bwd_defer.slot]++];
       J = FbJob{(const float4*)g_z_out, (const float4*)g_z_out2, (const float4*)g_v_out, (const float4*)v_out,
                 (const float4*)v_prev, z_prev, xT, zT_prev, leak, thresh, (float4*)g_cur, (uint2*)g_split, (float4*)g_v_prev, g_leak, g_thresh,
-                slab_ff, slab_rec, top, act_width, accumulate, topp ? 2 : (zT_prev ? 1 : 0), 0, 0, 0};
+                slab_ff, slab_rec, top, act_width, accumulate, (topp ? 2 : (zT_prev ? 1 : 0)) + (plp ? 3 : 0), 0, 0, 0,
+                plp ? *plp : FbPlif{}};
       return EVF_OK;
     }
     const int rc = evf_bwd_defer_flush_now(bctx, stream);  // not recordable: everything recorded runs first
@@ -1560,19 +1665,24 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
     const char* e = getenv("EVF_BWD_ONE");
     return !(e && e[0] == 'f');
   }();
-  if (fast && one_teams && (g_cur || g_split)) {
+  if (fast && (one_teams || plp) && (g_cur || g_split)) {
     static bool attr_ws = false;
     if (!attr_ws) {
       (void)hipFuncSetAttribute((const void*)k_bwd_diag_ws<8>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+      (void)hipFuncSetAttribute((const void*)k_bwd_diag_ws_plif, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
       attr_ws = true;
     }
     FbJobs jobs;
     const FbJob J{(const float4*)g_z_out, (const float4*)g_z_out2, (const float4*)g_v_out, (const float4*)v_out, (const float4*)v_prev,
                   z_prev, xT, zT_prev, leak, thresh, (float4*)g_cur, (uint2*)g_split, (float4*)g_v_prev, g_leak, g_thresh, slab_ff,
-                  slab_rec, top, act_width, accumulate, topp ? 2 : (zT_prev ? 1 : 0), 0, 0, 0};
+                  slab_rec, top, act_width, accumulate, (topp ? 2 : (zT_prev ? 1 : 0)) + (plp ? 3 : 0), 0, 0, 0,
+                  plp ? *plp : FbPlif{}};
     const int nblk = fb_blocks_per_cell(nunits, 1, 8);
     for (int k = 0; k < FB_MAX_JOBS; ++k) jobs.j[k] = J, jobs.j[k].blk0 = k ? 0x7fffffff : 0, jobs.j[k].nblk = nblk;
-    hipLaunchKernelGGL(k_bwd_diag_ws<8>, dim3(nblk), dim3(768), FB_LDS, st, jobs, B, H, W, nchunk, nunits, row_ld, nrows_all);
+    if (plp)
+      hipLaunchKernelGGL(k_bwd_diag_ws_plif, dim3(nblk), dim3(768), FB_LDS, st, jobs, B, H, W, nchunk, nunits, row_ld, nrows_all);
+    else
+      hipLaunchKernelGGL(k_bwd_diag_ws<8>, dim3(nblk), dim3(768), FB_LDS, st, jobs, B, H, W, nchunk, nunits, row_ld, nrows_all);
     return evf_status();
   }
 #define FB_GO(REC_, TOP_, FAST_, slot)                                                                                    \
@@ -1640,4 +1750,36 @@ extern "C" int evf_lif_bwd_wgrad_top(const float* flow, const float* g_flow, con
   const FbTop top{flow, g_flow, pred_w, z_out, d_pred_w, d_pred_b};
   return fb_launch(nullptr, nullptr, &top, g_v_out, v_out, v_prev, z_prev, xT, nullptr, leak, thresh, B, H, W, hard_reset, surrogate,
                    act_width, g_cur, g_split, g_v_prev, g_leak, g_thresh, slab_ff, nullptr, accumulate, stream);
+}
+
+// PLIF cells (spiking_submodules.py:557-655): evf_lif_bwd_wgrad2 / _top with the presynaptic trace's backward in the same pass
+// (what evf_plif_trace_bwd computes from g_cur as a pass of its own): g_pt_carry [B,H,W,32] or NULL, pt_prev [B,H,W,32] or
+// NULL, P [B,H,W]; out: g_pt_prev [B,H,W,32] (may alias g_pt_carry), g_P_raw [B,H,W], g_leak_pt / g_add_pt (rows of pitch
+// accumulate >> 8, like g_leak).  Default neuron only (hard reset, arctan surrogate): EVF_ENOTSUP otherwise.
+extern "C" int evf_plif_bwd_wgrad2(const float* g_z_out, const float* g_z_out2, const float* g_v_out, const float* v_out,
+                                   const float* v_prev, const uint32_t* z_prev, const uint32_t* xT, const uint32_t* zT_prev,
+                                   const float* leak, const float* thresh, int B, int H, int W, int hard_reset, int surrogate,
+                                   float act_width, float* g_cur, void* g_split, float* g_v_prev, float* g_leak, float* g_thresh,
+                                   float* slab_ff, float* slab_rec, int accumulate, const float* g_pt_carry, const float* pt_prev,
+                                   const float* P, const float* leak_pt, const float* add_pt, float* g_pt_prev, float* g_P_raw,
+                                   float* g_leak_pt, float* g_add_pt, void* stream) {
+  if (!P || !leak_pt || !add_pt || !g_pt_prev || !g_P_raw || !g_leak_pt || !g_add_pt) return EVF_EINVAL;
+  const FbPlif pl{(const float4*)g_pt_carry, (const float4*)pt_prev, P, leak_pt, add_pt, (float4*)g_pt_prev, g_P_raw, g_leak_pt, g_add_pt};
+  return fb_launch(g_z_out, g_z_out2, nullptr, g_v_out, v_out, v_prev, z_prev, xT, zT_prev, leak, thresh, B, H, W, hard_reset,
+                   surrogate, act_width, g_cur, g_split, g_v_prev, g_leak, g_thresh, slab_ff, slab_rec, accumulate, stream, &pl);
+}
+extern "C" int evf_plif_bwd_wgrad_top(const float* flow, const float* g_flow, const float* pred_w, const uint32_t* z_out,
+                                      float* d_pred_w, float* d_pred_b, const float* g_v_out, const float* v_out,
+                                      const float* v_prev, const uint32_t* z_prev, const uint32_t* xT, const float* leak,
+                                      const float* thresh, int B, int H, int W, int hard_reset, int surrogate, float act_width,
+                                      float* g_cur, void* g_split, float* g_v_prev, float* g_leak, float* g_thresh, float* slab_ff,
+                                      int accumulate, const float* g_pt_carry, const float* pt_prev, const float* P,
+                                      const float* leak_pt, const float* add_pt, float* g_pt_prev, float* g_P_raw, float* g_leak_pt,
+                                      float* g_add_pt, void* stream) {
+  if (!flow || !g_flow || !pred_w || !z_out || !d_pred_w || !d_pred_b) return EVF_EINVAL;
+  if (!P || !leak_pt || !add_pt || !g_pt_prev || !g_P_raw || !g_leak_pt || !g_add_pt) return EVF_EINVAL;
+  const FbTop top{flow, g_flow, pred_w, z_out, d_pred_w, d_pred_b};
+  const FbPlif pl{(const float4*)g_pt_carry, (const float4*)pt_prev, P, leak_pt, add_pt, (float4*)g_pt_prev, g_P_raw, g_leak_pt, g_add_pt};
+  return fb_launch(nullptr, nullptr, &top, g_v_out, v_out, v_prev, z_prev, xT, nullptr, leak, thresh, B, H, W, hard_reset, surrogate,
+                   act_width, g_cur, g_split, g_v_prev, g_leak, g_thresh, slab_ff, nullptr, accumulate, stream, &pl);
 }

@@ -18,6 +18,42 @@ static inline int evf_hip(hipError_t e) { return e == hipSuccess ? EVF_OK : -(10
 
 static inline int evf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// hipMemsetAsync as a KERNEL.  Inside a captured step a hipMemsetAsync is a memset node, which the runtime executes outside the
+// pre-built AQL packets of the kernel nodes around it; on ROCm 7.2 replays of such graphs returned corrupted results after a
+// hipDeviceSynchronize (train.GraphedWindowStep: loss inf on the first replay behind the synchronize, fine with
+// DEBUG_CLR_GRAPH_PACKET_CAPTURE=0).  A fill kernel is a kernel node like its neighbours.  `bytes` any size, `dst` 4-byte aligned
+// when bytes >= 4 (every caller clears float / uint32 tensors).
+static __global__ void k_evf_fill(uint32_t* __restrict__ dst, uint32_t word, size_t nwords, unsigned char* __restrict__ tail, int ntail,
+                                  unsigned char byte) {
+  const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4, stride = (size_t)gridDim.x * blockDim.x * 4;
+  const bool al16 = (((uintptr_t)dst) & 15) == 0;
+  for (size_t i = i0; i < nwords; i += stride) {
+    if (al16 && i + 4 <= nwords) {
+      *(uint4*)(dst + i) = make_uint4(word, word, word, word);
+    } else {
+      for (size_t k = i; k < nwords && k < i + 4; ++k) dst[k] = word;
+    }
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = byte;
+}
+static inline hipError_t evf_memset_async(void* dst, int value, size_t bytes, hipStream_t st) {
+  if (!bytes) return hipSuccess;
+#ifdef EVF_MEMSET_RUNTIME  // (A/B builds)
+  return hipMemsetAsync(dst, value, bytes, st);
+#endif
+  if (((uintptr_t)dst) & 3) return hipMemsetAsync(dst, value, bytes, st);  // (never taken by this library's callers)
+  const unsigned char b = (unsigned char)value;
+  const uint32_t w = 0x01010101u * b;
+  const size_t nwords = bytes / 4;
+  const int ntail = (int)(bytes & 3);
+  const size_t quads = (nwords + 3) / 4;
+  long nb = (long)((quads + 255) / 256);
+  if (nb < 1) nb = 1;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_evf_fill, dim3((unsigned)nb), dim3(256), 0, st, (uint32_t*)dst, w, nwords, (unsigned char*)dst + nwords * 4, ntail, b);
+  return hipGetLastError();
+}
+
 // hardware fp32 atomic add (global_atomic_add_f32 / ds_add_f32); plain
 // atomicAdd would lower to a CAS loop without -munsafe-fp-atomics.
 __device__ __forceinline__ void evf_atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }

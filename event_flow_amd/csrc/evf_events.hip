@@ -33,7 +33,7 @@ extern "C" int evf_events_to_image(const float* xs, const float* ys, const float
                                    int accumulate, float* out, void* stream) {
   if (!out || H <= 0 || W <= 0 || n < 0 || (n > 0 && (!xs || !ys || !vals))) return EVF_EINVAL;
   hipStream_t st = EVF_STREAM(stream);
-  int rc = evf_hip(hipMemsetAsync(out, 0, sizeof(float) * (size_t)H * W, st));
+  int rc = evf_hip(evf_memset_async(out, 0, sizeof(float) * (size_t)H * W, st));
   if (rc || n == 0) return rc;
   hipLaunchKernelGGL(k_events_to_image, dim3(evf_cdiv(n, 256)), dim3(256), 0, st, xs, ys, vals, n, H, W, accumulate, out);
   return evf_status();
@@ -70,9 +70,9 @@ extern "C" int evf_encode_events(const float* ev, int B, int N, int H, int W, in
   hipStream_t st = EVF_STREAM(stream);
   const size_t HW = (size_t)H * W;
   int rc = 0;
-  if (cnt) rc |= evf_hip(hipMemsetAsync(cnt, 0, sizeof(float) * B * 2 * HW, st));
-  if (mask) rc |= evf_hip(hipMemsetAsync(mask, 0, sizeof(float) * B * HW, st));
-  if (voxel) rc |= evf_hip(hipMemsetAsync(voxel, 0, sizeof(float) * B * num_bins * HW, st));
+  if (cnt) rc |= evf_hip(evf_memset_async(cnt, 0, sizeof(float) * B * 2 * HW, st));
+  if (mask) rc |= evf_hip(evf_memset_async(mask, 0, sizeof(float) * B * HW, st));
+  if (voxel) rc |= evf_hip(evf_memset_async(voxel, 0, sizeof(float) * B * num_bins * HW, st));
   if (rc || N == 0) return rc;
   hipLaunchKernelGGL(k_encode_events, dim3(evf_cdiv((long)B * N, 256)), dim3(256), 0, st, (const float4*)ev, B, N, H, W,
                      num_bins, round_ts, cnt, mask, voxel, (float2*)pol);
@@ -122,7 +122,7 @@ extern "C" int evf_encode_window(const float* ev, int B, int P, int N, int H, in
   float* mask = (want & 4) ? dense + ((want & 1) ? S * 2 * HW : 0) + ((want & 2) ? S * num_bins * HW : 0) : nullptr;
   const size_t total = ((want & 1) ? S * 2 * HW : 0) + ((want & 2) ? S * num_bins * HW : 0) + ((want & 4) ? S * HW : 0);
   if (total) {
-    const int rc = evf_hip(hipMemsetAsync(dense, 0, sizeof(float) * total, st));
+    const int rc = evf_hip(evf_memset_async(dense, 0, sizeof(float) * total, st));
     if (rc) return rc;
   }
   if (N == 0) return EVF_OK;
@@ -453,7 +453,7 @@ extern "C" int evf_iwe_splat(const float* flow, const float* ev, const int32_t* 
   if (nch == 4 && !(mode & 4)) return EVF_EINVAL;
   if (M > 0 && !ev) return EVF_EINVAL;
   hipStream_t st = EVF_STREAM(stream);
-  if (M == 0) return evf_hip(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * nch * H * W, st));
+  if (M == 0) return evf_hip(evf_memset_async(out, 0, sizeof(float) * (size_t)B * nch * H * W, st));
   // stripe height: as tall as 128 KiB of LDS allows, shrunk (down to 8 rows) until the grid has
   // >= 256 blocks; every block re-reads the sample's events (L2 resident), so shorter stripes
   // trade redundant event reads for parallelism
@@ -513,7 +513,7 @@ extern "C" int evf_iwe_splat(const float* flow, const float* ev, const int32_t* 
     return evf_status();
   }
   // very wide images: global-atomic fallback kernel
-  int rc = evf_hip(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * nch * H * W, st));
+  int rc = evf_hip(evf_memset_async(out, 0, sizeof(float) * (size_t)B * nch * H * W, st));
   if (rc) return rc;
   dim3 grid(evf_cdiv((long)B * M, 256)), block(256);
   if (mode & 1)
@@ -588,7 +588,7 @@ extern "C" int evf_interpolate(const float* idx, const float* weights, const flo
                                int H, int W, float* out, void* stream) {
   if (!idx || !weights || !out || B <= 0 || M <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
   hipStream_t st = EVF_STREAM(stream);
-  int rc = evf_hip(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * H * W, st));
+  int rc = evf_hip(evf_memset_async(out, 0, sizeof(float) * (size_t)B * H * W, st));
   if (rc) return rc;
   hipLaunchKernelGGL(k_interpolate, dim3(evf_cdiv((long)B * M, 256)), dim3(256), 0, st, idx, weights, pol_mask, pstride,
                      B, M, H * W, out);
@@ -959,7 +959,7 @@ extern "C" int evf_cm_loss_fwd(const float* flow, const float* ev, const float* 
                          rows, (float)P, images, fin);
       return evf_status();
     }
-    rc = evf_hip(hipMemsetAsync(stats, 0, sizeof(float) * (size_t)S * B * 4, st));
+    rc = evf_hip(evf_memset_async(stats, 0, sizeof(float) * (size_t)S * B * 4, st));
     if (rc) return rc;
     hipLaunchKernelGGL(k_cm_prewarp, dim3(evf_cdiv((long)B * M, 256), S), dim3(256), 0, st, flow, (const float4*)ev,
                        (const float2*)pol, ev_pass, S, Pm, P, B, M, H, W, flow_scaling, warp, tabs);
@@ -967,9 +967,9 @@ extern "C" int evf_cm_loss_fwd(const float* flow, const float* ev, const float* 
     hipLaunchKernelGGL(k_cm_splat_lds, dim3(evf_cdiv(H, rows), S * B * 2), dim3(1024), lds, st, (const float4*)warp, tabs, B,
                        M, H, W, rows, (float)P, images, none);
   } else {
-    rc = evf_hip(hipMemsetAsync(stats, 0, sizeof(float) * (size_t)S * B * 4, st));
+    rc = evf_hip(evf_memset_async(stats, 0, sizeof(float) * (size_t)S * B * 4, st));
     if (rc) return rc;
-    rc = evf_hip(hipMemsetAsync(images, 0, sizeof(float) * (size_t)S * B * 8 * HW, st));
+    rc = evf_hip(evf_memset_async(images, 0, sizeof(float) * (size_t)S * B * 8 * HW, st));
     if (rc) return rc;
     hipLaunchKernelGGL(k_cm_splat, dim3(evf_cdiv((long)B * M, 256), S), dim3(256), 0, st, flow, (const float4*)ev,
                        (const float2*)pol, ev_pass, S, Pm, P, B, M, H, W, flow_scaling, images);
@@ -1413,7 +1413,7 @@ __global__ void k_nz_apply(const float* __restrict__ x, long n, const double* __
 extern "C" int evf_norm_nonzero(const float* x, int64_t n, float* out, double* ws3, void* stream) {
   if (!x || !out || !ws3 || n <= 0) return EVF_EINVAL;
   hipStream_t st = EVF_STREAM(stream);
-  const int rc = evf_hip(hipMemsetAsync(ws3, 0, 3 * sizeof(double), st));
+  const int rc = evf_hip(evf_memset_async(ws3, 0, 3 * sizeof(double), st));
   if (rc) return rc;
   const int nb = (int)((n + 1023) / 1024 < 1024 ? (n + 1023) / 1024 : 1024);
   hipLaunchKernelGGL(k_nz_sum, dim3(nb), dim3(256), 0, st, x, (long)n, ws3);

@@ -779,10 +779,10 @@ static int launch_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_re
               plif ? plif->pt_out : nullptr, plif ? plif->P_out : nullptr};
     if (fw_poison) {  // debug aid: the outputs hold conspicuous garbage until the flush has run the cell
       const size_t npix = (size_t)B * H * W;
-      int rc = evf_hip(hipMemsetAsync(v_out, 0xFF, npix * C32 * sizeof(float), EVF_STREAM(stream)));  // 0xFFFFFFFF = NaN
-      if (!rc && z_out) rc = evf_hip(hipMemsetAsync(z_out, 0xFF, npix * sizeof(uint32_t), EVF_STREAM(stream)));
-      if (!rc && pd.flow) rc = evf_hip(hipMemsetAsync(pd.flow, 0xFF, npix * 2 * sizeof(float), EVF_STREAM(stream)));
-      if (!rc && plif) rc = evf_hip(hipMemsetAsync(plif->pt_out, 0xFF, npix * C32 * sizeof(float), EVF_STREAM(stream)));
+      int rc = evf_hip(evf_memset_async(v_out, 0xFF, npix * C32 * sizeof(float), EVF_STREAM(stream)));  // 0xFFFFFFFF = NaN
+      if (!rc && z_out) rc = evf_hip(evf_memset_async(z_out, 0xFF, npix * sizeof(uint32_t), EVF_STREAM(stream)));
+      if (!rc && pd.flow) rc = evf_hip(evf_memset_async(pd.flow, 0xFF, npix * 2 * sizeof(float), EVF_STREAM(stream)));
+      if (!rc && plif) rc = evf_hip(evf_memset_async(plif->pt_out, 0xFF, npix * C32 * sizeof(float), EVF_STREAM(stream)));
       if (rc) return rc;
     }
     return EVF_OK;

@@ -94,7 +94,7 @@ extern "C" int evf_reduce_slabs(const float* partial, int nslab, int n, int accu
   if (!partial || !dst || nslab <= 0 || n != 9 * C32 * C32) return EVF_EINVAL;
   hipStream_t st = EVF_STREAM(stream);
   if (!accumulate) {
-    int rc = evf_hip(hipMemsetAsync(dst, 0, sizeof(float) * n, st));
+    int rc = evf_hip(evf_memset_async(dst, 0, sizeof(float) * n, st));
     if (rc) return rc;
   }
   hipLaunchKernelGGL(k_reduce_wgrad_par, dim3(evf_cdiv(n, 256), RS_GROUPS), dim3(256), 0, st, partial, nslab, dst);
@@ -678,8 +678,8 @@ extern "C" int evf_head_lif_fwd(const float* x, const float* w, const float* lea
     hf.job[hf.n++] = HfJob{x, w, leak, thresh, v_prev, z_prev, B, Cin, H, W, hard_reset, v_out, z_out, zT_out};
     if (evf_defer_poisoned()) {
       const size_t npix = (size_t)B * H * W;
-      int rc = evf_hip(hipMemsetAsync(v_out, 0xFF, npix * C32 * sizeof(float), EVF_STREAM(stream)));
-      if (!rc) rc = evf_hip(hipMemsetAsync(z_out, 0xFF, npix * sizeof(uint32_t), EVF_STREAM(stream)));
+      int rc = evf_hip(evf_memset_async(v_out, 0xFF, npix * C32 * sizeof(float), EVF_STREAM(stream)));
+      if (!rc) rc = evf_hip(evf_memset_async(z_out, 0xFF, npix * sizeof(uint32_t), EVF_STREAM(stream)));
       if (rc) return rc;
     }
     return EVF_OK;
@@ -1982,7 +1982,7 @@ int evf_clip_adam_step_impl(float* param, float* grad, float* m, float* v, int64
   if (!param || !grad || !m || !v || !norm_ws || n <= 0) return EVF_EINVAL;
   hipStream_t st = EVF_STREAM(stream);
   const int device_step = step <= 0;  // step <= 0: use (and advance) the counter in norm_ws[1]
-  int rc = evf_hip(hipMemsetAsync(norm_ws, 0, sizeof(float), st));
+  int rc = evf_hip(evf_memset_async(norm_ws, 0, sizeof(float), st));
   if (rc) return rc;
   const int nblk = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
   hipLaunchKernelGGL(k_sumsq, dim3(nblk), dim3(256), 0, st, grad, (long)n, norm_ws, device_step);

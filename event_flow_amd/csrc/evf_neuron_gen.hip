@@ -460,7 +460,7 @@ extern "C" int evf_neuron_bwd(int kind, const float* g_v_out, const float* g_z_o
   if (kind == EVF_ALIF && g_v_prev && !g_z_prev) return EVF_EINVAL;
   hipStream_t st = EVF_STREAM(stream);
   if ((kind == EVF_PLIF || kind == EVF_XLIF) && Q > 64) {
-    const int rc = evf_hip(hipMemsetAsync(g_P, 0, sizeof(float) * (size_t)npix, st));
+    const int rc = evf_hip(evf_memset_async(g_P, 0, sizeof(float) * (size_t)npix, st));
     if (rc) return rc;
   }
   NgParams prm = {{p0, p1, p2, p3}, {g_p0, g_p1, g_p2, g_p3}};

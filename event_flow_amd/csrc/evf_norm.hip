@@ -53,7 +53,7 @@ extern "C" int evf_chan_reduce(const float* x, int ldx, const float* y, int ldy,
   if (!x || !out || G <= 0 || npg <= 0 || C <= 0 || ldx < C || mode < 0 || mode > 2 || (mode == 2 && (!y || ldy < C)))
     return EVF_EINVAL;
   hipStream_t st = EVF_STREAM(stream);
-  int rc = evf_hip(hipMemsetAsync(out, 0, sizeof(float) * (size_t)G * C, st));
+  int rc = evf_hip(evf_memset_async(out, 0, sizeof(float) * (size_t)G * C, st));
   if (rc) return rc;
   int ct = 1;
   while (ct < C && ct < 64) ct <<= 1;

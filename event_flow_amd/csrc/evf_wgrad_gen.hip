@@ -945,7 +945,7 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
   accumulate &= 1;
   hipStream_t st = EVF_STREAM(stream);
   if (!accumulate && g_bias) {
-    const int rc = evf_hip(hipMemsetAsync(g_bias, 0, sizeof(float) * (size_t)Cout, st));
+    const int rc = evf_hip(evf_memset_async(g_bias, 0, sizeof(float) * (size_t)Cout, st));
     if (rc) return rc;
   }
   static const bool fewin_on = !(getenv("EVF_WGRAD_FEWIN") && !strcmp(getenv("EVF_WGRAD_FEWIN"), "0"));
@@ -1044,7 +1044,7 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
     return evf_status();
   }
   if (!accumulate) {
-    const int rc = evf_hip(hipMemsetAsync(g_w, 0, sizeof(float) * (size_t)Cout * cin_total * ksz * ksz, st));
+    const int rc = evf_hip(evf_memset_async(g_w, 0, sizeof(float) * (size_t)Cout * cin_total * ksz * ksz, st));
     if (rc) return rc;
   }
   WgGeo g;
@@ -1114,7 +1114,7 @@ extern "C" int evf_head1x1_bwd(const float* x, int ldx, const float* y, int ldy,
     return EVF_EINVAL;
   hipStream_t st = EVF_STREAM(stream);
   if (!accumulate && g_bias) {
-    const int rc = evf_hip(hipMemsetAsync(g_bias, 0, sizeof(float) * (size_t)Cout, st));
+    const int rc = evf_hip(evf_memset_async(g_bias, 0, sizeof(float) * (size_t)Cout, st));
     if (rc) return rc;
   }
   const int ppb = (int)evf_cdiv(M, WG1_BLOCKS);

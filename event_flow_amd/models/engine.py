@@ -50,6 +50,9 @@ TOP_FUSED = os.environ.get("EVF_TOP_FUSED", "1") != "0"  # prediction-head backw
 PAIR_DGRAD = os.environ.get("EVF_PAIR_DGRAD", "1") != "0"
 # PLIF: AvgPool3x3^T / 32 of dL/d(pooled activity) inside the input-gradient kernels (0: a k_plif_box launch per cell; A/B, tests)
 PLIF_BOX_IN_DGRAD = os.environ.get("EVF_PLIF_BOX", "dgrad") != "kernel"
+# PLIF hidden cells: the trace backward inside the fused backward's streaming team (evf_plif_bwd_wgrad2 / _top); 0: evf_plif_trace_bwd
+# as a pass of its own behind evf_lif_bwd_wgrad2 (A/B, tests)
+PLIF_TRACE_FUSED = os.environ.get("EVF_PLIF_TRACE_FUSED", "1") != "0"
 # window gradients -> the flat gradient buffer in one launch (evf_grads_finalize); 0: row sums, slab reduction, segment add one by one
 FUSED_TAIL = os.environ.get("EVF_FUSED_TAIL", "1") != "0"
 PARAM_ROWS = os.environ.get("EVF_PARAM_ROWS", "1") != "0"  # per-channel gradients through per-block rows (0: atomics)  # ff + rec input gradients of a recurrent cell in one launch
@@ -194,11 +197,11 @@ class FireNetEngine:
             p.requires_grad and p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.is_cuda
             for name, p in zip(self.pnames, self.params) if name in self.small_off)
         if not ok:
-            return torch.zeros(self.small_size, dtype=torch.float32, device=dev), False
+            return _lib.zeros(self.small_size, dtype=torch.float32, device=dev), False
         if self._small_buf is None or self._small_buf.device != dev:
-            self._small_buf = torch.zeros(self.small_size, dtype=torch.float32, device=dev)
+            self._small_buf = _lib.zeros(self.small_size, dtype=torch.float32, device=dev)
         elif not self._small_clean:  # (a window that never reached _finalize)
-            self._small_buf.zero_()
+            _lib.zero_(self._small_buf)
         self._small_clean = False
         return self._small_buf, True
 
@@ -212,14 +215,14 @@ class FireNetEngine:
         n = max(L.evf_lif_bwd_wgrad_slabs(B, H, W), L.evf_head_lif_bwd_wgrad_slabs(B, H, W), 512)
         buf = self.__dict__.get("_rows_buf")
         if buf is None or buf.device != dev or buf.shape[0] < n or not self.__dict__.get("_rows_clean", False):
-            buf = torch.zeros((n, self.small_size), dtype=torch.float32, device=dev)
+            buf = _lib.zeros((n, self.small_size), dtype=torch.float32, device=dev)
             self._rows_buf = buf
         self._rows_clean = False
         return buf
 
     def _token(self, dev):
         if self._token0 is None or self._token0.device != dev:
-            self._token0 = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
+            self._token0 = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)  # (created once, outside any capture)
         return self._token0
 
     def _act_width(self, i):
@@ -590,6 +593,19 @@ class FireNetEngine:
             gv_out = win.buf(win.gv, i)
             leak_g, thr_g = self._small(win, f"{i}.leak"), self._small(win, f"{i}.thresh")
             (leak_r, row_ld), (thr_r, _) = self._rowed(win, f"{i}.leak"), self._rowed(win, f"{i}.thresh")
+            # PLIF: the trace backward rides in the fused backward (default neuron, pooling adjoint inside the input-gradient kernels)
+            trace_fused = (plif and PLIF_TRACE_FUSED and PLIF_BOX_IN_DGRAD and i > 0 and self.precision == "bf16x3"
+                           and c.hard_reset and c.activation == "arctanspike")
+            if trace_fused:
+                if win.gP is None:
+                    win.gP = _f32((B, H, W), dev)
+                    win.gP_raw = _f32((B, H, W), dev)
+                gpt_out = win.buf(win.gpt, i)
+                trace_args = (_lib.ptr(gpt_out if win.gpt_has[i] else None), _lib.ptr(pt_prev), _lib.ptr(P_sav),
+                              _lib.ptr(self._flat[f"{i}.leak_pt"]), _lib.ptr(self._flat[f"{i}.add_pt"]), _lib.ptr(gpt_out),
+                              _lib.ptr(win.gP_raw), _lib.ptr(self._rowed(win, f"{i}.leak_pt")[0]),
+                              _lib.ptr(self._rowed(win, f"{i}.add_pt")[0]))
+                win.gpt_has[i] = not is_first
             if i > 0 and self.precision == "bf16x3":
                 # neuron backward + both weight gradients in one pass (evf_bwd_fused.hip)
                 kf, kr = (i, "ff"), (i, "rec")
@@ -597,17 +613,18 @@ class FireNetEngine:
                 acc_flag = 1 if win.slab_init.get(kf) else 0
                 if use_rec and bool(win.slab_init.get(kr)) != bool(acc_flag):
                     # first recurrent contribution arrives later than the ff one: start its slab at zero
-                    self._slab(kr, nsl, dev).zero_()
+                    _lib.zero_(self._slab(kr, nsl, dev))
                 if top:
-                    _lib.call("evf_lif_bwd_wgrad_top", _lib.ptr(tape["flow"]), _lib.ptr(g_flow_c), _lib.ptr(self._flat["pred.w"]),
+                    _lib.call("evf_plif_bwd_wgrad_top" if trace_fused else "evf_lif_bwd_wgrad_top", _lib.ptr(tape["flow"]), _lib.ptr(g_flow_c), _lib.ptr(self._flat["pred.w"]),
                               _lib.ptr(layers[i][4]), _lib.ptr(self._rowed(win, "pred.w")[0]), _lib.ptr(self._rowed(win, "pred.b")[0]),
                               _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(in_bitsT),
                               _lib.ptr(self._flat[f"{i}.leak"]), _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W,
                               1 if c.hard_reset else 0, SURROGATE_ID[c.activation], self._act_width(i),
                               _lib.ptr(g_cur_i) if (plif or F32_DGRAD) else None, _lib.ptr(g_split_i), _lib.ptr(gv_out),
-                              _lib.ptr(leak_r), _lib.ptr(thr_r), _lib.ptr(self._slab(kf, nsl, dev)), acc_flag | (row_ld << 8))
+                              _lib.ptr(leak_r), _lib.ptr(thr_r), _lib.ptr(self._slab(kf, nsl, dev)), acc_flag | (row_ld << 8),
+                              *(trace_args if trace_fused else ()))
                 else:
-                    _lib.call("evf_lif_bwd_wgrad2", _lib.ptr(g_z), _lib.ptr(g_z2), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev),
+                    _lib.call("evf_plif_bwd_wgrad2" if trace_fused else "evf_lif_bwd_wgrad2", _lib.ptr(g_z), _lib.ptr(g_z2), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev),
                           _lib.ptr(z_prev),
                           _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None, _lib.ptr(self._flat[f"{i}.leak"]),
                           _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
@@ -615,7 +632,7 @@ class FireNetEngine:
                           _lib.ptr(gv_out),
                           _lib.ptr(leak_r), _lib.ptr(thr_r),
                           _lib.ptr(self._slab(kf, nsl, dev)), _lib.ptr(self._slab(kr, nsl, dev)) if use_rec else None,
-                          acc_flag | (row_ld << 8))
+                          acc_flag | (row_ld << 8), *(trace_args if trace_fused else ()))
                 win.slab_init[kf] = True
                 if use_rec:
                     win.slab_init[kr] = True
@@ -650,7 +667,7 @@ class FireNetEngine:
                     _lib.call("evf_conv_wgrad_bits", _lib.ptr(z_prev), _lib.ptr(win.g_cur), B, H, W,
                               _lib.ptr(self._slab(k, nslab, dev)), 1 if win.slab_init.get(k) else 0)
                     win.slab_init[k] = True
-            if plif:  # trace backward: carries dL/dpt, yields dL/d(pooled activity) for the input-spike gradient
+            if plif and not trace_fused:  # trace backward: carries dL/dpt, yields dL/d(pooled activity) for the input-spike gradient
                 if win.gP is None:
                     win.gP = _f32((B, H, W), dev)
                     win.gP_raw = _f32((B, H, W), dev)
@@ -799,7 +816,7 @@ class FireNetEngine:
                     red_dst.append(p.grad)
                 grads.append(None)
                 continue
-            g = torch.zeros(p.shape, dtype=torch.float32, device=win.dev)
+            g = _lib.zeros(p.shape, dtype=torch.float32, device=win.dev)
             if win.slab_init.get(k):
                 _lib.call("evf_reduce_slabs", _lib.ptr(self._slabs[k]), nslab, 9 * C * C, 0, _lib.ptr(g))
             grads.append(g.to(p.dtype))

@@ -252,9 +252,9 @@ def conv_wgrad(x, g_y, g_w, g_b, Cin, Cout, k, stride, cin_total=None, cin_off=0
     if spikes and analog_head and k == 3 and stride == 1 and cin_off == 0 and Cin > 8:
         a = (analog_head + 3) // 4 * 4  # (the tail must stay 16-byte aligned)
         if not accumulate:
-            g_w.zero_()
+            _lib.zero_(g_w)
             if g_b is not None:
-                g_b.zero_()
+                _lib.zero_(g_b)
         conv_wgrad(x, g_y, g_w, g_b, a, Cout, k, stride, ct, 0, 1, spikes=False)
         conv_wgrad(x[..., a:], g_y, g_w, None, Cin - a, Cout, k, stride, ct, a, 1, spikes=True,
                    exact_from=None if exact_from is None else max(exact_from - a, 0))
@@ -369,7 +369,7 @@ _NEURON_WS = {}
 def _neuron_ws(dev):
     """Zeroed scratch of evf_neuron_bwd (the kernel hands it back zeroed; one per device, calls are stream-ordered)."""
     if dev not in _NEURON_WS:
-        _NEURON_WS[dev] = torch.zeros(32 * 4096 + 64, dtype=torch.float32, device=dev)
+        _NEURON_WS[dev] = _lib.zeros(32 * 4096 + 64, dtype=torch.float32, device=dev)
     return _NEURON_WS[dev]
 
 
@@ -511,12 +511,12 @@ class _CellStep(torch.autograd.Function):
         g_prev = _new((ns, B, Ho, Wo, C), dev) if want_prev else None
         rec_dgrad = cell.recurrent and sp is not None and need[2]
         if kind != 2 and not rec_dgrad and sp is not None and need[2]:  # (only a returned state gradient needs the zeros)
-            g_prev[1].zero_()
+            _lib.zero_(g_prev[1])
         g_P = _new((B, Ho, Wo), dev) if kind in (1, 3) else None
         params = cell_params(cell)
         d_prm = [bound_grad(params[i]) if (prm[i] is not None and need[6 + i]) else None for i in range(4)]
         g_prm = [d_prm[i].view(-1) if d_prm[i] is not None else
-                 (torch.zeros(C, dtype=torch.float32, device=dev) if (prm[i] is not None and need[6 + i]) else None)
+                 (_lib.zeros(C, dtype=torch.float32, device=dev) if (prm[i] is not None and need[6 + i]) else None)
                  for i in range(4)]
         _lib.call("evf_neuron_bwd", kind, _lib.ptr(gs[0]) if gs is not None else None, _lib.ptr(gon),
                   _lib.ptr(gs[1]) if gs is not None else None, _lib.ptr(gs[2]) if (gs is not None and ns == 3) else None,
@@ -548,7 +548,7 @@ class _CellStep(torch.autograd.Function):
                 g_wrec = _new(tuple(wrec.shape), dev)
                 conv_wgrad(sp[1], g_cur, g_wrec, None, C, C, k, 1, spikes=True, exact_from=rec_exact)
             elif d is None:
-                g_wrec = torch.zeros(tuple(wrec.shape), dtype=torch.float32, device=dev)
+                g_wrec = _lib.zeros(tuple(wrec.shape), dtype=torch.float32, device=dev)
         if need[1]:
             g_xn = _new((B, H, W, Cin), dev)
             conv_dgrad(g_cur, _wcache(cell, "ffT").get(wff, 1, 0, Cin), g_xn, Cin, C, k, s)
@@ -616,7 +616,7 @@ def cell_forward(cell, input_, prev_state, residual=0, slots=None):
             if prev_state is None:  # (the reference normalises the zero state as well: z becomes the layer's bias)
                 k, s = cell.kernel_size, cell.stride
                 shp = (input_.shape[0], cell.hidden_size, _out_dim(input_.shape[2], k, s), _out_dim(input_.shape[3], k, s))
-                prev_state = torch.zeros((2,) + shp, dtype=torch.float32, device=input_.device)
+                prev_state = _lib.zeros((2,) + shp, dtype=torch.float32, device=input_.device)
             # the NORMALISED previous spikes feed the recurrent conv and the (detached) reset alike (:528-529, :539-546)
             prev_state = torch.stack([prev_state[0], group_norm1(prev_state[1], cell.norm_rec)])
     if getattr(cell, "wnorm", False):  # (the normalised weights are new tensors every call: nothing cached may outlive them)
@@ -800,7 +800,7 @@ class _Norm2d(torch.autograd.Function):
             var = layer.running_var.detach().float().reshape(1, C).expand(G, C).contiguous()
         rstd = torch.rsqrt(var + eps)
         w = weight.detach().float().reshape(1, C) if weight is not None else torch.ones((1, C), device=dev)
-        b = bias.detach().float().reshape(1, C) if bias is not None else torch.zeros((1, C), device=dev)
+        b = bias.detach().float().reshape(1, C) if bias is not None else _lib.zeros((1, C), device=dev)
         scale = (w * rstd).contiguous()
         shift = (b - mean * w * rstd).contiguous()
         y = _new((B, H, W, C), dev)
@@ -825,8 +825,8 @@ class _Norm2d(torch.autograd.Function):
             Bc = (-(rstd * rstd) * w * s2 / npg).contiguous()
             Cc = (-Bc * mean - rstd * w * s1 / npg).contiguous()
         else:
-            Bc = torch.zeros_like(A)
-            Cc = torch.zeros_like(A)
+            Bc = _lib.zeros(A.shape, dtype=A.dtype, device=A.device)
+            Cc = _lib.zeros(A.shape, dtype=A.dtype, device=A.device)
         gx = _new(tuple(xn.shape), dev)
         _lib.call("evf_chan_affine", _lib.ptr(g), C, _lib.ptr(xn), C, _lib.ptr(A), _lib.ptr(Bc), _lib.ptr(Cc), G, npg, C, _lib.ptr(gx), C)
         g_w = s2.sum(0).reshape(ctx.wshape) if has_w else None
@@ -984,7 +984,7 @@ class _LeakyMix(torch.autograd.Function):
         g_leak = d_leak = None
         if need[3]:
             d_leak = bound_grad(ctx.leak)
-            g_leak = d_leak.view(-1) if d_leak is not None else torch.zeros(C, dtype=torch.float32, device=mix.device)
+            g_leak = d_leak.view(-1) if d_leak is not None else _lib.zeros(C, dtype=torch.float32, device=mix.device)
         _lib.call("evf_leaky_bwd", _lib.ptr(gon), _lib.ptr(gmn), _lib.ptr(mix), _lib.ptr(pn), _lib.ptr(lk), ctx.act, B * H * W, C,
                   _lib.ptr(g_cur), _lib.ptr(g_prev), _lib.ptr(g_leak))
         gc = from_nhwc(g_cur)
@@ -1055,13 +1055,13 @@ class _ConvGRU(torch.autograd.Function):
             conv_dgrad(g_co, _wcache(owner, "ohT").get(wo, 1, Cx, Ch), g_hr, Ch, Ch, k, 1)
             _lib.call("evf_gru_gates_bwd", _lib.ptr(g_hr), _lib.ptr(hn), _lib.ptr(r), n, _lib.ptr(g_cr), _lib.ptr(g_h))
         else:
-            g_cr.zero_()
+            _lib.zero_(g_cr)
 
         def wgrads(w, b, gate_g, hsrc):
             d_w, d_b = bound_grad(w), bound_grad(b)
             direct = d_w is not None and d_b is not None
-            g_w = d_w if direct else torch.zeros(tuple(w.shape), dtype=torch.float32, device=dev)
-            g_b = d_b if direct else torch.zeros((Ch,), dtype=torch.float32, device=dev)
+            g_w = d_w if direct else _lib.zeros(tuple(w.shape), dtype=torch.float32, device=dev)
+            g_b = d_b if direct else _lib.zeros((Ch,), dtype=torch.float32, device=dev)
             conv_wgrad(xn, gate_g, g_w, g_b, Cx, Ch, k, 1, cin_total=Cx + Ch, cin_off=0, accumulate=1)
             if hsrc is not None:
                 conv_wgrad(hsrc, gate_g, g_w, None, Ch, Ch, k, 1, cin_total=Cx + Ch, cin_off=Cx, accumulate=1)
@@ -1132,8 +1132,8 @@ class _ConvLSTM(torch.autograd.Function):
         if need[4] or need[5]:
             d_w, d_b = bound_grad(w), bound_grad(ctx.bias)
             direct = d_w is not None and d_b is not None
-            g_w = d_w if direct else torch.zeros(tuple(w.shape), dtype=torch.float32, device=dev)
-            g_b = d_b if direct else torch.zeros((4 * Ch,), dtype=torch.float32, device=dev)
+            g_w = d_w if direct else _lib.zeros(tuple(w.shape), dtype=torch.float32, device=dev)
+            g_b = d_b if direct else _lib.zeros((4 * Ch,), dtype=torch.float32, device=dev)
             conv_wgrad(xn, g_gates, g_w, g_b, Cx, 4 * Ch, k, 1, cin_total=Cx + Ch, cin_off=0, accumulate=1)
             if hn is not None:
                 conv_wgrad(hn, g_gates, g_w, None, Ch, 4 * Ch, k, 1, cin_total=Cx + Ch, cin_off=Cx, accumulate=1)

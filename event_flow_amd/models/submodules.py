@@ -13,6 +13,7 @@ models/engine.py)."""
 import torch
 import torch.nn as nn
 
+from .. import _lib
 from . import hip_ops
 from .spiking_util import SURROGATE_ID
 
@@ -102,7 +103,7 @@ class ConvLSTM(nn.Module):
 
 def _zeros_like_state(x, channels):
     B, _, H, W = x.shape
-    return torch.zeros((B, H, W, channels), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+    return _lib.zeros((B, H, W, channels), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
 
 
 class ConvRecurrent(nn.Module):

@@ -18,6 +18,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import _lib
+
 
 class DataParallel:
     TAIL = 2  # [loss, new_seq flag]
@@ -115,9 +117,10 @@ class DataParallel:
         (device-side only; safe inside a hipGraph capture)."""
         n = comm.numel() - self.TAIL
         if loss is not None:
-            comm[n : n + 1].copy_(loss.detach().reshape(1))
+            # (a kernel, not copy_: a same-dtype device copy is a memcpy NODE in a captured step -- see _lib.zero_)
+            torch.mul(loss.detach().reshape(1).to(comm.dtype), 1.0, out=comm[n : n + 1])
         else:
-            comm[n : n + 1].zero_()
+            _lib.zero_(comm[n : n + 1])
         comm[n + 1 : n + 2].fill_(1.0 if new_seq else 0.0)
 
     def _on_comm_stream(self, fn):

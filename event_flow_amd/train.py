@@ -84,7 +84,7 @@ class FlatAdam:
         # the fused step clears the buffer as it consumes it: zero_grad() right after step() (train_flow.py:163-164)
         # needs no fill kernel.  A loop that runs a backward between step() and zero_grad() calls mark_grad_dirty().
         if not self._grad_clean:
-            self.flat_grad.zero_()
+            _lib.zero_(self.flat_grad)
         self._grad_clean = False
         if any(p.grad is None for p in self.params):  # keep .grad bound to the flat buffer
             self._rebind()
@@ -259,7 +259,7 @@ class StreamReplicas:
             shadow = copy.deepcopy(model)
             if eng is not None:
                 model._engine = eng
-            g = torch.zeros(optimizer.n, dtype=torch.float32, device=dev)
+            g = _lib.zeros(optimizer.n, dtype=torch.float32, device=dev)
             off = 0
             for p, q in zip([p for p in model.parameters() if p.requires_grad], [q for q in shadow.parameters() if q.requires_grad]):
                 k = p.numel()

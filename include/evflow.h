@@ -33,7 +33,7 @@ extern "C" {
 
 #define EVF_OK 0
 #define EVF_EINVAL (-22)
-#define EVF_ENOTSUP (-95) /* a run-time dependency is absent (evf_comm_*: no librccl) */
+#define EVF_ENOTSUP (-95) /* a run-time dependency is absent (evf_comm_*: no librccl), or this form does not serve the request */
 
 /* library / device probe (no GPU work) */
 int evf_version(void);          /* 100*major + minor */
@@ -380,6 +380,28 @@ int evf_plif_trace_bwd(const float* g_cur, const float* g_pt_carry, const float*
                        const float* P, const float* leak_pt, const float* add_pt, int B, int H, int W,
                        float* g_pt_prev, float* g_P_raw, float* g_P_in, float* g_leak_pt, float* g_add_pt,
                        int row_ld, void* stream);
+
+/* PLIF hidden cells, one pass: evf_lif_bwd_wgrad2 / evf_lif_bwd_wgrad_top with the presynaptic trace's backward inside
+ * (reference models/spiking_submodules.py:634-652, autograd of :557-632): what evf_plif_trace_bwd computes from g_cur in a
+ * pass of its own -- g_pt_prev (may alias g_pt_carry), the raw map g_P_raw and the sums for leak_pt / add_pt (per-block rows
+ * of pitch `accumulate >> 8`, like g_leak) -- comes out of the pass that produces g_cur (the same bits per element as the two
+ * calls).  g_pt_carry / pt_prev may be NULL (last pass of a window / zero state).  Recordable like the LIF forms
+ * (evf_bwd_defer_*).  Default neuron only (hard reset, arctan surrogate): EVF_ENOTSUP otherwise -- use the two calls. */
+int evf_plif_bwd_wgrad2(const float* g_z_out, const float* g_z_out2, const float* g_v_out, const float* v_out,
+                        const float* v_prev, const uint32_t* z_prev, const uint32_t* xT, const uint32_t* zT_prev,
+                        const float* leak, const float* thresh, int B, int H, int W, int hard_reset, int surrogate,
+                        float act_width, float* g_cur, void* g_split, float* g_v_prev, float* g_leak, float* g_thresh,
+                        float* slab_ff, float* slab_rec, int accumulate, const float* g_pt_carry, const float* pt_prev,
+                        const float* P, const float* leak_pt, const float* add_pt, float* g_pt_prev, float* g_P_raw,
+                        float* g_leak_pt, float* g_add_pt, void* stream);
+int evf_plif_bwd_wgrad_top(const float* flow, const float* g_flow, const float* pred_w, const uint32_t* z_out,
+                           float* d_pred_w, float* d_pred_b, const float* g_v_out, const float* v_out,
+                           const float* v_prev, const uint32_t* z_prev, const uint32_t* xT, const float* leak,
+                           const float* thresh, int B, int H, int W, int hard_reset, int surrogate, float act_width,
+                           float* g_cur, void* g_split, float* g_v_prev, float* g_leak, float* g_thresh, float* slab_ff,
+                           int accumulate, const float* g_pt_carry, const float* pt_prev, const float* P,
+                           const float* leak_pt, const float* add_pt, float* g_pt_prev, float* g_P_raw, float* g_leak_pt,
+                           float* g_add_pt, void* stream);
 
 /* Input-gradient conv: g_x[pix][ci] (+)= sum_tap,co g_cur[pix-tap][co]*w[co][ci][tap]
  * with wT packed by evf_pack_conv_weight(transposed=1).  g_cur, g_x [B,H,W,32].
@@ -731,6 +753,16 @@ int evf_comm_init(const void* id128, int rank, int world, void** comm);
 int evf_comm_destroy(void* comm);
 int evf_allreduce_sum(void* comm, float* buf, int64_t n, void* stream);
 int evf_allreduce_max(void* comm, float* buf, int64_t n, void* stream);
+
+/* memset as a kernel launch: `bytes` bytes at `dst` (4-byte aligned) set to the byte `value`.  Inside a captured step
+ * (hipGraph) a hipMemsetAsync becomes a memset node; on ROCm 7.2 graphs holding such nodes between kernel nodes replayed with
+ * corrupted results after a hipDeviceSynchronize (packet-captured kernel nodes; DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 hides it).
+ * The library and its Python host clear every buffer with this kernel instead. */
+int evf_memset(void* dst, int value, size_t bytes, void* stream);
+
+/* Debugging aid (csrc/evf_debug.hip): fills the LDS of every CU with `pattern` (0: a quiet NaN), so that a kernel reading an LDS
+ * word it never wrote shows it in its output.  EVF_DEBUG_POISON_LDS=1 makes the Python host call it in front of every entry point. */
+int evf_debug_poison_lds(uint32_t pattern, void* stream);
 
 #ifdef __cplusplus
 }

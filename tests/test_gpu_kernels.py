@@ -381,6 +381,101 @@ def test_recorded_fused_backward_cells_match_the_one_cell_launches(shape):
     assert L.evf_bwd_diag_select(3) != 0
 
 
+@pytest.mark.parametrize("shape", SHAPES + [(3, 20, 96), (2, 33, 70)])
+def test_plif_trace_backward_inside_the_fused_backward(shape):
+    """PLIF hidden cells: evf_plif_bwd_wgrad2 / _top (the presynaptic trace's backward in team E of the fused backward, g_cur
+    never read back) against evf_lif_bwd_wgrad2 / _top followed by evf_plif_trace_bwd: dL/d(current), its split planes, dL/dv,
+    the trace carry and the raw map dL/d(pooled activity) bit for bit; slabs and per-channel sums (leak, thresh, leak_pt,
+    add_pt) to fp32 round-off.  One launch per cell and recorded (three kinds in one index), with and without carry / previous
+    trace, carry written in place, first touch and accumulation, ragged shapes."""
+    B, H, W = shape
+    torch.manual_seed(23)
+    L = _lib.load()
+    nsl = max(L.evf_lif_bwd_wgrad_slabs(B, H, W), 512)
+    row_ld = 224
+
+    def cell(kind, carry, prev):
+        c = {"kind": kind, "gv": _f(B, H, W, C, scale=0.1), "vo": _f(B, H, W, C, scale=0.6), "vp": _f(B, H, W, C, scale=0.6),
+             "zp": _bits(B, H, W), "xT": _planes(_bits(B, H, W)), "leak": _f(32, scale=0.3), "thresh": _f(32, scale=0.1) + 0.4,
+             "gk": _f(B, H, W, C, scale=0.2) if carry else None, "pp": _f(B, H, W, C, scale=0.3).abs() if prev else None,
+             "P": _f(B, H, W, scale=0.2).abs(), "lpt": _f(32, scale=0.5) - 1.0, "apt": _f(32, scale=0.5) - 2.0}
+        if kind == "top":
+            c.update(flow=torch.tanh(_f(B, 2, H, W)), g_flow=_f(B, 2, H, W), pw=_f(2, 32, scale=0.05), zo=_bits(B, H, W, rate=0.4))
+        else:
+            c.update(gz=_f(B, H, W, C, scale=0.2), gz2=_f(B, H, W, C, scale=0.2) if kind == "rec" else None)
+        if kind == "rec":
+            c["zT"] = _planes(c["zp"])
+        return c
+
+    cells = [cell("ff", True, True), cell("rec", True, True), cell("top", False, True), cell("rec", True, False), cell("ff", False, False)]
+
+    def run(fused, recorded):
+        outs = []
+        for acc in (0, 1):
+            if recorded:
+                assert _lib.raw("evf_bwd_defer_begin") == 0 and _lib.raw("evf_bwd_defer_slot", 2) == 0
+            try:
+                for c in cells:
+                    if acc == 0:
+                        c["out"] = {"gcur": torch.full((B, H, W, C), 3.0, device=DEV), "gsp": torch.zeros(3, B, H, W, C, dtype=torch.bfloat16, device=DEV),
+                                    "gvp": torch.full((B, H, W, C), 3.0, device=DEV), "rows": torch.zeros(nsl, row_ld, device=DEV),
+                                    "sff": torch.full((nsl, 9216), 5.0, device=DEV), "srec": torch.full((nsl, 9216), 5.0, device=DEV),
+                                    # the carry is read and written in place (the engine's buffers)
+                                    "gpt": c["gk"].clone() if c["gk"] is not None else torch.full((B, H, W, C), 3.0, device=DEV),
+                                    "gP": torch.full((B, H, W), 3.0, device=DEV)}
+                    o = c["out"]
+                    if acc == 1 and c["gk"] is not None:
+                        o["gpt"].copy_(c["gk"])
+                    flag = acc | (row_ld << 8)
+                    carry = P(o["gpt"]) if c["gk"] is not None else None
+                    tr = (carry, P(c["pp"]), P(c["P"]), P(c["lpt"]), P(c["apt"]), P(o["gpt"]), P(o["gP"]), P(o["rows"][:, 160:]), P(o["rows"][:, 192:]))
+                    if c["kind"] == "top":
+                        _lib.call("evf_plif_bwd_wgrad_top" if fused else "evf_lif_bwd_wgrad_top", P(c["flow"]), P(c["g_flow"]), P(c["pw"]), P(c["zo"]),
+                                  P(o["rows"][:, 64:]), P(o["rows"][:, 128:]), P(c["gv"]), P(c["vo"]), P(c["vp"]), P(c["zp"]), P(c["xT"]), P(c["leak"]),
+                                  P(c["thresh"]), B, H, W, 1, 0, 10.0, P(o["gcur"]), P(o["gsp"]), P(o["gvp"]), P(o["rows"][:, :32]),
+                                  P(o["rows"][:, 32:]), P(o["sff"]), flag, *(tr if fused else ()))
+                    else:
+                        rec = c["kind"] == "rec"
+                        _lib.call("evf_plif_bwd_wgrad2" if fused else "evf_lif_bwd_wgrad2", P(c["gz"]), P(c["gz2"]), P(c["gv"]), P(c["vo"]), P(c["vp"]),
+                                  P(c["zp"]), P(c["xT"]), P(c["zT"]) if rec else None, P(c["leak"]), P(c["thresh"]), B, H, W, 1, 0, 10.0, P(o["gcur"]),
+                                  P(o["gsp"]), P(o["gvp"]), P(o["rows"][:, :32]), P(o["rows"][:, 32:]), P(o["sff"]), P(o["srec"]) if rec else None,
+                                  flag, *(tr if fused else ()))
+                    if not fused:
+                        _lib.call("evf_plif_trace_bwd", P(o["gcur"]), carry, P(c["pp"]), P(c["vo"]), P(c["P"]), P(c["lpt"]), P(c["apt"]), B, H, W,
+                                  P(o["gpt"]), P(o["gP"]), None, P(o["rows"][:, 160:]), P(o["rows"][:, 192:]), row_ld)
+                if recorded:
+                    assert _lib.raw("evf_bwd_defer_pending") == len(cells)
+            finally:
+                if recorded:
+                    _lib.call("evf_bwd_defer_flush")
+        torch.cuda.synchronize()
+        for c in cells:
+            o = c.pop("out")
+            outs.append((o["gcur"], o["gsp"], o["gvp"], o["gpt"], o["gP"], o["rows"].sum(0), o["sff"].sum(0),
+                         o["srec"].sum(0) if c["kind"] == "rec" else None))
+        return outs
+
+    ref = run(False, False)
+    assert all(float(r[3].abs().max()) > 0 and float(r[4].abs().max()) > 0 for r in ref)
+    assert all(float(r[5][160:].abs().min()) > 0 for r in ref)  # (every trace parameter has a gradient)
+    for recorded in (False, True):
+        got = run(True, recorded)
+        for n, (a, b) in enumerate(zip(ref, got)):
+            for name, x, y in zip(("g_cur", "split", "g_v_prev", "g_pt_prev", "g_P"), a[:5], b[:5]):
+                assert torch.equal(x, y), (recorded, n, name)
+            for name, x, y in zip(("rows", "slab_ff", "slab_rec"), a[5:], b[5:]):
+                if x is not None:
+                    assert float(x.abs().max()) > 0 and _rel(y, x) < 2e-5, (recorded, n, name, _rel(y, x))
+    # not the default neuron: the fused form refuses (the two-call path serves it)
+    c = cells[0]
+    o = torch.zeros(B, H, W, C, device=DEV)
+    rc = L.evf_plif_bwd_wgrad2(P(c["gz"]), None, P(c["gv"]), P(c["vo"]), P(c["vp"]), P(c["zp"]), P(c["xT"]), None, P(c["leak"]), P(c["thresh"]), B, H,
+                               W, 0, 0, 10.0, P(o), None, P(o.clone()), P(torch.zeros(nsl, row_ld, device=DEV)), P(torch.zeros(nsl, row_ld, device=DEV)),
+                               P(torch.zeros(nsl, 9216, device=DEV)), None, 0, None, None, P(c["P"]), P(c["lpt"]), P(c["apt"]), P(o.clone()),
+                               P(torch.zeros(B, H, W, device=DEV)), P(torch.zeros(64, device=DEV)), P(torch.zeros(64, device=DEV)), _lib.stream_ptr())
+    assert rc == -95  # EVF_ENOTSUP
+
+
 @pytest.mark.parametrize("shape", SHAPES + [(3, 21, 96), (1, 2, 32)])
 @pytest.mark.parametrize("hard", [1, 0])
 def test_recorded_forward_cells_are_bit_identical(shape, hard):

@@ -25,6 +25,7 @@ ap.add_argument("--events", type=int, default=1500)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--graph", action="store_true", help="replay the step from hipGraphs (train.GraphedWindowStep; fused LIF/PLIF FireNets)")
+ap.add_argument("--trace-loss", action="store_true", help="print the loss of every step (debugging: the same data every step)")
 a = ap.parse_args()
 dev = "cuda:0"
 torch.manual_seed(0)
@@ -67,11 +68,15 @@ def step():
 
 
 for _ in range(a.warmup):
-    step()
+    l_ = step()
+    if a.trace_loss:
+        print("warmup loss", float(l_), file=sys.stderr)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(a.steps):
     loss = step()
+    if a.trace_loss:
+        print("loss", float(loss), file=sys.stderr)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 print(json.dumps({"model": a.model, "shape": [a.B, a.H, a.W], "passes": a.passes, "events_per_pass": a.events, "launch": "hipgraph" if a.graph else "eager",
