@@ -56,6 +56,7 @@ NETWORK_SIGNATURES = {
     "evf_defer_poison": [I],
     "evf_bwd_defer_begin": [P],
     "evf_bwd_defer_slot": [I, P],
+    "evf_bwd_defer_hold_heads": [I, P],
     "evf_bwd_defer_pending": [P],
     "evf_bwd_defer_flush": [P],
     "evf_comm_load": [ctypes.c_char_p],
@@ -72,6 +73,7 @@ NETWORK_SIGNATURES = {
     "evf_lif_bwd_wgrad_slabs": [I, I, I],
     "evf_head_lif_bwd_wgrad_slabs": [I, I, I],
     "evf_head_lif_bwd_wgrad": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, P, P, P, P, I, P],
+    "evf_head_plif_bwd_wgrad": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, P, P, P, I, P, P, P, P, P, P, P, P, P],
     "evf_sum_rows": [P, I, I, I, P, P],
     "evf_add_segments": [P, P, P, P, I, I, P],
     "evf_pack_conv_weights_b3_multi": [P, P, P, I, P],
@@ -313,7 +315,8 @@ _DEFER_SAFE_FWD = {"evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_head_
                    "evf_encode_window", "evf_encode_events", "evf_events_to_image"}
 # backward recording (evf_bwd_defer_*): these record themselves, or flush inside the library when they cannot
 _DEFER_SAFE_BWD = {"evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad2", "evf_lif_bwd_wgrad_top", "evf_plif_bwd_wgrad2", "evf_plif_bwd_wgrad_top", "evf_conv_dgrad_b3_f32",
-                   "evf_conv_dgrad_b3_f32_pair", "evf_conv_dgrad_b3", "evf_conv_dgrad_b3_pair", "evf_head_lif_bwd_wgrad", "evf_bwd_defer_flush"}
+                   "evf_conv_dgrad_b3_f32_pair", "evf_conv_dgrad_b3", "evf_conv_dgrad_b3_pair", "evf_head_lif_bwd_wgrad", "evf_head_plif_bwd_wgrad",
+                   "evf_bwd_defer_flush"}
 
 
 def zero_(t):

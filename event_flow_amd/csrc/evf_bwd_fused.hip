@@ -1577,14 +1577,20 @@ static int fb_defer_launch(FbDefer& fb_defer, int d, void* stream) {
 //  can only hide under ONE fused-backward launch; as parallel branches of the replayed graph: 4.21 against 4.20 ms per step.)
 // (Later in round 3: with one dL/d(spikes) buffer PER PASS the head cells have no tie to the indices at all and run after
 //  the last one, all passes in one launch: evf_hd_defer_launch_window, evf_network.hip.)
-int evf_bwd_defer_flush_now(int ctx, void* stream) {
-  const bool heads_last = evf_hd_defer_window_ok(ctx) != 0;
+// final = false (a call that cannot be recorded runs everything recorded first) with evf_bwd_defer_hold_heads on: the head layer's
+// cells stay recorded -- the caller has promised that nothing recorded or launched later touches what they read or write (one
+// dL/d(spikes) buffer per pass), so they run at the recording's end, all passes in one launch.  PLIF networks: their hidden cells'
+// input gradients are not recordable (the pooling's adjoint), i.e. every pass flushes.
+int evf_bwd_defer_flush_now(int ctx, void* stream, bool final) {
+  const bool hold = !final && evf_bwd_defer_tab[ctx].hold_heads;
+  const bool heads_last = hold || evf_hd_defer_window_ok(ctx) != 0;
   for (int d = 0; d < EVF_BWD_DIAGS; ++d) {
     int rc = fb_defer_launch(fb_tab[ctx], d, stream);
     if (!rc) rc = evf_dg_defer_launch(ctx, d, stream);
     if (!rc && !heads_last) rc = evf_hd_defer_launch(ctx, d, stream);
     if (rc) return rc;
   }
+  if (hold) return EVF_OK;
   return heads_last ? evf_hd_defer_launch_window(ctx, stream) : EVF_OK;
 }
 
@@ -1595,6 +1601,13 @@ extern "C" int evf_bwd_defer_begin(void* stream) {
   if (ctx < 0) return EVF_EINVAL;
   evf_bwd_defer_tab[ctx].active = true;
   evf_bwd_defer_tab[ctx].slot = 0;
+  evf_bwd_defer_tab[ctx].hold_heads = false;
+  return EVF_OK;
+}
+extern "C" int evf_bwd_defer_hold_heads(int on, void* stream) {
+  const int c = evf_ctx_find(stream);
+  if (c < 0 || !evf_bwd_defer_tab[c].active) return EVF_EINVAL;
+  evf_bwd_defer_tab[c].hold_heads = on != 0;
   return EVF_OK;
 }
 extern "C" int evf_bwd_defer_slot(int d, void* stream) {
@@ -1613,7 +1626,7 @@ extern "C" int evf_bwd_defer_pending(void* stream) {
 extern "C" int evf_bwd_defer_flush(void* stream) {
   const int c = evf_ctx_find(stream);
   if (c < 0 || !evf_bwd_defer_tab[c].active) return EVF_OK;
-  const int rc = evf_bwd_defer_flush_now(c, stream);
+  const int rc = evf_bwd_defer_flush_now(c, stream, true);
   evf_bwd_defer_tab[c].active = false;
   evf_ctx_drop(c);
   return rc;
@@ -1639,7 +1652,7 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
   static bool attr[12] = {false};
   const bool fast = hard_reset != 0 && surrogate == EVF_ARCTAN;
   const int bctx = evf_ctx_find(stream);
-  const EvfBwdDefer evf_bwd_defer = bctx >= 0 ? evf_bwd_defer_tab[bctx] : EvfBwdDefer{false, 0};
+  const EvfBwdDefer evf_bwd_defer = bctx >= 0 ? evf_bwd_defer_tab[bctx] : EvfBwdDefer{false, 0, false};
   FbDefer& fb_defer = fb_tab[bctx < 0 ? 0 : bctx];
   if (evf_bwd_defer.active) {
     bool any = false;

@@ -211,9 +211,10 @@ void evf_ctx_drop(int ctx);         // one recording of the context ended (at ze
 struct EvfBwdDefer {
   bool active;
   int slot;
+  bool hold_heads;  // evf_bwd_defer_hold_heads: the head layer's recorded cells wait for the recording's END (evf_bwd_defer_flush)
 };
 extern EvfBwdDefer evf_bwd_defer_tab[EVF_CTX_MAX];
-int evf_bwd_defer_flush_now(int ctx, void* stream);  // launch what is recorded, keep recording
+int evf_bwd_defer_flush_now(int ctx, void* stream, bool final = false);  // launch what is recorded, keep recording
 int evf_dg_defer_launch(int ctx, int d, void* stream);  // evf_dgrad_b3.hip: launch and clear the cells of index d
 int evf_dg_defer_count(int ctx);
 int evf_dg_defer_pending(int ctx, int d);  // cells recorded under index d

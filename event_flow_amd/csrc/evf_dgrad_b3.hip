@@ -405,7 +405,7 @@ static int dg_launch(const void* g, int f32in, const void* wT_b3, float* g_x, in
   // one-phase-after-the-other kernel below is ~1 % ahead in the train step (128 x 128 x B8: 20.1 vs 21.3 us in the step).
   // evf_conv_dgrad_select() / EVF_DGRAD=lds|ws override the choice (A/B measurements, the equivalence test).
   const int bctx = evf_ctx_find(stream);
-  const EvfBwdDefer evf_bwd_defer = bctx >= 0 ? evf_bwd_defer_tab[bctx] : EvfBwdDefer{false, 0};
+  const EvfBwdDefer evf_bwd_defer = bctx >= 0 ? evf_bwd_defer_tab[bctx] : EvfBwdDefer{false, 0, false};
   DgDefer& dg_defer = dg_tab[bctx < 0 ? 0 : bctx];
   if (evf_bwd_defer.active) {  // a recording is open on this stream: record the cell (any size: the persistent launch of evf_dgrad_diag.hip) ...
     const bool any = evf_dg_defer_count(bctx) != 0;

@@ -986,11 +986,28 @@ struct HeadBwdPass {  // one pass of k_head_bwd_win
   const float* x_in;
   float4* g_v_prev;
   int slab_acc;
+  // PLIF (HeadPlifPass below): carry from pass t + 1, trace of pass t - 1, pooled activity (NULL: a LIF cell), carry to pass t - 1
+  const float4 *g_pt_out, *pt_prev;
+  const float* P;
+  float4* g_pt_prev;
 };
 struct HeadTripIn {  // what one trip loads
   float4 vo4, gvl, gzl, vpl;
   uint32_t zwl;
   float xb[4];
+  float4 gkl, ppl;  // PLIF: dL/d(pt') carried from pass t + 1 (first pass / NT = 0 only), pt of pass t - 1
+  float Pl;         // PLIF: pooled input activity of the pixel
+};
+// PLIF head (spiking_submodules.py:191-227 / :634-652): the presynaptic trace's backward in the same pass (evf_plif_trace_bwd read
+// g_cur back from HBM in a launch of its own).  The head's input is the event tensor: dL/d(pooled activity) is not needed.
+struct HeadPlifPass {
+  const float4 *g_pt_out, *pt_prev;  // carry from pass t + 1 (NULL: none), trace of pass t - 1 (NULL: zero state)
+  const float* P;                    // [B,H,W] pooled activity of pass t (NULL: not a PLIF cell)
+  float4* g_pt_prev;                 // carry to pass t - 1
+};
+struct HeadPlifPrm {
+  const float *leak_pt, *add_pt;
+  float *g_leak_pt, *g_add_pt;
 };
 // NT > 0 (k_head_bwd_win, a block makes at most NT trips): the carried gradient and the membrane potential of the pass before
 // stay in REGISTERS between the passes of the launch -- gvc[trip] = dL/dv written by the previous pass (read instead of
@@ -1003,14 +1020,22 @@ struct HeadBwdKeep {
   f32x16 acc;
   float sl[4], st[4], lam[4], th[4], oml[4], inv_oml[4];
 };
-template <bool FAST, int NT = 0, bool FIRST = true>
+struct HeadBwdKeepPlif {
+  float slp[4], sap[4], lpt[4], apt[4];
+};
+template <bool FAST, int NT = 0, bool FIRST = true, bool PLIF = false>
 __device__ __forceinline__ void head_bwd_pass(
     const float4* g_z_out, const float4* g_v_out, const float4* v_out, const float4* v_prev, const uint32_t* z_prev,
     const float* __restrict__ leak, const float* __restrict__ thresh, long npix, int hard_reset_rt, int surrogate_rt, float width,
     float4* g_cur, float4* g_v_prev, float* g_leak, float* g_thresh, const float* __restrict__ x_in, int Cin, int H, int W,
     float* slab, int slab_acc, int row_ld, float4 (&gvc)[NT ? NT : 1], float4 (&voc)[NT ? NT : 1], int (&xo)[NT ? NT : 1][4],
-    HeadBwdKeep& K, bool store_gv) {  // store_gv: the launch's last pass (NT = 0: every pass is first and last)
+    HeadBwdKeep& K, bool store_gv,  // store_gv: the launch's last pass (NT = 0: every pass is first and last)
+    const HeadPlifPass pq = HeadPlifPass{}, const HeadPlifPrm pm = HeadPlifPrm{}, float4* gpc_ = nullptr, HeadBwdKeepPlif* KP_ = nullptr) {
   const int hard_reset = FAST ? 1 : hard_reset_rt, surrogate = FAST ? EVF_ARCTAN : surrogate_rt;
+  float4 gpc_none[1];
+  HeadBwdKeepPlif kp_none;
+  float4* gpc = PLIF ? gpc_ : gpc_none;          // [NT] the carried dL/d(pt') of the block's trips
+  HeadBwdKeepPlif& KP = PLIF ? *KP_ : kp_none;
   __shared__ float s_red[2][4][C32];
   __shared__ __attribute__((aligned(16))) float s_g[2][4][8 * C32];  // [buffer][wave][pixel][channel]
   __shared__ float s_d[4][C32 * C32];
@@ -1028,10 +1053,17 @@ __device__ __forceinline__ void head_bwd_pass(
       oml[k] = 1.0f - lam[k];
       inv_oml[k] = 1.0f / oml[k];
       sl[k] = st[k] = 0.f;
+      if (PLIF) {
+        KP.lpt[k] = evf_sigmoid(pm.leak_pt[4 * cg + k]);
+        KP.apt[k] = evf_sigmoid(pm.add_pt[4 * cg + k]);
+        KP.slp[k] = KP.sap[k] = 0.f;
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   }
+  const float4* pgk = (PLIF && pq.g_pt_out) ? pq.g_pt_out : v_out;
+  const float4* ppp = (PLIF && pq.pt_prev) ? pq.pt_prev : v_out;
   const float4* pgz = g_z_out ? g_z_out : v_out;
   const float4* pgv = g_v_out ? g_v_out : v_out;
   const float4* pvp = v_prev ? v_prev : v_out;
@@ -1052,6 +1084,7 @@ __device__ __forceinline__ void head_bwd_pass(
 #pragma unroll
     for (int h = 0; h < 4; ++h) prev[h] = sl_out[min(tid + 256 * h, C32 * ncol - 1)];
     row_prev = (((tid >> 5) & 1) ? g_thresh : g_leak)[row_off + (tid & 31)];  // (used by threads < 64)
+    if (PLIF && tid >= 64 && tid < 128) row_prev = (((tid >> 5) & 1) ? pm.g_add_pt : pm.g_leak_pt)[row_off + (tid & 31)];
   }
   // a trip in two halves: fetch() issues its loads (unconditional, clamped addresses), work() consumes them.  NT > 0: the
   // loads of ALL trips of the pass are issued before the first is consumed -- with one trip's loads in flight at a time (the
@@ -1069,9 +1102,14 @@ __device__ __forceinline__ void head_bwd_pass(
     if (NT == 0 || first) {
       in.vo4 = v_out[ec];
       in.gvl = pgv[ec];
+      if (PLIF) in.gkl = pgk[ec];
     }
     in.gzl = pgz[ec], in.vpl = pvp[ec];
     in.zwl = pzw[pix];
+    if (PLIF) {
+      in.ppl = ppp[ec];
+      in.Pl = pq.P[pix];
+    }
     // B operand: the input value of the wave's pixels 2m + kg at this lane's (ci, tap)
     const long wp0 = (base >> 3) + wv * 8;  // first pixel of this wave
 #pragma unroll
@@ -1147,6 +1185,25 @@ __device__ __forceinline__ void head_bwd_pass(
     if (NT > 0) {
       gvc[ic] = make_float4(gp[0], gp[1], gp[2], gp[3]);
       voc[ic] = vpl;  // (v_prev == NULL: never read again -- the pass that starts from the zero state is the window's first)
+    }
+    if (PLIF) {  // trace backward: the expressions of k_plif_trace_bwd, the same bits per element
+      const float4 gk4 = (NT == 0 || FIRST) ? (pq.g_pt_out ? in.gkl : zero4) : gpc[ic];
+      const float4 pp4 = pq.pt_prev ? in.ppl : zero4;
+      const float gk[4] = {gk4.x, gk4.y, gk4.z, gk4.w}, pp[4] = {pp4.x, pp4.y, pp4.z, pp4.w};
+      const float Pv = in.Pl;
+      float gq[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float po = pp[k] * KP.lpt[k] + (1.0f - KP.lpt[k]) * Pv;
+        const float g = gk[k] - KP.apt[k] * gc[k];
+        gq[k] = g * KP.lpt[k];
+        if (ok) {
+          KP.slp[k] += g * (pp[k] - Pv);
+          KP.sap[k] -= gc[k] * po;
+        }
+      }
+      if (NT > 0) gpc[ic] = make_float4(gq[0], gq[1], gq[2], gq[3]);
+      if (ok && (NT == 0 || store_gv)) pq.g_pt_prev[e] = make_float4(gq[0], gq[1], gq[2], gq[3]);
     }
     if (ok) {
       if (g_cur) g_cur[e] = make_float4(gc[0], gc[1], gc[2], gc[3]);
@@ -1224,6 +1281,34 @@ __device__ __forceinline__ void head_bwd_pass(
       else evf_atomic_add(g_thresh + c, v);
     }
   }
+  if (PLIF) {  // the trace parameters' sums through the same arrays
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        KP.slp[k] += __shfl_xor(KP.slp[k], o, 64);
+        KP.sap[k] += __shfl_xor(KP.sap[k], o, 64);
+      }
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s_red[0][wv][4 * lane + k] = KP.slp[k];
+        s_red[1][wv][4 * lane + k] = KP.sap[k];
+      }
+    }
+    __syncthreads();
+    if (tid >= 64 && tid < 128) {
+      const int which = (tid >> 5) & 1, c = tid & 31;
+      float v = 0.f;
+      for (int w = 0; w < 4; ++w) v += s_red[which][w][c];
+      const float sgm = evf_sigmoid(which == 0 ? pm.leak_pt[c] : pm.add_pt[c]);
+      float* dst = which == 0 ? pm.g_leak_pt : pm.g_add_pt;
+      if (row_ld) dst[row_off + c] = row_prev + v * sgm * (1.0f - sgm);
+      else evf_atomic_add(dst + c, v * sgm * (1.0f - sgm));
+    }
+  }
 }
 
 template <bool FAST>
@@ -1240,6 +1325,21 @@ __global__ __launch_bounds__(256) void k_head_bwd_mfma(
                       g_v_prev, g_leak, g_thresh, x_in, Cin, H, W, slab, slab_acc, row_ld, none, none, nox, keep, true);
 }
 
+// PLIF head, one pass: the same with the trace backward inside (default neuron)
+__global__ __launch_bounds__(256) void k_head_plif_bwd_mfma(
+    const float4* __restrict__ g_z_out, const float4* __restrict__ g_v_out, const float4* __restrict__ v_out,
+    const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev, const float* __restrict__ leak,
+    const float* __restrict__ thresh, long npix, float width, float4* __restrict__ g_v_prev, float* __restrict__ g_leak,
+    float* __restrict__ g_thresh, const float* __restrict__ x_in, int Cin, int H, int W, float* __restrict__ slab, int slab_acc,
+    int row_ld, HeadPlifPass pq, HeadPlifPrm pm) {
+  float4 none[1], gpc[1];
+  int nox[1][4];
+  HeadBwdKeep keep;
+  HeadBwdKeepPlif kp;
+  head_bwd_pass<true, 0, true, true>(g_z_out, g_v_out, v_out, v_prev, z_prev, leak, thresh, npix, 1, EVF_ARCTAN, width, nullptr, g_v_prev,
+                                     g_leak, g_thresh, x_in, Cin, H, W, slab, slab_acc, row_ld, none, none, nox, keep, true, pq, pm, gpc, &kp);
+}
+
 // The head layer's backward of a whole WINDOW in one launch.  The head's backward chain is per pixel (dL/dv carried from pass
 // t to pass t-1 by the thread that computed it; the weight-gradient and per-channel partial sums are per block), so once the
 // input gradients of the layer above have written dL/d(spikes) of EVERY pass -- each into its own buffer -- one launch runs
@@ -1252,6 +1352,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_mfma(
 #endif
 struct HeadBwdWin {
   HeadBwdPass p[HEADBWD_MAX_P];
+  HeadPlifPrm pm;  // (PLIF windows)
   const float *leak, *thresh;
   float *g_leak, *g_thresh, *slab;
   long npix;
@@ -1259,24 +1360,27 @@ struct HeadBwdWin {
   float width;
 };
 #define HEADBWD_NT 4  // trips of a block whose carried values fit registers (8 x 128 x 128 on 1024 blocks: 4)
-template <bool FAST, int NT>
+template <bool FAST, int NT, bool PLIF = false>
 __global__ __launch_bounds__(HEADBWD_LB) void k_head_bwd_win(HeadBwdWin a) {
-  float4 gvc[NT ? NT : 1], voc[NT ? NT : 1];
+  float4 gvc[NT ? NT : 1], voc[NT ? NT : 1], gpc[NT ? NT : 1];
   int xo[NT ? NT : 1][4];
   HeadBwdKeep keep;
+  HeadBwdKeepPlif kp;
   const int acc0 = a.p[0].slab_acc;  // (NT > 0: the sums of all passes are added to the slab once, by the first pass's rule)
   {
     const HeadBwdPass& q = a.p[0];
-    head_bwd_pass<FAST, NT, true>(q.g_z_out, q.g_v_out, q.v_out, q.v_prev, q.z_prev, a.leak, a.thresh, a.npix, a.hard_reset,
-                                  a.surrogate, a.width, nullptr, q.g_v_prev, a.g_leak, a.g_thresh, q.x_in, a.Cin, a.H, a.W, a.slab,
-                                  NT > 0 ? acc0 : q.slab_acc, a.row_ld, gvc, voc, xo, keep, a.np == 1);
+    head_bwd_pass<FAST, NT, true, PLIF>(q.g_z_out, q.g_v_out, q.v_out, q.v_prev, q.z_prev, a.leak, a.thresh, a.npix, a.hard_reset,
+                                        a.surrogate, a.width, nullptr, q.g_v_prev, a.g_leak, a.g_thresh, q.x_in, a.Cin, a.H, a.W, a.slab,
+                                        NT > 0 ? acc0 : q.slab_acc, a.row_ld, gvc, voc, xo, keep, a.np == 1,
+                                        HeadPlifPass{q.g_pt_out, q.pt_prev, q.P, q.g_pt_prev}, a.pm, gpc, &kp);
   }
   for (int t = 1; t < a.np; ++t) {
     __syncthreads();  // (the pass's last reads of the reduction arrays before the next pass rewrites them)
     const HeadBwdPass& q = a.p[t];
-    head_bwd_pass<FAST, NT, false>(q.g_z_out, q.g_v_out, q.v_out, q.v_prev, q.z_prev, a.leak, a.thresh, a.npix, a.hard_reset,
-                                   a.surrogate, a.width, nullptr, q.g_v_prev, a.g_leak, a.g_thresh, q.x_in, a.Cin, a.H, a.W, a.slab,
-                                   NT > 0 ? acc0 : q.slab_acc, a.row_ld, gvc, voc, xo, keep, t == a.np - 1);
+    head_bwd_pass<FAST, NT, false, PLIF>(q.g_z_out, q.g_v_out, q.v_out, q.v_prev, q.z_prev, a.leak, a.thresh, a.npix, a.hard_reset,
+                                         a.surrogate, a.width, nullptr, q.g_v_prev, a.g_leak, a.g_thresh, q.x_in, a.Cin, a.H, a.W, a.slab,
+                                         NT > 0 ? acc0 : q.slab_acc, a.row_ld, gvc, voc, xo, keep, t == a.np - 1,
+                                         HeadPlifPass{q.g_pt_out, q.pt_prev, q.P, q.g_pt_prev}, a.pm, gpc, &kp);
   }
 }
 
@@ -1294,6 +1398,12 @@ extern "C" int evf_head_lif_bwd_wgrad_slabs(int B, int H, int W) {
   const long npix = (long)B * H * W;
   const long nb = (npix * 8 + 255) / 256;
   const int cap = head_bwd_blocks();
+  // beyond 4 trips per block at the default grid (sensor-size inputs: 260 x 346 x B4 = 11 trips of 1024 blocks) the window launch
+  // could not keep its carried values in registers (HEADBWD_NT): more blocks instead, three trips each
+  if (cap == HEAD_BWD_BLOCKS && nb > 4 * (long)HEAD_BWD_BLOCKS) {
+    const long n3 = (nb + 2) / 3;
+    return (int)(n3 < 4096 ? n3 : 4096);
+  }
   return (int)(nb < cap ? nb : cap);
 }
 
@@ -1308,12 +1418,23 @@ struct HdArgs {
   float act_width;
   float *g_cur, *g_v_prev, *g_leak, *g_thresh, *slab;
   int accumulate;
+  // PLIF head (evf_head_plif_bwd_wgrad): P != NULL
+  const float *g_pt_out, *pt_prev, *P, *leak_pt, *add_pt;
+  float *g_pt_prev, *g_leak_pt, *g_add_pt;
 };
 static int head_bwd_go(const HdArgs& a, void* stream) {
   const long npix = (long)a.B * a.H * a.W;
   const int nblk = evf_head_lif_bwd_wgrad_slabs(a.B, a.H, a.W);
   const int row_ld = a.accumulate >> 8;  // pitch of the per-block parameter-gradient rows (0: dense outputs, atomics)
   const int accumulate = a.accumulate & 1;
+  if (a.P) {
+    hipLaunchKernelGGL(k_head_plif_bwd_mfma, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)a.g_z_out,
+                       (const float4*)a.g_v_out, (const float4*)a.v_out, (const float4*)a.v_prev, a.z_prev, a.leak, a.thresh, npix,
+                       a.act_width, (float4*)a.g_v_prev, a.g_leak, a.g_thresh, a.x_in, a.Cin, a.H, a.W, a.slab, accumulate, row_ld,
+                       HeadPlifPass{(const float4*)a.g_pt_out, (const float4*)a.pt_prev, a.P, (float4*)a.g_pt_prev},
+                       HeadPlifPrm{a.leak_pt, a.add_pt, a.g_leak_pt, a.g_add_pt});
+    return evf_status();
+  }
 #define HEAD_BWD(FAST_)                                                                                                    \
   hipLaunchKernelGGL(k_head_bwd_mfma<FAST_>, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)a.g_z_out,       \
                      (const float4*)a.g_v_out, (const float4*)a.v_out, (const float4*)a.v_prev, a.z_prev, a.leak, a.thresh,  \
@@ -1382,6 +1503,10 @@ int evf_hd_defer_launch_window(int ctx, void* stream) {
             q.act_width == p.act_width && q.g_leak == p.g_leak && q.g_thresh == p.g_thresh && q.slab == p.slab &&
             (q.accumulate >> 8) == (p.accumulate >> 8)))
         break;
+      if ((q.P != nullptr) != (p.P != nullptr)) break;
+      if (q.P && !(q.g_pt_out == p.g_pt_prev && q.leak_pt == p.leak_pt && q.add_pt == p.add_pt && q.g_leak_pt == p.g_leak_pt &&
+                   q.g_add_pt == p.g_add_pt))
+        break;
       ++m;
     }
     evf_prof_mark(m == 1 ? 3 : 5, 0, stream);
@@ -1392,8 +1517,10 @@ int evf_hd_defer_launch_window(int ctx, void* stream) {
       for (int t = 0; t < HEADBWD_MAX_P; ++t) {
         const HdArgs& q = *jobs[k + (t < m ? t : 0)];
         a.p[t] = HeadBwdPass{(const float4*)q.g_z_out, (const float4*)q.g_v_out, (const float4*)q.v_out, (const float4*)q.v_prev,
-                             q.z_prev, q.x_in, (float4*)q.g_v_prev, q.accumulate & 1};
+                             q.z_prev, q.x_in, (float4*)q.g_v_prev, q.accumulate & 1,
+                             (const float4*)q.g_pt_out, (const float4*)q.pt_prev, q.P, (float4*)q.g_pt_prev};
       }
+      a.pm = HeadPlifPrm{f.leak_pt, f.add_pt, f.g_leak_pt, f.g_add_pt};
       a.leak = f.leak, a.thresh = f.thresh, a.g_leak = f.g_leak, a.g_thresh = f.g_thresh, a.slab = f.slab;
       a.npix = (long)f.B * f.H * f.W;
       a.np = m, a.hard_reset = f.hard_reset, a.surrogate = f.surrogate, a.Cin = f.Cin, a.H = f.H, a.W = f.W;
@@ -1406,7 +1533,12 @@ int evf_hd_defer_launch_window(int ctx, void* stream) {
         return !(e && e[0] == 'm');
       }();
 #define HEAD_BWD_WIN(FAST_, NT_) hipLaunchKernelGGL((k_head_bwd_win<FAST_, NT_>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a)
-      if (carry && fast && trips <= HEADBWD_NT && (long)f.B * f.Cin * f.H * f.W < (1L << 31)) {  // (other surrogates: 253 VGPRs)
+      if (f.P) {  // PLIF (default neuron only: evf_head_plif_bwd_wgrad): three trips' carried values fit the registers
+        if (carry && trips <= 3 && (long)f.B * f.Cin * f.H * f.W < (1L << 31))
+          hipLaunchKernelGGL((k_head_bwd_win<true, 3, true>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a);
+        else
+          hipLaunchKernelGGL((k_head_bwd_win<true, 0, true>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a);
+      } else if (carry && fast && trips <= HEADBWD_NT && (long)f.B * f.Cin * f.H * f.W < (1L << 31)) {  // (other surrogates: 253 VGPRs)
         HEAD_BWD_WIN(true, HEADBWD_NT);
       } else {
         if (fast) HEAD_BWD_WIN(true, 0); else HEAD_BWD_WIN(false, 0);
@@ -1432,18 +1564,9 @@ int evf_hd_defer_launch(int ctx, int d, void* stream) {
   return EVF_OK;
 }
 
-extern "C" int evf_head_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const float* v_out, const float* v_prev,
-                                      const uint32_t* z_prev, const float* x_in, const float* leak, const float* thresh,
-                                      int B, int Cin, int H, int W, int hard_reset, int surrogate, float act_width,
-                                      float* g_cur, float* g_v_prev, float* g_leak, float* g_thresh, float* slab,
-                                      int accumulate, void* stream) {
-  if (!v_out || !x_in || !leak || !thresh || !g_v_prev || !g_leak || !g_thresh || !slab || B <= 0 || H <= 0 || W <= 0 ||
-      Cin != 2)
-    return EVF_EINVAL;
-  const HdArgs a{g_z_out, g_v_out, v_out, v_prev, z_prev, x_in, leak, thresh, B, Cin, H, W, hard_reset, surrogate, act_width,
-                 g_cur, g_v_prev, g_leak, g_thresh, slab, accumulate};
+static int head_bwd_record_or_go(const HdArgs& a, void* stream) {
   const int bctx = evf_ctx_find(stream);
-  const EvfBwdDefer evf_bwd_defer = bctx >= 0 ? evf_bwd_defer_tab[bctx] : EvfBwdDefer{false, 0};
+  const EvfBwdDefer evf_bwd_defer = bctx >= 0 ? evf_bwd_defer_tab[bctx] : EvfBwdDefer{false, 0, false};
   HdDefer& hd_defer = hd_tab[bctx < 0 ? 0 : bctx];
   if (evf_bwd_defer.active) {
     if (hd_defer.n[evf_bwd_defer.slot] < HD_MAX_JOBS) {
@@ -1454,6 +1577,37 @@ extern "C" int evf_head_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out
     if (rc) return rc;
   }
   return head_bwd_go(a, stream);
+}
+
+extern "C" int evf_head_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const float* v_out, const float* v_prev,
+                                      const uint32_t* z_prev, const float* x_in, const float* leak, const float* thresh,
+                                      int B, int Cin, int H, int W, int hard_reset, int surrogate, float act_width,
+                                      float* g_cur, float* g_v_prev, float* g_leak, float* g_thresh, float* slab,
+                                      int accumulate, void* stream) {
+  if (!v_out || !x_in || !leak || !thresh || !g_v_prev || !g_leak || !g_thresh || !slab || B <= 0 || H <= 0 || W <= 0 ||
+      Cin != 2)
+    return EVF_EINVAL;
+  const HdArgs a{g_z_out, g_v_out, v_out, v_prev, z_prev, x_in, leak, thresh, B, Cin, H, W, hard_reset, surrogate, act_width,
+                 g_cur, g_v_prev, g_leak, g_thresh, slab, accumulate, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  return head_bwd_record_or_go(a, stream);
+}
+
+// PLIF head: evf_head_lif_bwd_wgrad with the presynaptic trace's backward inside (what evf_plif_trace_bwd computes from g_cur in a
+// launch of its own; g_cur is not written).  Recordable (evf_bwd_defer_*): the recorded cells of a window run in one launch.
+extern "C" int evf_head_plif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const float* v_out, const float* v_prev,
+                                       const uint32_t* z_prev, const float* x_in, const float* leak, const float* thresh, int B,
+                                       int Cin, int H, int W, int hard_reset, int surrogate, float act_width, float* g_v_prev,
+                                       float* g_leak, float* g_thresh, float* slab, int accumulate, const float* g_pt_carry,
+                                       const float* pt_prev, const float* P, const float* leak_pt, const float* add_pt,
+                                       float* g_pt_prev, float* g_leak_pt, float* g_add_pt, void* stream) {
+  if (!v_out || !x_in || !leak || !thresh || !g_v_prev || !g_leak || !g_thresh || !slab || B <= 0 || H <= 0 || W <= 0 ||
+      Cin != 2 || !P || !leak_pt || !add_pt || !g_pt_prev || !g_leak_pt || !g_add_pt)
+    return EVF_EINVAL;
+  if (!(hard_reset != 0 && surrogate == EVF_ARCTAN)) return EVF_ENOTSUP;  // (the two-call path serves the other neurons)
+  const HdArgs a{g_z_out, g_v_out, v_out, v_prev, z_prev, x_in, leak, thresh, B, Cin, H, W, hard_reset, surrogate, act_width,
+                 nullptr, g_v_prev, g_leak, g_thresh, slab, accumulate, g_pt_carry, pt_prev, P, leak_pt, add_pt, g_pt_prev,
+                 g_leak_pt, g_add_pt};
+  return head_bwd_record_or_go(a, stream);
 }
 
 // dst_k[i] += src[off_k + i], i < n_k, for up to 32 segments in one launch (block y = segment)

@@ -561,7 +561,17 @@ class FireNetEngine:
             win.gz_has[n - 1] = True
         bdefer = (self.__dict__.get("_bdefer_on", False) and self.precision == "bf16x3" and self.kind == "lif" and F32_DGRAD
                   and PAIR_DGRAD and (top_fused or g_flow is None) and tape["x_in"].shape[1] == 2)
-        if not bdefer:
+        # PLIF: only the head layer's cells wait for the window's end (their chain is per pixel and reads one dL/d(spikes) buffer per
+        # pass): a recording is open for them, the hidden cells' input gradients (pooling adjoint: not recordable) flush the rest
+        # pass by pass, and evf_bwd_defer_flush runs the head's passes in ONE launch with the trace backward inside
+        plif_hw = (self.kind == "plif" and HEAD_WIN and PLIF_TRACE_FUSED and self.__dict__.get("_bdefer_on", False)
+                   and self.precision == "bf16x3" and n > 1 and tape["x_in"].shape[1] == 2 and self.cells[0].hard_reset
+                   and self.cells[0].activation == "arctanspike" and (top_fused or g_flow is None))
+        if plif_hw:
+            self._bdefer_slot(win, 0)
+            if _lib.raw("evf_bwd_defer_hold_heads", 1) != 0:
+                raise _lib.EvflowError("evf_bwd_defer_hold_heads failed")
+        elif not bdefer:
             self.flush_backward()  # (a pass outside the recorded schedule: what is recorded runs first)
         if win.g_cur is None:
             win.g_cur = _f32((B, H, W, C), dev)
@@ -642,11 +652,24 @@ class FireNetEngine:
                 key = (0, "ff")
                 if key not in self._slabs or self._slabs[key].shape != (nsl, C * 18) or self._slabs[key].device != dev:
                     self._slabs[key] = _f32((nsl, C * 18), dev)
-                _lib.call("evf_head_lif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev),
-                          _lib.ptr(z_prev), _lib.ptr(tape["x_in"]), _lib.ptr(self._flat["0.leak"]),
-                          _lib.ptr(self._flat["0.thresh"]), B, 2, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
-                          self._act_width(0), _lib.ptr(win.g_cur) if plif else None, _lib.ptr(gv_out), _lib.ptr(leak_r),
-                          _lib.ptr(thr_r), _lib.ptr(self._slabs[key]), (1 if win.slab_init.get(key) else 0) | (row_ld << 8))
+                if plif_hw:  # ... and the trace backward in the same pass; recorded (see plif_hw above)
+                    gpt_out = win.buf(win.gpt, 0)
+                    _lib.call("evf_head_plif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev),
+                              _lib.ptr(z_prev), _lib.ptr(tape["x_in"]), _lib.ptr(self._flat["0.leak"]),
+                              _lib.ptr(self._flat["0.thresh"]), B, 2, H, W, 1, SURROGATE_ID[c.activation], self._act_width(0),
+                              _lib.ptr(gv_out), _lib.ptr(leak_r), _lib.ptr(thr_r), _lib.ptr(self._slabs[key]),
+                              (1 if win.slab_init.get(key) else 0) | (row_ld << 8),
+                              _lib.ptr(gpt_out if win.gpt_has[0] else None), _lib.ptr(pt_prev), _lib.ptr(P_sav),
+                              _lib.ptr(self._flat["0.leak_pt"]), _lib.ptr(self._flat["0.add_pt"]), _lib.ptr(gpt_out),
+                              _lib.ptr(self._rowed(win, "0.leak_pt")[0]), _lib.ptr(self._rowed(win, "0.add_pt")[0]))
+                    win.gpt_has[0] = not is_first
+                    trace_fused = True  # (no evf_plif_trace_bwd below)
+                else:
+                    _lib.call("evf_head_lif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev),
+                              _lib.ptr(z_prev), _lib.ptr(tape["x_in"]), _lib.ptr(self._flat["0.leak"]),
+                              _lib.ptr(self._flat["0.thresh"]), B, 2, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
+                              self._act_width(0), _lib.ptr(win.g_cur) if plif else None, _lib.ptr(gv_out), _lib.ptr(leak_r),
+                              _lib.ptr(thr_r), _lib.ptr(self._slabs[key]), (1 if win.slab_init.get(key) else 0) | (row_ld << 8))
                 win.slab_init[key] = True
             else:
                 _lib.call("evf_lif_bwd", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev),
@@ -686,7 +709,7 @@ class FireNetEngine:
             if i > 0:
                 if bdefer:
                     self._bdefer_slot(win, 2 * (n - 1 - i) + 1)
-                if bdefer and i == 1 and HEAD_WIN and not win.gz_has[0]:
+                if (bdefer or plif_hw) and i == 1 and HEAD_WIN and not win.gz_has[0]:
                     # dL/d(spikes) of the head layer in a buffer of this pass's own: the head's backward cells of the whole window
                     # then run after the last diagonal, all passes in one launch (evf_hd_defer_launch_window)
                     while len(win.gz0) <= win.bwd_k:

@@ -241,6 +241,12 @@ int evf_bwd_defer_begin(void* stream);
 int evf_bwd_defer_slot(int index, void* stream);
 int evf_bwd_defer_pending(void* stream);
 int evf_bwd_defer_flush(void* stream);
+/* evf_bwd_defer_hold_heads(1): the recorded head cells (evf_head_lif_bwd_wgrad, evf_head_plif_bwd_wgrad) wait for
+ * evf_bwd_defer_flush even when a call that cannot be recorded launches everything else recorded so far -- and then run all
+ * passes in one launch.  The caller promises one dL/d(spikes) buffer of the head layer per pass (nothing launched in between
+ * rewrites what a waiting head cell reads).  PLIF networks: their hidden cells' input gradients are not recordable, every pass
+ * flushes.  Reset by evf_bwd_defer_begin. */
+int evf_bwd_defer_hold_heads(int on, void* stream);
 /* Measurement aid: evf_defer_profile(1) brackets every launch of the following flushes with HIP events;
  * evf_defer_profile_read synchronises the device, returns per kind (0 forward cells, 1 fused-backward cells, 2
  * input-gradient cells, 3 head backward one pass per launch, 4 head forward of a window in one launch, 5 head backward of
@@ -432,6 +438,17 @@ int evf_head_lif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const flo
                            const float* thresh, int B, int Cin, int H, int W, int hard_reset, int surrogate,
                            float act_width, float* g_cur, float* g_v_prev, float* g_leak, float* g_thresh,
                            float* slab, int accumulate, void* stream);
+/* PLIF head (reference models/spiking_submodules.py:191-227, backward of :634-652): evf_head_lif_bwd_wgrad with the presynaptic
+ * trace's backward in the same pass -- what evf_plif_trace_bwd computes from g_cur in a launch of its own (g_cur is not written;
+ * the head's input is the event tensor, so dL/d(pooled activity) is not needed): g_pt_prev (may alias g_pt_carry) and the sums for
+ * leak_pt / add_pt (rows of pitch accumulate >> 8, like g_leak).  g_pt_carry / pt_prev may be NULL.  Recordable; the recorded
+ * cells of a window run in ONE launch with dL/dv and dL/d(pt) carried in registers.  Default neuron only (EVF_ENOTSUP otherwise). */
+int evf_head_plif_bwd_wgrad(const float* g_z_out, const float* g_v_out, const float* v_out, const float* v_prev,
+                            const uint32_t* z_prev, const float* x_in, const float* leak, const float* thresh, int B,
+                            int Cin, int H, int W, int hard_reset, int surrogate, float act_width, float* g_v_prev,
+                            float* g_leak, float* g_thresh, float* slab, int accumulate, const float* g_pt_carry,
+                            const float* pt_prev, const float* P, const float* leak_pt, const float* add_pt,
+                            float* g_pt_prev, float* g_leak_pt, float* g_add_pt, void* stream);
 /* dst[k][i] += src[off[k] + i], i < n[k], for nseg <= 32 segments (host arrays of device pointers / ints):
  * the per-channel gradients of a window added into the optimizer's flat gradient buffer in one launch.
  * clear != 0: the consumed source elements are zeroed (a persistent accumulator, handed back clean). */

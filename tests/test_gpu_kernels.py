@@ -306,6 +306,74 @@ def test_head_layer_of_a_window_in_one_launch_is_bit_identical_backward(shape, s
         assert _rel(b.sum(0), a.sum(0)) < 5e-6 and _rel(b, a) < 5e-5, (name, _rel(b, a))
 
 
+@pytest.mark.parametrize("shape", [(8, 128, 128), (2, 37, 50), (4, 260, 346), (16, 128, 128)])
+def test_plif_head_backward_of_a_window_with_the_trace_inside(shape):
+    """PLIF head: evf_head_plif_bwd_wgrad (neuron backward, weight gradient and the presynaptic trace's backward in one pass)
+    against evf_head_lif_bwd_wgrad + evf_plif_trace_bwd, one launch per pass and as the ONE launch a recording makes of the
+    window's passes (k_head_bwd_win<.., PLIF>: dL/dv and dL/d(pt) carried in registers when a block makes <= 3 trips -- 8 x 128 x 128
+    and, with the larger grid evf_head_lif_bwd_wgrad_slabs picks for it, 4 x 260 x 346 --, through memory otherwise: 16 x 128 x 128).
+    evf_bwd_defer_hold_heads: a call that cannot be recorded in the middle launches what else is recorded, the head cells wait.
+    dL/dv and dL/d(pt) entering the window bit for bit; slabs and per-channel sums (leak, thresh, leak_pt, add_pt) to round-off."""
+    B, H, W = shape
+    npass = 5
+    torch.manual_seed(29)
+    L = _lib.load()
+    nsl = max(L.evf_head_lif_bwd_wgrad_slabs(B, H, W), 512)
+    leak, thresh = _f(32, scale=0.3), _f(32, scale=0.1) + 0.5
+    lpt, apt = _f(32, scale=0.5) - 1.0, _f(32, scale=0.5) - 2.0
+    xs = [torch.poisson(torch.full((B, 2, H, W), 0.4, device=DEV)) for _ in range(npass)]
+    vs = [_f(B, H, W, C, scale=0.7) for _ in range(npass + 1)]   # vs[t]: v before pass t
+    pts = [_f(B, H, W, C, scale=0.3).abs() for _ in range(npass)]  # pts[t]: trace before pass t (pts[0] unused: zero state)
+    Ps = [_f(B, H, W, scale=0.2).abs() for _ in range(npass)]
+    zs = [_bits(B, H, W) for _ in range(npass)]
+    gzs = [_f(B, H, W, C, scale=0.2) for _ in range(npass)]
+    row_ld = 160
+
+    def run(mode):  # "two": two calls per pass; "one": fused, a launch per pass; "win": fused, recorded (one launch)
+        gv, gpt = torch.empty(B, H, W, C, device=DEV), torch.empty(B, H, W, C, device=DEV)
+        gcur = torch.empty(B, H, W, C, device=DEV)
+        slab = torch.full((nsl, 32 * 18), 7.0, device=DEV)
+        rows = torch.zeros(nsl, row_ld, device=DEV)
+        if mode == "win":
+            assert _lib.raw("evf_bwd_defer_begin") == 0 and _lib.raw("evf_bwd_defer_hold_heads", 1) == 0
+        try:
+            for k in range(npass):
+                t = npass - 1 - k
+                flag = (1 if k else 0) | (row_ld << 8)
+                head = (P(gzs[k]), P(gv) if k else None, P(vs[t + 1]), P(vs[t]) if t else None, P(zs[t]) if t else None, P(xs[t]),
+                        P(leak), P(thresh), B, 2, H, W, 1, 0, 10.0)
+                if mode == "two":
+                    _lib.call("evf_head_lif_bwd_wgrad", *head, P(gcur), P(gv), P(rows[:, :32]), P(rows[:, 32:]), P(slab), flag)
+                    _lib.call("evf_plif_trace_bwd", P(gcur), P(gpt) if k else None, P(pts[t]) if t else None, P(vs[0]), P(Ps[t]), P(lpt), P(apt),
+                              B, H, W, P(gpt), P(torch.empty(B, H, W, device=DEV)), None, P(rows[:, 64:]), P(rows[:, 96:]), row_ld)
+                else:
+                    if mode == "win":
+                        assert _lib.raw("evf_bwd_defer_slot", 2 * k) == 0
+                    _lib.call("evf_head_plif_bwd_wgrad", *head, P(gv), P(rows[:, :32]), P(rows[:, 32:]), P(slab), flag, P(gpt) if k else None,
+                              P(pts[t]) if t else None, P(Ps[t]), P(lpt), P(apt), P(gpt), P(rows[:, 64:]), P(rows[:, 96:]))
+                    if mode == "win" and k == 2:
+                        # a call that cannot be recorded (accumulating input gradient): launches what is recorded -- not the head cells
+                        g = _f(B, H, W, C)
+                        _lib.call("evf_conv_dgrad_b3_f32", P(g), P(_packs()[1]), P(torch.zeros(B, H, W, C, device=DEV)), 1, B, H, W, None, None)
+                        assert _lib.raw("evf_bwd_defer_pending") == 3
+            if mode == "win":
+                assert _lib.raw("evf_bwd_defer_pending") == npass
+        finally:
+            if mode == "win":
+                _lib.call("evf_bwd_defer_flush")
+        torch.cuda.synchronize()
+        return gv, gpt, slab, rows
+
+    ref = run("two")
+    assert float(ref[1].abs().max()) > 0 and float(ref[3][:, 64:128].sum(0).abs().min()) > 0
+    for mode in ("one", "win"):
+        got = run(mode)
+        assert torch.equal(ref[0], got[0]), (mode, "g_v")
+        assert torch.equal(ref[1], got[1]), (mode, "g_pt")
+        for name, a, b in zip(("slab", "rows"), ref[2:], got[2:]):
+            assert _rel(b.sum(0), a.sum(0)) < 2e-5, (mode, name, _rel(b.sum(0), a.sum(0)))
+
+
 @pytest.mark.parametrize("shape", SHAPES + [(3, 20, 96), (4, 64, 160)])
 def test_recorded_fused_backward_cells_match_the_one_cell_launches(shape):
     """The fused-backward cells of a backward index, recorded and launched together -- through k_bwd_diag (the one-cell kernel's
