@@ -311,7 +311,7 @@ def raw(name, *args):
 
 _DEFER_SAFE_FWD = {"evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_head_lif_fwd", "evf_fwd_defer_flush",
                    "evf_conv_plif_fwd_b3", "evf_conv_plif_fwd_b3_pred",
-                   "evf_head_plif_fwd",  # (launches at once: reads the window's input and its own state only)
+                   "evf_head_plif_fwd",  # (recorded like evf_head_lif_fwd: the window's passes in one launch)
                    "evf_encode_window", "evf_encode_events", "evf_events_to_image"}
 # backward recording (evf_bwd_defer_*): these record themselves, or flush inside the library when they cannot
 _DEFER_SAFE_BWD = {"evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad2", "evf_lif_bwd_wgrad_top", "evf_plif_bwd_wgrad2", "evf_plif_bwd_wgrad_top", "evf_conv_dgrad_b3_f32",

@@ -454,18 +454,23 @@ struct HeadWinPass {
   float* v_out;
   uint32_t* z_out;
   uint32_t* zT_out;
+  float *pt_out, *P_out;  // PLIF: the trace after the pass [B,H,W,32], the pooled input activity [B,H,W]
 };
 struct HeadWin {
   HeadWinPass p[HEADWIN_MAX_P];
   const float *w, *leak, *thresh, *v_prev;
   const uint32_t* z_prev;
   int np, B, Cin, H, W, hard_reset;
+  const float *leak_pt, *add_pt, *pt_prev;  // PLIF (pt_prev NULL: zero trace)
 };
 
-template <int S2>
+// PLIF: the presynaptic trace stays in registers between the passes as well (k_head_lif_fwd read it back every pass); every pass
+// does the arithmetic of k_head_lif_fwd's PLIF branch: the same bits.
+template <int S2, bool PLIF = false>
 __global__ __launch_bounds__(HEADWIN_LB) void k_head_lif_fwd_win(HeadWin a) {
   __shared__ float s_x[2][2 * S2][HALO_H * HALO_W];
   __shared__ float s_w[9 * S2 * 64];
+  __shared__ float s_P[PLIF ? TH * TW : 1];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
   const int B = a.B, Cin = a.Cin, H = a.H, W = a.W;
@@ -528,6 +533,20 @@ __global__ __launch_bounds__(HEADWIN_LB) void k_head_lif_fwd_win(HeadWin a) {
   const float th = fmaxf(a.thresh[j], 0.01f);
   const int hard_reset = a.hard_reset;
   const int nW = (W + 31) / 32;
+  float pt0[PLIF ? 16 : 1], pt1[PLIF ? 16 : 1], lpt = 0.f, apt = 0.f;
+  if (PLIF) {
+    lpt = evf_sigmoid(a.leak_pt[j]), apt = evf_sigmoid(a.add_pt[j]);
+    const float* ptsrc = a.pt_prev ? a.pt_prev : a.p[0].v_out;  // (dummy source: selected away)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int rq = min(y0 + r0 + m, H - 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = ptsrc[(((long)b * H + rq) * W + min(x0 + mfma_row(r, lane), W - 1)) * C32 + j];
+        (m ? pt1 : pt0)[r] = a.pt_prev ? v : 0.f;
+      }
+    }
+  }
   // LIF update of one row (lif_update) that also leaves the new state in vpv / zb for the next pass.  FULL: the tile lies
   // inside the image (block-uniform) -- no per-pixel branch.  The 16 spike words of the row go out in ONE store (lane r of
   // each half wave keeps word r) instead of 16 stores by lanes 0 and 32.
@@ -585,6 +604,35 @@ __global__ __launch_bounds__(HEADWIN_LB) void k_head_lif_fwd_win(HeadWin a) {
         acc1 = mfma32(xp[(r0 + 1 + dy) * HALO_W + i + dx], bw, acc1);
       }
     }
+    if (PLIF) {  // cur = ff - sigma(add_pt) * pt' (k_head_lif_fwd, spiking_submodules.py:191-227)
+      const int py = tid >> 5, px = tid & 31;
+      float sum9 = 0.f;
+      for (int dy = 0; dy < 3; ++dy)
+        for (int dx = 0; dx < 3; ++dx) {
+          float av = 0.f;
+          for (int ci = 0; ci < Cin; ++ci) av += fabsf(s_x[buf][ci][(py + dy) * HALO_W + px + dx]);
+          sum9 += av / (float)Cin;
+        }
+      const float Pv = sum9 / 9.0f;
+      s_P[tid] = Pv;
+      if (y0 + py < H && x0 + px < W) a.p[t].P_out[((long)b * H + y0 + py) * W + x0 + px] = Pv;
+      __syncthreads();  // (the next pass writes s_P behind the loop's barrier)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        f32x16& acc = m ? acc1 : acc0;
+        float(&ptv)[PLIF ? 16 : 1] = m ? pt1 : pt0;
+        const int row = y0 + r0 + m;
+        float* const prow = a.p[t].pt_out + (((long)b * H + min(row, H - 1)) * W + x0) * C32 + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cl = mfma_row(r, lane), col = x0 + cl;
+          const float pto = ptv[r] * lpt + (1.0f - lpt) * s_P[(r0 + m) * TW + cl];
+          acc[r] = acc[r] - apt * pto;
+          ptv[r] = pto;
+          if (row < H && col < W) prow[cl * C32] = pto;
+        }
+      }
+    }
     if (full) {
       update(acc0, vp0, zb0, y0 + r0, a.p[t], true);
       update(acc1, vp1, zb1, y0 + r0 + 1, a.p[t], true);
@@ -603,6 +651,8 @@ struct HfJob {
   int B, Cin, H, W, hard_reset;
   float* v_out;
   uint32_t *z_out, *zT_out;
+  const float *leak_pt, *add_pt, *pt_prev;  // PLIF head (pt_out != NULL)
+  float *pt_out, *P_out;
 };
 #define HF_MAX_JOBS 96
 struct HfDefer {
@@ -616,7 +666,7 @@ void evf_hf_defer_reset(int ctx) { hf_tab[ctx].n = 0; }
 static void head_fwd_one(const HfJob& q, hipStream_t st) {
   dim3 grid(evf_cdiv(q.W, TW), evf_cdiv(q.H, TH), q.B), block(256);
   launch_head_fwd(grid, block, st, q.x, q.w, q.leak, q.thresh, q.v_prev, q.z_prev, q.B, q.Cin, q.H, q.W, q.hard_reset, q.v_out,
-                  q.z_out, q.zT_out, nullptr, nullptr, nullptr, nullptr, nullptr);
+                  q.z_out, q.zT_out, q.leak_pt, q.add_pt, q.pt_prev, q.pt_out, q.P_out);
 }
 int evf_hf_defer_launch(int ctx, void* stream) {
   HfDefer& hf = hf_tab[ctx];
@@ -634,6 +684,8 @@ int evf_hf_defer_launch(int ctx, void* stream) {
       if (!(q.v_prev == p.v_out && q.z_prev == p.z_out && q.w == p.w && q.leak == p.leak && q.thresh == p.thresh && q.B == p.B &&
             q.Cin == p.Cin && q.H == p.H && q.W == p.W && q.hard_reset == p.hard_reset))
         break;
+      if ((q.pt_out != nullptr) != (p.pt_out != nullptr)) break;
+      if (q.pt_out && !(q.pt_prev == p.pt_out && q.leak_pt == p.leak_pt && q.add_pt == p.add_pt)) break;
       ++m;
     }
     const HfJob& f = hf.job[k];
@@ -644,11 +696,20 @@ int evf_hf_defer_launch(int ctx, void* stream) {
       HeadWin a;
       for (int t = 0; t < HEADWIN_MAX_P; ++t) {
         const HfJob& q = hf.job[k + (t < m ? t : 0)];
-        a.p[t] = HeadWinPass{q.x, q.v_out, q.z_out, q.zT_out};
+        a.p[t] = HeadWinPass{q.x, q.v_out, q.z_out, q.zT_out, q.pt_out, q.P_out};
       }
       a.w = f.w, a.leak = f.leak, a.thresh = f.thresh, a.v_prev = f.v_prev, a.z_prev = f.z_prev;
       a.np = m, a.B = f.B, a.Cin = f.Cin, a.H = f.H, a.W = f.W, a.hard_reset = f.hard_reset;
+      a.leak_pt = f.leak_pt, a.add_pt = f.add_pt, a.pt_prev = f.pt_prev;
       dim3 grid(evf_cdiv(f.W, TW), evf_cdiv(f.H, TH), f.B), block(256);
+      if (f.pt_out) {
+        switch ((f.Cin + 1) / 2) {
+          case 1: hipLaunchKernelGGL((k_head_lif_fwd_win<1, true>), grid, block, 0, st, a); break;
+          case 2: hipLaunchKernelGGL((k_head_lif_fwd_win<2, true>), grid, block, 0, st, a); break;
+          case 3: hipLaunchKernelGGL((k_head_lif_fwd_win<3, true>), grid, block, 0, st, a); break;
+          default: hipLaunchKernelGGL((k_head_lif_fwd_win<4, true>), grid, block, 0, st, a); break;
+        }
+      } else
       switch ((f.Cin + 1) / 2) {
         case 1: hipLaunchKernelGGL(k_head_lif_fwd_win<1>, grid, block, 0, st, a); break;
         case 2: hipLaunchKernelGGL(k_head_lif_fwd_win<2>, grid, block, 0, st, a); break;
@@ -675,7 +736,8 @@ extern "C" int evf_head_lif_fwd(const float* x, const float* w, const float* lea
       const int rc = evf_hf_defer_launch(fctx, stream);
       if (rc) return rc;
     }
-    hf.job[hf.n++] = HfJob{x, w, leak, thresh, v_prev, z_prev, B, Cin, H, W, hard_reset, v_out, z_out, zT_out};
+    hf.job[hf.n++] = HfJob{x, w, leak, thresh, v_prev, z_prev, B, Cin, H, W, hard_reset, v_out, z_out, zT_out,
+                           nullptr, nullptr, nullptr, nullptr, nullptr};
     if (evf_defer_poisoned()) {
       const size_t npix = (size_t)B * H * W;
       int rc = evf_hip(evf_memset_async(v_out, 0xFF, npix * C32 * sizeof(float), EVF_STREAM(stream)));
@@ -697,6 +759,25 @@ extern "C" int evf_head_plif_fwd(const float* x, const float* w, const float* le
   if (!x || !w || !leak_v || !leak_pt || !add_pt || !thresh || !v_out || !z_out || !pt_out || !P_out || B <= 0 ||
       Cin <= 0 || Cin > HEAD_MAX_CIN || H <= 0 || W <= 0)
     return EVF_EINVAL;
+  const int fctx = evf_ctx_find(stream);
+  if (fctx >= 0 && evf_fwd_defer_active(fctx)) {  // recorded like evf_head_lif_fwd: the window's passes in one launch at the flush
+    HfDefer& hf = hf_tab[fctx];
+    if (hf.n == HF_MAX_JOBS) {
+      const int rc = evf_hf_defer_launch(fctx, stream);
+      if (rc) return rc;
+    }
+    hf.job[hf.n++] = HfJob{x, w, leak_v, thresh, v_prev, z_prev, B, Cin, H, W, hard_reset, v_out, z_out, zT_out,
+                           leak_pt, add_pt, pt_prev, pt_out, P_out};
+    if (evf_defer_poisoned()) {
+      const size_t npix = (size_t)B * H * W;
+      int rc = evf_hip(evf_memset_async(v_out, 0xFF, npix * C32 * sizeof(float), EVF_STREAM(stream)));
+      if (!rc) rc = evf_hip(evf_memset_async(z_out, 0xFF, npix * sizeof(uint32_t), EVF_STREAM(stream)));
+      if (!rc) rc = evf_hip(evf_memset_async(pt_out, 0xFF, npix * C32 * sizeof(float), EVF_STREAM(stream)));
+      if (!rc) rc = evf_hip(evf_memset_async(P_out, 0xFF, npix * sizeof(float), EVF_STREAM(stream)));
+      if (rc) return rc;
+    }
+    return EVF_OK;
+  }
   dim3 grid(evf_cdiv(W, TW), evf_cdiv(H, TH), B), block(256);
   launch_head_fwd(grid, block, EVF_STREAM(stream), x, w, leak_v, thresh, v_prev, z_prev, B, Cin, H, W, hard_reset, v_out,
                   z_out, zT_out, leak_pt, add_pt, pt_prev, pt_out, P_out);

@@ -1137,9 +1137,11 @@ def test_stream_replicas_step_equals_the_unsplit_step():
 
 def test_plif_cells_recorded_on_diagonals_are_bit_identical(monkeypatch):
     """PLIF cells (pre-synaptic trace) through the recorded forward -- k_fwd_diag_t<.., PLIF>: team M pools the input spike
-    counts of its strip, team E carries the trace -- against one launch per cell (k_conv_lif_fwd_b3<.., true>): flows of every
+    counts of its strip, team E carries the trace; the head layer's passes in one launch with potential AND trace in registers
+    (k_head_lif_fwd_win<.., PLIF>) -- against one launch per cell (k_conv_lif_fwd_b3<.., true>, k_head_lif_fwd): flows of every
     pass, potentials, spike words, traces after the window BIT for bit; and a training window's loss / gradient norm like two
-    cell-by-cell runs (the backward cells of a PLIF network are not recorded)."""
+    cell-by-cell runs (backward: the head layer's cells of the window in one launch with the trace backward inside, the hidden
+    cells with the trace backward in their streaming team, launched pass by pass)."""
     from event_flow_amd import train as htrain
 
     g = load_golden("g7_pliffirenet_train")
@@ -1151,7 +1153,7 @@ def test_plif_cells_recorded_on_diagonals_are_bit_identical(monkeypatch):
         model.defer_forward(defer)
         flows = [model(d["event_voxel"], d["event_cnt"])["flow"][0] for d in passes_from_golden(g)]
         if defer:
-            assert _lib.raw("evf_fwd_defer_pending") == 6 * len(flows)  # the hidden cells; the PLIF head launches per pass
+            assert _lib.raw("evf_fwd_defer_pending") == 7 * len(flows)  # nothing has run yet (the head cells: one launch at the flush)
         model.defer_forward(False)
         assert _lib.raw("evf_fwd_defer_pending") == 0
         return [N(f).copy() for f in flows], [N(s).copy() for s in model.states]
@@ -1164,6 +1166,7 @@ def test_plif_cells_recorded_on_diagonals_are_bit_identical(monkeypatch):
 
     def run(defer):
         monkeypatch.setattr(htrain, "DEFER_FORWARD", defer)
+        monkeypatch.setattr(htrain, "DEFER_BACKWARD", defer)  # (PLIF: the head layer's backward cells of the window in one launch)
         model = build_from_golden(g, fix="g7_pliffirenet_train")
         model.train()
         lossf = hloss.EventWarping(loss_cfg(H, W), DEV)
@@ -1184,6 +1187,13 @@ def test_plif_cells_recorded_on_diagonals_are_bit_identical(monkeypatch):
     l2, n2 = run(True)
     np.testing.assert_allclose(l2, l1, rtol=1e-6)
     np.testing.assert_allclose(n2, n1, rtol=1e-6)
+    # the trace backward as a launch of its own per cell (evf_plif_trace_bwd) against the fused forms (team E of the hidden cells'
+    # fused backward, the head layer's window launch): the same bits per element, the per-channel sums to round-off
+    monkeypatch.setattr(heng, "PLIF_BOX_IN_DGRAD", True)
+    monkeypatch.setattr(heng, "PLIF_TRACE_FUSED", False)
+    l3, n3 = run(True)
+    np.testing.assert_allclose(l3, l1, rtol=1e-6)
+    np.testing.assert_allclose(n3, n1, rtol=1e-5)
 
 
 def test_diagonal_launches_equal_cell_by_cell_launches(monkeypatch):
