@@ -116,7 +116,7 @@ NETWORK_SIGNATURES = {
     "evf_clip_adam_step": [P, P, P, P, L, F, F, F, F, F, I, P, I, P],
     "evf_cm_merge": [I],
     "evf_clip_adam_fused": [P, P, P, P, L, F, F, F, F, F, I, P, I, P],
-    "evf_grads_finalize": [P, P, I, I, P, I, P, I, I, P, I, I, I, P, P, P, I, P],
+    "evf_grads_finalize": [P, P, I, I, P, I, P, I, I, P, I, I, I, P, P, P, P, I, P],
     # general path (any channel count, NHWC fp32)
     "evf_conv2d_packed_size": [I, I, I, I],
     "evf_pack_conv2d_weight": [P, I, I, I, I, I, I, P, P],

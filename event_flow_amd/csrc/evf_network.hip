@@ -466,8 +466,9 @@ struct HeadWin {
 
 // PLIF: the presynaptic trace stays in registers between the passes as well (k_head_lif_fwd read it back every pass); every pass
 // does the arithmetic of k_head_lif_fwd's PLIF branch: the same bits.
+// (PLIF: 288 registers wanted -- at one wave per SIMD the kernel ran at the latency of its stores; two blocks per CU with 32 spilled)
 template <int S2, bool PLIF = false>
-__global__ __launch_bounds__(HEADWIN_LB) void k_head_lif_fwd_win(HeadWin a) {
+__global__ __launch_bounds__(HEADWIN_LB, PLIF ? 2 : 1) void k_head_lif_fwd_win(HeadWin a) {
   __shared__ float s_x[2][2 * S2][HALO_H * HALO_W];
   __shared__ float s_w[9 * S2 * 64];
   __shared__ float s_P[PLIF ? TH * TW : 1];

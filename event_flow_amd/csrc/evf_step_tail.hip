@@ -19,6 +19,7 @@ struct GfArgs {
   float* seg_dst[32];     // segment k: seg_dst[k][i] += total[seg_off[k] + i], i < seg_n[k]
   int seg_off[32];
   int seg_n[32];
+  int seg_rows[32];       // rows of the per-block partials that can hold something for segment k (the others are zero: skipped)
   int seg_blk0[33];       // first block (of the segment part) of segment k; [nseg] = their number
 };
 
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(64 * GF_GROUPS) void k_grads_finalize(GfArgs a, int
   const bool in = i < a.seg_n[k];
   const int e = a.seg_off[k] + (in ? i : 0);  // column of the small accumulator
   float v = 0.f;
+  nrows = min(nrows, a.seg_rows[k]);
   if (rows && e < ncols) {  // (clamped rows + selects: every load of a trip is unconditional, i.e. in flight together)
     float* __restrict__ rp = rows + e;
     for (int r0 = 0; r0 < nrows; r0 += GF_GROUPS * GF_UNROLL) {
@@ -110,7 +112,8 @@ __global__ __launch_bounds__(64 * GF_GROUPS) void k_grads_finalize(GfArgs a, int
 
 extern "C" int evf_grads_finalize(const void* const* slabs, void* const* slab_dst, int nslabs, int nslab, float* small, int clear_small,
                                   float* rows, int nrows, int ncols, const float* head_rows, int nhrows, int nhcols, int head_off,
-                                  void* const* seg_dst, const int* seg_off, const int* seg_n, int nseg, void* stream) {
+                                  void* const* seg_dst, const int* seg_off, const int* seg_n, const int* seg_rows, int nseg,
+                                  void* stream) {
   if (nslabs < 0 || nslabs > 16 || nseg < 0 || nseg > 32 || (nslabs && (!slabs || !slab_dst || nslab <= 0)) ||
       (nseg && (!small || !seg_dst || !seg_off || !seg_n)) || (rows && (nrows <= 0 || ncols <= 0)) ||
       (head_rows && (nhrows <= 0 || nhcols <= 0 || head_off < 0)))
@@ -127,6 +130,7 @@ extern "C" int evf_grads_finalize(const void* const* slabs, void* const* slab_ds
     a.seg_dst[k] = k < nseg ? (float*)seg_dst[k] : nullptr;
     a.seg_off[k] = k < nseg ? seg_off[k] : 0;
     a.seg_n[k] = k < nseg ? seg_n[k] : 0;
+    a.seg_rows[k] = (k < nseg && seg_rows && seg_rows[k] > 0) ? seg_rows[k] : 0x7fffffff;
     if (k < nseg && (!a.seg_dst[k] || a.seg_off[k] < 0 || a.seg_n[k] <= 0)) return EVF_EINVAL;
     a.seg_blk0[k] = nb;
     if (k < nseg) nb += evf_cdiv(a.seg_n[k], 64);

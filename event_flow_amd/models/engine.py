@@ -761,7 +761,13 @@ class FireNetEngine:
         when every trainable parameter's .grad is bound to that buffer (FlatAdam).  False: the caller takes the step-by-step path."""
         if not hip_ops.DIRECT_PARAM_GRADS:
             return False
-        red_src, red_dst, seg_dst, seg_off, seg_n = [], [], [], [], []
+        red_src, red_dst, seg_dst, seg_off, seg_n, seg_rows = [], [], [], [], [], []
+        # rows of the per-block partials a segment's writers can have touched: the head layer's launches (evf_head_*_bwd_wgrad: one
+        # row per block of evf_head_lif_bwd_wgrad_slabs) / the hidden cells' (fused backward: <= evf_lif_bwd_wgrad_slabs blocks;
+        # evf_plif_trace_bwd: <= 512)
+        L = _lib.load()
+        rows_head = L.evf_head_lif_bwd_wgrad_slabs(*win.shape)
+        rows_hidden = max(L.evf_lif_bwd_wgrad_slabs(*win.shape), 512)
         for name, p in zip(self.pnames, self.params):
             if not p.requires_grad:
                 continue
@@ -771,6 +777,7 @@ class FireNetEngine:
                 seg_dst.append(p.grad)
                 seg_off.append(self.small_off[name][0])
                 seg_n.append(self.small_off[name][1])
+                seg_rows.append(rows_head if name.startswith("0.") else rows_hidden)
             else:
                 i, nm = name.split(".")
                 if win.slab_init.get((int(i), nm)):
@@ -786,7 +793,8 @@ class FireNetEngine:
                   1 if win.small_persistent else 0, _lib.ptr(rows), rows.shape[0] if rows is not None else 0,
                   rows.shape[1] if rows is not None else 0, _lib.ptr(head), head.shape[0] if head is not None else 0,
                   head.shape[1] if head is not None else 0, self.small_off["0.ff"][0] if head is not None else 0,
-                  (ctypes.c_void_p * n2)(*[t.data_ptr() for t in seg_dst]), (ctypes.c_int * n2)(*seg_off), (ctypes.c_int * n2)(*seg_n), n2)
+                  (ctypes.c_void_p * n2)(*[t.data_ptr() for t in seg_dst]), (ctypes.c_int * n2)(*seg_off), (ctypes.c_int * n2)(*seg_n),
+                  (ctypes.c_int * n2)(*seg_rows), n2)
         if rows is not None:
             # the kernel hands back zeroed the columns it consumed: the buffer as a whole is clean only when the trainable segments
             # cover every column (a frozen per-channel parameter's column keeps its partial sums -> _take_rows starts afresh)

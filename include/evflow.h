@@ -744,10 +744,13 @@ int evf_clip_adam_fused(float* param, float* grad, float* m, float* v, int64_t n
  *                       + sum_r head_rows[r][e - head_off] (head_off <= e < head_off + nhcols; null = none);
  *   seg_dst[k][i] += total[seg_off[k] + i], i < seg_n[k] (nseg <= 32); clear_small != 0: small[e] = 0 afterwards.
  * Every output element has ONE writer that sums in a fixed order: the result does not depend on the block schedule (segments
- * must not overlap).  Only the columns of `rows` that belong to a segment are read and zeroed. */
+ * must not overlap).  Only the columns of `rows` that belong to a segment are read and zeroed.  seg_rows (may be NULL: all):
+ * seg_rows[k] = the number of leading rows that can hold something for segment k -- the writers of a segment's columns are
+ * launches of at most that many blocks, the rows behind are zero and are skipped. */
 int evf_grads_finalize(const void* const* slabs, void* const* slab_dst, int nslabs, int nslab, float* small, int clear_small,
                        float* rows, int nrows, int ncols, const float* head_rows, int nhrows, int nhcols, int head_off,
-                       void* const* seg_dst, const int* seg_off, const int* seg_n, int nseg, void* stream);
+                       void* const* seg_dst, const int* seg_off, const int* seg_n, const int* seg_rows, int nseg,
+                       void* stream);
 
 /* ---- data parallelism: the ONE collective of an optimizer step (SURVEY.md 8(b) `evf_allreduce_sum`, 8(e)) ----------------
  * The reference is single-process (/root/reference/configs/parser.py:83-86, train_flow.py:98-171); its loss SUMS over the batch
