@@ -1304,7 +1304,16 @@ __global__ __launch_bounds__(768) void k_bwd_diag_ws_plif(FbJobs jobs, int B, in
 static long fb_units(int B, int H, int W) { return (long)B * H * ((W + FB_CW - 1) / FB_CW); }
 #define FB_LDS (FB_R0 + 2 * (2 * 3 * C32 * FB_NW * 4) + 256 * 16 + 2 * (2 * 8 * C32 * 4))  // (the second [2][8][32]: PLIF)
 
-extern "C" int evf_lif_bwd_wgrad_slabs(int B, int H, int W) { return evf_cdiv(fb_units(B, H, W), FB_UNITS); }
+// Slab rows per (cell, input) = the most blocks a launch may give a cell.  One row per FB_UNITS units up to one block per CU's
+// worth (256); beyond that a launch never takes more blocks than that anyway (fb_blocks_per_cell: 260 x 346 x B4 = 6240 units runs
+// on 250 blocks) -- with 780 rows the other 530 were zero-filled by every first-touch launch and read back by the reduction
+// (k_grads_finalize: 115 us per step).  At least cdiv(units, FB_UNITS_MAX): a block holds at most 64 units.
+static int fb_rows(long nunits) {
+  const long full = (nunits + FB_UNITS - 1) / FB_UNITS, need = (nunits + FB_UNITS_MAX - 1) / FB_UNITS_MAX;
+  const long cap = need > 256 ? need : 256;
+  return (int)(full < cap ? full : cap);
+}
+extern "C" int evf_lif_bwd_wgrad_slabs(int B, int H, int W) { return fb_rows(fb_units(B, H, W)); }
 
 EvfBwdDefer evf_bwd_defer_tab[EVF_CTX_MAX] = {};
 
@@ -1462,11 +1471,13 @@ static int fb_blocks_per_cell(long nunits, int n, int per_unit = 11) {  // per_u
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
     if (ncu <= 0) ncu = 256;
   }
-  if (mode) return evf_cdiv(nunits, mode);
+  const int rows = fb_rows(nunits);
+  if (mode) return evf_cdiv(nunits, mode) < rows ? evf_cdiv(nunits, mode) : rows;
   long best = -1;
-  int best_nb = evf_cdiv(nunits, FB_UNITS);
+  int best_nb = rows;
   for (int u = FB_UNITS; u <= FB_UNITS_MAX; ++u) {
     const int nb = evf_cdiv(nunits, u);
+    if (nb > rows) continue;
     const long cost = (long)evf_cdiv((long)n * nb, ncu) * (42 + per_unit * u);  // (x2: integers)
     if (best < 0 || cost < best) best = cost, best_nb = nb;
   }
@@ -1486,7 +1497,7 @@ static int fb_split_blocks(FbJobs& jobs, int n, int nblk, long nunits, bool team
     int a = 0, b = 0, c = 0;
     if (e && sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a >= 0 && b >= 0 && c >= 0 && a < 256 && b < 256 && c < 256) w[0] = a, w[1] = b, w[2] = c;
   }
-  const int lo = evf_cdiv(nunits, FB_UNITS_MAX), hi = evf_cdiv(nunits, FB_UNITS);
+  const int lo = evf_cdiv(nunits, FB_UNITS_MAX), hi = fb_rows(nunits);
   int nb[FB_MAX_JOBS], wj[FB_MAX_JOBS];
   long ws = 0;
   for (int k = 0; k < n; ++k) wj[k] = (teams8 && w[0] > 0 && w[1] > 0 && w[2] > 0) ? w[jobs.j[k].kind % 3] : 1, ws += wj[k];
@@ -1550,7 +1561,7 @@ static int fb_defer_launch(FbDefer& fb_defer, int d, void* stream) {
   FbJobs jobs;
   for (int k = 0; k < FB_MAX_JOBS; ++k) jobs.j[k] = fb_defer.job[d][k < n ? k : 0];
   const long nunits = fb_units(fb_defer.B, fb_defer.H, fb_defer.W);
-  const int nrows = evf_cdiv(nunits, FB_UNITS), nchunk = (fb_defer.W + FB_CW - 1) / FB_CW;
+  const int nrows = fb_rows(nunits), nchunk = (fb_defer.W + FB_CW - 1) / FB_CW;
   static const int cost_env = []() { const char* e = getenv("EVF_BWD_COST"); return e ? atoi(e) : 0; }();  // (A/B measurements)
   const int nblk = fb_blocks_per_cell(nunits, n, cost_env > 0 ? cost_env : (teams == 2 ? 8 : 11));  // (k_bwd_diag_ws<8>: ~4.0 k cycles per unit, phase stamps)
   const int ntot = fb_split_blocks(jobs, n, nblk, nunits, teams == 2);
@@ -1645,7 +1656,7 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
   accumulate &= 1;
   const long nunits = fb_units(B, H, W);
   const int nchunk = (W + FB_CW - 1) / FB_CW;
-  const int nrows_all = evf_cdiv(nunits, FB_UNITS);
+  const int nrows_all = fb_rows(nunits);
   dim3 grid(fb_blocks_per_cell(nunits, 1)), block(FB_THREADS);
   hipStream_t st = EVF_STREAM(stream);
   const FbTop top = topp ? *topp : FbTop{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
