@@ -466,9 +466,15 @@ struct HeadWin {
 
 // PLIF: the presynaptic trace stays in registers between the passes as well (k_head_lif_fwd read it back every pass); every pass
 // does the arithmetic of k_head_lif_fwd's PLIF branch: the same bits.
-// (PLIF: 288 registers wanted -- at one wave per SIMD the kernel ran at the latency of its stores; two blocks per CU with 32 spilled)
-template <int S2, bool PLIF = false>
-__global__ __launch_bounds__(HEADWIN_LB, PLIF ? 2 : 1) void k_head_lif_fwd_win(HeadWin a) {
+// NWV = waves per block: 4 (a wave takes two rows of the 8 x 32 tile) or 8 (one row each).  With two rows per wave the kernel
+// holds potential (+ trace) and accumulators of 32 pixels per lane: 212 registers (LIF) / 288 wanted (PLIF, i.e. one wave per
+// SIMD or spills) -- the block then runs at the latency of its own store -> barrier -> matrix chain.  One row per wave halves the
+// per-lane state; twice the waves per CU hide each other's chains.  Same MFMA order per row: the same bits.
+template <int S2, bool PLIF = false, int NWV = 4>
+// (second launch bound = waves per SIMD: LIF x 8 waves 130 -> 128 registers = two blocks per CU; PLIF x 4 waves: two blocks, spills)
+__global__ __launch_bounds__(64 * NWV, (NWV == 8 && !PLIF) ? 4 : ((NWV == 4 && PLIF) ? 2 : 1)) void k_head_lif_fwd_win(HeadWin a) {
+  constexpr int NTHR = 64 * NWV, RPW = TH / NWV;  // threads, rows per wave
+  static_assert(TH == 8 && TW == 32 && (NWV == 4 || NWV == 8), "8 x 32 tile");
   __shared__ float s_x[2][2 * S2][HALO_H * HALO_W];
   __shared__ float s_w[9 * S2 * 64];
   __shared__ float s_P[PLIF ? TH * TW : 1];
@@ -481,24 +487,23 @@ __global__ __launch_bounds__(HEADWIN_LB, PLIF ? 2 : 1) void k_head_lif_fwd_win(H
     const uint32_t wd = *(z_prev ? z_prev + ((long)b * H + row) * W + col : (const uint32_t*)a.p[0].v_out);
     return z_prev ? wd : 0u;
   };
-  float vp0[16], vp1[16];
-  uint32_t zb0 = 0u, zb1 = 0u;  // bit r: the previous spike of this lane's channel at its pixel r (all a lane needs of the words)
-  {
-    uint32_t zw0[16], zw1[16];
-    lif_load_prev(b, y0 + 2 * wv, x0, H, W, lane, a.v_prev, a.p[0].v_out, zword, vp0, zw0);
-    lif_load_prev(b, y0 + 2 * wv + 1, x0, H, W, lane, a.v_prev, a.p[0].v_out, zword, vp1, zw1);
+  const int r0 = RPW * wv;
+  float vp[RPW][16];
+  uint32_t zb[RPW];  // bit r: the previous spike of this lane's channel at its pixel r (all a lane needs of the words)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      zb0 |= ((zw0[r] >> (lane & 31)) & 1u) << r;
-      zb1 |= ((zw1[r] >> (lane & 31)) & 1u) << r;
-    }
+  for (int m = 0; m < RPW; ++m) {
+    uint32_t zw[16];
+    lif_load_prev(b, y0 + r0 + m, x0, H, W, lane, a.v_prev, a.p[0].v_out, zword, vp[m], zw);
+    zb[m] = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zb[m] |= ((zw[r] >> (lane & 31)) & 1u) << r;
   }
-  constexpr int NW = (9 * S2 * 64 + 255) / 256, NX = (2 * S2 * HALO_H * HALO_W + 255) / 256;
+  constexpr int NW = (9 * S2 * 64 + NTHR - 1) / NTHR, NX = (2 * S2 * HALO_H * HALO_W + NTHR - 1) / NTHR;
   float xreg[NX];
   auto fetch_x = [&](const float* __restrict__ x) {  // clamped addresses, selected afterwards: no load under a branch
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
-      const int e = min(tid + 256 * k, 2 * S2 * HALO_H * HALO_W - 1);
+      const int e = min(tid + NTHR * k, 2 * S2 * HALO_H * HALO_W - 1);
       const int ci = e / (HALO_H * HALO_W), p = e % (HALO_H * HALO_W);
       const int yy = y0 + p / HALO_W - 1, xx = x0 + p % HALO_W - 1;
       const bool in = ci < Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(HEADWIN_LB, PLIF ? 2 : 1) void k_head_lif_fwd_win(H
   auto put_x = [&](int buf) {
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
-      const int e = tid + 256 * k;
+      const int e = tid + NTHR * k;
       if (e < 2 * S2 * HALO_H * HALO_W) s_x[buf][e / (HALO_H * HALO_W)][e % (HALO_H * HALO_W)] = xreg[k];
     }
   };
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(HEADWIN_LB, PLIF ? 2 : 1) void k_head_lif_fwd_win(H
     float wreg[NW];
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
-      const int e = min(tid + 256 * k, 9 * S2 * 64 - 1);
+      const int e = min(tid + NTHR * k, 9 * S2 * 64 - 1);
       const int l = e & 63, s = (e >> 6) % S2, tau = (e >> 6) / S2;
       const int ci = 2 * s + (l >> 5), j = l & 31;
       const float wv0 = a.w[(j * Cin + min(ci, Cin - 1)) * 9 + tau];
@@ -526,32 +531,33 @@ __global__ __launch_bounds__(HEADWIN_LB, PLIF ? 2 : 1) void k_head_lif_fwd_win(H
     fetch_x(a.p[0].x);
 #pragma unroll
     for (int k = 0; k < NW; ++k)
-      if (tid + 256 * k < 9 * S2 * 64) s_w[tid + 256 * k] = wreg[k];
+      if (tid + NTHR * k < 9 * S2 * 64) s_w[tid + NTHR * k] = wreg[k];
     put_x(0);
   }
-  const int i = lane & 31, h = lane >> 5, r0 = 2 * wv, j = lane & 31;
+  const int i = lane & 31, h = lane >> 5, j = lane & 31;
   const float lam = evf_sigmoid(a.leak[j]);
   const float th = fmaxf(a.thresh[j], 0.01f);
   const int hard_reset = a.hard_reset;
   const int nW = (W + 31) / 32;
-  float pt0[PLIF ? 16 : 1], pt1[PLIF ? 16 : 1], lpt = 0.f, apt = 0.f;
+  float pt[PLIF ? RPW : 1][16];
+  float lpt = 0.f, apt = 0.f;
   if (PLIF) {
     lpt = evf_sigmoid(a.leak_pt[j]), apt = evf_sigmoid(a.add_pt[j]);
     const float* ptsrc = a.pt_prev ? a.pt_prev : a.p[0].v_out;  // (dummy source: selected away)
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < RPW; ++m) {
       const int rq = min(y0 + r0 + m, H - 1);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = ptsrc[(((long)b * H + rq) * W + min(x0 + mfma_row(r, lane), W - 1)) * C32 + j];
-        (m ? pt1 : pt0)[r] = a.pt_prev ? v : 0.f;
+        pt[PLIF ? m : 0][r] = a.pt_prev ? v : 0.f;
       }
     }
   }
   // LIF update of one row (lif_update) that also leaves the new state in vpv / zb for the next pass.  FULL: the tile lies
   // inside the image (block-uniform) -- no per-pixel branch.  The 16 spike words of the row go out in ONE store (lane r of
   // each half wave keeps word r) instead of 16 stores by lanes 0 and 32.
-  auto update = [&](const f32x16& acc, float (&vpv)[16], uint32_t& zb, int row, const HeadWinPass& o, const bool FULL) {
+  auto update = [&](const f32x16& acc, float (&vpv)[16], uint32_t& zbr, int row, const HeadWinPass& o, const bool FULL) {
     const bool row_ok = FULL || row < H;
     uint32_t plane = 0u, znew = 0u, zsel = 0u;
     // one base address per row; pixel r of the lane is a compile-time offset from it ((r & 3) + 8 (r >> 2) pixels)
@@ -563,7 +569,7 @@ __global__ __launch_bounds__(HEADWIN_LB, PLIF ? 2 : 1) void k_head_lif_fwd_win(H
       bool spike = false;
       if (ok) {
         const float v = vpv[r];
-        const float z = (float)((zb >> r) & 1u);
+        const float z = (float)((zbr >> r) & 1u);
         const float cur = acc[r];
         const float vo_hard = (v * lam) * (1.0f - z) + (1.0f - lam) * cur;
         const float vo_soft = v * lam + (1.0f - lam) * cur - z * th;
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(HEADWIN_LB, PLIF ? 2 : 1) void k_head_lif_fwd_win(H
       znew |= (spike ? 1u : 0u) << r;  // (pixels outside the image: never stored, never spiking)
       plane |= (spike ? 1u : 0u) << mfma_row(r, lane);
     }
-    zb = znew;
+    zbr = znew;
     if (j < 16) {
       const int col = x0 + mfma_row(j, lane);
       if (row_ok && (FULL || col < W)) o.z_out[((long)b * H + row) * W + col] = zsel;
@@ -593,7 +599,9 @@ __global__ __launch_bounds__(HEADWIN_LB, PLIF ? 2 : 1) void k_head_lif_fwd_win(H
     const int buf = t & 1;
     if (t + 1 < a.np) fetch_x(a.p[t + 1].x);  // (in flight under this pass's matrix phase and stores)
     __syncthreads();  // s_x[buf] (and, at t = 0, s_w) written; every wave is done reading s_x[buf ^ 1] (pass t - 1)
-    f32x16 acc0 = {0}, acc1 = {0};
+    f32x16 acc[RPW];
+#pragma unroll
+    for (int m = 0; m < RPW; ++m) acc[m] = f32x16{0};
 #pragma unroll 3
     for (int tau = 0; tau < 9; ++tau) {
       const int dy = tau / 3, dx = tau % 3;
@@ -601,45 +609,43 @@ __global__ __launch_bounds__(HEADWIN_LB, PLIF ? 2 : 1) void k_head_lif_fwd_win(H
       for (int s = 0; s < S2; ++s) {
         const float bw = s_w[(tau * S2 + s) * 64 + lane];
         const float* xp = s_x[buf][2 * s + h];
-        acc0 = mfma32(xp[(r0 + dy) * HALO_W + i + dx], bw, acc0);
-        acc1 = mfma32(xp[(r0 + 1 + dy) * HALO_W + i + dx], bw, acc1);
+#pragma unroll
+        for (int m = 0; m < RPW; ++m) acc[m] = mfma32(xp[(r0 + m + dy) * HALO_W + i + dx], bw, acc[m]);
       }
     }
     if (PLIF) {  // cur = ff - sigma(add_pt) * pt' (k_head_lif_fwd, spiking_submodules.py:191-227)
-      const int py = tid >> 5, px = tid & 31;
-      float sum9 = 0.f;
-      for (int dy = 0; dy < 3; ++dy)
-        for (int dx = 0; dx < 3; ++dx) {
-          float av = 0.f;
-          for (int ci = 0; ci < Cin; ++ci) av += fabsf(s_x[buf][ci][(py + dy) * HALO_W + px + dx]);
-          sum9 += av / (float)Cin;
-        }
-      const float Pv = sum9 / 9.0f;
-      s_P[tid] = Pv;
-      if (y0 + py < H && x0 + px < W) a.p[t].P_out[((long)b * H + y0 + py) * W + x0 + px] = Pv;
+      if (tid < TH * TW) {
+        const int py = tid >> 5, px = tid & 31;
+        float sum9 = 0.f;
+        for (int dy = 0; dy < 3; ++dy)
+          for (int dx = 0; dx < 3; ++dx) {
+            float av = 0.f;
+            for (int ci = 0; ci < Cin; ++ci) av += fabsf(s_x[buf][ci][(py + dy) * HALO_W + px + dx]);
+            sum9 += av / (float)Cin;
+          }
+        const float Pv = sum9 / 9.0f;
+        s_P[tid] = Pv;
+        if (y0 + py < H && x0 + px < W) a.p[t].P_out[((long)b * H + y0 + py) * W + x0 + px] = Pv;
+      }
       __syncthreads();  // (the next pass writes s_P behind the loop's barrier)
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        f32x16& acc = m ? acc1 : acc0;
-        float(&ptv)[PLIF ? 16 : 1] = m ? pt1 : pt0;
+      for (int m = 0; m < RPW; ++m) {
         const int row = y0 + r0 + m;
         float* const prow = a.p[t].pt_out + (((long)b * H + min(row, H - 1)) * W + x0) * C32 + j;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int cl = mfma_row(r, lane), col = x0 + cl;
-          const float pto = ptv[r] * lpt + (1.0f - lpt) * s_P[(r0 + m) * TW + cl];
-          acc[r] = acc[r] - apt * pto;
-          ptv[r] = pto;
+          const float pto = pt[PLIF ? m : 0][r] * lpt + (1.0f - lpt) * s_P[(r0 + m) * TW + cl];
+          acc[m][r] = acc[m][r] - apt * pto;
+          pt[PLIF ? m : 0][r] = pto;
           if (row < H && col < W) prow[cl * C32] = pto;
         }
       }
     }
-    if (full) {
-      update(acc0, vp0, zb0, y0 + r0, a.p[t], true);
-      update(acc1, vp1, zb1, y0 + r0 + 1, a.p[t], true);
-    } else {
-      update(acc0, vp0, zb0, y0 + r0, a.p[t], false);
-      update(acc1, vp1, zb1, y0 + r0 + 1, a.p[t], false);
+#pragma unroll
+    for (int m = 0; m < RPW; ++m) {
+      if (full) update(acc[m], vp[m], zb[m], y0 + r0 + m, a.p[t], true);
+      else update(acc[m], vp[m], zb[m], y0 + r0 + m, a.p[t], false);
     }
     if (t + 1 < a.np) put_x(buf ^ 1);
   }
@@ -702,21 +708,32 @@ int evf_hf_defer_launch(int ctx, void* stream) {
       a.w = f.w, a.leak = f.leak, a.thresh = f.thresh, a.v_prev = f.v_prev, a.z_prev = f.z_prev;
       a.np = m, a.B = f.B, a.Cin = f.Cin, a.H = f.H, a.W = f.W, a.hard_reset = f.hard_reset;
       a.leak_pt = f.leak_pt, a.add_pt = f.add_pt, a.pt_prev = f.pt_prev;
-      dim3 grid(evf_cdiv(f.W, TW), evf_cdiv(f.H, TH), f.B), block(256);
+      static const int waves = []() {  // EVF_HEAD_FWD_WAVES=4: two rows of the tile per wave (A/B; default 8: one row each)
+        const char* e = getenv("EVF_HEAD_FWD_WAVES");
+        return (e && e[0] == '4') ? 4 : 8;
+      }();
+      dim3 grid(evf_cdiv(f.W, TW), evf_cdiv(f.H, TH), f.B), block(64 * waves);
+#define HEAD_FWD_WIN(S2_, PLIF_)                                                                          \
+  do {                                                                                                    \
+    if (waves == 8) hipLaunchKernelGGL((k_head_lif_fwd_win<S2_, PLIF_, 8>), grid, block, 0, st, a);        \
+    else hipLaunchKernelGGL((k_head_lif_fwd_win<S2_, PLIF_, 4>), grid, block, 0, st, a);                   \
+  } while (0)
       if (f.pt_out) {
         switch ((f.Cin + 1) / 2) {
-          case 1: hipLaunchKernelGGL((k_head_lif_fwd_win<1, true>), grid, block, 0, st, a); break;
-          case 2: hipLaunchKernelGGL((k_head_lif_fwd_win<2, true>), grid, block, 0, st, a); break;
-          case 3: hipLaunchKernelGGL((k_head_lif_fwd_win<3, true>), grid, block, 0, st, a); break;
-          default: hipLaunchKernelGGL((k_head_lif_fwd_win<4, true>), grid, block, 0, st, a); break;
+          case 1: HEAD_FWD_WIN(1, true); break;
+          case 2: HEAD_FWD_WIN(2, true); break;
+          case 3: HEAD_FWD_WIN(3, true); break;
+          default: HEAD_FWD_WIN(4, true); break;
         }
-      } else
-      switch ((f.Cin + 1) / 2) {
-        case 1: hipLaunchKernelGGL(k_head_lif_fwd_win<1>, grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL(k_head_lif_fwd_win<2>, grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL(k_head_lif_fwd_win<3>, grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL(k_head_lif_fwd_win<4>, grid, block, 0, st, a); break;
+      } else {
+        switch ((f.Cin + 1) / 2) {
+          case 1: HEAD_FWD_WIN(1, false); break;
+          case 2: HEAD_FWD_WIN(2, false); break;
+          case 3: HEAD_FWD_WIN(3, false); break;
+          default: HEAD_FWD_WIN(4, false); break;
+        }
       }
+#undef HEAD_FWD_WIN
       evf_prof_mark(4, 1, stream);
     }
     k += m;
