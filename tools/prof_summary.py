@@ -30,7 +30,7 @@ for run, out in (("graph", "bench_hipgraph"), ("eager", "bench_eager"), ("evfn",
     if run == "graph":  # (the default bench run appends the c4 / c5 lines from child processes, each with files of its own: the
         #  headline step is in the process that ran the head layer's window kernel)
         cand = [g for g in sorted(glob.glob(os.path.join(SRC, f"{run}/*/*kernel_stats.csv")), key=os.path.getmtime)
-                if "k_head_lif_fwd_win" in open(g).read()]
+                if "k_bwd_diag_ws<" in open(g).read()]  # (the LIF diagonal kernel: the c5 child has head-window kernels too)
         f = cand[-1] if cand else f
     if f:
         shutil.copy(f, os.path.join(DST, f"{R}_{out}_kernel_stats.csv"))

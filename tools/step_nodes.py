@@ -18,8 +18,8 @@ files = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{R}", "graph", 
 if not files:
     sys.exit("no kernel trace under gpurun_out/prof_%s/graph" % R)
 # (the default bench run appends the c4 / c5 lines from child processes, each with a trace of its own: the headline step is in the
-#  trace that holds the head layer's window kernel)
-pick = [f for f in files if "k_head_lif_fwd_win" in open(f).read()]
+#  trace that holds the LIF diagonal kernel -- the PLIF child (c5) has a head-window kernel as well)
+pick = [f for f in files if "k_bwd_diag_ws<" in open(f).read()]
 rows = list(csv.DictReader(open(pick[-1] if pick else files[-1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 adam = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_clip_adam")]
