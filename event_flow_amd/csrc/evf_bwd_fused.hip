@@ -669,7 +669,7 @@ __device__ __forceinline__ void fb_body_ws(
       }
       if (PLIF) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) lpt[k] = fb_sigmoid(pl.leak_pt[4 * cg + k]), apt[k] = fb_sigmoid(pl.add_pt[4 * cg + k]);
+        for (int k = 0; k < 4; ++k) lpt[k] = evf_plif_sigmoid(pl.leak_pt[4 * cg + k]), apt[k] = evf_plif_sigmoid(pl.add_pt[4 * cg + k]);
       }
     };
     const float4* pgz = g_z_out ? g_z_out : v_out;
@@ -781,7 +781,7 @@ __device__ __forceinline__ void fb_body_ws(
         float gq[4], gPp = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const float po = pp[c] * lpt[c] + (1.0f - lpt[c]) * Pv;  // pt' of the forward pass, recomputed
+          const float po = evf_plif_trace(pp[c], lpt[c], Pv);  // pt' of the forward pass, recomputed
           const float g = gk[c] - apt[c] * gc[c];
           gq[c] = g * lpt[c];
           gPp += g * (1.0f - lpt[c]);

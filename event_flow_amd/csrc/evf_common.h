@@ -54,6 +54,15 @@ static inline hipError_t evf_memset_async(void* dst, int value, size_t bytes, hi
   return hipGetLastError();
 }
 
+// PLIF / XLIF presynaptic trace update (reference models/spiking_submodules.py:212, :418, :642):
+//   pt' = pt * sigma(leak_pt) + (1 - sigma(leak_pt)) * P
+// ONE expression for every forward kernel that produces pt' (fwd_b3_body, k_fwd_diag_t, k_head_lif_fwd[_win], k_neuron_fwd) and for
+// every backward that recomputes it from pt and P instead of reading it back (k_plif_trace_bwd, team E of k_bwd_diag_ws_plif,
+// head_bwd_pass<.., PLIF>): the library is built with -ffp-contract=off, so this is mul, sub, mul, add wherever it is inlined --
+// the recomputed trace equals the stored one bit for bit.  evf_plif_sigmoid: the one sigmoid of the trace parameters.
+__device__ __forceinline__ float evf_plif_trace(float pt, float lpt, float P) { return pt * lpt + (1.0f - lpt) * P; }
+__device__ __forceinline__ float evf_plif_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
 // hardware fp32 atomic add (global_atomic_add_f32 / ds_add_f32); plain
 // atomicAdd would lower to a CAS loop without -munsafe-fp-atomics.
 __device__ __forceinline__ void evf_atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }

@@ -161,8 +161,8 @@ __device__ __forceinline__ void fwd_b3_body(const int b, const uint32_t* __restr
   if (tid < C32) {  // per-channel constants, once per block (operands: top of the kernel)
     s_par[tid] = b3_sigmoid(par_leak);             // torch.sigmoid(self.leak)     spiking_submodules.py:111/:536
     s_par[C32 + tid] = fmaxf(par_thresh, 0.01f);   // self.thresh.clamp_min(0.01)  :108/:533
-    s_par[2 * C32 + tid] = PLIF ? b3_sigmoid(par_lpt) : 0.f;
-    s_par[3 * C32 + tid] = PLIF ? b3_sigmoid(par_apt) : 0.f;
+    s_par[2 * C32 + tid] = PLIF ? evf_plif_sigmoid(par_lpt) : 0.f;
+    s_par[3 * C32 + tid] = PLIF ? evf_plif_sigmoid(par_apt) : 0.f;
   }
   // The weight DMA (invisible to the compiler's counters) was issued before everything else and memory
   // returns in order: once at most the state prefetches issued above (8, or 16 with the PLIF trace) are still
@@ -246,7 +246,7 @@ __device__ __forceinline__ void fwd_b3_body(const int b, const uint32_t* __restr
         float pto = 0.f;
         if (PLIF) {
           const float lpt = s_par[2 * C32 + c], apt = s_par[3 * C32 + c];
-          pto = p4[e] * lpt + (1.0f - lpt) * Pq;  // :212 / :642
+          pto = evf_plif_trace(p4[e], lpt, Pq);  // :212 / :642
           cur = cur - apt * pto;                  // (ff + rec) - add_pt * pt_out, :220 / :650
         }
         // both reset rules evaluated, one selected: no per-element branch on the (uniform) flag

@@ -125,8 +125,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
       s_par[C32 + tid] = fmaxf(J.thresh[tid], 0.01f);  // self.thresh.clamp_min(0.01)  :108/:533
     }
     if (PLIF && tid < C32) {
-      s_par2[tid] = b3_sigmoid(J.leak_pt[tid]);
-      s_par2[C32 + tid] = b3_sigmoid(J.add_pt[tid]);
+      s_par2[tid] = evf_plif_sigmoid(J.leak_pt[tid]);
+      s_par2[C32 + tid] = evf_plif_sigmoid(J.add_pt[tid]);
     }
     if (J.pr.w) {
       if (tid < 2 * C32) s_pw[tid] = J.pr.w[tid];
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
                 float cur = cu[q];
                 po4[q] = 0.f;
                 if (PLIF) {
-                  po4[q] = p4[q] * lptL[q] + (1.0f - lptL[q]) * Pk[k];  // :212 / :642
+                  po4[q] = evf_plif_trace(p4[q], lptL[q], Pk[k]);  // :212 / :642
                   cur = cur - aptL[q] * po4[q];                         // (ff + rec) - add_pt * pt_out, :220 / :650
                 }
                 const float vo = HARD ? (v4[q] * lamL[q]) * (1.0f - z) + omlL[q] * cur    // :119/:544

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ 
     s_P[tid] = P;
     if (y0 + py < H && x0 + px < W) P_out[((long)b * H + y0 + py) * W + x0 + px] = P;
     __syncthreads();
-    const float lpt = evf_sigmoid(leak_pt[j]), apt = evf_sigmoid(add_pt[j]);
+    const float lpt = evf_plif_sigmoid(leak_pt[j]), apt = evf_plif_sigmoid(add_pt[j]);
     const float* ptsrc = pt_prev ? pt_prev : pt_out;  // dummy source when there is no previous trace
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int cl = mfma_row(r, lane), col = x0 + cl;
-        const float pto = (pt_prev ? ptv[r] : 0.f) * lpt + (1.0f - lpt) * s_P[(r0 + m) * TW + cl];
+        const float pto = evf_plif_trace(pt_prev ? ptv[r] : 0.f, lpt, s_P[(r0 + m) * TW + cl]);
         acc[r] = acc[r] - apt * pto;
         if (row < H && col < W) pt_out[(((long)b * H + row) * W + col) * C32 + j] = pto;
       }
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 && !PLIF) ? 4 : ((NWV == 4 && P
   float pt[PLIF ? RPW : 1][16];
   float lpt = 0.f, apt = 0.f;
   if (PLIF) {
-    lpt = evf_sigmoid(a.leak_pt[j]), apt = evf_sigmoid(a.add_pt[j]);
+    lpt = evf_plif_sigmoid(a.leak_pt[j]), apt = evf_plif_sigmoid(a.add_pt[j]);
     const float* ptsrc = a.pt_prev ? a.pt_prev : a.p[0].v_out;  // (dummy source: selected away)
 #pragma unroll
     for (int m = 0; m < RPW; ++m) {
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 && !PLIF) ? 4 : ((NWV == 4 && P
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int cl = mfma_row(r, lane), col = x0 + cl;
-          const float pto = pt[PLIF ? m : 0][r] * lpt + (1.0f - lpt) * s_P[(r0 + m) * TW + cl];
+          const float pto = evf_plif_trace(pt[PLIF ? m : 0][r], lpt, s_P[(r0 + m) * TW + cl]);
           acc[m][r] = acc[m][r] - apt * pto;
           pt[PLIF ? m : 0][r] = pto;
           if (row < H && col < W) prow[cl * C32] = pto;
@@ -821,8 +821,8 @@ __global__ void k_plif_trace_bwd(const float4* __restrict__ g_cur, const float4*
   float lp[4], ap[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    lp[k] = evf_sigmoid(leak_pt[4 * cg + k]);
-    ap[k] = evf_sigmoid(add_pt[4 * cg + k]);
+    lp[k] = evf_plif_sigmoid(leak_pt[4 * cg + k]);
+    ap[k] = evf_plif_sigmoid(add_pt[4 * cg + k]);
   }
   float sl[4] = {0, 0, 0, 0}, sa[4] = {0, 0, 0, 0};
   // TWO grid strides per trip: all eight loads of a thread's two elements are requested before the first is used (one element per
@@ -859,7 +859,7 @@ __global__ void k_plif_trace_bwd(const float4* __restrict__ g_cur, const float4*
       // forward's own expression (evf_fwd_b3.hip: pto = p * lpt + (1 - lpt) * P): 128 of the kernel's 640 B/px less
       float po[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) po[k] = pp[k] * lp[k] + (1.0f - lp[k]) * Pv;
+      for (int k = 0; k < 4; ++k) po[k] = evf_plif_trace(pp[k], lp[k], Pv);
       float gp[4], gPp = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -929,7 +929,8 @@ extern "C" int evf_plif_trace_bwd(const float* g_cur, const float* g_pt_carry, c
                                   const float* P, const float* leak_pt, const float* add_pt, int B, int H, int W,
                                   float* g_pt_prev, float* g_P_raw, float* g_P_in, float* g_leak_pt, float* g_add_pt,
                                   int row_ld, void* stream) {
-  if (!g_cur || !pt_out || !P || !leak_pt || !add_pt || !g_pt_prev || !g_P_raw || !g_leak_pt || !g_add_pt ||
+  (void)pt_out;  // (not read since round 5: pt' is recomputed from pt_prev and P with evf_plif_trace, the forward's expression; may be NULL)
+  if (!g_cur || !P || !leak_pt || !add_pt || !g_pt_prev || !g_P_raw || !g_leak_pt || !g_add_pt ||
       B <= 0 || H <= 0 || W <= 0)
     return EVF_EINVAL;
   const long npix = (long)B * H * W;
@@ -1153,8 +1154,8 @@ __device__ __forceinline__ void head_bwd_pass(
       inv_oml[k] = 1.0f / oml[k];
       sl[k] = st[k] = 0.f;
       if (PLIF) {
-        KP.lpt[k] = evf_sigmoid(pm.leak_pt[4 * cg + k]);
-        KP.apt[k] = evf_sigmoid(pm.add_pt[4 * cg + k]);
+        KP.lpt[k] = evf_plif_sigmoid(pm.leak_pt[4 * cg + k]);
+        KP.apt[k] = evf_plif_sigmoid(pm.add_pt[4 * cg + k]);
         KP.slp[k] = KP.sap[k] = 0.f;
       }
     }
@@ -1293,7 +1294,7 @@ __device__ __forceinline__ void head_bwd_pass(
       float gq[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float po = pp[k] * KP.lpt[k] + (1.0f - KP.lpt[k]) * Pv;
+        const float po = evf_plif_trace(pp[k], KP.lpt[k], Pv);
         const float g = gk[k] - KP.apt[k] * gc[k];
         gq[k] = g * KP.lpt[k];
         if (ok) {

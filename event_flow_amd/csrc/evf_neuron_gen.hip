@@ -66,7 +66,7 @@ __global__ void k_neuron_fwd(const float4* __restrict__ cur, const float4* __res
     const int c = 4 * cq + k;
     lam[k] = ng_sigmoid(prm.p[0][c]);
     a1[k] = fmaxf(prm.p[1][c], 0.01f);  // thresh / t0 .clamp_min(0.01)
-    if (KIND == EVF_PLIF) a2[k] = ng_sigmoid(prm.p[2][c]), a3[k] = ng_sigmoid(prm.p[3][c]);
+    if (KIND == EVF_PLIF) a2[k] = evf_plif_sigmoid(prm.p[2][c]), a3[k] = evf_plif_sigmoid(prm.p[3][c]);
     if (KIND == EVF_ALIF || KIND == EVF_XLIF) a2[k] = fmaxf(prm.p[2][c], 0.f), a3[k] = ng_sigmoid(prm.p[3][c]);
   }
   for (; e < total; e += stride) {
@@ -82,14 +82,14 @@ __global__ void k_neuron_fwd(const float4* __restrict__ cur, const float4* __res
     for (int k = 0; k < 4; ++k) {
       float th = a1[k], c = cu[k], soft_th = a1[k];
       if (KIND == EVF_PLIF) {
-        ao[k] = ax[k] * a2[k] + (1.0f - a2[k]) * Pv;  // pt' (:212)
+        ao[k] = evf_plif_trace(ax[k], a2[k], Pv);  // pt' (:212)
         c = c - a3[k] * ao[k];                         // ff [+ rec] - add_pt * pt' (:220)
       } else if (KIND == EVF_ALIF) {
         ao[k] = ax[k] * a3[k] + (1.0f - a3[k]) * z[k];  // t' (:317)
         th = a1[k] + a2[k] * ao[k];                      // t0 + t1 * t' (:319)
         soft_th = a1[k] + a2[k] * ax[k];                 // soft reset uses the OLD trace (:329)
       } else if (KIND == EVF_XLIF) {
-        ao[k] = ax[k] * a3[k] + (1.0f - a3[k]) * Pv;  // pt' (:418)
+        ao[k] = evf_plif_trace(ax[k], a3[k], Pv);  // pt' (:418)
         th = a1[k] + a2[k] * ao[k];
         soft_th = a1[k] + a2[k] * ax[k];
       }
@@ -252,7 +252,7 @@ __global__ void k_neuron_bwd(const float4* __restrict__ g_v_out, const float4* _
     a1[k] = fmaxf(prm.p[1][c], 0.01f);
     m1[k] = prm.p[1][c] >= 0.01f ? 1.f : 0.f;  // clamp_min passes the gradient where p >= min
     a2[k] = a3[k] = m2[k] = 0.f;
-    if (KIND == EVF_PLIF) a2[k] = ng_sigmoid(prm.p[2][c]), a3[k] = ng_sigmoid(prm.p[3][c]);
+    if (KIND == EVF_PLIF) a2[k] = evf_plif_sigmoid(prm.p[2][c]), a3[k] = evf_plif_sigmoid(prm.p[3][c]);
     if (KIND == EVF_ALIF || KIND == EVF_XLIF) {
       a2[k] = fmaxf(prm.p[2][c], 0.f), a3[k] = ng_sigmoid(prm.p[3][c]);
       m2[k] = prm.p[2][c] >= 0.f ? 1.f : 0.f;

@@ -363,7 +363,8 @@ int evf_conv_dgrad_b3_f32_pair(const float* g_cur, const void* wT_b3, float* g_x
  * reaches the input spikes through the trace is added by evf_conv_dgrad_b3 when g_P = g_P_in
  * and x_bits are given -- or when g_P = g_P_raw with bit 1 of `accumulate` set (`accumulate | 2`): the input-gradient kernel
  * then applies AvgPool3x3^T / 32 itself (the same sums in the same order), and evf_plif_trace_bwd may be called with
- * g_P_in = NULL (one launch less per cell). */
+ * g_P_in = NULL (one launch less per cell).  evf_plif_trace_bwd's `pt_out` is not read (may be NULL): pt' is recomputed from
+ * pt_prev and P with the forward kernels' own expression (evf_plif_trace, csrc/evf_common.h: the same bits). */
 int evf_conv_plif_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec,
                          const float* leak_v, const float* leak_pt, const float* add_pt, const float* thresh,
                          const float* v_prev, const uint32_t* z_prev, const float* pt_prev,
