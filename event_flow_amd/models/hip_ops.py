@@ -79,9 +79,20 @@ def invalidate_packed_weights():
     _EPOCH[0] += 1
 
 
+def _pack_tag(w):
+    """Identity of a weight tensor's VALUES for the pack caches.  A parameter: storage pointer + in-place version counter (+ the
+    epoch fused optimizer kernels bump).  A weight-normalised weight is a fresh tensor every forward (the allocator may even hand
+    out the same address again): its identity is that of the (v, g) pair it was made from (weight_norm()) -- the passes of a
+    BPTT window then share one pack per operand instead of re-packing 2-4 times per cell and pass."""
+    src = getattr(w, "_evf_src", None)
+    if src is not None:
+        return (src, w.device, _EPOCH[0])
+    return (w.data_ptr(), w._version, w.device, _EPOCH[0])
+
+
 class _PackCache:
     """Packed matrix-core operands of one weight tensor, re-packed when the
-    parameter changes (key: storage pointer + in-place version counter)."""
+    parameter changes (_pack_tag)."""
 
     def __init__(self):
         self.store = {}
@@ -91,9 +102,7 @@ class _PackCache:
         cin = Ctot if cin is None else cin
         sfx = "_b3" if CONV_B3 else ""
         key = (transpose, cin_off, cin, sfx)
-        # (a weight-normalised weight is a fresh tensor per forward -- the allocator may hand out the same address again: its
-        #  identity is that of the (v, g) pair it was made from, see weight_norm())
-        tag = (w.data_ptr(), w._version, w.device, _EPOCH[0], getattr(w, "_evf_src", None))
+        tag = _pack_tag(w)
         hit = self.store.get(key)
         if hit is not None and hit[0] == tag:
             return hit[1]
@@ -126,6 +135,8 @@ def repack_all():
                 w = ent[2]() if ent[2] is not None else None
                 if w is None or key[3] != "_b3" or not w.is_contiguous() or w.dtype != torch.float32 or w.device != ent[1].device:
                     continue
+                if getattr(w, "_evf_src", None) is not None:
+                    continue  # (a weight-normalised weight of the LAST step: stale values; the next forward makes and packs a new one)
                 by_dev.setdefault(w.device, []).append((pc, key, w, ent[1], ent[2]))
     for dev, ents in by_dev.items():
         n = len(ents)
@@ -138,7 +149,7 @@ def repack_all():
         with torch.cuda.device(dev):
             _lib.call("evf_pack_conv2d_weights_b3_multi", wp, dp, (ctypes.c_int * len(meta))(*meta), n)
         for pc, key, w, dst, r in ents:
-            pc.store[key] = ((w.data_ptr(), w._version, w.device, _EPOCH[0], getattr(w, "_evf_src", None)), dst, r)
+            pc.store[key] = (_pack_tag(w), dst, r)
 
 
 _CACHES = {}
@@ -619,10 +630,7 @@ def cell_forward(cell, input_, prev_state, residual=0, slots=None):
                 prev_state = _lib.zeros((2,) + shp, dtype=torch.float32, device=input_.device)
             # the NORMALISED previous spikes feed the recurrent conv and the (detached) reset alike (:528-529, :539-546)
             prev_state = torch.stack([prev_state[0], group_norm1(prev_state[1], cell.norm_rec)])
-    if getattr(cell, "wnorm", False):  # (the normalised weights are new tensors every call: nothing cached may outlive them)
-        d = pack_cache(cell)
-        for name in ("ff", "rec", "ffT", "recT"):
-            d.pop(name, None)
+    # (norm="weight": the normalised weights are new tensors every call; their packs are keyed by the (v, g) pair: _pack_tag)
     wrec = conv_weight(cell.rec) if cell.recurrent else None
     out, new = _CellStep.apply(cell, input_, prev_state, res, slots, conv_weight(cell.ff), wrec, *p)
     # provenance: out = spikes (+ residual); the state's z slice is spikes
