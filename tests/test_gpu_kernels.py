@@ -611,3 +611,25 @@ def test_recorded_forward_cells_are_bit_identical(shape, hard):
     finally:
         L.evf_fwd_diag_select(-1)
     assert L.evf_fwd_diag_select(7) != 0
+
+
+def test_evf_memset_is_a_kernel_fill_of_any_size():
+    """evf_memset (what the library and the Python host use instead of hipMemsetAsync / zero_(): no memset nodes in a captured
+    step): every byte of [dst, dst + bytes) set, nothing outside touched -- sizes around the 4- and 16-byte steps of the fill
+    kernel, destinations that are 4- but not 16-byte aligned, the byte patterns the library uses (0x00, 0xFF)."""
+    L = _lib.load()
+    for value in (0x00, 0xFF, 0x5A):
+        for nbytes in (0, 1, 3, 4, 5, 15, 16, 17, 4095, 4096, 4099, (1 << 20) + 7, (9 << 20) + 2):
+            for off in (0, 4, 12):
+                buf = torch.full((nbytes + 64,), 0x33, dtype=torch.uint8, device=DEV)
+                rc = L.evf_memset(buf.data_ptr() + 16 + off, value, nbytes, _lib.stream_ptr())
+                assert rc == 0
+                got = buf.cpu().numpy()
+                lo, hi = 16 + off, 16 + off + nbytes
+                assert (got[:lo] == 0x33).all() and (got[hi:] == 0x33).all(), (value, nbytes, off)
+                assert (got[lo:hi] == value).all(), (value, nbytes, off)
+    assert L.evf_memset(None, 0, 16, _lib.stream_ptr()) == -22
+    z = _lib.zeros((3, 5, 7), device=DEV)
+    assert z.dtype == torch.float32 and float(z.abs().sum()) == 0.0
+    t = torch.ones(1000, device=DEV)
+    assert _lib.zero_(t[10:20]) is not None and float(t.sum()) == 990.0
