@@ -24,38 +24,57 @@ struct GfArgs {
 };
 
 #define GF_GROUPS 16
+#define GF_SLAB_BLOCKS 36  // blocks per weight tensor of the slab part: 9216 outputs / (64 threads x 4)
 #define GF_UNROLL 16  // independent row loads per thread and trip of the segment part (512 .. 1024 rows: 2 .. 4 trips)
-// blocks [0, 144 * nslabs): 64 outputs x 16 slab groups of tensor block / 144 (as k_reduce_wgrad_multi);
+// blocks [0, GF_SLAB_BLOCKS * nslabs): 256 outputs x 16 slab groups of tensor block / GF_SLAB_BLOCKS;
 // blocks behind them: 64 columns x 16 row groups of one segment of the small gradients, all rows
 __global__ __launch_bounds__(64 * GF_GROUPS) void k_grads_finalize(GfArgs a, int nslabs, int nslab, float* __restrict__ small,
                                                                    int clear_small, float* __restrict__ rows, int nrows, int ncols,
                                                                    const float* __restrict__ hrows, int nhrows, int nhcols, int hoff,
                                                                    int nseg) {
-  __shared__ float red[GF_GROUPS][64];
+  __shared__ float4 red4[GF_GROUPS][64];
+  float(*red)[64] = (float(*)[64])red4;  // (the segment part below: [GF_GROUPS][64] floats of the same array)
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int nb_slab = 144 * nslabs;
+  const int nb_slab = GF_SLAB_BLOCKS * nslabs;
   if ((int)blockIdx.x < nb_slab) {
-    const int t = blockIdx.x / 144, bx = blockIdx.x - 144 * t;
-    const int e = bx * 64 + tx;  // e = (tau*32 + ci)*32 + co;  9216 = 144 * 64
-    const float* __restrict__ p = a.slab[t] + e;
-    constexpr long N = 9 * C32 * C32;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    // A thread takes FOUR consecutive outputs (one float4 per slab row), a wave 1 KB of a row, the block's 16 waves 16 rows of the
+    // same 1 KB span: with one float per thread a wave's load was 256 B of a row and the next one 36 KB away -- the launch ran at
+    // 1.9 TB/s on its 80 MB.  Per output the same sums in the same order as before (rows ty, ty + 16, ... into four accumulators,
+    // (s0 + s1) + (s2 + s3), then the 16 row groups in index order): the same bits.
+    const int t = blockIdx.x / GF_SLAB_BLOCKS, bx = blockIdx.x - GF_SLAB_BLOCKS * t;
+    const int e4 = bx * 64 + tx;  // float4 index; e = 4 e4 + c = (tau*32 + ci)*32 + co
+    constexpr long N4 = 9 * C32 * C32 / 4;
+    const float4* __restrict__ p = (const float4*)a.slab[t] + e4;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s0 = z4, s1 = z4, s2 = z4, s3 = z4;
+    auto add4 = [](float4& d, const float4& v) { d.x += v.x, d.y += v.y, d.z += v.z, d.w += v.w; };
     int k = ty;
-    for (; k + 3 * GF_GROUPS < nslab; k += 4 * GF_GROUPS) {  // four independent loads in flight
-      s0 += p[(long)k * N];
-      s1 += p[(long)(k + GF_GROUPS) * N];
-      s2 += p[(long)(k + 2 * GF_GROUPS) * N];
-      s3 += p[(long)(k + 3 * GF_GROUPS) * N];
-    }
-    for (; k < nslab; k += GF_GROUPS) s0 += p[(long)k * N];
-    red[ty][tx] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (ty == 0) {
-      float s = 0.f;
+    for (; k + 15 * GF_GROUPS < nslab; k += 16 * GF_GROUPS) {  // sixteen loads in flight (256 slab rows: one trip)
+      float4 q[16];
 #pragma unroll
-      for (int g = 0; g < GF_GROUPS; ++g) s += red[g][tx];
+      for (int j = 0; j < 16; ++j) q[j] = p[(long)(k + j * GF_GROUPS) * N4];
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) add4(s0, q[j]), add4(s1, q[j + 1]), add4(s2, q[j + 2]), add4(s3, q[j + 3]);
+    }
+    for (; k + 3 * GF_GROUPS < nslab; k += 4 * GF_GROUPS) {
+      const float4 q0 = p[(long)k * N4], q1 = p[(long)(k + GF_GROUPS) * N4], q2 = p[(long)(k + 2 * GF_GROUPS) * N4],
+                   q3 = p[(long)(k + 3 * GF_GROUPS) * N4];
+      add4(s0, q0), add4(s1, q1), add4(s2, q2), add4(s3, q3);
+    }
+    for (; k < nslab; k += GF_GROUPS) add4(s0, p[(long)k * N4]);
+    red4[ty][tx] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                               (s0.w + s1.w) + (s2.w + s3.w));
+    __syncthreads();
+    if (ty < 4) {  // (wave c of the first four adds component c: 64 outputs each)
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < GF_GROUPS; ++g) {
+        const float4 v = red4[g][tx];
+        sum += ty == 0 ? v.x : (ty == 1 ? v.y : (ty == 2 ? v.z : v.w));
+      }
+      const int e = 4 * e4 + ty;
       const int co = e & 31, ci = (e >> 5) & 31, tau = e >> 10;
-      a.slab_dst[t][(co * C32 + ci) * 9 + tau] += s;
+      a.slab_dst[t][(co * C32 + ci) * 9 + tau] += sum;
     }
     return;
   }
@@ -137,7 +156,7 @@ extern "C" int evf_grads_finalize(const void* const* slabs, void* const* slab_ds
   }
   a.seg_blk0[32] = nb;
   for (int k = nseg; k < 32; ++k) a.seg_blk0[k] = nb;
-  hipLaunchKernelGGL(k_grads_finalize, dim3(144 * nslabs + nb), dim3(64 * GF_GROUPS), 0, EVF_STREAM(stream), a, nslabs, nslab, small,
+  hipLaunchKernelGGL(k_grads_finalize, dim3(GF_SLAB_BLOCKS * nslabs + nb), dim3(64 * GF_GROUPS), 0, EVF_STREAM(stream), a, nslabs, nslab, small,
                      clear_small, rows, nrows, ncols, head_rows, nhrows, nhcols, head_off, nseg);
   return evf_status();
 }
