@@ -567,7 +567,25 @@ __device__ __forceinline__ void fb_body(
 // EW = waves of team E: 4 (a 512-thread block, one wave of each team per SIMD; a thread takes a float4 per HALF unit, four
 // half units of loads in flight) or 8 (a 768-thread block: two E waves per SIMD hide each other's dependent chains -- with
 // one, team E needed 4.4 k cycles per unit against team M's 3.6 k (phase stamps); a thread takes a float4 per unit).
-template <bool REC, bool TOP, int EW, bool PLIF = false>
+// WIN (k_bwd_win_plif): ALL passes of a window of one feed-forward cell in one launch.  A block's iteration space is (unit, pass)
+// with the passes of a unit back to back, last pass first: dL/dv, dL/d(pt) and the potential of the pass before stay in REGISTERS
+// from one iteration to the next (the thread keeps its pixel and channel quad), the matrix team's accumulators run over passes and
+// units alike.  Per pixel and pass the kernel then reads dL/dz, v_prev (+ pt_prev, P) and writes dL/d(current) (+ dL/dP): 640 B
+// instead of the 1152 B of a one-pass PLIF cell.  Same arithmetic per element; sums of the weight gradient in another order.
+#define FB_WIN_MAX 16
+struct FbWin {
+  int np;  // passes; index s = 0 is the window's LAST pass (backward order)
+  const float4* gz[FB_WIN_MAX];   // dL/d(spikes) of pass s (NULL: none)
+  const float4* vo[FB_WIN_MAX];   // potential after the pass (read at s = 0 only: vo[s] = vp[s - 1])
+  const float4* vp[FB_WIN_MAX];   // potential before the pass (NULL: zero state)
+  const uint32_t* zp[FB_WIN_MAX]; // spike words before the pass (NULL: none)
+  const uint32_t* xT[FB_WIN_MAX]; // input spike planes of the pass
+  float4* gcur[FB_WIN_MAX];       // out: dL/d(current) of the pass
+  const float4* pp[FB_WIN_MAX];   // PLIF: trace before the pass (NULL: zero)
+  const float* P[FB_WIN_MAX];     // PLIF: pooled activity of the pass
+  float* gP[FB_WIN_MAX];          // out: dL/d(pooled activity) of the pass (raw)
+};
+template <bool REC, bool TOP, int EW, bool PLIF = false, bool WIN = false>
 __device__ __forceinline__ void fb_body_ws(
     const int bid, const int nblk_, const float4* __restrict__ g_z_out, const float4* __restrict__ g_z_out2,
     const float4* __restrict__ g_v_out, const float4* __restrict__ v_out, const float4* __restrict__ v_prev,
@@ -575,8 +593,9 @@ __device__ __forceinline__ void fb_body_ws(
     const float* __restrict__ leak, const float* __restrict__ thresh, int B, int H, int W, int nchunk, long nunits, float width,
     int accumulate, int nrows_total, float4* __restrict__ g_cur, uint2* __restrict__ g_split, float4* __restrict__ g_v_prev,
     float* __restrict__ g_leak, float* __restrict__ g_thresh, float* __restrict__ slab_ff, float* __restrict__ slab_rec, FbTop top,
-    int row_ld, const FbPlif pl = FbPlif{}) {
+    int row_ld, const FbPlif pl = FbPlif{}, const FbWin* wp = nullptr) {
   static_assert(!PLIF || EW == 8, "PLIF cells: whole-unit stages only");
+  static_assert(!WIN || (PLIF && !REC && !TOP && EW == 8), "window launches: feed-forward PLIF cells");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   unsigned short* s_b = (unsigned short*)smem_raw;           // [2][3][FB_CW*32] bf16 (region of FB_R0 bytes)
   uint32_t* s_px = (uint32_t*)(smem_raw + FB_R0);             // [2][3][32][FB_NW]
@@ -612,6 +631,8 @@ __device__ __forceinline__ void fb_body_ws(
   }
   const int nblk = nblk_;
   const int nu = (int)((nunits - (long)bid + nblk - 1) / nblk);
+  const int T = WIN ? wp->np : 1;  // passes per unit (WIN)
+  const int nit = nu * T;          // iterations of the block: (unit, pass), the passes of a unit back to back
   static_assert(FB_UNITS_MAX <= 64, "geometry table: one lane per unit of the block");
   static_assert(FB_NW == 4 && FB_CW == 64 && (EW == 4 || EW == 8), "team E: (half) units of 8 EW pixels, 384 plane words per unit");
   int g_b, g_y, g_x0;
@@ -644,6 +665,7 @@ __device__ __forceinline__ void fb_body_ws(
   // team E state
   float sl[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
   float slp[4] = {0, 0, 0, 0}, sap[4] = {0, 0, 0, 0};  // PLIF: sums for leak_pt / add_pt
+  float4 gvc = make_float4(0.f, 0.f, 0.f, 0.f), voc = gvc, gkc = gvc;  // WIN: dL/dv, potential, dL/d(pt) carried to the next iteration
   float dwa[4] = {0, 0, 0, 0}, dwb[4] = {0, 0, 0, 0}, dba = 0.f, dbb = 0.f;
   // team M state: taps t0 = 2 mw, t1 = 2 mw + 1, the ninth tap's K step mw
   f32x16 acc0 = {0}, acc1 = {0}, accz0 = {0}, accz1 = {0}, acc8 = {0}, accz8 = {0};
@@ -686,10 +708,35 @@ __device__ __forceinline__ void fb_body_ws(
     // stage 1: the global loads of half h of unit k (straight-line, unconditional, clamped: see fb_body)
     auto issue = [&](const int k, const int h, FbStage& s, FbStagePlif& sp) {
       int b, y, x0, cw;
-      geom(min(k, nu - 1), b, y, x0, cw);
+      int ku = k, ks = 0;  // unit of the block, pass (WIN)
+      if (WIN) {
+        const int kk = min(k, nit - 1);
+        ku = kk / T, ks = kk - ku * T;
+      }
+      geom(min(ku, nu - 1), b, y, x0, cw);
       const long pix0 = ((long)b * H + y) * W + x0;
       const int pc = min(8 * EW * h + pe, cw - 1);
       const long ge = (pix0 + pc) * 8 + cg;
+      if (WIN) {  // (per-pass pointers: scalar loads from the argument table; optional tensors from a valid dummy)
+        const float4* wvo = wp->vo[ks];
+        const float4 *wgz = wp->gz[ks], *wvp = wp->vp[ks], *wpp = wp->pp[ks];
+        const uint32_t* wzp = wp->zp[ks];
+        if (ks == 0) s.vo = wvo[ge];  // (block-uniform: later passes take the potential the previous iteration loaded as v_prev)
+        s.gz = (wgz ? wgz : wvo)[ge];
+        s.vp = (wvp ? wvp : wvo)[ge];
+        s.zw = (wzp ? wzp : wp->xT[ks])[wzp ? pix0 + pc : 0];
+        sp.pp = (wpp ? wpp : wvo)[ge];
+        sp.P = wp->P[ks][pix0 + pc];
+        const int tpl = min(et + ETHR * h, 3 * C32 * FB_NW - 1);
+        const int pl_wq = tpl % FB_NW, pl_c = (tpl / FB_NW) % C32, pl_dy = tpl / (FB_NW * C32);
+        const int yy = y + pl_dy - 1, xw = x0 / 32 - 1 + pl_wq;
+        const bool in = yy >= 0 && yy < H && xw >= 0 && xw < nW;
+        const long src = in ? (((long)b * H + yy) * C32 + pl_c) * nW + xw : 0;
+        s.px = wp->xT[ks][src];
+        s.pz = 0u;
+        s.pin = in ? 0xFFFFFFFFu : 0u;
+        return;
+      }
       s.vo = v_out[ge];
       if (TOP) {
         const long hw = (long)H * W, q = (long)y * W + x0 + pc;
@@ -721,11 +768,21 @@ __device__ __forceinline__ void fb_body_ws(
     // stage 2: neuron backward in registers, results to HBM, split g_cur + spike planes to LDS buffer `buf`
     auto commit = [&](const int k, const int h, const FbStage& s, const FbStagePlif& sp, const int buf) {
       int b, y, x0, cw;
-      geom(min(k, nu - 1), b, y, x0, cw);
+      int ku = k, ks = 0;
+      if (WIN) {
+        const int kk = min(k, nit - 1);
+        ku = kk / T, ks = kk - ku * T;
+      }
+      geom(min(ku, nu - 1), b, y, x0, cw);
       const long pix0 = ((long)b * H + y) * W + x0;
       unsigned short* sb = s_b + buf * (3 * FB_CW * C32);
       const int p = 8 * EW * h + pe;
-      const bool ok = p < cw && k < nu;
+      const bool ok = p < cw && k < nit;
+      // WIN: which of the pass's optional tensors exist (block-uniform scalars), where its outputs go
+      const bool w_gz = WIN && wp->gz[ks] != nullptr, w_vp = WIN && wp->vp[ks] != nullptr, w_zp = WIN && wp->zp[ks] != nullptr,
+                 w_pp = WIN && wp->pp[ks] != nullptr;
+      float4* const w_gcur = WIN ? wp->gcur[ks] : nullptr;
+      float* const w_gP = WIN ? wp->gP[ks] : nullptr;
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       float gp0 = 0.f, gp1 = 0.f;
       if (TOP) {
@@ -734,10 +791,10 @@ __device__ __forceinline__ void fb_body_ws(
       }
       const float4 gz4 = TOP ? make_float4(gp0 * pwa[0] + gp1 * pwb[0], gp0 * pwa[1] + gp1 * pwb[1], gp0 * pwa[2] + gp1 * pwb[2],
                                            gp0 * pwa[3] + gp1 * pwb[3])
-                             : (has_gz ? s.gz : z4);
+                             : ((WIN ? w_gz : has_gz) ? s.gz : z4);
       float4 gzb4 = z4;
-      if (!TOP) gzb4 = has_gz2 ? s.gz2 : z4;
-      const float4 gv4 = has_gv ? s.gv : z4, vp4 = has_vp ? s.vp : z4;
+      if (!TOP && !WIN) gzb4 = has_gz2 ? s.gz2 : z4;
+      const float4 gv4 = WIN ? (ks > 0 ? gvc : z4) : (has_gv ? s.gv : z4), vp4 = (WIN ? w_vp : has_vp) ? s.vp : z4;
       if (TOP && ok) {
         const uint32_t zo = s.zo >> (4 * cg);
 #pragma unroll
@@ -748,11 +805,12 @@ __device__ __forceinline__ void fb_body_ws(
         }
         if (cg == 0) dba += gp0, dbb += gp1;
       }
-      const float vo[4] = {s.vo.x, s.vo.y, s.vo.z, s.vo.w};
+      const float4 vo4 = (WIN && ks > 0) ? voc : s.vo;
+      const float vo[4] = {vo4.x, vo4.y, vo4.z, vo4.w};
       const float gz[4] = {!TOP ? gz4.x + gzb4.x : gz4.x, !TOP ? gz4.y + gzb4.y : gz4.y, !TOP ? gz4.z + gzb4.z : gz4.z,
                            !TOP ? gz4.w + gzb4.w : gz4.w};
       const float gvo[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, vp[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
-      const uint32_t zw = (has_zw ? s.zw : 0u) >> (4 * cg);
+      const uint32_t zw = ((WIN ? w_zp : has_zw) ? s.zw : 0u) >> (4 * cg);
       float gc[4], gp[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {  // autograd of spiking_submodules.py:103-126 / :523-551 (hard reset, arctan surrogate)
@@ -770,12 +828,19 @@ __device__ __forceinline__ void fb_body_ws(
         }
       }
       const long eo = pix0 * 8 + ETHR * h + et;  // = (pix0 + p) * 8 + cg
-      if (ok) {
+      if (WIN) {
+        gvc = make_float4(gp[0], gp[1], gp[2], gp[3]);
+        voc = vp4;
+        if (ok) {
+          w_gcur[eo] = make_float4(gc[0], gc[1], gc[2], gc[3]);
+          if (ks == T - 1 && g_v_prev) g_v_prev[eo] = gvc;  // (the gradient on the state entering the window, when wanted)
+        }
+      } else if (ok) {
         if (g_cur) g_cur[eo] = make_float4(gc[0], gc[1], gc[2], gc[3]);
         g_v_prev[eo] = make_float4(gp[0], gp[1], gp[2], gp[3]);
       }
       if (PLIF) {  // trace backward (the expressions of k_plif_trace_bwd, evf_network.hip: the same bits per element)
-        const float4 gk4 = has_gk ? sp.gk : z4, pp4 = has_pp ? sp.pp : z4;
+        const float4 gk4 = WIN ? (ks > 0 ? gkc : z4) : (has_gk ? sp.gk : z4), pp4 = (WIN ? w_pp : has_pp) ? sp.pp : z4;
         const float gk[4] = {gk4.x, gk4.y, gk4.z, gk4.w}, pp[4] = {pp4.x, pp4.y, pp4.z, pp4.w};
         const float Pv = sp.P;
         float gq[4], gPp = 0.f;
@@ -790,11 +855,12 @@ __device__ __forceinline__ void fb_body_ws(
             sap[c] -= gc[c] * po;
           }
         }
-        if (ok) pl.g_pt_prev[eo] = make_float4(gq[0], gq[1], gq[2], gq[3]);
+        if (WIN) gkc = make_float4(gq[0], gq[1], gq[2], gq[3]);
+        if (ok && (!WIN || (ks == T - 1 && pl.g_pt_prev))) pl.g_pt_prev[eo] = make_float4(gq[0], gq[1], gq[2], gq[3]);
         gPp += __shfl_xor(gPp, 1, 64);  // the 8 lanes of a pixel hold its 32 channels
         gPp += __shfl_xor(gPp, 2, 64);
         gPp += __shfl_xor(gPp, 4, 64);
-        if (ok && cg == 0) pl.g_P[pix0 + p] = gPp;
+        if (ok && cg == 0) (WIN ? w_gP : pl.g_P)[pix0 + p] = gPp;
       }
       // exact split g = hi + mid + lo in B-operand order: 16-byte chunk (pixel group G = p >> 3, channel j) = the 8 pixels of
       // the group, chunk index G * 32 + (j ^ (j >> 4)).  A lane holds 4 channels of ONE pixel; as 12 two-byte stores a wave
@@ -878,7 +944,7 @@ __device__ __forceinline__ void fb_body_ws(
       __syncthreads();  // unit 0 staged
       FBW_STAMP();
 #pragma unroll 1
-      for (int k = 0; k < nu; k += 2) {
+      for (int k = 0; k < nit; k += 2) {
         issue(k + 2, 0, s_new, p_new);
         commit(k + 1, 0, s_nxt, p_nxt, 1);
         FBW_STAMP();
@@ -1048,7 +1114,7 @@ __device__ __forceinline__ void fb_body_ws(
     __syncthreads();  // unit 0 staged
     FBW_STAMP();
 #pragma unroll 1
-    for (int k = 0; k < nu; k += 2) {
+    for (int k = 0; k < nit; k += 2) {
       mfma_unit(0);
       FBW_STAMP();
       __syncthreads();
@@ -1299,6 +1365,14 @@ __global__ __launch_bounds__(768) void k_bwd_diag_ws_plif(FbJobs jobs, int B, in
     fb_body_ws<false, false, 8, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh, B, H, W,
                                       nchunk, nunits, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev, J.g_leak,
                                       J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld, J.pl);
+}
+
+// All passes of a window of ONE feed-forward PLIF cell (fb_body_ws<.., WIN>): a launch of its own
+__global__ __launch_bounds__(768) void k_bwd_win_plif(FbJob J, FbWin Wn, int B, int H, int W, int nchunk, long nunits, int row_ld,
+                                                      int nrows_total) {
+  fb_body_ws<false, false, 8, true, true>((int)blockIdx.x, (int)gridDim.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                          nullptr, J.leak, J.thresh, B, H, W, nchunk, nunits, J.width, J.accumulate, nrows_total, nullptr,
+                                          nullptr, J.g_v_prev, J.g_leak, J.g_thresh, J.slab_ff, nullptr, J.top, row_ld, J.pl, &Wn);
 }
 
 static long fb_units(int B, int H, int W) { return (long)B * H * ((W + FB_CW - 1) / FB_CW); }
@@ -1806,4 +1880,49 @@ extern "C" int evf_plif_bwd_wgrad_top(const float* flow, const float* g_flow, co
   const FbPlif pl{(const float4*)g_pt_carry, (const float4*)pt_prev, P, leak_pt, add_pt, (float4*)g_pt_prev, g_P_raw, g_leak_pt, g_add_pt};
   return fb_launch(nullptr, nullptr, &top, g_v_out, v_out, v_prev, z_prev, xT, nullptr, leak, thresh, B, H, W, hard_reset, surrogate,
                    act_width, g_cur, g_split, g_v_prev, g_leak, g_thresh, slab_ff, nullptr, accumulate, stream, &pl);
+}
+
+// A feed-forward PLIF hidden cell, ALL passes of a window in one launch (k_bwd_win_plif): the arrays hold np device pointers, index 0
+// = the window's LAST pass (backward order).  Per pass: g_z (dL/d(spikes), may be NULL), v_out / v_prev (v_prev NULL: zero state;
+// v_out[s] must be v_prev[s - 1]: only v_out[0] is read), z_prev (spike words before the pass, NULL: none), xT (input spike planes),
+// pt_prev (NULL: zero), P; out per pass: g_cur, g_P_raw.  dL/dv and dL/d(pt) are carried in registers from pass to pass and start at
+// zero behind the window's last pass; g_v_prev / g_pt_prev (may be NULL): the gradients on the state entering the window.  Slab and
+// per-channel sums as evf_plif_bwd_wgrad2 (accumulate: bit 0 = add to the slab, bits 8.. = pitch of the per-block rows).
+extern "C" int evf_plif_bwd_wgrad_window(int np, const void* const* g_z, const void* const* v_out, const void* const* v_prev,
+                                         const void* const* z_prev, const void* const* xT, void* const* g_cur,
+                                         const void* const* pt_prev, const void* const* P, void* const* g_P_raw, const float* leak,
+                                         const float* thresh, const float* leak_pt, const float* add_pt, int B, int H, int W,
+                                         float act_width, float* g_v_prev, float* g_pt_prev, float* g_leak, float* g_thresh,
+                                         float* g_leak_pt, float* g_add_pt, float* slab_ff, int accumulate, void* stream) {
+  if (np < 1 || np > FB_WIN_MAX || !g_z || !v_out || !v_prev || !z_prev || !xT || !g_cur || !pt_prev || !P || !g_P_raw || !leak ||
+      !thresh || !leak_pt || !add_pt || !g_leak || !g_thresh || !g_leak_pt || !g_add_pt || !slab_ff || B <= 0 || H <= 0 || W <= 0)
+    return EVF_EINVAL;
+  FbWin Wn;
+  Wn.np = np;
+  for (int s = 0; s < FB_WIN_MAX; ++s) {
+    const int q = s < np ? s : 0;
+    if (!v_out[q] || !xT[q] || !g_cur[q] || !P[q] || !g_P_raw[q]) return EVF_EINVAL;
+    Wn.gz[s] = (const float4*)g_z[q], Wn.vo[s] = (const float4*)v_out[q], Wn.vp[s] = (const float4*)v_prev[q];
+    Wn.zp[s] = (const uint32_t*)z_prev[q], Wn.xT[s] = (const uint32_t*)xT[q], Wn.gcur[s] = (float4*)g_cur[q];
+    Wn.pp[s] = (const float4*)pt_prev[q], Wn.P[s] = (const float*)P[q], Wn.gP[s] = (float*)g_P_raw[q];
+  }
+  const int row_ld = accumulate >> 8;
+  const long nunits = fb_units(B, H, W);
+  const int nchunk = (W + FB_CW - 1) / FB_CW;
+  FbJob J{};
+  J.leak = leak, J.thresh = thresh, J.g_v_prev = (float4*)g_v_prev, J.g_leak = g_leak, J.g_thresh = g_thresh, J.slab_ff = slab_ff;
+  J.width = act_width, J.accumulate = accumulate & 1, J.kind = 3;
+  J.pl = FbPlif{nullptr, nullptr, nullptr, leak_pt, add_pt, (float4*)g_pt_prev, nullptr, g_leak_pt, g_add_pt};
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_bwd_win_plif, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    attr = true;
+  }
+  // blocks: as a one-cell launch whose units cost np times as much (whole rounds of one block per CU)
+  const int nblk = fb_blocks_per_cell(nunits, 1, 8 * np);
+  evf_prof_mark(1, 0, stream);
+  hipLaunchKernelGGL(k_bwd_win_plif, dim3(nblk), dim3(768), FB_LDS, EVF_STREAM(stream), J, Wn, B, H, W, nchunk, nunits, row_ld,
+                     fb_rows(nunits));
+  evf_prof_mark(1, 1, stream);
+  return evf_status();
 }

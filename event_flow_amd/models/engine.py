@@ -53,6 +53,10 @@ PLIF_BOX_IN_DGRAD = os.environ.get("EVF_PLIF_BOX", "dgrad") != "kernel"
 # PLIF hidden cells: the trace backward inside the fused backward's streaming team (evf_plif_bwd_wgrad2 / _top); 0: evf_plif_trace_bwd
 # as a pass of its own behind evf_lif_bwd_wgrad2 (A/B, tests)
 PLIF_TRACE_FUSED = os.environ.get("EVF_PLIF_TRACE_FUSED", "1") != "0"
+# PLIF windows backward LAYER by layer: a feed-forward hidden layer's passes in ONE launch with dL/dv, dL/d(pt) and the potential in
+# registers (evf_plif_bwd_wgrad_window: 640 instead of 1152 bytes per pixel and pass); recurrent layers and the layer under the
+# prediction head pass by pass, the head layer's window last.  0: pass by pass (every cell a launch)
+PLIF_LAYER_MAJOR = os.environ.get("EVF_PLIF_LAYER_MAJOR", "1") != "0"
 # window gradients -> the flat gradient buffer in one launch (evf_grads_finalize); 0: row sums, slab reduction, segment add one by one
 FUSED_TAIL = os.environ.get("EVF_FUSED_TAIL", "1") != "0"
 PARAM_ROWS = os.environ.get("EVF_PARAM_ROWS", "1") != "0"  # per-channel gradients through per-block rows (0: atomics)  # ff + rec input gradients of a recurrent cell in one launch
@@ -84,6 +88,7 @@ class _Window:
         self.gsl = [None] * n_  # ... or per-layer split planes [3,B,H,W,32] bf16 (SPLIT_DGRAD)
         self.gz0 = []           # dL/d(spikes) of the head layer, one buffer per backward pass (HEAD_WIN)
         self.bwd_k = 0          # backward passes of this window so far
+        self.lm = []            # PLIF_LAYER_MAJOR: (tape, dL/dflow, is_first) of the passes whose backward waits for the window's first
         self.slab_init = {}
         self.token = eng._token(dev)  # (a leaf whose value is never read: only its autograd edge chains the passes)
         self.n_passes = 0
@@ -111,8 +116,15 @@ class _FireNetPass(torch.autograd.Function):
     def backward(ctx, g_flow, g_token):
         eng, win = ctx.eng, ctx.win
         eng.flush_forward()
-        eng._backward_pass(win, ctx.tape, g_flow, ctx.is_first)
-        win.bwd_k += 1
+        if eng._lm_wanted(win, ctx.tape, g_flow):
+            # layer-major backward of the window: nothing runs until the window's first pass has handed in its dL/dflow
+            win.lm.append((ctx.tape, g_flow, ctx.is_first))
+            if ctx.is_first:
+                eng._backward_window_lm(win)
+        else:
+            eng._lm_replay(win)  # (passes that waited for a layer-major backward this pass cannot join: pass by pass, in order)
+            eng._backward_pass(win, ctx.tape, g_flow, ctx.is_first)
+            win.bwd_k += 1
         if ctx.is_first:
             eng.flush_backward()  # (the recorded cells of all passes, diagonal by diagonal)
         ctx.tape = None  # (while a backward recording is open the engine holds the tape: _backward_pass, flush_backward)
@@ -537,6 +549,134 @@ class FireNetEngine:
         if key not in self._slabs or self._slabs[key].shape[0] != nslab or self._slabs[key].device != dev:
             self._slabs[key] = _f32((nslab, 9 * C * C), dev)
         return self._slabs[key]
+
+    # ---- PLIF: backward of a window layer by layer ---------------------------------------------------------------------------
+    def _lm_wanted(self, win, tape, g_flow):
+        if not (PLIF_LAYER_MAJOR and self.kind == "plif" and self.precision == "bf16x3" and g_flow is not None):
+            return False
+        n = len(self.cells)
+        return (HEAD_WIN and PLIF_TRACE_FUSED and PLIF_BOX_IN_DGRAD and TOP_FUSED and F32_DGRAD and PAIR_DGRAD and PARAM_ROWS
+                and self.__dict__.get("_bdefer_on", False) and win.rows is not None and n > 2 and not self.cells[n - 1].recurrent
+                and tape["x_in"].shape[1] == 2 and len(win.lm) < 16 and win.bwd_k == 0
+                and all(c.hard_reset and c.activation == "arctanspike" for c in self.cells))
+
+    def _lm_replay(self, win):
+        stash, win.lm = win.lm, []
+        for tape, g_flow, is_first in stash:
+            self._backward_pass(win, tape, g_flow, is_first)
+            win.bwd_k += 1
+
+    def _lm_buf(self, key, shape, dev):
+        """Persistent scratch of the layer-major backward (per-pass gradient maps: reused by every window of this shape)."""
+        d = self.__dict__.setdefault("_lm_bufs", {})
+        k = (key, tuple(shape), str(dev))
+        if k not in d:
+            d[k] = _f32(shape, dev)
+        return d[k]
+
+    def _backward_window_lm(self, win):
+        """The backward of all passes of a PLIF window, layer by layer from the top (reference: autograd of train_flow.py:141-154
+        over models/model.py:255-265 -- the same cells, another order: cell (l, t) needs (l + 1, t) and (l, t + 1) only).  Index s =
+        0 .. T-1 is the backward order (s = 0: the window's last pass)."""
+        stash, win.lm = win.lm, []
+        B, H, W = win.shape
+        dev, n, T = win.dev, len(self.cells), len(stash)
+        tapes = [st[0] for st in stash]
+        gflows = [st[1].float().contiguous() for st in stash]
+        firsts = [st[2] for st in stash]
+        L = _lib.load()
+        nsl = L.evf_lif_bwd_wgrad_slabs(B, H, W)
+        shp = (B, H, W, C)
+        gz = lambda i, s_: self._lm_buf(("gz", i, s_), shp, dev)  # noqa: E731  dL/d(spikes) of layer i at pass s
+        gcur = [self._lm_buf(("gcur", s_), shp, dev) for s_ in range(T)]  # dL/d(current) of the layer in work, per pass
+        gPs = [self._lm_buf(("gP", s_), (B, H, W), dev) for s_ in range(T)]
+        arr = lambda ts: (ctypes.c_void_p * T)(*[_lib.ptr(t) for t in ts])  # noqa: E731
+        rowp = lambda name: _lib.ptr(self._rowed(win, name)[0])  # noqa: E731
+        row_ld = win.rows.shape[1]
+        for i in range(n - 1, 0, -1):
+            c = self.cells[i]
+            lay = [tp["layers"][i] for tp in tapes]  # (in_bits, v_prev, z_prev, v_out, z_out, in_bitsT, zT_prev, pt_prev, pt_out, P)
+            kf, kr = (i, "ff"), (i, "rec")
+            gv_i, gpt_i = self._lm_buf(("gv", i), shp, dev), self._lm_buf(("gpt", i), shp, dev)
+            leak, thr = _lib.ptr(self._flat[f"{i}.leak"]), _lib.ptr(self._flat[f"{i}.thresh"])
+            lpt, apt = _lib.ptr(self._flat[f"{i}.leak_pt"]), _lib.ptr(self._flat[f"{i}.add_pt"])
+            width = self._act_width(i)
+            if i == n - 1:  # under the prediction head (its backward inside): pass by pass, the carries through memory
+                for s_ in range(T):
+                    in_bits, v_prev, z_prev, v_out, z_out, in_bitsT, _zT, pt_prev, _pto, P_sav = lay[s_]
+                    _lib.call("evf_plif_bwd_wgrad_top", _lib.ptr(tapes[s_]["flow"]), _lib.ptr(gflows[s_]), _lib.ptr(self._flat["pred.w"]),
+                              _lib.ptr(z_out), rowp("pred.w"), rowp("pred.b"), _lib.ptr(gv_i) if s_ else None, _lib.ptr(v_out),
+                              _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(in_bitsT), leak, thr, B, H, W, 1, SURROGATE_ID[c.activation],
+                              width, _lib.ptr(gcur[s_]), None, _lib.ptr(gv_i), rowp(f"{i}.leak"), rowp(f"{i}.thresh"),
+                              _lib.ptr(self._slab(kf, nsl, dev)), (1 if win.slab_init.get(kf) else 0) | (row_ld << 8),
+                              _lib.ptr(gpt_i) if s_ else None, _lib.ptr(pt_prev), _lib.ptr(P_sav), lpt, apt, _lib.ptr(gpt_i),
+                              _lib.ptr(gPs[s_]), rowp(f"{i}.leak_pt"), rowp(f"{i}.add_pt"))
+                    win.slab_init[kf] = True
+            elif not c.recurrent:  # feed-forward: all passes in one launch, the carries in registers
+                _lib.call("evf_plif_bwd_wgrad_window", T, arr([gz(i, s_) for s_ in range(T)]), arr([l_[3] for l_ in lay]),
+                          arr([l_[1] for l_ in lay]), arr([l_[2] for l_ in lay]), arr([l_[5] for l_ in lay]), arr(gcur),
+                          arr([l_[7] for l_ in lay]), arr([l_[9] for l_ in lay]), arr(gPs), leak, thr, lpt, apt, B, H, W, width, None, None,
+                          rowp(f"{i}.leak"), rowp(f"{i}.thresh"), rowp(f"{i}.leak_pt"), rowp(f"{i}.add_pt"),
+                          _lib.ptr(self._slab(kf, nsl, dev)), (1 if win.slab_init.get(kf) else 0) | (row_ld << 8))
+                win.slab_init[kf] = True
+            if not c.recurrent:  # input gradients of all passes (the pooling's adjoint of dL/dP inside: accumulate | 2)
+                for s_ in range(T):
+                    _lib.call("evf_conv_dgrad_b3_f32", _lib.ptr(gcur[s_]), _lib.ptr(self._packed[(i, "ff", "b3t")]), _lib.ptr(gz(i - 1, s_)),
+                              2, B, H, W, _lib.ptr(gPs[s_]), _lib.ptr(lay[s_][0]))
+                continue
+            # recurrent: pass by pass (the cell reads its own recurrent input gradient of the pass after)
+            gzr_i = self._lm_buf(("gzr", i), shp, dev)
+            has_gzr = False
+            for s_ in range(T):
+                in_bits, v_prev, z_prev, v_out, _zo, in_bitsT, zT_prev, pt_prev, _pto, P_sav = lay[s_]
+                use_rec = z_prev is not None
+                acc = 1 if win.slab_init.get(kf) else 0
+                if use_rec and bool(win.slab_init.get(kr)) != bool(acc):
+                    _lib.zero_(self._slab(kr, nsl, dev))  # (first recurrent contribution later than the feed-forward one)
+                _lib.call("evf_plif_bwd_wgrad2", _lib.ptr(gz(i, s_)), _lib.ptr(gzr_i) if has_gzr else None, _lib.ptr(gv_i) if s_ else None,
+                          _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None,
+                          leak, thr, B, H, W, 1, SURROGATE_ID[c.activation], width, _lib.ptr(gcur[s_]), None, _lib.ptr(gv_i),
+                          rowp(f"{i}.leak"), rowp(f"{i}.thresh"), _lib.ptr(self._slab(kf, nsl, dev)),
+                          _lib.ptr(self._slab(kr, nsl, dev)) if use_rec else None, acc | (row_ld << 8),
+                          _lib.ptr(gpt_i) if s_ else None, _lib.ptr(pt_prev), _lib.ptr(P_sav), lpt, apt, _lib.ptr(gpt_i), _lib.ptr(gPs[s_]),
+                          rowp(f"{i}.leak_pt"), rowp(f"{i}.add_pt"))
+                win.slab_init[kf] = True
+                if use_rec:
+                    win.slab_init[kr] = True
+                rec_grad = use_rec and not firsts[s_]
+                if rec_grad:
+                    _lib.call("evf_conv_dgrad_b3_f32_pair", _lib.ptr(gcur[s_]), _lib.ptr(self._packed[(i, "ff", "b3t")]),
+                              _lib.ptr(gz(i - 1, s_)), 2, _lib.ptr(self._packed[(i, "rec", "b3t")]), _lib.ptr(gzr_i), B, H, W,
+                              _lib.ptr(gPs[s_]), _lib.ptr(in_bits))
+                else:
+                    _lib.call("evf_conv_dgrad_b3_f32", _lib.ptr(gcur[s_]), _lib.ptr(self._packed[(i, "ff", "b3t")]), _lib.ptr(gz(i - 1, s_)),
+                              2, B, H, W, _lib.ptr(gPs[s_]), _lib.ptr(in_bits))
+                has_gzr = rec_grad
+        # head layer: its passes recorded, one launch at the flush (k_head_bwd_win<.., PLIF>)
+        c = self.cells[0]
+        nslh = L.evf_head_lif_bwd_wgrad_slabs(B, H, W)
+        key = (0, "ff")
+        if key not in self._slabs or self._slabs[key].shape != (nslh, C * 18) or self._slabs[key].device != dev:
+            self._slabs[key] = _f32((nslh, C * 18), dev)
+        gv0, gpt0 = self._lm_buf(("gv", 0), shp, dev), self._lm_buf(("gpt", 0), shp, dev)
+        self._bdefer_cur = None
+        self.__dict__.setdefault("_bdefer_keep", []).extend((tp, None, None) for tp in tapes)
+        self._bdefer_slot(win, 0)
+        if _lib.raw("evf_bwd_defer_hold_heads", 1) != 0:
+            raise _lib.EvflowError("evf_bwd_defer_hold_heads failed")
+        for s_ in range(T):
+            _in, v_prev, z_prev, v_out, _zo, _inT, _zT, pt_prev, _pto, P_sav = tapes[s_]["layers"][0]
+            if _lib.raw("evf_bwd_defer_slot", s_) != 0:
+                raise _lib.EvflowError("evf_bwd_defer_slot failed")
+            _lib.call("evf_head_plif_bwd_wgrad", _lib.ptr(gz(0, s_)), _lib.ptr(gv0) if s_ else None, _lib.ptr(v_out), _lib.ptr(v_prev),
+                      _lib.ptr(z_prev), _lib.ptr(tapes[s_]["x_in"]), _lib.ptr(self._flat["0.leak"]), _lib.ptr(self._flat["0.thresh"]), B, 2, H, W,
+                      1, SURROGATE_ID[c.activation], self._act_width(0), _lib.ptr(gv0), rowp("0.leak"), rowp("0.thresh"),
+                      _lib.ptr(self._slabs[key]), (1 if win.slab_init.get(key) else 0) | (row_ld << 8), _lib.ptr(gpt0) if s_ else None,
+                      _lib.ptr(pt_prev), _lib.ptr(P_sav), _lib.ptr(self._flat["0.leak_pt"]), _lib.ptr(self._flat["0.add_pt"]), _lib.ptr(gpt0),
+                      rowp("0.leak_pt"), rowp("0.add_pt"))
+            win.slab_init[key] = True
+        win.bwd_k += T
+        # (the caller -- _FireNetPass.backward of the window's first pass -- flushes the recording and finalizes)
 
     def _backward_pass(self, win, tape, g_flow, is_first):
         B, H, W = win.shape

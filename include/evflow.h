@@ -401,6 +401,19 @@ int evf_plif_bwd_wgrad2(const float* g_z_out, const float* g_z_out2, const float
                         float* slab_ff, float* slab_rec, int accumulate, const float* g_pt_carry, const float* pt_prev,
                         const float* P, const float* leak_pt, const float* add_pt, float* g_pt_prev, float* g_P_raw,
                         float* g_leak_pt, float* g_add_pt, void* stream);
+/* A FEED-FORWARD PLIF hidden cell, all passes of a window in ONE launch (k_bwd_win_plif): what np calls of evf_plif_bwd_wgrad2
+ * compute, with dL/dv and dL/d(pt) carried in registers from pass to pass and every potential read once -- 640 instead of 1152
+ * bytes per pixel and pass.  Host arrays of np <= 16 device pointers, index 0 = the window's LAST pass (backward order); per pass:
+ * g_z (may be NULL), v_out (only v_out[0] is read: v_out[s] = v_prev[s - 1]), v_prev (NULL: zero state), z_prev (NULL: none), xT,
+ * pt_prev (NULL: zero), P; outputs per pass: g_cur, g_P_raw.  The carries start at zero behind the last pass; g_v_prev /
+ * g_pt_prev (may be NULL) receive the gradients on the state entering the window.  Same arithmetic per element as the one-pass
+ * form (bit-identical g_cur / g_P_raw / carries); slab and per-channel sums in another order.  Default neuron only. */
+int evf_plif_bwd_wgrad_window(int np, const void* const* g_z, const void* const* v_out, const void* const* v_prev,
+                              const void* const* z_prev, const void* const* xT, void* const* g_cur,
+                              const void* const* pt_prev, const void* const* P, void* const* g_P_raw, const float* leak,
+                              const float* thresh, const float* leak_pt, const float* add_pt, int B, int H, int W,
+                              float act_width, float* g_v_prev, float* g_pt_prev, float* g_leak, float* g_thresh,
+                              float* g_leak_pt, float* g_add_pt, float* slab_ff, int accumulate, void* stream);
 int evf_plif_bwd_wgrad_top(const float* flow, const float* g_flow, const float* pred_w, const uint32_t* z_out,
                            float* d_pred_w, float* d_pred_b, const float* g_v_out, const float* v_out,
                            const float* v_prev, const uint32_t* z_prev, const uint32_t* xT, const float* leak,

@@ -613,6 +613,68 @@ def test_recorded_forward_cells_are_bit_identical(shape, hard):
     assert L.evf_fwd_diag_select(7) != 0
 
 
+@pytest.mark.parametrize("shape", [(8, 128, 128), (2, 33, 70), (4, 260, 346)])
+def test_plif_hidden_cell_backward_of_a_window_in_one_launch(shape):
+    """evf_plif_bwd_wgrad_window (all passes of a window of a feed-forward PLIF hidden cell in one launch: dL/dv, dL/d(pt) and the
+    potential carried in registers) against one evf_plif_bwd_wgrad2 launch per pass with the carries through memory: dL/d(current)
+    and dL/d(pooled activity) of every pass and the gradients on the window's entry state bit for bit; the weight-gradient slab and
+    the per-channel sums to round-off.  First pass of the window without previous state, one pass without dL/d(spikes)."""
+    import ctypes
+
+    B, H, W = shape
+    npass = 6
+    torch.manual_seed(31)
+    L = _lib.load()
+    nsl = max(L.evf_lif_bwd_wgrad_slabs(B, H, W), 512)
+    row_ld = 160
+    leak, thresh = _f(32, scale=0.3), _f(32, scale=0.1) + 0.4
+    lpt, apt = _f(32, scale=0.5) - 1.0, _f(32, scale=0.5) - 2.0
+    vs = [None] + [_f(B, H, W, C, scale=0.6) for _ in range(npass)]        # vs[t]: potential before pass t; vs[t + 1]: after
+    pts = [None] + [_f(B, H, W, C, scale=0.3).abs() for _ in range(npass - 1)]  # pts[t]: trace before pass t
+    zs = [None] + [_bits(B, H, W) for _ in range(npass - 1)]
+    xT = [_planes(_bits(B, H, W)) for _ in range(npass)]
+    Ps = [_f(B, H, W, scale=0.2).abs() for _ in range(npass)]
+    gzs = [_f(B, H, W, C, scale=0.2) for _ in range(npass)]
+    gzs[2] = None
+
+    def outs():
+        return {"gcur": [torch.full((B, H, W, C), 3.0, device=DEV) for _ in range(npass)],
+                "gP": [torch.full((B, H, W), 3.0, device=DEV) for _ in range(npass)],
+                "gv": torch.full((B, H, W, C), 3.0, device=DEV), "gpt": torch.full((B, H, W, C), 3.0, device=DEV),
+                "rows": torch.zeros(nsl, row_ld, device=DEV), "slab": torch.full((nsl, 9216), 5.0, device=DEV)}
+
+    def per_pass():
+        o = outs()
+        for k in range(npass):  # backward pass k = forward pass t
+            t = npass - 1 - k
+            _lib.call("evf_plif_bwd_wgrad2", P(gzs[t]), None, P(o["gv"]) if k else None, P(vs[t + 1]), P(vs[t]), P(zs[t]), P(xT[t]), None,
+                      P(leak), P(thresh), B, H, W, 1, 0, 10.0, P(o["gcur"][t]), None, P(o["gv"]), P(o["rows"][:, :32]), P(o["rows"][:, 32:]),
+                      P(o["slab"]), None, (1 if k else 0) | (row_ld << 8), P(o["gpt"]) if k else None, P(pts[t]), P(Ps[t]), P(lpt), P(apt),
+                      P(o["gpt"]), P(o["gP"][t]), P(o["rows"][:, 64:]), P(o["rows"][:, 96:]))
+        return o
+
+    def window():
+        o = outs()
+        order = list(range(npass - 1, -1, -1))  # index 0 = the last pass
+        arr = lambda ts: (ctypes.c_void_p * npass)(*[P(x) for x in ts])  # noqa: E731
+        _lib.call("evf_plif_bwd_wgrad_window", npass, arr([gzs[t] for t in order]), arr([vs[t + 1] for t in order]),
+                  arr([vs[t] for t in order]), arr([zs[t] for t in order]), arr([xT[t] for t in order]), arr([o["gcur"][t] for t in order]),
+                  arr([pts[t] for t in order]), arr([Ps[t] for t in order]), arr([o["gP"][t] for t in order]), P(leak), P(thresh), P(lpt),
+                  P(apt), B, H, W, 10.0, P(o["gv"]), P(o["gpt"]), P(o["rows"][:, :32]), P(o["rows"][:, 32:]), P(o["rows"][:, 64:]),
+                  P(o["rows"][:, 96:]), P(o["slab"]), 0 | (row_ld << 8))
+        return o
+
+    ref, got = per_pass(), window()
+    torch.cuda.synchronize()
+    for t in range(npass):
+        assert torch.equal(ref["gcur"][t], got["gcur"][t]), ("g_cur", t)
+        assert torch.equal(ref["gP"][t], got["gP"][t]), ("g_P", t)
+    assert torch.equal(ref["gv"], got["gv"]) and torch.equal(ref["gpt"], got["gpt"])
+    assert float(ref["gpt"].abs().max()) > 0 and float(ref["rows"][:, 64:128].sum(0).abs().min()) > 0
+    for name in ("slab", "rows"):
+        assert _rel(got[name].sum(0), ref[name].sum(0)) < 2e-5, (name, _rel(got[name].sum(0), ref[name].sum(0)))
+
+
 def test_evf_memset_is_a_kernel_fill_of_any_size():
     """evf_memset (what the library and the Python host use instead of hipMemsetAsync / zero_(): no memset nodes in a captured
     step): every byte of [dst, dst + bytes) set, nothing outside touched -- sizes around the 4- and 16-byte steps of the fill

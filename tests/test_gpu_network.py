@@ -1164,16 +1164,24 @@ def test_plif_cells_recorded_on_diagonals_are_bit_identical(monkeypatch):
         assert np.array_equal(a, b)
     assert max(float(np.abs(s).max()) for s in s1) > 0  # (the states are not trivially zero)
 
-    def run(defer):
+    grads = {}
+
+    def run(defer, tag=None):
         monkeypatch.setattr(htrain, "DEFER_FORWARD", defer)
-        monkeypatch.setattr(htrain, "DEFER_BACKWARD", defer)  # (PLIF: the head layer's backward cells of the window in one launch)
+        monkeypatch.setattr(htrain, "DEFER_BACKWARD", defer)  # (PLIF: the backward of the window layer by layer, see below)
         model = build_from_golden(g, fix="g7_pliffirenet_train")
         model.train()
         lossf = hloss.EventWarping(loss_cfg(H, W), DEV)
-        opt = FlatAdam(model, lr=2e-4, clip=100.0)
+        opt = FlatAdam(model, lr=2e-4, clip=100.0, device_step=False)
         opt.zero_grad()
+        seen = []
+        if tag is not None:  # the gradient as the window's backward leaves it (before clip + Adam consume it)
+            real_step = opt.step
+            opt.step = lambda *a_, **k_: (seen.append(opt.flat_grad.detach().clone()), real_step(*a_, **k_))[1]
         loss = htrain.train_window(model, lossf, opt, passes_from_golden(g))
         torch.cuda.synchronize()
+        if tag is not None:
+            grads[tag] = (seen[0], "_lm_bufs" in model._engine.__dict__)
         return float(loss), opt.grad_norm()
 
     (l0, n0), (l1, n1) = run(False), run(True)
@@ -1187,6 +1195,19 @@ def test_plif_cells_recorded_on_diagonals_are_bit_identical(monkeypatch):
     l2, n2 = run(True)
     np.testing.assert_allclose(l2, l1, rtol=1e-6)
     np.testing.assert_allclose(n2, n1, rtol=1e-6)
+    # the backward of the window LAYER by layer (feed-forward hidden layers: all passes in one launch with the carries in registers,
+    # evf_plif_bwd_wgrad_window) against pass by pass: the same cells in another order -- the whole gradient vector to round-off
+    from event_flow_amd.models import engine as heng2
+
+    monkeypatch.setattr(heng2, "PLIF_BOX_IN_DGRAD", True)
+    run(True, "lm")
+    monkeypatch.setattr(heng2, "PLIF_LAYER_MAJOR", False)
+    l4, n4 = run(True, "pp")
+    monkeypatch.setattr(heng2, "PLIF_LAYER_MAJOR", True)
+    assert grads["lm"][1] and not grads["pp"][1]  # (the layer-major path did run / did not run)
+    np.testing.assert_allclose(l4, l1, rtol=1e-6)
+    ga, gb = grads["lm"][0], grads["pp"][0]
+    assert float(gb.abs().max()) > 0 and float((ga - gb).norm() / gb.norm()) < 2e-6
     # the trace backward as a launch of its own per cell (evf_plif_trace_bwd) against the fused forms (team E of the hidden cells'
     # fused backward, the head layer's window launch): the same bits per element, the per-channel sums to round-off
     monkeypatch.setattr(heng, "PLIF_BOX_IN_DGRAD", True)
