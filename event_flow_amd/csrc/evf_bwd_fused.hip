@@ -584,6 +584,10 @@ struct FbWin {
   const float4* pp[FB_WIN_MAX];   // PLIF: trace before the pass (NULL: zero)
   const float* P[FB_WIN_MAX];     // PLIF: pooled activity of the pass
   float* gP[FB_WIN_MAX];          // out: dL/d(pooled activity) of the pass (raw)
+  // TOP (the layer under the prediction head, FbTop: pred_w / dw / db of the launch's FbTop): per pass
+  const float* flow[FB_WIN_MAX];     // [B,2,H,W]
+  const float* g_flow[FB_WIN_MAX];   // [B,2,H,W]
+  const uint32_t* z_out[FB_WIN_MAX]; // [B,H,W] the layer's own output spikes
 };
 template <bool REC, bool TOP, int EW, bool PLIF = false, bool WIN = false>
 __device__ __forceinline__ void fb_body_ws(
@@ -595,7 +599,7 @@ __device__ __forceinline__ void fb_body_ws(
     float* __restrict__ g_leak, float* __restrict__ g_thresh, float* __restrict__ slab_ff, float* __restrict__ slab_rec, FbTop top,
     int row_ld, const FbPlif pl = FbPlif{}, const FbWin* wp = nullptr) {
   static_assert(!PLIF || EW == 8, "PLIF cells: whole-unit stages only");
-  static_assert(!WIN || (PLIF && !REC && !TOP && EW == 8), "window launches: feed-forward PLIF cells");
+  static_assert(!WIN || (PLIF && !REC && EW == 8), "window launches: feed-forward PLIF cells");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   unsigned short* s_b = (unsigned short*)smem_raw;           // [2][3][FB_CW*32] bf16 (region of FB_R0 bytes)
   uint32_t* s_px = (uint32_t*)(smem_raw + FB_R0);             // [2][3][32][FB_NW]
@@ -722,7 +726,14 @@ __device__ __forceinline__ void fb_body_ws(
         const float4 *wgz = wp->gz[ks], *wvp = wp->vp[ks], *wpp = wp->pp[ks];
         const uint32_t* wzp = wp->zp[ks];
         if (ks == 0) s.vo = wvo[ge];  // (block-uniform: later passes take the potential the previous iteration loaded as v_prev)
-        s.gz = (wgz ? wgz : wvo)[ge];
+        if (TOP) {
+          const long hw = (long)H * W, q = (long)y * W + x0 + pc;
+          const float *wf = wp->flow[ks], *wg = wp->g_flow[ks];
+          s.f0 = wf[(long)b * 2 * hw + q], s.f1 = wf[((long)b * 2 + 1) * hw + q];
+          s.q0 = wg[(long)b * 2 * hw + q], s.q1 = wg[((long)b * 2 + 1) * hw + q];
+          s.zo = wp->z_out[ks][pix0 + pc];
+        } else
+          s.gz = (wgz ? wgz : wvo)[ge];
         s.vp = (wvp ? wvp : wvo)[ge];
         s.zw = (wzp ? wzp : wp->xT[ks])[wzp ? pix0 + pc : 0];
         sp.pp = (wpp ? wpp : wvo)[ge];
@@ -1375,6 +1386,14 @@ __global__ __launch_bounds__(768) void k_bwd_win_plif(FbJob J, FbWin Wn, int B, 
                                           nullptr, J.g_v_prev, J.g_leak, J.g_thresh, J.slab_ff, nullptr, J.top, row_ld, J.pl, &Wn);
 }
 
+// ... of the layer under the prediction head (the head's backward inside, per pass)
+__global__ __launch_bounds__(768) void k_bwd_win_plif_top(FbJob J, FbWin Wn, int B, int H, int W, int nchunk, long nunits, int row_ld,
+                                                          int nrows_total) {
+  fb_body_ws<false, true, 8, true, true>((int)blockIdx.x, (int)gridDim.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                         nullptr, J.leak, J.thresh, B, H, W, nchunk, nunits, J.width, J.accumulate, nrows_total, nullptr,
+                                         nullptr, J.g_v_prev, J.g_leak, J.g_thresh, J.slab_ff, nullptr, J.top, row_ld, J.pl, &Wn);
+}
+
 static long fb_units(int B, int H, int W) { return (long)B * H * ((W + FB_CW - 1) / FB_CW); }
 #define FB_LDS (FB_R0 + 2 * (2 * 3 * C32 * FB_NW * 4) + 256 * 16 + 2 * (2 * 8 * C32 * 4))  // (the second [2][8][32]: PLIF)
 
@@ -1888,41 +1907,78 @@ extern "C" int evf_plif_bwd_wgrad_top(const float* flow, const float* g_flow, co
 // pt_prev (NULL: zero), P; out per pass: g_cur, g_P_raw.  dL/dv and dL/d(pt) are carried in registers from pass to pass and start at
 // zero behind the window's last pass; g_v_prev / g_pt_prev (may be NULL): the gradients on the state entering the window.  Slab and
 // per-channel sums as evf_plif_bwd_wgrad2 (accumulate: bit 0 = add to the slab, bits 8.. = pitch of the per-block rows).
-extern "C" int evf_plif_bwd_wgrad_window(int np, const void* const* g_z, const void* const* v_out, const void* const* v_prev,
-                                         const void* const* z_prev, const void* const* xT, void* const* g_cur,
-                                         const void* const* pt_prev, const void* const* P, void* const* g_P_raw, const float* leak,
-                                         const float* thresh, const float* leak_pt, const float* add_pt, int B, int H, int W,
-                                         float act_width, float* g_v_prev, float* g_pt_prev, float* g_leak, float* g_thresh,
-                                         float* g_leak_pt, float* g_add_pt, float* slab_ff, int accumulate, void* stream) {
-  if (np < 1 || np > FB_WIN_MAX || !g_z || !v_out || !v_prev || !z_prev || !xT || !g_cur || !pt_prev || !P || !g_P_raw || !leak ||
-      !thresh || !leak_pt || !add_pt || !g_leak || !g_thresh || !g_leak_pt || !g_add_pt || !slab_ff || B <= 0 || H <= 0 || W <= 0)
+static int fb_window_launch(int np, const void* const* g_z, const void* const* flow, const void* const* g_flow, const void* const* z_out,
+                            const float* pred_w, float* d_pred_w, float* d_pred_b, const void* const* v_out, const void* const* v_prev,
+                            const void* const* z_prev, const void* const* xT, void* const* g_cur, const void* const* pt_prev,
+                            const void* const* P, void* const* g_P_raw, const float* leak, const float* thresh, const float* leak_pt,
+                            const float* add_pt, int B, int H, int W, float act_width, float* g_v_prev, float* g_pt_prev, float* g_leak,
+                            float* g_thresh, float* g_leak_pt, float* g_add_pt, float* slab_ff, int accumulate, void* stream) {
+  const bool top = flow != nullptr;
+  if (np < 1 || np > FB_WIN_MAX || (!top && !g_z) || !v_out || !v_prev || !z_prev || !xT || !g_cur || !pt_prev || !P || !g_P_raw ||
+      !leak || !thresh || !leak_pt || !add_pt || !g_leak || !g_thresh || !g_leak_pt || !g_add_pt || !slab_ff || B <= 0 || H <= 0 ||
+      W <= 0 || (top && (!g_flow || !z_out || !pred_w || !d_pred_w || !d_pred_b)))
     return EVF_EINVAL;
   FbWin Wn;
   Wn.np = np;
   for (int s = 0; s < FB_WIN_MAX; ++s) {
     const int q = s < np ? s : 0;
-    if (!v_out[q] || !xT[q] || !g_cur[q] || !P[q] || !g_P_raw[q]) return EVF_EINVAL;
-    Wn.gz[s] = (const float4*)g_z[q], Wn.vo[s] = (const float4*)v_out[q], Wn.vp[s] = (const float4*)v_prev[q];
+    if (!v_out[q] || !xT[q] || !g_cur[q] || !P[q] || !g_P_raw[q] || (top && (!flow[q] || !g_flow[q] || !z_out[q]))) return EVF_EINVAL;
+    Wn.gz[s] = top ? nullptr : (const float4*)g_z[q];
+    Wn.vo[s] = (const float4*)v_out[q], Wn.vp[s] = (const float4*)v_prev[q];
     Wn.zp[s] = (const uint32_t*)z_prev[q], Wn.xT[s] = (const uint32_t*)xT[q], Wn.gcur[s] = (float4*)g_cur[q];
     Wn.pp[s] = (const float4*)pt_prev[q], Wn.P[s] = (const float*)P[q], Wn.gP[s] = (float*)g_P_raw[q];
+    Wn.flow[s] = top ? (const float*)flow[q] : nullptr, Wn.g_flow[s] = top ? (const float*)g_flow[q] : nullptr;
+    Wn.z_out[s] = top ? (const uint32_t*)z_out[q] : nullptr;
   }
   const int row_ld = accumulate >> 8;
   const long nunits = fb_units(B, H, W);
   const int nchunk = (W + FB_CW - 1) / FB_CW;
   FbJob J{};
   J.leak = leak, J.thresh = thresh, J.g_v_prev = (float4*)g_v_prev, J.g_leak = g_leak, J.g_thresh = g_thresh, J.slab_ff = slab_ff;
-  J.width = act_width, J.accumulate = accumulate & 1, J.kind = 3;
+  J.width = act_width, J.accumulate = accumulate & 1, J.kind = top ? 5 : 3;
+  J.top = FbTop{nullptr, nullptr, pred_w, nullptr, d_pred_w, d_pred_b};
   J.pl = FbPlif{nullptr, nullptr, nullptr, leak_pt, add_pt, (float4*)g_pt_prev, nullptr, g_leak_pt, g_add_pt};
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k_bwd_win_plif, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    (void)hipFuncSetAttribute((const void*)k_bwd_win_plif_top, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
     attr = true;
   }
   // blocks: as a one-cell launch whose units cost np times as much (whole rounds of one block per CU)
   const int nblk = fb_blocks_per_cell(nunits, 1, 8 * np);
   evf_prof_mark(1, 0, stream);
-  hipLaunchKernelGGL(k_bwd_win_plif, dim3(nblk), dim3(768), FB_LDS, EVF_STREAM(stream), J, Wn, B, H, W, nchunk, nunits, row_ld,
-                     fb_rows(nunits));
+  if (top)
+    hipLaunchKernelGGL(k_bwd_win_plif_top, dim3(nblk), dim3(768), FB_LDS, EVF_STREAM(stream), J, Wn, B, H, W, nchunk, nunits, row_ld,
+                       fb_rows(nunits));
+  else
+    hipLaunchKernelGGL(k_bwd_win_plif, dim3(nblk), dim3(768), FB_LDS, EVF_STREAM(stream), J, Wn, B, H, W, nchunk, nunits, row_ld,
+                       fb_rows(nunits));
   evf_prof_mark(1, 1, stream);
   return evf_status();
+}
+
+extern "C" int evf_plif_bwd_wgrad_window(int np, const void* const* g_z, const void* const* v_out, const void* const* v_prev,
+                                         const void* const* z_prev, const void* const* xT, void* const* g_cur,
+                                         const void* const* pt_prev, const void* const* P, void* const* g_P_raw, const float* leak,
+                                         const float* thresh, const float* leak_pt, const float* add_pt, int B, int H, int W,
+                                         float act_width, float* g_v_prev, float* g_pt_prev, float* g_leak, float* g_thresh,
+                                         float* g_leak_pt, float* g_add_pt, float* slab_ff, int accumulate, void* stream) {
+  return fb_window_launch(np, g_z, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, v_out, v_prev, z_prev, xT, g_cur, pt_prev, P,
+                          g_P_raw, leak, thresh, leak_pt, add_pt, B, H, W, act_width, g_v_prev, g_pt_prev, g_leak, g_thresh, g_leak_pt,
+                          g_add_pt, slab_ff, accumulate, stream);
+}
+// ... of the (feed-forward) layer under the prediction head, with the head's backward inside (evf_plif_bwd_wgrad_top per pass):
+// flow / g_flow [B,2,H,W] and z_out [B,H,W] per pass instead of g_z; d_pred_w [2][32] / d_pred_b [2] rows like g_leak.
+extern "C" int evf_plif_bwd_wgrad_window_top(int np, const void* const* flow, const void* const* g_flow, const float* pred_w,
+                                             const void* const* z_out, float* d_pred_w, float* d_pred_b, const void* const* v_out,
+                                             const void* const* v_prev, const void* const* z_prev, const void* const* xT,
+                                             void* const* g_cur, const void* const* pt_prev, const void* const* P,
+                                             void* const* g_P_raw, const float* leak, const float* thresh, const float* leak_pt,
+                                             const float* add_pt, int B, int H, int W, float act_width, float* g_v_prev,
+                                             float* g_pt_prev, float* g_leak, float* g_thresh, float* g_leak_pt, float* g_add_pt,
+                                             float* slab_ff, int accumulate, void* stream) {
+  if (!flow) return EVF_EINVAL;
+  return fb_window_launch(np, nullptr, flow, g_flow, z_out, pred_w, d_pred_w, d_pred_b, v_out, v_prev, z_prev, xT, g_cur, pt_prev, P,
+                          g_P_raw, leak, thresh, leak_pt, add_pt, B, H, W, act_width, g_v_prev, g_pt_prev, g_leak, g_thresh, g_leak_pt,
+                          g_add_pt, slab_ff, accumulate, stream);
 }

@@ -601,17 +601,14 @@ class FireNetEngine:
             leak, thr = _lib.ptr(self._flat[f"{i}.leak"]), _lib.ptr(self._flat[f"{i}.thresh"])
             lpt, apt = _lib.ptr(self._flat[f"{i}.leak_pt"]), _lib.ptr(self._flat[f"{i}.add_pt"])
             width = self._act_width(i)
-            if i == n - 1:  # under the prediction head (its backward inside): pass by pass, the carries through memory
-                for s_ in range(T):
-                    in_bits, v_prev, z_prev, v_out, z_out, in_bitsT, _zT, pt_prev, _pto, P_sav = lay[s_]
-                    _lib.call("evf_plif_bwd_wgrad_top", _lib.ptr(tapes[s_]["flow"]), _lib.ptr(gflows[s_]), _lib.ptr(self._flat["pred.w"]),
-                              _lib.ptr(z_out), rowp("pred.w"), rowp("pred.b"), _lib.ptr(gv_i) if s_ else None, _lib.ptr(v_out),
-                              _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(in_bitsT), leak, thr, B, H, W, 1, SURROGATE_ID[c.activation],
-                              width, _lib.ptr(gcur[s_]), None, _lib.ptr(gv_i), rowp(f"{i}.leak"), rowp(f"{i}.thresh"),
-                              _lib.ptr(self._slab(kf, nsl, dev)), (1 if win.slab_init.get(kf) else 0) | (row_ld << 8),
-                              _lib.ptr(gpt_i) if s_ else None, _lib.ptr(pt_prev), _lib.ptr(P_sav), lpt, apt, _lib.ptr(gpt_i),
-                              _lib.ptr(gPs[s_]), rowp(f"{i}.leak_pt"), rowp(f"{i}.add_pt"))
-                    win.slab_init[kf] = True
+            if i == n - 1:  # under the prediction head: its backward inside, all passes in one launch
+                _lib.call("evf_plif_bwd_wgrad_window_top", T, arr([tp["flow"] for tp in tapes]), arr(gflows), _lib.ptr(self._flat["pred.w"]),
+                          arr([l_[4] for l_ in lay]), rowp("pred.w"), rowp("pred.b"), arr([l_[3] for l_ in lay]), arr([l_[1] for l_ in lay]),
+                          arr([l_[2] for l_ in lay]), arr([l_[5] for l_ in lay]), arr(gcur), arr([l_[7] for l_ in lay]),
+                          arr([l_[9] for l_ in lay]), arr(gPs), leak, thr, lpt, apt, B, H, W, width, None, None, rowp(f"{i}.leak"),
+                          rowp(f"{i}.thresh"), rowp(f"{i}.leak_pt"), rowp(f"{i}.add_pt"), _lib.ptr(self._slab(kf, nsl, dev)),
+                          (1 if win.slab_init.get(kf) else 0) | (row_ld << 8))
+                win.slab_init[kf] = True
             elif not c.recurrent:  # feed-forward: all passes in one launch, the carries in registers
                 _lib.call("evf_plif_bwd_wgrad_window", T, arr([gz(i, s_) for s_ in range(T)]), arr([l_[3] for l_ in lay]),
                           arr([l_[1] for l_ in lay]), arr([l_[2] for l_ in lay]), arr([l_[5] for l_ in lay]), arr(gcur),

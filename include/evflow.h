@@ -414,6 +414,16 @@ int evf_plif_bwd_wgrad_window(int np, const void* const* g_z, const void* const*
                               const float* thresh, const float* leak_pt, const float* add_pt, int B, int H, int W,
                               float act_width, float* g_v_prev, float* g_pt_prev, float* g_leak, float* g_thresh,
                               float* g_leak_pt, float* g_add_pt, float* slab_ff, int accumulate, void* stream);
+/* ... of the feed-forward layer under the prediction head, the head's backward inside (evf_plif_bwd_wgrad_top per pass): per
+ * pass flow / g_flow [B,2,H,W] and z_out [B,H,W] instead of g_z; pred_w [2][32]; d_pred_w / d_pred_b rows like g_leak. */
+int evf_plif_bwd_wgrad_window_top(int np, const void* const* flow, const void* const* g_flow, const float* pred_w,
+                                  const void* const* z_out, float* d_pred_w, float* d_pred_b, const void* const* v_out,
+                                  const void* const* v_prev, const void* const* z_prev, const void* const* xT,
+                                  void* const* g_cur, const void* const* pt_prev, const void* const* P,
+                                  void* const* g_P_raw, const float* leak, const float* thresh, const float* leak_pt,
+                                  const float* add_pt, int B, int H, int W, float act_width, float* g_v_prev,
+                                  float* g_pt_prev, float* g_leak, float* g_thresh, float* g_leak_pt, float* g_add_pt,
+                                  float* slab_ff, int accumulate, void* stream);
 int evf_plif_bwd_wgrad_top(const float* flow, const float* g_flow, const float* pred_w, const uint32_t* z_out,
                            float* d_pred_w, float* d_pred_b, const float* g_v_out, const float* v_out,
                            const float* v_prev, const uint32_t* z_prev, const uint32_t* xT, const float* leak,

@@ -626,7 +626,7 @@ def test_plif_hidden_cell_backward_of_a_window_in_one_launch(shape):
     torch.manual_seed(31)
     L = _lib.load()
     nsl = max(L.evf_lif_bwd_wgrad_slabs(B, H, W), 512)
-    row_ld = 160
+    row_ld = 224
     leak, thresh = _f(32, scale=0.3), _f(32, scale=0.1) + 0.4
     lpt, apt = _f(32, scale=0.5) - 1.0, _f(32, scale=0.5) - 2.0
     vs = [None] + [_f(B, H, W, C, scale=0.6) for _ in range(npass)]        # vs[t]: potential before pass t; vs[t + 1]: after
@@ -664,7 +664,40 @@ def test_plif_hidden_cell_backward_of_a_window_in_one_launch(shape):
                   P(o["rows"][:, 96:]), P(o["slab"]), 0 | (row_ld << 8))
         return o
 
-    ref, got = per_pass(), window()
+    # the layer under the prediction head: the head's backward inside (evf_plif_bwd_wgrad_top per pass / _window_top)
+    flows = [torch.tanh(_f(B, 2, H, W)) for _ in range(npass)]
+    gfl = [_f(B, 2, H, W) for _ in range(npass)]
+    zo = [_bits(B, H, W, rate=0.4) for _ in range(npass)]
+    pw = _f(2, 32, scale=0.05)
+
+    def top_per_pass():
+        o = outs()
+        for k in range(npass):
+            t = npass - 1 - k
+            _lib.call("evf_plif_bwd_wgrad_top", P(flows[t]), P(gfl[t]), P(pw), P(zo[t]), P(o["rows"][:, 128:]), P(o["rows"][:, 192:]),
+                      P(o["gv"]) if k else None, P(vs[t + 1]), P(vs[t]), P(zs[t]), P(xT[t]), P(leak), P(thresh), B, H, W, 1, 0, 10.0,
+                      P(o["gcur"][t]), None, P(o["gv"]), P(o["rows"][:, :32]), P(o["rows"][:, 32:]), P(o["slab"]), (1 if k else 0) | (row_ld << 8),
+                      P(o["gpt"]) if k else None, P(pts[t]), P(Ps[t]), P(lpt), P(apt), P(o["gpt"]), P(o["gP"][t]), P(o["rows"][:, 64:]),
+                      P(o["rows"][:, 96:]))
+        return o
+
+    def top_window():
+        o = outs()
+        order = list(range(npass - 1, -1, -1))
+        arr = lambda ts: (ctypes.c_void_p * npass)(*[P(x) for x in ts])  # noqa: E731
+        _lib.call("evf_plif_bwd_wgrad_window_top", npass, arr([flows[t] for t in order]), arr([gfl[t] for t in order]), P(pw),
+                  arr([zo[t] for t in order]), P(o["rows"][:, 128:]), P(o["rows"][:, 192:]), arr([vs[t + 1] for t in order]),
+                  arr([vs[t] for t in order]), arr([zs[t] for t in order]), arr([xT[t] for t in order]), arr([o["gcur"][t] for t in order]),
+                  arr([pts[t] for t in order]), arr([Ps[t] for t in order]), arr([o["gP"][t] for t in order]), P(leak), P(thresh), P(lpt),
+                  P(apt), B, H, W, 10.0, P(o["gv"]), P(o["gpt"]), P(o["rows"][:, :32]), P(o["rows"][:, 32:]), P(o["rows"][:, 64:]),
+                  P(o["rows"][:, 96:]), P(o["slab"]), 0 | (row_ld << 8))
+        return o
+
+    for ref, got in ((per_pass(), window()), (top_per_pass(), top_window())):
+        _check_window(ref, got, npass)
+
+
+def _check_window(ref, got, npass):
     torch.cuda.synchronize()
     for t in range(npass):
         assert torch.equal(ref["gcur"][t], got["gcur"][t]), ("g_cur", t)
