@@ -1208,6 +1208,25 @@ def test_plif_cells_recorded_on_diagonals_are_bit_identical(monkeypatch):
     np.testing.assert_allclose(l4, l1, rtol=1e-6)
     ga, gb = grads["lm"][0], grads["pp"][0]
     assert float(gb.abs().max()) > 0 and float((ga - gb).norm() / gb.norm()) < 2e-6
+    # a window of 18 passes (more than a window launch holds: the passes that waited are replayed pass by pass, in order)
+    def run_long(lm):
+        monkeypatch.setattr(heng2, "PLIF_LAYER_MAJOR", lm)
+        model = build_from_golden(g, fix="g7_pliffirenet_train")
+        model.train()
+        lossf = hloss.EventWarping(loss_cfg(H, W), DEV)
+        opt = FlatAdam(model, lr=2e-4, clip=100.0)
+        opt.zero_grad()
+        seen = []
+        real_step = opt.step
+        opt.step = lambda *a_, **k_: (seen.append(opt.flat_grad.detach().clone()), real_step(*a_, **k_))[1]
+        loss = htrain.train_window(model, lossf, opt, passes_from_golden(g) * 6)
+        torch.cuda.synchronize()
+        return float(loss), seen[0]
+
+    (la, ga2), (lb, gb2) = run_long(True), run_long(False)
+    monkeypatch.setattr(heng2, "PLIF_LAYER_MAJOR", True)
+    np.testing.assert_allclose(la, lb, rtol=1e-6)
+    assert float(gb2.abs().max()) > 0 and float((ga2 - gb2).norm() / gb2.norm()) < 2e-6
     # the trace backward as a launch of its own per cell (evf_plif_trace_bwd) against the fused forms (team E of the hidden cells'
     # fused backward, the head layer's window launch): the same bits per element, the per-channel sums to round-off
     monkeypatch.setattr(heng, "PLIF_BOX_IN_DGRAD", True)
