@@ -8,7 +8,7 @@ mkdir -p "$(dirname "$OUT")"
 {
   echo "# parity report: $(date -u +%Y-%m-%dT%H:%M:%SZ)  $(python -c 'import torch; print(torch.cuda.get_device_name(0))' 2>/dev/null)"
   echo "# kernel sources: $(python -c 'import bench; print(bench.source_hash())' 2>/dev/null)"
-  python -m pytest -s -q -m gpu tests/test_gpu_bench_parity.py \
+  python -m pytest -s -q -m gpu tests/test_gpu_bench_parity.py tests/test_gpu_teacher_forced.py \
       "tests/test_gpu_network.py::test_exact_split_input_gradient_is_fp32_equivalent" \
       "tests/test_gpu_network.py::test_exact_split_weight_gradient_is_fp32_equivalent" \
       "tests/test_gpu_network.py::test_bf16x3_forward_is_fp32_equivalent" 2>&1 | grep -v "^$"
