@@ -580,7 +580,8 @@ struct FbWin {
   const float4* vp[FB_WIN_MAX];   // potential before the pass (NULL: zero state)
   const uint32_t* zp[FB_WIN_MAX]; // spike words before the pass (NULL: none)
   const uint32_t* xT[FB_WIN_MAX]; // input spike planes of the pass
-  float4* gcur[FB_WIN_MAX];       // out: dL/d(current) of the pass
+  float4* gcur[FB_WIN_MAX];       // out: dL/d(current) of the pass (fp32; NULL: not wanted)
+  uint2* gsp[FB_WIN_MAX];         // out: its exact 3-way bf16 split, three planes [term][pix][32] (NULL: not wanted) -- k_dgrad_diag_dma
   const float4* pp[FB_WIN_MAX];   // PLIF: trace before the pass (NULL: zero)
   const float* P[FB_WIN_MAX];     // PLIF: pooled activity of the pass
   float* gP[FB_WIN_MAX];          // out: dL/d(pooled activity) of the pass (raw)
@@ -599,7 +600,7 @@ __device__ __forceinline__ void fb_body_ws(
     float* __restrict__ g_leak, float* __restrict__ g_thresh, float* __restrict__ slab_ff, float* __restrict__ slab_rec, FbTop top,
     int row_ld, const FbPlif pl = FbPlif{}, const FbWin* wp = nullptr) {
   static_assert(!PLIF || EW == 8, "PLIF cells: whole-unit stages only");
-  static_assert(!WIN || (PLIF && !REC && EW == 8), "window launches: feed-forward PLIF cells");
+  static_assert(!WIN || (!REC && EW == 8), "window launches: feed-forward cells");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   unsigned short* s_b = (unsigned short*)smem_raw;           // [2][3][FB_CW*32] bf16 (region of FB_R0 bytes)
   uint32_t* s_px = (uint32_t*)(smem_raw + FB_R0);             // [2][3][32][FB_NW]
@@ -736,8 +737,10 @@ __device__ __forceinline__ void fb_body_ws(
           s.gz = (wgz ? wgz : wvo)[ge];
         s.vp = (wvp ? wvp : wvo)[ge];
         s.zw = (wzp ? wzp : wp->xT[ks])[wzp ? pix0 + pc : 0];
-        sp.pp = (wpp ? wpp : wvo)[ge];
-        sp.P = wp->P[ks][pix0 + pc];
+        if (PLIF) {
+          sp.pp = (wpp ? wpp : wvo)[ge];
+          sp.P = wp->P[ks][pix0 + pc];
+        }
         const int tpl = min(et + ETHR * h, 3 * C32 * FB_NW - 1);
         const int pl_wq = tpl % FB_NW, pl_c = (tpl / FB_NW) % C32, pl_dy = tpl / (FB_NW * C32);
         const int yy = y + pl_dy - 1, xw = x0 / 32 - 1 + pl_wq;
@@ -793,6 +796,7 @@ __device__ __forceinline__ void fb_body_ws(
       const bool w_gz = WIN && wp->gz[ks] != nullptr, w_vp = WIN && wp->vp[ks] != nullptr, w_zp = WIN && wp->zp[ks] != nullptr,
                  w_pp = WIN && wp->pp[ks] != nullptr;
       float4* const w_gcur = WIN ? wp->gcur[ks] : nullptr;
+      uint2* const w_gsp = WIN ? wp->gsp[ks] : nullptr;
       float* const w_gP = WIN ? wp->gP[ks] : nullptr;
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       float gp0 = 0.f, gp1 = 0.f;
@@ -843,7 +847,7 @@ __device__ __forceinline__ void fb_body_ws(
         gvc = make_float4(gp[0], gp[1], gp[2], gp[3]);
         voc = vp4;
         if (ok) {
-          w_gcur[eo] = make_float4(gc[0], gc[1], gc[2], gc[3]);
+          if (w_gcur) w_gcur[eo] = make_float4(gc[0], gc[1], gc[2], gc[3]);
           if (ks == T - 1 && g_v_prev) g_v_prev[eo] = gvc;  // (the gradient on the state entering the window, when wanted)
         }
       } else if (ok) {
@@ -898,10 +902,11 @@ __device__ __forceinline__ void fb_body_ws(
           sbw[t3 * (FB_CW * C32 / 2) + d1] = __builtin_amdgcn_perm(od, ev, 0x07060302u);  // channel j0 + 1
         }
       }
-      if (ok && g_split) {
+      if (ok && (WIN ? w_gsp != nullptr : g_split != nullptr)) {
+        uint2* const gs = WIN ? w_gsp : g_split;
         const long ps = (long)B * H * W * 8;
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) g_split[t3 * ps + eo] = make_uint2(tp[t3][0], tp[t3][1]);
+        for (int t3 = 0; t3 < 3; ++t3) gs[t3 * ps + eo] = make_uint2(tp[t3][0], tp[t3][1]);
       }
       const int widx = et + ETHR * h;
       if (widx < 3 * C32 * FB_NW) {
@@ -1392,6 +1397,21 @@ __global__ __launch_bounds__(768) void k_bwd_win_plif_top(FbJob J, FbWin Wn, int
   fb_body_ws<false, true, 8, true, true>((int)blockIdx.x, (int)gridDim.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                          nullptr, J.leak, J.thresh, B, H, W, nchunk, nunits, J.width, J.accumulate, nrows_total, nullptr,
                                          nullptr, J.g_v_prev, J.g_leak, J.g_thresh, J.slab_ff, nullptr, J.top, row_ld, J.pl, &Wn);
+}
+
+// ... LIF cells (the feed-forward layers on top of a LIF-FireNet: their dL/d(spikes) of every pass is known before anything
+// below them has run)
+__global__ __launch_bounds__(768) void k_bwd_win_lif(FbJob J, FbWin Wn, int B, int H, int W, int nchunk, long nunits, int row_ld,
+                                                     int nrows_total) {
+  fb_body_ws<false, false, 8, false, true>((int)blockIdx.x, (int)gridDim.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                           nullptr, J.leak, J.thresh, B, H, W, nchunk, nunits, J.width, J.accumulate, nrows_total, nullptr,
+                                           nullptr, J.g_v_prev, J.g_leak, J.g_thresh, J.slab_ff, nullptr, J.top, row_ld, J.pl, &Wn);
+}
+__global__ __launch_bounds__(768) void k_bwd_win_lif_top(FbJob J, FbWin Wn, int B, int H, int W, int nchunk, long nunits, int row_ld,
+                                                         int nrows_total) {
+  fb_body_ws<false, true, 8, false, true>((int)blockIdx.x, (int)gridDim.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                          nullptr, J.leak, J.thresh, B, H, W, nchunk, nunits, J.width, J.accumulate, nrows_total, nullptr,
+                                          nullptr, J.g_v_prev, J.g_leak, J.g_thresh, J.slab_ff, nullptr, J.top, row_ld, J.pl, &Wn);
 }
 
 static long fb_units(int B, int H, int W) { return (long)B * H * ((W + FB_CW - 1) / FB_CW); }
@@ -1909,24 +1929,29 @@ extern "C" int evf_plif_bwd_wgrad_top(const float* flow, const float* g_flow, co
 // per-channel sums as evf_plif_bwd_wgrad2 (accumulate: bit 0 = add to the slab, bits 8.. = pitch of the per-block rows).
 static int fb_window_launch(int np, const void* const* g_z, const void* const* flow, const void* const* g_flow, const void* const* z_out,
                             const float* pred_w, float* d_pred_w, float* d_pred_b, const void* const* v_out, const void* const* v_prev,
-                            const void* const* z_prev, const void* const* xT, void* const* g_cur, const void* const* pt_prev,
-                            const void* const* P, void* const* g_P_raw, const float* leak, const float* thresh, const float* leak_pt,
+                            const void* const* z_prev, const void* const* xT, void* const* g_cur, void* const* g_split,
+                            const void* const* pt_prev, const void* const* P, void* const* g_P_raw, const float* leak, const float* thresh,
+                            const float* leak_pt,
                             const float* add_pt, int B, int H, int W, float act_width, float* g_v_prev, float* g_pt_prev, float* g_leak,
                             float* g_thresh, float* g_leak_pt, float* g_add_pt, float* slab_ff, int accumulate, void* stream) {
-  const bool top = flow != nullptr;
-  if (np < 1 || np > FB_WIN_MAX || (!top && !g_z) || !v_out || !v_prev || !z_prev || !xT || !g_cur || !pt_prev || !P || !g_P_raw ||
-      !leak || !thresh || !leak_pt || !add_pt || !g_leak || !g_thresh || !g_leak_pt || !g_add_pt || !slab_ff || B <= 0 || H <= 0 ||
-      W <= 0 || (top && (!g_flow || !z_out || !pred_w || !d_pred_w || !d_pred_b)))
+  const bool top = flow != nullptr, plif = leak_pt != nullptr;
+  if (np < 1 || np > FB_WIN_MAX || (!top && !g_z) || !v_out || !v_prev || !z_prev || !xT || (!g_cur && !g_split) || !leak || !thresh ||
+      !g_leak || !g_thresh || !slab_ff || B <= 0 || H <= 0 || W <= 0 || (top && (!g_flow || !z_out || !pred_w || !d_pred_w || !d_pred_b)) ||
+      (plif && (!pt_prev || !P || !g_P_raw || !add_pt || !g_leak_pt || !g_add_pt || !g_cur)))
     return EVF_EINVAL;
   FbWin Wn;
   Wn.np = np;
   for (int s = 0; s < FB_WIN_MAX; ++s) {
     const int q = s < np ? s : 0;
-    if (!v_out[q] || !xT[q] || !g_cur[q] || !P[q] || !g_P_raw[q] || (top && (!flow[q] || !g_flow[q] || !z_out[q]))) return EVF_EINVAL;
+    if (!v_out[q] || !xT[q] || (plif && (!g_cur[q] || !P[q] || !g_P_raw[q])) || (top && (!flow[q] || !g_flow[q] || !z_out[q])) ||
+        !((g_cur && g_cur[q]) || (g_split && g_split[q])))
+      return EVF_EINVAL;
     Wn.gz[s] = top ? nullptr : (const float4*)g_z[q];
     Wn.vo[s] = (const float4*)v_out[q], Wn.vp[s] = (const float4*)v_prev[q];
-    Wn.zp[s] = (const uint32_t*)z_prev[q], Wn.xT[s] = (const uint32_t*)xT[q], Wn.gcur[s] = (float4*)g_cur[q];
-    Wn.pp[s] = (const float4*)pt_prev[q], Wn.P[s] = (const float*)P[q], Wn.gP[s] = (float*)g_P_raw[q];
+    Wn.zp[s] = (const uint32_t*)z_prev[q], Wn.xT[s] = (const uint32_t*)xT[q], Wn.gcur[s] = g_cur ? (float4*)g_cur[q] : nullptr;
+    Wn.gsp[s] = g_split ? (uint2*)g_split[q] : nullptr;
+    Wn.pp[s] = plif ? (const float4*)pt_prev[q] : nullptr, Wn.P[s] = plif ? (const float*)P[q] : nullptr;
+    Wn.gP[s] = plif ? (float*)g_P_raw[q] : nullptr;
     Wn.flow[s] = top ? (const float*)flow[q] : nullptr, Wn.g_flow[s] = top ? (const float*)g_flow[q] : nullptr;
     Wn.z_out[s] = top ? (const uint32_t*)z_out[q] : nullptr;
   }
@@ -1935,24 +1960,27 @@ static int fb_window_launch(int np, const void* const* g_z, const void* const* f
   const int nchunk = (W + FB_CW - 1) / FB_CW;
   FbJob J{};
   J.leak = leak, J.thresh = thresh, J.g_v_prev = (float4*)g_v_prev, J.g_leak = g_leak, J.g_thresh = g_thresh, J.slab_ff = slab_ff;
-  J.width = act_width, J.accumulate = accumulate & 1, J.kind = top ? 5 : 3;
+  J.width = act_width, J.accumulate = accumulate & 1, J.kind = (top ? 2 : 0) + (plif ? 3 : 0);
   J.top = FbTop{nullptr, nullptr, pred_w, nullptr, d_pred_w, d_pred_b};
   J.pl = FbPlif{nullptr, nullptr, nullptr, leak_pt, add_pt, (float4*)g_pt_prev, nullptr, g_leak_pt, g_add_pt};
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k_bwd_win_plif, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
     (void)hipFuncSetAttribute((const void*)k_bwd_win_plif_top, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    (void)hipFuncSetAttribute((const void*)k_bwd_win_lif, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    (void)hipFuncSetAttribute((const void*)k_bwd_win_lif_top, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
     attr = true;
   }
   // blocks: as a one-cell launch whose units cost np times as much (whole rounds of one block per CU)
   const int nblk = fb_blocks_per_cell(nunits, 1, 8 * np);
   evf_prof_mark(1, 0, stream);
-  if (top)
-    hipLaunchKernelGGL(k_bwd_win_plif_top, dim3(nblk), dim3(768), FB_LDS, EVF_STREAM(stream), J, Wn, B, H, W, nchunk, nunits, row_ld,
-                       fb_rows(nunits));
-  else
-    hipLaunchKernelGGL(k_bwd_win_plif, dim3(nblk), dim3(768), FB_LDS, EVF_STREAM(stream), J, Wn, B, H, W, nchunk, nunits, row_ld,
-                       fb_rows(nunits));
+#define FB_WIN_GO(K_) hipLaunchKernelGGL(K_, dim3(nblk), dim3(768), FB_LDS, EVF_STREAM(stream), J, Wn, B, H, W, nchunk, nunits, row_ld, fb_rows(nunits))
+  if (plif) {
+    if (top) FB_WIN_GO(k_bwd_win_plif_top); else FB_WIN_GO(k_bwd_win_plif);
+  } else {
+    if (top) FB_WIN_GO(k_bwd_win_lif_top); else FB_WIN_GO(k_bwd_win_lif);
+  }
+#undef FB_WIN_GO
   evf_prof_mark(1, 1, stream);
   return evf_status();
 }
@@ -1963,8 +1991,9 @@ extern "C" int evf_plif_bwd_wgrad_window(int np, const void* const* g_z, const v
                                          const float* thresh, const float* leak_pt, const float* add_pt, int B, int H, int W,
                                          float act_width, float* g_v_prev, float* g_pt_prev, float* g_leak, float* g_thresh,
                                          float* g_leak_pt, float* g_add_pt, float* slab_ff, int accumulate, void* stream) {
-  return fb_window_launch(np, g_z, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, v_out, v_prev, z_prev, xT, g_cur, pt_prev, P,
-                          g_P_raw, leak, thresh, leak_pt, add_pt, B, H, W, act_width, g_v_prev, g_pt_prev, g_leak, g_thresh, g_leak_pt,
+  if (!leak_pt) return EVF_EINVAL;
+  return fb_window_launch(np, g_z, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, v_out, v_prev, z_prev, xT, g_cur, nullptr, pt_prev,
+                          P, g_P_raw, leak, thresh, leak_pt, add_pt, B, H, W, act_width, g_v_prev, g_pt_prev, g_leak, g_thresh, g_leak_pt,
                           g_add_pt, slab_ff, accumulate, stream);
 }
 // ... of the (feed-forward) layer under the prediction head, with the head's backward inside (evf_plif_bwd_wgrad_top per pass):
@@ -1977,8 +2006,22 @@ extern "C" int evf_plif_bwd_wgrad_window_top(int np, const void* const* flow, co
                                              const float* add_pt, int B, int H, int W, float act_width, float* g_v_prev,
                                              float* g_pt_prev, float* g_leak, float* g_thresh, float* g_leak_pt, float* g_add_pt,
                                              float* slab_ff, int accumulate, void* stream) {
-  if (!flow) return EVF_EINVAL;
-  return fb_window_launch(np, nullptr, flow, g_flow, z_out, pred_w, d_pred_w, d_pred_b, v_out, v_prev, z_prev, xT, g_cur, pt_prev, P,
+  if (!flow || !leak_pt) return EVF_EINVAL;
+  return fb_window_launch(np, nullptr, flow, g_flow, z_out, pred_w, d_pred_w, d_pred_b, v_out, v_prev, z_prev, xT, g_cur, nullptr, pt_prev, P,
                           g_P_raw, leak, thresh, leak_pt, add_pt, B, H, W, act_width, g_v_prev, g_pt_prev, g_leak, g_thresh, g_leak_pt,
                           g_add_pt, slab_ff, accumulate, stream);
+}
+
+// LIF feed-forward hidden cells (evf_lif_bwd_wgrad2 / _top per pass), all passes of a window in one launch: as the PLIF forms
+// without the trace; g_cur (fp32) and / or g_split (three bf16 planes per pass, what evf_conv_dgrad_b3 reads) per pass.
+// flow == NULL: a hidden cell with g_z per pass; else the layer under the prediction head (flow / g_flow / z_out per pass).
+extern "C" int evf_lif_bwd_wgrad_window(int np, const void* const* g_z, const void* const* flow, const void* const* g_flow,
+                                        const float* pred_w, const void* const* z_out, float* d_pred_w, float* d_pred_b,
+                                        const void* const* v_out, const void* const* v_prev, const void* const* z_prev,
+                                        const void* const* xT, void* const* g_cur, void* const* g_split, const float* leak,
+                                        const float* thresh, int B, int H, int W, float act_width, float* g_v_prev, float* g_leak,
+                                        float* g_thresh, float* slab_ff, int accumulate, void* stream) {
+  return fb_window_launch(np, g_z, flow, g_flow, z_out, pred_w, d_pred_w, d_pred_b, v_out, v_prev, z_prev, xT, g_cur, g_split, nullptr,
+                          nullptr, nullptr, leak, thresh, nullptr, nullptr, B, H, W, act_width, g_v_prev, nullptr, g_leak, g_thresh, nullptr,
+                          nullptr, slab_ff, accumulate, stream);
 }

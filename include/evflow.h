@@ -401,6 +401,18 @@ int evf_plif_bwd_wgrad2(const float* g_z_out, const float* g_z_out2, const float
                         float* slab_ff, float* slab_rec, int accumulate, const float* g_pt_carry, const float* pt_prev,
                         const float* P, const float* leak_pt, const float* add_pt, float* g_pt_prev, float* g_P_raw,
                         float* g_leak_pt, float* g_add_pt, void* stream);
+/* LIF feed-forward hidden cells, all passes of a window in ONE launch (k_bwd_win_lif[_top]): what np calls of
+ * evf_lif_bwd_wgrad2 (flow == NULL: g_z per pass) or evf_lif_bwd_wgrad_top (flow / g_flow / z_out per pass, pred_w, d_pred_w,
+ * d_pred_b) compute, with dL/dv and the potential carried in registers.  Outputs per pass: g_cur (fp32) and / or g_split (the three
+ * bf16 planes evf_conv_dgrad_b3 reads); either array may be NULL.  Arrays as in evf_plif_bwd_wgrad_window below (index 0 = the
+ * window's last pass).  The layers on top of a LIF-FireNet know their dL/d(spikes) of every pass before anything below them has
+ * run: `engine` runs them first, the rest of the window on diagonals. */
+int evf_lif_bwd_wgrad_window(int np, const void* const* g_z, const void* const* flow, const void* const* g_flow,
+                             const float* pred_w, const void* const* z_out, float* d_pred_w, float* d_pred_b,
+                             const void* const* v_out, const void* const* v_prev, const void* const* z_prev,
+                             const void* const* xT, void* const* g_cur, void* const* g_split, const float* leak,
+                             const float* thresh, int B, int H, int W, float act_width, float* g_v_prev, float* g_leak,
+                             float* g_thresh, float* slab_ff, int accumulate, void* stream);
 /* A FEED-FORWARD PLIF hidden cell, all passes of a window in ONE launch (k_bwd_win_plif): what np calls of evf_plif_bwd_wgrad2
  * compute, with dL/dv and dL/d(pt) carried in registers from pass to pass and every potential read once -- 640 instead of 1152
  * bytes per pixel and pass.  Host arrays of np <= 16 device pointers, index 0 = the window's LAST pass (backward order); per pass:

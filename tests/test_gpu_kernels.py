@@ -697,6 +697,66 @@ def test_plif_hidden_cell_backward_of_a_window_in_one_launch(shape):
         _check_window(ref, got, npass)
 
 
+@pytest.mark.parametrize("shape", [(8, 128, 128), (2, 33, 70)])
+def test_lif_hidden_cell_backward_of_a_window_in_one_launch(shape):
+    """evf_lif_bwd_wgrad_window (LIF feed-forward hidden cell / the layer under the prediction head, all passes of a window in one
+    launch) against evf_lif_bwd_wgrad2 / _top per pass: dL/d(current) as fp32 and as its three bf16 planes of every pass and the
+    gradient on the window's entry state bit for bit; slab and per-channel sums to round-off."""
+    import ctypes
+
+    B, H, W = shape
+    npass = 6
+    torch.manual_seed(37)
+    L = _lib.load()
+    nsl = max(L.evf_lif_bwd_wgrad_slabs(B, H, W), 512)
+    row_ld = 224
+    leak, thresh = _f(32, scale=0.3), _f(32, scale=0.1) + 0.4
+    vs = [None] + [_f(B, H, W, C, scale=0.6) for _ in range(npass)]
+    zs = [None] + [_bits(B, H, W) for _ in range(npass - 1)]
+    xT = [_planes(_bits(B, H, W)) for _ in range(npass)]
+    gzs = [_f(B, H, W, C, scale=0.2) for _ in range(npass)]
+    flows = [torch.tanh(_f(B, 2, H, W)) for _ in range(npass)]
+    gfl = [_f(B, 2, H, W) for _ in range(npass)]
+    zo = [_bits(B, H, W, rate=0.4) for _ in range(npass)]
+    pw = _f(2, 32, scale=0.05)
+    arr = lambda ts: (ctypes.c_void_p * npass)(*[P(x) for x in ts])  # noqa: E731
+    order = list(range(npass - 1, -1, -1))
+
+    def outs():
+        return {"gcur": [torch.full((B, H, W, C), 3.0, device=DEV) for _ in range(npass)],
+                "gsp": [torch.zeros(3, B, H, W, C, dtype=torch.bfloat16, device=DEV) for _ in range(npass)],
+                "gv": torch.full((B, H, W, C), 3.0, device=DEV), "rows": torch.zeros(nsl, row_ld, device=DEV),
+                "slab": torch.full((nsl, 9216), 5.0, device=DEV)}
+
+    for top in (False, True):
+        ref, got = outs(), outs()
+        for k in range(npass):
+            t = npass - 1 - k
+            flag = (1 if k else 0) | (row_ld << 8)
+            if top:
+                _lib.call("evf_lif_bwd_wgrad_top", P(flows[t]), P(gfl[t]), P(pw), P(zo[t]), P(ref["rows"][:, 128:]), P(ref["rows"][:, 192:]),
+                          P(ref["gv"]) if k else None, P(vs[t + 1]), P(vs[t]), P(zs[t]), P(xT[t]), P(leak), P(thresh), B, H, W, 1, 0, 10.0,
+                          P(ref["gcur"][t]), P(ref["gsp"][t]), P(ref["gv"]), P(ref["rows"][:, :32]), P(ref["rows"][:, 32:]), P(ref["slab"]), flag)
+            else:
+                _lib.call("evf_lif_bwd_wgrad2", P(gzs[t]), None, P(ref["gv"]) if k else None, P(vs[t + 1]), P(vs[t]), P(zs[t]), P(xT[t]), None,
+                          P(leak), P(thresh), B, H, W, 1, 0, 10.0, P(ref["gcur"][t]), P(ref["gsp"][t]), P(ref["gv"]), P(ref["rows"][:, :32]),
+                          P(ref["rows"][:, 32:]), P(ref["slab"]), None, flag)
+        _lib.call("evf_lif_bwd_wgrad_window", npass, None if top else arr([gzs[t] for t in order]),
+                  arr([flows[t] for t in order]) if top else None, arr([gfl[t] for t in order]) if top else None, P(pw) if top else None,
+                  arr([zo[t] for t in order]) if top else None, P(got["rows"][:, 128:]) if top else None,
+                  P(got["rows"][:, 192:]) if top else None, arr([vs[t + 1] for t in order]), arr([vs[t] for t in order]),
+                  arr([zs[t] for t in order]), arr([xT[t] for t in order]), arr([got["gcur"][t] for t in order]),
+                  arr([got["gsp"][t] for t in order]), P(leak), P(thresh), B, H, W, 10.0, P(got["gv"]), P(got["rows"][:, :32]),
+                  P(got["rows"][:, 32:]), P(got["slab"]), 0 | (row_ld << 8))
+        torch.cuda.synchronize()
+        for t in range(npass):
+            assert torch.equal(ref["gcur"][t], got["gcur"][t]), (top, "g_cur", t)
+            assert torch.equal(ref["gsp"][t], got["gsp"][t]), (top, "g_split", t)
+        assert torch.equal(ref["gv"], got["gv"]) and float(ref["gv"].abs().max()) > 0
+        for name in ("slab", "rows"):
+            assert _rel(got[name].sum(0), ref[name].sum(0)) < 2e-5, (top, name, _rel(got[name].sum(0), ref[name].sum(0)))
+
+
 def _check_window(ref, got, npass):
     torch.cuda.synchronize()
     for t in range(npass):
