@@ -190,6 +190,10 @@ struct EvfDgProd {
   const void* g;   // fp32 gradient [B,H,W,32] (k_dgrad_diag_ws) / its three bf16 planes [term][B,H,W,32] (k_dgrad_diag_dma)
   const void* wt;  // split transposed weights (evf_pack_conv_weight_b3t)
   float* gx;       // [B,H,W,32], written
+  // PLIF (k_dgrad_diag_dma only; NULL: none): the raw map dL/d(pooled activity) [B,H,W] and the layer's input spike words [B,H,W] --
+  // the product's output gets AvgPool3x3^T(gP) / 32 where the input spike is set (evf_plif_gp, `accumulate | 2` of evf_conv_dgrad_b3)
+  const float* gP;
+  const uint32_t* xb;
 };
 struct EvfDgProds {
   EvfDgProd p[EVF_DG_MAX_PROD];

@@ -282,9 +282,14 @@ struct WmTile {
   int prod, b, y0, x0;
   const char* g;  // the product's gradient planes / output: scalar loads at item_of time, outside the matrix phase (a load
   float* gx;      // from the argument table behind an MFMA would wait for lgkmcnt(0), i.e. for every operand read in flight)
+  const float* gP;     // PLIFT: the product's raw dL/d(pooled activity) map (NULL: no trace term) ...
+  const uint32_t* xb;  // ... and input spike words
 };
 
-template <bool FULL>  // FULL: H % 4 == 0 and W % 32 == 0 -- every output pixel of every tile exists, the stores need no test
+// PLIFT: products may carry the PLIF trace term (EvfDgProd.gP / .xb): the matrix wave requests the nine dL/dP values and the spike
+// word of its pixel a few MFMAs before it stores a line group and adds AvgPool3x3^T(gP) / 32 to the channels whose input spike is
+// set -- the expression of k_conv_dgrad_ws<.., PLIF, ..> (acc + term): the same bits.
+template <bool FULL, bool PLIFT = false>  // FULL: H % 4 == 0 and W % 32 == 0 -- every output pixel of every tile exists, the stores need no test
 __global__ __launch_bounds__(512) void k_dgrad_diag_dma(EvfDgProds P, unsigned plane_bytes, int H, int W, int ntx, int nty,
                                                         unsigned ntiles, unsigned total) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -322,6 +327,7 @@ __global__ __launch_bounds__(512) void k_dgrad_diag_dma(EvfDgProds P, unsigned p
     t.prod = __builtin_amdgcn_readfirstlane((int)pr), t.x0 = __builtin_amdgcn_readfirstlane((int)tx * 32);
     t.b = __builtin_amdgcn_readfirstlane((int)b), t.y0 = __builtin_amdgcn_readfirstlane((int)ty * WD_ROWS);
     t.g = (const char*)P.p[t.prod].g, t.gx = P.p[t.prod].gx;
+    if (PLIFT) t.gP = P.p[t.prod].gP, t.xb = P.p[t.prod].xb;
   };
   auto load_weights4 = [&](const uint4* src) {  // the four loader waves
     for (int u = wv - 4; u < WD_NFRAG; u += 4)
@@ -381,10 +387,25 @@ __global__ __launch_bounds__(512) void k_dgrad_diag_dma(EvfDgProds P, unsigned p
     const int p = 8 * r + (lane >> 3), c4 = (lane & 7) * 4;
     ev[r] = *(const float4*)(st + p * WD_SP + c4);
   };
+  float gpv[9];  // PLIFT: the 3 x 3 neighbourhood of dL/dP of this lane's pixel of the line group about to be stored ...
+  uint32_t xbv = 0u;  // ... and its input spike word
+  auto plif_load = [&](int r, const WmTile& t) {
+    if (PLIFT && t.gP) {  // (block-uniform; clamped addresses: partial tiles read in-image values they never store)
+      const int p = 8 * r + (lane >> 3);
+      const int y = min(t.y0 + wv, H - 1), x = min(t.x0 + p, W - 1);
+      evf_plif_gp_load(t.gP, 1, t.b, y, x, H, W, gpv);
+      xbv = t.xb[((long)t.b * H + y) * W + x];
+    }
+  };
   auto epi_store = [&](int r, const WmTile& t) {
     const int y = t.y0 + wv;
     const int p = 8 * r + (lane >> 3), c4 = (lane & 7) * 4;
     float* dst = t.gx + ((unsigned)((t.b * H + y) * W + t.x0 + p) * (unsigned)C32 + (unsigned)c4);
+    if (PLIFT && t.gP) {
+      const float pv = evf_plif_gp_sum(1, min(y, H - 1), min(t.x0 + p, W - 1), H, W, gpv);
+      const uint32_t xq = xbv >> c4;
+      ev[r].x += (xq & 1u) ? pv : 0.f, ev[r].y += (xq & 2u) ? pv : 0.f, ev[r].z += (xq & 4u) ? pv : 0.f, ev[r].w += (xq & 8u) ? pv : 0.f;
+    }
     if (FULL || (y < H && t.x0 + p < W)) evf_store_nt(dst, ev[r]);
   };
   // Two teams, SEPARATE loops with the same barrier sequence (one per item, one more at a product boundary):
@@ -471,6 +492,7 @@ __global__ __launch_bounds__(512) void k_dgrad_diag_dma(EvfDgProds P, unsigned p
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (slot == 13 + r) epi_read(r);
+            if (PLIFT && slot == 32 + 12 * r) plif_load(r, prv);
             if (slot == 40 + 12 * r) epi_store(r, prv);
           }
         }
@@ -483,7 +505,10 @@ __global__ __launch_bounds__(512) void k_dgrad_diag_dma(EvfDgProds P, unsigned p
 #pragma unroll
         for (int r = 0; r < 4; ++r) epi_read(r);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) epi_store(r, cur);
+        for (int r = 0; r < 4; ++r) {
+          plif_load(r, cur);
+          epi_store(r, cur);
+        }
         __builtin_amdgcn_wave_barrier();
       }
       acc_prev = acc;
@@ -507,7 +532,10 @@ __global__ __launch_bounds__(512) void k_dgrad_diag_dma(EvfDgProds P, unsigned p
 #pragma unroll
       for (int r = 0; r < 4; ++r) epi_read(r);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) epi_store(r, prv);
+      for (int r = 0; r < 4; ++r) {
+        plif_load(r, prv);
+        epi_store(r, prv);
+      }
     }
   }
   WM_STAMP();
@@ -790,13 +818,18 @@ int evf_dgrad_diag_dma_launch(const EvfDgProds& P, int nprod, int B, int H, int 
     attr = true;
   }
   const int nblk = (int)(total < ncu ? total : ncu);
+  bool plift = false;
+  for (int k = 0; k < nprod; ++k) {
+    plift = plift || P.p[k].gP != nullptr;
+    if (P.p[k].gP && !P.p[k].xb) return EVF_EINVAL;
+  }
   // default: k_dgrad_diag_dma (every tile's six halo rows loaded, items row by row); EVF_DGRAD_RING=1 / evf_dgrad_diag_select(2):
   // k_dgrad_diag_ring -- measured 76.3-78.7 against 72.4-73.6 us per launch at 128 x 128 x B8 (see the kernel's header)
   static const bool ring_env = []() {
     const char* e = getenv("EVF_DGRAD_RING");
     return e && e[0] == '1';
   }();
-  const bool ring = evf_dgrad_ring_select < 0 ? ring_env : evf_dgrad_ring_select == 1;
+  const bool ring = !plift && (evf_dgrad_ring_select < 0 ? ring_env : evf_dgrad_ring_select == 1);
   if (ring) {
     static bool rattr = false;
     if (!rattr) {
@@ -809,6 +842,21 @@ int evf_dgrad_diag_dma_launch(const EvfDgProds& P, int nprod, int B, int H, int 
                          ntx, nty, (unsigned)ntiles, (unsigned)total);
     else
       hipLaunchKernelGGL(k_dgrad_diag_ring<false>, dim3(nblk), dim3(512), WR_LDS, EVF_STREAM(stream), P, (unsigned)plane_bytes, H, W,
+                         ntx, nty, (unsigned)ntiles, (unsigned)total);
+    return evf_status();
+  }
+  if (plift) {  // (a product with the PLIF trace term: the epilogue's own instantiation, so that the LIF kernel stays what it is)
+    static bool pattr = false;
+    if (!pattr) {
+      (void)hipFuncSetAttribute((const void*)k_dgrad_diag_dma<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WM_LDS);
+      (void)hipFuncSetAttribute((const void*)k_dgrad_diag_dma<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WM_LDS);
+      pattr = true;
+    }
+    if (H % WD_ROWS == 0 && W % 32 == 0)
+      hipLaunchKernelGGL((k_dgrad_diag_dma<true, true>), dim3(nblk), dim3(512), WM_LDS, EVF_STREAM(stream), P, (unsigned)plane_bytes, H, W,
+                         ntx, nty, (unsigned)ntiles, (unsigned)total);
+    else
+      hipLaunchKernelGGL((k_dgrad_diag_dma<false, true>), dim3(nblk), dim3(512), WM_LDS, EVF_STREAM(stream), P, (unsigned)plane_bytes, H, W,
                          ntx, nty, (unsigned)ntiles, (unsigned)total);
     return evf_status();
   }
@@ -843,4 +891,25 @@ int evf_dgrad_diag_ws_launch(const EvfDgProds& P, int nprod, int B, int H, int W
   hipLaunchKernelGGL(k_dgrad_diag_ws, dim3(nblk), dim3(512), WD_LDS, EVF_STREAM(stream), P, H, W, ntx, nty, (unsigned)ntiles,
                      (unsigned)total);
   return evf_status();
+}
+
+// Input gradients of up to 16 products (gradient planes, weight set, output) in ONE persistent launch (k_dgrad_diag_dma), straight
+// from the caller instead of through a backward recording: host arrays of nprod device pointers.  g_split[k]: the three bf16 planes
+// [term][B,H,W,32] of dL/d(current) (what the fused backward kernels write); g_x[k] [B,H,W,32] is WRITTEN (no accumulation);
+// g_P_raw / x_bits (arrays may be NULL, entries may be NULL): the PLIF trace term of that product (evf_conv_dgrad_b3 with
+// `accumulate | 2`).  Bit-identical to one evf_conv_dgrad_b3 call per product.
+extern "C" int evf_conv_dgrad_b3_multi(int nprod, const void* const* g_split, const void* const* wT_b3, void* const* g_x,
+                                       const void* const* g_P_raw, const void* const* x_bits, int B, int H, int W, void* stream) {
+  if (nprod <= 0 || nprod > EVF_DG_MAX_PROD || !g_split || !wT_b3 || !g_x) return EVF_EINVAL;
+  if (!evf_dgrad_diag_fits(1, B, H, W)) return EVF_ENOTSUP;
+  EvfDgProds P;
+  for (int k = 0; k < EVF_DG_MAX_PROD; ++k) {
+    const int q = k < nprod ? k : 0;
+    if (!g_split[q] || !wT_b3[q] || !g_x[q]) return EVF_EINVAL;
+    const float* gp = g_P_raw ? (const float*)g_P_raw[q] : nullptr;
+    const uint32_t* xb = x_bits ? (const uint32_t*)x_bits[q] : nullptr;
+    if ((gp != nullptr) != (xb != nullptr)) return EVF_EINVAL;
+    P.p[k] = EvfDgProd{g_split[q], wT_b3[q], (float*)g_x[q], gp, xb};
+  }
+  return evf_dgrad_diag_dma_launch(P, nprod, B, H, W, stream);
 }

@@ -326,6 +326,13 @@ int evf_conv_dgrad_b3_f32(const float* g_cur, const void* wT_b3, float* g_x, int
 int evf_conv_dgrad_b3_pair(const void* g_split, const void* wT_b3, float* g_x, int accumulate,
                            const void* wT2_b3, float* g_x2, int B, int H, int W,
                            const float* g_P, const uint32_t* x_bits, void* stream);
+/* Input gradients of nprod <= 16 products (gradient planes, weight set, output) in ONE persistent launch (k_dgrad_diag_dma),
+ * straight from the caller instead of through a backward recording: host arrays of device pointers.  g_split[k]: the three bf16
+ * planes of dL/d(current) (as evf_conv_dgrad_b3); g_x[k] is WRITTEN; g_P_raw / x_bits (the arrays or single entries may be NULL):
+ * the PLIF trace term of product k from the RAW map (evf_conv_dgrad_b3 with `accumulate | 2`).  Bit-identical to one
+ * evf_conv_dgrad_b3 call per product.  EVF_ENOTSUP: the shape does not fit the persistent kernel's index arithmetic. */
+int evf_conv_dgrad_b3_multi(int nprod, const void* const* g_split, const void* const* wT_b3, void* const* g_x,
+                            const void* const* g_P_raw, const void* const* x_bits, int B, int H, int W, void* stream);
 /* Which kernel serves evf_conv_dgrad_b3_f32[_pair] (results are bit-identical): -1 chosen by shape (default), 0 the
  * one-phase-after-the-other LDS kernel, 1 the wave-specialised one (producer / consumer waves, double-buffered planes).
  * Process-wide; for A/B measurements and the equivalence test. */

@@ -757,6 +757,32 @@ def test_lif_hidden_cell_backward_of_a_window_in_one_launch(shape):
             assert _rel(got[name].sum(0), ref[name].sum(0)) < 2e-5, (top, name, _rel(got[name].sum(0), ref[name].sum(0)))
 
 
+@pytest.mark.parametrize("shape", [(8, 128, 128), (2, 33, 70), (4, 260, 346)])
+def test_input_gradients_of_a_product_list_in_one_launch(shape):
+    """evf_conv_dgrad_b3_multi (up to 16 products through k_dgrad_diag_dma in one launch, some with the PLIF trace term from the raw
+    dL/dP map) against one evf_conv_dgrad_b3 call per product (k_conv_dgrad_ws, `accumulate | 2` for the trace term): bit for bit."""
+    import ctypes
+
+    B, H, W = shape
+    torch.manual_seed(41)
+    L = _lib.load()
+    n = 7
+    packs = [_packs()[1] for _ in range(3)]
+    gsp = [(_f(3, B, H, W, C, scale=0.1)).to(torch.bfloat16) for _ in range(n)]
+    gP = [_f(B, H, W, scale=0.3) if k % 3 != 2 else None for k in range(n)]
+    xb = [_bits(B, H, W, rate=0.3) if gP[k] is not None else None for k in range(n)]
+    ref = [torch.full((B, H, W, C), 7.0, device=DEV) for _ in range(n)]
+    got = [torch.full((B, H, W, C), 9.0, device=DEV) for _ in range(n)]
+    for k in range(n):
+        _lib.call("evf_conv_dgrad_b3", P(gsp[k]), P(packs[k % 3]), P(ref[k]), 2 if gP[k] is not None else 0, B, H, W, P(gP[k]), P(xb[k]))
+    arr = lambda ts: (ctypes.c_void_p * n)(*[P(x) for x in ts])  # noqa: E731
+    _lib.call("evf_conv_dgrad_b3_multi", n, arr(gsp), arr([packs[k % 3] for k in range(n)]), arr(got), arr(gP), arr(xb), B, H, W)
+    torch.cuda.synchronize()
+    for k in range(n):
+        assert float(ref[k].abs().max()) > 0 and torch.equal(ref[k], got[k]), k
+    assert L.evf_conv_dgrad_b3_multi(17, arr(gsp), arr(gsp), arr(got), None, None, B, H, W, _lib.stream_ptr()) == -22
+
+
 def _check_window(ref, got, npass):
     torch.cuda.synchronize()
     for t in range(npass):
