@@ -85,9 +85,10 @@ NETWORK_SIGNATURES = {
     "evf_memset": [P, I, ctypes.c_size_t, P],
     "evf_plif_bwd_wgrad2": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P],
     "evf_conv_dgrad_b3_multi": [I, P, P, P, P, P, I, I, I, P],
+    "evf_conv_dgrad_b3_multi_fits": [I, I, I],
     "evf_lif_bwd_wgrad_window": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, P, P, P, I, P],
-    "evf_plif_bwd_wgrad_window_top": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, P, P, P, P, P, P, I, P],
-    "evf_plif_bwd_wgrad_window": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, P, P, P, P, P, P, I, P],
+    "evf_plif_bwd_wgrad_window_top": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, P, P, P, P, P, P, I, P],
+    "evf_plif_bwd_wgrad_window": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, P, P, P, P, P, P, I, P],
     "evf_plif_bwd_wgrad_top": [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, P, P, P, P, P, I,
                                P, P, P, P, P, P, P, P, P, P],
     "evf_pack_conv_weight_b3t": [P, I, I, P, P],

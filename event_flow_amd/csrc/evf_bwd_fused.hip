@@ -1937,13 +1937,13 @@ static int fb_window_launch(int np, const void* const* g_z, const void* const* f
   const bool top = flow != nullptr, plif = leak_pt != nullptr;
   if (np < 1 || np > FB_WIN_MAX || (!top && !g_z) || !v_out || !v_prev || !z_prev || !xT || (!g_cur && !g_split) || !leak || !thresh ||
       !g_leak || !g_thresh || !slab_ff || B <= 0 || H <= 0 || W <= 0 || (top && (!g_flow || !z_out || !pred_w || !d_pred_w || !d_pred_b)) ||
-      (plif && (!pt_prev || !P || !g_P_raw || !add_pt || !g_leak_pt || !g_add_pt || !g_cur)))
+      (plif && (!pt_prev || !P || !g_P_raw || !add_pt || !g_leak_pt || !g_add_pt)))
     return EVF_EINVAL;
   FbWin Wn;
   Wn.np = np;
   for (int s = 0; s < FB_WIN_MAX; ++s) {
     const int q = s < np ? s : 0;
-    if (!v_out[q] || !xT[q] || (plif && (!g_cur[q] || !P[q] || !g_P_raw[q])) || (top && (!flow[q] || !g_flow[q] || !z_out[q])) ||
+    if (!v_out[q] || !xT[q] || (plif && (!P[q] || !g_P_raw[q])) || (top && (!flow[q] || !g_flow[q] || !z_out[q])) ||
         !((g_cur && g_cur[q]) || (g_split && g_split[q])))
       return EVF_EINVAL;
     Wn.gz[s] = top ? nullptr : (const float4*)g_z[q];
@@ -1986,13 +1986,13 @@ static int fb_window_launch(int np, const void* const* g_z, const void* const* f
 }
 
 extern "C" int evf_plif_bwd_wgrad_window(int np, const void* const* g_z, const void* const* v_out, const void* const* v_prev,
-                                         const void* const* z_prev, const void* const* xT, void* const* g_cur,
+                                         const void* const* z_prev, const void* const* xT, void* const* g_cur, void* const* g_split,
                                          const void* const* pt_prev, const void* const* P, void* const* g_P_raw, const float* leak,
                                          const float* thresh, const float* leak_pt, const float* add_pt, int B, int H, int W,
                                          float act_width, float* g_v_prev, float* g_pt_prev, float* g_leak, float* g_thresh,
                                          float* g_leak_pt, float* g_add_pt, float* slab_ff, int accumulate, void* stream) {
   if (!leak_pt) return EVF_EINVAL;
-  return fb_window_launch(np, g_z, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, v_out, v_prev, z_prev, xT, g_cur, nullptr, pt_prev,
+  return fb_window_launch(np, g_z, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, v_out, v_prev, z_prev, xT, g_cur, g_split, pt_prev,
                           P, g_P_raw, leak, thresh, leak_pt, add_pt, B, H, W, act_width, g_v_prev, g_pt_prev, g_leak, g_thresh, g_leak_pt,
                           g_add_pt, slab_ff, accumulate, stream);
 }
@@ -2001,13 +2001,13 @@ extern "C" int evf_plif_bwd_wgrad_window(int np, const void* const* g_z, const v
 extern "C" int evf_plif_bwd_wgrad_window_top(int np, const void* const* flow, const void* const* g_flow, const float* pred_w,
                                              const void* const* z_out, float* d_pred_w, float* d_pred_b, const void* const* v_out,
                                              const void* const* v_prev, const void* const* z_prev, const void* const* xT,
-                                             void* const* g_cur, const void* const* pt_prev, const void* const* P,
+                                             void* const* g_cur, void* const* g_split, const void* const* pt_prev, const void* const* P,
                                              void* const* g_P_raw, const float* leak, const float* thresh, const float* leak_pt,
                                              const float* add_pt, int B, int H, int W, float act_width, float* g_v_prev,
                                              float* g_pt_prev, float* g_leak, float* g_thresh, float* g_leak_pt, float* g_add_pt,
                                              float* slab_ff, int accumulate, void* stream) {
   if (!flow || !leak_pt) return EVF_EINVAL;
-  return fb_window_launch(np, nullptr, flow, g_flow, z_out, pred_w, d_pred_w, d_pred_b, v_out, v_prev, z_prev, xT, g_cur, nullptr, pt_prev, P,
+  return fb_window_launch(np, nullptr, flow, g_flow, z_out, pred_w, d_pred_w, d_pred_b, v_out, v_prev, z_prev, xT, g_cur, g_split, pt_prev, P,
                           g_P_raw, leak, thresh, leak_pt, add_pt, B, H, W, act_width, g_v_prev, g_pt_prev, g_leak, g_thresh, g_leak_pt,
                           g_add_pt, slab_ff, accumulate, stream);
 }

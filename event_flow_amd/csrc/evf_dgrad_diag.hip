@@ -913,3 +913,4 @@ extern "C" int evf_conv_dgrad_b3_multi(int nprod, const void* const* g_split, co
   }
   return evf_dgrad_diag_dma_launch(P, nprod, B, H, W, stream);
 }
+extern "C" int evf_conv_dgrad_b3_multi_fits(int B, int H, int W) { return evf_dgrad_diag_fits(1, B, H, W) ? 1 : 0; }

@@ -57,6 +57,11 @@ PLIF_TRACE_FUSED = os.environ.get("EVF_PLIF_TRACE_FUSED", "1") != "0"
 # registers (evf_plif_bwd_wgrad_window: 640 instead of 1152 bytes per pixel and pass); recurrent layers and the layer under the
 # prediction head pass by pass, the head layer's window last.  0: pass by pass (every cell a launch)
 PLIF_LAYER_MAJOR = os.environ.get("EVF_PLIF_LAYER_MAJOR", "1") != "0"
+# ... its input gradients: "ws" (default) = one k_conv_dgrad_ws launch per product from the fp32 dL/d(current); "dma" = from the
+# pre-split planes through k_dgrad_diag_dma, a layer's passes (a recurrent cell's two products) per launch (evf_conv_dgrad_b3_multi)
+# -- measured SLOWER for PLIF (12.4 against 11.3 ms per step): the trace term's ten loads per pixel sit in the matrix waves' issue
+# stream there (59 against 47 us per product; without the term the kernel runs 43)
+PLIF_LM_DGRAD = os.environ.get("EVF_PLIF_LM_DGRAD", "ws")
 # window gradients -> the flat gradient buffer in one launch (evf_grads_finalize); 0: row sums, slab reduction, segment add one by one
 FUSED_TAIL = os.environ.get("EVF_FUSED_TAIL", "1") != "0"
 PARAM_ROWS = os.environ.get("EVF_PARAM_ROWS", "1") != "0"  # per-channel gradients through per-block rows (0: atomics)  # ff + rec input gradients of a recurrent cell in one launch
@@ -566,12 +571,12 @@ class FireNetEngine:
             self._backward_pass(win, tape, g_flow, is_first)
             win.bwd_k += 1
 
-    def _lm_buf(self, key, shape, dev):
+    def _lm_buf(self, key, shape, dev, dtype=torch.float32):
         """Persistent scratch of the layer-major backward (per-pass gradient maps: reused by every window of this shape)."""
         d = self.__dict__.setdefault("_lm_bufs", {})
         k = (key, tuple(shape), str(dev))
         if k not in d:
-            d[k] = _f32(shape, dev)
+            d[k] = torch.empty(shape, dtype=dtype, device=dev)
         return d[k]
 
     def _backward_window_lm(self, win):
@@ -588,9 +593,17 @@ class FireNetEngine:
         nsl = L.evf_lif_bwd_wgrad_slabs(B, H, W)
         shp = (B, H, W, C)
         gz = lambda i, s_: self._lm_buf(("gz", i, s_), shp, dev)  # noqa: E731  dL/d(spikes) of layer i at pass s
-        gcur = [self._lm_buf(("gcur", s_), shp, dev) for s_ in range(T)]  # dL/d(current) of the layer in work, per pass
+        # dL/d(current) of the layer in work, per pass: as its three bf16 planes (k_dgrad_diag_dma) or as the fp32 tensor (k_conv_dgrad_ws)
+        split = PLIF_LM_DGRAD != "ws" and L.evf_conv_dgrad_b3_multi_fits(B, H, W) == 1
+        if split:
+            gsp = [self._lm_buf(("gsp", s_), (3, B, H, W, C), dev, torch.bfloat16) for s_ in range(T)]
+            gcur = [None] * T
+        else:
+            gsp = [None] * T
+            gcur = [self._lm_buf(("gcur", s_), shp, dev) for s_ in range(T)]
         gPs = [self._lm_buf(("gP", s_), (B, H, W), dev) for s_ in range(T)]
-        arr = lambda ts: (ctypes.c_void_p * T)(*[_lib.ptr(t) for t in ts])  # noqa: E731
+        arr = lambda ts: (ctypes.c_void_p * len(ts))(*[_lib.ptr(t) for t in ts])  # noqa: E731
+        arr_n = lambda ts: arr(ts) if ts[0] is not None else None  # noqa: E731
         rowp = lambda name: _lib.ptr(self._rowed(win, name)[0])  # noqa: E731
         row_ld = win.rows.shape[1]
         for i in range(n - 1, 0, -1):
@@ -604,19 +617,24 @@ class FireNetEngine:
             if i == n - 1:  # under the prediction head: its backward inside, all passes in one launch
                 _lib.call("evf_plif_bwd_wgrad_window_top", T, arr([tp["flow"] for tp in tapes]), arr(gflows), _lib.ptr(self._flat["pred.w"]),
                           arr([l_[4] for l_ in lay]), rowp("pred.w"), rowp("pred.b"), arr([l_[3] for l_ in lay]), arr([l_[1] for l_ in lay]),
-                          arr([l_[2] for l_ in lay]), arr([l_[5] for l_ in lay]), arr(gcur), arr([l_[7] for l_ in lay]),
+                          arr([l_[2] for l_ in lay]), arr([l_[5] for l_ in lay]), arr_n(gcur), arr_n(gsp), arr([l_[7] for l_ in lay]),
                           arr([l_[9] for l_ in lay]), arr(gPs), leak, thr, lpt, apt, B, H, W, width, None, None, rowp(f"{i}.leak"),
                           rowp(f"{i}.thresh"), rowp(f"{i}.leak_pt"), rowp(f"{i}.add_pt"), _lib.ptr(self._slab(kf, nsl, dev)),
                           (1 if win.slab_init.get(kf) else 0) | (row_ld << 8))
                 win.slab_init[kf] = True
             elif not c.recurrent:  # feed-forward: all passes in one launch, the carries in registers
                 _lib.call("evf_plif_bwd_wgrad_window", T, arr([gz(i, s_) for s_ in range(T)]), arr([l_[3] for l_ in lay]),
-                          arr([l_[1] for l_ in lay]), arr([l_[2] for l_ in lay]), arr([l_[5] for l_ in lay]), arr(gcur),
+                          arr([l_[1] for l_ in lay]), arr([l_[2] for l_ in lay]), arr([l_[5] for l_ in lay]), arr_n(gcur), arr_n(gsp),
                           arr([l_[7] for l_ in lay]), arr([l_[9] for l_ in lay]), arr(gPs), leak, thr, lpt, apt, B, H, W, width, None, None,
                           rowp(f"{i}.leak"), rowp(f"{i}.thresh"), rowp(f"{i}.leak_pt"), rowp(f"{i}.add_pt"),
                           _lib.ptr(self._slab(kf, nsl, dev)), (1 if win.slab_init.get(kf) else 0) | (row_ld << 8))
                 win.slab_init[kf] = True
-            if not c.recurrent:  # input gradients of all passes (the pooling's adjoint of dL/dP inside: accumulate | 2)
+            if not c.recurrent and split:  # input gradients of all passes in one launch (the pooling's adjoint of dL/dP inside)
+                wts = [self._packed[(i, "ff", "b3t")]] * T
+                _lib.call("evf_conv_dgrad_b3_multi", T, arr(gsp), arr(wts), arr([gz(i - 1, s_) for s_ in range(T)]), arr(gPs),
+                          arr([l_[0] for l_ in lay]), B, H, W)
+                continue
+            if not c.recurrent:  # ... or one launch per pass (accumulate | 2: the pooling's adjoint inside)
                 for s_ in range(T):
                     _lib.call("evf_conv_dgrad_b3_f32", _lib.ptr(gcur[s_]), _lib.ptr(self._packed[(i, "ff", "b3t")]), _lib.ptr(gz(i - 1, s_)),
                               2, B, H, W, _lib.ptr(gPs[s_]), _lib.ptr(lay[s_][0]))
@@ -632,7 +650,7 @@ class FireNetEngine:
                     _lib.zero_(self._slab(kr, nsl, dev))  # (first recurrent contribution later than the feed-forward one)
                 _lib.call("evf_plif_bwd_wgrad2", _lib.ptr(gz(i, s_)), _lib.ptr(gzr_i) if has_gzr else None, _lib.ptr(gv_i) if s_ else None,
                           _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None,
-                          leak, thr, B, H, W, 1, SURROGATE_ID[c.activation], width, _lib.ptr(gcur[s_]), None, _lib.ptr(gv_i),
+                          leak, thr, B, H, W, 1, SURROGATE_ID[c.activation], width, _lib.ptr(gcur[s_]), _lib.ptr(gsp[s_]), _lib.ptr(gv_i),
                           rowp(f"{i}.leak"), rowp(f"{i}.thresh"), _lib.ptr(self._slab(kf, nsl, dev)),
                           _lib.ptr(self._slab(kr, nsl, dev)) if use_rec else None, acc | (row_ld << 8),
                           _lib.ptr(gpt_i) if s_ else None, _lib.ptr(pt_prev), _lib.ptr(P_sav), lpt, apt, _lib.ptr(gpt_i), _lib.ptr(gPs[s_]),
@@ -641,7 +659,13 @@ class FireNetEngine:
                 if use_rec:
                     win.slab_init[kr] = True
                 rec_grad = use_rec and not firsts[s_]
-                if rec_grad:
+                if split:  # both products of the pass (feed-forward: with the trace term; recurrent: to the cell's own previous spikes)
+                    np_ = 2 if rec_grad else 1
+                    a2 = lambda ts: (ctypes.c_void_p * np_)(*[_lib.ptr(t) for t in ts[:np_]])  # noqa: E731
+                    _lib.call("evf_conv_dgrad_b3_multi", np_, a2([gsp[s_], gsp[s_]]),
+                              a2([self._packed[(i, "ff", "b3t")], self._packed[(i, "rec", "b3t")]]), a2([gz(i - 1, s_), gzr_i]),
+                              a2([gPs[s_], None]), a2([in_bits, None]), B, H, W)
+                elif rec_grad:
                     _lib.call("evf_conv_dgrad_b3_f32_pair", _lib.ptr(gcur[s_]), _lib.ptr(self._packed[(i, "ff", "b3t")]),
                               _lib.ptr(gz(i - 1, s_)), 2, _lib.ptr(self._packed[(i, "rec", "b3t")]), _lib.ptr(gzr_i), B, H, W,
                               _lib.ptr(gPs[s_]), _lib.ptr(in_bits))

@@ -333,6 +333,7 @@ int evf_conv_dgrad_b3_pair(const void* g_split, const void* wT_b3, float* g_x, i
  * evf_conv_dgrad_b3 call per product.  EVF_ENOTSUP: the shape does not fit the persistent kernel's index arithmetic. */
 int evf_conv_dgrad_b3_multi(int nprod, const void* const* g_split, const void* const* wT_b3, void* const* g_x,
                             const void* const* g_P_raw, const void* const* x_bits, int B, int H, int W, void* stream);
+int evf_conv_dgrad_b3_multi_fits(int B, int H, int W); /* 1: the shape fits, 0: EVF_ENOTSUP */
 /* Which kernel serves evf_conv_dgrad_b3_f32[_pair] (results are bit-identical): -1 chosen by shape (default), 0 the
  * one-phase-after-the-other LDS kernel, 1 the wave-specialised one (producer / consumer waves, double-buffered planes).
  * Process-wide; for A/B measurements and the equivalence test. */
@@ -424,11 +425,12 @@ int evf_lif_bwd_wgrad_window(int np, const void* const* g_z, const void* const* 
  * compute, with dL/dv and dL/d(pt) carried in registers from pass to pass and every potential read once -- 640 instead of 1152
  * bytes per pixel and pass.  Host arrays of np <= 16 device pointers, index 0 = the window's LAST pass (backward order); per pass:
  * g_z (may be NULL), v_out (only v_out[0] is read: v_out[s] = v_prev[s - 1]), v_prev (NULL: zero state), z_prev (NULL: none), xT,
- * pt_prev (NULL: zero), P; outputs per pass: g_cur, g_P_raw.  The carries start at zero behind the last pass; g_v_prev /
+ * pt_prev (NULL: zero), P; outputs per pass: g_cur (fp32) and / or g_split (its three bf16 planes: evf_conv_dgrad_b3[_multi]; either
+ * array may be NULL), g_P_raw.  The carries start at zero behind the last pass; g_v_prev /
  * g_pt_prev (may be NULL) receive the gradients on the state entering the window.  Same arithmetic per element as the one-pass
  * form (bit-identical g_cur / g_P_raw / carries); slab and per-channel sums in another order.  Default neuron only. */
 int evf_plif_bwd_wgrad_window(int np, const void* const* g_z, const void* const* v_out, const void* const* v_prev,
-                              const void* const* z_prev, const void* const* xT, void* const* g_cur,
+                              const void* const* z_prev, const void* const* xT, void* const* g_cur, void* const* g_split,
                               const void* const* pt_prev, const void* const* P, void* const* g_P_raw, const float* leak,
                               const float* thresh, const float* leak_pt, const float* add_pt, int B, int H, int W,
                               float act_width, float* g_v_prev, float* g_pt_prev, float* g_leak, float* g_thresh,
@@ -438,7 +440,7 @@ int evf_plif_bwd_wgrad_window(int np, const void* const* g_z, const void* const*
 int evf_plif_bwd_wgrad_window_top(int np, const void* const* flow, const void* const* g_flow, const float* pred_w,
                                   const void* const* z_out, float* d_pred_w, float* d_pred_b, const void* const* v_out,
                                   const void* const* v_prev, const void* const* z_prev, const void* const* xT,
-                                  void* const* g_cur, const void* const* pt_prev, const void* const* P,
+                                  void* const* g_cur, void* const* g_split, const void* const* pt_prev, const void* const* P,
                                   void* const* g_P_raw, const float* leak, const float* thresh, const float* leak_pt,
                                   const float* add_pt, int B, int H, int W, float act_width, float* g_v_prev,
                                   float* g_pt_prev, float* g_leak, float* g_thresh, float* g_leak_pt, float* g_add_pt,

@@ -658,7 +658,7 @@ def test_plif_hidden_cell_backward_of_a_window_in_one_launch(shape):
         order = list(range(npass - 1, -1, -1))  # index 0 = the last pass
         arr = lambda ts: (ctypes.c_void_p * npass)(*[P(x) for x in ts])  # noqa: E731
         _lib.call("evf_plif_bwd_wgrad_window", npass, arr([gzs[t] for t in order]), arr([vs[t + 1] for t in order]),
-                  arr([vs[t] for t in order]), arr([zs[t] for t in order]), arr([xT[t] for t in order]), arr([o["gcur"][t] for t in order]),
+                  arr([vs[t] for t in order]), arr([zs[t] for t in order]), arr([xT[t] for t in order]), arr([o["gcur"][t] for t in order]), None,
                   arr([pts[t] for t in order]), arr([Ps[t] for t in order]), arr([o["gP"][t] for t in order]), P(leak), P(thresh), P(lpt),
                   P(apt), B, H, W, 10.0, P(o["gv"]), P(o["gpt"]), P(o["rows"][:, :32]), P(o["rows"][:, 32:]), P(o["rows"][:, 64:]),
                   P(o["rows"][:, 96:]), P(o["slab"]), 0 | (row_ld << 8))
@@ -687,7 +687,7 @@ def test_plif_hidden_cell_backward_of_a_window_in_one_launch(shape):
         arr = lambda ts: (ctypes.c_void_p * npass)(*[P(x) for x in ts])  # noqa: E731
         _lib.call("evf_plif_bwd_wgrad_window_top", npass, arr([flows[t] for t in order]), arr([gfl[t] for t in order]), P(pw),
                   arr([zo[t] for t in order]), P(o["rows"][:, 128:]), P(o["rows"][:, 192:]), arr([vs[t + 1] for t in order]),
-                  arr([vs[t] for t in order]), arr([zs[t] for t in order]), arr([xT[t] for t in order]), arr([o["gcur"][t] for t in order]),
+                  arr([vs[t] for t in order]), arr([zs[t] for t in order]), arr([xT[t] for t in order]), arr([o["gcur"][t] for t in order]), None,
                   arr([pts[t] for t in order]), arr([Ps[t] for t in order]), arr([o["gP"][t] for t in order]), P(leak), P(thresh), P(lpt),
                   P(apt), B, H, W, 10.0, P(o["gv"]), P(o["gpt"]), P(o["rows"][:, :32]), P(o["rows"][:, 32:]), P(o["rows"][:, 64:]),
                   P(o["rows"][:, 96:]), P(o["slab"]), 0 | (row_ld << 8))

@@ -44,7 +44,7 @@ arr = lambda ts: (ctypes.c_void_p * T)(*[P(x) for x in ts])  # noqa: E731
 
 def window():
     _lib.call("evf_plif_bwd_wgrad_window", T, arr([gzs[t] for t in order]), arr([vs[t + 1] for t in order]), arr([vs[t] for t in order]),
-              arr([zs[t] for t in order]), arr([xT[t] for t in order]), arr([gcur[t] for t in order]), arr([pts[t] for t in order]),
+              arr([zs[t] for t in order]), arr([xT[t] for t in order]), arr([gcur[t] for t in order]), None, arr([pts[t] for t in order]),
               arr([Ps[t] for t in order]), arr([gP[t] for t in order]), P(leak), P(thresh), P(lpt), P(apt), B, H, W, 10.0, P(gv), P(gpt),
               P(rows[:, :32]), P(rows[:, 32:]), P(rows[:, 64:]), P(rows[:, 96:]), P(slab), 1 | (row_ld << 8))
 
