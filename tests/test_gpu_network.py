@@ -1208,6 +1208,12 @@ def test_plif_cells_recorded_on_diagonals_are_bit_identical(monkeypatch):
     np.testing.assert_allclose(l4, l1, rtol=1e-6)
     ga, gb = grads["lm"][0], grads["pp"][0]
     assert float(gb.abs().max()) > 0 and float((ga - gb).norm() / gb.norm()) < 2e-6
+    # ... with its input gradients from pre-split planes through k_dgrad_diag_dma, a layer's passes per launch
+    monkeypatch.setattr(heng2, "PLIF_LM_DGRAD", "dma")
+    run(True, "lm_dma")
+    monkeypatch.setattr(heng2, "PLIF_LM_DGRAD", "ws")
+    # (two runs of one setting differ in the last bits already: the loss backward accumulates with float atomics)
+    assert grads["lm_dma"][1] and float((grads["lm_dma"][0] - grads["lm"][0]).norm() / grads["lm"][0].norm()) < 2e-6
     # a window of 18 passes (more than a window launch holds: the passes that waited are replayed pass by pass, in order)
     def run_long(lm):
         monkeypatch.setattr(heng2, "PLIF_LAYER_MAJOR", lm)
