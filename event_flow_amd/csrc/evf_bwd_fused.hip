@@ -1499,7 +1499,7 @@ void evf_prof_mark(int kind, int end, void* stream) {
 }
 // evf_defer_profile(1): time every dispatcher launch of the following flushes; evf_defer_profile_read: device sync, then
 // ms[k] = summed duration and count[k] = number of launches of kind k < 8 (0 k_fwd_diag, 1 k_bwd_diag, 2 k_dgrad_diag, 3 head
-// backward pass by pass, 4 k_head_lif_fwd_win, 5 k_head_bwd_win, 7 an EMPTY bracket = the bracket's own cost) since it was
+// backward pass by pass, 4 k_head_lif_fwd_win, 5 k_head_bwd_win, 6 k_fwd_win_t, 7 an EMPTY bracket = the bracket's own cost) since it was
 // switched on (event-bracket overhead included: ~1.6 us per launch); switches it off.
 // evf_defer_profile(2): the same brackets while the step is CAPTURED into a hipGraph -- a one-thread timestamp kernel in front
 // of and behind every dispatcher launch (and one empty bracket per forward flush, kind 7); evf_defer_profile(0) after the

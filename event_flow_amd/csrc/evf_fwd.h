@@ -70,3 +70,25 @@ struct FwJobs {
 // evf_fwd_teams.hip: the n (<= FW_MAX_JOBS) default-neuron cells of one index as ONE persistent launch of matrix + element-wise
 // wave teams; all cells of one reset rule.
 int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* stream);
+
+// ---- the passes of a window of ONE feed-forward layer in one launch (k_fwd_win_t, evf_fwd_teams.hip) ----------------------------
+// Cells recorded under one index that form a CHAIN (cell k + 1 starts from cell k's state, same weights, no recurrent conv) are a
+// window: the first cell carries weights, parameters and the state before the window, the table the per-pass operands.
+#define FW_WIN_MAX 16
+struct FwWinTab {
+  int np, pad_;
+  const uint32_t* x[FW_WIN_MAX];
+  float* v_out[FW_WIN_MAX];
+  uint32_t* z_out[FW_WIN_MAX];
+  uint32_t* zT_out[FW_WIN_MAX];
+  float* flow[FW_WIN_MAX];    // prediction head in the epilogue (cell 0's pr.w != NULL), else unused
+  float* pt_out[FW_WIN_MAX];  // PLIF
+  float* P_out[FW_WIN_MAX];   // PLIF
+};
+struct FwWinNone {};
+struct FwJob1 {
+  FwJob j[1];
+};
+// 1: the n cells are such a chain (n >= 2)
+int evf_fwd_win_is_chain(const FwJob* cells, int n);
+int evf_fwd_win_t_launch(const FwJob* cells, int n, int B, int H, int W, void* stream);

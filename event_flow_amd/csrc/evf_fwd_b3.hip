@@ -601,13 +601,15 @@ __global__ __launch_bounds__(FP_THREADS) void k_fwd_diag_p(FwJobs jobs, FpPlan p
 }
 
 #define FW_MAX_DIAGS 96
+#define FW_SLOT_JOBS FW_WIN_MAX  // cells an index holds: up to FW_MAX_JOBS independent ones per launch, or a chain of a feed-forward
+                                 // layer's passes (evf_fwd_win_is_chain: one k_fwd_win_t launch)
 // (one recorder per recording context = per stream, evf_common.h)
 struct FwDefer {
   bool active = false;
   int slot = 0;
   int B = 0, H = 0, W = 0;
   int n[FW_MAX_DIAGS] = {0};
-  FwJob job[FW_MAX_DIAGS][FW_MAX_JOBS];
+  FwJob job[FW_MAX_DIAGS][FW_SLOT_JOBS];
 };
 static FwDefer fw_tab[EVF_CTX_MAX];
 
@@ -660,10 +662,27 @@ static int fw_defer_launch(FwDefer& fw_defer, void* stream) {
     evf_prof_mark(7, 1, stream);
   }
   for (int d = 0; d < FW_MAX_DIAGS; ++d) {
-    const int n = fw_defer.n[d];
-    if (!n) continue;
+    const int ntot = fw_defer.n[d];
+    if (!ntot) continue;
+    if (evf_fwd_win_is_chain(fw_defer.job[d], ntot)) {  // the passes of a feed-forward layer: one launch, state in registers
+      evf_prof_mark(6, 0, stream);
+      const int rc = evf_fwd_win_t_launch(fw_defer.job[d], ntot, fw_defer.B, fw_defer.H, fw_defer.W, stream);
+      evf_prof_mark(6, 1, stream);
+      if (rc) return rc;
+      fw_defer.n[d] = 0;
+      continue;
+    }
+    // cells under one index that are neither independent nor one chain (a window interrupted by a state reset, a chain longer
+    // than a launch holds): one launch per cell, in the order recorded
+    bool dependent = false;
+    for (int k = 0; k < ntot && !dependent; ++k)
+      for (int j = 0; j < ntot; ++j)
+        if (j != k && fw_defer.job[d][k].v_prev && fw_defer.job[d][k].v_prev == fw_defer.job[d][j].v_out) dependent = true;
+    const int per_launch = dependent ? 1 : FW_MAX_JOBS;
+    for (int k0 = 0; k0 < ntot; k0 += per_launch) {  // (more than FW_MAX_JOBS independent cells under one index: several launches)
+    const int n = ntot - k0 < per_launch ? ntot - k0 : per_launch;
     FwJobs jobs;
-    for (int k = 0; k < FW_MAX_JOBS; ++k) jobs.j[k] = fw_defer.job[d][k < n ? k : 0];
+    for (int k = 0; k < FW_MAX_JOBS; ++k) jobs.j[k] = fw_defer.job[d][k0 + (k < n ? k : 0)];
     int nhard = 0, nplif = 0;
     for (int k = 0; k < n; ++k) nhard += jobs.j[k].hard_reset ? 1 : 0, nplif += jobs.j[k].leak_pt ? 1 : 0;
     evf_prof_mark(0, 0, stream);
@@ -702,6 +721,7 @@ static int fw_defer_launch(FwDefer& fw_defer, void* stream) {
       hipLaunchKernelGGL(k_fwd_diag, grid, block, lds, EVF_STREAM(stream), jobs, fw_defer.B, fw_defer.H, fw_defer.W);
     }
     evf_prof_mark(0, 1, stream);
+    }
     fw_defer.n[d] = 0;
   }
   return evf_status();
@@ -768,7 +788,7 @@ static int launch_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_re
       const int rc = fw_defer_launch(fw_defer, stream);
       if (rc) return rc;
     }
-    if (fw_defer.n[fw_defer.slot] == FW_MAX_JOBS) {  // (cannot happen with one cell per layer and <= 8 layers)
+    if (fw_defer.n[fw_defer.slot] == FW_SLOT_JOBS) {  // (the caller opens a new recording before an index overflows)
       const int rc = fw_defer_launch(fw_defer, stream);
       if (rc) return rc;
     }

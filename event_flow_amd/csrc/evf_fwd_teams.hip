@@ -55,6 +55,8 @@ struct FtPlan {
   int nquads;     // per cell: rounds of four strips
   int weight[FW_MAX_JOBS];  // relative cost of a round of the cell
   int total;      // sum of nquads * weight
+  int ilv;        // k_fwd_win_t: 1 = a block's rounds of strips are blockIdx + k * gridDim (at any moment the blocks write ONE
+                  // contiguous region of a pass's tape), 0 = a contiguous range per block
 };
 
 #ifdef FT_STAMPS  // phase stamps (debug build -DFT_STAMPS=<cells> through EVF_LIB; launches of that many cells): [blocks 0, 80, 160, 240][wave][128] shader-clock values
@@ -75,8 +77,16 @@ extern "C" int evf_debug_ft_stamps(void* dst) { return evf_hip(hipMemcpyFromSymb
 // its halo words (mean_c |x| = popcount / 32, AvgPool3x3 over the zero-padded halo) into a tile beside the accumulators, team E
 // reads the previous trace like the previous potential, updates it, subtracts sigma(add_pt) * pt' from the current and stores
 // pt' and the pooled activity (the backward's operands).  Same expressions as fwd_b3_body<.., true>: bit-identical.
-template <bool HARD, bool FULL, bool PLIF>
-__global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan plan, int B, int H, int W) {
+//
+// WIN (k_fwd_win_t): ONE feed-forward layer, the passes of a window back to back -- the iteration space is (round of four strips,
+// pass) with the pass running fastest.  A feed-forward cell (t, l) needs layer l - 1 at pass t (an earlier launch) and its OWN
+// pixels' state at t - 1 only, so team E keeps potential, trace and the pixel's previous spikes in REGISTERS from one pass to the
+// next (the register set the diagonal form loads every round is loaded once per round of strips, two rounds of strips ahead) and
+// writes the tape only: per pixel and pass 128 (+128 + 4 PLIF) bytes written and the 4-byte input words read, instead of the
+// potential (+ trace) read back as well.  Team M is the diagonal form's with the halo source and the pass advancing per round.
+// Same expressions in the same order: bit-identical to the cells launched one by one.
+template <bool HARD, bool FULL, bool PLIF, bool WIN, class JOBS, class WT>
+__device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, const int B, const int H, const int W, const WT& wt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* s_lut = (uint4*)(smem + FT_OFF_LUT);
   uint4* s_wff = (uint4*)(smem + FT_OFF_WFF);
@@ -108,9 +118,14 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
     cell0 += cw;
     int i0 = a0 <= 0 ? 0 : (int)((a0 + wgt - 1) / wgt), i1 = a1 <= 0 ? 0 : (int)((a1 + wgt - 1) / wgt);
     i0 = min(i0, plan.nquads), i1 = min(i1, plan.nquads);
+    // round of strips number k of this block (k in [i0, i1)) as an index of the cell's rounds
+    const bool ilv = WIN && plan.ilv != 0;
+    if (ilv) i0 = 0, i1 = ((int)blockIdx.x < plan.nquads) ? (plan.nquads - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int q_mul = ilv ? (int)gridDim.x : 1, q_add = ilv ? (int)blockIdx.x : 0;
+    auto qa = [&](int k) { return q_add + k * q_mul; };
     if (i0 >= i1) continue;  // (block-uniform)
     const FwJob& J = jobs.j[c];
-    const bool rec = J.wrec != nullptr;
+    const bool rec = !WIN && J.wrec != nullptr;
     // A feed-forward cell leaves the recurrent weights' 54 KiB unused: its tiles alternate between FT_OFF_ACC and that region,
     // so team M may run TWO rounds ahead of team E (with one tile per strip the two teams took turns waiting for each other:
     // phase stamps showed team M 3-6 k cycles per round at the `empty` poll although team E idles half of its round).
@@ -135,7 +150,9 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     FT_STAMP();
-    const int n = i1 - i0;  // rounds of this cell in this block; round r: team M strips 4 (i0 + r) + 0..3, team E those of round r - 1
+    int NP = 1;  // WIN: passes of the window (round r = (round of strips r / NP, pass r % NP))
+    if constexpr (WIN) NP = wt.np;
+    const int n = (i1 - i0) * NP;  // rounds of this cell in this block; round r: team M strips 4 (i0 + r) + 0..3, team E those of round r - 1
     const uint32_t* __restrict__ x = J.x;
     const uint32_t* __restrict__ z_prev = J.z_prev;
     const float* __restrict__ v_prev = J.v_prev;
@@ -178,11 +195,12 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
       // launch's pace (phase stamps).
       int gtx, gyy, gb;
       {
-        const int sk = min(4 * i0 + wv, nstrips - 1);
+        const int sk = min(4 * qa(i0) + wv, nstrips - 1);
         gtx = sk % plan.ntx;
         const int rr = sk / plan.ntx;
         gyy = rr % plan.nyy, gb = rr / plan.nyy;
       }
+      int gq = i0;  // WIN: the round of strips the request stream is at
       auto geom_adv = [&]() {
         gtx += 4;
         const int c = (gtx >= plan.ntx ? 1 : 0) + (gtx >= 2 * plan.ntx ? 1 : 0) + (gtx >= 3 * plan.ntx ? 1 : 0) + (gtx >= 4 * plan.ntx ? 1 : 0);
@@ -190,20 +208,43 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
         const int d = (gyy >= plan.nyy ? 1 : 0) + (gyy >= 2 * plan.nyy ? 1 : 0) + (gyy >= 3 * plan.nyy ? 1 : 0) + (gyy >= 4 * plan.nyy ? 1 : 0);
         gyy -= d * plan.nyy, gb += d;
       };
+      const uint32_t* __restrict__ xf = x;  // the input words the next halo request reads (WIN: those of pass ft)
+      int ft = 0, mq = 0, mt = 0;            // WIN: pass of the next request; round of strips / pass of the round in work
+      if constexpr (WIN) xf = wt.x[0];
       auto halo_fetch_q = [&](int q) {
         const int y0 = 2 * gyy, x0 = gtx * TW, b = min(gb, B - 1);
         const int ya = y0 + hro[q] - 1, xa = x0 + hco[q] - 1;
         hin[q] = ya >= 0 && ya < H && xa >= 0 && xa < W;
         const long p = ((long)b * H + min(max(ya, 0), H - 1)) * W + min(max(xa, 0), W - 1);
-        hx[q] = x[p], hz[q] = zsrc[p];
+        hx[q] = xf[p];
+        if constexpr (WIN) hz[q] = 0u; else hz[q] = zsrc[p];
+      };
+      auto round_adv = [&]() {  // the request stream's next round: WIN = the same strips at the next pass, the next strips after the last
+        if constexpr (WIN) {
+          ft = ft + 1 < NP ? ft + 1 : 0;
+          xf = wt.x[ft];
+          if (ft != 0) return;
+          if (ilv) {  // (two divisions per NP rounds)
+            ++gq;
+            const int sk = min(4 * qa(gq) + wv, nstrips - 1);
+            gtx = sk % plan.ntx;
+            const int rr = sk / plan.ntx;
+            gyy = rr % plan.nyy, gb = rr / plan.nyy;
+            return;
+          }
+        }
+        geom_adv();
       };
 #pragma unroll
       for (int q = 0; q < 3; ++q) halo_fetch_q(q);
-      geom_adv();
+      round_adv();
       const unsigned fl_full = FT_OFF_FLAG + 4 * wv, fl_empty = FT_OFF_FLAG + 16 + 8 * wv;  // (LDS byte addresses; `empty`: one counter per row's wave)
       for (int r = 0; r < n; ++r) {
         FT_STAMP();
-        const bool valid = 4 * (i0 + r) + wv < nstrips;  // (wave-uniform)
+        const bool valid = 4 * qa(i0 + (WIN ? mq : r)) + wv < nstrips;  // (wave-uniform)
+        if constexpr (WIN) {
+          if (++mt == NP) mt = 0, ++mq;
+        }
         // ---- commit the strip's halo words: per pixel two words = the table ADDRESSES (byte << 4) of its four channel
         // bytes, [kg][K half m] -- the matrix phase reads one word per (row, tap) and needs one vector instruction per look-up
 #pragma unroll
@@ -212,7 +253,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
           const uint32_t wx = hin[q] ? hx[q] : 0u, wz = (hin[q] && z_prev) ? hz[q] : 0u;
           if (l < FT_HW) {
             *(uint2*)(s_hx + 2 * l) = make_uint2((wx & 0x00FF00FFu) << 4, ((wx >> 8) & 0x00FF00FFu) << 4);
-            *(uint2*)(s_hz + 2 * l) = make_uint2((wz & 0x00FF00FFu) << 4, ((wz >> 8) & 0x00FF00FFu) << 4);
+            if constexpr (!WIN) *(uint2*)(s_hz + 2 * l) = make_uint2((wz & 0x00FF00FFu) << 4, ((wz >> 8) & 0x00FF00FFu) << 4);
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -289,7 +330,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
 #pragma unroll
           for (int q = 0; q < 3; ++q) halo_fetch_q(q);
         }
-        geom_adv();
+        round_adv();
         FT_STAMP();
         // ---- the tile this round's buffer held before (round r - depth) must have been read by both of team E's waves
         // (one counter per wave: with their sum and two tiles in flight, a wave two reads ahead would cover for the other one)
@@ -382,7 +423,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
       // sets (requested one round ahead the loads had ~0.3 of a round to land and the epilogue waited for them: 8.5 k cycles per
       // round against 7.3 k of MFMAs, phase stamps)
       auto e_fetch = [&](int qd, float4 (&vp)[4], uint32_t (&zq)[4], float4 (&pq)[PLIF ? 4 : 1]) {
-        const int sk = min(4 * qd + sidx, nstrips - 1);
+        const int sk = min(4 * qa(qd) + sidx, nstrips - 1);
         int b, row, tx;
         geom(sk, b, row, tx);
         const long pb = ((long)b * H + (FULL ? row : min(row, H - 1))) * W + tx * TW;
@@ -412,9 +453,21 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
         }
       };
       const unsigned fl_full = FT_OFF_FLAG + 4 * sidx, fl_empty = FT_OFF_FLAG + 16 + 8 * sidx + 4 * m;  // (LDS byte addresses)
-      auto e_round = [&](int r, float4 (&vp)[4], uint32_t (&zq)[4], float4 (&pq)[PLIF ? 4 : 1]) {  // the epilogue of round r's strips (r = 0 .. n - 1)
+      // the epilogue of round r's strips (r = 0 .. n - 1); WIN: round of strips rq, pass t (r = rq * NP + t), and the state of
+      // the pass stays in the register set for the next one
+      auto e_round = [&](int r, int rq, int t, float4 (&vp)[4], uint32_t (&zq)[4], float4 (&pq)[PLIF ? 4 : 1]) {
         FT_STAMP();
-        const int si = 4 * (i0 + r) + sidx;
+        float* __restrict__ v_out_r = v_out;
+        uint32_t* __restrict__ z_out_r = z_out;
+        uint32_t* __restrict__ zT_out_r = zT_out;
+        float* __restrict__ flow_out_r = flow_out;
+        float* __restrict__ pt_out_r = pt_out;
+        float* __restrict__ P_out_r = P_out;
+        if constexpr (WIN) {
+          v_out_r = wt.v_out[t], z_out_r = wt.z_out[t], zT_out_r = wt.zT_out[t], flow_out_r = wt.flow[t];
+          if constexpr (PLIF) pt_out_r = wt.pt_out[t], P_out_r = wt.P_out[t];
+        }
+        const int si = 4 * qa(i0 + rq) + sidx;
         const bool valid = si < nstrips;  // (wave-uniform)
         int b, row, tx;
         geom(min(si, nstrips - 1), b, row, tx);
@@ -493,7 +546,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
             // uniform base.  Same products and sums in the same order as the general form below.
             typedef float f2 __attribute__((ext_vector_type(2)));
             const f2 lam01 = {lam[0], lam[1]}, lam23 = {lam[2], lam[3]}, oml01 = {oml[0], oml[1]}, oml23 = {oml[2], oml[3]};
-            float* vo_base = v_out + pb * C32;
+            float* vo_base = v_out_r + pb * C32;
             const unsigned st_off = (unsigned)(p8 * C32 + c4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -519,6 +572,63 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
               asm volatile("" ::"v"(o01.x), "v"(o01.y), "v"(o23.x), "v"(o23.y));
 #endif
               uint32_t w = nib << c4;
+              if constexpr (WIN) vp[k] = make_float4(o01.x, o01.y, o23.x, o23.y), zq[k] = w;  // (the lane's own four channels of the word)
+              w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+              w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+              w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x114, 0xF, 0xF, true);  // row_shr:4
+              wk[k] = w;
+            }
+          } else if (HARD && PLIF) {
+            // The PLIF cell with the hard reset in the same form: team E's vector instructions, not the bytes, set the pace of a
+            // PLIF round (phase stamps of the window form: ~6 k cycles in this loop against 5 k of MFMAs) -- packed fp32 pairs for
+            // the trace, the current and the potential, (1 - z) as a bit pattern (two instructions instead of convert + subtract),
+            // the spike nibble by compare + add-with-carry.  Same products and sums in the same order as the general form below.
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 lam01 = {lamL[0], lamL[1]}, lam23 = {lamL[2], lamL[3]}, oml01 = {omlL[0], omlL[1]}, oml23 = {omlL[2], omlL[3]};
+            const f2 lpt01 = {lptL[0], lptL[1]}, lpt23 = {lptL[2], lptL[3]}, apt01 = {aptL[0], aptL[1]}, apt23 = {aptL[2], aptL[3]};
+            const f2 olp01 = {1.0f - lptL[0], 1.0f - lptL[1]}, olp23 = {1.0f - lptL[2], 1.0f - lptL[3]};
+            float* vo_base = v_out_r + pb * C32;
+            float* po_base = pt_out_r + pb * C32;
+            const unsigned st_off = (unsigned)(p8 * C32 + c4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const bool ok = FULL || (rowok && x0 + p8 + 8 * k < W);
+              const uint32_t nzn = ~(zw[k] >> c4);  // 1 - z = 1.0f where the previous spike bit is clear
+              const f2 z01 = {__uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)nzn, 0, 1) & 0x3F800000u),
+                              __uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)nzn, 1, 1) & 0x3F800000u)};
+              const f2 z23 = {__uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)nzn, 2, 1) & 0x3F800000u),
+                              __uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)nzn, 3, 1) & 0x3F800000u)};
+              const f2 P2 = {Pk[k], Pk[k]};
+              const f2 pp01 = {pq[PLIF ? k : 0].x, pq[PLIF ? k : 0].y}, pp23 = {pq[PLIF ? k : 0].z, pq[PLIF ? k : 0].w};
+              const f2 po01 = pp01 * lpt01 + olp01 * P2, po23 = pp23 * lpt23 + olp23 * P2;  // evf_plif_trace, :212 / :642
+              const f2 a01 = {a4[k].x, a4[k].y}, a23 = {a4[k].z, a4[k].w};
+              const f2 c01 = a01 - apt01 * po01, c23 = a23 - apt23 * po23;                   // (ff + rec) - add_pt * pt_out, :220 / :650
+              const f2 v01 = {vp[k].x, vp[k].y}, v23 = {vp[k].z, vp[k].w};
+              const f2 o01 = (v01 * lam01) * z01 + oml01 * c01;                             // :119/:544
+              const f2 o23 = (v23 * lam23) * z23 + oml23 * c23;
+              uint32_t nib = 0u;
+              asm volatile(
+                  "v_cmp_gt_f32 vcc, %1, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                  "v_cmp_gt_f32 vcc, %2, %6\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                  "v_cmp_gt_f32 vcc, %3, %7\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                  "v_cmp_gt_f32 vcc, %4, %8\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                  : "+v"(nib)
+                  : "v"(o23.y), "v"(o23.x), "v"(o01.y), "v"(o01.x), "v"(thL[3]), "v"(thL[2]), "v"(thL[1]), "v"(thL[0])
+                  : "vcc");
+              if (!FULL) nib = ok ? nib : 0u;
+#ifndef FT_PROBE_NOSTORE
+              if (ok) {
+                evf_store_nt(vo_base + st_off + k * (8 * C32), make_float4(o01.x, o01.y, o23.x, o23.y));
+                evf_store_nt(po_base + st_off + k * (8 * C32), make_float4(po01.x, po01.y, po23.x, po23.y));
+              }
+#else
+              asm volatile("" ::"v"(o01.x), "v"(o01.y), "v"(o23.x), "v"(o23.y), "v"(po01.x), "v"(po01.y), "v"(po23.x), "v"(po23.y));
+#endif
+              uint32_t w = nib << c4;
+              if constexpr (WIN) {  // the next pass's previous state (the lane's own four channels of the word)
+                vp[k] = make_float4(o01.x, o01.y, o23.x, o23.y), zq[k] = w;
+                pq[PLIF ? k : 0] = make_float4(po01.x, po01.y, po23.x, po23.y);
+              }
               w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
               w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
               w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x114, 0xF, 0xF, true);  // row_shr:4
@@ -552,13 +662,17 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
                 nib |= (spike ? 1u : 0u) << q;
               }
 #ifndef FT_PROBE_NOSTORE
-              if (ok) evf_store_nt(v_out + (pb + p) * C32 + c4, make_float4(vo4[0], vo4[1], vo4[2], vo4[3]));
-              if (PLIF && ok) evf_store_nt(pt_out + (pb + p) * C32 + c4, make_float4(po4[0], po4[1], po4[2], po4[3]));
+              if (ok) evf_store_nt(v_out_r + (pb + p) * C32 + c4, make_float4(vo4[0], vo4[1], vo4[2], vo4[3]));
+              if (PLIF && ok) evf_store_nt(pt_out_r + (pb + p) * C32 + c4, make_float4(po4[0], po4[1], po4[2], po4[3]));
 #else  // (probe build: the new potential is computed and dropped)
               asm volatile("" ::"v"(vo4[0]), "v"(vo4[1]), "v"(vo4[2]), "v"(vo4[3]));
 #endif
               // the pixel's word = OR of its 8 lanes' nibbles: complete in lanes 4..7 of the group after three DPP steps
               uint32_t w = nib << c4;
+              if constexpr (WIN) {  // the next pass's previous state (the lane's own four channels of the word)
+                vp[k] = make_float4(vo4[0], vo4[1], vo4[2], vo4[3]), zq[k] = w;
+                if constexpr (PLIF) pq[k] = make_float4(po4[0], po4[1], po4[2], po4[3]);
+              }
               w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
               w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
               w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x114, 0xF, 0xF, true);  // row_shr:4
@@ -569,8 +683,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
           const uint32_t word = kq == 0 ? wk[0] : kq == 1 ? wk[1] : kq == 2 ? wk[2] : wk[3];  // (publishing lanes: pixel vi)
           const bool okx = pub && rowok && (FULL || x0 + vi < W);
 #ifndef FT_PROBE_NOZOUT
-          if (okx) z_out[pb + vi] = word;
-          if (PLIF && okx) P_out[pb + vi] = Pvi;
+          if (okx) z_out_r[pb + vi] = word;
+          if (PLIF && okx) P_out_r[pb + vi] = Pvi;
 #else
           asm volatile("" ::"v"(word));
 #endif
@@ -589,15 +703,15 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
             }
             if (okx) {
               const long hw = (long)H * W, qq = (long)row * W + x0 + vi;
-              flow_out[(long)b * 2 * hw + qq] = tanhf(s0 + s_pw[2 * C32]);
-              flow_out[((long)b * 2 + 1) * hw + qq] = tanhf(s1 + s_pw[2 * C32 + 1]);
+              flow_out_r[(long)b * 2 * hw + qq] = tanhf(s0 + s_pw[2 * C32]);
+              flow_out_r[((long)b * 2 + 1) * hw + qq] = tanhf(s1 + s_pw[2 * C32 + 1]);
             }
           }
           FT_STAMP();
 #ifdef FT_PROBE_NOZT
           if (false) {
 #else
-          if (zT_out) {  // channel-major bit planes of the row = the transpose of its 32 words
+          if (zT_out_r) {  // channel-major bit planes of the row = the transpose of its 32 words
 #endif
             uint32_t a = word;
             uint32_t bf_keepL[5], bf_amtL[5];
@@ -629,14 +743,18 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
             }
             FT_BFLY(4, __builtin_amdgcn_update_dpp(0, (int)a, 0x128, 0xF, 0xF, true));  // row_ror:8
 #undef FT_BFLY
-            if (pub && rowok) zT_out[(((long)b * H + row) * C32 + vi) * nW + tx] = a;
+            if (pub && rowok) zT_out_r[(((long)b * H + row) * C32 + vi) * nW + tx] = a;
           }
         }
         FT_STAMP();
         // this register set's next use: round r + 2.  Unconditional (past the range: the last round again, never used) -- under
         // `if (r + 1 < n)` the compiler's counter bookkeeping at the join made round r + 1 wait for THESE loads as well
 #ifndef FT_PROBE_NOFETCH
-        e_fetch(min(i0 + r + 2, i1 - 1), vp, zq, pq);
+        if constexpr (WIN) {  // (the set's next use: the first pass of the round of strips after the next)
+          if (t == NP - 1) e_fetch(min(i0 + rq + 2, i1 - 1), vp, zq, pq);
+        } else {
+          e_fetch(min(i0 + r + 2, i1 - 1), vp, zq, pq);
+        }
 #endif
         FT_STAMP();
       };
@@ -644,14 +762,37 @@ __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan p
       uint32_t zqA[4], zqB[4];
       e_fetch(i0, vpA, zqA, pqA);
       e_fetch(min(i0 + 1, i1 - 1), vpB, zqB, pqB);
-      for (int r = 0; r < n; r += 2) {  // (unrolled by two: the register sets swap roles, no moves of loaded registers)
-        e_round(r, vpA, zqA, pqA);
-        if (r + 1 < n) e_round(r + 1, vpB, zqB, pqB);
+      if constexpr (WIN) {  // a round of strips keeps its register set for all its passes
+        const int nq = i1 - i0;
+        int r = 0;
+        for (int rq = 0; rq < nq; rq += 2) {
+#pragma unroll 1
+          for (int t = 0; t < NP; ++t, ++r) e_round(r, rq, t, vpA, zqA, pqA);
+          if (rq + 1 < nq) {
+#pragma unroll 1
+            for (int t = 0; t < NP; ++t, ++r) e_round(r, rq + 1, t, vpB, zqB, pqB);
+          }
+        }
+      } else {
+        for (int r = 0; r < n; r += 2) {  // (unrolled by two: the register sets swap roles, no moves of loaded registers)
+          e_round(r, r, 0, vpA, zqA, pqA);
+          if (r + 1 < n) e_round(r + 1, r + 1, 0, vpB, zqB, pqB);
+        }
       }
     }
     tile0 += n;
   }
   FT_STAMP();
+}
+
+template <bool HARD, bool FULL, bool PLIF>
+__global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan plan, int B, int H, int W) {
+  ft_body<HARD, FULL, PLIF, false>(jobs, plan, B, H, W, FwWinNone{});
+}
+
+template <bool HARD, bool FULL, bool PLIF>
+__global__ __launch_bounds__(FT_THREADS) void k_fwd_win_t(FwJob1 job, FwWinTab wt, FtPlan plan, int B, int H, int W) {
+  ft_body<HARD, FULL, PLIF, true>(job, plan, B, H, W, wt);
 }
 
 int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* stream) {
@@ -702,6 +843,7 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
   }
   if (total >= (1L << 31)) return EVF_EINVAL;
   plan.total = (int)total;
+  plan.ilv = 0;
   const long nq = (long)plan.nquads * n;
   const int nblk = (int)(nq / 2 < ncu ? (nq + 1) / 2 : ncu);  // (tiny launches: at least two rounds per block)
   const bool full = (H % 2 == 0) && (W % TW == 0);
@@ -714,6 +856,81 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
       hipLaunchKernelGGL((k_fwd_diag_t<HARD_, FULL_, false>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, jobs, plan, B, H, W); \
   } while (0)
   if (nhard) {
+    if (full) FT_GO(true, true); else FT_GO(true, false);
+  } else {
+    if (full) FT_GO(false, true); else FT_GO(false, false);
+  }
+#undef FT_GO
+  return evf_status();
+}
+
+int evf_fwd_win_is_chain(const FwJob* c, int n) {
+  if (n < 2 || n > FW_WIN_MAX) return 0;
+  if (c[0].wrec) return 0;
+  for (int k = 1; k < n; ++k) {
+    const FwJob &a = c[k - 1], &b = c[k];
+    if (b.wrec || b.wff != a.wff || b.leak != a.leak || b.thresh != a.thresh || b.hard_reset != a.hard_reset ||
+        b.leak_pt != a.leak_pt || b.add_pt != a.add_pt || b.pr.w != a.pr.w || b.pr.bias != a.pr.bias)
+      return 0;
+    if (b.v_prev != a.v_out || b.z_prev != a.z_out || b.pt_prev != a.pt_out) return 0;
+    if ((b.zT_out == nullptr) != (a.zT_out == nullptr)) return 0;
+  }
+  return 1;
+}
+
+// The chain `cells[0..n)` (evf_fwd_win_is_chain) as one launch: a block owns rounds of four strips and runs their n passes.
+int evf_fwd_win_t_launch(const FwJob* cells, int n, int B, int H, int W, void* stream) {
+  if (!cells || !evf_fwd_win_is_chain(cells, n) || B <= 0 || H <= 0 || W <= 0) return EVF_EINVAL;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+#define FT_ATTR(H_, F_, P_) \
+  (void)hipFuncSetAttribute((const void*)k_fwd_win_t<H_, F_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS)
+    FT_ATTR(true, true, false), FT_ATTR(true, false, false), FT_ATTR(false, true, false), FT_ATTR(false, false, false);
+    FT_ATTR(true, true, true), FT_ATTR(true, false, true), FT_ATTR(false, true, true), FT_ATTR(false, false, true);
+#undef FT_ATTR
+    attr_set = true;
+  }
+  FwJob1 job;
+  job.j[0] = cells[0];
+  FwWinTab wt;
+  wt.np = n, wt.pad_ = 0;
+  for (int k = 0; k < FW_WIN_MAX; ++k) {
+    const FwJob& c = cells[k < n ? k : n - 1];
+    wt.x[k] = c.x, wt.v_out[k] = c.v_out, wt.z_out[k] = c.z_out, wt.zT_out[k] = c.zT_out, wt.flow[k] = c.pr.flow;
+    wt.pt_out[k] = c.pt_out, wt.P_out[k] = c.P_out;
+  }
+  const bool plif = cells[0].leak_pt != nullptr, hard = cells[0].hard_reset != 0;
+  FtPlan plan;
+  plan.njobs = 1, plan.ntx = evf_cdiv(W, TW), plan.nyy = evf_cdiv(H, 2);
+  const long nstrips = (long)plan.ntx * plan.nyy * B;
+  if (nstrips >= (1L << 28)) return EVF_EINVAL;
+  plan.nstrips = (int)nstrips;
+  plan.nquads = evf_cdiv(nstrips, 4);
+  for (int k = 0; k < FW_MAX_JOBS; ++k) plan.weight[k] = 1;
+  plan.total = plan.nquads;
+  static const int ilv_env = []() {
+    const char* e = getenv("EVF_FWD_WIN_ILV");
+    return e ? atoi(e) : 1;
+  }();
+  plan.ilv = ilv_env;
+  const int nblk = plan.nquads < ncu ? plan.nquads : ncu;
+  const bool full = (H % 2 == 0) && (W % TW == 0);
+  hipStream_t st = EVF_STREAM(stream);
+#define FT_GO(HARD_, FULL_)                                                                                                     \
+  do {                                                                                                                          \
+    if (plif)                                                                                                                   \
+      hipLaunchKernelGGL((k_fwd_win_t<HARD_, FULL_, true>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, job, wt, plan, B, H, W);   \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((k_fwd_win_t<HARD_, FULL_, false>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, job, wt, plan, B, H, W);  \
+  } while (0)
+  if (hard) {
     if (full) FT_GO(true, true); else FT_GO(true, false);
   } else {
     if (full) FT_GO(false, true); else FT_GO(false, false);

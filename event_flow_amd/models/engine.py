@@ -62,6 +62,14 @@ PLIF_LAYER_MAJOR = os.environ.get("EVF_PLIF_LAYER_MAJOR", "1") != "0"
 # -- measured SLOWER for PLIF (12.4 against 11.3 ms per step): the trace term's ten loads per pixel sit in the matrix waves' issue
 # stream there (59 against 47 us per product; without the term the kernel runs 43)
 PLIF_LM_DGRAD = os.environ.get("EVF_PLIF_LM_DGRAD", "ws")
+# recorded FORWARD of a window LAYER by layer: a feed-forward hidden layer's passes are recorded under ONE index and launched as a
+# chain (k_fwd_win_t: potential, trace and previous spikes in registers across the passes, the tape is written only); recurrent
+# layers one pass per index.  "1": every hidden layer; "top": only the feed-forward layers above the last recurrent one (the
+# layers below stay on the diagonals); "0": diagonals (cell (t, l) under index t + l - 1); "auto": "1" when ONE cell's rounds of
+# strips fill the chip (>= FWD_LM_MIN_ROUNDS per CU-sized grid), else "0"
+FWD_LAYER_MAJOR = os.environ.get("EVF_FWD_LM", "auto")
+FWD_LM_MIN_QUADS = int(os.environ.get("EVF_FWD_LM_MIN_QUADS", "1024"))
+FWD_LM_PASSES = 16  # passes a recording holds in the layer-major forms (= FW_WIN_MAX, csrc/evf_fwd.h)
 # window gradients -> the flat gradient buffer in one launch (evf_grads_finalize); 0: row sums, slab reduction, segment add one by one
 FUSED_TAIL = os.environ.get("EVF_FUSED_TAIL", "1") != "0"
 PARAM_ROWS = os.environ.get("EVF_PARAM_ROWS", "1") != "0"  # per-channel gradients through per-block rows (0: atomics)  # ff + rec input gradients of a recurrent cell in one launch
@@ -437,6 +445,40 @@ class FireNetEngine:
         self._defer_stream = torch.cuda.current_stream()
         _lib.set_defer_hook(self.flush_forward, _lib._DEFER_SAFE_FWD, "fwd")
 
+    def _fwd_slots(self, B, H, W):
+        """Index plan of a recorded forward: None = diagonals (cell (t, l) under t + l - 1), else per layer (base, stride):
+        cell (t, l) is recorded under base + stride * t -- stride 0 = the layer's passes under one index (a chain, launched as one
+        k_fwd_win_t), stride 1 = a pass per index."""
+        mode = FWD_LAYER_MAJOR
+        if mode == "auto":
+            quads = (B * ((H + 1) // 2) * ((W + 31) // 32) + 3) // 4
+            mode = "1" if quads >= FWD_LM_MIN_QUADS else "0"
+        if mode not in ("1", "top"):
+            return None
+        key = (mode, tuple(c.recurrent for c in self.cells))
+        cache = self.__dict__.setdefault("_fwd_slot_cache", {})
+        if key not in cache:
+            n = len(self.cells)
+            last_rec = max([i for i, c in enumerate(self.cells) if c.recurrent], default=0)
+            plan, cur = [None] * n, 0
+            if mode == "top":  # layers up to the last recurrent one on diagonals, the rest as chains behind them
+                for i in range(1, last_rec + 1):
+                    plan[i] = (i - 1, 1)
+                cur = FWD_LM_PASSES + max(last_rec - 1, 0)
+                for i in range(last_rec + 1, n):
+                    plan[i] = (cur, 0)
+                    cur += 1
+            else:
+                for i in range(1, n):
+                    if self.cells[i].recurrent:
+                        plan[i] = (cur, 1)
+                        cur += FWD_LM_PASSES
+                    else:
+                        plan[i] = (cur, 0)
+                        cur += 1
+            cache[key] = plan if cur <= 96 else None
+        return cache[key]
+
     def _flow_out(self, B, H, W, dev):
         slot, self._flow_slot = self._flow_slot, None
         return slot if slot is not None else _f32((B, 2, H, W), dev)
@@ -463,13 +505,17 @@ class FireNetEngine:
         if not defer:
             self.flush_forward()  # (a pass outside the recorded schedule, e.g. under no_grad: what is recorded runs first)
         if defer:
-            if self.__dict__.get("_defer_open") and self._defer_t + len(self.cells) - 2 >= 96:
+            slots = self._fwd_slots(B, H, W)
+            if self.__dict__.get("_defer_open") and (self._defer_t + len(self.cells) - 2 >= 96 if slots is None
+                                                     else self._defer_t >= FWD_LM_PASSES):
                 self.flush_forward()
             if not self.__dict__.get("_defer_open"):
                 self._defer_begin()
         for i, c in enumerate(self.cells):
-            if defer and i > 0 and _lib.raw("evf_fwd_defer_slot", self._defer_t + i - 1) != 0:
-                raise _lib.EvflowError("evf_fwd_defer_slot failed")
+            if defer and i > 0:
+                d = self._defer_t + i - 1 if slots is None else slots[i][0] + slots[i][1] * self._defer_t
+                if _lib.raw("evf_fwd_defer_slot", d) != 0:
+                    raise _lib.EvflowError("evf_fwd_defer_slot failed")
             st = states[i]
             v_prev, z_prev, zT_prev = st[:3] if st is not None else (None, None, None)
             plif = self.kind == "plif"

@@ -1295,6 +1295,110 @@ def test_diagonal_launches_equal_cell_by_cell_launches(monkeypatch):
             assert np.mean(d > 2e-5) <= 0.02, (k, np.mean(d > 2e-5))
 
 
+@pytest.mark.parametrize("fix", ["g7_liffirenet_train", "g7_pliffirenet_train"])
+@pytest.mark.parametrize("mode", ["1", "top"])
+def test_layer_major_forward_is_bit_identical(monkeypatch, fix, mode):
+    """The recorded forward LAYER by layer (engine._fwd_slots, EVF_FWD_LM): the passes of a feed-forward hidden layer recorded
+    under one index and launched as a chain -- k_fwd_win_t: potential, trace and the pixel's previous spikes stay in team E's
+    registers from pass to pass, the tape is written only -- against the diagonal schedule (one launch per index t + l - 1, the
+    state read back every pass): flows of every pass, potentials, spike words and traces after the window BIT for bit, windows
+    of 4 passes, of 18 (more than a chain holds: the recording is launched and reopened) and a second window that starts from
+    the first one's state; a training window's loss and gradient like two runs of one schedule."""
+    from event_flow_amd import train as htrain
+    from event_flow_amd.models import engine as heng
+
+    g = load_golden(fix)
+    base = passes_from_golden(g)
+    H, W = base[0]["event_cnt"].shape[2:]
+
+    def forward_only(lm, reps):
+        monkeypatch.setattr(heng, "FWD_LAYER_MAJOR", lm)
+        model = build_from_golden(g, fix=fix)
+        model.train()
+        flows, states = [], []
+        for w in range(2):  # (the second window starts from the first one's final state)
+            model.defer_forward(True)
+            fl = [model(d["event_voxel"], d["event_cnt"])["flow"][0] for d in base * reps]
+            model.defer_forward(False)
+            assert _lib.raw("evf_fwd_defer_pending") == 0
+            flows += [N(f).copy() for f in fl]
+            states += [N(s).copy() for s in model.states]
+            model.detach_states()
+        return flows, states
+
+    for reps in (1, (18 + len(base) - 1) // len(base)):
+        (f0, s0), (f1, s1) = forward_only("0", reps), forward_only(mode, reps)
+        assert len(f0) == len(f1) and len(s0) == len(s1)
+        for a, b in zip(f0 + s0, f1 + s1):
+            assert np.array_equal(a, b)
+        assert max(float(np.abs(s).max()) for s in s1) > 0
+
+    def run(lm):
+        monkeypatch.setattr(heng, "FWD_LAYER_MAJOR", lm)
+        monkeypatch.setattr(htrain, "DEFER_FORWARD", True)
+        monkeypatch.setattr(htrain, "DEFER_BACKWARD", True)
+        model = build_from_golden(g, fix=fix)
+        model.train()
+        lossf = hloss.EventWarping(loss_cfg(H, W), DEV)
+        opt = FlatAdam(model, lr=2e-4, clip=100.0, device_step=False)
+        opt.zero_grad()
+        seen = []
+        real_step = opt.step
+        opt.step = lambda *a_, **k_: (seen.append(opt.flat_grad.detach().clone()), real_step(*a_, **k_))[1]
+        loss = htrain.train_window(model, lossf, opt, base)
+        torch.cuda.synchronize()
+        return float(loss), seen[0]
+
+    (l0, g0), (l1, g1) = run("0"), run(mode)
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    assert float(g0.abs().max()) > 0 and float((g1 - g0).norm() / g0.norm()) < 2e-6
+
+
+@pytest.mark.parametrize("cls_name", ["LIFFireNet", "PLIFFireNet"])
+@pytest.mark.parametrize("shape,hard", [((2, 18, 44), True), ((1, 7, 33), False), ((3, 32, 64), False), ((1, 64, 96), True)])
+def test_layer_major_forward_on_ragged_shapes_and_both_resets(monkeypatch, cls_name, shape, hard):
+    """k_fwd_win_t on partial strips (odd heights, widths that are no multiple of 32), whole ones, hard and soft reset, a network
+    made alive (thresholds x 0.3): flows of five passes and the final state bit for bit against the diagonal schedule."""
+    from event_flow_amd import train as htrain
+    from event_flow_amd.models import engine as heng
+
+    B, H, W = shape
+    n_ev, P = 40 * B * H * W // 64 + 50, 5
+    gen = torch.Generator().manual_seed(23)
+    lists = []
+    for _ in range(P):
+        ts = torch.sort(torch.rand(B, n_ev, generator=gen), dim=1).values
+        ys = torch.randint(0, H, (B, n_ev), generator=gen).float()
+        xs = torch.randint(0, W, (B, n_ev), generator=gen).float()
+        ps = torch.randint(0, 2, (B, n_ev), generator=gen).float() * 2 - 1
+        lists.append(torch.stack([ts, ys, xs, ps], dim=2).to(DEV))
+    passes = htrain.encode_passes(lists, 2, (H, W))
+    neuron = dict(NEURON if cls_name == "LIFFireNet" else FIXTURES["g7_pliffirenet_train"][1])
+    neuron["hard_reset"] = hard
+    cls = LIFFireNet if cls_name == "LIFFireNet" else PLIFFireNet
+
+    def forward_only(lm):
+        monkeypatch.setattr(heng, "FWD_LAYER_MAJOR", lm)
+        torch.manual_seed(4)
+        model = cls(model_cfg(neuron)).to(DEV)
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                if k.endswith("thresh"):
+                    p.mul_(0.3)
+        model.train()
+        model.defer_forward(True)
+        fl = [model(d["event_voxel"], d["event_cnt"])["flow"][0] for d in passes]
+        model.defer_forward(False)
+        return [N(f).copy() for f in fl], [N(s).copy() for s in model.states]
+
+    f0, s0 = forward_only("0")
+    assert sum(float(np.abs(s[1]).sum()) for s in s0) > 0  # (spikes in the final state: the network is alive)
+    for mode in ("1", "top"):
+        f1, s1 = forward_only(mode)
+        for a, b in zip(f0 + s0, f1 + s1):
+            assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("P", [1, 2, 50])
 def test_diagonal_launches_short_and_long_windows(monkeypatch, P):
     """Windows of 1 and 2 passes (diagonals of one cell) and of 50 passes (the backward index 2 (P - 1 - t) + step runs past
