@@ -288,7 +288,7 @@ _KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3_lds<false, false, false, fal
               "evf_conv_lif_fwd_b3/rec": "k_conv_lif_fwd_b3<true, false>", "evf_head_lif_fwd": "k_head_lif_fwd<1>",
               "k_head_lif_fwd_win": "k_head_lif_fwd_win<1, false, 8>", "k_head_bwd_win": "k_head_bwd_win<true, 4, false>",
               "evf_head_lif_bwd_wgrad": "k_head_bwd_mfma<true>", "evf_conv_dgrad/one": "k_conv_dgrad<false>",
-              "evf_conv_dgrad/two": "k_conv_dgrad<true>", "k_fwd_diag": "k_fwd_diag_t<true, true, false>", "k_bwd_diag": "k_bwd_diag_ws<8>",
+              "evf_conv_dgrad/two": "k_conv_dgrad<true>", "k_fwd_diag": "k_fwd_diag_t<true, true, false>", "k_fwd_win": "k_fwd_win_t<true, true, false>", "k_bwd_diag": "k_bwd_diag_ws<8>",
               "k_dgrad_diag": "k_dgrad_diag_dma<true, false>", "evf_conv_lif_fwd/ff": "k_conv_lif_fwd<false>",
               "evf_conv_lif_fwd/rec": "k_conv_lif_fwd<true>", "evf_conv_wgrad_bits": "k_conv_wgrad_bits"}
 
@@ -884,7 +884,7 @@ def main():
         raise RuntimeError("evf_defer_profile_read failed")
     prof_eager = {}
     for k, nm in enumerate([("k_fwd_diag", ""), ("k_bwd_diag", ""), ("k_dgrad_diag", ""), ("evf_head_lif_bwd_wgrad", ""),
-                            ("k_head_lif_fwd_win", ""), ("k_head_bwd_win", "")]):
+                            ("k_head_lif_fwd_win", ""), ("k_head_bwd_win", ""), ("k_fwd_win", "")]):
         if _cnt[k]:
             prof[nm] = [max(_ms[k] / _cnt[k] - _lib.last_event_overhead_ms, 0.0)] * _cnt[k]
             if gprof and "per_kind" in gprof and k in gprof["per_kind"]:
@@ -899,6 +899,7 @@ def main():
     loss_val = float(loss)
 
     model_precision = model.precision
+    _model_obj = model
     if dp.rank == 0:
         npix = (B_PER_GPU // nstream) * H * W  # pixels one LAUNCH covers (a micro-batch when the step is pipelined)
         # algorithmic work per launch: FLOP of the 3x3 32->32 contraction(s) and
@@ -949,7 +950,29 @@ def main():
         # diagonal launches: PASSES + 5 launches hold the window's cells; per LAUNCH = the window's total / (PASSES + 5)
         nl = PASSES + 5
         alt_bytes = {}
-        if diag_fwd:  # 6 hidden cells per pass (8 contractions: two recurrent cells), 272 B/px each, 280 under the prediction head
+        # the recorded forward layer by layer (engine._fwd_slots: shapes where one cell fills the chip, EVF_FWD_LM): recurrent
+        # layers one cell per launch, a feed-forward hidden layer's passes in ONE launch (k_fwd_win_t) that reads the input words
+        # and writes the tape only -- per pixel and pass 4 + 128 + 8 (PLIF: + 128 trace + 4 pooled activity), the state before
+        # the window once, the flow maps of the top layer (8 B per pass on one of the four layers)
+        _eng_obj = getattr((reps.models[0] if reps is not None else _model_obj), "_engine", None)
+        fwd_mode = _eng_obj._fwd_mode(B_PER_GPU // nstream, H, W) if (diag_fwd and _eng_obj is not None) else "0"
+        fwd_lm = fwd_mode == "1"
+        nl_f = nl  # launches that hold the diagonal cells of the forward
+        if diag_fwd and fwd_mode in ("1", "top"):
+            per_cell = 532 if plif_net else 272
+            per_pass = 272 if plif_net else 140
+            if fwd_lm:  # recurrent cells one per launch; four feed-forward layers as chains (the top one writes the flow maps: 8 B)
+                model[("k_fwd_diag", "")] = (2 * CONV_FLOP * npix, per_cell * npix)
+                per_pass += 2
+            else:  # "top": G1, R1a, R1b, G2 on P + 3 diagonals (6 contractions per pass), R2a and R2b (+ flow maps) as chains
+                nl_f = PASSES + 3
+                model[("k_fwd_diag", "")] = (6 * PASSES * CONV_FLOP * npix / nl_f, PASSES * 4 * per_cell * npix / nl_f)
+                per_pass += 4
+            model[("k_fwd_win", "")] = (PASSES * CONV_FLOP * npix, (PASSES * per_pass + (260 if plif_net else 132)) * npix)
+            hbm_bound |= {"k_fwd_diag", "k_fwd_win"}
+            bf16_terms["k_fwd_diag"] = 3
+            bf16_terms["k_fwd_win"] = 3
+        elif diag_fwd:  # 6 hidden cells per pass (8 contractions: two recurrent cells), 272 B/px each, 280 under the prediction head
             per_cell = 532 if plif_net else 272  # (PLIF: + trace in / out + pooled activity)
             model[("k_fwd_diag", "")] = (8 * PASSES * CONV_FLOP * npix / nl, PASSES * (5 * per_cell + per_cell + 8) * npix / nl)
             hbm_bound |= {"k_fwd_diag"}
@@ -1014,7 +1037,14 @@ def main():
             if diag_bwd and key[0] in alt_bytes and alt_bytes[key[0]] != model[key][1]:
                 ent["algorithmic_MB_fp32_layout"] = alt_bytes[key[0]] / 1e6
                 ent["frac_fp32_layout"] = alt_bytes[key[0]] / (ms.mean() * 1e-3) / 1e9 / HBM_PEAK
-            if key[0] in ("k_fwd_diag", "k_bwd_diag", "k_dgrad_diag"):
+            if key[0] == "k_fwd_diag" and fwd_lm:
+                ent["note"] = "forward layer by layer: a launch = ONE recurrent cell (k_fwd_diag_t); the feed-forward layers: k_fwd_win"
+            elif key[0] == "k_fwd_win":
+                ent["note"] = f"a feed-forward hidden layer's {PASSES} passes in one launch (k_fwd_win_t): state in registers, tape written only"
+            elif key[0] == "k_fwd_diag" and fwd_mode == "top":
+                ent["note"] = (f"diagonal launches: the {4 * PASSES} cells of the four hidden layers up to the last recurrent one in {nl_f} "
+                               "launches of 1..4 independent (pass, layer) cells; the two layers above them: k_fwd_win; per LAUNCH")
+            elif key[0] in ("k_fwd_diag", "k_bwd_diag", "k_dgrad_diag"):
                 ent["note"] = (f"diagonal launches: the window's {6 * PASSES} cells of this kind in {nl} launches of 1..6 independent "
                                "(pass, layer) cells; mean_us / algorithmic_MB are per LAUNCH (window total / launches)")
             kernels[name] = ent
@@ -1055,7 +1085,14 @@ def main():
                        "global_batch": B_PER_GPU * dp.world, "events_per_window": PASSES * EV_PER_PASS,
                        "parallelism": f"dp{dp.world}", "launch": mode, "loss": loss_val,
                        "streams": nstream,
-                       "forward_launches": ("diagonal: the window's hidden forward cells in P + 5 launches (k_fwd_diag, cells "
+                       "forward_launches": ("layer by layer: recurrent hidden layers one cell per launch (k_fwd_diag_t), a feed-forward hidden "
+                                            "layer's passes in one launch with the state in registers (k_fwd_win_t), the head layer of all "
+                                            "passes in 1; EVF_FWD_LM=0: diagonals" if (diag_fwd and fwd_lm) else
+                                            "diagonal + chains: the cells of the hidden layers up to the last recurrent one in P + 3 launches "
+                                            "(k_fwd_diag_t), the two feed-forward layers above them one launch each for all passes with the "
+                                            "state in registers (k_fwd_win_t), the head layer of all passes in 1 (k_head_lif_fwd_win); "
+                                            "EVF_FWD_LM=0: P + 5 diagonals" if (diag_fwd and fwd_mode == "top") else
+                                            "diagonal: the window's hidden forward cells in P + 5 launches (k_fwd_diag, cells "
                                             "(pass, layer) with equal pass + layer together), "
                                             + ("the PLIF head layer one launch per pass" if plif_net else
                                                "the head layer of all passes in 1 (k_head_lif_fwd_win)") + "; EVF_DEFER_FWD=0: one launch per cell"

@@ -319,12 +319,18 @@ __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, co
           }
         };
         if (valid) {
+#ifdef FT_PROBE_NOCONV  // (probe build: team M only requests halos and publishes tiles -- team E with the LDS pipe to itself)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) halo_fetch_q(q);
+          asm volatile("ds_read_b64 %0, %1" : "=v"(ev) : "v"(fl_empty) : "memory");
+#else
           if (rec) {
             conv_phase(s_hx, s_wff, std::false_type{}, std::true_type{});
             conv_phase(s_hz, s_wrec, std::true_type{}, std::false_type{});
           } else {
             conv_phase(s_hx, s_wff, std::true_type{}, std::true_type{});
           }
+#endif
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ev)::"memory");
         } else {
 #pragma unroll

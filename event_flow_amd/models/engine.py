@@ -66,7 +66,9 @@ PLIF_LM_DGRAD = os.environ.get("EVF_PLIF_LM_DGRAD", "ws")
 # chain (k_fwd_win_t: potential, trace and previous spikes in registers across the passes, the tape is written only); recurrent
 # layers one pass per index.  "1": every hidden layer; "top": only the feed-forward layers above the last recurrent one (the
 # layers below stay on the diagonals); "0": diagonals (cell (t, l) under index t + l - 1); "auto": "1" when ONE cell's rounds of
-# strips fill the chip (>= FWD_LM_MIN_ROUNDS per CU-sized grid), else "0"
+# strips fill the chip (>= FWD_LM_MIN_QUADS rounds of four strips: 4 x 260 x 346 has 1430, and its forward 2.35 -> 2.29 ms eager,
+# 11.48 -> 11.20 ms per replayed step), else "top" (8 x 128 x 128: 512 rounds; single recurrent cells would not fill the chip there,
+# 3.45 / 3.43 / 3.43 ms on diagonals, 3.42 / 3.40 / 3.41 with "top", 3.45 / 3.45 / 3.43 with "1" on one box)
 FWD_LAYER_MAJOR = os.environ.get("EVF_FWD_LM", "auto")
 FWD_LM_MIN_QUADS = int(os.environ.get("EVF_FWD_LM_MIN_QUADS", "1024"))
 FWD_LM_PASSES = 16  # passes a recording holds in the layer-major forms (= FW_WIN_MAX, csrc/evf_fwd.h)
@@ -445,14 +447,21 @@ class FireNetEngine:
         self._defer_stream = torch.cuda.current_stream()
         _lib.set_defer_hook(self.flush_forward, _lib._DEFER_SAFE_FWD, "fwd")
 
+    def _fwd_mode(self, B, H, W):
+        """The recorded forward's schedule at this shape: "0" diagonals, "1" layer by layer, "top" (FWD_LAYER_MAJOR)."""
+        mode = FWD_LAYER_MAJOR
+        if mode == "auto":
+            quads = (B * ((H + 1) // 2) * ((W + 31) // 32) + 3) // 4
+            mode = "1" if quads >= FWD_LM_MIN_QUADS else "top"
+        if mode == "top" and not any(not c.recurrent for c in self.cells[1 + max([i for i, c in enumerate(self.cells) if c.recurrent], default=0):]):
+            mode = "0"  # (no feed-forward layer above the last recurrent one)
+        return mode if mode in ("1", "top") else "0"
+
     def _fwd_slots(self, B, H, W):
         """Index plan of a recorded forward: None = diagonals (cell (t, l) under t + l - 1), else per layer (base, stride):
         cell (t, l) is recorded under base + stride * t -- stride 0 = the layer's passes under one index (a chain, launched as one
         k_fwd_win_t), stride 1 = a pass per index."""
-        mode = FWD_LAYER_MAJOR
-        if mode == "auto":
-            quads = (B * ((H + 1) // 2) * ((W + 31) // 32) + 3) // 4
-            mode = "1" if quads >= FWD_LM_MIN_QUADS else "0"
+        mode = self._fwd_mode(B, H, W)
         if mode not in ("1", "top"):
             return None
         key = (mode, tuple(c.recurrent for c in self.cells))
