@@ -195,3 +195,40 @@ def test_reference_pickled_checkpoint_restores(tmp_path):
     save_model(model, str(tmp_path / "x" / "m.pth"))
     again = load_model(str(tmp_path / "x" / "m.pth"), M.LIFFireNet(cfg(C=8)), "cpu")
     assert all(np.array_equal(v.numpy(), g["param_" + k]) for k, v in again.state_dict().items())
+
+
+def test_recorded_forward_index_plans(monkeypatch):
+    """engine._fwd_slots (host logic of the recorded forward, EVF_FWD_LM): diagonals, every hidden layer by layer, or only the
+    feed-forward layers above the last recurrent one as chains -- a chain's index lies behind every index of the layer it reads,
+    a recurrent layer gets an index per pass, everything fits the recorder's 96 indices, the choice follows the shape."""
+    from event_flow_amd.models import engine as heng
+
+    eng = M.LIFFireNet(cfg())._eng()  # head, G1 (rec), R1a, R1b, G2 (rec), R2a, R2b
+    assert [c.recurrent for c in eng.cells] == [False, True, False, False, True, False, False]
+    P = heng.FWD_LM_PASSES
+    monkeypatch.setattr(heng, "FWD_LAYER_MAJOR", "0")
+    assert eng._fwd_mode(8, 128, 128) == "0" and eng._fwd_slots(8, 128, 128) is None
+    monkeypatch.setattr(heng, "FWD_LAYER_MAJOR", "top")
+    assert eng._fwd_slots(8, 128, 128) == [None, (0, 1), (1, 1), (2, 1), (3, 1), (P + 3, 0), (P + 4, 0)]
+    monkeypatch.setattr(heng, "FWD_LAYER_MAJOR", "1")
+    assert eng._fwd_slots(8, 128, 128) == [None, (0, 1), (P, 0), (P + 1, 0), (P + 2, 1), (2 * P + 2, 0), (2 * P + 3, 0)]
+    for mode in ("top", "1"):
+        monkeypatch.setattr(heng, "FWD_LAYER_MAJOR", mode)
+        plan = eng._fwd_slots(2, 32, 32)
+        idx = lambda i, t: plan[i][0] + plan[i][1] * t  # noqa: E731
+        for t in range(P):
+            for i in range(1, 7):
+                assert 0 <= idx(i, t) < 96
+                if i > 1:  # the layer below at the same pass comes first
+                    assert idx(i - 1, t) < idx(i, t)
+                if t > 0 and plan[i][1]:  # the cell's own previous pass comes first (a chain holds both under one index)
+                    assert idx(i, t - 1) < idx(i, t)
+    monkeypatch.setattr(heng, "FWD_LAYER_MAJOR", "auto")
+    assert eng._fwd_mode(8, 128, 128) == "top" and eng._fwd_mode(4, 260, 346) == "1" and eng._fwd_mode(1, 32, 32) == "top"
+    # a network without recurrent layers: every hidden layer is a chain in both forms
+    ff = M.LIFFireFlowNet(cfg())._eng()
+    assert not any(c.recurrent for c in ff.cells)
+    for mode in ("top", "1"):
+        monkeypatch.setattr(heng, "FWD_LAYER_MAJOR", mode)
+        plan = ff._fwd_slots(2, 32, 32)
+        assert all(p[1] == 0 for p in plan[1:]) and [p[0] for p in plan[1:]] == sorted({p[0] for p in plan[1:]})
