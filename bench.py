@@ -288,7 +288,7 @@ _KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3_lds<false, false, false, fal
               "evf_conv_lif_fwd_b3/rec": "k_conv_lif_fwd_b3<true, false>", "evf_head_lif_fwd": "k_head_lif_fwd<1>",
               "k_head_lif_fwd_win": "k_head_lif_fwd_win<1, false, 8>", "k_head_bwd_win": "k_head_bwd_win<true, 4, false>",
               "evf_head_lif_bwd_wgrad": "k_head_bwd_mfma<true>", "evf_conv_dgrad/one": "k_conv_dgrad<false>",
-              "evf_conv_dgrad/two": "k_conv_dgrad<true>", "k_fwd_diag": "k_fwd_diag_t<true, true, false>", "k_fwd_win": "k_fwd_win_t<true, true, false>", "k_bwd_diag": "k_bwd_diag_ws<8>",
+              "evf_conv_dgrad/two": "k_conv_dgrad<true>", "k_fwd_diag": "k_fwd_diag_t<true, true, false>", "k_fwd_win": "k_fwd_win_t<true, true, false>", "k_bwd_win": "k_bwd_win_lif", "k_dgrad_multi": "k_dgrad_diag_dma<true, false>", "k_bwd_diag": "k_bwd_diag_ws<8>",
               "k_dgrad_diag": "k_dgrad_diag_dma<true, false>", "evf_conv_lif_fwd/ff": "k_conv_lif_fwd<false>",
               "evf_conv_lif_fwd/rec": "k_conv_lif_fwd<true>", "evf_conv_wgrad_bits": "k_conv_wgrad_bits"}
 
@@ -761,7 +761,8 @@ def main():
     names = ["evf_lif_bwd_wgrad2", "evf_conv_lif_fwd", "evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_conv_dgrad", "evf_conv_dgrad_b3",
              "evf_conv_dgrad_b3_f32", "evf_conv_dgrad_b3_f32_pair", "evf_conv_wgrad_bits", "evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad_top",
              "evf_lif_bwd", "evf_head_lif_bwd_wgrad", "evf_head_lif_fwd", "evf_head_wgrad", "evf_pred_bwd", "evf_reduce_slabs", "evf_reduce_slabs_multi", "evf_cm_loss_fwd",
-             "evf_cm_loss_bwd", "evf_conv_plif_fwd_b3", "evf_head_plif_fwd", "evf_plif_trace_bwd", "evf_encode_events", "evf_clip_adam_step"]
+             "evf_cm_loss_bwd", "evf_conv_plif_fwd_b3", "evf_head_plif_fwd", "evf_plif_trace_bwd", "evf_encode_events", "evf_clip_adam_step",
+             ]
     from event_flow_amd import train as _train
 
     # diagonal launches (train.window_backward -> engine.defer_forward): the hidden forward cells of a window are recorded and
@@ -854,11 +855,11 @@ def main():
             for i in range(nrep):
                 graphs_p[i % len(graphs_p)].replay()
             torch.cuda.synchronize()
-            _gms, _gcnt = (_ct0.c_float * 8)(), (_ct0.c_int * 8)()
+            _gms, _gcnt = (_ct0.c_float * 16)(), (_ct0.c_int * 16)()
             if L.evf_defer_profile_read(_gms, _gcnt) != 0:
                 raise RuntimeError("evf_defer_profile_read failed")
             empty_ms = (_gms[7] / _gcnt[7]) if _gcnt[7] else 0.0
-            gprof = {"empty_bracket_us": empty_ms * 1e3, "per_kind": {k: (_gms[k] / _gcnt[k], _gcnt[k]) for k in range(7) if _gcnt[k]}}
+            gprof = {"empty_bracket_us": empty_ms * 1e3, "per_kind": {k: (_gms[k] / _gcnt[k], _gcnt[k]) for k in range(16) if _gcnt[k] and k != 7}}
             del graphs_p
         except Exception as e:  # noqa: BLE001 -- the instrumented capture never costs the headline line
             print(f"[bench] rank {dp.rank}: instrumented graph capture failed ({type(e).__name__}: {e}); eager kernel timing only", file=sys.stderr)
@@ -879,13 +880,14 @@ def main():
     # the diagonal launches, timed per launch inside the flushes (HIP events in the library, same bracket overhead)
     import ctypes as _ct
 
-    _ms, _cnt = (_ct.c_float * 8)(), (_ct.c_int * 8)()
+    _ms, _cnt = (_ct.c_float * 16)(), (_ct.c_int * 16)()
     if _lib.load().evf_defer_profile_read(_ms, _cnt) != 0:
         raise RuntimeError("evf_defer_profile_read failed")
     prof_eager = {}
     for k, nm in enumerate([("k_fwd_diag", ""), ("k_bwd_diag", ""), ("k_dgrad_diag", ""), ("evf_head_lif_bwd_wgrad", ""),
-                            ("k_head_lif_fwd_win", ""), ("k_head_bwd_win", ""), ("k_fwd_win", "")]):
-        if _cnt[k]:
+                            ("k_head_lif_fwd_win", ""), ("k_head_bwd_win", ""), ("k_fwd_win", ""), ("-", ""), ("k_bwd_win", ""),
+                            ("k_dgrad_multi", "")]):
+        if _cnt[k] and k != 7:
             prof[nm] = [max(_ms[k] / _cnt[k] - _lib.last_event_overhead_ms, 0.0)] * _cnt[k]
             if gprof and "per_kind" in gprof and k in gprof["per_kind"]:
                 # inside the replayed graph: mean bracket of the last replay minus the empty bracket of the same graph
@@ -977,12 +979,19 @@ def main():
             model[("k_fwd_diag", "")] = (8 * PASSES * CONV_FLOP * npix / nl, PASSES * (5 * per_cell + per_cell + 8) * npix / nl)
             hbm_bound |= {"k_fwd_diag"}
             bf16_terms["k_fwd_diag"] = 3
+        # LIF: the two feed-forward layers above the last recurrent one run their backward of all passes ahead of the diagonals
+        # (engine._backward_window_top): the diagonals then hold four layers in P + 3 launches each way
+        bwd_top = bool(diag_bwd and _eng_obj is not None and _eng_obj._top_static(B_PER_GPU // nstream, H, W) and PASSES <= 16)
+        nl_b, n_bwd_layers = (PASSES + 3, 4) if bwd_top else (nl, 6)
         if diag_bwd:
             # fused-backward cells: per pass 3 feed-forward cells (776 B/px), the top one (668), 2 recurrent ones (780; 908 with the
             # second gradient part: every pass but the last; in the first pass they have no previous state: 904)
-            by_b = (3 * PASSES * 776 + PASSES * 668 + 2 * ((PASSES - 2) * 908 + 780 + 904)) * npix
+            rec_b = 2 * ((PASSES - 2) * 908 + 780 + 904)
+            by_b = ((2 * PASSES * 776 + rec_b) if bwd_top else (3 * PASSES * 776 + PASSES * 668 + rec_b)) * npix
             # input-gradient cells: per pass 4 with one weight set (256 B/px) and 2 with two (384); all six single in the first pass
-            by_d = ((PASSES - 1) * (4 * 256 + 2 * 384) + 6 * 256) * npix
+            # (window launches on top: 2 with one weight set and 2 with two)
+            n_one = 2 if bwd_top else 4
+            by_d = ((PASSES - 1) * (n_one * 256 + 2 * 384) + (n_one + 2) * 256) * npix
             by_b32, by_d32 = by_b, by_d
             from event_flow_amd.models import engine as _eng
 
@@ -990,11 +999,21 @@ def main():
                 # dL/d(current) travels as its exact 3-way bf16 split (three planes, 192 B/px) instead of the fp32 tensor (128): the
                 # fused backward writes +64 B/px per cell, the input gradient reads +64 B/px per cell (k_dgrad_diag_dma stages the
                 # planes by LDS-DMA).  `frac_fp32_layout` below prices the same launch with the fp32 layout's bytes.
-                by_b += 6 * PASSES * 64 * npix
-                by_d += 6 * PASSES * 64 * npix
-            model[("k_bwd_diag", "")] = (8 * PASSES * CONV_FLOP * npix / nl, by_b / nl)
-            model[("k_dgrad_diag", "")] = ((8 * (PASSES - 1) + 6) * CONV_FLOP * npix / nl, by_d / nl)
-            alt_bytes = {"k_bwd_diag": by_b32 / nl, "k_dgrad_diag": by_d32 / nl}
+                by_b += n_bwd_layers * PASSES * 64 * npix
+                by_d += n_bwd_layers * PASSES * 64 * npix
+            n_contr = n_bwd_layers + 2  # (two recurrent cells: two contractions each)
+            model[("k_bwd_diag", "")] = (n_contr * PASSES * CONV_FLOP * npix / nl_b, by_b / nl_b)
+            model[("k_dgrad_diag", "")] = ((n_contr * (PASSES - 1) + n_bwd_layers) * CONV_FLOP * npix / nl_b, by_d / nl_b)
+            alt_bytes = {"k_bwd_diag": by_b32 / nl_b, "k_dgrad_diag": by_d32 / nl_b}
+            if bwd_top:
+                # a layer's window launch (two per step: under the prediction head / below it), per pixel and pass: dL/d(spikes) 128 (top:
+                # flow + dL/dflow 16), v_prev 128, spike words and planes 12, the three planes of dL/d(current) 192 written; v' of the
+                # last pass once.  Its input gradients: P products per launch, planes in (192), gradient out (128)
+                model[("k_bwd_win", "")] = (PASSES * CONV_FLOP * npix, (PASSES * (460 + 348) / 2 + 128) * npix)
+                model[("k_dgrad_multi", "")] = (PASSES * CONV_FLOP * npix, PASSES * 320 * npix)
+                hbm_bound |= {"k_bwd_win", "k_dgrad_multi"}
+                bf16_terms["k_bwd_win"] = 3
+                bf16_terms["k_dgrad_multi"] = 6
             hbm_bound |= {"k_bwd_diag", "k_dgrad_diag"}
             bf16_terms["k_bwd_diag"] = 3
             bf16_terms["k_dgrad_diag"] = 6
@@ -1044,6 +1063,10 @@ def main():
             elif key[0] == "k_fwd_diag" and fwd_mode == "top":
                 ent["note"] = (f"diagonal launches: the {4 * PASSES} cells of the four hidden layers up to the last recurrent one in {nl_f} "
                                "launches of 1..4 independent (pass, layer) cells; the two layers above them: k_fwd_win; per LAUNCH")
+            elif key[0] in ("k_bwd_diag", "k_dgrad_diag") and bwd_top:
+                ent["note"] = (f"diagonal launches: the {4 * PASSES} cells of this kind of the four hidden layers up to the last recurrent one in "
+                               f"{nl_b} launches of 1..4 independent (pass, layer) cells; the two layers above them: evf_lif_bwd_wgrad_window / "
+                               "evf_conv_dgrad_b3_multi, all passes per launch; mean_us / algorithmic_MB are per LAUNCH (window total / launches)")
             elif key[0] in ("k_fwd_diag", "k_bwd_diag", "k_dgrad_diag"):
                 ent["note"] = (f"diagonal launches: the window's {6 * PASSES} cells of this kind in {nl} launches of 1..6 independent "
                                "(pass, layer) cells; mean_us / algorithmic_MB are per LAUNCH (window total / launches)")
@@ -1097,7 +1120,13 @@ def main():
                                             + ("the PLIF head layer one launch per pass" if plif_net else
                                                "the head layer of all passes in 1 (k_head_lif_fwd_win)") + "; EVF_DEFER_FWD=0: one launch per cell"
                                             if diag_fwd else "one launch per (pass, layer) cell"),
-                       "backward_launches": ("diagonal: fused-backward cells in P + 5 launches (k_bwd_diag), input-gradient cells in "
+                       "backward_launches": ("the two feed-forward layers above the last recurrent one first, all passes per launch with dL/dv "
+                                             "and the potential in registers (k_bwd_win_lif_top, k_bwd_win_lif) + their input gradients as one "
+                                             "launch per layer (k_dgrad_diag_dma over a product list); then diagonal: fused-backward cells of "
+                                             "the four layers below in P + 3 launches (k_bwd_diag), their input-gradient cells in P + 3 "
+                                             "(k_dgrad_diag), the head layer's backward of all passes in 1 (k_head_bwd_win); "
+                                             "EVF_LIF_BWD_TOP=0: all six hidden layers on P + 5 diagonals" if (diag_bwd and bwd_top) else
+                                             "diagonal: fused-backward cells in P + 5 launches (k_bwd_diag), input-gradient cells in "
                                              "P + 5 (k_dgrad_diag), the head layer's backward of all passes in 1 (k_head_bwd_win); EVF_DEFER_BWD=0: 13 launches per pass"
                                              if diag_bwd else "one launch per cell"),
                        "pipelining": (f"each rank's {B_PER_GPU} windows as {nstream} micro-batches of {B_PER_GPU // nstream} on {nstream} HIP "

@@ -1498,8 +1498,8 @@ void evf_prof_mark(int kind, int end, void* stream) {
   }
 }
 // evf_defer_profile(1): time every dispatcher launch of the following flushes; evf_defer_profile_read: device sync, then
-// ms[k] = summed duration and count[k] = number of launches of kind k < 8 (0 k_fwd_diag, 1 k_bwd_diag, 2 k_dgrad_diag, 3 head
-// backward pass by pass, 4 k_head_lif_fwd_win, 5 k_head_bwd_win, 6 k_fwd_win_t, 7 an EMPTY bracket = the bracket's own cost) since it was
+// ms[k] = summed duration and count[k] = number of launches of kind k < 16 (0 k_fwd_diag, 1 k_bwd_diag, 2 k_dgrad_diag, 3 head
+// backward pass by pass, 4 k_head_lif_fwd_win, 5 k_head_bwd_win, 6 k_fwd_win_t, 7 an EMPTY bracket, 8 k_bwd_win_* (a hidden layer's backward of a window in one launch), 9 evf_conv_dgrad_b3_multi = the bracket's own cost) since it was
 // switched on (event-bracket overhead included: ~1.6 us per launch); switches it off.
 // evf_defer_profile(2): the same brackets while the step is CAPTURED into a hipGraph -- a one-thread timestamp kernel in front
 // of and behind every dispatcher launch (and one empty bracket per forward flush, kind 7); evf_defer_profile(0) after the
@@ -1527,7 +1527,7 @@ extern "C" int evf_defer_profile_read(float* ms, int* count) {
   if (!ms || !count) return EVF_EINVAL;
   evf_prof.mode = 0;
   { const int rc = evf_hip(hipDeviceSynchronize()); if (rc) return rc; }
-  for (int k = 0; k < 8; ++k) ms[k] = 0.f, count[k] = 0;
+  for (int k = 0; k < 16; ++k) ms[k] = 0.f, count[k] = 0;
   if (evf_prof.stamped) {
     static unsigned long long host[2 * EVF_PROF_STAMPS];
     int dev = 0, khz = 0;
@@ -1538,8 +1538,8 @@ extern "C" int evf_defer_profile_read(float* ms, int* count) {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
       khz = 100000;  // 100 MHz
     for (int i = 0; i < evf_prof.n; ++i) {
-      ms[evf_prof.kind[i] & 7] += (float)((double)(host[2 * i + 1] - host[2 * i]) / (double)khz);
-      ++count[evf_prof.kind[i] & 7];
+      ms[evf_prof.kind[i] & 15] += (float)((double)(host[2 * i + 1] - host[2 * i]) / (double)khz);
+      ++count[evf_prof.kind[i] & 15];
     }
     evf_prof.n = 0, evf_prof.stamped = false;
     return EVF_OK;
@@ -1552,8 +1552,8 @@ extern "C" int evf_defer_profile_read(float* ms, int* count) {
       evf_prof.n = 0;
       return rc;
     }
-    ms[evf_prof.kind[i] & 7] += t;
-    ++count[evf_prof.kind[i] & 7];
+    ms[evf_prof.kind[i] & 15] += t;
+    ++count[evf_prof.kind[i] & 15];
   }
   evf_prof.n = 0;
   return EVF_OK;
@@ -1973,7 +1973,7 @@ static int fb_window_launch(int np, const void* const* g_z, const void* const* f
   }
   // blocks: as a one-cell launch whose units cost np times as much (whole rounds of one block per CU)
   const int nblk = fb_blocks_per_cell(nunits, 1, 8 * np);
-  evf_prof_mark(1, 0, stream);
+  evf_prof_mark(8, 0, stream);
 #define FB_WIN_GO(K_) hipLaunchKernelGGL(K_, dim3(nblk), dim3(768), FB_LDS, EVF_STREAM(stream), J, Wn, B, H, W, nchunk, nunits, row_ld, fb_rows(nunits))
   if (plif) {
     if (top) FB_WIN_GO(k_bwd_win_plif_top); else FB_WIN_GO(k_bwd_win_plif);
@@ -1981,7 +1981,7 @@ static int fb_window_launch(int np, const void* const* g_z, const void* const* f
     if (top) FB_WIN_GO(k_bwd_win_lif_top); else FB_WIN_GO(k_bwd_win_lif);
   }
 #undef FB_WIN_GO
-  evf_prof_mark(1, 1, stream);
+  evf_prof_mark(8, 1, stream);
   return evf_status();
 }
 

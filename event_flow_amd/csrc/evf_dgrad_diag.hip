@@ -911,6 +911,9 @@ extern "C" int evf_conv_dgrad_b3_multi(int nprod, const void* const* g_split, co
     if ((gp != nullptr) != (xb != nullptr)) return EVF_EINVAL;
     P.p[k] = EvfDgProd{g_split[q], wT_b3[q], (float*)g_x[q], gp, xb};
   }
-  return evf_dgrad_diag_dma_launch(P, nprod, B, H, W, stream);
+  evf_prof_mark(9, 0, stream);
+  const int rc = evf_dgrad_diag_dma_launch(P, nprod, B, H, W, stream);
+  evf_prof_mark(9, 1, stream);
+  return rc;
 }
 extern "C" int evf_conv_dgrad_b3_multi_fits(int B, int H, int W) { return evf_dgrad_diag_fits(1, B, H, W) ? 1 : 0; }

@@ -62,6 +62,12 @@ PLIF_LAYER_MAJOR = os.environ.get("EVF_PLIF_LAYER_MAJOR", "1") != "0"
 # -- measured SLOWER for PLIF (12.4 against 11.3 ms per step): the trace term's ten loads per pixel sit in the matrix waves' issue
 # stream there (59 against 47 us per product; without the term the kernel runs 43)
 PLIF_LM_DGRAD = os.environ.get("EVF_PLIF_LM_DGRAD", "ws")
+# LIF windows: the feed-forward layers ABOVE the last recurrent one (R2b under the prediction head, R2a) know their dL/d(spikes) of
+# every pass before anything below them has run: their backward of the whole window runs first, one launch per layer with dL/dv and
+# the potential in registers (evf_lif_bwd_wgrad_window: 17-19 us per cell at 8 x 128 x 128 against ~21 inside a diagonal launch of
+# four), their input gradients as one launch per layer (evf_conv_dgrad_b3_multi); the layers below stay on the recorded diagonals.
+# 0: every hidden layer on the diagonals
+LIF_BWD_TOP = os.environ.get("EVF_LIF_BWD_TOP", "1") != "0"
 # recorded FORWARD of a window LAYER by layer: a feed-forward hidden layer's passes are recorded under ONE index and launched as a
 # chain (k_fwd_win_t: potential, trace and previous spikes in registers across the passes, the tape is written only); recurrent
 # layers one pass per index.  "1": every hidden layer; "top": only the feed-forward layers above the last recurrent one (the
@@ -136,6 +142,11 @@ class _FireNetPass(torch.autograd.Function):
             win.lm.append((ctx.tape, g_flow, ctx.is_first))
             if ctx.is_first:
                 eng._backward_window_lm(win)
+        elif eng._top_wanted(win, ctx.tape, g_flow):
+            # LIF: the layers above the last recurrent one as window launches ahead of the diagonals (same stash)
+            win.lm.append((ctx.tape, g_flow, ctx.is_first))
+            if ctx.is_first:
+                eng._backward_window_top(win)
         else:
             eng._lm_replay(win)  # (passes that waited for a layer-major backward this pass cannot join: pass by pass, in order)
             eng._backward_pass(win, ctx.tape, g_flow, ctx.is_first)
@@ -619,6 +630,62 @@ class FireNetEngine:
                 and self.__dict__.get("_bdefer_on", False) and win.rows is not None and n > 2 and not self.cells[n - 1].recurrent
                 and tape["x_in"].shape[1] == 2 and len(win.lm) < 16 and win.bwd_k == 0
                 and all(c.hard_reset and c.activation == "arctanspike" for c in self.cells))
+
+    def _top_static(self, B, H, W):
+        """The part of _top_wanted that depends on the network, the switches and the shape only (bench.py's accounting asks)."""
+        if not (LIF_BWD_TOP and self.kind == "lif" and self.precision == "bf16x3"):
+            return False
+        n = len(self.cells)
+        last_rec = max([i for i, c in enumerate(self.cells) if c.recurrent], default=0)
+        return bool(HEAD_WIN and TOP_FUSED and F32_DGRAD and PAIR_DGRAD and PARAM_ROWS and SPLIT_DGRAD and n > 2 and 0 < last_rec < n - 1
+                    and all(c.hard_reset and c.activation == "arctanspike" for c in self.cells)
+                    and _lib.load().evf_conv_dgrad_b3_multi_fits(B, H, W) == 1)
+
+    def _top_wanted(self, win, tape, g_flow):
+        return bool(g_flow is not None and self.__dict__.get("_bdefer_on", False) and win.rows is not None
+                    and tape["x_in"].shape[1] == 2 and len(win.lm) < 16 and win.bwd_k == 0 and self._top_static(*win.shape))
+
+    def _backward_window_top(self, win):
+        """LIF: the backward of the window's passes for the feed-forward layers above the last recurrent one, a launch per layer
+        (k_bwd_win_lif[_top]: what evf_lif_bwd_wgrad_top / evf_lif_bwd_wgrad2 compute pass by pass, dL/dv and the potential carried in
+        registers) + a launch for the layer's input gradients of all passes; then the passes' remaining layers are recorded on the
+        diagonals as ever (_backward_pass without dL/dflow: the top layers have nothing pending).  Index s = 0 .. T-1 is the
+        backward order (s = 0: the window's last pass).  Reference: autograd of train_flow.py:141-154 over models/model.py:255-265."""
+        stash, win.lm = win.lm, []
+        B, H, W = win.shape
+        dev, n, T = win.dev, len(self.cells), len(stash)
+        tapes = [st[0] for st in stash]
+        gflows = [st[1].float().contiguous() for st in stash]
+        firsts = [st[2] for st in stash]
+        last_rec = max(i for i, c in enumerate(self.cells) if c.recurrent)
+        nsl = _lib.load().evf_lif_bwd_wgrad_slabs(B, H, W)
+        shp = (B, H, W, C)
+        gz = lambda i, s_: self._lm_buf(("gz", i, s_), shp, dev)  # noqa: E731  dL/d(spikes) of layer i at pass s
+        gsp = [self._lm_buf(("gsp", s_), (3, B, H, W, C), dev, torch.bfloat16) for s_ in range(T)]  # planes of dL/d(current)
+        arr = lambda ts: (ctypes.c_void_p * len(ts))(*[_lib.ptr(t) for t in ts])  # noqa: E731
+        rowp = lambda name: _lib.ptr(self._rowed(win, name)[0])  # noqa: E731
+        row_ld = win.rows.shape[1]
+        # (the launches below run at once, in stream order; the tapes and upstream gradients they read are kept like a recorded pass's)
+        self.__dict__.setdefault("_bdefer_keep", []).extend((tp, None, gf) for tp, gf in zip(tapes, gflows))
+        for i in range(n - 1, last_rec, -1):
+            lay = [tp["layers"][i] for tp in tapes]  # (in_bits, v_prev, z_prev, v_out, z_out, in_bitsT, zT_prev, ...)
+            top = i == n - 1
+            kf = (i, "ff")
+            _lib.call("evf_lif_bwd_wgrad_window", T, None if top else arr([gz(i, s_) for s_ in range(T)]),
+                      arr([tp["flow"] for tp in tapes]) if top else None, arr(gflows) if top else None,
+                      _lib.ptr(self._flat["pred.w"]) if top else None, arr([l_[4] for l_ in lay]) if top else None,
+                      rowp("pred.w") if top else None, rowp("pred.b") if top else None, arr([l_[3] for l_ in lay]),
+                      arr([l_[1] for l_ in lay]), arr([l_[2] for l_ in lay]), arr([l_[5] for l_ in lay]), None, arr(gsp),
+                      _lib.ptr(self._flat[f"{i}.leak"]), _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W, self._act_width(i), None,
+                      rowp(f"{i}.leak"), rowp(f"{i}.thresh"), _lib.ptr(self._slab(kf, nsl, dev)),
+                      (1 if win.slab_init.get(kf) else 0) | (row_ld << 8))
+            win.slab_init[kf] = True
+            _lib.call("evf_conv_dgrad_b3_multi", T, arr(gsp), arr([self._packed[(i, "ff", "b3t")]] * T),
+                      arr([gz(i - 1, s_) for s_ in range(T)]), None, None, B, H, W)
+        for s_ in range(T):  # the layers from the last recurrent one down: recorded, diagonal by diagonal
+            win.gz[last_rec], win.gz_has[last_rec] = gz(last_rec, s_), True
+            self._backward_pass(win, tapes[s_], None, firsts[s_])
+            win.bwd_k += 1
 
     def _lm_replay(self, win):
         stash, win.lm = win.lm, []

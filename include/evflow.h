@@ -250,12 +250,13 @@ int evf_bwd_defer_hold_heads(int on, void* stream);
 /* Measurement aid: evf_defer_profile(1) brackets every launch of the following flushes with HIP events;
  * evf_defer_profile_read synchronises the device, returns per kind (0 forward cells, 1 fused-backward cells, 2
  * input-gradient cells, 3 head backward one pass per launch, 4 head forward of a window in one launch, 5 head backward of
- * a window in one launch; 6 unused; 7 an empty bracket) the summed duration in ms and the number of launches -- EIGHT entries
- * each -- and switches it off.  evf_defer_profile(2): the brackets are recorded INTO a stream capture as one-thread timestamp
+ * a window in one launch; 6 a feed-forward hidden layer's forward of a window in one launch; 7 an empty bracket; 8 a hidden
+ * layer's backward of a window in one launch; 9 evf_conv_dgrad_b3_multi; 10..15 unused) the summed duration in ms and the number
+ * of launches -- SIXTEEN entries each -- and switches it off.  evf_defer_profile(2): the brackets are recorded INTO a stream capture as one-thread timestamp
  * kernels (wall clock) in front of and behind every launch; evf_defer_profile(0) after the capture stops recording and
  * keeps them; after replays of the graph evf_defer_profile_read returns the durations inside the LAST replay. */
 int evf_defer_profile(int on);
-int evf_defer_profile_read(float* ms8, int* count8);
+int evf_defer_profile_read(float* ms16, int* count16);
 
 /* Neuron backward (autograd of :103-126 / :523-551 with the surrogate of
  * spiking_util.py:88-93).  Per element:

@@ -1399,6 +1399,48 @@ def test_layer_major_forward_on_ragged_shapes_and_both_resets(monkeypatch, cls_n
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("fix,reps", [("g7_liffirenet_train", 1), ("g7_liffirenet_lowthresh", 1), ("g7_liffirenet_lowthresh", 5)])
+def test_lif_top_layers_backward_as_window_launches(monkeypatch, fix, reps):
+    """LIF windows: the backward of the feed-forward layers above the last recurrent one (R2b under the prediction head, R2a) for
+    ALL passes in one launch each ahead of the diagonals (engine._backward_window_top: evf_lif_bwd_wgrad_window + one
+    evf_conv_dgrad_b3_multi launch per layer) against every hidden layer on the diagonals: the same cells in another order -- loss
+    equal, the whole gradient vector to round-off; windows of the fixture's passes and of 5 x as many (more than a window launch
+    holds: the passes that waited are replayed pass by pass)."""
+    from event_flow_amd import train as htrain
+    from event_flow_amd.models import engine as heng
+
+    g = load_golden(fix)
+    base = passes_from_golden(g)
+    H, W = base[0]["event_cnt"].shape[2:]
+    used = {}
+
+    def run(top):
+        monkeypatch.setattr(heng, "LIF_BWD_TOP", top)
+        monkeypatch.setattr(htrain, "DEFER_FORWARD", True)
+        monkeypatch.setattr(htrain, "DEFER_BACKWARD", True)
+        model = build_from_golden(g, fix=fix)
+        model.train()
+        lossf = hloss.EventWarping(loss_cfg(H, W), DEV)
+        opt = FlatAdam(model, lr=2e-4, clip=100.0, device_step=False)
+        opt.zero_grad()
+        seen = []
+        real_step = opt.step
+        opt.step = lambda *a_, **k_: (seen.append(opt.flat_grad.detach().clone()), real_step(*a_, **k_))[1]
+        losses = []
+        for w in range(2):  # (the second window starts from the first one's state and from updated weights)
+            losses.append(float(htrain.train_window(model, lossf, opt, base * reps)))
+        torch.cuda.synchronize()
+        used[top] = "_lm_bufs" in model._engine.__dict__
+        return losses, seen
+
+    (l0, g0), (l1, g1) = run(False), run(True)
+    assert not used[False] and used[True] == (len(base) * reps <= 16)
+    np.testing.assert_allclose(l1[0], l0[0], rtol=1e-6)
+    assert float(g0[0].abs().max()) > 0 and float((g1[0] - g0[0]).norm() / g0[0].norm()) < 2e-6
+    # second window: after an Adam step on gradients that differ in the last bits
+    np.testing.assert_allclose(l1[1], l0[1], rtol=1e-4)
+
+
 @pytest.mark.parametrize("P", [1, 2, 50])
 def test_diagonal_launches_short_and_long_windows(monkeypatch, P):
     """Windows of 1 and 2 passes (diagonals of one cell) and of 50 passes (the backward index 2 (P - 1 - t) + step runs past
