@@ -1145,6 +1145,7 @@ def main():
                                                 "of the step's ONE hipGraph" if one_graph else
                                                 ("evf_allreduce_sum, eager" if dp.capturable else "torch.distributed all_reduce, eager")
                                                 + (" between the step's two hipGraphs" if graphs is not None else "")),
+                                       "native_fallback": getattr(dp, "native_fallback", None),
                                        "forced_at_one_rank": dp.world == 1}
                                       if dp.active else
                                       {"backend": dp.backend, "library": ("RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())

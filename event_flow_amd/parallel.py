@@ -61,40 +61,123 @@ class DataParallel:
         # the N-rank step replays as ONE hipGraph (bench.StepGraph).  Bootstrapped from torch's store (rank 0's 128-byte id).
         # EVF_DP_NATIVE=0 keeps every collective on torch.distributed (the step is then two graphs around an eager all-reduce).
         self.native = None
+        self.native_fallback = None
         if self.active and backend == "nccl" and device is not None and os.environ.get("EVF_DP_NATIVE", "1") != "0":
             self._init_native()
 
     def _init_native(self):
+        """Own RCCL communicator for the captured all-reduce.  Every step that can fail locally (library load, unique id,
+        ncclCommInitRank, a first eager SUM of known values) is followed by a VOTE over torch's process group: either every
+        rank ends up with a working communicator or every rank drops it and keeps the collectives on torch.distributed (the
+        two-graph step) -- never a mix, which would hang the first step.  EVF_DP_NATIVE_STRICT=1 raises instead."""
         import ctypes
 
         from . import _lib
 
+        strict = os.environ.get("EVF_DP_NATIVE_STRICT", "0") == "1"
+        inject = os.environ.get("EVF_DP_NATIVE_INJECT", "")  # test hook: "load" | "init" | "check" | "capture" fails that stage
+        self.native_fallback = None
         L = _lib.load()
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")  # the RCCL this process has loaded already
-        rc = L.evf_comm_load(path.encode() if os.path.exists(path) else None)
-        if rc != 0:
-            raise _lib.EvflowError(f"evf_comm_load failed with status {rc}: {L.evf_comm_last_error().decode()} "
-                                   "(EVF_DP_NATIVE=0 keeps the collectives on torch.distributed)")
         store = dist.distributed_c10d._get_default_store()
         key = "evf_rccl_unique_id/%d" % DataParallel._native_seq
         DataParallel._native_seq += 1
+        err = None
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")  # the RCCL this process has loaded already
+        rc = L.evf_comm_load(path.encode() if os.path.exists(path) else None)
+        if rc != 0:
+            err = f"evf_comm_load failed with status {rc}: {L.evf_comm_last_error().decode()}"
         ident = (ctypes.c_char * 128)()
         if self.rank == 0:
-            rc = L.evf_comm_unique_id(ident)
-            if rc != 0:
-                raise _lib.EvflowError(f"evf_comm_unique_id failed with status {rc}: {L.evf_comm_last_error().decode()}")
-            store.set(key, bytes(ident.raw))
+            if err is None:
+                rc = L.evf_comm_unique_id(ident)
+                if rc != 0:
+                    err = f"evf_comm_unique_id failed with status {rc}: {L.evf_comm_last_error().decode()}"
+            store.set(key, bytes(ident.raw) if err is None else b"")  # (always published: nobody waits for ever)
         else:
-            raw = store.get(key)  # (blocks until rank 0 has published it)
-            ident.raw = bytes(raw)[:128]
+            raw = bytes(store.get(key))  # (blocks until rank 0 has published it)
+            if len(raw) < 128:
+                err = err or "rank 0 could not create the RCCL unique id"
+            else:
+                ident.raw = raw[:128]
+        if inject == "load":
+            err = err or "injected failure (load)"
+        if not self._vote(err is None):
+            return self._native_off(err or "another rank could not load RCCL / read the unique id", strict)
         comm = ctypes.c_void_p()
         with torch.cuda.device(torch.device(self.device)):
             rc = L.evf_comm_init(ident, self.rank, self.world, ctypes.byref(comm))
         if rc != 0:
-            raise _lib.EvflowError(f"evf_comm_init failed with status {rc}: {L.evf_comm_last_error().decode()}")
+            err = f"evf_comm_init failed with status {rc}: {L.evf_comm_last_error().decode()}"
+            comm = None
+        if inject == "init":
+            err = err or "injected failure (init)"
+        if not self._vote(err is None):
+            if comm is not None:
+                L.evf_comm_destroy(comm)
+            return self._native_off(err or "evf_comm_init failed on another rank", strict)
+        # a first eager SUM of known values (rank r contributes r + 1): world * (world + 1) / 2 everywhere
+        try:
+            t = torch.full((1024,), float(self.rank + 1), dtype=torch.float32, device=torch.device(self.device))
+            _lib.call("evf_allreduce_sum", comm, _lib.ptr(t), t.numel())
+            torch.cuda.synchronize(torch.device(self.device))
+            want = self.world * (self.world + 1) / 2.0
+            if not bool((t == want).all().item()):
+                err = f"evf_allreduce_sum self-check: got {float(t[0])}, expected {want}"
+        except Exception as e:  # noqa: BLE001 -- whatever it was, the vote decides
+            err = f"evf_allreduce_sum self-check raised: {e}"
+        if inject == "check":
+            err = err or "injected failure (check)"
+        if not self._vote(err is None):
+            L.evf_comm_destroy(comm)
+            return self._native_off(err or "evf_allreduce_sum self-check failed on another rank", strict)
+        # ... and the same SUM as a NODE of a hipGraph, replayed twice: what the one-graph step relies on.  (At one rank RCCL's
+        # in-place all-reduce is trivial; only this check on the ranks of the run itself says that a multi-rank RCCL kernel
+        # survives capture + replay on this stack.)  A failure keeps the step on two graphs around torch's eager all-reduce.
+        if os.environ.get("EVF_DP_NATIVE_PREFLIGHT", "1") != "0":
+            try:
+                dev = torch.device(self.device)
+                t = torch.zeros((1024,), dtype=torch.float32, device=dev)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    _lib.call("evf_allreduce_sum", comm, _lib.ptr(t), t.numel())
+                for k in range(2):
+                    t.fill_(float(self.rank + 1 + k))
+                    g.replay()
+                    torch.cuda.synchronize(dev)
+                    want = self.world * (self.world + 1) / 2.0 + k * self.world
+                    if not bool((t == want).all().item()):
+                        err = f"captured evf_allreduce_sum: replay {k} gave {float(t[0])}, expected {want}"
+                        break
+                del g
+            except Exception as e:  # noqa: BLE001
+                err = f"captured evf_allreduce_sum raised: {e}"
+            if inject == "capture":
+                err = err or "injected failure (capture)"
+            if not self._vote(err is None):
+                # (the communicator is left alone: a capture that failed may have left it in a state destroy would wait on)
+                return self._native_off(err or "captured evf_allreduce_sum failed on another rank", strict)
         self.native = comm
         ver = ctypes.c_int()
         self.native_version = ver.value if L.evf_comm_version(ctypes.byref(ver)) == 0 else None
+
+    def _vote(self, ok):
+        """True when `ok` holds on every rank (one MIN all-reduce on torch's process group)."""
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=torch.device(self.device))
+        self._on_comm_stream(lambda: dist.all_reduce(t, op=dist.ReduceOp.MIN))
+        return bool(t.item() > 0.5)
+
+    def _native_off(self, why, strict):
+        from . import _lib
+
+        if strict:
+            raise _lib.EvflowError(why + " (EVF_DP_NATIVE=0 keeps the collectives on torch.distributed)")
+        self.native = None
+        self.native_fallback = why
+        if self.rank == 0:
+            import sys
+
+            print(f"[event_flow_amd.parallel] own RCCL communicator not used: {why}; the step's all-reduce stays on "
+                  "torch.distributed (two-graph step)", file=sys.stderr)
 
     _native_seq = 0
 

@@ -158,9 +158,9 @@ def test_bench_data_parallel_step_two_ranks_graph_equals_eager():
     assert lg == lg and abs(lg - le) <= 2e-3 * abs(le), (lg, le)
 
 
-def _bench_rccl_one_rank(extra, port):
+def _bench_rccl_one_rank(extra, port, **more_env):
     """bench.py under torch.distributed.run with ONE rank and EVF_DP_FORCE=1: backend "nccl" (= RCCL) on the one GPU."""
-    env = dict(os.environ, EVF_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, EVF_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **more_env)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "EVF_DP_BACKEND", "EVF_BENCH_SINGLE_DEVICE"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
@@ -197,6 +197,20 @@ def test_rccl_code_path_on_one_rank_graph_equals_eager_and_plain_step():
     lg, le, lp = g["config"]["loss"], e["config"]["loss"], p["config"]["loss"]
     print("loss: rccl graph", lg, "rccl eager", le, "plain", lp)
     assert lg == lg and abs(lg - le) <= 2e-3 * abs(le) and abs(lg - lp) <= 2e-3 * abs(lp), (lg, le, lp)
+
+
+@pytest.mark.parametrize("stage", ["init", "capture"])
+def test_own_rccl_communicator_that_fails_its_preflight_falls_back_to_torch(stage):
+    """parallel.DataParallel._init_native votes after every stage (load, ncclCommInitRank, an eager SUM of known values, the same
+    SUM as a node of a replayed hipGraph): a failure anywhere (injected here) leaves EVERY rank on torch.distributed's
+    all_reduce between the step's two graphs -- the run goes on, the bench line says why, the loss is the captured run's."""
+    g = _bench_rccl_one_rank([], _free_port())
+    f = _bench_rccl_one_rank([], _free_port(), EVF_DP_NATIVE_INJECT=stage)
+    cg, cf = g["config"]["collective"], f["config"]["collective"]
+    assert cg["mode"].startswith("captured") and cg["native_fallback"] is None, cg
+    assert cf["mode"].startswith("torch.distributed all_reduce, eager between") and stage in cf["native_fallback"], cf
+    lg, lf = g["config"]["loss"], f["config"]["loss"]
+    assert lg == lg and abs(lg - lf) <= 2e-3 * abs(lg), (lg, lf)
 
 
 def test_two_graph_rccl_step_is_bitwise_the_one_graph_step():
