@@ -567,29 +567,15 @@ def main_c4(args):
     # so the two graphs are independent and replay alternately.  Falls back to eager launches if the capture is refused.
     graphs, mode = None, "eager"
 
-    def state_tensors():
-        out = []
-        for st in model.multires_unetrec.states:
-            if st is not None:
-                out += list(st) if isinstance(st, tuple) else [st]
-        return out
-
+    state_copies = None
     if use_graph:
         try:
-            # the recurrent state crosses the windows: graph 0 starts from the tensors the warm-up left (`home`), graph 1 from
-            # the tensors graph 0 produces (fixed addresses in its pool) and ends by copying its final state back into `home`
-            home = state_tensors()
-            home_struct = list(model.multires_unetrec.states)
-            graphs = []
-            for w in range(2):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
-                    gl = train_window(model, lossf, opt, pool[w])
-                    if w == 1:
-                        for h, st in zip(home, state_tensors()):
-                            h.copy_(st)
-                graphs.append((g, gl))
-            model.multires_unetrec.states = home_struct
+            # the recurrent state crosses the windows: graph 0 starts from the tensors the warm-up left, graph 1 from the tensors
+            # graph 0 produces (fixed addresses in its pool), and graph 1's cells write their new states straight back into the
+            # first ones (train.capture_window_cycle / hip_ops.route_states: no copy of the 410 MB of state, no memcpy nodes)
+            from event_flow_amd.train import capture_window_cycle
+
+            graphs, state_copies = capture_window_cycle(model, lossf, opt, pool, side, route=os.environ.get("EVF_STATE_ROUTE", "1") != "0")
             torch.cuda.synchronize()
             for w in range(2):
                 graphs[w][0].replay()
@@ -651,6 +637,7 @@ def main_c4(args):
         "config": {"workload": "LIF-EV-FlowNet (SpikingRecEVFlowNet, base 32) full train step, 256x256, 50k events/window, batch 8, "
                                "4 flow scales, CM loss, clip+Adam [BASELINE configs[3]]", "baseline_config": "c4", "global_batch": Bc,
                    "events_per_window": nev, "parallelism": "dp1", "launch": mode, "loss": float(loss),
+                   "state_tensors_copied_per_cycle": state_copies,
                    "conv_precision": ("forward / input gradient: bf16 MFMA with exact 3-way operand splits, fp32 accumulation "
                                       "(3 products per 16 channels for spike-valued waves, 6 otherwise; EVF_CONV=f32 for the fp32 "
                                       "kernels); " if hip_ops_conv_b3() else "") +

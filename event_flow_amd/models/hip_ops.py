@@ -384,6 +384,39 @@ def _neuron_ws(dev):
     return _NEURON_WS[dev]
 
 
+# State routing (train.capture_window_cycle): a step replayed from hipGraphs needs its recurrent state at FIXED addresses, and the
+# last graph of a cycle has to leave its final state where the first graph reads it.  Instead of copying (410 MB of state per
+# step of the LIF-EV-FlowNet of BASELINE configs[3]: 0.25 ms, and memcpy NODES in the graph) a cell whose PREVIOUS state starts
+# at a registered address writes its NEW state straight into the tensor registered for it.
+_STATE_OUT = {}  # data_ptr of a previous state -> the tensor (logical layout of that state, NHWC memory) the new state goes into
+
+
+def route_states(prev, into):
+    """prev / into: lists of state tensors (a block's stacked state counts as one).  Until clear_state_routes() a cell (block)
+    that is handed prev[k] as its previous state writes its new state into the memory of into[k] (same shape and layout;
+    anything else is ignored and the cell allocates as usual -- the caller compares addresses afterwards)."""
+    for a, b in zip(prev, into):
+        if a is not None and b is not None:
+            _STATE_OUT[a.data_ptr()] = b
+
+
+def clear_state_routes():
+    _STATE_OUT.clear()
+
+
+def _routed(prev, shape_mem):
+    if not _STATE_OUT or prev is None:
+        return None
+    t = _STATE_OUT.get(prev.data_ptr())
+    if t is None or t.dim() < 4:
+        return None
+    nd = t.dim()
+    m = t.detach().permute(*range(nd - 3), nd - 2, nd - 1, nd - 3)  # logical [.., C, H, W] -> memory [.., H, W, C]
+    if not m.is_contiguous() or tuple(m.shape) != tuple(shape_mem) or m.dtype != torch.float32:
+        return None
+    return m
+
+
 class StateSlots:
     """New-state tensors of the n cells of a block in ONE buffer [n, S, B, H, W, C], so that the block's stacked state
     (reference: torch.stack([ff, rec]), spiking_submodules.py:926, :973) exists without a copy."""
@@ -391,7 +424,10 @@ class StateSlots:
     def __init__(self, n):
         self.n, self.base, self.used = n, None, 0
 
-    def take(self, shape, dev):
+    def take(self, shape, dev, prev=None):
+        if self.base is None:
+            # (prev: the first cell's previous state = slice 0 of the block's previous stacked state, i.e. that buffer's address)
+            self.base = _routed(prev, (self.n,) + tuple(shape))
         if self.base is None:
             self.base = _new((self.n,) + tuple(shape), dev)
         if self.used >= self.n or tuple(self.base.shape[1:]) != tuple(shape):
@@ -473,7 +509,12 @@ class _CellStep(torch.autograd.Function):
             ws = _new((B * H * W,), dev)
             P = _new((B, Ho, Wo), dev)
             _lib.call("evf_pretrace_fwd", _lib.ptr(xn), xn.stride(2), B, H, W, Cin, k, s, _lib.ptr(ws), _lib.ptr(P))
-        new = slots.take((ns, B, Ho, Wo, C), dev) if slots is not None else _new((ns, B, Ho, Wo, C), dev)
+        if slots is not None:
+            new = slots.take((ns, B, Ho, Wo, C), dev, state)
+        else:
+            new = _routed(state, (ns, B, Ho, Wo, C))
+            if new is None:
+                new = _new((ns, B, Ho, Wo, C), dev)
         out = _new((B, Ho, Wo, C), dev)
         prm = [p.detach().reshape(-1).contiguous() if p is not None else None for p in (p0, p1, p2, p3)]
         if parts is not None:

@@ -326,6 +326,56 @@ def encode_passes(event_lists, num_bins, res, want=("cnt", "mask", "voxel", "pol
     return encode_event_lists(event_lists, num_bins, res, want=want)
 
 
+def _general_states(model):
+    """(holder, flat list of the state tensors) of a general-path recurrent model (models.model: *EVFlowNet / E2VID families:
+    a `multires_unetrec` / `unetrecurrent` whose `.states` is a list of tensors, tuples of tensors or None)."""
+    holder = getattr(model, "multires_unetrec", None) or getattr(model, "unetrecurrent", None)
+    if holder is None or not hasattr(holder, "states"):
+        raise _lib.EvflowError("capture_window_cycle needs a model with multires_unetrec / unetrecurrent states")
+    flat = []
+    for st in holder.states:
+        if st is not None:
+            flat += list(st) if isinstance(st, (tuple, list)) else [st]
+    return holder, flat
+
+
+def capture_window_cycle(model, loss_function, optimizer, windows, stream, capture_error_mode="global", route=True):
+    """The training step of each window of `windows` (lists of encoded passes, fixed shapes) of a GENERAL-path recurrent model
+    as a hipGraph; the graphs replay in order, again and again.  The warm-up must have run eagerly on `stream` (the model
+    holds a state).  The recurrent state crosses replays WITHOUT copies: graph 0 reads the tensors the warm-up left (`home`),
+    graph k the tensors graph k - 1 wrote (fixed addresses in its pool), and the cells of the LAST graph write their new states
+    straight into `home` (hip_ops.route_states) -- a state tensor a cell could not be routed for (another shape or layout) is
+    copied at the end of the last graph instead.  Returns ([(graph, loss tensor)], number of state tensors copied)."""
+    from .models import hip_ops
+
+    if not getattr(optimizer, "device_step", False):
+        raise _lib.EvflowError("capture_window_cycle needs FlatAdam(..., device_step=True)")
+    holder, home = _general_states(model)
+    home_struct = list(holder.states)
+    graphs, ncopied = [], 0
+    try:
+        for w, passes in enumerate(windows):
+            last = w == len(windows) - 1
+            if last and route:  # (route=False: every state tensor is copied at the end of the last graph -- A/B, tests)
+                hip_ops.route_states(_general_states(model)[1], home)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream, capture_error_mode=capture_error_mode):
+                loss = train_window(model, loss_function, optimizer, passes)
+                if last:
+                    left = _general_states(model)[1]
+                    if len(left) != len(home):
+                        raise _lib.EvflowError("the window changed the structure of the recurrent state")
+                    for h, st in zip(home, left):
+                        if st.data_ptr() != h.data_ptr():
+                            h.copy_(st)
+                            ncopied += 1
+            graphs.append((g, loss))
+    finally:
+        hip_ops.clear_state_routes()
+    holder.states = home_struct
+    return graphs, ncopied
+
+
 class GraphedWindowStep:
     """`train_window` for windows of a FIXED shape (P passes of [B,N,4] events) replayed from hipGraphs: one graph
     launch per optimizer step instead of ~260 kernel launches (the eager step is host bound at this size).

@@ -1049,3 +1049,61 @@ def test_g16_norm_and_transposed_conv_layers():
             ye = m(xs[0], None, G(g[f"{tag}_res0"]))[0] if cls == "ConvLayer_" else m(xs[0])
         for j, yy in enumerate(ye if isinstance(ye, (list, tuple)) else [ye]):
             close(N(yy), g[f"{tag}_yeval_{j}"], 2e-5, f"{cls} {kw.get('norm')} eval {j}")
+
+
+def test_general_path_window_cycle_replays_without_state_copies():
+    """train.capture_window_cycle: the training steps of two windows of a spiking EV-FlowNet as two hipGraphs replayed
+    alternately.  The cells of the second graph write their new states straight into the tensors the first graph reads
+    (hip_ops.route_states): no state tensor is copied, and the replayed steps give the losses of the same steps launched
+    eagerly -- across device synchronizes (no memcpy / memset nodes in the graphs).  Learning rate 0: with the weights fixed
+    every loss is a deterministic function of the windows so far THROUGH the recurrent state (the forward has no float
+    atomics; the loss's own sum does: 1e-6) -- with a learning rate the atomics' round-off flips spikes and two EAGER runs
+    already differ by 1e-3 after four steps."""
+    from event_flow_amd import synthetic
+    from event_flow_amd.loss.flow import EventWarping
+    from event_flow_amd.train import FlatAdam, capture_window_cycle, encode_passes, train_window
+
+    B, n, H, W = 2, 3000, 64, 64
+    cfg = {"num_bins": 2, "base_num_channels": 8, "kernel_size": 3, "encoding": "cnt", "norm_input": False, "mask_output": True,
+           "activations": ["arctanspike", "arctanspike"],
+           "spiking_neuron": {"leak": [-4.0, 0.1], "thresh": [0.3, 0.05], "learn_leak": True, "learn_thresh": True, "hard_reset": True}}
+    lc = {"loader": {"resolution": [H, W]}, "loss": {"flow_regul_weight": 0.001, "overwrite_intermediate": False}, "model": {"mask_output": True}}
+    pool = [encode_passes([torch.from_numpy(synthetic.event_list_batch(B, n, H, W, 777 + 13 * w)).to(DEV)], 2, (H, W)) for w in range(2)]
+
+    def run(graphed, nsteps=6, warm=2):
+        torch.manual_seed(0)
+        model = SpikingRecEVFlowNet(dict(cfg)).to(DEV)
+        model.train()
+        lossf = EventWarping(lc, DEV)
+        opt = FlatAdam(model, lr=0.0, clip=100.0, device_step=True)
+        opt.zero_grad()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        losses = []
+        with torch.cuda.stream(side):
+            for i in range(warm):
+                losses.append(float(train_window(model, lossf, opt, pool[i % 2])))
+            torch.cuda.synchronize()
+            copied = None
+            if graphed:
+                graphs, copied = capture_window_cycle(model, lossf, opt, pool, side, route=graphed != "copy")  # (a capture launches nothing)
+                torch.cuda.synchronize()
+            for i in range(nsteps):
+                if graphed:
+                    graphs[i % 2][0].replay()
+                    torch.cuda.synchronize()
+                    losses.append(float(graphs[i % 2][1]))
+                else:
+                    losses.append(float(train_window(model, lossf, opt, pool[i % 2])))
+        torch.cuda.synchronize()
+        return losses, copied
+
+    eager, _ = run(False)
+    graphc, copiedc = run("copy")
+    graph, copied = run(True)
+    print("eager", eager, "\ngraph, states copied", graphc, copiedc, "\ngraph", graph, "state tensors copied", copied)
+    assert copied == 0 and copiedc > 0, (copied, copiedc)
+    # the state matters: the same window gives another loss every time it comes round
+    assert all(np.isfinite(graph)) and len({round(v, 5) for v in eager[0::2]}) > 2, eager
+    np.testing.assert_allclose(graphc, eager, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(graph, eager, rtol=1e-5, atol=1e-6)
