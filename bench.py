@@ -152,8 +152,9 @@ class StepGraph:
     """One training step of one input window as hipGraph replays.  The whole step is a single
     graph -- with several ranks too: the step's ONE all-reduce is evf_allreduce_sum
     (include/evflow.h) on the library's own RCCL communicator, a plain ncclAllReduce on the
-    capture stream, i.e. one more kernel node.  EVF_DP_TWO_GRAPHS=1 / EVF_DP_NATIVE=0 (or a
-    non-RCCL backend) keep the earlier form: two graphs -- (binning, passes, loss, backward,
+    capture stream, i.e. one more kernel node -- with EVF_DP_NATIVE=1 (opt-in: the captured
+    multi-rank collective has not run on hardware yet).  The default (and EVF_DP_TWO_GRAPHS=1, or a
+    non-RCCL backend) is the earlier form: two graphs -- (binning, passes, loss, backward,
     loss staged into the flat buffer) and (clip+Adam, detach, reset) -- with the all-reduce
     launched eagerly between them."""
 
@@ -388,13 +389,13 @@ def cpu_model():
     return platform.processor() or platform.machine()
 
 
-def other_config_line(cfg, steps=10, warmup=3, timeout=420):
-    """A short run of another BASELINE configuration in its own process (own model, own HIP context), summarised for the
-    headline line's `other_configs`: value, ms_per_step and the roofline object of that run."""
+def other_config_line(cfg, steps=10, warmup=3, timeout=420, extra=None):
+    """A short run of another BASELINE configuration (or of the headline one with other flags: `extra`) in its own process
+    (own model, own HIP context), summarised for the headline line: value, ms_per_step and the roofline object of that run."""
     import subprocess
 
-    cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(steps), "--warmup", str(warmup),
-           "--no-cpu-baseline", "--no-iwe", "--no-others"]
+    cmd = [sys.executable, os.path.abspath(__file__)] + (["--config", cfg] if cfg else []) + ["--steps", str(steps), "--warmup", str(warmup),
+           "--no-cpu-baseline", "--no-iwe", "--no-others"] + (["--no-graph-profile", "--repeat-blocks", "3"] + list(extra) if extra else [])
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
         lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
@@ -404,6 +405,8 @@ def other_config_line(cfg, steps=10, warmup=3, timeout=420):
         roof = d.get("roofline") or {}
         return {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
                 "warmup": d["warmup"], "dtype": d["dtype"], "launch": d["config"].get("launch"), "workload": d["config"]["workload"],
+                "timing_blocks_ms_per_step": (d.get("timing_blocks") or {}).get("ms_per_step"), "loss": d["config"].get("loss"),
+                "workload_activity": d.get("workload_activity"),
                 "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")}}
     except Exception as e:  # noqa: BLE001  (never costs the headline line)
         return {"error": f"{type(e).__name__}: {e}"}
@@ -549,6 +552,11 @@ def main_c4(args):
     torch.manual_seed(0)
     cfg = dict(MODEL_CFG, name="SpikingRecEVFlowNet")
     model = SpikingRecEVFlowNet(dict(cfg)).to(dev)
+    if args.thresh_scale != 1.0:
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                if k.endswith("thresh"):
+                    p.mul_(args.thresh_scale)
     model.train()
     lossf = EventWarping({"loader": {"resolution": [Hc, Wc]}, "loss": dict(LOSS_CFG["loss"]), "model": {"mask_output": True}}, dev)
     use_graph = not args.no_graph
@@ -594,6 +602,16 @@ def main_c4(args):
             loss = train_window(model, lossf, opt, pool[i % 2])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    block_ms = [elapsed / args.steps * 1e3]  # (the contract's block, then the same region repeated: median and spread)
+    if graphs is not None:
+        for _ in range(max(args.repeat_blocks, 1) - 1):
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for i in range(args.steps):
+                graphs[i % 2][0].replay()
+            torch.cuda.synchronize()
+            block_ms.append((time.perf_counter() - tb) / args.steps * 1e3)
+        loss = graphs[(args.steps - 1) % 2][1]
     names = ["evf_conv2d_fwd", "evf_conv2d_dgrad", "evf_conv2d_fwd_b3", "evf_conv2d_fwd_b3_parts", "evf_lif_fwd_parts", "evf_conv2d_dgrad_b3", "evf_conv2d_wgrad", "evf_neuron_fwd", "evf_neuron_bwd", "evf_upsample2x_fwd",
              "evf_upsample2x_bwd", "evf_upsample_nearest_fwd", "evf_upsample_nearest_bwd", "evf_cm_loss_fwd", "evf_cm_loss_bwd",
              "evf_clip_adam_step", "evf_pack_conv2d_weight", "evf_pack_conv2d_weight_b3", "evf_pack_conv2d_weights_b3_multi", "evf_encode_events"]
@@ -656,6 +674,10 @@ def main_c4(args):
                       "frac": dom["TFLOPs"] / FP32_MFMA_PEAK, "traffic": None,
                       "note": "all launches of the entry point in a step together: sum of 2*k*k*Cin*Cout*B*Ho*Wo over the launches / "
                               "their summed HIP-event time"}),
+        "timing_blocks": {"ms_per_step": [round(v, 4) for v in block_ms], "steps_per_block": args.steps,
+                          "median_ms_per_step": float(np.median(block_ms)),
+                          "spread_pct": float(100.0 * (np.max(block_ms) - np.min(block_ms)) / np.median(block_ms))},
+        "workload_activity": {"thresh_scale": args.thresh_scale, "events": "uniform"},
         "kernels": kernels,
         "kernel_timing": {"method": "HIP events around each launch over eager steps, bracket overhead removed",
                           "bracket_overhead_us": round(_lib.last_event_overhead_ms * 1e3, 2)},
@@ -684,6 +706,18 @@ def main():
                          "headline shape; with round 3's persistent one-block-per-CU launches it loses: 3.69 against 3.65 ms per step "
                          "(4 streams: 4.62)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--repeat-blocks", type=int, default=5,
+                    help="timed blocks of --steps replays each: the first is the contract's timed region (value / ms_per_step), the others "
+                         "follow it and give the median and the spread (timing_blocks)")
+    ap.add_argument("--thresh-scale", type=float, default=1.0,
+                    help="multiply every firing threshold of the model by this (0.25: an ALIVE network, every layer at 20-50 %% spike rate; the "
+                         "default initialisation with synthetic uniform events is nearly silent above the third layer)")
+    ap.add_argument("--events", choices=["uniform", "moving_dots"], default="uniform", help="synthetic event generator (synthetic.event_list_batch)")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="multi-GPU readiness check without a timed region: start the N ranks exactly as the real run does, bind one "
+                         "GPU per rank, bring the process group (and, with EVF_DP_NATIVE=1, the library's own RCCL communicator) up, "
+                         "SUM all-reduce one known buffer, print ONE JSON record and exit.  Fails loudly when fewer than N GPUs are visible")
+    ap.add_argument("--no-alive", action="store_true", help="skip the short run of the ALIVE workload the default invocation appends")
     ap.add_argument("--no-others", action="store_true",
                     help="skip the short c4 / c5 runs the default invocation appends as `other_configs` (after the c3 line's timed region)")
     ap.add_argument("--config", choices=["c3", "c4", "c5"], default="c3",
@@ -692,6 +726,13 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if args.config == "c4":
+            raise SystemExit("--config c4 is a single-GPU line (BASELINE configs[3]: 1 x MI355X)")
+        if not os.environ.get("EVF_BENCH_SINGLE_DEVICE") and torch.cuda.device_count() < args.gpus:
+            # fail HERE, with the count, not as N tracebacks out of the launcher (EVF_BENCH_SINGLE_DEVICE=1: the test hook that lets
+            # several gloo ranks share one GPU)
+            raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} visible GPUs (one rank per GPU), this node shows "
+                             f"{torch.cuda.device_count()}: nothing launched")
         raise SystemExit(self_launch(args.gpus))
 
     from event_flow_amd import _lib
@@ -725,9 +766,37 @@ def main():
             raise SystemExit(f"--gpus {args.gpus}: the {dp.backend} process group has {ranks} rank(s) after init (expected {args.gpus}); "
                              "check the launcher (one process per GPU, MASTER_ADDR=127.0.0.1) and HSA_ENABLE_IPC_MODE_LEGACY=0")
 
+    if args.dry_run_launch:
+        # everything the real run does up to the first step: ranks, devices, process group, (own communicator,) one collective
+        t = torch.full((1024,), float(dp.rank + 1), dtype=torch.float32, device=dev)
+        if dp.active:
+            dp.reduce(t)
+        torch.cuda.synchronize()
+        want = dp.world * (dp.world + 1) / 2.0
+        ok = bool((t == want).all().item()) if dp.active else True
+        bad = dp.max_over_ranks(0.0 if ok else 1.0)
+        if dp.rank == 0:
+            import torch.distributed as _dist
+
+            print(json.dumps({"dry_run_launch": True, "n_gpus": dp.world, "baseline_config": args.config,
+                              "global_batch": B_PER_GPU * dp.world, "per_gpu_batch": B_PER_GPU, "resolution": [H, W],
+                              "backend": dp.backend, "ranks_in_process_group": _dist.get_world_size() if _dist.is_initialized() else 1,
+                              "devices_visible": torch.cuda.device_count(), "device_of_rank0": torch.cuda.get_device_name(local_rank),
+                              "sum_allreduce_of_rank_plus_1": float(t[0]), "expected": want, "ok_all_ranks": bad == 0.0,
+                              "native_requested": dp.native_requested, "native_comm_count": dp.native_ranks,
+                              "native_fallback": dp.native_fallback, "capturable_collective": dp.capturable}), flush=True)
+        dp.barrier()
+        dp.close()
+        raise SystemExit(0 if bad == 0.0 else 1)
+
     torch.manual_seed(0)  # identical replicas on every rank
     model = getattr(models, wl["model"])(dict(MODEL_CFG)).to(dev)
     model.precision = args.precision
+    if args.thresh_scale != 1.0:
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                if k.endswith("thresh"):
+                    p.mul_(args.thresh_scale)
     model.train()
     lossf = EventWarping(LOSS_CFG, dev)
     use_graph = not args.no_graph
@@ -744,7 +813,7 @@ def main():
     if use_graph:
         for m in (reps.models if reps is not None else [model]):
             m.use_static_states(True)  # recurrent state must live at fixed addresses across replays
-    pool = make_windows(dp.rank, 2, dev, slices=nstream)
+    pool = make_windows(dp.rank, 2, dev, slices=nstream, kind=args.events)
     names = ["evf_lif_bwd_wgrad2", "evf_conv_lif_fwd", "evf_conv_lif_fwd_b3", "evf_conv_lif_fwd_b3_pred", "evf_conv_dgrad", "evf_conv_dgrad_b3",
              "evf_conv_dgrad_b3_f32", "evf_conv_dgrad_b3_f32_pair", "evf_conv_wgrad_bits", "evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad_top",
              "evf_lif_bwd", "evf_head_lif_bwd_wgrad", "evf_head_lif_fwd", "evf_head_wgrad", "evf_pred_bwd", "evf_reduce_slabs", "evf_reduce_slabs_multi", "evf_cm_loss_fwd",
@@ -813,6 +882,21 @@ def main():
     reduce_ms = dp.reduce_times_ms() if dp.active else []
     if dp.active:
         dp.time_reduces(False)
+    # Spread of the headline figure: the SAME timed region (barrier, K replays, synchronize, barrier) four more times, right
+    # after the contract's own block.  `value` / `ms_per_step` stay the first block's (the contract: exactly K steps); the
+    # blocks, their median and their spread are reported beside them (every rank runs the same number of replays).
+    block_ms = [elapsed / args.steps * 1e3]
+    if graphs is not None and args.repeat_blocks > 1:
+        for _ in range(args.repeat_blocks - 1):
+            dp.barrier()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for i in range(args.steps):
+                loss_b = graphs[i % len(graphs)].replay()
+            torch.cuda.synchronize()
+            dp.barrier()
+            block_ms.append(dp.max_over_ranks(time.perf_counter() - tb) / args.steps * 1e3)
+        del loss_b
     one_graph = bool(dp.active and graphs is not None and graphs[0].post is None)
     if dp.active and not reduce_ms:
         # the collective sits inside the replayed graph (no bracket there): its own device time from 20 eager launches of the same
@@ -1058,19 +1142,75 @@ def main():
                 ent["note"] = (f"diagonal launches: the window's {6 * PASSES} cells of this kind in {nl} launches of 1..6 independent "
                                "(pass, layer) cells; mean_us / algorithmic_MB are per LAUNCH (window total / launches)")
             kernels[name] = ent
-        dom_key = max((k for k in prof if k in model), key=lambda k: sum(prof[k]))
-        dom = kernels["/".join(k for k in dom_key if k)]
+        # The roofline object is the DEVICE kernel with the largest total time per step: entries that launch the same kernel (the
+        # input gradients on the diagonals and as product lists are both k_dgrad_diag_dma) count together; its figures are the
+        # sums over those launches (algorithmic bytes / FLOP of all of them over their summed duration).
+        groups = {}
+        for k in prof:
+            if k in model:
+                nm = "/".join(x for x in k if x)
+                groups.setdefault(_KERNEL_OF.get(nm, nm), []).append(k)
+        dom_dev = max(groups, key=lambda g: sum(sum(prof[k]) for k in groups[g]))
+        dom_keys = sorted(groups[dom_dev], key=lambda k: -sum(prof[k]))
+        dom_key = dom_keys[0]
+        dom = dict(kernels["/".join(k for k in dom_key if k)])
+        if len(dom_keys) > 1:  # several entries, one kernel: aggregate per launch
+            n_l = sum(len(prof[k]) for k in dom_keys)
+            t_ms = sum(float(np.sum(prof[k])) for k in dom_keys)
+            by_all = sum(model[k][1] * len(prof[k]) for k in dom_keys)
+            fl_all = sum(model[k][0] * len(prof[k]) for k in dom_keys)
+            dom.update({"launches": n_l, "mean_us": t_ms / n_l * 1e3, "total_ms_per_step": t_ms / prof_steps,
+                        "algorithmic_MB": by_all / n_l / 1e6, "GBps": by_all / (t_ms * 1e-3) / 1e9,
+                        "frac_of_hbm_peak": by_all / (t_ms * 1e-3) / 1e9 / HBM_PEAK})
+            if all(k in prof_eager for k in dom_keys):
+                dom["mean_us_eager"] = sum(prof_eager[k] * len(prof[k]) for k in dom_keys) / n_l * 1e3
+            if fl_all:
+                dom["fp32_equiv_TFLOPs"] = fl_all / (t_ms * 1e-3) / 1e12
+                if dom_key[0] in bf16_terms:
+                    dom["issued_bf16_TFLOPs"] = bf16_terms[dom_key[0]] * dom["fp32_equiv_TFLOPs"]
+                    dom["frac_of_bf16_peak"] = dom["issued_bf16_TFLOPs"] / BF16_MFMA_PEAK
+            if any(k[0] in alt_bytes for k in dom_keys):
+                by_alt = sum(alt_bytes.get(k[0], model[k][1]) * len(prof[k]) for k in dom_keys)
+                dom["algorithmic_MB_fp32_layout"] = by_alt / n_l / 1e6
+                dom["frac_fp32_layout"] = by_alt / (t_ms * 1e-3) / 1e9 / HBM_PEAK
+        # which side bounds it, by the figures themselves: the kernel sits on the matrix side when the bf16 matrix work it ISSUES is a
+        # larger fraction of the dense bf16 peak than its algorithmic bytes are of the HBM peak (the PMC's MFMA-busy says the same)
+        if dom.get("frac_of_bf16_peak") is not None and dom["frac_of_bf16_peak"] > dom.get("frac_fp32_layout", dom["frac_of_hbm_peak"]):
+            dom["bound"] = "mfma_bf16"
         detail, why_not = _pmc("/".join(k for k in dom_key if k))
         traffic = int(detail["MB_per_launch"] * 1e6) if detail else None  # HBM bytes per launch (PMC), next to ...
         algo = int(dom["algorithmic_MB"] * 1e6) if "algorithmic_MB" in dom else None  # ... the algorithmic bytes per launch
-        if dom["bound"] == "hbm":
+        per_step = {"launches_per_step": dom["launches"] / prof_steps, "total_ms_per_step": dom["total_ms_per_step"],
+                    "entries": ["/".join(x for x in k if x) for k in dom_keys], "device_kernel": dom_dev,
+                    "selection": "arg-max of total time per step over the DEVICE kernels (entries launching one kernel count together)"}
+        if dom["bound"] == "mfma_bf16":
+            # the six-term input gradient: priced on the matrix side.  `achieved` = bf16 matrix work ISSUED (6 exact-split
+            # products per fp32 product) per second against the dense bf16 peak; the algorithmic (fp32-equivalent) rate and the
+            # HBM fraction of the same launches stand beside it
+            hb = dom.get("frac_fp32_layout", dom["frac_of_hbm_peak"])
+            roof = {"kernel": dom_dev, "bound": "mfma", "achieved": dom["issued_bf16_TFLOPs"], "peak": BF16_MFMA_PEAK, "unit": "TFLOP/s",
+                    "frac": dom["frac_of_bf16_peak"], "mean_launch_us": dom["mean_us"],
+                    "timing": dom.get("timing", "HIP events around eager launches, bracket overhead removed"),
+                    "mean_launch_us_eager": dom.get("mean_us_eager"),
+                    "issued_bf16_TFLOPs": dom["issued_bf16_TFLOPs"], "algorithmic_fp32_equiv_TFLOPs": dom["fp32_equiv_TFLOPs"],
+                    "bf16_products_per_fp32_product": bf16_terms.get(dom_key[0]),
+                    "traffic": traffic, "traffic_unit": "bytes/launch (PMC pass: the diagonal launches)",
+                    "algorithmic_bytes": int(dom.get("algorithmic_MB_fp32_layout", dom["algorithmic_MB"]) * 1e6),
+                    "algorithmic_bytes_layout": int(dom["algorithmic_MB"] * 1e6), "frac_of_hbm_peak": hb,
+                    "frac_of_hbm_peak_layout": dom["frac_of_hbm_peak"],
+                    "traffic_detail": detail if detail else {"unavailable": why_not},
+                    "mfma_busy_pct": detail["mfma_busy_pct"] if detail else None, **per_step,
+                    "note": "input gradient g_x = sum_tap g[pix + tap] * W^T: both operands real-valued, so the exact bf16 split needs 6 "
+                            "products per fp32 product (DESIGN 4.1); 108 MFMAs per 4 x 32-pixel tile and wave. `frac` prices the ISSUED "
+                            "bf16 work; the fp32-equivalent rate is algorithmic_fp32_equiv_TFLOPs"}
+        elif dom["bound"] == "hbm":
             # `achieved` / `frac` price the launch with its COMPULSORY bytes (every tensor once in the fp32 layout:
             # dL/d(current) as 128 B/px).  What the kernel really moves in the layout it uses (that tensor as three bf16 planes,
             # 192 B/px) is reported beside it as *_layout.
             comp_frac = dom.get("frac_fp32_layout", dom["frac_of_hbm_peak"])
             comp_bytes = int(dom["algorithmic_MB_fp32_layout"] * 1e6) if "algorithmic_MB_fp32_layout" in dom else algo
             eager_scale = (dom["mean_us"] / dom["mean_us_eager"]) if dom.get("mean_us_eager") else None
-            roof = {"kernel": "/".join(k for k in dom_key if k), "bound": "hbm", "achieved": comp_frac * HBM_PEAK, "peak": HBM_PEAK,
+            roof = {"kernel": dom_dev, **per_step, "bound": "hbm", "achieved": comp_frac * HBM_PEAK, "peak": HBM_PEAK,
                     "unit": "GB/s", "frac": comp_frac, "mean_launch_us": dom["mean_us"],
                     "timing": dom.get("timing", "HIP events around eager launches, bracket overhead removed"),
                     "frac_eager": (comp_frac * eager_scale) if eager_scale else None, "mean_launch_us_eager": dom.get("mean_us_eager"),
@@ -1085,6 +1225,22 @@ def main():
             roof = {"kernel": "/".join(k for k in dom_key if k), "bound": "mfma", "achieved": dom["fp32_equiv_TFLOPs"], "peak": FP32_MFMA_PEAK,
                     "unit": "TFLOP/s", "frac": dom["fp32_equiv_TFLOPs"] / FP32_MFMA_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_detail": detail if detail else {"unavailable": why_not}}
+        # BASELINE's second target: MFMA utilisation of the ConvLIF stack = the PMC's MFMA-busy of every kernel that holds a 3 x 3
+        # contraction (forward diagonals / chains, fused backward, window backward, input gradients, head windows), weighted with
+        # the time that kernel takes inside the replayed step.  None when the committed PMC pass is of other sources.
+        stack, stack_ms, stack_busy_ms, stack_missing = {}, 0.0, 0.0, []
+        for nm, ent in kernels.items():
+            if ent.get("fp32_equiv_TFLOPs") is None:
+                continue
+            if ent.get("mfma_busy_pct") is None:
+                stack_missing.append(nm)
+                continue
+            stack[nm] = {"ms_per_step": round(ent["total_ms_per_step"], 4), "mfma_busy_pct": ent["mfma_busy_pct"]}
+            stack_ms += ent["total_ms_per_step"]
+            stack_busy_ms += ent["total_ms_per_step"] * ent["mfma_busy_pct"] / 100.0
+        mfma_busy_stack = (100.0 * stack_busy_ms / stack_ms) if (stack_ms > 0 and not stack_missing) else None
+        # ... and the matrix work ISSUED over the whole replayed step against the dense bf16 peak (no PMC needed)
+        issued_flop_step = sum(ent.get("issued_bf16_TFLOPs", 0.0) * 1e12 * ent["total_ms_per_step"] * 1e-3 for ent in kernels.values())
         out = {
             "metric": f"event-windows/sec (train step, {W}x{H}x{PASSES * EV_PER_PASS // 1000}k ev)" + ("" if args.config == "c3" else f" [{wl['model']}, {args.config}]"),
             "value": B_PER_GPU * dp.world * args.steps / elapsed,
@@ -1132,7 +1288,12 @@ def main():
                                                 "of the step's ONE hipGraph" if one_graph else
                                                 ("evf_allreduce_sum, eager" if dp.capturable else "torch.distributed all_reduce, eager")
                                                 + (" between the step's two hipGraphs" if graphs is not None else "")),
+                                       # the library's own communicator (EVF_DP_NATIVE=1, opt-in): asked for / why not used / the
+                                       # ranks RCCL itself counts on it (ncclCommCount) / RCCL's version code as that binding sees it
+                                       "native_requested": bool(getattr(dp, "native_requested", False)),
                                        "native_fallback": getattr(dp, "native_fallback", None),
+                                       "native_comm_count": getattr(dp, "native_ranks", None),
+                                       "native_rccl_version": getattr(dp, "native_version", None),
                                        "forced_at_one_rank": dp.world == 1}
                                       if dp.active else
                                       {"backend": dp.backend, "library": ("RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -1142,8 +1303,19 @@ def main():
                        "conv_precision": ("fp32 results via exact 3-way bf16 splits of the fp32 operands on the bf16 matrix cores, "
                                           "fp32 accumulation" if model_precision == "bf16x3" else "fp32 MFMA (v_mfma_f32_32x32x2_f32)")},
             "roofline": roof,
+            "mfma_stack": {"mfma_busy_stack_pct": mfma_busy_stack, "kernels": stack, "kernels_without_pmc": stack_missing,
+                           "issued_bf16_frac_of_peak_whole_step": issued_flop_step / (elapsed / args.steps) / 1e12 / BF16_MFMA_PEAK,
+                           "note": "sum(ms_per_step x SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE) / sum(ms_per_step) over the kernels that hold "
+                                   "a 3 x 3 contraction; PMC figures from the committed pass of the same kernel sources"},
             # all modelled kernels of a step together: algorithmic bytes / step time against the HBM peak
             "step_hbm_frac": step_alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK,
+            # the contract's timed region (block 0 = value / ms_per_step) and the same region repeated right after it
+            "timing_blocks": {"ms_per_step": [round(v, 4) for v in block_ms], "steps_per_block": args.steps,
+                              "median_ms_per_step": float(np.median(block_ms)), "min_ms_per_step": float(np.min(block_ms)),
+                              "max_ms_per_step": float(np.max(block_ms)),
+                              "spread_pct": float(100.0 * (np.max(block_ms) - np.min(block_ms)) / np.median(block_ms)),
+                              "windows_per_s_median": B_PER_GPU * dp.world / (float(np.median(block_ms)) * 1e-3)},
+            "workload_activity": {"thresh_scale": args.thresh_scale, "events": args.events},
             "kernels": kernels,
             "kernel_timing": {"method": "diagonal / head-window launches: HIP events captured into an instrumented copy of the step graphs "
                                         "(timestamp-kernel nodes), read after its replays, minus the empty bracket of the same graph; "
@@ -1191,8 +1363,42 @@ def main():
             out.setdefault("other_configs", {}).update({"c4": other_config_line("c4"), "c5": other_config_line("c5"),
                                     "note": "`python bench.py --config c4|c5 --steps 10 --warmup 3`, one process each, run after the c3 "
                                             "line's timed region and side measurements; full lines: profiles/"})
+        if dp.world == 1 and args.config == "c3" and not args.no_others and not args.no_alive and args.thresh_scale == 1.0:
+            # The same step on an ALIVE network (thresholds x 0.25, moving-dots events: every layer at 20-50 % spike rate; parity of
+            # exactly this workload: tests/test_gpu_teacher_forced.py).  The c3 kernels have no data-dependent path, so the time must
+            # not depend on the activity -- measured here, not assumed; c4's per-wave 3- / 6-term vote IS data dependent.
+            torch.cuda.synchronize()
+            alive = {}
+            for tag, extra in (("c3_thresh_x0.25_moving_dots", ["--thresh-scale", "0.25", "--events", "moving_dots"]),
+                               ("c3_thresh_x0.25_uniform", ["--thresh-scale", "0.25"]),
+                               ("c4_thresh_x0.25", ["--config", "c4", "--thresh-scale", "0.25"])):
+                alive[tag] = other_config_line(None, steps=20 if "c4" not in tag else 10, extra=extra)
+            out["alive_workloads"] = {**alive, "default_ms_per_step": out["ms_per_step"],
+                                      "note": "`python bench.py <flags> --no-cpu-baseline --no-iwe --no-others`, one process each, after the "
+                                              "headline line's measurements: the replayed step at another spike activity"}
+            for tag, ent in alive.items():
+                out["config"]["alive_" + tag.replace(".", "") + "_ms_per_step"] = round(ent["ms_per_step"], 3) if "ms_per_step" in ent else None
         # the driver's record keeps the scalar entries of `config` (strings cut at 120 characters) and drops nested objects: the
         # figures of the other BASELINE configurations and of the collective are repeated there in compact form
+        tb = out["timing_blocks"]
+        out["config"]["ms_per_step_median_of_blocks"] = round(tb["median_ms_per_step"], 4)
+        out["config"]["ms_per_step_spread_pct"] = round(tb["spread_pct"], 2)
+        out["config"]["timing_blocks"] = len(tb["ms_per_step"])
+        out["config"]["roofline_kernel"] = roof.get("kernel")
+        out["config"]["roofline_bound"] = roof.get("bound")
+        out["config"]["roofline_total_ms_per_step"] = round(roof.get("total_ms_per_step", 0.0), 4)
+        out["config"]["mfma_busy_stack_pct"] = round(mfma_busy_stack, 2) if mfma_busy_stack is not None else None
+        out["config"]["issued_bf16_frac_of_peak_whole_step"] = round(out["mfma_stack"]["issued_bf16_frac_of_peak_whole_step"], 4)
+        iw = out.get("iwe_warp") or {}
+        if "spec_shape" in iw:
+            # BASELINE's second headline ("IWE-warp GB/s"): compute_pol_iwe at the spec shape (8 x 15k events, 128 x 128) and at a
+            # bandwidth-saturating batch, as scalars the driver's record keeps
+            out["config"]["iwe_warp_spec_GBps"] = round(iw["spec_shape"]["GBps"], 1)
+            out["config"]["iwe_warp_spec_us"] = round(iw["spec_shape"]["ms_per_call"] * 1e3, 2)
+            out["config"]["iwe_warp_spec_frac"] = round(iw["spec_shape"]["frac_of_hbm_peak"], 4)
+            out["config"]["iwe_warp_spec_launches"] = iw["spec_shape"].get("launches_per_call")
+            out["config"]["iwe_warp_sat_GBps"] = round(iw["saturating_2048"]["GBps"], 1)
+            out["config"]["iwe_warp_sat_frac"] = round(iw["saturating_2048"]["frac_of_hbm_peak"], 4)
         oc = out.get("other_configs", {})
         for cname in ("c2", "c4", "c5"):
             ent = oc.get(cname) or {}
@@ -1205,6 +1411,12 @@ def main():
                 out["config"][f"{cname}_windows_per_s"] = None
         col = out["config"].get("collective") or {}
         ar = col.get("all_reduce_us") or {}
+        # scalars of the collective's preflight (the driver's record keeps scalars only): ranks torch's process group reports,
+        # ranks RCCL counts on the library's own communicator (None: not requested, EVF_DP_NATIVE=1 asks), why it fell back
+        out["config"]["collective_ranks"] = col.get("ranks")
+        out["config"]["collective_native_requested"] = col.get("native_requested", False)
+        out["config"]["collective_native_comm_count"] = col.get("native_comm_count")
+        out["config"]["collective_native_fallback"] = col.get("native_fallback")
         out["config"]["collective_short"] = ("%s, %s rank(s), %s%s" % (
             col.get("library") or col.get("backend"), col.get("ranks"), col.get("mode", "eager all-reduce between two graphs") if dp.active else "none at one rank",
             (", all-reduce mean %.1f us max %.1f us (n=%d)" % (ar["mean"], ar["max"], ar["n"])) if ar else ""))[:118]

@@ -64,6 +64,7 @@ NETWORK_SIGNATURES = {
     "evf_comm_version": [P],
     "evf_comm_unique_id": [P],
     "evf_comm_init": [P, I, I, P],
+    "evf_comm_count": [P, P],
     "evf_comm_destroy": [P],
     "evf_allreduce_sum": [P, P, L, P],
     "evf_allreduce_max": [P, P, L, P],

@@ -16,13 +16,25 @@
 #include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
-#include <rccl/rccl.h>
 
 #include <mutex>
 
 #include "evf_common.h"
 
 namespace {
+// The few RCCL / NCCL types and enumerators this file needs, declared here so that the BUILD needs no RCCL headers either (their
+// values are part of NCCL's stable ABI: nccl.h `ncclResult_t`, `ncclUniqueId` = 128 opaque bytes, `ncclDataType_t`, `ncclRedOp_t`).
+typedef int ncclResult_t;
+constexpr ncclResult_t ncclSuccess = 0;
+struct ncclUniqueId {
+  char internal[128];
+};
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclDataType_t;
+constexpr ncclDataType_t ncclFloat = 7;
+typedef int ncclRedOp_t;
+constexpr ncclRedOp_t ncclSum = 0, ncclMax = 2;
+
 struct Rccl {
   void* h = nullptr;
   ncclResult_t (*GetVersion)(int*) = nullptr;
@@ -34,8 +46,14 @@ struct Rccl {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl rccl;
-std::mutex rccl_mu;
+std::mutex rccl_mu;      // binding the library
+std::mutex rccl_err_mu;  // the text of the last error (written from any entry point)
 char rccl_err[256] = "";
+
+void set_err(const char* a, const char* b) {
+  std::lock_guard<std::mutex> g(rccl_err_mu);
+  snprintf(rccl_err, sizeof rccl_err, "%s: %s", a, b ? b : "(no text)");
+}
 
 bool bind(void* h) {
   if (!h) return false;
@@ -61,13 +79,14 @@ int load_locked(const char* path) {
     if (bind(dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) return EVF_OK;
   for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
     if (bind(dlopen(name, RTLD_NOW | RTLD_LOCAL))) return EVF_OK;
-  snprintf(rccl_err, sizeof rccl_err, "no usable librccl (%s)", dlerror() ? dlerror() : "symbols missing");
+  const char* e = dlerror();  // (read ONCE: dlerror() clears the message it returns)
+  set_err("no usable librccl", e ? e : "symbols missing");
   return EVF_ENOTSUP;
 }
 
 int nccl_rc(ncclResult_t r, const char* what) {
   if (r == ncclSuccess) return EVF_OK;
-  snprintf(rccl_err, sizeof rccl_err, "%s: %s", what, rccl.GetErrorString ? rccl.GetErrorString(r) : "RCCL error");
+  set_err(what, rccl.GetErrorString ? rccl.GetErrorString(r) : "RCCL error");
   return -(2000 + (int)r);
 }
 }  // namespace
@@ -107,6 +126,14 @@ extern "C" int evf_comm_init(const void* id128, int rank, int world, void** comm
   if (rc) return rc;
   *comm = (void*)c;
   return EVF_OK;
+}
+
+// Number of ranks RCCL itself sees on `comm` (ncclCommCount): the bench line records it, so that a scaling record shows
+// whether the collective really ran over N ranks.
+extern "C" int evf_comm_count(void* comm, int* ranks) {
+  if (!comm || !ranks) return EVF_EINVAL;
+  if (!rccl.h || !rccl.CommCount) return EVF_ENOTSUP;
+  return nccl_rc(rccl.CommCount((ncclComm_t)comm, ranks), "ncclCommCount");
 }
 
 extern "C" int evf_comm_destroy(void* comm) {

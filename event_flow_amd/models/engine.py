@@ -1060,7 +1060,10 @@ class FireNetEngine:
                 seg_dst.append(p.grad)
                 seg_off.append(self.small_off[name][0])
                 seg_n.append(self.small_off[name][1])
-                seg_rows.append(rows_head if name.startswith("0.") else rows_hidden)
+                # (the head layer's TRACE parameters can also be written by the stand-alone evf_plif_trace_bwd -- EVF_PLIF_TRACE_FUSED=0,
+                # or a head cell the fused window kernel does not serve -- with up to 512 rows whatever the head launch's block count)
+                trace_par = name.endswith(("leak_pt", "add_pt"))
+                seg_rows.append((max(rows_head, 512) if trace_par else rows_head) if name.startswith("0.") else rows_hidden)
             else:
                 i, nm = name.split(".")
                 if win.slab_init.get((int(i), nm)):

@@ -396,8 +396,15 @@ def route_states(prev, into):
     that is handed prev[k] as its previous state writes its new state into the memory of into[k] (same shape and layout;
     anything else is ignored and the cell allocates as usual -- the caller compares addresses afterwards)."""
     for a, b in zip(prev, into):
-        if a is not None and b is not None:
-            _STATE_OUT[a.data_ptr()] = b
+        if a is None or b is None:
+            continue
+        # a cell must never write its new state over the previous one it still has to read in the backward pass (a cycle of ONE
+        # window would map every state tensor onto itself): overlapping storages are not routed, the caller copies instead.
+        a0, a1 = a.data_ptr(), a.data_ptr() + a.numel() * a.element_size()
+        b0, b1 = b.data_ptr(), b.data_ptr() + b.numel() * b.element_size()
+        if a0 < b1 and b0 < a1:
+            continue
+        _STATE_OUT[a.data_ptr()] = b
 
 
 def clear_state_routes():
@@ -680,6 +687,9 @@ def cell_forward(cell, input_, prev_state, residual=0, slots=None):
         set_spike_tag(out, 1.0)
     elif rtag is not None and rtag[1] == 0:
         set_spike_tag(out, 1.0 + rtag[0])
+        # spikes + a residual that is a bilinear blend (multiples of 1/16) is no longer integer-valued: a second up-sampling of
+        # such a sum would make multiples of 1/256, which the exact-input kernels answer with NaN (the promise is guarded)
+        out._evf_spike_int = getattr(res, "_evf_spike_int", True)
     return out, new
 
 
@@ -1293,6 +1303,10 @@ def concat_up2(parts, pad=0):
     """upsample2x_bilinear(concat_channels(parts, pad)); one kernel when every part has an even channel count and pixel stride."""
     ok = (CONCAT_UP2 and pad % 2 == 0 and all(p.shape[1] % 2 == 0 and p.shape[2:] == parts[0].shape[2:] for p in parts)
           and (sum(p.shape[1] for p in parts) + pad) % 4 == 0)
+    if ok:  # the kernel reads channel PAIRS (8-byte loads) through the parts' NHWC views: channel-slice views with an odd pixel
+        #     stride or a base that is only 4-byte aligned take the two-kernel form instead of failing with EINVAL
+        views = [to_nhwc(p.detach()) for p in parts]
+        ok = all(v.stride(2) % 2 == 0 and v.data_ptr() % 8 == 0 for v in views)
     if not ok:
         return upsample2x_bilinear(concat_channels(parts, pad))
     out = _ConcatUp2.apply(int(pad), *parts)

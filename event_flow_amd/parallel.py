@@ -59,10 +59,16 @@ class DataParallel:
         # The step's ONE collective on a communicator of the library's own (include/evflow.h: evf_comm_*, evf_allreduce_sum):
         # a plain ncclAllReduce on the caller's stream -- no watchdog thread, no stream of its own -- and therefore CAPTURABLE:
         # the N-rank step replays as ONE hipGraph (bench.StepGraph).  Bootstrapped from torch's store (rank 0's 128-byte id).
-        # EVF_DP_NATIVE=0 keeps every collective on torch.distributed (the step is then two graphs around an eager all-reduce).
+        # OPT-IN (EVF_DP_NATIVE=1) since round 6: the captured multi-rank all-reduce has only ever executed at ONE rank (no
+        # multi-GPU box was available to the builder), and a second communicator that misbehaves at start-up can hang a run
+        # instead of failing it.  The default keeps every collective on torch.distributed: the step is then two graphs around
+        # one eager all-reduce (~one launch gap per 3 ms step), the path torch's own RCCL binding has carried everywhere.
         self.native = None
         self.native_fallback = None
-        if self.active and backend == "nccl" and device is not None and os.environ.get("EVF_DP_NATIVE", "1") != "0":
+        self.native_version = None
+        self.native_ranks = None  # ncclCommCount of the library's own communicator
+        self.native_requested = os.environ.get("EVF_DP_NATIVE", "0") == "1"
+        if self.active and backend == "nccl" and device is not None and self.native_requested:
             self._init_native()
 
     def _init_native(self):
@@ -77,24 +83,33 @@ class DataParallel:
         strict = os.environ.get("EVF_DP_NATIVE_STRICT", "0") == "1"
         inject = os.environ.get("EVF_DP_NATIVE_INJECT", "")  # test hook: "load" | "init" | "check" | "capture" fails that stage
         self.native_fallback = None
-        L = _lib.load()
         store = dist.distributed_c10d._get_default_store()
         key = "evf_rccl_unique_id/%d" % DataParallel._native_seq
         DataParallel._native_seq += 1
-        err = None
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")  # the RCCL this process has loaded already
-        rc = L.evf_comm_load(path.encode() if os.path.exists(path) else None)
-        if rc != 0:
-            err = f"evf_comm_load failed with status {rc}: {L.evf_comm_last_error().decode()}"
+        err, L = None, None
         ident = (ctypes.c_char * 128)()
-        if self.rank == 0:
-            if err is None:
+        # Everything a rank does BEFORE the first vote is local and wrapped: whatever raises (the library itself failing to
+        # load included), rank 0 still publishes a key -- an empty one as the sentinel -- so that nobody blocks in store.get
+        # until the store's timeout, and every rank reaches the vote.
+        try:
+            L = _lib.load()
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")  # the RCCL this process has loaded already
+            rc = L.evf_comm_load(path.encode() if os.path.exists(path) else None)
+            if rc != 0:
+                err = f"evf_comm_load failed with status {rc}: {L.evf_comm_last_error().decode()}"
+            if self.rank == 0 and err is None:
                 rc = L.evf_comm_unique_id(ident)
                 if rc != 0:
                     err = f"evf_comm_unique_id failed with status {rc}: {L.evf_comm_last_error().decode()}"
+        except Exception as e:  # noqa: BLE001 -- the vote decides
+            err = f"loading the library / RCCL raised: {e}"
+        if self.rank == 0:
             store.set(key, bytes(ident.raw) if err is None else b"")  # (always published: nobody waits for ever)
         else:
-            raw = bytes(store.get(key))  # (blocks until rank 0 has published it)
+            try:
+                raw = bytes(store.get(key))  # (blocks until rank 0 has published it)
+            except Exception as e:  # noqa: BLE001
+                raw, err = b"", err or f"reading the unique id from the store raised: {e}"
             if len(raw) < 128:
                 err = err or "rank 0 could not create the RCCL unique id"
             else:
@@ -103,12 +118,20 @@ class DataParallel:
             err = err or "injected failure (load)"
         if not self._vote(err is None):
             return self._native_off(err or "another rank could not load RCCL / read the unique id", strict)
+        # (every rank is past the vote with a bound RCCL and the id: the argument checks of evf_comm_init cannot fail on one
+        # rank only, so every rank enters ncclCommInitRank -- which blocks until all of them have)
         comm = ctypes.c_void_p()
         with torch.cuda.device(torch.device(self.device)):
             rc = L.evf_comm_init(ident, self.rank, self.world, ctypes.byref(comm))
         if rc != 0:
             err = f"evf_comm_init failed with status {rc}: {L.evf_comm_last_error().decode()}"
             comm = None
+        else:
+            cnt = ctypes.c_int(-1)
+            if L.evf_comm_count(comm, ctypes.byref(cnt)) == 0:
+                self.native_ranks = cnt.value
+                if cnt.value != self.world:
+                    err = f"ncclCommCount says {cnt.value} ranks, the process group has {self.world}"
         if inject == "init":
             err = err or "injected failure (init)"
         if not self._vote(err is None):
@@ -222,6 +245,8 @@ class DataParallel:
         if self.active and self.native is not None and comm.is_cuda:
             from . import _lib
 
+            if comm.dtype != torch.float32 or not comm.is_contiguous():  # (the buffer goes to RCCL as n ncclFloat values)
+                raise _lib.EvflowError(f"DataParallel.reduce needs a contiguous float32 buffer, got {comm.dtype}, strides {comm.stride()}")
             timed = self.__dict__.get("_timed") is not None and not torch.cuda.is_current_stream_capturing()
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -356,7 +356,10 @@ def capture_window_cycle(model, loss_function, optimizer, windows, stream, captu
     try:
         for w, passes in enumerate(windows):
             last = w == len(windows) - 1
-            if last and route:  # (route=False: every state tensor is copied at the end of the last graph -- A/B, tests)
+            # (route=False: every state tensor is copied at the end of the last graph -- A/B, tests.  A cycle of ONE window
+            # starts from `home` itself: its cells would overwrite the previous state the backward pass still reads, so it
+            # is copied as well; route_states refuses overlapping pairs on its own.)
+            if last and route and len(windows) > 1:
                 hip_ops.route_states(_general_states(model)[1], home)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=stream, capture_error_mode=capture_error_mode):

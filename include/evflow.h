@@ -816,6 +816,7 @@ const char* evf_comm_last_error(void);
 int evf_comm_version(int* version);
 int evf_comm_unique_id(void* id128);
 int evf_comm_init(const void* id128, int rank, int world, void** comm);
+int evf_comm_count(void* comm, int* ranks); /* ncclCommCount: the ranks RCCL sees on `comm` */
 int evf_comm_destroy(void* comm);
 int evf_allreduce_sum(void* comm, float* buf, int64_t n, void* stream);
 int evf_allreduce_max(void* comm, float* buf, int64_t n, void* stream);

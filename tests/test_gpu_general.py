@@ -1107,3 +1107,86 @@ def test_general_path_window_cycle_replays_without_state_copies():
     assert all(np.isfinite(graph)) and len({round(v, 5) for v in eager[0::2]}) > 2, eager
     np.testing.assert_allclose(graphc, eager, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(graph, eager, rtol=1e-5, atol=1e-6)
+
+
+def test_general_path_one_window_cycle_keeps_the_previous_state_for_the_backward():
+    """A cycle of ONE window starts from the very tensors it has to end in: its cells must not be routed onto themselves (the
+    neuron kernels would overwrite the previous state the backward pass and the recurrent weight gradient still read).  With a
+    learning rate > 0 the replayed step has to make the update of the same step launched eagerly from the same state."""
+    from event_flow_amd import synthetic
+    from event_flow_amd.loss.flow import EventWarping
+    from event_flow_amd.models import hip_ops
+    from event_flow_amd.train import FlatAdam, _general_states, capture_window_cycle, encode_passes, train_window
+
+    B, n, H, W = 2, 3000, 64, 64
+    cfg = {"num_bins": 2, "base_num_channels": 8, "kernel_size": 3, "encoding": "cnt", "norm_input": False, "mask_output": True,
+           "activations": ["arctanspike", "arctanspike"],
+           "spiking_neuron": {"leak": [-4.0, 0.1], "thresh": [0.3, 0.05], "learn_leak": True, "learn_thresh": True, "hard_reset": True}}
+    lc = {"loader": {"resolution": [H, W]}, "loss": {"flow_regul_weight": 0.001, "overwrite_intermediate": False}, "model": {"mask_output": True}}
+    win = encode_passes([torch.from_numpy(synthetic.event_list_batch(B, n, H, W, 4242)).to(DEV)], 2, (H, W))
+
+    # route_states itself refuses a pair that shares memory
+    t = torch.zeros(1, 4, 8, 8, device=DEV)
+    hip_ops.route_states([t, t[:, :2]], [t, t])
+    try:
+        assert hip_ops._routed(t, (1, 8, 8, 4)) is None and hip_ops._routed(t[:, :2], (1, 8, 8, 2)) is None
+    finally:
+        hip_ops.clear_state_routes()
+
+    torch.manual_seed(0)
+    model = SpikingRecEVFlowNet(dict(cfg)).to(DEV)
+    model.train()
+    lossf = EventWarping(lc, DEV)
+    opt = FlatAdam(model, lr=1e-3, clip=100.0, device_step=True)
+    opt.zero_grad()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            train_window(model, lossf, opt, win)
+        torch.cuda.synchronize()
+        home = _general_states(model)[1]
+        snap = ([h.clone() for h in home], opt.flat_param.clone(), opt.m.clone(), opt.v.clone(), opt.norm_ws.clone())
+
+        def restore():
+            for h, s in zip(home, snap[0]):
+                h.copy_(s)
+            opt.flat_param.copy_(snap[1]); opt.m.copy_(snap[2]); opt.v.copy_(snap[3]); opt.norm_ws.copy_(snap[4])
+            opt.step_invalidate()
+            hip_ops.repack_all()
+
+        l_eager = float(train_window(model, lossf, opt, win))
+        p_eager, s_eager = opt.flat_param.clone(), [s.clone() for s in _general_states(model)[1]]
+        torch.cuda.synchronize()
+        # back to the snapshot, with the model's states being the `home` tensors again
+        holder = _general_states(model)[0]
+        restore()
+        k = 0
+        st = []
+        for s in holder.states:
+            if s is None:
+                st.append(None)
+            elif isinstance(s, (tuple, list)):
+                st.append(type(s)(home[k : k + len(s)])); k += len(s)
+            else:
+                st.append(home[k]); k += 1
+        holder.states = st
+        torch.cuda.synchronize()
+        graphs, copied = capture_window_cycle(model, lossf, opt, [win], side)
+        torch.cuda.synchronize()
+        restore()
+        torch.cuda.synchronize()
+        graphs[0][0].replay()
+        torch.cuda.synchronize()
+        l_graph = float(graphs[0][1])
+        p_graph, s_graph = opt.flat_param.clone(), [h.clone() for h in home]
+        graphs[0][0].replay()  # a second replay starts from the state the first one left in `home`
+        torch.cuda.synchronize()
+        assert np.isfinite(float(graphs[0][1]))
+    assert copied == len(home), (copied, len(home))
+    upd_e, upd_g = N(p_eager - snap[1]), N(p_graph - snap[1])
+    print("one-window cycle: loss", l_eager, l_graph, "update rel-L2", float(np.linalg.norm(upd_g - upd_e) / np.linalg.norm(upd_e)))
+    assert abs(l_graph - l_eager) <= 1e-5 * abs(l_eager) + 1e-6
+    assert np.linalg.norm(upd_e) > 0 and np.linalg.norm(upd_g - upd_e) <= 1e-3 * np.linalg.norm(upd_e)
+    for a, b in zip(s_eager, s_graph):  # the forward is deterministic: the new state is the eager step's bit for bit
+        assert torch.equal(a, b)

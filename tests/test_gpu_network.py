@@ -107,6 +107,9 @@ def _train_once(g, use_flat_adam, fix="g7_liffirenet_train", precision=None):
     for d in passes:
         out = model(d["event_voxel"], d["event_cnt"])
         lossf.event_flow_association(out["flow"], d["event_list"], d["event_list_pol_mask"], d["event_mask"])
+    # spikes of the last pass against the reference's (the free-running bars below are conditioned on this count)
+    nflip = sum(int((N(model.states[li][1]) != g[f"p{len(passes) - 1}_z_{ln}"].astype(np.float32)).sum()) for li, ln in enumerate(LAYERS))
+    _train_once.last_flips = (nflip, sum(int(model.states[li][1].numel()) for li in range(len(LAYERS))))
     loss = lossf()
     loss.backward()
     grads = {k: N(p.grad).copy() for k, p in model.named_parameters()}
@@ -125,13 +128,22 @@ def _train_once(g, use_flat_adam, fix="g7_liffirenet_train", precision=None):
 def test_train_step_vs_golden(fix, flat):
     g = load_golden(fix)
     loss, grads, gn, newp = _train_once(g, flat, fix)
-    np.testing.assert_allclose(loss, float(g["loss"]), rtol=2e-4)
-    np.testing.assert_allclose(gn, float(g["grad_norm"]), rtol=2e-3)
+    # the bars of a FREE-RUNNING comparison depend on whether a borderline neuron fired differently: the flip
+    # count of the last pass is asserted, and with no flip the bars are the round-off ones (10x tighter)
+    nflip, ntot = _train_once.last_flips
+    assert nflip <= 1e-5 * ntot, (nflip, ntot)
+    tight = nflip == 0
+    np.testing.assert_allclose(loss, float(g["loss"]), rtol=2e-5 if tight else 2e-4)
+    np.testing.assert_allclose(gn, float(g["grad_norm"]), rtol=2e-4 if tight else 2e-3)
+    worst = 0.0
+    gall = np.sqrt(sum(float((g["grad_" + k].astype(np.float64) ** 2).sum()) for k in grads))
     for k, got in grads.items():
         ref = g["grad_" + k]
         # aggregate parity (spike-flip chaos forbids element-wise 1e-4 on every weight)
         denom = max(np.linalg.norm(ref), 1e-12)
-        assert np.linalg.norm(got - ref) <= 2e-3 * denom + 1e-10, (k, np.linalg.norm(got - ref) / denom)
+        worst = max(worst, float(np.linalg.norm(got - ref) / max(denom, 1e-6 * gall)))
+        assert np.linalg.norm(got - ref) <= (2e-4 if tight else 2e-3) * denom + 1e-6 * gall, (k, np.linalg.norm(got - ref) / denom)
+    print(f"[{fix} flat={flat}] spike flips in the last pass {nflip} of {ntot}; worst gradient tensor rel-L2 {worst:.2e}")
     for k, ref in ((k[len("param1_"):], g[k]) for k in g.files if k.startswith("param1_")):
         # the first Adam step moves every weight by ~lr*sign(g): weights whose gradient is at
         # the fp32 noise floor may move the other way (<= 2*lr apart); the bulk must agree
@@ -260,8 +272,15 @@ def test_plif_train_step_vs_oracle_at_config5_shape():
     gt[:, 0], gt[:, 1] = 3.0, -2.0
     mask = opasses[-1]["event_mask"][:, 0]
     aee_ref, _ = oloss.aee(f_ref, gt, mask, 128.0, 1.0, 1.0)
-    aee_got, _ = oloss.aee(flow, gt, mask, 128.0, 1.0, 1.0)
-    np.testing.assert_allclose(aee_got.numpy(), aee_ref.numpy(), rtol=1e-4 if nflip == 0 else 1e-3)
+    # ... the HIP flow through the HIP metric (loss.flow.AEE, reference loss/flow.py:560-628), per sample (B = 1 is the only
+    # batch size the reference's own broadcast is right for)
+    metric = hloss.AEE(loss_cfg(H, W), DEV, flow_scaling=128)
+    last = passes[-1]
+    metric.event_flow_association([out["flow"][0].detach()], {
+        "event_list": last["event_list"], "event_list_pol_mask": last["event_list_pol_mask"], "event_mask": last["event_mask"],
+        "gtflow": gt.to(DEV), "dt_input": torch.ones(B), "dt_gt": torch.ones(B)})
+    aee_got = N(metric()[0]).reshape(-1)
+    np.testing.assert_allclose(np.array(aee_got), aee_ref.numpy().reshape(-1), rtol=1e-4 if nflip == 0 else 1e-3)
     # where no neuron of the top layer flipped, the flow agrees to 1e-4
     same = (N(got_states[6][1]) == states[6][1].numpy()).all(axis=1)
     d = np.abs(flow.numpy() - f_ref.numpy()).max(axis=1)

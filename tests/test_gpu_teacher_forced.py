@@ -10,8 +10,8 @@ forcing removes the chaos and keeps the arithmetic: every kernel is fed the ORAC
             v' within 1e-5 (rel-L2 and max-abs relative to max|v'|), z' equal wherever |v' - thresh| > eps, flow within 1e-5.
   backward  the HIP window runs free (recorded forward), then the oracle's potentials, spike words / bit planes, traces and
             flow maps are loaded INTO THE HIP TAPE, and the HIP backward -- recorded fused-backward / input-gradient / head
-            window kernels -- runs from the oracle's dL/dflow.  Asserted: whole-vector and per-tensor gradient rel-L2 <= 1e-3,
-            clip + Adam update <= 1e-3 on the weights with signal.
+            window kernels -- runs from the oracle's dL/dflow.  Asserted: whole-vector gradient rel-L2 <= 1e-5 (per tensor 1e-4),
+            clip + Adam update <= 1e-6 on the weights with signal (measured 5e-7 / 4e-8).
 
 Reference: models/spiking_submodules.py:516-551 (ConvLIFRecurrent), :554-657 (ConvPLIFRecurrent), models/spiking_util.py:82-93
 (arctan surrogate), models/model.py:255-265, loss/flow.py:176-301, train_flow.py:141-171."""
@@ -263,11 +263,12 @@ def _teacher_forced(cls, name, cfg, H, W, B, P, n_ev, thresh_scale, kind, seed):
         r = np.sqrt(e) / max(np.sqrt(d), 1e-20)
         if r > worst[1]:
             worst = (k, r)
-        # every tensor: 1e-3 of its own norm (+ 1e-5 of the whole gradient for tensors that are round-off of cancelling sums)
-        assert np.sqrt(e) <= 1e-3 * np.sqrt(d) + 1e-5 * gn_all, (k, r)
+        # every tensor: 1e-4 of its own norm (measured worst 1.4e-5; + 1e-6 of the whole gradient for tensors that are round-off
+        # of cancelling sums)
+        assert np.sqrt(e) <= 1e-4 * np.sqrt(d) + 1e-6 * gn_all, (k, r)
     grel = np.sqrt(num / den)
     print(f"[teacher-forced backward] gradient rel-L2 {grel:.3e} (|g| = {np.sqrt(den):.4e}); worst tensor {worst[0]} {worst[1]:.3e}")
-    assert grel <= 1e-3, grel
+    assert grel <= 1e-5, grel  # (measured 4.9e-7 .. 5.9e-7: two fp32 summation orders of the same spike trains)
     # clip + Adam (train_flow.py:157-163) on both sides from the same parameters
     old = N(opt.flat_param).copy()
     opt.step()
@@ -285,7 +286,7 @@ def _teacher_forced(cls, name, cfg, H, W, B, P, n_ev, thresh_scale, kind, seed):
     sig = np.abs(gref) > 1e-3 * np.abs(gref).max()
     rel_sig = float(np.linalg.norm((upd - ref_upd)[sig]) / np.linalg.norm(ref_upd[sig]))
     print(f"[teacher-forced backward] clip+Adam update on the {int(sig.sum())} of {sig.size} weights with signal: rel-L2 {rel_sig:.3e}")
-    assert sig.sum() > 0.05 * sig.size and rel_sig <= 1e-3, (int(sig.sum()), rel_sig)
+    assert sig.sum() > 0.05 * sig.size and rel_sig <= 1e-6, (int(sig.sum()), rel_sig)  # (measured 4e-8)
     return {"v": worst_v, "flow": worst_flow, "band": band_mismatch, "grad_rel": grel, "worst_tensor": worst, "update_rel_sig": rel_sig,
             "nsig": int(sig.sum()), "rates": rates}
 
