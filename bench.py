@@ -1332,10 +1332,20 @@ def main():
                 # what bounds the call at the spec shape: one device-scope atomic per event (the image is far too small to
                 # saturate anything else) at the measured random-atomic rate, on top of the floor of a launch
                 spec["launch_floor_us"] = floor
-                spec["atomic_floor_us"] = 8 * 15000 / ATOMIC_RATE * 1e6
-                spec["note"] = ("latency / atomic-rate bound at this size: 4.4 MB is 0.55 us of HBM time; the call is a zero-fill + one "
-                                "scatter kernel whose 120 k device-scope atomics alone need atomic_floor_us at the measured "
-                                "21.4 G atomics/s (scope does not matter: tools/probes/atomic_probe.hip)")
+                one = os.environ.get("EVF_IWE_ONE", "0") == "1"
+                spec["launches_per_call"] = 1 if one else 2
+                spec["kernel"] = "k_iwe_splat_one" if one else "k_evf_fill + k_iwe_splat<true>"
+                if not one:
+                    spec["atomic_floor_us"] = 8 * 15000 / ATOMIC_RATE * 1e6
+                spec["hbm_time_us"] = spec["algorithmic_MB"] * 1e6 / (HBM_PEAK * 1e9) * 1e6
+                spec["event_pass_floor_us"] = 4.2  # rocprofv3, round 6: every event read + flow gathered + ONE 4-byte store, nothing else
+                spec["note"] = ("latency / atomic-rate bound at this size: 4.4 MB is 0.55 us of HBM time; an empty kernel under the same "
+                                "HIP-event bracket takes launch_floor_us, a kernel that only reads every event, gathers its flow and stores "
+                                "4 bytes 4.2-5.0 us by rocprofv3 (event_pass_floor_us).  The call is a zero-fill + one scatter kernel whose "
+                                "120 k device-scope atomics alone need atomic_floor_us at the measured 21.4 G atomics/s (scope does not "
+                                "matter: tools/probes/atomic_probe.hip).  EVF_IWE_ONE=1: the one-launch form (entries into the output's own "
+                                "memory, image built in LDS by the sample's last block, no global atomics) -- measured 10.0-11.3 us against "
+                                "9.1 + 1.8, not the default (csrc/evf_events.hip, k_iwe_splat_one)")
                 out["iwe_warp"] = {"spec_shape": spec, "saturating": iwe_warp_bandwidth(dev, 512, reps=5),
                                    "saturating_2048": iwe_warp_bandwidth(dev, 2048, reps=3),
                                    "empty_launch_us": {"tiny_kernel": floor, "event_bracket_overhead": bracket}}

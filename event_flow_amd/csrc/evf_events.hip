@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "evf_common.h"
+#include <mutex>
 
 // --------------------------------------------------------------------------
 // encodings
@@ -446,6 +447,145 @@ __global__ __launch_bounds__(IWR_THREADS) void k_iwe_splat_reg(const float* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_iwe_splat_one: compute_pol_iwe at the metric's own shape (8 x 15k events, 128 x 128: BASELINE "IWE-warp GB/s") in ONE
+// launch, without a zero-fill launch and without global atomics on the image.
+//
+// What bounds the event-parallel kernel there (k_iwe_splat: 7.6-10 us by rocprof + a 2-5 us fill launch) is the rate of
+// device-scope fp32 atomics (21.4 G/s measured, tools/probes/atomic_probe.hip: 120 k events = 5.6 us); the stripe kernels
+// (k_iwe_splat_lds, one block per band of rows) re-scan a sample's events once per band and pay its two random flow gathers
+// 8-16 times over (19-20 us, profiles/design_log_r01-r04.md).  Here every event is touched ONCE by an event-parallel phase and
+// the image is built in LDS by ONE block per sample -- the block that happens to finish the sample's first phase last:
+//
+//   phase 1  grid (ceil(M / 1024), B): one event per thread -- event, flow gather, warp, rounded destination -- and ONE
+//            4-byte entry per event [dst pixel | valid | a0 == 1 | a1 == 1 | weights not 0 / 1] written into the sample's own
+//            region of `out` (M <= nch * H * W entries fit; nobody reads `out` before it is complete);
+//   ticket   every block takes a DEPARTURE ticket of its sample (agent-scope acq_rel: the release writes the entries back
+//            past this XCD's L2, the acquire lets the last block see the other XCDs' entries).  Nobody ever WAITS: no
+//            co-residency assumption (ADVICE r04 on spinning tickets); all blocks but the last simply exit;
+//   phase 2  the block that drew the sample's last ticket reads the M entries (16 per thread, coalesced) into registers,
+//            clears a 64 KiB LDS plane, bins the entries with LDS atomics -- both polarity counts as the 16-bit halves of one
+//            u32 plane when every weight is 0 / 1 (ds_add_u32; counts < 2^16 exact in fp32, bit-identical to float adds), one
+//            fp32 plane per channel otherwise -- and writes the sample's nch x H x W image with coalesced 16-byte stores,
+//            over the entries it has already consumed.  The ticket word is left at zero for the next call.
+// Same per-event arithmetic as k_iwe_splat (evf_event_flow / evf_warp / rintf): integer histograms bit-exact.
+//
+// MEASURED (round 6, rocprofv3 kernel durations on two boxes, probe builds that cut the kernel short): phase 1 alone -- every
+// event read, its flow gathered, one entry stored -- 4.2-5.0 us (3.4 at best): the floor of ANY kernel that touches each event
+// once behind a dependent gather at this size; + the ticket 6.0 (relaxed) / 6.9 (acq_rel); + phase 2 10.0-11.3, of which the
+// 15 k LDS atomics of the one block per sample 1.2 and its 128 KiB image store 2.1.  That equals the two launches it replaces
+// (k_iwe_splat 9.1 + k_evf_fill 1.8; under bench.py's HIP-event bracket 15.5 against 13.3 us), so it is NOT the default:
+// EVF_IWE_ONE=1 selects it (tests/test_gpu_events.py holds it bit-exact).  What would beat both is phase 2 spread over the
+// sample's blocks (a row stripe each: ~1 us), which needs the blocks to WAIT for each other's entries -- an arrival barrier
+// inside the launch, i.e. co-residency of the grid, which a CU mask or another stream's blocks can break; a
+// departure ticket cannot hand the work to more than the one block that draws it last.
+// ---------------------------------------------------------------------------------------------------------------------
+#define IW1_SLOTS 64
+#define IW1_MAXB 32
+#define IW1_EPT 16
+__device__ unsigned iw1_ticket[IW1_SLOTS * IW1_MAXB];  // departure tickets, one word per (call slot, sample); zero between calls
+
+__global__ __launch_bounds__(1024) void k_iwe_splat_one(const float* __restrict__ flow, const float4* __restrict__ ev,
+                                                        const int32_t* __restrict__ map_of_event,
+                                                        const int32_t* __restrict__ ts_shift, const float* __restrict__ w0,
+                                                        const float* __restrict__ w1, int wstride, int B, int M, int H, int W,
+                                                        float S, float tref, int mode, int nch, unsigned* __restrict__ ticket,
+                                                        float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ int s_last;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int HW = H * W;
+  unsigned* list = (unsigned*)(out + (long)b * nch * HW);  // the sample's entries, M <= nch * HW
+  {
+    const int e = blockIdx.x * 1024 + tid;
+    if (e < M) {
+      const long i = (long)b * M + e;
+      const float4 q = ev[i];
+      float t = q.x;
+      if (ts_shift) t += (float)ts_shift[e];
+      float fy, fx;
+      evf_event_flow(flow, map_of_event ? map_of_event[e] : 0, B, b, (long)HW, q.y, q.z, W, fy, fx);
+      if (mode & 2) {  // `flow * 0` keeps the sign / NaN semantics of the reference
+        fy *= 0.f;
+        fx *= 0.f;
+      }
+      const float a0 = w0 ? w0[i * wstride] : 1.0f;
+      const float a1 = w1 ? w1[i * wstride] : 0.0f;
+      const Warp w = evf_warp(t, q.y, q.z, fy, fx, tref, S);
+      const float iy = rintf(w.wy), ix = rintf(w.wx);  // half-to-even like torch.round
+      unsigned ent = 0u;
+      if (!(iy < 0.f || iy >= (float)H || ix < 0.f || ix >= (float)W)) {
+        const bool gen = !((a0 == 0.f || a0 == 1.f) && (a1 == 0.f || a1 == 1.f));
+        ent = (unsigned)(iy * (float)W + ix) | (1u << 27) | (a0 == 1.f ? 1u << 28 : 0u) | (a1 == 1.f ? 1u << 29 : 0u) |
+              (gen ? 1u << 30 : 0u);
+      }
+      // an agent-scope store (written through this XCD's L2) that has COMPLETED before the block's ticket is taken: the
+      // workgroup barrier alone does not wait for stores in flight
+      __hip_atomic_store(list + e, ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket + b, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t + 1u >= gridDim.x;  // (>=: a ticket left behind by a launch that never finished cannot lock the sample out)
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // ---- the last block of the sample to leave phase 1: every entry of the sample is written and visible
+  unsigned ent[IW1_EPT];
+  bool gen = false;
+#pragma unroll
+  for (int u = 0; u < IW1_EPT; ++u) {
+    const int e = tid + u * 1024;
+    ent[u] = e < M ? __hip_atomic_load(list + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    gen = gen || (ent[u] >> 30 & 1u);
+  }
+  const int any_gen = __syncthreads_or(gen);  // (also: every thread holds its entries, `out` may be overwritten from here on)
+  const int HQ = HW / 4;
+  if (!any_gen) {
+    uint4* pl = (uint4*)smem_raw;  // [HW] u32: low half = channel 0 count, high half = channel 1 count
+    for (int q = tid; q < HQ; q += 1024) pl[q] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    unsigned* cnt = (unsigned*)smem_raw;
+#pragma unroll
+    for (int u = 0; u < IW1_EPT; ++u) {
+      const unsigned inc = (ent[u] >> 28 & 1u) | (nch > 1 ? (ent[u] >> 29 & 1u) << 16 : 0u);
+      if ((ent[u] >> 27 & 1u) && inc) atomicAdd(&cnt[ent[u] & 0x7FFFFFFu], inc);
+    }
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+      float4* o = (float4*)(out + ((long)b * nch + ch) * HW);
+      const int sh = 16 * ch;
+      for (int q = tid; q < HQ; q += 1024) {
+        const uint4 c = pl[q];
+        o[q] = make_float4((float)((c.x >> sh) & 0xFFFFu), (float)((c.y >> sh) & 0xFFFFu), (float)((c.z >> sh) & 0xFFFFu),
+                           (float)((c.w >> sh) & 0xFFFFu));
+      }
+    }
+  } else {
+    float* im = (float*)smem_raw;  // [nch][HW] fp32
+    for (int q = tid; q < nch * HQ; q += 1024) ((float4*)im)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < IW1_EPT; ++u) {
+      const int e = tid + u * 1024;
+      if (ent[u] >> 27 & 1u) {
+        const long i = (long)b * M + e;
+        const float a0 = w0 ? w0[i * wstride] : 1.0f;
+        const float a1 = w1 ? w1[i * wstride] : 0.0f;
+        const int px = (int)(ent[u] & 0x7FFFFFFu);
+        if (a0 != 0.f) atomicAdd(&im[px], a0);
+        if (nch > 1 && a1 != 0.f) atomicAdd(&im[HW + px], a1);
+      }
+    }
+    __syncthreads();
+    float4* o = (float4*)(out + (long)b * nch * HW);
+    for (int q = tid; q < nch * HQ; q += 1024) o[q] = ((const float4*)im)[q];
+  }
+  if (tid == 0) __hip_atomic_store(ticket + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 extern "C" int evf_iwe_splat(const float* flow, const float* ev, const int32_t* map_of_event, const int32_t* ts_shift,
                              const float* w0, const float* w1, int wstride, int B, int M, int H, int W,
                              float flow_scaling, float tref, float tref_ts, int mode, int nch, float* out, void* stream) {
@@ -487,9 +627,41 @@ extern "C" int evf_iwe_splat(const float* flow, const float* ev, const int32_t* 
     }
   }
   const int max_rows = (128 * 1024) / (nch * W * 4);
-  // small problems (a few 100k events) are latency bound: the plain global-atomic kernel (3 us at
-  // B=8 x 15k) wins there; the LDS version wins once the device-scope atomics saturate
+  // small problems (a few 100k events) are latency bound: there the one-launch kernel below (one entry per event, the image
+  // built in LDS by the sample's last block) or, for shapes it does not serve, the plain global-atomic kernel behind a
+  // zero-fill; the LDS stripe version wins once the device-scope atomics saturate
   static const long lds_min = getenv("EVF_IWE_LDS_MIN") ? atol(getenv("EVF_IWE_LDS_MIN")) : 400000;
+  {
+    // k_iwe_splat_one: rounded indices, count images only (no timestamp images), the sample's events fit 16 per thread and
+    // its entries fit its own region of `out`, the image fits the LDS plane(s)
+    // OPT-IN (EVF_IWE_ONE=1, read per call): measured on the MI355X (rocprofv3 kernel durations, 8 x 15k events, 128 x 128) it
+    // is no faster than the two launches it replaces -- 10.0-11.3 us against 9.1 (scatter) + 1.8 (fill); see the kernel's header
+    const char* one_env = getenv("EVF_IWE_ONE");
+    const int one_on = one_env ? atoi(one_env) : 0;
+    const long HWl = (long)H * W;
+    if (one_on && (mode & 1) && !(mode & 12) && (nch == 1 || nch == 2) && M <= IW1_EPT * 1024 && (long)M <= nch * HWl &&
+        HWl <= 16384 && (HWl & 3) == 0 && B <= IW1_MAXB && (long)B * M < lds_min && (((uintptr_t)out) & 15) == 0) {
+      static unsigned* tick_base = nullptr;
+      static unsigned slot = 0;
+      static std::mutex mu;
+      unsigned* tk;
+      {
+        std::lock_guard<std::mutex> g(mu);
+        if (!tick_base) {
+          const int rc = evf_hip(hipGetSymbolAddress((void**)&tick_base, HIP_SYMBOL(iw1_ticket)));
+          if (rc) return rc;
+          (void)hipFuncSetAttribute((const void*)k_iwe_splat_one, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        }
+        // a slot of ticket words per call, round robin: calls of one stream never overlap, calls of different streams that do
+        // overlap use different words (64 slots in flight)
+        tk = tick_base + (size_t)(slot++ % IW1_SLOTS) * IW1_MAXB;
+      }
+      const size_t lds = (size_t)nch * HWl * 4 > 65536 ? (size_t)nch * HWl * 4 : 65536;
+      hipLaunchKernelGGL(k_iwe_splat_one, dim3(evf_cdiv(M, 1024), B), dim3(1024), lds, st, flow, (const float4*)ev, map_of_event,
+                         ts_shift, w0, w1, wstride, B, M, H, W, flow_scaling, tref, mode, nch, tk, out);
+      return evf_status();
+    }
+  }
   if (max_rows >= 1 && (long)B * M >= lds_min) {
     int rows = max_rows < H ? max_rows : H;
     while (rows > 8 && (long)B * evf_cdiv(H, rows) < 256) rows = (rows + 1) / 2;

@@ -187,6 +187,44 @@ def test_pol_iwe_full_size_vs_oracle_and_properties():
     assert float(bl.sum()) == B * n
 
 
+@pytest.mark.parametrize("one", ["1", "0"])
+def test_pol_iwe_one_launch_kernel_small_batches_bit_exact(one, monkeypatch):
+    """EVF_IWE_ONE=1 selects k_iwe_splat_one (csrc/evf_events.hip; opt-in: measured no faster than fill + scatter, which "0" --
+    the default -- runs on the same cases): B * M < 400 k events, rounded indices -- one entry per event written into the
+    output's own memory, the image built in LDS by the sample's last block, no zero-fill launch, no global atomics.  Against
+    the oracle (utils/iwe.py:95-153) bit for bit on integer histograms: ragged event counts (M not a multiple of 1024, M < 1024,
+    M = the 16 Ki limit), 1 and 2 channels, small and non-square images, an output buffer full of garbage, the same call
+    repeated (the ticket words are left at zero), large flows (many events leave the image), zero flow; general (non 0 / 1)
+    weights through its fp32 LDS planes (sums of multiples of 1/8: exact in any order)."""
+    monkeypatch.setenv("EVF_IWE_ONE", one)  # (read by the library per call)
+    rng = np.random.default_rng(11)
+    for B, n, H, W, amp in [(8, 15000, 128, 128, 0.1), (3, 1000, 64, 64, 0.3), (1, 777, 32, 48, 0.05), (2, 16384, 128, 128, 2.0),
+                            (5, 4097, 96, 160, 0.2)]:
+        ev = synthetic.event_list_batch(B, n, H, W, 3100 + n)
+        flow = rng.uniform(-amp, amp, size=(B, 2, H, W)).astype(np.float32)
+        pol = np.stack([(ev[:, :, 3] > 0), (ev[:, :, 3] < 0)], 2).astype(np.float32)
+        gpol, gev, gfl = G(pol), G(ev), G(flow)
+        ref = oiwe.compute_pol_iwe(flow, ev, (H, W), pol[:, :, 0:1], pol[:, :, 1:2], flow_scaling=128, round_idx=True)
+        for rep in range(3):  # (the caching allocator hands back the previous result's memory: garbage the kernel must not count)
+            got = N(hiwe.compute_pol_iwe(gfl, gev, (H, W), gpol[:, :, 0:1], gpol[:, :, 1:2], flow_scaling=128, round_idx=True))
+            assert np.array_equal(got, ref), (B, n, H, W, rep, int((got != ref).sum()))
+        assert ref.sum() > 0 and (amp < 1.0 or ref.sum() < 0.9 * B * n)  # (large flows: events do leave the image)
+        # one channel, no weights / a polarity mask (deblur_events)
+        one = N(hiwe.deblur_events(gfl, gev, (H, W), flow_scaling=128, round_idx=True))
+        assert np.array_equal(one, oiwe.deblur_events(flow, ev, (H, W), 128, True))
+        onep = N(hiwe.deblur_events(gfl, gev, (H, W), flow_scaling=128, round_idx=True, polarity_mask=gpol[:, :, 0:1]))
+        assert np.array_equal(onep, oiwe.deblur_events(flow, ev, (H, W), 128, True, pol[:, :, 0:1]))
+        # zero flow: the event count image
+        z = N(hiwe.compute_pol_iwe(G(flow * 0), gev, (H, W), gpol[:, :, 0:1], gpol[:, :, 1:2], round_idx=True))
+        assert np.array_equal(z, N(enc.encode_event_list(gev, 2, (H, W))["event_cnt"]))
+        # general weights (multiples of 1/8 in [0, 4)): the fp32 planes of the same kernel, exact sums
+        wts = (rng.integers(0, 32, size=(B, n, 2)) / 8.0).astype(np.float32)
+        gw = G(wts)
+        gotw = N(hiwe.compute_pol_iwe(gfl, gev, (H, W), gw[:, :, 0:1], gw[:, :, 1:2], flow_scaling=128, round_idx=True))
+        refw = oiwe.compute_pol_iwe(flow, ev, (H, W), wts[:, :, 0:1], wts[:, :, 1:2], flow_scaling=128, round_idx=True)
+        assert np.array_equal(gotw, refw), (B, n, H, W)
+
+
 # ------------------------------------------------------------------ CM loss
 def _run_hip_loss(g, c, H, W):
     tag = c["tag"]

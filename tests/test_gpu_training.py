@@ -7,10 +7,13 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
 
 
 @pytest.mark.parametrize("model", ["LIFFireNet", "PLIFFireNet"])
