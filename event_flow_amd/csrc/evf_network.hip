@@ -500,22 +500,29 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 && !PLIF) ? 4 : ((NWV == 4 && P
   }
   constexpr int NW = (9 * S2 * 64 + NTHR - 1) / NTHR, NX = (2 * S2 * HALO_H * HALO_W + NTHR - 1) / NTHR;
   float xreg[NX];
+  // (the in-image select happens in put_x, from a mask that does not depend on the loaded value: a select right behind the load
+  // makes the wave wait for it at once -- and, vmcnt being in order, for every tape store of the pass before: one exposed store
+  // drain per pass, which was this kernel's time.  Now the loads of pass t + 1 are only waited for behind pass t's stores, with a
+  // count that leaves those stores in flight.)
+  unsigned xin = 0u;
   auto fetch_x = [&](const float* __restrict__ x) {  // clamped addresses, selected afterwards: no load under a branch
+    xin = 0u;
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
       const int e = min(tid + NTHR * k, 2 * S2 * HALO_H * HALO_W - 1);
       const int ci = e / (HALO_H * HALO_W), p = e % (HALO_H * HALO_W);
       const int yy = y0 + p / HALO_W - 1, xx = x0 + p % HALO_W - 1;
       const bool in = ci < Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
-      const float xv = x[(((long)b * Cin + min(ci, Cin - 1)) * H + min(max(yy, 0), H - 1)) * W + min(max(xx, 0), W - 1)];
-      xreg[k] = in ? xv : 0.f;
+      xreg[k] = x[(((long)b * Cin + min(ci, Cin - 1)) * H + min(max(yy, 0), H - 1)) * W + min(max(xx, 0), W - 1)];
+      xin |= (in ? 1u : 0u) << k;
     }
   };
+  static_assert(NX <= 32, "one mask bit per staged element");
   auto put_x = [&](int buf) {
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
       const int e = tid + NTHR * k;
-      if (e < 2 * S2 * HALO_H * HALO_W) s_x[buf][e / (HALO_H * HALO_W)][e % (HALO_H * HALO_W)] = xreg[k];
+      if (e < 2 * S2 * HALO_H * HALO_W) s_x[buf][e / (HALO_H * HALO_W)][e % (HALO_H * HALO_W)] = ((xin >> k) & 1u) ? xreg[k] : 0.f;
     }
   };
   {
@@ -613,6 +620,10 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 && !PLIF) ? 4 : ((NWV == 4 && P
         for (int m = 0; m < RPW; ++m) acc[m] = mfma32(xp[(r0 + m + dy) * HALO_W + i + dx], bw, acc[m]);
       }
     }
+    // the next pass's input halo into the other buffer BEFORE this pass's tape stores are issued: the wait for its loads (in
+    // order: it also covers the stores of pass t - 1, which have had a whole matrix phase to drain) then leaves pass t's stores
+    // in flight across the barrier and the next matrix phase.  (s_x[buf ^ 1] was last read in pass t - 1, before this pass's barrier.)
+    if (t + 1 < a.np) put_x(buf ^ 1);
     if (PLIF) {  // cur = ff - sigma(add_pt) * pt' (k_head_lif_fwd, spiking_submodules.py:191-227)
       if (tid < TH * TW) {
         const int py = tid >> 5, px = tid & 31;
@@ -647,7 +658,6 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 && !PLIF) ? 4 : ((NWV == 4 && P
       if (full) update(acc[m], vp[m], zb[m], y0 + r0 + m, a.p[t], true);
       else update(acc[m], vp[m], zb[m], y0 + r0 + m, a.p[t], false);
     }
-    if (t + 1 < a.np) put_x(buf ^ 1);
   }
 }
 

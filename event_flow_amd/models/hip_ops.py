@@ -544,24 +544,38 @@ class _CellStep(torch.autograd.Function):
         # the recurrent conv reads the z slice of the previous state: spikes by the cell's definition (a caller who hands in
         # anything else gets NaN weight gradients from the exact path, never rounded ones) -- unless group norm rescaled them
         ctx.rec_spikes = state is not None and not getattr(cell, "gnorm", False)
-        return from_nhwc(out), new.permute(0, 1, 4, 2, 3)
+        # the output TWICE (two views of the same memory): a layer output with two consumers (encoder -> next encoder + skip,
+        # decoder -> prediction + next decoder, residual block input) hands its second consumer the twin (hip_ops.twin), and the
+        # two upstream gradients arrive HERE as two arguments -- the neuron kernel adds them as it loads them (g_z_out + g_z_out2)
+        # instead of autograd launching an add kernel per fork (11 per step of the spiking EV-FlowNet).  An unused twin costs nothing.
+        return from_nhwc(out), new.permute(0, 1, 4, 2, 3), from_nhwc(out)
 
     @staticmethod
-    def backward(ctx, g_out, g_state):
+    def backward(ctx, g_out, g_state, g_out2=None):
         cell, kind, ns = ctx.cell, ctx.kind, ctx.ns
         B, H, W, Cin, Ho, Wo, C, k, s = ctx.geom
         xn, sp, new, P, prm, wff, wrec = ctx.saved
         dev = xn.device
         need = ctx.needs_input_grad  # (cell, x, state, residual, slots, wff, wrec, p0..p3)
         need = need[:4] + need[5:]  # (indices below: cell, x, state, residual, wff, wrec, p0..p3)
+        if g_out is None and g_out2 is not None:
+            g_out, g_out2 = g_out2, None
         if g_out is None and g_state is None:
             return (None,) * 11
         gon = to_nhwc(g_out) if g_out is not None else None
+        gon2 = to_nhwc(g_out2) if g_out2 is not None else None
         gs = None
         if g_state is not None:
             gs = g_state.permute(0, 1, 3, 4, 2)
             if not gs.is_contiguous():
                 gs = gs.contiguous()
+        if gon2 is not None and (gs is not None or (ctx.has_res and need[3])):
+            # the kernel's second gradient slot is taken by the state's z entry (a window of several passes), or the sum itself
+            # is needed (it is the residual's gradient): one add kernel, as autograd would have launched
+            ysum = _new(tuple(gon.shape), dev)
+            _lib.call("evf_act_fwd", 0, _lib.ptr(gon), _lib.ptr(gon2), ysum.numel(), _lib.ptr(ysum))
+            gon, gon2 = ysum, None
+            g_out = from_nhwc(ysum)
         g_cur = _new((B, Ho, Wo, C), dev)
         # the kernel writes dL/dv_prev and dL/d(trace)_prev; dL/dz_prev only for ALIF -- otherwise that slice is
         # the recurrent conv's input gradient (written below) or zero
@@ -578,7 +592,7 @@ class _CellStep(torch.autograd.Function):
                  (_lib.zeros(C, dtype=torch.float32, device=dev) if (prm[i] is not None and need[6 + i]) else None)
                  for i in range(4)]
         _lib.call("evf_neuron_bwd", kind, _lib.ptr(gs[0]) if gs is not None else None, _lib.ptr(gon),
-                  _lib.ptr(gs[1]) if gs is not None else None, _lib.ptr(gs[2]) if (gs is not None and ns == 3) else None,
+                  _lib.ptr(gs[1]) if gs is not None else _lib.ptr(gon2), _lib.ptr(gs[2]) if (gs is not None and ns == 3) else None,
                   _lib.ptr(new[0]), _lib.ptr(new[2]) if ns == 3 else None, _lib.ptr(sp[0]) if sp is not None else None,
                   _lib.ptr(sp[1]) if sp is not None else None, _lib.ptr(sp[2]) if (sp is not None and ns == 3) else None,
                   _lib.ptr(P), _lib.ptr(prm[0]), _lib.ptr(prm[1]), _lib.ptr(prm[2]), _lib.ptr(prm[3]), B * Ho * Wo, C,
@@ -680,17 +694,36 @@ def cell_forward(cell, input_, prev_state, residual=0, slots=None):
             prev_state = torch.stack([prev_state[0], group_norm1(prev_state[1], cell.norm_rec)])
     # (norm="weight": the normalised weights are new tensors every call; their packs are keyed by the (v, g) pair: _pack_tag)
     wrec = conv_weight(cell.rec) if cell.recurrent else None
-    out, new = _CellStep.apply(cell, input_, prev_state, res, slots, conv_weight(cell.ff), wrec, *p)
+    out, new, out2 = _CellStep.apply(cell, input_, prev_state, res, slots, conv_weight(cell.ff), wrec, *p)
     # provenance: out = spikes (+ residual); the state's z slice is spikes
     rtag = spike_tag(res)
-    if res is None:
-        set_spike_tag(out, 1.0)
-    elif rtag is not None and rtag[1] == 0:
-        set_spike_tag(out, 1.0 + rtag[0])
-        # spikes + a residual that is a bilinear blend (multiples of 1/16) is no longer integer-valued: a second up-sampling of
-        # such a sum would make multiples of 1/256, which the exact-input kernels answer with NaN (the promise is guarded)
-        out._evf_spike_int = getattr(res, "_evf_spike_int", True)
+    for o in (out, out2):
+        if res is None:
+            set_spike_tag(o, 1.0)
+        elif rtag is not None and rtag[1] == 0:
+            set_spike_tag(o, 1.0 + rtag[0])
+            # spikes + a residual that is a bilinear blend (multiples of 1/16) is no longer integer-valued: a second up-sampling of
+            # such a sum would make multiples of 1/256, which the exact-input kernels answer with NaN (the promise is guarded)
+            o._evf_spike_int = getattr(res, "_evf_spike_int", True)
+    if FORK_TWIN:
+        out._evf_twin = out2
     return out, new
+
+
+# OPT-IN (EVF_FORK_TWIN=1): measured on the spiking EV-FlowNet step (BASELINE configs[3], A/B twice on one box) 6.79 ms with the
+# twins against 6.775 ms without -- the neuron kernel's state-gradient variant (its second z-gradient slot) costs what the nine
+# saved add launches (~9 us each) bring.  Off: every consumer takes the output itself and autograd adds the gradients.
+FORK_TWIN = os.environ.get("EVF_FORK_TWIN", "0") == "1"
+
+
+def twin(x):
+    """The second view of a cell output for its SECOND consumer (see _CellStep.forward): same memory, same values, its own slot
+    in the producing cell's backward.  Handed out once; a third consumer (or a tensor that is no cell output) gets `x` itself."""
+    t = getattr(x, "_evf_twin", None)
+    if t is None:
+        return x
+    x._evf_twin = None
+    return t
 
 
 # ---------------------------------------------------------------------------

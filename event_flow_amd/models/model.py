@@ -11,6 +11,8 @@ work unchanged.  All arithmetic runs in libevflow_hip.so through
 models/engine.py; the model's tensors must be on the MI355X.
 """
 
+import os
+
 import torch
 
 from .. import _lib
@@ -93,7 +95,33 @@ class FireNet(BaseModel):
                 and len({c.kind for c in cells}) == 1
                 and all(c.hidden_size == 32 and c.kernel_size == 3 and c.stride == 1 for c in cells)
             )
+            if not self._use_fused and os.environ.get("EVF_PATH_NOTICE", "1") != "0":
+                # not silently: once per model, say which path serves it and why (both paths are HIP; there is no CPU path)
+                import sys
+
+                print(f"[event_flow_amd] {type(self).__name__}: general path (one fused conv + neuron kernel per cell, "
+                      f"models/hip_ops.py) -- {self.compute_path[1]}; the recorded 32-channel window kernels (models/engine.py) "
+                      "serve LIF / PLIF FireNets with base_num_channels=32, kernel_size=3, no residual / weight / group norm",
+                      file=sys.stderr)
         return self._use_fused
+
+    @property
+    def compute_path(self):
+        """("fused" | "general", reason): which HIP path serves this network (train.py, bench.py and the tests read it)."""
+        cells = self._cells()
+        kinds = {getattr(c, "kind", type(c).__name__) for c in cells}
+        why = []
+        if self.residual:
+            why.append("residual connections")
+        if any(getattr(c, "kind", None) not in ("lif", "plif") for c in cells):
+            why.append("cell kind(s) " + ", ".join(sorted(str(k) for k in kinds)))
+        elif len(kinds) > 1:
+            why.append("mixed cell kinds")
+        if any(getattr(c, "wnorm", False) or getattr(c, "gnorm", False) for c in cells):
+            why.append("normalised weights / group norm")
+        if any(getattr(c, "hidden_size", 32) != 32 or getattr(c, "kernel_size", 3) != 3 or getattr(c, "stride", 1) != 1 for c in cells):
+            why.append("width / kernel size other than 32 / 3")
+        return ("general", "; ".join(why)) if why else ("fused", "")
 
     def _eng(self):
         if self._engine is None:

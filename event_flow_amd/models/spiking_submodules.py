@@ -285,7 +285,7 @@ class SpikingResidualBlock(nn.Module):
         conv1, conv2 = prev_state
         slots = hip_ops.StateSlots(2)
         x1, conv1 = self.conv1(x, conv1, slots=slots)
-        x2, conv2 = self.conv2(x1, conv2, residual=x, slots=slots)
+        x2, conv2 = self.conv2(x1, conv2, residual=hip_ops.twin(x), slots=slots)  # (the block input's second consumer)
         return x2, stack_states([conv1, conv2], slots)
 
 

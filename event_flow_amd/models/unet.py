@@ -161,14 +161,14 @@ class BaseUNet(nn.Module):
                 # concatenation and bilinear x2 in one kernel: the low-resolution cat is never written
                 parts, pad = self._decoder_parts(x, blocks[-1 - i], predictions[-1] if i else None, decoder)
                 x, self.states[offset + i] = decoder.forward_upsampled(hip_ops.concat_up2(parts, pad), self.states[offset + i])
-                predictions.append(pred(x))
+                predictions.append(pred(hip_ops.twin(x)))  # (x feeds the prediction and the next decoder: the cell's twin output)
                 continue
             x = self._decoder_input(x, blocks[-1 - i], predictions[-1] if i else None, decoder)
             if stateful:
                 x, self.states[offset + i] = decoder(x, self.states[offset + i])
             else:
                 x = decoder(x)
-            predictions.append(pred(x))
+            predictions.append(pred(hip_ops.twin(x)))
         return predictions
 
 
@@ -245,10 +245,12 @@ class MultiResUNetRecurrent(BaseUNet):
         self.states = [None] * self.num_states
 
     def _encode(self, x):
+        from . import hip_ops
+
         blocks = []
         for i, encoder in enumerate(self.encoders):
             x, self.states[i] = encoder(x, self.states[i])
-            blocks.append(x)
+            blocks.append(hip_ops.twin(x))  # (the skip connection: the second consumer of the encoder's output)
         return x, blocks
 
     def forward(self, x):

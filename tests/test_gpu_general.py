@@ -1190,3 +1190,45 @@ def test_general_path_one_window_cycle_keeps_the_previous_state_for_the_backward
     assert np.linalg.norm(upd_e) > 0 and np.linalg.norm(upd_g - upd_e) <= 1e-3 * np.linalg.norm(upd_e)
     for a, b in zip(s_eager, s_graph):  # the forward is deterministic: the new state is the eager step's bit for bit
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("passes", [1, 2])
+def test_cell_output_twins_give_the_gradients_of_autograd_accumulation(passes, monkeypatch):
+    """hip_ops.FORK_TWIN (EVF_FORK_TWIN=1, opt-in): a cell output with two consumers hands the second one a twin view and the
+    producing cell's backward receives the two gradients as two arguments (added inside the neuron kernel, or by one add when
+    the state gradient holds that slot -- windows of several passes -- or the sum is the residual's gradient).  Same loss and
+    the same parameter gradients (round-off of a + b in another place) as with autograd's own accumulation, on a spiking
+    EV-FlowNet: encoders -> skip + next encoder, decoders -> prediction + next decoder, residual block inputs."""
+    from event_flow_amd import synthetic
+    from event_flow_amd.loss.flow import EventWarping
+    from event_flow_amd.models import hip_ops
+    from event_flow_amd.train import encode_passes
+
+    B, n, H, W = 2, 3000, 64, 64
+    cfg = {"num_bins": 2, "base_num_channels": 8, "kernel_size": 3, "encoding": "cnt", "norm_input": False, "mask_output": True,
+           "activations": ["arctanspike", "arctanspike"],
+           "spiking_neuron": {"leak": [-4.0, 0.1], "thresh": [0.3, 0.05], "learn_leak": True, "learn_thresh": True, "hard_reset": True}}
+    lc = {"loader": {"resolution": [H, W]}, "loss": {"flow_regul_weight": 0.001, "overwrite_intermediate": False}, "model": {"mask_output": True}}
+    win = encode_passes([torch.from_numpy(synthetic.event_list_batch(B, n, H, W, 900 + k)).to(DEV) for k in range(passes)], 2, (H, W))
+
+    def run(twins):
+        monkeypatch.setattr(hip_ops, "FORK_TWIN", twins)
+        torch.manual_seed(0)
+        model = SpikingRecEVFlowNet(dict(cfg)).to(DEV)
+        model.train()
+        lossf = EventWarping(lc, DEV)
+        for d in win:
+            out = model(d["event_voxel"], d["event_cnt"])
+            lossf.event_flow_association(out["flow"], d["event_list"], d["event_list_pol_mask"], d["event_mask"])
+        loss = lossf()
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {k: N(p.grad).copy() for k, p in model.named_parameters() if p.grad is not None}
+
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert l0 == l1 and set(g0) == set(g1) and len(g0) > 20
+    num = np.sqrt(sum(float(((g1[k] - g0[k]) ** 2).sum()) for k in g0))
+    den = np.sqrt(sum(float((g0[k] ** 2).sum()) for k in g0))
+    print(f"[twins, {passes} pass(es)] loss {l0:.6f}, gradient rel-L2 between the two forms {num / den:.2e}")
+    assert den > 0 and num <= 1e-5 * den
