@@ -122,6 +122,12 @@ int evf_conv3_b3t_plan(const float* src, int B, int H, int W, int K, int N, int 
 int evf_conv3_b3t_launch(const float* src, int lds, const void* wp, const float* bias, float* out, int ldo, int B, int H, int W,
                          int K, int N, int flip, int accumulate, int ksplit, hipStream_t st);
 
+// evf_conv_b3img.hip: 3x3 stride-1 convolution of images of at most 16 x 16 pixels with many channels (one block per image x 64
+// output channels x K split); same operands and meaning of the arguments as the tile kernel's pair above
+int evf_conv3_b3i_plan(const float* src, int B, int H, int W, int K, int N, int lds, bool force, int max_split, int force_split);
+int evf_conv3_b3i_launch(const float* src, int lds, const void* wp, const float* bias, float* out, int ldo, int B, int H, int W,
+                         int K, int N, int flip, int accumulate, int ksplit, hipStream_t st);
+
 // evf_conv_b3small.hip: 3x3 stride-1 forward product of an input exactly representable in bf16 from channel `exact_from` on (the
 // caller's promise; NaN if broken)
 int evf_conv3_b3x_plan(const float* src, int B, int H, int W, int K, int N, int lds, int exact_from, long slab_cap);

@@ -600,6 +600,24 @@ static int b3_launch(const float* src, const void* wp, const float* bias, float*
       return evf_status();
     }
   }
+  // low-resolution many-channel 3x3 stride-1 layers (images of at most 16 x 16): one block per image x 64 output channels x K
+  // split (evf_conv_b3img.hip); EVF_CONV_IMG=0 disables
+  if (g.ksz == 3 && g.stride == 1 && b3_tile_mode() != 0) {
+    const int ks = evf_conv3_b3i_plan(src, g.B, g.OH, g.OW, g.K, g.N, g.lds, b3_tile_mode() == 2, (int)min(cap, 8L), b3_split_force());
+    if (ks == 1)
+      return evf_conv3_b3i_launch(src, g.lds, wp, bias, out, g.ldo, g.B, g.OH, g.OW, g.K, g.N, g.mode, accumulate, 1, st);
+    if (ks > 1) {
+      const int rc = evf_conv3_b3i_launch(src, g.lds, wp, nullptr, ws, g.N, g.B, g.OH, g.OW, g.K, g.N, g.mode, 0, ks, st);
+      if (rc != EVF_OK) return rc;
+      if (parts) {
+        *parts = ks;
+        return EVF_OK;
+      }
+      hipLaunchKernelGGL(k_b3_reduce, dim3(evf_cdiv(M * (g.N >> 2), 256)), dim3(256), 0, st, ws, ks, M, g.N, bias, out, g.ldo,
+                         accumulate);
+      return evf_status();
+    }
+  }
   // wide high-resolution 3x3 stride-1 layers: the spatially tiled kernel (evf_conv_b3tile.hip); EVF_CONV_TILE=0 disables
   if (g.ksz == 3 && g.stride == 1 && b3_tile_mode() != 0) {
     const int ks = evf_conv3_b3t_plan(src, g.B, g.OH, g.OW, g.K, g.N, g.lds, b3_tile_mode() == 2, (int)min(cap, 8L),

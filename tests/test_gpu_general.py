@@ -69,6 +69,11 @@ CONV_CASES = [
     (1, 32, 132, 33, 65, 3, 1),
     (1, 20, 96, 18, 34, 3, 1),
     (2, 512, 64, 8, 8, 3, 1),  # low resolution, many channels: the layers that split their contraction
+    # images of at most 16 x 16 with many channels: the whole-image kernel (evf_conv_b3img.hip; forced in the b3tile modes)
+    (2, 128, 192, 16, 16, 3, 1),
+    (1, 96, 64, 13, 16, 3, 1),
+    (3, 64, 40, 4, 7, 3, 1),
+    (8, 512, 512, 16, 16, 3, 1),  # the spiking EV-FlowNet's 512-channel layers at their benched size (its own plan picks the kernel)
 ]
 
 
@@ -145,7 +150,8 @@ def test_conv2d_b3_spike_inputs_take_the_three_term_product_without_changing_res
 
 
 @pytest.mark.parametrize("conv_mode", ["b3", "b3tile", "b3split", "b3tilesplit"], indirect=True)
-@pytest.mark.parametrize("case", [(2, 64, 96, 20, 36, 3, 1), (1, 132, 30, 17, 33, 3, 1), (2, 32, 64, 12, 12, 3, 2), (1, 48, 8, 9, 9, 1, 1)])
+@pytest.mark.parametrize("case", [(2, 64, 96, 20, 36, 3, 1), (1, 132, 30, 17, 33, 3, 1), (2, 32, 64, 12, 12, 3, 2), (1, 48, 8, 9, 9, 1, 1),
+                                  (2, 64, 96, 16, 12, 3, 1)])
 def test_conv2d_b3_bias_and_accumulate_through_every_kernel(case, conv_mode):
     """y (+)= conv(x) + bias and g_x (+)= conv^T(g_y) through the general, tiled and split-K kernels: the accumulate and
     bias paths of their epilogues and of the slab reduction (recurrent cells accumulate the rec conv into the ff conv)."""
