@@ -122,6 +122,12 @@ int evf_conv3_b3t_plan(const float* src, int B, int H, int W, int K, int N, int 
 int evf_conv3_b3t_launch(const float* src, int lds, const void* wp, const float* bias, float* out, int ldo, int B, int H, int W,
                          int K, int N, int flip, int accumulate, int ksplit, hipStream_t st);
 
+// evf_conv_b3n.hip: 3x3 stride-1 convolution with the halo tile staged once per channel group and up to 192 output channels
+// streaming past it (layers with many output channels per input tile: the decoders' input gradients); same arguments as the tile kernel's
+int evf_conv3_b3n_plan(const float* src, int B, int H, int W, int K, int N, int lds, bool force, int max_split, int force_split);
+int evf_conv3_b3n_launch(const float* src, int lds, const void* wp, const float* bias, float* out, int ldo, int B, int H, int W,
+                         int K, int N, int flip, int accumulate, int ksplit, hipStream_t st);
+
 // evf_conv_b3img.hip: 3x3 stride-1 convolution of images of at most 16 x 16 pixels with many channels (one block per image x 64
 // output channels x K split); same operands and meaning of the arguments as the tile kernel's pair above
 int evf_conv3_b3i_plan(const float* src, int B, int H, int W, int K, int N, int lds, bool force, int max_split, int force_split);

@@ -562,6 +562,13 @@ static int b3_split_force() {
   return g_split_force;
 }
 
+// EVF_CONV_NSTREAM=2 (tests): with the tile family forced (evf_conv_tile_select(2)) take the N-streaming kernel wherever its operands
+// allow, instead of the tile kernel
+static bool b3_nstream_forced() {
+  const char* e = getenv("EVF_CONV_NSTREAM");
+  return e && e[0] == '2';
+}
+
 extern "C" int evf_conv_split_select(int n) {  // n > 0: force n K splits wherever the scratch allows; 0: by shape
   if (n < 0 || n > 64) return EVF_EINVAL;
   g_split_force = n;
@@ -608,6 +615,25 @@ static int b3_launch(const float* src, const void* wp, const float* bias, float*
       return evf_conv3_b3i_launch(src, g.lds, wp, bias, out, g.ldo, g.B, g.OH, g.OW, g.K, g.N, g.mode, accumulate, 1, st);
     if (ks > 1) {
       const int rc = evf_conv3_b3i_launch(src, g.lds, wp, nullptr, ws, g.N, g.B, g.OH, g.OW, g.K, g.N, g.mode, 0, ks, st);
+      if (rc != EVF_OK) return rc;
+      if (parts) {
+        *parts = ks;
+        return EVF_OK;
+      }
+      hipLaunchKernelGGL(k_b3_reduce, dim3(evf_cdiv(M * (g.N >> 2), 256)), dim3(256), 0, st, ws, ks, M, g.N, bias, out, g.ldo,
+                         accumulate);
+      return evf_status();
+    }
+  }
+  // 3x3 stride-1 layers with three or more 32-channel output tiles per input tile (the decoders' input gradients): the halo staged
+  // once per channel group, the output channels streaming past it (evf_conv_b3n.hip); EVF_CONV_NSTREAM=0 disables
+  if (g.ksz == 3 && g.stride == 1 && b3_tile_mode() != 0) {
+    const int ks = evf_conv3_b3n_plan(src, g.B, g.OH, g.OW, g.K, g.N, g.lds, b3_tile_mode() == 2 && b3_nstream_forced(), (int)min(cap, 8L),
+                                      b3_split_force());
+    if (ks == 1)
+      return evf_conv3_b3n_launch(src, g.lds, wp, bias, out, g.ldo, g.B, g.OH, g.OW, g.K, g.N, g.mode, accumulate, 1, st);
+    if (ks > 1) {
+      const int rc = evf_conv3_b3n_launch(src, g.lds, wp, nullptr, ws, g.N, g.B, g.OH, g.OW, g.K, g.N, g.mode, 0, ks, st);
       if (rc != EVF_OK) return rc;
       if (parts) {
         *parts = ks;

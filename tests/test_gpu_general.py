@@ -74,6 +74,11 @@ CONV_CASES = [
     (1, 96, 64, 13, 16, 3, 1),
     (3, 64, 40, 4, 7, 3, 1),
     (8, 512, 512, 16, 16, 3, 1),  # the spiking EV-FlowNet's 512-channel layers at their benched size (its own plan picks the kernel)
+    # many output channels per input tile: the decoders' input gradients (evf_conv_b3n.hip; forced in the b3nstream modes):
+    # 5 N tiles with a 4-channel remainder, 9 tiles in two chunks, ragged spatial tiles (8 x 32)
+    (2, 132, 32, 24, 40, 3, 1),
+    (1, 260, 64, 19, 33, 3, 1),
+    (1, 32, 200, 9, 70, 3, 1),
 ]
 
 
@@ -83,14 +88,16 @@ def conv_mode(request, monkeypatch):
     b3tile: its spatially tiled 3x3 stride-1 kernel wherever the operands allow; f32: the fp32-MFMA kernels."""
     mode = request.param
     monkeypatch.setattr(hip_ops, "CONV_B3", mode != "f32")
-    assert _lib.load().evf_conv_tile_select(2 if mode.startswith("b3tile") else 0) == 0
+    # b3nstream: the tile family forced AND its N-streaming member (evf_conv_b3n.hip) wherever the operands allow
+    monkeypatch.setenv("EVF_CONV_NSTREAM", "2" if mode.startswith("b3nstream") else "1")
+    assert _lib.load().evf_conv_tile_select(2 if mode.startswith(("b3tile", "b3nstream")) else 0) == 0
     assert _lib.load().evf_conv_split_select(3 if mode.endswith("split") else 0) == 0  # (deterministic slab reduction)
     yield mode
     _lib.load().evf_conv_tile_select(-1)
     _lib.load().evf_conv_split_select(0)
 
 
-@pytest.mark.parametrize("conv_mode", ["b3", "b3tile", "b3split", "b3tilesplit", "f32"], indirect=True)
+@pytest.mark.parametrize("conv_mode", ["b3", "b3tile", "b3split", "b3tilesplit", "b3nstream", "b3nstreamsplit", "f32"], indirect=True)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_forward_dgrad_wgrad_vs_cpu(case, conv_mode):
     B, Cin, Cout, H, W, k, s = case
@@ -117,7 +124,7 @@ def test_conv2d_forward_dgrad_wgrad_vs_cpu(case, conv_mode):
     close(N(bd.grad), br.grad.numpy(), 2e-5, "bias grad")
 
 
-@pytest.mark.parametrize("conv_mode", ["b3", "b3tile"], indirect=True)
+@pytest.mark.parametrize("conv_mode", ["b3", "b3tile", "b3nstream"], indirect=True)
 @pytest.mark.parametrize("case", [(2, 130, 32, 20, 24, 3, 1), (1, 64, 128, 16, 16, 3, 2), (2, 66, 40, 9, 11, 5, 1),
                                   (2, 132, 64, 40, 70, 3, 1)])
 def test_conv2d_b3_spike_inputs_take_the_three_term_product_without_changing_results(case, conv_mode):
@@ -149,7 +156,7 @@ def test_conv2d_b3_spike_inputs_take_the_three_term_product_without_changing_res
     assert not np.array_equal(ya[0, :, 0, 0], yb[0, :, 0, 0])
 
 
-@pytest.mark.parametrize("conv_mode", ["b3", "b3tile", "b3split", "b3tilesplit"], indirect=True)
+@pytest.mark.parametrize("conv_mode", ["b3", "b3tile", "b3split", "b3tilesplit", "b3nstream", "b3nstreamsplit"], indirect=True)
 @pytest.mark.parametrize("case", [(2, 64, 96, 20, 36, 3, 1), (1, 132, 30, 17, 33, 3, 1), (2, 32, 64, 12, 12, 3, 2), (1, 48, 8, 9, 9, 1, 1),
                                   (2, 64, 96, 16, 12, 3, 1)])
 def test_conv2d_b3_bias_and_accumulate_through_every_kernel(case, conv_mode):
