@@ -47,7 +47,7 @@ typedef __attribute__((address_space(1))) const void i_glb_void;
 #define I_NT 2                        // 32-channel N tiles per block
 #define I_WFRAG (I_NT * 27)           // 1 KiB weight fragments per group
 #define I_WBUF (I_WFRAG * 1024)       // bytes per weight buffer
-#define I_LDS (3 * I_PLANE + 2 * I_WBUF)
+#define I_LDS (3 * I_PLANE + 2 * I_WBUF)  // (the register form uses one weight buffer; the allocation stays: one block per CU either way)
 #ifndef I_UNROLL_TAPS
 #define I_UNROLL_TAPS 1  // the nine taps unrolled: the next tap's fragment reads issue under this tap's MFMAs (one wave per SIMD: nobody else hides them)
 #endif
@@ -107,6 +107,28 @@ __global__ __launch_bounds__(I_THREADS) void k_conv3_b3i(const float* __restrict
       __builtin_amdgcn_global_load_lds((i_glb_void*)srcw, (i_lds_void*)(s_w + buf * I_WBUF + f * 1024), 16, 0, 0);
     }
   };
+#ifndef I_WDMA
+#define I_WDMA 1  // 1: the weight fragments by LDS-DMA into the other of two buffers (the matrix waves issue the pieces themselves); 0: through
+#endif            //    registers like the halo -- requested before the matrix phase, written to LDS behind it into ONE buffer: measured
+                  //    110-114 against 64-65 us per 512 -> 512 input gradient (the write sits exposed between two barriers, 198 registers)
+  constexpr int WITER = (I_WFRAG * 64 + I_THREADS - 1) / I_THREADS;  // uint4 per thread and group (register form)
+  uint4 pw[I_WDMA ? 1 : WITER];
+  auto fetch_w = [&](int kc) {
+    const int gg = kc >> 2, ch = kc & 3;
+#pragma unroll
+    for (int i = 0; i < (I_WDMA ? 0 : WITER); ++i) {
+      const int idx = min(tid + I_THREADS * i, I_WFRAG * 64 - 1), ln = idx & 63, f = idx >> 6;
+      const int term = f % 3, f2 = f / 3, tap = f2 % 9, t = f2 / 9;
+      pw[i] = wp[min(nt_base + t, ntiles - 1) * wtile + (((long)tap * G64 + gg) * 4 + ch) * 192 + term * 64 + ln];
+    }
+  };
+  auto commit_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < (I_WDMA ? 0 : WITER); ++i) {
+      const int idx = tid + I_THREADS * i;
+      if (idx < I_WFRAG * 64) ((uint4*)(s_w + buf * I_WBUF))[idx] = pw[i];
+    }
+  };
   auto commit = [&](int kc) -> int {  // returns "some residual is not zero" for this thread's elements
     uint32_t nz = 0u;
 #pragma unroll
@@ -141,17 +163,23 @@ __global__ __launch_bounds__(I_THREADS) void k_conv3_b3i(const float* __restrict
 
   int inexact = 0;
   if (kc_hi > kc_lo) {
-    dma_w(kc_lo, 0);
+    if (I_WDMA) dma_w(kc_lo, 0);
+    else fetch_w(kc_lo);
     fetch(kc_lo);
     const int nzv = commit(kc_lo);
+    if (!I_WDMA) commit_w(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the weight DMA of this wave has landed)
     inexact = __syncthreads_or(nzv);
   }
 #pragma unroll 1
   for (int kc = kc_lo; kc < kc_hi; ++kc) {
-    const int buf = (kc - kc_lo) & 1;
+    const int buf = I_WDMA ? (kc - kc_lo) & 1 : 0;
     const bool more = kc + 1 < kc_hi;
-    if (more) dma_w(kc + 1, buf ^ 1);  // (the other buffer was last read in group kc - 1: every wave is past that barrier)
+    if (I_WDMA) {
+      if (more) dma_w(kc + 1, buf ^ 1);  // (the other buffer was last read in group kc - 1: every wave is past that barrier)
+    } else {
+      fetch_w(min(kc + 1, kc_hi - 1));
+    }
     fetch(min(kc + 1, kc_hi - 1));
     // ---- matrix phase: 9 taps x (2 M tiles x 2 N tiles) x 3 | 6 products
     // M tile m of this wave = image rows 4 wv + 2 m, + 1; the lane's pixel is (row 4 wv + 2 m + mr, column mc)
@@ -218,6 +246,7 @@ __global__ __launch_bounds__(I_THREADS) void k_conv3_b3i(const float* __restrict
     }
     __syncthreads();  // every wave is done with this group's planes (and with weight buffer `buf`)
     if (more) {
+      if (!I_WDMA) commit_w(0);
       const int nzv = commit(kc + 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's pieces of the next weight buffer have landed)
       inexact = __syncthreads_or(nzv);
