@@ -224,12 +224,17 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
           const wb_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           gq[pl] = *(const w_bf16x8*)&v;
         }
+#ifdef WB_PROBE_NOMFMA  // (A/B probe, never shipped: the operand reads stay, the matrix pipe is idle)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) asm volatile("" ::"v"(xa[c]), "v"(gq[0]), "v"(gq[1]), "v"(gq[2]));
+#else
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[c], gq[2], acc[c][t], 0, 0, 0);
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[c], gq[1], acc[c][t], 0, 0, 0);
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[c], gq[0], acc[c][t], 0, 0, 0);
+#endif
       }
     }
 #else
