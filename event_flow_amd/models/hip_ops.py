@@ -522,19 +522,23 @@ class _CellStep(torch.autograd.Function):
             new = _routed(state, (ns, B, Ho, Wo, C))
             if new is None:
                 new = _new((ns, B, Ho, Wo, C), dev)
-        out = _new((B, Ho, Wo, C), dev)
+        # without a residual the cell's output IS its spike tensor, the z entry of the new state: no second copy of it is written
+        # (one tensor pass of seven less per forward cell; EVF_OUT_ALIAS=0: a tensor of its own as before)
+        alias_out = OUT_ALIAS and rn is None
+        out = new[1] if alias_out else _new((B, Ho, Wo, C), dev)
+        out_ptr = None if alias_out else _lib.ptr(out)
         prm = [p.detach().reshape(-1).contiguous() if p is not None else None for p in (p0, p1, p2, p3)]
         if parts is not None:
             (ta, na, sa), (tb, nb, sb) = parts
             _lib.call("evf_lif_fwd_parts", _lib.ptr(ta), na, sa, _lib.ptr(tb), nb, sb, _lib.ptr(sp[0]) if sp is not None else None,
                       _lib.ptr(sp[1]) if sp is not None else None, _lib.ptr(rn), _lib.ptr(prm[0]), _lib.ptr(prm[1]), B * Ho * Wo, C,
-                      1 if cell.hard_reset else 0, _lib.ptr(new[0]), _lib.ptr(new[1]), _lib.ptr(out))
+                      1 if cell.hard_reset else 0, _lib.ptr(new[0]), _lib.ptr(new[1]), out_ptr)
         else:
             _lib.call("evf_neuron_fwd", kind, _lib.ptr(cur), _lib.ptr(sp[0]) if sp is not None else None,
                   _lib.ptr(sp[1]) if sp is not None else None, _lib.ptr(sp[2]) if (sp is not None and ns == 3) else None,
                   _lib.ptr(P), _lib.ptr(rn), _lib.ptr(prm[0]), _lib.ptr(prm[1]), _lib.ptr(prm[2]), _lib.ptr(prm[3]),
                   B * Ho * Wo, C, 1 if cell.hard_reset else 0, _lib.ptr(new[0]), _lib.ptr(new[1]),
-                  _lib.ptr(new[2]) if ns == 3 else None, _lib.ptr(out))
+                  _lib.ptr(new[2]) if ns == 3 else None, out_ptr)
         ctx.cell, ctx.kind, ctx.ns = cell, kind, ns
         tag = spike_tag(x)
         ctx.exact_from = tag[1] if tag is not None else None  # provenance of the input (conv_wgrad)
@@ -714,6 +718,7 @@ def cell_forward(cell, input_, prev_state, residual=0, slots=None):
 # twins against 6.775 ms without -- the neuron kernel's state-gradient variant (its second z-gradient slot) costs what the nine
 # saved add launches (~9 us each) bring.  Off: every consumer takes the output itself and autograd adds the gradients.
 FORK_TWIN = os.environ.get("EVF_FORK_TWIN", "0") == "1"
+OUT_ALIAS = os.environ.get("EVF_OUT_ALIAS", "1") != "0"  # a cell without residual returns the z slice of its new state as its output
 
 
 def twin(x):
