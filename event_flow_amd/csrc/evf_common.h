@@ -140,11 +140,12 @@ int evf_conv3_b3x_plan(const float* src, int B, int H, int W, int K, int N, int 
 int evf_conv3_b3x_launch(const float* src, int lds, const void* wp, float* dst, int ldo, int B, int H, int W, int K, int N,
                          int exact_from, long slab_cap, hipStream_t st);
 
-// evf_wgrad_b3gen.hip: bf16 matrix-core weight gradient of the general 3x3 stride-1 convolution behind evf_conv2d_wgrad
+// evf_wgrad_b3gen.hip: bf16 matrix-core weight gradient of the general 3x3 convolution (stride 1 or 2) behind evf_conv2d_wgrad
 bool evf_wgrad9_b3_ok(const float* x, const float* gy, int Cin, int Cout, int ldx, int ldg);
 int evf_wgrad9_b3_launch(const float* x, int ldx, const float* gy, int ldg, float* slab, float* gbias, int* redo, int B, int H,
                          int W, int Cin, int Cout, int nsplit, int CT, int NT, hipStream_t st, float* fuse_gw = nullptr,
-                         int* tickets = nullptr, int cin_total = 0, int cin_off = 0, int accumulate = 0, int promised = 0);
+                         int* tickets = nullptr, int cin_total = 0, int cin_off = 0, int accumulate = 0, int promised = 0,
+                         int stride = 1);
 
 // evf_dgrad_ws.hip: wave-specialised input-gradient kernel behind evf_conv_dgrad_b3_f32[_pair]
 // PLIF: d loss / d(input spike) through the pooled pre-synaptic trace at pixel (y, x) of sample b.  raw = 0: g_P is the boxed,

@@ -43,7 +43,8 @@ typedef short wb_s16x8 __attribute__((ext_vector_type(8)));
 #define WB_PPITCH(CH) ((CH) == 64 ? 192 : 64)  // bytes per pixel of a [pixel][CH channels] bf16 image
 
 struct WgB3Geo {
-  int B, H, W, Cin, Cout, ldx, ldg;
+  int B, H, W, Cin, Cout, ldx, ldg;  // H, W: the INPUT image
+  int OH, OW;                        // the output image (= H, W at stride 1; (H - 1) / 2 + 1 at stride 2, padding 1)
   int tiles_x, tiles_y, tiles_per_split, n_ct;
   long ntiles;
 };
@@ -65,20 +66,28 @@ struct WgFuse {
   int promised;  // the caller promised an exact x (with or without the fused reduction): a violation poisons the block's slab
 };
 
-template <int CT, int NT>
+// STRIDE 2 (round 6; the encoders of the spiking EV-FlowNet, reference models/unet.py:335-353): the 8 x 8 tile is a tile of the OUTPUT
+// (g) image, the x patch behind it is 17 x 17 input pixels (input pixel (2 oy + dy - 1, 2 ox + dx - 1) meets output pixel (oy, ox)), and
+// a fragment's pixel run steps over every other pixel of a patch row: the transposing read takes an address PER LANE, so the stride is
+// two pixel pitches instead of one -- the same kernel, nine waves = nine taps.  (Before: these layers ran the fp32-MFMA kernel
+// k_wgrad9 at 0.07-0.09 of the bf16 peak.)
+template <int CT, int NT, int STRIDE = 1>
 __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, const float* __restrict__ gy,
                                                    float* __restrict__ slab, float* __restrict__ gbias, int* __restrict__ redo,
                                                    WgB3Geo g, WgFuse fz) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int XQ = 8 * CT, GQ = 8 * NT;                 // float4 per pixel
-  constexpr int NLX = (WB_HP * XQ + 575) / 576;           // x float4 loads per thread
+  constexpr int HS = (WB_T - 1) * STRIDE + 3;             // edge of the x patch of a tile: 10 (stride 1) / 17 (stride 2)
+  constexpr int XHP = HS * HS;                            // its pixels
+  static_assert(STRIDE == 1 || WB_TR, "stride 2: transposing-read layout only");
+  constexpr int NLX = (XHP * XQ + 575) / 576;             // x float4 loads per thread
   constexpr int NLG = (WB_T * WB_T * GQ + 575) / 576;     // g float4 loads per thread
   constexpr int GPL = 32 * NT * WB_GP;                    // bytes per g plane
 #if WB_TR
   constexpr int XPP = WB_PPITCH(32 * CT), GPP = WB_PPITCH(32 * NT);  // pixel pitches
   constexpr int GPL_TR = WB_T * WB_T * GPP;                             // bytes per g plane
-  char* s_x = smem;                                       // [100 halo pixels][XPP]
-  char* s_g = smem + WB_HP * XPP;                         // [3 planes][64 pixels][GPP]
+  char* s_x = smem;                                       // [XHP patch pixels][XPP]
+  char* s_g = smem + XHP * XPP;                           // [3 planes][64 pixels][GPP]
   float* s_b = (float*)(s_g + 3 * GPL_TR);                // [32 NT] bias partial sums
 #else
   char* s_x = smem;                                       // [32 CT channels][WB_XP]
@@ -117,9 +126,9 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
 #pragma unroll
     for (int i = 0; i < NLX; ++i) {
       const int idx = tid + 576 * i, hp = idx / XQ, q = idx - hp * XQ;
-      const int hr = hp / (WB_T + 2), hc = hp - hr * (WB_T + 2);
-      const int sy = y0 + hr - 1, sx = x0 + hc - 1, c = ci0 + 4 * q;
-      const bool ok = tok && hp < WB_HP && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W && c + 4 <= g.Cin;
+      const int hr = hp / HS, hc = hp - hr * HS;
+      const int sy = STRIDE * y0 + hr - 1, sx = STRIDE * x0 + hc - 1, c = ci0 + 4 * q;
+      const bool ok = tok && hp < XHP && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W && c + 4 <= g.Cin;
       const float4 v = *(const float4*)(ok ? x + (((long)b * g.H + sy) * g.W + sx) * g.ldx + c : x);
       xr[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -127,8 +136,8 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
     for (int i = 0; i < NLG; ++i) {
       const int idx = tid + 576 * i, px = idx / GQ, q = idx - px * GQ;
       const int oy = y0 + (px >> 3), ox = x0 + (px & 7), c = co0 + 4 * q;
-      const bool ok = tok && px < WB_T * WB_T && oy < g.H && ox < g.W && c + 4 <= g.Cout;
-      const float4 v = *(const float4*)(ok ? gy + (((long)b * g.H + oy) * g.W + ox) * g.ldg + c : gy);
+      const bool ok = tok && px < WB_T * WB_T && oy < g.OH && ox < g.OW && c + 4 <= g.Cout;
+      const float4 v = *(const float4*)(ok ? gy + (((long)b * g.OH + oy) * g.OW + ox) * g.ldg + c : gy);
       gr[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (++n_tx == g.tiles_x) {
@@ -140,8 +149,8 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
 #pragma unroll
     for (int i = 0; i < NLX; ++i) {
       const int idx = tid + 576 * i, hp = idx / XQ, q = idx - hp * XQ;
-      if (hp >= WB_HP) continue;
-      const int hr = hp / (WB_T + 2), hc = hp - hr * (WB_T + 2);
+      if (hp >= XHP) continue;
+      const int hr = hp / HS, hc = hp - hr * HS;
       const uint32_t h01 = evf_pk_bf16(xr[i].x, xr[i].y), h23 = evf_pk_bf16(xr[i].z, xr[i].w);
       // exactly representable?  (else this channel tile is redone in fp32)
       inexact |= (int)(xr[i].x != __uint_as_float(h01 << 16)) | (int)(xr[i].y != __uint_as_float(h01 & 0xFFFF0000u)) |
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
     // (i16 & 3) of the group's 16 channels ((lane >> 4) & 1: lower / upper half of the 32-channel tile) and RECEIVES the four
     // pixels of channel (lane & 31); two reads (pixels 0..3, 4..7 of the tile row) make the fragment
     const int i16 = lane & 15, g16 = (lane >> 4) & 1;
-    const int lane_x = (i16 >> 2) * XPP + (g16 * 16 + (i16 & 3) * 4) * 2;
+    const int lane_x = (i16 >> 2) * STRIDE * XPP + (g16 * 16 + (i16 & 3) * 4) * 2;
     const int lane_g = (i16 >> 2) * GPP + (g16 * 16 + (i16 & 3) * 4) * 2;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -207,9 +216,9 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
       w_bf16x8 xa[CT];
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        const char* pp = s_x + ((r + dy) * (WB_T + 2) + dx) * XPP + c * 64 + lane_x;
+        const char* pp = s_x + ((STRIDE * r + dy) * HS + dx) * XPP + c * 64 + lane_x;
         const wb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((WB_LDS wb_s16x4*)pp);
-        const wb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((WB_LDS wb_s16x4*)(pp + 4 * XPP));
+        const wb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((WB_LDS wb_s16x4*)(pp + 4 * STRIDE * XPP));
         const wb_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         xa[c] = *(const w_bf16x8*)&v;
       }
@@ -362,20 +371,21 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
   }
 }
 
-template <int CT, int NT>
+template <int CT, int NT, int STRIDE = 1>
 static void wb_go(const float* x, const float* gy, float* slab, float* gbias, int* redo, const WgB3Geo& g, int nsplit, int n_nt,
                   hipStream_t st, const WgFuse& fz) {
 #if WB_TR
-  const size_t smem = (size_t)WB_HP * WB_PPITCH(32 * CT) + 3 * WB_T * WB_T * WB_PPITCH(32 * NT) + 32 * NT * sizeof(float) + 16;
+  constexpr int HS = (WB_T - 1) * STRIDE + 3;
+  const size_t smem = (size_t)HS * HS * WB_PPITCH(32 * CT) + 3 * WB_T * WB_T * WB_PPITCH(32 * NT) + 32 * NT * sizeof(float) + 16;
 #else
   const size_t smem = (size_t)32 * CT * WB_XP + 3 * 32 * NT * WB_GP + 32 * NT * sizeof(float) + 16;
 #endif
   static bool once = false;
   if (!once) {
-    (void)hipFuncSetAttribute((const void*)k_wgrad9_b3<CT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)k_wgrad9_b3<CT, NT, STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     once = true;
   }
-  hipLaunchKernelGGL((k_wgrad9_b3<CT, NT>), dim3(nsplit, g.n_ct * n_nt), dim3(576), smem, st, x, gy, slab, gbias, redo, g, fz);
+  hipLaunchKernelGGL((k_wgrad9_b3<CT, NT, STRIDE>), dim3(nsplit, g.n_ct * n_nt), dim3(576), smem, st, x, gy, slab, gbias, redo, g, fz);
 }
 
 // Can the bf16 kernel take this 3x3 stride-1 weight gradient?  (float4 tile loads of both operands)
@@ -387,17 +397,25 @@ bool evf_wgrad9_b3_ok(const float* x, const float* gy, int Cin, int Cout, int ld
 // fuse_gw != null: the fused reduction (x promised exact; `tickets` >= n_ct * n_nt zeroed ints, handed back zeroed; nsplit < 65536)
 int evf_wgrad9_b3_launch(const float* x, int ldx, const float* gy, int ldg, float* slab, float* gbias, int* redo, int B, int H,
                          int W, int Cin, int Cout, int nsplit, int CT, int NT, hipStream_t st, float* fuse_gw, int* tickets,
-                         int cin_total, int cin_off, int accumulate, int promised) {
+                         int cin_total, int cin_off, int accumulate, int promised, int stride) {
   WgFuse fz;
   fz.gw = fuse_gw, fz.ticket = fuse_gw ? tickets : nullptr, fz.cin_total = cin_total, fz.cin_off = cin_off, fz.accumulate = accumulate;
   fz.promised = (promised || fuse_gw) ? 1 : 0;
   WgB3Geo g;
   g.B = B, g.H = H, g.W = W, g.Cin = Cin, g.Cout = Cout, g.ldx = ldx, g.ldg = ldg;
-  g.tiles_x = evf_cdiv(W, WB_T), g.tiles_y = evf_cdiv(H, WB_T);
+  g.OH = stride == 2 ? (H - 1) / 2 + 1 : H, g.OW = stride == 2 ? (W - 1) / 2 + 1 : W;  // (3 x 3, padding 1)
+  g.tiles_x = evf_cdiv(g.OW, WB_T), g.tiles_y = evf_cdiv(g.OH, WB_T);
   g.ntiles = (long)B * g.tiles_x * g.tiles_y;
   g.tiles_per_split = (int)evf_cdiv(g.ntiles, (long)nsplit);
   g.n_ct = evf_cdiv(Cin, 32 * CT);
   const int n_nt = evf_cdiv(Cout, 32 * NT);
+  if (stride == 2) {  // (no fused reduction at stride 2: fz.ticket is null there)
+    if (CT == 2 && NT == 2) wb_go<2, 2, 2>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st, fz);
+    else if (CT == 2) wb_go<2, 1, 2>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st, fz);
+    else if (NT == 2) wb_go<1, 2, 2>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st, fz);
+    else wb_go<1, 1, 2>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st, fz);
+    return evf_status();
+  }
   if (CT == 2 && NT == 2)
     wb_go<2, 2>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st, fz);
   else if (CT == 2)

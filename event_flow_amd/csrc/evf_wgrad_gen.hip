@@ -967,7 +967,8 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
     static const bool b3 = !(getenv("EVF_WGRAD") && !strcmp(getenv("EVF_WGRAD"), "f32"));
     const int* redo = nullptr;
     float* bias_f32 = g_bias;
-    if (b3 && !analog && stride == 1 && p.g.n_ct <= 64 && evf_wgrad9_b3_ok(x, g_y, Cin, Cout, ldx, ldg)) {
+    static const bool b3_s2 = !(getenv("EVF_WGRAD_S2") && !strcmp(getenv("EVF_WGRAD_S2"), "f32"));  // (stride 2 on the bf16 kernel: A/B switch)
+    if (b3 && !analog && (stride == 1 || b3_s2) && p.g.n_ct <= 64 && evf_wgrad9_b3_ok(x, g_y, Cin, Cout, ldx, ldg)) {
       // 64 persistent flags per device (zero at load, cleared again by k_wgrad_reduce: no memset per call; calls are
       // stream-ordered on one stream per device)
       int* flags = wg_redo_flags();
@@ -977,14 +978,14 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
       // of the kernel with nothing to hide it -- +47 us per call over k_wgrad_reduce's 25 us launch (8.75 against 8.42 ms per step)
       // for <= 8 splits; with 16..256 splits (few weight tiles) the last block reads 1..9 MB through ONE CU: 13.4 ms per step.
       static const bool fuse_ok = getenv("EVF_WGRAD_FUSE") && !strcmp(getenv("EVF_WGRAD_FUSE"), "1");
-      if (exact && fuse_ok && p.nsplit <= 8 && (long)p.g.n_ct * p.n_nt <= WG_TICKETS) {
+      if (exact && fuse_ok && stride == 1 && p.nsplit <= 8 && (long)p.g.n_ct * p.n_nt <= WG_TICKETS) {
         int* tickets = wg_tickets();
         if (!tickets) return EVF_EINVAL;
         return evf_wgrad9_b3_launch(x, ldx, g_y, ldg, ws, g_bias, flags, B, H, W, Cin, Cout, p.nsplit, p.CT, p.NT, st, g_w, tickets,
-                                    cin_total, cin_off, accumulate);
+                                    cin_total, cin_off, accumulate, 1, 1);
       }
       int rc = evf_wgrad9_b3_launch(x, ldx, g_y, ldg, ws, g_bias, flags, B, H, W, Cin, Cout, p.nsplit, p.CT, p.NT, st, nullptr, nullptr,
-                                    0, 0, 0, exact ? 1 : 0);
+                                    0, 0, 0, exact ? 1 : 0, stride);
       if (rc) return rc;
       redo = flags;
       bias_f32 = nullptr;  // (summed by the bf16 kernel from the exact fp32 gradients)
