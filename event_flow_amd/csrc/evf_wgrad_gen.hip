@@ -804,6 +804,7 @@ static int wg_fewin_blocks(int B, int H, int W, int Cout) {
 // 16 x 9 = 144 consecutive floats of gw go out (and come in) as whole lines.
 #define WRT_CO 32  // (32 output channels = one whole 128-byte line of a slab row per (tap, input channel))
 #define WRT_CI 16
+template <bool V4>
 __global__ __launch_bounds__(256) void k_wgrad_reduce_t(const float* __restrict__ slab, int nsplit, int Cin, int Cout, int cin_total,
                                                         int cin_off, int accumulate, float* __restrict__ gw, int* __restrict__ clear_flags) {
   __shared__ float tile[WRT_CO * (WRT_CI * 9 + 1)];
@@ -811,6 +812,37 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_t(const float* __restrict_
   const int tid = threadIdx.x, co0 = blockIdx.x * WRT_CO, ci0 = blockIdx.y * WRT_CI;
   const long per = (long)9 * Cin * Cout;
   constexpr int NE = WRT_CO * WRT_CI * 9, NJ = NE / 256, TP = WRT_CI * 9 + 1;
+  if (V4) {
+    // 16-byte loads along co (round 6; Cout % 4 == 0, slabs 16-byte aligned): a thread takes four output channels of one (tap, input
+    // channel) -- 5 trips of 256 threads for the 1152 quads instead of 18 trips of scalar loads; per element the same four partial
+    // sums in the same order: the same bits
+    constexpr int NQ = NE / 4, NJ4 = (NQ + 255) / 256;
+#pragma unroll
+    for (int j = 0; j < NJ4; ++j) {
+      const int idx = tid + 256 * j, co4 = idx % (WRT_CO / 4), r = idx / (WRT_CO / 4), ci_l = r % WRT_CI, tap = r / WRT_CI;
+      const int co = co0 + 4 * co4, ci = ci0 + ci_l;
+      const bool ok = idx < NQ && co < Cout && ci < Cin;  // (Cout % 4 == 0: a quad is inside or outside as a whole)
+      const float4* __restrict__ p = (const float4*)(slab + ((long)min(tap, 8) * Cin + (ok ? ci : 0)) * Cout + (ok ? co : 0));
+      const long per4 = per >> 2;
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+      auto acc4 = [](float4& a, const float4 v) { a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w; };
+      int k = 0;
+      for (; k + 3 < nsplit; k += 4) {
+        acc4(a0, p[(long)k * per4]);
+        acc4(a1, p[(long)(k + 1) * per4]);
+        acc4(a2, p[(long)(k + 2) * per4]);
+        acc4(a3, p[(long)(k + 3) * per4]);
+      }
+      for (; k < nsplit; ++k) acc4(a0, p[(long)k * per4]);
+      if (idx < NQ) {
+        float* t = tile + (4 * co4) * TP + ci_l * 9 + tap;
+        t[0] = ok ? (a0.x + a1.x) + (a2.x + a3.x) : 0.f;
+        t[TP] = ok ? (a0.y + a1.y) + (a2.y + a3.y) : 0.f;
+        t[2 * TP] = ok ? (a0.z + a1.z) + (a2.z + a3.z) : 0.f;
+        t[3 * TP] = ok ? (a0.w + a1.w) + (a2.w + a3.w) : 0.f;
+      }
+    }
+  } else {
 #pragma unroll 3
   for (int j = 0; j < NJ; ++j) {  // (18 trips: three of them, i.e. twelve loads, in flight)
     const int idx = tid + 256 * j, co_l = idx % WRT_CO, r = idx / WRT_CO, ci_l = r % WRT_CI, tap = r / WRT_CI;
@@ -827,6 +859,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_t(const float* __restrict_
     }
     for (; k < nsplit; ++k) a0 += p[(long)k * per];
     tile[co_l * TP + ci_l * 9 + tap] = ok ? (a0 + a1) + (a2 + a3) : 0.f;
+  }
   }
   __syncthreads();
 #pragma unroll 2
@@ -1014,8 +1047,13 @@ extern "C" int evf_conv2d_wgrad(const float* x, int ldx, const float* g_y, int l
     // big weights with few splits: the transposing reduction (coalesced gradient lines); many splits of a small weight keep the
     // 16 split groups per output of k_wgrad_reduce
     if (rt_on && p.nsplit <= 32 && (long)evf_cdiv(Cout, WRT_CO) * evf_cdiv(Cin, WRT_CI) >= 128) {
-      hipLaunchKernelGGL(k_wgrad_reduce_t, dim3(evf_cdiv(Cout, WRT_CO), evf_cdiv(Cin, WRT_CI)), dim3(256), 0, st, ws, p.nsplit, Cin,
-                         Cout, cin_total, cin_off, accumulate, g_w, (int*)redo);
+      static const bool v4_on = !(getenv("EVF_WGRAD_REDUCE_V4") && !strcmp(getenv("EVF_WGRAD_REDUCE_V4"), "0"));
+      if (v4_on && Cout % 4 == 0 && (((uintptr_t)ws) & 15) == 0 && (per & 3) == 0)
+        hipLaunchKernelGGL(k_wgrad_reduce_t<true>, dim3(evf_cdiv(Cout, WRT_CO), evf_cdiv(Cin, WRT_CI)), dim3(256), 0, st, ws, p.nsplit, Cin,
+                           Cout, cin_total, cin_off, accumulate, g_w, (int*)redo);
+      else
+        hipLaunchKernelGGL(k_wgrad_reduce_t<false>, dim3(evf_cdiv(Cout, WRT_CO), evf_cdiv(Cin, WRT_CI)), dim3(256), 0, st, ws, p.nsplit, Cin,
+                           Cout, cin_total, cin_off, accumulate, g_w, (int*)redo);
       return evf_status();
     }
     const int rg = p.nsplit >= 16 ? 16 : (p.nsplit >= 8 ? 8 : (p.nsplit >= 4 ? 4 : (p.nsplit >= 2 ? 2 : 1)));
