@@ -136,6 +136,7 @@ NETWORK_SIGNATURES = {
     "evf_conv2d_dgrad_b3": [P, I, P, P, I, I, I, I, I, I, I, I, I, P, L, P],
     "evf_conv_tile_select": [I],
     "evf_conv_split_select": [I],
+    "evf_wgrad_teams_select": [I],
     "evf_conv2d_wgrad_ws": [I, I, I, I, I, I, I],
     "evf_conv2d_wgrad": [P, I, P, I, P, P, I, I, I, I, I, I, I, I, I, I, P, P],
     "evf_neuron_fwd": [I, P, P, P, P, P, P, P, P, P, P, L, I, I, P, P, P, P, P],

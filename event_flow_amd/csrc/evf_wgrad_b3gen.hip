@@ -16,6 +16,8 @@
 //           [split][tap][ci][co] k_wgrad_reduce sums (same layout as k_wgrad9)
 //   x not exactly representable (a decoder's two flow channels, analog networks): the block raises redo[ci tile] and the
 //           caller re-runs the fp32 kernel for exactly those channel tiles (k_wgrad9 exits at once for the others).
+#include <stdlib.h>
+
 #include "evf_common.h"
 #include "evf_split.h"
 
@@ -371,6 +373,257 @@ __global__ __launch_bounds__(576) void k_wgrad9_b3(const float* __restrict__ x, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_wgrad9_b3v (round 6): the same product, slabs and accumulation order as k_wgrad9_b3 at stride 1, as TWO TEAMS.
+//
+// What k_wgrad9_b3 loses (probe builds): nine tap waves on four SIMDs (the SIMD with three of them sets the pace: 3 x 48
+// MFMAs per tile against 108 per SIMD when balanced), every tap wave re-reads the tile's g fragments (64 transposing reads per 48
+// MFMAs: the LDS pipe is busier than the matrix pipe), and the conversion + LDS stores of the next tile sit BETWEEN two barriers
+// with the matrix pipe idle.  Here:
+//   waves 0..3  MATRIX team, one wave per SIMD: wave w owns ONE 32 ci x 32 co weight tile of the block's CTB x NTB = 4 and ALL nine
+//               taps of it (nine accumulators, 144 registers): 108 MFMAs per 8 x 8 pixel tile and wave -- balanced --; a g fragment
+//               is read once for the nine taps, an x fragment (patch row, column shift dx) once for the up to two (pixel row, dy)
+//               pairs that meet it: 78 transposing reads per 108 MFMAs;
+//   waves 4..7  LOADER team: float4 loads of the tile after next, bf16 conversion / exact 3-way split and the LDS stores of the next
+//               tile into the OTHER half of a double buffer, behind the matrix team's MFMAs: ONE barrier per tile.
+// Per accumulator the products arrive in k_wgrad9_b3's order (pixel tiles ascending, pixel rows 2 ks + kg ascending, lo / mid / hi),
+// so the slabs are bit-identical.  Blocks and slabs as before (one block per CU, <= 256 blocks).
+// ---------------------------------------------------------------------------------------------------------------------
+#define WV_PITCH(CH) ((CH) * 2 <= 64 ? 64 : (CH) * 2 + 64)  // bytes per pixel of a [pixel][CH] bf16 image: 64 (mod 256)
+#define WV_HS (WB_T + 2)
+#define WV_XHP (WV_HS * WV_HS)
+
+__device__ __forceinline__ w_bf16x8 wv_frag(const char* p, int half) {  // two transposing reads: pixels 0..3, 4..7 of the row
+  const wb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((WB_LDS wb_s16x4*)p);
+  const wb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((WB_LDS wb_s16x4*)(p + half));
+  const wb_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return *(const w_bf16x8*)&v;
+}
+
+template <int CTB, int NTB>
+__global__ __launch_bounds__(512) void k_wgrad9_b3v(const float* __restrict__ x, const float* __restrict__ gy,
+                                                    float* __restrict__ slab, float* __restrict__ gbias, int* __restrict__ redo,
+                                                    WgB3Geo g, int promised) {
+  static_assert(CTB * NTB == 4, "four matrix waves = four 32 x 32 weight tiles");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int XQ = 8 * CTB, GQ = 8 * NTB;                       // float4 per pixel
+  constexpr int XPP = WV_PITCH(32 * CTB), GPP = WV_PITCH(32 * NTB);
+  constexpr int XB = WV_XHP * XPP, GPL = WB_T * WB_T * GPP, BUF = XB + 3 * GPL;  // bytes: x image, one g plane, one buffer
+  constexpr int NLX = (WV_XHP * XQ + 255) / 256, NLG = (WB_T * WB_T * GQ) / 256;
+  static_assert((WB_T * WB_T * GQ) % 256 == 0 && 256 % GQ == 0, "loader thread <-> output-channel quad");
+  float* s_b = (float*)(smem + 2 * BUF);                          // [32 NTB] bias partial sums
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int cit = blockIdx.y % g.n_ct, cot = blockIdx.y / g.n_ct;
+  const int ci0 = cit * 32 * CTB, co0 = cot * 32 * NTB;
+  const bool do_bias = gbias && cit == 0;
+  if (tid < 32 * NTB) s_b[tid] = 0.f;
+  const int ntile = g.tiles_per_split;
+  int inexact = 0;
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  w_f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  if (wv >= 4) {
+    // ---------------- loader team
+    const int lt = tid - 256;
+    float4 xA[NLX], gA[NLG], xB[NLX], gB[NLG];  // two tiles of loads in flight (a tile's loads get two trips to land)
+    int n_tx, n_ty, n_b;
+    {
+      const long t0 = (long)blockIdx.x * g.tiles_per_split;
+      n_tx = (int)(t0 % g.tiles_x);
+      const long t1 = t0 / g.tiles_x;
+      n_ty = (int)(t1 % g.tiles_y), n_b = (int)(t1 / g.tiles_y);
+    }
+    // (no uniform branches around the loads: a load under a branch is followed by s_waitcnt vmcnt(0))
+    auto prefetch = [&](float4 (&xr)[NLX], float4 (&gr)[NLG], bool want) {
+      const bool tok = want && n_b < g.B;
+      const int b = min(n_b, g.B - 1);
+      const int y0 = n_ty * WB_T, x0 = n_tx * WB_T;
+#pragma unroll
+      for (int i = 0; i < NLX; ++i) {
+        const int idx = lt + 256 * i, hp = idx / XQ, q = idx - hp * XQ;
+        const int hr = hp / WV_HS, hc = hp - hr * WV_HS;
+        const int sy = y0 + hr - 1, sx = x0 + hc - 1, c = ci0 + 4 * q;
+        const bool ok = tok && hp < WV_XHP && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W && c + 4 <= g.Cin;
+        const float4 v = *(const float4*)(ok ? x + (((long)b * g.H + sy) * g.W + sx) * g.ldx + c : x);
+        xr[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < NLG; ++i) {
+        const int idx = lt + 256 * i, px = idx / GQ, q = idx - px * GQ;
+        const int oy = y0 + (px >> 3), ox = x0 + (px & 7), c = co0 + 4 * q;
+        const bool ok = tok && oy < g.OH && ox < g.OW && c + 4 <= g.Cout;
+        const float4 v = *(const float4*)(ok ? gy + (((long)b * g.OH + oy) * g.OW + ox) * g.ldg + c : gy);
+        gr[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (++n_tx == g.tiles_x) {
+        n_tx = 0;
+        if (++n_ty == g.tiles_y) n_ty = 0, ++n_b;
+      }
+    };
+    auto commit = [&](const float4 (&xr)[NLX], const float4 (&gr)[NLG], int buf) {
+      char* s_x = smem + buf * BUF;
+      char* s_g = s_x + XB;
+#pragma unroll
+      for (int i = 0; i < NLX; ++i) {
+        const int idx = lt + 256 * i, hp = idx / XQ, q = idx - hp * XQ;
+        if (hp >= WV_XHP) continue;
+        const uint32_t h01 = evf_pk_bf16(xr[i].x, xr[i].y), h23 = evf_pk_bf16(xr[i].z, xr[i].w);
+        inexact |= (int)(xr[i].x != __uint_as_float(h01 << 16)) | (int)(xr[i].y != __uint_as_float(h01 & 0xFFFF0000u)) |
+                   (int)(xr[i].z != __uint_as_float(h23 << 16)) | (int)(xr[i].w != __uint_as_float(h23 & 0xFFFF0000u));
+        *(uint2*)(s_x + hp * XPP + q * 8) = make_uint2(h01, h23);
+      }
+#pragma unroll
+      for (int i = 0; i < NLG; ++i) {
+        const int idx = lt + 256 * i, px = idx / GQ, q = idx - px * GQ;
+        uint32_t h0, m0, l0, h1, m1, l1;
+        evf_split3_pair(gr[i].x, gr[i].y, h0, m0, l0);
+        evf_split3_pair(gr[i].z, gr[i].w, h1, m1, l1);
+        bs[0] += gr[i].x, bs[1] += gr[i].y, bs[2] += gr[i].z, bs[3] += gr[i].w;
+        char* pt = s_g + px * GPP + q * 8;
+        *(uint2*)(pt) = make_uint2(h0, h1);
+        *(uint2*)(pt + GPL) = make_uint2(m0, m1);
+        *(uint2*)(pt + 2 * GPL) = make_uint2(l0, l1);
+      }
+    };
+    // tile k travels in register set A (k even) / B (k odd) and lands in buffer k & 1
+    prefetch(xA, gA, true);
+    prefetch(xB, gB, ntile > 1);
+    commit(xA, gA, 0);
+    prefetch(xA, gA, ntile > 2);
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < ntile; it += 2) {
+      // trip `it` (even): the matrix team reads buffer 0; tile it + 1 -> buffer 1 (last read in trip it - 1, before that trip's barrier)
+#ifndef WV_PROBE_NOCOMMIT  // (probe builds, never shipped: what do the loader team's LDS stores / loads cost the matrix team?)
+      if (it + 1 < ntile) commit(xB, gB, 1);
+#endif
+#ifndef WV_PROBE_NOLOAD
+      prefetch(xB, gB, it + 3 < ntile);
+#endif
+      __syncthreads();
+      if (it + 1 >= ntile) break;
+      // trip it + 1 (odd): tile it + 2 -> buffer 0
+#ifndef WV_PROBE_NOCOMMIT
+      if (it + 2 < ntile) commit(xA, gA, 0);
+#endif
+#ifndef WV_PROBE_NOLOAD
+      prefetch(xA, gA, it + 4 < ntile);
+#endif
+      __syncthreads();
+    }
+  } else {
+    // ---------------- matrix team: wave = weight tile (c, t), nine taps
+    const int c = wv / NTB, t = wv - c * NTB, kg = lane >> 5;
+    const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+    // transposing reads (see k_wgrad9_b3): lane i16 of a 16-lane group addresses pixel (i16 >> 2) of a 4-pixel run and the 4-channel
+    // piece (i16 & 3) of the group's 16 channels and RECEIVES the four pixels of channel (lane & 31)
+    const int off_x = (kg * WV_HS) * XPP + c * 64 + (i16 >> 2) * XPP + (g16 * 16 + (i16 & 3) * 4) * 2;
+    const int off_g = (kg * WB_T) * GPP + t * 64 + (i16 >> 2) * GPP + (g16 * 16 + (i16 & 3) * 4) * 2;
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < ntile; ++it) {
+      const char* bx = smem + (it & 1) * BUF + off_x;
+      const char* bg = smem + (it & 1) * BUF + XB + off_g;
+      w_bf16x8 gq[2][3];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {  // patch row j + kg meets pixel row 2 ks + kg at dy = j - 2 ks
+        w_bf16x8 xf[3];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) xf[dx] = wv_frag(bx + (j * WV_HS + dx) * XPP, 4 * XPP);
+        if (!(j & 1) && j < 8) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) gq[(j >> 1) & 1][pl] = wv_frag(bg + pl * GPL + (j * WB_T) * GPP, 4 * GPP);
+        }
+#pragma unroll
+        for (int dy = 2; dy >= 0; --dy) {  // (the older pixel row first: its g fragments are the ones about to be replaced)
+          const int k2 = j - dy;
+          if (k2 < 0 || (k2 & 1) || k2 > 6) continue;
+          const int sl = (k2 >> 1) & 1;
+#ifdef WV_PROBE_NOMFMA  // (probe build: the operand reads stay, the matrix pipe is idle)
+          asm volatile("" ::"v"(xf[0]), "v"(xf[1]), "v"(xf[2]), "v"(gq[sl][0]), "v"(gq[sl][1]), "v"(gq[sl][2]));
+#else
+#pragma unroll
+          for (int pl = 2; pl >= 0; --pl)  // smallest terms first
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+              acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[dx], gq[sl][pl], acc[dy * 3 + dx], 0, 0, 0);
+#endif
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  const int blk_inexact = __syncthreads_or(inexact);
+  const float poison = (promised && blk_inexact) ? __builtin_nanf("") : 0.f;
+  if (wv < 4) {  // slab[split][tap][ci][co] (co fastest)
+    const int c = wv / NTB, t = wv - c * NTB, row = lane & 31;
+    float* sl = slab + (long)blockIdx.x * 9 * g.Cin * g.Cout;
+    const int co = co0 + t * 32 + row;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + c * 32 + wb_row(r, lane);
+        if (ci < g.Cin && co < g.Cout) sl[((long)tap * g.Cin + ci) * g.Cout + co] = acc[tap][r] + poison;
+      }
+  }
+  if (blk_inexact && tid == 0 && !promised) atomicOr(redo + cit, 1);
+  if (do_bias) {
+    if (wv >= 4) {
+      const int q = (tid - 256) % GQ;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(s_b + 4 * q + j, bs[j]);
+    }
+    __syncthreads();
+    if (tid < 32 * NTB && co0 + tid < g.Cout) evf_atomic_add(gbias + co0 + tid, s_b[tid]);
+  }
+}
+
+template <int CTB, int NTB>
+static void wv_go(const float* x, const float* gy, float* slab, float* gbias, int* redo, const WgB3Geo& g, int nsplit, int n_nt,
+                  hipStream_t st, int promised) {
+  constexpr int XPP = WV_PITCH(32 * CTB), GPP = WV_PITCH(32 * NTB);
+  const size_t smem = (size_t)2 * (WV_XHP * XPP + 3 * WB_T * WB_T * GPP) + 32 * NTB * sizeof(float) + 16;
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute((const void*)k_wgrad9_b3v<CTB, NTB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    once = true;
+  }
+  hipLaunchKernelGGL((k_wgrad9_b3v<CTB, NTB>), dim3(nsplit, g.n_ct * n_nt), dim3(512), smem, st, x, gy, slab, gbias, redo, g, promised);
+}
+
+// MEASURED, NOT THE DEFAULT (EVF_WGRAD_TEAMS / evf_wgrad_teams_select: 0 off (default), 1 for blocks that walk >= 16 pixel tiles, 2
+// wherever the block shape fits (tests)).  LIF-EV-FlowNet shapes, B = 8, us per call incl. the slab reduction, the call repeated on
+// warm data, tap-per-wave / two teams: 64^2 x 512 -> 128: 130 / 121, 32^2 x 1024 -> 256: 127 / 119, 128^2 x 256 -> 64: 129 / 120;
+// 16^2 x 512 -> 512: 50.6 / 53.0, 32^2 x 256 -> 256: 51.1 / 53.4 (8 tiles per block: the fixed costs -- slab stores, reduction launch,
+// prologue -- decide).  Inside the replayed step (cold operands) mode 1 changes nothing: 6.540 / 6.535 against 6.533 / 6.562 ms.
+// Probe builds of THIS kernel at 128^2 x 256 -> 64 (us): complete 124; matrix team without its MFMAs 83; loader team idle (barriers
+// only) 98; loads without LDS stores 99; stores without loads 101; neither team working (operand reads, barriers, slab stores,
+// reduction) 43.  So: the fixed part is 43 of 124; the matrix team alone needs 55 on top of it for a bare-MFMA time of 46 (32 trips x
+// 108 MFMAs x 32 cycles at 2.1 GHz); the loader team alone 40 -- its 344 MB per call (fp32 spikes, 1.56x halo of the 8 x 8 tile, g
+// once per input-channel tile) are 5.9 TB/s there --; and together they take 81, not max(55, 40): matrix work under full memory
+// traffic runs at the lower clock the input-gradient kernels also see.  Two tiles of loads in flight instead of one
+// changed nothing (123 -> 120).  What would help is fewer BYTES: spike tensors kept in a 2-byte form beside the fp32 one.
+static int g_wb_teams = -1;
+static int wb_two_team() {
+  if (g_wb_teams < 0) {
+    const char* e = getenv("EVF_WGRAD_TEAMS");
+    g_wb_teams = e ? atoi(e) : 0;
+    if (g_wb_teams < 0 || g_wb_teams > 2) g_wb_teams = 0;
+  }
+  return g_wb_teams;
+}
+extern "C" int evf_wgrad_teams_select(int mode) {
+  if (mode < 0 || mode > 2) return EVF_EINVAL;
+  g_wb_teams = mode;
+  return EVF_OK;
+}
+
 template <int CT, int NT, int STRIDE = 1>
 static void wb_go(const float* x, const float* gy, float* slab, float* gbias, int* redo, const WgB3Geo& g, int nsplit, int n_nt,
                   hipStream_t st, const WgFuse& fz) {
@@ -414,6 +667,10 @@ int evf_wgrad9_b3_launch(const float* x, int ldx, const float* gy, int ldg, floa
     else if (CT == 2) wb_go<2, 1, 2>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st, fz);
     else if (NT == 2) wb_go<1, 2, 2>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st, fz);
     else wb_go<1, 1, 2>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st, fz);
+    return evf_status();
+  }
+  if (CT == 2 && NT == 2 && !fz.ticket && (wb_two_team() == 2 || (wb_two_team() == 1 && g.tiles_per_split >= 16))) {
+    wv_go<2, 2>(x, gy, slab, gbias, redo, g, nsplit, n_nt, st, fz.promised);
     return evf_status();
   }
   if (CT == 2 && NT == 2)

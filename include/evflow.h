@@ -623,6 +623,11 @@ int evf_conv_tile_select(int mode);
 /* K splits of the two entry points above: 0 by shape (default; environment EVF_CONV_SPLIT=n at load), n > 0 forces n
  * splits wherever the caller's scratch allows (tests). */
 int evf_conv_split_select(int n);
+/* 3x3 stride-1 weight gradients with > 32 input and output channels: the two-team kernel k_wgrad9_b3v (csrc/evf_wgrad_b3gen.hip:
+ * four matrix waves with nine taps each + four loader waves) -- 0 never (default; environment EVF_WGRAD_TEAMS at load: measured
+ * level with the tap-per-wave kernel k_wgrad9_b3 inside a train step), 1 where a block walks >= 16 pixel tiles, 2 wherever its
+ * block shape fits (tests).  Bit-identical slabs. */
+int evf_wgrad_teams_select(int mode);
 /* g_w [Cout][cin_total][k][k] (input channels cin_off ..) and optional g_bias [Cout]
  * (autograd w.r.t. weight / bias).  accumulate = 0 overwrites the outputs and needs cin_off = 0 and
  * Cin >= cin_total (channels past cin_total are activation padding and are skipped).  ws: scratch of evf_conv2d_wgrad_ws() floats (3x3, and 1x1 with Cout <= 4; null is accepted for 1x1 and selects the atomic split-K kernel):

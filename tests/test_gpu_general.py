@@ -247,6 +247,45 @@ def test_wgrad_fused_slab_reduction_equals_the_three_launch_path(case, monkeypat
     assert np.array_equal(N(g4), N(g2))
 
 
+@pytest.mark.parametrize("case", [(2, 128, 64, 16, 16), (1, 64, 64, 32, 40), (2, 72, 100, 17, 23), (8, 512, 512, 16, 16), (2, 256, 64, 64, 64),
+                                  (1, 64, 128, 9, 130), (3, 68, 64, 8, 8)])
+def test_wgrad_two_team_kernel_is_bit_identical_to_the_tap_per_wave_kernel(case):
+    """k_wgrad9_b3v (four matrix waves x nine taps + four loader waves, csrc/evf_wgrad_b3gen.hip) against k_wgrad9_b3 (a wave per tap):
+    the same products in the same order per accumulator -- the same bits --, and both against float64; bias gradient included;
+    spike-valued and real-valued x (the latter raises the redo flags: the fp32 pass recomputes the tiles)."""
+    B, Cin, Cout, H, W = case
+    gen = torch.Generator().manual_seed(B * 77 + Cin + W)
+    L = _lib.load()
+    ws = torch.empty(max(L.evf_conv2d_wgrad_ws(B, H, W, Cin, Cout, 3, 1), 1), device=DEV)
+    gy = torch.randn(B, Cout, H, W, generator=gen) * 0.1
+    gd = G(gy.permute(0, 2, 3, 1).contiguous().numpy())
+    for kind in ("spikes", "real"):
+        if kind == "spikes":
+            x = torch.randint(0, 3, (B, Cin, H, W), generator=gen).float() * (torch.rand(B, Cin, H, W, generator=gen) < 0.4)
+        else:
+            x = torch.randn(B, Cin, H, W, generator=gen)
+        xd = G(x.permute(0, 2, 3, 1).contiguous().numpy())
+        ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), gy.double(), padding=1).numpy()
+        out = {}
+        try:
+            for mode in (0, 2):  # (2: the two-team kernel wherever its block shape fits, whatever the tile count)
+                _lib.call("evf_wgrad_teams_select", mode)
+                g_w = torch.full((Cout, Cin, 3, 3), 3.0, device=DEV)
+                g_b = torch.full((Cout,), 5.0, device=DEV)
+                _lib.call("evf_conv2d_wgrad", _lib.ptr(xd), Cin, _lib.ptr(gd), Cout, _lib.ptr(g_w), _lib.ptr(g_b), B, H, W, Cin, Cout, 3, 1,
+                          Cin, 0, 0, _lib.ptr(ws))
+                torch.cuda.synchronize()
+                out[mode] = (N(g_w), N(g_b))
+        finally:
+            _lib.call("evf_wgrad_teams_select", 0)
+        assert np.array_equal(out[0][0], out[2][0]), (kind, np.abs(out[0][0] - out[2][0]).max())
+        scale = np.abs(ref).max()
+        assert np.abs(out[2][0] - ref).max() <= 1e-5 * scale, kind
+        bref = gy.double().sum((0, 2, 3)).numpy()
+        for m in (0, 2):
+            assert np.abs(out[m][1] - bref).max() <= 1e-5 * max(np.abs(bref).max(), 1.0), (kind, m)
+
+
 @pytest.mark.parametrize("case", [(8, 512, 512), (4, 128, 256), (2, 64, 512), (8, 1024, 128), (8, 256, 512), (16, 128, 512)])
 def test_small_image_exact_input_conv_equals_the_voting_kernels(case):
     """evf_conv2d_fwd_b3 with accumulate bit 2 ("x exactly representable in bf16 by construction") on 16 x 16 images: the
