@@ -608,7 +608,8 @@ static void wv_go(const float* x, const float* gy, float* slab, float* gbias, in
 // 108 MFMAs x 32 cycles at 2.1 GHz); the loader team alone 40 -- its 344 MB per call (fp32 spikes, 1.56x halo of the 8 x 8 tile, g
 // once per input-channel tile) are 5.9 TB/s there --; and together they take 81, not max(55, 40): matrix work under full memory
 // traffic runs at the lower clock the input-gradient kernels also see.  Two tiles of loads in flight instead of one
-// changed nothing (123 -> 120).  What would help is fewer BYTES: spike tensors kept in a 2-byte form beside the fp32 one.
+// changed nothing (123 -> 120), and neither does halving x's bytes (a probe build of k_wgrad9_b3 that loads 8 instead of 16 bytes
+// per four channels: 132 -> 128, 132 -> 131, 123 -> 125 us): what the loader team costs is not a matter of its bytes.
 static int g_wb_teams = -1;
 static int wb_two_team() {
   if (g_wb_teams < 0) {
