@@ -326,12 +326,32 @@ def encode_passes(event_lists, num_bins, res, want=("cnt", "mask", "voxel", "pol
     return encode_event_lists(event_lists, num_bins, res, want=want)
 
 
+class _CellListStates:
+    """`.states` of a FireNet-family network on the general path (models.model.FireNet._states: one entry per cell)."""
+
+    def __init__(self, model):
+        self.model = model
+
+    @property
+    def states(self):
+        return self.model._states
+
+    @states.setter
+    def states(self, value):
+        self.model._states = list(value)
+
+
 def _general_states(model):
-    """(holder, flat list of the state tensors) of a general-path recurrent model (models.model: *EVFlowNet / E2VID families:
-    a `multires_unetrec` / `unetrecurrent` whose `.states` is a list of tensors, tuples of tensors or None)."""
+    """(holder, flat list of the state tensors) of a general-path recurrent model: the *EVFlowNet / E2VID families (models.model: a
+    `multires_unetrec` / `unetrecurrent` whose `.states` is a list of tensors, tuples of tensors or None) and the FireNet family
+    when it is chained cell by cell (ANN / ALIF / XLIF / residual / other widths: `model._states`)."""
     holder = getattr(model, "multires_unetrec", None) or getattr(model, "unetrecurrent", None)
+    if holder is None and hasattr(model, "_states") and hasattr(model, "_fused") and not model._fused():
+        holder = _CellListStates(model)
     if holder is None or not hasattr(holder, "states"):
-        raise _lib.EvflowError("capture_window_cycle needs a model with multires_unetrec / unetrecurrent states")
+        raise _lib.EvflowError("capture_window_cycle needs a general-path recurrent model (multires_unetrec / unetrecurrent states, or "
+                               "a FireNet-family network off the fused engine); the fused LIF / PLIF FireNets replay through "
+                               "GraphedWindowStep")
     flat = []
     for st in holder.states:
         if st is not None:

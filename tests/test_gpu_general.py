@@ -1161,6 +1161,58 @@ def test_general_path_window_cycle_replays_without_state_copies():
     np.testing.assert_allclose(graph, eager, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("name", ["ALIFFireNet", "XLIFFireNet", "FireNet"])
+def test_general_path_window_cycle_of_the_firenet_family(name):
+    """train.capture_window_cycle also takes the FireNet family where it is chained cell by cell (ALIF / XLIF / ANN: `model._states`):
+    two windows of three passes each as two hipGraphs replayed alternately, the recurrent state crossing the replays, against the
+    same steps launched eagerly (learning rate 0, as the EV-FlowNet test above)."""
+    from event_flow_amd import synthetic
+    from event_flow_amd.loss.flow import EventWarping
+    from event_flow_amd.models import model as models
+    from event_flow_amd.train import FlatAdam, capture_window_cycle, encode_passes, train_window
+
+    B, n, H, W, P = 2, 1500, 32, 32, 3
+    cfg = {"num_bins": 2, "base_num_channels": 32, "kernel_size": 3, "encoding": "cnt", "norm_input": False, "mask_output": True,
+           "activations": ["relu", None] if name == "FireNet" else ["arctanspike", "arctanspike"]}
+    lc = {"loader": {"resolution": [H, W]}, "loss": {"flow_regul_weight": 0.001, "overwrite_intermediate": False}, "model": {"mask_output": True}}
+    pool = [encode_passes([torch.from_numpy(synthetic.event_list_batch(B, n, H, W, 31 + 7 * w + 1000 * k)).to(DEV) for k in range(P)], 2, (H, W))
+            for w in range(2)]
+
+    def run(graphed, nsteps=4, warm=2):
+        torch.manual_seed(0)
+        model = getattr(models, name)(dict(cfg)).to(DEV)
+        model.train()
+        assert model.compute_path[0] == ("general")
+        lossf = EventWarping(lc, DEV)
+        opt = FlatAdam(model, lr=0.0, clip=100.0, device_step=True)
+        opt.zero_grad()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        losses = []
+        with torch.cuda.stream(side):
+            for i in range(warm):
+                losses.append(float(train_window(model, lossf, opt, pool[i % 2])))
+            torch.cuda.synchronize()
+            if graphed:
+                graphs, _ = capture_window_cycle(model, lossf, opt, pool, side)
+                torch.cuda.synchronize()
+            for i in range(nsteps):
+                if graphed:
+                    graphs[i % 2][0].replay()
+                    torch.cuda.synchronize()
+                    losses.append(float(graphs[i % 2][1]))
+                else:
+                    losses.append(float(train_window(model, lossf, opt, pool[i % 2])))
+        torch.cuda.synchronize()
+        opt.close()
+        return losses
+
+    eager, graph = run(False), run(True)
+    print(name, "eager", eager, "\ngraph", graph)
+    assert all(np.isfinite(graph)) and len({round(v, 5) for v in eager[0::2]}) > 1, eager  # (the state matters)
+    np.testing.assert_allclose(graph, eager, rtol=1e-5, atol=1e-6)
+
+
 def test_general_path_one_window_cycle_keeps_the_previous_state_for_the_backward():
     """A cycle of ONE window starts from the very tensors it has to end in: its cells must not be routed onto themselves (the
     neuron kernels would overwrite the previous state the backward pass and the recurrent weight gradient still read).  With a
