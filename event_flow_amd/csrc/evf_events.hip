@@ -804,7 +804,7 @@ __global__ void k_cm_splat(const float* __restrict__ flow, const float4* __restr
 __device__ __forceinline__ void cm_prewarp_body(int bx, int s, const float* __restrict__ flow, const float4* __restrict__ ev,
                                                 const float2* __restrict__ pol, const int32_t* __restrict__ ev_pass, int S, int Pm,
                                                 int P, int B, int M, int H, int W, float Sc, float4* __restrict__ warp,
-                                                float* __restrict__ tabs) {
+                                                float* __restrict__ tabs, float* __restrict__ ys) {
   const long i = (long)bx * blockDim.x + threadIdx.x;
   if (i >= (long)B * M) return;
   const int b = (int)(i / M), e = (int)(i - (long)b * M);
@@ -819,12 +819,15 @@ __device__ __forceinline__ void cm_prewarp_body(int bx, int s, const float* __re
   float4* o = warp + ((long)(s * B + b) * 2) * M + e;
   o[0] = make_float4(f.wy, f.wx, pm.x, pm.y);
   o[M] = make_float4(g.wy, g.wx, pm.x, pm.y);
+  // the warped ROW once more, alone: a stripe block of k_cm_splat_lds decides on 4 bytes per event whether the event is its own
+  float* oy = ys + ((long)(s * B + b) * 2) * M + e;
+  oy[0] = f.wy, oy[M] = g.wy;
   if (s == 0) tabs[i] = t;
 }
 __global__ void k_cm_prewarp(const float* __restrict__ flow, const float4* __restrict__ ev, const float2* __restrict__ pol,
                              const int32_t* __restrict__ ev_pass, int S, int Pm, int P, int B, int M, int H, int W,
-                             float Sc, float4* __restrict__ warp, float* __restrict__ tabs) {
-  cm_prewarp_body(blockIdx.x, blockIdx.y, flow, ev, pol, ev_pass, S, Pm, P, B, M, H, W, Sc, warp, tabs);
+                             float Sc, float4* __restrict__ warp, float* __restrict__ tabs, float* __restrict__ ys) {
+  cm_prewarp_body(blockIdx.x, blockIdx.y, flow, ev, pol, ev_pass, S, Pm, P, B, M, H, W, Sc, warp, tabs, ys);
 }
 
 struct CmFin {  // what the LAST block of k_cm_splat_lds needs to finish the loss (stats == null: separate launches do it)
@@ -839,7 +842,7 @@ __device__ void cm_finalize_body(float* red, const float* stats, const float* __
                                  int nblk_per_scale, float weight, int comps, int loss_scaling, float* __restrict__ loss);
 
 __global__ __launch_bounds__(1024) void k_cm_splat_lds(const float4* __restrict__ warp, const float* __restrict__ tabs,
-                                                       int B, int M, int H, int W, int rows, float P,
+                                                       const float* __restrict__ ys, int B, int M, int H, int W, int rows, float P,
                                                        float* __restrict__ images, CmFin fin) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* img = (float*)smem_raw;  // [4][rows*W]: I_pos, I_neg, TS_pos, TS_neg of this direction
@@ -870,23 +873,70 @@ __global__ __launch_bounds__(1024) void k_cm_splat_lds(const float4* __restrict_
         float* px = img + ((int)cy[j] - r0) * W + (int)cx[i];
         const float wtau = wt * tau;
         const float v0 = wt * w4.z, v1 = wt * w4.w, u0 = wtau * w4.z, u1 = wtau * w4.w;
+#ifdef CM_PROBE_NOATOM  // (probe build: plain stores instead of the float atomics -- wrong sums, valid timing)
+        if (v0 != 0.f) px[0] = v0;
+        if (v1 != 0.f) px[plane] = v1;
+        if (u0 != 0.f) px[2 * plane] = u0;
+        if (u1 != 0.f) px[3 * plane] = u1;
+#else
         if (v0 != 0.f) atomicAdd(px, v0);
         if (v1 != 0.f) atomicAdd(px + plane, v1);
         if (u0 != 0.f) atomicAdd(px + 2 * plane, u0);
         if (u1 != 0.f) atomicAdd(px + 3 * plane, u1);
+#endif
       }
   };
-  // four events per thread and trip: their loads are issued together
-  int e = threadIdx.x;
-  for (; e + 3 * (int)blockDim.x < M; e += 4 * blockDim.x) {
-    const float4 a0 = wp[e], a1 = wp[e + blockDim.x], a2 = wp[e + 2 * blockDim.x], a3 = wp[e + 3 * blockDim.x];
-    const float t0 = tb[e], t1 = tb[e + blockDim.x], t2 = tb[e + 2 * blockDim.x], t3 = tb[e + 3 * blockDim.x];
-    one(a0, t0);
-    one(a1, t1);
-    one(a2, t2);
-    one(a3, t3);
+  // The scan.  Every stripe block passes over all M records of its sample; one event in H / rows is its own.  The warped ROW alone
+  // (4 bytes, `ys`) decides; CM_CH rows per thread are requested together, and the records of the accepted events are fetched CM_NB
+  // at a time, all loads of a batch issued before the first is used (a load under a divergent branch is waited for on the spot).
+  // Probe builds at 256 x 256 x 50 k events x 4 scales (512 blocks, us per launch): 189 complete = 39 without any event (fill,
+  // write-out, statistics, finish) + 21 rows tested and records fetched + 56 the weights and LDS stores of `one` + 73 that the float
+  // atomics cost over plain stores.  Tried on top, both level: the wave compacting its accepted events through an LDS queue so that
+  // `one` runs on full waves (188) -- the LDS float atomic is paid per LANE, 0.78 per CU and ns (tools/probes/lds_atomic_probe.hip;
+  // u32 14.8, u64 10.5) --, and 64-bit fixed-point slots (exact sums, 13x the atomic rate, but half the stripe height: every fixed
+  // and per-block cost twice; 424 us before the scan was cheap).
+#define CM_CH 16
+#define CM_NB 4
+  const float* __restrict__ yp = ys + (long)sbd * M;
+#ifdef CM_PROBE_NOSCAN  // (probe build: no events at all)
+  M = 0;
+#endif
+  auto mine = [&](float y) {  // (the row tests of `one`; NaN: no)
+    const float c0 = floorf(y), c1 = floorf(y + 1.0f);
+    return (c0 >= lo && c0 < hi) || (c1 >= lo && c1 < hi);
+  };
+  for (int e0 = threadIdx.x; e0 < M; e0 += CM_CH * (int)blockDim.x) {
+    float y[CM_CH];
+#pragma unroll
+    for (int k = 0; k < CM_CH; ++k) y[k] = yp[min(e0 + k * (int)blockDim.x, M - 1)];  // (clamped: the loads stay unconditional)
+    unsigned acc = 0u;
+#pragma unroll
+    for (int k = 0; k < CM_CH; ++k)
+      if (e0 + k * (int)blockDim.x < M && mine(y[k])) acc |= 1u << k;
+    while (__builtin_amdgcn_ballot_w64(acc != 0u) != 0ull) {  // (wave-uniform trip count: the loads below sit under no divergent branch)
+      int idx[CM_NB];
+      bool ok[CM_NB];
+#pragma unroll
+      for (int j = 0; j < CM_NB; ++j) {
+        ok[j] = acc != 0u;
+        const int k = ok[j] ? __builtin_ctz(acc) : 0;
+        acc &= acc - 1u;  // (0 stays 0)
+        idx[j] = min(e0 + k * (int)blockDim.x, M - 1);
+      }
+      float4 w4[CM_NB];
+      float tt[CM_NB];
+#pragma unroll
+      for (int j = 0; j < CM_NB; ++j) w4[j] = wp[idx[j]], tt[j] = tb[idx[j]];
+#ifdef CM_PROBE_NOONE  // (probe build: rows tested, records fetched, nothing accumulated)
+#pragma unroll
+      for (int j = 0; j < CM_NB; ++j) asm volatile("" ::"v"(w4[j].x), "v"(w4[j].y), "v"(w4[j].z), "v"(w4[j].w), "v"(tt[j]));
+#else
+#pragma unroll
+      for (int j = 0; j < CM_NB; ++j)
+        if (ok[j]) one(w4[j], tt[j]);
+#endif
+    }
   }
-  for (; e < M; e += blockDim.x) one(wp[e], tb[e]);
   __syncthreads();
   const long HW = (long)H * W;
   float* o = images + ((long)(sbd >> 1) * 8 + d * 4) * HW + (long)r0 * W;
@@ -912,8 +962,13 @@ __global__ __launch_bounds__(1024) void k_cm_splat_lds(const float4* __restrict_
   if (threadIdx.x == 0) {
     evf_atomic_add(fin.stats + sbd * 2, sq);
     evf_atomic_add(fin.stats + sbd * 2 + 1, nz);
-    __threadfence();
-    const unsigned t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    // The two sums are device-scope ATOMICS (performed at the memory side, never cached) and the last block reads them with
+    // device-scope loads: it is enough that they have COMPLETED before the ticket is drawn -- a workgroup-scope release is that wait
+    // and no cache maintenance.  An agent-scope release here (__threadfence, or an ACQ_REL ticket) writes the XCD's dirty L2 back --
+    // the image stripes the blocks have just stored, which the finish never reads -- once per block: 51 us of the 205 us launch at
+    // 256 x 256 x 4 scales x 8 samples were this.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    const unsigned t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = t == gridDim.x * gridDim.y - 1;
   }
   __syncthreads();
@@ -932,7 +987,8 @@ static int cm_lds_rows(int S, int B, int H, int W) {
 // floats of workspace that make evf_cm_loss_fwd take the LDS-privatised splat (0: image rows too wide for LDS)
 extern "C" int64_t evf_cm_loss_ws(int S, int B, int M, int H, int W) {
   if (S <= 0 || B <= 0 || M <= 0 || H <= 0 || W <= 0 || W > 2048) return 0;
-  return (int64_t)S * B * 2 * M * 4 + (int64_t)B * M + 4;  // pre-warped records, event times, the ticket of the merged launch
+  // pre-warped records, event times, the ticket of the merged launch, the warped rows alone
+  return (int64_t)S * B * 2 * M * 4 + (int64_t)B * M + 4 + (int64_t)S * B * 2 * M;
 }
 
 // stats [S][B][2][2] += (sum over px of A_pos^2 + A_neg^2, #px with I_pos+I_neg > 0)
@@ -1031,8 +1087,8 @@ __global__ __launch_bounds__(256) void k_cm_pre(const float* __restrict__ flow, 
                                                 const float2* __restrict__ pol, const int32_t* __restrict__ ev_pass,
                                                 const float* __restrict__ mask, int S, int Pm, int Pk, int P, int B, int M, int H,
                                                 int W, float Sc, int use_mask, int with_dt, float4* __restrict__ warp,
-                                                float* __restrict__ tabs, float* __restrict__ part, float* __restrict__ stats,
-                                                unsigned* __restrict__ ticket, int nbw) {
+                                                float* __restrict__ tabs, float* __restrict__ ys, float* __restrict__ part,
+                                                float* __restrict__ stats, unsigned* __restrict__ ticket, int nbw) {
   __shared__ float red[16];
   const int bid = blockIdx.x;
   if (bid < nbw * S) {
@@ -1040,7 +1096,7 @@ __global__ __launch_bounds__(256) void k_cm_pre(const float* __restrict__ flow, 
       for (int i = threadIdx.x; i < S * B * 4; i += blockDim.x) stats[i] = 0.f;
       if (threadIdx.x == 0) ticket[0] = 0u;
     }
-    cm_prewarp_body(bid % nbw, bid / nbw, flow, ev, pol, ev_pass, S, Pm, P, B, M, H, W, Sc, warp, tabs);
+    cm_prewarp_body(bid % nbw, bid / nbw, flow, ev, pol, ev_pass, S, Pm, P, B, M, H, W, Sc, warp, tabs, ys);
     return;
   }
   const int sb = bid - nbw * S, gx = (H + SM_ROWS - 1) / SM_ROWS;
@@ -1112,6 +1168,7 @@ extern "C" int evf_cm_loss_fwd(const float* flow, const float* ev, const float* 
     float4* warp = (float4*)ws;
     float* tabs = ws + (size_t)S * B * 2 * M * 4;
     unsigned* ticket = (unsigned*)(tabs + (size_t)B * M);
+    float* ys = tabs + (size_t)B * M + 4;  // [S][B][2][M]: the warped rows alone
     const int rows = cm_lds_rows(S, B, H, W);
     const size_t lds = (size_t)4 * rows * W * sizeof(float);
     static size_t lds_set = 0;
@@ -1124,19 +1181,19 @@ extern "C" int evf_cm_loss_fwd(const float* flow, const float* ev, const float* 
       // last block finishes the loss]
       const int nbw = evf_cdiv((long)B * M, 256);
       hipLaunchKernelGGL(k_cm_pre, dim3(nbw * S + srows * S * Pm * B), dim3(256), 0, st, flow, (const float4*)ev, (const float2*)pol,
-                         ev_pass, mask, S, Pm, Pk, P, B, M, H, W, flow_scaling, flags & 1, overwrite ? 0 : 1, warp, tabs, smooth_part,
+                         ev_pass, mask, S, Pm, Pk, P, B, M, H, W, flow_scaling, flags & 1, overwrite ? 0 : 1, warp, tabs, ys, smooth_part,
                          stats, ticket, nbw);
       const CmFin fin{stats, ticket, smooth_part, loss, S, Pm, srows * Pm * B, overwrite ? 4 : 5, (flags & 4) ? 1 : 0, regul_weight};
-      hipLaunchKernelGGL(k_cm_splat_lds, dim3(evf_cdiv(H, rows), S * B * 2), dim3(1024), lds, st, (const float4*)warp, tabs, B, M, H, W,
+      hipLaunchKernelGGL(k_cm_splat_lds, dim3(evf_cdiv(H, rows), S * B * 2), dim3(1024), lds, st, (const float4*)warp, tabs, ys, B, M, H, W,
                          rows, (float)P, images, fin);
       return evf_status();
     }
     rc = evf_hip(evf_memset_async(stats, 0, sizeof(float) * (size_t)S * B * 4, st));
     if (rc) return rc;
     hipLaunchKernelGGL(k_cm_prewarp, dim3(evf_cdiv((long)B * M, 256), S), dim3(256), 0, st, flow, (const float4*)ev,
-                       (const float2*)pol, ev_pass, S, Pm, P, B, M, H, W, flow_scaling, warp, tabs);
+                       (const float2*)pol, ev_pass, S, Pm, P, B, M, H, W, flow_scaling, warp, tabs, ys);
     const CmFin none{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0.f};
-    hipLaunchKernelGGL(k_cm_splat_lds, dim3(evf_cdiv(H, rows), S * B * 2), dim3(1024), lds, st, (const float4*)warp, tabs, B,
+    hipLaunchKernelGGL(k_cm_splat_lds, dim3(evf_cdiv(H, rows), S * B * 2), dim3(1024), lds, st, (const float4*)warp, tabs, ys, B,
                        M, H, W, rows, (float)P, images, none);
   } else {
     rc = evf_hip(evf_memset_async(stats, 0, sizeof(float) * (size_t)S * B * 4, st));

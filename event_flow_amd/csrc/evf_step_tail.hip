@@ -214,7 +214,9 @@ __global__ __launch_bounds__(1024) void k_clip_adam_fused(float* __restrict__ p,
   __syncthreads();  // (every thread of the block has read the gradient and ws[1])
   unsigned* tick = (unsigned*)(ws + 4);
   if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    // (relaxed: what the last block needs is that every block has READ the gradient and the counter -- their values were consumed
+    //  before the barrier above; an agent-scope release here would only write this XCD's dirty L2 back, once per block)
+    const unsigned t = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = t + 1u >= gridDim.x;  // (>=: a ticket left over by a launch that never finished cannot lock the tail out for good)
   }
   __syncthreads();
