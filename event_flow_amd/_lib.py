@@ -121,6 +121,7 @@ NETWORK_SIGNATURES = {
     "evf_nchw_to_nhwc": [P, I, I, I, I, P, P],
     "evf_clip_adam_step": [P, P, P, P, L, F, F, F, F, F, I, P, I, P],
     "evf_cm_merge": [I],
+    "evf_cm_bwd_lds": [I],
     "evf_clip_adam_fused": [P, P, P, P, L, F, F, F, F, F, I, P, I, P],
     "evf_grads_finalize": [P, P, I, I, P, I, P, I, I, P, I, I, I, P, P, P, P, I, P],
     # general path (any channel count, NHWC fp32)

@@ -1146,6 +1146,16 @@ extern "C" int evf_cm_merge(int on) {
   cm_merge_on = on != 0;
   return EVF_OK;
 }
+// evf_cm_bwd_lds: how dL/dflow of the events is summed -- -1 by size (LDS stripes from 8192 events per map on), 0 always with
+// device-scope atomics, 1 LDS stripes whenever a stripe fits (process-wide; tests, A/B; environment EVF_CM_BWD_LDS at load)
+static int cm_bwd_lds_mode = []() {
+  const char* e = getenv("EVF_CM_BWD_LDS");
+  return e ? atoi(e) : -1;
+}();
+extern "C" int evf_cm_bwd_lds(int mode) {
+  cm_bwd_lds_mode = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
+  return EVF_OK;
+}
 
 extern "C" int evf_cm_loss_fwd(const float* flow, const float* ev, const float* pol, const int32_t* ev_pass,
                                const float* mask, int S, int P, int B, int M, int H, int W, float flow_scaling,
@@ -1215,13 +1225,16 @@ extern "C" int evf_cm_loss_fwd(const float* flow, const float* ev, const float* 
 // --------------------------------------------------------------------------
 // contrast-maximisation loss, backward
 // --------------------------------------------------------------------------
-// gimages[ch] = dL/d images[ch] (scaled by grad_out / S)
+// gimages = dL/d images (scaled by grad_out / S).  Scratch layout [S][B][2 directions][H*W][4]: the four planes of a direction
+// (positive / negative event image, positive / negative timestamp image) INTERLEAVED per pixel, so that the event gather of
+// k_cm_event_bwd takes one 16-byte load per bilinear tap instead of two dependent-looking 4-byte loads from planes 256 KiB
+// apart (round 6: 254 -> see DESIGN 4.2 at 8 x 50 k events x 4 scales; the same sums per event).
 __device__ __forceinline__ void cm_gimages_body(int bx, int sbd, int gx, const float* __restrict__ images,
                                                 const float* __restrict__ stats, const float* __restrict__ grad_out, int S, int HW,
                                                 float P, int loss_scaling, float* __restrict__ gim) {
   const long base = ((long)(sbd >> 1) * 8 + (sbd & 1) * 4) * HW;
   const float* im = images + base;
-  float* g = gim + base;
+  float4* g = (float4*)(gim + base);
   const float sumsq = stats[sbd * 2], nnz = loss_scaling ? stats[sbd * 2 + 1] : 1.f;
   const float c = grad_out[0] / (float)S;
   for (int p = bx * blockDim.x + threadIdx.x; p < HW; p += gx * blockDim.x) {
@@ -1230,10 +1243,8 @@ __device__ __forceinline__ void cm_gimages_body(int bx, int sbd, int gx, const f
     const float ap = im[2 * HW + p] / dp / P, an = im[3 * HW + p] / dn / P;
     // d(#nonzero)/dI = 1 only where I_pos + I_neg is exactly 0 (masked assign, loss/flow.py:222-225)
     const float dnz = (loss_scaling && !(ip + in > 0.f)) ? -sumsq / (nnz * nnz) : 0.f;
-    g[p] = c * (-2.f * ap * ap / dp / nnz + dnz);
-    g[HW + p] = c * (-2.f * an * an / dn / nnz + dnz);
-    g[2 * HW + p] = c * (2.f * ap / (dp * P) / nnz);
-    g[3 * HW + p] = c * (2.f * an / (dn * P) / nnz);
+    g[p] = make_float4(c * (-2.f * ap * ap / dp / nnz + dnz), c * (-2.f * an * an / dn / nnz + dnz), c * (2.f * ap / (dp * P) / nnz),
+                       c * (2.f * an / (dn * P) / nnz));
   }
 }
 __global__ void k_cm_gimages(const float* __restrict__ images, const float* __restrict__ stats,
@@ -1260,8 +1271,10 @@ __device__ __forceinline__ void evf_tent(float w, float c, float& val, float& dv
   }
 }
 
+// g4: the direction's interleaved gradient image [H*W] of (pos, neg, pos ts, neg ts).  The four taps' loads are issued
+// unconditionally (clamped address) and selected afterwards: eight 16-byte gathers in flight per event and scale.
 __device__ __forceinline__ void evf_dir_grad(const Warp w, int H, int W, float a0, float a1, float tau,
-                                             const float* __restrict__ g, long HW, float& gwy, float& gwx) {
+                                             const float4* __restrict__ g4, float& gwy, float& gwx) {
   const float cy[2] = {floorf(w.wy), floorf(w.wy + 1.0f)};
   const float cx[2] = {floorf(w.wx), floorf(w.wx + 1.0f)};
   float ay[2], day[2], ax[2], dax[2];
@@ -1270,16 +1283,25 @@ __device__ __forceinline__ void evf_dir_grad(const Warp w, int H, int W, float a
     evf_tent(w.wy, cy[k], ay[k], day[k]);
     evf_tent(w.wx, cx[k], ax[k], dax[k]);
   }
+  float4 G[2][2];
+  bool in[2][2];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (cy[j] < 0.f || cy[j] >= (float)H || cx[i] < 0.f || cx[i] >= (float)W) continue;  // mask = 0
-      const long px = (long)(cy[j] * (float)W + cx[i]);
+      in[j][i] = !(cy[j] < 0.f || cy[j] >= (float)H || cx[i] < 0.f || cx[i] >= (float)W);  // (false for NaN as well: mask = 0)
+      const long px = in[j][i] ? (long)(cy[j] * (float)W + cx[i]) : 0;
+      G[j][i] = g4[px];
+    }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (!in[j][i]) continue;
       // dL/d(weight of this tap)
       float gw = 0.f;
-      if (a0 != 0.f) gw += a0 * (g[px] + tau * g[2 * HW + px]);
-      if (a1 != 0.f) gw += a1 * (g[HW + px] + tau * g[3 * HW + px]);
+      if (a0 != 0.f) gw += a0 * (G[j][i].x + tau * G[j][i].z);
+      if (a1 != 0.f) gw += a1 * (G[j][i].y + tau * G[j][i].w);
       gwy += gw * (day[j] * ax[i]);
       gwx += gw * (ay[j] * dax[i]);
     }
@@ -1289,7 +1311,11 @@ __global__ void k_cm_event_bwd(const float* __restrict__ flow, const float4* __r
                                const float2* __restrict__ pol, const int32_t* __restrict__ ev_pass, int S, int Pm, int P,
                                int B, int M, int H, int W, float Sc, const float* __restrict__ gim,
                                float* __restrict__ dflow) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // Blocks are dealt round-robin to the eight XCDs (block n -> XCD n % 8, observed; gridDim.x is a multiple of 8): block x takes
+  // chunk x % 8 of the event range, so that ONE XCD walks a contiguous eighth of the events -- one sample at batch 8 -- and its
+  // 4 MiB L2 holds that sample's gradient image, flow and dL/dflow maps (3 MB at 256 x 256) instead of every sample's.
+  const long vb = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const long i = vb * blockDim.x + threadIdx.x;
   if (i >= (long)B * M) return;
   const int s = blockIdx.y;
   const int b = (int)(i / M), e = (int)(i - (long)b * M);
@@ -1301,19 +1327,19 @@ __global__ void k_cm_event_bwd(const float* __restrict__ flow, const float4* __r
   const int map = Pm == 1 ? 0 : pass;
   float fy, fx;
   evf_event_flow(flow + (long)s * Pm * B * 2 * HW, map, B, b, HW, q.y, q.z, W, fy, fx);
-  const float* g = gim + ((long)s * B + b) * 8 * HW;
+  const float4* g = (const float4*)(gim + ((long)s * B + b) * 8 * HW);
   const float maxts = (float)P;
   float gfy = 0.f, gfx = 0.f;
   {
     float gwy = 0.f, gwx = 0.f;
-    evf_dir_grad(evf_warp(t, q.y, q.z, fy, fx, maxts, Sc), H, W, pm.x, pm.y, t, g, HW, gwy, gwx);
+    evf_dir_grad(evf_warp(t, q.y, q.z, fy, fx, maxts, Sc), H, W, pm.x, pm.y, t, g, gwy, gwx);
     const float k = (maxts - t) * Sc;  // d warped / d flow
     gfy += gwy * k;
     gfx += gwx * k;
   }
   {
     float gwy = 0.f, gwx = 0.f;
-    evf_dir_grad(evf_warp(t, q.y, q.z, fy, fx, 0.f, Sc), H, W, pm.x, pm.y, maxts - t, g + 4 * HW, HW, gwy, gwx);
+    evf_dir_grad(evf_warp(t, q.y, q.z, fy, fx, 0.f, Sc), H, W, pm.x, pm.y, maxts - t, g + HW, gwy, gwx);
     const float k = (0.f - t) * Sc;
     gfy += gwy * k;
     gfx += gwx * k;
@@ -1322,6 +1348,111 @@ __global__ void k_cm_event_bwd(const float* __restrict__ flow, const float4* __r
   float* d = dflow + (((long)s * Pm + map) * B + b) * 2 * HW;
   if (gfx != 0.f) evf_atomic_add(d + lin, gfx);
   if (gfy != 0.f) evf_atomic_add(d + HW + lin, gfy);
+}
+
+// ---- the same gather without global atomics (round 6) -------------------------------------------------------------------
+// dL/dflow is added at the event's SOURCE pixel; with 8 x 50 k events x 4 scales k_cm_event_bwd issues 3.2 M device-scope
+// float atomics, which resolve at the memory side at ~21 G/s: ~150 of its 254 us (config 4; 168 with the interleaved gradient
+// image).  Here one block owns a stripe of rows of ONE dL/dflow map (scale, map, sample) in LDS: it passes over the sample's
+// events in chunks of CMB_CHUNK, the waves COMPACT the events of the stripe (and map) into an LDS queue -- one in H / rows is
+// the block's own, and the event body is four dependent memory round trips: it has to run on full waves --, the queue is worked
+// off one event per thread (the arithmetic of k_cm_event_bwd, sums by LDS float atomics), and the stripe is finally ADDED to the
+// smoothness gradient k_cm_bwd_pre stored there (every pixel has one owner: plain loads and stores).  Blocks of one sample share
+// blockIdx.x % 8, i.e. (observed placement, speed only) an XCD and its L2.  Measured at 256 x 256 x 50 k x 4 scales x 8 samples
+// (rocprofv3): 123 us with 512 blocks of 512 threads (131 with 256 x 1024 and chunks of 16 k events: chunk size and block shape
+// hardly matter); the probe build -DCMB_PROBE_NOBODY (scan + queue alone) runs 48 us, i.e. ~75 us are the 12 divergent gathers
+// per event (record, polarity, two flow components, eight 16-byte taps: 19 M lines through the CUs' texture addressers).
+#define CMB_THREADS 512
+#define CMB_CHUNK 4096  // events per pass over the queue: CMB_CHUNK / CMB_THREADS coordinate pairs in flight per thread
+__global__ __launch_bounds__(CMB_THREADS) void k_cm_event_bwd_lds(const float* __restrict__ flow, const float4* __restrict__ ev,
+                                                                   const float2* __restrict__ pol, const int32_t* __restrict__ ev_pass,
+                                                                   int S, int Pm, int P, int B, int M, int H, int W, int rows, float Sc,
+                                                                   const float* __restrict__ gim, float* __restrict__ dflow) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* acc = (float*)smem_raw;                       // [2][rows * W]: x component, y component
+  int* queue = (int*)(acc + 2 * rows * W);             // [CMB_CHUNK] event numbers of the sample
+  __shared__ int s_qn[2];  // queue length, one counter per chunk parity (reset two barriers before its next use)
+  const int smb = blockIdx.x, b = smb % B, map = (smb / B) % Pm, s = smb / (B * Pm);
+  const int r0 = blockIdx.y * rows, nr = min(rows, H - r0), plane = rows * W;
+  const long HW = (long)H * W;
+  for (int q = threadIdx.x; q < 2 * plane; q += CMB_THREADS) acc[q] = 0.f;
+  if (threadIdx.x < 2) s_qn[threadIdx.x] = 0;
+  const float4* __restrict__ evb = ev + (long)b * M;
+  const float2* __restrict__ polb = pol + (long)b * M;
+  const float* __restrict__ fl = flow + (((long)s * Pm + map) * B + b) * 2 * HW;
+  const float4* __restrict__ g = (const float4*)(gim + ((long)s * B + b) * 8 * HW);
+  const long lo = (long)r0 * W, hi = (long)(r0 + nr) * W;
+  const float maxts = (float)P;
+  constexpr int NL = CMB_CHUNK / CMB_THREADS;
+  const int lane = threadIdx.x & 63;
+  float qy[NL], qx[NL];
+  int ps[NL];
+  const float* __restrict__ evf = (const float*)evb;
+  auto request = [&](int e0) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int e = min(e0 + k * CMB_THREADS + (int)threadIdx.x, M - 1);  // (clamped: the loads stay unconditional)
+      qy[k] = evf[4 * (long)e + 1], qx[k] = evf[4 * (long)e + 2];
+      ps[k] = 0;
+      if (Pm != 1) ps[k] = ev_pass[e];  // (uniform branch)
+    }
+  };
+  request(0);
+  __syncthreads();
+  for (int e0 = 0, par = 0; e0 < M; e0 += CMB_CHUNK, par ^= 1) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int e = e0 + k * CMB_THREADS + (int)threadIdx.x;
+      const long lin = (long)(qy[k] * (float)W + qx[k]);  // flow_idx (loss/flow.py:65-67), as evf_event_flow
+      const bool mine = e < M && ps[k] == map && lin >= lo && lin < hi;  // (NaN coordinates: lin is not in the stripe)
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+      int base = 0;
+      if (lane == 0 && m) base = atomicAdd(&s_qn[par], __builtin_popcountll(m));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (mine) queue[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = e;
+    }
+    if (e0 + CMB_CHUNK < M) request(e0 + CMB_CHUNK);  // (the next chunk's records travel while the queue is worked off)
+    __syncthreads();
+    const int qn = s_qn[par];
+#ifdef CMB_PROBE_NOBODY  // (probe build: the scan and the queue alone)
+    for (int j = threadIdx.x; j < qn; j += CMB_THREADS) acc[j & 1023] = (float)queue[j];
+    if (0)
+#endif
+    for (int j = threadIdx.x; j < qn; j += CMB_THREADS) {
+      const int e = queue[j];
+      const float4 q = evb[e];
+      const float2 pm = polb[e];
+      const float t = q.x + (float)(Pm == 1 ? ev_pass[e] : map);  // event_list[:, :, 0:1] += passes (loss/flow.py:90)
+      const long lin = (long)(q.y * (float)W + q.z);
+      const float fx = fl[lin], fy = fl[HW + lin];
+      float gfy = 0.f, gfx = 0.f;
+      {
+        float gwy = 0.f, gwx = 0.f;
+        evf_dir_grad(evf_warp(t, q.y, q.z, fy, fx, maxts, Sc), H, W, pm.x, pm.y, t, g, gwy, gwx);
+        const float k = (maxts - t) * Sc;  // d warped / d flow
+        gfy += gwy * k;
+        gfx += gwx * k;
+      }
+      {
+        float gwy = 0.f, gwx = 0.f;
+        evf_dir_grad(evf_warp(t, q.y, q.z, fy, fx, 0.f, Sc), H, W, pm.x, pm.y, maxts - t, g + HW, gwy, gwx);
+        const float k = (0.f - t) * Sc;
+        gfy += gwy * k;
+        gfx += gwx * k;
+      }
+      const int o = (int)(lin - lo);
+      if (gfx != 0.f) atomicAdd(acc + o, gfx);
+      if (gfy != 0.f) atomicAdd(acc + plane + o, gfy);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_qn[par] = 0;  // (everybody has read it; pushed to again two barriers from here)
+  }
+  float* d = dflow + (((long)s * Pm + map) * B + b) * 2 * HW + lo;
+  const int n = nr * W;
+  for (int q = threadIdx.x; q < 2 * n; q += CMB_THREADS) {
+    const int c = q >= n, r = q - c * n;
+    d[(long)c * HW + r] += acc[c * plane + r];
+  }
 }
 
 __device__ __forceinline__ float evf_dcharb(float fxa, float fya, float fxb, float fyb) {
@@ -1430,7 +1561,22 @@ extern "C" int evf_cm_loss_bwd(const float* flow, const float* ev, const float* 
     hipLaunchKernelGGL(k_cm_gimages, dim3(evf_cdiv(HW, 256), S * B * 2), dim3(256), 0, st, images, stats, grad_out, S, HW,
                        (float)P, (flags & 4) ? 1 : 0, gimages);
   }
-  hipLaunchKernelGGL(k_cm_event_bwd, dim3(evf_cdiv((long)B * M, 256), S), dim3(256), 0, st, flow, (const float4*)ev,
+  // many events per dL/dflow map: LDS stripes instead of device-scope atomics (EVF_CM_BWD_LDS=0: never, =1: whenever it fits)
+  const int lds_mode = cm_bwd_lds_mode;
+  int rows = W <= 8192 ? (H < 8192 / W ? H : 8192 / W) : 0;  // 2 components x rows x W floats <= 64 KiB of LDS
+  while (rows > 8 && (long)S * Pm * B * evf_cdiv(H, rows) < 512) rows >>= 1;  // two blocks per CU at least
+  const bool lds = rows > 0 && lds_mode != 0 && (lds_mode > 0 || (long)M >= 8192L * Pm);
+  if (lds) {
+    const size_t bytes = sizeof(float) * 2 * rows * W + sizeof(int) * CMB_CHUNK;
+    static std::once_flag once;
+    std::call_once(once, []() {
+      (void)hipFuncSetAttribute((const void*)k_cm_event_bwd_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + (int)sizeof(int) * CMB_CHUNK);
+    });
+    hipLaunchKernelGGL(k_cm_event_bwd_lds, dim3(S * Pm * B, evf_cdiv(H, rows)), dim3(CMB_THREADS), bytes, st, flow, (const float4*)ev,
+                       (const float2*)pol, ev_pass, S, Pm, P, B, M, H, W, rows, flow_scaling, gimages, dflow);
+    return evf_status();
+  }
+  hipLaunchKernelGGL(k_cm_event_bwd, dim3(8 * evf_cdiv((long)B * M, 256 * 8), S), dim3(256), 0, st, flow, (const float4*)ev,
                      (const float2*)pol, ev_pass, S, Pm, P, B, M, H, W, flow_scaling, gimages, dflow);
   return evf_status();
 }

@@ -112,6 +112,11 @@ int evf_cm_smooth_blocks(int B, int P, int H, int W);
  * last block finishes the loss]; backward = [smoothness gradient | image gradients] + [event gather].  evf_cm_merge(0): one
  * launch per pass as before (process-wide; the equivalence test, A/B measurements; environment EVF_CM_MERGE=0 likewise). */
 int evf_cm_merge(int on);
+/* dL/dflow of the events (loss/flow.py:56-119 under autograd: an index_add at the events' source pixels): device-scope float
+ * atomics, or -- many events per flow map -- one block per stripe of rows of a map that compacts its events into an LDS queue
+ * and sums in LDS (no global atomics).  mode -1: by size (default), 0: atomics, 1: stripes whenever they fit (process-wide;
+ * environment EVF_CM_BWD_LDS at load). */
+int evf_cm_bwd_lds(int mode);
 /* ws: NULL, or evf_cm_loss_ws(S,B,M,H,W) floats of scratch (when that is > 0): the images are then accumulated in
  * LDS stripes from pre-warped events instead of with device-scope atomics (same sums, other summation order). */
 int64_t evf_cm_loss_ws(int S, int B, int M, int H, int W);
@@ -121,7 +126,8 @@ int evf_cm_loss_fwd(const float* flow, const float* ev, const float* pol, const 
                     float* images, float* stats, float* smooth_part, float* loss, float* ws, void* stream);
 
 /* Backward of the above: dflow [S,Pm,B,2,H,W] = grad_out * dL/dflow (written,
- * not accumulated).  gimages [S,B,8,H,W] is scratch.  Reproduces the
+ * not accumulated).  gimages is scratch of S*B*8*H*W floats (16-byte aligned;
+ * internal layout [S][B][2][H*W][4]).  Reproduces the
  * max(0,1-|d|) tie sub-gradient (0.5) and the #nonzero-px denominator path
  * of the reference under torch>=1.8 autograd. */
 int evf_cm_loss_bwd(const float* flow, const float* ev, const float* pol, const int32_t* ev_pass,

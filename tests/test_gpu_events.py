@@ -244,17 +244,20 @@ def _run_hip_loss(g, c, H, W):
     return val, flows
 
 
-@pytest.mark.parametrize("splat", ["atomics", "lds", "lds-one-launch-per-pass"])
+@pytest.mark.parametrize("splat", ["atomics", "lds", "lds-one-launch-per-pass", "lds+bwd-stripes"])
 def test_event_warping_golden_loss_and_grad(splat, monkeypatch):
     # both image-accumulation paths of evf_cm_loss_fwd: device-scope atomics, and LDS stripes over pre-warped events -- the
     # latter with the loss launches merged (default: 2 forward + 2 backward launches, the last splat block finishes the loss)
     # and one launch per pass (evf_cm_merge(0): fill, pre-warp, splat, reduce, smooth, finalize / 3 backward)
     monkeypatch.setattr(hloss, "CM_LDS_MIN_EVENTS", 1 if splat.startswith("lds") else 1 << 60)
     assert _lib.load().evf_cm_merge(0 if splat.endswith("per-pass") else 1) == 0
+    # dL/dflow of the events: device-scope atomics (what these small cases take by size), or k_cm_event_bwd_lds forced
+    assert _lib.load().evf_cm_bwd_lds(1 if splat.endswith("bwd-stripes") else 0) == 0
     try:
         _golden_loss_and_grad()
     finally:
         _lib.load().evf_cm_merge(1)
+        _lib.load().evf_cm_bwd_lds(-1)
 
 
 def _golden_loss_and_grad():
@@ -276,9 +279,54 @@ def _golden_loss_and_grad():
                 assert np.linalg.norm(got - ref) <= 2e-4 * np.linalg.norm(ref) + 1e-9, (c, k, s)
 
 
-@pytest.mark.parametrize("P,n", [(1, 15000), (10, 1500)])
-def test_event_warping_full_size_vs_oracle(P, n):
-    """config 2 shape (B=8, 128x128, 15k events per window) against the oracle."""
+@pytest.mark.parametrize("P,n,bwd", [(1, 15000, -1), (10, 1500, -1), (1, 15000, 0), (10, 1500, 1)])
+def test_event_warping_full_size_vs_oracle(P, n, bwd):
+    """config 2 shape (B=8, 128x128, 15k events per window) against the oracle.  bwd: evf_cm_bwd_lds -- by size ((1, 15000) takes
+    the LDS stripes, (10, 1500) the atomics), and each case once more on the OTHER path."""
+    _lib.load().evf_cm_bwd_lds(bwd)
+    try:
+        _full_size_vs_oracle(P, n)
+    finally:
+        _lib.load().evf_cm_bwd_lds(-1)
+
+
+def test_event_gradient_stripes_match_atomics_on_ragged_shapes():
+    """k_cm_event_bwd_lds against k_cm_event_bwd: ragged image sizes (last stripe short, W not a multiple of anything), several
+    scales, per-pass maps and the overwritten single map, events crowded into a few rows (a queue fuller than a chunk's share)."""
+    lib = _lib.load()
+    for (B, H, W, P, n, S, overwrite, crowd) in ((3, 37, 53, 2, 9000, 2, False, False), (2, 70, 41, 3, 5000, 1, True, True),
+                                                 (1, 256, 256, 1, 50000, 4, False, False), (2, 33, 300, 1, 12000, 1, False, True)):
+        grads = []
+        for mode in (0, 1):
+            lib.evf_cm_bwd_lds(mode)
+            try:
+                rng = np.random.default_rng(5)
+                c = cfg(H, W)
+                c["loss"]["overwrite_intermediate"] = overwrite
+                lossf = hloss.EventWarping(c, DEV)
+                fls = []
+                for k in range(P):
+                    ev = synthetic.event_list_batch(B, n, H, W, 300 + k)
+                    if crowd:
+                        ev[:, :, 1] = np.floor(ev[:, :, 1] / H * 5.0) + (H - 6)  # rows H - 6 .. H - 2 only
+                    ev = G(ev)
+                    pol = torch.stack([(ev[:, :, 3] > 0).float(), (ev[:, :, 3] < 0).float()], 2).contiguous()
+                    fl = [G(rng.uniform(-0.1, 0.1, size=(B, 2, H, W)).astype(np.float32)).requires_grad_(True) for _ in range(S)]
+                    fls.append(fl)
+                    lossf.event_flow_association(fl, ev, pol, torch.ones(B, 1, H, W, device=DEV))
+                if overwrite:
+                    lossf.overwrite_intermediate_flow(fls[-1])
+                lossf().backward()
+                grads.append([N(f.grad) if f.grad is not None else None for fl in fls for f in fl])
+            finally:
+                lib.evf_cm_bwd_lds(-1)
+        for a, b in zip(*grads):
+            assert (a is None) == (b is None)
+            if a is not None:  # (the same per-event terms, summed in another order: float round-off of the sums)
+                assert np.abs(a - b).max() <= 1e-5 * max(np.abs(a).max(), 1e-12), (B, H, W, P, n, S, np.abs(a - b).max(), np.abs(a).max())
+
+
+def _full_size_vs_oracle(P, n):
     B, H, W = 8, 128, 128
     rng = np.random.default_rng(100 + P)
     lossf = hloss.EventWarping(cfg(H, W), DEV)

@@ -33,12 +33,16 @@ def run(B, H, W, P, n, S, min_events):
     for _ in range(5):
         vals.append(float(lossf()))
     t = _lib.profile_stop()[("evf_cm_loss_fwd", "")]
-    return float(np.median(t)) * 1e3, vals[0]
+    _lib.profile_start(["evf_cm_loss_bwd"])
+    for _ in range(5):
+        lossf().backward()
+    tb = _lib.profile_stop()[("evf_cm_loss_bwd", "")]
+    return float(np.median(t)) * 1e3, vals[0], float(np.median(tb)) * 1e3
 
 
 for name, shp in (("config 3: B8 128x128 10x1500 ev, 1 scale", (8, 128, 128, 10, 1500, 1)),
                   ("config 4: B8 256x256 1x50000 ev, 4 scales", (8, 256, 256, 1, 50000, 4)),
                   ("config 5: B4 260x346 10x1500 ev, 1 scale", (4, 260, 346, 10, 1500, 1))):
-    a, va = run(*shp, 1 << 60)
-    l, vl = run(*shp, 1)
-    print(f"{name}: atomics {a:7.1f} us  lds {l:7.1f} us   loss {va:.6f} / {vl:.6f}")
+    a, va, ba = run(*shp, 1 << 60)
+    l, vl, bl = run(*shp, 1)
+    print(f"{name}: atomics {a:7.1f} us  lds {l:7.1f} us   loss {va:.6f} / {vl:.6f}   backward (2 launches) {ba:7.1f} / {bl:7.1f} us")
