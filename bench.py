@@ -917,11 +917,20 @@ def main():
         try:
             L = _lib.load()
             L.evf_defer_profile(2)
+            graphs_p, cap_err = None, None
             try:
                 graphs_p = capture_step_graphs(model, lossf, opt, dp, pool, side, reps, capture_mode=args.profile_capture_mode)
+            except Exception as e:  # noqa: BLE001
+                cap_err = e
             finally:
                 L.evf_defer_profile(0)
             torch.cuda.synchronize()
+            # N ranks: the replays below hold the step's all-reduce -- every rank replays or none does (a rank that lost its
+            # instrumented capture alone would leave the others waiting inside the collective)
+            if dp.active and dp.max_over_ranks(0.0 if cap_err is None else 1.0) != 0.0:
+                raise RuntimeError(f"instrumented capture failed on a rank ({cap_err})")
+            if cap_err is not None:
+                raise cap_err
             nrep = 3 * len(graphs_p)
             for i in range(nrep):
                 graphs_p[i % len(graphs_p)].replay()
