@@ -294,14 +294,37 @@ _KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3_lds<false, false, false, fal
               "evf_conv_lif_fwd/rec": "k_conv_lif_fwd<true>", "evf_conv_wgrad_bits": "k_conv_wgrad_bits"}
 
 
+_PMC_FILE = "r*_bench_pmc_traffic.json"  # (config 5: r*_c5_pmc_traffic.json, see kernel_names_for)
+
+
+def kernel_names_for(model_name, B, Hh, Ww):
+    """The device kernels the library launches for THIS workload (rocprofv3's names): the table above is the LIF-FireNet at
+    8 x 128 x 128.  PLIF cells run the PLIF instantiations; from 6 tiles of 4 x 32 pixels per CU on the stand-alone input
+    gradient is the wave-specialised k_conv_dgrad_ws<ACC, PLIF, PAIR> (dg_launch, evf_dgrad_b3.hip) -- `acc` in the entry's
+    variant means accumulate != 0, which for a PLIF cell is the raw-dL/dP flag (ACC = false)."""
+    global _PMC_FILE
+    plif = model_name == "PLIFFireNet"
+    if plif:
+        _PMC_FILE = "r*_c5_pmc_traffic.json"
+        _KERNEL_OF.update({"k_fwd_diag": "k_fwd_diag_t<true, false, true>", "k_fwd_win": "k_fwd_win_t<true, false, true>",
+                           "k_bwd_win": "k_bwd_win_plif", "k_bwd_diag": "k_bwd_diag_ws_plif",
+                           "k_head_lif_fwd_win": "k_head_lif_fwd_win<1, true, 8>", "k_head_bwd_win": "k_head_bwd_win<true, 3, true>"})
+    if B * ((Hh + 3) // 4) * ((Ww + 31) // 32) >= 6 * 256:
+        tf = lambda v: "true" if v else "false"  # noqa: E731
+        for pair in (False, True):
+            for acc in (False, True):
+                ent = "evf_conv_dgrad_b3_f32" + ("_pair" if pair else "") + ("/acc" if acc else "")
+                _KERNEL_OF[ent] = f"k_conv_dgrad_ws<{tf(acc and not plif)}, {tf(plif)}, {tf(pair)}>"
+
+
 def _pmc(entry):
     """PMC figures of the kernel behind `entry` from the newest committed passes (rocprofv3 cannot run inside this
-    process): profiles/r*_bench_pmc_traffic.json -- HBM bytes per launch (FETCH_SIZE x2-corrected + WRITE_SIZE) and MFMA busy
-    (SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD).  The file carries the hash of the kernel sources it was
-    measured on; on any other sources the numbers are stale and NOT reported (-> (None, reason))."""
+    process): profiles/r*_bench_pmc_traffic.json (config 5: r*_c5_pmc_traffic.json) -- HBM bytes per launch (FETCH_SIZE
+    x2-corrected + WRITE_SIZE) and MFMA busy (SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD).  The file carries the
+    hash of the kernel sources it was measured on; on any other sources the numbers are stale and NOT reported (-> (None, reason))."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", _PMC_FILE)))
     if not files or entry not in _KERNEL_OF:
         return None, "no PMC pass for this kernel"
     d = json.load(open(files[-1]))
@@ -312,6 +335,33 @@ def _pmc(entry):
         return None, "kernel not in the PMC pass"
     return {"MB_per_launch": round(t["fetch_MB"] + t["write_MB"], 2), "fetch_MB": t["fetch_MB"], "write_MB": t["write_MB"],
             "mfma_busy_pct": t.get("mfma_busy_pct"), "source": os.path.basename(files[-1]), "src_hash": d["src_hash"]}, None
+
+
+# device kernels behind the general path's input-gradient entry point (evf_conv2d_dgrad_b3): the six-term tile kernels and the
+# parity-class (stride-2) form of the gather kernel; forward products run k_conv3_b3x / k_conv2d_b3<.., false, ..>
+def _c4_dgrad_kernel(name):
+    import re
+
+    return (name.startswith("k_conv3_b3t<") or name.startswith("k_conv3_b3n") or name.startswith("k_conv3_b3i") or
+            re.match(r"k_conv2d_b3<\d+, \d+, true, ", name) is not None)
+
+
+def _pmc_c4(entry):
+    """PMC bytes per STEP of the device kernels behind a general-path entry point, from the newest committed config-4 passes
+    (profiles/r*_c4_pmc_traffic.json: per-launch means x launches per step); refused on other kernel sources."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c4_pmc_traffic.json")))
+    if not files or entry != "evf_conv2d_dgrad_b3":
+        return None, "no PMC pass for this entry point"
+    d = json.load(open(files[-1]))
+    if d.get("src_hash") != source_hash():
+        return None, f"stale: {os.path.basename(files[-1])} was measured on sources {d.get('src_hash')}, these are {source_hash()}"
+    ks = {k: v for k, v in d["per_launch"].items() if _c4_dgrad_kernel(k)}
+    if not ks:
+        return None, "kernels not in the PMC pass"
+    tot = sum((v["fetch_MB"] + v["write_MB"]) * v["launches_per_step"] for v in ks.values())
+    return {"MB_per_step": round(tot, 1), "kernels": ks, "source": os.path.basename(files[-1]), "src_hash": d["src_hash"]}, None
 
 
 def gpu_forward_loss_line(wl, dev, pool, precision, reps_n=20, capture_mode="global"):
@@ -407,7 +457,7 @@ def other_config_line(cfg, steps=10, warmup=3, timeout=420, extra=None):
                 "warmup": d["warmup"], "dtype": d["dtype"], "launch": d["config"].get("launch"), "workload": d["config"]["workload"],
                 "timing_blocks_ms_per_step": (d.get("timing_blocks") or {}).get("ms_per_step"), "loss": d["config"].get("loss"),
                 "workload_activity": d.get("workload_activity"),
-                "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")}}
+                "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic")}}
     except Exception as e:  # noqa: BLE001  (never costs the headline line)
         return {"error": f"{type(e).__name__}: {e}"}
 
@@ -645,9 +695,10 @@ def main_c4(args):
                 ent["issued_bf16_TFLOPs_range"] = [ent["TFLOPs"] * lo_terms, ent["TFLOPs"] * 6]
                 ent["frac_of_bf16_peak_range"] = [ent["TFLOPs"] * lo_terms / BF16_MFMA_PEAK, ent["TFLOPs"] * 6 / BF16_MFMA_PEAK]
             ent["algorithmic_GBps"] = ent["bytes_per_step"] / (ent["total_ms_per_step"] * 1e-3) / 1e9
-        ent.pop("bytes_per_step")
+        ent["algorithmic_bytes_per_step"] = ent.pop("bytes_per_step")  # (fp32 input + output of every launch: 0 for the element-wise entries)
     dom_name = max((n for n in kernels if "TFLOPs" in kernels[n]), key=lambda n: kernels[n]["total_ms_per_step"])
     dom = kernels[dom_name]
+    c4_traffic, c4_traffic_why = _pmc_c4(dom_name)
     out = {
         "metric": "event-windows/sec (train step, 256x256x50k ev, LIF-EV-FlowNet)", "value": Bc * args.steps / elapsed,
         "unit": "event-windows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -663,7 +714,13 @@ def main_c4(args):
                                       "channel tiles), the rest fp32 MFMA; " if os.environ.get("EVF_WGRAD", "b3") != "f32" else
                                       "weight gradient: fp32 MFMA (v_mfma_f32_32x32x2_f32); ") + "NHWC fp32 activations"},
         "roofline": ({"kernel": dom_name, "bound": "mfma", "achieved": dom["issued_bf16_TFLOPs_range"][0], "peak": BF16_MFMA_PEAK,
-                      "unit": "TFLOP/s", "frac": dom["issued_bf16_TFLOPs_range"][0] / BF16_MFMA_PEAK, "traffic": None,
+                      "unit": "TFLOP/s", "frac": dom["issued_bf16_TFLOPs_range"][0] / BF16_MFMA_PEAK,
+                      "traffic": int(c4_traffic["MB_per_step"] * 1e6) if c4_traffic else None,
+                      "traffic_unit": "bytes per STEP over all launches of the entry point's device kernels (PMC passes: FETCH_SIZE x2-corrected + "
+                                      "WRITE_SIZE, per-launch means x launches per step)",
+                      "traffic_detail": c4_traffic if c4_traffic else {"unavailable": c4_traffic_why},
+                      "algorithmic_bytes_per_step": int(dom.get("algorithmic_bytes_per_step", 0)),
+                      "launches_per_step": dom["launches"], "total_ms_per_step": dom["total_ms_per_step"],
                       "fp32_equivalent_TFLOPs": dom["TFLOPs"],
                       "note": "all launches of the entry point in a step together: sum of 2*k*k*Cin*Cout*B*Ho*Wo over the launches / "
                               "their summed HIP-event time = fp32-equivalent TFLOP/s; `achieved` = the bf16 matrix work ISSUED for it "
@@ -745,6 +802,7 @@ def main():
     if args.config == "c4":
         return main_c4(args)
     wl = set_workload(args.config)
+    kernel_names_for(wl["model"], B_PER_GPU, H, W)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("EVF_BENCH_SINGLE_DEVICE"):  # test hook: several ranks share one GPU (with EVF_DP_BACKEND=gloo)
         local_rank = 0
@@ -1105,9 +1163,15 @@ def main():
         hbm_bound |= {"k_head_lif_fwd_win", "k_head_bwd_win"}
         kernels = {}
         step_alg_bytes = 0.0
+        recorded_only = []
         for key, ms in prof.items():
             ms = np.array(ms)
             name = "/".join(k for k in key if k)
+            if ms.size and float(ms.mean()) * 1e3 < 2.5 and key[0].startswith("evf_") and key[0] not in ("evf_cm_loss_fwd", "evf_cm_loss_bwd"):
+                # an entry point that only RECORDS its cell while a window is being recorded (its kernel runs inside a window /
+                # diagonal launch listed under k_*): an empty bracket is not a kernel time
+                recorded_only.append(name)
+                continue
             ent = {"launches": int(ms.size), "mean_us": float(ms.mean() * 1e3), "total_ms_per_step": float(ms.sum() / prof_steps)}
             if key in prof_eager:
                 ent["timing"] = "inside the replayed hipGraph (timestamp kernels of an instrumented capture, empty bracket removed)"
@@ -1325,7 +1389,7 @@ def main():
                               "spread_pct": float(100.0 * (np.max(block_ms) - np.min(block_ms)) / np.median(block_ms)),
                               "windows_per_s_median": B_PER_GPU * dp.world / (float(np.median(block_ms)) * 1e-3)},
             "workload_activity": {"thresh_scale": args.thresh_scale, "events": args.events},
-            "kernels": kernels,
+            "kernels": kernels, "entry_points_that_only_record": recorded_only,
             "kernel_timing": {"method": "diagonal / head-window launches: HIP events captured into an instrumented copy of the step graphs "
                                         "(timestamp-kernel nodes), read after its replays, minus the empty bracket of the same graph; "
                                         "every other entry: HIP events around each launch on its stream over eager steps, minus the bracket "

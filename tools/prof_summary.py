@@ -91,7 +91,13 @@ if lds or valu:
 # kernels that only exist on the fp32 path
 for n in sorted(set(mfma32) - set(mfma)):
     pass
-with open(os.path.join(DST, f"{R}_bench_pmc_summary.csv"), "w", newline="") as fh:
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (source_hash: bench.py refuses these numbers on any other kernel sources)
+
+if not rows:
+    print("(no c3 PMC passes in", SRC, "-- c3 summary files left as they are)")
+else:
+  with open(os.path.join(DST, f"{R}_bench_pmc_summary.csv"), "w", newline="") as fh:
     w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
     w.writeheader()
     w.writerows(rows)
@@ -99,10 +105,67 @@ with open(os.path.join(DST, f"{R}_bench_pmc_summary.csv"), "w", newline="") as f
 traffic = {r["kernel"]: {"fetch_MB": r["fetch_MB_x2_corrected"], "write_MB": round(r["write_size_KB"] / 1024, 2),
                          "mfma_busy_pct": r["mfma_util_pct"] if r["mfma_util_pct"] != "" else None} for r in rows
            if r["fetch_size_KB_raw"] == r["fetch_size_KB_raw"]}
-sys.path.insert(0, ROOT)
-import bench  # noqa: E402  (source_hash: bench.py refuses these numbers on any other kernel sources)
-
-json.dump({"round": R, "src_hash": bench.source_hash(), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --no-graph` (tools/profile_round.sh); "
+if rows:
+  json.dump({"round": R, "src_hash": bench.source_hash(), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --no-graph` (tools/profile_round.sh); "
            "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE uncalibrated",
            "per_launch": traffic}, open(os.path.join(DST, f"{R}_bench_pmc_traffic.json"), "w"), indent=1)
-print(open(os.path.join(DST, f"{R}_bench_pmc_summary.csv")).read())
+if rows:
+    print(open(os.path.join(DST, f"{R}_bench_pmc_summary.csv")).read())
+
+
+# ---- config 4: the same three PMC passes over `bench.py --config c4 --no-graph` -> per kernel of the LIF-EV-FlowNet step
+c4f, c4w, c4m = counters("c4fetch"), counters("c4write"), counters("c4mfma")
+if c4f and c4w:
+    def nsteps(acc, key):  # steps the pass ran = dispatches of the optimizer kernel (one per step)
+        return max(len(acc.get("k_clip_adam", {}).get(key, [])), 1)
+    sf, sw, sm = nsteps(c4f, "FETCH_SIZE"), nsteps(c4w, "WRITE_SIZE"), nsteps(c4m, "GRBM_GUI_ACTIVE")
+    rows4 = []
+    for n in sorted(set(c4f) | set(c4w), key=lambda n: -sum(c4m.get(n, {}).get("GRBM_GUI_ACTIVE", [0]))):
+        f_kb, w_kb = mean(c4f.get(n, {}).get("FETCH_SIZE", [])), mean(c4w.get(n, {}).get("WRITE_SIZE", []))
+        gui, busy = mean(c4m.get(n, {}).get("GRBM_GUI_ACTIVE", [])), mean(c4m.get(n, {}).get("SQ_VALU_MFMA_BUSY_CYCLES", []))
+        rows4.append({"kernel": n, "launches_per_step": round(len(c4f.get(n, {}).get("FETCH_SIZE", [])) / sf, 2),
+                      "fetch_MB_x2_corrected": round(2 * f_kb / 1024, 2) if f_kb == f_kb else "",
+                      "write_MB": round(w_kb / 1024, 2) if w_kb == w_kb else "",
+                      "gui_cycles_per_xcd": round(gui / 8, 0) if gui == gui else "",
+                      "mfma_util_pct": round(100 * (busy / 1024) / (gui / 8), 1) if busy == busy and gui == gui and gui > 0 else ""})
+    with open(os.path.join(DST, f"{R}_c4_pmc_summary.csv"), "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows4[0].keys()))
+        w.writeheader()
+        w.writerows(rows4)
+    json.dump({"round": R, "src_hash": bench.source_hash(), "steps_in_pass": [sf, sw, sm],
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES passes over `bench.py --config c4 --no-graph` "
+                         "(tools/profile_round.sh); per LAUNCH means, launches per step = dispatches / dispatches of k_clip_adam; FETCH_SIZE "
+                         "doubled per MI355X_MICROARCH.md",
+               "per_launch": {r["kernel"]: {"launches_per_step": r["launches_per_step"], "fetch_MB": r["fetch_MB_x2_corrected"],
+                                            "write_MB": r["write_MB"], "mfma_busy_pct": r["mfma_util_pct"] if r["mfma_util_pct"] != "" else None}
+                              for r in rows4 if r["fetch_MB_x2_corrected"] != "" and r["write_MB"] != ""}},
+              open(os.path.join(DST, f"{R}_c4_pmc_traffic.json"), "w"), indent=1)
+    print(open(os.path.join(DST, f"{R}_c4_pmc_summary.csv")).read())
+
+
+# ---- config 5 (PLIF-FireNet): per launch, in the format of the c3 traffic file (bench.py --config c5 reads it)
+c5f, c5w, c5m = counters("c5fetch"), counters("c5write"), counters("c5mfma")
+if c5f and c5w:
+    rows5 = []
+    for n in sorted(set(c5f) | set(c5m), key=lambda n: -sum(c5m.get(n, {}).get("GRBM_GUI_ACTIVE", [0]))):
+        if n.startswith("at::") or n.startswith("__amd") or "elementwise" in n:
+            continue
+        f_kb, w_kb = mean(c5f.get(n, {}).get("FETCH_SIZE", [])), mean(c5w.get(n, {}).get("WRITE_SIZE", []))
+        gui, busy = mean(c5m.get(n, {}).get("GRBM_GUI_ACTIVE", [])), mean(c5m.get(n, {}).get("SQ_VALU_MFMA_BUSY_CYCLES", []))
+        rows5.append({"kernel": n, "dispatches": len(c5f.get(n, {}).get("FETCH_SIZE", [])),
+                      "fetch_MB_x2_corrected": round(2 * f_kb / 1024, 2) if f_kb == f_kb else "",
+                      "write_MB": round(w_kb / 1024, 2) if w_kb == w_kb else "",
+                      "gui_cycles_per_xcd": round(gui / 8, 0) if gui == gui else "",
+                      "mfma_util_pct": round(100 * (busy / 1024) / (gui / 8), 1) if busy == busy and gui == gui and gui > 0 else ""})
+    with open(os.path.join(DST, f"{R}_c5_pmc_summary.csv"), "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows5[0].keys()))
+        w.writeheader()
+        w.writerows(rows5)
+    json.dump({"round": R, "src_hash": bench.source_hash(),
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES passes over `bench.py --config c5 --no-graph` "
+                         "(tools/profile_round.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md",
+               "per_launch": {r["kernel"]: {"fetch_MB": r["fetch_MB_x2_corrected"], "write_MB": r["write_MB"],
+                                            "mfma_busy_pct": r["mfma_util_pct"] if r["mfma_util_pct"] != "" else None}
+                              for r in rows5 if r["fetch_MB_x2_corrected"] != "" and r["write_MB"] != ""}},
+              open(os.path.join(DST, f"{R}_c5_pmc_traffic.json"), "w"), indent=1)
+    print(open(os.path.join(DST, f"{R}_c5_pmc_summary.csv")).read())
