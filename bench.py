@@ -1167,7 +1167,9 @@ def main():
         for key, ms in prof.items():
             ms = np.array(ms)
             name = "/".join(k for k in key if k)
-            if ms.size and float(ms.mean()) * 1e3 < 2.5 and key[0].startswith("evf_") and key[0] not in ("evf_cm_loss_fwd", "evf_cm_loss_bwd"):
+            if ms.size and float(ms.mean()) * 1e3 < 8.0 and key[0] in ("evf_head_plif_fwd", "evf_head_lif_fwd", "evf_conv_lif_fwd_b3", "evf_conv_plif_fwd_b3",
+                                                                          "evf_conv_lif_fwd_b3_pred", "evf_conv_plif_fwd_b3_pred", "evf_head_lif_bwd_wgrad",
+                                                                          "evf_lif_bwd_wgrad", "evf_lif_bwd_wgrad_top", "evf_conv_dgrad_b3"):
                 # an entry point that only RECORDS its cell while a window is being recorded (its kernel runs inside a window /
                 # diagonal launch listed under k_*): an empty bracket is not a kernel time
                 recorded_only.append(name)
