@@ -108,6 +108,8 @@ struct FbPlif {
   float4* g_pt_prev;        // [B,H,W,32] -> carry of pass t - 1 (may alias gpt_carry: same thread reads, then writes)
   float* g_P;               // [B,H,W] dL/d(pooled activity), raw (the input-gradient kernel applies the pooling's adjoint)
   float *g_leak_pt, *g_add_pt;  // per-block rows (row_ld) or dense (atomics)
+  int xl;  // an XLIF cell (spiking_submodules.py:337-435, :771-875; entry points: bit 1 of `hard_reset` / of `accumulate`): add_pt = t1,
+           // thresh = t0, threshold t0 + t1 * pt' -- the trace takes -t1 * dL/d(thresh) instead of -sigma(add_pt) * dL/d(current)
 };
 
 // TOP: the (non-recurrent) layer under the 1x1 tanh prediction head (models/model.py:197-199, :265).  The head's
@@ -696,7 +698,9 @@ __device__ __forceinline__ void fb_body_ws(
       }
       if (PLIF) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) lpt[k] = evf_plif_sigmoid(pl.leak_pt[4 * cg + k]), apt[k] = evf_plif_sigmoid(pl.add_pt[4 * cg + k]);
+        for (int k = 0; k < 4; ++k)
+          lpt[k] = evf_plif_sigmoid(pl.leak_pt[4 * cg + k]),
+          apt[k] = pl.xl ? fmaxf(pl.add_pt[4 * cg + k], 0.f) : evf_plif_sigmoid(pl.add_pt[4 * cg + k]);  // (XLIF: t1.clamp_min(0), :365/:810)
       }
     };
     const float4* pgz = g_z_out ? g_z_out : v_out;
@@ -826,12 +830,20 @@ __device__ __forceinline__ void fb_body_ws(
                            !TOP ? gz4.w + gzb4.w : gz4.w};
       const float gvo[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, vp[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
       const uint32_t zw = ((WIN ? w_zp : has_zw) ? s.zw : 0u) >> (4 * cg);
-      float gc[4], gp[4];
+      float gc[4], gp[4], gsv[4], pov[4] = {0.f, 0.f, 0.f, 0.f};
+      const bool xl = PLIF && pl.xl != 0;  // (cell-uniform)
+      if (PLIF) {  // pt' of the forward pass, recomputed (an XLIF cell: it is part of the threshold, t0 + t1 * pt', :419 / :864)
+        const float4 pp4 = (WIN ? w_pp : has_pp) ? sp.pp : z4;
+        const float pp[4] = {pp4.x, pp4.y, pp4.z, pp4.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pov[c] = evf_plif_trace(pp[c], lpt[c], sp.P);
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {  // autograd of spiking_submodules.py:103-126 / :523-551 (hard reset, arctan surrogate)
         const float z = (float)((zw >> c) & 1u);
-        const float sg = fb_surrogate(EVF_ARCTAN, vo[c] - th[c], width);
+        const float sg = fb_surrogate(EVF_ARCTAN, vo[c] - (xl ? th[c] + apt[c] * pov[c] : th[c]), width);
         const float gsp = gz[c] * sg;
+        gsv[c] = gsp;
         const float gv = gvo[c] + gsp;
         gc[c] = gv * oml[c];
         gp[c] = gv * lam[c] * (1.0f - z);
@@ -861,13 +873,14 @@ __device__ __forceinline__ void fb_body_ws(
         float gq[4], gPp = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const float po = evf_plif_trace(pp[c], lpt[c], Pv);  // pt' of the forward pass, recomputed
-          const float g = gk[c] - apt[c] * gc[c];
+          const float po = pov[c];                // pt' of the forward pass, recomputed
+          const float gx = xl ? gsv[c] : gc[c];  // what the trace scaled in the forward pass: the threshold's / the current's gradient (negated)
+          const float g = gk[c] - apt[c] * gx;
           gq[c] = g * lpt[c];
           gPp += g * (1.0f - lpt[c]);
           if (ok) {
             slp[c] += g * (pp[c] - Pv);
-            sap[c] -= gc[c] * po;
+            sap[c] -= gx * po;
           }
         }
         if (WIN) gkc = make_float4(gq[0], gq[1], gq[2], gq[3]);
@@ -1216,8 +1229,10 @@ __device__ __forceinline__ void fb_body_ws(
     for (int w = 0; w < EW; ++w) v += s_red2[(which * 8 + w) * C32 + c];
     const float sgm = fb_sigmoid(which == 0 ? pl.leak_pt[c] : pl.add_pt[c]);
     float* dst = which == 0 ? pl.g_leak_pt : pl.g_add_pt;
-    if (row_ld) dst[row_off + c] = rowp_prev + v * sgm * (1.0f - sgm);
-    else evf_atomic_add(dst + c, v * sgm * (1.0f - sgm));
+    // chain factor of the raw parameter: sigmoid' -- or, XLIF's t1.clamp_min(0), one where the clamp is inactive
+    const float dv = (pl.xl && which == 1) ? (pl.add_pt[c] > 0.f ? v : 0.f) : v * sgm * (1.0f - sgm);
+    if (row_ld) dst[row_off + c] = rowp_prev + dv;
+    else evf_atomic_add(dst + c, dv);
   }
 
   // ---- first touch of the slabs by a launch with fewer blocks than slab rows: the other rows start at zero (see fb_body)
@@ -1901,8 +1916,9 @@ extern "C" int evf_plif_bwd_wgrad2(const float* g_z_out, const float* g_z_out2, 
                                    const float* P, const float* leak_pt, const float* add_pt, float* g_pt_prev, float* g_P_raw,
                                    float* g_leak_pt, float* g_add_pt, void* stream) {
   if (!P || !leak_pt || !add_pt || !g_pt_prev || !g_P_raw || !g_leak_pt || !g_add_pt) return EVF_EINVAL;
-  const FbPlif pl{(const float4*)g_pt_carry, (const float4*)pt_prev, P, leak_pt, add_pt, (float4*)g_pt_prev, g_P_raw, g_leak_pt, g_add_pt};
-  return fb_launch(g_z_out, g_z_out2, nullptr, g_v_out, v_out, v_prev, z_prev, xT, zT_prev, leak, thresh, B, H, W, hard_reset,
+  const FbPlif pl{(const float4*)g_pt_carry, (const float4*)pt_prev, P, leak_pt, add_pt, (float4*)g_pt_prev, g_P_raw, g_leak_pt, g_add_pt,
+                  (hard_reset >> 1) & 1};  // (bit 1 of hard_reset: an XLIF cell)
+  return fb_launch(g_z_out, g_z_out2, nullptr, g_v_out, v_out, v_prev, z_prev, xT, zT_prev, leak, thresh, B, H, W, hard_reset & 1,
                    surrogate, act_width, g_cur, g_split, g_v_prev, g_leak, g_thresh, slab_ff, slab_rec, accumulate, stream, &pl);
 }
 extern "C" int evf_plif_bwd_wgrad_top(const float* flow, const float* g_flow, const float* pred_w, const uint32_t* z_out,
@@ -1916,8 +1932,9 @@ extern "C" int evf_plif_bwd_wgrad_top(const float* flow, const float* g_flow, co
   if (!flow || !g_flow || !pred_w || !z_out || !d_pred_w || !d_pred_b) return EVF_EINVAL;
   if (!P || !leak_pt || !add_pt || !g_pt_prev || !g_P_raw || !g_leak_pt || !g_add_pt) return EVF_EINVAL;
   const FbTop top{flow, g_flow, pred_w, z_out, d_pred_w, d_pred_b};
-  const FbPlif pl{(const float4*)g_pt_carry, (const float4*)pt_prev, P, leak_pt, add_pt, (float4*)g_pt_prev, g_P_raw, g_leak_pt, g_add_pt};
-  return fb_launch(nullptr, nullptr, &top, g_v_out, v_out, v_prev, z_prev, xT, nullptr, leak, thresh, B, H, W, hard_reset, surrogate,
+  const FbPlif pl{(const float4*)g_pt_carry, (const float4*)pt_prev, P, leak_pt, add_pt, (float4*)g_pt_prev, g_P_raw, g_leak_pt, g_add_pt,
+                  (hard_reset >> 1) & 1};
+  return fb_launch(nullptr, nullptr, &top, g_v_out, v_out, v_prev, z_prev, xT, nullptr, leak, thresh, B, H, W, hard_reset & 1, surrogate,
                    act_width, g_cur, g_split, g_v_prev, g_leak, g_thresh, slab_ff, nullptr, accumulate, stream, &pl);
 }
 
@@ -1962,7 +1979,8 @@ static int fb_window_launch(int np, const void* const* g_z, const void* const* f
   J.leak = leak, J.thresh = thresh, J.g_v_prev = (float4*)g_v_prev, J.g_leak = g_leak, J.g_thresh = g_thresh, J.slab_ff = slab_ff;
   J.width = act_width, J.accumulate = accumulate & 1, J.kind = (top ? 2 : 0) + (plif ? 3 : 0);
   J.top = FbTop{nullptr, nullptr, pred_w, nullptr, d_pred_w, d_pred_b};
-  J.pl = FbPlif{nullptr, nullptr, nullptr, leak_pt, add_pt, (float4*)g_pt_prev, nullptr, g_leak_pt, g_add_pt};
+  J.pl = FbPlif{nullptr, nullptr, nullptr, leak_pt, add_pt, (float4*)g_pt_prev, nullptr, g_leak_pt, g_add_pt,
+                (accumulate >> 1) & 1};  // (bit 1 of accumulate: an XLIF cell)
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k_bwd_win_plif, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);

@@ -54,7 +54,8 @@ struct FwJob {
   uint32_t* zT_out;
   PredArgs pr;
   int hard_reset;
-  int pad_;
+  int xl;  // PLIF fields describe an XLIF cell (spiking_submodules.py:337-435, :771-875): `add_pt` holds t1, `thresh` t0 -- the trace
+           // raises the THRESHOLD (t0 + t1 * pt') instead of being subtracted from the current
   // PLIF cell (spiking_submodules.py:191-227, :618-657; leak_pt == NULL: LIF): per-channel trace parameters, previous trace
   // [B,H,W,32] or NULL, new trace, pooled pre-synaptic activity [B,H,W] (saved for the backward)
   const float* leak_pt;

@@ -68,6 +68,8 @@ struct PlifArgs {
   const float* pt_prev;  // [B,H,W,32] or NULL
   float* pt_out;         // [B,H,W,32]
   float* P_out;          // [B,H,W] pooled pre-synaptic activity (saved for the backward)
+  int xl;                // XLIF cell (spiking_submodules.py:337-435, :771-875): add_pt = t1, thresh = t0; threshold t0 + t1 * pt', the
+                         // current stays ff (+ rec).  Entry points: bit 1 of `hard_reset`
 };
 
 #ifdef EVF_SPAN  // start / end of every block in the chip-wide 100 MHz counter (probe build through EVF_LIB)
@@ -99,7 +101,8 @@ __device__ __forceinline__ void fwd_b3_body(const int b, const uint32_t* __restr
   uint32_t* s_z = s_x + HALO_H * HALO_W;
   float* s_P = (float*)(s_z + HALO_H * HALO_W);  // TH*TW (PLIF)
   float* s_pw = s_P + TH * TW;                   // 2*32 + 2 prediction-head weights and bias
-  float* s_par = s_pw + 2 * C32 + 2;             // [4][32]: sigmoid(leak), clamped thresh, sigmoid(leak_pt), sigmoid(add_pt)
+  float* s_par = s_pw + 2 * C32 + 2;             // [5][32]: sigmoid(leak), clamped thresh, sigmoid(leak_pt), alpha, beta (PLIF: alpha =
+                                                 // sigmoid(add_pt), beta = 0; XLIF: alpha = 0, beta = max(t1, 0))
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;  // b: the sample (blockIdx.z of the one-layer kernel)
   FW_SPAN_MARK(0);
@@ -162,7 +165,9 @@ __device__ __forceinline__ void fwd_b3_body(const int b, const uint32_t* __restr
     s_par[tid] = b3_sigmoid(par_leak);             // torch.sigmoid(self.leak)     spiking_submodules.py:111/:536
     s_par[C32 + tid] = fmaxf(par_thresh, 0.01f);   // self.thresh.clamp_min(0.01)  :108/:533
     s_par[2 * C32 + tid] = PLIF ? evf_plif_sigmoid(par_lpt) : 0.f;
-    s_par[3 * C32 + tid] = PLIF ? evf_plif_sigmoid(par_apt) : 0.f;
+    // cur = (ff + rec) - alpha * pt', threshold = thresh + beta * pt': one of the two is zero (x - 0 * pt' = x, th + 0 * pt' = th exactly)
+    s_par[3 * C32 + tid] = (PLIF && !pl.xl) ? evf_plif_sigmoid(par_apt) : 0.f;
+    s_par[4 * C32 + tid] = (PLIF && pl.xl) ? fmaxf(par_apt, 0.f) : 0.f;  // self.t1.clamp_min(0)  :365/:810
   }
   // The weight DMA (invisible to the compiler's counters) was issued before everything else and memory
   // returns in order: once at most the state prefetches issued above (8, or 16 with the PLIF trace) are still
@@ -243,17 +248,19 @@ __device__ __forceinline__ void fwd_b3_body(const int b, const uint32_t* __restr
         const float lam = s_par[c], th = s_par[C32 + c];
         const float z = (float)((zw >> c) & 1u);
         float cur = acc[r];
-        float pto = 0.f;
+        float pto = 0.f, th_e = th, th_p = th;  // threshold of this element now / at the previous pass (soft reset)
         if (PLIF) {
-          const float lpt = s_par[2 * C32 + c], apt = s_par[3 * C32 + c];
+          const float lpt = s_par[2 * C32 + c], apt = s_par[3 * C32 + c], bet = s_par[4 * C32 + c];
           pto = evf_plif_trace(p4[e], lpt, Pq);  // :212 / :642
           cur = cur - apt * pto;                  // (ff + rec) - add_pt * pt_out, :220 / :650
+          th_e = th + bet * pto;                  // XLIF: thresh = t0 + t1 * pt_out, :419 / :864
+          th_p = th + bet * p4[e];                // XLIF soft reset: - z * (t0 + t1 * pt), :430 / :871
         }
         // both reset rules evaluated, one selected: no per-element branch on the (uniform) flag
         const float vo_hard = (v4[e] * lam) * (1.0f - z) + (1.0f - lam) * cur;  // :119/:544
-        const float vo_soft = v4[e] * lam + (1.0f - lam) * cur - z * th;        // :121/:546
+        const float vo_soft = v4[e] * lam + (1.0f - lam) * cur - z * th_p;      // :121/:546
         const float vo = hard_reset ? vo_hard : vo_soft;
-        const bool spike = ok && (vo - th) > 0.f;
+        const bool spike = ok && (vo - th_e) > 0.f;
         vo4[e] = vo, po4[e] = pto;
         bits |= (spike ? 1u : 0u) << c;
         // channel-major bit plane of channel c over the tile's 32 pixels = this ballot (low half: kg = 0)
@@ -614,7 +621,7 @@ struct FwDefer {
 static FwDefer fw_tab[EVF_CTX_MAX];
 
 static size_t fw_lds_bytes() {
-  return WB3_BYTES + 256 * 16 + 2 * HALO_H * HALO_W * 4 + TH * TW * 4 + (2 * C32 + 2) * 4 + 4 * C32 * 4;
+  return WB3_BYTES + 256 * 16 + 2 * HALO_H * HALO_W * 4 + TH * TW * 4 + (2 * C32 + 2) * 4 + 5 * C32 * 4;
 }
 
 static int fw_diag_select = -1;  // -1 environment / default, 0 k_fwd_diag (a tile per block), 1 k_fwd_diag_p, 2 k_fwd_diag_t
@@ -695,7 +702,7 @@ static int fw_defer_launch(FwDefer& fw_defer, void* stream) {
     } else if (nplif) {  // (only the teams kernel and the one-cell kernel know the trace: cell by cell)
       for (int k = 0; k < n; ++k) {
         const FwJob& J = jobs.j[k];
-        const PlifArgs pa{J.leak_pt, J.add_pt, J.pt_prev, J.pt_out, J.P_out};
+        const PlifArgs pa{J.leak_pt, J.add_pt, J.pt_prev, J.pt_out, J.P_out, J.xl};
         const int rc = launch_fwd_b3_now(J.x, J.wff, J.wrec, J.leak, J.thresh, J.v_prev, J.z_prev, fw_defer.B, fw_defer.H, fw_defer.W,
                                          J.hard_reset, J.v_out, J.z_out, J.zT_out, J.leak_pt ? &pa : nullptr, stream, J.pr);
         if (rc) return rc;
@@ -794,7 +801,7 @@ static int launch_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_re
     }
     fw_defer.B = B, fw_defer.H = H, fw_defer.W = W;
     fw_defer.job[fw_defer.slot][fw_defer.n[fw_defer.slot]++] =
-        FwJob{x, (const uint4*)wb_ff, (const uint4*)wb_rec, leak, thresh, v_prev, z_prev, v_out, z_out, zT_out, pd, hard_reset, 0,
+        FwJob{x, (const uint4*)wb_ff, (const uint4*)wb_rec, leak, thresh, v_prev, z_prev, v_out, z_out, zT_out, pd, hard_reset, plif ? plif->xl : 0,
               plif ? plif->leak_pt : nullptr, plif ? plif->add_pt : nullptr, plif ? plif->pt_prev : nullptr,
               plif ? plif->pt_out : nullptr, plif ? plif->P_out : nullptr};
     if (fw_poison) {  // debug aid: the outputs hold conspicuous garbage until the flush has run the cell
@@ -871,7 +878,8 @@ extern "C" int evf_conv_plif_fwd_b3(const uint32_t* x, const void* wb_ff, const 
   if (!x || !wb_ff || !leak_v || !leak_pt || !add_pt || !thresh || !v_out || !z_out || !pt_out || !P_out || B <= 0 ||
       H <= 0 || W <= 0)
     return EVF_EINVAL;
-  PlifArgs pa{leak_pt, add_pt, pt_prev, pt_out, P_out};
+  PlifArgs pa{leak_pt, add_pt, pt_prev, pt_out, P_out, (hard_reset >> 1) & 1};  // (bit 1: an XLIF cell)
+  hard_reset &= 1;
   return launch_fwd_b3(x, wb_ff, wb_rec, leak_v, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out, &pa,
                        stream);
 }
@@ -886,7 +894,8 @@ extern "C" int evf_conv_plif_fwd_b3_pred(const uint32_t* x, const void* wb_ff, c
   if (!x || !wb_ff || !leak_v || !leak_pt || !add_pt || !thresh || !v_out || !z_out || !pt_out || !P_out || !pred_w || !pred_b ||
       !flow || B <= 0 || H <= 0 || W <= 0)
     return EVF_EINVAL;
-  PlifArgs pa{leak_pt, add_pt, pt_prev, pt_out, P_out};
+  PlifArgs pa{leak_pt, add_pt, pt_prev, pt_out, P_out, (hard_reset >> 1) & 1};  // (bit 1: an XLIF cell)
+  hard_reset &= 1;
   const PredArgs pd{pred_w, pred_b, flow};
   return launch_fwd_b3(x, wb_ff, wb_rec, leak_v, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out, &pa,
                        stream, &pd);

@@ -141,7 +141,9 @@ __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, co
     }
     if (PLIF && tid < C32) {
       s_par2[tid] = evf_plif_sigmoid(J.leak_pt[tid]);
-      s_par2[C32 + tid] = evf_plif_sigmoid(J.add_pt[tid]);
+      // (XLIF cell: the slot holds max(t1, 0) -- self.t1.clamp_min(0), spiking_submodules.py:365/:810 -- and the cell's `xl` flag, a
+      // block-uniform scalar, picks the formula: the two neuron models share every register)
+      s_par2[C32 + tid] = J.xl ? fmaxf(J.add_pt[tid], 0.f) : evf_plif_sigmoid(J.add_pt[tid]);
     }
     if (J.pr.w) {
       if (tid < 2 * C32) s_pw[tid] = J.pr.w[tid];
@@ -166,6 +168,7 @@ __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, co
     float* __restrict__ pt_out = PLIF ? J.pt_out : nullptr;
     float* __restrict__ P_out = PLIF ? J.P_out : nullptr;
     const bool has_pred = J.pr.w != nullptr;
+    const bool xl = PLIF && J.xl != 0;  // (cell-uniform: an XLIF cell, see FwJob)
     const int nstrips = plan.nstrips;
 
     if (wv < 4) {
@@ -608,7 +611,13 @@ __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, co
               const f2 pp01 = {pq[PLIF ? k : 0].x, pq[PLIF ? k : 0].y}, pp23 = {pq[PLIF ? k : 0].z, pq[PLIF ? k : 0].w};
               const f2 po01 = pp01 * lpt01 + olp01 * P2, po23 = pp23 * lpt23 + olp23 * P2;  // evf_plif_trace, :212 / :642
               const f2 a01 = {a4[k].x, a4[k].y}, a23 = {a4[k].z, a4[k].w};
-              const f2 c01 = a01 - apt01 * po01, c23 = a23 - apt23 * po23;                   // (ff + rec) - add_pt * pt_out, :220 / :650
+              f2 c01, c23, t01 = {thL[0], thL[1]}, t23 = {thL[2], thL[3]};
+              if (xl) {  // (cell-uniform) XLIF: the current stays ff + rec, the trace raises the threshold: t0 + t1 * pt_out, :419 / :864
+                c01 = a01, c23 = a23;
+                t01 = t01 + apt01 * po01, t23 = t23 + apt23 * po23;
+              } else {
+                c01 = a01 - apt01 * po01, c23 = a23 - apt23 * po23;                          // (ff + rec) - add_pt * pt_out, :220 / :650
+              }
               const f2 v01 = {vp[k].x, vp[k].y}, v23 = {vp[k].z, vp[k].w};
               const f2 o01 = (v01 * lam01) * z01 + oml01 * c01;                             // :119/:544
               const f2 o23 = (v23 * lam23) * z23 + oml23 * c23;
@@ -619,7 +628,7 @@ __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, co
                   "v_cmp_gt_f32 vcc, %3, %7\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
                   "v_cmp_gt_f32 vcc, %4, %8\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
                   : "+v"(nib)
-                  : "v"(o23.y), "v"(o23.x), "v"(o01.y), "v"(o01.x), "v"(thL[3]), "v"(thL[2]), "v"(thL[1]), "v"(thL[0])
+                  : "v"(o23.y), "v"(o23.x), "v"(o01.y), "v"(o01.x), "v"(t23.y), "v"(t23.x), "v"(t01.y), "v"(t01.x)
                   : "vcc");
               if (!FULL) nib = ok ? nib : 0u;
 #ifndef FT_PROBE_NOSTORE
@@ -656,14 +665,20 @@ __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, co
               for (int q = 0; q < 4; ++q) {
                 const float z = (float)((zn >> q) & 1u);
                 float cur = cu[q];
+                float th_e = thL[q], th_p = thL[q];  // threshold of the element now / at the previous pass (soft reset)
                 po4[q] = 0.f;
                 if (PLIF) {
                   po4[q] = evf_plif_trace(p4[q], lptL[q], Pk[k]);  // :212 / :642
-                  cur = cur - aptL[q] * po4[q];                         // (ff + rec) - add_pt * pt_out, :220 / :650
+                  if (xl) {  // (cell-uniform) XLIF: thresh = t0 + t1 * pt_out, :419 / :864; soft reset - z * (t0 + t1 * pt), :430 / :871
+                    th_e = thL[q] + aptL[q] * po4[q];
+                    th_p = thL[q] + aptL[q] * p4[q];
+                  } else {
+                    cur = cur - aptL[q] * po4[q];                       // (ff + rec) - add_pt * pt_out, :220 / :650
+                  }
                 }
                 const float vo = HARD ? (v4[q] * lamL[q]) * (1.0f - z) + omlL[q] * cur    // :119/:544
-                                      : v4[q] * lamL[q] + omlL[q] * cur - z * thL[q];     // :121/:546
-                const bool spike = ok && (vo - thL[q]) > 0.f;
+                                      : v4[q] * lamL[q] + omlL[q] * cur - z * th_p;       // :121/:546
+                const bool spike = ok && (vo - th_e) > 0.f;
                 vo4[q] = vo;
                 nib |= (spike ? 1u : 0u) << q;
               }
@@ -876,7 +891,7 @@ int evf_fwd_win_is_chain(const FwJob* c, int n) {
   for (int k = 1; k < n; ++k) {
     const FwJob &a = c[k - 1], &b = c[k];
     if (b.wrec || b.wff != a.wff || b.leak != a.leak || b.thresh != a.thresh || b.hard_reset != a.hard_reset ||
-        b.leak_pt != a.leak_pt || b.add_pt != a.add_pt || b.pr.w != a.pr.w || b.pr.bias != a.pr.bias)
+        b.leak_pt != a.leak_pt || b.add_pt != a.add_pt || b.xl != a.xl || b.pr.w != a.pr.w || b.pr.bias != a.pr.bias)
       return 0;
     if (b.v_prev != a.v_out || b.z_prev != a.z_out || b.pt_prev != a.pt_out) return 0;
     if ((b.zT_out == nullptr) != (a.zT_out == nullptr)) return 0;

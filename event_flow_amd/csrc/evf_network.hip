@@ -177,10 +177,11 @@ __device__ __forceinline__ void lif_load_prev(int b, int row, int x0, int H, int
   }
 }
 
+// thx: NULL, or the 16 per-element increments of the threshold (XLIF head: t1 * pt', spiking_submodules.py:419; hard reset only)
 __device__ __forceinline__ void lif_update(const f32x16& acc, const float (&vpv)[16], const uint32_t (&zw)[16], int b,
                                            int row, int x0, int H, int W, int lane, float lam, float th, int hard_reset,
                                            float* __restrict__ v_out, uint32_t* __restrict__ z_out,
-                                           uint32_t* __restrict__ zT_out) {
+                                           uint32_t* __restrict__ zT_out, const float* thx = nullptr) {
   const int j = lane & 31;
   const bool row_ok = row < H;
   uint32_t plane = 0u;  // this channel's spikes over the tile's 32 pixels (bit = column)
@@ -198,7 +199,7 @@ __device__ __forceinline__ void lif_update(const f32x16& acc, const float (&vpv)
       const float vo_soft = v * lam + (1.0f - lam) * cur - z * th;
       const float vo = hard_reset ? vo_hard : vo_soft;  // (a select, not a branch, inside the unrolled pixel loop)
       v_out[pix * C32 + j] = vo;
-      spike = (vo - th) > 0.f;
+      spike = (vo - (thx ? th + thx[r] : th)) > 0.f;
     }
     const unsigned long long m = __ballot(spike);
     if (ok && j == 0) z_out[pix] = (lane >> 5) ? (uint32_t)(m >> 32) : (uint32_t)m;
@@ -384,6 +385,9 @@ __global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ 
   const int j = lane & 31;
   const float lam = evf_sigmoid(leak[j]);
   const float th = fmaxf(thresh[j], 0.01f);
+  const bool xl = pt_out && (hard_reset & 2);  // XLIF head (bit 1 of the flag, evf_head_plif_fwd): add_pt = t1, thresh = t0
+  hard_reset &= 1;
+  float thx0[16], thx1[16];  // (XLIF: t1 * pt' per element of the wave's two rows)
   if (pt_out) {  // PLIF head (spiking_submodules.py:191-227): cur = ff - sigma(add_pt) * pt'
     const int py = tid >> 5, px = tid & 31;
     float sum9 = 0.f;
@@ -397,11 +401,12 @@ __global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ 
     s_P[tid] = P;
     if (y0 + py < H && x0 + px < W) P_out[((long)b * H + y0 + py) * W + x0 + px] = P;
     __syncthreads();
-    const float lpt = evf_plif_sigmoid(leak_pt[j]), apt = evf_plif_sigmoid(add_pt[j]);
+    const float lpt = evf_plif_sigmoid(leak_pt[j]), apt = xl ? fmaxf(add_pt[j], 0.f) : evf_plif_sigmoid(add_pt[j]);  // (XLIF: t1.clamp_min(0), :365)
     const float* ptsrc = pt_prev ? pt_prev : pt_out;  // dummy source when there is no previous trace
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       f32x16& acc = m ? acc1 : acc0;
+      float (&thx)[16] = m ? thx1 : thx0;
       const int row = y0 + r0 + m, rq = min(row, H - 1);
       // the 16 previous-trace values of this lane: unconditional loads from clamped addresses, all in flight
       // together (under `if (ok)` each load is its own round trip: this loop was 32 serial latencies)
@@ -413,13 +418,19 @@ __global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ 
       for (int r = 0; r < 16; ++r) {
         const int cl = mfma_row(r, lane), col = x0 + cl;
         const float pto = evf_plif_trace(pt_prev ? ptv[r] : 0.f, lpt, s_P[(r0 + m) * TW + cl]);
-        acc[r] = acc[r] - apt * pto;
+        thx[r] = apt * pto;
+        if (!xl) acc[r] = acc[r] - thx[r];  // (XLIF: the current stays ff, the threshold becomes t0 + t1 * pt', :419)
         if (row < H && col < W) pt_out[(((long)b * H + row) * W + col) * C32 + j] = pto;
       }
     }
   }
-  lif_update(acc0, vp0, zw0, b, y0 + r0, x0, H, W, lane, lam, th, hard_reset, v_out, z_out, zT_out);
-  lif_update(acc1, vp1, zw1, b, y0 + r0 + 1, x0, H, W, lane, lam, th, hard_reset, v_out, z_out, zT_out);
+  if (xl) {  // (block-uniform)
+    lif_update(acc0, vp0, zw0, b, y0 + r0, x0, H, W, lane, lam, th, hard_reset, v_out, z_out, zT_out, thx0);
+    lif_update(acc1, vp1, zw1, b, y0 + r0 + 1, x0, H, W, lane, lam, th, hard_reset, v_out, z_out, zT_out, thx1);
+  } else {
+    lif_update(acc0, vp0, zw0, b, y0 + r0, x0, H, W, lane, lam, th, hard_reset, v_out, z_out, zT_out);
+    lif_update(acc1, vp1, zw1, b, y0 + r0 + 1, x0, H, W, lane, lam, th, hard_reset, v_out, z_out, zT_out);
+  }
 }
 
 static void launch_head_fwd(dim3 grid, dim3 block, hipStream_t st, const float* x, const float* w, const float* leak,
@@ -544,12 +555,13 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 && !PLIF) ? 4 : ((NWV == 4 && P
   const int i = lane & 31, h = lane >> 5, j = lane & 31;
   const float lam = evf_sigmoid(a.leak[j]);
   const float th = fmaxf(a.thresh[j], 0.01f);
-  const int hard_reset = a.hard_reset;
+  const int hard_reset = a.hard_reset & 1;
+  const bool xl = PLIF && (a.hard_reset & 2);  // XLIF head (bit 1 of the flag, evf_head_plif_fwd): add_pt = t1, thresh = t0
   const int nW = (W + 31) / 32;
   float pt[PLIF ? RPW : 1][16];
   float lpt = 0.f, apt = 0.f;
   if (PLIF) {
-    lpt = evf_plif_sigmoid(a.leak_pt[j]), apt = evf_plif_sigmoid(a.add_pt[j]);
+    lpt = evf_plif_sigmoid(a.leak_pt[j]), apt = xl ? fmaxf(a.add_pt[j], 0.f) : evf_plif_sigmoid(a.add_pt[j]);  // (XLIF: t1.clamp_min(0), :365)
     const float* ptsrc = a.pt_prev ? a.pt_prev : a.p[0].v_out;  // (dummy source: selected away)
 #pragma unroll
     for (int m = 0; m < RPW; ++m) {
@@ -564,7 +576,9 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 && !PLIF) ? 4 : ((NWV == 4 && P
   // LIF update of one row (lif_update) that also leaves the new state in vpv / zb for the next pass.  FULL: the tile lies
   // inside the image (block-uniform) -- no per-pixel branch.  The 16 spike words of the row go out in ONE store (lane r of
   // each half wave keeps word r) instead of 16 stores by lanes 0 and 32.
-  auto update = [&](const f32x16& acc, float (&vpv)[16], uint32_t& zbr, int row, const HeadWinPass& o, const bool FULL) {
+  // ptr: the row's new traces (PLIF / XLIF; XLIF: threshold t0 + t1 * pt' per element, spiking_submodules.py:419, hard reset only)
+  auto update = [&](const f32x16& acc, float (&vpv)[16], uint32_t& zbr, int row, const HeadWinPass& o, const bool FULL,
+                    const float (&ptr)[16]) {
     const bool row_ok = FULL || row < H;
     uint32_t plane = 0u, znew = 0u, zsel = 0u;
     // one base address per row; pixel r of the lane is a compile-time offset from it ((r & 3) + 8 (r >> 2) pixels)
@@ -582,7 +596,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 && !PLIF) ? 4 : ((NWV == 4 && P
         const float vo_soft = v * lam + (1.0f - lam) * cur - z * th;
         const float vo = hard_reset ? vo_hard : vo_soft;
         vrow[((r & 3) + 8 * (r >> 2)) * C32] = vo;
-        spike = (vo - th) > 0.f;
+        spike = (vo - ((PLIF && xl) ? th + apt * ptr[r] : th)) > 0.f;
         vpv[r] = vo;
       }
       const unsigned long long m = __ballot(spike);
@@ -647,7 +661,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 && !PLIF) ? 4 : ((NWV == 4 && P
         for (int r = 0; r < 16; ++r) {
           const int cl = mfma_row(r, lane), col = x0 + cl;
           const float pto = evf_plif_trace(pt[PLIF ? m : 0][r], lpt, s_P[(r0 + m) * TW + cl]);
-          acc[m][r] = acc[m][r] - apt * pto;
+          if (!xl) acc[m][r] = acc[m][r] - apt * pto;  // (XLIF: the current stays ff)
           pt[PLIF ? m : 0][r] = pto;
           if (row < H && col < W) prow[cl * C32] = pto;
         }
@@ -655,8 +669,8 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 && !PLIF) ? 4 : ((NWV == 4 && P
     }
 #pragma unroll
     for (int m = 0; m < RPW; ++m) {
-      if (full) update(acc[m], vp[m], zb[m], y0 + r0 + m, a.p[t], true);
-      else update(acc[m], vp[m], zb[m], y0 + r0 + m, a.p[t], false);
+      if (full) update(acc[m], vp[m], zb[m], y0 + r0 + m, a.p[t], true, pt[PLIF ? m : 0]);
+      else update(acc[m], vp[m], zb[m], y0 + r0 + m, a.p[t], false, pt[PLIF ? m : 0]);
     }
   }
 }
@@ -787,6 +801,7 @@ extern "C" int evf_head_plif_fwd(const float* x, const float* w, const float* le
   if (!x || !w || !leak_v || !leak_pt || !add_pt || !thresh || !v_out || !z_out || !pt_out || !P_out || B <= 0 ||
       Cin <= 0 || Cin > HEAD_MAX_CIN || H <= 0 || W <= 0)
     return EVF_EINVAL;
+  if (hard_reset == 2) return EVF_ENOTSUP;  // (an XLIF head with the soft reset: its threshold of the pass before is not kept here)
   const int fctx = evf_ctx_find(stream);
   if (fctx >= 0 && evf_fwd_defer_active(fctx)) {  // recorded like evf_head_lif_fwd: the window's passes in one launch at the flush
     HfDefer& hf = hf_tab[fctx];
@@ -1141,7 +1156,10 @@ __device__ __forceinline__ void head_bwd_pass(
     float* slab, int slab_acc, int row_ld, float4 (&gvc)[NT ? NT : 1], float4 (&voc)[NT ? NT : 1], int (&xo)[NT ? NT : 1][4],
     HeadBwdKeep& K, bool store_gv,  // store_gv: the launch's last pass (NT = 0: every pass is first and last)
     const HeadPlifPass pq = HeadPlifPass{}, const HeadPlifPrm pm = HeadPlifPrm{}, float4* gpc_ = nullptr, HeadBwdKeepPlif* KP_ = nullptr) {
-  const int hard_reset = FAST ? 1 : hard_reset_rt, surrogate = FAST ? EVF_ARCTAN : surrogate_rt;
+  const int hard_reset = FAST ? 1 : (hard_reset_rt & 1), surrogate = FAST ? EVF_ARCTAN : surrogate_rt;
+  // XLIF head (bit 1 of the flag, evf_head_plif_bwd_wgrad): add_pt = t1, thresh = t0; the trace raised the THRESHOLD (t0 + t1 * pt',
+  // spiking_submodules.py:419), so it takes -t1 * dL/d(thresh) instead of -sigma(add_pt) * dL/d(current)
+  const bool xl = PLIF && (hard_reset_rt & 2) != 0;
   float4 gpc_none[1];
   HeadBwdKeepPlif kp_none;
   float4* gpc = PLIF ? gpc_ : gpc_none;          // [NT] the carried dL/d(pt') of the block's trips
@@ -1165,7 +1183,7 @@ __device__ __forceinline__ void head_bwd_pass(
       sl[k] = st[k] = 0.f;
       if (PLIF) {
         KP.lpt[k] = evf_plif_sigmoid(pm.leak_pt[4 * cg + k]);
-        KP.apt[k] = evf_plif_sigmoid(pm.add_pt[4 * cg + k]);
+        KP.apt[k] = xl ? fmaxf(pm.add_pt[4 * cg + k], 0.f) : evf_plif_sigmoid(pm.add_pt[4 * cg + k]);
         KP.slp[k] = KP.sap[k] = 0.f;
       }
     }
@@ -1268,12 +1286,19 @@ __device__ __forceinline__ void head_bwd_pass(
     const uint32_t zw = z_prev ? (zwl >> (4 * cg)) : 0u;
     const float vo[4] = {vo4.x, vo4.y, vo4.z, vo4.w}, gz[4] = {gz4.x, gz4.y, gz4.z, gz4.w};
     const float gvo[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, vp[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
-    float gc[4], gp[4];
+    float gc[4], gp[4], gsv[4], pov[4] = {0.f, 0.f, 0.f, 0.f};
+    if (PLIF) {  // pt' of the forward pass, recomputed (XLIF: it is part of the threshold)
+      const float4 pp4 = pq.pt_prev ? in.ppl : zero4;
+      const float pp[4] = {pp4.x, pp4.y, pp4.z, pp4.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pov[k] = evf_plif_trace(pp[k], KP.lpt[k], in.Pl);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float z = (float)((zw >> k) & 1u);
-      const float sg = evf_surrogate(surrogate, vo[k] - th[k], width);
+      const float sg = evf_surrogate(surrogate, vo[k] - ((PLIF && xl) ? th[k] + KP.apt[k] * pov[k] : th[k]), width);
       const float gsp = gz[k] * sg;
+      gsv[k] = gsp;
       const float gv = gvo[k] + gsp;
       gc[k] = gv * oml[k];
       float cur, dlam, dth = 0.f;
@@ -1304,12 +1329,13 @@ __device__ __forceinline__ void head_bwd_pass(
       float gq[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float po = evf_plif_trace(pp[k], KP.lpt[k], Pv);
-        const float g = gk[k] - KP.apt[k] * gc[k];
+        const float po = pov[k];
+        const float gx = xl ? gsv[k] : gc[k];  // what the trace scaled in the forward pass: the threshold's / the current's gradient (negated)
+        const float g = gk[k] - KP.apt[k] * gx;
         gq[k] = g * KP.lpt[k];
         if (ok) {
           KP.slp[k] += g * (pp[k] - Pv);
-          KP.sap[k] -= gc[k] * po;
+          KP.sap[k] -= gx * po;
         }
       }
       if (NT > 0) gpc[ic] = make_float4(gq[0], gq[1], gq[2], gq[3]);
@@ -1415,8 +1441,10 @@ __device__ __forceinline__ void head_bwd_pass(
       for (int w = 0; w < 4; ++w) v += s_red[which][w][c];
       const float sgm = evf_sigmoid(which == 0 ? pm.leak_pt[c] : pm.add_pt[c]);
       float* dst = which == 0 ? pm.g_leak_pt : pm.g_add_pt;
-      if (row_ld) dst[row_off + c] = row_prev + v * sgm * (1.0f - sgm);
-      else evf_atomic_add(dst + c, v * sgm * (1.0f - sgm));
+      // chain factor of the raw parameter: sigmoid' -- or, XLIF's t1.clamp_min(0), one where the clamp is inactive
+      const float dv = (xl && which == 1) ? (pm.add_pt[c] > 0.f ? v : 0.f) : v * sgm * (1.0f - sgm);
+      if (row_ld) dst[row_off + c] = row_prev + dv;
+      else evf_atomic_add(dst + c, dv);
     }
   }
 }
@@ -1441,12 +1469,12 @@ __global__ __launch_bounds__(256) void k_head_plif_bwd_mfma(
     const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev, const float* __restrict__ leak,
     const float* __restrict__ thresh, long npix, float width, float4* __restrict__ g_v_prev, float* __restrict__ g_leak,
     float* __restrict__ g_thresh, const float* __restrict__ x_in, int Cin, int H, int W, float* __restrict__ slab, int slab_acc,
-    int row_ld, HeadPlifPass pq, HeadPlifPrm pm) {
+    int row_ld, HeadPlifPass pq, HeadPlifPrm pm, int xl) {  // xl: an XLIF head (bit 1 of the entry point's reset flag)
   float4 none[1], gpc[1];
   int nox[1][4];
   HeadBwdKeep keep;
   HeadBwdKeepPlif kp;
-  head_bwd_pass<true, 0, true, true>(g_z_out, g_v_out, v_out, v_prev, z_prev, leak, thresh, npix, 1, EVF_ARCTAN, width, nullptr, g_v_prev,
+  head_bwd_pass<true, 0, true, true>(g_z_out, g_v_out, v_out, v_prev, z_prev, leak, thresh, npix, 1 | (xl ? 2 : 0), EVF_ARCTAN, width, nullptr, g_v_prev,
                                      g_leak, g_thresh, x_in, Cin, H, W, slab, slab_acc, row_ld, none, none, nox, keep, true, pq, pm, gpc, &kp);
 }
 
@@ -1542,7 +1570,7 @@ static int head_bwd_go(const HdArgs& a, void* stream) {
                        (const float4*)a.g_v_out, (const float4*)a.v_out, (const float4*)a.v_prev, a.z_prev, a.leak, a.thresh, npix,
                        a.act_width, (float4*)a.g_v_prev, a.g_leak, a.g_thresh, a.x_in, a.Cin, a.H, a.W, a.slab, accumulate, row_ld,
                        HeadPlifPass{(const float4*)a.g_pt_out, (const float4*)a.pt_prev, a.P, (float4*)a.g_pt_prev},
-                       HeadPlifPrm{a.leak_pt, a.add_pt, a.g_leak_pt, a.g_add_pt});
+                       HeadPlifPrm{a.leak_pt, a.add_pt, a.g_leak_pt, a.g_add_pt}, (a.hard_reset >> 1) & 1);
     return evf_status();
   }
 #define HEAD_BWD(FAST_)                                                                                                    \
@@ -1713,7 +1741,7 @@ extern "C" int evf_head_plif_bwd_wgrad(const float* g_z_out, const float* g_v_ou
   if (!v_out || !x_in || !leak || !thresh || !g_v_prev || !g_leak || !g_thresh || !slab || B <= 0 || H <= 0 || W <= 0 ||
       Cin != 2 || !P || !leak_pt || !add_pt || !g_pt_prev || !g_leak_pt || !g_add_pt)
     return EVF_EINVAL;
-  if (!(hard_reset != 0 && surrogate == EVF_ARCTAN)) return EVF_ENOTSUP;  // (the two-call path serves the other neurons)
+  if (!((hard_reset & 1) && surrogate == EVF_ARCTAN)) return EVF_ENOTSUP;  // (the two-call path serves the other neurons; bit 1: an XLIF head)
   const HdArgs a{g_z_out, g_v_out, v_out, v_prev, z_prev, x_in, leak, thresh, B, Cin, H, W, hard_reset, surrogate, act_width,
                  nullptr, g_v_prev, g_leak, g_thresh, slab, accumulate, g_pt_carry, pt_prev, P, leak_pt, add_pt, g_pt_prev,
                  g_leak_pt, g_add_pt};

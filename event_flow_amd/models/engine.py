@@ -171,14 +171,20 @@ class FireNetEngine:
         self.pred = pred
         self.num_bins = num_bins
         self.kind = cells[0].kind
+        # XLIF cells (reference spiking_submodules.py:337-435, :771-875) run through the PLIF kernels: the same pre-synaptic trace, which
+        # raises the THRESHOLD (t0 + t1 * pt') instead of being subtracted from the current.  Their t1 travels in the `add_pt` slot,
+        # t0 in the `thresh` slot, and bit 1 of the entry points' reset / accumulate flag says so (include/evflow.h).
+        self._plif = self.kind in ("plif", "xlif")
+        self._xl = self.kind == "xlif"
         for i, c in enumerate(cells):
-            if c.kind not in ("lif", "plif") or c.kind != self.kind:
+            if c.kind not in ("lif", "plif", "xlif") or c.kind != self.kind:
                 raise NotImplementedError(
-                    f"{type(c).__name__}: LIF and PLIF cells are accelerated so far (ALIF/XLIF are a later row of "
-                    "SURVEY.md section 8); there is no CPU fallback"
+                    f"{type(c).__name__}: LIF, PLIF and XLIF cells are accelerated so far (ALIF: the general path); there is no CPU fallback"
                 )
-            if c.kind == "plif" and precision != "bf16x3":
-                raise NotImplementedError("PLIF cells are implemented on the bf16x3 path only")
+            if self._plif and precision != "bf16x3":
+                raise NotImplementedError("PLIF / XLIF cells are implemented on the bf16x3 path only")
+            if c.kind == "xlif" and not (c.hard_reset and c.activation == "arctanspike" and PLIF_TRACE_FUSED):
+                raise NotImplementedError("fused XLIF cells: hard reset, arctan surrogate, trace backward inside the fused backward")
             if c.hidden_size != C or c.kernel_size != 3 or c.stride != 1 or (i > 0 and c.input_size != C):
                 raise NotImplementedError("accelerated FireNet kernels need base_num_channels=32, kernel_size=3")
             if i == 0 and c.recurrent:
@@ -195,9 +201,13 @@ class FireNetEngine:
                 self._reg(f"{i}.leak", c.leak_v)
                 self._reg(f"{i}.leak_pt", c.leak_pt)
                 self._reg(f"{i}.add_pt", c.add_pt)
+            elif c.kind == "xlif":
+                self._reg(f"{i}.leak", c.leak_v)
+                self._reg(f"{i}.leak_pt", c.leak_pt)
+                self._reg(f"{i}.add_pt", c.t1)  # (the kernels' slot of the trace's weight: t1 here)
             else:
                 self._reg(f"{i}.leak", c.leak)
-            self._reg(f"{i}.thresh", c.thresh)
+            self._reg(f"{i}.thresh", c.t0 if c.kind == "xlif" else c.thresh)
         self._reg("pred.w", pred.conv2d.weight)
         self._reg("pred.b", pred.conv2d.bias)
         # layout of the small-accumulator buffer
@@ -333,7 +343,7 @@ class FireNetEngine:
             _lib.call("evf_nchw_to_bits", _lib.ptr(zz), B, H, W, _lib.ptr(z))
             zT = _i32((B, H, C, (W + 31) // 32), vv.device)
             _lib.call("evf_bits_transpose", _lib.ptr(z), B, H, W, _lib.ptr(zT))
-            if self.kind == "plif":
+            if self._plif:
                 pp = st[2].detach().float().contiguous()
                 pt = _f32((B, H, W, C), vv.device)
                 _lib.call("evf_nchw_to_nhwc", _lib.ptr(pp), B, C, H, W, _lib.ptr(pt))
@@ -520,7 +530,7 @@ class FireNetEngine:
                 for tg in target)
             if not ok:  # one-pass window starting from the target itself, or another geometry: fresh tensors
                 target = None
-        defer = (record and self.__dict__.get("_defer_on", False) and self.precision == "bf16x3" and self.kind in ("lif", "plif")
+        defer = (record and self.__dict__.get("_defer_on", False) and self.precision == "bf16x3" and self.kind in ("lif", "plif", "xlif")
                  and PRED_FUSED)
         if not defer:
             self.flush_forward()  # (a pass outside the recorded schedule, e.g. under no_grad: what is recorded runs first)
@@ -538,7 +548,8 @@ class FireNetEngine:
                     raise _lib.EvflowError("evf_fwd_defer_slot failed")
             st = states[i]
             v_prev, z_prev, zT_prev = st[:3] if st is not None else (None, None, None)
-            plif = self.kind == "plif"
+            plif = self._plif
+            xf = 2 if self._xl else 0  # (bit 1 of the reset flag: an XLIF cell, include/evflow.h)
             pt_prev = st[3] if (plif and st is not None) else None
             if target is not None:
                 pt_out = target[i][3] if plif else None
@@ -556,14 +567,14 @@ class FireNetEngine:
             if plif and i == 0:
                 _lib.call("evf_head_plif_fwd", _lib.ptr(x_in), _lib.ptr(self._flat["0.ff"]), _lib.ptr(leak),
                           _lib.ptr(self._flat["0.leak_pt"]), _lib.ptr(self._flat["0.add_pt"]), _lib.ptr(thresh), _lib.ptr(v_prev),
-                          _lib.ptr(z_prev), _lib.ptr(pt_prev), B, Cin, H, W, 1 if c.hard_reset else 0, _lib.ptr(v_out),
+                          _lib.ptr(z_prev), _lib.ptr(pt_prev), B, Cin, H, W, (1 if c.hard_reset else 0) | xf, _lib.ptr(v_out),
                           _lib.ptr(z_out), _lib.ptr(zT_out), _lib.ptr(pt_out), _lib.ptr(P_out))
             elif plif:
                 wrec = self._packed[(i, "rec", "b3")] if c.recurrent else None
                 args = (_lib.ptr(in_bits), _lib.ptr(self._packed[(i, "ff", "b3")]), _lib.ptr(wrec),
                         _lib.ptr(leak), _lib.ptr(self._flat[f"{i}.leak_pt"]), _lib.ptr(self._flat[f"{i}.add_pt"]),
                         _lib.ptr(thresh), _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(pt_prev), B, H, W,
-                        1 if c.hard_reset else 0, _lib.ptr(v_out), _lib.ptr(z_out), _lib.ptr(zT_out), _lib.ptr(pt_out),
+                        (1 if c.hard_reset else 0) | xf, _lib.ptr(v_out), _lib.ptr(z_out), _lib.ptr(zT_out), _lib.ptr(pt_out),
                         _lib.ptr(P_out))
                 if i == len(self.cells) - 1 and PRED_FUSED:  # last layer: the prediction head runs in this kernel's epilogue
                     flow = self._flow_out(B, H, W, dev)
@@ -623,7 +634,7 @@ class FireNetEngine:
 
     # ---- PLIF: backward of a window layer by layer ---------------------------------------------------------------------------
     def _lm_wanted(self, win, tape, g_flow):
-        if not (PLIF_LAYER_MAJOR and self.kind == "plif" and self.precision == "bf16x3" and g_flow is not None):
+        if not (PLIF_LAYER_MAJOR and self._plif and self.precision == "bf16x3" and g_flow is not None):
             return False
         n = len(self.cells)
         return (HEAD_WIN and PLIF_TRACE_FUSED and PLIF_BOX_IN_DGRAD and TOP_FUSED and F32_DGRAD and PAIR_DGRAD and PARAM_ROWS
@@ -728,6 +739,7 @@ class FireNetEngine:
         arr_n = lambda ts: arr(ts) if ts[0] is not None else None  # noqa: E731
         rowp = lambda name: _lib.ptr(self._rowed(win, name)[0])  # noqa: E731
         row_ld = win.rows.shape[1]
+        xf = 2 if self._xl else 0  # (bit 1 of the reset / accumulate flag: XLIF cells, include/evflow.h)
         for i in range(n - 1, 0, -1):
             c = self.cells[i]
             lay = [tp["layers"][i] for tp in tapes]  # (in_bits, v_prev, z_prev, v_out, z_out, in_bitsT, zT_prev, pt_prev, pt_out, P)
@@ -742,14 +754,14 @@ class FireNetEngine:
                           arr([l_[2] for l_ in lay]), arr([l_[5] for l_ in lay]), arr_n(gcur), arr_n(gsp), arr([l_[7] for l_ in lay]),
                           arr([l_[9] for l_ in lay]), arr(gPs), leak, thr, lpt, apt, B, H, W, width, None, None, rowp(f"{i}.leak"),
                           rowp(f"{i}.thresh"), rowp(f"{i}.leak_pt"), rowp(f"{i}.add_pt"), _lib.ptr(self._slab(kf, nsl, dev)),
-                          (1 if win.slab_init.get(kf) else 0) | (row_ld << 8))
+                          (1 if win.slab_init.get(kf) else 0) | xf | (row_ld << 8))
                 win.slab_init[kf] = True
             elif not c.recurrent:  # feed-forward: all passes in one launch, the carries in registers
                 _lib.call("evf_plif_bwd_wgrad_window", T, arr([gz(i, s_) for s_ in range(T)]), arr([l_[3] for l_ in lay]),
                           arr([l_[1] for l_ in lay]), arr([l_[2] for l_ in lay]), arr([l_[5] for l_ in lay]), arr_n(gcur), arr_n(gsp),
                           arr([l_[7] for l_ in lay]), arr([l_[9] for l_ in lay]), arr(gPs), leak, thr, lpt, apt, B, H, W, width, None, None,
                           rowp(f"{i}.leak"), rowp(f"{i}.thresh"), rowp(f"{i}.leak_pt"), rowp(f"{i}.add_pt"),
-                          _lib.ptr(self._slab(kf, nsl, dev)), (1 if win.slab_init.get(kf) else 0) | (row_ld << 8))
+                          _lib.ptr(self._slab(kf, nsl, dev)), (1 if win.slab_init.get(kf) else 0) | xf | (row_ld << 8))
                 win.slab_init[kf] = True
             if not c.recurrent and split:  # input gradients of all passes in one launch (the pooling's adjoint of dL/dP inside)
                 wts = [self._packed[(i, "ff", "b3t")]] * T
@@ -772,7 +784,7 @@ class FireNetEngine:
                     _lib.zero_(self._slab(kr, nsl, dev))  # (first recurrent contribution later than the feed-forward one)
                 _lib.call("evf_plif_bwd_wgrad2", _lib.ptr(gz(i, s_)), _lib.ptr(gzr_i) if has_gzr else None, _lib.ptr(gv_i) if s_ else None,
                           _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None,
-                          leak, thr, B, H, W, 1, SURROGATE_ID[c.activation], width, _lib.ptr(gcur[s_]), _lib.ptr(gsp[s_]), _lib.ptr(gv_i),
+                          leak, thr, B, H, W, 1 | xf, SURROGATE_ID[c.activation], width, _lib.ptr(gcur[s_]), _lib.ptr(gsp[s_]), _lib.ptr(gv_i),
                           rowp(f"{i}.leak"), rowp(f"{i}.thresh"), _lib.ptr(self._slab(kf, nsl, dev)),
                           _lib.ptr(self._slab(kr, nsl, dev)) if use_rec else None, acc | (row_ld << 8),
                           _lib.ptr(gpt_i) if s_ else None, _lib.ptr(pt_prev), _lib.ptr(P_sav), lpt, apt, _lib.ptr(gpt_i), _lib.ptr(gPs[s_]),
@@ -813,7 +825,7 @@ class FireNetEngine:
                 raise _lib.EvflowError("evf_bwd_defer_slot failed")
             _lib.call("evf_head_plif_bwd_wgrad", _lib.ptr(gz(0, s_)), _lib.ptr(gv0) if s_ else None, _lib.ptr(v_out), _lib.ptr(v_prev),
                       _lib.ptr(z_prev), _lib.ptr(tapes[s_]["x_in"]), _lib.ptr(self._flat["0.leak"]), _lib.ptr(self._flat["0.thresh"]), B, 2, H, W,
-                      1, SURROGATE_ID[c.activation], self._act_width(0), _lib.ptr(gv0), rowp("0.leak"), rowp("0.thresh"),
+                      1 | xf, SURROGATE_ID[c.activation], self._act_width(0), _lib.ptr(gv0), rowp("0.leak"), rowp("0.thresh"),
                       _lib.ptr(self._slabs[key]), (1 if win.slab_init.get(key) else 0) | (row_ld << 8), _lib.ptr(gpt0) if s_ else None,
                       _lib.ptr(pt_prev), _lib.ptr(P_sav), _lib.ptr(self._flat["0.leak_pt"]), _lib.ptr(self._flat["0.add_pt"]), _lib.ptr(gpt0),
                       rowp("0.leak_pt"), rowp("0.add_pt"))
@@ -847,7 +859,7 @@ class FireNetEngine:
         # PLIF: only the head layer's cells wait for the window's end (their chain is per pixel and reads one dL/d(spikes) buffer per
         # pass): a recording is open for them, the hidden cells' input gradients (pooling adjoint: not recordable) flush the rest
         # pass by pass, and evf_bwd_defer_flush runs the head's passes in ONE launch with the trace backward inside
-        plif_hw = (self.kind == "plif" and HEAD_WIN and PLIF_TRACE_FUSED and self.__dict__.get("_bdefer_on", False)
+        plif_hw = (self._plif and HEAD_WIN and PLIF_TRACE_FUSED and self.__dict__.get("_bdefer_on", False)
                    and self.precision == "bf16x3" and n > 1 and tape["x_in"].shape[1] == 2 and self.cells[0].hard_reset
                    and self.cells[0].activation == "arctanspike" and (top_fused or g_flow is None))
         if plif_hw:
@@ -864,7 +876,8 @@ class FireNetEngine:
         for i in range(n - 1, -1, -1):
             c = self.cells[i]
             in_bits, v_prev, z_prev, v_out, _, in_bitsT, zT_prev, pt_prev, pt_out, P_sav = layers[i]
-            plif = self.kind == "plif"
+            plif = self._plif
+            xf = 2 if self._xl else 0
             g_z = win.gz[i] if win.gz_has[i] else None
             g_z2 = win.gzr[i] if win.gzr_has[i] else None  # from the cell's own recurrent input gradient (pass t + 1)
             g_v = win.gv[i]
@@ -889,6 +902,9 @@ class FireNetEngine:
             # PLIF: the trace backward rides in the fused backward (default neuron, pooling adjoint inside the input-gradient kernels)
             trace_fused = (plif and PLIF_TRACE_FUSED and PLIF_BOX_IN_DGRAD and i > 0 and self.precision == "bf16x3"
                            and c.hard_reset and c.activation == "arctanspike")
+            if self._xl and ((i > 0 and not trace_fused) or (i == 0 and tape["x_in"].shape[1] != 2)):
+                raise _lib.EvflowError("fused XLIF cells need the trace backward inside the fused backward kernels (EVF_PLIF_TRACE_FUSED, "
+                                       "EVF_PLIF_BOX=dgrad, a two-channel input); EVF_XLIF_FUSED=0 serves the network on the general path")
             if trace_fused:
                 if win.gP is None:
                     win.gP = _f32((B, H, W), dev)
@@ -912,7 +928,7 @@ class FireNetEngine:
                               _lib.ptr(layers[i][4]), _lib.ptr(self._rowed(win, "pred.w")[0]), _lib.ptr(self._rowed(win, "pred.b")[0]),
                               _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(in_bitsT),
                               _lib.ptr(self._flat[f"{i}.leak"]), _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W,
-                              1 if c.hard_reset else 0, SURROGATE_ID[c.activation], self._act_width(i),
+                              (1 if c.hard_reset else 0) | (xf if trace_fused else 0), SURROGATE_ID[c.activation], self._act_width(i),
                               _lib.ptr(g_cur_i) if (plif or F32_DGRAD) else None, _lib.ptr(g_split_i), _lib.ptr(gv_out),
                               _lib.ptr(leak_r), _lib.ptr(thr_r), _lib.ptr(self._slab(kf, nsl, dev)), acc_flag | (row_ld << 8),
                               *(trace_args if trace_fused else ()))
@@ -920,7 +936,7 @@ class FireNetEngine:
                     _lib.call("evf_plif_bwd_wgrad2" if trace_fused else "evf_lif_bwd_wgrad2", _lib.ptr(g_z), _lib.ptr(g_z2), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev),
                           _lib.ptr(z_prev),
                           _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None, _lib.ptr(self._flat[f"{i}.leak"]),
-                          _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W, 1 if c.hard_reset else 0, SURROGATE_ID[c.activation],
+                          _lib.ptr(self._flat[f"{i}.thresh"]), B, H, W, (1 if c.hard_reset else 0) | (xf if trace_fused else 0), SURROGATE_ID[c.activation],
                           self._act_width(i), _lib.ptr(g_cur_i) if (plif or F32_DGRAD) else None, _lib.ptr(g_split_i),
                           _lib.ptr(gv_out),
                           _lib.ptr(leak_r), _lib.ptr(thr_r),
@@ -935,11 +951,11 @@ class FireNetEngine:
                 key = (0, "ff")
                 if key not in self._slabs or self._slabs[key].shape != (nsl, C * 18) or self._slabs[key].device != dev:
                     self._slabs[key] = _f32((nsl, C * 18), dev)
-                if plif_hw:  # ... and the trace backward in the same pass; recorded (see plif_hw above)
+                if plif_hw or self._xl:  # ... and the trace backward in the same pass; recorded (see plif_hw above; XLIF: always this form)
                     gpt_out = win.buf(win.gpt, 0)
                     _lib.call("evf_head_plif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev),
                               _lib.ptr(z_prev), _lib.ptr(tape["x_in"]), _lib.ptr(self._flat["0.leak"]),
-                              _lib.ptr(self._flat["0.thresh"]), B, 2, H, W, 1, SURROGATE_ID[c.activation], self._act_width(0),
+                              _lib.ptr(self._flat["0.thresh"]), B, 2, H, W, 1 | xf, SURROGATE_ID[c.activation], self._act_width(0),
                               _lib.ptr(gv_out), _lib.ptr(leak_r), _lib.ptr(thr_r), _lib.ptr(self._slabs[key]),
                               (1 if win.slab_init.get(key) else 0) | (row_ld << 8),
                               _lib.ptr(gpt_out if win.gpt_has[0] else None), _lib.ptr(pt_prev), _lib.ptr(P_sav),
