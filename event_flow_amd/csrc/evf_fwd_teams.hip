@@ -85,7 +85,9 @@ extern "C" int evf_debug_ft_stamps(void* dst) { return evf_hip(hipMemcpyFromSymb
 // writes the tape only: per pixel and pass 128 (+128 + 4 PLIF) bytes written and the 4-byte input words read, instead of the
 // potential (+ trace) read back as well.  Team M is the diagonal form's with the halo source and the pass advancing per round.
 // Same expressions in the same order: bit-identical to the cells launched one by one.
-template <bool HARD, bool FULL, bool PLIF, bool WIN, class JOBS, class WT>
+// XL (PLIF instantiations with the hard reset): XLIF cells -- a compile-time switch; as a run-time (cell-uniform) branch it cost the
+// PLIF chain kernel 3 % (the round holds both formulas' values live: 168 registers, spills).
+template <bool HARD, bool FULL, bool PLIF, bool WIN, class JOBS, class WT, bool XL = false>
 __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, const int B, const int H, const int W, const WT& wt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* s_lut = (uint4*)(smem + FT_OFF_LUT);
@@ -143,7 +145,7 @@ __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, co
       s_par2[tid] = evf_plif_sigmoid(J.leak_pt[tid]);
       // (XLIF cell: the slot holds max(t1, 0) -- self.t1.clamp_min(0), spiking_submodules.py:365/:810 -- and the cell's `xl` flag, a
       // block-uniform scalar, picks the formula: the two neuron models share every register)
-      s_par2[C32 + tid] = J.xl ? fmaxf(J.add_pt[tid], 0.f) : evf_plif_sigmoid(J.add_pt[tid]);
+      s_par2[C32 + tid] = XL ? fmaxf(J.add_pt[tid], 0.f) : evf_plif_sigmoid(J.add_pt[tid]);
     }
     if (J.pr.w) {
       if (tid < 2 * C32) s_pw[tid] = J.pr.w[tid];
@@ -168,7 +170,7 @@ __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, co
     float* __restrict__ pt_out = PLIF ? J.pt_out : nullptr;
     float* __restrict__ P_out = PLIF ? J.P_out : nullptr;
     const bool has_pred = J.pr.w != nullptr;
-    const bool xl = PLIF && J.xl != 0;  // (cell-uniform: an XLIF cell, see FwJob)
+    constexpr bool xl = PLIF && XL;  // (an XLIF cell, see FwJob: the launcher picks the instantiation by the cells' flag)
     const int nstrips = plan.nstrips;
 
     if (wv < 4) {
@@ -612,7 +614,7 @@ __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, co
               const f2 po01 = pp01 * lpt01 + olp01 * P2, po23 = pp23 * lpt23 + olp23 * P2;  // evf_plif_trace, :212 / :642
               const f2 a01 = {a4[k].x, a4[k].y}, a23 = {a4[k].z, a4[k].w};
               f2 c01, c23, t01 = {thL[0], thL[1]}, t23 = {thL[2], thL[3]};
-              if (xl) {  // (cell-uniform) XLIF: the current stays ff + rec, the trace raises the threshold: t0 + t1 * pt_out, :419 / :864
+              if constexpr (xl) {  // XLIF: the current stays ff + rec, the trace raises the threshold: t0 + t1 * pt_out, :419 / :864
                 c01 = a01, c23 = a23;
                 t01 = t01 + apt01 * po01, t23 = t23 + apt23 * po23;
               } else {
@@ -669,7 +671,7 @@ __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, co
                 po4[q] = 0.f;
                 if (PLIF) {
                   po4[q] = evf_plif_trace(p4[q], lptL[q], Pk[k]);  // :212 / :642
-                  if (xl) {  // (cell-uniform) XLIF: thresh = t0 + t1 * pt_out, :419 / :864; soft reset - z * (t0 + t1 * pt), :430 / :871
+                  if constexpr (xl) {  // XLIF: thresh = t0 + t1 * pt_out, :419 / :864; soft reset - z * (t0 + t1 * pt), :430 / :871
                     th_e = thL[q] + aptL[q] * po4[q];
                     th_p = thL[q] + aptL[q] * p4[q];
                   } else {
@@ -806,14 +808,14 @@ __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, co
   FT_STAMP();
 }
 
-template <bool HARD, bool FULL, bool PLIF>
+template <bool HARD, bool FULL, bool PLIF, bool XL = false>
 __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan plan, int B, int H, int W) {
-  ft_body<HARD, FULL, PLIF, false>(jobs, plan, B, H, W, FwWinNone{});
+  ft_body<HARD, FULL, PLIF, false, FwJobs, FwWinNone, XL>(jobs, plan, B, H, W, FwWinNone{});
 }
 
-template <bool HARD, bool FULL, bool PLIF>
+template <bool HARD, bool FULL, bool PLIF, bool XL = false>
 __global__ __launch_bounds__(FT_THREADS) void k_fwd_win_t(FwJob1 job, FwWinTab wt, FtPlan plan, int B, int H, int W) {
-  ft_body<HARD, FULL, PLIF, true>(job, plan, B, H, W, wt);
+  ft_body<HARD, FULL, PLIF, true, FwJob1, FwWinTab, XL>(job, plan, B, H, W, wt);
 }
 
 int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* stream) {
@@ -832,6 +834,8 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
     FT_ATTR(true, true, false), FT_ATTR(true, false, false), FT_ATTR(false, true, false), FT_ATTR(false, false, false);
     FT_ATTR(true, true, true), FT_ATTR(true, false, true), FT_ATTR(false, true, true), FT_ATTR(false, false, true);
 #undef FT_ATTR
+    (void)hipFuncSetAttribute((const void*)k_fwd_diag_t<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
+    (void)hipFuncSetAttribute((const void*)k_fwd_diag_t<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
     attr_set = true;
   }
   // relative cost of a round: feed-forward / recurrent cell / feed-forward cell with the prediction head in team E's epilogue (its
@@ -847,6 +851,8 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
   int nhard = 0, nplif = 0;
   for (int k = 0; k < n; ++k) nhard += jobs.j[k].hard_reset ? 1 : 0, nplif += jobs.j[k].leak_pt ? 1 : 0;
   if ((nhard != 0 && nhard != n) || (nplif != 0 && nplif != n)) return EVF_EINVAL;
+  for (int k = 0; k < n; ++k)  // XLIF cells: one kind per launch, hard reset (the caller then runs the cells one by one: evf_fwd_b3.hip)
+    if (jobs.j[k].xl != jobs.j[0].xl || (jobs.j[k].xl && !jobs.j[k].hard_reset)) return EVF_EINVAL;
   FtPlan plan;
   plan.njobs = n, plan.ntx = evf_cdiv(W, TW), plan.nyy = evf_cdiv(H, 2);
   const long nstrips = (long)plan.ntx * plan.nyy * B;
@@ -871,7 +877,9 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
   hipStream_t st = EVF_STREAM(stream);
 #define FT_GO(HARD_, FULL_)                                                                                                  \
   do {                                                                                                                       \
-    if (nplif)                                                                                                               \
+    if (nplif && jobs.j[0].xl)                                                                                               \
+      hipLaunchKernelGGL((k_fwd_diag_t<true, FULL_, true, true>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, jobs, plan, B, H, W); \
+    else if (nplif)                                                                                                          \
       hipLaunchKernelGGL((k_fwd_diag_t<HARD_, FULL_, true>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, jobs, plan, B, H, W);  \
     else                                                                                                                     \
       hipLaunchKernelGGL((k_fwd_diag_t<HARD_, FULL_, false>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, jobs, plan, B, H, W); \
@@ -888,6 +896,7 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
 int evf_fwd_win_is_chain(const FwJob* c, int n) {
   if (n < 2 || n > FW_WIN_MAX) return 0;
   if (c[0].wrec) return 0;
+  if (c[0].xl && !c[0].hard_reset) return 0;  // (XLIF cells with the soft reset: the one-cell kernel)
   for (int k = 1; k < n; ++k) {
     const FwJob &a = c[k - 1], &b = c[k];
     if (b.wrec || b.wff != a.wff || b.leak != a.leak || b.thresh != a.thresh || b.hard_reset != a.hard_reset ||
@@ -916,6 +925,8 @@ int evf_fwd_win_t_launch(const FwJob* cells, int n, int B, int H, int W, void* s
     FT_ATTR(true, true, false), FT_ATTR(true, false, false), FT_ATTR(false, true, false), FT_ATTR(false, false, false);
     FT_ATTR(true, true, true), FT_ATTR(true, false, true), FT_ATTR(false, true, true), FT_ATTR(false, false, true);
 #undef FT_ATTR
+    (void)hipFuncSetAttribute((const void*)k_fwd_win_t<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
+    (void)hipFuncSetAttribute((const void*)k_fwd_win_t<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
     attr_set = true;
   }
   FwJob1 job;
@@ -946,7 +957,9 @@ int evf_fwd_win_t_launch(const FwJob* cells, int n, int B, int H, int W, void* s
   hipStream_t st = EVF_STREAM(stream);
 #define FT_GO(HARD_, FULL_)                                                                                                     \
   do {                                                                                                                          \
-    if (plif)                                                                                                                   \
+    if (plif && cells[0].xl)                                                                                                    \
+      hipLaunchKernelGGL((k_fwd_win_t<true, FULL_, true, true>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, job, wt, plan, B, H, W); \
+    else if (plif)                                                                                                              \
       hipLaunchKernelGGL((k_fwd_win_t<HARD_, FULL_, true>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, job, wt, plan, B, H, W);   \
     else                                                                                                                        \
       hipLaunchKernelGGL((k_fwd_win_t<HARD_, FULL_, false>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, job, wt, plan, B, H, W);  \

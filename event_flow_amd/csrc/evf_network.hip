@@ -1148,7 +1148,10 @@ struct HeadBwdKeep {
 struct HeadBwdKeepPlif {
   float slp[4], sap[4], lpt[4], apt[4];
 };
-template <bool FAST, int NT = 0, bool FIRST = true, bool PLIF = false>
+// XL (PLIF bodies only): an XLIF head -- add_pt = t1, thresh = t0; the trace raised the THRESHOLD (t0 + t1 * pt',
+// spiking_submodules.py:419), so it takes -t1 * dL/d(thresh) instead of -sigma(add_pt) * dL/d(current).  A template parameter: with
+// a run-time flag the PLIF window kernel kept eight more values live across the element loop and spilled (401 -> 628 us per window)
+template <bool FAST, int NT = 0, bool FIRST = true, bool PLIF = false, bool XL = false>
 __device__ __forceinline__ void head_bwd_pass(
     const float4* g_z_out, const float4* g_v_out, const float4* v_out, const float4* v_prev, const uint32_t* z_prev,
     const float* __restrict__ leak, const float* __restrict__ thresh, long npix, int hard_reset_rt, int surrogate_rt, float width,
@@ -1157,9 +1160,7 @@ __device__ __forceinline__ void head_bwd_pass(
     HeadBwdKeep& K, bool store_gv,  // store_gv: the launch's last pass (NT = 0: every pass is first and last)
     const HeadPlifPass pq = HeadPlifPass{}, const HeadPlifPrm pm = HeadPlifPrm{}, float4* gpc_ = nullptr, HeadBwdKeepPlif* KP_ = nullptr) {
   const int hard_reset = FAST ? 1 : (hard_reset_rt & 1), surrogate = FAST ? EVF_ARCTAN : surrogate_rt;
-  // XLIF head (bit 1 of the flag, evf_head_plif_bwd_wgrad): add_pt = t1, thresh = t0; the trace raised the THRESHOLD (t0 + t1 * pt',
-  // spiking_submodules.py:419), so it takes -t1 * dL/d(thresh) instead of -sigma(add_pt) * dL/d(current)
-  const bool xl = PLIF && (hard_reset_rt & 2) != 0;
+  constexpr bool xl = PLIF && XL;
   float4 gpc_none[1];
   HeadBwdKeepPlif kp_none;
   float4* gpc = PLIF ? gpc_ : gpc_none;          // [NT] the carried dL/d(pt') of the block's trips
@@ -1286,8 +1287,8 @@ __device__ __forceinline__ void head_bwd_pass(
     const uint32_t zw = z_prev ? (zwl >> (4 * cg)) : 0u;
     const float vo[4] = {vo4.x, vo4.y, vo4.z, vo4.w}, gz[4] = {gz4.x, gz4.y, gz4.z, gz4.w};
     const float gvo[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, vp[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
-    float gc[4], gp[4], gsv[4], pov[4] = {0.f, 0.f, 0.f, 0.f};
-    if (PLIF) {  // pt' of the forward pass, recomputed (XLIF: it is part of the threshold)
+    float gc[4], gp[4], gsv[xl ? 4 : 1], pov[xl ? 4 : 1];
+    if constexpr (xl) {  // pt' of the forward pass, recomputed: it is part of the threshold
       const float4 pp4 = pq.pt_prev ? in.ppl : zero4;
       const float pp[4] = {pp4.x, pp4.y, pp4.z, pp4.w};
 #pragma unroll
@@ -1296,9 +1297,11 @@ __device__ __forceinline__ void head_bwd_pass(
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float z = (float)((zw >> k) & 1u);
-      const float sg = evf_surrogate(surrogate, vo[k] - ((PLIF && xl) ? th[k] + KP.apt[k] * pov[k] : th[k]), width);
+      float the = th[k];
+      if constexpr (xl) the = th[k] + KP.apt[k] * pov[k];
+      const float sg = evf_surrogate(surrogate, vo[k] - the, width);
       const float gsp = gz[k] * sg;
-      gsv[k] = gsp;
+      if constexpr (xl) gsv[k] = gsp;
       const float gv = gvo[k] + gsp;
       gc[k] = gv * oml[k];
       float cur, dlam, dth = 0.f;
@@ -1329,8 +1332,9 @@ __device__ __forceinline__ void head_bwd_pass(
       float gq[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float po = pov[k];
-        const float gx = xl ? gsv[k] : gc[k];  // what the trace scaled in the forward pass: the threshold's / the current's gradient (negated)
+        float po, gx;  // pt'; what the trace scaled in the forward pass: the threshold's / the current's gradient (negated)
+        if constexpr (xl) po = pov[k], gx = gsv[k];
+        else po = evf_plif_trace(pp[k], KP.lpt[k], Pv), gx = gc[k];
         const float g = gk[k] - KP.apt[k] * gx;
         gq[k] = g * KP.lpt[k];
         if (ok) {
@@ -1464,17 +1468,18 @@ __global__ __launch_bounds__(256) void k_head_bwd_mfma(
 }
 
 // PLIF head, one pass: the same with the trace backward inside (default neuron)
+template <bool XL>
 __global__ __launch_bounds__(256) void k_head_plif_bwd_mfma(
     const float4* __restrict__ g_z_out, const float4* __restrict__ g_v_out, const float4* __restrict__ v_out,
     const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev, const float* __restrict__ leak,
     const float* __restrict__ thresh, long npix, float width, float4* __restrict__ g_v_prev, float* __restrict__ g_leak,
     float* __restrict__ g_thresh, const float* __restrict__ x_in, int Cin, int H, int W, float* __restrict__ slab, int slab_acc,
-    int row_ld, HeadPlifPass pq, HeadPlifPrm pm, int xl) {  // xl: an XLIF head (bit 1 of the entry point's reset flag)
+    int row_ld, HeadPlifPass pq, HeadPlifPrm pm) {
   float4 none[1], gpc[1];
   int nox[1][4];
   HeadBwdKeep keep;
   HeadBwdKeepPlif kp;
-  head_bwd_pass<true, 0, true, true>(g_z_out, g_v_out, v_out, v_prev, z_prev, leak, thresh, npix, 1 | (xl ? 2 : 0), EVF_ARCTAN, width, nullptr, g_v_prev,
+  head_bwd_pass<true, 0, true, true, XL>(g_z_out, g_v_out, v_out, v_prev, z_prev, leak, thresh, npix, 1, EVF_ARCTAN, width, nullptr, g_v_prev,
                                      g_leak, g_thresh, x_in, Cin, H, W, slab, slab_acc, row_ld, none, none, nox, keep, true, pq, pm, gpc, &kp);
 }
 
@@ -1498,7 +1503,7 @@ struct HeadBwdWin {
   float width;
 };
 #define HEADBWD_NT 4  // trips of a block whose carried values fit registers (8 x 128 x 128 on 1024 blocks: 4)
-template <bool FAST, int NT, bool PLIF = false>
+template <bool FAST, int NT, bool PLIF = false, bool XL = false>
 __global__ __launch_bounds__(HEADBWD_LB) void k_head_bwd_win(HeadBwdWin a) {
   float4 gvc[NT ? NT : 1], voc[NT ? NT : 1], gpc[NT ? NT : 1];
   int xo[NT ? NT : 1][4];
@@ -1507,7 +1512,7 @@ __global__ __launch_bounds__(HEADBWD_LB) void k_head_bwd_win(HeadBwdWin a) {
   const int acc0 = a.p[0].slab_acc;  // (NT > 0: the sums of all passes are added to the slab once, by the first pass's rule)
   {
     const HeadBwdPass& q = a.p[0];
-    head_bwd_pass<FAST, NT, true, PLIF>(q.g_z_out, q.g_v_out, q.v_out, q.v_prev, q.z_prev, a.leak, a.thresh, a.npix, a.hard_reset,
+    head_bwd_pass<FAST, NT, true, PLIF, XL>(q.g_z_out, q.g_v_out, q.v_out, q.v_prev, q.z_prev, a.leak, a.thresh, a.npix, a.hard_reset,
                                         a.surrogate, a.width, nullptr, q.g_v_prev, a.g_leak, a.g_thresh, q.x_in, a.Cin, a.H, a.W, a.slab,
                                         NT > 0 ? acc0 : q.slab_acc, a.row_ld, gvc, voc, xo, keep, a.np == 1,
                                         HeadPlifPass{q.g_pt_out, q.pt_prev, q.P, q.g_pt_prev}, a.pm, gpc, &kp);
@@ -1515,7 +1520,7 @@ __global__ __launch_bounds__(HEADBWD_LB) void k_head_bwd_win(HeadBwdWin a) {
   for (int t = 1; t < a.np; ++t) {
     __syncthreads();  // (the pass's last reads of the reduction arrays before the next pass rewrites them)
     const HeadBwdPass& q = a.p[t];
-    head_bwd_pass<FAST, NT, false, PLIF>(q.g_z_out, q.g_v_out, q.v_out, q.v_prev, q.z_prev, a.leak, a.thresh, a.npix, a.hard_reset,
+    head_bwd_pass<FAST, NT, false, PLIF, XL>(q.g_z_out, q.g_v_out, q.v_out, q.v_prev, q.z_prev, a.leak, a.thresh, a.npix, a.hard_reset,
                                          a.surrogate, a.width, nullptr, q.g_v_prev, a.g_leak, a.g_thresh, q.x_in, a.Cin, a.H, a.W, a.slab,
                                          NT > 0 ? acc0 : q.slab_acc, a.row_ld, gvc, voc, xo, keep, t == a.np - 1,
                                          HeadPlifPass{q.g_pt_out, q.pt_prev, q.P, q.g_pt_prev}, a.pm, gpc, &kp);
@@ -1566,11 +1571,15 @@ static int head_bwd_go(const HdArgs& a, void* stream) {
   const int row_ld = a.accumulate >> 8;  // pitch of the per-block parameter-gradient rows (0: dense outputs, atomics)
   const int accumulate = a.accumulate & 1;
   if (a.P) {
-    hipLaunchKernelGGL(k_head_plif_bwd_mfma, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)a.g_z_out,
-                       (const float4*)a.g_v_out, (const float4*)a.v_out, (const float4*)a.v_prev, a.z_prev, a.leak, a.thresh, npix,
-                       a.act_width, (float4*)a.g_v_prev, a.g_leak, a.g_thresh, a.x_in, a.Cin, a.H, a.W, a.slab, accumulate, row_ld,
-                       HeadPlifPass{(const float4*)a.g_pt_out, (const float4*)a.pt_prev, a.P, (float4*)a.g_pt_prev},
-                       HeadPlifPrm{a.leak_pt, a.add_pt, a.g_leak_pt, a.g_add_pt}, (a.hard_reset >> 1) & 1);
+#define HEAD_PLIF_BWD(XL_)                                                                                                       \
+  hipLaunchKernelGGL(k_head_plif_bwd_mfma<XL_>, dim3(nblk), dim3(256), 0, EVF_STREAM(stream), (const float4*)a.g_z_out,           \
+                     (const float4*)a.g_v_out, (const float4*)a.v_out, (const float4*)a.v_prev, a.z_prev, a.leak, a.thresh, npix, \
+                     a.act_width, (float4*)a.g_v_prev, a.g_leak, a.g_thresh, a.x_in, a.Cin, a.H, a.W, a.slab, accumulate, row_ld,  \
+                     HeadPlifPass{(const float4*)a.g_pt_out, (const float4*)a.pt_prev, a.P, (float4*)a.g_pt_prev},               \
+                     HeadPlifPrm{a.leak_pt, a.add_pt, a.g_leak_pt, a.g_add_pt})
+    if (a.hard_reset & 2) HEAD_PLIF_BWD(true);  // (bit 1: an XLIF head)
+    else HEAD_PLIF_BWD(false);
+#undef HEAD_PLIF_BWD
     return evf_status();
   }
 #define HEAD_BWD(FAST_)                                                                                                    \
@@ -1672,10 +1681,14 @@ int evf_hd_defer_launch_window(int ctx, void* stream) {
       }();
 #define HEAD_BWD_WIN(FAST_, NT_) hipLaunchKernelGGL((k_head_bwd_win<FAST_, NT_>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a)
       if (f.P) {  // PLIF (default neuron only: evf_head_plif_bwd_wgrad): three trips' carried values fit the registers
-        if (carry && trips <= 3 && (long)f.B * f.Cin * f.H * f.W < (1L << 31))
-          hipLaunchKernelGGL((k_head_bwd_win<true, 3, true>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a);
-        else
-          hipLaunchKernelGGL((k_head_bwd_win<true, 0, true>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a);
+        const bool win3 = carry && trips <= 3 && (long)f.B * f.Cin * f.H * f.W < (1L << 31);
+        if (f.hard_reset & 2) {  // (bit 1: an XLIF head)
+          if (win3) hipLaunchKernelGGL((k_head_bwd_win<true, 3, true, true>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a);
+          else hipLaunchKernelGGL((k_head_bwd_win<true, 0, true, true>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a);
+        } else {
+          if (win3) hipLaunchKernelGGL((k_head_bwd_win<true, 3, true>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a);
+          else hipLaunchKernelGGL((k_head_bwd_win<true, 0, true>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a);
+        }
       } else if (carry && fast && trips <= HEADBWD_NT && (long)f.B * f.Cin * f.H * f.W < (1L << 31)) {  // (other surrogates: 253 VGPRs)
         HEAD_BWD_WIN(true, HEADBWD_NT);
       } else {

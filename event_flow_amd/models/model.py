@@ -126,7 +126,10 @@ class FireNet(BaseModel):
         if any(getattr(c, "kind", None) not in ("lif", "plif", "xlif") for c in cells):
             why.append("cell kind(s) " + ", ".join(sorted(str(k) for k in kinds)))
         elif any(c.kind == "xlif" and not _xlif_fused_ok(c) for c in cells):
-            why.append("XLIF cells with the soft reset or another surrogate than arctanspike (the fused XLIF kernels: hard reset, arctan)")
+            import os
+
+            why.append("EVF_XLIF_FUSED=0" if os.environ.get("EVF_XLIF_FUSED", "1") == "0" else
+                       "XLIF cells with the soft reset or another surrogate than arctanspike (the fused XLIF kernels: hard reset, arctan)")
         elif len(kinds) > 1:
             why.append("mixed cell kinds")
         if any(getattr(c, "wnorm", False) or getattr(c, "gnorm", False) for c in cells):

@@ -379,7 +379,16 @@ int evf_conv_dgrad_b3_f32_pair(const float* g_cur, const void* wT_b3, float* g_x
  * and x_bits are given -- or when g_P = g_P_raw with bit 1 of `accumulate` set (`accumulate | 2`): the input-gradient kernel
  * then applies AvgPool3x3^T / 32 itself (the same sums in the same order), and evf_plif_trace_bwd may be called with
  * g_P_in = NULL (one launch less per cell).  evf_plif_trace_bwd's `pt_out` is not read (may be NULL): pt' is recomputed from
- * pt_prev and P with the forward kernels' own expression (evf_plif_trace, csrc/evf_common.h: the same bits). */
+ * pt_prev and P with the forward kernels' own expression (evf_plif_trace, csrc/evf_common.h: the same bits).
+ *
+ * XLIF cells (models/spiking_submodules.py:337-435, :771-875) ride on these entry points: the SAME pre-synaptic trace, which
+ * raises the threshold -- thresh = t0.clamp_min(0.01) + t1.clamp_min(0) * pt' -- instead of being subtracted from the current
+ * (current = ff (+rec)).  Bit 1 of `hard_reset` (evf_conv_plif_fwd_b3[_pred], evf_head_plif_fwd, evf_plif_bwd_wgrad2 / _top,
+ * evf_head_plif_bwd_wgrad: pass `hard_reset | 2`) or of `accumulate` (evf_plif_bwd_wgrad_window[_top]: `accumulate | 2`) selects
+ * them; `thresh` / `g_thresh` then carry t0 and its gradient, `add_pt` / `g_add_pt` carry t1 and its gradient (no sigmoid:
+ * the clamp's sub-gradient).  Backward forms: hard reset + arctan surrogate only, like the PLIF ones; the forward also takes
+ * the soft reset (v' -= z * (t0 + t1 * pt)) cell by cell, except for the head (EVF_ENOTSUP).  evf_plif_trace_bwd has no XLIF
+ * form (the trace backward of an XLIF cell lives in the fused backward kernels). */
 int evf_conv_plif_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec,
                          const float* leak_v, const float* leak_pt, const float* add_pt, const float* thresh,
                          const float* v_prev, const uint32_t* z_prev, const float* pt_prev,
