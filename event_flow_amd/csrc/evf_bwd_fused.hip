@@ -108,8 +108,12 @@ struct FbPlif {
   float4* g_pt_prev;        // [B,H,W,32] -> carry of pass t - 1 (may alias gpt_carry: same thread reads, then writes)
   float* g_P;               // [B,H,W] dL/d(pooled activity), raw (the input-gradient kernel applies the pooling's adjoint)
   float *g_leak_pt, *g_add_pt;  // per-block rows (row_ld) or dense (atomics)
-  int xl;  // an XLIF cell (spiking_submodules.py:337-435, :771-875; entry points: bit 1 of `hard_reset` / of `accumulate`): add_pt = t1,
-           // thresh = t0, threshold t0 + t1 * pt' -- the trace takes -t1 * dL/d(thresh) instead of -sigma(add_pt) * dL/d(current)
+  int xl;  // 1: an XLIF cell (spiking_submodules.py:337-435, :771-875; entry points: bits 1-2 of `hard_reset` / of `accumulate`): add_pt =
+           // t1, thresh = t0, threshold t0 + t1 * pt' -- the trace takes -t1 * dL/d(thresh) instead of -sigma(add_pt) * dL/d(current).
+           // 2: an ALIF cell (:230-334, :660-768): the same, with the trace (leak_pt = leak_t) driven by the cell's OWN previous spikes z
+           // (un-detached, :311): no pooled activity, and (1 - sigma(leak_t)) * dL/d(t') flows into dL/d(spikes) of the pass BEFORE --
+           // a window launch carries it in registers, a one-pass launch writes it to g_zx (the caller hands it back as g_z_out2)
+  float4* g_zx;  // ALIF, one-pass launches: [B,H,W,32] out (may alias g_z_out2: the same thread reads, then writes)
 };
 
 // TOP: the (non-recurrent) layer under the 1x1 tanh prediction head (models/model.py:197-199, :265).  The head's
@@ -592,7 +596,8 @@ struct FbWin {
   const float* g_flow[FB_WIN_MAX];   // [B,2,H,W]
   const uint32_t* z_out[FB_WIN_MAX]; // [B,H,W] the layer's own output spikes
 };
-template <bool REC, bool TOP, int EW, bool PLIF = false, bool WIN = false>
+// AL (PLIF instantiations): ALIF cells, see FbPlif::xl -- a template parameter, so that the PLIF / XLIF kernels keep their registers
+template <bool REC, bool TOP, int EW, bool PLIF = false, bool WIN = false, bool AL = false>
 __device__ __forceinline__ void fb_body_ws(
     const int bid, const int nblk_, const float4* __restrict__ g_z_out, const float4* __restrict__ g_z_out2,
     const float4* __restrict__ g_v_out, const float4* __restrict__ v_out, const float4* __restrict__ v_prev,
@@ -602,6 +607,8 @@ __device__ __forceinline__ void fb_body_ws(
     float* __restrict__ g_leak, float* __restrict__ g_thresh, float* __restrict__ slab_ff, float* __restrict__ slab_rec, FbTop top,
     int row_ld, const FbPlif pl = FbPlif{}, const FbWin* wp = nullptr) {
   static_assert(!PLIF || EW == 8, "PLIF cells: whole-unit stages only");
+  static_assert(!AL || PLIF, "ALIF cells run the PLIF body");
+  static_assert(!(AL && TOP && !WIN), "ALIF under the prediction head: window launches only (one pass: evf_pred_bwd + the plain cell)");
   static_assert(!WIN || (!REC && EW == 8), "window launches: feed-forward cells");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   unsigned short* s_b = (unsigned short*)smem_raw;           // [2][3][FB_CW*32] bf16 (region of FB_R0 bytes)
@@ -673,6 +680,7 @@ __device__ __forceinline__ void fb_body_ws(
   float sl[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
   float slp[4] = {0, 0, 0, 0}, sap[4] = {0, 0, 0, 0};  // PLIF: sums for leak_pt / add_pt
   float4 gvc = make_float4(0.f, 0.f, 0.f, 0.f), voc = gvc, gkc = gvc;  // WIN: dL/dv, potential, dL/d(pt) carried to the next iteration
+  float4 gzxc = gvc;  // WIN, ALIF: (1 - sigma(leak_t)) * dL/d(t') of this pass = part of dL/d(spikes) of the pass before
   float dwa[4] = {0, 0, 0, 0}, dwb[4] = {0, 0, 0, 0}, dba = 0.f, dbb = 0.f;
   // team M state: taps t0 = 2 mw, t1 = 2 mw + 1, the ninth tap's K step mw
   f32x16 acc0 = {0}, acc1 = {0}, accz0 = {0}, accz1 = {0}, acc8 = {0}, accz8 = {0};
@@ -813,6 +821,7 @@ __device__ __forceinline__ void fb_body_ws(
                              : ((WIN ? w_gz : has_gz) ? s.gz : z4);
       float4 gzb4 = z4;
       if (!TOP && !WIN) gzb4 = has_gz2 ? s.gz2 : z4;
+      if (AL && WIN) gzb4 = ks > 0 ? gzxc : z4;
       const float4 gv4 = WIN ? (ks > 0 ? gvc : z4) : (has_gv ? s.gv : z4), vp4 = (WIN ? w_vp : has_vp) ? s.vp : z4;
       if (TOP && ok) {
         const uint32_t zo = s.zo >> (4 * cg);
@@ -826,8 +835,9 @@ __device__ __forceinline__ void fb_body_ws(
       }
       const float4 vo4 = (WIN && ks > 0) ? voc : s.vo;
       const float vo[4] = {vo4.x, vo4.y, vo4.z, vo4.w};
-      const float gz[4] = {!TOP ? gz4.x + gzb4.x : gz4.x, !TOP ? gz4.y + gzb4.y : gz4.y, !TOP ? gz4.z + gzb4.z : gz4.z,
-                           !TOP ? gz4.w + gzb4.w : gz4.w};
+      constexpr bool two = !TOP || (AL && WIN);  // dL/d(spikes) has a second part
+      const float gz[4] = {two ? gz4.x + gzb4.x : gz4.x, two ? gz4.y + gzb4.y : gz4.y, two ? gz4.z + gzb4.z : gz4.z,
+                           two ? gz4.w + gzb4.w : gz4.w};
       const float gvo[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, vp[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
       const uint32_t zw = ((WIN ? w_zp : has_zw) ? s.zw : 0u) >> (4 * cg);
       float gc[4], gp[4], gsv[4], pov[4] = {0.f, 0.f, 0.f, 0.f};
@@ -836,7 +846,7 @@ __device__ __forceinline__ void fb_body_ws(
         const float4 pp4 = (WIN ? w_pp : has_pp) ? sp.pp : z4;
         const float pp[4] = {pp4.x, pp4.y, pp4.z, pp4.w};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) pov[c] = evf_plif_trace(pp[c], lpt[c], sp.P);
+        for (int c = 0; c < 4; ++c) pov[c] = evf_plif_trace(pp[c], lpt[c], AL ? (float)((zw >> c) & 1u) : sp.P);  // (ALIF: t * leak_t + (1 - leak_t) * z, :311)
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {  // autograd of spiking_submodules.py:103-126 / :523-551 (hard reset, arctan surrogate)
@@ -870,25 +880,30 @@ __device__ __forceinline__ void fb_body_ws(
         const float4 gk4 = WIN ? (ks > 0 ? gkc : z4) : (has_gk ? sp.gk : z4), pp4 = (WIN ? w_pp : has_pp) ? sp.pp : z4;
         const float gk[4] = {gk4.x, gk4.y, gk4.z, gk4.w}, pp[4] = {pp4.x, pp4.y, pp4.z, pp4.w};
         const float Pv = sp.P;
-        float gq[4], gPp = 0.f;
+        float gq[4], gPp = 0.f, gzx[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const float po = pov[c];                // pt' of the forward pass, recomputed
           const float gx = xl ? gsv[c] : gc[c];  // what the trace scaled in the forward pass: the threshold's / the current's gradient (negated)
           const float g = gk[c] - apt[c] * gx;
           gq[c] = g * lpt[c];
-          gPp += g * (1.0f - lpt[c]);
+          gzx[c] = g * (1.0f - lpt[c]);
+          gPp += gzx[c];
           if (ok) {
-            slp[c] += g * (pp[c] - Pv);
+            slp[c] += g * (pp[c] - (AL ? (float)((zw >> c) & 1u) : Pv));
             sap[c] -= gx * po;
           }
+        }
+        if constexpr (AL) {  // the trace's drive was the cell's own previous spikes: their gradient, to the pass before
+          if (WIN) gzxc = make_float4(gzx[0], gzx[1], gzx[2], gzx[3]);
+          else if (ok && pl.g_zx) pl.g_zx[eo] = make_float4(gzx[0], gzx[1], gzx[2], gzx[3]);
         }
         if (WIN) gkc = make_float4(gq[0], gq[1], gq[2], gq[3]);
         if (ok && (!WIN || (ks == T - 1 && pl.g_pt_prev))) pl.g_pt_prev[eo] = make_float4(gq[0], gq[1], gq[2], gq[3]);
         gPp += __shfl_xor(gPp, 1, 64);  // the 8 lanes of a pixel hold its 32 channels
         gPp += __shfl_xor(gPp, 2, 64);
         gPp += __shfl_xor(gPp, 4, 64);
-        if (ok && cg == 0) (WIN ? w_gP : pl.g_P)[pix0 + p] = gPp;
+        if (!AL && ok && cg == 0) (WIN ? w_gP : pl.g_P)[pix0 + p] = gPp;  // (ALIF: no pooled activity)
       }
       // exact split g = hi + mid + lo in B-operand order: 16-byte chunk (pixel group G = p >> 3, channel j) = the 8 pixels of
       // the group, chunk index G * 32 + (j ^ (j >> 4)).  A lane holds 4 channels of ONE pixel; as 12 two-byte stores a wave
@@ -1398,6 +1413,34 @@ __global__ __launch_bounds__(768) void k_bwd_diag_ws_plif(FbJobs jobs, int B, in
                                       J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld, J.pl);
 }
 
+// ALIF cells (FbPlif::xl == 2): the same three launches with the trace driven by the cell's own previous spikes (fb_body_ws<.., AL>)
+__global__ __launch_bounds__(768) void k_bwd_diag_ws_alif(FbJobs jobs, int B, int H, int W, int nchunk, long nunits, int row_ld,
+                                                          int nrows_total) {
+  const int jb = fb_job_of_block(jobs, (int)blockIdx.x);
+  const FbJob& J = jobs.j[jb];
+  const int bid = (int)blockIdx.x - J.blk0, nblk = J.nblk;
+  if (J.kind == 4)
+    fb_body_ws<true, false, 8, true, false, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh,
+                                                  B, H, W, nchunk, nunits, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev,
+                                                  J.g_leak, J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld, J.pl);
+  else
+    fb_body_ws<false, false, 8, true, false, true>(bid, nblk, J.g_z, J.g_z2, J.g_v, J.v_out, J.v_prev, J.z_prev, J.xT, J.zT, J.leak, J.thresh,
+                                                   B, H, W, nchunk, nunits, J.width, J.accumulate, nrows_total, J.g_cur, J.g_split, J.g_v_prev,
+                                                   J.g_leak, J.g_thresh, J.slab_ff, J.slab_rec, J.top, row_ld, J.pl);
+}
+__global__ __launch_bounds__(768) void k_bwd_win_alif(FbJob J, FbWin Wn, int B, int H, int W, int nchunk, long nunits, int row_ld,
+                                                      int nrows_total) {
+  fb_body_ws<false, false, 8, true, true, true>((int)blockIdx.x, (int)gridDim.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                nullptr, J.leak, J.thresh, B, H, W, nchunk, nunits, J.width, J.accumulate, nrows_total, nullptr,
+                                                nullptr, J.g_v_prev, J.g_leak, J.g_thresh, J.slab_ff, nullptr, J.top, row_ld, J.pl, &Wn);
+}
+__global__ __launch_bounds__(768) void k_bwd_win_alif_top(FbJob J, FbWin Wn, int B, int H, int W, int nchunk, long nunits, int row_ld,
+                                                          int nrows_total) {
+  fb_body_ws<false, true, 8, true, true, true>((int)blockIdx.x, (int)gridDim.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                               nullptr, J.leak, J.thresh, B, H, W, nchunk, nunits, J.width, J.accumulate, nrows_total, nullptr,
+                                               nullptr, J.g_v_prev, J.g_leak, J.g_thresh, J.slab_ff, nullptr, J.top, row_ld, J.pl, &Wn);
+}
+
 // All passes of a window of ONE feed-forward PLIF cell (fb_body_ws<.., WIN>): a launch of its own
 __global__ __launch_bounds__(768) void k_bwd_win_plif(FbJob J, FbWin Wn, int B, int H, int W, int nchunk, long nunits, int row_ld,
                                                       int nrows_total) {
@@ -1676,6 +1719,7 @@ static int fb_defer_launch(FbDefer& fb_defer, int d, void* stream) {
     (void)hipFuncSetAttribute((const void*)k_bwd_diag_ws<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
     (void)hipFuncSetAttribute((const void*)k_bwd_diag_ws<8>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
     (void)hipFuncSetAttribute((const void*)k_bwd_diag_ws_plif, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    (void)hipFuncSetAttribute((const void*)k_bwd_diag_ws_alif, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
     attr_set = true;
   }
   // EVF_BWD_DIAG=fused: every wave through all phases (k_bwd_diag); teams4: 4 + 4 waves; default (teams): 8 + 4 waves
@@ -1694,7 +1738,10 @@ static int fb_defer_launch(FbDefer& fb_defer, int d, void* stream) {
   const int nblk = fb_blocks_per_cell(nunits, n, cost_env > 0 ? cost_env : (teams == 2 ? 8 : 11));  // (k_bwd_diag_ws<8>: ~4.0 k cycles per unit, phase stamps)
   const int ntot = fb_split_blocks(jobs, n, nblk, nunits, teams == 2);
   evf_prof_mark(1, 0, stream);
-  if (plif)
+  if (plif && jobs.j[0].pl.xl == 2)
+    hipLaunchKernelGGL(k_bwd_diag_ws_alif, dim3(ntot), dim3(768), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
+                       fb_defer.W, nchunk, nunits, fb_defer.row_ld, nrows);
+  else if (plif)
     hipLaunchKernelGGL(k_bwd_diag_ws_plif, dim3(ntot), dim3(768), FB_LDS, EVF_STREAM(stream), jobs, fb_defer.B, fb_defer.H,
                        fb_defer.W, nchunk, nunits, fb_defer.row_ld, nrows);
   else if (teams == 2)
@@ -1777,6 +1824,7 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
                      float* g_cur, void* g_split, float* g_v_prev, float* g_leak, float* g_thresh, float* slab_ff,
                      float* slab_rec, int accumulate, void* stream, const FbPlif* plp = nullptr) {
   if (plp && !(hard_reset != 0 && surrogate == EVF_ARCTAN)) return EVF_ENOTSUP;  // (the trace backward lives in the two-team body)
+  if (plp && plp->xl == 2 && topp) return EVF_ENOTSUP;  // (an ALIF cell under the prediction head, one pass: evf_pred_bwd + evf_plif_bwd_wgrad2)
   if (!v_out || !xT || !leak || !thresh || (!g_cur && !g_split) || !g_v_prev || !g_leak || !g_thresh || !slab_ff || B <= 0 || H <= 0 ||
       W <= 0 || ((zT_prev != nullptr) != (slab_rec != nullptr)) || (topp && (g_z_out || zT_prev)) || (topp && g_z_out2))
     return EVF_EINVAL;
@@ -1798,7 +1846,8 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
     for (int d = 0; d < EVF_BWD_DIAGS && !any; ++d) any = fb_defer.n[d] != 0;
     bool same = !any || (fb_defer.B == B && fb_defer.H == H && fb_defer.W == W && fb_defer.row_ld == row_ld);
     for (int d = 0; d < EVF_BWD_DIAGS && same; ++d)
-      if (fb_defer.n[d]) same = (fb_defer.job[d][0].kind >= 3) == (plp != nullptr);  // one neuron model per recording
+      if (fb_defer.n[d])  // one neuron model per recording
+        same = (fb_defer.job[d][0].kind >= 3) == (plp != nullptr) && (!plp || fb_defer.job[d][0].pl.xl == plp->xl);
     if (fast && (g_cur || g_split) && same && fb_defer.n[evf_bwd_defer.slot] < FB_MAX_JOBS) {
       fb_defer.B = B, fb_defer.H = H, fb_defer.W = W, fb_defer.row_ld = row_ld;
       FbJob& J = fb_defer.job[evf_bwd_defer.slot][fb_defer.n[evf_bwd_defer.slot]++];
@@ -1822,6 +1871,7 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
     if (!attr_ws) {
       (void)hipFuncSetAttribute((const void*)k_bwd_diag_ws<8>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
       (void)hipFuncSetAttribute((const void*)k_bwd_diag_ws_plif, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+      (void)hipFuncSetAttribute((const void*)k_bwd_diag_ws_alif, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
       attr_ws = true;
     }
     FbJobs jobs;
@@ -1831,7 +1881,9 @@ static int fb_launch(const float* g_z_out, const float* g_z_out2, const FbTop* t
                   plp ? *plp : FbPlif{}};
     const int nblk = fb_blocks_per_cell(nunits, 1, 8);
     for (int k = 0; k < FB_MAX_JOBS; ++k) jobs.j[k] = J, jobs.j[k].blk0 = k ? 0x7fffffff : 0, jobs.j[k].nblk = nblk;
-    if (plp)
+    if (plp && plp->xl == 2)
+      hipLaunchKernelGGL(k_bwd_diag_ws_alif, dim3(nblk), dim3(768), FB_LDS, st, jobs, B, H, W, nchunk, nunits, row_ld, nrows_all);
+    else if (plp)
       hipLaunchKernelGGL(k_bwd_diag_ws_plif, dim3(nblk), dim3(768), FB_LDS, st, jobs, B, H, W, nchunk, nunits, row_ld, nrows_all);
     else
       hipLaunchKernelGGL(k_bwd_diag_ws<8>, dim3(nblk), dim3(768), FB_LDS, st, jobs, B, H, W, nchunk, nunits, row_ld, nrows_all);
@@ -1916,8 +1968,9 @@ extern "C" int evf_plif_bwd_wgrad2(const float* g_z_out, const float* g_z_out2, 
                                    const float* P, const float* leak_pt, const float* add_pt, float* g_pt_prev, float* g_P_raw,
                                    float* g_leak_pt, float* g_add_pt, void* stream) {
   if (!P || !leak_pt || !add_pt || !g_pt_prev || !g_P_raw || !g_leak_pt || !g_add_pt) return EVF_EINVAL;
+  const int xl = (hard_reset >> 1) & 3;  // (bits 1-2 of hard_reset: 1 an XLIF cell, 2 an ALIF cell -- g_P_raw then is g_zx [B,H,W,32])
   const FbPlif pl{(const float4*)g_pt_carry, (const float4*)pt_prev, P, leak_pt, add_pt, (float4*)g_pt_prev, g_P_raw, g_leak_pt, g_add_pt,
-                  (hard_reset >> 1) & 1};  // (bit 1 of hard_reset: an XLIF cell)
+                  xl, xl == 2 ? (float4*)g_P_raw : nullptr};
   return fb_launch(g_z_out, g_z_out2, nullptr, g_v_out, v_out, v_prev, z_prev, xT, zT_prev, leak, thresh, B, H, W, hard_reset & 1,
                    surrogate, act_width, g_cur, g_split, g_v_prev, g_leak, g_thresh, slab_ff, slab_rec, accumulate, stream, &pl);
 }
@@ -1933,7 +1986,7 @@ extern "C" int evf_plif_bwd_wgrad_top(const float* flow, const float* g_flow, co
   if (!P || !leak_pt || !add_pt || !g_pt_prev || !g_P_raw || !g_leak_pt || !g_add_pt) return EVF_EINVAL;
   const FbTop top{flow, g_flow, pred_w, z_out, d_pred_w, d_pred_b};
   const FbPlif pl{(const float4*)g_pt_carry, (const float4*)pt_prev, P, leak_pt, add_pt, (float4*)g_pt_prev, g_P_raw, g_leak_pt, g_add_pt,
-                  (hard_reset >> 1) & 1};
+                  (hard_reset >> 1) & 3, nullptr};
   return fb_launch(nullptr, nullptr, &top, g_v_out, v_out, v_prev, z_prev, xT, nullptr, leak, thresh, B, H, W, hard_reset & 1, surrogate,
                    act_width, g_cur, g_split, g_v_prev, g_leak, g_thresh, slab_ff, nullptr, accumulate, stream, &pl);
 }
@@ -1980,11 +2033,13 @@ static int fb_window_launch(int np, const void* const* g_z, const void* const* f
   J.width = act_width, J.accumulate = accumulate & 1, J.kind = (top ? 2 : 0) + (plif ? 3 : 0);
   J.top = FbTop{nullptr, nullptr, pred_w, nullptr, d_pred_w, d_pred_b};
   J.pl = FbPlif{nullptr, nullptr, nullptr, leak_pt, add_pt, (float4*)g_pt_prev, nullptr, g_leak_pt, g_add_pt,
-                (accumulate >> 1) & 1};  // (bit 1 of accumulate: an XLIF cell)
+                (accumulate >> 1) & 3, nullptr};  // (bits 1-2 of accumulate: 1 an XLIF cell, 2 an ALIF cell)
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k_bwd_win_plif, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
     (void)hipFuncSetAttribute((const void*)k_bwd_win_plif_top, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    (void)hipFuncSetAttribute((const void*)k_bwd_win_alif, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    (void)hipFuncSetAttribute((const void*)k_bwd_win_alif_top, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
     (void)hipFuncSetAttribute((const void*)k_bwd_win_lif, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
     (void)hipFuncSetAttribute((const void*)k_bwd_win_lif_top, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
     attr = true;
@@ -1993,7 +2048,9 @@ static int fb_window_launch(int np, const void* const* g_z, const void* const* f
   const int nblk = fb_blocks_per_cell(nunits, 1, 8 * np);
   evf_prof_mark(8, 0, stream);
 #define FB_WIN_GO(K_) hipLaunchKernelGGL(K_, dim3(nblk), dim3(768), FB_LDS, EVF_STREAM(stream), J, Wn, B, H, W, nchunk, nunits, row_ld, fb_rows(nunits))
-  if (plif) {
+  if (plif && J.pl.xl == 2) {
+    if (top) FB_WIN_GO(k_bwd_win_alif_top); else FB_WIN_GO(k_bwd_win_alif);
+  } else if (plif) {
     if (top) FB_WIN_GO(k_bwd_win_plif_top); else FB_WIN_GO(k_bwd_win_plif);
   } else {
     if (top) FB_WIN_GO(k_bwd_win_lif_top); else FB_WIN_GO(k_bwd_win_lif);

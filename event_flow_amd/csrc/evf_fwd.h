@@ -54,8 +54,9 @@ struct FwJob {
   uint32_t* zT_out;
   PredArgs pr;
   int hard_reset;
-  int xl;  // PLIF fields describe an XLIF cell (spiking_submodules.py:337-435, :771-875): `add_pt` holds t1, `thresh` t0 -- the trace
-           // raises the THRESHOLD (t0 + t1 * pt') instead of being subtracted from the current
+  int xl;  // 1: the PLIF fields describe an XLIF cell (spiking_submodules.py:337-435, :771-875): `add_pt` holds t1, `thresh` t0 -- the
+           // trace raises the THRESHOLD (t0 + t1 * pt') instead of being subtracted from the current.  2: an ALIF cell (:230-334,
+           // :660-768): the same with the trace driven by the cell's OWN previous spikes instead of the pooled input activity
   // PLIF cell (spiking_submodules.py:191-227, :618-657; leak_pt == NULL: LIF): per-channel trace parameters, previous trace
   // [B,H,W,32] or NULL, new trace, pooled pre-synaptic activity [B,H,W] (saved for the backward)
   const float* leak_pt;

@@ -68,8 +68,9 @@ struct PlifArgs {
   const float* pt_prev;  // [B,H,W,32] or NULL
   float* pt_out;         // [B,H,W,32]
   float* P_out;          // [B,H,W] pooled pre-synaptic activity (saved for the backward)
-  int xl;                // XLIF cell (spiking_submodules.py:337-435, :771-875): add_pt = t1, thresh = t0; threshold t0 + t1 * pt', the
-                         // current stays ff (+ rec).  Entry points: bit 1 of `hard_reset`
+  int xl;                // 1: XLIF cell (spiking_submodules.py:337-435, :771-875): add_pt = t1, thresh = t0; threshold t0 + t1 * pt', the
+                         // current stays ff (+ rec).  2: ALIF cell (:230-334, :660-768): the same, the trace (leak_pt = leak_t) driven by
+                         // the cell's own previous spikes.  Entry points: bits 1-2 of `hard_reset`
 };
 
 #ifdef EVF_SPAN  // start / end of every block in the chip-wide 100 MHz counter (probe build through EVF_LIB)
@@ -251,7 +252,7 @@ __device__ __forceinline__ void fwd_b3_body(const int b, const uint32_t* __restr
         float pto = 0.f, th_e = th, th_p = th;  // threshold of this element now / at the previous pass (soft reset)
         if (PLIF) {
           const float lpt = s_par[2 * C32 + c], apt = s_par[3 * C32 + c], bet = s_par[4 * C32 + c];
-          pto = evf_plif_trace(p4[e], lpt, Pq);  // :212 / :642
+          pto = evf_plif_trace(p4[e], lpt, pl.xl == 2 ? z : Pq);  // :212 / :642; ALIF: t * leak_t + (1 - leak_t) * z, :311 / :744
           cur = cur - apt * pto;                  // (ff + rec) - add_pt * pt_out, :220 / :650
           th_e = th + bet * pto;                  // XLIF: thresh = t0 + t1 * pt_out, :419 / :864
           th_p = th + bet * p4[e];                // XLIF soft reset: - z * (t0 + t1 * pt), :430 / :871
@@ -878,7 +879,7 @@ extern "C" int evf_conv_plif_fwd_b3(const uint32_t* x, const void* wb_ff, const 
   if (!x || !wb_ff || !leak_v || !leak_pt || !add_pt || !thresh || !v_out || !z_out || !pt_out || !P_out || B <= 0 ||
       H <= 0 || W <= 0)
     return EVF_EINVAL;
-  PlifArgs pa{leak_pt, add_pt, pt_prev, pt_out, P_out, (hard_reset >> 1) & 1};  // (bit 1: an XLIF cell)
+  PlifArgs pa{leak_pt, add_pt, pt_prev, pt_out, P_out, (hard_reset >> 1) & 3};  // (bits 1-2: 1 an XLIF cell, 2 an ALIF cell)
   hard_reset &= 1;
   return launch_fwd_b3(x, wb_ff, wb_rec, leak_v, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out, &pa,
                        stream);
@@ -894,7 +895,7 @@ extern "C" int evf_conv_plif_fwd_b3_pred(const uint32_t* x, const void* wb_ff, c
   if (!x || !wb_ff || !leak_v || !leak_pt || !add_pt || !thresh || !v_out || !z_out || !pt_out || !P_out || !pred_w || !pred_b ||
       !flow || B <= 0 || H <= 0 || W <= 0)
     return EVF_EINVAL;
-  PlifArgs pa{leak_pt, add_pt, pt_prev, pt_out, P_out, (hard_reset >> 1) & 1};  // (bit 1: an XLIF cell)
+  PlifArgs pa{leak_pt, add_pt, pt_prev, pt_out, P_out, (hard_reset >> 1) & 3};  // (bits 1-2: 1 an XLIF cell, 2 an ALIF cell)
   hard_reset &= 1;
   const PredArgs pd{pred_w, pred_b, flow};
   return launch_fwd_b3(x, wb_ff, wb_rec, leak_v, thresh, v_prev, z_prev, B, H, W, hard_reset, v_out, z_out, zT_out, &pa,

@@ -852,7 +852,7 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
   for (int k = 0; k < n; ++k) nhard += jobs.j[k].hard_reset ? 1 : 0, nplif += jobs.j[k].leak_pt ? 1 : 0;
   if ((nhard != 0 && nhard != n) || (nplif != 0 && nplif != n)) return EVF_EINVAL;
   for (int k = 0; k < n; ++k)  // XLIF cells: one kind per launch, hard reset (the caller then runs the cells one by one: evf_fwd_b3.hip)
-    if (jobs.j[k].xl != jobs.j[0].xl || (jobs.j[k].xl && !jobs.j[k].hard_reset)) return EVF_EINVAL;
+    if (jobs.j[k].xl != jobs.j[0].xl || (jobs.j[k].xl && !jobs.j[k].hard_reset) || jobs.j[k].xl == 2) return EVF_EINVAL;  // (ALIF: the one-cell kernel)
   FtPlan plan;
   plan.njobs = n, plan.ntx = evf_cdiv(W, TW), plan.nyy = evf_cdiv(H, 2);
   const long nstrips = (long)plan.ntx * plan.nyy * B;
@@ -896,7 +896,7 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
 int evf_fwd_win_is_chain(const FwJob* c, int n) {
   if (n < 2 || n > FW_WIN_MAX) return 0;
   if (c[0].wrec) return 0;
-  if (c[0].xl && !c[0].hard_reset) return 0;  // (XLIF cells with the soft reset: the one-cell kernel)
+  if ((c[0].xl && !c[0].hard_reset) || c[0].xl == 2) return 0;  // (XLIF cells with the soft reset, ALIF cells: the one-cell kernel)
   for (int k = 1; k < n; ++k) {
     const FwJob &a = c[k - 1], &b = c[k];
     if (b.wrec || b.wff != a.wff || b.leak != a.leak || b.thresh != a.thresh || b.hard_reset != a.hard_reset ||

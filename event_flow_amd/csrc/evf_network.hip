@@ -385,7 +385,8 @@ __global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ 
   const int j = lane & 31;
   const float lam = evf_sigmoid(leak[j]);
   const float th = fmaxf(thresh[j], 0.01f);
-  const bool xl = pt_out && (hard_reset & 2);  // XLIF head (bit 1 of the flag, evf_head_plif_fwd): add_pt = t1, thresh = t0
+  const bool xl = pt_out && (hard_reset & 6);  // XLIF / ALIF head (bits 1-2 of the flag, evf_head_plif_fwd): add_pt = t1, thresh = t0
+  const bool al = pt_out && ((hard_reset >> 1) & 3) == 2;  // ALIF: the trace is driven by the cell's own previous spikes (:311)
   hard_reset &= 1;
   float thx0[16], thx1[16];  // (XLIF: t1 * pt' per element of the wave's two rows)
   if (pt_out) {  // PLIF head (spiking_submodules.py:191-227): cur = ff - sigma(add_pt) * pt'
@@ -417,7 +418,8 @@ __global__ __launch_bounds__(256) void k_head_lif_fwd(const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int cl = mfma_row(r, lane), col = x0 + cl;
-        const float pto = evf_plif_trace(pt_prev ? ptv[r] : 0.f, lpt, s_P[(r0 + m) * TW + cl]);
+        const float zprev = (float)((((m ? zw1 : zw0)[r]) >> j) & 1u);
+        const float pto = evf_plif_trace(pt_prev ? ptv[r] : 0.f, lpt, al ? zprev : s_P[(r0 + m) * TW + cl]);
         thx[r] = apt * pto;
         if (!xl) acc[r] = acc[r] - thx[r];  // (XLIF: the current stays ff, the threshold becomes t0 + t1 * pt', :419)
         if (row < H && col < W) pt_out[(((long)b * H + row) * W + col) * C32 + j] = pto;
@@ -556,7 +558,8 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 && !PLIF) ? 4 : ((NWV == 4 && P
   const float lam = evf_sigmoid(a.leak[j]);
   const float th = fmaxf(a.thresh[j], 0.01f);
   const int hard_reset = a.hard_reset & 1;
-  const bool xl = PLIF && (a.hard_reset & 2);  // XLIF head (bit 1 of the flag, evf_head_plif_fwd): add_pt = t1, thresh = t0
+  const bool xl = PLIF && (a.hard_reset & 6);  // XLIF / ALIF head (bits 1-2 of the flag, evf_head_plif_fwd): add_pt = t1, thresh = t0
+  const bool al = PLIF && ((a.hard_reset >> 1) & 3) == 2;  // ALIF: the trace is driven by the cell's own previous spikes
   const int nW = (W + 31) / 32;
   float pt[PLIF ? RPW : 1][16];
   float lpt = 0.f, apt = 0.f;
@@ -660,8 +663,8 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 && !PLIF) ? 4 : ((NWV == 4 && P
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int cl = mfma_row(r, lane), col = x0 + cl;
-          const float pto = evf_plif_trace(pt[PLIF ? m : 0][r], lpt, s_P[(r0 + m) * TW + cl]);
-          if (!xl) acc[m][r] = acc[m][r] - apt * pto;  // (XLIF: the current stays ff)
+          const float pto = evf_plif_trace(pt[PLIF ? m : 0][r], lpt, al ? (float)((zb[m] >> r) & 1u) : s_P[(r0 + m) * TW + cl]);
+          if (!xl) acc[m][r] = acc[m][r] - apt * pto;  // (XLIF / ALIF: the current stays ff)
           pt[PLIF ? m : 0][r] = pto;
           if (row < H && col < W) prow[cl * C32] = pto;
         }
@@ -801,7 +804,7 @@ extern "C" int evf_head_plif_fwd(const float* x, const float* w, const float* le
   if (!x || !w || !leak_v || !leak_pt || !add_pt || !thresh || !v_out || !z_out || !pt_out || !P_out || B <= 0 ||
       Cin <= 0 || Cin > HEAD_MAX_CIN || H <= 0 || W <= 0)
     return EVF_EINVAL;
-  if (hard_reset == 2) return EVF_ENOTSUP;  // (an XLIF head with the soft reset: its threshold of the pass before is not kept here)
+  if ((hard_reset & 6) && !(hard_reset & 1)) return EVF_ENOTSUP;  // (an XLIF / ALIF head with the soft reset: its threshold of the pass before is not kept here)
   const int fctx = evf_ctx_find(stream);
   if (fctx >= 0 && evf_fwd_defer_active(fctx)) {  // recorded like evf_head_lif_fwd: the window's passes in one launch at the flush
     HfDefer& hf = hf_tab[fctx];
@@ -1122,12 +1125,15 @@ struct HeadTripIn {  // what one trip loads
   float xb[4];
   float4 gkl, ppl;  // PLIF: dL/d(pt') carried from pass t + 1 (first pass / NT = 0 only), pt of pass t - 1
   float Pl;         // PLIF: pooled input activity of the pixel
+  float4 gxl;       // ALIF: the part of dL/d(spikes) that the pass after sent through the threshold trace
 };
 // PLIF head (spiking_submodules.py:191-227 / :634-652): the presynaptic trace's backward in the same pass (evf_plif_trace_bwd read
 // g_cur back from HBM in a launch of its own).  The head's input is the event tensor: dL/d(pooled activity) is not needed.
 struct HeadPlifPass {
   const float4 *g_pt_out, *pt_prev;  // carry from pass t + 1 (NULL: none), trace of pass t - 1 (NULL: zero state)
-  const float* P;                    // [B,H,W] pooled activity of pass t (NULL: not a PLIF cell)
+  const float* P;                    // [B,H,W] pooled activity of pass t (NULL: not a PLIF cell).  ALIF head (XL = 2): instead the
+                                     // buffer g_zx [B,H,W,32] -- (1 - sigma(leak_t)) * dL/d(t') of pass t + 1 is READ from it as a second
+                                     // part of dL/d(spikes) (when g_pt_out != NULL: there is a pass after), this pass's WRITTEN to it
   float4* g_pt_prev;                 // carry to pass t - 1
 };
 struct HeadPlifPrm {
@@ -1151,7 +1157,9 @@ struct HeadBwdKeepPlif {
 // XL (PLIF bodies only): an XLIF head -- add_pt = t1, thresh = t0; the trace raised the THRESHOLD (t0 + t1 * pt',
 // spiking_submodules.py:419), so it takes -t1 * dL/d(thresh) instead of -sigma(add_pt) * dL/d(current).  A template parameter: with
 // a run-time flag the PLIF window kernel kept eight more values live across the element loop and spilled (401 -> 628 us per window)
-template <bool FAST, int NT = 0, bool FIRST = true, bool PLIF = false, bool XL = false>
+// XL = 2: an ALIF head (spiking_submodules.py:230-334) -- the XLIF arithmetic with the trace driven by the cell's OWN previous spikes
+// (un-detached, :311): their gradient (1 - sigma(leak_t)) * dL/d(t') goes to the pass before through the buffer HeadPlifPass::P.
+template <bool FAST, int NT = 0, bool FIRST = true, bool PLIF = false, int XL = 0>
 __device__ __forceinline__ void head_bwd_pass(
     const float4* g_z_out, const float4* g_v_out, const float4* v_out, const float4* v_prev, const uint32_t* z_prev,
     const float* __restrict__ leak, const float* __restrict__ thresh, long npix, int hard_reset_rt, int surrogate_rt, float width,
@@ -1160,7 +1168,9 @@ __device__ __forceinline__ void head_bwd_pass(
     HeadBwdKeep& K, bool store_gv,  // store_gv: the launch's last pass (NT = 0: every pass is first and last)
     const HeadPlifPass pq = HeadPlifPass{}, const HeadPlifPrm pm = HeadPlifPrm{}, float4* gpc_ = nullptr, HeadBwdKeepPlif* KP_ = nullptr) {
   const int hard_reset = FAST ? 1 : (hard_reset_rt & 1), surrogate = FAST ? EVF_ARCTAN : surrogate_rt;
-  constexpr bool xl = PLIF && XL;
+  constexpr bool xl = PLIF && XL != 0, al = PLIF && XL == 2;
+  float4* const gzxb = al ? (float4*)pq.P : nullptr;
+  const bool has_gx = al && (FIRST ? pq.g_pt_out != nullptr : true);  // (a pass after this one exists: its g_zx is in the buffer)
   float4 gpc_none[1];
   HeadBwdKeepPlif kp_none;
   float4* gpc = PLIF ? gpc_ : gpc_none;          // [NT] the carried dL/d(pt') of the block's trips
@@ -1237,7 +1247,8 @@ __device__ __forceinline__ void head_bwd_pass(
     in.zwl = pzw[pix];
     if (PLIF) {
       in.ppl = ppp[ec];
-      in.Pl = pq.P[pix];
+      if constexpr (al) in.gxl = (has_gx ? (const float4*)gzxb : v_out)[ec];
+      else in.Pl = pq.P[pix];
     }
     // B operand: the input value of the wave's pixels 2m + kg at this lane's (ci, tap)
     const long wp0 = (base >> 3) + wv * 8;  // first pixel of this wave
@@ -1283,7 +1294,12 @@ __device__ __forceinline__ void head_bwd_pass(
     }
     const float4 gzl = in.gzl, vpl = in.vpl;
     const uint32_t zwl = in.zwl;
-    const float4 gz4 = g_z_out ? gzl : zero4, gv4 = (g_v_out || (NT > 0 && !FIRST)) ? gvl : zero4, vp4 = v_prev ? vpl : zero4;
+    float4 gz4 = g_z_out ? gzl : zero4;
+    if constexpr (al) {
+      const float4 gx4 = has_gx ? in.gxl : zero4;
+      gz4 = make_float4(gz4.x + gx4.x, gz4.y + gx4.y, gz4.z + gx4.z, gz4.w + gx4.w);
+    }
+    const float4 gv4 = (g_v_out || (NT > 0 && !FIRST)) ? gvl : zero4, vp4 = v_prev ? vpl : zero4;
     const uint32_t zw = z_prev ? (zwl >> (4 * cg)) : 0u;
     const float vo[4] = {vo4.x, vo4.y, vo4.z, vo4.w}, gz[4] = {gz4.x, gz4.y, gz4.z, gz4.w};
     const float gvo[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, vp[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
@@ -1292,7 +1308,7 @@ __device__ __forceinline__ void head_bwd_pass(
       const float4 pp4 = pq.pt_prev ? in.ppl : zero4;
       const float pp[4] = {pp4.x, pp4.y, pp4.z, pp4.w};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) pov[k] = evf_plif_trace(pp[k], KP.lpt[k], in.Pl);
+      for (int k = 0; k < 4; ++k) pov[k] = evf_plif_trace(pp[k], KP.lpt[k], al ? (float)((zw >> k) & 1u) : in.Pl);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1328,8 +1344,8 @@ __device__ __forceinline__ void head_bwd_pass(
       const float4 gk4 = (NT == 0 || FIRST) ? (pq.g_pt_out ? in.gkl : zero4) : gpc[ic];
       const float4 pp4 = pq.pt_prev ? in.ppl : zero4;
       const float gk[4] = {gk4.x, gk4.y, gk4.z, gk4.w}, pp[4] = {pp4.x, pp4.y, pp4.z, pp4.w};
-      const float Pv = in.Pl;
-      float gq[4];
+      const float Pv = al ? 0.f : in.Pl;
+      float gq[4], gzx[al ? 4 : 1];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float po, gx;  // pt'; what the trace scaled in the forward pass: the threshold's / the current's gradient (negated)
@@ -1337,10 +1353,14 @@ __device__ __forceinline__ void head_bwd_pass(
         else po = evf_plif_trace(pp[k], KP.lpt[k], Pv), gx = gc[k];
         const float g = gk[k] - KP.apt[k] * gx;
         gq[k] = g * KP.lpt[k];
+        if constexpr (al) gzx[k] = g * (1.0f - KP.lpt[k]);
         if (ok) {
-          KP.slp[k] += g * (pp[k] - Pv);
+          KP.slp[k] += g * (pp[k] - (al ? (float)((zw >> k) & 1u) : Pv));
           KP.sap[k] -= gx * po;
         }
+      }
+      if constexpr (al) {
+        if (ok) gzxb[e] = make_float4(gzx[0], gzx[1], gzx[2], gzx[3]);
       }
       if (NT > 0) gpc[ic] = make_float4(gq[0], gq[1], gq[2], gq[3]);
       if (ok && (NT == 0 || store_gv)) pq.g_pt_prev[e] = make_float4(gq[0], gq[1], gq[2], gq[3]);
@@ -1468,7 +1488,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_mfma(
 }
 
 // PLIF head, one pass: the same with the trace backward inside (default neuron)
-template <bool XL>
+template <int XL>
 __global__ __launch_bounds__(256) void k_head_plif_bwd_mfma(
     const float4* __restrict__ g_z_out, const float4* __restrict__ g_v_out, const float4* __restrict__ v_out,
     const float4* __restrict__ v_prev, const uint32_t* __restrict__ z_prev, const float* __restrict__ leak,
@@ -1503,7 +1523,7 @@ struct HeadBwdWin {
   float width;
 };
 #define HEADBWD_NT 4  // trips of a block whose carried values fit registers (8 x 128 x 128 on 1024 blocks: 4)
-template <bool FAST, int NT, bool PLIF = false, bool XL = false>
+template <bool FAST, int NT, bool PLIF = false, int XL = 0>
 __global__ __launch_bounds__(HEADBWD_LB) void k_head_bwd_win(HeadBwdWin a) {
   float4 gvc[NT ? NT : 1], voc[NT ? NT : 1], gpc[NT ? NT : 1];
   int xo[NT ? NT : 1][4];
@@ -1577,8 +1597,9 @@ static int head_bwd_go(const HdArgs& a, void* stream) {
                      a.act_width, (float4*)a.g_v_prev, a.g_leak, a.g_thresh, a.x_in, a.Cin, a.H, a.W, a.slab, accumulate, row_ld,  \
                      HeadPlifPass{(const float4*)a.g_pt_out, (const float4*)a.pt_prev, a.P, (float4*)a.g_pt_prev},               \
                      HeadPlifPrm{a.leak_pt, a.add_pt, a.g_leak_pt, a.g_add_pt})
-    if (a.hard_reset & 2) HEAD_PLIF_BWD(true);  // (bit 1: an XLIF head)
-    else HEAD_PLIF_BWD(false);
+    if (((a.hard_reset >> 1) & 3) == 2) HEAD_PLIF_BWD(2);  // (bits 1-2: 1 an XLIF head, 2 an ALIF head)
+    else if (a.hard_reset & 2) HEAD_PLIF_BWD(1);
+    else HEAD_PLIF_BWD(0);
 #undef HEAD_PLIF_BWD
     return evf_status();
   }
@@ -1682,9 +1703,12 @@ int evf_hd_defer_launch_window(int ctx, void* stream) {
 #define HEAD_BWD_WIN(FAST_, NT_) hipLaunchKernelGGL((k_head_bwd_win<FAST_, NT_>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a)
       if (f.P) {  // PLIF (default neuron only: evf_head_plif_bwd_wgrad): three trips' carried values fit the registers
         const bool win3 = carry && trips <= 3 && (long)f.B * f.Cin * f.H * f.W < (1L << 31);
-        if (f.hard_reset & 2) {  // (bit 1: an XLIF head)
-          if (win3) hipLaunchKernelGGL((k_head_bwd_win<true, 3, true, true>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a);
-          else hipLaunchKernelGGL((k_head_bwd_win<true, 0, true, true>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a);
+        if (((f.hard_reset >> 1) & 3) == 2) {  // (bits 1-2: 2 an ALIF head, 1 an XLIF head)
+          if (win3) hipLaunchKernelGGL((k_head_bwd_win<true, 3, true, 2>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a);
+          else hipLaunchKernelGGL((k_head_bwd_win<true, 0, true, 2>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a);
+        } else if (f.hard_reset & 2) {
+          if (win3) hipLaunchKernelGGL((k_head_bwd_win<true, 3, true, 1>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a);
+          else hipLaunchKernelGGL((k_head_bwd_win<true, 0, true, 1>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a);
         } else {
           if (win3) hipLaunchKernelGGL((k_head_bwd_win<true, 3, true>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a);
           else hipLaunchKernelGGL((k_head_bwd_win<true, 0, true>), dim3(nblk), dim3(256), 0, EVF_STREAM(stream), a);

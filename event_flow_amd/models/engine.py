@@ -174,17 +174,19 @@ class FireNetEngine:
         # XLIF cells (reference spiking_submodules.py:337-435, :771-875) run through the PLIF kernels: the same pre-synaptic trace, which
         # raises the THRESHOLD (t0 + t1 * pt') instead of being subtracted from the current.  Their t1 travels in the `add_pt` slot,
         # t0 in the `thresh` slot, and bit 1 of the entry points' reset / accumulate flag says so (include/evflow.h).
-        self._plif = self.kind in ("plif", "xlif")
+        # ALIF cells (:230-334, :660-768): the XLIF arithmetic with the threshold trace driven by the cell's OWN previous spikes (un-detached:
+        # one more part of dL/d(spikes) of the pass before): mode 2 of the same entry points (bits 1-2 of the flag)
+        self._plif = self.kind in ("plif", "xlif", "alif")
         self._xl = self.kind == "xlif"
+        self._al = self.kind == "alif"
+        self._xf = 2 if self._xl else (4 if self._al else 0)
         for i, c in enumerate(cells):
-            if c.kind not in ("lif", "plif", "xlif") or c.kind != self.kind:
-                raise NotImplementedError(
-                    f"{type(c).__name__}: LIF, PLIF and XLIF cells are accelerated so far (ALIF: the general path); there is no CPU fallback"
-                )
+            if c.kind not in ("lif", "plif", "xlif", "alif") or c.kind != self.kind:
+                raise NotImplementedError(f"{type(c).__name__}: LIF, PLIF, XLIF and ALIF cells are accelerated; there is no CPU fallback")
             if self._plif and precision != "bf16x3":
-                raise NotImplementedError("PLIF / XLIF cells are implemented on the bf16x3 path only")
-            if c.kind == "xlif" and not (c.hard_reset and c.activation == "arctanspike" and PLIF_TRACE_FUSED):
-                raise NotImplementedError("fused XLIF cells: hard reset, arctan surrogate, trace backward inside the fused backward")
+                raise NotImplementedError("PLIF / XLIF / ALIF cells are implemented on the bf16x3 path only")
+            if c.kind in ("xlif", "alif") and not (c.hard_reset and c.activation == "arctanspike" and PLIF_TRACE_FUSED):
+                raise NotImplementedError("fused XLIF / ALIF cells: hard reset, arctan surrogate, trace backward inside the fused backward")
             if c.hidden_size != C or c.kernel_size != 3 or c.stride != 1 or (i > 0 and c.input_size != C):
                 raise NotImplementedError("accelerated FireNet kernels need base_num_channels=32, kernel_size=3")
             if i == 0 and c.recurrent:
@@ -201,13 +203,13 @@ class FireNetEngine:
                 self._reg(f"{i}.leak", c.leak_v)
                 self._reg(f"{i}.leak_pt", c.leak_pt)
                 self._reg(f"{i}.add_pt", c.add_pt)
-            elif c.kind == "xlif":
+            elif c.kind in ("xlif", "alif"):
                 self._reg(f"{i}.leak", c.leak_v)
-                self._reg(f"{i}.leak_pt", c.leak_pt)
+                self._reg(f"{i}.leak_pt", c.leak_pt if c.kind == "xlif" else c.leak_t)  # (the trace's leak: leak_t of an ALIF cell)
                 self._reg(f"{i}.add_pt", c.t1)  # (the kernels' slot of the trace's weight: t1 here)
             else:
                 self._reg(f"{i}.leak", c.leak)
-            self._reg(f"{i}.thresh", c.t0 if c.kind == "xlif" else c.thresh)
+            self._reg(f"{i}.thresh", c.t0 if c.kind in ("xlif", "alif") else c.thresh)
         self._reg("pred.w", pred.conv2d.weight)
         self._reg("pred.b", pred.conv2d.bias)
         # layout of the small-accumulator buffer
@@ -549,7 +551,7 @@ class FireNetEngine:
             st = states[i]
             v_prev, z_prev, zT_prev = st[:3] if st is not None else (None, None, None)
             plif = self._plif
-            xf = 2 if self._xl else 0  # (bit 1 of the reset flag: an XLIF cell, include/evflow.h)
+            xf = self._xf  # (bits 1-2 of the reset flag: 2 an XLIF cell, 4 an ALIF cell, include/evflow.h)
             pt_prev = st[3] if (plif and st is not None) else None
             if target is not None:
                 pt_out = target[i][3] if plif else None
@@ -634,7 +636,7 @@ class FireNetEngine:
 
     # ---- PLIF: backward of a window layer by layer ---------------------------------------------------------------------------
     def _lm_wanted(self, win, tape, g_flow):
-        if not (PLIF_LAYER_MAJOR and self._plif and self.precision == "bf16x3" and g_flow is not None):
+        if not (PLIF_LAYER_MAJOR and self._plif and not self._al and self.precision == "bf16x3" and g_flow is not None):  # (ALIF: pass by pass)
             return False
         n = len(self.cells)
         return (HEAD_WIN and PLIF_TRACE_FUSED and PLIF_BOX_IN_DGRAD and TOP_FUSED and F32_DGRAD and PAIR_DGRAD and PARAM_ROWS
@@ -739,7 +741,7 @@ class FireNetEngine:
         arr_n = lambda ts: arr(ts) if ts[0] is not None else None  # noqa: E731
         rowp = lambda name: _lib.ptr(self._rowed(win, name)[0])  # noqa: E731
         row_ld = win.rows.shape[1]
-        xf = 2 if self._xl else 0  # (bit 1 of the reset / accumulate flag: XLIF cells, include/evflow.h)
+        xf = self._xf  # (bits 1-2 of the reset / accumulate flag: XLIF / ALIF cells, include/evflow.h)
         for i in range(n - 1, 0, -1):
             c = self.cells[i]
             lay = [tp["layers"][i] for tp in tapes]  # (in_bits, v_prev, z_prev, v_out, z_out, in_bitsT, zT_prev, pt_prev, pt_out, P)
@@ -840,8 +842,8 @@ class FireNetEngine:
         layers = tape["layers"]
         nslab = _lib.load().evf_conv_wgrad_slabs(B, H, W)
         # the prediction head's backward runs inside the fused backward of the (non-recurrent) layer below it
-        top_fused = (TOP_FUSED and g_flow is not None and self.precision == "bf16x3" and n > 1
-                     and not self.cells[n - 1].recurrent and not win.gz_has[n - 1])
+        top_fused = (TOP_FUSED and g_flow is not None and self.precision == "bf16x3" and n > 1 and not self._al
+                     and not self.cells[n - 1].recurrent and not win.gz_has[n - 1])  # (ALIF: evf_pred_bwd + the plain cell)
         g_flow_c = g_flow.float().contiguous() if g_flow is not None else None
         if self.__dict__.get("_bdefer_on", False):
             # recorded cells of this pass are launched later (flush_backward): its tape and the contiguous upstream gradient
@@ -877,7 +879,7 @@ class FireNetEngine:
             c = self.cells[i]
             in_bits, v_prev, z_prev, v_out, _, in_bitsT, zT_prev, pt_prev, pt_out, P_sav = layers[i]
             plif = self._plif
-            xf = 2 if self._xl else 0
+            xf = self._xf
             g_z = win.gz[i] if win.gz_has[i] else None
             g_z2 = win.gzr[i] if win.gzr_has[i] else None  # from the cell's own recurrent input gradient (pass t + 1)
             g_v = win.gv[i]
@@ -902,19 +904,24 @@ class FireNetEngine:
             # PLIF: the trace backward rides in the fused backward (default neuron, pooling adjoint inside the input-gradient kernels)
             trace_fused = (plif and PLIF_TRACE_FUSED and PLIF_BOX_IN_DGRAD and i > 0 and self.precision == "bf16x3"
                            and c.hard_reset and c.activation == "arctanspike")
-            if self._xl and ((i > 0 and not trace_fused) or (i == 0 and tape["x_in"].shape[1] != 2)):
-                raise _lib.EvflowError("fused XLIF cells need the trace backward inside the fused backward kernels (EVF_PLIF_TRACE_FUSED, "
+            if (self._xl or self._al) and ((i > 0 and not trace_fused) or (i == 0 and tape["x_in"].shape[1] != 2)):
+                raise _lib.EvflowError("fused XLIF / ALIF cells need the trace backward inside the fused backward kernels (EVF_PLIF_TRACE_FUSED, "
                                        "EVF_PLIF_BOX=dgrad, a two-channel input); EVF_XLIF_FUSED=0 serves the network on the general path")
             if trace_fused:
                 if win.gP is None:
                     win.gP = _f32((B, H, W), dev)
                     win.gP_raw = _f32((B, H, W), dev)
                 gpt_out = win.buf(win.gpt, i)
+                # ALIF: the kernel's g_P_raw slot takes g_zx [B,H,W,32] -- what this pass sends into dL/d(spikes) of the pass before
+                # through the threshold trace; it comes back as g_z_out2 (same buffer: read, then written, by the same thread)
+                gzx_buf = win.buf(win.gzr, i) if self._al else None
                 trace_args = (_lib.ptr(gpt_out if win.gpt_has[i] else None), _lib.ptr(pt_prev), _lib.ptr(P_sav),
                               _lib.ptr(self._flat[f"{i}.leak_pt"]), _lib.ptr(self._flat[f"{i}.add_pt"]), _lib.ptr(gpt_out),
-                              _lib.ptr(win.gP_raw), _lib.ptr(self._rowed(win, f"{i}.leak_pt")[0]),
+                              _lib.ptr(gzx_buf if self._al else win.gP_raw), _lib.ptr(self._rowed(win, f"{i}.leak_pt")[0]),
                               _lib.ptr(self._rowed(win, f"{i}.add_pt")[0]))
                 win.gpt_has[i] = not is_first
+                if self._al:
+                    win.gzr_has[i] = not is_first
             if i > 0 and self.precision == "bf16x3":
                 # neuron backward + both weight gradients in one pass (evf_bwd_fused.hip)
                 kf, kr = (i, "ff"), (i, "rec")
@@ -951,14 +958,15 @@ class FireNetEngine:
                 key = (0, "ff")
                 if key not in self._slabs or self._slabs[key].shape != (nsl, C * 18) or self._slabs[key].device != dev:
                     self._slabs[key] = _f32((nsl, C * 18), dev)
-                if plif_hw or self._xl:  # ... and the trace backward in the same pass; recorded (see plif_hw above; XLIF: always this form)
+                if plif_hw or self._xl or self._al:  # ... and the trace backward in the same pass; recorded (see plif_hw above; XLIF / ALIF: always this form)
                     gpt_out = win.buf(win.gpt, 0)
                     _lib.call("evf_head_plif_bwd_wgrad", _lib.ptr(g_z), _lib.ptr(g_v), _lib.ptr(v_out), _lib.ptr(v_prev),
                               _lib.ptr(z_prev), _lib.ptr(tape["x_in"]), _lib.ptr(self._flat["0.leak"]),
                               _lib.ptr(self._flat["0.thresh"]), B, 2, H, W, 1 | xf, SURROGATE_ID[c.activation], self._act_width(0),
                               _lib.ptr(gv_out), _lib.ptr(leak_r), _lib.ptr(thr_r), _lib.ptr(self._slabs[key]),
                               (1 if win.slab_init.get(key) else 0) | (row_ld << 8),
-                              _lib.ptr(gpt_out if win.gpt_has[0] else None), _lib.ptr(pt_prev), _lib.ptr(P_sav),
+                              _lib.ptr(gpt_out if win.gpt_has[0] else None), _lib.ptr(pt_prev),
+                              _lib.ptr(win.buf(win.gzr, 0) if self._al else P_sav),  # (ALIF: the g_zx buffer in the P slot, include/evflow.h)
                               _lib.ptr(self._flat["0.leak_pt"]), _lib.ptr(self._flat["0.add_pt"]), _lib.ptr(gpt_out),
                               _lib.ptr(self._rowed(win, "0.leak_pt")[0]), _lib.ptr(self._rowed(win, "0.add_pt")[0]))
                     win.gpt_has[0] = not is_first
@@ -1017,13 +1025,14 @@ class FireNetEngine:
                 ga = win.buf(win.gz, i - 1)
                 acc_a = 1 if win.gz_has[i - 1] else 0
                 # PLIF: the input-gradient kernel applies AvgPool3x3^T / 32 to the trace backward's raw map itself (accumulate | 2)
-                gp_flag = 2 if (plif and PLIF_BOX_IN_DGRAD) else 0
-                gp_map = (win.gP_raw if PLIF_BOX_IN_DGRAD else win.gP) if plif else None
+                trace_in = plif and not self._al  # (the trace depends on the INPUT: PLIF / XLIF; an ALIF cell's on its own spikes)
+                gp_flag = 2 if (trace_in and PLIF_BOX_IN_DGRAD) else 0
+                gp_map = (win.gP_raw if PLIF_BOX_IN_DGRAD else win.gP) if trace_in else None
                 if self.precision == "bf16x3":
                     dg, gsrc = ("evf_conv_dgrad_b3_f32", g_cur_i) if F32_DGRAD else ("evf_conv_dgrad_b3", win.g_split)
                     if split:
                         dg, gsrc = "evf_conv_dgrad_b3", g_split_i
-                    if rec_grad and (F32_DGRAD or split) and PAIR_DGRAD:  # both input gradients of the recurrent cell in one launch
+                    if rec_grad and (F32_DGRAD or split) and PAIR_DGRAD and not self._al:  # both input gradients of the recurrent cell in one launch
                         # the recurrent one goes to its OWN buffer (gzr): the cell's backward of the previous pass adds the
                         # two parts itself (evf_lif_bwd_wgrad2), so the input gradient of the layer above needs no
                         # accumulating form there, and those two launches may come in either order
@@ -1031,15 +1040,18 @@ class FireNetEngine:
                         _lib.call("evf_conv_dgrad_b3_pair" if split else "evf_conv_dgrad_b3_f32_pair", _lib.ptr(gsrc),
                                   _lib.ptr(self._packed[(i, "ff", "b3t")]),
                                   _lib.ptr(ga), acc_a | gp_flag, _lib.ptr(self._packed[(i, "rec", "b3t")]), _lib.ptr(gb), B, H, W,
-                                  _lib.ptr(gp_map) if plif else None, _lib.ptr(in_bits) if plif else None)
+                                  _lib.ptr(gp_map) if trace_in else None, _lib.ptr(in_bits) if trace_in else None)
                         if plif:
                             win.gz_has[i] = True
                         else:
                             win.gzr_has[i] = True
                     else:
                         _lib.call(dg, _lib.ptr(gsrc), _lib.ptr(self._packed[(i, "ff", "b3t")]), _lib.ptr(ga),
-                                  acc_a | gp_flag, B, H, W, _lib.ptr(gp_map) if plif else None, _lib.ptr(in_bits) if plif else None)
-                        if rec_grad:
+                                  acc_a | gp_flag, B, H, W, _lib.ptr(gp_map) if trace_in else None, _lib.ptr(in_bits) if trace_in else None)
+                        if rec_grad and self._al:  # ... ADDED to g_zx, which the cell's backward has just stored there
+                            _lib.call(dg, _lib.ptr(gsrc), _lib.ptr(self._packed[(i, "rec", "b3t")]),
+                                      _lib.ptr(win.buf(win.gzr, i)), 1, B, H, W, None, None)
+                        elif rec_grad:
                             gb = win.buf(win.gz, i)
                             _lib.call(dg, _lib.ptr(gsrc), _lib.ptr(self._packed[(i, "rec", "b3t")]),
                                       _lib.ptr(gb), 0, B, H, W, None, None)

@@ -21,8 +21,9 @@ from .engine import FireNetEngine
 
 
 def _xlif_fused_ok(c):
-    """XLIF cells ride on the PLIF window kernels (threshold t0 + t1 * trace instead of the trace in the current); their backward
-    forms exist for the default neuron only (configs/train_SNN.yml: hard reset, arctan surrogate) -- other XLIF cells: general path."""
+    """XLIF and ALIF cells ride on the PLIF kernels (threshold t0 + t1 * trace instead of the trace in the current; ALIF: the trace
+    driven by the cell's own previous spikes); their backward forms exist for the default neuron only (configs/train_SNN.yml: hard
+    reset, arctan surrogate) -- other XLIF / ALIF cells: general path (EVF_XLIF_FUSED=0: always)."""
     import os
 
     return bool(c.hard_reset) and c.activation == "arctanspike" and os.environ.get("EVF_XLIF_FUSED", "1") != "0"
@@ -98,9 +99,9 @@ class FireNet(BaseModel):
             cells = self._cells()
             self._use_fused = (
                 not self.residual
-                and all(getattr(c, "kind", None) in ("lif", "plif", "xlif") and not getattr(c, "wnorm", False) and not getattr(c, "gnorm", False)
+                and all(getattr(c, "kind", None) in ("lif", "plif", "xlif", "alif") and not getattr(c, "wnorm", False) and not getattr(c, "gnorm", False)
                         for c in cells)
-                and all(c.kind != "xlif" or _xlif_fused_ok(c) for c in cells)
+                and all(c.kind not in ("xlif", "alif") or _xlif_fused_ok(c) for c in cells)
                 and len({c.kind for c in cells}) == 1
                 and all(c.hidden_size == 32 and c.kernel_size == 3 and c.stride == 1 for c in cells)
             )
@@ -110,7 +111,7 @@ class FireNet(BaseModel):
 
                 print(f"[event_flow_amd] {type(self).__name__}: general path (one fused conv + neuron kernel per cell, "
                       f"models/hip_ops.py) -- {self.compute_path[1]}; the recorded 32-channel window kernels (models/engine.py) "
-                      "serve LIF / PLIF FireNets (and XLIF ones with the hard reset and the arctan surrogate) with base_num_channels=32, "
+                      "serve LIF / PLIF FireNets (and XLIF / ALIF ones with the hard reset and the arctan surrogate) with base_num_channels=32, "
                       "kernel_size=3, no residual / weight / group norm",
                       file=sys.stderr)
         return self._use_fused
@@ -123,13 +124,13 @@ class FireNet(BaseModel):
         why = []
         if self.residual:
             why.append("residual connections")
-        if any(getattr(c, "kind", None) not in ("lif", "plif", "xlif") for c in cells):
+        if any(getattr(c, "kind", None) not in ("lif", "plif", "xlif", "alif") for c in cells):
             why.append("cell kind(s) " + ", ".join(sorted(str(k) for k in kinds)))
-        elif any(c.kind == "xlif" and not _xlif_fused_ok(c) for c in cells):
+        elif any(c.kind in ("xlif", "alif") and not _xlif_fused_ok(c) for c in cells):
             import os
 
             why.append("EVF_XLIF_FUSED=0" if os.environ.get("EVF_XLIF_FUSED", "1") == "0" else
-                       "XLIF cells with the soft reset or another surrogate than arctanspike (the fused XLIF kernels: hard reset, arctan)")
+                       "XLIF / ALIF cells with the soft reset or another surrogate than arctanspike (their fused kernels: hard reset, arctan)")
         elif len(kinds) > 1:
             why.append("mixed cell kinds")
         if any(getattr(c, "wnorm", False) or getattr(c, "gnorm", False) for c in cells):

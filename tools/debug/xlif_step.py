@@ -1,6 +1,6 @@
 """Train-step time of the XLIF-FireNet (hard reset, arctan: configs/train_SNN.yml) at the headline shape (8 x 128 x 128, 10 passes x
 1500 events): on the recorded window kernels (models/engine.py), replayed from hipGraphs (train.GraphedWindowStep), and -- EVF_XLIF_FUSED=0
--- cell by cell on the general path (train.capture_window_cycle).  python tools/debug/xlif_step.py [PLIFFireNet]"""
+-- cell by cell on the general path (train.capture_window_cycle).  python tools/debug/xlif_step.py [ALIFFireNet | PLIFFireNet]"""
 import os
 import sys
 import time
@@ -20,6 +20,9 @@ bench.set_workload("c3")
 cfg = dict(bench.MODEL_CFG)
 if name == "XLIFFireNet":
     cfg["spiking_neuron"] = {"leak_v": [-4.0, 0.1], "leak_pt": [-4.0, 0.1], "t0": [0.8, 0.1], "t1": [0.5, 0.1], "learn_leak": True,
+                             "learn_thresh": True, "hard_reset": True}
+elif name == "ALIFFireNet":
+    cfg["spiking_neuron"] = {"leak_v": [-4.0, 0.1], "leak_t": [-4.0, 0.1], "t0": [0.8, 0.1], "t1": [0.5, 0.1], "learn_leak": True,
                              "learn_thresh": True, "hard_reset": True}
 elif name == "PLIFFireNet":
     cfg["spiking_neuron"] = {"leak_v": [-4.0, 0.1], "leak_pt": [-4.0, 0.1], "add_pt": [-2.0, 0.1], "thresh": [0.8, 0.1], "learn_leak": True,
