@@ -87,7 +87,8 @@ extern "C" int evf_debug_ft_stamps(void* dst) { return evf_hip(hipMemcpyFromSymb
 // Same expressions in the same order: bit-identical to the cells launched one by one.
 // XL (PLIF instantiations with the hard reset): XLIF cells -- a compile-time switch; as a run-time (cell-uniform) branch it cost the
 // PLIF chain kernel 3 % (the round holds both formulas' values live: 168 registers, spills).
-template <bool HARD, bool FULL, bool PLIF, bool WIN, class JOBS, class WT, bool XL = false>
+// XL = 2: ALIF cells (FwJob::xl): the XLIF arithmetic with the trace driven by the lane's own previous spike bits instead of the pooled activity.
+template <bool HARD, bool FULL, bool PLIF, bool WIN, class JOBS, class WT, int XL = 0>
 __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, const int B, const int H, const int W, const WT& wt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* s_lut = (uint4*)(smem + FT_OFF_LUT);
@@ -145,7 +146,7 @@ __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, co
       s_par2[tid] = evf_plif_sigmoid(J.leak_pt[tid]);
       // (XLIF cell: the slot holds max(t1, 0) -- self.t1.clamp_min(0), spiking_submodules.py:365/:810 -- and the cell's `xl` flag, a
       // block-uniform scalar, picks the formula: the two neuron models share every register)
-      s_par2[C32 + tid] = XL ? fmaxf(J.add_pt[tid], 0.f) : evf_plif_sigmoid(J.add_pt[tid]);
+      s_par2[C32 + tid] = XL != 0 ? fmaxf(J.add_pt[tid], 0.f) : evf_plif_sigmoid(J.add_pt[tid]);
     }
     if (J.pr.w) {
       if (tid < 2 * C32) s_pw[tid] = J.pr.w[tid];
@@ -170,7 +171,7 @@ __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, co
     float* __restrict__ pt_out = PLIF ? J.pt_out : nullptr;
     float* __restrict__ P_out = PLIF ? J.P_out : nullptr;
     const bool has_pred = J.pr.w != nullptr;
-    constexpr bool xl = PLIF && XL;  // (an XLIF cell, see FwJob: the launcher picks the instantiation by the cells' flag)
+    constexpr bool xl = PLIF && XL != 0, al = PLIF && XL == 2;  // (XLIF / ALIF cells, see FwJob: the launcher picks the instantiation by the cells' flag)
     const int nstrips = plan.nstrips;
 
     if (wv < 4) {
@@ -611,7 +612,13 @@ __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, co
                               __uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)nzn, 3, 1) & 0x3F800000u)};
               const f2 P2 = {Pk[k], Pk[k]};
               const f2 pp01 = {pq[PLIF ? k : 0].x, pq[PLIF ? k : 0].y}, pp23 = {pq[PLIF ? k : 0].z, pq[PLIF ? k : 0].w};
-              const f2 po01 = pp01 * lpt01 + olp01 * P2, po23 = pp23 * lpt23 + olp23 * P2;  // evf_plif_trace, :212 / :642
+              f2 po01, po23;
+              if constexpr (al) {  // t * leak_t + (1 - leak_t) * z (:311 / :744): z01 / z23 hold 1 - z
+                const f2 one2 = {1.0f, 1.0f};
+                po01 = pp01 * lpt01 + olp01 * (one2 - z01), po23 = pp23 * lpt23 + olp23 * (one2 - z23);
+              } else {
+                po01 = pp01 * lpt01 + olp01 * P2, po23 = pp23 * lpt23 + olp23 * P2;  // evf_plif_trace, :212 / :642
+              }
               const f2 a01 = {a4[k].x, a4[k].y}, a23 = {a4[k].z, a4[k].w};
               f2 c01, c23, t01 = {thL[0], thL[1]}, t23 = {thL[2], thL[3]};
               if constexpr (xl) {  // XLIF: the current stays ff + rec, the trace raises the threshold: t0 + t1 * pt_out, :419 / :864
@@ -670,7 +677,7 @@ __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, co
                 float th_e = thL[q], th_p = thL[q];  // threshold of the element now / at the previous pass (soft reset)
                 po4[q] = 0.f;
                 if (PLIF) {
-                  po4[q] = evf_plif_trace(p4[q], lptL[q], Pk[k]);  // :212 / :642
+                  po4[q] = evf_plif_trace(p4[q], lptL[q], al ? z : Pk[k]);  // :212 / :642 (ALIF: the own previous spike, :311 / :744)
                   if constexpr (xl) {  // XLIF: thresh = t0 + t1 * pt_out, :419 / :864; soft reset - z * (t0 + t1 * pt), :430 / :871
                     th_e = thL[q] + aptL[q] * po4[q];
                     th_p = thL[q] + aptL[q] * p4[q];
@@ -808,12 +815,12 @@ __device__ __forceinline__ void ft_body(const JOBS& jobs, const FtPlan& plan, co
   FT_STAMP();
 }
 
-template <bool HARD, bool FULL, bool PLIF, bool XL = false>
+template <bool HARD, bool FULL, bool PLIF, int XL = 0>
 __global__ __launch_bounds__(FT_THREADS) void k_fwd_diag_t(FwJobs jobs, FtPlan plan, int B, int H, int W) {
   ft_body<HARD, FULL, PLIF, false, FwJobs, FwWinNone, XL>(jobs, plan, B, H, W, FwWinNone{});
 }
 
-template <bool HARD, bool FULL, bool PLIF, bool XL = false>
+template <bool HARD, bool FULL, bool PLIF, int XL = 0>
 __global__ __launch_bounds__(FT_THREADS) void k_fwd_win_t(FwJob1 job, FwWinTab wt, FtPlan plan, int B, int H, int W) {
   ft_body<HARD, FULL, PLIF, true, FwJob1, FwWinTab, XL>(job, plan, B, H, W, wt);
 }
@@ -834,8 +841,10 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
     FT_ATTR(true, true, false), FT_ATTR(true, false, false), FT_ATTR(false, true, false), FT_ATTR(false, false, false);
     FT_ATTR(true, true, true), FT_ATTR(true, false, true), FT_ATTR(false, true, true), FT_ATTR(false, false, true);
 #undef FT_ATTR
-    (void)hipFuncSetAttribute((const void*)k_fwd_diag_t<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
-    (void)hipFuncSetAttribute((const void*)k_fwd_diag_t<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
+    (void)hipFuncSetAttribute((const void*)k_fwd_diag_t<true, true, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
+    (void)hipFuncSetAttribute((const void*)k_fwd_diag_t<true, false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
+    (void)hipFuncSetAttribute((const void*)k_fwd_diag_t<true, true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
+    (void)hipFuncSetAttribute((const void*)k_fwd_diag_t<true, false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
     attr_set = true;
   }
   // relative cost of a round: feed-forward / recurrent cell / feed-forward cell with the prediction head in team E's epilogue (its
@@ -852,7 +861,7 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
   for (int k = 0; k < n; ++k) nhard += jobs.j[k].hard_reset ? 1 : 0, nplif += jobs.j[k].leak_pt ? 1 : 0;
   if ((nhard != 0 && nhard != n) || (nplif != 0 && nplif != n)) return EVF_EINVAL;
   for (int k = 0; k < n; ++k)  // XLIF cells: one kind per launch, hard reset (the caller then runs the cells one by one: evf_fwd_b3.hip)
-    if (jobs.j[k].xl != jobs.j[0].xl || (jobs.j[k].xl && !jobs.j[k].hard_reset) || jobs.j[k].xl == 2) return EVF_EINVAL;  // (ALIF: the one-cell kernel)
+    if (jobs.j[k].xl != jobs.j[0].xl || (jobs.j[k].xl && !jobs.j[k].hard_reset)) return EVF_EINVAL;
   FtPlan plan;
   plan.njobs = n, plan.ntx = evf_cdiv(W, TW), plan.nyy = evf_cdiv(H, 2);
   const long nstrips = (long)plan.ntx * plan.nyy * B;
@@ -877,8 +886,10 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
   hipStream_t st = EVF_STREAM(stream);
 #define FT_GO(HARD_, FULL_)                                                                                                  \
   do {                                                                                                                       \
-    if (nplif && jobs.j[0].xl)                                                                                               \
-      hipLaunchKernelGGL((k_fwd_diag_t<true, FULL_, true, true>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, jobs, plan, B, H, W); \
+    if (nplif && jobs.j[0].xl == 2)                                                                                          \
+      hipLaunchKernelGGL((k_fwd_diag_t<true, FULL_, true, 2>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, jobs, plan, B, H, W); \
+    else if (nplif && jobs.j[0].xl)                                                                                          \
+      hipLaunchKernelGGL((k_fwd_diag_t<true, FULL_, true, 1>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, jobs, plan, B, H, W); \
     else if (nplif)                                                                                                          \
       hipLaunchKernelGGL((k_fwd_diag_t<HARD_, FULL_, true>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, jobs, plan, B, H, W);  \
     else                                                                                                                     \
@@ -896,7 +907,7 @@ int evf_fwd_diag_t_launch(const FwJobs& jobs, int n, int B, int H, int W, void* 
 int evf_fwd_win_is_chain(const FwJob* c, int n) {
   if (n < 2 || n > FW_WIN_MAX) return 0;
   if (c[0].wrec) return 0;
-  if ((c[0].xl && !c[0].hard_reset) || c[0].xl == 2) return 0;  // (XLIF cells with the soft reset, ALIF cells: the one-cell kernel)
+  if (c[0].xl && !c[0].hard_reset) return 0;  // (XLIF / ALIF cells with the soft reset: the one-cell kernel)
   for (int k = 1; k < n; ++k) {
     const FwJob &a = c[k - 1], &b = c[k];
     if (b.wrec || b.wff != a.wff || b.leak != a.leak || b.thresh != a.thresh || b.hard_reset != a.hard_reset ||
@@ -925,8 +936,10 @@ int evf_fwd_win_t_launch(const FwJob* cells, int n, int B, int H, int W, void* s
     FT_ATTR(true, true, false), FT_ATTR(true, false, false), FT_ATTR(false, true, false), FT_ATTR(false, false, false);
     FT_ATTR(true, true, true), FT_ATTR(true, false, true), FT_ATTR(false, true, true), FT_ATTR(false, false, true);
 #undef FT_ATTR
-    (void)hipFuncSetAttribute((const void*)k_fwd_win_t<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
-    (void)hipFuncSetAttribute((const void*)k_fwd_win_t<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
+    (void)hipFuncSetAttribute((const void*)k_fwd_win_t<true, true, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
+    (void)hipFuncSetAttribute((const void*)k_fwd_win_t<true, false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
+    (void)hipFuncSetAttribute((const void*)k_fwd_win_t<true, true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
+    (void)hipFuncSetAttribute((const void*)k_fwd_win_t<true, false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS);
     attr_set = true;
   }
   FwJob1 job;
@@ -957,8 +970,10 @@ int evf_fwd_win_t_launch(const FwJob* cells, int n, int B, int H, int W, void* s
   hipStream_t st = EVF_STREAM(stream);
 #define FT_GO(HARD_, FULL_)                                                                                                     \
   do {                                                                                                                          \
-    if (plif && cells[0].xl)                                                                                                    \
-      hipLaunchKernelGGL((k_fwd_win_t<true, FULL_, true, true>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, job, wt, plan, B, H, W); \
+    if (plif && cells[0].xl == 2)                                                                                               \
+      hipLaunchKernelGGL((k_fwd_win_t<true, FULL_, true, 2>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, job, wt, plan, B, H, W); \
+    else if (plif && cells[0].xl)                                                                                               \
+      hipLaunchKernelGGL((k_fwd_win_t<true, FULL_, true, 1>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, job, wt, plan, B, H, W); \
     else if (plif)                                                                                                              \
       hipLaunchKernelGGL((k_fwd_win_t<HARD_, FULL_, true>), dim3(nblk), dim3(FT_THREADS), FT_LDS, st, job, wt, plan, B, H, W);   \
     else                                                                                                                        \

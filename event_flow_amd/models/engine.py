@@ -636,7 +636,7 @@ class FireNetEngine:
 
     # ---- PLIF: backward of a window layer by layer ---------------------------------------------------------------------------
     def _lm_wanted(self, win, tape, g_flow):
-        if not (PLIF_LAYER_MAJOR and self._plif and not self._al and self.precision == "bf16x3" and g_flow is not None):  # (ALIF: pass by pass)
+        if not (PLIF_LAYER_MAJOR and self._plif and self.precision == "bf16x3" and g_flow is not None):
             return False
         n = len(self.cells)
         return (HEAD_WIN and PLIF_TRACE_FUSED and PLIF_BOX_IN_DGRAD and TOP_FUSED and F32_DGRAD and PAIR_DGRAD and PARAM_ROWS
@@ -730,6 +730,9 @@ class FireNetEngine:
         gz = lambda i, s_: self._lm_buf(("gz", i, s_), shp, dev)  # noqa: E731  dL/d(spikes) of layer i at pass s
         # dL/d(current) of the layer in work, per pass: as its three bf16 planes (k_dgrad_diag_dma) or as the fp32 tensor (k_conv_dgrad_ws)
         split = PLIF_LM_DGRAD != "ws" and L.evf_conv_dgrad_b3_multi_fits(B, H, W) == 1
+        if self._al:
+            split = False  # (ALIF: a recurrent cell's input gradient is ADDED to g_zx -- the accumulating fp32 form, evf_conv_dgrad_b3_f32)
+        trace_in = not self._al  # the trace depends on the cell's INPUT (PLIF / XLIF: its gradient rides in the input-gradient kernels)
         if split:
             gsp = [self._lm_buf(("gsp", s_), (3, B, H, W, C), dev, torch.bfloat16) for s_ in range(T)]
             gcur = [None] * T
@@ -773,7 +776,7 @@ class FireNetEngine:
             if not c.recurrent:  # ... or one launch per pass (accumulate | 2: the pooling's adjoint inside)
                 for s_ in range(T):
                     _lib.call("evf_conv_dgrad_b3_f32", _lib.ptr(gcur[s_]), _lib.ptr(self._packed[(i, "ff", "b3t")]), _lib.ptr(gz(i - 1, s_)),
-                              2, B, H, W, _lib.ptr(gPs[s_]), _lib.ptr(lay[s_][0]))
+                              2 if trace_in else 0, B, H, W, _lib.ptr(gPs[s_]) if trace_in else None, _lib.ptr(lay[s_][0]) if trace_in else None)
                 continue
             # recurrent: pass by pass (the cell reads its own recurrent input gradient of the pass after)
             gzr_i = self._lm_buf(("gzr", i), shp, dev)
@@ -784,13 +787,14 @@ class FireNetEngine:
                 acc = 1 if win.slab_init.get(kf) else 0
                 if use_rec and bool(win.slab_init.get(kr)) != bool(acc):
                     _lib.zero_(self._slab(kr, nsl, dev))  # (first recurrent contribution later than the feed-forward one)
+                # (ALIF: gzr_i also takes the cell's g_zx -- read as the second part of dL/d(spikes), then written, by the same thread)
                 _lib.call("evf_plif_bwd_wgrad2", _lib.ptr(gz(i, s_)), _lib.ptr(gzr_i) if has_gzr else None, _lib.ptr(gv_i) if s_ else None,
                           _lib.ptr(v_out), _lib.ptr(v_prev), _lib.ptr(z_prev), _lib.ptr(in_bitsT), _lib.ptr(zT_prev) if use_rec else None,
                           leak, thr, B, H, W, 1 | xf, SURROGATE_ID[c.activation], width, _lib.ptr(gcur[s_]), _lib.ptr(gsp[s_]), _lib.ptr(gv_i),
                           rowp(f"{i}.leak"), rowp(f"{i}.thresh"), _lib.ptr(self._slab(kf, nsl, dev)),
                           _lib.ptr(self._slab(kr, nsl, dev)) if use_rec else None, acc | (row_ld << 8),
-                          _lib.ptr(gpt_i) if s_ else None, _lib.ptr(pt_prev), _lib.ptr(P_sav), lpt, apt, _lib.ptr(gpt_i), _lib.ptr(gPs[s_]),
-                          rowp(f"{i}.leak_pt"), rowp(f"{i}.add_pt"))
+                          _lib.ptr(gpt_i) if s_ else None, _lib.ptr(pt_prev), _lib.ptr(P_sav), lpt, apt, _lib.ptr(gpt_i),
+                          _lib.ptr(gzr_i if self._al else gPs[s_]), rowp(f"{i}.leak_pt"), rowp(f"{i}.add_pt"))
                 win.slab_init[kf] = True
                 if use_rec:
                     win.slab_init[kr] = True
@@ -801,14 +805,17 @@ class FireNetEngine:
                     _lib.call("evf_conv_dgrad_b3_multi", np_, a2([gsp[s_], gsp[s_]]),
                               a2([self._packed[(i, "ff", "b3t")], self._packed[(i, "rec", "b3t")]]), a2([gz(i - 1, s_), gzr_i]),
                               a2([gPs[s_], None]), a2([in_bits, None]), B, H, W)
-                elif rec_grad:
+                elif rec_grad and trace_in:
                     _lib.call("evf_conv_dgrad_b3_f32_pair", _lib.ptr(gcur[s_]), _lib.ptr(self._packed[(i, "ff", "b3t")]),
                               _lib.ptr(gz(i - 1, s_)), 2, _lib.ptr(self._packed[(i, "rec", "b3t")]), _lib.ptr(gzr_i), B, H, W,
                               _lib.ptr(gPs[s_]), _lib.ptr(in_bits))
                 else:
                     _lib.call("evf_conv_dgrad_b3_f32", _lib.ptr(gcur[s_]), _lib.ptr(self._packed[(i, "ff", "b3t")]), _lib.ptr(gz(i - 1, s_)),
-                              2, B, H, W, _lib.ptr(gPs[s_]), _lib.ptr(in_bits))
-                has_gzr = rec_grad
+                              2 if trace_in else 0, B, H, W, _lib.ptr(gPs[s_]) if trace_in else None, _lib.ptr(in_bits) if trace_in else None)
+                    if rec_grad:  # (ALIF) ... and the recurrent product ADDED to the g_zx the cell has just stored
+                        _lib.call("evf_conv_dgrad_b3_f32", _lib.ptr(gcur[s_]), _lib.ptr(self._packed[(i, "rec", "b3t")]), _lib.ptr(gzr_i),
+                                  1, B, H, W, None, None)
+                has_gzr = rec_grad or self._al
         # head layer: its passes recorded, one launch at the flush (k_head_bwd_win<.., PLIF>)
         c = self.cells[0]
         nslh = L.evf_head_lif_bwd_wgrad_slabs(B, H, W)
@@ -829,7 +836,8 @@ class FireNetEngine:
                       _lib.ptr(z_prev), _lib.ptr(tapes[s_]["x_in"]), _lib.ptr(self._flat["0.leak"]), _lib.ptr(self._flat["0.thresh"]), B, 2, H, W,
                       1 | xf, SURROGATE_ID[c.activation], self._act_width(0), _lib.ptr(gv0), rowp("0.leak"), rowp("0.thresh"),
                       _lib.ptr(self._slabs[key]), (1 if win.slab_init.get(key) else 0) | (row_ld << 8), _lib.ptr(gpt0) if s_ else None,
-                      _lib.ptr(pt_prev), _lib.ptr(P_sav), _lib.ptr(self._flat["0.leak_pt"]), _lib.ptr(self._flat["0.add_pt"]), _lib.ptr(gpt0),
+                      _lib.ptr(pt_prev), _lib.ptr(self._lm_buf(("gzx", 0), shp, dev) if self._al else P_sav),  # (ALIF: g_zx in the P slot)
+                      _lib.ptr(self._flat["0.leak_pt"]), _lib.ptr(self._flat["0.add_pt"]), _lib.ptr(gpt0),
                       rowp("0.leak_pt"), rowp("0.add_pt"))
             win.slab_init[key] = True
         win.bwd_k += T
