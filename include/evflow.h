@@ -383,12 +383,22 @@ int evf_conv_dgrad_b3_f32_pair(const float* g_cur, const void* wT_b3, float* g_x
  *
  * XLIF cells (models/spiking_submodules.py:337-435, :771-875) ride on these entry points: the SAME pre-synaptic trace, which
  * raises the threshold -- thresh = t0.clamp_min(0.01) + t1.clamp_min(0) * pt' -- instead of being subtracted from the current
- * (current = ff (+rec)).  Bit 1 of `hard_reset` (evf_conv_plif_fwd_b3[_pred], evf_head_plif_fwd, evf_plif_bwd_wgrad2 / _top,
- * evf_head_plif_bwd_wgrad: pass `hard_reset | 2`) or of `accumulate` (evf_plif_bwd_wgrad_window[_top]: `accumulate | 2`) selects
+ * (current = ff (+rec)).  Bits 1-2 of `hard_reset` (evf_conv_plif_fwd_b3[_pred], evf_head_plif_fwd, evf_plif_bwd_wgrad2 / _top,
+ * evf_head_plif_bwd_wgrad: pass `hard_reset | 2`) or of `accumulate` (evf_plif_bwd_wgrad_window[_top]: `accumulate | 2`) select
  * them; `thresh` / `g_thresh` then carry t0 and its gradient, `add_pt` / `g_add_pt` carry t1 and its gradient (no sigmoid:
  * the clamp's sub-gradient).  Backward forms: hard reset + arctan surrogate only, like the PLIF ones; the forward also takes
  * the soft reset (v' -= z * (t0 + t1 * pt)) cell by cell, except for the head (EVF_ENOTSUP).  evf_plif_trace_bwd has no XLIF
- * form (the trace backward of an XLIF cell lives in the fused backward kernels). */
+ * form (the trace backward of an XLIF cell lives in the fused backward kernels).
+ *
+ * ALIF cells (:230-334, :660-768): the value 2 in those two bits (`hard_reset | 4`, `accumulate | 4`).  The XLIF arithmetic with
+ * the trace t' = t * s(leak_t) + (1 - s(leak_t)) * z driven by the cell's OWN previous spikes z (`leak_pt` = leak_t, `pt_*` = the
+ * trace t; P_out is still written by the forward, nobody reads it).  z enters t' un-detached (:311): (1 - s(leak_t)) * dL/d(t') is a
+ * part of dL/d(spikes) of the pass BEFORE.  Window launches carry it in registers; a one-pass launch writes it to g_zx [B,H,W,32],
+ * which takes the place of an argument the ALIF cell does not need -- evf_plif_bwd_wgrad2: `g_P_raw` IS g_zx (hand it back as
+ * `g_z_out2` of the pass before; it may be the same buffer: read, then written, by the same thread; a recurrent cell's own input
+ * gradient is then ADDED to it, evf_conv_dgrad_b3_f32 with accumulate = 1); evf_head_plif_bwd_wgrad: `P` IS g_zx (read when
+ * g_pt_carry != NULL, i.e. when there is a pass after, and written).  The input gradient has no trace term (g_P = NULL).
+ * evf_plif_bwd_wgrad_top has no ALIF form (EVF_ENOTSUP: evf_pred_bwd + evf_plif_bwd_wgrad2). */
 int evf_conv_plif_fwd_b3(const uint32_t* x, const void* wb_ff, const void* wb_rec,
                          const float* leak_v, const float* leak_pt, const float* add_pt, const float* thresh,
                          const float* v_prev, const uint32_t* z_prev, const float* pt_prev,
