@@ -1463,6 +1463,25 @@ def main():
                                               "headline line's measurements: the replayed step at another spike activity"}
             for tag, ent in alive.items():
                 out["config"]["alive_" + tag.replace(".", "") + "_ms_per_step"] = round(ent["ms_per_step"], 3) if "ms_per_step" in ent else None
+        if dp.world == 1 and args.config == "c3" and not args.no_others:
+            # the other neuron models of the FireNet family on the same recorded window kernels (PLIF; XLIF / ALIF: modes of the PLIF
+            # kernels), at the headline shape, one short process each (tools/debug/xlif_step.py: train.GraphedWindowStep)
+            import re
+            import subprocess
+
+            fam = {}
+            for nm in ("PLIFFireNet", "XLIFFireNet", "ALIFFireNet"):
+                try:
+                    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "debug", "xlif_step.py"), nm], capture_output=True,
+                                       text=True, timeout=300, cwd=ROOT)
+                    m = re.search(r"(fused|general path)[^:]*: ([0-9.]+) ms per step", r.stdout)
+                    fam[nm] = {"path": m.group(1), "ms_per_step": float(m.group(2))} if m else {"error": (r.stderr or r.stdout)[-300:]}
+                except Exception as e:  # noqa: BLE001
+                    fam[nm] = {"error": f"{type(e).__name__}: {e}"}
+            out["firenet_family_at_c3_shape"] = {**fam, "note": "train step (hard reset, arctan) at 8 x 128 x 128, 10 passes x 1500 events, "
+                                                 "replayed from hipGraphs; LIFFireNet = the headline line"}
+            for nm, ent in fam.items():
+                out["config"][nm.lower() + "_c3_shape_ms_per_step"] = ent.get("ms_per_step")
         # the driver's record keeps the scalar entries of `config` (strings cut at 120 characters) and drops nested objects: the
         # figures of the other BASELINE configurations and of the collective are repeated there in compact form
         tb = out["timing_blocks"]

@@ -1,4 +1,4 @@
-"""XLIF FireNets (reference models/model.py:672-681; cells spiking_submodules.py:337-435, :771-875) on the recorded 32-channel
+"""XLIF and ALIF FireNets (reference models/model.py:660-681; cells spiking_submodules.py:230-435, :660-875) on the recorded 32-channel
 window kernels: the PLIF kernels with the pre-synaptic trace in the THRESHOLD (t0 + t1 * pt') instead of in the current
 (include/evflow.h: bit 1 of the PLIF entry points' reset / accumulate flag).  Against the CPU oracle (pinned by the single-cell
 goldens G6) and against the same network chained cell by cell on the general path."""
