@@ -71,6 +71,24 @@ def test_model_zoo_names_and_ctor_does_not_mutate_config():
     assert hasattr(a.head, "leak") and hasattr(b.head, "leak_v")  # no shared class-level kwargs (quirk q2)
 
 
+def test_compute_path_of_the_adaptive_threshold_firenets(monkeypatch):
+    """Which HIP path serves a network is host logic: XLIF / ALIF FireNets go to the recorded window kernels with the reference's
+    TRAINING neuron (configs/train_SNN.yml: hard reset, arctan) and stay on the general path with the cells' own default (soft
+    reset), another surrogate, or EVF_XLIF_FUSED=0; LIF / PLIF FireNets are fused either way."""
+    monkeypatch.setenv("EVF_PATH_NOTICE", "0")
+    for name, leak in (("XLIFFireNet", "leak_pt"), ("ALIFFireNet", "leak_t")):
+        hard = {"leak_v": [-4.0, 0.1], leak: [-4.0, 0.1], "t0": [0.3, 0.0], "t1": [0.5, 0.0], "hard_reset": True}
+        assert M.MODELS[name](cfg(neuron=hard)).compute_path == ("fused", "")
+        path, why = M.MODELS[name](cfg(neuron={k: v for k, v in hard.items() if k != "hard_reset"})).compute_path
+        assert path == "general" and "soft reset" in why
+        path, why = M.MODELS[name](cfg(neuron=hard, acts=("superspike", "superspike"))).compute_path
+        assert path == "general"
+        monkeypatch.setenv("EVF_XLIF_FUSED", "0")
+        assert M.MODELS[name](cfg(neuron=hard)).compute_path == ("general", "EVF_XLIF_FUSED=0")
+        monkeypatch.delenv("EVF_XLIF_FUSED")
+    assert M.LIFFireNet(cfg()).compute_path[0] == "fused"
+
+
 def test_cell_constructors_mirror_reference_defaults():
     c = cells.ConvALIF(4, 8, 3)
     assert not c.hard_reset and c.kind == "alif" and "t0" in dict(c.named_buffers())  # learn_thresh=False -> buffers
