@@ -287,9 +287,9 @@ _KERNEL_OF = {"evf_conv_dgrad_b3": "k_conv_dgrad_b3_lds<false, false, false, fal
               "evf_lif_bwd_wgrad/rec": "k_lif_bwd_wgrad<true, false, true>", "evf_lif_bwd_wgrad/rec+2": "k_lif_bwd_wgrad<true, false, true>",
               "evf_lif_bwd_wgrad/ff+2": "k_lif_bwd_wgrad<false, false, true>", "evf_conv_lif_fwd_b3/ff": "k_conv_lif_fwd_b3<false, false>",
               "evf_conv_lif_fwd_b3/rec": "k_conv_lif_fwd_b3<true, false>", "evf_head_lif_fwd": "k_head_lif_fwd<1>",
-              "k_head_lif_fwd_win": "k_head_lif_fwd_win<1, false, 8>", "k_head_bwd_win": "k_head_bwd_win<true, 4, false, false>",
+              "k_head_lif_fwd_win": "k_head_lif_fwd_win<1, false, 8>", "k_head_bwd_win": "k_head_bwd_win<true, 4, false, 0>",
               "evf_head_lif_bwd_wgrad": "k_head_bwd_mfma<true>", "evf_conv_dgrad/one": "k_conv_dgrad<false>",
-              "evf_conv_dgrad/two": "k_conv_dgrad<true>", "k_fwd_diag": "k_fwd_diag_t<true, true, false, false>", "k_fwd_win": "k_fwd_win_t<true, true, false, false>", "k_bwd_win": "k_bwd_win_lif", "k_dgrad_multi": "k_dgrad_diag_dma<true, false>", "k_bwd_diag": "k_bwd_diag_ws<8>",
+              "evf_conv_dgrad/two": "k_conv_dgrad<true>", "k_fwd_diag": "k_fwd_diag_t<true, true, false, 0>", "k_fwd_win": "k_fwd_win_t<true, true, false, 0>", "k_bwd_win": "k_bwd_win_lif", "k_dgrad_multi": "k_dgrad_diag_dma<true, false>", "k_bwd_diag": "k_bwd_diag_ws<8>",
               "k_dgrad_diag": "k_dgrad_diag_dma<true, false>", "evf_conv_lif_fwd/ff": "k_conv_lif_fwd<false>",
               "evf_conv_lif_fwd/rec": "k_conv_lif_fwd<true>", "evf_conv_wgrad_bits": "k_conv_wgrad_bits"}
 
@@ -306,9 +306,9 @@ def kernel_names_for(model_name, B, Hh, Ww):
     plif = model_name == "PLIFFireNet"
     if plif:
         _PMC_FILE = "r*_c5_pmc_traffic.json"
-        _KERNEL_OF.update({"k_fwd_diag": "k_fwd_diag_t<true, false, true, false>", "k_fwd_win": "k_fwd_win_t<true, false, true, false>",
+        _KERNEL_OF.update({"k_fwd_diag": "k_fwd_diag_t<true, false, true, 0>", "k_fwd_win": "k_fwd_win_t<true, false, true, 0>",
                            "k_bwd_win": "k_bwd_win_plif", "k_bwd_diag": "k_bwd_diag_ws_plif",
-                           "k_head_lif_fwd_win": "k_head_lif_fwd_win<1, true, 8>", "k_head_bwd_win": "k_head_bwd_win<true, 3, true, false>"})
+                           "k_head_lif_fwd_win": "k_head_lif_fwd_win<1, true, 8>", "k_head_bwd_win": "k_head_bwd_win<true, 3, true, 0>"})
     if B * ((Hh + 3) // 4) * ((Ww + 31) // 32) >= 6 * 256:
         tf = lambda v: "true" if v else "false"  # noqa: E731
         for pair in (False, True):
