@@ -532,7 +532,7 @@ class FireNetEngine:
                 for tg in target)
             if not ok:  # one-pass window starting from the target itself, or another geometry: fresh tensors
                 target = None
-        defer = (record and self.__dict__.get("_defer_on", False) and self.precision == "bf16x3" and self.kind in ("lif", "plif", "xlif")
+        defer = (record and self.__dict__.get("_defer_on", False) and self.precision == "bf16x3" and self.kind in ("lif", "plif", "xlif", "alif")
                  and PRED_FUSED)
         if not defer:
             self.flush_forward()  # (a pass outside the recorded schedule, e.g. under no_grad: what is recorded runs first)

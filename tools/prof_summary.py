@@ -25,7 +25,8 @@ def short(name):
     return name.replace("void ", "").strip()
 
 
-for run, out in (("graph", "bench_hipgraph"), ("eager", "bench_eager"), ("evfn", "evflownet"), ("plif", "plif_firenet"), ("iwe", "iwe_b2048")):
+for run, out in (("graph", "bench_hipgraph"), ("eager", "bench_eager"), ("evfn", "evflownet"), ("plif", "plif_firenet"), ("iwe", "iwe_b2048"),
+                 ("xlif", "xlif_step"), ("alif", "alif_step")):
     f = one(f"{run}/*/*kernel_stats.csv")
     if run == "graph":  # (the default bench run appends the c4 / c5 lines from child processes, each with files of its own: the
         #  headline step is in the process that ran the head layer's window kernel)
@@ -39,6 +40,8 @@ for run, out in (("graph", "bench_hipgraph"), ("eager", "bench_eager"), ("evfn",
         for line in open(log):
             if line.startswith("{"):
                 open(os.path.join(DST, f"{R}_{out}.json"), "w").write(line)
+            elif "ms per step" in line and run in ("xlif", "alif"):
+                open(os.path.join(DST, f"{R}_{out}.txt"), "w").write(line)
             elif line.startswith("B="):
                 open(os.path.join(DST, f"{R}_{out}.txt"), "w").write(line)
 

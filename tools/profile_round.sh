@@ -27,5 +27,8 @@ run c5fetch rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/
 run c5write rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/c5write -- python bench.py --config c5 --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe --no-others
 run c5mfma  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/c5mfma -- python bench.py --config c5 --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-iwe --no-others
 run plif   rocprofv3 --kernel-trace --stats --output-format csv -d $O/plif -- python bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-iwe --no-others
+# the other neuron models of the FireNet family on the recorded window kernels, at the headline shape
+run xlif   rocprofv3 --kernel-trace --stats --output-format csv -d $O/xlif -- python tools/debug/xlif_step.py XLIFFireNet
+run alif   rocprofv3 --kernel-trace --stats --output-format csv -d $O/alif -- python tools/debug/xlif_step.py ALIFFireNet
 run iwe    rocprofv3 --kernel-trace --stats --output-format csv -d $O/iwe -- python tools/iwe_bench.py 2048
 ls -R $O | head -60
